@@ -1,0 +1,390 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into or imported by the product.
+//
+// Thin C ABI over the REAL reference CPU library (oracle/_ref/libctranslate2_ref.so,
+// compiled unmodified from /root/reference by oracle/Makefile). It exists so that the
+// Python test-suite can (a) pin our plain-C restatement (ct2_oracle.c) against the
+// reference's own op implementations, (b) generate the golden fixtures committed under
+// tests/golden/, and (c) time the reference's CPU path as the `cpu_baseline`.
+//
+// Every entry point drives the reference through its public C++ API:
+//   ops::*            include/ctranslate2/ops/*.h
+//   Translator        include/ctranslate2/translator.h:27-60
+//   layers::Transformer{Encoder,Decoder}  include/ctranslate2/layers/transformer.h
+// and returns 0 on success, -1 on exception (message via ct2ref_last_error()).
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <ctranslate2/layers/transformer.h>
+#include <ctranslate2/models/model.h>
+#include <ctranslate2/models/sequence_to_sequence.h>
+#include <ctranslate2/models/language_model.h>
+#include <ctranslate2/ops/ops.h>
+#include <ctranslate2/translator.h>
+#include <ctranslate2/generator.h>
+#include <ctranslate2/utils.h>
+
+using namespace ctranslate2;
+
+static thread_local std::string g_last_error;
+
+#define CT2REF_TRY try {
+#define CT2REF_CATCH                                   \
+  }                                                    \
+  catch (const std::exception& e) {                    \
+    g_last_error = e.what();                           \
+    return -1;                                         \
+  }                                                    \
+  return 0;
+
+template <typename T>
+static StorageView view(const T* data, Shape shape) {
+  return StorageView(std::move(shape), const_cast<T*>(data), Device::CPU);
+}
+
+template <typename T>
+static void copy_out(const StorageView& x, T* out) {
+  std::memcpy(out, x.data<T>(), x.size() * sizeof(T));
+}
+
+extern "C" {
+
+const char* ct2ref_last_error() { return g_last_error.c_str(); }
+
+int ct2ref_set_num_threads(int n) {
+  CT2REF_TRY
+  set_num_threads(n);
+  CT2REF_CATCH
+}
+
+int ct2ref_mayiuse_int8() { return mayiuse_int8(Device::CPU) ? 1 : 0; }
+
+// ops::Quantize (src/ops/quantize.cc:21-51), INT8 per-row.
+int ct2ref_quantize_s8(const float* x, int64_t rows, int64_t depth, int round_before_cast,
+                       int8_t* q, float* scales) {
+  CT2REF_TRY
+  StorageView in = view(x, {rows, depth});
+  StorageView out(DataType::INT8), scale(DataType::FLOAT32);
+  ops::Quantize(ops::Quantize::ScaleType::GLOBAL, /*shift_to_uint8=*/false,
+                round_before_cast != 0)(in, out, scale);
+  copy_out(out, q);
+  copy_out(scale, scales);
+  CT2REF_CATCH
+}
+
+// ops::Gemm s8*s8->s32 with trans_b (src/ops/gemm.cc:45-107).
+int ct2ref_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int64_t k,
+                   int32_t* c) {
+  CT2REF_TRY
+  StorageView A = view(a, {m, k});
+  StorageView B = view(b, {n, k});
+  StorageView C(DataType::INT32);
+  ops::Gemm(1.f, 0.f, false, true)(A, B, C);
+  copy_out(C, c);
+  CT2REF_CATCH
+}
+
+// ops::Gemm f32 with trans_b, optional bias / residual / activation.
+int ct2ref_gemm_f32(const float* a, const float* b, int64_t m, int64_t n, int64_t k,
+                    int trans_b, const float* bias, const float* residual, int act, float* c) {
+  CT2REF_TRY
+  StorageView A = view(a, {m, k});
+  StorageView B = trans_b ? view(b, {n, k}) : view(b, {k, n});
+  StorageView C(DataType::FLOAT32);
+  ops::ActivationType act_type = static_cast<ops::ActivationType>(act < 0 ? 0 : act);
+  std::unique_ptr<StorageView> bias_v, res_v;
+  if (bias) bias_v = std::make_unique<StorageView>(view(bias, {n}));
+  if (residual) res_v = std::make_unique<StorageView>(view(residual, {m, n}));
+  ops::Gemm(1.f, 0.f, false, trans_b != 0, false, false, act < 0 ? nullptr : &act_type)(
+      A, B, C, nullptr, bias_v.get(), res_v.get());
+  copy_out(C, c);
+  CT2REF_CATCH
+}
+
+// ops::Dequantize GEMM-output form (src/ops/dequantize.cc:46-59). act < 0 => none,
+// otherwise the integer value of ops::ActivationType (include/ctranslate2/ops/activation.h).
+int ct2ref_dequantize_gemm_output(const int32_t* c, const float* a_scale, const float* b_scale,
+                                  const float* bias, int64_t m, int64_t n, int act, float* y) {
+  CT2REF_TRY
+  StorageView C = view(c, {m, n});
+  StorageView sa = view(a_scale, {m});
+  StorageView sb = view(b_scale, {n});
+  std::unique_ptr<StorageView> bias_v;
+  if (bias) bias_v = std::make_unique<StorageView>(view(bias, {n}));
+  ops::ActivationType act_type = static_cast<ops::ActivationType>(act < 0 ? 0 : act);
+  StorageView Y(DataType::FLOAT32);
+  ops::Dequantize(act < 0 ? nullptr : &act_type)(C, sa, sb, false, true, Y, bias_v.get());
+  copy_out(Y, y);
+  CT2REF_CATCH
+}
+
+// ops::Dequantize int8 rows -> float (embedding path).
+int ct2ref_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, int64_t depth,
+                           float* y) {
+  CT2REF_TRY
+  StorageView X = view(x, {rows, depth});
+  StorageView S = view(scale, {rows});
+  StorageView Y(DataType::FLOAT32);
+  ops::Dequantize()(X, S, Y);
+  copy_out(Y, y);
+  CT2REF_CATCH
+}
+
+int ct2ref_layer_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
+                      int64_t depth, float eps, float* y) {
+  CT2REF_TRY
+  StorageView X = view(x, {rows, depth});
+  StorageView G = view(gamma, {depth});
+  StorageView B = view(beta, {depth});
+  StorageView Y(DataType::FLOAT32);
+  ops::LayerNorm(-1, eps)(B, G, X, Y);
+  copy_out(Y, y);
+  CT2REF_CATCH
+}
+
+int ct2ref_rms_norm(const float* x, const float* gamma, int64_t rows, int64_t depth, float eps,
+                    int use_residual, float* y) {
+  CT2REF_TRY
+  StorageView X = view(x, {rows, depth});
+  StorageView G = view(gamma, {depth});
+  StorageView Y(DataType::FLOAT32);
+  ops::RMSNorm(eps, use_residual != 0)(G, X, Y);
+  copy_out(Y, y);
+  CT2REF_CATCH
+}
+
+int ct2ref_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth, int log,
+                   float* y) {
+  CT2REF_TRY
+  StorageView X = view(x, {rows, depth});
+  StorageView Y(DataType::FLOAT32);
+  std::unique_ptr<StorageView> L;
+  if (lengths) L = std::make_unique<StorageView>(view(lengths, {rows}));
+  ops::SoftMax(log != 0)(X, L.get(), Y);
+  copy_out(Y, y);
+  CT2REF_CATCH
+}
+
+// ops::Rotary on [batch, heads, time, dhead]; sin/cos are [time, ndims] (already offset).
+int ct2ref_rotary(const float* x, const float* sin, const float* cos, int64_t batch,
+                  int64_t heads, int64_t time, int64_t dhead, int64_t ndims, int interleave,
+                  float* y) {
+  CT2REF_TRY
+  StorageView X = view(x, {batch, heads, time, dhead});
+  StorageView S = view(sin, {time, ndims});
+  StorageView C = view(cos, {time, ndims});
+  StorageView Y(DataType::FLOAT32);
+  ops::Rotary(ndims, interleave != 0)(X, S, C, Y, true);
+  copy_out(Y, y);
+  CT2REF_CATCH
+}
+
+int ct2ref_topk(const float* x, int64_t rows, int64_t depth, int64_t k, float* values,
+                int32_t* indices) {
+  CT2REF_TRY
+  StorageView X = view(x, {rows, depth});
+  StorageView V(DataType::FLOAT32), I(DataType::INT32);
+  const ops::TopK topk_op(k);
+  topk_op(X, V, I);
+  copy_out(V, values);
+  copy_out(I, indices);
+  CT2REF_CATCH
+}
+
+int ct2ref_gather_rows(const float* data, int64_t n_rows, int64_t row_size, const int32_t* idx,
+                       int64_t n_idx, float* out) {
+  CT2REF_TRY
+  StorageView D = view(data, {n_rows, row_size});
+  StorageView I = view(idx, {n_idx});
+  StorageView O(DataType::FLOAT32);
+  ops::Gather()(D, I, O);
+  copy_out(O, out);
+  CT2REF_CATCH
+}
+
+// ops::MatMul on [batch, m, k] x [batch, k|n, n|k] (src/ops/matmul.cc:14-84).
+int ct2ref_matmul(const float* a, const float* b, int64_t batch, int64_t m, int64_t n, int64_t k,
+                  int trans_b, float alpha, float* c) {
+  CT2REF_TRY
+  StorageView A = view(a, {batch, m, k});
+  StorageView B = trans_b ? view(b, {batch, n, k}) : view(b, {batch, k, n});
+  StorageView C(DataType::FLOAT32);
+  ops::MatMul(false, trans_b != 0, alpha)(A, B, C);
+  copy_out(C, c);
+  CT2REF_CATCH
+}
+
+// ---------------------------------------------------------------------------------------
+// Model-level entry points.
+// ---------------------------------------------------------------------------------------
+
+struct RefModel {
+  std::shared_ptr<const models::Model> model;
+  std::unique_ptr<Translator> translator;
+  std::unique_ptr<Generator> generator;
+  int intra_threads = 0;
+};
+
+void* ct2ref_model_load(const char* path, const char* compute_type, int inter_threads,
+                        int intra_threads) {
+  try {
+    auto handle = std::make_unique<RefModel>();
+    handle->intra_threads = intra_threads;
+    models::ModelLoader loader(path);
+    loader.device = Device::CPU;
+    loader.device_indices = {0};
+    loader.num_replicas_per_device = inter_threads > 0 ? inter_threads : 1;
+    loader.compute_type = str_to_compute_type(compute_type);
+    auto models = loader.load();
+    handle->model = models[0];
+    ReplicaPoolConfig config;
+    config.num_threads_per_replica = intra_threads;
+    if (dynamic_cast<const models::SequenceToSequenceModel*>(handle->model.get()))
+      handle->translator = std::make_unique<Translator>(models, config);
+    else
+      handle->generator = std::make_unique<Generator>(models, config);
+    return handle.release();
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return nullptr;
+  }
+}
+
+void ct2ref_model_free(void* h) { delete static_cast<RefModel*>(h); }
+
+int ct2ref_model_compute_type(void* h, char* out, int out_size) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const std::string s = compute_type_to_str(m->model->effective_compute_type());
+  std::strncpy(out, s.c_str(), out_size - 1);
+  out[out_size - 1] = 0;
+  CT2REF_CATCH
+}
+
+static std::vector<std::vector<std::string>>
+ids_to_tokens(const Vocabulary& vocab, const int32_t* ids, const int32_t* lengths, int batch,
+              int stride) {
+  std::vector<std::vector<std::string>> out(batch);
+  for (int b = 0; b < batch; ++b) {
+    out[b].reserve(lengths[b]);
+    for (int t = 0; t < lengths[b]; ++t)
+      out[b].push_back(vocab.to_token(ids[b * stride + t]));
+  }
+  return out;
+}
+
+// Translator::translate_batch (src/translator.cc:8-28) on integer ids.
+// src_ids: [batch, src_stride] raw token ids WITHOUT the implicit </s> (the reference adds
+// source BOS/EOS itself per the model config). Outputs: out_ids [batch, num_hyp, max_len],
+// out_lengths [batch, num_hyp], out_scores [batch, num_hyp] (if return_scores).
+int ct2ref_translate(void* h, const int32_t* src_ids, const int32_t* src_lengths, int batch,
+                     int src_stride, int beam_size, int max_len, int min_len,
+                     float length_penalty, int num_hyp, int return_scores, int max_batch_size,
+                     int32_t* out_ids, int32_t* out_lengths, float* out_scores) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const auto* s2s = dynamic_cast<const models::SequenceToSequenceModel*>(m->model.get());
+  if (!s2s || !m->translator) throw std::runtime_error("not a sequence-to-sequence model");
+  auto source = ids_to_tokens(s2s->get_source_vocabulary(), src_ids, src_lengths, batch, src_stride);
+  TranslationOptions opt;
+  opt.beam_size = beam_size;
+  opt.max_decoding_length = max_len;
+  opt.min_decoding_length = min_len;
+  opt.length_penalty = length_penalty;
+  opt.num_hypotheses = num_hyp;
+  opt.return_scores = return_scores != 0;
+  opt.max_input_length = 0;
+  auto results = m->translator->translate_batch(source, opt, max_batch_size);
+  const auto& tv = s2s->get_target_vocabulary();
+  for (int b = 0; b < batch; ++b) {
+    for (int k = 0; k < num_hyp; ++k) {
+      int32_t* dst = out_ids + (static_cast<int64_t>(b) * num_hyp + k) * max_len;
+      int len = 0;
+      if (k < static_cast<int>(results[b].hypotheses.size())) {
+        const auto& hyp = results[b].hypotheses[k];
+        len = static_cast<int>(hyp.size());
+        for (int t = 0; t < len && t < max_len; ++t) dst[t] = tv.to_id(hyp[t]);
+        if (return_scores && out_scores) out_scores[b * num_hyp + k] = results[b].scores[k];
+      }
+      out_lengths[b * num_hyp + k] = len;
+    }
+  }
+  CT2REF_CATCH
+}
+
+// Generator::generate_batch on integer ids (decoder-only models).
+int ct2ref_generate(void* h, const int32_t* prompt_ids, const int32_t* prompt_lengths, int batch,
+                    int stride, int beam_size, int max_len, int min_len, int return_scores,
+                    int32_t* out_ids, int32_t* out_lengths, float* out_scores) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const auto* lm = dynamic_cast<const models::LanguageModel*>(m->model.get());
+  if (!lm || !m->generator) throw std::runtime_error("not a language model");
+  auto prompts = ids_to_tokens(lm->get_vocabulary(), prompt_ids, prompt_lengths, batch, stride);
+  GenerationOptions opt;
+  opt.beam_size = beam_size;
+  opt.max_length = max_len;
+  opt.min_length = min_len;
+  opt.sampling_topk = 1;
+  opt.return_scores = return_scores != 0;
+  opt.include_prompt_in_result = false;
+  auto futures = m->generator->generate_batch_async(prompts, opt);
+  std::vector<GenerationResult> results;
+  for (auto& f : futures) results.emplace_back(f.get());
+  for (int b = 0; b < batch; ++b) {
+    const auto& ids = results[b].sequences_ids[0];
+    const int len = static_cast<int>(ids.size());
+    for (int t = 0; t < len && t < max_len; ++t) out_ids[b * max_len + t] = ids[t];
+    out_lengths[b] = len;
+    if (return_scores && out_scores) out_scores[b] = results[b].scores[0];
+  }
+  CT2REF_CATCH
+}
+
+// Teacher-forced decoding through layers::TransformerEncoder / TransformerDecoder
+// (src/layers/transformer.cc:427-471, 621-871): runs the encoder on `src_ids`
+// ([batch, src_stride] INCLUDING any special tokens, lengths in src_lengths; pass
+// batch==0 sources for decoder-only models), then feeds tgt_in[:, t] at step t and writes the
+// step logits to logits_out [T, batch, vocab]. This is the "logits within 1e-3" oracle.
+int ct2ref_step_logits(void* h, const int32_t* src_ids, const int32_t* src_lengths, int batch,
+                       int src_stride, const int32_t* tgt_in, int T, float* logits_out,
+                       int64_t* vocab_out) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  if (m->intra_threads > 0) set_num_threads(m->intra_threads);
+  const auto& model = *m->model;
+  const bool s2s = dynamic_cast<const models::SequenceToSequenceModel*>(m->model.get()) != nullptr;
+  layers::TransformerDecoder decoder(model, "decoder");
+  layers::DecoderState state = decoder.initial_state();
+  if (s2s) {
+    layers::TransformerEncoder encoder(model, "encoder");
+    std::vector<std::vector<size_t>> ids(batch);
+    for (int b = 0; b < batch; ++b)
+      ids[b].assign(src_ids + b * src_stride, src_ids + b * src_stride + src_lengths[b]);
+    StorageView lengths(DataType::INT32);
+    std::vector<StorageView> inputs;
+    inputs.emplace_back(layers::make_sequence_inputs(ids, Device::CPU, 1, &lengths));
+    StorageView memory(encoder.output_type(), Device::CPU);
+    encoder(inputs, &lengths, memory);
+    state.emplace("memory", std::move(memory));
+    state.emplace("memory_lengths", std::move(lengths));
+  }
+  int64_t vocab = 0;
+  for (int t = 0; t < T; ++t) {
+    StorageView step_ids({batch}, DataType::INT32);
+    for (int b = 0; b < batch; ++b) step_ids.at<int32_t>(b) = tgt_in[b * T + t];
+    StorageView logits(decoder.output_type(), Device::CPU);
+    decoder(t, step_ids, state, &logits);
+    vocab = logits.dim(-1);
+    StorageView lf = logits.to_float32();
+    std::memcpy(logits_out + static_cast<int64_t>(t) * batch * vocab, lf.data<float>(),
+                sizeof(float) * batch * vocab);
+  }
+  if (vocab_out) *vocab_out = vocab;
+  CT2REF_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes loader for oracle/_ref/libct2ref_capi.so -- the REAL
+reference CPU library (compiled from /root/reference by oracle/Makefile) behind a C ABI.
+Used to pin the C restatement oracle, to generate tests/golden fixtures and to time the
+`cpu_baseline`. Never imported by the product package."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(os.path.dirname(_HERE), "oracle", "_ref")
+MKL_DIR = os.environ.get("CT2REF_MKL_DIR", "/opt/conda/lib")
+
+_lib = None
+
+
+def available():
+    return os.path.exists(os.path.join(REF_DIR, "libct2ref_capi.so")) and bool(
+        glob.glob(os.path.join(MKL_DIR, "libmkl_core.so*")))
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    # The reference selects MKL only on GenuineIntel CPUs unless told otherwise
+    # (src/cpu/backend.cc:10-31); the GPU box has AMD EPYC host cores.
+    os.environ.setdefault("CT2_USE_MKL", "1")
+    mode = os.RTLD_GLOBAL | os.RTLD_LAZY  # MKL's core library needs lazy binding
+    for name in ("libmkl_core.so", "libmkl_gnu_thread.so", "libmkl_intel_ilp64.so"):
+        cands = sorted(glob.glob(os.path.join(MKL_DIR, name + "*")))
+        if not cands:
+            raise OSError("MKL runtime %s not found under %s" % (name, MKL_DIR))
+    try:
+        C.CDLL("libgomp.so.1", mode=mode)
+    except OSError:
+        pass
+    for name in ("libmkl_core.so", "libmkl_gnu_thread.so", "libmkl_intel_ilp64.so"):
+        C.CDLL(sorted(glob.glob(os.path.join(MKL_DIR, name + "*")))[0], mode=mode)
+    C.CDLL(os.path.join(REF_DIR, "libctranslate2_ref.so"), mode=mode)
+    L = C.CDLL(os.path.join(REF_DIR, "libct2ref_capi.so"), mode=mode)
+    L.ct2ref_last_error.restype = C.c_char_p
+    L.ct2ref_model_load.restype = C.c_void_p
+    L.ct2ref_model_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    L.ct2ref_model_free.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().ct2ref_last_error().decode())
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def set_num_threads(n):
+    _check(lib().ct2ref_set_num_threads(C.c_int(n)))
+
+
+def quantize_s8(x, round_before_cast=True):
+    x = _f32(x)
+    rows, depth = x.shape
+    q = np.empty((rows, depth), np.int8)
+    s = np.empty((rows,), np.float32)
+    _check(lib().ct2ref_quantize_s8(_p(x), C.c_int64(rows), C.c_int64(depth),
+                                    C.c_int(int(round_before_cast)), _p(q), _p(s)))
+    return q, s
+
+
+def gemm_s8(a, b):
+    a = np.ascontiguousarray(a, np.int8)
+    b = np.ascontiguousarray(b, np.int8)
+    m, k = a.shape
+    n = b.shape[0]
+    c = np.empty((m, n), np.int32)
+    _check(lib().ct2ref_gemm_s8(_p(a), _p(b), C.c_int64(m), C.c_int64(n), C.c_int64(k), _p(c)))
+    return c
+
+
+def gemm_f32(a, b, trans_b=True, bias=None, residual=None, act=-1):
+    a, b, bias, residual = _f32(a), _f32(b), _f32(bias), _f32(residual)
+    m, k = a.shape
+    n = b.shape[0] if trans_b else b.shape[1]
+    c = np.empty((m, n), np.float32)
+    _check(lib().ct2ref_gemm_f32(_p(a), _p(b), C.c_int64(m), C.c_int64(n), C.c_int64(k),
+                                 C.c_int(int(trans_b)), _p(bias), _p(residual), C.c_int(act), _p(c)))
+    return c
+
+
+def dequantize_gemm_output(c, a_scale, b_scale, bias=None, act=-1):
+    c = np.ascontiguousarray(c, np.int32)
+    a_scale, b_scale, bias = _f32(a_scale), _f32(b_scale), _f32(bias)
+    m, n = c.shape
+    y = np.empty((m, n), np.float32)
+    _check(lib().ct2ref_dequantize_gemm_output(_p(c), _p(a_scale), _p(b_scale), _p(bias),
+                                               C.c_int64(m), C.c_int64(n), C.c_int(act), _p(y)))
+    return y
+
+
+def dequantize_rows(x, scale):
+    x = np.ascontiguousarray(x, np.int8)
+    scale = _f32(scale)
+    rows, depth = x.shape
+    y = np.empty((rows, depth), np.float32)
+    _check(lib().ct2ref_dequantize_rows(_p(x), _p(scale), C.c_int64(rows), C.c_int64(depth), _p(y)))
+    return y
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    x, gamma, beta = _f32(x), _f32(gamma), _f32(beta)
+    rows, depth = x.shape
+    y = np.empty_like(x)
+    _check(lib().ct2ref_layer_norm(_p(x), _p(gamma), _p(beta), C.c_int64(rows), C.c_int64(depth),
+                                   C.c_float(eps), _p(y)))
+    return y
+
+
+def rms_norm(x, gamma, eps=1e-6, use_residual=False):
+    x, gamma = _f32(x), _f32(gamma)
+    rows, depth = x.shape
+    y = np.empty_like(x)
+    _check(lib().ct2ref_rms_norm(_p(x), _p(gamma), C.c_int64(rows), C.c_int64(depth),
+                                 C.c_float(eps), C.c_int(int(use_residual)), _p(y)))
+    return y
+
+
+def softmax(x, lengths=None, log=False):
+    x = _f32(x)
+    rows, depth = x.shape
+    if lengths is not None:
+        lengths = np.ascontiguousarray(lengths, np.int32)
+    y = np.empty_like(x)
+    _check(lib().ct2ref_softmax(_p(x), _p(lengths), C.c_int64(rows), C.c_int64(depth),
+                                C.c_int(int(log)), _p(y)))
+    return y
+
+
+def rotary(x, sin, cos, ndims, interleave):
+    x, sin, cos = _f32(x), _f32(sin), _f32(cos)
+    b, h, t, d = x.shape
+    y = np.empty_like(x)
+    _check(lib().ct2ref_rotary(_p(x), _p(sin), _p(cos), C.c_int64(b), C.c_int64(h), C.c_int64(t),
+                               C.c_int64(d), C.c_int64(ndims), C.c_int(int(interleave)), _p(y)))
+    return y
+
+
+def topk(x, k):
+    x = _f32(x)
+    rows, depth = x.shape
+    v = np.empty((rows, k), np.float32)
+    i = np.empty((rows, k), np.int32)
+    _check(lib().ct2ref_topk(_p(x), C.c_int64(rows), C.c_int64(depth), C.c_int64(k), _p(v), _p(i)))
+    return v, i
+
+
+def matmul(a, b, trans_b=False, alpha=1.0):
+    a, b = _f32(a), _f32(b)
+    batch, m, k = a.shape
+    n = b.shape[1] if trans_b else b.shape[2]
+    c = np.empty((batch, m, n), np.float32)
+    _check(lib().ct2ref_matmul(_p(a), _p(b), C.c_int64(batch), C.c_int64(m), C.c_int64(n),
+                               C.c_int64(k), C.c_int(int(trans_b)), C.c_float(alpha), _p(c)))
+    return c
+
+
+class RefModel:
+    """The reference's Translator / Generator on CPU."""
+
+    def __init__(self, path, compute_type="int8", inter_threads=1, intra_threads=0):
+        self._h = lib().ct2ref_model_load(path.encode(), compute_type.encode(),
+                                          C.c_int(inter_threads), C.c_int(intra_threads))
+        if not self._h:
+            raise RuntimeError(lib().ct2ref_last_error().decode())
+
+    def close(self):
+        if self._h:
+            lib().ct2ref_model_free(C.c_void_p(self._h))
+            self._h = None
+
+    def compute_type(self):
+        buf = C.create_string_buffer(64)
+        _check(lib().ct2ref_model_compute_type(C.c_void_p(self._h), buf, C.c_int(64)))
+        return buf.value.decode()
+
+    @staticmethod
+    def _pack(seqs):
+        batch = len(seqs)
+        lengths = np.array([len(s) for s in seqs], np.int32)
+        stride = max(1, int(lengths.max()) if batch else 1)
+        ids = np.zeros((batch, stride), np.int32)
+        for i, s in enumerate(seqs):
+            ids[i, :len(s)] = s
+        return ids, lengths, stride
+
+    def translate_ids(self, src, beam_size=1, max_len=256, min_len=1, length_penalty=1.0,
+                      num_hypotheses=1, return_scores=True, max_batch_size=0):
+        ids, lengths, stride = self._pack(src)
+        batch = len(src)
+        out = np.zeros((batch, num_hypotheses, max_len), np.int32)
+        out_len = np.zeros((batch, num_hypotheses), np.int32)
+        scores = np.zeros((batch, num_hypotheses), np.float32)
+        _check(lib().ct2ref_translate(C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch),
+                                      C.c_int(stride), C.c_int(beam_size), C.c_int(max_len),
+                                      C.c_int(min_len), C.c_float(length_penalty),
+                                      C.c_int(num_hypotheses), C.c_int(int(return_scores)),
+                                      C.c_int(max_batch_size), _p(out), _p(out_len), _p(scores)))
+        hyps = [[out[b, k, :out_len[b, k]].tolist() for k in range(num_hypotheses)]
+                for b in range(batch)]
+        return hyps, scores
+
+    def generate_ids(self, prompts, beam_size=1, max_len=64, min_len=0, return_scores=True):
+        ids, lengths, stride = self._pack(prompts)
+        batch = len(prompts)
+        out = np.zeros((batch, max_len), np.int32)
+        out_len = np.zeros((batch,), np.int32)
+        scores = np.zeros((batch,), np.float32)
+        _check(lib().ct2ref_generate(C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch),
+                                     C.c_int(stride), C.c_int(beam_size), C.c_int(max_len),
+                                     C.c_int(min_len), C.c_int(int(return_scores)), _p(out),
+                                     _p(out_len), _p(scores)))
+        return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
+
+    def step_logits(self, src, tgt_in, vocab_size):
+        """Teacher-forced per-step logits [T, batch, vocab]. `src` includes special tokens."""
+        batch = len(tgt_in)
+        if src:
+            ids, lengths, stride = self._pack(src)
+        else:
+            ids, lengths, stride = np.zeros((1, 1), np.int32), np.zeros((1,), np.int32), 1
+        tgt = np.ascontiguousarray(tgt_in, np.int32)
+        T = tgt.shape[1]
+        logits = np.empty((T, batch, vocab_size), np.float32)
+        v = C.c_int64(0)
+        _check(lib().ct2ref_step_logits(C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch),
+                                        C.c_int(stride), _p(tgt), C.c_int(T), _p(logits),
+                                        C.byref(v)))
+        assert v.value == vocab_size, (v.value, vocab_size)
+        return logits
