@@ -1,0 +1,98 @@
+"""ctypes binding of libct2_mi355.so (the C ABI in include/ct2_mi355.h).
+
+The library is the product: there is no Python/CPU fallback. Importing this module without
+the built extension raises; calling a compute entry point without a GPU returns the HIP
+error from the runtime.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libct2_mi355.so")
+
+_lib = None
+
+
+class Ct2xError(RuntimeError):
+    pass
+
+
+class TranslationOptions(C.Structure):
+    """struct ct2x_translation_options (include/ct2_mi355.h)."""
+    _fields_ = [
+        ("beam_size", C.c_int32),
+        ("max_decoding_length", C.c_int32),
+        ("min_decoding_length", C.c_int32),
+        ("num_hypotheses", C.c_int32),
+        ("return_scores", C.c_int32),
+        ("return_end_token", C.c_int32),
+        ("max_batch_size", C.c_int32),
+        ("max_input_length", C.c_int32),
+        ("length_penalty", C.c_float),
+        ("patience", C.c_float),
+        ("use_graph", C.c_int32),
+        ("reserved", C.c_int32 * 5),
+    ]
+
+
+class ExecStats(C.Structure):
+    """struct ct2x_exec_stats (include/ct2_mi355.h)."""
+    _fields_ = [
+        ("num_tokens", C.c_int64),
+        ("num_examples", C.c_int64),
+        ("decode_steps", C.c_int64),
+        ("kernels_per_step", C.c_int64),
+        ("total_ms", C.c_double),
+        ("encode_ms", C.c_double),
+        ("decode_ms", C.c_double),
+    ]
+
+
+def lib():
+    """Loads the HIP extension (once). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        # Share PyTorch's HIP runtime when torch is in the process (same libamdhip64 soname),
+        # so device pointers from torch tensors are valid in this library.
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
+    L = C.CDLL(LIB_PATH, mode=os.RTLD_GLOBAL | os.RTLD_NOW)
+    L.ct2x_last_error.restype = C.c_char_p
+    L.ct2x_thread_stream.restype = C.c_void_p
+    L.ct2x_allocated_bytes.restype = C.c_int64
+    if hasattr(L, "ct2x_translator_create"):
+        L.ct2x_translator_create.restype = C.c_void_p
+        L.ct2x_translator_create.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+        L.ct2x_translator_destroy.argtypes = [C.c_void_p]
+        L.ct2x_vocab_token.restype = C.c_char_p
+        L.ct2x_vocab_token.argtypes = [C.c_void_p, C.c_int, C.c_int32]
+        L.ct2x_vocab_id.restype = C.c_int32
+        L.ct2x_vocab_id.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+        L.ct2x_vocab_size.argtypes = [C.c_void_p, C.c_int]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise Ct2xError(lib().ct2x_last_error().decode("utf-8", "replace"))
+
+
+def ptr(x):
+    """Device/host pointer of a torch tensor / numpy array / int / None as c_void_p."""
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if hasattr(x, "ctypes"):
+        return x.ctypes.data_as(C.c_void_p)
+    raise TypeError("cannot take a pointer of %r" % type(x))

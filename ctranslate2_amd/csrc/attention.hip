@@ -1,0 +1,332 @@
+// Fused single-query-row attention for gfx950: QK^T * scale -> length mask -> softmax -> PV in
+// one launch over a PRE-ALLOCATED KV cache, replacing the reference's per-step
+// Concat(cache) + MatMul + SoftMax + MatMul chain (src/layers/attention.cc:541-546, 216-277)
+// and ops::Tile head replication for GQA (attention.cc:291-295).
+//
+// One wave64 per (row, head). A key row of `dhead` floats is covered by G = dhead/4 lanes
+// reading 16 bytes each (coalesced 1 KiB per wave-instruction for dhead = 64); 64/G keys are
+// processed per iteration. Scores live in LDS; softmax is a wave64 shuffle reduction;
+// PV accumulates float4 per lane and is folded across the key groups with xor-shuffles.
+// HBM-bound: K and V are each read exactly once.
+//
+// Float formulas follow the reference CPU path: scores = alpha * (q . k)
+// (ops::MatMul alpha = queries_scale, attention.cc:216-217), softmax = exp(x - max) * (1/sum)
+// (src/cpu/kernels.cc:452-455), masked positions contribute exact 0.
+
+#include "device_utils.h"
+#include "kernels.h"
+
+#include <float.h>
+
+namespace ct2x {
+
+namespace {
+
+constexpr int kMaxChunks = 2;  // float4 chunks per lane => dhead <= 4 * G * kMaxChunks
+
+// Loads 4 consecutive elements [i0, i0+4) of a head vector, applying RoPE at `pos` when
+// requested (reference formula src/ops/rotary_cpu.cc:31-36).
+__device__ __forceinline__ float4 load4_rope(const float* __restrict__ base, int i0,
+                                             const float* __restrict__ sin_t,
+                                             const float* __restrict__ cos_t, int rot_dim,
+                                             bool interleave) {
+  float4 v = *reinterpret_cast<const float4*>(base + i0);
+  if (sin_t == nullptr || i0 >= rot_dim) return v;
+  float x[4] = {v.x, v.y, v.z, v.w};
+  float y[4];
+  const int middle = rot_dim / 2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = i0 + e;
+    if (i < rot_dim) {
+      float other;
+      if (interleave)
+        other = (i % 2 == 0) ? -base[i + 1] : base[i - 1];
+      else
+        other = (i < middle) ? -base[i + middle] : base[i - middle];
+      y[e] = x[e] * cos_t[i] + other * sin_t[i];
+    } else {
+      y[e] = x[e];
+    }
+  }
+  return make_float4(y[0], y[1], y[2], y[3]);
+}
+
+__device__ __forceinline__ float dot4(float4 a, float4 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+struct AttnKernelArgs {
+  AttnDecodeParams p;
+  int causal_tq;     // >0: rows are (batch, query i = row % causal_tq); keys limited to i+q_offset+1
+  int64_t q_offset;
+  int mask_tq;       // >0: rows are (batch, query) pairs without causality (encoder)
+};
+
+template <int G>
+__global__ __launch_bounds__(64) void attn_row_kernel(AttnKernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float scores[];
+  const AttnDecodeParams& p = a.p;
+  constexpr int KPI = 64 / G;  // keys per iteration
+  const int lane = threadIdx.x;
+  const int kg = lane / G, c = lane % G;
+  const int64_t row = blockIdx.x / p.heads;
+  const int h = static_cast<int>(blockIdx.x % p.heads);
+  const int group = static_cast<int>(p.heads / p.heads_kv);
+  const int hk = h / group;
+  const int64_t kvrow = row / p.kv_group;
+  const int nc = static_cast<int>(p.dhead / 4);
+
+  int64_t t_cached;
+  if (p.lengths != nullptr)
+    t_cached = p.lengths[kvrow];
+  else if (p.step_ptr != nullptr)
+    t_cached = *p.step_ptr;
+  else
+    t_cached = p.length;
+  if (a.causal_tq > 0) {
+    const int64_t i = row % a.causal_tq;
+    const int64_t lim = i + a.q_offset + 1;
+    if (lim < t_cached) t_cached = lim;
+  }
+  if (t_cached > p.t_max) t_cached = p.t_max;
+  if (t_cached < 0) t_cached = 0;
+  const int64_t pos = t_cached;  // position of the token being decoded (self-attention)
+  const bool has_new = (p.k_new != nullptr);
+  const int64_t t_total = t_cached + (has_new ? 1 : 0);
+
+  const float* sin_t = p.rope_sin ? p.rope_sin + pos * p.rot_dim : nullptr;
+  const float* cos_t = p.rope_cos ? p.rope_cos + pos * p.rot_dim : nullptr;
+  const int rot_dim = static_cast<int>(p.rot_dim);
+
+  // ---- q (and the new k / v) into registers -------------------------------------------
+  const float* qh = p.q + row * p.q_row_stride + static_cast<int64_t>(h) * p.dhead;
+  float4 qv[kMaxChunks], knew[kMaxChunks], vnew[kMaxChunks];
+#pragma unroll
+  for (int u = 0; u < kMaxChunks; ++u) {
+    const int cc = c + u * G;
+    qv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    knew[u] = qv[u];
+    vnew[u] = qv[u];
+    if (cc < nc) {
+      qv[u] = load4_rope(qh, cc * 4, sin_t, cos_t, rot_dim, p.rope_interleave);
+      if (has_new) {
+        const float* kn = p.k_new + row * p.new_row_stride + static_cast<int64_t>(hk) * p.dhead;
+        const float* vn = p.v_new + row * p.new_row_stride + static_cast<int64_t>(hk) * p.dhead;
+        knew[u] = load4_rope(kn, cc * 4, sin_t, cos_t, rot_dim, p.rope_interleave);
+        vnew[u] = *reinterpret_cast<const float4*>(vn + cc * 4);
+      }
+    }
+  }
+
+  float* kc = p.k_cache + kvrow * p.kv_row_stride + static_cast<int64_t>(hk) * p.kv_head_stride;
+  float* vc = p.v_cache + kvrow * p.kv_row_stride + static_cast<int64_t>(hk) * p.kv_head_stride;
+
+  // Cache append (in place of ops::Concat): the first query head of each KV head owns it.
+  if (has_new && (h % group) == 0 && kg == 0) {
+#pragma unroll
+    for (int u = 0; u < kMaxChunks; ++u) {
+      const int cc = c + u * G;
+      if (cc < nc) {
+        *reinterpret_cast<float4*>(kc + pos * p.kv_time_stride + cc * 4) = knew[u];
+        *reinterpret_cast<float4*>(vc + pos * p.kv_time_stride + cc * 4) = vnew[u];
+      }
+    }
+  }
+
+  // ---- phase 1: scores = scale * (q . k_t) ----------------------------------------------
+  for (int64_t t0 = 0; t0 < t_cached; t0 += KPI) {
+    const int64_t t = t0 + kg;
+    float part = 0.f;
+    if (t < t_cached) {
+#pragma unroll
+      for (int u = 0; u < kMaxChunks; ++u) {
+        const int cc = c + u * G;
+        if (cc < nc) {
+          const float4 kv = *reinterpret_cast<const float4*>(kc + t * p.kv_time_stride + cc * 4);
+          part += dot4(qv[u], kv);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (c == 0 && t < t_cached) scores[t] = part * p.scale;
+  }
+  if (has_new) {
+    float part = 0.f;
+#pragma unroll
+    for (int u = 0; u < kMaxChunks; ++u) part += dot4(qv[u], knew[u]);
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) scores[t_cached] = part * p.scale;
+  }
+  __syncthreads();
+
+  // ---- phase 2: softmax over [0, t_total) -------------------------------------------------
+  float* out = p.out + row * (p.heads * p.dhead) + static_cast<int64_t>(h) * p.dhead;
+  if (t_total == 0) {  // fully masked row: softmax output is all zeros -> context is zero
+    if (kg == 0) {
+#pragma unroll
+      for (int u = 0; u < kMaxChunks; ++u) {
+        const int cc = c + u * G;
+        if (cc < nc) *reinterpret_cast<float4*>(out + cc * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    return;
+  }
+  float m = -FLT_MAX;
+  for (int64_t t = lane; t < t_total; t += 64) m = fmaxf(m, scores[t]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int64_t t = lane; t < t_total; t += 64) {
+    const float e = expf(scores[t] - m);
+    scores[t] = e;
+    s += e;
+  }
+  s = wave_sum(s);
+  const float r = 1.f / s;
+  for (int64_t t = lane; t < t_total; t += 64) scores[t] = scores[t] * r;
+  __syncthreads();
+
+  // ---- phase 3: out = sum_t p_t * v_t -------------------------------------------------------
+  float4 acc[kMaxChunks];
+#pragma unroll
+  for (int u = 0; u < kMaxChunks; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t t = kg; t < t_cached; t += KPI) {
+    const float pt = scores[t];
+#pragma unroll
+    for (int u = 0; u < kMaxChunks; ++u) {
+      const int cc = c + u * G;
+      if (cc < nc) {
+        const float4 vv = *reinterpret_cast<const float4*>(vc + t * p.kv_time_stride + cc * 4);
+        acc[u].x += pt * vv.x;
+        acc[u].y += pt * vv.y;
+        acc[u].z += pt * vv.z;
+        acc[u].w += pt * vv.w;
+      }
+    }
+  }
+  if (has_new && kg == static_cast<int>(t_cached % KPI)) {
+    const float pt = scores[t_cached];
+#pragma unroll
+    for (int u = 0; u < kMaxChunks; ++u) {
+      acc[u].x += pt * vnew[u].x;
+      acc[u].y += pt * vnew[u].y;
+      acc[u].z += pt * vnew[u].z;
+      acc[u].w += pt * vnew[u].w;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kMaxChunks; ++u) {
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) {
+      acc[u].x += __shfl_xor(acc[u].x, o, 64);
+      acc[u].y += __shfl_xor(acc[u].y, o, 64);
+      acc[u].z += __shfl_xor(acc[u].z, o, 64);
+      acc[u].w += __shfl_xor(acc[u].w, o, 64);
+    }
+  }
+  if (kg == 0) {
+#pragma unroll
+    for (int u = 0; u < kMaxChunks; ++u) {
+      const int cc = c + u * G;
+      if (cc < nc) *reinterpret_cast<float4*>(out + cc * 4) = acc[u];
+    }
+  }
+}
+
+template <int G>
+void launch_rows(const AttnKernelArgs& a, hipStream_t stream) {
+  const AttnDecodeParams& p = a.p;
+  const size_t lds = static_cast<size_t>(p.t_max + 1) * sizeof(float);
+  hipLaunchKernelGGL(attn_row_kernel<G>, dim3(static_cast<unsigned>(p.rows * p.heads)), dim3(64),
+                     lds, stream, a);
+}
+
+void dispatch(const AttnKernelArgs& a, hipStream_t stream) {
+  const int nc = static_cast<int>(a.p.dhead / 4);
+  if (nc <= 1) launch_rows<1>(a, stream);
+  else if (nc <= 2) launch_rows<2>(a, stream);
+  else if (nc <= 4) launch_rows<4>(a, stream);
+  else if (nc <= 8) launch_rows<8>(a, stream);
+  else if (nc <= 16) launch_rows<16>(a, stream);
+  else if (nc <= 32) launch_rows<32>(a, stream);
+  else launch_rows<64>(a, stream);
+}
+
+}  // namespace
+
+void launch_attention_decode(const AttnDecodeParams& p, hipStream_t stream) {
+  if (p.rows == 0) return;
+  AttnKernelArgs a;
+  a.p = p;
+  a.causal_tq = 0;
+  a.q_offset = 0;
+  a.mask_tq = 0;
+  dispatch(a, stream);
+}
+
+// Prefill / encoder attention expressed on the same kernel: every (batch, query) pair is a
+// "row" that shares its batch's K/V (kv_group = tq). Reference masks:
+// MultiHeadAttention::prepare_length_mask (src/layers/attention_layer.cc:152-174):
+// valid = min(length[b], q + 1) when causal.
+void launch_attention_full(const AttnFullParams& f, hipStream_t stream) {
+  if (f.batch * f.tq == 0) return;
+  AttnKernelArgs a;
+  AttnDecodeParams& p = a.p;
+  p.q = f.q;
+  p.q_row_stride = f.q_time_stride;  // rows are contiguous (b, t) pairs: requires
+                                     // q_batch_stride == tq * q_time_stride
+  p.k_cache = const_cast<float*>(f.k);
+  p.v_cache = const_cast<float*>(f.v);
+  p.kv_row_stride = f.k_batch_stride;
+  p.kv_head_stride = f.k_head_stride;
+  p.kv_time_stride = f.k_time_stride;
+  p.lengths = f.lengths;
+  p.length = f.tk;
+  p.rows = f.batch * f.tq;
+  p.heads = f.heads;
+  p.heads_kv = f.heads_kv;
+  p.dhead = f.dhead;
+  p.kv_group = f.tq;
+  p.t_max = f.tk;
+  p.scale = f.scale;
+  p.out = f.out;
+  a.causal_tq = f.causal ? static_cast<int>(f.tq) : 0;
+  a.q_offset = f.q_offset;
+  a.mask_tq = static_cast<int>(f.tq);
+  dispatch(a, stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// Beam reorder of the pre-allocated self-attention caches (Decoder::update_state ->
+// ops::Gather on every cache tensor, src/layers/decoder.cc:33-56): only the `len` live
+// positions of each (row, head) are moved, src -> dst (ping-pong buffers).
+// ---------------------------------------------------------------------------------------
+__global__ void cache_gather_kernel(const float* const* __restrict__ src,
+                                    float* const* __restrict__ dst,
+                                    const int32_t* __restrict__ parent, int64_t heads,
+                                    int64_t t_max, int64_t dhead,
+                                    const int32_t* __restrict__ step_ptr, int64_t length) {
+  const int64_t r = blockIdx.x / heads;
+  const int64_t h = blockIdx.x % heads;
+  const int t = blockIdx.y;
+  const int64_t len = step_ptr ? *step_ptr : length;
+  const int64_t n4 = len * dhead / 4;
+  const float4* s = reinterpret_cast<const float4*>(
+      src[t] + (static_cast<int64_t>(parent[r]) * heads + h) * t_max * dhead);
+  float4* d = reinterpret_cast<float4*>(dst[t] + (r * heads + h) * t_max * dhead);
+  for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) d[i] = s[i];
+}
+
+void launch_cache_gather(const float* const* tensors_src, float* const* tensors_dst,
+                         int n_tensors, const int32_t* parent, int64_t rows, int64_t heads,
+                         int64_t t_max, int64_t dhead, const int32_t* step_ptr, int64_t length,
+                         hipStream_t stream) {
+  if (rows == 0 || n_tensors == 0) return;
+  hipLaunchKernelGGL(cache_gather_kernel, dim3(static_cast<unsigned>(rows * heads), n_tensors),
+                     dim3(128), 0, stream, tensors_src, tensors_dst, parent, heads, t_max, dhead,
+                     step_ptr, length);
+}
+
+}  // namespace ct2x

@@ -1,0 +1,350 @@
+// extern "C" surface of the op-level boundary declared in include/ct2_mi355.h.
+// Argument checking + launch + error translation only; no arithmetic happens on the host.
+
+#include "../../include/ct2_mi355.h"
+
+#include <cstring>
+
+#include "kernels.h"
+#include "runtime.h"
+
+using namespace ct2x;
+
+#define API_TRY try {
+#define API_CATCH                                     \
+  }                                                   \
+  catch (const std::exception& e) {                   \
+    set_last_error(e.what());                         \
+    return 1;                                         \
+  }                                                   \
+  return 0;
+
+static void require_f32(int dtype, const char* what) {
+  if (dtype != CT2X_F32)
+    throw Error(std::string(what) + ": only float32 activations are implemented in this "
+                "round (float16/bfloat16 variants are declared but not built yet)");
+}
+
+extern "C" {
+
+const char* ct2x_last_error(void) { return last_error(); }
+int ct2x_version(void) { return CT2X_VERSION; }
+
+int ct2x_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ct2x_set_device(int device_index) {
+  API_TRY
+  CT2X_HIP_CHECK(hipSetDevice(device_index));
+  API_CATCH
+}
+
+int ct2x_get_device(int* device_index) {
+  API_TRY
+  CT2X_HIP_CHECK(hipGetDevice(device_index));
+  API_CATCH
+}
+
+int ct2x_device_info(int device_index, char* name, int name_size, char* arch, int arch_size,
+                     int* compute_units, int64_t* hbm_bytes) {
+  API_TRY
+  hipDeviceProp_t prop;
+  CT2X_HIP_CHECK(hipGetDeviceProperties(&prop, device_index));
+  if (name && name_size > 0) {
+    std::strncpy(name, prop.name, name_size - 1);
+    name[name_size - 1] = 0;
+  }
+  if (arch && arch_size > 0) {
+    std::strncpy(arch, prop.gcnArchName, arch_size - 1);
+    arch[arch_size - 1] = 0;
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = static_cast<int64_t>(prop.totalGlobalMem);
+  API_CATCH
+}
+
+void* ct2x_thread_stream(void) {
+  try {
+    return thread_stream();
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return nullptr;
+  }
+}
+
+int ct2x_stream_synchronize(void* stream) {
+  API_TRY
+  CT2X_HIP_CHECK(hipStreamSynchronize(resolve_stream(stream)));
+  API_CATCH
+}
+
+int ct2x_malloc(void** d_ptr, size_t bytes) {
+  API_TRY
+  *d_ptr = device_malloc(bytes);
+  API_CATCH
+}
+
+int ct2x_free(void* d_ptr) {
+  API_TRY
+  device_free(d_ptr);
+  API_CATCH
+}
+
+int ct2x_clear_cache(void) {
+  API_TRY
+  clear_cache();
+  API_CATCH
+}
+
+int64_t ct2x_allocated_bytes(void) { return allocated_bytes(); }
+
+int ct2x_copy_to_device(const void* h_src, void* d_dst, size_t bytes, void* stream) {
+  API_TRY
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice,
+                                resolve_stream(stream)));
+  // Pageable host memory: the call returns once the source buffer may be reused.
+  API_CATCH
+}
+
+int ct2x_copy_to_host(const void* d_src, void* h_dst, size_t bytes, void* stream) {
+  API_TRY
+  hipStream_t s = resolve_stream(stream);
+  CT2X_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+  CT2X_HIP_CHECK(hipStreamSynchronize(s));  // callers read the host buffer immediately
+  API_CATCH
+}
+
+int ct2x_copy_device(const void* d_src, void* d_dst, size_t bytes, void* stream) {
+  API_TRY
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice,
+                                resolve_stream(stream)));
+  API_CATCH
+}
+
+int ct2x_event_create(void** event) {
+  API_TRY
+  hipEvent_t e;
+  CT2X_HIP_CHECK(hipEventCreate(&e));
+  *event = e;
+  API_CATCH
+}
+
+int ct2x_event_destroy(void* event) {
+  API_TRY
+  CT2X_HIP_CHECK(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  API_CATCH
+}
+
+int ct2x_event_record(void* event, void* stream) {
+  API_TRY
+  CT2X_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(event), resolve_stream(stream)));
+  API_CATCH
+}
+
+int ct2x_event_elapsed_ms(void* start, void* stop, float* ms) {
+  API_TRY
+  CT2X_HIP_CHECK(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+  CT2X_HIP_CHECK(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start),
+                                     static_cast<hipEvent_t>(stop)));
+  API_CATCH
+}
+
+// ---- ops ------------------------------------------------------------------------------
+
+int ct2x_quantize_s8(const void* d_x, int dtype, int64_t rows, int64_t depth,
+                     int round_before_cast, int8_t* d_q, float* d_scales, void* stream) {
+  API_TRY
+  require_f32(dtype, "ct2x_quantize_s8");
+  launch_quantize_s8(static_cast<const float*>(d_x), rows, depth, round_before_cast != 0, d_q,
+                     d_scales, resolve_stream(stream));
+  check_last_launch("quantize_s8");
+  API_CATCH
+}
+
+int ct2x_gemm_s8s8s32(const int8_t* d_a, const int8_t* d_b, int64_t m, int64_t n, int64_t k,
+                      int32_t* d_c, void* stream) {
+  API_TRY
+  GemmS8Epilogue ep;
+  ep.mode = 0;
+  ep.c_i32 = d_c;
+  ep.ldy = n;
+  launch_gemm_s8(d_a, d_b, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("gemm_s8s8s32");
+  API_CATCH
+}
+
+int ct2x_dequantize_gemm_output(const int32_t* d_c, const float* d_a_scale,
+                                const float* d_b_scale, const float* d_bias, int64_t m,
+                                int64_t n, int activation, void* d_y, int dtype, void* stream) {
+  API_TRY
+  require_f32(dtype, "ct2x_dequantize_gemm_output");
+  launch_dequantize_gemm_output(d_c, d_a_scale, d_b_scale, d_bias, m, n, activation,
+                                static_cast<float*>(d_y), resolve_stream(stream));
+  check_last_launch("dequantize_gemm_output");
+  API_CATCH
+}
+
+int ct2x_gemm_s8_dequant(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w,
+                         const float* d_w_scale, const float* d_bias, const void* d_residual,
+                         int64_t m, int64_t n, int64_t k, int activation, void* d_y, int dtype,
+                         void* stream) {
+  API_TRY
+  require_f32(dtype, "ct2x_gemm_s8_dequant");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.a_scale = d_a_scale;
+  ep.w_scale = d_w_scale;
+  ep.bias = d_bias;
+  ep.residual = static_cast<const float*>(d_residual);
+  ep.y = static_cast<float*>(d_y);
+  ep.act = activation;
+  ep.ldy = n;
+  launch_gemm_s8(d_qa, d_w, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("gemm_s8_dequant");
+  API_CATCH
+}
+
+int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,
+                         void* d_y, int dtype, void* stream) {
+  API_TRY
+  require_f32(dtype, "ct2x_dequantize_rows");
+  launch_dequantize_rows(d_x, d_scale, rows, depth, static_cast<float*>(d_y),
+                         resolve_stream(stream));
+  check_last_launch("dequantize_rows");
+  API_CATCH
+}
+
+int ct2x_gemm_f32(const float* d_a, const float* d_b, int64_t m, int64_t n, int64_t k,
+                  int trans_b, const float* d_bias, const float* d_residual, int activation,
+                  float* d_c, void* stream) {
+  API_TRY
+  launch_gemm_f32(d_a, d_b, 1, m, n, k, trans_b != 0, 1.f, 0, 0, 0, d_bias, d_residual,
+                  activation, d_c, resolve_stream(stream));
+  check_last_launch("gemm_f32");
+  API_CATCH
+}
+
+int ct2x_layer_norm(const void* d_x, const float* d_gamma, const float* d_beta, int64_t rows,
+                    int64_t depth, float epsilon, void* d_y, int dtype, void* stream) {
+  API_TRY
+  require_f32(dtype, "ct2x_layer_norm");
+  CT2X_CHECK(d_beta != nullptr, "ct2x_layer_norm: beta is required (use ct2x_rms_norm)");
+  CT2X_CHECK(depth * 4 <= 64 * 1024, "ct2x_layer_norm: depth > 16384 is not supported");
+  launch_norm(static_cast<const float*>(d_x), d_gamma, d_beta, rows, depth, epsilon, false, true,
+              static_cast<float*>(d_y), nullptr, nullptr, resolve_stream(stream));
+  check_last_launch("layer_norm");
+  API_CATCH
+}
+
+int ct2x_rms_norm(const void* d_x, const float* d_gamma, int64_t rows, int64_t depth,
+                  float epsilon, int use_residual, void* d_y, int dtype, void* stream) {
+  API_TRY
+  require_f32(dtype, "ct2x_rms_norm");
+  CT2X_CHECK(depth * 4 <= 64 * 1024, "ct2x_rms_norm: depth > 16384 is not supported");
+  launch_norm(static_cast<const float*>(d_x), d_gamma, nullptr, rows, depth, epsilon,
+              use_residual != 0, true, static_cast<float*>(d_y), nullptr, nullptr,
+              resolve_stream(stream));
+  check_last_launch("rms_norm");
+  API_CATCH
+}
+
+int ct2x_norm_quantize_s8(const float* d_x, const float* d_gamma, const float* d_beta,
+                          int64_t rows, int64_t depth, float epsilon, int use_residual,
+                          int round_before_cast, float* d_y, int8_t* d_q, float* d_scales,
+                          void* stream) {
+  API_TRY
+  CT2X_CHECK(depth * 4 <= 64 * 1024, "ct2x_norm_quantize_s8: depth > 16384 is not supported");
+  launch_norm(d_x, d_gamma, d_beta, rows, depth, epsilon, use_residual != 0,
+              round_before_cast != 0, d_y, d_q, d_scales, resolve_stream(stream));
+  check_last_launch("norm_quantize_s8");
+  API_CATCH
+}
+
+int ct2x_softmax(const void* d_x, const int32_t* d_lengths, int64_t rows, int64_t depth,
+                 int log, void* d_y, int dtype, void* stream) {
+  API_TRY
+  require_f32(dtype, "ct2x_softmax");
+  launch_softmax(static_cast<const float*>(d_x), d_lengths, rows, depth, log != 0,
+                 static_cast<float*>(d_y), resolve_stream(stream));
+  check_last_launch("softmax");
+  API_CATCH
+}
+
+int ct2x_rotary(const float* d_x, const float* d_sin, const float* d_cos, int64_t batch,
+                int64_t time, int64_t depth, int64_t ndims, int interleave, float* d_y,
+                void* stream) {
+  API_TRY
+  CT2X_CHECK(ndims <= depth && ndims % 2 == 0, "ct2x_rotary: invalid ndims");
+  launch_rotary(d_x, d_sin, d_cos, batch, time, depth, ndims, interleave != 0, d_y,
+                resolve_stream(stream));
+  check_last_launch("rotary");
+  API_CATCH
+}
+
+int ct2x_topk(const void* d_x, int dtype, int64_t rows, int64_t depth, int64_t k,
+              void* d_values, int32_t* d_indices, void* stream) {
+  API_TRY
+  require_f32(dtype, "ct2x_topk");
+  CT2X_CHECK(k >= 1 && k <= depth, "ct2x_topk: k must be in [1, depth]");
+  launch_topk(static_cast<const float*>(d_x), rows, depth, k, static_cast<float*>(d_values),
+              d_indices, resolve_stream(stream));
+  check_last_launch("topk");
+  API_CATCH
+}
+
+int ct2x_gather_rows(const void* d_data, const int32_t* d_idx, int64_t n_idx,
+                     int64_t row_bytes, void* d_out, void* stream) {
+  API_TRY
+  launch_gather_rows(d_data, d_idx, n_idx, row_bytes, d_out, resolve_stream(stream));
+  check_last_launch("gather_rows");
+  API_CATCH
+}
+
+int ct2x_matmul_f32(const float* d_a, const float* d_b, int64_t batch, int64_t m, int64_t n,
+                    int64_t k, int trans_b, float alpha, float* d_c, void* stream) {
+  API_TRY
+  launch_gemm_f32(d_a, d_b, batch, m, n, k, trans_b != 0, alpha, m * k, n * k, m * n, nullptr,
+                  nullptr, -1, d_c, resolve_stream(stream));
+  check_last_launch("matmul_f32");
+  API_CATCH
+}
+
+int ct2x_attention_decode(const float* d_q, const float* d_k_cache, const float* d_v_cache,
+                          const int32_t* d_lengths, int64_t length, int64_t rows, int64_t heads,
+                          int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t kv_group,
+                          float scale, float* d_out, void* stream) {
+  API_TRY
+  CT2X_CHECK(dhead % 4 == 0 && dhead <= 512, "ct2x_attention_decode: dhead must be a multiple "
+             "of 4 and <= 512");
+  CT2X_CHECK(heads_kv >= 1 && heads % heads_kv == 0, "ct2x_attention_decode: heads must be a "
+             "multiple of heads_kv");
+  CT2X_CHECK(kv_group >= 1 && rows % kv_group == 0, "ct2x_attention_decode: rows must be a "
+             "multiple of kv_group");
+  CT2X_CHECK(t_max + 1 <= 16384, "ct2x_attention_decode: t_max > 16383 is not supported");
+  AttnDecodeParams p;
+  p.q = d_q;
+  p.q_row_stride = heads * dhead;
+  p.k_cache = const_cast<float*>(d_k_cache);
+  p.v_cache = const_cast<float*>(d_v_cache);
+  p.kv_row_stride = heads_kv * t_max * dhead;
+  p.kv_head_stride = t_max * dhead;
+  p.kv_time_stride = dhead;
+  p.lengths = d_lengths;
+  p.length = length;
+  p.rows = rows;
+  p.heads = heads;
+  p.heads_kv = heads_kv;
+  p.dhead = dhead;
+  p.kv_group = kv_group;
+  p.t_max = t_max;
+  p.scale = scale;
+  p.out = d_out;
+  launch_attention_decode(p, resolve_stream(stream));
+  check_last_launch("attention_decode");
+  API_CATCH
+}
+
+}  // extern "C"

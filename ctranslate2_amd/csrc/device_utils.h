@@ -1,0 +1,122 @@
+// Device-side helpers shared by the gfx950 kernels (wave64 reductions, vector types,
+// activation functors). CDNA4 only: wavefront = 64 lanes, no 32-lane assumptions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ct2x {
+
+constexpr int kWave = 64;
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide reductions through a small LDS scratch (one float per wave, up to 16 waves).
+// All threads of the block must call; every thread receives the result.
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();  // protect scratch reuse
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  float r = scratch[0];
+  for (int i = 1; i < nwaves; ++i) r = fmaxf(r, scratch[i]);
+  return r;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  float r = scratch[0];
+  for (int i = 1; i < nwaves; ++i) r += scratch[i];
+  return r;
+}
+
+// (value, index) argmax with lowest-index tie-break == std::max_element
+// (reference CPU TopK, src/ops/topk_cpu.cc:27).
+struct ValIdx {
+  float v;
+  int i;
+};
+
+__device__ __forceinline__ ValIdx better(ValIdx a, ValIdx b) {
+  // a wins if larger, or equal with a lower index. Empty slots carry i = INT_MAX and
+  // always lose (even against -inf).
+  if (a.i == 0x7fffffff) return b;
+  if (b.i == 0x7fffffff) return a;
+  if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+  return a;
+}
+
+__device__ __forceinline__ ValIdx wave_argmax(ValIdx x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ValIdx y;
+    y.v = __shfl_xor(x.v, o, 64);
+    y.i = __shfl_xor(x.i, o, 64);
+    x = better(x, y);
+  }
+  return x;
+}
+
+// Activation epilogues: float math identical in form to the reference CPU functors
+// (src/cpu/kernels.cc:146-207).
+__device__ __forceinline__ float apply_activation(float v, int act) {
+  switch (act) {
+    case 0:  // ReLU
+      return fmaxf(v, 0.f);
+    case 1: {  // GELUTanh
+      float u = v * v * v;
+      u = 0.044715f * u + v;
+      u = 0.7978845608028654f * u;
+      u = tanhf(u);
+      u = 1.f + u;
+      u = v * u;
+      return 0.5f * u;
+    }
+    case 2:  // Swish
+      return v / (1.f + expf(-v));
+    case 3: {  // GELU
+      float u = 0.7071067811865475f * v;
+      u = 1.f + erff(u);
+      u = v * u;
+      return 0.5f * u;
+    }
+    case 4:  // GELUSigmoid
+      return v / (1.f + expf(-1.702f * v));
+    case 5:  // Tanh
+      return tanhf(v);
+    case 6:  // Sigmoid
+      return 1.f / (1.f + expf(-v));
+    default:
+      return v;
+  }
+}
+
+// float -> int8 exactly as the reference CPU path: optional round-to-nearest-even
+// (Vec::round = _mm256_round_ps NEAREST, src/cpu/vec_avx.h:192-202) then truncating
+// conversion (cvttps) and a narrowing store.
+__device__ __forceinline__ int8_t to_s8(float v, bool round_before_cast) {
+  if (round_before_cast) v = rintf(v);
+  return static_cast<int8_t>(static_cast<int>(v));
+}
+
+}  // namespace ct2x

@@ -1,0 +1,184 @@
+// int8 x int8 -> int32 projection GEMM for gfx950 with the Dequantize(+bias,+activation,
+// +residual) epilogue fused in, replacing the reference's cuBLAS GemmEx 8I->32I call
+// (src/cuda/primitives.cu:571-597) + dequantize_gemm_output kernel
+// (src/ops/dequantize_gpu.cu:31-55) + residual Add (src/layers/common.cc:392-401).
+//
+//   C[m,n] = A[m,k] . B[n,k]^T     A = quantised activations, B = int8 weight [N,K] row-major
+//
+// Both operands are K-contiguous, which is exactly the MFMA i8 fragment shape:
+// v_mfma_i32_16x16x64_i8 takes 16 consecutive K bytes per lane for A (row = lane&15) and for B
+// (col = lane&15), K-block = lane>>4. Tiles are staged through LDS with a 16-byte row pad
+// (144-byte stride => conflict-free ds_read_b128), global->register->LDS with the next tile's
+// global loads in flight during the MFMAs.
+//
+// Integer accumulation is exact, so any correct tiling is bit-identical to the oracle.
+
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace ct2x {
+
+namespace {
+
+constexpr int BK = 128;            // K bytes per LDS tile (two MFMA K-steps of 64)
+constexpr int LDS_STRIDE = BK + 16;  // bytes per tile row in LDS
+
+__device__ __forceinline__ void store_epilogue(const GemmS8Epilogue& ep, int64_t row, int64_t col,
+                                               int acc, float r_a) {
+  const int64_t idx = row * ep.ldy + col;
+  if (ep.mode == 0) {
+    ep.c_i32[idx] = acc;
+  } else {
+    // CPU formula order (src/cpu/kernels.cc:666-673): c * (1/a_scale) / b_scale + bias.
+    float v = static_cast<float>(acc) * r_a;
+    v = v / ep.w_scale[col];
+    if (ep.bias) v = v + ep.bias[col];
+    v = apply_activation(v, ep.act);
+    if (ep.residual) v = ep.residual[idx] + v;  // ops::Add()(residual, output, output)
+    ep.y[idx] = v;
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restrict__ A,
+                                                           const int8_t* __restrict__ B,
+                                                           int M, int N, int K,
+                                                           GemmS8Epilogue ep) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;  // 16-byte chunks per thread per tile
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows are loaded 32 at a time");
+
+  __shared__ __attribute__((aligned(16))) int8_t lds[(BM + BN) * LDS_STRIDE];
+  int8_t* As = lds;
+  int8_t* Bs = lds + BM * LDS_STRIDE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.y) * BM;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * BN;
+
+  // Staging map: 8 consecutive threads fetch one 128-byte row segment.
+  const int ld_row = tid >> 3;  // 0..31
+  const int ld_chunk = tid & 7;  // 16-byte chunk within the BK segment
+
+  v4i acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+  uint4 ra[A_LOADS], rb[B_LOADS];
+
+  auto load_tile = [&](int k0) {
+    const int kk = k0 + ld_chunk * 16;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int64_t row = m0 + ld_row + i * 32;
+      ra[i] = (row < M && kk < K) ? *reinterpret_cast<const uint4*>(A + row * K + kk)
+                                  : uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int64_t row = n0 + ld_row + i * 32;
+      rb[i] = (row < N && kk < K) ? *reinterpret_cast<const uint4*>(B + row * K + kk)
+                                  : uint4{0, 0, 0, 0};
+    }
+  };
+
+  load_tile(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i)
+      *reinterpret_cast<uint4*>(As + (ld_row + i * 32) * LDS_STRIDE + ld_chunk * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i)
+      *reinterpret_cast<uint4*>(Bs + (ld_row + i * 32) * LDS_STRIDE + ld_chunk * 16) = rb[i];
+    __syncthreads();
+    if (k0 + BK < K) load_tile(k0 + BK);  // in flight while the MFMAs run
+
+#pragma unroll
+    for (int ks = 0; ks < BK / 64; ++ks) {
+      v4i af[TM], bf[TN];
+      const int koff = ks * 64 + (lane >> 4) * 16;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const v4i*>(As + (wm * WTM + i * 16 + (lane & 15)) * LDS_STRIDE +
+                                              koff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const v4i*>(Bs + (wn * WTN + j * 16 + (lane & 15)) * LDS_STRIDE +
+                                              koff);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = m0 + wm * WTM + i * 16 + (lane >> 4) * 4 + r;
+      if (row >= M) continue;
+      const float r_a = (ep.mode == 1) ? 1.f / ep.a_scale[row] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int64_t col = n0 + wn * WTN + j * 16 + (lane & 15);
+        if (col < N) store_epilogue(ep, row, col, acc[i][j][r], r_a);
+      }
+    }
+  }
+}
+
+// Shapes the MFMA path cannot take (K not a multiple of 16 or unaligned bases): one thread
+// per output element. Only tiny fixture models hit this.
+__global__ void gemm_s8_naive_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ B,
+                                     int M, int N, int K, GemmS8Epilogue ep) {
+  const int64_t col = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t row = blockIdx.y;
+  if (col >= N || row >= M) return;
+  const int8_t* a = A + row * K;
+  const int8_t* b = B + col * K;
+  int acc = 0;
+  for (int k = 0; k < K; ++k) acc += static_cast<int>(a[k]) * static_cast<int>(b[k]);
+  const float r_a = (ep.mode == 1) ? 1.f / ep.a_scale[row] : 0.f;
+  store_epilogue(ep, row, col, acc, r_a);
+}
+
+}  // namespace
+
+void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int64_t k,
+                    const GemmS8Epilogue& ep_in, hipStream_t stream) {
+  if (m == 0 || n == 0) return;
+  GemmS8Epilogue ep = ep_in;
+  if (ep.ldy == 0) ep.ldy = n;
+  const bool mfma_ok = (k % 16 == 0) && k > 0 &&
+                       ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
+  const int M = static_cast<int>(m), N = static_cast<int>(n), K = static_cast<int>(k);
+  if (!mfma_ok) {
+    hipLaunchKernelGGL(gemm_s8_naive_kernel, dim3((n + 63) / 64, m), dim3(64), 0, stream, a, b,
+                       M, N, K, ep);
+    return;
+  }
+  if (m <= 32) {
+    hipLaunchKernelGGL((gemm_s8_mfma_kernel<32, 64, 1, 4>), dim3((n + 63) / 64, (m + 31) / 32),
+                       dim3(256), 0, stream, a, b, M, N, K, ep);
+  } else if (m <= 64) {
+    hipLaunchKernelGGL((gemm_s8_mfma_kernel<64, 64, 2, 2>), dim3((n + 63) / 64, (m + 63) / 64),
+                       dim3(256), 0, stream, a, b, M, N, K, ep);
+  } else {
+    hipLaunchKernelGGL((gemm_s8_mfma_kernel<128, 128, 2, 2>),
+                       dim3((n + 127) / 128, (m + 127) / 128), dim3(256), 0, stream, a, b, M, N,
+                       K, ep);
+  }
+}
+
+}  // namespace ct2x

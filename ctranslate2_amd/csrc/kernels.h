@@ -1,0 +1,152 @@
+// Host-callable launchers for the gfx950 kernels. Everything is asynchronous on `stream`.
+// Pointers are device pointers. These are the functions behind the C ABI (include/ct2_mi355.h)
+// and the building blocks of the decode engine (engine.cc).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ct2x {
+
+// ---- quantisation / normalisation (rowops.hip) ---------------------------------------
+
+void launch_quantize_s8(const float* x, int64_t rows, int64_t depth, bool round_before_cast,
+                        int8_t* q, float* scales, hipStream_t stream);
+
+void launch_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, int64_t depth,
+                            float* y, hipStream_t stream);
+
+void launch_dequantize_gemm_output(const int32_t* c, const float* a_scale, const float* b_scale,
+                                   const float* bias, int64_t m, int64_t n, int act, float* y,
+                                   hipStream_t stream);
+
+// beta == nullptr -> RMSNorm. y and/or q may be nullptr (q==nullptr: plain norm).
+void launch_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
+                 int64_t depth, float eps, bool rms_use_residual, bool round_before_cast,
+                 float* y, int8_t* q, float* scales, hipStream_t stream);
+
+void launch_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth,
+                    bool log, float* y, hipStream_t stream);
+
+// log_softmax(x[row,:]) + row_bias[row] (beam scores), the prologue of beam-search TopK
+// (src/decoding.cc:545-556). row_bias may be nullptr.
+void launch_log_softmax_bias(const float* x, const float* row_bias, int64_t rows, int64_t depth,
+                             float* y, hipStream_t stream);
+
+void launch_rotary(const float* x, const float* sin, const float* cos, int64_t batch,
+                   int64_t time, int64_t depth, int64_t ndims, bool interleave, float* y,
+                   hipStream_t stream);
+
+// Top-k per row over `depth` columns (values desc; ties -> lowest index first).
+void launch_topk(const float* x, int64_t rows, int64_t depth, int64_t k, float* values,
+                 int32_t* indices, hipStream_t stream);
+
+void launch_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int64_t row_bytes,
+                        void* out, hipStream_t stream);
+
+// out[r,:] = table[ids[r],:] (dequantised with 1/scale[id] when table is int8) * emb_scale
+//            + pos[(pos_base + r % time) ...]   (see engine.cc for the position convention)
+// Mirrors Embeddings::operator() + Mul + PositionEncoder (src/layers/common.cc:64-81,151-174,
+// src/layers/transformer.cc:636-648). `step_ptr` (device int) overrides pos_index when non-null.
+void launch_embed(const void* table, bool table_is_int8, const float* table_scale,
+                  const int32_t* ids, int64_t rows, int64_t depth, float emb_scale,
+                  bool apply_scale, const float* pos_table, int64_t time, int64_t pos_index,
+                  const int32_t* step_ptr, float* out, hipStream_t stream);
+
+// y = a + b (residual adds outside a GEMM epilogue), y = a * b (GLU gate).
+void launch_add(const float* a, const float* b, int64_t n, float* y, hipStream_t stream);
+void launch_mul(const float* a, const float* b, int64_t n, float* y, hipStream_t stream);
+
+// ---- int8 GEMM (gemm_s8.hip) ---------------------------------------------------------
+
+struct GemmS8Epilogue {
+  // mode 0: raw int32 store to c_i32.
+  // mode 1: y = act(acc * (1/a_scale[i]) / w_scale[j] + bias[j]) + residual[i,j]  (fp32 store)
+  int mode = 0;
+  int32_t* c_i32 = nullptr;
+  const float* a_scale = nullptr;
+  const float* w_scale = nullptr;
+  const float* bias = nullptr;
+  const float* residual = nullptr;
+  float* y = nullptr;
+  int act = -1;
+  int64_t ldy = 0;  // leading dimension of y / residual / c_i32 (>= n)
+};
+
+// C[m,n] = A[m,k] . B[n,k]^T   (lda = ldb = k). Chooses a tile shape from (m, n, k).
+void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int64_t k,
+                    const GemmS8Epilogue& ep, hipStream_t stream);
+
+// ---- fp32 GEMM (gemm_f32.hip) --------------------------------------------------------
+
+// C[b] = alpha * A[b] . op(B[b]) (+ bias[j]) -> act -> (+ residual). batch==1 for plain GEMM.
+void launch_gemm_f32(const float* a, const float* b, int64_t batch, int64_t m, int64_t n,
+                     int64_t k, bool trans_b, float alpha, int64_t stride_a, int64_t stride_b,
+                     int64_t stride_c, const float* bias, const float* residual, int act,
+                     float* c, hipStream_t stream);
+
+// ---- attention (attention.hip) -------------------------------------------------------
+
+struct AttnDecodeParams {
+  // Queries: q + row*q_row_stride + head*dhead.
+  const float* q = nullptr;
+  int64_t q_row_stride = 0;
+  // New K/V of this step (self-attention only; nullptr for cross-attention):
+  // k_new + row*new_row_stride + head_kv*dhead. They are appended to the cache at position
+  // `pos` by the wave of the first query head of each KV head.
+  const float* k_new = nullptr;
+  const float* v_new = nullptr;
+  int64_t new_row_stride = 0;
+  // Caches: k_cache + kvrow*kv_row_stride + head_kv*kv_head_stride + t*kv_time_stride.
+  float* k_cache = nullptr;
+  float* v_cache = nullptr;
+  int64_t kv_row_stride = 0, kv_head_stride = 0, kv_time_stride = 0;
+  // Number of valid cached positions (excluding the new one): lengths[kvrow] if given, else
+  // *step_ptr if given, else `length`.
+  const int32_t* lengths = nullptr;
+  const int32_t* step_ptr = nullptr;
+  int64_t length = 0;
+  int64_t rows = 0, heads = 0, heads_kv = 0, dhead = 0;
+  int64_t kv_group = 1;  // rows sharing one cache row (beam over encoder memory)
+  int64_t t_max = 0;     // bound on positions (LDS sizing)
+  float scale = 1.f;
+  // Optional RoPE applied to q and k_new at position `pos` (non-interleaved or interleaved),
+  // tables [positions, rot_dim].
+  const float* rope_sin = nullptr;
+  const float* rope_cos = nullptr;
+  int64_t rot_dim = 0;
+  bool rope_interleave = false;
+  float* out = nullptr;  // [rows, heads*dhead]
+};
+
+void launch_attention_decode(const AttnDecodeParams& p, hipStream_t stream);
+
+// Full (prefill / encoder) attention: q [B, Tq, H, dh] (row stride given), k/v with strides,
+// lengths[b] valid keys, causal => key t visible to query i iff t <= i + q_offset.
+struct AttnFullParams {
+  const float* q = nullptr;
+  const float* k = nullptr;
+  const float* v = nullptr;
+  int64_t q_batch_stride = 0, q_time_stride = 0;   // head stride = dhead
+  int64_t k_batch_stride = 0, k_time_stride = 0, k_head_stride = 0;
+  int64_t v_batch_stride = 0, v_time_stride = 0, v_head_stride = 0;
+  const int32_t* lengths = nullptr;  // [B] valid key count (nullptr = tk)
+  int64_t batch = 0, tq = 0, tk = 0, heads = 0, heads_kv = 0, dhead = 0;
+  bool causal = false;
+  int64_t q_offset = 0;
+  float scale = 1.f;
+  float* out = nullptr;  // [B, Tq, H*dh]
+  int64_t out_batch_stride = 0, out_time_stride = 0;
+};
+
+void launch_attention_full(const AttnFullParams& p, hipStream_t stream);
+
+// Beam reorder of pre-allocated caches: for each tensor t in [0, n_tensors):
+//   dst[t][r, :, 0:len, :] = src[t][parent[r], :, 0:len, :]
+// `tensors_src/dst` are device arrays of base pointers.
+void launch_cache_gather(const float* const* tensors_src, float* const* tensors_dst,
+                         int n_tensors, const int32_t* parent, int64_t rows, int64_t heads,
+                         int64_t t_max, int64_t dhead, const int32_t* step_ptr, int64_t length,
+                         hipStream_t stream);
+
+}  // namespace ct2x

@@ -1,0 +1,479 @@
+// Row-wise HBM-bound kernels of the decoder hot path for gfx950 (wave64):
+// Quantize, Dequantize, LayerNorm/RMSNorm (+fused Quantize), (Log)SoftMax, Rotary, TopK,
+// Gather, embedding lookup. One workgroup per row, 16-byte loads where the row allows,
+// wave64 shuffle reductions + one LDS hop per block reduction.
+//
+// Float formulas follow the reference CPU path (the parity oracle), cited per kernel.
+// Compiled with -ffp-contract=off so every expression rounds like the plain C oracle.
+
+#include "device_utils.h"
+#include "kernels.h"
+
+#include <float.h>
+#include <limits.h>
+
+namespace ct2x {
+
+static inline int pick_block(int64_t depth) {
+  // One 16-byte chunk per thread is the sweet spot; clamp to [64, 1024] lanes, wave multiple.
+  int64_t t = (depth + 3) / 4;
+  int b = 64;
+  while (b < t && b < 1024) b <<= 1;
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------
+// ops::Quantize (int8, per row). Reference: src/cpu/kernels.cc:577-651 (quantize_s8_row),
+// GPU counterpart src/ops/quantize_gpu.cu:58-103.
+// ---------------------------------------------------------------------------------------
+__global__ void quantize_s8_kernel(const float* __restrict__ x, int64_t depth,
+                                   bool round_before_cast, int8_t* __restrict__ q,
+                                   float* __restrict__ scales) {
+  __shared__ float scratch[16];
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * depth;
+  int8_t* qr = q + row * depth;
+  const bool vec = (depth % 4 == 0) && ((reinterpret_cast<uintptr_t>(xr) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(qr) & 3) == 0);
+  float amax = 0.f;
+  if (vec) {
+    const float4* xv = reinterpret_cast<const float4*>(xr);
+    for (int64_t i = threadIdx.x; i < depth / 4; i += blockDim.x) {
+      float4 v = xv[i];
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) amax = fmaxf(amax, fabsf(xr[i]));
+  }
+  amax = block_max(amax, scratch);
+  const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+  if (threadIdx.x == 0) scales[row] = scale;
+  if (vec) {
+    const float4* xv = reinterpret_cast<const float4*>(xr);
+    char4* qv = reinterpret_cast<char4*>(qr);
+    for (int64_t i = threadIdx.x; i < depth / 4; i += blockDim.x) {
+      float4 v = xv[i];
+      char4 o;
+      o.x = to_s8(v.x * scale, round_before_cast);
+      o.y = to_s8(v.y * scale, round_before_cast);
+      o.z = to_s8(v.z * scale, round_before_cast);
+      o.w = to_s8(v.w * scale, round_before_cast);
+      qv[i] = o;
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x)
+      qr[i] = to_s8(xr[i] * scale, round_before_cast);
+  }
+}
+
+void launch_quantize_s8(const float* x, int64_t rows, int64_t depth, bool round_before_cast,
+                        int8_t* q, float* scales, hipStream_t stream) {
+  if (rows == 0 || depth == 0) return;
+  hipLaunchKernelGGL(quantize_s8_kernel, dim3(rows), dim3(pick_block(depth)), 0, stream, x,
+                     depth, round_before_cast, q, scales);
+}
+
+// ---------------------------------------------------------------------------------------
+// ops::Dequantize rows: y = x / scale[row]   (src/ops/dequantize_cpu.cc, dequantize_kernel:
+// "x / scale" per element; GPU src/ops/dequantize_gpu.cu:17-28).
+// ---------------------------------------------------------------------------------------
+__global__ void dequantize_rows_kernel(const int8_t* __restrict__ x,
+                                       const float* __restrict__ scale, int64_t depth,
+                                       float* __restrict__ y) {
+  const int64_t row = blockIdx.x;
+  const float s = scale[row];
+  const int8_t* xr = x + row * depth;
+  float* yr = y + row * depth;
+  for (int64_t i = threadIdx.x; i < depth; i += blockDim.x)
+    yr[i] = static_cast<float>(xr[i]) / s;
+}
+
+void launch_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, int64_t depth,
+                            float* y, hipStream_t stream) {
+  if (rows == 0 || depth == 0) return;
+  hipLaunchKernelGGL(dequantize_rows_kernel, dim3(rows), dim3(256), 0, stream, x, scale, depth,
+                     y);
+}
+
+// ---------------------------------------------------------------------------------------
+// ops::Dequantize GEMM-output form, standalone (the fused form lives in gemm_s8.hip).
+// CPU formula order (src/cpu/kernels.cc:653-692): c * (1/a_scale) / b_scale + bias -> act.
+// ---------------------------------------------------------------------------------------
+__global__ void dequantize_gemm_output_kernel(const int32_t* __restrict__ c,
+                                              const float* __restrict__ a_scale,
+                                              const float* __restrict__ b_scale,
+                                              const float* __restrict__ bias, int64_t n, int act,
+                                              float* __restrict__ y) {
+  const int64_t row = blockIdx.x;
+  const float r_a = 1.f / a_scale[row];
+  const int32_t* cr = c + row * n;
+  float* yr = y + row * n;
+  for (int64_t j = threadIdx.x; j < n; j += blockDim.x) {
+    float v = static_cast<float>(cr[j]) * r_a;
+    v = v / b_scale[j];
+    if (bias) v = v + bias[j];
+    yr[j] = apply_activation(v, act);
+  }
+}
+
+void launch_dequantize_gemm_output(const int32_t* c, const float* a_scale, const float* b_scale,
+                                   const float* bias, int64_t m, int64_t n, int act, float* y,
+                                   hipStream_t stream) {
+  if (m == 0 || n == 0) return;
+  hipLaunchKernelGGL(dequantize_gemm_output_kernel, dim3(m), dim3(256), 0, stream, c, a_scale,
+                     b_scale, bias, n, act, y);
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm / RMSNorm (+ optional fused int8 Quantize of the normalised row).
+// Reference: src/cpu/kernels.cc:461-496 (layer_norm: mean = sum/n,
+// var = max(sumsq/n - mean^2, 0), rstd = 1/sqrt(var+eps), y=(x-mean)*rstd*gamma+beta) and
+// :543-573 (rms_norm: inv = 1/sqrt(sumsq/n + eps), y = x*inv*gamma or x*inv*(1+gamma)).
+// The row is staged once in LDS (dynamic, depth floats) so x is read from HBM exactly once.
+// ---------------------------------------------------------------------------------------
+__global__ void norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, int64_t depth, float eps,
+                            bool rms_use_residual, bool round_before_cast,
+                            float* __restrict__ y, int8_t* __restrict__ q,
+                            float* __restrict__ scales) {
+  extern __shared__ __attribute__((aligned(16))) float row_buf[];
+  __shared__ float scratch[16];
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * depth;
+
+  float sum = 0.f, sumsq = 0.f;
+  for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
+    const float v = xr[i];
+    row_buf[i] = v;
+    sum += v;
+    sumsq += v * v;
+  }
+  const float fdepth = static_cast<float>(depth);
+  float amax = 0.f;
+  if (beta != nullptr) {
+    sum = block_sum(sum, scratch);
+    sumsq = block_sum(sumsq, scratch);
+    const float mean = sum / fdepth;
+    const float variance = fmaxf(sumsq / fdepth - mean * mean, 0.f);
+    const float rstd = 1.f / sqrtf(variance + eps);
+    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
+      const float v = (row_buf[i] - mean) * rstd * gamma[i] + beta[i];
+      row_buf[i] = v;
+      amax = fmaxf(amax, fabsf(v));
+    }
+  } else {
+    sumsq = block_sum(sumsq, scratch);
+    const float inv_rms = 1.f / sqrtf(sumsq / fdepth + eps);
+    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
+      const float g = rms_use_residual ? (1.f + gamma[i]) : gamma[i];
+      const float v = row_buf[i] * inv_rms * g;
+      row_buf[i] = v;
+      amax = fmaxf(amax, fabsf(v));
+    }
+  }
+  // Each thread re-reads only the elements it wrote itself: no barrier needed for row_buf.
+  if (y != nullptr) {
+    float* yr = y + row * depth;
+    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) yr[i] = row_buf[i];
+  }
+  if (q != nullptr) {
+    amax = block_max(amax, scratch);
+    const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+    if (threadIdx.x == 0) scales[row] = scale;
+    int8_t* qr = q + row * depth;
+    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x)
+      qr[i] = to_s8(row_buf[i] * scale, round_before_cast);
+  }
+}
+
+void launch_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
+                 int64_t depth, float eps, bool rms_use_residual, bool round_before_cast,
+                 float* y, int8_t* q, float* scales, hipStream_t stream) {
+  if (rows == 0 || depth == 0) return;
+  int block = 64;
+  while (block < depth && block < 512) block <<= 1;
+  hipLaunchKernelGGL(norm_kernel, dim3(rows), dim3(block), depth * sizeof(float), stream, x,
+                     gamma, beta, depth, eps, rms_use_residual, round_before_cast, y, q, scales);
+}
+
+// ---------------------------------------------------------------------------------------
+// SoftMax / LogSoftMax with optional per-row valid length.
+// Reference: src/cpu/kernels.cc:402-459: masked tail = 0; softmax = exp(x-max) * (1/sum);
+// log-softmax = x + (-max - log(sum)).
+// ---------------------------------------------------------------------------------------
+__global__ void softmax_kernel(const float* __restrict__ x, const int32_t* __restrict__ lengths,
+                               const float* __restrict__ row_bias, int64_t depth, bool log,
+                               float* __restrict__ y) {
+  __shared__ float scratch[16];
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * depth;
+  float* yr = y + row * depth;
+  int64_t size = depth;
+  if (lengths != nullptr) {
+    size = lengths[row];
+    if (size > depth) size = depth;
+    if (size < 0) size = 0;
+    for (int64_t j = size + threadIdx.x; j < depth; j += blockDim.x) yr[j] = 0.f;
+    if (size == 0) return;
+  }
+  float m = -FLT_MAX;
+  for (int64_t j = threadIdx.x; j < size; j += blockDim.x) m = fmaxf(m, xr[j]);
+  m = block_max(m, scratch);
+  float s = 0.f;
+  for (int64_t j = threadIdx.x; j < size; j += blockDim.x) s += expf(xr[j] - m);
+  s = block_sum(s, scratch);
+  if (log) {
+    float c = -m - logf(s);
+    for (int64_t j = threadIdx.x; j < size; j += blockDim.x) {
+      float v = xr[j] + c;
+      if (row_bias) v = v + row_bias[row];
+      yr[j] = v;
+    }
+  } else {
+    const float r = 1.f / s;
+    for (int64_t j = threadIdx.x; j < size; j += blockDim.x) yr[j] = expf(xr[j] - m) * r;
+  }
+}
+
+void launch_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth,
+                    bool log, float* y, hipStream_t stream) {
+  if (rows == 0 || depth == 0) return;
+  hipLaunchKernelGGL(softmax_kernel, dim3(rows), dim3(pick_block(depth)), 0, stream, x, lengths,
+                     (const float*)nullptr, depth, log, y);
+}
+
+void launch_log_softmax_bias(const float* x, const float* row_bias, int64_t rows, int64_t depth,
+                             float* y, hipStream_t stream) {
+  if (rows == 0 || depth == 0) return;
+  hipLaunchKernelGGL(softmax_kernel, dim3(rows), dim3(pick_block(depth)), 0, stream, x,
+                     (const int32_t*)nullptr, row_bias, depth, true, y);
+}
+
+// ---------------------------------------------------------------------------------------
+// Rotary embeddings. Reference: src/ops/rotary_cpu.cc:9-44.
+//   interleave:     y[i] = x[i]*c[i] + (i even ? -x[i+1] : x[i-1]) * s[i]
+//   non-interleave: y[i] = x[i]*c[i] + (i < nd/2 ? -x[i+nd/2] : x[i-nd/2]) * s[i]
+// x [batch, time, depth] (batch = B*H), sin/cos [time, ndims]; dims >= ndims are copied.
+// ---------------------------------------------------------------------------------------
+__global__ void rotary_kernel(const float* __restrict__ x, const float* __restrict__ sin,
+                              const float* __restrict__ cos, int64_t time, int64_t depth,
+                              int64_t ndims, bool interleave, float* __restrict__ y) {
+  const int64_t r = blockIdx.x;  // over batch*time
+  const int64_t t = r % time;
+  const float* xr = x + r * depth;
+  float* yr = y + r * depth;
+  const float* s = sin + t * ndims;
+  const float* c = cos + t * ndims;
+  const int64_t middle = ndims / 2;
+  for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
+    if (i < ndims) {
+      float other;
+      if (interleave)
+        other = (i % 2 == 0) ? -xr[i + 1] : xr[i - 1];
+      else
+        other = (i < middle) ? -xr[i + middle] : xr[i - middle];
+      yr[i] = xr[i] * c[i] + other * s[i];
+    } else {
+      yr[i] = xr[i];
+    }
+  }
+}
+
+void launch_rotary(const float* x, const float* sin, const float* cos, int64_t batch,
+                   int64_t time, int64_t depth, int64_t ndims, bool interleave, float* y,
+                   hipStream_t stream) {
+  if (batch * time == 0) return;
+  if (ndims == 0) ndims = depth;
+  int block = 64;
+  while (block < depth && block < 256) block <<= 1;
+  hipLaunchKernelGGL(rotary_kernel, dim3(batch * time), dim3(block), 0, stream, x, sin, cos,
+                     time, depth, ndims, interleave, y);
+}
+
+// ---------------------------------------------------------------------------------------
+// TopK. Reference: src/ops/topk_cpu.cc:13-55 (k==1: std::max_element -> first maximum;
+// k>1: partial_sort by value). Selection here is k rounds of block arg-max over the
+// lexicographic order (value desc, index asc); round j only considers candidates strictly
+// after the (value,index) picked in round j-1, so the input is never mutated (the reference
+// GPU kernel mutates and restores, src/ops/topk_gpu.cu:182-335).
+// ---------------------------------------------------------------------------------------
+__global__ void topk_kernel(const float* __restrict__ x, int64_t depth, int k,
+                            float* __restrict__ values, int32_t* __restrict__ indices) {
+  __shared__ float s_v[16];
+  __shared__ int s_i[16];
+  __shared__ float prev_v;
+  __shared__ int prev_i;
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * depth;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = (blockDim.x + 63) >> 6;
+  float pv = 0.f;
+  int pi = -1;  // -1: nothing selected yet
+  for (int j = 0; j < k; ++j) {
+    ValIdx best;
+    best.v = -FLT_MAX;
+    best.i = INT_MAX;
+    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
+      const float v = xr[i];
+      const bool eligible = (pi < 0) || (v < pv) || (v == pv && static_cast<int>(i) > pi);
+      if (eligible) {
+        ValIdx c;
+        c.v = v;
+        c.i = static_cast<int>(i);
+        // -FLT_MAX sentinel: an eligible element always beats the empty slot.
+        best = better(best, c);
+      }
+    }
+    // wave reduce (empty slots have i == INT_MAX and v == -FLT_MAX; `better` prefers real
+    // entries with the same value because their index is lower).
+    best = wave_argmax(best);
+    __syncthreads();
+    if (lane == 0) {
+      s_v[wave] = best.v;
+      s_i[wave] = best.i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      ValIdx r;
+      r.v = s_v[0];
+      r.i = s_i[0];
+      for (int w = 1; w < nwaves; ++w) {
+        ValIdx c;
+        c.v = s_v[w];
+        c.i = s_i[w];
+        r = better(r, c);
+      }
+      prev_v = r.v;
+      prev_i = r.i;
+      if (r.i == INT_MAX) {  // fewer than k finite candidates
+        values[row * k + j] = -FLT_MAX;
+        indices[row * k + j] = 0;
+      } else {
+        values[row * k + j] = r.v;
+        indices[row * k + j] = r.i;
+      }
+    }
+    __syncthreads();
+    pv = prev_v;
+    pi = prev_i;
+    if (pi == INT_MAX) pi = INT_MAX - 1;  // exhausted: nothing is eligible any more
+  }
+}
+
+void launch_topk(const float* x, int64_t rows, int64_t depth, int64_t k, float* values,
+                 int32_t* indices, hipStream_t stream) {
+  if (rows == 0 || depth == 0 || k == 0) return;
+  int block = 64;
+  while (block < depth / 4 && block < 1024) block <<= 1;
+  hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(block), 0, stream, x, depth,
+                     static_cast<int>(k), values, indices);
+}
+
+// ---------------------------------------------------------------------------------------
+// Gather rows (ops::Gather axis 0, src/ops/gather_gpu.cu:53-91): out[i] = data[idx[i]].
+// 16-byte lanes when the row size allows (it always does for fp32 rows with depth%4==0).
+// ---------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const char* __restrict__ data, const int32_t* __restrict__ idx,
+                                   int64_t row_bytes, char* __restrict__ out) {
+  const int64_t i = blockIdx.x;
+  const char* src = data + static_cast<int64_t>(idx[i]) * row_bytes;
+  char* dst = out + i * row_bytes;
+  const bool vec = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+  if (vec) {
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    for (int64_t j = threadIdx.x; j < row_bytes / 16; j += blockDim.x) d[j] = s[j];
+  } else {
+    for (int64_t j = threadIdx.x; j < row_bytes; j += blockDim.x) dst[j] = src[j];
+  }
+}
+
+void launch_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int64_t row_bytes,
+                        void* out, hipStream_t stream) {
+  if (n_idx == 0 || row_bytes == 0) return;
+  int block = 64;
+  while (block < row_bytes / 16 && block < 256) block <<= 1;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n_idx), dim3(block), 0, stream,
+                     static_cast<const char*>(data), idx, row_bytes, static_cast<char*>(out));
+}
+
+// ---------------------------------------------------------------------------------------
+// Embedding lookup fused with int8 dequantisation, sqrt(d) scaling and position encoding.
+// Reference op order: Gather (+Dequantize x/scale) [src/layers/common.cc:64-81] -> Mul by the
+// embedding scale [src/layers/transformer.cc:640] -> add position encoding row
+// [src/layers/common.cc:151-174]. Row r = (b, t): position = pos_index + t.
+// ---------------------------------------------------------------------------------------
+__global__ void embed_kernel(const void* __restrict__ table, bool table_is_int8,
+                             const float* __restrict__ table_scale,
+                             const int32_t* __restrict__ ids, int64_t depth, float emb_scale,
+                             bool apply_scale, const float* __restrict__ pos_table, int64_t time,
+                             int64_t pos_index, const int32_t* __restrict__ step_ptr,
+                             float* __restrict__ out) {
+  const int64_t r = blockIdx.x;
+  const int64_t id = ids[r];
+  if (step_ptr != nullptr) pos_index = *step_ptr;
+  const int64_t pos = pos_index + (r % time);
+  float* o = out + r * depth;
+  const float* p = pos_table ? pos_table + pos * depth : nullptr;
+  if (table_is_int8) {
+    const int8_t* e = static_cast<const int8_t*>(table) + id * depth;
+    const float s = table_scale[id];
+    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
+      float v = static_cast<float>(e[i]) / s;
+      if (apply_scale) v = v * emb_scale;
+      if (p) v = v + p[i];
+      o[i] = v;
+    }
+  } else {
+    const float* e = static_cast<const float*>(table) + id * depth;
+    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
+      float v = e[i];
+      if (apply_scale) v = v * emb_scale;
+      if (p) v = v + p[i];
+      o[i] = v;
+    }
+  }
+}
+
+void launch_embed(const void* table, bool table_is_int8, const float* table_scale,
+                  const int32_t* ids, int64_t rows, int64_t depth, float emb_scale,
+                  bool apply_scale, const float* pos_table, int64_t time, int64_t pos_index,
+                  const int32_t* step_ptr, float* out, hipStream_t stream) {
+  if (rows == 0) return;
+  int block = 64;
+  while (block < depth && block < 256) block <<= 1;
+  hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(block), 0, stream, table, table_is_int8,
+                     table_scale, ids, depth, emb_scale, apply_scale, pos_table, time, pos_index,
+                     step_ptr, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// Element-wise add / mul (grid-stride, 16-byte lanes when aligned).
+// ---------------------------------------------------------------------------------------
+template <bool kMul>
+__global__ void binary_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                              int64_t n, float* __restrict__ y) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    y[i] = kMul ? a[i] * b[i] : a[i] + b[i];
+}
+
+static int grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return static_cast<int>(g);
+}
+
+void launch_add(const float* a, const float* b, int64_t n, float* y, hipStream_t stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(binary_kernel<false>, dim3(grid_for(n)), dim3(256), 0, stream, a, b, n, y);
+}
+
+void launch_mul(const float* a, const float* b, int64_t n, float* y, hipStream_t stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(binary_kernel<true>, dim3(grid_for(n)), dim3(256), 0, stream, a, b, n, y);
+}
+
+}  // namespace ct2x

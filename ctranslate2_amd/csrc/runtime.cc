@@ -1,0 +1,133 @@
+#include "runtime.h"
+
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace ct2x {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+const char* last_error() { return g_last_error.c_str(); }
+
+namespace {
+
+struct ThreadStream {
+  hipStream_t stream = nullptr;
+  int device = -1;
+  ~ThreadStream() {
+    // Streams are intentionally leaked at thread exit when the runtime may already be
+    // torn down (same choice as a process-lifetime handle).
+  }
+};
+
+thread_local ThreadStream t_stream;
+
+size_t size_class(size_t bytes) {
+  if (bytes <= 256) return 256;
+  if (bytes <= (1u << 20)) {  // next power of two up to 1 MiB
+    size_t s = 256;
+    while (s < bytes) s <<= 1;
+    return s;
+  }
+  const size_t step = size_t(2) << 20;  // 2 MiB granules above
+  return (bytes + step - 1) / step * step;
+}
+
+struct Pool {
+  std::mutex mutex;
+  // (device, size class) -> free blocks
+  std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;
+  std::unordered_map<void*, std::pair<int, size_t>> live;  // ptr -> (device, class)
+  int64_t allocated = 0;
+};
+
+Pool& pool() {
+  static Pool* p = new Pool();  // leaked on purpose: outlives static destruction order
+  return *p;
+}
+
+}  // namespace
+
+hipStream_t thread_stream() {
+  int device = 0;
+  CT2X_HIP_CHECK(hipGetDevice(&device));
+  if (t_stream.stream == nullptr || t_stream.device != device) {
+    CT2X_HIP_CHECK(hipStreamCreateWithFlags(&t_stream.stream, hipStreamNonBlocking));
+    t_stream.device = device;
+  }
+  return t_stream.stream;
+}
+
+void* device_malloc(size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  int device = 0;
+  CT2X_HIP_CHECK(hipGetDevice(&device));
+  const size_t cls = size_class(bytes);
+  Pool& p = pool();
+  {
+    std::lock_guard<std::mutex> lock(p.mutex);
+    auto it = p.free_blocks.find({device, cls});
+    if (it != p.free_blocks.end() && !it->second.empty()) {
+      void* ptr = it->second.back();
+      it->second.pop_back();
+      p.live[ptr] = {device, cls};
+      return ptr;
+    }
+  }
+  void* ptr = nullptr;
+  hipError_t e = hipMalloc(&ptr, cls);
+  if (e != hipSuccess) {
+    clear_cache();
+    CT2X_HIP_CHECK(hipMalloc(&ptr, cls));
+  }
+  std::lock_guard<std::mutex> lock(p.mutex);
+  p.live[ptr] = {device, cls};
+  p.allocated += static_cast<int64_t>(cls);
+  return ptr;
+}
+
+void device_free(void* ptr) {
+  if (!ptr) return;
+  Pool& p = pool();
+  std::lock_guard<std::mutex> lock(p.mutex);
+  auto it = p.live.find(ptr);
+  if (it == p.live.end()) throw Error("ct2x_free: pointer was not allocated by ct2x_malloc");
+  p.free_blocks[it->second].push_back(ptr);
+  p.live.erase(it);
+}
+
+void clear_cache() {
+  Pool& p = pool();
+  std::vector<void*> to_free;
+  {
+    std::lock_guard<std::mutex> lock(p.mutex);
+    for (auto& kv : p.free_blocks) {
+      for (void* ptr : kv.second) {
+        to_free.push_back(ptr);
+        p.allocated -= static_cast<int64_t>(kv.first.second);
+      }
+      kv.second.clear();
+    }
+  }
+  if (!to_free.empty()) {
+    (void)hipDeviceSynchronize();
+    for (void* ptr : to_free) (void)hipFree(ptr);
+  }
+}
+
+int64_t allocated_bytes() {
+  Pool& p = pool();
+  std::lock_guard<std::mutex> lock(p.mutex);
+  return p.allocated;
+}
+
+void check_last_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    throw Error(std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
+}
+
+}  // namespace ct2x

@@ -1,0 +1,54 @@
+// Host runtime of the MI355X backend: error plumbing, per-thread HIP stream, caching device
+// allocator, events. Mirrors the contracts of the reference's CUDA runtime glue
+// (src/cuda/utils.cc:75-130 stream-per-thread; src/cuda/allocator.cc:34-185 caching
+// allocator; src/cuda/utils.h:68-96 error macros) without any of its code.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+namespace ct2x {
+
+class Error : public std::runtime_error {
+public:
+  explicit Error(const std::string& msg) : std::runtime_error(msg) {}
+};
+
+#define CT2X_HIP_CHECK(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      throw ::ct2x::Error(std::string("HIP failure in " #expr ": ") +                     \
+                          hipGetErrorString(_e) + " (" __FILE__ ":" +                     \
+                          std::to_string(__LINE__) + ")");                                \
+  } while (0)
+
+#define CT2X_CHECK(cond, msg)                                                             \
+  do {                                                                                    \
+    if (!(cond)) throw ::ct2x::Error(std::string(msg));                                   \
+  } while (0)
+
+void set_last_error(const std::string& msg);
+const char* last_error();
+
+// The calling thread's stream (created on first use on the current device).
+hipStream_t thread_stream();
+inline hipStream_t resolve_stream(void* s) {
+  return s ? static_cast<hipStream_t>(s) : thread_stream();
+}
+
+// Caching allocator: blocks are recycled per size class and never returned to the driver
+// until clear_cache(). Safe because each thread enqueues on one stream in program order.
+void* device_malloc(size_t bytes);
+void device_free(void* ptr);
+void clear_cache();
+int64_t allocated_bytes();
+
+// Launch bookkeeping used by the engine to report kernels/step.
+void check_last_launch(const char* what);
+
+}  // namespace ct2x

@@ -1,0 +1,287 @@
+/*
+ * ct2_mi355.h -- C ABI of the MI355X (gfx950) backend for CTranslate2's quantized
+ * decoder hot path.
+ *
+ * The reference has no FFI for this path: its device boundary is C++ explicit template
+ * specialisation (`primitives<Device::CUDA>` and `ops::X::compute<Device::CUDA, T>`,
+ * selected by src/device_dispatch.h:20-32). Each entry point below is what such a
+ * specialisation would call; the comment on each one names the reference symbol it
+ * stands behind (file:line under /root/reference). INTEGRATION.md shows the C++ stub a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - Every pointer named d_* is a DEVICE pointer on the current HIP device; `stream`
+ *    is a hipStream_t passed as void* (NULL = the library's per-thread stream, the
+ *    reference's stream-per-thread contract, src/cuda/utils.cc:75-125).
+ *  - All work is enqueued asynchronously on `stream`; nothing synchronises the device
+ *    except ct2x_stream_synchronize / the *_to_host helpers.
+ *  - Row-major, contiguous tensors; sizes are int64_t (the reference's dim_t).
+ *  - Return value: 0 on success, non-zero on error (ct2x_last_error() gives the
+ *    message; the C++ stub rethrows it as std::runtime_error / std::invalid_argument
+ *    like CUDA_CHECK / THROW_RUNTIME_ERROR do, src/cuda/utils.h:68-96).
+ *  - Float tensors are fp32 unless a `dtype` argument says otherwise
+ *    (CT2X_F32 / CT2X_F16 / CT2X_BF16 mirror DataType, include/ctranslate2/types.h:16-23).
+ *  - No CPU fallback exists anywhere in this library.
+ */
+#ifndef CT2_MI355_H_
+#define CT2_MI355_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CT2X_VERSION 1
+
+/* DataType ids = the reference's enum (include/ctranslate2/types.h:16-23) and the
+ * type ids stored in model.bin (python/ctranslate2/specs/model_spec.py:_dtype_to_type_id). */
+enum ct2x_dtype {
+  CT2X_F32 = 0,
+  CT2X_I8 = 1,
+  CT2X_I16 = 2,
+  CT2X_I32 = 3,
+  CT2X_F16 = 4,
+  CT2X_BF16 = 5,
+};
+
+/* ops::ActivationType (include/ctranslate2/ops/activation.h:9-17); CT2X_ACT_NONE = no
+ * activation (a null ActivationType* in the reference). */
+enum ct2x_activation {
+  CT2X_ACT_NONE = -1,
+  CT2X_ACT_RELU = 0,
+  CT2X_ACT_GELU_TANH = 1,
+  CT2X_ACT_SWISH = 2,
+  CT2X_ACT_GELU = 3,
+  CT2X_ACT_GELU_SIGMOID = 4,
+  CT2X_ACT_TANH = 5,
+  CT2X_ACT_SIGMOID = 6,
+};
+
+/* ---- runtime ------------------------------------------------------------------- */
+
+const char* ct2x_last_error(void);
+int ct2x_version(void);
+
+/* cuda::get_gpu_count / has_gpu (src/cuda/utils.cc:163-175). */
+int ct2x_device_count(void);
+/* set_device_index<Device::CUDA> / get_device_index (src/devices.cc:78-88). */
+int ct2x_set_device(int device_index);
+int ct2x_get_device(int* device_index);
+/* cuda::get_device_properties(i).name, gcnArchName, CU count, HBM bytes. */
+int ct2x_device_info(int device_index, char* name, int name_size, char* arch, int arch_size,
+                     int* compute_units, int64_t* hbm_bytes);
+/* cuda::get_cuda_stream() (src/cuda/utils.cc:122-125): the calling thread's stream. */
+void* ct2x_thread_stream(void);
+/* synchronize_stream(Device::CUDA) (src/devices.cc:106-117). */
+int ct2x_stream_synchronize(void* stream);
+
+/* get_allocator<Device::CUDA>() (src/cuda/allocator.cc:34-185): stream-ordered arena.
+ * allocate/free are safe to call in any order on one stream; blocks are recycled
+ * without returning to the driver until ct2x_clear_cache (Allocator::clear_cache). */
+int ct2x_malloc(void** d_ptr, size_t bytes);
+int ct2x_free(void* d_ptr);
+int ct2x_clear_cache(void);
+int64_t ct2x_allocated_bytes(void);
+
+/* cross_device_primitives<CPU,CUDA>::copy / <CUDA,CPU>::copy (src/cuda/primitives.cu:685-754).
+ * The D2H form returns only after the bytes have landed (callers read the host buffer
+ * immediately, src/sampling.cc:19-20 -> src/decoding.cc:900). */
+int ct2x_copy_to_device(const void* h_src, void* d_dst, size_t bytes, void* stream);
+int ct2x_copy_to_host(const void* d_src, void* h_dst, size_t bytes, void* stream);
+int ct2x_copy_device(const void* d_src, void* d_dst, size_t bytes, void* stream);
+
+/* HIP events on the library's stream, for benchmark timing (bench.py roofline leg). */
+int ct2x_event_create(void** event);
+int ct2x_event_destroy(void* event);
+int ct2x_event_record(void* event, void* stream);
+int ct2x_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+
+/* ---- hot-path ops -------------------------------------------------------------- */
+
+/* ops::Quantize::quantize<Device::CUDA, T, int8_t> (src/ops/quantize_gpu.cu:87-103;
+ * CPU semantics src/cpu/kernels.cc:577-651): per row amax -> scale = amax ? 127/amax : 1,
+ * q = int8(round_or_trunc(x*scale)). round_before_cast=0 is the legacy truncation of
+ * binary_version < 5 models (include/ctranslate2/models/model.h:87-89). */
+int ct2x_quantize_s8(const void* d_x, int dtype, int64_t rows, int64_t depth,
+                     int round_before_cast, int8_t* d_q, float* d_scales, void* stream);
+
+/* primitives<Device::CUDA>::gemm<int8_t,int32_t> (src/cuda/primitives.cu:571-597), the
+ * call shape Dense uses (src/layers/common.cc:287-293,392): C[m,n] = A[m,k] . B[n,k]^T,
+ * alpha=1, beta=0, exact int32. */
+int ct2x_gemm_s8s8s32(const int8_t* d_a, const int8_t* d_b, int64_t m, int64_t n, int64_t k,
+                      int32_t* d_c, void* stream);
+
+/* ops::Dequantize::dequantize_gemm_output<Device::CUDA, T> (src/ops/dequantize_gpu.cu:31-121)
+ * with the CPU formula order (src/cpu/kernels.cc:666-673), chosen for token parity:
+ *   y[i,j] = act( float(c[i,j]) * (1/a_scale[i]) / b_scale[j] + bias[j] ). */
+int ct2x_dequantize_gemm_output(const int32_t* d_c, const float* d_a_scale,
+                                const float* d_b_scale, const float* d_bias, int64_t m,
+                                int64_t n, int activation, void* d_y, int dtype, void* stream);
+
+/* The fused form the backend actually runs for layers::Dense on int8 weights
+ * (src/layers/common.cc:353-401: Quantize -> Gemm -> Dequantize(+bias,+act) -> Add residual):
+ *   y = act( (qa . W^T) * (1/a_scale) / w_scale + bias ) + residual
+ * The int32 accumulator never reaches HBM. d_bias / d_residual may be NULL. */
+int ct2x_gemm_s8_dequant(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w,
+                         const float* d_w_scale, const float* d_bias, const void* d_residual,
+                         int64_t m, int64_t n, int64_t k, int activation, void* d_y, int dtype,
+                         void* stream);
+
+/* ops::Dequantize::dequantize<Device::CUDA,int8_t,T> (src/ops/dequantize_gpu.cu:17-28):
+ * y[r,:] = x[r,:] / scale[r]  (int8 embedding rows, src/layers/common.cc:64-81). */
+int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,
+                         void* d_y, int dtype, void* stream);
+
+/* primitives<Device::CUDA>::gemm<float,float> + apply_bias_and_activation
+ * (src/cuda/primitives.cu:485-517, src/ops/gemm.cc:11-25): C = act(A.B^T + bias) + residual. */
+int ct2x_gemm_f32(const float* d_a, const float* d_b, int64_t m, int64_t n, int64_t k,
+                  int trans_b, const float* d_bias, const float* d_residual, int activation,
+                  float* d_c, void* stream);
+
+/* ops::LayerNorm::compute<Device::CUDA,T> last-axis form (src/ops/layer_norm_gpu.cu:174-213;
+ * CPU src/cpu/kernels.cc:461-496): y = (x-mean)*rsqrt(max(E[x^2]-mean^2,0)+eps)*gamma+beta. */
+int ct2x_layer_norm(const void* d_x, const float* d_gamma, const float* d_beta, int64_t rows,
+                    int64_t depth, float epsilon, void* d_y, int dtype, void* stream);
+
+/* ops::RMSNorm::compute<Device::CUDA,T> (src/ops/rms_norm_gpu.cu:20-63; CPU
+ * src/cpu/kernels.cc:543-573): y = x*rsqrt(mean(x^2)+eps)*(gamma or 1+gamma). */
+int ct2x_rms_norm(const void* d_x, const float* d_gamma, int64_t rows, int64_t depth,
+                  float epsilon, int use_residual, void* d_y, int dtype, void* stream);
+
+/* Fused norm + Quantize (the first two ops of every pre-norm Dense; replaces
+ * layer_norm_gpu.cu + quantize_gpu.cu launches). d_beta==NULL selects RMSNorm as
+ * layers::LayerNorm::operator() does (src/layers/common.cc:464-472). d_y (the float norm
+ * output) may be NULL when only the quantised form is consumed. */
+int ct2x_norm_quantize_s8(const float* d_x, const float* d_gamma, const float* d_beta,
+                          int64_t rows, int64_t depth, float epsilon, int use_residual,
+                          int round_before_cast, float* d_y, int8_t* d_q, float* d_scales,
+                          void* stream);
+
+/* ops::SoftMax / LogSoftMax::compute<Device::CUDA,T> (src/ops/softmax_gpu.cu:196-272; CPU
+ * src/cpu/kernels.cc:402-459): per-row (log-)softmax over the first lengths[row] columns
+ * (all when d_lengths==NULL); masked tail is exact 0. In-place allowed. */
+int ct2x_softmax(const void* d_x, const int32_t* d_lengths, int64_t rows, int64_t depth,
+                 int log, void* d_y, int dtype, void* stream);
+
+/* ops::Rotary::compute<Device::CUDA,T> (src/ops/rotary_gpu.cu:28-85; CPU
+ * src/ops/rotary_cpu.cc:9-62) on x[batch*heads, time, depth]; sin/cos [time, ndims]. */
+int ct2x_rotary(const float* d_x, const float* d_sin, const float* d_cos, int64_t batch,
+                int64_t time, int64_t depth, int64_t ndims, int interleave, float* d_y,
+                void* stream);
+
+/* ops::TopK::compute<Device::CUDA,T,int32_t> (src/ops/topk_gpu.cu:28-54; CPU
+ * src/ops/topk_cpu.cc:13-55). Ties resolve to the LOWEST index, like std::max_element. */
+int ct2x_topk(const void* d_x, int dtype, int64_t rows, int64_t depth, int64_t k,
+              void* d_values, int32_t* d_indices, void* stream);
+
+/* ops::Gather::compute<Device::CUDA,T> axis 0 (src/ops/gather_gpu.cu:53-91):
+ * out[i,:] = data[idx[i],:] for rows of row_bytes bytes. */
+int ct2x_gather_rows(const void* d_data, const int32_t* d_idx, int64_t n_idx,
+                     int64_t row_bytes, void* d_out, void* stream);
+
+/* primitives<Device::CUDA>::gemm_batch_strided<float> as ops::MatMul calls it
+ * (src/cuda/primitives.cu:599-683, src/ops/matmul.cc:62-73):
+ * C_b[m,n] = alpha * A_b[m,k] . op(B_b). */
+int ct2x_matmul_f32(const float* d_a, const float* d_b, int64_t batch, int64_t m, int64_t n,
+                    int64_t k, int trans_b, float alpha, float* d_c, void* stream);
+
+/* The fused single-query attention the backend runs in place of
+ * MatMul(QK^T, alpha) -> SoftMax(lengths) -> MatMul(PV) (src/layers/attention.cc:216-277)
+ * for decode steps. q [rows, heads, dhead]; K/V caches [rows/kv_group, heads_kv, t_max, dhead]
+ * (kv_group>1 = beam rows sharing one encoder memory, attention.cc:805-806; heads_kv<heads =
+ * GQA without materialising replicate_heads, attention.cc:291-295). Row r attends to the first
+ * lengths[r / kv_group] (or `length` when d_lengths==NULL) positions. out [rows, heads*dhead]. */
+int ct2x_attention_decode(const float* d_q, const float* d_k_cache, const float* d_v_cache,
+                          const int32_t* d_lengths, int64_t length, int64_t rows, int64_t heads,
+                          int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t kv_group,
+                          float scale, float* d_out, void* stream);
+
+/* ---- engine: ctranslate2::Translator / Generator ------------------------------- */
+
+/* models::Model::load + ReplicaPool ctor (src/models/model.cc:561-784,
+ * include/ctranslate2/replica_pool.h:33-45). compute_type strings are the reference's
+ * ("default","auto","int8","int8_float32","int8_float16","int8_bfloat16","float32",
+ * "float16","bfloat16"; src/types.cc:18-66). Returns NULL on error. */
+void* ct2x_translator_create(const char* model_dir, int device_index, const char* compute_type);
+void ct2x_translator_destroy(void* translator);
+
+/* TranslationOptions subset on the hot path (include/ctranslate2/translation.h:11-96). */
+struct ct2x_translation_options {
+  int32_t beam_size;            /* 1 = greedy */
+  int32_t max_decoding_length;
+  int32_t min_decoding_length;
+  int32_t num_hypotheses;
+  int32_t return_scores;
+  int32_t return_end_token;
+  int32_t max_batch_size;       /* 0 = whole batch */
+  int32_t max_input_length;     /* 0 = no truncation */
+  float length_penalty;
+  float patience;
+  int32_t use_graph;            /* replay the decode step from a hipGraph */
+  int32_t reserved[5];
+};
+
+void ct2x_translation_options_default(struct ct2x_translation_options* opt);
+
+/* Translator::translate_batch on token ids (src/translator.cc:8-28 ->
+ * src/models/sequence_to_sequence.cc:305-432). src_ids [batch, src_stride] raw ids
+ * WITHOUT the implicit source BOS/EOS (added per config.json like Vocabulary::to_ids).
+ * out_ids [batch, num_hypotheses, max_decoding_length], out_lengths/out_scores
+ * [batch, num_hypotheses]. */
+int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
+                         int32_t batch, int32_t src_stride,
+                         const struct ct2x_translation_options* opt, int32_t* out_ids,
+                         int32_t* out_lengths, float* out_scores);
+
+/* Generator::generate_batch for decoder-only models (src/generator.cc:8-24 ->
+ * src/models/language_model.cc:150-282); prompts are consumed in one prefill call. */
+int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
+                        const int32_t* prompt_lengths, int32_t batch, int32_t stride,
+                        const struct ct2x_translation_options* opt, int32_t* out_ids,
+                        int32_t* out_lengths, float* out_scores);
+
+/* Teacher-forced step logits (layers::Decoder::operator()(step, ids, state, logits),
+ * include/ctranslate2/layers/decoder.h:25-29): src_ids INCLUDE special tokens here;
+ * logits_out is a HOST buffer [T, batch, vocab]. */
+int ct2x_step_logits(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
+                     int32_t batch, int32_t src_stride, const int32_t* tgt_in, int32_t T,
+                     float* logits_out);
+
+/* Model facts used by bindings and tests. */
+int ct2x_model_info(void* translator, int32_t* is_seq2seq, int32_t* vocab_size,
+                    int32_t* d_model, int32_t* num_layers_dec, int32_t* num_heads,
+                    int32_t* bos_id, int32_t* eos_id, char* compute_type, int ct_size);
+/* Vocabulary lookups (include/ctranslate2/vocabulary.h:16-70); which: 0 source, 1 target. */
+int ct2x_vocab_size(void* translator, int which);
+const char* ct2x_vocab_token(void* translator, int which, int32_t id);
+int32_t ct2x_vocab_id(void* translator, int which, const char* token);
+
+/* ExecutionStats-style counters of the last translate/generate call
+ * (include/ctranslate2/translator.h:9-13) + device timing of the decode loop. */
+struct ct2x_exec_stats {
+  int64_t num_tokens;
+  int64_t num_examples;
+  int64_t decode_steps;
+  int64_t kernels_per_step;
+  double total_ms;
+  double encode_ms;
+  double decode_ms;
+};
+int ct2x_last_stats(void* translator, struct ct2x_exec_stats* stats);
+
+/* ---- host-only helpers (no GPU needed; exercised by the CPU test-suite) --------- */
+
+/* Parses model.bin exactly as Model::load does (src/models/model.cc:594-661,767-777) and
+ * reports what it found. Returns number of variables, <0 on error. */
+int ct2x_inspect_model(const char* model_dir, char* spec_name, int spec_size,
+                       int32_t* binary_version, int32_t* revision, int32_t* num_aliases);
+/* i-th variable of model.bin: name, dtype id, rank, dims (up to 8), payload bytes. */
+int ct2x_inspect_variable(const char* model_dir, int32_t index, char* name, int name_size,
+                          int32_t* dtype, int32_t* rank, int64_t* dims, int64_t* nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CT2_MI355_H_ */

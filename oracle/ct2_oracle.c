@@ -1,0 +1,326 @@
+/* TEST INFRASTRUCTURE ONLY -- see ct2_oracle.h. Build: oracle/Makefile (gcc -O2, no fast-math,
+ * -ffp-contract=off). Scalar loops; OpenMP only over independent rows. */
+#include "ct2_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* Activation functors: src/cpu/kernels.cc:146-207 (relu_func ... tanh_func). Enum order:
+ * include/ctranslate2/ops/activation.h:9-17. */
+float orc_activation(float v, int act) {
+  switch (act) {
+    case 0: /* ReLU: max(v, 0) */
+      return v > 0.f ? v : 0.f;
+    case 1: { /* GELUTanh */
+      float u = v * v * v;
+      u = 0.044715f * u + v;
+      u = 0.7978845608028654f * u;
+      u = tanhf(u);
+      u = 1.f + u;
+      u = v * u;
+      return 0.5f * u;
+    }
+    case 2: /* Swish: v / (1 + exp(-v)) */
+      return v / (1.f + expf(-v));
+    case 3: { /* GELU: 0.5 * v * (1 + erf(v / sqrt 2)) */
+      float u = 0.7071067811865475f * v;
+      u = 1.f + erff(u);
+      u = v * u;
+      return 0.5f * u;
+    }
+    case 4: /* GELUSigmoid */
+      return v / (1.f + expf(-1.702f * v));
+    case 5:
+      return tanhf(v);
+    case 6:
+      return 1.f / (1.f + expf(-v));
+    default:
+      return v;
+  }
+}
+
+/* quantize_s8_row (src/cpu/kernels.cc:577-620): amax = max |x|; scale = amax != 0 ? 127/amax : 1;
+ * y = (int8) trunc(round_func(x * scale)) with round_func = round-to-nearest-even when
+ * round_before_cast (Vec::round, src/cpu/vec_avx.h) else identity, conversion by cvttps. */
+void orc_quantize_s8(const float* x, int64_t rows, int64_t depth, int round_before_cast,
+                     int8_t* q, float* scales) {
+#pragma omp parallel for if (rows > 64)
+  for (int64_t i = 0; i < rows; ++i) {
+    const float* xr = x + i * depth;
+    int8_t* qr = q + i * depth;
+    float amax = 0.f;
+    for (int64_t j = 0; j < depth; ++j) {
+      const float a = fabsf(xr[j]);
+      if (a > amax) amax = a;
+    }
+    const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+    scales[i] = scale;
+    for (int64_t j = 0; j < depth; ++j) {
+      float v = xr[j] * scale;
+      if (round_before_cast) v = nearbyintf(v); /* default rounding mode = RNE */
+      qr[j] = (int8_t)(int32_t)v;
+    }
+  }
+}
+
+/* Exact s8*s8->s32: what MKL's u8s8 + compensation computes (src/cpu/primitives.cc:869-972). */
+void orc_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int64_t k, int32_t* c) {
+#pragma omp parallel for if (m * n * k > (1 << 16))
+  for (int64_t i = 0; i < m; ++i) {
+    for (int64_t j = 0; j < n; ++j) {
+      const int8_t* ar = a + i * k;
+      const int8_t* br = b + j * k;
+      int32_t acc = 0;
+      for (int64_t t = 0; t < k; ++t) acc += (int32_t)ar[t] * (int32_t)br[t];
+      c[i * n + j] = acc;
+    }
+  }
+}
+
+/* dequantize_gemm_output_row (src/cpu/kernels.cc:653-692):
+ * v = float(c) * (1/a_scale) ; v = v / b_scale[j] ; v += bias[j] ; y = epilogue(v). */
+void orc_dequantize_gemm_output(const int32_t* c, const float* a_scale, const float* b_scale,
+                                const float* bias, int64_t m, int64_t n, int act, float* y) {
+#pragma omp parallel for if (m * n > (1 << 16))
+  for (int64_t i = 0; i < m; ++i) {
+    const float r_a = 1.f / a_scale[i];
+    for (int64_t j = 0; j < n; ++j) {
+      float v = (float)c[i * n + j] * r_a;
+      v = v / b_scale[j];
+      if (bias) v = v + bias[j];
+      y[i * n + j] = orc_activation(v, act);
+    }
+  }
+}
+
+void orc_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, int64_t depth,
+                         float* y) {
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < depth; ++j) y[i * depth + j] = (float)x[i * depth + j] / scale[i];
+}
+
+/* k-ordered fmaf chain (sgemm kernels are FMA based); epilogue per src/ops/gemm.cc:11-25 /
+ * src/ops/bias_add_cpu.cc:8-35: act(x + bias + residual). */
+void orc_gemm_f32(const float* a, const float* b, int64_t m, int64_t n, int64_t k, int trans_b,
+                  float alpha, const float* bias, const float* residual, int act, float* c) {
+#pragma omp parallel for if (m * n * k > (1 << 16))
+  for (int64_t i = 0; i < m; ++i) {
+    for (int64_t j = 0; j < n; ++j) {
+      float acc = 0.f;
+      for (int64_t t = 0; t < k; ++t) {
+        const float bv = trans_b ? b[j * k + t] : b[t * n + j];
+        acc = fmaf(a[i * k + t], bv, acc);
+      }
+      float v = acc;
+      if (alpha != 1.f) v = v * alpha;
+      if (bias) v = v + bias[j];
+      if (residual) v = v + residual[i * n + j];
+      c[i * n + j] = orc_activation(v, act);
+    }
+  }
+}
+
+/* layer_norm (src/cpu/kernels.cc:461-496). */
+void orc_layer_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
+                    int64_t depth, float eps, float* y) {
+  for (int64_t i = 0; i < rows; ++i) {
+    const float* xr = x + i * depth;
+    float* yr = y + i * depth;
+    float sum = 0.f, sumsq = 0.f;
+    for (int64_t j = 0; j < depth; ++j) {
+      sum += xr[j];
+      sumsq += xr[j] * xr[j];
+    }
+    const float mean = sum / (float)depth;
+    float variance = sumsq / (float)depth - mean * mean;
+    if (variance < 0.f) variance = 0.f;
+    const float rstd = 1.f / sqrtf(variance + eps);
+    for (int64_t j = 0; j < depth; ++j) yr[j] = (xr[j] - mean) * rstd * gamma[j] + beta[j];
+  }
+}
+
+/* rms_norm (src/cpu/kernels.cc:543-573). */
+void orc_rms_norm(const float* x, const float* gamma, int64_t rows, int64_t depth, float eps,
+                  int use_residual, float* y) {
+  for (int64_t i = 0; i < rows; ++i) {
+    const float* xr = x + i * depth;
+    float* yr = y + i * depth;
+    float sumsq = 0.f;
+    for (int64_t j = 0; j < depth; ++j) sumsq += xr[j] * xr[j];
+    const float inv_rms = 1.f / sqrtf(sumsq / (float)depth + eps);
+    for (int64_t j = 0; j < depth; ++j) {
+      if (use_residual)
+        yr[j] = xr[j] * inv_rms * (1.f + gamma[j]);
+      else
+        yr[j] = xr[j] * inv_rms * gamma[j];
+    }
+  }
+}
+
+/* vectorized_map_reduce_all on the AVX2 ISA the reference dispatches to by default
+ * (src/cpu/kernels.cc:86-123, src/cpu/cpu_isa.cc:45-78): 8 strided partial sums, horizontal add,
+ * then the scalar tail. Restated because a single sequential fp32 sum over a 32k..128k
+ * vocabulary row drifts by ~1e-5 relative, which the reference does not. */
+static float sum8_exp(const float* x, int64_t size, float x_max, float* store) {
+  if (size <= 8) {
+    float acc = 0.f;
+    for (int64_t j = 0; j < size; ++j) {
+      const float e = expf(x[j] - x_max);
+      if (store) store[j] = e;
+      acc += e;
+    }
+    return acc;
+  }
+  const int64_t remaining = size % 8;
+  const int64_t vsize = size - remaining;
+  float lane[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t j = 0; j < vsize; j += 8)
+    for (int l = 0; l < 8; ++l) {
+      const float e = expf(x[j + l] - x_max);
+      if (store) store[j + l] = e;
+      lane[l] += e;
+    }
+  /* reduce_m256: (lo + hi) halves, then pairwise */
+  float h4[4], h2[2];
+  for (int l = 0; l < 4; ++l) h4[l] = lane[l] + lane[l + 4];
+  for (int l = 0; l < 2; ++l) h2[l] = h4[l] + h4[l + 2];
+  float acc = h2[0] + h2[1];
+  for (int64_t j = vsize; j < size; ++j) {
+    const float e = expf(x[j] - x_max);
+    if (store) store[j] = e;
+    acc += e;
+  }
+  return acc;
+}
+
+/* softmax (src/cpu/kernels.cc:402-459). */
+void orc_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth, int log,
+                 float* y) {
+#pragma omp parallel for if (rows * depth > (1 << 16))
+  for (int64_t i = 0; i < rows; ++i) {
+    const float* xr = x + i * depth;
+    float* yr = y + i * depth;
+    int64_t size = depth;
+    if (lengths) {
+      size = lengths[i];
+      if (size > depth) size = depth;
+      for (int64_t j = size; j < depth; ++j) yr[j] = 0.f;
+      if (size <= 0) continue;
+    }
+    float x_max = xr[0];
+    for (int64_t j = 1; j < size; ++j)
+      if (xr[j] > x_max) x_max = xr[j];
+    if (log) {
+      const float exp_sum = sum8_exp(xr, size, x_max, NULL);
+      const float c = -x_max - logf(exp_sum);
+      for (int64_t j = 0; j < size; ++j) yr[j] = xr[j] + c;
+    } else {
+      const float exp_sum = sum8_exp(xr, size, x_max, yr);
+      const float r = 1.f / exp_sum;
+      for (int64_t j = 0; j < size; ++j) yr[j] = yr[j] * r;
+    }
+  }
+}
+
+/* rotary_kernel (src/ops/rotary_cpu.cc:9-44). */
+void orc_rotary(const float* x, const float* sin, const float* cos, int64_t batch, int64_t time,
+                int64_t depth, int64_t ndims, int interleave, float* y) {
+  const int64_t middle = ndims / 2;
+  for (int64_t b = 0; b < batch; ++b) {
+    for (int64_t t = 0; t < time; ++t) {
+      const float* s = sin + t * ndims;
+      const float* c = cos + t * ndims;
+      const float* xr = x + b * (time * depth) + t * depth;
+      float* yr = y + b * (time * depth) + t * depth;
+      for (int64_t i = 0; i < ndims; ++i) {
+        float other;
+        if (interleave)
+          other = (i % 2 == 0) ? -xr[i + 1] : xr[i - 1];
+        else
+          other = (i < middle) ? -xr[i + middle] : xr[i - middle];
+        yr[i] = xr[i] * c[i] + other * s[i];
+      }
+      for (int64_t i = ndims; i < depth; ++i) yr[i] = xr[i];
+    }
+  }
+}
+
+/* TopK (src/ops/topk_cpu.cc:13-55): k == 1 -> std::max_element (first maximum); k > 1 ->
+ * partial_sort by value descending. Ties are resolved towards the lowest index here. */
+void orc_topk(const float* x, int64_t rows, int64_t depth, int64_t k, float* values,
+              int32_t* indices) {
+#pragma omp parallel for if (rows * depth > (1 << 16))
+  for (int64_t i = 0; i < rows; ++i) {
+    const float* xr = x + i * depth;
+    float pv = 0.f;
+    int64_t pi = -1;
+    for (int64_t j = 0; j < k; ++j) {
+      int64_t best = -1;
+      for (int64_t t = 0; t < depth; ++t) {
+        const float v = xr[t];
+        const int eligible = (pi < 0) || (v < pv) || (v == pv && t > pi);
+        if (!eligible) continue;
+        if (best < 0 || v > xr[best]) best = t;
+      }
+      if (best < 0) {
+        values[i * k + j] = -FLT_MAX;
+        indices[i * k + j] = 0;
+        pi = depth;
+      } else {
+        values[i * k + j] = xr[best];
+        indices[i * k + j] = (int32_t)best;
+        pv = xr[best];
+        pi = best;
+      }
+    }
+  }
+}
+
+void orc_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int64_t row_bytes,
+                     void* out) {
+  for (int64_t i = 0; i < n_idx; ++i)
+    memcpy((char*)out + i * row_bytes, (const char*)data + (int64_t)idx[i] * row_bytes,
+           (size_t)row_bytes);
+}
+
+/* dot_product_attention with one query per row (src/layers/attention.cc:178-287):
+ * MatMul(trans_b, alpha=scale) -> SoftMax(lengths) -> MatMul. */
+void orc_attention_decode(const float* q, const float* k, const float* v,
+                          const int32_t* lengths, int64_t length, int64_t rows, int64_t heads,
+                          int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t kv_group,
+                          float scale, float* out) {
+  const int64_t group = heads / heads_kv;
+#pragma omp parallel for if (rows * heads > 64)
+  for (int64_t rh = 0; rh < rows * heads; ++rh) {
+    const int64_t r = rh / heads, h = rh % heads;
+    const int64_t kvrow = r / kv_group, hk = h / group;
+    int64_t len = lengths ? lengths[kvrow] : length;
+    if (len > t_max) len = t_max;
+    const float* qv = q + (r * heads + h) * dhead;
+    const float* kb = k + (kvrow * heads_kv + hk) * t_max * dhead;
+    const float* vb = v + (kvrow * heads_kv + hk) * t_max * dhead;
+    float* o = out + (r * heads + h) * dhead;
+    for (int64_t d = 0; d < dhead; ++d) o[d] = 0.f;
+    if (len <= 0) continue;
+    float* p = (float*)malloc(sizeof(float) * (size_t)len);
+    float m = -FLT_MAX;
+    for (int64_t t = 0; t < len; ++t) {
+      float acc = 0.f;
+      for (int64_t d = 0; d < dhead; ++d) acc = fmaf(qv[d], kb[t * dhead + d], acc);
+      p[t] = acc * scale;
+      if (p[t] > m) m = p[t];
+    }
+    float s = 0.f;
+    for (int64_t t = 0; t < len; ++t) {
+      p[t] = expf(p[t] - m);
+      s += p[t];
+    }
+    const float rcp = 1.f / s;
+    for (int64_t t = 0; t < len; ++t) p[t] = p[t] * rcp;
+    for (int64_t t = 0; t < len; ++t)
+      for (int64_t d = 0; d < dhead; ++d) o[d] = fmaf(p[t], vb[t * dhead + d], o[d]);
+    free(p);
+  }
+}

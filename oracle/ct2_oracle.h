@@ -1,0 +1,78 @@
+/* TEST INFRASTRUCTURE ONLY -- the parity oracle. Never linked into, imported or called by the
+ * product (ctranslate2_amd/): only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may use it, and only as the checker.
+ *
+ * Plain-C (scalar, IEEE, no fast-math, no FMA contraction) restatement of the reference's CPU
+ * algorithm for the quantized decoder hot path. Each function cites the reference file:line it
+ * follows. Pinned against the reference's own known-answer vectors (tests/golden/*.json,
+ * transcribed from tests/ops_test.cc) and against the reference itself (oracle/_ref) by
+ * tests/test_oracle.py.
+ */
+#ifndef CT2_ORACLE_H_
+#define CT2_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ops::Quantize int8 (src/ops/quantize_cpu.cc:12-25 -> src/cpu/kernels.cc:577-651). */
+void orc_quantize_s8(const float* x, int64_t rows, int64_t depth, int round_before_cast,
+                     int8_t* q, float* scales);
+
+/* primitives<CPU>::gemm<int8,int32> semantic (src/cpu/primitives.cc:901-1073; KAT
+ * tests/ops_test.cc:683-708): C[m,n] = A[m,k] . B[n,k]^T exactly. */
+void orc_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int64_t k, int32_t* c);
+
+/* cpu::dequantize_gemm_output (src/cpu/kernels.cc:653-756). act = ops::ActivationType or -1. */
+void orc_dequantize_gemm_output(const int32_t* c, const float* a_scale, const float* b_scale,
+                                const float* bias, int64_t m, int64_t n, int act, float* y);
+
+/* Dequantize rows x/scale (src/ops/dequantize_cpu.cc:10-30). */
+void orc_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, int64_t depth,
+                         float* y);
+
+/* sgemm semantic used by ops::Gemm float / ops::MatMul (src/cpu/primitives.cc:660-790,
+ * 1085-1160): C = alpha * A . op(B); then act(x + bias + residual) (src/ops/gemm.cc:11-25). */
+void orc_gemm_f32(const float* a, const float* b, int64_t m, int64_t n, int64_t k, int trans_b,
+                  float alpha, const float* bias, const float* residual, int act, float* c);
+
+/* cpu::layer_norm (src/cpu/kernels.cc:461-496) / cpu::rms_norm (:543-573). */
+void orc_layer_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
+                    int64_t depth, float eps, float* y);
+void orc_rms_norm(const float* x, const float* gamma, int64_t rows, int64_t depth, float eps,
+                  int use_residual, float* y);
+
+/* cpu::softmax (src/cpu/kernels.cc:402-459). lengths may be NULL. */
+void orc_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth, int log,
+                 float* y);
+
+/* rotary_kernel (src/ops/rotary_cpu.cc:9-44): x [batch, time, depth], sin/cos [time, ndims]. */
+void orc_rotary(const float* x, const float* sin, const float* cos, int64_t batch, int64_t time,
+                int64_t depth, int64_t ndims, int interleave, float* y);
+
+/* TopK::compute<CPU> (src/ops/topk_cpu.cc:13-55); ties -> lowest index. */
+void orc_topk(const float* x, int64_t rows, int64_t depth, int64_t k, float* values,
+              int32_t* indices);
+
+/* ops::Gather axis 0 (src/ops/gather_cpu.cc). */
+void orc_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int64_t row_bytes,
+                     void* out);
+
+/* Activation functors (src/cpu/kernels.cc:146-207). */
+float orc_activation(float v, int act);
+
+/* dot_product_attention for one query per row (src/layers/attention.cc:178-287 with
+ * Tq = 1): scores = scale * q.k_t over the first len positions, softmax, out = P.V.
+ * q [rows, heads, dhead]; k/v [rows/kv_group, heads_kv, t_max, dhead]; lengths per kv row
+ * (NULL -> `length`). */
+void orc_attention_decode(const float* q, const float* k, const float* v,
+                          const int32_t* lengths, int64_t length, int64_t rows, int64_t heads,
+                          int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t kv_group,
+                          float scale, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,197 @@
+"""Helpers for the -m gpu parity tests: call the C ABI (include/ct2_mi355.h) on torch device
+tensors. torch is only the device-memory plumbing here."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ctranslate2_amd import _lib
+
+F32 = 0
+
+
+def dev(a):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    torch.cuda.synchronize()
+    return t
+
+
+def host(t):
+    sync()
+    return t.cpu().numpy()
+
+
+def sync():
+    _lib.check(_lib.lib().ct2x_stream_synchronize(None))
+    torch.cuda.synchronize()
+
+
+def i64(v):
+    return C.c_int64(int(v))
+
+
+def quantize_s8(x, round_before_cast=True):
+    L = _lib.lib()
+    xd = dev(x.astype(np.float32))
+    rows, depth = x.shape
+    q = torch.empty((rows, depth), dtype=torch.int8, device="cuda")
+    s = torch.empty((rows,), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_quantize_s8(_lib.ptr(xd), F32, i64(rows), i64(depth),
+                                  C.c_int(int(round_before_cast)), _lib.ptr(q), _lib.ptr(s), None))
+    return host(q), host(s)
+
+
+def gemm_s8(a, b):
+    L = _lib.lib()
+    ad, bd = dev(a.astype(np.int8)), dev(b.astype(np.int8))
+    m, k = a.shape
+    n = b.shape[0]
+    c = torch.empty((m, n), dtype=torch.int32, device="cuda")
+    _lib.check(L.ct2x_gemm_s8s8s32(_lib.ptr(ad), _lib.ptr(bd), i64(m), i64(n), i64(k), _lib.ptr(c), None))
+    return host(c)
+
+
+def dequantize_gemm_output(c, sa, sb, bias=None, act=-1):
+    L = _lib.lib()
+    cd, sad, sbd = dev(c.astype(np.int32)), dev(sa.astype(np.float32)), dev(sb.astype(np.float32))
+    bd = dev(bias.astype(np.float32)) if bias is not None else None
+    m, n = c.shape
+    y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_dequantize_gemm_output(_lib.ptr(cd), _lib.ptr(sad), _lib.ptr(sbd), _lib.ptr(bd),
+                                             i64(m), i64(n), C.c_int(act), _lib.ptr(y), F32, None))
+    return host(y)
+
+
+def gemm_s8_dequant(q, sa, w, sw, bias=None, residual=None, act=-1):
+    L = _lib.lib()
+    qd, sad, wd, swd = dev(q.astype(np.int8)), dev(sa.astype(np.float32)), dev(w.astype(np.int8)), dev(sw.astype(np.float32))
+    bd = dev(bias.astype(np.float32)) if bias is not None else None
+    rd = dev(residual.astype(np.float32)) if residual is not None else None
+    m, k = q.shape
+    n = w.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_gemm_s8_dequant(_lib.ptr(qd), _lib.ptr(sad), _lib.ptr(wd), _lib.ptr(swd),
+                                      _lib.ptr(bd), _lib.ptr(rd), i64(m), i64(n), i64(k),
+                                      C.c_int(act), _lib.ptr(y), F32, None))
+    return host(y)
+
+
+def dequantize_rows(x, scale):
+    L = _lib.lib()
+    xd, sd = dev(x.astype(np.int8)), dev(scale.astype(np.float32))
+    rows, depth = x.shape
+    y = torch.empty((rows, depth), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_dequantize_rows(_lib.ptr(xd), _lib.ptr(sd), i64(rows), i64(depth), _lib.ptr(y), F32, None))
+    return host(y)
+
+
+def gemm_f32(a, b, trans_b=True, bias=None, residual=None, act=-1):
+    L = _lib.lib()
+    ad, bd = dev(a.astype(np.float32)), dev(b.astype(np.float32))
+    biasd = dev(bias.astype(np.float32)) if bias is not None else None
+    rd = dev(residual.astype(np.float32)) if residual is not None else None
+    m, k = a.shape
+    n = b.shape[0] if trans_b else b.shape[1]
+    c = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_gemm_f32(_lib.ptr(ad), _lib.ptr(bd), i64(m), i64(n), i64(k), C.c_int(int(trans_b)),
+                               _lib.ptr(biasd), _lib.ptr(rd), C.c_int(act), _lib.ptr(c), None))
+    return host(c)
+
+
+def matmul_f32(a, b, trans_b=False, alpha=1.0):
+    L = _lib.lib()
+    ad, bd = dev(a.astype(np.float32)), dev(b.astype(np.float32))
+    batch, m, k = a.shape
+    n = b.shape[1] if trans_b else b.shape[2]
+    c = torch.empty((batch, m, n), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_matmul_f32(_lib.ptr(ad), _lib.ptr(bd), i64(batch), i64(m), i64(n), i64(k),
+                                 C.c_int(int(trans_b)), C.c_float(alpha), _lib.ptr(c), None))
+    return host(c)
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    L = _lib.lib()
+    xd, gd, bd = dev(x.astype(np.float32)), dev(gamma.astype(np.float32)), dev(beta.astype(np.float32))
+    rows, depth = x.shape
+    y = torch.empty_like(xd)
+    _lib.check(L.ct2x_layer_norm(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), i64(rows), i64(depth),
+                                 C.c_float(eps), _lib.ptr(y), F32, None))
+    return host(y)
+
+
+def rms_norm(x, gamma, eps=1e-6, use_residual=False):
+    L = _lib.lib()
+    xd, gd = dev(x.astype(np.float32)), dev(gamma.astype(np.float32))
+    rows, depth = x.shape
+    y = torch.empty_like(xd)
+    _lib.check(L.ct2x_rms_norm(_lib.ptr(xd), _lib.ptr(gd), i64(rows), i64(depth), C.c_float(eps),
+                               C.c_int(int(use_residual)), _lib.ptr(y), F32, None))
+    return host(y)
+
+
+def norm_quantize_s8(x, gamma, beta, eps, use_residual=False, round_before_cast=True, want_y=True):
+    L = _lib.lib()
+    xd, gd = dev(x.astype(np.float32)), dev(gamma.astype(np.float32))
+    bd = dev(beta.astype(np.float32)) if beta is not None else None
+    rows, depth = x.shape
+    y = torch.empty_like(xd) if want_y else None
+    q = torch.empty((rows, depth), dtype=torch.int8, device="cuda")
+    s = torch.empty((rows,), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_norm_quantize_s8(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), i64(rows), i64(depth),
+                                       C.c_float(eps), C.c_int(int(use_residual)),
+                                       C.c_int(int(round_before_cast)), _lib.ptr(y), _lib.ptr(q),
+                                       _lib.ptr(s), None))
+    return (host(y) if want_y else None), host(q), host(s)
+
+
+def softmax(x, lengths=None, log=False):
+    L = _lib.lib()
+    xd = dev(x.astype(np.float32))
+    ld = dev(np.asarray(lengths, np.int32)) if lengths is not None else None
+    rows, depth = x.shape
+    y = torch.full_like(xd, 7.0)
+    _lib.check(L.ct2x_softmax(_lib.ptr(xd), _lib.ptr(ld), i64(rows), i64(depth), C.c_int(int(log)),
+                              _lib.ptr(y), F32, None))
+    return host(y)
+
+
+def rotary(x, sin, cos, ndims, interleave):
+    L = _lib.lib()
+    xd, sd, cd = dev(x.astype(np.float32)), dev(sin.astype(np.float32)), dev(cos.astype(np.float32))
+    batch, time, depth = x.shape
+    y = torch.empty_like(xd)
+    _lib.check(L.ct2x_rotary(_lib.ptr(xd), _lib.ptr(sd), _lib.ptr(cd), i64(batch), i64(time), i64(depth),
+                             i64(ndims), C.c_int(int(interleave)), _lib.ptr(y), None))
+    return host(y)
+
+
+def topk(x, k):
+    L = _lib.lib()
+    xd = dev(x.astype(np.float32))
+    rows, depth = x.shape
+    v = torch.empty((rows, k), dtype=torch.float32, device="cuda")
+    i = torch.empty((rows, k), dtype=torch.int32, device="cuda")
+    _lib.check(L.ct2x_topk(_lib.ptr(xd), F32, i64(rows), i64(depth), i64(k), _lib.ptr(v), _lib.ptr(i), None))
+    return host(v), host(i)
+
+
+def gather_rows(data, idx):
+    L = _lib.lib()
+    dd, idd = dev(data), dev(np.asarray(idx, np.int32))
+    row_bytes = data.strides[0]
+    out = torch.empty((len(idx),) + tuple(data.shape[1:]), dtype=dd.dtype, device="cuda")
+    _lib.check(L.ct2x_gather_rows(_lib.ptr(dd), _lib.ptr(idd), i64(len(idx)), i64(row_bytes), _lib.ptr(out), None))
+    return host(out)
+
+
+def attention_decode(q, k, v, lengths=None, length=0, kv_group=1, scale=1.0):
+    L = _lib.lib()
+    qd, kd, vd = dev(q.astype(np.float32)), dev(k.astype(np.float32)), dev(v.astype(np.float32))
+    ld = dev(np.asarray(lengths, np.int32)) if lengths is not None else None
+    rows, heads, dhead = q.shape
+    _, heads_kv, t_max, _ = k.shape
+    out = torch.empty((rows, heads * dhead), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_attention_decode(_lib.ptr(qd), _lib.ptr(kd), _lib.ptr(vd), _lib.ptr(ld), i64(length),
+                                       i64(rows), i64(heads), i64(heads_kv), i64(dhead), i64(t_max),
+                                       i64(kv_group), C.c_float(scale), _lib.ptr(out), None))
+    return host(out)

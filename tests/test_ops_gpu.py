@@ -1,0 +1,271 @@
+"""-m gpu parity tests: every hot-path op through the C ABI (include/ct2_mi355.h) on a real
+MI355X against the plain-C oracle (oracle/ct2_oracle.c) on the same seeded inputs.
+
+Bar: bit-exact for integer/byte/index outputs (quantised values, int32 GEMM, top-k indices,
+gathers); float outputs within the tolerance written next to each assert (the op is computed in
+fp32 with the oracle's formula order; differences come only from reduction order / libm)."""
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# Decoder shapes from SURVEY.md section 8(a): Transformer-base and Llama-3-8B rows/depths.
+QUANT_SHAPES = [(32, 512), (128, 2048), (16, 4096), (3, 96), (1, 32), (5, 7), (2, 14336)]
+
+
+@pytest.mark.parametrize("rows,depth", QUANT_SHAPES)
+@pytest.mark.parametrize("rbc", [True, False])
+def test_quantize_s8(gpu, rows, depth, rbc):
+    import _gpuops as G
+    rng = np.random.default_rng(rows * 1000 + depth)
+    x = (rng.standard_normal((rows, depth)) * 3).astype(np.float32)
+    x[0, :] = 0.0  # zero row -> scale 1 (tests/ops_test.cc:969-991)
+    q, s = G.quantize_s8(x, rbc)
+    qo, so = O.quantize_s8(x, rbc)
+    assert np.array_equal(s, so)  # 127/amax is one IEEE division: must be bit-identical
+    assert np.array_equal(q, qo)
+
+
+GEMM_SHAPES = [
+    (32, 1536, 512), (32, 512, 512), (32, 2048, 512), (32, 512, 2048), (32, 32000, 512),
+    (128, 1536, 512), (1024, 2048, 512), (16, 6144, 4096), (1, 64, 64), (3, 43, 32),
+    (33, 70, 48), (65, 130, 144), (200, 100, 16), (7, 9, 13),
+]
+
+
+@pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
+def test_gemm_s8_exact(gpu, m, n, k):
+    import _gpuops as G
+    rng = np.random.default_rng(m + n + k)
+    a = rng.integers(-127, 128, (m, k), dtype=np.int8)
+    b = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    c = G.gemm_s8(a, b)
+    assert np.array_equal(c, O.gemm_s8(a, b))
+
+
+def test_gemm_s8_transpose_detecting(gpu):
+    """A = I-like pattern with ASYMMETRIC B: catches row/col swaps in the MFMA C layout."""
+    import _gpuops as G
+    m, n, k = 32, 64, 64
+    a = np.zeros((m, k), np.int8)
+    for i in range(m):
+        a[i, i] = 1
+    b = (np.arange(n)[:, None] * 2 + np.arange(k)[None, :] * 1 - 60).clip(-127, 127).astype(np.int8)
+    c = G.gemm_s8(a, b)
+    assert np.array_equal(c, O.gemm_s8(a, b))
+    assert np.array_equal(c, b[:, :m].T.astype(np.int32))
+
+
+def test_gemm_s8_extremes(gpu):
+    """|acc| up to 127*127*K: no saturation anywhere (the reference CPU u8s8 path can saturate
+    without VNNI; the MFMA path must not)."""
+    import _gpuops as G
+    m, n, k = 16, 32, 4096
+    a = np.full((m, k), 127, np.int8)
+    b = np.full((n, k), -127, np.int8)
+    b[::2] = 127
+    c = G.gemm_s8(a, b)
+    assert np.array_equal(c, O.gemm_s8(a, b))
+    assert abs(int(c[0, 0])) == 127 * 127 * k
+
+
+@pytest.mark.parametrize("act", [-1, 0, 1, 2, 3, 4, 5, 6])
+def test_dequantize_gemm_output(gpu, act):
+    import _gpuops as G
+    rng = np.random.default_rng(7 + act)
+    m, n = 33, 130
+    c = rng.integers(-200000, 200000, (m, n), dtype=np.int32)
+    sa = rng.uniform(5, 80, m).astype(np.float32)
+    sb = rng.uniform(50, 4000, n).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    y = G.dequantize_gemm_output(c, sa, sb, bias, act)
+    yo = O.dequantize_gemm_output(c, sa, sb, bias, act)
+    if act in (-1, 0):
+        assert np.array_equal(y, yo)  # mul, div, add, max: IEEE-exact on both sides
+    else:
+        np.testing.assert_allclose(y, yo, rtol=2e-6, atol=2e-6)  # libm expf/erff/tanhf
+
+
+@pytest.mark.parametrize("m,n,k", [(32, 1536, 512), (32, 512, 2048), (128, 2048, 512),
+                                   (16, 4096, 4096), (5, 43, 32), (70, 96, 32)])
+@pytest.mark.parametrize("act,with_res", [(-1, True), (0, False), (2, False), (-1, False)])
+def test_dense_fused_vs_unfused_oracle(gpu, m, n, k, act, with_res):
+    """layers::Dense int8 (Quantize -> Gemm -> Dequantize(+bias,act) -> Add residual) as ONE fused
+    launch after the quantize kernel, against the oracle's four separate steps."""
+    import _gpuops as G
+    rng = np.random.default_rng(m * 7 + n + k + act)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = rng.standard_normal((n, k)).astype(np.float32) * 0.02
+    wq, ws = O.quantize_s8(w, True)  # weights quantised offline (model_spec.py:233-240)
+    bias = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32) if with_res else None
+    q, s = G.quantize_s8(x, True)
+    y = G.gemm_s8_dequant(q, s, wq, ws, bias, res, act)
+    yo = O.dense_s8(x, wq, ws, bias, res, act, True)
+    if act in (-1, 0):
+        assert np.array_equal(y, yo)
+    else:
+        np.testing.assert_allclose(y, yo, rtol=2e-6, atol=2e-6)
+
+
+def test_dequantize_rows(gpu):
+    import _gpuops as G
+    rng = np.random.default_rng(3)
+    x = rng.integers(-127, 128, (9, 512), dtype=np.int8)
+    s = rng.uniform(10, 500, 9).astype(np.float32)
+    assert np.array_equal(G.dequantize_rows(x, s), O.dequantize_rows(x, s))
+
+
+NORM_SHAPES = [(32, 512), (100, 512), (16, 4096), (3, 32), (2, 1280), (5, 96)]
+
+
+@pytest.mark.parametrize("rows,depth", NORM_SHAPES)
+def test_layer_norm(gpu, rows, depth):
+    import _gpuops as G
+    rng = np.random.default_rng(rows + depth)
+    x = (rng.standard_normal((rows, depth)) * 2 + 0.3).astype(np.float32)
+    g = rng.standard_normal(depth).astype(np.float32)
+    b = rng.standard_normal(depth).astype(np.float32)
+    y = G.layer_norm(x, g, b, 1e-5)
+    # fp32 sums in a different order than the oracle's sequential loop: 1e-5 is the
+    # reference's own CPU-vs-GPU tolerance for this op (tests/ops_test.cc:1434-1436).
+    np.testing.assert_allclose(y, O.layer_norm(x, g, b, 1e-5), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,depth", NORM_SHAPES)
+@pytest.mark.parametrize("use_residual", [False, True])
+def test_rms_norm(gpu, rows, depth, use_residual):
+    import _gpuops as G
+    rng = np.random.default_rng(rows + depth + 1)
+    x = (rng.standard_normal((rows, depth)) * 2).astype(np.float32)
+    g = rng.standard_normal(depth).astype(np.float32)
+    y = G.rms_norm(x, g, 1e-6, use_residual)
+    np.testing.assert_allclose(y, O.rms_norm(x, g, 1e-6, use_residual), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,depth", [(32, 512), (16, 4096), (3, 32)])
+@pytest.mark.parametrize("rms", [False, True])
+@pytest.mark.parametrize("rbc", [True, False])
+def test_norm_quantize_fused(gpu, rows, depth, rms, rbc):
+    """Fused norm+quantize: the float output must match the standalone norm kernel bit for bit,
+    and the int8 output must be the oracle quantisation OF THAT float output (exact)."""
+    import _gpuops as G
+    rng = np.random.default_rng(rows * 3 + depth)
+    x = (rng.standard_normal((rows, depth)) * 2).astype(np.float32)
+    g = rng.standard_normal(depth).astype(np.float32)
+    b = None if rms else rng.standard_normal(depth).astype(np.float32)
+    eps = 1e-6 if rms else 1e-5
+    y, q, s = G.norm_quantize_s8(x, g, b, eps, False, rbc, True)
+    y_alone = G.rms_norm(x, g, eps) if rms else G.layer_norm(x, g, b, eps)
+    assert np.array_equal(y, y_alone)
+    qo, so = O.quantize_s8(y, rbc)
+    assert np.array_equal(s, so)
+    assert np.array_equal(q, qo)
+    _, q2, s2 = G.norm_quantize_s8(x, g, b, eps, False, rbc, False)
+    assert np.array_equal(q2, q) and np.array_equal(s2, s)
+
+
+@pytest.mark.parametrize("rows,depth", [(256, 36), (32, 32000), (8, 128256), (5, 7), (64, 64)])
+@pytest.mark.parametrize("log", [False, True])
+@pytest.mark.parametrize("masked", [False, True])
+def test_softmax(gpu, rows, depth, log, masked):
+    import _gpuops as G
+    rng = np.random.default_rng(rows + depth)
+    x = (rng.standard_normal((rows, depth)) * 4).astype(np.float32)
+    lengths = None
+    if masked:
+        lengths = rng.integers(0, depth + 1, rows).astype(np.int32)
+        lengths[0] = 0       # fully masked row -> all zeros (kernels.cc:417-428)
+        lengths[-1] = depth
+    y = G.softmax(x, lengths, log)
+    yo = O.softmax(x, lengths, log)
+    if masked:
+        for r in range(rows):
+            assert np.all(y[r, lengths[r]:] == 0.0)
+    np.testing.assert_allclose(y, yo, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("interleave", [True, False])
+@pytest.mark.parametrize("depth,ndims", [(128, 128), (64, 64), (64, 32), (8, 4)])
+def test_rotary(gpu, interleave, depth, ndims):
+    import _gpuops as G
+    rng = np.random.default_rng(depth + ndims)
+    batch, time = 6, 5
+    x = rng.standard_normal((batch, time, depth)).astype(np.float32)
+    ang = rng.uniform(0, 6.28, (time, ndims)).astype(np.float32)
+    s, c = np.sin(ang).astype(np.float32), np.cos(ang).astype(np.float32)
+    y = G.rotary(x, s, c, ndims, interleave)
+    assert np.array_equal(y, O.rotary(x, s, c, ndims, interleave))
+
+
+@pytest.mark.parametrize("rows,depth,k", [(32, 32000, 1), (32, 128000, 8), (8, 128256, 1),
+                                          (3, 43, 4), (4, 10, 10), (2, 5, 1)])
+def test_topk(gpu, rows, depth, k):
+    import _gpuops as G
+    rng = np.random.default_rng(rows + depth + k)
+    x = rng.standard_normal((rows, depth)).astype(np.float32)
+    # duplicates force the tie-break: lowest index first (std::max_element, topk_cpu.cc:27)
+    x[:, depth // 2] = x[:, 0] = x.max(axis=1) + 1.0
+    v, i = G.topk(x, k)
+    vo, io = O.topk(x, k)
+    assert np.array_equal(i, io)
+    assert np.array_equal(v, vo)
+    assert np.all(i[:, 0] == 0)
+
+
+def test_gather_rows(gpu):
+    import _gpuops as G
+    rng = np.random.default_rng(5)
+    data = rng.standard_normal((50, 8, 16)).astype(np.float32)
+    idx = rng.integers(0, 50, 77).astype(np.int32)
+    assert np.array_equal(G.gather_rows(data, idx), O.gather_rows(data, idx))
+    odd = rng.integers(-100, 100, (20, 7), dtype=np.int8)
+    assert np.array_equal(G.gather_rows(odd, idx % 20), O.gather_rows(odd, idx % 20))
+
+
+@pytest.mark.parametrize("m,n,k,trans_b", [(32, 96, 32, True), (70, 130, 50, True),
+                                           (64, 64, 64, False), (5, 7, 3, False)])
+def test_gemm_f32(gpu, m, n, k, trans_b):
+    import _gpuops as G
+    rng = np.random.default_rng(m + n)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal((n, k) if trans_b else (k, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32)
+    y = G.gemm_f32(a, b, trans_b, bias, res, 0)
+    yo = O.gemm_f32(a, b, trans_b, 1.0, bias, res, 0)
+    # same k-ordered fmaf chain on both sides
+    np.testing.assert_allclose(y, yo, rtol=1e-6, atol=1e-6)
+
+
+ATTN_CASES = [
+    # rows, heads, heads_kv, dhead, t_max, kv_group
+    (32, 8, 8, 64, 64, 1),     # Transformer-base self-attention
+    (128, 8, 8, 64, 40, 4),    # cross-attention over encoder memory, beam 4
+    (16, 32, 8, 128, 256, 1),  # Llama-3 8B GQA without head replication
+    (3, 8, 8, 4, 12, 1),       # aren-transliteration fixture (d_head 4)
+    (4, 2, 1, 96, 33, 2),      # MQA, non power-of-two chunk count
+    (2, 1, 1, 256, 9, 1),      # two float4 chunks per lane
+]
+
+
+@pytest.mark.parametrize("rows,heads,heads_kv,dhead,t_max,kv_group", ATTN_CASES)
+def test_attention_decode(gpu, rows, heads, heads_kv, dhead, t_max, kv_group):
+    import _gpuops as G
+    rng = np.random.default_rng(rows + heads + dhead + t_max)
+    q = rng.standard_normal((rows, heads, dhead)).astype(np.float32)
+    k = rng.standard_normal((rows // kv_group, heads_kv, t_max, dhead)).astype(np.float32)
+    v = rng.standard_normal((rows // kv_group, heads_kv, t_max, dhead)).astype(np.float32)
+    lengths = rng.integers(1, t_max + 1, rows // kv_group).astype(np.int32)
+    lengths[0] = t_max
+    if rows // kv_group > 1:
+        lengths[1] = 0  # fully masked row -> zero context
+    scale = 1.0 / np.sqrt(dhead)
+    y = G.attention_decode(q, k, v, lengths, 0, kv_group, scale)
+    yo = O.attention_decode(q, k, v, lengths, 0, kv_group, scale)
+    np.testing.assert_allclose(y, yo, rtol=2e-5, atol=2e-6)
+    y2 = G.attention_decode(q, k, v, None, t_max // 2 + 1, kv_group, scale)
+    yo2 = O.attention_decode(q, k, v, None, t_max // 2 + 1, kv_group, scale)
+    np.testing.assert_allclose(y2, yo2, rtol=2e-5, atol=2e-6)
