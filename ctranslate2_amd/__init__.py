@@ -1,0 +1,173 @@
+"""ctranslate2_amd -- MI355X (gfx950) native backend for CTranslate2's quantized decoder hot path.
+
+Python surface: a thin ctypes mirror of the reference's Python API for this path
+(`ctranslate2.Translator.translate_batch`, python/cpp/translator.cc:286-420) over the C ABI in
+include/ct2_mi355.h. All compute happens in libct2_mi355.so (hand-written HIP kernels); there is
+no CPU or PyTorch fallback.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import Ct2xError, ExecStats, TranslationOptions
+
+__version__ = "0.1.0"
+
+
+class TranslationResult:
+    """ctranslate2.TranslationResult: hypotheses (token lists) and scores."""
+
+    def __init__(self, hypotheses, scores, hypotheses_ids):
+        self.hypotheses = hypotheses
+        self.scores = scores
+        self.hypotheses_ids = hypotheses_ids
+
+    def __repr__(self):
+        return "TranslationResult(hypotheses=%r, scores=%r)" % (self.hypotheses, self.scores)
+
+
+class Translator:
+    """ctranslate2.Translator for converted models, on one MI355X.
+
+    Arguments follow the reference (python/cpp/translator.cc:286-297). `device` must be "cuda"
+    (the reference's name for the GPU device, Device::CUDA) -- this backend has no CPU path.
+    """
+
+    def __init__(self, model_path: str, device: str = "cuda", device_index: int = 0,
+                 compute_type: str = "default"):
+        if device not in ("cuda", "auto"):
+            raise ValueError("ctranslate2_amd only implements the GPU device (device='cuda'); "
+                             "got device=%r" % device)
+        self._L = _lib.lib()
+        self._h = self._L.ct2x_translator_create(model_path.encode(), C.c_int(device_index),
+                                                 compute_type.encode())
+        if not self._h:
+            raise Ct2xError(self._L.ct2x_last_error().decode("utf-8", "replace"))
+        self.model_path = model_path
+        self.device_index = device_index
+        info = self._model_info()
+        self.compute_type = info["compute_type"]
+        self.vocab_size = info["vocab_size"]
+        self.is_seq2seq = info["is_seq2seq"]
+        self.eos_id = info["eos_id"]
+        self.bos_id = info["bos_id"]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ct2x_translator_destroy(C.c_void_p(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- model facts ---------------------------------------------------------------------
+    def _model_info(self):
+        vals = [C.c_int32() for _ in range(7)]
+        buf = C.create_string_buffer(64)
+        _lib.check(self._L.ct2x_model_info(C.c_void_p(self._h), *[C.byref(v) for v in vals], buf,
+                                           C.c_int(64)))
+        keys = ["is_seq2seq", "vocab_size", "d_model", "num_layers", "num_heads", "bos_id", "eos_id"]
+        out = {k: v.value for k, v in zip(keys, vals)}
+        out["is_seq2seq"] = bool(out["is_seq2seq"])
+        out["compute_type"] = buf.value.decode()
+        return out
+
+    def token_to_id(self, token: str, target: bool = False) -> int:
+        return int(self._L.ct2x_vocab_id(C.c_void_p(self._h), C.c_int(int(target)), token.encode("utf-8")))
+
+    def id_to_token(self, idx: int, target: bool = True) -> str:
+        s = self._L.ct2x_vocab_token(C.c_void_p(self._h), C.c_int(int(target)), C.c_int32(idx))
+        if s is None:
+            raise Ct2xError(self._L.ct2x_last_error().decode("utf-8", "replace"))
+        return s.decode("utf-8")
+
+    # -- translation -----------------------------------------------------------------------
+    def _options(self, beam_size, max_decoding_length, min_decoding_length, num_hypotheses,
+                 return_scores, return_end_token, max_batch_size, max_input_length,
+                 length_penalty, patience, use_graph):
+        opt = TranslationOptions()
+        self._L.ct2x_translation_options_default(C.byref(opt))
+        opt.beam_size = beam_size
+        opt.max_decoding_length = max_decoding_length
+        opt.min_decoding_length = min_decoding_length
+        opt.num_hypotheses = num_hypotheses
+        opt.return_scores = int(return_scores)
+        opt.return_end_token = int(return_end_token)
+        opt.max_batch_size = max_batch_size
+        opt.max_input_length = max_input_length
+        opt.length_penalty = length_penalty
+        opt.patience = patience
+        opt.use_graph = int(use_graph)
+        return opt
+
+    def translate_ids(self, source_ids: Sequence[Sequence[int]], beam_size: int = 2,
+                      max_decoding_length: int = 256, min_decoding_length: int = 1,
+                      num_hypotheses: int = 1, return_scores: bool = False,
+                      return_end_token: bool = False, max_batch_size: int = 0,
+                      max_input_length: int = 1024, length_penalty: float = 1.0,
+                      patience: float = 1.0, use_graph: bool = True):
+        """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores)."""
+        batch = len(source_ids)
+        lengths = np.array([len(s) for s in source_ids], np.int32)
+        stride = max(1, int(lengths.max()) if batch else 1)
+        ids = np.zeros((batch, stride), np.int32)
+        for i, s in enumerate(source_ids):
+            ids[i, :len(s)] = s
+        out = np.zeros((batch, num_hypotheses, max_decoding_length), np.int32)
+        out_len = np.zeros((batch, num_hypotheses), np.int32)
+        scores = np.zeros((batch, num_hypotheses), np.float32)
+        opt = self._options(beam_size, max_decoding_length, min_decoding_length, num_hypotheses,
+                            return_scores, return_end_token, max_batch_size, max_input_length,
+                            length_penalty, patience, use_graph)
+        _lib.check(self._L.ct2x_translate_batch(
+            C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
+            C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
+        hyps = [[out[b, k, :out_len[b, k]].tolist() for k in range(num_hypotheses)
+                 if out_len[b, k] > 0 or k == 0] for b in range(batch)]
+        return hyps, scores
+
+    def translate_batch(self, source: List[List[str]], target_prefix: Optional[list] = None,
+                        **kwargs) -> List[TranslationResult]:
+        """ctranslate2.Translator.translate_batch on tokens (same keyword names)."""
+        if target_prefix is not None:
+            raise NotImplementedError("target_prefix is not supported by this backend yet")
+        return_scores = kwargs.get("return_scores", False)
+        src_ids = [[self.token_to_id(t) for t in sent] for sent in source]
+        hyps, scores = self.translate_ids(src_ids, **kwargs)
+        results = []
+        for b, sent_hyps in enumerate(hyps):
+            tokens = [[self.id_to_token(i) for i in h] for h in sent_hyps]
+            sc = [float(scores[b, k]) for k in range(len(sent_hyps))] if return_scores else []
+            results.append(TranslationResult(tokens, sc, sent_hyps))
+        return results
+
+    def step_logits(self, source_ids, target_in):
+        """Teacher-forced per-step logits [T, batch, vocab] (source ids INCLUDE special tokens)."""
+        batch = len(target_in)
+        tgt = np.ascontiguousarray(target_in, np.int32)
+        T = tgt.shape[1]
+        if source_ids:
+            lengths = np.array([len(s) for s in source_ids], np.int32)
+            stride = int(lengths.max())
+            ids = np.zeros((batch, stride), np.int32)
+            for i, s in enumerate(source_ids):
+                ids[i, :len(s)] = s
+        else:
+            lengths = np.zeros((batch,), np.int32)
+            stride = 1
+            ids = np.zeros((batch, 1), np.int32)
+        logits = np.empty((T, batch, self.vocab_size), np.float32)
+        _lib.check(self._L.ct2x_step_logits(C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths),
+                                            C.c_int32(batch), C.c_int32(stride), _lib.ptr(tgt),
+                                            C.c_int32(T), _lib.ptr(logits)))
+        return logits
+
+    def last_stats(self) -> dict:
+        st = ExecStats()
+        _lib.check(self._L.ct2x_last_stats(C.c_void_p(self._h), C.byref(st)))
+        return {name: getattr(st, name) for name, _ in ExecStats._fields_}

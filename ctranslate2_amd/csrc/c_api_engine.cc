@@ -1,0 +1,388 @@
+// extern "C" surface of ctranslate2::Translator / Generator on the MI355X engine
+// (include/ct2_mi355.h, "engine" section) + the host-only model inspection helpers.
+
+#include "../../include/ct2_mi355.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+
+#include "decoding.h"
+#include "engine.h"
+#include "model.h"
+#include "runtime.h"
+
+using namespace ct2x;
+
+namespace {
+
+struct Translator {
+  std::shared_ptr<ModelFile> model;
+  std::unique_ptr<Engine> engine;
+  std::shared_ptr<Vocabulary> src_vocab, tgt_vocab;
+  bool add_source_bos = false, add_source_eos = false;
+  bool has_start_token = true;
+  int32_t start_id = 1, eos_id = 2, bos_id = 1;
+  std::mutex mutex;
+  ct2x_exec_stats last{};
+};
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// SequenceToSequenceModel::initialize + load_vocabularies (src/models/sequence_to_sequence.cc:13-77)
+// / LanguageModel (src/models/language_model.cc:13-40).
+void load_vocabularies(Translator& t) {
+  const ModelFile& m = *t.model;
+  const std::string unk = m.config_string("unk_token", "<unk>");
+  const std::string bos = m.config_string("bos_token", "<s>");
+  const std::string eos = m.config_string("eos_token", "</s>");
+  const std::string& dir = m.dir;
+  if (t.engine->is_seq2seq()) {
+    auto shared = Vocabulary::load(dir, "shared_vocabulary", unk, bos, eos);
+    if (shared) {
+      t.src_vocab = t.tgt_vocab = shared;
+    } else {
+      t.tgt_vocab = Vocabulary::load(dir, "target_vocabulary", unk, bos, eos);
+      if (!t.tgt_vocab)
+        throw std::runtime_error("Cannot load the target vocabulary from the model directory");
+      t.src_vocab = Vocabulary::load(dir, "source_vocabulary", unk, bos, eos);
+      if (!t.src_vocab)
+        throw std::runtime_error("Cannot load the source vocabulary from the model directory");
+    }
+    if (m.binary_version < 6 || m.config.kind == Json::kNull) {
+      t.add_source_bos = m.flag("with_source_bos", false);
+      t.add_source_eos = m.flag("with_source_eos", false);
+    }
+    t.add_source_bos = m.config_bool("add_source_bos", t.add_source_bos);
+    t.add_source_eos = m.config_bool("add_source_eos", t.add_source_eos);
+  } else {
+    t.src_vocab = t.tgt_vocab = Vocabulary::load(dir, "vocabulary", unk, bos, eos);
+    if (!t.tgt_vocab) throw std::runtime_error("Cannot load the vocabulary from the model directory");
+  }
+  t.bos_id = static_cast<int32_t>(t.tgt_vocab->bos_id());
+  t.eos_id = static_cast<int32_t>(t.tgt_vocab->eos_id());
+  // decoder_start_token (sequence_to_sequence.cc:68-73): config value, else BOS when
+  // with_target_bos (default), else EOS.
+  const Json* start = m.config.get("decoder_start_token");
+  if (start && start->kind == Json::kString) {
+    t.start_id = static_cast<int32_t>(t.tgt_vocab->to_id(start->str));
+  } else if (start && start->kind == Json::kNull && m.config.kind == Json::kObject) {
+    t.has_start_token = false;
+  } else {
+    if (m.flag("user_decoder_start_tokens", false))
+      t.has_start_token = false;
+    else
+      t.start_id = m.flag("with_target_bos", true) ? t.bos_id : t.eos_id;
+  }
+  if (static_cast<int64_t>(t.tgt_vocab->size()) != t.engine->vocab_size())
+    throw std::runtime_error("The target vocabulary has " + std::to_string(t.tgt_vocab->size()) +
+                             " tokens but the model output layer has " +
+                             std::to_string(t.engine->vocab_size()));
+}
+
+DecodingOptions to_decoding_options(const ct2x_translation_options& o) {
+  DecodingOptions d;
+  d.beam_size = o.beam_size;
+  d.max_length = o.max_decoding_length;
+  d.min_length = o.min_decoding_length;
+  d.num_hypotheses = o.num_hypotheses;
+  d.return_scores = o.return_scores != 0;
+  d.length_penalty = o.length_penalty;
+  d.patience = o.patience;
+  d.use_graph = o.use_graph != 0;
+  d.include_eos_in_hypotheses = true;  // DecodingOptions default (include/ctranslate2/decoding.h:154)
+  return d;
+}
+
+}  // namespace
+
+#define API_TRY try {
+#define API_CATCH                                     \
+  }                                                   \
+  catch (const std::exception& e) {                   \
+    set_last_error(e.what());                         \
+    return 1;                                         \
+  }                                                   \
+  return 0;
+
+extern "C" {
+
+void ct2x_translation_options_default(struct ct2x_translation_options* o) {
+  // TranslationOptions defaults (include/ctranslate2/translation.h:11-96).
+  std::memset(o, 0, sizeof(*o));
+  o->beam_size = 2;
+  o->max_decoding_length = 256;
+  o->min_decoding_length = 1;
+  o->num_hypotheses = 1;
+  o->return_scores = 0;
+  o->return_end_token = 0;
+  o->max_batch_size = 0;
+  o->max_input_length = 1024;
+  o->length_penalty = 1.f;
+  o->patience = 1.f;
+  o->use_graph = 1;
+}
+
+void* ct2x_translator_create(const char* model_dir, int device_index, const char* compute_type) {
+  try {
+    auto t = std::make_unique<Translator>();
+    t->model = ModelFile::load(model_dir);
+    t->engine = std::make_unique<Engine>(t->model, compute_type ? compute_type : "default",
+                                         device_index);
+    load_vocabularies(*t);
+    return t.release();
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return nullptr;
+  }
+}
+
+void ct2x_translator_destroy(void* translator) { delete static_cast<Translator*>(translator); }
+
+int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
+                         int32_t batch, int32_t src_stride,
+                         const struct ct2x_translation_options* opt_in, int32_t* out_ids,
+                         int32_t* out_lengths, float* out_scores) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  std::lock_guard<std::mutex> lock(t->mutex);
+  CT2X_CHECK(t->engine->is_seq2seq(), "This model cannot be used as a sequence-to-sequence model");
+  CT2X_CHECK(t->has_start_token, "models that need user decoder start tokens are not supported");
+  ct2x_translation_options opt = *opt_in;
+  DecodingOptions dopt = to_decoding_options(opt);
+  validate_decoding_options(dopt);
+  const int32_t nh = opt.num_hypotheses, max_len = opt.max_decoding_length;
+  const double t0 = now_ms();
+  t->last = ct2x_exec_stats{};
+
+  // make_source_ids (sequence_to_sequence.cc:140-165) + Vocabulary::to_ids truncation
+  // (src/vocabulary.cc:108-146).
+  std::vector<std::vector<int32_t>> sources(batch);
+  for (int32_t b = 0; b < batch; ++b) {
+    auto& s = sources[b];
+    if (src_lengths[b] == 0) continue;  // skip_translation: empty source -> empty result
+    if (t->add_source_bos) s.push_back(static_cast<int32_t>(t->src_vocab->bos_id()));
+    for (int32_t i = 0; i < src_lengths[b]; ++i) {
+      const int32_t id = src_ids[static_cast<int64_t>(b) * src_stride + i];
+      CT2X_CHECK(id >= 0 && id < static_cast<int32_t>(t->src_vocab->size()),
+                 "Invalid source token ID " + std::to_string(id));
+      s.push_back(id);
+    }
+    if (t->add_source_eos) s.push_back(static_cast<int32_t>(t->src_vocab->eos_id()));
+    const size_t ml = static_cast<size_t>(opt.max_input_length);
+    if (ml > 0 && s.size() > ml) {
+      const int32_t eos = static_cast<int32_t>(t->src_vocab->eos_id());
+      if (s.back() == eos)
+        s[ml - 1] = eos;
+      else if (s[s.size() - 2] == eos && ml >= 2) {
+        s[ml - 2] = eos;
+        s[ml - 1] = s.back();
+      }
+      s.resize(ml);
+    }
+  }
+
+  // rebatch_input (src/batch_reader.cc:175-228): longest first, split by max_batch_size.
+  std::vector<int32_t> order;
+  for (int32_t b = 0; b < batch; ++b)
+    if (!sources[b].empty()) order.push_back(b);
+  for (int32_t b = 0; b < batch; ++b)
+    for (int32_t k = 0; k < nh; ++k) out_lengths[b * nh + k] = 0;
+  if (opt.max_batch_size > 0)
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+      return sources[a].size() > sources[b].size();
+    });
+  const size_t chunk = opt.max_batch_size > 0 ? static_cast<size_t>(opt.max_batch_size)
+                                              : std::max<size_t>(order.size(), 1);
+  double encode_ms = 0, decode_ms = 0;
+  for (size_t begin = 0; begin < order.size(); begin += chunk) {
+    const size_t end = std::min(order.size(), begin + chunk);
+    const int64_t B = static_cast<int64_t>(end - begin);
+    int64_t s_max = 0;
+    for (size_t i = begin; i < end; ++i)
+      s_max = std::max<int64_t>(s_max, static_cast<int64_t>(sources[order[i]].size()));
+    std::vector<int32_t> ids(B * s_max, 0), lens(B);
+    for (int64_t i = 0; i < B; ++i) {
+      const auto& s = sources[order[begin + i]];
+      std::copy(s.begin(), s.end(), ids.begin() + i * s_max);
+      lens[i] = static_cast<int32_t>(s.size());
+    }
+    const double te0 = now_ms();
+    auto st = t->engine->start(ids.data(), lens.data(), B, s_max, dopt.beam_size,
+                               dopt.max_length);
+    t->engine->synchronize();
+    const double te1 = now_ms();
+    std::vector<int32_t> start_ids(B, t->start_id);
+    DecodeStats ds;
+    std::vector<DecodingResult> results =
+        dopt.beam_size == 1 ? greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds)
+                            : beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds);
+    t->engine->synchronize();
+    const double te2 = now_ms();
+    encode_ms += te1 - te0;
+    decode_ms += te2 - te1;
+    t->last.decode_steps += ds.steps;
+    for (int64_t i = 0; i < B; ++i) {
+      const int32_t b = order[begin + i];
+      DecodingResult& r = results[i];
+      for (int32_t k = 0; k < nh && k < static_cast<int32_t>(r.hypotheses.size()); ++k) {
+        auto& hyp = r.hypotheses[k];
+        // "Remove EOS token" (sequence_to_sequence.cc:374-384).
+        if (!opt.return_end_token)
+          while (!hyp.empty() && hyp.back() == t->eos_id) hyp.pop_back();
+        const int32_t len = static_cast<int32_t>(hyp.size());
+        std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
+                  out_ids + (static_cast<int64_t>(b) * nh + k) * max_len);
+        out_lengths[b * nh + k] = len;
+        if (opt.return_scores && out_scores && k < static_cast<int32_t>(r.scores.size()))
+          out_scores[b * nh + k] = r.scores[k];
+        if (k == 0) t->last.num_tokens += len;  // ExecutionStats: hypothesis 0 tokens
+      }
+    }
+  }
+  t->last.num_examples = batch;
+  t->last.kernels_per_step = t->engine->kernels_per_step();
+  t->last.encode_ms = encode_ms;
+  t->last.decode_ms = decode_ms;
+  t->last.total_ms = now_ms() - t0;
+  API_CATCH
+}
+
+int ct2x_generate_batch(void* translator, const int32_t*, const int32_t*, int32_t, int32_t,
+                        const struct ct2x_translation_options*, int32_t*, int32_t*, float*) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  throw Error("ct2x_generate_batch: decoder-only generation (prompt prefill) is not built in "
+              "this round");
+  API_CATCH
+}
+
+int ct2x_step_logits(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
+                     int32_t batch, int32_t src_stride, const int32_t* tgt_in, int32_t T,
+                     float* logits_out) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  std::lock_guard<std::mutex> lock(t->mutex);
+  Engine& e = *t->engine;
+  std::unique_ptr<DecodeState> st;
+  if (e.is_seq2seq())
+    st = e.start(src_ids, src_lengths, batch, src_stride, 1, T);
+  else
+    st = e.start_decoder_only(batch, 1, T);
+  const int64_t V = e.vocab_size();
+  std::vector<int32_t> ids(batch);
+  e.set_step(*st, 0);
+  for (int32_t s = 0; s < T; ++s) {
+    for (int32_t b = 0; b < batch; ++b) ids[b] = tgt_in[static_cast<int64_t>(b) * T + s];
+    e.set_ids(*st, ids.data());
+    e.step(*st, /*graph=*/false);
+    e.copy_logits_to_host(*st, logits_out + static_cast<int64_t>(s) * batch * V);
+    e.advance_step(*st);
+  }
+  e.synchronize();
+  API_CATCH
+}
+
+int ct2x_model_info(void* translator, int32_t* is_seq2seq, int32_t* vocab_size, int32_t* d_model,
+                    int32_t* num_layers_dec, int32_t* num_heads, int32_t* bos_id, int32_t* eos_id,
+                    char* compute_type, int ct_size) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  if (is_seq2seq) *is_seq2seq = t->engine->is_seq2seq();
+  if (vocab_size) *vocab_size = static_cast<int32_t>(t->engine->vocab_size());
+  if (d_model) *d_model = static_cast<int32_t>(t->engine->d_model());
+  if (num_layers_dec) *num_layers_dec = static_cast<int32_t>(t->engine->num_decoder_layers());
+  if (num_heads) *num_heads = static_cast<int32_t>(t->engine->num_heads());
+  if (bos_id) *bos_id = t->bos_id;
+  if (eos_id) *eos_id = t->eos_id;
+  if (compute_type && ct_size > 0) {
+    const std::string s = compute_type_name(t->engine->compute_type());
+    std::strncpy(compute_type, s.c_str(), ct_size - 1);
+    compute_type[ct_size - 1] = 0;
+  }
+  API_CATCH
+}
+
+int ct2x_vocab_size(void* translator, int which) {
+  auto* t = static_cast<Translator*>(translator);
+  if (!t) return -1;
+  return static_cast<int>((which == 0 ? t->src_vocab : t->tgt_vocab)->size());
+}
+
+const char* ct2x_vocab_token(void* translator, int which, int32_t id) {
+  auto* t = static_cast<Translator*>(translator);
+  try {
+    return (which == 0 ? t->src_vocab : t->tgt_vocab)->to_token(static_cast<size_t>(id)).c_str();
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return nullptr;
+  }
+}
+
+int32_t ct2x_vocab_id(void* translator, int which, const char* token) {
+  auto* t = static_cast<Translator*>(translator);
+  return static_cast<int32_t>((which == 0 ? t->src_vocab : t->tgt_vocab)->to_id(token));
+}
+
+int ct2x_last_stats(void* translator, struct ct2x_exec_stats* stats) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr && stats != nullptr, "null argument");
+  *stats = t->last;
+  API_CATCH
+}
+
+// ---- host-only ---------------------------------------------------------------------------
+
+int ct2x_inspect_model(const char* model_dir, char* spec_name, int spec_size,
+                       int32_t* binary_version, int32_t* revision, int32_t* num_aliases) {
+  try {
+    auto m = ModelFile::load(model_dir);
+    if (spec_name && spec_size > 0) {
+      std::strncpy(spec_name, m->spec.c_str(), spec_size - 1);
+      spec_name[spec_size - 1] = 0;
+    }
+    if (binary_version) *binary_version = static_cast<int32_t>(m->binary_version);
+    if (revision) *revision = static_cast<int32_t>(m->revision);
+    if (num_aliases) *num_aliases = static_cast<int32_t>(m->aliases.size());
+    return static_cast<int>(m->variables.size());
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+
+int ct2x_inspect_variable(const char* model_dir, int32_t index, char* name, int name_size,
+                          int32_t* dtype, int32_t* rank, int64_t* dims, int64_t* nbytes) {
+  API_TRY
+  static thread_local std::string cached_dir;
+  static thread_local std::shared_ptr<ModelFile> cached;
+  if (!cached || cached_dir != model_dir) {
+    cached = ModelFile::load(model_dir);
+    cached_dir = model_dir;
+  }
+  CT2X_CHECK(index >= 0 && index < static_cast<int32_t>(cached->variables.size()),
+             "variable index out of range");
+  const Variable& v = cached->variables[index];
+  if (name && name_size > 0) {
+    std::strncpy(name, v.name.c_str(), name_size - 1);
+    name[name_size - 1] = 0;
+  }
+  if (dtype) *dtype = v.dtype;
+  if (rank) *rank = static_cast<int32_t>(v.shape.size());
+  if (dims)
+    for (size_t i = 0; i < v.shape.size() && i < 8; ++i) dims[i] = v.shape[i];
+  if (nbytes) *nbytes = static_cast<int64_t>(v.data.size());
+  API_CATCH
+}
+
+}  // extern "C"

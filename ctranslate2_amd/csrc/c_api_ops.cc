@@ -158,7 +158,7 @@ int ct2x_quantize_s8(const void* d_x, int dtype, int64_t rows, int64_t depth,
                      int round_before_cast, int8_t* d_q, float* d_scales, void* stream) {
   API_TRY
   require_f32(dtype, "ct2x_quantize_s8");
-  launch_quantize_s8(static_cast<const float*>(d_x), rows, depth, round_before_cast != 0, d_q,
+  launch_quantize_s8(static_cast<const float*>(d_x), rows, depth, round_before_cast, d_q,
                      d_scales, resolve_stream(stream));
   check_last_launch("quantize_s8");
   API_CATCH
@@ -233,7 +233,7 @@ int ct2x_layer_norm(const void* d_x, const float* d_gamma, const float* d_beta, 
   require_f32(dtype, "ct2x_layer_norm");
   CT2X_CHECK(d_beta != nullptr, "ct2x_layer_norm: beta is required (use ct2x_rms_norm)");
   CT2X_CHECK(depth * 4 <= 64 * 1024, "ct2x_layer_norm: depth > 16384 is not supported");
-  launch_norm(static_cast<const float*>(d_x), d_gamma, d_beta, rows, depth, epsilon, false, true,
+  launch_norm(static_cast<const float*>(d_x), d_gamma, d_beta, rows, depth, epsilon, false, 1,
               static_cast<float*>(d_y), nullptr, nullptr, resolve_stream(stream));
   check_last_launch("layer_norm");
   API_CATCH
@@ -245,7 +245,7 @@ int ct2x_rms_norm(const void* d_x, const float* d_gamma, int64_t rows, int64_t d
   require_f32(dtype, "ct2x_rms_norm");
   CT2X_CHECK(depth * 4 <= 64 * 1024, "ct2x_rms_norm: depth > 16384 is not supported");
   launch_norm(static_cast<const float*>(d_x), d_gamma, nullptr, rows, depth, epsilon,
-              use_residual != 0, true, static_cast<float*>(d_y), nullptr, nullptr,
+              use_residual != 0, 1, static_cast<float*>(d_y), nullptr, nullptr,
               resolve_stream(stream));
   check_last_launch("rms_norm");
   API_CATCH
@@ -258,7 +258,7 @@ int ct2x_norm_quantize_s8(const float* d_x, const float* d_gamma, const float* d
   API_TRY
   CT2X_CHECK(depth * 4 <= 64 * 1024, "ct2x_norm_quantize_s8: depth > 16384 is not supported");
   launch_norm(d_x, d_gamma, d_beta, rows, depth, epsilon, use_residual != 0,
-              round_before_cast != 0, d_y, d_q, d_scales, resolve_stream(stream));
+              round_before_cast, d_y, d_q, d_scales, resolve_stream(stream));
   check_last_launch("norm_quantize_s8");
   API_CATCH
 }

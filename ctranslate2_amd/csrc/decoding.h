@@ -1,0 +1,74 @@
+// Host side of the decoding loops: GreedySearch::search and BeamSearch::search
+// (src/decoding.cc:733-974, 425-720) re-hosted over the device-resident engine. The
+// bookkeeping (hypothesis registration, EOS handling, candidate replacement, length penalty,
+// result ordering) follows the reference line by line; the difference is mechanical:
+//  - the batch is static (finished sentences stay in place and are ignored) instead of being
+//    physically gathered out of every cache tensor, which is row-independent and therefore
+//    result-neutral;
+//  - greedy steps are enqueued `sync_every` at a time: ids are sampled and fed back on the device,
+//    the host only reads the id history to detect EOS.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "engine.h"
+
+namespace ct2x {
+
+struct DecodingOptions {
+  int32_t beam_size = 1;
+  int32_t max_length = 256;
+  int32_t min_length = 0;
+  int32_t num_hypotheses = 1;
+  bool return_scores = false;
+  bool include_eos_in_hypotheses = true;
+  float length_penalty = 0.f;
+  float patience = 1.f;
+  bool use_graph = true;
+  int32_t sync_every = 8;
+  int32_t start_step = 0;
+};
+
+struct DecodingResult {
+  std::vector<std::vector<int32_t>> hypotheses;
+  std::vector<float> scores;
+};
+
+struct DecodeStats {
+  int64_t steps = 0;
+};
+
+void validate_decoding_options(const DecodingOptions& options);
+
+std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& state,
+                                          const std::vector<int32_t>& start_ids, int32_t end_id,
+                                          const DecodingOptions& options, DecodeStats* stats);
+
+std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& state,
+                                        const std::vector<int32_t>& start_ids, int32_t end_id,
+                                        const DecodingOptions& options, DecodeStats* stats);
+
+// Host-only pieces, exported for the CPU test-suite -------------------------------------------
+
+// finalize_hypothesis_score without coverage penalty (src/decoding.cc:192-207).
+float finalize_score(float score, float length, float length_penalty);
+
+// One batch entry of BeamSearch's post-TopK bookkeeping (src/decoding.cc:596-676): given the
+// 2*beam candidates (word ids, cumulative scores, origin beams) decide which hypotheses finish
+// and which candidates become the next active beams. Pure function of its inputs.
+struct BeamStepInput {
+  int32_t beam_size = 1;
+  int32_t step = 0;
+  bool is_last_step = false;
+  int32_t end_id = 0;
+  const int32_t* word_ids = nullptr;   // [2*beam]
+  const float* scores = nullptr;       // [2*beam]
+};
+struct BeamStepOutput {
+  std::vector<int32_t> finished;       // candidate slots k < beam whose hypothesis finished
+  std::vector<int32_t> next;           // [beam] candidate index that occupies beam k next step
+};
+BeamStepOutput beam_step_select(const BeamStepInput& in);
+
+}  // namespace ct2x

@@ -111,11 +111,34 @@ __device__ __forceinline__ float apply_activation(float v, int act) {
   }
 }
 
+// Quantisation mode flags (the `round_before_cast` argument of the C ABI):
+//   bit 0: round to nearest even before the cast (binary_version >= 5 models), else truncate;
+//   bit 1: reproduce the reference CPU backends' u8 domain shift. On x86 the reference runs
+//          s8 x s8 GEMMs as u8 x s8 (MKL / oneDNN, cpu::prefer_u8s8s32_gemm), so Dense quantises
+//          with shift_to_uint8: q_u8 = cvtt(round_func(x*scale - (-128))) and compensates
+//          -128*sum(W) afterwards (src/cpu/kernels.cc:592-604, src/cpu/primitives.cc:869-898).
+//          The effective signed activation is q_u8 - 128. That differs from cvtt(round_func(x*scale))
+//          (a) for every negative value in truncation mode (floor vs trunc-toward-zero) and
+//          (b) at fp32 rounding boundaries of the +128 add in rounding mode. Token parity with
+//          the CPU oracle needs the same integers, so the engine sets this bit by default.
+constexpr int kQuantRound = 1;
+constexpr int kQuantU8Shift = 2;
+
 // float -> int8 exactly as the reference CPU path: optional round-to-nearest-even
 // (Vec::round = _mm256_round_ps NEAREST, src/cpu/vec_avx.h:192-202) then truncating
 // conversion (cvttps) and a narrowing store.
-__device__ __forceinline__ int8_t to_s8(float v, bool round_before_cast) {
-  if (round_before_cast) v = rintf(v);
+// `x`, `scale`: the product is formed here because the u8-shift arm is a fused multiply-add in
+// the reference's compiled AVX2 kernels (x*scale + 128 with a single rounding).
+__device__ __forceinline__ int8_t to_s8(float x, float scale, int mode) {
+  float v;
+  if (mode & kQuantU8Shift) {
+    v = fmaf(x, scale, 128.f);
+    if (mode & kQuantRound) v = rintf(v);
+    const int u = static_cast<int>(v) & 0xff;  // narrowing int32 -> uint8 store
+    return static_cast<int8_t>(u - 128);
+  }
+  v = x * scale;
+  if (mode & kQuantRound) v = rintf(v);
   return static_cast<int8_t>(static_cast<int>(v));
 }
 

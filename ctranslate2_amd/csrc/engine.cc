@@ -1,0 +1,1056 @@
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+#include "runtime.h"
+
+namespace ct2x {
+
+std::string compute_type_name(ComputeType t) {
+  switch (t) {
+    case ComputeType::kFloat32: return "float32";
+    case ComputeType::kInt8Float32: return "int8_float32";
+  }
+  return "?";
+}
+
+namespace {
+
+bool ends_with(const std::string& s, const std::string& suffix) {
+  return s.size() >= suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0;
+}
+
+// Host restatement of ops::Quantize for weights converted at load time
+// (Model::ensure_dtype, src/models/model.cc:304-369 uses the model's rounding mode).
+void host_quantize_rows(const std::vector<float>& w, int64_t rows, int64_t depth, bool round,
+                        std::vector<int8_t>& q, std::vector<float>& scales) {
+  q.resize(rows * depth);
+  scales.resize(rows);
+  for (int64_t i = 0; i < rows; ++i) {
+    const float* x = w.data() + i * depth;
+    float amax = 0.f;
+    for (int64_t j = 0; j < depth; ++j) amax = std::max(amax, std::fabs(x[j]));
+    const float scale = amax != 0.f ? 127.f / amax : 1.f;
+    scales[i] = scale;
+    for (int64_t j = 0; j < depth; ++j) {
+      float v = x[j] * scale;
+      if (round) v = std::nearbyintf(v);
+      q[i * depth + j] = static_cast<int8_t>(static_cast<int32_t>(v));
+    }
+  }
+}
+
+// Resolution of the requested compute type against what this backend implements
+// (reference: resolve_compute_type, src/types.cc:156-295).
+ComputeType resolve(const std::string& requested, bool model_is_quantized) {
+  if (requested == "float32") return ComputeType::kFloat32;
+  if (requested == "int8" || requested == "int8_float32" || requested == "auto")
+    return ComputeType::kInt8Float32;
+  if (requested == "default" || requested.empty())
+    return model_is_quantized ? ComputeType::kInt8Float32 : ComputeType::kFloat32;
+  if (requested == "int8_float16" || requested == "int8_bfloat16" || requested == "float16" ||
+      requested == "bfloat16" || requested == "int16")
+    throw std::invalid_argument("Requested " + requested + " compute type, but this backend "
+                                "build only implements int8_float32 and float32");
+  throw std::invalid_argument("Invalid compute type: " + requested);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Loading
+// ---------------------------------------------------------------------------------------------
+
+Engine::Engine(std::shared_ptr<ModelFile> model, const std::string& compute_type,
+               int device_index)
+    : model_(std::move(model)), device_(device_index) {
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  stream_ = thread_stream();
+  round_before_cast_ = model_->round_before_cast_in_quantization();
+  // Activation quantisation reproduces the reference CPU backends' u8-shifted arithmetic by
+  // default (device_utils.h, kQuantU8Shift); CT2X_S8_ACTIVATIONS=1 selects the plain signed
+  // form the reference's own GPU kernels use (src/ops/quantize_gpu.cu:46-55).
+  quant_mode_ = (round_before_cast_ ? 1 : 0) | 2;
+  if (const char* env = std::getenv("CT2X_S8_ACTIVATIONS"))
+    if (env[0] == '1') quant_mode_ &= ~2;
+
+  bool quantized = false;
+  for (const auto& v : model_->variables)
+    if (ends_with(v.name, "/weight") && (v.dtype == kI8 || v.dtype == kI16)) quantized = true;
+  compute_type_ = resolve(compute_type, quantized);
+
+  const std::string& spec = model_->spec;
+  if (spec == "TransformerSpec" || spec == "TransformerBase" || spec == "TransformerBig" ||
+      spec.empty()) {
+    has_encoder_ = true;
+  } else if (spec == "TransformerDecoderSpec") {
+    has_encoder_ = false;
+  } else {
+    throw std::runtime_error("Model specification '" + spec + "' is not handled by this backend "
+                             "(Transformer encoder-decoder and decoder-only models are)");
+  }
+  load_weights();
+}
+
+Engine::~Engine() {
+  (void)hipSetDevice(device_);
+  (void)hipStreamSynchronize(stream_);
+  for (void* p : device_blocks_) {
+    try { device_free(p); } catch (...) {}
+  }
+  if (sin_pos_table_) { try { device_free(sin_pos_table_); } catch (...) {} }
+  if (rope_sin_) { try { device_free(rope_sin_); } catch (...) {} }
+  if (rope_cos_) { try { device_free(rope_cos_); } catch (...) {} }
+}
+
+const void* Engine::upload(const void* host, size_t bytes) {
+  void* d = device_malloc(bytes);
+  device_blocks_.push_back(d);
+  CT2X_HIP_CHECK(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+  weight_bytes_ += static_cast<int64_t>(bytes);
+  return d;
+}
+
+const float* Engine::upload_floats(const std::vector<float>& v) {
+  return static_cast<const float*>(upload(v.data(), v.size() * sizeof(float)));
+}
+
+DenseW Engine::load_dense(const std::string& scope, bool required) {
+  DenseW d;
+  const Variable* w = model_->find(scope + "/weight");
+  if (!w) {
+    if (model_->has(scope + "/weight_packed"))
+      throw std::runtime_error(scope + ": pre-packed CPU weights cannot be loaded on the GPU");
+    if (required) throw std::out_of_range("variable " + scope + "/weight not found");
+    return d;
+  }
+  if (model_->has(scope + "/weight_zero"))
+    throw std::invalid_argument("AWQ weights (" + scope + ") are not supported by this backend");
+  if (w->shape.size() != 2) throw std::runtime_error(scope + "/weight is not a matrix");
+  d.present = true;
+  d.n = w->shape[0];
+  d.k = w->shape[1];
+  const Variable* scale = model_->find(scope + "/weight_scale");
+  const bool want_int8 = (compute_type_ == ComputeType::kInt8Float32);
+
+  if (want_int8 && w->dtype == kI8 && scale && scale->size() == d.n) {
+    d.quantized = true;
+    d.wq = static_cast<const int8_t*>(upload(w->data.data(), w->data.size()));
+    d.wscale = upload_floats(scale->to_float());
+  } else {
+    // Bring the weight to float first (Dequantize: x / scale, src/ops/dequantize_cpu.cc).
+    std::vector<float> wf = w->to_float();
+    if (w->dtype == kI8 || w->dtype == kI16) {
+      if (!scale) {
+        if (w->dtype == kI16) {
+          for (auto& v : wf) v = v / 1000.f;  // ops::Quantize::global_int16_scale
+        } else {
+          throw std::runtime_error("variable " + scope + "/weight_scale not found");
+        }
+      } else {
+        const std::vector<float> s = scale->to_float();
+        if (scale->size() == 1) {
+          for (auto& v : wf) v = v / s[0];
+        } else {
+          for (int64_t i = 0; i < d.n; ++i)
+            for (int64_t j = 0; j < d.k; ++j) wf[i * d.k + j] = wf[i * d.k + j] / s[i];
+        }
+      }
+    }
+    if (want_int8) {
+      std::vector<int8_t> q;
+      std::vector<float> s;
+      host_quantize_rows(wf, d.n, d.k, round_before_cast_, q, s);
+      d.quantized = true;
+      d.wq = static_cast<const int8_t*>(upload(q.data(), q.size()));
+      d.wscale = upload_floats(s);
+    } else {
+      d.wf = upload_floats(wf);
+    }
+  }
+  if (const Variable* b = model_->find(scope + "/bias")) d.bias = upload_floats(b->to_float());
+  return d;
+}
+
+NormW Engine::load_norm(const std::string& scope) {
+  NormW n;
+  const Variable* gamma = model_->find(scope + "/gamma");
+  if (!gamma) return n;
+  n.present = true;
+  n.gamma = upload_floats(gamma->to_float());
+  if (const Variable* beta = model_->find(scope + "/beta")) n.beta = upload_floats(beta->to_float());
+  n.use_residual = model_->flag(scope + "/layer_norm_use_residual", false);
+  // layers::LayerNorm ctor (src/layers/common.cc:444-454).
+  if (model_->config_has_number("layer_norm_epsilon"))
+    n.eps = static_cast<float>(model_->config_number("layer_norm_epsilon", 0));
+  else
+    n.eps = n.beta ? 1e-5f : 1e-6f;
+  return n;
+}
+
+AttnW Engine::load_attention(const std::string& scope, bool self_attention, int64_t num_heads) {
+  AttnW a;
+  for (const char* unsupported : {"/relative_attention_bias", "/relative_position_keys",
+                                  "/relative_asymmetric_position_keys",
+                                  "/relative_position_values", "/q_norm/gamma", "/k_norm/gamma",
+                                  "/v_norm/gamma", "/memory_kv/weight"})
+    if (model_->has(scope + unsupported))
+      throw std::runtime_error("attention variant with " + scope + unsupported +
+                               " is not supported by this backend yet");
+  a.ln = load_norm(scope + "/layer_norm");
+  a.n_lin = self_attention ? 2 : 3;
+  for (int i = 0; i < a.n_lin; ++i)
+    a.lin[i] = load_dense(scope + "/linear_" + std::to_string(i), true);
+  a.heads = num_heads;
+  const int64_t d_model = a.lin[a.n_lin - 1].n;
+  a.dhead = static_cast<int64_t>(model_->attribute(scope + "/head_dim", double(d_model / num_heads)));
+  a.queries_scale = static_cast<float>(
+      model_->attribute(scope + "/queries_scale", 1.0 / std::sqrt(static_cast<float>(a.dhead))));
+  if (!model_->has(scope + "/queries_scale"))
+    a.queries_scale = 1.f / std::sqrt(static_cast<float>(a.dhead));
+  const bool multi_query = model_->flag(scope + "/multi_query", false);
+  a.heads_kv = multi_query ? 1
+                           : static_cast<int64_t>(model_->attribute(scope + "/num_heads_kv",
+                                                                    double(num_heads)));
+  if (model_->attribute(scope + "/sliding_window", 0) != 0)
+    throw std::runtime_error("sliding window attention is not supported by this backend yet");
+  // make_rotary_embeddings (src/layers/attention_layer.cc:68-110).
+  const int64_t rotary_dim = static_cast<int64_t>(model_->attribute(scope + "/rotary_dim", -1));
+  if (rotary_dim >= 0) {
+    a.rotary = true;
+    a.rotary_dim = rotary_dim;
+    a.rotary_interleave = model_->flag(scope + "/rotary_interleave", true);
+    a.rotary_base = static_cast<float>(model_->attribute(scope + "/rotary_base", 10000.0));
+    a.rotary_scaling_type = static_cast<int>(model_->attribute(scope + "/rotary_scaling_type", -1));
+    a.rotary_scaling_factor =
+        static_cast<float>(model_->attribute(scope + "/rotary_scaling_factor", 1.0));
+    a.rotary_low_freq_factor =
+        static_cast<float>(model_->attribute(scope + "/rotary_low_freq_factor", 1.0));
+    a.rotary_high_freq_factor =
+        static_cast<float>(model_->attribute(scope + "/rotary_high_freq_factor", 4.0));
+    a.original_max_position_embeddings = static_cast<int64_t>(
+        model_->attribute(scope + "/original_max_position_embeddings", 0));
+    a.max_position_embeddings =
+        static_cast<int64_t>(model_->attribute(scope + "/max_position_embeddings", 0));
+    if (a.rotary_scaling_type == 1)
+      throw std::runtime_error("Su rotary scaling is not supported by this backend yet");
+  }
+  if (a.dhead % 4 != 0 || a.dhead > 512)
+    throw std::runtime_error("head dimension must be a multiple of 4 and <= 512");
+  return a;
+}
+
+FfnW Engine::load_ffn(const std::string& scope, int activation) {
+  FfnW f;
+  f.ln = load_norm(scope + "/layer_norm");
+  f.l0 = load_dense(scope + "/linear_0", true);
+  f.l0_noact = load_dense(scope + "/linear_0_noact", false);
+  f.l1 = load_dense(scope + "/linear_1", true);
+  f.activation = activation;
+  return f;
+}
+
+void Engine::load_stack(const std::string& scope, bool decoder, StackW& out) {
+  const ModelFile& m = *model_;
+  // Spec revisions < 5 keep these attributes at the model root
+  // (TransformerModel::initialize, src/models/transformer.cc:62-81).
+  auto attr = [&](const std::string& name, double def) {
+    if (m.has(scope + "/" + name)) return m.attribute(scope + "/" + name, def);
+    return m.attribute(name, def);
+  };
+  int64_t default_heads = 8;
+  if (m.spec == "TransformerBig") default_heads = 16;
+  out.num_heads = static_cast<int64_t>(attr("num_heads", double(default_heads)));
+  out.pre_norm = attr("pre_norm", 1) != 0;
+  const int activation = static_cast<int>(attr("activation", 0));
+
+  for (const char* unsupported : {"/project_in/weight", "/project_out/weight", "/scale_outputs"})
+    if (m.has(scope + unsupported))
+      throw std::runtime_error(scope + unsupported + " is not supported by this backend yet");
+  if (m.flag(scope + "/alibi", false))
+    throw std::runtime_error("ALiBi models are not supported by this backend yet");
+  if (m.attribute(scope + "/sliding_window", 0) != 0)
+    throw std::runtime_error("sliding window models are not supported by this backend yet");
+  if (m.attribute(scope + "/final_logit_softcapping", 0) != 0)
+    throw std::runtime_error("final logit soft-capping is not supported by this backend yet");
+  if (m.flag(scope + "/start_from_zero_embedding", false))
+    throw std::runtime_error("start_from_zero_embedding is not supported by this backend yet");
+
+  // Embeddings (layers::Embeddings / ParallelEmbeddings, src/layers/common.cc:49-148).
+  std::string emb_scope = scope + "/embeddings";
+  if (!m.has(emb_scope + "/weight")) {
+    emb_scope = scope + "/embeddings_0";
+    if (m.has(scope + "/embeddings_1/weight"))
+      throw std::runtime_error("multiple input features are not supported by this backend yet");
+  }
+  const Variable& ew = m.get(emb_scope + "/weight");
+  out.emb.vocab = ew.shape.at(0);
+  out.emb.depth = ew.shape.at(1);
+  out.d_model = out.emb.depth;
+  {
+    const Variable* es = m.find(emb_scope + "/weight_scale");
+    const bool want_int8 = (compute_type_ == ComputeType::kInt8Float32);
+    if (want_int8 && ew.dtype == kI8 && es && es->size() == out.emb.vocab) {
+      out.emb.is_int8 = true;
+      out.emb.table = upload(ew.data.data(), ew.data.size());
+      out.emb.scale = upload_floats(es->to_float());
+    } else {
+      std::vector<float> wf = ew.to_float();
+      if (ew.dtype == kI8 || ew.dtype == kI16) {
+        std::vector<float> s = es ? es->to_float() : std::vector<float>{1000.f};
+        for (int64_t i = 0; i < out.emb.vocab; ++i)
+          for (int64_t j = 0; j < out.emb.depth; ++j)
+            wf[i * out.emb.depth + j] = wf[i * out.emb.depth + j] / (s.size() == 1 ? s[0] : s[i]);
+      }
+      if (want_int8) {
+        std::vector<int8_t> q;
+        std::vector<float> s;
+        host_quantize_rows(wf, out.emb.vocab, out.emb.depth, round_before_cast_, q, s);
+        out.emb.is_int8 = true;
+        out.emb.table = upload(q.data(), q.size());
+        out.emb.scale = upload_floats(s);
+      } else {
+        out.emb.table = upload_floats(wf);
+      }
+    }
+  }
+
+  // build_embeddings_scale (src/layers/transformer.cc:378-399).
+  {
+    const Variable* scale = m.find(scope + "/scale_embeddings");
+    if (!scale) scale = m.find(scope + "/embeddings/multiply_by_sqrt_depth");
+    if (!scale || (scale->dtype == kI8 && scale->as_number() != 0)) {
+      out.scale_embeddings = true;
+      out.embeddings_scale = std::sqrt(static_cast<float>(out.emb.depth));
+    } else if (scale->dtype != kI8 && scale->as_number() != 1.0) {
+      out.scale_embeddings = true;
+      out.embeddings_scale = static_cast<float>(scale->as_number());
+    }
+  }
+
+  out.layernorm_embedding = load_norm(scope + "/layernorm_embedding");
+  out.output_norm = load_norm(scope + "/layer_norm");
+
+  for (int64_t l = 0;; ++l) {
+    const std::string ls = scope + "/layer_" + std::to_string(l);
+    if (!m.has(ls + "/self_attention/linear_0/weight")) break;
+    for (const char* unsupported : {"/shared_layer_norm/gamma", "/input_layer_norm/gamma",
+                                    "/post_attention_layer_norm/gamma",
+                                    "/pre_feedforward_layer_norm/gamma",
+                                    "/post_feedforward_layer_norm/gamma"})
+      if (m.has(ls + unsupported))
+        throw std::runtime_error("layer variant with " + ls + unsupported +
+                                 " is not supported by this backend yet");
+    LayerW layer;
+    layer.self = load_attention(ls + "/self_attention", true, out.num_heads);
+    if (decoder && m.has(ls + "/attention/linear_0/weight")) {
+      layer.has_cross = true;
+      layer.cross = load_attention(ls + "/attention", false, out.num_heads);
+    }
+    layer.ffn = load_ffn(ls + "/ffn", activation);
+    out.layers.emplace_back(std::move(layer));
+  }
+  if (out.layers.empty()) throw std::runtime_error("no layers found under " + scope);
+
+  // Position encodings (build_position_encoder, src/layers/transformer.cc:366-376): learned table
+  // if present, else sinusoidal -- unless the attention layers carry their own (rotary).
+  if (!out.layers.front().self.rotary) {
+    if (const Variable* pe = m.find(scope + "/position_encodings/encodings")) {
+      out.position_table = upload_floats(pe->to_float());
+      out.num_positions = pe->shape.at(0);
+    } else {
+      out.sinusoidal_positions = true;
+    }
+  }
+
+  if (decoder) out.projection = load_dense(scope + "/projection", true);
+}
+
+void Engine::load_weights() {
+  if (has_encoder_) load_stack("encoder", false, enc_);
+  load_stack("decoder", true, dec_);
+  if (has_encoder_ != dec_.layers.front().has_cross)
+    throw std::runtime_error("inconsistent model: encoder presence and cross-attention differ");
+}
+
+// generate_sinusoidal_position_encoding (src/layers/common.cc:204-229).
+const float* Engine::sinusoidal_table(int64_t positions, int64_t depth) {
+  if (sin_pos_table_ && positions <= sin_pos_positions_ && depth == sin_pos_depth_)
+    return sin_pos_table_;
+  positions = std::max<int64_t>(positions, 500);
+  const int64_t half = depth / 2;
+  const float log_timescale_increment = std::log(10000.f) / static_cast<float>(half - 1);
+  std::vector<float> timescales(half);
+  for (int64_t i = 0; i < half; ++i)
+    timescales[i] = std::exp(-log_timescale_increment * static_cast<float>(i));
+  std::vector<float> table(positions * depth);
+  for (int64_t p = 0; p < positions; ++p) {
+    for (int64_t j = 0; j < half; ++j) {
+      const float scaled = static_cast<float>(p + 1) * timescales[j];
+      table[p * depth + j] = std::sin(scaled);
+      table[p * depth + half + j] = std::cos(scaled);
+    }
+  }
+  if (sin_pos_table_) {
+    CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+    device_free(sin_pos_table_);
+  }
+  sin_pos_table_ = static_cast<float*>(device_malloc(table.size() * sizeof(float)));
+  CT2X_HIP_CHECK(hipMemcpy(sin_pos_table_, table.data(), table.size() * sizeof(float),
+                           hipMemcpyHostToDevice));
+  sin_pos_positions_ = positions;
+  sin_pos_depth_ = depth;
+  return sin_pos_table_;
+}
+
+// RotaryEmbeddings::initialize (src/layers/attention_layer.cc:252-343), default / linear /
+// Llama-3 scaling. Tables are [positions, dim].
+void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_out,
+                           const float** cos_out) {
+  const int64_t dim = a.rotary_dim == 0 ? a.dhead : a.rotary_dim;
+  if (rope_sin_ && positions <= rope_positions_) {
+    *sin_out = rope_sin_;
+    *cos_out = rope_cos_;
+    return;
+  }
+  positions = std::max<int64_t>(positions, 2048);
+  const int64_t half = dim / 2;
+  std::vector<float> inv_freq(half);
+  for (int64_t i = 0; i < half; ++i)
+    inv_freq[i] = 1.f / std::pow(a.rotary_base, static_cast<float>(i * 2) / static_cast<float>(dim));
+  if (a.rotary_scaling_type == 2) {  // Llama3
+    std::vector<float> new_freqs = inv_freq;
+    const float factor = a.rotary_scaling_factor;
+    const float old_context_len = static_cast<float>(a.original_max_position_embeddings);
+    const float low_freq_wavelen = old_context_len / a.rotary_low_freq_factor;
+    const float high_freq_wavelen = old_context_len / a.rotary_high_freq_factor;
+    for (int64_t i = 0; i < half; ++i) {
+      const float wavelen = 2.0f * static_cast<float>(M_PI) / inv_freq[i];
+      if (wavelen < high_freq_wavelen) {
+      } else if (wavelen > low_freq_wavelen) {
+        new_freqs[i] /= factor;
+      } else {
+        const float smooth = (old_context_len / wavelen - a.rotary_low_freq_factor) /
+                             (a.rotary_high_freq_factor - a.rotary_low_freq_factor);
+        new_freqs[i] = ((1 - smooth) * inv_freq[i] / factor + smooth * inv_freq[i]);
+      }
+    }
+    inv_freq = new_freqs;
+  }
+  std::vector<float> s(positions * dim), c(positions * dim);
+  for (int64_t p = 0; p < positions; ++p) {
+    const float t = (a.rotary_scaling_type == 0) ? static_cast<float>(p) / a.rotary_scaling_factor
+                                                 : static_cast<float>(p);
+    for (int64_t i = 0; i < half; ++i) {
+      const float f = t * inv_freq[i];
+      if (a.rotary_interleave) {
+        s[p * dim + 2 * i] = s[p * dim + 2 * i + 1] = std::sin(f);
+        c[p * dim + 2 * i] = c[p * dim + 2 * i + 1] = std::cos(f);
+      } else {
+        s[p * dim + i] = s[p * dim + half + i] = std::sin(f);
+        c[p * dim + i] = c[p * dim + half + i] = std::cos(f);
+      }
+    }
+  }
+  if (rope_sin_) {
+    CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+    device_free(rope_sin_);
+    device_free(rope_cos_);
+  }
+  rope_sin_ = static_cast<float*>(device_malloc(s.size() * sizeof(float)));
+  rope_cos_ = static_cast<float*>(device_malloc(c.size() * sizeof(float)));
+  CT2X_HIP_CHECK(hipMemcpy(rope_sin_, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice));
+  CT2X_HIP_CHECK(hipMemcpy(rope_cos_, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice));
+  rope_positions_ = positions;
+  *sin_out = rope_sin_;
+  *cos_out = rope_cos_;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Building blocks
+// ---------------------------------------------------------------------------------------------
+
+void Engine::quant(const float* x, int64_t rows, int64_t depth, int8_t* q, float* s) {
+  launch_quantize_s8(x, rows, depth, quant_mode_, q, s, stream_);
+  count_kernel();
+}
+
+void Engine::norm(const NormW& w, const float* x, int64_t rows, int64_t depth, float* y) {
+  launch_norm(x, w.gamma, w.beta, rows, depth, w.eps, w.use_residual, quant_mode_, y,
+              nullptr, nullptr, stream_);
+  count_kernel();
+}
+
+void Engine::norm_quant(const NormW& w, const float* x, int64_t rows, int64_t depth, float* y,
+                        int8_t* q, float* s) {
+  launch_norm(x, w.gamma, w.beta, rows, depth, w.eps, w.use_residual, quant_mode_, y, q, s,
+              stream_);
+  count_kernel();
+}
+
+// layers::Dense::operator() (src/layers/common.cc:339-442).
+void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t m, int act,
+                   const float* residual, float* y, DecodeState* ws) {
+  if (w.quantized) {
+    QuantIn local;
+    if (!qin) {
+      quant(x, m, w.k, ws->qbuf, ws->qscale);
+      local.q = ws->qbuf;
+      local.s = ws->qscale;
+      qin = &local;
+    }
+    GemmS8Epilogue ep;
+    ep.mode = 1;
+    ep.a_scale = qin->s;
+    ep.w_scale = w.wscale;
+    ep.bias = w.bias;
+    ep.residual = residual;
+    ep.y = y;
+    ep.act = act;
+    ep.ldy = w.n;
+    launch_gemm_s8(qin->q, w.wq, m, w.n, w.k, ep, stream_);
+    count_kernel();
+  } else {
+    launch_gemm_f32(x, w.wf, 1, m, w.n, w.k, true, 1.f, 0, 0, 0, w.bias, residual, act, y,
+                    stream_);
+    count_kernel();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Session
+// ---------------------------------------------------------------------------------------------
+
+DecodeState::~DecodeState() {
+  if (engine) {
+    (void)hipSetDevice(engine->device_index());
+    (void)hipStreamSynchronize(engine->stream());
+  }
+  for (int i = 0; i < 2; ++i)
+    if (graph_exec[i]) (void)hipGraphExecDestroy(graph_exec[i]);
+  if (graph) (void)hipGraphDestroy(graph);
+  for (void* p : owned) {
+    try { device_free(p); } catch (...) {}
+  }
+}
+
+namespace {
+
+template <typename T>
+T* alloc(DecodeState& st, int64_t count) {
+  void* p = device_malloc(static_cast<size_t>(std::max<int64_t>(count, 1)) * sizeof(T));
+  st.owned.push_back(p);
+  return static_cast<T*>(p);
+}
+
+}  // namespace
+
+std::unique_ptr<DecodeState> Engine::start_decoder_only(int64_t batch, int64_t beam,
+                                                        int64_t t_max) {
+  return start(nullptr, nullptr, batch, 0, beam, t_max);
+}
+
+std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t* src_lengths,
+                                           int64_t batch, int64_t s_max, int64_t beam,
+                                           int64_t t_max) {
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  auto st = std::make_unique<DecodeState>();
+  st->engine = this;
+  st->batch = batch;
+  st->beam = beam;
+  st->rows = batch * beam;
+  st->t_max = t_max;
+  st->s_max = s_max;
+  const int64_t rows = st->rows, d = dec_.d_model, V = dec_.projection.n;
+  CT2X_CHECK(t_max + 1 <= 16384 && s_max + 1 <= 16384,
+             "sequences longer than 16383 positions are not supported by this backend yet");
+
+  int64_t ffn = 0, qkv_dim = 0;
+  for (const auto& l : dec_.layers) {
+    ffn = std::max(ffn, l.ffn.l0.n);
+    qkv_dim = std::max(qkv_dim, l.self.lin[0].n);
+  }
+  // Workspace sized for the larger of the decode rows and the encoder rows.
+  const int64_t enc_rows = has_encoder_ ? batch * s_max : 0;
+  int64_t enc_ffn = 0, enc_qkv = 0;
+  for (const auto& l : enc_.layers) {
+    enc_ffn = std::max(enc_ffn, l.ffn.l0.n);
+    enc_qkv = std::max(enc_qkv, l.self.lin[0].n);
+  }
+  const int64_t wrows = std::max(rows, enc_rows);
+  const int64_t wffn = std::max(ffn, enc_ffn);
+  const int64_t wqkv = std::max(qkv_dim, enc_qkv);
+  st->x0 = alloc<float>(*st, wrows * d);
+  st->x1 = alloc<float>(*st, wrows * d);
+  st->qkv = alloc<float>(*st, wrows * wqkv);
+  st->ctx = alloc<float>(*st, wrows * d);
+  st->inner = alloc<float>(*st, wrows * wffn);
+  st->inner2 = alloc<float>(*st, wrows * wffn);
+  st->qbuf = alloc<int8_t>(*st, wrows * std::max(d, wffn));
+  st->qscale = alloc<float>(*st, wrows);
+  st->logits = alloc<float>(*st, rows * V);
+  st->d_ids = alloc<int32_t>(*st, rows);
+  st->d_step = alloc<int32_t>(*st, 1);
+  st->hist_ids = alloc<int32_t>(*st, (t_max + 1) * rows);
+  st->hist_scores = alloc<float>(*st, (t_max + 1) * rows);
+  CT2X_HIP_CHECK(hipMemsetAsync(st->d_step, 0, sizeof(int32_t), stream_));
+  if (beam > 1) {
+    st->logprobs = alloc<float>(*st, rows * V);
+    st->beam_scores = alloc<float>(*st, rows);
+    st->topk_scores = alloc<float>(*st, batch * 2 * beam);
+    st->topk_ids = alloc<int32_t>(*st, batch * 2 * beam);
+    st->d_parents = alloc<int32_t>(*st, rows);
+  }
+
+  const int n_layers = static_cast<int>(dec_.layers.size());
+  const int n_sets = beam > 1 ? 2 : 1;
+  for (int s = 0; s < n_sets; ++s) {
+    for (int l = 0; l < n_layers; ++l) {
+      const AttnW& a = dec_.layers[l].self;
+      const int64_t sz = rows * a.heads_kv * t_max * a.dhead;
+      st->self_k[s].push_back(alloc<float>(*st, sz));
+      st->self_v[s].push_back(alloc<float>(*st, sz));
+    }
+  }
+  if (beam > 1) {
+    // Device tables of cache base pointers for the one-launch beam gather, both directions.
+    std::vector<const float*> src(2 * n_layers), src_alt(2 * n_layers);
+    std::vector<float*> dst(2 * n_layers), dst_alt(2 * n_layers);
+    for (int l = 0; l < n_layers; ++l) {
+      src[2 * l] = st->self_k[0][l];
+      src[2 * l + 1] = st->self_v[0][l];
+      dst[2 * l] = st->self_k[1][l];
+      dst[2 * l + 1] = st->self_v[1][l];
+      src_alt[2 * l] = st->self_k[1][l];
+      src_alt[2 * l + 1] = st->self_v[1][l];
+      dst_alt[2 * l] = st->self_k[0][l];
+      dst_alt[2 * l + 1] = st->self_v[0][l];
+    }
+    st->d_cache_src = alloc<const float*>(*st, 2 * n_layers);
+    st->d_cache_dst = alloc<float*>(*st, 2 * n_layers);
+    st->d_cache_src_alt = alloc<const float*>(*st, 2 * n_layers);
+    st->d_cache_dst_alt = alloc<float*>(*st, 2 * n_layers);
+    const size_t bytes = sizeof(void*) * 2 * n_layers;
+    CT2X_HIP_CHECK(hipMemcpy(st->d_cache_src, src.data(), bytes, hipMemcpyHostToDevice));
+    CT2X_HIP_CHECK(hipMemcpy(st->d_cache_dst, dst.data(), bytes, hipMemcpyHostToDevice));
+    CT2X_HIP_CHECK(hipMemcpy(st->d_cache_src_alt, src_alt.data(), bytes, hipMemcpyHostToDevice));
+    CT2X_HIP_CHECK(hipMemcpy(st->d_cache_dst_alt, dst_alt.data(), bytes, hipMemcpyHostToDevice));
+  }
+
+  if (has_encoder_) {
+    st->mem_lengths = alloc<int32_t>(*st, batch);
+    for (int l = 0; l < n_layers; ++l) {
+      const AttnW& a = dec_.layers[l].cross;
+      st->cross_kv.push_back(alloc<float>(*st, batch * s_max * a.lin[1].n));
+    }
+    encode(*st, src_ids, src_lengths);
+  }
+  return st;
+}
+
+// TransformerEncoder::operator() (src/layers/transformer.cc:427-471) on padded rows followed by
+// the cross-attention K/V projection of every decoder layer (process_cross_attention,
+// src/layers/attention.cc:371-440), which the reference runs lazily at decoding step 0.
+// Padded positions are computed but never observed: every op on this path is row-wise and the
+// attention kernels mask keys beyond lengths[b].
+void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_lengths) {
+  const int64_t B = st.batch, S = st.s_max, d = enc_.d_model, rows = B * S;
+  int32_t* d_src = alloc<int32_t>(st, rows);
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_src, src_ids, sizeof(int32_t) * rows, hipMemcpyHostToDevice,
+                                stream_));
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.mem_lengths, src_lengths, sizeof(int32_t) * B,
+                                hipMemcpyHostToDevice, stream_));
+  const float* pos = enc_.position_table;
+  if (enc_.sinusoidal_positions) pos = sinusoidal_table(S, d);
+  if (enc_.position_table && S > enc_.num_positions)
+    throw std::runtime_error("No position encodings are defined for positions >= " +
+                             std::to_string(enc_.num_positions) + ", but got position " +
+                             std::to_string(S - 1));
+  float* x = st.x0;
+  float* y = st.x1;
+  launch_embed(enc_.emb.table, enc_.emb.is_int8, enc_.emb.scale, d_src, rows, d,
+               enc_.embeddings_scale, enc_.scale_embeddings, pos, S, 0, nullptr, x, stream_);
+  if (enc_.layernorm_embedding.present) norm(enc_.layernorm_embedding, x, rows, d, x);
+
+  for (const LayerW& layer : enc_.layers) {
+    const AttnW& a = layer.self;
+    // --- self attention (MultiHeadAttention::operator(), src/layers/attention.cc:442-615)
+    QuantIn qin;
+    const float* attn_in = x;
+    const bool q8 = a.lin[0].quantized;
+    if (a.ln.present && enc_.pre_norm) {
+      if (q8) {
+        norm_quant(a.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
+        qin.q = st.qbuf;
+        qin.s = st.qscale;
+      } else {
+        norm(a.ln, x, rows, d, st.ctx);
+        attn_in = st.ctx;
+      }
+    }
+    dense(a.lin[0], attn_in, qin.q ? &qin : nullptr, rows, -1, nullptr, st.qkv, &st);
+    const int64_t qdim = a.heads * a.dhead, kvdim = a.heads_kv * a.dhead;
+    const int64_t ld = qdim + 2 * kvdim;
+    AttnFullParams f;
+    f.q = st.qkv;
+    f.k = st.qkv + qdim;
+    f.v = st.qkv + qdim + kvdim;
+    f.q_batch_stride = S * ld;
+    f.q_time_stride = ld;
+    f.k_batch_stride = S * ld;
+    f.k_time_stride = ld;
+    f.k_head_stride = a.dhead;
+    f.v_batch_stride = S * ld;
+    f.v_time_stride = ld;
+    f.v_head_stride = a.dhead;
+    f.lengths = st.mem_lengths;
+    f.batch = B;
+    f.tq = S;
+    f.tk = S;
+    f.heads = a.heads;
+    f.heads_kv = a.heads_kv;
+    f.dhead = a.dhead;
+    f.causal = false;
+    f.scale = a.queries_scale;
+    f.out = st.ctx;
+    launch_attention_full(f, stream_);
+    count_kernel();
+    dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+    if (a.ln.present && !enc_.pre_norm) norm(a.ln, y, rows, d, y);
+    std::swap(x, y);
+
+    // --- feed forward (FeedForwardNetwork::operator(), src/layers/transformer.cc:21-51)
+    const FfnW& ffn = layer.ffn;
+    QuantIn fq;
+    const float* ffn_in = x;
+    if (ffn.ln.present && enc_.pre_norm) {
+      if (ffn.l0.quantized) {
+        norm_quant(ffn.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
+        fq.q = st.qbuf;
+        fq.s = st.qscale;
+      } else {
+        norm(ffn.ln, x, rows, d, st.ctx);
+        ffn_in = st.ctx;
+      }
+    } else if (ffn.l0.quantized && ffn.l0_noact.present) {
+      quant(x, rows, d, st.qbuf, st.qscale);
+      fq.q = st.qbuf;
+      fq.s = st.qscale;
+    }
+    dense(ffn.l0, ffn_in, fq.q ? &fq : nullptr, rows, ffn.activation, nullptr, st.inner, &st);
+    if (ffn.l0_noact.present) {
+      dense(ffn.l0_noact, ffn_in, fq.q ? &fq : nullptr, rows, -1, nullptr, st.inner2, &st);
+      launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, stream_);
+      count_kernel();
+    }
+    dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
+    if (ffn.ln.present && !enc_.pre_norm) norm(ffn.ln, y, rows, d, y);
+    std::swap(x, y);
+  }
+  if (enc_.output_norm.present) norm(enc_.output_norm, x, rows, d, x);
+
+  // Cross-attention memory projections: linear_1(memory) -> [B*S, 2*kv_dim], kept in the GEMM
+  // output layout (the attention kernel takes strides; no split_heads transpose).
+  bool quantized_once = false;
+  for (size_t l = 0; l < dec_.layers.size(); ++l) {
+    const AttnW& a = dec_.layers[l].cross;
+    QuantIn mq;
+    if (a.lin[1].quantized) {
+      if (!quantized_once) {  // the same memory feeds every layer: quantise it once
+        quant(x, rows, d, st.qbuf, st.qscale);
+        quantized_once = true;
+      }
+      mq.q = st.qbuf;
+      mq.s = st.qscale;
+    }
+    dense(a.lin[1], x, mq.q ? &mq : nullptr, rows, -1, nullptr, st.cross_kv[l], &st);
+  }
+  check_last_launch("encode");
+}
+
+// TransformerDecoder::decode for one step (src/layers/transformer.cc:621-871) with
+// TransformerDecoderLayer::operator() (standard pre/post-norm arm, :334-365).
+void Engine::launch_step(DecodeState& st) {
+  const int64_t rows = st.rows, d = dec_.d_model;
+  const float* pos = dec_.position_table;
+  if (dec_.sinusoidal_positions) pos = sinusoidal_table(st.t_max, d);
+  float* x = st.x0;
+  float* y = st.x1;
+  launch_embed(dec_.emb.table, dec_.emb.is_int8, dec_.emb.scale, st.d_ids, rows, d,
+               dec_.embeddings_scale, dec_.scale_embeddings, pos, 1, 0, st.d_step, x, stream_);
+  count_kernel();
+  if (dec_.layernorm_embedding.present) norm(dec_.layernorm_embedding, x, rows, d, x);
+
+  for (size_t l = 0; l < dec_.layers.size(); ++l) {
+    const LayerW& layer = dec_.layers[l];
+    // ---- masked self-attention -----------------------------------------------------------
+    {
+      const AttnW& a = layer.self;
+      QuantIn qin;
+      const float* attn_in = x;
+      if (a.ln.present && dec_.pre_norm) {
+        if (a.lin[0].quantized) {
+          norm_quant(a.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
+          qin.q = st.qbuf;
+          qin.s = st.qscale;
+        } else {
+          norm(a.ln, x, rows, d, st.ctx);
+          attn_in = st.ctx;
+        }
+      }
+      dense(a.lin[0], attn_in, qin.q ? &qin : nullptr, rows, -1, nullptr, st.qkv, &st);
+      const int64_t qdim = a.heads * a.dhead, kvdim = a.heads_kv * a.dhead;
+      const int64_t ld = qdim + 2 * kvdim;
+      AttnDecodeParams p;
+      p.q = st.qkv;
+      p.q_row_stride = ld;
+      p.k_new = st.qkv + qdim;
+      p.v_new = st.qkv + qdim + kvdim;
+      p.new_row_stride = ld;
+      p.k_cache = st.self_k[st.cur][l];
+      p.v_cache = st.self_v[st.cur][l];
+      p.kv_row_stride = a.heads_kv * st.t_max * a.dhead;
+      p.kv_head_stride = st.t_max * a.dhead;
+      p.kv_time_stride = a.dhead;
+      p.step_ptr = st.d_step;
+      p.rows = rows;
+      p.heads = a.heads;
+      p.heads_kv = a.heads_kv;
+      p.dhead = a.dhead;
+      p.kv_group = 1;
+      p.t_max = st.t_max;
+      p.scale = a.queries_scale;
+      if (a.rotary) {
+        rotary_tables(a, st.t_max + 1, &p.rope_sin, &p.rope_cos);
+        p.rot_dim = a.rotary_dim == 0 ? a.dhead : a.rotary_dim;
+        p.rope_interleave = a.rotary_interleave;
+      }
+      p.out = st.ctx;
+      launch_attention_decode(p, stream_);
+      count_kernel();
+      dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+      if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
+      std::swap(x, y);
+    }
+    // ---- encoder-decoder attention -------------------------------------------------------
+    if (layer.has_cross) {
+      const AttnW& a = layer.cross;
+      QuantIn qin;
+      const float* attn_in = x;
+      if (a.ln.present && dec_.pre_norm) {
+        if (a.lin[0].quantized) {
+          norm_quant(a.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
+          qin.q = st.qbuf;
+          qin.s = st.qscale;
+        } else {
+          norm(a.ln, x, rows, d, st.ctx);
+          attn_in = st.ctx;
+        }
+      }
+      dense(a.lin[0], attn_in, qin.q ? &qin : nullptr, rows, -1, nullptr, st.qkv, &st);
+      const int64_t kvdim = a.heads_kv * a.dhead;
+      AttnDecodeParams p;
+      p.q = st.qkv;
+      p.q_row_stride = a.heads * a.dhead;
+      p.k_cache = st.cross_kv[l];
+      p.v_cache = st.cross_kv[l] + kvdim;
+      p.kv_row_stride = st.s_max * 2 * kvdim;
+      p.kv_head_stride = a.dhead;
+      p.kv_time_stride = 2 * kvdim;
+      p.lengths = st.mem_lengths;
+      p.rows = rows;
+      p.heads = a.heads;
+      p.heads_kv = a.heads_kv;
+      p.dhead = a.dhead;
+      p.kv_group = st.beam;
+      p.t_max = st.s_max;
+      p.scale = a.queries_scale;
+      p.out = st.ctx;
+      launch_attention_decode(p, stream_);
+      count_kernel();
+      dense(a.lin[2], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+      if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
+      std::swap(x, y);
+    }
+    // ---- feed forward ----------------------------------------------------------------------
+    {
+      const FfnW& ffn = layer.ffn;
+      QuantIn fq;
+      const float* ffn_in = x;
+      if (ffn.ln.present && dec_.pre_norm) {
+        if (ffn.l0.quantized) {
+          norm_quant(ffn.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
+          fq.q = st.qbuf;
+          fq.s = st.qscale;
+        } else {
+          norm(ffn.ln, x, rows, d, st.ctx);
+          ffn_in = st.ctx;
+        }
+      } else if (ffn.l0.quantized && ffn.l0_noact.present) {
+        quant(x, rows, d, st.qbuf, st.qscale);
+        fq.q = st.qbuf;
+        fq.s = st.qscale;
+      }
+      dense(ffn.l0, ffn_in, fq.q ? &fq : nullptr, rows, ffn.activation, nullptr, st.inner, &st);
+      if (ffn.l0_noact.present) {
+        dense(ffn.l0_noact, ffn_in, fq.q ? &fq : nullptr, rows, -1, nullptr, st.inner2, &st);
+        launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, stream_);
+        count_kernel();
+      }
+      dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
+      if (ffn.ln.present && !dec_.pre_norm) norm(ffn.ln, y, rows, d, y);
+      std::swap(x, y);
+    }
+  }
+
+  // Final norm + vocabulary projection (transformer.cc:842-855).
+  QuantIn pq;
+  const float* proj_in = x;
+  if (dec_.output_norm.present) {
+    if (dec_.projection.quantized) {
+      norm_quant(dec_.output_norm, x, rows, d, nullptr, st.qbuf, st.qscale);
+      pq.q = st.qbuf;
+      pq.s = st.qscale;
+    } else {
+      norm(dec_.output_norm, x, rows, d, st.ctx);
+      proj_in = st.ctx;
+    }
+  }
+  dense(dec_.projection, proj_in, pq.q ? &pq : nullptr, rows, -1, nullptr, st.logits, &st);
+
+  if (st.fuse_greedy) {
+    launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
+                         st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores, stream_);
+    count_kernel();
+    launch_advance_step(st.d_step, stream_);
+    count_kernel();
+  }
+}
+
+void Engine::step(DecodeState& st, bool graph) {
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  // Make sure lazily built tables exist before any capture (no allocation inside a capture).
+  if (dec_.sinusoidal_positions) (void)sinusoidal_table(st.t_max, dec_.d_model);
+  if (dec_.layers.front().self.rotary) {
+    const float *s, *c;
+    rotary_tables(dec_.layers.front().self, st.t_max + 1, &s, &c);
+  }
+  if (!graph) {
+    const int64_t before = launch_counter_;
+    launch_step(st);
+    kernels_per_step_ = launch_counter_ - before;
+    check_last_launch("decoder step");
+    return;
+  }
+  const int parity = st.cur;
+  if (!st.graph_ready[parity]) {
+    hipGraph_t g = nullptr;
+    const int64_t before = launch_counter_;
+    CT2X_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    try {
+      launch_step(st);
+    } catch (...) {
+      hipGraph_t dead = nullptr;
+      (void)hipStreamEndCapture(stream_, &dead);
+      if (dead) (void)hipGraphDestroy(dead);
+      throw;
+    }
+    CT2X_HIP_CHECK(hipStreamEndCapture(stream_, &g));
+    kernels_per_step_ = launch_counter_ - before;
+    CT2X_HIP_CHECK(hipGraphInstantiate(&st.graph_exec[parity], g, nullptr, nullptr, 0));
+    CT2X_HIP_CHECK(hipGraphDestroy(g));
+    st.graph_ready[parity] = true;
+  }
+  CT2X_HIP_CHECK(hipGraphLaunch(st.graph_exec[parity], stream_));
+}
+
+void Engine::sample_greedy(DecodeState& st, int32_t eos_id, int32_t min_length,
+                           bool with_scores) {
+  launch_greedy_sample(st.logits, st.rows, dec_.projection.n, eos_id, min_length, with_scores,
+                       st.d_step, st.d_ids, st.hist_ids, st.hist_scores, stream_);
+  launch_advance_step(st.d_step, stream_);
+  check_last_launch("greedy sample");
+}
+
+void Engine::advance_step(DecodeState& st) {
+  launch_advance_step(st.d_step, stream_);
+}
+
+void Engine::beam_candidates(DecodeState& st, int32_t eos_id, int32_t min_length,
+                             float* h_scores, int32_t* h_ids) {
+  const int64_t V = dec_.projection.n;
+  launch_beam_logprobs(st.logits, st.beam_scores, st.rows, V, eos_id, min_length, st.d_step,
+                       st.logprobs, stream_);
+  const int64_t k = 2 * st.beam;
+  launch_topk(st.logprobs, st.batch, st.beam * V, k, st.topk_scores, st.topk_ids, stream_);
+  check_last_launch("beam candidates");
+  CT2X_HIP_CHECK(hipMemcpyAsync(h_scores, st.topk_scores, sizeof(float) * st.batch * k,
+                                hipMemcpyDeviceToHost, stream_));
+  CT2X_HIP_CHECK(hipMemcpyAsync(h_ids, st.topk_ids, sizeof(int32_t) * st.batch * k,
+                                hipMemcpyDeviceToHost, stream_));
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::beam_update(DecodeState& st, const int32_t* h_next_ids, const int32_t* h_parents,
+                         const float* h_scores) {
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.d_ids, h_next_ids, sizeof(int32_t) * st.rows,
+                                hipMemcpyHostToDevice, stream_));
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.d_parents, h_parents, sizeof(int32_t) * st.rows,
+                                hipMemcpyHostToDevice, stream_));
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.beam_scores, h_scores, sizeof(float) * st.rows,
+                                hipMemcpyHostToDevice, stream_));
+  // Positions [0, step] are live at this point (the step counter has not advanced yet).
+  launch_advance_step(st.d_step, stream_);
+  const AttnW& a = dec_.layers.front().self;
+  const int n_tensors = static_cast<int>(2 * dec_.layers.size());
+  launch_cache_gather(st.cur == 0 ? st.d_cache_src : st.d_cache_src_alt,
+                      st.cur == 0 ? st.d_cache_dst : st.d_cache_dst_alt, n_tensors, st.d_parents,
+                      st.rows, a.heads_kv, st.t_max, a.dhead, st.d_step, 0, stream_);
+  st.cur ^= 1;
+  check_last_launch("beam update");
+}
+
+void Engine::set_beam_scores(DecodeState& st, const float* h_scores) {
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.beam_scores, h_scores, sizeof(float) * st.rows,
+                                hipMemcpyHostToDevice, stream_));
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::read_history(DecodeState& st, int64_t first, int64_t count, int32_t* h_ids,
+                          float* h_scores) {
+  if (count <= 0) return;
+  CT2X_HIP_CHECK(hipMemcpyAsync(h_ids, st.hist_ids + first * st.rows,
+                                sizeof(int32_t) * count * st.rows, hipMemcpyDeviceToHost,
+                                stream_));
+  if (h_scores)
+    CT2X_HIP_CHECK(hipMemcpyAsync(h_scores, st.hist_scores + first * st.rows,
+                                  sizeof(float) * count * st.rows, hipMemcpyDeviceToHost,
+                                  stream_));
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::copy_logits_to_host(DecodeState& st, float* h_logits) {
+  CT2X_HIP_CHECK(hipMemcpyAsync(h_logits, st.logits, sizeof(float) * st.rows * dec_.projection.n,
+                                hipMemcpyDeviceToHost, stream_));
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::set_ids(DecodeState& st, const int32_t* h_ids) {
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.d_ids, h_ids, sizeof(int32_t) * st.rows,
+                                hipMemcpyHostToDevice, stream_));
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));  // h_ids may be a temporary
+}
+
+void Engine::set_step(DecodeState& st, int32_t step) {
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.d_step, &step, sizeof(int32_t), hipMemcpyHostToDevice,
+                                stream_));
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::synchronize() { CT2X_HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+}  // namespace ct2x

@@ -1,0 +1,260 @@
+// MI355X-native execution engine for Transformer encoder/decoder models: the device side of
+// ctranslate2::Translator / Generator. Where the reference composes ~50 generic ops over
+// freshly allocated StorageViews per step (src/layers/transformer.cc:621-871,
+// src/layers/attention.cc:442-615, src/layers/common.cc:339-442), this engine
+//   * keeps every weight and activation buffer resident in HBM for the whole call,
+//   * runs each decoder sub-layer as a short chain of fused gfx950 kernels
+//     (norm+quantize -> int8 MFMA GEMM+dequant+bias(+act)(+residual) -> fused attention),
+//   * appends to a PRE-ALLOCATED KV cache in place and reorders beams by one gather launch,
+//   * reads the decoding step from device memory so a whole step is one replayable hipGraph,
+//   * samples greedy tokens on the device so consecutive steps need no host round trip.
+// Results are the reference's: same formulas, same op order (see the citations in engine.cc).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "model.h"
+
+namespace ct2x {
+
+enum class ComputeType { kFloat32, kInt8Float32 };
+
+std::string compute_type_name(ComputeType t);
+
+struct DenseW {
+  bool quantized = false;
+  const int8_t* wq = nullptr;     // [n, k] int8
+  const float* wscale = nullptr;  // [n]
+  const float* wf = nullptr;      // [n, k] fp32 (float models)
+  const float* bias = nullptr;    // [n] or nullptr
+  int64_t n = 0, k = 0;
+  bool present = false;
+};
+
+struct NormW {
+  bool present = false;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;  // nullptr => RMSNorm
+  float eps = 1e-5f;
+  bool use_residual = false;
+};
+
+struct AttnW {
+  NormW ln;
+  DenseW lin[3];  // self: [qkv, out]; cross: [q, kv, out]
+  int n_lin = 0;
+  int64_t heads = 0, heads_kv = 0, dhead = 0;
+  float queries_scale = 1.f;
+  bool rotary = false;
+  bool rotary_interleave = true;
+  int64_t rotary_dim = 0;  // 0 => dhead
+  float rotary_base = 10000.f;
+  int rotary_scaling_type = -1;  // -1 none, 0 linear, 1 su, 2 llama3
+  float rotary_scaling_factor = 1.f;
+  float rotary_low_freq_factor = 1.f, rotary_high_freq_factor = 4.f;
+  int64_t original_max_position_embeddings = 0, max_position_embeddings = 0;
+};
+
+struct FfnW {
+  NormW ln;
+  DenseW l0, l0_noact, l1;
+  int activation = 0;
+};
+
+struct EmbW {
+  const void* table = nullptr;
+  bool is_int8 = false;
+  const float* scale = nullptr;  // per-row scales of an int8 table
+  int64_t vocab = 0, depth = 0;
+};
+
+struct LayerW {
+  AttnW self;
+  bool has_cross = false;
+  AttnW cross;
+  FfnW ffn;
+};
+
+struct StackW {  // encoder or decoder
+  EmbW emb;
+  bool scale_embeddings = false;
+  float embeddings_scale = 1.f;
+  const float* position_table = nullptr;  // learned positions [num_positions, d] or nullptr
+  int64_t num_positions = 0;
+  bool sinusoidal_positions = false;
+  NormW layernorm_embedding;
+  NormW output_norm;
+  std::vector<LayerW> layers;
+  bool pre_norm = true;
+  int64_t num_heads = 8;
+  DenseW projection;  // decoder only
+  int64_t d_model = 0;
+};
+
+// Per-call device state of one decoding session over `rows` = batch * beam hypotheses.
+struct DecodeState;
+
+class Engine {
+public:
+  Engine(std::shared_ptr<ModelFile> model, const std::string& compute_type, int device_index);
+  ~Engine();
+
+  const ModelFile& model() const { return *model_; }
+  ComputeType compute_type() const { return compute_type_; }
+  bool is_seq2seq() const { return has_encoder_; }
+  int64_t vocab_size() const { return dec_.projection.n; }
+  int64_t d_model() const { return dec_.d_model; }
+  int64_t num_decoder_layers() const { return static_cast<int64_t>(dec_.layers.size()); }
+  int64_t num_heads() const { return dec_.num_heads; }
+  int device_index() const { return device_; }
+  hipStream_t stream() const { return stream_; }
+  int64_t weight_bytes() const { return weight_bytes_; }
+
+  // ---- session API used by decoding.cc -------------------------------------------------
+  // Encodes `batch` padded source sequences (ids [batch, s_max] on host, lengths [batch]) and
+  // prepares a decoding state for batch*beam rows and up to t_max decoded positions.
+  std::unique_ptr<DecodeState> start(const int32_t* src_ids, const int32_t* src_lengths,
+                                     int64_t batch, int64_t s_max, int64_t beam, int64_t t_max);
+  // Decoder-only models: no encoder; the prompt is consumed by prefill().
+  std::unique_ptr<DecodeState> start_decoder_only(int64_t batch, int64_t beam, int64_t t_max);
+
+  // One decoder step over state.rows rows: reads token ids from state.d_ids and the step index
+  // from state.d_step (device memory), leaves logits in state.logits [rows, vocab].
+  // With `graph`, the launch sequence is captured once and replayed.
+  void step(DecodeState& state, bool graph);
+
+  // Greedy sampling on device (BestSampler k=1, src/sampling.cc:25-32 + DisableTokens min-length
+  // masking, src/decoding.cc:384-408, + optional LogSoftMax for scores, src/decoding.cc:874-880):
+  // writes next ids into state.d_ids, appends (id, score) to the device history at the current
+  // step and increments state.d_step.
+  void sample_greedy(DecodeState& state, int32_t eos_id, int32_t min_length, bool with_scores);
+  void advance_step(DecodeState& state);
+
+  // Beam search device legs (src/decoding.cc:545-562): log_softmax(logits)+beam score, then
+  // top-(2*beam) over the flattened [batch, beam*vocab] candidates. Results land in
+  // state.topk_scores / state.topk_ids (device) and are copied to the given host buffers.
+  void beam_candidates(DecodeState& state, int32_t eos_id, int32_t min_length,
+                       float* h_scores, int32_t* h_ids);
+  // Installs the host-selected next ids / parent rows / cumulative scores for the next step and
+  // reorders the self-attention caches (Decoder::update_state, src/layers/decoder.cc:33-56).
+  void beam_update(DecodeState& state, const int32_t* h_next_ids, const int32_t* h_parents,
+                   const float* h_scores);
+  // Initial cumulative scores (initialize_beam_scores, src/decoding.cc:84-93).
+  void set_beam_scores(DecodeState& state, const float* h_scores);
+
+  // Copies `count` history steps starting at `first` (ids and scores, [step][rows]) to host.
+  void read_history(DecodeState& state, int64_t first, int64_t count, int32_t* h_ids,
+                    float* h_scores);
+  void copy_logits_to_host(DecodeState& state, float* h_logits);
+  void set_ids(DecodeState& state, const int32_t* h_ids);
+  void set_step(DecodeState& state, int32_t step);
+  void synchronize();
+
+  // Number of kernel launches recorded for one decoder step (reported by bench.py).
+  int64_t kernels_per_step() const { return kernels_per_step_; }
+
+private:
+  friend struct DecodeState;
+  struct QuantIn {  // an activation matrix already quantised for an int8 Dense
+    const int8_t* q = nullptr;
+    const float* s = nullptr;
+  };
+
+  void load_weights();
+  DenseW load_dense(const std::string& scope, bool required);
+  NormW load_norm(const std::string& scope);
+  AttnW load_attention(const std::string& scope, bool self_attention, int64_t num_heads);
+  FfnW load_ffn(const std::string& scope, int activation);
+  void load_stack(const std::string& scope, bool decoder, StackW& out);
+  const void* upload(const void* host, size_t bytes);
+  const float* upload_floats(const std::vector<float>& v);
+
+  // y[m, n] = act(x . W^T + b) (+ residual). Exactly one of `x` (fp32, quantised on the fly for
+  // int8 weights) or `qin` must be given.
+  void dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t m, int act,
+             const float* residual, float* y, DecodeState* ws);
+  void norm(const NormW& w, const float* x, int64_t rows, int64_t depth, float* y);
+  void norm_quant(const NormW& w, const float* x, int64_t rows, int64_t depth, float* y,
+                  int8_t* q, float* s);
+  void quant(const float* x, int64_t rows, int64_t depth, int8_t* q, float* s);
+
+  void encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_lengths);
+  void launch_step(DecodeState& st);
+  const float* sinusoidal_table(int64_t positions, int64_t depth);
+  void rotary_tables(const AttnW& a, int64_t positions, const float** sin, const float** cos);
+  void count_kernel() { ++launch_counter_; }
+
+  std::shared_ptr<ModelFile> model_;
+  ComputeType compute_type_;
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  bool round_before_cast_ = true;  // weights converted at load time
+  int quant_mode_ = 1;             // activation quantisation flags (device_utils.h)
+  bool has_encoder_ = false;
+  StackW enc_, dec_;
+  std::vector<void*> device_blocks_;
+  int64_t weight_bytes_ = 0;
+  int64_t launch_counter_ = 0;
+  int64_t kernels_per_step_ = 0;
+
+  // Lazily grown tables.
+  float* sin_pos_table_ = nullptr;
+  int64_t sin_pos_positions_ = 0, sin_pos_depth_ = 0;
+  float* rope_sin_ = nullptr;
+  float* rope_cos_ = nullptr;
+  int64_t rope_positions_ = 0;
+};
+
+struct DecodeState {
+  Engine* engine = nullptr;
+  int64_t batch = 0, beam = 1, rows = 0, t_max = 0, s_max = 0;
+  // device buffers (owned; released in the destructor through the caching allocator)
+  std::vector<void*> owned;
+  float* x0 = nullptr;       // residual stream [rows, d]
+  float* x1 = nullptr;
+  float* qkv = nullptr;      // [rows, q_dim + 2 * kv_dim]
+  float* ctx = nullptr;      // [rows, d]
+  float* inner = nullptr;    // [rows, ffn]
+  float* inner2 = nullptr;   // [rows, ffn] (GLU gate)
+  float* logits = nullptr;   // [rows, vocab]
+  float* logprobs = nullptr; // [rows, vocab] (beam search)
+  int8_t* qbuf = nullptr;    // [rows, max(d, ffn)]
+  float* qscale = nullptr;   // [rows]
+  int32_t* d_ids = nullptr;  // [rows] next input ids
+  int32_t* d_step = nullptr; // [1]
+  int32_t* mem_lengths = nullptr;  // [batch]
+  // self-attention caches, ping-pong for beam reorder: [2][layers] each [rows, heads_kv, t_max, dh]
+  std::vector<float*> self_k[2], self_v[2];
+  int cur = 0;
+  const float** d_cache_src = nullptr;  // device arrays of the 2*layers cache base pointers
+  float** d_cache_dst = nullptr;
+  const float** d_cache_src_alt = nullptr;
+  float** d_cache_dst_alt = nullptr;
+  // cross-attention K/V: per layer [batch, s_max, 2 * kv_dim] (GEMM output layout)
+  std::vector<float*> cross_kv;
+  // history of sampled ids / scores: [t_max][rows]
+  int32_t* hist_ids = nullptr;
+  float* hist_scores = nullptr;
+  // beam search
+  float* beam_scores = nullptr;   // [rows] cumulative log prob
+  float* topk_scores = nullptr;   // [batch, 2*beam]
+  int32_t* topk_ids = nullptr;    // [batch, 2*beam]
+  int32_t* d_parents = nullptr;   // [rows]
+  // Greedy sampling fused at the end of the step (and of its graph): set by decoding.cc.
+  bool fuse_greedy = false;
+  int32_t g_eos = -1, g_min_length = 0;
+  bool g_scores = false;
+  // graph
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // one per cache parity
+  bool graph_ready[2] = {false, false};
+
+  ~DecodeState();
+};
+
+}  // namespace ct2x

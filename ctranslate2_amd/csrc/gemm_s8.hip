@@ -16,6 +16,8 @@
 #include "device_utils.h"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace ct2x {
 
 namespace {
@@ -168,10 +170,16 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
                        M, N, K, ep);
     return;
   }
-  if (m <= 32) {
+  // Debug override of the tile choice (CT2X_GEMM_TILE=32|64|128).
+  static const int forced = [] {
+    const char* e = std::getenv("CT2X_GEMM_TILE");
+    return e ? std::atoi(e) : 0;
+  }();
+  const int64_t sel = forced ? (forced <= 32 ? 1 : (forced <= 64 ? 33 : 65)) : m;
+  if (sel <= 32) {
     hipLaunchKernelGGL((gemm_s8_mfma_kernel<32, 64, 1, 4>), dim3((n + 63) / 64, (m + 31) / 32),
                        dim3(256), 0, stream, a, b, M, N, K, ep);
-  } else if (m <= 64) {
+  } else if (sel <= 64) {
     hipLaunchKernelGGL((gemm_s8_mfma_kernel<64, 64, 2, 2>), dim3((n + 63) / 64, (m + 63) / 64),
                        dim3(256), 0, stream, a, b, M, N, K, ep);
   } else {

@@ -10,7 +10,7 @@ namespace ct2x {
 
 // ---- quantisation / normalisation (rowops.hip) ---------------------------------------
 
-void launch_quantize_s8(const float* x, int64_t rows, int64_t depth, bool round_before_cast,
+void launch_quantize_s8(const float* x, int64_t rows, int64_t depth, int quant_mode,
                         int8_t* q, float* scales, hipStream_t stream);
 
 void launch_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, int64_t depth,
@@ -22,7 +22,7 @@ void launch_dequantize_gemm_output(const int32_t* c, const float* a_scale, const
 
 // beta == nullptr -> RMSNorm. y and/or q may be nullptr (q==nullptr: plain norm).
 void launch_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
-                 int64_t depth, float eps, bool rms_use_residual, bool round_before_cast,
+                 int64_t depth, float eps, bool rms_use_residual, int quant_mode,
                  float* y, int8_t* q, float* scales, hipStream_t stream);
 
 void launch_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth,
@@ -148,5 +148,27 @@ void launch_cache_gather(const float* const* tensors_src, float* const* tensors_
                          int n_tensors, const int32_t* parent, int64_t rows, int64_t heads,
                          int64_t t_max, int64_t dhead, const int32_t* step_ptr, int64_t length,
                          hipStream_t stream);
+
+}  // namespace ct2x
+
+// ---- decode-loop helpers (decode_ops.hip) ---------------------------------------------
+namespace ct2x {
+
+// Device-resident greedy step: DisableTokens(min length) + [LogSoftMax] + TopK(k=1) + id feed
+// for the next step + history append, one launch (src/decoding.cc:852-880, src/sampling.cc:25-32).
+// step = *step_ptr. The disabled token (if step < min_length) is treated as -FLT_MAX.
+void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int32_t disable_id,
+                          int32_t min_length, bool with_scores, const int32_t* step_ptr,
+                          int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
+                          hipStream_t stream);
+
+// *step_ptr += 1
+void launch_advance_step(int32_t* step_ptr, hipStream_t stream);
+
+// Beam-search scores: y[row, :] = log_softmax(x[row, :] with x[disable_id] = -FLT_MAX while
+// step < min_length) + beam_scores[row]   (src/decoding.cc:512-556).
+void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t rows,
+                          int64_t vocab, int32_t disable_id, int32_t min_length,
+                          const int32_t* step_ptr, float* y, hipStream_t stream);
 
 }  // namespace ct2x

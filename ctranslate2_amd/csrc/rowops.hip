@@ -27,7 +27,7 @@ static inline int pick_block(int64_t depth) {
 // GPU counterpart src/ops/quantize_gpu.cu:58-103.
 // ---------------------------------------------------------------------------------------
 __global__ void quantize_s8_kernel(const float* __restrict__ x, int64_t depth,
-                                   bool round_before_cast, int8_t* __restrict__ q,
+                                   int quant_mode, int8_t* __restrict__ q,
                                    float* __restrict__ scales) {
   __shared__ float scratch[16];
   const int64_t row = blockIdx.x;
@@ -54,23 +54,23 @@ __global__ void quantize_s8_kernel(const float* __restrict__ x, int64_t depth,
     for (int64_t i = threadIdx.x; i < depth / 4; i += blockDim.x) {
       float4 v = xv[i];
       char4 o;
-      o.x = to_s8(v.x * scale, round_before_cast);
-      o.y = to_s8(v.y * scale, round_before_cast);
-      o.z = to_s8(v.z * scale, round_before_cast);
-      o.w = to_s8(v.w * scale, round_before_cast);
+      o.x = to_s8(v.x, scale, quant_mode);
+      o.y = to_s8(v.y, scale, quant_mode);
+      o.z = to_s8(v.z, scale, quant_mode);
+      o.w = to_s8(v.w, scale, quant_mode);
       qv[i] = o;
     }
   } else {
     for (int64_t i = threadIdx.x; i < depth; i += blockDim.x)
-      qr[i] = to_s8(xr[i] * scale, round_before_cast);
+      qr[i] = to_s8(xr[i], scale, quant_mode);
   }
 }
 
-void launch_quantize_s8(const float* x, int64_t rows, int64_t depth, bool round_before_cast,
+void launch_quantize_s8(const float* x, int64_t rows, int64_t depth, int quant_mode,
                         int8_t* q, float* scales, hipStream_t stream) {
   if (rows == 0 || depth == 0) return;
   hipLaunchKernelGGL(quantize_s8_kernel, dim3(rows), dim3(pick_block(depth)), 0, stream, x,
-                     depth, round_before_cast, q, scales);
+                     depth, quant_mode, q, scales);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -133,7 +133,7 @@ void launch_dequantize_gemm_output(const int32_t* c, const float* a_scale, const
 // ---------------------------------------------------------------------------------------
 __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                             const float* __restrict__ beta, int64_t depth, float eps,
-                            bool rms_use_residual, bool round_before_cast,
+                            bool rms_use_residual, int quant_mode,
                             float* __restrict__ y, int8_t* __restrict__ q,
                             float* __restrict__ scales) {
   extern __shared__ __attribute__((aligned(16))) float row_buf[];
@@ -182,18 +182,18 @@ __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict
     if (threadIdx.x == 0) scales[row] = scale;
     int8_t* qr = q + row * depth;
     for (int64_t i = threadIdx.x; i < depth; i += blockDim.x)
-      qr[i] = to_s8(row_buf[i] * scale, round_before_cast);
+      qr[i] = to_s8(row_buf[i], scale, quant_mode);
   }
 }
 
 void launch_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
-                 int64_t depth, float eps, bool rms_use_residual, bool round_before_cast,
+                 int64_t depth, float eps, bool rms_use_residual, int quant_mode,
                  float* y, int8_t* q, float* scales, hipStream_t stream) {
   if (rows == 0 || depth == 0) return;
   int block = 64;
   while (block < depth && block < 512) block <<= 1;
   hipLaunchKernelGGL(norm_kernel, dim3(rows), dim3(block), depth * sizeof(float), stream, x,
-                     gamma, beta, depth, eps, rms_use_residual, round_before_cast, y, q, scales);
+                     gamma, beta, depth, eps, rms_use_residual, quant_mode, y, q, scales);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,226 @@
+"""Writes CTranslate2 model directories (model.bin + config.json + vocabulary) for SYNTHETIC
+models: random weights of a named architecture, used by bench.py and the tests because no
+network/checkpoints are available. The wire format is the reference's
+(python/ctranslate2/specs/model_spec.py:382-415, binary version 6), the variable names are the
+reference spec's (python/ctranslate2/specs/transformer_spec.py), and weight quantisation follows
+model_spec.py:223-245 -- so the reference CPU library loads these directories unchanged (that is
+how the golden outputs under tests/golden/ were produced, see tests/golden/make_golden.py).
+
+numpy only; never touches the GPU.
+"""
+import json
+import os
+import struct
+
+import numpy as np
+
+BINARY_VERSION = 6
+_TYPE_IDS = {"float32": 0, "int8": 1, "int16": 2, "int32": 3, "float16": 4}
+
+# ops::ActivationType (include/ctranslate2/ops/activation.h:9-17)
+RELU, GELU_TANH, SWISH, GELU, GELU_SIGMOID, TANH, SIGMOID = range(7)
+
+
+def _write_string(f, s):
+    data = s.encode("utf-8")
+    f.write(struct.pack("H", len(data) + 1))
+    f.write(data)
+    f.write(struct.pack("B", 0))
+
+
+def write_model_bin(path, spec_name, revision, variables, aliases=()):
+    """variables: dict name -> np.ndarray (0-d arrays for attributes); written in sorted order
+    like ModelSpec.variables(ordered=True)."""
+    names = sorted(variables)
+    with open(path, "wb") as f:
+        f.write(struct.pack("I", BINARY_VERSION))
+        _write_string(f, spec_name)
+        f.write(struct.pack("I", revision))
+        f.write(struct.pack("I", len(names)))
+        for name in names:
+            value = np.asarray(variables[name])
+            if value.ndim > 0:  # ascontiguousarray would promote 0-d attributes to 1-d
+                value = np.ascontiguousarray(value)
+            _write_string(f, name)
+            f.write(struct.pack("B", value.ndim))
+            for dim in value.shape:
+                f.write(struct.pack("I", dim))
+            f.write(struct.pack("B", _TYPE_IDS[str(value.dtype)]))
+            f.write(struct.pack("I", value.nbytes))
+            f.write(value.tobytes())
+        aliases = sorted(aliases)
+        f.write(struct.pack("I", len(aliases)))
+        for alias, target in aliases:
+            _write_string(f, alias)
+            _write_string(f, target)
+
+
+def quantize_int8(weight):
+    """model_spec.py:233-240: per-row scale = 127/absmax (absmax 0 -> 127), rint, int8."""
+    value = weight.astype(np.float32, copy=True)
+    amax = np.amax(np.absolute(value), axis=1)
+    amax[amax == 0] = 127.0
+    scale = (127.0 / amax).astype(np.float32)
+    value *= np.expand_dims(scale, 1)
+    value = np.rint(value).astype(np.int8)
+    return value, scale
+
+
+class _Builder:
+    def __init__(self, seed, quantization, w_std=0.02, b_std=0.01):
+        self.rng = np.random.default_rng(seed)
+        self.quantization = quantization
+        self.w_std, self.b_std = w_std, b_std
+        self.vars = {}
+
+    def attr(self, name, value, dtype):
+        self.vars[name] = np.array(value, dtype=dtype)
+
+    def linear(self, scope, n, k, bias=True):
+        w = self.rng.normal(0, self.w_std, (n, k)).astype(np.float32)
+        self.weight(scope + "/weight", w)
+        if bias:
+            self.vars[scope + "/bias"] = self.rng.normal(0, self.b_std, (n,)).astype(np.float32)
+
+    def weight(self, name, w):
+        if self.quantization == "int8":
+            q, s = quantize_int8(w)
+            self.vars[name] = q
+            self.vars[name + "_scale"] = s
+        else:
+            self.vars[name] = w.astype(np.float32)
+
+    def layer_norm(self, scope, d, rms=False):
+        # gamma ~ 1, beta ~ 0 with a little noise so every norm is a distinct variable
+        self.vars[scope + "/gamma"] = (1.0 + self.rng.normal(0, 0.02, (d,))).astype(np.float32)
+        if not rms:
+            self.vars[scope + "/beta"] = self.rng.normal(0, 0.02, (d,)).astype(np.float32)
+
+
+def _vocab_tokens(vocab_size):
+    return ["<blank>", "<s>", "</s>", "<unk>"] + ["tok%d" % i for i in range(4, vocab_size)]
+
+
+def build_transformer(output_dir, num_encoder_layers=6, num_decoder_layers=6, d_model=512,
+                      ffn_dim=2048, num_heads=8, vocab_size=32000, seed=0, quantization="int8",
+                      activation=RELU, pre_norm=True, w_std=0.02, proj_std=None):
+    """TransformerSpec.from_config((enc, dec), heads) with sinusoidal positions, shared
+    vocabulary -- the Transformer-base En->De shape of BASELINE.json when left at the defaults."""
+    os.makedirs(output_dir, exist_ok=True)
+    b = _Builder(seed, quantization, w_std=w_std)
+    d = d_model
+
+    def mha(scope, self_attention):
+        b.layer_norm(scope + "/layer_norm", d)
+        if self_attention:
+            b.linear(scope + "/linear_0", 3 * d, d)
+            b.linear(scope + "/linear_1", d, d)
+        else:
+            b.linear(scope + "/linear_0", d, d)
+            b.linear(scope + "/linear_1", 2 * d, d)
+            b.linear(scope + "/linear_2", d, d)
+
+    def ffn(scope):
+        b.layer_norm(scope + "/layer_norm", d)
+        b.linear(scope + "/linear_0", ffn_dim, d)
+        b.linear(scope + "/linear_1", d, ffn_dim)
+
+    emb_std = w_std
+    b.weight("encoder/embeddings_0/weight", b.rng.normal(0, emb_std, (vocab_size, d)).astype(np.float32))
+    b.weight("decoder/embeddings/weight", b.rng.normal(0, emb_std, (vocab_size, d)).astype(np.float32))
+    for l in range(num_encoder_layers):
+        mha("encoder/layer_%d/self_attention" % l, True)
+        ffn("encoder/layer_%d/ffn" % l)
+    for l in range(num_decoder_layers):
+        mha("decoder/layer_%d/self_attention" % l, True)
+        mha("decoder/layer_%d/attention" % l, False)
+        ffn("decoder/layer_%d/ffn" % l)
+    if pre_norm:
+        b.layer_norm("encoder/layer_norm", d)
+        b.layer_norm("decoder/layer_norm", d)
+    if proj_std is not None:
+        b.w_std = proj_std
+    b.linear("decoder/projection", vocab_size, d)
+
+    for scope in ("encoder", "decoder"):
+        b.attr(scope + "/num_heads", num_heads, np.int16)
+        b.attr(scope + "/pre_norm", int(pre_norm), np.int8)
+        b.attr(scope + "/activation", activation, np.int8)
+        b.attr(scope + "/scale_embeddings", 1, np.int8)
+    b.attr("encoder/embeddings_merge", 0, np.int8)
+    b.attr("encoder/multi_query_attention", 0, np.int8)
+    b.attr("decoder/alibi", 0, np.int8)
+    b.attr("decoder/alibi_use_positive_positions", 0, np.int8)
+    b.attr("decoder/scale_alibi", 0, np.int8)
+    b.attr("decoder/alignment_heads", 1, np.int16)
+    b.attr("decoder/alignment_layer", -1, np.int16)
+    b.attr("decoder/start_from_zero_embedding", 0, np.int8)
+
+    write_model_bin(os.path.join(output_dir, "model.bin"), "TransformerSpec", 7, b.vars)
+    config = {
+        "add_source_bos": False,
+        "add_source_eos": False,
+        "bos_token": "<s>",
+        "decoder_start_token": "<s>",
+        "eos_token": "</s>",
+        "layer_norm_epsilon": None,
+        "multi_query_attention": False,
+        "unk_token": "<unk>",
+    }
+    with open(os.path.join(output_dir, "config.json"), "w") as f:
+        json.dump(config, f, indent=2, sort_keys=True)
+    with open(os.path.join(output_dir, "shared_vocabulary.json"), "w", encoding="utf-8") as f:
+        json.dump(_vocab_tokens(vocab_size), f, indent=2)
+    return output_dir
+
+
+def build_decoder_lm(output_dir, num_layers=32, d_model=4096, ffn_dim=14336, num_heads=32,
+                     num_heads_kv=8, vocab_size=128256, seed=0, quantization="int8",
+                     rotary_base=500000.0, w_std=0.02):
+    """TransformerDecoderModelSpec.from_config(layers, heads, activation=SWISH, ffn_glu=True,
+    rms_norm=True, rotary_dim=0, rotary_interleave=False, num_heads_kv=...) -- the Llama-3 shape
+    (python/ctranslate2/converters/transformers.py:1736-1752)."""
+    os.makedirs(output_dir, exist_ok=True)
+    b = _Builder(seed, quantization, w_std=w_std)
+    d = d_model
+    dh = d // num_heads
+    b.weight("decoder/embeddings/weight", b.rng.normal(0, w_std, (vocab_size, d)).astype(np.float32))
+    for l in range(num_layers):
+        s = "decoder/layer_%d" % l
+        b.layer_norm(s + "/self_attention/layer_norm", d, rms=True)
+        b.linear(s + "/self_attention/linear_0", (num_heads + 2 * num_heads_kv) * dh, d, bias=False)
+        b.linear(s + "/self_attention/linear_1", d, d, bias=False)
+        b.attr(s + "/self_attention/rotary_dim", 0, np.int32)
+        b.attr(s + "/self_attention/rotary_interleave", 0, np.int8)
+        b.attr(s + "/self_attention/rotary_base", rotary_base, np.float32)
+        b.attr(s + "/self_attention/num_heads_kv", num_heads_kv, np.int32)
+        b.layer_norm(s + "/ffn/layer_norm", d, rms=True)
+        b.linear(s + "/ffn/linear_0", ffn_dim, d, bias=False)
+        b.linear(s + "/ffn/linear_0_noact", ffn_dim, d, bias=False)
+        b.linear(s + "/ffn/linear_1", d, ffn_dim, bias=False)
+    b.layer_norm("decoder/layer_norm", d, rms=True)
+    b.linear("decoder/projection", vocab_size, d, bias=False)
+    b.attr("decoder/num_heads", num_heads, np.int16)
+    b.attr("decoder/pre_norm", 1, np.int8)
+    b.attr("decoder/activation", SWISH, np.int8)
+    b.attr("decoder/scale_embeddings", 0, np.int8)
+    b.attr("decoder/alibi", 0, np.int8)
+    b.attr("decoder/alibi_use_positive_positions", 0, np.int8)
+    b.attr("decoder/scale_alibi", 0, np.int8)
+    b.attr("decoder/start_from_zero_embedding", 0, np.int8)
+    write_model_bin(os.path.join(output_dir, "model.bin"), "TransformerDecoderSpec", 8, b.vars)
+    config = {
+        "bos_token": "<s>",
+        "eos_token": "</s>",
+        "layer_norm_epsilon": 1e-05,
+        "multi_query_attention": True,
+        "quantization_bits": None,
+        "quantization_group_size": None,
+        "quantization_type": 0,
+        "unk_token": "<unk>",
+    }
+    with open(os.path.join(output_dir, "config.json"), "w") as f:
+        json.dump(config, f, indent=2, sort_keys=True)
+    with open(os.path.join(output_dir, "vocabulary.json"), "w", encoding="utf-8") as f:
+        json.dump(_vocab_tokens(vocab_size), f, indent=2)
+    return output_dir

@@ -102,8 +102,11 @@ int ct2x_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises o
 
 /* ops::Quantize::quantize<Device::CUDA, T, int8_t> (src/ops/quantize_gpu.cu:87-103;
  * CPU semantics src/cpu/kernels.cc:577-651): per row amax -> scale = amax ? 127/amax : 1,
- * q = int8(round_or_trunc(x*scale)). round_before_cast=0 is the legacy truncation of
- * binary_version < 5 models (include/ctranslate2/models/model.h:87-89). */
+ * q = int8(round_or_trunc(x*scale)). `round_before_cast` is a flag word: bit 0 = round to
+ * nearest even (0 = the legacy truncation of binary_version < 5 models,
+ * include/ctranslate2/models/model.h:87-89); bit 1 = reproduce the u8 domain shift of the
+ * reference's x86 CPU GEMM backends, q = cvtt(round_func(x*scale + 128)) - 128
+ * (shift_to_uint8, src/cpu/kernels.cc:592-604), which the engine uses for CPU token parity. */
 int ct2x_quantize_s8(const void* d_x, int dtype, int64_t rows, int64_t depth,
                      int round_before_cast, int8_t* d_q, float* d_scales, void* stream);
 

@@ -43,7 +43,9 @@ float orc_activation(float v, int act) {
 
 /* quantize_s8_row (src/cpu/kernels.cc:577-620): amax = max |x|; scale = amax != 0 ? 127/amax : 1;
  * y = (int8) trunc(round_func(x * scale)) with round_func = round-to-nearest-even when
- * round_before_cast (Vec::round, src/cpu/vec_avx.h) else identity, conversion by cvttps. */
+ * round_before_cast bit 0 (Vec::round, src/cpu/vec_avx.h) else identity, conversion by cvttps.
+ * Bit 1 selects the shift_to_uint8 arm that layers::Dense uses with the MKL / oneDNN u8s8 GEMM
+ * (src/layers/common.cc:296-298); the value returned is then q_u8 - 128. */
 void orc_quantize_s8(const float* x, int64_t rows, int64_t depth, int round_before_cast,
                      int8_t* q, float* scales) {
 #pragma omp parallel for if (rows > 64)
@@ -59,8 +61,19 @@ void orc_quantize_s8(const float* x, int64_t rows, int64_t depth, int round_befo
     scales[i] = scale;
     for (int64_t j = 0; j < depth; ++j) {
       float v = xr[j] * scale;
-      if (round_before_cast) v = nearbyintf(v); /* default rounding mode = RNE */
-      qr[j] = (int8_t)(int32_t)v;
+      if (round_before_cast & 2) {
+        /* shift_to_uint8 arm (kernels.cc:592-604): round_func(v - int8_min), cvtt, narrowing
+         * store to uint8; the GEMM compensation makes the effective operand q_u8 - 128. */
+        /* The reference's AVX2/AVX512 kernel objects are built with -mfma and GCC's default
+         * -ffp-contract=fast, which fuses mul(v, scale) and sub(.., int8_min) into one FMA
+         * (verified against oracle/_ref: the unfused form differs in ~5e-4 of truncated values). */
+        v = fmaf(xr[j], scale, 128.f);
+        if (round_before_cast & 1) v = nearbyintf(v);
+        qr[j] = (int8_t)((int32_t)((uint8_t)(int32_t)v) - 128);
+      } else {
+        if (round_before_cast & 1) v = nearbyintf(v); /* default rounding mode = RNE */
+        qr[j] = (int8_t)(int32_t)v;
+      }
     }
   }
 }

