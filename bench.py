@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path named by BASELINE.json: generated tokens/s of int8 Transformer-base
+En->De greedy decoding (batch 32, beam 1) on MI355X, whole-job over N GPUs (one process per GPU,
+independent replicas = the reference's data-parallel ReplicaPool, no collective on the data path).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One "step" = one Translator.translate_batch call over one synthetic batch: 32 source sentences of
+32 random token ids, 64 forced decoding steps (min = max decoding length) => exactly 2048 generated
+tokens per step per GPU, encoder + decoder + sampling + host loop included, model load excluded
+(the reference's own tokens/s accounting, include/ctranslate2/translator.h:176-209). Inputs are
+host id arrays (a few KB); weights, KV cache and all activations are resident in HBM.
+
+Rank 0 prints ONE JSON line. Besides the contract fields it carries
+  roofline:     the dominant kernel of the step, timed with HIP events on the engine's stream in a
+                profiling pass of the same workload (ct2x_profile_begin/end), algorithmic bytes from
+                the engine's per-launch accounting (DESIGN.md "Roofline accounting").
+  cpu_baseline: the REAL reference CPU library (oracle/_ref: CTranslate2 + MKL, int8) timed on the
+                host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+INT8_MFMA_PEAK_TOPS = 5000.0   # dense int8 MFMA ~= 2x bf16 (same guide)
+
+TB = dict(num_encoder_layers=6, num_decoder_layers=6, d_model=512, ffn_dim=2048, num_heads=8,
+          vocab_size=32000, seed=0)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--batch", type=int, default=32)
+    p.add_argument("--beam", type=int, default=1)
+    p.add_argument("--src-len", type=int, default=32)
+    p.add_argument("--max-len", type=int, default=64)
+    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-profile", action="store_true")
+    p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline")
+    return p.parse_args()
+
+
+def make_sources(rank, batch, src_len, vocab):
+    rng = np.random.default_rng(1 + rank)
+    return [rng.integers(4, vocab, src_len).tolist() for _ in range(batch)]
+
+
+def shard_info():
+    """(rank, local_rank, world) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def aggregate_throughput(local_tokens, elapsed_s, dist=None, device=None):
+    """Whole-job throughput: tokens of ALL ranks / max-over-ranks time (weak scaling: every rank
+    processes its own batch). Works with any torch.distributed backend (gloo in the CPU tests)."""
+    import torch
+    if dist is None or not dist.is_initialized():
+        return float(local_tokens) / elapsed_s, elapsed_s, int(local_tokens)
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    n = torch.tensor([float(local_tokens)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(n.item()) / float(t.item()), float(t.item()), int(n.item())
+
+
+def pick_dominant(profile):
+    """Kernel label with the largest accumulated device time."""
+    label = max(profile, key=lambda k: profile[k]["total_ms"])
+    return label, profile[label]
+
+
+def roofline_entry(label, st):
+    avg_ms = st["total_ms"] / max(st["launches"], 1)
+    seconds = st["total_ms"] * 1e-3
+    gbs = st["bytes"] / seconds / 1e9 if st["bytes"] > 0 and seconds > 0 else None
+    tops = st["ops"] / seconds / 1e12 if st["ops"] > 0 and seconds > 0 else None
+    entry = {"kernel": label, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": None,
+             "launches": st["launches"], "avg_us": avg_ms * 1e3,
+             "bytes_per_launch": st["bytes"] / max(st["launches"], 1)}
+    if tops is not None:
+        entry["int8_tops"] = tops
+        entry["mfma_frac"] = tops / INT8_MFMA_PEAK_TOPS
+    return entry
+
+
+def cpu_baseline(model_dir, sources, args):
+    """The reference's own CPU path (MKL int8) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _refshim as R
+    if not R.available():
+        return {"value": None, "unit": "tokens/s", "kind": "reference",
+                "error": "oracle/_ref or the MKL runtime is not present on this host"}
+    cores = os.cpu_count() or 1
+    threads = args.cpu_threads or min(32, cores)
+    intra = 4 if threads >= 8 else threads
+    inter = max(1, threads // intra)
+    m = R.RefModel(model_dir, "int8", inter, intra)
+    mbs = max(1, len(sources) // inter)
+    kw = dict(beam_size=args.beam, max_len=args.max_len, min_len=args.max_len, return_scores=False,
+              max_batch_size=mbs)
+    m.translate_ids(sources[:mbs], **kw)  # warm-up (MKL packing, thread pools)
+    t0 = time.perf_counter()
+    reps = 0
+    tokens = 0
+    while True:
+        hyps, _ = m.translate_ids(sources, **kw)
+        tokens += sum(len(h[0]) for h in hyps)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 5:
+            break
+    dt = time.perf_counter() - t0
+    m.close()
+    return {"value": tokens / dt, "unit": "tokens/s", "cores": inter * intra, "kind": "reference",
+            "sample": "%d x translate_batch(%d sentences, %d forced steps), inter_threads=%d "
+                      "intra_threads=%d, compute_type=int8 (MKL u8s8), %.1f s" %
+                      (reps, len(sources), args.max_len, inter, intra, dt),
+            "host_cpus": cores}
+
+
+def main():
+    args = parse_args()
+    rank, local_rank, world = shard_info()
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+
+    import ctranslate2_amd as ct2
+    from ctranslate2_amd import model_builder as mb
+
+    model_dir = "/tmp/ct2x_bench_tb_r%d" % local_rank
+    if not os.path.exists(os.path.join(model_dir, "model.bin")):
+        mb.build_transformer(model_dir, **TB)
+    translator = ct2.Translator(model_dir, device="cuda", device_index=local_rank, compute_type="int8")
+    sources = make_sources(rank, args.batch, args.src_len, TB["vocab_size"])
+    kw = dict(beam_size=args.beam, max_decoding_length=args.max_len, min_decoding_length=args.max_len,
+              use_graph=not args.no_graph)
+
+    def one_step():
+        hyps, _ = translator.translate_ids(sources, **kw)
+        return sum(len(h[0]) for h in hyps)
+
+    for _ in range(args.warmup):
+        one_step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    tokens = 0
+    for _ in range(args.steps):
+        tokens += one_step()   # translate_ids returns after the engine's stream has drained
+    fence()
+    elapsed = time.perf_counter() - t0
+    value, max_elapsed, total_tokens = aggregate_throughput(tokens, elapsed, dist if world > 1 else None, device)
+    stats = translator.last_stats()
+
+    result = {
+        "metric": "generated tokens/sec (int8, batch=32, beam=%d), whole job" % args.beam,
+        "value": value,
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": max_elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int8",
+        "data": "synthetic",
+        "config": {
+            "workload": "Transformer-base En->De int8 (int8 weights + int8 activations, fp32 "
+                        "accumulate/epilogue = compute type int8_float32), batch=%d beam=%d, "
+                        "source length %d, %d forced decode steps, random-init weights N(0,0.02)"
+                        % (args.batch, args.beam, args.src_len, args.max_len),
+            "tokens_per_step_per_gpu": tokens // max(args.steps, 1),
+            "parallelism": "replicas x%d (one process per GPU, no data-path collective)" % world,
+            "hip_graph": not args.no_graph,
+            "kernels_per_decode_step": stats["kernels_per_step"],
+            "decode_ms_last_call": stats["decode_ms"],
+            "encode_ms_last_call": stats["encode_ms"],
+        },
+    }
+
+    if rank == 0:
+        if not args.no_profile:
+            translator.profile_begin()
+            one_step()
+            profile = translator.profile_end()
+            label, st = pick_dominant(profile)
+            result["roofline"] = roofline_entry(label, st)
+            total_ms = sum(v["total_ms"] for v in profile.values())
+            top = sorted(profile.items(), key=lambda kv: -kv[1]["total_ms"])[:8]
+            result["profile"] = {
+                "device_ms_per_step_eager": total_ms,
+                "top": [{"kernel": k, "launches": v["launches"], "total_ms": round(v["total_ms"], 4),
+                         "share": round(v["total_ms"] / total_ms, 4),
+                         "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["total_ms"] else None}
+                        for k, v in top],
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(model_dir, sources, args)
+            except Exception as e:  # the baseline leg must never break the GPU measurement
+                result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "kind": "reference",
+                                          "error": "%s: %s" % (type(e).__name__, e)}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,6 +167,15 @@ class Translator:
                                             C.c_int32(T), _lib.ptr(logits)))
         return logits
 
+    def profile_begin(self):
+        _lib.check(self._L.ct2x_profile_begin(C.c_void_p(self._h)))
+
+    def profile_end(self) -> dict:
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(self._L.ct2x_profile_end(C.c_void_p(self._h), buf, C.c_int(1 << 16)))
+        return json.loads(buf.value.decode())
+
     def last_stats(self) -> dict:
         st = ExecStats()
         _lib.check(self._L.ct2x_last_stats(C.c_void_p(self._h), C.byref(st)))

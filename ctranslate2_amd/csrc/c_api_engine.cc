@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -338,6 +339,39 @@ int ct2x_last_stats(void* translator, struct ct2x_exec_stats* stats) {
   auto* t = static_cast<Translator*>(translator);
   CT2X_CHECK(t != nullptr && stats != nullptr, "null argument");
   *stats = t->last;
+  API_CATCH
+}
+
+int ct2x_profile_begin(void* translator) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  std::lock_guard<std::mutex> lock(t->mutex);
+  t->engine->profile_begin();
+  API_CATCH
+}
+
+int ct2x_profile_end(void* translator, char* json_out, int json_size) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  std::lock_guard<std::mutex> lock(t->mutex);
+  const auto stats = t->engine->profile_end();
+  std::string js = "{";
+  bool first = true;
+  char buf[256];
+  for (const auto& kv : stats) {
+    if (!first) js += ",";
+    first = false;
+    std::snprintf(buf, sizeof(buf), "{\"launches\":%lld,\"total_ms\":%.6f,\"bytes\":%.1f,\"ops\":%.1f}",
+                  static_cast<long long>(kv.second.launches), kv.second.total_ms, kv.second.bytes,
+                  kv.second.ops);
+    js += "\"" + kv.first + "\":" + buf;
+  }
+  js += "}";
+  CT2X_CHECK(json_out != nullptr && static_cast<int>(js.size()) < json_size,
+             "ct2x_profile_end: output buffer too small");
+  std::memcpy(json_out, js.c_str(), js.size() + 1);
   API_CATCH
 }
 

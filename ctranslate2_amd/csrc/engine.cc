@@ -474,22 +474,82 @@ void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_
 // Building blocks
 // ---------------------------------------------------------------------------------------------
 
+void Engine::begin_kernel(const char* kind, double bytes, double ops, int64_t m, int64_t n,
+                          int64_t k) {
+  ++launch_counter_;
+  if (!profiling_) return;
+  PendingKernel pk;
+  pk.label = kind;
+  if (m || n || k)
+    pk.label += "[m=" + std::to_string(m) + ",n=" + std::to_string(n) + ",k=" + std::to_string(k) + "]";
+  pk.bytes = bytes;
+  pk.ops = ops;
+  auto get_event = [this]() {
+    if (!event_pool_.empty()) {
+      hipEvent_t e = event_pool_.back();
+      event_pool_.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    CT2X_HIP_CHECK(hipEventCreate(&e));
+    return e;
+  };
+  pk.start = get_event();
+  pk.stop = get_event();
+  CT2X_HIP_CHECK(hipEventRecord(pk.start, stream_));
+  pending_.push_back(pk);
+}
+
+void Engine::end_kernel() {
+  if (!profiling_) return;
+  CT2X_HIP_CHECK(hipEventRecord(pending_.back().stop, stream_));
+}
+
+void Engine::profile_begin() {
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+  pending_.clear();
+  profiling_ = true;
+}
+
+std::map<std::string, Engine::KernelStat> Engine::profile_end() {
+  std::map<std::string, KernelStat> stats;
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+  for (auto& pk : pending_) {
+    float ms = 0;
+    CT2X_HIP_CHECK(hipEventElapsedTime(&ms, pk.start, pk.stop));
+    KernelStat& st = stats[pk.label];
+    st.launches += 1;
+    st.total_ms += ms;
+    st.bytes += pk.bytes;
+    st.ops += pk.ops;
+    event_pool_.push_back(pk.start);
+    event_pool_.push_back(pk.stop);
+  }
+  pending_.clear();
+  profiling_ = false;
+  return stats;
+}
+
 void Engine::quant(const float* x, int64_t rows, int64_t depth, int8_t* q, float* s) {
+  begin_kernel("quantize_s8", double(rows) * depth * 5 + rows * 4, 0, rows, 0, depth);
   launch_quantize_s8(x, rows, depth, quant_mode_, q, s, stream_);
-  count_kernel();
+  end_kernel();
 }
 
 void Engine::norm(const NormW& w, const float* x, int64_t rows, int64_t depth, float* y) {
+  begin_kernel("norm", double(rows) * depth * 8 + depth * 8, 0, rows, 0, depth);
   launch_norm(x, w.gamma, w.beta, rows, depth, w.eps, w.use_residual, quant_mode_, y,
               nullptr, nullptr, stream_);
-  count_kernel();
+  end_kernel();
 }
 
 void Engine::norm_quant(const NormW& w, const float* x, int64_t rows, int64_t depth, float* y,
                         int8_t* q, float* s) {
+  begin_kernel("norm_quantize", double(rows) * depth * (y ? 9 : 5) + depth * 8 + rows * 4, 0, rows,
+               0, depth);
   launch_norm(x, w.gamma, w.beta, rows, depth, w.eps, w.use_residual, quant_mode_, y, q, s,
               stream_);
-  count_kernel();
+  end_kernel();
 }
 
 // layers::Dense::operator() (src/layers/common.cc:339-442).
@@ -512,12 +572,23 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
     ep.y = y;
     ep.act = act;
     ep.ldy = w.n;
+    {
+      const double M = double(m), N = double(w.n), K = double(w.k);
+      begin_kernel("gemm_s8_dequant", M * K + N * K + 4 * N + 4 * M + 4 * M * N +
+                                          (residual ? 4 * M * N : 0) + (w.bias ? 4 * N : 0),
+                   2 * M * N * K, m, w.n, w.k);
+    }
     launch_gemm_s8(qin->q, w.wq, m, w.n, w.k, ep, stream_);
-    count_kernel();
+    end_kernel();
   } else {
+    {
+      const double M = double(m), N = double(w.n), K = double(w.k);
+      begin_kernel("gemm_f32", 4 * (M * K + N * K + M * N + (residual ? M * N : 0)), 2 * M * N * K,
+                   m, w.n, w.k);
+    }
     launch_gemm_f32(x, w.wf, 1, m, w.n, w.k, true, 1.f, 0, 0, 0, w.bias, residual, act, y,
                     stream_);
-    count_kernel();
+    end_kernel();
   }
 }
 
@@ -717,8 +788,9 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
     f.causal = false;
     f.scale = a.queries_scale;
     f.out = st.ctx;
+    begin_kernel("attention_encoder", 0, 0, rows, a.heads, a.dhead);
     launch_attention_full(f, stream_);
-    count_kernel();
+    end_kernel();
     dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
     if (a.ln.present && !enc_.pre_norm) norm(a.ln, y, rows, d, y);
     std::swap(x, y);
@@ -744,8 +816,9 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
     dense(ffn.l0, ffn_in, fq.q ? &fq : nullptr, rows, ffn.activation, nullptr, st.inner, &st);
     if (ffn.l0_noact.present) {
       dense(ffn.l0_noact, ffn_in, fq.q ? &fq : nullptr, rows, -1, nullptr, st.inner2, &st);
+      begin_kernel("mul");
       launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, stream_);
-      count_kernel();
+      end_kernel();
     }
     dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
     if (ffn.ln.present && !enc_.pre_norm) norm(ffn.ln, y, rows, d, y);
@@ -780,9 +853,10 @@ void Engine::launch_step(DecodeState& st) {
   if (dec_.sinusoidal_positions) pos = sinusoidal_table(st.t_max, d);
   float* x = st.x0;
   float* y = st.x1;
+  begin_kernel("embed");
   launch_embed(dec_.emb.table, dec_.emb.is_int8, dec_.emb.scale, st.d_ids, rows, d,
                dec_.embeddings_scale, dec_.scale_embeddings, pos, 1, 0, st.d_step, x, stream_);
-  count_kernel();
+  end_kernel();
   if (dec_.layernorm_embedding.present) norm(dec_.layernorm_embedding, x, rows, d, x);
 
   for (size_t l = 0; l < dec_.layers.size(); ++l) {
@@ -830,8 +904,11 @@ void Engine::launch_step(DecodeState& st) {
         p.rope_interleave = a.rotary_interleave;
       }
       p.out = st.ctx;
+      // K and V read once up to the current step (upper bound t_max/2 on average is not known
+      // on the host: the step lives on the device), q + out: reported with t = t_max.
+      begin_kernel("attention_self_decode", 0, 0, rows, a.heads, a.dhead);
       launch_attention_decode(p, stream_);
-      count_kernel();
+      end_kernel();
       dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
       if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
       std::swap(x, y);
@@ -870,8 +947,11 @@ void Engine::launch_step(DecodeState& st) {
       p.t_max = st.s_max;
       p.scale = a.queries_scale;
       p.out = st.ctx;
+      begin_kernel("attention_cross_decode",
+                   double(st.batch) * st.s_max * 2 * kvdim * 4 + double(rows) * a.heads * a.dhead * 8,
+                   double(rows) * a.heads * st.s_max * a.dhead * 4, rows, a.heads, a.dhead);
       launch_attention_decode(p, stream_);
-      count_kernel();
+      end_kernel();
       dense(a.lin[2], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
       if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
       std::swap(x, y);
@@ -898,8 +978,9 @@ void Engine::launch_step(DecodeState& st) {
       dense(ffn.l0, ffn_in, fq.q ? &fq : nullptr, rows, ffn.activation, nullptr, st.inner, &st);
       if (ffn.l0_noact.present) {
         dense(ffn.l0_noact, ffn_in, fq.q ? &fq : nullptr, rows, -1, nullptr, st.inner2, &st);
+        begin_kernel("mul");
         launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, stream_);
-        count_kernel();
+        end_kernel();
       }
       dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
       if (ffn.ln.present && !dec_.pre_norm) norm(ffn.ln, y, rows, d, y);
@@ -923,11 +1004,13 @@ void Engine::launch_step(DecodeState& st) {
   dense(dec_.projection, proj_in, pq.q ? &pq : nullptr, rows, -1, nullptr, st.logits, &st);
 
   if (st.fuse_greedy) {
+    begin_kernel("greedy_sample");
     launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
                          st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores, stream_);
-    count_kernel();
+    end_kernel();
+    begin_kernel("advance_step");
     launch_advance_step(st.d_step, stream_);
-    count_kernel();
+    end_kernel();
   }
 }
 
@@ -939,7 +1022,7 @@ void Engine::step(DecodeState& st, bool graph) {
     const float *s, *c;
     rotary_tables(dec_.layers.front().self, st.t_max + 1, &s, &c);
   }
-  if (!graph) {
+  if (!graph || profiling_) {
     const int64_t before = launch_counter_;
     launch_step(st);
     kernels_per_step_ = launch_counter_ - before;

@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -158,6 +159,18 @@ public:
   // Number of kernel launches recorded for one decoder step (reported by bench.py).
   int64_t kernels_per_step() const { return kernels_per_step_; }
 
+  // Per-kernel timing with HIP events on the engine's stream (eager launches only: profiling
+  // disables graph replay). Stats are keyed by a label that includes the GEMM shape.
+  struct KernelStat {
+    int64_t launches = 0;
+    double total_ms = 0;
+    double bytes = 0;  // algorithmic bytes, summed over launches
+    double ops = 0;    // algorithmic integer/float ops, summed over launches
+  };
+  void profile_begin();
+  std::map<std::string, KernelStat> profile_end();
+  bool profiling() const { return profiling_; }
+
 private:
   friend struct DecodeState;
   struct QuantIn {  // an activation matrix already quantised for an int8 Dense
@@ -187,7 +200,9 @@ private:
   void launch_step(DecodeState& st);
   const float* sinusoidal_table(int64_t positions, int64_t depth);
   void rotary_tables(const AttnW& a, int64_t positions, const float** sin, const float** cos);
-  void count_kernel() { ++launch_counter_; }
+  void begin_kernel(const char* kind, double bytes = 0, double ops = 0, int64_t m = 0,
+                    int64_t n = 0, int64_t k = 0);
+  void end_kernel();
 
   std::shared_ptr<ModelFile> model_;
   ComputeType compute_type_;
@@ -200,6 +215,14 @@ private:
   std::vector<void*> device_blocks_;
   int64_t weight_bytes_ = 0;
   int64_t launch_counter_ = 0;
+  bool profiling_ = false;
+  struct PendingKernel {
+    std::string label;
+    hipEvent_t start, stop;
+    double bytes, ops;
+  };
+  std::vector<PendingKernel> pending_;
+  std::vector<hipEvent_t> event_pool_;
   int64_t kernels_per_step_ = 0;
 
   // Lazily grown tables.

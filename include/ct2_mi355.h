@@ -274,6 +274,13 @@ struct ct2x_exec_stats {
 };
 int ct2x_last_stats(void* translator, struct ct2x_exec_stats* stats);
 
+/* Per-kernel profile of the next translate/generate calls, measured with HIP events on the
+ * engine's stream around every launch (graph replay is disabled while profiling). profile_end
+ * writes a JSON object {label: {"launches":n,"total_ms":t,"bytes":b,"ops":o}, ...} where bytes /
+ * ops are the ALGORITHMIC traffic / work of the launches ("Roofline accounting"). */
+int ct2x_profile_begin(void* translator);
+int ct2x_profile_end(void* translator, char* json_out, int json_size);
+
 /* ---- host-only helpers (no GPU needed; exercised by the CPU test-suite) --------- */
 
 /* Parses model.bin exactly as Model::load does (src/models/model.cc:594-661,767-777) and
