@@ -23,6 +23,7 @@ namespace ct2x {
 namespace {
 
 constexpr int kMaxChunks = 2;  // float4 chunks per lane => dhead <= 4 * G * kMaxChunks
+constexpr int kUnroll = 8;    // key blocks in flight per lane group
 
 // Loads 4 consecutive elements [i0, i0+4) of a head vector, applying RoPE at `pos` when
 // requested (reference formula src/ops/rotary_cpu.cc:31-36).
@@ -135,22 +136,31 @@ __global__ __launch_bounds__(64) void attn_row_kernel(AttnKernelArgs a) {
   }
 
   // ---- phase 1: scores = scale * (q . k_t) ----------------------------------------------
-  for (int64_t t0 = 0; t0 < t_cached; t0 += KPI) {
-    const int64_t t = t0 + kg;
-    float part = 0.f;
-    if (t < t_cached) {
+  // Latency-bound at decode sizes: all K loads of a block of KPI*kUnroll keys are issued before
+  // the first one is consumed, so a block costs one memory round trip instead of kUnroll.
+  for (int64_t t0 = 0; t0 < t_cached; t0 += KPI * kUnroll) {
+    float4 kreg[kUnroll][kMaxChunks];
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) {
+      const int64_t t = t0 + j * KPI + kg;
 #pragma unroll
       for (int u = 0; u < kMaxChunks; ++u) {
         const int cc = c + u * G;
-        if (cc < nc) {
-          const float4 kv = *reinterpret_cast<const float4*>(kc + t * p.kv_time_stride + cc * 4);
-          part += dot4(qv[u], kv);
-        }
+        kreg[j][u] = (t < t_cached && cc < nc)
+                         ? *reinterpret_cast<const float4*>(kc + t * p.kv_time_stride + cc * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    if (c == 0 && t < t_cached) scores[t] = part * p.scale;
+    for (int j = 0; j < kUnroll; ++j) {
+      const int64_t t = t0 + j * KPI + kg;
+      float part = 0.f;
+#pragma unroll
+      for (int u = 0; u < kMaxChunks; ++u) part += dot4(qv[u], kreg[j][u]);
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+      if (c == 0 && t < t_cached) scores[t] = part * p.scale;
+    }
   }
   if (has_new) {
     float part = 0.f;
@@ -192,17 +202,29 @@ __global__ __launch_bounds__(64) void attn_row_kernel(AttnKernelArgs a) {
   float4 acc[kMaxChunks];
 #pragma unroll
   for (int u = 0; u < kMaxChunks; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t t = kg; t < t_cached; t += KPI) {
-    const float pt = scores[t];
+  for (int64_t t0 = 0; t0 < t_cached; t0 += KPI * kUnroll) {
+    float4 vreg[kUnroll][kMaxChunks];
 #pragma unroll
-    for (int u = 0; u < kMaxChunks; ++u) {
-      const int cc = c + u * G;
-      if (cc < nc) {
-        const float4 vv = *reinterpret_cast<const float4*>(vc + t * p.kv_time_stride + cc * 4);
-        acc[u].x += pt * vv.x;
-        acc[u].y += pt * vv.y;
-        acc[u].z += pt * vv.z;
-        acc[u].w += pt * vv.w;
+    for (int j = 0; j < kUnroll; ++j) {
+      const int64_t t = t0 + j * KPI + kg;
+#pragma unroll
+      for (int u = 0; u < kMaxChunks; ++u) {
+        const int cc = c + u * G;
+        vreg[j][u] = (t < t_cached && cc < nc)
+                         ? *reinterpret_cast<const float4*>(vc + t * p.kv_time_stride + cc * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) {
+      const int64_t t = t0 + j * KPI + kg;
+      const float pt = (t < t_cached) ? scores[t] : 0.f;
+#pragma unroll
+      for (int u = 0; u < kMaxChunks; ++u) {
+        acc[u].x += pt * vreg[j][u].x;
+        acc[u].y += pt * vreg[j][u].y;
+        acc[u].z += pt * vreg[j][u].z;
+        acc[u].w += pt * vreg[j][u].w;
       }
     }
   }

@@ -32,11 +32,42 @@ __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t v
   ValIdx best;
   best.v = -FLT_MAX;
   best.i = INT_MAX;
-  for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
-    ValIdx c;
-    c.v = (j == masked) ? -FLT_MAX : x[j];  // DisableTokens: lowest() (decoding_utils.cc:19-35)
-    c.i = static_cast<int>(j);
-    best = better(best, c);
+  const bool vec = (vocab % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (vec) {
+    // 16-byte loads, 8 in flight per lane before the first compare (latency, not bandwidth,
+    // bounds a 128 KB row scan from one workgroup).
+    constexpr int kU = 8;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const int64_t n4 = vocab / 4;
+    for (int64_t base = threadIdx.x; base < n4; base += static_cast<int64_t>(blockDim.x) * kU) {
+      float4 v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
+        v[u] = (i < n4) ? x4[i] : make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
+        if (i >= n4) continue;
+        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = static_cast<int>(i * 4 + k);
+          ValIdx c;
+          c.v = (j == masked) ? -FLT_MAX : e[k];  // DisableTokens: lowest() (decoding_utils.cc:19-35)
+          c.i = j;
+          best = better(best, c);
+        }
+      }
+    }
+  } else {
+    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
+      ValIdx c;
+      c.v = (j == masked) ? -FLT_MAX : x[j];
+      c.i = static_cast<int>(j);
+      best = better(best, c);
+    }
   }
   best = wave_argmax(best);
   if (lane == 0) {

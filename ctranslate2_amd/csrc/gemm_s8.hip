@@ -139,6 +139,91 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Skinny-M kernel for decode steps (M = batch*beam <= 32): the GEMM is a weight stream, not a
+// tile problem, and its wall time is ONE memory round trip if every load is in flight at once.
+// A workgroup owns NT*16 output columns and all M rows; its waves split K (wave w takes the
+// 64-byte K-steps w, w+WAVES, ...), load their A/B MFMA fragments straight from global memory
+// into registers (no LDS staging: a weight byte is used by exactly one wave), and the partial
+// int32 tiles are summed through LDS (exact, order independent) before the fused epilogue.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NT, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
+    const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
+    GemmS8Epilogue ep) {
+  __shared__ int partial[WAVES][MT][NT][64][4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * (NT * 16);
+  const int ksteps = (K + 63) / 64;
+
+  v4i acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+
+  for (int ks0 = wave; ks0 < ksteps; ks0 += WAVES * U) {
+    v4i af[U][MT], bf[U][NT];
+    // Issue every load of this round before the first MFMA consumes one.
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ks = ks0 + u * WAVES;
+      const int kk = ks * 64 + g * 16;
+      const bool k_ok = (ks < ksteps) && (kk < K);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = i * 16 + r;
+        af[u][i] = (k_ok && row < M)
+                       ? *reinterpret_cast<const v4i*>(A + static_cast<int64_t>(row) * K + kk)
+                       : v4i{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int64_t col = n0 + j * 16 + r;
+        bf[u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B + col * K + kk)
+                                     : v4i{0, 0, 0, 0};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u][i], bf[u][j], acc[i][j], 0, 0, 0);
+  }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) partial[wave][i][j][lane][e] = acc[i][j][e];
+  __syncthreads();
+
+  // Tiles are distributed over the waves for the cross-wave sum + epilogue.
+  for (int t = wave; t < MT * NT; t += WAVES) {
+    const int i = t / NT, j = t % NT;
+    int sum[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum[e] += partial[w][i][j][lane][e];
+    const int64_t col = n0 + j * 16 + r;
+    if (col >= N) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = i * 16 + g * 4 + e;
+      if (row >= M) continue;
+      const float r_a = (ep.mode == 1) ? 1.f / ep.a_scale[row] : 0.f;
+      store_epilogue(ep, row, col, sum[e], r_a);
+    }
+  }
+}
+
 // Shapes the MFMA path cannot take (K not a multiple of 16 or unaligned bases): one thread
 // per output element. Only tiny fixture models hit this.
 __global__ void gemm_s8_naive_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ B,
@@ -176,6 +261,33 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
     return e ? std::atoi(e) : 0;
   }();
   const int64_t sel = forced ? (forced <= 32 ? 1 : (forced <= 64 ? 33 : 65)) : m;
+  static const bool no_skinny = std::getenv("CT2X_NO_SKINNY_GEMM") != nullptr;
+  if (m <= 32 && !forced && !no_skinny) {
+    // Decode-step shapes: one memory round trip per launch (see gemm_s8_skinny_kernel).
+    if (n >= 8192) {
+      if (m <= 16)
+        hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, 4, 4, 2>), dim3((n + 63) / 64), dim3(256), 0,
+                           stream, a, b, M, N, K, ep);
+      else
+        hipLaunchKernelGGL((gemm_s8_skinny_kernel<2, 4, 4, 2>), dim3((n + 63) / 64), dim3(256), 0,
+                           stream, a, b, M, N, K, ep);
+    } else if (k >= 2048) {
+      if (m <= 16)
+        hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, 1, 8, 4>), dim3((n + 15) / 16), dim3(512), 0,
+                           stream, a, b, M, N, K, ep);
+      else
+        hipLaunchKernelGGL((gemm_s8_skinny_kernel<2, 1, 8, 4>), dim3((n + 15) / 16), dim3(512), 0,
+                           stream, a, b, M, N, K, ep);
+    } else {
+      if (m <= 16)
+        hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, 1, 4, 4>), dim3((n + 15) / 16), dim3(256), 0,
+                           stream, a, b, M, N, K, ep);
+      else
+        hipLaunchKernelGGL((gemm_s8_skinny_kernel<2, 1, 4, 4>), dim3((n + 15) / 16), dim3(256), 0,
+                           stream, a, b, M, N, K, ep);
+    }
+    return;
+  }
   if (sel <= 32) {
     hipLaunchKernelGGL((gemm_s8_mfma_kernel<32, 64, 1, 4>), dim3((n + 63) / 64, (m + 31) / 32),
                        dim3(256), 0, stream, a, b, M, N, K, ep);

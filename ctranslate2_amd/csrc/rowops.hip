@@ -186,10 +186,135 @@ __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict
   }
 }
 
+
+// Register-resident variant for the decoder shapes (depth % 4 == 0, depth <= 4 * 256 * kNormChunks):
+// every lane keeps its float4 chunks in VGPRs, sum and sum-of-squares share ONE block reduction
+// (two barriers instead of four), and all loads are issued before the first reduction step.
+constexpr int kNormChunks = 4;
+
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if (nwaves == 1) return;
+  __syncthreads();
+  if (lane == 0) {
+    scratch[wave] = a;
+    scratch[16 + wave] = b;
+  }
+  __syncthreads();
+  a = scratch[0];
+  b = scratch[16];
+  for (int i = 1; i < nwaves; ++i) {
+    a += scratch[i];
+    b += scratch[16 + i];
+  }
+}
+
+__global__ void norm_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, int64_t depth, float eps,
+                                bool rms_use_residual, int quant_mode, float* __restrict__ y,
+                                int8_t* __restrict__ q, float* __restrict__ scales) {
+  __shared__ float scratch[32];
+  const int64_t row = blockIdx.x;
+  const int n4 = static_cast<int>(depth / 4);
+  const float4* xr = reinterpret_cast<const float4*>(x + row * depth);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  float4 v[kNormChunks], gv[kNormChunks], bv[kNormChunks];
+#pragma unroll
+  for (int u = 0; u < kNormChunks; ++u) {
+    const int i = threadIdx.x + u * blockDim.x;
+    v[u] = gv[u] = bv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      v[u] = xr[i];
+      gv[u] = g4[i];
+      if (beta != nullptr) bv[u] = b4[i];
+    }
+  }
+  float sum = 0.f, sumsq = 0.f;
+#pragma unroll
+  for (int u = 0; u < kNormChunks; ++u) {
+    sum += v[u].x + v[u].y + v[u].z + v[u].w;
+    sumsq += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+  }
+  block_sum2(sum, sumsq, scratch);
+  const float fdepth = static_cast<float>(depth);
+  float amax = 0.f;
+  if (beta != nullptr) {
+    const float mean = sum / fdepth;
+    const float variance = fmaxf(sumsq / fdepth - mean * mean, 0.f);
+    const float rstd = 1.f / sqrtf(variance + eps);
+#pragma unroll
+    for (int u = 0; u < kNormChunks; ++u) {
+      v[u].x = (v[u].x - mean) * rstd * gv[u].x + bv[u].x;
+      v[u].y = (v[u].y - mean) * rstd * gv[u].y + bv[u].y;
+      v[u].z = (v[u].z - mean) * rstd * gv[u].z + bv[u].z;
+      v[u].w = (v[u].w - mean) * rstd * gv[u].w + bv[u].w;
+    }
+  } else {
+    const float inv_rms = 1.f / sqrtf(sumsq / fdepth + eps);
+#pragma unroll
+    for (int u = 0; u < kNormChunks; ++u) {
+      if (rms_use_residual) {
+        gv[u].x = 1.f + gv[u].x;
+        gv[u].y = 1.f + gv[u].y;
+        gv[u].z = 1.f + gv[u].z;
+        gv[u].w = 1.f + gv[u].w;
+      }
+      v[u].x = v[u].x * inv_rms * gv[u].x;
+      v[u].y = v[u].y * inv_rms * gv[u].y;
+      v[u].z = v[u].z * inv_rms * gv[u].z;
+      v[u].w = v[u].w * inv_rms * gv[u].w;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kNormChunks; ++u) {
+    const int i = threadIdx.x + u * blockDim.x;
+    if (i < n4) {
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
+      if (y != nullptr) reinterpret_cast<float4*>(y + row * depth)[i] = v[u];
+    }
+  }
+  if (q != nullptr) {
+    amax = block_max(amax, scratch);
+    const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+    if (threadIdx.x == 0) scales[row] = scale;
+    char4* qr = reinterpret_cast<char4*>(q + row * depth);
+#pragma unroll
+    for (int u = 0; u < kNormChunks; ++u) {
+      const int i = threadIdx.x + u * blockDim.x;
+      if (i < n4) {
+        char4 o;
+        o.x = to_s8(v[u].x, scale, quant_mode);
+        o.y = to_s8(v[u].y, scale, quant_mode);
+        o.z = to_s8(v[u].z, scale, quant_mode);
+        o.w = to_s8(v[u].w, scale, quant_mode);
+        qr[i] = o;
+      }
+    }
+  }
+}
+
 void launch_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
                  int64_t depth, float eps, bool rms_use_residual, int quant_mode,
                  float* y, int8_t* q, float* scales, hipStream_t stream) {
   if (rows == 0 || depth == 0) return;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) |
+                         reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(y) |
+                         reinterpret_cast<uintptr_t>(q)) & 15) == 0;
+  if (depth % 4 == 0 && depth <= 4 * 256 * kNormChunks && aligned) {
+    int threads = 64;
+    while (threads * kNormChunks * 4 < depth || (threads < 256 && threads * 4 < depth)) threads <<= 1;
+    if (threads > 256) threads = 256;
+    hipLaunchKernelGGL(norm_vec_kernel, dim3(rows), dim3(threads), 0, stream, x, gamma, beta,
+                       depth, eps, rms_use_residual, quant_mode, y, q, scales);
+    return;
+  }
   int block = 64;
   while (block < depth && block < 512) block <<= 1;
   hipLaunchKernelGGL(norm_kernel, dim3(rows), dim3(block), depth * sizeof(float), stream, x,
