@@ -46,6 +46,8 @@ def parse_args():
     p.add_argument("--beam", type=int, default=1)
     p.add_argument("--src-len", type=int, default=32)
     p.add_argument("--max-len", type=int, default=64)
+    p.add_argument("--streams", type=int, default=0,
+                   help="concurrent decode streams per GPU (0 = library default)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-profile", action="store_true")
@@ -153,7 +155,7 @@ def main():
     translator = ct2.Translator(model_dir, device="cuda", device_index=local_rank, compute_type="int8")
     sources = make_sources(rank, args.batch, args.src_len, TB["vocab_size"])
     kw = dict(beam_size=args.beam, max_decoding_length=args.max_len, min_decoding_length=args.max_len,
-              use_graph=not args.no_graph)
+              use_graph=not args.no_graph, num_streams=args.streams)
 
     def one_step():
         hyps, _ = translator.translate_ids(sources, **kw)
@@ -199,6 +201,7 @@ def main():
             "tokens_per_step_per_gpu": tokens // max(args.steps, 1),
             "parallelism": "replicas x%d (one process per GPU, no data-path collective)" % world,
             "hip_graph": not args.no_graph,
+            "streams_per_gpu": args.streams if args.streams > 0 else int(os.environ.get("CT2X_NUM_STREAMS", "4")),
             "kernels_per_decode_step": stats["kernels_per_step"],
             "decode_ms_last_call": stats["decode_ms"],
             "encode_ms_last_call": stats["encode_ms"],

@@ -89,7 +89,7 @@ class Translator:
     # -- translation -----------------------------------------------------------------------
     def _options(self, beam_size, max_decoding_length, min_decoding_length, num_hypotheses,
                  return_scores, return_end_token, max_batch_size, max_input_length,
-                 length_penalty, patience, use_graph):
+                 length_penalty, patience, use_graph, num_streams=0):
         opt = TranslationOptions()
         self._L.ct2x_translation_options_default(C.byref(opt))
         opt.beam_size = beam_size
@@ -103,6 +103,7 @@ class Translator:
         opt.length_penalty = length_penalty
         opt.patience = patience
         opt.use_graph = int(use_graph)
+        opt.num_streams = int(num_streams)
         return opt
 
     def translate_ids(self, source_ids: Sequence[Sequence[int]], beam_size: int = 2,
@@ -110,7 +111,7 @@ class Translator:
                       num_hypotheses: int = 1, return_scores: bool = False,
                       return_end_token: bool = False, max_batch_size: int = 0,
                       max_input_length: int = 1024, length_penalty: float = 1.0,
-                      patience: float = 1.0, use_graph: bool = True):
+                      patience: float = 1.0, use_graph: bool = True, num_streams: int = 0):
         """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores)."""
         batch = len(source_ids)
         lengths = np.array([len(s) for s in source_ids], np.int32)
@@ -123,7 +124,7 @@ class Translator:
         scores = np.zeros((batch, num_hypotheses), np.float32)
         opt = self._options(beam_size, max_decoding_length, min_decoding_length, num_hypotheses,
                             return_scores, return_end_token, max_batch_size, max_input_length,
-                            length_penalty, patience, use_graph)
+                            length_penalty, patience, use_graph, num_streams)
         _lib.check(self._L.ct2x_translate_batch(
             C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
             C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))

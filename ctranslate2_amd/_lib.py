@@ -31,7 +31,8 @@ class TranslationOptions(C.Structure):
         ("length_penalty", C.c_float),
         ("patience", C.c_float),
         ("use_graph", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("num_streams", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 

@@ -7,8 +7,14 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <cstdlib>
+#include <condition_variable>
+#include <exception>
+#include <functional>
 #include <mutex>
 #include <numeric>
+#include <thread>
 
 #include "decoding.h"
 #include "engine.h"
@@ -19,6 +25,65 @@ using namespace ct2x;
 
 namespace {
 
+// Persistent worker threads (one HIP stream each, created once): the reference's replica workers
+// (include/ctranslate2/replica_pool.h:305-367) reduced to "run this closure on n threads".
+class WorkerPool {
+public:
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> lock(mutex_);
+      stop_ = true;
+      ++generation_;
+    }
+    cv_.notify_all();
+    for (auto& th : threads_) th.join();
+  }
+
+  void run(size_t n, const std::function<void()>& fn) {
+    std::unique_lock<std::mutex> lock(mutex_);
+    while (threads_.size() < n) {
+      const size_t index = threads_.size();
+      threads_.emplace_back([this, index] { loop(index); });
+    }
+    job_ = &fn;
+    active_ = n;
+    pending_ = n;
+    ++generation_;
+    cv_.notify_all();
+    done_cv_.wait(lock, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+private:
+  void loop(size_t index) {
+    uint64_t seen = 0;
+    while (true) {
+      const std::function<void()>* job = nullptr;
+      {
+        std::unique_lock<std::mutex> lock(mutex_);
+        cv_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+        if (index >= active_) continue;
+        job = job_;
+      }
+      (*job)();
+      {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (--pending_ == 0) done_cv_.notify_all();
+      }
+    }
+  }
+
+  std::vector<std::thread> threads_;
+  std::mutex mutex_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void()>* job_ = nullptr;
+  size_t active_ = 0, pending_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
 struct Translator {
   std::shared_ptr<ModelFile> model;
   std::unique_ptr<Engine> engine;
@@ -28,6 +93,7 @@ struct Translator {
   int32_t start_id = 1, eos_id = 2, bos_id = 1;
   std::mutex mutex;
   ct2x_exec_stats last{};
+  WorkerPool pool;  // declared last: joined before the engine is destroyed
 };
 
 double now_ms() {
@@ -199,54 +265,97 @@ int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
       return sources[a].size() > sources[b].size();
     });
-  const size_t chunk = opt.max_batch_size > 0 ? static_cast<size_t>(opt.max_batch_size)
-                                              : std::max<size_t>(order.size(), 1);
-  double encode_ms = 0, decode_ms = 0;
-  for (size_t begin = 0; begin < order.size(); begin += chunk) {
-    const size_t end = std::min(order.size(), begin + chunk);
-    const int64_t B = static_cast<int64_t>(end - begin);
-    int64_t s_max = 0;
-    for (size_t i = begin; i < end; ++i)
-      s_max = std::max<int64_t>(s_max, static_cast<int64_t>(sources[order[i]].size()));
-    std::vector<int32_t> ids(B * s_max, 0), lens(B);
-    for (int64_t i = 0; i < B; ++i) {
-      const auto& s = sources[order[begin + i]];
-      std::copy(s.begin(), s.end(), ids.begin() + i * s_max);
-      lens[i] = static_cast<int32_t>(s.size());
-    }
-    const double te0 = now_ms();
-    auto st = t->engine->start(ids.data(), lens.data(), B, s_max, dopt.beam_size,
-                               dopt.max_length);
-    t->engine->synchronize();
-    const double te1 = now_ms();
-    std::vector<int32_t> start_ids(B, t->start_id);
-    DecodeStats ds;
-    std::vector<DecodingResult> results =
-        dopt.beam_size == 1 ? greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds)
-                            : beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds);
-    t->engine->synchronize();
-    const double te2 = now_ms();
-    encode_ms += te1 - te0;
-    decode_ms += te2 - te1;
-    t->last.decode_steps += ds.steps;
-    for (int64_t i = 0; i < B; ++i) {
-      const int32_t b = order[begin + i];
-      DecodingResult& r = results[i];
-      for (int32_t k = 0; k < nh && k < static_cast<int32_t>(r.hypotheses.size()); ++k) {
-        auto& hyp = r.hypotheses[k];
-        // "Remove EOS token" (sequence_to_sequence.cc:374-384).
-        if (!opt.return_end_token)
-          while (!hyp.empty() && hyp.back() == t->eos_id) hyp.pop_back();
-        const int32_t len = static_cast<int32_t>(hyp.size());
-        std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
-                  out_ids + (static_cast<int64_t>(b) * nh + k) * max_len);
-        out_lengths[b * nh + k] = len;
-        if (opt.return_scores && out_scores && k < static_cast<int32_t>(r.scores.size()))
-          out_scores[b * nh + k] = r.scores[k];
-        if (k == 0) t->last.num_tokens += len;  // ExecutionStats: hypothesis 0 tokens
-      }
-    }
+  // Work list: contiguous groups of the (sorted) examples. max_batch_size bounds a group like
+  // rebatch_input does; num_streams additionally splits the work into that many groups so that
+  // independent sub-batches decode concurrently on separate streams. Every op on the path is
+  // row-wise, so the grouping cannot change a hypothesis (tests/test_translator_gpu.py).
+  int32_t streams = opt.num_streams;
+  if (streams <= 0) {
+    const char* env = std::getenv("CT2X_NUM_STREAMS");
+    streams = env ? std::atoi(env) : 4;
   }
+  streams = std::max<int32_t>(1, std::min<int32_t>(streams, 16));
+  if (t->engine->profiling()) streams = 1;  // event bookkeeping is single-stream
+  size_t chunk = opt.max_batch_size > 0 ? static_cast<size_t>(opt.max_batch_size)
+                                        : std::max<size_t>(order.size(), 1);
+  if (streams > 1 && !order.empty()) {
+    const size_t per_stream = (order.size() + streams - 1) / streams;
+    chunk = std::max<size_t>(1, std::min(chunk, per_stream));
+  }
+  std::vector<std::pair<size_t, size_t>> groups;
+  for (size_t begin = 0; begin < order.size(); begin += chunk)
+    groups.emplace_back(begin, std::min(order.size(), begin + chunk));
+
+  double encode_ms = 0, decode_ms = 0;
+  std::mutex stats_mutex;
+  std::atomic<size_t> next_group{0};
+  std::exception_ptr first_error;
+  auto worker = [&]() {
+    try {
+      CT2X_HIP_CHECK(hipSetDevice(t->engine->device_index()));
+      while (true) {
+        const size_t gi = next_group.fetch_add(1);
+        if (gi >= groups.size()) break;
+        const size_t begin = groups[gi].first, end = groups[gi].second;
+        const int64_t B = static_cast<int64_t>(end - begin);
+        int64_t s_max = 0;
+        for (size_t i = begin; i < end; ++i)
+          s_max = std::max<int64_t>(s_max, static_cast<int64_t>(sources[order[i]].size()));
+        std::vector<int32_t> ids(B * s_max, 0), lens(B);
+        for (int64_t i = 0; i < B; ++i) {
+          const auto& s = sources[order[begin + i]];
+          std::copy(s.begin(), s.end(), ids.begin() + i * s_max);
+          lens[i] = static_cast<int32_t>(s.size());
+        }
+        const double te0 = now_ms();
+        auto st = t->engine->start(ids.data(), lens.data(), B, s_max, dopt.beam_size,
+                                   dopt.max_length);
+        t->engine->synchronize();
+        const double te1 = now_ms();
+        std::vector<int32_t> start_ids(B, t->start_id);
+        DecodeStats ds;
+        std::vector<DecodingResult> results =
+            dopt.beam_size == 1 ? greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds)
+                                : beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds);
+        t->engine->synchronize();
+        const double te2 = now_ms();
+        int64_t tokens = 0;
+        for (int64_t i = 0; i < B; ++i) {
+          const int32_t b = order[begin + i];
+          DecodingResult& r = results[i];
+          for (int32_t k = 0; k < nh && k < static_cast<int32_t>(r.hypotheses.size()); ++k) {
+            auto& hyp = r.hypotheses[k];
+            // "Remove EOS token" (sequence_to_sequence.cc:374-384).
+            if (!opt.return_end_token)
+              while (!hyp.empty() && hyp.back() == t->eos_id) hyp.pop_back();
+            const int32_t len = static_cast<int32_t>(hyp.size());
+            std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
+                      out_ids + (static_cast<int64_t>(b) * nh + k) * max_len);
+            out_lengths[b * nh + k] = len;
+            if (opt.return_scores && out_scores && k < static_cast<int32_t>(r.scores.size()))
+              out_scores[b * nh + k] = r.scores[k];
+            if (k == 0) tokens += len;  // ExecutionStats: hypothesis 0 tokens
+          }
+        }
+        std::lock_guard<std::mutex> lock(stats_mutex);
+        encode_ms += te1 - te0;
+        decode_ms += te2 - te1;
+        t->last.decode_steps = std::max<int64_t>(t->last.decode_steps, ds.steps);
+        t->last.num_tokens += tokens;
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(stats_mutex);
+      if (!first_error) first_error = std::current_exception();
+    }
+  };
+  const size_t n_threads = std::min<size_t>(static_cast<size_t>(streams), groups.size());
+  if (n_threads <= 1) {
+    worker();
+  } else {
+    const std::function<void()> job = worker;
+    t->pool.run(n_threads, job);
+  }
+  if (first_error) std::rethrow_exception(first_error);
   t->last.num_examples = batch;
   t->last.kernels_per_step = t->engine->kernels_per_step();
   t->last.encode_ms = encode_ms;

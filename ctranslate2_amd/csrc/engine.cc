@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 
 #include "runtime.h"
@@ -19,6 +20,9 @@ std::string compute_type_name(ComputeType t) {
 }
 
 namespace {
+
+// The stream of the session the calling thread is driving (one worker thread per session).
+thread_local hipStream_t tls_stream = nullptr;
 
 bool ends_with(const std::string& s, const std::string& suffix) {
   return s.size() >= suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0;
@@ -60,6 +64,8 @@ ComputeType resolve(const std::string& requested, bool model_is_quantized) {
 }
 
 }  // namespace
+
+hipStream_t Engine::cur_stream() const { return tls_stream ? tls_stream : stream_; }
 
 // ---------------------------------------------------------------------------------------------
 // Loading
@@ -379,6 +385,7 @@ void Engine::load_weights() {
 
 // generate_sinusoidal_position_encoding (src/layers/common.cc:204-229).
 const float* Engine::sinusoidal_table(int64_t positions, int64_t depth) {
+  std::lock_guard<std::mutex> lock(table_mutex_);
   if (sin_pos_table_ && positions <= sin_pos_positions_ && depth == sin_pos_depth_)
     return sin_pos_table_;
   positions = std::max<int64_t>(positions, 500);
@@ -395,10 +402,8 @@ const float* Engine::sinusoidal_table(int64_t positions, int64_t depth) {
       table[p * depth + half + j] = std::cos(scaled);
     }
   }
-  if (sin_pos_table_) {
-    CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
-    device_free(sin_pos_table_);
-  }
+  // A superseded table is kept until the engine dies: graphs of live sessions may point at it.
+  if (sin_pos_table_) device_blocks_.push_back(sin_pos_table_);
   sin_pos_table_ = static_cast<float*>(device_malloc(table.size() * sizeof(float)));
   CT2X_HIP_CHECK(hipMemcpy(sin_pos_table_, table.data(), table.size() * sizeof(float),
                            hipMemcpyHostToDevice));
@@ -411,6 +416,7 @@ const float* Engine::sinusoidal_table(int64_t positions, int64_t depth) {
 // Llama-3 scaling. Tables are [positions, dim].
 void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_out,
                            const float** cos_out) {
+  std::lock_guard<std::mutex> lock(table_mutex_);
   const int64_t dim = a.rotary_dim == 0 ? a.dhead : a.rotary_dim;
   if (rope_sin_ && positions <= rope_positions_) {
     *sin_out = rope_sin_;
@@ -456,10 +462,9 @@ void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_
       }
     }
   }
-  if (rope_sin_) {
-    CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
-    device_free(rope_sin_);
-    device_free(rope_cos_);
+  if (rope_sin_) {  // kept alive for sessions that captured the old pointers
+    device_blocks_.push_back(rope_sin_);
+    device_blocks_.push_back(rope_cos_);
   }
   rope_sin_ = static_cast<float*>(device_malloc(s.size() * sizeof(float)));
   rope_cos_ = static_cast<float*>(device_malloc(c.size() * sizeof(float)));
@@ -496,24 +501,24 @@ void Engine::begin_kernel(const char* kind, double bytes, double ops, int64_t m,
   };
   pk.start = get_event();
   pk.stop = get_event();
-  CT2X_HIP_CHECK(hipEventRecord(pk.start, stream_));
+  CT2X_HIP_CHECK(hipEventRecord(pk.start, cur_stream()));
   pending_.push_back(pk);
 }
 
 void Engine::end_kernel() {
   if (!profiling_) return;
-  CT2X_HIP_CHECK(hipEventRecord(pending_.back().stop, stream_));
+  CT2X_HIP_CHECK(hipEventRecord(pending_.back().stop, cur_stream()));
 }
 
 void Engine::profile_begin() {
-  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
   pending_.clear();
   profiling_ = true;
 }
 
 std::map<std::string, Engine::KernelStat> Engine::profile_end() {
   std::map<std::string, KernelStat> stats;
-  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
   for (auto& pk : pending_) {
     float ms = 0;
     CT2X_HIP_CHECK(hipEventElapsedTime(&ms, pk.start, pk.stop));
@@ -532,14 +537,14 @@ std::map<std::string, Engine::KernelStat> Engine::profile_end() {
 
 void Engine::quant(const float* x, int64_t rows, int64_t depth, int8_t* q, float* s) {
   begin_kernel("quantize_s8", double(rows) * depth * 5 + rows * 4, 0, rows, 0, depth);
-  launch_quantize_s8(x, rows, depth, quant_mode_, q, s, stream_);
+  launch_quantize_s8(x, rows, depth, quant_mode_, q, s, cur_stream());
   end_kernel();
 }
 
 void Engine::norm(const NormW& w, const float* x, int64_t rows, int64_t depth, float* y) {
   begin_kernel("norm", double(rows) * depth * 8 + depth * 8, 0, rows, 0, depth);
   launch_norm(x, w.gamma, w.beta, rows, depth, w.eps, w.use_residual, quant_mode_, y,
-              nullptr, nullptr, stream_);
+              nullptr, nullptr, cur_stream());
   end_kernel();
 }
 
@@ -548,7 +553,7 @@ void Engine::norm_quant(const NormW& w, const float* x, int64_t rows, int64_t de
   begin_kernel("norm_quantize", double(rows) * depth * (y ? 9 : 5) + depth * 8 + rows * 4, 0, rows,
                0, depth);
   launch_norm(x, w.gamma, w.beta, rows, depth, w.eps, w.use_residual, quant_mode_, y, q, s,
-              stream_);
+              cur_stream());
   end_kernel();
 }
 
@@ -578,7 +583,7 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
                                           (residual ? 4 * M * N : 0) + (w.bias ? 4 * N : 0),
                    2 * M * N * K, m, w.n, w.k);
     }
-    launch_gemm_s8(qin->q, w.wq, m, w.n, w.k, ep, stream_);
+    launch_gemm_s8(qin->q, w.wq, m, w.n, w.k, ep, cur_stream());
     end_kernel();
   } else {
     {
@@ -587,7 +592,7 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
                    m, w.n, w.k);
     }
     launch_gemm_f32(x, w.wf, 1, m, w.n, w.k, true, 1.f, 0, 0, 0, w.bias, residual, act, y,
-                    stream_);
+                    cur_stream());
     end_kernel();
   }
 }
@@ -599,7 +604,7 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
 DecodeState::~DecodeState() {
   if (engine) {
     (void)hipSetDevice(engine->device_index());
-    (void)hipStreamSynchronize(engine->stream());
+    (void)hipStreamSynchronize(stream ? stream : engine->stream());
   }
   for (int i = 0; i < 2; ++i)
     if (graph_exec[i]) (void)hipGraphExecDestroy(graph_exec[i]);
@@ -631,6 +636,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   CT2X_HIP_CHECK(hipSetDevice(device_));
   auto st = std::make_unique<DecodeState>();
   st->engine = this;
+  st->stream = thread_stream();  // the calling (worker) thread's stream: sessions run concurrently
+  tls_stream = st->stream;
   st->batch = batch;
   st->beam = beam;
   st->rows = batch * beam;
@@ -668,7 +675,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   st->d_step = alloc<int32_t>(*st, 1);
   st->hist_ids = alloc<int32_t>(*st, (t_max + 1) * rows);
   st->hist_scores = alloc<float>(*st, (t_max + 1) * rows);
-  CT2X_HIP_CHECK(hipMemsetAsync(st->d_step, 0, sizeof(int32_t), stream_));
+  CT2X_HIP_CHECK(hipMemsetAsync(st->d_step, 0, sizeof(int32_t), cur_stream()));
   if (beam > 1) {
     st->logprobs = alloc<float>(*st, rows * V);
     st->beam_scores = alloc<float>(*st, rows);
@@ -732,9 +739,9 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
   const int64_t B = st.batch, S = st.s_max, d = enc_.d_model, rows = B * S;
   int32_t* d_src = alloc<int32_t>(st, rows);
   CT2X_HIP_CHECK(hipMemcpyAsync(d_src, src_ids, sizeof(int32_t) * rows, hipMemcpyHostToDevice,
-                                stream_));
+                                cur_stream()));
   CT2X_HIP_CHECK(hipMemcpyAsync(st.mem_lengths, src_lengths, sizeof(int32_t) * B,
-                                hipMemcpyHostToDevice, stream_));
+                                hipMemcpyHostToDevice, cur_stream()));
   const float* pos = enc_.position_table;
   if (enc_.sinusoidal_positions) pos = sinusoidal_table(S, d);
   if (enc_.position_table && S > enc_.num_positions)
@@ -744,7 +751,7 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
   float* x = st.x0;
   float* y = st.x1;
   launch_embed(enc_.emb.table, enc_.emb.is_int8, enc_.emb.scale, d_src, rows, d,
-               enc_.embeddings_scale, enc_.scale_embeddings, pos, S, 0, nullptr, x, stream_);
+               enc_.embeddings_scale, enc_.scale_embeddings, pos, S, 0, nullptr, x, cur_stream());
   if (enc_.layernorm_embedding.present) norm(enc_.layernorm_embedding, x, rows, d, x);
 
   for (const LayerW& layer : enc_.layers) {
@@ -789,7 +796,7 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
     f.scale = a.queries_scale;
     f.out = st.ctx;
     begin_kernel("attention_encoder", 0, 0, rows, a.heads, a.dhead);
-    launch_attention_full(f, stream_);
+    launch_attention_full(f, cur_stream());
     end_kernel();
     dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
     if (a.ln.present && !enc_.pre_norm) norm(a.ln, y, rows, d, y);
@@ -817,7 +824,7 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
     if (ffn.l0_noact.present) {
       dense(ffn.l0_noact, ffn_in, fq.q ? &fq : nullptr, rows, -1, nullptr, st.inner2, &st);
       begin_kernel("mul");
-      launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, stream_);
+      launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, cur_stream());
       end_kernel();
     }
     dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
@@ -855,7 +862,7 @@ void Engine::launch_step(DecodeState& st) {
   float* y = st.x1;
   begin_kernel("embed");
   launch_embed(dec_.emb.table, dec_.emb.is_int8, dec_.emb.scale, st.d_ids, rows, d,
-               dec_.embeddings_scale, dec_.scale_embeddings, pos, 1, 0, st.d_step, x, stream_);
+               dec_.embeddings_scale, dec_.scale_embeddings, pos, 1, 0, st.d_step, x, cur_stream());
   end_kernel();
   if (dec_.layernorm_embedding.present) norm(dec_.layernorm_embedding, x, rows, d, x);
 
@@ -907,7 +914,7 @@ void Engine::launch_step(DecodeState& st) {
       // K and V read once up to the current step (upper bound t_max/2 on average is not known
       // on the host: the step lives on the device), q + out: reported with t = t_max.
       begin_kernel("attention_self_decode", 0, 0, rows, a.heads, a.dhead);
-      launch_attention_decode(p, stream_);
+      launch_attention_decode(p, cur_stream());
       end_kernel();
       dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
       if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
@@ -950,7 +957,7 @@ void Engine::launch_step(DecodeState& st) {
       begin_kernel("attention_cross_decode",
                    double(st.batch) * st.s_max * 2 * kvdim * 4 + double(rows) * a.heads * a.dhead * 8,
                    double(rows) * a.heads * st.s_max * a.dhead * 4, rows, a.heads, a.dhead);
-      launch_attention_decode(p, stream_);
+      launch_attention_decode(p, cur_stream());
       end_kernel();
       dense(a.lin[2], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
       if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
@@ -979,7 +986,7 @@ void Engine::launch_step(DecodeState& st) {
       if (ffn.l0_noact.present) {
         dense(ffn.l0_noact, ffn_in, fq.q ? &fq : nullptr, rows, -1, nullptr, st.inner2, &st);
         begin_kernel("mul");
-        launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, stream_);
+        launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, cur_stream());
         end_kernel();
       }
       dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
@@ -1006,15 +1013,16 @@ void Engine::launch_step(DecodeState& st) {
   if (st.fuse_greedy) {
     begin_kernel("greedy_sample");
     launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
-                         st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores, stream_);
+                         st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores, cur_stream());
     end_kernel();
     begin_kernel("advance_step");
-    launch_advance_step(st.d_step, stream_);
+    launch_advance_step(st.d_step, cur_stream());
     end_kernel();
   }
 }
 
 void Engine::step(DecodeState& st, bool graph) {
+  tls_stream = st.stream;
   CT2X_HIP_CHECK(hipSetDevice(device_));
   // Make sure lazily built tables exist before any capture (no allocation inside a capture).
   if (dec_.sinusoidal_positions) (void)sinusoidal_table(st.t_max, dec_.d_model);
@@ -1033,107 +1041,116 @@ void Engine::step(DecodeState& st, bool graph) {
   if (!st.graph_ready[parity]) {
     hipGraph_t g = nullptr;
     const int64_t before = launch_counter_;
-    CT2X_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    CT2X_HIP_CHECK(hipStreamBeginCapture(cur_stream(), hipStreamCaptureModeThreadLocal));
     try {
       launch_step(st);
     } catch (...) {
       hipGraph_t dead = nullptr;
-      (void)hipStreamEndCapture(stream_, &dead);
+      (void)hipStreamEndCapture(cur_stream(), &dead);
       if (dead) (void)hipGraphDestroy(dead);
       throw;
     }
-    CT2X_HIP_CHECK(hipStreamEndCapture(stream_, &g));
+    CT2X_HIP_CHECK(hipStreamEndCapture(cur_stream(), &g));
     kernels_per_step_ = launch_counter_ - before;
     CT2X_HIP_CHECK(hipGraphInstantiate(&st.graph_exec[parity], g, nullptr, nullptr, 0));
     CT2X_HIP_CHECK(hipGraphDestroy(g));
     st.graph_ready[parity] = true;
   }
-  CT2X_HIP_CHECK(hipGraphLaunch(st.graph_exec[parity], stream_));
+  CT2X_HIP_CHECK(hipGraphLaunch(st.graph_exec[parity], cur_stream()));
 }
 
 void Engine::sample_greedy(DecodeState& st, int32_t eos_id, int32_t min_length,
                            bool with_scores) {
+  tls_stream = st.stream;
   launch_greedy_sample(st.logits, st.rows, dec_.projection.n, eos_id, min_length, with_scores,
-                       st.d_step, st.d_ids, st.hist_ids, st.hist_scores, stream_);
-  launch_advance_step(st.d_step, stream_);
+                       st.d_step, st.d_ids, st.hist_ids, st.hist_scores, cur_stream());
+  launch_advance_step(st.d_step, cur_stream());
   check_last_launch("greedy sample");
 }
 
 void Engine::advance_step(DecodeState& st) {
-  launch_advance_step(st.d_step, stream_);
+  tls_stream = st.stream;
+  launch_advance_step(st.d_step, cur_stream());
 }
 
 void Engine::beam_candidates(DecodeState& st, int32_t eos_id, int32_t min_length,
                              float* h_scores, int32_t* h_ids) {
+  tls_stream = st.stream;
   const int64_t V = dec_.projection.n;
   launch_beam_logprobs(st.logits, st.beam_scores, st.rows, V, eos_id, min_length, st.d_step,
-                       st.logprobs, stream_);
+                       st.logprobs, cur_stream());
   const int64_t k = 2 * st.beam;
-  launch_topk(st.logprobs, st.batch, st.beam * V, k, st.topk_scores, st.topk_ids, stream_);
+  launch_topk(st.logprobs, st.batch, st.beam * V, k, st.topk_scores, st.topk_ids, cur_stream());
   check_last_launch("beam candidates");
   CT2X_HIP_CHECK(hipMemcpyAsync(h_scores, st.topk_scores, sizeof(float) * st.batch * k,
-                                hipMemcpyDeviceToHost, stream_));
+                                hipMemcpyDeviceToHost, cur_stream()));
   CT2X_HIP_CHECK(hipMemcpyAsync(h_ids, st.topk_ids, sizeof(int32_t) * st.batch * k,
-                                hipMemcpyDeviceToHost, stream_));
-  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+                                hipMemcpyDeviceToHost, cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
 }
 
 void Engine::beam_update(DecodeState& st, const int32_t* h_next_ids, const int32_t* h_parents,
                          const float* h_scores) {
+  tls_stream = st.stream;
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_ids, h_next_ids, sizeof(int32_t) * st.rows,
-                                hipMemcpyHostToDevice, stream_));
+                                hipMemcpyHostToDevice, cur_stream()));
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_parents, h_parents, sizeof(int32_t) * st.rows,
-                                hipMemcpyHostToDevice, stream_));
+                                hipMemcpyHostToDevice, cur_stream()));
   CT2X_HIP_CHECK(hipMemcpyAsync(st.beam_scores, h_scores, sizeof(float) * st.rows,
-                                hipMemcpyHostToDevice, stream_));
+                                hipMemcpyHostToDevice, cur_stream()));
   // Positions [0, step] are live at this point (the step counter has not advanced yet).
-  launch_advance_step(st.d_step, stream_);
+  launch_advance_step(st.d_step, cur_stream());
   const AttnW& a = dec_.layers.front().self;
   const int n_tensors = static_cast<int>(2 * dec_.layers.size());
   launch_cache_gather(st.cur == 0 ? st.d_cache_src : st.d_cache_src_alt,
                       st.cur == 0 ? st.d_cache_dst : st.d_cache_dst_alt, n_tensors, st.d_parents,
-                      st.rows, a.heads_kv, st.t_max, a.dhead, st.d_step, 0, stream_);
+                      st.rows, a.heads_kv, st.t_max, a.dhead, st.d_step, 0, cur_stream());
   st.cur ^= 1;
   check_last_launch("beam update");
 }
 
 void Engine::set_beam_scores(DecodeState& st, const float* h_scores) {
+  tls_stream = st.stream;
   CT2X_HIP_CHECK(hipMemcpyAsync(st.beam_scores, h_scores, sizeof(float) * st.rows,
-                                hipMemcpyHostToDevice, stream_));
-  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+                                hipMemcpyHostToDevice, cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
 }
 
 void Engine::read_history(DecodeState& st, int64_t first, int64_t count, int32_t* h_ids,
                           float* h_scores) {
+  tls_stream = st.stream;
   if (count <= 0) return;
   CT2X_HIP_CHECK(hipMemcpyAsync(h_ids, st.hist_ids + first * st.rows,
                                 sizeof(int32_t) * count * st.rows, hipMemcpyDeviceToHost,
-                                stream_));
+                                cur_stream()));
   if (h_scores)
     CT2X_HIP_CHECK(hipMemcpyAsync(h_scores, st.hist_scores + first * st.rows,
                                   sizeof(float) * count * st.rows, hipMemcpyDeviceToHost,
-                                  stream_));
-  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+                                  cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
 }
 
 void Engine::copy_logits_to_host(DecodeState& st, float* h_logits) {
+  tls_stream = st.stream;
   CT2X_HIP_CHECK(hipMemcpyAsync(h_logits, st.logits, sizeof(float) * st.rows * dec_.projection.n,
-                                hipMemcpyDeviceToHost, stream_));
-  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+                                hipMemcpyDeviceToHost, cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
 }
 
 void Engine::set_ids(DecodeState& st, const int32_t* h_ids) {
+  tls_stream = st.stream;
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_ids, h_ids, sizeof(int32_t) * st.rows,
-                                hipMemcpyHostToDevice, stream_));
-  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));  // h_ids may be a temporary
+                                hipMemcpyHostToDevice, cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // h_ids may be a temporary
 }
 
 void Engine::set_step(DecodeState& st, int32_t step) {
+  tls_stream = st.stream;
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_step, &step, sizeof(int32_t), hipMemcpyHostToDevice,
-                                stream_));
-  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
+                                cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
 }
 
-void Engine::synchronize() { CT2X_HIP_CHECK(hipStreamSynchronize(stream_)); }
+void Engine::synchronize() { CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream())); }
 
 }  // namespace ct2x

@@ -13,8 +13,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -114,6 +116,7 @@ public:
   int64_t num_heads() const { return dec_.num_heads; }
   int device_index() const { return device_; }
   hipStream_t stream() const { return stream_; }
+  hipStream_t cur_stream() const;  // stream of the session driven by the calling thread
   int64_t weight_bytes() const { return weight_bytes_; }
 
   // ---- session API used by decoding.cc -------------------------------------------------
@@ -214,7 +217,8 @@ private:
   StackW enc_, dec_;
   std::vector<void*> device_blocks_;
   int64_t weight_bytes_ = 0;
-  int64_t launch_counter_ = 0;
+  std::atomic<int64_t> launch_counter_{0};
+  std::mutex table_mutex_;
   bool profiling_ = false;
   struct PendingKernel {
     std::string label;
@@ -223,7 +227,7 @@ private:
   };
   std::vector<PendingKernel> pending_;
   std::vector<hipEvent_t> event_pool_;
-  int64_t kernels_per_step_ = 0;
+  std::atomic<int64_t> kernels_per_step_{0};
 
   // Lazily grown tables.
   float* sin_pos_table_ = nullptr;
@@ -235,6 +239,7 @@ private:
 
 struct DecodeState {
   Engine* engine = nullptr;
+  hipStream_t stream = nullptr;  // all work of this session is enqueued here
   int64_t batch = 0, beam = 1, rows = 0, t_max = 0, s_max = 0;
   // device buffers (owned; released in the destructor through the caching allocator)
   std::vector<void*> owned;

@@ -223,7 +223,11 @@ struct ct2x_translation_options {
   float length_penalty;
   float patience;
   int32_t use_graph;            /* replay the decode step from a hipGraph */
-  int32_t reserved[5];
+  int32_t num_streams;          /* >1: split the batch into independent sub-batches decoded
+                                   concurrently on separate HIP streams of the SAME GPU (the
+                                   reference's several replicas per device, replica_pool.h:243-260);
+                                   0 = choose automatically */
+  int32_t reserved[4];
 };
 
 void ct2x_translation_options_default(struct ct2x_translation_options* opt);
