@@ -201,7 +201,7 @@ def main():
             "tokens_per_step_per_gpu": tokens // max(args.steps, 1),
             "parallelism": "replicas x%d (one process per GPU, no data-path collective)" % world,
             "hip_graph": not args.no_graph,
-            "streams_per_gpu": args.streams if args.streams > 0 else int(os.environ.get("CT2X_NUM_STREAMS", "4")),
+            "streams_per_gpu": args.streams if args.streams > 0 else int(os.environ.get("CT2X_NUM_STREAMS", "1")),
             "kernels_per_decode_step": stats["kernels_per_step"],
             "decode_ms_last_call": stats["decode_ms"],
             "encode_ms_last_call": stats["encode_ms"],

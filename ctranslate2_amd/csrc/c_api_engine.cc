@@ -272,7 +272,7 @@ int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t
   int32_t streams = opt.num_streams;
   if (streams <= 0) {
     const char* env = std::getenv("CT2X_NUM_STREAMS");
-    streams = env ? std::atoi(env) : 4;
+    streams = env ? std::atoi(env) : 1;
   }
   streams = std::max<int32_t>(1, std::min<int32_t>(streams, 16));
   if (t->engine->profiling()) streams = 1;  // event bookkeeping is single-stream
@@ -282,6 +282,10 @@ int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t
     const size_t per_stream = (order.size() + streams - 1) / streams;
     chunk = std::max<size_t>(1, std::min(chunk, per_stream));
   }
+  // Concurrent hipGraph captures from several threads are not reliable on ROCm 7.2 ("operation
+  // failed due to a previous error during capture"); concurrent sessions launch eagerly -- the
+  // host has a thread per stream, so launches still overlap across streams.
+  if (streams > 1) dopt.use_graph = false;
   std::vector<std::pair<size_t, size_t>> groups;
   for (size_t begin = 0; begin < order.size(); begin += chunk)
     groups.emplace_back(begin, std::min(order.size(), begin + chunk));
