@@ -62,17 +62,28 @@ struct AttnKernelArgs {
   int causal_tq;     // >0: rows are (batch, query i = row % causal_tq); keys limited to i+q_offset+1
   int64_t q_offset;
   int mask_tq;       // >0: rows are (batch, query) pairs without causality (encoder)
+  // kFusedQ outputs: the quantised context row and its scale
+  int8_t* q_out;
+  float* q_scales;
+  int quant_mode;
 };
 
-template <int G>
-__global__ __launch_bounds__(64) void attn_row_kernel(AttnKernelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float scores[];
+// kFusedQ = false: one wave64 workgroup per (row, head), fp32 context out.
+// kFusedQ = true : one workgroup per ROW with one wave per head; after PV the waves exchange their
+//                  |max| through LDS and emit the row already quantised for the following int8
+//                  Dense (ops::Quantize of the combined heads, src/layers/common.cc:389), so the
+//                  standalone quantize launch and the fp32 context round trip disappear.
+template <int G, bool kFusedQ>
+__global__ __launch_bounds__(kFusedQ ? 512 : 64) void attn_row_kernel(AttnKernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const AttnDecodeParams& p = a.p;
   constexpr int KPI = 64 / G;  // keys per iteration
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int kg = lane / G, c = lane % G;
-  const int64_t row = blockIdx.x / p.heads;
-  const int h = static_cast<int>(blockIdx.x % p.heads);
+  const int64_t row = kFusedQ ? static_cast<int64_t>(blockIdx.x) : blockIdx.x / p.heads;
+  const int h = kFusedQ ? wave : static_cast<int>(blockIdx.x % p.heads);
+  float* scores = smem + (kFusedQ ? static_cast<int64_t>(wave) * (p.t_max + 1) : 0);
   const int group = static_cast<int>(p.heads / p.heads_kv);
   const int hk = h / group;
   const int64_t kvrow = row / p.kv_group;
@@ -173,17 +184,8 @@ __global__ __launch_bounds__(64) void attn_row_kernel(AttnKernelArgs a) {
   __syncthreads();
 
   // ---- phase 2: softmax over [0, t_total) -------------------------------------------------
-  float* out = p.out + row * (p.heads * p.dhead) + static_cast<int64_t>(h) * p.dhead;
-  if (t_total == 0) {  // fully masked row: softmax output is all zeros -> context is zero
-    if (kg == 0) {
-#pragma unroll
-      for (int u = 0; u < kMaxChunks; ++u) {
-        const int cc = c + u * G;
-        if (cc < nc) *reinterpret_cast<float4*>(out + cc * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    return;
-  }
+  // A fully masked row (t_total == 0) has an all-zero softmax: the loops below do not execute and
+  // the context stays zero (no early return: the barriers must be reached by every wave).
   float m = -FLT_MAX;
   for (int64_t t = lane; t < t_total; t += 64) m = fmaxf(m, scores[t]);
   m = wave_max(m);
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(64) void attn_row_kernel(AttnKernelArgs a) {
     s += e;
   }
   s = wave_sum(s);
-  const float r = 1.f / s;
+  const float r = (t_total > 0) ? 1.f / s : 0.f;
   for (int64_t t = lane; t < t_total; t += 64) scores[t] = scores[t] * r;
   __syncthreads();
 
@@ -248,11 +250,50 @@ __global__ __launch_bounds__(64) void attn_row_kernel(AttnKernelArgs a) {
       acc[u].w += __shfl_xor(acc[u].w, o, 64);
     }
   }
+  if (!kFusedQ) {
+    float* out = p.out + row * (p.heads * p.dhead) + static_cast<int64_t>(h) * p.dhead;
+    if (kg == 0) {
+#pragma unroll
+      for (int u = 0; u < kMaxChunks; ++u) {
+        const int cc = c + u * G;
+        if (cc < nc) *reinterpret_cast<float4*>(out + cc * 4) = acc[u];
+      }
+    }
+    return;
+  }
+  // ---- fused ops::Quantize of the row [heads * dhead] (src/cpu/kernels.cc:577-620) ---------
+  float amax = 0.f;
   if (kg == 0) {
 #pragma unroll
     for (int u = 0; u < kMaxChunks; ++u) {
       const int cc = c + u * G;
-      if (cc < nc) *reinterpret_cast<float4*>(out + cc * 4) = acc[u];
+      if (cc < nc)
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc[u].x), fabsf(acc[u].y)),
+                                 fmaxf(fabsf(acc[u].z), fabsf(acc[u].w))));
+    }
+  }
+  amax = wave_max(amax);
+  float* wave_amax = smem + static_cast<int64_t>(p.heads) * (p.t_max + 1);
+  __syncthreads();
+  if (lane == 0) wave_amax[wave] = amax;
+  __syncthreads();
+  amax = wave_amax[0];
+  for (int w = 1; w < static_cast<int>(p.heads); ++w) amax = fmaxf(amax, wave_amax[w]);
+  const float qscale = (amax != 0.f) ? 127.f / amax : 1.f;
+  if (threadIdx.x == 0) a.q_scales[row] = qscale;
+  if (kg == 0) {
+    int8_t* qo = a.q_out + row * (p.heads * p.dhead) + static_cast<int64_t>(h) * p.dhead;
+#pragma unroll
+    for (int u = 0; u < kMaxChunks; ++u) {
+      const int cc = c + u * G;
+      if (cc < nc) {
+        char4 o;
+        o.x = to_s8(acc[u].x, qscale, a.quant_mode);
+        o.y = to_s8(acc[u].y, qscale, a.quant_mode);
+        o.z = to_s8(acc[u].z, qscale, a.quant_mode);
+        o.w = to_s8(acc[u].w, qscale, a.quant_mode);
+        *reinterpret_cast<char4*>(qo + cc * 4) = o;
+      }
     }
   }
 }
@@ -260,9 +301,15 @@ __global__ __launch_bounds__(64) void attn_row_kernel(AttnKernelArgs a) {
 template <int G>
 void launch_rows(const AttnKernelArgs& a, hipStream_t stream) {
   const AttnDecodeParams& p = a.p;
+  if (a.q_out != nullptr) {
+    const size_t lds = (static_cast<size_t>(p.heads) * (p.t_max + 1) + p.heads) * sizeof(float);
+    hipLaunchKernelGGL((attn_row_kernel<G, true>), dim3(static_cast<unsigned>(p.rows)),
+                       dim3(static_cast<unsigned>(p.heads * 64)), lds, stream, a);
+    return;
+  }
   const size_t lds = static_cast<size_t>(p.t_max + 1) * sizeof(float);
-  hipLaunchKernelGGL(attn_row_kernel<G>, dim3(static_cast<unsigned>(p.rows * p.heads)), dim3(64),
-                     lds, stream, a);
+  hipLaunchKernelGGL((attn_row_kernel<G, false>), dim3(static_cast<unsigned>(p.rows * p.heads)),
+                     dim3(64), lds, stream, a);
 }
 
 void dispatch(const AttnKernelArgs& a, hipStream_t stream) {
@@ -285,6 +332,29 @@ void launch_attention_decode(const AttnDecodeParams& p, hipStream_t stream) {
   a.causal_tq = 0;
   a.q_offset = 0;
   a.mask_tq = 0;
+  a.q_out = nullptr;
+  a.q_scales = nullptr;
+  a.quant_mode = 0;
+  dispatch(a, stream);
+}
+
+bool attention_decode_can_fuse_quantize(const AttnDecodeParams& p) {
+  // one wave per head in one workgroup, scores of every head in LDS
+  return p.heads >= 1 && p.heads <= 8 &&
+         (static_cast<size_t>(p.heads) * (p.t_max + 1) + p.heads) * sizeof(float) <= 60 * 1024;
+}
+
+void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
+                                       float* q_scales, hipStream_t stream) {
+  if (p.rows == 0) return;
+  AttnKernelArgs a;
+  a.p = p;
+  a.causal_tq = 0;
+  a.q_offset = 0;
+  a.mask_tq = 0;
+  a.q_out = q_out;
+  a.q_scales = q_scales;
+  a.quant_mode = quant_mode;
   dispatch(a, stream);
 }
 
@@ -317,6 +387,9 @@ void launch_attention_full(const AttnFullParams& f, hipStream_t stream) {
   a.causal_tq = f.causal ? static_cast<int>(f.tq) : 0;
   a.q_offset = f.q_offset;
   a.mask_tq = static_cast<int>(f.tq);
+  a.q_out = nullptr;
+  a.q_scales = nullptr;
+  a.quant_mode = 0;
   dispatch(a, stream);
 }
 

@@ -911,12 +911,21 @@ void Engine::launch_step(DecodeState& st) {
         p.rope_interleave = a.rotary_interleave;
       }
       p.out = st.ctx;
-      // K and V read once up to the current step (upper bound t_max/2 on average is not known
-      // on the host: the step lives on the device), q + out: reported with t = t_max.
-      begin_kernel("attention_self_decode", 0, 0, rows, a.heads, a.dhead);
-      launch_attention_decode(p, cur_stream());
-      end_kernel();
-      dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+      if (a.lin[1].quantized && attention_decode_can_fuse_quantize(p)) {
+        // attention + ops::Quantize of the context in one launch (kFusedQ)
+        begin_kernel("attention_self_decode_q", 0, 0, rows, a.heads, a.dhead);
+        launch_attention_decode_quantized(p, quant_mode_, st.qbuf, st.qscale, cur_stream());
+        end_kernel();
+        QuantIn cq;
+        cq.q = st.qbuf;
+        cq.s = st.qscale;
+        dense(a.lin[1], nullptr, &cq, rows, -1, a.ln.present ? x : nullptr, y, &st);
+      } else {
+        begin_kernel("attention_self_decode", 0, 0, rows, a.heads, a.dhead);
+        launch_attention_decode(p, cur_stream());
+        end_kernel();
+        dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+      }
       if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
       std::swap(x, y);
     }
@@ -954,12 +963,23 @@ void Engine::launch_step(DecodeState& st) {
       p.t_max = st.s_max;
       p.scale = a.queries_scale;
       p.out = st.ctx;
-      begin_kernel("attention_cross_decode",
-                   double(st.batch) * st.s_max * 2 * kvdim * 4 + double(rows) * a.heads * a.dhead * 8,
-                   double(rows) * a.heads * st.s_max * a.dhead * 4, rows, a.heads, a.dhead);
-      launch_attention_decode(p, cur_stream());
-      end_kernel();
-      dense(a.lin[2], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+      const double attn_bytes =
+          double(st.batch) * st.s_max * 2 * kvdim * 4 + double(rows) * a.heads * a.dhead * 8;
+      const double attn_ops = double(rows) * a.heads * st.s_max * a.dhead * 4;
+      if (a.lin[2].quantized && attention_decode_can_fuse_quantize(p)) {
+        begin_kernel("attention_cross_decode_q", attn_bytes, attn_ops, rows, a.heads, a.dhead);
+        launch_attention_decode_quantized(p, quant_mode_, st.qbuf, st.qscale, cur_stream());
+        end_kernel();
+        QuantIn cq;
+        cq.q = st.qbuf;
+        cq.s = st.qscale;
+        dense(a.lin[2], nullptr, &cq, rows, -1, a.ln.present ? x : nullptr, y, &st);
+      } else {
+        begin_kernel("attention_cross_decode", attn_bytes, attn_ops, rows, a.heads, a.dhead);
+        launch_attention_decode(p, cur_stream());
+        end_kernel();
+        dense(a.lin[2], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+      }
       if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
       std::swap(x, y);
     }

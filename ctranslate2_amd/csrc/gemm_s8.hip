@@ -153,11 +153,34 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
     GemmS8Epilogue ep) {
   __shared__ int partial[WAVES][MT][NT][64][4];
+  constexpr int THREADS = WAVES * 64;
+  constexpr int OUTS = MT * NT * 256;                       // outputs of the workgroup tile
+  constexpr int OPT = (OUTS + THREADS - 1) / THREADS;       // outputs per thread in the epilogue
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int64_t n0 = static_cast<int64_t>(blockIdx.x) * (NT * 16);
   const int ksteps = (K + 63) / 64;
+
+  // Epilogue operands are fetched FIRST so their latency hides under the weight stream: thread t
+  // finalises outputs t, t+THREADS, ... of the [MT*16, NT*16] tile, 16 consecutive threads = 16
+  // consecutive columns (coalesced 64-byte stores).
+  float e_ra[OPT], e_ws[OPT], e_bias[OPT], e_res[OPT];
+#pragma unroll
+  for (int o = 0; o < OPT; ++o) {
+    const int flat = tid + o * THREADS;
+    const int tile = flat >> 8, within = flat & 255;
+    const int row = (tile / NT) * 16 + (within >> 4);
+    const int64_t col = n0 + (tile % NT) * 16 + (within & 15);
+    e_ra[o] = e_ws[o] = 1.f;
+    e_bias[o] = e_res[o] = 0.f;
+    if (ep.mode == 1 && flat < OUTS && row < M && col < N) {
+      e_ra[o] = ep.a_scale[row];
+      e_ws[o] = ep.w_scale[col];
+      if (ep.bias) e_bias[o] = ep.bias[col];
+      if (ep.residual) e_res[o] = ep.residual[static_cast<int64_t>(row) * ep.ldy + col];
+    }
+  }
 
   v4i acc[MT][NT];
 #pragma unroll
@@ -200,26 +223,36 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) partial[wave][i][j][lane][e] = acc[i][j][e];
+      *reinterpret_cast<v4i*>(&partial[wave][i][j][lane][0]) = acc[i][j];
   __syncthreads();
 
-  // Tiles are distributed over the waves for the cross-wave sum + epilogue.
-  for (int t = wave; t < MT * NT; t += WAVES) {
-    const int i = t / NT, j = t % NT;
-    int sum[4] = {0, 0, 0, 0};
+  // Cross-wave sum (exact int32) + fused epilogue, spread over ALL threads of the workgroup.
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w)
+  for (int o = 0; o < OPT; ++o) {
+    const int flat = tid + o * THREADS;
+    if (flat >= OUTS) continue;
+    const int tile = flat >> 8, within = flat & 255;
+    const int i = tile / NT, j = tile % NT;
+    const int rt = within >> 4, ct = within & 15;
+    const int row = i * 16 + rt;
+    const int64_t col = n0 + j * 16 + ct;
+    // MFMA C layout: element (row rt, col ct) lives in lane (rt/4)*16 + ct, register rt%4.
+    const int src_lane = ((rt >> 2) << 4) | ct;
+    int sum = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sum[e] += partial[w][i][j][lane][e];
-    const int64_t col = n0 + j * 16 + r;
-    if (col >= N) continue;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t row = i * 16 + g * 4 + e;
-      if (row >= M) continue;
-      const float r_a = (ep.mode == 1) ? 1.f / ep.a_scale[row] : 0.f;
-      store_epilogue(ep, row, col, sum[e], r_a);
+    for (int w = 0; w < WAVES; ++w) sum += partial[w][i][j][src_lane][rt & 3];
+    if (row >= M || col >= N) continue;
+    const int64_t idx = static_cast<int64_t>(row) * ep.ldy + col;
+    if (ep.mode == 0) {
+      ep.c_i32[idx] = sum;
+    } else {
+      // CPU formula order (src/cpu/kernels.cc:666-673): c * (1/a_scale) / b_scale + bias.
+      float v = static_cast<float>(sum) * (1.f / e_ra[o]);
+      v = v / e_ws[o];
+      if (ep.bias) v = v + e_bias[o];
+      v = apply_activation(v, ep.act);
+      if (ep.residual) v = e_res[o] + v;
+      ep.y[idx] = v;
     }
   }
 }

@@ -121,6 +121,12 @@ struct AttnDecodeParams {
 
 void launch_attention_decode(const AttnDecodeParams& p, hipStream_t stream);
 
+// Same attention with ops::Quantize of the combined-heads context fused in (one workgroup per
+// row): writes q_out [rows, heads*dhead] int8 + q_scales [rows] instead of p.out.
+bool attention_decode_can_fuse_quantize(const AttnDecodeParams& p);
+void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
+                                       float* q_scales, hipStream_t stream);
+
 // Full (prefill / encoder) attention: q [B, Tq, H, dh] (row stride given), k/v with strides,
 // lengths[b] valid keys, causal => key t visible to query i iff t <= i + q_offset.
 struct AttnFullParams {
