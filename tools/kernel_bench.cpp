@@ -79,6 +79,19 @@ int main(int argc, char** argv) {
     const double bytes = (double)M * sh.k + (double)sh.n * sh.k + 4.0 * sh.n + 4.0 * M + 4.0 * M * sh.n;
     run(name, bytes, [&] { CX(ct2x_gemm_s8_dequant(q, qs, sh.k == 2048 ? w2 : w, wscale, bias, nullptr, M, sh.n, sh.k, -1, y, 0, s)); });
   }
+  {
+    // Same GEMM, but cycling through 152 distinct 256 KB weight matrices (38 MB, the per-step
+    // weight footprint of Transformer-base): what the decode loop sees, where a weight byte is
+    // never L2-resident from the previous step.
+    int8_t* wbig = dalloc<int8_t>((size_t)152 * 512 * 512);
+    int idx = 0;
+    run("gemm_s8_dequant [M,512,512] rotating 38MB weights", (double)M * 512 + 512.0 * 512 + 4.0 * M * 512,
+        [&] { CX(ct2x_gemm_s8_dequant(q, qs, wbig + (size_t)(idx++ % 152) * 512 * 512, wscale, bias, nullptr, M, 512, 512, -1, y, 0, s)); });
+    int8_t* wbig2 = dalloc<int8_t>((size_t)40 * 512 * 2048);
+    idx = 0;
+    run("gemm_s8_dequant [M,2048,512] rotating 40MB weights", (double)M * 512 + 2048.0 * 512 + 4.0 * M * 2048,
+        [&] { CX(ct2x_gemm_s8_dequant(q, qs, wbig2 + (size_t)(idx++ % 40) * 512 * 2048, wscale, bias, nullptr, M, 2048, 512, -1, y, 0, s)); });
+  }
   run("gemm_s8_dequant+residual [M,512,512]", 0, [&] { CX(ct2x_gemm_s8_dequant(q, qs, w, wscale, bias, res, M, 512, 512, -1, y, 0, s)); });
   for (int t : {1, 16, 32, 64}) {
     char name[128]; snprintf(name, sizeof name, "attention_decode rows=%d H=8 dh=64 T=%d", M, t);
