@@ -28,7 +28,7 @@ class TranslationResult:
         return "TranslationResult(hypotheses=%r, scores=%r)" % (self.hypotheses, self.scores)
 
 
-class Translator:
+class Translator:  # also serves decoder-only models (ctranslate2.Generator) via generate_ids
     """ctranslate2.Translator for converted models, on one MI355X.
 
     Arguments follow the reference (python/cpp/translator.cc:286-297). `device` must be "cuda"
@@ -146,6 +146,28 @@ class Translator:
             sc = [float(scores[b, k]) for k in range(len(sent_hyps))] if return_scores else []
             results.append(TranslationResult(tokens, sc, sent_hyps))
         return results
+
+    def generate_ids(self, prompts: Sequence[Sequence[int]], max_length: int = 512,
+                     min_length: int = 0, return_scores: bool = False,
+                     return_end_token: bool = False, use_graph: bool = True):
+        """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False,
+        sampling_topk=1 (greedy). Returns (generated ids per prompt, scores)."""
+        batch = len(prompts)
+        lengths = np.array([len(p) for p in prompts], np.int32)
+        stride = int(lengths.max())
+        ids = np.zeros((batch, stride), np.int32)
+        for i, p in enumerate(prompts):
+            ids[i, :len(p)] = p
+        out = np.zeros((batch, max_length), np.int32)
+        out_len = np.zeros((batch,), np.int32)
+        scores = np.zeros((batch,), np.float32)
+        opt = self._options(1, max_length, min_length, 1, return_scores, return_end_token, 0, 0,
+                            1.0, 1.0, use_graph, 1)
+        opt.length_penalty = 1.0
+        _lib.check(self._L.ct2x_generate_batch(
+            C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
+            C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
+        return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
 
     def step_logits(self, source_ids, target_in):
         """Teacher-forced per-step logits [T, batch, vocab] (source ids INCLUDE special tokens)."""

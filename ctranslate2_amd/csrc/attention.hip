@@ -394,6 +394,60 @@ void launch_attention_full(const AttnFullParams& f, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Prefill: scatter a fused QKV projection into the rotated query buffer and the KV caches.
+// ---------------------------------------------------------------------------------------
+__global__ void qkv_to_cache_kernel(const float* __restrict__ qkv, int64_t time, int64_t heads,
+                                    int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t pos0,
+                                    const float* __restrict__ rope_sin,
+                                    const float* __restrict__ rope_cos, int64_t rot_dim,
+                                    bool interleave, float* __restrict__ q_out,
+                                    float* __restrict__ cache_k, float* __restrict__ cache_v) {
+  const int64_t row = blockIdx.x;  // (b, t)
+  const int64_t b = row / time, t = row % time;
+  const int64_t pos = pos0 + t;
+  const int64_t qdim = heads * dhead, kvdim = heads_kv * dhead;
+  const float* src = qkv + row * (qdim + 2 * kvdim);
+  const float* s = rope_sin ? rope_sin + pos * rot_dim : nullptr;
+  const float* c = rope_cos ? rope_cos + pos * rot_dim : nullptr;
+  const int64_t middle = rot_dim / 2;
+  // q heads then k heads: same rotation (reference formula src/ops/rotary_cpu.cc:31-36)
+  for (int64_t e = threadIdx.x; e < qdim + kvdim; e += blockDim.x) {
+    const bool is_q = e < qdim;
+    const int64_t local = is_q ? e : e - qdim;
+    const int64_t h = local / dhead, i = local % dhead;
+    const float* x = src + (is_q ? 0 : qdim) + h * dhead;
+    float v = x[i];
+    if (s != nullptr && i < rot_dim) {
+      float other;
+      if (interleave)
+        other = (i % 2 == 0) ? -x[i + 1] : x[i - 1];
+      else
+        other = (i < middle) ? -x[i + middle] : x[i - middle];
+      v = x[i] * c[i] + other * s[i];
+    }
+    if (is_q)
+      q_out[row * qdim + e] = v;
+    else
+      cache_k[((b * heads_kv + h) * t_max + pos) * dhead + i] = v;
+  }
+  for (int64_t e = threadIdx.x; e < kvdim; e += blockDim.x) {
+    const int64_t h = e / dhead, i = e % dhead;
+    cache_v[((b * heads_kv + h) * t_max + pos) * dhead + i] = src[qdim + kvdim + e];
+  }
+}
+
+void launch_qkv_to_cache(const float* qkv, int64_t batch, int64_t time, int64_t heads,
+                         int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t pos0,
+                         const float* rope_sin, const float* rope_cos, int64_t rot_dim,
+                         bool interleave, float* q_out, float* cache_k, float* cache_v,
+                         hipStream_t stream) {
+  if (batch * time == 0) return;
+  hipLaunchKernelGGL(qkv_to_cache_kernel, dim3(static_cast<unsigned>(batch * time)), dim3(256), 0,
+                     stream, qkv, time, heads, heads_kv, dhead, t_max, pos0, rope_sin, rope_cos,
+                     rot_dim, interleave, q_out, cache_k, cache_v);
+}
+
+// ---------------------------------------------------------------------------------------
 // Beam reorder of the pre-allocated self-attention caches (Decoder::update_state ->
 // ops::Gather on every cache tensor, src/layers/decoder.cc:33-56): only the `len` live
 // positions of each (row, head) are moved, src -> dst (ping-pong buffers).

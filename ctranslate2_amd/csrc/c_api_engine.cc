@@ -368,13 +368,70 @@ int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t
   API_CATCH
 }
 
-int ct2x_generate_batch(void* translator, const int32_t*, const int32_t*, int32_t, int32_t,
-                        const struct ct2x_translation_options*, int32_t*, int32_t*, float*) {
+int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
+                        const int32_t* prompt_lengths, int32_t batch, int32_t stride,
+                        const struct ct2x_translation_options* opt_in, int32_t* out_ids,
+                        int32_t* out_lengths, float* out_scores) {
   API_TRY
   auto* t = static_cast<Translator*>(translator);
   CT2X_CHECK(t != nullptr, "null translator");
-  throw Error("ct2x_generate_batch: decoder-only generation (prompt prefill) is not built in "
-              "this round");
+  std::lock_guard<std::mutex> lock(t->mutex);
+  CT2X_CHECK(!t->engine->is_seq2seq(), "This model cannot be used as a sequence generator");
+  // DecoderReplica::run_generation with include_prompt_in_result = false
+  // (src/models/language_model.cc:150-282): all but the last prompt token are consumed by one
+  // sequence-mode pass, decoding starts from the last prompt token at step = prompt_length - 1.
+  ct2x_translation_options opt = *opt_in;
+  DecodingOptions dopt = to_decoding_options(opt);
+  validate_decoding_options(dopt);
+  CT2X_CHECK(dopt.beam_size == 1, "generate_batch: beam search over a prefilled prompt is not "
+             "supported by this backend yet (greedy only)");
+  CT2X_CHECK(batch > 0, "No decoder start tokens are set");
+  const int32_t plen = prompt_lengths[0];
+  CT2X_CHECK(plen >= 1, "generate_batch: empty prompt");
+  for (int32_t b = 1; b < batch; ++b)
+    CT2X_CHECK(prompt_lengths[b] == plen, "generate_batch: prompts of different lengths are not "
+               "supported by this backend yet");
+  const int32_t forward_length = plen - 1;
+  const double t0 = now_ms();
+  t->last = ct2x_exec_stats{};
+  const int64_t t_max = static_cast<int64_t>(forward_length) + dopt.max_length + 1;
+  auto st = t->engine->start_decoder_only(batch, 1, t_max, forward_length);
+  std::vector<int32_t> prefix(static_cast<size_t>(batch) * std::max(forward_length, 1));
+  std::vector<int32_t> start_ids(batch);
+  for (int32_t b = 0; b < batch; ++b) {
+    for (int32_t i = 0; i < forward_length; ++i)
+      prefix[static_cast<size_t>(b) * forward_length + i] = prompt_ids[static_cast<int64_t>(b) * stride + i];
+    start_ids[b] = prompt_ids[static_cast<int64_t>(b) * stride + plen - 1];
+  }
+  const double te0 = now_ms();
+  if (forward_length > 0) t->engine->prefill(*st, prefix.data(), forward_length);
+  t->engine->synchronize();
+  const double te1 = now_ms();
+  dopt.start_step = forward_length;
+  DecodeStats ds;
+  std::vector<DecodingResult> results =
+      greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds);
+  t->engine->synchronize();
+  const double te2 = now_ms();
+  const int32_t max_len = opt.max_decoding_length;
+  for (int32_t b = 0; b < batch; ++b) {
+    auto& hyp = results[b].hypotheses[0];
+    if (!opt.return_end_token)
+      while (!hyp.empty() && hyp.back() == t->eos_id) hyp.pop_back();
+    const int32_t len = static_cast<int32_t>(hyp.size());
+    std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
+              out_ids + static_cast<int64_t>(b) * max_len);
+    out_lengths[b] = len;
+    if (opt.return_scores && out_scores && !results[b].scores.empty())
+      out_scores[b] = results[b].scores[0];
+    t->last.num_tokens += len;
+  }
+  t->last.num_examples = batch;
+  t->last.decode_steps = ds.steps;
+  t->last.kernels_per_step = t->engine->kernels_per_step();
+  t->last.encode_ms = te1 - te0;  // prompt prefill
+  t->last.decode_ms = te2 - te1;
+  t->last.total_ms = now_ms() - t0;
   API_CATCH
 }
 

@@ -626,8 +626,11 @@ T* alloc(DecodeState& st, int64_t count) {
 }  // namespace
 
 std::unique_ptr<DecodeState> Engine::start_decoder_only(int64_t batch, int64_t beam,
-                                                        int64_t t_max) {
-  return start(nullptr, nullptr, batch, 0, beam, t_max);
+                                                        int64_t t_max, int64_t prefill_len) {
+  pending_prefill_len_ = prefill_len;
+  auto st = start(nullptr, nullptr, batch, 0, beam, t_max);
+  pending_prefill_len_ = 0;
+  return st;
 }
 
 std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t* src_lengths,
@@ -653,7 +656,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     qkv_dim = std::max(qkv_dim, l.self.lin[0].n);
   }
   // Workspace sized for the larger of the decode rows and the encoder rows.
-  const int64_t enc_rows = has_encoder_ ? batch * s_max : 0;
+  const int64_t enc_rows = has_encoder_ ? batch * s_max : batch * pending_prefill_len_;
+  st->prefill_max = pending_prefill_len_;
   int64_t enc_ffn = 0, enc_qkv = 0;
   for (const auto& l : enc_.layers) {
     enc_ffn = std::max(enc_ffn, l.ffn.l0.n);
@@ -803,33 +807,7 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
     std::swap(x, y);
 
     // --- feed forward (FeedForwardNetwork::operator(), src/layers/transformer.cc:21-51)
-    const FfnW& ffn = layer.ffn;
-    QuantIn fq;
-    const float* ffn_in = x;
-    if (ffn.ln.present && enc_.pre_norm) {
-      if (ffn.l0.quantized) {
-        norm_quant(ffn.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
-        fq.q = st.qbuf;
-        fq.s = st.qscale;
-      } else {
-        norm(ffn.ln, x, rows, d, st.ctx);
-        ffn_in = st.ctx;
-      }
-    } else if (ffn.l0.quantized && ffn.l0_noact.present) {
-      quant(x, rows, d, st.qbuf, st.qscale);
-      fq.q = st.qbuf;
-      fq.s = st.qscale;
-    }
-    dense(ffn.l0, ffn_in, fq.q ? &fq : nullptr, rows, ffn.activation, nullptr, st.inner, &st);
-    if (ffn.l0_noact.present) {
-      dense(ffn.l0_noact, ffn_in, fq.q ? &fq : nullptr, rows, -1, nullptr, st.inner2, &st);
-      begin_kernel("mul");
-      launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, cur_stream());
-      end_kernel();
-    }
-    dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
-    if (ffn.ln.present && !enc_.pre_norm) norm(ffn.ln, y, rows, d, y);
-    std::swap(x, y);
+    run_ffn(layer.ffn, enc_.pre_norm, rows, d, x, y, st);
   }
   if (enc_.output_norm.present) norm(enc_.output_norm, x, rows, d, x);
 
@@ -850,6 +828,133 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
     dense(a.lin[1], x, mq.q ? &mq : nullptr, rows, -1, nullptr, st.cross_kv[l], &st);
   }
   check_last_launch("encode");
+}
+
+// FeedForwardNetwork::operator() (src/layers/transformer.cc:21-51): pre-norm -> Dense+act
+// [-> x Dense-noact (GLU)] -> Dense + residual -> post-norm. x is the sub-layer input, the result
+// lands in y and the pointers are swapped so that x is the output on return.
+void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, float*& x, float*& y,
+                     DecodeState& st) {
+  QuantIn fq;
+  const float* ffn_in = x;
+  if (ffn.ln.present && pre_norm) {
+    if (ffn.l0.quantized) {
+      norm_quant(ffn.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
+      fq.q = st.qbuf;
+      fq.s = st.qscale;
+    } else {
+      norm(ffn.ln, x, rows, d, st.ctx);
+      ffn_in = st.ctx;
+    }
+  } else if (ffn.l0.quantized && ffn.l0_noact.present) {
+    quant(x, rows, d, st.qbuf, st.qscale);
+    fq.q = st.qbuf;
+    fq.s = st.qscale;
+  }
+  dense(ffn.l0, ffn_in, fq.q ? &fq : nullptr, rows, ffn.activation, nullptr, st.inner, &st);
+  if (ffn.l0_noact.present) {
+    dense(ffn.l0_noact, ffn_in, fq.q ? &fq : nullptr, rows, -1, nullptr, st.inner2, &st);
+    begin_kernel("mul");
+    launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, cur_stream());
+    end_kernel();
+  }
+  dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
+  if (ffn.ln.present && !pre_norm) norm(ffn.ln, y, rows, d, y);
+  std::swap(x, y);
+}
+
+// Sequence-mode forward of a decoder-only model over the prompt (TransformerDecoder::decode with
+// lengths, src/layers/transformer.cc:673-696; DecoderReplica::run_generation prefill,
+// src/models/language_model.cc:217-238): fills the self-attention caches for positions
+// [0, time) of every row and leaves the step counter at `time`. No logits are produced.
+void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time) {
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  tls_stream = st.stream;
+  CT2X_CHECK(!has_encoder_, "prefill is only defined for decoder-only models");
+  CT2X_CHECK(st.beam == 1, "prefill expects an unexpanded batch");
+  CT2X_CHECK(time <= st.t_max && time <= st.prefill_max, "prompt longer than the decoding state");
+  if (time == 0) return;
+  const int64_t B = st.rows, d = dec_.d_model, rows = B * time;
+  int32_t* d_prompt = nullptr;
+  {
+    void* p = device_malloc(sizeof(int32_t) * rows);
+    st.owned.push_back(p);
+    d_prompt = static_cast<int32_t*>(p);
+  }
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_prompt, h_ids, sizeof(int32_t) * rows, hipMemcpyHostToDevice,
+                                cur_stream()));
+  const float* pos = dec_.position_table;
+  if (dec_.sinusoidal_positions) pos = sinusoidal_table(st.t_max, d);
+  float* x = st.x0;
+  float* y = st.x1;
+  begin_kernel("embed");
+  launch_embed(dec_.emb.table, dec_.emb.is_int8, dec_.emb.scale, d_prompt, rows, d,
+               dec_.embeddings_scale, dec_.scale_embeddings, pos, time, 0, nullptr, x,
+               cur_stream());
+  end_kernel();
+  if (dec_.layernorm_embedding.present) norm(dec_.layernorm_embedding, x, rows, d, x);
+
+  for (size_t l = 0; l < dec_.layers.size(); ++l) {
+    const LayerW& layer = dec_.layers[l];
+    const AttnW& a = layer.self;
+    QuantIn qin;
+    const float* attn_in = x;
+    if (a.ln.present && dec_.pre_norm) {
+      if (a.lin[0].quantized) {
+        norm_quant(a.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
+        qin.q = st.qbuf;
+        qin.s = st.qscale;
+      } else {
+        norm(a.ln, x, rows, d, st.ctx);
+        attn_in = st.ctx;
+      }
+    }
+    dense(a.lin[0], attn_in, qin.q ? &qin : nullptr, rows, -1, nullptr, st.qkv, &st);
+    const float *rs = nullptr, *rc = nullptr;
+    int64_t rot_dim = 0;
+    if (a.rotary) {
+      rotary_tables(a, st.t_max + 1, &rs, &rc);
+      rot_dim = a.rotary_dim == 0 ? a.dhead : a.rotary_dim;
+    }
+    float* q_rot = st.inner;  // [rows, heads*dhead]; dead before the FFN reuses the buffer
+    begin_kernel("qkv_to_cache");
+    launch_qkv_to_cache(st.qkv, B, time, a.heads, a.heads_kv, a.dhead, st.t_max, 0, rs, rc, rot_dim,
+                        a.rotary_interleave, q_rot, st.self_k[st.cur][l], st.self_v[st.cur][l],
+                        cur_stream());
+    end_kernel();
+    AttnFullParams f;
+    f.q = q_rot;
+    f.q_batch_stride = time * a.heads * a.dhead;
+    f.q_time_stride = a.heads * a.dhead;
+    f.k = st.self_k[st.cur][l];
+    f.v = st.self_v[st.cur][l];
+    f.k_batch_stride = f.v_batch_stride = a.heads_kv * st.t_max * a.dhead;
+    f.k_head_stride = f.v_head_stride = st.t_max * a.dhead;
+    f.k_time_stride = f.v_time_stride = a.dhead;
+    f.lengths = nullptr;
+    f.batch = B;
+    f.tq = time;
+    f.tk = time;
+    f.heads = a.heads;
+    f.heads_kv = a.heads_kv;
+    f.dhead = a.dhead;
+    f.causal = true;
+    f.q_offset = 0;
+    f.scale = a.queries_scale;
+    f.out = st.ctx;
+    begin_kernel("attention_prefill", 0, 0, rows, a.heads, a.dhead);
+    launch_attention_full(f, cur_stream());
+    end_kernel();
+    dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+    if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
+    std::swap(x, y);
+    run_ffn(layer.ffn, dec_.pre_norm, rows, d, x, y, st);
+  }
+  const int32_t step = static_cast<int32_t>(time);
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.d_step, &step, sizeof(int32_t), hipMemcpyHostToDevice,
+                                cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+  check_last_launch("prefill");
 }
 
 // TransformerDecoder::decode for one step (src/layers/transformer.cc:621-871) with
@@ -984,35 +1089,7 @@ void Engine::launch_step(DecodeState& st) {
       std::swap(x, y);
     }
     // ---- feed forward ----------------------------------------------------------------------
-    {
-      const FfnW& ffn = layer.ffn;
-      QuantIn fq;
-      const float* ffn_in = x;
-      if (ffn.ln.present && dec_.pre_norm) {
-        if (ffn.l0.quantized) {
-          norm_quant(ffn.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
-          fq.q = st.qbuf;
-          fq.s = st.qscale;
-        } else {
-          norm(ffn.ln, x, rows, d, st.ctx);
-          ffn_in = st.ctx;
-        }
-      } else if (ffn.l0.quantized && ffn.l0_noact.present) {
-        quant(x, rows, d, st.qbuf, st.qscale);
-        fq.q = st.qbuf;
-        fq.s = st.qscale;
-      }
-      dense(ffn.l0, ffn_in, fq.q ? &fq : nullptr, rows, ffn.activation, nullptr, st.inner, &st);
-      if (ffn.l0_noact.present) {
-        dense(ffn.l0_noact, ffn_in, fq.q ? &fq : nullptr, rows, -1, nullptr, st.inner2, &st);
-        begin_kernel("mul");
-        launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, cur_stream());
-        end_kernel();
-      }
-      dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
-      if (ffn.ln.present && !dec_.pre_norm) norm(ffn.ln, y, rows, d, y);
-      std::swap(x, y);
-    }
+    run_ffn(layer.ffn, dec_.pre_norm, rows, d, x, y, st);
   }
 
   // Final norm + vocabulary projection (transformer.cc:842-855).

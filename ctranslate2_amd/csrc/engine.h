@@ -125,7 +125,10 @@ public:
   std::unique_ptr<DecodeState> start(const int32_t* src_ids, const int32_t* src_lengths,
                                      int64_t batch, int64_t s_max, int64_t beam, int64_t t_max);
   // Decoder-only models: no encoder; the prompt is consumed by prefill().
-  std::unique_ptr<DecodeState> start_decoder_only(int64_t batch, int64_t beam, int64_t t_max);
+  std::unique_ptr<DecodeState> start_decoder_only(int64_t batch, int64_t beam, int64_t t_max,
+                                                  int64_t prefill_len = 0);
+  // Consumes `time` prompt tokens per row (h_ids [rows, time]) in one sequence-mode pass.
+  void prefill(DecodeState& state, const int32_t* h_ids, int64_t time);
 
   // One decoder step over state.rows rows: reads token ids from state.d_ids and the step index
   // from state.d_step (device memory), leaves logits in state.logits [rows, vocab].
@@ -200,6 +203,8 @@ private:
   void quant(const float* x, int64_t rows, int64_t depth, int8_t* q, float* s);
 
   void encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_lengths);
+  void run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, float*& x, float*& y,
+               DecodeState& st);
   void launch_step(DecodeState& st);
   const float* sinusoidal_table(int64_t positions, int64_t depth);
   void rotary_tables(const AttnW& a, int64_t positions, const float** sin, const float** cos);
@@ -217,6 +222,7 @@ private:
   StackW enc_, dec_;
   std::vector<void*> device_blocks_;
   int64_t weight_bytes_ = 0;
+  int64_t pending_prefill_len_ = 0;  // set around start() by start_decoder_only (translator mutex held)
   std::atomic<int64_t> launch_counter_{0};
   std::mutex table_mutex_;
   bool profiling_ = false;
@@ -240,7 +246,7 @@ private:
 struct DecodeState {
   Engine* engine = nullptr;
   hipStream_t stream = nullptr;  // all work of this session is enqueued here
-  int64_t batch = 0, beam = 1, rows = 0, t_max = 0, s_max = 0;
+  int64_t batch = 0, beam = 1, rows = 0, t_max = 0, s_max = 0, prefill_max = 0;
   // device buffers (owned; released in the destructor through the caching allocator)
   std::vector<void*> owned;
   float* x0 = nullptr;       // residual stream [rows, d]

@@ -147,6 +147,17 @@ struct AttnFullParams {
 
 void launch_attention_full(const AttnFullParams& p, hipStream_t stream);
 
+// Prefill helper: for every (row = (b, t), head) of a fused QKV projection [R, q_dim + 2*kv_dim]
+// (R = batch * time): q -> q_out [R, q_dim] (RoPE applied at position pos0 + t when tables are
+// given), k -> cache_k[b, hk, pos0 + t, :] (RoPE applied), v -> cache_v[b, hk, pos0 + t, :].
+// Replaces split_heads + Rotary + the cache Concat of sequence-mode decoding
+// (src/layers/attention.cc:514-546).
+void launch_qkv_to_cache(const float* qkv, int64_t batch, int64_t time, int64_t heads,
+                         int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t pos0,
+                         const float* rope_sin, const float* rope_cos, int64_t rot_dim,
+                         bool interleave, float* q_out, float* cache_k, float* cache_v,
+                         hipStream_t stream);
+
 // Beam reorder of pre-allocated caches: for each tensor t in [0, n_tensors):
 //   dst[t][r, :, 0:len, :] = src[t][parent[r], :, 0:len, :]
 // `tensors_src/dst` are device arrays of base pointers.

@@ -101,9 +101,35 @@ def main():
         golden[key + "_f32"] = run_case(d, "float32", sources, V, False, [1], cfg["max_len"],
                                         cfg["min_len"], min(cfg["logits_steps"], 16),
                                         "float32 compute on the int8 model " + key)
+    # (c) synthetic decoder-only models through Generator::generate_batch
+    # (include_prompt_in_result=False, greedy) + teacher-forced logits over prompt + continuation.
+    for key, cfg in GC.SYNTHETIC_LM.items():
+        d = "/tmp/ct2x_golden_%s" % key
+        mb.build_decoder_lm(d, **cfg["model"])
+        rng = np.random.default_rng(cfg["data_seed"])
+        V = cfg["model"]["vocab_size"]
+        prompts = [rng.integers(4, V, cfg["prompt_len"]).tolist() for _ in range(cfg["batch"])]
+        for ct, suffix in (("int8", ""), ("float32", "_f32")):
+            m = R.RefModel(d, ct, 1, 0)
+            gen, scores = m.generate_ids(prompts, max_len=cfg["max_len"], min_len=cfg["max_len"],
+                                         return_scores=True)
+            full = [p + g for p, g in zip(prompts, gen)]
+            tgt_in = np.array([f[:-1] for f in full], np.int32)
+            logits = m.step_logits([], tgt_in, V)
+            rng2 = np.random.default_rng(1234)
+            cols = np.sort(rng2.choice(V, size=min(16, V), replace=False))
+            top2 = np.sort(logits, axis=-1)[..., -2:][..., ::-1]
+            golden[key + suffix] = {
+                "compute_type": m.compute_type(), "prompts": prompts, "max_len": cfg["max_len"],
+                "generated": gen, "scores": scores.tolist(),
+                "teacher_forced": {"tgt_in": tgt_in.tolist(), "argmax": logits.argmax(-1).tolist(),
+                                   "top2": top2.tolist(), "cols": cols.tolist(),
+                                   "values": logits[..., cols].tolist()},
+            }
+            m.close()
     with open(os.path.join(HERE, "model_golden.json"), "w") as f:
         json.dump(golden, f)
-    print({k: list(v["runs"].keys()) for k, v in golden.items()})
+    print({k: list(v.get("runs", {"generate": 0}).keys()) for k, v in golden.items()})
     print(golden["aren-transliteration-i8"]["first_output_tokens"],
           golden["aren-transliteration-i8"]["runs"]["beam1"]["scores"][0])
 

@@ -37,3 +37,17 @@ SYNTHETIC = {
         "max_len": 64, "min_len": 64, "logits_steps": 64,
     },
 }
+
+# Synthetic decoder-only (Llama-shaped: RMSNorm, RoPE non-interleaved, GQA, SwiGLU) models.
+SYNTHETIC_LM = {
+    "lm_tiny": {
+        "model": dict(num_layers=2, d_model=64, ffn_dim=128, num_heads=4, num_heads_kv=2,
+                      vocab_size=100, seed=5),
+        "data_seed": 7, "batch": 4, "prompt_len": 6, "max_len": 12,
+    },
+    "lm_small": {
+        "model": dict(num_layers=4, d_model=256, ffn_dim=512, num_heads=8, num_heads_kv=2,
+                      vocab_size=2000, seed=6, w_std=0.05),
+        "data_seed": 8, "batch": 6, "prompt_len": 16, "max_len": 16,
+    },
+}

@@ -1,0 +1,106 @@
+"""-m gpu parity for decoder-only (Llama-shaped) models: ctranslate2_amd generate_ids (prompt
+prefill in one sequence-mode pass + device-resident greedy loop; RMSNorm, RoPE, GQA without head
+replication, SwiGLU) against golden outputs of the REAL reference Generator::generate_batch
+(tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as GC
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+LOGIT_TOL = 1e-3
+
+_models = {}
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "model_golden.json")) as f:
+        return json.load(f)
+
+
+def get_lm(key, compute_type):
+    import ctranslate2_amd as ct2
+    from ctranslate2_amd import model_builder as mb
+    ck = (key, compute_type)
+    if ck not in _models:
+        path = "/tmp/ct2x_test_%s" % key
+        if not os.path.exists(os.path.join(path, "model.bin")):
+            mb.build_decoder_lm(path, **GC.SYNTHETIC_LM[key]["model"])
+        _models[ck] = ct2.Translator(path, device="cuda", compute_type=compute_type)
+    return _models[ck]
+
+
+@pytest.mark.parametrize("key", ["lm_tiny", "lm_small"])
+def test_teacher_forced_logits_float32(gpu, golden, key):
+    g = golden[key + "_f32"]
+    t = get_lm(key, "float32")
+    assert not t.is_seq2seq
+    tf = g["teacher_forced"]
+    logits = t.step_logits([], np.array(tf["tgt_in"], np.int32))
+    cols = np.array(tf["cols"])
+    err = np.abs(logits[..., cols] - np.array(tf["values"], np.float32))
+    print("%s f32: max |logit - ref| = %.3e" % (key, err.max()))
+    assert err.max() < LOGIT_TOL
+    top2 = np.array(tf["top2"])
+    decided = (top2[..., 0] - top2[..., 1]) > 2 * LOGIT_TOL
+    assert np.array_equal(logits.argmax(-1)[decided], np.array(tf["argmax"])[decided])
+
+
+@pytest.mark.parametrize("key", ["lm_tiny", "lm_small"])
+@pytest.mark.parametrize("ct", ["float32", "int8"])
+def test_generate_matches_reference(gpu, golden, key, ct):
+    """Prefill (sequence mode) + greedy continuation. float32: token-identical. int8: identical up
+    to the first position where the reference's own margin is inside the re-quantisation noise
+    (see test_translator_gpu.test_teacher_forced_logits_int8)."""
+    g = golden[key + ("_f32" if ct == "float32" else "")]
+    t = get_lm(key, ct)
+    gen, scores = t.generate_ids(g["prompts"], max_length=g["max_len"], min_length=g["max_len"],
+                                 return_scores=True)
+    ref = g["generated"]
+    identical = sum(int(a == b) for a, b in zip(gen, ref))
+    print("%s %s: %d/%d continuations token-identical" % (key, ct, identical, len(ref)))
+    assert all(len(a) == g["max_len"] for a in gen)
+    if ct == "float32":
+        assert gen == ref
+        np.testing.assert_allclose(scores, np.array(g["scores"], np.float32), atol=1e-3)
+    else:
+        tf = g["teacher_forced"]
+        top2 = np.array(tf["top2"])
+        margin = top2[..., 0] - top2[..., 1]  # [T, B], T = prompt + continuation - 1
+        std = float(np.array(tf["values"]).std())
+        plen = len(g["prompts"][0])
+        for b, (a, r) in enumerate(zip(gen, ref)):
+            if a == r:
+                continue
+            first = next(i for i, (x, y) in enumerate(zip(a, r)) if x != y)
+            assert margin[plen - 1 + first, b] < 0.3 * std
+        assert identical >= len(ref) // 2
+
+
+def test_prefill_equals_stepwise(gpu, golden):
+    """The sequence-mode prefill must leave the same caches as feeding the prompt token by token
+    (tests/model_test.cc:99-151 DecoderIterativeSequence): the continuation after a prefilled
+    prompt equals the continuation computed by teacher-forced single steps."""
+    key = "lm_small"
+    g = golden[key + "_f32"]
+    t = get_lm(key, "float32")
+    prompts = g["prompts"]
+    gen, _ = t.generate_ids(prompts, max_length=4, min_length=4)
+    # teacher-forced step logits over prompt + generated tokens (token-by-token path)
+    full = np.array([p + c for p, c in zip(prompts, gen)], np.int32)
+    logits = t.step_logits([], full[:, :-1])
+    plen = len(prompts[0])
+    stepwise = logits.argmax(-1)[plen - 1:, :].T.tolist()
+    assert stepwise == gen
+
+
+def test_ragged_prompts_are_rejected_loudly(gpu):
+    import ctranslate2_amd as ct2
+    t = get_lm("lm_tiny", "int8")
+    with pytest.raises(ct2.Ct2xError):
+        t.generate_ids([[5, 6, 7], [5, 6]], max_length=4)
