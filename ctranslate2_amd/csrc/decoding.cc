@@ -75,21 +75,37 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
 
   const int64_t max_step = opt.max_length;
   const int64_t sync_every = std::max<int32_t>(1, opt.sync_every);
-  std::vector<int32_t> h_ids;
-  std::vector<float> h_scores;
-  int64_t processed = 0;  // steps already examined on the host
   int64_t launched = 0;   // steps enqueued on the device
+  int64_t examined = 0;   // steps whose ids the host has looked at
 
-  while (processed < max_step && count_alive > 0) {
-    const int64_t target = std::min(max_step, processed + sync_every);
+  // Software pipeline of depth 2: group k+1 is queued on the device before the host waits for
+  // the ids of group k, so the GPU never idles on the host's EOS scan. At most one group of
+  // steps is computed past the point where every sentence had finished (their results are
+  // simply not read).
+  struct Group { int64_t first, count; int slot; };
+  std::vector<Group> inflight;
+  int next_slot = 0;
+  auto launch_group = [&]() {
+    const int64_t target = std::min(max_step, launched + sync_every);
+    if (target == launched) return false;
+    Group g{launched, target - launched, next_slot};
     for (; launched < target; ++launched) engine.step(st, opt.use_graph);
-    const int64_t count = launched - processed;
-    h_ids.resize(count * batch);
-    h_scores.resize(count * batch);
-    engine.read_history(st, opt.start_step + processed, count, h_ids.data(),
-                        opt.return_scores ? h_scores.data() : nullptr);
-    for (int64_t s = 0; s < count && count_alive > 0; ++s) {
-      const int64_t step = processed + s;
+    engine.read_history_async(st, opt.start_step + g.first, g.count, g.slot);
+    next_slot ^= 1;
+    inflight.push_back(g);
+    return true;
+  };
+
+  launch_group();
+  while (!inflight.empty() && count_alive > 0) {
+    if (inflight.size() < 2) launch_group();  // keep the device busy while we scan group k
+    const Group g = inflight.front();
+    inflight.erase(inflight.begin());
+    const int32_t* h_ids = nullptr;
+    const float* h_scores = nullptr;
+    engine.wait_history(st, g.slot, &h_ids, &h_scores);
+    for (int64_t s = 0; s < g.count && count_alive > 0; ++s) {
+      const int64_t step = g.first + s;
       const bool last = (step + 1 == max_step);  // is_last_step (src/decoding.cc:368-373)
       for (int64_t i = 0; i < batch; ++i) {
         if (!alive[i]) continue;
@@ -105,8 +121,10 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
         }
       }
     }
-    processed = launched;
+    examined = g.first + g.count;
   }
+  (void)examined;
+  engine.synchronize();  // drain a speculative group before the state is torn down
   st.fuse_greedy = false;
   if (stats) stats->steps = launched;
   return results;

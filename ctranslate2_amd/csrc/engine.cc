@@ -606,8 +606,12 @@ DecodeState::~DecodeState() {
     (void)hipSetDevice(engine->device_index());
     (void)hipStreamSynchronize(stream ? stream : engine->stream());
   }
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
     if (graph_exec[i]) (void)hipGraphExecDestroy(graph_exec[i]);
+    if (pin_ids[i]) (void)hipHostFree(pin_ids[i]);
+    if (pin_scores[i]) (void)hipHostFree(pin_scores[i]);
+    if (pin_event[i]) (void)hipEventDestroy(pin_event[i]);
+  }
   if (graph) (void)hipGraphDestroy(graph);
   for (void* p : owned) {
     try { device_free(p); } catch (...) {}
@@ -1225,6 +1229,33 @@ void Engine::read_history(DecodeState& st, int64_t first, int64_t count, int32_t
                                   sizeof(float) * count * st.rows, hipMemcpyDeviceToHost,
                                   cur_stream()));
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+}
+
+void Engine::read_history_async(DecodeState& st, int64_t first, int64_t count, int slot) {
+  tls_stream = st.stream;
+  const int64_t need = count * st.rows;
+  if (st.pin_capacity < need) {
+    for (int i = 0; i < 2; ++i) {
+      if (st.pin_ids[i]) (void)hipHostFree(st.pin_ids[i]);
+      if (st.pin_scores[i]) (void)hipHostFree(st.pin_scores[i]);
+      CT2X_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.pin_ids[i]), need * sizeof(int32_t)));
+      CT2X_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.pin_scores[i]), need * sizeof(float)));
+      if (!st.pin_event[i]) CT2X_HIP_CHECK(hipEventCreateWithFlags(&st.pin_event[i], hipEventDisableTiming));
+    }
+    st.pin_capacity = need;
+  }
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.pin_ids[slot], st.hist_ids + first * st.rows,
+                                sizeof(int32_t) * need, hipMemcpyDeviceToHost, cur_stream()));
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.pin_scores[slot], st.hist_scores + first * st.rows,
+                                sizeof(float) * need, hipMemcpyDeviceToHost, cur_stream()));
+  CT2X_HIP_CHECK(hipEventRecord(st.pin_event[slot], cur_stream()));
+}
+
+void Engine::wait_history(DecodeState& st, int slot, const int32_t** h_ids,
+                          const float** h_scores) {
+  CT2X_HIP_CHECK(hipEventSynchronize(st.pin_event[slot]));
+  *h_ids = st.pin_ids[slot];
+  *h_scores = st.pin_scores[slot];
 }
 
 void Engine::copy_logits_to_host(DecodeState& st, float* h_logits) {

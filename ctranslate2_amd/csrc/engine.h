@@ -157,6 +157,11 @@ public:
   // Copies `count` history steps starting at `first` (ids and scores, [step][rows]) to host.
   void read_history(DecodeState& state, int64_t first, int64_t count, int32_t* h_ids,
                     float* h_scores);
+  // Asynchronous form: enqueues the D2H copy into pinned slot `slot` (0/1) behind the steps
+  // launched so far and records an event; wait_history() blocks on that event only, so the
+  // next group of steps can already be queued on the device while the host examines this one.
+  void read_history_async(DecodeState& state, int64_t first, int64_t count, int slot);
+  void wait_history(DecodeState& state, int slot, const int32_t** h_ids, const float** h_scores);
   void copy_logits_to_host(DecodeState& state, float* h_logits);
   void set_ids(DecodeState& state, const int32_t* h_ids);
   void set_step(DecodeState& state, int32_t step);
@@ -279,6 +284,11 @@ struct DecodeState {
   float* topk_scores = nullptr;   // [batch, 2*beam]
   int32_t* topk_ids = nullptr;    // [batch, 2*beam]
   int32_t* d_parents = nullptr;   // [rows]
+  // pinned host staging for the pipelined history read-back (greedy loop)
+  int32_t* pin_ids[2] = {nullptr, nullptr};
+  float* pin_scores[2] = {nullptr, nullptr};
+  int64_t pin_capacity = 0;
+  hipEvent_t pin_event[2] = {nullptr, nullptr};
   // Greedy sampling fused at the end of the step (and of its graph): set by decoding.cc.
   bool fuse_greedy = false;
   int32_t g_eos = -1, g_min_length = 0;
