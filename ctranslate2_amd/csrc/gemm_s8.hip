@@ -295,30 +295,30 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
   }();
   const int64_t sel = forced ? (forced <= 32 ? 1 : (forced <= 64 ? 33 : 65)) : m;
   static const bool no_skinny = std::getenv("CT2X_NO_SKINNY_GEMM") != nullptr;
-  if (m <= 32 && !forced && !no_skinny) {
-    // Decode-step shapes: one memory round trip per launch (see gemm_s8_skinny_kernel).
+  if (m <= 128 && !forced && !no_skinny) {
+    // Decode-step shapes (rows = batch * beam): one memory round trip per launch
+    // (see gemm_s8_skinny_kernel). MT = row tiles of 16, NT = column tiles per workgroup.
+#define CT2X_SKINNY(MT, NT, WAVES, U)                                                          \
+  hipLaunchKernelGGL((gemm_s8_skinny_kernel<MT, NT, WAVES, U>), dim3((n + 16 * NT - 1) / (16 * NT)), \
+                     dim3(WAVES * 64), 0, stream, a, b, M, N, K, ep)
+    const int mt = m <= 16 ? 1 : (m <= 32 ? 2 : (m <= 64 ? 4 : 8));
     if (n >= 8192) {
-      if (m <= 16)
-        hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, 4, 4, 2>), dim3((n + 63) / 64), dim3(256), 0,
-                           stream, a, b, M, N, K, ep);
-      else
-        hipLaunchKernelGGL((gemm_s8_skinny_kernel<2, 4, 4, 2>), dim3((n + 63) / 64), dim3(256), 0,
-                           stream, a, b, M, N, K, ep);
+      if (mt == 1) CT2X_SKINNY(1, 4, 4, 2);
+      else if (mt == 2) CT2X_SKINNY(2, 4, 4, 2);
+      else if (mt == 4) CT2X_SKINNY(4, 2, 4, 2);
+      else CT2X_SKINNY(8, 2, 4, 1);
     } else if (k >= 2048) {
-      if (m <= 16)
-        hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, 1, 8, 4>), dim3((n + 15) / 16), dim3(512), 0,
-                           stream, a, b, M, N, K, ep);
-      else
-        hipLaunchKernelGGL((gemm_s8_skinny_kernel<2, 1, 8, 4>), dim3((n + 15) / 16), dim3(512), 0,
-                           stream, a, b, M, N, K, ep);
+      if (mt == 1) CT2X_SKINNY(1, 1, 8, 4);
+      else if (mt == 2) CT2X_SKINNY(2, 1, 8, 4);
+      else if (mt == 4) CT2X_SKINNY(4, 1, 8, 2);
+      else CT2X_SKINNY(8, 1, 8, 2);
     } else {
-      if (m <= 16)
-        hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, 1, 4, 4>), dim3((n + 15) / 16), dim3(256), 0,
-                           stream, a, b, M, N, K, ep);
-      else
-        hipLaunchKernelGGL((gemm_s8_skinny_kernel<2, 1, 4, 4>), dim3((n + 15) / 16), dim3(256), 0,
-                           stream, a, b, M, N, K, ep);
+      if (mt == 1) CT2X_SKINNY(1, 1, 4, 4);
+      else if (mt == 2) CT2X_SKINNY(2, 1, 4, 4);
+      else if (mt == 4) CT2X_SKINNY(4, 1, 4, 2);
+      else CT2X_SKINNY(8, 1, 4, 2);
     }
+#undef CT2X_SKINNY
     return;
   }
   if (sel <= 32) {
