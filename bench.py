@@ -85,13 +85,27 @@ def pick_dominant(profile):
     return label, profile[label]
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied) or None."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_pmc_traffic.json"):
+            with open(os.path.join(pdir, name)) as f:
+                entry = json.load(f).get(label)
+            if entry:
+                best = entry["traffic_bytes"]
+    return best
+
+
 def roofline_entry(label, st):
     avg_ms = st["total_ms"] / max(st["launches"], 1)
     seconds = st["total_ms"] * 1e-3
     gbs = st["bytes"] / seconds / 1e9 if st["bytes"] > 0 and seconds > 0 else None
     tops = st["ops"] / seconds / 1e12 if st["ops"] > 0 and seconds > 0 else None
     entry = {"kernel": label, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": None,
+             "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": pmc_traffic(label),
              "launches": st["launches"], "avg_us": avg_ms * 1e3,
              "bytes_per_launch": st["bytes"] / max(st["launches"], 1)}
     if tops is not None:
