@@ -321,6 +321,12 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
 #undef CT2X_SKINNY
     return;
   }
+  static const bool no_big = std::getenv("CT2X_NO_BIG_GEMM") != nullptr;
+  if (!forced && !no_big && (reinterpret_cast<uintptr_t>(a) & 15) == 0 &&
+      gemm_s8_big_applicable(m, n, k)) {
+    launch_gemm_s8_big(a, b, M, N, K, ep, stream);
+    return;
+  }
   if (sel <= 32) {
     hipLaunchKernelGGL((gemm_s8_mfma_kernel<32, 64, 1, 4>), dim3((n + 63) / 64, (m + 31) / 32),
                        dim3(256), 0, stream, a, b, M, N, K, ep);

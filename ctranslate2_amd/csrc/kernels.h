@@ -77,6 +77,12 @@ struct GemmS8Epilogue {
 void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int64_t k,
                     const GemmS8Epilogue& ep, hipStream_t stream);
 
+// 256x256-tile DMA-staged kernel for MFMA-bound shapes (gemm_s8_big.hip); launch_gemm_s8 picks
+// it when gemm_s8_big_applicable (env CT2X_NO_BIG_GEMM=1 disables, for A/B comparisons).
+bool gemm_s8_big_applicable(int64_t m, int64_t n, int64_t k);
+void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
+                        const GemmS8Epilogue& ep, hipStream_t stream);
+
 // ---- fp32 GEMM (gemm_f32.hip) --------------------------------------------------------
 
 // C[b] = alpha * A[b] . op(B[b]) (+ bias[j]) -> act -> (+ residual). batch==1 for plain GEMM.
