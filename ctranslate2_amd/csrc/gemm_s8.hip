@@ -123,19 +123,74 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
   }
 
   // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
+  // Every epilogue operand is fetched BEFORE the first store: a load that follows a store to y
+  // in program order has to assume aliasing, and the epilogue would serialise on memory latency
+  // (measured: +23 us per launch at [1024, 512] x 512). The residual of row group i+1 is
+  // requested ahead of the stores of row group i.
+  const int r16 = lane & 15, g4 = lane >> 4;
+  float ws[TN], bias[TN];
+  bool col_ok[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int j = 0; j < TN; ++j) {
+    const int64_t col = n0 + wn * WTN + j * 16 + r16;
+    col_ok[j] = col < N;
+    ws[j] = (ep.mode == 1 && col_ok[j]) ? ep.w_scale[col] : 1.f;
+    bias[j] = (ep.mode == 1 && ep.bias && col_ok[j]) ? ep.bias[col] : 0.f;
+  }
+  float row_scale[TM][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = m0 + wm * WTM + i * 16 + (lane >> 4) * 4 + r;
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = m0 + wm * WTM + i * 16 + g4 * 4 + e;
+      row_scale[i][e] = (ep.mode == 1 && row < M) ? ep.a_scale[row] : 1.f;
+    }
+  const bool has_res = ep.mode == 1 && ep.residual != nullptr;
+  const int64_t col0 = n0 + wn * WTN + r16;
+  auto load_residual = [&](int i, float (&res)[4][TN]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = m0 + wm * WTM + i * 16 + g4 * 4 + e;
+      const float* p = ep.residual + row * ep.ldy + col0;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        res[e][j] = (has_res && row < M && col_ok[j]) ? p[j * 16] : 0.f;
+    }
+  };
+  auto store_group = [&](int i, const float (&res)[4][TN]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = m0 + wm * WTM + i * 16 + g4 * 4 + e;
       if (row >= M) continue;
-      const float r_a = (ep.mode == 1) ? 1.f / ep.a_scale[row] : 0.f;
+      if (ep.mode == 0) {
+        int32_t* p = ep.c_i32 + row * ep.ldy + col0;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int64_t col = n0 + wn * WTN + j * 16 + (lane & 15);
-        if (col < N) store_epilogue(ep, row, col, acc[i][j][r], r_a);
+        for (int j = 0; j < TN; ++j)
+          if (col_ok[j]) p[j * 16] = acc[i][j][e];
+      } else {
+        const float r_a = 1.f / row_scale[i][e];
+        float* p = ep.y + row * ep.ldy + col0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // CPU formula order (src/cpu/kernels.cc:666-673): c * (1/a_scale) / b_scale + bias.
+          float v = static_cast<float>(acc[i][j][e]) * r_a;
+          v = v / ws[j];
+          if (ep.bias) v = v + bias[j];
+          v = apply_activation(v, ep.act);
+          if (has_res) v = res[e][j] + v;
+          if (col_ok[j]) p[j * 16] = v;
+        }
       }
     }
+  };
+  float res_a[4][TN], res_b[4][TN];
+  load_residual(0, res_a);
+#pragma unroll
+  for (int i = 0; i < TM; i += 2) {
+    if (i + 1 < TM) load_residual(i + 1, res_b);
+    store_group(i, res_a);
+    if (i + 2 < TM) load_residual(i + 2, res_a);
+    if (i + 1 < TM) store_group(i + 1, res_b);
   }
 }
 
@@ -327,10 +382,20 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
     launch_gemm_s8_big(a, b, M, N, K, ep, stream);
     return;
   }
-  if (sel <= 32) {
+  // Tile choice: the largest tile that still gives every CU work (>= 192 workgroups on the 256
+  // CUs); these launches are microseconds long, so parallelism beats per-tile reuse.
+  int tile = 0;
+  if (forced) {
+    tile = sel <= 32 ? 32 : (sel <= 64 ? 64 : 128);
+  } else {
+    const int64_t wg128 = ((m + 127) / 128) * ((n + 127) / 128);
+    const int64_t wg64 = ((m + 63) / 64) * ((n + 63) / 64);
+    tile = wg128 >= 192 ? 128 : (wg64 >= 192 ? 64 : 32);
+  }
+  if (tile == 32) {
     hipLaunchKernelGGL((gemm_s8_mfma_kernel<32, 64, 1, 4>), dim3((n + 63) / 64, (m + 31) / 32),
                        dim3(256), 0, stream, a, b, M, N, K, ep);
-  } else if (sel <= 64) {
+  } else if (tile == 64) {
     hipLaunchKernelGGL((gemm_s8_mfma_kernel<64, 64, 2, 2>), dim3((n + 63) / 64, (m + 63) / 64),
                        dim3(256), 0, stream, a, b, M, N, K, ep);
   } else {
