@@ -22,8 +22,7 @@ namespace ct2x {
 
 namespace {
 
-constexpr int kMaxChunks = 2;  // float4 chunks per lane => dhead <= 4 * G * kMaxChunks
-constexpr int kUnroll = 8;    // key blocks in flight per lane group
+constexpr int kUnroll = 8;  // keys per lane group and block; a block is one memory round trip
 
 // Loads 4 consecutive elements [i0, i0+4) of a head vector, applying RoPE at `pos` when
 // requested (reference formula src/ops/rotary_cpu.cc:31-36).
@@ -73,7 +72,8 @@ struct AttnKernelArgs {
 //                  |max| through LDS and emit the row already quantised for the following int8
 //                  Dense (ops::Quantize of the combined heads, src/layers/common.cc:389), so the
 //                  standalone quantize launch and the fp32 context round trip disappear.
-template <int G, bool kFusedQ>
+// kMaxChunks = float4 chunks of a head vector per lane (dhead <= 4 * G * kMaxChunks).
+template <int G, bool kFusedQ, int kMaxChunks = 1>
 __global__ __launch_bounds__(kFusedQ ? 512 : 64) void attn_row_kernel(AttnKernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const AttnDecodeParams& p = a.p;
@@ -146,32 +146,50 @@ __global__ __launch_bounds__(kFusedQ ? 512 : 64) void attn_row_kernel(AttnKernel
     }
   }
 
-  // ---- phase 1: scores = scale * (q . k_t) ----------------------------------------------
-  // Latency-bound at decode sizes: all K loads of a block of KPI*kUnroll keys are issued before
-  // the first one is consumed, so a block costs one memory round trip instead of kUnroll.
-  for (int64_t t0 = 0; t0 < t_cached; t0 += KPI * kUnroll) {
-    float4 kreg[kUnroll][kMaxChunks];
+  // Latency-bound at decode sizes, so everything that does not depend on the scores is requested
+  // up front: a block is KPI * kUnroll keys, two K blocks AND two V blocks are in flight before
+  // the first score is computed (decode lengths <= 2 blocks cost ONE memory round trip for the
+  // whole cache instead of one per phase and block); longer rows refill a block as soon as it
+  // has been consumed.
+  constexpr int BLK = KPI * kUnroll;
+  auto load_blk = [&](const float* base, int64_t t0, float4 (&reg)[kUnroll][kMaxChunks]) {
 #pragma unroll
     for (int j = 0; j < kUnroll; ++j) {
       const int64_t t = t0 + j * KPI + kg;
 #pragma unroll
       for (int u = 0; u < kMaxChunks; ++u) {
         const int cc = c + u * G;
-        kreg[j][u] = (t < t_cached && cc < nc)
-                         ? *reinterpret_cast<const float4*>(kc + t * p.kv_time_stride + cc * 4)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        reg[j][u] = (t < t_cached && cc < nc)
+                        ? *reinterpret_cast<const float4*>(base + t * p.kv_time_stride + cc * 4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+  };
+  float4 k0[kUnroll][kMaxChunks], k1[kUnroll][kMaxChunks];
+  float4 v0[kUnroll][kMaxChunks], v1[kUnroll][kMaxChunks];
+  load_blk(kc, 0, k0);
+  load_blk(kc, BLK, k1);
+  load_blk(vc, 0, v0);
+  load_blk(vc, BLK, v1);
+
+  // ---- phase 1: scores = scale * (q . k_t) ----------------------------------------------
+  auto score_blk = [&](int64_t t0, const float4 (&reg)[kUnroll][kMaxChunks]) {
 #pragma unroll
     for (int j = 0; j < kUnroll; ++j) {
       const int64_t t = t0 + j * KPI + kg;
       float part = 0.f;
 #pragma unroll
-      for (int u = 0; u < kMaxChunks; ++u) part += dot4(qv[u], kreg[j][u]);
+      for (int u = 0; u < kMaxChunks; ++u) part += dot4(qv[u], reg[j][u]);
 #pragma unroll
       for (int o = G / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
       if (c == 0 && t < t_cached) scores[t] = part * p.scale;
     }
+  };
+  for (int64_t t0 = 0; t0 < t_cached; t0 += 2 * BLK) {
+    score_blk(t0, k0);
+    if (t0 + 2 * BLK < t_cached) load_blk(kc, t0 + 2 * BLK, k0);
+    if (t0 + BLK < t_cached) score_blk(t0 + BLK, k1);
+    if (t0 + 3 * BLK < t_cached) load_blk(kc, t0 + 3 * BLK, k1);
   }
   if (has_new) {
     float part = 0.f;
@@ -204,31 +222,25 @@ __global__ __launch_bounds__(kFusedQ ? 512 : 64) void attn_row_kernel(AttnKernel
   float4 acc[kMaxChunks];
 #pragma unroll
   for (int u = 0; u < kMaxChunks; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t t0 = 0; t0 < t_cached; t0 += KPI * kUnroll) {
-    float4 vreg[kUnroll][kMaxChunks];
-#pragma unroll
-    for (int j = 0; j < kUnroll; ++j) {
-      const int64_t t = t0 + j * KPI + kg;
-#pragma unroll
-      for (int u = 0; u < kMaxChunks; ++u) {
-        const int cc = c + u * G;
-        vreg[j][u] = (t < t_cached && cc < nc)
-                         ? *reinterpret_cast<const float4*>(vc + t * p.kv_time_stride + cc * 4)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+  auto pv_blk = [&](int64_t t0, const float4 (&reg)[kUnroll][kMaxChunks]) {
 #pragma unroll
     for (int j = 0; j < kUnroll; ++j) {
       const int64_t t = t0 + j * KPI + kg;
       const float pt = (t < t_cached) ? scores[t] : 0.f;
 #pragma unroll
       for (int u = 0; u < kMaxChunks; ++u) {
-        acc[u].x += pt * vreg[j][u].x;
-        acc[u].y += pt * vreg[j][u].y;
-        acc[u].z += pt * vreg[j][u].z;
-        acc[u].w += pt * vreg[j][u].w;
+        acc[u].x += pt * reg[j][u].x;
+        acc[u].y += pt * reg[j][u].y;
+        acc[u].z += pt * reg[j][u].z;
+        acc[u].w += pt * reg[j][u].w;
       }
     }
+  };
+  for (int64_t t0 = 0; t0 < t_cached; t0 += 2 * BLK) {
+    pv_blk(t0, v0);
+    if (t0 + 2 * BLK < t_cached) load_blk(vc, t0 + 2 * BLK, v0);
+    if (t0 + BLK < t_cached) pv_blk(t0 + BLK, v1);
+    if (t0 + 3 * BLK < t_cached) load_blk(vc, t0 + 3 * BLK, v1);
   }
   if (has_new && kg == static_cast<int>(t_cached % KPI)) {
     const float pt = scores[t_cached];
@@ -298,17 +310,17 @@ __global__ __launch_bounds__(kFusedQ ? 512 : 64) void attn_row_kernel(AttnKernel
   }
 }
 
-template <int G>
+template <int G, int CH = 1>
 void launch_rows(const AttnKernelArgs& a, hipStream_t stream) {
   const AttnDecodeParams& p = a.p;
   if (a.q_out != nullptr) {
     const size_t lds = (static_cast<size_t>(p.heads) * (p.t_max + 1) + p.heads) * sizeof(float);
-    hipLaunchKernelGGL((attn_row_kernel<G, true>), dim3(static_cast<unsigned>(p.rows)),
+    hipLaunchKernelGGL((attn_row_kernel<G, true, CH>), dim3(static_cast<unsigned>(p.rows)),
                        dim3(static_cast<unsigned>(p.heads * 64)), lds, stream, a);
     return;
   }
   const size_t lds = static_cast<size_t>(p.t_max + 1) * sizeof(float);
-  hipLaunchKernelGGL((attn_row_kernel<G, false>), dim3(static_cast<unsigned>(p.rows * p.heads)),
+  hipLaunchKernelGGL((attn_row_kernel<G, false, CH>), dim3(static_cast<unsigned>(p.rows * p.heads)),
                      dim3(64), lds, stream, a);
 }
 
@@ -320,13 +332,18 @@ void dispatch(const AttnKernelArgs& a, hipStream_t stream) {
   else if (nc <= 8) launch_rows<8>(a, stream);
   else if (nc <= 16) launch_rows<16>(a, stream);
   else if (nc <= 32) launch_rows<32>(a, stream);
-  else launch_rows<64>(a, stream);
+  else if (nc <= 64) launch_rows<64>(a, stream);
+  else launch_rows<64, 2>(a, stream);
 }
 
 }  // namespace
 
 void launch_attention_decode(const AttnDecodeParams& p, hipStream_t stream) {
   if (p.rows == 0) return;
+  if (attention_decode2_applicable(p, false)) {
+    launch_attention_decode2(p, 0, nullptr, nullptr, stream);
+    return;
+  }
   AttnKernelArgs a;
   a.p = p;
   a.causal_tq = 0;
@@ -339,6 +356,7 @@ void launch_attention_decode(const AttnDecodeParams& p, hipStream_t stream) {
 }
 
 bool attention_decode_can_fuse_quantize(const AttnDecodeParams& p) {
+  if (attention_decode2_applicable(p, true)) return true;
   // one wave per head in one workgroup, scores of every head in LDS
   return p.heads >= 1 && p.heads <= 8 &&
          (static_cast<size_t>(p.heads) * (p.t_max + 1) + p.heads) * sizeof(float) <= 60 * 1024;
@@ -347,6 +365,10 @@ bool attention_decode_can_fuse_quantize(const AttnDecodeParams& p) {
 void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
                                        float* q_scales, hipStream_t stream) {
   if (p.rows == 0) return;
+  if (attention_decode2_applicable(p, true)) {
+    launch_attention_decode2(p, quant_mode, q_out, q_scales, stream);
+    return;
+  }
   AttnKernelArgs a;
   a.p = p;
   a.causal_tq = 0;

@@ -133,6 +133,12 @@ bool attention_decode_can_fuse_quantize(const AttnDecodeParams& p);
 void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
                                        float* q_scales, hipStream_t stream);
 
+// Second-generation decode kernel (attention_decode2.hip: lane = key for QK^T, lane = channel for
+// PV, GQA group per wave); launch_attention_decode[_quantized] route to it when applicable.
+bool attention_decode2_applicable(const AttnDecodeParams& p, bool fused_quantize);
+void launch_attention_decode2(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
+                              float* q_scales, hipStream_t stream);
+
 // Full (prefill / encoder) attention: q [B, Tq, H, dh] (row stride given), k/v with strides,
 // lengths[b] valid keys, causal => key t visible to query i iff t <= i + q_offset.
 struct AttnFullParams {

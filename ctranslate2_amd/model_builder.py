@@ -67,18 +67,30 @@ def quantize_int8(weight):
 
 
 class _Builder:
-    def __init__(self, seed, quantization, w_std=0.02, b_std=0.01):
+    def __init__(self, seed, quantization, w_std=0.02, b_std=0.01, direct_int8=False):
         self.rng = np.random.default_rng(seed)
         self.quantization = quantization
         self.w_std, self.b_std = w_std, b_std
+        # direct_int8: draw the int8 weights themselves (uniform in [-127, 127]) and per-row scales
+        # 127/absmax with absmax ~ w_std*sqrt(3) (same variance as N(0, w_std^2)) instead of
+        # quantising a float matrix: multi-GB benchmark models in seconds, not minutes.
+        self.direct_int8 = direct_int8 and quantization == "int8"
         self.vars = {}
 
     def attr(self, name, value, dtype):
         self.vars[name] = np.array(value, dtype=dtype)
 
+    def random_weight(self, name, n, k):
+        if self.direct_int8:
+            q = self.rng.integers(-127, 128, (n, k), dtype=np.int8)
+            amax = self.w_std * np.sqrt(3.0) * (1.0 + 0.1 * self.rng.random(n))
+            self.vars[name] = q
+            self.vars[name + "_scale"] = (127.0 / amax).astype(np.float32)
+        else:
+            self.weight(name, self.rng.normal(0, self.w_std, (n, k)).astype(np.float32))
+
     def linear(self, scope, n, k, bias=True):
-        w = self.rng.normal(0, self.w_std, (n, k)).astype(np.float32)
-        self.weight(scope + "/weight", w)
+        self.random_weight(scope + "/weight", n, k)
         if bias:
             self.vars[scope + "/bias"] = self.rng.normal(0, self.b_std, (n,)).astype(np.float32)
 
@@ -176,15 +188,15 @@ def build_transformer(output_dir, num_encoder_layers=6, num_decoder_layers=6, d_
 
 def build_decoder_lm(output_dir, num_layers=32, d_model=4096, ffn_dim=14336, num_heads=32,
                      num_heads_kv=8, vocab_size=128256, seed=0, quantization="int8",
-                     rotary_base=500000.0, w_std=0.02):
+                     rotary_base=500000.0, w_std=0.02, direct_int8=False):
     """TransformerDecoderModelSpec.from_config(layers, heads, activation=SWISH, ffn_glu=True,
     rms_norm=True, rotary_dim=0, rotary_interleave=False, num_heads_kv=...) -- the Llama-3 shape
     (python/ctranslate2/converters/transformers.py:1736-1752)."""
     os.makedirs(output_dir, exist_ok=True)
-    b = _Builder(seed, quantization, w_std=w_std)
+    b = _Builder(seed, quantization, w_std=w_std, direct_int8=direct_int8)
     d = d_model
     dh = d // num_heads
-    b.weight("decoder/embeddings/weight", b.rng.normal(0, w_std, (vocab_size, d)).astype(np.float32))
+    b.random_weight("decoder/embeddings/weight", vocab_size, d)
     for l in range(num_layers):
         s = "decoder/layer_%d" % l
         b.layer_norm(s + "/self_attention/layer_norm", d, rms=True)

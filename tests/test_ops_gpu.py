@@ -259,6 +259,9 @@ ATTN_CASES = [
     (3, 8, 8, 4, 12, 1),       # aren-transliteration fixture (d_head 4)
     (4, 2, 1, 96, 33, 2),      # MQA, non power-of-two chunk count
     (2, 1, 1, 256, 9, 1),      # two float4 chunks per lane
+    (16, 8, 2, 64, 100, 1),    # GQA group 4, keys split over 4 waves (attention_decode2 split mode)
+    (8, 4, 2, 128, 70, 2),     # GQA group 2, d_head 128, shared cache rows
+    (5, 8, 8, 64, 200, 1),     # 4 chunks of 64 keys
 ]
 
 
