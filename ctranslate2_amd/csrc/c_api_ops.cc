@@ -207,6 +207,29 @@ int ct2x_gemm_s8_dequant(const int8_t* d_qa, const float* d_a_scale, const int8_
   API_CATCH
 }
 
+int ct2x_gemm_s8_glu(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w0,
+                     const float* d_w0_scale, const float* d_b0, const int8_t* d_w1,
+                     const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n, int64_t k,
+                     int activation, void* d_y, int dtype, void* stream) {
+  API_TRY
+  require_f32(dtype, "ct2x_gemm_s8_glu");
+  CT2X_CHECK(m <= 32 && k % 16 == 0, "ct2x_gemm_s8_glu: decode rows only (m <= 32, k % 16 == 0)");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.a_scale = d_a_scale;
+  ep.w_scale = d_w0_scale;
+  ep.bias = d_b0;
+  ep.b2 = d_w1;
+  ep.w_scale2 = d_w1_scale;
+  ep.bias2 = d_b1;
+  ep.y = static_cast<float*>(d_y);
+  ep.act = activation;
+  ep.ldy = n;
+  launch_gemm_s8(d_qa, d_w0, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("gemm_s8_glu");
+  API_CATCH
+}
+
 int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,
                          void* d_y, int dtype, void* stream) {
   API_TRY

@@ -855,12 +855,34 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
     fq.q = st.qbuf;
     fq.s = st.qscale;
   }
+  if (ffn.l0_noact.present && fq.q && ffn.l0.quantized && ffn.l0_noact.quantized && rows <= 32 &&
+      ffn.l0.k % 16 == 0 && ffn.l0_noact.n == ffn.l0.n) {
+    // Decode rows: gate and up projection in ONE launch, y = act(gate) * up (no fp32
+    // intermediates, no ops::Mul launch).
+    GemmS8Epilogue ep;
+    ep.mode = 1;
+    ep.a_scale = fq.s;
+    ep.w_scale = ffn.l0.wscale;
+    ep.bias = ffn.l0.bias;
+    ep.act = ffn.activation;
+    ep.b2 = ffn.l0_noact.wq;
+    ep.w_scale2 = ffn.l0_noact.wscale;
+    ep.bias2 = ffn.l0_noact.bias;
+    ep.y = st.inner;
+    ep.ldy = ffn.l0.n;
+    const double M = double(rows), N = double(ffn.l0.n), K = double(ffn.l0.k);
+    begin_kernel("gemm_s8_glu", M * K + 2 * N * K + 8 * N + 4 * M + 4 * M * N, 4 * M * N * K, rows,
+                 ffn.l0.n, ffn.l0.k);
+    launch_gemm_s8(fq.q, ffn.l0.wq, rows, ffn.l0.n, ffn.l0.k, ep, cur_stream());
+    end_kernel();
+  } else {
   dense(ffn.l0, ffn_in, fq.q ? &fq : nullptr, rows, ffn.activation, nullptr, st.inner, &st);
   if (ffn.l0_noact.present) {
     dense(ffn.l0_noact, ffn_in, fq.q ? &fq : nullptr, rows, -1, nullptr, st.inner2, &st);
     begin_kernel("mul");
     launch_mul(st.inner2, st.inner, rows * ffn.l0.n, st.inner, cur_stream());
     end_kernel();
+  }
   }
   dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
   if (ffn.ln.present && !pre_norm) norm(ffn.ln, y, rows, d, y);

@@ -15,7 +15,9 @@
 
 #include "device_utils.h"
 #include "kernels.h"
+#include "runtime.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace ct2x {
@@ -203,11 +205,15 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
 // into registers (no LDS staging: a weight byte is used by exactly one wave), and the partial
 // int32 tiles are summed through LDS (exact, order independent) before the fused epilogue.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int WAVES, int U>
+// DUAL: the gated FFN input pair of FeedForwardNetwork::operator() (src/layers/transformer.cc:
+// 21-51, ffn_glu) in one launch: y = act(x.W0^T + b0) * (x.W1^T + b1) - both weight streams share
+// the activation fragments, the two fp32 intermediates and the ops::Mul launch disappear.
+template <int MT, int NT, int WAVES, int U, bool DUAL = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
     GemmS8Epilogue ep) {
-  __shared__ int partial[WAVES][MT][NT][64][4];
+  constexpr int ND = DUAL ? 2 : 1;
+  __shared__ int partial[ND][WAVES][MT][NT][64][4];
   constexpr int THREADS = WAVES * 64;
   constexpr int OUTS = MT * NT * 256;                       // outputs of the workgroup tile
   constexpr int OPT = (OUTS + THREADS - 1) / THREADS;       // outputs per thread in the epilogue
@@ -216,35 +222,42 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
   const int r = lane & 15, g = lane >> 4;
   const int64_t n0 = static_cast<int64_t>(blockIdx.x) * (NT * 16);
   const int ksteps = (K + 63) / 64;
+  const int8_t* __restrict__ B2 = DUAL ? ep.b2 : nullptr;
 
   // Epilogue operands are fetched FIRST so their latency hides under the weight stream: thread t
   // finalises outputs t, t+THREADS, ... of the [MT*16, NT*16] tile, 16 consecutive threads = 16
   // consecutive columns (coalesced 64-byte stores).
-  float e_ra[OPT], e_ws[OPT], e_bias[OPT], e_res[OPT];
+  float e_ra[OPT], e_ws[OPT], e_bias[OPT], e_res[OPT], e_ws2[OPT], e_bias2[OPT];
 #pragma unroll
   for (int o = 0; o < OPT; ++o) {
     const int flat = tid + o * THREADS;
     const int tile = flat >> 8, within = flat & 255;
     const int row = (tile / NT) * 16 + (within >> 4);
     const int64_t col = n0 + (tile % NT) * 16 + (within & 15);
-    e_ra[o] = e_ws[o] = 1.f;
-    e_bias[o] = e_res[o] = 0.f;
+    e_ra[o] = e_ws[o] = e_ws2[o] = 1.f;
+    e_bias[o] = e_res[o] = e_bias2[o] = 0.f;
     if (ep.mode == 1 && flat < OUTS && row < M && col < N) {
       e_ra[o] = ep.a_scale[row];
       e_ws[o] = ep.w_scale[col];
       if (ep.bias) e_bias[o] = ep.bias[col];
       if (ep.residual) e_res[o] = ep.residual[static_cast<int64_t>(row) * ep.ldy + col];
+      if (DUAL) {
+        e_ws2[o] = ep.w_scale2[col];
+        if (ep.bias2) e_bias2[o] = ep.bias2[col];
+      }
     }
   }
 
-  v4i acc[MT][NT];
+  v4i acc[ND][MT][NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int d = 0; d < ND; ++d)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[d][i][j] = v4i{0, 0, 0, 0};
 
   for (int ks0 = wave; ks0 < ksteps; ks0 += WAVES * U) {
-    v4i af[U][MT], bf[U][NT];
+    v4i af[U][MT], bf[ND][U][NT];
     // Issue every load of this round before the first MFMA consumes one.
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -261,8 +274,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int64_t col = n0 + j * 16 + r;
-        bf[u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B + col * K + kk)
-                                     : v4i{0, 0, 0, 0};
+        bf[0][u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B + col * K + kk)
+                                        : v4i{0, 0, 0, 0};
+        if (DUAL)
+          bf[ND - 1][u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B2 + col * K + kk)
+                                               : v4i{0, 0, 0, 0};
       }
     }
 #pragma unroll
@@ -271,14 +287,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u][i], bf[u][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+            acc[d][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[u][i], bf[d][u][j],
+                                                                 acc[d][i][j], 0, 0, 0);
   }
 
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int d = 0; d < ND; ++d)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-      *reinterpret_cast<v4i*>(&partial[wave][i][j][lane][0]) = acc[i][j];
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        *reinterpret_cast<v4i*>(&partial[d][wave][i][j][lane][0]) = acc[d][i][j];
   __syncthreads();
 
   // Cross-wave sum (exact int32) + fused epilogue, spread over ALL threads of the workgroup.
@@ -293,19 +314,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int64_t col = n0 + j * 16 + ct;
     // MFMA C layout: element (row rt, col ct) lives in lane (rt/4)*16 + ct, register rt%4.
     const int src_lane = ((rt >> 2) << 4) | ct;
-    int sum = 0;
+    int sum = 0, sum2 = 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) sum += partial[w][i][j][src_lane][rt & 3];
+    for (int w = 0; w < WAVES; ++w) {
+      sum += partial[0][w][i][j][src_lane][rt & 3];
+      if (DUAL) sum2 += partial[ND - 1][w][i][j][src_lane][rt & 3];
+    }
     if (row >= M || col >= N) continue;
     const int64_t idx = static_cast<int64_t>(row) * ep.ldy + col;
     if (ep.mode == 0) {
       ep.c_i32[idx] = sum;
     } else {
       // CPU formula order (src/cpu/kernels.cc:666-673): c * (1/a_scale) / b_scale + bias.
-      float v = static_cast<float>(sum) * (1.f / e_ra[o]);
+      const float r_a = 1.f / e_ra[o];
+      float v = static_cast<float>(sum) * r_a;
       v = v / e_ws[o];
       if (ep.bias) v = v + e_bias[o];
       v = apply_activation(v, ep.act);
+      if (DUAL) {
+        float v2 = static_cast<float>(sum2) * r_a;
+        v2 = v2 / e_ws2[o];
+        if (ep.bias2) v2 = v2 + e_bias2[o];
+        v = v2 * v;  // ops::Mul()(linear_0_noact_out, activated, out)
+      }
       if (ep.residual) v = e_res[o] + v;
       ep.y[idx] = v;
     }
@@ -350,6 +381,27 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
   }();
   const int64_t sel = forced ? (forced <= 32 ? 1 : (forced <= 64 ? 33 : 65)) : m;
   static const bool no_skinny = std::getenv("CT2X_NO_SKINNY_GEMM") != nullptr;
+  if (ep.b2 != nullptr) {
+    // Gated pair (see gemm_s8_skinny_kernel<..., DUAL>): only the decode shapes take this form
+    // (gemm_s8_dual_applicable); column tiles per workgroup are halved, both streams count.
+    if (!(mfma_ok && m <= 32 && ep.mode == 1 && (reinterpret_cast<uintptr_t>(ep.b2) & 15) == 0))
+      throw Error("launch_gemm_s8: the gated (dual) form needs M <= 32 and 16-byte aligned operands");
+#define CT2X_DUAL(MT, NT, WAVES, U)                                                              \
+  hipLaunchKernelGGL((gemm_s8_skinny_kernel<MT, NT, WAVES, U, true>),                            \
+                     dim3((n + 16 * NT - 1) / (16 * NT)), dim3(WAVES * 64), 0, stream, a, b, M, N, \
+                     K, ep)
+    if (m <= 16) {
+      if (k >= 4096) CT2X_DUAL(1, 2, 16, 2);
+      else if (k >= 2048) CT2X_DUAL(1, 1, 8, 4);
+      else CT2X_DUAL(1, 1, 4, 4);
+    } else {
+      if (k >= 4096) CT2X_DUAL(2, 2, 8, 2);
+      else if (k >= 2048) CT2X_DUAL(2, 1, 8, 2);
+      else CT2X_DUAL(2, 1, 4, 2);
+    }
+#undef CT2X_DUAL
+    return;
+  }
   if (m <= 128 && !forced && !no_skinny) {
     // Decode-step shapes (rows = batch * beam): one memory round trip per launch
     // (see gemm_s8_skinny_kernel). MT = row tiles of 16, NT = column tiles per workgroup.
@@ -357,7 +409,35 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
   hipLaunchKernelGGL((gemm_s8_skinny_kernel<MT, NT, WAVES, U>), dim3((n + 16 * NT - 1) / (16 * NT)), \
                      dim3(WAVES * 64), 0, stream, a, b, M, N, K, ep)
     const int mt = m <= 16 ? 1 : (m <= 32 ? 2 : (m <= 64 ? 4 : 8));
-    if (n >= 8192) {
+    // Tuning override (tools/gemm_bench.cpp): CT2X_SKINNY_CFG="NT,WAVES,U" for m <= 32.
+    static const int cfg = [] {
+      const char* e = std::getenv("CT2X_SKINNY_CFG");
+      int nt = 0, wv = 0, u = 0;
+      if (e && std::sscanf(e, "%d,%d,%d", &nt, &wv, &u) == 3) return nt * 10000 + wv * 100 + u;
+      return 0;
+    }();
+    if (cfg != 0 && mt <= 2) {
+#define CT2X_TRY(NT, WAVES, U)                                         \
+  if (cfg == NT * 10000 + WAVES * 100 + U) {                           \
+    if (mt == 1) CT2X_SKINNY(1, NT, WAVES, U);                         \
+    else CT2X_SKINNY(2, NT, WAVES, U);                                 \
+    return;                                                            \
+  }
+      CT2X_TRY(1, 4, 4) CT2X_TRY(1, 4, 8) CT2X_TRY(1, 8, 4) CT2X_TRY(1, 8, 8) CT2X_TRY(1, 16, 4)
+      CT2X_TRY(2, 4, 4) CT2X_TRY(2, 4, 8) CT2X_TRY(2, 8, 2) CT2X_TRY(2, 8, 4) CT2X_TRY(2, 8, 8)
+      CT2X_TRY(2, 16, 2) CT2X_TRY(2, 16, 4)
+      CT2X_TRY(4, 4, 2) CT2X_TRY(4, 4, 4) CT2X_TRY(4, 8, 2) CT2X_TRY(4, 8, 4) CT2X_TRY(4, 16, 2)
+#undef CT2X_TRY
+    }
+    // Shapes measured with tools/skinny_sweep.sh (weights rotated through 600 MB, MI355X):
+    // long weight streams want 16 waves per workgroup (more bytes in flight per CU); the
+    // Transformer-base shapes (K = 512 / 2048) keep the 4-8 wave forms.
+    if (mt == 1 && k >= 4096) {
+      if (n >= 8192) CT2X_SKINNY(1, 4, 16, 2);        // [16, 14336, 4096] 19.2 -> 15.5 us
+      else if (k >= 8192) CT2X_SKINNY(1, 1, 16, 4);   // [16, 4096, 14336] 20.5 -> 18.3 us
+      else if (n >= 6144) CT2X_SKINNY(1, 2, 8, 8);    // [16, 6144, 4096]  10.4 ->  9.3 us
+      else CT2X_SKINNY(1, 1, 16, 4);                  // [16, 4096, 4096]   7.6 ->  6.7 us
+    } else if (n >= 8192) {
       if (mt == 1) CT2X_SKINNY(1, 4, 4, 2);
       else if (mt == 2) CT2X_SKINNY(2, 4, 4, 2);
       else if (mt == 4) CT2X_SKINNY(4, 2, 4, 2);

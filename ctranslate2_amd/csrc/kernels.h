@@ -71,6 +71,11 @@ struct GemmS8Epilogue {
   float* y = nullptr;
   int act = -1;
   int64_t ldy = 0;  // leading dimension of y / residual / c_i32 (>= n)
+  // Gated pair (ffn_glu): when b2 != nullptr the launch also streams a second weight [n, k] and
+  // stores y = act(acc * .. / w_scale + bias) * (acc2 * .. / w_scale2 + bias2). M <= 32 only.
+  const int8_t* b2 = nullptr;
+  const float* w_scale2 = nullptr;
+  const float* bias2 = nullptr;
 };
 
 // C[m,n] = A[m,k] . B[n,k]^T   (lda = ldb = k). Chooses a tile shape from (m, n, k).

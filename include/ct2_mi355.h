@@ -132,6 +132,15 @@ int ct2x_gemm_s8_dequant(const int8_t* d_qa, const float* d_a_scale, const int8_
                          int64_t m, int64_t n, int64_t k, int activation, void* d_y, int dtype,
                          void* stream);
 
+/* The gated FFN input pair (FeedForwardNetwork::operator(), src/layers/transformer.cc:21-51 with
+ * ffn_glu: linear_0 + activation, linear_0_noact, ops::Mul) as ONE launch for decode rows
+ * (m <= 32):  y = act( (qa . W0^T) * (1/a_scale) / w0_scale + b0 ) * ( (qa . W1^T) * (1/a_scale)
+ * / w1_scale + b1 ). Biases may be NULL. */
+int ct2x_gemm_s8_glu(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w0,
+                     const float* d_w0_scale, const float* d_b0, const int8_t* d_w1,
+                     const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n, int64_t k,
+                     int activation, void* d_y, int dtype, void* stream);
+
 /* ops::Dequantize::dequantize<Device::CUDA,int8_t,T> (src/ops/dequantize_gpu.cu:17-28):
  * y[r,:] = x[r,:] / scale[r]  (int8 embedding rows, src/layers/common.cc:64-81). */
 int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,

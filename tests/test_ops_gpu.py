@@ -118,6 +118,27 @@ def test_dense_fused_vs_unfused_oracle(gpu, m, n, k, act, with_res):
         np.testing.assert_allclose(y, yo, rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("m,n,k", [(16, 14336, 4096), (32, 2048, 512), (5, 96, 64), (16, 1000, 2048)])
+@pytest.mark.parametrize("act,with_bias", [(2, False), (0, True), (3, True)])
+def test_dense_glu_fused(gpu, m, n, k, act, with_bias):
+    """ffn_glu input pair (src/layers/transformer.cc:21-51): act(Dense0(x)) * Dense1(x) as one
+    launch against the oracle's two Dense chains and the element-wise product."""
+    import _gpuops as G
+    rng = np.random.default_rng(m + n + k + act)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w0q, w0s = O.quantize_s8((rng.standard_normal((n, k)) * 0.02).astype(np.float32), True)
+    w1q, w1s = O.quantize_s8((rng.standard_normal((n, k)) * 0.02).astype(np.float32), True)
+    b0 = (rng.standard_normal(n) * 0.01).astype(np.float32) if with_bias else None
+    b1 = (rng.standard_normal(n) * 0.01).astype(np.float32) if with_bias else None
+    q, s = G.quantize_s8(x, True)
+    y = G.gemm_s8_glu(q, s, w0q, w0s, b0, w1q, w1s, b1, act)
+    yo = O.dense_s8(x, w1q, w1s, b1, None, -1, True) * O.dense_s8(x, w0q, w0s, b0, None, act, True)
+    if act == 0:
+        assert np.array_equal(y, yo)
+    else:
+        np.testing.assert_allclose(y, yo, rtol=2e-5, atol=1e-6)  # libm expf/erff in the gate, times up
+
+
 def test_dequantize_rows(gpu):
     import _gpuops as G
     rng = np.random.default_rng(3)

@@ -72,10 +72,23 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(s));
     const double ops = 2.0 * M * N * K;
     const int reps = ops > 1e11 ? 20 : 100;
+    // Decode shapes (M <= 128) stream weights that are never cache resident in the real loop
+    // (7.5 GB per step for the Llama shape): rotate through > 512 MB of weight copies so the
+    // 256 MB Infinity Cache cannot flatter the number.
+    int copies = 1;
+    int8_t* brot = nullptr;
+    if (M <= 128) {
+      copies = (int)((600ull << 20) / (N * K)) + 1;
+      CK(hipMalloc(&brot, (size_t)copies * N * K));
+      hipLaunchKernelGGL(fill_s8, dim3(4096), dim3(256), 0, s, brot, (size_t)copies * N * K, 3u);
+      CK(hipStreamSynchronize(s));
+    }
+    int rot = 0;
     for (int mode = 0; mode < 2; ++mode) {
       auto launch = [&] {
-        if (mode == 0) CX(ct2x_gemm_s8s8s32(a, b, M, N, K, c, s));
-        else CX(ct2x_gemm_s8_dequant(a, as, b, ws, bias, nullptr, M, N, K, 0, y, 0, s));
+        const int8_t* bb = brot ? brot + (size_t)(rot++ % copies) * N * K : b;
+        if (mode == 0) CX(ct2x_gemm_s8s8s32(a, bb, M, N, K, c, s));
+        else CX(ct2x_gemm_s8_dequant(a, as, bb, ws, bias, nullptr, M, N, K, 0, y, 0, s));
       };
       for (int i = 0; i < 3; ++i) launch();
       CK(hipEventRecord(e0, s));
@@ -89,6 +102,7 @@ int main(int argc, char** argv) {
              mode == 0 ? "gemm_s8s8s32" : "gemm_s8_dequant+relu", sh.m, sh.n, sh.k, us, ops / us / 1e6,
              ops / us / 1e6 / 50.0, bytes / us / 1e3, mis, samples);
     }
+    if (brot) CK(hipFree(brot));
     CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(c)); CK(hipFree(y)); CK(hipFree(as)); CK(hipFree(ws)); CK(hipFree(bias));
   }
   return 0;
