@@ -49,6 +49,10 @@ def parse_args():
     p.add_argument("--streams", type=int, default=0,
                    help="concurrent decode streams per GPU (0 = library default)")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--tp", action="store_true",
+                   help="tensor parallel over the --gpus ranks (one sharded model, every rank runs "
+                        "the same batch, RCCL all-reduce after each row-parallel Dense) instead of "
+                        "independent replicas; strong scaling")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-profile", action="store_true")
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline")
@@ -166,8 +170,11 @@ def main():
     model_dir = "/tmp/ct2x_bench_tb_r%d" % local_rank
     if not os.path.exists(os.path.join(model_dir, "model.bin")):
         mb.build_transformer(model_dir, **TB)
-    translator = ct2.Translator(model_dir, device="cuda", device_index=local_rank, compute_type="int8")
-    sources = make_sources(rank, args.batch, args.src_len, TB["vocab_size"])
+    tp = args.tp and world > 1
+    translator = ct2.Translator(model_dir, device="cuda", device_index=local_rank, compute_type="int8",
+                                tensor_parallel=tp)
+    # replicas: every rank has its own batch; tensor parallel: ONE batch, computed by all ranks
+    sources = make_sources(0 if tp else rank, args.batch, args.src_len, TB["vocab_size"])
     kw = dict(beam_size=args.beam, max_decoding_length=args.max_len, min_decoding_length=args.max_len,
               use_graph=not args.no_graph, num_streams=args.streams)
 
@@ -192,6 +199,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     value, max_elapsed, total_tokens = aggregate_throughput(tokens, elapsed, dist if world > 1 else None, device)
+    if tp:  # the ranks produced the SAME tokens together
+        total_tokens //= world
+        value /= world
     stats = translator.last_stats()
 
     result = {
@@ -203,7 +213,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": max_elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if tp else "weak",
         "vs_baseline": None,
         "dtype": "int8",
         "data": "synthetic",
@@ -213,7 +223,9 @@ def main():
                         "source length %d, %d forced decode steps, random-init weights N(0,0.02)"
                         % (args.batch, args.beam, args.src_len, args.max_len),
             "tokens_per_step_per_gpu": tokens // max(args.steps, 1),
-            "parallelism": "replicas x%d (one process per GPU, no data-path collective)" % world,
+            "parallelism": ("tensor parallel x%d (heads / FFN split, RCCL all-reduce of int32 partial "
+                            "products after every row-parallel Dense)" % world) if tp else
+                           "replicas x%d (one process per GPU, no data-path collective)" % world,
             "hip_graph": not args.no_graph,
             "streams_per_gpu": args.streams if args.streams > 0 else int(os.environ.get("CT2X_NUM_STREAMS", "1")),
             "kernels_per_decode_step": stats["kernels_per_step"],

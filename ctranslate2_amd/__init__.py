@@ -36,13 +36,22 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
     """
 
     def __init__(self, model_path: str, device: str = "cuda", device_index: int = 0,
-                 compute_type: str = "default"):
+                 compute_type: str = "default", tensor_parallel: bool = False, _handle=None):
+        """tensor_parallel=True (reference: ctranslate2.Translator(..., tensor_parallel=True) under
+        mpirun): one process per GPU launched by torch.distributed.run; torch.distributed must be
+        initialised. Heads and the FFN inner dimension are split over the WORLD_SIZE ranks and the
+        row-parallel layers all-reduce over RCCL/xGMI; every rank must make the same calls."""
         if device not in ("cuda", "auto"):
             raise ValueError("ctranslate2_amd only implements the GPU device (device='cuda'); "
                              "got device=%r" % device)
         self._L = _lib.lib()
-        self._h = self._L.ct2x_translator_create(model_path.encode(), C.c_int(device_index),
-                                                 compute_type.encode())
+        if _handle is not None:
+            self._h = _handle
+        elif tensor_parallel:
+            self._h = self._create_tensor_parallel(model_path, device_index, compute_type)
+        else:
+            self._h = self._L.ct2x_translator_create(model_path.encode(), C.c_int(device_index),
+                                                     compute_type.encode())
         if not self._h:
             raise Ct2xError(self._L.ct2x_last_error().decode("utf-8", "replace"))
         self.model_path = model_path
@@ -53,6 +62,42 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         self.is_seq2seq = info["is_seq2seq"]
         self.eos_id = info["eos_id"]
         self.bos_id = info["bos_id"]
+
+    def _create_tensor_parallel(self, model_path, device_index, compute_type):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("tensor_parallel=True needs an initialised torch.distributed "
+                               "process group (one process per GPU)")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            _lib.check(self._L.ct2x_tp_unique_id(buf))
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if world > 1:
+            if dist.get_backend() == "nccl":  # RCCL group: the broadcast needs a device tensor
+                dev = uid.to(torch.device("cuda", device_index))
+                dist.broadcast(dev, src=0)
+                uid = dev.cpu()
+            else:
+                dist.broadcast(uid, src=0)
+        raw = bytes(uid.numpy().tobytes())
+        return self._L.ct2x_translator_create_tp(model_path.encode(), C.c_int(device_index),
+                                                 compute_type.encode(), C.c_int(rank), C.c_int(world),
+                                                 C.c_char_p(raw))
+
+    @classmethod
+    def tensor_parallel_local(cls, model_path: str, world: int, device_index: int = 0,
+                              compute_type: str = "default"):
+        """`world` tensor-parallel ranks inside THIS process on one device, connected by the
+        in-process communicator (tests: drive each returned Translator from its own thread)."""
+        L = _lib.lib()
+        handles = (C.c_void_p * world)()
+        _lib.check(L.ct2x_translator_create_tp_local(model_path.encode(), C.c_int(device_index),
+                                                     compute_type.encode(), C.c_int(world), handles))
+        return [cls(model_path, device_index=device_index, compute_type=compute_type,
+                    _handle=handles[r]) for r in range(world)]
 
     def close(self):
         if getattr(self, "_h", None):

@@ -72,6 +72,12 @@ def lib():
         L.ct2x_translator_create.restype = C.c_void_p
         L.ct2x_translator_create.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
         L.ct2x_translator_destroy.argtypes = [C.c_void_p]
+        L.ct2x_translator_create_tp.restype = C.c_void_p
+        L.ct2x_translator_create_tp.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                                C.c_char_p]
+        L.ct2x_translator_create_tp_local.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int,
+                                                      C.POINTER(C.c_void_p)]
+        L.ct2x_tp_unique_id.argtypes = [C.c_char_p]
         L.ct2x_vocab_token.restype = C.c_char_p
         L.ct2x_vocab_token.argtypes = [C.c_void_p, C.c_int, C.c_int32]
         L.ct2x_vocab_id.restype = C.c_int32

@@ -209,6 +209,109 @@ void* ct2x_translator_create(const char* model_dir, int device_index, const char
   }
 }
 
+// ---- tensor parallelism (reference ScopedMPISetter + Model::load sharding) --------
+
+int ct2x_tp_unique_id(void* id_out_128_bytes) {
+  API_TRY
+  rccl_get_unique_id(id_out_128_bytes);
+  API_CATCH
+}
+
+int ct2x_tp_shard_rows(int64_t n, const int64_t* blocks, int32_t num_blocks, int32_t rank,
+                       int32_t world, int64_t* first_out, int64_t* count_out) {
+  API_TRY
+  CT2X_CHECK(world >= 1 && rank >= 0 && rank < world, "invalid tensor-parallel rank / world size");
+  std::vector<int64_t> sizes(blocks, blocks + num_blocks);
+  if (sizes.empty()) sizes.push_back(n);
+  int64_t total = 0;
+  for (int64_t b : sizes) total += b;
+  CT2X_CHECK(total == n, "fused blocks do not add up to the weight's rows");
+  int64_t base = 0;
+  for (size_t i = 0; i < sizes.size(); ++i) {
+    CT2X_CHECK(sizes[i] % world == 0, "dimension " + std::to_string(sizes[i]) +
+                                          " is not divisible by the tensor-parallel world size");
+    first_out[i] = base + rank * (sizes[i] / world);
+    count_out[i] = sizes[i] / world;
+    base += sizes[i];
+  }
+  API_CATCH
+}
+
+int ct2x_tp_selftest_rccl(int device_index) {
+  API_TRY
+  // One-rank RCCL communicator on this device: exercises library resolution, the by-value
+  // unique id, the datatype / op codes and the stream plumbing of the multi-GPU path on a
+  // single-GPU box (an all-reduce over one rank is the identity).
+  CT2X_HIP_CHECK(hipSetDevice(device_index));
+  char id[kTpUniqueIdBytes];
+  rccl_get_unique_id(id);
+  auto comm = make_rccl_comm(0, 1, id);
+  hipStream_t stream = thread_stream();
+  const int n = 1024;
+  std::vector<int32_t> hi(n);
+  std::vector<float> hf(n);
+  for (int i = 0; i < n; ++i) {
+    hi[i] = i * 7 - 100;
+    hf[i] = 0.25f * i - 3.f;
+  }
+  auto* di = static_cast<int32_t*>(device_malloc(n * 4));
+  auto* df = static_cast<float*>(device_malloc(n * 4));
+  CT2X_HIP_CHECK(hipMemcpyAsync(di, hi.data(), n * 4, hipMemcpyHostToDevice, stream));
+  CT2X_HIP_CHECK(hipMemcpyAsync(df, hf.data(), n * 4, hipMemcpyHostToDevice, stream));
+  comm->all_reduce_sum_i32(di, n, stream);
+  comm->all_reduce_max_f32(df, n, stream);
+  comm->all_reduce_sum_f32(df, n, stream);
+  std::vector<int32_t> oi(n);
+  std::vector<float> of(n);
+  CT2X_HIP_CHECK(hipMemcpyAsync(oi.data(), di, n * 4, hipMemcpyDeviceToHost, stream));
+  CT2X_HIP_CHECK(hipMemcpyAsync(of.data(), df, n * 4, hipMemcpyDeviceToHost, stream));
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+  device_free(di);
+  device_free(df);
+  CT2X_CHECK(oi == hi && of == hf, "one-rank RCCL all-reduce did not return its input");
+  API_CATCH
+}
+
+void* ct2x_translator_create_tp(const char* model_dir, int device_index, const char* compute_type,
+                                int rank, int world, const void* unique_id_128_bytes) {
+  try {
+    CT2X_CHECK(world >= 1 && rank >= 0 && rank < world, "invalid tensor-parallel rank / world size");
+    auto t = std::make_unique<Translator>();
+    t->model = ModelFile::load(model_dir);
+    std::shared_ptr<TpComm> comm;
+    if (world > 1) {
+      CT2X_CHECK(unique_id_128_bytes != nullptr, "tensor parallelism needs the RCCL unique id");
+      CT2X_HIP_CHECK(hipSetDevice(device_index));
+      comm = make_rccl_comm(rank, world, unique_id_128_bytes);
+    }
+    t->engine = std::make_unique<Engine>(t->model, compute_type ? compute_type : "default",
+                                         device_index, comm);
+    load_vocabularies(*t);
+    return t.release();
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return nullptr;
+  }
+}
+
+int ct2x_translator_create_tp_local(const char* model_dir, int device_index,
+                                    const char* compute_type, int world, void** handles_out) {
+  API_TRY
+  CT2X_HIP_CHECK(hipSetDevice(device_index));
+  auto comms = make_local_comms(world);
+  std::vector<std::unique_ptr<Translator>> ts;
+  for (int r = 0; r < world; ++r) {
+    auto t = std::make_unique<Translator>();
+    t->model = ModelFile::load(model_dir);
+    t->engine = std::make_unique<Engine>(t->model, compute_type ? compute_type : "default",
+                                         device_index, comms[r]);
+    load_vocabularies(*t);
+    ts.push_back(std::move(t));
+  }
+  for (int r = 0; r < world; ++r) handles_out[r] = ts[r].release();
+  API_CATCH
+}
+
 void ct2x_translator_destroy(void* translator) { delete static_cast<Translator*>(translator); }
 
 int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t* src_lengths,

@@ -72,8 +72,9 @@ hipStream_t Engine::cur_stream() const { return tls_stream ? tls_stream : stream
 // ---------------------------------------------------------------------------------------------
 
 Engine::Engine(std::shared_ptr<ModelFile> model, const std::string& compute_type,
-               int device_index)
-    : model_(std::move(model)), device_(device_index) {
+               int device_index, std::shared_ptr<TpComm> tp)
+    : model_(std::move(model)), tp_(std::move(tp)), device_(device_index) {
+  if (tp_ && tp_->world() <= 1) tp_.reset();
   CT2X_HIP_CHECK(hipSetDevice(device_));
   stream_ = thread_stream();
   round_before_cast_ = model_->round_before_cast_in_quantization();
@@ -125,7 +126,50 @@ const float* Engine::upload_floats(const std::vector<float>& v) {
   return static_cast<const float*>(upload(v.data(), v.size() * sizeof(float)));
 }
 
-DenseW Engine::load_dense(const std::string& scope, bool required) {
+namespace {
+
+// Row ranges [first, first + count) of a [n, *] matrix owned by `rank` when every block of
+// `blocks` rows (fused sub-matrices; one block = the whole matrix) is split evenly.
+std::vector<std::pair<int64_t, int64_t>> column_shard_rows(int64_t n, const std::vector<int64_t>& blocks,
+                                                           int rank, int world,
+                                                           const std::string& scope) {
+  std::vector<int64_t> sizes = blocks.empty() ? std::vector<int64_t>{n} : blocks;
+  int64_t total = 0;
+  for (int64_t b : sizes) total += b;
+  if (total != n)
+    throw std::runtime_error(scope + ": fused blocks do not add up to the weight's rows");
+  std::vector<std::pair<int64_t, int64_t>> out;
+  int64_t base = 0;
+  for (int64_t b : sizes) {
+    if (b % world != 0)
+      throw std::invalid_argument(scope + ": output dimension " + std::to_string(b) +
+                                  " is not divisible by the tensor-parallel world size " +
+                                  std::to_string(world));
+    out.emplace_back(base + rank * (b / world), b / world);
+    base += b;
+  }
+  return out;
+}
+
+template <typename T>
+std::vector<T> take_rows(const T* src, int64_t k, const std::vector<std::pair<int64_t, int64_t>>& rows) {
+  std::vector<T> out;
+  for (const auto& r : rows) out.insert(out.end(), src + r.first * k, src + (r.first + r.second) * k);
+  return out;
+}
+
+template <typename T>
+std::vector<T> take_cols(const T* src, int64_t n, int64_t k, int64_t k0, int64_t k1) {
+  std::vector<T> out(static_cast<size_t>(n) * (k1 - k0));
+  for (int64_t i = 0; i < n; ++i)
+    std::copy(src + i * k + k0, src + i * k + k1, out.begin() + i * (k1 - k0));
+  return out;
+}
+
+}  // namespace
+
+DenseW Engine::load_dense(const std::string& scope, bool required, Shard shard,
+                          const std::vector<int64_t>& blocks) {
   DenseW d;
   const Variable* w = model_->find(scope + "/weight");
   if (!w) {
@@ -142,14 +186,21 @@ DenseW Engine::load_dense(const std::string& scope, bool required) {
   d.k = w->shape[1];
   const Variable* scale = model_->find(scope + "/weight_scale");
   const bool want_int8 = (compute_type_ == ComputeType::kInt8Float32);
+  if (!tp_) shard = Shard::kNone;
 
+  // The whole matrix is brought to its device form on the host first (int8 + per-row scales, or
+  // fp32); the tensor-parallel slice is cut afterwards so that a row-parallel layer keeps the
+  // scales of the FULL rows (Model::load shards after conversion too, src/models/model.cc:662-743).
+  const int8_t* q_src = nullptr;
+  std::vector<int8_t> q_own;
+  std::vector<float> s_full, wf;
   if (want_int8 && w->dtype == kI8 && scale && scale->size() == d.n) {
     d.quantized = true;
-    d.wq = static_cast<const int8_t*>(upload(w->data.data(), w->data.size()));
-    d.wscale = upload_floats(scale->to_float());
+    q_src = reinterpret_cast<const int8_t*>(w->data.data());
+    s_full = scale->to_float();
   } else {
     // Bring the weight to float first (Dequantize: x / scale, src/ops/dequantize_cpu.cc).
-    std::vector<float> wf = w->to_float();
+    wf = w->to_float();
     if (w->dtype == kI8 || w->dtype == kI16) {
       if (!scale) {
         if (w->dtype == kI16) {
@@ -168,17 +219,49 @@ DenseW Engine::load_dense(const std::string& scope, bool required) {
       }
     }
     if (want_int8) {
-      std::vector<int8_t> q;
-      std::vector<float> s;
-      host_quantize_rows(wf, d.n, d.k, round_before_cast_, q, s);
+      host_quantize_rows(wf, d.n, d.k, round_before_cast_, q_own, s_full);
       d.quantized = true;
-      d.wq = static_cast<const int8_t*>(upload(q.data(), q.size()));
-      d.wscale = upload_floats(s);
-    } else {
-      d.wf = upload_floats(wf);
+      q_src = q_own.data();
+      wf.clear();
     }
   }
-  if (const Variable* b = model_->find(scope + "/bias")) d.bias = upload_floats(b->to_float());
+  std::vector<float> bias;
+  if (const Variable* b = model_->find(scope + "/bias")) bias = b->to_float();
+
+  if (shard == Shard::kColumn) {
+    const auto rows = column_shard_rows(d.n, blocks, tp_->rank(), tp_->world(), scope);
+    if (d.quantized) {
+      q_own = take_rows(q_src, d.k, rows);
+      q_src = q_own.data();
+      s_full = take_rows(s_full.data(), 1, rows);
+    } else {
+      wf = take_rows(wf.data(), d.k, rows);
+    }
+    if (!bias.empty()) bias = take_rows(bias.data(), 1, rows);
+    d.n = 0;
+    for (const auto& r : rows) d.n += r.second;
+  } else if (shard == Shard::kRow) {
+    if (d.k % tp_->world() != 0)
+      throw std::invalid_argument(scope + ": input dimension " + std::to_string(d.k) +
+                                  " is not divisible by the tensor-parallel world size");
+    const int64_t kl = d.k / tp_->world(), k0 = tp_->rank() * kl;
+    if (d.quantized) {
+      q_own = take_cols(q_src, d.n, d.k, k0, k0 + kl);
+      q_src = q_own.data();
+    } else {
+      wf = take_cols(wf.data(), d.n, d.k, k0, k0 + kl);
+    }
+    d.k = kl;
+    d.row_parallel = true;  // scales and bias stay whole: applied once, after the rank sum
+  }
+
+  if (d.quantized) {
+    d.wq = static_cast<const int8_t*>(upload(q_src, static_cast<size_t>(d.n) * d.k));
+    d.wscale = upload_floats(s_full);
+  } else {
+    d.wf = upload_floats(wf);
+  }
+  if (!bias.empty()) d.bias = upload_floats(bias);
   return d;
 }
 
@@ -209,11 +292,31 @@ AttnW Engine::load_attention(const std::string& scope, bool self_attention, int6
                                " is not supported by this backend yet");
   a.ln = load_norm(scope + "/layer_norm");
   a.n_lin = self_attention ? 2 : 3;
-  for (int i = 0; i < a.n_lin; ++i)
-    a.lin[i] = load_dense(scope + "/linear_" + std::to_string(i), true);
   a.heads = num_heads;
-  const int64_t d_model = a.lin[a.n_lin - 1].n;
+  // Geometry from the unsharded variables.
+  const Variable* w_out = model_->find(scope + "/linear_" + std::to_string(a.n_lin - 1) + "/weight");
+  if (!w_out || w_out->shape.size() != 2)
+    throw std::out_of_range("variable " + scope + "/linear_" + std::to_string(a.n_lin - 1) +
+                            "/weight not found");
+  const int64_t d_model = w_out->shape[0];
   a.dhead = static_cast<int64_t>(model_->attribute(scope + "/head_dim", double(d_model / num_heads)));
+  {
+    const bool mq = model_->flag(scope + "/multi_query", false);
+    const int64_t hkv = mq ? 1
+                           : static_cast<int64_t>(
+                                 model_->attribute(scope + "/num_heads_kv", double(num_heads)));
+    const int64_t qdim = num_heads * a.dhead, kvdim = hkv * a.dhead;
+    // Tensor parallel: heads are split over the ranks - column-parallel input projections
+    // (Q | K | V split block-wise), row-parallel output projection.
+    if (self_attention) {
+      a.lin[0] = load_dense(scope + "/linear_0", true, Shard::kColumn, {qdim, kvdim, kvdim});
+      a.lin[1] = load_dense(scope + "/linear_1", true, Shard::kRow);
+    } else {
+      a.lin[0] = load_dense(scope + "/linear_0", true, Shard::kColumn, {qdim});
+      a.lin[1] = load_dense(scope + "/linear_1", true, Shard::kColumn, {kvdim, kvdim});
+      a.lin[2] = load_dense(scope + "/linear_2", true, Shard::kRow);
+    }
+  }
   a.queries_scale = static_cast<float>(
       model_->attribute(scope + "/queries_scale", 1.0 / std::sqrt(static_cast<float>(a.dhead))));
   if (!model_->has(scope + "/queries_scale"))
@@ -222,6 +325,10 @@ AttnW Engine::load_attention(const std::string& scope, bool self_attention, int6
   a.heads_kv = multi_query ? 1
                            : static_cast<int64_t>(model_->attribute(scope + "/num_heads_kv",
                                                                     double(num_heads)));
+  if (tp_) {  // this rank's share of the heads (divisibility was checked by load_dense)
+    a.heads /= tp_->world();
+    a.heads_kv /= tp_->world();
+  }
   if (model_->attribute(scope + "/sliding_window", 0) != 0)
     throw std::runtime_error("sliding window attention is not supported by this backend yet");
   // make_rotary_embeddings (src/layers/attention_layer.cc:68-110).
@@ -253,9 +360,9 @@ AttnW Engine::load_attention(const std::string& scope, bool self_attention, int6
 FfnW Engine::load_ffn(const std::string& scope, int activation) {
   FfnW f;
   f.ln = load_norm(scope + "/layer_norm");
-  f.l0 = load_dense(scope + "/linear_0", true);
-  f.l0_noact = load_dense(scope + "/linear_0_noact", false);
-  f.l1 = load_dense(scope + "/linear_1", true);
+  f.l0 = load_dense(scope + "/linear_0", true, Shard::kColumn);
+  f.l0_noact = load_dense(scope + "/linear_0_noact", false, Shard::kColumn);
+  f.l1 = load_dense(scope + "/linear_1", true, Shard::kRow);
   f.activation = activation;
   return f;
 }
@@ -560,6 +667,56 @@ void Engine::norm_quant(const NormW& w, const float* x, int64_t rows, int64_t de
 // layers::Dense::operator() (src/layers/common.cc:339-442).
 void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t m, int act,
                    const float* residual, float* y, DecodeState* ws) {
+  if (w.row_parallel && tp_) {
+    // Row-parallel Dense (attention-out / FFN-out; layers::Dense TP arm, src/layers/common.cc:
+    // 348-401): this rank holds K/world input columns. int8: global Quantize scale = max over
+    // ranks of the slice absmax, exact int32 partial products summed over ranks, ONE dequantise
+    // (+bias, +residual) on every rank - bit-identical to the unsharded layer. float: fp32 partial
+    // products summed over ranks, then bias and residual.
+    CT2X_CHECK(x != nullptr && act < 0, "row-parallel Dense takes the fp32 activation, no activation");
+    CT2X_CHECK(ws && ws->tp_acc && ws->tp_amax, "tensor-parallel scratch buffers are missing");
+    if (w.quantized) {
+      begin_kernel("tp_row_amax", double(m) * w.k * 4, 0, m, 0, w.k);
+      launch_row_amax(x, m, w.k, ws->tp_amax, cur_stream());
+      end_kernel();
+      begin_kernel("tp_all_reduce_max", double(m) * 4, 0, m, 0, 0);
+      tp_->all_reduce_max_f32(ws->tp_amax, m, cur_stream());
+      end_kernel();
+      begin_kernel("tp_quantize", double(m) * w.k * 5, 0, m, 0, w.k);
+      launch_quantize_with_amax(x, ws->tp_amax, m, w.k, quant_mode_, ws->qbuf, ws->qscale,
+                                cur_stream());
+      end_kernel();
+      GemmS8Epilogue ep;
+      ep.mode = 0;
+      ep.c_i32 = ws->tp_acc;
+      ep.ldy = w.n;
+      begin_kernel("gemm_s8s8s32", double(m) * w.k + double(w.n) * w.k + 4.0 * m * w.n,
+                   2.0 * m * w.n * w.k, m, w.n, w.k);
+      launch_gemm_s8(ws->qbuf, w.wq, m, w.n, w.k, ep, cur_stream());
+      end_kernel();
+      begin_kernel("tp_all_reduce_sum", double(m) * w.n * 4, 0, m, w.n, 0);
+      tp_->all_reduce_sum_i32(ws->tp_acc, m * w.n, cur_stream());
+      end_kernel();
+      begin_kernel("dequantize_gemm_output", double(m) * w.n * 8, 0, m, w.n, 0);
+      launch_dequantize_gemm_output(ws->tp_acc, ws->qscale, w.wscale, w.bias, m, w.n, -1, y,
+                                    cur_stream(), residual);
+      end_kernel();
+    } else {
+      float* acc = reinterpret_cast<float*>(ws->tp_acc);
+      begin_kernel("gemm_f32", 4.0 * (double(m) * w.k + double(w.n) * w.k + double(m) * w.n),
+                   2.0 * m * w.n * w.k, m, w.n, w.k);
+      launch_gemm_f32(x, w.wf, 1, m, w.n, w.k, true, 1.f, 0, 0, 0, nullptr, nullptr, -1, acc,
+                      cur_stream());
+      end_kernel();
+      begin_kernel("tp_all_reduce_sum", double(m) * w.n * 4, 0, m, w.n, 0);
+      tp_->all_reduce_sum_f32(acc, m * w.n, cur_stream());
+      end_kernel();
+      begin_kernel("bias_residual", double(m) * w.n * 8, 0, m, w.n, 0);
+      launch_bias_residual(acc, w.bias, residual, m, w.n, y, cur_stream());
+      end_kernel();
+    }
+    return;
+  }
   if (w.quantized) {
     QuantIn local;
     if (!qin) {
@@ -676,6 +833,10 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   st->ctx = alloc<float>(*st, wrows * d);
   st->inner = alloc<float>(*st, wrows * wffn);
   st->inner2 = alloc<float>(*st, wrows * wffn);
+  if (tp_) {
+    st->tp_acc = alloc<int32_t>(*st, wrows * d);
+    st->tp_amax = alloc<float>(*st, wrows);
+  }
   st->qbuf = alloc<int8_t>(*st, wrows * std::max(d, wffn));
   st->qscale = alloc<float>(*st, wrows);
   st->logits = alloc<float>(*st, rows * V);
@@ -1042,7 +1203,7 @@ void Engine::launch_step(DecodeState& st) {
         p.rope_interleave = a.rotary_interleave;
       }
       p.out = st.ctx;
-      if (a.lin[1].quantized && attention_decode_can_fuse_quantize(p)) {
+      if (a.lin[1].quantized && !tp_ && attention_decode_can_fuse_quantize(p)) {
         // attention + ops::Quantize of the context in one launch (kFusedQ)
         begin_kernel("attention_self_decode_q", 0, 0, rows, a.heads, a.dhead);
         launch_attention_decode_quantized(p, quant_mode_, st.qbuf, st.qscale, cur_stream());
@@ -1097,7 +1258,7 @@ void Engine::launch_step(DecodeState& st) {
       const double attn_bytes =
           double(st.batch) * st.s_max * 2 * kvdim * 4 + double(rows) * a.heads * a.dhead * 8;
       const double attn_ops = double(rows) * a.heads * st.s_max * a.dhead * 4;
-      if (a.lin[2].quantized && attention_decode_can_fuse_quantize(p)) {
+      if (a.lin[2].quantized && !tp_ && attention_decode_can_fuse_quantize(p)) {
         begin_kernel("attention_cross_decode_q", attn_bytes, attn_ops, rows, a.heads, a.dhead);
         launch_attention_decode_quantized(p, quant_mode_, st.qbuf, st.qscale, cur_stream());
         end_kernel();
@@ -1153,7 +1314,7 @@ void Engine::step(DecodeState& st, bool graph) {
     const float *s, *c;
     rotary_tables(dec_.layers.front().self, st.t_max + 1, &s, &c);
   }
-  if (!graph || profiling_) {
+  if (!graph || profiling_ || tp_) {  // collectives are not captured: eager launches under TP
     const int64_t before = launch_counter_;
     launch_step(st);
     kernels_per_step_ = launch_counter_ - before;

@@ -22,6 +22,7 @@
 
 #include "kernels.h"
 #include "model.h"
+#include "tp_comm.h"
 
 namespace ct2x {
 
@@ -30,6 +31,9 @@ enum class ComputeType { kFloat32, kInt8Float32 };
 std::string compute_type_name(ComputeType t);
 
 struct DenseW {
+  // Tensor parallel: the K dimension is split over the ranks (attention-out / FFN-out); the
+  // partial products are summed across ranks before bias, residual (see Engine::dense).
+  bool row_parallel = false;
   bool quantized = false;
   const int8_t* wq = nullptr;     // [n, k] int8
   const float* wscale = nullptr;  // [n]
@@ -104,7 +108,9 @@ struct DecodeState;
 
 class Engine {
 public:
-  Engine(std::shared_ptr<ModelFile> model, const std::string& compute_type, int device_index);
+  // `tp`: tensor-parallel communicator (nullptr or world 1 = the whole model on this device).
+  Engine(std::shared_ptr<ModelFile> model, const std::string& compute_type, int device_index,
+         std::shared_ptr<TpComm> tp = nullptr);
   ~Engine();
 
   const ModelFile& model() const { return *model_; }
@@ -115,6 +121,8 @@ public:
   int64_t num_decoder_layers() const { return static_cast<int64_t>(dec_.layers.size()); }
   int64_t num_heads() const { return dec_.num_heads; }
   int device_index() const { return device_; }
+  int tp_world() const { return tp_ ? tp_->world() : 1; }
+  int tp_rank() const { return tp_ ? tp_->rank() : 0; }
   hipStream_t stream() const { return stream_; }
   hipStream_t cur_stream() const;  // stream of the session driven by the calling thread
   int64_t weight_bytes() const { return weight_bytes_; }
@@ -190,7 +198,13 @@ private:
   };
 
   void load_weights();
-  DenseW load_dense(const std::string& scope, bool required);
+  // How a Dense is split over the tensor-parallel ranks (Model::load, src/models/model.cc:
+  // 662-743): kColumn = output rows; `blocks` lists the sizes of the fused sub-matrices that are
+  // each split separately and re-concatenated (Q | K | V of linear_0, K | V of the cross
+  // attention linear_1); kRow = input columns.
+  enum class Shard { kNone, kColumn, kRow };
+  DenseW load_dense(const std::string& scope, bool required, Shard shard = Shard::kNone,
+                    const std::vector<int64_t>& blocks = {});
   NormW load_norm(const std::string& scope);
   AttnW load_attention(const std::string& scope, bool self_attention, int64_t num_heads);
   FfnW load_ffn(const std::string& scope, int activation);
@@ -218,6 +232,7 @@ private:
   void end_kernel();
 
   std::shared_ptr<ModelFile> model_;
+  std::shared_ptr<TpComm> tp_;  // nullptr: no tensor parallelism
   ComputeType compute_type_;
   int device_ = 0;
   hipStream_t stream_ = nullptr;
@@ -262,6 +277,8 @@ struct DecodeState {
   float* inner2 = nullptr;   // [rows, ffn] (GLU gate)
   float* logits = nullptr;   // [rows, vocab]
   float* logprobs = nullptr; // [rows, vocab] (beam search)
+  int32_t* tp_acc = nullptr; // tensor parallel: int32 / fp32 partial products [rows, d]
+  float* tp_amax = nullptr;  // tensor parallel: per-row absmax [rows]
   int8_t* qbuf = nullptr;    // [rows, max(d, ffn)]
   float* qscale = nullptr;   // [rows]
   int32_t* d_ids = nullptr;  // [rows] next input ids

@@ -18,7 +18,18 @@ void launch_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, i
 
 void launch_dequantize_gemm_output(const int32_t* c, const float* a_scale, const float* b_scale,
                                    const float* bias, int64_t m, int64_t n, int act, float* y,
-                                   hipStream_t stream);
+                                   hipStream_t stream, const float* residual = nullptr);
+
+// Tensor-parallel helpers (rowops.hip): per-row absmax of a K slice, Quantize with a given
+// (rank-reduced) absmax, the float row-parallel epilogue, and the rank-order combine used by the
+// in-process communicator.
+void launch_row_amax(const float* x, int64_t rows, int64_t depth, float* amax, hipStream_t stream);
+void launch_quantize_with_amax(const float* x, const float* amax, int64_t rows, int64_t depth,
+                               int quant_mode, int8_t* q, float* scales, hipStream_t stream);
+void launch_bias_residual(const float* x, const float* bias, const float* residual, int64_t m,
+                          int64_t n, float* y, hipStream_t stream);
+void launch_reduce_ranks(const void* const* src, int world, int64_t n, bool is_int32, bool is_max,
+                         void* out, hipStream_t stream);
 
 // beta == nullptr -> RMSNorm. y and/or q may be nullptr (q==nullptr: plain norm).
 void launch_norm(const float* x, const float* gamma, const float* beta, int64_t rows,

@@ -66,6 +66,48 @@ __global__ void quantize_s8_kernel(const float* __restrict__ x, int64_t depth,
   }
 }
 
+// Two-step form of the same Quantize for tensor-parallel row-parallel layers: the row absmax is
+// taken over the rank's K slice, max-reduced across ranks, and the slice is then quantised with
+// the GLOBAL scale - bit-identical to quantising the gathered row (what the reference does by
+// all-gathering the activations, src/layers/common.cc:360-387), for m floats of traffic instead.
+__global__ void row_amax_kernel(const float* __restrict__ x, int64_t depth,
+                                float* __restrict__ amax_out) {
+  __shared__ float scratch[16];
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * depth;
+  float amax = 0.f;
+  for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) amax = fmaxf(amax, fabsf(xr[i]));
+  amax = block_max(amax, scratch);
+  if (threadIdx.x == 0) amax_out[row] = amax;
+}
+
+__global__ void quantize_with_amax_kernel(const float* __restrict__ x,
+                                          const float* __restrict__ amax, int64_t depth,
+                                          int quant_mode, int8_t* __restrict__ q,
+                                          float* __restrict__ scales) {
+  const int64_t row = blockIdx.x;
+  const float a = amax[row];
+  const float scale = (a != 0.f) ? 127.f / a : 1.f;
+  if (threadIdx.x == 0) scales[row] = scale;
+  const float* xr = x + row * depth;
+  int8_t* qr = q + row * depth;
+  for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) qr[i] = to_s8(xr[i], scale, quant_mode);
+}
+
+void launch_row_amax(const float* x, int64_t rows, int64_t depth, float* amax,
+                     hipStream_t stream) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(row_amax_kernel, dim3(rows), dim3(pick_block(depth)), 0, stream, x, depth,
+                     amax);
+}
+
+void launch_quantize_with_amax(const float* x, const float* amax, int64_t rows, int64_t depth,
+                               int quant_mode, int8_t* q, float* scales, hipStream_t stream) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(quantize_with_amax_kernel, dim3(rows), dim3(pick_block(depth)), 0, stream, x,
+                     amax, depth, quant_mode, q, scales);
+}
+
 void launch_quantize_s8(const float* x, int64_t rows, int64_t depth, int quant_mode,
                         int8_t* q, float* scales, hipStream_t stream) {
   if (rows == 0 || depth == 0) return;
@@ -102,8 +144,9 @@ void launch_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, i
 __global__ void dequantize_gemm_output_kernel(const int32_t* __restrict__ c,
                                               const float* __restrict__ a_scale,
                                               const float* __restrict__ b_scale,
-                                              const float* __restrict__ bias, int64_t n, int act,
-                                              float* __restrict__ y) {
+                                              const float* __restrict__ bias,
+                                              const float* residual, int64_t n, int act,
+                                              float* y) {
   const int64_t row = blockIdx.x;
   const float r_a = 1.f / a_scale[row];
   const int32_t* cr = c + row * n;
@@ -112,16 +155,70 @@ __global__ void dequantize_gemm_output_kernel(const int32_t* __restrict__ c,
     float v = static_cast<float>(cr[j]) * r_a;
     v = v / b_scale[j];
     if (bias) v = v + bias[j];
-    yr[j] = apply_activation(v, act);
+    v = apply_activation(v, act);
+    if (residual) v = residual[row * n + j] + v;  // ops::Add()(residual, output, output)
+    yr[j] = v;
   }
 }
 
 void launch_dequantize_gemm_output(const int32_t* c, const float* a_scale, const float* b_scale,
                                    const float* bias, int64_t m, int64_t n, int act, float* y,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, const float* residual) {
   if (m == 0 || n == 0) return;
   hipLaunchKernelGGL(dequantize_gemm_output_kernel, dim3(m), dim3(256), 0, stream, c, a_scale,
-                     b_scale, bias, n, act, y);
+                     b_scale, bias, residual, n, act, y);
+}
+
+// y[i, j] = residual[i, j] + (x[i, j] + bias[j]): the epilogue of a float row-parallel Dense after
+// its partial products have been summed over the ranks.
+__global__ void bias_residual_kernel(const float* x, const float* __restrict__ bias,
+                                     const float* residual, int64_t n, int64_t total, float* y) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= total) return;
+  float v = x[i];
+  if (bias) v = v + bias[i % n];
+  if (residual) v = residual[i] + v;
+  y[i] = v;
+}
+
+void launch_bias_residual(const float* x, const float* bias, const float* residual, int64_t m,
+                          int64_t n, float* y, hipStream_t stream) {
+  const int64_t total = m * n;
+  if (total == 0) return;
+  hipLaunchKernelGGL(bias_residual_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, x, bias,
+                     residual, n, total, y);
+}
+
+// Element-wise combine of up to 8 equally sized buffers in rank order (the in-process
+// "loopback" communicator of tp_comm.cc; RCCL does this on real multi-GPU runs).
+struct ReducePtrs { const void* p[8]; };
+template <typename T, bool kMax>
+__global__ void reduce_ranks_kernel(ReducePtrs src, int world, int64_t n, T* out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  T v = static_cast<const T*>(src.p[0])[i];
+  for (int r = 1; r < world; ++r) {
+    const T o = static_cast<const T*>(src.p[r])[i];
+    v = kMax ? (o > v ? o : v) : v + o;
+  }
+  out[i] = v;
+}
+
+void launch_reduce_ranks(const void* const* src, int world, int64_t n, bool is_int32, bool is_max,
+                         void* out, hipStream_t stream) {
+  if (n == 0) return;
+  ReducePtrs ptrs;
+  for (int r = 0; r < 8; ++r) ptrs.p[r] = r < world ? src[r] : nullptr;
+  const dim3 grid((n + 255) / 256), block(256);
+  if (is_int32)
+    hipLaunchKernelGGL((reduce_ranks_kernel<int32_t, false>), grid, block, 0, stream, ptrs, world,
+                       n, static_cast<int32_t*>(out));
+  else if (is_max)
+    hipLaunchKernelGGL((reduce_ranks_kernel<float, true>), grid, block, 0, stream, ptrs, world, n,
+                       static_cast<float*>(out));
+  else
+    hipLaunchKernelGGL((reduce_ranks_kernel<float, false>), grid, block, 0, stream, ptrs, world, n,
+                       static_cast<float*>(out));
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,215 @@
+// Communicators behind the tensor-parallel Dense layers (see tp_comm.h).
+
+#include "tp_comm.h"
+
+#include <dlfcn.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "kernels.h"
+#include "runtime.h"
+
+namespace ct2x {
+
+// ---------------------------------------------------------------------------------------------
+// RCCL over xGMI. The library is resolved at run time: the single-GPU product path must load on
+// hosts without RCCL, and nothing here is a shim over NCCL semantics - these are RCCL's own entry
+// points (RCCL keeps the nccl* symbol names).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+  using Comm = void*;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(Comm*, int, const void* /* ncclUniqueId by value, 128 bytes */, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  void* handle = nullptr;
+};
+
+// ncclDataType_t / ncclRedOp_t values (rccl.h): ncclInt32 = 2, ncclFloat32 = 7; ncclSum = 0,
+// ncclMax = 2.
+constexpr int kNcclInt32 = 2, kNcclFloat32 = 7, kNcclSum = 0, kNcclMax = 2;
+
+struct UniqueIdByValue {
+  char bytes[kTpUniqueIdBytes];
+};
+
+RcclApi& rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.handle) break;
+    }
+    if (!a.handle)
+      throw Error(std::string("tensor parallelism needs RCCL (librccl.so): ") + dlerror());
+    auto sym = [&](const char* n) {
+      void* p = dlsym(a.handle, n);
+      if (!p) throw Error(std::string("librccl.so lacks ") + n);
+      return p;
+    };
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    return a;
+  }();
+  return api;
+}
+
+void rccl_check(int rc, const char* what) {
+  if (rc != 0) throw Error(std::string(what) + ": " + rccl().GetErrorString(rc));
+}
+
+class RcclComm : public TpComm {
+public:
+  RcclComm(int rank, int world, const void* unique_id) : rank_(rank), world_(world) {
+    // ncclCommInitRank takes the 128-byte id BY VALUE.
+    using InitFn = int (*)(RcclApi::Comm*, int, UniqueIdByValue, int);
+    UniqueIdByValue id;
+    std::memcpy(id.bytes, unique_id, kTpUniqueIdBytes);
+    rccl_check(reinterpret_cast<InitFn>(rccl().CommInitRank)(&comm_, world, id, rank),
+               "ncclCommInitRank");
+  }
+  ~RcclComm() override {
+    if (comm_) (void)rccl().CommDestroy(comm_);
+  }
+  int rank() const override { return rank_; }
+  int world() const override { return world_; }
+  const char* backend() const override { return "rccl"; }
+  void all_reduce_sum_i32(int32_t* buf, int64_t count, hipStream_t stream) override {
+    rccl_check(rccl().AllReduce(buf, buf, count, kNcclInt32, kNcclSum, comm_, stream),
+               "ncclAllReduce(int32, sum)");
+  }
+  void all_reduce_sum_f32(float* buf, int64_t count, hipStream_t stream) override {
+    rccl_check(rccl().AllReduce(buf, buf, count, kNcclFloat32, kNcclSum, comm_, stream),
+               "ncclAllReduce(float, sum)");
+  }
+  void all_reduce_max_f32(float* buf, int64_t count, hipStream_t stream) override {
+    rccl_check(rccl().AllReduce(buf, buf, count, kNcclFloat32, kNcclMax, comm_, stream),
+               "ncclAllReduce(float, max)");
+  }
+
+private:
+  int rank_, world_;
+  RcclApi::Comm comm_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// In-process communicator: `world` ranks = `world` host threads driving their own streams on ONE
+// device. An all-reduce is two host rendezvous around a rank-order combine kernel:
+//   1. every rank publishes its buffer and an event recorded on its stream, then waits (host);
+//   2. every rank makes its stream wait for the other ranks' events and combines ALL buffers, in
+//      rank order (identical result on every rank), into a private scratch buffer; records a
+//      second event; waits (host);
+//   3. every rank makes its stream wait for the others' second events (nobody still reads its
+//      buffer) and copies the scratch back in place.
+// ---------------------------------------------------------------------------------------------
+struct LocalShared {
+  explicit LocalShared(int w) : world(w), bufs(w, nullptr), ready(w, nullptr), done(w, nullptr) {}
+  int world;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  std::vector<void*> bufs;
+  std::vector<hipEvent_t> ready, done;
+  bool poisoned = false;
+
+  void barrier() {
+    std::unique_lock<std::mutex> lock(mu);
+    const uint64_t gen = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      // A rank that failed elsewhere never arrives: give up instead of hanging the test run.
+      if (!cv.wait_for(lock, std::chrono::seconds(60), [&] { return generation != gen; })) {
+        poisoned = true;
+        cv.notify_all();
+        throw Error("in-process tensor-parallel communicator: a rank did not reach the collective");
+      }
+    }
+    if (poisoned) throw Error("in-process tensor-parallel communicator: aborted");
+  }
+};
+
+class LocalComm : public TpComm {
+public:
+  LocalComm(std::shared_ptr<LocalShared> shared, int rank) : s_(std::move(shared)), rank_(rank) {
+    CT2X_HIP_CHECK(hipEventCreateWithFlags(&s_->ready[rank], hipEventDisableTiming));
+    CT2X_HIP_CHECK(hipEventCreateWithFlags(&s_->done[rank], hipEventDisableTiming));
+  }
+  ~LocalComm() override {
+    if (scratch_) { try { device_free(scratch_); } catch (...) {} }
+    (void)hipEventDestroy(s_->ready[rank_]);
+    (void)hipEventDestroy(s_->done[rank_]);
+  }
+  int rank() const override { return rank_; }
+  int world() const override { return s_->world; }
+  const char* backend() const override { return "in-process"; }
+  void all_reduce_sum_i32(int32_t* buf, int64_t count, hipStream_t stream) override {
+    run(buf, count, true, false, stream);
+  }
+  void all_reduce_sum_f32(float* buf, int64_t count, hipStream_t stream) override {
+    run(buf, count, false, false, stream);
+  }
+  void all_reduce_max_f32(float* buf, int64_t count, hipStream_t stream) override {
+    run(buf, count, false, true, stream);
+  }
+
+private:
+  void run(void* buf, int64_t count, bool is_int32, bool is_max, hipStream_t stream) {
+    const size_t bytes = static_cast<size_t>(count) * 4;
+    if (bytes > scratch_bytes_) {
+      if (scratch_) device_free(scratch_);
+      scratch_ = device_malloc(bytes);
+      scratch_bytes_ = bytes;
+    }
+    s_->bufs[rank_] = buf;
+    CT2X_HIP_CHECK(hipEventRecord(s_->ready[rank_], stream));
+    s_->barrier();
+    for (int r = 0; r < s_->world; ++r)
+      if (r != rank_) CT2X_HIP_CHECK(hipStreamWaitEvent(stream, s_->ready[r], 0));
+    launch_reduce_ranks(s_->bufs.data(), s_->world, count, is_int32, is_max, scratch_, stream);
+    CT2X_HIP_CHECK(hipEventRecord(s_->done[rank_], stream));
+    s_->barrier();
+    for (int r = 0; r < s_->world; ++r)
+      if (r != rank_) CT2X_HIP_CHECK(hipStreamWaitEvent(stream, s_->done[r], 0));
+    CT2X_HIP_CHECK(hipMemcpyAsync(buf, scratch_, bytes, hipMemcpyDeviceToDevice, stream));
+    s_->barrier();  // bufs[] / events may be reused by the next collective
+  }
+
+  std::shared_ptr<LocalShared> s_;
+  int rank_;
+  void* scratch_ = nullptr;
+  size_t scratch_bytes_ = 0;
+};
+
+}  // namespace
+
+void rccl_get_unique_id(void* id_out) {
+  rccl_check(rccl().GetUniqueId(id_out), "ncclGetUniqueId");
+}
+
+std::shared_ptr<TpComm> make_rccl_comm(int rank, int world, const void* unique_id) {
+  return std::make_shared<RcclComm>(rank, world, unique_id);
+}
+
+std::vector<std::shared_ptr<TpComm>> make_local_comms(int world) {
+  if (world < 1 || world > 8) throw Error("in-process communicator: world size must be 1..8");
+  auto shared = std::make_shared<LocalShared>(world);
+  std::vector<std::shared_ptr<TpComm>> comms;
+  for (int r = 0; r < world; ++r) comms.push_back(std::make_shared<LocalComm>(shared, r));
+  return comms;
+}
+
+}  // namespace ct2x

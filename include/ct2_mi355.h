@@ -241,6 +241,34 @@ struct ct2x_translation_options {
 
 void ct2x_translation_options_default(struct ct2x_translation_options* opt);
 
+/* ---- tensor parallelism (one process per GPU, RCCL over xGMI) ------------------------------
+ * Reference: tensor_parallel=True in ctranslate2.Translator -> ScopedMPISetter / ncclComm
+ * (src/devices.cc:141-229), weight sharding in Model::load (src/models/model.cc:662-743),
+ * ops::ReduceAll after every row-parallel Dense (src/layers/common.cc:348-401,
+ * src/layers/attention.cc:606-612, src/layers/transformer.cc:21-51).
+ * Here: heads and the FFN inner dimension are split over `world` ranks; a row-parallel Dense
+ * max-reduces the per-row absmax (global Quantize scale), sum-reduces the exact int32 partial
+ * products and dequantises once, so the sharded model is bit-identical to the unsharded one.
+ * Launch: rank 0 calls ct2x_tp_unique_id, the 128 bytes travel to every rank by the launcher's
+ * own means (torch.distributed / MPI / a file), every rank calls ct2x_translator_create_tp with
+ * its own device. Every rank must then issue the same translate / generate calls. */
+int ct2x_tp_unique_id(void* id_out_128_bytes);
+void* ct2x_translator_create_tp(const char* model_dir, int device_index, const char* compute_type,
+                                int rank, int world, const void* unique_id_128_bytes);
+/* The same sharded engines with an in-process communicator: `world` ranks in THIS process on ONE
+ * device, each handle driven by its own host thread (the single-GPU test double of the above). */
+/* Host-only: the rows of a column-parallel weight [n, k] owned by `rank` (Model::load,
+ * src/models/model.cc:662-743). `blocks` are the sizes of the fused sub-matrices split separately
+ * (Q | K | V); num_blocks = 0 means one block of n rows. first_out / count_out get one entry per
+ * block. A row-parallel weight owns input columns [rank * k / world, (rank + 1) * k / world). */
+int ct2x_tp_shard_rows(int64_t n, const int64_t* blocks, int32_t num_blocks, int32_t rank,
+                       int32_t world, int64_t* first_out, int64_t* count_out);
+/* One-rank RCCL communicator + all-reduces on `device_index` (identity): checks the RCCL binding
+ * of the multi-GPU path where only one GPU is visible. */
+int ct2x_tp_selftest_rccl(int device_index);
+int ct2x_translator_create_tp_local(const char* model_dir, int device_index,
+                                    const char* compute_type, int world, void** handles_out);
+
 /* Translator::translate_batch on token ids (src/translator.cc:8-28 ->
  * src/models/sequence_to_sequence.cc:305-432). src_ids [batch, src_stride] raw ids
  * WITHOUT the implicit source BOS/EOS (added per config.json like Vocabulary::to_ids).

@@ -1,0 +1,151 @@
+"""-m gpu tensor-parallel parity: the model sharded over `world` ranks
+(heads and FFN inner dimension split, row-parallel layers all-reduced) must reproduce the
+unsharded engine. The ranks run as threads of this process on the one visible GPU, connected by
+the in-process communicator (ct2x_translator_create_tp_local); the RCCL binding used on real
+multi-GPU nodes is exercised by a one-rank communicator.
+
+int8: bit-identical (the exchange carries exact int32 partial products and a max of absmax).
+float32: partial fp32 products are summed in rank order - tokens equal, scores within 1e-4."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import golden_cases as GC
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_dir(key):
+    from ctranslate2_amd import model_builder as mb
+    path = "/tmp/ct2x_test_%s" % key
+    if not os.path.exists(os.path.join(path, "model.bin")):
+        if key in GC.SYNTHETIC:
+            mb.build_transformer(path, **GC.SYNTHETIC[key]["model"])
+        else:
+            mb.build_decoder_lm(path, **GC.SYNTHETIC_LM[key]["model"])
+    return path
+
+
+def _run_ranks(ranks, fn):
+    """fn(translator) on every rank concurrently (each rank = one host thread)."""
+    out = [None] * len(ranks)
+    err = [None] * len(ranks)
+
+    def work(i):
+        try:
+            out[i] = fn(ranks[i])
+        except Exception as e:  # noqa: BLE001 - surfaced below
+            err[i] = e
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(ranks))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+def _sources(key):
+    cfg = GC.SYNTHETIC[key]
+    rng = np.random.default_rng(cfg["data_seed"])
+    vocab = cfg["model"]["vocab_size"]
+    return [rng.integers(4, vocab, n).tolist() for n in cfg["src_lengths"]]
+
+
+@pytest.mark.parametrize("key,world", [("tiny", 2), ("small", 2), ("small", 4)])
+@pytest.mark.parametrize("beam", [1, 4])
+def test_translate_int8_bit_identical(gpu, key, world, beam):
+    import ctranslate2_amd as ct2
+    path = _model_dir(key)
+    cfg = GC.SYNTHETIC[key]
+    src = _sources(key)
+    kw = dict(beam_size=beam, max_decoding_length=cfg["max_len"], min_decoding_length=cfg["min_len"],
+              return_scores=True, use_graph=False)
+    single = ct2.Translator(path, compute_type="int8")
+    ref_h, ref_s = single.translate_ids(src, **kw)
+    ranks = ct2.Translator.tensor_parallel_local(path, world, compute_type="int8")
+    outs = _run_ranks(ranks, lambda t: t.translate_ids(src, **kw))
+    for hyps, scores in outs:
+        assert hyps == ref_h
+        assert np.array_equal(scores, ref_s)
+    for t in ranks:
+        t.close()
+
+
+def test_step_logits_int8_bit_identical(gpu):
+    import ctranslate2_amd as ct2
+    path = _model_dir("small")
+    cfg = GC.SYNTHETIC["small"]
+    src = [[1] + s + [2] for s in _sources("small")]  # step_logits takes ids WITH specials
+    m = max(len(s) for s in src)
+    src = [s for s in src if len(s) == m]
+    rng = np.random.default_rng(11)
+    tgt = rng.integers(4, cfg["model"]["vocab_size"], (len(src), 6)).astype(np.int32)
+    single = ct2.Translator(path, compute_type="int8")
+    ref = single.step_logits(src, tgt)
+    ranks = ct2.Translator.tensor_parallel_local(path, 2, compute_type="int8")
+    outs = _run_ranks(ranks, lambda t: t.step_logits(src, tgt))
+    for logits in outs:
+        assert np.array_equal(logits, ref)
+    for t in ranks:
+        t.close()
+
+
+def test_translate_float32(gpu):
+    import ctranslate2_amd as ct2
+    path = _model_dir("small")
+    cfg = GC.SYNTHETIC["small"]
+    src = _sources("small")
+    kw = dict(beam_size=1, max_decoding_length=cfg["max_len"], min_decoding_length=cfg["min_len"],
+              return_scores=True, use_graph=False)
+    single = ct2.Translator(path, compute_type="float32")
+    ref_h, ref_s = single.translate_ids(src, **kw)
+    ranks = ct2.Translator.tensor_parallel_local(path, 2, compute_type="float32")
+    outs = _run_ranks(ranks, lambda t: t.translate_ids(src, **kw))
+    for hyps, scores in outs:
+        assert hyps == ref_h
+        np.testing.assert_allclose(scores, ref_s, atol=1e-4)
+    for t in ranks:
+        t.close()
+
+
+def test_generate_decoder_only_int8_bit_identical(gpu):
+    """Llama-style path under tensor parallelism: GQA (8 heads / 2 KV heads -> 4 / 1 per rank),
+    RoPE, RMSNorm, gated FFN, sequence-mode prefill."""
+    import ctranslate2_amd as ct2
+    key = "lm_small"
+    path = _model_dir(key)
+    cfg = GC.SYNTHETIC_LM[key]
+    rng = np.random.default_rng(cfg["data_seed"])
+    prompts = [rng.integers(4, cfg["model"]["vocab_size"], cfg["prompt_len"]).tolist()
+               for _ in range(cfg["batch"])]
+    kw = dict(max_length=cfg["max_len"], min_length=cfg["max_len"], return_scores=True, use_graph=False)
+    single = ct2.Translator(path, compute_type="int8")
+    ref_o, ref_s = single.generate_ids(prompts, **kw)
+    ranks = ct2.Translator.tensor_parallel_local(path, 2, compute_type="int8")
+    outs = _run_ranks(ranks, lambda t: t.generate_ids(prompts, **kw))
+    for o, s in outs:
+        assert o == ref_o
+        assert np.array_equal(s, ref_s)
+    for t in ranks:
+        t.close()
+
+
+def test_indivisible_heads_are_rejected(gpu):
+    import ctranslate2_amd as ct2
+    path = _model_dir("tiny")  # 4 heads
+    with pytest.raises(ct2.Ct2xError, match="not divisible"):
+        ct2.Translator.tensor_parallel_local(path, 3, compute_type="int8")
+
+
+def test_rccl_binding_one_rank(gpu):
+    """The RCCL entry points used on multi-GPU nodes (ncclGetUniqueId, ncclCommInitRank with the
+    id by value, ncclAllReduce int32-sum / float-max / float-sum on the engine's stream)."""
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.ct2x_tp_selftest_rccl(0))
