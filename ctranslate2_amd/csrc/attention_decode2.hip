@@ -558,7 +558,11 @@ bool attention_decode2_applicable(const AttnDecodeParams& p, bool fused_quantize
   if (p.heads_kv < 1 || p.heads % p.heads_kv != 0) return false;
   const int64_t gq = p.heads / p.heads_kv;
   if (gq != 1 && gq != 2 && gq != 4) return false;
-  if (p.kv_time_stride != p.dhead || p.t_max < 1) return false;
+  // cache rows may be strided (encoder memory K/V live interleaved in the projection output)
+  if (p.kv_time_stride < p.dhead || p.kv_time_stride % 4 != 0 || p.t_max < 1) return false;
+  if ((reinterpret_cast<uintptr_t>(p.k_cache) & 15) || (reinterpret_cast<uintptr_t>(p.v_cache) & 15) ||
+      p.kv_head_stride % 4 != 0 || p.kv_row_stride % 4 != 0)
+    return false;
   if (p.rot_dim > p.dhead) return false;
   const int64_t t_pad = ((p.t_max + 1 + 63) / 64) * 64;
   if (fused_quantize) {
