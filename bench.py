@@ -49,6 +49,9 @@ def parse_args():
     p.add_argument("--streams", type=int, default=0,
                    help="concurrent decode streams per GPU (0 = library default)")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--compute-type", default="int8",
+                   help="int8 (the metric), float16, bfloat16 or float32: same model, weights "
+                        "converted at load")
     p.add_argument("--tp", action="store_true",
                    help="tensor parallel over the --gpus ranks (one sharded model, every rank runs "
                         "the same batch, RCCL all-reduce after each row-parallel Dense) instead of "
@@ -171,7 +174,7 @@ def main():
     if not os.path.exists(os.path.join(model_dir, "model.bin")):
         mb.build_transformer(model_dir, **TB)
     tp = args.tp and world > 1
-    translator = ct2.Translator(model_dir, device="cuda", device_index=local_rank, compute_type="int8",
+    translator = ct2.Translator(model_dir, device="cuda", device_index=local_rank, compute_type=args.compute_type,
                                 tensor_parallel=tp)
     # replicas: every rank has its own batch; tensor parallel: ONE batch, computed by all ranks
     sources = make_sources(0 if tp else rank, args.batch, args.src_len, TB["vocab_size"])
@@ -205,7 +208,7 @@ def main():
     stats = translator.last_stats()
 
     result = {
-        "metric": "generated tokens/sec (int8, batch=32, beam=%d), whole job" % args.beam,
+        "metric": "generated tokens/sec (%s, batch=32, beam=%d), whole job" % (args.compute_type, args.beam),
         "value": value,
         "unit": "tokens/s",
         "n_gpus": world,
@@ -215,13 +218,14 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if tp else "weak",
         "vs_baseline": None,
-        "dtype": "int8",
+        "dtype": args.compute_type,
         "data": "synthetic",
         "config": {
-            "workload": "Transformer-base En->De int8 (int8 weights + int8 activations, fp32 "
-                        "accumulate/epilogue = compute type int8_float32), batch=%d beam=%d, "
+            "workload": "Transformer-base En->De %s, batch=%d beam=%d, "
                         "source length %d, %d forced decode steps, random-init weights N(0,0.02)"
-                        % (args.batch, args.beam, args.src_len, args.max_len),
+                        % ("int8 (int8 weights + int8 activations, fp32 accumulate/epilogue = compute "
+                           "type int8_float32)" if args.compute_type == "int8" else args.compute_type,
+                           args.batch, args.beam, args.src_len, args.max_len),
             "tokens_per_step_per_gpu": tokens // max(args.steps, 1),
             "parallelism": ("tensor parallel x%d (heads / FFN split, RCCL all-reduce of int32 partial "
                             "products after every row-parallel Dense)" % world) if tp else

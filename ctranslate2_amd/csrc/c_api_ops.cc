@@ -230,6 +230,18 @@ int ct2x_gemm_s8_glu(const int8_t* d_qa, const float* d_a_scale, const int8_t* d
   API_CATCH
 }
 
+int ct2x_gemm_f16w(const float* d_a, const void* d_w, int w_dtype, int64_t m, int64_t n, int64_t k,
+                   const float* d_bias, const float* d_residual, int activation, float* d_c,
+                   void* stream) {
+  API_TRY
+  CT2X_CHECK(w_dtype == CT2X_F16 || w_dtype == CT2X_BF16,
+             "ct2x_gemm_f16w: the weight type must be CT2X_F16 or CT2X_BF16");
+  launch_gemm_h(d_a, d_w, w_dtype == CT2X_BF16, m, n, k, d_bias, d_residual, activation, d_c,
+                resolve_stream(stream));
+  check_last_launch("gemm_f16w");
+  API_CATCH
+}
+
 int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,
                          void* d_y, int dtype, void* stream) {
   API_TRY

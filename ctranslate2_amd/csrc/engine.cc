@@ -15,6 +15,8 @@ std::string compute_type_name(ComputeType t) {
   switch (t) {
     case ComputeType::kFloat32: return "float32";
     case ComputeType::kInt8Float32: return "int8_float32";
+    case ComputeType::kFloat16: return "float16";
+    case ComputeType::kBFloat16: return "bfloat16";
   }
   return "?";
 }
@@ -50,17 +52,60 @@ void host_quantize_rows(const std::vector<float>& w, int64_t rows, int64_t depth
 
 // Resolution of the requested compute type against what this backend implements
 // (reference: resolve_compute_type, src/types.cc:156-295).
-ComputeType resolve(const std::string& requested, bool model_is_quantized) {
+// int8_float16 / int8_bfloat16 (int8 weights, 16-bit activations) resolve to int8_float32: the
+// activations of this backend are fp32 throughout, a superset of the requested precision - the
+// reference downgrades the same way when the 16-bit float type is not supported by the device.
+ComputeType resolve(const std::string& requested, int model_weight_dtype) {
+  const bool model_is_quantized = model_weight_dtype == kI8 || model_weight_dtype == kI16;
   if (requested == "float32") return ComputeType::kFloat32;
-  if (requested == "int8" || requested == "int8_float32" || requested == "auto")
+  if (requested == "float16") return ComputeType::kFloat16;
+  if (requested == "bfloat16") return ComputeType::kBFloat16;
+  if (requested == "int8" || requested == "int8_float32" || requested == "auto" ||
+      requested == "int8_float16" || requested == "int8_bfloat16")
     return ComputeType::kInt8Float32;
-  if (requested == "default" || requested.empty())
-    return model_is_quantized ? ComputeType::kInt8Float32 : ComputeType::kFloat32;
-  if (requested == "int8_float16" || requested == "int8_bfloat16" || requested == "float16" ||
-      requested == "bfloat16" || requested == "int16")
-    throw std::invalid_argument("Requested " + requested + " compute type, but this backend "
-                                "build only implements int8_float32 and float32");
+  if (requested == "default" || requested.empty()) {
+    if (model_is_quantized) return ComputeType::kInt8Float32;
+    if (model_weight_dtype == kF16) return ComputeType::kFloat16;
+    if (model_weight_dtype == kBF16) return ComputeType::kBFloat16;
+    return ComputeType::kFloat32;
+  }
+  if (requested == "int16")
+    throw std::invalid_argument("Requested int16 compute type, but this backend build only "
+                                "implements int8_float32, float16, bfloat16 and float32");
   throw std::invalid_argument("Invalid compute type: " + requested);
+}
+
+uint16_t float_to_bf16_bits(float f) {  // round to nearest even, NaN kept quiet
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+
+uint16_t float_to_half_bits(float f) {  // IEEE binary16, round to nearest even
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return static_cast<uint16_t>(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+  if (x >= 0x477ff000u) return static_cast<uint16_t>(sign | 0x7c00u);  // overflows to inf
+  if (x < 0x33000001u) return static_cast<uint16_t>(sign);              // underflows to zero
+  int32_t exp = static_cast<int32_t>(x >> 23) - 127 + 15;
+  uint32_t mant = x & 0x7fffffu;
+  if (exp <= 0) {  // subnormal half
+    mant |= 0x800000u;
+    const int shift = 14 - exp;
+    const uint32_t half_mant = mant >> shift;
+    const uint32_t rem = mant & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    uint32_t r = half_mant;
+    if (rem > halfway || (rem == halfway && (half_mant & 1u))) ++r;
+    return static_cast<uint16_t>(sign | r);
+  }
+  uint32_t r = (static_cast<uint32_t>(exp) << 10) | (mant >> 13);
+  const uint32_t rem = mant & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;  // carries into the exponent correctly
+  return static_cast<uint16_t>(sign | r);
 }
 
 }  // namespace
@@ -85,10 +130,13 @@ Engine::Engine(std::shared_ptr<ModelFile> model, const std::string& compute_type
   if (const char* env = std::getenv("CT2X_S8_ACTIVATIONS"))
     if (env[0] == '1') quant_mode_ &= ~2;
 
-  bool quantized = false;
+  int weight_dtype = kF32;
   for (const auto& v : model_->variables)
-    if (ends_with(v.name, "/weight") && (v.dtype == kI8 || v.dtype == kI16)) quantized = true;
-  compute_type_ = resolve(compute_type, quantized);
+    if (ends_with(v.name, "/weight") && v.shape.size() == 2) {
+      if (v.dtype == kI8 || v.dtype == kI16) { weight_dtype = v.dtype; break; }
+      if (v.dtype == kF16 || v.dtype == kBF16) weight_dtype = v.dtype;
+    }
+  compute_type_ = resolve(compute_type, weight_dtype);
 
   const std::string& spec = model_->spec;
   if (spec == "TransformerSpec" || spec == "TransformerBase" || spec == "TransformerBig" ||
@@ -225,6 +273,18 @@ DenseW Engine::load_dense(const std::string& scope, bool required, Shard shard,
       wf.clear();
     }
   }
+  // 16-bit compute types: the (dequantised / converted) weight is rounded to the type once here
+  // (Model::ensure_dtype, src/models/model.cc:304-369); K must suit the 8-element MFMA fragments.
+  const bool want_half = (compute_type_ == ComputeType::kFloat16 ||
+                          compute_type_ == ComputeType::kBFloat16) && d.k % 8 == 0;
+  std::vector<uint16_t> wh;
+  if (want_half) {
+    const bool bf = compute_type_ == ComputeType::kBFloat16;
+    wh.resize(wf.size());
+    for (size_t i = 0; i < wf.size(); ++i)
+      wh[i] = bf ? float_to_bf16_bits(wf[i]) : float_to_half_bits(wf[i]);
+    wf.clear();
+  }
   std::vector<float> bias;
   if (const Variable* b = model_->find(scope + "/bias")) bias = b->to_float();
 
@@ -234,6 +294,8 @@ DenseW Engine::load_dense(const std::string& scope, bool required, Shard shard,
       q_own = take_rows(q_src, d.k, rows);
       q_src = q_own.data();
       s_full = take_rows(s_full.data(), 1, rows);
+    } else if (want_half) {
+      wh = take_rows(wh.data(), d.k, rows);
     } else {
       wf = take_rows(wf.data(), d.k, rows);
     }
@@ -248,6 +310,8 @@ DenseW Engine::load_dense(const std::string& scope, bool required, Shard shard,
     if (d.quantized) {
       q_own = take_cols(q_src, d.n, d.k, k0, k0 + kl);
       q_src = q_own.data();
+    } else if (want_half) {
+      wh = take_cols(wh.data(), d.n, d.k, k0, k0 + kl);
     } else {
       wf = take_cols(wf.data(), d.n, d.k, k0, k0 + kl);
     }
@@ -258,6 +322,11 @@ DenseW Engine::load_dense(const std::string& scope, bool required, Shard shard,
   if (d.quantized) {
     d.wq = static_cast<const int8_t*>(upload(q_src, static_cast<size_t>(d.n) * d.k));
     d.wscale = upload_floats(s_full);
+  } else if (want_half) {
+    if (d.k % 8 != 0)  // a row-parallel slice may have lost the divisibility
+      throw std::invalid_argument(scope + ": the 16-bit GEMM needs an input dimension divisible by 8");
+    d.wh = upload(wh.data(), wh.size() * sizeof(uint16_t));
+    d.wh_bf16 = compute_type_ == ComputeType::kBFloat16;
   } else {
     d.wf = upload_floats(wf);
   }
@@ -703,10 +772,16 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
       end_kernel();
     } else {
       float* acc = reinterpret_cast<float*>(ws->tp_acc);
-      begin_kernel("gemm_f32", 4.0 * (double(m) * w.k + double(w.n) * w.k + double(m) * w.n),
-                   2.0 * m * w.n * w.k, m, w.n, w.k);
-      launch_gemm_f32(x, w.wf, 1, m, w.n, w.k, true, 1.f, 0, 0, 0, nullptr, nullptr, -1, acc,
-                      cur_stream());
+      if (w.wh) {
+        begin_kernel("gemm_h", 4.0 * m * w.k + 2.0 * w.n * w.k + 4.0 * m * w.n, 2.0 * m * w.n * w.k,
+                     m, w.n, w.k);
+        launch_gemm_h(x, w.wh, w.wh_bf16, m, w.n, w.k, nullptr, nullptr, -1, acc, cur_stream());
+      } else {
+        begin_kernel("gemm_f32", 4.0 * (double(m) * w.k + double(w.n) * w.k + double(m) * w.n),
+                     2.0 * m * w.n * w.k, m, w.n, w.k);
+        launch_gemm_f32(x, w.wf, 1, m, w.n, w.k, true, 1.f, 0, 0, 0, nullptr, nullptr, -1, acc,
+                        cur_stream());
+      }
       end_kernel();
       begin_kernel("tp_all_reduce_sum", double(m) * w.n * 4, 0, m, w.n, 0);
       tp_->all_reduce_sum_f32(acc, m * w.n, cur_stream());
@@ -741,6 +816,14 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
                    2 * M * N * K, m, w.n, w.k);
     }
     launch_gemm_s8(qin->q, w.wq, m, w.n, w.k, ep, cur_stream());
+    end_kernel();
+  } else if (w.wh) {
+    {
+      const double M = double(m), N = double(w.n), K = double(w.k);
+      begin_kernel("gemm_h", 4 * M * K + 2 * N * K + 4 * M * N + (residual ? 4 * M * N : 0),
+                   2 * M * N * K, m, w.n, w.k);
+    }
+    launch_gemm_h(x, w.wh, w.wh_bf16, m, w.n, w.k, w.bias, residual, act, y, cur_stream());
     end_kernel();
   } else {
     {

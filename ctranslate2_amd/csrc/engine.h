@@ -26,7 +26,9 @@
 
 namespace ct2x {
 
-enum class ComputeType { kFloat32, kInt8Float32 };
+// kFloat16 / kBFloat16: Dense weights in the 16-bit type through the fp16 / bf16 MFMA GEMM
+// (gemm_h.hip), fp32 activations everywhere else.
+enum class ComputeType { kFloat32, kInt8Float32, kFloat16, kBFloat16 };
 
 std::string compute_type_name(ComputeType t);
 
@@ -38,6 +40,8 @@ struct DenseW {
   const int8_t* wq = nullptr;     // [n, k] int8
   const float* wscale = nullptr;  // [n]
   const float* wf = nullptr;      // [n, k] fp32 (float models)
+  const void* wh = nullptr;       // [n, k] float16 / bfloat16 (compute types float16 / bfloat16)
+  bool wh_bf16 = false;
   const float* bias = nullptr;    // [n] or nullptr
   int64_t n = 0, k = 0;
   bool present = false;

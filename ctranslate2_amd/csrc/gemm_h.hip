@@ -1,0 +1,335 @@
+// float16 / bfloat16 projection GEMM for gfx950: the half-precision arm of ops::Gemm
+// (src/ops/gemm.cc:45-107 -> primitives<CUDA>::gemm<float16_t / bfloat16_t>,
+// src/cuda/primitives.cu:519-569: cublasGemmEx, fp32 accumulate for bf16 and, unless
+// CT2_CUDA_TRUE_FP16_GEMM, for fp16) with apply_bias_and_activation + residual
+// (src/ops/gemm.cc:11-25, src/ops/bias_add_gpu.cu:46-102) fused in.
+//
+//   Y[m,n] = act( A[m,k] . W[n,k]^T + bias[n] ) + residual[m,n]
+//
+// W is stored in the 16-bit type (half the weight stream of an fp32 model); A arrives in fp32 and
+// is rounded to the 16-bit type when it enters the matrix pipe - exactly the rounding the
+// reference applies to its 16-bit activations - and every product is accumulated in fp32 by
+// v_mfma_f32_16x16x32_{f16,bf16}. Everything outside the GEMM (norms, softmax, attention,
+// residual stream) stays in fp32, i.e. is at least as accurate as the reference's 16-bit pipeline.
+//
+// Two kernels, as for int8 (gemm_s8.hip): a skinny split-K form for decode rows (M <= 128: a
+// weight stream, one memory round trip) and an LDS-tiled 128x128x64 form for encoder / prefill.
+
+#include "device_utils.h"
+#include "kernels.h"
+#include "runtime.h"
+
+namespace ct2x {
+
+namespace {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 v8b __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <bool kBF16>
+struct HalfOps;
+template <>
+struct HalfOps<false> {
+  using vec = v8h;
+  __device__ static __forceinline__ v4f mfma(vec a, vec b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ vec from_f32(const float4& lo, const float4& hi) {
+    vec v;
+    v[0] = static_cast<_Float16>(lo.x); v[1] = static_cast<_Float16>(lo.y);
+    v[2] = static_cast<_Float16>(lo.z); v[3] = static_cast<_Float16>(lo.w);
+    v[4] = static_cast<_Float16>(hi.x); v[5] = static_cast<_Float16>(hi.y);
+    v[6] = static_cast<_Float16>(hi.z); v[7] = static_cast<_Float16>(hi.w);
+    return v;
+  }
+};
+template <>
+struct HalfOps<true> {
+  using vec = v8b;
+  __device__ static __forceinline__ v4f mfma(vec a, vec b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ vec from_f32(const float4& lo, const float4& hi) {
+    vec v;
+    v[0] = static_cast<__bf16>(lo.x); v[1] = static_cast<__bf16>(lo.y);
+    v[2] = static_cast<__bf16>(lo.z); v[3] = static_cast<__bf16>(lo.w);
+    v[4] = static_cast<__bf16>(hi.x); v[5] = static_cast<__bf16>(hi.y);
+    v[6] = static_cast<__bf16>(hi.z); v[7] = static_cast<__bf16>(hi.w);
+    return v;
+  }
+};
+
+struct HalfEpilogue {
+  const float* bias;
+  const float* residual;
+  float* y;
+  int act;
+};
+
+__device__ __forceinline__ float finish(float v, float bias, bool has_bias, int act, float res,
+                                        bool has_res) {
+  if (has_bias) v = v + bias;
+  v = apply_activation(v, act);
+  if (has_res) v = res + v;
+  return v;
+}
+
+// ---- skinny split-K form (M <= 16 * MT) -------------------------------------------------------
+// A workgroup owns NT*16 output columns and all rows; wave w takes the 32-element K-steps
+// w, w + WAVES, ...; A fragments are read as fp32 (2 x 16 bytes per lane) and converted, W
+// fragments are 16 bytes per lane straight from memory; fp32 partial tiles are summed through LDS
+// in wave order (deterministic).
+template <bool kBF16, int MT, int NT, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void gemm_h_skinny_kernel(const float* __restrict__ A,
+                                                                   const uint16_t* __restrict__ W,
+                                                                   int M, int N, int K,
+                                                                   HalfEpilogue ep) {
+  using Ops = HalfOps<kBF16>;
+  using vec = typename Ops::vec;
+  __shared__ float partial[WAVES][MT][NT][64][4];
+  constexpr int THREADS = WAVES * 64;
+  constexpr int OUTS = MT * NT * 256;
+  constexpr int OPT = (OUTS + THREADS - 1) / THREADS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * (NT * 16);
+  const int ksteps = (K + 31) / 32;
+
+  float e_bias[OPT], e_res[OPT];
+#pragma unroll
+  for (int o = 0; o < OPT; ++o) {
+    const int flat = tid + o * THREADS;
+    const int tile = flat >> 8, within = flat & 255;
+    const int row = (tile / NT) * 16 + (within >> 4);
+    const int64_t col = n0 + (tile % NT) * 16 + (within & 15);
+    e_bias[o] = e_res[o] = 0.f;
+    if (flat < OUTS && row < M && col < N) {
+      if (ep.bias) e_bias[o] = ep.bias[col];
+      if (ep.residual) e_res[o] = ep.residual[static_cast<int64_t>(row) * N + col];
+    }
+  }
+
+  v4f acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  for (int ks0 = wave; ks0 < ksteps; ks0 += WAVES * U) {
+    float4 alo[U][MT], ahi[U][MT];
+    vec bf[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ks = ks0 + u * WAVES;
+      const int kk = ks * 32 + g * 8;
+      const bool k_ok = (ks < ksteps) && (kk < K);  // K % 8 == 0 is a launch precondition
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = i * 16 + r;
+        alo[u][i] = ahi[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k_ok && row < M) {
+          const float4* p = reinterpret_cast<const float4*>(A + static_cast<int64_t>(row) * K + kk);
+          alo[u][i] = p[0];
+          ahi[u][i] = p[1];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int64_t col = n0 + j * 16 + r;
+        vec z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = 0;
+        bf[u][j] = (k_ok && col < N) ? *reinterpret_cast<const vec*>(W + col * K + kk) : z;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const vec af = Ops::from_f32(alo[u][i], ahi[u][i]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = Ops::mfma(af, bf[u][j], acc[i][j]);
+      }
+  }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      *reinterpret_cast<v4f*>(&partial[wave][i][j][lane][0]) = acc[i][j];
+  __syncthreads();
+
+#pragma unroll
+  for (int o = 0; o < OPT; ++o) {
+    const int flat = tid + o * THREADS;
+    if (flat >= OUTS) continue;
+    const int tile = flat >> 8, within = flat & 255;
+    const int i = tile / NT, j = tile % NT;
+    const int rt = within >> 4, ct = within & 15;
+    const int row = i * 16 + rt;
+    const int64_t col = n0 + j * 16 + ct;
+    const int src_lane = ((rt >> 2) << 4) | ct;  // MFMA C layout: col = lane & 15, row = 4*(lane>>4)+reg
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) sum += partial[w][i][j][src_lane][rt & 3];
+    if (row >= M || col >= N) continue;
+    ep.y[static_cast<int64_t>(row) * N + col] =
+        finish(sum, e_bias[o], ep.bias != nullptr, ep.act, e_res[o], ep.residual != nullptr);
+  }
+}
+
+// ---- LDS-tiled form (encoder / prefill rows) ------------------------------------------------
+// 128 x 128 output tile, 64 K elements (128 bytes of the 16-bit type) per stage, 4 waves as
+// 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles. Rows are padded to 144 bytes in LDS (conflict-free
+// ds_read_b128 fragments); the A tile is converted fp32 -> 16 bit on its way into LDS; the next
+// stage's global loads are in flight during the MFMAs.
+template <bool kBF16>
+__global__ __launch_bounds__(256) void gemm_h_tiled_kernel(const float* __restrict__ A,
+                                                           const uint16_t* __restrict__ W, int M,
+                                                           int N, int K, HalfEpilogue ep) {
+  using Ops = HalfOps<kBF16>;
+  using vec = typename Ops::vec;
+  constexpr int BM = 128, BN = 128, BK = 64, STRIDE = BK * 2 + 16;  // bytes per LDS row
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(BM + BN) * STRIDE];
+  uint8_t* As = lds;
+  uint8_t* Bs = lds + BM * STRIDE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.y) * BM;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * BN;
+  // staging map: 8 threads per row (8 elements = 16 bytes of the 16-bit type each), 32 rows per pass
+  const int ld_row = tid >> 3, ld_c = tid & 7;
+
+  v4f acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra_lo[4], ra_hi[4];
+  vec rb[4];
+  auto load_tile = [&](int k0) {
+    const int kk = k0 + ld_c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = m0 + ld_row + i * 32;
+      ra_lo[i] = ra_hi[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < M && kk < K) {
+        const float4* p = reinterpret_cast<const float4*>(A + row * K + kk);
+        ra_lo[i] = p[0];
+        ra_hi[i] = p[1];
+      }
+      const int64_t col = n0 + ld_row + i * 32;
+      vec z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = 0;
+      rb[i] = (col < N && kk < K) ? *reinterpret_cast<const vec*>(W + col * K + kk) : z;
+    }
+  };
+
+  load_tile(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<vec*>(As + (ld_row + i * 32) * STRIDE + ld_c * 16) =
+          Ops::from_f32(ra_lo[i], ra_hi[i]);
+      *reinterpret_cast<vec*>(Bs + (ld_row + i * 32) * STRIDE + ld_c * 16) = rb[i];
+    }
+    __syncthreads();
+    if (k0 + BK < K) load_tile(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      vec af[4], bfr[4];
+      const int koff = ks * 64 + g * 16;  // bytes: 32 elements per MFMA K-step, 8 per lane group
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const vec*>(As + (wm * 64 + i * 16 + r) * STRIDE + koff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bfr[j] = *reinterpret_cast<const vec*>(Bs + (wn * 64 + j * 16 + r) * STRIDE + koff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Ops::mfma(af[i], bfr[j], acc[i][j]);
+    }
+  }
+
+  // Epilogue: operands first, then stores (see gemm_s8.hip).
+  float bias[4];
+  bool col_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t col = n0 + wn * 64 + j * 16 + r;
+    col_ok[j] = col < N;
+    bias[j] = (ep.bias && col_ok[j]) ? ep.bias[col] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float res[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = m0 + wm * 64 + i * 16 + g * 4 + e;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 16 + r;
+        res[e][j] = (ep.residual && row < M && col_ok[j]) ? ep.residual[row * N + col] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = m0 + wm * 64 + i * 16 + g * 4 + e;
+      if (row >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 16 + r;
+        if (col_ok[j])
+          ep.y[row * N + col] = finish(acc[i][j][e], bias[j], ep.bias != nullptr, ep.act, res[e][j],
+                                       ep.residual != nullptr);
+      }
+    }
+  }
+}
+
+template <bool kBF16>
+void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const HalfEpilogue& ep,
+                  hipStream_t stream) {
+#define CT2X_HSKINNY(MT, NT, WAVES, U)                                                       \
+  hipLaunchKernelGGL((gemm_h_skinny_kernel<kBF16, MT, NT, WAVES, U>),                        \
+                     dim3((N + 16 * NT - 1) / (16 * NT)), dim3(WAVES * 64), 0, stream, a, w, M, N, \
+                     K, ep)
+  if (M <= 128) {
+    const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 64 ? 4 : 8));
+    const bool wide = N >= 8192;
+    if (mt == 1) { if (wide) CT2X_HSKINNY(1, 4, 4, 2); else CT2X_HSKINNY(1, 1, 4, 4); }
+    else if (mt == 2) { if (wide) CT2X_HSKINNY(2, 4, 4, 2); else CT2X_HSKINNY(2, 1, 4, 4); }
+    else if (mt == 4) { if (wide) CT2X_HSKINNY(4, 2, 4, 2); else CT2X_HSKINNY(4, 1, 4, 2); }
+    else { if (wide) CT2X_HSKINNY(8, 2, 4, 1); else CT2X_HSKINNY(8, 1, 4, 2); }
+    return;
+  }
+#undef CT2X_HSKINNY
+  hipLaunchKernelGGL((gemm_h_tiled_kernel<kBF16>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256),
+                     0, stream, a, w, M, N, K, ep);
+}
+
+}  // namespace
+
+void launch_gemm_h(const float* a, const void* w, bool bf16, int64_t m, int64_t n, int64_t k,
+                   const float* bias, const float* residual, int act, float* y,
+                   hipStream_t stream) {
+  if (m == 0 || n == 0) return;
+  if (k % 8 != 0 || (reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(w) & 15))
+    throw Error("16-bit GEMM: K must be a multiple of 8 and the operands 16-byte aligned");
+  HalfEpilogue ep{bias, residual, y, act};
+  const auto* wp = static_cast<const uint16_t*>(w);
+  if (bf16)
+    launch_typed<true>(a, wp, static_cast<int>(m), static_cast<int>(n), static_cast<int>(k), ep, stream);
+  else
+    launch_typed<false>(a, wp, static_cast<int>(m), static_cast<int>(n), static_cast<int>(k), ep, stream);
+}
+
+}  // namespace ct2x

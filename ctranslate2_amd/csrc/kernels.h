@@ -107,6 +107,14 @@ void launch_gemm_f32(const float* a, const float* b, int64_t batch, int64_t m, i
                      int64_t stride_c, const float* bias, const float* residual, int act,
                      float* c, hipStream_t stream);
 
+// ---- float16 / bfloat16 weight GEMM (gemm_h.hip) -------------------------------------
+
+// y = act(a[m,k] (fp32, rounded to the weight type at the matrix pipe) . w[n,k]^T + bias) + residual,
+// fp32 accumulation on v_mfma_f32_16x16x32_{f16,bf16}. k % 8 == 0.
+void launch_gemm_h(const float* a, const void* w, bool bf16, int64_t m, int64_t n, int64_t k,
+                   const float* bias, const float* residual, int act, float* y,
+                   hipStream_t stream);
+
 // ---- attention (attention.hip) -------------------------------------------------------
 
 struct AttnDecodeParams {

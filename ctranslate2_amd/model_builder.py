@@ -15,7 +15,16 @@ import struct
 import numpy as np
 
 BINARY_VERSION = 6
-_TYPE_IDS = {"float32": 0, "int8": 1, "int16": 2, "int32": 3, "float16": 4}
+_TYPE_IDS = {"float32": 0, "int8": 1, "int16": 2, "int32": 3, "float16": 4, "bfloat16": 5}
+
+
+class BF16(np.ndarray):
+    """uint16 array holding bfloat16 bit patterns (numpy has no bfloat16); written with type id 5."""
+
+
+def to_bf16(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16).view(BF16)
 
 # ops::ActivationType (include/ctranslate2/ops/activation.h:9-17)
 RELU, GELU_TANH, SWISH, GELU, GELU_SIGMOID, TANH, SIGMOID = range(7)
@@ -45,7 +54,8 @@ def write_model_bin(path, spec_name, revision, variables, aliases=()):
             f.write(struct.pack("B", value.ndim))
             for dim in value.shape:
                 f.write(struct.pack("I", dim))
-            f.write(struct.pack("B", _TYPE_IDS[str(value.dtype)]))
+            type_name = "bfloat16" if isinstance(variables[name], BF16) else str(value.dtype)
+            f.write(struct.pack("B", _TYPE_IDS[type_name]))
             f.write(struct.pack("I", value.nbytes))
             f.write(value.tobytes())
         aliases = sorted(aliases)
@@ -99,6 +109,10 @@ class _Builder:
             q, s = quantize_int8(w)
             self.vars[name] = q
             self.vars[name + "_scale"] = s
+        elif self.quantization == "float16":
+            self.vars[name] = w.astype(np.float16)
+        elif self.quantization == "bfloat16":
+            self.vars[name] = to_bf16(w)
         else:
             self.vars[name] = w.astype(np.float32)
 

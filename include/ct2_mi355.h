@@ -152,6 +152,15 @@ int ct2x_gemm_f32(const float* d_a, const float* d_b, int64_t m, int64_t n, int6
                   int trans_b, const float* d_bias, const float* d_residual, int activation,
                   float* d_c, void* stream);
 
+/* primitives<Device::CUDA>::gemm<float16_t / bfloat16_t> + apply_bias_and_activation
+ * (src/cuda/primitives.cu:519-569 cublasGemmEx with fp32 accumulation, src/ops/gemm.cc:11-25):
+ * C = act(A.W^T + bias) + residual with W [n, k] stored as CT2X_F16 or CT2X_BF16, A [m, k] fp32
+ * rounded to that type when it enters the matrix pipe, fp32 accumulation (MFMA), fp32 output.
+ * k % 8 == 0. This is what the float16 / bfloat16 compute types of the engine run. */
+int ct2x_gemm_f16w(const float* d_a, const void* d_w, int w_dtype, int64_t m, int64_t n, int64_t k,
+                   const float* d_bias, const float* d_residual, int activation, float* d_c,
+                   void* stream);
+
 /* ops::LayerNorm::compute<Device::CUDA,T> last-axis form (src/ops/layer_norm_gpu.cu:174-213;
  * CPU src/cpu/kernels.cc:461-496): y = (x-mean)*rsqrt(max(E[x^2]-mean^2,0)+eps)*gamma+beta. */
 int ct2x_layer_norm(const void* d_x, const float* d_gamma, const float* d_beta, int64_t rows,

@@ -113,6 +113,21 @@ def gemm_f32(a, b, trans_b=True, bias=None, residual=None, act=-1):
     return host(c)
 
 
+def gemm_f16w(a, w_bits, bf16, bias=None, residual=None, act=-1):
+    """a fp32 [m, k]; w_bits uint16 [n, k] holding float16 or bfloat16 bit patterns."""
+    L = _lib.lib()
+    ad = dev(a.astype(np.float32))
+    wd = torch.from_numpy(np.ascontiguousarray(w_bits).view(np.int16)).cuda()
+    biasd = dev(bias.astype(np.float32)) if bias is not None else None
+    rd = dev(residual.astype(np.float32)) if residual is not None else None
+    m, k = a.shape
+    n = w_bits.shape[0]
+    c = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_gemm_f16w(_lib.ptr(ad), _lib.ptr(wd), C.c_int(5 if bf16 else 4), i64(m), i64(n),
+                                i64(k), _lib.ptr(biasd), _lib.ptr(rd), C.c_int(act), _lib.ptr(c), None))
+    return host(c)
+
+
 def matmul_f32(a, b, trans_b=False, alpha=1.0):
     L = _lib.lib()
     ad, bd = dev(a.astype(np.float32)), dev(b.astype(np.float32))

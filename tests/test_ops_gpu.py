@@ -139,6 +139,45 @@ def test_dense_glu_fused(gpu, m, n, k, act, with_bias):
         np.testing.assert_allclose(y, yo, rtol=2e-5, atol=1e-6)  # libm expf/erff in the gate, times up
 
 
+def _to_bf16_bits(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def _from_bf16_bits(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+@pytest.mark.parametrize("m,n,k", [(32, 1536, 512), (16, 14336, 4096), (128, 2048, 512), (5, 43, 40),
+                                   (1000, 777, 264), (2048, 512, 2048)])
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("act,with_res", [(-1, True), (0, False)])
+def test_gemm_half_weights(gpu, m, n, k, bf16, act, with_res):
+    """float16 / bfloat16 arm of ops::Gemm: operands rounded to the 16-bit type, products summed in
+    fp32 (MFMA). Oracle: the same rounded operands multiplied in float64; the only difference left
+    is the fp32 accumulation order (<= ~sqrt(k) * 2^-24 relative to the sum of |products|)."""
+    import _gpuops as G
+    rng = np.random.default_rng(m + n + k + int(bf16))
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    bias = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32) if with_res else None
+    if bf16:
+        wb = _to_bf16_bits(w)
+        wr, ar = _from_bf16_bits(wb), _from_bf16_bits(_to_bf16_bits(a))
+    else:
+        wh = w.astype(np.float16)
+        wb, wr, ar = wh.view(np.uint16), wh.astype(np.float32), a.astype(np.float16).astype(np.float32)
+    y = G.gemm_f16w(a, wb, bf16, bias, res, act)
+    ref = ar.astype(np.float64) @ wr.astype(np.float64).T + bias
+    if act == 0:
+        ref = np.maximum(ref, 0)
+    if res is not None:
+        ref = ref + res
+    bound = (np.abs(ar).astype(np.float64) @ np.abs(wr).astype(np.float64).T + 4) * 3e-6
+    assert np.all(np.abs(y - ref) <= bound), float(np.max(np.abs(y - ref) / bound))
+
+
 def test_dequantize_rows(gpu):
     import _gpuops as G
     rng = np.random.default_rng(3)

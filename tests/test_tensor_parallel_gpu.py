@@ -96,20 +96,26 @@ def test_step_logits_int8_bit_identical(gpu):
         t.close()
 
 
-def test_translate_float32(gpu):
+@pytest.mark.parametrize("compute_type", ["float32", "float16", "bfloat16"])
+def test_translate_float_types(gpu, compute_type):
     import ctranslate2_amd as ct2
     path = _model_dir("small")
     cfg = GC.SYNTHETIC["small"]
     src = _sources("small")
     kw = dict(beam_size=1, max_decoding_length=cfg["max_len"], min_decoding_length=cfg["min_len"],
               return_scores=True, use_graph=False)
-    single = ct2.Translator(path, compute_type="float32")
+    single = ct2.Translator(path, compute_type=compute_type)
     ref_h, ref_s = single.translate_ids(src, **kw)
-    ranks = ct2.Translator.tensor_parallel_local(path, 2, compute_type="float32")
+    ranks = ct2.Translator.tensor_parallel_local(path, 2, compute_type=compute_type)
     outs = _run_ranks(ranks, lambda t: t.translate_ids(src, **kw))
     for hyps, scores in outs:
-        assert hyps == ref_h
-        np.testing.assert_allclose(scores, ref_s, atol=1e-4)
+        if compute_type == "float32":
+            assert hyps == ref_h
+            np.testing.assert_allclose(scores, ref_s, atol=1e-4)
+        else:  # a different fp32 summation order ahead of a 16-bit rounding: allow near-tie flips
+            same = [a == b for a, b in zip(hyps, ref_h)]
+            assert sum(same) >= len(same) - 1
+            np.testing.assert_allclose(scores[same], ref_s[same], atol=5e-3)
     for t in ranks:
         t.close()
 

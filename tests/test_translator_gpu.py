@@ -103,11 +103,13 @@ def test_batch_composition_is_result_neutral(gpu, golden):
     assert mixed[0] == full[0] and mixed[1] == [[]] and mixed[2] == full[1]
 
 
-def _teacher_forced(gpu, golden, key):
+def _teacher_forced(gpu, golden, key, compute_type=None):
     g = golden[key]
     tf = g["teacher_forced"]
     model_key = key[:-4] if key.endswith("_f32") else key
-    t = get_translator(gpu, model_key, "float32" if (key.endswith("_f32") or key == "aren-transliteration") else "int8")
+    if compute_type is None:
+        compute_type = "float32" if (key.endswith("_f32") or key == "aren-transliteration") else "int8"
+    t = get_translator(gpu, model_key, compute_type)
     tgt_in = np.array(tf["tgt_in"], np.int32)
     logits = t.step_logits(g["sources"], tgt_in)  # [T, B, V]
     cols = np.array(tf["cols"])
@@ -130,6 +132,44 @@ def test_teacher_forced_logits_float32(gpu, golden, key):
     assert err.max() < LOGIT_TOL and top1_err.max() < LOGIT_TOL
     decided = margin > 2 * LOGIT_TOL
     assert np.array_equal(logits.argmax(-1)[decided], ref_arg[decided])
+
+
+# 16-bit compute types against the reference's float32 logits (the reference has no 16-bit CPU
+# path; north_star: "within 1e-3 on fp16 logits"). Weights and the activations entering a GEMM are
+# rounded to the type (2^-11 / 2^-8 relative), everything else is fp32.
+HALF_TOL = {"float16": 2e-3, "bfloat16": 1.6e-2}  # x max(1, std of the logits)
+
+
+@pytest.mark.parametrize("key", ["tiny_f32", "small_f32", "tb_f32"])
+@pytest.mark.parametrize("ct", ["float16", "bfloat16"])
+def test_teacher_forced_logits_half(gpu, golden, key, ct):
+    logits, err, top1_err, margin, ref_arg, std = _teacher_forced(gpu, golden, key, ct)
+    print("%s %s: max |logit - ref| = %.3e (sampled cols), %.3e (top-1), logits std %.3f"
+          % (key, ct, err.max(), top1_err.max(), std))
+    tol = HALF_TOL[ct] * max(1.0, std)
+    assert err.max() < tol and top1_err.max() < tol
+    decided = margin > 2 * tol
+    assert np.array_equal(logits.argmax(-1)[decided], ref_arg[decided])
+
+
+def test_half_models_resolve_their_compute_type(gpu):
+    """model.bin stored in float16 / bfloat16 loads unchanged and "default" resolves to that type
+    (resolve_compute_type, src/types.cc:156-295); int8_float16 requests run as int8_float32."""
+    import ctranslate2_amd as ct2
+    from ctranslate2_amd import model_builder as mb
+    cfg = dict(GC.SYNTHETIC["tiny"]["model"])
+    src = [[5, 6, 7, 8, 9]]
+    outs = {}
+    for q in ("float16", "bfloat16", None):
+        path = "/tmp/ct2x_test_tiny_store_%s" % q
+        if not os.path.exists(os.path.join(path, "model.bin")):
+            mb.build_transformer(path, quantization=q, **cfg)
+        t = ct2.Translator(path, compute_type="default")
+        assert t.compute_type == (q or "float32")
+        outs[q] = t.translate_ids(src, max_decoding_length=8, min_decoding_length=8)[0]
+    assert outs["float16"] == outs[None]
+    ti = get_translator(gpu, "tiny", "int8_float16")
+    assert ti.compute_type == "int8_float32"
 
 
 @pytest.mark.parametrize("key", ["aren-transliteration-i8", "tiny", "small", "tb"])
