@@ -242,6 +242,33 @@ int ct2x_gemm_f16w(const float* d_a, const void* d_w, int w_dtype, int64_t m, in
   API_CATCH
 }
 
+int ct2x_norm_gemm_s8_dequant(const float* d_x, const float* d_gamma, const float* d_beta, float eps,
+                              int rms_use_residual, int quant_flags, const int8_t* d_w,
+                              const float* d_w_scale, const float* d_bias, const float* d_residual,
+                              int64_t m, int64_t n, int64_t k, int activation, float* d_y,
+                              void* stream) {
+  API_TRY
+  CT2X_CHECK(gemm_s8_norm_applicable(m, n, k),
+             "ct2x_norm_gemm_s8_dequant: needs m <= 32, 64 <= k <= 1024, k % 16 == 0");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.w_scale = d_w_scale;
+  ep.bias = d_bias;
+  ep.residual = d_residual;
+  ep.y = d_y;
+  ep.act = activation;
+  ep.ldy = n;
+  ep.norm_x = d_x;
+  ep.norm_gamma = d_gamma;
+  ep.norm_beta = d_beta;
+  ep.norm_eps = eps;
+  ep.norm_rms_residual = rms_use_residual != 0;
+  ep.quant_mode = quant_flags;
+  launch_gemm_s8(nullptr, d_w, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("norm_gemm_s8_dequant");
+  API_CATCH
+}
+
 int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,
                          void* d_y, int dtype, void* stream) {
   API_TRY

@@ -2,6 +2,8 @@
 // activation functors). CDNA4 only: wavefront = 64 lanes, no 32-lane assumptions.
 #pragma once
 
+#include <float.h>
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -79,6 +81,33 @@ __device__ __forceinline__ ValIdx wave_argmax(ValIdx x) {
 
 // Activation epilogues: float math identical in form to the reference CPU functors
 // (src/cpu/kernels.cc:146-207).
+// Wave64 reductions on the DPP network (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast
+// 15 / 31 across rows; total in lane 63, broadcast by v_readlane): ~7 VALU issues instead of six
+// dependent ds_bpermute round trips (~130 cycles each) per reduction.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), kCtrl,
+                                                    kRowMask, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_move<0x111, 0xf>(0.f, v);
+  v += dpp_move<0x112, 0xf>(0.f, v);
+  v += dpp_move<0x114, 0xf>(0.f, v);
+  v += dpp_move<0x118, 0xf>(0.f, v);
+  v += dpp_move<0x142, 0xa>(0.f, v);
+  v += dpp_move<0x143, 0xc>(0.f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_move<0x111, 0xf>(-FLT_MAX, v));
+  v = fmaxf(v, dpp_move<0x112, 0xf>(-FLT_MAX, v));
+  v = fmaxf(v, dpp_move<0x114, 0xf>(-FLT_MAX, v));
+  v = fmaxf(v, dpp_move<0x118, 0xf>(-FLT_MAX, v));
+  v = fmaxf(v, dpp_move<0x142, 0xa>(-FLT_MAX, v));
+  v = fmaxf(v, dpp_move<0x143, 0xc>(-FLT_MAX, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __device__ __forceinline__ float apply_activation(float v, int act) {
   switch (act) {
     case 0:  // ReLU

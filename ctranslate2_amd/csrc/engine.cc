@@ -734,6 +734,34 @@ void Engine::norm_quant(const NormW& w, const float* x, int64_t rows, int64_t de
 }
 
 // layers::Dense::operator() (src/layers/common.cc:339-442).
+bool Engine::dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_t m, int act,
+                        const float* residual, float* y) {
+  if (!gemm_s8_norm_fusion_enabled() || !ln.present || !w.quantized || w.row_parallel ||
+      !gemm_s8_norm_applicable(m, w.n, w.k))
+    return false;
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.w_scale = w.wscale;
+  ep.bias = w.bias;
+  ep.residual = residual;
+  ep.y = y;
+  ep.act = act;
+  ep.ldy = w.n;
+  ep.norm_x = x;
+  ep.norm_gamma = ln.gamma;
+  ep.norm_beta = ln.beta;
+  ep.norm_eps = ln.eps;
+  ep.norm_rms_residual = ln.use_residual;
+  ep.quant_mode = quant_mode_;
+  const double M = double(m), N = double(w.n), K = double(w.k);
+  begin_kernel("norm_gemm_s8_dequant", 4 * M * K + N * K + 4 * N + 8 * K + 4 * M * N +
+                                           (residual ? 4 * M * N : 0) + (w.bias ? 4 * N : 0),
+               2 * M * N * K, m, w.n, w.k);
+  launch_gemm_s8(nullptr, w.wq, m, w.n, w.k, ep, cur_stream());
+  end_kernel();
+  return true;
+}
+
 void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t m, int act,
                    const float* residual, float* y, DecodeState* ws) {
   if (w.row_parallel && tp_) {
@@ -1085,6 +1113,12 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
                      DecodeState& st) {
   QuantIn fq;
   const float* ffn_in = x;
+  if (ffn.ln.present && pre_norm && !ffn.l0_noact.present &&
+      dense_norm(ffn.ln, ffn.l0, x, rows, ffn.activation, nullptr, st.inner)) {
+    dense(ffn.l1, st.inner, nullptr, rows, -1, x, y, &st);
+    std::swap(x, y);
+    return;
+  }
   if (ffn.ln.present && pre_norm) {
     if (ffn.l0.quantized) {
       norm_quant(ffn.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
@@ -1248,7 +1282,8 @@ void Engine::launch_step(DecodeState& st) {
       const AttnW& a = layer.self;
       QuantIn qin;
       const float* attn_in = x;
-      if (a.ln.present && dec_.pre_norm) {
+      const bool fused_in = dec_.pre_norm && dense_norm(a.ln, a.lin[0], x, rows, -1, nullptr, st.qkv);
+      if (!fused_in && a.ln.present && dec_.pre_norm) {
         if (a.lin[0].quantized) {
           norm_quant(a.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
           qin.q = st.qbuf;
@@ -1258,7 +1293,8 @@ void Engine::launch_step(DecodeState& st) {
           attn_in = st.ctx;
         }
       }
-      dense(a.lin[0], attn_in, qin.q ? &qin : nullptr, rows, -1, nullptr, st.qkv, &st);
+      if (!fused_in)
+        dense(a.lin[0], attn_in, qin.q ? &qin : nullptr, rows, -1, nullptr, st.qkv, &st);
       const int64_t qdim = a.heads * a.dhead, kvdim = a.heads_kv * a.dhead;
       const int64_t ld = qdim + 2 * kvdim;
       AttnDecodeParams p;
@@ -1309,7 +1345,8 @@ void Engine::launch_step(DecodeState& st) {
       const AttnW& a = layer.cross;
       QuantIn qin;
       const float* attn_in = x;
-      if (a.ln.present && dec_.pre_norm) {
+      const bool fused_in = dec_.pre_norm && dense_norm(a.ln, a.lin[0], x, rows, -1, nullptr, st.qkv);
+      if (!fused_in && a.ln.present && dec_.pre_norm) {
         if (a.lin[0].quantized) {
           norm_quant(a.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
           qin.q = st.qbuf;
@@ -1319,7 +1356,8 @@ void Engine::launch_step(DecodeState& st) {
           attn_in = st.ctx;
         }
       }
-      dense(a.lin[0], attn_in, qin.q ? &qin : nullptr, rows, -1, nullptr, st.qkv, &st);
+      if (!fused_in)
+        dense(a.lin[0], attn_in, qin.q ? &qin : nullptr, rows, -1, nullptr, st.qkv, &st);
       const int64_t kvdim = a.heads_kv * a.dhead;
       AttnDecodeParams p;
       p.q = st.qkv;
@@ -1365,17 +1403,19 @@ void Engine::launch_step(DecodeState& st) {
   // Final norm + vocabulary projection (transformer.cc:842-855).
   QuantIn pq;
   const float* proj_in = x;
-  if (dec_.output_norm.present) {
-    if (dec_.projection.quantized) {
-      norm_quant(dec_.output_norm, x, rows, d, nullptr, st.qbuf, st.qscale);
-      pq.q = st.qbuf;
-      pq.s = st.qscale;
-    } else {
-      norm(dec_.output_norm, x, rows, d, st.ctx);
-      proj_in = st.ctx;
+  if (!dense_norm(dec_.output_norm, dec_.projection, x, rows, -1, nullptr, st.logits)) {
+    if (dec_.output_norm.present) {
+      if (dec_.projection.quantized) {
+        norm_quant(dec_.output_norm, x, rows, d, nullptr, st.qbuf, st.qscale);
+        pq.q = st.qbuf;
+        pq.s = st.qscale;
+      } else {
+        norm(dec_.output_norm, x, rows, d, st.ctx);
+        proj_in = st.ctx;
+      }
     }
+    dense(dec_.projection, proj_in, pq.q ? &pq : nullptr, rows, -1, nullptr, st.logits, &st);
   }
-  dense(dec_.projection, proj_in, pq.q ? &pq : nullptr, rows, -1, nullptr, st.logits, &st);
 
   if (st.fuse_greedy) {
     begin_kernel("greedy_sample");

@@ -201,6 +201,10 @@ private:
     const float* s = nullptr;
   };
 
+  // Pre-norm Dense at decode rows with the norm + Quantize as the GEMM's prologue (one launch);
+  // false when the shape / layer does not qualify (the caller then runs norm_quant + dense).
+  bool dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_t m, int act,
+                  const float* residual, float* y);
   void load_weights();
   // How a Dense is split over the tensor-parallel ranks (Model::load, src/models/model.cc:
   // 662-743): kColumn = output rows; `blocks` lists the sizes of the fused sub-matrices that are

@@ -18,6 +18,7 @@
 #include "runtime.h"
 
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 namespace ct2x {
@@ -208,12 +209,20 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
 // DUAL: the gated FFN input pair of FeedForwardNetwork::operator() (src/layers/transformer.cc:
 // 21-51, ffn_glu) in one launch: y = act(x.W0^T + b0) * (x.W1^T + b1) - both weight streams share
 // the activation fragments, the two fp32 intermediates and the ops::Mul launch disappear.
-template <int MT, int NT, int WAVES, int U, bool DUAL = false>
+// NORM: the LayerNorm / RMSNorm + Quantize that feeds a pre-norm Dense runs as the prologue of
+// this launch (every workgroup normalises and quantises the <= 32 input rows itself: 64 KB of
+// fp32 from L2, one wave per row, DPP reductions) - one launch and one activation round trip
+// less per Dense. The quantised rows live in LDS (row stride K + 16 bytes) and the MFMA A
+// fragments are read from there.
+template <int MT, int NT, int WAVES, int U, bool DUAL = false, bool NORM = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
     GemmS8Epilogue ep) {
   constexpr int ND = DUAL ? 2 : 1;
   __shared__ int partial[ND][WAVES][MT][NT][64][4];
+  extern __shared__ __attribute__((aligned(16))) int8_t norm_lds[];  // NORM: qa rows + scales
+  const int qa_stride = K + 16;
+  float* norm_scales = reinterpret_cast<float*>(norm_lds + MT * 16 * qa_stride);
   constexpr int THREADS = WAVES * 64;
   constexpr int OUTS = MT * NT * 256;                       // outputs of the workgroup tile
   constexpr int OPT = (OUTS + THREADS - 1) / THREADS;       // outputs per thread in the epilogue
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     e_ra[o] = e_ws[o] = e_ws2[o] = 1.f;
     e_bias[o] = e_res[o] = e_bias2[o] = 0.f;
     if (ep.mode == 1 && flat < OUTS && row < M && col < N) {
-      e_ra[o] = ep.a_scale[row];
+      if (!NORM) e_ra[o] = ep.a_scale[row];
       e_ws[o] = ep.w_scale[col];
       if (ep.bias) e_bias[o] = ep.bias[col];
       if (ep.residual) e_res[o] = ep.residual[static_cast<int64_t>(row) * ep.ldy + col];
@@ -246,6 +255,98 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
         if (ep.bias2) e_bias2[o] = ep.bias2[col];
       }
     }
+  }
+
+  if (NORM) {
+    // One wave per row (rows wave, wave + WAVES, ...), float4 per lane and 256-element chunk
+    // (K <= 1024, K % 4 == 0). EVERY load of the prologue - gamma, beta and all of this wave's
+    // rows - is issued before the first reduction, so the prologue costs one memory round trip.
+    // Formulas: src/cpu/kernels.cc:461-496 (layer_norm), :543-573 (rms_norm), :577-651 (quantize).
+    constexpr int RPW = (MT * 16 + WAVES - 1) / WAVES;  // rows per wave
+    const int n4 = K / 4;
+    const int chunks = (n4 + 63) / 64;                  // 1..4
+    const float4* g4 = reinterpret_cast<const float4*>(ep.norm_gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(ep.norm_beta);
+    const float fdepth = static_cast<float>(K);
+    auto norm_rows = [&](auto ch_tag) __attribute__((always_inline)) {
+      constexpr int CH = decltype(ch_tag)::value;
+      v4f gv[CH], bv[CH], xv[RPW][CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int i = lane + u * 64;
+        gv[u] = bv[u] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (i < n4) {
+          gv[u] = *reinterpret_cast<const v4f*>(g4 + i);
+          if (ep.norm_beta != nullptr) bv[u] = *reinterpret_cast<const v4f*>(b4 + i);
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wave + rr * WAVES;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int i = lane + u * 64;
+          xv[rr][u] = v4f{0.f, 0.f, 0.f, 0.f};
+          if (row < M && i < n4)
+            xv[rr][u] = *reinterpret_cast<const v4f*>(ep.norm_x + static_cast<int64_t>(row) * K + i * 4);
+        }
+      }
+      if (ep.norm_beta == nullptr && ep.norm_rms_residual) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) gv[u] = gv[u] + 1.f;
+      }
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wave + rr * WAVES;
+        if (row >= M) continue;  // wave-uniform
+        float sum = 0.f, sumsq = 0.f;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const v4f v = xv[rr][u];
+          sum += v[0] + v[1] + v[2] + v[3];
+          sumsq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        sum = wave_sum_dpp(sum);
+        sumsq = wave_sum_dpp(sumsq);
+        v4f y[CH];
+        if (ep.norm_beta != nullptr) {
+          const float mean = sum / fdepth;
+          const float variance = fmaxf(sumsq / fdepth - mean * mean, 0.f);
+          const float rstd = 1.f / sqrtf(variance + ep.norm_eps);
+#pragma unroll
+          for (int u = 0; u < CH; ++u) y[u] = (xv[rr][u] - mean) * rstd * gv[u] + bv[u];
+        } else {
+          const float inv_rms = 1.f / sqrtf(sumsq / fdepth + ep.norm_eps);
+#pragma unroll
+          for (int u = 0; u < CH; ++u) y[u] = xv[rr][u] * inv_rms * gv[u];
+        }
+        float amax = 0.f;
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (lane + u * 64 < n4)
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(y[u][0]), fabsf(y[u][1])),
+                                     fmaxf(fabsf(y[u][2]), fabsf(y[u][3]))));
+        amax = wave_max_dpp(amax);
+        const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+        if (lane == 0) norm_scales[row] = scale;
+        char4* qr = reinterpret_cast<char4*>(norm_lds + row * qa_stride);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int i = lane + u * 64;
+          if (i < n4) {
+            char4 o;
+            o.x = to_s8(y[u][0], scale, ep.quant_mode);
+            o.y = to_s8(y[u][1], scale, ep.quant_mode);
+            o.z = to_s8(y[u][2], scale, ep.quant_mode);
+            o.w = to_s8(y[u][3], scale, ep.quant_mode);
+            qr[i] = o;
+          }
+        }
+      }
+    };
+    if (chunks <= 2) norm_rows(std::integral_constant<int, 2>{});
+    else norm_rows(std::integral_constant<int, 4>{});
+    __syncthreads();
   }
 
   v4i acc[ND][MT][NT];
@@ -267,9 +368,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int row = i * 16 + r;
-        af[u][i] = (k_ok && row < M)
-                       ? *reinterpret_cast<const v4i*>(A + static_cast<int64_t>(row) * K + kk)
-                       : v4i{0, 0, 0, 0};
+        if (NORM)
+          af[u][i] = (k_ok && row < M)
+                         ? *reinterpret_cast<const v4i*>(norm_lds + row * qa_stride + kk)
+                         : v4i{0, 0, 0, 0};
+        else
+          af[u][i] = (k_ok && row < M)
+                         ? *reinterpret_cast<const v4i*>(A + static_cast<int64_t>(row) * K + kk)
+                         : v4i{0, 0, 0, 0};
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -326,7 +432,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
       ep.c_i32[idx] = sum;
     } else {
       // CPU formula order (src/cpu/kernels.cc:666-673): c * (1/a_scale) / b_scale + bias.
-      const float r_a = 1.f / e_ra[o];
+      const float r_a = 1.f / (NORM ? norm_scales[row] : e_ra[o]);
       float v = static_cast<float>(sum) * r_a;
       v = v / e_ws[o];
       if (ep.bias) v = v + e_bias[o];
@@ -360,6 +466,22 @@ __global__ void gemm_s8_naive_kernel(const int8_t* __restrict__ A, const int8_t*
 
 }  // namespace
 
+bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k) {
+  return m >= 1 && m <= 32 && k >= 64 && k <= 1024 && k % 16 == 0 && n >= 1;
+}
+
+// Measured on MI355X (tools/op_time.py, bench.py): the prologue makes every workgroup redo the
+// norm of all rows with one wave per row - ~2000 dependent VALU issues per wave - which costs MORE
+// than the launch it saves (Transformer-base step 24.3 -> 35 ms per 64 steps; [32, 512] x 512:
+// ~10 us fused vs 2.7 + 2.8 us as two launches). The engine therefore only uses it on request.
+bool gemm_s8_norm_fusion_enabled() {
+  static const bool enabled = [] {
+    const char* e = std::getenv("CT2X_NORM_FUSION");
+    return e != nullptr && e[0] == '1';
+  }();
+  return enabled;
+}
+
 void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int64_t k,
                     const GemmS8Epilogue& ep_in, hipStream_t stream) {
   if (m == 0 || n == 0) return;
@@ -381,6 +503,25 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
   }();
   const int64_t sel = forced ? (forced <= 32 ? 1 : (forced <= 64 ? 33 : 65)) : m;
   static const bool no_skinny = std::getenv("CT2X_NO_SKINNY_GEMM") != nullptr;
+  if (ep.norm_x != nullptr) {
+    // Norm + Quantize prologue (gemm_s8_norm_applicable): decode rows of a pre-norm Dense.
+    if (!(mfma_ok && gemm_s8_norm_applicable(m, n, k) && ep.mode == 1 && ep.b2 == nullptr))
+      throw Error("launch_gemm_s8: the norm-prologue form needs M <= 32, K <= 1024, K % 16 == 0");
+    const size_t lds = static_cast<size_t>(m <= 16 ? 16 : 32) * (k + 16) + 32 * sizeof(float);
+#define CT2X_NORMG(MT, NT, WAVES, U)                                                              \
+  hipLaunchKernelGGL((gemm_s8_skinny_kernel<MT, NT, WAVES, U, false, true>),                      \
+                     dim3((n + 16 * NT - 1) / (16 * NT)), dim3(WAVES * 64), lds, stream, a, b, M, N, \
+                     K, ep)
+    if (m <= 16) {
+      if (n >= 8192) CT2X_NORMG(1, 4, 4, 2);
+      else CT2X_NORMG(1, 1, 4, 4);
+    } else {
+      if (n >= 8192) CT2X_NORMG(2, 4, 4, 2);
+      else CT2X_NORMG(2, 1, 4, 4);
+    }
+#undef CT2X_NORMG
+    return;
+  }
   if (ep.b2 != nullptr) {
     // Gated pair (see gemm_s8_skinny_kernel<..., DUAL>): only the decode shapes take this form
     // (gemm_s8_dual_applicable); column tiles per workgroup are halved, both streams count.

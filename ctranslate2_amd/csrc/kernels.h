@@ -87,7 +87,19 @@ struct GemmS8Epilogue {
   const int8_t* b2 = nullptr;
   const float* w_scale2 = nullptr;
   const float* bias2 = nullptr;
+  // Norm prologue (pre-norm Dense at decode rows): when norm_x != nullptr the launch ignores `a`
+  // and a_scale and computes them itself: LayerNorm (norm_beta != nullptr) or RMSNorm of
+  // norm_x [m, k] followed by Quantize (quant_mode = device_utils.h flags). M <= 32, K <= 1024.
+  const float* norm_x = nullptr;
+  const float* norm_gamma = nullptr;
+  const float* norm_beta = nullptr;
+  float norm_eps = 1e-5f;
+  bool norm_rms_residual = false;
+  int quant_mode = 0;
 };
+
+bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k);
+bool gemm_s8_norm_fusion_enabled();  // CT2X_NORM_FUSION=1 (off by default: measured slower)
 
 // C[m,n] = A[m,k] . B[n,k]^T   (lda = ldb = k). Chooses a tile shape from (m, n, k).
 void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int64_t k,

@@ -141,6 +141,16 @@ int ct2x_gemm_s8_glu(const int8_t* d_qa, const float* d_a_scale, const int8_t* d
                      const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n, int64_t k,
                      int activation, void* d_y, int dtype, void* stream);
 
+/* A pre-norm int8 Dense at decode rows as ONE launch: layers::LayerNorm (LayerNorm when d_beta is
+ * given, RMSNorm otherwise; src/layers/common.cc:464-472) -> ops::Quantize -> Gemm -> Dequantize
+ * (+bias, activation) -> Add(residual). m <= 32, k <= 1024, k % 16 == 0. quant_flags as in
+ * ct2x_quantize_s8. */
+int ct2x_norm_gemm_s8_dequant(const float* d_x, const float* d_gamma, const float* d_beta, float eps,
+                              int rms_use_residual, int quant_flags, const int8_t* d_w,
+                              const float* d_w_scale, const float* d_bias, const float* d_residual,
+                              int64_t m, int64_t n, int64_t k, int activation, float* d_y,
+                              void* stream);
+
 /* ops::Dequantize::dequantize<Device::CUDA,int8_t,T> (src/ops/dequantize_gpu.cu:17-28):
  * y[r,:] = x[r,:] / scale[r]  (int8 embedding rows, src/layers/common.cc:64-81). */
 int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,

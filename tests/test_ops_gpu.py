@@ -235,6 +235,35 @@ def test_norm_quantize_fused(gpu, rows, depth, rms, rbc):
     assert np.array_equal(q2, q) and np.array_equal(s2, s)
 
 
+@pytest.mark.parametrize("m,n,k", [(32, 1536, 512), (32, 32000, 512), (16, 512, 1024), (5, 48, 64)])
+@pytest.mark.parametrize("rms", [False, True])
+@pytest.mark.parametrize("act,with_res", [(-1, True), (0, False)])
+def test_norm_gemm_fused(gpu, m, n, k, rms, act, with_res):
+    """Pre-norm Dense as one launch (norm + Quantize as the GEMM prologue) against the two-launch
+    path (ct2x_norm_quantize_s8 + ct2x_gemm_s8_dequant). The prologue reduces a row inside one wave
+    instead of one workgroup, so mean / variance / absmax may differ in the last ulp (the whole
+    row then moves by ~1e-7 relative) and, rarely, one int8 activation flips (an output moves by
+    at most |w|max / a_scale)."""
+    import _gpuops as G
+    rng = np.random.default_rng(m + n + k + int(rms))
+    x = (rng.standard_normal((m, k)) * 1.5).astype(np.float32)
+    gamma = (1 + 0.1 * rng.standard_normal(k)).astype(np.float32)
+    beta = None if rms else (0.1 * rng.standard_normal(k)).astype(np.float32)
+    eps = 1e-6 if rms else 1e-5
+    wq, ws = O.quantize_s8((rng.standard_normal((n, k)) * 0.02).astype(np.float32), True)
+    bias = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32) if with_res else None
+    y = G.norm_gemm_s8_dequant(x, gamma, beta, eps, 3, wq, ws, bias, res, act)
+    _, q, s = G.norm_quantize_s8(x, gamma, beta, eps, False, 3, False)
+    y2 = G.gemm_s8_dequant(q, s, wq, ws, bias, res, act)
+    # last-ulp differences of the row scale move a whole row by ~1e-7 relative; a flipped
+    # activation moves an output by one weight quantum
+    close = np.abs(y - y2) <= 2e-6 * np.maximum(np.abs(y2), 1.0)
+    assert close.mean() >= 0.98, close.mean()
+    quantum = (127.0 / ws.min()) / s            # |w|max * (row absmax / 127), per row
+    assert np.all(np.abs(y - y2) <= 3 * quantum[:, None] + 1e-6)
+
+
 @pytest.mark.parametrize("rows,depth", [(256, 36), (32, 32000), (8, 128256), (5, 7), (64, 64)])
 @pytest.mark.parametrize("log", [False, True])
 @pytest.mark.parametrize("masked", [False, True])
