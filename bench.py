@@ -87,9 +87,21 @@ def aggregate_throughput(local_tokens, elapsed_s, dist=None, device=None):
 
 
 def pick_dominant(profile):
-    """Kernel label with the largest accumulated device time."""
-    label = max(profile, key=lambda k: profile[k]["total_ms"])
-    return label, profile[label]
+    """The kernel with the largest accumulated device time. Profile labels carry the launch shape
+    (gemm_s8_dequant[m=32,n=512,k=512], ...): they are first grouped by kernel, the way rocprofv3's
+    kernel stats group them, and the group's most frequent shape is reported alongside."""
+    groups = {}
+    for label, st in profile.items():
+        kind = label.split("[")[0]
+        g = groups.setdefault(kind, {"launches": 0, "total_ms": 0.0, "bytes": 0.0, "ops": 0.0,
+                                     "shapes": {}})
+        for key in ("launches", "total_ms", "bytes", "ops"):
+            g[key] += st[key]
+        g["shapes"][label] = st["launches"]
+    kind = max(groups, key=lambda k: groups[k]["total_ms"])
+    g = groups[kind]
+    g["main_shape"] = max(g["shapes"], key=g["shapes"].get)
+    return kind, g
 
 
 def pmc_traffic(label):
@@ -112,9 +124,15 @@ def roofline_entry(label, st):
     gbs = st["bytes"] / seconds / 1e9 if st["bytes"] > 0 and seconds > 0 else None
     tops = st["ops"] / seconds / 1e12 if st["ops"] > 0 and seconds > 0 else None
     entry = {"kernel": label, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": pmc_traffic(label),
+             "frac": (gbs / HBM_PEAK_GBS) if gbs else None,
+             "traffic": pmc_traffic(st.get("main_shape", label)),
              "launches": st["launches"], "avg_us": avg_ms * 1e3,
-             "bytes_per_launch": st["bytes"] / max(st["launches"], 1)}
+             "bytes_per_launch": st["bytes"] / max(st["launches"], 1),
+             "main_shape": st.get("main_shape", label),
+             "timing": "HIP events around every launch of an eager (graph-free) pass of the same "
+                       "workload on the engine's stream; includes the event pair's own cost "
+                       "(about 3-4 us per launch at these sizes: a decode step is latency bound, "
+                       "see DESIGN.md section 4)"}
     if tops is not None:
         entry["int8_tops"] = tops
         entry["mfma_frac"] = tops / INT8_MFMA_PEAK_TOPS

@@ -569,10 +569,22 @@ void launch_attention_decode2(const AttnDecodeParams& p, int quant_mode, int8_t*
     a.per_q_head = 0;
     tw = 1;
   } else {
+    // Split mode. Default: one workgroup per QUERY head (more waves in flight, K/V re-read from
+    // L2 once per head of a GQA group). CT2X_ATTN_SHARE_KV=1: one workgroup per KV head whose
+    // waves carry the whole group in registers (K/V read once) - for comparison runs.
+    static const bool share_kv = [] {
+      const char* e = std::getenv("CT2X_ATTN_SHARE_KV");
+      return e != nullptr && e[0] == '1';
+    }();
     a.teams = 1;
-    a.wg_per_row = static_cast<int>(p.heads);
-    a.per_q_head = 1;
-    gq = 1;
+    if (share_kv) {
+      a.wg_per_row = static_cast<int>(p.heads_kv);
+      a.per_q_head = 0;
+    } else {
+      a.wg_per_row = static_cast<int>(p.heads);
+      a.per_q_head = 1;
+      gq = 1;
+    }
     tw = p.t_max > 64 ? 4 : 1;
   }
   if (p.dhead == 64) launch_gq<64>(a, gq, tw, stream);
