@@ -21,8 +21,8 @@ using namespace ct2x;
 
 static void require_f32(int dtype, const char* what) {
   if (dtype != CT2X_F32)
-    throw Error(std::string(what) + ": only float32 activations are implemented in this "
-                "round (float16/bfloat16 variants are declared but not built yet)");
+    throw Error(std::string(what) + ": activations are float32 in this backend (the float16 / "
+                "bfloat16 compute types keep 16-bit WEIGHTS, see ct2x_gemm_f16w)");
 }
 
 extern "C" {
