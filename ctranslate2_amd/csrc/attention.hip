@@ -386,6 +386,10 @@ void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode
 // valid = min(length[b], q + 1) when causal.
 void launch_attention_full(const AttnFullParams& f, hipStream_t stream) {
   if (f.batch * f.tq == 0) return;
+  if (attention_prefill_applicable(f)) {
+    launch_attention_prefill(f, stream);
+    return;
+  }
   AttnKernelArgs a;
   AttnDecodeParams& p = a.p;
   p.q = f.q;

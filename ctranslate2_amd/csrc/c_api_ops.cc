@@ -409,4 +409,41 @@ int ct2x_attention_decode(const float* d_q, const float* d_k_cache, const float*
   API_CATCH
 }
 
+int ct2x_attention_full(const float* d_q, const float* d_k, const float* d_v,
+                        const int32_t* d_lengths, int64_t batch, int64_t tq, int64_t tk,
+                        int64_t heads, int64_t heads_kv, int64_t dhead, int causal,
+                        int64_t q_offset, float scale, float* d_out, void* stream) {
+  API_TRY
+  CT2X_CHECK(dhead % 4 == 0 && dhead <= 512, "ct2x_attention_full: dhead must be a multiple of 4 "
+             "and <= 512");
+  CT2X_CHECK(heads_kv >= 1 && heads % heads_kv == 0, "ct2x_attention_full: heads must be a "
+             "multiple of heads_kv");
+  CT2X_CHECK(tk + 1 <= 16384, "ct2x_attention_full: tk > 16383 is not supported");
+  AttnFullParams f;
+  f.q = d_q;
+  f.k = d_k;
+  f.v = d_v;
+  f.q_time_stride = heads * dhead;
+  f.q_batch_stride = tq * heads * dhead;
+  f.k_time_stride = f.v_time_stride = heads_kv * dhead;
+  f.k_batch_stride = f.v_batch_stride = tk * heads_kv * dhead;
+  f.k_head_stride = f.v_head_stride = dhead;
+  f.lengths = d_lengths;
+  f.batch = batch;
+  f.tq = tq;
+  f.tk = tk;
+  f.heads = heads;
+  f.heads_kv = heads_kv;
+  f.dhead = dhead;
+  f.causal = causal != 0;
+  f.q_offset = q_offset;
+  f.scale = scale;
+  f.out = d_out;
+  f.out_time_stride = heads * dhead;
+  f.out_batch_stride = tq * heads * dhead;
+  launch_attention_full(f, resolve_stream(stream));
+  check_last_launch("attention_full");
+  API_CATCH
+}
+
 }  // extern "C"

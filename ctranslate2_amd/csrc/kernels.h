@@ -195,6 +195,11 @@ struct AttnFullParams {
 
 void launch_attention_full(const AttnFullParams& p, hipStream_t stream);
 
+// Tiled form for d_head 64 / 128 (attention_prefill.hip: 64-query tiles, K/V tiles shared through
+// LDS, both products on v_mfma_f32_16x16x4_f32, online softmax); launch_attention_full routes to it.
+bool attention_prefill_applicable(const AttnFullParams& p);
+void launch_attention_prefill(const AttnFullParams& p, hipStream_t stream);
+
 // Prefill helper: for every (row = (b, t), head) of a fused QKV projection [R, q_dim + 2*kv_dim]
 // (R = batch * time): q -> q_out [R, q_dim] (RoPE applied at position pos0 + t when tables are
 // given), k -> cache_k[b, hk, pos0 + t, :] (RoPE applied), v -> cache_v[b, hk, pos0 + t, :].

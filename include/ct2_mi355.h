@@ -229,6 +229,15 @@ int ct2x_attention_decode(const float* d_q, const float* d_k_cache, const float*
                           int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t kv_group,
                           float scale, float* d_out, void* stream);
 
+/* Sequence-mode MultiHeadAttention core (src/layers/attention.cc:178-287 dot_product_attention:
+ * MatMul QK^T * queries_scale -> length / causal mask -> SoftMax -> MatMul PV) for Tq > 1:
+ * q [B, Tq, H*dh], k / v [B, Tk, Hkv*dh] (heads contiguous per token), lengths [B] valid keys
+ * (NULL = Tk), causal: key t visible to query i iff t <= i + q_offset. out [B, Tq, H*dh]. */
+int ct2x_attention_full(const float* d_q, const float* d_k, const float* d_v,
+                        const int32_t* d_lengths, int64_t batch, int64_t tq, int64_t tk,
+                        int64_t heads, int64_t heads_kv, int64_t dhead, int causal,
+                        int64_t q_offset, float scale, float* d_out, void* stream);
+
 /* ---- engine: ctranslate2::Translator / Generator ------------------------------- */
 
 /* models::Model::load + ReplicaPool ctor (src/models/model.cc:561-784,

@@ -242,3 +242,17 @@ def attention_decode(q, k, v, lengths=None, length=0, kv_group=1, scale=1.0):
                                        i64(rows), i64(heads), i64(heads_kv), i64(dhead), i64(t_max),
                                        i64(kv_group), C.c_float(scale), _lib.ptr(out), None))
     return host(out)
+
+
+def attention_full(q, k, v, lengths, causal, q_offset, scale):
+    """q [B, Tq, H, dh], k / v [B, Tk, Hkv, dh] -> [B, Tq, H, dh]."""
+    L = _lib.lib()
+    b, tq, h, dh = q.shape
+    tk, hkv = k.shape[1], k.shape[2]
+    qd, kd, vd = dev(q.astype(np.float32)), dev(k.astype(np.float32)), dev(v.astype(np.float32))
+    ld = torch.from_numpy(np.ascontiguousarray(lengths, np.int32)).cuda() if lengths is not None else None
+    out = torch.empty((b, tq, h, dh), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_attention_full(_lib.ptr(qd), _lib.ptr(kd), _lib.ptr(vd), _lib.ptr(ld), i64(b),
+                                     i64(tq), i64(tk), i64(h), i64(hkv), i64(dh), C.c_int(int(causal)),
+                                     i64(q_offset), C.c_float(scale), _lib.ptr(out), None))
+    return host(out)

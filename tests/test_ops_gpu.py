@@ -372,3 +372,44 @@ def test_attention_decode(gpu, rows, heads, heads_kv, dhead, t_max, kv_group):
     y2 = G.attention_decode(q, k, v, None, t_max // 2 + 1, kv_group, scale)
     yo2 = O.attention_decode(q, k, v, None, t_max // 2 + 1, kv_group, scale)
     np.testing.assert_allclose(y2, yo2, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("b,tq,tk,h,hkv,dh,causal", [
+    (4, 32, 32, 8, 8, 64, False),     # Transformer-base encoder tile
+    (3, 128, 128, 8, 2, 128, True),   # Llama-style prefill: GQA, causal
+    (2, 100, 100, 4, 4, 64, True),    # ragged query tile (100 = 64 + 36)
+    (2, 70, 45, 4, 2, 128, False),    # Tq != Tk
+    (2, 20, 20, 2, 2, 32, True),      # head size of the per-row kernel
+])
+def test_attention_full(gpu, b, tq, tk, h, hkv, dh, causal):
+    """Sequence-mode attention against a float64 statement of dot_product_attention
+    (src/layers/attention.cc:178-287): scores = scale * q.k, length mask (and causal mask),
+    softmax, P.V; masked rows give zeros."""
+    import _gpuops as G
+    rng = np.random.default_rng(b + tq + tk + h + dh)
+    q = rng.standard_normal((b, tq, h, dh)).astype(np.float32)
+    k = rng.standard_normal((b, tk, hkv, dh)).astype(np.float32)
+    v = rng.standard_normal((b, tk, hkv, dh)).astype(np.float32)
+    lengths = rng.integers(1, tk + 1, b).astype(np.int32)
+    lengths[0] = tk
+    if b > 2:
+        lengths[1] = 0
+    scale = 1.0 / np.sqrt(dh)
+    y = G.attention_full(q, k, v, lengths, causal, 0, scale)
+    group = h // hkv
+    ref = np.zeros((b, tq, h, dh))
+    for bi in range(b):
+        for hi in range(h):
+            kk, vv = k[bi, :, hi // group].astype(np.float64), v[bi, :, hi // group].astype(np.float64)
+            s = scale * (q[bi, :, hi].astype(np.float64) @ kk.T)            # [tq, tk]
+            mask = np.arange(tk)[None, :] < lengths[bi]
+            if causal:
+                mask = mask & (np.arange(tk)[None, :] <= np.arange(tq)[:, None])
+            s = np.where(mask, s, -np.inf)
+            with np.errstate(invalid="ignore"):
+                e = np.exp(s - np.max(s, axis=1, keepdims=True))
+            e = np.where(mask, e, 0.0)
+            den = e.sum(axis=1, keepdims=True)
+            pmat = np.divide(e, den, out=np.zeros_like(e), where=den > 0)
+            ref[bi, :, hi] = pmat @ vv
+    np.testing.assert_allclose(y, ref, rtol=2e-5, atol=3e-6)
