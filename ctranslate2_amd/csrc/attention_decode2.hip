@@ -443,12 +443,22 @@ __global__ __launch_bounds__(TW == 1 ? 512 : TW * 64) void attn2_kernel(Attn2Arg
   CT2X_STAMP(7)
   if (a.q_out == nullptr) {
     if (tw == 0) {
+      float amax = 0.f;
 #pragma unroll
       for (int g = 0; g < GQ; ++g)
 #pragma unroll
-        for (int e = 0; e < E; ++e)
+        for (int e = 0; e < E; ++e) {
           p.out[static_cast<int64_t>(row) * (p.heads * DH) + (hq0 + g) * DH + CT2X_PVD(e)] =
               acc[g][e];
+          amax = fmaxf(amax, fabsf(acc[g][e]));
+        }
+      if (p.row_amax_out != nullptr) {
+        // first half of the ops::Quantize that follows: max over the row's heads (bit patterns of
+        // non-negative floats order like unsigned integers: exact, order independent)
+        amax = wave_max_dpp(amax);
+        if (lane == 0)
+          atomicMax(reinterpret_cast<unsigned int*>(p.row_amax_out) + row, __float_as_uint(amax));
+      }
     }
     return;
   }
@@ -549,6 +559,10 @@ bool attention_decode2_applicable(const AttnDecodeParams& p, bool fused_quantize
   const int64_t team_floats =
       p.dhead + t_pad + 4 * 2 + 4 * p.dhead + 4 * 64 * 68 + 8;  // split mode: one query head per team
   return team_floats * 4 <= 156 * 1024;
+}
+
+bool attention_decode_emits_row_amax(const AttnDecodeParams& p) {
+  return attention_decode2_applicable(p, false);
 }
 
 void launch_attention_decode2(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,

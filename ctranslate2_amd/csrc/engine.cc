@@ -944,6 +944,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   st->ctx = alloc<float>(*st, wrows * d);
   st->inner = alloc<float>(*st, wrows * wffn);
   st->inner2 = alloc<float>(*st, wrows * wffn);
+  st->row_amax = alloc<float>(*st, 2 * static_cast<int64_t>(dec_.layers.size()) * rows);
   if (tp_) {
     st->tp_acc = alloc<int32_t>(*st, wrows * d);
     st->tp_amax = alloc<float>(*st, wrows);
@@ -1110,7 +1111,7 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
 // [-> x Dense-noact (GLU)] -> Dense + residual -> post-norm. x is the sub-layer input, the result
 // lands in y and the pointers are swapped so that x is the output on return.
 void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, float*& x, float*& y,
-                     DecodeState& st) {
+                     DecodeState& st, float* amax_buf) {
   QuantIn fq;
   const float* ffn_in = x;
   if (ffn.ln.present && pre_norm && !ffn.l0_noact.present &&
@@ -1148,11 +1149,28 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
     ep.bias2 = ffn.l0_noact.bias;
     ep.y = st.inner;
     ep.ldy = ffn.l0.n;
+    // The gated pair also leaves the row absmax of its output: the Quantize that feeds linear_1
+    // becomes an element-wise launch over (rows x column chunks) instead of one workgroup per row.
+    const bool split_quant = amax_buf != nullptr && !tp_ && ffn.l1.quantized && !ffn.l1.row_parallel;
+    if (split_quant) ep.row_amax_out = amax_buf;
     const double M = double(rows), N = double(ffn.l0.n), K = double(ffn.l0.k);
     begin_kernel("gemm_s8_glu", M * K + 2 * N * K + 8 * N + 4 * M + 4 * M * N, 4 * M * N * K, rows,
                  ffn.l0.n, ffn.l0.k);
     launch_gemm_s8(fq.q, ffn.l0.wq, rows, ffn.l0.n, ffn.l0.k, ep, cur_stream());
     end_kernel();
+    if (split_quant) {
+      begin_kernel("quantize_cols", double(rows) * ffn.l0.n * 5, 0, rows, 0, ffn.l0.n);
+      launch_quantize_cols(st.inner, amax_buf, rows, ffn.l0.n, quant_mode_, st.qbuf, st.qscale,
+                           cur_stream());
+      end_kernel();
+      QuantIn iq;
+      iq.q = st.qbuf;
+      iq.s = st.qscale;
+      dense(ffn.l1, nullptr, &iq, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
+      if (ffn.ln.present && !pre_norm) norm(ffn.ln, y, rows, d, y);
+      std::swap(x, y);
+      return;
+    }
   } else {
   dense(ffn.l0, ffn_in, fq.q ? &fq : nullptr, rows, ffn.activation, nullptr, st.inner, &st);
   if (ffn.l0_noact.present) {
@@ -1269,6 +1287,11 @@ void Engine::launch_step(DecodeState& st) {
   if (dec_.sinusoidal_positions) pos = sinusoidal_table(st.t_max, d);
   float* x = st.x0;
   float* y = st.x1;
+  // producer-side absmax slots (2 per layer) are max-combined into: zero them for this step
+  const bool split_quant = !tp_ && rows <= 32;
+  if (split_quant)
+    CT2X_HIP_CHECK(hipMemsetAsync(st.row_amax, 0,
+                                  sizeof(float) * 2 * dec_.layers.size() * rows, cur_stream()));
   begin_kernel("embed");
   launch_embed(dec_.emb.table, dec_.emb.is_int8, dec_.emb.scale, st.d_ids, rows, d,
                dec_.embeddings_scale, dec_.scale_embeddings, pos, 1, 0, st.d_step, x, cur_stream());
@@ -1326,6 +1349,22 @@ void Engine::launch_step(DecodeState& st) {
         // attention + ops::Quantize of the context in one launch (kFusedQ)
         begin_kernel("attention_self_decode_q", 0, 0, rows, a.heads, a.dhead);
         launch_attention_decode_quantized(p, quant_mode_, st.qbuf, st.qscale, cur_stream());
+        end_kernel();
+        QuantIn cq;
+        cq.q = st.qbuf;
+        cq.s = st.qscale;
+        dense(a.lin[1], nullptr, &cq, rows, -1, a.ln.present ? x : nullptr, y, &st);
+      } else if (split_quant && a.lin[1].quantized && !a.lin[1].row_parallel &&
+                 attention_decode_emits_row_amax(p)) {
+        // long caches / few rows: one workgroup per (row, head) + producer-side absmax, then an
+        // element-wise Quantize over (rows x column chunks) workgroups
+        float* amax = st.row_amax + (2 * l) * rows;
+        p.row_amax_out = amax;
+        begin_kernel("attention_self_decode", 0, 0, rows, a.heads, a.dhead);
+        launch_attention_decode(p, cur_stream());
+        end_kernel();
+        begin_kernel("quantize_cols", double(rows) * qdim * 5, 0, rows, 0, qdim);
+        launch_quantize_cols(st.ctx, amax, rows, qdim, quant_mode_, st.qbuf, st.qscale, cur_stream());
         end_kernel();
         QuantIn cq;
         cq.q = st.qbuf;
@@ -1397,7 +1436,8 @@ void Engine::launch_step(DecodeState& st) {
       std::swap(x, y);
     }
     // ---- feed forward ----------------------------------------------------------------------
-    run_ffn(layer.ffn, dec_.pre_norm, rows, d, x, y, st);
+    run_ffn(layer.ffn, dec_.pre_norm, rows, d, x, y, st,
+            split_quant ? st.row_amax + (2 * l + 1) * rows : nullptr);
   }
 
   // Final norm + vocabulary projection (transformer.cc:842-855).

@@ -230,8 +230,9 @@ private:
   void quant(const float* x, int64_t rows, int64_t depth, int8_t* q, float* s);
 
   void encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_lengths);
+  // amax_buf: zeroed [rows] scratch for the producer-side absmax of the gated pair (decode steps)
   void run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, float*& x, float*& y,
-               DecodeState& st);
+               DecodeState& st, float* amax_buf = nullptr);
   void launch_step(DecodeState& st);
   const float* sinusoidal_table(int64_t positions, int64_t depth);
   void rotary_tables(const AttnW& a, int64_t positions, const float** sin, const float** cos);
@@ -285,6 +286,7 @@ struct DecodeState {
   float* inner2 = nullptr;   // [rows, ffn] (GLU gate)
   float* logits = nullptr;   // [rows, vocab]
   float* logprobs = nullptr; // [rows, vocab] (beam search)
+  float* row_amax = nullptr; // [2 * layers, rows]: producer-side row absmax (zeroed every step)
   int32_t* tp_acc = nullptr; // tensor parallel: int32 / fp32 partial products [rows, d]
   float* tp_amax = nullptr;  // tensor parallel: per-row absmax [rows]
   int8_t* qbuf = nullptr;    // [rows, max(d, ffn)]

@@ -408,6 +408,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
         *reinterpret_cast<v4i*>(&partial[d][wave][i][j][lane][0]) = acc[d][i][j];
   __syncthreads();
 
+  // Optional per-row absmax of the stored values (first half of the next Quantize): LDS max per
+  // row of the tile, then one global max per row and workgroup. |y| >= 0, so the IEEE bit
+  // patterns order like unsigned integers: the max is exact and order independent.
+  __shared__ unsigned int tile_amax[MT * 16];
+  if (ep.row_amax_out != nullptr) {
+    if (tid < MT * 16) tile_amax[tid] = 0u;
+    __syncthreads();
+  }
+
   // Cross-wave sum (exact int32) + fused epilogue, spread over ALL threads of the workgroup.
 #pragma unroll
   for (int o = 0; o < OPT; ++o) {
@@ -445,7 +454,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
       }
       if (ep.residual) v = e_res[o] + v;
       ep.y[idx] = v;
+      if (ep.row_amax_out != nullptr) atomicMax(&tile_amax[row], __float_as_uint(fabsf(v)));
     }
+  }
+  if (ep.row_amax_out != nullptr) {
+    __syncthreads();
+    if (tid < MT * 16 && tid < M)
+      atomicMax(reinterpret_cast<unsigned int*>(ep.row_amax_out) + tid, tile_amax[tid]);
   }
 }
 

@@ -23,6 +23,11 @@ void launch_dequantize_gemm_output(const int32_t* c, const float* a_scale, const
 // Tensor-parallel helpers (rowops.hip): per-row absmax of a K slice, Quantize with a given
 // (rank-reduced) absmax, the float row-parallel epilogue, and the rank-order combine used by the
 // in-process communicator.
+// Second half of a Quantize whose row absmax was produced by the previous launch (absmax in
+// amax[rows]): element-wise over (rows x column chunks) workgroups instead of one workgroup per
+// row - at 16 decode rows the row-per-workgroup kernels leave 240 CUs idle.
+void launch_quantize_cols(const float* x, const float* amax, int64_t rows, int64_t depth,
+                          int quant_mode, int8_t* q, float* scales, hipStream_t stream);
 void launch_row_amax(const float* x, int64_t rows, int64_t depth, float* amax, hipStream_t stream);
 void launch_quantize_with_amax(const float* x, const float* amax, int64_t rows, int64_t depth,
                                int quant_mode, int8_t* q, float* scales, hipStream_t stream);
@@ -96,6 +101,9 @@ struct GemmS8Epilogue {
   float norm_eps = 1e-5f;
   bool norm_rms_residual = false;
   int quant_mode = 0;
+  // Skinny kernel: per-row absmax of the stored y, max-combined into row_amax_out[m] (must be
+  // zero beforehand) - the first half of the following ops::Quantize, see launch_quantize_cols.
+  float* row_amax_out = nullptr;
 };
 
 bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k);
@@ -159,7 +167,12 @@ struct AttnDecodeParams {
   int64_t rot_dim = 0;
   bool rope_interleave = false;
   float* out = nullptr;  // [rows, heads*dhead]
+  // attention_decode2 split mode only: per-row absmax of the context, max-combined into
+  // row_amax_out[rows] (zero beforehand); attention_decode_emits_row_amax tells whether it will.
+  float* row_amax_out = nullptr;
 };
+
+bool attention_decode_emits_row_amax(const AttnDecodeParams& p);
 
 void launch_attention_decode(const AttnDecodeParams& p, hipStream_t stream);
 

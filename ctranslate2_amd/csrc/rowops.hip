@@ -94,6 +94,37 @@ __global__ void quantize_with_amax_kernel(const float* __restrict__ x,
   for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) qr[i] = to_s8(xr[i], scale, quant_mode);
 }
 
+__global__ void quantize_cols_kernel(const float* __restrict__ x, const float* __restrict__ amax,
+                                     int64_t depth, int quant_mode, int8_t* __restrict__ q,
+                                     float* __restrict__ scales) {
+  const int64_t row = blockIdx.y;
+  const float a = amax[row];
+  const float scale = (a != 0.f) ? 127.f / a : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scales[row] = scale;
+  const int64_t i = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) * 4;
+  if (i >= depth) return;
+  const float4 v = *reinterpret_cast<const float4*>(x + row * depth + i);
+  char4 o;
+  o.x = to_s8(v.x, scale, quant_mode);
+  o.y = to_s8(v.y, scale, quant_mode);
+  o.z = to_s8(v.z, scale, quant_mode);
+  o.w = to_s8(v.w, scale, quant_mode);
+  *reinterpret_cast<char4*>(q + row * depth + i) = o;
+}
+
+void launch_quantize_cols(const float* x, const float* amax, int64_t rows, int64_t depth,
+                          int quant_mode, int8_t* q, float* scales, hipStream_t stream) {
+  if (rows == 0 || depth == 0) return;
+  if (depth % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(q) & 3)) {
+    launch_quantize_with_amax(x, amax, rows, depth, quant_mode, q, scales, stream);
+    return;
+  }
+  const int threads = 256;
+  const dim3 grid(static_cast<unsigned>((depth / 4 + threads - 1) / threads), static_cast<unsigned>(rows));
+  hipLaunchKernelGGL(quantize_cols_kernel, grid, dim3(threads), 0, stream, x, amax, depth, quant_mode,
+                     q, scales);
+}
+
 void launch_row_amax(const float* x, int64_t rows, int64_t depth, float* amax,
                      hipStream_t stream) {
   if (rows == 0) return;
