@@ -1288,7 +1288,9 @@ void Engine::launch_step(DecodeState& st) {
   float* x = st.x0;
   float* y = st.x1;
   // producer-side absmax slots (2 per layer) are max-combined into: zero them for this step
-  const bool split_quant = !tp_ && rows <= 32;
+  // (only models whose layers take that path pay for the memset node: gated-FFN decoders)
+  const bool split_quant = !tp_ && rows <= 32 && !dec_.layers.empty() &&
+                           dec_.layers[0].ffn.l0_noact.present;
   if (split_quant)
     CT2X_HIP_CHECK(hipMemsetAsync(st.row_amax, 0,
                                   sizeof(float) * 2 * dec_.layers.size() * rows, cur_stream()));
