@@ -134,7 +134,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
     # -- translation -----------------------------------------------------------------------
     def _options(self, beam_size, max_decoding_length, min_decoding_length, num_hypotheses,
                  return_scores, return_end_token, max_batch_size, max_input_length,
-                 length_penalty, patience, use_graph, num_streams=0):
+                 length_penalty, patience, use_graph, num_streams=0, sampling_topk=1,
+                 sampling_topp=1.0, sampling_temperature=1.0, seed=0):
         opt = TranslationOptions()
         self._L.ct2x_translation_options_default(C.byref(opt))
         opt.beam_size = beam_size
@@ -149,6 +150,10 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         opt.patience = patience
         opt.use_graph = int(use_graph)
         opt.num_streams = int(num_streams)
+        opt.sampling_topk = int(sampling_topk)
+        opt.sampling_topp = float(sampling_topp)
+        opt.sampling_temperature = float(sampling_temperature)
+        opt.seed = int(seed) & 0xFFFFFFFF
         return opt
 
     def translate_ids(self, source_ids: Sequence[Sequence[int]], beam_size: int = 2,
@@ -156,8 +161,12 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                       num_hypotheses: int = 1, return_scores: bool = False,
                       return_end_token: bool = False, max_batch_size: int = 0,
                       max_input_length: int = 1024, length_penalty: float = 1.0,
-                      patience: float = 1.0, use_graph: bool = True, num_streams: int = 0):
-        """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores)."""
+                      patience: float = 1.0, use_graph: bool = True, num_streams: int = 0,
+                      sampling_topk: int = 1, sampling_topp: float = 1.0,
+                      sampling_temperature: float = 1.0, seed: int = 0):
+        """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores).
+        sampling_* (reference names, python/cpp/translator.cc): random sampling among the best
+        sampling_topk candidates (beam_size must be 1), reproducible for a `seed`."""
         batch = len(source_ids)
         lengths = np.array([len(s) for s in source_ids], np.int32)
         stride = max(1, int(lengths.max()) if batch else 1)
@@ -169,7 +178,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         scores = np.zeros((batch, num_hypotheses), np.float32)
         opt = self._options(beam_size, max_decoding_length, min_decoding_length, num_hypotheses,
                             return_scores, return_end_token, max_batch_size, max_input_length,
-                            length_penalty, patience, use_graph, num_streams)
+                            length_penalty, patience, use_graph, num_streams, sampling_topk,
+                            sampling_topp, sampling_temperature, seed)
         _lib.check(self._L.ct2x_translate_batch(
             C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
             C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
@@ -194,9 +204,12 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
 
     def generate_ids(self, prompts: Sequence[Sequence[int]], max_length: int = 512,
                      min_length: int = 0, return_scores: bool = False,
-                     return_end_token: bool = False, use_graph: bool = True):
-        """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False,
-        sampling_topk=1 (greedy). Returns (generated ids per prompt, scores)."""
+                     return_end_token: bool = False, use_graph: bool = True,
+                     sampling_topk: int = 1, sampling_topp: float = 1.0,
+                     sampling_temperature: float = 1.0, seed: int = 0):
+        """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False.
+        sampling_topk=1 is greedy; 2..64 samples among the best k (sampling_topp / temperature as
+        in the reference). Returns (generated ids per prompt, scores)."""
         batch = len(prompts)
         lengths = np.array([len(p) for p in prompts], np.int32)
         stride = int(lengths.max())
@@ -207,7 +220,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         out_len = np.zeros((batch,), np.int32)
         scores = np.zeros((batch,), np.float32)
         opt = self._options(1, max_length, min_length, 1, return_scores, return_end_token, 0, 0,
-                            1.0, 1.0, use_graph, 1)
+                            1.0, 1.0, use_graph, 1, sampling_topk, sampling_topp,
+                            sampling_temperature, seed)
         opt.length_penalty = 1.0
         _lib.check(self._L.ct2x_generate_batch(
             C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),

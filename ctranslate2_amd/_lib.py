@@ -32,7 +32,10 @@ class TranslationOptions(C.Structure):
         ("patience", C.c_float),
         ("use_graph", C.c_int32),
         ("num_streams", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("sampling_topk", C.c_int32),
+        ("sampling_topp", C.c_float),
+        ("sampling_temperature", C.c_float),
+        ("seed", C.c_uint32),
     ]
 
 

@@ -163,6 +163,10 @@ DecodingOptions to_decoding_options(const ct2x_translation_options& o) {
   d.patience = o.patience;
   d.use_graph = o.use_graph != 0;
   d.include_eos_in_hypotheses = true;  // DecodingOptions default (include/ctranslate2/decoding.h:154)
+  d.sampling_topk = o.sampling_topk == 0 ? 1 : o.sampling_topk;  // zero-initialised structs: arg-max
+  d.sampling_topp = o.sampling_topp == 0.f ? 1.f : o.sampling_topp;
+  d.sampling_temperature = o.sampling_temperature == 0.f ? 1.f : o.sampling_temperature;
+  d.seed = o.seed;
   return d;
 }
 
@@ -193,6 +197,10 @@ void ct2x_translation_options_default(struct ct2x_translation_options* o) {
   o->length_penalty = 1.f;
   o->patience = 1.f;
   o->use_graph = 1;
+  o->sampling_topk = 1;
+  o->sampling_topp = 1.f;
+  o->sampling_temperature = 1.f;
+  o->seed = 0;
 }
 
 void* ct2x_translator_create(const char* model_dir, int device_index, const char* compute_type) {

@@ -120,6 +120,156 @@ void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int3
                      hist_scores);
 }
 
+// ---------------------------------------------------------------------------------------------
+// RandomSampler (src/sampling.cc:41-101) for one sample per row, fused like the greedy sampler:
+// min-length EOS masking -> restrict to the best `topk` candidates (ops::TopK order: value
+// descending, ties by lowest index) -> divide by the temperature -> TopPMask (keep a candidate
+// while the probability mass ranked before it is < topp, src/ops/topp_mask_cpu.cc:24-31) ->
+// SoftMax -> Multinomial (inverse CDF on a uniform draw) -> id to the next step + history; the
+// returned score is the log-probability of the id under the ORIGINAL distribution
+// (ops::Gather(scores, sampled_ids)). The uniform draw is a counter-based hash of
+// (seed, step, row): reproducible for a seed, independent of batch composition and of
+// hipGraph replay (the step counter lives in device memory).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxSampleTopK = 64;
+
+__device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_t row) {
+  uint64_t z = (static_cast<uint64_t>(seed) << 32) ^ (static_cast<uint64_t>(step) << 20) ^ row;
+  z += 0x9E3779B97F4A7C15ull;  // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return static_cast<float>(z >> 40) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
+}
+
+__global__ void random_sample_kernel(const float* __restrict__ logits, int64_t vocab,
+                                     int32_t disable_id, int32_t min_length, bool with_scores,
+                                     int topk, float topp, float temperature, uint32_t seed,
+                                     const int32_t* __restrict__ step_ptr,
+                                     int32_t* __restrict__ next_ids,
+                                     int32_t* __restrict__ hist_ids,
+                                     float* __restrict__ hist_scores) {
+  __shared__ float s_v[16];
+  __shared__ int s_i[16];
+  __shared__ float scratch[16];
+  __shared__ float cand_v[kMaxSampleTopK];
+  __shared__ int cand_i[kMaxSampleTopK];
+  const int64_t row = blockIdx.x;
+  const int64_t rows = gridDim.x;
+  const int step = *step_ptr;
+  const int masked = (step < min_length) ? disable_id : -1;
+  const float* x = logits + row * vocab;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = (blockDim.x + 63) >> 6;
+
+  // log-softmax constant of the original distribution (only needed for the returned score)
+  float lse_c = 0.f;
+  if (with_scores) {
+    float m = -FLT_MAX;
+    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
+      m = fmaxf(m, (j == masked) ? -FLT_MAX : x[j]);
+    m = block_max(m, scratch);
+    float s = 0.f;
+    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
+      s += expf(((j == masked) ? -FLT_MAX : x[j]) - m);
+    s = block_sum(s, scratch);
+    lse_c = -m - logf(s);
+  }
+
+  // top-k by repeated arg-max: pass p selects the best element ranked after the previous pick
+  float last_v = FLT_MAX;
+  int last_i = -1;
+  for (int pass = 0; pass < topk; ++pass) {
+    ValIdx best;
+    best.v = -FLT_MAX;
+    best.i = INT_MAX;
+    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
+      const float v = (j == masked) ? -FLT_MAX : x[j];
+      const bool after = (v < last_v) || (v == last_v && static_cast<int>(j) > last_i);
+      if (!after) continue;
+      ValIdx c;
+      c.v = v;
+      c.i = static_cast<int>(j);
+      best = better(best, c);
+    }
+    best = wave_argmax(best);
+    if (lane == 0) {
+      s_v[wave] = best.v;
+      s_i[wave] = best.i;
+    }
+    __syncthreads();
+    ValIdx r;
+    r.v = s_v[0];
+    r.i = s_i[0];
+    for (int w = 1; w < nwaves; ++w) {
+      ValIdx c;
+      c.v = s_v[w];
+      c.i = s_i[w];
+      r = better(r, c);
+    }
+    if (threadIdx.x == 0) {
+      cand_v[pass] = r.v;
+      cand_i[pass] = r.i;
+    }
+    last_v = r.v;
+    last_i = r.i;
+    __syncthreads();
+  }
+
+  if (threadIdx.x == 0) {
+    // candidates are sorted by value, descending: cand_v[0] is the maximum
+    const float inv_t = 1.f / temperature;
+    float probs[kMaxSampleTopK];
+    float total = 0.f;
+    for (int c = 0; c < topk; ++c) {
+      probs[c] = (cand_i[c] == INT_MAX) ? 0.f : expf((cand_v[c] - cand_v[0]) * inv_t);
+      total += probs[c];
+    }
+    int kept = topk;
+    float kept_total = total;
+    if (topp < 1.f) {  // TopPMask over the (temperature-scaled) softmax of the candidates
+      float mass = 0.f;
+      kept = 0;
+      kept_total = 0.f;
+      for (int c = 0; c < topk; ++c) {
+        if (!(mass < topp)) break;
+        mass += probs[c] / total;
+        kept_total += probs[c];
+        ++kept;
+      }
+    }
+    const float u = uniform01(seed, static_cast<uint32_t>(step), static_cast<uint32_t>(row)) * kept_total;
+    int pick = kept - 1;
+    float acc = 0.f;
+    for (int c = 0; c < kept; ++c) {
+      acc += probs[c];
+      if (u < acc) {
+        pick = c;
+        break;
+      }
+    }
+    const int id = cand_i[pick];
+    next_ids[row] = id;
+    hist_ids[static_cast<int64_t>(step) * rows + row] = id;
+    hist_scores[static_cast<int64_t>(step) * rows + row] = with_scores ? cand_v[pick] + lse_c : 0.f;
+  }
+}
+
+void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int32_t disable_id,
+                          int32_t min_length, bool with_scores, int topk, float topp,
+                          float temperature, uint32_t seed, const int32_t* step_ptr,
+                          int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
+                          hipStream_t stream) {
+  if (rows == 0) return;
+  int block = 64;
+  while (block < vocab / 4 && block < 1024) block <<= 1;
+  hipLaunchKernelGGL(random_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
+                     disable_id, min_length, with_scores, topk, topp, temperature, seed, step_ptr,
+                     next_ids, hist_ids, hist_scores);
+}
+
+int max_sampling_topk() { return kMaxSampleTopK; }
+
 __global__ void advance_step_kernel(int32_t* step_ptr) { *step_ptr = *step_ptr + 1; }
 
 void launch_advance_step(int32_t* step_ptr, hipStream_t stream) {

@@ -1,4 +1,5 @@
 #include "decoding.h"
+#include "kernels.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -21,6 +22,18 @@ void validate_decoding_options(const DecodingOptions& o) {
     throw std::invalid_argument("The minimum decoding length is greater than "
                                 "the maximum decoding length");
   if (o.max_length <= 0) throw std::invalid_argument("The maximum decoding length must be > 0");
+  if (o.sampling_topk != 1) {
+    if (o.beam_size != 1)
+      throw std::invalid_argument("Random sampling (sampling_topk != 1) requires beam_size 1");
+    if (o.sampling_topk < 1 || o.sampling_topk > max_sampling_topk())
+      throw std::invalid_argument("sampling_topk must be between 1 and " +
+                                  std::to_string(max_sampling_topk()) + " in this backend (sampling "
+                                  "from the full vocabulary, sampling_topk = 0, is not built)");
+  }
+  if (!(o.sampling_topp > 0.f && o.sampling_topp <= 1.f))
+    throw std::invalid_argument("sampling_topp must be in (0, 1]");
+  if (!(o.sampling_temperature > 0.f))
+    throw std::invalid_argument("sampling_temperature must be > 0");
 }
 
 float finalize_score(float score, float length, float length_penalty) {
@@ -72,6 +85,10 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
   st.g_eos = end_id;
   st.g_min_length = opt.start_step + opt.min_length;  // device step counts from start_step
   st.g_scores = opt.return_scores;
+  st.g_topk = opt.sampling_topk;
+  st.g_topp = opt.sampling_topp;
+  st.g_temperature = opt.sampling_temperature;
+  st.g_seed = opt.seed;
 
   const int64_t max_step = opt.max_length;
   const int64_t sync_every = std::max<int32_t>(1, opt.sync_every);

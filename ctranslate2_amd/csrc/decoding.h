@@ -28,6 +28,11 @@ struct DecodingOptions {
   bool use_graph = true;
   int32_t sync_every = 8;
   int32_t start_step = 0;
+  // RandomSampler (src/sampling.cc:41-101), greedy search only: sampling_topk == 1 is arg-max.
+  int32_t sampling_topk = 1;
+  float sampling_topp = 1.f;
+  float sampling_temperature = 1.f;
+  uint32_t seed = 0;
 };
 
 struct DecodingResult {

@@ -1460,10 +1460,19 @@ void Engine::launch_step(DecodeState& st) {
   }
 
   if (st.fuse_greedy) {
-    begin_kernel("greedy_sample");
-    launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
-                         st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores, cur_stream());
-    end_kernel();
+    if (st.g_topk == 1) {
+      begin_kernel("greedy_sample");
+      launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
+                           st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores,
+                           cur_stream());
+      end_kernel();
+    } else {
+      begin_kernel("random_sample");
+      launch_random_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
+                           st.g_scores, st.g_topk, st.g_topp, st.g_temperature, st.g_seed, st.d_step,
+                           st.d_ids, st.hist_ids, st.hist_scores, cur_stream());
+      end_kernel();
+    }
     begin_kernel("advance_step");
     launch_advance_step(st.d_step, cur_stream());
     end_kernel();

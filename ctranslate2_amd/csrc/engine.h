@@ -320,6 +320,10 @@ struct DecodeState {
   bool fuse_greedy = false;
   int32_t g_eos = -1, g_min_length = 0;
   bool g_scores = false;
+  // RandomSampler settings of the fused sampler (topk == 1: BestSampler / arg-max)
+  int32_t g_topk = 1;
+  float g_topp = 1.f, g_temperature = 1.f;
+  uint32_t g_seed = 0;
   // graph
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // one per cache parity

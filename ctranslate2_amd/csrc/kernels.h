@@ -248,6 +248,16 @@ void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int3
 // *step_ptr += 1
 void launch_advance_step(int32_t* step_ptr, hipStream_t stream);
 
+// RandomSampler (src/sampling.cc:41-101), one sample per row: top-k restriction (1 < topk <=
+// max_sampling_topk()), temperature, top-p mask, softmax, multinomial draw from a counter-based
+// hash of (seed, step, row). Same outputs as launch_greedy_sample.
+void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int32_t disable_id,
+                          int32_t min_length, bool with_scores, int topk, float topp,
+                          float temperature, uint32_t seed, const int32_t* step_ptr,
+                          int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
+                          hipStream_t stream);
+int max_sampling_topk();
+
 // Beam-search scores: y[row, :] = log_softmax(x[row, :] with x[disable_id] = -FLT_MAX while
 // step < min_length) + beam_scores[row]   (src/decoding.cc:512-556).
 void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t rows,

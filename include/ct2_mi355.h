@@ -264,7 +264,15 @@ struct ct2x_translation_options {
                                    concurrently on separate HIP streams of the SAME GPU (the
                                    reference's several replicas per device, replica_pool.h:243-260);
                                    0 = choose automatically */
-  int32_t reserved[4];
+  /* RandomSampler (src/sampling.cc:41-101; python: sampling_topk / sampling_topp /
+   * sampling_temperature), greedy search (beam_size 1) only. sampling_topk: 1 = arg-max
+   * (BestSampler), 2..64 = sample among the best k; sampling_topp < 1 keeps the smallest
+   * prefix of those whose mass reaches it; seed drives a counter-based generator
+   * (seed, step, row) -> reproducible for a seed. */
+  int32_t sampling_topk;
+  float sampling_topp;
+  float sampling_temperature;
+  uint32_t seed;
 };
 
 void ct2x_translation_options_default(struct ct2x_translation_options* opt);

@@ -255,3 +255,49 @@ def test_full_size_properties(gpu):
     perm = list(reversed(range(32)))
     p, _ = t.translate_ids([src[i] for i in perm], use_graph=True, **kw)
     assert [p[perm.index(i)] for i in range(32)] == a
+
+
+def test_random_sampling(gpu):
+    """RandomSampler (src/sampling.cc:41-101) on the device: sampling_topk = 1 is the arg-max path;
+    a draw is reproducible for a seed, independent of batch composition and of hipGraph replay;
+    every sampled token is one of the k best of its step; with a flat temperature the empirical
+    distribution over the k candidates of the first step matches softmax(logits / T)."""
+    t = get_translator(gpu, "small", "int8")
+    cfg = GC.SYNTHETIC["small"]
+    rng = np.random.default_rng(5)
+    src = [rng.integers(4, cfg["model"]["vocab_size"], 12).tolist() for _ in range(6)]
+    kw = dict(beam_size=1, max_decoding_length=10, min_decoding_length=10, return_scores=True)
+    greedy, gs = t.translate_ids(src, **kw)
+    same, ss = t.translate_ids(src, sampling_topk=1, seed=123, **kw)
+    assert same == greedy and np.array_equal(ss, gs)
+    a, sa = t.translate_ids(src, sampling_topk=8, sampling_temperature=1.5, seed=7, **kw)
+    b, sb = t.translate_ids(src, sampling_topk=8, sampling_temperature=1.5, seed=7, use_graph=False, **kw)
+    assert a == b and np.allclose(sa, sb)
+    # rows are keyed by their index in the batch: the same sentence in another row draws differently,
+    # the same (row, seed) draws the same
+    c0, _ = t.translate_ids([src[0]], sampling_topk=8, sampling_temperature=1.5, seed=7, **kw)
+    assert c0[0] == a[0]
+    d, _ = t.translate_ids(src, sampling_topk=8, sampling_temperature=1.5, seed=8, **kw)
+    assert d != a
+    assert np.all(sa <= 0)
+
+    # first-step distribution: teacher-forced logits of step 0 vs the empirical frequencies
+    one = [src[0]]
+    bos = np.array([[t.bos_id]], np.int32)
+    logits = t.step_logits(one, bos)[0, 0]  # synthetic models add no source BOS/EOS
+    k, temp, n = 4, 2.0, 400
+    top = np.argsort(-logits, kind="stable")[:k]
+    prob = np.exp((logits[top] - logits[top[0]]) / temp)
+    prob /= prob.sum()
+    counts = np.zeros(k)
+    for seed in range(n):
+        h, _ = t.translate_ids(one, beam_size=1, max_decoding_length=1, min_decoding_length=0,
+                               sampling_topk=k, sampling_temperature=temp, seed=seed)
+        tok = h[0][0][0] if h[0][0] else t.eos_id
+        assert tok in top
+        counts[list(top).index(tok)] += 1
+    chi2 = float(((counts - n * prob) ** 2 / (n * prob)).sum())
+    assert chi2 < 20.0, (counts, n * prob)   # 3 degrees of freedom: p(chi2 > 20) < 2e-4
+
+    with pytest.raises(Exception, match="beam_size 1"):
+        t.translate_ids(src, beam_size=2, sampling_topk=4)
