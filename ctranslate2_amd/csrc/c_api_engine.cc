@@ -497,31 +497,40 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   CT2X_CHECK(dopt.beam_size == 1, "generate_batch: beam search over a prefilled prompt is not "
              "supported by this backend yet (greedy only)");
   CT2X_CHECK(batch > 0, "No decoder start tokens are set");
-  const int32_t plen = prompt_lengths[0];
-  CT2X_CHECK(plen >= 1, "generate_batch: empty prompt");
-  for (int32_t b = 1; b < batch; ++b)
-    CT2X_CHECK(prompt_lengths[b] == plen, "generate_batch: prompts of different lengths are not "
-               "supported by this backend yet");
-  const int32_t forward_length = plen - 1;
+  // Prompts of different lengths: the shortest prompt minus one token is consumed by the
+  // sequence-mode pass for every row; the remaining tokens of a row are its start token and a
+  // hard decoding prefix (language_model.cc:218-238 -> decode(..., prefix_ids)).
+  int32_t min_len_prompt = prompt_lengths[0], max_len_prompt = prompt_lengths[0];
+  for (int32_t b = 0; b < batch; ++b) {
+    CT2X_CHECK(prompt_lengths[b] >= 1, "generate_batch: empty prompt");
+    min_len_prompt = std::min(min_len_prompt, prompt_lengths[b]);
+    max_len_prompt = std::max(max_len_prompt, prompt_lengths[b]);
+  }
+  const int32_t forward_length = min_len_prompt - 1;
+  const int32_t longest_prefix = max_len_prompt - min_len_prompt;
   const double t0 = now_ms();
   t->last = ct2x_exec_stats{};
-  const int64_t t_max = static_cast<int64_t>(forward_length) + dopt.max_length + 1;
+  const int64_t t_max = static_cast<int64_t>(forward_length) + longest_prefix + dopt.max_length + 1;
   auto st = t->engine->start_decoder_only(batch, 1, t_max, forward_length);
-  std::vector<int32_t> prefix(static_cast<size_t>(batch) * std::max(forward_length, 1));
+  std::vector<int32_t> prefill_ids(static_cast<size_t>(batch) * std::max(forward_length, 1));
   std::vector<int32_t> start_ids(batch);
+  std::vector<std::vector<int32_t>> prefix(batch);
   for (int32_t b = 0; b < batch; ++b) {
+    const int32_t* row = prompt_ids + static_cast<int64_t>(b) * stride;
     for (int32_t i = 0; i < forward_length; ++i)
-      prefix[static_cast<size_t>(b) * forward_length + i] = prompt_ids[static_cast<int64_t>(b) * stride + i];
-    start_ids[b] = prompt_ids[static_cast<int64_t>(b) * stride + plen - 1];
+      prefill_ids[static_cast<size_t>(b) * forward_length + i] = row[i];
+    start_ids[b] = row[forward_length];
+    prefix[b].assign(row + forward_length + 1, row + prompt_lengths[b]);
   }
   const double te0 = now_ms();
-  if (forward_length > 0) t->engine->prefill(*st, prefix.data(), forward_length);
+  if (forward_length > 0) t->engine->prefill(*st, prefill_ids.data(), forward_length);
   t->engine->synchronize();
   const double te1 = now_ms();
   dopt.start_step = forward_length;
   DecodeStats ds;
   std::vector<DecodingResult> results =
-      greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds);
+      greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds,
+                    longest_prefix > 0 ? &prefix : nullptr);
   t->engine->synchronize();
   const double te2 = now_ms();
   const int32_t max_len = opt.max_decoding_length;

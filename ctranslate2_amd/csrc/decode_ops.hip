@@ -10,9 +10,35 @@
 
 namespace ct2x {
 
+// Hard prefix (update_sample_with_prefix, src/decoding.cc:21-62, greedy arm): while the step,
+// counted from prefix.first_step, is inside a row's prefix the sampled id is replaced by the prefix
+// token and its score by 0; EOS stays disabled for prefix_len + min_length steps
+// (apply_min_length, src/decoding.cc:384-408).
+struct SamplePrefix {
+  const int32_t* ids;   // [rows, stride] or nullptr
+  const int32_t* lens;  // [rows]
+  int32_t stride;
+  int32_t first_step;
+};
+
+__device__ __forceinline__ bool forced_by_prefix(const SamplePrefix& pf, int64_t row, int64_t rows,
+                                                 int step, int32_t* next_ids, int32_t* hist_ids,
+                                                 float* hist_scores) {
+  if (pf.ids == nullptr) return false;
+  const int local = step - pf.first_step;
+  if (local < 0 || local >= pf.lens[row]) return false;
+  if (threadIdx.x == 0) {
+    const int32_t id = pf.ids[row * pf.stride + local];
+    next_ids[row] = id;
+    hist_ids[static_cast<int64_t>(step) * rows + row] = id;
+    hist_scores[static_cast<int64_t>(step) * rows + row] = 0.f;
+  }
+  return true;
+}
+
 __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t vocab,
                                      int32_t disable_id, int32_t min_length, bool with_scores,
-                                     const int32_t* __restrict__ step_ptr,
+                                     SamplePrefix pf, const int32_t* __restrict__ step_ptr,
                                      int32_t* __restrict__ next_ids,
                                      int32_t* __restrict__ hist_ids,
                                      float* __restrict__ hist_scores) {
@@ -24,7 +50,9 @@ __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t v
   const int64_t row = blockIdx.x;
   const int64_t rows = gridDim.x;
   const int step = *step_ptr;
-  const int masked = (step < min_length) ? disable_id : -1;
+  if (forced_by_prefix(pf, row, rows, step, next_ids, hist_ids, hist_scores)) return;
+  const int row_min = min_length + (pf.ids ? pf.lens[row] : 0);
+  const int masked = (step < row_min) ? disable_id : -1;
   const float* x = logits + row * vocab;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = (blockDim.x + 63) >> 6;
@@ -111,12 +139,14 @@ __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t v
 void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int32_t disable_id,
                           int32_t min_length, bool with_scores, const int32_t* step_ptr,
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
-                          hipStream_t stream) {
+                          hipStream_t stream, const int32_t* prefix_ids, const int32_t* prefix_lens,
+                          int32_t prefix_stride, int32_t prefix_first_step) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
+  const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step};
   hipLaunchKernelGGL(greedy_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
-                     disable_id, min_length, with_scores, step_ptr, next_ids, hist_ids,
+                     disable_id, min_length, with_scores, pf, step_ptr, next_ids, hist_ids,
                      hist_scores);
 }
 
@@ -145,7 +175,7 @@ __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_
 __global__ void random_sample_kernel(const float* __restrict__ logits, int64_t vocab,
                                      int32_t disable_id, int32_t min_length, bool with_scores,
                                      int topk, float topp, float temperature, uint32_t seed,
-                                     const int32_t* __restrict__ step_ptr,
+                                     SamplePrefix pf, const int32_t* __restrict__ step_ptr,
                                      int32_t* __restrict__ next_ids,
                                      int32_t* __restrict__ hist_ids,
                                      float* __restrict__ hist_scores) {
@@ -157,7 +187,9 @@ __global__ void random_sample_kernel(const float* __restrict__ logits, int64_t v
   const int64_t row = blockIdx.x;
   const int64_t rows = gridDim.x;
   const int step = *step_ptr;
-  const int masked = (step < min_length) ? disable_id : -1;
+  if (forced_by_prefix(pf, row, rows, step, next_ids, hist_ids, hist_scores)) return;
+  const int row_min = min_length + (pf.ids ? pf.lens[row] : 0);
+  const int masked = (step < row_min) ? disable_id : -1;
   const float* x = logits + row * vocab;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = (blockDim.x + 63) >> 6;
@@ -259,12 +291,14 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           int32_t min_length, bool with_scores, int topk, float topp,
                           float temperature, uint32_t seed, const int32_t* step_ptr,
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
-                          hipStream_t stream) {
+                          hipStream_t stream, const int32_t* prefix_ids, const int32_t* prefix_lens,
+                          int32_t prefix_stride, int32_t prefix_first_step) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
+  const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step};
   hipLaunchKernelGGL(random_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
-                     disable_id, min_length, with_scores, topk, topp, temperature, seed, step_ptr,
+                     disable_id, min_length, with_scores, topk, topp, temperature, seed, pf, step_ptr,
                      next_ids, hist_ids, hist_scores);
 }
 

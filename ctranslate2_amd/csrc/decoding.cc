@@ -70,7 +70,8 @@ void finalize(DecodingResult& r, size_t max_hypotheses, float length_penalty, bo
 // GreedySearch::search (src/decoding.cc:733-974), num_hypotheses == 1, no prefix.
 std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
                                           const std::vector<int32_t>& start_ids, int32_t end_id,
-                                          const DecodingOptions& opt, DecodeStats* stats) {
+                                          const DecodingOptions& opt, DecodeStats* stats,
+                                          const std::vector<std::vector<int32_t>>* prefix_ids) {
   const int64_t batch = static_cast<int64_t>(start_ids.size());
   if (batch != st.rows) throw std::runtime_error("greedy_search: state/batch size mismatch");
   std::vector<DecodingResult> results(batch);
@@ -89,8 +90,21 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
   st.g_topp = opt.sampling_topp;
   st.g_temperature = opt.sampling_temperature;
   st.g_seed = opt.seed;
+  // Hard prefix: forced on the device by the fused sampler; the host only has to know how many
+  // leading steps of each row to skip (get_max_step / is_last_step, src/decoding.cc:357-382).
+  std::vector<int64_t> prefix_len(batch, 0);
+  int64_t longest_prefix = 0;
+  if (prefix_ids) {
+    for (int64_t i = 0; i < batch; ++i) {
+      prefix_len[i] = static_cast<int64_t>((*prefix_ids)[i].size());
+      longest_prefix = std::max(longest_prefix, prefix_len[i]);
+    }
+    engine.set_prefix(st, *prefix_ids, opt.start_step);
+  } else {
+    engine.set_prefix(st, {}, opt.start_step);
+  }
 
-  const int64_t max_step = opt.max_length;
+  const int64_t max_step = opt.max_length + longest_prefix;
   const int64_t sync_every = std::max<int32_t>(1, opt.sync_every);
   int64_t launched = 0;   // steps enqueued on the device
   int64_t examined = 0;   // steps whose ids the host has looked at
@@ -123,13 +137,16 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
     engine.wait_history(st, g.slot, &h_ids, &h_scores);
     for (int64_t s = 0; s < g.count && count_alive > 0; ++s) {
       const int64_t step = g.first + s;
-      const bool last = (step + 1 == max_step);  // is_last_step (src/decoding.cc:368-373)
       for (int64_t i = 0; i < batch; ++i) {
         if (!alive[i]) continue;
+        // is_last_step (src/decoding.cc:376-382): max_length steps after the row's own prefix
+        const bool last = (step + 1 == opt.max_length + prefix_len[i]);
         const int32_t word = h_ids[s * batch + i];
-        const bool eos = (word == end_id);
-        if (!eos || opt.include_eos_in_hypotheses) results[i].hypotheses[0].push_back(word);
-        if (opt.return_scores) score_sum[i] += h_scores[s * batch + i];
+        const bool in_prefix = step < prefix_len[i];
+        const bool eos = (word == end_id) && !in_prefix;
+        if (!in_prefix && (!eos || opt.include_eos_in_hypotheses))
+          results[i].hypotheses[0].push_back(word);
+        if (opt.return_scores) score_sum[i] += h_scores[s * batch + i];  // forced steps add 0
         if (eos || last) {
           alive[i] = 0;
           --count_alive;

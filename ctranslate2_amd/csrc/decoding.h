@@ -46,9 +46,14 @@ struct DecodeStats {
 
 void validate_decoding_options(const DecodingOptions& options);
 
+// prefix_ids (optional, one entry per row): tokens forced at the first steps of a row (hard
+// prefix of decode(), src/decoding.cc:21-62 / 842-925 with return_prefix = false): they are not
+// part of the returned hypothesis, contribute 0 to its score, and a row may use max_length steps
+// AFTER its prefix.
 std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& state,
                                           const std::vector<int32_t>& start_ids, int32_t end_id,
-                                          const DecodingOptions& options, DecodeStats* stats);
+                                          const DecodingOptions& options, DecodeStats* stats,
+                                          const std::vector<std::vector<int32_t>>* prefix_ids = nullptr);
 
 std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& state,
                                         const std::vector<int32_t>& start_ids, int32_t end_id,

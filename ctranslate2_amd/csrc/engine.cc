@@ -1464,13 +1464,15 @@ void Engine::launch_step(DecodeState& st) {
       begin_kernel("greedy_sample");
       launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
                            st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores,
-                           cur_stream());
+                           cur_stream(), st.d_prefix, st.d_prefix_len, st.prefix_stride,
+                           st.prefix_first_step);
       end_kernel();
     } else {
       begin_kernel("random_sample");
       launch_random_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
                            st.g_scores, st.g_topk, st.g_topp, st.g_temperature, st.g_seed, st.d_step,
-                           st.d_ids, st.hist_ids, st.hist_scores, cur_stream());
+                           st.d_ids, st.hist_ids, st.hist_scores, cur_stream(), st.d_prefix,
+                           st.d_prefix_len, st.prefix_stride, st.prefix_first_step);
       end_kernel();
     }
     begin_kernel("advance_step");
@@ -1627,6 +1629,36 @@ void Engine::set_ids(DecodeState& st, const int32_t* h_ids) {
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_ids, h_ids, sizeof(int32_t) * st.rows,
                                 hipMemcpyHostToDevice, cur_stream()));
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // h_ids may be a temporary
+}
+
+void Engine::set_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>& prefix,
+                        int32_t first_step) {
+  tls_stream = st.stream;
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  size_t longest = 0;
+  for (const auto& p : prefix) longest = std::max(longest, p.size());
+  st.d_prefix = nullptr;
+  st.d_prefix_len = nullptr;
+  st.prefix_stride = 0;
+  st.prefix_first_step = first_step;
+  if (longest == 0) return;
+  CT2X_CHECK(static_cast<int64_t>(prefix.size()) == st.rows, "set_prefix: one prefix per row");
+  std::vector<int32_t> ids(static_cast<size_t>(st.rows) * longest, 0), lens(st.rows, 0);
+  for (int64_t r = 0; r < st.rows; ++r) {
+    lens[r] = static_cast<int32_t>(prefix[r].size());
+    std::copy(prefix[r].begin(), prefix[r].end(), ids.begin() + r * longest);
+  }
+  auto upload_i32 = [&](const std::vector<int32_t>& v) {
+    void* p = device_malloc(v.size() * sizeof(int32_t));
+    st.owned.push_back(p);
+    CT2X_HIP_CHECK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                                  cur_stream()));
+    return static_cast<int32_t*>(p);
+  };
+  st.d_prefix = upload_i32(ids);
+  st.d_prefix_len = upload_i32(lens);
+  st.prefix_stride = static_cast<int32_t>(longest);
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // the host vectors go out of scope
 }
 
 void Engine::set_step(DecodeState& st, int32_t step) {

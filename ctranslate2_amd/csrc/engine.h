@@ -176,6 +176,9 @@ public:
   void wait_history(DecodeState& state, int slot, const int32_t** h_ids, const float** h_scores);
   void copy_logits_to_host(DecodeState& state, float* h_logits);
   void set_ids(DecodeState& state, const int32_t* h_ids);
+  // Installs per-row forced tokens for the steps first_step, first_step + 1, ... (empty = none).
+  void set_prefix(DecodeState& state, const std::vector<std::vector<int32_t>>& prefix,
+                  int32_t first_step);
   void set_step(DecodeState& state, int32_t step);
   void synchronize();
 
@@ -320,6 +323,10 @@ struct DecodeState {
   bool fuse_greedy = false;
   int32_t g_eos = -1, g_min_length = 0;
   bool g_scores = false;
+  // Hard decoding prefix of the fused sampler (ragged prompts): ids [rows, prefix_stride], lengths
+  int32_t* d_prefix = nullptr;
+  int32_t* d_prefix_len = nullptr;
+  int32_t prefix_stride = 0, prefix_first_step = 0;
   // RandomSampler settings of the fused sampler (topk == 1: BestSampler / arg-max)
   int32_t g_topk = 1;
   float g_topp = 1.f, g_temperature = 1.f;

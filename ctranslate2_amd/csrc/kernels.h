@@ -243,7 +243,9 @@ namespace ct2x {
 void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int32_t disable_id,
                           int32_t min_length, bool with_scores, const int32_t* step_ptr,
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
-                          hipStream_t stream);
+                          hipStream_t stream, const int32_t* prefix_ids = nullptr,
+                          const int32_t* prefix_lens = nullptr, int32_t prefix_stride = 0,
+                          int32_t prefix_first_step = 0);
 
 // *step_ptr += 1
 void launch_advance_step(int32_t* step_ptr, hipStream_t stream);
@@ -255,7 +257,9 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           int32_t min_length, bool with_scores, int topk, float topp,
                           float temperature, uint32_t seed, const int32_t* step_ptr,
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
-                          hipStream_t stream);
+                          hipStream_t stream, const int32_t* prefix_ids = nullptr,
+                          const int32_t* prefix_lens = nullptr, int32_t prefix_stride = 0,
+                          int32_t prefix_first_step = 0);
 int max_sampling_topk();
 
 // Beam-search scores: y[row, :] = log_softmax(x[row, :] with x[disable_id] = -FLT_MAX while
