@@ -206,7 +206,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                      min_length: int = 0, return_scores: bool = False,
                      return_end_token: bool = False, use_graph: bool = True,
                      sampling_topk: int = 1, sampling_topp: float = 1.0,
-                     sampling_temperature: float = 1.0, seed: int = 0):
+                     sampling_temperature: float = 1.0, seed: int = 0, beam_size: int = 1,
+                     length_penalty: float = 1.0):
         """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False.
         sampling_topk=1 is greedy; 2..64 samples among the best k (sampling_topp / temperature as
         in the reference). Returns (generated ids per prompt, scores)."""
@@ -219,10 +220,9 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         out = np.zeros((batch, max_length), np.int32)
         out_len = np.zeros((batch,), np.int32)
         scores = np.zeros((batch,), np.float32)
-        opt = self._options(1, max_length, min_length, 1, return_scores, return_end_token, 0, 0,
-                            1.0, 1.0, use_graph, 1, sampling_topk, sampling_topp,
+        opt = self._options(beam_size, max_length, min_length, 1, return_scores, return_end_token,
+                            0, 0, length_penalty, 1.0, use_graph, 1, sampling_topk, sampling_topp,
                             sampling_temperature, seed)
-        opt.length_penalty = 1.0
         _lib.check(self._L.ct2x_generate_batch(
             C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
             C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))

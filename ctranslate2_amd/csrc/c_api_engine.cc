@@ -494,9 +494,8 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   ct2x_translation_options opt = *opt_in;
   DecodingOptions dopt = to_decoding_options(opt);
   validate_decoding_options(dopt);
-  CT2X_CHECK(dopt.beam_size == 1, "generate_batch: beam search over a prefilled prompt is not "
-             "supported by this backend yet (greedy only)");
   CT2X_CHECK(batch > 0, "No decoder start tokens are set");
+  const int32_t beam = dopt.beam_size;
   // Prompts of different lengths: the shortest prompt minus one token is consumed by the
   // sequence-mode pass for every row; the remaining tokens of a row are its start token and a
   // hard decoding prefix (language_model.cc:218-238 -> decode(..., prefix_ids)).
@@ -510,15 +509,21 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   const int32_t longest_prefix = max_len_prompt - min_len_prompt;
   const double t0 = now_ms();
   t->last = ct2x_exec_stats{};
+  CT2X_CHECK(beam == 1 || longest_prefix == 0, "generate_batch: beam search needs prompts of one "
+             "length in this backend (a hard prefix is only forced by the greedy sampler)");
   const int64_t t_max = static_cast<int64_t>(forward_length) + longest_prefix + dopt.max_length + 1;
-  auto st = t->engine->start_decoder_only(batch, 1, t_max, forward_length);
-  std::vector<int32_t> prefill_ids(static_cast<size_t>(batch) * std::max(forward_length, 1));
+  // Beam search: every hypothesis row starts from the same prefilled prompt state; the prompt is
+  // forwarded once per row (beam x the prefill work instead of a cache replication pass).
+  auto st = t->engine->start_decoder_only(batch, beam, t_max, forward_length);
+  const int64_t rows = static_cast<int64_t>(batch) * beam;
+  std::vector<int32_t> prefill_ids(static_cast<size_t>(rows) * std::max(forward_length, 1));
   std::vector<int32_t> start_ids(batch);
   std::vector<std::vector<int32_t>> prefix(batch);
   for (int32_t b = 0; b < batch; ++b) {
     const int32_t* row = prompt_ids + static_cast<int64_t>(b) * stride;
-    for (int32_t i = 0; i < forward_length; ++i)
-      prefill_ids[static_cast<size_t>(b) * forward_length + i] = row[i];
+    for (int32_t k = 0; k < beam; ++k)
+      for (int32_t i = 0; i < forward_length; ++i)
+        prefill_ids[(static_cast<size_t>(b) * beam + k) * forward_length + i] = row[i];
     start_ids[b] = row[forward_length];
     prefix[b].assign(row + forward_length + 1, row + prompt_lengths[b]);
   }
@@ -529,8 +534,9 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   dopt.start_step = forward_length;
   DecodeStats ds;
   std::vector<DecodingResult> results =
-      greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds,
-                    longest_prefix > 0 ? &prefix : nullptr);
+      beam > 1 ? beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds)
+               : greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds,
+                               longest_prefix > 0 ? &prefix : nullptr);
   t->engine->synchronize();
   const double te2 = now_ms();
   const int32_t max_len = opt.max_decoding_length;

@@ -928,7 +928,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     qkv_dim = std::max(qkv_dim, l.self.lin[0].n);
   }
   // Workspace sized for the larger of the decode rows and the encoder rows.
-  const int64_t enc_rows = has_encoder_ ? batch * s_max : batch * pending_prefill_len_;
+  // (a beam-search prefill forwards the prompt once per hypothesis row)
+  const int64_t enc_rows = has_encoder_ ? batch * s_max : rows * pending_prefill_len_;
   st->prefill_max = pending_prefill_len_;
   int64_t enc_ffn = 0, enc_qkv = 0;
   for (const auto& l : enc_.layers) {
@@ -1193,7 +1194,7 @@ void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time) {
   CT2X_HIP_CHECK(hipSetDevice(device_));
   tls_stream = st.stream;
   CT2X_CHECK(!has_encoder_, "prefill is only defined for decoder-only models");
-  CT2X_CHECK(st.beam == 1, "prefill expects an unexpanded batch");
+  // (with beam > 1 the caller passes the prompt of a sentence once per hypothesis row)
   CT2X_CHECK(time <= st.t_max && time <= st.prefill_max, "prompt longer than the decoding state");
   if (time == 0) return;
   const int64_t B = st.rows, d = dec_.d_model, rows = B * time;

@@ -33,6 +33,8 @@ def main():
         rng = np.random.default_rng(cfg["data_seed"] + 100)
         vocab = cfg["model"]["vocab_size"]
         prompts = [rng.integers(4, vocab, n).tolist() for n in LENGTHS[key]]
+        rng_eq = np.random.default_rng(cfg["data_seed"] + 200)
+        eq_prompts = None
         for ct, suffix in (("float32", "_f32"), ("int8", "")):
             m = R.RefModel(path, ct, 1, 4)
             runs = {}
@@ -40,8 +42,16 @@ def main():
                 gen, scores = m.generate_ids(prompts, max_len=cfg["max_len"], min_len=min_len,
                                              return_scores=True)
                 runs[name] = {"min_len": min_len, "generated": gen, "scores": scores.tolist()}
+            # beam search over equal-length prompts (Generator beam_size = 4, length_penalty = 1,
+            # GenerationOptions defaults, include/ctranslate2/generation.h)
+            eq_prompts = [rng_eq.integers(4, vocab, cfg["prompt_len"]).tolist() for _ in range(cfg["batch"])] \
+                if suffix == "_f32" else eq_prompts
+            gen, scores = m.generate_ids(eq_prompts, beam_size=4, max_len=cfg["max_len"],
+                                         min_len=cfg["max_len"] // 2, return_scores=True)
             out[key + suffix] = {"prompts": prompts, "max_len": cfg["max_len"], "runs": runs,
-                                 "compute_type": m.compute_type()}
+                                 "compute_type": m.compute_type(),
+                                 "beam4": {"prompts": eq_prompts, "min_len": cfg["max_len"] // 2,
+                                           "generated": gen, "scores": scores.tolist()}}
             m.close()
     with open(os.path.join(HERE, "ragged_golden.json"), "w") as f:
         json.dump(out, f)

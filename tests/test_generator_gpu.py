@@ -141,3 +141,26 @@ def test_ragged_equals_padded_free_run(gpu):
     both, _ = t.generate_ids([long_p, short_p], **kw)
     assert both[0] == alone_long[0]
     assert both[1] == alone_short[0]
+
+
+@pytest.mark.parametrize("key", ["lm_tiny", "lm_small"])
+@pytest.mark.parametrize("ct", ["float32", "int8"])
+def test_generator_beam_search_matches_reference(gpu, key, ct):
+    """Generator::generate_batch with beam_size 4 (BeamSearch::search over the prefilled prompt
+    state) against the real reference (tests/golden/make_golden_ragged.py)."""
+    with open(os.path.join(HERE, "golden", "ragged_golden.json")) as f:
+        g = json.load(f)[key + ("_f32" if ct == "float32" else "")]
+    b = g["beam4"]
+    t = get_lm(key, ct)
+    gen, scores = t.generate_ids(b["prompts"], max_length=g["max_len"], min_length=b["min_len"],
+                                 return_scores=True, beam_size=4)
+    ref = b["generated"]
+    same = [x == y for x, y in zip(gen, ref)]
+    print("%s %s beam 4: %d/%d token-identical" % (key, ct, sum(same), len(same)))
+    if ct == "float32":
+        assert all(same)
+        np.testing.assert_allclose(scores, np.array(b["scores"], np.float32), atol=1e-3)
+    else:
+        assert sum(same) >= len(same) - 2
+        ok = np.array(same)
+        np.testing.assert_allclose(scores[ok], np.array(b["scores"], np.float32)[ok], atol=2e-2)
