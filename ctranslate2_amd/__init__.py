@@ -163,7 +163,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                       max_input_length: int = 1024, length_penalty: float = 1.0,
                       patience: float = 1.0, use_graph: bool = True, num_streams: int = 0,
                       sampling_topk: int = 1, sampling_topp: float = 1.0,
-                      sampling_temperature: float = 1.0, seed: int = 0):
+                      sampling_temperature: float = 1.0, seed: int = 0,
+                      target_prefix_ids: Optional[Sequence[Sequence[int]]] = None):
         """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores).
         sampling_* (reference names, python/cpp/translator.cc): random sampling among the best
         sampling_topk candidates (beam_size must be 1), reproducible for a `seed`."""
@@ -180,9 +181,20 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                             return_scores, return_end_token, max_batch_size, max_input_length,
                             length_penalty, patience, use_graph, num_streams, sampling_topk,
                             sampling_topp, sampling_temperature, seed)
-        _lib.check(self._L.ct2x_translate_batch(
-            C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
-            C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
+        if target_prefix_ids is not None:
+            plen = np.array([len(p) for p in target_prefix_ids], np.int32)
+            pstride = max(1, int(plen.max()) if batch else 1)
+            pids = np.zeros((batch, pstride), np.int32)
+            for i, pfx in enumerate(target_prefix_ids):
+                pids[i, :len(pfx)] = pfx
+            _lib.check(self._L.ct2x_translate_batch_prefix(
+                C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
+                C.c_int32(stride), _lib.ptr(pids), _lib.ptr(plen), C.c_int32(pstride), C.byref(opt),
+                _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
+        else:
+            _lib.check(self._L.ct2x_translate_batch(
+                C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
+                C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
         hyps = [[out[b, k, :out_len[b, k]].tolist() for k in range(num_hypotheses)
                  if out_len[b, k] > 0 or k == 0] for b in range(batch)]
         return hyps, scores
@@ -190,10 +202,11 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
     def translate_batch(self, source: List[List[str]], target_prefix: Optional[list] = None,
                         **kwargs) -> List[TranslationResult]:
         """ctranslate2.Translator.translate_batch on tokens (same keyword names)."""
-        if target_prefix is not None:
-            raise NotImplementedError("target_prefix is not supported by this backend yet")
         return_scores = kwargs.get("return_scores", False)
         src_ids = [[self.token_to_id(t) for t in sent] for sent in source]
+        if target_prefix is not None:
+            kwargs["target_prefix_ids"] = [[self.token_to_id(t, target=True) for t in (pfx or [])]
+                                           for pfx in target_prefix]
         hyps, scores = self.translate_ids(src_ids, **kwargs)
         results = []
         for b, sent_hyps in enumerate(hyps):

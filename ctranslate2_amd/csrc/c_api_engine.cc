@@ -322,10 +322,12 @@ int ct2x_translator_create_tp_local(const char* model_dir, int device_index,
 
 void ct2x_translator_destroy(void* translator) { delete static_cast<Translator*>(translator); }
 
-int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
-                         int32_t batch, int32_t src_stride,
-                         const struct ct2x_translation_options* opt_in, int32_t* out_ids,
-                         int32_t* out_lengths, float* out_scores) {
+static int translate_batch_impl(void* translator, const int32_t* src_ids,
+                                const int32_t* src_lengths, int32_t batch, int32_t src_stride,
+                                const int32_t* prefix_ids, const int32_t* prefix_lengths,
+                                int32_t prefix_stride,
+                                const struct ct2x_translation_options* opt_in, int32_t* out_ids,
+                                int32_t* out_lengths, float* out_scores) {
   API_TRY
   auto* t = static_cast<Translator*>(translator);
   CT2X_CHECK(t != nullptr, "null translator");
@@ -428,10 +430,28 @@ int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t
         t->engine->synchronize();
         const double te1 = now_ms();
         std::vector<int32_t> start_ids(B, t->start_id);
+        // target_prefix (make_target_ids with is_prefix, sequence_to_sequence.cc:168-186): forced
+        // after the decoder start token, part of the returned hypothesis (return_prefix).
+        std::vector<std::vector<int32_t>> prefix;
+        bool any_prefix = false;
+        if (prefix_ids != nullptr) {
+          prefix.resize(B);
+          for (int64_t i = 0; i < B; ++i) {
+            const int32_t b = order[begin + i];
+            const int32_t* p = prefix_ids + static_cast<int64_t>(b) * prefix_stride;
+            prefix[i].assign(p, p + prefix_lengths[b]);
+            for (int32_t id : prefix[i])
+              CT2X_CHECK(id >= 0 && id < static_cast<int32_t>(t->engine->vocab_size()),
+                         "Invalid target prefix token ID " + std::to_string(id));
+            any_prefix = any_prefix || !prefix[i].empty();
+          }
+        }
+        const std::vector<std::vector<int32_t>>* pf = any_prefix ? &prefix : nullptr;
         DecodeStats ds;
         std::vector<DecodingResult> results =
-            dopt.beam_size == 1 ? greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds)
-                                : beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds);
+            dopt.beam_size == 1
+                ? greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds, pf)
+                : beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds, pf);
         t->engine->synchronize();
         const double te2 = now_ms();
         int64_t tokens = 0;
@@ -477,6 +497,24 @@ int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t
   t->last.decode_ms = decode_ms;
   t->last.total_ms = now_ms() - t0;
   API_CATCH
+}
+
+int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
+                         int32_t batch, int32_t src_stride,
+                         const struct ct2x_translation_options* opt, int32_t* out_ids,
+                         int32_t* out_lengths, float* out_scores) {
+  return translate_batch_impl(translator, src_ids, src_lengths, batch, src_stride, nullptr, nullptr,
+                              0, opt, out_ids, out_lengths, out_scores);
+}
+
+int ct2x_translate_batch_prefix(void* translator, const int32_t* src_ids,
+                                const int32_t* src_lengths, int32_t batch, int32_t src_stride,
+                                const int32_t* prefix_ids, const int32_t* prefix_lengths,
+                                int32_t prefix_stride,
+                                const struct ct2x_translation_options* opt, int32_t* out_ids,
+                                int32_t* out_lengths, float* out_scores) {
+  return translate_batch_impl(translator, src_ids, src_lengths, batch, src_stride, prefix_ids,
+                              prefix_lengths, prefix_stride, opt, out_ids, out_lengths, out_scores);
 }
 
 int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
@@ -532,6 +570,7 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   t->engine->synchronize();
   const double te1 = now_ms();
   dopt.start_step = forward_length;
+  dopt.return_prefix = false;  // include_prompt_in_result = false
   DecodeStats ds;
   std::vector<DecodingResult> results =
       beam > 1 ? beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds)

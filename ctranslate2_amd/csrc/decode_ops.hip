@@ -19,6 +19,7 @@ struct SamplePrefix {
   const int32_t* lens;  // [rows]
   int32_t stride;
   int32_t first_step;
+  int32_t extends_min_length;  // return_prefix == false: EOS stays disabled prefix_len steps longer
 };
 
 __device__ __forceinline__ bool forced_by_prefix(const SamplePrefix& pf, int64_t row, int64_t rows,
@@ -51,7 +52,7 @@ __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t v
   const int64_t rows = gridDim.x;
   const int step = *step_ptr;
   if (forced_by_prefix(pf, row, rows, step, next_ids, hist_ids, hist_scores)) return;
-  const int row_min = min_length + (pf.ids ? pf.lens[row] : 0);
+  const int row_min = min_length + ((pf.ids && pf.extends_min_length) ? pf.lens[row] : 0);
   const int masked = (step < row_min) ? disable_id : -1;
   const float* x = logits + row * vocab;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -140,11 +141,12 @@ void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           int32_t min_length, bool with_scores, const int32_t* step_ptr,
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
                           hipStream_t stream, const int32_t* prefix_ids, const int32_t* prefix_lens,
-                          int32_t prefix_stride, int32_t prefix_first_step) {
+                          int32_t prefix_stride, int32_t prefix_first_step, bool prefix_extends_min) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
-  const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step};
+  const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step,
+                        prefix_extends_min ? 1 : 0};
   hipLaunchKernelGGL(greedy_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
                      disable_id, min_length, with_scores, pf, step_ptr, next_ids, hist_ids,
                      hist_scores);
@@ -188,7 +190,7 @@ __global__ void random_sample_kernel(const float* __restrict__ logits, int64_t v
   const int64_t rows = gridDim.x;
   const int step = *step_ptr;
   if (forced_by_prefix(pf, row, rows, step, next_ids, hist_ids, hist_scores)) return;
-  const int row_min = min_length + (pf.ids ? pf.lens[row] : 0);
+  const int row_min = min_length + ((pf.ids && pf.extends_min_length) ? pf.lens[row] : 0);
   const int masked = (step < row_min) ? disable_id : -1;
   const float* x = logits + row * vocab;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -292,11 +294,12 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           float temperature, uint32_t seed, const int32_t* step_ptr,
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
                           hipStream_t stream, const int32_t* prefix_ids, const int32_t* prefix_lens,
-                          int32_t prefix_stride, int32_t prefix_first_step) {
+                          int32_t prefix_stride, int32_t prefix_first_step, bool prefix_extends_min) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
-  const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step};
+  const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step,
+                        prefix_extends_min ? 1 : 0};
   hipLaunchKernelGGL(random_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
                      disable_id, min_length, with_scores, topk, topp, temperature, seed, pf, step_ptr,
                      next_ids, hist_ids, hist_scores);

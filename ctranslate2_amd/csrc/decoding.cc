@@ -99,12 +99,13 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
       prefix_len[i] = static_cast<int64_t>((*prefix_ids)[i].size());
       longest_prefix = std::max(longest_prefix, prefix_len[i]);
     }
-    engine.set_prefix(st, *prefix_ids, opt.start_step);
+    engine.set_prefix(st, *prefix_ids, opt.start_step, !opt.return_prefix);
   } else {
     engine.set_prefix(st, {}, opt.start_step);
   }
-
-  const int64_t max_step = opt.max_length + longest_prefix;
+  // return_prefix: the prefix is part of the hypothesis and counts towards max_length
+  const int64_t extra = opt.return_prefix ? 0 : 1;
+  const int64_t max_step = opt.max_length + extra * longest_prefix;
   const int64_t sync_every = std::max<int32_t>(1, opt.sync_every);
   int64_t launched = 0;   // steps enqueued on the device
   int64_t examined = 0;   // steps whose ids the host has looked at
@@ -140,11 +141,11 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
       for (int64_t i = 0; i < batch; ++i) {
         if (!alive[i]) continue;
         // is_last_step (src/decoding.cc:376-382): max_length steps after the row's own prefix
-        const bool last = (step + 1 == opt.max_length + prefix_len[i]);
+        const bool last = (step + 1 == opt.max_length + extra * prefix_len[i]);
         const int32_t word = h_ids[s * batch + i];
         const bool in_prefix = step < prefix_len[i];
         const bool eos = (word == end_id) && !in_prefix;
-        if (!in_prefix && (!eos || opt.include_eos_in_hypotheses))
+        if ((!in_prefix || opt.return_prefix) && (!eos || opt.include_eos_in_hypotheses))
           results[i].hypotheses[0].push_back(word);
         if (opt.return_scores) score_sum[i] += h_scores[s * batch + i];  // forced steps add 0
         if (eos || last) {
@@ -172,7 +173,7 @@ BeamStepOutput beam_step_select(const BeamStepInput& in) {
   for (int32_t k = 0; k < beam; ++k) {
     const int32_t last_id = in.word_ids[k];
     int32_t next_beam_id = k;
-    if (last_id == in.end_id || in.is_last_step) {
+    if ((last_id == in.end_id && in.step >= in.prefix_length) || in.is_last_step) {
       out.finished.push_back(k);
       // Move another active beam to this position (src/decoding.cc:638-646).
       for (int32_t j = secondary_candidates_offset; j < num_candidates; ++j) {
@@ -193,9 +194,12 @@ BeamStepOutput beam_step_select(const BeamStepInput& in) {
 // beams start at lowest() (:84-93).
 std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
                                         const std::vector<int32_t>& start_ids, int32_t end_id,
-                                        const DecodingOptions& opt, DecodeStats* stats) {
+                                        const DecodingOptions& opt, DecodeStats* stats,
+                                        const std::vector<std::vector<int32_t>>* prefix_ids) {
   const int64_t batch = static_cast<int64_t>(start_ids.size());
   const int32_t beam = opt.beam_size;
+  if (prefix_ids && !opt.return_prefix)
+    throw std::invalid_argument("beam search with a hidden prefix (generation) is not supported");
   const int32_t num_candidates = 2 * beam;
   const int64_t rows = batch * beam;
   if (rows != st.rows || st.beam != beam)
@@ -244,12 +248,30 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
         }
         continue;
       }
-      const float* sc = cand_scores.data() + i * num_candidates;
+      float* sc = cand_scores.data() + i * num_candidates;
       const int32_t* flat = cand_flat.data() + i * num_candidates;
       // unflatten_ids (src/decoding.cc:95-116)
       for (int32_t j = 0; j < num_candidates; ++j) {
         cand_origin[j] = static_cast<int32_t>(flat[j] / vocab);
         cand_word[j] = static_cast<int32_t>(flat[j] % vocab);
+      }
+      // update_sample_with_prefix, beam arm (src/decoding.cc:21-66): inside the prefix every
+      // candidate becomes the prefix token, only the first keeps a live score (0: the prefix does
+      // not count) and all descend from beam 0; at the first free step an EOS in a secondary
+      // candidate is neutralised.
+      const int64_t plen = prefix_ids ? static_cast<int64_t>((*prefix_ids)[i].size()) : 0;
+      if (prefix_ids && step <= plen) {
+        for (int32_t j = 0; j < num_candidates; ++j) {
+          if (step < plen) {
+            cand_word[j] = (*prefix_ids)[i][step];
+            sc[j] = (j == 0) ? 0.f : -1e10f;
+            cand_origin[j] = 0;
+          } else if (j > 0 && cand_word[j] == end_id) {
+            cand_word[j] = 0;
+            sc[j] = -1e10f;
+            cand_origin[j] = 0;
+          }
+        }
       }
       // append_step_output: every candidate inherits its origin beam's history + its word.
       std::vector<std::vector<int32_t>> cand_seq(num_candidates);
@@ -265,6 +287,7 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
       in.end_id = end_id;
       in.word_ids = cand_word.data();
       in.scores = sc;
+      in.prefix_length = static_cast<int32_t>(plen);
       const BeamStepOutput sel = beam_step_select(in);
 
       DecodingResult& result = results[i];

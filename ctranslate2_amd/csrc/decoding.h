@@ -33,6 +33,9 @@ struct DecodingOptions {
   float sampling_topp = 1.f;
   float sampling_temperature = 1.f;
   uint32_t seed = 0;
+  // DecodingOptions::return_prefix (include/ctranslate2/decoding.h): true for translation (the
+  // target prefix is part of the hypothesis and of max_length), false for generation.
+  bool return_prefix = true;
 };
 
 struct DecodingResult {
@@ -57,7 +60,8 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& state,
 
 std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& state,
                                         const std::vector<int32_t>& start_ids, int32_t end_id,
-                                        const DecodingOptions& options, DecodeStats* stats);
+                                        const DecodingOptions& options, DecodeStats* stats,
+                                        const std::vector<std::vector<int32_t>>* prefix_ids = nullptr);
 
 // Host-only pieces, exported for the CPU test-suite -------------------------------------------
 
@@ -74,6 +78,7 @@ struct BeamStepInput {
   int32_t end_id = 0;
   const int32_t* word_ids = nullptr;   // [2*beam]
   const float* scores = nullptr;       // [2*beam]
+  int32_t prefix_length = 0;           // an EOS before this step does not finish the hypothesis
 };
 struct BeamStepOutput {
   std::vector<int32_t> finished;       // candidate slots k < beam whose hypothesis finished

@@ -1466,14 +1466,15 @@ void Engine::launch_step(DecodeState& st) {
       launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
                            st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores,
                            cur_stream(), st.d_prefix, st.d_prefix_len, st.prefix_stride,
-                           st.prefix_first_step);
+                           st.prefix_first_step, st.prefix_extends_min);
       end_kernel();
     } else {
       begin_kernel("random_sample");
       launch_random_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
                            st.g_scores, st.g_topk, st.g_topp, st.g_temperature, st.g_seed, st.d_step,
                            st.d_ids, st.hist_ids, st.hist_scores, cur_stream(), st.d_prefix,
-                           st.d_prefix_len, st.prefix_stride, st.prefix_first_step);
+                           st.d_prefix_len, st.prefix_stride, st.prefix_first_step,
+                           st.prefix_extends_min);
       end_kernel();
     }
     begin_kernel("advance_step");
@@ -1633,7 +1634,8 @@ void Engine::set_ids(DecodeState& st, const int32_t* h_ids) {
 }
 
 void Engine::set_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>& prefix,
-                        int32_t first_step) {
+                        int32_t first_step, bool extends_min_length) {
+  st.prefix_extends_min = extends_min_length;
   tls_stream = st.stream;
   CT2X_HIP_CHECK(hipSetDevice(device_));
   size_t longest = 0;

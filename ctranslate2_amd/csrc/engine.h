@@ -178,7 +178,7 @@ public:
   void set_ids(DecodeState& state, const int32_t* h_ids);
   // Installs per-row forced tokens for the steps first_step, first_step + 1, ... (empty = none).
   void set_prefix(DecodeState& state, const std::vector<std::vector<int32_t>>& prefix,
-                  int32_t first_step);
+                  int32_t first_step, bool extends_min_length = true);
   void set_step(DecodeState& state, int32_t step);
   void synchronize();
 
@@ -327,6 +327,7 @@ struct DecodeState {
   int32_t* d_prefix = nullptr;
   int32_t* d_prefix_len = nullptr;
   int32_t prefix_stride = 0, prefix_first_step = 0;
+  bool prefix_extends_min = true;  // return_prefix == false (generation)
   // RandomSampler settings of the fused sampler (topk == 1: BestSampler / arg-max)
   int32_t g_topk = 1;
   float g_topp = 1.f, g_temperature = 1.f;

@@ -315,6 +315,18 @@ int ct2x_translate_batch(void* translator, const int32_t* src_ids, const int32_t
                          const struct ct2x_translation_options* opt, int32_t* out_ids,
                          int32_t* out_lengths, float* out_scores);
 
+/* translate_batch with a target prefix per sentence (Translator::translate_batch(source,
+ * target_prefix, options), src/translator.cc:8-28): prefix_ids [batch, prefix_stride] raw target
+ * ids forced right after the decoder start token (hard prefix, src/decoding.cc:21-66); they are
+ * part of the returned hypotheses and of max_decoding_length, and contribute 0 to the score.
+ * prefix_lengths may contain zeros. */
+int ct2x_translate_batch_prefix(void* translator, const int32_t* src_ids,
+                                const int32_t* src_lengths, int32_t batch, int32_t src_stride,
+                                const int32_t* prefix_ids, const int32_t* prefix_lengths,
+                                int32_t prefix_stride,
+                                const struct ct2x_translation_options* opt, int32_t* out_ids,
+                                int32_t* out_lengths, float* out_scores);
+
 /* Generator::generate_batch for decoder-only models (src/generator.cc:8-24 ->
  * src/models/language_model.cc:150-282); prompts are consumed in one prefill call. */
 int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,

@@ -319,6 +319,40 @@ int ct2ref_translate(void* h, const int32_t* src_ids, const int32_t* src_lengths
   CT2REF_CATCH
 }
 
+// Translator::translate_batch(source, target_prefix, options) on integer ids.
+int ct2ref_translate_prefix(void* h, const int32_t* src_ids, const int32_t* src_lengths, int batch,
+                            int src_stride, const int32_t* prefix_ids,
+                            const int32_t* prefix_lengths, int prefix_stride, int beam_size,
+                            int max_len, int min_len, float length_penalty, int return_scores,
+                            int32_t* out_ids, int32_t* out_lengths, float* out_scores) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const auto* s2s = dynamic_cast<const models::SequenceToSequenceModel*>(m->model.get());
+  if (!s2s || !m->translator) throw std::runtime_error("not a sequence-to-sequence model");
+  auto source = ids_to_tokens(s2s->get_source_vocabulary(), src_ids, src_lengths, batch, src_stride);
+  auto prefix = ids_to_tokens(s2s->get_target_vocabulary(), prefix_ids, prefix_lengths, batch,
+                              prefix_stride);
+  TranslationOptions opt;
+  opt.beam_size = beam_size;
+  opt.max_decoding_length = max_len;
+  opt.min_decoding_length = min_len;
+  opt.length_penalty = length_penalty;
+  opt.num_hypotheses = 1;
+  opt.return_scores = return_scores != 0;
+  opt.max_input_length = 0;
+  auto results = m->translator->translate_batch(source, prefix, opt);
+  const auto& tv = s2s->get_target_vocabulary();
+  for (int b = 0; b < batch; ++b) {
+    const auto& hyp = results[b].hypotheses[0];
+    const int len = static_cast<int>(hyp.size());
+    for (int t = 0; t < len && t < max_len; ++t)
+      out_ids[static_cast<int64_t>(b) * max_len + t] = tv.to_id(hyp[t]);
+    out_lengths[b] = len;
+    if (return_scores && out_scores) out_scores[b] = results[b].scores[0];
+  }
+  CT2REF_CATCH
+}
+
 // Generator::generate_batch on integer ids (decoder-only models).
 int ct2ref_generate(void* h, const int32_t* prompt_ids, const int32_t* prompt_lengths, int batch,
                     int stride, int beam_size, int max_len, int min_len, int return_scores,

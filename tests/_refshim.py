@@ -216,6 +216,21 @@ class RefModel:
                 for b in range(batch)]
         return hyps, scores
 
+    def translate_prefix_ids(self, sources, prefixes, beam_size=1, max_len=64, min_len=1,
+                             length_penalty=1.0, return_scores=True):
+        ids, lengths, stride = self._pack(sources)
+        pids, plens, pstride = self._pack(prefixes)
+        batch = len(sources)
+        out = np.zeros((batch, max_len), np.int32)
+        out_len = np.zeros((batch,), np.int32)
+        scores = np.zeros((batch,), np.float32)
+        _check(lib().ct2ref_translate_prefix(C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch),
+                                             C.c_int(stride), _p(pids), _p(plens), C.c_int(pstride),
+                                             C.c_int(beam_size), C.c_int(max_len), C.c_int(min_len),
+                                             C.c_float(length_penalty), C.c_int(int(return_scores)),
+                                             _p(out), _p(out_len), _p(scores)))
+        return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
+
     def generate_ids(self, prompts, beam_size=1, max_len=64, min_len=0, return_scores=True):
         ids, lengths, stride = self._pack(prompts)
         batch = len(prompts)

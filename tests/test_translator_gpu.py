@@ -301,3 +301,30 @@ def test_random_sampling(gpu):
 
     with pytest.raises(Exception, match="beam_size 1"):
         t.translate_ids(src, beam_size=2, sampling_topk=4)
+
+
+@pytest.mark.parametrize("ct", ["float32", "int8"])
+@pytest.mark.parametrize("beam", [1, 4])
+def test_target_prefix_matches_reference(gpu, ct, beam):
+    """translate_batch(source, target_prefix) - hard prefix of decode() (src/decoding.cc:21-66),
+    greedy and beam - against the real reference (tests/golden/make_golden_prefix.py): the prefix
+    is part of the hypothesis and of max_decoding_length and adds nothing to the score."""
+    with open(os.path.join(GOLDEN, "prefix_golden.json")) as f:
+        g = json.load(f)["small" + ("_f32" if ct == "float32" else "")]
+    run = g["runs"]["beam%d" % beam]
+    t = get_translator(gpu, "small", ct)
+    hyps, scores = t.translate_ids(g["sources"], beam_size=beam, max_decoding_length=g["max_len"],
+                                   min_decoding_length=g["min_len"], return_scores=True,
+                                   length_penalty=1.0, target_prefix_ids=g["prefixes"])
+    got = [h[0] for h in hyps]
+    for h, p in zip(got, g["prefixes"]):
+        assert h[:len(p)] == p
+    same = [a == b for a, b in zip(got, run["hypotheses"])]
+    print("prefix %s beam %d: %d/%d token-identical" % (ct, beam, sum(same), len(same)))
+    if ct == "float32":
+        assert all(same)
+        np.testing.assert_allclose(scores[:, 0], np.array(run["scores"], np.float32), atol=1e-3)
+    else:
+        assert sum(same) >= len(same) - 2
+        ok = np.array(same)
+        np.testing.assert_allclose(scores[ok, 0], np.array(run["scores"], np.float32)[ok], atol=2e-2)
