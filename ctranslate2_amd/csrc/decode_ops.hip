@@ -22,7 +22,26 @@ struct SamplePrefix {
   int32_t extends_min_length;  // return_prefix == false: EOS stays disabled prefix_len steps longer
 };
 
-__device__ __forceinline__ bool forced_by_prefix(const SamplePrefix& pf, int64_t row, int64_t rows,
+// Last-row-out advances the device-resident step counter (one launch less per step than a
+// separate advance_step kernel). Every workgroup reads *step_ptr at its start and the counter is
+// only written once ALL rows have finished, so no row can observe the incremented value; the
+// kernel boundary publishes it to the next step's kernels. Called by thread 0 of each row.
+struct StepAdvance {
+  int32_t* step_ptr;  // nullptr: the caller advances the step itself
+  int32_t* done;      // zero between launches
+};
+
+__device__ __forceinline__ void row_finished(const StepAdvance& adv, int64_t rows, int step) {
+  if (adv.step_ptr == nullptr) return;
+  __threadfence();
+  if (atomicAdd(adv.done, 1) == static_cast<int>(rows) - 1) {
+    *adv.done = 0;
+    *adv.step_ptr = step + 1;
+  }
+}
+
+__device__ __forceinline__ bool forced_by_prefix(const SamplePrefix& pf, const StepAdvance& adv,
+                                                 int64_t row, int64_t rows,
                                                  int step, int32_t* next_ids, int32_t* hist_ids,
                                                  float* hist_scores) {
   if (pf.ids == nullptr) return false;
@@ -33,14 +52,15 @@ __device__ __forceinline__ bool forced_by_prefix(const SamplePrefix& pf, int64_t
     next_ids[row] = id;
     hist_ids[static_cast<int64_t>(step) * rows + row] = id;
     hist_scores[static_cast<int64_t>(step) * rows + row] = 0.f;
+    row_finished(adv, rows, step);
   }
   return true;
 }
 
 __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t vocab,
                                      int32_t disable_id, int32_t min_length, bool with_scores,
-                                     SamplePrefix pf, const int32_t* __restrict__ step_ptr,
-                                     int32_t* __restrict__ next_ids,
+                                     SamplePrefix pf, StepAdvance adv,
+                                     const int32_t* step_ptr, int32_t* __restrict__ next_ids,
                                      int32_t* __restrict__ hist_ids,
                                      float* __restrict__ hist_scores) {
   __shared__ float s_v[16];
@@ -51,7 +71,7 @@ __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t v
   const int64_t row = blockIdx.x;
   const int64_t rows = gridDim.x;
   const int step = *step_ptr;
-  if (forced_by_prefix(pf, row, rows, step, next_ids, hist_ids, hist_scores)) return;
+  if (forced_by_prefix(pf, adv, row, rows, step, next_ids, hist_ids, hist_scores)) return;
   const int row_min = min_length + ((pf.ids && pf.extends_min_length) ? pf.lens[row] : 0);
   const int masked = (step < row_min) ? disable_id : -1;
   const float* x = logits + row * vocab;
@@ -134,6 +154,7 @@ __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t v
     next_ids[row] = best_i;
     hist_ids[static_cast<int64_t>(step) * rows + row] = best_i;
     hist_scores[static_cast<int64_t>(step) * rows + row] = score;
+    row_finished(adv, rows, step);
   }
 }
 
@@ -141,14 +162,16 @@ void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           int32_t min_length, bool with_scores, const int32_t* step_ptr,
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
                           hipStream_t stream, const int32_t* prefix_ids, const int32_t* prefix_lens,
-                          int32_t prefix_stride, int32_t prefix_first_step, bool prefix_extends_min) {
+                          int32_t prefix_stride, int32_t prefix_first_step, bool prefix_extends_min,
+                          int32_t* advance_step_ptr, int32_t* done_counter) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
   const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step,
                         prefix_extends_min ? 1 : 0};
+  const StepAdvance adv{advance_step_ptr, done_counter};
   hipLaunchKernelGGL(greedy_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
-                     disable_id, min_length, with_scores, pf, step_ptr, next_ids, hist_ids,
+                     disable_id, min_length, with_scores, pf, adv, step_ptr, next_ids, hist_ids,
                      hist_scores);
 }
 
@@ -177,8 +200,8 @@ __device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_
 __global__ void random_sample_kernel(const float* __restrict__ logits, int64_t vocab,
                                      int32_t disable_id, int32_t min_length, bool with_scores,
                                      int topk, float topp, float temperature, uint32_t seed,
-                                     SamplePrefix pf, const int32_t* __restrict__ step_ptr,
-                                     int32_t* __restrict__ next_ids,
+                                     SamplePrefix pf, StepAdvance adv,
+                                     const int32_t* step_ptr, int32_t* __restrict__ next_ids,
                                      int32_t* __restrict__ hist_ids,
                                      float* __restrict__ hist_scores) {
   __shared__ float s_v[16];
@@ -189,7 +212,7 @@ __global__ void random_sample_kernel(const float* __restrict__ logits, int64_t v
   const int64_t row = blockIdx.x;
   const int64_t rows = gridDim.x;
   const int step = *step_ptr;
-  if (forced_by_prefix(pf, row, rows, step, next_ids, hist_ids, hist_scores)) return;
+  if (forced_by_prefix(pf, adv, row, rows, step, next_ids, hist_ids, hist_scores)) return;
   const int row_min = min_length + ((pf.ids && pf.extends_min_length) ? pf.lens[row] : 0);
   const int masked = (step < row_min) ? disable_id : -1;
   const float* x = logits + row * vocab;
@@ -286,6 +309,7 @@ __global__ void random_sample_kernel(const float* __restrict__ logits, int64_t v
     next_ids[row] = id;
     hist_ids[static_cast<int64_t>(step) * rows + row] = id;
     hist_scores[static_cast<int64_t>(step) * rows + row] = with_scores ? cand_v[pick] + lse_c : 0.f;
+    row_finished(adv, rows, step);
   }
 }
 
@@ -294,15 +318,17 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           float temperature, uint32_t seed, const int32_t* step_ptr,
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
                           hipStream_t stream, const int32_t* prefix_ids, const int32_t* prefix_lens,
-                          int32_t prefix_stride, int32_t prefix_first_step, bool prefix_extends_min) {
+                          int32_t prefix_stride, int32_t prefix_first_step, bool prefix_extends_min,
+                          int32_t* advance_step_ptr, int32_t* done_counter) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
   const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step,
                         prefix_extends_min ? 1 : 0};
+  const StepAdvance adv{advance_step_ptr, done_counter};
   hipLaunchKernelGGL(random_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
-                     disable_id, min_length, with_scores, topk, topp, temperature, seed, pf, step_ptr,
-                     next_ids, hist_ids, hist_scores);
+                     disable_id, min_length, with_scores, topk, topp, temperature, seed, pf, adv,
+                     step_ptr, next_ids, hist_ids, hist_scores);
 }
 
 int max_sampling_topk() { return kMaxSampleTopK; }

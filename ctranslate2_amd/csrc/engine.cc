@@ -955,6 +955,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   st->logits = alloc<float>(*st, rows * V);
   st->d_ids = alloc<int32_t>(*st, rows);
   st->d_step = alloc<int32_t>(*st, 1);
+  st->d_done = alloc<int32_t>(*st, 1);
+  CT2X_HIP_CHECK(hipMemsetAsync(st->d_done, 0, sizeof(int32_t), cur_stream()));
   st->hist_ids = alloc<int32_t>(*st, (t_max + 1) * rows);
   st->hist_scores = alloc<float>(*st, (t_max + 1) * rows);
   CT2X_HIP_CHECK(hipMemsetAsync(st->d_step, 0, sizeof(int32_t), cur_stream()));
@@ -1466,7 +1468,7 @@ void Engine::launch_step(DecodeState& st) {
       launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
                            st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores,
                            cur_stream(), st.d_prefix, st.d_prefix_len, st.prefix_stride,
-                           st.prefix_first_step, st.prefix_extends_min);
+                           st.prefix_first_step, st.prefix_extends_min, st.d_step, st.d_done);
       end_kernel();
     } else {
       begin_kernel("random_sample");
@@ -1474,12 +1476,10 @@ void Engine::launch_step(DecodeState& st) {
                            st.g_scores, st.g_topk, st.g_topp, st.g_temperature, st.g_seed, st.d_step,
                            st.d_ids, st.hist_ids, st.hist_scores, cur_stream(), st.d_prefix,
                            st.d_prefix_len, st.prefix_stride, st.prefix_first_step,
-                           st.prefix_extends_min);
+                           st.prefix_extends_min, st.d_step, st.d_done);
       end_kernel();
     }
-    begin_kernel("advance_step");
-    launch_advance_step(st.d_step, cur_stream());
-    end_kernel();
+    // the sampler's last row advanced d_step (decode_ops.hip: row_finished)
   }
 }
 

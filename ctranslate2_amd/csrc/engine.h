@@ -324,6 +324,7 @@ struct DecodeState {
   int32_t g_eos = -1, g_min_length = 0;
   bool g_scores = false;
   // Hard decoding prefix of the fused sampler (ragged prompts): ids [rows, prefix_stride], lengths
+  int32_t* d_done = nullptr;   // rows-finished counter of the fused sampler (advances d_step)
   int32_t* d_prefix = nullptr;
   int32_t* d_prefix_len = nullptr;
   int32_t prefix_stride = 0, prefix_first_step = 0;

@@ -245,7 +245,8 @@ void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
                           hipStream_t stream, const int32_t* prefix_ids = nullptr,
                           const int32_t* prefix_lens = nullptr, int32_t prefix_stride = 0,
-                          int32_t prefix_first_step = 0, bool prefix_extends_min = true);
+                          int32_t prefix_first_step = 0, bool prefix_extends_min = true,
+                          int32_t* advance_step_ptr = nullptr, int32_t* done_counter = nullptr);
 
 // *step_ptr += 1
 void launch_advance_step(int32_t* step_ptr, hipStream_t stream);
@@ -259,7 +260,8 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
                           hipStream_t stream, const int32_t* prefix_ids = nullptr,
                           const int32_t* prefix_lens = nullptr, int32_t prefix_stride = 0,
-                          int32_t prefix_first_step = 0, bool prefix_extends_min = true);
+                          int32_t prefix_first_step = 0, bool prefix_extends_min = true,
+                          int32_t* advance_step_ptr = nullptr, int32_t* done_counter = nullptr);
 int max_sampling_topk();
 
 // Beam-search scores: y[row, :] = log_softmax(x[row, :] with x[disable_id] = -FLT_MAX while
