@@ -150,11 +150,26 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         opt.patience = patience
         opt.use_graph = int(use_graph)
         opt.num_streams = int(num_streams)
-        opt.sampling_topk = int(sampling_topk)
+        # reference semantics: 0 = the whole vocabulary (-1 in the C struct, where 0 = arg-max)
+        opt.sampling_topk = -1 if int(sampling_topk) <= 0 else int(sampling_topk)
         opt.sampling_topp = float(sampling_topp)
         opt.sampling_temperature = float(sampling_temperature)
         opt.seed = int(seed) & 0xFFFFFFFF
         return opt
+
+    @staticmethod
+    def _set_processors(opt, repetition_penalty, no_repeat_ngram_size, suppress_sequences_ids):
+        """Fills the logits-processor fields of the options; returns the arrays the struct points
+        into (keep them alive for the duration of the call)."""
+        opt.repetition_penalty = float(repetition_penalty)
+        opt.no_repeat_ngram_size = int(no_repeat_ngram_size)
+        seqs = [list(q) for q in (suppress_sequences_ids or []) if len(q) > 0]
+        flat = np.array([t for q in seqs for t in q] or [0], np.int32)
+        lens = np.array([len(q) for q in seqs] or [0], np.int32)
+        opt.num_suppress_sequences = len(seqs)
+        opt.suppress_ids = flat.ctypes.data_as(C.POINTER(C.c_int32))
+        opt.suppress_lengths = lens.ctypes.data_as(C.POINTER(C.c_int32))
+        return flat, lens
 
     def translate_ids(self, source_ids: Sequence[Sequence[int]], beam_size: int = 2,
                       max_decoding_length: int = 256, min_decoding_length: int = 1,
@@ -164,10 +179,14 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                       patience: float = 1.0, use_graph: bool = True, num_streams: int = 0,
                       sampling_topk: int = 1, sampling_topp: float = 1.0,
                       sampling_temperature: float = 1.0, seed: int = 0,
-                      target_prefix_ids: Optional[Sequence[Sequence[int]]] = None):
+                      target_prefix_ids: Optional[Sequence[Sequence[int]]] = None,
+                      repetition_penalty: float = 1.0, no_repeat_ngram_size: int = 0,
+                      suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None):
         """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores).
         sampling_* (reference names, python/cpp/translator.cc): random sampling among the best
-        sampling_topk candidates (beam_size must be 1), reproducible for a `seed`."""
+        sampling_topk candidates (beam_size must be 1), reproducible for a `seed`.
+        repetition_penalty / no_repeat_ngram_size as in the reference; suppress_sequences_ids:
+        id sequences that must not be generated (a single id is disabled at every step)."""
         batch = len(source_ids)
         lengths = np.array([len(s) for s in source_ids], np.int32)
         stride = max(1, int(lengths.max()) if batch else 1)
@@ -181,6 +200,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                             return_scores, return_end_token, max_batch_size, max_input_length,
                             length_penalty, patience, use_graph, num_streams, sampling_topk,
                             sampling_topp, sampling_temperature, seed)
+        _keep = self._set_processors(opt, repetition_penalty, no_repeat_ngram_size,
+                                     suppress_sequences_ids)
         if target_prefix_ids is not None:
             plen = np.array([len(p) for p in target_prefix_ids], np.int32)
             pstride = max(1, int(plen.max()) if batch else 1)
@@ -204,6 +225,13 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         """ctranslate2.Translator.translate_batch on tokens (same keyword names)."""
         return_scores = kwargs.get("return_scores", False)
         src_ids = [[self.token_to_id(t) for t in sent] for sent in source]
+        # suppress_sequences / disable_unk (python/cpp/translator.cc) -> id sequences
+        suppress = [[self.token_to_id(t, target=True) for t in q]
+                    for q in (kwargs.pop("suppress_sequences", None) or [])]
+        if kwargs.pop("disable_unk", False):
+            suppress.append([self.token_to_id("<unk>", target=True)])
+        if suppress:
+            kwargs["suppress_sequences_ids"] = suppress
         if target_prefix is not None:
             kwargs["target_prefix_ids"] = [[self.token_to_id(t, target=True) for t in (pfx or [])]
                                            for pfx in target_prefix]
@@ -220,7 +248,9 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                      return_end_token: bool = False, use_graph: bool = True,
                      sampling_topk: int = 1, sampling_topp: float = 1.0,
                      sampling_temperature: float = 1.0, seed: int = 0, beam_size: int = 1,
-                     length_penalty: float = 1.0):
+                     length_penalty: float = 1.0, repetition_penalty: float = 1.0,
+                     no_repeat_ngram_size: int = 0,
+                     suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None):
         """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False.
         sampling_topk=1 is greedy; 2..64 samples among the best k (sampling_topp / temperature as
         in the reference). Returns (generated ids per prompt, scores)."""
@@ -236,6 +266,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         opt = self._options(beam_size, max_length, min_length, 1, return_scores, return_end_token,
                             0, 0, length_penalty, 1.0, use_graph, 1, sampling_topk, sampling_topp,
                             sampling_temperature, seed)
+        _keep = self._set_processors(opt, repetition_penalty, no_repeat_ngram_size,
+                                     suppress_sequences_ids)
         _lib.check(self._L.ct2x_generate_batch(
             C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
             C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))

@@ -36,6 +36,12 @@ class TranslationOptions(C.Structure):
         ("sampling_topp", C.c_float),
         ("sampling_temperature", C.c_float),
         ("seed", C.c_uint32),
+        ("repetition_penalty", C.c_float),
+        ("no_repeat_ngram_size", C.c_int32),
+        ("num_suppress_sequences", C.c_int32),
+        ("reserved", C.c_int32),
+        ("suppress_ids", C.POINTER(C.c_int32)),
+        ("suppress_lengths", C.POINTER(C.c_int32)),
     ]
 
 

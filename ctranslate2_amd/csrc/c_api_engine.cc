@@ -163,10 +163,24 @@ DecodingOptions to_decoding_options(const ct2x_translation_options& o) {
   d.patience = o.patience;
   d.use_graph = o.use_graph != 0;
   d.include_eos_in_hypotheses = true;  // DecodingOptions default (include/ctranslate2/decoding.h:154)
-  d.sampling_topk = o.sampling_topk == 0 ? 1 : o.sampling_topk;  // zero-initialised structs: arg-max
+  // zero-initialised structs: arg-max; -1 = the whole vocabulary (the reference's 0)
+  d.sampling_topk = o.sampling_topk == 0 ? 1 : (o.sampling_topk < 0 ? 0 : o.sampling_topk);
   d.sampling_topp = o.sampling_topp == 0.f ? 1.f : o.sampling_topp;
   d.sampling_temperature = o.sampling_temperature == 0.f ? 1.f : o.sampling_temperature;
   d.seed = o.seed;
+  LogitsProcessing& lp = d.logits_processing;
+  lp.repetition_penalty = o.repetition_penalty == 0.f ? 1.f : o.repetition_penalty;
+  lp.no_repeat_ngram_size = o.no_repeat_ngram_size;
+  if (o.num_suppress_sequences < 0 ||
+      (o.num_suppress_sequences > 0 && (!o.suppress_ids || !o.suppress_lengths)))
+    throw std::invalid_argument("suppress_sequences: ids / lengths missing");
+  const int32_t* ids = o.suppress_ids;
+  for (int32_t s = 0; s < o.num_suppress_sequences; ++s) {
+    const int32_t n = o.suppress_lengths[s];
+    if (n < 0) throw std::invalid_argument("suppress_sequences: negative length");
+    lp.suppress_sequences.emplace_back(ids, ids + n);
+    ids += n;
+  }
   return d;
 }
 
@@ -201,6 +215,7 @@ void ct2x_translation_options_default(struct ct2x_translation_options* o) {
   o->sampling_topp = 1.f;
   o->sampling_temperature = 1.f;
   o->seed = 0;
+  o->repetition_penalty = 1.f;
 }
 
 void* ct2x_translator_create(const char* model_dir, int device_index, const char* compute_type) {

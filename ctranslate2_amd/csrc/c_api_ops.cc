@@ -3,6 +3,7 @@
 
 #include "../../include/ct2_mi355.h"
 
+#include <algorithm>
 #include <cstring>
 
 #include "kernels.h"
@@ -354,6 +355,22 @@ int ct2x_topk(const void* d_x, int dtype, int64_t rows, int64_t depth, int64_t k
   launch_topk(static_cast<const float*>(d_x), rows, depth, k, static_cast<float*>(d_values),
               d_indices, resolve_stream(stream));
   check_last_launch("topk");
+  API_CATCH
+}
+
+int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int32_t* d_sequences,
+                        int32_t length, float repetition_penalty, int32_t no_repeat_ngram_size,
+                        const int32_t* d_suppress_ids, const int32_t* d_suppress_offsets,
+                        int32_t num_suppress, void* stream) {
+  API_TRY
+  CT2X_CHECK(length >= 0 && length <= 16000, "ct2x_process_logits: length must be in [0, 16000]");
+  CT2X_CHECK(repetition_penalty > 0.f, "ct2x_process_logits: repetition_penalty must be > 0");
+  CT2X_CHECK(no_repeat_ngram_size >= 0 && num_suppress >= 0, "ct2x_process_logits: bad sizes");
+  CT2X_CHECK(length == 0 || d_sequences != nullptr, "ct2x_process_logits: sequences missing");
+  launch_process_logits(d_logits, rows, vocab, d_sequences, 1, length, nullptr, 0, length,
+                        std::max(length, 1), repetition_penalty, no_repeat_ngram_size,
+                        d_suppress_ids, d_suppress_offsets, num_suppress, resolve_stream(stream));
+  check_last_launch("process_logits");
   API_CATCH
 }
 

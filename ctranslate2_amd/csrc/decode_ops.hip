@@ -313,6 +313,115 @@ __global__ void random_sample_kernel(const float* __restrict__ logits, int64_t v
   }
 }
 
+// RandomSampler over the WHOLE vocabulary (sampling_topk = 0 in the reference: no TopK
+// restriction, src/sampling.cc:54-66): temperature -> [TopPMask] -> SoftMax -> Multinomial.
+//  * the multinomial draw is an inverse CDF in index order: every thread owns a contiguous
+//    segment of the vocabulary, a block scan of the segment masses finds the owner of the
+//    uniform draw, which then walks its segment;
+//  * TopPMask (src/ops/topp_mask_cpu.cc:24-31: in value order, keep a token while the mass ranked
+//    before it is < topp) needs no sort here: the kept set is {i : M(x_i) < topp} with
+//    M(v) = mass of the tokens with a value > v, a threshold found by bisection on the ordered
+//    bit pattern of the float (32 vocabulary passes). Tokens whose value TIES with the threshold
+//    are all kept (the reference keeps those its sort happens to rank first).
+__device__ __forceinline__ uint32_t ordered_key(float v) {
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void random_sample_full_kernel(
+    const float* __restrict__ logits, int64_t vocab, int32_t disable_id, int32_t min_length,
+    bool with_scores, float topp, float temperature, uint32_t seed, SamplePrefix pf,
+    StepAdvance adv, const int32_t* step_ptr, int32_t* __restrict__ next_ids,
+    int32_t* __restrict__ hist_ids, float* __restrict__ hist_scores) {
+  __shared__ float scratch[16];
+  __shared__ float seg_incl[1024];
+  __shared__ int s_pick;
+  const int64_t row = blockIdx.x;
+  const int64_t rows = gridDim.x;
+  const int step = *step_ptr;
+  if (forced_by_prefix(pf, adv, row, rows, step, next_ids, hist_ids, hist_scores)) return;
+  const int row_min = min_length + ((pf.ids && pf.extends_min_length) ? pf.lens[row] : 0);
+  const int masked = (step < row_min) ? disable_id : -1;
+  const float* x = logits + row * vocab;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  auto val = [&](int64_t j) { return (j == masked) ? -FLT_MAX : x[j]; };
+
+  float m = -FLT_MAX;
+  for (int64_t j = tid; j < vocab; j += nthreads) m = fmaxf(m, val(j));
+  m = block_max(m, scratch);
+  const float inv_t = 1.f / temperature;
+  // weights of the sampling distribution: exp((x - max) / T); of the original one: exp(x - max)
+  float lse_c = 0.f;
+  if (with_scores) {
+    float s = 0.f;
+    for (int64_t j = tid; j < vocab; j += nthreads) s += expf(val(j) - m);
+    s = block_sum(s, scratch);
+    lse_c = -m - logf(s);
+  }
+  uint32_t keep_key = 0;  // tokens with ordered_key >= keep_key take part
+  if (topp < 1.f) {
+    float total = 0.f;
+    for (int64_t j = tid; j < vocab; j += nthreads) total += expf((val(j) - m) * inv_t);
+    total = block_sum(total, scratch);
+    uint32_t lo = 0, hi = ordered_key(m);
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      float above = 0.f;
+      for (int64_t j = tid; j < vocab; j += nthreads) {
+        const float v = val(j);
+        if (ordered_key(v) > mid) above += expf((v - m) * inv_t);
+      }
+      above = block_sum(above, scratch);
+      if (above / total < topp)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    keep_key = lo;
+  }
+  auto weight = [&](int64_t j) {
+    const float v = val(j);
+    return (ordered_key(v) >= keep_key) ? expf((v - m) * inv_t) : 0.f;
+  };
+
+  const int64_t seg = (vocab + nthreads - 1) / nthreads;
+  const int64_t j0 = min(vocab, static_cast<int64_t>(tid) * seg), j1 = min(vocab, j0 + seg);
+  float mass = 0.f;
+  for (int64_t j = j0; j < j1; ++j) mass += weight(j);
+  seg_incl[tid] = mass;
+  if (tid == 0) s_pick = -1;
+  __syncthreads();
+  for (int off = 1; off < nthreads; off <<= 1) {  // Hillis-Steele inclusive scan
+    const float add = (tid >= off) ? seg_incl[tid - off] : 0.f;
+    __syncthreads();
+    seg_incl[tid] += add;
+    __syncthreads();
+  }
+  const float total = seg_incl[nthreads - 1];
+  float u = uniform01(seed, static_cast<uint32_t>(step), static_cast<uint32_t>(row)) * total;
+  u = fminf(u, total * (1.f - 1.f / 16777216.f));  // strictly below the total: exactly one owner
+  const float excl = tid ? seg_incl[tid - 1] : 0.f;
+  if (excl <= u && u < seg_incl[tid]) {
+    float acc = excl;
+    int pick = -1, last = -1;
+    for (int64_t j = j0; j < j1 && pick < 0; ++j) {
+      const float w = weight(j);
+      if (w > 0.f) last = static_cast<int>(j);
+      acc += w;
+      if (u < acc) pick = static_cast<int>(j);
+    }
+    s_pick = pick >= 0 ? pick : last;  // the scan and the walk associate the sums differently
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int id = s_pick;
+    next_ids[row] = id;
+    hist_ids[static_cast<int64_t>(step) * rows + row] = id;
+    hist_scores[static_cast<int64_t>(step) * rows + row] = with_scores ? x[id] + lse_c : 0.f;
+    row_finished(adv, rows, step);
+  }
+}
+
 void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int32_t disable_id,
                           int32_t min_length, bool with_scores, int topk, float topp,
                           float temperature, uint32_t seed, const int32_t* step_ptr,
@@ -326,12 +435,98 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
   const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step,
                         prefix_extends_min ? 1 : 0};
   const StepAdvance adv{advance_step_ptr, done_counter};
+  if (topk <= 0) {  // the whole vocabulary
+    hipLaunchKernelGGL(random_sample_full_kernel, dim3(rows), dim3(1024), 0, stream, logits, vocab,
+                       disable_id, min_length, with_scores, topp, temperature, seed, pf, adv,
+                       step_ptr, next_ids, hist_ids, hist_scores);
+    return;
+  }
   hipLaunchKernelGGL(random_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
                      disable_id, min_length, with_scores, topk, topp, temperature, seed, pf, adv,
                      step_ptr, next_ids, hist_ids, hist_scores);
 }
 
 int max_sampling_topk() { return kMaxSampleTopK; }
+
+// ---------------------------------------------------------------------------------------------
+// Logits processors (src/decoding_utils.cc): RepetitionPenalty -> NoRepeatNgram -> SuppressTokens /
+// SuppressSequences, in the order make_logits_processors builds them (src/decoding.cc:1091-1120),
+// applied in place on the step's logits BEFORE log-softmax / sampling (src/decoding.cc:863-866).
+// One workgroup per row; `seq` is the row's generated history (prefix tokens included, start
+// token excluded: alive_seq, src/decoding.cc:886-892) addressed as seq[t * t_stride + row *
+// row_stride] so that both the device-resident greedy history ([step, rows]) and an uploaded
+// beam history ([rows, len]) fit.
+//  * RepetitionPenalty (:43-66 + primitives::penalize_previous_tokens, src/cpu/primitives.cc:
+//    411-428): the previous tokens' scores are GATHERED first and then scattered back as
+//    s < 0 ? s * p : s / p, so a token that occurs twice is penalised once - hence the two
+//    phases around a barrier.
+//  * NoRepeatNgram (:74-105): every earlier occurrence of the last n-1 tokens bans the token
+//    that followed it.
+//  * SuppressSequences (:108-153): length-1 sequences are always banned (this is also how
+//    disable_unk / disable_ids arrive); a longer one bans its last token when the history ends
+//    with the rest.
+// Banned = numeric_limits<float>::lowest() (DisableTokens, decoding_utils.h:36-71).
+struct LogitsProcessParams {
+  float* logits;
+  int64_t rows, vocab;
+  const int32_t* seq;
+  int64_t t_stride, row_stride;
+  const int32_t* step_ptr;  // history length = *step_ptr - first_step (or `length` when null)
+  int32_t first_step;
+  int32_t length;
+  float penalty;            // 1 = off
+  int32_t ngram;            // 0 = off
+  const int32_t* sup_ids;   // flattened suppressed sequences
+  const int32_t* sup_off;   // [n_sup + 1]
+  int32_t n_sup;
+};
+
+__global__ __launch_bounds__(256) void process_logits_kernel(LogitsProcessParams p) {
+  extern __shared__ float s_prev[];  // [length] gathered scores
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int len = p.step_ptr ? (*p.step_ptr - p.first_step) : p.length;
+  float* lg = p.logits + row * p.vocab;
+  const int32_t* sq = p.seq + row * p.row_stride;
+  auto tok = [&](int t) { return sq[static_cast<int64_t>(t) * p.t_stride]; };
+
+  if (p.penalty != 1.f && len > 0) {
+    for (int j = tid; j < len; j += blockDim.x) s_prev[j] = lg[tok(j)];
+    __syncthreads();
+    for (int j = tid; j < len; j += blockDim.x) {
+      const float s = s_prev[j];
+      lg[tok(j)] = s < 0.f ? s * p.penalty : s / p.penalty;
+    }
+    __syncthreads();  // bans below must land after the penalties
+  }
+  if (p.ngram > 0 && len >= p.ngram) {
+    const int cmp = p.ngram - 1;
+    for (int i = tid; i + p.ngram <= len; i += blockDim.x) {
+      bool same = true;
+      for (int c = 0; c < cmp && same; ++c) same = tok(i + c) == tok(len - cmp + c);
+      if (same) lg[tok(i + cmp)] = -FLT_MAX;
+    }
+  }
+  for (int s = tid; s < p.n_sup; s += blockDim.x) {
+    const int32_t* ids = p.sup_ids + p.sup_off[s];
+    const int cmp = p.sup_off[s + 1] - p.sup_off[s] - 1;
+    bool ban = len >= cmp;
+    for (int c = 0; c < cmp && ban; ++c) ban = tok(len - cmp + c) == ids[c];
+    if (ban) lg[ids[cmp]] = -FLT_MAX;
+  }
+}
+
+void launch_process_logits(float* logits, int64_t rows, int64_t vocab, const int32_t* seq,
+                           int64_t t_stride, int64_t row_stride, const int32_t* step_ptr,
+                           int32_t first_step, int32_t length, int32_t max_length, float penalty,
+                           int32_t ngram, const int32_t* sup_ids, const int32_t* sup_off,
+                           int32_t n_sup, hipStream_t stream) {
+  if (rows == 0) return;
+  const LogitsProcessParams p{logits, rows, vocab, seq, t_stride, row_stride, step_ptr, first_step,
+                              length, penalty, ngram, sup_ids, sup_off, n_sup};
+  const size_t lds = penalty != 1.f ? static_cast<size_t>(max_length) * sizeof(float) : 0;
+  hipLaunchKernelGGL(process_logits_kernel, dim3(rows), dim3(256), lds, stream, p);
+}
 
 __global__ void advance_step_kernel(int32_t* step_ptr) { *step_ptr = *step_ptr + 1; }
 

@@ -25,10 +25,10 @@ void validate_decoding_options(const DecodingOptions& o) {
   if (o.sampling_topk != 1) {
     if (o.beam_size != 1)
       throw std::invalid_argument("Random sampling (sampling_topk != 1) requires beam_size 1");
-    if (o.sampling_topk < 1 || o.sampling_topk > max_sampling_topk())
-      throw std::invalid_argument("sampling_topk must be between 1 and " +
-                                  std::to_string(max_sampling_topk()) + " in this backend (sampling "
-                                  "from the full vocabulary, sampling_topk = 0, is not built)");
+    // 0 = the whole vocabulary (the reference's sampling_topk <= 0), else the best k <= 64
+    if (o.sampling_topk < 0 || o.sampling_topk > max_sampling_topk())
+      throw std::invalid_argument("sampling_topk must be 0 (whole vocabulary) or between 1 and " +
+                                  std::to_string(max_sampling_topk()) + " in this backend");
   }
   if (!(o.sampling_topp > 0.f && o.sampling_topp <= 1.f))
     throw std::invalid_argument("sampling_topp must be in (0, 1]");
@@ -90,6 +90,7 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
   st.g_topp = opt.sampling_topp;
   st.g_temperature = opt.sampling_temperature;
   st.g_seed = opt.seed;
+  engine.set_logits_processing(st, opt.logits_processing);
   // Hard prefix: forced on the device by the fused sampler; the host only has to know how many
   // leading steps of each row to skip (get_max_step / is_last_step, src/decoding.cc:357-382).
   std::vector<int64_t> prefix_len(batch, 0);
@@ -223,6 +224,9 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   engine.set_step(st, opt.start_step);
   engine.set_beam_scores(st, beam_scores.data());
   st.fuse_greedy = false;
+  engine.set_logits_processing(st, opt.logits_processing);
+  const bool processing = opt.logits_processing.active();
+  std::vector<int32_t> flat_seq;
 
   // alive_seq[i][k]: tokens of active beam k of batch i.
   std::vector<std::vector<std::vector<int32_t>>> alive_seq(
@@ -235,6 +239,17 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   int64_t step = 0;
   for (; step < opt.max_length && remaining > 0; ++step) {
     engine.step(st, opt.use_graph);
+    if (processing) {
+      // merge_batch_beam(alive_seq) (src/decoding.cc:518-525): every active beam has `step` tokens
+      flat_seq.assign(static_cast<size_t>(rows) * step, 0);
+      for (int64_t i = 0; i < batch; ++i)
+        for (int32_t k = 0; k < beam; ++k) {
+          const auto& seq = alive_seq[i][k];
+          if (static_cast<int64_t>(seq.size()) == step)
+            std::copy(seq.begin(), seq.end(), flat_seq.begin() + (i * beam + k) * step);
+        }
+      engine.process_logits_beam(st, flat_seq.data(), static_cast<int32_t>(step));
+    }
     engine.beam_candidates(st, end_id, min_length_abs, cand_scores.data(), cand_flat.data());
     const bool last = (step + 1 == opt.max_length);
 

@@ -28,7 +28,8 @@ struct DecodingOptions {
   bool use_graph = true;
   int32_t sync_every = 8;
   int32_t start_step = 0;
-  // RandomSampler (src/sampling.cc:41-101), greedy search only: sampling_topk == 1 is arg-max.
+  // RandomSampler (src/sampling.cc:41-101), greedy search only: sampling_topk == 1 is arg-max,
+  // 0 samples from the whole vocabulary.
   int32_t sampling_topk = 1;
   float sampling_topp = 1.f;
   float sampling_temperature = 1.f;
@@ -36,6 +37,11 @@ struct DecodingOptions {
   // DecodingOptions::return_prefix (include/ctranslate2/decoding.h): true for translation (the
   // target prefix is part of the hypothesis and of max_length), false for generation.
   bool return_prefix = true;
+  // repetition_penalty / no_repeat_ngram_size / disable_ids + disable_sequences
+  // (include/ctranslate2/decoding.h DecodingOptions; make_logits_processors,
+  // src/decoding.cc:1091-1120). Single-token entries of suppress_sequences are the reference's
+  // disable_ids (disable_unk) list.
+  LogitsProcessing logits_processing;
 };
 
 struct DecodingResult {

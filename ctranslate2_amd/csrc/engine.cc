@@ -1463,6 +1463,16 @@ void Engine::launch_step(DecodeState& st) {
   }
 
   if (st.fuse_greedy) {
+    if (st.lp_active) {
+      // history of this decoding session: hist_ids rows [first_step, *d_step)
+      begin_kernel("process_logits");
+      launch_process_logits(st.logits, st.rows, dec_.projection.n,
+                            st.hist_ids + static_cast<int64_t>(st.prefix_first_step) * st.rows,
+                            st.rows, 1, st.d_step, st.prefix_first_step, 0,
+                            static_cast<int32_t>(st.t_max), st.lp_penalty, st.lp_ngram,
+                            st.d_sup_ids, st.d_sup_off, st.lp_n_sup, cur_stream());
+      end_kernel();
+    }
     if (st.g_topk == 1) {
       begin_kernel("greedy_sample");
       launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
@@ -1662,6 +1672,64 @@ void Engine::set_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>
   st.d_prefix_len = upload_i32(lens);
   st.prefix_stride = static_cast<int32_t>(longest);
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // the host vectors go out of scope
+}
+
+void Engine::set_logits_processing(DecodeState& st, const LogitsProcessing& lp) {
+  tls_stream = st.stream;
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  st.lp_active = lp.active();
+  st.lp_penalty = lp.repetition_penalty;
+  st.lp_ngram = lp.no_repeat_ngram_size;
+  st.lp_n_sup = 0;
+  st.d_sup_ids = st.d_sup_off = nullptr;
+  if (!st.lp_active) return;
+  CT2X_CHECK(lp.repetition_penalty > 0.f, "repetition_penalty must be > 0");
+  CT2X_CHECK(lp.no_repeat_ngram_size >= 0, "no_repeat_ngram_size must be >= 0");
+  // the gather buffer of the penalty lives in LDS: one float per generated position
+  CT2X_CHECK(lp.repetition_penalty == 1.f || st.t_max <= 16000,
+             "repetition_penalty supports at most 16000 decoding positions");
+  const int64_t vocab = dec_.projection.n;
+  std::vector<int32_t> ids, off{0};
+  for (const auto& s : lp.suppress_sequences) {
+    if (s.empty()) continue;  // SuppressSequences ctor, src/decoding_utils.cc:109-111
+    for (int32_t id : s) {
+      CT2X_CHECK(id >= 0 && id < vocab, "suppressed token id out of the vocabulary");
+      ids.push_back(id);
+    }
+    off.push_back(static_cast<int32_t>(ids.size()));
+  }
+  auto upload_i32 = [&](const std::vector<int32_t>& v) {
+    void* p = device_malloc(v.size() * sizeof(int32_t));
+    st.owned.push_back(p);
+    CT2X_HIP_CHECK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                                  cur_stream()));
+    return static_cast<int32_t*>(p);
+  };
+  st.lp_n_sup = static_cast<int32_t>(off.size()) - 1;
+  if (st.lp_n_sup > 0) {
+    st.d_sup_ids = upload_i32(ids);
+    st.d_sup_off = upload_i32(off);
+  }
+  if (st.beam > 1 && st.d_seq == nullptr) {
+    st.d_seq = static_cast<int32_t*>(device_malloc(sizeof(int32_t) * st.rows * st.t_max));
+    st.owned.push_back(st.d_seq);
+  }
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // the host vectors go out of scope
+}
+
+void Engine::process_logits_beam(DecodeState& st, const int32_t* h_seq, int32_t length) {
+  if (!st.lp_active) return;
+  tls_stream = st.stream;
+  CT2X_CHECK(st.d_seq != nullptr && length <= st.t_max, "process_logits_beam: no staging buffer");
+  if (length > 0)
+    CT2X_HIP_CHECK(hipMemcpyAsync(st.d_seq, h_seq, sizeof(int32_t) * st.rows * length,
+                                  hipMemcpyHostToDevice, cur_stream()));
+  launch_process_logits(st.logits, st.rows, dec_.projection.n, st.d_seq, 1, length, nullptr, 0,
+                        length, static_cast<int32_t>(st.t_max), st.lp_penalty, st.lp_ngram,
+                        st.d_sup_ids, st.d_sup_off, st.lp_n_sup, cur_stream());
+  check_last_launch("process_logits");
+  // h_seq is pageable host memory owned by the caller: the copy has been staged when
+  // hipMemcpyAsync returns, and the next beam_candidates() synchronises the stream anyway.
 }
 
 void Engine::set_step(DecodeState& st, int32_t step) {

@@ -110,6 +110,16 @@ struct StackW {  // encoder or decoder
 // Per-call device state of one decoding session over `rows` = batch * beam hypotheses.
 struct DecodeState;
 
+// RepetitionPenalty, NoRepeatNgram, SuppressTokens / SuppressSequences (src/decoding_utils.cc).
+struct LogitsProcessing {
+  float repetition_penalty = 1.f;                          // 1 = off
+  int32_t no_repeat_ngram_size = 0;                        // 0 = off
+  std::vector<std::vector<int32_t>> suppress_sequences;    // length 1 = token always disabled
+  bool active() const {
+    return repetition_penalty != 1.f || no_repeat_ngram_size > 0 || !suppress_sequences.empty();
+  }
+};
+
 class Engine {
 public:
   // `tp`: tensor-parallel communicator (nullptr or world 1 = the whole model on this device).
@@ -181,6 +191,14 @@ public:
                   int32_t first_step, bool extends_min_length = true);
   void set_step(DecodeState& state, int32_t step);
   void synchronize();
+
+  // Logits processors of the decoding loop (make_logits_processors, src/decoding.cc:1091-1120):
+  // installs them for every following step of `state`. Greedy steps apply them on the device
+  // from the device-resident id history (inside the step's graph); beam search calls
+  // process_logits_beam() with the alive sequences it keeps on the host.
+  void set_logits_processing(DecodeState& state, const LogitsProcessing& processing);
+  // h_seq: [rows, length] tokens generated so far by each active beam.
+  void process_logits_beam(DecodeState& state, const int32_t* h_seq, int32_t length);
 
   // Number of kernel launches recorded for one decoder step (reported by bench.py).
   int64_t kernels_per_step() const { return kernels_per_step_; }
@@ -329,6 +347,13 @@ struct DecodeState {
   int32_t* d_prefix_len = nullptr;
   int32_t prefix_stride = 0, prefix_first_step = 0;
   bool prefix_extends_min = true;  // return_prefix == false (generation)
+  // logits processors (set_logits_processing)
+  bool lp_active = false;
+  float lp_penalty = 1.f;
+  int32_t lp_ngram = 0, lp_n_sup = 0;
+  int32_t* d_sup_ids = nullptr;
+  int32_t* d_sup_off = nullptr;
+  int32_t* d_seq = nullptr;    // [rows, t_max] staging of the beam histories
   // RandomSampler settings of the fused sampler (topk == 1: BestSampler / arg-max)
   int32_t g_topk = 1;
   float g_topp = 1.f, g_temperature = 1.f;

@@ -264,6 +264,16 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           int32_t* advance_step_ptr = nullptr, int32_t* done_counter = nullptr);
 int max_sampling_topk();
 
+// RepetitionPenalty / NoRepeatNgram / SuppressSequences (src/decoding_utils.cc:37-153) in place on
+// the step's logits, one launch. seq[t * t_stride + row * row_stride] = token t of the row's
+// generated history; its length is *step_ptr - first_step (device resident) or `length`.
+// max_length bounds the history (sizes the gather buffer, <= 16000).
+void launch_process_logits(float* logits, int64_t rows, int64_t vocab, const int32_t* seq,
+                           int64_t t_stride, int64_t row_stride, const int32_t* step_ptr,
+                           int32_t first_step, int32_t length, int32_t max_length, float penalty,
+                           int32_t ngram, const int32_t* sup_ids, const int32_t* sup_off,
+                           int32_t n_sup, hipStream_t stream);
+
 // Beam-search scores: y[row, :] = log_softmax(x[row, :] with x[disable_id] = -FLT_MAX while
 // step < min_length) + beam_scores[row]   (src/decoding.cc:512-556).
 void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t rows,

@@ -207,6 +207,19 @@ int ct2x_rotary(const float* d_x, const float* d_sin, const float* d_cos, int64_
 int ct2x_topk(const void* d_x, int dtype, int64_t rows, int64_t depth, int64_t k,
               void* d_values, int32_t* d_indices, void* stream);
 
+/* The logits processors of the decoding loop in one launch, in place on d_logits [rows, vocab]:
+ * RepetitionPenalty (src/decoding_utils.cc:37-66 + primitives<D>::penalize_previous_tokens,
+ * src/cpu/primitives.cc:411-428; CUDA src/cuda/primitives.cu penalize_previous_tokens),
+ * NoRepeatNgram (:69-105), SuppressTokens / SuppressSequences (:108-170) followed by
+ * DisableTokens::apply (primitives<D>::indexed_fill, :19-35). d_sequences [rows, length] = the
+ * tokens generated so far (alive_seq). d_suppress_ids holds num_suppress sequences back to back,
+ * d_suppress_offsets [num_suppress + 1] their start offsets. repetition_penalty 1 / ngram 0 /
+ * num_suppress 0 switch a processor off. length <= 16000. */
+int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int32_t* d_sequences,
+                        int32_t length, float repetition_penalty, int32_t no_repeat_ngram_size,
+                        const int32_t* d_suppress_ids, const int32_t* d_suppress_offsets,
+                        int32_t num_suppress, void* stream);
+
 /* ops::Gather::compute<Device::CUDA,T> axis 0 (src/ops/gather_gpu.cu:53-91):
  * out[i,:] = data[idx[i],:] for rows of row_bytes bytes. */
 int ct2x_gather_rows(const void* d_data, const int32_t* d_idx, int64_t n_idx,
@@ -266,13 +279,27 @@ struct ct2x_translation_options {
                                    0 = choose automatically */
   /* RandomSampler (src/sampling.cc:41-101; python: sampling_topk / sampling_topp /
    * sampling_temperature), greedy search (beam_size 1) only. sampling_topk: 1 = arg-max
-   * (BestSampler), 2..64 = sample among the best k; sampling_topp < 1 keeps the smallest
+   * (BestSampler), 2..64 = sample among the best k, -1 = sample from the whole vocabulary (the
+   * reference's sampling_topk = 0; 0 here means arg-max so that a zero-initialised struct is
+   * deterministic); sampling_topp < 1 keeps the smallest
    * prefix of those whose mass reaches it; seed drives a counter-based generator
    * (seed, step, row) -> reproducible for a seed. */
   int32_t sampling_topk;
   float sampling_topp;
   float sampling_temperature;
   uint32_t seed;
+  /* Logits processors (TranslationOptions::repetition_penalty / no_repeat_ngram_size /
+   * disable_unk / suppress_sequences, include/ctranslate2/translation.h:25-31 ->
+   * make_logits_processors, src/decoding.cc:1091-1120; src/decoding_utils.cc:37-153), greedy,
+   * sampling and beam search. Sequences are given as ids: `suppress_ids` holds
+   * `num_suppress_sequences` sequences back to back, `suppress_lengths` their lengths; a
+   * sequence of ONE id is disabled at every step (pass the <unk> id for disable_unk). */
+  float repetition_penalty;        /* 1 (or 0 in a zero-initialised struct) = off */
+  int32_t no_repeat_ngram_size;    /* 0 = off */
+  int32_t num_suppress_sequences;
+  int32_t reserved;
+  const int32_t* suppress_ids;
+  const int32_t* suppress_lengths;
 };
 
 void ct2x_translation_options_default(struct ct2x_translation_options* opt);

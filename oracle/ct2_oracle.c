@@ -337,3 +337,45 @@ void orc_attention_decode(const float* q, const float* k, const float* v,
     free(p);
   }
 }
+
+/* Logits processors of the decoding loop, applied in the order make_logits_processors builds
+ * them (src/decoding.cc:1091-1120) on logits [rows, vocab] given the generated history
+ * seq [rows, length]:
+ *  - RepetitionPenalty::apply (src/decoding_utils.cc:43-66): Gather the previous tokens' scores,
+ *    then penalize_previous_tokens (src/cpu/primitives.cc:411-428): s < 0 ? s * p : s / p
+ *    (the gather happens BEFORE any write: a token seen twice is penalised once);
+ *  - NoRepeatNgram::apply (:74-105): for every earlier occurrence of the last n-1 tokens, ban
+ *    the token that followed (skipped while length < n);
+ *  - SuppressSequences::apply (:125-153): single tokens always banned, longer sequences ban their
+ *    last token when the history ends with their first len-1 tokens.
+ * Banned = numeric_limits<float>::lowest() (DisableTokens, decoding_utils.h:38-39). */
+void orc_process_logits(float* logits, int64_t rows, int64_t vocab, const int32_t* seq,
+                        int32_t length, float penalty, int32_t ngram, const int32_t* sup_ids,
+                        const int32_t* sup_off, int32_t n_sup) {
+  for (int64_t r = 0; r < rows; ++r) {
+    float* lg = logits + r * vocab;
+    const int32_t* sq = seq ? seq + r * (int64_t)length : 0;
+    if (penalty != 1.f && length > 0) {
+      float* prev = (float*)malloc(sizeof(float) * (size_t)length);
+      for (int32_t j = 0; j < length; ++j) prev[j] = lg[sq[j]];
+      for (int32_t j = 0; j < length; ++j)
+        lg[sq[j]] = prev[j] < 0.f ? prev[j] * penalty : prev[j] / penalty;
+      free(prev);
+    }
+    if (ngram > 0 && length >= ngram) {
+      const int32_t cmp = ngram - 1;
+      for (int32_t i = 0; i + ngram <= length; ++i) {
+        int same = 1;
+        for (int32_t c = 0; c < cmp && same; ++c) same = sq[i + c] == sq[length - cmp + c];
+        if (same) lg[sq[i + cmp]] = -FLT_MAX;
+      }
+    }
+    for (int32_t s = 0; s < n_sup; ++s) {
+      const int32_t* ids = sup_ids + sup_off[s];
+      const int32_t cmp = sup_off[s + 1] - sup_off[s] - 1;
+      int ban = length >= cmp;
+      for (int32_t c = 0; c < cmp && ban; ++c) ban = sq[length - cmp + c] == ids[c];
+      if (ban) lg[ids[cmp]] = -FLT_MAX;
+    }
+  }
+}

@@ -56,6 +56,11 @@ void orc_rotary(const float* x, const float* sin, const float* cos, int64_t batc
 void orc_topk(const float* x, int64_t rows, int64_t depth, int64_t k, float* values,
               int32_t* indices);
 
+/* RepetitionPenalty / NoRepeatNgram / SuppressSequences (src/decoding_utils.cc:37-153), in place. */
+void orc_process_logits(float* logits, int64_t rows, int64_t vocab, const int32_t* seq,
+                        int32_t length, float penalty, int32_t ngram, const int32_t* sup_ids,
+                        const int32_t* sup_off, int32_t n_sup);
+
 /* ops::Gather axis 0 (src/ops/gather_cpu.cc). */
 void orc_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int64_t row_bytes,
                      void* out);

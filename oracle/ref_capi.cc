@@ -26,6 +26,7 @@
 #include <ctranslate2/translator.h>
 #include <ctranslate2/generator.h>
 #include <ctranslate2/utils.h>
+#include <ctranslate2/decoding_utils.h>
 
 using namespace ctranslate2;
 
@@ -221,6 +222,35 @@ int ct2ref_matmul(const float* a, const float* b, int64_t batch, int64_t m, int6
   CT2REF_CATCH
 }
 
+// The reference's own LogitsProcessor classes (include/ctranslate2/decoding_utils.h) applied in
+// make_logits_processors order on a CPU logits tensor [rows, vocab], history seq [rows, length].
+int ct2ref_process_logits(float* logits, int64_t rows, int64_t vocab, const int32_t* seq,
+                          int32_t length, float penalty, int32_t ngram, const int32_t* sup_ids,
+                          const int32_t* sup_off, int32_t n_sup) {
+  CT2REF_TRY
+  StorageView lg({rows, vocab}, logits, Device::CPU);  // view over the caller's buffer
+  StorageView sequences(DataType::INT32);
+  if (length > 0) {
+    std::vector<int32_t> flat(seq, seq + rows * length);
+    sequences = StorageView({rows, static_cast<dim_t>(length)}, flat, Device::CPU);
+  }
+  std::vector<std::shared_ptr<LogitsProcessor>> processors;
+  if (penalty != 1.f) processors.emplace_back(std::make_shared<RepetitionPenalty>(penalty));
+  if (ngram > 0) processors.emplace_back(std::make_shared<NoRepeatNgram>(ngram));
+  if (n_sup > 0) {
+    std::vector<std::vector<size_t>> banned;
+    for (int32_t s = 0; s < n_sup; ++s)
+      banned.emplace_back(sup_ids + sup_off[s], sup_ids + sup_off[s + 1]);
+    processors.emplace_back(std::make_shared<SuppressSequences>(std::move(banned)));
+  }
+  DisableTokens disable_tokens(lg);
+  const std::vector<dim_t> batch_offset(rows, 0);
+  for (const auto& p : processors)
+    p->apply(length, lg, disable_tokens, sequences, batch_offset, nullptr);
+  disable_tokens.apply();
+  CT2REF_CATCH
+}
+
 // ---------------------------------------------------------------------------------------
 // Model-level entry points.
 // ---------------------------------------------------------------------------------------
@@ -342,6 +372,49 @@ int ct2ref_translate_prefix(void* h, const int32_t* src_ids, const int32_t* src_
   opt.max_input_length = 0;
   auto results = m->translator->translate_batch(source, prefix, opt);
   const auto& tv = s2s->get_target_vocabulary();
+  for (int b = 0; b < batch; ++b) {
+    const auto& hyp = results[b].hypotheses[0];
+    const int len = static_cast<int>(hyp.size());
+    for (int t = 0; t < len && t < max_len; ++t)
+      out_ids[static_cast<int64_t>(b) * max_len + t] = tv.to_id(hyp[t]);
+    out_lengths[b] = len;
+    if (return_scores && out_scores) out_scores[b] = results[b].scores[0];
+  }
+  CT2REF_CATCH
+}
+
+// Translator::translate_batch with the logits-processor options (TranslationOptions::
+// repetition_penalty / no_repeat_ngram_size / suppress_sequences, include/ctranslate2/
+// translation.h:25-31). suppress_ids: num_suppress sequences back to back, lengths in
+// suppress_lengths (ids are mapped to the target vocabulary's tokens).
+int ct2ref_translate_processors(void* h, const int32_t* src_ids, const int32_t* src_lengths,
+                                int batch, int src_stride, int beam_size, int max_len, int min_len,
+                                float length_penalty, int return_scores, float repetition_penalty,
+                                int no_repeat_ngram_size, const int32_t* suppress_ids,
+                                const int32_t* suppress_lengths, int num_suppress,
+                                int32_t* out_ids, int32_t* out_lengths, float* out_scores) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const auto* s2s = dynamic_cast<const models::SequenceToSequenceModel*>(m->model.get());
+  if (!s2s || !m->translator) throw std::runtime_error("not a sequence-to-sequence model");
+  auto source = ids_to_tokens(s2s->get_source_vocabulary(), src_ids, src_lengths, batch, src_stride);
+  const auto& tv = s2s->get_target_vocabulary();
+  TranslationOptions opt;
+  opt.beam_size = beam_size;
+  opt.max_decoding_length = max_len;
+  opt.min_decoding_length = min_len;
+  opt.length_penalty = length_penalty;
+  opt.num_hypotheses = 1;
+  opt.return_scores = return_scores != 0;
+  opt.max_input_length = 0;
+  opt.repetition_penalty = repetition_penalty;
+  opt.no_repeat_ngram_size = static_cast<size_t>(no_repeat_ngram_size);
+  for (int s = 0; s < num_suppress; ++s) {
+    std::vector<std::string> seq;
+    for (int t = 0; t < suppress_lengths[s]; ++t) seq.push_back(tv.to_token(*suppress_ids++));
+    opt.suppress_sequences.push_back(std::move(seq));
+  }
+  auto results = m->translator->translate_batch(source, opt);
   for (int b = 0; b < batch; ++b) {
     const auto& hyp = results[b].hypotheses[0];
     const int len = static_cast<int>(hyp.size());

@@ -222,6 +222,22 @@ def topk(x, k):
     return host(v), host(i)
 
 
+def process_logits(logits, seq, penalty=1.0, ngram=0, suppress=()):
+    L = _lib.lib()
+    lg = dev(np.ascontiguousarray(logits, np.float32))
+    rows, vocab = logits.shape
+    seq = np.ascontiguousarray(seq, np.int32).reshape(rows, -1)
+    length = seq.shape[1]
+    sd = dev(seq if length else np.zeros((rows, 1), np.int32))
+    seqs = [list(q) for q in suppress if len(q) > 0]
+    ids = dev(np.array([t for q in seqs for t in q] or [0], np.int32))
+    off = dev(np.concatenate([[0], np.cumsum([len(q) for q in seqs])]).astype(np.int32))
+    _lib.check(L.ct2x_process_logits(_lib.ptr(lg), i64(rows), i64(vocab), _lib.ptr(sd),
+                                     C.c_int32(length), C.c_float(penalty), C.c_int32(ngram),
+                                     _lib.ptr(ids), _lib.ptr(off), C.c_int32(len(seqs)), None))
+    return host(lg)
+
+
 def gather_rows(data, idx):
     L = _lib.lib()
     dd, idd = dev(data), dev(np.asarray(idx, np.int32))

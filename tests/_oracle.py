@@ -131,6 +131,24 @@ def rotary(x, sin, cos, ndims, interleave):
     return y
 
 
+def _pack_suppress(suppress):
+    seqs = [list(q) for q in suppress if len(q) > 0]
+    ids = np.array([t for q in seqs for t in q] or [0], np.int32)
+    off = np.concatenate([[0], np.cumsum([len(q) for q in seqs])]).astype(np.int32)
+    return ids, off, len(seqs)
+
+
+def process_logits(logits, seq, penalty=1.0, ngram=0, suppress=()):
+    """RepetitionPenalty / NoRepeatNgram / SuppressSequences on a copy of logits [rows, vocab]."""
+    lg = _f32(logits).copy()
+    rows, vocab = lg.shape
+    seq = np.ascontiguousarray(seq, np.int32).reshape(rows, -1)
+    ids, off, n = _pack_suppress(suppress)
+    lib().orc_process_logits(_p(lg), _i64(rows), _i64(vocab), _p(seq), C.c_int32(seq.shape[1]),
+                             C.c_float(penalty), C.c_int32(ngram), _p(ids), _p(off), C.c_int32(n))
+    return lg
+
+
 def topk(x, k):
     x = _f32(x)
     rows, depth = x.shape

@@ -171,6 +171,20 @@ def matmul(a, b, trans_b=False, alpha=1.0):
     return c
 
 
+def process_logits(logits, seq, penalty=1.0, ngram=0, suppress=()):
+    """The reference's LogitsProcessor classes on a copy of logits [rows, vocab]."""
+    lg = np.ascontiguousarray(logits, np.float32).copy()
+    rows, vocab = lg.shape
+    seq = np.ascontiguousarray(seq, np.int32).reshape(rows, -1)
+    seqs = [list(q) for q in suppress if len(q) > 0]
+    ids = np.array([t for q in seqs for t in q] or [0], np.int32)
+    off = np.concatenate([[0], np.cumsum([len(q) for q in seqs])]).astype(np.int32)
+    _check(lib().ct2ref_process_logits(_p(lg), C.c_int64(rows), C.c_int64(vocab), _p(seq),
+                                       C.c_int32(seq.shape[1]), C.c_float(penalty),
+                                       C.c_int32(ngram), _p(ids), _p(off), C.c_int32(len(seqs))))
+    return lg
+
+
 class RefModel:
     """The reference's Translator / Generator on CPU."""
 
@@ -229,6 +243,25 @@ class RefModel:
                                              C.c_int(beam_size), C.c_int(max_len), C.c_int(min_len),
                                              C.c_float(length_penalty), C.c_int(int(return_scores)),
                                              _p(out), _p(out_len), _p(scores)))
+        return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
+
+    def translate_processors_ids(self, sources, beam_size=1, max_len=64, min_len=1,
+                                 length_penalty=1.0, return_scores=True, repetition_penalty=1.0,
+                                 no_repeat_ngram_size=0, suppress_sequences_ids=()):
+        ids, lengths, stride = self._pack(sources)
+        batch = len(sources)
+        out = np.zeros((batch, max_len), np.int32)
+        out_len = np.zeros((batch,), np.int32)
+        scores = np.zeros((batch,), np.float32)
+        seqs = [list(q) for q in suppress_sequences_ids]
+        flat = np.array([t for q in seqs for t in q] or [0], np.int32)
+        lens = np.array([len(q) for q in seqs] or [0], np.int32)
+        _check(lib().ct2ref_translate_processors(
+            C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch), C.c_int(stride),
+            C.c_int(beam_size), C.c_int(max_len), C.c_int(min_len), C.c_float(length_penalty),
+            C.c_int(int(return_scores)), C.c_float(repetition_penalty),
+            C.c_int(no_repeat_ngram_size), _p(flat), _p(lens), C.c_int(len(seqs)), _p(out),
+            _p(out_len), _p(scores)))
         return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
 
     def generate_ids(self, prompts, beam_size=1, max_len=64, min_len=0, return_scores=True):

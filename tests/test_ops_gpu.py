@@ -315,6 +315,23 @@ def test_topk(gpu, rows, depth, k):
     assert np.all(i[:, 0] == 0)
 
 
+def test_process_logits(gpu):
+    """ct2x_process_logits (RepetitionPenalty / NoRepeatNgram / SuppressSequences + the
+    indexed_fill of DisableTokens, src/decoding_utils.cc) == the oracle bit for bit."""
+    import _gpuops as G
+    from test_oracle import _processor_cases
+    for lg, seq, kw in _processor_cases():
+        got = G.process_logits(lg, seq, **kw)
+        want = O.process_logits(lg, seq, **kw)
+        assert np.array_equal(got, want), (seq.shape, kw)
+    # vocabulary-sized rows, long history (several passes of the 256-thread loops)
+    rng = np.random.default_rng(2)
+    lg = rng.standard_normal((32, 32000)).astype(np.float32)
+    seq = rng.integers(0, 40, (32, 700)).astype(np.int32)
+    kw = {"penalty": 1.3, "ngram": 2, "suppress": [[5], [seq[0, -1], 17], [1, 2, 3]]}
+    assert np.array_equal(G.process_logits(lg, seq, **kw), O.process_logits(lg, seq, **kw))
+
+
 def test_gather_rows(gpu):
     import _gpuops as G
     rng = np.random.default_rng(5)

@@ -178,3 +178,36 @@ def test_ref_attention_composition():
     out = R.matmul(probs.reshape(rows * H, 1, T), v.reshape(rows * H, T, dh), False, 1.0)
     mine = O.attention_decode(q, k, v, lengths, 0, 1, scale)
     np.testing.assert_allclose(mine, out.reshape(rows, H * dh), atol=2e-6, rtol=1e-5)
+
+
+def _processor_cases():
+    """(logits, history, kwargs) covering every branch of the three processors."""
+    rng = np.random.default_rng(5)
+    rows, vocab = 6, 50
+    cases = []
+    for length in (0, 1, 2, 5, 17):
+        lg = rng.standard_normal((rows, vocab)).astype(np.float32) * 3
+        # a small alphabet makes repeated tokens and repeated n-grams certain
+        seq = rng.integers(0, 6, (rows, length)).astype(np.int32)
+        tail2 = seq[0, -2:].tolist() if length >= 2 else [1, 2]
+        suppress = [[7], tail2 + [9], [seq[1, -1] if length else 3, 11], [], [3, 4, 5, 6, 8]]
+        for kw in ({"penalty": 1.5}, {"penalty": 0.7}, {"ngram": 1}, {"ngram": 2}, {"ngram": 3},
+                   {"ngram": 6}, {"suppress": suppress},
+                   {"penalty": 1.2, "ngram": 2, "suppress": suppress}):
+            cases.append((lg, seq, kw))
+    return cases
+
+
+def test_ref_logits_processors_exact():
+    """orc_process_logits == the reference's RepetitionPenalty / NoRepeatNgram / SuppressSequences
+    classes (src/decoding_utils.cc) bit for bit, incl. empty histories, n-grams longer than the
+    history, tokens repeated in the history (penalised once) and empty banned sequences."""
+    R = _ref()
+    for lg, seq, kw in _processor_cases():
+        a = O.process_logits(lg, seq, **kw)
+        b = R.process_logits(lg, seq, **kw)
+        assert np.array_equal(a, b), (seq.shape, kw)
+    # the penalty must not compound on a repeated token
+    lg = np.full((1, 8), 2.0, np.float32)
+    out = O.process_logits(lg, np.array([[3, 3, 3]], np.int32), penalty=2.0)
+    assert out[0, 3] == 1.0 and out[0, 2] == 2.0

@@ -303,6 +303,64 @@ def test_random_sampling(gpu):
         t.translate_ids(src, beam_size=2, sampling_topk=4)
 
 
+def test_random_sampling_whole_vocabulary(gpu):
+    """sampling_topk = 0 (the reference: no TopK restriction, src/sampling.cc:54-66): temperature
+    -> TopPMask -> SoftMax -> Multinomial over the whole vocabulary. Checked: graph == eager for a
+    seed; T -> 0 and topp -> 0 degenerate to arg-max; the first-step draws follow
+    softmax(logits / T), restricted to the TopPMask set (src/ops/topp_mask_cpu.cc:24-31) when
+    topp < 1; the returned score is the log-probability under the original distribution."""
+    t = get_translator(gpu, "small", "float32")
+    cfg = GC.SYNTHETIC["small"]
+    rng = np.random.default_rng(9)
+    src = [rng.integers(4, cfg["model"]["vocab_size"], 12).tolist() for _ in range(6)]
+    kw = dict(beam_size=1, max_decoding_length=10, min_decoding_length=10, return_scores=True)
+    greedy, _ = t.translate_ids(src, **kw)
+    a, sa = t.translate_ids(src, sampling_topk=0, sampling_temperature=1.3, seed=3, **kw)
+    b, sb = t.translate_ids(src, sampling_topk=0, sampling_temperature=1.3, seed=3, use_graph=False, **kw)
+    assert a == b and np.allclose(sa, sb)
+    assert a != greedy and np.all(sa < 0)
+    cold, _ = t.translate_ids(src, sampling_topk=0, sampling_temperature=1e-3, seed=3, **kw)
+    assert cold == greedy
+    narrow, _ = t.translate_ids(src, sampling_topk=0, sampling_topp=1e-4, seed=3, **kw)
+    assert narrow == greedy
+
+    one = [src[0]]
+    logits = t.step_logits(one, np.array([[t.bos_id]], np.int32))[0, 0].astype(np.float64)
+    logits[t.eos_id] = -np.inf   # min_decoding_length = 1 disables EOS at the first step
+    logp = logits - logits.max() - np.log(np.exp(logits - logits.max()).sum())
+    rows = 32
+    for temp, topp in ((0.25, 1.0), (0.25, 0.7)):
+        prob = np.exp((logits - logits.max()) / temp)
+        prob /= prob.sum()
+        if topp < 1:
+            order = np.argsort(-prob, kind="stable")
+            before = np.cumsum(prob[order]) - prob[order]
+            keep = order[before < topp]
+            masked = np.zeros_like(prob)
+            masked[keep] = prob[keep]
+            prob = masked / masked.sum()
+        counts = np.zeros_like(prob)
+        n = 0
+        for seed in range(25):
+            h, sc = t.translate_ids(one * rows, beam_size=1, max_decoding_length=1,
+                                    min_decoding_length=1, sampling_topk=0, sampling_topp=topp,
+                                    sampling_temperature=temp, seed=seed, return_scores=True)
+            for r in range(rows):
+                tok = h[r][0][0]
+                assert prob[tok] > 0, "token outside the top-p set"
+                assert abs(sc[r, 0] - logp[tok]) < 1e-3
+                counts[tok] += 1
+                n += 1
+        # pool the tail so that every cell expects >= 5 draws
+        big = np.argsort(-prob)[:6]
+        exp_big = n * prob[big]
+        obs = np.append(counts[big], n - counts[big].sum())
+        exp = np.append(exp_big, n - exp_big.sum())
+        cells = exp >= 5
+        chi2 = float(((obs[cells] - exp[cells]) ** 2 / exp[cells]).sum())
+        assert chi2 < 30.0, (temp, topp, obs, exp)   # <= 6 degrees of freedom: p < 4e-5
+
+
 @pytest.mark.parametrize("ct", ["float32", "int8"])
 @pytest.mark.parametrize("beam", [1, 4])
 def test_target_prefix_matches_reference(gpu, ct, beam):
@@ -328,3 +386,53 @@ def test_target_prefix_matches_reference(gpu, ct, beam):
         assert sum(same) >= len(same) - 2
         ok = np.array(same)
         np.testing.assert_allclose(scores[ok, 0], np.array(run["scores"], np.float32)[ok], atol=2e-2)
+
+
+PROCESSOR_CASES = ["plain", "penalty", "penalty_lt1", "ngram1", "ngram2", "ngram3", "suppress", "all"]
+
+
+@pytest.mark.parametrize("ct", ["float32", "int8"])
+@pytest.mark.parametrize("beam", [1, 4])
+@pytest.mark.parametrize("case", PROCESSOR_CASES)
+def test_logits_processors_match_reference(gpu, ct, beam, case):
+    """repetition_penalty / no_repeat_ngram_size / suppress_sequences (make_logits_processors,
+    src/decoding.cc:1091-1120; src/decoding_utils.cc) in greedy and beam search against the real
+    reference (tests/golden/make_golden_processors.py). Greedy applies them on the device from
+    the device-resident id history inside the step graph; beam search from the host histories."""
+    with open(os.path.join(GOLDEN, "processors_golden.json")) as f:
+        g = json.load(f)["small" + ("_f32" if ct == "float32" else "")]
+    run = g["runs"]["%s_beam%d" % (case, beam)]
+    t = get_translator(gpu, "small", ct)
+    hyps, scores = t.translate_ids(g["sources"], beam_size=beam, max_decoding_length=g["max_len"],
+                                   min_decoding_length=g["min_len"], return_scores=True,
+                                   length_penalty=1.0, **run["options"])
+    got = [h[0] for h in hyps]
+    same = [a == b for a, b in zip(got, run["hypotheses"])]
+    print("processors %s %s beam %d: %d/%d token-identical" % (case, ct, beam, sum(same), len(same)))
+    opts = run["options"]
+    for h in got:  # the constraints hold whatever the model does
+        n = opts.get("no_repeat_ngram_size", 0)
+        if n:
+            grams = [tuple(h[i:i + n]) for i in range(len(h) - n + 1)]
+            assert len(grams) == len(set(grams))
+        for q in opts.get("suppress_sequences_ids", []):
+            assert not any(h[i:i + len(q)] == q for i in range(len(h) - len(q) + 1))
+    if ct == "float32":
+        assert all(same)
+        np.testing.assert_allclose(scores[:, 0], np.array(run["scores"], np.float32), atol=1e-3)
+    else:
+        assert sum(same) >= len(same) - 2
+        ok = np.array(same)
+        np.testing.assert_allclose(scores[ok, 0], np.array(run["scores"], np.float32)[ok], atol=2e-2)
+
+
+def test_logits_processors_eager_equals_graph(gpu):
+    """The processor launch is part of the captured decode step: graph replay == eager."""
+    with open(os.path.join(GOLDEN, "processors_golden.json")) as f:
+        g = json.load(f)["small"]
+    t = get_translator(gpu, "small", "int8")
+    kw = dict(beam_size=1, max_decoding_length=g["max_len"], min_decoding_length=g["min_len"],
+              repetition_penalty=1.3, no_repeat_ngram_size=2)
+    a, _ = t.translate_ids(g["sources"], use_graph=True, **kw)
+    b, _ = t.translate_ids(g["sources"], use_graph=False, **kw)
+    assert a == b
