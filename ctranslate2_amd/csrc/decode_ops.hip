@@ -26,6 +26,9 @@ struct SamplePrefix {
 // separate advance_step kernel). Every workgroup reads *step_ptr at its start and the counter is
 // only written once ALL rows have finished, so no row can observe the incremented value; the
 // kernel boundary publishes it to the next step's kernels. Called by thread 0 of each row.
+// No fence: nothing written here is read again inside this launch (an agent-scope fence on
+// gfx950 writes back and invalidates the XCD's whole L2 - measured 2x on the decode step when
+// every workgroup of a launch executes one).
 struct StepAdvance {
   int32_t* step_ptr;  // nullptr: the caller advances the step itself
   int32_t* done;      // zero between launches
@@ -33,7 +36,6 @@ struct StepAdvance {
 
 __device__ __forceinline__ void row_finished(const StepAdvance& adv, int64_t rows, int step) {
   if (adv.step_ptr == nullptr) return;
-  __threadfence();
   if (atomicAdd(adv.done, 1) == static_cast<int>(rows) - 1) {
     *adv.done = 0;
     *adv.step_ptr = step + 1;
