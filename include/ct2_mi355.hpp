@@ -1,0 +1,416 @@
+// C++ host API of the MI355X backend: the surface of ctranslate2::Translator / ctranslate2::Generator
+// (include/ctranslate2/translator.h:26-60, generator.h:10-30, translation.h:11-135,
+// generation.h:12-110) restated over the C ABI of ct2_mi355.h, header only. An application
+// written against the reference replaces
+//     ctranslate2::Translator t(path, Device::CUDA, ComputeType::INT8, {0});
+// by
+//     ct2_mi355::Translator   t(path, Device::CUDA, ComputeType::INT8, {0});
+// and keeps its calls: option and result members carry the reference's names, defaults and
+// meaning, errors are std::invalid_argument / std::runtime_error as in the reference. Options the
+// backend does not implement are present (so code compiles unchanged) and rejected with
+// std::invalid_argument when they are set to a non-default value - nothing is silently ignored.
+// There is no CPU arm: Device::CPU throws.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ct2_mi355.h"
+
+namespace ct2_mi355 {
+
+// include/ctranslate2/devices.h:9-12 - Device::CUDA is the (HIP) GPU, as in the reference's own
+// ROCm build.
+enum class Device { CPU, CUDA };
+
+// include/ctranslate2/types.h:26-37 (the subset with a GPU arm here)
+enum class ComputeType { DEFAULT, AUTO, FLOAT32, INT8, INT8_FLOAT32, INT8_FLOAT16, INT8_BFLOAT16, FLOAT16, BFLOAT16 };
+
+inline const char* compute_type_name(ComputeType t) {
+  switch (t) {
+    case ComputeType::DEFAULT: return "default";
+    case ComputeType::AUTO: return "auto";
+    case ComputeType::FLOAT32: return "float32";
+    case ComputeType::INT8: return "int8";
+    case ComputeType::INT8_FLOAT32: return "int8_float32";
+    case ComputeType::INT8_FLOAT16: return "int8_float16";
+    case ComputeType::INT8_BFLOAT16: return "int8_bfloat16";
+    case ComputeType::FLOAT16: return "float16";
+    case ComputeType::BFLOAT16: return "bfloat16";
+  }
+  return "default";
+}
+
+// translation.h:11-96
+struct TranslationOptions {
+  size_t beam_size = 2;
+  float patience = 1;
+  float length_penalty = 1;
+  float coverage_penalty = 0;            // not built (needs attention weights): must stay 0
+  float repetition_penalty = 1;
+  size_t no_repeat_ngram_size = 0;
+  bool disable_unk = false;
+  std::vector<std::vector<std::string>> suppress_sequences;
+  float prefix_bias_beta = 0;            // not built: must stay 0
+  bool return_end_token = false;
+  size_t max_input_length = 1024;
+  size_t max_decoding_length = 256;
+  size_t min_decoding_length = 1;
+  size_t sampling_topk = 1;              // 0 = the whole vocabulary, otherwise <= 64 here
+  float sampling_topp = 1;
+  float sampling_temperature = 1;
+  size_t num_hypotheses = 1;
+  bool return_scores = false;
+  bool return_attention = false;         // not built: must stay false
+  bool return_alternatives = false;      // not built: must stay false
+  bool replace_unknowns = false;         // not built: must stay false
+  // backend additions
+  unsigned int seed = 0;                 // random sampling is reproducible for a seed
+  bool use_graph = true;                 // replay decode steps from a hipGraph
+};
+
+// translation.h:98-135
+struct TranslationResult {
+  std::vector<std::vector<std::string>> hypotheses;
+  std::vector<float> scores;
+
+  const std::vector<std::string>& output() const {
+    if (hypotheses.empty()) throw std::runtime_error("This result is empty");
+    return hypotheses[0];
+  }
+  float score() const {
+    if (scores.empty()) throw std::runtime_error("This result has no scores");
+    return scores[0];
+  }
+  size_t num_hypotheses() const { return hypotheses.size(); }
+  bool has_scores() const { return !scores.empty(); }
+};
+
+// generation.h:12-76
+struct GenerationOptions {
+  size_t beam_size = 1;
+  float patience = 1;
+  float length_penalty = 1;
+  float repetition_penalty = 1;
+  size_t no_repeat_ngram_size = 0;
+  bool disable_unk = false;
+  std::vector<std::vector<std::string>> suppress_sequences;
+  bool return_end_token = false;
+  size_t max_length = 512;
+  size_t min_length = 0;
+  size_t sampling_topk = 1;
+  float sampling_topp = 1;
+  float sampling_temperature = 1;
+  size_t num_hypotheses = 1;             // 1 only
+  bool return_scores = false;
+  bool return_alternatives = false;      // not built: must stay false
+  std::vector<std::string> static_prompt;
+  bool cache_static_prompt = true;       // accepted; the prompt is simply forwarded
+  bool include_prompt_in_result = true;
+  unsigned int seed = 0;
+  bool use_graph = true;
+};
+
+// generation.h:78-110
+struct GenerationResult {
+  std::vector<std::vector<std::string>> sequences;
+  std::vector<std::vector<size_t>> sequences_ids;
+  std::vector<float> scores;
+  size_t num_sequences() const { return sequences.size(); }
+  bool has_scores() const { return !scores.empty(); }
+};
+
+namespace detail {
+
+inline void check(int rc) {
+  if (rc != 0) throw std::runtime_error(ct2x_last_error());
+}
+
+inline void reject(bool set, const char* what) {
+  if (set) throw std::invalid_argument(std::string(what) + " is not supported by the MI355X backend");
+}
+
+// Owns the C handle of one model on one device.
+class Handle {
+public:
+  Handle(const std::string& model_path, Device device, ComputeType compute_type,
+         const std::vector<int>& device_indices) {
+    if (device != Device::CUDA)
+      throw std::invalid_argument("the MI355X backend has no CPU arm: use Device::CUDA");
+    if (device_indices.size() != 1)
+      throw std::invalid_argument("one device index per Translator/Generator (one process per GPU; "
+                                  "see ct2x_translator_create_tp for tensor parallelism)");
+    h_ = ct2x_translator_create(model_path.c_str(), device_indices[0], compute_type_name(compute_type));
+    if (!h_) throw std::runtime_error(ct2x_last_error());
+    int32_t s2s = 0, vocab = 0, d = 0, layers = 0, heads = 0, bos = 0, eos = 0;
+    char ct[32];
+    check(ct2x_model_info(h_, &s2s, &vocab, &d, &layers, &heads, &bos, &eos, ct, sizeof(ct)));
+    is_seq2seq_ = s2s != 0;
+    compute_type_ = ct;
+  }
+  ~Handle() {
+    if (h_) ct2x_translator_destroy(h_);
+  }
+  Handle(const Handle&) = delete;
+  Handle& operator=(const Handle&) = delete;
+
+  void* get() const { return h_; }
+  bool is_seq2seq() const { return is_seq2seq_; }
+  const std::string& compute_type() const { return compute_type_; }
+
+  // Vocabulary::to_id / to_token (include/ctranslate2/vocabulary.h:16-70); which: 0 source, 1 target
+  int32_t to_id(int which, const std::string& token) const {
+    return ct2x_vocab_id(h_, which, token.c_str());
+  }
+  std::string to_token(int which, int32_t id) const {
+    const char* t = ct2x_vocab_token(h_, which, id);
+    if (!t) throw std::runtime_error(ct2x_last_error());
+    return t;
+  }
+
+private:
+  void* h_ = nullptr;
+  bool is_seq2seq_ = false;
+  std::string compute_type_;
+};
+
+// Ragged token batch -> padded id matrix.
+struct IdBatch {
+  std::vector<int32_t> ids, lengths;
+  int32_t stride = 1;
+};
+
+inline IdBatch to_ids(const Handle& h, int which, const std::vector<std::vector<std::string>>& batch) {
+  IdBatch out;
+  size_t longest = 1;
+  for (const auto& s : batch) longest = std::max(longest, s.size());
+  out.stride = static_cast<int32_t>(longest);
+  out.ids.assign(batch.size() * longest, 0);
+  out.lengths.resize(batch.size());
+  for (size_t b = 0; b < batch.size(); ++b) {
+    out.lengths[b] = static_cast<int32_t>(batch[b].size());
+    for (size_t t = 0; t < batch[b].size(); ++t) out.ids[b * longest + t] = h.to_id(which, batch[b][t]);
+  }
+  return out;
+}
+
+// suppress_sequences + disable_unk -> the id lists of ct2x_translation_options
+struct Suppressed {
+  std::vector<int32_t> ids, lengths;
+};
+
+inline Suppressed suppressed_ids(const Handle& h, int which,
+                                 const std::vector<std::vector<std::string>>& sequences,
+                                 bool disable_unk) {
+  Suppressed s;
+  for (const auto& seq : sequences) {
+    if (seq.empty()) continue;
+    for (const auto& token : seq) s.ids.push_back(h.to_id(which, token));
+    s.lengths.push_back(static_cast<int32_t>(seq.size()));
+  }
+  if (disable_unk) {  // Vocabulary::unk_id(): the id an unknown token maps to
+    s.ids.push_back(h.to_id(which, "<unk>"));
+    s.lengths.push_back(1);
+  }
+  return s;
+}
+
+inline void set_processors(ct2x_translation_options& o, float repetition_penalty,
+                           size_t no_repeat_ngram_size, const Suppressed& s) {
+  o.repetition_penalty = repetition_penalty;
+  o.no_repeat_ngram_size = static_cast<int32_t>(no_repeat_ngram_size);
+  o.num_suppress_sequences = static_cast<int32_t>(s.lengths.size());
+  o.suppress_ids = s.ids.empty() ? nullptr : s.ids.data();
+  o.suppress_lengths = s.lengths.empty() ? nullptr : s.lengths.data();
+}
+
+inline int32_t sampling_topk_field(size_t topk) {
+  // the C struct keeps 0 = arg-max for zero-initialised options; -1 = the whole vocabulary
+  return topk == 0 ? -1 : static_cast<int32_t>(topk);
+}
+
+}  // namespace detail
+
+// ctranslate2::Translator (include/ctranslate2/translator.h:26-60)
+class Translator {
+public:
+  Translator(const std::string& model_path, Device device = Device::CUDA,
+             ComputeType compute_type = ComputeType::DEFAULT,
+             const std::vector<int>& device_indices = {0})
+      : h_(model_path, device, compute_type, device_indices) {
+    if (!h_.is_seq2seq())
+      throw std::invalid_argument("The model is not a sequence-to-sequence model: use Generator");
+  }
+
+  std::vector<TranslationResult>
+  translate_batch(const std::vector<std::vector<std::string>>& source,
+                  const TranslationOptions& options = TranslationOptions(),
+                  size_t max_batch_size = 0) {
+    return translate_batch(source, {}, options, max_batch_size);
+  }
+
+  std::vector<TranslationResult>
+  translate_batch(const std::vector<std::vector<std::string>>& source,
+                  const std::vector<std::vector<std::string>>& target_prefix,
+                  const TranslationOptions& options = TranslationOptions(),
+                  size_t max_batch_size = 0) {
+    detail::reject(options.coverage_penalty != 0, "coverage_penalty");
+    detail::reject(options.prefix_bias_beta != 0, "prefix_bias_beta");
+    detail::reject(options.return_attention, "return_attention");
+    detail::reject(options.return_alternatives, "return_alternatives");
+    detail::reject(options.replace_unknowns, "replace_unknowns");
+    if (!target_prefix.empty() && target_prefix.size() != source.size())
+      throw std::invalid_argument("Batch size mismatch: got " + std::to_string(source.size()) +
+                                  " for source and " + std::to_string(target_prefix.size()) +
+                                  " for target_prefix");
+    const size_t batch = source.size();
+    if (batch == 0) return {};
+
+    ct2x_translation_options o;
+    ct2x_translation_options_default(&o);
+    o.beam_size = static_cast<int32_t>(options.beam_size);
+    o.patience = options.patience;
+    o.length_penalty = options.length_penalty;
+    o.return_end_token = options.return_end_token;
+    o.max_input_length = static_cast<int32_t>(options.max_input_length);
+    o.max_decoding_length = static_cast<int32_t>(options.max_decoding_length);
+    o.min_decoding_length = static_cast<int32_t>(options.min_decoding_length);
+    o.sampling_topk = detail::sampling_topk_field(options.sampling_topk);
+    o.sampling_topp = options.sampling_topp;
+    o.sampling_temperature = options.sampling_temperature;
+    o.num_hypotheses = static_cast<int32_t>(options.num_hypotheses);
+    o.return_scores = options.return_scores;
+    o.max_batch_size = static_cast<int32_t>(max_batch_size);
+    o.seed = options.seed;
+    o.use_graph = options.use_graph;
+    const detail::Suppressed sup =
+        detail::suppressed_ids(h_, 1, options.suppress_sequences, options.disable_unk);
+    detail::set_processors(o, options.repetition_penalty, options.no_repeat_ngram_size, sup);
+
+    const detail::IdBatch src = detail::to_ids(h_, 0, source);
+    const size_t hyp = options.num_hypotheses, len = options.max_decoding_length;
+    std::vector<int32_t> out(batch * hyp * len, 0), out_len(batch * hyp, 0);
+    std::vector<float> scores(batch * hyp, 0.f);
+    if (target_prefix.empty()) {
+      detail::check(ct2x_translate_batch(h_.get(), src.ids.data(), src.lengths.data(),
+                                         static_cast<int32_t>(batch), src.stride, &o, out.data(),
+                                         out_len.data(), scores.data()));
+    } else {
+      const detail::IdBatch pfx = detail::to_ids(h_, 1, target_prefix);
+      detail::check(ct2x_translate_batch_prefix(h_.get(), src.ids.data(), src.lengths.data(),
+                                                static_cast<int32_t>(batch), src.stride,
+                                                pfx.ids.data(), pfx.lengths.data(), pfx.stride, &o,
+                                                out.data(), out_len.data(), scores.data()));
+    }
+    std::vector<TranslationResult> results(batch);
+    for (size_t b = 0; b < batch; ++b) {
+      for (size_t k = 0; k < hyp; ++k) {
+        const int32_t n = out_len[b * hyp + k];
+        if (k > 0 && n == 0) continue;  // fewer finished hypotheses than requested
+        std::vector<std::string> tokens;
+        for (int32_t t = 0; t < n; ++t) tokens.push_back(h_.to_token(1, out[(b * hyp + k) * len + t]));
+        results[b].hypotheses.push_back(std::move(tokens));
+        if (options.return_scores) results[b].scores.push_back(scores[b * hyp + k]);
+      }
+    }
+    return results;
+  }
+
+  // ExecutionStats-like counters of the last call (include/ctranslate2/translator.h:9-13)
+  ct2x_exec_stats last_stats() const {
+    ct2x_exec_stats st;
+    detail::check(ct2x_last_stats(h_.get(), &st));
+    return st;
+  }
+  const std::string& compute_type() const { return h_.compute_type(); }
+
+private:
+  detail::Handle h_;
+};
+
+// ctranslate2::Generator (include/ctranslate2/generator.h:10-30)
+class Generator {
+public:
+  Generator(const std::string& model_path, Device device = Device::CUDA,
+            ComputeType compute_type = ComputeType::DEFAULT,
+            const std::vector<int>& device_indices = {0})
+      : h_(model_path, device, compute_type, device_indices) {
+    if (h_.is_seq2seq())
+      throw std::invalid_argument("The model is a sequence-to-sequence model: use Translator");
+  }
+
+  std::vector<GenerationResult>
+  generate_batch(const std::vector<std::vector<std::string>>& start_tokens,
+                 const GenerationOptions& options = GenerationOptions()) {
+    detail::reject(options.return_alternatives, "return_alternatives");
+    detail::reject(options.num_hypotheses != 1, "num_hypotheses > 1 in generate_batch");
+    const size_t batch = start_tokens.size();
+    if (batch == 0) return {};
+    // static_prompt + start_tokens is what the model consumes (language_model.cc:184-206)
+    std::vector<std::vector<std::string>> prompts(batch);
+    for (size_t b = 0; b < batch; ++b) {
+      prompts[b] = options.static_prompt;
+      prompts[b].insert(prompts[b].end(), start_tokens[b].begin(), start_tokens[b].end());
+      if (prompts[b].empty()) throw std::invalid_argument("a prompt needs at least one token");
+    }
+
+    ct2x_translation_options o;
+    ct2x_translation_options_default(&o);
+    o.beam_size = static_cast<int32_t>(options.beam_size);
+    o.patience = options.patience;
+    o.length_penalty = options.length_penalty;
+    o.return_end_token = options.return_end_token;
+    o.max_decoding_length = static_cast<int32_t>(options.max_length);
+    o.min_decoding_length = static_cast<int32_t>(options.min_length);
+    o.sampling_topk = detail::sampling_topk_field(options.sampling_topk);
+    o.sampling_topp = options.sampling_topp;
+    o.sampling_temperature = options.sampling_temperature;
+    o.num_hypotheses = 1;
+    o.return_scores = options.return_scores;
+    o.max_input_length = 0;
+    o.seed = options.seed;
+    o.use_graph = options.use_graph;
+    const detail::Suppressed sup =
+        detail::suppressed_ids(h_, 1, options.suppress_sequences, options.disable_unk);
+    detail::set_processors(o, options.repetition_penalty, options.no_repeat_ngram_size, sup);
+
+    const detail::IdBatch in = detail::to_ids(h_, 1, prompts);
+    const size_t len = options.max_length;
+    std::vector<int32_t> out(batch * len, 0), out_len(batch, 0);
+    std::vector<float> scores(batch, 0.f);
+    detail::check(ct2x_generate_batch(h_.get(), in.ids.data(), in.lengths.data(),
+                                      static_cast<int32_t>(batch), in.stride, &o, out.data(),
+                                      out_len.data(), scores.data()));
+    std::vector<GenerationResult> results(batch);
+    for (size_t b = 0; b < batch; ++b) {
+      std::vector<std::string> tokens;
+      std::vector<size_t> ids;
+      if (options.include_prompt_in_result) {
+        tokens = start_tokens[b];
+        for (int32_t t = static_cast<int32_t>(options.static_prompt.size()); t < in.lengths[b]; ++t)
+          ids.push_back(static_cast<size_t>(in.ids[b * in.stride + t]));
+      }
+      for (int32_t t = 0; t < out_len[b]; ++t) {
+        const int32_t id = out[b * len + t];
+        ids.push_back(static_cast<size_t>(id));
+        tokens.push_back(h_.to_token(1, id));
+      }
+      results[b].sequences.push_back(std::move(tokens));
+      results[b].sequences_ids.push_back(std::move(ids));
+      if (options.return_scores) results[b].scores.push_back(scores[b]);
+    }
+    return results;
+  }
+
+  const std::string& compute_type() const { return h_.compute_type(); }
+
+private:
+  detail::Handle h_;
+};
+
+}  // namespace ct2_mi355

@@ -1,0 +1,69 @@
+// Test program of the C++ host API (include/ct2_mi355.hpp): the reference's own usage example
+// (README "C++" section / tests/translator_test.cc:53-97) with the namespace swapped.
+//   api_example translate <model_dir> <beam> <token> ...      -> hypothesis tokens + score
+//   api_example generate  <model_dir> <max_length> <token> ... -> generated tokens
+//   api_example reject    <model_dir>                          -> an unsupported option must throw
+// Exit code 0 on success, 2 when the backend reports an error (printed on stderr).
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "ct2_mi355.hpp"
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: api_example translate|generate|reject <model_dir> ...\n");
+    return 1;
+  }
+  const std::string mode = argv[1], model = argv[2];
+  try {
+    if (mode == "translate") {
+      ct2_mi355::Translator translator(model, ct2_mi355::Device::CUDA, ct2_mi355::ComputeType::DEFAULT, {0});
+      ct2_mi355::TranslationOptions options;
+      options.beam_size = static_cast<size_t>(std::atoi(argv[3]));
+      options.return_scores = true;
+      const std::vector<std::vector<std::string>> batch = {std::vector<std::string>(argv + 4, argv + argc)};
+      const auto results = translator.translate_batch(batch, options);
+      for (const auto& token : results[0].output()) std::cout << token << ' ';
+      std::cout << "| " << results[0].score() << " | " << translator.compute_type() << std::endl;
+      // target prefix: the first two tokens of the hypothesis must come back as its prefix
+      const auto& hyp = results[0].output();
+      if (hyp.size() >= 2) {
+        const std::vector<std::vector<std::string>> prefix = {{hyp[0], hyp[1]}};
+        const auto again = translator.translate_batch(batch, prefix, options);
+        if (again[0].output() != hyp) {
+          std::fprintf(stderr, "target_prefix changed the hypothesis\n");
+          return 3;
+        }
+      }
+    } else if (mode == "generate") {
+      ct2_mi355::Generator generator(model, ct2_mi355::Device::CUDA);
+      ct2_mi355::GenerationOptions options;
+      options.max_length = static_cast<size_t>(std::atoi(argv[3]));
+      options.include_prompt_in_result = false;
+      const std::vector<std::vector<std::string>> batch = {std::vector<std::string>(argv + 4, argv + argc)};
+      const auto results = generator.generate_batch(batch, options);
+      for (const auto& token : results[0].sequences[0]) std::cout << token << ' ';
+      std::cout << std::endl;
+    } else if (mode == "reject") {
+      ct2_mi355::Translator translator(model);
+      ct2_mi355::TranslationOptions options;
+      options.return_attention = true;
+      try {
+        translator.translate_batch({{"a"}}, options);
+      } catch (const std::invalid_argument& e) {
+        std::cout << "rejected: " << e.what() << std::endl;
+        return 0;
+      }
+      return 4;
+    } else {
+      return 1;
+    }
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 2;
+  }
+  return 0;
+}

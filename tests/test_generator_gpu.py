@@ -164,3 +164,16 @@ def test_generator_beam_search_matches_reference(gpu, key, ct):
         assert sum(same) >= len(same) - 2
         ok = np.array(same)
         np.testing.assert_allclose(scores[ok], np.array(b["scores"], np.float32)[ok], atol=2e-2)
+
+
+def test_cpp_api_generator(gpu):
+    """The C++ host API (include/ct2_mi355.hpp: Generator::generate_batch) returns what the id-level
+    entry point returns."""
+    import _cppapi
+    t = get_lm("lm_tiny", "float32")
+    prompt = [5, 9, 13, 7]
+    ids, _ = t.generate_ids([prompt], max_length=8)
+    rc, out, err = _cppapi.run("generate", "/tmp/ct2x_test_lm_tiny", 8,
+                               *[t.id_to_token(i) for i in prompt])
+    assert rc == 0, err
+    assert out.split() == [t.id_to_token(i) for i in ids[0]]

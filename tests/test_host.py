@@ -102,3 +102,17 @@ def test_corrupt_model_is_rejected(tmp_path):
     (d / "model.bin").write_bytes(src[:5000])
     assert L.ct2x_inspect_model(str(d).encode(), None, 0, None, None, None) < 0
     assert L.ct2x_inspect_model(str(tmp_path / "missing").encode(), None, 0, None, None, None) < 0
+
+
+def test_cpp_api_header_builds_and_fails_loudly_without_gpu():
+    """include/ct2_mi355.hpp (the ctranslate2::Translator / Generator surface over the C ABI)
+    compiles warning-free with plain g++ and links against the in-tree library; with no GPU the
+    constructor throws the HIP error - there is no CPU arm to fall back to."""
+    import torch
+    import _cppapi
+    _cppapi.build()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rc, out, err = _cppapi.run("translate", os.path.join(GOLDEN, "models", "aren-transliteration-i8"),
+                               2, "a")
+    assert rc == 2 and "HIP" in err and out == ""

@@ -436,3 +436,21 @@ def test_logits_processors_eager_equals_graph(gpu):
     a, _ = t.translate_ids(g["sources"], use_graph=True, **kw)
     b, _ = t.translate_ids(g["sources"], use_graph=False, **kw)
     assert a == b
+
+
+def test_cpp_api_translator(gpu):
+    """The C++ host API (include/ct2_mi355.hpp: Translator::translate_batch with the reference's
+    option / result names) on the reference's transliteration KAT (tests/translator_test.cc:53-97),
+    incl. translate_batch(source, target_prefix) and the rejection of unsupported options."""
+    import _cppapi
+    model = os.path.join(GOLDEN, "models", "aren-transliteration-i8")
+    rc, out, err = _cppapi.run("translate", model, 2, *GC.AREN_SOURCES[0])
+    assert rc == 0, err
+    tokens, score, compute_type = [s.strip() for s in out.strip().split("|")]
+    assert tokens.split() == ["a", "t", "z", "m", "o", "n"]
+    assert compute_type == "int8_float32" and float(score) < 0
+    t = get_translator(gpu, "aren-transliteration-i8")
+    want = t.translate_batch([GC.AREN_SOURCES[0]], beam_size=2, return_scores=True)[0]
+    assert abs(float(score) - want.scores[0]) < 1e-4
+    rc, out, err = _cppapi.run("reject", model)
+    assert rc == 0 and "return_attention" in out, (out, err)
