@@ -352,8 +352,27 @@ int ct2x_topk(const void* d_x, int dtype, int64_t rows, int64_t depth, int64_t k
   API_TRY
   require_f32(dtype, "ct2x_topk");
   CT2X_CHECK(k >= 1 && k <= depth, "ct2x_topk: k must be in [1, depth]");
+  // scratch of the two-launch form: one grow-only buffer per calling thread (= per stream),
+  // like the temporaries ops::TopK takes from the allocator (src/ops/topk_gpu.cu:35-53)
+  struct Scratch {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    ~Scratch() {
+      try { if (ptr) device_free(ptr); } catch (...) {}
+    }
+  };
+  static thread_local Scratch scratch;
+  const size_t need = topk_workspace_bytes(rows, depth, k);
+  if (need > scratch.bytes) {
+    if (scratch.ptr) {  // an earlier launch of this thread may still read the old block
+      CT2X_HIP_CHECK(hipStreamSynchronize(resolve_stream(stream)));
+      device_free(scratch.ptr);
+    }
+    scratch.ptr = device_malloc(need);
+    scratch.bytes = need;
+  }
   launch_topk(static_cast<const float*>(d_x), rows, depth, k, static_cast<float*>(d_values),
-              d_indices, resolve_stream(stream));
+              d_indices, resolve_stream(stream), scratch.ptr, scratch.bytes);
   check_last_launch("topk");
   API_CATCH
 }

@@ -574,4 +574,119 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
                      beam_scores, vocab, disable_id, min_length, step_ptr, y);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device side of one beam-search step after TopK (src/decoding.cc:559-700): unflatten the
+// 2*beam candidates of a batch entry, apply the hard target prefix (update_sample_with_prefix,
+// beam arm, :21-66), record them for the host's hypothesis bookkeeping, and choose the beams of
+// the next step exactly as the reference does (:596-676: a candidate among the first `beam` that
+// ended is replaced by the next secondary candidate that did not) - ids, cumulative scores and
+// parent rows for the cache reorder never leave the device, so consecutive steps can be queued
+// (and replayed from a hipGraph) without a host round trip. The host replays the same rule on
+// the recorded candidates later (decoding.cc beam_search) to build the hypotheses.
+// One workgroup (64 lanes) per batch entry; 2 * beam <= 64.
+// ---------------------------------------------------------------------------------------------
+struct BeamSelectParams {
+  const float* topk_scores;   // [batch, 2*beam] descending
+  const int32_t* topk_ids;    // [batch, 2*beam] flat (beam * vocab + word)
+  int32_t beam, vocab, eos;
+  const int32_t* prefix_ids;  // [batch, prefix_stride] or nullptr
+  const int32_t* prefix_lens; // [batch]
+  int32_t prefix_stride;
+  const int32_t* step_ptr;
+  int32_t first_step;
+  // history of candidates: [step - first_step][batch, 2*beam]
+  int32_t* hist_word;
+  float* hist_score;
+  int32_t* hist_origin;
+  // next step
+  int32_t* next_ids;          // [batch*beam]
+  int32_t* parents;           // [batch*beam] parent row
+  float* beam_scores;         // [batch*beam]
+  // generated tokens per active beam (for the logits processors), ping-pong; may be nullptr
+  const int32_t* seq_src;     // [batch*beam, seq_stride]
+  int32_t* seq_dst;
+  int32_t seq_stride;
+};
+
+__global__ __launch_bounds__(64) void beam_select_kernel(BeamSelectParams p) {
+  __shared__ int32_t s_word[64], s_origin[64], s_next[32];
+  __shared__ float s_score[64];
+  const int b = blockIdx.x, j = threadIdx.x;
+  const int nc = 2 * p.beam;
+  const int step = *p.step_ptr - p.first_step;
+  const int plen = p.prefix_ids ? p.prefix_lens[b] : 0;
+  if (j < nc) {
+    const int32_t flat = p.topk_ids[b * nc + j];
+    int32_t origin = flat / p.vocab, word = flat % p.vocab;   // unflatten_ids, :95-116
+    float sc = p.topk_scores[b * nc + j];
+    if (p.prefix_ids && step <= plen) {
+      if (step < plen) {        // inside the prefix: every candidate is the prefix token
+        word = p.prefix_ids[b * p.prefix_stride + step];
+        sc = (j == 0) ? 0.f : -1e10f;
+        origin = 0;
+      } else if (j > 0 && word == p.eos) {   // first free step: no EOS in a secondary candidate
+        word = 0;
+        sc = -1e10f;
+        origin = 0;
+      }
+    }
+    s_word[j] = word;
+    s_origin[j] = origin;
+    s_score[j] = sc;
+    const int64_t h = (static_cast<int64_t>(step) * gridDim.x + b) * nc + j;
+    p.hist_word[h] = word;
+    p.hist_score[h] = sc;
+    p.hist_origin[h] = origin;
+  }
+  __syncthreads();
+  if (j == 0) {
+    int secondary = p.beam;
+    for (int k = 0; k < p.beam; ++k) {
+      int next = k;
+      if (s_word[k] == p.eos && step >= plen) {
+        for (int c = secondary; c < nc; ++c) {
+          if (s_word[c] != p.eos) {
+            next = c;
+            secondary = c + 1;
+            break;
+          }
+        }
+      }
+      s_next[k] = next;
+    }
+  }
+  __syncthreads();
+  if (j < p.beam) {
+    const int c = s_next[j];
+    const int row = b * p.beam + j;
+    p.next_ids[row] = s_word[c];
+    p.beam_scores[row] = s_score[c];
+    p.parents[row] = b * p.beam + s_origin[c];
+  }
+  if (p.seq_dst != nullptr) {
+    // append_step_output + gather_beam_flat (:588, :686): beam k inherits its parent's tokens
+    for (int k = 0; k < p.beam; ++k) {
+      const int c = s_next[k];
+      const int32_t* src = p.seq_src + static_cast<int64_t>(b * p.beam + s_origin[c]) * p.seq_stride;
+      int32_t* dst = p.seq_dst + static_cast<int64_t>(b * p.beam + k) * p.seq_stride;
+      for (int t = j; t < step; t += 64) dst[t] = src[t];
+      if (j == 0 && step < p.seq_stride) dst[step] = s_word[c];
+    }
+  }
+}
+
+void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64_t batch,
+                        int32_t beam, int64_t vocab, int32_t eos, const int32_t* prefix_ids,
+                        const int32_t* prefix_lens, int32_t prefix_stride, const int32_t* step_ptr,
+                        int32_t first_step, int32_t* hist_word, float* hist_score,
+                        int32_t* hist_origin, int32_t* next_ids, int32_t* parents,
+                        float* beam_scores, const int32_t* seq_src, int32_t* seq_dst,
+                        int32_t seq_stride, hipStream_t stream) {
+  if (batch == 0) return;
+  const BeamSelectParams p{topk_scores, topk_ids, beam, static_cast<int32_t>(vocab), eos, prefix_ids,
+                           prefix_lens, prefix_stride, step_ptr, first_step, hist_word, hist_score,
+                           hist_origin, next_ids, parents, beam_scores, seq_src, seq_dst, seq_stride};
+  hipLaunchKernelGGL(beam_select_kernel, dim3(batch), dim3(64), 0, stream, p);
+}
+
 }  // namespace ct2x

@@ -193,6 +193,13 @@ BeamStepOutput beam_step_select(const BeamStepInput& in) {
 // BeamSearch::search (src/decoding.cc:425-720) on the GPU arm of the reference: the batch is
 // expanded before the first step (expand_after_first_step is CPU-only, :453-454) and secondary
 // beams start at lowest() (:84-93).
+// The step itself - log-softmax + beam scores, TopK, hard prefix, candidate selection, cache
+// reorder - runs on the device (Engine::launch_step with fuse_beam, beam_select_kernel) and
+// records its 2*beam candidates per batch entry; steps are queued `sync_every` at a time like the
+// greedy loop. The host reads the recorded candidates one group behind and replays the
+// reference's bookkeeping on them (which hypotheses finished, which candidates stay alive,
+// when a sentence is complete). Finished sentences keep stepping on the device (static batch);
+// their rows are ignored.
 std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
                                         const std::vector<int32_t>& start_ids, int32_t end_id,
                                         const DecodingOptions& opt, DecodeStats* stats,
@@ -205,7 +212,6 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   const int64_t rows = batch * beam;
   if (rows != st.rows || st.beam != beam)
     throw std::runtime_error("beam_search: state/batch size mismatch");
-  const int64_t vocab = engine.vocab_size();
   const size_t max_candidates = static_cast<size_t>(std::llround(float(beam) * opt.patience));
   const bool allow_early_exit = (opt.length_penalty == 0);
 
@@ -213,147 +219,120 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   std::vector<char> finished(batch, 0), top_beam_finished(batch, 0);
   int64_t remaining = batch;
 
-  std::vector<int32_t> next_ids(rows), parents(rows);
-  std::vector<float> beam_scores(rows);
-  for (int64_t i = 0; i < batch; ++i)
-    for (int32_t k = 0; k < beam; ++k) {
-      next_ids[i * beam + k] = start_ids[i];
-      beam_scores[i * beam + k] = (k == 0) ? 0.f : -FLT_MAX;  // numeric_limits<float>::lowest()
-    }
-  engine.set_ids(st, next_ids.data());
-  engine.set_step(st, opt.start_step);
-  engine.set_beam_scores(st, beam_scores.data());
+  {
+    std::vector<int32_t> first_ids(rows);
+    std::vector<float> beam_scores(rows);
+    for (int64_t i = 0; i < batch; ++i)
+      for (int32_t k = 0; k < beam; ++k) {
+        first_ids[i * beam + k] = start_ids[i];
+        beam_scores[i * beam + k] = (k == 0) ? 0.f : -FLT_MAX;  // numeric_limits<float>::lowest()
+      }
+    engine.set_ids(st, first_ids.data());
+    engine.set_step(st, opt.start_step);
+    engine.set_beam_scores(st, beam_scores.data());
+  }
   st.fuse_greedy = false;
+  st.fuse_beam = true;
+  st.g_eos = end_id;
+  st.g_min_length = opt.start_step + opt.min_length;  // device step counts from start_step
   engine.set_logits_processing(st, opt.logits_processing);
-  const bool processing = opt.logits_processing.active();
-  std::vector<int32_t> flat_seq;
+  if (prefix_ids)
+    engine.set_beam_prefix(st, *prefix_ids, opt.start_step);
+  else
+    engine.set_beam_prefix(st, {}, opt.start_step);
 
   // alive_seq[i][k]: tokens of active beam k of batch i.
   std::vector<std::vector<std::vector<int32_t>>> alive_seq(
       batch, std::vector<std::vector<int32_t>>(beam));
-  std::vector<float> cand_scores(batch * num_candidates);
-  std::vector<int32_t> cand_flat(batch * num_candidates);
-  std::vector<int32_t> cand_word(num_candidates), cand_origin(num_candidates);
-  const int32_t min_length_abs = opt.start_step + opt.min_length;
 
-  int64_t step = 0;
-  for (; step < opt.max_length && remaining > 0; ++step) {
-    engine.step(st, opt.use_graph);
-    if (processing) {
-      // merge_batch_beam(alive_seq) (src/decoding.cc:518-525): every active beam has `step` tokens
-      flat_seq.assign(static_cast<size_t>(rows) * step, 0);
-      for (int64_t i = 0; i < batch; ++i)
-        for (int32_t k = 0; k < beam; ++k) {
-          const auto& seq = alive_seq[i][k];
-          if (static_cast<int64_t>(seq.size()) == step)
-            std::copy(seq.begin(), seq.end(), flat_seq.begin() + (i * beam + k) * step);
-        }
-      engine.process_logits_beam(st, flat_seq.data(), static_cast<int32_t>(step));
-    }
-    engine.beam_candidates(st, end_id, min_length_abs, cand_scores.data(), cand_flat.data());
-    const bool last = (step + 1 == opt.max_length);
+  const int64_t max_step = opt.max_length;
+  const int64_t sync_every = std::max<int32_t>(1, opt.sync_every);
+  int64_t launched = 0, step = 0;
+  struct Group { int64_t first, count; int slot; };
+  std::vector<Group> inflight;
+  int next_slot = 0;
+  auto launch_group = [&]() {
+    const int64_t target = std::min(max_step, launched + sync_every);
+    if (target == launched) return false;
+    Group g{launched, target - launched, next_slot};
+    for (; launched < target; ++launched) engine.step(st, opt.use_graph);
+    engine.read_beam_history_async(st, g.first, g.count, g.slot);
+    next_slot ^= 1;
+    inflight.push_back(g);
+    return true;
+  };
 
-    for (int64_t i = 0; i < batch; ++i) {
-      if (finished[i]) {
-        for (int32_t k = 0; k < beam; ++k) {
-          parents[i * beam + k] = static_cast<int32_t>(i * beam + k);
-          // ids / scores of finished batches are irrelevant: keep the rows computable.
-          next_ids[i * beam + k] = end_id;
-          beam_scores[i * beam + k] = 0.f;
-        }
-        continue;
-      }
-      float* sc = cand_scores.data() + i * num_candidates;
-      const int32_t* flat = cand_flat.data() + i * num_candidates;
-      // unflatten_ids (src/decoding.cc:95-116)
-      for (int32_t j = 0; j < num_candidates; ++j) {
-        cand_origin[j] = static_cast<int32_t>(flat[j] / vocab);
-        cand_word[j] = static_cast<int32_t>(flat[j] % vocab);
-      }
-      // update_sample_with_prefix, beam arm (src/decoding.cc:21-66): inside the prefix every
-      // candidate becomes the prefix token, only the first keeps a live score (0: the prefix does
-      // not count) and all descend from beam 0; at the first free step an EOS in a secondary
-      // candidate is neutralised.
-      const int64_t plen = prefix_ids ? static_cast<int64_t>((*prefix_ids)[i].size()) : 0;
-      if (prefix_ids && step <= plen) {
+  launch_group();
+  while (!inflight.empty() && remaining > 0) {
+    if (inflight.size() < 2) launch_group();  // keep the device busy while this group is replayed
+    const Group g = inflight.front();
+    inflight.erase(inflight.begin());
+    const int32_t* h_word = nullptr;
+    const float* h_score = nullptr;
+    const int32_t* h_origin = nullptr;
+    engine.wait_beam_history(st, g.slot, &h_word, &h_score, &h_origin);
+    for (int64_t s = 0; s < g.count && remaining > 0; ++s, ++step) {
+      const bool last = (step + 1 == opt.max_length);
+      for (int64_t i = 0; i < batch; ++i) {
+        if (finished[i]) continue;
+        // candidates as the device selected from them: unflattened, hard prefix applied
+        const int64_t base = (s * batch + i) * num_candidates;
+        const int32_t* cand_word = h_word + base;
+        const int32_t* cand_origin = h_origin + base;
+        const float* sc = h_score + base;
+        const int64_t plen = prefix_ids ? static_cast<int64_t>((*prefix_ids)[i].size()) : 0;
+        // append_step_output: every candidate inherits its origin beam's history + its word.
+        std::vector<std::vector<int32_t>> cand_seq(num_candidates);
         for (int32_t j = 0; j < num_candidates; ++j) {
-          if (step < plen) {
-            cand_word[j] = (*prefix_ids)[i][step];
-            sc[j] = (j == 0) ? 0.f : -1e10f;
-            cand_origin[j] = 0;
-          } else if (j > 0 && cand_word[j] == end_id) {
-            cand_word[j] = 0;
-            sc[j] = -1e10f;
-            cand_origin[j] = 0;
-          }
+          cand_seq[j] = alive_seq[i][cand_origin[j]];
+          cand_seq[j].push_back(cand_word[j]);
         }
-      }
-      // append_step_output: every candidate inherits its origin beam's history + its word.
-      std::vector<std::vector<int32_t>> cand_seq(num_candidates);
-      for (int32_t j = 0; j < num_candidates; ++j) {
-        cand_seq[j] = alive_seq[i][cand_origin[j]];
-        cand_seq[j].push_back(cand_word[j]);
-      }
 
-      BeamStepInput in;
-      in.beam_size = beam;
-      in.step = static_cast<int32_t>(step);
-      in.is_last_step = last;
-      in.end_id = end_id;
-      in.word_ids = cand_word.data();
-      in.scores = sc;
-      in.prefix_length = static_cast<int32_t>(plen);
-      const BeamStepOutput sel = beam_step_select(in);
+        BeamStepInput in;
+        in.beam_size = beam;
+        in.step = static_cast<int32_t>(step);
+        in.is_last_step = last;
+        in.end_id = end_id;
+        in.word_ids = cand_word;
+        in.scores = sc;
+        in.prefix_length = static_cast<int32_t>(plen);
+        const BeamStepOutput sel = beam_step_select(in);
 
-      DecodingResult& result = results[i];
-      for (int32_t k : sel.finished) {
-        if (k == 0) top_beam_finished[i] = 1;
-        const bool ignore_last = (cand_word[k] == end_id) && !opt.include_eos_in_hypotheses;
-        std::vector<int32_t> hyp = cand_seq[k];
-        if (ignore_last) hyp.pop_back();
-        result.scores.push_back(sc[k]);
-        result.hypotheses.emplace_back(std::move(hyp));
-      }
-
-      bool is_finished = false;
-      if (last)
-        is_finished = true;
-      else if (allow_early_exit)
-        is_finished = top_beam_finished[i] &&
-                      result.hypotheses.size() >= static_cast<size_t>(opt.num_hypotheses);
-      else
-        is_finished = result.hypotheses.size() >= max_candidates;
-
-      if (is_finished) {
-        finalize(result, opt.num_hypotheses, opt.length_penalty, opt.return_scores);
-        finished[i] = 1;
-        --remaining;
-        for (int32_t k = 0; k < beam; ++k) {
-          parents[i * beam + k] = static_cast<int32_t>(i * beam + k);
-          next_ids[i * beam + k] = end_id;
-          beam_scores[i * beam + k] = 0.f;
+        DecodingResult& result = results[i];
+        for (int32_t k : sel.finished) {
+          if (k == 0) top_beam_finished[i] = 1;
+          const bool ignore_last = (cand_word[k] == end_id) && !opt.include_eos_in_hypotheses;
+          std::vector<int32_t> hyp = cand_seq[k];
+          if (ignore_last) hyp.pop_back();
+          result.scores.push_back(sc[k]);
+          result.hypotheses.emplace_back(std::move(hyp));
         }
-        continue;
-      }
 
-      std::vector<std::vector<int32_t>> new_alive(beam);
-      for (int32_t k = 0; k < beam; ++k) {
-        const int32_t j = sel.next[k];
-        new_alive[k] = std::move(cand_seq[j]);
-        next_ids[i * beam + k] = cand_word[j];
-        beam_scores[i * beam + k] = sc[j];
-        parents[i * beam + k] = static_cast<int32_t>(i * beam + cand_origin[j]);
-        // a candidate selected twice cannot happen: `next` indices are distinct by construction
-      }
-      alive_seq[i] = std::move(new_alive);
-    }
+        bool is_finished = false;
+        if (last)
+          is_finished = true;
+        else if (allow_early_exit)
+          is_finished = top_beam_finished[i] &&
+                        result.hypotheses.size() >= static_cast<size_t>(opt.num_hypotheses);
+        else
+          is_finished = result.hypotheses.size() >= max_candidates;
 
-    if (remaining == 0) {
-      ++step;
-      break;
+        if (is_finished) {
+          finalize(result, opt.num_hypotheses, opt.length_penalty, opt.return_scores);
+          finished[i] = 1;
+          --remaining;
+          continue;
+        }
+
+        // the device made the same choice (beam_select_kernel); keep the host copy of the tokens
+        std::vector<std::vector<int32_t>> new_alive(beam);
+        for (int32_t k = 0; k < beam; ++k) new_alive[k] = std::move(cand_seq[sel.next[k]]);
+        alive_seq[i] = std::move(new_alive);
+      }
     }
-    engine.beam_update(st, next_ids.data(), parents.data(), beam_scores.data());
   }
+  engine.synchronize();  // drain a speculative group before the state is torn down
+  st.fuse_beam = false;
   if (stats) stats->steps = step;
   return results;
 }

@@ -108,6 +108,36 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// (value descending, index ascending) arg-max of a wave in two DPP reductions: the maximum, then
+// the lowest index among the lanes that hold it. Empty slots are (v = -inf, i = INT_MAX): a real
+// entry with the same value always has the lower index, so it wins (as in better()).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_move_i32(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, kCtrl, kRowMask, 0xf, false);
+}
+__device__ __forceinline__ ValIdx wave_argmax_dpp(ValIdx x) {
+  const float ninf = -__builtin_huge_valf();
+  float m = x.v;
+  m = fmaxf(m, dpp_move<0x111, 0xf>(ninf, m));
+  m = fmaxf(m, dpp_move<0x112, 0xf>(ninf, m));
+  m = fmaxf(m, dpp_move<0x114, 0xf>(ninf, m));
+  m = fmaxf(m, dpp_move<0x118, 0xf>(ninf, m));
+  m = fmaxf(m, dpp_move<0x142, 0xa>(ninf, m));
+  m = fmaxf(m, dpp_move<0x143, 0xc>(ninf, m));
+  m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+  int c = (x.v == m) ? x.i : 0x7fffffff;
+  c = min(c, dpp_move_i32<0x111, 0xf>(0x7fffffff, c));
+  c = min(c, dpp_move_i32<0x112, 0xf>(0x7fffffff, c));
+  c = min(c, dpp_move_i32<0x114, 0xf>(0x7fffffff, c));
+  c = min(c, dpp_move_i32<0x118, 0xf>(0x7fffffff, c));
+  c = min(c, dpp_move_i32<0x142, 0xa>(0x7fffffff, c));
+  c = min(c, dpp_move_i32<0x143, 0xc>(0x7fffffff, c));
+  ValIdx r;
+  r.v = m;
+  r.i = __builtin_amdgcn_readlane(c, 63);
+  return r;
+}
+
 __device__ __forceinline__ float apply_activation(float v, int act) {
   switch (act) {
     case 0:  // ReLU

@@ -879,6 +879,10 @@ DecodeState::~DecodeState() {
     if (pin_ids[i]) (void)hipHostFree(pin_ids[i]);
     if (pin_scores[i]) (void)hipHostFree(pin_scores[i]);
     if (pin_event[i]) (void)hipEventDestroy(pin_event[i]);
+    if (pin_cand_word[i]) (void)hipHostFree(pin_cand_word[i]);
+    if (pin_cand_score[i]) (void)hipHostFree(pin_cand_score[i]);
+    if (pin_cand_origin[i]) (void)hipHostFree(pin_cand_origin[i]);
+    if (pin_cand_event[i]) (void)hipEventDestroy(pin_cand_event[i]);
   }
   if (graph) (void)hipGraphDestroy(graph);
   for (void* p : owned) {
@@ -966,6 +970,13 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     st->topk_scores = alloc<float>(*st, batch * 2 * beam);
     st->topk_ids = alloc<int32_t>(*st, batch * 2 * beam);
     st->d_parents = alloc<int32_t>(*st, rows);
+    CT2X_CHECK(2 * beam <= 64, "beam_size must be <= 32");
+    st->topk_ws_bytes = topk_workspace_bytes(batch, beam * V, 2 * beam);
+    if (st->topk_ws_bytes) st->topk_ws = alloc<char>(*st, static_cast<int64_t>(st->topk_ws_bytes));
+    const int64_t cand = (t_max + 1) * batch * 2 * beam;
+    st->hist_cand_word = alloc<int32_t>(*st, cand);
+    st->hist_cand_score = alloc<float>(*st, cand);
+    st->hist_cand_origin = alloc<int32_t>(*st, cand);
   }
 
   const int n_layers = static_cast<int>(dec_.layers.size());
@@ -1491,6 +1502,47 @@ void Engine::launch_step(DecodeState& st) {
     }
     // the sampler's last row advanced d_step (decode_ops.hip: row_finished)
   }
+
+  if (st.fuse_beam) {
+    // The rest of a beam-search step (src/decoding.cc:507-700) on the device.
+    const int64_t V = dec_.projection.n;
+    const int par = st.cur;
+    if (st.lp_active) {
+      begin_kernel("process_logits");
+      launch_process_logits(st.logits, st.rows, V, st.alive_seq[par], 1, st.t_max, st.d_step,
+                            st.prefix_first_step, 0, static_cast<int32_t>(st.t_max), st.lp_penalty,
+                            st.lp_ngram, st.d_sup_ids, st.d_sup_off, st.lp_n_sup, cur_stream());
+      end_kernel();
+    }
+    begin_kernel("beam_logprobs", double(st.rows) * V * 12, 0, st.rows, 0, V);
+    launch_beam_logprobs(st.logits, st.beam_scores, st.rows, V, st.g_eos, st.g_min_length,
+                         st.d_step, st.logprobs, cur_stream());
+    end_kernel();
+    begin_kernel("beam_topk", double(st.rows) * V * 4, 0, st.batch, 2 * st.beam, st.beam * V);
+    launch_topk(st.logprobs, st.batch, st.beam * V, 2 * st.beam, st.topk_scores, st.topk_ids,
+                cur_stream(), st.topk_ws, st.topk_ws_bytes);
+    end_kernel();
+    begin_kernel("beam_select");
+    launch_beam_select(st.topk_scores, st.topk_ids, st.batch, static_cast<int32_t>(st.beam), V,
+                       st.g_eos, st.d_bprefix, st.d_bprefix_len, st.bprefix_stride, st.d_step,
+                       st.prefix_first_step, st.hist_cand_word, st.hist_cand_score,
+                       st.hist_cand_origin, st.d_ids, st.d_parents, st.beam_scores,
+                       st.lp_active ? st.alive_seq[par] : nullptr,
+                       st.lp_active ? st.alive_seq[par ^ 1] : nullptr,
+                       static_cast<int32_t>(st.t_max), cur_stream());
+    end_kernel();
+    // Positions [0, step] are live; the gather copies the positions below the advanced counter.
+    begin_kernel("advance_step");
+    launch_advance_step(st.d_step, cur_stream());
+    end_kernel();
+    const AttnW& a0 = dec_.layers.front().self;
+    const int n_tensors = static_cast<int>(2 * dec_.layers.size());
+    begin_kernel("cache_gather");
+    launch_cache_gather(par == 0 ? st.d_cache_src : st.d_cache_src_alt,
+                        par == 0 ? st.d_cache_dst : st.d_cache_dst_alt, n_tensors, st.d_parents,
+                        st.rows, a0.heads_kv, st.t_max, a0.dhead, st.d_step, 0, cur_stream());
+    end_kernel();
+  }
 }
 
 void Engine::step(DecodeState& st, bool graph) {
@@ -1507,6 +1559,7 @@ void Engine::step(DecodeState& st, bool graph) {
     launch_step(st);
     kernels_per_step_ = launch_counter_ - before;
     check_last_launch("decoder step");
+    if (st.fuse_beam) st.cur ^= 1;  // the step reordered the caches into the other buffer set
     return;
   }
   const int parity = st.cur;
@@ -1529,6 +1582,7 @@ void Engine::step(DecodeState& st, bool graph) {
     st.graph_ready[parity] = true;
   }
   CT2X_HIP_CHECK(hipGraphLaunch(st.graph_exec[parity], cur_stream()));
+  if (st.fuse_beam) st.cur ^= 1;
 }
 
 void Engine::sample_greedy(DecodeState& st, int32_t eos_id, int32_t min_length,
@@ -1545,40 +1599,68 @@ void Engine::advance_step(DecodeState& st) {
   launch_advance_step(st.d_step, cur_stream());
 }
 
-void Engine::beam_candidates(DecodeState& st, int32_t eos_id, int32_t min_length,
-                             float* h_scores, int32_t* h_ids) {
+void Engine::read_beam_history_async(DecodeState& st, int64_t first, int64_t count, int slot) {
   tls_stream = st.stream;
-  const int64_t V = dec_.projection.n;
-  launch_beam_logprobs(st.logits, st.beam_scores, st.rows, V, eos_id, min_length, st.d_step,
-                       st.logprobs, cur_stream());
-  const int64_t k = 2 * st.beam;
-  launch_topk(st.logprobs, st.batch, st.beam * V, k, st.topk_scores, st.topk_ids, cur_stream());
-  check_last_launch("beam candidates");
-  CT2X_HIP_CHECK(hipMemcpyAsync(h_scores, st.topk_scores, sizeof(float) * st.batch * k,
-                                hipMemcpyDeviceToHost, cur_stream()));
-  CT2X_HIP_CHECK(hipMemcpyAsync(h_ids, st.topk_ids, sizeof(int32_t) * st.batch * k,
-                                hipMemcpyDeviceToHost, cur_stream()));
-  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+  const int64_t per_step = st.batch * 2 * st.beam;
+  const int64_t need = count * per_step;
+  if (st.pin_cand_capacity < need) {
+    for (int i = 0; i < 2; ++i) {
+      if (st.pin_cand_word[i]) (void)hipHostFree(st.pin_cand_word[i]);
+      if (st.pin_cand_score[i]) (void)hipHostFree(st.pin_cand_score[i]);
+      if (st.pin_cand_origin[i]) (void)hipHostFree(st.pin_cand_origin[i]);
+      CT2X_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.pin_cand_word[i]), need * sizeof(int32_t)));
+      CT2X_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.pin_cand_score[i]), need * sizeof(float)));
+      CT2X_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.pin_cand_origin[i]), need * sizeof(int32_t)));
+      if (!st.pin_cand_event[i])
+        CT2X_HIP_CHECK(hipEventCreateWithFlags(&st.pin_cand_event[i], hipEventDisableTiming));
+    }
+    st.pin_cand_capacity = need;
+  }
+  const int64_t off = first * per_step;
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.pin_cand_word[slot], st.hist_cand_word + off,
+                                sizeof(int32_t) * need, hipMemcpyDeviceToHost, cur_stream()));
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.pin_cand_score[slot], st.hist_cand_score + off,
+                                sizeof(float) * need, hipMemcpyDeviceToHost, cur_stream()));
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.pin_cand_origin[slot], st.hist_cand_origin + off,
+                                sizeof(int32_t) * need, hipMemcpyDeviceToHost, cur_stream()));
+  CT2X_HIP_CHECK(hipEventRecord(st.pin_cand_event[slot], cur_stream()));
 }
 
-void Engine::beam_update(DecodeState& st, const int32_t* h_next_ids, const int32_t* h_parents,
-                         const float* h_scores) {
+void Engine::wait_beam_history(DecodeState& st, int slot, const int32_t** h_words,
+                               const float** h_scores, const int32_t** h_origins) {
+  CT2X_HIP_CHECK(hipEventSynchronize(st.pin_cand_event[slot]));
+  *h_words = st.pin_cand_word[slot];
+  *h_scores = st.pin_cand_score[slot];
+  *h_origins = st.pin_cand_origin[slot];
+}
+
+void Engine::set_beam_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>& prefix,
+                             int32_t first_step) {
   tls_stream = st.stream;
-  CT2X_HIP_CHECK(hipMemcpyAsync(st.d_ids, h_next_ids, sizeof(int32_t) * st.rows,
-                                hipMemcpyHostToDevice, cur_stream()));
-  CT2X_HIP_CHECK(hipMemcpyAsync(st.d_parents, h_parents, sizeof(int32_t) * st.rows,
-                                hipMemcpyHostToDevice, cur_stream()));
-  CT2X_HIP_CHECK(hipMemcpyAsync(st.beam_scores, h_scores, sizeof(float) * st.rows,
-                                hipMemcpyHostToDevice, cur_stream()));
-  // Positions [0, step] are live at this point (the step counter has not advanced yet).
-  launch_advance_step(st.d_step, cur_stream());
-  const AttnW& a = dec_.layers.front().self;
-  const int n_tensors = static_cast<int>(2 * dec_.layers.size());
-  launch_cache_gather(st.cur == 0 ? st.d_cache_src : st.d_cache_src_alt,
-                      st.cur == 0 ? st.d_cache_dst : st.d_cache_dst_alt, n_tensors, st.d_parents,
-                      st.rows, a.heads_kv, st.t_max, a.dhead, st.d_step, 0, cur_stream());
-  st.cur ^= 1;
-  check_last_launch("beam update");
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  st.prefix_first_step = first_step;
+  st.d_bprefix = st.d_bprefix_len = nullptr;
+  st.bprefix_stride = 0;
+  size_t longest = 0;
+  for (const auto& p : prefix) longest = std::max(longest, p.size());
+  if (longest == 0) return;
+  CT2X_CHECK(static_cast<int64_t>(prefix.size()) == st.batch, "set_beam_prefix: one prefix per batch entry");
+  std::vector<int32_t> ids(static_cast<size_t>(st.batch) * longest, 0), lens(st.batch, 0);
+  for (int64_t b = 0; b < st.batch; ++b) {
+    lens[b] = static_cast<int32_t>(prefix[b].size());
+    std::copy(prefix[b].begin(), prefix[b].end(), ids.begin() + b * longest);
+  }
+  auto upload_i32 = [&](const std::vector<int32_t>& v) {
+    void* p = device_malloc(v.size() * sizeof(int32_t));
+    st.owned.push_back(p);
+    CT2X_HIP_CHECK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                                  cur_stream()));
+    return static_cast<int32_t*>(p);
+  };
+  st.d_bprefix = upload_i32(ids);
+  st.d_bprefix_len = upload_i32(lens);
+  st.bprefix_stride = static_cast<int32_t>(longest);
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // the host vectors go out of scope
 }
 
 void Engine::set_beam_scores(DecodeState& st, const float* h_scores) {
@@ -1710,26 +1792,13 @@ void Engine::set_logits_processing(DecodeState& st, const LogitsProcessing& lp) 
     st.d_sup_ids = upload_i32(ids);
     st.d_sup_off = upload_i32(off);
   }
-  if (st.beam > 1 && st.d_seq == nullptr) {
-    st.d_seq = static_cast<int32_t*>(device_malloc(sizeof(int32_t) * st.rows * st.t_max));
-    st.owned.push_back(st.d_seq);
+  if (st.beam > 1 && st.alive_seq[0] == nullptr) {
+    for (int i = 0; i < 2; ++i) {
+      st.alive_seq[i] = static_cast<int32_t*>(device_malloc(sizeof(int32_t) * st.rows * st.t_max));
+      st.owned.push_back(st.alive_seq[i]);
+    }
   }
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // the host vectors go out of scope
-}
-
-void Engine::process_logits_beam(DecodeState& st, const int32_t* h_seq, int32_t length) {
-  if (!st.lp_active) return;
-  tls_stream = st.stream;
-  CT2X_CHECK(st.d_seq != nullptr && length <= st.t_max, "process_logits_beam: no staging buffer");
-  if (length > 0)
-    CT2X_HIP_CHECK(hipMemcpyAsync(st.d_seq, h_seq, sizeof(int32_t) * st.rows * length,
-                                  hipMemcpyHostToDevice, cur_stream()));
-  launch_process_logits(st.logits, st.rows, dec_.projection.n, st.d_seq, 1, length, nullptr, 0,
-                        length, static_cast<int32_t>(st.t_max), st.lp_penalty, st.lp_ngram,
-                        st.d_sup_ids, st.d_sup_off, st.lp_n_sup, cur_stream());
-  check_last_launch("process_logits");
-  // h_seq is pageable host memory owned by the caller: the copy has been staged when
-  // hipMemcpyAsync returns, and the next beam_candidates() synchronises the stream anyway.
 }
 
 void Engine::set_step(DecodeState& st, int32_t step) {

@@ -164,15 +164,21 @@ public:
   void sample_greedy(DecodeState& state, int32_t eos_id, int32_t min_length, bool with_scores);
   void advance_step(DecodeState& state);
 
-  // Beam search device legs (src/decoding.cc:545-562): log_softmax(logits)+beam score, then
-  // top-(2*beam) over the flattened [batch, beam*vocab] candidates. Results land in
-  // state.topk_scores / state.topk_ids (device) and are copied to the given host buffers.
-  void beam_candidates(DecodeState& state, int32_t eos_id, int32_t min_length,
-                       float* h_scores, int32_t* h_ids);
-  // Installs the host-selected next ids / parent rows / cumulative scores for the next step and
-  // reorders the self-attention caches (Decoder::update_state, src/layers/decoder.cc:33-56).
-  void beam_update(DecodeState& state, const int32_t* h_next_ids, const int32_t* h_parents,
-                   const float* h_scores);
+  // Beam search (src/decoding.cc:425-720) is device resident: with state.fuse_beam set (by
+  // decoding.cc) every step() ends with log_softmax + beam score, top-(2*beam) over the flattened
+  // [batch, beam*vocab] candidates, the reference's candidate selection, the cache reorder
+  // (Decoder::update_state, src/layers/decoder.cc:33-56) and the step advance - no host round
+  // trip. The candidates of every step are recorded; the host reads them in groups and replays
+  // the hypothesis bookkeeping.
+  // Copies `count` steps of recorded candidates starting at step `first` (relative to the first
+  // decoding step) into pinned slot `slot`: word ids, cumulative scores, origin beams, each
+  // [count][batch, 2*beam].
+  void read_beam_history_async(DecodeState& state, int64_t first, int64_t count, int slot);
+  void wait_beam_history(DecodeState& state, int slot, const int32_t** h_words,
+                         const float** h_scores, const int32_t** h_origins);
+  // Hard target prefix of beam search, one entry per BATCH element (empty = none).
+  void set_beam_prefix(DecodeState& state, const std::vector<std::vector<int32_t>>& prefix,
+                       int32_t first_step);
   // Initial cumulative scores (initialize_beam_scores, src/decoding.cc:84-93).
   void set_beam_scores(DecodeState& state, const float* h_scores);
 
@@ -194,11 +200,9 @@ public:
 
   // Logits processors of the decoding loop (make_logits_processors, src/decoding.cc:1091-1120):
   // installs them for every following step of `state`. Greedy steps apply them on the device
-  // from the device-resident id history (inside the step's graph); beam search calls
-  // process_logits_beam() with the alive sequences it keeps on the host.
+  // from the device-resident id history, beam steps from the device-resident tokens of the
+  // active beams (both inside the step's graph).
   void set_logits_processing(DecodeState& state, const LogitsProcessing& processing);
-  // h_seq: [rows, length] tokens generated so far by each active beam.
-  void process_logits_beam(DecodeState& state, const int32_t* h_seq, int32_t length);
 
   // Number of kernel launches recorded for one decoder step (reported by bench.py).
   int64_t kernels_per_step() const { return kernels_per_step_; }
@@ -332,6 +336,22 @@ struct DecodeState {
   float* topk_scores = nullptr;   // [batch, 2*beam]
   int32_t* topk_ids = nullptr;    // [batch, 2*beam]
   int32_t* d_parents = nullptr;   // [rows]
+  void* topk_ws = nullptr;        // scratch of the two-launch TopK
+  size_t topk_ws_bytes = 0;
+  // Device-resident beam step (set by decoding.cc): candidates of every step, [t_max + 1][batch,
+  // 2*beam], and the batch-level hard prefix.
+  bool fuse_beam = false;
+  int32_t* hist_cand_word = nullptr;
+  float* hist_cand_score = nullptr;
+  int32_t* hist_cand_origin = nullptr;
+  int32_t* d_bprefix = nullptr;      // [batch, bprefix_stride]
+  int32_t* d_bprefix_len = nullptr;  // [batch]
+  int32_t bprefix_stride = 0;
+  int32_t* pin_cand_word[2] = {nullptr, nullptr};
+  float* pin_cand_score[2] = {nullptr, nullptr};
+  int32_t* pin_cand_origin[2] = {nullptr, nullptr};
+  int64_t pin_cand_capacity = 0;
+  hipEvent_t pin_cand_event[2] = {nullptr, nullptr};
   // pinned host staging for the pipelined history read-back (greedy loop)
   int32_t* pin_ids[2] = {nullptr, nullptr};
   float* pin_scores[2] = {nullptr, nullptr};
@@ -353,7 +373,8 @@ struct DecodeState {
   int32_t lp_ngram = 0, lp_n_sup = 0;
   int32_t* d_sup_ids = nullptr;
   int32_t* d_sup_off = nullptr;
-  int32_t* d_seq = nullptr;    // [rows, t_max] staging of the beam histories
+  int32_t* alive_seq[2] = {nullptr, nullptr};  // beam search: tokens of the active beams,
+                                               // [rows, t_max], ping-pong with the cache parity
   // RandomSampler settings of the fused sampler (topk == 1: BestSampler / arg-max)
   int32_t g_topk = 1;
   float g_topp = 1.f, g_temperature = 1.f;

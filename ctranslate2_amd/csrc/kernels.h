@@ -54,8 +54,13 @@ void launch_rotary(const float* x, const float* sin, const float* cos, int64_t b
                    hipStream_t stream);
 
 // Top-k per row over `depth` columns (values desc; ties -> lowest index first).
+// Rows of >= 8192 columns take a two-launch form (per-chunk top-k, then merge) when the caller
+// provides topk_workspace_bytes() bytes of scratch; without it they fall back to one workgroup
+// per row.
+size_t topk_workspace_bytes(int64_t rows, int64_t depth, int64_t k);
 void launch_topk(const float* x, int64_t rows, int64_t depth, int64_t k, float* values,
-                 int32_t* indices, hipStream_t stream);
+                 int32_t* indices, hipStream_t stream, void* workspace = nullptr,
+                 size_t workspace_bytes = 0);
 
 void launch_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int64_t row_bytes,
                         void* out, hipStream_t stream);
@@ -273,6 +278,18 @@ void launch_process_logits(float* logits, int64_t rows, int64_t vocab, const int
                            int32_t first_step, int32_t length, int32_t max_length, float penalty,
                            int32_t ngram, const int32_t* sup_ids, const int32_t* sup_off,
                            int32_t n_sup, hipStream_t stream);
+
+// One beam-search step after TopK on the device (src/decoding.cc:559-700): unflatten, hard
+// prefix, record the candidates (hist_*[step - first_step][batch, 2*beam]) and install the next
+// step's ids / cumulative scores / parent rows. 2 * beam <= 64. seq_src/seq_dst (optional):
+// the tokens generated by each active beam, [batch*beam, seq_stride], ping-pong.
+void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64_t batch,
+                        int32_t beam, int64_t vocab, int32_t eos, const int32_t* prefix_ids,
+                        const int32_t* prefix_lens, int32_t prefix_stride, const int32_t* step_ptr,
+                        int32_t first_step, int32_t* hist_word, float* hist_score,
+                        int32_t* hist_origin, int32_t* next_ids, int32_t* parents,
+                        float* beam_scores, const int32_t* seq_src, int32_t* seq_dst,
+                        int32_t seq_stride, hipStream_t stream);
 
 // Beam-search scores: y[row, :] = log_softmax(x[row, :] with x[disable_id] = -FLT_MAX while
 // step < min_length) + beam_scores[row]   (src/decoding.cc:512-556).
