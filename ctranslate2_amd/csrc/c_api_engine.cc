@@ -562,8 +562,6 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   const int32_t longest_prefix = max_len_prompt - min_len_prompt;
   const double t0 = now_ms();
   t->last = ct2x_exec_stats{};
-  CT2X_CHECK(beam == 1 || longest_prefix == 0, "generate_batch: beam search needs prompts of one "
-             "length in this backend (a hard prefix is only forced by the greedy sampler)");
   const int64_t t_max = static_cast<int64_t>(forward_length) + longest_prefix + dopt.max_length + 1;
   // Beam search: every hypothesis row starts from the same prefilled prompt state; the prompt is
   // forwarded once per row (beam x the prefill work instead of a cache replication pass).
@@ -588,7 +586,8 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   dopt.return_prefix = false;  // include_prompt_in_result = false
   DecodeStats ds;
   std::vector<DecodingResult> results =
-      beam > 1 ? beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds)
+      beam > 1 ? beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds,
+                             longest_prefix > 0 ? &prefix : nullptr)
                : greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds,
                                longest_prefix > 0 ? &prefix : nullptr);
   t->engine->synchronize();

@@ -540,11 +540,15 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
                                      const float* __restrict__ beam_scores, int64_t vocab,
                                      int32_t disable_id, int32_t min_length,
                                      const int32_t* __restrict__ step_ptr,
+                                     const int32_t* __restrict__ extra_min, int32_t beam,
                                      float* __restrict__ y) {
   __shared__ float scratch[16];
   const int64_t row = blockIdx.x;
   const int step = *step_ptr;
-  const int masked = (step < min_length) ? disable_id : -1;
+  // apply_min_length with a hidden prefix (src/decoding.cc:384-408): EOS stays disabled
+  // prefix_length steps longer for that batch entry
+  const int row_min = min_length + (extra_min ? extra_min[row / beam] : 0);
+  const int masked = (step < row_min) ? disable_id : -1;
   const float* x = logits + row * vocab;
   float* yr = y + row * vocab;
   float m = -FLT_MAX;
@@ -566,12 +570,14 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
 
 void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t rows,
                           int64_t vocab, int32_t disable_id, int32_t min_length,
-                          const int32_t* step_ptr, float* y, hipStream_t stream) {
+                          const int32_t* step_ptr, float* y, hipStream_t stream,
+                          const int32_t* extra_min_per_batch, int32_t beam) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
   hipLaunchKernelGGL(beam_logprobs_kernel, dim3(rows), dim3(block), 0, stream, logits,
-                     beam_scores, vocab, disable_id, min_length, step_ptr, y);
+                     beam_scores, vocab, disable_id, min_length, step_ptr, extra_min_per_batch,
+                     beam > 0 ? beam : 1, y);
 }
 
 // ---------------------------------------------------------------------------------------------

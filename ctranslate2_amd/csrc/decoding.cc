@@ -206,8 +206,6 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
                                         const std::vector<std::vector<int32_t>>* prefix_ids) {
   const int64_t batch = static_cast<int64_t>(start_ids.size());
   const int32_t beam = opt.beam_size;
-  if (prefix_ids && !opt.return_prefix)
-    throw std::invalid_argument("beam search with a hidden prefix (generation) is not supported");
   const int32_t num_candidates = 2 * beam;
   const int64_t rows = batch * beam;
   if (rows != st.rows || st.beam != beam)
@@ -236,16 +234,24 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   st.g_eos = end_id;
   st.g_min_length = opt.start_step + opt.min_length;  // device step counts from start_step
   engine.set_logits_processing(st, opt.logits_processing);
-  if (prefix_ids)
-    engine.set_beam_prefix(st, *prefix_ids, opt.start_step);
-  else
+  // return_prefix == false (generation): the prefix is forced but hidden - it is not part of the
+  // hypotheses, and max_length / min_length count from its end (get_max_step, is_last_step,
+  // apply_min_length, src/decoding.cc:357-408).
+  const int64_t extra = opt.return_prefix ? 0 : 1;
+  int64_t longest_prefix = 0;
+  if (prefix_ids) {
+    for (const auto& pfx : *prefix_ids)
+      longest_prefix = std::max<int64_t>(longest_prefix, static_cast<int64_t>(pfx.size()));
+    engine.set_beam_prefix(st, *prefix_ids, opt.start_step, !opt.return_prefix);
+  } else {
     engine.set_beam_prefix(st, {}, opt.start_step);
+  }
 
   // alive_seq[i][k]: tokens of active beam k of batch i.
   std::vector<std::vector<std::vector<int32_t>>> alive_seq(
       batch, std::vector<std::vector<int32_t>>(beam));
 
-  const int64_t max_step = opt.max_length;
+  const int64_t max_step = opt.max_length + extra * longest_prefix;
   const int64_t sync_every = std::max<int32_t>(1, opt.sync_every);
   int64_t launched = 0, step = 0;
   struct Group { int64_t first, count; int slot; };
@@ -272,7 +278,6 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
     const int32_t* h_origin = nullptr;
     engine.wait_beam_history(st, g.slot, &h_word, &h_score, &h_origin);
     for (int64_t s = 0; s < g.count && remaining > 0; ++s, ++step) {
-      const bool last = (step + 1 == opt.max_length);
       for (int64_t i = 0; i < batch; ++i) {
         if (finished[i]) continue;
         // candidates as the device selected from them: unflattened, hard prefix applied
@@ -281,6 +286,7 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
         const int32_t* cand_origin = h_origin + base;
         const float* sc = h_score + base;
         const int64_t plen = prefix_ids ? static_cast<int64_t>((*prefix_ids)[i].size()) : 0;
+        const bool last = (step + 1 == opt.max_length + extra * plen);  // is_last_step
         // append_step_output: every candidate inherits its origin beam's history + its word.
         std::vector<std::vector<int32_t>> cand_seq(num_candidates);
         for (int32_t j = 0; j < num_candidates; ++j) {
@@ -302,8 +308,10 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
         for (int32_t k : sel.finished) {
           if (k == 0) top_beam_finished[i] = 1;
           const bool ignore_last = (cand_word[k] == end_id) && !opt.include_eos_in_hypotheses;
-          std::vector<int32_t> hyp = cand_seq[k];
-          if (ignore_last) hyp.pop_back();
+          // build_hypothesis(alive_seq, i, k, start, end): a hidden prefix is cut off
+          std::vector<int32_t> hyp(cand_seq[k].begin() + std::min<int64_t>(extra * plen, cand_seq[k].size()),
+                                   cand_seq[k].end());
+          if (ignore_last && !hyp.empty()) hyp.pop_back();
           result.scores.push_back(sc[k]);
           result.hypotheses.emplace_back(std::move(hyp));
         }

@@ -1516,7 +1516,9 @@ void Engine::launch_step(DecodeState& st) {
     }
     begin_kernel("beam_logprobs", double(st.rows) * V * 12, 0, st.rows, 0, V);
     launch_beam_logprobs(st.logits, st.beam_scores, st.rows, V, st.g_eos, st.g_min_length,
-                         st.d_step, st.logprobs, cur_stream());
+                         st.d_step, st.logprobs, cur_stream(),
+                         st.prefix_extends_min ? st.d_bprefix_len : nullptr,
+                         static_cast<int32_t>(st.beam));
     end_kernel();
     begin_kernel("beam_topk", double(st.rows) * V * 4, 0, st.batch, 2 * st.beam, st.beam * V);
     launch_topk(st.logprobs, st.batch, st.beam * V, 2 * st.beam, st.topk_scores, st.topk_ids,
@@ -1635,10 +1637,11 @@ void Engine::wait_beam_history(DecodeState& st, int slot, const int32_t** h_word
 }
 
 void Engine::set_beam_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>& prefix,
-                             int32_t first_step) {
+                             int32_t first_step, bool extends_min_length) {
   tls_stream = st.stream;
   CT2X_HIP_CHECK(hipSetDevice(device_));
   st.prefix_first_step = first_step;
+  st.prefix_extends_min = extends_min_length;
   st.d_bprefix = st.d_bprefix_len = nullptr;
   st.bprefix_stride = 0;
   size_t longest = 0;

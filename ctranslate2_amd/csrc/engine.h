@@ -177,8 +177,10 @@ public:
   void wait_beam_history(DecodeState& state, int slot, const int32_t** h_words,
                          const float** h_scores, const int32_t** h_origins);
   // Hard target prefix of beam search, one entry per BATCH element (empty = none).
+  // extends_min_length: the prefix is hidden (generation): EOS stays disabled prefix_length steps
+  // longer for that entry.
   void set_beam_prefix(DecodeState& state, const std::vector<std::vector<int32_t>>& prefix,
-                       int32_t first_step);
+                       int32_t first_step, bool extends_min_length = false);
   // Initial cumulative scores (initialize_beam_scores, src/decoding.cc:84-93).
   void set_beam_scores(DecodeState& state, const float* h_scores);
 

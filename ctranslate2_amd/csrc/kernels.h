@@ -293,8 +293,11 @@ void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64
 
 // Beam-search scores: y[row, :] = log_softmax(x[row, :] with x[disable_id] = -FLT_MAX while
 // step < min_length) + beam_scores[row]   (src/decoding.cc:512-556).
+// extra_min_per_batch (optional, [rows / beam]): added to min_length for the rows of that batch
+// entry (hidden hard prefix, apply_min_length with return_prefix = false).
 void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t rows,
                           int64_t vocab, int32_t disable_id, int32_t min_length,
-                          const int32_t* step_ptr, float* y, hipStream_t stream);
+                          const int32_t* step_ptr, float* y, hipStream_t stream,
+                          const int32_t* extra_min_per_batch = nullptr, int32_t beam = 1);
 
 }  // namespace ct2x

@@ -48,10 +48,20 @@ def main():
                 if suffix == "_f32" else eq_prompts
             gen, scores = m.generate_ids(eq_prompts, beam_size=4, max_len=cfg["max_len"],
                                          min_len=cfg["max_len"] // 2, return_scores=True)
+            # beam search over the RAGGED prompts: hard prefix in BeamSearch::search with
+            # return_prefix = false (hidden prefix; max length counts from its end). min_length = 0
+            # on purpose: with a hidden prefix the reference's apply_min_length disables EOS in the
+            # flattened rows 0..batch-1 of the [batch * beam, vocab] logits (disable_tokens.add(i,
+            # end_id) with i a BATCH index, src/decoding.cc:392-402), i.e. in the wrong rows - a
+            # quirk this backend does not reproduce (it disables EOS in every beam of the entry).
+            rgen, rscores = m.generate_ids(prompts, beam_size=4, max_len=cfg["max_len"],
+                                           min_len=0, return_scores=True)
             out[key + suffix] = {"prompts": prompts, "max_len": cfg["max_len"], "runs": runs,
                                  "compute_type": m.compute_type(),
                                  "beam4": {"prompts": eq_prompts, "min_len": cfg["max_len"] // 2,
-                                           "generated": gen, "scores": scores.tolist()}}
+                                           "generated": gen, "scores": scores.tolist()},
+                                 "beam4_ragged": {"min_len": 0, "generated": rgen,
+                                                  "scores": rscores.tolist()}}
             m.close()
     with open(os.path.join(HERE, "ragged_golden.json"), "w") as f:
         json.dump(out, f)
