@@ -768,4 +768,33 @@ int ct2x_inspect_variable(const char* model_dir, int32_t index, char* name, int 
   API_CATCH
 }
 
+int ct2x_host_beam_step_select(int32_t beam_size, int32_t step, int32_t is_last_step,
+                               int32_t end_id, int32_t prefix_length, const int32_t* word_ids,
+                               int32_t* finished, int32_t* next) {
+  try {
+    if (beam_size < 1 || !word_ids || !finished || !next)
+      throw std::invalid_argument("ct2x_host_beam_step_select: bad arguments");
+    BeamStepInput in;
+    in.beam_size = beam_size;
+    in.step = step;
+    in.is_last_step = is_last_step != 0;
+    in.end_id = end_id;
+    in.word_ids = word_ids;
+    in.prefix_length = prefix_length;
+    const BeamStepOutput out = beam_step_select(in);
+    for (int32_t k = 0; k < beam_size; ++k) {
+      finished[k] = k < static_cast<int32_t>(out.finished.size()) ? out.finished[k] : -1;
+      next[k] = out.next[k];
+    }
+    return static_cast<int>(out.finished.size());
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return -1;
+  }
+}
+
+float ct2x_host_finalize_score(float score, float length, float length_penalty) {
+  return finalize_score(score, length, length_penalty);
+}
+
 }  // extern "C"

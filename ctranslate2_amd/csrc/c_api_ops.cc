@@ -393,6 +393,23 @@ int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int3
   API_CATCH
 }
 
+int ct2x_beam_select(const float* d_topk_scores, const int32_t* d_topk_ids, int64_t batch,
+                     int32_t beam_size, int64_t vocab, int32_t end_id,
+                     const int32_t* d_prefix_ids, const int32_t* d_prefix_lens,
+                     int32_t prefix_stride, const int32_t* d_step, int32_t first_step,
+                     int32_t* d_cand_word, float* d_cand_score, int32_t* d_cand_origin,
+                     int32_t* d_next_ids, float* d_next_scores, int32_t* d_parents, void* stream) {
+  API_TRY
+  CT2X_CHECK(beam_size >= 1 && beam_size <= 32, "ct2x_beam_select: beam_size must be in [1, 32]");
+  CT2X_CHECK(d_step != nullptr, "ct2x_beam_select: the step counter is a device pointer");
+  launch_beam_select(d_topk_scores, d_topk_ids, batch, beam_size, vocab, end_id, d_prefix_ids,
+                     d_prefix_lens, prefix_stride, d_step, first_step, d_cand_word, d_cand_score,
+                     d_cand_origin, d_next_ids, d_parents, d_next_scores, nullptr, nullptr, 0,
+                     resolve_stream(stream));
+  check_last_launch("beam_select");
+  API_CATCH
+}
+
 int ct2x_gather_rows(const void* d_data, const int32_t* d_idx, int64_t n_idx,
                      int64_t row_bytes, void* d_out, void* stream) {
   API_TRY

@@ -220,6 +220,20 @@ int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int3
                         const int32_t* d_suppress_ids, const int32_t* d_suppress_offsets,
                         int32_t num_suppress, void* stream);
 
+/* One beam-search step after TopK on the device (BeamSearch::search, src/decoding.cc:559-700):
+ * unflatten_ids (:95-116), update_sample_with_prefix beam arm (:21-66), the candidate selection
+ * (:618-655). d_topk_* [batch, 2*beam]; d_prefix_ids [batch, prefix_stride] / d_prefix_lens
+ * [batch] may be NULL; d_step: device int32 = the absolute step, first_step is subtracted.
+ * Outputs: the candidates as selected from (d_cand_* [batch, 2*beam], written at step index
+ * step - first_step of those arrays) and per active beam the next input id, cumulative score
+ * and parent row. beam_size <= 32. */
+int ct2x_beam_select(const float* d_topk_scores, const int32_t* d_topk_ids, int64_t batch,
+                     int32_t beam_size, int64_t vocab, int32_t end_id,
+                     const int32_t* d_prefix_ids, const int32_t* d_prefix_lens,
+                     int32_t prefix_stride, const int32_t* d_step, int32_t first_step,
+                     int32_t* d_cand_word, float* d_cand_score, int32_t* d_cand_origin,
+                     int32_t* d_next_ids, float* d_next_scores, int32_t* d_parents, void* stream);
+
 /* ops::Gather::compute<Device::CUDA,T> axis 0 (src/ops/gather_gpu.cu:53-91):
  * out[i,:] = data[idx[i],:] for rows of row_bytes bytes. */
 int ct2x_gather_rows(const void* d_data, const int32_t* d_idx, int64_t n_idx,
@@ -406,6 +420,18 @@ int ct2x_inspect_model(const char* model_dir, char* spec_name, int spec_size,
 /* i-th variable of model.bin: name, dtype id, rank, dims (up to 8), payload bytes. */
 int ct2x_inspect_variable(const char* model_dir, int32_t index, char* name, int name_size,
                           int32_t* dtype, int32_t* rank, int64_t* dims, int64_t* nbytes);
+
+/* The host side of a beam-search step (the bookkeeping BeamSearch::search does on the TopK
+ * candidates, src/decoding.cc:596-676), as replayed by the decoding loop on the candidates the
+ * device recorded: which of the first beam_size candidates finished (EOS at step >= prefix_length,
+ * or the last step) and which candidate occupies each beam next. word_ids [2*beam_size];
+ * finished [beam_size] (candidate slots, -1 padded), next [beam_size]. Returns the number of
+ * finished candidates, <0 on error. */
+int ct2x_host_beam_step_select(int32_t beam_size, int32_t step, int32_t is_last_step,
+                               int32_t end_id, int32_t prefix_length, const int32_t* word_ids,
+                               int32_t* finished, int32_t* next);
+/* finalize_hypothesis_score without coverage penalty (src/decoding.cc:192-207). */
+float ct2x_host_finalize_score(float score, float length, float length_penalty);
 
 #ifdef __cplusplus
 }

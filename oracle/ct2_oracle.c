@@ -379,3 +379,61 @@ void orc_process_logits(float* logits, int64_t rows, int64_t vocab, const int32_
     }
   }
 }
+
+/* One beam-search step after TopK for `batch` entries (src/decoding.cc:559-700), the part the
+ * GPU backend keeps on the device:
+ *  - unflatten_ids (:95-116): word = flat % vocab, origin beam = flat / vocab;
+ *  - update_sample_with_prefix, beam arm (:21-66): while step < prefix length every candidate
+ *    becomes the prefix token, candidate 0 scores 0 and the others -1e10, origin beam 0; at
+ *    step == prefix length an EOS in a secondary candidate becomes (0, -1e10, origin 0);
+ *  - candidate selection (:618-655): a candidate k < beam that ended (EOS and step >= prefix
+ *    length) is replaced by the next secondary candidate (index >= beam, in order, each used
+ *    once) whose word is not EOS, otherwise it stays.
+ * Outputs: the modified candidates cand_* [batch, 2*beam], and per active beam [batch*beam] the
+ * next input id, cumulative score and parent row (batch_id * beam + origin). */
+void orc_beam_select(const float* topk_scores, const int32_t* topk_ids, int64_t batch,
+                     int32_t beam, int32_t vocab, int32_t eos, const int32_t* prefix_ids,
+                     const int32_t* prefix_lens, int32_t prefix_stride, int32_t step,
+                     int32_t* cand_word, float* cand_score, int32_t* cand_origin,
+                     int32_t* next_ids, float* next_scores, int32_t* parents) {
+  const int32_t nc = 2 * beam;
+  for (int64_t b = 0; b < batch; ++b) {
+    const int32_t plen = prefix_ids ? prefix_lens[b] : 0;
+    int32_t* w = cand_word + b * nc;
+    int32_t* o = cand_origin + b * nc;
+    float* sc = cand_score + b * nc;
+    for (int32_t j = 0; j < nc; ++j) {
+      const int32_t flat = topk_ids[b * nc + j];
+      w[j] = flat % vocab;
+      o[j] = flat / vocab;
+      sc[j] = topk_scores[b * nc + j];
+      if (prefix_ids && step <= plen) {
+        if (step < plen) {
+          w[j] = prefix_ids[b * prefix_stride + step];
+          sc[j] = (j == 0) ? 0.f : -1e10f;
+          o[j] = 0;
+        } else if (j > 0 && w[j] == eos) {
+          w[j] = 0;
+          sc[j] = -1e10f;
+          o[j] = 0;
+        }
+      }
+    }
+    int32_t secondary = beam;
+    for (int32_t k = 0; k < beam; ++k) {
+      int32_t next = k;
+      if (w[k] == eos && step >= plen) {
+        for (int32_t j = secondary; j < nc; ++j) {
+          if (w[j] != eos) {
+            next = j;
+            secondary = j + 1;
+            break;
+          }
+        }
+      }
+      next_ids[b * beam + k] = w[next];
+      next_scores[b * beam + k] = sc[next];
+      parents[b * beam + k] = (int32_t)(b * beam) + o[next];
+    }
+  }
+}

@@ -61,6 +61,14 @@ void orc_process_logits(float* logits, int64_t rows, int64_t vocab, const int32_
                         int32_t length, float penalty, int32_t ngram, const int32_t* sup_ids,
                         const int32_t* sup_off, int32_t n_sup);
 
+/* One beam-search step after TopK (src/decoding.cc:559-700): unflatten, hard prefix, candidate
+ * selection. */
+void orc_beam_select(const float* topk_scores, const int32_t* topk_ids, int64_t batch,
+                     int32_t beam, int32_t vocab, int32_t eos, const int32_t* prefix_ids,
+                     const int32_t* prefix_lens, int32_t prefix_stride, int32_t step,
+                     int32_t* cand_word, float* cand_score, int32_t* cand_origin,
+                     int32_t* next_ids, float* next_scores, int32_t* parents);
+
 /* ops::Gather axis 0 (src/ops/gather_cpu.cc). */
 void orc_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int64_t row_bytes,
                      void* out);

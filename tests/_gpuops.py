@@ -238,6 +238,36 @@ def process_logits(logits, seq, penalty=1.0, ngram=0, suppress=()):
     return host(lg)
 
 
+def beam_select(topk_scores, topk_ids, beam, vocab, eos, prefix=None, step=0, first_step=0):
+    L = _lib.lib()
+    sc = dev(np.ascontiguousarray(topk_scores, np.float32))
+    ids = dev(np.ascontiguousarray(topk_ids, np.int32))
+    batch, nc = topk_ids.shape
+    pid = plen = None
+    stride = 0
+    if prefix is not None:
+        stride = max(1, max(len(q) for q in prefix))
+        host_pid = np.zeros((batch, stride), np.int32)
+        for b, q in enumerate(prefix):
+            host_pid[b, :len(q)] = q
+        pid = dev(host_pid)
+        plen = dev(np.array([len(q) for q in prefix], np.int32))
+    d_step = dev(np.array([first_step + step], np.int32))
+    # the kernel records the candidates at history index (step - first_step)
+    hist = (step + 1, batch, nc)
+    cw = torch.zeros(hist, dtype=torch.int32, device="cuda")
+    cs = torch.zeros(hist, dtype=torch.float32, device="cuda")
+    co = torch.zeros(hist, dtype=torch.int32, device="cuda")
+    ni = torch.empty((batch * beam,), dtype=torch.int32, device="cuda")
+    ns = torch.empty((batch * beam,), dtype=torch.float32, device="cuda")
+    pa = torch.empty((batch * beam,), dtype=torch.int32, device="cuda")
+    _lib.check(L.ct2x_beam_select(_lib.ptr(sc), _lib.ptr(ids), i64(batch), C.c_int32(beam), i64(vocab),
+                                  C.c_int32(eos), _lib.ptr(pid), _lib.ptr(plen), C.c_int32(stride),
+                                  _lib.ptr(d_step), C.c_int32(first_step), _lib.ptr(cw), _lib.ptr(cs),
+                                  _lib.ptr(co), _lib.ptr(ni), _lib.ptr(ns), _lib.ptr(pa), None))
+    return host(cw)[step], host(cs)[step], host(co)[step], host(ni), host(ns), host(pa)
+
+
 def gather_rows(data, idx):
     L = _lib.lib()
     dd, idd = dev(data), dev(np.asarray(idx, np.int32))

@@ -149,6 +149,32 @@ def process_logits(logits, seq, penalty=1.0, ngram=0, suppress=()):
     return lg
 
 
+def beam_select(topk_scores, topk_ids, beam, vocab, eos, prefix=None, step=0):
+    """One beam step after TopK. prefix: list of per-batch id lists or None. Returns the
+    candidates (word, score, origin) [batch, 2*beam] and next ids / scores / parents [batch*beam]."""
+    sc = _f32(topk_scores)
+    ids = np.ascontiguousarray(topk_ids, np.int32)
+    batch, nc = ids.shape
+    pid = plen = None
+    stride = 0
+    if prefix is not None:
+        stride = max(1, max(len(q) for q in prefix))
+        pid = np.zeros((batch, stride), np.int32)
+        for b, q in enumerate(prefix):
+            pid[b, :len(q)] = q
+        plen = np.array([len(q) for q in prefix], np.int32)
+    cw = np.empty((batch, nc), np.int32)
+    cs = np.empty((batch, nc), np.float32)
+    co = np.empty((batch, nc), np.int32)
+    ni = np.empty((batch * beam,), np.int32)
+    ns = np.empty((batch * beam,), np.float32)
+    pa = np.empty((batch * beam,), np.int32)
+    lib().orc_beam_select(_p(sc), _p(ids), _i64(batch), C.c_int32(beam), C.c_int32(vocab),
+                          C.c_int32(eos), _p(pid), _p(plen), C.c_int32(stride), C.c_int32(step),
+                          _p(cw), _p(cs), _p(co), _p(ni), _p(ns), _p(pa))
+    return cw, cs, co, ni, ns, pa
+
+
 def topk(x, k):
     x = _f32(x)
     rows, depth = x.shape

@@ -116,3 +116,45 @@ def test_cpp_api_header_builds_and_fails_loudly_without_gpu():
     rc, out, err = _cppapi.run("translate", os.path.join(GOLDEN, "models", "aren-transliteration-i8"),
                                2, "a")
     assert rc == 2 and "HIP" in err and out == ""
+
+
+def test_host_beam_bookkeeping_matches_the_oracle():
+    """The rule the host replays on the recorded candidates (ct2x_host_beam_step_select =
+    beam_step_select, src/decoding.cc:618-655) picks the same next beams as the oracle restatement
+    orc_beam_select - which is what the device kernel is tested against on the GPU - and reports
+    exactly the ended primaries as finished; the last step finishes every primary."""
+    import sys
+    sys.path.insert(0, HERE)
+    import _oracle as O
+    L = _lib.lib()
+    L.ct2x_host_finalize_score.restype = C.c_float
+    rng = np.random.default_rng(3)
+    vocab, eos = 40, 2
+    for beam in (1, 2, 4, 7):
+        nc = 2 * beam
+        for trial in range(200):
+            words = rng.integers(0, vocab, (1, nc)).astype(np.int32)
+            words[rng.random((1, nc)) < 0.4] = eos
+            plen = int(rng.integers(0, 3))
+            step = int(rng.integers(0, 5))
+            ids = (rng.integers(0, beam, (1, nc)) * vocab + words).astype(np.int32)
+            scores = -np.sort(rng.random((1, nc)).astype(np.float32), axis=1)
+            # candidates after the device's prefix handling are what the host sees
+            cw, cs, co, ni, ns, pa = O.beam_select(scores, ids, beam, vocab, eos,
+                                                   [list(range(3, 3 + plen))], step)
+            fin = (C.c_int32 * beam)()
+            nxt = (C.c_int32 * beam)()
+            w = np.ascontiguousarray(cw[0])
+            n = L.ct2x_host_beam_step_select(beam, step, 0, eos, plen,
+                                             w.ctypes.data_as(C.POINTER(C.c_int32)), fin, nxt)
+            assert n >= 0
+            assert [w[j] for j in nxt] == ni.tolist()
+            assert [cs[0][j] for j in nxt] == ns.tolist()
+            ended = [k for k in range(beam) if w[k] == eos and step >= plen]
+            assert list(fin)[:n] == ended
+            n_last = L.ct2x_host_beam_step_select(beam, step, 1, eos, plen,
+                                                  w.ctypes.data_as(C.POINTER(C.c_int32)), fin, nxt)
+            assert n_last == beam and list(fin) == list(range(beam))
+    # finalize_hypothesis_score: score / length^penalty (src/decoding.cc:192-207)
+    assert abs(L.ct2x_host_finalize_score(C.c_float(-6.0), C.c_float(3.0), C.c_float(1.0)) + 2.0) < 1e-6
+    assert L.ct2x_host_finalize_score(C.c_float(-6.0), C.c_float(3.0), C.c_float(0.0)) == -6.0

@@ -332,6 +332,34 @@ def test_process_logits(gpu):
     assert np.array_equal(G.process_logits(lg, seq, **kw), O.process_logits(lg, seq, **kw))
 
 
+@pytest.mark.parametrize("beam", [1, 2, 4, 32])
+def test_beam_select(gpu, beam):
+    """ct2x_beam_select (the device side of a beam-search step after TopK: unflatten_ids, hard
+    prefix, candidate selection; src/decoding.cc:21-66, 95-116, 618-655) == the oracle
+    restatement, bit for bit, over steps inside / at the end of / after the prefix and candidate
+    sets with several EOS among primary and secondary candidates."""
+    import _gpuops as G
+    rng = np.random.default_rng(beam)
+    batch, vocab, eos = 9, 50, 2
+    nc = 2 * beam
+    prefix = [rng.integers(3, vocab, n).tolist() for n in (0, 1, 3, 2, 0, 3, 1, 2, 3)]
+    for step in range(5):
+        for use_prefix in (False, True):
+            words = rng.integers(0, vocab, (batch, nc))
+            words[rng.random((batch, nc)) < 0.35] = eos        # many ended candidates
+            words[0, :] = eos                                   # nothing left to promote
+            words[1, :beam] = eos                               # every primary ended
+            origin = rng.integers(0, beam, (batch, nc))
+            ids = (origin * vocab + words).astype(np.int32)
+            scores = -np.sort(rng.random((batch, nc)).astype(np.float32) * 9, axis=1)
+            got = G.beam_select(scores, ids, beam, vocab, eos, prefix if use_prefix else None, step,
+                                first_step=3)
+            want = O.beam_select(scores, ids, beam, vocab, eos, prefix if use_prefix else None, step)
+            for a, b, name in zip(got, want, ("word", "score", "origin", "next_ids", "next_scores",
+                                              "parents")):
+                assert np.array_equal(a, b), (name, step, use_prefix)
+
+
 def test_gather_rows(gpu):
     import _gpuops as G
     rng = np.random.default_rng(5)
