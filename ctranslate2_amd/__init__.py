@@ -157,6 +157,14 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         opt.seed = int(seed) & 0xFFFFFFFF
         return opt
 
+    def _known_id(self, token: str, what: str) -> int:
+        """Vocabulary::to_id with allow_unk = false: an out-of-vocabulary token is an error
+        (std::invalid_argument in the reference, sequence_to_sequence.cc:330-361)."""
+        idx = self.token_to_id(token, target=True)
+        if self.id_to_token(idx) != token:
+            raise ValueError("%s token '%s' is not in the vocabulary" % (what, token))
+        return idx
+
     @staticmethod
     def _set_processors(opt, repetition_penalty, no_repeat_ngram_size, suppress_sequences_ids):
         """Fills the logits-processor fields of the options; returns the arrays the struct points
@@ -181,8 +189,10 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                       sampling_temperature: float = 1.0, seed: int = 0,
                       target_prefix_ids: Optional[Sequence[Sequence[int]]] = None,
                       repetition_penalty: float = 1.0, no_repeat_ngram_size: int = 0,
-                      suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None):
+                      suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None,
+                      end_token_id: Optional[int] = None):
         """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores).
+        end_token_id: another target id that ends decoding (TranslationOptions::end_token).
         sampling_* (reference names, python/cpp/translator.cc): random sampling among the best
         sampling_topk candidates (beam_size must be 1), reproducible for a `seed`.
         repetition_penalty / no_repeat_ngram_size as in the reference; suppress_sequences_ids:
@@ -202,6 +212,7 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                             sampling_topp, sampling_temperature, seed)
         _keep = self._set_processors(opt, repetition_penalty, no_repeat_ngram_size,
                                      suppress_sequences_ids)
+        opt.end_token_plus_one = 0 if end_token_id is None else int(end_token_id) + 1
         if target_prefix_ids is not None:
             plen = np.array([len(p) for p in target_prefix_ids], np.int32)
             pstride = max(1, int(plen.max()) if batch else 1)
@@ -226,8 +237,11 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         return_scores = kwargs.get("return_scores", False)
         src_ids = [[self.token_to_id(t) for t in sent] for sent in source]
         # suppress_sequences / disable_unk (python/cpp/translator.cc) -> id sequences
-        suppress = [[self.token_to_id(t, target=True) for t in q]
+        suppress = [[self._known_id(t, "suppress_sequences") for t in q]
                     for q in (kwargs.pop("suppress_sequences", None) or [])]
+        end_token = kwargs.pop("end_token", None)
+        if end_token is not None:
+            kwargs["end_token_id"] = self._known_id(end_token, "end_token")
         if kwargs.pop("disable_unk", False):
             suppress.append([self.token_to_id("<unk>", target=True)])
         if suppress:
@@ -250,7 +264,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                      sampling_temperature: float = 1.0, seed: int = 0, beam_size: int = 1,
                      length_penalty: float = 1.0, repetition_penalty: float = 1.0,
                      no_repeat_ngram_size: int = 0,
-                     suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None):
+                     suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None,
+                     end_token_id: Optional[int] = None):
         """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False.
         sampling_topk=1 is greedy; 2..64 samples among the best k (sampling_topp / temperature as
         in the reference). Returns (generated ids per prompt, scores)."""
@@ -268,6 +283,7 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                             sampling_temperature, seed)
         _keep = self._set_processors(opt, repetition_penalty, no_repeat_ngram_size,
                                      suppress_sequences_ids)
+        opt.end_token_plus_one = 0 if end_token_id is None else int(end_token_id) + 1
         _lib.check(self._L.ct2x_generate_batch(
             C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
             C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))

@@ -39,7 +39,7 @@ class TranslationOptions(C.Structure):
         ("repetition_penalty", C.c_float),
         ("no_repeat_ngram_size", C.c_int32),
         ("num_suppress_sequences", C.c_int32),
-        ("reserved", C.c_int32),
+        ("end_token_plus_one", C.c_int32),
         ("suppress_ids", C.POINTER(C.c_int32)),
         ("suppress_lengths", C.POINTER(C.c_int32)),
     ]

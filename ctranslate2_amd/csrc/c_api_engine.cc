@@ -353,6 +353,10 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
   DecodingOptions dopt = to_decoding_options(opt);
   validate_decoding_options(dopt);
   const int32_t nh = opt.num_hypotheses, max_len = opt.max_decoding_length;
+  // TranslationOptions::end_token (sequence_to_sequence.cc:330-334): another token ends decoding
+  const int32_t end_id = opt.end_token_plus_one > 0 ? opt.end_token_plus_one - 1 : t->eos_id;
+  CT2X_CHECK(end_id >= 0 && end_id < static_cast<int32_t>(t->engine->vocab_size()),
+             "end_token is not in the target vocabulary");
   const double t0 = now_ms();
   t->last = ct2x_exec_stats{};
 
@@ -465,8 +469,8 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
         DecodeStats ds;
         std::vector<DecodingResult> results =
             dopt.beam_size == 1
-                ? greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds, pf)
-                : beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds, pf);
+                ? greedy_search(*t->engine, *st, start_ids, end_id, dopt, &ds, pf)
+                : beam_search(*t->engine, *st, start_ids, end_id, dopt, &ds, pf);
         t->engine->synchronize();
         const double te2 = now_ms();
         int64_t tokens = 0;
@@ -477,7 +481,7 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
             auto& hyp = r.hypotheses[k];
             // "Remove EOS token" (sequence_to_sequence.cc:374-384).
             if (!opt.return_end_token)
-              while (!hyp.empty() && hyp.back() == t->eos_id) hyp.pop_back();
+              while (!hyp.empty() && hyp.back() == end_id) hyp.pop_back();
             const int32_t len = static_cast<int32_t>(hyp.size());
             std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
                       out_ids + (static_cast<int64_t>(b) * nh + k) * max_len);
@@ -549,6 +553,9 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   validate_decoding_options(dopt);
   CT2X_CHECK(batch > 0, "No decoder start tokens are set");
   const int32_t beam = dopt.beam_size;
+  const int32_t end_id = opt.end_token_plus_one > 0 ? opt.end_token_plus_one - 1 : t->eos_id;
+  CT2X_CHECK(end_id >= 0 && end_id < static_cast<int32_t>(t->engine->vocab_size()),
+             "end_token is not in the vocabulary");
   // Prompts of different lengths: the shortest prompt minus one token is consumed by the
   // sequence-mode pass for every row; the remaining tokens of a row are its start token and a
   // hard decoding prefix (language_model.cc:218-238 -> decode(..., prefix_ids)).
@@ -586,9 +593,9 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   dopt.return_prefix = false;  // include_prompt_in_result = false
   DecodeStats ds;
   std::vector<DecodingResult> results =
-      beam > 1 ? beam_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds,
+      beam > 1 ? beam_search(*t->engine, *st, start_ids, end_id, dopt, &ds,
                              longest_prefix > 0 ? &prefix : nullptr)
-               : greedy_search(*t->engine, *st, start_ids, t->eos_id, dopt, &ds,
+               : greedy_search(*t->engine, *st, start_ids, end_id, dopt, &ds,
                                longest_prefix > 0 ? &prefix : nullptr);
   t->engine->synchronize();
   const double te2 = now_ms();
@@ -596,7 +603,7 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   for (int32_t b = 0; b < batch; ++b) {
     auto& hyp = results[b].hypotheses[0];
     if (!opt.return_end_token)
-      while (!hyp.empty() && hyp.back() == t->eos_id) hyp.pop_back();
+      while (!hyp.empty() && hyp.back() == end_id) hyp.pop_back();
     const int32_t len = static_cast<int32_t>(hyp.size());
     std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
               out_ids + static_cast<int64_t>(b) * max_len);

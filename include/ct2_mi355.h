@@ -311,7 +311,8 @@ struct ct2x_translation_options {
   float repetition_penalty;        /* 1 (or 0 in a zero-initialised struct) = off */
   int32_t no_repeat_ngram_size;    /* 0 = off */
   int32_t num_suppress_sequences;
-  int32_t reserved;
+  int32_t end_token_plus_one;      /* TranslationOptions::end_token as a target id, + 1;
+                                      0 = the model's end token */
   const int32_t* suppress_ids;
   const int32_t* suppress_lengths;
 };

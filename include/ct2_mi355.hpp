@@ -57,6 +57,7 @@ struct TranslationOptions {
   bool disable_unk = false;
   std::vector<std::vector<std::string>> suppress_sequences;
   float prefix_bias_beta = 0;            // not built: must stay 0
+  std::string end_token;                 // empty = the model's end token (single token form)
   bool return_end_token = false;
   size_t max_input_length = 1024;
   size_t max_decoding_length = 256;
@@ -100,6 +101,7 @@ struct GenerationOptions {
   size_t no_repeat_ngram_size = 0;
   bool disable_unk = false;
   std::vector<std::vector<std::string>> suppress_sequences;
+  std::string end_token;                 // empty = the model's end token
   bool return_end_token = false;
   size_t max_length = 512;
   size_t min_length = 0;
@@ -167,6 +169,13 @@ public:
   int32_t to_id(int which, const std::string& token) const {
     return ct2x_vocab_id(h_, which, token.c_str());
   }
+  // Vocabulary::to_id with allow_unk = false (src/vocabulary.cc): out-of-vocabulary is an error
+  int32_t known_id(int which, const std::string& token, const char* what) const {
+    const int32_t id = to_id(which, token);
+    if (to_token(which, id) != token)
+      throw std::invalid_argument(std::string(what) + " token '" + token + "' is not in the vocabulary");
+    return id;
+  }
   std::string to_token(int which, int32_t id) const {
     const char* t = ct2x_vocab_token(h_, which, id);
     if (!t) throw std::runtime_error(ct2x_last_error());
@@ -210,7 +219,7 @@ inline Suppressed suppressed_ids(const Handle& h, int which,
   Suppressed s;
   for (const auto& seq : sequences) {
     if (seq.empty()) continue;
-    for (const auto& token : seq) s.ids.push_back(h.to_id(which, token));
+    for (const auto& token : seq) s.ids.push_back(h.known_id(which, token, "suppress_sequences"));
     s.lengths.push_back(static_cast<int32_t>(seq.size()));
   }
   if (disable_unk) {  // Vocabulary::unk_id(): the id an unknown token maps to
@@ -291,6 +300,8 @@ public:
     const detail::Suppressed sup =
         detail::suppressed_ids(h_, 1, options.suppress_sequences, options.disable_unk);
     detail::set_processors(o, options.repetition_penalty, options.no_repeat_ngram_size, sup);
+    if (!options.end_token.empty())
+      o.end_token_plus_one = h_.known_id(1, options.end_token, "end_token") + 1;
 
     const detail::IdBatch src = detail::to_ids(h_, 0, source);
     const size_t hyp = options.num_hypotheses, len = options.max_decoding_length;
@@ -378,6 +389,8 @@ public:
     const detail::Suppressed sup =
         detail::suppressed_ids(h_, 1, options.suppress_sequences, options.disable_unk);
     detail::set_processors(o, options.repetition_penalty, options.no_repeat_ngram_size, sup);
+    if (!options.end_token.empty())
+      o.end_token_plus_one = h_.known_id(1, options.end_token, "end_token") + 1;
 
     const detail::IdBatch in = detail::to_ids(h_, 1, prompts);
     const size_t len = options.max_length;
