@@ -28,6 +28,19 @@ class TranslationResult:
         return "TranslationResult(hypotheses=%r, scores=%r)" % (self.hypotheses, self.scores)
 
 
+class ScoringResult:
+    """ctranslate2.ScoringResult: the scored tokens (target + </s>) and their log-probabilities."""
+
+    def __init__(self, tokens, log_probs, tokens_ids):
+        self.tokens = tokens
+        self.log_probs = log_probs
+        self.tokens_score = log_probs   # the C++ member name (include/ctranslate2/scoring.h)
+        self.tokens_ids = tokens_ids
+
+    def __repr__(self):
+        return "ScoringResult(tokens=%r, log_probs=%r)" % (self.tokens, self.log_probs)
+
+
 class Translator:  # also serves decoder-only models (ctranslate2.Generator) via generate_ids
     """ctranslate2.Translator for converted models, on one MI355X.
 
@@ -256,6 +269,48 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
             sc = [float(scores[b, k]) for k in range(len(sent_hyps))] if return_scores else []
             results.append(TranslationResult(tokens, sc, sent_hyps))
         return results
+
+    def score_ids(self, source_ids: Sequence[Sequence[int]], target_ids: Sequence[Sequence[int]],
+                  max_input_length: int = 1024):
+        """Translator.score_batch on ids (no special tokens): per example the scored ids
+        (target + </s>, truncated like the reference) and their log-probabilities."""
+        batch = len(source_ids)
+        if len(target_ids) != batch:
+            raise ValueError("Batch size mismatch: got %d for source and %d for target"
+                             % (batch, len(target_ids)))
+        if batch == 0:
+            return [], []
+
+        def pack(seqs):
+            lengths = np.array([len(q) for q in seqs], np.int32)
+            stride = max(1, int(lengths.max()))
+            ids = np.zeros((len(seqs), stride), np.int32)
+            for i, q in enumerate(seqs):
+                ids[i, :len(q)] = q
+            return ids, lengths, stride
+
+        src, src_len, src_stride = pack(source_ids)
+        tgt, tgt_len, tgt_stride = pack(target_ids)
+        out_stride = int(tgt_len.max()) + 1
+        out_ids = np.zeros((batch, out_stride), np.int32)
+        out_scores = np.zeros((batch, out_stride), np.float32)
+        out_len = np.zeros((batch,), np.int32)
+        _lib.check(self._L.ct2x_score_batch(
+            C.c_void_p(self._h), _lib.ptr(src), _lib.ptr(src_len), C.c_int32(batch),
+            C.c_int32(src_stride), _lib.ptr(tgt), _lib.ptr(tgt_len), C.c_int32(tgt_stride),
+            C.c_int32(max_input_length), _lib.ptr(out_ids), _lib.ptr(out_scores),
+            C.c_int32(out_stride), _lib.ptr(out_len)))
+        return ([out_ids[b, :out_len[b]].tolist() for b in range(batch)],
+                [out_scores[b, :out_len[b]].tolist() for b in range(batch)])
+
+    def score_batch(self, source: List[List[str]], target: List[List[str]],
+                    max_input_length: int = 1024) -> List[ScoringResult]:
+        """ctranslate2.Translator.score_batch on tokens."""
+        ids, scores = self.score_ids([[self.token_to_id(t) for t in q] for q in source],
+                                     [[self.token_to_id(t, target=True) for t in q] for q in target],
+                                     max_input_length=max_input_length)
+        return [ScoringResult([self.id_to_token(i) for i in row], sc, row)
+                for row, sc in zip(ids, scores)]
 
     def generate_ids(self, prompts: Sequence[Sequence[int]], max_length: int = 512,
                      min_length: int = 0, return_scores: bool = False,

@@ -621,6 +621,109 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   API_CATCH
 }
 
+namespace {
+
+// Vocabulary::to_ids truncation (src/vocabulary.cc:130-141): keep </s> (and an optional language
+// code after it) in the last positions.
+void truncate_ids(std::vector<int32_t>& ids, size_t max_length, int32_t eos) {
+  if (max_length == 0 || ids.size() <= max_length) return;
+  if (ids.back() == eos)
+    ids[max_length - 1] = eos;
+  else if (ids.size() >= 2 && ids[ids.size() - 2] == eos && max_length >= 2) {
+    ids[max_length - 2] = eos;
+    ids[max_length - 1] = ids.back();
+  }
+  ids.resize(max_length);
+}
+
+}  // namespace
+
+int ct2x_score_batch(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
+                     int32_t batch, int32_t src_stride, const int32_t* tgt_ids,
+                     const int32_t* tgt_lengths, int32_t tgt_stride, int32_t max_input_length,
+                     int32_t* out_ids, float* out_scores, int32_t out_stride,
+                     int32_t* out_lengths) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  std::lock_guard<std::mutex> lock(t->mutex);
+  CT2X_CHECK(t->engine->is_seq2seq(), "This model cannot be used as a sequence-to-sequence model");
+  CT2X_CHECK(t->has_start_token, "models that need user decoder start tokens are not supported");
+  CT2X_CHECK(max_input_length >= 0, "max_input_length must be >= 0");
+  const int32_t src_eos = static_cast<int32_t>(t->src_vocab->eos_id());
+  // make_source_ids / make_target_ids (sequence_to_sequence.cc:143-186): the full target is
+  // "<s> a b c </s>", one more than max_input_length since the decoder input is "<s> a b c".
+  std::vector<std::vector<int32_t>> sources(batch), targets(batch);
+  for (int32_t b = 0; b < batch; ++b) {
+    auto& s = sources[b];
+    if (src_lengths[b] > 0 || t->add_source_bos || t->add_source_eos) {
+      if (t->add_source_bos) s.push_back(static_cast<int32_t>(t->src_vocab->bos_id()));
+      for (int32_t i = 0; i < src_lengths[b]; ++i) {
+        const int32_t id = src_ids[static_cast<int64_t>(b) * src_stride + i];
+        CT2X_CHECK(id >= 0 && id < static_cast<int32_t>(t->src_vocab->size()),
+                   "Invalid source token ID " + std::to_string(id));
+        s.push_back(id);
+      }
+      if (t->add_source_eos) s.push_back(src_eos);
+      truncate_ids(s, static_cast<size_t>(max_input_length), src_eos);
+    }
+    auto& y = targets[b];
+    y.push_back(t->start_id);
+    for (int32_t i = 0; i < tgt_lengths[b]; ++i) {
+      const int32_t id = tgt_ids[static_cast<int64_t>(b) * tgt_stride + i];
+      CT2X_CHECK(id >= 0 && id < static_cast<int32_t>(t->engine->vocab_size()),
+                 "Invalid target token ID " + std::to_string(id));
+      y.push_back(id);
+    }
+    y.push_back(t->eos_id);
+    truncate_ids(y, max_input_length > 0 ? static_cast<size_t>(max_input_length) + 1 : 0, t->eos_id);
+    CT2X_CHECK(static_cast<int32_t>(y.size()) - 1 <= out_stride, "ct2x_score_batch: out_stride is too small");
+  }
+  std::vector<int32_t> order;
+  for (int32_t b = 0; b < batch; ++b) {
+    const int32_t n = static_cast<int32_t>(targets[b].size()) - 1;
+    out_lengths[b] = n;
+    for (int32_t i = 0; i < n; ++i) {
+      out_ids[static_cast<int64_t>(b) * out_stride + i] = targets[b][i + 1];
+      out_scores[static_cast<int64_t>(b) * out_stride + i] = 0.f;  // skip_scoring: empty source
+    }
+    if (!sources[b].empty()) order.push_back(b);
+  }
+  if (order.empty()) return 0;
+  const int64_t B = static_cast<int64_t>(order.size());
+  int64_t s_max = 0, steps = 0;
+  for (int32_t b : order) {
+    s_max = std::max<int64_t>(s_max, static_cast<int64_t>(sources[b].size()));
+    steps = std::max<int64_t>(steps, static_cast<int64_t>(targets[b].size()) - 1);
+  }
+  std::vector<int32_t> ids(B * s_max, 0), lens(B);
+  for (int64_t i = 0; i < B; ++i) {
+    const auto& s = sources[order[i]];
+    std::copy(s.begin(), s.end(), ids.begin() + i * s_max);
+    lens[i] = static_cast<int32_t>(s.size());
+  }
+  auto st = t->engine->start(ids.data(), lens.data(), B, s_max, 1, steps);
+  // decoder inputs "<s> a b c", outputs "a b c </s>"; rows past their end repeat </s> (ignored)
+  std::vector<int32_t> inputs(steps * B, t->eos_id), outputs(steps * B, t->eos_id);
+  for (int64_t i = 0; i < B; ++i) {
+    const auto& y = targets[order[i]];
+    for (size_t s = 0; s + 1 < y.size(); ++s) {
+      inputs[s * B + i] = y[s];
+      outputs[s * B + i] = y[s + 1];
+    }
+  }
+  t->engine->score_targets(*st, inputs.data(), outputs.data(), steps);
+  std::vector<int32_t> h_ids(steps * B);
+  std::vector<float> h_scores(steps * B);
+  t->engine->read_history(*st, 0, steps, h_ids.data(), h_scores.data());
+  for (int64_t i = 0; i < B; ++i) {
+    const int32_t b = order[i];
+    for (int32_t s = 0; s < out_lengths[b]; ++s)
+      out_scores[static_cast<int64_t>(b) * out_stride + s] = h_scores[s * B + i];
+  }
+  API_CATCH
+}
+
 int ct2x_step_logits(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
                      int32_t batch, int32_t src_stride, const int32_t* tgt_in, int32_t T,
                      float* logits_out) {

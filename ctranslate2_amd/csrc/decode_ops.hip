@@ -695,4 +695,34 @@ void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64
   hipLaunchKernelGGL(beam_select_kernel, dim3(batch), dim3(64), 0, stream, p);
 }
 
+// score_sequences (src/scoring.cc:42-48): LogSoftMax over the step's logits, then Gather of the
+// given target id - one launch, the log-probability of targets[row] under logits[row, :]
+// (x + (-max - log(sum exp(x - max))), the reference's log-softmax form, src/cpu/kernels.cc:452).
+__global__ void score_tokens_kernel(const float* __restrict__ logits, int64_t vocab,
+                                    const int32_t* __restrict__ targets,
+                                    float* __restrict__ out) {
+  __shared__ float scratch[16];
+  const int64_t row = blockIdx.x;
+  const float* x = logits + row * vocab;
+  float m = -FLT_MAX;
+  for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) m = fmaxf(m, x[j]);
+  m = block_max(m, scratch);
+  float s = 0.f;
+  for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) s += expf(x[j] - m);
+  s = block_sum(s, scratch);
+  if (threadIdx.x == 0) {
+    const float c = -m - logf(s);
+    out[row] = x[targets[row]] + c;
+  }
+}
+
+void launch_score_tokens(const float* logits, int64_t rows, int64_t vocab, const int32_t* targets,
+                         float* out, hipStream_t stream) {
+  if (rows == 0) return;
+  int block = 64;
+  while (block < vocab / 4 && block < 1024) block <<= 1;
+  hipLaunchKernelGGL(score_tokens_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
+                     targets, out);
+}
+
 }  // namespace ct2x

@@ -1813,4 +1813,31 @@ void Engine::set_step(DecodeState& st, int32_t step) {
 
 void Engine::synchronize() { CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream())); }
 
+void Engine::score_targets(DecodeState& st, const int32_t* h_inputs, const int32_t* h_outputs,
+                           int64_t steps) {
+  tls_stream = st.stream;
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  CT2X_CHECK(steps <= st.t_max, "score_targets: more steps than the decoding state holds");
+  if (steps == 0) return;
+  const size_t bytes = sizeof(int32_t) * static_cast<size_t>(steps) * st.rows;
+  int32_t* d_inputs = static_cast<int32_t*>(device_malloc(bytes));
+  st.owned.push_back(d_inputs);
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_inputs, h_inputs, bytes, hipMemcpyHostToDevice, cur_stream()));
+  // the id history doubles as the table of target ids, the score history receives the result
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.hist_ids, h_outputs, bytes, hipMemcpyHostToDevice, cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // the host arrays may go away
+  st.fuse_greedy = false;
+  st.fuse_beam = false;
+  set_step(st, 0);
+  for (int64_t s = 0; s < steps; ++s) {
+    CT2X_HIP_CHECK(hipMemcpyAsync(st.d_ids, d_inputs + s * st.rows, sizeof(int32_t) * st.rows,
+                                  hipMemcpyDeviceToDevice, cur_stream()));
+    step(st, /*graph=*/false);
+    launch_score_tokens(st.logits, st.rows, dec_.projection.n, st.hist_ids + s * st.rows,
+                        st.hist_scores + s * st.rows, cur_stream());
+    launch_advance_step(st.d_step, cur_stream());
+  }
+  check_last_launch("score_targets");
+}
+
 }  // namespace ct2x

@@ -199,6 +199,11 @@ public:
                   int32_t first_step, bool extends_min_length = true);
   void set_step(DecodeState& state, int32_t step);
   void synchronize();
+  // Teacher-forced scoring (score_sequences, src/scoring.cc): runs `steps` decoder steps feeding
+  // h_inputs[s][row] and leaves log P(h_outputs[s][row]) of every step in the score history
+  // (read_history). Both arrays are [steps][rows]; nothing is read back between the steps.
+  void score_targets(DecodeState& state, const int32_t* h_inputs, const int32_t* h_outputs,
+                     int64_t steps);
 
   // Logits processors of the decoding loop (make_logits_processors, src/decoding.cc:1091-1120):
   // installs them for every following step of `state`. Greedy steps apply them on the device

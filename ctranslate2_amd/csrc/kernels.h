@@ -279,6 +279,10 @@ void launch_process_logits(float* logits, int64_t rows, int64_t vocab, const int
                            int32_t ngram, const int32_t* sup_ids, const int32_t* sup_off,
                            int32_t n_sup, hipStream_t stream);
 
+// out[row] = log_softmax(logits[row, :])[targets[row]]  (score_sequences, src/scoring.cc:42-48)
+void launch_score_tokens(const float* logits, int64_t rows, int64_t vocab, const int32_t* targets,
+                         float* out, hipStream_t stream);
+
 // One beam-search step after TopK on the device (src/decoding.cc:559-700): unflatten, hard
 // prefix, record the candidates (hist_*[step - first_step][batch, 2*beam]) and install the next
 // step's ids / cumulative scores / parent rows. 2 * beam <= 64. seq_src/seq_dst (optional):

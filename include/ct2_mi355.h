@@ -376,6 +376,20 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
                         const struct ct2x_translation_options* opt, int32_t* out_ids,
                         int32_t* out_lengths, float* out_scores);
 
+/* Translator::score_batch (include/ctranslate2/translator.h:62-76 -> EncoderDecoderReplica::
+ * run_scoring, src/models/sequence_to_sequence.cc:236-261 -> score_sequences, src/scoring.cc):
+ * the log-probability of every target token (and of the final </s>) given the source, teacher
+ * forced. src_ids / tgt_ids are raw ids WITHOUT special tokens; the decoder start token and </s>
+ * are added and both sides truncated to max_input_length like Vocabulary::to_ids (0 = no limit).
+ * out_ids / out_scores [batch, out_stride] receive the scored tokens (target + </s>) and their
+ * log-probabilities, out_lengths [batch] their count (<= out_stride, or the call fails). An
+ * example whose source is empty scores 0 for every token (skip_scoring, :263-283). */
+int ct2x_score_batch(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
+                     int32_t batch, int32_t src_stride, const int32_t* tgt_ids,
+                     const int32_t* tgt_lengths, int32_t tgt_stride, int32_t max_input_length,
+                     int32_t* out_ids, float* out_scores, int32_t out_stride,
+                     int32_t* out_lengths);
+
 /* Teacher-forced step logits (layers::Decoder::operator()(step, ids, state, logits),
  * include/ctranslate2/layers/decoder.h:25-29): src_ids INCLUDE special tokens here;
  * logits_out is a HOST buffer [T, batch, vocab]. */

@@ -92,6 +92,24 @@ struct TranslationResult {
   bool has_scores() const { return !scores.empty(); }
 };
 
+// scoring.h:9-40
+struct ScoringOptions {
+  size_t max_input_length = 1024;
+};
+
+struct ScoringResult {
+  std::vector<std::string> tokens;
+  std::vector<float> tokens_score;
+  float cumulated_score() const {
+    float total = 0;
+    for (const float s : tokens_score) total += s;
+    return total;
+  }
+  float normalized_score() const {
+    return tokens_score.empty() ? 0.f : cumulated_score() / static_cast<float>(tokens_score.size());
+  }
+};
+
 // generation.h:12-76
 struct GenerationOptions {
   size_t beam_size = 1;
@@ -329,6 +347,35 @@ public:
         if (options.return_scores) results[b].scores.push_back(scores[b * hyp + k]);
       }
     }
+    return results;
+  }
+
+  // Translator::score_batch (include/ctranslate2/translator.h:62-76)
+  std::vector<ScoringResult>
+  score_batch(const std::vector<std::vector<std::string>>& source,
+              const std::vector<std::vector<std::string>>& target,
+              const ScoringOptions& options = ScoringOptions()) {
+    if (source.size() != target.size())
+      throw std::invalid_argument("Batch size mismatch: got " + std::to_string(source.size()) +
+                                  " for source and " + std::to_string(target.size()) + " for target");
+    const size_t batch = source.size();
+    if (batch == 0) return {};
+    const detail::IdBatch src = detail::to_ids(h_, 0, source);
+    const detail::IdBatch tgt = detail::to_ids(h_, 1, target);
+    const int32_t out_stride = tgt.stride + 1;
+    std::vector<int32_t> out_ids(batch * out_stride, 0), out_len(batch, 0);
+    std::vector<float> out_scores(batch * out_stride, 0.f);
+    detail::check(ct2x_score_batch(h_.get(), src.ids.data(), src.lengths.data(),
+                                   static_cast<int32_t>(batch), src.stride, tgt.ids.data(),
+                                   tgt.lengths.data(), tgt.stride,
+                                   static_cast<int32_t>(options.max_input_length), out_ids.data(),
+                                   out_scores.data(), out_stride, out_len.data()));
+    std::vector<ScoringResult> results(batch);
+    for (size_t b = 0; b < batch; ++b)
+      for (int32_t i = 0; i < out_len[b]; ++i) {
+        results[b].tokens.push_back(h_.to_token(1, out_ids[b * out_stride + i]));
+        results[b].tokens_score.push_back(out_scores[b * out_stride + i]);
+      }
     return results;
   }
 

@@ -2,6 +2,7 @@
 // (README "C++" section / tests/translator_test.cc:53-97) with the namespace swapped.
 //   api_example translate <model_dir> <beam> <token> ...      -> hypothesis tokens + score
 //   api_example generate  <model_dir> <max_length> <token> ... -> generated tokens
+//   api_example score     <model_dir> <n_src> <src tokens> <tgt tokens> -> token log-probabilities
 //   api_example reject    <model_dir>                          -> an unsupported option must throw
 // Exit code 0 on success, 2 when the backend reports an error (printed on stderr).
 #include <cstdio>
@@ -47,6 +48,15 @@ int main(int argc, char** argv) {
       const auto results = generator.generate_batch(batch, options);
       for (const auto& token : results[0].sequences[0]) std::cout << token << ' ';
       std::cout << std::endl;
+    } else if (mode == "score") {
+      // api_example score <model_dir> <n_source> <source tokens...> <target tokens...>
+      ct2_mi355::Translator translator(model);
+      const int n_src = std::atoi(argv[3]);
+      const std::vector<std::vector<std::string>> source = {std::vector<std::string>(argv + 4, argv + 4 + n_src)};
+      const std::vector<std::vector<std::string>> target = {std::vector<std::string>(argv + 4 + n_src, argv + argc)};
+      const auto results = translator.score_batch(source, target);
+      for (size_t i = 0; i < results[0].tokens.size(); ++i)
+        std::cout << results[0].tokens[i] << ' ' << results[0].tokens_score[i] << std::endl;
     } else if (mode == "reject") {
       ct2_mi355::Translator translator(model);
       ct2_mi355::TranslationOptions options;

@@ -332,6 +332,19 @@ def test_process_logits(gpu):
     assert np.array_equal(G.process_logits(lg, seq, **kw), O.process_logits(lg, seq, **kw))
 
 
+def test_kat_penalize_previous_tokens_and_logsumexp(gpu):
+    """tests/primitives_test.cc:25-52 on the device entry points (the CUDA instantiation of the
+    reference's PrimitiveTest)."""
+    import _gpuops as G
+    from test_oracle import PENALIZE_KAT, penalize_kat_expected
+    got = G.process_logits(PENALIZE_KAT["scores"], PENALIZE_KAT["previous_ids"],
+                           penalty=PENALIZE_KAT["penalty"])
+    assert np.array_equal(got, penalize_kat_expected())
+    x = np.array([[0.6, 0.2, -1.2, 0.1, 0.3, 0.5, -1.3, 0.2]], np.float32)
+    lse = x[0, 0] - G.softmax(x, None, True)[0, 0]
+    assert abs(float(lse) - 2.1908040046691895) < 1e-6
+
+
 @pytest.mark.parametrize("beam", [1, 2, 4, 32])
 def test_beam_select(gpu, beam):
     """ct2x_beam_select (the device side of a beam-search step after TopK: unflatten_ids, hard

@@ -211,3 +211,28 @@ def test_ref_logits_processors_exact():
     lg = np.full((1, 8), 2.0, np.float32)
     out = O.process_logits(lg, np.array([[3, 3, 3]], np.int32), penalty=2.0)
     assert out[0, 3] == 1.0 and out[0, 2] == 2.0
+
+
+PENALIZE_KAT = dict(  # tests/primitives_test.cc:33-52 (PrimitiveTest.PenalizePreviousTokens)
+    scores=np.array([[0.6, 0.2, -1.2, 0.1], [0.3, 0.5, -1.3, 0.2]], np.float32),
+    previous_ids=np.array([[2, 2], [1, 2]], np.int32), penalty=1.2)
+
+
+def penalize_kat_expected():
+    e = PENALIZE_KAT["scores"].copy()
+    p = np.float32(PENALIZE_KAT["penalty"])
+    e[0, 2] *= p
+    e[1, 1] /= p
+    e[1, 2] *= p
+    return e
+
+
+def test_kat_penalize_previous_tokens_and_logsumexp():
+    """The reference's own vectors: PrimitiveTest.PenalizePreviousTokens (a token repeated in the
+    history is penalised once) and PrimitiveTest.LogSumExp (tests/primitives_test.cc:25-52)."""
+    got = O.process_logits(PENALIZE_KAT["scores"], PENALIZE_KAT["previous_ids"],
+                           penalty=PENALIZE_KAT["penalty"])
+    assert np.array_equal(got, penalize_kat_expected())
+    x = np.array([[0.6, 0.2, -1.2, 0.1, 0.3, 0.5, -1.3, 0.2]], np.float32)
+    lse = x[0, 0] - O.softmax(x, None, True)[0, 0]
+    assert abs(float(lse) - 2.1908040046691895) < 1e-6

@@ -202,3 +202,28 @@ def test_beam_size_larger_than_vocab_size(gpu):  # BeamSizeLargerThanVocabSize :
     # 22 * 2 = 44 candidates are retrieved from the model output but the vocabulary size is 42
     res = translate([INPUT], beam_size=22, num_hypotheses=22)[0]
     assert len(res.hypotheses) == 22
+
+
+def test_scoring(gpu):  # TranslatorTest.Scoring :942 (expected scores of the reference, 1e-5)
+    source = [INPUT, ["آ", "ت", "ش", "ي", "س", "و", "ن"], ["آ", "ر", "ب", "ا", "ك", "ه"], [],
+              ["آ", "ر", "ث", "ر"]]
+    target = [["a", "t", "z", "m", "o", "n"], ["a", "c", "h", "i", "s", "o", "n"],
+              ["a", "r", "b", "a", "k", "e"], [], ["a", "r", "t", "h", "e", "r"]]
+    expected = [
+        [-0.106023, -0.065410, -0.056002, -0.447953, -0.230714, -0.092184, -0.063463],
+        [-0.072660, -0.300309, -0.181187, -0.395671, -0.025631, -0.123466, -0.002034, -0.012639],
+        [-0.103136, -0.089504, -0.063889, -0.007327, -0.452072, -0.060154, -0.016636],
+        [0],
+        [-0.076704, -0.036037, -0.029253, -0.030273, -0.149276, -0.002440, -0.003742],
+    ]
+    results = translator().score_batch(source, target)
+    assert len(results) == len(expected)
+    for res, tgt, exp in zip(results, target, expected):
+        assert res.tokens == tgt + ["</s>"]
+        np.testing.assert_allclose(res.log_probs, exp, atol=1e-5)
+
+
+def test_scoring_max_input_length(gpu):  # ScoringMaxInputLength :974
+    res = translator().score_batch([INPUT], [["a", "t", "z", "m", "o", "n"]], max_input_length=4)[0]
+    assert res.tokens == ["a", "t", "z", "</s>"]
+    assert len(res.log_probs) == 4

@@ -454,3 +454,11 @@ def test_cpp_api_translator(gpu):
     assert abs(float(score) - want.scores[0]) < 1e-4
     rc, out, err = _cppapi.run("reject", model)
     assert rc == 0 and "return_attention" in out, (out, err)
+    # Translator::score_batch through the C++ surface == the Python surface
+    src, tgt = GC.AREN_SOURCES[0], ["a", "t", "z", "m", "o", "n"]
+    rc, out, err = _cppapi.run("score", model, len(src), *(src + tgt))
+    assert rc == 0, err
+    rows = [line.split() for line in out.strip().splitlines()]
+    want = t.score_batch([src], [tgt])[0]
+    assert [r[0] for r in rows] == want.tokens
+    np.testing.assert_allclose([float(r[1]) for r in rows], want.log_probs, atol=1e-5)
