@@ -256,6 +256,22 @@ def main():
         },
     }
 
+    if rank == 0 and world == 1 and args.beam == 1 and not args.no_profile:
+        # BASELINE.json configs[1] (batch 32 x beam 4) beside the metric's beam-1 line: a short,
+        # separately timed leg after the measured region (5 calls), reported as `config.beam4`.
+        kw4 = dict(kw, beam_size=4)
+        translator.translate_ids(sources, **kw4)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        tok4 = 0
+        for _ in range(5):
+            hyps4, _ = translator.translate_ids(sources, **kw4)
+            tok4 += sum(len(h[0]) for h in hyps4)
+        torch.cuda.synchronize()
+        dt4 = time.perf_counter() - t4
+        result["config"]["beam4"] = {"workload": "same model and batch, beam_size=4 (BASELINE configs[1])",
+                                     "value": tok4 / dt4, "unit": "tokens/s", "ms_per_step": dt4 / 5 * 1e3}
+
     if rank == 0:
         if not args.no_profile:
             translator.profile_begin()
