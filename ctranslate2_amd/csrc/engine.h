@@ -287,6 +287,7 @@ private:
   std::atomic<int64_t> launch_counter_{0};
   std::mutex table_mutex_;
   bool profiling_ = false;
+  int32_t* profile_scratch_ = nullptr;  // target of the calibration no-op (profile_begin)
   struct PendingKernel {
     std::string label;
     hipEvent_t start, stop;
