@@ -118,6 +118,7 @@ def main():
         gen.profile_begin()
         one()
         prof = gen.profile_end()
+        noop = prof.pop("noop[calibration]", None)  # the profile's own empty-kernel calibration
         total = sum(x["total_ms"] for x in prof.values())
         top = sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:12]
         result["profile"] = {
@@ -129,6 +130,8 @@ def main():
                      "TOPS": round(x["ops"] / (x["total_ms"] * 1e-3) / 1e12, 1) if x["ops"] and x["total_ms"] else None}
                     for k, x in top],
         }
+        if noop and noop["launches"]:
+            result["profile"]["noop_bracket_us"] = noop["total_ms"] / noop["launches"] * 1e3
     print(json.dumps(result))
 
 
