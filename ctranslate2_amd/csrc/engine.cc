@@ -1602,15 +1602,6 @@ void Engine::step(DecodeState& st, bool graph) {
   if (st.fuse_beam) st.cur ^= 1;
 }
 
-void Engine::sample_greedy(DecodeState& st, int32_t eos_id, int32_t min_length,
-                           bool with_scores) {
-  tls_stream = st.stream;
-  launch_greedy_sample(st.logits, st.rows, dec_.projection.n, eos_id, min_length, with_scores,
-                       st.d_step, st.d_ids, st.hist_ids, st.hist_scores, cur_stream());
-  launch_advance_step(st.d_step, cur_stream());
-  check_last_launch("greedy sample");
-}
-
 void Engine::advance_step(DecodeState& st) {
   tls_stream = st.stream;
   launch_advance_step(st.d_step, cur_stream());

@@ -157,11 +157,11 @@ public:
   // With `graph`, the launch sequence is captured once and replayed.
   void step(DecodeState& state, bool graph);
 
-  // Greedy sampling on device (BestSampler k=1, src/sampling.cc:25-32 + DisableTokens min-length
-  // masking, src/decoding.cc:384-408, + optional LogSoftMax for scores, src/decoding.cc:874-880):
-  // writes next ids into state.d_ids, appends (id, score) to the device history at the current
-  // step and increments state.d_step.
-  void sample_greedy(DecodeState& state, int32_t eos_id, int32_t min_length, bool with_scores);
+  // Greedy / random sampling (BestSampler / RandomSampler, src/sampling.cc, + DisableTokens
+  // min-length masking, src/decoding.cc:384-408, + optional LogSoftMax for scores, :874-880) is
+  // part of step() when state.fuse_greedy is set: next ids into state.d_ids, (id, score) appended
+  // to the device history, step counter advanced by the sampler itself.
+  // Teacher-forced callers advance the step counter themselves:
   void advance_step(DecodeState& state);
 
   // Beam search (src/decoding.cc:425-720) is device resident: with state.fuse_beam set (by
