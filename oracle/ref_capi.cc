@@ -455,6 +455,47 @@ int ct2ref_generate(void* h, const int32_t* prompt_ids, const int32_t* prompt_le
   CT2REF_CATCH
 }
 
+// Generator::generate_batch with the logits-processor options (GenerationOptions::
+// repetition_penalty / no_repeat_ngram_size / suppress_sequences, include/ctranslate2/generation.h).
+int ct2ref_generate_processors(void* h, const int32_t* prompt_ids, const int32_t* prompt_lengths,
+                               int batch, int stride, int beam_size, int max_len, int min_len,
+                               int return_scores, float repetition_penalty,
+                               int no_repeat_ngram_size, const int32_t* suppress_ids,
+                               const int32_t* suppress_lengths, int num_suppress,
+                               int32_t* out_ids, int32_t* out_lengths, float* out_scores) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const auto* lm = dynamic_cast<const models::LanguageModel*>(m->model.get());
+  if (!lm || !m->generator) throw std::runtime_error("not a language model");
+  const auto& vocab = lm->get_vocabulary();
+  auto prompts = ids_to_tokens(vocab, prompt_ids, prompt_lengths, batch, stride);
+  GenerationOptions opt;
+  opt.beam_size = beam_size;
+  opt.max_length = max_len;
+  opt.min_length = min_len;
+  opt.sampling_topk = 1;
+  opt.return_scores = return_scores != 0;
+  opt.include_prompt_in_result = false;
+  opt.repetition_penalty = repetition_penalty;
+  opt.no_repeat_ngram_size = static_cast<size_t>(no_repeat_ngram_size);
+  for (int s = 0; s < num_suppress; ++s) {
+    std::vector<std::string> seq;
+    for (int t = 0; t < suppress_lengths[s]; ++t) seq.push_back(vocab.to_token(*suppress_ids++));
+    opt.suppress_sequences.push_back(std::move(seq));
+  }
+  auto futures = m->generator->generate_batch_async(prompts, opt);
+  std::vector<GenerationResult> results;
+  for (auto& f : futures) results.emplace_back(f.get());
+  for (int b = 0; b < batch; ++b) {
+    const auto& ids = results[b].sequences_ids[0];
+    const int len = static_cast<int>(ids.size());
+    for (int t = 0; t < len && t < max_len; ++t) out_ids[b * max_len + t] = ids[t];
+    out_lengths[b] = len;
+    if (return_scores && out_scores) out_scores[b] = results[b].scores[0];
+  }
+  CT2REF_CATCH
+}
+
 // Teacher-forced decoding through layers::TransformerEncoder / TransformerDecoder
 // (src/layers/transformer.cc:427-471, 621-871): runs the encoder on `src_ids`
 // ([batch, src_stride] INCLUDING any special tokens, lengths in src_lengths; pass

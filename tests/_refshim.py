@@ -276,6 +276,24 @@ class RefModel:
                                      _p(out_len), _p(scores)))
         return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
 
+    def generate_processors_ids(self, prompts, beam_size=1, max_len=64, min_len=0,
+                                return_scores=True, repetition_penalty=1.0, no_repeat_ngram_size=0,
+                                suppress_sequences_ids=()):
+        ids, lengths, stride = self._pack(prompts)
+        batch = len(prompts)
+        out = np.zeros((batch, max_len), np.int32)
+        out_len = np.zeros((batch,), np.int32)
+        scores = np.zeros((batch,), np.float32)
+        seqs = [list(q) for q in suppress_sequences_ids]
+        flat = np.array([t for q in seqs for t in q] or [0], np.int32)
+        lens = np.array([len(q) for q in seqs] or [0], np.int32)
+        _check(lib().ct2ref_generate_processors(
+            C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch), C.c_int(stride),
+            C.c_int(beam_size), C.c_int(max_len), C.c_int(min_len), C.c_int(int(return_scores)),
+            C.c_float(repetition_penalty), C.c_int(no_repeat_ngram_size), _p(flat), _p(lens),
+            C.c_int(len(seqs)), _p(out), _p(out_len), _p(scores)))
+        return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
+
     def step_logits(self, src, tgt_in, vocab_size):
         """Teacher-forced per-step logits [T, batch, vocab]. `src` includes special tokens."""
         batch = len(tgt_in)

@@ -207,3 +207,29 @@ def test_generator_beam_search_ragged_prompts(gpu, key, ct):
     gen, _ = t.generate_ids(g["prompts"], max_length=g["max_len"], min_length=g["max_len"] // 2,
                             beam_size=4)
     assert all(len(x) >= g["max_len"] // 2 for x in gen)
+
+
+@pytest.mark.parametrize("ct", ["float32", "int8"])
+@pytest.mark.parametrize("beam", [1, 4])
+@pytest.mark.parametrize("case", ["plain", "penalty", "ngram2", "suppress", "all"])
+def test_generator_logits_processors_ragged(gpu, ct, beam, case):
+    """Logits processors in Generator::generate_batch over ragged prompts (decoding starts at
+    step = shortest prompt - 1, longer prompts continue as a hidden hard prefix): the processors
+    read the device-resident token history - greedy: the id history offset by the start step;
+    beam search: the tokens of the active beams including the hidden prefix - against the real
+    reference (tests/golden/make_golden_generator_processors.py)."""
+    with open(os.path.join(HERE, "golden", "generator_processors_golden.json")) as f:
+        g = json.load(f)["lm_small" + ("_f32" if ct == "float32" else "")]
+    run = g["runs"]["%s_beam%d" % (case, beam)]
+    t = get_lm("lm_small", ct)
+    gen, scores = t.generate_ids(g["prompts"], max_length=g["max_len"], return_scores=True,
+                                 beam_size=beam, **run["options"])
+    same = [a == b for a, b in zip(gen, run["generated"])]
+    print("generator processors %s %s beam %d: %d/%d token-identical" % (case, ct, beam, sum(same), len(same)))
+    if ct == "float32":
+        assert all(same)
+        np.testing.assert_allclose(scores, np.array(run["scores"], np.float32), atol=1e-3)
+    else:
+        assert sum(same) >= len(same) - 2
+        ok = np.array(same)
+        np.testing.assert_allclose(scores[ok], np.array(run["scores"], np.float32)[ok], atol=2e-2)
