@@ -437,3 +437,35 @@ void orc_beam_select(const float* topk_scores, const int32_t* topk_ids, int64_t 
     }
   }
 }
+
+/* ops::TopPMask (src/ops/topp_mask.cc + topp_mask_cpu.cc:13-38): probs = SoftMax(x); visit the
+ * classes by decreasing probability and keep x while the probability mass visited BEFORE the
+ * class is < p, otherwise write `mask`. (std::sort is not stable: equal probabilities may be
+ * visited in any order - the restatement visits the lower index first.) */
+void orc_topp_mask(const float* x, int64_t rows, int64_t depth, float p, float mask, float* y) {
+  float* probs = (float*)malloc(sizeof(float) * (size_t)depth);
+  int64_t* ids = (int64_t*)malloc(sizeof(int64_t) * (size_t)depth);
+  for (int64_t r = 0; r < rows; ++r) {
+    const float* xr = x + r * depth;
+    float* yr = y + r * depth;
+    orc_softmax(xr, 0, 1, depth, 0, probs);
+    for (int64_t i = 0; i < depth; ++i) ids[i] = i;
+    for (int64_t i = 1; i < depth; ++i) {  /* insertion sort: probability desc, index asc */
+      const int64_t id = ids[i];
+      int64_t j = i - 1;
+      while (j >= 0 && probs[ids[j]] < probs[id]) {
+        ids[j + 1] = ids[j];
+        --j;
+      }
+      ids[j + 1] = id;
+    }
+    float total = 0.f;
+    for (int64_t i = 0; i < depth; ++i) {
+      const int64_t id = ids[i];
+      yr[id] = total < p ? xr[id] : mask;
+      total += probs[id];
+    }
+  }
+  free(probs);
+  free(ids);
+}

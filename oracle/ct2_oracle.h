@@ -69,6 +69,9 @@ void orc_beam_select(const float* topk_scores, const int32_t* topk_ids, int64_t 
                      int32_t* cand_word, float* cand_score, int32_t* cand_origin,
                      int32_t* next_ids, float* next_scores, int32_t* parents);
 
+/* ops::TopPMask (src/ops/topp_mask_cpu.cc:13-38): keep while the mass visited before is < p. */
+void orc_topp_mask(const float* x, int64_t rows, int64_t depth, float p, float mask, float* y);
+
 /* ops::Gather axis 0 (src/ops/gather_cpu.cc). */
 void orc_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int64_t row_bytes,
                      void* out);

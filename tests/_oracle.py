@@ -175,6 +175,19 @@ def beam_select(topk_scores, topk_ids, beam, vocab, eos, prefix=None, step=0):
     return cw, cs, co, ni, ns, pa
 
 
+def topp_mask(x, p, mask=-np.inf):
+    x = _f32(x)
+    rows, depth = x.shape
+    y = np.empty_like(x)
+    lib().orc_topp_mask(_p(x), _i64(rows), _i64(depth), C.c_float(p), C.c_float(mask), _p(y))
+    return y
+
+
+def activation(x, act):
+    return np.array([lib().orc_activation(C.c_float(float(v)), C.c_int(act)) for v in np.ravel(x)],
+                    np.float32).reshape(np.shape(x))
+
+
 def topk(x, k):
     x = _f32(x)
     rows, depth = x.shape

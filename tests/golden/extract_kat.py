@@ -4,8 +4,9 @@ CPU test-suite can pin the oracle (and the -m gpu suite the HIP kernels) against
 golden values without /root/reference being present. Only numbers are extracted.
 
 Sources: tests/ops_test.cc (GemmInt8 :683, QuantizeINT8 :936, QuantizeINT8ZeroRow :969, TopK :710,
-SoftMax :791, LogSoftMax :807, MaskedSoftMax :825, LayerNorm :880, RMSNorm :920) and
-tests/layers_test.cc (RotaryEmbedding :108).
+TopKVariableDepth :726, TopKChangeK :746, TopPMask :772, SoftMax :791, LogSoftMax :807,
+MaskedSoftMax :825, MaskedSoftMaxTriangular :841, LayerNorm :880, RMSNorm :920, the float Gemm
+family :516-680, the activations :1015-1095) and tests/layers_test.cc (RotaryEmbedding :108).
 """
 import json
 import os
@@ -32,7 +33,10 @@ def vectors(body):
         kind, payload = m.group(1), m.group(2)
         vals = [v.strip() for v in payload.replace("\n", " ").split(",") if v.strip()]
         if kind in ("float",):
-            out.append([float(v.rstrip("f")) for v in vals])
+            def num(v):
+                v = v.replace("inf", "INF")          # the TopPMask vectors use +-inf
+                return float(v.rstrip("f").replace("INF", "inf"))
+            out.append([num(v) for v in vals])
         else:
             out.append([int(v) for v in vals])
     return out
@@ -64,6 +68,42 @@ kat["RMSNorm"] = {"gamma": v[0], "x": v[1], "shape": [2, 5], "y": v[2], "eps": 1
 v = vectors(test_body(layers, "RotaryEmbedding"))
 kat["RotaryEmbedding"] = {"x": v[0], "shape": [2, 4, 2, 6], "y": v[1], "offset": 2,
                           "base": 10000.0, "interleave": True}
+
+# float Gemm with fused bias / residual / activation (tests/ops_test.cc:516-680): shared inputs
+m = re.search(r"static const StorageView gemm_a\(.*?\);\s*static const StorageView gemm_b\(.*?\);"
+              r"\s*static const StorageView gemm_y\(.*?\);", ops, re.S)
+ga, gb, gy = vectors(m.group(0))
+v = vectors(test_body(ops, "Gemm"))
+gemm = {"a": ga, "a_shape": [4, 5], "b": gb, "b_shape": [5, 2], "y": gy, "y_shape": [4, 2],
+        "a_b_plus_y": v[0]}
+v = vectors(test_body(ops, "GemmBias"))
+gemm["bias"] = v[0]
+gemm["a_b_plus_bias_plus_y"] = v[1]
+v = vectors(test_body(ops, "GemmResidual"))
+gemm["residual"] = v[0]
+gemm["residual_bias"] = v[1]
+gemm["a_b_plus_bias_plus_y_plus_residual"] = v[2]
+gemm["a_b_plus_y_plus_residual"] = v[3]
+v = vectors(test_body(ops, "GemmGELU"))
+gemm["gelu_bias"] = v[0]
+gemm["gelu_a_b_plus_bias"] = v[3]
+gemm["gelu_a_b"] = v[4]
+kat["GemmFloat"] = gemm
+v = vectors(test_body(ops, "TopKVariableDepth"))
+kat["TopKVariableDepth"] = {"x": v[3], "shape": [2, 4], "k": 3, "values": v[4], "indices": v[5]}
+v = vectors(test_body(ops, "TopKChangeK"))
+kat["TopKChangeK"] = {"x": v[0], "shape": [2, 6], "values_k2": v[1], "indices_k2": v[2],
+                      "values_k3": v[3], "indices_k3": v[4]}
+v = vectors(test_body(ops, "TopPMask"))
+kat["TopPMask"] = {"x": v[0], "shape": [2, 5], "p": 0.97, "kept": [[1, 1, 1, 0, 1], [1, 1, 0, 0, 1]]}
+v = vectors(test_body(ops, "MaskedSoftMaxTriangular"))
+kat["MaskedSoftMaxTriangular"] = {"x": v[0], "shape": [2, 2, 3, 3], "lengths": v[1], "y": v[2]}
+acts = {}
+for name, act_id in (("ReLU", 0), ("GELUTanh", 1), ("Swish", 2), ("GELU", 3), ("GELUSigmoid", 4),
+                     ("Tanh", 5), ("Sigmoid", 6)):
+    v = vectors(test_body(ops, name))
+    acts[name] = {"act": act_id, "x": v[0], "y": v[1]}
+kat["Activations"] = acts
 
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ops_kat.json")
 with open(out, "w") as f:

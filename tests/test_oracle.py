@@ -236,3 +236,66 @@ def test_kat_penalize_previous_tokens_and_logsumexp():
     x = np.array([[0.6, 0.2, -1.2, 0.1, 0.3, 0.5, -1.3, 0.2]], np.float32)
     lse = x[0, 0] - O.softmax(x, None, True)[0, 0]
     assert abs(float(lse) - 2.1908040046691895) < 1e-6
+
+
+def test_kat_float_gemm_family():
+    """OpDeviceFPTest.Gemm / GemmBias / GemmResidual / GemmGELU (tests/ops_test.cc:516-680): the
+    float Gemm with fused bias, residual and activation. beta = 1 cases (`+ y`) are expressed as a
+    residual, which is how layers::Dense uses the op."""
+    g = KAT["GemmFloat"]
+    a = np.array(g["a"], np.float32).reshape(g["a_shape"])
+    b = np.array(g["b"], np.float32).reshape(g["b_shape"])
+    y = np.array(g["y"], np.float32).reshape(g["y_shape"])
+    res = np.array(g["residual"], np.float32).reshape(g["y_shape"])
+
+    def run(**kw):
+        return O.gemm_f32(a, b, trans_b=False, **kw).ravel()
+
+    tol = dict(atol=1e-5, rtol=0)
+    np.testing.assert_allclose(run(residual=y), g["a_b_plus_y"], **tol)
+    np.testing.assert_allclose(O.gemm_f32(a, np.ascontiguousarray(b.T), trans_b=True, residual=y).ravel(),
+                               g["a_b_plus_y"], **tol)
+    np.testing.assert_allclose(run(bias=np.array(g["bias"], np.float32), residual=y),
+                               g["a_b_plus_bias_plus_y"], **tol)
+    np.testing.assert_allclose(run(bias=np.array(g["residual_bias"], np.float32), residual=y + res),
+                               g["a_b_plus_bias_plus_y_plus_residual"], **tol)
+    np.testing.assert_allclose(run(residual=y + res), g["a_b_plus_y_plus_residual"], **tol)
+    np.testing.assert_allclose(run(bias=np.array(g["gelu_bias"], np.float32), act=3),
+                               g["gelu_a_b_plus_bias"], **tol)
+    np.testing.assert_allclose(run(act=3), g["gelu_a_b"], **tol)
+
+
+def test_kat_topk_variants_and_topp_mask():
+    """OpDeviceTest.TopKVariableDepth / TopKChangeK and OpDeviceFPTest.TopPMask
+    (tests/ops_test.cc:726-790)."""
+    t = KAT["TopKVariableDepth"]
+    v, i = O.topk(np.array(t["x"], np.float32).reshape(t["shape"]), t["k"])
+    assert np.array_equal(v.ravel(), np.array(t["values"], np.float32))
+    assert np.array_equal(i.ravel(), np.array(t["indices"], np.int32))
+    t = KAT["TopKChangeK"]
+    x = np.array(t["x"], np.float32).reshape(t["shape"])
+    for k in (2, 3):
+        v, i = O.topk(x, k)
+        assert np.array_equal(v.ravel(), np.array(t["values_k%d" % k], np.float32))
+        assert np.array_equal(i.ravel(), np.array(t["indices_k%d" % k], np.int32))
+    t = KAT["TopPMask"]
+    x = np.array(t["x"], np.float32).reshape(t["shape"])
+    y = O.topp_mask(x, t["p"])
+    kept = np.array(t["kept"], bool)
+    assert np.array_equal(np.isfinite(y), kept)
+    assert np.array_equal(y[kept], x[kept])
+
+
+def test_kat_masked_softmax_triangular_and_activations():
+    """OpDeviceFPTest.MaskedSoftMaxTriangular (tests/ops_test.cc:841-878: lengths from
+    prepare_length_mask(lengths, heads = 2, queries = 3, triangular) = min(length, q + 1)) and the
+    activation functors ReLU / GELU / GELUTanh / GELUSigmoid / Sigmoid / Swish / Tanh (:1015-1095)."""
+    t = KAT["MaskedSoftMaxTriangular"]
+    b, h, q, kk = t["shape"]
+    x = np.array(t["x"], np.float32).reshape(b * h * q, kk)
+    lengths = np.array([min(t["lengths"][bi], qi + 1) for bi in range(b) for _ in range(h)
+                        for qi in range(q)], np.int32)
+    np.testing.assert_allclose(O.softmax(x, lengths, False).ravel(), t["y"], atol=1e-5, rtol=0)
+    for name, a in KAT["Activations"].items():
+        np.testing.assert_allclose(O.activation(np.array(a["x"], np.float32), a["act"]),
+                                   np.array(a["y"], np.float32), atol=1e-5, rtol=0, err_msg=name)
