@@ -158,3 +158,59 @@ def test_host_beam_bookkeeping_matches_the_oracle():
     # finalize_hypothesis_score: score / length^penalty (src/decoding.cc:192-207)
     assert abs(L.ct2x_host_finalize_score(C.c_float(-6.0), C.c_float(3.0), C.c_float(1.0)) + 2.0) < 1e-6
     assert L.ct2x_host_finalize_score(C.c_float(-6.0), C.c_float(3.0), C.c_float(0.0)) == -6.0
+
+
+REFERENCE = "/root/reference"
+
+
+def _nm(path, flag):
+    import subprocess
+    out = subprocess.check_output(["nm", flag, path], text=True)
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "include", "ctranslate2", "ops", "ops.h")),
+                    reason="needs the reference headers (/root/reference)")
+def test_integration_stubs_match_the_reference_headers(tmp_path):
+    """The drop-in boundary, proven at link level. tests/integration/ops_mi355_stub.cc (the Level-1
+    stubs of INTEGRATION.md) compiles warning-free against the reference's REAL headers, and it
+    defines, with identical mangled names, the Device::CUDA float symbols that the reference's own
+    op front-ends (src/ops/*.cc compiled with the CUDA arm of DEVICE_DISPATCH enabled,
+    -DCT2_WITH_CUDA) leave undefined - i.e. exactly what src/ops/*_gpu.cu provides today.
+    Reference sources are only compiled where they lie; objects go to a temporary directory."""
+    import subprocess
+    inc = ["-I" + os.path.join(ROOT, "oracle", "shim"), "-I" + os.path.join(REFERENCE, "include"),
+           "-I" + os.path.join(REFERENCE, "src"), "-I" + os.path.join(REFERENCE, "third_party"),
+           "-I" + os.path.join(ROOT, "include")]
+    stub = str(tmp_path / "stub.o")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-c"] + inc +
+                          [os.path.join(HERE, "integration", "ops_mi355_stub.cc"), "-o", stub])
+    defined = _nm(stub, "--defined-only")
+    checked = 0
+    for op in ("quantize", "dequantize", "layer_norm", "rms_norm", "softmax", "rotary", "topk", "gather"):
+        obj = str(tmp_path / (op + ".o"))
+        subprocess.check_call(["g++", "-std=c++17", "-DCT2_WITH_CUDA", "-w", "-c"] + inc +
+                              [os.path.join(REFERENCE, "src", "ops", op + ".cc"), "-o", obj])
+        # undefined Device::CUDA (enumerator 1) member templates of namespace ops whose builtin
+        # template arguments include float and no int16 (the float arm: "f", "fa", "af", "fi");
+        # the half / bfloat16 arms and the integer payloads of Gather forward the same way
+        needed = set()
+        for sym in _nm(obj, "-u"):
+            m = re.search(r"11ctranslate23ops.*ILNS_6DeviceE1E([a-z]+)EE", sym)
+            if m and "f" in m.group(1) and "s" not in m.group(1):
+                needed.add(sym)
+        assert needed, op
+        missing = needed - defined
+        assert not missing, (op, sorted(missing))
+        checked += len(needed)
+    assert checked >= 9
+    # primitives<Device::CUDA> / cross_device_primitives the front-ends reach for on this path
+    for src, pattern in (("ops/gemm", r"10primitivesILNS_6DeviceE1EE4gemmIaiEE"),
+                         ("decoding_utils", r"10primitivesILNS_6DeviceE1EE24penalize_previous_tokensIfEE"),
+                         ("storage_view", r"23cross_device_primitivesILNS_6DeviceE(1ELS1_0|0ELS1_1)EE4copyIfEE")):
+        obj = str(tmp_path / (os.path.basename(src) + ".o"))
+        subprocess.check_call(["g++", "-std=c++17", "-DCT2_WITH_CUDA", "-w", "-c"] + inc +
+                              [os.path.join(REFERENCE, "src", src + ".cc"), "-o", obj])
+        needed = {sym for sym in _nm(obj, "-u") if re.search(pattern, sym)}
+        assert needed, src
+        assert needed <= defined, (src, sorted(needed - defined))
