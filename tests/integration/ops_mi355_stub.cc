@@ -138,19 +138,26 @@ namespace ctranslate2 {
                       values.data<float>(), indices.data<int32_t>(), stream()));
     }
 
-    // include/ctranslate2/ops/gather.h:19-24  <-  src/ops/gather_gpu.cu:53-91 (axis 0 form)
-    template<>
-    void Gather::compute<Device::CUDA, float>(const StorageView& data,
-                                              const StorageView& input,
-                                              const dim_t axis,
-                                              const dim_t batch_dims,
-                                              StorageView& output) const {
-      if (axis != 0 || batch_dims != 0)
-        throw std::invalid_argument("Gather: only axis 0 (the beam reorder / embedding form)");
-      const dim_t row_size = data.size() / data.dim(0);
-      check(ct2x_gather_rows(data.data<float>(), input.data<int32_t>(), input.size(),
-                             row_size * dim_t(sizeof (float)), output.data<float>(), stream()));
+    // include/ctranslate2/ops/gather.h:19-24  <-  src/ops/gather_gpu.cu:53-91 (axis 0 form).
+    // Rows are moved as bytes, so every payload type of the dispatch shares one device entry.
+#define CT2X_GATHER_STUB(T)                                                                  \
+    template<>                                                                               \
+    void Gather::compute<Device::CUDA, T>(const StorageView& data,                           \
+                                          const StorageView& input,                          \
+                                          const dim_t axis,                                  \
+                                          const dim_t batch_dims,                            \
+                                          StorageView& output) const {                       \
+      if (axis != 0 || batch_dims != 0)                                                      \
+        throw std::invalid_argument("Gather: only axis 0 (the beam reorder / embedding form)"); \
+      const dim_t row_size = data.size() / data.dim(0);                                      \
+      check(ct2x_gather_rows(data.data<T>(), input.data<int32_t>(), input.size(),            \
+                             row_size * dim_t(sizeof (T)), output.data<T>(), stream()));     \
     }
+    CT2X_GATHER_STUB(float)
+    CT2X_GATHER_STUB(int8_t)
+    CT2X_GATHER_STUB(int16_t)
+    CT2X_GATHER_STUB(int32_t)
+#undef CT2X_GATHER_STUB
 
   }
 
@@ -188,18 +195,26 @@ namespace ctranslate2 {
                               stream()));
   }
 
-  // include/ctranslate2/primitives.h:235-239  <-  src/cuda/primitives.cu:685-754
-  template<>
-  template<>
-  void cross_device_primitives<Device::CUDA, Device::CPU>::copy(const float* x, float* y, dim_t size) {
-    check(ct2x_copy_to_host(x, y, size * sizeof (float), stream()));  // returns when landed
+  // include/ctranslate2/primitives.h:24 (copy) and :235-239 (cross_device_primitives)
+  //   <-  src/cuda/primitives.cu:97-101, 685-754. Byte copies: one macro over the payload types.
+#define CT2X_COPY_STUBS(T)                                                                        \
+  template<> template<>                                                                           \
+  void primitives<Device::CUDA>::copy(const T* x, T* y, dim_t size) {                             \
+    check(ct2x_copy_device(x, y, size * sizeof (T), stream()));                                   \
+  }                                                                                               \
+  template<> template<>                                                                           \
+  void cross_device_primitives<Device::CUDA, Device::CPU>::copy(const T* x, T* y, dim_t size) {   \
+    check(ct2x_copy_to_host(x, y, size * sizeof (T), stream())); /* returns when landed */        \
+  }                                                                                               \
+  template<> template<>                                                                           \
+  void cross_device_primitives<Device::CPU, Device::CUDA>::copy(const T* x, T* y, dim_t size) {   \
+    check(ct2x_copy_to_device(x, y, size * sizeof (T), stream()));                                \
   }
-
-  template<>
-  template<>
-  void cross_device_primitives<Device::CPU, Device::CUDA>::copy(const float* x, float* y, dim_t size) {
-    check(ct2x_copy_to_device(x, y, size * sizeof (float), stream()));
-  }
+  CT2X_COPY_STUBS(float)
+  CT2X_COPY_STUBS(int8_t)
+  CT2X_COPY_STUBS(int16_t)
+  CT2X_COPY_STUBS(int32_t)
+#undef CT2X_COPY_STUBS
 
   // include/ctranslate2/allocator.h:24-26  <-  src/cuda/allocator.cc
   class Mi355Allocator : public Allocator {
