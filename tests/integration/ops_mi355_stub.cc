@@ -178,6 +178,58 @@ namespace ctranslate2 {
     check(ct2x_gemm_s8s8s32(a, b, m, n, k, c, stream()));
   }
 
+  // include/ctranslate2/primitives.h (gemm<float, float>)  <-  src/cuda/primitives.cu:485-520:
+  // the shapes ops::Gemm produces for layers::Dense (row-major, no padding, alpha 1, beta 0).
+  template<>
+  template<>
+  void primitives<Device::CUDA>::gemm(bool, bool,
+                                      bool transpose_a, bool transpose_b,
+                                      dim_t m, dim_t n, dim_t k,
+                                      float alpha,
+                                      const float* a, dim_t lda,
+                                      const float* b, dim_t ldb,
+                                      float beta,
+                                      float* c, dim_t ldc,
+                                      const float*) {
+    if (transpose_a || alpha != 1 || beta != 0 || lda != k || ldb != (transpose_b ? k : n) || ldc != n)
+      throw std::invalid_argument("float GEMM: only contiguous A.B / A.B^T with alpha=1, beta=0");
+    check(ct2x_gemm_f32(a, b, m, n, k, transpose_b ? 1 : 0, nullptr, nullptr, CT2X_ACT_NONE, c,
+                        stream()));
+  }
+
+  // include/ctranslate2/primitives.h:224-232  <-  src/cuda/primitives.cu:599-683, as ops::MatMul
+  // calls it (src/ops/matmul.cc:62-73): contiguous batches, beta 0.
+  template<>
+  template<>
+  void primitives<Device::CUDA>::gemm_batch_strided(bool transpose_a, bool transpose_b,
+                                                    dim_t m, dim_t n, dim_t k,
+                                                    float alpha,
+                                                    const float* a, dim_t lda, dim_t stridea,
+                                                    const float* b, dim_t ldb, dim_t strideb,
+                                                    float beta,
+                                                    float* c, dim_t ldc, dim_t stridec,
+                                                    dim_t batch_size) {
+    if (transpose_a || beta != 0 || lda != k || ldb != (transpose_b ? k : n) || ldc != n
+        || stridea != m * k || strideb != n * k || stridec != m * n)
+      throw std::invalid_argument("batched float GEMM: only contiguous batches of A.B / A.B^T, beta=0");
+    check(ct2x_matmul_f32(a, b, batch_size, m, n, k, transpose_b ? 1 : 0, alpha, c, stream()));
+  }
+
+  // include/ctranslate2/primitives.h:13-14  <-  src/cuda/primitives.cu:60-65: scalar read, the
+  // copy has landed when the call returns.
+#define CT2X_AT_STUB(T)                                                    \
+  template<> template<>                                                    \
+  T primitives<Device::CUDA>::at(const T* x, dim_t index) {                \
+    T value = T();                                                         \
+    check(ct2x_copy_to_host(x + index, &value, sizeof (T), stream()));     \
+    return value;                                                          \
+  }
+  CT2X_AT_STUB(float)
+  CT2X_AT_STUB(int8_t)
+  CT2X_AT_STUB(int16_t)
+  CT2X_AT_STUB(int32_t)
+#undef CT2X_AT_STUB
+
   // include/ctranslate2/primitives.h:145-151  <-  src/cuda/primitives.cu (penalize_previous_tokens):
   // RepetitionPenalty has already gathered previous_scores; the one-launch processor redoes the
   // gather itself, so the stub passes the scores and the ids and leaves the other processors off.
