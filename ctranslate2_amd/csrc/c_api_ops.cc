@@ -410,6 +410,72 @@ int ct2x_beam_select(const float* d_topk_scores, const int32_t* d_topk_ids, int6
   API_CATCH
 }
 
+int ct2x_binary(int op, const void* d_a, const void* d_b, void* d_c, int64_t size, int dtype,
+                void* stream) {
+  API_TRY
+  launch_binary(op, d_a, d_b, d_c, size, dtype, resolve_stream(stream));
+  check_last_launch("binary");
+  API_CATCH
+}
+
+int ct2x_binary_scalar(int op, double a, const void* d_x, void* d_y, int64_t size, int dtype,
+                       void* stream) {
+  API_TRY
+  launch_binary_scalar(op, a, d_x, d_y, size, dtype, resolve_stream(stream));
+  check_last_launch("binary_scalar");
+  API_CATCH
+}
+
+int ct2x_broadcast(int op, int kind, const void* d_a, const void* d_b, void* d_c, int64_t a_size,
+                   int64_t b_size, int64_t block, int dtype, void* stream) {
+  API_TRY
+  launch_broadcast(op, kind, d_a, d_b, d_c, a_size, b_size, block, dtype, resolve_stream(stream));
+  check_last_launch("broadcast");
+  API_CATCH
+}
+
+int ct2x_fill(void* d_x, double value, int64_t size, int64_t stride, int dtype, void* stream) {
+  API_TRY
+  CT2X_CHECK(stride >= 1, "ct2x_fill: stride must be >= 1");
+  launch_fill(d_x, value, size, stride, dtype, resolve_stream(stream));
+  check_last_launch("fill");
+  API_CATCH
+}
+
+int ct2x_indexed_fill(void* d_x, double value, const int32_t* d_indices, int64_t num_indices,
+                      int dtype, void* stream) {
+  API_TRY
+  launch_indexed_fill(d_x, value, d_indices, num_indices, dtype, resolve_stream(stream));
+  check_last_launch("indexed_fill");
+  API_CATCH
+}
+
+int ct2x_unary(int fn, const float* d_x, float* d_y, int64_t size, void* stream) {
+  API_TRY
+  launch_unary(fn, d_x, d_y, size, resolve_stream(stream));
+  check_last_launch("unary");
+  API_CATCH
+}
+
+int ct2x_transpose(const void* d_a, const int64_t* dims, const int64_t* perm, int rank, void* d_b,
+                   int dtype, void* stream) {
+  API_TRY
+  CT2X_CHECK(dims != nullptr && perm != nullptr, "ct2x_transpose: dims / perm missing");
+  launch_transpose(d_a, dims, perm, rank, d_b, dtype, resolve_stream(stream));
+  check_last_launch("transpose");
+  API_CATCH
+}
+
+int ct2x_prepare_length_mask(const int32_t* d_lengths, int64_t batch, int64_t heads,
+                             int64_t queries, int mask_future, int multi_query, int32_t* d_mask,
+                             void* stream) {
+  API_TRY
+  launch_prepare_length_mask(d_lengths, batch, heads, queries, mask_future != 0, multi_query != 0,
+                             d_mask, resolve_stream(stream));
+  check_last_launch("prepare_length_mask");
+  API_CATCH
+}
+
 int ct2x_gather_rows(const void* d_data, const int32_t* d_idx, int64_t n_idx,
                      int64_t row_bytes, void* d_out, void* stream) {
   API_TRY

@@ -305,3 +305,30 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
                           const int32_t* extra_min_per_batch = nullptr, int32_t beam = 1);
 
 }  // namespace ct2x
+
+// ---- element-wise / layout members of primitives<Device::CUDA> (primitives.hip) -------------
+namespace ct2x {
+
+// op: 0 add, 1 sub, 2 mul, 3 min, 4 max. dtype: ct2x_dtype (float32, int8, int16, int32).
+void launch_binary(int op, const void* a, const void* b, void* c, int64_t size, int dtype,
+                   hipStream_t stream);
+// y = x op scalar (add, mul, min, max)
+void launch_binary_scalar(int op, double scalar, const void* x, void* y, int64_t size, int dtype,
+                          hipStream_t stream);
+// kind 0 batch (c[i] = a[i % a_size] op b[i]), 1 depth (a[i / (b_size / a_size)]), 2 block
+// (a[(i / block) % a_size]); op add or mul.
+void launch_broadcast(int op, int kind, const void* a, const void* b, void* c, int64_t a_size,
+                      int64_t b_size, int64_t block, int dtype, hipStream_t stream);
+void launch_fill(void* x, double value, int64_t size, int64_t stride, int dtype, hipStream_t stream);
+void launch_indexed_fill(void* x, double value, const int32_t* indices, int64_t n, int dtype,
+                         hipStream_t stream);
+// fn 0..6 = ops::ActivationType, 7 exp, 8 log, 9 sin, 10 cos
+void launch_unary(int fn, const float* x, float* y, int64_t size, hipStream_t stream);
+// b = transpose(a reshaped to dims[rank], perm); rank 2..4; dims / perm are HOST arrays
+void launch_transpose(const void* a, const int64_t* dims, const int64_t* perm, int rank, void* b,
+                      int dtype, hipStream_t stream);
+void launch_prepare_length_mask(const int32_t* lengths, int64_t batch, int64_t heads,
+                                int64_t queries, bool mask_future, bool multi_query,
+                                int32_t* mask, hipStream_t stream);
+
+}  // namespace ct2x

@@ -1,0 +1,266 @@
+// Element-wise / layout members of primitives<Device::CUDA> that the reference's UNFUSED front-end
+// calls between the hot ops (include/ctranslate2/primitives.h:10-233; CUDA bodies in
+// src/cuda/primitives.cu, CPU bodies in src/cpu/primitives.cc): add / sub / mul / min / max in
+// their vector and scalar forms, the batch / depth / block broadcasts, fill / strided_fill /
+// indexed_fill, the unary float functions, transpose_2d/3d/4d and prepare_length_mask. The fused
+// engine uses none of them (the work is folded into its kernels); they exist so that the Level-1
+// stubs (tests/integration/ops_mi355_stub.cc, BOUNDARY.md) cover what a maintainer's op-by-op
+// build links against. All of them are plain HBM-bound scans: one element per lane and
+// grid-stride step, consecutive lanes on consecutive addresses.
+#include "device_utils.h"
+#include "kernels.h"
+#include "runtime.h"
+
+namespace ct2x {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline unsigned blocks_for(int64_t size) {
+  const int64_t b = (size + kThreads - 1) / kThreads;
+  return static_cast<unsigned>(b < 1 ? 1 : (b > 65535 ? 65535 : b));
+}
+
+template <typename T>
+__device__ __forceinline__ T apply_binary(int op, T a, T b) {
+  switch (op) {
+    case 0: return static_cast<T>(a + b);
+    case 1: return static_cast<T>(a - b);
+    case 2: return static_cast<T>(a * b);
+    case 3: return a < b ? a : b;
+    default: return a > b ? a : b;
+  }
+}
+
+// c[i] = a[i] op b[i]
+template <typename T>
+__global__ void binary_kernel(int op, const T* __restrict__ a, const T* __restrict__ b,
+                              T* __restrict__ c, int64_t size) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < size;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    c[i] = apply_binary<T>(op, a[i], b[i]);
+}
+
+// y[i] = x[i] op a   (add / mul / min / max with a scalar; commutative forms only)
+template <typename T>
+__global__ void binary_scalar_kernel(int op, T a, const T* __restrict__ x, T* __restrict__ y,
+                                     int64_t size) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < size;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    y[i] = apply_binary<T>(op, x[i], a);
+}
+
+// kind 0: batch broadcast  c[i] = a[i % a_size] op b[i]        (add_/mul_batch_broadcast)
+// kind 1: depth broadcast  c[i] = a[i / depth] op b[i], depth = b_size / a_size
+// kind 2: block broadcast  c[i] = a[(i / block) % a_size] op b[i]
+template <typename T>
+__global__ void broadcast_kernel(int op, int kind, const T* __restrict__ a,
+                                 const T* __restrict__ b, T* __restrict__ c, int64_t a_size,
+                                 int64_t b_size, int64_t block) {
+  const int64_t depth = a_size > 0 ? b_size / a_size : 1;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < b_size;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    int64_t ai;
+    if (kind == 0)
+      ai = i % a_size;
+    else if (kind == 1)
+      ai = i / depth;
+    else
+      ai = (i / block) % a_size;
+    c[i] = apply_binary<T>(op, a[ai], b[i]);
+  }
+}
+
+template <typename T>
+__global__ void fill_kernel(T* __restrict__ x, T value, int64_t size, int64_t stride) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < size;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    x[i * stride] = value;
+}
+
+template <typename T>
+__global__ void indexed_fill_kernel(T* __restrict__ x, T value, const int32_t* __restrict__ idx,
+                                    int64_t n) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    x[idx[i]] = value;
+}
+
+// fn: 0..6 = ops::ActivationType (ReLU, GELUTanh, Swish, GELU, GELUSigmoid, Tanh, Sigmoid),
+// 7 exp, 8 log, 9 sin, 10 cos.
+__global__ void unary_kernel(int fn, const float* __restrict__ x, float* __restrict__ y,
+                             int64_t size) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < size;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const float v = x[i];
+    float r;
+    if (fn <= 6)
+      r = apply_activation(v, fn);
+    else if (fn == 7)
+      r = expf(v);
+    else if (fn == 8)
+      r = logf(v);
+    else if (fn == 9)
+      r = sinf(v);
+    else
+      r = cosf(v);
+    y[i] = r;
+  }
+}
+
+// b = transpose(a, perm): rank padded to 4, out shape[k] = dims[perm[k]], consecutive lanes
+// write consecutive output elements.
+struct TransposeParams {
+  int64_t out_dims[4];
+  int64_t in_strides_of_out[4];  // stride in `a` of the input axis that output axis k walks
+};
+
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ a, T* __restrict__ b, int64_t size,
+                                 TransposeParams p) {
+  for (int64_t o = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; o < size;
+       o += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    int64_t rem = o, in = 0;
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+      const int64_t j = rem % p.out_dims[k];
+      rem /= p.out_dims[k];
+      in += j * p.in_strides_of_out[k];
+    }
+    b[o] = a[in];
+  }
+}
+
+// AttentionLayer::prepare_length_mask (src/cpu/primitives.cc:431-448)
+__global__ void length_mask_kernel(const int32_t* __restrict__ lengths, int64_t heads,
+                                   int64_t queries, bool mask_future, bool multi_query,
+                                   int32_t* __restrict__ mask, int64_t total) {
+  const int64_t per_batch = heads * queries;
+  for (int64_t o = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; o < total;
+       o += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t b = o / per_batch, i = o % per_batch;
+    const int32_t length = lengths[b];
+    int32_t v = length;
+    if (mask_future) {
+      const int32_t q = static_cast<int32_t>(multi_query ? i / heads : i % queries) + 1;
+      v = length < q ? length : q;
+    }
+    mask[o] = v;
+  }
+}
+
+template <typename F>
+void by_dtype(int dtype, F&& f) {
+  switch (dtype) {
+    case 0: f(float()); break;
+    case 1: f(int8_t()); break;
+    case 2: f(int16_t()); break;
+    case 3: f(int32_t()); break;
+    default: throw Error("element-wise primitive: dtype must be float32, int8, int16 or int32");
+  }
+}
+
+}  // namespace
+
+void launch_binary(int op, const void* a, const void* b, void* c, int64_t size, int dtype,
+                   hipStream_t stream) {
+  if (size == 0) return;
+  if (op < 0 || op > 4) throw Error("launch_binary: op must be add, sub, mul, min or max");
+  by_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(binary_kernel<T>, dim3(blocks_for(size)), dim3(kThreads), 0, stream, op,
+                       static_cast<const T*>(a), static_cast<const T*>(b), static_cast<T*>(c), size);
+  });
+}
+
+void launch_binary_scalar(int op, double scalar, const void* x, void* y, int64_t size, int dtype,
+                          hipStream_t stream) {
+  if (size == 0) return;
+  if (op != 0 && op != 2 && op != 3 && op != 4)
+    throw Error("launch_binary_scalar: op must be add, mul, min or max");
+  by_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(binary_scalar_kernel<T>, dim3(blocks_for(size)), dim3(kThreads), 0, stream,
+                       op, static_cast<T>(scalar), static_cast<const T*>(x), static_cast<T*>(y), size);
+  });
+}
+
+void launch_broadcast(int op, int kind, const void* a, const void* b, void* c, int64_t a_size,
+                      int64_t b_size, int64_t block, int dtype, hipStream_t stream) {
+  if (b_size == 0) return;
+  if (a_size <= 0 || kind < 0 || kind > 2 || (kind == 2 && block <= 0) || (op != 0 && op != 2))
+    throw Error("launch_broadcast: bad arguments");
+  by_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(broadcast_kernel<T>, dim3(blocks_for(b_size)), dim3(kThreads), 0, stream, op,
+                       kind, static_cast<const T*>(a), static_cast<const T*>(b), static_cast<T*>(c),
+                       a_size, b_size, block);
+  });
+}
+
+void launch_fill(void* x, double value, int64_t size, int64_t stride, int dtype, hipStream_t stream) {
+  if (size == 0) return;
+  by_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(fill_kernel<T>, dim3(blocks_for(size)), dim3(kThreads), 0, stream,
+                       static_cast<T*>(x), static_cast<T>(value), size, stride);
+  });
+}
+
+void launch_indexed_fill(void* x, double value, const int32_t* indices, int64_t n, int dtype,
+                         hipStream_t stream) {
+  if (n == 0) return;
+  by_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(indexed_fill_kernel<T>, dim3(blocks_for(n)), dim3(kThreads), 0, stream,
+                       static_cast<T*>(x), static_cast<T>(value), indices, n);
+  });
+}
+
+void launch_unary(int fn, const float* x, float* y, int64_t size, hipStream_t stream) {
+  if (size == 0) return;
+  if (fn < 0 || fn > 10) throw Error("launch_unary: unknown function");
+  hipLaunchKernelGGL(unary_kernel, dim3(blocks_for(size)), dim3(kThreads), 0, stream, fn, x, y, size);
+}
+
+void launch_transpose(const void* a, const int64_t* dims, const int64_t* perm, int rank, void* b,
+                      int dtype, hipStream_t stream) {
+  if (rank < 2 || rank > 4) throw Error("launch_transpose: rank must be 2, 3 or 4");
+  int64_t d[4] = {1, 1, 1, 1}, pm[4] = {0, 1, 2, 3};
+  const int pad = 4 - rank;  // leading unit axes
+  bool seen[4] = {false, false, false, false};
+  for (int i = 0; i < rank; ++i) {
+    if (perm[i] < 0 || perm[i] >= rank || seen[perm[i]]) throw Error("launch_transpose: bad permutation");
+    seen[perm[i]] = true;
+    d[pad + i] = dims[i];
+    pm[pad + i] = pad + perm[i];
+  }
+  int64_t in_stride[4];
+  in_stride[3] = 1;
+  for (int i = 2; i >= 0; --i) in_stride[i] = in_stride[i + 1] * d[i + 1];
+  TransposeParams p;
+  int64_t size = 1;
+  for (int k = 0; k < 4; ++k) {
+    p.out_dims[k] = d[pm[k]];
+    p.in_strides_of_out[k] = in_stride[pm[k]];
+    size *= d[k];
+  }
+  if (size == 0) return;
+  by_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(transpose_kernel<T>, dim3(blocks_for(size)), dim3(kThreads), 0, stream,
+                       static_cast<const T*>(a), static_cast<T*>(b), size, p);
+  });
+}
+
+void launch_prepare_length_mask(const int32_t* lengths, int64_t batch, int64_t heads,
+                                int64_t queries, bool mask_future, bool multi_query,
+                                int32_t* mask, hipStream_t stream) {
+  const int64_t total = batch * heads * queries;
+  if (total == 0) return;
+  hipLaunchKernelGGL(length_mask_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, stream, lengths,
+                     heads, queries, mask_future, multi_query, mask, total);
+}
+
+}  // namespace ct2x

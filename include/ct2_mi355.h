@@ -234,6 +234,39 @@ int ct2x_beam_select(const float* d_topk_scores, const int32_t* d_topk_ids, int6
                      int32_t* d_cand_word, float* d_cand_score, int32_t* d_cand_origin,
                      int32_t* d_next_ids, float* d_next_scores, int32_t* d_parents, void* stream);
 
+/* ---- element-wise / layout members of primitives<Device::CUDA> --------------------------------
+ * What the reference's UNFUSED front-end calls between the hot ops (include/ctranslate2/
+ * primitives.h:10-233; src/cuda/primitives.cu, CPU bodies src/cpu/primitives.cc). The fused engine
+ * needs none of them. dtype: CT2X_F32, CT2X_I8, CT2X_I16 or CT2X_I32. */
+enum ct2x_binary_op { CT2X_OP_ADD = 0, CT2X_OP_SUB = 1, CT2X_OP_MUL = 2, CT2X_OP_MIN = 3, CT2X_OP_MAX = 4 };
+/* primitives::add / sub / mul / min / max (const T* a, const T* b, T* c, size): c = a op b. */
+int ct2x_binary(int op, const void* d_a, const void* d_b, void* d_c, int64_t size, int dtype,
+                void* stream);
+/* primitives::add / mul / min / max (T a, const T* x, T* y, size): y = x op a. */
+int ct2x_binary_scalar(int op, double a, const void* d_x, void* d_y, int64_t size, int dtype,
+                       void* stream);
+/* primitives::add_batch_broadcast / mul_batch_broadcast (kind 0: c[i] = a[i % a_size] op b[i]),
+ * add_depth_broadcast (kind 1: a[i / (b_size / a_size)]), add_block_broadcast (kind 2:
+ * a[(i / block) % a_size]); op CT2X_OP_ADD or CT2X_OP_MUL (src/cpu/primitives.cc:150-190,283-292). */
+int ct2x_broadcast(int op, int kind, const void* d_a, const void* d_b, void* d_c, int64_t a_size,
+                   int64_t b_size, int64_t block, int dtype, void* stream);
+/* primitives::fill (stride 1) / strided_fill: x[i * stride] = value for i < size. */
+int ct2x_fill(void* d_x, double value, int64_t size, int64_t stride, int dtype, void* stream);
+/* primitives::indexed_fill: x[indices[i]] = value (DisableTokens::apply, src/decoding_utils.cc:19-35). */
+int ct2x_indexed_fill(void* d_x, double value, const int32_t* d_indices, int64_t num_indices,
+                      int dtype, void* stream);
+/* primitives::relu / gelu / gelu_tanh / gelu_sigmoid / sigmoid / swish / tanh (fn = the
+ * ct2x_activation id) and exp / log / sin / cos (fn = 7 / 8 / 9 / 10), float32. */
+int ct2x_unary(int fn, const float* d_x, float* d_y, int64_t size, void* stream);
+/* primitives::transpose_2d / 3d / 4d: b = transpose(a viewed as dims[rank], perm), rank 2..4;
+ * dims and perm are HOST arrays. */
+int ct2x_transpose(const void* d_a, const int64_t* dims, const int64_t* perm, int rank, void* d_b,
+                   int dtype, void* stream);
+/* primitives::prepare_length_mask (src/cpu/primitives.cc:431-448): mask [batch, heads * queries]. */
+int ct2x_prepare_length_mask(const int32_t* d_lengths, int64_t batch, int64_t heads,
+                             int64_t queries, int mask_future, int multi_query, int32_t* d_mask,
+                             void* stream);
+
 /* ops::Gather::compute<Device::CUDA,T> axis 0 (src/ops/gather_gpu.cu:53-91):
  * out[i,:] = data[idx[i],:] for rows of row_bytes bytes. */
 int ct2x_gather_rows(const void* d_data, const int32_t* d_idx, int64_t n_idx,

@@ -268,6 +268,134 @@ namespace ctranslate2 {
   CT2X_COPY_STUBS(int32_t)
 #undef CT2X_COPY_STUBS
 
+  // ---- element-wise / layout members (include/ctranslate2/primitives.h:16-185  <-
+  //      src/cuda/primitives.cu:103-483): one device entry per family, see primitives.hip -----
+  template <typename T> struct ct2x_type;
+  template<> struct ct2x_type<float> { static constexpr int id = CT2X_F32; };
+  template<> struct ct2x_type<int8_t> { static constexpr int id = CT2X_I8; };
+  template<> struct ct2x_type<int16_t> { static constexpr int id = CT2X_I16; };
+  template<> struct ct2x_type<int32_t> { static constexpr int id = CT2X_I32; };
+
+#define CT2X_ARITH_STUBS(T)                                                                          \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::fill(T* x, T a, dim_t size) {                                       \
+    check(ct2x_fill(x, double(a), size, 1, ct2x_type<T>::id, stream()));                             \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::strided_fill(T* x, T a, dim_t inc_x, dim_t size) {                  \
+    check(ct2x_fill(x, double(a), size, inc_x, ct2x_type<T>::id, stream()));                         \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::indexed_fill(T* x, T a, const int32_t* indices, dim_t n) {          \
+    check(ct2x_indexed_fill(x, double(a), indices, n, ct2x_type<T>::id, stream()));                  \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::add(T a, const T* x, T* y, dim_t size) {                            \
+    check(ct2x_binary_scalar(CT2X_OP_ADD, double(a), x, y, size, ct2x_type<T>::id, stream()));       \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::add(const T* a, const T* b, T* c, dim_t size) {                     \
+    check(ct2x_binary(CT2X_OP_ADD, a, b, c, size, ct2x_type<T>::id, stream()));                      \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::sub(const T* a, const T* b, T* c, dim_t size) {                     \
+    check(ct2x_binary(CT2X_OP_SUB, a, b, c, size, ct2x_type<T>::id, stream()));                      \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::mul(T a, const T* x, T* y, dim_t size) {                            \
+    check(ct2x_binary_scalar(CT2X_OP_MUL, double(a), x, y, size, ct2x_type<T>::id, stream()));       \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::mul(const T* a, const T* b, T* c, dim_t size) {                     \
+    check(ct2x_binary(CT2X_OP_MUL, a, b, c, size, ct2x_type<T>::id, stream()));                      \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::min(T a, const T* x, T* y, dim_t size) {                            \
+    check(ct2x_binary_scalar(CT2X_OP_MIN, double(a), x, y, size, ct2x_type<T>::id, stream()));       \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::min(const T* a, const T* b, T* c, dim_t size) {                     \
+    check(ct2x_binary(CT2X_OP_MIN, a, b, c, size, ct2x_type<T>::id, stream()));                      \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::max(T a, const T* x, T* y, dim_t size) {                            \
+    check(ct2x_binary_scalar(CT2X_OP_MAX, double(a), x, y, size, ct2x_type<T>::id, stream()));       \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::max(const T* a, const T* b, T* c, dim_t size) {                     \
+    check(ct2x_binary(CT2X_OP_MAX, a, b, c, size, ct2x_type<T>::id, stream()));                      \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::add_batch_broadcast(const T* a, const T* b, T* c,                   \
+                                                     dim_t a_size, dim_t b_size) {                   \
+    check(ct2x_broadcast(CT2X_OP_ADD, 0, a, b, c, a_size, b_size, 0, ct2x_type<T>::id, stream()));   \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::add_depth_broadcast(const T* a, const T* b, T* c,                   \
+                                                     dim_t a_size, dim_t b_size) {                   \
+    check(ct2x_broadcast(CT2X_OP_ADD, 1, a, b, c, a_size, b_size, 0, ct2x_type<T>::id, stream()));   \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::add_block_broadcast(const T* a, const T* b, T* c, dim_t block,      \
+                                                     dim_t a_size, dim_t b_size) {                   \
+    check(ct2x_broadcast(CT2X_OP_ADD, 2, a, b, c, a_size, b_size, block, ct2x_type<T>::id, stream())); \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::mul_batch_broadcast(const T* a, const T* b, T* c,                   \
+                                                     dim_t a_size, dim_t b_size) {                   \
+    check(ct2x_broadcast(CT2X_OP_MUL, 0, a, b, c, a_size, b_size, 0, ct2x_type<T>::id, stream()));   \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::transpose_2d(const T* a, const dim_t* dims, T* b) {                 \
+    const int64_t perm[2] = {1, 0};                                                                  \
+    check(ct2x_transpose(a, dims, perm, 2, b, ct2x_type<T>::id, stream()));                          \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::transpose_3d(const T* a, const dim_t* dims, const dim_t* perm,      \
+                                              T* b) {                                                \
+    check(ct2x_transpose(a, dims, perm, 3, b, ct2x_type<T>::id, stream()));                          \
+  }                                                                                                  \
+  template<> template<>                                                                              \
+  void primitives<Device::CUDA>::transpose_4d(const T* a, const dim_t* dims, const dim_t* perm,      \
+                                              T* b) {                                                \
+    check(ct2x_transpose(a, dims, perm, 4, b, ct2x_type<T>::id, stream()));                          \
+  }
+  CT2X_ARITH_STUBS(float)
+  CT2X_ARITH_STUBS(int8_t)
+  CT2X_ARITH_STUBS(int16_t)
+  CT2X_ARITH_STUBS(int32_t)
+#undef CT2X_ARITH_STUBS
+
+#define CT2X_UNARY_STUB(NAME, FN)                                                  \
+  template<> template<>                                                            \
+  void primitives<Device::CUDA>::NAME(const float* x, float* y, dim_t size) {      \
+    check(ct2x_unary(FN, x, y, size, stream()));                                   \
+  }
+  CT2X_UNARY_STUB(relu, CT2X_ACT_RELU)
+  CT2X_UNARY_STUB(gelu_tanh, CT2X_ACT_GELU_TANH)
+  CT2X_UNARY_STUB(swish, CT2X_ACT_SWISH)
+  CT2X_UNARY_STUB(gelu, CT2X_ACT_GELU)
+  CT2X_UNARY_STUB(gelu_sigmoid, CT2X_ACT_GELU_SIGMOID)
+  CT2X_UNARY_STUB(tanh, CT2X_ACT_TANH)
+  CT2X_UNARY_STUB(sigmoid, CT2X_ACT_SIGMOID)
+  CT2X_UNARY_STUB(exp, 7)
+  CT2X_UNARY_STUB(log, 8)
+  CT2X_UNARY_STUB(sin, 9)
+  CT2X_UNARY_STUB(cos, 10)
+#undef CT2X_UNARY_STUB
+
+  template<>
+  void primitives<Device::CUDA>::prepare_length_mask(const int32_t* lengths,
+                                                     dim_t batch_size,
+                                                     dim_t num_heads,
+                                                     dim_t num_queries,
+                                                     bool mask_future,
+                                                     bool multi_query,
+                                                     int32_t* mask) {
+    check(ct2x_prepare_length_mask(lengths, batch_size, num_heads, num_queries, mask_future ? 1 : 0,
+                                   multi_query ? 1 : 0, mask, stream()));
+  }
+
   // include/ctranslate2/allocator.h:24-26  <-  src/cuda/allocator.cc
   class Mi355Allocator : public Allocator {
   public:
