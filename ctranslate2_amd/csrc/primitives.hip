@@ -34,9 +34,10 @@ __device__ __forceinline__ T apply_binary(int op, T a, T b) {
 }
 
 // c[i] = a[i] op b[i]
+// (no __restrict__ on these element-wise kernels: the reference calls them in place, e.g.
+// primitives::add(x, y, size) = add(x, y, y, size), include/ctranslate2/primitives.h:36-38)
 template <typename T>
-__global__ void binary_kernel(int op, const T* __restrict__ a, const T* __restrict__ b,
-                              T* __restrict__ c, int64_t size) {
+__global__ void binary_kernel(int op, const T* a, const T* b, T* c, int64_t size) {
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < size;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x)
     c[i] = apply_binary<T>(op, a[i], b[i]);
@@ -44,8 +45,7 @@ __global__ void binary_kernel(int op, const T* __restrict__ a, const T* __restri
 
 // y[i] = x[i] op a   (add / mul / min / max with a scalar; commutative forms only)
 template <typename T>
-__global__ void binary_scalar_kernel(int op, T a, const T* __restrict__ x, T* __restrict__ y,
-                                     int64_t size) {
+__global__ void binary_scalar_kernel(int op, T a, const T* x, T* y, int64_t size) {
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < size;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x)
     y[i] = apply_binary<T>(op, x[i], a);
@@ -55,9 +55,8 @@ __global__ void binary_scalar_kernel(int op, T a, const T* __restrict__ x, T* __
 // kind 1: depth broadcast  c[i] = a[i / depth] op b[i], depth = b_size / a_size
 // kind 2: block broadcast  c[i] = a[(i / block) % a_size] op b[i]
 template <typename T>
-__global__ void broadcast_kernel(int op, int kind, const T* __restrict__ a,
-                                 const T* __restrict__ b, T* __restrict__ c, int64_t a_size,
-                                 int64_t b_size, int64_t block) {
+__global__ void broadcast_kernel(int op, int kind, const T* __restrict__ a, const T* b, T* c,
+                                 int64_t a_size, int64_t b_size, int64_t block) {
   const int64_t depth = a_size > 0 ? b_size / a_size : 1;
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < b_size;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
@@ -89,8 +88,7 @@ __global__ void indexed_fill_kernel(T* __restrict__ x, T value, const int32_t* _
 
 // fn: 0..6 = ops::ActivationType (ReLU, GELUTanh, Swish, GELU, GELUSigmoid, Tanh, Sigmoid),
 // 7 exp, 8 log, 9 sin, 10 cos.
-__global__ void unary_kernel(int fn, const float* __restrict__ x, float* __restrict__ y,
-                             int64_t size) {
+__global__ void unary_kernel(int fn, const float* x, float* y, int64_t size) {
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < size;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const float v = x[i];

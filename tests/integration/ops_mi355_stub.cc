@@ -159,6 +159,34 @@ namespace ctranslate2 {
     CT2X_GATHER_STUB(int32_t)
 #undef CT2X_GATHER_STUB
 
+    // include/ctranslate2/ops/bias_add.h:20-24  <-  src/ops/bias_add_gpu.cu:46-102 (the CPU body,
+    // src/ops/bias_add_cpu.cc:6-34, composes the same three steps): broadcast add of the bias,
+    // optional residual, optional activation - here over the element-wise entry points.
+    template<>
+    void BiasAdd::compute<Device::CUDA, float>(const StorageView& value,
+                                               const StorageView& bias,
+                                               StorageView& output,
+                                               const StorageView* residual) const {
+      if (_axis == -1 || _axis == value.rank() - 1) {
+        check(ct2x_broadcast(CT2X_OP_ADD, 0, bias.data<float>(), value.data<float>(),
+                             output.data<float>(), bias.size(), value.size(), 0, CT2X_F32, stream()));
+      } else {
+        const dim_t axis = _axis < 0 ? value.rank() + _axis : _axis;
+        dim_t width = 1;
+        for (dim_t i = axis + 1; i < value.rank(); ++i)
+          width *= value.dim(i);
+        check(ct2x_broadcast(CT2X_OP_ADD, 2, bias.data<float>(), value.data<float>(),
+                             output.data<float>(), bias.size(), value.size(), width, CT2X_F32,
+                             stream()));
+      }
+      if (residual)
+        check(ct2x_binary(CT2X_OP_ADD, residual->data<float>(), output.data<float>(),
+                          output.data<float>(), output.size(), CT2X_F32, stream()));
+      if (_activation_type)
+        check(ct2x_unary(int(*_activation_type), output.data<float>(), output.data<float>(),
+                         output.size(), stream()));
+    }
+
   }
 
   // include/ctranslate2/primitives.h (gemm)  <-  src/cuda/primitives.cu:571-597
