@@ -48,6 +48,10 @@ def test_binary_vector_scalar_and_broadcast(gpu, code):
             _lib.check(L.ct2x_binary_scalar(op, C.c_double(float(s)), _lib.ptr(ad), _lib.ptr(c),
                                             G.i64(n), code, None))
             assert np.array_equal(G.host(c), fn(a, s).astype(dt)), op
+    # in place, as the reference calls it: primitives::add(x, y, size) = add(x, y, y, size)
+    acc = G.dev(b.copy())
+    _lib.check(L.ct2x_binary(0, _lib.ptr(ad), _lib.ptr(acc), _lib.ptr(acc), G.i64(n), code, None))
+    assert np.array_equal(G.host(acc), np.add(a, b).astype(dt))
     # broadcasts: batch (add, mul), depth, block
     a_size, reps = 37, 211
     av, bv = _rand(rng, a_size, dt), _rand(rng, a_size * reps, dt)
