@@ -135,80 +135,111 @@ void orc_gemm_f32(const float* a, const float* b, int64_t m, int64_t n, int64_t 
   }
 }
 
-/* layer_norm (src/cpu/kernels.cc:461-496). */
+/* ---------------------------------------------------------------------------------------------
+ * Bit-exact restatements of the reference's fp32 row kernels AS COMPILED into oracle/_ref
+ * (g++ -O2, -mavx2 -mfma, GCC's default -ffp-contract=fast; ISA picked at run time = AVX2,
+ * src/cpu/cpu_isa.cc:45-78). Read from the disassembly of oracle/_ref/obj/cpu/kernels_avx2.o and
+ * pinned bit for bit against oracle/_ref by tests/test_oracle.py::test_exact_*.
+ * ------------------------------------------------------------------------------------------- */
+
+/* layer_norm (src/cpu/kernels.cc:461-496, a CT2_FFAST_MATH region, scalar at -O2):
+ *   inv_n = 1/n; sum += x, sumsq = fma(x, x, sumsq) strictly in index order;
+ *   mean = sum*inv_n; var = max(fma(sumsq, inv_n, -(mean*mean)), 0); rstd = 1/sqrt(var+eps);
+ *   y = fma(x - mean, rstd*gamma, beta)           (fast-math re-association of (x-mean)*rstd*gamma) */
 void orc_layer_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
                     int64_t depth, float eps, float* y) {
+  const float inv_n = 1.f / (float)depth;
   for (int64_t i = 0; i < rows; ++i) {
     const float* xr = x + i * depth;
     float* yr = y + i * depth;
     float sum = 0.f, sumsq = 0.f;
     for (int64_t j = 0; j < depth; ++j) {
-      sum += xr[j];
-      sumsq += xr[j] * xr[j];
+      sumsq = fmaf(xr[j], xr[j], sumsq);
+      sum = sum + xr[j];
     }
-    const float mean = sum / (float)depth;
-    float variance = sumsq / (float)depth - mean * mean;
-    if (variance < 0.f) variance = 0.f;
+    const float mean = sum * inv_n;
+    const float mm = mean * mean;
+    float variance = fmaf(sumsq, inv_n, -mm);
+    if (!(variance > 0.f)) variance = 0.f; /* std::max(variance, 0.f) */
     const float rstd = 1.f / sqrtf(variance + eps);
-    for (int64_t j = 0; j < depth; ++j) yr[j] = (xr[j] - mean) * rstd * gamma[j] + beta[j];
+    for (int64_t j = 0; j < depth; ++j) yr[j] = fmaf(xr[j] - mean, rstd * gamma[j], beta[j]);
   }
 }
 
-/* rms_norm (src/cpu/kernels.cc:543-573). */
+/* rms_norm (src/cpu/kernels.cc:543-573, same region): sumsq = fma(x, x, sumsq) in order;
+ * inv_rms = 1/sqrt(fma(sumsq, 1/n, eps)); y = (inv_rms*x)*gamma  or (inv_rms*x)*(gamma+1). */
 void orc_rms_norm(const float* x, const float* gamma, int64_t rows, int64_t depth, float eps,
                   int use_residual, float* y) {
+  const float inv_n = 1.f / (float)depth;
   for (int64_t i = 0; i < rows; ++i) {
     const float* xr = x + i * depth;
     float* yr = y + i * depth;
     float sumsq = 0.f;
-    for (int64_t j = 0; j < depth; ++j) sumsq += xr[j] * xr[j];
-    const float inv_rms = 1.f / sqrtf(sumsq / (float)depth + eps);
+    for (int64_t j = 0; j < depth; ++j) sumsq = fmaf(xr[j], xr[j], sumsq);
+    const float inv_rms = 1.f / sqrtf(fmaf(sumsq, inv_n, eps));
     for (int64_t j = 0; j < depth; ++j) {
-      if (use_residual)
-        yr[j] = xr[j] * inv_rms * (1.f + gamma[j]);
-      else
-        yr[j] = xr[j] * inv_rms * gamma[j];
+      const float t = inv_rms * xr[j];
+      yr[j] = use_residual ? t * (gamma[j] + 1.f) : t * gamma[j];
     }
   }
 }
 
-/* vectorized_map_reduce_all on the AVX2 ISA the reference dispatches to by default
- * (src/cpu/kernels.cc:86-123, src/cpu/cpu_isa.cc:45-78): 8 strided partial sums, horizontal add,
- * then the scalar tail. Restated because a single sequential fp32 sum over a 32k..128k
- * vocabulary row drifts by ~1e-5 relative, which the reference does not. */
-static float sum8_exp(const float* x, int64_t size, float x_max, float* store) {
-  if (size <= 8) {
-    float acc = 0.f;
-    for (int64_t j = 0; j < size; ++j) {
-      const float e = expf(x[j] - x_max);
-      if (store) store[j] = e;
-      acc += e;
-    }
-    return acc;
-  }
-  const int64_t remaining = size % 8;
-  const int64_t vsize = size - remaining;
-  float lane[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int64_t j = 0; j < vsize; j += 8)
-    for (int l = 0; l < 8; ++l) {
-      const float e = expf(x[j + l] - x_max);
-      if (store) store[j + l] = e;
-      lane[l] += e;
-    }
-  /* reduce_m256: (lo + hi) halves, then pairwise */
+/* exp256_ps (third_party/avx_mathfun.h:290-344) as GCC contracts it for the AVX2 kernels:
+ * every mul+add pair of the Cephes polynomial became one FMA (disassembly of cpu::softmax). */
+float orc_exp_avx2(float x) {
+  if (x > 88.3762626647949f) x = 88.3762626647949f;
+  if (x < -88.3762626647949f) x = -88.3762626647949f;
+  float fx = fmaf(x, 1.44269504088896341f, 0.5f);
+  float tmp = floorf(fx);
+  if (tmp > fx) tmp = tmp - 1.f;
+  fx = tmp;
+  x = fmaf(-fx, 0.693359375f, x);
+  x = fmaf(-fx, -2.12194440e-4f, x);
+  const float z = x * x;
+  float y = 1.9875691500E-4f;
+  y = fmaf(y, x, 1.3981999507E-3f);
+  y = fmaf(y, x, 8.3334519073E-3f);
+  y = fmaf(y, x, 4.1665795894E-2f);
+  y = fmaf(y, x, 1.6666665459E-1f);
+  y = fmaf(y, x, 5.0000001201E-1f);
+  y = fmaf(y, z, x);
+  y = y + 1.f;
+  union { int32_t i; float f; } pow2n;
+  pow2n.i = ((int32_t)fx + 0x7f) << 23;
+  return y * pow2n.f;
+}
+
+/* reduce_m256 (src/cpu/vec_avx.h:27-41): lane l + lane l^4, then l^2, then l^1. */
+static float hsum8(const float* lane) {
   float h4[4], h2[2];
   for (int l = 0; l < 4; ++l) h4[l] = lane[l] + lane[l + 4];
   for (int l = 0; l < 2; ++l) h2[l] = h4[l] + h4[l + 2];
-  float acc = h2[0] + h2[1];
-  for (int64_t j = vsize; j < size; ++j) {
-    const float e = expf(x[j] - x_max);
-    if (store) store[j] = e;
-    acc += e;
+  return h2[0] + h2[1];
+}
+
+/* vectorized_map_reduce_all / vectorized_reduce_all with Vec::add (src/cpu/kernels.cc:86-139):
+ * 8 strided partial sums, reduce_m256, then the scalar tail; a row of <= 8 elements is summed
+ * sequentially. e[j] are the already mapped values. */
+static float sum8_ordered(const float* e, int64_t size) {
+  if (size <= 8) {
+    float acc = 0.f;
+    for (int64_t j = 0; j < size; ++j) acc += e[j];
+    return acc;
   }
+  const int64_t vsize = size - size % 8;
+  float lane[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t j = 0; j < vsize; j += 8)
+    for (int l = 0; l < 8; ++l) lane[l] += e[j + l];
+  float acc = hsum8(lane);
+  for (int64_t j = vsize; j < size; ++j) acc += e[j];
   return acc;
 }
 
-/* softmax (src/cpu/kernels.cc:402-459). */
+/* softmax (src/cpu/kernels.cc:402-459).
+ *  - plain: y = exp256(x - max) for EVERY element (the tail goes through a padded vector, so it
+ *    uses the polynomial too), s = reduce_sum(y), y *= 1/s;
+ *  - log:   s = map-reduce where the vector body uses exp256 and the scalar TAIL (size % 8, or
+ *    the whole row when size <= 8) uses libm expf; y = x + (-max - logf(s)). */
 void orc_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth, int log,
                  float* y) {
 #pragma omp parallel for if (rows * depth > (1 << 16))
@@ -226,15 +257,133 @@ void orc_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t d
     for (int64_t j = 1; j < size; ++j)
       if (xr[j] > x_max) x_max = xr[j];
     if (log) {
-      const float exp_sum = sum8_exp(xr, size, x_max, NULL);
+      float* e = (float*)malloc(sizeof(float) * (size_t)size);
+      const int64_t vsize = size <= 8 ? 0 : size - size % 8;
+      for (int64_t j = 0; j < vsize; ++j) e[j] = orc_exp_avx2(xr[j] - x_max);
+      for (int64_t j = vsize; j < size; ++j) e[j] = expf(xr[j] - x_max);
+      const float exp_sum = sum8_ordered(e, size);
+      free(e);
       const float c = -x_max - logf(exp_sum);
       for (int64_t j = 0; j < size; ++j) yr[j] = xr[j] + c;
     } else {
-      const float exp_sum = sum8_exp(xr, size, x_max, yr);
+      for (int64_t j = 0; j < size; ++j) yr[j] = orc_exp_avx2(xr[j] - x_max);
+      const float exp_sum = sum8_ordered(yr, size);
       const float r = 1.f / exp_sum;
       for (int64_t j = 0; j < size; ++j) yr[j] = yr[j] * r;
     }
   }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * ops::MatMul on CPU = MKL cblas_sgemm_batch_strided (src/cpu/primitives.cc:1085-1101). MKL is a
+ * closed third-party library (Intel oneMKL 2021.4.0, conda-meta mkl-2021.4.0; not under
+ * /root/reference), so its summation order cannot be cited: it was RECOVERED on this container
+ * with cancellation probes (+2^24, -2^24, 0.25 triples give the tree; random data picks
+ * fma vs mul+add per node) and is pinned bit for bit against oracle/_ref for every shape class
+ * below by tests/test_oracle.py::test_exact_matmul_*. The results do not depend on operand
+ * alignment. Shapes outside the validated envelope return -1.
+ *
+ *  (1) m == 1, trans_b, k == 64 (decode QK^T, one query per (row, head)):
+ *      outputs are produced in groups of 4 columns ("main") and a tail of n % 4 columns.
+ *      16 lane accumulators over k = 1..k-1, lane (k-1) % 16, element 0 handled apart.
+ *  (2) m == 1, no transpose (decode P.V): k consumed in blocks of 8 through four 2-element FMA
+ *      chains, then sequential FMAs.
+ *  (3) m >= 3 and n >= 5 (trans_b), or m >= 2 (no transpose): plain k-ordered FMA chain.
+ * ------------------------------------------------------------------------------------------- */
+static float tree16(float* acc) {
+  for (int w = 8; w >= 1; w /= 2)
+    for (int l = 0; l < w; ++l) acc[l] = acc[l] + acc[l + w];
+  return acc[0];
+}
+
+static float mkl_dot_main(const float* a, const float* b, int64_t k) {
+  float acc[16], r[16];
+  for (int l = 0; l < 16; ++l) acc[l] = r[l] = 0.f;
+  const int64_t body = ((k - 1) / 16) * 16;
+  acc[0] = a[0] * b[0];
+  for (int64_t t = 1; t <= body; ++t) acc[(t - 1) % 16] = fmaf(a[t], b[t], acc[(t - 1) % 16]);
+  const float s = tree16(acc);
+  for (int64_t t = body + 2; t < k; ++t) r[t - body - 1] = a[t] * b[t];
+  r[0] = fmaf(a[body + 1], b[body + 1], s);
+  return tree16(r);
+}
+
+static float mkl_dot_tail(const float* a, const float* b, int64_t k, int type_a) {
+  float acc[16];
+  for (int l = 0; l < 16; ++l) acc[l] = 0.f;
+  for (int64_t t = 1; t < k; ++t) {
+    const int l = (int)((t - 1) % 16), c = (int)((t - 1) / 16);
+    if (c == 0)
+      acc[l] = a[t] * b[t];
+    else if (c == 1 && type_a) {
+      const float p = a[t] * b[t];
+      acc[l] = acc[l] + p;
+    } else
+      acc[l] = fmaf(a[t], b[t], acc[l]);
+  }
+  const float s = tree16(acc);
+  const float p0 = a[0] * b[0];
+  return s + p0;
+}
+
+static void mkl_qk_m1(const float* q, const float* km, int64_t n, int64_t k, float* y) {
+  const int64_t main_n = (n / 4) * 4;
+  for (int64_t t = 0; t < main_n; ++t) y[t] = mkl_dot_main(q, km + t * k, k);
+  for (int64_t t = main_n; t < n; ++t) y[t] = mkl_dot_tail(q, km + t * k, k, (t - main_n) != 1);
+}
+
+static float mkl_pv_m1_col(const float* p, const float* v, int64_t ldv, int64_t k) {
+  float y = 0.f;
+  int has = 0;
+  const int64_t nb = k / 8;
+  for (int64_t b = 0; b < nb; ++b) {
+    const float* pp = p + 8 * b;
+    const float* vv = v + 8 * b * ldv;
+    const float A = fmaf(pp[0], vv[0 * ldv], pp[2] * vv[2 * ldv]);
+    const float B = fmaf(pp[1], vv[1 * ldv], pp[3] * vv[3 * ldv]);
+    const float c6 = has ? fmaf(pp[6], vv[6 * ldv], y) : pp[6] * vv[6 * ldv];
+    const float C = fmaf(pp[4], vv[4 * ldv], c6);
+    const float D = fmaf(pp[5], vv[5 * ldv], pp[7] * vv[7 * ldv]);
+    y = (C + D) + (A + B);
+    has = 1;
+  }
+  for (int64_t t = 8 * nb; t < k; ++t) {
+    if (!has) {
+      y = p[t] * v[t * ldv];
+      has = 1;
+    } else
+      y = fmaf(p[t], v[t * ldv], y);
+  }
+  return y;
+}
+
+int orc_matmul(const float* a, const float* b, int64_t batch, int64_t m, int64_t n, int64_t k,
+               int trans_b, float alpha, float* c) {
+  int status = 0;
+  for (int64_t bi = 0; bi < batch; ++bi) {
+    const float* A = a + bi * m * k;
+    const float* B = b + bi * n * k;
+    float* C = c + bi * m * n;
+    if (m == 1 && trans_b && k == 64) {
+      mkl_qk_m1(A, B, n, k, C);
+    } else if (m == 1 && !trans_b) {
+      for (int64_t j = 0; j < n; ++j) C[j] = mkl_pv_m1_col(A, B + j, n, k);
+    } else if ((trans_b && m >= 3 && n >= 5) || (!trans_b && m >= 2)) {
+      for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < n; ++j) {
+          float acc = 0.f;
+          for (int64_t t = 0; t < k; ++t)
+            acc = fmaf(A[i * k + t], trans_b ? B[j * k + t] : B[t * n + j], acc);
+          C[i * n + j] = acc;
+        }
+    } else {
+      status = -1;
+      continue;
+    }
+    if (alpha != 1.f)
+      for (int64_t e = 0; e < m * n; ++e) C[e] = C[e] * alpha;
+  }
+  return status;
 }
 
 /* rotary_kernel (src/ops/rotary_cpu.cc:9-44). */
@@ -304,37 +453,47 @@ void orc_attention_decode(const float* q, const float* k, const float* v,
                           const int32_t* lengths, int64_t length, int64_t rows, int64_t heads,
                           int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t kv_group,
                           float scale, float* out) {
+  /* Exactly the reference's three ops per (kv row, head): MatMul(trans_b, alpha = scale) over
+   * n = the padded key count (self-attention: the cache length; cross-attention: the padded
+   * memory length t_max), SoftMax(lengths), MatMul - each through the bit-exact restatements
+   * above. The kv_group query rows that share a kv row form the m dimension of the MatMul
+   * (beam search on the encoder memory, src/layers/attention.cc:805-806,840-841). */
   const int64_t group = heads / heads_kv;
+  const int64_t n = lengths ? t_max : (length < t_max ? length : t_max);
+  const int64_t kv_rows = rows / kv_group;
 #pragma omp parallel for if (rows * heads > 64)
-  for (int64_t rh = 0; rh < rows * heads; ++rh) {
-    const int64_t r = rh / heads, h = rh % heads;
-    const int64_t kvrow = r / kv_group, hk = h / group;
-    int64_t len = lengths ? lengths[kvrow] : length;
-    if (len > t_max) len = t_max;
-    const float* qv = q + (r * heads + h) * dhead;
+  for (int64_t bh = 0; bh < kv_rows * heads; ++bh) {
+    const int64_t kvrow = bh / heads, h = bh % heads, hk = h / group;
+    const int64_t m = kv_group;
     const float* kb = k + (kvrow * heads_kv + hk) * t_max * dhead;
     const float* vb = v + (kvrow * heads_kv + hk) * t_max * dhead;
-    float* o = out + (r * heads + h) * dhead;
-    for (int64_t d = 0; d < dhead; ++d) o[d] = 0.f;
-    if (len <= 0) continue;
-    float* p = (float*)malloc(sizeof(float) * (size_t)len);
-    float m = -FLT_MAX;
-    for (int64_t t = 0; t < len; ++t) {
-      float acc = 0.f;
-      for (int64_t d = 0; d < dhead; ++d) acc = fmaf(qv[d], kb[t * dhead + d], acc);
-      p[t] = acc * scale;
-      if (p[t] > m) m = p[t];
+    if (n <= 0) {
+      for (int64_t i = 0; i < m; ++i)
+        for (int64_t d = 0; d < dhead; ++d) out[((kvrow * m + i) * heads + h) * dhead + d] = 0.f;
+      continue;
     }
-    float s = 0.f;
-    for (int64_t t = 0; t < len; ++t) {
-      p[t] = expf(p[t] - m);
-      s += p[t];
+    float* qm = (float*)malloc(sizeof(float) * (size_t)(m * dhead));
+    float* sc = (float*)malloc(sizeof(float) * (size_t)(m * n));
+    float* om = (float*)malloc(sizeof(float) * (size_t)(m * dhead));
+    int32_t* ln = (int32_t*)malloc(sizeof(int32_t) * (size_t)m);
+    for (int64_t i = 0; i < m; ++i) {
+      memcpy(qm + i * dhead, q + ((kvrow * m + i) * heads + h) * dhead, sizeof(float) * dhead);
+      ln[i] = (int32_t)(lengths ? lengths[kvrow] : n);
     }
-    const float rcp = 1.f / s;
-    for (int64_t t = 0; t < len; ++t) p[t] = p[t] * rcp;
-    for (int64_t t = 0; t < len; ++t)
-      for (int64_t d = 0; d < dhead; ++d) o[d] = fmaf(p[t], vb[t * dhead + d], o[d]);
-    free(p);
+    if (orc_matmul(qm, kb, 1, m, n, dhead, 1, scale, sc) != 0) {
+      /* shape outside the recovered MKL envelope: k-ordered FMA chain (documented deviation) */
+      for (int64_t i = 0; i < m; ++i)
+        for (int64_t t = 0; t < n; ++t) {
+          float acc = 0.f;
+          for (int64_t d = 0; d < dhead; ++d) acc = fmaf(qm[i * dhead + d], kb[t * dhead + d], acc);
+          sc[i * n + t] = acc * scale;
+        }
+    }
+    orc_softmax(sc, ln, m, n, 0, sc);
+    orc_matmul(sc, vb, 1, m, dhead, n, 0, 1.f, om);
+    for (int64_t i = 0; i < m; ++i)
+      memcpy(out + ((kvrow * m + i) * heads + h) * dhead, om + i * dhead, sizeof(float) * dhead);
+    free(qm); free(sc); free(om); free(ln);
   }
 }
 

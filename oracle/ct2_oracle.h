@@ -48,6 +48,17 @@ void orc_rms_norm(const float* x, const float* gamma, int64_t rows, int64_t dept
 void orc_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth, int log,
                  float* y);
 
+/* exp256_ps as compiled into the reference's AVX2 kernels (third_party/avx_mathfun.h:290-344). */
+float orc_exp_avx2(float x);
+
+/* ops::MatMul on CPU (MKL cblas_sgemm_batch_strided, src/cpu/primitives.cc:1085-1101) with the
+ * summation order recovered from MKL 2021.4 on this container; see ct2_oracle.c. a [batch, m, k],
+ * b [batch, n, k] (trans_b) or [batch, k, n]. Returns -1 when a shape is outside the validated
+ * envelope (that batch entry is left untouched). alpha must be 1 or a power of two for the
+ * m == 1 paths to be exact (MKL's placement of alpha was only pinned for those). */
+int orc_matmul(const float* a, const float* b, int64_t batch, int64_t m, int64_t n, int64_t k,
+               int trans_b, float alpha, float* c);
+
 /* rotary_kernel (src/ops/rotary_cpu.cc:9-44): x [batch, time, depth], sin/cos [time, ndims]. */
 void orc_rotary(const float* x, const float* sin, const float* cos, int64_t batch, int64_t time,
                 int64_t depth, int64_t ndims, int interleave, float* y);

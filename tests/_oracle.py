@@ -217,3 +217,25 @@ def attention_decode(q, k, v, lengths=None, length=0, kv_group=1, scale=1.0):
                                _i64(heads), _i64(heads_kv), _i64(dhead), _i64(t_max),
                                _i64(kv_group), C.c_float(scale), _p(out))
     return out
+
+
+def matmul(a, b, trans_b=False, alpha=1.0):
+    """orc_matmul: ops::MatMul with MKL's recovered summation order; raises outside the envelope."""
+    a, b = _f32(a), _f32(b)
+    batch, m, k = a.shape
+    n = b.shape[1] if trans_b else b.shape[2]
+    c = np.zeros((batch, m, n), np.float32)
+    L = lib()
+    L.orc_matmul.restype = C.c_int
+    rc = L.orc_matmul(_p(a), _p(b), _i64(batch), _i64(m), _i64(n), _i64(k), C.c_int(int(trans_b)),
+                      C.c_float(alpha), _p(c))
+    if rc != 0:
+        raise ValueError("shape outside the validated MKL envelope")
+    return c
+
+
+def exp_avx2(x):
+    x = _f32(x)
+    L = lib()
+    L.orc_exp_avx2.restype = C.c_float
+    return np.array([L.orc_exp_avx2(C.c_float(float(v))) for v in x.ravel()], np.float32).reshape(x.shape)

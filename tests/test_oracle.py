@@ -163,6 +163,108 @@ def test_ref_float_ops_close():
                                R.rotary(xr, sin, cos, 64, False), atol=1e-6)
 
 
+# ------------------------------------------------------------------------------------------
+# Bit-exact pins: the oracle's fp32 row kernels and MatMul restate the arithmetic of oracle/_ref
+# AS COMPILED (GCC FMA contraction, scalar fast-math LayerNorm, MKL's summation trees), so the
+# comparison is array_equal, not a tolerance. These are what the HIP kernels are held to.
+# ------------------------------------------------------------------------------------------
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.int32)
+
+
+@pytest.mark.parametrize("depth", [1, 7, 8, 9, 64, 512, 1000, 4096])
+def test_exact_norms(depth):
+    R = _ref()
+    rng = np.random.default_rng(depth)
+    x = (rng.standard_normal((11, depth)) * 3 + 0.3).astype(np.float32)
+    g = rng.standard_normal(depth).astype(np.float32)
+    b = rng.standard_normal(depth).astype(np.float32)
+    assert np.array_equal(_bits(O.layer_norm(x, g, b)), _bits(R.layer_norm(x, g, b)))
+    assert np.array_equal(_bits(O.layer_norm(x, g, b, 1e-6)), _bits(R.layer_norm(x, g, b, 1e-6)))
+    for res in (False, True):
+        assert np.array_equal(_bits(O.rms_norm(x, g, 1e-6, res)), _bits(R.rms_norm(x, g, 1e-6, res)))
+    const = np.full((2, depth), 1.25, np.float32)  # variance clamps at 0
+    assert np.array_equal(_bits(O.layer_norm(const, g, b)), _bits(R.layer_norm(const, g, b)))
+
+
+@pytest.mark.parametrize("depth", [1, 2, 5, 8, 9, 15, 16, 17, 33, 64, 100, 1000, 32000])
+@pytest.mark.parametrize("log", [False, True])
+def test_exact_softmax(depth, log):
+    R = _ref()
+    rng = np.random.default_rng(depth + 7 * log)
+    rows = 9 if depth < 5000 else 3
+    x = (rng.standard_normal((rows, depth)) * 4).astype(np.float32)
+    assert np.array_equal(_bits(O.softmax(x, None, log)), _bits(R.softmax(x, None, log)))
+    L = rng.integers(0, depth + 1, rows).astype(np.int32)
+    assert np.array_equal(_bits(O.softmax(x, L, log)), _bits(R.softmax(x, L, log)))
+    wide = (x * 30).astype(np.float32)  # exercises the exp clamp at -88.376
+    assert np.array_equal(_bits(O.softmax(wide, L, log)), _bits(R.softmax(wide, L, log)))
+
+
+def test_exact_matmul_decode_qk():
+    """m = 1, trans_b, k = 64: every key count 1..70 (main groups of 4 + the three tail forms)."""
+    R = _ref()
+    rng = np.random.default_rng(21)
+    for n in range(1, 71):
+        q = rng.standard_normal((24, 1, 64)).astype(np.float32)
+        k = rng.standard_normal((24, n, 64)).astype(np.float32)
+        assert np.array_equal(_bits(O.matmul(q, k, True, 0.125)), _bits(R.matmul(q, k, True, 0.125))), n
+
+
+def test_exact_matmul_decode_pv():
+    """m = 1, no transpose: every k 1..70 and a long one; n = 64 and 128."""
+    R = _ref()
+    rng = np.random.default_rng(22)
+    for k in list(range(1, 71)) + [100, 257]:
+        for n in (64, 128):
+            p = rng.random((6, 1, k)).astype(np.float32)
+            v = rng.standard_normal((6, k, n)).astype(np.float32)
+            assert np.array_equal(_bits(O.matmul(p, v, False, 1.0)), _bits(R.matmul(p, v, False, 1.0))), (k, n)
+
+
+def test_exact_matmul_sequence():
+    """m >= 3 (encoder / beam >= 3 on the memory): k-ordered FMA chains."""
+    R = _ref()
+    rng = np.random.default_rng(23)
+    for m, n, k, tb in [(32, 32, 64, True), (4, 32, 64, True), (3, 5, 64, True), (17, 40, 64, True),
+                        (32, 64, 32, False), (4, 64, 32, False), (2, 64, 9, False), (17, 64, 40, False),
+                        (32, 32, 128, True), (20, 128, 37, False)]:
+        a = rng.standard_normal((5, m, k)).astype(np.float32)
+        b = rng.standard_normal((5, n, k) if tb else (5, k, n)).astype(np.float32)
+        assert np.array_equal(_bits(O.matmul(a, b, tb, 0.125 if tb else 1.0)),
+                              _bits(R.matmul(a, b, tb, 0.125 if tb else 1.0))), (m, n, k, tb)
+
+
+def test_matmul_envelope_is_explicit():
+    with pytest.raises(ValueError):
+        O.matmul(np.zeros((1, 1, 128), np.float32), np.zeros((1, 4, 128), np.float32), True)
+    with pytest.raises(ValueError):
+        O.matmul(np.zeros((1, 2, 64), np.float32), np.zeros((1, 8, 64), np.float32), True)
+
+
+@pytest.mark.parametrize("kv_group", [1, 4])
+def test_exact_attention_composition(kv_group):
+    """orc_attention_decode == the reference's MatMul -> SoftMax(lengths) -> MatMul, bit for bit
+    (self-attention: n = cache length; memory attention: n = padded length + lengths)."""
+    R = _ref()
+    rng = np.random.default_rng(24 + kv_group)
+    B, H, dh = 5, 8, 64
+    rows = B * kv_group
+    for T, masked in [(1, False), (6, False), (31, False), (64, False), (33, True), (8, True)]:
+        q = rng.standard_normal((rows, H, dh)).astype(np.float32)
+        k = rng.standard_normal((B, H, T, dh)).astype(np.float32)
+        v = rng.standard_normal((B, H, T, dh)).astype(np.float32)
+        lengths = rng.integers(1, T + 1, B).astype(np.int32) if masked else None
+        qm = q.reshape(B, kv_group, H, dh).transpose(0, 2, 1, 3).reshape(B * H, kv_group, dh)
+        scores = R.matmul(qm, k.reshape(B * H, T, dh), True, 0.125)
+        rep = np.repeat(lengths if masked else np.full(B, T, np.int32), H * kv_group)
+        probs = R.softmax(scores.reshape(B * H * kv_group, T), rep, False)
+        out = R.matmul(probs.reshape(B * H, kv_group, T), v.reshape(B * H, T, dh), False, 1.0)
+        out = out.reshape(B, H, kv_group, dh).transpose(0, 2, 1, 3).reshape(rows, H * dh)
+        mine = O.attention_decode(q, k, v, lengths, T, kv_group, 0.125)
+        assert np.array_equal(_bits(mine), _bits(out)), (T, masked)
+
+
 def test_ref_attention_composition():
     """The oracle's fused single-query attention == the reference's MatMul/SoftMax/MatMul chain."""
     R = _ref()
