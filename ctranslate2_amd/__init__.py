@@ -365,6 +365,41 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                                             C.c_int32(T), _lib.ptr(logits)))
         return logits
 
+    def step_taps(self, source_ids, target_in):
+        """Debugging (tests): step_logits with every producer on the path tapped. Returns
+        (logits [T, batch, vocab], [(name, array)]) - see ct2x_debug_step_taps."""
+        batch = len(target_in)
+        tgt = np.ascontiguousarray(target_in, np.int32)
+        T = tgt.shape[1]
+        lengths = np.array([len(s) for s in source_ids], np.int32)
+        stride = int(lengths.max())
+        ids = np.zeros((batch, stride), np.int32)
+        for i, s in enumerate(source_ids):
+            ids[i, :len(s)] = s
+        logits = np.empty((T, batch, self.vocab_size), np.float32)
+        _lib.check(self._L.ct2x_debug_step_taps(C.c_void_p(self._h), _lib.ptr(ids),
+                                                _lib.ptr(lengths), C.c_int32(batch),
+                                                C.c_int32(stride), _lib.ptr(tgt), C.c_int32(T),
+                                                _lib.ptr(logits)))
+        taps = []
+        name = C.create_string_buffer(96)
+        dtype, rows, cols = C.c_int32(), C.c_int64(), C.c_int64()
+        for i in range(self._L.ct2x_debug_tap_count()):
+            self._L.ct2x_debug_tap_info(C.c_int(i), name, C.c_int(96), C.byref(dtype),
+                                        C.byref(rows), C.byref(cols))
+            a = np.empty((rows.value, cols.value), np.float32 if dtype.value == 0 else np.int8)
+            if a.size:
+                self._L.ct2x_debug_tap_data(C.c_int(i), _lib.ptr(a))
+            taps.append((name.value.decode(), a))
+        return logits, taps
+
+    def set_position_table(self, table):
+        """Debugging (tests): replaces the sinusoidal position table [positions, depth]."""
+        table = np.ascontiguousarray(table, np.float32)
+        _lib.check(self._L.ct2x_debug_set_position_table(C.c_void_p(self._h), _lib.ptr(table),
+                                                         C.c_int64(table.shape[0]),
+                                                         C.c_int64(table.shape[1])))
+
     def profile_begin(self):
         _lib.check(self._L.ct2x_profile_begin(C.c_void_p(self._h)))
 

@@ -340,6 +340,10 @@ void dispatch(const AttnKernelArgs& a, hipStream_t stream) {
 
 void launch_attention_decode(const AttnDecodeParams& p, hipStream_t stream) {
   if (p.rows == 0) return;
+  if (p.row_amax_out == nullptr && attention_exact_decode_applicable(p, false)) {
+    launch_attention_exact_decode(p, 0, nullptr, nullptr, stream);  // bit-exact vs the CPU reference
+    return;
+  }
   if (attention_decode2_applicable(p, false)) {
     launch_attention_decode2(p, 0, nullptr, nullptr, stream);
     return;
@@ -356,6 +360,9 @@ void launch_attention_decode(const AttnDecodeParams& p, hipStream_t stream) {
 }
 
 bool attention_decode_can_fuse_quantize(const AttnDecodeParams& p) {
+  if (attention_exact_decode_applicable(p, true)) return true;
+  // shapes the exact kernel serves unfused must not fall back to an inexact fused form
+  if (attention_exact_decode_applicable(p, false)) return false;
   if (attention_decode2_applicable(p, true)) return true;
   // one wave per head in one workgroup, scores of every head in LDS
   return p.heads >= 1 && p.heads <= 8 &&
@@ -365,6 +372,10 @@ bool attention_decode_can_fuse_quantize(const AttnDecodeParams& p) {
 void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
                                        float* q_scales, hipStream_t stream) {
   if (p.rows == 0) return;
+  if (attention_exact_decode_applicable(p, true)) {
+    launch_attention_exact_decode(p, quant_mode, q_out, q_scales, stream);
+    return;
+  }
   if (attention_decode2_applicable(p, true)) {
     launch_attention_decode2(p, quant_mode, q_out, q_scales, stream);
     return;
@@ -386,6 +397,10 @@ void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode
 // valid = min(length[b], q + 1) when causal.
 void launch_attention_full(const AttnFullParams& f, hipStream_t stream) {
   if (f.batch * f.tq == 0) return;
+  if (attention_exact_full_applicable(f)) {
+    launch_attention_exact_full(f, stream);  // bit-exact vs the CPU reference (d_head 64, tk <= ~300)
+    return;
+  }
   if (attention_prefill_applicable(f)) {
     launch_attention_prefill(f, stream);
     return;

@@ -1,0 +1,499 @@
+// Attention that reproduces the reference CPU path BIT FOR BIT (d_head = 64), for gfx950.
+//
+// The int8 decoder re-quantises every Dense input, so a last-ulp difference in an fp32 op that
+// lands on a rounding boundary flips an int8 activation and the layers above amplify it to the
+// quantisation-noise floor: "token-identical to the CPU reference" needs the fp32 ops of
+// MultiHeadAttention (src/layers/attention.cc:178-287: MatMul(trans_b, alpha) -> SoftMax(lengths)
+// -> MatMul) to round exactly like the reference's. On the CPU these are
+//   * MatMul = MKL cblas_sgemm_batch_strided (src/cpu/primitives.cc:1085-1101). MKL's summation
+//     trees were recovered on the authoring host (see oracle/ct2_oracle.c, orc_matmul):
+//       - one query per (row, head) (m = 1): the QK^T dot products use 16 lane accumulators over
+//         k = 1..63 with element 0 apart, in a "main" form for the key groups of four and two
+//         "tail" forms for the n % 4 last keys; P.V consumes the keys in blocks of eight through
+//         four 2-element FMA chains, then one FMA per remaining key;
+//       - several queries (sequence mode, beam >= 3 over the encoder memory): k-ordered FMA chains;
+//   * SoftMax = cpu::softmax<AVX2> (src/cpu/kernels.cc:402-459): exp256_ps with GCC's FMA
+//     contraction, eight strided partial sums + reduce_m256 + scalar tail, multiply by 1 / sum.
+// The lane roles follow attention_decode2.hip (QK^T: lane = key, P.V: lane = channel); what
+// changes is the ORDER in which each lane adds. One wave per (row, query head); the heads of a
+// row share a workgroup so that ops::Quantize of the context can stay fused.
+//
+// Checked bit for bit against oracle/ct2_oracle.c (orc_attention_decode), which is itself pinned
+// bit for bit against the reference library (tests/test_oracle.py::test_exact_*).
+
+#include "device_utils.h"
+#include "kernels.h"
+#include "runtime.h"
+
+#include <atomic>
+#include <cstdlib>
+#include <float.h>
+
+namespace ct2x {
+
+namespace {
+
+__device__ __forceinline__ float tree16(float (&a)[16]) {
+#pragma unroll
+  for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+    for (int l = 0; l < w; ++l) a[l] = a[l] + a[l + w];
+  return a[0];
+}
+
+// MKL's m = 1 dot product over k = K (K <= 64; longer rows use another tail form that was not
+// recovered), "main" form (keys in the groups of four): lane accumulators over k = 1 .. body,
+// lane (k - 1) % 16, accumulator 0 seeded with q0*k0; the remainder k = body + 1 .. K - 1 goes
+// through a second 16-lane tree whose lane 0 fuses its product onto the first tree's sum.
+template <int K>
+__device__ __forceinline__ float dot_main(const float (&q)[K], const float (&k)[K]) {
+  constexpr int body = ((K - 1) / 16) * 16;
+  float acc[16], r[16];
+  acc[0] = q[0] * k[0];
+#pragma unroll
+  for (int l = 1; l < 16; ++l) acc[l] = 0.f;
+#pragma unroll
+  for (int t = 1; t <= body; ++t) acc[(t - 1) & 15] = fmaf(q[t], k[t], acc[(t - 1) & 15]);
+  const float s = tree16(acc);
+#pragma unroll
+  for (int l = 0; l < 16; ++l) r[l] = 0.f;
+  r[0] = fmaf(q[body + 1], k[body + 1], s);
+#pragma unroll
+  for (int t = body + 2; t < K; ++t) r[t - body - 1] = q[t] * k[t];
+  return tree16(r);
+}
+
+// ... and the "tail" forms (the n % 4 last keys): element 0 is added last as a rounded product;
+// type A (first and third tail key) adds the second 16-channel chunk as a rounded product when
+// the row is longer than two chunks, type B (second tail key) fuses every chunk.
+template <int K>
+__device__ __forceinline__ float dot_tail(const float (&q)[K], const float (&k)[K], bool type_a) {
+  float acc[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) acc[l] = 0.f;
+#pragma unroll
+  for (int t = 1; t < K; ++t) {
+    const int l = (t - 1) & 15, c = (t - 1) >> 4;
+    if (c == 0) {
+      acc[l] = q[t] * k[t];
+    } else if (c == 1 && K > 33) {
+      const float prod = q[t] * k[t];
+      const float fused = fmaf(q[t], k[t], acc[l]);
+      acc[l] = type_a ? acc[l] + prod : fused;
+    } else {
+      acc[l] = fmaf(q[t], k[t], acc[l]);
+    }
+  }
+  const float s = tree16(acc);
+  const float p0 = q[0] * k[0];
+  return s + p0;
+}
+
+template <int K>
+__device__ __forceinline__ float dot_seq(const float (&q)[K], const float (&k)[K]) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < K; ++t) s = fmaf(q[t], k[t], s);
+  return s;
+}
+
+struct AttnXArgs {
+  AttnDecodeParams p;
+  int8_t* q_out;
+  float* q_scales;
+  int quant_mode;
+  int teams;       // waves (query heads) per workgroup
+  int wg_per_row;
+  int group;       // query heads per KV head
+  int t_pad;       // score slots per wave (multiple of 16, >= keys + 16)
+  int wave_floats; // LDS floats per wave
+};
+
+constexpr int XVB = 16;      // V rows per batch (two blocks of eight)
+
+template <int DH, bool kSeq>
+__global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int XKS = DH + 4;   // LDS row stride of the K staging tile (floats)
+  constexpr int R4 = DH / 4;    // float4 per cache row
+  const AttnDecodeParams& p = a.p;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row = blockIdx.x / a.wg_per_row;
+  const int head = (blockIdx.x % a.wg_per_row) * a.teams + wave;
+  const bool active = head < p.heads;
+  const int hq = active ? head : 0;
+  const int hk = hq / a.group;
+  const bool appends = (hq % a.group) == 0;
+  const int kvrow = row / static_cast<int>(p.kv_group);
+  const bool chan = lane < DH;       // lanes that own a channel in the prologue / P.V phases
+  const int cl = chan ? lane : 0;
+
+  float* tq = smem + static_cast<size_t>(wave) * a.wave_floats;  // q [64]
+  float* tp = tq + 64;                                           // scores / probabilities [t_pad]
+  float* ks = tp + a.t_pad;                                      // K staging tile [64][XKS]
+  float* team_amax = smem + static_cast<size_t>(a.teams) * a.wave_floats;
+
+  float* kc = p.k_cache + static_cast<int64_t>(kvrow) * p.kv_row_stride +
+              static_cast<int64_t>(hk) * p.kv_head_stride;
+  float* vc = p.v_cache + static_cast<int64_t>(kvrow) * p.kv_row_stride +
+              static_cast<int64_t>(hk) * p.kv_head_stride;
+  const int kvs = static_cast<int>(p.kv_time_stride);
+
+  int t_cached;
+  if (p.lengths != nullptr)
+    t_cached = p.lengths[kvrow];
+  else if (p.step_ptr != nullptr)
+    t_cached = *p.step_ptr;
+  else
+    t_cached = static_cast<int>(p.length);
+  t_cached = max(0, min(t_cached, static_cast<int>(p.t_max)));
+  const bool has_new = p.k_new != nullptr;
+  const int pos = t_cached;
+  // n of the reference's MatMul: the cache length after the Concat (self-attention), or the
+  // PADDED memory length (cross-attention: masked keys still take part in the product);
+  // size of its SoftMax: the valid keys.
+  const int n_valid = t_cached + (has_new ? 1 : 0);
+  const int n_keys = p.lengths != nullptr ? static_cast<int>(p.t_max) : n_valid;
+  const int t_last = max(t_cached - 1, 0);  // loads are clamped to rows that were written
+
+  float acc_out = 0.f;
+  if (active) {
+    // ---- prologue: lane = channel ---------------------------------------------------------
+    float knew = 0.f, vnew = 0.f;
+    {
+      const float* qh = p.q + static_cast<int64_t>(row) * p.q_row_stride + hq * DH;
+      const float qd = qh[cl];
+      if (has_new) {
+        knew = p.k_new[static_cast<int64_t>(row) * p.new_row_stride + hk * DH + cl];
+        vnew = p.v_new[static_cast<int64_t>(row) * p.new_row_stride + hk * DH + cl];
+        if (appends && chan) {  // cache append in place of ops::Concat (attention.cc:541-546)
+          kc[pos * kvs + cl] = knew;
+          vc[pos * kvs + cl] = vnew;
+        }
+      }
+      if (chan) tq[cl] = qd;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- QK^T: lane = key -------------------------------------------------------------------
+    const int main_n = (n_keys / 4) * 4;
+    for (int t0 = 0; t0 < n_keys; t0 += 64) {
+      v4f st[R4];
+#pragma unroll
+      for (int it = 0; it < R4; ++it) {
+        const int i_ = it * 64 + lane;  // R4 float4 per row
+        const int tl = min(t0 + i_ / R4, t_last);
+        st[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < R4; ++it) {
+        const int i_ = it * 64 + lane;
+        *reinterpret_cast<v4f*>(ks + (i_ / R4) * XKS + (i_ % R4) * 4) = st[it];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (has_new && chan && pos >= t0 && pos < t0 + 64) ks[(pos - t0) * XKS + cl] = knew;
+      __builtin_amdgcn_wave_barrier();
+      float qv[DH], kv[DH];
+      const v4f* krow = reinterpret_cast<const v4f*>(ks + lane * XKS);
+      const v4f* qrow = reinterpret_cast<const v4f*>(tq);
+#pragma unroll
+      for (int c = 0; c < R4; ++c) {
+        const v4f k4 = krow[c], q4 = qrow[c];
+        kv[4 * c + 0] = k4.x; kv[4 * c + 1] = k4.y; kv[4 * c + 2] = k4.z; kv[4 * c + 3] = k4.w;
+        qv[4 * c + 0] = q4.x; qv[4 * c + 1] = q4.y; qv[4 * c + 2] = q4.z; qv[4 * c + 3] = q4.w;
+      }
+      const int t = t0 + lane;
+      float s;
+      if (kSeq) {
+        s = dot_seq<DH>(qv, kv);
+      } else if (t < main_n) {
+        s = dot_main<DH>(qv, kv);
+      } else {
+        s = dot_tail<DH>(qv, kv, (t - main_n) != 1);
+      }
+      if (t < n_keys) tp[t] = s * p.scale;
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- SoftMax over the n_valid leading keys; masked keys get probability 0 ---------------
+    float m = -FLT_MAX;
+    for (int t = lane; t < n_valid; t += 64) m = fmaxf(m, tp[t]);
+    m = wave_max_dpp(m);
+    for (int t = lane; t < a.t_pad; t += 64) {
+      const float sc = tp[t];
+      tp[t] = (t < n_valid) ? exp_avx2(sc - m) : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float esum = ordered_sum8(tp, n_valid);
+    const float rcp = 1.f / esum;
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < n_valid; t += 64) tp[t] = tp[t] * rcp;
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- P.V: lane = channel --------------------------------------------------------------
+    float y = 0.f;
+    bool has = false;
+    const int n_blocks = kSeq ? 0 : n_keys / 8;
+    float va[XVB], vb[XVB];
+#define CT2X_XLOAD_V(VR, T0)                                              \
+  _Pragma("unroll") for (int j = 0; j < XVB; ++j) {                       \
+    const int t_ = (T0) + j;                                              \
+    const float g_ = vc[min(t_, t_last) * kvs + cl];                      \
+    VR[j] = (has_new && t_ == pos) ? vnew : g_;                           \
+  }
+#define CT2X_XBLOCK(VR, J0, T0)                                                              \
+  {                                                                                          \
+    const v4f pa_ = *reinterpret_cast<const v4f*>(tp + (T0));                                \
+    const v4f pb_ = *reinterpret_cast<const v4f*>(tp + (T0) + 4);                            \
+    if ((T0) + 8 <= n_blocks * 8) {                                                          \
+      const float A_ = fmaf(pa_.x, VR[J0 + 0], pa_.z * VR[J0 + 2]);                          \
+      const float B_ = fmaf(pa_.y, VR[J0 + 1], pa_.w * VR[J0 + 3]);                          \
+      const float c6_ = has ? fmaf(pb_.z, VR[J0 + 6], y) : pb_.z * VR[J0 + 6];               \
+      const float C_ = fmaf(pb_.x, VR[J0 + 4], c6_);                                         \
+      const float D_ = fmaf(pb_.y, VR[J0 + 5], pb_.w * VR[J0 + 7]);                          \
+      y = (C_ + D_) + (A_ + B_);                                                             \
+      has = true;                                                                            \
+    } else {                                                                                 \
+      const float pj_[8] = {pa_.x, pa_.y, pa_.z, pa_.w, pb_.x, pb_.y, pb_.z, pb_.w};         \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
+        if ((T0) + j < n_keys) {                                                             \
+          y = has ? fmaf(pj_[j], VR[J0 + j], y) : pj_[j] * VR[J0 + j];                       \
+          has = true;                                                                        \
+        }                                                                                    \
+      }                                                                                      \
+    }                                                                                        \
+  }
+    CT2X_XLOAD_V(va, 0)
+    for (int t0 = 0; t0 < n_keys; t0 += 2 * XVB) {
+      CT2X_XLOAD_V(vb, t0 + XVB)
+      CT2X_XBLOCK(va, 0, t0)
+      if (t0 + 8 < n_keys) CT2X_XBLOCK(va, 8, t0 + 8)
+      if (!(t0 + XVB < n_keys)) break;
+      CT2X_XLOAD_V(va, t0 + 2 * XVB)
+      CT2X_XBLOCK(vb, 0, t0 + XVB)
+      if (t0 + XVB + 8 < n_keys) CT2X_XBLOCK(vb, 8, t0 + XVB + 8)
+    }
+#undef CT2X_XLOAD_V
+#undef CT2X_XBLOCK
+    acc_out = y;
+  }
+
+  if (a.q_out == nullptr) {
+    if (active && chan) p.out[static_cast<int64_t>(row) * (p.heads * DH) + hq * DH + cl] = acc_out;
+    return;
+  }
+  // ---- fused ops::Quantize of the row [heads * DH] (src/cpu/kernels.cc:577-620) -------------
+  float amax = (active && chan) ? fabsf(acc_out) : 0.f;
+  amax = wave_max_dpp(amax);
+  if (lane == 0) team_amax[wave] = amax;
+  __syncthreads();
+  amax = team_amax[0];
+  for (int w = 1; w < a.teams; ++w) amax = fmaxf(amax, team_amax[w]);
+  const float qscale = (amax != 0.f) ? 127.f / amax : 1.f;
+  if (threadIdx.x == 0) a.q_scales[row] = qscale;
+  if (active && chan)
+    a.q_out[static_cast<int64_t>(row) * (p.heads * DH) + hq * DH + cl] =
+        to_s8(acc_out, qscale, a.quant_mode);
+}
+
+// Sequence mode (encoder self-attention, prompt prefill), d_head = 64: the reference runs
+// MatMul / SoftMax / MatMul over [B*H] matrices of Tq x Tk; MKL's GEMM kernels add in k order
+// (fma chain), the SoftMax row is as above, and the masked / padded keys keep probability 0 in
+// the second product. One workgroup per (batch, head): K and V of the head live in LDS, each
+// wave takes every 4th query; lane = key for the scores, lane = channel for P.V.
+struct AttnXFullArgs {
+  AttnFullParams p;
+  int t_pad;  // score slots per wave
+};
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_x_full_kernel(AttnXFullArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const AttnFullParams& p = a.p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int hk = h / static_cast<int>(p.heads / p.heads_kv);
+  const int tk = static_cast<int>(p.tk);
+  const int length = p.lengths ? min(max(p.lengths[b], 0), tk) : tk;
+  constexpr int KS = DH + 1;  // conflict-free row reads (lane = key)
+  constexpr int R4 = DH / 4;
+  const bool chan = lane < DH;
+  const int cl = chan ? lane : 0;
+  float* k_s = smem;                                                      // [tk][KS]
+  float* v_s = k_s + ((static_cast<size_t>(tk) * KS + 3) & ~size_t(3));   // [tk][DH], 16-byte aligned
+  float* wq = v_s + static_cast<size_t>(tk) * DH + static_cast<size_t>(wave) * (64 + a.t_pad);
+  float* wp = wq + 64;                                                    // [t_pad]
+
+  const float* qb = p.q + static_cast<int64_t>(b) * p.q_batch_stride + static_cast<int64_t>(h) * DH;
+  const float* kb = p.k + static_cast<int64_t>(b) * p.k_batch_stride + static_cast<int64_t>(hk) * p.k_head_stride;
+  const float* vb = p.v + static_cast<int64_t>(b) * p.v_batch_stride + static_cast<int64_t>(hk) * p.v_head_stride;
+  for (int e = tid; e < tk * R4; e += 256) {
+    const int t = e / R4, c4 = e % R4;
+    const float4 k4 = *reinterpret_cast<const float4*>(kb + static_cast<int64_t>(t) * p.k_time_stride + c4 * 4);
+    const float4 v4 = *reinterpret_cast<const float4*>(vb + static_cast<int64_t>(t) * p.v_time_stride + c4 * 4);
+    float* kd = k_s + t * KS + c4 * 4;
+    kd[0] = k4.x; kd[1] = k4.y; kd[2] = k4.z; kd[3] = k4.w;
+    *reinterpret_cast<float4*>(v_s + t * DH + c4 * 4) = v4;
+  }
+  __syncthreads();
+
+  const int64_t ots = p.out_time_stride ? p.out_time_stride : p.heads * DH;
+  const int64_t obs = p.out_batch_stride ? p.out_batch_stride : p.tq * ots;
+  for (int qi = wave; qi < p.tq; qi += 4) {
+    if (chan) wq[cl] = qb[static_cast<int64_t>(qi) * p.q_time_stride + cl];
+    __builtin_amdgcn_wave_barrier();
+    // valid keys of this query (prepare_length_mask, src/layers/attention_layer.cc:152-174)
+    int size = length;
+    if (p.causal) size = min(size, qi + static_cast<int>(p.q_offset) + 1);
+    float m = -FLT_MAX;
+    for (int t0 = 0; t0 < tk; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < tk) {
+        const float* kr = k_s + t * KS;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) s = fmaf(wq[c], kr[c], s);
+        s = s * p.scale;
+        wp[t] = s;
+        if (t < size) m = fmaxf(m, s);
+      }
+    }
+    m = wave_max_dpp(m);
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < a.t_pad; t += 64) {
+      const float sc = wp[t];
+      wp[t] = (t < size) ? exp_avx2(sc - m) : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float y = 0.f;
+    if (size > 0) {
+      const float rcp = 1.f / ordered_sum8(wp, size);
+      __builtin_amdgcn_wave_barrier();
+      for (int t = lane; t < size; t += 64) wp[t] = wp[t] * rcp;
+      __builtin_amdgcn_wave_barrier();
+      for (int t = 0; t < tk; ++t) y = fmaf(wp[t], v_s[t * DH + cl], y);
+    }
+    if (chan) p.out[static_cast<int64_t>(b) * obs + static_cast<int64_t>(qi) * ots + h * DH + cl] = y;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+bool exact_disabled() {
+  static const bool off = [] {
+    const char* e = std::getenv("CT2X_FAST_ATTENTION");
+    return e != nullptr && e[0] == '1';
+  }();
+  return off;
+}
+
+void ensure_lds(const void* fn, size_t lds) {
+  if (lds <= 64 * 1024) return;
+  // > 64 KiB of dynamic LDS has to be opted into (once per function; cheap to repeat)
+  CT2X_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+
+int x_t_pad(const AttnDecodeParams& p) {
+  return static_cast<int>(((p.t_max + 1 + 15) / 16) * 16 + 16);
+}
+
+}  // namespace
+
+// Decode shapes the exact kernel covers: d_head 4 .. 64 (a multiple of 4; MKL's one-row tail
+// form for longer rows was not recovered), no RoPE (its CPU rounding is not restated), aligned
+// caches, and the per-wave LDS (q + scores + one K tile) of `teams` heads within 160 KiB.
+static bool x_dhead_ok(int64_t dh) { return dh == 4 || dh == 8 || dh == 16 || dh == 32 || dh == 64; }
+
+bool attention_exact_decode_applicable(const AttnDecodeParams& p, bool fused_quantize) {
+  if (exact_disabled()) return false;
+  if (!x_dhead_ok(p.dhead) || p.heads < 1 || p.heads_kv < 1 || p.heads % p.heads_kv != 0) return false;
+  if (p.rope_sin != nullptr) return false;
+  if (p.kv_time_stride < p.dhead || p.kv_time_stride % 4 != 0 || p.t_max < 1) return false;
+  if ((reinterpret_cast<uintptr_t>(p.k_cache) & 15) || (reinterpret_cast<uintptr_t>(p.v_cache) & 15) ||
+      p.kv_head_stride % 4 != 0 || p.kv_row_stride % 4 != 0)
+    return false;
+  const size_t wave_floats = 64 + x_t_pad(p) + 64 * (p.dhead + 4);
+  if (wave_floats * 4 + 64 > 160 * 1024) return false;
+  if (fused_quantize)
+    return p.heads <= 8 && (static_cast<size_t>(p.heads) * wave_floats + 16) * 4 <= 160 * 1024;
+  return true;
+}
+
+template <int DH>
+static void launch_x(const AttnXArgs& a, bool seq, size_t lds, hipStream_t stream) {
+  const unsigned grid = static_cast<unsigned>(a.p.rows * a.wg_per_row);
+  if (seq) {
+    ensure_lds(reinterpret_cast<const void*>(attn_x_decode_kernel<DH, true>), lds);
+    hipLaunchKernelGGL((attn_x_decode_kernel<DH, true>), dim3(grid), dim3(a.teams * 64), lds, stream, a);
+  } else {
+    ensure_lds(reinterpret_cast<const void*>(attn_x_decode_kernel<DH, false>), lds);
+    hipLaunchKernelGGL((attn_x_decode_kernel<DH, false>), dim3(grid), dim3(a.teams * 64), lds, stream, a);
+  }
+}
+
+void launch_attention_exact_decode(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
+                                   float* q_scales, hipStream_t stream) {
+  AttnXArgs a;
+  a.p = p;
+  a.q_out = q_out;
+  a.q_scales = q_scales;
+  a.quant_mode = quant_mode;
+  a.group = static_cast<int>(p.heads / p.heads_kv);
+  a.t_pad = x_t_pad(p);
+  a.wave_floats = 64 + a.t_pad + 64 * (static_cast<int>(p.dhead) + 4);
+  const int fit = static_cast<int>((160 * 1024 - 64) / (static_cast<size_t>(a.wave_floats) * 4));
+  a.teams = static_cast<int>(p.heads);
+  if (q_out == nullptr && a.teams > fit) a.teams = fit;
+  if (a.teams > 8) a.teams = 8;  // 2 waves per SIMD: the dot-product forms keep ~170 VGPRs live
+  a.wg_per_row = static_cast<int>((p.heads + a.teams - 1) / a.teams);
+  const size_t lds = (static_cast<size_t>(a.teams) * a.wave_floats + 16) * sizeof(float);
+  // Several query rows on one cache row = the m dimension of the reference's MatMul: MKL's GEMM
+  // path (k-ordered) instead of its one-row path.
+  const bool seq = p.kv_group > 1;
+  switch (p.dhead) {
+    case 4: launch_x<4>(a, seq, lds, stream); break;
+    case 8: launch_x<8>(a, seq, lds, stream); break;
+    case 16: launch_x<16>(a, seq, lds, stream); break;
+    case 32: launch_x<32>(a, seq, lds, stream); break;
+    default: launch_x<64>(a, seq, lds, stream); break;
+  }
+}
+
+bool attention_exact_full_applicable(const AttnFullParams& p) {
+  if (exact_disabled()) return false;
+  if (!x_dhead_ok(p.dhead) || p.heads_kv < 1 || p.heads % p.heads_kv != 0 || p.tk < 1) return false;
+  auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!(aligned16(p.k) && aligned16(p.v) && p.k_time_stride % 4 == 0 && p.v_time_stride % 4 == 0 &&
+        p.k_head_stride % 4 == 0 && p.v_head_stride % 4 == 0 && p.k_batch_stride % 4 == 0 &&
+        p.v_batch_stride % 4 == 0))
+    return false;
+  const size_t t_pad = ((p.tk + 63) / 64) * 64;
+  const size_t floats = static_cast<size_t>(p.tk) * (2 * p.dhead + 1) + 4 + 4 * (64 + t_pad);
+  return floats * 4 <= 160 * 1024;  // K and V of one head in LDS (tk <= ~300 at d_head 64)
+}
+
+template <int DH>
+static void launch_xfull(const AttnXFullArgs& a, size_t lds, hipStream_t stream) {
+  ensure_lds(reinterpret_cast<const void*>(attn_x_full_kernel<DH>), lds);
+  hipLaunchKernelGGL(attn_x_full_kernel<DH>,
+                     dim3(static_cast<unsigned>(a.p.heads), static_cast<unsigned>(a.p.batch)),
+                     dim3(256), lds, stream, a);
+}
+
+void launch_attention_exact_full(const AttnFullParams& p, hipStream_t stream) {
+  AttnXFullArgs a;
+  a.p = p;
+  a.t_pad = static_cast<int>(((p.tk + 63) / 64) * 64);
+  const size_t lds =
+      (static_cast<size_t>(p.tk) * (2 * p.dhead + 1) + 4 + 4 * (64 + a.t_pad)) * sizeof(float);
+  switch (p.dhead) {
+    case 4: launch_xfull<4>(a, lds, stream); break;
+    case 8: launch_xfull<8>(a, lds, stream); break;
+    case 16: launch_xfull<16>(a, lds, stream); break;
+    case 32: launch_xfull<32>(a, lds, stream); break;
+    default: launch_xfull<64>(a, lds, stream); break;
+  }
+}
+
+}  // namespace ct2x

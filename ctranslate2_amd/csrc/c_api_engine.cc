@@ -751,6 +751,88 @@ int ct2x_step_logits(void* translator, const int32_t* src_ids, const int32_t* sr
   API_CATCH
 }
 
+// ---- debugging taps (tests only) -------------------------------------------------------------
+namespace {
+std::vector<ct2x::Engine::Tap> g_taps;
+std::mutex g_taps_mutex;
+}  // namespace
+
+int ct2x_debug_step_taps(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
+                         int32_t batch, int32_t src_stride, const int32_t* tgt_in, int32_t T,
+                         float* logits_out) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  std::lock_guard<std::mutex> lock(t->mutex);
+  std::lock_guard<std::mutex> tlock(g_taps_mutex);
+  Engine& e = *t->engine;
+  g_taps.clear();
+  struct Guard {
+    Engine& e;
+    ~Guard() {
+      e.set_tap_sink(nullptr);
+      e.set_tap_step(-1);
+    }
+  } guard{e};
+  e.set_tap_sink(&g_taps);
+  e.set_tap_step(-1);
+  std::unique_ptr<DecodeState> st;
+  if (e.is_seq2seq())
+    st = e.start(src_ids, src_lengths, batch, src_stride, 1, T);
+  else
+    st = e.start_decoder_only(batch, 1, T);
+  const int64_t V = e.vocab_size();
+  std::vector<int32_t> ids(batch);
+  e.set_step(*st, 0);
+  for (int32_t s = 0; s < T; ++s) {
+    for (int32_t b = 0; b < batch; ++b) ids[b] = tgt_in[static_cast<int64_t>(b) * T + s];
+    e.set_ids(*st, ids.data());
+    e.set_tap_step(s);
+    e.step(*st, /*graph=*/false);
+    if (logits_out) e.copy_logits_to_host(*st, logits_out + static_cast<int64_t>(s) * batch * V);
+    e.advance_step(*st);
+  }
+  e.synchronize();
+  API_CATCH
+}
+
+int ct2x_debug_tap_count() {
+  std::lock_guard<std::mutex> tlock(g_taps_mutex);
+  return static_cast<int>(g_taps.size());
+}
+
+int ct2x_debug_tap_info(int index, char* name, int name_size, int32_t* dtype, int64_t* rows,
+                        int64_t* cols) {
+  std::lock_guard<std::mutex> tlock(g_taps_mutex);
+  if (index < 0 || index >= static_cast<int>(g_taps.size())) return -1;
+  const auto& t = g_taps[index];
+  if (name && name_size > 0) {
+    std::strncpy(name, t.name.c_str(), name_size - 1);
+    name[name_size - 1] = 0;
+  }
+  if (dtype) *dtype = t.dtype;
+  if (rows) *rows = t.rows;
+  if (cols) *cols = t.cols;
+  return 0;
+}
+
+int ct2x_debug_tap_data(int index, void* out) {
+  std::lock_guard<std::mutex> tlock(g_taps_mutex);
+  if (index < 0 || index >= static_cast<int>(g_taps.size())) return -1;
+  std::memcpy(out, g_taps[index].data.data(), g_taps[index].data.size());
+  return 0;
+}
+
+int ct2x_debug_set_position_table(void* translator, const float* table, int64_t positions,
+                                  int64_t depth) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  std::lock_guard<std::mutex> lock(t->mutex);
+  t->engine->debug_set_position_table(table, positions, depth);
+  API_CATCH
+}
+
 int ct2x_model_info(void* translator, int32_t* is_seq2seq, int32_t* vocab_size, int32_t* d_model,
                     int32_t* num_layers_dec, int32_t* num_heads, int32_t* bos_id, int32_t* eos_id,
                     char* compute_type, int ct_size) {

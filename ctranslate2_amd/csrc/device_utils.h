@@ -201,4 +201,49 @@ __device__ __forceinline__ int8_t to_s8(float x, float scale, int mode) {
   return static_cast<int8_t>(static_cast<int>(v));
 }
 
+// exp256_ps (third_party/avx_mathfun.h:290-344) as compiled into the reference's AVX2 kernels:
+// every mul+add pair of the Cephes polynomial is one FMA.
+__device__ __forceinline__ float exp_avx2(float x) {
+  x = fminf(x, 88.3762626647949f);
+  x = fmaxf(x, -88.3762626647949f);
+  float fx = fmaf(x, 1.44269504088896341f, 0.5f);
+  float tmp = floorf(fx);
+  if (tmp > fx) tmp = tmp - 1.f;
+  fx = tmp;
+  x = fmaf(-fx, 0.693359375f, x);
+  x = fmaf(-fx, -2.12194440e-4f, x);
+  const float z = x * x;
+  float y = 1.9875691500E-4f;
+  y = fmaf(y, x, 1.3981999507E-3f);
+  y = fmaf(y, x, 8.3334519073E-3f);
+  y = fmaf(y, x, 4.1665795894E-2f);
+  y = fmaf(y, x, 1.6666665459E-1f);
+  y = fmaf(y, x, 5.0000001201E-1f);
+  y = fmaf(y, z, x);
+  y = y + 1.f;
+  const float pow2n = __int_as_float((static_cast<int>(fx) + 0x7f) << 23);
+  return y * pow2n;
+}
+
+// Sum of e[0, size) in the order of vectorized_reduce_all<AVX2> (src/cpu/kernels.cc:86-139):
+// eight strided partial sums, reduce_m256 (lane l + l^4, + l^2, + l^1), then the scalar tail; a
+// row of <= 8 elements is summed front to back. `e` is LDS (or global) memory written by this
+// wave; every lane of the wave returns the sum.
+__device__ __forceinline__ float ordered_sum8(const float* e, int size) {
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  if (size <= 8) {
+    for (int j = 0; j < size; ++j) acc += e[j];  // every lane reads the same addresses
+    return acc;
+  }
+  const int vsize = size & ~7;
+  const int l = lane & 7;
+  for (int j = l; j < vsize; j += 8) acc += e[j];
+  acc = acc + __shfl_xor(acc, 4, 64);
+  acc = acc + __shfl_xor(acc, 2, 64);
+  acc = acc + __shfl_xor(acc, 1, 64);
+  for (int j = vsize; j < size; ++j) acc += e[j];
+  return acc;
+}
+
 }  // namespace ct2x

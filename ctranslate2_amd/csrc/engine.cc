@@ -726,10 +726,40 @@ std::map<std::string, Engine::KernelStat> Engine::profile_end() {
   return stats;
 }
 
+void Engine::tap(const char* producer, const void* dev, int dtype, int64_t rows, int64_t cols,
+                 bool indexed) {
+  if (!taps_ || dev == nullptr) return;
+  Tap t;
+  (void)indexed;
+  t.name = tap_scope_ + "." + std::to_string(tap_index_++) + "." + producer;
+  t.dtype = dtype;
+  t.rows = rows;
+  t.cols = cols;
+  t.data.resize(static_cast<size_t>(rows * cols) * (dtype == 1 ? 1 : 4));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+  CT2X_HIP_CHECK(hipMemcpy(t.data.data(), dev, t.data.size(), hipMemcpyDeviceToHost));
+  taps_->push_back(std::move(t));
+}
+
+void Engine::debug_set_position_table(const float* host, int64_t positions, int64_t depth) {
+  std::lock_guard<std::mutex> lock(table_mutex_);
+  if (sin_pos_table_) device_blocks_.push_back(sin_pos_table_);
+  sin_pos_table_ = static_cast<float*>(device_malloc(static_cast<size_t>(positions * depth) * sizeof(float)));
+  CT2X_HIP_CHECK(hipMemcpy(sin_pos_table_, host, static_cast<size_t>(positions * depth) * sizeof(float),
+                           hipMemcpyHostToDevice));
+  sin_pos_positions_ = positions;
+  sin_pos_depth_ = depth;
+}
+
 void Engine::quant(const float* x, int64_t rows, int64_t depth, int8_t* q, float* s) {
   begin_kernel("quantize_s8", double(rows) * depth * 5 + rows * 4, 0, rows, 0, depth);
   launch_quantize_s8(x, rows, depth, quant_mode_, q, s, cur_stream());
   end_kernel();
+  if (taps_) {
+    tap("f", x, 0, rows, depth);
+    tap("q", q, 1, rows, depth);
+    tap("qs", s, 0, rows, 1);
+  }
 }
 
 void Engine::norm(const NormW& w, const float* x, int64_t rows, int64_t depth, float* y) {
@@ -743,9 +773,23 @@ void Engine::norm_quant(const NormW& w, const float* x, int64_t rows, int64_t de
                         int8_t* q, float* s) {
   begin_kernel("norm_quantize", double(rows) * depth * (y ? 9 : 5) + depth * 8 + rows * 4, 0, rows,
                0, depth);
+  float* tap_y = nullptr;
+  if (taps_ && y == nullptr) {  // tap mode: also materialise the fp32 row the Quantize consumes
+    tap_y = static_cast<float*>(device_malloc(static_cast<size_t>(rows * depth) * sizeof(float)));
+    y = tap_y;
+  }
   launch_norm(x, w.gamma, w.beta, rows, depth, w.eps, w.use_residual, quant_mode_, y, q, s,
               cur_stream());
   end_kernel();
+  if (taps_) {
+    tap("f", y, 0, rows, depth);
+    tap("q", q, 1, rows, depth);
+    tap("qs", s, 0, rows, 1);
+    if (tap_y) {
+      CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+      device_free(tap_y);
+    }
+  }
 }
 
 // layers::Dense::operator() (src/layers/common.cc:339-442).
@@ -878,6 +922,7 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
                     cur_stream());
     end_kernel();
   }
+  if (taps_) tap("d", y, 0, m, w.n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1062,10 +1107,14 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
   float* y = st.x1;
   launch_embed(enc_.emb.table, enc_.emb.is_int8, enc_.emb.scale, d_src, rows, d,
                enc_.embeddings_scale, enc_.scale_embeddings, pos, S, 0, nullptr, x, cur_stream());
+  tap_scope("enc");
+  tap("emb", x, 0, rows, d);
   if (enc_.layernorm_embedding.present) norm(enc_.layernorm_embedding, x, rows, d, x);
 
+  int enc_layer_index = 0;
   for (const LayerW& layer : enc_.layers) {
     const AttnW& a = layer.self;
+    tap_scope("enc.l" + std::to_string(enc_layer_index) + ".self");
     // --- self attention (MultiHeadAttention::operator(), src/layers/attention.cc:442-615)
     QuantIn qin;
     const float* attn_in = x;
@@ -1108,18 +1157,24 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
     begin_kernel("attention_encoder", 0, 0, rows, a.heads, a.dhead);
     launch_attention_full(f, cur_stream());
     end_kernel();
+    tap("ctx", st.ctx, 0, rows, a.heads * a.dhead);
     dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
     if (a.ln.present && !enc_.pre_norm) norm(a.ln, y, rows, d, y);
     std::swap(x, y);
 
     // --- feed forward (FeedForwardNetwork::operator(), src/layers/transformer.cc:21-51)
+    tap_scope("enc.l" + std::to_string(enc_layer_index) + ".ffn");
     run_ffn(layer.ffn, enc_.pre_norm, rows, d, x, y, st);
+    ++enc_layer_index;
   }
   if (enc_.output_norm.present) norm(enc_.output_norm, x, rows, d, x);
+  tap_scope("enc.out");
+  tap("x", x, 0, rows, d);
 
   // Cross-attention memory projections: linear_1(memory) -> [B*S, 2*kv_dim], kept in the GEMM
   // output layout (the attention kernel takes strides; no split_heads transpose).
   bool quantized_once = false;
+  tap_scope("enc.kv");
   for (size_t l = 0; l < dec_.layers.size(); ++l) {
     const AttnW& a = dec_.layers[l].cross;
     QuantIn mq;
@@ -1327,6 +1382,8 @@ void Engine::launch_step(DecodeState& st) {
   launch_embed(dec_.emb.table, dec_.emb.is_int8, dec_.emb.scale, st.d_ids, rows, d,
                dec_.embeddings_scale, dec_.scale_embeddings, pos, 1, 0, st.d_step, x, cur_stream());
   end_kernel();
+  tap_scope("dec");
+  tap("emb", x, 0, rows, d);
   if (dec_.layernorm_embedding.present) norm(dec_.layernorm_embedding, x, rows, d, x);
 
   for (size_t l = 0; l < dec_.layers.size(); ++l) {
@@ -1334,6 +1391,7 @@ void Engine::launch_step(DecodeState& st) {
     // ---- masked self-attention -----------------------------------------------------------
     {
       const AttnW& a = layer.self;
+      tap_scope("dec.l" + std::to_string(l) + ".self");
       QuantIn qin;
       const float* attn_in = x;
       const bool fused_in = dec_.pre_norm && dense_norm(a.ln, a.lin[0], x, rows, -1, nullptr, st.qkv);
@@ -1381,6 +1439,12 @@ void Engine::launch_step(DecodeState& st) {
         begin_kernel("attention_self_decode_q", 0, 0, rows, a.heads, a.dhead);
         launch_attention_decode_quantized(p, quant_mode_, st.qbuf, st.qscale, cur_stream());
         end_kernel();
+        if (taps_) {
+          launch_attention_decode(p, cur_stream());  // same context in fp32 (idempotent append)
+          tap("f", st.ctx, 0, rows, qdim);
+          tap("q", st.qbuf, 1, rows, qdim);
+          tap("qs", st.qscale, 0, rows, 1);
+        }
         QuantIn cq;
         cq.q = st.qbuf;
         cq.s = st.qscale;
@@ -1413,6 +1477,7 @@ void Engine::launch_step(DecodeState& st) {
     // ---- encoder-decoder attention -------------------------------------------------------
     if (layer.has_cross) {
       const AttnW& a = layer.cross;
+      tap_scope("dec.l" + std::to_string(l) + ".cross");
       QuantIn qin;
       const float* attn_in = x;
       const bool fused_in = dec_.pre_norm && dense_norm(a.ln, a.lin[0], x, rows, -1, nullptr, st.qkv);
@@ -1453,6 +1518,12 @@ void Engine::launch_step(DecodeState& st) {
         begin_kernel("attention_cross_decode_q", attn_bytes, attn_ops, rows, a.heads, a.dhead);
         launch_attention_decode_quantized(p, quant_mode_, st.qbuf, st.qscale, cur_stream());
         end_kernel();
+        if (taps_) {
+          launch_attention_decode(p, cur_stream());
+          tap("f", st.ctx, 0, rows, a.heads * a.dhead);
+          tap("q", st.qbuf, 1, rows, a.heads * a.dhead);
+          tap("qs", st.qscale, 0, rows, 1);
+        }
         QuantIn cq;
         cq.q = st.qbuf;
         cq.s = st.qscale;
@@ -1467,11 +1538,13 @@ void Engine::launch_step(DecodeState& st) {
       std::swap(x, y);
     }
     // ---- feed forward ----------------------------------------------------------------------
+    tap_scope("dec.l" + std::to_string(l) + ".ffn");
     run_ffn(layer.ffn, dec_.pre_norm, rows, d, x, y, st,
             split_quant ? st.row_amax + (2 * l + 1) * rows : nullptr);
   }
 
   // Final norm + vocabulary projection (transformer.cc:842-855).
+  tap_scope("dec.out");
   QuantIn pq;
   const float* proj_in = x;
   if (!dense_norm(dec_.output_norm, dec_.projection, x, rows, -1, nullptr, st.logits)) {

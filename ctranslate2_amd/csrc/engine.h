@@ -226,6 +226,24 @@ public:
   std::map<std::string, KernelStat> profile_end();
   bool profiling() const { return profiling_; }
 
+  // ---- debugging taps (tests only; eager steps) -------------------------------------------
+  // With a sink installed, every producer on the path (embedding, norm + Quantize, Quantize,
+  // Dense, attention) copies its output to the host right after its launch, named
+  // "<scope>.<producer><index>": the parity tests line these up against the same points of the
+  // reference's layers (oracle/ref_capi.cc, ct2ref_tap_forward) and report the FIRST tensor that
+  // differs. dtype: 0 = fp32, 1 = int8.
+  struct Tap {
+    std::string name;
+    int dtype = 0;
+    int64_t rows = 0, cols = 0;
+    std::vector<char> data;
+  };
+  void set_tap_sink(std::vector<Tap>* sink) { taps_ = sink; }
+  void set_tap_step(int step) { tap_step_ = step; }
+  // Replaces the sinusoidal position table (debug: lets a test inject the reference's table,
+  // which comes from MKL's closed vsSin / vsCos, to show that nothing else differs).
+  void debug_set_position_table(const float* host, int64_t positions, int64_t depth);
+
 private:
   friend struct DecodeState;
   struct QuantIn {  // an activation matrix already quantised for an int8 Dense
@@ -296,6 +314,17 @@ private:
   std::vector<PendingKernel> pending_;
   std::vector<hipEvent_t> event_pool_;
   std::atomic<int64_t> kernels_per_step_{0};
+  std::vector<Tap>* taps_ = nullptr;
+  std::string tap_scope_;
+  int tap_step_ = -1;
+  int tap_index_ = 0;
+  void tap_scope(const std::string& scope) {
+    if (!taps_) return;
+    tap_scope_ = (tap_step_ >= 0 ? "s" + std::to_string(tap_step_) + "." : std::string()) + scope;
+    tap_index_ = 0;
+  }
+  void tap(const char* producer, const void* dev, int dtype, int64_t rows, int64_t cols,
+           bool indexed = true);
 
   // Lazily grown tables.
   float* sin_pos_table_ = nullptr;

@@ -187,6 +187,14 @@ bool attention_decode_can_fuse_quantize(const AttnDecodeParams& p);
 void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
                                        float* q_scales, hipStream_t stream);
 
+// Attention that rounds exactly like the reference CPU path (attention_exact.hip: MKL's sgemm
+// summation trees, the AVX2 exp polynomial and sum order of cpu::softmax); d_head 64, no RoPE.
+// launch_attention_decode / _quantized / _full route to it whenever it applies
+// (CT2X_FAST_ATTENTION=1 switches it off for comparison runs).
+bool attention_exact_decode_applicable(const AttnDecodeParams& p, bool fused_quantize);
+void launch_attention_exact_decode(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
+                                   float* q_scales, hipStream_t stream);
+
 // Second-generation decode kernel (attention_decode2.hip: lane = key for QK^T, lane = channel for
 // PV, GQA group per wave); launch_attention_decode[_quantized] route to it when applicable.
 bool attention_decode2_applicable(const AttnDecodeParams& p, bool fused_quantize);
@@ -212,6 +220,9 @@ struct AttnFullParams {
 };
 
 void launch_attention_full(const AttnFullParams& p, hipStream_t stream);
+
+bool attention_exact_full_applicable(const AttnFullParams& p);
+void launch_attention_exact_full(const AttnFullParams& p, hipStream_t stream);
 
 // Tiled form for d_head 64 / 128 (attention_prefill.hip: 64-query tiles, K/V tiles shared through
 // LDS, both products on v_mfma_f32_16x16x4_f32, online softmax); launch_attention_full routes to it.

@@ -147,18 +147,19 @@ void launch_quantize_s8(const float* x, int64_t rows, int64_t depth, int quant_m
 }
 
 // ---------------------------------------------------------------------------------------
-// ops::Dequantize rows: y = x / scale[row]   (src/ops/dequantize_cpu.cc, dequantize_kernel:
-// "x / scale" per element; GPU src/ops/dequantize_gpu.cu:17-28).
+// ops::Dequantize rows: y = x * (1 / scale[row])   (src/ops/dequantize_cpu.cc:10-19,
+// dequantize_kernel: r_scale = 1.f / scale, then v * r_scale; the reference's GPU kernel divides,
+// src/ops/dequantize_gpu.cu:17-28 - the CPU form is the parity target).
 // ---------------------------------------------------------------------------------------
 __global__ void dequantize_rows_kernel(const int8_t* __restrict__ x,
                                        const float* __restrict__ scale, int64_t depth,
                                        float* __restrict__ y) {
   const int64_t row = blockIdx.x;
-  const float s = scale[row];
+  const float r_s = 1.f / scale[row];
   const int8_t* xr = x + row * depth;
   float* yr = y + row * depth;
   for (int64_t i = threadIdx.x; i < depth; i += blockDim.x)
-    yr[i] = static_cast<float>(xr[i]) / s;
+    yr[i] = static_cast<float>(xr[i]) * r_s;
 }
 
 void launch_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, int64_t depth,
@@ -253,12 +254,66 @@ void launch_reduce_ranks(const void* const* src, int world, int64_t n, bool is_i
 }
 
 // ---------------------------------------------------------------------------------------
-// LayerNorm / RMSNorm (+ optional fused int8 Quantize of the normalised row).
-// Reference: src/cpu/kernels.cc:461-496 (layer_norm: mean = sum/n,
-// var = max(sumsq/n - mean^2, 0), rstd = 1/sqrt(var+eps), y=(x-mean)*rstd*gamma+beta) and
-// :543-573 (rms_norm: inv = 1/sqrt(sumsq/n + eps), y = x*inv*gamma or x*inv*(1+gamma)).
-// The row is staged once in LDS (dynamic, depth floats) so x is read from HBM exactly once.
+// LayerNorm / RMSNorm (+ optional fused int8 Quantize of the normalised row), BIT-EXACT with the
+// reference CPU kernels as compiled (src/cpu/kernels.cc:461-496 and :543-573, a CT2_FFAST_MATH
+// region that GCC -O2 leaves scalar; oracle/ct2_oracle.c orc_layer_norm / orc_rms_norm give the
+// decoded arithmetic and are pinned against the reference library):
+//   inv_n = 1/n;  sum += x and sumsq = fma(x, x, sumsq) STRICTLY IN INDEX ORDER;
+//   LayerNorm: mean = sum*inv_n; var = max(fma(sumsq, inv_n, -(mean*mean)), 0);
+//              rstd = 1/sqrt(var+eps); y = fma(x - mean, rstd*gamma, beta)
+//   RMSNorm:   inv = 1/sqrt(fma(sumsq, inv_n, eps)); y = (inv*x)*gamma  or  (inv*x)*(gamma+1)
+// The int8 decoder re-quantises this output: a last-ulp difference flips int8 activations, so the
+// sequential sums are reproduced as they are: the row is staged in LDS, every wave walks it front
+// to back with broadcast ds_read_b128 (two independent dependency chains, ~2 VALU issues per
+// element), then each lane normalises the elements it holds in registers.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void ordered_row_sums(const float* row, int n4, float& sum, float& sumsq) {
+  const v4f* r4 = reinterpret_cast<const v4f*>(row);
+  float s = 0.f, ss = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < n4; ++i) {
+    const v4f v = r4[i];
+    ss = fmaf(v.x, v.x, ss);
+    s = s + v.x;
+    ss = fmaf(v.y, v.y, ss);
+    s = s + v.y;
+    ss = fmaf(v.z, v.z, ss);
+    s = s + v.z;
+    ss = fmaf(v.w, v.w, ss);
+    s = s + v.w;
+  }
+  sum = s;
+  sumsq = ss;
+}
+
+struct NormStats {
+  float mean, mul;  // LayerNorm: y = fma(x - mean, mul*gamma, beta); RMSNorm: y = (mul*x)*g
+};
+
+__device__ __forceinline__ NormStats norm_stats(float sum, float sumsq, int64_t depth, float eps,
+                                                bool layer_norm) {
+  const float inv_n = 1.f / static_cast<float>(depth);
+  NormStats st;
+  if (layer_norm) {
+    st.mean = sum * inv_n;
+    const float mm = st.mean * st.mean;
+    float variance = fmaf(sumsq, inv_n, -mm);
+    variance = (variance > 0.f) ? variance : 0.f;
+    st.mul = 1.f / sqrtf(variance + eps);
+  } else {
+    st.mean = 0.f;
+    st.mul = 1.f / sqrtf(fmaf(sumsq, inv_n, eps));
+  }
+  return st;
+}
+
+__device__ __forceinline__ float norm_apply(float x, float g, float b, const NormStats& st,
+                                            bool layer_norm, bool rms_use_residual) {
+  if (layer_norm) return fmaf(x - st.mean, st.mul * g, b);
+  const float t = st.mul * x;
+  return rms_use_residual ? t * (g + 1.f) : t * g;
+}
+
 __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                             const float* __restrict__ beta, int64_t depth, float eps,
                             bool rms_use_residual, int quant_mode,
@@ -268,36 +323,23 @@ __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict
   __shared__ float scratch[16];
   const int64_t row = blockIdx.x;
   const float* xr = x + row * depth;
-
+  for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) row_buf[i] = xr[i];
+  __syncthreads();
+  // every thread walks the row in index order (same addresses: LDS broadcasts)
   float sum = 0.f, sumsq = 0.f;
-  for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
-    const float v = xr[i];
-    row_buf[i] = v;
-    sum += v;
-    sumsq += v * v;
+  for (int64_t i = 0; i < depth; ++i) {
+    const float v = row_buf[i];
+    sumsq = fmaf(v, v, sumsq);
+    sum = sum + v;
   }
-  const float fdepth = static_cast<float>(depth);
+  const bool ln = beta != nullptr;
+  const NormStats st = norm_stats(sum, sumsq, depth, eps, ln);
+  __syncthreads();  // everyone has read the row before it is overwritten
   float amax = 0.f;
-  if (beta != nullptr) {
-    sum = block_sum(sum, scratch);
-    sumsq = block_sum(sumsq, scratch);
-    const float mean = sum / fdepth;
-    const float variance = fmaxf(sumsq / fdepth - mean * mean, 0.f);
-    const float rstd = 1.f / sqrtf(variance + eps);
-    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
-      const float v = (row_buf[i] - mean) * rstd * gamma[i] + beta[i];
-      row_buf[i] = v;
-      amax = fmaxf(amax, fabsf(v));
-    }
-  } else {
-    sumsq = block_sum(sumsq, scratch);
-    const float inv_rms = 1.f / sqrtf(sumsq / fdepth + eps);
-    for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
-      const float g = rms_use_residual ? (1.f + gamma[i]) : gamma[i];
-      const float v = row_buf[i] * inv_rms * g;
-      row_buf[i] = v;
-      amax = fmaxf(amax, fabsf(v));
-    }
+  for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
+    const float v = norm_apply(row_buf[i], gamma[i], ln ? beta[i] : 0.f, st, ln, rms_use_residual);
+    row_buf[i] = v;
+    amax = fmaxf(amax, fabsf(v));
   }
   // Each thread re-reads only the elements it wrote itself: no barrier needed for row_buf.
   if (y != nullptr) {
@@ -316,37 +358,15 @@ __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict
 
 
 // Register-resident variant for the decoder shapes (depth % 4 == 0, depth <= 4 * 256 * kNormChunks):
-// every lane keeps its float4 chunks in VGPRs, sum and sum-of-squares share ONE block reduction
-// (two barriers instead of four), and all loads are issued before the first reduction step.
+// every lane keeps its float4 chunks in VGPRs (and drops a copy into the LDS row for the ordered
+// sums); all loads are issued before the first use.
 constexpr int kNormChunks = 4;
-
-__device__ __forceinline__ void block_sum2(float& a, float& b, float* scratch) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nwaves = (blockDim.x + 63) >> 6;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    a += __shfl_xor(a, o, 64);
-    b += __shfl_xor(b, o, 64);
-  }
-  if (nwaves == 1) return;
-  __syncthreads();
-  if (lane == 0) {
-    scratch[wave] = a;
-    scratch[16 + wave] = b;
-  }
-  __syncthreads();
-  a = scratch[0];
-  b = scratch[16];
-  for (int i = 1; i < nwaves; ++i) {
-    a += scratch[i];
-    b += scratch[16 + i];
-  }
-}
 
 __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, int64_t depth, float eps,
                                 bool rms_use_residual, int quant_mode, float* __restrict__ y,
                                 int8_t* __restrict__ q, float* __restrict__ scales) {
+  extern __shared__ __attribute__((aligned(16))) float row_buf[];
   __shared__ float scratch[32];
   const int64_t row = blockIdx.x;
   const int n4 = static_cast<int>(depth / 4);
@@ -364,41 +384,23 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
       if (beta != nullptr) bv[u] = b4[i];
     }
   }
-  float sum = 0.f, sumsq = 0.f;
 #pragma unroll
   for (int u = 0; u < kNormChunks; ++u) {
-    sum += v[u].x + v[u].y + v[u].z + v[u].w;
-    sumsq += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+    const int i = threadIdx.x + u * blockDim.x;
+    if (i < n4) reinterpret_cast<float4*>(row_buf)[i] = v[u];
   }
-  block_sum2(sum, sumsq, scratch);
-  const float fdepth = static_cast<float>(depth);
+  __syncthreads();
+  float sum, sumsq;
+  ordered_row_sums(row_buf, n4, sum, sumsq);
+  const bool ln = beta != nullptr;
+  const NormStats st = norm_stats(sum, sumsq, depth, eps, ln);
   float amax = 0.f;
-  if (beta != nullptr) {
-    const float mean = sum / fdepth;
-    const float variance = fmaxf(sumsq / fdepth - mean * mean, 0.f);
-    const float rstd = 1.f / sqrtf(variance + eps);
 #pragma unroll
-    for (int u = 0; u < kNormChunks; ++u) {
-      v[u].x = (v[u].x - mean) * rstd * gv[u].x + bv[u].x;
-      v[u].y = (v[u].y - mean) * rstd * gv[u].y + bv[u].y;
-      v[u].z = (v[u].z - mean) * rstd * gv[u].z + bv[u].z;
-      v[u].w = (v[u].w - mean) * rstd * gv[u].w + bv[u].w;
-    }
-  } else {
-    const float inv_rms = 1.f / sqrtf(sumsq / fdepth + eps);
-#pragma unroll
-    for (int u = 0; u < kNormChunks; ++u) {
-      if (rms_use_residual) {
-        gv[u].x = 1.f + gv[u].x;
-        gv[u].y = 1.f + gv[u].y;
-        gv[u].z = 1.f + gv[u].z;
-        gv[u].w = 1.f + gv[u].w;
-      }
-      v[u].x = v[u].x * inv_rms * gv[u].x;
-      v[u].y = v[u].y * inv_rms * gv[u].y;
-      v[u].z = v[u].z * inv_rms * gv[u].z;
-      v[u].w = v[u].w * inv_rms * gv[u].w;
-    }
+  for (int u = 0; u < kNormChunks; ++u) {
+    v[u].x = norm_apply(v[u].x, gv[u].x, bv[u].x, st, ln, rms_use_residual);
+    v[u].y = norm_apply(v[u].y, gv[u].y, bv[u].y, st, ln, rms_use_residual);
+    v[u].z = norm_apply(v[u].z, gv[u].z, bv[u].z, st, ln, rms_use_residual);
+    v[u].w = norm_apply(v[u].w, gv[u].w, bv[u].w, st, ln, rms_use_residual);
   }
 #pragma unroll
   for (int u = 0; u < kNormChunks; ++u) {
@@ -439,8 +441,8 @@ void launch_norm(const float* x, const float* gamma, const float* beta, int64_t 
     int threads = 64;
     while (threads * kNormChunks * 4 < depth || (threads < 256 && threads * 4 < depth)) threads <<= 1;
     if (threads > 256) threads = 256;
-    hipLaunchKernelGGL(norm_vec_kernel, dim3(rows), dim3(threads), 0, stream, x, gamma, beta,
-                       depth, eps, rms_use_residual, quant_mode, y, q, scales);
+    hipLaunchKernelGGL(norm_vec_kernel, dim3(rows), dim3(threads), depth * sizeof(float), stream,
+                       x, gamma, beta, depth, eps, rms_use_residual, quant_mode, y, q, scales);
     return;
   }
   int block = 64;
@@ -450,13 +452,18 @@ void launch_norm(const float* x, const float* gamma, const float* beta, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------
-// SoftMax / LogSoftMax with optional per-row valid length.
-// Reference: src/cpu/kernels.cc:402-459: masked tail = 0; softmax = exp(x-max) * (1/sum);
-// log-softmax = x + (-max - log(sum)).
+// SoftMax / LogSoftMax with optional per-row valid length, BIT-EXACT with cpu::softmax<AVX2>
+// (src/cpu/kernels.cc:402-459; oracle/ct2_oracle.c orc_softmax): masked tail = 0; exp256_ps with
+// GCC's FMA contraction (exp_avx2, attention_exact.hip); the sum runs as eight strided partial
+// sums + reduce_m256 + scalar tail; softmax = e * (1/sum); log-softmax = x + (-max - log(sum)).
+// The exps are parked in the output row (global memory, re-read by wave 0 for the ordered sum).
+// Two documented residuals of the log form: the scalar tail (depth % 8 elements, or a whole row
+// of <= 8) uses libm expf and the final log is libm logf on the CPU - the device's expf / a
+// double-precision log stand in for them (vocabulary rows are multiples of 8).
 // ---------------------------------------------------------------------------------------
-__global__ void softmax_kernel(const float* __restrict__ x, const int32_t* __restrict__ lengths,
+__global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengths,
                                const float* __restrict__ row_bias, int64_t depth, bool log,
-                               float* __restrict__ y) {
+                               float* y) {  // x == y is allowed (ops::SoftMax runs in place)
   __shared__ float scratch[16];
   const int64_t row = blockIdx.x;
   const float* xr = x + row * depth;
@@ -472,11 +479,40 @@ __global__ void softmax_kernel(const float* __restrict__ x, const int32_t* __res
   float m = -FLT_MAX;
   for (int64_t j = threadIdx.x; j < size; j += blockDim.x) m = fmaxf(m, xr[j]);
   m = block_max(m, scratch);
-  float s = 0.f;
-  for (int64_t j = threadIdx.x; j < size; j += blockDim.x) s += expf(xr[j] - m);
-  s = block_sum(s, scratch);
+  const int64_t vsize = (log && size > 8) ? size - size % 8 : (log ? 0 : size);
+  float s;
+  if (log && x == y) {
+    // in place: the inputs are still needed for the result, so the eight chain lanes of wave 0
+    // evaluate their own exps (slow; the engine never takes this arm)
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x & 7;
+      float acc = 0.f;
+      if (size <= 8) {
+        for (int64_t j = 0; j < size; ++j) acc += expf(xr[j] - m);
+      } else {
+        for (int64_t j = l; j < vsize; j += 8) acc += exp_avx2(xr[j] - m);
+        acc = acc + __shfl_xor(acc, 4, 64);
+        acc = acc + __shfl_xor(acc, 2, 64);
+        acc = acc + __shfl_xor(acc, 1, 64);
+        for (int64_t j = vsize; j < size; ++j) acc += expf(xr[j] - m);
+      }
+      if (threadIdx.x == 0) scratch[0] = acc;
+    }
+    __syncthreads();
+    s = scratch[0];
+  } else {
+    for (int64_t j = threadIdx.x; j < size; j += blockDim.x)
+      yr[j] = (j < vsize) ? exp_avx2(xr[j] - m) : expf(xr[j] - m);
+    __syncthreads();  // the row of exps is visible to wave 0 (same CU)
+    if (threadIdx.x < 64) {
+      const float t = ordered_sum8(yr, static_cast<int>(size));
+      if (threadIdx.x == 0) scratch[0] = t;
+    }
+    __syncthreads();
+    s = scratch[0];
+  }
   if (log) {
-    float c = -m - logf(s);
+    const float c = -m - static_cast<float>(::log(static_cast<double>(s)));
     for (int64_t j = threadIdx.x; j < size; j += blockDim.x) {
       float v = xr[j] + c;
       if (row_bias) v = v + row_bias[row];
@@ -484,7 +520,7 @@ __global__ void softmax_kernel(const float* __restrict__ x, const int32_t* __res
     }
   } else {
     const float r = 1.f / s;
-    for (int64_t j = threadIdx.x; j < size; j += blockDim.x) yr[j] = expf(xr[j] - m) * r;
+    for (int64_t j = threadIdx.x; j < size; j += blockDim.x) yr[j] = yr[j] * r;
   }
 }
 
@@ -828,9 +864,11 @@ __global__ void embed_kernel(const void* __restrict__ table, bool table_is_int8,
   const float* p = pos_table ? pos_table + pos * depth : nullptr;
   if (table_is_int8) {
     const int8_t* e = static_cast<const int8_t*>(table) + id * depth;
-    const float s = table_scale[id];
+    // ops::Dequantize on the CPU multiplies by the reciprocal (dequantize_kernel,
+    // src/ops/dequantize_cpu.cc:10-19: r_scale = 1.f / scale; v * r_scale), which is not x / scale
+    const float r_s = 1.f / table_scale[id];
     for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
-      float v = static_cast<float>(e[i]) / s;
+      float v = static_cast<float>(e[i]) * r_s;
       if (apply_scale) v = v * emb_scale;
       if (p) v = v + p[i];
       o[i] = v;

@@ -430,6 +430,23 @@ int ct2x_step_logits(void* translator, const int32_t* src_ids, const int32_t* sr
                      int32_t batch, int32_t src_stride, const int32_t* tgt_in, int32_t T,
                      float* logits_out);
 
+/* ---- debugging taps (tests only; not part of the reference boundary) ----------------------
+ * ct2x_debug_step_taps = ct2x_step_logits with every producer on the path (embedding, norm +
+ * Quantize, Quantize, Dense, attention) copying its output to the host, named
+ * "<scope>.<index>.<producer>"; tests line them up against the same points of the reference's
+ * layers and report the first tensor that differs. logits_out may be NULL. dtype: 0 fp32, 1 int8.
+ * ct2x_debug_set_position_table replaces the sinusoidal position table (the reference's comes
+ * from MKL's closed vsSin / vsCos; injecting it isolates that residual). */
+int ct2x_debug_step_taps(void* translator, const int32_t* src_ids, const int32_t* src_lengths,
+                         int32_t batch, int32_t src_stride, const int32_t* tgt_in, int32_t T,
+                         float* logits_out);
+int ct2x_debug_tap_count(void);
+int ct2x_debug_tap_info(int index, char* name, int name_size, int32_t* dtype, int64_t* rows,
+                        int64_t* cols);
+int ct2x_debug_tap_data(int index, void* out);
+int ct2x_debug_set_position_table(void* translator, const float* table, int64_t positions,
+                                  int64_t depth);
+
 /* Model facts used by bindings and tests. */
 int ct2x_model_info(void* translator, int32_t* is_seq2seq, int32_t* vocab_size,
                     int32_t* d_model, int32_t* num_layers_dec, int32_t* num_heads,

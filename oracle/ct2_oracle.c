@@ -110,8 +110,11 @@ void orc_dequantize_gemm_output(const int32_t* c, const float* a_scale, const fl
 
 void orc_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, int64_t depth,
                          float* y) {
-  for (int64_t i = 0; i < rows; ++i)
-    for (int64_t j = 0; j < depth; ++j) y[i * depth + j] = (float)x[i * depth + j] / scale[i];
+  /* dequantize_kernel (src/ops/dequantize_cpu.cc:10-19): r_scale = 1.f / scale; v * r_scale */
+  for (int64_t i = 0; i < rows; ++i) {
+    const float r_scale = 1.f / scale[i];
+    for (int64_t j = 0; j < depth; ++j) y[i * depth + j] = (float)x[i * depth + j] * r_scale;
+  }
 }
 
 /* k-ordered fmaf chain (sgemm kernels are FMA based); epilogue per src/ops/gemm.cc:11-25 /
@@ -283,7 +286,8 @@ void orc_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t d
  * below by tests/test_oracle.py::test_exact_matmul_*. The results do not depend on operand
  * alignment. Shapes outside the validated envelope return -1.
  *
- *  (1) m == 1, trans_b, k == 64 (decode QK^T, one query per (row, head)):
+ *  (1) m == 1, trans_b, k = 4, 8, .. 64 (decode QK^T, one query per (row, head); longer rows use
+ *      another tail form that was not recovered):
  *      outputs are produced in groups of 4 columns ("main") and a tail of n % 4 columns.
  *      16 lane accumulators over k = 1..k-1, lane (k-1) % 16, element 0 handled apart.
  *  (2) m == 1, no transpose (decode P.V): k consumed in blocks of 8 through four 2-element FMA
@@ -315,7 +319,7 @@ static float mkl_dot_tail(const float* a, const float* b, int64_t k, int type_a)
     const int l = (int)((t - 1) % 16), c = (int)((t - 1) / 16);
     if (c == 0)
       acc[l] = a[t] * b[t];
-    else if (c == 1 && type_a) {
+    else if (c == 1 && type_a && k > 33) {
       const float p = a[t] * b[t];
       acc[l] = acc[l] + p;
     } else
@@ -364,7 +368,7 @@ int orc_matmul(const float* a, const float* b, int64_t batch, int64_t m, int64_t
     const float* A = a + bi * m * k;
     const float* B = b + bi * n * k;
     float* C = c + bi * m * n;
-    if (m == 1 && trans_b && k == 64) {
+    if (m == 1 && trans_b && k >= 4 && k <= 64 && k % 4 == 0) {
       mkl_qk_m1(A, B, n, k, C);
     } else if (m == 1 && !trans_b) {
       for (int64_t j = 0; j < n; ++j) C[j] = mkl_pv_m1_col(A, B + j, n, k);

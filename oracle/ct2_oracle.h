@@ -29,7 +29,7 @@ void orc_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int64_t
 void orc_dequantize_gemm_output(const int32_t* c, const float* a_scale, const float* b_scale,
                                 const float* bias, int64_t m, int64_t n, int act, float* y);
 
-/* Dequantize rows x/scale (src/ops/dequantize_cpu.cc:10-30). */
+/* Dequantize rows x * (1/scale) (src/ops/dequantize_cpu.cc:10-50). */
 void orc_dequantize_rows(const int8_t* x, const float* scale, int64_t rows, int64_t depth,
                          float* y);
 
@@ -54,8 +54,8 @@ float orc_exp_avx2(float x);
 /* ops::MatMul on CPU (MKL cblas_sgemm_batch_strided, src/cpu/primitives.cc:1085-1101) with the
  * summation order recovered from MKL 2021.4 on this container; see ct2_oracle.c. a [batch, m, k],
  * b [batch, n, k] (trans_b) or [batch, k, n]. Returns -1 when a shape is outside the validated
- * envelope (that batch entry is left untouched). alpha must be 1 or a power of two for the
- * m == 1 paths to be exact (MKL's placement of alpha was only pinned for those). */
+ * envelope (that batch entry is left untouched). alpha multiplies the finished sum (pinned for
+ * the trans_b and sequence forms; the one-row no-transpose form is only pinned at alpha = 1). */
 int orc_matmul(const float* a, const float* b, int64_t batch, int64_t m, int64_t n, int64_t k,
                int trans_b, float alpha, float* c);
 

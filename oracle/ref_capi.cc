@@ -539,4 +539,16 @@ int ct2ref_step_logits(void* h, const int32_t* src_ids, const int32_t* src_lengt
   CT2REF_CATCH
 }
 
+// The reference's sinusoidal position table (generate_sinusoidal_position_encoding,
+// src/layers/common.cc:204-229: logf / expf, then ops::Sin / ops::Cos = MKL VML vsSin / vsCos on
+// this build): out [positions, depth]. Obtained by adding the encodings to zeros.
+int ct2ref_sinusoidal_table(int64_t depth, int64_t positions, float* out) {
+  CT2REF_TRY
+  layers::SinusoidalPositionEncoder enc(depth);
+  StorageView x({1, positions, depth}, 0.f);
+  enc(x);
+  copy_out(x, out);
+  CT2REF_CATCH
+}
+
 }  // extern "C"

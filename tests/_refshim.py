@@ -38,6 +38,12 @@ def lib():
         pass
     for name in ("libmkl_core.so", "libmkl_gnu_thread.so", "libmkl_intel_ilp64.so"):
         C.CDLL(sorted(glob.glob(os.path.join(MKL_DIR, name + "*")))[0], mode=mode)
+    # Op-level taps by symbol interposition (oracle/ref_tap.cc): must enter the global scope
+    # BEFORE the reference library so that the reference's own PLT calls resolve to the shims.
+    global _tap
+    tap_path = os.path.join(REF_DIR, "libct2ref_tap.so")
+    if os.path.exists(tap_path):
+        _tap = C.CDLL(tap_path, mode=mode)
     C.CDLL(os.path.join(REF_DIR, "libctranslate2_ref.so"), mode=mode)
     L = C.CDLL(os.path.join(REF_DIR, "libct2ref_capi.so"), mode=mode)
     L.ct2ref_last_error.restype = C.c_char_p
@@ -46,6 +52,38 @@ def lib():
     L.ct2ref_model_free.argtypes = [C.c_void_p]
     _lib = L
     return L
+
+
+_tap = None
+
+
+class taps:
+    """with taps() as t: ...reference calls...; t.records -> [(kind, array)] of every
+    ops::Quantize (in / out / scale), LayerNorm, MatMul, SoftMax and Dense (Dequantize) call the
+    reference made, in call order."""
+
+    def __enter__(self):
+        lib()
+        if _tap is None:
+            raise RuntimeError("oracle/_ref/libct2ref_tap.so is not built")
+        _tap.ct2tap_begin()
+        self.records = []
+        return self
+
+    def __exit__(self, *exc):
+        _tap.ct2tap_end()
+        n = _tap.ct2tap_count()
+        name = C.create_string_buffer(64)
+        dtype, rank = C.c_int32(), C.c_int32()
+        shape = (C.c_int64 * 8)()
+        for i in range(n):
+            _tap.ct2tap_info(i, name, 64, C.byref(dtype), C.byref(rank), shape)
+            shp = tuple(shape[d] for d in range(rank.value))
+            a = np.empty(shp, np.float32 if dtype.value == 0 else np.int8)
+            if a.size:
+                _tap.ct2tap_data(i, a.ctypes.data_as(C.c_void_p))
+            self.records.append((name.value.decode(), a))
+        return False
 
 
 def _p(a):
@@ -169,6 +207,12 @@ def matmul(a, b, trans_b=False, alpha=1.0):
     _check(lib().ct2ref_matmul(_p(a), _p(b), C.c_int64(batch), C.c_int64(m), C.c_int64(n),
                                C.c_int64(k), C.c_int(int(trans_b)), C.c_float(alpha), _p(c)))
     return c
+
+
+def sinusoidal_table(depth, positions):
+    out = np.empty((positions, depth), np.float32)
+    _check(lib().ct2ref_sinusoidal_table(C.c_int64(depth), C.c_int64(positions), _p(out)))
+    return out
 
 
 def process_logits(logits, seq, penalty=1.0, ngram=0, suppress=()):

@@ -201,6 +201,15 @@ def test_exact_softmax(depth, log):
     assert np.array_equal(_bits(O.softmax(wide, L, log)), _bits(R.softmax(wide, L, log)))
 
 
+def test_exact_dequantize_rows():
+    """Embedding rows: the CPU multiplies by 1/scale (src/ops/dequantize_cpu.cc:10-19)."""
+    R = _ref()
+    rng = np.random.default_rng(20)
+    x = rng.integers(-127, 128, (50, 512)).astype(np.int8)
+    s = (127.0 / (rng.random(50) * 0.1 + 0.01)).astype(np.float32)
+    assert np.array_equal(_bits(O.dequantize_rows(x, s)), _bits(R.dequantize_rows(x, s)))
+
+
 def test_exact_matmul_decode_qk():
     """m = 1, trans_b, k = 64: every key count 1..70 (main groups of 4 + the three tail forms)."""
     R = _ref()
@@ -209,6 +218,17 @@ def test_exact_matmul_decode_qk():
         q = rng.standard_normal((24, 1, 64)).astype(np.float32)
         k = rng.standard_normal((24, n, 64)).astype(np.float32)
         assert np.array_equal(_bits(O.matmul(q, k, True, 0.125)), _bits(R.matmul(q, k, True, 0.125))), n
+
+
+def test_exact_matmul_decode_qk_every_head_size():
+    """... and every head size 4, 8, .. 64 (the fixtures use d_head 4, 16, 32, 64)."""
+    R = _ref()
+    rng = np.random.default_rng(25)
+    for kk in range(4, 65, 4):
+        for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 33):
+            q = rng.standard_normal((10, 1, kk)).astype(np.float32)
+            k = rng.standard_normal((10, n, kk)).astype(np.float32)
+            assert np.array_equal(_bits(O.matmul(q, k, True, 0.5)), _bits(R.matmul(q, k, True, 0.5))), (kk, n)
 
 
 def test_exact_matmul_decode_pv():
@@ -237,7 +257,7 @@ def test_exact_matmul_sequence():
 
 def test_matmul_envelope_is_explicit():
     with pytest.raises(ValueError):
-        O.matmul(np.zeros((1, 1, 128), np.float32), np.zeros((1, 4, 128), np.float32), True)
+        O.matmul(np.zeros((1, 1, 128), np.float32), np.zeros((1, 5, 128), np.float32), True)
     with pytest.raises(ValueError):
         O.matmul(np.zeros((1, 2, 64), np.float32), np.zeros((1, 8, 64), np.float32), True)
 
