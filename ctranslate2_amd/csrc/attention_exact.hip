@@ -10,7 +10,8 @@
 //       - one query per (row, head) (m = 1): the QK^T dot products use 16 lane accumulators over
 //         k = 1..63 with element 0 apart, in a "main" form for the key groups of four and two
 //         "tail" forms for the n % 4 last keys; P.V consumes the keys in blocks of eight through
-//         four 2-element FMA chains, then one FMA per remaining key;
+//         four 2-element FMA chains, then one FMA per remaining key (d_head >= 16; narrower
+//         outputs are plain k-ordered chains);
 //       - several queries (sequence mode, beam >= 3 over the encoder memory): k-ordered FMA chains;
 //   * SoftMax = cpu::softmax<AVX2> (src/cpu/kernels.cc:402-459): exp256_ps with GCC's FMA
 //     contraction, eight strided partial sums + reduce_m256 + scalar tail, multiply by 1 / sum.
@@ -25,6 +26,7 @@
 #include "kernels.h"
 #include "runtime.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <float.h>
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
     // ---- P.V: lane = channel --------------------------------------------------------------
     float y = 0.f;
     bool has = false;
-    const int n_blocks = kSeq ? 0 : n_keys / 8;
+    // narrow outputs (d_head 4 / 8) take MKL's plain k-ordered form even for one query row
+    const int n_blocks = (kSeq || DH < 16) ? 0 : n_keys / 8;
     float va[XVB], vb[XVB];
 #define CT2X_XLOAD_V(VR, T0)                                              \
   _Pragma("unroll") for (int j = 0; j < XVB; ++j) {                       \
@@ -458,6 +461,113 @@ void launch_attention_exact_decode(const AttnDecodeParams& p, int quant_mode, in
     case 32: launch_x<32>(a, seq, lds, stream); break;
     default: launch_x<64>(a, seq, lds, stream); break;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ops::MatMul standalone (the unfused front-end of the Level-1 integration calls MatMul, SoftMax,
+// MatMul as three ops): C[b] = alpha * A[b] . op(B[b]) with MKL's summation order per output
+// element - the same forms as above, one thread per output (a parity path, not a fast one):
+//   trans_b, m == 1, k in {4, 8, .. 64}:   main / tail dot forms by column
+//   no transpose, m == 1, n >= 16:         blocks of eight keys, then one FMA per remaining key
+//   everything else in the envelope:       k-ordered FMA chain
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <int K>
+__device__ __forceinline__ float matmul_x_qk(const float* q, const float* kr, bool is_main, bool type_a) {
+  float qv[K], kv[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    qv[c] = q[c];
+    kv[c] = kr[c];
+  }
+  return is_main ? dot_main<K>(qv, kv) : dot_tail<K>(qv, kv, type_a);
+}
+
+__device__ __forceinline__ float matmul_x_qk_any(int k, const float* q, const float* kr, bool is_main,
+                                                 bool type_a) {
+  switch (k) {
+    case 4: return matmul_x_qk<4>(q, kr, is_main, type_a);
+    case 8: return matmul_x_qk<8>(q, kr, is_main, type_a);
+    case 12: return matmul_x_qk<12>(q, kr, is_main, type_a);
+    case 16: return matmul_x_qk<16>(q, kr, is_main, type_a);
+    case 20: return matmul_x_qk<20>(q, kr, is_main, type_a);
+    case 24: return matmul_x_qk<24>(q, kr, is_main, type_a);
+    case 28: return matmul_x_qk<28>(q, kr, is_main, type_a);
+    case 32: return matmul_x_qk<32>(q, kr, is_main, type_a);
+    case 36: return matmul_x_qk<36>(q, kr, is_main, type_a);
+    case 40: return matmul_x_qk<40>(q, kr, is_main, type_a);
+    case 44: return matmul_x_qk<44>(q, kr, is_main, type_a);
+    case 48: return matmul_x_qk<48>(q, kr, is_main, type_a);
+    case 52: return matmul_x_qk<52>(q, kr, is_main, type_a);
+    case 56: return matmul_x_qk<56>(q, kr, is_main, type_a);
+    case 60: return matmul_x_qk<60>(q, kr, is_main, type_a);
+    default: return matmul_x_qk<64>(q, kr, is_main, type_a);
+  }
+}
+
+__global__ void matmul_x_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                int64_t batch, int m, int n, int k, bool trans_b, float alpha,
+                                float* __restrict__ c) {
+  const int64_t total = batch * m * n;
+  for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t bi = e / (static_cast<int64_t>(m) * n);
+    const int i = static_cast<int>((e / n) % m), j = static_cast<int>(e % n);
+    const float* A = a + bi * m * k + static_cast<int64_t>(i) * k;
+    const float* B = b + bi * static_cast<int64_t>(n) * k;
+    float s;
+    if (trans_b && m == 1) {
+      const int main_n = (n / 4) * 4;
+      s = matmul_x_qk_any(k, A, B + static_cast<int64_t>(j) * k, j < main_n, (j - main_n) != 1);
+    } else if (!trans_b && m == 1 && n >= 16) {
+      float y = 0.f;
+      bool has = false;
+      const int nb = k / 8;
+      for (int blk = 0; blk < nb; ++blk) {
+        const float* pp = A + 8 * blk;
+        const float* vv = B + static_cast<int64_t>(8 * blk) * n + j;
+        const float A_ = fmaf(pp[0], vv[0], pp[2] * vv[2 * n]);
+        const float B_ = fmaf(pp[1], vv[n], pp[3] * vv[3 * n]);
+        const float c6 = has ? fmaf(pp[6], vv[6 * n], y) : pp[6] * vv[6 * n];
+        const float C_ = fmaf(pp[4], vv[4 * n], c6);
+        const float D_ = fmaf(pp[5], vv[5 * n], pp[7] * vv[7 * n]);
+        y = (C_ + D_) + (A_ + B_);
+        has = true;
+      }
+      for (int t = 8 * nb; t < k; ++t) {
+        const float bv = B[static_cast<int64_t>(t) * n + j];
+        y = has ? fmaf(A[t], bv, y) : A[t] * bv;
+        has = true;
+      }
+      s = y;
+    } else {
+      s = 0.f;
+      for (int t = 0; t < k; ++t)
+        s = fmaf(A[t], trans_b ? B[static_cast<int64_t>(j) * k + t] : B[static_cast<int64_t>(t) * n + j], s);
+    }
+    c[e] = (alpha != 1.f) ? s * alpha : s;
+  }
+}
+
+}  // namespace
+
+// The envelope in which MKL's order is known (oracle/ct2_oracle.c orc_matmul).
+bool matmul_exact_applicable(int64_t m, int64_t n, int64_t k, bool trans_b) {
+  if (exact_disabled()) return false;
+  if (m == 1 && trans_b) return k >= 4 && k <= 64 && k % 4 == 0;
+  if (m == 1 && !trans_b) return true;
+  if (trans_b) return m >= 3 && n >= 5;
+  return true;
+}
+
+void launch_matmul_exact(const float* a, const float* b, int64_t batch, int64_t m, int64_t n,
+                         int64_t k, bool trans_b, float alpha, float* c, hipStream_t stream) {
+  const int64_t total = batch * m * n;
+  if (total <= 0) return;
+  const unsigned grid = static_cast<unsigned>(std::min<int64_t>((total + 127) / 128, 65535));
+  hipLaunchKernelGGL(matmul_x_kernel, dim3(grid), dim3(128), 0, stream, a, b, batch,
+                     static_cast<int>(m), static_cast<int>(n), static_cast<int>(k), trans_b, alpha, c);
 }
 
 bool attention_exact_full_applicable(const AttnFullParams& p) {

@@ -82,6 +82,12 @@ int ct2x_stream_synchronize(void* stream) {
   API_CATCH
 }
 
+int ct2x_device_synchronize(void) {
+  API_TRY
+  CT2X_HIP_CHECK(hipDeviceSynchronize());
+  API_CATCH
+}
+
 int ct2x_malloc(void** d_ptr, size_t bytes) {
   API_TRY
   *d_ptr = device_malloc(bytes);
@@ -466,6 +472,24 @@ int ct2x_transpose(const void* d_a, const int64_t* dims, const int64_t* perm, in
   API_CATCH
 }
 
+int ct2x_block_copy(const void* d_src, void* d_dst, int64_t outer, int64_t block_bytes,
+                    int64_t src_stride_bytes, int64_t dst_stride_bytes, void* stream) {
+  API_TRY
+  CT2X_CHECK(outer >= 0 && block_bytes >= 0, "ct2x_block_copy: negative extent");
+  launch_block_copy(d_src, d_dst, outer, block_bytes, src_stride_bytes, dst_stride_bytes,
+                    resolve_stream(stream));
+  check_last_launch("block_copy");
+  API_CATCH
+}
+
+int ct2x_mean(const float* d_x, int64_t outer, int64_t axis, int64_t inner, int get_sum, float* d_y,
+              void* stream) {
+  API_TRY
+  launch_mean(d_x, outer, axis, inner, get_sum != 0, d_y, resolve_stream(stream));
+  check_last_launch("mean");
+  API_CATCH
+}
+
 int ct2x_prepare_length_mask(const int32_t* d_lengths, int64_t batch, int64_t heads,
                              int64_t queries, int mask_future, int multi_query, int32_t* d_mask,
                              void* stream) {
@@ -487,8 +511,13 @@ int ct2x_gather_rows(const void* d_data, const int32_t* d_idx, int64_t n_idx,
 int ct2x_matmul_f32(const float* d_a, const float* d_b, int64_t batch, int64_t m, int64_t n,
                     int64_t k, int trans_b, float alpha, float* d_c, void* stream) {
   API_TRY
-  launch_gemm_f32(d_a, d_b, batch, m, n, k, trans_b != 0, alpha, m * k, n * k, m * n, nullptr,
-                  nullptr, -1, d_c, resolve_stream(stream));
+  if (matmul_exact_applicable(m, n, k, trans_b != 0)) {
+    // the reference CPU path's (MKL) summation order, bit for bit (attention_exact.hip)
+    launch_matmul_exact(d_a, d_b, batch, m, n, k, trans_b != 0, alpha, d_c, resolve_stream(stream));
+  } else {
+    launch_gemm_f32(d_a, d_b, batch, m, n, k, trans_b != 0, alpha, m * k, n * k, m * n, nullptr,
+                    nullptr, -1, d_c, resolve_stream(stream));
+  }
   check_last_launch("matmul_f32");
   API_CATCH
 }

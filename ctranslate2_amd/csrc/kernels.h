@@ -221,6 +221,11 @@ struct AttnFullParams {
 
 void launch_attention_full(const AttnFullParams& p, hipStream_t stream);
 
+// ops::MatMul with MKL's summation order per output element (one thread per output; the unfused
+// Level-1 front-end calls MatMul / SoftMax / MatMul as separate ops).
+bool matmul_exact_applicable(int64_t m, int64_t n, int64_t k, bool trans_b);
+void launch_matmul_exact(const float* a, const float* b, int64_t batch, int64_t m, int64_t n,
+                         int64_t k, bool trans_b, float alpha, float* c, hipStream_t stream);
 bool attention_exact_full_applicable(const AttnFullParams& p);
 void launch_attention_exact_full(const AttnFullParams& p, hipStream_t stream);
 
@@ -335,6 +340,11 @@ void launch_indexed_fill(void* x, double value, const int32_t* indices, int64_t 
                          hipStream_t stream);
 // fn 0..6 = ops::ActivationType, 7 exp, 8 log, 9 sin, 10 cos
 void launch_unary(int fn, const float* x, float* y, int64_t size, hipStream_t stream);
+// Concat / Split / Slide / Tile as strided block copies; Mean / Sum over the middle axis.
+void launch_block_copy(const void* src, void* dst, int64_t outer, int64_t block_bytes,
+                       int64_t src_stride_bytes, int64_t dst_stride_bytes, hipStream_t stream);
+void launch_mean(const float* x, int64_t outer, int64_t axis, int64_t inner, bool get_sum, float* y,
+                 hipStream_t stream);
 // b = transpose(a reshaped to dims[rank], perm); rank 2..4; dims / perm are HOST arrays
 void launch_transpose(const void* a, const int64_t* dims, const int64_t* perm, int rank, void* b,
                       int dtype, hipStream_t stream);

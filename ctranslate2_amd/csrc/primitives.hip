@@ -7,6 +7,8 @@
 // stubs (tests/integration/ops_mi355_stub.cc, BOUNDARY.md) cover what a maintainer's op-by-op
 // build links against. All of them are plain HBM-bound scans: one element per lane and
 // grid-stride step, consecutive lanes on consecutive addresses.
+#include <algorithm>
+
 #include "device_utils.h"
 #include "kernels.h"
 #include "runtime.h"
@@ -159,7 +161,70 @@ void by_dtype(int dtype, F&& f) {
   }
 }
 
+// Layout ops of the unfused front-end (ops::Concat / Split / Slide: src/ops/
+// concat_split_slide_gpu.cu:66-209; ops::Tile: src/ops/tile_gpu.cu:36-70): all of them are
+// "outer x block" strided copies. block_copy moves `outer` blocks of `block` bytes, source block o
+// at src + o*src_stride, destination block o at dst + o*dst_stride; 16-byte lanes when the
+// pointers, the strides and the block size allow, bytes otherwise.
+template <typename V>
+__global__ void block_copy_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                  int64_t outer, int64_t block_v, int64_t src_stride,
+                                  int64_t dst_stride) {
+  const int64_t total = outer * block_v;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t o = i / block_v, e = i % block_v;
+    reinterpret_cast<V*>(dst + o * dst_stride)[e] = reinterpret_cast<const V*>(src + o * src_stride)[e];
+  }
+}
+
+// ops::Mean / Sum over the middle axis of [outer, axis, inner] (src/ops/mean_gpu.cu:12-63): one
+// thread per (outer, inner) element walks the axis in order (fp32 accumulation, as the CPU's
+// sequential loop, src/ops/mean_cpu.cc).
+__global__ void mean_kernel(const float* __restrict__ x, int64_t outer, int64_t axis, int64_t inner,
+                            bool get_sum, float* __restrict__ y) {
+  const int64_t total = outer * inner;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t o = i / inner, e = i % inner;
+    const float* p = x + o * axis * inner + e;
+    float acc = 0.f;
+    for (int64_t a = 0; a < axis; ++a) acc += p[a * inner];
+    y[i] = get_sum ? acc : acc / static_cast<float>(axis);
+  }
+}
+
 }  // namespace
+
+void launch_block_copy(const void* src, void* dst, int64_t outer, int64_t block_bytes,
+                       int64_t src_stride_bytes, int64_t dst_stride_bytes, hipStream_t stream) {
+  if (outer <= 0 || block_bytes <= 0) return;
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) |
+                         static_cast<uintptr_t>(block_bytes) | static_cast<uintptr_t>(src_stride_bytes) |
+                         static_cast<uintptr_t>(dst_stride_bytes);
+  const int64_t unit = (bits & 15) == 0 ? 16 : ((bits & 3) == 0 ? 4 : 1);
+  const int64_t total = outer * (block_bytes / unit);
+  const unsigned grid = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 65535));
+  const char* s = static_cast<const char*>(src);
+  char* d = static_cast<char*>(dst);
+  if (unit == 16)
+    hipLaunchKernelGGL(block_copy_kernel<int4>, dim3(grid), dim3(256), 0, stream, s, d, outer,
+                       block_bytes / 16, src_stride_bytes, dst_stride_bytes);
+  else if (unit == 4)
+    hipLaunchKernelGGL(block_copy_kernel<int32_t>, dim3(grid), dim3(256), 0, stream, s, d, outer,
+                       block_bytes / 4, src_stride_bytes, dst_stride_bytes);
+  else
+    hipLaunchKernelGGL(block_copy_kernel<char>, dim3(grid), dim3(256), 0, stream, s, d, outer,
+                       block_bytes, src_stride_bytes, dst_stride_bytes);
+}
+
+void launch_mean(const float* x, int64_t outer, int64_t axis, int64_t inner, bool get_sum, float* y,
+                 hipStream_t stream) {
+  const int64_t total = outer * inner;
+  if (total <= 0) return;
+  const unsigned grid = static_cast<unsigned>(std::min<int64_t>((total + 255) / 256, 65535));
+  hipLaunchKernelGGL(mean_kernel, dim3(grid), dim3(256), 0, stream, x, outer, axis, inner, get_sum, y);
+}
 
 void launch_binary(int op, const void* a, const void* b, void* c, int64_t size, int dtype,
                    hipStream_t stream) {

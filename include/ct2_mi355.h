@@ -76,6 +76,8 @@ int ct2x_device_info(int device_index, char* name, int name_size, char* arch, in
 void* ct2x_thread_stream(void);
 /* synchronize_stream(Device::CUDA) (src/devices.cc:106-117). */
 int ct2x_stream_synchronize(void* stream);
+/* synchronize_device(Device::CUDA) (src/devices.cc:95-105): every stream of the current device. */
+int ct2x_device_synchronize(void);
 
 /* get_allocator<Device::CUDA>() (src/cuda/allocator.cc:34-185): stream-ordered arena.
  * allocate/free are safe to call in any order on one stream; blocks are recycled
@@ -263,6 +265,17 @@ int ct2x_unary(int fn, const float* d_x, float* d_y, int64_t size, void* stream)
 int ct2x_transpose(const void* d_a, const int64_t* dims, const int64_t* perm, int rank, void* d_b,
                    int dtype, void* stream);
 /* primitives::prepare_length_mask (src/cpu/primitives.cc:431-448): mask [batch, heads * queries]. */
+/* ops::Concat / Split / Slide / Tile (src/ops/concat_split_slide_gpu.cu:66-209,
+ * src/ops/tile_gpu.cu:36-70) are "outer x block" strided copies: `outer` blocks of block_bytes,
+ * block o read at d_src + o*src_stride_bytes and written at d_dst + o*dst_stride_bytes (a stride
+ * of 0 repeats the block: Tile). Any dtype. */
+int ct2x_block_copy(const void* d_src, void* d_dst, int64_t outer, int64_t block_bytes,
+                    int64_t src_stride_bytes, int64_t dst_stride_bytes, void* stream);
+/* ops::Mean / the Sum form (src/ops/mean_gpu.cu:12-63) over the middle axis of
+ * [outer, axis, inner] fp32. */
+int ct2x_mean(const float* d_x, int64_t outer, int64_t axis, int64_t inner, int get_sum, float* d_y,
+              void* stream);
+
 int ct2x_prepare_length_mask(const int32_t* d_lengths, int64_t batch, int64_t heads,
                              int64_t queries, int mask_future, int multi_query, int32_t* d_mask,
                              void* stream);

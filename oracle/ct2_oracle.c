@@ -290,9 +290,10 @@ void orc_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t d
  *      another tail form that was not recovered):
  *      outputs are produced in groups of 4 columns ("main") and a tail of n % 4 columns.
  *      16 lane accumulators over k = 1..k-1, lane (k-1) % 16, element 0 handled apart.
- *  (2) m == 1, no transpose (decode P.V): k consumed in blocks of 8 through four 2-element FMA
- *      chains, then sequential FMAs.
- *  (3) m >= 3 and n >= 5 (trans_b), or m >= 2 (no transpose): plain k-ordered FMA chain.
+ *  (2) m == 1, no transpose, n >= 16 (decode P.V, d_head >= 16): k consumed in blocks of 8
+ *      through four 2-element FMA chains, then sequential FMAs.
+ *  (3) m >= 3 and n >= 5 (trans_b), or no transpose with m >= 2 or a narrow output (n = 4, 8:
+ *      d_head 4 / 8): plain k-ordered FMA chain.
  * ------------------------------------------------------------------------------------------- */
 static float tree16(float* acc) {
   for (int w = 8; w >= 1; w /= 2)
@@ -370,9 +371,9 @@ int orc_matmul(const float* a, const float* b, int64_t batch, int64_t m, int64_t
     float* C = c + bi * m * n;
     if (m == 1 && trans_b && k >= 4 && k <= 64 && k % 4 == 0) {
       mkl_qk_m1(A, B, n, k, C);
-    } else if (m == 1 && !trans_b) {
+    } else if (m == 1 && !trans_b && n >= 16) {
       for (int64_t j = 0; j < n; ++j) C[j] = mkl_pv_m1_col(A, B + j, n, k);
-    } else if ((trans_b && m >= 3 && n >= 5) || (!trans_b && m >= 2)) {
+    } else if ((trans_b && m >= 3 && n >= 5) || (!trans_b && (m >= 2 || n == 4 || n == 8))) {
       for (int64_t i = 0; i < m; ++i)
         for (int64_t j = 0; j < n; ++j) {
           float acc = 0.f;

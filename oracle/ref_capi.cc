@@ -262,13 +262,15 @@ struct RefModel {
   int intra_threads = 0;
 };
 
-void* ct2ref_model_load(const char* path, const char* compute_type, int inter_threads,
-                        int intra_threads) {
+// device: "cpu", or "cuda" in the Level-1 integration build (oracle/Makefile target mi355: the
+// reference's own front-end on the MI355X kernels; Device::CUDA is the reference's name for it).
+void* ct2ref_model_load_device(const char* path, const char* device, const char* compute_type,
+                               int inter_threads, int intra_threads) {
   try {
     auto handle = std::make_unique<RefModel>();
     handle->intra_threads = intra_threads;
     models::ModelLoader loader(path);
-    loader.device = Device::CPU;
+    loader.device = str_to_device(device);
     loader.device_indices = {0};
     loader.num_replicas_per_device = inter_threads > 0 ? inter_threads : 1;
     loader.compute_type = str_to_compute_type(compute_type);
@@ -285,6 +287,11 @@ void* ct2ref_model_load(const char* path, const char* compute_type, int inter_th
     g_last_error = e.what();
     return nullptr;
   }
+}
+
+void* ct2ref_model_load(const char* path, const char* compute_type, int inter_threads,
+                        int intra_threads) {
+  return ct2ref_model_load_device(path, "cpu", compute_type, inter_threads, intra_threads);
 }
 
 void ct2ref_model_free(void* h) { delete static_cast<RefModel*>(h); }

@@ -15,6 +15,9 @@ MKL_DIR = os.environ.get("CT2REF_MKL_DIR", "/opt/conda/lib")
 _lib = None
 
 
+VARIANT = os.environ.get("CT2REF_VARIANT", "cpu")
+
+
 def available():
     return os.path.exists(os.path.join(REF_DIR, "libct2ref_capi.so")) and bool(
         glob.glob(os.path.join(MKL_DIR, "libmkl_core.so*")))
@@ -41,11 +44,23 @@ def lib():
     # Op-level taps by symbol interposition (oracle/ref_tap.cc): must enter the global scope
     # BEFORE the reference library so that the reference's own PLT calls resolve to the shims.
     global _tap
-    tap_path = os.path.join(REF_DIR, "libct2ref_tap.so")
-    if os.path.exists(tap_path):
-        _tap = C.CDLL(tap_path, mode=mode)
-    C.CDLL(os.path.join(REF_DIR, "libctranslate2_ref.so"), mode=mode)
-    L = C.CDLL(os.path.join(REF_DIR, "libct2ref_capi.so"), mode=mode)
+    if VARIANT == "mi355":
+        # Level-1 integration build (oracle/Makefile target mi355): the reference's own front-end
+        # linked against the MI355X backend. Same exported names as the CPU build, so the two
+        # cannot share a process: CT2REF_VARIANT=mi355 selects this one (tests run it in a
+        # subprocess, tests/integration/run_level1.py).
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        C.CDLL(os.path.join(root, "ctranslate2_amd", "libct2_mi355.so"), mode=mode)
+        C.CDLL(os.path.join(REF_DIR, "libctranslate2_mi355.so"), mode=mode)
+        L = C.CDLL(os.path.join(REF_DIR, "libct2ref_capi_mi355.so"), mode=mode)
+    else:
+        tap_path = os.path.join(REF_DIR, "libct2ref_tap.so")
+        if os.path.exists(tap_path):
+            _tap = C.CDLL(tap_path, mode=mode)
+        C.CDLL(os.path.join(REF_DIR, "libctranslate2_ref.so"), mode=mode)
+        L = C.CDLL(os.path.join(REF_DIR, "libct2ref_capi.so"), mode=mode)
+    L.ct2ref_model_load_device.restype = C.c_void_p
+    L.ct2ref_model_load_device.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
     L.ct2ref_last_error.restype = C.c_char_p
     L.ct2ref_model_load.restype = C.c_void_p
     L.ct2ref_model_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
@@ -232,9 +247,10 @@ def process_logits(logits, seq, penalty=1.0, ngram=0, suppress=()):
 class RefModel:
     """The reference's Translator / Generator on CPU."""
 
-    def __init__(self, path, compute_type="int8", inter_threads=1, intra_threads=0):
-        self._h = lib().ct2ref_model_load(path.encode(), compute_type.encode(),
-                                          C.c_int(inter_threads), C.c_int(intra_threads))
+    def __init__(self, path, compute_type="int8", inter_threads=1, intra_threads=0, device="cpu"):
+        self._h = lib().ct2ref_model_load_device(path.encode(), device.encode(),
+                                                 compute_type.encode(), C.c_int(inter_threads),
+                                                 C.c_int(intra_threads))
         if not self._h:
             raise RuntimeError(lib().ct2ref_last_error().decode())
 

@@ -38,8 +38,11 @@ namespace ctranslate2 {
       if (_shift_to_uint8)
         throw std::invalid_argument("Shift to uin8_t is not defined on CUDA");
       const dim_t depth = input.dim(-1);
+      // bit 1: round like the reference's CPU path (src/cpu/kernels.cc:592-604: fma(x, scale, 128),
+      // round, cvtt, then the u8s8 GEMM's -128 compensation = an s8 operand), so that Device::CUDA
+      // results equal Device::CPU results (ct2_mi355.h, ct2x_quantize_s8)
       check(ct2x_quantize_s8(input.data<float>(), CT2X_F32, scale.size(), depth,
-                             _round_before_cast ? 1 : 0,
+                             (_round_before_cast ? 1 : 0) | 2,
                              output.data<int8_t>(), scale.data<float>(), stream()));
     }
 

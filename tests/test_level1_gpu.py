@@ -1,0 +1,78 @@
+"""-m gpu: the Level-1 boundary EXECUTED. oracle/_ref/libctranslate2_mi355.so is the reference's
+OWN front-end - ctranslate2::Translator, ReplicaPool, models::Model, layers::Dense /
+MultiHeadAttention / TransformerDecoder, decoding.cc, every ops::X front-end - compiled from the
+sources where they lie with -DCT2_WITH_CUDA by the plain host compiler (oracle/Makefile target
+mi355, tests/integration/shim_cuda/ for the CUDA runtime names its headers leak) and linked with
+tests/integration/{ops,host}_mi355_stub.cc + libct2_mi355.so in place of src/cuda/* and
+src/ops/*_gpu.cu. Here it runs Translator(model, Device::CUDA, ComputeType::INT8) op by op on the
+MI355X kernels and must reproduce what the same front-end computes on Device::CPU
+(tests/golden/model_golden.json; include/ctranslate2/translator.h:26-60,
+tests/translator_test.cc:53-97)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import golden_cases as GC
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(ROOT, "oracle", "_ref", "libct2ref_capi_mi355.so")
+
+
+def run_level1(model_dir, compute_type, sources, runs):
+    if not os.path.exists(LIB):
+        pytest.skip("Level-1 integration library not built (make -C oracle mi355)")
+    spec = json.dumps({"sources": sources, "runs": runs})
+    p = subprocess.run([sys.executable, os.path.join(HERE, "integration", "run_level1.py"), model_dir,
+                        compute_type, spec], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "model_golden.json")) as f:
+        return json.load(f)
+
+
+def test_reference_translator_on_device_cuda_transliteration(gpu, golden):
+    """The reference's own KAT (tests/translator_test.cc:53-97) through the reference's own
+    Translator on Device::CUDA = this backend: "a t z m o n", and every golden sentence."""
+    g = golden["aren-transliteration-i8"]
+    out = run_level1(os.path.join(HERE, "golden", "models", "aren-transliteration-i8"), "int8",
+                     g["sources"], [{"beam": 1, "max_len": g["max_len"], "min_len": g["min_len"]},
+                                    {"beam": 4, "max_len": g["max_len"], "min_len": g["min_len"]}])
+    assert out["compute_type"] == "int8_float32"
+    vocab = [l.rstrip("\n") for l in open(os.path.join(HERE, "golden", "models",
+                                                        "aren-transliteration-i8",
+                                                        "target_vocabulary.txt"), encoding="utf-8")]
+    first = [vocab[i] for i in out["runs"][0]["hypotheses"][0]]
+    assert first == ["a", "t", "z", "m", "o", "n"], first
+    for run, key in zip(out["runs"], ("beam1", "beam4")):
+        want = [h[0] for h in g["runs"][key]["hypotheses"]]
+        same = sum(int(a == b) for a, b in zip(run["hypotheses"], want))
+        print("Level-1 aren-i8 %s: %d/%d sentences identical to Device::CPU" % (key, same, len(want)))
+        assert run["hypotheses"] == want
+
+
+@pytest.mark.parametrize("key", ["tiny", "small", "tb"])
+def test_reference_translator_on_device_cuda_synthetic(gpu, golden, key):
+    from ctranslate2_amd import model_builder as mb
+    g = golden[key]
+    path = "/tmp/ct2x_test_%s" % key
+    if not os.path.exists(os.path.join(path, "model.bin")):
+        mb.build_transformer(path, **GC.SYNTHETIC[key]["model"])
+    out = run_level1(path, "int8", g["sources"],
+                     [{"beam": 1, "max_len": g["max_len"], "min_len": g["min_len"]}])
+    want = [h[0] for h in g["runs"]["beam1"]["hypotheses"]]
+    got = out["runs"][0]["hypotheses"]
+    same = sum(int(a == b) for a, b in zip(got, want))
+    print("Level-1 %s greedy: %d/%d sentences token-identical to the reference on Device::CPU"
+          % (key, same, len(want)))
+    # the position table is made by the host's MKL VML here too; everything else is bit-exact
+    assert same >= len(want) - max(1, len(want) // 16)

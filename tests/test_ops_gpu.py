@@ -443,24 +443,27 @@ def test_attention_decode(gpu, rows, heads, heads_kv, dhead, t_max, kv_group):
         np.testing.assert_allclose(y2, yo2, rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("rows,kv_group", [(32, 1), (24, 3), (128, 4)])
-def test_attention_decode_exact_every_length(gpu, rows, kv_group):
-    """d_head 64, every key count 1..70: the three tail forms of MKL's one-row product, the
-    block-of-eight P.V, the sequence forms of beam search on the memory - bit for bit."""
+@pytest.mark.parametrize("rows,kv_group,dhead", [(32, 1, 64), (24, 3, 64), (128, 4, 64), (8, 1, 4),
+                                                  (8, 1, 8), (6, 1, 16), (8, 1, 32), (12, 4, 8)])
+def test_attention_decode_exact_every_length(gpu, rows, kv_group, dhead):
+    """Every key count 1..70: the three tail forms of MKL's one-row product, the block-of-eight
+    P.V (plain chains for d_head 4 / 8), the sequence forms of beam search on the memory - bit
+    for bit, at every head size of the fixtures."""
     import _gpuops as G
-    rng = np.random.default_rng(rows + kv_group)
+    rng = np.random.default_rng(rows + kv_group + dhead)
+    scale = float(np.float32(1.0 / np.sqrt(dhead)))
     for t_max in list(range(1, 71)) + [130]:
         b = rows // kv_group
-        q = rng.standard_normal((rows, 8, 64)).astype(np.float32)
-        k = rng.standard_normal((b, 8, t_max, 64)).astype(np.float32)
-        v = rng.standard_normal((b, 8, t_max, 64)).astype(np.float32)
+        q = rng.standard_normal((rows, 8, dhead)).astype(np.float32)
+        k = rng.standard_normal((b, 8, t_max, dhead)).astype(np.float32)
+        v = rng.standard_normal((b, 8, t_max, dhead)).astype(np.float32)
         if kv_group >= 3 and t_max < 5:
             continue  # outside the recovered MKL envelope (m >= 3 needs n >= 5)
-        y = G.attention_decode(q, k, v, None, t_max, kv_group, 0.125)
-        assert np.array_equal(y, O.attention_decode(q, k, v, None, t_max, kv_group, 0.125)), t_max
+        y = G.attention_decode(q, k, v, None, t_max, kv_group, scale)
+        assert np.array_equal(y, O.attention_decode(q, k, v, None, t_max, kv_group, scale)), t_max
         lengths = rng.integers(1, t_max + 1, b).astype(np.int32)
-        y = G.attention_decode(q, k, v, lengths, 0, kv_group, 0.125)
-        assert np.array_equal(y, O.attention_decode(q, k, v, lengths, 0, kv_group, 0.125)), t_max
+        y = G.attention_decode(q, k, v, lengths, 0, kv_group, scale)
+        assert np.array_equal(y, O.attention_decode(q, k, v, lengths, 0, kv_group, scale)), t_max
 
 
 @pytest.mark.parametrize("b,tq,tk,h,hkv,dh,causal", [

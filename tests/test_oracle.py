@@ -232,11 +232,11 @@ def test_exact_matmul_decode_qk_every_head_size():
 
 
 def test_exact_matmul_decode_pv():
-    """m = 1, no transpose: every k 1..70 and a long one; n = 64 and 128."""
+    """m = 1, no transpose: every k 1..70 and a long one; every head size in use."""
     R = _ref()
     rng = np.random.default_rng(22)
     for k in list(range(1, 71)) + [100, 257]:
-        for n in (64, 128):
+        for n in (4, 8, 16, 32, 64, 128):
             p = rng.random((6, 1, k)).astype(np.float32)
             v = rng.standard_normal((6, k, n)).astype(np.float32)
             assert np.array_equal(_bits(O.matmul(p, v, False, 1.0)), _bits(R.matmul(p, v, False, 1.0))), (k, n)
