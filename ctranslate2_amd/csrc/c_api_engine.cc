@@ -18,6 +18,7 @@
 
 #include "decoding.h"
 #include "engine.h"
+#include "host_math.h"
 #include "model.h"
 #include "runtime.h"
 
@@ -748,6 +749,24 @@ int ct2x_step_logits(void* translator, const int32_t* src_ids, const int32_t* sr
     e.advance_step(*st);
   }
   e.synchronize();
+  API_CATCH
+}
+
+const char* ct2x_host_math_backend(void) {
+  try {
+    return host_math_backend();
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return nullptr;
+  }
+}
+
+int ct2x_host_sinusoidal_table(int64_t positions, int64_t depth, float* out) {
+  API_TRY
+  CT2X_CHECK(positions > 0 && depth >= 2 && depth % 2 == 0 && out != nullptr,
+             "ct2x_host_sinusoidal_table: positions > 0, even depth, output buffer");
+  const std::vector<float> t = make_sinusoidal_table(positions, depth);
+  std::memcpy(out, t.data(), t.size() * sizeof(float));
   API_CATCH
 }
 

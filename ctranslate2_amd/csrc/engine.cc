@@ -1,4 +1,5 @@
 #include "engine.h"
+#include "host_math.h"
 
 #include <algorithm>
 #include <cmath>
@@ -560,24 +561,37 @@ void Engine::load_weights() {
 }
 
 // generate_sinusoidal_position_encoding (src/layers/common.cc:204-229).
+std::vector<float> make_sinusoidal_table(int64_t positions, int64_t depth) {
+  const int64_t half = depth / 2;
+  // depth 2 would divide by zero here exactly as the reference does (inf increment): guarded
+  const float log_timescale_increment =
+      std::log(10000.f) / static_cast<float>(half > 1 ? half - 1 : 1);
+  std::vector<float> timescales(half);
+  for (int64_t i = 0; i < half; ++i)
+    timescales[i] = std::exp(-log_timescale_increment * static_cast<float>(i));
+  // ops::Sin / ops::Cos on the CPU = the host math backend (MKL VML when installed, host_math.h)
+  std::vector<float> scaled(positions * half), sv(positions * half), cv(positions * half);
+  for (int64_t p = 0; p < positions; ++p)
+    for (int64_t j = 0; j < half; ++j)
+      scaled[p * half + j] = static_cast<float>(p + 1) * timescales[j];
+  host_vsin(positions * half, scaled.data(), sv.data());
+  host_vcos(positions * half, scaled.data(), cv.data());
+  std::vector<float> table(positions * depth);
+  for (int64_t p = 0; p < positions; ++p) {
+    for (int64_t j = 0; j < half; ++j) {
+      table[p * depth + j] = sv[p * half + j];
+      table[p * depth + half + j] = cv[p * half + j];
+    }
+  }
+  return table;
+}
+
 const float* Engine::sinusoidal_table(int64_t positions, int64_t depth) {
   std::lock_guard<std::mutex> lock(table_mutex_);
   if (sin_pos_table_ && positions <= sin_pos_positions_ && depth == sin_pos_depth_)
     return sin_pos_table_;
   positions = std::max<int64_t>(positions, 500);
-  const int64_t half = depth / 2;
-  const float log_timescale_increment = std::log(10000.f) / static_cast<float>(half - 1);
-  std::vector<float> timescales(half);
-  for (int64_t i = 0; i < half; ++i)
-    timescales[i] = std::exp(-log_timescale_increment * static_cast<float>(i));
-  std::vector<float> table(positions * depth);
-  for (int64_t p = 0; p < positions; ++p) {
-    for (int64_t j = 0; j < half; ++j) {
-      const float scaled = static_cast<float>(p + 1) * timescales[j];
-      table[p * depth + j] = std::sin(scaled);
-      table[p * depth + half + j] = std::cos(scaled);
-    }
-  }
+  const std::vector<float> table = make_sinusoidal_table(positions, depth);
   // A superseded table is kept until the engine dies: graphs of live sessions may point at it.
   if (sin_pos_table_) device_blocks_.push_back(sin_pos_table_);
   sin_pos_table_ = static_cast<float*>(device_malloc(table.size() * sizeof(float)));
@@ -624,17 +638,25 @@ void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_
     inv_freq = new_freqs;
   }
   std::vector<float> s(positions * dim), c(positions * dim);
-  for (int64_t p = 0; p < positions; ++p) {
-    const float t = (a.rotary_scaling_type == 0) ? static_cast<float>(p) / a.rotary_scaling_factor
-                                                 : static_cast<float>(p);
-    for (int64_t i = 0; i < half; ++i) {
-      const float f = t * inv_freq[i];
-      if (a.rotary_interleave) {
-        s[p * dim + 2 * i] = s[p * dim + 2 * i + 1] = std::sin(f);
-        c[p * dim + 2 * i] = c[p * dim + 2 * i + 1] = std::cos(f);
-      } else {
-        s[p * dim + i] = s[p * dim + half + i] = std::sin(f);
-        c[p * dim + i] = c[p * dim + half + i] = std::cos(f);
+  {
+    std::vector<float> freqs(positions * half), fs(positions * half), fc(positions * half);
+    for (int64_t p = 0; p < positions; ++p) {
+      const float t = (a.rotary_scaling_type == 0) ? static_cast<float>(p) / a.rotary_scaling_factor
+                                                   : static_cast<float>(p);
+      for (int64_t i = 0; i < half; ++i) freqs[p * half + i] = t * inv_freq[i];
+    }
+    host_vsin(positions * half, freqs.data(), fs.data());
+    host_vcos(positions * half, freqs.data(), fc.data());
+    for (int64_t p = 0; p < positions; ++p) {
+      for (int64_t i = 0; i < half; ++i) {
+        const float sf = fs[p * half + i], cf = fc[p * half + i];
+        if (a.rotary_interleave) {
+          s[p * dim + 2 * i] = s[p * dim + 2 * i + 1] = sf;
+          c[p * dim + 2 * i] = c[p * dim + 2 * i + 1] = cf;
+        } else {
+          s[p * dim + i] = s[p * dim + half + i] = sf;
+          c[p * dim + i] = c[p * dim + half + i] = cf;
+        }
       }
     }
   }

@@ -32,6 +32,10 @@ enum class ComputeType { kFloat32, kInt8Float32, kFloat16, kBFloat16 };
 
 std::string compute_type_name(ComputeType t);
 
+// generate_sinusoidal_position_encoding (src/layers/common.cc:204-229) on the host:
+// [positions, depth], sin half then cos half, through the host math backend (host_math.h).
+std::vector<float> make_sinusoidal_table(int64_t positions, int64_t depth);
+
 struct DenseW {
   // Tensor parallel: the K dimension is split over the ranks (attention-out / FFN-out); the
   // partial products are summed across ranks before bias, residual (see Engine::dense).

@@ -443,6 +443,18 @@ int ct2x_step_logits(void* translator, const int32_t* src_ids, const int32_t* sr
                      int32_t batch, int32_t src_stride, const int32_t* tgt_in, int32_t T,
                      float* logits_out);
 
+/* Host side of the path: the reference builds its sinusoidal position encodings and RoPE tables
+ * on the CPU with ops::Sin / ops::Cos (src/layers/common.cc:204-229,
+ * src/layers/attention_layer.cc:252-343), which an MKL build routes to VML (vsSin / vsCos,
+ * src/cpu/primitives.cc:378-394). VML is neither libm nor correctly rounded, and a one-ulp table
+ * difference flips int8 activations, so this backend resolves the same two functions from an
+ * MKL runtime when one is installed (dlopen of libmkl_rt; CT2X_MKL_PATH / MKLROOT / CONDA_PREFIX
+ * searched) and uses libm otherwise (CT2X_HOST_MATH=libm | mkl forces it).
+ * ct2x_host_math_backend: "mkl-vml" or "libm". ct2x_host_sinusoidal_table: host only,
+ * out [positions, depth]. */
+const char* ct2x_host_math_backend(void);
+int ct2x_host_sinusoidal_table(int64_t positions, int64_t depth, float* out);
+
 /* ---- debugging taps (tests only; not part of the reference boundary) ----------------------
  * ct2x_debug_step_taps = ct2x_step_logits with every producer on the path (embedding, norm +
  * Quantize, Quantize, Dense, attention) copying its output to the host, named

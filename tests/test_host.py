@@ -214,3 +214,26 @@ def test_integration_stubs_match_the_reference_headers(tmp_path):
         needed = {sym for sym in _nm(obj, "-u") if re.search(pattern, sym)}
         assert needed, src
         assert needed <= defined, (src, sorted(needed - defined))
+
+
+def test_host_sinusoidal_table_matches_the_reference():
+    """The position table is host work (src/layers/common.cc:204-229 runs on the CPU even for
+    GPU models). With an MKL runtime installed the backend uses VML as the reference does and the
+    table must equal the reference's bit for bit (tests/golden/tap_golden.npz holds tables made by
+    the real reference); with libm it may differ by one ulp in a few percent of the entries."""
+    import ctypes as C
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    L.ct2x_host_math_backend.restype = C.c_char_p
+    backend = L.ct2x_host_math_backend().decode()
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tap_golden.npz"))
+    for depth in (32, 64, 256, 512):
+        want = z["postable/%d" % depth]
+        got = np.empty_like(want)
+        assert L.ct2x_host_sinusoidal_table(C.c_int64(want.shape[0]), C.c_int64(depth),
+                                            got.ctypes.data_as(C.c_void_p)) == 0
+        if backend == "mkl-vml":
+            assert np.array_equal(got, want), depth
+        else:
+            assert np.mean(got == want) > 0.9
+            np.testing.assert_allclose(got, want, rtol=2e-7, atol=1e-7)
