@@ -4,6 +4,7 @@
 
 #include "device_utils.h"
 #include "kernels.h"
+#include "runtime.h"
 
 #include <float.h>
 #include <limits.h>
@@ -59,8 +60,33 @@ __device__ __forceinline__ bool forced_by_prefix(const SamplePrefix& pf, const S
   return true;
 }
 
+// Denominator of the reference's LogSoftMax over one vocabulary row, bit for bit
+// (cpu::softmax<AVX2> log arm, src/cpu/kernels.cc:430-451; oracle orc_softmax): exp256_ps of
+// x - max for the vector body, libm expf for the scalar tail (vocab % 8 elements - vocabularies
+// here are padded to multiples of 8 or 16, where the tail is empty and the result exact), eight
+// strided partial sums + reduce_m256 + tail. The exps are parked in `park` (a scratch row in
+// global memory) because the ordered sum walks them front to back from one wave. All threads
+// of the block call; every thread receives the sum. scratch: one __shared__ float.
+__device__ __forceinline__ float ordered_row_exp_sum(const float* __restrict__ x, int64_t vocab,
+                                                     int masked, float m, float* __restrict__ park,
+                                                     float* scratch) {
+  const int64_t vsize = vocab > 8 ? vocab - vocab % 8 : 0;
+  for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
+    const float v = ((j == masked) ? -FLT_MAX : x[j]) - m;
+    park[j] = (j < vsize) ? exp_avx2(v) : expf(v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float s = ordered_sum8(park, static_cast<int>(vocab));
+    if (threadIdx.x == 0) *scratch = s;
+  }
+  __syncthreads();
+  return *scratch;
+}
+
 __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t vocab,
                                      int32_t disable_id, int32_t min_length, bool with_scores,
+                                     float* __restrict__ exp_scratch,
                                      SamplePrefix pf, StepAdvance adv,
                                      const int32_t* step_ptr, int32_t* __restrict__ next_ids,
                                      int32_t* __restrict__ hist_ids,
@@ -143,14 +169,10 @@ __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t v
   const float m = best_v;
   float score = m;
   if (with_scores) {
-    // LogSoftMax (src/cpu/kernels.cc:441-451): y = x + (-max - log(sum exp(x - max))).
-    float s = 0.f;
-    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
-      const float v = (j == masked) ? -FLT_MAX : x[j];
-      s += expf(v - m);
-    }
-    s = block_sum(s, scratch);
-    score = m + (-m - logf(s));
+    // LogSoftMax (src/cpu/kernels.cc:441-451): y = x + (-max - log(sum exp(x - max))), with the
+    // reference's exp polynomial, sum order and libm logf
+    const float s = ordered_row_exp_sum(x, vocab, masked, m, exp_scratch + row * vocab, scratch);
+    score = m + (-m - logf_glibc(s));
   }
   if (threadIdx.x == 0) {
     next_ids[row] = best_i;
@@ -165,16 +187,17 @@ void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
                           hipStream_t stream, const int32_t* prefix_ids, const int32_t* prefix_lens,
                           int32_t prefix_stride, int32_t prefix_first_step, bool prefix_extends_min,
-                          int32_t* advance_step_ptr, int32_t* done_counter) {
+                          int32_t* advance_step_ptr, int32_t* done_counter, float* exp_scratch) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
   const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step,
                         prefix_extends_min ? 1 : 0};
   const StepAdvance adv{advance_step_ptr, done_counter};
+  CT2X_CHECK(!with_scores || exp_scratch != nullptr, "greedy sampler: scores need a scratch row buffer");
   hipLaunchKernelGGL(greedy_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
-                     disable_id, min_length, with_scores, pf, adv, step_ptr, next_ids, hist_ids,
-                     hist_scores);
+                     disable_id, min_length, with_scores, exp_scratch, pf, adv, step_ptr, next_ids,
+                     hist_ids, hist_scores);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -555,11 +578,10 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
   for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
     m = fmaxf(m, (j == masked) ? -FLT_MAX : x[j]);
   m = block_max(m, scratch);
-  float s = 0.f;
-  for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
-    s += expf(((j == masked) ? -FLT_MAX : x[j]) - m);
-  s = block_sum(s, scratch);
-  const float c = -m - logf(s);
+  // the reference's LogSoftMax bit for bit: exp polynomial, sum order, libm logf (the output row
+  // parks the exps until the sum is known)
+  const float s = ordered_row_exp_sum(x, vocab, masked, m, yr, scratch);
+  const float c = -m - logf_glibc(s);
   const float b = beam_scores ? beam_scores[row] : 0.f;
   for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
     const float v = ((j == masked) ? -FLT_MAX : x[j]) + c;

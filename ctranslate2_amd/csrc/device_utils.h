@@ -225,6 +225,50 @@ __device__ __forceinline__ float exp_avx2(float x) {
   return y * pow2n;
 }
 
+// logf exactly as glibc computes it (sysdeps/ieee754/flt-32/e_logf.c, the ARM optimized-routines
+// algorithm, MIT): 16-entry table of (1/c, log c), a degree-3 polynomial, everything in double,
+// one final rounding. The reference's CPU LogSoftMax ends with std::log(exp_sum)
+// (src/cpu/kernels.cc:449); glibc's logf is NOT correctly rounded (0.17 percent of inputs differ
+// from the rounded double log), and a one-ulp shift of a whole log-probability row is enough to
+// swap near-tied beams. The constants were read out of the libm.so.6 of the authoring image
+// (glibc 2.35) and the restatement checked bit for bit against it on 5e5 inputs. x must be a
+// positive normal float (a softmax denominator is >= 1).
+__device__ __forceinline__ float logf_glibc(float x) {
+  static constexpr double kTab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2},
+    {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+    {0x1.49539f0f010b0p+0, -0x1.01eae7f513a67p-2},
+    {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+    {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3},
+    {0x1.25e227b0b8ea0p+0, -0x1.1aa2bc79c8100p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4},
+    {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+    {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5},
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},
+    {0x1.ca4b31f026aa0p-1, 0x1.c5e53aa362eb4p-4},
+    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},
+    {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d224770p-3},
+    {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
+    {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2},
+  };
+  constexpr double kLn2 = 0x1.62e42fefa39efp-1;
+  constexpr double kA0 = -0x1.00ea348b88334p-2, kA1 = 0x1.5575b0be00b6ap-2, kA2 = -0x1.ffffef20a4123p-2;
+  const uint32_t ix = __float_as_uint(x);
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = static_cast<int>((tmp >> 19) & 15);
+  const int k = static_cast<int32_t>(tmp) >> 23;
+  const uint32_t iz = ix - (tmp & 0xff800000u);
+  const double z = static_cast<double>(__uint_as_float(iz));
+  const double r = z * kTab[i][0] - 1.0;
+  const double y0 = kTab[i][1] + static_cast<double>(k) * kLn2;
+  const double r2 = r * r;
+  double y = kA1 * r + kA2;
+  y = kA0 * r2 + y;
+  y = y * r2 + (y0 + r);
+  return static_cast<float>(y);
+}
+
 // Sum of e[0, size) in the order of vectorized_reduce_all<AVX2> (src/cpu/kernels.cc:86-139):
 // eight strided partial sums, reduce_m256 (lane l + l^4, + l^2, + l^1), then the scalar tail; a
 // row of <= 8 elements is summed front to back. `e` is LDS (or global) memory written by this

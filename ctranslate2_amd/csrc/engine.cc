@@ -1046,8 +1046,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   st->hist_ids = alloc<int32_t>(*st, (t_max + 1) * rows);
   st->hist_scores = alloc<float>(*st, (t_max + 1) * rows);
   CT2X_HIP_CHECK(hipMemsetAsync(st->d_step, 0, sizeof(int32_t), cur_stream()));
+  st->logprobs = alloc<float>(*st, rows * V);  // log-probabilities (beam search) / exp scratch
   if (beam > 1) {
-    st->logprobs = alloc<float>(*st, rows * V);
     st->beam_scores = alloc<float>(*st, rows);
     st->topk_scores = alloc<float>(*st, batch * 2 * beam);
     st->topk_ids = alloc<int32_t>(*st, batch * 2 * beam);
@@ -1599,7 +1599,8 @@ void Engine::launch_step(DecodeState& st) {
       launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
                            st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores,
                            cur_stream(), st.d_prefix, st.d_prefix_len, st.prefix_stride,
-                           st.prefix_first_step, st.prefix_extends_min, st.d_step, st.d_done);
+                           st.prefix_first_step, st.prefix_extends_min, st.d_step, st.d_done,
+                           st.logprobs);
       end_kernel();
     } else {
       begin_kernel("random_sample");

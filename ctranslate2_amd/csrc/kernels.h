@@ -267,7 +267,8 @@ void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           hipStream_t stream, const int32_t* prefix_ids = nullptr,
                           const int32_t* prefix_lens = nullptr, int32_t prefix_stride = 0,
                           int32_t prefix_first_step = 0, bool prefix_extends_min = true,
-                          int32_t* advance_step_ptr = nullptr, int32_t* done_counter = nullptr);
+                          int32_t* advance_step_ptr = nullptr, int32_t* done_counter = nullptr,
+                          float* exp_scratch = nullptr /* [rows, vocab], needed with_scores */);
 
 // *step_ptr += 1
 void launch_advance_step(int32_t* step_ptr, hipStream_t stream);

@@ -457,9 +457,9 @@ void launch_norm(const float* x, const float* gamma, const float* beta, int64_t 
 // GCC's FMA contraction (exp_avx2, attention_exact.hip); the sum runs as eight strided partial
 // sums + reduce_m256 + scalar tail; softmax = e * (1/sum); log-softmax = x + (-max - log(sum)).
 // The exps are parked in the output row (global memory, re-read by wave 0 for the ordered sum).
-// Two documented residuals of the log form: the scalar tail (depth % 8 elements, or a whole row
-// of <= 8) uses libm expf and the final log is libm logf on the CPU - the device's expf / a
-// double-precision log stand in for them (vocabulary rows are multiples of 8).
+// The final log is glibc's logf restated (logf_glibc, device_utils.h). One documented residual of
+// the log form: the scalar tail (depth % 8 elements, or a whole row of <= 8) uses libm expf on
+// the CPU - the device's expf stands in for it (vocabulary rows are multiples of 8).
 // ---------------------------------------------------------------------------------------
 __global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengths,
                                const float* __restrict__ row_bias, int64_t depth, bool log,
@@ -512,7 +512,7 @@ __global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengt
     s = scratch[0];
   }
   if (log) {
-    const float c = -m - static_cast<float>(::log(static_cast<double>(s)));
+    const float c = -m - logf_glibc(s);
     for (int64_t j = threadIdx.x; j < size; j += blockDim.x) {
       float v = xr[j] + c;
       if (row_bias) v = v + row_bias[row];
