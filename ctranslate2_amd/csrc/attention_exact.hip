@@ -109,11 +109,12 @@ struct AttnXArgs {
   int group;       // query heads per KV head
   int t_pad;       // score slots per wave (multiple of 16, >= keys + 16)
   int wave_floats; // LDS floats per wave
+  int seq;         // several query rows share a cache row: the MatMul has m > 1 (k-ordered forms)
 };
 
 constexpr int XVB = 16;      // V rows per batch (two blocks of eight)
 
-template <int DH, bool kSeq>
+template <int DH>
 __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int XKS = DH + 4;   // LDS row stride of the K staging tile (floats)
@@ -158,6 +159,11 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
   const int n_valid = t_cached + (has_new ? 1 : 0);
   const int n_keys = p.lengths != nullptr ? static_cast<int>(p.t_max) : n_valid;
   const int t_last = max(t_cached - 1, 0);  // loads are clamped to rows that were written
+  // m of the reference's MatMul: the rows of a kv group (beam search on the encoder memory) -
+  // except at the first step of a CPU beam search, which still runs one row per batch entry
+  // (expand_after_first_step, src/decoding.cc:453-454, 700-712) and so takes the one-row forms.
+  const bool kSeq = a.seq != 0 &&
+                    !(p.one_row_step_ptr != nullptr && *p.one_row_step_ptr == p.one_row_step);
 
   float acc_out = 0.f;
   if (active) {
@@ -177,6 +183,17 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
       if (chan) tq[cl] = qd;
     }
     __builtin_amdgcn_wave_barrier();
+
+    // The first batch of V rows is requested now, before the QK^T phase: one memory round trip
+    // covers both phases (the rows are only consumed by P.V at the end).
+#define CT2X_XLOAD_V(VR, T0)                                              \
+  _Pragma("unroll") for (int j = 0; j < XVB; ++j) {                       \
+    const int t_ = (T0) + j;                                              \
+    const float g_ = vc[min(t_, t_last) * kvs + cl];                      \
+    VR[j] = (has_new && t_ == pos) ? vnew : g_;                           \
+  }
+    float va[XVB], vb[XVB];
+    CT2X_XLOAD_V(va, 0)
 
     // ---- QK^T: lane = key -------------------------------------------------------------------
     const int main_n = (n_keys / 4) * 4;
@@ -239,13 +256,6 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
     bool has = false;
     // narrow outputs (d_head 4 / 8) take MKL's plain k-ordered form even for one query row
     const int n_blocks = (kSeq || DH < 16) ? 0 : n_keys / 8;
-    float va[XVB], vb[XVB];
-#define CT2X_XLOAD_V(VR, T0)                                              \
-  _Pragma("unroll") for (int j = 0; j < XVB; ++j) {                       \
-    const int t_ = (T0) + j;                                              \
-    const float g_ = vc[min(t_, t_last) * kvs + cl];                      \
-    VR[j] = (has_new && t_ == pos) ? vnew : g_;                           \
-  }
 #define CT2X_XBLOCK(VR, J0, T0)                                                              \
   {                                                                                          \
     const v4f pa_ = *reinterpret_cast<const v4f*>(tp + (T0));                                \
@@ -268,7 +278,6 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
       }                                                                                      \
     }                                                                                        \
   }
-    CT2X_XLOAD_V(va, 0)
     for (int t0 = 0; t0 < n_keys; t0 += 2 * XVB) {
       CT2X_XLOAD_V(vb, t0 + XVB)
       CT2X_XBLOCK(va, 0, t0)
@@ -424,15 +433,10 @@ bool attention_exact_decode_applicable(const AttnDecodeParams& p, bool fused_qua
 }
 
 template <int DH>
-static void launch_x(const AttnXArgs& a, bool seq, size_t lds, hipStream_t stream) {
+static void launch_x(const AttnXArgs& a, size_t lds, hipStream_t stream) {
   const unsigned grid = static_cast<unsigned>(a.p.rows * a.wg_per_row);
-  if (seq) {
-    ensure_lds(reinterpret_cast<const void*>(attn_x_decode_kernel<DH, true>), lds);
-    hipLaunchKernelGGL((attn_x_decode_kernel<DH, true>), dim3(grid), dim3(a.teams * 64), lds, stream, a);
-  } else {
-    ensure_lds(reinterpret_cast<const void*>(attn_x_decode_kernel<DH, false>), lds);
-    hipLaunchKernelGGL((attn_x_decode_kernel<DH, false>), dim3(grid), dim3(a.teams * 64), lds, stream, a);
-  }
+  ensure_lds(reinterpret_cast<const void*>(attn_x_decode_kernel<DH>), lds);
+  hipLaunchKernelGGL((attn_x_decode_kernel<DH>), dim3(grid), dim3(a.teams * 64), lds, stream, a);
 }
 
 void launch_attention_exact_decode(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
@@ -453,13 +457,13 @@ void launch_attention_exact_decode(const AttnDecodeParams& p, int quant_mode, in
   const size_t lds = (static_cast<size_t>(a.teams) * a.wave_floats + 16) * sizeof(float);
   // Several query rows on one cache row = the m dimension of the reference's MatMul: MKL's GEMM
   // path (k-ordered) instead of its one-row path.
-  const bool seq = p.kv_group > 1;
+  a.seq = p.kv_group > 1 ? 1 : 0;
   switch (p.dhead) {
-    case 4: launch_x<4>(a, seq, lds, stream); break;
-    case 8: launch_x<8>(a, seq, lds, stream); break;
-    case 16: launch_x<16>(a, seq, lds, stream); break;
-    case 32: launch_x<32>(a, seq, lds, stream); break;
-    default: launch_x<64>(a, seq, lds, stream); break;
+    case 4: launch_x<4>(a, lds, stream); break;
+    case 8: launch_x<8>(a, lds, stream); break;
+    case 16: launch_x<16>(a, lds, stream); break;
+    case 32: launch_x<32>(a, lds, stream); break;
+    default: launch_x<64>(a, lds, stream); break;
   }
 }
 

@@ -64,21 +64,41 @@ __device__ __forceinline__ bool forced_by_prefix(const SamplePrefix& pf, const S
 // (cpu::softmax<AVX2> log arm, src/cpu/kernels.cc:430-451; oracle orc_softmax): exp256_ps of
 // x - max for the vector body, libm expf for the scalar tail (vocab % 8 elements - vocabularies
 // here are padded to multiples of 8 or 16, where the tail is empty and the result exact), eight
-// strided partial sums + reduce_m256 + tail. The exps are parked in `park` (a scratch row in
-// global memory) because the ordered sum walks them front to back from one wave. All threads
-// of the block call; every thread receives the sum. scratch: one __shared__ float.
+// strided partial sums + reduce_m256 + tail. Each partial sum is a dependent chain of vocab / 8
+// additions (4000 for a 32000-word vocabulary: ~8 us at one add per ~4 cycles - the price of the
+// reference's order); what must stay off the chain is memory latency, so the exps are parked
+// TRANSPOSED in LDS - chain l owns the contiguous run e[l], e[l + 8], ... - and walked with
+// hand-pipelined 16-byte reads. Rows too long for LDS park in global memory (`park`) and walk it
+// with ordered_sum8 (slow, exact). All threads of the block call; every thread receives the sum.
 __device__ __forceinline__ float ordered_row_exp_sum(const float* __restrict__ x, int64_t vocab,
                                                      int masked, float m, float* __restrict__ park,
-                                                     float* scratch) {
+                                                     float* lds, int chain_pad, float* scratch) {
   const int64_t vsize = vocab > 8 ? vocab - vocab % 8 : 0;
+  if (lds == nullptr) {
+    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
+      const float v = ((j == masked) ? -FLT_MAX : x[j]) - m;
+      park[j] = (j < vsize) ? exp_avx2(v) : expf(v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const float s = ordered_sum8(park, static_cast<int>(vocab));
+      if (threadIdx.x == 0) *scratch = s;
+    }
+    __syncthreads();
+    return *scratch;
+  }
+  float* tail = lds + 8 * chain_pad;
   for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
     const float v = ((j == masked) ? -FLT_MAX : x[j]) - m;
-    park[j] = (j < vsize) ? exp_avx2(v) : expf(v);
+    if (j < vsize)
+      lds[(j & 7) * chain_pad + (j >> 3)] = exp_avx2(v);
+    else
+      tail[j - vsize] = expf(v);
   }
   __syncthreads();
   if (threadIdx.x < 64) {
-    const float s = ordered_sum8(park, static_cast<int>(vocab));
-    if (threadIdx.x == 0) *scratch = s;
+    const float acc = ordered_chain_sum_lds(lds, chain_pad, vsize, vocab);
+    if (threadIdx.x == 0) *scratch = acc;
   }
   __syncthreads();
   return *scratch;
@@ -86,7 +106,7 @@ __device__ __forceinline__ float ordered_row_exp_sum(const float* __restrict__ x
 
 __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t vocab,
                                      int32_t disable_id, int32_t min_length, bool with_scores,
-                                     float* __restrict__ exp_scratch,
+                                     float* __restrict__ exp_scratch, int chain_pad,
                                      SamplePrefix pf, StepAdvance adv,
                                      const int32_t* step_ptr, int32_t* __restrict__ next_ids,
                                      int32_t* __restrict__ hist_ids,
@@ -171,7 +191,9 @@ __global__ void greedy_sample_kernel(const float* __restrict__ logits, int64_t v
   if (with_scores) {
     // LogSoftMax (src/cpu/kernels.cc:441-451): y = x + (-max - log(sum exp(x - max))), with the
     // reference's exp polynomial, sum order and libm logf
-    const float s = ordered_row_exp_sum(x, vocab, masked, m, exp_scratch + row * vocab, scratch);
+    extern __shared__ __attribute__((aligned(16))) float exp_lds[];
+    const float s = ordered_row_exp_sum(x, vocab, masked, m, exp_scratch + row * vocab,
+                                        chain_pad > 0 ? exp_lds : nullptr, chain_pad, scratch);
     score = m + (-m - logf_glibc(s));
   }
   if (threadIdx.x == 0) {
@@ -195,9 +217,12 @@ void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int3
                         prefix_extends_min ? 1 : 0};
   const StepAdvance adv{advance_step_ptr, done_counter};
   CT2X_CHECK(!with_scores || exp_scratch != nullptr, "greedy sampler: scores need a scratch row buffer");
-  hipLaunchKernelGGL(greedy_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
-                     disable_id, min_length, with_scores, exp_scratch, pf, adv, step_ptr, next_ids,
-                     hist_ids, hist_scores);
+  const ExpSumLayout el = with_scores ? exp_sum_layout(vocab) : ExpSumLayout{0, 0};
+  const size_t lds = static_cast<size_t>(el.lds_floats) * sizeof(float);
+  allow_big_lds(reinterpret_cast<const void*>(greedy_sample_kernel), lds);
+  hipLaunchKernelGGL(greedy_sample_kernel, dim3(rows), dim3(block), lds, stream, logits, vocab,
+                     disable_id, min_length, with_scores, exp_scratch, el.chain_pad, pf, adv, step_ptr,
+                     next_ids, hist_ids, hist_scores);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,7 +589,8 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
                                      int32_t disable_id, int32_t min_length,
                                      const int32_t* __restrict__ step_ptr,
                                      const int32_t* __restrict__ extra_min, int32_t beam,
-                                     float* __restrict__ y) {
+                                     int chain_pad, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float exp_lds[];
   __shared__ float scratch[16];
   const int64_t row = blockIdx.x;
   const int step = *step_ptr;
@@ -580,7 +606,8 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
   m = block_max(m, scratch);
   // the reference's LogSoftMax bit for bit: exp polynomial, sum order, libm logf (the output row
   // parks the exps until the sum is known)
-  const float s = ordered_row_exp_sum(x, vocab, masked, m, yr, scratch);
+  const float s = ordered_row_exp_sum(x, vocab, masked, m, yr, chain_pad > 0 ? exp_lds : nullptr,
+                                      chain_pad, scratch);
   const float c = -m - logf_glibc(s);
   const float b = beam_scores ? beam_scores[row] : 0.f;
   for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
@@ -597,9 +624,12 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
-  hipLaunchKernelGGL(beam_logprobs_kernel, dim3(rows), dim3(block), 0, stream, logits,
+  const ExpSumLayout el = exp_sum_layout(vocab);
+  const size_t lds = static_cast<size_t>(el.lds_floats) * sizeof(float);
+  allow_big_lds(reinterpret_cast<const void*>(beam_logprobs_kernel), lds);
+  hipLaunchKernelGGL(beam_logprobs_kernel, dim3(rows), dim3(block), lds, stream, logits,
                      beam_scores, vocab, disable_id, min_length, step_ptr, extra_min_per_batch,
-                     beam > 0 ? beam : 1, y);
+                     beam > 0 ? beam : 1, el.chain_pad, y);
 }
 
 // ---------------------------------------------------------------------------------------------

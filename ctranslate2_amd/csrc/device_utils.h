@@ -290,4 +290,89 @@ __device__ __forceinline__ float ordered_sum8(const float* e, int size) {
   return acc;
 }
 
+// ---- ordered sums over long rows (vocabulary LogSoftMax) ------------------------------------------
+// vectorized_reduce_all<AVX2> is eight strided partial sums, each a dependent chain of size / 8
+// additions (4000 for a 32000-word vocabulary: ~8 us at one add per ~4 cycles - the price of the
+// reference's order). What must stay off the chain is memory latency: the addends are parked
+// TRANSPOSED in LDS - chain l owns the contiguous run e[l], e[l + 8], ... - and walked with
+// hand-pipelined 16-byte reads (fenced with sched_barrier, see ordered_row_sums in rowops.hip).
+struct ExpSumLayout {
+  int lds_floats;  // 0: the row does not fit, use the global park row
+  int chain_pad;   // floats per chain in LDS (a multiple of 4, = 4 mod 8: conflict-free 8-lane reads)
+};
+
+inline ExpSumLayout exp_sum_layout(int64_t vocab) {
+  ExpSumLayout l{0, 0};
+  const int64_t chain = vocab > 8 ? vocab / 8 : 0;
+  int64_t pad = (chain + 3) / 4 * 4;
+  while (pad % 8 != 4) pad += 4;
+  const int64_t floats = 8 * pad + 8 + 128;  // chains + tail + read-ahead slack (3 batches of 8 x 4)
+  if (chain > 0 && floats * 4 <= 152 * 1024) {
+    l.lds_floats = static_cast<int>(floats);
+    l.chain_pad = static_cast<int>(pad);
+  }
+  return l;
+}
+
+
+// > 64 KiB of dynamic LDS has to be opted into per kernel.
+inline void allow_big_lds(const void* fn, size_t bytes) {
+  if (bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+// Where element j < vsize of the row is parked.
+__device__ __forceinline__ int chain_slot(int64_t j, int chain_pad) {
+  return static_cast<int>((j & 7) * chain_pad + (j >> 3));
+}
+
+// Sum in the reference's order of a row parked by chain_slot (elements [0, vsize), vsize a
+// multiple of 8) followed by the scalar tail lds[8 * chain_pad + t] = e[vsize + t]. Called by the
+// 64 lanes of ONE wave after a barrier; every lane returns the sum.
+__device__ __forceinline__ float ordered_chain_sum_lds(const float* lds, int chain_pad, int64_t vsize,
+                                                       int64_t size) {
+  const float* tail = lds + 8 * chain_pad;
+  float acc = 0.f;
+  {
+    const int n = static_cast<int>(vsize / 8);  // elements per chain
+    const int n4 = (n + 3) / 4;
+    const v4f* c4 = reinterpret_cast<const v4f*>(lds + (threadIdx.x & 7) * chain_pad);
+    constexpr int B = 8;
+    v4f a[B], b[B];
+#define CT2X_CH_LOAD(A, BASE) _Pragma("unroll") for (int u = 0; u < B; ++u) A[u] = c4[(BASE) + u];
+#define CT2X_CH_EAT(A, BASE)                                                      \
+  _Pragma("unroll") for (int u = 0; u < B; ++u) {                                 \
+    const int e_ = 4 * ((BASE) + u);                                              \
+    if (e_ + 3 < n) {                                                             \
+      acc = acc + A[u].x;                                                         \
+      acc = acc + A[u].y;                                                         \
+      acc = acc + A[u].z;                                                         \
+      acc = acc + A[u].w;                                                         \
+    } else {                                                                      \
+      if (e_ < n) acc = acc + A[u].x;                                             \
+      if (e_ + 1 < n) acc = acc + A[u].y;                                         \
+      if (e_ + 2 < n) acc = acc + A[u].z;                                         \
+    }                                                                             \
+  }
+    CT2X_CH_LOAD(a, 0)
+    for (int base = 0; base < n4; base += 2 * B) {
+      CT2X_CH_LOAD(b, base + B)
+      __builtin_amdgcn_sched_barrier(0);
+      CT2X_CH_EAT(a, base)
+      __builtin_amdgcn_sched_barrier(0);
+      CT2X_CH_LOAD(a, base + 2 * B)
+      __builtin_amdgcn_sched_barrier(0);
+      CT2X_CH_EAT(b, base + B)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef CT2X_CH_LOAD
+#undef CT2X_CH_EAT
+  }
+  acc = acc + __shfl_xor(acc, 4, 64);
+  acc = acc + __shfl_xor(acc, 2, 64);
+  acc = acc + __shfl_xor(acc, 1, 64);
+  for (int64_t j = vsize; j < size; ++j) acc = acc + tail[j - vsize];
+  return acc;
+}
+
 }  // namespace ct2x

@@ -1533,6 +1533,10 @@ void Engine::launch_step(DecodeState& st) {
       p.t_max = st.s_max;
       p.scale = a.queries_scale;
       p.out = st.ctx;
+      if (st.beam > 1) {  // first beam-search step: the CPU reference has not expanded the batch yet
+        p.one_row_step_ptr = st.d_step;
+        p.one_row_step = st.prefix_first_step;
+      }
       const double attn_bytes =
           double(st.batch) * st.s_max * 2 * kvdim * 4 + double(rows) * a.heads * a.dhead * 8;
       const double attn_ops = double(rows) * a.heads * st.s_max * a.dhead * 4;

@@ -175,6 +175,11 @@ struct AttnDecodeParams {
   // attention_decode2 split mode only: per-row absmax of the context, max-combined into
   // row_amax_out[rows] (zero beforehand); attention_decode_emits_row_amax tells whether it will.
   float* row_amax_out = nullptr;
+  // attention_exact only: while *one_row_step_ptr == one_row_step the rows of a kv group are
+  // computed with the one-query-row forms of the reference's MatMul (first step of a CPU beam
+  // search: the batch is not expanded yet, src/decoding.cc:453-454).
+  const int32_t* one_row_step_ptr = nullptr;
+  int32_t one_row_step = 0;
 };
 
 bool attention_decode_emits_row_amax(const AttnDecodeParams& p);

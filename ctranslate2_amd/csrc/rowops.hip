@@ -267,23 +267,55 @@ void launch_reduce_ranks(const void* const* src, int world, int64_t n, bool is_i
 // to back with broadcast ds_read_b128 (two independent dependency chains, ~2 VALU issues per
 // element), then each lane normalises the elements it holds in registers.
 // ---------------------------------------------------------------------------------------
+// The chain is ~2 dependent VALU issues per element; what has to be kept off it is the LDS
+// latency. The reads (every lane the same address: broadcasts) are software-pipelined by hand in
+// two register batches of 16 x 16 bytes, fenced with sched_barrier: left to itself the compiler
+// keeps only four reads in flight and then waits on every single one (measured: 19 cycles per
+// element instead of ~4).
 __device__ __forceinline__ void ordered_row_sums(const float* row, int n4, float& sum, float& sumsq) {
   const v4f* r4 = reinterpret_cast<const v4f*>(row);
+  constexpr int B = 16;
   float s = 0.f, ss = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < n4; ++i) {
-    const v4f v = r4[i];
-    ss = fmaf(v.x, v.x, ss);
-    s = s + v.x;
-    ss = fmaf(v.y, v.y, ss);
-    s = s + v.y;
-    ss = fmaf(v.z, v.z, ss);
-    s = s + v.z;
-    ss = fmaf(v.w, v.w, ss);
-    s = s + v.w;
+  v4f a[B], b[B];
+  // (the row buffer is over-allocated by the caller - norm_row_lds_bytes - so that the batches
+  // past the end read in-bounds LDS; what they read is never consumed)
+#define CT2X_ROW_LOAD(A, BASE)                                             \
+  _Pragma("unroll") for (int u = 0; u < B; ++u) A[u] = r4[(BASE) + u];
+#define CT2X_ROW_EAT(A, BASE)                                              \
+  _Pragma("unroll") for (int u = 0; u < B; ++u) {                          \
+    if ((BASE) + u < n4) {                                                 \
+      ss = fmaf(A[u].x, A[u].x, ss);                                       \
+      s = s + A[u].x;                                                      \
+      ss = fmaf(A[u].y, A[u].y, ss);                                       \
+      s = s + A[u].y;                                                      \
+      ss = fmaf(A[u].z, A[u].z, ss);                                       \
+      s = s + A[u].z;                                                      \
+      ss = fmaf(A[u].w, A[u].w, ss);                                       \
+      s = s + A[u].w;                                                      \
+    }                                                                      \
   }
+  CT2X_ROW_LOAD(a, 0)
+  for (int base = 0; base < n4; base += 2 * B) {
+    CT2X_ROW_LOAD(b, base + B)
+    __builtin_amdgcn_sched_barrier(0);
+    CT2X_ROW_EAT(a, base)
+    __builtin_amdgcn_sched_barrier(0);
+    CT2X_ROW_LOAD(a, base + 2 * B)
+    __builtin_amdgcn_sched_barrier(0);
+    CT2X_ROW_EAT(b, base + B)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef CT2X_ROW_LOAD
+#undef CT2X_ROW_EAT
   sum = s;
   sumsq = ss;
+}
+
+// Dynamic LDS of norm_vec_kernel: the row, rounded up to whole double batches of the pipelined
+// walk plus one batch of read-ahead (16-byte units).
+static inline size_t norm_row_lds_bytes(int64_t depth) {
+  const int64_t n4 = depth / 4;
+  return static_cast<size_t>(((n4 + 31) / 32) * 32 + 16) * 16;
 }
 
 struct NormStats {
@@ -441,7 +473,7 @@ void launch_norm(const float* x, const float* gamma, const float* beta, int64_t 
     int threads = 64;
     while (threads * kNormChunks * 4 < depth || (threads < 256 && threads * 4 < depth)) threads <<= 1;
     if (threads > 256) threads = 256;
-    hipLaunchKernelGGL(norm_vec_kernel, dim3(rows), dim3(threads), depth * sizeof(float), stream,
+    hipLaunchKernelGGL(norm_vec_kernel, dim3(rows), dim3(threads), norm_row_lds_bytes(depth), stream,
                        x, gamma, beta, depth, eps, rms_use_residual, quant_mode, y, q, scales);
     return;
   }
@@ -463,7 +495,8 @@ void launch_norm(const float* x, const float* gamma, const float* beta, int64_t 
 // ---------------------------------------------------------------------------------------
 __global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengths,
                                const float* __restrict__ row_bias, int64_t depth, bool log,
-                               float* y) {  // x == y is allowed (ops::SoftMax runs in place)
+                               int chain_pad, float* y) {  // x == y is allowed (ops::SoftMax runs in place)
+  extern __shared__ __attribute__((aligned(16))) float exp_lds[];
   __shared__ float scratch[16];
   const int64_t row = blockIdx.x;
   const float* xr = x + row * depth;
@@ -479,11 +512,38 @@ __global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengt
   float m = -FLT_MAX;
   for (int64_t j = threadIdx.x; j < size; j += blockDim.x) m = fmaxf(m, xr[j]);
   m = block_max(m, scratch);
-  const int64_t vsize = (log && size > 8) ? size - size % 8 : (log ? 0 : size);
+  // body / tail split of the reference: the log form sends the last size % 8 elements (a whole
+  // row of <= 8) through libm expf, the plain form sends everything through the polynomial
+  const int64_t poly_end = log ? (size > 8 ? size - size % 8 : 0) : size;
+  const int64_t vsize = size > 8 ? size - size % 8 : 0;  // part summed by the eight chains
   float s;
-  if (log && x == y) {
-    // in place: the inputs are still needed for the result, so the eight chain lanes of wave 0
-    // evaluate their own exps (slow; the engine never takes this arm)
+  if (chain_pad > 0) {
+    // exps parked transposed in LDS for the ordered sum (and written to y for the plain form)
+    float* tail = exp_lds + 8 * chain_pad;
+    for (int64_t j = threadIdx.x; j < size; j += blockDim.x) {
+      const float e = (j < poly_end) ? exp_avx2(xr[j] - m) : expf(xr[j] - m);
+      if (j < vsize)
+        exp_lds[chain_slot(j, chain_pad)] = e;
+      else
+        tail[j - vsize] = e;
+      if (!log) yr[j] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t;
+      if (size <= 8) {  // front to back
+        t = 0.f;
+        for (int64_t j = 0; j < size; ++j) t = t + tail[j];
+      } else {
+        t = ordered_chain_sum_lds(exp_lds, chain_pad, vsize, size);
+      }
+      if (threadIdx.x == 0) scratch[0] = t;
+    }
+    __syncthreads();
+    s = scratch[0];
+  } else if (log && x == y) {
+    // in place and too long for LDS: the inputs are still needed for the result, so the eight
+    // chain lanes of wave 0 evaluate their own exps (slow; the engine never takes this arm)
     if (threadIdx.x < 64) {
       const int l = threadIdx.x & 7;
       float acc = 0.f;
@@ -502,7 +562,7 @@ __global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengt
     s = scratch[0];
   } else {
     for (int64_t j = threadIdx.x; j < size; j += blockDim.x)
-      yr[j] = (j < vsize) ? exp_avx2(xr[j] - m) : expf(xr[j] - m);
+      yr[j] = (j < poly_end) ? exp_avx2(xr[j] - m) : expf(xr[j] - m);
     __syncthreads();  // the row of exps is visible to wave 0 (same CU)
     if (threadIdx.x < 64) {
       const float t = ordered_sum8(yr, static_cast<int>(size));
@@ -524,18 +584,25 @@ __global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengt
   }
 }
 
+static void launch_softmax_impl(const float* x, const int32_t* lengths, const float* row_bias,
+                                int64_t rows, int64_t depth, bool log, float* y, hipStream_t stream) {
+  const ExpSumLayout el = exp_sum_layout(depth);
+  const size_t lds = static_cast<size_t>(el.lds_floats) * sizeof(float);
+  allow_big_lds(reinterpret_cast<const void*>(softmax_kernel), lds);
+  hipLaunchKernelGGL(softmax_kernel, dim3(rows), dim3(pick_block(depth)), lds, stream, x, lengths,
+                     row_bias, depth, log, el.chain_pad, y);
+}
+
 void launch_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth,
                     bool log, float* y, hipStream_t stream) {
   if (rows == 0 || depth == 0) return;
-  hipLaunchKernelGGL(softmax_kernel, dim3(rows), dim3(pick_block(depth)), 0, stream, x, lengths,
-                     (const float*)nullptr, depth, log, y);
+  launch_softmax_impl(x, lengths, nullptr, rows, depth, log, y, stream);
 }
 
 void launch_log_softmax_bias(const float* x, const float* row_bias, int64_t rows, int64_t depth,
                              float* y, hipStream_t stream) {
   if (rows == 0 || depth == 0) return;
-  hipLaunchKernelGGL(softmax_kernel, dim3(rows), dim3(pick_block(depth)), 0, stream, x,
-                     (const int32_t*)nullptr, row_bias, depth, true, y);
+  launch_softmax_impl(x, nullptr, row_bias, rows, depth, true, y, stream);
 }
 
 // ---------------------------------------------------------------------------------------
