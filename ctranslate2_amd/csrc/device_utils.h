@@ -317,8 +317,9 @@ inline ExpSumLayout exp_sum_layout(int64_t vocab) {
 
 // > 64 KiB of dynamic LDS has to be opted into per kernel.
 inline void allow_big_lds(const void* fn, size_t bytes) {
-  if (bytes > 64 * 1024)
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // (the limit covers static + dynamic LDS: ask for what the launch uses, not for the maximum)
+  if (bytes > 48 * 1024)
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
 }
 
 // Where element j < vsize of the row is parked.

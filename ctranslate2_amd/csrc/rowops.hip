@@ -255,71 +255,65 @@ void launch_reduce_ranks(const void* const* src, int world, int64_t n, bool is_i
 
 // ---------------------------------------------------------------------------------------
 // LayerNorm / RMSNorm (+ optional fused int8 Quantize of the normalised row), BIT-EXACT with the
-// reference CPU kernels as compiled (src/cpu/kernels.cc:461-496 and :543-573, a CT2_FFAST_MATH
-// region that GCC -O2 leaves scalar; oracle/ct2_oracle.c orc_layer_norm / orc_rms_norm give the
-// decoded arithmetic and are pinned against the reference library):
-//   inv_n = 1/n;  sum += x and sumsq = fma(x, x, sumsq) STRICTLY IN INDEX ORDER;
+// reference CPU kernels as compiled (src/cpu/kernels.cc:461-496 and :543-573: a CT2_FFAST_MATH
+// region that GCC -O3 - the reference's Release build, CMakeLists.txt:59-61 - vectorises for
+// AVX2; oracle/ct2_oracle.c row_stats / orc_layer_norm / orc_rms_norm give the decoded
+// arithmetic and are pinned against the reference library):
+//   statistics: eight lane accumulators over the leading depth & ~7 elements (sum += x,
+//     sumsq = fma(x, x, sumsq)), reduced lane l + l^4, then ^2, then ^1; a remainder of >= 4
+//     elements goes four at once (rounded squares, (q1+q3) + (q0+q2)), then <= 3 scalar steps;
 //   LayerNorm: mean = sum*inv_n; var = max(fma(sumsq, inv_n, -(mean*mean)), 0);
 //              rstd = 1/sqrt(var+eps); y = fma(x - mean, rstd*gamma, beta)
-//   RMSNorm:   inv = 1/sqrt(fma(sumsq, inv_n, eps)); y = (inv*x)*gamma  or  (inv*x)*(gamma+1)
+//   RMSNorm:   inv = 1/sqrt(fma(sumsq, inv_n, eps)); x*inv*g re-associated per loop version:
+//              (x*g)*inv [gamma] / (inv*x)*g [gamma + 1] in the 8-wide body and the scalar tail,
+//              x*(inv*g) / (x*g)*inv in the 4-wide remainder.
 // The int8 decoder re-quantises this output: a last-ulp difference flips int8 activations, so the
-// sequential sums are reproduced as they are: the row is staged in LDS, every wave walks it front
-// to back with broadcast ds_read_b128 (two independent dependency chains, ~2 VALU issues per
-// element), then each lane normalises the elements it holds in registers.
+// order is reproduced as it is. The row is staged in LDS; lanes 0..7 of every wave walk their
+// strided chains (depth / 8 dependent steps: ~64 x 13 cycles at depth 512 - a dependent fp32 add
+// costs ~10 cycles on this chip, which is why the eight-lane order is 8x cheaper here than a
+// scalar one), then each lane normalises the elements it holds in registers.
 // ---------------------------------------------------------------------------------------
-// The chain is ~2 dependent VALU issues per element; what has to be kept off it is the LDS
-// latency. The reads (every lane the same address: broadcasts) are software-pipelined by hand in
-// two register batches of 16 x 16 bytes, fenced with sched_barrier: left to itself the compiler
-// keeps only four reads in flight and then waits on every single one (measured: 19 cycles per
-// element instead of ~4).
-__device__ __forceinline__ void ordered_row_sums(const float* row, int n4, float& sum, float& sumsq) {
-  const v4f* r4 = reinterpret_cast<const v4f*>(row);
-  constexpr int B = 16;
+// `row`: the depth floats of the row in LDS (linear). Every lane of the calling wave returns the
+// statistics.
+__device__ __forceinline__ void ordered_row_stats(const float* row, int64_t depth, float& sum,
+                                                  float& sumsq) {
+  const int l = threadIdx.x & 7;
+  const int vsize = static_cast<int>(depth >= 8 ? depth - depth % 8 : 0);
   float s = 0.f, ss = 0.f;
-  v4f a[B], b[B];
-  // (the row buffer is over-allocated by the caller - norm_row_lds_bytes - so that the batches
-  // past the end read in-bounds LDS; what they read is never consumed)
-#define CT2X_ROW_LOAD(A, BASE)                                             \
-  _Pragma("unroll") for (int u = 0; u < B; ++u) A[u] = r4[(BASE) + u];
-#define CT2X_ROW_EAT(A, BASE)                                              \
-  _Pragma("unroll") for (int u = 0; u < B; ++u) {                          \
-    if ((BASE) + u < n4) {                                                 \
-      ss = fmaf(A[u].x, A[u].x, ss);                                       \
-      s = s + A[u].x;                                                      \
-      ss = fmaf(A[u].y, A[u].y, ss);                                       \
-      s = s + A[u].y;                                                      \
-      ss = fmaf(A[u].z, A[u].z, ss);                                       \
-      s = s + A[u].z;                                                      \
-      ss = fmaf(A[u].w, A[u].w, ss);                                       \
-      s = s + A[u].w;                                                      \
-    }                                                                      \
+  if (vsize > 0) {
+#pragma unroll 8
+    for (int j = l; j < vsize; j += 8) {
+      const float v = row[j];
+      ss = fmaf(v, v, ss);
+      s = s + v;
+    }
+    ss = __shfl_xor(ss, 4, 64) + ss;
+    s = __shfl_xor(s, 4, 64) + s;
+    ss = __shfl_xor(ss, 2, 64) + ss;
+    s = __shfl_xor(s, 2, 64) + s;
+    ss = __shfl_xor(ss, 1, 64) + ss;
+    s = __shfl_xor(s, 1, 64) + s;
   }
-  CT2X_ROW_LOAD(a, 0)
-  for (int base = 0; base < n4; base += 2 * B) {
-    CT2X_ROW_LOAD(b, base + B)
-    __builtin_amdgcn_sched_barrier(0);
-    CT2X_ROW_EAT(a, base)
-    __builtin_amdgcn_sched_barrier(0);
-    CT2X_ROW_LOAD(a, base + 2 * B)
-    __builtin_amdgcn_sched_barrier(0);
-    CT2X_ROW_EAT(b, base + B)
-    __builtin_amdgcn_sched_barrier(0);
+  int j = vsize;
+  if (depth - j >= 4) {
+    const float x0 = row[j], x1 = row[j + 1], x2 = row[j + 2], x3 = row[j + 3];
+    const float q0 = x0 * x0, q1 = x1 * x1, q2 = x2 * x2, q3 = x3 * x3;
+    ss = ss + ((q3 + q1) + (q2 + q0));
+    s = s + ((x3 + x1) + (x2 + x0));
+    j += 4;
   }
-#undef CT2X_ROW_LOAD
-#undef CT2X_ROW_EAT
+  for (; j < depth; ++j) {
+    const float v = row[j];
+    ss = fmaf(v, v, ss);
+    s = s + v;
+  }
   sum = s;
   sumsq = ss;
 }
 
-// Dynamic LDS of norm_vec_kernel: the row, rounded up to whole double batches of the pipelined
-// walk plus one batch of read-ahead (16-byte units).
-static inline size_t norm_row_lds_bytes(int64_t depth) {
-  const int64_t n4 = depth / 4;
-  return static_cast<size_t>(((n4 + 31) / 32) * 32 + 16) * 16;
-}
-
 struct NormStats {
-  float mean, mul;  // LayerNorm: y = fma(x - mean, mul*gamma, beta); RMSNorm: y = (mul*x)*g
+  float mean, mul;  // LayerNorm: y = fma(x - mean, mul*gamma, beta); RMSNorm: see norm_apply
+  int four_begin, four_end;  // columns served by the 4-wide remainder version of the loop
 };
 
 __device__ __forceinline__ NormStats norm_stats(float sum, float sumsq, int64_t depth, float eps,
@@ -336,14 +330,21 @@ __device__ __forceinline__ NormStats norm_stats(float sum, float sumsq, int64_t 
     st.mean = 0.f;
     st.mul = 1.f / sqrtf(fmaf(sumsq, inv_n, eps));
   }
+  const int vsize = static_cast<int>(depth >= 8 ? depth - depth % 8 : 0);
+  st.four_begin = vsize;
+  st.four_end = (depth - vsize >= 4) ? vsize + 4 : vsize;
   return st;
 }
 
 __device__ __forceinline__ float norm_apply(float x, float g, float b, const NormStats& st,
-                                            bool layer_norm, bool rms_use_residual) {
+                                            bool layer_norm, bool rms_use_residual, int col) {
   if (layer_norm) return fmaf(x - st.mean, st.mul * g, b);
-  const float t = st.mul * x;
-  return rms_use_residual ? t * (g + 1.f) : t * g;
+  const bool four = col >= st.four_begin && col < st.four_end;
+  if (rms_use_residual) {
+    const float g1 = g + 1.f;
+    return four ? (x * g1) * st.mul : (st.mul * x) * g1;
+  }
+  return four ? x * (st.mul * g) : (x * g) * st.mul;
 }
 
 __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -357,19 +358,15 @@ __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict
   const float* xr = x + row * depth;
   for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) row_buf[i] = xr[i];
   __syncthreads();
-  // every thread walks the row in index order (same addresses: LDS broadcasts)
-  float sum = 0.f, sumsq = 0.f;
-  for (int64_t i = 0; i < depth; ++i) {
-    const float v = row_buf[i];
-    sumsq = fmaf(v, v, sumsq);
-    sum = sum + v;
-  }
+  float sum, sumsq;
+  ordered_row_stats(row_buf, depth, sum, sumsq);  // every wave, redundantly
   const bool ln = beta != nullptr;
   const NormStats st = norm_stats(sum, sumsq, depth, eps, ln);
   __syncthreads();  // everyone has read the row before it is overwritten
   float amax = 0.f;
   for (int64_t i = threadIdx.x; i < depth; i += blockDim.x) {
-    const float v = norm_apply(row_buf[i], gamma[i], ln ? beta[i] : 0.f, st, ln, rms_use_residual);
+    const float v = norm_apply(row_buf[i], gamma[i], ln ? beta[i] : 0.f, st, ln, rms_use_residual,
+                               static_cast<int>(i));
     row_buf[i] = v;
     amax = fmaxf(amax, fabsf(v));
   }
@@ -391,7 +388,7 @@ __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict
 
 // Register-resident variant for the decoder shapes (depth % 4 == 0, depth <= 4 * 256 * kNormChunks):
 // every lane keeps its float4 chunks in VGPRs (and drops a copy into the LDS row for the ordered
-// sums); all loads are issued before the first use.
+// statistics); all loads are issued before the first use.
 constexpr int kNormChunks = 4;
 
 __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -423,16 +420,17 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
   }
   __syncthreads();
   float sum, sumsq;
-  ordered_row_sums(row_buf, n4, sum, sumsq);
+  ordered_row_stats(row_buf, depth, sum, sumsq);
   const bool ln = beta != nullptr;
   const NormStats st = norm_stats(sum, sumsq, depth, eps, ln);
   float amax = 0.f;
 #pragma unroll
   for (int u = 0; u < kNormChunks; ++u) {
-    v[u].x = norm_apply(v[u].x, gv[u].x, bv[u].x, st, ln, rms_use_residual);
-    v[u].y = norm_apply(v[u].y, gv[u].y, bv[u].y, st, ln, rms_use_residual);
-    v[u].z = norm_apply(v[u].z, gv[u].z, bv[u].z, st, ln, rms_use_residual);
-    v[u].w = norm_apply(v[u].w, gv[u].w, bv[u].w, st, ln, rms_use_residual);
+    const int c = 4 * (threadIdx.x + u * blockDim.x);
+    v[u].x = norm_apply(v[u].x, gv[u].x, bv[u].x, st, ln, rms_use_residual, c);
+    v[u].y = norm_apply(v[u].y, gv[u].y, bv[u].y, st, ln, rms_use_residual, c + 1);
+    v[u].z = norm_apply(v[u].z, gv[u].z, bv[u].z, st, ln, rms_use_residual, c + 2);
+    v[u].w = norm_apply(v[u].w, gv[u].w, bv[u].w, st, ln, rms_use_residual, c + 3);
   }
 #pragma unroll
   for (int u = 0; u < kNormChunks; ++u) {
@@ -473,7 +471,7 @@ void launch_norm(const float* x, const float* gamma, const float* beta, int64_t 
     int threads = 64;
     while (threads * kNormChunks * 4 < depth || (threads < 256 && threads * 4 < depth)) threads <<= 1;
     if (threads > 256) threads = 256;
-    hipLaunchKernelGGL(norm_vec_kernel, dim3(rows), dim3(threads), norm_row_lds_bytes(depth), stream,
+    hipLaunchKernelGGL(norm_vec_kernel, dim3(rows), dim3(threads), depth * sizeof(float), stream,
                        x, gamma, beta, depth, eps, rms_use_residual, quant_mode, y, q, scales);
     return;
   }

@@ -140,26 +140,71 @@ void orc_gemm_f32(const float* a, const float* b, int64_t m, int64_t n, int64_t 
 
 /* ---------------------------------------------------------------------------------------------
  * Bit-exact restatements of the reference's fp32 row kernels AS COMPILED into oracle/_ref
- * (g++ -O2, -mavx2 -mfma, GCC's default -ffp-contract=fast; ISA picked at run time = AVX2,
+ * (g++ 11.4 -O3 = the reference's Release build type, CMakeLists.txt:59-61; -mavx2 -mfma, GCC's
+ * default -ffp-contract=fast; ISA picked at run time = AVX2,
  * src/cpu/cpu_isa.cc:45-78). Read from the disassembly of oracle/_ref/obj/cpu/kernels_avx2.o and
  * pinned bit for bit against oracle/_ref by tests/test_oracle.py::test_exact_*.
  * ------------------------------------------------------------------------------------------- */
 
-/* layer_norm (src/cpu/kernels.cc:461-496, a CT2_FFAST_MATH region, scalar at -O2):
- *   inv_n = 1/n; sum += x, sumsq = fma(x, x, sumsq) strictly in index order;
- *   mean = sum*inv_n; var = max(fma(sumsq, inv_n, -(mean*mean)), 0); rstd = 1/sqrt(var+eps);
- *   y = fma(x - mean, rstd*gamma, beta)           (fast-math re-association of (x-mean)*rstd*gamma) */
+/* reduce of an 8-lane accumulator as GCC emits it for a vectorised fast-math reduction
+ * (vextractf128 + vaddps, vmovhlps + vaddps, vshufps 0x55 + vaddps): lane l + lane l+4, then
+ * +2, then +1 - the same tree as reduce_m256. */
+static float hsum8v(const float* v) {
+  float h[4];
+  for (int l = 0; l < 4; ++l) h[l] = v[l + 4] + v[l];
+  const float u0 = h[2] + h[0], u1 = h[3] + h[1];
+  return u1 + u0;
+}
+
+/* Row statistics of layer_norm / rms_norm (src/cpu/kernels.cc:461-573, a CT2_FFAST_MATH region)
+ * as GCC 11 -O3 vectorises them for AVX2 (the reference builds Release = -O3,
+ * CMakeLists.txt:59-61): eight lane accumulators over the leading depth & ~7 elements
+ * (sum += x; sumsq = fma(x, x, sumsq)), the tree above, then the remainder: four elements at
+ * once when at least four are left (their squares are rounded products here, summed
+ * (q1 + q3) + (q0 + q2) and added to the running scalar), then up to three scalar steps
+ * (sumsq = fma(x, x, sumsq); sum += x). */
+static void row_stats(const float* x, int64_t depth, float* sum_out, float* sumsq_out) {
+  float sum = 0.f, sumsq = 0.f;
+  int64_t j = 0;
+  if (depth >= 8) {
+    float s8[8] = {0}, q8[8] = {0};
+    const int64_t vsize = depth - depth % 8;
+    for (; j < vsize; j += 8)
+      for (int l = 0; l < 8; ++l) {
+        q8[l] = fmaf(x[j + l], x[j + l], q8[l]);
+        s8[l] = s8[l] + x[j + l];
+      }
+    sumsq = hsum8v(q8);
+    sum = hsum8v(s8);
+  }
+  if (depth - j >= 4) {
+    float q[4];
+    for (int l = 0; l < 4; ++l) q[l] = x[j + l] * x[j + l];
+    sumsq = sumsq + ((q[3] + q[1]) + (q[2] + q[0]));
+    sum = sum + ((x[j + 3] + x[j + 1]) + (x[j + 2] + x[j]));
+    j += 4;
+  }
+  for (; j < depth; ++j) {
+    sumsq = fmaf(x[j], x[j], sumsq);
+    sum = sum + x[j];
+  }
+  *sum_out = sum;
+  *sumsq_out = sumsq;
+}
+
+/* layer_norm (src/cpu/kernels.cc:461-496):
+ *   inv_n = 1/n; mean = sum*inv_n; var = max(fma(sumsq, inv_n, -(mean*mean)), 0);
+ *   rstd = 1/sqrt(var+eps); y = fma(x - mean, rstd*gamma, beta)
+ * (fast-math re-association of (x-mean)*rstd*gamma; every code version of the loop - 8-wide,
+ * 4-wide, scalar - uses this form). */
 void orc_layer_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
                     int64_t depth, float eps, float* y) {
   const float inv_n = 1.f / (float)depth;
   for (int64_t i = 0; i < rows; ++i) {
     const float* xr = x + i * depth;
     float* yr = y + i * depth;
-    float sum = 0.f, sumsq = 0.f;
-    for (int64_t j = 0; j < depth; ++j) {
-      sumsq = fmaf(xr[j], xr[j], sumsq);
-      sum = sum + xr[j];
-    }
+    float sum, sumsq;
+    row_stats(xr, depth, &sum, &sumsq);
     const float mean = sum * inv_n;
     const float mm = mean * mean;
     float variance = fmaf(sumsq, inv_n, -mm);
@@ -169,20 +214,29 @@ void orc_layer_norm(const float* x, const float* gamma, const float* beta, int64
   }
 }
 
-/* rms_norm (src/cpu/kernels.cc:543-573, same region): sumsq = fma(x, x, sumsq) in order;
- * inv_rms = 1/sqrt(fma(sumsq, 1/n, eps)); y = (inv_rms*x)*gamma  or (inv_rms*x)*(gamma+1). */
+/* rms_norm (src/cpu/kernels.cc:543-573): inv_rms = 1/sqrt(fma(sumsq, 1/n, eps)); the product
+ * x * inv_rms * g is re-associated by fast-math differently in each code version of the loop:
+ *   gamma:      (x*g)*inv_rms  in the 8-wide body and the scalar tail,  x*(inv_rms*g) 4-wide
+ *   gamma + 1:  (inv_rms*x)*g  in the 8-wide body and the scalar tail,  (x*g)*inv_rms 4-wide. */
 void orc_rms_norm(const float* x, const float* gamma, int64_t rows, int64_t depth, float eps,
                   int use_residual, float* y) {
   const float inv_n = 1.f / (float)depth;
   for (int64_t i = 0; i < rows; ++i) {
     const float* xr = x + i * depth;
     float* yr = y + i * depth;
-    float sumsq = 0.f;
-    for (int64_t j = 0; j < depth; ++j) sumsq = fmaf(xr[j], xr[j], sumsq);
+    float sum, sumsq;
+    row_stats(xr, depth, &sum, &sumsq);
     const float inv_rms = 1.f / sqrtf(fmaf(sumsq, inv_n, eps));
+    const int64_t vsize = depth >= 8 ? depth - depth % 8 : 0;
+    const int64_t four_end = (depth - vsize >= 4) ? vsize + 4 : vsize;
     for (int64_t j = 0; j < depth; ++j) {
-      const float t = inv_rms * xr[j];
-      yr[j] = use_residual ? t * (gamma[j] + 1.f) : t * gamma[j];
+      const int four = j >= vsize && j < four_end;
+      if (use_residual) {
+        const float g = gamma[j] + 1.f;
+        yr[j] = four ? (xr[j] * g) * inv_rms : (inv_rms * xr[j]) * g;
+      } else {
+        yr[j] = four ? xr[j] * (inv_rms * gamma[j]) : (xr[j] * gamma[j]) * inv_rms;
+      }
     }
   }
 }

@@ -172,7 +172,7 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.int32)
 
 
-@pytest.mark.parametrize("depth", [1, 7, 8, 9, 64, 512, 1000, 4096])
+@pytest.mark.parametrize("depth", [1, 3, 7, 8, 9, 11, 12, 13, 15, 16, 20, 64, 100, 512, 1000, 1001, 4096])
 def test_exact_norms(depth):
     R = _ref()
     rng = np.random.default_rng(depth)
