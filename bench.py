@@ -142,38 +142,70 @@ def roofline_entry(label, st):
     return entry
 
 
+def physical_cores():
+    """Distinct (socket, core) pairs of /proc/cpuinfo; falls back to os.cpu_count()."""
+    try:
+        pairs = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(model_dir, sources, args):
-    """The reference's own CPU path (MKL int8) on a bounded sample of the same workload."""
+    """The reference's own CPU path (MKL int8, oracle/_ref) on a bounded sample of the same
+    workload, on ALL physical cores of this host, in the two settings SURVEY section 8(d) names:
+    one replica with intra_threads = N, and the reference's throughput recipe inter_threads = N/4,
+    intra_threads = 4 (docs/performance.md:8-10). `value` is the better of the two."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _refshim as R
     if not R.available():
         return {"value": None, "unit": "tokens/s", "kind": "reference",
                 "error": "oracle/_ref or the MKL runtime is not present on this host"}
-    cores = os.cpu_count() or 1
-    threads = args.cpu_threads or min(32, cores)
-    intra = 4 if threads >= 8 else threads
-    inter = max(1, threads // intra)
-    m = R.RefModel(model_dir, "int8", inter, intra)
-    mbs = max(1, len(sources) // inter)
-    kw = dict(beam_size=args.beam, max_len=args.max_len, min_len=args.max_len, return_scores=False,
-              max_batch_size=mbs)
-    m.translate_ids(sources[:mbs], **kw)  # warm-up (MKL packing, thread pools)
-    t0 = time.perf_counter()
-    reps = 0
-    tokens = 0
-    while True:
-        hyps, _ = m.translate_ids(sources, **kw)
-        tokens += sum(len(h[0]) for h in hyps)
-        reps += 1
-        if time.perf_counter() - t0 > 10.0 or reps >= 5:
-            break
-    dt = time.perf_counter() - t0
-    m.close()
-    return {"value": tokens / dt, "unit": "tokens/s", "cores": inter * intra, "kind": "reference",
-            "sample": "%d x translate_batch(%d sentences, %d forced steps), inter_threads=%d "
-                      "intra_threads=%d, compute_type=int8 (MKL u8s8), %.1f s" %
-                      (reps, len(sources), args.max_len, inter, intra, dt),
-            "host_cpus": cores}
+    logical = os.cpu_count() or 1
+    cores = args.cpu_threads or physical_cores()
+    settings = [(1, cores)]
+    if cores >= 8:
+        settings.append((max(1, cores // 4), 4))
+    runs = []
+    for inter, intra in settings:
+        m = R.RefModel(model_dir, "int8", inter, intra)
+        # every replica gets batches of 8 sentences; the sample is the bench batch repeated
+        need = max(len(sources), inter * 8)
+        sample = (sources * ((need + len(sources) - 1) // len(sources)))[:need]
+        mbs = len(sources) if inter == 1 else 8
+        kw = dict(beam_size=args.beam, max_len=args.max_len, min_len=args.max_len,
+                  return_scores=False, max_batch_size=mbs)
+        m.translate_ids(sample, **kw)  # warm-up (MKL packing, thread pools)
+        t0 = time.perf_counter()
+        reps = tokens = 0
+        while True:
+            hyps, _ = m.translate_ids(sample, **kw)
+            tokens += sum(len(h[0]) for h in hyps)
+            reps += 1
+            if time.perf_counter() - t0 > 8.0 or reps >= 5:
+                break
+        dt = time.perf_counter() - t0
+        m.close()
+        runs.append({"inter_threads": inter, "intra_threads": intra, "value": tokens / dt,
+                     "sample": "%d x translate_batch(%d sentences, %d forced steps, "
+                               "max_batch_size=%d), %.1f s" % (reps, len(sample), args.max_len, mbs, dt)})
+    best = max(runs, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "tokens/s", "cores": cores, "kind": "reference",
+            "sample": "inter_threads=%d intra_threads=%d: %s; compute_type=int8 (MKL u8s8)" %
+                      (best["inter_threads"], best["intra_threads"], best["sample"]),
+            "settings": runs, "host_logical_cpus": logical, "host_physical_cores": physical_cores()}
 
 
 def main():

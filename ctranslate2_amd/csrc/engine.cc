@@ -395,9 +395,19 @@ AttnW Engine::load_attention(const std::string& scope, bool self_attention, int6
   a.heads_kv = multi_query ? 1
                            : static_cast<int64_t>(model_->attribute(scope + "/num_heads_kv",
                                                                     double(num_heads)));
-  if (tp_) {  // this rank's share of the heads (divisibility was checked by load_dense)
-    a.heads /= tp_->world();
-    a.heads_kv /= tp_->world();
+  if (tp_) {
+    // This rank's share of the heads. The column split of the projections only checks the
+    // DIMENSIONS (load_dense); the split must also fall on head boundaries, and a KV head cannot
+    // be divided (the reference's own TP path requires num_heads % world == 0 as well,
+    // src/layers/attention_layer.cc / SAFE_DIVIDE).
+    const int64_t world = tp_->world();
+    if (a.heads % world != 0 || a.heads_kv % world != 0)
+      throw std::runtime_error("tensor parallelism: " + scope + " has " + std::to_string(a.heads) +
+                               " query heads and " + std::to_string(a.heads_kv) +
+                               " key/value heads, which cannot be divided over " +
+                               std::to_string(world) + " ranks on head boundaries");
+    a.heads /= world;
+    a.heads_kv /= world;
   }
   if (model_->attribute(scope + "/sliding_window", 0) != 0)
     throw std::runtime_error("sliding window attention is not supported by this backend yet");
@@ -524,10 +534,17 @@ void Engine::load_stack(const std::string& scope, bool decoder, StackW& out) {
     for (const char* unsupported : {"/shared_layer_norm/gamma", "/input_layer_norm/gamma",
                                     "/post_attention_layer_norm/gamma",
                                     "/pre_feedforward_layer_norm/gamma",
-                                    "/post_feedforward_layer_norm/gamma"})
+                                    "/post_feedforward_layer_norm/gamma",
+                                    "/external_pre_encoder_attention_layer_norm/gamma",
+                                    "/external_post_encoder_attention_layer_norm/gamma"})
       if (m.has(ls + unsupported))
         throw std::runtime_error("layer variant with " + ls + unsupported +
                                  " is not supported by this backend yet");
+    // layer_scalar (src/layers/transformer.cc:189): a non-unit output scale would be silently
+    // dropped - refuse the model instead
+    if (m.has(ls + "/layer_scalar") && m.get(ls + "/layer_scalar").as_number() != 1.0)
+      throw std::runtime_error("layer variant with " + ls + "/layer_scalar is not supported by "
+                               "this backend yet");
     LayerW layer;
     layer.self = load_attention(ls + "/self_attention", true, out.num_heads);
     if (decoder && m.has(ls + "/attention/linear_0/weight")) {
@@ -608,6 +625,17 @@ void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_
                            const float** cos_out) {
   std::lock_guard<std::mutex> lock(table_mutex_);
   const int64_t dim = a.rotary_dim == 0 ? a.dhead : a.rotary_dim;
+  // the cached tables belong to ONE rotary configuration: another layer asking with a different
+  // one (dimension, base, scaling, interleave) gets its own tables
+  const std::string key = std::to_string(dim) + "/" + std::to_string(a.rotary_base) + "/" +
+                          std::to_string(a.rotary_scaling_type) + "/" +
+                          std::to_string(a.rotary_scaling_factor) + "/" +
+                          std::to_string(a.rotary_low_freq_factor) + "/" +
+                          std::to_string(a.rotary_high_freq_factor) + "/" +
+                          std::to_string(a.original_max_position_embeddings) + "/" +
+                          (a.rotary_interleave ? "i" : "h");
+  if (rope_sin_ && key != rope_key_) rope_positions_ = 0;  // rebuild below (old tables stay alive)
+  rope_key_ = key;
   if (rope_sin_ && positions <= rope_positions_) {
     *sin_out = rope_sin_;
     *cos_out = rope_cos_;
@@ -999,6 +1027,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   st->engine = this;
   st->stream = thread_stream();  // the calling (worker) thread's stream: sessions run concurrently
   tls_stream = st->stream;
+  set_active_stream(tls_stream);
   st->batch = batch;
   st->beam = beam;
   st->rows = batch * beam;
@@ -1298,6 +1327,7 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
 void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time) {
   CT2X_HIP_CHECK(hipSetDevice(device_));
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   CT2X_CHECK(!has_encoder_, "prefill is only defined for decoder-only models");
   // (with beam > 1 the caller passes the prompt of a sentence once per hypothesis row)
   CT2X_CHECK(time <= st.t_max && time <= st.prefill_max, "prompt longer than the decoding state");
@@ -1664,6 +1694,7 @@ void Engine::launch_step(DecodeState& st) {
 
 void Engine::step(DecodeState& st, bool graph) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipSetDevice(device_));
   // Make sure lazily built tables exist before any capture (no allocation inside a capture).
   if (dec_.sinusoidal_positions) (void)sinusoidal_table(st.t_max, dec_.d_model);
@@ -1704,11 +1735,13 @@ void Engine::step(DecodeState& st, bool graph) {
 
 void Engine::advance_step(DecodeState& st) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   launch_advance_step(st.d_step, cur_stream());
 }
 
 void Engine::read_beam_history_async(DecodeState& st, int64_t first, int64_t count, int slot) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   const int64_t per_step = st.batch * 2 * st.beam;
   const int64_t need = count * per_step;
   if (st.pin_cand_capacity < need) {
@@ -1745,6 +1778,7 @@ void Engine::wait_beam_history(DecodeState& st, int slot, const int32_t** h_word
 void Engine::set_beam_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>& prefix,
                              int32_t first_step, bool extends_min_length) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipSetDevice(device_));
   st.prefix_first_step = first_step;
   st.prefix_extends_min = extends_min_length;
@@ -1774,6 +1808,7 @@ void Engine::set_beam_prefix(DecodeState& st, const std::vector<std::vector<int3
 
 void Engine::set_beam_scores(DecodeState& st, const float* h_scores) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipMemcpyAsync(st.beam_scores, h_scores, sizeof(float) * st.rows,
                                 hipMemcpyHostToDevice, cur_stream()));
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
@@ -1782,6 +1817,7 @@ void Engine::set_beam_scores(DecodeState& st, const float* h_scores) {
 void Engine::read_history(DecodeState& st, int64_t first, int64_t count, int32_t* h_ids,
                           float* h_scores) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   if (count <= 0) return;
   CT2X_HIP_CHECK(hipMemcpyAsync(h_ids, st.hist_ids + first * st.rows,
                                 sizeof(int32_t) * count * st.rows, hipMemcpyDeviceToHost,
@@ -1795,6 +1831,7 @@ void Engine::read_history(DecodeState& st, int64_t first, int64_t count, int32_t
 
 void Engine::read_history_async(DecodeState& st, int64_t first, int64_t count, int slot) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   const int64_t need = count * st.rows;
   if (st.pin_capacity < need) {
     for (int i = 0; i < 2; ++i) {
@@ -1822,6 +1859,7 @@ void Engine::wait_history(DecodeState& st, int slot, const int32_t** h_ids,
 
 void Engine::copy_logits_to_host(DecodeState& st, float* h_logits) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipMemcpyAsync(h_logits, st.logits, sizeof(float) * st.rows * dec_.projection.n,
                                 hipMemcpyDeviceToHost, cur_stream()));
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
@@ -1829,6 +1867,7 @@ void Engine::copy_logits_to_host(DecodeState& st, float* h_logits) {
 
 void Engine::set_ids(DecodeState& st, const int32_t* h_ids) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_ids, h_ids, sizeof(int32_t) * st.rows,
                                 hipMemcpyHostToDevice, cur_stream()));
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // h_ids may be a temporary
@@ -1838,6 +1877,7 @@ void Engine::set_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>
                         int32_t first_step, bool extends_min_length) {
   st.prefix_extends_min = extends_min_length;
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipSetDevice(device_));
   size_t longest = 0;
   for (const auto& p : prefix) longest = std::max(longest, p.size());
@@ -1867,6 +1907,7 @@ void Engine::set_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>
 
 void Engine::set_logits_processing(DecodeState& st, const LogitsProcessing& lp) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipSetDevice(device_));
   st.lp_active = lp.active();
   st.lp_penalty = lp.repetition_penalty;
@@ -1912,6 +1953,7 @@ void Engine::set_logits_processing(DecodeState& st, const LogitsProcessing& lp) 
 
 void Engine::set_step(DecodeState& st, int32_t step) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_step, &step, sizeof(int32_t), hipMemcpyHostToDevice,
                                 cur_stream()));
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
@@ -1922,6 +1964,7 @@ void Engine::synchronize() { CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
 void Engine::score_targets(DecodeState& st, const int32_t* h_inputs, const int32_t* h_outputs,
                            int64_t steps) {
   tls_stream = st.stream;
+  set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipSetDevice(device_));
   CT2X_CHECK(steps <= st.t_max, "score_targets: more steps than the decoding state holds");
   if (steps == 0) return;

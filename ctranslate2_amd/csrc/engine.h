@@ -336,6 +336,7 @@ private:
   float* rope_sin_ = nullptr;
   float* rope_cos_ = nullptr;
   int64_t rope_positions_ = 0;
+  std::string rope_key_;  // rotary configuration the cached tables were built for
 };
 
 struct DecodeState {

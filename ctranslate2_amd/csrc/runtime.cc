@@ -36,10 +36,19 @@ size_t size_class(size_t bytes) {
   return (bytes + step - 1) / step * step;
 }
 
+struct FreeBlock {
+  void* ptr;
+  hipStream_t stream;  // the stream the freeing thread was enqueueing on
+  hipEvent_t event;    // recorded on it at free time (nullptr: nothing was pending)
+};
+
+thread_local hipStream_t t_active = nullptr;
+
 struct Pool {
   std::mutex mutex;
   // (device, size class) -> free blocks
-  std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;
+  std::map<std::pair<int, size_t>, std::vector<FreeBlock>> free_blocks;
+  std::vector<hipEvent_t> spare_events;
   std::unordered_map<void*, std::pair<int, size_t>> live;  // ptr -> (device, class)
   int64_t allocated = 0;
 };
@@ -61,6 +70,9 @@ hipStream_t thread_stream() {
   return t_stream.stream;
 }
 
+void set_active_stream(hipStream_t stream) { t_active = stream; }
+hipStream_t active_stream() { return t_active ? t_active : thread_stream(); }
+
 void* device_malloc(size_t bytes) {
   if (bytes == 0) bytes = 1;
   int device = 0;
@@ -68,13 +80,22 @@ void* device_malloc(size_t bytes) {
   const size_t cls = size_class(bytes);
   Pool& p = pool();
   {
+    const hipStream_t mine = active_stream();
     std::lock_guard<std::mutex> lock(p.mutex);
     auto it = p.free_blocks.find({device, cls});
-    if (it != p.free_blocks.end() && !it->second.empty()) {
-      void* ptr = it->second.back();
-      it->second.pop_back();
-      p.live[ptr] = {device, cls};
-      return ptr;
+    if (it != p.free_blocks.end()) {
+      auto& blocks = it->second;
+      // newest first: same-stream blocks are reusable at once, others once their event is done
+      for (size_t i = blocks.size(); i-- > 0;) {
+        FreeBlock& b = blocks[i];
+        const bool ready = b.event == nullptr || b.stream == mine || hipEventQuery(b.event) == hipSuccess;
+        if (!ready) continue;
+        void* ptr = b.ptr;
+        if (b.event) p.spare_events.push_back(b.event);
+        blocks.erase(blocks.begin() + static_cast<std::ptrdiff_t>(i));
+        p.live[ptr] = {device, cls};
+        return ptr;
+      }
     }
   }
   void* ptr = nullptr;
@@ -95,7 +116,31 @@ void device_free(void* ptr) {
   std::lock_guard<std::mutex> lock(p.mutex);
   auto it = p.live.find(ptr);
   if (it == p.live.end()) throw Error("ct2x_free: pointer was not allocated by ct2x_malloc");
-  p.free_blocks[it->second].push_back(ptr);
+  FreeBlock b{ptr, nullptr, nullptr};
+  // Work that still uses the block may be queued on the caller's stream: remember the stream and
+  // an event behind that work (no device means nothing can be pending).
+  int device = 0;
+  if (hipGetDevice(&device) == hipSuccess && device == it->second.first) {
+    hipStream_t stream = t_active ? t_active : t_stream.stream;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (stream != nullptr) (void)hipStreamIsCapturing(stream, &capturing);
+    if (stream != nullptr && capturing == hipStreamCaptureStatusNone) {
+      hipEvent_t ev = nullptr;
+      if (!p.spare_events.empty()) {
+        ev = p.spare_events.back();
+        p.spare_events.pop_back();
+      } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+        ev = nullptr;
+      }
+      if (ev != nullptr && hipEventRecord(ev, stream) == hipSuccess) {
+        b.stream = stream;
+        b.event = ev;
+      } else if (ev != nullptr) {
+        p.spare_events.push_back(ev);
+      }
+    }
+  }
+  p.free_blocks[it->second].push_back(b);
   p.live.erase(it);
 }
 
@@ -105,8 +150,9 @@ void clear_cache() {
   {
     std::lock_guard<std::mutex> lock(p.mutex);
     for (auto& kv : p.free_blocks) {
-      for (void* ptr : kv.second) {
-        to_free.push_back(ptr);
+      for (const FreeBlock& b : kv.second) {
+        to_free.push_back(b.ptr);
+        if (b.event) p.spare_events.push_back(b.event);
         p.allocated -= static_cast<int64_t>(kv.first.second);
       }
       kv.second.clear();

@@ -41,8 +41,18 @@ inline hipStream_t resolve_stream(void* s) {
   return s ? static_cast<hipStream_t>(s) : thread_stream();
 }
 
-// Caching allocator: blocks are recycled per size class and never returned to the driver
-// until clear_cache(). Safe because each thread enqueues on one stream in program order.
+// The stream the calling thread is enqueueing on right now: the engine sets it while it drives a
+// session on that session's stream; otherwise it is thread_stream(). The allocator orders the
+// reuse of freed blocks against it.
+void set_active_stream(hipStream_t stream);  // nullptr: back to thread_stream()
+hipStream_t active_stream();
+
+// Stream-ordered caching allocator (the contract of the reference's CUDA allocator,
+// src/cuda/allocator.cc:34-185): blocks are recycled per size class and never returned to the
+// driver until clear_cache(). device_free() may be called while work that uses the block is still
+// queued on the calling thread's active stream: the block remembers that stream and an event
+// recorded behind the queued work; it is handed out again either to a request on the SAME stream
+// (stream order makes that safe) or, to any other stream, only once the event has completed.
 void* device_malloc(size_t bytes);
 void device_free(void* ptr);
 void clear_cache();

@@ -514,3 +514,82 @@ def test_attention_full(gpu, b, tq, tk, h, hkv, dh, causal):
                 pm = O.softmax(sc, size.astype(np.int32), False)
                 want = O.matmul(pm[None], v[bi, :, hi // group][None], False, 1.0)[0]
                 assert np.array_equal(y[bi, :, hi], want), (bi, hi)
+
+
+@pytest.mark.parametrize("batch,m,n,k,trans_b,alpha", [
+    (256, 1, 33, 64, True, 0.125),     # decode QK^T: one query per (row, head), tail of 1 key
+    (256, 1, 64, 33, False, 1.0),      # decode P.V: blocks of eight + one key
+    (64, 1, 7, 32, True, 0.17677669),  # d_head 32, non power-of-two scale
+    (64, 1, 4, 9, False, 1.0),         # d_head 4: narrow output, plain chain
+    (32, 4, 40, 64, True, 0.125),      # beam 4 on the encoder memory
+    (32, 4, 64, 40, False, 1.0),
+    (8, 32, 32, 64, True, 0.125),      # encoder self-attention tile
+    (8, 32, 64, 32, False, 1.0),
+])
+def test_matmul_f32_exact(gpu, batch, m, n, k, trans_b, alpha):
+    """ops::MatMul (SURVEY 8 a7) through the C ABI = the reference CPU path's MKL sgemm, bit for bit
+    (orc_matmul is pinned against the reference library for exactly these shape classes)."""
+    import _gpuops as G
+    rng = np.random.default_rng(batch + m + n + k)
+    a = rng.standard_normal((batch, m, k)).astype(np.float32)
+    b = rng.standard_normal((batch, n, k) if trans_b else (batch, k, n)).astype(np.float32)
+    y = G.matmul_f32(a, b, trans_b, alpha)
+    assert np.array_equal(y, O.matmul(a, b, trans_b, alpha))
+
+
+def test_matmul_f32_outside_the_envelope_is_close(gpu):
+    """Shapes whose MKL order was not recovered (k > 64 with one query row) run the plain fp32
+    GEMM: within fp32 accumulation error of a float64 product."""
+    import _gpuops as G
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((6, 1, 128)).astype(np.float32)
+    b = rng.standard_normal((6, 50, 128)).astype(np.float32)
+    y = G.matmul_f32(a, b, True, 0.5)
+    ref = 0.5 * np.einsum("bmk,bnk->bmn", a.astype(np.float64), b.astype(np.float64))
+    np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
+
+
+def test_runtime_abi_round_trip(gpu):
+    """The runtime entry points of the boundary (allocator, copies, events, streams):
+    include/ct2_mi355.h 'runtime'."""
+    import ctypes as C
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    L.ct2x_thread_stream.restype = C.c_void_p
+    L.ct2x_allocated_bytes.restype = C.c_int64
+    stream = C.c_void_p(L.ct2x_thread_stream())
+    before = L.ct2x_allocated_bytes()
+    src = np.arange(1 << 16, dtype=np.float32)
+    d1, d2 = C.c_void_p(), C.c_void_p()
+    _lib.check(L.ct2x_malloc(C.byref(d1), C.c_size_t(src.nbytes)))
+    _lib.check(L.ct2x_malloc(C.byref(d2), C.c_size_t(src.nbytes)))
+    assert d1.value and d2.value and d1.value != d2.value
+    assert L.ct2x_allocated_bytes() >= before + 2 * src.nbytes
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    _lib.check(L.ct2x_event_create(C.byref(e0)))
+    _lib.check(L.ct2x_event_create(C.byref(e1)))
+    _lib.check(L.ct2x_event_record(e0, stream))
+    _lib.check(L.ct2x_copy_to_device(src.ctypes.data_as(C.c_void_p), d1, C.c_size_t(src.nbytes), stream))
+    _lib.check(L.ct2x_copy_device(d1, d2, C.c_size_t(src.nbytes), stream))
+    out = np.zeros_like(src)
+    _lib.check(L.ct2x_copy_to_host(d2, out.ctypes.data_as(C.c_void_p), C.c_size_t(src.nbytes), stream))
+    assert np.array_equal(out, src)  # the D2H copy has landed when the call returns
+    _lib.check(L.ct2x_event_record(e1, stream))
+    ms = C.c_float(-1)
+    _lib.check(L.ct2x_event_elapsed_ms(e0, e1, C.byref(ms)))
+    assert ms.value >= 0
+    # stream-ordered reuse: a block freed with work queued behind it comes back to the same
+    # stream at once (and only to it)
+    _lib.check(L.ct2x_free(d1))
+    d3 = C.c_void_p()
+    _lib.check(L.ct2x_malloc(C.byref(d3), C.c_size_t(src.nbytes)))
+    assert d3.value == d1.value
+    _lib.check(L.ct2x_free(d2))
+    _lib.check(L.ct2x_free(d3))
+    _lib.check(L.ct2x_stream_synchronize(stream))
+    _lib.check(L.ct2x_device_synchronize())
+    _lib.check(L.ct2x_clear_cache())
+    assert L.ct2x_allocated_bytes() <= before
+    assert L.ct2x_free(d3) != 0  # double free is an error, not a crash
+    _lib.check(L.ct2x_event_destroy(e0))
+    _lib.check(L.ct2x_event_destroy(e1))
