@@ -871,6 +871,27 @@ bool Engine::dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_
   return true;
 }
 
+// Output projection of an attention block + residual + the NEXT sub-layer's pre-norm + Quantize
+// as one row-owning launch (rowblock.hip). Returns false when the shape / layer does not qualify
+// (the caller then runs dense + norm_quant).
+bool Engine::dense_out_next_norm(const DenseW& w, const QuantIn& cq, int64_t rows,
+                                 const float* residual, float* y, const NormW* next_ln,
+                                 const DenseW* next_dense, DecodeState& st) {
+  if (tp_ || taps_ || !dec_.pre_norm || next_ln == nullptr || !next_ln->present ||
+      next_dense == nullptr || !next_dense->quantized || !w.quantized || w.row_parallel ||
+      next_dense->k != w.n || !rowgemv_ln_applicable(rows, w.n, w.k))
+    return false;
+  const double M = double(rows), N = double(w.n), K = double(w.k);
+  // algorithmic bytes: the weight once (every row re-reads it from L2), rows in / out
+  begin_kernel("rowgemv_norm_quantize", M * K + N * K + 16 * N + 8 * M + 8 * M * N + M * N,
+               2 * M * N * K, rows, w.n, w.k);
+  launch_rowgemv_ln(cq.q, cq.s, w.wq, w.wscale, w.bias, residual, y, rows, w.n, w.k, next_ln->gamma,
+                    next_ln->beta, next_ln->eps, next_ln->use_residual, quant_mode_, st.qbuf,
+                    st.qscale, cur_stream());
+  end_kernel();
+  return true;
+}
+
 void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t m, int act,
                    const float* residual, float* y, DecodeState* ws) {
   if (w.row_parallel && tp_) {
@@ -1246,16 +1267,21 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
 // [-> x Dense-noact (GLU)] -> Dense + residual -> post-norm. x is the sub-layer input, the result
 // lands in y and the pointers are swapped so that x is the output on return.
 void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, float*& x, float*& y,
-                     DecodeState& st, float* amax_buf) {
+                     DecodeState& st, float* amax_buf, bool qin_ready) {
   QuantIn fq;
   const float* ffn_in = x;
-  if (ffn.ln.present && pre_norm && !ffn.l0_noact.present &&
+  if (qin_ready) {
+    // the previous block's row-owning output projection already normalised and quantised x
+    fq.q = st.qbuf;
+    fq.s = st.qscale;
+  } else if (ffn.ln.present && pre_norm && !ffn.l0_noact.present &&
       dense_norm(ffn.ln, ffn.l0, x, rows, ffn.activation, nullptr, st.inner)) {
     dense(ffn.l1, st.inner, nullptr, rows, -1, x, y, &st);
     std::swap(x, y);
     return;
   }
-  if (ffn.ln.present && pre_norm) {
+  if (qin_ready) {
+  } else if (ffn.ln.present && pre_norm) {
     if (ffn.l0.quantized) {
       norm_quant(ffn.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
       fq.q = st.qbuf;
@@ -1438,6 +1464,9 @@ void Engine::launch_step(DecodeState& st) {
   tap("emb", x, 0, rows, d);
   if (dec_.layernorm_embedding.present) norm(dec_.layernorm_embedding, x, rows, d, x);
 
+  // set when the previous block's row-owning output projection already produced LayerNorm(x) +
+  // Quantize for the block that follows (st.qbuf / st.qscale)
+  bool qin_ready = false;
   for (size_t l = 0; l < dec_.layers.size(); ++l) {
     const LayerW& layer = dec_.layers[l];
     // ---- masked self-attention -----------------------------------------------------------
@@ -1446,8 +1475,13 @@ void Engine::launch_step(DecodeState& st) {
       tap_scope("dec.l" + std::to_string(l) + ".self");
       QuantIn qin;
       const float* attn_in = x;
-      const bool fused_in = dec_.pre_norm && dense_norm(a.ln, a.lin[0], x, rows, -1, nullptr, st.qkv);
-      if (!fused_in && a.ln.present && dec_.pre_norm) {
+      const bool fused_in = !qin_ready && dec_.pre_norm &&
+                            dense_norm(a.ln, a.lin[0], x, rows, -1, nullptr, st.qkv);
+      if (qin_ready) {
+        qin.q = st.qbuf;
+        qin.s = st.qscale;
+        qin_ready = false;
+      } else if (!fused_in && a.ln.present && dec_.pre_norm) {
         if (a.lin[0].quantized) {
           norm_quant(a.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
           qin.q = st.qbuf;
@@ -1500,7 +1534,13 @@ void Engine::launch_step(DecodeState& st) {
         QuantIn cq;
         cq.q = st.qbuf;
         cq.s = st.qscale;
-        dense(a.lin[1], nullptr, &cq, rows, -1, a.ln.present ? x : nullptr, y, &st);
+        const NormW* next_ln = layer.has_cross ? &layer.cross.ln : &layer.ffn.ln;
+        const DenseW* next_dense = layer.has_cross ? &layer.cross.lin[0] : &layer.ffn.l0;
+        if (a.ln.present && (layer.has_cross || !layer.ffn.l0_noact.present) &&
+            dense_out_next_norm(a.lin[1], cq, rows, x, y, next_ln, next_dense, st))
+          qin_ready = true;
+        else
+          dense(a.lin[1], nullptr, &cq, rows, -1, a.ln.present ? x : nullptr, y, &st);
       } else if (split_quant && a.lin[1].quantized && !a.lin[1].row_parallel &&
                  attention_decode_emits_row_amax(p)) {
         // long caches / few rows: one workgroup per (row, head) + producer-side absmax, then an
@@ -1532,8 +1572,13 @@ void Engine::launch_step(DecodeState& st) {
       tap_scope("dec.l" + std::to_string(l) + ".cross");
       QuantIn qin;
       const float* attn_in = x;
-      const bool fused_in = dec_.pre_norm && dense_norm(a.ln, a.lin[0], x, rows, -1, nullptr, st.qkv);
-      if (!fused_in && a.ln.present && dec_.pre_norm) {
+      const bool fused_in = !qin_ready && dec_.pre_norm &&
+                            dense_norm(a.ln, a.lin[0], x, rows, -1, nullptr, st.qkv);
+      if (qin_ready) {
+        qin.q = st.qbuf;
+        qin.s = st.qscale;
+        qin_ready = false;
+      } else if (!fused_in && a.ln.present && dec_.pre_norm) {
         if (a.lin[0].quantized) {
           norm_quant(a.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
           qin.q = st.qbuf;
@@ -1583,7 +1628,11 @@ void Engine::launch_step(DecodeState& st) {
         QuantIn cq;
         cq.q = st.qbuf;
         cq.s = st.qscale;
-        dense(a.lin[2], nullptr, &cq, rows, -1, a.ln.present ? x : nullptr, y, &st);
+        if (a.ln.present && !layer.ffn.l0_noact.present &&
+            dense_out_next_norm(a.lin[2], cq, rows, x, y, &layer.ffn.ln, &layer.ffn.l0, st))
+          qin_ready = true;
+        else
+          dense(a.lin[2], nullptr, &cq, rows, -1, a.ln.present ? x : nullptr, y, &st);
       } else {
         begin_kernel("attention_cross_decode", attn_bytes, attn_ops, rows, a.heads, a.dhead);
         launch_attention_decode(p, cur_stream());
@@ -1596,7 +1645,8 @@ void Engine::launch_step(DecodeState& st) {
     // ---- feed forward ----------------------------------------------------------------------
     tap_scope("dec.l" + std::to_string(l) + ".ffn");
     run_ffn(layer.ffn, dec_.pre_norm, rows, d, x, y, st,
-            split_quant ? st.row_amax + (2 * l + 1) * rows : nullptr);
+            split_quant ? st.row_amax + (2 * l + 1) * rows : nullptr, qin_ready);
+    qin_ready = false;
   }
 
   // Final norm + vocabulary projection (transformer.cc:842-855).

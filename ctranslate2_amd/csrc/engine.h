@@ -286,7 +286,10 @@ private:
   void encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_lengths);
   // amax_buf: zeroed [rows] scratch for the producer-side absmax of the gated pair (decode steps)
   void run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, float*& x, float*& y,
-               DecodeState& st, float* amax_buf = nullptr);
+               DecodeState& st, float* amax_buf = nullptr, bool qin_ready = false);
+  bool dense_out_next_norm(const DenseW& w, const QuantIn& cq, int64_t rows, const float* residual,
+                           float* y, const NormW* next_ln, const DenseW* next_dense,
+                           DecodeState& st);
   void launch_step(DecodeState& st);
   const float* sinusoidal_table(int64_t positions, int64_t depth);
   void rotary_tables(const AttnW& a, int64_t positions, const float** sin, const float** cos);

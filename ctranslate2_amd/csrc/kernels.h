@@ -192,6 +192,14 @@ bool attention_decode_can_fuse_quantize(const AttnDecodeParams& p);
 void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
                                        float* q_scales, hipStream_t stream);
 
+// Row-owning Dense(out) + residual + next norm + Quantize in one launch (rowblock.hip).
+bool rowgemv_ln_applicable(int64_t rows, int64_t n, int64_t k);
+void launch_rowgemv_ln(const int8_t* qa, const float* a_scale, const int8_t* w, const float* w_scale,
+                       const float* bias, const float* residual, float* y, int64_t rows, int64_t n,
+                       int64_t k, const float* gamma, const float* beta, float eps,
+                       bool rms_use_residual, int quant_mode, int8_t* q_out, float* q_scale_out,
+                       hipStream_t stream);
+
 // Attention that rounds exactly like the reference CPU path (attention_exact.hip: MKL's sgemm
 // summation trees, the AVX2 exp polynomial and sum order of cpu::softmax); d_head 64, no RoPE.
 // launch_attention_decode / _quantized / _full route to it whenever it applies
