@@ -167,8 +167,18 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
 
   float acc_out = 0.f;
   if (active) {
+    // Every global load of the launch that does not depend on another is requested up front -
+    // the first K tile, q, the new key / value, then (below) the first batch of V rows - so that
+    // the prologue and both phases share ONE memory round trip.
+    v4f kpre[R4];
+#pragma unroll
+    for (int it = 0; it < R4; ++it) {
+      const int i_ = it * 64 + lane;  // R4 float4 per row
+      const int tl = min(i_ / R4, t_last);
+      kpre[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+    }
     // ---- prologue: lane = channel ---------------------------------------------------------
-    float knew = 0.f, vnew = 0.f;
+    float knew = 0.f, vnew = 0.f, tq_pending = 0.f;
     {
       const float* qh = p.q + static_cast<int64_t>(row) * p.q_row_stride + hq * DH;
       const float qd = qh[cl];
@@ -180,9 +190,9 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
           vc[pos * kvs + cl] = vnew;
         }
       }
-      if (chan) tq[cl] = qd;
+      // (q reaches LDS only after the V request below has been issued)
+      tq_pending = qd;
     }
-    __builtin_amdgcn_wave_barrier();
 
     // The first batch of V rows is requested now, before the QK^T phase: one memory round trip
     // covers both phases (the rows are only consumed by P.V at the end).
@@ -194,16 +204,23 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
   }
     float va[XVB], vb[XVB];
     CT2X_XLOAD_V(va, 0)
+    if (chan) tq[cl] = tq_pending;
+    __builtin_amdgcn_wave_barrier();
 
     // ---- QK^T: lane = key -------------------------------------------------------------------
     const int main_n = (n_keys / 4) * 4;
     for (int t0 = 0; t0 < n_keys; t0 += 64) {
       v4f st[R4];
+      if (t0 == 0) {
 #pragma unroll
-      for (int it = 0; it < R4; ++it) {
-        const int i_ = it * 64 + lane;  // R4 float4 per row
-        const int tl = min(t0 + i_ / R4, t_last);
-        st[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+        for (int it = 0; it < R4; ++it) st[it] = kpre[it];
+      } else {
+#pragma unroll
+        for (int it = 0; it < R4; ++it) {
+          const int i_ = it * 64 + lane;  // R4 float4 per row
+          const int tl = min(t0 + i_ / R4, t_last);
+          st[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+        }
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll

@@ -8,6 +8,11 @@
 
 namespace ct2x {
 
+__device__ __forceinline__ float dpp_xor4(float v) {
+  const float m = dpp_move<0x141, 0xf>(0.f, v);  // row_half_mirror: lane i <- lane 7 - i (per 8)
+  return dpp_move<0x1B, 0xf>(0.f, m);             // quad_perm [3,2,1,0]: lane i <- lane i ^ 3
+}
+
 // `row`: the depth floats of the row in LDS (linear). Every lane of the calling wave returns the
 // statistics.
 __device__ __forceinline__ void ordered_row_stats(const float* row, int64_t depth, float& sum,
@@ -22,12 +27,14 @@ __device__ __forceinline__ void ordered_row_stats(const float* row, int64_t dept
       ss = fmaf(v, v, ss);
       s = s + v;
     }
-    ss = __shfl_xor(ss, 4, 64) + ss;
-    s = __shfl_xor(s, 4, 64) + s;
-    ss = __shfl_xor(ss, 2, 64) + ss;
-    s = __shfl_xor(s, 2, 64) + s;
-    ss = __shfl_xor(ss, 1, 64) + ss;
-    s = __shfl_xor(s, 1, 64) + s;
+    // lane ^ 4, ^ 2, ^ 1 on the DPP network (no LDS round trips): ^4 = half-row mirror (i -> 7 - i)
+    // followed by a reversal inside the quad ((7 - i) ^ 3 = i ^ 4); ^2 and ^1 are quad permutes
+    ss = dpp_xor4(ss) + ss;
+    s = dpp_xor4(s) + s;
+    ss = dpp_move<0x4E, 0xf>(0.f, ss) + ss;  // quad_perm [2,3,0,1]
+    s = dpp_move<0x4E, 0xf>(0.f, s) + s;
+    ss = dpp_move<0xB1, 0xf>(0.f, ss) + ss;  // quad_perm [1,0,3,2]
+    s = dpp_move<0xB1, 0xf>(0.f, s) + s;
   }
   int j = vsize;
   if (depth - j >= 4) {

@@ -1,5 +1,7 @@
 // Row-owning fused blocks for decode steps (rows <= 32) on gfx950.
 //
+// (An experiment that lost - see rowblock_disabled() - kept for the record and for comparison
+// runs.)
 // At batch * beam = 32 a decode step is a chain of ~76 tiny dependent launches, each costing a
 // kernel boundary (~1.5 us) plus a memory round trip for data the previous kernel just wrote.
 // The column-split skinny GEMM (gemm_s8.hip) is the right shape for streaming a weight ONCE, but
@@ -155,12 +157,16 @@ void launch_rowgemv(const RowGemvLnArgs& a, int64_t rows, int waves, hipStream_t
                      lds, stream, a);
 }
 
+// MEASURED AND REJECTED as the default (profiles/r02_rowgemv_fusion.txt): the launch it removes
+// costs ~4.4 us, but a row-owning workgroup has to pull the whole 256 KB weight through ONE CU's
+// L2 port (~30 B/clk): 8.6 us in the kernel against 3.2 + 4.4 us for the two launches it replaces
+// (Transformer-base: 80.0k -> 68.2k tokens/s). Kept behind CT2X_ROW_FUSION=1 (bit-identical).
 bool rowblock_disabled() {
-  static const bool off = [] {
+  static const bool on = [] {
     const char* e = std::getenv("CT2X_ROW_FUSION");
-    return e != nullptr && e[0] == '0';
+    return e != nullptr && e[0] == '1';
   }();
-  return off;
+  return !on;
 }
 
 }  // namespace
