@@ -57,6 +57,8 @@ def parse_args():
                         "the same batch, RCCL all-reduce after each row-parallel Dense) instead of "
                         "independent replicas; strong scaling")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-l8", action="store_true",
+                   help="skip the Llama-3-8B-shape leg (BASELINE configs[2], reported as config.l8)")
     p.add_argument("--no-profile", action="store_true")
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline")
     return p.parse_args()
@@ -331,6 +333,28 @@ def main():
                          "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["total_ms"] else None}
                         for k, v in top],
             }
+        if world == 1 and not args.no_l8 and args.beam == 1 and args.compute_type == "int8":
+            # BASELINE.json configs[2] (Llama-3 8B shape, int8, batch 16 greedy) under the same
+            # clock: tools/bench_l8.py in its own process (7.5 GB of weights), two timed calls of
+            # 16 prompts x 128 tokens + 128 forced new tokens; its decode step is the
+            # HBM-roofline case of this backend (weights streamed once per step).
+            try:
+                import subprocess
+                translator.close()
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_l8.py"),
+                                      "--steps", "2", "--warmup", "1", "--no-profile"],
+                                     capture_output=True, text=True, timeout=600)
+                l8 = json.loads(out.stdout.strip().splitlines()[-1])
+                result["config"]["l8"] = {
+                    "workload": l8["config"]["workload"], "value": l8["value"], "unit": l8["unit"],
+                    "ms_per_call": l8["ms_per_step"],
+                    "prefill_ms": l8["config"]["prefill_ms_last_call"],
+                    "decode_ms_per_step": l8["config"]["decode_ms_per_step"],
+                    "kernels_per_decode_step": l8["config"]["kernels_per_decode_step"],
+                    "roofline": l8["decode_roofline"],
+                }
+            except Exception as e:  # never break the headline line
+                result["config"]["l8"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(model_dir, sources, args)

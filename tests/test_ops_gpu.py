@@ -558,6 +558,7 @@ def test_runtime_abi_round_trip(gpu):
     L.ct2x_thread_stream.restype = C.c_void_p
     L.ct2x_allocated_bytes.restype = C.c_int64
     stream = C.c_void_p(L.ct2x_thread_stream())
+    _lib.check(L.ct2x_clear_cache())  # earlier tests leave cached blocks: start from the driver
     before = L.ct2x_allocated_bytes()
     src = np.arange(1 << 16, dtype=np.float32)
     d1, d2 = C.c_void_p(), C.c_void_p()
