@@ -418,7 +418,13 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
   // Concurrent hipGraph captures from several threads are not reliable on ROCm 7.2 ("operation
   // failed due to a previous error during capture"); concurrent sessions launch eagerly -- the
   // host has a thread per stream, so launches still overlap across streams.
-  if (streams > 1) dopt.use_graph = false;
+  if (streams > 1) {
+    static const bool stream_graphs = [] {
+      const char* e = std::getenv("CT2X_STREAM_GRAPHS");
+      return e != nullptr && e[0] == '1';
+    }();
+    if (!stream_graphs) dopt.use_graph = false;
+  }
   std::vector<std::pair<size_t, size_t>> groups;
   for (size_t begin = 0; begin < order.size(); begin += chunk)
     groups.emplace_back(begin, std::min(order.size(), begin + chunk));

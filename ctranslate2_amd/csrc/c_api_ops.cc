@@ -256,7 +256,7 @@ int ct2x_norm_gemm_s8_dequant(const float* d_x, const float* d_gamma, const floa
                               void* stream) {
   API_TRY
   CT2X_CHECK(gemm_s8_norm_applicable(m, n, k),
-             "ct2x_norm_gemm_s8_dequant: needs m <= 32, 64 <= k <= 1024, k % 16 == 0");
+             "ct2x_norm_gemm_s8_dequant: needs m <= 128, k in {64, 128, 256, 512}, n < 8192");
   GemmS8Epilogue ep;
   ep.mode = 1;
   ep.w_scale = d_w_scale;

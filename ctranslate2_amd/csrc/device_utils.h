@@ -14,10 +14,26 @@ constexpr int kWave = 64;
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Wave64 reductions on the DPP network (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast
+// 15 / 31 across rows; total in lane 63, broadcast by v_readlane): ~7 VALU issues instead of six
+// dependent ds_bpermute round trips (~130 cycles each) per reduction.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), kCtrl,
+                                                    kRowMask, 0xf, false));
+}
+
+// The maximum is order independent: every caller gets the DPP form (measured on the norm +
+// Quantize launch: the ds_bpermute butterfly cost ~700 of the kernel's 5900 cycles).
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const float ninf = -__builtin_huge_valf();
+  v = fmaxf(v, dpp_move<0x111, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_move<0x112, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_move<0x114, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_move<0x118, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_move<0x142, 0xa>(ninf, v));
+  v = fmaxf(v, dpp_move<0x143, 0xc>(ninf, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -81,14 +97,6 @@ __device__ __forceinline__ ValIdx wave_argmax(ValIdx x) {
 
 // Activation epilogues: float math identical in form to the reference CPU functors
 // (src/cpu/kernels.cc:146-207).
-// Wave64 reductions on the DPP network (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast
-// 15 / 31 across rows; total in lane 63, broadcast by v_readlane): ~7 VALU issues instead of six
-// dependent ds_bpermute round trips (~130 cycles each) per reduction.
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ float dpp_move(float old, float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), kCtrl,
-                                                    kRowMask, 0xf, false));
-}
 __device__ __forceinline__ float wave_sum_dpp(float v) {
   v += dpp_move<0x111, 0xf>(0.f, v);
   v += dpp_move<0x112, 0xf>(0.f, v);

@@ -845,7 +845,7 @@ void Engine::norm_quant(const NormW& w, const float* x, int64_t rows, int64_t de
 // layers::Dense::operator() (src/layers/common.cc:339-442).
 bool Engine::dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_t m, int act,
                         const float* residual, float* y) {
-  if (!gemm_s8_norm_fusion_enabled() || !ln.present || !w.quantized || w.row_parallel ||
+  if (!gemm_s8_norm_fusion_enabled() || taps_ || !ln.present || !w.quantized || w.row_parallel ||
       !gemm_s8_norm_applicable(m, w.n, w.k))
     return false;
   GemmS8Epilogue ep;
@@ -1762,6 +1762,10 @@ void Engine::step(DecodeState& st, bool graph) {
   }
   const int parity = st.cur;
   if (!st.graph_ready[parity]) {
+    // One capture at a time per process: concurrent captures from several worker threads fail on
+    // ROCm 7.2 ("operation failed due to a previous error during capture"); replays are free.
+    static std::mutex capture_mutex;
+    std::lock_guard<std::mutex> capture_lock(capture_mutex);
     hipGraph_t g = nullptr;
     const int64_t before = launch_counter_;
     CT2X_HIP_CHECK(hipStreamBeginCapture(cur_stream(), hipStreamCaptureModeThreadLocal));

@@ -15,6 +15,7 @@
 
 #include "device_utils.h"
 #include "kernels.h"
+#include "row_norm.h"
 #include "runtime.h"
 
 #include <cstdio>
@@ -214,15 +215,34 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
 // fp32 from L2, one wave per row, DPP reductions) - one launch and one activation round trip
 // less per Dense. The quantised rows live in LDS (row stride K + 16 bytes) and the MFMA A
 // fragments are read from there.
-template <int MT, int NT, int WAVES, int U, bool DUAL = false, bool NORM = false>
+template <int MT, int NT, int WAVES, int U, bool DUAL = false, int NORM = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
     GemmS8Epilogue ep) {
   constexpr int ND = DUAL ? 2 : 1;
   __shared__ int partial[ND][WAVES][MT][NT][64][4];
-  extern __shared__ __attribute__((aligned(16))) int8_t norm_lds[];  // NORM: qa rows + scales
+  // NORM (dynamic LDS): transposed fp32 rows [16][8 * pad] (row_norm.h norm_chain_slot) | gamma [K]
+  // | beta [K] | int8 A tile [16][K + 16] | row scales [16]
+  extern __shared__ __attribute__((aligned(16))) int8_t norm_lds[];
+  constexpr int NORM_CH = NORM > 0 ? NORM : 1;  // float4s per lane: K == 64 * NORM
+  static_assert(!NORM || (MT == 1 && WAVES == 4), "NORM: 16 rows on four waves, 16 lanes per row");
   const int qa_stride = K + 16;
-  float* norm_scales = reinterpret_cast<float*>(norm_lds + MT * 16 * qa_stride);
+  const int norm_pad = NORM ? norm_chain_pad(K) : 0;
+  const int norm_x_stride = 8 * norm_pad;
+  float* norm_x_lds = reinterpret_cast<float*>(norm_lds);
+  float* norm_gamma_lds = norm_x_lds + 16 * norm_x_stride;
+  float* norm_beta_lds = norm_gamma_lds + K;
+  int8_t* norm_qa_lds = reinterpret_cast<int8_t*>(norm_beta_lds + K);
+  float* norm_scales = reinterpret_cast<float*>(norm_qa_lds + 16 * qa_stride);
+  if (NORM) {
+    // this workgroup's 16-row block (grid.y): rebase the row-indexed operands
+    const int rb = blockIdx.y * 16;
+    M -= rb;
+    ep.norm_x += static_cast<int64_t>(rb) * K;
+    ep.y += static_cast<int64_t>(rb) * ep.ldy;
+    if (ep.residual) ep.residual += static_cast<int64_t>(rb) * ep.ldy;
+    if (ep.row_amax_out) ep.row_amax_out += rb;
+  }
   constexpr int THREADS = WAVES * 64;
   constexpr int OUTS = MT * NT * 256;                       // outputs of the workgroup tile
   constexpr int OPT = (OUTS + THREADS - 1) / THREADS;       // outputs per thread in the epilogue
@@ -257,95 +277,158 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     }
   }
 
+  // NORM: the weight fragments of the single K round are requested before the prologue, so the
+  // weight stream's latency hides under the normalisation
+  v4i bpre[U][NT];
   if (NORM) {
-    // One wave per row (rows wave, wave + WAVES, ...), float4 per lane and 256-element chunk
-    // (K <= 1024, K % 4 == 0). EVERY load of the prologue - gamma, beta and all of this wave's
-    // rows - is issued before the first reduction, so the prologue costs one memory round trip.
-    // Formulas: src/cpu/kernels.cc:461-496 (layer_norm), :543-573 (rms_norm), :577-651 (quantize).
-    constexpr int RPW = (MT * 16 + WAVES - 1) / WAVES;  // rows per wave
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ks = wave + u * WAVES;
+      const int kk = ks * 64 + g * 16;
+      const bool k_ok = (ks < ksteps) && (kk < K);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int64_t col = n0 + j * 16 + r;
+        bpre[u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B + col * K + kk)
+                                       : v4i{0, 0, 0, 0};
+      }
+    }
+  }
+
+  if (NORM) {
+    // FOUR ROWS PER WAVE, 16 lanes per row, 16 rows per workgroup (grid.y walks the row blocks;
+    // the weight tile is re-read per block from L2). The reference's compiled statistics are
+    // eight lane accumulators walking the row with stride 8 followed by a 4/2/1 xor tree
+    // (row_norm.h): lanes l and l + 8 of a row both run chain l, so the normalisation of a whole
+    // step is ONE pass of depth/8 dependent steps on every wave. Lane (rg, l16) loads the float4s
+    // l16, l16 + 16, ... of its row (16 lanes = 256 contiguous bytes), parks them transposed in
+    // LDS for the contiguous chain reads, keeps them in registers for the normalisation, and
+    // writes the quantised bytes to the LDS A tile.
+    // Formulas: src/cpu/kernels.cc:461-496 (layer_norm), :543-573 (rms_norm), :577-651
+    // (quantize), in the compiled order restated by oracle/ct2_oracle.c row_stats.
+    // The code below is branch-free per element on purpose (uniform choices are hoisted or turned
+    // into selects): a first version with per-element branches was 6000 instructions long and
+    // slower than the launch it replaced. Per-lane work is what bounds the prologue (a wave64
+    // VALU instruction occupies its SIMD for 4 cycles), hence 16 rows per workgroup, not 32.
+    const int rg = lane >> 4, l16 = lane & 15, l = lane & 7;
+    const int row = wave * 4 + rg;
+    const bool valid = row < M;
+    const int src_row = valid ? row : 0;        // idle lanes shadow row 0 and store nothing
     const int n4 = K / 4;
-    const int chunks = (n4 + 63) / 64;                  // 1..4
-    const float4* g4 = reinterpret_cast<const float4*>(ep.norm_gamma);
-    const float4* b4 = reinterpret_cast<const float4*>(ep.norm_beta);
-    const float fdepth = static_cast<float>(K);
-    auto norm_rows = [&](auto ch_tag) __attribute__((always_inline)) {
-      constexpr int CH = decltype(ch_tag)::value;
-      v4f gv[CH], bv[CH], xv[RPW][CH];
+    const v4f* g4 = reinterpret_cast<const v4f*>(ep.norm_gamma);
+    const v4f* b4 = reinterpret_cast<const v4f*>(ep.norm_beta);
+    const bool ln = ep.norm_beta != nullptr;
+    const v4f* xg = reinterpret_cast<const v4f*>(ep.norm_x + static_cast<int64_t>(src_row) * K) + l16;
+    v4f xv[NORM_CH];
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int i = lane + u * 64;
-        gv[u] = bv[u] = v4f{0.f, 0.f, 0.f, 0.f};
-        if (i < n4) {
-          gv[u] = *reinterpret_cast<const v4f*>(g4 + i);
-          if (ep.norm_beta != nullptr) bv[u] = *reinterpret_cast<const v4f*>(b4 + i);
+    for (int j = 0; j < NORM_CH; ++j) xv[j] = xg[16 * j];
+    for (int i = tid; i < n4; i += THREADS) {
+      reinterpret_cast<v4f*>(norm_gamma_lds)[i] = g4[i];
+      if (ln) reinterpret_cast<v4f*>(norm_beta_lds)[i] = b4[i];
+    }
+    float* my_row = norm_x_lds + row * norm_x_stride;
+    {
+      // column c = 4 * (l16 + 16 j) + e sits at (c & 7) * pad + (c >> 3)
+      float* park = my_row + ((4 * l16) & 7) * norm_pad + (l16 >> 1);
+#pragma unroll
+      for (int j = 0; j < NORM_CH; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) park[e * norm_pad + 8 * j] = xv[j][e];
+      }
+    }
+    __syncthreads();
+    float sum = 0.f, sumsq = 0.f;
+    {
+      const v4f* chain = reinterpret_cast<const v4f*>(my_row + l * norm_pad);
+      constexpr int STEPS4 = NORM_CH * 2;  // K / 8 chain steps, four per 16-byte read
+#pragma unroll
+      for (int i = 0; i < STEPS4; ++i) {
+        const v4f v = chain[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sumsq = fmaf(v[e], v[e], sumsq);
+          sum = sum + v[e];
         }
       }
+      sumsq = dpp_xor4(sumsq) + sumsq;
+      sum = dpp_xor4(sum) + sum;
+      sumsq = dpp_move<0x4E, 0xf>(0.f, sumsq) + sumsq;
+      sum = dpp_move<0x4E, 0xf>(0.f, sum) + sum;
+      sumsq = dpp_move<0xB1, 0xf>(0.f, sumsq) + sumsq;
+      sum = dpp_move<0xB1, 0xf>(0.f, sum) + sum;
+    }
+    const NormStats st = norm_stats(sum, sumsq, K, ep.norm_eps, ln);
+    const v4f* gl = reinterpret_cast<const v4f*>(norm_gamma_lds) + l16;
+    const v4f* bl = reinterpret_cast<const v4f*>(norm_beta_lds) + l16;
+    // K % 8 == 0: no column takes the 4-wide remainder form of norm_apply (row_norm.h)
+    if (ln) {
 #pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = wave + rr * WAVES;
+      for (int j = 0; j < NORM_CH; ++j) {
+        const v4f gv = gl[16 * j], bv = bl[16 * j];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int i = lane + u * 64;
-          xv[rr][u] = v4f{0.f, 0.f, 0.f, 0.f};
-          if (row < M && i < n4)
-            xv[rr][u] = *reinterpret_cast<const v4f*>(ep.norm_x + static_cast<int64_t>(row) * K + i * 4);
-        }
+        for (int e = 0; e < 4; ++e) xv[j][e] = fmaf(xv[j][e] - st.mean, st.mul * gv[e], bv[e]);
       }
-      if (ep.norm_beta == nullptr && ep.norm_rms_residual) {
+    } else if (ep.norm_rms_residual) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) gv[u] = gv[u] + 1.f;
+      for (int j = 0; j < NORM_CH; ++j) {
+        const v4f gv = gl[16 * j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[j][e] = (st.mul * xv[j][e]) * (gv[e] + 1.f);
       }
+    } else {
 #pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = wave + rr * WAVES;
-        if (row >= M) continue;  // wave-uniform
-        float sum = 0.f, sumsq = 0.f;
+      for (int j = 0; j < NORM_CH; ++j) {
+        const v4f gv = gl[16 * j];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const v4f v = xv[rr][u];
-          sum += v[0] + v[1] + v[2] + v[3];
-          sumsq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        for (int e = 0; e < 4; ++e) xv[j][e] = (xv[j][e] * gv[e]) * st.mul;
+      }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < NORM_CH; ++j)
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(xv[j][0]), fabsf(xv[j][1])),
+                               fmaxf(fabsf(xv[j][2]), fabsf(xv[j][3]))));
+    amax = fmaxf(amax, dpp_move<0x140, 0xf>(0.f, amax));  // row_mirror: lane i <- lane 15 - i
+    amax = fmaxf(amax, dpp_xor4(amax));
+    amax = fmaxf(amax, dpp_move<0x4E, 0xf>(0.f, amax));
+    amax = fmaxf(amax, dpp_move<0xB1, 0xf>(0.f, amax));
+    const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+    const bool q_shift = (ep.quant_mode & kQuantU8Shift) != 0;
+    const bool q_round = (ep.quant_mode & kQuantRound) != 0;
+    if (valid) {
+      if (l16 == 0) norm_scales[row] = scale;
+      int* qr = reinterpret_cast<int*>(norm_qa_lds + row * qa_stride) + l16;
+      if (q_shift && q_round) {
+        // the x86 default (u8 shift + round to nearest even): three VALU ops per element, the four
+        // low bytes gathered by two v_perm, and "- 128" on every byte as one xor
+#pragma unroll
+        for (int j = 0; j < NORM_CH; ++j) {
+          int b[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[e] = static_cast<int>(rintf(fmaf(xv[j][e], scale, 128.f)));
+          const unsigned lo = __builtin_amdgcn_perm(static_cast<unsigned>(b[1]),
+                                                    static_cast<unsigned>(b[0]), 0x0c0c0400u);
+          const unsigned hi = __builtin_amdgcn_perm(static_cast<unsigned>(b[3]),
+                                                    static_cast<unsigned>(b[2]), 0x04000c0cu);
+          qr[16 * j] = static_cast<int>((lo | hi) ^ 0x80808080u);
         }
-        sum = wave_sum_dpp(sum);
-        sumsq = wave_sum_dpp(sumsq);
-        v4f y[CH];
-        if (ep.norm_beta != nullptr) {
-          const float mean = sum / fdepth;
-          const float variance = fmaxf(sumsq / fdepth - mean * mean, 0.f);
-          const float rstd = 1.f / sqrtf(variance + ep.norm_eps);
+      } else {
 #pragma unroll
-          for (int u = 0; u < CH; ++u) y[u] = (xv[rr][u] - mean) * rstd * gv[u] + bv[u];
-        } else {
-          const float inv_rms = 1.f / sqrtf(sumsq / fdepth + ep.norm_eps);
+        for (int j = 0; j < NORM_CH; ++j) {
+          int packed = 0;
 #pragma unroll
-          for (int u = 0; u < CH; ++u) y[u] = xv[rr][u] * inv_rms * gv[u];
-        }
-        float amax = 0.f;
-#pragma unroll
-        for (int u = 0; u < CH; ++u)
-          if (lane + u * 64 < n4)
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(y[u][0]), fabsf(y[u][1])),
-                                     fmaxf(fabsf(y[u][2]), fabsf(y[u][3]))));
-        amax = wave_max_dpp(amax);
-        const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
-        if (lane == 0) norm_scales[row] = scale;
-        char4* qr = reinterpret_cast<char4*>(norm_lds + row * qa_stride);
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int i = lane + u * 64;
-          if (i < n4) {
-            char4 o;
-            o.x = to_s8(y[u][0], scale, ep.quant_mode);
-            o.y = to_s8(y[u][1], scale, ep.quant_mode);
-            o.z = to_s8(y[u][2], scale, ep.quant_mode);
-            o.w = to_s8(y[u][3], scale, ep.quant_mode);
-            qr[i] = o;
+          for (int e = 0; e < 4; ++e) {
+            // to_s8 (device_utils.h) with the two uniform mode bits as selects
+            float v = q_shift ? fmaf(xv[j][e], scale, 128.f) : xv[j][e] * scale;
+            v = q_round ? rintf(v) : v;
+            const int i32 = static_cast<int>(v);
+            const int b = q_shift ? ((i32 & 0xff) - 128) : i32;
+            packed |= (b & 0xff) << (8 * e);
           }
+          qr[16 * j] = packed;
         }
       }
-    };
-    if (chunks <= 2) norm_rows(std::integral_constant<int, 2>{});
-    else norm_rows(std::integral_constant<int, 4>{});
+    }
     __syncthreads();
   }
 
@@ -370,7 +453,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
         const int row = i * 16 + r;
         if (NORM)
           af[u][i] = (k_ok && row < M)
-                         ? *reinterpret_cast<const v4i*>(norm_lds + row * qa_stride + kk)
+                         ? *reinterpret_cast<const v4i*>(norm_qa_lds + row * qa_stride + kk)
                          : v4i{0, 0, 0, 0};
         else
           af[u][i] = (k_ok && row < M)
@@ -380,8 +463,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int64_t col = n0 + j * 16 + r;
-        bf[0][u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B + col * K + kk)
-                                        : v4i{0, 0, 0, 0};
+        if (NORM)
+          bf[0][u][j] = bpre[u][j];
+        else
+          bf[0][u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B + col * K + kk)
+                                          : v4i{0, 0, 0, 0};
         if (DUAL)
           bf[ND - 1][u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B2 + col * K + kk)
                                                : v4i{0, 0, 0, 0};
@@ -481,18 +567,22 @@ __global__ void gemm_s8_naive_kernel(const int8_t* __restrict__ A, const int8_t*
 
 }  // namespace
 
+// Shapes the norm-prologue form serves: decode rows (<= 128, in blocks of 16 rows per workgroup), a
+// row that fits the float4 registers a lane keeps (K = 64, 128, 256 or 512: one compiled
+// form per depth, no per-element bounds) and a
+// projection narrow enough that redoing the norm in every workgroup is cheaper than a launch
+// (N < 8192: the vocabulary projection keeps its own norm launch).
 bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k) {
-  return m >= 1 && m <= 32 && k >= 64 && k <= 1024 && k % 16 == 0 && n >= 1;
+  return m >= 1 && m <= 128 && (k == 64 || k == 128 || k == 256 || k == 512) && n >= 1 && n < 8192;
 }
 
-// Measured on MI355X (tools/op_time.py, bench.py): the prologue makes every workgroup redo the
-// norm of all rows with one wave per row - ~2000 dependent VALU issues per wave - which costs MORE
-// than the launch it saves (Transformer-base step 24.3 -> 35 ms per 64 steps; [32, 512] x 512:
-// ~10 us fused vs 2.7 + 2.8 us as two launches). The engine therefore only uses it on request.
+// Round 1 measured a one-wave-per-row prologue at ~10 us (eight dependent row reductions per
+// wave) and switched it off. The eight-rows-per-wave form runs the same arithmetic in one pass
+// (see the kernel); CT2X_NORM_FUSION=0 restores the separate norm launch (bit-identical).
 bool gemm_s8_norm_fusion_enabled() {
   static const bool enabled = [] {
     const char* e = std::getenv("CT2X_NORM_FUSION");
-    return e != nullptr && e[0] == '1';
+    return e == nullptr || e[0] != '0';
   }();
   return enabled;
 }
@@ -521,19 +611,20 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
   if (ep.norm_x != nullptr) {
     // Norm + Quantize prologue (gemm_s8_norm_applicable): decode rows of a pre-norm Dense.
     if (!(mfma_ok && gemm_s8_norm_applicable(m, n, k) && ep.mode == 1 && ep.b2 == nullptr))
-      throw Error("launch_gemm_s8: the norm-prologue form needs M <= 32, K <= 1024, K % 16 == 0");
-    const size_t lds = static_cast<size_t>(m <= 16 ? 16 : 32) * (k + 16) + 32 * sizeof(float);
-#define CT2X_NORMG(MT, NT, WAVES, U)                                                              \
-  hipLaunchKernelGGL((gemm_s8_skinny_kernel<MT, NT, WAVES, U, false, true>),                      \
-                     dim3((n + 16 * NT - 1) / (16 * NT)), dim3(WAVES * 64), lds, stream, a, b, M, N, \
-                     K, ep)
-    if (m <= 16) {
-      if (n >= 8192) CT2X_NORMG(1, 4, 4, 2);
-      else CT2X_NORMG(1, 1, 4, 4);
-    } else {
-      if (n >= 8192) CT2X_NORMG(2, 4, 4, 2);
-      else CT2X_NORMG(2, 1, 4, 4);
-    }
+      throw Error("launch_gemm_s8: the norm-prologue form needs M <= 128, K in {64, 128, 256, 512}, N < 8192");
+    const size_t lds = 16 * 8 * static_cast<size_t>(norm_chain_pad(k)) * sizeof(float) +
+                       2 * k * sizeof(float) + 16 * (k + 16) + 16 * sizeof(float);
+#define CT2X_NORMG(CH)                                                                            \
+  do {                                                                                            \
+    auto fn = gemm_s8_skinny_kernel<1, 1, 4, 4, false, CH>;                                       \
+    allow_big_lds(reinterpret_cast<const void*>(fn), lds);                                        \
+    hipLaunchKernelGGL(fn, dim3((n + 15) / 16, (m + 15) / 16), dim3(256), lds, stream, a, b, M, N, \
+                       K, ep);                                                                    \
+  } while (0)
+    if (k == 512) CT2X_NORMG(8);
+    else if (k == 256) CT2X_NORMG(4);
+    else if (k == 128) CT2X_NORMG(2);
+    else CT2X_NORMG(1);
 #undef CT2X_NORMG
     return;
   }

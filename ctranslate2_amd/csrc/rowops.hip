@@ -313,25 +313,29 @@ __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict
 }
 
 
-// Register-resident variant for the decoder shapes (depth % 4 == 0, depth <= 4 * 256 * kNormChunks):
-// every lane keeps its float4 chunks in VGPRs (and drops a copy into the LDS row for the ordered
-// statistics); all loads are issued before the first use.
-constexpr int kNormChunks = 4;
-
+// Register-resident variant for the decoder shapes (depth % 4 == 0, depth <= 4096): every lane
+// keeps its CH float4 chunks in VGPRs and drops a TRANSPOSED copy into LDS for the ordered
+// statistics (row_norm.h ordered_row_stats_t); all loads are issued before the first use. Rows of
+// <= 1024 elements run as ONE wave (no block barrier on the way to the absmax), wider rows as four.
+// Phase costs measured with tools/norm_probe.cpp ([32, 512], cycles): loads 850, strided chains
+// 2500 -> contiguous chains, ds_bpermute block max 1130 -> DPP, stats + apply 670, quantize 630.
+template <int CH>
 __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, int64_t depth, float eps,
-                                bool rms_use_residual, int quant_mode, float* __restrict__ y,
-                                int8_t* __restrict__ q, float* __restrict__ scales) {
-  extern __shared__ __attribute__((aligned(16))) float row_buf[];
+                                bool rms_use_residual, int quant_mode, int pad,
+                                float* __restrict__ y, int8_t* __restrict__ q,
+                                float* __restrict__ scales) {
+  extern __shared__ __attribute__((aligned(16))) float chain_buf[];
   __shared__ float scratch[32];
   const int64_t row = blockIdx.x;
   const int n4 = static_cast<int>(depth / 4);
+  const int vsize = static_cast<int>(depth - depth % 8);
   const float4* xr = reinterpret_cast<const float4*>(x + row * depth);
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
   const float4* b4 = reinterpret_cast<const float4*>(beta);
-  float4 v[kNormChunks], gv[kNormChunks], bv[kNormChunks];
+  float4 v[CH], gv[CH], bv[CH];
 #pragma unroll
-  for (int u = 0; u < kNormChunks; ++u) {
+  for (int u = 0; u < CH; ++u) {
     const int i = threadIdx.x + u * blockDim.x;
     v[u] = gv[u] = bv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n4) {
@@ -341,18 +345,24 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
     }
   }
 #pragma unroll
-  for (int u = 0; u < kNormChunks; ++u) {
+  for (int u = 0; u < CH; ++u) {
     const int i = threadIdx.x + u * blockDim.x;
-    if (i < n4) reinterpret_cast<float4*>(row_buf)[i] = v[u];
+    if (i < n4) {
+      const int c = 4 * i;
+      chain_buf[norm_chain_slot(c, vsize, pad)] = v[u].x;
+      chain_buf[norm_chain_slot(c + 1, vsize, pad)] = v[u].y;
+      chain_buf[norm_chain_slot(c + 2, vsize, pad)] = v[u].z;
+      chain_buf[norm_chain_slot(c + 3, vsize, pad)] = v[u].w;
+    }
   }
   __syncthreads();
   float sum, sumsq;
-  ordered_row_stats(row_buf, depth, sum, sumsq);
+  ordered_row_stats_t(chain_buf, pad, depth, sum, sumsq);  // every wave, redundantly
   const bool ln = beta != nullptr;
   const NormStats st = norm_stats(sum, sumsq, depth, eps, ln);
   float amax = 0.f;
 #pragma unroll
-  for (int u = 0; u < kNormChunks; ++u) {
+  for (int u = 0; u < CH; ++u) {
     const int c = 4 * (threadIdx.x + u * blockDim.x);
     v[u].x = norm_apply(v[u].x, gv[u].x, bv[u].x, st, ln, rms_use_residual, c);
     v[u].y = norm_apply(v[u].y, gv[u].y, bv[u].y, st, ln, rms_use_residual, c + 1);
@@ -360,7 +370,7 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
     v[u].w = norm_apply(v[u].w, gv[u].w, bv[u].w, st, ln, rms_use_residual, c + 3);
   }
 #pragma unroll
-  for (int u = 0; u < kNormChunks; ++u) {
+  for (int u = 0; u < CH; ++u) {
     const int i = threadIdx.x + u * blockDim.x;
     if (i < n4) {
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
@@ -368,12 +378,12 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
     }
   }
   if (q != nullptr) {
-    amax = block_max(amax, scratch);
+    amax = (blockDim.x == 64) ? wave_max(amax) : block_max(amax, scratch);
     const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
     if (threadIdx.x == 0) scales[row] = scale;
     char4* qr = reinterpret_cast<char4*>(q + row * depth);
 #pragma unroll
-    for (int u = 0; u < kNormChunks; ++u) {
+    for (int u = 0; u < CH; ++u) {
       const int i = threadIdx.x + u * blockDim.x;
       if (i < n4) {
         char4 o;
@@ -394,12 +404,19 @@ void launch_norm(const float* x, const float* gamma, const float* beta, int64_t 
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) |
                          reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(y) |
                          reinterpret_cast<uintptr_t>(q)) & 15) == 0;
-  if (depth % 4 == 0 && depth <= 4 * 256 * kNormChunks && aligned) {
-    int threads = 64;
-    while (threads * kNormChunks * 4 < depth || (threads < 256 && threads * 4 < depth)) threads <<= 1;
-    if (threads > 256) threads = 256;
-    hipLaunchKernelGGL(norm_vec_kernel, dim3(rows), dim3(threads), depth * sizeof(float), stream,
-                       x, gamma, beta, depth, eps, rms_use_residual, quant_mode, y, q, scales);
+  if (depth % 4 == 0 && depth <= 4096 && aligned) {
+    const int n4 = static_cast<int>(depth / 4);
+    const int threads = depth <= 1024 ? 64 : 256;
+    const int ch = (n4 + threads - 1) / threads;  // 1..4
+    const int pad = norm_chain_pad(depth);
+    const size_t lds = (static_cast<size_t>(8) * pad + 8) * sizeof(float);
+#define CT2X_NORMV(CH)                                                                          \
+  hipLaunchKernelGGL(norm_vec_kernel<CH>, dim3(rows), dim3(threads), lds, stream, x, gamma, beta, \
+                     depth, eps, rms_use_residual, quant_mode, pad, y, q, scales)
+    if (ch <= 1) CT2X_NORMV(1);
+    else if (ch == 2) CT2X_NORMV(2);
+    else CT2X_NORMV(4);
+#undef CT2X_NORMV
     return;
   }
   int block = 64;

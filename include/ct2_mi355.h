@@ -145,8 +145,9 @@ int ct2x_gemm_s8_glu(const int8_t* d_qa, const float* d_a_scale, const int8_t* d
 
 /* A pre-norm int8 Dense at decode rows as ONE launch: layers::LayerNorm (LayerNorm when d_beta is
  * given, RMSNorm otherwise; src/layers/common.cc:464-472) -> ops::Quantize -> Gemm -> Dequantize
- * (+bias, activation) -> Add(residual). m <= 32, k <= 1024, k % 16 == 0. quant_flags as in
- * ct2x_quantize_s8. */
+ * (+bias, activation) -> Add(residual); bit-identical to ct2x_norm_quantize_s8 followed by
+ * ct2x_gemm_s8_dequant. m <= 128, k in {64, 128, 256, 512}, n < 8192 (an error otherwise).
+ * quant_flags as in ct2x_quantize_s8. */
 int ct2x_norm_gemm_s8_dequant(const float* d_x, const float* d_gamma, const float* d_beta, float eps,
                               int rms_use_residual, int quant_flags, const int8_t* d_w,
                               const float* d_w_scale, const float* d_bias, const float* d_residual,

@@ -235,15 +235,16 @@ def test_norm_quantize_fused(gpu, rows, depth, rms, rbc):
     assert np.array_equal(q2, q) and np.array_equal(s2, s)
 
 
-@pytest.mark.parametrize("m,n,k", [(32, 1536, 512), (32, 32000, 512), (16, 512, 1024), (5, 48, 64)])
+@pytest.mark.parametrize("m,n,k", [(32, 1536, 512), (32, 512, 512), (32, 2048, 512), (16, 512, 256),
+                                   (17, 100, 256), (5, 48, 64), (1, 512, 512), (9, 640, 128),
+                                   (128, 512, 512), (100, 1536, 512)])
 @pytest.mark.parametrize("rms", [False, True])
 @pytest.mark.parametrize("act,with_res", [(-1, True), (0, False)])
 def test_norm_gemm_fused(gpu, m, n, k, rms, act, with_res):
-    """Pre-norm Dense as one launch (norm + Quantize as the GEMM prologue) against the two-launch
-    path (ct2x_norm_quantize_s8 + ct2x_gemm_s8_dequant). The prologue reduces a row inside one wave
-    instead of one workgroup, so mean / variance / absmax may differ in the last ulp (the whole
-    row then moves by ~1e-7 relative) and, rarely, one int8 activation flips (an output moves by
-    at most |w|max / a_scale)."""
+    """Pre-norm Dense as one launch (LayerNorm / RMSNorm + Quantize as the GEMM prologue, eight
+    rows per wave) against the two-launch path (ct2x_norm_quantize_s8 + ct2x_gemm_s8_dequant): the
+    prologue runs the reference's compiled summation order (row_norm.h), so both must agree BIT
+    FOR BIT."""
     import _gpuops as G
     rng = np.random.default_rng(m + n + k + int(rms))
     x = (rng.standard_normal((m, k)) * 1.5).astype(np.float32)
@@ -256,12 +257,19 @@ def test_norm_gemm_fused(gpu, m, n, k, rms, act, with_res):
     y = G.norm_gemm_s8_dequant(x, gamma, beta, eps, 3, wq, ws, bias, res, act)
     _, q, s = G.norm_quantize_s8(x, gamma, beta, eps, False, 3, False)
     y2 = G.gemm_s8_dequant(q, s, wq, ws, bias, res, act)
-    # last-ulp differences of the row scale move a whole row by ~1e-7 relative; a flipped
-    # activation moves an output by one weight quantum
-    close = np.abs(y - y2) <= 2e-6 * np.maximum(np.abs(y2), 1.0)
-    assert close.mean() >= 0.98, close.mean()
-    quantum = (127.0 / ws.min()) / s            # |w|max * (row absmax / 127), per row
-    assert np.all(np.abs(y - y2) <= 3 * quantum[:, None] + 1e-6)
+    assert np.array_equal(y, y2)
+
+
+def test_norm_gemm_fused_envelope(gpu):
+    """Outside the envelope (K not 64 / 128 / 256 / 512, more than 128 rows, the vocabulary projection) the entry point
+    refuses instead of computing something else."""
+    import _gpuops as G
+    rng = np.random.default_rng(0)
+    for m, n, k in [(16, 512, 1024), (129, 512, 512), (32, 32000, 512), (8, 64, 96), (16, 512, 448)]:
+        x = rng.standard_normal((m, k)).astype(np.float32)
+        wq, ws = O.quantize_s8(rng.standard_normal((n, k)).astype(np.float32), True)
+        with pytest.raises(RuntimeError):
+            G.norm_gemm_s8_dequant(x, np.ones(k, np.float32), None, 1e-6, 3, wq, ws, None, None, -1)
 
 
 @pytest.mark.parametrize("rows,depth", [(256, 36), (32, 32000), (8, 128256), (5, 7), (64, 64)])

@@ -92,6 +92,11 @@ int main(int argc, char** argv) {
     run("gemm_s8_dequant [M,2048,512] rotating 40MB weights", (double)M * 512 + 2048.0 * 512 + 4.0 * M * 2048,
         [&] { CX(ct2x_gemm_s8_dequant(q, qs, wbig2 + (size_t)(idx++ % 40) * 512 * 2048, wscale, bias, nullptr, M, 2048, 512, -1, y, 0, s)); });
   }
+  for (int n : {512, 1536, 2048}) {
+    char name[128]; snprintf(name, sizeof name, "norm_gemm_s8_dequant (LN prologue) [M,%d,512]", n);
+    run(name, M * 512.0 * 4 + n * 512.0 + 4.0 * M * n,
+        [&] { CX(ct2x_norm_gemm_s8_dequant(x, gamma, beta, 1e-5f, 0, 3, w, wscale, bias, nullptr, M, n, 512, -1, y, s)); });
+  }
   run("gemm_s8_dequant+residual [M,512,512]", 0, [&] { CX(ct2x_gemm_s8_dequant(q, qs, w, wscale, bias, res, M, 512, 512, -1, y, 0, s)); });
   for (int t : {1, 16, 32, 64}) {
     char name[128]; snprintf(name, sizeof name, "attention_decode rows=%d H=8 dh=64 T=%d", M, t);
