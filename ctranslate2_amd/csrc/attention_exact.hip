@@ -114,6 +114,11 @@ struct AttnXArgs {
 
 constexpr int XVB = 16;      // V rows per batch (two blocks of eight)
 
+// tools/attn_probe.cpp defines this to stamp the phases with s_memtime
+#ifndef CT2X_ATTN_STAMP
+#define CT2X_ATTN_STAMP(i)
+#endif
+
 template <int DH>
 __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -166,16 +171,23 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
                     !(p.one_row_step_ptr != nullptr && *p.one_row_step_ptr == p.one_row_step);
 
   float acc_out = 0.f;
+  CT2X_ATTN_STAMP(0)
   if (active) {
     // Every global load of the launch that does not depend on another is requested up front -
     // the first K tile, q, the new key / value, then (below) the first batch of V rows - so that
     // the prologue and both phases share ONE memory round trip.
+    // (only the keys that exist are staged: an iteration covers 64 / R4 keys; the K tile's LDS
+    // traffic - 32 KB per wave for 64 keys - is what bounds the QK^T phase)
+    constexpr int KPI = 64 / R4;  // keys per staging iteration
     v4f kpre[R4];
 #pragma unroll
     for (int it = 0; it < R4; ++it) {
-      const int i_ = it * 64 + lane;  // R4 float4 per row
-      const int tl = min(i_ / R4, t_last);
-      kpre[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+      kpre[it] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (it * KPI < n_keys) {
+        const int i_ = it * 64 + lane;  // R4 float4 per row
+        const int tl = min(i_ / R4, t_last);
+        kpre[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+      }
     }
     // ---- prologue: lane = channel ---------------------------------------------------------
     float knew = 0.f, vnew = 0.f, tq_pending = 0.f;
@@ -202,14 +214,22 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
     const float g_ = vc[min(t_, t_last) * kvs + cl];                      \
     VR[j] = (has_new && t_ == pos) ? vnew : g_;                           \
   }
-    float va[XVB], vb[XVB];
-    CT2X_XLOAD_V(va, 0)
+    // (four batches = 64 keys: a decode step of Transformer-base never waits for V twice)
+    float vr[4][XVB];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (b * XVB < n_keys) CT2X_XLOAD_V(vr[b], b * XVB)
     if (chan) tq[cl] = tq_pending;
     __builtin_amdgcn_wave_barrier();
+    CT2X_ATTN_STAMP(1)
 
     // ---- QK^T: lane = key -------------------------------------------------------------------
     const int main_n = (n_keys / 4) * 4;
+    float s_reg = 0.f;        // this lane's score of the LAST tile (the only one when n_keys <= 64)
+    float m_run = -FLT_MAX;   // running maximum over the valid keys this lane has seen
+    const bool single = n_keys <= 64;
     for (int t0 = 0; t0 < n_keys; t0 += 64) {
+      const int n_tile = min(64, n_keys - t0);
       v4f st[R4];
       if (t0 == 0) {
 #pragma unroll
@@ -217,57 +237,79 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
       } else {
 #pragma unroll
         for (int it = 0; it < R4; ++it) {
-          const int i_ = it * 64 + lane;  // R4 float4 per row
-          const int tl = min(t0 + i_ / R4, t_last);
-          st[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+          st[it] = v4f{0.f, 0.f, 0.f, 0.f};
+          if (it * KPI < n_tile) {
+            const int i_ = it * 64 + lane;  // R4 float4 per row
+            const int tl = min(t0 + i_ / R4, t_last);
+            st[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int it = 0; it < R4; ++it) {
-        const int i_ = it * 64 + lane;
-        *reinterpret_cast<v4f*>(ks + (i_ / R4) * XKS + (i_ % R4) * 4) = st[it];
+        if (it * KPI < n_tile) {
+          const int i_ = it * 64 + lane;
+          *reinterpret_cast<v4f*>(ks + (i_ / R4) * XKS + (i_ % R4) * 4) = st[it];
+        }
       }
       __builtin_amdgcn_wave_barrier();
       if (has_new && chan && pos >= t0 && pos < t0 + 64) ks[(pos - t0) * XKS + cl] = knew;
       __builtin_amdgcn_wave_barrier();
-      float qv[DH], kv[DH];
-      const v4f* krow = reinterpret_cast<const v4f*>(ks + lane * XKS);
-      const v4f* qrow = reinterpret_cast<const v4f*>(tq);
-#pragma unroll
-      for (int c = 0; c < R4; ++c) {
-        const v4f k4 = krow[c], q4 = qrow[c];
-        kv[4 * c + 0] = k4.x; kv[4 * c + 1] = k4.y; kv[4 * c + 2] = k4.z; kv[4 * c + 3] = k4.w;
-        qv[4 * c + 0] = q4.x; qv[4 * c + 1] = q4.y; qv[4 * c + 2] = q4.z; qv[4 * c + 3] = q4.w;
-      }
       const int t = t0 + lane;
-      float s;
-      if (kSeq) {
-        s = dot_seq<DH>(qv, kv);
-      } else if (t < main_n) {
-        s = dot_main<DH>(qv, kv);
-      } else {
-        s = dot_tail<DH>(qv, kv, (t - main_n) != 1);
+      float s = 0.f;
+      if (lane < n_tile) {
+        float qv[DH], kv[DH];
+        const v4f* krow = reinterpret_cast<const v4f*>(ks + lane * XKS);
+        const v4f* qrow = reinterpret_cast<const v4f*>(tq);
+#pragma unroll
+        for (int c = 0; c < R4; ++c) {
+          const v4f k4 = krow[c], q4 = qrow[c];
+          kv[4 * c + 0] = k4.x; kv[4 * c + 1] = k4.y; kv[4 * c + 2] = k4.z; kv[4 * c + 3] = k4.w;
+          qv[4 * c + 0] = q4.x; qv[4 * c + 1] = q4.y; qv[4 * c + 2] = q4.z; qv[4 * c + 3] = q4.w;
+        }
+        if (kSeq) {
+          s = dot_seq<DH>(qv, kv);
+        } else if (t < main_n) {
+          s = dot_main<DH>(qv, kv);
+        } else {
+          s = dot_tail<DH>(qv, kv, (t - main_n) != 1);
+        }
+        s = s * p.scale;
+        if (!single) tp[t] = s;
+        if (t < n_valid) m_run = fmaxf(m_run, s);
       }
-      if (t < n_keys) tp[t] = s * p.scale;
+      s_reg = s;
       __builtin_amdgcn_wave_barrier();
     }
 
+    CT2X_ATTN_STAMP(2)
     // ---- SoftMax over the n_valid leading keys; masked keys get probability 0 ---------------
-    float m = -FLT_MAX;
-    for (int t = lane; t < n_valid; t += 64) m = fmaxf(m, tp[t]);
-    m = wave_max_dpp(m);
-    for (int t = lane; t < a.t_pad; t += 64) {
-      const float sc = tp[t];
-      tp[t] = (t < n_valid) ? exp_avx2(sc - m) : 0.f;
+    // (the scores of a single tile never visit LDS: maximum, exp and the scaling run on the
+    // register copy; LDS sees the exps once for the ordered sum and the probabilities once for P.V)
+    const float m = wave_max_dpp(m_run);
+    float e_reg = 0.f;
+    if (single) {
+      e_reg = (lane < n_valid) ? exp_avx2(s_reg - m) : 0.f;
+      for (int t = lane; t < a.t_pad; t += 64) tp[t] = (t == lane) ? e_reg : 0.f;
+    } else {
+      for (int t = lane; t < a.t_pad; t += 64) {
+        const float sc = tp[t];
+        tp[t] = (t < n_valid) ? exp_avx2(sc - m) : 0.f;
+      }
     }
     __builtin_amdgcn_wave_barrier();
-    const float esum = ordered_sum8(tp, n_valid);
+    const float esum = ordered_sum8_short(tp, n_valid);
     const float rcp = 1.f / esum;
     __builtin_amdgcn_wave_barrier();
-    for (int t = lane; t < n_valid; t += 64) tp[t] = tp[t] * rcp;
+    if (single) {
+      if (lane < n_valid) tp[lane] = e_reg * rcp;
+    } else {
+      for (int t = lane; t < n_valid; t += 64) tp[t] = tp[t] * rcp;
+    }
     __builtin_amdgcn_wave_barrier();
 
+    CT2X_ATTN_STAMP(3)
     // ---- P.V: lane = channel --------------------------------------------------------------
     float y = 0.f;
     bool has = false;
@@ -295,18 +337,30 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
       }                                                                                      \
     }                                                                                        \
   }
-    for (int t0 = 0; t0 < n_keys; t0 += 2 * XVB) {
-      CT2X_XLOAD_V(vb, t0 + XVB)
-      CT2X_XBLOCK(va, 0, t0)
-      if (t0 + 8 < n_keys) CT2X_XBLOCK(va, 8, t0 + 8)
-      if (!(t0 + XVB < n_keys)) break;
-      CT2X_XLOAD_V(va, t0 + 2 * XVB)
-      CT2X_XBLOCK(vb, 0, t0 + XVB)
-      if (t0 + XVB + 8 < n_keys) CT2X_XBLOCK(vb, 8, t0 + XVB + 8)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b * XVB < n_keys) {
+        CT2X_XBLOCK(vr[b], 0, b * XVB)
+        if (b * XVB + 8 < n_keys) CT2X_XBLOCK(vr[b], 8, b * XVB + 8)
+      }
+    }
+    if (n_keys > 4 * XVB) {  // longer rows: two batches in flight, alternating
+      CT2X_XLOAD_V(vr[0], 4 * XVB)
+      for (int t0 = 4 * XVB; t0 < n_keys; t0 += 2 * XVB) {
+        CT2X_XLOAD_V(vr[1], t0 + XVB)
+        CT2X_XBLOCK(vr[0], 0, t0)
+        if (t0 + 8 < n_keys) CT2X_XBLOCK(vr[0], 8, t0 + 8)
+        if (!(t0 + XVB < n_keys)) break;
+        CT2X_XLOAD_V(vr[0], t0 + 2 * XVB)
+        CT2X_XBLOCK(vr[1], 0, t0 + XVB)
+        if (t0 + XVB + 8 < n_keys) CT2X_XBLOCK(vr[1], 8, t0 + XVB + 8)
+      }
     }
 #undef CT2X_XLOAD_V
 #undef CT2X_XBLOCK
     acc_out = y;
+    asm volatile("" ::"v"(acc_out));
+    CT2X_ATTN_STAMP(4)
   }
 
   if (a.q_out == nullptr) {
@@ -325,6 +379,7 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
   if (active && chan)
     a.q_out[static_cast<int64_t>(row) * (p.heads * DH) + hq * DH + cl] =
         to_s8(acc_out, qscale, a.quant_mode);
+  CT2X_ATTN_STAMP(5)
 }
 
 // Sequence mode (encoder self-attention, prompt prefill), d_head = 64: the reference runs

@@ -281,6 +281,36 @@ __device__ __forceinline__ float logf_glibc(float x) {
 // eight strided partial sums, reduce_m256 (lane l + l^4, + l^2, + l^1), then the scalar tail; a
 // row of <= 8 elements is summed front to back. `e` is LDS (or global) memory written by this
 // wave; every lane of the wave returns the sum.
+__device__ __forceinline__ float dpp_xor4(float v) {
+  const float m = dpp_move<0x141, 0xf>(0.f, v);  // row_half_mirror: lane i <- lane 7 - i (per 8)
+  return dpp_move<0x1B, 0xf>(0.f, m);             // quad_perm [3,2,1,0]: lane i <- lane i ^ 3
+}
+
+// ordered_sum8 for rows of <= 64 elements (the decode attention's scores): the <= 8 addends of
+// every chain and the <= 7 tail elements are requested together (one LDS round trip instead of one
+// per addend; adding the +0.f of an absent addend leaves a sum of exps unchanged) and the
+// 4 / 2 / 1 tree runs on the DPP network. Longer rows take the loop form.
+__device__ __forceinline__ float ordered_sum8(const float* e, int size);
+__device__ __forceinline__ float ordered_sum8_short(const float* e, int size) {
+  if (size > 64 || size <= 8) return ordered_sum8(e, size);
+  const int l = threadIdx.x & 7;
+  const int vsize = size & ~7;
+  float a[8], t[7];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = (l + 8 * k < vsize) ? e[l + 8 * k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) t[k] = (vsize + k < size) ? e[vsize + k] : 0.f;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc = acc + a[k];
+  acc = acc + dpp_xor4(acc);
+  acc = acc + dpp_move<0x4E, 0xf>(0.f, acc);
+  acc = acc + dpp_move<0xB1, 0xf>(0.f, acc);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) acc = acc + t[k];
+  return acc;
+}
+
 __device__ __forceinline__ float ordered_sum8(const float* e, int size) {
   const int lane = threadIdx.x & 63;
   float acc = 0.f;

@@ -234,12 +234,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
   float* norm_beta_lds = norm_gamma_lds + K;
   int8_t* norm_qa_lds = reinterpret_cast<int8_t*>(norm_beta_lds + K);
   float* norm_scales = reinterpret_cast<float*>(norm_qa_lds + 16 * qa_stride);
-  if (NORM) {
-    // this workgroup's 16-row block (grid.y): rebase the row-indexed operands
-    const int rb = blockIdx.y * 16;
+  if (blockIdx.y != 0) {
+    // this workgroup's block of MT * 16 rows (grid.y): rebase the row-indexed operands. Many
+    // short row blocks beat one tall workgroup per column tile: [128, 512] x 512 runs 6.9 us as
+    // 32 workgroups of 8 row tiles and 4.7 us as 256 workgroups of one (the weight tile is
+    // re-read per block, from L2).
+    const int rb = blockIdx.y * (MT * 16);
     M -= rb;
-    ep.norm_x += static_cast<int64_t>(rb) * K;
-    ep.y += static_cast<int64_t>(rb) * ep.ldy;
+    if (NORM) ep.norm_x += static_cast<int64_t>(rb) * K;
+    else A += static_cast<int64_t>(rb) * K;
+    if (ep.a_scale) ep.a_scale += rb;
+    if (ep.c_i32) ep.c_i32 += static_cast<int64_t>(rb) * ep.ldy;
+    if (ep.y) ep.y += static_cast<int64_t>(rb) * ep.ldy;
     if (ep.residual) ep.residual += static_cast<int64_t>(rb) * ep.ldy;
     if (ep.row_amax_out) ep.row_amax_out += rb;
   }
@@ -653,9 +659,23 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
     // Decode-step shapes (rows = batch * beam): one memory round trip per launch
     // (see gemm_s8_skinny_kernel). MT = row tiles of 16, NT = column tiles per workgroup.
 #define CT2X_SKINNY(MT, NT, WAVES, U)                                                          \
-  hipLaunchKernelGGL((gemm_s8_skinny_kernel<MT, NT, WAVES, U>), dim3((n + 16 * NT - 1) / (16 * NT)), \
+  hipLaunchKernelGGL((gemm_s8_skinny_kernel<MT, NT, WAVES, U>),                                \
+                     dim3((n + 16 * NT - 1) / (16 * NT), (m + 16 * MT - 1) / (16 * MT)),       \
                      dim3(WAVES * 64), 0, stream, a, b, M, N, K, ep)
-    const int mt = m <= 16 ? 1 : (m <= 32 ? 2 : (m <= 64 ? 4 : 8));
+    // Rows beyond 16 are split into row blocks (grid.y) of `mt` 16-row tiles; one tile per block
+    // measured best at every decode shape of Transformer-base ([32|64|128, 512] x 512: 2.7 us
+    // against 3.2 / 4.5 / 7.0 us with 2 / 4 / 8 tiles per workgroup; tools/kernel_bench.cpp).
+    static const int mt_env = [] {
+      const char* e = std::getenv("CT2X_SKINNY_MT");
+      const int v = e ? std::atoi(e) : 0;
+      return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;
+    }();
+    int mt = 1;
+    if (m > 16) {
+      // (the vocabulary projection at <= 32 rows streams 16 MB of weights: read them once)
+      mt = mt_env ? mt_env : ((n >= 8192 && m <= 32) ? 2 : 1);
+      while (mt > 1 && (mt / 2) * 16 >= m) mt /= 2;  // never more tiles than rows
+    }
     // Tuning override (tools/gemm_bench.cpp): CT2X_SKINNY_CFG="NT,WAVES,U" for m <= 32.
     static const int cfg = [] {
       const char* e = std::getenv("CT2X_SKINNY_CFG");

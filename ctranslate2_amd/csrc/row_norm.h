@@ -8,11 +8,6 @@
 
 namespace ct2x {
 
-__device__ __forceinline__ float dpp_xor4(float v) {
-  const float m = dpp_move<0x141, 0xf>(0.f, v);  // row_half_mirror: lane i <- lane 7 - i (per 8)
-  return dpp_move<0x1B, 0xf>(0.f, m);             // quad_perm [3,2,1,0]: lane i <- lane i ^ 3
-}
-
 // `row`: the depth floats of the row in LDS (linear). Every lane of the calling wave returns the
 // statistics.
 __device__ __forceinline__ void ordered_row_stats(const float* row, int64_t depth, float& sum,
