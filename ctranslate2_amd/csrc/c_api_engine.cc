@@ -285,14 +285,101 @@ int ct2x_tp_selftest_rccl(int device_index) {
   comm->all_reduce_sum_i32(di, n, stream);
   comm->all_reduce_max_f32(df, n, stream);
   comm->all_reduce_sum_f32(df, n, stream);
-  std::vector<int32_t> oi(n);
+  // GatherAll over one rank = a copy
+  auto* dg = static_cast<int32_t*>(device_malloc(n * 4));
+  comm->all_gather(di, dg, n * 4, stream);
+  std::vector<int32_t> oi(n), og(n);
   std::vector<float> of(n);
   CT2X_HIP_CHECK(hipMemcpyAsync(oi.data(), di, n * 4, hipMemcpyDeviceToHost, stream));
   CT2X_HIP_CHECK(hipMemcpyAsync(of.data(), df, n * 4, hipMemcpyDeviceToHost, stream));
+  CT2X_HIP_CHECK(hipMemcpyAsync(og.data(), dg, n * 4, hipMemcpyDeviceToHost, stream));
   CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+  CT2X_CHECK(oi == hi && of == hf, "one-rank RCCL all-reduce did not return its input");
+  CT2X_CHECK(og == hi, "one-rank RCCL all-gather did not return its input");
+  // The collectives are stream work: a hipGraph captures and replays them (what lets a sharded
+  // decode step run as one graph like the unsharded one).
+  CT2X_CHECK(comm->capturable(), "the RCCL communicator reports itself not capturable");
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  CT2X_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+  comm->all_reduce_sum_i32(di, n, stream);
+  comm->all_reduce_max_f32(df, n, stream);
+  comm->all_gather(di, dg, n * 4, stream);
+  CT2X_HIP_CHECK(hipStreamEndCapture(stream, &graph));
+  CT2X_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  CT2X_HIP_CHECK(hipMemsetAsync(dg, 0, n * 4, stream));
+  for (int rep = 0; rep < 3; ++rep) CT2X_HIP_CHECK(hipGraphLaunch(exec, stream));
+  CT2X_HIP_CHECK(hipMemcpyAsync(og.data(), dg, n * 4, hipMemcpyDeviceToHost, stream));
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
   device_free(di);
   device_free(df);
-  CT2X_CHECK(oi == hi && of == hf, "one-rank RCCL all-reduce did not return its input");
+  device_free(dg);
+  CT2X_CHECK(og == hi, "replayed graph with RCCL collectives did not reproduce the gather");
+  API_CATCH
+}
+
+int ct2x_tp_selftest_local(int device_index, int world) {
+  API_TRY
+  // The in-process communicator (ranks = threads on one device): all-reduce (int32 sum, float
+  // max) and GatherAll on known data, checked on every rank.
+  CT2X_CHECK(world >= 1 && world <= 8, "ct2x_tp_selftest_local: world must be in [1, 8]");
+  auto comms = make_local_comms(world);
+  const int n = 777;
+  std::vector<std::string> errors(world);
+  std::vector<std::thread> threads;
+  for (int r = 0; r < world; ++r) {
+    threads.emplace_back([&, r] {
+      try {
+        CT2X_HIP_CHECK(hipSetDevice(device_index));
+        hipStream_t stream = thread_stream();
+        std::vector<int32_t> hi(n);
+        std::vector<float> hf(n);
+        for (int i = 0; i < n; ++i) {
+          hi[i] = (r + 1) * (i - 300);
+          hf[i] = static_cast<float>((i * 13 + r * 7) % 101) - 50.f;
+        }
+        auto* di = static_cast<int32_t*>(device_malloc(n * 4));
+        auto* df = static_cast<float*>(device_malloc(n * 4));
+        auto* dsend = static_cast<int32_t*>(device_malloc(n * 4));
+        auto* dg = static_cast<int32_t*>(device_malloc(static_cast<size_t>(world) * n * 4));
+        CT2X_HIP_CHECK(hipMemcpyAsync(di, hi.data(), n * 4, hipMemcpyHostToDevice, stream));
+        CT2X_HIP_CHECK(hipMemcpyAsync(dsend, hi.data(), n * 4, hipMemcpyHostToDevice, stream));
+        CT2X_HIP_CHECK(hipMemcpyAsync(df, hf.data(), n * 4, hipMemcpyHostToDevice, stream));
+        comms[r]->all_reduce_sum_i32(di, n, stream);
+        comms[r]->all_reduce_max_f32(df, n, stream);
+        comms[r]->all_gather(dsend, dg, n * 4, stream);
+        std::vector<int32_t> oi(n), og(static_cast<size_t>(world) * n);
+        std::vector<float> of(n);
+        CT2X_HIP_CHECK(hipMemcpyAsync(oi.data(), di, n * 4, hipMemcpyDeviceToHost, stream));
+        CT2X_HIP_CHECK(hipMemcpyAsync(of.data(), df, n * 4, hipMemcpyDeviceToHost, stream));
+        CT2X_HIP_CHECK(hipMemcpyAsync(og.data(), dg, og.size() * 4, hipMemcpyDeviceToHost, stream));
+        CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+        device_free(di);
+        device_free(df);
+        device_free(dsend);
+        device_free(dg);
+        for (int i = 0; i < n; ++i) {
+          int32_t want_sum = 0;
+          float want_max = -1e30f;
+          for (int q = 0; q < world; ++q) {
+            want_sum += (q + 1) * (i - 300);
+            want_max = std::max(want_max, static_cast<float>((i * 13 + q * 7) % 101) - 50.f);
+            if (og[static_cast<size_t>(q) * n + i] != (q + 1) * (i - 300))
+              throw Error("all_gather: wrong element");
+          }
+          if (oi[i] != want_sum) throw Error("all_reduce(int32, sum): wrong element");
+          if (of[i] != want_max) throw Error("all_reduce(float, max): wrong element");
+        }
+      } catch (const std::exception& e) {
+        errors[r] = e.what();
+      }
+    });
+  }
+  for (auto& th : threads) th.join();
+  for (int r = 0; r < world; ++r)
+    CT2X_CHECK(errors[r].empty(), "rank " + std::to_string(r) + ": " + errors[r]);
   API_CATCH
 }
 
@@ -773,6 +860,23 @@ int ct2x_host_sinusoidal_table(int64_t positions, int64_t depth, float* out) {
              "ct2x_host_sinusoidal_table: positions > 0, even depth, output buffer");
   const std::vector<float> t = make_sinusoidal_table(positions, depth);
   std::memcpy(out, t.data(), t.size() * sizeof(float));
+  API_CATCH
+}
+
+int ct2x_host_rotary_tables(int64_t dim, int interleave, int scaling_type, float scaling_factor,
+                            float base, float low_freq_factor, float high_freq_factor,
+                            int64_t original_max_position_embeddings, int64_t positions,
+                            float* sin_out, float* cos_out) {
+  API_TRY
+  CT2X_CHECK(positions > 0 && dim >= 2 && dim % 2 == 0 && sin_out != nullptr && cos_out != nullptr,
+             "ct2x_host_rotary_tables: positions > 0, even dim, output buffers");
+  CT2X_CHECK(scaling_type == -1 || scaling_type == 0 || scaling_type == 2,
+             "ct2x_host_rotary_tables: scaling type None (-1), Linear (0) or Llama3 (2)");
+  std::vector<float> s, c;
+  make_rotary_tables(dim, interleave != 0, scaling_type, scaling_factor, base, low_freq_factor,
+                     high_freq_factor, original_max_position_embeddings, positions, s, c);
+  std::memcpy(sin_out, s.data(), s.size() * sizeof(float));
+  std::memcpy(cos_out, c.data(), c.size() * sizeof(float));
   API_CATCH
 }
 

@@ -399,6 +399,27 @@ int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int3
   API_CATCH
 }
 
+int ct2x_random_sample(const float* d_logits, int64_t rows, int64_t vocab, int32_t sampling_topk,
+                       float sampling_topp, float temperature, uint32_t seed,
+                       const float* d_uniforms, const int32_t* d_step, int32_t* d_ids,
+                       float* d_scores, void* stream) {
+  API_TRY
+  CT2X_CHECK(rows >= 0 && vocab >= 1, "ct2x_random_sample: bad shape");
+  CT2X_CHECK(sampling_topk <= max_sampling_topk(),
+             "ct2x_random_sample: sampling_topk must be <= 64 (or <= 0 for the whole vocabulary)");
+  CT2X_CHECK(temperature > 0.f && sampling_topp > 0.f && sampling_topp <= 1.f,
+             "ct2x_random_sample: temperature > 0, 0 < sampling_topp <= 1");
+  CT2X_CHECK(d_step != nullptr && d_ids != nullptr && d_scores != nullptr,
+             "ct2x_random_sample: the step counter and the outputs are device pointers");
+  // history layout of the fused sampler with a one-step history: hist[step * rows + row]; the
+  // caller passes *d_step == 0
+  launch_random_sample(d_logits, rows, vocab, -1, 0, true, sampling_topk, sampling_topp, temperature,
+                       seed, d_step, d_ids, d_ids, d_scores, resolve_stream(stream), nullptr, nullptr,
+                       0, 0, true, nullptr, nullptr, d_uniforms);
+  check_last_launch("random_sample");
+  API_CATCH
+}
+
 int ct2x_beam_select(const float* d_topk_scores, const int32_t* d_topk_ids, int64_t batch,
                      int32_t beam_size, int64_t vocab, int32_t end_id,
                      const int32_t* d_prefix_ids, const int32_t* d_prefix_lens,

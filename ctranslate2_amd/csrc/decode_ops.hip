@@ -253,7 +253,8 @@ __global__ void random_sample_kernel(const float* __restrict__ logits, int64_t v
                                      SamplePrefix pf, StepAdvance adv,
                                      const int32_t* step_ptr, int32_t* __restrict__ next_ids,
                                      int32_t* __restrict__ hist_ids,
-                                     float* __restrict__ hist_scores) {
+                                     float* __restrict__ hist_scores,
+                                     const float* __restrict__ uniforms) {
   __shared__ float s_v[16];
   __shared__ int s_i[16];
   __shared__ float scratch[16];
@@ -345,7 +346,10 @@ __global__ void random_sample_kernel(const float* __restrict__ logits, int64_t v
         ++kept;
       }
     }
-    const float u = uniform01(seed, static_cast<uint32_t>(step), static_cast<uint32_t>(row)) * kept_total;
+    // (tests inject the draw: uniforms[row] in [0, 1) replaces the hash)
+    const float u01 = uniforms ? uniforms[row]
+                               : uniform01(seed, static_cast<uint32_t>(step), static_cast<uint32_t>(row));
+    const float u = u01 * kept_total;
     int pick = kept - 1;
     float acc = 0.f;
     for (int c = 0; c < kept; ++c) {
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(1024) void random_sample_full_kernel(
     const float* __restrict__ logits, int64_t vocab, int32_t disable_id, int32_t min_length,
     bool with_scores, float topp, float temperature, uint32_t seed, SamplePrefix pf,
     StepAdvance adv, const int32_t* step_ptr, int32_t* __restrict__ next_ids,
-    int32_t* __restrict__ hist_ids, float* __restrict__ hist_scores) {
+    int32_t* __restrict__ hist_ids, float* __restrict__ hist_scores,
+    const float* __restrict__ uniforms) {
   __shared__ float scratch[16];
   __shared__ float seg_incl[1024];
   __shared__ int s_pick;
@@ -448,7 +453,8 @@ __global__ __launch_bounds__(1024) void random_sample_full_kernel(
     __syncthreads();
   }
   const float total = seg_incl[nthreads - 1];
-  float u = uniform01(seed, static_cast<uint32_t>(step), static_cast<uint32_t>(row)) * total;
+  float u = (uniforms ? uniforms[row]
+                      : uniform01(seed, static_cast<uint32_t>(step), static_cast<uint32_t>(row))) * total;
   u = fminf(u, total * (1.f - 1.f / 16777216.f));  // strictly below the total: exactly one owner
   const float excl = tid ? seg_incl[tid - 1] : 0.f;
   if (excl <= u && u < seg_incl[tid]) {
@@ -478,7 +484,7 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           int32_t* next_ids, int32_t* hist_ids, float* hist_scores,
                           hipStream_t stream, const int32_t* prefix_ids, const int32_t* prefix_lens,
                           int32_t prefix_stride, int32_t prefix_first_step, bool prefix_extends_min,
-                          int32_t* advance_step_ptr, int32_t* done_counter) {
+                          int32_t* advance_step_ptr, int32_t* done_counter, const float* uniforms) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
@@ -488,12 +494,12 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
   if (topk <= 0) {  // the whole vocabulary
     hipLaunchKernelGGL(random_sample_full_kernel, dim3(rows), dim3(1024), 0, stream, logits, vocab,
                        disable_id, min_length, with_scores, topp, temperature, seed, pf, adv,
-                       step_ptr, next_ids, hist_ids, hist_scores);
+                       step_ptr, next_ids, hist_ids, hist_scores, uniforms);
     return;
   }
   hipLaunchKernelGGL(random_sample_kernel, dim3(rows), dim3(block), 0, stream, logits, vocab,
                      disable_id, min_length, with_scores, topk, topp, temperature, seed, pf, adv,
-                     step_ptr, next_ids, hist_ids, hist_scores);
+                     step_ptr, next_ids, hist_ids, hist_scores, uniforms);
 }
 
 int max_sampling_topk() { return kMaxSampleTopK; }

@@ -120,6 +120,8 @@ hipStream_t Engine::cur_stream() const { return tls_stream ? tls_stream : stream
 Engine::Engine(std::shared_ptr<ModelFile> model, const std::string& compute_type,
                int device_index, std::shared_ptr<TpComm> tp)
     : model_(std::move(model)), tp_(std::move(tp)), device_(device_index) {
+  if (const char* e = std::getenv("CT2X_TP_FAST")) tp_fast_ = e[0] == '1';
+  if (const char* e = std::getenv("CT2X_TP_GRAPH")) tp_graph_ = e[0] != '0';
   if (tp_ && tp_->world() <= 1) tp_.reset();
   CT2X_HIP_CHECK(hipSetDevice(device_));
   stream_ = thread_stream();
@@ -621,6 +623,63 @@ const float* Engine::sinusoidal_table(int64_t positions, int64_t depth) {
 
 // RotaryEmbeddings::initialize (src/layers/attention_layer.cc:252-343), default / linear /
 // Llama-3 scaling. Tables are [positions, dim].
+// RotaryEmbeddings::initialize (src/layers/attention_layer.cc:254-330) on the host: inv_freq with
+// None (-1) / Linear (0) / Llama3 (2) scaling, the position x frequency products, then sin / cos
+// through the host math backend (host_math.h: MKL VML like the reference's ops::Sin / ops::Cos
+// when an MKL runtime is installed). Tables are [positions, dim], halves or pairs duplicated.
+void make_rotary_tables(int64_t dim, bool interleave, int scaling_type, float scaling_factor,
+                        float base, float low_freq_factor, float high_freq_factor,
+                        int64_t original_max_position_embeddings, int64_t positions,
+                        std::vector<float>& s, std::vector<float>& c) {
+  const int64_t half = dim / 2;
+  std::vector<float> inv_freq(half);
+  for (int64_t i = 0; i < half; ++i)
+    inv_freq[i] = 1.f / std::pow(base, static_cast<float>(i * 2) / static_cast<float>(dim));
+  if (scaling_type == 2) {  // Llama3
+    std::vector<float> new_freqs = inv_freq;
+    const float factor = scaling_factor;
+    const float old_context_len = static_cast<float>(original_max_position_embeddings);
+    const float low_freq_wavelen = old_context_len / low_freq_factor;
+    const float high_freq_wavelen = old_context_len / high_freq_factor;
+    for (int64_t i = 0; i < half; ++i) {
+      // `float wavelen = 2.0f * M_PI / inv_freq` (attention_layer.cc:283): M_PI is a double, so the
+      // quotient is formed in double precision and rounded once
+      const float wavelen = static_cast<float>(2.0 * M_PI / static_cast<double>(inv_freq[i]));
+      if (wavelen < high_freq_wavelen) {
+      } else if (wavelen > low_freq_wavelen) {
+        new_freqs[i] /= factor;
+      } else {
+        const float smooth = (old_context_len / wavelen - low_freq_factor) /
+                             (high_freq_factor - low_freq_factor);
+        new_freqs[i] = ((1 - smooth) * inv_freq[i] / factor + smooth * inv_freq[i]);
+      }
+    }
+    inv_freq = new_freqs;
+  }
+  s.assign(positions * dim, 0.f);
+  c.assign(positions * dim, 0.f);
+  std::vector<float> freqs(positions * half), fs(positions * half), fc(positions * half);
+  for (int64_t p = 0; p < positions; ++p) {
+    const float t = (scaling_type == 0) ? static_cast<float>(p) / scaling_factor
+                                        : static_cast<float>(p);
+    for (int64_t i = 0; i < half; ++i) freqs[p * half + i] = t * inv_freq[i];
+  }
+  host_vsin(positions * half, freqs.data(), fs.data());
+  host_vcos(positions * half, freqs.data(), fc.data());
+  for (int64_t p = 0; p < positions; ++p) {
+    for (int64_t i = 0; i < half; ++i) {
+      const float sf = fs[p * half + i], cf = fc[p * half + i];
+      if (interleave) {
+        s[p * dim + 2 * i] = s[p * dim + 2 * i + 1] = sf;
+        c[p * dim + 2 * i] = c[p * dim + 2 * i + 1] = cf;
+      } else {
+        s[p * dim + i] = s[p * dim + half + i] = sf;
+        c[p * dim + i] = c[p * dim + half + i] = cf;
+      }
+    }
+  }
+}
+
 void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_out,
                            const float** cos_out) {
   std::lock_guard<std::mutex> lock(table_mutex_);
@@ -642,52 +701,10 @@ void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_
     return;
   }
   positions = std::max<int64_t>(positions, 2048);
-  const int64_t half = dim / 2;
-  std::vector<float> inv_freq(half);
-  for (int64_t i = 0; i < half; ++i)
-    inv_freq[i] = 1.f / std::pow(a.rotary_base, static_cast<float>(i * 2) / static_cast<float>(dim));
-  if (a.rotary_scaling_type == 2) {  // Llama3
-    std::vector<float> new_freqs = inv_freq;
-    const float factor = a.rotary_scaling_factor;
-    const float old_context_len = static_cast<float>(a.original_max_position_embeddings);
-    const float low_freq_wavelen = old_context_len / a.rotary_low_freq_factor;
-    const float high_freq_wavelen = old_context_len / a.rotary_high_freq_factor;
-    for (int64_t i = 0; i < half; ++i) {
-      const float wavelen = 2.0f * static_cast<float>(M_PI) / inv_freq[i];
-      if (wavelen < high_freq_wavelen) {
-      } else if (wavelen > low_freq_wavelen) {
-        new_freqs[i] /= factor;
-      } else {
-        const float smooth = (old_context_len / wavelen - a.rotary_low_freq_factor) /
-                             (a.rotary_high_freq_factor - a.rotary_low_freq_factor);
-        new_freqs[i] = ((1 - smooth) * inv_freq[i] / factor + smooth * inv_freq[i]);
-      }
-    }
-    inv_freq = new_freqs;
-  }
-  std::vector<float> s(positions * dim), c(positions * dim);
-  {
-    std::vector<float> freqs(positions * half), fs(positions * half), fc(positions * half);
-    for (int64_t p = 0; p < positions; ++p) {
-      const float t = (a.rotary_scaling_type == 0) ? static_cast<float>(p) / a.rotary_scaling_factor
-                                                   : static_cast<float>(p);
-      for (int64_t i = 0; i < half; ++i) freqs[p * half + i] = t * inv_freq[i];
-    }
-    host_vsin(positions * half, freqs.data(), fs.data());
-    host_vcos(positions * half, freqs.data(), fc.data());
-    for (int64_t p = 0; p < positions; ++p) {
-      for (int64_t i = 0; i < half; ++i) {
-        const float sf = fs[p * half + i], cf = fc[p * half + i];
-        if (a.rotary_interleave) {
-          s[p * dim + 2 * i] = s[p * dim + 2 * i + 1] = sf;
-          c[p * dim + 2 * i] = c[p * dim + 2 * i + 1] = cf;
-        } else {
-          s[p * dim + i] = s[p * dim + half + i] = sf;
-          c[p * dim + i] = c[p * dim + half + i] = cf;
-        }
-      }
-    }
-  }
+  std::vector<float> s, c;
+  make_rotary_tables(dim, a.rotary_interleave, a.rotary_scaling_type, a.rotary_scaling_factor,
+                     a.rotary_base, a.rotary_low_freq_factor, a.rotary_high_freq_factor,
+                     a.original_max_position_embeddings, positions, s, c);
   if (rope_sin_) {  // kept alive for sessions that captured the old pointers
     device_blocks_.push_back(rope_sin_);
     device_blocks_.push_back(rope_cos_);
@@ -902,7 +919,30 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
     // products summed over ranks, then bias and residual.
     CT2X_CHECK(x != nullptr && act < 0, "row-parallel Dense takes the fp32 activation, no activation");
     CT2X_CHECK(ws && ws->tp_acc && ws->tp_amax, "tensor-parallel scratch buffers are missing");
-    if (w.quantized) {
+    if (w.quantized && tp_fast_) {
+      // The reference's exchange (src/layers/common.cc:348-401 + the ReduceAll of its callers):
+      // every rank quantises ITS slice with its own row scale, dequantises its partial product
+      // and the float outputs are summed - ONE collective per layer instead of two, not
+      // bit-identical to the unsharded layer (CT2X_TP_FAST=1).
+      quant(x, m, w.k, ws->qbuf, ws->qscale);
+      float* acc = reinterpret_cast<float*>(ws->tp_acc);
+      GemmS8Epilogue ep;
+      ep.mode = 1;
+      ep.a_scale = ws->qscale;
+      ep.w_scale = w.wscale;
+      ep.y = acc;
+      ep.ldy = w.n;
+      begin_kernel("gemm_s8_dequant", double(m) * w.k + double(w.n) * w.k + 4.0 * m * w.n,
+                   2.0 * m * w.n * w.k, m, w.n, w.k);
+      launch_gemm_s8(ws->qbuf, w.wq, m, w.n, w.k, ep, cur_stream());
+      end_kernel();
+      begin_kernel("tp_all_reduce_sum", double(m) * w.n * 4, 0, m, w.n, 0);
+      tp_->all_reduce_sum_f32(acc, m * w.n, cur_stream());
+      end_kernel();
+      begin_kernel("bias_residual", double(m) * w.n * 8, 0, m, w.n, 0);
+      launch_bias_residual(acc, w.bias, residual, m, w.n, y, cur_stream());
+      end_kernel();
+    } else if (w.quantized) {
       begin_kernel("tp_row_amax", double(m) * w.k * 4, 0, m, 0, w.k);
       launch_row_amax(x, m, w.k, ws->tp_amax, cur_stream());
       end_kernel();
@@ -1752,7 +1792,10 @@ void Engine::step(DecodeState& st, bool graph) {
     const float *s, *c;
     rotary_tables(dec_.layers.front().self, st.t_max + 1, &s, &c);
   }
-  if (!graph || profiling_ || tp_) {  // collectives are not captured: eager launches under TP
+  // Under tensor parallelism the step is captured when the communicator's collectives are plain
+  // stream work (RCCL); the in-process test double rendezvous on the host and runs eagerly.
+  const bool tp_eager = tp_ && !(tp_graph_ && tp_->capturable());
+  if (!graph || profiling_ || tp_eager || st.graph_failed) {
     const int64_t before = launch_counter_;
     launch_step(st);
     kernels_per_step_ = launch_counter_ - before;
@@ -1777,11 +1820,27 @@ void Engine::step(DecodeState& st, bool graph) {
       if (dead) (void)hipGraphDestroy(dead);
       throw;
     }
+    if (tp_) {
+      // a collective library that refuses capture must not take the session down: this state
+      // falls back to eager launches (the step has not run yet - a capture records, not executes)
+      hipError_t e = hipStreamEndCapture(cur_stream(), &g);
+      if (e == hipSuccess) e = hipGraphInstantiate(&st.graph_exec[parity], g, nullptr, nullptr, 0);
+      if (g) (void)hipGraphDestroy(g);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        st.graph_failed = true;
+        step(st, false);
+        return;
+      }
+      kernels_per_step_ = launch_counter_ - before;
+      st.graph_ready[parity] = true;
+    } else {
     CT2X_HIP_CHECK(hipStreamEndCapture(cur_stream(), &g));
     kernels_per_step_ = launch_counter_ - before;
     CT2X_HIP_CHECK(hipGraphInstantiate(&st.graph_exec[parity], g, nullptr, nullptr, 0));
     CT2X_HIP_CHECK(hipGraphDestroy(g));
     st.graph_ready[parity] = true;
+    }
   }
   CT2X_HIP_CHECK(hipGraphLaunch(st.graph_exec[parity], cur_stream()));
   if (st.fuse_beam) st.cur ^= 1;

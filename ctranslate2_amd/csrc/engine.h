@@ -35,6 +35,11 @@ std::string compute_type_name(ComputeType t);
 // generate_sinusoidal_position_encoding (src/layers/common.cc:204-229) on the host:
 // [positions, depth], sin half then cos half, through the host math backend (host_math.h).
 std::vector<float> make_sinusoidal_table(int64_t positions, int64_t depth);
+// Host side of the rotary tables (RotaryEmbeddings::initialize): s, c [positions, dim].
+void make_rotary_tables(int64_t dim, bool interleave, int scaling_type, float scaling_factor,
+                        float base, float low_freq_factor, float high_freq_factor,
+                        int64_t original_max_position_embeddings, int64_t positions,
+                        std::vector<float>& s, std::vector<float>& c);
 
 struct DenseW {
   // Tensor parallel: the K dimension is split over the ranks (attention-out / FFN-out); the
@@ -299,6 +304,8 @@ private:
 
   std::shared_ptr<ModelFile> model_;
   std::shared_ptr<TpComm> tp_;  // nullptr: no tensor parallelism
+  bool tp_fast_ = false;  // CT2X_TP_FAST=1: the reference's single fp32 all-reduce (not bit-exact)
+  bool tp_graph_ = true;  // CT2X_TP_GRAPH=0: eager launches under tensor parallelism
   ComputeType compute_type_;
   int device_ = 0;
   hipStream_t stream_ = nullptr;
@@ -427,6 +434,7 @@ struct DecodeState {
   // graph
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // one per cache parity
+  bool graph_failed = false;  // capture refused (tensor parallel + collective library): eager
   bool graph_ready[2] = {false, false};
 
   ~DecodeState();

@@ -296,7 +296,8 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           hipStream_t stream, const int32_t* prefix_ids = nullptr,
                           const int32_t* prefix_lens = nullptr, int32_t prefix_stride = 0,
                           int32_t prefix_first_step = 0, bool prefix_extends_min = true,
-                          int32_t* advance_step_ptr = nullptr, int32_t* done_counter = nullptr);
+                          int32_t* advance_step_ptr = nullptr, int32_t* done_counter = nullptr,
+                          const float* uniforms = nullptr /* tests: [rows] draws in [0, 1) */);
 int max_sampling_topk();
 
 // RepetitionPenalty / NoRepeatNgram / SuppressSequences (src/decoding_utils.cc:37-153) in place on

@@ -27,6 +27,7 @@ struct RcclApi {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(Comm*, int, const void* /* ncclUniqueId by value, 128 bytes */, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
   int (*CommDestroy)(Comm) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   void* handle = nullptr;
@@ -34,7 +35,7 @@ struct RcclApi {
 
 // ncclDataType_t / ncclRedOp_t values (rccl.h): ncclInt32 = 2, ncclFloat32 = 7; ncclSum = 0,
 // ncclMax = 2.
-constexpr int kNcclInt32 = 2, kNcclFloat32 = 7, kNcclSum = 0, kNcclMax = 2;
+constexpr int kNcclInt8 = 0, kNcclInt32 = 2, kNcclFloat32 = 7, kNcclSum = 0, kNcclMax = 2;
 
 struct UniqueIdByValue {
   char bytes[kTpUniqueIdBytes];
@@ -57,6 +58,7 @@ RcclApi& rccl() {
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
     return a;
@@ -84,6 +86,10 @@ public:
   int rank() const override { return rank_; }
   int world() const override { return world_; }
   const char* backend() const override { return "rccl"; }
+  bool capturable() const override { return true; }  // RCCL collectives are stream-ordered
+  void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+    rccl_check(rccl().AllGather(send, recv, bytes, kNcclInt8, comm_, stream), "ncclAllGather");
+  }
   void all_reduce_sum_i32(int32_t* buf, int64_t count, hipStream_t stream) override {
     rccl_check(rccl().AllReduce(buf, buf, count, kNcclInt32, kNcclSum, comm_, stream),
                "ncclAllReduce(int32, sum)");
@@ -156,6 +162,23 @@ public:
   int rank() const override { return rank_; }
   int world() const override { return s_->world; }
   const char* backend() const override { return "in-process"; }
+  bool capturable() const override { return false; }  // host rendezvous inside every collective
+  void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+    s_->bufs[rank_] = const_cast<void*>(send);
+    CT2X_HIP_CHECK(hipEventRecord(s_->ready[rank_], stream));
+    s_->barrier();
+    for (int r = 0; r < s_->world; ++r) {
+      if (r != rank_) CT2X_HIP_CHECK(hipStreamWaitEvent(stream, s_->ready[r], 0));
+      CT2X_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(recv) + static_cast<size_t>(r) * bytes,
+                                    s_->bufs[r], bytes, hipMemcpyDeviceToDevice, stream));
+    }
+    CT2X_HIP_CHECK(hipEventRecord(s_->done[rank_], stream));
+    s_->barrier();
+    // nobody may overwrite its send buffer before every rank has copied it
+    for (int r = 0; r < s_->world; ++r)
+      if (r != rank_) CT2X_HIP_CHECK(hipStreamWaitEvent(stream, s_->done[r], 0));
+    s_->barrier();
+  }
   void all_reduce_sum_i32(int32_t* buf, int64_t count, hipStream_t stream) override {
     run(buf, count, true, false, stream);
   }

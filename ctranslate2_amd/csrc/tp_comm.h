@@ -32,7 +32,12 @@ public:
   virtual void all_reduce_sum_i32(int32_t* buf, int64_t count, hipStream_t stream) = 0;
   virtual void all_reduce_sum_f32(float* buf, int64_t count, hipStream_t stream) = 0;
   virtual void all_reduce_max_f32(float* buf, int64_t count, hipStream_t stream) = 0;
+  // ops::GatherAll (src/ops/nccl_ops_gpu.cu:70-85): every rank contributes `bytes` bytes at `send`;
+  // recv [world][bytes] holds the contributions in rank order on every rank. send may not alias recv.
+  virtual void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) = 0;
   virtual const char* backend() const = 0;
+  // true when the collectives are plain stream work that a hipGraph can capture and replay
+  virtual bool capturable() const = 0;
 };
 
 // 128-byte ncclUniqueId created on rank 0 and handed to every rank by the launcher.

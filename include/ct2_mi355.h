@@ -223,6 +223,17 @@ int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int3
                         const int32_t* d_suppress_ids, const int32_t* d_suppress_offsets,
                         int32_t num_suppress, void* stream);
 
+/* RandomSampler for one step (src/sampling.cc:41-101): best `sampling_topk` candidates (2..64;
+ * <= 0: the whole vocabulary) -> temperature -> TopPMask (src/ops/topp_mask_cpu.cc:24-31) ->
+ * SoftMax -> Multinomial by inverse CDF (candidates in TopK order; index order for the whole
+ * vocabulary). d_uniforms [rows] in [0, 1) injects the draws (tests); NULL uses the counter-based
+ * hash of (seed, *d_step, row). d_ids [rows], d_scores [rows] = log-probability of the id under the
+ * ORIGINAL distribution. *d_step must be 0 for this standalone form. */
+int ct2x_random_sample(const float* d_logits, int64_t rows, int64_t vocab, int32_t sampling_topk,
+                       float sampling_topp, float temperature, uint32_t seed,
+                       const float* d_uniforms, const int32_t* d_step, int32_t* d_ids,
+                       float* d_scores, void* stream);
+
 /* One beam-search step after TopK on the device (BeamSearch::search, src/decoding.cc:559-700):
  * unflatten_ids (:95-116), update_sample_with_prefix beam arm (:21-66), the candidate selection
  * (:618-655). d_topk_* [batch, 2*beam]; d_prefix_ids [batch, prefix_stride] / d_prefix_lens
@@ -391,6 +402,9 @@ int ct2x_tp_shard_rows(int64_t n, const int64_t* blocks, int32_t num_blocks, int
 /* One-rank RCCL communicator + all-reduces on `device_index` (identity): checks the RCCL binding
  * of the multi-GPU path where only one GPU is visible. */
 int ct2x_tp_selftest_rccl(int device_index);
+/* The in-process communicator's collectives (all-reduce int32 sum / float max, GatherAll) with
+ * `world` ranks as threads on one device, verified on every rank. */
+int ct2x_tp_selftest_local(int device_index, int world);
 int ct2x_translator_create_tp_local(const char* model_dir, int device_index,
                                     const char* compute_type, int world, void** handles_out);
 
@@ -455,6 +469,14 @@ int ct2x_step_logits(void* translator, const int32_t* src_ids, const int32_t* sr
  * out [positions, depth]. */
 const char* ct2x_host_math_backend(void);
 int ct2x_host_sinusoidal_table(int64_t positions, int64_t depth, float* out);
+
+/* Host side of RotaryEmbeddings::initialize (src/layers/attention_layer.cc:254-330): sin / cos
+ * tables [positions, dim] for scaling type None (-1), Linear (0) or Llama3 (2), built through the
+ * same host math backend as the engine's tables (no GPU needed). */
+int ct2x_host_rotary_tables(int64_t dim, int interleave, int scaling_type, float scaling_factor,
+                            float base, float low_freq_factor, float high_freq_factor,
+                            int64_t original_max_position_embeddings, int64_t positions,
+                            float* sin_out, float* cos_out);
 
 /* ---- debugging taps (tests only; not part of the reference boundary) ----------------------
  * ct2x_debug_step_taps = ct2x_step_logits with every producer on the path (embedding, norm +

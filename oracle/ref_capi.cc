@@ -558,4 +558,47 @@ int ct2ref_sinusoidal_table(int64_t depth, int64_t positions, float* out) {
   CT2REF_CATCH
 }
 
+// The reference's rotary tables (RotaryEmbeddings::initialize, src/layers/attention_layer.cc:
+// 254-330: inv_freq with None / Linear / Llama3 scaling, MatMul, ops::Sin / ops::Cos): sin_out,
+// cos_out [positions, dim]. The tables are private; they are read back by applying the layer to
+// unit patterns: ops::Rotary computes y[i] = x[i] * c[i] + rot(x)[i] * s[i]
+// (src/ops/rotary_cpu.cc:30-35), so x = 1 on the first half (even slots when interleaved) and 0
+// on the other returns c on the ones and s on the zeros, and the complementary pattern returns
+// the rest (-s on the zeros) - all exactly (products with 0 and 1, one addend +-0).
+int ct2ref_rotary_tables(int64_t dim, int interleave, int scaling_type, float scaling_factor,
+                         float base, int64_t num_initial_positions, float low_freq_factor,
+                         float high_freq_factor, int64_t original_max_position_embeddings,
+                         int64_t positions, float* sin_out, float* cos_out) {
+  CT2REF_TRY
+  layers::RotaryEmbeddings rot(dim, interleave != 0,
+                               static_cast<layers::RotaryScalingType>(scaling_type), scaling_factor,
+                               base, num_initial_positions, nullptr, nullptr, low_freq_factor,
+                               high_freq_factor, original_max_position_embeddings, 0, true);
+  const int64_t half = dim / 2;
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<float> pattern(static_cast<size_t>(positions * dim));
+    for (int64_t p = 0; p < positions; ++p)
+      for (int64_t i = 0; i < dim; ++i) {
+        const bool first = interleave ? (i % 2 == 0) : (i < half);
+        pattern[p * dim + i] = (first == (pass == 0)) ? 1.f : 0.f;
+      }
+    StorageView x({1, 1, positions, dim}, pattern);
+    rot.apply(x, 0, false);
+    const float* y = x.data<float>();
+    for (int64_t p = 0; p < positions; ++p)
+      for (int64_t i = 0; i < dim; ++i) {
+        const bool first = interleave ? (i % 2 == 0) : (i < half);
+        const bool one = first == (pass == 0);
+        if (one) {
+          cos_out[p * dim + i] = y[p * dim + i];
+        } else {
+          // zero slot: y = rot(x) * s with rot(x) = +1 on the second kind of slot, -1 on the first
+          const float v = y[p * dim + i];
+          sin_out[p * dim + i] = first ? -v : v;
+        }
+      }
+  }
+  CT2REF_CATCH
+}
+
 }  // extern "C"

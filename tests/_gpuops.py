@@ -222,6 +222,21 @@ def topk(x, k):
     return host(v), host(i)
 
 
+def random_sample(logits, topk, topp, temperature, uniforms=None, seed=1234):
+    """ct2x_random_sample on [rows, vocab] logits; uniforms [rows] in [0, 1) injects the draws."""
+    L = _lib.lib()
+    lg = dev(np.ascontiguousarray(logits, np.float32))
+    rows, vocab = logits.shape
+    ud = dev(np.ascontiguousarray(uniforms, np.float32)) if uniforms is not None else None
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ids = torch.empty(rows, dtype=torch.int32, device="cuda")
+    scores = torch.empty(rows, dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_random_sample(_lib.ptr(lg), i64(rows), i64(vocab), C.c_int32(topk),
+                                    C.c_float(topp), C.c_float(temperature), C.c_uint32(seed),
+                                    _lib.ptr(ud), _lib.ptr(step), _lib.ptr(ids), _lib.ptr(scores), None))
+    return host(ids), host(scores)
+
+
 def process_logits(logits, seq, penalty=1.0, ngram=0, suppress=()):
     L = _lib.lib()
     lg = dev(np.ascontiguousarray(logits, np.float32))

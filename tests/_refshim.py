@@ -230,6 +230,22 @@ def sinusoidal_table(depth, positions):
     return out
 
 
+def rotary_tables(dim, positions, interleave=False, scaling_type=-1, scaling_factor=1.0,
+                  base=10000.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                  original_max_position_embeddings=0, num_initial_positions=2048):
+    """The reference's RotaryEmbeddings sin / cos tables [positions, dim] (read back through
+    unit patterns, oracle/ref_capi.cc ct2ref_rotary_tables)."""
+    sin = np.empty((positions, dim), np.float32)
+    cos = np.empty((positions, dim), np.float32)
+    _check(lib().ct2ref_rotary_tables(C.c_int64(dim), C.c_int(int(interleave)), C.c_int(scaling_type),
+                                      C.c_float(scaling_factor), C.c_float(base),
+                                      C.c_int64(num_initial_positions), C.c_float(low_freq_factor),
+                                      C.c_float(high_freq_factor),
+                                      C.c_int64(original_max_position_embeddings),
+                                      C.c_int64(positions), _p(sin), _p(cos)))
+    return sin, cos
+
+
 def process_logits(logits, seq, penalty=1.0, ngram=0, suppress=()):
     """The reference's LogitsProcessor classes on a copy of logits [rows, vocab]."""
     lg = np.ascontiguousarray(logits, np.float32).copy()

@@ -67,3 +67,79 @@ def test_single_process_path():
     r = bench.roofline_entry(label, st)
     assert abs(r["achieved"] - 2.0) < 1e-9 and r["bound"] == "hbm" and r["peak"] == 8000.0
     assert abs(r["frac"] - 2.0 / 8000.0) < 1e-12 and abs(r["avg_us"] - 1000.0) < 1e-9
+
+
+TP_WORKER = textwrap.dedent("""
+    import ctypes as C, json, os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import ctranslate2_amd as ct2
+    from ctranslate2_amd import _lib, model_builder as mb
+    L = _lib.lib()
+    # 1. the bootstrap of Translator(..., tensor_parallel=True): rank 0 draws the ncclUniqueId,
+    #    every rank receives it over the process group
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = C.create_string_buffer(128)
+        _lib.check(L.ct2x_tp_unique_id(buf))
+        uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    dist.broadcast(uid, src=0)
+    # 2. the partition this rank would load (fused Q | K | V of 8 / 2 heads of 16, host only)
+    q, kv = 8 * 16, 2 * 16
+    blocks = (C.c_int64 * 3)(q, kv, kv)
+    first, count = (C.c_int64 * 3)(), (C.c_int64 * 3)()
+    _lib.check(L.ct2x_tp_shard_rows(C.c_int64(q + 2 * kv), blocks, C.c_int32(3), C.c_int32(rank),
+                                    C.c_int32(world), first, count))
+    mine = torch.zeros(q + 2 * kv, dtype=torch.int32)
+    for f, c in zip(first, count):
+        mine[f:f + c] += 1
+    dist.all_reduce(mine)
+    # 3. the real constructor: bootstraps the same way, then must stop LOUDLY at the first HIP
+    #    call on a box without a GPU (no CPU fallback, no hang)
+    path = os.environ["CT2X_TP_MODEL"]
+    if rank == 0 and not os.path.exists(os.path.join(path, "model.bin")):
+        mb.build_transformer(path, num_encoder_layers=1, num_decoder_layers=1, d_model=32, num_heads=2, ffn_dim=64, vocab_size=40, seed=3)
+    dist.barrier()
+    err = None
+    try:
+        ct2.Translator(path, device="cuda", compute_type="int8", tensor_parallel=True)
+    except Exception as e:
+        err = "%%s: %%s" %% (type(e).__name__, e)
+    print(json.dumps({"rank": rank, "uid": bytes(uid.numpy().tobytes()).hex(),
+                      "cover": [int(mine.min()), int(mine.max())], "error": err}))
+    dist.barrier()
+    dist.destroy_process_group()
+""" % ROOT)
+
+
+def test_two_rank_tensor_parallel_bootstrap(tmp_path):
+    """Two processes, gloo: the unique-id hand-out and the per-rank partition of the tensor-parallel
+    constructor run on CPU; ct2x_translator_create_tp itself needs the device and must fail with the
+    HIP error on every rank instead of falling back or hanging."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the constructor would succeed (covered by tests/test_tensor_parallel_gpu.py)")
+    script = tmp_path / "tp_worker.py"
+    script.write_text(TP_WORKER)
+    port = 31500 + os.getpid() % 2000
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CT2X_TP_MODEL=str(tmp_path / "model"))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    outs.sort(key=lambda o: o["rank"])
+    assert outs[0]["uid"] == outs[1]["uid"] and set(outs[0]["uid"]) != {"0"}
+    assert outs[0]["cover"] == outs[1]["cover"] == [1, 1]      # every row owned exactly once
+    for o in outs:
+        assert o["error"] is not None and ("hip" in o["error"].lower() or "device" in o["error"].lower()), o

@@ -237,3 +237,39 @@ def test_host_sinusoidal_table_matches_the_reference():
         else:
             assert np.mean(got == want) > 0.9
             np.testing.assert_allclose(got, want, rtol=2e-7, atol=1e-7)
+
+
+def test_host_rotary_tables_match_the_reference():
+    """RotaryEmbeddings::initialize (src/layers/attention_layer.cc:254-330) is host work: plain,
+    interleaved, Linear and Llama3 scaling. tests/golden/rotary_golden.npz holds the tables of the
+    REAL reference (tests/golden/make_rotary_golden.py drives layers::RotaryEmbeddings through
+    oracle/ref_capi.cc). With the MKL VML backend the tables must be identical bit for bit; with
+    libm they may differ by one ulp in a few percent of the entries (and by sin / cos argument
+    reduction at large angles: 2e-7 absolute)."""
+    import ctypes as C
+    import json
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    L.ct2x_host_math_backend.restype = C.c_char_p
+    backend = L.ct2x_host_math_backend().decode()
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rotary_golden.npz"))
+    cases = json.loads(bytes(z["meta"]).decode())
+    assert any(kw.get("scaling_type") == 2 for kw in cases.values())
+    for name, kw in cases.items():
+        want_s, want_c = z[name + "/sin"], z[name + "/cos"]
+        got_s, got_c = np.empty_like(want_s), np.empty_like(want_c)
+        rc = L.ct2x_host_rotary_tables(
+            C.c_int64(kw["dim"]), C.c_int(int(kw.get("interleave", False))),
+            C.c_int(kw.get("scaling_type", -1)), C.c_float(kw.get("scaling_factor", 1.0)),
+            C.c_float(kw.get("base", 10000.0)), C.c_float(kw.get("low_freq_factor", 1.0)),
+            C.c_float(kw.get("high_freq_factor", 4.0)),
+            C.c_int64(kw.get("original_max_position_embeddings", 0)), C.c_int64(kw["positions"]),
+            got_s.ctypes.data_as(C.c_void_p), got_c.ctypes.data_as(C.c_void_p))
+        assert rc == 0, _lib.last_error() if hasattr(_lib, "last_error") else rc
+        if backend == "mkl-vml":
+            assert np.array_equal(got_s, want_s), name
+            assert np.array_equal(got_c, want_c), name
+        else:
+            assert np.mean(got_s == want_s) > 0.9 and np.mean(got_c == want_c) > 0.9, name
+            np.testing.assert_allclose(got_s, want_s, rtol=0, atol=3e-7)
+            np.testing.assert_allclose(got_c, want_c, rtol=0, atol=3e-7)

@@ -602,3 +602,63 @@ def test_runtime_abi_round_trip(gpu):
     assert L.ct2x_free(d3) != 0  # double free is an error, not a crash
     _lib.check(L.ct2x_event_destroy(e0))
     _lib.check(L.ct2x_event_destroy(e1))
+
+
+@pytest.mark.parametrize("topk,topp,temp", [(8, 0.7, 1.0), (40, 0.9, 0.8), (64, 1.0, 1.3), (2, 0.5, 1.0),
+                                            (0, 0.8, 1.0), (0, 1.0, 0.7), (0, 0.3, 1.5)])
+def test_random_sample_with_injected_uniforms(gpu, topk, topp, temp):
+    """RandomSampler's chain TopK -> temperature -> TopPMask -> SoftMax -> Multinomial
+    (src/sampling.cc:41-101) with the uniform draws INJECTED: the id each row returns must be the
+    inverse CDF, at its draw, of the distribution the oracle's TopPMask (orc_topp_mask, pinned against
+    the reference's TopPMask KAT) leaves - candidates in TopK order for sampling_topk > 0, in
+    index order for the whole vocabulary - and the score the log-probability under the original
+    distribution. Rows whose draw or whose top-p mass sits within 1e-5 of a boundary are not
+    decidable across float formats and are skipped (a handful at most)."""
+    import _gpuops as G
+    rng = np.random.default_rng(topk * 31 + int(topp * 100) + int(temp * 10))
+    rows, vocab = 96, 1500
+    logits = (rng.standard_normal((rows, vocab)) * 3).astype(np.float32)
+    u = rng.random(rows).astype(np.float32)
+    u[:4] = [0.0, 0.999999, 0.5, 1e-7]
+    ids, scores = G.random_sample(logits, topk, topp, temp, u)
+    checked = 0
+    for r in range(rows):
+        x = logits[r]
+        if topk > 0:
+            order = np.argsort(-x, kind="stable")[:topk]
+        else:
+            order = np.arange(vocab)
+        z = (x[order].astype(np.float64) - x.max()) / temp
+        y = O.topp_mask((x[order] / np.float32(temp))[None, :].astype(np.float32), topp, -np.inf)[0]
+        kept = np.isfinite(y)
+        p_all = np.exp(z) / np.exp(z).sum()
+        # decidability of the mask: mass ranked before each candidate vs topp
+        srt = np.argsort(-z, kind="stable")
+        before = np.concatenate([[0.0], np.cumsum(p_all[srt])[:-1]])
+        if topp < 1.0 and np.min(np.abs(before - topp)) < 1e-5:
+            continue
+        w = np.where(kept, np.exp(z), 0.0)
+        cdf = np.cumsum(w) / w.sum()
+        target = float(u[r])
+        if np.min(np.abs(cdf - target)) < 1e-5:
+            continue
+        pick = int(np.searchsorted(cdf, target, side="right"))
+        pick = min(pick, len(cdf) - 1)
+        assert kept[pick]
+        assert ids[r] == order[pick], (r, ids[r], order[pick])
+        lse = np.log(np.exp(x.astype(np.float64) - x.max()).sum()) + x.max()
+        assert abs(scores[r] - (x[ids[r]] - lse)) < 1e-4
+        checked += 1
+    assert checked >= rows - 8
+
+
+def test_random_sample_hash_is_reproducible(gpu):
+    """Without injected draws the sampler uses its counter-based hash of (seed, step, row): same
+    seed, same ids; another seed, another sample."""
+    import _gpuops as G
+    rng = np.random.default_rng(5)
+    logits = rng.standard_normal((64, 2000)).astype(np.float32)
+    a, _ = G.random_sample(logits, 16, 1.0, 1.0, None, seed=7)
+    b, _ = G.random_sample(logits, 16, 1.0, 1.0, None, seed=7)
+    c, _ = G.random_sample(logits, 16, 1.0, 1.0, None, seed=8)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)

@@ -155,3 +155,44 @@ def test_rccl_binding_one_rank(gpu):
     from ctranslate2_amd import _lib
     L = _lib.lib()
     _lib.check(L.ct2x_tp_selftest_rccl(0))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_local_collectives(gpu, world):
+    """ReduceAll (int32 sum, float max) and GatherAll of the in-process communicator, checked on
+    every rank (src/ops/nccl_ops_gpu.cu:53-85)."""
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.ct2x_tp_selftest_local(0, world))
+
+
+def test_fast_exchange_mode_is_close_not_exact(gpu):
+    """CT2X_TP_FAST=1: the reference's own exchange (local Quantize scale per rank, ONE fp32
+    all-reduce of the dequantised partial outputs, src/layers/common.cc:348-401) instead of the
+    exact int32 exchange. One collective less per row-parallel layer; the logits then differ from
+    the unsharded engine by int8 quantisation noise, not more."""
+    import ctranslate2_amd as ct2
+    path = _model_dir("small")
+    cfg = GC.SYNTHETIC["small"]
+    src = [[1] + s + [2] for s in _sources("small")]
+    m = max(len(s) for s in src)
+    src = [s for s in src if len(s) == m]
+    rng = np.random.default_rng(12)
+    tgt = rng.integers(4, cfg["model"]["vocab_size"], (len(src), 6)).astype(np.int32)
+    single = ct2.Translator(path, compute_type="int8")
+    ref = single.step_logits(src, tgt)
+    os.environ["CT2X_TP_FAST"] = "1"
+    try:
+        ranks = ct2.Translator.tensor_parallel_local(path, 2, compute_type="int8")
+    finally:
+        del os.environ["CT2X_TP_FAST"]
+    outs = _run_ranks(ranks, lambda t: t.step_logits(src, tgt))
+    assert np.array_equal(outs[0], outs[1])          # every rank holds the same sum
+    err = np.abs(outs[0] - ref)
+    spread = ref.std()
+    print("fast exchange: max |d| = %.3g (logit sigma %.3g), identical = %s"
+          % (err.max(), spread, np.array_equal(outs[0], ref)))
+    assert err.max() < 0.15 * spread                  # quantisation noise of one more scale choice
+    assert np.mean(outs[0].argmax(-1) == ref.argmax(-1)) > 0.9
+    for t in ranks:
+        t.close()
