@@ -193,9 +193,35 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
     float knew = 0.f, vnew = 0.f, tq_pending = 0.f;
     {
       const float* qh = p.q + static_cast<int64_t>(row) * p.q_row_stride + hq * DH;
-      const float qd = qh[cl];
+      float qd = qh[cl];
+      // RoPE at position `pos` on q and the new key (RotaryEmbeddings::apply before the cache
+      // Concat, src/layers/attention.cc:521-533; ops::Rotary src/ops/rotary_cpu.cc:30-35:
+      // y[i] = x[i] * cos[i] + rot(x)[i] * sin[i] with rot = -x[partner] on the first element of a
+      // pair / the first half, two products and one sum - that translation unit is built without
+      // FMA). The sign is folded into sin, which is exact.
+      const bool rope = p.rope_sin != nullptr && cl < static_cast<int>(p.rot_dim);
+      int partner = cl;
+      float cs = 1.f, sn = 0.f, qo = 0.f;
+      if (rope) {
+        const int rd = static_cast<int>(p.rot_dim), middle = rd / 2;
+        bool neg;
+        if (p.rope_interleave) {
+          partner = cl ^ 1;
+          neg = (cl & 1) == 0;
+        } else {
+          partner = cl < middle ? cl + middle : cl - middle;
+          neg = cl < middle;
+        }
+        cs = p.rope_cos[static_cast<int64_t>(pos) * rd + cl];
+        const float sv = p.rope_sin[static_cast<int64_t>(pos) * rd + cl];
+        sn = neg ? -sv : sv;
+        qo = qh[partner];
+        qd = qd * cs + qo * sn;
+      }
       if (has_new) {
-        knew = p.k_new[static_cast<int64_t>(row) * p.new_row_stride + hk * DH + cl];
+        const float* kn = p.k_new + static_cast<int64_t>(row) * p.new_row_stride + hk * DH;
+        knew = kn[cl];
+        if (rope) knew = knew * cs + kn[partner] * sn;
         vnew = p.v_new[static_cast<int64_t>(row) * p.new_row_stride + hk * DH + cl];
         if (appends && chan) {  // cache append in place of ops::Concat (attention.cc:541-546)
           kc[pos * kvs + cl] = knew;
@@ -485,14 +511,16 @@ int x_t_pad(const AttnDecodeParams& p) {
 }  // namespace
 
 // Decode shapes the exact kernel covers: d_head 4 .. 64 (a multiple of 4; MKL's one-row tail
-// form for longer rows was not recovered), no RoPE (its CPU rounding is not restated), aligned
+// form for longer rows was not recovered), RoPE on self-attention (new key present), aligned
 // caches, and the per-wave LDS (q + scores + one K tile) of `teams` heads within 160 KiB.
 static bool x_dhead_ok(int64_t dh) { return dh == 4 || dh == 8 || dh == 16 || dh == 32 || dh == 64; }
 
 bool attention_exact_decode_applicable(const AttnDecodeParams& p, bool fused_quantize) {
   if (exact_disabled()) return false;
   if (!x_dhead_ok(p.dhead) || p.heads < 1 || p.heads_kv < 1 || p.heads % p.heads_kv != 0) return false;
-  if (p.rope_sin != nullptr) return false;
+  if (p.rope_sin != nullptr && (p.rope_cos == nullptr || p.rot_dim < 2 || p.rot_dim > p.dhead ||
+                                p.rot_dim % 2 != 0 || p.k_new == nullptr))
+    return false;
   if (p.kv_time_stride < p.dhead || p.kv_time_stride % 4 != 0 || p.t_max < 1) return false;
   if ((reinterpret_cast<uintptr_t>(p.k_cache) & 15) || (reinterpret_cast<uintptr_t>(p.v_cache) & 15) ||
       p.kv_head_stride % 4 != 0 || p.kv_row_stride % 4 != 0)

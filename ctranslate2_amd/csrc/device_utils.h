@@ -146,6 +146,8 @@ __device__ __forceinline__ ValIdx wave_argmax_dpp(ValIdx x) {
   return r;
 }
 
+__device__ __forceinline__ float exp_avx2(float x);
+
 __device__ __forceinline__ float apply_activation(float v, int act) {
   switch (act) {
     case 0:  // ReLU
@@ -159,8 +161,9 @@ __device__ __forceinline__ float apply_activation(float v, int act) {
       u = v * u;
       return 0.5f * u;
     }
-    case 2:  // Swish
-      return v / (1.f + expf(-v));
+    case 2:  // Swish: v / (1 + exp256_ps(-v)), the AVX2 functor of the reference's fused Dense
+             // epilogue (src/cpu/kernels.cc:194-199, 664-680) - bit-exact, not libm's expf
+      return v / (1.f + exp_avx2(-v));
     case 3: {  // GELU
       float u = 0.7071067811865475f * v;
       u = 1.f + erff(u);

@@ -26,6 +26,7 @@ namespace {
 
 // The stream of the session the calling thread is driving (one worker thread per session).
 thread_local hipStream_t tls_stream = nullptr;
+thread_local int64_t tls_launches = 0;  // begin_kernel calls of this thread (kernels per step)
 
 bool ends_with(const std::string& s, const std::string& suffix) {
   return s.size() >= suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0;
@@ -725,6 +726,7 @@ void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_
 void Engine::begin_kernel(const char* kind, double bytes, double ops, int64_t m, int64_t n,
                           int64_t k) {
   ++launch_counter_;
+  ++tls_launches;  // what step() differences: launches of THIS thread (sessions run concurrently)
   if (!profiling_) return;
   PendingKernel pk;
   pk.label = kind;
@@ -1074,15 +1076,12 @@ T* alloc(DecodeState& st, int64_t count) {
 
 std::unique_ptr<DecodeState> Engine::start_decoder_only(int64_t batch, int64_t beam,
                                                         int64_t t_max, int64_t prefill_len) {
-  pending_prefill_len_ = prefill_len;
-  auto st = start(nullptr, nullptr, batch, 0, beam, t_max);
-  pending_prefill_len_ = 0;
-  return st;
+  return start(nullptr, nullptr, batch, 0, beam, t_max, prefill_len);
 }
 
 std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t* src_lengths,
                                            int64_t batch, int64_t s_max, int64_t beam,
-                                           int64_t t_max) {
+                                           int64_t t_max, int64_t prefill_len) {
   CT2X_HIP_CHECK(hipSetDevice(device_));
   auto st = std::make_unique<DecodeState>();
   st->engine = this;
@@ -1105,8 +1104,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   }
   // Workspace sized for the larger of the decode rows and the encoder rows.
   // (a beam-search prefill forwards the prompt once per hypothesis row)
-  const int64_t enc_rows = has_encoder_ ? batch * s_max : rows * pending_prefill_len_;
-  st->prefill_max = pending_prefill_len_;
+  const int64_t enc_rows = has_encoder_ ? batch * s_max : rows * prefill_len;
+  st->prefill_max = prefill_len;
   int64_t enc_ffn = 0, enc_qkv = 0;
   for (const auto& l : enc_.layers) {
     enc_ffn = std::max(enc_ffn, l.ffn.l0.n);
@@ -1796,9 +1795,9 @@ void Engine::step(DecodeState& st, bool graph) {
   // stream work (RCCL); the in-process test double rendezvous on the host and runs eagerly.
   const bool tp_eager = tp_ && !(tp_graph_ && tp_->capturable());
   if (!graph || profiling_ || tp_eager || st.graph_failed) {
-    const int64_t before = launch_counter_;
+    const int64_t before = tls_launches;
     launch_step(st);
-    kernels_per_step_ = launch_counter_ - before;
+    kernels_per_step_ = tls_launches - before;
     check_last_launch("decoder step");
     if (st.fuse_beam) st.cur ^= 1;  // the step reordered the caches into the other buffer set
     return;
@@ -1810,7 +1809,7 @@ void Engine::step(DecodeState& st, bool graph) {
     static std::mutex capture_mutex;
     std::lock_guard<std::mutex> capture_lock(capture_mutex);
     hipGraph_t g = nullptr;
-    const int64_t before = launch_counter_;
+    const int64_t before = tls_launches;
     CT2X_HIP_CHECK(hipStreamBeginCapture(cur_stream(), hipStreamCaptureModeThreadLocal));
     try {
       launch_step(st);
@@ -1832,11 +1831,11 @@ void Engine::step(DecodeState& st, bool graph) {
         step(st, false);
         return;
       }
-      kernels_per_step_ = launch_counter_ - before;
+      kernels_per_step_ = tls_launches - before;
       st.graph_ready[parity] = true;
     } else {
     CT2X_HIP_CHECK(hipStreamEndCapture(cur_stream(), &g));
-    kernels_per_step_ = launch_counter_ - before;
+    kernels_per_step_ = tls_launches - before;
     CT2X_HIP_CHECK(hipGraphInstantiate(&st.graph_exec[parity], g, nullptr, nullptr, 0));
     CT2X_HIP_CHECK(hipGraphDestroy(g));
     st.graph_ready[parity] = true;

@@ -154,7 +154,8 @@ public:
   // Encodes `batch` padded source sequences (ids [batch, s_max] on host, lengths [batch]) and
   // prepares a decoding state for batch*beam rows and up to t_max decoded positions.
   std::unique_ptr<DecodeState> start(const int32_t* src_ids, const int32_t* src_lengths,
-                                     int64_t batch, int64_t s_max, int64_t beam, int64_t t_max);
+                                     int64_t batch, int64_t s_max, int64_t beam, int64_t t_max,
+                                     int64_t prefill_len = 0);
   // Decoder-only models: no encoder; the prompt is consumed by prefill().
   std::unique_ptr<DecodeState> start_decoder_only(int64_t batch, int64_t beam, int64_t t_max,
                                                   int64_t prefill_len = 0);
@@ -315,10 +316,9 @@ private:
   StackW enc_, dec_;
   std::vector<void*> device_blocks_;
   int64_t weight_bytes_ = 0;
-  int64_t pending_prefill_len_ = 0;  // set around start() by start_decoder_only (translator mutex held)
   std::atomic<int64_t> launch_counter_{0};
   std::mutex table_mutex_;
-  bool profiling_ = false;
+  std::atomic<bool> profiling_{false};
   int32_t* profile_scratch_ = nullptr;  // target of the calibration no-op (profile_begin)
   struct PendingKernel {
     std::string label;

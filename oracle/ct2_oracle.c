@@ -9,6 +9,8 @@
 
 /* Activation functors: src/cpu/kernels.cc:146-207 (relu_func ... tanh_func). Enum order:
  * include/ctranslate2/ops/activation.h:9-17. */
+float orc_exp_avx2(float x);
+
 float orc_activation(float v, int act) {
   switch (act) {
     case 0: /* ReLU: max(v, 0) */
@@ -103,7 +105,10 @@ void orc_dequantize_gemm_output(const int32_t* c, const float* a_scale, const fl
       float v = (float)c[i * n + j] * r_a;
       v = v / b_scale[j];
       if (bias) v = v + bias[j];
-      y[i * n + j] = orc_activation(v, act);
+      /* the fused epilogue runs every column through the ISA's vector functor, masked loads for
+       * the remainder (kernels.cc:664-680): Swish = v / (1 + exp256_ps(-v)) for ALL columns on the
+       * AVX2 dispatch (swish_func, :194-199), not libm's expf */
+      y[i * n + j] = (act == 2) ? v / (1.f + orc_exp_avx2(-v)) : orc_activation(v, act);
     }
   }
 }

@@ -51,6 +51,37 @@ def test_teacher_forced_logits_float32(gpu, golden, key):
     assert np.array_equal(logits.argmax(-1)[decided], np.array(tf["argmax"])[decided])
 
 
+def _host_math_is_mkl():
+    import ctypes
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    L.ct2x_host_math_backend.restype = ctypes.c_char_p
+    return L.ct2x_host_math_backend().decode() == "mkl-vml"
+
+
+@pytest.mark.parametrize("key", ["lm_tiny", "lm_small"])
+def test_teacher_forced_logits_int8(gpu, golden, key):
+    """The decoder-only int8 path (RMSNorm, RoPE, GQA, SwiGLU) step by step against the reference's
+    decoder run the same way (ct2ref_step_logits): with the RoPE tables built through MKL VML
+    (host_math.h), the rotation in the reference's two-products-and-a-sum form, the exact
+    attention forms (d_head 16 / 32, one-row MatMul) and Swish = v / (1 + exp256_ps(-v)), the logits
+    are IDENTICAL; with a libm host backend they stay within the int8 re-quantisation noise."""
+    g = golden[key]
+    t = get_lm(key, "int8")
+    tf = g["teacher_forced"]
+    logits = t.step_logits([], np.array(tf["tgt_in"], np.int32))
+    cols = np.array(tf["cols"])
+    ref = np.array(tf["values"], np.float32)
+    err = np.abs(logits[..., cols] - ref)
+    agree = float(np.mean(logits.argmax(-1) == np.array(tf["argmax"])))
+    print("%s int8: max |logit - ref| = %.3e, arg-max agreement %.4f" % (key, err.max(), agree))
+    if _host_math_is_mkl():
+        assert err.max() == 0.0
+        assert agree == 1.0
+    else:
+        assert err.max() < 0.2 * ref.std()
+
+
 @pytest.mark.parametrize("key", ["lm_tiny", "lm_small"])
 @pytest.mark.parametrize("ct", ["float32", "int8"])
 def test_generate_matches_reference(gpu, golden, key, ct):
@@ -68,6 +99,10 @@ def test_generate_matches_reference(gpu, golden, key, ct):
     if ct == "float32":
         assert gen == ref
         np.testing.assert_allclose(scores, np.array(g["scores"], np.float32), atol=1e-3)
+    elif _host_math_is_mkl():
+        # the int8 path is bit-exact (test_teacher_forced_logits_int8): same tokens, same scores
+        assert gen == ref
+        np.testing.assert_allclose(scores, np.array(g["scores"], np.float32), rtol=0, atol=2e-6)
     else:
         tf = g["teacher_forced"]
         top2 = np.array(tf["top2"])
@@ -121,7 +156,7 @@ def test_ragged_prompts_match_reference(gpu, key, ct, run):
     else:
         same = [a == b for a, b in zip(gen, ref)]
         print("%s int8 %s: %d/%d ragged continuations token-identical" % (key, run, sum(same), len(same)))
-        assert sum(same) >= len(same) - 2
+        assert sum(same) >= len(same) - (0 if _host_math_is_mkl() else 2)
         # rows that agree have matching scores; rows that left the reference did so at a near tie
         ok = np.array(same)
         np.testing.assert_allclose(scores[ok], np.array(r["scores"], np.float32)[ok], atol=2e-2)
@@ -161,7 +196,9 @@ def test_generator_beam_search_matches_reference(gpu, key, ct):
         assert all(same)
         np.testing.assert_allclose(scores, np.array(b["scores"], np.float32), atol=1e-3)
     else:
-        assert sum(same) >= len(same) - 2
+        # (beam search prefills per hypothesis row and expands after the first step: the exact
+        # forms cover it - measured identical with the MKL host backend)
+        assert sum(same) >= len(same) - (0 if _host_math_is_mkl() else 2)
         ok = np.array(same)
         np.testing.assert_allclose(scores[ok], np.array(b["scores"], np.float32)[ok], atol=2e-2)
 
