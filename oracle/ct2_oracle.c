@@ -373,17 +373,32 @@ static float mkl_dot_main(const float* a, const float* b, int64_t k) {
 }
 
 static float mkl_dot_tail(const float* a, const float* b, int64_t k, int type_a) {
-  float acc[16];
-  for (int l = 0; l < 16; ++l) acc[l] = 0.f;
-  for (int64_t t = 1; t < k; ++t) {
-    const int l = (int)((t - 1) % 16), c = (int)((t - 1) / 16);
-    if (c == 0)
-      acc[l] = a[t] * b[t];
-    else if (c == 1 && type_a && k > 33) {
-      const float p = a[t] * b[t];
-      acc[l] = acc[l] + p;
-    } else
+  /* Recovered with pair probes (one (1, -1) element + one (1 + 2^-12)^2 element per call: the
+   * result shows whether the second product was FUSED onto an accumulator holding the first):
+   * the "type A" columns (tail index 0 and 2) walk elements 1 .. 32 * ((k - 1) / 32) with
+   * THIRTY-TWO lane accumulators (first chunk = rounded products, later chunks FMA), fold lane
+   * l + 16 onto lane l, and continue with sixteen lanes; the "type B" column (index 1) uses
+   * sixteen lanes throughout. (For k <= 64 this is the earlier "second chunk is added as a
+   * rounded product" rule; it was checked up to k = 256.) */
+  float acc[32];
+  for (int l = 0; l < 32; ++l) acc[l] = 0.f;
+  int64_t t = 1;
+  if (type_a && k > 33) {
+    const int64_t body32 = ((k - 1) / 32) * 32;
+    for (; t <= body32; ++t) {
+      const int l = (int)((t - 1) % 32);
+      acc[l] = (t <= 32) ? a[t] * b[t] : fmaf(a[t], b[t], acc[l]);
+    }
+    for (int l = 0; l < 16; ++l) acc[l] = acc[l] + acc[l + 16];
+    for (; t < k; ++t) {
+      const int l = (int)((t - 1) % 16);
       acc[l] = fmaf(a[t], b[t], acc[l]);
+    }
+  } else {
+    for (; t < k; ++t) {
+      const int l = (int)((t - 1) % 16);
+      acc[l] = (t <= 16) ? a[t] * b[t] : fmaf(a[t], b[t], acc[l]);
+    }
   }
   const float s = tree16(acc);
   const float p0 = a[0] * b[0];
@@ -428,11 +443,15 @@ int orc_matmul(const float* a, const float* b, int64_t batch, int64_t m, int64_t
     const float* A = a + bi * m * k;
     const float* B = b + bi * n * k;
     float* C = c + bi * m * n;
-    if (m == 1 && trans_b && k >= 4 && k <= 64 && k % 4 == 0) {
+    if (m == 1 && trans_b && k >= 4 && k <= 256 && k % 4 == 0) {
       mkl_qk_m1(A, B, n, k, C);
     } else if (m == 1 && !trans_b && n >= 16) {
       for (int64_t j = 0; j < n; ++j) C[j] = mkl_pv_m1_col(A, B + j, n, k);
-    } else if ((trans_b && m >= 3 && n >= 5) || (!trans_b && (m >= 2 || n == 4 || n == 8))) {
+    } else if ((trans_b && m >= 3 && n >= 5 && k < 24 * m) ||
+               (!trans_b && (m >= 2 || n == 4 || n == 8))) {
+      /* (trans_b with long dot products and few rows, k >= 24 m - e.g. k = 128 with m <= 5 - goes
+       * through another MKL kernel that was not recovered: outside the envelope; mapped for
+       * k = 68 .. 256, m = 3 .. 13) */
       for (int64_t i = 0; i < m; ++i)
         for (int64_t j = 0; j < n; ++j) {
           float acc = 0.f;

@@ -54,7 +54,9 @@ float orc_exp_avx2(float x);
 /* ops::MatMul on CPU (MKL cblas_sgemm_batch_strided, src/cpu/primitives.cc:1085-1101) with the
  * summation order recovered from MKL 2021.4 on this container; see ct2_oracle.c. a [batch, m, k],
  * b [batch, n, k] (trans_b) or [batch, k, n]. Returns -1 when a shape is outside the validated
- * envelope (that batch entry is left untouched). alpha multiplies the finished sum (pinned for
+ * envelope (that batch entry is left untouched): one query row with trans_b needs k % 4 == 0,
+ * 4 <= k <= 256; several rows with trans_b need m >= 3, n >= 5 and k < 24 m; the no-transpose
+ * forms need m >= 2 or n in {4, 8} or n >= 16. alpha multiplies the finished sum (pinned for
  * the trans_b and sequence forms; the one-row no-transpose form is only pinned at alpha = 1). */
 int orc_matmul(const float* a, const float* b, int64_t batch, int64_t m, int64_t n, int64_t k,
                int trans_b, float alpha, float* c);

@@ -223,10 +223,11 @@ def test_exact_matmul_decode_qk():
 
 
 def test_exact_matmul_decode_qk_every_head_size():
-    """... and every head size 4, 8, .. 64 (the fixtures use d_head 4, 16, 32, 64)."""
+    """... and every head size 4, 8, .. 128 plus 160 / 192 / 256 (the fixtures use d_head 4, 16, 32,
+    64; Llama-family models 128): the 32-lane "type A" tail form covers every k % 4 == 0."""
     R = _ref()
     rng = np.random.default_rng(25)
-    for kk in range(4, 65, 4):
+    for kk in list(range(4, 129, 4)) + [160, 192, 256]:
         for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 33):
             q = rng.standard_normal((10, 1, kk)).astype(np.float32)
             k = rng.standard_normal((10, n, kk)).astype(np.float32)
@@ -258,10 +259,12 @@ def test_exact_matmul_sequence():
 
 
 def test_matmul_envelope_is_explicit():
-    with pytest.raises(ValueError):
-        O.matmul(np.zeros((1, 1, 128), np.float32), np.zeros((1, 5, 128), np.float32), True)
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):   # one-row form: k % 4 != 0 was not recovered
+        O.matmul(np.zeros((1, 1, 130), np.float32), np.zeros((1, 5, 130), np.float32), True)
+    with pytest.raises(ValueError):   # two query rows
         O.matmul(np.zeros((1, 2, 64), np.float32), np.zeros((1, 8, 64), np.float32), True)
+    with pytest.raises(ValueError):   # few query rows with long dot products (k > 64)
+        O.matmul(np.zeros((1, 3, 128), np.float32), np.zeros((1, 8, 128), np.float32), True)
 
 
 @pytest.mark.parametrize("kv_group", [1, 4])
