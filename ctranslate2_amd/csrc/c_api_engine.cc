@@ -496,15 +496,11 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
   }
   streams = std::max<int32_t>(1, std::min<int32_t>(streams, 16));
   if (t->engine->profiling()) streams = 1;  // event bookkeeping is single-stream
-  size_t chunk = opt.max_batch_size > 0 ? static_cast<size_t>(opt.max_batch_size)
-                                        : std::max<size_t>(order.size(), 1);
-  if (streams > 1 && !order.empty()) {
-    const size_t per_stream = (order.size() + streams - 1) / streams;
-    chunk = std::max<size_t>(1, std::min(chunk, per_stream));
-  }
+  const size_t ref_chunk = opt.max_batch_size > 0 ? static_cast<size_t>(opt.max_batch_size)
+                                                  : std::max<size_t>(order.size(), 1);
   // Concurrent hipGraph captures from several threads are not reliable on ROCm 7.2 ("operation
-  // failed due to a previous error during capture"); concurrent sessions launch eagerly -- the
-  // host has a thread per stream, so launches still overlap across streams.
+  // failed due to a previous error during capture"); captures are serialised (Engine::step) and
+  // CT2X_STREAM_GRAPHS=1 lets concurrent sessions replay graphs; by default they launch eagerly.
   if (streams > 1) {
     static const bool stream_graphs = [] {
       const char* e = std::getenv("CT2X_STREAM_GRAPHS");
@@ -512,9 +508,24 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
     }();
     if (!stream_graphs) dopt.use_graph = false;
   }
-  std::vector<std::pair<size_t, size_t>> groups;
-  for (size_t begin = 0; begin < order.size(); begin += chunk)
-    groups.emplace_back(begin, std::min(order.size(), begin + chunk));
+  // A group = (begin, end, padded source length). The padded length is that of the REFERENCE's
+  // batch (rebatch_input) the group is cut from: MKL's one-row attention forms depend on the
+  // padded key count, so a sub-batch must keep its parent's padding to stay bit-identical.
+  struct Group {
+    size_t begin, end;
+    int64_t s_max;
+  };
+  std::vector<Group> groups;
+  for (size_t rb = 0; rb < order.size(); rb += ref_chunk) {
+    const size_t re = std::min(order.size(), rb + ref_chunk);
+    int64_t s_max = 0;
+    for (size_t i = rb; i < re; ++i)
+      s_max = std::max<int64_t>(s_max, static_cast<int64_t>(sources[order[i]].size()));
+    size_t sub = re - rb;
+    if (streams > 1) sub = std::max<size_t>(1, (sub + streams - 1) / streams);
+    for (size_t begin = rb; begin < re; begin += sub)
+      groups.push_back(Group{begin, std::min(re, begin + sub), s_max});
+  }
 
   double encode_ms = 0, decode_ms = 0;
   std::mutex stats_mutex;
@@ -526,11 +537,9 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
       while (true) {
         const size_t gi = next_group.fetch_add(1);
         if (gi >= groups.size()) break;
-        const size_t begin = groups[gi].first, end = groups[gi].second;
+        const size_t begin = groups[gi].begin, end = groups[gi].end;
         const int64_t B = static_cast<int64_t>(end - begin);
-        int64_t s_max = 0;
-        for (size_t i = begin; i < end; ++i)
-          s_max = std::max<int64_t>(s_max, static_cast<int64_t>(sources[order[i]].size()));
+        const int64_t s_max = groups[gi].s_max;
         std::vector<int32_t> ids(B * s_max, 0), lens(B);
         for (int64_t i = 0; i < B; ++i) {
           const auto& s = sources[order[begin + i]];

@@ -606,6 +606,51 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
   const int masked = (step < row_min) ? disable_id : -1;
   const float* x = logits + row * vocab;
   float* yr = y + row * vocab;
+  constexpr int XR = 32;  // row elements a thread can keep in registers
+  if (chain_pad > 0 && vocab <= static_cast<int64_t>(XR) * blockDim.x) {
+    // The row is read ONCE: each thread keeps its <= 32 elements in registers for the maximum,
+    // the exps (parked transposed in LDS for the ordered sum) and the final x + c.
+    float xv[XR];
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+      const int64_t j = threadIdx.x + static_cast<int64_t>(u) * blockDim.x;
+      xv[u] = (j < vocab && j != masked) ? x[j] : -FLT_MAX;
+    }
+    float m = -FLT_MAX;
+#pragma unroll
+    for (int u = 0; u < XR; ++u) m = fmaxf(m, xv[u]);
+    m = block_max(m, scratch);
+    const int64_t vsize = vocab > 8 ? vocab - vocab % 8 : 0;
+    float* tail = exp_lds + 8 * chain_pad;
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+      const int64_t j = threadIdx.x + static_cast<int64_t>(u) * blockDim.x;
+      if (j < vocab) {
+        const float v = xv[u] - m;
+        if (j < vsize)
+          exp_lds[(j & 7) * chain_pad + (j >> 3)] = exp_avx2(v);
+        else
+          tail[j - vsize] = expf(v);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const float acc = ordered_chain_sum_lds(exp_lds, chain_pad, vsize, vocab);
+      if (threadIdx.x == 0) scratch[0] = acc;
+    }
+    __syncthreads();
+    const float c = -m - logf_glibc(scratch[0]);
+    const float b = beam_scores ? beam_scores[row] : 0.f;
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+      const int64_t j = threadIdx.x + static_cast<int64_t>(u) * blockDim.x;
+      if (j < vocab) {
+        const float v = xv[u] + c;
+        yr[j] = beam_scores ? b + v : v;
+      }
+    }
+    return;
+  }
   float m = -FLT_MAX;
   for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
     m = fmaxf(m, (j == masked) ? -FLT_MAX : x[j]);

@@ -376,43 +376,28 @@ __device__ __forceinline__ float ordered_chain_sum_lds(const float* lds, int cha
   const float* tail = lds + 8 * chain_pad;
   float acc = 0.f;
   {
+    // One dependent v_add_f32 per element (~10 cycles each on this chip: 4000 elements of a
+    // 32000-word row = ~17 us, the floor of the reference's order). The loop is left to the
+    // compiler's schedule - contiguous 16-byte LDS reads unrolled eight deep stay ahead of the
+    // adds (tools/chain_probe.cpp: a hand-pipelined sched_barrier version was 2x slower) - and
+    // carries no per-element bounds: whole float4s first, then the <= 3 leftovers.
     const int n = static_cast<int>(vsize / 8);  // elements per chain
-    const int n4 = (n + 3) / 4;
-    const v4f* c4 = reinterpret_cast<const v4f*>(lds + (threadIdx.x & 7) * chain_pad);
-    constexpr int B = 8;
-    v4f a[B], b[B];
-#define CT2X_CH_LOAD(A, BASE) _Pragma("unroll") for (int u = 0; u < B; ++u) A[u] = c4[(BASE) + u];
-#define CT2X_CH_EAT(A, BASE)                                                      \
-  _Pragma("unroll") for (int u = 0; u < B; ++u) {                                 \
-    const int e_ = 4 * ((BASE) + u);                                              \
-    if (e_ + 3 < n) {                                                             \
-      acc = acc + A[u].x;                                                         \
-      acc = acc + A[u].y;                                                         \
-      acc = acc + A[u].z;                                                         \
-      acc = acc + A[u].w;                                                         \
-    } else {                                                                      \
-      if (e_ < n) acc = acc + A[u].x;                                             \
-      if (e_ + 1 < n) acc = acc + A[u].y;                                         \
-      if (e_ + 2 < n) acc = acc + A[u].z;                                         \
-    }                                                                             \
-  }
-    CT2X_CH_LOAD(a, 0)
-    for (int base = 0; base < n4; base += 2 * B) {
-      CT2X_CH_LOAD(b, base + B)
-      __builtin_amdgcn_sched_barrier(0);
-      CT2X_CH_EAT(a, base)
-      __builtin_amdgcn_sched_barrier(0);
-      CT2X_CH_LOAD(a, base + 2 * B)
-      __builtin_amdgcn_sched_barrier(0);
-      CT2X_CH_EAT(b, base + B)
-      __builtin_amdgcn_sched_barrier(0);
+    const float* chain = lds + (threadIdx.x & 7) * chain_pad;
+    const v4f* c4 = reinterpret_cast<const v4f*>(chain);
+    const int n4 = n / 4;
+#pragma unroll 8
+    for (int i = 0; i < n4; ++i) {
+      const v4f v = c4[i];
+      acc = acc + v.x;
+      acc = acc + v.y;
+      acc = acc + v.z;
+      acc = acc + v.w;
     }
-#undef CT2X_CH_LOAD
-#undef CT2X_CH_EAT
+    for (int e = 4 * n4; e < n; ++e) acc = acc + chain[e];
   }
-  acc = acc + __shfl_xor(acc, 4, 64);
-  acc = acc + __shfl_xor(acc, 2, 64);
-  acc = acc + __shfl_xor(acc, 1, 64);
+  acc = acc + dpp_xor4(acc);
+  acc = acc + dpp_move<0x4E, 0xf>(0.f, acc);
+  acc = acc + dpp_move<0xB1, 0xf>(0.f, acc);
   for (int64_t j = vsize; j < size; ++j) acc = acc + tail[j - vsize];
   return acc;
 }
