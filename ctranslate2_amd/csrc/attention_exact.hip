@@ -147,6 +147,13 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
   float* vc = p.v_cache + static_cast<int64_t>(kvrow) * p.kv_row_stride +
               static_cast<int64_t>(hk) * p.kv_head_stride;
   const int kvs = static_cast<int>(p.kv_time_stride);
+  // Beam search through the ancestry table: position t of this row's history is read from cache
+  // row anc[t * stride + row] (element offset of that row relative to this row's own: `hop`).
+  const int32_t* anc = p.ancestry ? p.ancestry + row : nullptr;
+  const int64_t anc_stride = p.ancestry_stride;
+#define CT2X_XHOP(T)                                                                               \
+  (anc ? (static_cast<int64_t>(anc[static_cast<int64_t>(T) * anc_stride]) - kvrow) * p.kv_row_stride \
+       : static_cast<int64_t>(0))
 
   int t_cached;
   if (p.lengths != nullptr)
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
       if (it * KPI < n_keys) {
         const int i_ = it * 64 + lane;  // R4 float4 per row
         const int tl = min(i_ / R4, t_last);
-        kpre[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+        kpre[it] = *reinterpret_cast<const v4f*>(kc + CT2X_XHOP(tl) + tl * kvs + (i_ % R4) * 4);
       }
     }
     // ---- prologue: lane = channel ---------------------------------------------------------
@@ -237,7 +244,8 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
 #define CT2X_XLOAD_V(VR, T0)                                              \
   _Pragma("unroll") for (int j = 0; j < XVB; ++j) {                       \
     const int t_ = (T0) + j;                                              \
-    const float g_ = vc[min(t_, t_last) * kvs + cl];                      \
+    const int tc_ = min(t_, t_last);                                      \
+    const float g_ = vc[CT2X_XHOP(tc_) + tc_ * kvs + cl];                 \
     VR[j] = (has_new && t_ == pos) ? vnew : g_;                           \
   }
     // (four batches = 64 keys: a decode step of Transformer-base never waits for V twice)
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
           if (it * KPI < n_tile) {
             const int i_ = it * 64 + lane;  // R4 float4 per row
             const int tl = min(t0 + i_ / R4, t_last);
-            st[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+            st[it] = *reinterpret_cast<const v4f*>(kc + CT2X_XHOP(tl) + tl * kvs + (i_ % R4) * 4);
           }
         }
       }
@@ -383,6 +391,7 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
       }
     }
 #undef CT2X_XLOAD_V
+#undef CT2X_XHOP
 #undef CT2X_XBLOCK
     acc_out = y;
     asm volatile("" ::"v"(acc_out));
@@ -517,6 +526,7 @@ static bool x_dhead_ok(int64_t dh) { return dh == 4 || dh == 8 || dh == 16 || dh
 
 bool attention_exact_decode_applicable(const AttnDecodeParams& p, bool fused_quantize) {
   if (exact_disabled()) return false;
+  if (p.ancestry != nullptr && (p.kv_group != 1 || p.lengths != nullptr)) return false;
   if (!x_dhead_ok(p.dhead) || p.heads < 1 || p.heads_kv < 1 || p.heads % p.heads_kv != 0) return false;
   if (p.rope_sin != nullptr && (p.rope_cos == nullptr || p.rot_dim < 2 || p.rot_dim > p.dhead ||
                                 p.rot_dim % 2 != 0 || p.k_new == nullptr))

@@ -715,6 +715,10 @@ struct BeamSelectParams {
   const int32_t* seq_src;     // [batch*beam, seq_stride]
   int32_t* seq_dst;
   int32_t seq_stride;
+  // ancestry of the self-attention caches (AttnDecodeParams::ancestry), ping-pong; may be nullptr:
+  // [positions][batch*beam] -> cache row holding that position of the beam's history
+  const int32_t* anc_src;
+  int32_t* anc_dst;
 };
 
 __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelectParams p) {
@@ -772,6 +776,19 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelectParams p) {
     p.beam_scores[row] = s_score[c];
     p.parents[row] = b * p.beam + s_origin[c];
   }
+  if (p.anc_dst != nullptr) {
+    // gather_beam_flat on the caches (src/layers/decoder.cc:33-56) WITHOUT moving them: beam k
+    // inherits its parent's table of cache rows for every position written so far (0 .. *step_ptr;
+    // the parent's own row holds the position it just appended - the tables start as the identity)
+    const int rows = static_cast<int>(gridDim.x) * p.beam;
+    const int written = *p.step_ptr + 1;
+    for (int e = j; e < written * p.beam; e += 64) {
+      const int t = e / p.beam, k = e % p.beam;
+      const int parent = b * p.beam + s_origin[s_next[k]];
+      p.anc_dst[static_cast<int64_t>(t) * rows + b * p.beam + k] =
+          p.anc_src[static_cast<int64_t>(t) * rows + parent];
+    }
+  }
   if (p.seq_dst != nullptr) {
     // append_step_output + gather_beam_flat (:588, :686): beam k inherits its parent's tokens
     for (int k = 0; k < p.beam; ++k) {
@@ -790,11 +807,13 @@ void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64
                         int32_t first_step, int32_t* hist_word, float* hist_score,
                         int32_t* hist_origin, int32_t* next_ids, int32_t* parents,
                         float* beam_scores, const int32_t* seq_src, int32_t* seq_dst,
-                        int32_t seq_stride, hipStream_t stream) {
+                        int32_t seq_stride, hipStream_t stream, const int32_t* ancestry_src,
+                        int32_t* ancestry_dst) {
   if (batch == 0) return;
   const BeamSelectParams p{topk_scores, topk_ids, beam, static_cast<int32_t>(vocab), eos, prefix_ids,
                            prefix_lens, prefix_stride, step_ptr, first_step, hist_word, hist_score,
-                           hist_origin, next_ids, parents, beam_scores, seq_src, seq_dst, seq_stride};
+                           hist_origin, next_ids, parents, beam_scores, seq_src, seq_dst, seq_stride,
+                           ancestry_src, ancestry_dst};
   hipLaunchKernelGGL(beam_select_kernel, dim3(batch), dim3(64), 0, stream, p);
 }
 

@@ -1151,7 +1151,50 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   }
 
   const int n_layers = static_cast<int>(dec_.layers.size());
-  const int n_sets = beam > 1 ? 2 : 1;
+  // Beam search reads the self-attention caches through an ancestry table instead of reordering
+  // them every step when every layer's decode attention runs the exact kernel, which follows the
+  // table (CT2X_BEAM_ANCESTRY=0: the one-launch gather between two buffer sets).
+  if (beam > 1) {
+    static const bool allowed = [] {
+      const char* e = std::getenv("CT2X_BEAM_ANCESTRY");
+      return e == nullptr || e[0] != '0';
+    }();
+    bool ok = allowed;
+    const float* aligned = reinterpret_cast<const float*>(static_cast<uintptr_t>(256));
+    for (int l = 0; ok && l < n_layers; ++l) {
+      const AttnW& a = dec_.layers[l].self;
+      AttnDecodeParams p;
+      p.q = p.k_new = p.v_new = aligned;
+      p.k_cache = p.v_cache = const_cast<float*>(aligned);
+      p.kv_row_stride = a.heads_kv * t_max * a.dhead;
+      p.kv_head_stride = t_max * a.dhead;
+      p.kv_time_stride = a.dhead;
+      p.rows = rows;
+      p.heads = a.heads;
+      p.heads_kv = a.heads_kv;
+      p.dhead = a.dhead;
+      p.t_max = t_max;
+      if (a.rotary) {
+        p.rope_sin = p.rope_cos = aligned;
+        p.rot_dim = a.rotary_dim == 0 ? a.dhead : a.rotary_dim;
+      }
+      p.ancestry = reinterpret_cast<const int32_t*>(aligned);
+      p.ancestry_stride = rows;
+      ok = attention_exact_decode_applicable(p, false);
+    }
+    st->ancestry = ok;
+    if (ok) {
+      std::vector<int32_t> identity(static_cast<size_t>((t_max + 1) * rows));
+      for (int64_t t = 0; t <= t_max; ++t)
+        for (int64_t r = 0; r < rows; ++r) identity[t * rows + r] = static_cast<int32_t>(r);
+      for (int i = 0; i < 2; ++i) {
+        st->anc[i] = alloc<int32_t>(*st, (t_max + 1) * rows);
+        CT2X_HIP_CHECK(hipMemcpy(st->anc[i], identity.data(), identity.size() * sizeof(int32_t),
+                                 hipMemcpyHostToDevice));
+      }
+    }
+  }
+  const int n_sets = (beam > 1 && !st->ancestry) ? 2 : 1;
   for (int s = 0; s < n_sets; ++s) {
     for (int l = 0; l < n_layers; ++l) {
       const AttnW& a = dec_.layers[l].self;
@@ -1160,7 +1203,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       st->self_v[s].push_back(alloc<float>(*st, sz));
     }
   }
-  if (beam > 1) {
+  if (beam > 1 && !st->ancestry) {
     // Device tables of cache base pointers for the one-launch beam gather, both directions.
     std::vector<const float*> src(2 * n_layers), src_alt(2 * n_layers);
     std::vector<float*> dst(2 * n_layers), dst_alt(2 * n_layers);
@@ -1442,15 +1485,16 @@ void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time) {
     float* q_rot = st.inner;  // [rows, heads*dhead]; dead before the FFN reuses the buffer
     begin_kernel("qkv_to_cache");
     launch_qkv_to_cache(st.qkv, B, time, a.heads, a.heads_kv, a.dhead, st.t_max, 0, rs, rc, rot_dim,
-                        a.rotary_interleave, q_rot, st.self_k[st.cur][l], st.self_v[st.cur][l],
+                        a.rotary_interleave, q_rot, st.self_k[st.ancestry ? 0 : st.cur][l],
+                        st.self_v[st.ancestry ? 0 : st.cur][l],
                         cur_stream());
     end_kernel();
     AttnFullParams f;
     f.q = q_rot;
     f.q_batch_stride = time * a.heads * a.dhead;
     f.q_time_stride = a.heads * a.dhead;
-    f.k = st.self_k[st.cur][l];
-    f.v = st.self_v[st.cur][l];
+    f.k = st.self_k[st.ancestry ? 0 : st.cur][l];
+    f.v = st.self_v[st.ancestry ? 0 : st.cur][l];
     f.k_batch_stride = f.v_batch_stride = a.heads_kv * st.t_max * a.dhead;
     f.k_head_stride = f.v_head_stride = st.t_max * a.dhead;
     f.k_time_stride = f.v_time_stride = a.dhead;
@@ -1540,8 +1584,12 @@ void Engine::launch_step(DecodeState& st) {
       p.k_new = st.qkv + qdim;
       p.v_new = st.qkv + qdim + kvdim;
       p.new_row_stride = ld;
-      p.k_cache = st.self_k[st.cur][l];
-      p.v_cache = st.self_v[st.cur][l];
+      p.k_cache = st.self_k[st.ancestry ? 0 : st.cur][l];
+      p.v_cache = st.self_v[st.ancestry ? 0 : st.cur][l];
+      if (st.ancestry) {
+        p.ancestry = st.anc[st.cur];
+        p.ancestry_stride = rows;
+      }
       p.kv_row_stride = a.heads_kv * st.t_max * a.dhead;
       p.kv_head_stride = st.t_max * a.dhead;
       p.kv_time_stride = a.dhead;
@@ -1765,19 +1813,22 @@ void Engine::launch_step(DecodeState& st) {
                        st.hist_cand_origin, st.d_ids, st.d_parents, st.beam_scores,
                        st.lp_active ? st.alive_seq[par] : nullptr,
                        st.lp_active ? st.alive_seq[par ^ 1] : nullptr,
-                       static_cast<int32_t>(st.t_max), cur_stream());
+                       static_cast<int32_t>(st.t_max), cur_stream(),
+                       st.ancestry ? st.anc[par] : nullptr, st.ancestry ? st.anc[par ^ 1] : nullptr);
     end_kernel();
     // Positions [0, step] are live; the gather copies the positions below the advanced counter.
     begin_kernel("advance_step");
     launch_advance_step(st.d_step, cur_stream());
     end_kernel();
-    const AttnW& a0 = dec_.layers.front().self;
-    const int n_tensors = static_cast<int>(2 * dec_.layers.size());
-    begin_kernel("cache_gather");
-    launch_cache_gather(par == 0 ? st.d_cache_src : st.d_cache_src_alt,
-                        par == 0 ? st.d_cache_dst : st.d_cache_dst_alt, n_tensors, st.d_parents,
-                        st.rows, a0.heads_kv, st.t_max, a0.dhead, st.d_step, 0, cur_stream());
-    end_kernel();
+    if (!st.ancestry) {
+      const AttnW& a0 = dec_.layers.front().self;
+      const int n_tensors = static_cast<int>(2 * dec_.layers.size());
+      begin_kernel("cache_gather");
+      launch_cache_gather(par == 0 ? st.d_cache_src : st.d_cache_src_alt,
+                          par == 0 ? st.d_cache_dst : st.d_cache_dst_alt, n_tensors, st.d_parents,
+                          st.rows, a0.heads_kv, st.t_max, a0.dhead, st.d_step, 0, cur_stream());
+      end_kernel();
+    }
   }
 }
 

@@ -373,6 +373,10 @@ struct DecodeState {
   int32_t* mem_lengths = nullptr;  // [batch]
   // self-attention caches, ping-pong for beam reorder: [2][layers] each [rows, heads_kv, t_max, dh]
   std::vector<float*> self_k[2], self_v[2];
+  // Beam search without moving the caches (AttnDecodeParams::ancestry): ONE buffer set and two
+  // ping-pong tables [t_max + 1][rows] of cache rows, updated by the beam selection kernel.
+  bool ancestry = false;
+  int32_t* anc[2] = {nullptr, nullptr};
   int cur = 0;
   const float** d_cache_src = nullptr;  // device arrays of the 2*layers cache base pointers
   float** d_cache_dst = nullptr;

@@ -180,6 +180,12 @@ struct AttnDecodeParams {
   // search: the batch is not expanded yet, src/decoding.cc:453-454).
   const int32_t* one_row_step_ptr = nullptr;
   int32_t one_row_step = 0;
+  // attention_exact only - beam search without moving the caches (the reference reorders every
+  // cache tensor with ops::Gather after each step, src/layers/decoder.cc:33-56): position t of
+  // this row's history lives in cache row ancestry[t * ancestry_stride + row]; the new key / value
+  // is appended to the row's own cache row. nullptr: the row's own cache row holds everything.
+  const int32_t* ancestry = nullptr;
+  int64_t ancestry_stride = 0;
 };
 
 bool attention_decode_emits_row_amax(const AttnDecodeParams& p);
@@ -324,7 +330,8 @@ void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64
                         int32_t first_step, int32_t* hist_word, float* hist_score,
                         int32_t* hist_origin, int32_t* next_ids, int32_t* parents,
                         float* beam_scores, const int32_t* seq_src, int32_t* seq_dst,
-                        int32_t seq_stride, hipStream_t stream);
+                        int32_t seq_stride, hipStream_t stream,
+                        const int32_t* ancestry_src = nullptr, int32_t* ancestry_dst = nullptr);
 
 // Beam-search scores: y[row, :] = log_softmax(x[row, :] with x[disable_id] = -FLT_MAX while
 // step < min_length) + beam_scores[row]   (src/decoding.cc:512-556).
