@@ -52,6 +52,7 @@ struct Attn2Args {
   int group;        // query heads per KV head
   int t_pad;        // score slots per query head (multiple of 64, > t_max)
   long long* trace; // debugging: per-phase s_memtime stamps of workgroup 0 (nullptr = off)
+  int xcd_remap;    // 1: logical workgroup id = (id % 8) * (grid / 8) + id / 8 (grid % 8 == 0)
 };
 
 #define CT2X_STAMP(K)                                                                   \
@@ -65,11 +66,21 @@ __global__ __launch_bounds__(TW == 1 ? 512 : TW * 64) void attn2_kernel(Attn2Arg
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int team = wave / TW, tw = wave % TW;
-  const int row = blockIdx.x / a.wg_per_row;
+  // XCD-aware placement: consecutive workgroup ids are dealt round-robin to the eight XCDs, each
+  // with its own L2. In split mode the query heads of a GQA group (and the heads of a row) are
+  // consecutive ids - i.e. on eight DIFFERENT L2s, every one of which fetches the group's K/V from
+  // memory again. Remapped so that a run of gridDim / 8 logical ids shares an XCD, the group's
+  // K/V is fetched once per L2 (Llama-3-8B shape: 4 query heads per KV head).
+  unsigned bid = blockIdx.x;
+  if (a.xcd_remap) {
+    const unsigned per_xcd = gridDim.x >> 3;
+    bid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  }
+  const int row = static_cast<int>(bid) / a.wg_per_row;
   // A team is either a KV head with its GQ query heads, or (per_q_head) one query head of a GQA
   // group: at decode sizes the chip is starved for waves, so re-reading K/V from L2 once per query
   // head beats sharing the loads inside one wave.
-  const int unit = (blockIdx.x % a.wg_per_row) * a.teams + team;
+  const int unit = (static_cast<int>(bid) % a.wg_per_row) * a.teams + team;
   const int hk = a.per_q_head ? unit / a.group : unit;   // cache head
   const int hq0 = a.per_q_head ? unit : unit * GQ;       // first query head of the team
   const bool appends = a.per_q_head ? (unit % a.group == 0) : true;
@@ -602,6 +613,10 @@ void launch_attention_decode2(const AttnDecodeParams& p, int quant_mode, int8_t*
     }
     tw = p.t_max > 64 ? 4 : 1;
   }
+  static const bool no_remap = std::getenv("CT2X_ATTN_NO_XCD_REMAP") != nullptr;
+  const int64_t grid = p.rows * a.wg_per_row;
+  a.xcd_remap = (!no_remap && q_out == nullptr && a.per_q_head && a.group > 1 && grid % 8 == 0 &&
+                 grid >= 64) ? 1 : 0;
   if (p.dhead == 64) launch_gq<64>(a, gq, tw, stream);
   else launch_gq<128>(a, gq, tw, stream);
 }
