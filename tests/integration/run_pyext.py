@@ -1,0 +1,57 @@
+"""Runner for the reference's OWN Python extension on this backend (own process: the module links
+oracle/_ref/libctranslate2_mi355.so, which exports the same names as the CPU reference build).
+
+`oracle/_ref/pyext/_ext*.so` is python/cpp/*.cc of the reference (pybind11: Translator, Generator,
+StorageView ...) compiled where it lies (`make -C oracle pyext`) and linked with the Level-1
+library = the reference's host sources + the stub translation units + libct2_mi355.so. It is the
+module the reference's `ctranslate2` package imports as `_ext`; here it is loaded directly.
+
+  python tests/integration/run_pyext.py '<json spec>'
+spec: {"model": dir, "device": "cuda"|"cpu", "compute_type": ..., "tokens": [[str]], "beams": [1, 4],
+       "max_decoding_length": n}
+prints one JSON line: {"device_count": n, "runs": [{"beam": b, "hypotheses": [[str]], "scores": [...]}]}
+"""
+import ctypes
+import glob
+import importlib.util
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def load_ext():
+    # the reference only uses MKL's int8 GEMM on CPUs it identifies as Intel unless told otherwise
+    # (src/cpu/backend.cc); the GPU box's host is an AMD EPYC
+    os.environ.setdefault("CT2_USE_MKL", "1")
+    found = glob.glob(os.path.join(ROOT, "oracle", "_ref", "pyext", "_ext*.so"))
+    if not found:
+        raise SystemExit("oracle/_ref/pyext/_ext*.so is not built (make -C oracle pyext)")
+    # lazy binding: the 16-bit arms of the Level-1 library are unresolved functions that an
+    # int8 / float32 model never calls
+    sys.setdlopenflags(os.RTLD_LAZY | os.RTLD_GLOBAL)
+    ctypes.CDLL(os.path.join(ROOT, "ctranslate2_amd", "libct2_mi355.so"), mode=os.RTLD_LAZY | os.RTLD_GLOBAL)
+    spec = importlib.util.spec_from_file_location("_ext", found[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    spec = json.loads(sys.argv[1])
+    ext = load_ext()
+    out = {"device_count": ext.get_cuda_device_count(),
+           "compute_types": sorted(ext.get_supported_compute_types(spec["device"])), "runs": []}
+    t = ext.Translator(spec["model"], device=spec["device"], compute_type=spec["compute_type"])
+    for beam in spec["beams"]:
+        res = t.translate_batch(spec["tokens"], beam_size=beam, return_scores=True,
+                                max_decoding_length=spec.get("max_decoding_length", 256))
+        out["runs"].append({"beam": beam, "hypotheses": [r.hypotheses[0] for r in res],
+                            "scores": [float(r.scores[0]) for r in res]})
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
