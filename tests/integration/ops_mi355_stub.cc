@@ -9,7 +9,10 @@
 //
 // This file is written for this repository; it contains no reference code. float32 arm only
 // (T = float): the 16-bit arms forward the same way with CT2X_F16 / CT2X_BF16.
+#include <cstdlib>
+#include <memory>
 #include <stdexcept>
+#include <vector>
 
 #include "ctranslate2/allocator.h"
 #include "ctranslate2/ops/ops.h"
@@ -28,6 +31,14 @@ namespace ctranslate2 {
     return ct2x_thread_stream();
   }
 
+  // Scratch device memory of the composed (non hot path) forms below; stream-ordered allocator.
+  struct Scratch {
+    explicit Scratch(size_t bytes) { check(ct2x_malloc(&ptr, bytes ? bytes : 1)); }
+    ~Scratch() { (void)ct2x_free(ptr); }
+    float* f() const { return static_cast<float*>(ptr); }
+    void* ptr = nullptr;
+  };
+
   namespace ops {
 
     // include/ctranslate2/ops/quantize.h:27-30  <-  src/ops/quantize_gpu.cu:87-103
@@ -41,8 +52,15 @@ namespace ctranslate2 {
       // bit 1: round like the reference's CPU path (src/cpu/kernels.cc:592-604: fma(x, scale, 128),
       // round, cvtt, then the u8s8 GEMM's -128 compensation = an s8 operand), so that Device::CUDA
       // results equal Device::CPU results (ct2_mi355.h, ct2x_quantize_s8)
+      // CT2X_S8_ACTIVATIONS=1 (the engine's switch of the same name) selects the reference's GPU
+      // arithmetic instead - rint(x * scale) / truncation toward zero, src/ops/quantize_gpu.cu:
+      // 36-57 - which is what the reference's own op tests expect of Device::CUDA
+      static const bool gpu_form = [] {
+        const char* e = std::getenv("CT2X_S8_ACTIVATIONS");
+        return e != nullptr && e[0] == '1';
+      }();
       check(ct2x_quantize_s8(input.data<float>(), CT2X_F32, scale.size(), depth,
-                             (_round_before_cast ? 1 : 0) | 2,
+                             (_round_before_cast ? 1 : 0) | (gpu_form ? 0 : 2),
                              output.data<int8_t>(), scale.data<float>(), stream()));
     }
 
@@ -80,16 +98,37 @@ namespace ctranslate2 {
     void LayerNorm::compute<Device::CUDA, float>(const StorageView* beta,
                                                  const StorageView* gamma,
                                                  const StorageView& input,
-                                                 const dim_t axis,
+                                                 const dim_t /*axis*/,
                                                  const dim_t outer_size,
                                                  const dim_t axis_size,
                                                  const dim_t inner_size,
                                                  StorageView& output) const {
-      if (axis != input.rank() - 1 || inner_size != 1 || !beta || !gamma)
-        throw std::invalid_argument("LayerNorm: only the last-axis form with gamma and beta");
-      check(ct2x_layer_norm(input.data<float>(), gamma->data<float>(), beta->data<float>(),
-                            outer_size, axis_size, _epsilon, output.data<float>(), CT2X_F32,
-                            stream()));
+      if (inner_size == 1 && beta && gamma) {  // layers::LayerNorm: last axis, affine
+        check(ct2x_layer_norm(input.data<float>(), gamma->data<float>(), beta->data<float>(),
+                              outer_size, axis_size, _epsilon, output.data<float>(), CT2X_F32,
+                              stream()));
+        return;
+      }
+      // Any axis, optional affine (src/ops/layer_norm_gpu.cu:174-213): bring the axis last with a
+      // transpose, normalise with unit gamma / zero beta where none is given, transpose back.
+      Scratch ones(size_t(axis_size) * sizeof (float)), zeros(size_t(axis_size) * sizeof (float));
+      check(ct2x_fill(ones.ptr, 1.0, axis_size, 1, CT2X_F32, stream()));
+      check(ct2x_fill(zeros.ptr, 0.0, axis_size, 1, CT2X_F32, stream()));
+      const float* g = gamma ? gamma->data<float>() : ones.f();
+      const float* b = beta ? beta->data<float>() : zeros.f();
+      if (inner_size == 1) {
+        check(ct2x_layer_norm(input.data<float>(), g, b, outer_size, axis_size, _epsilon,
+                              output.data<float>(), CT2X_F32, stream()));
+      } else {
+        Scratch t_in(size_t(input.size()) * sizeof (float)), t_out(size_t(input.size()) * sizeof (float));
+        const int64_t dims[3] = {outer_size, axis_size, inner_size}, perm[3] = {0, 2, 1};
+        check(ct2x_transpose(input.data<float>(), dims, perm, 3, t_in.ptr, CT2X_F32, stream()));
+        check(ct2x_layer_norm(t_in.f(), g, b, outer_size * inner_size, axis_size, _epsilon, t_out.f(),
+                              CT2X_F32, stream()));
+        const int64_t back[3] = {outer_size, inner_size, axis_size};
+        check(ct2x_transpose(t_out.ptr, back, perm, 3, output.data<float>(), CT2X_F32, stream()));
+      }
+      check(ct2x_stream_synchronize(stream()));  // the scratch buffers go out of scope
     }
 
     // include/ctranslate2/ops/rms_norm.h:17-20  <-  src/ops/rms_norm_gpu.cu:20-63
@@ -150,11 +189,34 @@ namespace ctranslate2 {
                                           const dim_t axis,                                  \
                                           const dim_t batch_dims,                            \
                                           StorageView& output) const {                       \
-      if (axis != 0 || batch_dims != 0)                                                      \
-        throw std::invalid_argument("Gather: only axis 0 (the beam reorder / embedding form)"); \
-      const dim_t row_size = data.size() / data.dim(0);                                      \
-      check(ct2x_gather_rows(data.data<T>(), input.data<int32_t>(), input.size(),            \
-                             row_size * dim_t(sizeof (T)), output.data<T>(), stream()));     \
+      if (axis == 0 && batch_dims == 0) {                                                    \
+        const dim_t row_size = data.size() / data.dim(0);                                    \
+        check(ct2x_gather_rows(data.data<T>(), input.data<int32_t>(), input.size(),          \
+                               row_size * dim_t(sizeof (T)), output.data<T>(), stream()));   \
+        return;                                                                              \
+      }                                                                                      \
+      /* gather along the first non-batch dimension (src/ops/gather_gpu.cu:53-91): the same row   \
+       * gather on data viewed as [batch * T, inner] with ids offset by batch * T (the offsets  \
+       * are added on the host: this form is not on the decoding hot path) */               \
+      if (axis != batch_dims)                                                                \
+        throw std::invalid_argument("Gather: the axis must be the first non-batch dimension"); \
+      dim_t batch = 1, inner = 1;                                                            \
+      for (dim_t i = 0; i < axis; ++i) batch *= data.dim(i);                                 \
+      for (dim_t i = axis + 1; i < data.rank(); ++i) inner *= data.dim(i);                   \
+      const dim_t time = data.dim(axis), per_batch = input.size() / batch;                   \
+      std::vector<int32_t> ids(input.size());                                                \
+      check(ct2x_copy_to_host(input.data<int32_t>(), ids.data(), ids.size() * 4, stream())); \
+      for (dim_t b = 0; b < batch; ++b)                                                      \
+        for (dim_t j = 0; j < per_batch; ++j) ids[b * per_batch + j] += int32_t(b * time);   \
+      void* d_ids = nullptr;                                                                 \
+      check(ct2x_malloc(&d_ids, ids.size() * 4));                                            \
+      check(ct2x_copy_to_device(ids.data(), d_ids, ids.size() * 4, stream()));               \
+      check(ct2x_stream_synchronize(stream()));                                              \
+      const int rc = ct2x_gather_rows(data.data<T>(), static_cast<const int32_t*>(d_ids),    \
+                                      dim_t(ids.size()), inner * dim_t(sizeof (T)),          \
+                                      output.data<T>(), stream());                           \
+      check(ct2x_free(d_ids));                                                               \
+      check(rc);                                                                             \
     }
     CT2X_GATHER_STUB(float)
     CT2X_GATHER_STUB(int8_t)
@@ -204,9 +266,39 @@ namespace ctranslate2 {
                                       float beta,
                                       int32_t* c, dim_t ldc,
                                       const int32_t*) {
-    if (transpose_a || !transpose_b || alpha != 1 || beta != 0 || lda != k || ldb != k || ldc != n)
-      throw std::invalid_argument("int8 GEMM: only the Dense call shape (A.B^T, alpha=1, beta=0)");
-    check(ct2x_gemm_s8s8s32(a, b, m, n, k, c, stream()));
+    if (alpha != 1 || beta != 0 || ldc != n)
+      throw std::invalid_argument("int8 GEMM: alpha = 1, beta = 0 and a dense output only");
+    if (!transpose_a && transpose_b && lda == k && ldb == k) {  // the Dense call shape: A.B^T
+      check(ct2x_gemm_s8s8s32(a, b, m, n, k, c, stream()));
+      return;
+    }
+    // Other operand layouts (the reference's op tests use A.B): brought to A.B^T through the
+    // host - not a path any layer takes.
+    std::vector<int8_t> ha(size_t(m) * k), hb(size_t(n) * k);
+    {
+      const dim_t a_rows = transpose_a ? k : m, b_rows = transpose_b ? n : k;
+      std::vector<int8_t> ra(size_t(a_rows) * lda), rb(size_t(b_rows) * ldb);
+      check(ct2x_copy_to_host(a, ra.data(), ra.size(), stream()));
+      check(ct2x_copy_to_host(b, rb.data(), rb.size(), stream()));
+      for (dim_t i = 0; i < m; ++i)
+        for (dim_t t = 0; t < k; ++t)
+          ha[i * k + t] = transpose_a ? ra[t * lda + i] : ra[i * lda + t];
+      for (dim_t j = 0; j < n; ++j)
+        for (dim_t t = 0; t < k; ++t)
+          hb[j * k + t] = transpose_b ? rb[j * ldb + t] : rb[t * ldb + j];
+    }
+    void *da = nullptr, *db = nullptr;
+    check(ct2x_malloc(&da, ha.size()));
+    check(ct2x_malloc(&db, hb.size()));
+    check(ct2x_copy_to_device(ha.data(), da, ha.size(), stream()));
+    check(ct2x_copy_to_device(hb.data(), db, hb.size(), stream()));
+    check(ct2x_stream_synchronize(stream()));
+    const int rc = ct2x_gemm_s8s8s32(static_cast<const int8_t*>(da), static_cast<const int8_t*>(db),
+                                     m, n, k, c, stream());
+    check(ct2x_stream_synchronize(stream()));
+    check(ct2x_free(da));
+    check(ct2x_free(db));
+    check(rc);
   }
 
   // include/ctranslate2/primitives.h (gemm<float, float>)  <-  src/cuda/primitives.cu:485-520:
@@ -222,10 +314,37 @@ namespace ctranslate2 {
                                       float beta,
                                       float* c, dim_t ldc,
                                       const float*) {
-    if (transpose_a || alpha != 1 || beta != 0 || lda != k || ldb != (transpose_b ? k : n) || ldc != n)
-      throw std::invalid_argument("float GEMM: only contiguous A.B / A.B^T with alpha=1, beta=0");
-    check(ct2x_gemm_f32(a, b, m, n, k, transpose_b ? 1 : 0, nullptr, nullptr, CT2X_ACT_NONE, c,
-                        stream()));
+    if (lda != (transpose_a ? m : k) || ldb != (transpose_b ? k : n) || ldc != n)
+      throw std::invalid_argument("float GEMM: contiguous row-major operands only");
+    if (!transpose_a && alpha == 1 && beta == 0) {  // what ops::Gemm produces for layers::Dense
+      check(ct2x_gemm_f32(a, b, m, n, k, transpose_b ? 1 : 0, nullptr, nullptr, CT2X_ACT_NONE, c,
+                          stream()));
+      return;
+    }
+    // General form C = alpha * op(A) . op(B) + beta * C (src/cuda/primitives.cu:485-520, cublasSgemm)
+    // composed from device entry points: transpose A when asked, product into scratch, then the
+    // two scalings and the sum.
+    const float* a_rm = a;
+    std::unique_ptr<Scratch> at;
+    if (transpose_a) {
+      at.reset(new Scratch(size_t(m) * k * sizeof (float)));
+      const int64_t dims[2] = {k, m}, perm[2] = {1, 0};
+      check(ct2x_transpose(a, dims, perm, 2, at->ptr, CT2X_F32, stream()));
+      a_rm = at->f();
+    }
+    Scratch prod(size_t(m) * n * sizeof (float));
+    check(ct2x_gemm_f32(a_rm, b, m, n, k, transpose_b ? 1 : 0, nullptr, nullptr, CT2X_ACT_NONE,
+                        prod.f(), stream()));
+    if (alpha != 1)
+      check(ct2x_binary_scalar(CT2X_OP_MUL, alpha, prod.f(), prod.f(), m * n, CT2X_F32, stream()));
+    if (beta == 0) {
+      check(ct2x_copy_device(prod.ptr, c, size_t(m) * n * sizeof (float), stream()));
+    } else {
+      if (beta != 1)
+        check(ct2x_binary_scalar(CT2X_OP_MUL, beta, c, c, m * n, CT2X_F32, stream()));
+      check(ct2x_binary(CT2X_OP_ADD, prod.f(), c, c, m * n, CT2X_F32, stream()));
+    }
+    check(ct2x_stream_synchronize(stream()));  // the scratch buffers go out of scope
   }
 
   // include/ctranslate2/primitives.h:224-232  <-  src/cuda/primitives.cu:599-683, as ops::MatMul
