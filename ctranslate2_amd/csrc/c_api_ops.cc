@@ -4,6 +4,7 @@
 #include "../../include/ct2_mi355.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 
 #include "kernels.h"
@@ -396,6 +397,27 @@ int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int3
                         std::max(length, 1), repetition_penalty, no_repeat_ngram_size,
                         d_suppress_ids, d_suppress_offsets, num_suppress, resolve_stream(stream));
   check_last_launch("process_logits");
+  API_CATCH
+}
+
+int ct2x_topp_mask(const float* d_x, const float* d_probs, int64_t rows, int64_t depth, float p,
+                   float mask_value, float* d_y, void* stream) {
+  API_TRY
+  CT2X_CHECK(rows >= 0 && depth >= 1 && d_x && d_probs && d_y, "ct2x_topp_mask: bad arguments");
+  launch_topp_mask(d_x, d_probs, rows, depth, p, mask_value, d_y, resolve_stream(stream));
+  check_last_launch("topp_mask");
+  API_CATCH
+}
+
+int ct2x_multinomial(const float* d_weights, int64_t rows, int64_t classes, int64_t samples,
+                     uint32_t seed, int32_t* d_out, void* stream) {
+  API_TRY
+  CT2X_CHECK(rows >= 0 && classes >= 1 && samples >= 1 && d_weights && d_out,
+             "ct2x_multinomial: bad arguments");
+  static std::atomic<uint32_t> calls{0};  // successive calls draw fresh numbers for one seed
+  launch_multinomial(d_weights, rows, classes, samples, seed, calls.fetch_add(1), d_out,
+                     resolve_stream(stream));
+  check_last_launch("multinomial");
   API_CATCH
 }
 

@@ -478,6 +478,79 @@ __global__ __launch_bounds__(1024) void random_sample_full_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ops::TopPMask standalone (src/ops/topp_mask_cpu.cc:12-39, src/ops/topp_mask_gpu.cu): in order of
+// decreasing probability, an element keeps its input value while the mass ranked before it is
+// < p, else it becomes `mask`. No sort: kept = { i : mass of the elements with a LARGER
+// probability < p }, the threshold found by bisection on the ordered bit pattern of the
+// probability (32 passes over the row; elements that tie with the threshold are all kept - the
+// reference keeps those its unstable sort happens to rank first). One workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topp_mask_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ probs, float p,
+                                                        float mask, int64_t depth,
+                                                        float* __restrict__ y) {
+  __shared__ float scratch[16];
+  const int64_t row = blockIdx.x;
+  const float* pr = probs + row * depth;
+  float top = -FLT_MAX;
+  for (int64_t j = threadIdx.x; j < depth; j += blockDim.x) top = fmaxf(top, pr[j]);
+  top = block_max(top, scratch);
+  uint32_t lo = 0, hi = ordered_key(top);
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    float above = 0.f;
+    for (int64_t j = threadIdx.x; j < depth; j += blockDim.x)
+      if (ordered_key(pr[j]) > mid) above += pr[j];
+    above = block_sum(above, scratch);
+    if (above < p)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  for (int64_t j = threadIdx.x; j < depth; j += blockDim.x)
+    y[row * depth + j] = (ordered_key(pr[j]) >= lo) ? x[row * depth + j] : mask;
+}
+
+void launch_topp_mask(const float* x, const float* probs, int64_t rows, int64_t depth, float p,
+                      float mask, float* y, hipStream_t stream) {
+  if (rows == 0 || depth == 0) return;
+  hipLaunchKernelGGL(topp_mask_kernel, dim3(rows), dim3(256), 0, stream, x, probs, p, mask, depth, y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ops::Multinomial standalone (src/ops/multinomial_cpu.cc / _gpu.cu): `samples` independent draws
+// per row of a (not necessarily normalised) weight row, by inverse CDF in index order; draw s of
+// row r of call c uses the counter-based hash of (seed, c, r * samples + s). One thread per draw.
+// ---------------------------------------------------------------------------------------------
+__global__ void multinomial_kernel(const float* __restrict__ weights, int64_t rows, int64_t classes,
+                                   int64_t samples, uint32_t seed, uint32_t call,
+                                   int32_t* __restrict__ out) {
+  const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (e >= rows * samples) return;
+  const int64_t row = e / samples;
+  const float* w = weights + row * classes;
+  float total = 0.f;
+  for (int64_t j = 0; j < classes; ++j) total += w[j];
+  const float u = uniform01(seed, call, static_cast<uint32_t>(e)) * total;
+  float acc = 0.f;
+  int32_t pick = -1, last = 0;
+  for (int64_t j = 0; j < classes && pick < 0; ++j) {
+    if (w[j] > 0.f) last = static_cast<int32_t>(j);
+    acc += w[j];
+    if (u < acc) pick = static_cast<int32_t>(j);
+  }
+  out[e] = pick >= 0 ? pick : last;
+}
+
+void launch_multinomial(const float* weights, int64_t rows, int64_t classes, int64_t samples,
+                        uint32_t seed, uint32_t call, int32_t* out, hipStream_t stream) {
+  const int64_t n = rows * samples;
+  if (n == 0) return;
+  hipLaunchKernelGGL(multinomial_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, weights, rows,
+                     classes, samples, seed, call, out);
+}
+
 void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int32_t disable_id,
                           int32_t min_length, bool with_scores, int topk, float topp,
                           float temperature, uint32_t seed, const int32_t* step_ptr,

@@ -306,6 +306,13 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           const float* uniforms = nullptr /* tests: [rows] draws in [0, 1) */);
 int max_sampling_topk();
 
+// ops::TopPMask / ops::Multinomial as standalone ops (the Level-1 stubs; the engine fuses both
+// into the samplers above).
+void launch_topp_mask(const float* x, const float* probs, int64_t rows, int64_t depth, float p,
+                      float mask, float* y, hipStream_t stream);
+void launch_multinomial(const float* weights, int64_t rows, int64_t classes, int64_t samples,
+                        uint32_t seed, uint32_t call, int32_t* out, hipStream_t stream);
+
 // RepetitionPenalty / NoRepeatNgram / SuppressSequences (src/decoding_utils.cc:37-153) in place on
 // the step's logits, one launch. seq[t * t_stride + row * row_stride] = token t of the row's
 // generated history; its length is *step_ptr - first_step (device resident) or `length`.

@@ -223,6 +223,15 @@ int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int3
                         const int32_t* d_suppress_ids, const int32_t* d_suppress_offsets,
                         int32_t num_suppress, void* stream);
 
+/* ops::TopPMask (src/ops/topp_mask_cpu.cc:12-39): y = x where the probability mass ranked before
+ * the element (by decreasing d_probs) is < p, else mask_value. Rows of any width. */
+int ct2x_topp_mask(const float* d_x, const float* d_probs, int64_t rows, int64_t depth, float p,
+                   float mask_value, float* d_y, void* stream);
+/* ops::Multinomial (src/ops/multinomial_cpu.cc): `samples` draws per row of weights [rows, classes]
+ * by inverse CDF; counter-based RNG on (seed, call number, draw). d_out [rows, samples]. */
+int ct2x_multinomial(const float* d_weights, int64_t rows, int64_t classes, int64_t samples,
+                     uint32_t seed, int32_t* d_out, void* stream);
+
 /* RandomSampler for one step (src/sampling.cc:41-101): best `sampling_topk` candidates (2..64;
  * <= 0: the whole vocabulary) -> temperature -> TopPMask (src/ops/topp_mask_cpu.cc:24-31) ->
  * SoftMax -> Multinomial by inverse CDF (candidates in TopK order; index order for the whole

@@ -15,6 +15,7 @@
 
 #include "ctranslate2/ops/ops.h"
 #include "ctranslate2/primitives.h"
+#include "ctranslate2/random.h"
 #include "cuda/random.h"
 #include "cuda/utils.h"
 
@@ -175,8 +176,11 @@ namespace ctranslate2 {
     }
 
     template<>
-    void Multinomial::compute<Device::CUDA, float>(const StorageView&, StorageView&) const {
-      not_provided("ops::Multinomial (random sampling runs fused: ct2x_translate_batch sampling_topk)");
+    void Multinomial::compute<Device::CUDA, float>(const StorageView& input, StorageView& output) const {
+      // src/ops/multinomial_gpu.cu: one inverse-CDF draw per (row, sample)
+      const dim_t classes = input.dim(-1);
+      check(ct2x_multinomial(input.data<float>(), input.size() / classes, classes, _sample_size,
+                             get_random_seed(), output.data<int32_t>(), ct2x_thread_stream()));
     }
 
     template<>
@@ -185,9 +189,11 @@ namespace ctranslate2 {
     }
 
     template<>
-    void TopPMask::compute<Device::CUDA, float>(const StorageView&, const StorageView&,
-                                                StorageView&) const {
-      not_provided("ops::TopPMask (random sampling runs fused: ct2x_translate_batch sampling_topp)");
+    void TopPMask::compute<Device::CUDA, float>(const StorageView& input, const StorageView& probs,
+                                                StorageView& output) const {
+      const dim_t depth = input.dim(-1);
+      check(ct2x_topp_mask(input.data<float>(), probs.data<float>(), input.size() / depth, depth, _p,
+                           _mask_value, output.data<float>(), ct2x_thread_stream()));
     }
 
   }

@@ -18,8 +18,8 @@ built = pytest.mark.skipif(not os.path.exists(BINARY),
 
 # Device::CUDA ops the stubs define as throwers (no int8 / float32 Transformer reaches them), ops
 # whose test drives a 16-bit arm, and fixtures this repository does not carry.
-NOT_PROVIDED = ("Conv1D", "Alibi", "FlashAttention", "GumbelMax", "MedianFilter", "Multinomial",
-                "TopPMask", "Half", "float16", "bfloat16")
+NOT_PROVIDED = ("Conv1D", "Alibi", "FlashAttention", "GumbelMax", "MedianFilter", "Half", "float16",
+                "bfloat16")
 
 
 def _run(flt):
@@ -52,6 +52,6 @@ def test_reference_cpp_tests_on_this_backend(gpu):
     assert out["ran"] >= 80
     # the hot path's op classes must be among the passes
     for needle in ("GemmInt8", "QuantizeINT8", "SoftMax", "LayerNorm", "RMSNorm", "TopK",
-                   "Gather", "Gemm", "Transpose", "Concat", "Split", "Tile"):
+                   "Gather", "Gemm", "Transpose", "Concat", "Split", "Tile", "TopPMask", "Multinomial"):
         assert any(needle in t for t in out["passed"]), needle
     assert not unexpected, unexpected
