@@ -400,6 +400,42 @@ int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int3
   API_CATCH
 }
 
+int ct2x_conv1d(const float* d_x, const float* d_w, int64_t batch, int64_t in_channels, int64_t length,
+                int64_t out_channels, int64_t kernel, int64_t stride, int64_t padding,
+                int64_t dilation, int64_t groups, float* d_y, void* stream) {
+  API_TRY
+  CT2X_CHECK(batch >= 0 && in_channels >= 1 && out_channels >= 1 && kernel >= 1 && stride >= 1 &&
+                 dilation >= 1 && padding >= 0 && groups >= 1 && in_channels % groups == 0 &&
+                 out_channels % groups == 0,
+             "ct2x_conv1d: bad geometry");
+  launch_conv1d(d_x, d_w, batch, in_channels, length, out_channels, kernel, stride, padding, dilation,
+                groups, d_y, resolve_stream(stream));
+  check_last_launch("conv1d");
+  API_CATCH
+}
+
+int ct2x_median_filter(const float* d_x, int64_t rows, int64_t depth, int64_t width, float* d_y,
+                       void* stream) {
+  API_TRY
+  CT2X_CHECK(width >= 1 && width <= 63 && width % 2 == 1, "ct2x_median_filter: odd width <= 63");
+  CT2X_CHECK(depth > width / 2, "ct2x_median_filter: the axis must be longer than half the window");
+  launch_median_filter(d_x, rows, depth, width, d_y, resolve_stream(stream));
+  check_last_launch("median_filter");
+  API_CATCH
+}
+
+int ct2x_alibi_add(const float* d_x, const float* d_alibi, int64_t batch, int64_t heads,
+                   int64_t queries, int64_t keys, int64_t alibi_keys, int64_t alibi_offset,
+                   float* d_y, void* stream) {
+  API_TRY
+  CT2X_CHECK(alibi_offset >= 0 && alibi_offset + keys <= alibi_keys,
+             "ct2x_alibi_add: the bias table is shorter than offset + keys");
+  launch_alibi_add(d_x, d_alibi, batch, heads, queries, keys, alibi_keys, alibi_offset, d_y,
+                   resolve_stream(stream));
+  check_last_launch("alibi_add");
+  API_CATCH
+}
+
 int ct2x_topp_mask(const float* d_x, const float* d_probs, int64_t rows, int64_t depth, float p,
                    float mask_value, float* d_y, void* stream) {
   API_TRY

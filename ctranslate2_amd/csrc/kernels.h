@@ -310,6 +310,15 @@ int max_sampling_topk();
 // into the samplers above).
 void launch_topp_mask(const float* x, const float* probs, int64_t rows, int64_t depth, float p,
                       float mask, float* y, hipStream_t stream);
+// Ops outside the hot path (primitives.hip): Whisper's Conv1D / MedianFilter, ALiBi bias.
+void launch_conv1d(const float* x, const float* w, int64_t batch, int64_t in_ch, int64_t len,
+                   int64_t out_ch, int64_t kernel, int64_t stride, int64_t padding, int64_t dilation,
+                   int64_t groups, float* y, hipStream_t stream);
+void launch_median_filter(const float* x, int64_t rows, int64_t depth, int64_t width, float* y,
+                          hipStream_t stream);
+void launch_alibi_add(const float* x, const float* alibi, int64_t batch, int64_t heads,
+                      int64_t queries, int64_t keys, int64_t alibi_keys, int64_t offset, float* y,
+                      hipStream_t stream);
 void launch_multinomial(const float* weights, int64_t rows, int64_t classes, int64_t samples,
                         uint32_t seed, uint32_t call, int32_t* out, hipStream_t stream);
 

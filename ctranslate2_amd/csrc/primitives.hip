@@ -326,4 +326,95 @@ void launch_prepare_length_mask(const int32_t* lengths, int64_t batch, int64_t h
                      heads, queries, mask_future, multi_query, mask, total);
 }
 
+// ---- ops outside the decoder hot path that the reference's front-end can still ask a device for
+// (Whisper's Conv1D front-end and MedianFilter alignment smoothing, ALiBi position bias): direct,
+// one thread per output element - correctness arms of the Level-1 boundary, not tuned kernels.
+
+// ops::Conv1D (src/ops/conv1d_cpu.cc / conv1d_gpu.cu; bias and activation are applied by the
+// caller through apply_bias_and_activation): x [batch, in_ch, len], w [out_ch, in_ch / groups,
+// kernel], y [batch, out_ch, out_len].
+__global__ void conv1d_kernel(const float* __restrict__ x, const float* __restrict__ w, int64_t in_ch,
+                              int64_t len, int64_t out_ch, int64_t kernel, int64_t stride,
+                              int64_t padding, int64_t dilation, int64_t groups, int64_t out_len,
+                              int64_t total, float* __restrict__ y) {
+  const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (e >= total) return;
+  const int64_t t = e % out_len, oc = (e / out_len) % out_ch, b = e / (out_len * out_ch);
+  const int64_t icg = in_ch / groups, ocg = out_ch / groups, g = oc / ocg;
+  const float* xb = x + (b * in_ch + g * icg) * len;
+  const float* wo = w + oc * icg * kernel;
+  float acc = 0.f;
+  for (int64_t ic = 0; ic < icg; ++ic)
+    for (int64_t k = 0; k < kernel; ++k) {
+      const int64_t pos = t * stride - padding + k * dilation;
+      if (pos >= 0 && pos < len) acc = fmaf(wo[ic * kernel + k], xb[ic * len + pos], acc);
+    }
+  y[e] = acc;
+}
+
+void launch_conv1d(const float* x, const float* w, int64_t batch, int64_t in_ch, int64_t len,
+                   int64_t out_ch, int64_t kernel, int64_t stride, int64_t padding, int64_t dilation,
+                   int64_t groups, float* y, hipStream_t stream) {
+  const int64_t out_len = (len + 2 * padding - (dilation * (kernel - 1) + 1)) / stride + 1;
+  const int64_t total = batch * out_ch * out_len;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(conv1d_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, stream, x, w, in_ch,
+                     len, out_ch, kernel, stride, padding, dilation, groups, out_len, total, y);
+}
+
+// ops::MedianFilter (src/ops/median_filter_cpu.cc:12-61): median of a window of `width` (odd,
+// <= 63) around every element of the last axis, reflected at both ends.
+__global__ void median_filter_kernel(const float* __restrict__ x, int64_t depth, int64_t width,
+                                     int64_t total, float* __restrict__ y) {
+  const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (e >= total) return;
+  const int64_t j = e % depth;
+  const float* in = x + (e - j);
+  const int64_t rank = width / 2;
+  float window[63];
+  for (int64_t k = -rank; k <= rank; ++k) {
+    int64_t read = j + k < 0 ? -(j + k) : j + k;
+    if (read >= depth) read = depth - (read - depth) - 2;
+    window[k + rank] = in[read];
+  }
+  for (int64_t a = 1; a < width; ++a) {  // insertion sort of the (short) window
+    const float v = window[a];
+    int64_t b = a - 1;
+    while (b >= 0 && window[b] > v) {
+      window[b + 1] = window[b];
+      --b;
+    }
+    window[b + 1] = v;
+  }
+  y[e] = window[rank];
+}
+
+void launch_median_filter(const float* x, int64_t rows, int64_t depth, int64_t width, float* y,
+                          hipStream_t stream) {
+  const int64_t total = rows * depth;
+  if (total == 0) return;
+  hipLaunchKernelGGL(median_filter_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, stream, x, depth,
+                     width, total, y);
+}
+
+// ops::AlibiAdd (src/ops/alibi_add_cpu.cc:8-31): y[b, h, q, k] = x[b, h, q, k] +
+// alibi[h, alibi_offset + k], alibi [1, heads, 1, alibi_keys].
+__global__ void alibi_add_kernel(const float* __restrict__ x, const float* __restrict__ alibi,
+                                 int64_t heads, int64_t queries, int64_t keys, int64_t alibi_keys,
+                                 int64_t offset, int64_t total, float* __restrict__ y) {
+  const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (e >= total) return;
+  const int64_t k = e % keys, h = (e / (keys * queries)) % heads;
+  y[e] = x[e] + alibi[h * alibi_keys + offset + k];
+}
+
+void launch_alibi_add(const float* x, const float* alibi, int64_t batch, int64_t heads,
+                      int64_t queries, int64_t keys, int64_t alibi_keys, int64_t offset, float* y,
+                      hipStream_t stream) {
+  const int64_t total = batch * heads * queries * keys;
+  if (total == 0) return;
+  hipLaunchKernelGGL(alibi_add_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, stream, x, alibi,
+                     heads, queries, keys, alibi_keys, offset, total, y);
+}
+
 }  // namespace ct2x

@@ -223,6 +223,21 @@ int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int3
                         const int32_t* d_suppress_ids, const int32_t* d_suppress_offsets,
                         int32_t num_suppress, void* stream);
 
+/* Ops outside the decoder hot path that the reference's front-end can still ask Device::CUDA for
+ * (direct one-thread-per-output kernels; correctness arms of the Level-1 boundary):
+ * ops::Conv1D without bias / activation (src/ops/conv1d_gpu.cu; x [batch, in, len], w [out,
+ * in / groups, kernel], y [batch, out, (len + 2 pad - dil (kernel - 1) - 1) / stride + 1]);
+ * ops::MedianFilter over the last axis (src/ops/median_filter_cpu.cc:12-61, odd width <= 63);
+ * ops::AlibiAdd (src/ops/alibi_add_cpu.cc:8-31; alibi [1, heads, 1, alibi_keys]). */
+int ct2x_conv1d(const float* d_x, const float* d_w, int64_t batch, int64_t in_channels, int64_t length,
+                int64_t out_channels, int64_t kernel, int64_t stride, int64_t padding,
+                int64_t dilation, int64_t groups, float* d_y, void* stream);
+int ct2x_median_filter(const float* d_x, int64_t rows, int64_t depth, int64_t width, float* d_y,
+                       void* stream);
+int ct2x_alibi_add(const float* d_x, const float* d_alibi, int64_t batch, int64_t heads,
+                   int64_t queries, int64_t keys, int64_t alibi_keys, int64_t alibi_offset,
+                   float* d_y, void* stream);
+
 /* ops::TopPMask (src/ops/topp_mask_cpu.cc:12-39): y = x where the probability mass ranked before
  * the element (by decreasing d_probs) is < p, else mask_value. Rows of any width. */
 int ct2x_topp_mask(const float* d_x, const float* d_probs, int64_t rows, int64_t depth, float p,

@@ -144,16 +144,24 @@ namespace ctranslate2 {
     }
 
     template<>
-    void AlibiAdd::compute<Device::CUDA, float>(const StorageView&, const StorageView&, const dim_t,
-                                                StorageView&) const {
-      not_provided("ops::AlibiAdd");
+    void AlibiAdd::compute<Device::CUDA, float>(const StorageView& input, const StorageView& alibi,
+                                                const dim_t alibi_offset, StorageView& output) const {
+      check(ct2x_alibi_add(input.data<float>(), alibi.data<float>(), input.dim(0), input.dim(1),
+                           input.dim(2), input.dim(3), alibi.dim(-1), alibi_offset,
+                           output.data<float>(), ct2x_thread_stream()));
     }
 
     template<>
-    void Conv1D::compute<Device::CUDA, float>(const StorageView&, const StorageView&,
-                                              const StorageView*, StorageView&,
-                                              const StorageView*) const {
-      not_provided("ops::Conv1D");
+    void Conv1D::compute<Device::CUDA, float>(const StorageView& input, const StorageView& weight,
+                                              const StorageView* bias, StorageView& output,
+                                              const StorageView* qscale) const {
+      if (qscale)
+        not_provided("ops::Conv1D with quantised weights");
+      // src/ops/conv1d_gpu.cu:12-131: the convolution, then bias + activation over the channel axis
+      check(ct2x_conv1d(input.data<float>(), weight.data<float>(), input.dim(0), input.dim(1),
+                        input.dim(2), weight.dim(0), weight.dim(2), _stride, _padding, _dilation,
+                        _groups, output.data<float>(), ct2x_thread_stream()));
+      apply_bias_and_activation(output, bias, _activation_type, /*residual=*/nullptr, /*axis=*/-2);
     }
 
     template<>
@@ -170,9 +178,15 @@ namespace ctranslate2 {
     }
 
     template<>
-    void MedianFilter::compute<Device::CUDA, float>(const StorageView&, const dim_t,
-                                                    StorageView&) const {
-      not_provided("ops::MedianFilter");
+    void MedianFilter::compute<Device::CUDA, float>(const StorageView& input, const dim_t axis_size,
+                                                    StorageView& output) const {
+      if (axis_size <= _width / 2) {  // src/ops/median_filter_cpu.cc:24-28: pass through
+        if (&output != &input)
+          output.copy_from(input);
+        return;
+      }
+      check(ct2x_median_filter(input.data<float>(), input.size() / axis_size, axis_size, _width,
+                               output.data<float>(), ct2x_thread_stream()));
     }
 
     template<>

@@ -18,8 +18,7 @@ built = pytest.mark.skipif(not os.path.exists(BINARY),
 
 # Device::CUDA ops the stubs define as throwers (no int8 / float32 Transformer reaches them), ops
 # whose test drives a 16-bit arm, and fixtures this repository does not carry.
-NOT_PROVIDED = ("Conv1D", "Alibi", "FlashAttention", "GumbelMax", "MedianFilter", "Half", "float16",
-                "bfloat16")
+NOT_PROVIDED = ("FlashAttention", "GumbelMax", "Half", "float16", "bfloat16")
 
 
 def _run(flt):
