@@ -400,6 +400,16 @@ int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int3
   API_CATCH
 }
 
+int ct2x_convert(const void* d_x, int src_dtype, void* d_y, int dst_dtype, int64_t size, void* stream) {
+  API_TRY
+  auto is_float = [](int d) { return d == CT2X_F32 || d == CT2X_F16 || d == CT2X_BF16; };
+  CT2X_CHECK(is_float(src_dtype) && is_float(dst_dtype) && size >= 0,
+             "ct2x_convert: float32 / float16 / bfloat16 only");
+  launch_convert(d_x, src_dtype, d_y, dst_dtype, size, resolve_stream(stream));
+  check_last_launch("convert");
+  API_CATCH
+}
+
 int ct2x_conv1d(const float* d_x, const float* d_w, int64_t batch, int64_t in_channels, int64_t length,
                 int64_t out_channels, int64_t kernel, int64_t stride, int64_t padding,
                 int64_t dilation, int64_t groups, float* d_y, void* stream) {

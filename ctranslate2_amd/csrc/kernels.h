@@ -310,6 +310,9 @@ int max_sampling_topk();
 // into the samplers above).
 void launch_topp_mask(const float* x, const float* probs, int64_t rows, int64_t depth, float p,
                       float mask, float* y, hipStream_t stream);
+// primitives::convert between CT2X_F32 / CT2X_F16 / CT2X_BF16 (the values of ct2x_dtype).
+void launch_convert(const void* x, int src_dtype, void* y, int dst_dtype, int64_t n,
+                    hipStream_t stream);
 // Ops outside the hot path (primitives.hip): Whisper's Conv1D / MedianFilter, ALiBi bias.
 void launch_conv1d(const float* x, const float* w, int64_t batch, int64_t in_ch, int64_t len,
                    int64_t out_ch, int64_t kernel, int64_t stride, int64_t padding, int64_t dilation,

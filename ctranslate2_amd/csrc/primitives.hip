@@ -9,6 +9,8 @@
 // grid-stride step, consecutive lanes on consecutive addresses.
 #include <algorithm>
 
+#include <hip/hip_fp16.h>
+
 #include "device_utils.h"
 #include "kernels.h"
 #include "runtime.h"
@@ -324,6 +326,42 @@ void launch_prepare_length_mask(const int32_t* lengths, int64_t batch, int64_t h
   if (total == 0) return;
   hipLaunchKernelGGL(length_mask_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, stream, lengths,
                      heads, queries, mask_future, multi_query, mask, total);
+}
+
+// primitives::convert between float32, float16 and bfloat16 (src/cuda/primitives.cu:160-196):
+// round to nearest even on the way down (the hardware conversion for fp16, the usual bias trick
+// for bf16 with quiet NaNs), exact on the way up; 16 -> 16 goes through float.
+__device__ __forceinline__ float load_as_float(const void* p, int64_t i, int dtype) {
+  if (dtype == 0) return static_cast<const float*>(p)[i];
+  const uint16_t b = static_cast<const uint16_t*>(p)[i];
+  if (dtype == 4) return __half2float(__ushort_as_half(b));
+  return __uint_as_float(static_cast<uint32_t>(b) << 16);
+}
+__device__ __forceinline__ void store_from_float(void* p, int64_t i, int dtype, float v) {
+  if (dtype == 0) {
+    static_cast<float*>(p)[i] = v;
+  } else if (dtype == 4) {
+    static_cast<uint16_t*>(p)[i] = __half_as_ushort(__float2half_rn(v));
+  } else {
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u)
+      u = 0x7fc00000u;  // NaN
+    else
+      u += 0x7fffu + ((u >> 16) & 1u);
+    static_cast<uint16_t*>(p)[i] = static_cast<uint16_t>(u >> 16);
+  }
+}
+__global__ void convert_kernel(const void* __restrict__ x, int src, void* __restrict__ y, int dst,
+                               int64_t n) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) store_from_float(y, i, dst, load_as_float(x, i, src));
+}
+
+void launch_convert(const void* x, int src_dtype, void* y, int dst_dtype, int64_t n,
+                    hipStream_t stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(convert_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, stream, x, src_dtype, y,
+                     dst_dtype, n);
 }
 
 // ---- ops outside the decoder hot path that the reference's front-end can still ask a device for

@@ -223,6 +223,10 @@ int ct2x_process_logits(float* d_logits, int64_t rows, int64_t vocab, const int3
                         const int32_t* d_suppress_ids, const int32_t* d_suppress_offsets,
                         int32_t num_suppress, void* stream);
 
+/* primitives::convert (src/cuda/primitives.cu:160-196): element-wise conversion between CT2X_F32,
+ * CT2X_F16 and CT2X_BF16 (round to nearest even on the way down). */
+int ct2x_convert(const void* d_x, int src_dtype, void* d_y, int dst_dtype, int64_t size, void* stream);
+
 /* Ops outside the decoder hot path that the reference's front-end can still ask Device::CUDA for
  * (direct one-thread-per-output kernels; correctness arms of the Level-1 boundary):
  * ops::Conv1D without bias / activation (src/ops/conv1d_gpu.cu; x [batch, in, len], w [out,

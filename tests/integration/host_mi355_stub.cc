@@ -124,6 +124,8 @@ namespace ctranslate2 {
     CT2X_LAYOUT_STUBS(int8_t)
     CT2X_LAYOUT_STUBS(int16_t)
     CT2X_LAYOUT_STUBS(int32_t)
+    CT2X_LAYOUT_STUBS(float16_t)   // 2-byte payloads: the 16-bit float arms move bytes like int16
+    CT2X_LAYOUT_STUBS(bfloat16_t)
 #undef CT2X_LAYOUT_STUBS
 
     // include/ctranslate2/ops/mean.h:16-22  <-  src/ops/mean_gpu.cu:12-63

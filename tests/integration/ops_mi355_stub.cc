@@ -222,6 +222,8 @@ namespace ctranslate2 {
     CT2X_GATHER_STUB(int8_t)
     CT2X_GATHER_STUB(int16_t)
     CT2X_GATHER_STUB(int32_t)
+    CT2X_GATHER_STUB(float16_t)   // rows are moved as bytes
+    CT2X_GATHER_STUB(bfloat16_t)
 #undef CT2X_GATHER_STUB
 
     // include/ctranslate2/ops/bias_add.h:20-24  <-  src/ops/bias_add_gpu.cu:46-102 (the CPU body,

@@ -39,9 +39,19 @@ def test_reference_python_extension_loads_and_translates_on_cpu():
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not _built(), reason="oracle/_ref/pyext is built where /root/reference exists")
-@pytest.mark.parametrize("compute_type", ["int8", "float32"])
+@pytest.mark.parametrize("compute_type", ["int8", "float32", "float16", "bfloat16"])
 def test_reference_python_extension_on_this_backend(gpu, compute_type):
+    """float16 / bfloat16: the reference's front-end keeps 16-bit activations end to end and every op
+    goes through the 16-bit arms of the stubs (tests/integration/half_mi355_stub.cc)."""
     model = AREN if compute_type == "int8" else AREN.replace("-i8", "")
+    if compute_type in ("float16", "bfloat16"):
+        spec = {"model": model, "device": "cuda", "compute_type": compute_type, "tokens": AREN_SRC,
+                "beams": [1, 4]}
+        dev = _run(spec)
+        assert compute_type in dev["compute_types"]
+        for run in dev["runs"]:
+            assert run["hypotheses"][0] == ["a", "t", "z", "m", "o", "n"]
+        return
     spec = {"model": model, "device": "cuda", "compute_type": compute_type, "tokens": AREN_SRC,
             "beams": [1, 4]}
     dev = _run(spec)

@@ -1,6 +1,7 @@
 """The reference's own C++ test-suite (tests/*.cc, compiled unmodified: `make -C oracle reftests`)
 against the Level-1 library. CPU here: proves the googletest stand-in and the build. GPU: the
-suites the reference instantiates for Device::CUDA (float32 arm) run on the MI355X through
+suites the reference instantiates for Device::CUDA (float32, float16 and bfloat16 arms) run on the
+MI355X through
 libct2_mi355.so - the reference's own known-answer tests judging this backend."""
 import json
 import os
@@ -18,7 +19,7 @@ built = pytest.mark.skipif(not os.path.exists(BINARY),
 
 # Device::CUDA ops the stubs define as throwers (no int8 / float32 Transformer reaches them), ops
 # whose test drives a 16-bit arm, and fixtures this repository does not carry.
-NOT_PROVIDED = ("FlashAttention", "GumbelMax", "Half", "float16", "bfloat16")
+NOT_PROVIDED = ("FlashAttention", "GumbelMax")
 
 
 def _run(flt):
@@ -40,7 +41,7 @@ def test_reference_cpp_tests_cpu_ops():
 @pytest.mark.gpu
 @built
 def test_reference_cpp_tests_on_this_backend(gpu):
-    out = _run("CUDA/*-*float16*:*bfloat16*")
+    out = _run("CUDA/*")
     bad = out["failed"] + out["crashed"]
     unexpected = [t for t in bad if not any(k in t for k in NOT_PROVIDED)]
     print("Device::CUDA instantiations on the MI355X: %d ran, %d passed, %d skipped; not provided: %s; "
