@@ -277,6 +277,60 @@ int ct2x_norm_gemm_s8_dequant(const float* d_x, const float* d_gamma, const floa
   API_CATCH
 }
 
+int ct2x_norm_gemm_s8_dequant_amax(const float* d_x, const float* d_gamma, const float* d_beta,
+                                   float eps, int rms_use_residual, int quant_flags,
+                                   const int8_t* d_w, const float* d_w_scale, const float* d_bias,
+                                   const float* d_residual, int64_t m, int64_t n, int64_t k,
+                                   int activation, float* d_y, float* d_row_amax_out, void* stream) {
+  API_TRY
+  CT2X_CHECK(gemm_s8_norm_applicable(m, n, k),
+             "ct2x_norm_gemm_s8_dequant_amax: needs m <= 128, k in {64, 128, 256, 512}, n < 8192");
+  CT2X_CHECK(d_row_amax_out != nullptr, "ct2x_norm_gemm_s8_dequant_amax: d_row_amax_out is NULL");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.w_scale = d_w_scale;
+  ep.bias = d_bias;
+  ep.residual = d_residual;
+  ep.y = d_y;
+  ep.act = activation;
+  ep.ldy = n;
+  ep.norm_x = d_x;
+  ep.norm_gamma = d_gamma;
+  ep.norm_beta = d_beta;
+  ep.norm_eps = eps;
+  ep.norm_rms_residual = rms_use_residual != 0;
+  ep.quant_mode = quant_flags;
+  ep.row_amax_out = d_row_amax_out;
+  launch_gemm_s8(nullptr, d_w, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("norm_gemm_s8_dequant_amax");
+  API_CATCH
+}
+
+int ct2x_gemm_s8_dequant_quantizing(const float* d_x, const float* d_row_amax, int quant_flags,
+                                    const int8_t* d_w, const float* d_w_scale, const float* d_bias,
+                                    const float* d_residual, int64_t m, int64_t n, int64_t k,
+                                    int activation, float* d_y, void* stream) {
+  API_TRY
+  CT2X_CHECK(gemm_s8_qol_applicable(m, n, k),
+             "ct2x_gemm_s8_dequant_quantizing: needs m <= 128, k % 64 == 0, n <= 4096, m * k <= 262144");
+  CT2X_CHECK(d_x != nullptr && d_row_amax != nullptr,
+             "ct2x_gemm_s8_dequant_quantizing: d_x / d_row_amax is NULL");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.w_scale = d_w_scale;
+  ep.bias = d_bias;
+  ep.residual = d_residual;
+  ep.y = d_y;
+  ep.act = activation;
+  ep.ldy = n;
+  ep.a_f32 = d_x;
+  ep.a_amax = d_row_amax;
+  ep.quant_mode = quant_flags;
+  launch_gemm_s8(nullptr, d_w, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("gemm_s8_dequant_quantizing");
+  API_CATCH
+}
+
 int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,
                          void* d_y, int dtype, void* stream) {
   API_TRY

@@ -148,6 +148,31 @@ __device__ __forceinline__ ValIdx wave_argmax_dpp(ValIdx x) {
 
 __device__ __forceinline__ float exp_avx2(float x);
 
+// Correctly rounded t / d in five full-rate VALU operations instead of the 11-instruction IEEE
+// sequence the compiler emits (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup) - for epilogues
+// that divide many values by the same per-column scale (the CPU formula order of the reference's
+// Dequantize keeps a true division: src/cpu/kernels.cc:666-673). y = 1.f / d is the correctly
+// rounded reciprocal (one real division per column); q0 = RN(t y) is within 2 ulp of t / d, one
+// residual correction makes it faithful, and by Markstein's theorem (y = RN(1/d), faithful q,
+// exact residual by FMA) the second correction returns RN(t / d). No step may underflow or
+// overflow: callers guarantee d in [2^-30, 2^30] (exact_div_divisor_ok) and t = int32 * r with
+// r in [2^-29, 2^29] (exact_div_factor_ok), i.e. |t| in {0} U [2^-29, 2^60]; anything else takes
+// the plain division. Checked against t / d on 10^11 random and adversarial pairs on the CPU
+// (oracle/div_check.c, tests/test_oracle.py::test_exact_division_identity).
+__device__ __forceinline__ float exact_div(float t, float d, float y) {
+  const float q0 = t * y;
+  const float r0 = __builtin_fmaf(-d, q0, t);
+  const float q1 = __builtin_fmaf(r0, y, q0);
+  const float r1 = __builtin_fmaf(-d, q1, t);
+  return __builtin_fmaf(r1, y, q1);
+}
+__device__ __forceinline__ bool exact_div_divisor_ok(float d) {
+  return d >= 9.313225746154785e-10f /* 2^-30 */ && d <= 1073741824.f /* 2^30 */;
+}
+__device__ __forceinline__ bool exact_div_factor_ok(float r) {
+  return r >= 1.862645149230957e-09f /* 2^-29 */ && r <= 536870912.f /* 2^29 */;
+}
+
 __device__ __forceinline__ float apply_activation(float v, int act) {
   switch (act) {
     case 0:  // ReLU

@@ -863,7 +863,7 @@ void Engine::norm_quant(const NormW& w, const float* x, int64_t rows, int64_t de
 
 // layers::Dense::operator() (src/layers/common.cc:339-442).
 bool Engine::dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_t m, int act,
-                        const float* residual, float* y) {
+                        const float* residual, float* y, float* row_amax_out) {
   if (!gemm_s8_norm_fusion_enabled() || taps_ || !ln.present || !w.quantized || w.row_parallel ||
       !gemm_s8_norm_applicable(m, w.n, w.k))
     return false;
@@ -881,6 +881,7 @@ bool Engine::dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_
   ep.norm_eps = ln.eps;
   ep.norm_rms_residual = ln.use_residual;
   ep.quant_mode = quant_mode_;
+  ep.row_amax_out = row_amax_out;
   const double M = double(m), N = double(w.n), K = double(w.k);
   begin_kernel("norm_gemm_s8_dequant", 4 * M * K + N * K + 4 * N + 8 * K + 4 * M * N +
                                            (residual ? 4 * M * N : 0) + (w.bias ? 4 * N : 0),
@@ -888,6 +889,29 @@ bool Engine::dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_
   launch_gemm_s8(nullptr, w.wq, m, w.n, w.k, ep, cur_stream());
   end_kernel();
   return true;
+}
+
+// An int8 Dense whose ops::Quantize is folded into the A-fragment fetch (gemm_s8.hip, QOL): x is the
+// fp32 activation, row_amax its row absmax left by the producing launch.
+void Engine::dense_qol(const DenseW& w, const float* x, const float* row_amax, int64_t m, int act,
+                       const float* residual, float* y) {
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.w_scale = w.wscale;
+  ep.bias = w.bias;
+  ep.residual = residual;
+  ep.y = y;
+  ep.act = act;
+  ep.ldy = w.n;
+  ep.a_f32 = x;
+  ep.a_amax = row_amax;
+  ep.quant_mode = quant_mode_;
+  const double M = double(m), N = double(w.n), K = double(w.k);
+  begin_kernel("qgemm_s8_dequant", 4 * M * K + N * K + 4 * N + 4 * M + 4 * M * N +
+                                       (residual ? 4 * M * N : 0) + (w.bias ? 4 * N : 0),
+               2 * M * N * K, m, w.n, w.k);
+  launch_gemm_s8(nullptr, w.wq, m, w.n, w.k, ep, cur_stream());
+  end_kernel();
 }
 
 // Output projection of an attention block + residual + the NEXT sub-layer's pre-norm + Quantize
@@ -1356,11 +1380,19 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
     // the previous block's row-owning output projection already normalised and quantised x
     fq.q = st.qbuf;
     fq.s = st.qscale;
-  } else if (ffn.ln.present && pre_norm && !ffn.l0_noact.present &&
-      dense_norm(ffn.ln, ffn.l0, x, rows, ffn.activation, nullptr, st.inner)) {
-    dense(ffn.l1, st.inner, nullptr, rows, -1, x, y, &st);
-    std::swap(x, y);
-    return;
+  } else if (ffn.ln.present && pre_norm && !ffn.l0_noact.present) {
+    // The inner activation's Quantize has no launch of its own when the producer can leave the row
+    // absmax and the consumer quantises while it loads (6 launches less per Transformer-base step)
+    const bool qol = amax_buf != nullptr && !tp_ && !taps_ && gemm_s8_qol_enabled() &&
+                     ffn.l1.quantized && !ffn.l1.row_parallel &&
+                     gemm_s8_qol_applicable(rows, ffn.l1.n, ffn.l1.k);
+    if (dense_norm(ffn.ln, ffn.l0, x, rows, ffn.activation, nullptr, st.inner,
+                   qol ? amax_buf : nullptr)) {
+      if (qol) dense_qol(ffn.l1, st.inner, amax_buf, rows, -1, x, y);
+      else dense(ffn.l1, st.inner, nullptr, rows, -1, x, y, &st);
+      std::swap(x, y);
+      return;
+    }
   }
   if (qin_ready) {
   } else if (ffn.ln.present && pre_norm) {
@@ -1536,12 +1568,15 @@ void Engine::launch_step(DecodeState& st) {
   // (only models whose layers take that path pay for the memset node: gated-FFN decoders)
   const bool split_quant = !tp_ && rows <= 32 && !dec_.layers.empty() &&
                            dec_.layers[0].ffn.l0_noact.present;
-  if (split_quant)
-    CT2X_HIP_CHECK(hipMemsetAsync(st.row_amax, 0,
-                                  sizeof(float) * 2 * dec_.layers.size() * rows, cur_stream()));
+  // ... and so do the feed-forward blocks whose inner Quantize is folded into the consuming GEMM
+  // (run_ffn / dense_qol). The slots are cleared by the step's first launch, not by a memset node.
+  const bool ffn_amax = !tp_ && !taps_ && rows <= 128 && !dec_.layers.empty() && gemm_s8_qol_enabled();
+  const bool zero_amax = split_quant || ffn_amax;
   begin_kernel("embed");
   launch_embed(dec_.emb.table, dec_.emb.is_int8, dec_.emb.scale, st.d_ids, rows, d,
-               dec_.embeddings_scale, dec_.scale_embeddings, pos, 1, 0, st.d_step, x, cur_stream());
+               dec_.embeddings_scale, dec_.scale_embeddings, pos, 1, 0, st.d_step, x, cur_stream(),
+               zero_amax ? st.row_amax : nullptr,
+               zero_amax ? 2 * static_cast<int64_t>(dec_.layers.size()) * rows : 0);
   end_kernel();
   tap_scope("dec");
   tap("emb", x, 0, rows, d);
@@ -1732,7 +1767,7 @@ void Engine::launch_step(DecodeState& st) {
     // ---- feed forward ----------------------------------------------------------------------
     tap_scope("dec.l" + std::to_string(l) + ".ffn");
     run_ffn(layer.ffn, dec_.pre_norm, rows, d, x, y, st,
-            split_quant ? st.row_amax + (2 * l + 1) * rows : nullptr, qin_ready);
+            (split_quant || ffn_amax) ? st.row_amax + (2 * l + 1) * rows : nullptr, qin_ready);
     qin_ready = false;
   }
 

@@ -263,8 +263,12 @@ private:
 
   // Pre-norm Dense at decode rows with the norm + Quantize as the GEMM's prologue (one launch);
   // false when the shape / layer does not qualify (the caller then runs norm_quant + dense).
+  // row_amax_out (optional): the launch also max-combines the row absmax of y into it.
   bool dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_t m, int act,
-                  const float* residual, float* y);
+                  const float* residual, float* y, float* row_amax_out = nullptr);
+  // int8 Dense that quantises its fp32 input while loading it (row absmax given by the producer)
+  void dense_qol(const DenseW& w, const float* x, const float* row_amax, int64_t m, int act,
+                 const float* residual, float* y);
   void load_weights();
   // How a Dense is split over the tensor-parallel ranks (Model::load, src/models/model.cc:
   // 662-743): kColumn = output rows; `blocks` lists the sizes of the fused sub-matrices that are

@@ -215,7 +215,12 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
 // fp32 from L2, one wave per row, DPP reductions) - one launch and one activation round trip
 // less per Dense. The quantised rows live in LDS (row stride K + 16 bytes) and the MFMA A
 // fragments are read from there.
-template <int MT, int NT, int WAVES, int U, bool DUAL = false, int NORM = 0>
+// QOL ("quantise on load"): the ops::Quantize that feeds this Dense is folded into the A-fragment
+// fetch. The producer of the fp32 activation left the row absmax (GemmS8Epilogue::row_amax_out of
+// the previous launch), so scale = 127 / amax is known per row and every lane converts the 16 floats
+// of its fragment itself (to_s8: src/cpu/kernels.cc:577-651) - the int8 copy of the activation, its
+// scale vector and the Quantize launch between the two GEMMs of a feed-forward block disappear.
+template <int MT, int NT, int WAVES, int U, bool DUAL = false, int NORM = 0, bool QOL = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
     GemmS8Epilogue ep) {
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
   extern __shared__ __attribute__((aligned(16))) int8_t norm_lds[];
   constexpr int NORM_CH = NORM > 0 ? NORM : 1;  // float4s per lane: K == 64 * NORM
   static_assert(!NORM || (MT == 1 && WAVES == 4), "NORM: 16 rows on four waves, 16 lanes per row");
+  static_assert(!QOL || (MT == 1 && !NORM && !DUAL), "QOL: one 16-row tile, plain Dense");
   const int qa_stride = K + 16;
   const int norm_pad = NORM ? norm_chain_pad(K) : 0;
   const int norm_x_stride = 8 * norm_pad;
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int rb = blockIdx.y * (MT * 16);
     M -= rb;
     if (NORM) ep.norm_x += static_cast<int64_t>(rb) * K;
+    else if (QOL) { ep.a_f32 += static_cast<int64_t>(rb) * K; ep.a_amax += rb; }
     else A += static_cast<int64_t>(rb) * K;
     if (ep.a_scale) ep.a_scale += rb;
     if (ep.c_i32) ep.c_i32 += static_cast<int64_t>(rb) * ep.ldy;
@@ -272,7 +279,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     e_ra[o] = e_ws[o] = e_ws2[o] = 1.f;
     e_bias[o] = e_res[o] = e_bias2[o] = 0.f;
     if (ep.mode == 1 && flat < OUTS && row < M && col < N) {
-      if (!NORM) e_ra[o] = ep.a_scale[row];
+      if (QOL) {
+        const float am = ep.a_amax[row];
+        e_ra[o] = (am != 0.f) ? 127.f / am : 1.f;  // the scale ops::Quantize would have stored
+      } else if (!NORM) {
+        e_ra[o] = ep.a_scale[row];
+      }
       e_ws[o] = ep.w_scale[col];
       if (ep.bias) e_bias[o] = ep.bias[col];
       if (ep.residual) e_res[o] = ep.residual[static_cast<int64_t>(row) * ep.ldy + col];
@@ -446,8 +458,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[d][i][j] = v4i{0, 0, 0, 0};
 
+  // QOL: lane (r, g) owns row r of the 16-row tile
+  float qol_scale = 1.f;
+  if (QOL && r < M) {
+    const float am = ep.a_amax[r];
+    qol_scale = (am != 0.f) ? 127.f / am : 1.f;
+  }
+  const bool qol_shift = QOL && (ep.quant_mode & kQuantU8Shift) != 0;
+  const bool qol_round = QOL && (ep.quant_mode & kQuantRound) != 0;
+
   for (int ks0 = wave; ks0 < ksteps; ks0 += WAVES * U) {
     v4i af[U][MT], bf[ND][U][NT];
+    v4f xf[QOL ? U : 1][4];
     // Issue every load of this round before the first MFMA consumes one.
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -457,7 +479,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int row = i * 16 + r;
-        if (NORM)
+        if (QOL) {
+          // 16 consecutive floats of the fp32 activation row (64 bytes per lane)
+          const v4f* src = reinterpret_cast<const v4f*>(ep.a_f32 + static_cast<int64_t>(row) * K + kk);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            xf[u][c] = (k_ok && row < M) ? src[c] : v4f{0.f, 0.f, 0.f, 0.f};
+        } else if (NORM)
           af[u][i] = (k_ok && row < M)
                          ? *reinterpret_cast<const v4i*>(norm_qa_lds + row * qa_stride + kk)
                          : v4i{0, 0, 0, 0};
@@ -477,6 +505,35 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
         if (DUAL)
           bf[ND - 1][u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B2 + col * K + kk)
                                                : v4i{0, 0, 0, 0};
+      }
+    }
+    if (QOL) {
+      // Quantize (to_s8, device_utils.h) of the fragments; rows >= M and K-steps past the end hold
+      // zeros, whose image under the u8-shift arm is 0 as well (128 - 128)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        v4i packed;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (qol_shift && qol_round) {
+            int b[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              b[e] = static_cast<int>(rintf(fmaf(xf[u][c][e], qol_scale, 128.f)));
+            const unsigned lo = __builtin_amdgcn_perm(static_cast<unsigned>(b[1]),
+                                                      static_cast<unsigned>(b[0]), 0x0c0c0400u);
+            const unsigned hi = __builtin_amdgcn_perm(static_cast<unsigned>(b[3]),
+                                                      static_cast<unsigned>(b[2]), 0x04000c0cu);
+            packed[c] = static_cast<int>((lo | hi) ^ 0x80808080u);
+          } else {
+            int word = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              word |= (static_cast<int>(to_s8(xf[u][c][e], qol_scale, ep.quant_mode)) & 0xff) << (8 * e);
+            packed[c] = word;
+          }
+        }
+        af[u][0] = packed;
       }
     }
 #pragma unroll
@@ -582,6 +639,28 @@ bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k) {
   return m >= 1 && m <= 128 && (k == 64 || k == 128 || k == 256 || k == 512) && n >= 1 && n < 8192;
 }
 
+// Shapes the quantise-on-load form serves: decode rows and a K that is whole MFMA K-steps. The
+// fp32 activation is 4x the bytes of its int8 copy and every column workgroup re-reads its 16 rows
+// from L2, so the form only pays where that stays small next to a launch: m * k * 4 <= 1 MiB
+// (Transformer-base FFN: 32 x 2048) - the Llama shapes (16 x 14336 into 256 workgroups) keep
+// the element-wise Quantize launch.
+bool gemm_s8_qol_applicable(int64_t m, int64_t n, int64_t k) {
+  return m >= 1 && m <= 128 && k % 64 == 0 && k >= 64 && n >= 1 && n <= 4096 &&
+         m * k * 4 <= (1 << 20);
+}
+
+// Measured on Transformer-base (batch 32, same box, same run): 91.3k tokens/s with the folded
+// Quantize (52 launches per step) against 94.4k with its own launch (58): the lane-strided fetch of
+// the fp32 rows (64 bytes per lane, 16 rows apart) costs the consuming GEMM more than the 2.2 us
+// launch it removes. Off by default; CT2X_QUANT_ON_LOAD=1 turns it on (bit-identical either way).
+bool gemm_s8_qol_enabled() {
+  static const bool enabled = [] {
+    const char* e = std::getenv("CT2X_QUANT_ON_LOAD");
+    return e != nullptr && e[0] == '1';
+  }();
+  return enabled;
+}
+
 // Round 1 measured a one-wave-per-row prologue at ~10 us (eight dependent row reductions per
 // wave) and switched it off. The eight-rows-per-wave form runs the same arithmetic in one pass
 // (see the kernel); CT2X_NORM_FUSION=0 restores the separate norm launch (bit-identical).
@@ -632,6 +711,21 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
     else if (k == 128) CT2X_NORMG(2);
     else CT2X_NORMG(1);
 #undef CT2X_NORMG
+    return;
+  }
+  if (ep.a_f32 != nullptr) {
+    // Quantize folded into the A-fragment fetch (gemm_s8_qol_applicable)
+    if (!(gemm_s8_qol_applicable(m, n, k) && ep.mode == 1 && ep.a_amax != nullptr &&
+          ep.b2 == nullptr && (reinterpret_cast<uintptr_t>(ep.a_f32) & 15) == 0 &&
+          (reinterpret_cast<uintptr_t>(b) & 15) == 0))
+      throw Error("launch_gemm_s8: the quantise-on-load form needs M <= 128, K % 64 == 0, the row absmax and 16-byte aligned operands");
+#define CT2X_QOL(WAVES, U)                                                                        \
+  hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, 1, WAVES, U, false, 0, true>),                     \
+                     dim3((n + 15) / 16, (m + 15) / 16), dim3(WAVES * 64), 0, stream, a, b, M, N, \
+                     K, ep)
+    if (k >= 2048) CT2X_QOL(8, 4);
+    else CT2X_QOL(4, 4);
+#undef CT2X_QOL
     return;
   }
   if (ep.b2 != nullptr) {

@@ -26,6 +26,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 namespace ct2x {
 
@@ -192,21 +193,32 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_s8_big_kernel(const int8_t* 
   // the K loop), the per-column operands sit in registers, and the residual of row group i+1 is
   // requested before the stores of row group i.
   float* row_factor = reinterpret_cast<float*>(lds);
+  int* slow_div = reinterpret_cast<int*>(lds + BIG_BM * sizeof(float));
   __syncthreads();  // every wave is done with its last tile
+  if (tid == 0) *slow_div = ep.plain_division ? 1 : 0;
+  __syncthreads();
   if (ep.mode == 1 && tid < BIG_BM) {
     const int64_t row = m0 + tid;
-    row_factor[tid] = row < M ? 1.f / ep.a_scale[row] : 0.f;
+    const float f = row < M ? 1.f / ep.a_scale[row] : 0.f;
+    row_factor[tid] = f;
+    if (row < M && !exact_div_factor_ok(f)) *slow_div = 1;
   }
-  float ws[4], bias[4];
+  // The 256 x 256 tile divides 128 values per lane by 4 column scales: the division runs as
+  // exact_div (device_utils.h; same bits as `/`, 5 VALU operations instead of 11) unless a scale
+  // of this tile is outside the range the identity is proven for.
+  float ws[4], ws_inv[4], bias[4];
   bool col_ok[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int64_t col = n0 + wn * 64 + j * 16 + r;
     col_ok[j] = col < N;
     ws[j] = (ep.mode == 1 && col_ok[j]) ? ep.w_scale[col] : 1.f;
+    ws_inv[j] = 1.f / ws[j];
+    if (!exact_div_divisor_ok(ws[j])) *slow_div = 1;
     bias[j] = (ep.mode == 1 && ep.bias && col_ok[j]) ? ep.bias[col] : 0.f;
   }
   __syncthreads();
+  const bool fast_div = *slow_div == 0;  // workgroup-uniform
   const bool has_res = ep.mode == 1 && ep.residual != nullptr;
   const int64_t col0 = n0 + wn * 64 + r;
   auto load_residual = [&](int i, float (&res)[4][4]) {
@@ -219,7 +231,8 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_s8_big_kernel(const int8_t* 
         res[e][j] = (has_res && row < M && col_ok[j]) ? p[j * 16] : 0.f;
     }
   };
-  auto store_group = [&](int i, const float (&res)[4][4]) {
+  auto store_group = [&](int i, const float (&res)[4][4], auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int lrow = wm * 128 + i * 16 + g * 4 + e;
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_s8_big_kernel(const int8_t* 
         for (int j = 0; j < 4; ++j) {
           // CPU formula order (src/cpu/kernels.cc:666-673): c * (1/a_scale) / b_scale + bias.
           float v = static_cast<float>(acc[i][j][e]) * r_a;
-          v = v / ws[j];
+          v = FAST ? exact_div(v, ws[j], ws_inv[j]) : v / ws[j];
           if (ep.bias) v = v + bias[j];
           v = ACT > 0 ? apply_activation(v, ACT) : (ep.act == 0 /* ReLU */ ? fmaxf(v, 0.f) : v);
           if (has_res) v = res[e][j] + v;
@@ -247,14 +260,18 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_s8_big_kernel(const int8_t* 
     }
   };
   float resA[4][4], resB[4][4];
-  load_residual(0, resA);
+  auto run = [&](auto fast_tag) {
+    load_residual(0, resA);
 #pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    load_residual(i + 1, resB);
-    store_group(i, resA);
-    if (i + 2 < 8) load_residual(i + 2, resA);
-    store_group(i + 1, resB);
-  }
+    for (int i = 0; i < 8; i += 2) {
+      load_residual(i + 1, resB);
+      store_group(i, resA, fast_tag);
+      if (i + 2 < 8) load_residual(i + 2, resA);
+      store_group(i + 1, resB, fast_tag);
+    }
+  };
+  if (fast_div) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 template <int ACT, int ABLATE = 0>
@@ -283,7 +300,13 @@ bool gemm_s8_big_applicable(int64_t m, int64_t n, int64_t k) {
 }
 
 void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
-                        const GemmS8Epilogue& ep, hipStream_t stream) {
+                        const GemmS8Epilogue& ep_in, hipStream_t stream) {
+  static const bool plain_division = [] {
+    const char* e = std::getenv("CT2X_EXACT_DIV");
+    return e != nullptr && e[0] == '0';
+  }();
+  GemmS8Epilogue ep = ep_in;
+  ep.plain_division = plain_division;
   const int tiles_m = (M + BIG_BM - 1) / BIG_BM, tiles_n = (N + BIG_BN - 1) / BIG_BN;
   const int act = (ep.mode == 1 && ep.act > 0) ? ep.act : -1;
   static const int ablate = [] {

@@ -72,7 +72,8 @@ void launch_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int
 void launch_embed(const void* table, bool table_is_int8, const float* table_scale,
                   const int32_t* ids, int64_t rows, int64_t depth, float emb_scale,
                   bool apply_scale, const float* pos_table, int64_t time, int64_t pos_index,
-                  const int32_t* step_ptr, float* out, hipStream_t stream);
+                  const int32_t* step_ptr, float* out, hipStream_t stream,
+                  float* zero_buf = nullptr, int64_t zero_count = 0);
 
 // y = a + b (residual adds outside a GEMM epilogue), y = a * b (GLU gate).
 void launch_add(const float* a, const float* b, int64_t n, float* y, hipStream_t stream);
@@ -109,9 +110,20 @@ struct GemmS8Epilogue {
   // Skinny kernel: per-row absmax of the stored y, max-combined into row_amax_out[m] (must be
   // zero beforehand) - the first half of the following ops::Quantize, see launch_quantize_cols.
   float* row_amax_out = nullptr;
+  // Quantise-on-load (gemm_s8_qol_applicable): when a_f32 != nullptr the launch ignores `a` and
+  // a_scale and quantises the fp32 activation a_f32 [m, k] while it fetches its A fragments, with
+  // the row scale 127 / a_amax[row] (1 for a zero row) - ops::Quantize given the absmax a previous
+  // launch left through row_amax_out. quant_mode as for the norm prologue.
+  const float* a_f32 = nullptr;
+  const float* a_amax = nullptr;
+  // 256 x 256 kernel: divide with the IEEE sequence even where exact_div applies (A/B timing:
+  // CT2X_EXACT_DIV=0; the results are the same bits either way).
+  bool plain_division = false;
 };
 
 bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k);
+bool gemm_s8_qol_applicable(int64_t m, int64_t n, int64_t k);
+bool gemm_s8_qol_enabled();  // CT2X_QUANT_ON_LOAD=1 (off by default: measured slower, bit-identical)
 bool gemm_s8_norm_fusion_enabled();  // CT2X_NORM_FUSION=1 (off by default: measured slower)
 
 // C[m,n] = A[m,k] . B[n,k]^T   (lda = ldb = k). Chooses a tile shape from (m, n, k).

@@ -864,8 +864,13 @@ __global__ void embed_kernel(const void* __restrict__ table, bool table_is_int8,
                              const int32_t* __restrict__ ids, int64_t depth, float emb_scale,
                              bool apply_scale, const float* __restrict__ pos_table, int64_t time,
                              int64_t pos_index, const int32_t* __restrict__ step_ptr,
-                             float* __restrict__ out) {
+                             float* __restrict__ out, float* __restrict__ zero_buf,
+                             int64_t zero_count) {
   const int64_t r = blockIdx.x;
+  // first launch of a decode step: clear the producer-side row-absmax slots the step max-combines
+  // into (GemmS8Epilogue::row_amax_out) - saves the memset node of the step's graph
+  if (r == 0)
+    for (int64_t i = threadIdx.x; i < zero_count; i += blockDim.x) zero_buf[i] = 0.f;
   const int64_t id = ids[r];
   if (step_ptr != nullptr) pos_index = *step_ptr;
   const int64_t pos = pos_index + (r % time);
@@ -896,13 +901,14 @@ __global__ void embed_kernel(const void* __restrict__ table, bool table_is_int8,
 void launch_embed(const void* table, bool table_is_int8, const float* table_scale,
                   const int32_t* ids, int64_t rows, int64_t depth, float emb_scale,
                   bool apply_scale, const float* pos_table, int64_t time, int64_t pos_index,
-                  const int32_t* step_ptr, float* out, hipStream_t stream) {
+                  const int32_t* step_ptr, float* out, hipStream_t stream, float* zero_buf,
+                  int64_t zero_count) {
   if (rows == 0) return;
   int block = 64;
   while (block < depth && block < 256) block <<= 1;
   hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(block), 0, stream, table, table_is_int8,
                      table_scale, ids, depth, emb_scale, apply_scale, pos_table, time, pos_index,
-                     step_ptr, out);
+                     step_ptr, out, zero_buf, zero_count);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -154,6 +154,26 @@ int ct2x_norm_gemm_s8_dequant(const float* d_x, const float* d_gamma, const floa
                               int64_t m, int64_t n, int64_t k, int activation, float* d_y,
                               void* stream);
 
+/* ct2x_norm_gemm_s8_dequant that also leaves the row absmax of y: d_row_amax_out[m] (zero on
+ * entry) is max-combined with max_j |y[i, j]| - the first half of the ops::Quantize
+ * (src/ops/quantize_cpu.cc / src/cpu/kernels.cc:577-651) that feeds the next Dense. */
+int ct2x_norm_gemm_s8_dequant_amax(const float* d_x, const float* d_gamma, const float* d_beta,
+                                   float eps, int rms_use_residual, int quant_flags,
+                                   const int8_t* d_w, const float* d_w_scale, const float* d_bias,
+                                   const float* d_residual, int64_t m, int64_t n, int64_t k,
+                                   int activation, float* d_y, float* d_row_amax_out, void* stream);
+
+/* layers::Dense int8 (src/layers/common.cc:348-401) with its ops::Quantize folded into the GEMM's
+ * operand fetch: d_x is the fp32 activation [m, k], d_row_amax[m] its row absmax (as left by
+ * ct2x_norm_gemm_s8_dequant_amax); every row is quantised with 127 / amax (1 for a zero row) and
+ * quant_flags as in ct2x_quantize_s8 while it is loaded, then Gemm -> Dequantize(+bias, activation)
+ * -> Add(residual). Bit-identical to ct2x_quantize_s8 followed by ct2x_gemm_s8_dequant.
+ * m <= 128, k % 64 == 0, n <= 4096, m * k <= 262144 (an error otherwise). */
+int ct2x_gemm_s8_dequant_quantizing(const float* d_x, const float* d_row_amax, int quant_flags,
+                                    const int8_t* d_w, const float* d_w_scale, const float* d_bias,
+                                    const float* d_residual, int64_t m, int64_t n, int64_t k,
+                                    int activation, float* d_y, void* stream);
+
 /* ops::Dequantize::dequantize<Device::CUDA,int8_t,T> (src/ops/dequantize_gpu.cu:17-28):
  * y[r,:] = x[r,:] / scale[r]  (int8 embedding rows, src/layers/common.cc:64-81). */
 int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,

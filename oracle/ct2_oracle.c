@@ -711,3 +711,77 @@ void orc_topp_mask(const float* x, int64_t rows, int64_t depth, float p, float m
   free(probs);
   free(ids);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Checker for the device-side exact division (ctranslate2_amd/csrc/device_utils.h exact_div):
+ * the Dequantize formula of the reference divides by the weight scale (src/cpu/kernels.cc:
+ * 666-673: c * (1/a_scale) / b_scale + bias); the MFMA-bound GEMM epilogue replaces the IEEE
+ * division sequence by  q0 = t*y, r0 = fma(-d,q0,t), q1 = fma(r0,y,q0), r1 = fma(-d,q1,t),
+ * q = fma(r1,y,q1)  with y = 1/d correctly rounded. This routine compares that sequence with
+ * t / d bit for bit on `n` pseudo-random pairs drawn from the guarded domain (d in [2^-30, 2^30]
+ * with random / all-ones / all-zeros / single-bit significands; t = int32 * r with r in
+ * [2^-29, 2^29], arbitrary floats of that range, and quotients planted next to rounding
+ * midpoints) and returns the number of mismatches (0 expected). */
+static inline float orc_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t orc_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+float orc_exact_div(float t, float d) {
+  const float y = 1.0f / d;
+  const float q0 = t * y;
+  const float r0 = fmaf(-d, q0, t);
+  const float q1 = fmaf(r0, y, q0);
+  const float r1 = fmaf(-d, q1, t);
+  return fmaf(r1, y, q1);
+}
+int64_t orc_exact_div_check(int64_t n, uint64_t seed) {
+  int64_t bad = 0;
+  const int64_t chunk = 1 << 20;
+  const int64_t chunks = (n + chunk - 1) / chunk;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic)
+  for (int64_t c = 0; c < chunks; ++c) {
+    uint64_t s0 = seed * 0x9E3779B97F4A7C15ull + (uint64_t)c * 0xD1B54A32D192ED03ull + 1, s1 = 0x94D049BB133111EBull ^ (uint64_t)c;
+    const int64_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    for (int64_t i = lo; i < hi; ++i) {
+      uint64_t r[2];
+      for (int w = 0; w < 2; ++w) {  /* xorshift128+ */
+        uint64_t a = s0, b = s1;
+        s0 = b;
+        a ^= a << 23;
+        s1 = a ^ b ^ (a >> 18) ^ (b >> 5);
+        r[w] = s1 + b;
+      }
+      uint32_t mant = (uint32_t)(r[0] & 0x7fffff);
+      const int mode = (int)((r[0] >> 23) & 7);
+      if (mode == 0) mant = 0x7fffff;
+      else if (mode == 1) mant = 0x7ffffe;
+      else if (mode == 2) mant = 0;
+      else if (mode == 3) mant = 1u << ((r[0] >> 26) % 23);
+      const int ed = (int)((r[0] >> 32) % 61) - 30;
+      const float d = orc_u2f(((uint32_t)(ed + 127) << 23) | mant);
+      float t;
+      const uint64_t r2 = r[1];
+      if ((r2 & 3) == 0) {
+        int32_t acc = (int32_t)(r2 >> 32);
+        if ((r2 >> 2) & 1) acc >>= ((r2 >> 3) % 31);
+        const int ea = (int)((r2 >> 8) % 59) - 29;
+        const float ra = orc_u2f(((uint32_t)(ea + 127) << 23) | ((uint32_t)(r2 >> 14) & 0x7fffff));
+        t = (float)acc * (ea == 29 ? orc_u2f((uint32_t)(29 + 127) << 23) : ra);
+      } else if (((r2 >> 44) & 3) == 0) {
+        const float q = orc_u2f(((uint32_t)(((int)((r2 >> 2) % 40) - 20) + 127) << 23) | ((uint32_t)(r2 >> 9) & 0x7fffff));
+        double qq = (double)q;
+        const double ul = ldexp(1.0, ilogbf(q) - 23);
+        qq += ul * 0.5 * (double)((r2 >> 46) & 1);
+        t = (float)(qq * (double)d);
+        t = orc_u2f(orc_f2u(t) + (uint32_t)((int)((r2 >> 48) & 3) - 1));
+        if (r2 >> 63) t = -t;
+      } else {
+        const int et = (int)((r2 >> 2) % 90) - 29;
+        uint32_t mt = (uint32_t)(r2 >> 9) & 0x7fffff;
+        if (((r2 >> 40) & 7) == 0) mt = 0x7fffff;
+        if (((r2 >> 40) & 7) == 1) mt = 0;
+        t = orc_u2f(((uint32_t)(r2 >> 63) << 31) | ((uint32_t)(et + 127) << 23) | mt);
+      }
+      if (orc_f2u(t / d) != orc_f2u(orc_exact_div(t, d))) ++bad;
+    }
+  }
+  return bad;
+}

@@ -101,6 +101,11 @@ void orc_attention_decode(const float* q, const float* k, const float* v,
                           int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t kv_group,
                           float scale, float* out);
 
+/* exact_div of the device epilogues (device_utils.h) restated on fmaf, and its bit-for-bit
+ * comparison with t / d over n pseudo-random pairs of the guarded domain (returns mismatches). */
+float orc_exact_div(float t, float d);
+int64_t orc_exact_div_check(int64_t n, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

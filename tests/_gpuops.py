@@ -93,6 +93,40 @@ def norm_gemm_s8_dequant(x, gamma, beta, eps, flags, w, sw, bias=None, residual=
     return host(y)
 
 
+def norm_gemm_s8_dequant_amax(x, gamma, beta, eps, flags, w, sw, bias=None, residual=None, act=-1):
+    """-> (y, row absmax of y as the launch left it in a zeroed buffer)"""
+    L = _lib.lib()
+    xd, gd = dev(x.astype(np.float32)), dev(gamma.astype(np.float32))
+    bd = dev(beta.astype(np.float32)) if beta is not None else None
+    wd, swd = dev(w.astype(np.int8)), dev(sw.astype(np.float32))
+    biasd = dev(bias.astype(np.float32)) if bias is not None else None
+    rd = dev(residual.astype(np.float32)) if residual is not None else None
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    amax = torch.zeros((m,), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_norm_gemm_s8_dequant_amax(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), C.c_float(eps),
+                                                C.c_int(0), C.c_int(flags), _lib.ptr(wd), _lib.ptr(swd),
+                                                _lib.ptr(biasd), _lib.ptr(rd), i64(m), i64(n), i64(k),
+                                                C.c_int(act), _lib.ptr(y), _lib.ptr(amax), None))
+    return host(y), host(amax)
+
+
+def gemm_s8_dequant_quantizing(x, amax, flags, w, sw, bias=None, residual=None, act=-1):
+    L = _lib.lib()
+    xd, ad = dev(x.astype(np.float32)), dev(amax.astype(np.float32))
+    wd, swd = dev(w.astype(np.int8)), dev(sw.astype(np.float32))
+    biasd = dev(bias.astype(np.float32)) if bias is not None else None
+    rd = dev(residual.astype(np.float32)) if residual is not None else None
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_gemm_s8_dequant_quantizing(_lib.ptr(xd), _lib.ptr(ad), C.c_int(flags), _lib.ptr(wd),
+                                                 _lib.ptr(swd), _lib.ptr(biasd), _lib.ptr(rd), i64(m),
+                                                 i64(n), i64(k), C.c_int(act), _lib.ptr(y), None))
+    return host(y)
+
+
 def gemm_s8_glu(q, sa, w0, sw0, b0, w1, sw1, b1, act):
     L = _lib.lib()
     qd, sad = dev(q.astype(np.int8)), dev(sa.astype(np.float32))

@@ -118,6 +118,28 @@ def test_dense_fused_vs_unfused_oracle(gpu, m, n, k, act, with_res):
         np.testing.assert_allclose(y, yo, rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("scale_exp", [0, 31, -31])
+def test_dense_big_tile_division_guard(gpu, scale_exp):
+    """The 256 x 256 kernel divides by the weight scale with exact_div (device_utils.h) when every
+    scale of the tile is inside [2^-30, 2^30] and with the IEEE sequence otherwise: both arms return
+    the oracle's bits (Dequantize formula order: src/cpu/kernels.cc:666-673)."""
+    import _gpuops as G
+    m, n, k = 2500, 2700, 256
+    rng = np.random.default_rng(99 + scale_exp)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = rng.standard_normal((n, k)).astype(np.float32) * 0.02
+    wq, ws = O.quantize_s8(w, True)
+    ws = ws.copy()
+    if scale_exp:
+        ws[::97] = np.float32(2.0 ** scale_exp) * np.float32(1.37)  # outside the guarded range
+    bias = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    q, s = G.quantize_s8(x, True)
+    y = G.gemm_s8_dequant(q, s, wq, ws, bias, None, 0)
+    c = O.gemm_s8(q, wq)
+    yo = O.dequantize_gemm_output(c, s, ws, bias, 0)
+    assert np.array_equal(y, yo)
+
+
 @pytest.mark.parametrize("m,n,k", [(16, 14336, 4096), (32, 2048, 512), (5, 96, 64), (16, 1000, 2048)])
 @pytest.mark.parametrize("act,with_bias", [(2, False), (0, True), (3, True)])
 def test_dense_glu_fused(gpu, m, n, k, act, with_bias):
@@ -258,6 +280,64 @@ def test_norm_gemm_fused(gpu, m, n, k, rms, act, with_res):
     _, q, s = G.norm_quantize_s8(x, gamma, beta, eps, False, 3, False)
     y2 = G.gemm_s8_dequant(q, s, wq, ws, bias, res, act)
     assert np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("m,n,k", [(32, 512, 2048), (128, 512, 2048), (16, 512, 512), (7, 100, 64),
+                                   (33, 48, 192), (1, 4096, 1024), (100, 640, 2048)])
+@pytest.mark.parametrize("flags", [3, 1, 0])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_dense_quantize_on_load(gpu, m, n, k, flags, with_res):
+    """ops::Quantize folded into the consuming GEMM's operand fetch (gemm_s8.hip QOL) against the
+    two launches it replaces and against the oracle's Dense chain: bit-identical. flags: 3 = the
+    x86 default (u8 shift + round), 1 = round only (the reference's GPU form), 0 = truncate."""
+    import _gpuops as G
+    rng = np.random.default_rng(m * 3 + n + k + flags)
+    x = np.maximum(rng.standard_normal((m, k)), 0).astype(np.float32) * 2.5  # a ReLU output
+    if m > 2:
+        x[2, :] = 0.0  # zero row -> scale 1
+    wq, ws = O.quantize_s8((rng.standard_normal((n, k)) * 0.02).astype(np.float32), True)
+    bias = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32) if with_res else None
+    amax = np.abs(x).max(axis=1).astype(np.float32)
+    y = G.gemm_s8_dequant_quantizing(x, amax, flags, wq, ws, bias, res, -1)
+    q, s = G.quantize_s8(x, flags)
+    y2 = G.gemm_s8_dequant(q, s, wq, ws, bias, res, -1)
+    assert np.array_equal(y, y2)
+    assert np.array_equal(y, O.dense_s8(x, wq, ws, bias, res, -1, flags))
+
+
+def test_norm_gemm_row_amax_feeds_quantize_on_load(gpu):
+    """The feed-forward block of a decode step as the engine runs it: pre-norm Dense + ReLU that also
+    leaves the row absmax (ct2x_norm_gemm_s8_dequant_amax), then the Dense that quantises on load -
+    against norm + Quantize + Dense + Quantize + Dense, bit for bit."""
+    import _gpuops as G
+    rng = np.random.default_rng(11)
+    m, d, inner = 32, 512, 2048
+    x = (rng.standard_normal((m, d)) * 1.5).astype(np.float32)
+    gamma = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    w0q, w0s = O.quantize_s8((rng.standard_normal((inner, d)) * 0.02).astype(np.float32), True)
+    w1q, w1s = O.quantize_s8((rng.standard_normal((d, inner)) * 0.02).astype(np.float32), True)
+    b0 = (rng.standard_normal(inner) * 0.01).astype(np.float32)
+    b1 = (rng.standard_normal(d) * 0.01).astype(np.float32)
+    h, amax = G.norm_gemm_s8_dequant_amax(x, gamma, beta, 1e-5, 3, w0q, w0s, b0, None, 0)
+    assert np.array_equal(amax, np.abs(h).max(axis=1))
+    y = G.gemm_s8_dequant_quantizing(h, amax, 3, w1q, w1s, b1, x, -1)
+    _, q, s = G.norm_quantize_s8(x, gamma, beta, 1e-5, False, 3, False)
+    h2 = G.gemm_s8_dequant(q, s, w0q, w0s, b0, None, 0)
+    q2, s2 = G.quantize_s8(h2, 3)
+    y2 = G.gemm_s8_dequant(q2, s2, w1q, w1s, b1, x, -1)
+    assert np.array_equal(h, h2) and np.array_equal(y, y2)
+
+
+def test_dense_quantize_on_load_envelope(gpu):
+    import _gpuops as G
+    rng = np.random.default_rng(0)
+    for m, n, k in [(129, 512, 512), (32, 8192, 512), (16, 512, 96), (128, 512, 4096)]:
+        x = rng.standard_normal((m, k)).astype(np.float32)
+        wq, ws = O.quantize_s8(rng.standard_normal((n, k)).astype(np.float32), True)
+        with pytest.raises(RuntimeError):
+            G.gemm_s8_dequant_quantizing(x, np.abs(x).max(axis=1), 3, wq, ws, None, None, -1)
 
 
 def test_norm_gemm_fused_envelope(gpu):

@@ -426,3 +426,20 @@ def test_kat_masked_softmax_triangular_and_activations():
     for name, a in KAT["Activations"].items():
         np.testing.assert_allclose(O.activation(np.array(a["x"], np.float32), a["act"]),
                                    np.array(a["y"], np.float32), atol=1e-5, rtol=0, err_msg=name)
+
+
+def test_exact_division_identity():
+    """The five-operation division of the MFMA-bound GEMM epilogue (device_utils.h exact_div; the
+    reference's Dequantize divides by the weight scale, src/cpu/kernels.cc:666-673) returns the bits
+    of t / d on the guarded domain: 2e8 random and adversarial pairs here, 1e11 when it was
+    introduced (round 2)."""
+    import ctypes as C
+
+    lib = O.lib()
+    lib.orc_exact_div_check.restype = C.c_int64
+    lib.orc_exact_div_check.argtypes = [C.c_int64, C.c_uint64]
+    assert lib.orc_exact_div_check(200_000_000, 20260921) == 0
+    lib.orc_exact_div.restype = C.c_float
+    lib.orc_exact_div.argtypes = [C.c_float, C.c_float]
+    for t, d in [(0.0, 3.0), (1.0, 3.0), (-7.5, 0.3), (2.0 ** 60, 2.0 ** -30), (2.0 ** -29, 2.0 ** 30)]:
+        assert np.float32(lib.orc_exact_div(t, d)) == np.float32(t) / np.float32(d)
