@@ -238,6 +238,30 @@ int ct2x_gemm_s8_glu(const int8_t* d_qa, const float* d_a_scale, const int8_t* d
   API_CATCH
 }
 
+int ct2x_gemm_s8_glu_amax(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w0,
+                          const float* d_w0_scale, const float* d_b0, const int8_t* d_w1,
+                          const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n, int64_t k,
+                          int activation, float* d_y, float* d_row_amax_out, void* stream) {
+  API_TRY
+  CT2X_CHECK(m <= 32 && k % 16 == 0, "ct2x_gemm_s8_glu_amax: decode rows only (m <= 32, k % 16 == 0)");
+  CT2X_CHECK(d_row_amax_out != nullptr, "ct2x_gemm_s8_glu_amax: d_row_amax_out is NULL");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.a_scale = d_a_scale;
+  ep.w_scale = d_w0_scale;
+  ep.bias = d_b0;
+  ep.b2 = d_w1;
+  ep.w_scale2 = d_w1_scale;
+  ep.bias2 = d_b1;
+  ep.y = d_y;
+  ep.act = activation;
+  ep.ldy = n;
+  ep.row_amax_out = d_row_amax_out;
+  launch_gemm_s8(d_qa, d_w0, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("gemm_s8_glu_amax");
+  API_CATCH
+}
+
 int ct2x_gemm_f16w(const float* d_a, const void* d_w, int w_dtype, int64_t m, int64_t n, int64_t k,
                    const float* d_bias, const float* d_residual, int activation, float* d_c,
                    void* stream) {

@@ -220,7 +220,13 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
 // the previous launch), so scale = 127 / amax is known per row and every lane converts the 16 floats
 // of its fragment itself (to_s8: src/cpu/kernels.cc:577-651) - the int8 copy of the activation, its
 // scale vector and the Quantize launch between the two GEMMs of a feed-forward block disappear.
-template <int MT, int NT, int WAVES, int U, bool DUAL = false, int NORM = 0, bool QOL = false>
+// NTW: the weight stream is requested with the non-temporal policy (`global_load_dwordx4 ... nt`):
+// for models whose weights are far larger than the 256 MB MALL (the Llama shapes stream 7.5 GB per
+// step) a weight byte is used once, and keeping it out of the cache hierarchy's retention policy
+// shortens issue -> landed (MI355X_MICROARCH.md, "nt-weights"). Transformer-base (38 MB of decoder
+// weights, MALL resident from step to step) keeps the default policy.
+template <int MT, int NT, int WAVES, int U, bool DUAL = false, int NORM = 0, bool QOL = false,
+          bool NTW = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
     GemmS8Epilogue ep) {
@@ -500,11 +506,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
         if (NORM)
           bf[0][u][j] = bpre[u][j];
         else
-          bf[0][u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B + col * K + kk)
-                                          : v4i{0, 0, 0, 0};
+          bf[0][u][j] = (k_ok && col < N)
+                            ? (NTW ? __builtin_nontemporal_load(reinterpret_cast<const v4i*>(B + col * K + kk))
+                                   : *reinterpret_cast<const v4i*>(B + col * K + kk))
+                            : v4i{0, 0, 0, 0};
         if (DUAL)
-          bf[ND - 1][u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B2 + col * K + kk)
-                                               : v4i{0, 0, 0, 0};
+          bf[ND - 1][u][j] = (k_ok && col < N)
+                                 ? (NTW ? __builtin_nontemporal_load(reinterpret_cast<const v4i*>(B2 + col * K + kk))
+                                        : *reinterpret_cast<const v4i*>(B2 + col * K + kk))
+                                 : v4i{0, 0, 0, 0};
       }
     }
     if (QOL) {
@@ -672,6 +682,17 @@ bool gemm_s8_norm_fusion_enabled() {
   return enabled;
 }
 
+// Non-temporal weight stream for the long-K decode forms (CT2X_NT_WEIGHTS=1). Measured on the
+// Llama-3-8B shape, same box, alternating runs: 3.81 - 3.84 ms per decode step with `nt` against
+// 3.65 - 3.66 without - the guide's gain belongs to LDS-DMA streams, register loads lose. Off.
+static bool nt_weights(int64_t, int64_t) {
+  static const bool on = [] {
+    const char* e = std::getenv("CT2X_NT_WEIGHTS");
+    return e != nullptr && e[0] == '1';
+  }();
+  return on;
+}
+
 void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int64_t k,
                     const GemmS8Epilogue& ep_in, hipStream_t stream) {
   if (m == 0 || n == 0) return;
@@ -713,6 +734,12 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
 #undef CT2X_NORMG
     return;
   }
+  if (ep.norm_x == nullptr && ep.a_f32 == nullptr &&
+      (ep.b2 == nullptr || (reinterpret_cast<uintptr_t>(ep.b2) & 15) == 0) &&
+      gemm_s8_stream_applicable(m, n, k, ep.b2 != nullptr)) {
+    launch_gemm_s8_stream(a, b, M, N, K, ep, stream);
+    return;
+  }
   if (ep.a_f32 != nullptr) {
     // Quantize folded into the A-fragment fetch (gemm_s8_qol_applicable)
     if (!(gemm_s8_qol_applicable(m, n, k) && ep.mode == 1 && ep.a_amax != nullptr &&
@@ -738,7 +765,10 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
                      dim3((n + 16 * NT - 1) / (16 * NT)), dim3(WAVES * 64), 0, stream, a, b, M, N, \
                      K, ep)
     if (m <= 16) {
-      if (k >= 4096) CT2X_DUAL(1, 2, 16, 2);
+      if (k >= 4096 && nt_weights(n, k))
+        hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, 2, 16, 2, true, 0, false, true>),
+                           dim3((n + 31) / 32), dim3(1024), 0, stream, a, b, M, N, K, ep);
+      else if (k >= 4096) CT2X_DUAL(1, 2, 16, 2);
       else if (k >= 2048) CT2X_DUAL(1, 1, 8, 4);
       else CT2X_DUAL(1, 1, 4, 4);
     } else {
@@ -793,7 +823,17 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
     // Shapes measured with tools/skinny_sweep.sh (weights rotated through 600 MB, MI355X):
     // long weight streams want 16 waves per workgroup (more bytes in flight per CU); the
     // Transformer-base shapes (K = 512 / 2048) keep the 4-8 wave forms.
-    if (mt == 1 && k >= 4096) {
+    if (mt == 1 && k >= 4096 && nt_weights(n, k)) {
+#define CT2X_SKINNY_NT(NT, WAVES, U)                                                            \
+  hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, NT, WAVES, U, false, 0, false, true>),            \
+                     dim3((n + 16 * NT - 1) / (16 * NT), (m + 15) / 16), dim3(WAVES * 64), 0,    \
+                     stream, a, b, M, N, K, ep)
+      if (n >= 8192) CT2X_SKINNY_NT(4, 16, 2);
+      else if (k >= 8192) CT2X_SKINNY_NT(1, 16, 4);
+      else if (n >= 6144) CT2X_SKINNY_NT(2, 8, 8);
+      else CT2X_SKINNY_NT(1, 16, 4);
+#undef CT2X_SKINNY_NT
+    } else if (mt == 1 && k >= 4096) {
       if (n >= 8192) CT2X_SKINNY(1, 4, 16, 2);        // [16, 14336, 4096] 19.2 -> 15.5 us
       else if (k >= 8192) CT2X_SKINNY(1, 1, 16, 4);   // [16, 4096, 14336] 20.5 -> 18.3 us
       else if (n >= 6144) CT2X_SKINNY(1, 2, 8, 8);    // [16, 6144, 4096]  10.4 ->  9.3 us

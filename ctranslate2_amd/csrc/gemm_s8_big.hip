@@ -47,7 +47,8 @@ __device__ __forceinline__ void glds16(const int8_t* src, int8_t* lds_wave_base)
 }
 
 // ABLATE (timing experiments only, tools/gemm_bench.cpp): 1 = no DMA after the prologue,
-// 2 = no MFMAs, 3 = no fragment reads, 4 = MFMAs only (no DMA, no fragment reads, no barriers).
+// 2 = no MFMAs, 3 = no fragment reads, 4 = MFMAs only (no DMA, no fragment reads, no barriers),
+// 5 = K loop only (no epilogue).
 template <int ACT, int ABLATE = 0>
 __global__ __launch_bounds__(BIG_THREADS) void gemm_s8_big_kernel(const int8_t* __restrict__ A,
                                                                   const int8_t* __restrict__ B,
@@ -192,6 +193,15 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_s8_big_kernel(const int8_t* 
   // and serialise on memory latency): the per-row factors 1/a_scale go through LDS (free after
   // the K loop), the per-column operands sit in registers, and the residual of row group i+1 is
   // requested before the stores of row group i.
+  if (ABLATE == 5) {  // K loop only: one store per lane keeps the accumulators alive
+    int keep = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) keep ^= acc[i][j][0] ^ acc[i][j][1] ^ acc[i][j][2] ^ acc[i][j][3];
+    if (keep == 0x7fffffff && ep.c_i32) ep.c_i32[0] = keep;
+    return;
+  }
   float* row_factor = reinterpret_cast<float*>(lds);
   int* slow_div = reinterpret_cast<int*>(lds + BIG_BM * sizeof(float));
   __syncthreads();  // every wave is done with its last tile
@@ -317,6 +327,7 @@ void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
   if (ablate == 2) return launch_big<-1, 2>(a, b, M, N, K, tiles_m, tiles_n, ep, stream);
   if (ablate == 3) return launch_big<-1, 3>(a, b, M, N, K, tiles_m, tiles_n, ep, stream);
   if (ablate == 4) return launch_big<-1, 4>(a, b, M, N, K, tiles_m, tiles_n, ep, stream);
+  if (ablate == 5) return launch_big<-1, 5>(a, b, M, N, K, tiles_m, tiles_n, ep, stream);
   switch (act) {
     case 1: launch_big<1>(a, b, M, N, K, tiles_m, tiles_n, ep, stream); break;
     case 2: launch_big<2>(a, b, M, N, K, tiles_m, tiles_n, ep, stream); break;

@@ -136,6 +136,13 @@ bool gemm_s8_big_applicable(int64_t m, int64_t n, int64_t k);
 void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
                         const GemmS8Epilogue& ep, hipStream_t stream);
 
+// Persistent weight-streaming form for decode rows of models whose weights are not cache resident
+// (gemm_s8_stream.hip); launch_gemm_s8 picks it when gemm_s8_stream_applicable
+// (CT2X_STREAM_GEMM=0 disables, for A/B comparisons; bit-identical).
+bool gemm_s8_stream_applicable(int64_t m, int64_t n, int64_t k, bool dual);
+void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K,
+                           const GemmS8Epilogue& ep, hipStream_t stream);
+
 // ---- fp32 GEMM (gemm_f32.hip) --------------------------------------------------------
 
 // C[b] = alpha * A[b] . op(B[b]) (+ bias[j]) -> act -> (+ residual). batch==1 for plain GEMM.

@@ -143,6 +143,14 @@ int ct2x_gemm_s8_glu(const int8_t* d_qa, const float* d_a_scale, const int8_t* d
                      const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n, int64_t k,
                      int activation, void* d_y, int dtype, void* stream);
 
+/* ct2x_gemm_s8_glu that also leaves the row absmax of y in d_row_amax_out[m] (zero on entry;
+ * max-combined): the producer half of the ops::Quantize that feeds linear_1 of the feed-forward
+ * block (src/layers/transformer.cc:21-51), consumed by the engine's element-wise Quantize. */
+int ct2x_gemm_s8_glu_amax(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w0,
+                          const float* d_w0_scale, const float* d_b0, const int8_t* d_w1,
+                          const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n, int64_t k,
+                          int activation, float* d_y, float* d_row_amax_out, void* stream);
+
 /* A pre-norm int8 Dense at decode rows as ONE launch: layers::LayerNorm (LayerNorm when d_beta is
  * given, RMSNorm otherwise; src/layers/common.cc:464-472) -> ops::Quantize -> Gemm -> Dequantize
  * (+bias, activation) -> Add(residual); bit-identical to ct2x_norm_quantize_s8 followed by

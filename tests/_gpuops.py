@@ -142,6 +142,22 @@ def gemm_s8_glu(q, sa, w0, sw0, b0, w1, sw1, b1, act):
     return host(y)
 
 
+def gemm_s8_glu_amax(q, sa, w0, sw0, b0, w1, sw1, b1, act):
+    L = _lib.lib()
+    qd, sad = dev(q.astype(np.int8)), dev(sa.astype(np.float32))
+    w0d, s0d, w1d, s1d = dev(w0.astype(np.int8)), dev(sw0.astype(np.float32)), dev(w1.astype(np.int8)), dev(sw1.astype(np.float32))
+    b0d = dev(b0.astype(np.float32)) if b0 is not None else None
+    b1d = dev(b1.astype(np.float32)) if b1 is not None else None
+    m, k = q.shape
+    n = w0.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    amax = torch.zeros((m,), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_gemm_s8_glu_amax(_lib.ptr(qd), _lib.ptr(sad), _lib.ptr(w0d), _lib.ptr(s0d), _lib.ptr(b0d),
+                                       _lib.ptr(w1d), _lib.ptr(s1d), _lib.ptr(b1d), i64(m), i64(n), i64(k),
+                                       C.c_int(act), _lib.ptr(y), _lib.ptr(amax), None))
+    return host(y), host(amax)
+
+
 def dequantize_rows(x, scale):
     L = _lib.lib()
     xd, sd = dev(x.astype(np.int8)), dev(scale.astype(np.float32))

@@ -118,6 +118,55 @@ def test_dense_fused_vs_unfused_oracle(gpu, m, n, k, act, with_res):
         np.testing.assert_allclose(y, yo, rtol=2e-6, atol=2e-6)
 
 
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+STREAM_SHAPES = [(16, 6144, 4096), (16, 4096, 4096), (16, 4096, 14336), (16, 128256, 4096),
+                 (5, 14336, 4096), (1, 4096, 8192), (16, 8208, 4096)]
+
+
+@pytest.mark.parametrize("m,n,k", STREAM_SHAPES)
+def test_dense_streaming_form(gpu, m, n, k, monkeypatch):
+    """The persistent weight-streaming GEMM (gemm_s8_stream.hip; Llama-shape decode rows, weights
+    >= 8 MB) against the one-shot kernel it replaces (CT2X_STREAM_GEMM is read once per process, so
+    the comparison partner is the oracle's Dense chain) - bit-identical; int32 form too."""
+    import _gpuops as G
+    rng = np.random.default_rng(m + n + k)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    wq = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    ws = rng.uniform(50, 4000, n).astype(np.float32)
+    bias = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32)
+    q, s = G.quantize_s8(x, 3)
+    c = G.gemm_s8(q, wq)
+    co = O.gemm_s8(q, wq)
+    assert np.array_equal(c, co)
+    y = G.gemm_s8_dequant(q, s, wq, ws, bias, res, 0)
+    yo = _f32(res) + O.dequantize_gemm_output(co, s, ws, bias, 0)
+    assert np.array_equal(y, yo)
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 14336, 4096), (7, 14336, 4096), (16, 4096, 8192)])
+def test_dense_glu_streaming_form_with_row_amax(gpu, m, n, k):
+    """Gated pair in the streaming form + the row absmax it leaves for the following Quantize."""
+    import _gpuops as G
+    rng = np.random.default_rng(m + n + k)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w0q = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    w1q = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    w0s = rng.uniform(2000, 9000, n).astype(np.float32)
+    w1s = rng.uniform(2000, 9000, n).astype(np.float32)
+    q, s = G.quantize_s8(x, 3)
+    y, amax = G.gemm_s8_glu_amax(q, s, w0q, w0s, None, w1q, w1s, None, 0)
+    c0, c1 = O.gemm_s8(q, w0q), O.gemm_s8(q, w1q)
+    yo = O.dequantize_gemm_output(c1, s, w1s, None, -1) * O.dequantize_gemm_output(c0, s, w0s, None, 0)
+    assert np.array_equal(y, yo)
+    assert np.array_equal(amax, np.abs(yo).max(axis=1))
+    y2 = G.gemm_s8_glu(q, s, w0q, w0s, None, w1q, w1s, None, 0)
+    assert np.array_equal(y2, yo)
+
+
 @pytest.mark.parametrize("scale_exp", [0, 31, -31])
 def test_dense_big_tile_division_guard(gpu, scale_exp):
     """The 256 x 256 kernel divides by the weight scale with exact_div (device_utils.h) when every
