@@ -262,6 +262,72 @@ int ct2x_gemm_s8_glu_amax(const int8_t* d_qa, const float* d_a_scale, const int8
   API_CATCH
 }
 
+int ct2x_gemm_s8_stream_packable(int64_t n, int64_t k, int dual) {
+  try {
+    return gemm_s8_stream_pack_applicable(n, k, dual != 0) ? 1 : 0;
+  } catch (...) {
+    return 0;
+  }
+}
+
+int ct2x_gemm_s8_stream_pack(const int8_t* d_w, int64_t n, int64_t k, int dual, int8_t* d_packed,
+                             void* stream) {
+  API_TRY
+  CT2X_CHECK(gemm_s8_stream_pack_applicable(n, k, dual != 0),
+             "ct2x_gemm_s8_stream_pack: this (n, k) has no streaming form");
+  launch_pack_stream_weight(d_w, n, k, dual != 0, d_packed, resolve_stream(stream));
+  check_last_launch("gemm_s8_stream_pack");
+  API_CATCH
+}
+
+int ct2x_gemm_s8_dequant_packed(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w_packed,
+                                const float* d_w_scale, const float* d_bias, const float* d_residual,
+                                int64_t m, int64_t n, int64_t k, int activation, float* d_y,
+                                void* stream) {
+  API_TRY
+  CT2X_CHECK(gemm_s8_stream_applicable(m, n, k, false),
+             "ct2x_gemm_s8_dequant_packed: needs m <= 16 and a (n, k) with a streaming form");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.a_scale = d_a_scale;
+  ep.w_scale = d_w_scale;
+  ep.bias = d_bias;
+  ep.residual = d_residual;
+  ep.y = d_y;
+  ep.act = activation;
+  ep.ldy = n;
+  ep.packed_b = true;
+  launch_gemm_s8(d_qa, d_w_packed, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("gemm_s8_dequant_packed");
+  API_CATCH
+}
+
+int ct2x_gemm_s8_glu_packed(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w0_packed,
+                            const float* d_w0_scale, const float* d_b0, const int8_t* d_w1_packed,
+                            const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n,
+                            int64_t k, int activation, float* d_y, float* d_row_amax_out,
+                            void* stream) {
+  API_TRY
+  CT2X_CHECK(gemm_s8_stream_applicable(m, n, k, true),
+             "ct2x_gemm_s8_glu_packed: needs m <= 16 and a (n, k) with a gated streaming form");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.a_scale = d_a_scale;
+  ep.w_scale = d_w0_scale;
+  ep.bias = d_b0;
+  ep.b2 = d_w1_packed;
+  ep.w_scale2 = d_w1_scale;
+  ep.bias2 = d_b1;
+  ep.y = d_y;
+  ep.act = activation;
+  ep.ldy = n;
+  ep.row_amax_out = d_row_amax_out;
+  ep.packed_b = true;
+  launch_gemm_s8(d_qa, d_w0_packed, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("gemm_s8_glu_packed");
+  API_CATCH
+}
+
 int ct2x_gemm_f16w(const float* d_a, const void* d_w, int w_dtype, int64_t m, int64_t n, int64_t k,
                    const float* d_bias, const float* d_residual, int activation, float* d_c,
                    void* stream) {

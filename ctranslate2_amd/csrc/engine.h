@@ -47,6 +47,10 @@ struct DenseW {
   bool row_parallel = false;
   bool quantized = false;
   const int8_t* wq = nullptr;     // [n, k] int8
+  // fragment-major copy for the streaming decode GEMM (gemm_s8_stream.hip; models whose weights
+  // are not cache resident), packed for the single or for the gated-pair plan
+  const int8_t* wq_stream = nullptr;
+  bool wq_stream_dual = false;
   const float* wscale = nullptr;  // [n]
   const float* wf = nullptr;      // [n, k] fp32 (float models)
   const void* wh = nullptr;       // [n, k] float16 / bfloat16 (compute types float16 / bfloat16)
@@ -270,6 +274,8 @@ private:
   void dense_qol(const DenseW& w, const float* x, const float* row_amax, int64_t m, int act,
                  const float* residual, float* y);
   void load_weights();
+  void pack_stream_weights();
+  void pack_stream(DenseW& w, bool dual);
   // How a Dense is split over the tensor-parallel ranks (Model::load, src/models/model.cc:
   // 662-743): kColumn = output rows; `blocks` lists the sizes of the fused sub-matrices that are
   // each split separately and re-concatenated (Q | K | V of linear_0, K | V of the cross

@@ -740,6 +740,8 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
     launch_gemm_s8_stream(a, b, M, N, K, ep, stream);
     return;
   }
+  if (ep.packed_b)
+    throw Error("launch_gemm_s8: a packed (fragment-major) weight only runs in the streaming form (m <= 16)");
   if (ep.a_f32 != nullptr) {
     // Quantize folded into the A-fragment fetch (gemm_s8_qol_applicable)
     if (!(gemm_s8_qol_applicable(m, n, k) && ep.mode == 1 && ep.a_amax != nullptr &&

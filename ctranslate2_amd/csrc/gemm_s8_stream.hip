@@ -69,7 +69,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
     const int kk = (wave + i * WAVES) * 64 + g * 16;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int64_t off = (n0 + j * 16 + r) * K + kk;
+      const int64_t off =
+          ep.packed_b ? ((((static_cast<int64_t>(slab) * WAVES + wave) * KS + i) * NT + j) << 10) + lane * 16
+                      : (n0 + j * 16 + r) * K + kk;
       bf[i % P][0][j] = *reinterpret_cast<const v4i*>(B + off);
       if (DUAL) bf[i % P][ND - 1][j] = *reinterpret_cast<const v4i*>(B2 + off);
     }
@@ -218,6 +220,27 @@ bool plan_stream(int64_t n, int64_t k, bool dual, int cus, StreamPlan* plan) {
   return false;
 }
 
+// Row-major [n, k] -> fragment-major: 16-byte chunk `o` of the packed weight is lane o % 64 of the
+// 1 KB block ((slab * WAVES + wave) * KS + i) * NT + j, i.e. the bytes the streaming kernel's wave
+// `wave` requests for K-step i, column tile j of slab `slab` (request() above).
+template <int WAVES>
+__global__ void pack_stream_weight_kernel(const int8_t* __restrict__ src, int64_t k, int nt, int ks,
+                                          int64_t chunks, int8_t* __restrict__ dst) {
+  const int64_t o = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (o >= chunks) return;
+  const int lane = static_cast<int>(o & 63);
+  int64_t blk = o >> 6;
+  const int j = static_cast<int>(blk % nt);
+  blk /= nt;
+  const int i = static_cast<int>(blk % ks);
+  blk /= ks;
+  const int wave = static_cast<int>(blk % WAVES);
+  const int64_t slab = blk / WAVES;
+  const int64_t row = slab * nt * 16 + j * 16 + (lane & 15);
+  const int64_t kk = static_cast<int64_t>(wave + i * WAVES) * 64 + (lane >> 4) * 16;
+  reinterpret_cast<uint4*>(dst)[o] = *reinterpret_cast<const uint4*>(src + row * k + kk);
+}
+
 int device_cus() {
   static const int cus = [] {
     int dev = 0, n = 256;
@@ -247,12 +270,36 @@ bool gemm_s8_stream_applicable(int64_t m, int64_t n, int64_t k, bool dual) {
   return plan_stream(n, k, dual, device_cus(), &plan);
 }
 
+// Whether weights of this shape have a packed (fragment-major) streaming form at all - independent
+// of the row count of a particular launch. CT2X_STREAM_PACKED=0 keeps the row-major weight.
+bool gemm_s8_stream_pack_applicable(int64_t n, int64_t k, bool dual) {
+  static const bool enabled = [] {
+    const char* e = std::getenv("CT2X_STREAM_PACKED");
+    return e == nullptr || e[0] != '0';
+  }();
+  return enabled && gemm_s8_stream_applicable(1, n, k, dual);
+}
+
+void launch_pack_stream_weight(const int8_t* src, int64_t n, int64_t k, bool dual, int8_t* dst,
+                               hipStream_t stream) {
+  StreamPlan plan;
+  if (!plan_stream(n, k, dual, device_cus(), &plan))
+    throw Error("launch_pack_stream_weight: shape outside the streaming form");
+  const int64_t chunks = n * k / 16;
+  hipLaunchKernelGGL(pack_stream_weight_kernel<16>, dim3(static_cast<unsigned>((chunks + 255) / 256)),
+                     dim3(256), 0, stream, src, k, plan.nt, plan.ks, chunks, dst);
+}
+
 void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K,
-                           const GemmS8Epilogue& ep, hipStream_t stream) {
-  const bool dual = ep.b2 != nullptr;
+                           const GemmS8Epilogue& ep_in, hipStream_t stream) {
+  const bool dual = ep_in.b2 != nullptr;
   StreamPlan plan;
   if (!plan_stream(N, K, dual, device_cus(), &plan))
     throw Error("launch_gemm_s8_stream: shape outside the streaming form");
+  // TIMING EXPERIMENT ONLY (results are wrong): read the row-major weight as if it were packed
+  static const bool fake_packed = std::getenv("CT2X_STREAM_FAKE_PACKED") != nullptr;
+  GemmS8Epilogue ep = ep_in;
+  if (fake_packed) ep.packed_b = true;
 #define CT2X_STREAM(NT, KS, P, DUAL)                                                              \
   if (plan.nt == NT && plan.ks == KS && plan.p == P && dual == DUAL) {                            \
     auto fn = gemm_s8_stream_kernel<NT, 16, KS, P, DUAL>;                                         \

@@ -119,6 +119,10 @@ struct GemmS8Epilogue {
   // 256 x 256 kernel: divide with the IEEE sequence even where exact_div applies (A/B timing:
   // CT2X_EXACT_DIV=0; the results are the same bits either way).
   bool plain_division = false;
+  // Streaming form (gemm_s8_stream.hip): `b` (and b2) hold the weight in the fragment-major
+  // layout pack_stream_weight() produced for this (n, k) - every 1 KB request of a wave is one
+  // contiguous block and a wave's requests of a slab follow each other in memory.
+  bool packed_b = false;
 };
 
 bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k);
@@ -142,6 +146,11 @@ void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
 bool gemm_s8_stream_applicable(int64_t m, int64_t n, int64_t k, bool dual);
 void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K,
                            const GemmS8Epilogue& ep, hipStream_t stream);
+// Fragment-major copy of a weight for the streaming form (GemmS8Epilogue::packed_b): dst [n * k]
+// bytes. `dual` = the weight is one of a gated pair (the pair's plan differs from the single one).
+bool gemm_s8_stream_pack_applicable(int64_t n, int64_t k, bool dual);
+void launch_pack_stream_weight(const int8_t* src, int64_t n, int64_t k, bool dual, int8_t* dst,
+                               hipStream_t stream);
 
 // ---- fp32 GEMM (gemm_f32.hip) --------------------------------------------------------
 

@@ -151,6 +151,26 @@ int ct2x_gemm_s8_glu_amax(const int8_t* d_qa, const float* d_a_scale, const int8
                           const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n, int64_t k,
                           int activation, float* d_y, float* d_row_amax_out, void* stream);
 
+/* Fragment-major copy of an int8 weight [n, k] for the persistent streaming decode GEMM (models
+ * whose weights are not cache resident; gemm_s8_stream.hip): d_packed [n * k] bytes. `dual` != 0
+ * packs for the gated-pair launch (ct2x_gemm_s8_glu_packed). Returns an error when (n, k) has no
+ * streaming form (ct2x_gemm_s8_stream_packable() == 0). The packed weight replaces d_w in
+ * ct2x_gemm_s8_dequant_packed / ct2x_gemm_s8_glu_packed (m <= 16 rows), same results bit for bit
+ * as the row-major entry points (the reference keeps one row-major weight:
+ * src/layers/common.cc:266-303; its CPU build packs for MKL the same way, `weight_packed`). */
+int ct2x_gemm_s8_stream_packable(int64_t n, int64_t k, int dual);
+int ct2x_gemm_s8_stream_pack(const int8_t* d_w, int64_t n, int64_t k, int dual, int8_t* d_packed,
+                             void* stream);
+int ct2x_gemm_s8_dequant_packed(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w_packed,
+                                const float* d_w_scale, const float* d_bias, const float* d_residual,
+                                int64_t m, int64_t n, int64_t k, int activation, float* d_y,
+                                void* stream);
+int ct2x_gemm_s8_glu_packed(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w0_packed,
+                            const float* d_w0_scale, const float* d_b0, const int8_t* d_w1_packed,
+                            const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n,
+                            int64_t k, int activation, float* d_y, float* d_row_amax_out,
+                            void* stream);
+
 /* A pre-norm int8 Dense at decode rows as ONE launch: layers::LayerNorm (LayerNorm when d_beta is
  * given, RMSNorm otherwise; src/layers/common.cc:464-472) -> ops::Quantize -> Gemm -> Dequantize
  * (+bias, activation) -> Add(residual); bit-identical to ct2x_norm_quantize_s8 followed by

@@ -158,6 +158,49 @@ def gemm_s8_glu_amax(q, sa, w0, sw0, b0, w1, sw1, b1, act):
     return host(y), host(amax)
 
 
+def stream_packable(n, k, dual=False):
+    return bool(_lib.lib().ct2x_gemm_s8_stream_packable(i64(n), i64(k), C.c_int(int(dual))))
+
+
+def _stream_pack(wd, n, k, dual):
+    packed = torch.empty((n * k,), dtype=torch.int8, device="cuda")
+    _lib.check(_lib.lib().ct2x_gemm_s8_stream_pack(_lib.ptr(wd), i64(n), i64(k), C.c_int(int(dual)),
+                                                   _lib.ptr(packed), None))
+    return packed
+
+
+def gemm_s8_dequant_packed(q, sa, w, sw, bias=None, residual=None, act=-1):
+    L = _lib.lib()
+    qd, sad, wd, swd = dev(q.astype(np.int8)), dev(sa.astype(np.float32)), dev(w.astype(np.int8)), dev(sw.astype(np.float32))
+    bd = dev(bias.astype(np.float32)) if bias is not None else None
+    rd = dev(residual.astype(np.float32)) if residual is not None else None
+    m, k = q.shape
+    n = w.shape[0]
+    packed = _stream_pack(wd, n, k, False)
+    y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_gemm_s8_dequant_packed(_lib.ptr(qd), _lib.ptr(sad), _lib.ptr(packed), _lib.ptr(swd),
+                                             _lib.ptr(bd), _lib.ptr(rd), i64(m), i64(n), i64(k),
+                                             C.c_int(act), _lib.ptr(y), None))
+    return host(y)
+
+
+def gemm_s8_glu_packed(q, sa, w0, sw0, b0, w1, sw1, b1, act):
+    L = _lib.lib()
+    qd, sad = dev(q.astype(np.int8)), dev(sa.astype(np.float32))
+    w0d, s0d, w1d, s1d = dev(w0.astype(np.int8)), dev(sw0.astype(np.float32)), dev(w1.astype(np.int8)), dev(sw1.astype(np.float32))
+    b0d = dev(b0.astype(np.float32)) if b0 is not None else None
+    b1d = dev(b1.astype(np.float32)) if b1 is not None else None
+    m, k = q.shape
+    n = w0.shape[0]
+    p0, p1 = _stream_pack(w0d, n, k, True), _stream_pack(w1d, n, k, True)
+    y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    amax = torch.zeros((m,), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_gemm_s8_glu_packed(_lib.ptr(qd), _lib.ptr(sad), _lib.ptr(p0), _lib.ptr(s0d), _lib.ptr(b0d),
+                                         _lib.ptr(p1), _lib.ptr(s1d), _lib.ptr(b1d), i64(m), i64(n), i64(k),
+                                         C.c_int(act), _lib.ptr(y), _lib.ptr(amax), None))
+    return host(y), host(amax)
+
+
 def dequantize_rows(x, scale):
     L = _lib.lib()
     xd, sd = dev(x.astype(np.int8)), dev(scale.astype(np.float32))

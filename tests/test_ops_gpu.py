@@ -145,6 +145,13 @@ def test_dense_streaming_form(gpu, m, n, k, monkeypatch):
     y = G.gemm_s8_dequant(q, s, wq, ws, bias, res, 0)
     yo = _f32(res) + O.dequantize_gemm_output(co, s, ws, bias, 0)
     assert np.array_equal(y, yo)
+    # the same launch reading the fragment-major copy of the weight
+    if G.stream_packable(n, k):
+        assert np.array_equal(G.gemm_s8_dequant_packed(q, s, wq, ws, bias, res, 0), yo)
+    else:
+        assert (m, n, k) == (16, 8208, 4096)
+        with pytest.raises(RuntimeError):
+            G.gemm_s8_dequant_packed(q, s, wq, ws, bias, res, 0)
 
 
 @pytest.mark.parametrize("m,n,k", [(16, 14336, 4096), (7, 14336, 4096), (16, 4096, 8192)])
@@ -165,6 +172,8 @@ def test_dense_glu_streaming_form_with_row_amax(gpu, m, n, k):
     assert np.array_equal(amax, np.abs(yo).max(axis=1))
     y2 = G.gemm_s8_glu(q, s, w0q, w0s, None, w1q, w1s, None, 0)
     assert np.array_equal(y2, yo)
+    y3, amax3 = G.gemm_s8_glu_packed(q, s, w0q, w0s, None, w1q, w1s, None, 0)
+    assert np.array_equal(y3, yo) and np.array_equal(amax3, amax)
 
 
 @pytest.mark.parametrize("scale_exp", [0, 31, -31])
