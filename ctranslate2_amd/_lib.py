@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libct2_mi355.so")
+# CT2X_LIBRARY: another build of the same library (A/B timing of two builds inside one gpurun call)
+LIB_PATH = os.environ.get("CT2X_LIBRARY") or os.path.join(_HERE, "libct2_mi355.so")
 
 _lib = None
 

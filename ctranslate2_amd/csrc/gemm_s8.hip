@@ -246,16 +246,49 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
   float* norm_beta_lds = norm_gamma_lds + K;
   int8_t* norm_qa_lds = reinterpret_cast<int8_t*>(norm_beta_lds + K);
   float* norm_scales = reinterpret_cast<float*>(norm_qa_lds + 16 * qa_stride);
+  // Only A, B, M, N, K arrive preloaded in SGPRs; every field of `ep` costs a kernarg round trip
+  // (s_load + wait, ~1 us cold). The first round of weight and activation fragments needs nothing
+  // but the preloaded arguments, so it is requested BEFORE the first access to `ep`: the kernarg
+  // fetch, the epilogue operands and the weight stream share one memory round trip instead of
+  // queueing behind each other.
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * (NT * 16);
+  const int ksteps = (K + 63) / 64;
+  const int rb = blockIdx.y * (MT * 16);  // this workgroup's block of MT * 16 rows (grid.y)
+  M -= rb;
+  if (!NORM && !QOL) A += static_cast<int64_t>(rb) * K;
+  v4i bpre[U][NT], apre[U][MT];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int ks = wave + u * WAVES;
+    const int kk = ks * 64 + g * 16;
+    const bool k_ok = (ks < ksteps) && (kk < K);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int64_t col = n0 + j * 16 + r;
+      bpre[u][j] = (k_ok && col < N)
+                       ? (NTW ? __builtin_nontemporal_load(reinterpret_cast<const v4i*>(B + col * K + kk))
+                              : *reinterpret_cast<const v4i*>(B + col * K + kk))
+                       : v4i{0, 0, 0, 0};
+    }
+    if (!NORM && !QOL) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = i * 16 + r;
+        apre[u][i] = (k_ok && row < M)
+                         ? *reinterpret_cast<const v4i*>(A + static_cast<int64_t>(row) * K + kk)
+                         : v4i{0, 0, 0, 0};
+      }
+    }
+  }
   if (blockIdx.y != 0) {
-    // this workgroup's block of MT * 16 rows (grid.y): rebase the row-indexed operands. Many
-    // short row blocks beat one tall workgroup per column tile: [128, 512] x 512 runs 6.9 us as
-    // 32 workgroups of 8 row tiles and 4.7 us as 256 workgroups of one (the weight tile is
-    // re-read per block, from L2).
-    const int rb = blockIdx.y * (MT * 16);
-    M -= rb;
+    // rebase the row-indexed operands of the epilogue. Many short row blocks beat one tall
+    // workgroup per column tile: [128, 512] x 512 runs 6.9 us as 32 workgroups of 8 row tiles and
+    // 4.7 us as 256 workgroups of one (the weight tile is re-read per block, from L2).
     if (NORM) ep.norm_x += static_cast<int64_t>(rb) * K;
     else if (QOL) { ep.a_f32 += static_cast<int64_t>(rb) * K; ep.a_amax += rb; }
-    else A += static_cast<int64_t>(rb) * K;
     if (ep.a_scale) ep.a_scale += rb;
     if (ep.c_i32) ep.c_i32 += static_cast<int64_t>(rb) * ep.ldy;
     if (ep.y) ep.y += static_cast<int64_t>(rb) * ep.ldy;
@@ -265,11 +298,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
   constexpr int THREADS = WAVES * 64;
   constexpr int OUTS = MT * NT * 256;                       // outputs of the workgroup tile
   constexpr int OPT = (OUTS + THREADS - 1) / THREADS;       // outputs per thread in the epilogue
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * (NT * 16);
-  const int ksteps = (K + 63) / 64;
   const int8_t* __restrict__ B2 = DUAL ? ep.b2 : nullptr;
 
   // Epilogue operands are fetched FIRST so their latency hides under the weight stream: thread t
@@ -297,24 +325,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
       if (DUAL) {
         e_ws2[o] = ep.w_scale2[col];
         if (ep.bias2) e_bias2[o] = ep.bias2[col];
-      }
-    }
-  }
-
-  // NORM: the weight fragments of the single K round are requested before the prologue, so the
-  // weight stream's latency hides under the normalisation
-  v4i bpre[U][NT];
-  if (NORM) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int ks = wave + u * WAVES;
-      const int kk = ks * 64 + g * 16;
-      const bool k_ok = (ks < ksteps) && (kk < K);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int64_t col = n0 + j * 16 + r;
-        bpre[u][j] = (k_ok && col < N) ? *reinterpret_cast<const v4i*>(B + col * K + kk)
-                                       : v4i{0, 0, 0, 0};
       }
     }
   }
@@ -474,6 +484,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
   const bool qol_round = QOL && (ep.quant_mode & kQuantRound) != 0;
 
   for (int ks0 = wave; ks0 < ksteps; ks0 += WAVES * U) {
+    const bool first_round = ks0 == wave;  // its fragments were requested at the top of the kernel
     v4i af[U][MT], bf[ND][U][NT];
     v4f xf[QOL ? U : 1][4];
     // Issue every load of this round before the first MFMA consumes one.
@@ -496,14 +507,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
                          ? *reinterpret_cast<const v4i*>(norm_qa_lds + row * qa_stride + kk)
                          : v4i{0, 0, 0, 0};
         else
-          af[u][i] = (k_ok && row < M)
+          af[u][i] = first_round ? apre[u][i]
+                     : (k_ok && row < M)
                          ? *reinterpret_cast<const v4i*>(A + static_cast<int64_t>(row) * K + kk)
                          : v4i{0, 0, 0, 0};
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int64_t col = n0 + j * 16 + r;
-        if (NORM)
+        if (NORM || first_round)
           bf[0][u][j] = bpre[u][j];
         else
           bf[0][u][j] = (k_ok && col < N)

@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     // 256 MB Infinity Cache cannot flatter the number.
     int copies = 1;
     int8_t* brot = nullptr;
-    if (M <= 128) {
+    if (M <= 128 && !getenv("GB_NO_ROTATE")) {
       copies = (int)((600ull << 20) / (N * K)) + 1;
       CK(hipMalloc(&brot, (size_t)copies * N * K));
       hipLaunchKernelGGL(fill_s8, dim3(4096), dim3(256), 0, s, brot, (size_t)copies * N * K, 3u);
