@@ -119,14 +119,74 @@ constexpr int XVB = 16;      // V rows per batch (two blocks of eight)
 #define CT2X_ATTN_STAMP(i)
 #endif
 
+// The sixteen leading scalar arguments are the ones the hardware preloads into SGPRs at wave launch
+// (Makefile: -amdgpu-kernarg-preload-count=16); everything inside AttnXArgs costs an s_load round
+// trip to kernarg memory first. They duplicate exactly what the launch's FIRST memory requests
+// need - the cache length (a dependent load itself), the first K tile, q and the new key - so those
+// requests leave before the argument block has arrived: three dependent round trips (arguments ->
+// length -> K tile) become one.
+// (14 dwords fit next to the kernarg segment pointer in the 16 user SGPRs.)
+//   geom  = wg_per_row | teams << 8 | flags << 12 | group << 16 | kv_group << 24
+//   shape = heads | len_imm << 8 | t_max << 9   (len_imm: the len_ptr slot carries the length itself)
+//   flags: 1 = len_ptr is indexed by the cache row (cross-attention lengths), 2 = the first K tile
+//   may be requested before the length is known (no ancestry table: rows past the length are
+//   allocated but unwritten memory that is never used in arithmetic),
+//   8 = q and the new key share row_stride_e (or there is no new key): they are requested early.
+constexpr unsigned kXLenPerRow = 1u, kXSpecK = 2u, kXEarlyQ = 8u;
+
 template <int DH>
-__global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
+__global__ __launch_bounds__(512) void attn_x_decode_kernel(
+    const float* __restrict__ k_cache_e, const int32_t* __restrict__ len_ptr_e,
+    const float* __restrict__ q_e, const float* __restrict__ k_new_e, int kv_row_stride_e,
+    int kv_head_stride_e, int kv_time_stride_e, int row_stride_e, unsigned geom_e,
+    unsigned shape_e, AttnXArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int XKS = DH + 4;   // LDS row stride of the K staging tile (floats)
   constexpr int R4 = DH / 4;    // float4 per cache row
-  const AttnDecodeParams& p = a.p;
+  constexpr int KPI = 64 / R4;  // keys per staging iteration
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const bool chan = lane < DH;       // lanes that own a channel in the prologue / P.V phases
+  const int cl = chan ? lane : 0;
+  // ---- requests that need nothing but the preloaded arguments --------------------------------
+  const int wg_per_row_e = geom_e & 255u, teams_e = (geom_e >> 8) & 15u, group_e = (geom_e >> 16) & 255u;
+  const unsigned flags_e = (geom_e >> 12) & 15u;
+  const int kv_group_e = geom_e >> 24, heads_e = shape_e & 255u, t_max_e = shape_e >> 9;
+  const bool len_imm_e = (shape_e >> 8) & 1u;
+  const int row_e = blockIdx.x / wg_per_row_e;
+  const int hq_e = (blockIdx.x % wg_per_row_e) * teams_e + wave;  // >= heads: an idle wave (clamped below)
+  const int kvrow_e = row_e / kv_group_e;
+  int len_e = static_cast<int>(reinterpret_cast<uintptr_t>(len_ptr_e));  // len_imm
+  if (!len_imm_e) len_e = len_ptr_e[(flags_e & kXLenPerRow) ? kvrow_e : 0];
+  v4f kpre[R4];
+  float q_early = 0.f, knew_early = 0.f;
+  {
+    // (an idle wave of the last workgroup reads head 0's data and discards it, as before)
+    const int hq_c = hq_e < heads_e ? hq_e : 0;
+    const int hk_c = hq_c / group_e;
+    // (branch-free on purpose: a load under its own branch is waited for before the next one is
+    // issued; the row index is clamped to the allocation instead, t_max >= 1)
+    const bool spec = (flags_e & kXSpecK) != 0;
+    const float* kc_e = k_cache_e + static_cast<int64_t>(kvrow_e) * kv_row_stride_e +
+                        static_cast<int64_t>(hk_c) * kv_head_stride_e;
+    if (spec) {
+#pragma unroll
+      for (int it = 0; it < R4; ++it) {
+        const int i_ = it * 64 + lane;
+        const int tl = min(i_ / R4, t_max_e - 1);
+        kpre[it] = *reinterpret_cast<const v4f*>(kc_e + static_cast<int64_t>(tl) * kv_time_stride_e + (i_ % R4) * 4);
+      }
+    }
+    if (flags_e & kXEarlyQ) {
+      q_early = q_e[static_cast<int64_t>(row_e) * row_stride_e + hq_c * DH + cl];
+      if (k_new_e != nullptr)
+        knew_early = k_new_e[static_cast<int64_t>(row_e) * row_stride_e + hk_c * DH + cl];
+    }
+  }
+  // nothing below may be scheduled above the early requests (the argument block's s_loads would
+  // otherwise be hoisted to the top and waited for first)
+  __builtin_amdgcn_sched_barrier(0);
+  const AttnDecodeParams& p = a.p;
   const int row = blockIdx.x / a.wg_per_row;
   const int head = (blockIdx.x % a.wg_per_row) * a.teams + wave;
   const bool active = head < p.heads;
@@ -134,8 +194,6 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
   const int hk = hq / a.group;
   const bool appends = (hq % a.group) == 0;
   const int kvrow = row / static_cast<int>(p.kv_group);
-  const bool chan = lane < DH;       // lanes that own a channel in the prologue / P.V phases
-  const int cl = chan ? lane : 0;
 
   float* tq = smem + static_cast<size_t>(wave) * a.wave_floats;  // q [64]
   float* tp = tq + 64;                                           // scores / probabilities [t_pad]
@@ -155,13 +213,7 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
   (anc ? (static_cast<int64_t>(anc[static_cast<int64_t>(T) * anc_stride]) - kvrow) * p.kv_row_stride \
        : static_cast<int64_t>(0))
 
-  int t_cached;
-  if (p.lengths != nullptr)
-    t_cached = p.lengths[kvrow];
-  else if (p.step_ptr != nullptr)
-    t_cached = *p.step_ptr;
-  else
-    t_cached = static_cast<int>(p.length);
+  int t_cached = len_e;  // p.lengths[kvrow], *p.step_ptr or p.length: requested / delivered at the top
   t_cached = max(0, min(t_cached, static_cast<int>(p.t_max)));
   const bool has_new = p.k_new != nullptr;
   const int pos = t_cached;
@@ -185,22 +237,22 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
     // the prologue and both phases share ONE memory round trip.
     // (only the keys that exist are staged: an iteration covers 64 / R4 keys; the K tile's LDS
     // traffic - 32 KB per wave for 64 keys - is what bounds the QK^T phase)
-    constexpr int KPI = 64 / R4;  // keys per staging iteration
-    v4f kpre[R4];
+    if (!(flags_e & kXSpecK)) {
 #pragma unroll
-    for (int it = 0; it < R4; ++it) {
-      kpre[it] = v4f{0.f, 0.f, 0.f, 0.f};
-      if (it * KPI < n_keys) {
-        const int i_ = it * 64 + lane;  // R4 float4 per row
-        const int tl = min(i_ / R4, t_last);
-        kpre[it] = *reinterpret_cast<const v4f*>(kc + CT2X_XHOP(tl) + tl * kvs + (i_ % R4) * 4);
+      for (int it = 0; it < R4; ++it) {
+        kpre[it] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (it * KPI < n_keys) {
+          const int i_ = it * 64 + lane;  // R4 float4 per row
+          const int tl = min(i_ / R4, t_last);
+          kpre[it] = *reinterpret_cast<const v4f*>(kc + CT2X_XHOP(tl) + tl * kvs + (i_ % R4) * 4);
+        }
       }
     }
     // ---- prologue: lane = channel ---------------------------------------------------------
     float knew = 0.f, vnew = 0.f, tq_pending = 0.f;
     {
       const float* qh = p.q + static_cast<int64_t>(row) * p.q_row_stride + hq * DH;
-      float qd = qh[cl];
+      float qd = (flags_e & kXEarlyQ) ? q_early : qh[cl];  // requested at the top when possible
       // RoPE at position `pos` on q and the new key (RotaryEmbeddings::apply before the cache
       // Concat, src/layers/attention.cc:521-533; ops::Rotary src/ops/rotary_cpu.cc:30-35:
       // y[i] = x[i] * cos[i] + rot(x)[i] * sin[i] with rot = -x[partner] on the first element of a
@@ -227,7 +279,7 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(AttnXArgs a) {
       }
       if (has_new) {
         const float* kn = p.k_new + static_cast<int64_t>(row) * p.new_row_stride + hk * DH;
-        knew = kn[cl];
+        knew = (flags_e & kXEarlyQ) ? knew_early : kn[cl];
         if (rope) knew = knew * cs + kn[partner] * sn;
         vnew = p.v_new[static_cast<int64_t>(row) * p.new_row_stride + hk * DH + cl];
         if (appends && chan) {  // cache append in place of ops::Concat (attention.cc:541-546)
@@ -546,7 +598,31 @@ template <int DH>
 static void launch_x(const AttnXArgs& a, size_t lds, hipStream_t stream) {
   const unsigned grid = static_cast<unsigned>(a.p.rows * a.wg_per_row);
   ensure_lds(reinterpret_cast<const void*>(attn_x_decode_kernel<DH>), lds);
-  hipLaunchKernelGGL((attn_x_decode_kernel<DH>), dim3(grid), dim3(a.teams * 64), lds, stream, a);
+  const AttnDecodeParams& p = a.p;
+  const int32_t* len_ptr = p.lengths != nullptr ? p.lengths : p.step_ptr;
+  const int64_t big = int64_t(1) << 31;
+  unsigned flags = 0;
+  const bool fits = p.kv_row_stride < big && p.kv_head_stride < big && p.kv_time_stride < big &&
+                    a.wg_per_row <= 255 && a.teams <= 15 && a.group <= 255 && p.kv_group <= 255 &&
+                    p.heads <= 255 && p.t_max < (int64_t(1) << 23) && p.length >= 0 && p.length < big;
+  if (!fits)
+    throw Error("attention: geometry outside the exact decode kernel's packed arguments");
+  const bool len_imm = len_ptr == nullptr;
+  if (len_imm) len_ptr = reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(p.length));
+  if (p.lengths != nullptr) flags |= kXLenPerRow;
+  if (p.ancestry == nullptr) flags |= kXSpecK;
+  if (p.q_row_stride < big && (p.k_new == nullptr || p.new_row_stride == p.q_row_stride))
+    flags |= kXEarlyQ;
+  const unsigned geom = static_cast<unsigned>(a.wg_per_row) | static_cast<unsigned>(a.teams) << 8 |
+                        flags << 12 | static_cast<unsigned>(a.group) << 16 |
+                        static_cast<unsigned>(p.kv_group) << 24;
+  const unsigned shape = static_cast<unsigned>(p.heads) | (len_imm ? 256u : 0u) |
+                         static_cast<unsigned>(p.t_max) << 9;
+  hipLaunchKernelGGL((attn_x_decode_kernel<DH>), dim3(grid), dim3(a.teams * 64), lds, stream,
+                     static_cast<const float*>(p.k_cache), len_ptr, p.q, p.k_new,
+                     static_cast<int>(p.kv_row_stride), static_cast<int>(p.kv_head_stride),
+                     static_cast<int>(p.kv_time_stride), static_cast<int>(p.q_row_stride), geom,
+                     shape, a);
 }
 
 void launch_attention_exact_decode(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
