@@ -258,7 +258,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
   const int ksteps = (K + 63) / 64;
   const int rb = blockIdx.y * (MT * 16);  // this workgroup's block of MT * 16 rows (grid.y)
   M -= rb;
+  // NORM: the fp32 rows to normalise travel in the (otherwise unused) A slot, so that their request
+  // does not wait for the argument block either
+  const float* norm_x_pre = NORM ? reinterpret_cast<const float*>(A) + static_cast<int64_t>(rb) * K : nullptr;
   if (!NORM && !QOL) A += static_cast<int64_t>(rb) * K;
+  v4f xv[NORM_CH];
+  if (NORM) {
+    // lane (rg, l16) of wave w: the float4s l16, l16 + 16, ... of row 4 w + rg (see the prologue)
+    const int row_pre = wave * 4 + (lane >> 4);
+    const v4f* xg = reinterpret_cast<const v4f*>(norm_x_pre + static_cast<int64_t>(row_pre < M ? row_pre : 0) * K) + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < NORM_CH; ++j) xv[j] = xg[16 * j];
+  }
   v4i bpre[U][NT], apre[U][MT];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -287,8 +298,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     // rebase the row-indexed operands of the epilogue. Many short row blocks beat one tall
     // workgroup per column tile: [128, 512] x 512 runs 6.9 us as 32 workgroups of 8 row tiles and
     // 4.7 us as 256 workgroups of one (the weight tile is re-read per block, from L2).
-    if (NORM) ep.norm_x += static_cast<int64_t>(rb) * K;
-    else if (QOL) { ep.a_f32 += static_cast<int64_t>(rb) * K; ep.a_amax += rb; }
+    if (QOL) { ep.a_f32 += static_cast<int64_t>(rb) * K; ep.a_amax += rb; }
     if (ep.a_scale) ep.a_scale += rb;
     if (ep.c_i32) ep.c_i32 += static_cast<int64_t>(rb) * ep.ldy;
     if (ep.y) ep.y += static_cast<int64_t>(rb) * ep.ldy;
@@ -347,15 +357,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int rg = lane >> 4, l16 = lane & 15, l = lane & 7;
     const int row = wave * 4 + rg;
     const bool valid = row < M;
-    const int src_row = valid ? row : 0;        // idle lanes shadow row 0 and store nothing
     const int n4 = K / 4;
     const v4f* g4 = reinterpret_cast<const v4f*>(ep.norm_gamma);
     const v4f* b4 = reinterpret_cast<const v4f*>(ep.norm_beta);
     const bool ln = ep.norm_beta != nullptr;
-    const v4f* xg = reinterpret_cast<const v4f*>(ep.norm_x + static_cast<int64_t>(src_row) * K) + l16;
-    v4f xv[NORM_CH];
-#pragma unroll
-    for (int j = 0; j < NORM_CH; ++j) xv[j] = xg[16 * j];
+    // (xv: the row's float4s, requested at the top of the kernel)
     for (int i = tid; i < n4; i += THREADS) {
       reinterpret_cast<v4f*>(norm_gamma_lds)[i] = g4[i];
       if (ln) reinterpret_cast<v4f*>(norm_beta_lds)[i] = b4[i];
@@ -736,8 +742,8 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
   do {                                                                                            \
     auto fn = gemm_s8_skinny_kernel<1, 1, 4, 4, false, CH>;                                       \
     allow_big_lds(reinterpret_cast<const void*>(fn), lds);                                        \
-    hipLaunchKernelGGL(fn, dim3((n + 15) / 16, (m + 15) / 16), dim3(256), lds, stream, a, b, M, N, \
-                       K, ep);                                                                    \
+    hipLaunchKernelGGL(fn, dim3((n + 15) / 16, (m + 15) / 16), dim3(256), lds, stream,            \
+                       reinterpret_cast<const int8_t*>(ep.norm_x), b, M, N, K, ep);               \
   } while (0)
     if (k == 512) CT2X_NORMG(8);
     else if (k == 256) CT2X_NORMG(4);

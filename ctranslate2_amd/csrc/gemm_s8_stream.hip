@@ -34,7 +34,10 @@ namespace {
 template <int NT, int WAVES, int KS, int P, bool DUAL>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
-    int slabs_per_wg, int total_slabs, GemmS8Epilogue ep) {
+    int slabs_per_wg, int total_slabs, const int8_t* __restrict__ B2, int packed_b,
+    GemmS8Epilogue ep) {
+  // (A .. packed_b are preloaded into SGPRs; `ep` costs a kernarg round trip and is first touched
+  // after the activation fragments and the first ring of weight requests have left)
   static_assert(KS % P == 0, "the ring slot of K-step i is i % P in every slab");
   constexpr int ND = DUAL ? 2 : 1;
   constexpr int THREADS = WAVES * 64;
@@ -51,7 +54,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int8_t* __restrict__ B2 = DUAL ? ep.b2 : nullptr;
 
   // activation fragments of this wave's K-steps: resident for the whole launch
   v4i af[KS];
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int64_t off =
-          ep.packed_b ? ((((static_cast<int64_t>(slab) * WAVES + wave) * KS + i) * NT + j) << 10) + lane * 16
+          packed_b ? ((((static_cast<int64_t>(slab) * WAVES + wave) * KS + i) * NT + j) << 10) + lane * 16
                       : (n0 + j * 16 + r) * K + kk;
       bf[i % P][0][j] = *reinterpret_cast<const v4i*>(B + off);
       if (DUAL) bf[i % P][ND - 1][j] = *reinterpret_cast<const v4i*>(B2 + off);
@@ -306,7 +308,7 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
     const size_t lds = sizeof(int) * 2 * (DUAL ? 2 : 1) * 16 * NT * 256 + 2 * 16 * sizeof(int);   \
     allow_big_lds(reinterpret_cast<const void*>(fn), lds);                                        \
     hipLaunchKernelGGL(fn, dim3(plan.grid), dim3(1024), lds, stream, a, b, M, N, K,               \
-                       plan.slabs_per_wg, plan.slabs, ep);                                        \
+                       plan.slabs_per_wg, plan.slabs, ep.b2, ep.packed_b ? 1 : 0, ep);            \
     return;                                                                                       \
   }
   // (forms whose register ring spills at 128 VGPRs - 16 waves per workgroup - are not compiled:
