@@ -1617,7 +1617,7 @@ void Engine::launch_step(DecodeState& st) {
                            dec_.layers[0].ffn.l0_noact.present;
   // ... and so do the feed-forward blocks whose inner Quantize is folded into the consuming GEMM
   // (run_ffn / dense_qol). The slots are cleared by the step's first launch, not by a memset node.
-  const bool ffn_amax = !tp_ && !taps_ && rows <= 128 && !dec_.layers.empty() && gemm_s8_qol_enabled();
+  const bool ffn_amax = !tp_ && !taps_ && rows <= 32 && !dec_.layers.empty() && gemm_s8_qol_enabled();
   const bool zero_amax = split_quant || ffn_amax;
   begin_kernel("embed");
   launch_embed(dec_.emb.table, dec_.emb.is_int8, dec_.emb.scale, st.d_ids, rows, d,

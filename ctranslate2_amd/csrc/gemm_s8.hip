@@ -229,7 +229,8 @@ template <int MT, int NT, int WAVES, int U, bool DUAL = false, int NORM = 0, boo
           bool NTW = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
-    GemmS8Epilogue ep) {
+    const float* __restrict__ aux, GemmS8Epilogue ep) {
+  // aux (preloaded like A .. K): QOL = the row absmax of the fp32 activation; unused otherwise
   constexpr int ND = DUAL ? 2 : 1;
   __shared__ int partial[ND][WAVES][MT][NT][64][4];
   // NORM (dynamic LDS): transposed fp32 rows [16][8 * pad] (row_norm.h norm_chain_slot) | gamma [K]
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
   extern __shared__ __attribute__((aligned(16))) int8_t norm_lds[];
   constexpr int NORM_CH = NORM > 0 ? NORM : 1;  // float4s per lane: K == 64 * NORM
   static_assert(!NORM || (MT == 1 && WAVES == 4), "NORM: 16 rows on four waves, 16 lanes per row");
-  static_assert(!QOL || (MT == 1 && !NORM && !DUAL), "QOL: one 16-row tile, plain Dense");
+  static_assert(!QOL || (MT == 1 && !NORM && !DUAL && (WAVES == 4 || WAVES == 8)),
+                "QOL: one 16-row tile, plain Dense, K <= 256 * WAVES");
   const int qa_stride = K + 16;
   const int norm_pad = NORM ? norm_chain_pad(K) : 0;
   const int norm_x_stride = 8 * norm_pad;
@@ -270,6 +272,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
 #pragma unroll
     for (int j = 0; j < NORM_CH; ++j) xv[j] = xg[16 * j];
   }
+  // QOL: thread t owns float4 column t of every row of the 16-row tile (K / 4 <= THREADS): sixteen
+  // coalesced row segments, requested here, quantised into the LDS A tile once the row scales are
+  // known (the strided per-lane fetch of the first version cost more than the Quantize launch)
+  v4f qx[QOL ? 16 : 1];
+  if (QOL) {
+    const v4f* xsrc = reinterpret_cast<const v4f*>(reinterpret_cast<const float*>(A) +
+                                                   static_cast<int64_t>(rb) * K);
+    const int k4 = K >> 2;
+#pragma unroll
+    for (int row = 0; row < 16; ++row)
+      qx[row] = (tid < k4 && row < M) ? xsrc[static_cast<int64_t>(row) * k4 + tid] : v4f{0.f, 0.f, 0.f, 0.f};
+  }
   v4i bpre[U][NT], apre[U][MT];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -298,7 +312,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     // rebase the row-indexed operands of the epilogue. Many short row blocks beat one tall
     // workgroup per column tile: [128, 512] x 512 runs 6.9 us as 32 workgroups of 8 row tiles and
     // 4.7 us as 256 workgroups of one (the weight tile is re-read per block, from L2).
-    if (QOL) { ep.a_f32 += static_cast<int64_t>(rb) * K; ep.a_amax += rb; }
     if (ep.a_scale) ep.a_scale += rb;
     if (ep.c_i32) ep.c_i32 += static_cast<int64_t>(rb) * ep.ldy;
     if (ep.y) ep.y += static_cast<int64_t>(rb) * ep.ldy;
@@ -323,12 +336,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     e_ra[o] = e_ws[o] = e_ws2[o] = 1.f;
     e_bias[o] = e_res[o] = e_bias2[o] = 0.f;
     if (ep.mode == 1 && flat < OUTS && row < M && col < N) {
-      if (QOL) {
-        const float am = ep.a_amax[row];
-        e_ra[o] = (am != 0.f) ? 127.f / am : 1.f;  // the scale ops::Quantize would have stored
-      } else if (!NORM) {
-        e_ra[o] = ep.a_scale[row];
-      }
+      if (!NORM && !QOL) e_ra[o] = ep.a_scale[row];
       e_ws[o] = ep.w_scale[col];
       if (ep.bias) e_bias[o] = ep.bias[col];
       if (ep.residual) e_res[o] = ep.residual[static_cast<int64_t>(row) * ep.ldy + col];
@@ -480,19 +488,48 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[d][i][j] = v4i{0, 0, 0, 0};
 
-  // QOL: lane (r, g) owns row r of the 16-row tile
-  float qol_scale = 1.f;
-  if (QOL && r < M) {
-    const float am = ep.a_amax[r];
-    qol_scale = (am != 0.f) ? 127.f / am : 1.f;
+  // QOL prologue: row scales (127 / absmax, 1 for a zero row: what ops::Quantize would have stored),
+  // then every thread quantises its column of the tile into LDS (to_s8, device_utils.h).
+  float* qol_scales = reinterpret_cast<float*>(norm_lds);          // [16]
+  int8_t* qol_qa = norm_lds + 64;                                  // [16][K + 16]
+  if (QOL) {
+    if (tid < 16) {
+      const float am = (tid < M) ? aux[rb + tid] : 0.f;
+      qol_scales[tid] = (am != 0.f) ? 127.f / am : 1.f;
+    }
+    __syncthreads();
+    const bool q_shift = (ep.quant_mode & kQuantU8Shift) != 0;
+    const bool q_round = (ep.quant_mode & kQuantRound) != 0;
+    if (tid < (K >> 2)) {
+#pragma unroll
+      for (int row = 0; row < 16; ++row) {
+        const float scale = qol_scales[row];
+        int word;
+        if (q_shift && q_round) {
+          int b[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[e] = static_cast<int>(rintf(fmaf(qx[row][e], scale, 128.f)));
+          const unsigned lo = __builtin_amdgcn_perm(static_cast<unsigned>(b[1]),
+                                                    static_cast<unsigned>(b[0]), 0x0c0c0400u);
+          const unsigned hi = __builtin_amdgcn_perm(static_cast<unsigned>(b[3]),
+                                                    static_cast<unsigned>(b[2]), 0x04000c0cu);
+          word = static_cast<int>((lo | hi) ^ 0x80808080u);
+        } else {
+          word = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            word |= (static_cast<int>(to_s8(qx[row][e], scale, ep.quant_mode)) & 0xff) << (8 * e);
+        }
+        // rows >= M hold zeros, whose image under the u8-shift arm is 0 as well (128 - 128)
+        reinterpret_cast<int*>(qol_qa + row * qa_stride)[tid] = word;
+      }
+    }
+    __syncthreads();
   }
-  const bool qol_shift = QOL && (ep.quant_mode & kQuantU8Shift) != 0;
-  const bool qol_round = QOL && (ep.quant_mode & kQuantRound) != 0;
 
   for (int ks0 = wave; ks0 < ksteps; ks0 += WAVES * U) {
     const bool first_round = ks0 == wave;  // its fragments were requested at the top of the kernel
     v4i af[U][MT], bf[ND][U][NT];
-    v4f xf[QOL ? U : 1][4];
     // Issue every load of this round before the first MFMA consumes one.
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -503,11 +540,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
       for (int i = 0; i < MT; ++i) {
         const int row = i * 16 + r;
         if (QOL) {
-          // 16 consecutive floats of the fp32 activation row (64 bytes per lane)
-          const v4f* src = reinterpret_cast<const v4f*>(ep.a_f32 + static_cast<int64_t>(row) * K + kk);
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            xf[u][c] = (k_ok && row < M) ? src[c] : v4f{0.f, 0.f, 0.f, 0.f};
+          af[u][i] = (k_ok && row < M) ? *reinterpret_cast<const v4i*>(qol_qa + row * qa_stride + kk)
+                                       : v4i{0, 0, 0, 0};
         } else if (NORM)
           af[u][i] = (k_ok && row < M)
                          ? *reinterpret_cast<const v4i*>(norm_qa_lds + row * qa_stride + kk)
@@ -533,35 +567,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
                                  ? (NTW ? __builtin_nontemporal_load(reinterpret_cast<const v4i*>(B2 + col * K + kk))
                                         : *reinterpret_cast<const v4i*>(B2 + col * K + kk))
                                  : v4i{0, 0, 0, 0};
-      }
-    }
-    if (QOL) {
-      // Quantize (to_s8, device_utils.h) of the fragments; rows >= M and K-steps past the end hold
-      // zeros, whose image under the u8-shift arm is 0 as well (128 - 128)
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        v4i packed;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (qol_shift && qol_round) {
-            int b[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              b[e] = static_cast<int>(rintf(fmaf(xf[u][c][e], qol_scale, 128.f)));
-            const unsigned lo = __builtin_amdgcn_perm(static_cast<unsigned>(b[1]),
-                                                      static_cast<unsigned>(b[0]), 0x0c0c0400u);
-            const unsigned hi = __builtin_amdgcn_perm(static_cast<unsigned>(b[3]),
-                                                      static_cast<unsigned>(b[2]), 0x04000c0cu);
-            packed[c] = static_cast<int>((lo | hi) ^ 0x80808080u);
-          } else {
-            int word = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              word |= (static_cast<int>(to_s8(xf[u][c][e], qol_scale, ep.quant_mode)) & 0xff) << (8 * e);
-            packed[c] = word;
-          }
-        }
-        af[u][0] = packed;
       }
     }
 #pragma unroll
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
       ep.c_i32[idx] = sum;
     } else {
       // CPU formula order (src/cpu/kernels.cc:666-673): c * (1/a_scale) / b_scale + bias.
-      const float r_a = 1.f / (NORM ? norm_scales[row] : e_ra[o]);
+      const float r_a = 1.f / (NORM ? norm_scales[row] : (QOL ? qol_scales[row] : e_ra[o]));
       float v = static_cast<float>(sum) * r_a;
       v = v / e_ws[o];
       if (ep.bias) v = v + e_bias[o];
@@ -667,24 +672,29 @@ bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k) {
   return m >= 1 && m <= 128 && (k == 64 || k == 128 || k == 256 || k == 512) && n >= 1 && n < 8192;
 }
 
-// Shapes the quantise-on-load form serves: decode rows and a K that is whole MFMA K-steps. The
+// Shapes the quantise-on-load form serves: decode rows and a K that is whole MFMA K-steps and at
+// most 2048 (one float4 column of the 16-row tile per thread of an 8-wave workgroup). The
 // fp32 activation is 4x the bytes of its int8 copy and every column workgroup re-reads its 16 rows
 // from L2, so the form only pays where that stays small next to a launch: m * k * 4 <= 1 MiB
 // (Transformer-base FFN: 32 x 2048) - the Llama shapes (16 x 14336 into 256 workgroups) keep
 // the element-wise Quantize launch.
 bool gemm_s8_qol_applicable(int64_t m, int64_t n, int64_t k) {
-  return m >= 1 && m <= 128 && k % 64 == 0 && k >= 64 && n >= 1 && n <= 4096 &&
+  return m >= 1 && m <= 128 && k % 64 == 0 && k >= 64 && k <= 2048 && n >= 1 && n <= 4096 &&
          m * k * 4 <= (1 << 20);
 }
 
-// Measured on Transformer-base (batch 32, same box, same run): 91.3k tokens/s with the folded
-// Quantize (52 launches per step) against 94.4k with its own launch (58): the lane-strided fetch of
-// the fp32 rows (64 bytes per lane, 16 rows apart) costs the consuming GEMM more than the 2.2 us
-// launch it removes. Off by default; CT2X_QUANT_ON_LOAD=1 turns it on (bit-identical either way).
+// Measured on Transformer-base (batch 32, same box, alternating runs). First version (every lane
+// fetched and converted the 16 floats of its own fragment, 64 bytes per lane and 16 rows apart):
+// 91.3k tokens/s against 94.4k with the Quantize launch - a loss. Second version (coalesced row
+// segments, one conversion per tile through LDS): 97.9 - 98.2k against 97.6 - 99.7k - break-even:
+// what a decode kernel costs is its chain of dependent memory round trips, and the folded form
+// trades the Quantize launch's round trip for 64 conversions per thread on the consumer's critical
+// path. On by default for <= 32 rows (six launches less per Transformer-base step at the same
+// speed: less host-side graph work); CT2X_QUANT_ON_LOAD=0 restores the launch (bit-identical).
 bool gemm_s8_qol_enabled() {
   static const bool enabled = [] {
     const char* e = std::getenv("CT2X_QUANT_ON_LOAD");
-    return e != nullptr && e[0] == '1';
+    return e == nullptr || e[0] != '0';
   }();
   return enabled;
 }
@@ -743,7 +753,8 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
     auto fn = gemm_s8_skinny_kernel<1, 1, 4, 4, false, CH>;                                       \
     allow_big_lds(reinterpret_cast<const void*>(fn), lds);                                        \
     hipLaunchKernelGGL(fn, dim3((n + 15) / 16, (m + 15) / 16), dim3(256), lds, stream,            \
-                       reinterpret_cast<const int8_t*>(ep.norm_x), b, M, N, K, ep);               \
+                       reinterpret_cast<const int8_t*>(ep.norm_x), b, M, N, K,                    \
+                       static_cast<const float*>(nullptr), ep);                                   \
   } while (0)
     if (k == 512) CT2X_NORMG(8);
     else if (k == 256) CT2X_NORMG(4);
@@ -767,10 +778,14 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
           (reinterpret_cast<uintptr_t>(b) & 15) == 0))
       throw Error("launch_gemm_s8: the quantise-on-load form needs M <= 128, K % 64 == 0, the row absmax and 16-byte aligned operands");
 #define CT2X_QOL(WAVES, U)                                                                        \
-  hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, 1, WAVES, U, false, 0, true>),                     \
-                     dim3((n + 15) / 16, (m + 15) / 16), dim3(WAVES * 64), 0, stream, a, b, M, N, \
-                     K, ep)
-    if (k >= 2048) CT2X_QOL(8, 4);
+  do {                                                                                            \
+    auto fn = gemm_s8_skinny_kernel<1, 1, WAVES, U, false, 0, true>;                              \
+    const size_t lds = 64 + 16 * static_cast<size_t>(k + 16);                                     \
+    allow_big_lds(reinterpret_cast<const void*>(fn), lds);                                        \
+    hipLaunchKernelGGL(fn, dim3((n + 15) / 16, (m + 15) / 16), dim3(WAVES * 64), lds, stream,     \
+                       reinterpret_cast<const int8_t*>(ep.a_f32), b, M, N, K, ep.a_amax, ep);     \
+  } while (0)
+    if (k > 1024) CT2X_QOL(8, 4);
     else CT2X_QOL(4, 4);
 #undef CT2X_QOL
     return;
@@ -783,11 +798,12 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
 #define CT2X_DUAL(MT, NT, WAVES, U)                                                              \
   hipLaunchKernelGGL((gemm_s8_skinny_kernel<MT, NT, WAVES, U, true>),                            \
                      dim3((n + 16 * NT - 1) / (16 * NT)), dim3(WAVES * 64), 0, stream, a, b, M, N, \
-                     K, ep)
+                     K, static_cast<const float*>(nullptr), ep)
     if (m <= 16) {
       if (k >= 4096 && nt_weights(n, k))
         hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, 2, 16, 2, true, 0, false, true>),
-                           dim3((n + 31) / 32), dim3(1024), 0, stream, a, b, M, N, K, ep);
+                           dim3((n + 31) / 32), dim3(1024), 0, stream, a, b, M, N, K,
+                           static_cast<const float*>(nullptr), ep);
       else if (k >= 4096) CT2X_DUAL(1, 2, 16, 2);
       else if (k >= 2048) CT2X_DUAL(1, 1, 8, 4);
       else CT2X_DUAL(1, 1, 4, 4);
@@ -805,7 +821,7 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
 #define CT2X_SKINNY(MT, NT, WAVES, U)                                                          \
   hipLaunchKernelGGL((gemm_s8_skinny_kernel<MT, NT, WAVES, U>),                                \
                      dim3((n + 16 * NT - 1) / (16 * NT), (m + 16 * MT - 1) / (16 * MT)),       \
-                     dim3(WAVES * 64), 0, stream, a, b, M, N, K, ep)
+                     dim3(WAVES * 64), 0, stream, a, b, M, N, K, static_cast<const float*>(nullptr), ep)
     // Rows beyond 16 are split into row blocks (grid.y) of `mt` 16-row tiles; one tile per block
     // measured best at every decode shape of Transformer-base ([32|64|128, 512] x 512: 2.7 us
     // against 3.2 / 4.5 / 7.0 us with 2 / 4 / 8 tiles per workgroup; tools/kernel_bench.cpp).
@@ -847,7 +863,7 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
 #define CT2X_SKINNY_NT(NT, WAVES, U)                                                            \
   hipLaunchKernelGGL((gemm_s8_skinny_kernel<1, NT, WAVES, U, false, 0, false, true>),            \
                      dim3((n + 16 * NT - 1) / (16 * NT), (m + 15) / 16), dim3(WAVES * 64), 0,    \
-                     stream, a, b, M, N, K, ep)
+                     stream, a, b, M, N, K, static_cast<const float*>(nullptr), ep)
       if (n >= 8192) CT2X_SKINNY_NT(4, 16, 2);
       else if (k >= 8192) CT2X_SKINNY_NT(1, 16, 4);
       else if (n >= 6144) CT2X_SKINNY_NT(2, 8, 8);

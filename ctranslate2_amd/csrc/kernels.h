@@ -127,7 +127,7 @@ struct GemmS8Epilogue {
 
 bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k);
 bool gemm_s8_qol_applicable(int64_t m, int64_t n, int64_t k);
-bool gemm_s8_qol_enabled();  // CT2X_QUANT_ON_LOAD=1 (off by default: measured slower, bit-identical)
+bool gemm_s8_qol_enabled();  // CT2X_QUANT_ON_LOAD=0 restores the Quantize launch (bit-identical, same speed)
 bool gemm_s8_norm_fusion_enabled();  // CT2X_NORM_FUSION=1 (off by default: measured slower)
 
 // C[m,n] = A[m,k] . B[n,k]^T   (lda = ldb = k). Chooses a tile shape from (m, n, k).
