@@ -131,8 +131,10 @@ constexpr int XVB = 16;      // V rows per batch (two blocks of eight)
 //   flags: 1 = len_ptr is indexed by the cache row (cross-attention lengths), 2 = the first K tile
 //   may be requested before the length is known (no ancestry table: rows past the length are
 //   allocated but unwritten memory that is never used in arithmetic),
+//   4 = only the first half of the tile (32 keys at d_head 64) is requested early, the rest once
+//   the length is known (CT2X_ATTN_SPEC_K=half),
 //   8 = q and the new key share row_stride_e (or there is no new key): they are requested early.
-constexpr unsigned kXLenPerRow = 1u, kXSpecK = 2u, kXEarlyQ = 8u;
+constexpr unsigned kXLenPerRow = 1u, kXSpecK = 2u, kXSpecHalf = 4u, kXEarlyQ = 8u;
 
 template <int DH>
 __global__ __launch_bounds__(512) void attn_x_decode_kernel(
@@ -169,12 +171,21 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(
     const bool spec = (flags_e & kXSpecK) != 0;
     const float* kc_e = k_cache_e + static_cast<int64_t>(kvrow_e) * kv_row_stride_e +
                         static_cast<int64_t>(hk_c) * kv_head_stride_e;
+    constexpr int HALF = R4 > 1 ? R4 / 2 : 1;
     if (spec) {
 #pragma unroll
-      for (int it = 0; it < R4; ++it) {
+      for (int it = 0; it < HALF; ++it) {
         const int i_ = it * 64 + lane;
         const int tl = min(i_ / R4, t_max_e - 1);
         kpre[it] = *reinterpret_cast<const v4f*>(kc_e + static_cast<int64_t>(tl) * kv_time_stride_e + (i_ % R4) * 4);
+      }
+      if (!(flags_e & kXSpecHalf)) {
+#pragma unroll
+        for (int it = HALF; it < R4; ++it) {
+          const int i_ = it * 64 + lane;
+          const int tl = min(i_ / R4, t_max_e - 1);
+          kpre[it] = *reinterpret_cast<const v4f*>(kc_e + static_cast<int64_t>(tl) * kv_time_stride_e + (i_ % R4) * 4);
+        }
       }
     }
     if (flags_e & kXEarlyQ) {
@@ -237,9 +248,11 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(
     // the prologue and both phases share ONE memory round trip.
     // (only the keys that exist are staged: an iteration covers 64 / R4 keys; the K tile's LDS
     // traffic - 32 KB per wave for 64 keys - is what bounds the QK^T phase)
-    if (!(flags_e & kXSpecK)) {
+    if (!(flags_e & kXSpecK) || (flags_e & kXSpecHalf)) {
+      constexpr int HALF2 = R4 > 1 ? R4 / 2 : 1;
 #pragma unroll
       for (int it = 0; it < R4; ++it) {
+        if ((flags_e & kXSpecK) && it < HALF2) continue;  // requested at the top
         kpre[it] = v4f{0.f, 0.f, 0.f, 0.f};
         if (it * KPI < n_keys) {
           const int i_ = it * 64 + lane;  // R4 float4 per row
@@ -610,7 +623,16 @@ static void launch_x(const AttnXArgs& a, size_t lds, hipStream_t stream) {
   const bool len_imm = len_ptr == nullptr;
   if (len_imm) len_ptr = reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(p.length));
   if (p.lengths != nullptr) flags |= kXLenPerRow;
-  if (p.ancestry == nullptr) flags |= kXSpecK;
+  // CT2X_ATTN_SPEC_K = 0 (no early K request) | half | 1 (whole first tile; default)
+  static const int spec_mode = [] {
+    const char* e = std::getenv("CT2X_ATTN_SPEC_K");
+    if (e == nullptr) return 2;
+    if (e[0] == '0') return 0;
+    if (e[0] == 'h') return 1;
+    return 2;
+  }();
+  if (p.ancestry == nullptr && spec_mode > 0) flags |= kXSpecK;
+  if (spec_mode == 1) flags |= kXSpecHalf;
   if (p.q_row_stride < big && (p.k_new == nullptr || p.new_row_stride == p.q_row_stride))
     flags |= kXEarlyQ;
   const unsigned geom = static_cast<unsigned>(a.wg_per_row) | static_cast<unsigned>(a.teams) << 8 |
