@@ -381,6 +381,36 @@ inline ExpSumLayout exp_sum_layout(int64_t vocab) {
 }
 
 
+// Spare workgroup `wg` of `nwg` (256 threads each) of a row-wide launch: request its share of up to
+// two weight ranges (kernels.h PrefetchArgs) and drop the data - the point is that the lines are in
+// the memory-side cache when the next GEMM streams them.
+template <typename Args>
+__device__ __forceinline__ void weight_prefetch_wg(const Args& pf, int wg, int nwg) {
+  unsigned acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const uint4* p = static_cast<const uint4*>(pf.r[k].p);
+    if (p == nullptr) continue;
+    const int64_t take16 = pf.r[k].take16, unit16 = pf.r[k].unit16, chunks = pf.r[k].chunks;
+    const int64_t stride = static_cast<int64_t>(nwg) * 256;
+    for (int64_t c = static_cast<int64_t>(wg) * 256 + threadIdx.x; c < chunks; c += 8 * stride) {
+      uint4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t cc = c + j * stride;
+        v[j] = make_uint4(0, 0, 0, 0);
+        if (cc < chunks) {
+          const int64_t u = cc / take16;
+          v[j] = p[u * unit16 + (cc - u * take16)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+    }
+  }
+  asm volatile("" ::"v"(acc));  // the loads are the point
+}
+
 // > 64 KiB of dynamic LDS has to be opted into per kernel.
 inline void allow_big_lds(const void* fn, size_t bytes) {
   // (the limit covers static + dynamic LDS: ask for what the launch uses, not for the maximum)

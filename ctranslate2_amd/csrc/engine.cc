@@ -112,6 +112,8 @@ uint16_t float_to_half_bits(float f) {  // IEEE binary16, round to nearest even
 
 }  // namespace
 
+thread_local DecodeState* Engine::pf_state_ = nullptr;
+
 hipStream_t Engine::cur_stream() const { return tls_stream ? tls_stream : stream_; }
 
 // ---------------------------------------------------------------------------------------------
@@ -595,6 +597,31 @@ void Engine::pack_stream(DenseW& w, bool dual) {
   w.wq_stream_dual = dual;
 }
 
+// HBM sits idle during the row-wide launches of a layer (norm + Quantize, element-wise Quantize:
+// 48 of the Llama shape's 102 us per layer). The weight of the Dense that FOLLOWS such a launch is
+// requested by spare workgroups appended to that launch (kernels.h PrefetchArgs), so the GEMM finds
+// (a leading fraction of every wave's stream of) its weight in the memory-side cache.
+// MEASURED NEGATIVE on the Llama-3-8B shape, both ways, and therefore off by default
+// (CT2X_WEIGHT_PREFETCH=1 turns it on): as a parallel branch of the step's hipGraph (side stream,
+// event fork / join per Dense) every cross-queue dependency cost ~18 us - 5.6 instead of 3.3 ms per
+// step (`profiles/r02b_l8_side_stream_prefetch_negative.txt`); as spare workgroups of the row-wide
+// launches 3.45 - 3.48 against 3.27 - 3.28 ms, 3.39 with half the bytes
+// (`profiles/r02b_l8_inkernel_prefetch_negative.txt`): the carrying launches grow by more than the
+// GEMMs shrink - a GEMM whose weight is MALL resident is only 20 % faster
+// (`profiles/r02_skinny_hbm_vs_mall.txt`), and the requests compete with the norm's own chain.
+void Engine::prefetch_weight(DecodeState& st, const DenseW& w, int site) {
+  if (!weight_prefetch_ || !st.pf_active || profiling_ || taps_ || w.wq_stream == nullptr ||
+      st.rows > 16 || prefetch_bytes_[site] <= 0)
+    return;
+  for (PrefetchRange& r : st.pf_pending.r) {
+    if (r.p != nullptr) continue;
+    if (weight_prefetch_range(w.wq_stream, w.n, w.k, w.wq_stream_dual,
+                              prefetch_bytes_[site] / (w.wq_stream_dual ? 2 : 1), &r))
+      st.pf_pending.wgs = prefetch_wgs_;
+    return;
+  }
+}
+
 void Engine::pack_stream_weights() {
   if (tp_) return;
   for (LayerW& layer : dec_.layers) {
@@ -611,6 +638,20 @@ void Engine::pack_stream_weights() {
     pack_stream(layer.ffn.l1, false);
   }
   pack_stream(dec_.projection, false);
+  {
+    // CT2X_WEIGHT_PREFETCH=1 switches the weight prefetch on (measured NEGATIVE, off by default: see
+    // Engine::prefetch_weight); CT2X_PREFETCH_MB="qkv,out,ffn_in,ffn_out" sets the megabytes requested
+    // next to the launch in front of each Dense, CT2X_PREFETCH_WGS the spare workgroups
+    const char* e = std::getenv("CT2X_WEIGHT_PREFETCH");
+    bool any = false;
+    for (const LayerW& layer : dec_.layers) any = any || layer.ffn.l1.wq_stream != nullptr;
+    weight_prefetch_ = any && e != nullptr && e[0] == '1';
+    double mb[4] = {25, 17, 36, 18};
+    if (const char* m = std::getenv("CT2X_PREFETCH_MB"))
+      (void)std::sscanf(m, "%lf,%lf,%lf,%lf", &mb[0], &mb[1], &mb[2], &mb[3]);
+    for (int i = 0; i < 4; ++i) prefetch_bytes_[i] = static_cast<int64_t>(mb[i] * 1048576.0);
+    if (const char* g = std::getenv("CT2X_PREFETCH_WGS")) prefetch_wgs_ = std::max(1, std::atoi(g));
+  }
   CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
   check_last_launch("pack_stream_weights");
 }
@@ -882,8 +923,11 @@ void Engine::norm_quant(const NormW& w, const float* x, int64_t rows, int64_t de
     tap_y = static_cast<float*>(device_malloc(static_cast<size_t>(rows * depth) * sizeof(float)));
     y = tap_y;
   }
+  DecodeState* pst = pf_state_;
+  const PrefetchArgs* pf = (pst != nullptr && pst->pf_pending.wgs > 0) ? &pst->pf_pending : nullptr;
   launch_norm(x, w.gamma, w.beta, rows, depth, w.eps, w.use_residual, quant_mode_, y, q, s,
-              cur_stream());
+              cur_stream(), pf);
+  if (pf != nullptr) pst->pf_pending = PrefetchArgs();
   end_kernel();
   if (taps_) {
     tap("f", y, 0, rows, depth);
@@ -1122,6 +1166,7 @@ DecodeState::~DecodeState() {
     if (pin_cand_event[i]) (void)hipEventDestroy(pin_cand_event[i]);
   }
   if (graph) (void)hipGraphDestroy(graph);
+
   for (void* p : owned) {
     try { device_free(p); } catch (...) {}
   }
@@ -1437,6 +1482,8 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
   if (qin_ready) {
   } else if (ffn.ln.present && pre_norm) {
     if (ffn.l0.quantized) {
+      prefetch_weight(st, ffn.l0, 2);  // FFN input weight(s), next to the norm launch
+      if (ffn.l0_noact.present) prefetch_weight(st, ffn.l0_noact, 2);
       norm_quant(ffn.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
       fq.q = st.qbuf;
       fq.s = st.qscale;
@@ -1481,9 +1528,11 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
     launch_gemm_s8(fq.q, w0, rows, ffn.l0.n, ffn.l0.k, ep, cur_stream());
     end_kernel();
     if (split_quant) {
+      prefetch_weight(st, ffn.l1, 3);  // FFN output weight, next to the Quantize launch
       begin_kernel("quantize_cols", double(rows) * ffn.l0.n * 5, 0, rows, 0, ffn.l0.n);
       launch_quantize_cols(st.inner, amax_buf, rows, ffn.l0.n, quant_mode_, st.qbuf, st.qscale,
-                           cur_stream());
+                           cur_stream(), st.pf_pending.wgs > 0 ? &st.pf_pending : nullptr);
+      st.pf_pending = PrefetchArgs();
       end_kernel();
       QuantIn iq;
       iq.q = st.qbuf;
@@ -1613,6 +1662,9 @@ void Engine::launch_step(DecodeState& st) {
   float* y = st.x1;
   // producer-side absmax slots (2 per layer) are max-combined into: zero them for this step
   // (only models whose layers take that path pay for the memset node: gated-FFN decoders)
+  st.pf_active = true;
+  st.pf_pending = PrefetchArgs();
+  pf_state_ = &st;
   const bool split_quant = !tp_ && rows <= 32 && !dec_.layers.empty() &&
                            dec_.layers[0].ffn.l0_noact.present;
   // ... and so do the feed-forward blocks whose inner Quantize is folded into the consuming GEMM
@@ -1648,6 +1700,7 @@ void Engine::launch_step(DecodeState& st) {
         qin_ready = false;
       } else if (!fused_in && a.ln.present && dec_.pre_norm) {
         if (a.lin[0].quantized) {
+          prefetch_weight(st, a.lin[0], 0);  // QKV weight, next to the norm launch
           norm_quant(a.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
           qin.q = st.qbuf;
           qin.s = st.qscale;
@@ -1719,8 +1772,11 @@ void Engine::launch_step(DecodeState& st) {
         begin_kernel("attention_self_decode", 0, 0, rows, a.heads, a.dhead);
         launch_attention_decode(p, cur_stream());
         end_kernel();
+        prefetch_weight(st, a.lin[1], 1);  // attention output weight, next to the Quantize launch
         begin_kernel("quantize_cols", double(rows) * qdim * 5, 0, rows, 0, qdim);
-        launch_quantize_cols(st.ctx, amax, rows, qdim, quant_mode_, st.qbuf, st.qscale, cur_stream());
+        launch_quantize_cols(st.ctx, amax, rows, qdim, quant_mode_, st.qbuf, st.qscale, cur_stream(),
+                             st.pf_pending.wgs > 0 ? &st.pf_pending : nullptr);
+        st.pf_pending = PrefetchArgs();
         end_kernel();
         QuantIn cq;
         cq.q = st.qbuf;
@@ -1818,6 +1874,9 @@ void Engine::launch_step(DecodeState& st) {
     qin_ready = false;
   }
 
+  st.pf_active = false;
+  st.pf_pending = PrefetchArgs();
+  pf_state_ = nullptr;
   // Final norm + vocabulary projection (transformer.cc:842-855).
   tap_scope("dec.out");
   QuantIn pq;

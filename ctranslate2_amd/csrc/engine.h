@@ -274,6 +274,12 @@ private:
   void dense_qol(const DenseW& w, const float* x, const float* row_amax, int64_t m, int act,
                  const float* residual, float* y);
   void load_weights();
+  // weight prefetch by spare workgroups of the row-wide launches of a decode step (engine.cc)
+  void prefetch_weight(DecodeState& st, const DenseW& w, int site);
+  bool weight_prefetch_ = false;
+  int prefetch_wgs_ = 192;
+  static thread_local DecodeState* pf_state_;  // session whose launch_step is running on this thread
+  int64_t prefetch_bytes_[4] = {0, 0, 0, 0};
   void pack_stream_weights();
   void pack_stream(DenseW& w, bool dual);
   // How a Dense is split over the tensor-parallel ranks (Model::load, src/models/model.cc:
@@ -362,6 +368,9 @@ private:
 struct DecodeState {
   Engine* engine = nullptr;
   hipStream_t stream = nullptr;  // all work of this session is enqueued here
+  // weight prefetch (Engine::prefetch_weight): ranges the next row-wide launch carries along
+  PrefetchArgs pf_pending;
+  bool pf_active = false;  // inside Engine::launch_step (not prefill / encode)
   int64_t batch = 0, beam = 1, rows = 0, t_max = 0, s_max = 0, prefill_max = 0;
   // device buffers (owned; released in the destructor through the caching allocator)
   std::vector<void*> owned;

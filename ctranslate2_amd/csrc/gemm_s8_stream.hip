@@ -25,6 +25,7 @@
 #include "kernels.h"
 #include "runtime.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace ct2x {
@@ -290,6 +291,28 @@ void launch_pack_stream_weight(const int8_t* src, int64_t n, int64_t k, bool dua
   const int64_t chunks = n * k / 16;
   hipLaunchKernelGGL(pack_stream_weight_kernel<16>, dim3(static_cast<unsigned>((chunks + 255) / 256)),
                      dim3(256), 0, stream, src, k, plan.nt, plan.ks, chunks, dst);
+}
+
+// `bytes` of the fragment-major weight [n, k] as a PrefetchRange: for a packed weight a unit is what
+// one wave requests for one slab (KS * NT KB), so "the first take16 pieces of every unit" is the
+// same leading fraction of EVERY wave's stream - a plain prefix would serve a few workgroups
+// completely and the others not at all (whole weight when bytes >= n * k).
+bool weight_prefetch_range(const int8_t* packed, int64_t n, int64_t k, bool dual, int64_t bytes,
+                           PrefetchRange* out) {
+  StreamPlan plan;
+  if (bytes <= 0 || packed == nullptr || !plan_stream(n, k, dual, device_cus(), &plan)) return false;
+  const int64_t unit16 = static_cast<int64_t>(plan.ks) * plan.nt * 64;
+  const int64_t units = n * k / 16 / unit16;
+  int64_t take16 = unit16;
+  if (bytes < n * k) {
+    take16 = (bytes / 16 / units) & ~int64_t(63);  // whole 1 KB requests
+    if (take16 <= 0) return false;
+  }
+  out->p = packed;
+  out->unit16 = unit16;
+  out->take16 = take16;
+  out->chunks = units * take16;
+  return true;
 }
 
 void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K,

@@ -26,8 +26,18 @@ void launch_dequantize_gemm_output(const int32_t* c, const float* a_scale, const
 // Second half of a Quantize whose row absmax was produced by the previous launch (absmax in
 // amax[rows]): element-wise over (rows x column chunks) workgroups instead of one workgroup per
 // row - at 16 decode rows the row-per-workgroup kernels leave 240 CUs idle.
+struct PrefetchRange {
+  const void* p = nullptr;
+  int64_t unit16 = 0, take16 = 0, chunks = 0;
+};
+struct PrefetchArgs {
+  PrefetchRange r[2];
+  int wgs = 0;  // spare workgroups of 256 threads appended to the launch (0 = none)
+};
+
 void launch_quantize_cols(const float* x, const float* amax, int64_t rows, int64_t depth,
-                          int quant_mode, int8_t* q, float* scales, hipStream_t stream);
+                          int quant_mode, int8_t* q, float* scales, hipStream_t stream,
+                          const PrefetchArgs* pf = nullptr);
 void launch_row_amax(const float* x, int64_t rows, int64_t depth, float* amax, hipStream_t stream);
 void launch_quantize_with_amax(const float* x, const float* amax, int64_t rows, int64_t depth,
                                int quant_mode, int8_t* q, float* scales, hipStream_t stream);
@@ -39,7 +49,8 @@ void launch_reduce_ranks(const void* const* src, int world, int64_t n, bool is_i
 // beta == nullptr -> RMSNorm. y and/or q may be nullptr (q==nullptr: plain norm).
 void launch_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
                  int64_t depth, float eps, bool rms_use_residual, int quant_mode,
-                 float* y, int8_t* q, float* scales, hipStream_t stream);
+                 float* y, int8_t* q, float* scales, hipStream_t stream,
+                 const PrefetchArgs* pf = nullptr);
 
 void launch_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth,
                     bool log, float* y, hipStream_t stream);
@@ -151,6 +162,13 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
 bool gemm_s8_stream_pack_applicable(int64_t n, int64_t k, bool dual);
 void launch_pack_stream_weight(const int8_t* src, int64_t n, int64_t k, bool dual, int8_t* dst,
                                hipStream_t stream);
+// Warm the memory-side cache with (a leading fraction of every wave's stream of) a packed weight:
+// up to two ranges carried by spare workgroups of a row-wide launch (launch_norm,
+// launch_quantize_cols) while HBM is otherwise idle. Piece c of a range is the (c % take16)-th
+// 16-byte piece of unit c / take16; units are unit16 pieces apart.
+// Fills one range for `bytes` of the fragment-major weight [n, k] (false: no streaming form).
+bool weight_prefetch_range(const int8_t* packed, int64_t n, int64_t k, bool dual, int64_t bytes,
+                           PrefetchRange* out);
 
 // ---- fp32 GEMM (gemm_f32.hip) --------------------------------------------------------
 

@@ -97,7 +97,11 @@ __global__ void quantize_with_amax_kernel(const float* __restrict__ x,
 
 __global__ void quantize_cols_kernel(const float* __restrict__ x, const float* __restrict__ amax,
                                      int64_t depth, int quant_mode, int8_t* __restrict__ q,
-                                     float* __restrict__ scales) {
+                                     float* __restrict__ scales, int rows, PrefetchArgs pf) {
+  if (static_cast<int>(blockIdx.y) >= rows) {  // spare workgroups: warm the next GEMM's weight
+    weight_prefetch_wg(pf, (static_cast<int>(blockIdx.y) - rows) * gridDim.x + blockIdx.x, pf.wgs);
+    return;
+  }
   const int64_t row = blockIdx.y;
   const float a = amax[row];
   const float scale = (a != 0.f) ? 127.f / a : 1.f;
@@ -114,16 +118,24 @@ __global__ void quantize_cols_kernel(const float* __restrict__ x, const float* _
 }
 
 void launch_quantize_cols(const float* x, const float* amax, int64_t rows, int64_t depth,
-                          int quant_mode, int8_t* q, float* scales, hipStream_t stream) {
+                          int quant_mode, int8_t* q, float* scales, hipStream_t stream,
+                          const PrefetchArgs* pf_in) {
   if (rows == 0 || depth == 0) return;
   if (depth % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(q) & 3)) {
     launch_quantize_with_amax(x, amax, rows, depth, quant_mode, q, scales, stream);
     return;
   }
   const int threads = 256;
-  const dim3 grid(static_cast<unsigned>((depth / 4 + threads - 1) / threads), static_cast<unsigned>(rows));
+  dim3 grid(static_cast<unsigned>((depth / 4 + threads - 1) / threads), static_cast<unsigned>(rows));
+  PrefetchArgs pf;
+  if (pf_in != nullptr && pf_in->wgs > 0) {
+    pf = *pf_in;
+    const unsigned extra_y = (static_cast<unsigned>(pf.wgs) + grid.x - 1) / grid.x;
+    pf.wgs = static_cast<int>(extra_y * grid.x);  // whole grid rows of spare workgroups
+    grid.y += extra_y;
+  }
   hipLaunchKernelGGL(quantize_cols_kernel, grid, dim3(threads), 0, stream, x, amax, depth, quant_mode,
-                     q, scales);
+                     q, scales, static_cast<int>(rows), pf);
 }
 
 void launch_row_amax(const float* x, int64_t rows, int64_t depth, float* amax,
@@ -324,9 +336,13 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
                                 const float* __restrict__ beta, int64_t depth, float eps,
                                 bool rms_use_residual, int quant_mode, int pad,
                                 float* __restrict__ y, int8_t* __restrict__ q,
-                                float* __restrict__ scales) {
+                                float* __restrict__ scales, int rows, PrefetchArgs pf) {
   extern __shared__ __attribute__((aligned(16))) float chain_buf[];
   __shared__ float scratch[32];
+  if (static_cast<int>(blockIdx.x) >= rows) {  // spare workgroups: warm the next GEMM's weight
+    weight_prefetch_wg(pf, static_cast<int>(blockIdx.x) - rows, pf.wgs);
+    return;
+  }
   const int64_t row = blockIdx.x;
   const int n4 = static_cast<int>(depth / 4);
   const int vsize = static_cast<int>(depth - depth % 8);
@@ -399,7 +415,7 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
 
 void launch_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
                  int64_t depth, float eps, bool rms_use_residual, int quant_mode,
-                 float* y, int8_t* q, float* scales, hipStream_t stream) {
+                 float* y, int8_t* q, float* scales, hipStream_t stream, const PrefetchArgs* pf_in) {
   if (rows == 0 || depth == 0) return;
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) |
                          reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(y) |
@@ -408,11 +424,14 @@ void launch_norm(const float* x, const float* gamma, const float* beta, int64_t 
     const int n4 = static_cast<int>(depth / 4);
     const int threads = depth <= 1024 ? 64 : 256;
     const int ch = (n4 + threads - 1) / threads;  // 1..4
+    PrefetchArgs pf;
+    if (pf_in != nullptr && threads == 256) pf = *pf_in;  // spare workgroups are 256 threads wide
     const int pad = norm_chain_pad(depth);
     const size_t lds = (static_cast<size_t>(8) * pad + 8) * sizeof(float);
 #define CT2X_NORMV(CH)                                                                          \
-  hipLaunchKernelGGL(norm_vec_kernel<CH>, dim3(rows), dim3(threads), lds, stream, x, gamma, beta, \
-                     depth, eps, rms_use_residual, quant_mode, pad, y, q, scales)
+  hipLaunchKernelGGL(norm_vec_kernel<CH>, dim3(rows + pf.wgs), dim3(threads), lds, stream, x, gamma,  \
+                     beta, depth, eps, rms_use_residual, quant_mode, pad, y, q, scales,               \
+                     static_cast<int>(rows), pf)
     if (ch <= 1) CT2X_NORMV(1);
     else if (ch == 2) CT2X_NORMV(2);
     else CT2X_NORMV(4);
