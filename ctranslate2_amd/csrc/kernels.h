@@ -170,6 +170,22 @@ void launch_pack_stream_weight(const int8_t* src, int64_t n, int64_t k, bool dua
 bool weight_prefetch_range(const int8_t* packed, int64_t n, int64_t k, bool dual, int64_t bytes,
                            PrefetchRange* out);
 
+// ---- AWQ int4 weights (awq.hip; ops::DequantizeAwq / GemmAwq / GemvAwq, src/ops/awq/*) ----------
+// GEMM layout: qweight [in_c, out_c / 8], scales [in_c / G, out_c] f16, qzeros [in_c / G, out_c / 8].
+void launch_awq_dequantize_gemm(const int32_t* qweight, const void* scales_f16, const int32_t* qzeros,
+                                int64_t in_c, int64_t out_c, int64_t group, void* out_f16,
+                                hipStream_t stream);
+void launch_awq_gemm(const void* x_f16, const int32_t* qweight, const void* scales_f16,
+                     const int32_t* qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
+                     void* y_f16, float* y_f32, hipStream_t stream);
+// GEMV layout: qweight [out_c, in_c / 8], scales [out_c, sf_w] f16, qzeros [out_c, zeros_w].
+void launch_awq_dequantize_gemv(const int32_t* qweight, const void* scales_f16, const int32_t* qzeros,
+                                int64_t out_c, int64_t in_c, int64_t group, int64_t zeros_w,
+                                int64_t sf_w, void* out_f16, hipStream_t stream);
+void launch_awq_gemv(const void* x_f16, const int32_t* qweight, const void* scales_f16,
+                     const int32_t* qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
+                     int64_t zeros_w, int64_t sf_w, void* y_f16, float* y_f32, hipStream_t stream);
+
 // ---- fp32 GEMM (gemm_f32.hip) --------------------------------------------------------
 
 // C[b] = alpha * A[b] . op(B[b]) (+ bias[j]) -> act -> (+ residual). batch==1 for plain GEMM.

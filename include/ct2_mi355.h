@@ -202,6 +202,37 @@ int ct2x_gemm_s8_dequant_quantizing(const float* d_x, const float* d_row_amax, i
                                     const float* d_residual, int64_t m, int64_t n, int64_t k,
                                     int activation, float* d_y, void* stream);
 
+/* ---- AWQ int4 weights. The reference implements these for CUDA only and refuses
+ * them on ROCm (src/layers/common.cc:402-404, "AWQ unsupported with ROCm"); parity is unpinned
+ * (no CPU implementation, no vectors): oracle/awq_oracle.py restates formats and arithmetic.
+ * float16 activations / scales / outputs are passed as raw 2-byte data. ---- */
+
+/* ops::DequantizeAwq::dequantize<Device::CUDA,int,float16_t> (src/ops/awq/dequantize_gpu.cu:8-98):
+ * GEMM layout - d_qweight [in_c, out_c / 8] int32 (nibble i of a word = output channel
+ * {0,2,4,6,1,3,5,7}[i] of its group of eight), d_scales [in_c / group, out_c] f16, d_qzeros
+ * [in_c / group, out_c / 8] - to d_out [in_c, out_c] f16, w = (q - z) * s rounded once. */
+int ct2x_awq_dequantize(const int32_t* d_qweight, const void* d_scales_f16, const int32_t* d_qzeros,
+                        int64_t in_c, int64_t out_c, int64_t group, void* d_out_f16, void* stream);
+
+/* ops::GemmAwq::compute<Device::CUDA,float16_t,int> + the ops::Sum over its split-K slices
+ * (src/ops/awq/gemm.cc:9-31, gemm_gpu.cu:470-530): y[m, out_c] = x[m, in_c] . dequantize(w), one
+ * fused launch (fp32 accumulation, one rounding of the result). d_y_f16 and / or d_y_f32 receive
+ * the result (either may be NULL). in_c % 32 == 0, out_c % 8 == 0, group % 8 == 0. */
+int ct2x_awq_gemm(const void* d_x_f16, const int32_t* d_qweight, const void* d_scales_f16,
+                  const int32_t* d_qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
+                  void* d_y_f16, float* d_y_f32, void* stream);
+
+/* ops::GemvAwq::compute_gemv / compute_gemv2 (src/ops/awq/gemv_gpu.cu:236-547): GEMV layout -
+ * d_qweight [out_c, in_c / 8] (nibble i of word w = input channel 8 w + i), d_scales [out_c, sf_w]
+ * f16, d_qzeros [out_c, zeros_w] (group g = nibble g % 8 of word g / 8). in_c % 128 == 0,
+ * group % 32 == 0. The dequantised weight alone: ct2x_awq_dequantize_gemv -> [out_c, in_c] f16. */
+int ct2x_awq_gemv(const void* d_x_f16, const int32_t* d_qweight, const void* d_scales_f16,
+                  const int32_t* d_qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
+                  int64_t zeros_w, int64_t sf_w, void* d_y_f16, float* d_y_f32, void* stream);
+int ct2x_awq_dequantize_gemv(const int32_t* d_qweight, const void* d_scales_f16,
+                             const int32_t* d_qzeros, int64_t out_c, int64_t in_c, int64_t group,
+                             int64_t zeros_w, int64_t sf_w, void* d_out_f16, void* stream);
+
 /* ops::Dequantize::dequantize<Device::CUDA,int8_t,T> (src/ops/dequantize_gpu.cu:17-28):
  * y[r,:] = x[r,:] / scale[r]  (int8 embedding rows, src/layers/common.cc:64-81). */
 int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,

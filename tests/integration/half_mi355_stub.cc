@@ -420,34 +420,69 @@ namespace ctranslate2 {
     template<>                                                                                      \
     void GumbelMax::add_gumbel_noise<Device::CUDA, T>(const StorageView&, StorageView&) const {     \
       not_provided16("ops::GumbelMax");                                                             \
-    }                                                                                               \
-    template<>                                                                                      \
-    void DequantizeAwq::dequantize<Device::CUDA, int, T>(const StorageView&, const StorageView&,    \
-                                                         const StorageView&, StorageView&) const {  \
-      not_provided16("AWQ");                                                                        \
-    }                                                                                               \
-    template<>                                                                                      \
-    void GemmAwq::compute<Device::CUDA, T, int>(const StorageView&, const StorageView&,             \
-                                                const StorageView&, const StorageView&,             \
-                                                StorageView&) const {                               \
-      not_provided16("AWQ");                                                                        \
-    }                                                                                               \
-    template<>                                                                                      \
-    void GemvAwq::compute_gemv<Device::CUDA, T, int>(const StorageView&, const StorageView&,        \
-                                                     const StorageView&, const StorageView&,        \
-                                                     StorageView&) const {                          \
-      not_provided16("AWQ");                                                                        \
-    }                                                                                               \
-    template<>                                                                                      \
-    void GemvAwq::compute_gemv2<Device::CUDA, T, int>(const StorageView&, const StorageView&,       \
-                                                      const StorageView&, const StorageView&,       \
-                                                      StorageView&) const {                         \
-      not_provided16("AWQ");                                                                        \
     }
 
     CT2X_HALF_OPS(float16_t)
     CT2X_HALF_OPS(bfloat16_t)
 #undef CT2X_HALF_OPS
+
+    // ---- AWQ int4 (include/ctranslate2/ops/awq/*.h; CUDA: src/ops/awq/dequantize_gpu.cu:66-98,
+    // gemm_gpu.cu:470-530, gemv_gpu.cu:428-530). float16 only, as in the reference. ----------------
+    template<>
+    void DequantizeAwq::dequantize<Device::CUDA, int, float16_t>(const StorageView& input,
+                                                                 const StorageView& scale,
+                                                                 const StorageView& zero,
+                                                                 StorageView& output) const {
+      if (input.rank() != 2)
+        throw std::invalid_argument("DequantizeAwq on this backend takes one [in_c, out_c / 8] weight");
+      const dim_t in_c = input.dim(0), out_c = input.dim(1) * 8;
+      const dim_t group = in_c / scale.dim(0);
+      output.resize({in_c, out_c});
+      check16(ct2x_awq_dequantize(input.data<int32_t>(), scale.data<float16_t>(), zero.data<int32_t>(),
+                                  in_c, out_c, group, output.data<float16_t>(), stream16()));
+    }
+    // The reference returns eight split-K slices that its front-end adds up with ops::Sum(0)
+    // (src/ops/awq/gemm.cc:24-27): this backend accumulates over the whole K in one launch and
+    // returns ONE slice, so the front-end's Sum is the identity.
+    template<>
+    void GemmAwq::compute<Device::CUDA, float16_t, int>(const StorageView& a, const StorageView& b,
+                                                        const StorageView& scale,
+                                                        const StorageView& zero,
+                                                        StorageView& c) const {
+      const dim_t in_c = a.dim(-1), m = a.size() / in_c, out_c = b.dim(1) * 8;
+      const dim_t group = in_c / scale.dim(0);
+      if (a.rank() == 2) c.resize({1, m, out_c});
+      else c.resize({1, a.dim(0), a.dim(1), out_c});
+      check16(ct2x_awq_gemm(a.data<float16_t>(), b.data<int32_t>(), scale.data<float16_t>(),
+                            zero.data<int32_t>(), m, in_c, out_c, group, c.data<float16_t>(), nullptr,
+                            stream16()));
+    }
+    template<>
+    void GemvAwq::compute_gemv<Device::CUDA, float16_t, int>(const StorageView& a, const StorageView& b,
+                                                             const StorageView& scale,
+                                                             const StorageView& zero,
+                                                             StorageView& c) const {
+      const dim_t in_c = a.dim(-1), m = a.size() / in_c, out_c = b.dim(0);
+      const dim_t group = in_c / scale.dim(-1);  // gemv_gpu.cu:447
+      if (a.rank() == 2) c.resize({m, out_c});
+      else c.resize({a.dim(0), a.dim(1), out_c});
+      check16(ct2x_awq_gemv(a.data<float16_t>(), b.data<int32_t>(), scale.data<float16_t>(),
+                            zero.data<int32_t>(), m, in_c, out_c, group, zero.dim(-1), scale.dim(-1),
+                            c.data<float16_t>(), nullptr, stream16()));
+    }
+    template<>
+    void GemvAwq::compute_gemv2<Device::CUDA, float16_t, int>(const StorageView& a, const StorageView& b,
+                                                              const StorageView& scale,
+                                                              const StorageView& zero,
+                                                              StorageView& c) const {
+      const dim_t in_c = a.dim(-1), m = a.size() / in_c, out_c = b.dim(0);
+      const dim_t group = in_c / scale.dim(-1);  // gemv_gpu.cu:493
+      if (a.rank() == 2) c.resize({1, m, out_c});  // one slice: the front-end's Sum(0) is the identity
+      else c.resize({1, a.dim(0), a.dim(1), out_c});
+      check16(ct2x_awq_gemv(a.data<float16_t>(), b.data<int32_t>(), scale.data<float16_t>(),
+                            zero.data<int32_t>(), m, in_c, out_c, group, zero.dim(-1), scale.dim(-1),
+                            c.data<float16_t>(), nullptr, stream16()));
+    }
 
   }
 

@@ -1,0 +1,117 @@
+"""AWQ int4 ops (ops::DequantizeAwq / GemmAwq / GemvAwq, src/ops/awq/*) against the numpy
+restatement in oracle/awq_oracle.py. PARITY UNPINNED: the reference implements these for CUDA only
+(no CPU path, no vectors), so the checks are (a) the dequantised weight bit for bit against the
+restated arithmetic - integer subtraction, one float16 rounding of the product - and (b) the fused
+products against the float64 product of the float16-rounded operands, within the error of an fp32
+accumulation rounded to float16 once."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import awq_oracle as A  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _i64(v):
+    return C.c_int64(int(v))
+
+
+def _case_gemm(rng, in_c, out_c, group):
+    q = rng.integers(0, 16, (in_c, out_c))
+    z = rng.integers(0, 16, (in_c // group, out_c))
+    s = (rng.random((in_c // group, out_c)) * 0.02 + 0.001).astype(np.float16)
+    qw, qz = A.pack_gemm(q, z, group)
+    return qw, s, qz
+
+
+@pytest.mark.parametrize("in_c,out_c,group", [(256, 128, 128), (4096, 4096, 128), (512, 1032, 64),
+                                              (128, 8, 32)])
+def test_awq_dequantize_gemm_layout(gpu, in_c, out_c, group):
+    import torch
+    from ctranslate2_amd import _lib
+    rng = np.random.default_rng(in_c + out_c)
+    qw, s, qz = _case_gemm(rng, in_c, out_c, group)
+    out = torch.empty((in_c, out_c), dtype=torch.float16, device="cuda")
+    dq, ds, dz = _dev(qw), _dev(s), _dev(qz)
+    _lib.check(gpu.ct2x_awq_dequantize(_ptr(dq), _ptr(ds), _ptr(dz), _i64(in_c), _i64(out_c),
+                                       _i64(group), _ptr(out), None))
+    assert np.array_equal(out.cpu().numpy(), A.dequantize_gemm(qw, s, qz))
+
+
+@pytest.mark.parametrize("m,in_c,out_c,group", [(16, 4096, 4096, 128), (1, 4096, 11008, 128),
+                                                (5, 512, 1032, 64), (40, 1024, 256, 128),
+                                                (16, 128, 8, 32)])
+def test_awq_gemm_fused(gpu, m, in_c, out_c, group):
+    import torch
+    from ctranslate2_amd import _lib
+    rng = np.random.default_rng(m + in_c + out_c)
+    qw, s, qz = _case_gemm(rng, in_c, out_c, group)
+    x = (rng.standard_normal((m, in_c)) * 0.5).astype(np.float16)
+    y16 = torch.empty((m, out_c), dtype=torch.float16, device="cuda")
+    y32 = torch.empty((m, out_c), dtype=torch.float32, device="cuda")
+    dx, dq, ds, dz = _dev(x), _dev(qw), _dev(s), _dev(qz)
+    _lib.check(gpu.ct2x_awq_gemm(_ptr(dx), _ptr(dq), _ptr(ds), _ptr(dz), _i64(m), _i64(in_c),
+                                 _i64(out_c), _i64(group), _ptr(y16), _ptr(y32), None))
+    ref = A.gemm(x, qw, s, qz)
+    scale = np.abs(ref).max()
+    # fp32 accumulation over in_c products: relative error ~ in_c * 2^-24 of the row's magnitude
+    assert np.abs(y32.cpu().numpy() - ref).max() <= 2e-5 * scale * max(1, in_c // 1024)
+    assert np.array_equal(y16.cpu().numpy(), y32.cpu().numpy().astype(np.float16))
+
+
+@pytest.mark.parametrize("m,in_c,out_c,group", [(1, 4096, 4096, 128), (8, 4096, 4096, 64),
+                                                (16, 1024, 11008, 128), (33, 256, 48, 128),
+                                                (3, 128, 16, 64)])
+def test_awq_gemv_layout(gpu, m, in_c, out_c, group):
+    import torch
+    from ctranslate2_amd import _lib
+    rng = np.random.default_rng(m + in_c + out_c + group)
+    q = rng.integers(0, 16, (out_c, in_c))
+    z = rng.integers(0, 16, (out_c, in_c // group))
+    s = (rng.random((out_c, in_c // group)) * 0.02 + 0.001).astype(np.float16)
+    qw, qz, sc = A.pack_gemv(q, z, s, group)
+    zeros_w, sf_w = A.gemv_widths(in_c, group)
+    assert qz.shape[1] == zeros_w and sc.shape[1] == sf_w
+    dq, ds, dz = _dev(qw), _dev(sc), _dev(qz)
+    wd = torch.empty((out_c, in_c), dtype=torch.float16, device="cuda")
+    _lib.check(gpu.ct2x_awq_dequantize_gemv(_ptr(dq), _ptr(ds), _ptr(dz), _i64(out_c), _i64(in_c),
+                                            _i64(group), _i64(zeros_w), _i64(sf_w), _ptr(wd), None))
+    assert np.array_equal(wd.cpu().numpy(), A.dequantize_gemv(qw, sc, qz, group))
+    x = (rng.standard_normal((m, in_c)) * 0.5).astype(np.float16)
+    y32 = torch.empty((m, out_c), dtype=torch.float32, device="cuda")
+    y16 = torch.empty((m, out_c), dtype=torch.float16, device="cuda")
+    dx = _dev(x)
+    _lib.check(gpu.ct2x_awq_gemv(_ptr(dx), _ptr(dq), _ptr(ds), _ptr(dz), _i64(m), _i64(in_c),
+                                 _i64(out_c), _i64(group), _i64(zeros_w), _i64(sf_w), _ptr(y16),
+                                 _ptr(y32), None))
+    ref = A.gemv(x, qw, sc, qz, group)
+    scale = np.abs(ref).max()
+    assert np.abs(y32.cpu().numpy() - ref).max() <= 2e-5 * scale * max(1, in_c // 1024)
+    assert np.array_equal(y16.cpu().numpy(), y32.cpu().numpy().astype(np.float16))
+
+
+def test_awq_envelope_is_explicit(gpu):
+    """Shapes outside the fused kernels' envelope are refused, not mis-computed."""
+    import torch
+    from ctranslate2_amd import _lib
+    buf = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError):
+        _lib.check(gpu.ct2x_awq_gemm(_ptr(buf), _ptr(buf), _ptr(buf), _ptr(buf), _i64(4), _i64(48),
+                                     _i64(64), _i64(16), _ptr(buf), None, None))
+    with pytest.raises(RuntimeError):
+        _lib.check(gpu.ct2x_awq_gemv(_ptr(buf), _ptr(buf), _ptr(buf), _ptr(buf), _i64(4), _i64(192),
+                                     _i64(64), _i64(64), _i64(1), _i64(8), _ptr(buf), None, None))

@@ -1,0 +1,50 @@
+"""oracle/awq_oracle.py is the CPU restatement of the reference's AWQ int4 formats (parity
+unpinned: the reference has no CPU implementation and no vectors). What CAN be pinned on the CPU:
+pack -> dequantise round trips of both layouts, the nibble order against the unpack sequence of the
+reference's dequantize_s4_to_fp16x2 (src/ops/awq/dequantize.cuh:16-76, executed here on integers),
+and the padded widths of the GEMV layout against the formulas in gemv_gpu.cu."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import awq_oracle as A  # noqa: E402
+
+
+def _reference_unpack(word):
+    """dequantize_s4_to_fp16x2 on one word, with the fp16 magic-number arithmetic replaced by its
+    exact integer meaning: h[0] = nibbles (0, 4), h[1] = (1, 5), h[2] = (2, 6), h[3] = (3, 7); the
+    eight halves it returns, in memory order, are the eight output channels of the group."""
+    n = [(int(word) >> (4 * i)) & 15 for i in range(8)]
+    return [n[0], n[4], n[1], n[5], n[2], n[6], n[3], n[7]]
+
+
+def test_gemm_layout_nibble_order_follows_the_cuda_unpack():
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 16, (4, 16))
+    qw, _ = A.pack_gemm(q, np.zeros((1, 16), np.int64), 4)
+    for r in range(4):
+        for cw in range(2):
+            assert _reference_unpack(qw.view(np.uint32)[r, cw]) == q[r, cw * 8:(cw + 1) * 8].tolist()
+
+
+def test_round_trips_and_widths():
+    rng = np.random.default_rng(2)
+    in_c, out_c, g = 256, 64, 64
+    q = rng.integers(0, 16, (in_c, out_c))
+    z = rng.integers(0, 16, (in_c // g, out_c))
+    s = (rng.random((in_c // g, out_c)) * 0.02 + 0.001).astype(np.float16)
+    qw, qz = A.pack_gemm(q, z, g)
+    want = ((q - np.repeat(z, g, 0)).astype(np.float32) * np.repeat(s.astype(np.float32), g, 0)).astype(np.float16)
+    assert np.array_equal(A.dequantize_gemm(qw, s, qz), want)
+    qv = rng.integers(0, 16, (out_c, in_c))
+    zv = rng.integers(0, 16, (out_c, in_c // g))
+    sv = (rng.random((out_c, in_c // g)) * 0.02 + 0.001).astype(np.float16)
+    qw2, qz2, sc2 = A.pack_gemv(qv, zv, sv, g)
+    want2 = ((qv - np.repeat(zv, g, 1)).astype(np.float32) * np.repeat(sv.astype(np.float32), g, 1)).astype(np.float16)
+    assert np.array_equal(A.dequantize_gemv(qw2, sc2, qz2, g), want2)
+    # gemv_gpu.cu:296-302 (g64) and :365-369 (g128): zeros_w / sf_w for IC = 4096
+    assert A.gemv_widths(4096, 64) == (8, 64) and A.gemv_widths(4096, 128) == (4, 32)
+    # the reference recovers the group size as IC / scale.dim(-1) (gemv_gpu.cu:447): consistent
+    assert 4096 // A.gemv_widths(4096, 64)[1] == 64 and 4096 // A.gemv_widths(4096, 128)[1] == 128
