@@ -208,7 +208,13 @@ __global__ __launch_bounds__(256) void awq_gemm_kernel(const _Float16* __restric
                                                        const unsigned* __restrict__ qz, int M,
                                                        int in_c, int qout, int group,
                                                        _Float16* __restrict__ y16,
-                                                       float* __restrict__ y32) {
+                                                       float* __restrict__ y32,
+                                                       float* __restrict__ slices) {
+  // gridDim.z > 1: split K - this workgroup covers steps [z, z + 1) * steps / gridDim.z and writes
+  // its fp32 tile to slices[z][m][out_c]; awq_sum_slices_kernel adds the slices in z order (the
+  // reference does the same with eight slices and ops::Sum, src/ops/awq/gemm.cc:24-27 - here the
+  // split only exists to put >= 256 workgroups on the chip: a 128-column tile per workgroup leaves
+  // a 4096-wide projection with 32 of them).
   __shared__ float partial[4][8][64][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kb = lane >> 4;
@@ -217,7 +223,10 @@ __global__ __launch_bounds__(256) void awq_gemm_kernel(const _Float16* __restric
   const bool cw_ok = cw < qout;
   const int out_c = qout * 8;
   const int steps = in_c >> 5;  // in_c % 32 == 0
-  const int s_begin = (steps * wave) / 4, s_end = (steps * (wave + 1)) / 4;
+  const int z_begin = static_cast<int>(static_cast<int64_t>(steps) * blockIdx.z / gridDim.z);
+  const int z_end = static_cast<int>(static_cast<int64_t>(steps) * (blockIdx.z + 1) / gridDim.z);
+  const int zsteps = z_end - z_begin;
+  const int s_begin = z_begin + (zsteps * wave) / 4, s_end = z_begin + (zsteps * (wave + 1)) / 4;
   const bool row_ok = m0 + r < M;
   const _Float16* xr = x + static_cast<int64_t>(row_ok ? m0 + r : 0) * in_c;
   const v2h sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
@@ -280,10 +289,24 @@ __global__ __launch_bounds__(256) void awq_gemm_kernel(const _Float16* __restric
     const int64_t col = (static_cast<int64_t>(blockIdx.x) * 16 + ct) * 8 + c;
     if (m0 + rt < M && col < out_c) {
       const int64_t idx = static_cast<int64_t>(m0 + rt) * out_c + col;
-      if (y16) y16[idx] = static_cast<_Float16>(v);
-      if (y32) y32[idx] = v;
+      if (slices) {
+        slices[static_cast<int64_t>(blockIdx.z) * M * out_c + idx] = v;
+      } else {
+        if (y16) y16[idx] = static_cast<_Float16>(v);
+        if (y32) y32[idx] = v;
+      }
     }
   }
+}
+
+__global__ void awq_sum_slices_kernel(const float* __restrict__ slices, int splits, int64_t n,
+                                      _Float16* __restrict__ y16, float* __restrict__ y32) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  float v = 0.f;
+  for (int z = 0; z < splits; ++z) v += slices[z * n + i];  // fixed order: deterministic
+  if (y16) y16[i] = static_cast<_Float16>(v);
+  if (y32) y32[i] = v;
 }
 
 }  // namespace
@@ -323,13 +346,31 @@ void launch_awq_gemm(const void* x_f16, const int32_t* qweight, const void* scal
       (reinterpret_cast<uintptr_t>(x_f16) & 15) != 0 || (reinterpret_cast<uintptr_t>(scales_f16) & 15) != 0)
     throw Error("awq gemm: needs in_c % 32 == 0, out_c % 8 == 0, group % 8 == 0 and 16-byte aligned x / scales");
   const int64_t qout = out_c / 8;
+  const int64_t tiles = ((qout + 15) / 16) * ((m + 15) / 16);
+  // K slices so that ~256+ workgroups stream the weight; each slice keeps >= 4 steps per wave
+  int64_t splits = 1;
+  while (tiles * splits < 256 && (in_c / 32) / (splits * 2) >= 16 && splits < 16) splits *= 2;
+  float* slices = nullptr;
+  if (splits > 1)
+    slices = static_cast<float*>(device_malloc(static_cast<size_t>(splits) * m * out_c * sizeof(float)));
   hipLaunchKernelGGL(awq_gemm_kernel, dim3(static_cast<unsigned>((qout + 15) / 16),
-                                           static_cast<unsigned>((m + 15) / 16)),
+                                           static_cast<unsigned>((m + 15) / 16),
+                                           static_cast<unsigned>(splits)),
                      dim3(256), 0, stream, static_cast<const _Float16*>(x_f16),
                      reinterpret_cast<const unsigned*>(qweight), static_cast<const _Float16*>(scales_f16),
                      reinterpret_cast<const unsigned*>(qzeros), static_cast<int>(m),
                      static_cast<int>(in_c), static_cast<int>(qout), static_cast<int>(group),
-                     static_cast<_Float16*>(y_f16), y_f32);
+                     static_cast<_Float16*>(y_f16), y_f32, slices);
+  if (splits > 1) {
+    const int64_t n = m * out_c;
+    hipLaunchKernelGGL(awq_sum_slices_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256),
+                       0, stream, slices, static_cast<int>(splits), n, static_cast<_Float16*>(y_f16),
+                       y_f32);
+    // stream-ordered allocator: the block is reused only after the work queued on the calling
+    // thread's active stream; a launch on some other stream has to finish first
+    if (stream != active_stream()) CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+    device_free(slices);
+  }
 }
 
 void launch_awq_gemv(const void* x_f16, const int32_t* qweight, const void* scales_f16,
