@@ -232,9 +232,41 @@ DenseW Engine::load_dense(const std::string& scope, bool required, Shard shard,
     if (required) throw std::out_of_range("variable " + scope + "/weight not found");
     return d;
   }
-  if (model_->has(scope + "/weight_zero"))
-    throw std::invalid_argument("AWQ weights (" + scope + ") are not supported by this backend");
   if (w->shape.size() != 2) throw std::runtime_error(scope + "/weight is not a matrix");
+  if (const Variable* zero = model_->find(scope + "/weight_zero")) {
+    // AWQ int4 (layers::Dense AWQ branch, src/layers/common.cc:402-438; formats: awq.hip). The
+    // reference forces FLOAT16 for such models (src/models/model.cc:754-757): here the fp32
+    // activation is rounded to float16 as it enters the GEMM, everything else stays fp32.
+    const int method = static_cast<int>(model_->config_number("quantization_type", 0));
+    const Variable* scale = model_->find(scope + "/weight_scale");
+    if ((method != 1 && method != 2) || !scale || w->dtype != kI32 || zero->dtype != kI32 ||
+        scale->dtype != kF16 || scale->shape.size() != 2 || zero->shape.size() != 2)
+      throw std::invalid_argument(scope + ": malformed AWQ weight (needs quantization_type 1 / 2, "
+                                  "int32 weight / zeros, float16 scales)");
+    if (tp_) throw std::invalid_argument(scope + ": AWQ weights are not supported under tensor parallelism");
+    d.present = true;
+    d.awq = method;
+    if (method == 1) {  // GEMM layout: weight [in_c, out_c / 8]
+      d.k = w->shape[0];
+      d.n = w->shape[1] * 8;
+      d.aq_group = d.k / scale->shape[0];
+    } else {            // GEMV layout: weight [out_c, in_c / 8]
+      d.n = w->shape[0];
+      d.k = w->shape[1] * 8;
+      d.aq_sw = scale->shape[1];
+      d.aq_zw = zero->shape[1];
+      // the reference recovers the group size as in_c / sf_w (src/ops/awq/gemv_gpu.cu:447), which
+      // only holds when in_c / G fills the padded width: config.json's quantization_group_size wins
+      d.aq_group = static_cast<int64_t>(
+          model_->config_number("quantization_group_size", static_cast<double>(d.k / d.aq_sw)));
+    }
+    d.aq_w = static_cast<const int32_t*>(upload(w->data.data(), w->data.size()));
+    d.aq_s = upload(scale->data.data(), scale->data.size());
+    d.aq_z = static_cast<const int32_t*>(upload(zero->data.data(), zero->data.size()));
+    if (const Variable* b = model_->find(scope + "/bias")) d.bias = upload_floats(b->to_float());
+    has_awq_ = true;
+    return d;
+  }
   d.present = true;
   d.n = w->shape[0];
   d.k = w->shape[1];
@@ -1014,8 +1046,53 @@ bool Engine::dense_out_next_norm(const DenseW& w, const QuantIn& cq, int64_t row
   return true;
 }
 
+// layers::Dense, AWQ branch (src/layers/common.cc:402-438: GemmAwq / GemvAwq + bias, activation,
+// residual; the reference's other arm - dequantise the whole weight, then a float16 GEMM, when
+// m >= 1024 - computes the same product). x is rounded to float16 here.
+void Engine::dense_awq(const DenseW& w, const float* x, int64_t m, int act, const float* residual,
+                       float* y, DecodeState* ws) {
+  CT2X_CHECK(ws != nullptr && ws->hbuf != nullptr, "AWQ Dense without its float16 scratch buffer");
+  begin_kernel("convert_f16", double(m) * w.k * 6, 0, m, 0, w.k);
+  launch_convert(x, kF32, ws->hbuf, kF16, m * w.k, cur_stream());  // DType values = ct2x_dtype
+  end_kernel();
+  const double bytes = double(w.n) * w.k / 2 + 2.0 * m * w.k + 4.0 * m * w.n;
+  begin_kernel(w.awq == 1 ? "awq_gemm" : "awq_gemv", bytes, 2.0 * m * w.n * w.k, m, w.n, w.k);
+  if (w.awq == 1)
+    launch_awq_gemm(ws->hbuf, w.aq_w, w.aq_s, w.aq_z, m, w.k, w.n, w.aq_group, nullptr, y, cur_stream());
+  else
+    launch_awq_gemv(ws->hbuf, w.aq_w, w.aq_s, w.aq_z, m, w.k, w.n, w.aq_group, w.aq_zw, w.aq_sw,
+                    nullptr, y, cur_stream());
+  end_kernel();
+  // apply_bias_and_activation (src/ops/gemm.cc:11-25): bias, activation, then the residual
+  if (act >= 0) {
+    if (w.bias) {
+      begin_kernel("bias_residual");
+      launch_bias_residual(y, w.bias, nullptr, m, w.n, y, cur_stream());
+      end_kernel();
+    }
+    begin_kernel("activation");
+    launch_unary(act, y, y, m * w.n, cur_stream());
+    end_kernel();
+    if (residual) {
+      begin_kernel("bias_residual");
+      launch_bias_residual(y, nullptr, residual, m, w.n, y, cur_stream());
+      end_kernel();
+    }
+  } else if (w.bias || residual) {
+    begin_kernel("bias_residual");
+    launch_bias_residual(y, w.bias, residual, m, w.n, y, cur_stream());
+    end_kernel();
+  }
+  if (taps_) tap("d", y, 0, m, w.n);
+}
+
 void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t m, int act,
                    const float* residual, float* y, DecodeState* ws) {
+  if (w.awq) {
+    CT2X_CHECK(x != nullptr, "AWQ Dense takes the fp32 activation");
+    dense_awq(w, x, m, act, residual, y, ws);
+    return;
+  }
   if (w.row_parallel && tp_) {
     // Row-parallel Dense (attention-out / FFN-out; layers::Dense TP arm, src/layers/common.cc:
     // 348-401): this rank holds K/world input columns. int8: global Quantize scale = max over
@@ -1235,6 +1312,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     st->tp_amax = alloc<float>(*st, wrows);
   }
   st->qbuf = alloc<int8_t>(*st, wrows * std::max(d, wffn));
+  if (has_awq_) st->hbuf = alloc<uint16_t>(*st, wrows * std::max(d, wffn));
   st->qscale = alloc<float>(*st, wrows);
   st->logits = alloc<float>(*st, rows * V);
   st->d_ids = alloc<int32_t>(*st, rows);

@@ -58,6 +58,12 @@ struct DenseW {
   const float* bias = nullptr;    // [n] or nullptr
   int64_t n = 0, k = 0;
   bool present = false;
+  // AWQ int4 weight (awq.hip): 1 = GEMM layout [k, n / 8], 2 = GEMV layout [n, k / 8]
+  int awq = 0;
+  const int32_t* aq_w = nullptr;
+  const void* aq_s = nullptr;      // float16 scales
+  const int32_t* aq_z = nullptr;
+  int64_t aq_group = 0, aq_zw = 0, aq_sw = 0;
 };
 
 struct NormW {
@@ -274,6 +280,9 @@ private:
   void dense_qol(const DenseW& w, const float* x, const float* row_amax, int64_t m, int act,
                  const float* residual, float* y);
   void load_weights();
+  bool has_awq_ = false;
+  void dense_awq(const DenseW& w, const float* x, int64_t m, int act, const float* residual, float* y,
+                 DecodeState* ws);
   // weight prefetch by spare workgroups of the row-wide launches of a decode step (engine.cc)
   void prefetch_weight(DecodeState& st, const DenseW& w, int site);
   bool weight_prefetch_ = false;
@@ -386,6 +395,7 @@ struct DecodeState {
   int32_t* tp_acc = nullptr; // tensor parallel: int32 / fp32 partial products [rows, d]
   float* tp_amax = nullptr;  // tensor parallel: per-row absmax [rows]
   int8_t* qbuf = nullptr;    // [rows, max(d, ffn)]
+  uint16_t* hbuf = nullptr;  // [rows, max(d, ffn)] float16 activations (AWQ Dense only)
   float* qscale = nullptr;   // [rows]
   int32_t* d_ids = nullptr;  // [rows] next input ids
   int32_t* d_step = nullptr; // [1]

@@ -76,6 +76,62 @@ def quantize_int8(weight):
     return value, scale
 
 
+# AutoAWQ order_map of the GEMM layout: nibble i of a packed word holds output channel
+# _AWQ_ORDER[i] of its group of eight (python/ctranslate2/converters/transformers.py keeps the
+# checkpoint's qweight / qzeros / scales as they are).
+_AWQ_ORDER = (0, 2, 4, 6, 1, 3, 5, 7)
+
+
+def awq_quantize(weight, group):
+    """weight [out_c, in_c] float -> (q, z, s): 4-bit asymmetric group quantisation along in_c as
+    AutoAWQ's pseudo_quantize_tensor does it (zero point + scale per (output channel, group)):
+    q, z in 0..15 and s float16, with w ~ (q - z) * s."""
+    out_c, in_c = weight.shape
+    w = weight.reshape(out_c, in_c // group, group).astype(np.float32)
+    hi, lo = w.max(axis=2), w.min(axis=2)
+    s = np.maximum((hi - lo) / 15.0, 1e-5).astype(np.float16)
+    sf = s.astype(np.float32)
+    z = np.clip(np.rint(-lo / sf), 0, 15).astype(np.int32)
+    q = np.clip(np.rint(w / sf[:, :, None]) + z[:, :, None], 0, 15).astype(np.int32)
+    return q.reshape(out_c, in_c), z, s
+
+
+def awq_dequantize(q, z, s, group):
+    """(q - z) * s rounded to float16 once: the weight the AWQ kernels multiply with, [out_c, in_c]."""
+    zz = np.repeat(z, group, axis=1)
+    ss = np.repeat(s.astype(np.float32), group, axis=1)
+    return ((q - zz).astype(np.float32) * ss).astype(np.float16)
+
+
+def _pack_nibbles(m, order):
+    r, c = m.shape
+    blocks = m.reshape(r, c // 8, 8).astype(np.uint32)
+    out = np.zeros((r, c // 8), np.uint32)
+    for i in range(8):
+        out |= blocks[:, :, order[i]] << np.uint32(4 * i)
+    return out.view(np.int32)
+
+
+def awq_pack(q, z, s, group, layout):
+    """-> (weight, weight_scale, weight_zero) variables of a Dense in the AWQ GEMM layout (weight
+    [in_c, out_c / 8], scales [in_c / G, out_c], zeros [in_c / G, out_c / 8]) or GEMV layout (weight
+    [out_c, in_c / 8], scales [out_c, sf_w], zeros [out_c, zeros_w], widths padded as
+    src/ops/awq/gemv_gpu.cu:296-302 / 365-369 expect)."""
+    out_c, in_c = q.shape
+    if layout == "gemm":
+        return (_pack_nibbles(q.T.copy(), _AWQ_ORDER), np.ascontiguousarray(s.T),
+                _pack_nibbles(z.T.copy(), _AWQ_ORDER))
+    md = lambda c, d: (c + d - 1) // d
+    groups = in_c // group
+    zeros_w = md(md(groups, 8), 2) * 2 if group == 64 else md(groups, 8)
+    zp = np.zeros((out_c, zeros_w * 8), np.int32)
+    zp[:, :groups] = z
+    sc = np.zeros((out_c, zeros_w * 8), np.float16)
+    sc[:, :groups] = s
+    seq = tuple(range(8))
+    return _pack_nibbles(q, seq), sc, _pack_nibbles(zp, seq)
+
+
 class _Builder:
     def __init__(self, seed, quantization, w_std=0.02, b_std=0.01, direct_int8=False):
         self.rng = np.random.default_rng(seed)
@@ -86,6 +142,10 @@ class _Builder:
         # quantising a float matrix: multi-GB benchmark models in seconds, not minutes.
         self.direct_int8 = direct_int8 and quantization == "int8"
         self.vars = {}
+        # awq = (layout, group, twin): layer linears are stored as AWQ int4 weights; with twin=True the
+        # builder instead stores the float16 weight those int4 values dequantise to (the comparison
+        # model of tests/test_awq_gpu.py)
+        self.awq = None
 
     def attr(self, name, value, dtype):
         self.vars[name] = np.array(value, dtype=dtype)
@@ -99,8 +159,20 @@ class _Builder:
         else:
             self.weight(name, self.rng.normal(0, self.w_std, (n, k)).astype(np.float32))
 
-    def linear(self, scope, n, k, bias=True):
-        self.random_weight(scope + "/weight", n, k)
+    def linear(self, scope, n, k, bias=True, awq_ok=False):
+        if self.awq is not None and awq_ok:
+            layout, group, twin = self.awq
+            w = self.rng.normal(0, self.w_std, (n, k)).astype(np.float32)
+            q, z, s = awq_quantize(w, group)
+            if twin:
+                self.vars[scope + "/weight"] = awq_dequantize(q, z, s, group)
+            else:
+                qw, sc, qz = awq_pack(q, z, s, group, layout)
+                self.vars[scope + "/weight"] = qw
+                self.vars[scope + "/weight_scale"] = sc
+                self.vars[scope + "/weight_zero"] = qz
+        else:
+            self.random_weight(scope + "/weight", n, k)
         if bias:
             self.vars[scope + "/bias"] = self.rng.normal(0, self.b_std, (n,)).astype(np.float32)
 
@@ -202,28 +274,29 @@ def build_transformer(output_dir, num_encoder_layers=6, num_decoder_layers=6, d_
 
 def build_decoder_lm(output_dir, num_layers=32, d_model=4096, ffn_dim=14336, num_heads=32,
                      num_heads_kv=8, vocab_size=128256, seed=0, quantization="int8",
-                     rotary_base=500000.0, w_std=0.02, direct_int8=False):
+                     rotary_base=500000.0, w_std=0.02, direct_int8=False, awq=None):
     """TransformerDecoderModelSpec.from_config(layers, heads, activation=SWISH, ffn_glu=True,
     rms_norm=True, rotary_dim=0, rotary_interleave=False, num_heads_kv=...) -- the Llama-3 shape
     (python/ctranslate2/converters/transformers.py:1736-1752)."""
     os.makedirs(output_dir, exist_ok=True)
     b = _Builder(seed, quantization, w_std=w_std, direct_int8=direct_int8)
+    b.awq = awq  # None, or (layout "gemm" | "gemv", group size, twin)
     d = d_model
     dh = d // num_heads
     b.random_weight("decoder/embeddings/weight", vocab_size, d)
     for l in range(num_layers):
         s = "decoder/layer_%d" % l
         b.layer_norm(s + "/self_attention/layer_norm", d, rms=True)
-        b.linear(s + "/self_attention/linear_0", (num_heads + 2 * num_heads_kv) * dh, d, bias=False)
-        b.linear(s + "/self_attention/linear_1", d, d, bias=False)
+        b.linear(s + "/self_attention/linear_0", (num_heads + 2 * num_heads_kv) * dh, d, bias=False, awq_ok=True)
+        b.linear(s + "/self_attention/linear_1", d, d, bias=False, awq_ok=True)
         b.attr(s + "/self_attention/rotary_dim", 0, np.int32)
         b.attr(s + "/self_attention/rotary_interleave", 0, np.int8)
         b.attr(s + "/self_attention/rotary_base", rotary_base, np.float32)
         b.attr(s + "/self_attention/num_heads_kv", num_heads_kv, np.int32)
         b.layer_norm(s + "/ffn/layer_norm", d, rms=True)
-        b.linear(s + "/ffn/linear_0", ffn_dim, d, bias=False)
-        b.linear(s + "/ffn/linear_0_noact", ffn_dim, d, bias=False)
-        b.linear(s + "/ffn/linear_1", d, ffn_dim, bias=False)
+        b.linear(s + "/ffn/linear_0", ffn_dim, d, bias=False, awq_ok=True)
+        b.linear(s + "/ffn/linear_0_noact", ffn_dim, d, bias=False, awq_ok=True)
+        b.linear(s + "/ffn/linear_1", d, ffn_dim, bias=False, awq_ok=True)
     b.layer_norm("decoder/layer_norm", d, rms=True)
     b.linear("decoder/projection", vocab_size, d, bias=False)
     b.attr("decoder/num_heads", num_heads, np.int16)
@@ -245,6 +318,11 @@ def build_decoder_lm(output_dir, num_layers=32, d_model=4096, ffn_dim=14336, num
         "quantization_type": 0,
         "unk_token": "<unk>",
     }
+    if awq is not None and not awq[2]:
+        # common_spec.Quantization: CT2 = 0, AWQ_GEMM = 1, AWQ_GEMV = 2
+        config["quantization_type"] = 1 if awq[0] == "gemm" else 2
+        config["quantization_bits"] = 4
+        config["quantization_group_size"] = awq[1]
     with open(os.path.join(output_dir, "config.json"), "w") as f:
         json.dump(config, f, indent=2, sort_keys=True)
     with open(os.path.join(output_dir, "vocabulary.json"), "w", encoding="utf-8") as f:

@@ -115,3 +115,29 @@ def test_awq_envelope_is_explicit(gpu):
     with pytest.raises(RuntimeError):
         _lib.check(gpu.ct2x_awq_gemv(_ptr(buf), _ptr(buf), _ptr(buf), _ptr(buf), _i64(4), _i64(192),
                                      _i64(64), _i64(64), _i64(1), _i64(8), _ptr(buf), None, None))
+
+
+@pytest.mark.parametrize("layout,group", [("gemm", 128), ("gemv", 128), ("gemv", 64)])
+def test_awq_model_runs_like_its_float16_twin(gpu, layout, group, tmp_path):
+    """A Llama-style decoder whose layer Dense weights are AWQ int4 (model.bin variables weight /
+    weight_scale / weight_zero + config.json quantization_type, as the reference's converter writes
+    them) against the float16 model holding exactly the weights those int4 values dequantise to:
+    same teacher-forced logits up to the summation order of two different GEMM kernels, same greedy
+    tokens. (The reference itself refuses AWQ on ROCm and has no CPU path: src/layers/common.cc:402.)"""
+    import ctranslate2_amd as ct2
+    from ctranslate2_amd import model_builder as mb
+    kw = dict(num_layers=2, d_model=256, ffn_dim=512, num_heads=4, num_heads_kv=2, vocab_size=320,
+              seed=3, quantization="float16", w_std=0.05)
+    d_awq = mb.build_decoder_lm(str(tmp_path / "awq"), awq=(layout, group, False), **kw)
+    d_twin = mb.build_decoder_lm(str(tmp_path / "twin"), awq=(layout, group, True), **kw)
+    a = ct2.Translator(d_awq, device="cuda", compute_type="float16")
+    b = ct2.Translator(d_twin, device="cuda", compute_type="float16")
+    rng = np.random.default_rng(0)
+    tgt = rng.integers(4, 320, (3, 12)).astype(np.int32)
+    la, lb = a.step_logits([], tgt), b.step_logits([], tgt)
+    assert np.isfinite(la).all() and np.abs(la).max() > 0.1
+    assert np.abs(la - lb).max() <= 2e-3 * np.abs(lb).max()
+    prompts = [rng.integers(4, 320, n).tolist() for n in (5, 9, 3)]
+    out_a, _ = a.generate_ids(prompts, max_length=10, min_length=10)
+    out_b, _ = b.generate_ids(prompts, max_length=10, min_length=10)
+    assert out_a == out_b

@@ -48,3 +48,21 @@ def test_round_trips_and_widths():
     assert A.gemv_widths(4096, 64) == (8, 64) and A.gemv_widths(4096, 128) == (4, 32)
     # the reference recovers the group size as IC / scale.dim(-1) (gemv_gpu.cu:447): consistent
     assert 4096 // A.gemv_widths(4096, 64)[1] == 64 and 4096 // A.gemv_widths(4096, 128)[1] == 128
+
+
+def test_model_builder_packing_agrees_with_the_restatement():
+    """ctranslate2_amd.model_builder writes the AWQ variables of the synthetic models; what it packs
+    must dequantise (oracle) to what it says the twin float16 weight is."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ctranslate2_amd import model_builder as mb
+    rng = np.random.default_rng(4)
+    w = rng.normal(0, 0.05, (48, 256)).astype(np.float32)
+    for group in (64, 128):
+        q, z, s = mb.awq_quantize(w, group)
+        want = mb.awq_dequantize(q, z, s, group)                      # [out_c, in_c]
+        qw, sc, qz = mb.awq_pack(q, z, s, group, "gemm")
+        assert np.array_equal(A.dequantize_gemm(qw, sc, qz), want.T)
+        qw, sc, qz = mb.awq_pack(q, z, s, group, "gemv")
+        assert qz.shape[1] == A.gemv_widths(256, group)[0] and sc.shape[1] == A.gemv_widths(256, group)[1]
+        assert np.array_equal(A.dequantize_gemv(qw, sc, qz, group), want)
+        assert np.abs(want.astype(np.float32) - w).max() < 0.02  # 4-bit groups: coarse but sane
