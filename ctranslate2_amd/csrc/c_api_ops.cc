@@ -652,6 +652,15 @@ int ct2x_multinomial(const float* d_weights, int64_t rows, int64_t classes, int6
   API_CATCH
 }
 
+int ct2x_gumbel_noise(const float* d_x, float* d_y, int64_t size, uint32_t seed, void* stream) {
+  API_TRY
+  CT2X_CHECK(size >= 0 && (size == 0 || (d_x && d_y)), "ct2x_gumbel_noise: bad arguments");
+  static std::atomic<uint32_t> calls{0};  // successive calls draw fresh numbers for one seed
+  launch_gumbel_noise(d_x, d_y, size, seed, calls.fetch_add(1), resolve_stream(stream));
+  check_last_launch("gumbel_noise");
+  API_CATCH
+}
+
 int ct2x_random_sample(const float* d_logits, int64_t rows, int64_t vocab, int32_t sampling_topk,
                        float sampling_topp, float temperature, uint32_t seed,
                        const float* d_uniforms, const int32_t* d_step, int32_t* d_ids,

@@ -543,6 +543,26 @@ __global__ void multinomial_kernel(const float* __restrict__ weights, int64_t ro
   out[e] = pick >= 0 ? pick : last;
 }
 
+// ops::GumbelMax::add_gumbel_noise (src/ops/gumbel_max_gpu.cu:12-38; CPU: gumbel_max_cpu.cc:12-26):
+// y = x - log(u), u uniform in (0, 1] - the noise the reference adds before its TopK (an
+// exponential variate; the op keeps the reference's name). One draw per element from the
+// counter-based hash on (seed, call number, element): reproducible for a seed, fresh per call.
+__global__ void gumbel_noise_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                    uint32_t seed, uint32_t call) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t lo = static_cast<uint32_t>(i), hi = static_cast<uint32_t>(i >> 32);
+  const float u = 1.f - uniform01(seed ^ (hi * 0x9E3779B9u), call, lo);  // (0, 1]
+  y[i] = x[i] + (-logf(u));
+}
+
+void launch_gumbel_noise(const float* x, float* y, int64_t n, uint32_t seed, uint32_t call,
+                         hipStream_t stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(gumbel_noise_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                     stream, x, y, n, seed, call);
+}
+
 void launch_multinomial(const float* weights, int64_t rows, int64_t classes, int64_t samples,
                         uint32_t seed, uint32_t call, int32_t* out, hipStream_t stream) {
   const int64_t n = rows * samples;

@@ -384,6 +384,8 @@ void launch_median_filter(const float* x, int64_t rows, int64_t depth, int64_t w
 void launch_alibi_add(const float* x, const float* alibi, int64_t batch, int64_t heads,
                       int64_t queries, int64_t keys, int64_t alibi_keys, int64_t offset, float* y,
                       hipStream_t stream);
+void launch_gumbel_noise(const float* x, float* y, int64_t n, uint32_t seed, uint32_t call,
+                         hipStream_t stream);
 void launch_multinomial(const float* weights, int64_t rows, int64_t classes, int64_t samples,
                         uint32_t seed, uint32_t call, int32_t* out, hipStream_t stream);
 

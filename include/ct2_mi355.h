@@ -330,6 +330,11 @@ int ct2x_topp_mask(const float* d_x, const float* d_probs, int64_t rows, int64_t
 int ct2x_multinomial(const float* d_weights, int64_t rows, int64_t classes, int64_t samples,
                      uint32_t seed, int32_t* d_out, void* stream);
 
+/* ops::GumbelMax::add_gumbel_noise<Device::CUDA,float> (src/ops/gumbel_max_gpu.cu:12-38):
+ * y[i] = x[i] - log(u_i), u_i uniform in (0, 1] (x == y allowed); the front-end's TopK follows
+ * (src/ops/gumbel_max.cc:14-30). Counter-based RNG on (seed, call number, element). */
+int ct2x_gumbel_noise(const float* d_x, float* d_y, int64_t size, uint32_t seed, void* stream);
+
 /* RandomSampler for one step (src/sampling.cc:41-101): best `sampling_topk` candidates (2..64;
  * <= 0: the whole vocabulary) -> temperature -> TopPMask (src/ops/topp_mask_cpu.cc:24-31) ->
  * SoftMax -> Multinomial by inverse CDF (candidates in TopK order; index order for the whole

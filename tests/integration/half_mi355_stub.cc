@@ -418,8 +418,10 @@ namespace ctranslate2 {
       from_f32<T>(out32, output);                                                                   \
     }                                                                                               \
     template<>                                                                                      \
-    void GumbelMax::add_gumbel_noise<Device::CUDA, T>(const StorageView&, StorageView&) const {     \
-      not_provided16("ops::GumbelMax");                                                             \
+    void GumbelMax::add_gumbel_noise<Device::CUDA, T>(const StorageView& x, StorageView& y) const { \
+      StorageView x32 = to_f32<T>(x), y32 = f32_like(y);                                            \
+      add_gumbel_noise<Device::CUDA, float>(x32, y32);                                              \
+      from_f32<T>(y32, y);                                                                          \
     }
 
     CT2X_HALF_OPS(float16_t)

@@ -175,8 +175,10 @@ namespace ctranslate2 {
     }
 
     template<>
-    void GumbelMax::add_gumbel_noise<Device::CUDA, float>(const StorageView&, StorageView&) const {
-      not_provided("ops::GumbelMax");
+    void GumbelMax::add_gumbel_noise<Device::CUDA, float>(const StorageView& x, StorageView& y) const {
+      // src/ops/gumbel_max_gpu.cu:27-35
+      check(ct2x_gumbel_noise(x.data<float>(), y.data<float>(), x.size(), get_random_seed(),
+                              ct2x_thread_stream()));
     }
 
     template<>

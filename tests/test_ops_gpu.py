@@ -800,3 +800,26 @@ def test_random_sample_hash_is_reproducible(gpu):
     b, _ = G.random_sample(logits, 16, 1.0, 1.0, None, seed=7)
     c, _ = G.random_sample(logits, 16, 1.0, 1.0, None, seed=8)
     assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_gumbel_noise_is_exponential_and_seeded(gpu):
+    """ops::GumbelMax::add_gumbel_noise (src/ops/gumbel_max_gpu.cu:12-38): y = x - log(u), u uniform
+    in (0, 1]: the added noise is a unit exponential variate (mean 1, variance 1, median ln 2); the
+    arg-max of log-probabilities + that noise follows... whatever the reference's TopK makes of it -
+    what is pinned here is the op: the noise distribution, x == y in place, fresh draws per call."""
+    import ctypes as C
+    import torch
+    from ctranslate2_amd import _lib
+    n = 1 << 20
+    x = torch.full((n,), 3.0, dtype=torch.float32, device="cuda")
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(gpu.ct2x_gumbel_noise(p(x), p(y1), C.c_int64(n), C.c_uint32(7), None))
+    _lib.check(gpu.ct2x_gumbel_noise(p(x), p(y2), C.c_int64(n), C.c_uint32(7), None))
+    z1, z2 = (y1 - 3.0).cpu().numpy(), (y2 - 3.0).cpu().numpy()
+    assert z1.min() >= 0 and np.isfinite(z1).all()
+    assert abs(z1.mean() - 1.0) < 0.01 and abs(z1.var() - 1.0) < 0.02
+    assert abs(np.median(z1) - np.log(2.0)) < 0.01
+    assert not np.array_equal(z1, z2)  # successive calls draw fresh numbers
+    _lib.check(gpu.ct2x_gumbel_noise(p(x), p(x), C.c_int64(n), C.c_uint32(7), None))  # in place
+    assert abs((x - 3.0).mean().item() - 1.0) < 0.01
