@@ -32,12 +32,12 @@ namespace ct2x {
 
 namespace {
 
-template <int NT, int WAVES, int KS, int P, bool DUAL>
+template <int NT, int WAVES, int KS, int P, bool DUAL, bool PACKED>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
-    int slabs_per_wg, int total_slabs, const int8_t* __restrict__ B2, int packed_b,
-    GemmS8Epilogue ep) {
-  // (A .. packed_b are preloaded into SGPRs; `ep` costs a kernarg round trip and is first touched
+    int slabs_per_wg, int total_slabs, const int8_t* __restrict__ B2, GemmS8Epilogue ep) {
+  // (A .. B2 are preloaded into SGPRs; PACKED - the weight is the fragment-major copy - is a
+  // template parameter: with both address forms live the long-K ring spilled 15 registers; `ep` costs a kernarg round trip and is first touched
   // after the activation fragments and the first ring of weight requests have left)
   static_assert(KS % P == 0, "the ring slot of K-step i is i % P in every slab");
   constexpr int ND = DUAL ? 2 : 1;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int64_t off =
-          packed_b ? ((((static_cast<int64_t>(slab) * WAVES + wave) * KS + i) * NT + j) << 10) + lane * 16
+          PACKED ? ((((static_cast<int64_t>(slab) * WAVES + wave) * KS + i) * NT + j) << 10) + lane * 16
                       : (n0 + j * 16 + r) * K + kk;
       bf[i % P][0][j] = *reinterpret_cast<const v4i*>(B + off);
       if (DUAL) bf[i % P][ND - 1][j] = *reinterpret_cast<const v4i*>(B2 + off);
@@ -325,13 +325,18 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
   static const bool fake_packed = std::getenv("CT2X_STREAM_FAKE_PACKED") != nullptr;
   GemmS8Epilogue ep = ep_in;
   if (fake_packed) ep.packed_b = true;
-#define CT2X_STREAM(NT, KS, P, DUAL)                                                              \
-  if (plan.nt == NT && plan.ks == KS && plan.p == P && dual == DUAL) {                            \
-    auto fn = gemm_s8_stream_kernel<NT, 16, KS, P, DUAL>;                                         \
+#define CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, PACKED)                                               \
+  do {                                                                                            \
+    auto fn = gemm_s8_stream_kernel<NT, 16, KS, P, DUAL, PACKED>;                                 \
     const size_t lds = sizeof(int) * 2 * (DUAL ? 2 : 1) * 16 * NT * 256 + 2 * 16 * sizeof(int);   \
     allow_big_lds(reinterpret_cast<const void*>(fn), lds);                                        \
     hipLaunchKernelGGL(fn, dim3(plan.grid), dim3(1024), lds, stream, a, b, M, N, K,               \
-                       plan.slabs_per_wg, plan.slabs, ep.b2, ep.packed_b ? 1 : 0, ep);            \
+                       plan.slabs_per_wg, plan.slabs, ep.b2, ep);                                 \
+  } while (0)
+#define CT2X_STREAM(NT, KS, P, DUAL)                                                              \
+  if (plan.nt == NT && plan.ks == KS && plan.p == P && dual == DUAL) {                            \
+    if (ep.packed_b) CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, true);                                   \
+    else CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, false);                                              \
     return;                                                                                       \
   }
   // (forms whose register ring spills at 128 VGPRs - 16 waves per workgroup - are not compiled:
@@ -342,6 +347,7 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
   CT2X_STREAM(2, 4, 2, true) CT2X_STREAM(1, 4, 4, true)
   CT2X_STREAM(2, 8, 2, true) CT2X_STREAM(1, 8, 4, true)
 #undef CT2X_STREAM
+#undef CT2X_STREAM_LAUNCH
   throw Error("launch_gemm_s8_stream: no compiled form for this plan");
 }
 

@@ -273,3 +273,34 @@ def test_host_rotary_tables_match_the_reference():
             assert np.mean(got_s == want_s) > 0.9 and np.mean(got_c == want_c) > 0.9, name
             np.testing.assert_allclose(got_s, want_s, rtol=0, atol=3e-7)
             np.testing.assert_allclose(got_c, want_c, rtol=0, atol=3e-7)
+
+
+def test_hot_kernels_do_not_spill():
+    """The decode-path kernels must keep their working set in registers: a spill turns into HBM
+    write traffic per thread (found once with the PMC WRITE_SIZE counter: 15 spilled VGPRs of the
+    long-K streaming GEMM = 15 MB per launch, profiles/r02b_pmc_stream_gemm.json). Compiles the
+    three hot translation units for gfx950 and reads the kernel metadata."""
+    import re
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "ctranslate2_amd", "csrc")
+    hot = {"gemm_s8_stream.hip": "stream_kernel", "gemm_s8.hip": "skinny_kernel",
+           "attention_exact.hip": "attn_x_decode_kernel"}
+    with tempfile.TemporaryDirectory() as tmp:
+        for src, needle in hot.items():
+            out = os.path.join(tmp, src + ".s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                                   "-ffp-contract=off", "-I" + os.path.join(root, "include"), "-mllvm",
+                                   "-amdgpu-kernarg-preload-count=16", "-S", "--cuda-device-only", "-o", out,
+                                   os.path.join(csrc, src)], stderr=subprocess.DEVNULL)
+            text = open(out).read()
+            checked = 0
+            for block in text.split("  - .agpr_count:")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", block).group(1)
+                if needle not in name:
+                    continue
+                checked += 1
+                assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)) == 0, name
+                assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
+            assert checked >= 5, (src, checked)

@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/r2zz_pytest.log 2>&1; grep -E "passed|failed" gpurun_out/r2zz_pytest.log | tail -2
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py --no-cpu-baseline > gpurun_out/r2zz_bench.json 2> gpurun_out/r2zz_bench.err; python -c "
+import json; d=json.loads(open('gpurun_out/r2zz_bench.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['config'].get('kernels_per_decode_step')); print(json.dumps(d['config'].get('l8'))[:400]); print(json.dumps(d['config'].get('beam4'))[:200])"
+timeout 300 python tools/pmc_stream_gemm.py gpurun_out/pmc_r2zz > gpurun_out/r2zz_pmc_stream_gemm.json 2> gpurun_out/r2zz_pmc.err; cat gpurun_out/r2zz_pmc_stream_gemm.json | head -60
+find gpurun_out/pmc_r2zz -name "*.csv" -size +1M -delete; find gpurun_out/pmc_r2zz -name "*.db" -delete
