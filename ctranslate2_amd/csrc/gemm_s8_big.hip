@@ -269,19 +269,25 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_s8_big_kernel(const int8_t* 
       }
     }
   };
+  // (A macro, not a closure: register arrays reached through a nested closure are demoted to
+  // scratch memory - a first version of this dispatch cost the Swish instantiation 1040 bytes of
+  // stack per thread and 3.5x its run time, which the kernel metadata scan of
+  // tests/test_host.py::test_hot_kernels_do_not_spill now guards.)
   float resA[4][4], resB[4][4];
-  auto run = [&](auto fast_tag) {
-    load_residual(0, resA);
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-      load_residual(i + 1, resB);
-      store_group(i, resA, fast_tag);
-      if (i + 2 < 8) load_residual(i + 2, resA);
-      store_group(i + 1, resB, fast_tag);
-    }
-  };
-  if (fast_div) run(std::true_type{});
-  else run(std::false_type{});
+#define CT2X_BIG_EPILOGUE(TAG)                     \
+  load_residual(0, resA);                          \
+  _Pragma("unroll") for (int i = 0; i < 8; i += 2) { \
+    load_residual(i + 1, resB);                    \
+    store_group(i, resA, TAG);                     \
+    if (i + 2 < 8) load_residual(i + 2, resA);     \
+    store_group(i + 1, resB, TAG);                 \
+  }
+  if (fast_div) {
+    CT2X_BIG_EPILOGUE(std::true_type{})
+  } else {
+    CT2X_BIG_EPILOGUE(std::false_type{})
+  }
+#undef CT2X_BIG_EPILOGUE
 }
 
 template <int ACT, int ABLATE = 0>

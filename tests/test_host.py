@@ -286,7 +286,7 @@ def test_hot_kernels_do_not_spill():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "ctranslate2_amd", "csrc")
     hot = {"gemm_s8_stream.hip": "stream_kernel", "gemm_s8.hip": "skinny_kernel",
-           "attention_exact.hip": "attn_x_decode_kernel"}
+           "attention_exact.hip": "attn_x_decode_kernel", "gemm_s8_big.hip": "big_kernel"}
     with tempfile.TemporaryDirectory() as tmp:
         for src, needle in hot.items():
             out = os.path.join(tmp, src + ".s")
