@@ -304,3 +304,20 @@ def test_hot_kernels_do_not_spill():
                 assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)) == 0, name
                 assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
             assert checked >= 5, (src, checked)
+
+
+def test_streaming_gemm_plan_is_host_logic():
+    """Which (n, k) get a persistent streaming form / a fragment-major weight copy is decided on the
+    host (gemm_s8_stream.hip plan_stream; 256 CUs assumed without a device): the Llama-3-8B shapes
+    do, small or ragged weights do not - and the answer is the same for the weight packer and the
+    launcher (a packed weight must always find its kernel)."""
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    import ctypes as C
+    L.ct2x_gemm_s8_stream_packable.restype = C.c_int
+    q = lambda n, k, dual=0: L.ct2x_gemm_s8_stream_packable(C.c_int64(n), C.c_int64(k), C.c_int(dual))
+    assert q(6144, 4096) and q(4096, 4096) and q(4096, 14336) and q(128256, 4096) and q(14336, 4096, 1)
+    assert not q(512, 512) and not q(2048, 512)          # Transformer-base: cache resident, one-shot kernel
+    assert not q(8208, 4096)                             # no even split into >= 192 workgroups
+    assert not q(4096, 4160)                             # K not a multiple of 16 waves x 64 bytes
+    assert not q(14336, 14336, 1)                        # gated pair at K = 14336: the ring would spill
