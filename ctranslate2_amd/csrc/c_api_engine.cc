@@ -3,6 +3,7 @@
 
 #include "../../include/ct2_mi355.h"
 
+#include <limits>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -1125,6 +1126,53 @@ int ct2x_host_beam_step_select(int32_t beam_size, int32_t step, int32_t is_last_
 
 float ct2x_host_finalize_score(float score, float length, float length_penalty) {
   return finalize_score(score, length, length_penalty);
+}
+
+// negative_dtw (src/dtw.cc:40-82): host work on a small [text tokens, audio frames] matrix. One
+// flat cost row pair and a byte trace instead of the reference's vector-of-vectors; same
+// recurrence, same column-major fill order, same tie rule, same backtrace (the first row / column
+// of the trace are forced to "left" / "up", src/dtw.cc:11-14).
+int64_t ct2x_host_negative_dtw(const float* x, int64_t n, int64_t m, int64_t* path_i, int64_t* path_j) {
+  try {
+    if (!x || !path_i || !path_j || n < 1 || m < 1)
+      throw std::invalid_argument("ct2x_host_negative_dtw: bad arguments");
+    const float inf = std::numeric_limits<float>::infinity();
+    const int64_t w = m + 1;
+    std::vector<float> cost(static_cast<size_t>((n + 1) * w), inf);
+    std::vector<int8_t> trace(static_cast<size_t>((n + 1) * w), -1);
+    cost[0] = 0.f;
+    for (int64_t j = 1; j <= m; ++j) {
+      for (int64_t i = 1; i <= n; ++i) {
+        const float c0 = cost[(i - 1) * w + (j - 1)], c1 = cost[(i - 1) * w + j], c2 = cost[i * w + (j - 1)];
+        float c;
+        int8_t t;
+        if (c0 < c1 && c0 < c2) { c = c0; t = 0; }
+        else if (c1 < c0 && c1 < c2) { c = c1; t = 1; }
+        else { c = c2; t = 2; }
+        cost[i * w + j] = -x[(i - 1) * m + (j - 1)] + c;
+        trace[i * w + j] = t;
+      }
+    }
+    for (int64_t k = 0; k <= m; ++k) trace[k] = 2;
+    for (int64_t k = 0; k <= n; ++k) trace[k * w] = 1;
+    int64_t i = n, j = m, len = 0;
+    while (i > 0 || j > 0) {
+      path_i[len] = i - 1;
+      path_j[len] = j - 1;
+      ++len;
+      const int8_t t = trace[i * w + j];
+      if (t == 0) { --i; --j; }
+      else if (t == 1) --i;
+      else if (t == 2) --j;
+      else throw std::runtime_error("ct2x_host_negative_dtw: unexpected trace entry");
+    }
+    std::reverse(path_i, path_i + len);
+    std::reverse(path_j, path_j + len);
+    return len;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return -1;
+  }
 }
 
 }  // extern "C"

@@ -658,6 +658,13 @@ int ct2x_host_beam_step_select(int32_t beam_size, int32_t step, int32_t is_last_
 /* finalize_hypothesis_score without coverage penalty (src/decoding.cc:192-207). */
 float ct2x_host_finalize_score(float score, float length, float length_penalty);
 
+/* negative_dtw (src/dtw.cc:40-82; Whisper word alignment, src/models/whisper.cc:418): dynamic time
+ * warping over the NEGATED matrix x [n, m] (host memory), i.e. the monotone path from (0, 0) to
+ * (n - 1, m - 1) that maximises the summed x, with the reference's tie rule (diagonal only when
+ * strictly cheaper than both, then "up" only when strictly cheaper than both, else "left").
+ * path_i / path_j [n + m] receive the path in order; returns its length (<= n + m - 1), <0 on error. */
+int64_t ct2x_host_negative_dtw(const float* x, int64_t n, int64_t m, int64_t* path_i, int64_t* path_j);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "dtw.h"
 #include <ctranslate2/layers/transformer.h>
 #include <ctranslate2/models/model.h>
 #include <ctranslate2/models/sequence_to_sequence.h>
@@ -249,6 +250,23 @@ int ct2ref_process_logits(float* logits, int64_t rows, int64_t vocab, const int3
     p->apply(length, lg, disable_tokens, sequences, batch_offset, nullptr);
   disable_tokens.apply();
   CT2REF_CATCH
+}
+
+// The reference's own negative_dtw (src/dtw.cc) on a host matrix: pins ct2x_host_negative_dtw.
+int64_t ct2ref_negative_dtw(const float* x, int64_t n, int64_t m, int64_t* path_i, int64_t* path_j) {
+  try {
+    std::vector<float> flat(x, x + n * m);
+    StorageView X({n, m}, flat, Device::CPU);
+    const auto path = negative_dtw(X);
+    for (size_t k = 0; k < path.size(); ++k) {
+      path_i[k] = path[k].first;
+      path_j[k] = path[k].second;
+    }
+    return static_cast<int64_t>(path.size());
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "ct2ref_negative_dtw: %s\n", e.what());
+    return -1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------

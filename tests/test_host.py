@@ -321,3 +321,31 @@ def test_streaming_gemm_plan_is_host_logic():
     assert not q(8208, 4096)                             # no even split into >= 192 workgroups
     assert not q(4096, 4160)                             # K not a multiple of 16 waves x 64 bytes
     assert not q(14336, 14336, 1)                        # gated pair at K = 14336: the ring would spill
+
+
+def test_negative_dtw_against_the_reference():
+    """ct2x_host_negative_dtw (Whisper word alignment) against the reference's own
+    negative_dtw (src/dtw.cc) driven through oracle/ref_capi.cc: identical paths on random cost
+    matrices, on matrices full of ties (the tie rule decides the path) and on degenerate shapes."""
+    import ctypes as C
+    import _refshim as R
+    from ctranslate2_amd import _lib
+    L, ref = _lib.lib(), R.lib()
+    for f in (L.ct2x_host_negative_dtw, ref.ct2ref_negative_dtw):
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(0)
+    cases = [rng.standard_normal((n, m)).astype(np.float32) for n, m in [(1, 1), (1, 9), (7, 1), (5, 8),
+                                                                         (40, 150), (33, 33)]]
+    cases += [np.zeros((6, 9), np.float32), rng.integers(0, 2, (12, 20)).astype(np.float32),
+              np.eye(10, dtype=np.float32)]
+    for x in cases:
+        n, m = x.shape
+        got, want = [], []
+        for f, out in ((L.ct2x_host_negative_dtw, got), (ref.ct2ref_negative_dtw, want)):
+            pi, pj = np.zeros(n + m, np.int64), np.zeros(n + m, np.int64)
+            k = f(x.ctypes.data, n, m, pi.ctypes.data, pj.ctypes.data)
+            assert k > 0
+            out.extend(zip(pi[:k].tolist(), pj[:k].tolist()))
+        assert got == want
+        assert got[0] == (0, 0) and got[-1] == (n - 1, m - 1)
