@@ -36,9 +36,10 @@ template <int NT, int WAVES, int KS, int P, bool DUAL, bool PACKED>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
     int slabs_per_wg, int total_slabs, const int8_t* __restrict__ B2, GemmS8Epilogue ep) {
-  // (A .. B2 are preloaded into SGPRs; PACKED - the weight is the fragment-major copy - is a
-  // template parameter: with both address forms live the long-K ring spilled 15 registers; `ep` costs a kernarg round trip and is first touched
-  // after the activation fragments and the first ring of weight requests have left)
+  // (A .. B2 are preloaded into SGPRs; `ep` costs a kernarg round trip and is first touched after
+  // the activation fragments and the first ring of weight requests have left. PACKED - the weight
+  // is the fragment-major copy - is a template parameter: with both address forms live the long-K
+  // ring spilled 15 registers.)
   static_assert(KS % P == 0, "the ring slot of K-step i is i % P in every slab");
   constexpr int ND = DUAL ? 2 : 1;
   constexpr int THREADS = WAVES * 64;
@@ -192,8 +193,8 @@ struct StreamPlan {
   int slabs_per_wg = 0, grid = 0, slabs = 0;
 };
 
-// Equal slabs per workgroup (but the last) and at least 3/4 of the CUs busy, as many bytes in flight per wave as the
-// register file allows (P * NT * ND KB per wave, 16 waves per CU).
+// Equal slabs per workgroup (but the last) and at least 3/4 of the CUs busy, as many bytes in
+// flight per wave as the register file allows (P * NT * ND KB per wave, 16 waves per CU).
 bool plan_stream(int64_t n, int64_t k, bool dual, int cus, StreamPlan* plan) {
   if (k % 1024 != 0) return false;  // 16 waves x 64-byte K-steps
   const int ks = static_cast<int>(k / 1024);
