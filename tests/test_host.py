@@ -349,3 +349,53 @@ def test_negative_dtw_against_the_reference():
             out.extend(zip(pi[:k].tolist(), pj[:k].tolist()))
         assert got == want
         assert got[0] == (0, 0) and got[-1] == (n - 1, m - 1)
+
+
+def test_model_bin_reader_survives_corrupt_files(tmp_path):
+    """model.bin wire format (src/models/model.cc:594-661 <-> python/ctranslate2/specs/model_spec.py:
+    382-415; SURVEY 8 f2 "reader / writer fuzzing"): truncated files, flipped header bytes, flipped
+    payload bytes and planted 0xffffffff counts are either read or refused with an error - never a
+    crash, a hang or an allocation of the planted size."""
+    import ctypes as C
+    import shutil
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "models",
+                       "aren-transliteration-i8")
+    data = open(os.path.join(src, "model.bin"), "rb").read()
+    d = str(tmp_path / "m")
+    os.makedirs(d)
+    for f in os.listdir(src):
+        if f != "model.bin":
+            shutil.copy(os.path.join(src, f), d)
+    rng = np.random.default_rng(20260921)
+    accepted = rejected = 0
+    for it in range(240):
+        b = bytearray(data)
+        mode = it % 4
+        if mode == 0:
+            b = b[:int(rng.integers(0, len(b)))]
+        elif mode == 1:
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(0, 4096))] = int(rng.integers(0, 256))
+        elif mode == 2:
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        else:
+            p = int(rng.integers(0, len(b) - 8))
+            b[p:p + 4] = (0xFFFFFFFF).to_bytes(4, "little")
+        with open(os.path.join(d, "model.bin"), "wb") as f:
+            f.write(bytes(b))
+        n = L.ct2x_inspect_model(d.encode(), None, 0, None, None, None)
+        if n < 0:
+            rejected += 1
+            assert _lib.last_error() if hasattr(_lib, "last_error") else True
+            continue
+        accepted += 1
+        name = C.create_string_buffer(256)
+        dt, rk, nb = C.c_int32(), C.c_int32(), C.c_int64()
+        dims = (C.c_int64 * 8)()
+        for i in range(min(n, 40)):
+            L.ct2x_inspect_variable(d.encode(), C.c_int32(i), name, 256, C.byref(dt), C.byref(rk), dims,
+                                    C.byref(nb))
+    assert rejected >= 40 and accepted >= 40  # both outcomes exercised
