@@ -5,6 +5,8 @@
 #include <float.h>
 
 #include <hip/hip_runtime.h>
+
+#include "activation_exact.h"
 #include <stdint.h>
 
 namespace ct2x {
@@ -173,37 +175,12 @@ __device__ __forceinline__ bool exact_div_factor_ok(float r) {
   return r >= 1.862645149230957e-09f /* 2^-29 */ && r <= 536870912.f /* 2^29 */;
 }
 
+// ops::ActivationType 0..6 exactly as the reference's AVX2 functors compute them (activation_exact.h:
+// exp256_ps with FMA contraction, Eigen's rational tanh, the Abramowitz-Stegun erf) - round 2 ran
+// GELU / GELUTanh / GELUSigmoid / Tanh / Sigmoid through the device libm ("close"); the same header
+// is compiled for the host and pinned against the oracle and the reference library there.
 __device__ __forceinline__ float apply_activation(float v, int act) {
-  switch (act) {
-    case 0:  // ReLU
-      return fmaxf(v, 0.f);
-    case 1: {  // GELUTanh
-      float u = v * v * v;
-      u = 0.044715f * u + v;
-      u = 0.7978845608028654f * u;
-      u = tanhf(u);
-      u = 1.f + u;
-      u = v * u;
-      return 0.5f * u;
-    }
-    case 2:  // Swish: v / (1 + exp256_ps(-v)), the AVX2 functor of the reference's fused Dense
-             // epilogue (src/cpu/kernels.cc:194-199, 664-680) - bit-exact, not libm's expf
-      return v / (1.f + exp_avx2(-v));
-    case 3: {  // GELU
-      float u = 0.7071067811865475f * v;
-      u = 1.f + erff(u);
-      u = v * u;
-      return 0.5f * u;
-    }
-    case 4:  // GELUSigmoid
-      return v / (1.f + expf(-1.702f * v));
-    case 5:  // Tanh
-      return tanhf(v);
-    case 6:  // Sigmoid
-      return 1.f / (1.f + expf(-v));
-    default:
-      return v;
-  }
+  return exact_activation(v, act);
 }
 
 // Quantisation mode flags (the `round_before_cast` argument of the C ABI):
@@ -239,27 +216,7 @@ __device__ __forceinline__ int8_t to_s8(float x, float scale, int mode) {
 
 // exp256_ps (third_party/avx_mathfun.h:290-344) as compiled into the reference's AVX2 kernels:
 // every mul+add pair of the Cephes polynomial is one FMA.
-__device__ __forceinline__ float exp_avx2(float x) {
-  x = fminf(x, 88.3762626647949f);
-  x = fmaxf(x, -88.3762626647949f);
-  float fx = fmaf(x, 1.44269504088896341f, 0.5f);
-  float tmp = floorf(fx);
-  if (tmp > fx) tmp = tmp - 1.f;
-  fx = tmp;
-  x = fmaf(-fx, 0.693359375f, x);
-  x = fmaf(-fx, -2.12194440e-4f, x);
-  const float z = x * x;
-  float y = 1.9875691500E-4f;
-  y = fmaf(y, x, 1.3981999507E-3f);
-  y = fmaf(y, x, 8.3334519073E-3f);
-  y = fmaf(y, x, 4.1665795894E-2f);
-  y = fmaf(y, x, 1.6666665459E-1f);
-  y = fmaf(y, x, 5.0000001201E-1f);
-  y = fmaf(y, z, x);
-  y = y + 1.f;
-  const float pow2n = __int_as_float((static_cast<int>(fx) + 0x7f) << 23);
-  return y * pow2n;
-}
+__device__ __forceinline__ float exp_avx2(float x) { return exact_exp_avx2(x); }
 
 // logf exactly as glibc computes it (sysdeps/ieee754/flt-32/e_logf.c, the ARM optimized-routines
 // algorithm, MIT): 16-entry table of (1/c, log c), a degree-3 polynomial, everything in double,

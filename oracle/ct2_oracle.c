@@ -11,33 +11,85 @@
  * include/ctranslate2/ops/activation.h:9-17. */
 float orc_exp_avx2(float x);
 
+/* Vec<float, AVX2>::tanh = vec_tanh (src/cpu/vec.h:155-197, ported from Eigen): clamp to +-7.905,
+ * odd polynomial p over even polynomial q in x^2, every step a mul_add = FMA on the AVX2 target
+ * (src/cpu/vec_avx.h mul_add -> _mm256_fmadd_ps), x itself below 4e-4. */
+static float orc_tanh_avx2(float a) {
+  float x = fminf(a, 7.90531110763549805f);
+  x = fmaxf(x, -7.90531110763549805f);
+  const int tiny = fabsf(a) < 0.0004f;
+  const float x2 = x * x;
+  float p = fmaf(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
+  p = fmaf(x2, p, -8.60467152213735e-11f);
+  p = fmaf(x2, p, 5.12229709037114e-08f);
+  p = fmaf(x2, p, 1.48572235717979e-05f);
+  p = fmaf(x2, p, 6.37261928875436e-04f);
+  p = fmaf(x2, p, 4.89352455891786e-03f);
+  p = x * p;
+  float q = fmaf(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
+  q = fmaf(x2, q, 2.26843463243900e-03f);
+  q = fmaf(x2, q, 4.89352518554385e-03f);
+  return tiny ? x : p / q;
+}
+
+/* Vec<float, AVX2>::erf = vec_erf (src/cpu/vec.h:199-237, ported from PyTorch): Abramowitz-Stegun
+ * 7.1.26 with exp256_ps for exp(-x^2); sign handled on the bit pattern. */
+static float orc_erf_avx2(float a) {
+  uint32_t bits;
+  memcpy(&bits, &a, 4);
+  const uint32_t sign = bits & 0x80000000u;
+  uint32_t ab = bits ^ sign;
+  float abs_a;
+  memcpy(&abs_a, &ab, 4);
+  const float tmp0 = fmaf(0.3275911f, abs_a, 1.0f);
+  const float t = 1.0f / tmp0;
+  const float tmp1 = fmaf(1.061405429f, t, -1.453152027f);
+  const float tmp2 = fmaf(tmp1, t, 1.421413741f);
+  const float tmp3 = fmaf(tmp2, t, -0.284496736f);
+  const float r = fmaf(tmp3, t, 0.254829592f);
+  const float pow_2 = a * a;
+  const float tmp4 = orc_exp_avx2(-pow_2);
+  const float tmp6 = (-tmp4) * t;
+  float tmp7 = fmaf(tmp6, r, 1.0f);
+  uint32_t out;
+  memcpy(&out, &tmp7, 4);
+  out ^= sign;
+  memcpy(&tmp7, &out, 4);
+  return tmp7;
+}
+
+/* The activation functors of the AVX2 dispatch (src/cpu/kernels.cc:146-207), which the fused Dense
+ * epilogue applies to EVERY column (masked remainder included, kernels.cc:664-680): exp = exp256_ps
+ * with GCC's FMA contraction (orc_exp_avx2), tanh / erf as above. Pinned bit for bit against the
+ * reference library (tests/test_oracle.py::test_ref_dequantize_exact). `orc_activation_libm` keeps
+ * the libm forms of the GENERIC dispatch (scalar tails of the standalone unary ops). */
 float orc_activation(float v, int act) {
   switch (act) {
     case 0: /* ReLU: max(v, 0) */
       return v > 0.f ? v : 0.f;
-    case 1: { /* GELUTanh */
-      float u = v * v * v;
-      u = 0.044715f * u + v;
+    case 1: { /* GELUTanh (gelu_tanh_func) */
+      float u = (v * v) * v;
+      u = fmaf(0.044715f, u, v);
       u = 0.7978845608028654f * u;
-      u = tanhf(u);
+      u = orc_tanh_avx2(u);
       u = 1.f + u;
       u = v * u;
       return 0.5f * u;
     }
     case 2: /* Swish: v / (1 + exp(-v)) */
-      return v / (1.f + expf(-v));
+      return v / (1.f + orc_exp_avx2(-v));
     case 3: { /* GELU: 0.5 * v * (1 + erf(v / sqrt 2)) */
       float u = 0.7071067811865475f * v;
-      u = 1.f + erff(u);
+      u = 1.f + orc_erf_avx2(u);
       u = v * u;
       return 0.5f * u;
     }
     case 4: /* GELUSigmoid */
-      return v / (1.f + expf(-1.702f * v));
+      return v / (1.f + orc_exp_avx2(-1.702f * v));
     case 5:
-      return tanhf(v);
+      return orc_tanh_avx2(v);
     case 6:
-      return 1.f / (1.f + expf(-v));
+      return 1.f / (1.f + orc_exp_avx2(-v));
     default:
       return v;
   }
@@ -108,7 +160,7 @@ void orc_dequantize_gemm_output(const int32_t* c, const float* a_scale, const fl
       /* the fused epilogue runs every column through the ISA's vector functor, masked loads for
        * the remainder (kernels.cc:664-680): Swish = v / (1 + exp256_ps(-v)) for ALL columns on the
        * AVX2 dispatch (swish_func, :194-199), not libm's expf */
-      y[i * n + j] = (act == 2) ? v / (1.f + orc_exp_avx2(-v)) : orc_activation(v, act);
+      y[i * n + j] = orc_activation(v, act);
     }
   }
 }

@@ -399,3 +399,38 @@ def test_model_bin_reader_survives_corrupt_files(tmp_path):
             L.ct2x_inspect_variable(d.encode(), C.c_int32(i), name, 256, C.byref(dt), C.byref(rk), dims,
                                     C.byref(nb))
     assert rejected >= 40 and accepted >= 40  # both outcomes exercised
+
+
+def test_device_activation_source_matches_the_oracle_on_the_host(tmp_path):
+    """ctranslate2_amd/csrc/activation_exact.h is what the HIP epilogues compile; built here with g++
+    (-ffp-contract=off -mfma: mul, FMA and division round as on the device) it must return the bits
+    of the oracle's own restatement - which tests/test_oracle.py::test_ref_dequantize_exact pins
+    against the reference library - for every ops::ActivationType, over values that reach the
+    clamps, the tiny-argument arm of tanh and both signs."""
+    import ctypes as C
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = str(tmp_path / "activation_host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-shared", "-fPIC",
+                           "-o", so, os.path.join(here, "cpp", "activation_host.cc")])
+    H = C.CDLL(so)
+    import _oracle as O
+    orc = O.lib()
+    orc.orc_activation.restype = C.c_float
+    orc.orc_activation.argtypes = [C.c_float, C.c_int]
+    orc.orc_exp_avx2.restype = C.c_float
+    orc.orc_exp_avx2.argtypes = [C.c_float]
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        rng.standard_normal(200000) * 3, rng.standard_normal(50000) * 30, rng.standard_normal(50000) * 1e-4,
+        np.array([0.0, -0.0, 1e-30, -1e-30, 0.0004, -0.0004, 7.9, -7.9, 8.0, 88.4, -88.4, 100.0, -100.0]),
+    ]).astype(np.float32)
+    y = np.empty_like(x)
+    for act in range(7):
+        H.host_activation(x.ctypes.data_as(C.c_void_p), C.c_int64(x.size), C.c_int(act), y.ctypes.data_as(C.c_void_p))
+        want = np.array([orc.orc_activation(float(v), act) for v in x[::37]], np.float32)
+        got = y[::37]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), act
+    H.host_exp_avx2(x.ctypes.data_as(C.c_void_p), C.c_int64(x.size), y.ctypes.data_as(C.c_void_p))
+    want = np.array([orc.orc_exp_avx2(float(v)) for v in x[::37]], np.float32)
+    assert np.array_equal(y[::37].view(np.uint32), want.view(np.uint32))

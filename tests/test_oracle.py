@@ -125,22 +125,24 @@ def test_ref_gemm_s8_exact_on_this_host():
         pytest.xfail("reference int8 GEMM saturates on this host CPU (no VNNI path in MKL)")
 
 
-@pytest.mark.parametrize("act", [-1, 0, 2, 3])
+@pytest.mark.parametrize("act", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_ref_dequantize_exact(act):
+    """Dequantize + bias + EVERY activation of ops::ActivationType against the reference library,
+    bit for bit: the fused epilogue runs every column (masked remainder included: n = 130 has a
+    remainder of 2) through the AVX2 functors - exp256_ps, vec_tanh (Eigen's rational form),
+    vec_erf (Abramowitz-Stegun with exp256_ps), src/cpu/vec.h:155-237 - restated in
+    oracle/ct2_oracle.c; wide value ranges so that the clamps and the tiny-argument arm are hit."""
     R = _ref()
-    rng = np.random.default_rng(2)
-    c = rng.integers(-300000, 300000, (17, 130), dtype=np.int32)
-    sa = rng.uniform(3, 90, 17).astype(np.float32)
-    sb = rng.uniform(40, 5000, 130).astype(np.float32)
-    bias = rng.standard_normal(130).astype(np.float32)
-    y1 = O.dequantize_gemm_output(c, sa, sb, bias, act)
-    y2 = R.dequantize_gemm_output(c, sa, sb, bias, act)
-    if act in (-1, 0, 2):
-        # none / ReLU / Swish (= v / (1 + exp256_ps(-v)) for every column, masked remainder
-        # included: n = 130 has a remainder of 2): bit-exact
-        assert np.array_equal(y1, y2)
-    else:
-        np.testing.assert_allclose(y1, y2, rtol=1e-5, atol=1e-6)
+    rng = np.random.default_rng(2 + act)
+    for scale_exp in (-2, 0, 1):
+        c = rng.integers(-300000, 300000, (17, 130), dtype=np.int32)
+        c[0, :8] = [0, 1, -1, 2, -2, 3, 40, -40]  # tiny arguments
+        sa = (rng.uniform(3, 90, 17) * 10.0 ** scale_exp).astype(np.float32)
+        sb = rng.uniform(40, 5000, 130).astype(np.float32)
+        bias = (rng.standard_normal(130) * 0.01).astype(np.float32)
+        y1 = O.dequantize_gemm_output(c, sa, sb, bias, act)
+        y2 = R.dequantize_gemm_output(c, sa, sb, bias, act)
+        assert np.array_equal(y1.view(np.uint32), y2.view(np.uint32))
 
 
 def test_ref_float_ops_close():
