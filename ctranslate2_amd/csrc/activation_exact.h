@@ -79,6 +79,76 @@ CT2X_HD float exact_erf_avx2(float a) {
   return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, tmp7) ^ sign);
 }
 
+// expf exactly as the reference's libm computes it (glibc >= 2.27, sysdeps/ieee754/flt-32/e_expf.c: the
+// ARM optimized-routines algorithm - 2^(k/32) table, degree-3 polynomial, everything in double, one
+// final rounding - in the FMA build x86-64 machines dispatch to, where the compiler contracted the
+// reduction r = InvLn2N * x - kd into one fma). The reference's CPU LogSoftMax sends the last
+// depth mod 8 elements of a row (and whole rows of <= 8) through std::exp (src/cpu/kernels.cc:433-455
+// scalar tail); this restatement returns libm's bits for EVERY float (compared exhaustively, all
+// 2^32 inputs, by tests/test_host.py on the host build of this header). Table: asuint64(2^(i/32)) -
+// (i << 47), the values of glibc's __exp2f_data.
+CT2X_HD float exact_expf_glibc(float x) {
+  const unsigned long long kTab[32] = {
+    0x3ff0000000000000ull,
+    0x3fefd9b0d3158574ull,
+    0x3fefb5586cf9890full,
+    0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull,
+    0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull,
+    0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull,
+    0x3feece086061892dull,
+    0x3feebfdad5362a27ull,
+    0x3feeb42b569d4f82ull,
+    0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull,
+    0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull,
+    0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull,
+    0x3feeb737b0cdc5e5ull,
+    0x3feec49182a3f090ull,
+    0x3feed503b23e255dull,
+    0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull,
+    0x3fef199bdd85529cull,
+    0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull,
+    0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull,
+    0x3fefd0765b6e4540ull
+  };
+  const double kInvLn2N = 0x1.71547652b82fep+0 * 32, kShift = 0x1.8p+52;
+  const double kC0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, kC1 = 0x1.ebfce50fac4f3p-3 / 32 / 32,
+               kC2 = 0x1.62e42ff0c52d6p-1 / 32;
+  const unsigned ux = __builtin_bit_cast(unsigned, x);
+  const unsigned abstop = (ux >> 20) & 0x7ffu;
+  if (abstop >= 0x42bu) {  // |x| >= 88 or NaN
+    if (ux == 0xff800000u) return 0.0f;
+    if (abstop >= 0x7f8u) return x + x;
+    if (x > 0x1.62e42ep6f) return __builtin_huge_valf();
+    if (x < -0x1.9fe368p6f) return 0.0f;
+  }
+  const double xd = static_cast<double>(x);
+  const double z = kInvLn2N * xd;
+  double kd = z + kShift;
+  const unsigned long long ki = __builtin_bit_cast(unsigned long long, kd);
+  kd -= kShift;
+  const double r = fma(kInvLn2N, xd, -kd);
+  const unsigned long long t = kTab[ki & 31u] + (ki << 47);
+  const double s = __builtin_bit_cast(double, t);
+  const double zz = kC0 * r + kC1;
+  const double r2 = r * r;
+  double y = kC2 * r + 1.0;
+  y = zz * r2 + y;
+  y = y * s;
+  return static_cast<float>(y);
+}
+
 // ops::ActivationType 0..6 (include/ctranslate2/ops/activation.h:9-17) as the AVX2 functors compute
 // them; any other value is the identity.
 CT2X_HD float exact_activation(float v, int act) {

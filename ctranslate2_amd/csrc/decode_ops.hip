@@ -77,7 +77,7 @@ __device__ __forceinline__ float ordered_row_exp_sum(const float* __restrict__ x
   if (lds == nullptr) {
     for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
       const float v = ((j == masked) ? -FLT_MAX : x[j]) - m;
-      park[j] = (j < vsize) ? exp_avx2(v) : expf(v);
+      park[j] = (j < vsize) ? exp_avx2(v) : expf_glibc(v);
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -93,7 +93,7 @@ __device__ __forceinline__ float ordered_row_exp_sum(const float* __restrict__ x
     if (j < vsize)
       lds[(j & 7) * chain_pad + (j >> 3)] = exp_avx2(v);
     else
-      tail[j - vsize] = expf(v);
+      tail[j - vsize] = expf_glibc(v);
   }
   __syncthreads();
   if (threadIdx.x < 64) {
@@ -723,7 +723,7 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
         if (j < vsize)
           exp_lds[(j & 7) * chain_pad + (j >> 3)] = exp_avx2(v);
         else
-          tail[j - vsize] = expf(v);
+          tail[j - vsize] = expf_glibc(v);
       }
     }
     __syncthreads();

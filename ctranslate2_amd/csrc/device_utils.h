@@ -217,6 +217,8 @@ __device__ __forceinline__ int8_t to_s8(float x, float scale, int mode) {
 // exp256_ps (third_party/avx_mathfun.h:290-344) as compiled into the reference's AVX2 kernels:
 // every mul+add pair of the Cephes polynomial is one FMA.
 __device__ __forceinline__ float exp_avx2(float x) { return exact_exp_avx2(x); }
+// std::exp of the reference's scalar tails = glibc's expf, restated (activation_exact.h)
+__device__ __forceinline__ float expf_glibc(float x) { return exact_expf_glibc(x); }
 
 // logf exactly as glibc computes it (sysdeps/ieee754/flt-32/e_logf.c, the ARM optimized-routines
 // algorithm, MIT): 16-entry table of (1/c, log c), a degree-3 polynomial, everything in double,

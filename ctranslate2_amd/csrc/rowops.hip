@@ -452,7 +452,8 @@ void launch_norm(const float* x, const float* gamma, const float* beta, int64_t 
 // The exps are parked in the output row (global memory, re-read by wave 0 for the ordered sum).
 // The final log is glibc's logf restated (logf_glibc, device_utils.h). One documented residual of
 // the log form: the scalar tail (depth % 8 elements, or a whole row of <= 8) uses libm expf on
-// the CPU - the device's expf stands in for it (vocabulary rows are multiples of 8).
+// the CPU = glibc's expf, restated exactly as expf_glibc (activation_exact.h; exhaustively equal to
+// libm on the host).
 // ---------------------------------------------------------------------------------------
 __global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengths,
                                const float* __restrict__ row_bias, int64_t depth, bool log,
@@ -482,7 +483,7 @@ __global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengt
     // exps parked transposed in LDS for the ordered sum (and written to y for the plain form)
     float* tail = exp_lds + 8 * chain_pad;
     for (int64_t j = threadIdx.x; j < size; j += blockDim.x) {
-      const float e = (j < poly_end) ? exp_avx2(xr[j] - m) : expf(xr[j] - m);
+      const float e = (j < poly_end) ? exp_avx2(xr[j] - m) : expf_glibc(xr[j] - m);
       if (j < vsize)
         exp_lds[chain_slot(j, chain_pad)] = e;
       else
@@ -509,13 +510,13 @@ __global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengt
       const int l = threadIdx.x & 7;
       float acc = 0.f;
       if (size <= 8) {
-        for (int64_t j = 0; j < size; ++j) acc += expf(xr[j] - m);
+        for (int64_t j = 0; j < size; ++j) acc += expf_glibc(xr[j] - m);
       } else {
         for (int64_t j = l; j < vsize; j += 8) acc += exp_avx2(xr[j] - m);
         acc = acc + __shfl_xor(acc, 4, 64);
         acc = acc + __shfl_xor(acc, 2, 64);
         acc = acc + __shfl_xor(acc, 1, 64);
-        for (int64_t j = vsize; j < size; ++j) acc += expf(xr[j] - m);
+        for (int64_t j = vsize; j < size; ++j) acc += expf_glibc(xr[j] - m);
       }
       if (threadIdx.x == 0) scratch[0] = acc;
     }
@@ -523,7 +524,7 @@ __global__ void softmax_kernel(const float* x, const int32_t* __restrict__ lengt
     s = scratch[0];
   } else {
     for (int64_t j = threadIdx.x; j < size; j += blockDim.x)
-      yr[j] = (j < poly_end) ? exp_avx2(xr[j] - m) : expf(xr[j] - m);
+      yr[j] = (j < poly_end) ? exp_avx2(xr[j] - m) : expf_glibc(xr[j] - m);
     __syncthreads();  // the row of exps is visible to wave 0 (same CU)
     if (threadIdx.x < 64) {
       const float t = ordered_sum8(yr, static_cast<int>(size));

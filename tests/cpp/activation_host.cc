@@ -12,3 +12,22 @@ extern "C" void host_activation(const float* x, int64_t n, int act, float* y) {
 extern "C" void host_exp_avx2(const float* x, int64_t n, float* y) {
   for (int64_t i = 0; i < n; ++i) y[i] = ct2x::exact_exp_avx2(x[i]);
 }
+
+// exact_expf_glibc against this machine's libm over EVERY float (NaNs skipped): mismatch count.
+#include <cstring>
+extern "C" long long host_expf_glibc_exhaustive() {
+  long long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+  for (long long b = 0; b < (1ll << 32); ++b) {
+    const uint32_t u = static_cast<uint32_t>(b);
+    float x;
+    std::memcpy(&x, &u, 4);
+    if (x != x) continue;
+    const float a = ct2x::exact_expf_glibc(x), e = expf(x);
+    uint32_t ua, ue;
+    std::memcpy(&ua, &a, 4);
+    std::memcpy(&ue, &e, 4);
+    bad += ua != ue;
+  }
+  return bad;
+}

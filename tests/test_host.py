@@ -411,9 +411,12 @@ def test_device_activation_source_matches_the_oracle_on_the_host(tmp_path):
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     so = str(tmp_path / "activation_host.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-shared", "-fPIC",
-                           "-o", so, os.path.join(here, "cpp", "activation_host.cc")])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-fopenmp", "-shared",
+                           "-fPIC", "-o", so, os.path.join(here, "cpp", "activation_host.cc")])
     H = C.CDLL(so)
+    # glibc's expf (the scalar tail of the CPU LogSoftMax), restated: every one of the 2^32 floats
+    H.host_expf_glibc_exhaustive.restype = C.c_longlong
+    assert H.host_expf_glibc_exhaustive() == 0
     import _oracle as O
     orc = O.lib()
     orc.orc_activation.restype = C.c_float
