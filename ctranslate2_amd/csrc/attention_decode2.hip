@@ -546,7 +546,7 @@ void launch_gq(const Attn2Args& a, int gq, int tw, hipStream_t stream) {
 
 // Shapes the second-generation kernel covers; everything else stays on attention.hip.
 bool attention_decode2_applicable(const AttnDecodeParams& p, bool fused_quantize) {
-  static const bool disabled = std::getenv("CT2X_ATTN_V1") != nullptr;
+  static const bool disabled = tuning_env("CT2X_ATTN_V1") != nullptr;
   if (disabled) return false;
   if (p.dhead != 64 && p.dhead != 128) return false;
   if (p.heads_kv < 1 || p.heads % p.heads_kv != 0) return false;
@@ -599,7 +599,7 @@ void launch_attention_decode2(const AttnDecodeParams& p, int quant_mode, int8_t*
     // L2 once per head of a GQA group). CT2X_ATTN_SHARE_KV=1: one workgroup per KV head whose
     // waves carry the whole group in registers (K/V read once) - for comparison runs.
     static const bool share_kv = [] {
-      const char* e = std::getenv("CT2X_ATTN_SHARE_KV");
+      const char* e = tuning_env("CT2X_ATTN_SHARE_KV");
       return e != nullptr && e[0] == '1';
     }();
     a.teams = 1;
@@ -613,7 +613,7 @@ void launch_attention_decode2(const AttnDecodeParams& p, int quant_mode, int8_t*
     }
     tw = p.t_max > 64 ? 4 : 1;
   }
-  static const bool no_remap = std::getenv("CT2X_ATTN_NO_XCD_REMAP") != nullptr;
+  static const bool no_remap = tuning_env("CT2X_ATTN_NO_XCD_REMAP") != nullptr;
   const int64_t grid = p.rows * a.wg_per_row;
   a.xcd_remap = (!no_remap && q_out == nullptr && a.per_q_head && a.group > 1 && grid % 8 == 0 &&
                  grid >= 64) ? 1 : 0;

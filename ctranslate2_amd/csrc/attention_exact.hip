@@ -625,7 +625,7 @@ static void launch_x(const AttnXArgs& a, size_t lds, hipStream_t stream) {
   if (p.lengths != nullptr) flags |= kXLenPerRow;
   // CT2X_ATTN_SPEC_K = 0 (no early K request) | half | 1 (whole first tile; default)
   static const int spec_mode = [] {
-    const char* e = std::getenv("CT2X_ATTN_SPEC_K");
+    const char* e = tuning_env("CT2X_ATTN_SPEC_K");
     if (e == nullptr) return 2;
     if (e[0] == '0') return 0;
     if (e[0] == 'h') return 1;

@@ -18,6 +18,7 @@
 
 #include "device_utils.h"
 #include "kernels.h"
+#include "runtime.h"
 
 #include <cstdlib>
 
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnFullParams p) {
 }  // namespace
 
 bool attention_prefill_applicable(const AttnFullParams& p) {
-  static const bool disabled = std::getenv("CT2X_ATTN_PREFILL_V1") != nullptr;
+  static const bool disabled = tuning_env("CT2X_ATTN_PREFILL_V1") != nullptr;
   if (disabled) return false;
   if (p.dhead != 64 && p.dhead != 128) return false;
   if (p.heads_kv < 1 || p.heads % p.heads_kv != 0) return false;

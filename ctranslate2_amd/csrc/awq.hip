@@ -340,7 +340,7 @@ void launch_awq_dequantize_gemv(const int32_t* qweight, const void* scales_f16, 
 
 void launch_awq_gemm(const void* x_f16, const int32_t* qweight, const void* scales_f16,
                      const int32_t* qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
-                     void* y_f16, float* y_f32, hipStream_t stream) {
+                     void* y_f16, float* y_f32, hipStream_t stream, float* slices_ws) {
   if (m == 0 || out_c == 0) return;
   if (in_c % 32 != 0 || out_c % 8 != 0 || group % 8 != 0 || group <= 0 || in_c % group != 0 ||
       (reinterpret_cast<uintptr_t>(x_f16) & 15) != 0 || (reinterpret_cast<uintptr_t>(scales_f16) & 15) != 0)
@@ -350,9 +350,17 @@ void launch_awq_gemm(const void* x_f16, const int32_t* qweight, const void* scal
   // K slices so that ~256+ workgroups stream the weight; each slice keeps >= 4 steps per wave
   int64_t splits = 1;
   while (tiles * splits < 256 && (in_c / 32) / (splits * 2) >= 16 && splits < 16) splits *= 2;
+  // splits > 1 only while tiles * splits < 512, i.e. splits * m * out_c < 512 * 16 * 128 floats:
+  // kAwqGemmWorkspaceFloats always holds the slices. A caller-owned workspace keeps the launch
+  // free of allocator calls (a captured decode step must not allocate); without one the slices
+  // come from the caching allocator (eager callers of the C ABI).
   float* slices = nullptr;
-  if (splits > 1)
-    slices = static_cast<float*>(device_malloc(static_cast<size_t>(splits) * m * out_c * sizeof(float)));
+  if (splits > 1) {
+    CT2X_CHECK(static_cast<size_t>(splits) * m * out_c <= kAwqGemmWorkspaceFloats,
+               "awq gemm: split-K workspace bound violated");
+    slices = slices_ws ? slices_ws
+                       : static_cast<float*>(device_malloc(static_cast<size_t>(splits) * m * out_c * sizeof(float)));
+  }
   hipLaunchKernelGGL(awq_gemm_kernel, dim3(static_cast<unsigned>((qout + 15) / 16),
                                            static_cast<unsigned>((m + 15) / 16),
                                            static_cast<unsigned>(splits)),
@@ -368,8 +376,10 @@ void launch_awq_gemm(const void* x_f16, const int32_t* qweight, const void* scal
                        y_f32);
     // stream-ordered allocator: the block is reused only after the work queued on the calling
     // thread's active stream; a launch on some other stream has to finish first
-    if (stream != active_stream()) CT2X_HIP_CHECK(hipStreamSynchronize(stream));
-    device_free(slices);
+    if (slices_ws == nullptr) {
+      if (stream != active_stream()) CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+      device_free(slices);
+    }
   }
 }
 

@@ -674,15 +674,15 @@ void Engine::pack_stream_weights() {
     // CT2X_WEIGHT_PREFETCH=1 switches the weight prefetch on (measured NEGATIVE, off by default: see
     // Engine::prefetch_weight); CT2X_PREFETCH_MB="qkv,out,ffn_in,ffn_out" sets the megabytes requested
     // next to the launch in front of each Dense, CT2X_PREFETCH_WGS the spare workgroups
-    const char* e = std::getenv("CT2X_WEIGHT_PREFETCH");
+    const char* e = tuning_env("CT2X_WEIGHT_PREFETCH");
     bool any = false;
     for (const LayerW& layer : dec_.layers) any = any || layer.ffn.l1.wq_stream != nullptr;
     weight_prefetch_ = any && e != nullptr && e[0] == '1';
     double mb[4] = {25, 17, 36, 18};
-    if (const char* m = std::getenv("CT2X_PREFETCH_MB"))
+    if (const char* m = tuning_env("CT2X_PREFETCH_MB"))
       (void)std::sscanf(m, "%lf,%lf,%lf,%lf", &mb[0], &mb[1], &mb[2], &mb[3]);
     for (int i = 0; i < 4; ++i) prefetch_bytes_[i] = static_cast<int64_t>(mb[i] * 1048576.0);
-    if (const char* g = std::getenv("CT2X_PREFETCH_WGS")) prefetch_wgs_ = std::max(1, std::atoi(g));
+    if (const char* g = tuning_env("CT2X_PREFETCH_WGS")) prefetch_wgs_ = std::max(1, std::atoi(g));
   }
   CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
   check_last_launch("pack_stream_weights");
@@ -1033,8 +1033,8 @@ bool Engine::dense_out_next_norm(const DenseW& w, const QuantIn& cq, int64_t row
                                  const DenseW* next_dense, DecodeState& st) {
   if (tp_ || taps_ || !dec_.pre_norm || next_ln == nullptr || !next_ln->present ||
       next_dense == nullptr || !next_dense->quantized || !w.quantized || w.row_parallel ||
-      next_dense->k != w.n || !rowgemv_ln_applicable(rows, w.n, w.k))
-    return false;
+      next_dense->k != w.n || w.k != w.n || !rowgemv_ln_applicable(rows, w.n, w.k))
+    return false;  // (w.k == w.n: the launch quantises in place, row strides must agree)
   const double M = double(rows), N = double(w.n), K = double(w.k);
   // algorithmic bytes: the weight once (every row re-reads it from L2), rows in / out
   begin_kernel("rowgemv_norm_quantize", M * K + N * K + 16 * N + 8 * M + 8 * M * N + M * N,
@@ -1058,7 +1058,8 @@ void Engine::dense_awq(const DenseW& w, const float* x, int64_t m, int act, cons
   const double bytes = double(w.n) * w.k / 2 + 2.0 * m * w.k + 4.0 * m * w.n;
   begin_kernel(w.awq == 1 ? "awq_gemm" : "awq_gemv", bytes, 2.0 * m * w.n * w.k, m, w.n, w.k);
   if (w.awq == 1)
-    launch_awq_gemm(ws->hbuf, w.aq_w, w.aq_s, w.aq_z, m, w.k, w.n, w.aq_group, nullptr, y, cur_stream());
+    launch_awq_gemm(ws->hbuf, w.aq_w, w.aq_s, w.aq_z, m, w.k, w.n, w.aq_group, nullptr, y, cur_stream(),
+                    ws->awq_ws);
   else
     launch_awq_gemv(ws->hbuf, w.aq_w, w.aq_s, w.aq_z, m, w.k, w.n, w.aq_group, w.aq_zw, w.aq_sw,
                     nullptr, y, cur_stream());
@@ -1312,7 +1313,12 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     st->tp_amax = alloc<float>(*st, wrows);
   }
   st->qbuf = alloc<int8_t>(*st, wrows * std::max(d, wffn));
-  if (has_awq_) st->hbuf = alloc<uint16_t>(*st, wrows * std::max(d, wffn));
+  if (has_awq_) {
+    st->hbuf = alloc<uint16_t>(*st, wrows * std::max(d, wffn));
+    // split-K slices of the GEMM-layout AWQ Dense: owned by the session, so that a captured step
+    // neither allocates nor replays a pointer the allocator has handed to someone else
+    st->awq_ws = alloc<float>(*st, static_cast<int64_t>(kAwqGemmWorkspaceFloats));
+  }
   st->qscale = alloc<float>(*st, wrows);
   st->logits = alloc<float>(*st, rows * V);
   st->d_ids = alloc<int32_t>(*st, rows);
@@ -1343,7 +1349,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   // table (CT2X_BEAM_ANCESTRY=0: the one-launch gather between two buffer sets).
   if (beam > 1) {
     static const bool allowed = [] {
-      const char* e = std::getenv("CT2X_BEAM_ANCESTRY");
+      const char* e = tuning_env("CT2X_BEAM_ANCESTRY");
       return e == nullptr || e[0] != '0';
     }();
     bool ok = allowed;
@@ -1743,6 +1749,15 @@ void Engine::launch_step(DecodeState& st) {
   st.pf_active = true;
   st.pf_pending = PrefetchArgs();
   pf_state_ = &st;
+  // (a launch that throws must not leave the worker thread pointing at a dead session)
+  struct PfGuard {
+    DecodeState& s;
+    ~PfGuard() {
+      s.pf_active = false;
+      s.pf_pending = PrefetchArgs();
+      Engine::pf_state_ = nullptr;
+    }
+  } pf_guard{st};
   const bool split_quant = !tp_ && rows <= 32 && !dec_.layers.empty() &&
                            dec_.layers[0].ffn.l0_noact.present;
   // ... and so do the feed-forward blocks whose inner Quantize is folded into the consuming GEMM
@@ -2087,7 +2102,13 @@ void Engine::step(DecodeState& st, bool graph) {
       hipGraph_t dead = nullptr;
       (void)hipStreamEndCapture(cur_stream(), &dead);
       if (dead) (void)hipGraphDestroy(dead);
-      throw;
+      if (!tp_) throw;
+      // tensor parallel: a collective that refuses capture throws from inside launch_step; the
+      // capture recorded, it did not execute - this session runs eagerly from here on
+      (void)hipGetLastError();
+      st.graph_failed = true;
+      step(st, false);
+      return;
     }
     if (tp_) {
       // a collective library that refuses capture must not take the session down: this state

@@ -396,6 +396,7 @@ struct DecodeState {
   float* tp_amax = nullptr;  // tensor parallel: per-row absmax [rows]
   int8_t* qbuf = nullptr;    // [rows, max(d, ffn)]
   uint16_t* hbuf = nullptr;  // [rows, max(d, ffn)] float16 activations (AWQ Dense only)
+  float* awq_ws = nullptr;   // split-K slices of the AWQ GEMM (kAwqGemmWorkspaceFloats)
   float* qscale = nullptr;   // [rows]
   int32_t* d_ids = nullptr;  // [rows] next input ids
   int32_t* d_step = nullptr; // [1]

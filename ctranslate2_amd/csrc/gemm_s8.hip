@@ -693,7 +693,7 @@ bool gemm_s8_qol_applicable(int64_t m, int64_t n, int64_t k) {
 // speed: less host-side graph work); CT2X_QUANT_ON_LOAD=0 restores the launch (bit-identical).
 bool gemm_s8_qol_enabled() {
   static const bool enabled = [] {
-    const char* e = std::getenv("CT2X_QUANT_ON_LOAD");
+    const char* e = tuning_env("CT2X_QUANT_ON_LOAD");
     return e == nullptr || e[0] != '0';
   }();
   return enabled;
@@ -704,7 +704,7 @@ bool gemm_s8_qol_enabled() {
 // (see the kernel); CT2X_NORM_FUSION=0 restores the separate norm launch (bit-identical).
 bool gemm_s8_norm_fusion_enabled() {
   static const bool enabled = [] {
-    const char* e = std::getenv("CT2X_NORM_FUSION");
+    const char* e = tuning_env("CT2X_NORM_FUSION");
     return e == nullptr || e[0] != '0';
   }();
   return enabled;
@@ -715,7 +715,7 @@ bool gemm_s8_norm_fusion_enabled() {
 // 3.65 - 3.66 without - the guide's gain belongs to LDS-DMA streams, register loads lose. Off.
 static bool nt_weights(int64_t, int64_t) {
   static const bool on = [] {
-    const char* e = std::getenv("CT2X_NT_WEIGHTS");
+    const char* e = tuning_env("CT2X_NT_WEIGHTS");
     return e != nullptr && e[0] == '1';
   }();
   return on;
@@ -737,11 +737,11 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
   }
   // Debug override of the tile choice (CT2X_GEMM_TILE=32|64|128).
   static const int forced = [] {
-    const char* e = std::getenv("CT2X_GEMM_TILE");
+    const char* e = tuning_env("CT2X_GEMM_TILE");
     return e ? std::atoi(e) : 0;
   }();
   const int64_t sel = forced ? (forced <= 32 ? 1 : (forced <= 64 ? 33 : 65)) : m;
-  static const bool no_skinny = std::getenv("CT2X_NO_SKINNY_GEMM") != nullptr;
+  static const bool no_skinny = tuning_env("CT2X_NO_SKINNY_GEMM") != nullptr;
   if (ep.norm_x != nullptr) {
     // Norm + Quantize prologue (gemm_s8_norm_applicable): decode rows of a pre-norm Dense.
     if (!(mfma_ok && gemm_s8_norm_applicable(m, n, k) && ep.mode == 1 && ep.b2 == nullptr))
@@ -826,7 +826,7 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
     // measured best at every decode shape of Transformer-base ([32|64|128, 512] x 512: 2.7 us
     // against 3.2 / 4.5 / 7.0 us with 2 / 4 / 8 tiles per workgroup; tools/kernel_bench.cpp).
     static const int mt_env = [] {
-      const char* e = std::getenv("CT2X_SKINNY_MT");
+      const char* e = tuning_env("CT2X_SKINNY_MT");
       const int v = e ? std::atoi(e) : 0;
       return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;
     }();
@@ -838,7 +838,7 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
     }
     // Tuning override (tools/gemm_bench.cpp): CT2X_SKINNY_CFG="NT,WAVES,U" for m <= 32.
     static const int cfg = [] {
-      const char* e = std::getenv("CT2X_SKINNY_CFG");
+      const char* e = tuning_env("CT2X_SKINNY_CFG");
       int nt = 0, wv = 0, u = 0;
       if (e && std::sscanf(e, "%d,%d,%d", &nt, &wv, &u) == 3) return nt * 10000 + wv * 100 + u;
       return 0;
@@ -893,7 +893,7 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
 #undef CT2X_SKINNY
     return;
   }
-  static const bool no_big = std::getenv("CT2X_NO_BIG_GEMM") != nullptr;
+  static const bool no_big = tuning_env("CT2X_NO_BIG_GEMM") != nullptr;
   if (!forced && !no_big && (reinterpret_cast<uintptr_t>(a) & 15) == 0 &&
       gemm_s8_big_applicable(m, n, k)) {
     launch_gemm_s8_big(a, b, M, N, K, ep, stream);

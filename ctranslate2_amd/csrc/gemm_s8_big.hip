@@ -318,7 +318,7 @@ bool gemm_s8_big_applicable(int64_t m, int64_t n, int64_t k) {
 void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
                         const GemmS8Epilogue& ep_in, hipStream_t stream) {
   static const bool plain_division = [] {
-    const char* e = std::getenv("CT2X_EXACT_DIV");
+    const char* e = tuning_env("CT2X_EXACT_DIV");
     return e != nullptr && e[0] == '0';
   }();
   GemmS8Epilogue ep = ep_in;
@@ -326,7 +326,7 @@ void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
   const int tiles_m = (M + BIG_BM - 1) / BIG_BM, tiles_n = (N + BIG_BN - 1) / BIG_BN;
   const int act = (ep.mode == 1 && ep.act > 0) ? ep.act : -1;
   static const int ablate = [] {
-    const char* e = std::getenv("CT2X_BIG_GEMM_ABLATE");
+    const char* e = tuning_env("CT2X_BIG_GEMM_ABLATE");
     return e ? std::atoi(e) : 0;
   }();
   if (ablate == 1) return launch_big<-1, 1>(a, b, M, N, K, tiles_m, tiles_n, ep, stream);

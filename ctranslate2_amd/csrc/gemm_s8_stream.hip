@@ -322,10 +322,7 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
   StreamPlan plan;
   if (!plan_stream(N, K, dual, device_cus(), &plan))
     throw Error("launch_gemm_s8_stream: shape outside the streaming form");
-  // TIMING EXPERIMENT ONLY (results are wrong): read the row-major weight as if it were packed
-  static const bool fake_packed = std::getenv("CT2X_STREAM_FAKE_PACKED") != nullptr;
-  GemmS8Epilogue ep = ep_in;
-  if (fake_packed) ep.packed_b = true;
+  const GemmS8Epilogue& ep = ep_in;
 #define CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, PACKED)                                               \
   do {                                                                                            \
     auto fn = gemm_s8_stream_kernel<NT, 16, KS, P, DUAL, PACKED>;                                 \

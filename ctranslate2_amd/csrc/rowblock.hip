@@ -163,7 +163,7 @@ void launch_rowgemv(const RowGemvLnArgs& a, int64_t rows, int waves, hipStream_t
 // (Transformer-base: 80.0k -> 68.2k tokens/s). Kept behind CT2X_ROW_FUSION=1 (bit-identical).
 bool rowblock_disabled() {
   static const bool on = [] {
-    const char* e = std::getenv("CT2X_ROW_FUSION");
+    const char* e = tuning_env("CT2X_ROW_FUSION");
     return e != nullptr && e[0] == '1';
   }();
   return !on;

@@ -8,6 +8,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -57,6 +58,17 @@ void* device_malloc(size_t bytes);
 void device_free(void* ptr);
 void clear_cache();
 int64_t allocated_bytes();
+
+// Experiment switches (kernel-variant A/B knobs of tools/*): read only by a library built with
+// `make TUNING=1`; the shipped library ignores them (returns nullptr) and runs the measured winners.
+inline const char* tuning_env(const char* name) {
+#ifdef CT2X_TUNING
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // Launch bookkeeping used by the engine to report kernels/step.
 void check_last_launch(const char* what);

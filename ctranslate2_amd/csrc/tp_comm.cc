@@ -44,9 +44,21 @@ struct UniqueIdByValue {
 RcclApi& rccl() {
   static RcclApi api = [] {
     RcclApi a;
-    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // A process that already carries an RCCL (torch.distributed maps its own librccl.so) must not
+    // get a second copy: first look for the library that is ALREADY loaded (RTLD_NOLOAD, sonames
+    // in the order a loader would have registered them), only then load one.
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      a.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
       if (a.handle) break;
+    }
+    if (!a.handle && dlsym(RTLD_DEFAULT, "ncclAllReduce") != nullptr)
+      a.handle = dlopen(nullptr, RTLD_NOW);  // linked into the process under another path
+    if (!a.handle) {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
+                               "/opt/rocm/lib/librccl.so"}) {
+        a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (a.handle) break;
+      }
     }
     if (!a.handle)
       throw Error(std::string("tensor parallelism needs RCCL (librccl.so): ") + dlerror());

@@ -19,7 +19,7 @@ built = pytest.mark.skipif(not os.path.exists(BINARY),
 
 # Device::CUDA ops the stubs define as throwers (no int8 / float32 Transformer reaches them), ops
 # whose test drives a 16-bit arm, and fixtures this repository does not carry.
-NOT_PROVIDED = ("FlashAttention", "GumbelMax")
+NOT_PROVIDED = ("FlashAttention",)
 
 
 def _run(flt):
