@@ -137,6 +137,63 @@ def roofline_entry(label, st):
     return entry
 
 
+def prefill_gemm_leg():
+    """The MFMA-bound face of the same Dense (north_star's ">= 70 % of the int8-MFMA
+    roofline for the projection GEMMs"): the fused Quantize'd-input GEMM + Dequantize (+ activation)
+    launch at the two M >= 1024 shapes of the path - the Llama-3-8B prefill FFN-in projection
+    [2048 x 4096] x [14336 x 4096]^T with the Swish epilogue, and Transformer-base's cross-attention
+    K/V projection [1024 x 512] x [1024 x 512]^T - random int8 operands resident in HBM, fp32 result
+    written to HBM, HIP events on the launch stream around `reps` back-to-back launches.
+    algorithmic ops = 2 M N K; bytes = M K + N K + 4 N + 4 M + 4 M N."""
+    import ctypes as C
+    import torch
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    out = {}
+    L.ct2x_thread_stream.restype = C.c_void_p
+    stream = C.c_void_p(L.ct2x_thread_stream())
+    for name, (m, n, k, act, reps) in {"l8_prefill_ffn_in_swish": (2048, 14336, 4096, 2, 20),
+                                       "tb_cross_kv": (1024, 1024, 512, -1, 200)}.items():
+        g = torch.Generator(device="cuda").manual_seed(m + n + k)
+        qa = torch.randint(-127, 128, (m, k), dtype=torch.int8, device="cuda", generator=g)
+        w = torch.randint(-127, 128, (n, k), dtype=torch.int8, device="cuda", generator=g)
+        sa = torch.rand(m, device="cuda", generator=g) * 20 + 1
+        sw = torch.rand(n, device="cuda", generator=g) * 200 + 50
+        y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+
+        def launch():
+            _lib.check(L.ct2x_gemm_s8_dequant(C.c_void_p(qa.data_ptr()), C.c_void_p(sa.data_ptr()),
+                                              C.c_void_p(w.data_ptr()), C.c_void_p(sw.data_ptr()), None, None,
+                                              C.c_int64(m), C.c_int64(n), C.c_int64(k), C.c_int(act),
+                                              C.c_void_p(y.data_ptr()), C.c_int(0), stream))
+        for _ in range(3):
+            launch()
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _lib.check(L.ct2x_event_create(C.byref(e0)))
+        _lib.check(L.ct2x_event_create(C.byref(e1)))
+        _lib.check(L.ct2x_event_record(e0, stream))
+        for _ in range(reps):
+            launch()
+        _lib.check(L.ct2x_event_record(e1, stream))
+        ms = C.c_float()
+        _lib.check(L.ct2x_event_elapsed_ms(e0, e1, C.byref(ms)))
+        L.ct2x_event_destroy(e0)
+        L.ct2x_event_destroy(e1)
+        us = ms.value * 1e3 / reps
+        ops = 2.0 * m * n * k
+        nbytes = m * k + n * k + 4 * n + 4 * m + 4.0 * m * n
+        tops = ops / (us * 1e-6) / 1e12
+        out[name] = {"m": m, "n": n, "k": k, "activation": {2: "swish", -1: "none"}[act],
+                     "avg_us": us, "launches": reps,
+                     "roofline": {"bound": "mfma", "achieved": tops, "peak": INT8_MFMA_PEAK_TOPS,
+                                  "unit": "TOP/s", "frac": tops / INT8_MFMA_PEAK_TOPS,
+                                  "ops_per_launch": ops, "bytes_per_launch": nbytes,
+                                  "hbm_frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+        del qa, w, y
+    return out
+
+
 def physical_cores():
     """Distinct (socket, core) pairs of /proc/cpuinfo; falls back to os.cpu_count()."""
     try:
@@ -345,6 +402,11 @@ def main():
                          "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["total_ms"] else None}
                         for k, v in top],
             }
+        if world == 1 and not args.no_profile and args.compute_type == "int8":
+            try:
+                result["config"]["prefill_gemm"] = prefill_gemm_leg()
+            except Exception as e:  # never break the headline line
+                result["config"]["prefill_gemm"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_l8 and args.beam == 1 and args.compute_type == "int8":
             # BASELINE.json configs[2] (Llama-3 8B shape, int8, batch 16 greedy) under the same
             # clock: tools/bench_l8.py in its own process (7.5 GB of weights), two timed calls of

@@ -340,7 +340,8 @@ void dispatch(const AttnKernelArgs& a, hipStream_t stream) {
 
 void launch_attention_decode(const AttnDecodeParams& p, hipStream_t stream) {
   if (p.rows == 0) return;
-  if (p.row_amax_out == nullptr && attention_exact_decode_applicable(p, false)) {
+  // (the d_head 128 form emits the producer-side row absmax itself)
+  if ((p.row_amax_out == nullptr || p.dhead == 128) && attention_exact_decode_applicable(p, false)) {
     launch_attention_exact_decode(p, 0, nullptr, nullptr, stream);  // bit-exact vs the CPU reference
     return;
   }
@@ -398,7 +399,11 @@ void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode
 void launch_attention_full(const AttnFullParams& f, hipStream_t stream) {
   if (f.batch * f.tq == 0) return;
   if (attention_exact_full_applicable(f)) {
-    launch_attention_exact_full(f, stream);  // bit-exact vs the CPU reference (d_head 64, tk <= ~300)
+    launch_attention_exact_full(f, stream);  // bit-exact vs the CPU reference (K / V of a head in LDS)
+    return;
+  }
+  if (attention_seq_exact_applicable(f)) {
+    launch_attention_seq_exact(f, stream);  // bit-exact at any length / head size (fp32 MFMA chains)
     return;
   }
   if (attention_prefill_applicable(f)) {

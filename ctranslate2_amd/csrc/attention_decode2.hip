@@ -573,7 +573,7 @@ bool attention_decode2_applicable(const AttnDecodeParams& p, bool fused_quantize
 }
 
 bool attention_decode_emits_row_amax(const AttnDecodeParams& p) {
-  if (attention_exact_decode_applicable(p, false)) return false;  // the exact kernel is preferred
+  if (attention_exact_decode_applicable(p, false)) return p.dhead == 128;  // the exact kernel is preferred
   return attention_decode2_applicable(p, false);
 }
 

@@ -240,6 +240,11 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(
   const bool kSeq = a.seq != 0 &&
                     !(p.one_row_step_ptr != nullptr && *p.one_row_step_ptr == p.one_row_step);
 
+  // Where alpha enters MKL's several-row product: once B is packed (n >= 192, or n > m and
+  // n >= max(k, 12)) the packed keys carry alpha (oracle/ct2_oracle.c orc_matmul, round 3).
+  const bool pack_b = kSeq && p.scale != 1.f &&
+                      (n_keys >= 192 || (n_keys > static_cast<int>(p.kv_group) && n_keys >= (DH > 12 ? DH : 12)));
+
   float acc_out = 0.f;
   CT2X_ATTN_STAMP(0)
   if (active) {
@@ -368,13 +373,17 @@ __global__ __launch_bounds__(512) void attn_x_decode_kernel(
           qv[4 * c + 0] = q4.x; qv[4 * c + 1] = q4.y; qv[4 * c + 2] = q4.z; qv[4 * c + 3] = q4.w;
         }
         if (kSeq) {
+          if (pack_b) {
+#pragma unroll
+            for (int c = 0; c < DH; ++c) kv[c] = kv[c] * p.scale;
+          }
           s = dot_seq<DH>(qv, kv);
         } else if (t < main_n) {
           s = dot_main<DH>(qv, kv);
         } else {
           s = dot_tail<DH>(qv, kv, (t - main_n) != 1);
         }
-        s = s * p.scale;
+        if (!pack_b) s = s * p.scale;
         if (!single) tp[t] = s;
         if (t < n_valid) m_run = fmaxf(m_run, s);
       }
@@ -591,6 +600,7 @@ static bool x_dhead_ok(int64_t dh) { return dh == 4 || dh == 8 || dh == 16 || dh
 
 bool attention_exact_decode_applicable(const AttnDecodeParams& p, bool fused_quantize) {
   if (exact_disabled()) return false;
+  if (p.dhead == 128) return !fused_quantize && attention_exact128_decode_applicable(p);
   if (p.ancestry != nullptr && (p.kv_group != 1 || p.lengths != nullptr)) return false;
   if (!x_dhead_ok(p.dhead) || p.heads < 1 || p.heads_kv < 1 || p.heads % p.heads_kv != 0) return false;
   if (p.rope_sin != nullptr && (p.rope_cos == nullptr || p.rot_dim < 2 || p.rot_dim > p.dhead ||
@@ -649,6 +659,11 @@ static void launch_x(const AttnXArgs& a, size_t lds, hipStream_t stream) {
 
 void launch_attention_exact_decode(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
                                    float* q_scales, hipStream_t stream) {
+  if (p.dhead == 128) {
+    CT2X_CHECK(q_out == nullptr, "attention: the d_head 128 exact kernel has no fused Quantize");
+    launch_attention_exact128_decode(p, stream);
+    return;
+  }
   AttnXArgs a;
   a.p = p;
   a.q_out = q_out;
@@ -753,10 +768,32 @@ __global__ void matmul_x_kernel(const float* __restrict__ a, const float* __rest
         has = true;
       }
       s = y;
-    } else {
+    } else if (trans_b) {
+      // several rows: k-ordered chain; alpha on the sum, or carried by MKL's packed copy of B
+      const bool pack_b = alpha != 1.f && (n >= 192 || (n > m && n >= (k > 12 ? k : 12)));
       s = 0.f;
-      for (int t = 0; t < k; ++t)
-        s = fmaf(A[t], trans_b ? B[static_cast<int64_t>(j) * k + t] : B[static_cast<int64_t>(t) * n + j], s);
+      const float* Bj = B + static_cast<int64_t>(j) * k;
+      if (pack_b) {
+        for (int t = 0; t < k; ++t) s = fmaf(A[t], Bj[t] * alpha, s);
+        c[e] = s;
+        continue;
+      }
+      for (int t = 0; t < k; ++t) s = fmaf(A[t], Bj[t], s);
+    } else {
+      // k-ordered chains over MKL's partition of a long k (384-blocks while > 768 remain, then
+      // ceil / floor halves), blocks added in order
+      int t0 = 0, rem = k;
+      bool first = true;
+      s = 0.f;
+      while (rem > 0) {
+        const int blk = rem > 768 ? 384 : (rem > 384 ? (rem + 1) / 2 : rem);
+        float acc = 0.f;
+        for (int t = t0; t < t0 + blk; ++t) acc = fmaf(A[t], B[static_cast<int64_t>(t) * n + j], acc);
+        s = first ? acc : s + acc;
+        first = false;
+        t0 += blk;
+        rem -= blk;
+      }
     }
     c[e] = (alpha != 1.f) ? s * alpha : s;
   }
@@ -784,6 +821,9 @@ void launch_matmul_exact(const float* a, const float* b, int64_t batch, int64_t 
 
 bool attention_exact_full_applicable(const AttnFullParams& p) {
   if (exact_disabled()) return false;
+  // (this kernel scales the finished sum and adds the keys in one chain: shapes where MKL packs
+  // B or cuts k go to attention_seq_exact.hip)
+  if (mkl_sequence_packs_b(p.tq, p.tk, p.dhead, p.scale) || p.tk > 384) return false;
   if (!x_dhead_ok(p.dhead) || p.heads_kv < 1 || p.heads % p.heads_kv != 0 || p.tk < 1) return false;
   auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!(aligned16(p.k) && aligned16(p.v) && p.k_time_stride % 4 == 0 && p.v_time_stride % 4 == 0 &&

@@ -278,6 +278,11 @@ bool attention_exact_decode_applicable(const AttnDecodeParams& p, bool fused_qua
 void launch_attention_exact_decode(const AttnDecodeParams& p, int quant_mode, int8_t* q_out,
                                    float* q_scales, hipStream_t stream);
 
+// d_head 128 (attention_exact128.hip; Llama-3 geometry): self-attention decode with MKL's one-row
+// forms on 16-lane DPP rows, one workgroup per (row, KV head), optional producer-side row absmax.
+bool attention_exact128_decode_applicable(const AttnDecodeParams& p);
+void launch_attention_exact128_decode(const AttnDecodeParams& p, hipStream_t stream);
+
 // Second-generation decode kernel (attention_decode2.hip: lane = key for QK^T, lane = channel for
 // PV, GQA group per wave); launch_attention_decode[_quantized] route to it when applicable.
 bool attention_decode2_applicable(const AttnDecodeParams& p, bool fused_quantize);
@@ -310,6 +315,11 @@ bool matmul_exact_applicable(int64_t m, int64_t n, int64_t k, bool trans_b);
 void launch_matmul_exact(const float* a, const float* b, int64_t batch, int64_t m, int64_t n,
                          int64_t k, bool trans_b, float alpha, float* c, hipStream_t stream);
 bool attention_exact_full_applicable(const AttnFullParams& p);
+// Any head size / length, on the fp32 matrix cores (attention_seq_exact.hip): bit for bit the
+// reference's MatMul -> SoftMax -> MatMul with MKL's several-row forms (alpha placement, k partition).
+bool mkl_sequence_packs_b(int64_t m, int64_t n, int64_t k, float alpha);
+bool attention_seq_exact_applicable(const AttnFullParams& p);
+void launch_attention_seq_exact(const AttnFullParams& p, hipStream_t stream);
 void launch_attention_exact_full(const AttnFullParams& p, hipStream_t stream);
 
 // Tiled form for d_head 64 / 128 (attention_prefill.hip: 64-query tiles, K/V tiles shared through

@@ -499,17 +499,58 @@ int orc_matmul(const float* a, const float* b, int64_t batch, int64_t m, int64_t
       mkl_qk_m1(A, B, n, k, C);
     } else if (m == 1 && !trans_b && n >= 16) {
       for (int64_t j = 0; j < n; ++j) C[j] = mkl_pv_m1_col(A, B + j, n, k);
-    } else if ((trans_b && m >= 3 && n >= 5 && k < 24 * m) ||
-               (!trans_b && (m >= 2 || n == 4 || n == 8))) {
+    } else if (trans_b && m >= 3 && n >= 5 && k < 24 * m) {
       /* (trans_b with long dot products and few rows, k >= 24 m - e.g. k = 128 with m <= 5 - goes
        * through another MKL kernel that was not recovered: outside the envelope; mapped for
-       * k = 68 .. 256, m = 3 .. 13) */
+       * k = 68 .. 256, m = 3 .. 13)
+       * Where alpha enters (recovered in round 3, one MKL thread per matrix - the regime of
+       * cblas_sgemm_batch_strided whenever batch >= threads; with fewer matrices than threads MKL
+       * splits a matrix and the choice below moves with the thread count): small problems scale
+       * the finished sum, C = alpha * chain(a, b); once B is copied into MKL's packed layout the
+       * copy carries alpha, C = chain(a, RN(alpha * b)). B is packed iff n >= 192, or n > m and
+       * n >= max(k, 12) (mapped for k = 8 .. 256, m = 6 .. 1024, every n = 5 .. 300; for k < 12
+       * the columns 8 .. 11 of a wide problem take a further form: outside the envelope).
+       * Powers of two (d_head 4, 16, 64) cannot tell the two apart. */
+      const int pack_b = alpha != 1.f && (n >= 192 || (n > m && n >= (k > 12 ? k : 12)));
+      if (alpha != 1.f && k < 12 && n > m && n >= 8 && n < 12) {
+        status = -1;
+        continue;
+      }
       for (int64_t i = 0; i < m; ++i)
         for (int64_t j = 0; j < n; ++j) {
           float acc = 0.f;
-          for (int64_t t = 0; t < k; ++t)
-            acc = fmaf(A[i * k + t], trans_b ? B[j * k + t] : B[t * n + j], acc);
+          if (pack_b) {
+            for (int64_t t = 0; t < k; ++t) acc = fmaf(A[i * k + t], B[j * k + t] * alpha, acc);
+          } else {
+            for (int64_t t = 0; t < k; ++t) acc = fmaf(A[i * k + t], B[j * k + t], acc);
+            if (alpha != 1.f) acc = acc * alpha;
+          }
           C[i * n + j] = acc;
+        }
+      continue;
+    } else if (!trans_b && (m >= 2 || n == 4 || n == 8)) {
+      /* k-ordered FMA chains; MKL blocks a long k (recovered in round 3 with the partition
+       * search of tests/test_oracle.py::test_exact_matmul_k_blocking): blocks of 384 while more
+       * than 768 remain, a remainder above 384 is split into ceil / floor halves; every block is
+       * a chain from zero and the blocks are added to C in order. */
+      for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < n; ++j) {
+          float c_acc = 0.f;
+          int64_t t0 = 0, rem = k;
+          int first = 1;
+          while (rem > 0) {
+            int64_t blk;
+            if (rem > 768) blk = 384;
+            else if (rem > 384) blk = (rem + 1) / 2;
+            else blk = rem;
+            float acc = 0.f;
+            for (int64_t t = t0; t < t0 + blk; ++t) acc = fmaf(A[i * k + t], B[t * n + j], acc);
+            c_acc = first ? acc : c_acc + acc;
+            first = 0;
+            t0 += blk;
+            rem -= blk;
+          }
+          C[i * n + j] = c_acc;
         }
     } else {
       status = -1;

@@ -51,3 +51,17 @@ SYNTHETIC_LM = {
         "data_seed": 8, "batch": 6, "prompt_len": 16, "max_len": 16,
     },
 }
+
+# Decoder-only model at the Llama-3-8B geometry (BASELINE.json configs[2]): d_head 128, GQA 32 / 8,
+# RMSNorm depth 4096, SwiGLU 14336 - two layers, small vocabulary (tests/golden/
+# make_golden_llama3_geometry.py; the GPU test rebuilds the ~450 MB model directory from the seed).
+LLAMA3_GEOMETRY = {
+    "model": dict(num_layers=2, d_model=4096, ffn_dim=14336, num_heads=32, num_heads_kv=8,
+                  vocab_size=4096, seed=11, w_std=0.02),
+    "cases": {
+        # prefill: MKL scales the finished sum (m = n = 40 < 192)
+        "p40": {"data_seed": 12, "batch": 4, "prompt_len": 40, "max_len": 24, "teacher_forced": True},
+        # prefill: MKL packs K, the packed copy carries the scale (m = n = 200 >= 192)
+        "p200": {"data_seed": 13, "batch": 2, "prompt_len": 200, "max_len": 12, "teacher_forced": False},
+    },
+}

@@ -583,7 +583,11 @@ def test_attention_decode(gpu, rows, heads, heads_kv, dhead, t_max, kv_group):
         assert np.array_equal(y2, yo2)
     else:
         np.testing.assert_allclose(y, yo, rtol=2e-5, atol=2e-6)
-        np.testing.assert_allclose(y2, yo2, rtol=2e-5, atol=2e-6)
+        if dhead == 128 and kv_group == 1:
+            # attention_exact128.hip (self-attention form: one cache length, no length vector)
+            assert np.array_equal(y2, yo2)
+        else:
+            np.testing.assert_allclose(y2, yo2, rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("rows,kv_group,dhead", [(32, 1, 64), (24, 3, 64), (128, 4, 64), (8, 1, 4),
@@ -609,12 +613,36 @@ def test_attention_decode_exact_every_length(gpu, rows, kv_group, dhead):
         assert np.array_equal(y, O.attention_decode(q, k, v, lengths, 0, kv_group, scale)), t_max
 
 
+@pytest.mark.parametrize("group", [1, 2, 4, 8])
+def test_attention_decode_exact128_every_length(gpu, group):
+    """d_head 128 (Llama-3 geometry), every cache length 1..140 and a few long ones: MKL's main /
+    tail-A / tail-B dot forms on 16-lane DPP rows, the block-of-eight P.V, every GQA group size -
+    bit for bit against the oracle (pinned against the reference library for k = 128)."""
+    import _gpuops as G
+    rng = np.random.default_rng(100 + group)
+    scale = float(np.float32(1.0 / np.sqrt(128)))
+    heads_kv = 2
+    heads = heads_kv * group
+    for t_max in list(range(1, 141)) + [255, 256, 257, 600, 1031]:
+        rows = 3 if t_max < 200 else 2
+        q = rng.standard_normal((rows, heads, 128)).astype(np.float32)
+        k = rng.standard_normal((rows, heads_kv, t_max, 128)).astype(np.float32)
+        v = rng.standard_normal((rows, heads_kv, t_max, 128)).astype(np.float32)
+        y = G.attention_decode(q, k, v, None, t_max, 1, scale)
+        assert np.array_equal(y, O.attention_decode(q, k, v, None, t_max, 1, scale)), t_max
+
+
 @pytest.mark.parametrize("b,tq,tk,h,hkv,dh,causal", [
     (4, 32, 32, 8, 8, 64, False),     # Transformer-base encoder tile
     (3, 128, 128, 8, 2, 128, True),   # Llama-style prefill: GQA, causal
     (2, 100, 100, 4, 4, 64, True),    # ragged query tile (100 = 64 + 36)
     (2, 70, 45, 4, 2, 128, False),    # Tq != Tk
     (2, 20, 20, 2, 2, 32, True),      # head size of the per-row kernel
+    (1, 400, 400, 2, 1, 128, True),   # MKL packs K (n >= 192) and cuts the P.V chain (400 > 384)
+    (1, 200, 200, 2, 2, 64, False),   # packed K at d_head 64 (power-of-two scale: same bits)
+    (2, 150, 150, 2, 1, 32, True),    # d_head 32: scale not a power of two, m == n < 192
+    (1, 100, 160, 2, 2, 32, False),   # n > m, n >= k: packed K below 192 keys
+    (1, 40, 1200, 1, 1, 16, False),   # long memory: three blocks of the k partition
 ])
 def test_attention_full(gpu, b, tq, tk, h, hkv, dh, causal):
     """Sequence-mode attention against a float64 statement of dot_product_attention
@@ -648,8 +676,9 @@ def test_attention_full(gpu, b, tq, tk, h, hkv, dh, causal):
             pmat = np.divide(e, den, out=np.zeros_like(e), where=den > 0)
             ref[bi, :, hi] = pmat @ vv
     np.testing.assert_allclose(y, ref, rtol=2e-5, atol=3e-6)
-    if dh in (4, 8, 16, 32, 64):
-        # bit for bit against the reference's MatMul -> SoftMax -> MatMul chain (oracle restatement)
+    if dh in (4, 8, 16, 32, 64, 128):
+        # bit for bit against the reference's MatMul -> SoftMax -> MatMul chain (oracle restatement;
+        # attention_exact.hip in its envelope, attention_seq_exact.hip - fp32 MFMA chains - beyond)
         for bi in range(b):
             for hi in range(h):
                 sc = O.matmul(q[bi, :, hi][None], k[bi, :, hi // group][None], True, scale)[0]

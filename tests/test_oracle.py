@@ -260,6 +260,40 @@ def test_exact_matmul_sequence():
                               _bits(R.matmul(a, b, tb, 0.125 if tb else 1.0))), (m, n, k, tb)
 
 
+def test_exact_matmul_sequence_alpha_forms():
+    """Where alpha enters MKL's sequence-mode product (round 3): scaled sum for small problems,
+    carried by the packed copy of B once n >= 192 or (n > m and n >= max(k, 12)). One MKL thread
+    per matrix = the batched regime (batch >= threads), checked both ways here. Head sizes whose
+    scale is not a power of two (32, 128, 96) are the ones that can tell."""
+    R = _ref()
+    rng = np.random.default_rng(31)
+    shapes = [(6, 127, 128), (6, 128, 128), (100, 128, 128), (128, 128, 128), (128, 129, 128),
+              (150, 151, 128), (191, 191, 128), (192, 192, 128), (300, 200, 128), (256, 256, 128),
+              (20, 20, 32), (4, 31, 32), (4, 32, 32), (4, 40, 32), (40, 41, 32), (200, 192, 32),
+              (16, 95, 96), (16, 96, 96), (33, 300, 64), (6, 12, 12), (6, 11, 12)]
+    import os
+    for threads, batch in ((os.cpu_count() or 4, 16), (1, 2)):
+        R.set_num_threads(threads)
+        for m, n, k in shapes:
+            alpha = float(np.float32(1.0 / np.sqrt(k)))
+            a = rng.standard_normal((batch, m, k)).astype(np.float32)
+            b = rng.standard_normal((batch, n, k)).astype(np.float32)
+            assert np.array_equal(_bits(O.matmul(a, b, True, alpha)), _bits(R.matmul(a, b, True, alpha))), (threads, m, n, k)
+    R.set_num_threads(os.cpu_count() or 4)
+
+
+def test_exact_matmul_k_blocking():
+    """Sequence-mode P.V with long rows: MKL's k partition (384-blocks while > 768 remain, then
+    ceil / floor halves above 384), every block a chain from zero, blocks added in order."""
+    R = _ref()
+    rng = np.random.default_rng(32)
+    for m, n, k in [(16, 128, 384), (16, 128, 385), (16, 128, 389), (8, 64, 500), (128, 128, 768),
+                    (16, 128, 769), (16, 64, 1024), (5, 128, 1153), (16, 128, 2049), (3, 32, 4097)]:
+        p = rng.random((9, m, k)).astype(np.float32)
+        v = rng.standard_normal((9, k, n)).astype(np.float32)
+        assert np.array_equal(_bits(O.matmul(p, v, False, 1.0)), _bits(R.matmul(p, v, False, 1.0))), (m, n, k)
+
+
 def test_matmul_envelope_is_explicit():
     with pytest.raises(ValueError):   # one-row form: k % 4 != 0 was not recovered
         O.matmul(np.zeros((1, 1, 130), np.float32), np.zeros((1, 5, 130), np.float32), True)
