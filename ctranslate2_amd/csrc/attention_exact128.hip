@@ -18,13 +18,13 @@
 // MI355X mapping - the 16 accumulators of MKL's dot product ARE the 16 lanes of a DPP row:
 //   * one workgroup (8 waves) per (row, KV head): the G query heads of a GQA group share every K
 //     and V byte the workgroup reads (the reference replicates the KV heads, attention.cc:291-295);
+//   * K and V travel global -> LDS in tiles of 64 rows by global_load_lds_dwordx4 (1 KB per wave
+//     instruction, double buffered, the next tile in flight under the arithmetic of this one);
 //   * QK^T: a 16-lane row owns one key at a time - lane l holds channels l + 1, l + 17, ... of the
-//     key in 8 registers, straight from global memory (64-byte segments, no LDS staging, no
-//     barrier), q of all G heads in G x 8 registers; the 16-accumulator tree is four row_shl DPP
-//     adds. A wave works on 4 keys per pass, the 8 waves on 32, two passes of loads in flight;
+//     key in 8 registers (conflict-free 4-byte LDS reads), q of all G heads in G x 8 registers; the
+//     16-accumulator tree is four row_shl DPP adds. A wave works on 4 keys per pass;
 //   * SoftMax: one wave per head on the scores in LDS;
-//   * P.V: lane = (head of the group, channel) - the G lanes that need V[t][c] read the same
-//     address, so V is fetched once; 16 keys per batch, two batches in flight.
+//   * P.V: lane = (head of the group, channel), values from the LDS tile.
 // No matrix cores: the order of every addition is prescribed; the kernel is bound by the K / V
 // stream (2 * T * 512 B per (row, KV head)) and by the dependent add chains of the order.
 
@@ -33,6 +33,7 @@
 #include "runtime.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <float.h>
 
@@ -44,10 +45,21 @@ constexpr int X128_DH = 128;
 constexpr int X128_WAVES = 8;
 constexpr int X128_VB = 16;  // V rows per batch
 
+// tools/attn128_probe.cpp defines this to stamp the phases with s_memtime
+#ifndef CT2X_X128_STAMP
+#define CT2X_X128_STAMP(i)
+#define CT2X_X128_TICK(i)
+#endif
+// tools/attn128_probe.cpp: timing experiments that end the kernel after phase N (results are wrong)
+#ifndef CT2X_X128_STOP_AFTER
+#define CT2X_X128_STOP_AFTER 99
+#endif
+
 struct AttnX128Args {
   AttnDecodeParams p;
   int group;   // query heads per KV head
   int t_pad;   // score slots per head (multiple of 16, >= keys + 16)
+  int n_buf;   // K / V tiles in the LDS ring
 };
 
 // a[l] + a[l + w] for the lanes l < w of every 16-lane row (w = 8, 4, 2, 1): the sum lands in lane
@@ -93,6 +105,113 @@ __device__ __forceinline__ float x128_dot(const float (&qr)[8], const float (&kr
   return s + p0;
 }
 
+// The main form for the G heads of the group at once (branch free; the heads' chains interleave).
+template <int G>
+__device__ __forceinline__ void x128_dot_main(const float (&qr)[G][8], const float (&kr)[8], int l,
+                                              float (&out)[G]) {
+  float acc[G], last[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    last[g] = qr[g][7] * kr[7];                              // lane 15: q0 * k0
+    const float p0 = dpp_move<0x121, 0xf>(0.f, last[g]);     // row_ror:1 - lane 0 <- lane 15
+    acc[g] = (l == 0) ? p0 : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = fmaf(qr[g][i], kr[i], acc[g]);
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = acc[g] + dpp_move<0x108, 0xf>(0.f, acc[g]);
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = acc[g] + dpp_move<0x104, 0xf>(0.f, acc[g]);
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = acc[g] + dpp_move<0x102, 0xf>(0.f, acc[g]);
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = acc[g] + dpp_move<0x101, 0xf>(0.f, acc[g]);
+  // second tree: lane 0 fuses its product onto the first tree's sum, lanes 1 .. 14 hold rounded
+  // products, lane 15 holds 0. Branch free: fma(q, k, -0) == RN(q * k) for every q * k (also for a
+  // zero product of either sign), so ONE fma with a per-lane addend serves lanes 0 .. 14.
+  float r[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float addend = (l == 0) ? acc[g] : -0.f;
+    const float f = fmaf(qr[g][7], kr[7], addend);
+    r[g] = (l < 15) ? f : 0.f;
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) r[g] = r[g] + dpp_move<0x108, 0xf>(0.f, r[g]);
+#pragma unroll
+  for (int g = 0; g < G; ++g) r[g] = r[g] + dpp_move<0x104, 0xf>(0.f, r[g]);
+#pragma unroll
+  for (int g = 0; g < G; ++g) r[g] = r[g] + dpp_move<0x102, 0xf>(0.f, r[g]);
+#pragma unroll
+  for (int g = 0; g < G; ++g) out[g] = r[g] + dpp_move<0x101, 0xf>(0.f, r[g]);
+}
+
+// MKL's "main" one-row dot product with FOUR lanes per key (round 3, second form: the 16-lane form
+// above spends most of its instructions on the two 16-way trees; here a lane owns four of MKL's
+// sixteen accumulators, the trees are two quad permutes and three in-lane adds, and a wave works
+// on 16 keys per pass). Lane j of a quad holds channels 16 c + 4 j + e (c = 0 .. 7, e = 0 .. 3) of
+// the key (kq[c][e]) and of the query (qq[c][e]); channel t >= 1 belongs to MKL accumulator
+// (t - 1) % 16 = (4 j + e - 1) % 16:  lane 0: {15, 0, 1, 2}, lane 1: {3 .. 6}, lane 2: {7 .. 10},
+// lane 3: {11 .. 14}. Channel 0 seeds accumulator 0; channels 1 .. 112 accumulate; the tree
+// 8 / 4 / 2 / 1 gives s; the 15 channels 113 .. 127 go through a second tree whose element 0 fuses
+// its product onto s (oracle/ct2_oracle.c mkl_dot_main). Result in lane 0 of the quad.
+__device__ __forceinline__ float x128_quad_tree(const float (&x)[4], int j) {
+  // level 1: a[l] += a[l + 8] = quad lane ^ 2 (a7 + a15 lands in lane 0 slot 0); level 2:
+  // a[l] += a[l + 4] = quad lane ^ 1; levels 3, 4 in lane 0: (e1 + e3) + (e2 + e0)
+  float y[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y[e] = x[e] + dpp_move<0x4E, 0xf>(0.f, x[e]);   // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y[e] = y[e] + dpp_move<0xB1, 0xf>(0.f, y[e]);   // quad_perm [1,0,3,2]
+  (void)j;
+  return (y[1] + y[3]) + (y[2] + y[0]);
+}
+
+template <int H>
+__device__ __forceinline__ void x128_dot_main_quad(const float (&qq)[H][8][4], const v4f (&kq)[8], int j,
+                                                   float (&out)[H]) {
+  float acc[H][4];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    // chunk 0: channel 0 (lane 0, e = 0) is the seed of accumulator 0 (lane 0, e = 1); accumulator
+    // 15 (lane 0, e = 0) starts at channel 16
+    // (accumulators start at +0 and take an FMA - fma(q, k, +0), not the bare product: the two
+    // differ in the sign of a zero product)
+    const float p0 = qq[h][0][0] * kq[0][0];
+    const float f0 = fmaf(qq[h][0][0], kq[0][0], 0.f);
+    acc[h][0] = (j == 0) ? 0.f : f0;
+    acc[h][1] = fmaf(qq[h][0][1], kq[0][1], (j == 0) ? p0 : 0.f);
+    acc[h][2] = fmaf(qq[h][0][2], kq[0][2], 0.f);
+    acc[h][3] = fmaf(qq[h][0][3], kq[0][3], 0.f);
+  }
+#pragma unroll
+  for (int c = 1; c < 7; ++c)
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[h][e] = fmaf(qq[h][c][e], kq[c][e], acc[h][e]);
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    // channel 112 (chunk 7, lane 0, e = 0) is the last element of accumulator 15
+    const float f = fmaf(qq[h][7][0], kq[7][0], acc[h][0]);
+    acc[h][0] = (j == 0) ? f : acc[h][0];
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float s = x128_quad_tree(acc[h], j);             // lane 0
+    // second tree: r[4 j + e - 1] = q k of channel 112 + 4 j + e; r[0] (lane 0, e = 1) fuses onto s;
+    // r[15] (lane 0, e = 0) = 0. fma(q, k, -0) == RN(q k) bit for bit.
+    float r[4];
+    r[0] = (j == 0) ? 0.f : qq[h][7][0] * kq[7][0];
+    r[1] = fmaf(qq[h][7][1], kq[7][1], (j == 0) ? s : -0.f);
+    r[2] = qq[h][7][2] * kq[7][2];
+    r[3] = qq[h][7][3] * kq[7][3];
+    out[h] = x128_quad_tree(r, j);
+  }
+}
+
 // vectorized_reduce_all<AVX2> over e[0 .. size): eight strided partial sums, 4 / 2 / 1 tree, scalar
 // tail (device_utils.h ordered_sum8), with the addends of a chain requested ahead of its adds.
 __device__ __forceinline__ float x128_ordered_sum8(const float* e, int size) {
@@ -116,36 +235,104 @@ __device__ __forceinline__ float x128_ordered_sum8(const float* e, int size) {
   return acc;
 }
 
+typedef __attribute__((address_space(3))) void x128_lds_void;
+typedef const __attribute__((address_space(1))) void x128_glb_void;
+
+constexpr int X128_TILE = 64;                    // keys per staged K / V tile
+constexpr int X128_TILE_FLOATS = X128_TILE * X128_DH;  // 32 KB
+
+// One K or V tile of 64 cache rows, global -> LDS by global_load_lds_dwordx4 (1 KB per wave
+// instruction, no staging registers; measured: with per-lane dword loads this kernel was bound by
+// the ISSUE of its ~2600 vector-memory instructions per workgroup - 19k cycles for QK^T and 29k for
+// P.V at 255 keys, profiles/r03_attn128_probe_a.txt - not by bytes or arithmetic). Wave w moves the
+// rows 8 w .. 8 w + 7, two per instruction: lane -> (row parity, 16-byte unit). The DMA writes LDS
+// lane-linearly, so the bank swizzle is applied to the SOURCE address: row r is stored rotated by
+// 16 (r & 3) floats, which puts the four key rows that one 16-lane group of a ds_read_b128 touches
+// (QK^T: four lanes per key) on four different 64-byte bank quarters.
+// Rows past the cache are clamped to the allocation (t_max); they never enter a result.
+__device__ __forceinline__ void x128_stage(const float* base, int kvs, int t0, int t_max, float* tile,
+                                           int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 2 * (wave * 4 + j) + (lane >> 5);
+    const int u = ((lane & 31) + 4 * (r & 3)) & 31;  // source unit of LDS unit (lane & 31)
+    const int t = min(t0 + r, t_max - 1);
+    __builtin_amdgcn_global_load_lds((x128_glb_void*)(base + static_cast<int64_t>(t) * kvs + 4 * u),
+                                     (x128_lds_void*)(tile + (wave * 4 + j) * 256), 16, 0, 0);
+  }
+}
+// Waits until at most `later` tiles (4 DMA instructions per wave each) are still in flight.
+__device__ __forceinline__ void x128_wait_tiles(int later) {
+  if (later <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+// Workgroup barrier that does NOT drain the vector-memory queue (__syncthreads() carries a fence
+// that waits for every outstanding DMA): LDS traffic of this wave is complete, then s_barrier.
+__device__ __forceinline__ void x128_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+// float index of channel ch of tile row r
+__device__ __forceinline__ int x128_slot(int r, int ch) { return r * X128_DH + ((ch - 16 * (r & 3)) & 127); }
+
+// The leading scalars are what the launch's FIRST memory requests need (they are preloaded into
+// SGPRs at wave launch, Makefile -amdgpu-kernarg-preload-count; the AttnX128Args block costs an
+// s_load round trip): the cache length and the first K tile leave before anything else is known.
+//   geom = t_max | heads_kv << 24
 template <int G>
-__global__ __launch_bounds__(X128_WAVES * 64) void attn_x128_decode_kernel(AttnX128Args a) {
+__global__ __launch_bounds__(X128_WAVES * 64) void attn_x128_decode_kernel(
+    const float* __restrict__ k_cache_e, const float* __restrict__ v_cache_e,
+    const float* __restrict__ q_e, const int32_t* __restrict__ step_ptr_e, int kv_row_stride_e,
+    int kv_head_stride_e, int kvs_e, int q_row_stride_e, unsigned geom_e, int length_e,
+    AttnX128Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int DH = X128_DH;
+  constexpr int THREADS = X128_WAVES * 64;
+  constexpr int CPW = 64 / G;        // P.V: channels per wave item
+  constexpr int ITEMS = DH / CPW;    // 2 G
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (in an SGPR: wave-uniform branches)
+  const int t_max_e = static_cast<int>(geom_e & 0xffffffu), heads_kv_e = static_cast<int>(geom_e >> 24);
+  const int row = blockIdx.x / heads_kv_e;
+  const int hk = blockIdx.x % heads_kv_e;
+  const int l = lane & 15, grp = lane >> 4;
+  const int NB = a.n_buf;                               // tiles in the LDS ring (2 .. 4)
+  float* stage = smem;                                  // [NB][64][128] K / V tiles (DMA targets)
+  float* qs = stage + NB * X128_TILE_FLOATS;            // [G][128] rotated queries
+  float* knew_s = qs + G * DH;                          // [128] rotated new key
+  float* vnew_s = knew_s + DH;                          // [128]
+  float* sc = vnew_s + DH;                              // [G][t_pad] scores, then probabilities
+
+  CT2X_X128_STAMP(0)
+  // ---- requests that need nothing but the preloaded arguments ---------------------------------
+  int t_cached = length_e;
+  if (step_ptr_e != nullptr) t_cached = *step_ptr_e;
+  const float* kc_e = k_cache_e + static_cast<int64_t>(row) * kv_row_stride_e + static_cast<int64_t>(hk) * kv_head_stride_e;
+  const float* vc_e = v_cache_e + static_cast<int64_t>(row) * kv_row_stride_e + static_cast<int64_t>(hk) * kv_head_stride_e;
+  x128_stage(kc_e, kvs_e, 0, t_max_e, stage, wave, lane);
+  __builtin_amdgcn_sched_barrier(0);  // the argument block's s_loads stay below the requests
+  CT2X_X128_STAMP(1)
+
   const AttnDecodeParams& p = a.p;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row = blockIdx.x / static_cast<int>(p.heads_kv);
-  const int hk = blockIdx.x % static_cast<int>(p.heads_kv);
-
-  float* qs = smem;                    // [G][128] rotated queries
-  float* knew_s = qs + G * DH;         // [128] rotated new key
-  float* vnew_s = knew_s + DH;         // [128]
-  float* sc = vnew_s + DH;             // [G][t_pad] scores, then probabilities
   const int t_pad = a.t_pad;
-
-  int t_cached = p.step_ptr != nullptr ? *p.step_ptr : static_cast<int>(p.length);
   t_cached = max(0, min(t_cached, static_cast<int>(p.t_max)));
   const bool has_new = p.k_new != nullptr;
   const int pos = t_cached;
   const int n_keys = t_cached + (has_new ? 1 : 0);
-  const int t_last = max(t_cached - 1, 0);
-  const int kvs = static_cast<int>(p.kv_time_stride);
-  float* kc = p.k_cache + static_cast<int64_t>(row) * p.kv_row_stride + static_cast<int64_t>(hk) * p.kv_head_stride;
-  float* vc = p.v_cache + static_cast<int64_t>(row) * p.kv_row_stride + static_cast<int64_t>(hk) * p.kv_head_stride;
+  const int n_tiles = (n_keys + X128_TILE - 1) / X128_TILE;
+  const int kvs = kvs_e;
+  float* kc = const_cast<float*>(kc_e);
+  float* vc = const_cast<float*>(vc_e);
 
   // ---- prologue: RoPE on q (G heads) and the new key, cache append --------------------------
   {
     const int rd = static_cast<int>(p.rot_dim), middle = rd / 2;
     const bool has_rope = p.rope_sin != nullptr;
-    for (int idx = tid; idx < (G + 2) * DH; idx += X128_WAVES * 64) {
+    for (int idx = tid; idx < (G + 2) * DH; idx += THREADS) {
       const int which = idx / DH, c = idx % DH;  // 0 .. G-1: query heads, G: new key, G + 1: new value
       if (which > G) {
         if (has_new) {
@@ -157,7 +344,7 @@ __global__ __launch_bounds__(X128_WAVES * 64) void attn_x128_decode_kernel(AttnX
       }
       if (which == G && !has_new) continue;
       const float* src = which < G
-                             ? p.q + static_cast<int64_t>(row) * p.q_row_stride + (hk * G + which) * DH
+                             ? q_e + static_cast<int64_t>(row) * q_row_stride_e + (hk * G + which) * DH
                              : p.k_new + static_cast<int64_t>(row) * p.new_row_stride + hk * DH;
       float x = src[c];
       if (has_rope && c < rd) {
@@ -170,10 +357,11 @@ __global__ __launch_bounds__(X128_WAVES * 64) void attn_x128_decode_kernel(AttnX
           partner = c < middle ? c + middle : c - middle;
           neg = c < middle;
         }
+        const float xo = src[partner];
         const float cs = p.rope_cos[static_cast<int64_t>(pos) * rd + c];
         const float sv = p.rope_sin[static_cast<int64_t>(pos) * rd + c];
         const float sn = neg ? -sv : sv;  // the sign of rot(x) folded into sin: exact
-        x = x * cs + src[partner] * sn;
+        x = x * cs + xo * sn;
       }
       if (which < G) {
         qs[which * DH + c] = x;
@@ -183,52 +371,125 @@ __global__ __launch_bounds__(X128_WAVES * 64) void attn_x128_decode_kernel(AttnX
       }
     }
   }
-  __syncthreads();
+  CT2X_X128_STAMP(2)
+  if (CT2X_X128_STOP_AFTER <= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  // Tile pipeline (K tiles, then V tiles, ONE stream of 2 n_tiles tiles through a ring of NB LDS
+  // buffers): tile s sits in buffer s % NB. Before tile s is used its own DMA is waited for (counted
+  // vmcnt: the NB - 2 younger tiles stay in flight), a barrier makes everybody's share visible - and
+  // says tile s - 1 has been consumed, whose buffer the request of tile s + NB - 1 then takes.
+  // (The prologue's cache-append stores share the vmcnt queue: they are drained once, below, before
+  // the counted waits start.)
+  const int n_stream = 2 * n_tiles;
+#define CT2X_X128_REQUEST(S)                                                                      \
+  {                                                                                               \
+    const int rq_ = (S);                                                                           \
+    if (rq_ < n_stream) {                                                                          \
+      const bool rv_ = rq_ >= n_tiles;                                                            \
+      x128_stage(rv_ ? vc : kc, kvs, (rv_ ? rq_ - n_tiles : rq_) * X128_TILE, t_max_e,            \
+                 stage + (rq_ % NB) * X128_TILE_FLOATS, wave, lane);                               \
+    }                                                                                             \
+  }
+#define CT2X_X128_ACQUIRE(S)                                                                      \
+  {                                                                                               \
+    const int s_ = (S);                                                                           \
+    if (s_ == 0) {                                                                                \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+      x128_barrier();                                                                             \
+      for (int n_ = 1; n_ < NB; ++n_) CT2X_X128_REQUEST(n_)                                       \
+    } else {                                                                                      \
+      x128_wait_tiles(min(NB - 2, n_stream - 1 - s_));                                            \
+      x128_barrier();                                                                             \
+      CT2X_X128_REQUEST(s_ + NB - 1)                                                              \
+    }                                                                                             \
+  }
 
-  // ---- QK^T: a 16-lane row per key ------------------------------------------------------------
+  // ---- QK^T ------------------------------------------------------------------------------------
+  // Main keys (the groups of four): four lanes per key, 16 keys per wave pass; wave w takes the rows
+  // 16 (w & 3) .. + 15 of the tile for the heads of its half of the group (w >> 2). The n % 4 tail
+  // keys (at most three, in the last tile) run the 16-lane forms on wave 0.
   {
-    const int l = lane & 15, grp = lane >> 4;
-    float qr[G][8];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) qr[g][i] = qs[g * DH + ((16 * i + l + 1) & 127)];
+    constexpr int HPW = G >= 2 ? G / 2 : 1;   // heads per wave
+    const int hg = wave >> 2;                 // which half of the group's heads
+    const bool works = G >= 2 || hg == 0;
+    const int jq = lane & 3, kslot = lane >> 2;
+    float qq[HPW][8][4];
+    float qr[G][8];                           // 16-lane layout, tail keys only (wave 0)
     const int main_n = (n_keys / 4) * 4;
-    const int n_pass = (n_keys + 4 * X128_WAVES - 1) / (4 * X128_WAVES);
-    float kr[2][8];
-    auto request = [&](int pass, float (&dst)[8]) {
-      const int t = (pass * X128_WAVES + wave) * 4 + grp;
-      // rows past the cache are clamped (their scores are never stored); the new key comes from LDS
-      const int tc = min(t, t_last);
-      const float* kp = kc + static_cast<int64_t>(tc) * kvs;
+    for (int ti = 0; ti < n_tiles; ++ti) {
+      CT2X_X128_TICK(0)
+      CT2X_X128_ACQUIRE(ti)
+      CT2X_X128_TICK(1)
+      if (ti == 0) {
+        CT2X_X128_STAMP(3)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dst[i] = kp[(16 * i + l + 1) & 127];
-    };
-    auto compute = [&](int pass, const float (&kreg)[8]) {
-      const int t = (pass * X128_WAVES + wave) * 4 + grp;
-      float kk[8];
+        for (int h = 0; h < HPW; ++h)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) kk[i] = kreg[i];
-      if (has_new && t == pos) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) kk[i] = knew_s[(16 * i + l + 1) & 127];
+          for (int c = 0; c < 8; ++c) {
+            const v4f v = *reinterpret_cast<const v4f*>(qs + (hg * HPW + h) * DH + 16 * c + 4 * jq);
+            qq[h][c][0] = v.x; qq[h][c][1] = v.y; qq[h][c][2] = v.z; qq[h][c][3] = v.w;
+          }
       }
-      const int form = t < main_n ? 0 : ((t - main_n) != 1 ? 1 : 2);
+      const float* tile = stage + (ti % NB) * X128_TILE_FLOATS;
+      const int t_pass = ti * X128_TILE + (wave & 3) * 16;   // first key of this wave's pass
+      if (works && t_pass < main_n) {
+        const int r = (wave & 3) * 16 + kslot;
+        const int t = ti * X128_TILE + r;
+        v4f kq[8];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float s = x128_dot(qr[g], kk, l, form) * p.scale;
-        if (l == 0 && t < n_keys) sc[g * t_pad + t] = s;
+        for (int c = 0; c < 8; ++c)
+          kq[c] = *reinterpret_cast<const v4f*>(tile + x128_slot(r, 16 * c + 4 * jq));
+        if (has_new && pos >= t_pass && pos < t_pass + 16) {  // (uniform: the pass that holds pos)
+          if (t == pos) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) kq[c] = *reinterpret_cast<const v4f*>(knew_s + 16 * c + 4 * jq);
+          }
+        }
+        float sv[HPW];
+        x128_dot_main_quad<HPW>(qq, kq, jq, sv);
+        if (jq == 0 && t < main_n) {
+#pragma unroll
+          for (int h = 0; h < HPW; ++h) sc[(hg * HPW + h) * t_pad + t] = sv[h] * p.scale;
+        }
       }
-    };
-    if (n_pass > 0) request(0, kr[0]);
-    for (int pass = 0; pass < n_pass; pass += 2) {  // two passes of loads in flight
-      if (pass + 1 < n_pass) request(pass + 1, kr[1]);
-      compute(pass, kr[0]);
-      if (pass + 2 < n_pass) request(pass + 2, kr[0]);
-      if (pass + 1 < n_pass) compute(pass + 1, kr[1]);
+      // tail keys main_n .. n_keys - 1 that live in this tile: 16 lanes per key, wave 0
+      if (wave == 0 && main_n < n_keys && main_n < (ti + 1) * X128_TILE && n_keys > ti * X128_TILE) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) qr[g][i] = qs[g * DH + ((16 * i + l + 1) & 127)];
+        const int t = main_n + grp;                       // grp 0 .. 2 hold keys, 3 idles
+        const int r = min(t - ti * X128_TILE, X128_TILE - 1);
+        float kk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kk[i] = tile[x128_slot(max(r, 0), (16 * i + l + 1) & 127)];
+        if (has_new && t == pos) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) kk[i] = knew_s[(16 * i + l + 1) & 127];
+        }
+        const int form = grp != 1 ? 1 : 2;
+        const bool here = t < n_keys && t >= ti * X128_TILE && t < (ti + 1) * X128_TILE;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float s = x128_dot(qr[g], kk, l, form) * p.scale;
+          if (l == 0 && here) sc[g * t_pad + t] = s;
+        }
+      }
     }
   }
-  __syncthreads();
+  CT2X_X128_STAMP(4)
+  if (CT2X_X128_STOP_AFTER <= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  if (n_tiles == 0) {  // (no keys at all: drain the speculative first tile, publish the prologue)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    x128_barrier();
+  }
+  x128_barrier();  // scores complete
+  CT2X_X128_STAMP(5)
 
   // ---- SoftMax: one wave per head --------------------------------------------------------------
   for (int g = wave; g < G; g += X128_WAVES) {
@@ -236,7 +497,6 @@ __global__ __launch_bounds__(X128_WAVES * 64) void attn_x128_decode_kernel(AttnX
     float m = -FLT_MAX;
     for (int t = lane; t < n_keys; t += 64) m = fmaxf(m, e[t]);
     m = wave_max_dpp(m);
-    m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
     for (int t = lane; t < t_pad; t += 64) e[t] = (t < n_keys) ? exp_avx2(e[t] - m) : 0.f;
     __builtin_amdgcn_wave_barrier();
     const float esum = x128_ordered_sum8(e, n_keys);
@@ -244,69 +504,107 @@ __global__ __launch_bounds__(X128_WAVES * 64) void attn_x128_decode_kernel(AttnX
     __builtin_amdgcn_wave_barrier();
     for (int t = lane; t < n_keys; t += 64) e[t] = e[t] * rcp;
   }
-  __syncthreads();
+  CT2X_X128_STAMP(6)
+  if (CT2X_X128_STOP_AFTER <= 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
 
   // ---- P.V: lane = (head of the group, channel) -----------------------------------------------
-  constexpr int CPW = 64 / G;        // channels per wave item
-  constexpr int ITEMS = DH / CPW;    // 2 G
-  float row_max = 0.f;
-  for (int item = wave; item < ITEMS; item += X128_WAVES) {
-    const int g = lane / CPW, c = item * CPW + lane % CPW;
-    const float* pr = sc + g * t_pad;
-    const float vnew = has_new ? vnew_s[c] : 0.f;
-    float y = 0.f;
-    bool has = false;
-    const int n_blocks = n_keys / 8;
-#define CT2X_X128_LOAD_V(VR, T0)                                    \
-  _Pragma("unroll") for (int j = 0; j < X128_VB; ++j) {             \
-    const int t_ = (T0) + j;                                        \
-    const int tc_ = min(t_, t_last);                                \
-    const float g_ = vc[static_cast<int64_t>(tc_) * kvs + c];       \
-    VR[j] = (has_new && t_ == pos) ? vnew : g_;                     \
+  // (ITEMS = 2 G wave items; with G = 8 every wave carries two - their chains interleave)
+  constexpr int IPW = (ITEMS + X128_WAVES - 1) / X128_WAVES;
+  float y[IPW];
+  bool has[IPW];
+#pragma unroll
+  for (int it = 0; it < IPW; ++it) {
+    y[it] = 0.f;
+    has[it] = false;
   }
-#define CT2X_X128_BLOCK(VR, J0, T0)                                                          \
-  {                                                                                          \
-    const v4f pa_ = *reinterpret_cast<const v4f*>(pr + (T0));                                \
-    const v4f pb_ = *reinterpret_cast<const v4f*>(pr + (T0) + 4);                            \
-    if ((T0) + 8 <= n_blocks * 8) {                                                          \
-      const float A_ = fmaf(pa_.x, VR[J0 + 0], pa_.z * VR[J0 + 2]);                          \
-      const float B_ = fmaf(pa_.y, VR[J0 + 1], pa_.w * VR[J0 + 3]);                          \
-      const float c6_ = has ? fmaf(pb_.z, VR[J0 + 6], y) : pb_.z * VR[J0 + 6];               \
-      const float C_ = fmaf(pb_.x, VR[J0 + 4], c6_);                                         \
-      const float D_ = fmaf(pb_.y, VR[J0 + 5], pb_.w * VR[J0 + 7]);                          \
-      y = (C_ + D_) + (A_ + B_);                                                             \
-      has = true;                                                                            \
-    } else {                                                                                 \
-      const float pj_[8] = {pa_.x, pa_.y, pa_.z, pa_.w, pb_.x, pb_.y, pb_.z, pb_.w};         \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
-        if ((T0) + j < n_keys) {                                                             \
-          y = has ? fmaf(pj_[j], VR[J0 + j], y) : pj_[j] * VR[J0 + j];                       \
-          has = true;                                                                        \
-        }                                                                                    \
-      }                                                                                      \
-    }                                                                                        \
-  }
-    float vr[2][X128_VB];
-    if (n_keys > 0) CT2X_X128_LOAD_V(vr[0], 0)
-    for (int t0 = 0; t0 < n_keys; t0 += 2 * X128_VB) {
-      if (t0 + X128_VB < n_keys) CT2X_X128_LOAD_V(vr[1], t0 + X128_VB)
-      CT2X_X128_BLOCK(vr[0], 0, t0)
-      if (t0 + 8 < n_keys) CT2X_X128_BLOCK(vr[0], 8, t0 + 8)
-      if (!(t0 + X128_VB < n_keys)) break;
-      if (t0 + 2 * X128_VB < n_keys) CT2X_X128_LOAD_V(vr[0], t0 + 2 * X128_VB)
-      CT2X_X128_BLOCK(vr[1], 0, t0 + X128_VB)
-      if (t0 + X128_VB + 8 < n_keys) CT2X_X128_BLOCK(vr[1], 8, t0 + X128_VB + 8)
+  const int n_blocks = n_keys / 8;
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    CT2X_X128_ACQUIRE(n_tiles + ti)  // (first pass: the barrier also publishes the probabilities)
+    if (ti == 0) {
+      CT2X_X128_STAMP(7)
     }
-#undef CT2X_X128_LOAD_V
-#undef CT2X_X128_BLOCK
-    p.out[static_cast<int64_t>(row) * (p.heads * DH) + (hk * G + g) * DH + c] = y;
-    row_max = fmaxf(row_max, fabsf(y));
+    const float* tile = stage + ((n_tiles + ti) % NB) * X128_TILE_FLOATS;
+#pragma unroll
+    for (int it = 0; it < IPW; ++it) {
+      const int item = wave + it * X128_WAVES;
+      if (item >= ITEMS) continue;
+      const int g = lane / CPW, c = item * CPW + lane % CPW;
+      const float* pr = sc + g * t_pad;
+      const float vnew = has_new ? vnew_s[c] : 0.f;
+#pragma unroll
+      for (int b = 0; b < X128_TILE / X128_VB; ++b) {
+        const int tb = ti * X128_TILE + b * X128_VB;
+        if (tb >= n_keys) break;
+        float w[X128_VB];
+#pragma unroll
+        for (int jv = 0; jv < X128_VB; ++jv) w[jv] = tile[x128_slot(b * X128_VB + jv, c)];
+        if (has_new && pos >= tb && pos < tb + X128_VB) {  // (uniform: the batch that holds pos)
+#pragma unroll
+          for (int jv = 0; jv < X128_VB; ++jv)
+            if (tb + jv == pos) w[jv] = vnew;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int t8 = tb + 8 * half;
+          if (t8 >= n_keys) break;
+          const v4f pa = *reinterpret_cast<const v4f*>(pr + t8);
+          const v4f pb = *reinterpret_cast<const v4f*>(pr + t8 + 4);
+          const float* wv = w + 8 * half;
+          if (t8 + 8 <= n_blocks * 8) {
+            const float A_ = fmaf(pa.x, wv[0], pa.z * wv[2]);
+            const float B_ = fmaf(pa.y, wv[1], pa.w * wv[3]);
+            const float c6 = has[it] ? fmaf(pb.z, wv[6], y[it]) : pb.z * wv[6];
+            const float C_ = fmaf(pb.x, wv[4], c6);
+            const float D_ = fmaf(pb.y, wv[5], pb.w * wv[7]);
+            y[it] = (C_ + D_) + (A_ + B_);
+            has[it] = true;
+          } else {
+            const float pj[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+            for (int jv = 0; jv < 8; ++jv) {
+              if (t8 + jv < n_keys) {
+                y[it] = has[it] ? fmaf(pj[jv], wv[jv], y[it]) : pj[jv] * wv[jv];
+                has[it] = true;
+              }
+            }
+          }
+        }
+      }
+    }
   }
+#undef CT2X_X128_ACQUIRE
+#undef CT2X_X128_REQUEST
+  float row_max = 0.f;
+#pragma unroll
+  for (int it = 0; it < IPW; ++it) {
+    const int item = wave + it * X128_WAVES;
+    if (item >= ITEMS) continue;
+    const int g = lane / CPW, c = item * CPW + lane % CPW;
+    p.out[static_cast<int64_t>(row) * (p.heads * DH) + (hk * G + g) * DH + c] = y[it];
+    row_max = fmaxf(row_max, fabsf(y[it]));
+  }
+  CT2X_X128_STAMP(8)
   if (p.row_amax_out != nullptr) {
-    // producer-side absmax of the context row for the Quantize that follows (|y| >= 0: the bit
-    // patterns order like unsigned integers; exact and order independent)
+    // producer-side absmax of the context row for the Quantize that follows: the workgroup's maximum
+    // through LDS, then ONE plain store at [row, kv head] (row_amax_parts) - or, for callers that
+    // want the folded vector, one atomicMax per workgroup (|y| >= 0: bit patterns order like
+    // unsigned integers; exact and order independent)
     row_max = wave_max_dpp(row_max);
-    if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(p.row_amax_out) + row, __float_as_uint(row_max));
+    x128_barrier();  // (every wave is past its last read of the score buffer)
+    if (lane == 0) sc[wave] = row_max;
+    x128_barrier();
+    if (tid == 0) {
+      float m = sc[0];
+#pragma unroll
+      for (int w = 1; w < X128_WAVES; ++w) m = fmaxf(m, sc[w]);
+      if (p.row_amax_parts > 0)
+        p.row_amax_out[static_cast<int64_t>(row) * p.row_amax_parts + hk] = m;
+      else
+        atomicMax(reinterpret_cast<unsigned int*>(p.row_amax_out) + row, __float_as_uint(m));
+    }
   }
 }
 
@@ -314,9 +612,20 @@ int x128_t_pad(const AttnDecodeParams& p) {
   return static_cast<int>(((p.t_max + 1 + 15) / 16) * 16 + 16);
 }
 
-size_t x128_lds_bytes(const AttnDecodeParams& p) {
+size_t x128_lds_bytes(const AttnDecodeParams& p, int n_buf) {
   const size_t group = static_cast<size_t>(p.heads / p.heads_kv);
-  return ((group + 2) * X128_DH + group * static_cast<size_t>(x128_t_pad(p))) * sizeof(float);
+  return (n_buf * static_cast<size_t>(X128_TILE_FLOATS) + (group + 2) * X128_DH +
+          group * static_cast<size_t>(x128_t_pad(p))) * sizeof(float);
+}
+// As many tiles in the ring as fit (4: three tiles = 96 KB in flight per workgroup; a cold tile
+// takes ~1.7 us to arrive, profiles/r03_attn128_probe_b.txt).
+int x128_n_buf(const AttnDecodeParams& p) {
+#ifdef CT2X_X128_FORCE_NB
+  return CT2X_X128_FORCE_NB;
+#endif
+  for (int nb = 4; nb >= 2; --nb)
+    if (x128_lds_bytes(p, nb) <= 160 * 1024) return nb;
+  return 0;
 }
 
 bool x128_disabled() {
@@ -329,11 +638,23 @@ bool x128_disabled() {
 
 template <int G>
 void launch_x128(const AttnX128Args& a, size_t lds, hipStream_t stream) {
-  if (lds > 64 * 1024)
+  static std::atomic<bool> configured[64];  // > 64 KiB of dynamic LDS: opted into once per device
+  int dev = 0;
+  CT2X_HIP_CHECK(hipGetDevice(&dev));
+  if (!configured[dev & 63].load(std::memory_order_acquire)) {
     CT2X_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x128_decode_kernel<G>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL(attn_x128_decode_kernel<G>, dim3(static_cast<unsigned>(a.p.rows * a.p.heads_kv)),
-                     dim3(X128_WAVES * 64), lds, stream, a);
+    configured[dev & 63].store(true, std::memory_order_release);
+  }
+  (void)lds;
+  const AttnDecodeParams& p = a.p;
+  const unsigned geom = static_cast<unsigned>(p.t_max) | static_cast<unsigned>(p.heads_kv) << 24;
+  hipLaunchKernelGGL(attn_x128_decode_kernel<G>, dim3(static_cast<unsigned>(p.rows * p.heads_kv)),
+                     dim3(X128_WAVES * 64), lds, stream, static_cast<const float*>(p.k_cache),
+                     static_cast<const float*>(p.v_cache), p.q, p.step_ptr,
+                     static_cast<int>(p.kv_row_stride), static_cast<int>(p.kv_head_stride),
+                     static_cast<int>(p.kv_time_stride), static_cast<int>(p.q_row_stride), geom,
+                     static_cast<int>(p.length), a);
 }
 
 }  // namespace
@@ -352,7 +673,11 @@ bool attention_exact128_decode_applicable(const AttnDecodeParams& p) {
     return false;
   if (p.k_new != nullptr && p.v_new == nullptr) return false;
   if (p.kv_time_stride < p.dhead || p.t_max < 1) return false;
-  return x128_lds_bytes(p) <= 160 * 1024;
+  const int64_t big = int64_t(1) << 31;
+  if (p.kv_row_stride >= big || p.kv_head_stride >= big || p.kv_time_stride >= big ||
+      p.q_row_stride >= big || p.t_max >= (int64_t(1) << 24) || p.heads_kv > 255 || p.length >= big)
+    return false;
+  return x128_n_buf(p) >= 2;
 }
 
 void launch_attention_exact128_decode(const AttnDecodeParams& p, hipStream_t stream) {
@@ -360,7 +685,8 @@ void launch_attention_exact128_decode(const AttnDecodeParams& p, hipStream_t str
   a.p = p;
   a.group = static_cast<int>(p.heads / p.heads_kv);
   a.t_pad = x128_t_pad(p);
-  const size_t lds = x128_lds_bytes(p);
+  a.n_buf = x128_n_buf(p);
+  const size_t lds = x128_lds_bytes(p, a.n_buf);
   switch (a.group) {
     case 1: launch_x128<1>(a, lds, stream); break;
     case 2: launch_x128<2>(a, lds, stream); break;

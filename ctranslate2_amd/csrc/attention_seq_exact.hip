@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <float.h>
 
 namespace ct2x {
 
@@ -42,9 +43,14 @@ struct XSeqArgs {
   int32_t* row_len;     // [batch, heads, tq]
   int64_t tk_pad;
   int pack_b;           // alpha travels with K (MKL packed B) instead of scaling the sum
+  int s_stride;         // fused SoftMax: LDS row stride of the score tile (floats)
 };
 
-template <int DH>
+// FUSED: the 64 x tk score tile stays in LDS, the SoftMax of its rows runs in the same launch
+// (cpu::softmax<AVX2> in the reference's order: exp256_ps, eight strided partial sums, e * (1 / sum)
+// - the sequence of attn_x_full_kernel / softmax_kernel) and only the probabilities reach the
+// workspace. Rows longer than the LDS budget take the three-launch form.
+template <int DH, bool FUSED>
 __global__ __launch_bounds__(256) void xseq_scores_kernel(XSeqArgs a) {
   constexpr int QS = DH + 2;  // LDS row strides (floats): lanes (r, g) -> bank 2 r + g
   constexpr int KS = DH + 2;
@@ -52,6 +58,7 @@ __global__ __launch_bounds__(256) void xseq_scores_kernel(XSeqArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* qs = smem;               // [64][QS]
   float* ks = qs + XS_BQ * QS;    // [64][KS]
+  float* ss = ks + XS_BK * KS;    // FUSED: [64][a.s_stride] scores, then probabilities
   const AttnFullParams& p = a.p;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -64,11 +71,15 @@ __global__ __launch_bounds__(256) void xseq_scores_kernel(XSeqArgs a) {
   const int64_t bh = static_cast<int64_t>(b) * p.heads + h;
 
   // valid keys of every query row (prepare_length_mask, src/layers/attention_layer.cc:152-174)
-  if (tid < XS_BQ && q0 + tid < tq) {
-    int size = p.lengths ? min(max(p.lengths[b], 0), tk) : tk;
+  const int len_b = p.lengths ? min(max(p.lengths[b], 0), tk) : tk;
+  if (!FUSED && tid < XS_BQ && q0 + tid < tq) {
+    int size = len_b;
     if (p.causal) size = min(size, q0 + tid + static_cast<int>(p.q_offset) + 1);
     a.row_len[bh * tq + q0 + tid] = max(size, 0);
   }
+  // keys no row of this tile can see: their scores are never read (SoftMax writes 0 behind a row's
+  // length), so their tiles are not computed
+  const int k_hi = p.causal ? max(0, min(len_b, q0 + XS_BQ + static_cast<int>(p.q_offset))) : len_b;
 
   // Q tile -> LDS (rows past tq are clamped: their scores are never stored)
   for (int e = tid; e < XS_BQ * (DH / 4); e += 256) {
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(256) void xseq_scores_kernel(XSeqArgs a) {
   for (int j = 0; j < NK; ++j) af[j] = qs[(16 * wave + r) * QS + 4 * j + g];
 
   float* srow = a.scores + bh * tq * a.tk_pad;
-  for (int t0 = 0; t0 < tk; t0 += XS_BK) {
+  for (int t0 = 0; t0 < k_hi; t0 += XS_BK) {
     __syncthreads();  // the previous tile has been consumed
     for (int e = tid; e < XS_BK * (DH / 4); e += 256) {
       const int row = e / (DH / 4), c4 = e % (DH / 4);
@@ -118,10 +129,32 @@ __global__ __launch_bounds__(256) void xseq_scores_kernel(XSeqArgs a) {
         if (qi < tq && t < tk) {
           float v = acc[s][ii];
           if (!a.pack_b && p.scale != 1.f) v = v * p.scale;
-          srow[static_cast<int64_t>(qi) * a.tk_pad + t] = v;
+          if (FUSED) ss[(16 * wave + 4 * g + ii) * a.s_stride + t] = v;
+          else srow[static_cast<int64_t>(qi) * a.tk_pad + t] = v;
         }
       }
     }
+  }
+  if (!FUSED) return;
+  __syncthreads();
+  // SoftMax of this wave's 16 rows, one after the other (lane = key)
+  for (int rr = 0; rr < 16; ++rr) {
+    const int qi = q0 + 16 * wave + rr;
+    if (qi >= tq) break;
+    int size = len_b;
+    if (p.causal) size = min(size, qi + static_cast<int>(p.q_offset) + 1);
+    size = max(size, 0);
+    float* e = ss + (16 * wave + rr) * a.s_stride;
+    float* out = srow + static_cast<int64_t>(qi) * a.tk_pad;
+    float m = -FLT_MAX;
+    for (int t = lane; t < size; t += 64) m = fmaxf(m, e[t]);
+    m = wave_max_dpp(m);
+    for (int t = lane; t < size; t += 64) e[t] = exp_avx2(e[t] - m);
+    __builtin_amdgcn_wave_barrier();
+    float rcp = 0.f;
+    if (size > 0) rcp = 1.f / ordered_sum8(e, size);
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < tk; t += 64) out[t] = (t < size) ? e[t] * rcp : 0.f;
   }
 }
 
@@ -150,6 +183,10 @@ __global__ __launch_bounds__(256) void xseq_context_kernel(XSeqArgs a) {
   const int64_t bh = static_cast<int64_t>(b) * p.heads + h;
   const float* prow = a.scores + bh * tq * a.tk_pad;
 
+  // keys no row of this tile can see carry probability 0: fma(0, v, acc) == acc, their tiles are
+  // skipped (exact: acc is never -0)
+  const int len_b = p.lengths ? min(max(p.lengths[b], 0), tk) : tk;
+  const int k_hi = p.causal ? max(0, min(len_b, q0 + XS_BQ + static_cast<int>(p.q_offset))) : len_b;
   v4f tot[NC], acc[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) tot[c] = acc[c] = v4f{0.f, 0.f, 0.f, 0.f};
@@ -158,7 +195,7 @@ __global__ __launch_bounds__(256) void xseq_context_kernel(XSeqArgs a) {
   while (rem > 0) {
     const int blk = xseq_block(rem);
     const int e0 = s0 + blk;
-    for (int t0 = s0; t0 < e0; t0 += XS_BV) {
+    for (int t0 = s0; t0 < min(e0, k_hi); t0 += XS_BV) {
       __syncthreads();
       // P tile: keys outside the block enter as 0 (fma(0, v, acc) == acc: acc is never -0)
       for (int e = tid; e < XS_BQ * XS_BV; e += 256) {
@@ -224,11 +261,17 @@ void launch_xseq(const XSeqArgs& a, hipStream_t stream) {
                   static_cast<unsigned>(p.batch));
   const size_t lds1 = sizeof(float) * (XS_BQ * (DH + 2) + XS_BK * (DH + 2));
   const size_t lds3 = sizeof(float) * (XS_BQ * (XS_BV + 2) + XS_BV * (DH + 16));
-  allow_big_lds(reinterpret_cast<const void*>(xseq_scores_kernel<DH>), lds1);
-  hipLaunchKernelGGL(xseq_scores_kernel<DH>, grid, dim3(256), lds1, stream, a);
-  const int64_t rows = p.batch * p.heads * p.tq;
-  // SoftMax over the padded row: columns tk .. tk_pad - 1 sit behind every row's length -> 0
-  launch_softmax(a.scores, a.row_len, rows, a.tk_pad, false, a.scores, stream);
+  const size_t lds_fused = lds1 + sizeof(float) * XS_BQ * static_cast<size_t>(a.s_stride);
+  if (lds_fused <= 160 * 1024) {
+    allow_big_lds(reinterpret_cast<const void*>(xseq_scores_kernel<DH, true>), lds_fused);
+    hipLaunchKernelGGL((xseq_scores_kernel<DH, true>), grid, dim3(256), lds_fused, stream, a);
+  } else {
+    allow_big_lds(reinterpret_cast<const void*>(xseq_scores_kernel<DH, false>), lds1);
+    hipLaunchKernelGGL((xseq_scores_kernel<DH, false>), grid, dim3(256), lds1, stream, a);
+    const int64_t rows = p.batch * p.heads * p.tq;
+    // SoftMax over the padded row: columns tk .. tk_pad - 1 sit behind every row's length -> 0
+    launch_softmax(a.scores, a.row_len, rows, a.tk_pad, false, a.scores, stream);
+  }
   hipLaunchKernelGGL(xseq_context_kernel<DH>, grid, dim3(256), lds3, stream, a);
 }
 
@@ -282,6 +325,7 @@ void launch_attention_seq_exact(const AttnFullParams& p_in, hipStream_t stream) 
     a.row_len = row_len;
     a.tk_pad = tk_pad;
     a.pack_b = mkl_sequence_packs_b(p_in.tq, p_in.tk, p_in.dhead, p_in.scale) ? 1 : 0;
+    a.s_stride = static_cast<int>(tk_pad + 4);
     switch (p_in.dhead) {
       case 16: launch_xseq<16>(a, stream); break;
       case 32: launch_xseq<32>(a, stream); break;

@@ -1308,6 +1308,12 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   st->inner = alloc<float>(*st, wrows * wffn);
   st->inner2 = alloc<float>(*st, wrows * wffn);
   st->row_amax = alloc<float>(*st, 2 * static_cast<int64_t>(dec_.layers.size()) * rows);
+  {
+    int64_t max_kv = 0;
+    for (const auto& l : dec_.layers)
+      if (l.self.dhead == 128) max_kv = std::max(max_kv, l.self.heads_kv);
+    if (max_kv > 0) st->attn_amax_parts = alloc<float>(*st, rows * max_kv);
+  }
   if (tp_) {
     st->tp_acc = alloc<int32_t>(*st, wrows * d);
     st->tp_amax = alloc<float>(*st, wrows);
@@ -1861,6 +1867,13 @@ void Engine::launch_step(DecodeState& st) {
         // long caches / few rows: one workgroup per (row, head) + producer-side absmax, then an
         // element-wise Quantize over (rows x column chunks) workgroups
         float* amax = st.row_amax + (2 * l) * rows;
+        int amax_parts = 1;
+        if (st.attn_amax_parts != nullptr && p.dhead == 128) {
+          // (the d_head 128 exact kernel: one plain store per (row, kv head) instead of atomics)
+          amax = st.attn_amax_parts;
+          amax_parts = static_cast<int>(a.heads_kv);
+          p.row_amax_parts = amax_parts;
+        }
         p.row_amax_out = amax;
         begin_kernel("attention_self_decode", 0, 0, rows, a.heads, a.dhead);
         launch_attention_decode(p, cur_stream());
@@ -1868,7 +1881,7 @@ void Engine::launch_step(DecodeState& st) {
         prefetch_weight(st, a.lin[1], 1);  // attention output weight, next to the Quantize launch
         begin_kernel("quantize_cols", double(rows) * qdim * 5, 0, rows, 0, qdim);
         launch_quantize_cols(st.ctx, amax, rows, qdim, quant_mode_, st.qbuf, st.qscale, cur_stream(),
-                             st.pf_pending.wgs > 0 ? &st.pf_pending : nullptr);
+                             st.pf_pending.wgs > 0 ? &st.pf_pending : nullptr, amax_parts);
         st.pf_pending = PrefetchArgs();
         end_kernel();
         QuantIn cq;

@@ -392,6 +392,7 @@ struct DecodeState {
   float* logits = nullptr;   // [rows, vocab]
   float* logprobs = nullptr; // [rows, vocab] (beam search)
   float* row_amax = nullptr; // [2 * layers, rows]: producer-side row absmax (zeroed every step)
+  float* attn_amax_parts = nullptr;  // [rows, heads_kv]: partial maxima of the d_head 128 attention
   int32_t* tp_acc = nullptr; // tensor parallel: int32 / fp32 partial products [rows, d]
   float* tp_amax = nullptr;  // tensor parallel: per-row absmax [rows]
   int8_t* qbuf = nullptr;    // [rows, max(d, ffn)]

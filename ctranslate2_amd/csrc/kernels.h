@@ -37,7 +37,7 @@ struct PrefetchArgs {
 
 void launch_quantize_cols(const float* x, const float* amax, int64_t rows, int64_t depth,
                           int quant_mode, int8_t* q, float* scales, hipStream_t stream,
-                          const PrefetchArgs* pf = nullptr);
+                          const PrefetchArgs* pf = nullptr, int amax_parts = 1);
 void launch_row_amax(const float* x, int64_t rows, int64_t depth, float* amax, hipStream_t stream);
 void launch_quantize_with_amax(const float* x, const float* amax, int64_t rows, int64_t depth,
                                int quant_mode, int8_t* q, float* scales, hipStream_t stream);
@@ -239,6 +239,11 @@ struct AttnDecodeParams {
   // attention_decode2 split mode only: per-row absmax of the context, max-combined into
   // row_amax_out[rows] (zero beforehand); attention_decode_emits_row_amax tells whether it will.
   float* row_amax_out = nullptr;
+  // attention_exact128 only: > 0 = row_amax_out is [rows, row_amax_parts] and workgroup (row, kv
+  // head) STORES its partial maximum at [row, kv head] (no atomics, nothing to zero): 1024 device
+  // scope atomicMax on the one cache line of a 16-row vector cost this launch 12 us
+  // (profiles/r03_attn128_probe_g.txt); the consumer (launch_quantize_cols) folds the parts.
+  int row_amax_parts = 0;
   // attention_exact only: while *one_row_step_ptr == one_row_step the rows of a kv group are
   // computed with the one-query-row forms of the reference's MatMul (first step of a CPU beam
   // search: the batch is not expanded yet, src/decoding.cc:453-454).

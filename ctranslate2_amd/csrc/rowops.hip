@@ -9,6 +9,7 @@
 #include "device_utils.h"
 #include "row_norm.h"
 #include "kernels.h"
+#include "runtime.h"
 
 #include <float.h>
 #include <limits.h>
@@ -97,13 +98,16 @@ __global__ void quantize_with_amax_kernel(const float* __restrict__ x,
 
 __global__ void quantize_cols_kernel(const float* __restrict__ x, const float* __restrict__ amax,
                                      int64_t depth, int quant_mode, int8_t* __restrict__ q,
-                                     float* __restrict__ scales, int rows, PrefetchArgs pf) {
+                                     float* __restrict__ scales, int rows, PrefetchArgs pf,
+                                     int amax_parts) {
   if (static_cast<int>(blockIdx.y) >= rows) {  // spare workgroups: warm the next GEMM's weight
     weight_prefetch_wg(pf, (static_cast<int>(blockIdx.y) - rows) * gridDim.x + blockIdx.x, pf.wgs);
     return;
   }
   const int64_t row = blockIdx.y;
-  const float a = amax[row];
+  // amax [rows, amax_parts]: partial maxima left by the producer's workgroups (plain stores)
+  float a = amax[row * amax_parts];
+  for (int i = 1; i < amax_parts; ++i) a = fmaxf(a, amax[row * amax_parts + i]);
   const float scale = (a != 0.f) ? 127.f / a : 1.f;
   if (blockIdx.x == 0 && threadIdx.x == 0) scales[row] = scale;
   const int64_t i = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) * 4;
@@ -119,9 +123,10 @@ __global__ void quantize_cols_kernel(const float* __restrict__ x, const float* _
 
 void launch_quantize_cols(const float* x, const float* amax, int64_t rows, int64_t depth,
                           int quant_mode, int8_t* q, float* scales, hipStream_t stream,
-                          const PrefetchArgs* pf_in) {
+                          const PrefetchArgs* pf_in, int amax_parts) {
   if (rows == 0 || depth == 0) return;
   if (depth % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(q) & 3)) {
+    if (amax_parts != 1) throw Error("quantize_cols: partial maxima need the aligned form");
     launch_quantize_with_amax(x, amax, rows, depth, quant_mode, q, scales, stream);
     return;
   }
@@ -135,7 +140,7 @@ void launch_quantize_cols(const float* x, const float* amax, int64_t rows, int64
     grid.y += extra_y;
   }
   hipLaunchKernelGGL(quantize_cols_kernel, grid, dim3(threads), 0, stream, x, amax, depth, quant_mode,
-                     q, scales, static_cast<int>(rows), pf);
+                     q, scales, static_cast<int>(rows), pf, amax_parts);
 }
 
 void launch_row_amax(const float* x, int64_t rows, int64_t depth, float* amax,
