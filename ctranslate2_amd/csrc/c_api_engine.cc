@@ -864,6 +864,15 @@ const char* ct2x_host_math_backend(void) {
   }
 }
 
+int ct2x_host_sin_cos(int64_t n, const float* x, float* sin_out, float* cos_out) {
+  API_TRY
+  CT2X_CHECK(n >= 0 && (n == 0 || x != nullptr), "ct2x_host_sin_cos: bad arguments");
+  if (sin_out) host_vsin(n, x, sin_out);
+  if (cos_out) host_vcos(n, x, cos_out);
+  return 0;
+  API_CATCH
+}
+
 int ct2x_host_sinusoidal_table(int64_t positions, int64_t depth, float* out) {
   API_TRY
   CT2X_CHECK(positions > 0 && depth >= 2 && depth % 2 == 0 && out != nullptr,

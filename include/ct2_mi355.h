@@ -574,12 +574,16 @@ int ct2x_step_logits(void* translator, const int32_t* src_ids, const int32_t* sr
  * on the CPU with ops::Sin / ops::Cos (src/layers/common.cc:204-229,
  * src/layers/attention_layer.cc:252-343), which an MKL build routes to VML (vsSin / vsCos,
  * src/cpu/primitives.cc:378-394). VML is neither libm nor correctly rounded, and a one-ulp table
- * difference flips int8 activations, so this backend resolves the same two functions from an
- * MKL runtime when one is installed (dlopen of libmkl_rt; CT2X_MKL_PATH / MKLROOT / CONDA_PREFIX
- * searched) and uses libm otherwise (CT2X_HOST_MATH=libm | mkl forces it).
- * ct2x_host_math_backend: "mkl-vml" or "libm". ct2x_host_sinusoidal_table: host only,
- * out [positions, depth]. */
+ * difference flips int8 activations, so this backend carries VML's two kernels RESTATED (from the
+ * library's disassembly, pinned bit for bit against it; arguments up to 10000 rad): token parity
+ * does not depend on an MKL runtime on the host. CT2X_HOST_MATH=mkl uses an installed MKL instead
+ * (dlopen of libmkl_rt; CT2X_MKL_PATH / MKLROOT / CONDA_PREFIX searched), CT2X_HOST_MATH=libm the
+ * C library (not bit-identical to the reference).
+ * ct2x_host_math_backend: "vml-restated" (default), "mkl-vml" or "libm".
+ * ct2x_host_sin_cos: y = sin / cos of n floats through that backend (host only; tests).
+ * ct2x_host_sinusoidal_table: host only, out [positions, depth]. */
 const char* ct2x_host_math_backend(void);
+int ct2x_host_sin_cos(int64_t n, const float* x, float* sin_out, float* cos_out);
 int ct2x_host_sinusoidal_table(int64_t positions, int64_t depth, float* out);
 
 /* Host side of RotaryEmbeddings::initialize (src/layers/attention_layer.cc:254-330): sin / cos

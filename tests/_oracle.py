@@ -239,3 +239,21 @@ def exp_avx2(x):
     L = lib()
     L.orc_exp_avx2.restype = C.c_float
     return np.array([L.orc_exp_avx2(C.c_float(float(v))) for v in x.ravel()], np.float32).reshape(x.shape)
+
+
+def _vml(fn, x):
+    x = _f32(x).ravel()
+    y = np.empty_like(x)
+    f = getattr(lib(), fn)
+    f.restype = C.c_int
+    f(_p(x), _i64(len(x)), _p(y))
+    return y
+
+
+def vml_sin(x):
+    """orc_vml_sin: MKL VML vsSin (HA) restated; arguments beyond 10000 rad give 0."""
+    return _vml("orc_vml_sin", x)
+
+
+def vml_cos(x):
+    return _vml("orc_vml_cos", x)

@@ -56,7 +56,7 @@ def _host_math_is_mkl():
     from ctranslate2_amd import _lib
     L = _lib.lib()
     L.ct2x_host_math_backend.restype = ctypes.c_char_p
-    return L.ct2x_host_math_backend().decode() == "mkl-vml"
+    return L.ct2x_host_math_backend().decode() in ("mkl-vml", "vml-restated")
 
 
 @pytest.mark.parametrize("key", ["lm_tiny", "lm_small"])

@@ -232,11 +232,37 @@ def test_host_sinusoidal_table_matches_the_reference():
         got = np.empty_like(want)
         assert L.ct2x_host_sinusoidal_table(C.c_int64(want.shape[0]), C.c_int64(depth),
                                             got.ctypes.data_as(C.c_void_p)) == 0
-        if backend == "mkl-vml":
+        if backend in ("mkl-vml", "vml-restated"):
             assert np.array_equal(got, want), depth
         else:
             assert np.mean(got == want) > 0.9
             np.testing.assert_allclose(got, want, rtol=2e-7, atol=1e-7)
+
+
+def test_host_sin_cos_is_the_restated_vml():
+    """The product's host sin / cos (host_math.cc: MKL VML's HA kernels restated) equal the oracle's
+    restatement - which tests/test_oracle.py pins bit for bit against the MKL library itself - on
+    table arguments, random arguments and a whole binade; beyond 10000 rad it says so."""
+    import ctypes as C
+    from ctranslate2_amd import _lib
+    import _oracle as O
+    L = _lib.lib()
+    L.ct2x_host_math_backend.restype = C.c_char_p
+    if L.ct2x_host_math_backend().decode() != "vml-restated":
+        pytest.skip("CT2X_HOST_MATH selects another backend")
+    rng = np.random.default_rng(3)
+    xs = [rng.uniform(-10000, 10000, 1_000_000).astype(np.float32),
+          (np.arange(1, 4001, dtype=np.float32)[:, None] *
+           np.exp(-np.float32(0.036) * np.arange(256, dtype=np.float32))[None, :]).astype(np.float32).ravel(),
+          np.arange(0x3F800000, 0x3F800000 + (1 << 20), dtype=np.uint32).view(np.float32),
+          np.array([0.0, -0.0, 1e-30, np.pi, -np.pi, 10000.0, -10000.0], np.float32)]
+    for x in xs:
+        s, c = np.empty_like(x), np.empty_like(x)
+        assert L.ct2x_host_sin_cos(C.c_int64(len(x)), x.ctypes.data_as(C.c_void_p),
+                                   s.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p)) == 0
+        so, co = O.vml_sin(x), O.vml_cos(x)
+        assert np.array_equal(s.view(np.uint32), so.view(np.uint32))
+        assert np.array_equal(c.view(np.uint32), co.view(np.uint32))
 
 
 def test_host_rotary_tables_match_the_reference():
@@ -266,7 +292,7 @@ def test_host_rotary_tables_match_the_reference():
             C.c_int64(kw.get("original_max_position_embeddings", 0)), C.c_int64(kw["positions"]),
             got_s.ctypes.data_as(C.c_void_p), got_c.ctypes.data_as(C.c_void_p))
         assert rc == 0, _lib.last_error() if hasattr(_lib, "last_error") else rc
-        if backend == "mkl-vml":
+        if backend in ("mkl-vml", "vml-restated"):
             assert np.array_equal(got_s, want_s), name
             assert np.array_equal(got_c, want_c), name
         else:

@@ -294,6 +294,37 @@ def test_exact_matmul_k_blocking():
         assert np.array_equal(_bits(O.matmul(p, v, False, 1.0)), _bits(R.matmul(p, v, False, 1.0))), (m, n, k)
 
 
+def test_vml_sin_cos_restated():
+    """orc_vml_sin / orc_vml_cos against the MKL library itself (vsSin / vsCos of libmkl_rt, the
+    entry points the reference's ops::Sin / ops::Cos call, src/cpu/primitives.cc:378-394): every
+    float of a binade, 2 million random arguments in the restated range, sinusoidal-table and RoPE
+    arguments - bit for bit. (On an AVX-512 host MKL runs its Z0 kernels, not the L9 kernels the
+    restatement was read from: same bits.)"""
+    import ctypes as C
+    import glob
+    import _refshim as RS
+    _ref()
+    RS.lib()  # loads the reference library and, in the global scope, the MKL runtime it is linked to
+    # (the ILP64 interface: MKL_INT is 64 bits wide)
+    mkl = C.CDLL(sorted(glob.glob(os.path.join(RS.MKL_DIR, "libmkl_intel_ilp64.so*")))[0],
+                 mode=os.RTLD_GLOBAL | os.RTLD_LAZY)
+    rng = np.random.default_rng(41)
+    half = 256
+    inc = np.float32(np.log(np.float32(10000.0)) / np.float32(half - 1))
+    ts = np.exp(-inc * np.arange(half, dtype=np.float32)).astype(np.float32)
+    inv = (1.0 / np.power(np.float32(500000.0), np.arange(0, 128, 2, dtype=np.float32) / np.float32(128))).astype(np.float32)
+    xs = [np.arange(0x3F800000, 0x40000000, dtype=np.uint32).view(np.float32),
+          rng.uniform(-10000, 10000, 2_000_000).astype(np.float32),
+          (np.arange(1, 5001, dtype=np.float32)[:, None] * ts[None, :]).astype(np.float32).ravel(),
+          (np.arange(0, 9000, dtype=np.float32)[:, None] * inv[None, :]).astype(np.float32).ravel(),
+          np.array([0.0, -0.0, 1e-30, 1.5e-45, np.pi, -np.pi, np.pi / 2, 10000.0, -10000.0], np.float32)]
+    for x in xs:
+        for fn, mine in (("vsSin", O.vml_sin), ("vsCos", O.vml_cos)):
+            want = np.empty_like(x)
+            getattr(mkl, fn)(C.c_int64(len(x)), x.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(_bits(mine(x)), _bits(want)), fn
+
+
 def test_matmul_envelope_is_explicit():
     with pytest.raises(ValueError):   # one-row form: k % 4 != 0 was not recovered
         O.matmul(np.zeros((1, 1, 130), np.float32), np.zeros((1, 5, 130), np.float32), True)

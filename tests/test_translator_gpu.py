@@ -179,7 +179,7 @@ def host_math_is_mkl():
     from ctranslate2_amd import _lib
     L = _lib.lib()
     L.ct2x_host_math_backend.restype = ctypes.c_char_p
-    return L.ct2x_host_math_backend().decode() == "mkl-vml"
+    return L.ct2x_host_math_backend().decode() in ("mkl-vml", "vml-restated")
 
 
 @pytest.mark.parametrize("key", ["aren-transliteration-i8", "tiny", "small", "tb"])
