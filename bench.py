@@ -56,6 +56,9 @@ def parse_args():
                    help="tensor parallel over the --gpus ranks (one sharded model, every rank runs "
                         "the same batch, RCCL all-reduce after each row-parallel Dense) instead of "
                         "independent replicas; strong scaling")
+    p.add_argument("--check-tp-parity", action="store_true",
+                   help="with --tp: rank 0 also decodes the batch on an unsharded engine and reports "
+                        "whether the tensor-parallel tokens are identical (config.tp_tokens_equal_unsharded)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-l8", action="store_true",
                    help="skip the Llama-3-8B-shape leg (BASELINE configs[2], reported as config.l8)")
@@ -192,6 +195,51 @@ def prefill_gemm_leg():
                                   "hbm_frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
         del qa, w, y
     return out
+
+
+def tp_local_leg(model_dir, sources, kw, ref_hyps):
+    """Tensor parallelism on the ONE visible GPU: the model sharded over 2 ranks that live as threads
+    of this process (in-process communicator), row-parallel layers exchanged through the one-shot
+    mailbox kernels (tp_oneshot.hip) - the code path a multi-GPU node runs over xGMI, minus the
+    links. Reports tokens/s of the sharded decode (NOT a scaling number: both ranks share one GPU),
+    whether its tokens equal the unsharded engine's, and the loopback price of one exchange pair."""
+    import ctypes as C
+    import threading
+    import ctranslate2_amd as ct2
+    from ctranslate2_amd import _lib
+    ranks = ct2.Translator.tensor_parallel_local(model_dir, 2, compute_type="int8")
+    outs, errs = [None, None], [None, None]
+
+    def work(i):
+        try:
+            ranks[i].translate_ids(sources, **kw)  # warm-up (graph capture)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                outs[i] = ranks[i].translate_ids(sources, **kw)[0]
+            outs[i] = (outs[i], (time.perf_counter() - t0) / 3)
+        except Exception as e:  # noqa: BLE001
+            errs[i] = e
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for e in errs:
+        if e is not None:
+            raise e
+    for t in ranks:
+        t.close()
+    (hyps0, dt0), (hyps1, dt1) = outs
+    tokens = sum(len(h[0]) for h in hyps0)
+    us = C.c_float()
+    L = _lib.lib()
+    _lib.check(L.ct2x_tp_selftest_oneshot(0, 2, C.c_int64(32), C.c_int64(256), C.c_int64(512), 200, C.byref(us)))
+    return {"workload": "same model and batch, tensor parallel x2 as two in-process ranks on this one GPU "
+                        "(one-shot mailbox exchanges; functional leg, not a scaling number)",
+            "value": tokens / max(dt0, dt1), "unit": "tokens/s",
+            "tokens_equal_unsharded": bool(hyps0 == ref_hyps and hyps1 == ref_hyps),
+            "exchange_pair_us_loopback": us.value,
+            "collective_calls_per_row_parallel_dense": 0, "device_side_exchanges_per_row_parallel_dense": 2}
 
 
 def physical_cores():
@@ -343,6 +391,15 @@ def main():
         },
     }
 
+    if tp and args.check_tp_parity:
+        hyps_tp, _ = translator.translate_ids(sources, **kw)
+        if rank == 0:
+            single = ct2.Translator(model_dir, device="cuda", device_index=local_rank, compute_type=args.compute_type)
+            hyps_1, _ = single.translate_ids(sources, **kw)
+            result["config"]["tp_tokens_equal_unsharded"] = bool(hyps_tp == hyps_1)
+            single.close()
+        dist.barrier()
+
     if rank == 0 and world == 1 and args.beam == 1 and not args.no_profile:
         # BASELINE.json configs[1] (batch 32 x beam 4) beside the metric's beam-1 line: a short,
         # separately timed leg after the measured region (5 calls), reported as `config.beam4`.
@@ -402,6 +459,12 @@ def main():
                          "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["total_ms"] else None}
                         for k, v in top],
             }
+        if world == 1 and not args.no_profile and args.compute_type == "int8" and args.beam == 1:
+            try:
+                ref_hyps, _ = translator.translate_ids(sources, **kw)
+                result["config"]["tp_local"] = tp_local_leg(model_dir, sources, kw, ref_hyps)
+            except Exception as e:  # never break the headline line
+                result["config"]["tp_local"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_profile and args.compute_type == "int8":
             try:
                 result["config"]["prefill_gemm"] = prefill_gemm_leg()

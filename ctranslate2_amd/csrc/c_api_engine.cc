@@ -384,6 +384,132 @@ int ct2x_tp_selftest_local(int device_index, int world) {
   API_CATCH
 }
 
+int ct2x_tp_selftest_oneshot(int device_index, int world, int64_t rows, int64_t depth, int64_t n,
+                             int iters, float* us_per_dense_out) {
+  API_TRY
+  // The one-shot exchanges of a row-parallel int8 Dense (tp_oneshot.hip) on the in-process
+  // communicator: `world` rank threads, each with a [rows, depth] slice of one activation and its
+  // own int32 partial product [rows, n]. Checked against what ONE device computes from the whole
+  // row (global absmax -> scale -> Quantize; sum of the partials -> Dequantize): every rank must
+  // hold identical, bit-exact results. Then `iters` exchange pairs are timed per rank (HIP events
+  // on the rank's stream; all ranks run concurrently) - the single-device loopback price of the
+  // two exchanges, reported as the maximum over the ranks.
+  CT2X_CHECK(world >= 2 && world <= kTpMaxWorld, "ct2x_tp_selftest_oneshot: world must be in [2, 8]");
+  CT2X_CHECK(tp_oneshot_fits(rows, rows * n), "ct2x_tp_selftest_oneshot: message larger than the mailbox");
+  auto comms = make_local_comms(world);
+  CT2X_CHECK(comms[0]->peer_box() != nullptr, "one-shot mailboxes are disabled (CT2X_TP_ONESHOT=0)");
+  std::vector<std::string> errors(world);
+  std::vector<float> us(world, 0.f);
+  // host data: x [rows, world * depth], partial_r [rows, n] = (r + 1) * pattern
+  std::vector<float> hx(static_cast<size_t>(rows) * world * depth);
+  for (size_t i = 0; i < hx.size(); ++i)
+    hx[i] = static_cast<float>(static_cast<int>((i * 2654435761u) % 2001) - 1000) / 37.f;
+  std::vector<float> h_ws(n), h_bias(n);
+  for (int64_t j = 0; j < n; ++j) {
+    h_ws[j] = 50.f + static_cast<float>(j % 97);
+    h_bias[j] = static_cast<float>(j % 13) * 0.01f;
+  }
+  std::vector<std::thread> threads;
+  std::vector<std::vector<float>> outs(world);
+  std::vector<std::vector<int8_t>> qouts(world);
+  for (int r = 0; r < world; ++r) {
+    threads.emplace_back([&, r] {
+      try {
+        CT2X_HIP_CHECK(hipSetDevice(device_index));
+        hipStream_t stream = thread_stream();
+        const TpPeerBox& pb = *comms[r]->peer_box();
+        std::vector<float> xs(static_cast<size_t>(rows) * depth);
+        for (int64_t i = 0; i < rows; ++i)
+          for (int64_t j = 0; j < depth; ++j)
+            xs[i * depth + j] = hx[(i * world + r) * depth + j];
+        std::vector<int32_t> part(static_cast<size_t>(rows) * n);
+        for (size_t i = 0; i < part.size(); ++i)
+          part[i] = (r + 1) * (static_cast<int32_t>(i % 1999) - 1000);
+        auto* dx = static_cast<float*>(device_malloc(xs.size() * 4));
+        auto* dq = static_cast<int8_t*>(device_malloc(xs.size()));
+        auto* ds = static_cast<float*>(device_malloc(rows * 4));
+        auto* dp = static_cast<int32_t*>(device_malloc(part.size() * 4));
+        auto* dy = static_cast<float*>(device_malloc(part.size() * 4));
+        auto* dws = static_cast<float*>(device_malloc(n * 4));
+        auto* dbias = static_cast<float*>(device_malloc(n * 4));
+        CT2X_HIP_CHECK(hipMemcpyAsync(dx, xs.data(), xs.size() * 4, hipMemcpyHostToDevice, stream));
+        CT2X_HIP_CHECK(hipMemcpyAsync(dp, part.data(), part.size() * 4, hipMemcpyHostToDevice, stream));
+        CT2X_HIP_CHECK(hipMemcpyAsync(dws, h_ws.data(), n * 4, hipMemcpyHostToDevice, stream));
+        CT2X_HIP_CHECK(hipMemcpyAsync(dbias, h_bias.data(), n * 4, hipMemcpyHostToDevice, stream));
+        launch_tp_amax_quantize(pb, dx, rows, depth, 3, dq, ds, stream);
+        launch_tp_sum_dequant(pb, dp, ds, dws, dbias, nullptr, rows, n, dy, stream);
+        outs[r].resize(part.size());
+        qouts[r].resize(xs.size());
+        CT2X_HIP_CHECK(hipMemcpyAsync(outs[r].data(), dy, part.size() * 4, hipMemcpyDeviceToHost, stream));
+        CT2X_HIP_CHECK(hipMemcpyAsync(qouts[r].data(), dq, xs.size(), hipMemcpyDeviceToHost, stream));
+        CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+        if (iters > 0) {
+          hipEvent_t e0, e1;
+          CT2X_HIP_CHECK(hipEventCreate(&e0));
+          CT2X_HIP_CHECK(hipEventCreate(&e1));
+          CT2X_HIP_CHECK(hipEventRecord(e0, stream));
+          for (int it = 0; it < iters; ++it) {
+            launch_tp_amax_quantize(pb, dx, rows, depth, 3, dq, ds, stream);
+            launch_tp_sum_dequant(pb, dp, ds, dws, dbias, nullptr, rows, n, dy, stream);
+          }
+          CT2X_HIP_CHECK(hipEventRecord(e1, stream));
+          CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+          float ms = 0.f;
+          CT2X_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+          us[r] = ms * 1e3f / static_cast<float>(iters);
+          (void)hipEventDestroy(e0);
+          (void)hipEventDestroy(e1);
+        }
+        TpBoxControl ctl;
+        CT2X_HIP_CHECK(hipMemcpy(&ctl, pb.box[r], sizeof(ctl), hipMemcpyDeviceToHost));
+        if (ctl.status != 0) throw Error("a poll of the one-shot exchange gave up (peer never arrived)");
+        for (void* ptr : {static_cast<void*>(dx), static_cast<void*>(dq), static_cast<void*>(ds),
+                          static_cast<void*>(dp), static_cast<void*>(dy), static_cast<void*>(dws),
+                          static_cast<void*>(dbias)})
+          device_free(ptr);
+      } catch (const std::exception& e) {
+        errors[r] = e.what();
+      }
+    });
+  }
+  for (auto& th : threads) th.join();
+  for (int r = 0; r < world; ++r)
+    CT2X_CHECK(errors[r].empty(), "rank " + std::to_string(r) + ": " + errors[r]);
+  // reference: what one device computes from the whole rows (same formulas, host arithmetic)
+  for (int64_t i = 0; i < rows; ++i) {
+    float amax = 0.f;
+    for (int64_t j = 0; j < world * depth; ++j) amax = std::max(amax, std::fabs(hx[i * world * depth + j]));
+    const float scale = amax != 0.f ? 127.f / amax : 1.f;
+    const float r_a = 1.f / scale;
+    for (int r = 0; r < world; ++r) {
+      for (int64_t j = 0; j < depth; ++j) {
+        // quant_mode 3: u8 shift + round to nearest even (device_utils.h to_s8)
+        const float v = std::fmaf(hx[(i * world + r) * depth + j], scale, 128.f);
+        const int q = static_cast<int>(std::nearbyintf(v)) - 128;
+        if (qouts[r][i * depth + j] != static_cast<int8_t>(q))
+          throw Error("one-shot absmax exchange: quantised value differs from the unsharded row");
+      }
+    }
+    for (int64_t j = 0; j < n; ++j) {
+      int32_t sum = 0;
+      for (int r = 0; r < world; ++r) sum += (r + 1) * (static_cast<int32_t>((i * n + j) % 1999) - 1000);
+      float v = static_cast<float>(sum) * r_a;
+      v = v / h_ws[j];
+      v = v + h_bias[j];
+      for (int r = 0; r < world; ++r)
+        if (std::memcmp(&outs[r][i * n + j], &v, 4) != 0)
+          throw Error("one-shot sum exchange: dequantised value differs from the unsharded product");
+    }
+  }
+  if (us_per_dense_out) {
+    float worst = 0.f;
+    for (float u : us) worst = std::max(worst, u);
+    *us_per_dense_out = worst;
+  }
+  return 0;
+  API_CATCH
+}
+
 void* ct2x_translator_create_tp(const char* model_dir, int device_index, const char* compute_type,
                                 int rank, int world, const void* unique_id_128_bytes) {
   try {

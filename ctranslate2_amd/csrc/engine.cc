@@ -1125,6 +1125,25 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
       begin_kernel("bias_residual", double(m) * w.n * 8, 0, m, w.n, 0);
       launch_bias_residual(acc, w.bias, residual, m, w.n, y, cur_stream());
       end_kernel();
+    } else if (w.quantized && tp_->peer_box() && tp_oneshot_fits(m, m * w.n)) {
+      // One-shot exchanges inside the producer / consumer kernels (tp_oneshot.hip): 3 launches and
+      // no collective call instead of 6 launches with two all-reduces.
+      const TpPeerBox& pb = *tp_->peer_box();
+      begin_kernel("tp_amax_quantize", double(m) * w.k * 5 + 16.0 * m * pb.world, 0, m, 0, w.k);
+      launch_tp_amax_quantize(pb, x, m, w.k, quant_mode_, ws->qbuf, ws->qscale, cur_stream());
+      end_kernel();
+      GemmS8Epilogue ep;
+      ep.mode = 0;
+      ep.c_i32 = ws->tp_acc;
+      ep.ldy = w.n;
+      begin_kernel("gemm_s8s8s32", double(m) * w.k + double(w.n) * w.k + 4.0 * m * w.n,
+                   2.0 * m * w.n * w.k, m, w.n, w.k);
+      launch_gemm_s8(ws->qbuf, w.wq, m, w.n, w.k, ep, cur_stream());
+      end_kernel();
+      begin_kernel("tp_sum_dequant", double(m) * w.n * (8 + 16.0 * (pb.world - 1)), 0, m, w.n, 0);
+      launch_tp_sum_dequant(pb, ws->tp_acc, ws->qscale, w.wscale, w.bias, residual, m, w.n, y,
+                            cur_stream());
+      end_kernel();
     } else if (w.quantized) {
       begin_kernel("tp_row_amax", double(m) * w.k * 4, 0, m, 0, w.k);
       launch_row_amax(x, m, w.k, ws->tp_amax, cur_stream());
@@ -1164,12 +1183,18 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
                         cur_stream());
       }
       end_kernel();
-      begin_kernel("tp_all_reduce_sum", double(m) * w.n * 4, 0, m, w.n, 0);
-      tp_->all_reduce_sum_f32(acc, m * w.n, cur_stream());
-      end_kernel();
-      begin_kernel("bias_residual", double(m) * w.n * 8, 0, m, w.n, 0);
-      launch_bias_residual(acc, w.bias, residual, m, w.n, y, cur_stream());
-      end_kernel();
+      if (tp_->peer_box() && tp_oneshot_fits(m, m * w.n)) {
+        begin_kernel("tp_sum_bias", double(m) * w.n * (8 + 16.0 * (tp_->world() - 1)), 0, m, w.n, 0);
+        launch_tp_sum_bias(*tp_->peer_box(), acc, w.bias, residual, m, w.n, y, cur_stream());
+        end_kernel();
+      } else {
+        begin_kernel("tp_all_reduce_sum", double(m) * w.n * 4, 0, m, w.n, 0);
+        tp_->all_reduce_sum_f32(acc, m * w.n, cur_stream());
+        end_kernel();
+        begin_kernel("bias_residual", double(m) * w.n * 8, 0, m, w.n, 0);
+        launch_bias_residual(acc, w.bias, residual, m, w.n, y, cur_stream());
+        end_kernel();
+      }
     }
     return;
   }
@@ -2091,7 +2116,14 @@ void Engine::step(DecodeState& st, bool graph) {
   }
   // Under tensor parallelism the step is captured when the communicator's collectives are plain
   // stream work (RCCL); the in-process test double rendezvous on the host and runs eagerly.
-  const bool tp_eager = tp_ && !(tp_graph_ && tp_->capturable());
+  // (with mailboxes, a step whose exchanges all fit the one-shot form contains no collective call at
+  // all - that also makes the in-process communicator capturable)
+  bool tp_stream_only = tp_ && tp_->capturable();
+  if (tp_ && !tp_stream_only && tp_->peer_box() && !tp_fast_) {
+    int64_t widest = dec_.d_model;
+    tp_stream_only = tp_oneshot_fits(st.rows, st.rows * widest);
+  }
+  const bool tp_eager = tp_ && !(tp_graph_ && tp_stream_only);
   if (!graph || profiling_ || tp_eager || st.graph_failed) {
     const int64_t before = tls_launches;
     launch_step(st);

@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -91,10 +92,24 @@ public:
     std::memcpy(id.bytes, unique_id, kTpUniqueIdBytes);
     rccl_check(reinterpret_cast<InitFn>(rccl().CommInitRank)(&comm_, world, id, rank),
                "ncclCommInitRank");
+    const char* e = std::getenv("CT2X_TP_ONESHOT");
+    if (world > 1 && world <= kTpMaxWorld && !(e && e[0] == '0')) {
+      try {
+        setup_peer_boxes();
+      } catch (const std::exception&) {
+        // peer mapping refused (no xGMI / IPC between these devices): RCCL collectives only
+        (void)hipGetLastError();
+        has_box_ = false;
+      }
+    }
   }
   ~RcclComm() override {
+    for (int r = 0; r < world_; ++r)
+      if (r != rank_ && has_box_ && pb_.box[r]) (void)hipIpcCloseMemHandle(pb_.box[r]);
+    if (own_box_) (void)hipFree(own_box_);
     if (comm_) (void)rccl().CommDestroy(comm_);
   }
+  const TpPeerBox* peer_box() const override { return has_box_ ? &pb_ : nullptr; }
   int rank() const override { return rank_; }
   int world() const override { return world_; }
   const char* backend() const override { return "rccl"; }
@@ -116,8 +131,45 @@ public:
   }
 
 private:
+  // One mailbox per rank in fine-grained device memory (peer stores must become visible without a
+  // kernel boundary), its IPC handle all-gathered over the communicator that was just created,
+  // every peer's box opened and mapped. Any refusal leaves the communicator on RCCL collectives.
+  void setup_peer_boxes() {
+    const size_t bytes = tp_box_bytes();
+    CT2X_HIP_CHECK(hipExtMallocWithFlags(reinterpret_cast<void**>(&own_box_), bytes,
+                                         hipDeviceMallocFinegrained));
+    CT2X_HIP_CHECK(hipMemset(own_box_, 0, bytes));
+    hipIpcMemHandle_t mine;
+    CT2X_HIP_CHECK(hipIpcGetMemHandle(&mine, own_box_));
+    void *d_send = nullptr, *d_recv = nullptr;
+    CT2X_HIP_CHECK(hipMalloc(&d_send, sizeof(mine)));
+    CT2X_HIP_CHECK(hipMalloc(&d_recv, sizeof(mine) * world_));
+    CT2X_HIP_CHECK(hipMemcpy(d_send, &mine, sizeof(mine), hipMemcpyHostToDevice));
+    rccl_check(rccl().AllGather(d_send, d_recv, sizeof(mine), kNcclInt8, comm_, nullptr), "ncclAllGather(ipc)");
+    CT2X_HIP_CHECK(hipStreamSynchronize(nullptr));
+    std::vector<hipIpcMemHandle_t> all(world_);
+    CT2X_HIP_CHECK(hipMemcpy(all.data(), d_recv, sizeof(mine) * world_, hipMemcpyDeviceToHost));
+    (void)hipFree(d_send);
+    (void)hipFree(d_recv);
+    pb_.rank = rank_;
+    pb_.world = world_;
+    for (int r = 0; r < world_; ++r) {
+      if (r == rank_) {
+        pb_.box[r] = own_box_;
+      } else {
+        void* p = nullptr;
+        CT2X_HIP_CHECK(hipIpcOpenMemHandle(&p, all[r], hipIpcMemLazyEnablePeerAccess));
+        pb_.box[r] = static_cast<char*>(p);
+      }
+    }
+    has_box_ = true;
+  }
+
   int rank_, world_;
   RcclApi::Comm comm_ = nullptr;
+  char* own_box_ = nullptr;
+  bool has_box_ = false;
+  TpPeerBox pb_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -140,6 +192,11 @@ struct LocalShared {
   std::vector<void*> bufs;
   std::vector<hipEvent_t> ready, done;
   bool poisoned = false;
+  char* boxes[kTpMaxWorld] = {nullptr};  // one-shot mailboxes of the ranks (same device)
+  ~LocalShared() {
+    for (char* b : boxes)
+      if (b) (void)hipFree(b);
+  }
 
   void barrier() {
     std::unique_lock<std::mutex> lock(mu);
@@ -166,6 +223,14 @@ public:
     CT2X_HIP_CHECK(hipEventCreateWithFlags(&s_->ready[rank], hipEventDisableTiming));
     CT2X_HIP_CHECK(hipEventCreateWithFlags(&s_->done[rank], hipEventDisableTiming));
   }
+  // (the boxes are allocated by make_local_comms once every rank exists)
+  void set_boxes() {
+    pb_.rank = rank_;
+    pb_.world = s_->world;
+    for (int r = 0; r < s_->world; ++r) pb_.box[r] = s_->boxes[r];
+    has_box_ = s_->boxes[0] != nullptr;
+  }
+  const TpPeerBox* peer_box() const override { return has_box_ ? &pb_ : nullptr; }
   ~LocalComm() override {
     if (scratch_) { try { device_free(scratch_); } catch (...) {} }
     (void)hipEventDestroy(s_->ready[rank_]);
@@ -227,6 +292,8 @@ private:
   int rank_;
   void* scratch_ = nullptr;
   size_t scratch_bytes_ = 0;
+  TpPeerBox pb_;
+  bool has_box_ = false;
 };
 
 }  // namespace
@@ -243,7 +310,22 @@ std::vector<std::shared_ptr<TpComm>> make_local_comms(int world) {
   if (world < 1 || world > 8) throw Error("in-process communicator: world size must be 1..8");
   auto shared = std::make_shared<LocalShared>(world);
   std::vector<std::shared_ptr<TpComm>> comms;
-  for (int r = 0; r < world; ++r) comms.push_back(std::make_shared<LocalComm>(shared, r));
+  std::vector<std::shared_ptr<LocalComm>> locals;
+  for (int r = 0; r < world; ++r) locals.push_back(std::make_shared<LocalComm>(shared, r));
+  const char* e = std::getenv("CT2X_TP_ONESHOT");
+  if (world > 1 && !(e && e[0] == '0')) {
+    // the same mailboxes and kernels as between GPUs, on one device: what the single-GPU box can
+    // verify of the one-shot exchanges (protocol, tags, parity, exactness) and time as a loopback
+    for (int r = 0; r < world; ++r) {
+      CT2X_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&shared->boxes[r]), tp_box_bytes()));
+      CT2X_HIP_CHECK(hipMemset(shared->boxes[r], 0, tp_box_bytes()));
+    }
+    CT2X_HIP_CHECK(hipDeviceSynchronize());
+  }
+  for (auto& l : locals) {
+    l->set_boxes();
+    comms.push_back(l);
+  }
   return comms;
 }
 

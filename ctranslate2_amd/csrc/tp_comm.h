@@ -23,9 +23,40 @@
 
 namespace ct2x {
 
+// ---- one-shot exchanges over peer-mapped mailboxes (tp_oneshot.hip) ---------------------------
+// Every rank owns one mailbox ("box") that every other rank can store into: peer-mapped device
+// memory between GPUs (hipIpc handles exchanged at bootstrap), plain device memory for the
+// in-process communicator. Layout: control block | absmax granules [2 parity][R sources][rows] |
+// sum granules [2 parity][R sources][elements]; a granule is 8 bytes {payload, tag}.
+constexpr int kTpMaxWorld = 8;
+constexpr int64_t kTpBoxMaxRows = 4096;            // rows per absmax exchange
+constexpr int64_t kTpBoxMaxElements = 1 << 18;     // 4-byte elements per sum exchange (1 MiB)
+struct TpBoxControl {
+  uint32_t seq;     // tag of the last finished exchange (advanced by the exchange kernels)
+  uint32_t done;    // workgroups of the running exchange kernel that have finished
+  uint32_t status;  // 1: a poll gave up (a peer never arrived)
+  uint32_t pad[61];
+};
+static_assert(sizeof(TpBoxControl) == 256, "control block");
+inline __host__ __device__ size_t tp_box_amax_offset(int parity, int src) {
+  return sizeof(TpBoxControl) + (static_cast<size_t>(parity) * kTpMaxWorld + src) * kTpBoxMaxRows * 8;
+}
+inline __host__ __device__ size_t tp_box_sum_offset(int parity, int src) {
+  return sizeof(TpBoxControl) + 2 * static_cast<size_t>(kTpMaxWorld) * kTpBoxMaxRows * 8 +
+         (static_cast<size_t>(parity) * kTpMaxWorld + src) * kTpBoxMaxElements * 8;
+}
+inline size_t tp_box_bytes() { return tp_box_sum_offset(2, 0); }
+struct TpPeerBox {
+  int rank = 0, world = 1;
+  char* box[kTpMaxWorld] = {nullptr};  // box[r]: rank r's mailbox as THIS rank addresses it
+};
+
 class TpComm {
 public:
   virtual ~TpComm() = default;
+  // Mailboxes for the one-shot exchanges, or nullptr when this communicator has none (the engine
+  // then uses the collectives below).
+  virtual const TpPeerBox* peer_box() const { return nullptr; }
   virtual int rank() const = 0;
   virtual int world() const = 0;
   // In-place all-reduce of `count` elements at `buf` (device memory of this rank) on `stream`.
@@ -39,6 +70,16 @@ public:
   // true when the collectives are plain stream work that a hipGraph can capture and replay
   virtual bool capturable() const = 0;
 };
+
+// tp_oneshot.hip: fused producer / consumer kernels of a row-parallel Dense (see the file header).
+bool tp_oneshot_fits(int64_t rows, int64_t elements);
+void launch_tp_amax_quantize(const TpPeerBox& pb, const float* x, int64_t rows, int64_t depth,
+                             int quant_mode, int8_t* q, float* scales, hipStream_t stream);
+void launch_tp_sum_dequant(const TpPeerBox& pb, const int32_t* partial, const float* a_scale,
+                           const float* w_scale, const float* bias, const float* residual,
+                           int64_t m, int64_t n, float* y, hipStream_t stream);
+void launch_tp_sum_bias(const TpPeerBox& pb, const float* partial, const float* bias,
+                        const float* residual, int64_t m, int64_t n, float* y, hipStream_t stream);
 
 // 128-byte ncclUniqueId created on rank 0 and handed to every rank by the launcher.
 constexpr int kTpUniqueIdBytes = 128;

@@ -517,6 +517,13 @@ int ct2x_tp_selftest_rccl(int device_index);
 /* The in-process communicator's collectives (all-reduce int32 sum / float max, GatherAll) with
  * `world` ranks as threads on one device, verified on every rank. */
 int ct2x_tp_selftest_local(int device_index, int world);
+/* The one-shot exchanges of a row-parallel int8 Dense (peer-mapped mailboxes, 8-byte {payload, tag}
+ * granules stored and polled inside the producer / consumer kernels; SURVEY 8(e) "custom <= 1 MiB
+ * one-shot path" instead of ops::ReduceAll, src/ops/nccl_ops_gpu.cu:53-68) on `world` in-process
+ * ranks of one device: results checked bit for bit against the unsharded row, then `iters` exchange
+ * pairs timed; *us_per_dense_out = microseconds per (absmax exchange + sum exchange), worst rank. */
+int ct2x_tp_selftest_oneshot(int device_index, int world, int64_t rows, int64_t depth, int64_t n,
+                             int iters, float* us_per_dense_out);
 int ct2x_translator_create_tp_local(const char* model_dir, int device_index,
                                     const char* compute_type, int world, void** handles_out);
 

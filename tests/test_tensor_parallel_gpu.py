@@ -14,7 +14,7 @@ import pytest
 
 import golden_cases as GC
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
 
 
 def _model_dir(key):
@@ -164,6 +164,71 @@ def test_local_collectives(gpu, world):
     from ctranslate2_amd import _lib
     L = _lib.lib()
     _lib.check(L.ct2x_tp_selftest_local(0, world))
+
+
+# (in-process ranks share ONE GPU: every rank's exchange kernel must be resident at the same time,
+# so the double is exercised with 2 and 4 ranks and modest grids; 8 ranks belong on 8 GPUs)
+@pytest.mark.parametrize("world,rows,depth,n", [(2, 32, 256, 512), (4, 32, 512, 512), (2, 16, 7168, 4096),
+                                                (4, 128, 512, 512)])
+def test_one_shot_exchanges(gpu, world, rows, depth, n):
+    """The one-shot exchanges of a row-parallel int8 Dense (tp_oneshot.hip: granules {payload, tag}
+    stored into peer mailboxes and polled inside the producer / consumer kernels, no collective
+    call): every rank's Quantize output equals the unsharded row's, every rank's dequantised sum
+    equals the unsharded product, bit for bit - and the loopback price of the exchange pair on one
+    device is printed (the number DESIGN section 7 quotes)."""
+    import ctypes as C
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    us = C.c_float()
+    _lib.check(L.ct2x_tp_selftest_oneshot(0, world, C.c_int64(rows), C.c_int64(depth), C.c_int64(n), 50,
+                                          C.byref(us)))
+    print("one-shot exchange pair, world %d, [%d, %d] -> [%d, %d]: %.2f us per row-parallel Dense "
+          "(two launches incl. Quantize and Dequantize, single-device loopback)"
+          % (world, rows, depth, rows, n, us.value))
+    assert 0 < us.value < 500
+
+
+def test_one_shot_off_is_the_collective_path(gpu):
+    """CT2X_TP_ONESHOT=0 keeps the all-reduce form (what a communicator without peer mapping runs):
+    same bits."""
+    import ctranslate2_amd as ct2
+    path = _model_dir("small")
+    src = _sources("small")
+    single = ct2.Translator(path, compute_type="int8")
+    ref, _ = single.translate_ids(src, beam_size=1, max_decoding_length=12, min_decoding_length=12)
+    os.environ["CT2X_TP_ONESHOT"] = "0"
+    try:
+        ranks = ct2.Translator.tensor_parallel_local(path, 2, compute_type="int8")
+    finally:
+        del os.environ["CT2X_TP_ONESHOT"]
+    outs = _run_ranks(ranks, lambda t: t.translate_ids(src, beam_size=1, max_decoding_length=12,
+                                                       min_decoding_length=12)[0])
+    assert outs[0] == ref and outs[1] == ref
+    for t in ranks:
+        t.close()
+
+
+def test_rccl_two_process_tensor_parallel():
+    """The REAL multi-GPU path - one process per GPU, RCCL bootstrap, peer-mapped mailboxes over
+    xGMI (hipIpc), one-shot exchanges - through bench.py --tp under torch.distributed.run. Needs two
+    visible GPUs: collected everywhere, skipped on single-GPU boxes (the driver's GPU tier has one)."""
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--tp", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-l8",
+           "--no-profile", "--check-tp-parity"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    import json
+    res = json.loads(line)
+    assert res["config"]["tp_tokens_equal_unsharded"] is True
 
 
 def test_fast_exchange_mode_is_close_not_exact(gpu):
