@@ -62,6 +62,9 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-l8", action="store_true",
                    help="skip the Llama-3-8B-shape leg (BASELINE configs[2], reported as config.l8)")
+    p.add_argument("--no-nllb", action="store_true",
+                   help="skip the NLLB-3.3B-shape float16 leg (BASELINE configs[3] geometry on one GPU, "
+                        "reported as config.nllb)")
     p.add_argument("--no-profile", action="store_true")
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline")
     return p.parse_args()
@@ -492,6 +495,28 @@ def main():
                 }
             except Exception as e:  # never break the headline line
                 result["config"]["l8"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.no_nllb and args.beam == 1 and args.compute_type == "int8":
+            # BASELINE.json configs[3]'s model and batch (NLLB-200 3.3B shape, float16, batch 64 beam 4)
+            # on this one GPU: tools/bench_nllb.py in its own process (6.6 GB of weights).
+            try:
+                import subprocess
+                translator.close()
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_nllb.py"),
+                                      "--steps", "2", "--warmup", "1"],
+                                     capture_output=True, text=True, timeout=900)
+                nl = json.loads(out.stdout.strip().splitlines()[-1])
+                result["config"]["nllb"] = {
+                    "workload": nl["config"]["workload"], "value": nl["value"], "unit": nl["unit"],
+                    "dtype": nl["dtype"], "ms_per_call": nl["ms_per_step"],
+                    "encode_ms": nl["config"]["encode_ms_last_call"],
+                    "decode_ms_per_step": nl["config"]["decode_ms_per_step"],
+                    "roofline": nl["decode_roofline"],
+                    "parity": "teacher-forced float16 logits within 1e-3 of the reference's float32 "
+                              "evaluation at this geometry (2 + 2 layers): "
+                              "tests/test_translator_gpu.py::test_nllb_geometry_float16_logits",
+                }
+            except Exception as e:  # never break the headline line
+                result["config"]["nllb"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(model_dir, sources, args)

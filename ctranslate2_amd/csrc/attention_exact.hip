@@ -599,7 +599,7 @@ int x_t_pad(const AttnDecodeParams& p) {
 static bool x_dhead_ok(int64_t dh) { return dh == 4 || dh == 8 || dh == 16 || dh == 32 || dh == 64; }
 
 bool attention_exact_decode_applicable(const AttnDecodeParams& p, bool fused_quantize) {
-  if (exact_disabled()) return false;
+  if (exact_disabled() || p.allow_inexact) return false;
   if (p.dhead == 128) return !fused_quantize && attention_exact128_decode_applicable(p);
   if (p.ancestry != nullptr && (p.kv_group != 1 || p.lengths != nullptr)) return false;
   if (!x_dhead_ok(p.dhead) || p.heads < 1 || p.heads_kv < 1 || p.heads % p.heads_kv != 0) return false;

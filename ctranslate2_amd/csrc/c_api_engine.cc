@@ -394,7 +394,7 @@ int ct2x_tp_selftest_oneshot(int device_index, int world, int64_t rows, int64_t 
   // hold identical, bit-exact results. Then `iters` exchange pairs are timed per rank (HIP events
   // on the rank's stream; all ranks run concurrently) - the single-device loopback price of the
   // two exchanges, reported as the maximum over the ranks.
-  CT2X_CHECK(world >= 2 && world <= kTpMaxWorld, "ct2x_tp_selftest_oneshot: world must be in [2, 8]");
+  CT2X_CHECK(world == 2, "ct2x_tp_selftest_oneshot: the in-process form has two ranks (see make_local_comms)");
   CT2X_CHECK(tp_oneshot_fits(rows, rows * n), "ct2x_tp_selftest_oneshot: message larger than the mailbox");
   auto comms = make_local_comms(world);
   CT2X_CHECK(comms[0]->peer_box() != nullptr, "one-shot mailboxes are disabled (CT2X_TP_ONESHOT=0)");
@@ -416,7 +416,7 @@ int ct2x_tp_selftest_oneshot(int device_index, int world, int64_t rows, int64_t 
     threads.emplace_back([&, r] {
       try {
         CT2X_HIP_CHECK(hipSetDevice(device_index));
-        hipStream_t stream = thread_stream();
+        hipStream_t stream = thread_stream_with_priority(r);
         const TpPeerBox& pb = *comms[r]->peer_box();
         std::vector<float> xs(static_cast<size_t>(rows) * depth);
         for (int64_t i = 0; i < rows; ++i)

@@ -688,7 +688,7 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
                                      int32_t disable_id, int32_t min_length,
                                      const int32_t* __restrict__ step_ptr,
                                      const int32_t* __restrict__ extra_min, int32_t beam,
-                                     int chain_pad, float* __restrict__ y) {
+                                     int chain_pad, float* __restrict__ y, int fast) {
   extern __shared__ __attribute__((aligned(16))) float exp_lds[];
   __shared__ float scratch[16];
   const int64_t row = blockIdx.x;
@@ -700,7 +700,7 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
   const float* x = logits + row * vocab;
   float* yr = y + row * vocab;
   constexpr int XR = 32;  // row elements a thread can keep in registers
-  if (chain_pad > 0 && vocab <= static_cast<int64_t>(XR) * blockDim.x) {
+  if (!fast && chain_pad > 0 && vocab <= static_cast<int64_t>(XR) * blockDim.x) {
     // The row is read ONCE: each thread keeps its <= 32 elements in registers for the maximum,
     // the exps (parked transposed in LDS for the ordered sum) and the final x + c.
     float xv[XR];
@@ -748,6 +748,27 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
   for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
     m = fmaxf(m, (j == masked) ? -FLT_MAX : x[j]);
   m = block_max(m, scratch);
+  if (fast) {
+    // 16-bit compute types (no CPU counterpart to reproduce bit for bit): a parallel sum instead of
+    // the reference's eight dependent chains - 32 000 sequential adds per row of a 256 206-word
+    // vocabulary cost 4.8 ms per beam step of the NLLB shape (profiles/r03_nllb_kernel_stats_b.csv)
+    float part = 0.f;
+    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
+      if (j != masked) part += __expf(x[j] - m);
+    part = wave_sum(part);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = part;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < static_cast<int>((blockDim.x + 63) >> 6); ++w) tot += scratch[w];
+    const float c = -m - logf(tot);
+    const float b = beam_scores ? beam_scores[row] : 0.f;
+    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
+      const float v = ((j == masked) ? -FLT_MAX : x[j]) + c;
+      yr[j] = beam_scores ? b + v : v;
+    }
+    return;
+  }
   // the reference's LogSoftMax bit for bit: exp polynomial, sum order, libm logf (the output row
   // parks the exps until the sum is known)
   const float s = ordered_row_exp_sum(x, vocab, masked, m, yr, chain_pad > 0 ? exp_lds : nullptr,
@@ -764,7 +785,7 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
 void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t rows,
                           int64_t vocab, int32_t disable_id, int32_t min_length,
                           const int32_t* step_ptr, float* y, hipStream_t stream,
-                          const int32_t* extra_min_per_batch, int32_t beam) {
+                          const int32_t* extra_min_per_batch, int32_t beam, bool exact) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
@@ -773,7 +794,7 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
   allow_big_lds(reinterpret_cast<const void*>(beam_logprobs_kernel), lds);
   hipLaunchKernelGGL(beam_logprobs_kernel, dim3(rows), dim3(block), lds, stream, logits,
                      beam_scores, vocab, disable_id, min_length, step_ptr, extra_min_per_batch,
-                     beam > 0 ? beam : 1, el.chain_pad, y);
+                     beam > 0 ? beam : 1, el.chain_pad, y, exact ? 0 : 1);
 }
 
 // ---------------------------------------------------------------------------------------------

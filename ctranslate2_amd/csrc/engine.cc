@@ -1175,7 +1175,8 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
       if (w.wh) {
         begin_kernel("gemm_h", 4.0 * m * w.k + 2.0 * w.n * w.k + 4.0 * m * w.n, 2.0 * m * w.n * w.k,
                      m, w.n, w.k);
-        launch_gemm_h(x, w.wh, w.wh_bf16, m, w.n, w.k, nullptr, nullptr, -1, acc, cur_stream());
+        launch_gemm_h(x, w.wh, w.wh_bf16, m, w.n, w.k, nullptr, nullptr, -1, acc, cur_stream(),
+                      ws ? ws->splitk_ws : nullptr, ws ? ws->splitk_floats : 0);
       } else {
         begin_kernel("gemm_f32", 4.0 * (double(m) * w.k + double(w.n) * w.k + double(m) * w.n),
                      2.0 * m * w.n * w.k, m, w.n, w.k);
@@ -1234,7 +1235,8 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
       begin_kernel("gemm_h", 4 * M * K + 2 * N * K + 4 * M * N + (residual ? 4 * M * N : 0),
                    2 * M * N * K, m, w.n, w.k);
     }
-    launch_gemm_h(x, w.wh, w.wh_bf16, m, w.n, w.k, w.bias, residual, act, y, cur_stream());
+    launch_gemm_h(x, w.wh, w.wh_bf16, m, w.n, w.k, w.bias, residual, act, y, cur_stream(),
+                  ws ? ws->splitk_ws : nullptr, ws ? ws->splitk_floats : 0);
     end_kernel();
   } else {
     {
@@ -1298,6 +1300,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   auto st = std::make_unique<DecodeState>();
   st->engine = this;
   st->stream = thread_stream();  // the calling (worker) thread's stream: sessions run concurrently
+  if (tp_ && tp_->peer_box() && std::string(tp_->backend()) == "in-process")
+    st->stream = thread_stream_with_priority(tp_->rank());  // (ranks on one GPU: distinct queues)
   tls_stream = st->stream;
   set_active_stream(tls_stream);
   st->batch = batch;
@@ -1351,6 +1355,12 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     st->awq_ws = alloc<float>(*st, static_cast<int64_t>(kAwqGemmWorkspaceFloats));
   }
   st->qscale = alloc<float>(*st, wrows);
+  if (compute_type_ == ComputeType::kFloat16 || compute_type_ == ComputeType::kBFloat16) {
+    // split-K partials of the 16-bit GEMM at a few hundred decode rows (beam search on large
+    // batches): session owned, so a captured step never allocates
+    st->splitk_floats = static_cast<size_t>(16) * rows * std::max(std::max(d, wffn), wqkv);
+    st->splitk_ws = alloc<float>(*st, static_cast<int64_t>(st->splitk_floats));
+  }
   st->logits = alloc<float>(*st, rows * V);
   st->d_ids = alloc<int32_t>(*st, rows);
   st->d_step = alloc<int32_t>(*st, 1);
@@ -1404,6 +1414,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       }
       p.ancestry = reinterpret_cast<const int32_t*>(aligned);
       p.ancestry_stride = rows;
+      p.allow_inexact = half_compute();
       ok = attention_exact_decode_applicable(p, false);
     }
     st->ancestry = ok;
@@ -1860,6 +1871,7 @@ void Engine::launch_step(DecodeState& st) {
       p.kv_group = 1;
       p.t_max = st.t_max;
       p.scale = a.queries_scale;
+      p.allow_inexact = half_compute();
       if (a.rotary) {
         rotary_tables(a, st.t_max + 1, &p.rope_sin, &p.rope_cos);
         p.rot_dim = a.rotary_dim == 0 ? a.dhead : a.rotary_dim;
@@ -1963,6 +1975,7 @@ void Engine::launch_step(DecodeState& st) {
       p.kv_group = st.beam;
       p.t_max = st.s_max;
       p.scale = a.queries_scale;
+      p.allow_inexact = half_compute();
       p.out = st.ctx;
       if (st.beam > 1) {  // first beam-search step: the CPU reference has not expanded the batch yet
         p.one_row_step_ptr = st.d_step;
@@ -2072,7 +2085,7 @@ void Engine::launch_step(DecodeState& st) {
     launch_beam_logprobs(st.logits, st.beam_scores, st.rows, V, st.g_eos, st.g_min_length,
                          st.d_step, st.logprobs, cur_stream(),
                          st.prefix_extends_min ? st.d_bprefix_len : nullptr,
-                         static_cast<int32_t>(st.beam));
+                         static_cast<int32_t>(st.beam), !half_compute());
     end_kernel();
     begin_kernel("beam_topk", double(st.rows) * V * 4, 0, st.batch, 2 * st.beam, st.beam * V);
     launch_topk(st.logprobs, st.batch, st.beam * V, 2 * st.beam, st.topk_scores, st.topk_ids,

@@ -148,6 +148,10 @@ public:
 
   const ModelFile& model() const { return *model_; }
   ComputeType compute_type() const { return compute_type_; }
+  // float16 / bfloat16: no CPU counterpart exists, the exact-order kernels are not required
+  bool half_compute() const {
+    return compute_type_ == ComputeType::kFloat16 || compute_type_ == ComputeType::kBFloat16;
+  }
   bool is_seq2seq() const { return has_encoder_; }
   int64_t vocab_size() const { return dec_.projection.n; }
   int64_t d_model() const { return dec_.d_model; }
@@ -397,6 +401,8 @@ struct DecodeState {
   float* tp_amax = nullptr;  // tensor parallel: per-row absmax [rows]
   int8_t* qbuf = nullptr;    // [rows, max(d, ffn)]
   uint16_t* hbuf = nullptr;  // [rows, max(d, ffn)] float16 activations (AWQ Dense only)
+  float* splitk_ws = nullptr;  // split-K partial sums of the 16-bit GEMM (decode rows > 128)
+  size_t splitk_floats = 0;
   float* awq_ws = nullptr;   // split-K slices of the AWQ GEMM (kAwqGemmWorkspaceFloats)
   float* qscale = nullptr;   // [rows]
   int32_t* d_ids = nullptr;  // [rows] next input ids

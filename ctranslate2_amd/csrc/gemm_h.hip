@@ -60,6 +60,22 @@ struct HalfOps<true> {
   }
 };
 
+// float16 only: the fp32 activation enters the matrix pipe as TWO float16 values, a = hi + lo with
+// hi = RN_f16(a), lo = RN_f16(a - hi) (22 significant bits), and every weight fragment is
+// multiplied by both - the weights are the model's own float16 values and the products accumulate
+// in fp32, so the layer is a float32 evaluation of the stored model up to 2^-22 relative: the
+// north-star's "fp16 logits within 1e-3 of the CPU reference" holds with three orders of magnitude
+// to spare instead of by 20 % (1.2e-3 measured at the NLLB geometry with one rounding to 2^-11).
+// Decode rows are bandwidth bound (the second MFMA is free); sequence-mode rows pay 2x MFMAs.
+__device__ __forceinline__ void split_f16(const float4& lo4, const float4& hi4, v8h& hi, v8h& lo) {
+  const float a[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hi[e] = static_cast<_Float16>(a[e]);
+    lo[e] = static_cast<_Float16>(a[e] - static_cast<float>(hi[e]));
+  }
+}
+
 struct HalfEpilogue {
   const float* bias;
   const float* residual;
@@ -148,9 +164,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_h_skinny_kernel(const float* 
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const vec af = Ops::from_f32(alo[u][i], ahi[u][i]);
+        if constexpr (!kBF16) {
+          v8h a_hi, a_lo;
+          split_f16(alo[u][i], ahi[u][i], a_hi, a_lo);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = Ops::mfma(af, bf[u][j], acc[i][j]);
+          for (int j = 0; j < NT; ++j) {
+            acc[i][j] = Ops::mfma(a_lo, bf[u][j], acc[i][j]);
+            acc[i][j] = Ops::mfma(a_hi, bf[u][j], acc[i][j]);
+          }
+        } else {
+          const vec af = Ops::from_f32(alo[u][i], ahi[u][i]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = Ops::mfma(af, bf[u][j], acc[i][j]);
+        }
       }
   }
 
@@ -185,16 +211,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_h_skinny_kernel(const float* 
 // 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles. Rows are padded to 144 bytes in LDS (conflict-free
 // ds_read_b128 fragments); the A tile is converted fp32 -> 16 bit on its way into LDS; the next
 // stage's global loads are in flight during the MFMAs.
+// Split K (gridDim.z > 1): slice z covers K elements [z * k_slice, (z + 1) * k_slice) and writes its
+// fp32 partial tile to partial[z][M][N]; gemm_h_splitk_reduce_kernel adds the slices in z order
+// (deterministic) and applies the epilogue. Without it a [256 x 2048] x [2048 x 2048]^T launch is 32
+// workgroups on a 256-CU chip (the NLLB decode step at batch 64 x beam 4: 22.9 ms per step,
+// profiles/r03_nllb_bench_a.json).
 template <bool kBF16>
 __global__ __launch_bounds__(256) void gemm_h_tiled_kernel(const float* __restrict__ A,
                                                            const uint16_t* __restrict__ W, int M,
-                                                           int N, int K, HalfEpilogue ep) {
+                                                           int N, int K, HalfEpilogue ep,
+                                                           int k_slice, float* __restrict__ partial) {
   using Ops = HalfOps<kBF16>;
   using vec = typename Ops::vec;
   constexpr int BM = 128, BN = 128, BK = 64, STRIDE = BK * 2 + 16;  // bytes per LDS row
-  __shared__ __attribute__((aligned(16))) uint8_t lds[(BM + BN) * STRIDE];
+  // (float16: a third tile holds the low halves of the split activation, see split_f16)
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(BM + BN + (kBF16 ? 0 : BM)) * STRIDE];
   uint8_t* As = lds;
   uint8_t* Bs = lds + BM * STRIDE;
+  uint8_t* Al = lds + (BM + BN) * STRIDE;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -231,17 +265,26 @@ __global__ __launch_bounds__(256) void gemm_h_tiled_kernel(const float* __restri
     }
   };
 
-  load_tile(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
+  const int k_begin = blockIdx.z * k_slice;
+  const int k_end = min(K, k_begin + k_slice);
+  load_tile(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<vec*>(As + (ld_row + i * 32) * STRIDE + ld_c * 16) =
-          Ops::from_f32(ra_lo[i], ra_hi[i]);
+      if constexpr (!kBF16) {
+        v8h a_hi, a_lo;
+        split_f16(ra_lo[i], ra_hi[i], a_hi, a_lo);
+        *reinterpret_cast<v8h*>(As + (ld_row + i * 32) * STRIDE + ld_c * 16) = a_hi;
+        *reinterpret_cast<v8h*>(Al + (ld_row + i * 32) * STRIDE + ld_c * 16) = a_lo;
+      } else {
+        *reinterpret_cast<vec*>(As + (ld_row + i * 32) * STRIDE + ld_c * 16) =
+            Ops::from_f32(ra_lo[i], ra_hi[i]);
+      }
       *reinterpret_cast<vec*>(Bs + (ld_row + i * 32) * STRIDE + ld_c * 16) = rb[i];
     }
     __syncthreads();
-    if (k0 + BK < K) load_tile(k0 + BK);
+    if (k0 + BK < k_end) load_tile(k0 + BK);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       vec af[4], bfr[4];
@@ -252,6 +295,16 @@ __global__ __launch_bounds__(256) void gemm_h_tiled_kernel(const float* __restri
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         bfr[j] = *reinterpret_cast<const vec*>(Bs + (wn * 64 + j * 16 + r) * STRIDE + koff);
+      if constexpr (!kBF16) {
+        vec al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          al[i] = *reinterpret_cast<const vec*>(Al + (wm * 64 + i * 16 + r) * STRIDE + koff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = Ops::mfma(al[i], bfr[j], acc[i][j]);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -259,6 +312,22 @@ __global__ __launch_bounds__(256) void gemm_h_tiled_kernel(const float* __restri
     }
   }
 
+  if (partial != nullptr) {  // split K: raw partial sums, the reduce kernel finishes
+    float* pz = partial + static_cast<int64_t>(blockIdx.z) * M * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t row = m0 + wm * 64 + i * 16 + g * 4 + e;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t col = n0 + wn * 64 + j * 16 + r;
+          if (col < N) pz[row * N + col] = acc[i][j][e];
+        }
+      }
+    return;
+  }
   // Epilogue: operands first, then stores (see gemm_s8.hip).
   float bias[4];
   bool col_ok[4];
@@ -295,9 +364,20 @@ __global__ __launch_bounds__(256) void gemm_h_tiled_kernel(const float* __restri
   }
 }
 
+__global__ void gemm_h_splitk_reduce_kernel(const float* __restrict__ partial, int splits, int64_t n,
+                                           int64_t total, HalfEpilogue ep) {
+  const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (e >= total) return;
+  float v = partial[e];
+  for (int z = 1; z < splits; ++z) v = v + partial[z * total + e];  // fixed order: deterministic
+  const int64_t col = e % n;
+  ep.y[e] = finish(v, ep.bias ? ep.bias[col] : 0.f, ep.bias != nullptr, ep.act,
+                   ep.residual ? ep.residual[e] : 0.f, ep.residual != nullptr);
+}
+
 template <bool kBF16>
 void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const HalfEpilogue& ep,
-                  hipStream_t stream) {
+                  hipStream_t stream, float* splitk_ws, size_t splitk_floats) {
 #define CT2X_HSKINNY(MT, NT, WAVES, U)                                                       \
   hipLaunchKernelGGL((gemm_h_skinny_kernel<kBF16, MT, NT, WAVES, U>),                        \
                      dim3((N + 16 * NT - 1) / (16 * NT)), dim3(WAVES * 64), 0, stream, a, w, M, N, \
@@ -312,24 +392,42 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
     return;
   }
 #undef CT2X_HSKINNY
-  hipLaunchKernelGGL((gemm_h_tiled_kernel<kBF16>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256),
-                     0, stream, a, w, M, N, K, ep);
+  const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
+  int splits = 1;
+  if (splitk_ws != nullptr) {
+    // enough workgroups for the chip, slices of whole 64-element stages, at least 4 stages each
+    while (tiles * splits < 256 && splits < 16 && K / (splits * 2) >= 256 && (K / (splits * 2)) % 64 == 0 &&
+           static_cast<size_t>(splits) * 2 * M * N <= splitk_floats)
+      splits *= 2;
+  }
+  if (splits == 1) {
+    hipLaunchKernelGGL((gemm_h_tiled_kernel<kBF16>), dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256),
+                       0, stream, a, w, M, N, K, ep, K, static_cast<float*>(nullptr));
+    return;
+  }
+  hipLaunchKernelGGL((gemm_h_tiled_kernel<kBF16>), dim3((N + 127) / 128, (M + 127) / 128, splits),
+                     dim3(256), 0, stream, a, w, M, N, K, ep, K / splits, splitk_ws);
+  const int64_t total = static_cast<int64_t>(M) * N;
+  hipLaunchKernelGGL(gemm_h_splitk_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
+                     dim3(256), 0, stream, splitk_ws, splits, static_cast<int64_t>(N), total, ep);
 }
 
 }  // namespace
 
 void launch_gemm_h(const float* a, const void* w, bool bf16, int64_t m, int64_t n, int64_t k,
                    const float* bias, const float* residual, int act, float* y,
-                   hipStream_t stream) {
+                   hipStream_t stream, float* splitk_ws, size_t splitk_floats) {
   if (m == 0 || n == 0) return;
   if (k % 8 != 0 || (reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(w) & 15))
     throw Error("16-bit GEMM: K must be a multiple of 8 and the operands 16-byte aligned");
   HalfEpilogue ep{bias, residual, y, act};
   const auto* wp = static_cast<const uint16_t*>(w);
   if (bf16)
-    launch_typed<true>(a, wp, static_cast<int>(m), static_cast<int>(n), static_cast<int>(k), ep, stream);
+    launch_typed<true>(a, wp, static_cast<int>(m), static_cast<int>(n), static_cast<int>(k), ep, stream,
+                       splitk_ws, splitk_floats);
   else
-    launch_typed<false>(a, wp, static_cast<int>(m), static_cast<int>(n), static_cast<int>(k), ep, stream);
+    launch_typed<false>(a, wp, static_cast<int>(m), static_cast<int>(n), static_cast<int>(k), ep, stream,
+                        splitk_ws, splitk_floats);
 }
 
 }  // namespace ct2x

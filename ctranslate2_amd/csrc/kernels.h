@@ -198,11 +198,13 @@ void launch_gemm_f32(const float* a, const float* b, int64_t batch, int64_t m, i
 
 // ---- float16 / bfloat16 weight GEMM (gemm_h.hip) -------------------------------------
 
+// splitk_ws (optional, caller owned, splitk_floats floats): lets launches with too few 128 x 128 tiles
+// for the chip split K over gridDim.z and reduce in a second launch (deterministic order).
 // y = act(a[m,k] (fp32, rounded to the weight type at the matrix pipe) . w[n,k]^T + bias) + residual,
 // fp32 accumulation on v_mfma_f32_16x16x32_{f16,bf16}. k % 8 == 0.
 void launch_gemm_h(const float* a, const void* w, bool bf16, int64_t m, int64_t n, int64_t k,
                    const float* bias, const float* residual, int act, float* y,
-                   hipStream_t stream);
+                   hipStream_t stream, float* splitk_ws = nullptr, size_t splitk_floats = 0);
 
 // ---- attention (attention.hip) -------------------------------------------------------
 
@@ -255,6 +257,9 @@ struct AttnDecodeParams {
   // is appended to the row's own cache row. nullptr: the row's own cache row holds everything.
   const int32_t* ancestry = nullptr;
   int64_t ancestry_stride = 0;
+  // 16-bit compute types have no CPU counterpart to reproduce bit for bit: the exact-order kernels
+  // are skipped in favour of the fast ones
+  bool allow_inexact = false;
 };
 
 bool attention_decode_emits_row_amax(const AttnDecodeParams& p);
@@ -440,7 +445,8 @@ void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64
 void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t rows,
                           int64_t vocab, int32_t disable_id, int32_t min_length,
                           const int32_t* step_ptr, float* y, hipStream_t stream,
-                          const int32_t* extra_min_per_batch = nullptr, int32_t beam = 1);
+                          const int32_t* extra_min_per_batch = nullptr, int32_t beam = 1,
+                          bool exact = true);
 
 }  // namespace ct2x
 

@@ -70,6 +70,28 @@ hipStream_t thread_stream() {
   return t_stream.stream;
 }
 
+// The calling thread's stream re-created at priority level `level` (0 = default, 1 = highest).
+// Streams of different priorities never share a hardware queue; the in-process tensor-parallel
+// double needs that (its two ranks run kernels that wait for each other: on one shared queue the
+// second would sit behind the first forever).
+hipStream_t thread_stream_with_priority(int level) {
+  int device = 0;
+  CT2X_HIP_CHECK(hipGetDevice(&device));
+  int least = 0, greatest = 0;
+  CT2X_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const int prio = level > 0 ? greatest : 0;
+  if (t_stream.stream != nullptr && t_stream.device == device) {
+    int cur = 0;
+    if (hipStreamGetPriority(t_stream.stream, &cur) == hipSuccess && cur == prio) return t_stream.stream;
+    (void)hipStreamSynchronize(t_stream.stream);
+    (void)hipStreamDestroy(t_stream.stream);
+    t_stream.stream = nullptr;
+  }
+  CT2X_HIP_CHECK(hipStreamCreateWithPriority(&t_stream.stream, hipStreamNonBlocking, prio));
+  t_stream.device = device;
+  return t_stream.stream;
+}
+
 void set_active_stream(hipStream_t stream) { t_active = stream; }
 hipStream_t active_stream() { return t_active ? t_active : thread_stream(); }
 

@@ -38,6 +38,7 @@ const char* last_error();
 
 // The calling thread's stream (created on first use on the current device).
 hipStream_t thread_stream();
+hipStream_t thread_stream_with_priority(int level);
 inline hipStream_t resolve_stream(void* s) {
   return s ? static_cast<hipStream_t>(s) : thread_stream();
 }

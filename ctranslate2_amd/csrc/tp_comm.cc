@@ -313,9 +313,12 @@ std::vector<std::shared_ptr<TpComm>> make_local_comms(int world) {
   std::vector<std::shared_ptr<LocalComm>> locals;
   for (int r = 0; r < world; ++r) locals.push_back(std::make_shared<LocalComm>(shared, r));
   const char* e = std::getenv("CT2X_TP_ONESHOT");
-  if (world > 1 && !(e && e[0] == '0')) {
+  if (world == 2 && !(e && e[0] == '0')) {
     // the same mailboxes and kernels as between GPUs, on one device: what the single-GPU box can
-    // verify of the one-shot exchanges (protocol, tags, parity, exactness) and time as a loopback
+    // verify of the one-shot exchanges (protocol, tags, parity, exactness) and time as a loopback.
+    // TWO ranks only: their kernels wait for each other, so they must sit on different hardware
+    // queues - guaranteed by giving the two rank threads streams of different priority
+    // (thread_stream_with_priority); more in-process ranks keep the host-rendezvous collectives.
     for (int r = 0; r < world; ++r) {
       CT2X_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&shared->boxes[r]), tp_box_bytes()));
       CT2X_HIP_CHECK(hipMemset(shared->boxes[r], 0, tp_box_bytes()));

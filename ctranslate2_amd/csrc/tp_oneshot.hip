@@ -34,19 +34,19 @@ __device__ __forceinline__ void granule_store(uint64_t* p, uint32_t payload, uin
   __hip_atomic_store(p, (static_cast<uint64_t>(tag) << 32) | payload, __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// Polls until the granule carries `tag`; false (and status = 1) after ~2 s without it.
+// Polls until the granule carries `tag`; false (and status = 1) after a few seconds without it.
 __device__ __forceinline__ bool granule_wait(const uint64_t* p, uint32_t tag, uint32_t* payload,
                                              uint32_t* status) {
   // (fail fast: once any poll of this rank has given up, nobody waits again - a dead peer costs one
   // time-out, not one per granule)
-  const uint32_t limit = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : (1u << 20);
+  const uint32_t limit = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : (1u << 22);
   for (uint32_t spin = 0; spin < limit; ++spin) {
     const uint64_t g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (static_cast<uint32_t>(g >> 32) == tag) {
       *payload = static_cast<uint32_t>(g);
       return true;
     }
-    if (spin > 64) __builtin_amdgcn_s_sleep(8);
+    if (spin > 64) __builtin_amdgcn_s_sleep(32);
   }
   __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   *payload = 0;

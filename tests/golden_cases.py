@@ -65,3 +65,12 @@ LLAMA3_GEOMETRY = {
         "p200": {"data_seed": 13, "batch": 2, "prompt_len": 200, "max_len": 12, "teacher_forced": False},
     },
 }
+
+# Encoder-decoder model at the NLLB-200 3.3B geometry (BASELINE.json configs[3]): d_head 128, 16 heads,
+# FFN 8192, shared embeddings, float16 weights - two layers each side (tests/golden/
+# make_golden_nllb_geometry.py; the GPU test rebuilds the model directory from the seed).
+NLLB_GEOMETRY = {
+    "model": dict(num_encoder_layers=2, num_decoder_layers=2, d_model=2048, ffn_dim=8192, num_heads=16,
+                  vocab_size=8192, seed=21, quantization="float16", direct_f16=True, share_embeddings=True),
+    "data_seed": 22, "src_lengths": [24, 24, 17, 24, 9, 24], "max_len": 12, "logits_steps": 12,
+}

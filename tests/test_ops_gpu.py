@@ -229,8 +229,9 @@ def _from_bf16_bits(b):
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("act,with_res", [(-1, True), (0, False)])
 def test_gemm_half_weights(gpu, m, n, k, bf16, act, with_res):
-    """float16 / bfloat16 arm of ops::Gemm: operands rounded to the 16-bit type, products summed in
-    fp32 (MFMA). Oracle: the same rounded operands multiplied in float64; the only difference left
+    """float16 / bfloat16 arm of ops::Gemm: weights in the 16-bit type, activation rounded to bfloat16
+    (bf16) or split into two float16 halves (fp16, gemm_h.hip split_f16), products summed in fp32
+    (MFMA). Oracle: the same rounded operands multiplied in float64; the only difference left
     is the fp32 accumulation order (<= ~sqrt(k) * 2^-24 relative to the sum of |products|)."""
     import _gpuops as G
     rng = np.random.default_rng(m + n + k + int(bf16))
@@ -243,7 +244,9 @@ def test_gemm_half_weights(gpu, m, n, k, bf16, act, with_res):
         wr, ar = _from_bf16_bits(wb), _from_bf16_bits(_to_bf16_bits(a))
     else:
         wh = w.astype(np.float16)
-        wb, wr, ar = wh.view(np.uint16), wh.astype(np.float32), a.astype(np.float16).astype(np.float32)
+        # (float16: the activation enters as hi + lo float16 halves - 22 bits - so the oracle keeps it
+        # in fp32; only the WEIGHT is a float16 value)
+        wb, wr, ar = wh.view(np.uint16), wh.astype(np.float32), a
     y = G.gemm_f16w(a, wb, bf16, bias, res, act)
     ref = ar.astype(np.float64) @ wr.astype(np.float64).T + bias
     if act == 0:

@@ -152,6 +152,36 @@ def test_teacher_forced_logits_half(gpu, golden, key, ct):
     assert np.array_equal(logits.argmax(-1)[decided], ref_arg[decided])
 
 
+def test_nllb_geometry_float16_logits(gpu):
+    """BASELINE.json configs[3]'s geometry (NLLB-200 3.3B: d_model 2048, 16 heads of 128, FFN 8192,
+    shared embeddings; two layers each side) stored in float16, run with compute type float16,
+    against the reference's float32 evaluation of the same weights (tests/golden/
+    make_golden_nllb_geometry.py): teacher-forced logits within 1e-3 (north_star), greedy tokens
+    equal wherever the reference's own margin exceeds the tolerance."""
+    import ctranslate2_amd as ct2
+    from ctranslate2_amd import model_builder as mb
+    with open(os.path.join(HERE, "golden", "nllb_geometry_golden.json")) as f:
+        g = json.load(f)
+    path = "/tmp/ct2x_test_nllb_geom"
+    if not os.path.exists(os.path.join(path, "model.bin")):
+        mb.build_transformer(path, **GC.NLLB_GEOMETRY["model"])
+    t = ct2.Translator(path, device="cuda", compute_type="float16")
+    assert t.compute_type == "float16"
+    tf = g["teacher_forced"]
+    src = [g["sources"][i] for i in tf["rows"]]
+    logits = t.step_logits(src, np.array(tf["tgt_in"], np.int32))  # [T, B, V]
+    cols = np.array(tf["cols"])
+    err = np.abs(logits[..., cols] - np.array(tf["values"], np.float32))
+    top2 = np.array(tf["top2"])
+    margin = top2[..., 0] - top2[..., 1]
+    print("nllb geometry float16: max |logit - ref| = %.3e, logits std %.3f / absmax %.1f"
+          % (err.max(), tf["logit_std"], tf["logit_absmax"]))
+    assert err.max() < 1e-3
+    decided = margin > 2e-3
+    assert np.array_equal(logits.argmax(-1)[decided], np.array(tf["argmax"])[decided])
+    t.close()
+
+
 def test_half_models_resolve_their_compute_type(gpu):
     """model.bin stored in float16 / bfloat16 loads unchanged and "default" resolves to that type
     (resolve_compute_type, src/types.cc:156-295); int8_float16 requests run as int8_float32."""
