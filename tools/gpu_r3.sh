@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3
-timeout 300 python -m pytest tests/test_tensor_parallel_gpu.py -q -s -x -k "one_shot" > gpurun_out/r3/pytest_tp.log 2>&1; tail -6 gpurun_out/r3/pytest_tp.log
-timeout 900 python -m pytest tests/test_translator_gpu.py tests/test_ops_gpu.py tests/test_generator_gpu.py -q -x > gpurun_out/r3/pytest_c.log 2>&1; tail -4 gpurun_out/r3/pytest_c.log
-timeout 500 python tools/bench_nllb.py > gpurun_out/r3/nllb_c.json 2> gpurun_out/r3/nllb_c.err; python -c "
-import json;d=json.loads(open('gpurun_out/r3/nllb_c.json').read().strip().splitlines()[-1]);print(d['value'],d['config']['decode_ms_per_step'],d['config']['encode_ms_last_call'])"
+export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/ctranslate2_amd:$LD_LIBRARY_PATH
+(for s in 4096 4224 8192 8320 16384; do timeout 120 ./build/tools/big2_loop_probe 2048 $s brief; done) > gpurun_out/r3/big2_loop_probe_strides.txt 2>&1; cat gpurun_out/r3/big2_loop_probe_strides.txt
+(echo "== one wave per SIMD (gemm_s8_big2)"; ./build/tools/gemm_bench 4096 4096 4096 4096 4096 4224 8192 8192 8192 8192 8192 8320; echo "== 8-wave ping-pong (gemm_s8_big)"; CT2X_GEMM_BIG=1 ./build/tools/gemm_bench 4096 4096 4096 4096 4096 4224 8192 8192 8192 8192 8192 8320) > gpurun_out/r3/gemm_bench_strides.txt 2>&1; grep s8s8s32 gpurun_out/r3/gemm_bench_strides.txt
