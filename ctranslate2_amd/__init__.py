@@ -203,8 +203,13 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                       target_prefix_ids: Optional[Sequence[Sequence[int]]] = None,
                       repetition_penalty: float = 1.0, no_repeat_ngram_size: int = 0,
                       suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None,
-                      end_token_id: Optional[int] = None):
-        """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores).
+                      end_token_id: Optional[int] = None, return_alternatives: bool = False,
+                      min_alternative_expansion_prob: float = 0.0, prefix_bias_beta: float = 0.0,
+                      coverage_penalty: float = 0.0, return_attention: bool = False):
+        """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores), plus
+        the attention ([batch][hyp] arrays [tokens, source length]) when return_attention is set.
+        return_alternatives / min_alternative_expansion_prob / prefix_bias_beta / coverage_penalty /
+        return_attention: as in the reference's TranslationOptions.
         end_token_id: another target id that ends decoding (TranslationOptions::end_token).
         sampling_* (reference names, python/cpp/translator.cc): random sampling among the best
         sampling_topk candidates (beam_size must be 1), reproducible for a `seed`.
@@ -226,6 +231,15 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         _keep = self._set_processors(opt, repetition_penalty, no_repeat_ngram_size,
                                      suppress_sequences_ids)
         opt.end_token_plus_one = 0 if end_token_id is None else int(end_token_id) + 1
+        opt.return_alternatives = int(return_alternatives)
+        opt.min_alternative_expansion_prob = float(min_alternative_expansion_prob)
+        opt.prefix_bias_beta = float(prefix_bias_beta)
+        opt.coverage_penalty = float(coverage_penalty)
+        att = None
+        if return_attention:
+            att = np.zeros((batch, num_hypotheses, max_decoding_length, stride), np.float32)
+            opt.attention_stride = stride
+            opt.attention_out = att.ctypes.data_as(C.POINTER(C.c_float))
         if target_prefix_ids is not None:
             plen = np.array([len(p) for p in target_prefix_ids], np.int32)
             pstride = max(1, int(plen.max()) if batch else 1)
@@ -240,8 +254,14 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
             _lib.check(self._L.ct2x_translate_batch(
                 C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
                 C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
-        hyps = [[out[b, k, :out_len[b, k]].tolist() for k in range(num_hypotheses)
-                 if out_len[b, k] > 0 or k == 0] for b in range(batch)]
+        keep = [[k for k in range(num_hypotheses)
+                 if (out_len[b, k] >= 0 if return_alternatives else (out_len[b, k] > 0 or k == 0))]
+                for b in range(batch)]
+        hyps = [[out[b, k, :max(out_len[b, k], 0)].tolist() for k in keep[b]] for b in range(batch)]
+        if return_attention:
+            atts = [[att[b, k, :max(out_len[b, k], 0), :len(source_ids[b])].copy() for k in keep[b]]
+                    for b in range(batch)]
+            return hyps, scores, atts
         return hyps, scores
 
     def translate_batch(self, source: List[List[str]], target_prefix: Optional[list] = None,
@@ -322,7 +342,7 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                      suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None,
                      end_token_id: Optional[int] = None):
         """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False.
-        sampling_topk=1 is greedy; 2..64 samples among the best k (sampling_topp / temperature as
+        sampling_topk=1 is greedy; k >= 2 samples among the best k, 0 from the whole vocabulary (sampling_topp / temperature as
         in the reference). Returns (generated ids per prompt, scores)."""
         batch = len(prompts)
         lengths = np.array([len(p) for p in prompts], np.int32)
@@ -343,6 +363,37 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
             C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
             C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
         return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
+
+    @staticmethod
+    def _pack_ids(seqs):
+        lengths = np.array([len(s) for s in seqs], np.int32)
+        stride = max(1, int(lengths.max())) if len(seqs) else 1
+        ids = np.zeros((len(seqs), stride), np.int32)
+        for i, s in enumerate(seqs):
+            ids[i, :len(s)] = s
+        return ids, lengths, stride
+
+    def forward_ids(self, sequences: Sequence[Sequence[int]], return_log_probs: bool = False):
+        """ctranslate2.Generator.forward_batch on token ids: logits (or log-probabilities) of every
+        position, [batch, longest sequence, vocabulary]."""
+        ids, lengths, stride = self._pack_ids(sequences)
+        out = np.empty((len(sequences), int(lengths.max()), self.vocab_size), np.float32)
+        _lib.check(self._L.ct2x_forward_batch(
+            C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(len(sequences)),
+            C.c_int32(stride), C.c_int32(1 if return_log_probs else 0), _lib.ptr(out)))
+        return out
+
+    def score_tokens_ids(self, sequences: Sequence[Sequence[int]], max_input_length: int = 1024):
+        """ctranslate2.Generator.score_batch on token ids: for every sequence the log-probabilities
+        of tokens[1:] given what precedes them (an empty list for sequences of fewer than 2
+        tokens)."""
+        ids, lengths, stride = self._pack_ids(sequences)
+        scores = np.zeros((len(sequences), stride), np.float32)
+        out_len = np.zeros((len(sequences),), np.int32)
+        _lib.check(self._L.ct2x_generator_score_batch(
+            C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(len(sequences)),
+            C.c_int32(stride), C.c_int32(max_input_length), _lib.ptr(scores), _lib.ptr(out_len)))
+        return [scores[b, :out_len[b]].copy() for b in range(len(sequences))]
 
     def step_logits(self, source_ids, target_in):
         """Teacher-forced per-step logits [T, batch, vocab] (source ids INCLUDE special tokens)."""

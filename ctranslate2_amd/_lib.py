@@ -43,6 +43,13 @@ class TranslationOptions(C.Structure):
         ("end_token_plus_one", C.c_int32),
         ("suppress_ids", C.POINTER(C.c_int32)),
         ("suppress_lengths", C.POINTER(C.c_int32)),
+        ("return_alternatives", C.c_int32),
+        ("min_alternative_expansion_prob", C.c_float),
+        ("prefix_bias_beta", C.c_float),
+        ("coverage_penalty", C.c_float),
+        ("attention_stride", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("attention_out", C.POINTER(C.c_float)),
     ]
 
 

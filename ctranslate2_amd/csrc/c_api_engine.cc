@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <exception>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -170,6 +171,11 @@ DecodingOptions to_decoding_options(const ct2x_translation_options& o) {
   d.sampling_topp = o.sampling_topp == 0.f ? 1.f : o.sampling_topp;
   d.sampling_temperature = o.sampling_temperature == 0.f ? 1.f : o.sampling_temperature;
   d.seed = o.seed;
+  d.prefix_bias_beta = o.prefix_bias_beta;
+  d.return_alternatives = o.return_alternatives != 0;
+  d.min_alternative_expansion_prob = o.min_alternative_expansion_prob;
+  d.coverage_penalty = o.coverage_penalty;
+  d.return_attention = o.attention_out != nullptr;
   LogitsProcessing& lp = d.logits_processing;
   lp.repetition_penalty = o.repetition_penalty == 0.f ? 1.f : o.repetition_penalty;
   lp.no_repeat_ngram_size = o.no_repeat_ngram_size;
@@ -552,6 +558,153 @@ int ct2x_translator_create_tp_local(const char* model_dir, int device_index,
 
 void ct2x_translator_destroy(void* translator) { delete static_cast<Translator*>(translator); }
 
+// decode_alternatives (src/decoding.cc:1122-1290) for a batch of sentences: the target prefix is
+// consumed by ONE sequence-mode pass of the decoder, the num_hypotheses best next tokens are
+// expanded by a one-step beam search, and every (sentence, alternative) pair is then continued
+// independently with the requested search. The reference runs this sentence by sentence; here
+// sentences with the same prefix length share their launches (the prefix length fixes the shape
+// of the sequence-mode pass, hence its summation order - sentences of different prefix lengths
+// cannot share it bit for bit). `sources` hold the prepared source ids (empty: skipped).
+static void decode_alternatives(Translator& t, const std::vector<std::vector<int32_t>>& sources,
+                                const std::vector<std::vector<int32_t>>& prefixes_in,
+                                const ct2x_translation_options& opt, const DecodingOptions& dopt,
+                                int32_t end_id, std::vector<DecodingResult>& out, double* encode_ms,
+                                double* decode_ms) {
+  Engine& e = *t.engine;
+  const int32_t batch = static_cast<int32_t>(sources.size());
+  const int32_t nh = dopt.num_hypotheses, max_length = dopt.max_length;
+  // the encoder output of the reference's batch pads every sentence to the longest source
+  int64_t s_max = 0;
+  for (const auto& s : sources) s_max = std::max<int64_t>(s_max, static_cast<int64_t>(s.size()));
+  std::map<size_t, std::vector<int32_t>> by_prefix_length;
+  std::vector<std::vector<int32_t>> prefixes(batch);
+  for (int32_t b = 0; b < batch; ++b) {
+    if (sources[b].empty()) continue;
+    prefixes[b] = prefixes_in[b];
+    // start_tokens (= start token + prefix) longer than max_length + 1 are cut (:1139-1140)
+    if (static_cast<int32_t>(prefixes[b].size()) > max_length) prefixes[b].resize(max_length);
+    by_prefix_length[prefixes[b].size()].push_back(b);
+  }
+  for (const auto& group : by_prefix_length) {
+    const int64_t plen = static_cast<int64_t>(group.first);
+    const std::vector<int32_t>& members = group.second;
+    const int64_t B = static_cast<int64_t>(members.size());
+    if (plen == max_length) {  // the prefix is the whole hypothesis (:1176-1177)
+      for (int32_t b : members) {
+        out[b].hypotheses.assign(nh, prefixes[b]);
+        if (dopt.return_scores) out[b].scores.assign(nh, 0.f);
+      }
+      continue;
+    }
+    auto make_state = [&](const std::vector<int32_t>& rows_of, int64_t beam, int64_t t_max) {
+      const int64_t R = static_cast<int64_t>(rows_of.size());
+      std::vector<int32_t> ids(R * s_max, 0), lens(R);
+      for (int64_t i = 0; i < R; ++i) {
+        const auto& src = sources[rows_of[i]];
+        std::copy(src.begin(), src.end(), ids.begin() + i * s_max);
+        lens[i] = static_cast<int32_t>(src.size());
+      }
+      const double t0 = now_ms();
+      auto st = e.start(ids.data(), lens.data(), R, s_max, beam, t_max, plen);
+      e.synchronize();
+      *encode_ms += now_ms() - t0;
+      if (plen > 0) {  // decoder inputs "<s> p0 .. p(n-2)" at positions 0 .. n-1 (:1148-1160)
+        std::vector<int32_t> pre(static_cast<size_t>(R * beam * plen));
+        for (int64_t i = 0; i < R; ++i)
+          for (int64_t k = 0; k < beam; ++k) {
+            int32_t* row = pre.data() + (i * beam + k) * plen;
+            row[0] = t.start_id;
+            for (int64_t p = 1; p < plen; ++p) row[p] = prefixes[rows_of[i]][p - 1];
+          }
+        e.prefill(*st, pre.data(), plen);
+      }
+      return st;
+    };
+    // ---- the num_hypotheses best next tokens: BeamSearch(num_hypotheses), one step (:1183-1197)
+    const double td0 = now_ms();
+    std::vector<int32_t> last_token(B);
+    for (int64_t i = 0; i < B; ++i)
+      last_token[i] = plen > 0 ? prefixes[members[i]].back() : t.start_id;
+    std::vector<DecodingResult> expansion;
+    {
+      auto st = make_state(members, nh, plen + 2);
+      DecodingOptions d1;
+      d1.beam_size = nh;
+      d1.num_hypotheses = nh;
+      d1.max_length = 1;
+      d1.min_length = 1;
+      d1.length_penalty = 0.f;
+      d1.return_scores = true;
+      d1.use_graph = false;
+      d1.start_step = static_cast<int32_t>(plen);
+      d1.logits_processing = dopt.logits_processing;
+      expansion = beam_search(e, *st, last_token, end_id, d1, nullptr, nullptr);
+      e.synchronize();
+    }
+    // ---- every alternative that is probable enough becomes a row of the suffix search
+    std::vector<int32_t> alt_sentence, alt_token;
+    std::vector<float> alt_score;
+    for (int64_t i = 0; i < B; ++i) {
+      const int32_t b = members[i];
+      for (int32_t k = 0; k < nh && k < static_cast<int32_t>(expansion[i].hypotheses.size()); ++k) {
+        const float prob = std::exp(expansion[i].scores[k]);
+        if (prob < opt.min_alternative_expansion_prob) break;
+        std::vector<int32_t> hyp = prefixes[b];
+        hyp.push_back(expansion[i].hypotheses[k].back());
+        out[b].hypotheses.emplace_back(std::move(hyp));
+        if (dopt.return_scores) out[b].scores.push_back(expansion[i].scores[k]);
+        alt_sentence.push_back(b);
+        alt_token.push_back(expansion[i].hypotheses[k].back());
+        alt_score.push_back(expansion[i].scores[k]);
+      }
+    }
+    const int64_t start_step = plen + 1;
+    if (start_step == max_length || alt_sentence.empty()) {  // (:1236-1238)
+      *decode_ms += now_ms() - td0;
+      continue;
+    }
+    // ---- continue from each alternative independently (:1240-1256)
+    DecodingOptions d2 = dopt;
+    d2.max_length = std::max<int32_t>(max_length - static_cast<int32_t>(start_step), 0);
+    d2.min_length = std::max<int32_t>(dopt.min_length - static_cast<int32_t>(start_step), 0);
+    d2.num_hypotheses = 1;
+    d2.start_step = static_cast<int32_t>(start_step);
+    auto st = make_state(alt_sentence, d2.beam_size, start_step + d2.max_length + 1);
+    {
+      // the decode step of the last prefix token (the expansion step of the reference, whose
+      // state the suffix search inherits)
+      std::vector<int32_t> ids(st->rows);
+      for (size_t a = 0; a < alt_sentence.size(); ++a) {
+        const auto& pfx = prefixes[alt_sentence[a]];
+        for (int64_t k = 0; k < d2.beam_size; ++k)
+          ids[a * d2.beam_size + k] = plen > 0 ? pfx.back() : t.start_id;
+      }
+      // (in the reference that step belongs to the expansion search, whose first step runs one row
+      // per sentence - the encoder-decoder attention takes the one-row forms, as at every first
+      // step of a CPU beam search)
+      st->prefix_first_step = static_cast<int32_t>(plen);
+      e.set_step(*st, static_cast<int32_t>(plen));
+      e.set_ids(*st, ids.data());
+      e.step(*st, /*graph=*/false);
+      e.advance_step(*st);
+    }
+    std::vector<DecodingResult> suffix =
+        d2.beam_size == 1 ? greedy_search(e, *st, alt_token, end_id, d2, nullptr, nullptr)
+                          : beam_search(e, *st, alt_token, end_id, d2, nullptr, nullptr);
+    e.synchronize();
+    std::map<int32_t, int32_t> next_slot;
+    for (size_t a = 0; a < alt_sentence.size(); ++a) {
+      const int32_t b = alt_sentence[a];
+      const int32_t k = next_slot[b]++;
+      auto& hyp = out[b].hypotheses[k];
+      if (!suffix[a].hypotheses.empty())
+        hyp.insert(hyp.end(), suffix[a].hypotheses[0].begin(), suffix[a].hypotheses[0].end());
+      if (dopt.return_scores && !suffix[a].scores.empty()) out[b].scores[k] += suffix[a].scores[0];
+    }
+    *decode_ms += now_ms() - td0;
+  }
+}
+
 static int translate_batch_impl(void* translator, const int32_t* src_ids,
                                 const int32_t* src_lengths, int32_t batch, int32_t src_stride,
                                 const int32_t* prefix_ids, const int32_t* prefix_lengths,
@@ -602,12 +755,30 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
     }
   }
 
+  std::vector<DecodingResult> all_results(batch);
+  double encode_ms = 0, decode_ms = 0;
+  for (int32_t b = 0; b < batch; ++b)
+    for (int32_t k = 0; k < nh; ++k) out_lengths[b * nh + k] = 0;
+  if (opt.return_alternatives) {
+    CT2X_CHECK(opt.prefix_bias_beta <= 0.f, "Biased decoding is not compatible with the "
+               "return_alternatives mode");
+    CT2X_CHECK(opt.attention_out == nullptr, "return_attention is not supported together with "
+               "return_alternatives in this backend yet");
+    std::vector<std::vector<int32_t>> prefixes(batch);
+    if (prefix_ids != nullptr)
+      for (int32_t b = 0; b < batch; ++b) {
+        const int32_t* p = prefix_ids + static_cast<int64_t>(b) * prefix_stride;
+        prefixes[b].assign(p, p + prefix_lengths[b]);
+        for (int32_t id : prefixes[b])
+          CT2X_CHECK(id >= 0 && id < static_cast<int32_t>(t->engine->vocab_size()),
+                     "Invalid target prefix token ID " + std::to_string(id));
+      }
+    decode_alternatives(*t, sources, prefixes, opt, dopt, end_id, all_results, &encode_ms, &decode_ms);
+  } else {
   // rebatch_input (src/batch_reader.cc:175-228): longest first, split by max_batch_size.
   std::vector<int32_t> order;
   for (int32_t b = 0; b < batch; ++b)
     if (!sources[b].empty()) order.push_back(b);
-  for (int32_t b = 0; b < batch; ++b)
-    for (int32_t k = 0; k < nh; ++k) out_lengths[b * nh + k] = 0;
   if (opt.max_batch_size > 0)
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
       return sources[a].size() > sources[b].size();
@@ -654,7 +825,6 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
       groups.push_back(Group{begin, std::min(re, begin + sub), s_max});
   }
 
-  double encode_ms = 0, decode_ms = 0;
   std::mutex stats_mutex;
   std::atomic<size_t> next_group{0};
   std::exception_ptr first_error;
@@ -674,8 +844,9 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
           lens[i] = static_cast<int32_t>(s.size());
         }
         const double te0 = now_ms();
+        const bool biased = dopt.prefix_bias_beta > 0 && prefix_ids != nullptr;
         auto st = t->engine->start(ids.data(), lens.data(), B, s_max, dopt.beam_size,
-                                   dopt.max_length);
+                                   dopt.max_length, 0, /*beam_search_state=*/biased);
         t->engine->synchronize();
         const double te1 = now_ms();
         std::vector<int32_t> start_ids(B, t->start_id);
@@ -697,35 +868,18 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
         }
         const std::vector<std::vector<int32_t>>* pf = any_prefix ? &prefix : nullptr;
         DecodeStats ds;
+        // make_search_strategy (src/decoding.cc:1075-1087): biased decoding is a beam search
         std::vector<DecodingResult> results =
-            dopt.beam_size == 1
+            (dopt.beam_size == 1 && !(dopt.prefix_bias_beta > 0 && pf))
                 ? greedy_search(*t->engine, *st, start_ids, end_id, dopt, &ds, pf)
                 : beam_search(*t->engine, *st, start_ids, end_id, dopt, &ds, pf);
         t->engine->synchronize();
         const double te2 = now_ms();
-        int64_t tokens = 0;
-        for (int64_t i = 0; i < B; ++i) {
-          const int32_t b = order[begin + i];
-          DecodingResult& r = results[i];
-          for (int32_t k = 0; k < nh && k < static_cast<int32_t>(r.hypotheses.size()); ++k) {
-            auto& hyp = r.hypotheses[k];
-            // "Remove EOS token" (sequence_to_sequence.cc:374-384).
-            if (!opt.return_end_token)
-              while (!hyp.empty() && hyp.back() == end_id) hyp.pop_back();
-            const int32_t len = static_cast<int32_t>(hyp.size());
-            std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
-                      out_ids + (static_cast<int64_t>(b) * nh + k) * max_len);
-            out_lengths[b * nh + k] = len;
-            if (opt.return_scores && out_scores && k < static_cast<int32_t>(r.scores.size()))
-              out_scores[b * nh + k] = r.scores[k];
-            if (k == 0) tokens += len;  // ExecutionStats: hypothesis 0 tokens
-          }
-        }
+        for (int64_t i = 0; i < B; ++i) all_results[order[begin + i]] = std::move(results[i]);
         std::lock_guard<std::mutex> lock(stats_mutex);
         encode_ms += te1 - te0;
         decode_ms += te2 - te1;
         t->last.decode_steps = std::max<int64_t>(t->last.decode_steps, ds.steps);
-        t->last.num_tokens += tokens;
       }
     } catch (...) {
       std::lock_guard<std::mutex> lock(stats_mutex);
@@ -740,6 +894,45 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
     t->pool.run(n_threads, job);
   }
   if (first_error) std::rethrow_exception(first_error);
+  }  // (plain decoding)
+  for (int32_t b = 0; b < batch; ++b) {
+    DecodingResult& r = all_results[b];
+    for (int32_t k = 0; k < nh; ++k) {
+      if (k >= static_cast<int32_t>(r.hypotheses.size())) {
+        // fewer alternatives than num_hypotheses passed min_alternative_expansion_prob
+        if (opt.return_alternatives && !sources[b].empty()) out_lengths[b * nh + k] = -1;
+        continue;
+      }
+      auto& hyp = r.hypotheses[k];
+      // "Remove EOS token" (sequence_to_sequence.cc:374-384).
+      if (!opt.return_end_token)
+        while (!hyp.empty() && hyp.back() == end_id) hyp.pop_back();
+      const int32_t len = static_cast<int32_t>(hyp.size());
+      std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
+                out_ids + (static_cast<int64_t>(b) * nh + k) * max_len);
+      out_lengths[b * nh + k] = len;
+      if (opt.return_scores && out_scores && k < static_cast<int32_t>(r.scores.size()))
+        out_scores[b * nh + k] = r.scores[k];
+      if (opt.attention_out && k < static_cast<int32_t>(r.attention.size())) {
+        // one source attention vector per returned token (the end token's goes with it)
+        // "Remove attention positions for padding and implicit special tokens"
+        // (sequence_to_sequence.cc:399-412): the vector covers the caller's source tokens
+        const auto& att = r.attention[k];
+        float* dst = opt.attention_out + (static_cast<int64_t>(b) * nh + k) * max_len * opt.attention_stride;
+        const size_t first = t->add_source_bos ? 1 : 0;
+        const size_t with_specials = sources[b].size();
+        const size_t last = with_specials - (t->add_source_eos ? 1 : 0);
+        for (int32_t s_ = 0; s_ < len && s_ < max_len && s_ < static_cast<int32_t>(att.size()); ++s_) {
+          float* row = dst + static_cast<int64_t>(s_) * opt.attention_stride;
+          std::fill(row, row + opt.attention_stride, 0.f);
+          for (size_t j = first; j < last && j < att[s_].size() &&
+                                 j - first < static_cast<size_t>(opt.attention_stride); ++j)
+            row[j - first] = att[s_][j];
+        }
+      }
+      if (k == 0) t->last.num_tokens += len;  // ExecutionStats: hypothesis 0 tokens
+    }
+  }
   t->last.num_examples = batch;
   t->last.kernels_per_step = t->engine->kernels_per_step();
   t->last.encode_ms = encode_ms;
@@ -950,6 +1143,105 @@ int ct2x_score_batch(void* translator, const int32_t* src_ids, const int32_t* sr
     const int32_t b = order[i];
     for (int32_t s = 0; s < out_lengths[b]; ++s)
       out_scores[static_cast<int64_t>(b) * out_stride + s] = h_scores[s * B + i];
+  }
+  API_CATCH
+}
+
+// Generator::forward_batch (include/ctranslate2/generator.h:31-35; SequenceGeneratorReplica::
+// forward, src/models/language_model.cc:73-100): one sequence-mode pass, logits of every position.
+int ct2x_forward_batch(void* translator, const int32_t* ids, const int32_t* lengths, int32_t batch,
+                       int32_t stride, int32_t return_log_probs, float* out) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  std::lock_guard<std::mutex> lock(t->mutex);
+  Engine& e = *t->engine;
+  CT2X_CHECK(!e.is_seq2seq(), "This model cannot be used as a sequence generator");
+  CT2X_CHECK(batch > 0 && ids && lengths && out, "ct2x_forward_batch: empty input");
+  int64_t T = 0;
+  for (int32_t b = 0; b < batch; ++b) {
+    CT2X_CHECK(lengths[b] >= 0 && lengths[b] <= stride, "ct2x_forward_batch: bad length");
+    T = std::max<int64_t>(T, lengths[b]);
+  }
+  CT2X_CHECK(T > 0, "ct2x_forward_batch: every sequence is empty");
+  const int64_t V = e.vocab_size(), rows = static_cast<int64_t>(batch) * T;
+  std::vector<int32_t> padded(rows, 0);  // make_sequence_inputs pads with 0
+  for (int32_t b = 0; b < batch; ++b)
+    for (int32_t i = 0; i < lengths[b]; ++i) {
+      const int32_t id = ids[static_cast<int64_t>(b) * stride + i];
+      CT2X_CHECK(id >= 0 && id < V, "Invalid token ID " + std::to_string(id));
+      padded[b * T + i] = id;
+    }
+  auto st = e.start_decoder_only(batch, 1, T, T);
+  float* d_logits = static_cast<float*>(device_malloc(sizeof(float) * rows * V));
+  st->owned.push_back(d_logits);
+  e.prefill(*st, padded.data(), T, d_logits);
+  if (return_log_probs) launch_softmax(d_logits, nullptr, rows, V, /*log=*/true, d_logits, st->stream);
+  CT2X_HIP_CHECK(hipMemcpyAsync(out, d_logits, sizeof(float) * rows * V, hipMemcpyDeviceToHost, st->stream));
+  CT2X_HIP_CHECK(hipStreamSynchronize(st->stream));
+  API_CATCH
+}
+
+// Generator::score_batch (include/ctranslate2/generator.h:21-25; DecoderReplica::run_scoring ->
+// score_sequences, src/models/language_model.cc:110-135, src/scoring.cc:9-60): the log-probability
+// of tokens[1:] given the tokens before them; sequences of fewer than 2 tokens are skipped
+// (out_lengths 0). out_scores [batch, stride].
+int ct2x_generator_score_batch(void* translator, const int32_t* ids, const int32_t* lengths,
+                               int32_t batch, int32_t stride, int32_t max_input_length,
+                               float* out_scores, int32_t* out_lengths) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  std::lock_guard<std::mutex> lock(t->mutex);
+  Engine& e = *t->engine;
+  CT2X_CHECK(!e.is_seq2seq(), "This model cannot be used as a sequence generator");
+  CT2X_CHECK(max_input_length >= 0, "max_input_length must be >= 0");
+  const int64_t V = e.vocab_size();
+  std::vector<std::vector<int32_t>> seqs(batch);
+  std::vector<int32_t> order;
+  int64_t T = 0;
+  for (int32_t b = 0; b < batch; ++b) {
+    out_lengths[b] = 0;
+    if (lengths[b] < 2) continue;  // skip_scoring
+    auto& s = seqs[b];
+    for (int32_t i = 0; i < lengths[b]; ++i) {
+      const int32_t id = ids[static_cast<int64_t>(b) * stride + i];
+      CT2X_CHECK(id >= 0 && id < V, "Invalid token ID " + std::to_string(id));
+      s.push_back(id);
+    }
+    truncate_ids(s, static_cast<size_t>(max_input_length), t->eos_id);
+    if (s.size() < 2) continue;
+    order.push_back(b);
+    out_lengths[b] = static_cast<int32_t>(s.size()) - 1;
+    T = std::max<int64_t>(T, static_cast<int64_t>(s.size()) - 1);
+  }
+  if (order.empty()) return 0;
+  const int64_t B = static_cast<int64_t>(order.size()), rows = B * T;
+  std::vector<int32_t> inputs(rows, 0), targets(rows, 0);
+  for (int64_t i = 0; i < B; ++i) {
+    const auto& s = seqs[order[i]];
+    for (size_t k = 0; k + 1 < s.size(); ++k) {
+      inputs[i * T + k] = s[k];
+      targets[i * T + k] = s[k + 1];
+    }
+  }
+  auto st = e.start_decoder_only(B, 1, T, T);
+  float* d_logits = static_cast<float*>(device_malloc(sizeof(float) * rows * V));
+  st->owned.push_back(d_logits);
+  int32_t* d_targets = static_cast<int32_t*>(device_malloc(sizeof(int32_t) * rows));
+  st->owned.push_back(d_targets);
+  float* d_scores = static_cast<float*>(device_malloc(sizeof(float) * rows));
+  st->owned.push_back(d_scores);
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_targets, targets.data(), sizeof(int32_t) * rows, hipMemcpyHostToDevice, st->stream));
+  e.prefill(*st, inputs.data(), T, d_logits);
+  launch_score_tokens(d_logits, rows, V, d_targets, d_scores, st->stream);
+  std::vector<float> h(rows);
+  CT2X_HIP_CHECK(hipMemcpyAsync(h.data(), d_scores, sizeof(float) * rows, hipMemcpyDeviceToHost, st->stream));
+  CT2X_HIP_CHECK(hipStreamSynchronize(st->stream));
+  for (int64_t i = 0; i < B; ++i) {
+    const int32_t b = order[i];
+    for (int32_t k = 0; k < out_lengths[b] && k < stride; ++k)
+      out_scores[static_cast<int64_t>(b) * stride + k] = h[i * T + k];
   }
   API_CATCH
 }

@@ -667,8 +667,6 @@ int ct2x_random_sample(const float* d_logits, int64_t rows, int64_t vocab, int32
                        float* d_scores, void* stream) {
   API_TRY
   CT2X_CHECK(rows >= 0 && vocab >= 1, "ct2x_random_sample: bad shape");
-  CT2X_CHECK(sampling_topk <= max_sampling_topk(),
-             "ct2x_random_sample: sampling_topk must be <= 64 (or <= 0 for the whole vocabulary)");
   CT2X_CHECK(temperature > 0.f && sampling_topp > 0.f && sampling_topp <= 1.f,
              "ct2x_random_sample: temperature > 0, 0 < sampling_topp <= 1");
   CT2X_CHECK(d_step != nullptr && d_ids != nullptr && d_scores != nullptr,

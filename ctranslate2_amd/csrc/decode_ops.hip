@@ -368,7 +368,13 @@ __global__ void random_sample_kernel(const float* __restrict__ logits, int64_t v
 }
 
 // RandomSampler over the WHOLE vocabulary (sampling_topk = 0 in the reference: no TopK
-// restriction, src/sampling.cc:54-66): temperature -> [TopPMask] -> SoftMax -> Multinomial.
+// restriction, src/sampling.cc:54-66) or over the best `topk` tokens for a topk too large for the
+// candidate lists of random_sample_kernel (65 .. vocabulary - 1):
+// [TopK] -> temperature -> [TopPMask] -> SoftMax -> Multinomial.
+//  * TopK without a sort: the value of the topk-th largest token is found by bisection on the
+//    ordered bit pattern (32 counting passes); tokens above it are in, and of the tokens that TIE
+//    with it the ones with the lowest indices, as many as are missing (ops::TopK's order:
+//    src/ops/topk_cpu.cc:13-55). TopPMask and the draw then see only those tokens;
 //  * the multinomial draw is an inverse CDF in index order: every thread owns a contiguous
 //    segment of the vocabulary, a block scan of the segment masses finds the owner of the
 //    uniform draw, which then walks its segment;
@@ -384,13 +390,14 @@ __device__ __forceinline__ uint32_t ordered_key(float v) {
 
 __global__ __launch_bounds__(1024) void random_sample_full_kernel(
     const float* __restrict__ logits, int64_t vocab, int32_t disable_id, int32_t min_length,
-    bool with_scores, float topp, float temperature, uint32_t seed, SamplePrefix pf,
+    bool with_scores, int topk, float topp, float temperature, uint32_t seed, SamplePrefix pf,
     StepAdvance adv, const int32_t* step_ptr, int32_t* __restrict__ next_ids,
     int32_t* __restrict__ hist_ids, float* __restrict__ hist_scores,
     const float* __restrict__ uniforms) {
   __shared__ float scratch[16];
   __shared__ float seg_incl[1024];
   __shared__ int s_pick;
+  __shared__ int s_tie_limit;
   const int64_t row = blockIdx.x;
   const int64_t rows = gridDim.x;
   const int step = *step_ptr;
@@ -413,10 +420,60 @@ __global__ __launch_bounds__(1024) void random_sample_full_kernel(
     s = block_sum(s, scratch);
     lse_c = -m - logf(s);
   }
-  uint32_t keep_key = 0;  // tokens with ordered_key >= keep_key take part
+  const int64_t seg = (vocab + nthreads - 1) / nthreads;
+  const int64_t j0 = min(vocab, static_cast<int64_t>(tid) * seg), j1 = min(vocab, j0 + seg);
+  // TopK: candidates are the tokens with a key above k_key, and those with key == k_key up to
+  // index tie_limit (counts as floats: exact below 2^24 tokens)
+  uint32_t k_key = 0;
+  int64_t tie_limit = vocab;
+  if (topk > 0 && topk < vocab) {
+    uint32_t lo = 0, hi = ordered_key(m);
+    while (lo < hi) {  // the smallest key with fewer than topk tokens above it
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      float above = 0.f;
+      for (int64_t j = tid; j < vocab; j += nthreads) above += (ordered_key(val(j)) > mid) ? 1.f : 0.f;
+      above = block_sum(above, scratch);
+      if (above < static_cast<float>(topk))
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    k_key = lo;
+    float above = 0.f;
+    for (int64_t j = tid; j < vocab; j += nthreads) above += (ordered_key(val(j)) > k_key) ? 1.f : 0.f;
+    above = block_sum(above, scratch);
+    const int need = topk - static_cast<int>(above);  // >= 1 tied tokens complete the list
+    float ties = 0.f;
+    for (int64_t j = j0; j < j1; ++j) ties += (ordered_key(val(j)) == k_key) ? 1.f : 0.f;
+    seg_incl[tid] = ties;
+    if (tid == 0) s_tie_limit = static_cast<int>(vocab);
+    __syncthreads();
+    for (int off = 1; off < nthreads; off <<= 1) {
+      const float add = (tid >= off) ? seg_incl[tid - off] : 0.f;
+      __syncthreads();
+      seg_incl[tid] += add;
+      __syncthreads();
+    }
+    const int before = static_cast<int>(tid ? seg_incl[tid - 1] : 0.f);
+    if (before < need && need <= static_cast<int>(seg_incl[tid])) {  // the need-th tie is in this segment
+      int seen = before;
+      for (int64_t j = j0; j < j1; ++j)
+        if (ordered_key(val(j)) == k_key && ++seen == need) s_tie_limit = static_cast<int>(j);
+    }
+    __syncthreads();
+    tie_limit = s_tie_limit;
+    __syncthreads();
+  }
+  auto candidate = [&](int64_t j, uint32_t key) {
+    return key > k_key || (key == k_key && j <= tie_limit);
+  };
+  uint32_t keep_key = 0;  // candidates with ordered_key >= keep_key take part
   if (topp < 1.f) {
     float total = 0.f;
-    for (int64_t j = tid; j < vocab; j += nthreads) total += expf((val(j) - m) * inv_t);
+    for (int64_t j = tid; j < vocab; j += nthreads) {
+      const float v = val(j);
+      if (candidate(j, ordered_key(v))) total += expf((v - m) * inv_t);
+    }
     total = block_sum(total, scratch);
     uint32_t lo = 0, hi = ordered_key(m);
     while (lo < hi) {
@@ -424,7 +481,8 @@ __global__ __launch_bounds__(1024) void random_sample_full_kernel(
       float above = 0.f;
       for (int64_t j = tid; j < vocab; j += nthreads) {
         const float v = val(j);
-        if (ordered_key(v) > mid) above += expf((v - m) * inv_t);
+        const uint32_t key = ordered_key(v);
+        if (key > mid && candidate(j, key)) above += expf((v - m) * inv_t);
       }
       above = block_sum(above, scratch);
       if (above / total < topp)
@@ -436,11 +494,10 @@ __global__ __launch_bounds__(1024) void random_sample_full_kernel(
   }
   auto weight = [&](int64_t j) {
     const float v = val(j);
-    return (ordered_key(v) >= keep_key) ? expf((v - m) * inv_t) : 0.f;
+    const uint32_t key = ordered_key(v);
+    return (key >= keep_key && candidate(j, key)) ? expf((v - m) * inv_t) : 0.f;
   };
 
-  const int64_t seg = (vocab + nthreads - 1) / nthreads;
-  const int64_t j0 = min(vocab, static_cast<int64_t>(tid) * seg), j1 = min(vocab, j0 + seg);
   float mass = 0.f;
   for (int64_t j = j0; j < j1; ++j) mass += weight(j);
   seg_incl[tid] = mass;
@@ -584,9 +641,10 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
   const SamplePrefix pf{prefix_ids, prefix_lens, prefix_stride, prefix_first_step,
                         prefix_extends_min ? 1 : 0};
   const StepAdvance adv{advance_step_ptr, done_counter};
-  if (topk <= 0) {  // the whole vocabulary
+  if (topk <= 0 || topk > kMaxSampleTopK) {  // the whole vocabulary, or a long candidate list
     hipLaunchKernelGGL(random_sample_full_kernel, dim3(rows), dim3(1024), 0, stream, logits, vocab,
-                       disable_id, min_length, with_scores, topp, temperature, seed, pf, adv,
+                       disable_id, min_length, with_scores, (topk <= 0 || topk >= vocab) ? 0 : topk, topp,
+                       temperature, seed, pf, adv,
                        step_ptr, next_ids, hist_ids, hist_scores, uniforms);
     return;
   }
@@ -595,7 +653,7 @@ void launch_random_sample(const float* logits, int64_t rows, int64_t vocab, int3
                      step_ptr, next_ids, hist_ids, hist_scores, uniforms);
 }
 
-int max_sampling_topk() { return kMaxSampleTopK; }
+int max_sampling_topk() { return kMaxSampleTopK; }  // longest candidate LIST; larger k: threshold form
 
 // ---------------------------------------------------------------------------------------------
 // Logits processors (src/decoding_utils.cc): RepetitionPenalty -> NoRepeatNgram -> SuppressTokens /
@@ -683,12 +741,25 @@ void launch_advance_step(int32_t* step_ptr, hipStream_t stream) {
   hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, stream, step_ptr);
 }
 
+// Biased decoding (BiasedDecoder::decode, src/decoding.cc:263-323): while a beam has followed the
+// target prefix so far, its next-token distribution is (1 - beta) * softmax(logits) + beta * onehot
+// (prefix token of this step); a beam that left the prefix (`diverged`, kept by beam_select_kernel)
+// and every step past the prefix use the plain LogSoftMax.
+struct BeamBias {
+  const int32_t* ids;       // [batch, stride] target prefixes, nullptr = no biased decoding
+  const int32_t* lens;      // [batch]
+  int32_t stride;
+  int32_t first_step;
+  float beta;
+  const uint8_t* diverged;  // [batch * beam]
+};
+
 __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
                                      const float* __restrict__ beam_scores, int64_t vocab,
                                      int32_t disable_id, int32_t min_length,
                                      const int32_t* __restrict__ step_ptr,
                                      const int32_t* __restrict__ extra_min, int32_t beam,
-                                     int chain_pad, float* __restrict__ y, int fast) {
+                                     int chain_pad, float* __restrict__ y, int fast, BeamBias bias) {
   extern __shared__ __attribute__((aligned(16))) float exp_lds[];
   __shared__ float scratch[16];
   const int64_t row = blockIdx.x;
@@ -699,6 +770,31 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
   const int masked = (step < row_min) ? disable_id : -1;
   const float* x = logits + row * vocab;
   float* yr = y + row * vocab;
+  if (bias.ids != nullptr) {
+    const int pstep = step - bias.first_step;
+    const int64_t b = row / beam;
+    if (pstep >= 0 && pstep < bias.lens[b] && !bias.diverged[row]) {
+      // SoftMax -> * (1 - beta) -> [prefix token] += beta -> Log (the reference's op sequence; its
+      // Log is MKL's vsLn, here logf: the scores agree to float rounding, not bit for bit)
+      const int32_t biased = bias.ids[b * bias.stride + pstep];
+      float m = -FLT_MAX;
+      for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
+        m = fmaxf(m, (j == masked) ? -FLT_MAX : x[j]);
+      m = block_max(m, scratch);
+      const float s = ordered_row_exp_sum(x, vocab, masked, m, yr, chain_pad > 0 ? exp_lds : nullptr,
+                                          chain_pad, scratch);
+      const float bs = beam_scores ? beam_scores[row] : 0.f;
+      const float discount = 1.f - bias.beta;
+      for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
+        const float xv = (j == masked) ? -FLT_MAX : x[j];
+        float pr = (expf(xv - m) / s) * discount;
+        if (j == biased) pr = pr + bias.beta;
+        const float v = logf(pr);
+        yr[j] = beam_scores ? bs + v : v;
+      }
+      return;
+    }
+  }
   constexpr int XR = 32;  // row elements a thread can keep in registers
   if (!fast && chain_pad > 0 && vocab <= static_cast<int64_t>(XR) * blockDim.x) {
     // The row is read ONCE: each thread keeps its <= 32 elements in registers for the maximum,
@@ -785,16 +881,20 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
 void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t rows,
                           int64_t vocab, int32_t disable_id, int32_t min_length,
                           const int32_t* step_ptr, float* y, hipStream_t stream,
-                          const int32_t* extra_min_per_batch, int32_t beam, bool exact) {
+                          const int32_t* extra_min_per_batch, int32_t beam, bool exact,
+                          const int32_t* bias_ids, const int32_t* bias_lens, int32_t bias_stride,
+                          int32_t bias_first_step, float bias_beta, const uint8_t* diverged) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
+  const BeamBias bias{bias_beta > 0.f ? bias_ids : nullptr, bias_lens, bias_stride, bias_first_step,
+                      bias_beta, diverged};
   const ExpSumLayout el = exp_sum_layout(vocab);
   const size_t lds = static_cast<size_t>(el.lds_floats) * sizeof(float);
   allow_big_lds(reinterpret_cast<const void*>(beam_logprobs_kernel), lds);
   hipLaunchKernelGGL(beam_logprobs_kernel, dim3(rows), dim3(block), lds, stream, logits,
                      beam_scores, vocab, disable_id, min_length, step_ptr, extra_min_per_batch,
-                     beam > 0 ? beam : 1, el.chain_pad, y, exact ? 0 : 1);
+                     beam > 0 ? beam : 1, el.chain_pad, y, exact ? 0 : 1, bias);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -833,6 +933,10 @@ struct BeamSelectParams {
   // [positions][batch*beam] -> cache row holding that position of the beam's history
   const int32_t* anc_src;
   int32_t* anc_dst;
+  // biased decoding: the prefix does not constrain; diverged[batch * beam + k] records that the
+  // candidate at position k has left it (get_beams_divergence_from_prefix, src/decoding.cc:325-342 -
+  // the reference keeps the flag per POSITION, not per origin beam; reproduced as is)
+  uint8_t* diverged;
 };
 
 __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelectParams p) {
@@ -841,12 +945,14 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelectParams p) {
   const int b = blockIdx.x, j = threadIdx.x;
   const int nc = 2 * p.beam;
   const int step = *p.step_ptr - p.first_step;
-  const int plen = p.prefix_ids ? p.prefix_lens[b] : 0;
+  const bool biased = p.diverged != nullptr;
+  const int plen_given = p.prefix_ids ? p.prefix_lens[b] : 0;
+  const int plen = biased ? 0 : plen_given;  // (use_hard_prefix == false: no forced tokens)
   if (j < nc) {
     const int32_t flat = p.topk_ids[b * nc + j];
     int32_t origin = flat / p.vocab, word = flat % p.vocab;   // unflatten_ids, :95-116
     float sc = p.topk_scores[b * nc + j];
-    if (p.prefix_ids && step <= plen) {
+    if (p.prefix_ids && !biased && step <= plen) {
       if (step < plen) {        // inside the prefix: every candidate is the prefix token
         word = p.prefix_ids[b * p.prefix_stride + step];
         sc = (j == 0) ? 0.f : -1e10f;
@@ -866,6 +972,11 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelectParams p) {
     p.hist_origin[h] = origin;
   }
   __syncthreads();
+  if (biased && j < p.beam) {
+    const int row = b * p.beam + j;
+    p.diverged[row] = (step >= plen_given || p.diverged[row] ||
+                       s_word[j] != p.prefix_ids[b * p.prefix_stride + step]) ? 1 : 0;
+  }
   if (j == 0) {
     int secondary = p.beam;
     for (int k = 0; k < p.beam; ++k) {
@@ -922,13 +1033,72 @@ void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64
                         int32_t* hist_origin, int32_t* next_ids, int32_t* parents,
                         float* beam_scores, const int32_t* seq_src, int32_t* seq_dst,
                         int32_t seq_stride, hipStream_t stream, const int32_t* ancestry_src,
-                        int32_t* ancestry_dst) {
+                        int32_t* ancestry_dst, uint8_t* diverged) {
   if (batch == 0) return;
   const BeamSelectParams p{topk_scores, topk_ids, beam, static_cast<int32_t>(vocab), eos, prefix_ids,
                            prefix_lens, prefix_stride, step_ptr, first_step, hist_word, hist_score,
                            hist_origin, next_ids, parents, beam_scores, seq_src, seq_dst, seq_stride,
-                           ancestry_src, ancestry_dst};
+                           ancestry_src, ancestry_dst, diverged};
   hipLaunchKernelGGL(beam_select_kernel, dim3(batch), dim3(64), 0, stream, p);
+}
+
+// return_attention (src/decoding.cc:503, 586-593; TransformerDecoder::decode collecting the
+// alignment heads, src/layers/transformer.cc:770-828): the encoder-decoder attention distribution
+// of the first `align_heads` heads of the alignment layer, averaged (ops::Mean over the heads), for
+// every row of the step: out[*step_ptr][row][0 .. s_max) (zero past the source length). The
+// probabilities are recomputed here from the layer's queries and the projected memory keys - the
+// attention kernels keep theirs in registers / LDS - in plain fp32 (softmax(q.k * scale)).
+// One workgroup per row.
+__global__ __launch_bounds__(256) void attention_probs_kernel(
+    const float* __restrict__ q, int64_t q_row_stride, const float* __restrict__ k,
+    int64_t k_batch_stride, int64_t k_time_stride, const int32_t* __restrict__ lengths,
+    int32_t kv_group, int32_t heads_per_kv, int32_t dhead, int32_t align_heads, int32_t s_max,
+    float scale, const int32_t* __restrict__ step_ptr, int64_t rows, float* __restrict__ out) {
+  extern __shared__ float probs[];  // [s_max] scores of one head
+  __shared__ float scratch[16];
+  const int64_t row = blockIdx.x;
+  const int64_t b = row / kv_group;
+  const int len = lengths ? min(lengths[b], s_max) : s_max;
+  float* o = out + (static_cast<int64_t>(*step_ptr) * rows + row) * s_max;
+  for (int t = threadIdx.x; t < s_max; t += blockDim.x) o[t] = 0.f;
+  const float inv_heads = 1.f / static_cast<float>(align_heads);
+  for (int h = 0; h < align_heads; ++h) {
+    const float* qh = q + row * q_row_stride + static_cast<int64_t>(h) * dhead;
+    const float* kh = k + b * k_batch_stride + static_cast<int64_t>(h / heads_per_kv) * dhead;
+    float m = -FLT_MAX;
+    for (int t = threadIdx.x; t < len; t += blockDim.x) {
+      const float* kt = kh + static_cast<int64_t>(t) * k_time_stride;
+      float acc = 0.f;
+      for (int d = 0; d < dhead; ++d) acc = fmaf(qh[d], kt[d], acc);
+      acc *= scale;
+      probs[t] = acc;
+      m = fmaxf(m, acc);
+    }
+    m = block_max(m, scratch);
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < len; t += blockDim.x) {
+      const float e = expf(probs[t] - m);
+      probs[t] = e;
+      sum += e;
+    }
+    sum = block_sum(sum, scratch);
+    __syncthreads();
+    for (int t = threadIdx.x; t < len; t += blockDim.x) o[t] += (probs[t] / sum) * inv_heads;
+    __syncthreads();
+  }
+}
+
+void launch_attention_probs(const float* q, int64_t q_row_stride, const float* k, int64_t k_batch_stride,
+                            int64_t k_time_stride, const int32_t* lengths, int64_t rows,
+                            int32_t kv_group, int32_t heads, int32_t heads_kv, int32_t dhead,
+                            int32_t align_heads, int32_t s_max, float scale, const int32_t* step_ptr,
+                            float* out, hipStream_t stream) {
+  if (rows == 0) return;
+  const size_t lds = sizeof(float) * static_cast<size_t>(s_max);
+  allow_big_lds(reinterpret_cast<const void*>(attention_probs_kernel), lds);
+  hipLaunchKernelGGL(attention_probs_kernel, dim3(rows), dim3(256), lds, stream, q, q_row_stride, k,
+                     k_batch_stride, k_time_stride, lengths, kv_group, heads / heads_kv, dhead,
+                     align_heads, s_max, scale, step_ptr, rows, out);
 }
 
 // score_sequences (src/scoring.cc:42-48): LogSoftMax over the step's logits, then Gather of the

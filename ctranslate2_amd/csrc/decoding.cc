@@ -15,7 +15,7 @@ void validate_decoding_options(const DecodingOptions& o) {
   if (o.patience <= 0) throw std::invalid_argument("The patience factor must be > 0");
   if (o.num_hypotheses <= 0) throw std::invalid_argument("The number of hypotheses must be > 0");
   const int64_t max_candidates = std::llround(float(o.beam_size) * o.patience);
-  if (o.num_hypotheses > max_candidates)
+  if (o.num_hypotheses > max_candidates && !o.return_alternatives)
     throw std::invalid_argument("The number of hypotheses cannot be greater than "
                                 "beam_size * patience");
   if (o.min_length > o.max_length)
@@ -25,15 +25,25 @@ void validate_decoding_options(const DecodingOptions& o) {
   if (o.sampling_topk != 1) {
     if (o.beam_size != 1)
       throw std::invalid_argument("Random sampling (sampling_topk != 1) requires beam_size 1");
-    // 0 = the whole vocabulary (the reference's sampling_topk <= 0), else the best k <= 64
-    if (o.sampling_topk < 0 || o.sampling_topk > max_sampling_topk())
-      throw std::invalid_argument("sampling_topk must be 0 (whole vocabulary) or between 1 and " +
-                                  std::to_string(max_sampling_topk()) + " in this backend");
+    // 0 = the whole vocabulary (the reference's sampling_topk <= 0), else the best k (any k:
+    // candidate lists up to max_sampling_topk(), the threshold form of the sampler above)
+    if (o.sampling_topk < 0)
+      throw std::invalid_argument("sampling_topk must be 0 (whole vocabulary) or positive");
   }
   if (!(o.sampling_topp > 0.f && o.sampling_topp <= 1.f))
     throw std::invalid_argument("sampling_topp must be in (0, 1]");
   if (!(o.sampling_temperature > 0.f))
     throw std::invalid_argument("sampling_temperature must be > 0");
+  // (src/decoding.cc:1040-1051)
+  if (o.prefix_bias_beta >= 1)
+    throw std::invalid_argument("The beta value in biased decoding must be smaller than 1");
+  if (o.prefix_bias_beta > 0 && o.return_alternatives)
+    throw std::invalid_argument("Biased decoding is not compatible with the return_alternatives mode");
+  if (o.return_alternatives &&
+      (o.min_alternative_expansion_prob < 0 || o.min_alternative_expansion_prob > 1))
+    throw std::invalid_argument("The minimum alternative expansion probability must be between 0 and 1");
+  if (o.prefix_bias_beta > 0 && o.sampling_topk != 1)
+    throw std::invalid_argument("Biased decoding runs a beam search: random sampling is not available with it");
 }
 
 float finalize_score(float score, float length, float length_penalty) {
@@ -44,7 +54,7 @@ float finalize_score(float score, float length, float length_penalty) {
 namespace {
 
 // sort_hypotheses (src/decoding.cc:209-240).
-void sort_and_trim(DecodingResult& r, size_t max_hypotheses, bool keep_scores) {
+void sort_and_trim(DecodingResult& r, size_t max_hypotheses, bool keep_scores, bool keep_attention) {
   std::vector<size_t> idx(r.hypotheses.size());
   std::iota(idx.begin(), idx.end(), 0);
   std::sort(idx.begin(), idx.end(), [&r](size_t a, size_t b) { return r.scores[a] > r.scores[b]; });
@@ -53,16 +63,32 @@ void sort_and_trim(DecodingResult& r, size_t max_hypotheses, bool keep_scores) {
   for (size_t i : idx) {
     out.hypotheses.emplace_back(std::move(r.hypotheses[i]));
     if (keep_scores) out.scores.push_back(r.scores[i]);
+    if (keep_attention && i < r.attention.size()) out.attention.emplace_back(std::move(r.attention[i]));
   }
   r = std::move(out);
 }
 
+// compute_coverage_penalty (src/decoding.cc:176-188).
+float coverage_term(const std::vector<std::vector<float>>& attention, float beta) {
+  float penalty = 0;
+  if (attention.empty()) return 0.f;
+  for (size_t column = 0; column < attention[0].size(); ++column) {
+    float coverage = 0;
+    for (size_t row = 0; row < attention.size(); ++row) coverage += attention[row][column];
+    if (coverage > 0) penalty += std::log(std::min(coverage, 1.f));
+  }
+  return beta * penalty;
+}
+
 // finalize_result (src/decoding.cc:242-262).
-void finalize(DecodingResult& r, size_t max_hypotheses, float length_penalty, bool keep_scores) {
-  for (size_t i = 0; i < r.scores.size(); ++i)
+void finalize(DecodingResult& r, size_t max_hypotheses, const DecodingOptions& opt) {
+  for (size_t i = 0; i < r.scores.size(); ++i) {
     r.scores[i] = finalize_score(r.scores[i], static_cast<float>(r.hypotheses[i].size()),
-                                 length_penalty);
-  sort_and_trim(r, max_hypotheses, keep_scores);
+                                 opt.length_penalty);
+    if (opt.coverage_penalty != 0 && i < r.attention.size())
+      r.scores[i] += coverage_term(r.attention[i], opt.coverage_penalty);
+  }
+  sort_and_trim(r, max_hypotheses, opt.return_scores, opt.return_attention);
 }
 
 }  // namespace
@@ -79,6 +105,14 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
   std::vector<char> alive(batch, 1);
   for (auto& r : results) r.hypotheses.resize(1);
   int64_t count_alive = batch;
+  // gather_attention (src/decoding.cc:819): the attention also feeds the coverage penalty
+  const bool gather_attention =
+      opt.return_attention || (opt.return_scores && opt.coverage_penalty != 0);
+  std::vector<float> att_steps;
+  if (gather_attention) {
+    engine.enable_attention(st);
+    for (auto& r : results) r.attention.resize(1);
+  }
 
   engine.set_ids(st, start_ids.data());
   engine.set_step(st, opt.start_step);
@@ -137,6 +171,10 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
     const int32_t* h_ids = nullptr;
     const float* h_scores = nullptr;
     engine.wait_history(st, g.slot, &h_ids, &h_scores);
+    if (gather_attention) {
+      att_steps.resize(static_cast<size_t>(g.count) * batch * st.s_max);
+      engine.read_attention(st, opt.start_step + g.first, g.count, att_steps.data());
+    }
     for (int64_t s = 0; s < g.count && count_alive > 0; ++s) {
       const int64_t step = g.first + s;
       for (int64_t i = 0; i < batch; ++i) {
@@ -146,14 +184,19 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
         const int32_t word = h_ids[s * batch + i];
         const bool in_prefix = step < prefix_len[i];
         const bool eos = (word == end_id) && !in_prefix;
-        if ((!in_prefix || opt.return_prefix) && (!eos || opt.include_eos_in_hypotheses))
+        if ((!in_prefix || opt.return_prefix) && (!eos || opt.include_eos_in_hypotheses)) {
           results[i].hypotheses[0].push_back(word);
+          if (gather_attention) {
+            const float* a = att_steps.data() + (static_cast<size_t>(s) * batch + i) * st.s_max;
+            results[i].attention[0].emplace_back(a, a + st.s_max);
+          }
+        }
         if (opt.return_scores) score_sum[i] += h_scores[s * batch + i];  // forced steps add 0
         if (eos || last) {
           alive[i] = 0;
           --count_alive;
           results[i].scores.assign(1, score_sum[i]);
-          finalize(results[i], 1, opt.length_penalty, opt.return_scores);
+          finalize(results[i], 1, opt);
         }
       }
     }
@@ -211,7 +254,7 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   if (rows != st.rows || st.beam != beam)
     throw std::runtime_error("beam_search: state/batch size mismatch");
   const size_t max_candidates = static_cast<size_t>(std::llround(float(beam) * opt.patience));
-  const bool allow_early_exit = (opt.length_penalty == 0);
+  const bool allow_early_exit = (opt.length_penalty == 0 && opt.coverage_penalty == 0);
 
   std::vector<DecodingResult> results(batch);
   std::vector<char> finished(batch, 0), top_beam_finished(batch, 0);
@@ -239,7 +282,13 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   // apply_min_length, src/decoding.cc:357-408).
   const int64_t extra = opt.return_prefix ? 0 : 1;
   int64_t longest_prefix = 0;
-  if (prefix_ids) {
+  // biased decoding (src/decoding.cc:478-483): the prefix biases the distributions on the device
+  // (beam_logprobs_kernel) and constrains nothing - no forced tokens, no effect on the lengths
+  const bool bias_towards_prefix = prefix_ids && opt.prefix_bias_beta > 0;
+  if (bias_towards_prefix) {
+    engine.set_beam_prefix(st, *prefix_ids, opt.start_step, !opt.return_prefix, opt.prefix_bias_beta);
+    prefix_ids = nullptr;
+  } else if (prefix_ids) {
     for (const auto& pfx : *prefix_ids)
       longest_prefix = std::max<int64_t>(longest_prefix, static_cast<int64_t>(pfx.size()));
     engine.set_beam_prefix(st, *prefix_ids, opt.start_step, !opt.return_prefix);
@@ -250,6 +299,14 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   // alive_seq[i][k]: tokens of active beam k of batch i.
   std::vector<std::vector<std::vector<int32_t>>> alive_seq(
       batch, std::vector<std::vector<int32_t>>(beam));
+  // alive_attention[i][k]: one source attention vector per token of that beam (:586-593)
+  const bool gather_attention = opt.return_attention || opt.coverage_penalty != 0;
+  std::vector<std::vector<std::vector<std::vector<float>>>> alive_attention;
+  std::vector<float> att_steps;
+  if (gather_attention) {
+    engine.enable_attention(st);
+    alive_attention.assign(batch, std::vector<std::vector<std::vector<float>>>(beam));
+  }
 
   const int64_t max_step = opt.max_length + extra * longest_prefix;
   const int64_t sync_every = std::max<int32_t>(1, opt.sync_every);
@@ -277,6 +334,10 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
     const float* h_score = nullptr;
     const int32_t* h_origin = nullptr;
     engine.wait_beam_history(st, g.slot, &h_word, &h_score, &h_origin);
+    if (gather_attention) {
+      att_steps.resize(static_cast<size_t>(g.count) * rows * st.s_max);
+      engine.read_attention(st, opt.start_step + g.first, g.count, att_steps.data());
+    }
     for (int64_t s = 0; s < g.count && remaining > 0; ++s, ++step) {
       for (int64_t i = 0; i < batch; ++i) {
         if (finished[i]) continue;
@@ -292,6 +353,17 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
         for (int32_t j = 0; j < num_candidates; ++j) {
           cand_seq[j] = alive_seq[i][cand_origin[j]];
           cand_seq[j].push_back(cand_word[j]);
+        }
+        // the attention of a candidate = its origin beam's history + that beam's vector of this step
+        std::vector<std::vector<std::vector<float>>> cand_att;
+        if (gather_attention) {
+          cand_att.resize(num_candidates);
+          for (int32_t j = 0; j < num_candidates; ++j) {
+            cand_att[j] = alive_attention[i][cand_origin[j]];
+            const float* a = att_steps.data() +
+                             (static_cast<size_t>(s) * rows + i * beam + cand_origin[j]) * st.s_max;
+            cand_att[j].emplace_back(a, a + st.s_max);
+          }
         }
 
         BeamStepInput in;
@@ -313,6 +385,12 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
                                    cand_seq[k].end());
           if (ignore_last && !hyp.empty()) hyp.pop_back();
           result.scores.push_back(sc[k]);
+          if (gather_attention) {  // build_attention with the same start / end as the hypothesis
+            const size_t a0 = std::min<size_t>(extra * plen, cand_att[k].size());
+            std::vector<std::vector<float>> att(cand_att[k].begin() + a0, cand_att[k].end());
+            if (ignore_last && !att.empty()) att.pop_back();
+            result.attention.emplace_back(std::move(att));
+          }
           result.hypotheses.emplace_back(std::move(hyp));
         }
 
@@ -326,7 +404,7 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
           is_finished = result.hypotheses.size() >= max_candidates;
 
         if (is_finished) {
-          finalize(result, opt.num_hypotheses, opt.length_penalty, opt.return_scores);
+          finalize(result, opt.num_hypotheses, opt);
           finished[i] = 1;
           --remaining;
           continue;
@@ -336,6 +414,11 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
         std::vector<std::vector<int32_t>> new_alive(beam);
         for (int32_t k = 0; k < beam; ++k) new_alive[k] = std::move(cand_seq[sel.next[k]]);
         alive_seq[i] = std::move(new_alive);
+        if (gather_attention) {
+          std::vector<std::vector<std::vector<float>>> new_att(beam);
+          for (int32_t k = 0; k < beam; ++k) new_att[k] = cand_att[sel.next[k]];
+          alive_attention[i] = std::move(new_att);
+        }
       }
     }
   }

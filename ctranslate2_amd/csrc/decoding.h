@@ -42,11 +42,23 @@ struct DecodingOptions {
   // src/decoding.cc:1091-1120). Single-token entries of suppress_sequences are the reference's
   // disable_ids (disable_unk) list.
   LogitsProcessing logits_processing;
+  // Biased decoding (DecodingOptions::prefix_bias_beta, BiasedDecoder, src/decoding.cc:256-343):
+  // beam search only; the prefix passed to beam_search biases instead of constraining.
+  float prefix_bias_beta = 0.f;
+  // return_alternatives (composition in c_api_engine.cc decode_alternatives; here: validation)
+  bool return_alternatives = false;
+  float min_alternative_expansion_prob = 0.f;
+  // return_attention / coverage_penalty (src/decoding.cc:176-207, 503, 586-593): the searches
+  // record, per step and row, the attention vector of the alignment heads over the source.
+  bool return_attention = false;
+  float coverage_penalty = 0.f;
 };
 
 struct DecodingResult {
   std::vector<std::vector<int32_t>> hypotheses;
   std::vector<float> scores;
+  // return_attention: attention[h][t] = the source attention vector of token t of hypothesis h
+  std::vector<std::vector<std::vector<float>>> attention;
 };
 
 struct DecodeStats {

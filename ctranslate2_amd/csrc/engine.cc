@@ -612,6 +612,15 @@ void Engine::load_weights() {
   load_stack("decoder", true, dec_);
   if (has_encoder_ != dec_.layers.front().has_cross)
     throw std::runtime_error("inconsistent model: encoder presence and cross-attention differ");
+  // TransformerDecoder ctor (src/layers/transformer.cc:516-528): which encoder-decoder attention
+  // return_attention reports - the first alignment_heads heads (0 = all) of alignment_layer
+  alignment_layer_ = static_cast<int64_t>(model_->attribute("decoder/alignment_layer", -1));
+  alignment_heads_ = static_cast<int64_t>(model_->attribute("decoder/alignment_heads", 1));
+  if (alignment_layer_ < 0) alignment_layer_ += static_cast<int64_t>(dec_.layers.size());
+  if (alignment_heads_ == 0) alignment_heads_ = dec_.num_heads;
+  if (alignment_layer_ < 0 || alignment_layer_ >= static_cast<int64_t>(dec_.layers.size()) ||
+      alignment_heads_ < 0 || alignment_heads_ > dec_.num_heads)
+    throw std::runtime_error("decoder/alignment_layer or alignment_heads is out of range");
   pack_stream_weights();
 }
 
@@ -1295,7 +1304,7 @@ std::unique_ptr<DecodeState> Engine::start_decoder_only(int64_t batch, int64_t b
 
 std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t* src_lengths,
                                            int64_t batch, int64_t s_max, int64_t beam,
-                                           int64_t t_max, int64_t prefill_len) {
+                                           int64_t t_max, int64_t prefill_len, bool beam_search_state) {
   CT2X_HIP_CHECK(hipSetDevice(device_));
   auto st = std::make_unique<DecodeState>();
   st->engine = this;
@@ -1306,6 +1315,9 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   set_active_stream(tls_stream);
   st->batch = batch;
   st->beam = beam;
+  // a beam search of width 1 (biased decoding with beam_size 1) still needs the search's buffers
+  const bool beam_mode = beam > 1 || beam_search_state;
+  st->beam_mode = beam_mode;
   st->rows = batch * beam;
   st->t_max = t_max;
   st->s_max = s_max;
@@ -1320,7 +1332,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   }
   // Workspace sized for the larger of the decode rows and the encoder rows.
   // (a beam-search prefill forwards the prompt once per hypothesis row)
-  const int64_t enc_rows = has_encoder_ ? batch * s_max : rows * prefill_len;
+  const int64_t enc_rows = std::max(has_encoder_ ? batch * s_max : 0, rows * prefill_len);
   st->prefill_max = prefill_len;
   int64_t enc_ffn = 0, enc_qkv = 0;
   for (const auto& l : enc_.layers) {
@@ -1370,7 +1382,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   st->hist_scores = alloc<float>(*st, (t_max + 1) * rows);
   CT2X_HIP_CHECK(hipMemsetAsync(st->d_step, 0, sizeof(int32_t), cur_stream()));
   st->logprobs = alloc<float>(*st, rows * V);  // log-probabilities (beam search) / exp scratch
-  if (beam > 1) {
+  if (beam_mode) {
     st->beam_scores = alloc<float>(*st, rows);
     st->topk_scores = alloc<float>(*st, batch * 2 * beam);
     st->topk_ids = alloc<int32_t>(*st, batch * 2 * beam);
@@ -1388,7 +1400,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   // Beam search reads the self-attention caches through an ancestry table instead of reordering
   // them every step when every layer's decode attention runs the exact kernel, which follows the
   // table (CT2X_BEAM_ANCESTRY=0: the one-launch gather between two buffer sets).
-  if (beam > 1) {
+  if (beam_mode) {
     static const bool allowed = [] {
       const char* e = tuning_env("CT2X_BEAM_ANCESTRY");
       return e == nullptr || e[0] != '0';
@@ -1429,7 +1441,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       }
     }
   }
-  const int n_sets = (beam > 1 && !st->ancestry) ? 2 : 1;
+  const int n_sets = (beam_mode && !st->ancestry) ? 2 : 1;
   for (int s = 0; s < n_sets; ++s) {
     for (int l = 0; l < n_layers; ++l) {
       const AttnW& a = dec_.layers[l].self;
@@ -1438,7 +1450,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       st->self_v[s].push_back(alloc<float>(*st, sz));
     }
   }
-  if (beam > 1 && !st->ancestry) {
+  if (beam_mode && !st->ancestry) {
     // Device tables of cache base pointers for the one-launch beam gather, both directions.
     std::vector<const float*> src(2 * n_layers), src_alt(2 * n_layers);
     std::vector<float*> dst(2 * n_layers), dst_alt(2 * n_layers);
@@ -1686,11 +1698,10 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
 // lengths, src/layers/transformer.cc:673-696; DecoderReplica::run_generation prefill,
 // src/models/language_model.cc:217-238): fills the self-attention caches for positions
 // [0, time) of every row and leaves the step counter at `time`. No logits are produced.
-void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time) {
+void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time, float* logits_all) {
   CT2X_HIP_CHECK(hipSetDevice(device_));
   tls_stream = st.stream;
   set_active_stream(tls_stream);
-  CT2X_CHECK(!has_encoder_, "prefill is only defined for decoder-only models");
   // (with beam > 1 the caller passes the prompt of a sentence once per hypothesis row)
   CT2X_CHECK(time <= st.t_max && time <= st.prefill_max, "prompt longer than the decoding state");
   if (time == 0) return;
@@ -1769,7 +1780,66 @@ void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time) {
     dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
     if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
     std::swap(x, y);
+    if (layer.has_cross) {
+      // encoder-decoder attention in sequence mode (the target prefix of decode_alternatives,
+      // src/decoding.cc:1148-1160; WhisperDecoder::forward_prompt): queries of every prefix
+      // position against the memory keys projected by encode()
+      const AttnW& c = layer.cross;
+      QuantIn cq;
+      const float* cin = x;
+      if (c.ln.present && dec_.pre_norm) {
+        if (c.lin[0].quantized) {
+          norm_quant(c.ln, x, rows, d, nullptr, st.qbuf, st.qscale);
+          cq.q = st.qbuf;
+          cq.s = st.qscale;
+        } else {
+          norm(c.ln, x, rows, d, st.ctx);
+          cin = st.ctx;
+        }
+      }
+      dense(c.lin[0], cin, cq.q ? &cq : nullptr, rows, -1, nullptr, st.qkv, &st);
+      const int64_t qdim = c.heads * c.dhead, kvdim = c.heads_kv * c.dhead;
+      for (int64_t j = 0; j < st.beam; ++j) {  // hypothesis row j of every sentence: the same memory
+        AttnFullParams f;
+        f.q = st.qkv + j * time * qdim;
+        f.q_batch_stride = st.beam * time * qdim;
+        f.q_time_stride = qdim;
+        f.k = st.cross_kv[l];
+        f.v = st.cross_kv[l] + kvdim;
+        f.k_batch_stride = f.v_batch_stride = st.s_max * 2 * kvdim;
+        f.k_time_stride = f.v_time_stride = 2 * kvdim;
+        f.k_head_stride = f.v_head_stride = c.dhead;
+        f.lengths = st.mem_lengths;
+        f.batch = st.batch;
+        f.tq = time;
+        f.tk = st.s_max;
+        f.heads = c.heads;
+        f.heads_kv = c.heads_kv;
+        f.dhead = c.dhead;
+        f.causal = false;
+        f.scale = c.queries_scale;
+        f.out = st.ctx + j * time * qdim;
+        f.out_batch_stride = st.beam * time * qdim;
+        f.out_time_stride = qdim;
+        begin_kernel("attention_cross_prefill", 0, 0, st.batch * time, c.heads, c.dhead);
+        launch_attention_full(f, cur_stream());
+        end_kernel();
+      }
+      dense(c.lin[2], st.ctx, nullptr, rows, -1, c.ln.present ? x : nullptr, y, &st);
+      if (c.ln.present && !dec_.pre_norm) norm(c.ln, y, rows, d, y);
+      std::swap(x, y);
+    }
     run_ffn(layer.ffn, dec_.pre_norm, rows, d, x, y, st);
+  }
+  if (logits_all) {
+    // every position's logits (DecoderReplica::forward / score_sequences: the decoder in sequence
+    // mode with a logits output, src/models/language_model.cc:279-300, src/scoring.cc:9-60)
+    const float* h = x;
+    if (dec_.output_norm.present) {
+      norm(dec_.output_norm, x, rows, d, y);
+      h = y;
+    }
+    dense(dec_.projection, h, nullptr, rows, -1, nullptr, logits_all, &st);
   }
   const int32_t step = static_cast<int32_t>(time);
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_step, &step, sizeof(int32_t), hipMemcpyHostToDevice,
@@ -1959,6 +2029,16 @@ void Engine::launch_step(DecodeState& st) {
       if (!fused_in)
         dense(a.lin[0], attn_in, qin.q ? &qin : nullptr, rows, -1, nullptr, st.qkv, &st);
       const int64_t kvdim = a.heads_kv * a.dhead;
+      if (st.att_hist && static_cast<int64_t>(l) == alignment_layer_) {
+        begin_kernel("attention_probs");
+        launch_attention_probs(st.qkv, a.heads * a.dhead, st.cross_kv[l], st.s_max * 2 * kvdim,
+                               2 * kvdim, st.mem_lengths, rows, static_cast<int32_t>(st.beam),
+                               static_cast<int32_t>(a.heads), static_cast<int32_t>(a.heads_kv),
+                               static_cast<int32_t>(a.dhead), static_cast<int32_t>(alignment_heads_),
+                               static_cast<int32_t>(st.s_max), a.queries_scale, st.d_step,
+                               st.att_hist, cur_stream());
+        end_kernel();
+      }
       AttnDecodeParams p;
       p.q = st.qkv;
       p.q_row_stride = a.heads * a.dhead;
@@ -2085,7 +2165,9 @@ void Engine::launch_step(DecodeState& st) {
     launch_beam_logprobs(st.logits, st.beam_scores, st.rows, V, st.g_eos, st.g_min_length,
                          st.d_step, st.logprobs, cur_stream(),
                          st.prefix_extends_min ? st.d_bprefix_len : nullptr,
-                         static_cast<int32_t>(st.beam), !half_compute());
+                         static_cast<int32_t>(st.beam), !half_compute(), st.d_bprefix, st.d_bprefix_len,
+                         st.bprefix_stride, st.prefix_first_step, st.d_bprefix ? st.bias_beta : 0.f,
+                         st.d_diverged);
     end_kernel();
     begin_kernel("beam_topk", double(st.rows) * V * 4, 0, st.batch, 2 * st.beam, st.beam * V);
     launch_topk(st.logprobs, st.batch, st.beam * V, 2 * st.beam, st.topk_scores, st.topk_ids,
@@ -2099,7 +2181,8 @@ void Engine::launch_step(DecodeState& st) {
                        st.lp_active ? st.alive_seq[par] : nullptr,
                        st.lp_active ? st.alive_seq[par ^ 1] : nullptr,
                        static_cast<int32_t>(st.t_max), cur_stream(),
-                       st.ancestry ? st.anc[par] : nullptr, st.ancestry ? st.anc[par ^ 1] : nullptr);
+                       st.ancestry ? st.anc[par] : nullptr, st.ancestry ? st.anc[par ^ 1] : nullptr,
+                       (st.d_bprefix && st.bias_beta > 0.f) ? st.d_diverged : nullptr);
     end_kernel();
     // Positions [0, step] are live; the gather copies the positions below the advanced counter.
     begin_kernel("advance_step");
@@ -2237,12 +2320,20 @@ void Engine::wait_beam_history(DecodeState& st, int slot, const int32_t** h_word
 }
 
 void Engine::set_beam_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>& prefix,
-                             int32_t first_step, bool extends_min_length) {
+                             int32_t first_step, bool extends_min_length, float bias_beta) {
   tls_stream = st.stream;
   set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipSetDevice(device_));
   st.prefix_first_step = first_step;
   st.prefix_extends_min = extends_min_length;
+  st.bias_beta = bias_beta;
+  if (bias_beta > 0.f) {  // biased decoding: no beam has left its prefix yet
+    if (!st.d_diverged) {
+      st.d_diverged = static_cast<uint8_t*>(device_malloc(static_cast<size_t>(st.rows)));
+      st.owned.push_back(st.d_diverged);
+    }
+    CT2X_HIP_CHECK(hipMemsetAsync(st.d_diverged, 0, static_cast<size_t>(st.rows), cur_stream()));
+  }
   st.d_bprefix = st.d_bprefix_len = nullptr;
   st.bprefix_stride = 0;
   size_t longest = 0;
@@ -2403,13 +2494,37 @@ void Engine::set_logits_processing(DecodeState& st, const LogitsProcessing& lp) 
     st.d_sup_ids = upload_i32(ids);
     st.d_sup_off = upload_i32(off);
   }
-  if (st.beam > 1 && st.alive_seq[0] == nullptr) {
+  if (st.beam_mode && st.alive_seq[0] == nullptr) {
     for (int i = 0; i < 2; ++i) {
       st.alive_seq[i] = static_cast<int32_t*>(device_malloc(sizeof(int32_t) * st.rows * st.t_max));
       st.owned.push_back(st.alive_seq[i]);
     }
   }
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // the host vectors go out of scope
+}
+
+void Engine::enable_attention(DecodeState& st) {
+  CT2X_CHECK(has_encoder_, "return_attention / coverage_penalty need an encoder-decoder model");
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  if (st.att_hist) return;
+  const size_t n = static_cast<size_t>(st.t_max + 1) * st.rows * st.s_max;
+  st.att_hist = static_cast<float*>(device_malloc(n * sizeof(float)));
+  st.owned.push_back(st.att_hist);
+  CT2X_HIP_CHECK(hipMemsetAsync(st.att_hist, 0, n * sizeof(float), cur_stream()));
+  st.graph_ready[0] = st.graph_ready[1] = false;  // (called before the first step: nothing captured yet)
+}
+
+void Engine::read_attention(DecodeState& st, int64_t first, int64_t count, float* out) {
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_CHECK(st.att_hist != nullptr && first >= 0 && first + count <= st.t_max + 1,
+             "read_attention: no attention history for these steps");
+  const size_t per_step = static_cast<size_t>(st.rows) * st.s_max;
+  CT2X_HIP_CHECK(hipMemcpyAsync(out, st.att_hist + first * per_step, sizeof(float) * count * per_step,
+                                hipMemcpyDeviceToHost, cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
 }
 
 void Engine::set_step(DecodeState& st, int32_t step) {

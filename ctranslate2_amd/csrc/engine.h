@@ -169,12 +169,13 @@ public:
   // prepares a decoding state for batch*beam rows and up to t_max decoded positions.
   std::unique_ptr<DecodeState> start(const int32_t* src_ids, const int32_t* src_lengths,
                                      int64_t batch, int64_t s_max, int64_t beam, int64_t t_max,
-                                     int64_t prefill_len = 0);
+                                     int64_t prefill_len = 0, bool beam_search_state = false);
   // Decoder-only models: no encoder; the prompt is consumed by prefill().
   std::unique_ptr<DecodeState> start_decoder_only(int64_t batch, int64_t beam, int64_t t_max,
                                                   int64_t prefill_len = 0);
   // Consumes `time` prompt tokens per row (h_ids [rows, time]) in one sequence-mode pass.
-  void prefill(DecodeState& state, const int32_t* h_ids, int64_t time);
+  // logits_all (optional): device [rows * time, vocabulary] - the logits of every position
+  void prefill(DecodeState& state, const int32_t* h_ids, int64_t time, float* logits_all = nullptr);
 
   // One decoder step over state.rows rows: reads token ids from state.d_ids and the step index
   // from state.d_step (device memory), leaves logits in state.logits [rows, vocab].
@@ -204,7 +205,8 @@ public:
   // extends_min_length: the prefix is hidden (generation): EOS stays disabled prefix_length steps
   // longer for that entry.
   void set_beam_prefix(DecodeState& state, const std::vector<std::vector<int32_t>>& prefix,
-                       int32_t first_step, bool extends_min_length = false);
+                       int32_t first_step, bool extends_min_length = false,
+                       float bias_beta = 0.f /* > 0: the prefix biases instead of constraining */);
   // Initial cumulative scores (initialize_beam_scores, src/decoding.cc:84-93).
   void set_beam_scores(DecodeState& state, const float* h_scores);
 
@@ -222,6 +224,12 @@ public:
   void set_prefix(DecodeState& state, const std::vector<std::vector<int32_t>>& prefix,
                   int32_t first_step, bool extends_min_length = true);
   void set_step(DecodeState& state, int32_t step);
+  // return_attention / coverage_penalty: from now on every decode step records, per row, the
+  // encoder-decoder attention of the alignment layer / heads (decoder attributes alignment_layer,
+  // alignment_heads; src/layers/transformer.cc:516-528) at att_hist[step]. read_attention copies
+  // steps [first, first + count) to the host: out [count][rows][s_max].
+  void enable_attention(DecodeState& state);
+  void read_attention(DecodeState& state, int64_t first, int64_t count, float* out);
   void synchronize();
   // Teacher-forced scoring (score_sequences, src/scoring.cc): runs `steps` decoder steps feeding
   // h_inputs[s][row] and leaves log P(h_outputs[s][row]) of every step in the score history
@@ -341,6 +349,7 @@ private:
   hipStream_t stream_ = nullptr;
   bool round_before_cast_ = true;  // weights converted at load time
   int quant_mode_ = 1;             // activation quantisation flags (device_utils.h)
+  int64_t alignment_layer_ = 0, alignment_heads_ = 1;  // return_attention (decoder attributes)
   bool has_encoder_ = false;
   StackW enc_, dec_;
   std::vector<void*> device_blocks_;
@@ -440,6 +449,10 @@ struct DecodeState {
   int32_t* d_bprefix = nullptr;      // [batch, bprefix_stride]
   int32_t* d_bprefix_len = nullptr;  // [batch]
   int32_t bprefix_stride = 0;
+  float* att_hist = nullptr;         // return_attention: [t_max + 1][rows][s_max] (enable_attention)
+  bool beam_mode = false;            // the state holds the beam search's buffers (beam > 1, or forced)
+  float bias_beta = 0.f;             // biased decoding (DecodingOptions::prefix_bias_beta)
+  uint8_t* d_diverged = nullptr;     // [rows] beams that left their prefix
   int32_t* pin_cand_word[2] = {nullptr, nullptr};
   float* pin_cand_score[2] = {nullptr, nullptr};
   int32_t* pin_cand_origin[2] = {nullptr, nullptr};

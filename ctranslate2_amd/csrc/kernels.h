@@ -436,7 +436,16 @@ void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64
                         int32_t* hist_origin, int32_t* next_ids, int32_t* parents,
                         float* beam_scores, const int32_t* seq_src, int32_t* seq_dst,
                         int32_t seq_stride, hipStream_t stream,
-                        const int32_t* ancestry_src = nullptr, int32_t* ancestry_dst = nullptr);
+                        const int32_t* ancestry_src = nullptr, int32_t* ancestry_dst = nullptr,
+                        uint8_t* diverged = nullptr /* biased decoding: [batch * beam] flags */);
+
+// return_attention: out[*step_ptr][row][0 .. s_max) = mean over the first align_heads heads of
+// softmax(q . k * scale) against the projected memory keys (decode_ops.hip).
+void launch_attention_probs(const float* q, int64_t q_row_stride, const float* k, int64_t k_batch_stride,
+                            int64_t k_time_stride, const int32_t* lengths, int64_t rows,
+                            int32_t kv_group, int32_t heads, int32_t heads_kv, int32_t dhead,
+                            int32_t align_heads, int32_t s_max, float scale, const int32_t* step_ptr,
+                            float* out, hipStream_t stream);
 
 // Beam-search scores: y[row, :] = log_softmax(x[row, :] with x[disable_id] = -FLT_MAX while
 // step < min_length) + beam_scores[row]   (src/decoding.cc:512-556).
@@ -446,7 +455,11 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
                           int64_t vocab, int32_t disable_id, int32_t min_length,
                           const int32_t* step_ptr, float* y, hipStream_t stream,
                           const int32_t* extra_min_per_batch = nullptr, int32_t beam = 1,
-                          bool exact = true);
+                          bool exact = true,
+                          // biased decoding (BiasedDecoder, src/decoding.cc:256-323): bias_beta > 0
+                          const int32_t* bias_ids = nullptr, const int32_t* bias_lens = nullptr,
+                          int32_t bias_stride = 0, int32_t bias_first_step = 0, float bias_beta = 0.f,
+                          const uint8_t* diverged = nullptr);
 
 }  // namespace ct2x
 

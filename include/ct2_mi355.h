@@ -335,10 +335,10 @@ int ct2x_multinomial(const float* d_weights, int64_t rows, int64_t classes, int6
  * (src/ops/gumbel_max.cc:14-30). Counter-based RNG on (seed, call number, element). */
 int ct2x_gumbel_noise(const float* d_x, float* d_y, int64_t size, uint32_t seed, void* stream);
 
-/* RandomSampler for one step (src/sampling.cc:41-101): best `sampling_topk` candidates (2..64;
+/* RandomSampler for one step (src/sampling.cc:41-101): best `sampling_topk` candidates (any k;
  * <= 0: the whole vocabulary) -> temperature -> TopPMask (src/ops/topp_mask_cpu.cc:24-31) ->
- * SoftMax -> Multinomial by inverse CDF (candidates in TopK order; index order for the whole
- * vocabulary). d_uniforms [rows] in [0, 1) injects the draws (tests); NULL uses the counter-based
+ * SoftMax -> Multinomial by inverse CDF (candidates in TopK order for k <= 64; index order for a
+ * larger k and the whole vocabulary). d_uniforms [rows] in [0, 1) injects the draws (tests); NULL uses the counter-based
  * hash of (seed, *d_step, row). d_ids [rows], d_scores [rows] = log-probability of the id under the
  * ORIGINAL distribution. *d_step must be 0 for this standalone form. */
 int ct2x_random_sample(const float* d_logits, int64_t rows, int64_t vocab, int32_t sampling_topk,
@@ -463,7 +463,7 @@ struct ct2x_translation_options {
                                    0 = choose automatically */
   /* RandomSampler (src/sampling.cc:41-101; python: sampling_topk / sampling_topp /
    * sampling_temperature), greedy search (beam_size 1) only. sampling_topk: 1 = arg-max
-   * (BestSampler), 2..64 = sample among the best k, -1 = sample from the whole vocabulary (the
+   * (BestSampler), k >= 2 = sample among the best k, -1 = sample from the whole vocabulary (the
    * reference's sampling_topk = 0; 0 here means arg-max so that a zero-initialised struct is
    * deterministic); sampling_topp < 1 keeps the smallest
    * prefix of those whose mass reaches it; seed drives a counter-based generator
@@ -485,6 +485,24 @@ struct ct2x_translation_options {
                                       0 = the model's end token */
   const int32_t* suppress_ids;
   const int32_t* suppress_lengths;
+  /* The remaining decoding options of TranslationOptions (include/ctranslate2/translation.h:33-71):
+   *  return_alternatives: the num_hypotheses best FIRST tokens after the target prefix, each
+   *    continued independently (decode_alternatives, src/decoding.cc:1122-1290); alternatives whose
+   *    probability is below min_alternative_expansion_prob are dropped - the missing hypotheses of a
+   *    sentence get out_lengths -1;
+   *  prefix_bias_beta in (0, 1): the target prefix is a BIAS instead of a constraint (BiasedDecoder,
+   *    src/decoding.cc:256-343; always a beam search, beam_size 1 included);
+   *  attention_out (return_attention): HOST buffer [batch, num_hypotheses, max_decoding_length,
+   *    attention_stride] receiving, per generated token, the encoder-decoder attention of the
+   *    decoder's alignment layer and heads over the source positions (zero beyond them);
+   *  coverage_penalty: GNMT coverage term of the final score (src/decoding.cc:176-207). */
+  int32_t return_alternatives;
+  float min_alternative_expansion_prob;
+  float prefix_bias_beta;
+  float coverage_penalty;
+  int32_t attention_stride;
+  int32_t reserved0;
+  float* attention_out;
 };
 
 void ct2x_translation_options_default(struct ct2x_translation_options* opt);
@@ -569,6 +587,23 @@ int ct2x_score_batch(void* translator, const int32_t* src_ids, const int32_t* sr
                      const int32_t* tgt_lengths, int32_t tgt_stride, int32_t max_input_length,
                      int32_t* out_ids, float* out_scores, int32_t out_stride,
                      int32_t* out_lengths);
+
+/* Generator::forward_batch (include/ctranslate2/generator.h:31-35; SequenceGeneratorReplica::
+ * forward, src/models/language_model.cc:73-100), decoder-only models: ONE sequence-mode pass over
+ * ids [batch, stride] (lengths [batch]); out is a HOST buffer [batch, max(lengths), vocab] of logits,
+ * or of log-probabilities (ops::LogSoftMax) when return_log_probs != 0. Positions past a row's
+ * length hold the values of the padding token 0, as in the reference. */
+int ct2x_forward_batch(void* translator, const int32_t* ids, const int32_t* lengths, int32_t batch,
+                       int32_t stride, int32_t return_log_probs, float* out);
+
+/* Generator::score_batch (include/ctranslate2/generator.h:21-25; DecoderReplica::run_scoring ->
+ * score_sequences, src/models/language_model.cc:110-135, src/scoring.cc:9-60): out_scores
+ * [batch, stride] receives log P(ids[b][k + 1] | ids[b][..k]) for k < out_lengths[b] = length - 1
+ * (after the max_input_length truncation of Vocabulary::to_ids; 0 = no limit). Sequences of fewer
+ * than 2 tokens are skipped (out_lengths 0), as skip_scoring does. */
+int ct2x_generator_score_batch(void* translator, const int32_t* ids, const int32_t* lengths,
+                               int32_t batch, int32_t stride, int32_t max_input_length,
+                               float* out_scores, int32_t* out_lengths);
 
 /* Teacher-forced step logits (layers::Decoder::operator()(step, ids, state, logits),
  * include/ctranslate2/layers/decoder.h:25-29): src_ids INCLUDE special tokens here;

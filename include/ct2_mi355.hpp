@@ -51,24 +51,25 @@ struct TranslationOptions {
   size_t beam_size = 2;
   float patience = 1;
   float length_penalty = 1;
-  float coverage_penalty = 0;            // not built (needs attention weights): must stay 0
+  float coverage_penalty = 0;
   float repetition_penalty = 1;
   size_t no_repeat_ngram_size = 0;
   bool disable_unk = false;
   std::vector<std::vector<std::string>> suppress_sequences;
-  float prefix_bias_beta = 0;            // not built: must stay 0
+  float prefix_bias_beta = 0;            // biased decoding towards target_prefix (beam search)
   std::string end_token;                 // empty = the model's end token (single token form)
   bool return_end_token = false;
   size_t max_input_length = 1024;
   size_t max_decoding_length = 256;
   size_t min_decoding_length = 1;
-  size_t sampling_topk = 1;              // 0 = the whole vocabulary, otherwise <= 64 here
+  size_t sampling_topk = 1;              // 0 = the whole vocabulary
   float sampling_topp = 1;
   float sampling_temperature = 1;
   size_t num_hypotheses = 1;
   bool return_scores = false;
-  bool return_attention = false;         // not built: must stay false
-  bool return_alternatives = false;      // not built: must stay false
+  bool return_attention = false;
+  bool return_alternatives = false;
+  float min_alternative_expansion_prob = 0;
   bool replace_unknowns = false;         // not built: must stay false
   // backend additions
   unsigned int seed = 0;                 // random sampling is reproducible for a seed
@@ -79,6 +80,8 @@ struct TranslationOptions {
 struct TranslationResult {
   std::vector<std::vector<std::string>> hypotheses;
   std::vector<float> scores;
+  std::vector<std::vector<std::vector<float>>> attention;  // [hypothesis][token][source position]
+  bool has_attention() const { return !attention.empty(); }
 
   const std::vector<std::string>& output() const {
     if (hypotheses.empty()) throw std::runtime_error("This result is empty");
@@ -286,10 +289,6 @@ public:
                   const std::vector<std::vector<std::string>>& target_prefix,
                   const TranslationOptions& options = TranslationOptions(),
                   size_t max_batch_size = 0) {
-    detail::reject(options.coverage_penalty != 0, "coverage_penalty");
-    detail::reject(options.prefix_bias_beta != 0, "prefix_bias_beta");
-    detail::reject(options.return_attention, "return_attention");
-    detail::reject(options.return_alternatives, "return_alternatives");
     detail::reject(options.replace_unknowns, "replace_unknowns");
     if (!target_prefix.empty() && target_prefix.size() != source.size())
       throw std::invalid_argument("Batch size mismatch: got " + std::to_string(source.size()) +
@@ -325,6 +324,16 @@ public:
     const size_t hyp = options.num_hypotheses, len = options.max_decoding_length;
     std::vector<int32_t> out(batch * hyp * len, 0), out_len(batch * hyp, 0);
     std::vector<float> scores(batch * hyp, 0.f);
+    o.return_alternatives = options.return_alternatives;
+    o.min_alternative_expansion_prob = options.min_alternative_expansion_prob;
+    o.prefix_bias_beta = options.prefix_bias_beta;
+    o.coverage_penalty = options.coverage_penalty;
+    std::vector<float> attention;
+    if (options.return_attention) {
+      attention.assign(batch * hyp * len * static_cast<size_t>(src.stride), 0.f);
+      o.attention_out = attention.data();
+      o.attention_stride = src.stride;
+    }
     if (target_prefix.empty()) {
       detail::check(ct2x_translate_batch(h_.get(), src.ids.data(), src.lengths.data(),
                                          static_cast<int32_t>(batch), src.stride, &o, out.data(),
@@ -340,11 +349,20 @@ public:
     for (size_t b = 0; b < batch; ++b) {
       for (size_t k = 0; k < hyp; ++k) {
         const int32_t n = out_len[b * hyp + k];
-        if (k > 0 && n == 0) continue;  // fewer finished hypotheses than requested
+        if (n < 0 || (k > 0 && n == 0 && !options.return_alternatives))
+          continue;  // fewer finished hypotheses (or alternatives) than requested
         std::vector<std::string> tokens;
         for (int32_t t = 0; t < n; ++t) tokens.push_back(h_.to_token(1, out[(b * hyp + k) * len + t]));
         results[b].hypotheses.push_back(std::move(tokens));
         if (options.return_scores) results[b].scores.push_back(scores[b * hyp + k]);
+        if (options.return_attention) {
+          std::vector<std::vector<float>> att(static_cast<size_t>(n));
+          for (int32_t t = 0; t < n; ++t) {
+            const float* row = attention.data() + ((b * hyp + k) * len + t) * static_cast<size_t>(src.stride);
+            att[t].assign(row, row + source[b].size());
+          }
+          results[b].attention.push_back(std::move(att));
+        }
       }
     }
     return results;
@@ -465,6 +483,50 @@ public:
       if (options.return_scores) results[b].scores.push_back(scores[b]);
     }
     return results;
+  }
+
+  // Generator::score_batch (include/ctranslate2/generator.h:21-25): log P(token k + 1 | tokens ..k);
+  // sequences of fewer than 2 tokens give an empty result.
+  std::vector<ScoringResult>
+  score_batch(const std::vector<std::vector<std::string>>& tokens,
+              const ScoringOptions& options = ScoringOptions()) {
+    const size_t batch = tokens.size();
+    if (batch == 0) return {};
+    const detail::IdBatch in = detail::to_ids(h_, 1, tokens);
+    std::vector<float> scores(batch * static_cast<size_t>(in.stride), 0.f);
+    std::vector<int32_t> out_len(batch, 0);
+    detail::check(ct2x_generator_score_batch(h_.get(), in.ids.data(), in.lengths.data(),
+                                             static_cast<int32_t>(batch), in.stride,
+                                             static_cast<int32_t>(options.max_input_length),
+                                             scores.data(), out_len.data()));
+    std::vector<ScoringResult> results(batch);
+    for (size_t b = 0; b < batch; ++b)
+      for (int32_t i = 0; i < out_len[b]; ++i) {
+        // (the scored tokens are tokens[1:], or their truncation to max_input_length)
+        results[b].tokens.push_back(tokens[b][static_cast<size_t>(i) + 1]);
+        results[b].tokens_score.push_back(scores[b * static_cast<size_t>(in.stride) + i]);
+      }
+    return results;
+  }
+
+  // Generator::forward_batch (include/ctranslate2/generator.h:27-35): the logits (or
+  // log-probabilities) of every position, flattened [batch, longest sequence, vocabulary].
+  std::vector<float> forward_batch(const std::vector<std::vector<std::string>>& tokens,
+                                   bool return_log_probs, size_t* time_out = nullptr,
+                                   size_t* vocab_out = nullptr) {
+    const size_t batch = tokens.size();
+    if (batch == 0) return {};
+    const detail::IdBatch in = detail::to_ids(h_, 1, tokens);
+    size_t T = 0;
+    for (size_t b = 0; b < batch; ++b) T = std::max<size_t>(T, static_cast<size_t>(in.lengths[b]));
+    const size_t V = static_cast<size_t>(ct2x_vocab_size(h_.get(), 1));
+    std::vector<float> out(batch * T * V);
+    detail::check(ct2x_forward_batch(h_.get(), in.ids.data(), in.lengths.data(),
+                                     static_cast<int32_t>(batch), in.stride, return_log_probs ? 1 : 0,
+                                     out.data()));
+    if (time_out) *time_out = T;
+    if (vocab_out) *vocab_out = V;
+    return out;
   }
 
   const std::string& compute_type() const { return h_.compute_type(); }

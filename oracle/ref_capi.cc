@@ -521,6 +521,108 @@ int ct2ref_generate_processors(void* h, const int32_t* prompt_ids, const int32_t
   CT2REF_CATCH
 }
 
+// Translator::translate_batch with every decoding option the fused engine's "remaining decoding"
+// row covers (include/ctranslate2/translation.h): target prefix, return_alternatives +
+// min_alternative_expansion_prob (decode_alternatives, src/decoding.cc:1122-1290), biased decoding
+// (prefix_bias_beta, BiasedDecoder :256-343), return_attention, coverage_penalty.
+// out_ids [batch, num_hyp, max_len], out_lengths / out_scores [batch, num_hyp] (length -1: the
+// reference returned fewer hypotheses), out_attention [batch, num_hyp, max_len, att_stride] or NULL.
+int ct2ref_translate_ex(void* h, const int32_t* src_ids, const int32_t* src_lengths, int batch,
+                        int src_stride, const int32_t* prefix_ids, const int32_t* prefix_lengths,
+                        int prefix_stride, int beam_size, int max_len, int min_len,
+                        float length_penalty, float coverage_penalty, int num_hyp,
+                        int return_alternatives, float min_alternative_expansion_prob,
+                        float prefix_bias_beta, int32_t* out_ids, int32_t* out_lengths,
+                        float* out_scores, float* out_attention, int att_stride) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const auto* s2s = dynamic_cast<const models::SequenceToSequenceModel*>(m->model.get());
+  if (!s2s || !m->translator) throw std::runtime_error("not a sequence-to-sequence model");
+  auto source = ids_to_tokens(s2s->get_source_vocabulary(), src_ids, src_lengths, batch, src_stride);
+  std::vector<std::vector<std::string>> prefix;
+  if (prefix_ids)
+    prefix = ids_to_tokens(s2s->get_target_vocabulary(), prefix_ids, prefix_lengths, batch,
+                           prefix_stride);
+  TranslationOptions opt;
+  opt.beam_size = beam_size;
+  opt.max_decoding_length = max_len;
+  opt.min_decoding_length = min_len;
+  opt.length_penalty = length_penalty;
+  opt.coverage_penalty = coverage_penalty;
+  opt.num_hypotheses = num_hyp;
+  opt.return_scores = true;
+  opt.return_attention = out_attention != nullptr;
+  opt.return_alternatives = return_alternatives != 0;
+  opt.min_alternative_expansion_prob = min_alternative_expansion_prob;
+  opt.prefix_bias_beta = prefix_bias_beta;
+  opt.max_input_length = 0;
+  auto results = m->translator->translate_batch(source, prefix, opt);
+  const auto& tv = s2s->get_target_vocabulary();
+  for (int b = 0; b < batch; ++b) {
+    for (int k = 0; k < num_hyp; ++k) {
+      const int64_t slot = static_cast<int64_t>(b) * num_hyp + k;
+      if (k >= static_cast<int>(results[b].hypotheses.size())) {
+        out_lengths[slot] = -1;
+        continue;
+      }
+      const auto& hyp = results[b].hypotheses[k];
+      const int len = static_cast<int>(hyp.size());
+      for (int t = 0; t < len && t < max_len; ++t) out_ids[slot * max_len + t] = tv.to_id(hyp[t]);
+      out_lengths[slot] = len;
+      out_scores[slot] = k < static_cast<int>(results[b].scores.size()) ? results[b].scores[k] : 0.f;
+      if (out_attention && k < static_cast<int>(results[b].attention.size())) {
+        const auto& att = results[b].attention[k];
+        for (int t = 0; t < static_cast<int>(att.size()) && t < max_len; ++t)
+          for (int j = 0; j < static_cast<int>(att[t].size()) && j < att_stride; ++j)
+            out_attention[(slot * max_len + t) * att_stride + j] = att[t][j];
+      }
+    }
+  }
+  CT2REF_CATCH
+}
+
+// Generator::score_batch (include/ctranslate2/generator.h:21-29; models::DecoderReplica::
+// run_scoring -> score_sequences, src/scoring.cc): log-probability of tokens[1:] given the tokens
+// before them. out_scores [batch, stride]; out_lengths[b] = scored tokens (0: skipped, < 2 tokens).
+int ct2ref_generator_score(void* h, const int32_t* ids, const int32_t* lengths, int batch,
+                           int stride, int max_input_length, float* out_scores,
+                           int32_t* out_lengths) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const auto* lm = dynamic_cast<const models::LanguageModel*>(m->model.get());
+  if (!lm || !m->generator) throw std::runtime_error("not a language model");
+  auto tokens = ids_to_tokens(lm->get_vocabulary(), ids, lengths, batch, stride);
+  ScoringOptions opt;
+  opt.max_input_length = max_input_length;
+  auto futures = m->generator->score_batch_async(tokens, opt);
+  for (int b = 0; b < batch; ++b) {
+    const ScoringResult r = futures[b].get();
+    out_lengths[b] = static_cast<int32_t>(r.tokens_score.size());
+    for (size_t t = 0; t < r.tokens_score.size() && t < static_cast<size_t>(stride); ++t)
+      out_scores[static_cast<int64_t>(b) * stride + t] = r.tokens_score[t];
+  }
+  CT2REF_CATCH
+}
+
+// Generator::forward_batch (include/ctranslate2/generator.h:31-35; SequenceGeneratorReplica::
+// forward, src/models/language_model.cc:66-100): logits (or log-probabilities) of every position,
+// out [batch, max(lengths), vocab]; rows are padded to the longest sequence.
+int ct2ref_generator_forward(void* h, const int32_t* ids, const int32_t* lengths, int batch,
+                             int stride, int return_log_probs, float* out, int64_t* vocab_out) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const auto* lm = dynamic_cast<const models::LanguageModel*>(m->model.get());
+  if (!lm || !m->generator) throw std::runtime_error("not a language model");
+  std::vector<std::vector<size_t>> seqs(batch);
+  for (int b = 0; b < batch; ++b)
+    seqs[b].assign(ids + b * stride, ids + b * stride + lengths[b]);
+  StorageView logits = m->generator->forward_batch_async(seqs, return_log_probs != 0).get();
+  StorageView lf = logits.to_float32();
+  if (vocab_out) *vocab_out = lf.dim(-1);
+  std::memcpy(out, lf.data<float>(), sizeof(float) * lf.size());
+  CT2REF_CATCH
+}
+
 // Teacher-forced decoding through layers::TransformerEncoder / TransformerDecoder
 // (src/layers/transformer.cc:427-471, 621-871): runs the encoder on `src_ids`
 // ([batch, src_stride] INCLUDING any special tokens, lengths in src_lengths; pass

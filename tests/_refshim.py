@@ -370,6 +370,60 @@ class RefModel:
             C.c_int(len(seqs)), _p(out), _p(out_len), _p(scores)))
         return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
 
+    def translate_ex_ids(self, sources, prefixes=None, beam_size=1, max_len=64, min_len=1,
+                         length_penalty=1.0, coverage_penalty=0.0, num_hypotheses=1,
+                         return_alternatives=False, min_alternative_expansion_prob=0.0,
+                         prefix_bias_beta=0.0, return_attention=False):
+        """Translator::translate_batch with the remaining decoding options (ct2ref_translate_ex).
+        Returns (hypotheses [batch][<= num_hypotheses], scores likewise, attention or None)."""
+        ids, lengths, stride = self._pack(sources)
+        batch = len(sources)
+        if prefixes is not None:
+            pids, plens, pstride = self._pack(prefixes)
+        out = np.zeros((batch, num_hypotheses, max_len), np.int32)
+        out_len = np.zeros((batch, num_hypotheses), np.int32)
+        scores = np.zeros((batch, num_hypotheses), np.float32)
+        att_stride = stride + 2
+        att = np.zeros((batch, num_hypotheses, max_len, att_stride), np.float32) if return_attention else None
+        _check(lib().ct2ref_translate_ex(
+            C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch), C.c_int(stride),
+            _p(pids) if prefixes is not None else None, _p(plens) if prefixes is not None else None,
+            C.c_int(pstride if prefixes is not None else 0), C.c_int(beam_size), C.c_int(max_len),
+            C.c_int(min_len), C.c_float(length_penalty), C.c_float(coverage_penalty),
+            C.c_int(num_hypotheses), C.c_int(int(return_alternatives)),
+            C.c_float(min_alternative_expansion_prob), C.c_float(prefix_bias_beta), _p(out),
+            _p(out_len), _p(scores), _p(att) if return_attention else None, C.c_int(att_stride)))
+        hyps = [[out[b, k, :out_len[b, k]].tolist() for k in range(num_hypotheses) if out_len[b, k] >= 0]
+                for b in range(batch)]
+        scs = [[float(scores[b, k]) for k in range(num_hypotheses) if out_len[b, k] >= 0]
+               for b in range(batch)]
+        atts = None
+        if return_attention:
+            atts = [[att[b, k, :out_len[b, k]].copy() for k in range(num_hypotheses) if out_len[b, k] >= 0]
+                    for b in range(batch)]
+        return hyps, scs, atts
+
+    def generator_score_ids(self, sequences, max_input_length=1024):
+        ids, lengths, stride = self._pack(sequences)
+        batch = len(sequences)
+        scores = np.zeros((batch, stride), np.float32)
+        out_len = np.zeros((batch,), np.int32)
+        _check(lib().ct2ref_generator_score(C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch),
+                                            C.c_int(stride), C.c_int(max_input_length), _p(scores),
+                                            _p(out_len)))
+        return [scores[b, :out_len[b]].copy() for b in range(batch)]
+
+    def generator_forward_ids(self, sequences, vocab_size, return_log_probs=False):
+        ids, lengths, stride = self._pack(sequences)
+        batch = len(sequences)
+        out = np.empty((batch, int(lengths.max()), vocab_size), np.float32)
+        v = C.c_int64(0)
+        _check(lib().ct2ref_generator_forward(C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch),
+                                              C.c_int(stride), C.c_int(int(return_log_probs)), _p(out),
+                                              C.byref(v)))
+        assert v.value == vocab_size, (v.value, vocab_size)
+        return out
+
     def step_logits(self, src, tgt_in, vocab_size):
         """Teacher-forced per-step logits [T, batch, vocab]. `src` includes special tokens."""
         batch = len(tgt_in)

@@ -772,13 +772,16 @@ def test_runtime_abi_round_trip(gpu):
 
 
 @pytest.mark.parametrize("topk,topp,temp", [(8, 0.7, 1.0), (40, 0.9, 0.8), (64, 1.0, 1.3), (2, 0.5, 1.0),
-                                            (0, 0.8, 1.0), (0, 1.0, 0.7), (0, 0.3, 1.5)])
+                                            (0, 0.8, 1.0), (0, 1.0, 0.7), (0, 0.3, 1.5),
+                                            (65, 1.0, 1.0), (200, 0.9, 0.8), (1000, 0.6, 1.2), (1499, 1.0, 1.0),
+                                            (5000, 0.9, 1.0)])
 def test_random_sample_with_injected_uniforms(gpu, topk, topp, temp):
     """RandomSampler's chain TopK -> temperature -> TopPMask -> SoftMax -> Multinomial
     (src/sampling.cc:41-101) with the uniform draws INJECTED: the id each row returns must be the
     inverse CDF, at its draw, of the distribution the oracle's TopPMask (orc_topp_mask, pinned against
     the reference's TopPMask KAT) leaves - candidates in TopK order for sampling_topk > 0, in
-    index order for the whole vocabulary - and the score the log-probability under the original
+    index order for the whole vocabulary and for candidate sets longer than 64 (found by a value
+    threshold instead of a list, so any sampling_topk up to the vocabulary works) - and the score the log-probability under the original
     distribution. Rows whose draw or whose top-p mass sits within 1e-5 of a boundary are not
     decidable across float formats and are skipped (a handful at most)."""
     import _gpuops as G
@@ -791,8 +794,10 @@ def test_random_sample_with_injected_uniforms(gpu, topk, topp, temp):
     checked = 0
     for r in range(rows):
         x = logits[r]
-        if topk > 0:
+        if 0 < topk <= 64:
             order = np.argsort(-x, kind="stable")[:topk]
+        elif 64 < topk < vocab:
+            order = np.sort(np.argsort(-x, kind="stable")[:topk])
         else:
             order = np.arange(vocab)
         z = (x[order].astype(np.float64) - x.max()) / temp
@@ -817,6 +822,25 @@ def test_random_sample_with_injected_uniforms(gpu, topk, topp, temp):
         assert abs(scores[r] - (x[ids[r]] - lse)) < 1e-4
         checked += 1
     assert checked >= rows - 8
+
+
+def test_random_sample_long_candidate_list_breaks_ties_by_index(gpu):
+    """ops::TopK keeps the LOWEST indices among equal values (src/ops/topk_cpu.cc:13-55): with a
+    plateau of equal logits straddling the k-th rank, only the plateau's first tokens are candidates."""
+    import _gpuops as G
+    rows, vocab, topk = 64, 3000, 300
+    rng = np.random.default_rng(17)
+    logits = np.full((rows, vocab), -5.0, np.float32)
+    high = rng.permutation(vocab)[:250]
+    logits[:, high] = 2.0                       # 250 clear winners, then a plateau of 2750 equal values
+    u = rng.random(rows).astype(np.float32)
+    ids, _ = G.random_sample(logits, topk, 1.0, 1.0, u)
+    plateau = np.setdiff1d(np.arange(vocab), high)[:topk - 250]
+    allowed = set(high.tolist()) | set(plateau.tolist())
+    assert all(int(i) in allowed for i in ids)
+    # the plateau members are reachable: force the draw into the tail of the CDF
+    ids_tail, _ = G.random_sample(logits, topk, 1.0, 1.0, np.full(rows, 0.999999, np.float32))
+    assert all(int(i) == max(allowed) for i in ids_tail)
 
 
 def test_random_sample_hash_is_reproducible(gpu):
