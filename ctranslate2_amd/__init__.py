@@ -464,3 +464,186 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         st = ExecStats()
         _lib.check(self._L.ct2x_last_stats(C.c_void_p(self._h), C.byref(st)))
         return {name: getattr(st, name) for name, _ in ExecStats._fields_}
+
+
+class WhisperOptions(C.Structure):
+    """struct ct2x_whisper_options = models::WhisperOptions
+    (include/ctranslate2/models/whisper.h:11-58)."""
+    _fields_ = [("beam_size", C.c_int32), ("patience", C.c_float), ("length_penalty", C.c_float),
+                ("repetition_penalty", C.c_float), ("no_repeat_ngram_size", C.c_int32),
+                ("max_length", C.c_int32), ("sampling_topk", C.c_int32),
+                ("sampling_temperature", C.c_float), ("num_hypotheses", C.c_int32),
+                ("return_scores", C.c_int32), ("return_no_speech_prob", C.c_int32),
+                ("max_initial_timestamp_index", C.c_int32), ("suppress_blank", C.c_int32),
+                ("num_suppress_tokens", C.c_int32), ("suppress_tokens", C.POINTER(C.c_int32))]
+
+
+class WhisperGenerationResult:
+    """ctranslate2.models.WhisperGenerationResult (python/cpp/whisper.cc:229-249)."""
+
+    def __init__(self, sequences, sequences_ids, scores, no_speech_prob):
+        self.sequences = sequences
+        self.sequences_ids = sequences_ids
+        self.scores = scores
+        self.no_speech_prob = no_speech_prob
+
+    def __repr__(self):
+        return ("WhisperGenerationResult(sequences=%r, sequences_ids=%r, scores=%r, "
+                "no_speech_prob=%r)" % (self.sequences, self.sequences_ids, self.scores,
+                                         self.no_speech_prob))
+
+
+class WhisperAlignmentResult:
+    """ctranslate2.models.WhisperAlignmentResult (python/cpp/whisper.cc:251-263)."""
+
+    def __init__(self, alignments, text_token_probs):
+        self.alignments = alignments
+        self.text_token_probs = text_token_probs
+
+    def __repr__(self):
+        return "WhisperAlignmentResult(alignments=%r, text_token_probs=%r)" % (
+            self.alignments, self.text_token_probs)
+
+
+class Whisper:
+    """ctranslate2.models.Whisper (python/cpp/whisper.cc:265-420) on one MI355X: encode, generate,
+    detect_language, align over float32 features [batch, n_mels, frames] (numpy)."""
+
+    def __init__(self, model_path: str, device: str = "cuda", device_index: int = 0,
+                 compute_type: str = "default"):
+        if device not in ("cuda", "auto"):
+            raise ValueError("ctranslate2_amd only implements the GPU device (device='cuda'); "
+                             "got device=%r" % device)
+        self._L = L = _lib.lib()
+        L.ct2x_whisper_create.restype = C.c_void_p
+        L.ct2x_whisper_create.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+        L.ct2x_whisper_destroy.argtypes = [C.c_void_p]
+        L.ct2x_whisper_vocab_token.restype = C.c_char_p
+        L.ct2x_whisper_vocab_token.argtypes = [C.c_void_p, C.c_int32]
+        L.ct2x_whisper_vocab_id.restype = C.c_int32
+        L.ct2x_whisper_vocab_id.argtypes = [C.c_void_p, C.c_char_p]
+        L.ct2x_whisper_vocab_size.argtypes = [C.c_void_p]
+        self._h = L.ct2x_whisper_create(model_path.encode(), C.c_int(device_index),
+                                        compute_type.encode())
+        if not self._h:
+            raise Ct2xError(L.ct2x_last_error().decode("utf-8", "replace"))
+        v = [C.c_int32() for _ in range(3)]
+        _lib.check(L.ct2x_whisper_info(C.c_void_p(self._h), *[C.byref(x) for x in v]))
+        self.is_multilingual = bool(v[0].value)
+        self.n_mels = v[1].value
+        self.num_languages = v[2].value
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ct2x_whisper_destroy(C.c_void_p(self._h))
+            self._h = None
+
+    def _token(self, i):
+        t = self._L.ct2x_whisper_vocab_token(C.c_void_p(self._h), C.c_int32(int(i)))
+        return t.decode("utf-8", "replace") if t is not None else None
+
+    def _id(self, token):
+        return int(self._L.ct2x_whisper_vocab_id(C.c_void_p(self._h), token.encode("utf-8")))
+
+    def _ids(self, seq):
+        return [self._id(t) if isinstance(t, str) else int(t) for t in seq]
+
+    @staticmethod
+    def _features(features):
+        f = np.ascontiguousarray(features, dtype=np.float32)
+        if f.ndim != 3:
+            raise ValueError("Expected input features to have 3 dimensions, but got %d "
+                             "dimension(s) instead" % f.ndim)
+        return f
+
+    def encode(self, features) -> np.ndarray:
+        f = self._features(features)
+        b, m, t = f.shape
+        self._L.ct2x_whisper_d_model.restype = C.c_int64
+        d_model = int(self._L.ct2x_whisper_d_model(C.c_void_p(self._h)))
+        out = np.zeros((b, (t - 1) // 2 + 1, d_model), np.float32)
+        dims = np.zeros(3, np.int64)
+        _lib.check(self._L.ct2x_whisper_encode(C.c_void_p(self._h), _lib.ptr(f), C.c_int32(b),
+                                               C.c_int32(m), C.c_int32(t), _lib.ptr(out),
+                                               C.c_int64(out.size), _lib.ptr(dims)))
+        n = int(dims[0] * dims[1] * dims[2])
+        return out.reshape(-1)[:n].reshape(tuple(int(x) for x in dims)).copy()
+
+    def generate(self, features, prompts, *, beam_size=5, patience=1.0, num_hypotheses=1,
+                 length_penalty=1.0, repetition_penalty=1.0, no_repeat_ngram_size=0,
+                 max_length=448, return_scores=False, return_no_speech_prob=False,
+                 max_initial_timestamp_index=50, suppress_blank=True, suppress_tokens=(-1,),
+                 sampling_topk=1, sampling_temperature=1.0) -> List[WhisperGenerationResult]:
+        f = self._features(features)
+        b, m, t = f.shape
+        prompts = [self._ids(p) for p in prompts]
+        if len(prompts) != b:
+            raise ValueError("one prompt per batch entry is required")
+        lengths = np.array([len(p) for p in prompts], np.int32)
+        stride = max(1, int(lengths.max()) if b else 1)
+        ids = np.zeros((b, stride), np.int32)
+        for i, p in enumerate(prompts):
+            ids[i, :len(p)] = p
+        sup = np.array(list(suppress_tokens or ()), np.int32)
+        o = WhisperOptions(beam_size, patience, length_penalty, repetition_penalty,
+                           no_repeat_ngram_size, max_length, sampling_topk, sampling_temperature,
+                           num_hypotheses, int(return_scores), int(return_no_speech_prob),
+                           max_initial_timestamp_index, int(suppress_blank), len(sup),
+                           sup.ctypes.data_as(C.POINTER(C.c_int32)))
+        max_len = max(1, max_length)
+        out = np.zeros((b, num_hypotheses, max_len), np.int32)
+        out_len = np.zeros((b, num_hypotheses), np.int32)
+        scores = np.zeros((b, num_hypotheses), np.float32)
+        nsp = np.zeros(b, np.float32)
+        _lib.check(self._L.ct2x_whisper_generate(
+            C.c_void_p(self._h), _lib.ptr(f), C.c_int32(b), C.c_int32(m), C.c_int32(t),
+            _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(stride), C.byref(o), C.c_int32(max_len),
+            _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores), _lib.ptr(nsp)))
+        results = []
+        for i in range(b):
+            seq_ids = [out[i, k, :out_len[i, k]].tolist() for k in range(num_hypotheses)
+                       if out_len[i, k] >= 0]
+            results.append(WhisperGenerationResult(
+                [[self._token(x) for x in s] for s in seq_ids], seq_ids,
+                [float(scores[i, k]) for k in range(len(seq_ids))] if return_scores else [],
+                float(nsp[i]) if return_no_speech_prob else 0.0))
+        return results
+
+    def detect_language(self, features):
+        f = self._features(features)
+        b, m, t = f.shape
+        n = self.num_languages
+        ids = np.zeros((b, n), np.int32)
+        probs = np.zeros((b, n), np.float32)
+        _lib.check(self._L.ct2x_whisper_detect_language(
+            C.c_void_p(self._h), _lib.ptr(f), C.c_int32(b), C.c_int32(m), C.c_int32(t),
+            C.c_int32(n), _lib.ptr(ids), _lib.ptr(probs)))
+        return [[(self._token(ids[i, j]), float(probs[i, j])) for j in range(n)] for i in range(b)]
+
+    def align(self, features, start_sequence, text_tokens, num_frames, *, median_filter_width=7):
+        f = self._features(features)
+        b, m, t = f.shape
+        start = np.array(self._ids(start_sequence), np.int32)
+        text_tokens = [self._ids(x) for x in text_tokens]
+        lengths = np.array([len(x) for x in text_tokens], np.int32)
+        stride = max(1, int(lengths.max()) if b else 1)
+        ids = np.zeros((b, stride), np.int32)
+        for i, x in enumerate(text_tokens):
+            ids[i, :len(x)] = x
+        nf = np.array(list(num_frames), np.int32)
+        if len(nf) != b:
+            raise ValueError("Invalid batch size for argument num_frames")
+        cap = int(stride + 2 + t)
+        pairs = np.zeros((b, cap, 2), np.int32)
+        n_pairs = np.zeros(b, np.int32)
+        probs = np.zeros((b, stride), np.float32)
+        _lib.check(self._L.ct2x_whisper_align(
+            C.c_void_p(self._h), _lib.ptr(f), C.c_int32(b), C.c_int32(m), C.c_int32(t),
+            _lib.ptr(start), C.c_int32(len(start)), _lib.ptr(ids), _lib.ptr(lengths),
+            C.c_int32(stride), _lib.ptr(nf), C.c_int32(median_filter_width), C.c_int32(cap),
+            _lib.ptr(pairs), _lib.ptr(n_pairs), _lib.ptr(probs)))
+        return [WhisperAlignmentResult([tuple(p) for p in pairs[i, :n_pairs[i]].tolist()],
+                                       probs[i, :lengths[i]].tolist()) for i in range(b)]

@@ -138,6 +138,7 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
   } else {
     engine.set_prefix(st, {}, opt.start_step);
   }
+  if (opt.whisper) engine.set_whisper_processing(st, *opt.whisper);
   // return_prefix: the prefix is part of the hypothesis and counts towards max_length
   const int64_t extra = opt.return_prefix ? 0 : 1;
   const int64_t max_step = opt.max_length + extra * longest_prefix;
@@ -295,6 +296,7 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   } else {
     engine.set_beam_prefix(st, {}, opt.start_step);
   }
+  if (opt.whisper) engine.set_whisper_processing(st, *opt.whisper);
 
   // alive_seq[i][k]: tokens of active beam k of batch i.
   std::vector<std::vector<std::vector<int32_t>>> alive_seq(

@@ -52,6 +52,9 @@ struct DecodingOptions {
   // record, per step and row, the attention vector of the alignment heads over the source.
   bool return_attention = false;
   float coverage_penalty = 0.f;
+  // Whisper's logits processors (DecodingOptions::logits_processors + disable_ids_begin of
+  // WhisperReplica::generate, src/models/whisper.cc:312-343); nullptr = none
+  const WhisperProcessing* whisper = nullptr;
 };
 
 struct DecodingResult {

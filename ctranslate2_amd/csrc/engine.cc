@@ -148,11 +148,13 @@ Engine::Engine(std::shared_ptr<ModelFile> model, const std::string& compute_type
   if (spec == "TransformerSpec" || spec == "TransformerBase" || spec == "TransformerBig" ||
       spec.empty()) {
     has_encoder_ = true;
+  } else if (spec == "WhisperSpec") {
+    has_encoder_ = true;  // convolutional front end instead of source embeddings (load_stack)
   } else if (spec == "TransformerDecoderSpec") {
     has_encoder_ = false;
   } else {
     throw std::runtime_error("Model specification '" + spec + "' is not handled by this backend "
-                             "(Transformer encoder-decoder and decoder-only models are)");
+                             "(Transformer encoder-decoder, decoder-only and Whisper models are)");
   }
   load_weights();
 }
@@ -232,7 +234,11 @@ DenseW Engine::load_dense(const std::string& scope, bool required, Shard shard,
     if (required) throw std::out_of_range("variable " + scope + "/weight not found");
     return d;
   }
-  if (w->shape.size() != 2) throw std::runtime_error(scope + "/weight is not a matrix");
+  // Conv1D weights [out, in, kernel] are the [out, in * kernel] matrix of the convolution run as a
+  // GEMM over im2col rows (Conv1D::compute_with_gemm, src/ops/conv1d_cpu.cc:139-207; Model::load
+  // reshapes them the same way to convert them, src/models/model.cc:208-227)
+  const bool is_conv = w->shape.size() == 3 && scope.find("conv") != std::string::npos;
+  if (w->shape.size() != 2 && !is_conv) throw std::runtime_error(scope + "/weight is not a matrix");
   if (const Variable* zero = model_->find(scope + "/weight_zero")) {
     // AWQ int4 (layers::Dense AWQ branch, src/layers/common.cc:402-438; formats: awq.hip). The
     // reference forces FLOAT16 for such models (src/models/model.cc:754-757): here the fp32
@@ -269,7 +275,7 @@ DenseW Engine::load_dense(const std::string& scope, bool required, Shard shard,
   }
   d.present = true;
   d.n = w->shape[0];
-  d.k = w->shape[1];
+  d.k = is_conv ? w->shape[1] * w->shape[2] : w->shape[1];
   const Variable* scale = model_->find(scope + "/weight_scale");
   const bool want_int8 = (compute_type_ == ComputeType::kInt8Float32);
   if (!tp_) shard = Shard::kNone;
@@ -496,7 +502,8 @@ void Engine::load_stack(const std::string& scope, bool decoder, StackW& out) {
   if (m.spec == "TransformerBig") default_heads = 16;
   out.num_heads = static_cast<int64_t>(attr("num_heads", double(default_heads)));
   out.pre_norm = attr("pre_norm", 1) != 0;
-  const int activation = static_cast<int>(attr("activation", 0));
+  int activation = static_cast<int>(attr("activation", 0));
+  if (!decoder && m.has(scope + "/conv1/weight")) activation = 3;  // GELU (src/layers/whisper.cc:7)
 
   for (const char* unsupported : {"/project_in/weight", "/project_out/weight", "/scale_outputs"})
     if (m.has(scope + unsupported))
@@ -510,8 +517,28 @@ void Engine::load_stack(const std::string& scope, bool decoder, StackW& out) {
   if (m.flag(scope + "/start_from_zero_embedding", false))
     throw std::runtime_error("start_from_zero_embedding is not supported by this backend yet");
 
+  const bool conv_front_end = !decoder && m.has(scope + "/conv1/weight");
+  if (conv_front_end) {
+    // layers::WhisperEncoder (src/layers/whisper.cc:9-24): conv1 (stride 1) and conv2 (stride 2),
+    // kernel 3, padding 1, GELU; GELU encoder layers, pre-norm; learned positions
+    for (const char* cs : {"/conv1/weight", "/conv2/weight"}) {
+      const Variable& cw = m.get(scope + cs);
+      if (cw.shape.size() != 3 || cw.shape[2] != 3)
+        throw std::runtime_error(scope + cs + ": expected a [out, in, 3] convolution weight");
+    }
+    out.has_conv = true;
+    out.conv1 = load_dense(scope + "/conv1", true);
+    out.conv2 = load_dense(scope + "/conv2", true);
+    out.n_mels = out.conv1.k / 3;
+    out.d_model = out.conv2.n;
+    if (out.conv2.k != 3 * out.conv1.n)
+      throw std::runtime_error(scope + "/conv2: input channels differ from conv1's outputs");
+  }
   // Embeddings (layers::Embeddings / ParallelEmbeddings, src/layers/common.cc:49-148).
   std::string emb_scope = scope + "/embeddings";
+  if (conv_front_end) {
+    // (no embeddings)
+  } else {
   if (!m.has(emb_scope + "/weight")) {
     emb_scope = scope + "/embeddings_0";
     if (m.has(scope + "/embeddings_1/weight"))
@@ -548,9 +575,10 @@ void Engine::load_stack(const std::string& scope, bool decoder, StackW& out) {
       }
     }
   }
+  }  // (!conv_front_end)
 
   // build_embeddings_scale (src/layers/transformer.cc:378-399).
-  {
+  if (!conv_front_end) {
     const Variable* scale = m.find(scope + "/scale_embeddings");
     if (!scale) scale = m.find(scope + "/embeddings/multiply_by_sqrt_depth");
     if (!scale || (scale->dtype == kI8 && scale->as_number() != 0)) {
@@ -1302,9 +1330,27 @@ std::unique_ptr<DecodeState> Engine::start_decoder_only(int64_t batch, int64_t b
   return start(nullptr, nullptr, batch, 0, beam, t_max, prefill_len);
 }
 
+std::unique_ptr<DecodeState> Engine::start_features(const float* features, int64_t batch,
+                                                    int64_t frames, int64_t beam, int64_t t_max,
+                                                    int64_t prefill_len, bool beam_search_state) {
+  CT2X_CHECK(is_whisper(), "this model has no convolutional front end (not a Whisper model)");
+  CT2X_CHECK(features != nullptr && batch > 0, "start_features: no features");
+  // WhisperEncoder::operator() (src/layers/whisper.cc:33-50): at most max_input_time() =
+  // 2 * positions frames
+  if (frames < 1 || whisper_memory_length(frames) > enc_.num_positions)
+    throw std::invalid_argument("Invalid input features shape: expected at most " +
+                                std::to_string(2 * enc_.num_positions) + " frames, but got " +
+                                std::to_string(frames));
+  return start(nullptr, nullptr, batch, whisper_memory_length(frames), beam, t_max, prefill_len,
+               beam_search_state, features, frames);
+}
+
 std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t* src_lengths,
                                            int64_t batch, int64_t s_max, int64_t beam,
-                                           int64_t t_max, int64_t prefill_len, bool beam_search_state) {
+                                           int64_t t_max, int64_t prefill_len, bool beam_search_state,
+                                           const float* features, int64_t frames) {
+  CT2X_CHECK(is_whisper() == (features != nullptr),
+             "Whisper models take input features, every other model token ids");
   CT2X_HIP_CHECK(hipSetDevice(device_));
   auto st = std::make_unique<DecodeState>();
   st->engine = this;
@@ -1332,7 +1378,9 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   }
   // Workspace sized for the larger of the decode rows and the encoder rows.
   // (a beam-search prefill forwards the prompt once per hypothesis row)
-  const int64_t enc_rows = std::max(has_encoder_ ? batch * s_max : 0, rows * prefill_len);
+  // (the first convolution of a Whisper encoder runs over `frames` rows per batch entry)
+  const int64_t enc_rows = std::max(has_encoder_ ? batch * std::max(s_max, frames) : 0,
+                                    rows * prefill_len);
   st->prefill_max = prefill_len;
   int64_t enc_ffn = 0, enc_qkv = 0;
   for (const auto& l : enc_.layers) {
@@ -1481,7 +1529,10 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       const AttnW& a = dec_.layers[l].cross;
       st->cross_kv.push_back(alloc<float>(*st, batch * s_max * a.lin[1].n));
     }
-    encode(*st, src_ids, src_lengths);
+    if (features)
+      encode_features(*st, features, frames);
+    else
+      encode(*st, src_ids, src_lengths);
   }
   return st;
 }
@@ -1511,7 +1562,63 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
   tap_scope("enc");
   tap("emb", x, 0, rows, d);
   if (enc_.layernorm_embedding.present) norm(enc_.layernorm_embedding, x, rows, d, x);
+  encode_layers(st, x, y);
+}
 
+// WhisperEncoder::operator() (src/layers/whisper.cc:26-62): conv1 -> conv2 -> Transpose ->
+// position embeddings -> encoder layers -> layer_norm. Each convolution is im2col + Dense with
+// the bias + GELU epilogue (the reference's CPU path is the same GEMM, conv1d_cpu.cc:139-207, with
+// the operands swapped); the GEMM output [batch * time, channels] is already the transposed
+// layout. int8 weights: the im2col rows are quantised per row, round-before-cast, no u8 shift
+// (conv1d_cpu.cc:176-178, ops::Quantize::operator() INT8 arm, src/ops/quantize.cc:35-43).
+void Engine::encode_features(DecodeState& st, const float* features, int64_t frames) {
+  const int64_t B = st.batch, S = st.s_max, d = enc_.d_model, C = enc_.n_mels;
+  CT2X_CHECK(S == whisper_memory_length(frames), "encode_features: state / frames mismatch");
+  std::vector<int32_t> lens(static_cast<size_t>(B), static_cast<int32_t>(S));
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.mem_lengths, lens.data(), sizeof(int32_t) * B,
+                                hipMemcpyHostToDevice, cur_stream()));
+  float* d_feat = alloc<float>(st, B * C * frames);
+  float* col1 = alloc<float>(st, B * frames * C * 3);
+  float* h1 = alloc<float>(st, B * frames * enc_.conv1.n);
+  float* col2 = alloc<float>(st, B * S * enc_.conv2.k);
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_feat, features, sizeof(float) * B * C * frames,
+                                hipMemcpyHostToDevice, cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // `lens` and the caller's features may go away
+  auto conv = [&](const DenseW& w, const float* cols, int64_t rows, float* y) {
+    const int kGelu = 3;  // ops::ActivationType::GELU
+    if (w.quantized) {
+      begin_kernel("quantize_s8", double(rows) * w.k * 5 + rows * 4, 0, rows, 0, w.k);
+      launch_quantize_s8(cols, rows, w.k, /*round before cast, no u8 shift*/ 1, st.qbuf, st.qscale, cur_stream());
+      end_kernel();
+      QuantIn q;
+      q.q = st.qbuf;
+      q.s = st.qscale;
+      dense(w, nullptr, &q, rows, kGelu, nullptr, y, &st);
+    } else {
+      dense(w, cols, nullptr, rows, kGelu, nullptr, y, &st);
+    }
+  };
+  tap_scope("enc.conv");
+  begin_kernel("im2col", double(B) * frames * C * 16, 0, B * frames, 0, C * 3);
+  launch_im2col_k3(d_feat, B, C, frames, frames, 1, 1, /*time_major=*/false, col1, cur_stream());
+  end_kernel();
+  conv(enc_.conv1, col1, B * frames, h1);
+  begin_kernel("im2col", double(B) * S * enc_.conv2.k * 8, 0, B * S, 0, enc_.conv2.k);
+  launch_im2col_k3(h1, B, enc_.conv1.n, frames, S, 2, 1, /*time_major=*/true, col2, cur_stream());
+  end_kernel();
+  float* x = st.x0;
+  float* y = st.x1;
+  conv(enc_.conv2, col2, B * S, x);
+  CT2X_CHECK(enc_.position_table != nullptr, "Whisper encoder without position encodings");
+  begin_kernel("add_positions", double(B) * S * d * 12, 0, B * S, 0, d);
+  launch_add_positions(x, enc_.position_table, B, S, d, cur_stream());
+  end_kernel();
+  tap("emb", x, 0, B * S, d);
+  encode_layers(st, x, y);
+}
+
+void Engine::encode_layers(DecodeState& st, float* x, float* y) {
+  const int64_t B = st.batch, S = st.s_max, d = enc_.d_model, rows = B * S;
   int enc_layer_index = 0;
   for (const LayerW& layer : enc_.layers) {
     const AttnW& a = layer.self;
@@ -1569,6 +1676,7 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
     ++enc_layer_index;
   }
   if (enc_.output_norm.present) norm(enc_.output_norm, x, rows, d, x);
+  st.enc_out = x;
   tap_scope("enc.out");
   tap("x", x, 0, rows, d);
 
@@ -1698,7 +1806,8 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
 // lengths, src/layers/transformer.cc:673-696; DecoderReplica::run_generation prefill,
 // src/models/language_model.cc:217-238): fills the self-attention caches for positions
 // [0, time) of every row and leaves the step counter at `time`. No logits are produced.
-void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time, float* logits_all) {
+void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time, float* logits_all,
+                     const ScoreCapture* capture) {
   CT2X_HIP_CHECK(hipSetDevice(device_));
   tls_stream = st.stream;
   set_active_stream(tls_stream);
@@ -1799,6 +1908,23 @@ void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time, float*
       }
       dense(c.lin[0], cin, cq.q ? &cq : nullptr, rows, -1, nullptr, st.qkv, &st);
       const int64_t qdim = c.heads * c.dhead, kvdim = c.heads_kv * c.dhead;
+      if (capture && !capture->heads[l].empty()) {
+        // the scores before their softmax (return_normalized_attention() == false,
+        // include/ctranslate2/layers/whisper.h), selected heads only (transformer.cc:811-814)
+        CT2X_CHECK(st.beam == 1 && c.heads_kv == c.heads, "attention scores: beam 1, no GQA");
+        int64_t offset = 0;
+        for (size_t k = 0; k < l; ++k) offset += static_cast<int64_t>(capture->heads[k].size());
+        const int64_t n_here = static_cast<int64_t>(capture->heads[l].size());
+        begin_kernel("attention_scores", 0, 0, rows, n_here, c.dhead);
+        for (int64_t b = 0; b < st.batch; ++b)  // [batch, n_sel, time, s_max]: this layer's slice
+          launch_attention_scores(st.qkv + b * time * qdim, 0, qdim,
+                                  st.cross_kv[l] + b * st.s_max * 2 * kvdim, 0, 2 * kvdim,
+                                  capture->d_heads[l], 1, n_here, time, st.s_max, c.dhead,
+                                  c.queries_scale,
+                                  capture->scores + (b * capture->n_sel + offset) * time * st.s_max,
+                                  cur_stream());
+        end_kernel();
+      }
       for (int64_t j = 0; j < st.beam; ++j) {  // hypothesis row j of every sentence: the same memory
         AttnFullParams f;
         f.q = st.qkv + j * time * qdim;
@@ -2119,6 +2245,13 @@ void Engine::launch_step(DecodeState& st) {
     dense(dec_.projection, proj_in, pq.q ? &pq : nullptr, rows, -1, nullptr, st.logits, &st);
   }
 
+  if (st.wh_no_speech_id >= 0 && (st.fuse_greedy || st.fuse_beam)) {
+    // GetNoSpeechProbs (apply_first, src/models/whisper.cc:202-231): the untouched logits of step 0
+    begin_kernel("no_speech_prob");
+    launch_no_speech_prob(st.logits, st.rows, dec_.projection.n, st.wh_no_speech_id, st.d_step,
+                          st.prefix_first_step, st.d_no_speech, cur_stream());
+    end_kernel();
+  }
   if (st.fuse_greedy) {
     if (st.lp_active) {
       // history of this decoding session: hist_ids rows [first_step, *d_step)
@@ -2128,6 +2261,22 @@ void Engine::launch_step(DecodeState& st) {
                             st.rows, 1, st.d_step, st.prefix_first_step, 0,
                             static_cast<int32_t>(st.t_max), st.lp_penalty, st.lp_ngram,
                             st.d_sup_ids, st.d_sup_off, st.lp_n_sup, cur_stream());
+      end_kernel();
+    }
+    if (st.wh_active) {
+      WhisperRulesParams wp = st.wh;
+      wp.logits = st.logits;
+      wp.rows = st.rows;
+      wp.vocab = dec_.projection.n;
+      wp.seq = st.hist_ids + static_cast<int64_t>(st.prefix_first_step) * st.rows;
+      wp.t_stride = st.rows;
+      wp.row_stride = 1;
+      wp.step_ptr = st.d_step;
+      wp.first_step = st.prefix_first_step;
+      wp.prefix_len = st.d_prefix_len;
+      wp.prefix_div = 1;
+      begin_kernel("whisper_rules");
+      launch_whisper_rules(wp, cur_stream());
       end_kernel();
     }
     if (st.g_topk == 1) {
@@ -2161,6 +2310,22 @@ void Engine::launch_step(DecodeState& st) {
                             st.lp_ngram, st.d_sup_ids, st.d_sup_off, st.lp_n_sup, cur_stream());
       end_kernel();
     }
+    if (st.wh_active) {
+      WhisperRulesParams wp = st.wh;
+      wp.logits = st.logits;
+      wp.rows = st.rows;
+      wp.vocab = V;
+      wp.seq = st.alive_seq[par];
+      wp.t_stride = 1;
+      wp.row_stride = st.t_max;
+      wp.step_ptr = st.d_step;
+      wp.first_step = st.prefix_first_step;
+      wp.prefix_len = st.d_bprefix_len;
+      wp.prefix_div = static_cast<int32_t>(st.beam);
+      begin_kernel("whisper_rules");
+      launch_whisper_rules(wp, cur_stream());
+      end_kernel();
+    }
     begin_kernel("beam_logprobs", double(st.rows) * V * 12, 0, st.rows, 0, V);
     launch_beam_logprobs(st.logits, st.beam_scores, st.rows, V, st.g_eos, st.g_min_length,
                          st.d_step, st.logprobs, cur_stream(),
@@ -2178,8 +2343,8 @@ void Engine::launch_step(DecodeState& st) {
                        st.g_eos, st.d_bprefix, st.d_bprefix_len, st.bprefix_stride, st.d_step,
                        st.prefix_first_step, st.hist_cand_word, st.hist_cand_score,
                        st.hist_cand_origin, st.d_ids, st.d_parents, st.beam_scores,
-                       st.lp_active ? st.alive_seq[par] : nullptr,
-                       st.lp_active ? st.alive_seq[par ^ 1] : nullptr,
+                       (st.lp_active || st.wh_active) ? st.alive_seq[par] : nullptr,
+                       (st.lp_active || st.wh_active) ? st.alive_seq[par ^ 1] : nullptr,
                        static_cast<int32_t>(st.t_max), cur_stream(),
                        st.ancestry ? st.anc[par] : nullptr, st.ancestry ? st.anc[par ^ 1] : nullptr,
                        (st.d_bprefix && st.bias_beta > 0.f) ? st.d_diverged : nullptr);
@@ -2536,6 +2701,137 @@ void Engine::set_step(DecodeState& st, int32_t step) {
 }
 
 void Engine::synchronize() { CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream())); }
+
+void Engine::read_encoder_output(DecodeState& st, float* out) {
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_CHECK(st.enc_out != nullptr, "read_encoder_output: the state holds no encoder output");
+  CT2X_HIP_CHECK(hipMemcpyAsync(out, st.enc_out, sizeof(float) * st.batch * st.s_max * enc_.d_model,
+                                hipMemcpyDeviceToHost, cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+}
+
+void Engine::set_whisper_processing(DecodeState& st, const WhisperProcessing& wp) {
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  const int64_t vocab = dec_.projection.n;
+  st.wh = WhisperRulesParams();
+  st.wh_active = !wp.begin_ids.empty() || wp.timestamp_rules;
+  st.wh_no_speech_id = wp.no_speech_id;
+  if (wp.no_speech_id >= 0) {
+    CT2X_CHECK(wp.no_speech_id < vocab, "no-speech token id out of the vocabulary");
+    if (!st.d_no_speech) st.d_no_speech = alloc<float>(st, st.rows);
+  }
+  if (!wp.begin_ids.empty()) {
+    for (int32_t id : wp.begin_ids)
+      CT2X_CHECK(id >= 0 && id < vocab, "suppressed token id out of the vocabulary");
+    int32_t* d = alloc<int32_t>(st, static_cast<int64_t>(wp.begin_ids.size()));
+    CT2X_HIP_CHECK(hipMemcpyAsync(d, wp.begin_ids.data(), sizeof(int32_t) * wp.begin_ids.size(),
+                                  hipMemcpyHostToDevice, cur_stream()));
+    st.wh.begin_ids = d;
+    st.wh.n_begin = static_cast<int32_t>(wp.begin_ids.size());
+  }
+  st.wh.timestamp_rules = wp.timestamp_rules;
+  if (wp.timestamp_rules) {
+    CT2X_CHECK(wp.eot_id >= 0 && wp.eot_id < vocab && wp.no_timestamps_id >= 0 &&
+                   wp.no_timestamps_id < vocab && wp.timestamp_begin >= 0 &&
+                   wp.timestamp_begin <= wp.timestamp_end && wp.timestamp_end < vocab,
+               "timestamp rules: token ids out of the vocabulary");
+    st.wh.eot_id = wp.eot_id;
+    st.wh.no_timestamps_id = wp.no_timestamps_id;
+    st.wh.timestamp_begin = wp.timestamp_begin;
+    st.wh.timestamp_end = wp.timestamp_end;
+    st.wh.max_initial_timestamp = wp.max_initial_timestamp;
+  }
+  // beam search: the rules read the tokens of the active beams (kept by beam_select_kernel)
+  if (st.wh_active && st.beam_mode && st.alive_seq[0] == nullptr) {
+    for (int i = 0; i < 2; ++i) st.alive_seq[i] = alloc<int32_t>(st, st.rows * st.t_max);
+  }
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // the host vector may go out of scope
+}
+
+void Engine::whisper_align_forward(DecodeState& st, const int32_t* h_ids, const int32_t* h_targets,
+                                   int64_t time, const std::vector<int32_t>& lengths,
+                                   const std::vector<int32_t>& frames,
+                                   const std::vector<std::pair<int32_t, int32_t>>& alignment_heads,
+                                   int64_t text_classes, int64_t median_filter_width,
+                                   float* h_token_probs, float* h_weights) {
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  const int64_t B = st.batch, S = st.s_max, V = dec_.projection.n;
+  CT2X_CHECK(st.beam == 1 && static_cast<int64_t>(lengths.size()) == B &&
+                 static_cast<int64_t>(frames.size()) == B, "whisper_align_forward: batch mismatch");
+  const int64_t n_layers = static_cast<int64_t>(dec_.layers.size());
+  ScoreCapture cap;
+  cap.heads.resize(n_layers);
+  cap.d_heads.resize(n_layers, nullptr);
+  for (const auto& lh : alignment_heads) {
+    CT2X_CHECK(lh.first >= 0 && lh.first < n_layers && lh.second >= 0 && lh.second < dec_.num_heads,
+               "alignment_heads: (layer, head) out of range");
+    cap.heads[lh.first].push_back(lh.second);
+  }
+  cap.n_sel = static_cast<int64_t>(alignment_heads.size());
+  CT2X_CHECK(cap.n_sel > 0, "alignment_heads is empty");
+  for (int64_t l = 0; l < n_layers; ++l)
+    if (!cap.heads[l].empty()) {
+      int32_t* d = alloc<int32_t>(st, static_cast<int64_t>(cap.heads[l].size()));
+      CT2X_HIP_CHECK(hipMemcpyAsync(d, cap.heads[l].data(), sizeof(int32_t) * cap.heads[l].size(),
+                                    hipMemcpyHostToDevice, cur_stream()));
+      cap.d_heads[l] = d;
+    }
+  cap.scores = alloc<float>(st, B * cap.n_sel * time * S);
+  float* logits_all = alloc<float>(st, B * time * V);
+  int32_t* d_targets = alloc<int32_t>(st, B * time);
+  float* d_probs = alloc<float>(st, B * time);
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_targets, h_targets, sizeof(int32_t) * B * time,
+                                hipMemcpyHostToDevice, cur_stream()));
+  prefill(st, h_ids, time, logits_all, &cap);
+  // "Get the probabilities of the text tokens" (whisper.cc:497-506)
+  launch_token_probs(logits_all, B * time, V, text_classes, d_targets, d_probs, cur_stream());
+  CT2X_HIP_CHECK(hipMemcpyAsync(h_token_probs, d_probs, sizeof(float) * B * time,
+                                hipMemcpyDeviceToHost, cur_stream()));
+  // compute_alignments (whisper.cc:388-423) per batch entry. With the same number of frames for
+  // every entry the reference normalises over the batch's padded token axis (rows past an entry's
+  // length repeat its last row); with different numbers it cuts every entry to its own length.
+  bool variable_frames = false;
+  for (int64_t b = 0; b < B; ++b) variable_frames = variable_frames || frames[b] != frames[0];
+  float* probs = alloc<float>(st, cap.n_sel * time * S);
+  float* normed = alloc<float>(st, cap.n_sel * time * S);
+  float* mean = alloc<float>(st, time * S);
+  for (int64_t b = 0; b < B; ++b) {
+    const int64_t F = frames[b], len = lengths[b];
+    if (F <= 0 || len <= 0) continue;
+    CT2X_CHECK(F <= S && len <= time, "whisper_align_forward: frames / length out of range");
+    const int64_t rows_out = variable_frames ? len : time;
+    launch_align_softmax(cap.scores + b * cap.n_sel * time * S, cap.n_sel, time, S, len, rows_out, F,
+                         probs, cur_stream());
+    launch_layer_norm_axis(probs, cap.n_sel, rows_out, F, F, normed, cur_stream());
+    // MedianFilter passes the input through when the axis is not longer than width / 2
+    // (src/ops/median_filter_cpu.cc:24-28)
+    const float* filtered = normed;
+    if (F > median_filter_width / 2) {
+      launch_median_filter(normed, cap.n_sel * rows_out, F, median_filter_width, probs, cur_stream());
+      filtered = probs;
+    }
+    launch_mean(filtered, 1, cap.n_sel, rows_out * F, false, mean, cur_stream());
+    CT2X_HIP_CHECK(hipMemcpyAsync(h_weights + b * time * S, mean, sizeof(float) * rows_out * F,
+                                  hipMemcpyDeviceToHost, cur_stream()));
+    CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+  }
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+  check_last_launch("whisper_align_forward");
+}
+
+void Engine::read_no_speech_probs(DecodeState& st, float* out) {
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_CHECK(st.d_no_speech != nullptr, "read_no_speech_probs: GetNoSpeechProbs was not installed");
+  CT2X_HIP_CHECK(hipMemcpyAsync(out, st.d_no_speech, sizeof(float) * st.rows, hipMemcpyDeviceToHost,
+                                cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+}
 
 void Engine::score_targets(DecodeState& st, const int32_t* h_inputs, const int32_t* h_outputs,
                            int64_t steps) {

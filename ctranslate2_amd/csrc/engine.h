@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "kernels.h"
@@ -124,6 +125,11 @@ struct StackW {  // encoder or decoder
   int64_t num_heads = 8;
   DenseW projection;  // decoder only
   int64_t d_model = 0;
+  // Whisper encoder front end (layers::WhisperEncoder, src/layers/whisper.cc:9-24): two kernel-3
+  // convolutions stored as Dense weights [out, in * 3] over im2col rows
+  bool has_conv = false;
+  DenseW conv1, conv2;
+  int64_t n_mels = 0;
 };
 
 // Per-call device state of one decoding session over `rows` = batch * beam hypotheses.
@@ -137,6 +143,15 @@ struct LogitsProcessing {
   bool active() const {
     return repetition_penalty != 1.f || no_repeat_ngram_size > 0 || !suppress_sequences.empty();
   }
+};
+
+// Whisper's logits processors (src/models/whisper.cc:202-231, 741-861; decoding_utils.cc:172-194)
+struct WhisperProcessing {
+  std::vector<int32_t> begin_ids;  // SuppressTokensBegin (suppress_blank)
+  bool timestamp_rules = false;    // ApplyTimestampRules
+  int32_t eot_id = 0, no_timestamps_id = 0, timestamp_begin = 0, timestamp_end = 0,
+          max_initial_timestamp = 0;
+  int32_t no_speech_id = -1;       // >= 0: GetNoSpeechProbs at the first decoding step
 };
 
 class Engine {
@@ -153,6 +168,10 @@ public:
     return compute_type_ == ComputeType::kFloat16 || compute_type_ == ComputeType::kBFloat16;
   }
   bool is_seq2seq() const { return has_encoder_; }
+  bool is_whisper() const { return enc_.has_conv; }
+  int64_t n_mels() const { return enc_.n_mels; }
+  int64_t max_source_positions() const { return enc_.num_positions; }
+  int64_t max_target_positions() const { return dec_.num_positions; }
   int64_t vocab_size() const { return dec_.projection.n; }
   int64_t d_model() const { return dec_.d_model; }
   int64_t num_decoder_layers() const { return static_cast<int64_t>(dec_.layers.size()); }
@@ -169,13 +188,32 @@ public:
   // prepares a decoding state for batch*beam rows and up to t_max decoded positions.
   std::unique_ptr<DecodeState> start(const int32_t* src_ids, const int32_t* src_lengths,
                                      int64_t batch, int64_t s_max, int64_t beam, int64_t t_max,
-                                     int64_t prefill_len = 0, bool beam_search_state = false);
+                                     int64_t prefill_len = 0, bool beam_search_state = false,
+                                     const float* features = nullptr, int64_t frames = 0);
+  // Whisper: `features` [batch, n_mels, frames] (host) go through the convolutional front end and
+  // the encoder (WhisperEncoder::operator(), src/layers/whisper.cc:26-62); the memory has
+  // whisper_memory_length(frames) positions.
+  std::unique_ptr<DecodeState> start_features(const float* features, int64_t batch, int64_t frames,
+                                              int64_t beam, int64_t t_max, int64_t prefill_len = 0,
+                                              bool beam_search_state = false);
+  static int64_t whisper_memory_length(int64_t frames) { return frames <= 0 ? 0 : (frames - 1) / 2 + 1; }
+  // Copies the encoder output of a state made by start() / start_features() to the host:
+  // [batch, s_max, d_model]. Valid until the first prefill / step of that state.
+  void read_encoder_output(DecodeState& state, float* out);
   // Decoder-only models: no encoder; the prompt is consumed by prefill().
   std::unique_ptr<DecodeState> start_decoder_only(int64_t batch, int64_t beam, int64_t t_max,
                                                   int64_t prefill_len = 0);
   // Consumes `time` prompt tokens per row (h_ids [rows, time]) in one sequence-mode pass.
   // logits_all (optional): device [rows * time, vocabulary] - the logits of every position
-  void prefill(DecodeState& state, const int32_t* h_ids, int64_t time, float* logits_all = nullptr);
+  // capture (optional): raw encoder-decoder attention scores of selected heads (Whisper::align)
+  struct ScoreCapture {
+    std::vector<std::vector<int32_t>> heads;  // per decoder layer: the heads to record
+    std::vector<const int32_t*> d_heads;      // the same lists on the device
+    int64_t n_sel = 0;                        // total number of (layer, head) pairs
+    float* scores = nullptr;                  // device [batch, n_sel, time, s_max], layer order
+  };
+  void prefill(DecodeState& state, const int32_t* h_ids, int64_t time, float* logits_all = nullptr,
+               const ScoreCapture* capture = nullptr);
 
   // One decoder step over state.rows rows: reads token ids from state.d_ids and the step index
   // from state.d_step (device memory), leaves logits in state.logits [rows, vocab].
@@ -242,6 +280,25 @@ public:
   // from the device-resident id history, beam steps from the device-resident tokens of the
   // active beams (both inside the step's graph).
   void set_logits_processing(DecodeState& state, const LogitsProcessing& processing);
+
+  // Whisper's processors for every following step of `state` (after set_logits_processing).
+  void set_whisper_processing(DecodeState& state, const WhisperProcessing& processing);
+  // GetNoSpeechProbs result of the first decoding step: out [rows]
+  void read_no_speech_probs(DecodeState& state, float* out);
+  // Whisper::align's device part (src/models/whisper.cc:425-553): the decoder in sequence mode over
+  // h_ids [batch, time] (state made by start_features with beam 1, prefill_len >= time). Leaves
+  //  * token_probs [batch, time]: softmax over the first `text_classes` logits at every position,
+  //    probability of h_targets [batch, time];
+  //  * weights [batch, time, s_max]: the raw encoder-decoder attention scores of the (layer, head)
+  //    pairs, softmax over the first frames[b] memory positions, normalised over the time axis
+  //    (per batch entry: its own length lengths[b] and frames[b]), median-filtered over the memory
+  //    axis and averaged over the pairs. Entries outside [lengths[b], frames[b]] are unspecified.
+  void whisper_align_forward(DecodeState& state, const int32_t* h_ids, const int32_t* h_targets,
+                             int64_t time, const std::vector<int32_t>& lengths,
+                             const std::vector<int32_t>& frames,
+                             const std::vector<std::pair<int32_t, int32_t>>& alignment_heads,
+                             int64_t text_classes, int64_t median_filter_width, float* h_token_probs,
+                             float* h_weights);
 
   // Number of kernel launches recorded for one decoder step (reported by bench.py).
   int64_t kernels_per_step() const { return kernels_per_step_; }
@@ -327,6 +384,9 @@ private:
   void quant(const float* x, int64_t rows, int64_t depth, int8_t* q, float* s);
 
   void encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_lengths);
+  void encode_features(DecodeState& st, const float* features, int64_t frames);
+  // encoder layers + output norm + the cross-attention K/V projections, on x (scratch y)
+  void encode_layers(DecodeState& st, float* x, float* y);
   // amax_buf: zeroed [rows] scratch for the producer-side absmax of the gated pair (decode steps)
   void run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, float*& x, float*& y,
                DecodeState& st, float* amax_buf = nullptr, bool qin_ready = false);
@@ -481,6 +541,12 @@ struct DecodeState {
   int32_t* d_sup_off = nullptr;
   int32_t* alive_seq[2] = {nullptr, nullptr};  // beam search: tokens of the active beams,
                                                // [rows, t_max], ping-pong with the cache parity
+  // Whisper's processors (set_whisper_processing)
+  bool wh_active = false;          // SuppressTokensBegin and / or ApplyTimestampRules
+  WhisperRulesParams wh;           // static part: ids, flags
+  int32_t wh_no_speech_id = -1;    // >= 0: GetNoSpeechProbs at the first decoding step
+  float* d_no_speech = nullptr;    // [rows]
+  float* enc_out = nullptr;        // encoder output (read_encoder_output)
   // RandomSampler settings of the fused sampler (topk == 1: BestSampler / arg-max)
   int32_t g_topk = 1;
   float g_topp = 1.f, g_temperature = 1.f;

@@ -493,4 +493,59 @@ void launch_prepare_length_mask(const int32_t* lengths, int64_t batch, int64_t h
                                 int64_t queries, bool mask_future, bool multi_query,
                                 int32_t* mask, hipStream_t stream);
 
+// ---- Whisper glue (whisper_ops.hip; src/models/whisper.cc, src/layers/whisper.cc) -------------
+// im2col of a kernel-3 convolution: out [batch * out_len, channels * 3] (column = c * 3 + k), from
+// x [batch, channels, length] or, time_major, [batch, length, channels].
+void launch_im2col_k3(const float* x, int64_t batch, int64_t channels, int64_t length,
+                      int64_t out_len, int stride, int padding, bool time_major, float* out,
+                      hipStream_t stream);
+// x [batch, time, depth] += table [time, depth]
+void launch_add_positions(float* x, const float* table, int64_t batch, int64_t time, int64_t depth,
+                          hipStream_t stream);
+// GetNoSpeechProbs (whisper.cc:202-231): softmax(logits)[no_speech_id] per row, only at the
+// first step of the decoding loop (*step_ptr == first_step).
+void launch_no_speech_prob(const float* logits, int64_t rows, int64_t vocab, int32_t no_speech_id,
+                           const int32_t* step_ptr, int32_t first_step, float* out,
+                           hipStream_t stream);
+// SuppressTokensBegin (decoding_utils.cc:172-194) + ApplyTimestampRules (whisper.cc:741-861) in
+// place on the step's logits. History addressing as in launch_process_logits; prefix_len (optional)
+// holds the hard-prefix length of entry row / prefix_div (the rule's sample_begin).
+struct WhisperRulesParams {
+  float* logits = nullptr;
+  int64_t rows = 0, vocab = 0;
+  const int32_t* seq = nullptr;
+  int64_t t_stride = 0, row_stride = 0;
+  const int32_t* step_ptr = nullptr;
+  int32_t first_step = 0;
+  const int32_t* prefix_len = nullptr;
+  int32_t prefix_div = 1;
+  const int32_t* begin_ids = nullptr;  // SuppressTokensBegin ids
+  int32_t n_begin = 0;
+  bool timestamp_rules = false;
+  int32_t eot_id = 0, no_timestamps_id = 0, timestamp_begin = 0, timestamp_end = 0,
+          max_initial_timestamp = 0;
+};
+void launch_whisper_rules(const WhisperRulesParams& p, hipStream_t stream);
+// out [batch, n_sel, tq, tk] = scale * q[b, t, heads[i]] . k[b, s, heads[i]] (no softmax)
+void launch_attention_scores(const float* q, int64_t q_batch_stride, int64_t q_time_stride,
+                             const float* k, int64_t k_batch_stride, int64_t k_time_stride,
+                             const int32_t* heads, int64_t batch, int64_t n_sel, int64_t tq,
+                             int64_t tk, int64_t dhead, float scale, float* out,
+                             hipStream_t stream);
+// ops::LayerNorm(axis -2, epsilon 0), no gamma / beta, on [outer, axis, inner]; only the first
+// inner_used columns are normalised.
+void launch_layer_norm_axis(const float* x, int64_t outer, int64_t axis, int64_t inner,
+                            int64_t inner_used, float* y, hipStream_t stream);
+// softmax over the first `classes` logits of every row, probability of targets[row]
+void launch_token_probs(const float* logits, int64_t rows, int64_t vocab, int64_t classes,
+                        const int32_t* targets, float* out, hipStream_t stream);
+// out [rows, n] = softmax_j(logits[row, ids[j]])
+void launch_gather_softmax(const float* logits, int64_t rows, int64_t vocab, const int32_t* ids,
+                           int64_t n, float* out, hipStream_t stream);
+
+// scores [n_sel, tq, tk] of one batch entry -> out [n_sel, rows_out, frames]: softmax over the
+// first `frames` keys of row min(t, length - 1)
+void launch_align_softmax(const float* scores, int64_t n_sel, int64_t tq, int64_t tk, int64_t length,
+                          int64_t rows_out, int64_t frames, float* out, hipStream_t stream);
+
 }  // namespace ct2x

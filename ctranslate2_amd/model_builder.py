@@ -356,3 +356,129 @@ def build_decoder_lm(output_dir, num_layers=32, d_model=4096, ffn_dim=14336, num
     with open(os.path.join(output_dir, "vocabulary.json"), "w", encoding="utf-8") as f:
         json.dump(_vocab_tokens(vocab_size), f, indent=2)
     return output_dir
+
+
+def whisper_vocab_tokens(num_text_tokens, languages, num_timestamps):
+    """The Whisper vocabulary layout WhisperReplica relies on (src/models/whisper.cc:62-77):
+    text tokens..., <|endoftext|>, <|startoftranscript|>, language tokens..., <|translate|>,
+    <|transcribe|>, <|startoflm|>, <|startofprev|>, <|nospeech|>, <|notimestamps|>, time tokens.
+    Token 0 is the empty string: this copy of the reference calls a model multilingual when
+    Vocabulary::to_id("") is not the unknown token (whisper.cc:72)."""
+    tokens = [""] + ["tx%d" % i for i in range(1, num_text_tokens)]
+    tokens += ["<|endoftext|>", "<|startoftranscript|>"]
+    tokens += ["<|%s|>" % lang for lang in languages]
+    tokens += ["<|translate|>", "<|transcribe|>", "<|startoflm|>", "<|startofprev|>",
+               "<|nospeech|>", "<|notimestamps|>"]
+    tokens += ["<|%.2f|>" % (0.02 * i) for i in range(num_timestamps)]
+    return tokens
+
+
+def build_whisper(output_dir, num_encoder_layers=2, num_decoder_layers=2, d_model=64, ffn_dim=256,
+                  num_heads=4, n_mels=8, max_source_positions=12, max_target_positions=32,
+                  num_text_tokens=40, languages=("en", "fr", "de", "es"), num_timestamps=21,
+                  seed=0, quantization="float32", w_std=0.08, alignment_heads=((1, 0), (1, 2), (0, 3)),
+                  direct_f16=False):
+    """WhisperSpec (python/ctranslate2/specs/whisper_spec.py): encoder = two Conv1D (kernel 3,
+    padding 1, stride 1 / 2, GELU) + learned positions + pre-norm GELU encoder layers + layer_norm;
+    decoder = TransformerDecoderSpec(activation=GELU) with learned positions, scale_embeddings
+    False and the output projection aliased to the embeddings
+    (python/ctranslate2/converters/transformers.py WhisperLoader). Whisper-large-v3 shape:
+    32 + 32 layers, d_model 1280, 20 heads, ffn 5120, n_mels 128, 1500 / 448 positions,
+    51866 tokens."""
+    os.makedirs(output_dir, exist_ok=True)
+    b = _Builder(seed, quantization, w_std=w_std, direct_f16=direct_f16)
+    d = d_model
+
+    def conv(scope, out_c, in_c):
+        w = b.rng.normal(0, w_std, (out_c, in_c, 3)).astype(np.float32)
+        if quantization == "int8":
+            # model_spec.py:229-243: scale per output channel over the [in, kernel] plane
+            q, s = quantize_int8(w.reshape(out_c, -1))
+            b.vars[scope + "/weight"] = q.reshape(w.shape)
+            b.vars[scope + "/weight_scale"] = s
+        elif quantization == "float16":
+            b.vars[scope + "/weight"] = w.astype(np.float16)
+        elif quantization == "bfloat16":
+            b.vars[scope + "/weight"] = to_bf16(w)
+        else:
+            b.vars[scope + "/weight"] = w
+        b.vars[scope + "/bias"] = b.rng.normal(0, b.b_std, (out_c,)).astype(np.float32)
+
+    def mha(scope, self_attention):
+        b.layer_norm(scope + "/layer_norm", d)
+        if self_attention:
+            b.linear(scope + "/linear_0", 3 * d, d)
+            b.linear(scope + "/linear_1", d, d)
+        else:
+            b.linear(scope + "/linear_0", d, d)
+            b.linear(scope + "/linear_1", 2 * d, d)
+            b.linear(scope + "/linear_2", d, d)
+
+    def ffn(scope):
+        b.layer_norm(scope + "/layer_norm", d)
+        b.linear(scope + "/linear_0", ffn_dim, d)
+        b.linear(scope + "/linear_1", d, ffn_dim)
+
+    def positions(scope, n):
+        t = b.rng.normal(0, w_std, (n, d)).astype(np.float32)
+        if quantization == "float16":
+            t = t.astype(np.float16)
+        elif quantization == "bfloat16":
+            t = to_bf16(t)
+        b.vars[scope + "/encodings"] = t
+
+    conv("encoder/conv1", d, n_mels)
+    conv("encoder/conv2", d, d)
+    positions("encoder/position_encodings", max_source_positions)
+    for l in range(num_encoder_layers):
+        mha("encoder/layer_%d/self_attention" % l, True)
+        ffn("encoder/layer_%d/ffn" % l)
+    b.layer_norm("encoder/layer_norm", d)
+    b.attr("encoder/num_heads", num_heads, np.int16)
+
+    tokens = whisper_vocab_tokens(num_text_tokens, languages, num_timestamps)
+    vocab_size = len(tokens)
+    if direct_f16:
+        b.random_weight("decoder/embeddings/weight", vocab_size, d)
+    else:
+        b.weight("decoder/embeddings/weight", b.rng.normal(0, w_std, (vocab_size, d)).astype(np.float32))
+    aliases = [("decoder/projection/weight", "decoder/embeddings/weight")]
+    if "decoder/embeddings/weight_scale" in b.vars:
+        aliases.append(("decoder/projection/weight_scale", "decoder/embeddings/weight_scale"))
+    positions("decoder/position_encodings", max_target_positions)
+    for l in range(num_decoder_layers):
+        mha("decoder/layer_%d/self_attention" % l, True)
+        mha("decoder/layer_%d/attention" % l, False)
+        ffn("decoder/layer_%d/ffn" % l)
+    b.layer_norm("decoder/layer_norm", d)
+    b.attr("decoder/num_heads", num_heads, np.int16)
+    b.attr("decoder/pre_norm", 1, np.int8)
+    b.attr("decoder/activation", GELU, np.int8)
+    b.attr("decoder/scale_embeddings", 0, np.int8)
+    b.attr("decoder/alibi", 0, np.int8)
+    b.attr("decoder/alibi_use_positive_positions", 0, np.int8)
+    b.attr("decoder/scale_alibi", 0, np.int8)
+    b.attr("decoder/alignment_heads", 1, np.int16)
+    b.attr("decoder/alignment_layer", -1, np.int16)
+    b.attr("decoder/start_from_zero_embedding", 0, np.int8)
+    write_model_bin(os.path.join(output_dir, "model.bin"), "WhisperSpec", 3, b.vars, aliases)
+
+    eot = num_text_tokens
+    sot = eot + 1
+    first_lang = sot + 1
+    no_timestamps = first_lang + len(languages) + 5
+    config = {
+        # a few text tokens, the special tokens below <|notimestamps|> except the languages' tasks
+        "suppress_ids": [1, 2, 7, sot, first_lang + len(languages), first_lang + len(languages) + 1,
+                         first_lang + len(languages) + 2, first_lang + len(languages) + 3,
+                         first_lang + len(languages) + 4],
+        "suppress_ids_begin": [3, eot],
+        "lang_ids": list(range(first_lang, first_lang + len(languages))),
+        "alignment_heads": [list(p) for p in alignment_heads],
+    }
+    assert no_timestamps + 1 + num_timestamps == vocab_size
+    with open(os.path.join(output_dir, "config.json"), "w") as f:
+        json.dump(config, f, indent=2, sort_keys=True)
+    with open(os.path.join(output_dir, "vocabulary.json"), "w", encoding="utf-8") as f:
+        json.dump(tokens, f, indent=2)
+    return output_dir

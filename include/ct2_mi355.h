@@ -711,6 +711,71 @@ float ct2x_host_finalize_score(float score, float length, float length_penalty);
  * path_i / path_j [n + m] receive the path in order; returns its length (<= n + m - 1), <0 on error. */
 int64_t ct2x_host_negative_dtw(const float* x, int64_t n, int64_t m, int64_t* path_i, int64_t* path_j);
 
+/* ---- Whisper (include/ctranslate2/models/whisper.h; python/cpp/whisper.cc binds these) ---------
+ * models::Whisper on the fused engine: the convolutional front end as im2col + MFMA GEMMs, the
+ * encoder / decoder of the Translator path, Whisper's logits processors (ApplyTimestampRules,
+ * SuppressTokensBegin, GetNoSpeechProbs) inside the decoding step's graph. Features are float32
+ * [batch, n_mels, frames] on the host. */
+
+/* models::WhisperOptions (whisper.h:11-58), field for field (return_logits_vocab excluded). */
+struct ct2x_whisper_options {
+  int32_t beam_size;                    /* 5 */
+  float patience;                       /* 1 */
+  float length_penalty;                 /* 1 */
+  float repetition_penalty;             /* 1 */
+  int32_t no_repeat_ngram_size;         /* 0 */
+  int32_t max_length;                   /* 448 */
+  int32_t sampling_topk;                /* 1 */
+  float sampling_temperature;           /* 1 */
+  int32_t num_hypotheses;               /* 1 */
+  int32_t return_scores;                /* 0 */
+  int32_t return_no_speech_prob;        /* 0 */
+  int32_t max_initial_timestamp_index;  /* 50 */
+  int32_t suppress_blank;               /* 1 */
+  int32_t num_suppress_tokens;          /* 1 */
+  const int32_t* suppress_tokens;       /* {-1}: the model's config.json suppress_ids */
+};
+void ct2x_whisper_options_default(struct ct2x_whisper_options* options);
+
+/* models::Whisper(model_path, Device::CUDA, compute_type) (replica_pool.h:33-45). NULL on error. */
+void* ct2x_whisper_create(const char* model_dir, int device_index, const char* compute_type);
+void ct2x_whisper_destroy(void* whisper);
+/* Whisper::is_multilingual / n_mels / num_languages (whisper.h:166-168). */
+int ct2x_whisper_info(void* whisper, int32_t* is_multilingual, int32_t* n_mels,
+                      int32_t* num_languages);
+/* Vocabulary of the model (WhisperModel::get_vocabulary): size, id -> token (NULL when out of
+ * range), token -> id (the unknown token's id when absent). */
+int ct2x_whisper_vocab_size(void* whisper);
+int64_t ct2x_whisper_d_model(void* whisper); /* depth of the encoder output */
+const char* ct2x_whisper_vocab_token(void* whisper, int32_t id);
+int32_t ct2x_whisper_vocab_id(void* whisper, const char* token);
+/* Whisper::encode (src/models/whisper.cc:80-106): out [batch, (frames - 1) / 2 + 1, d_model]
+ * float32 on the host (to_cpu = true); out_dims[3] receives the shape. */
+int ct2x_whisper_encode(void* whisper, const float* features, int32_t batch, int32_t n_mels,
+                        int32_t frames, float* out, int64_t out_capacity, int64_t* out_dims);
+/* Whisper::generate on id prompts (whisper.cc:232-371): prompts [batch, prompt_stride]. out_ids
+ * [batch, num_hypotheses, max_len], out_lengths (-1: fewer hypotheses) / out_scores [batch,
+ * num_hypotheses], out_no_speech [batch] (return_no_speech_prob). */
+int ct2x_whisper_generate(void* whisper, const float* features, int32_t batch, int32_t n_mels,
+                          int32_t frames, const int32_t* prompts, const int32_t* prompt_lengths,
+                          int32_t prompt_stride, const struct ct2x_whisper_options* options,
+                          int32_t max_len, int32_t* out_ids, int32_t* out_lengths,
+                          float* out_scores, float* out_no_speech);
+/* Whisper::detect_language (whisper.cc:562-630): the language token ids of every batch entry by
+ * decreasing probability; out_ids / out_probs [batch, num_languages]. */
+int ct2x_whisper_detect_language(void* whisper, const float* features, int32_t batch,
+                                 int32_t n_mels, int32_t frames, int32_t num_languages,
+                                 int32_t* out_ids, float* out_probs);
+/* Whisper::align (whisper.cc:425-560): text_tokens [batch, text_stride], num_frames [batch].
+ * out_pairs [batch, pair_capacity, 2] = (text token index, frame index) of the DTW path,
+ * out_num_pairs [batch], out_token_probs [batch, text_stride]. */
+int ct2x_whisper_align(void* whisper, const float* features, int32_t batch, int32_t n_mels,
+                       int32_t frames, const int32_t* start_sequence, int32_t num_start,
+                       const int32_t* text_tokens, const int32_t* text_lengths, int32_t text_stride,
+                       const int32_t* num_frames, int32_t median_filter_width,
+                       int32_t pair_capacity, int32_t* out_pairs, int32_t* out_num_pairs,
+                       float* out_token_probs);
+
 #ifdef __cplusplus
 }
 #endif

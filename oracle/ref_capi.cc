@@ -23,6 +23,7 @@
 #include <ctranslate2/models/model.h>
 #include <ctranslate2/models/sequence_to_sequence.h>
 #include <ctranslate2/models/language_model.h>
+#include <ctranslate2/models/whisper.h>
 #include <ctranslate2/ops/ops.h>
 #include <ctranslate2/translator.h>
 #include <ctranslate2/generator.h>
@@ -717,6 +718,187 @@ int ct2ref_rotary_tables(int64_t dim, int interleave, int scaling_type, float sc
           sin_out[p * dim + i] = first ? -v : v;
         }
       }
+  }
+  CT2REF_CATCH
+}
+
+// ---------------------------------------------------------------------------------------
+// Whisper (include/ctranslate2/models/whisper.h): the reference's own models::Whisper pool
+// (encode / generate / detect_language / align, src/models/whisper.cc:80-630) on float features
+// [batch, n_mels, frames]. With device "cuda" in the Level-1 build the same calls run on the
+// MI355X kernels.
+// ---------------------------------------------------------------------------------------
+struct RefWhisper {
+  std::unique_ptr<models::Whisper> pool;
+};
+
+// Field for field models::WhisperOptions (whisper.h:11-58); return_logits_vocab is not exposed.
+struct ct2ref_whisper_options {
+  int32_t beam_size;
+  float patience;
+  float length_penalty;
+  float repetition_penalty;
+  int32_t no_repeat_ngram_size;
+  int32_t max_length;
+  int32_t sampling_topk;
+  float sampling_temperature;
+  int32_t num_hypotheses;
+  int32_t return_scores;
+  int32_t return_no_speech_prob;
+  int32_t max_initial_timestamp_index;
+  int32_t suppress_blank;
+  int32_t num_suppress_tokens;
+  const int32_t* suppress_tokens;
+};
+
+void* ct2ref_whisper_load(const char* path, const char* device, const char* compute_type,
+                          int intra_threads) {
+  try {
+    models::ModelLoader loader(path);
+    loader.device = str_to_device(device);
+    loader.device_indices = {0};
+    loader.num_replicas_per_device = 1;
+    loader.compute_type = str_to_compute_type(compute_type);
+    ReplicaPoolConfig config;
+    config.num_threads_per_replica = intra_threads;
+    auto handle = std::make_unique<RefWhisper>();
+    handle->pool = std::make_unique<models::Whisper>(loader, config);
+    return handle.release();
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return nullptr;
+  }
+}
+
+void ct2ref_whisper_free(void* h) { delete static_cast<RefWhisper*>(h); }
+
+int ct2ref_whisper_info(void* h, int32_t* is_multilingual, int32_t* n_mels, int32_t* num_languages) {
+  CT2REF_TRY
+  auto* w = static_cast<RefWhisper*>(h);
+  *is_multilingual = w->pool->is_multilingual() ? 1 : 0;
+  *n_mels = static_cast<int32_t>(w->pool->n_mels());
+  *num_languages = static_cast<int32_t>(w->pool->num_languages());
+  CT2REF_CATCH
+}
+
+static StorageView whisper_features(const float* features, int batch, int n_mels, int frames) {
+  StorageView f({batch, n_mels, frames}, DataType::FLOAT32, Device::CPU);
+  std::memcpy(f.data<float>(), features, sizeof(float) * batch * n_mels * frames);
+  return f;
+}
+
+// Whisper::encode (whisper.cc:80-106): out [batch, frames / 2, d_model] as float32;
+// out_dims receives the three dimensions.
+int ct2ref_whisper_encode(void* h, const float* features, int batch, int n_mels, int frames,
+                          float* out, int64_t out_capacity, int64_t* out_dims) {
+  CT2REF_TRY
+  auto* w = static_cast<RefWhisper*>(h);
+  StorageView y = w->pool->encode(whisper_features(features, batch, n_mels, frames), true).get();
+  if (y.dtype() != DataType::FLOAT32) y = y.to_float32();
+  for (int i = 0; i < 3; ++i) out_dims[i] = y.dim(i);
+  if (y.size() > out_capacity) throw std::runtime_error("ct2ref_whisper_encode: output too small");
+  copy_out<float>(y, out);
+  CT2REF_CATCH
+}
+
+// Whisper::generate (whisper.cc:232-371) on id prompts [batch, prompt_stride].
+// out_ids [batch, num_hypotheses, max_len], out_lengths / out_scores [batch, num_hypotheses],
+// out_no_speech [batch].
+int ct2ref_whisper_generate(void* h, const float* features, int batch, int n_mels, int frames,
+                            const int32_t* prompts, const int32_t* prompt_lengths,
+                            int prompt_stride, const ct2ref_whisper_options* o, int max_len,
+                            int32_t* out_ids, int32_t* out_lengths, float* out_scores,
+                            float* out_no_speech) {
+  CT2REF_TRY
+  auto* w = static_cast<RefWhisper*>(h);
+  models::WhisperOptions opt;
+  opt.beam_size = o->beam_size;
+  opt.patience = o->patience;
+  opt.length_penalty = o->length_penalty;
+  opt.repetition_penalty = o->repetition_penalty;
+  opt.no_repeat_ngram_size = o->no_repeat_ngram_size;
+  opt.max_length = o->max_length;
+  opt.sampling_topk = o->sampling_topk;
+  opt.sampling_temperature = o->sampling_temperature;
+  opt.num_hypotheses = o->num_hypotheses;
+  opt.return_scores = o->return_scores != 0;
+  opt.return_no_speech_prob = o->return_no_speech_prob != 0;
+  opt.max_initial_timestamp_index = o->max_initial_timestamp_index;
+  opt.suppress_blank = o->suppress_blank != 0;
+  opt.suppress_tokens.assign(o->suppress_tokens, o->suppress_tokens + o->num_suppress_tokens);
+  std::vector<std::vector<size_t>> p(batch);
+  for (int b = 0; b < batch; ++b)
+    for (int i = 0; i < prompt_lengths[b]; ++i) p[b].push_back(prompts[b * prompt_stride + i]);
+  auto futures = w->pool->generate(whisper_features(features, batch, n_mels, frames), std::move(p), opt);
+  const int nh = o->num_hypotheses;
+  for (int b = 0; b < batch; ++b) {
+    const models::WhisperGenerationResult r = futures[b].get();
+    for (int k = 0; k < nh; ++k) {
+      out_lengths[b * nh + k] = -1;
+      if (k >= static_cast<int>(r.sequences_ids.size())) continue;
+      const auto& ids = r.sequences_ids[k];
+      out_lengths[b * nh + k] = static_cast<int32_t>(ids.size());
+      for (size_t i = 0; i < ids.size() && static_cast<int>(i) < max_len; ++i)
+        out_ids[(static_cast<int64_t>(b) * nh + k) * max_len + i] = static_cast<int32_t>(ids[i]);
+      if (out_scores && k < static_cast<int>(r.scores.size())) out_scores[b * nh + k] = r.scores[k];
+    }
+    if (out_no_speech) out_no_speech[b] = r.no_speech_prob;
+  }
+  CT2REF_CATCH
+}
+
+// Whisper::detect_language (whisper.cc:562-630): per batch entry the language token ids sorted by
+// decreasing probability. out_ids / out_probs [batch, num_languages].
+int ct2ref_whisper_detect_language(void* h, const float* features, int batch, int n_mels,
+                                   int frames, int num_languages, int32_t* out_ids,
+                                   float* out_probs) {
+  CT2REF_TRY
+  auto* w = static_cast<RefWhisper*>(h);
+  auto futures = w->pool->detect_language(whisper_features(features, batch, n_mels, frames));
+  const auto& vocab = dynamic_cast<const models::WhisperModel&>(*w->pool->get_first_replica().model())
+                          .get_vocabulary();
+  for (int b = 0; b < batch; ++b) {
+    const auto r = futures[b].get();
+    if (static_cast<int>(r.size()) != num_languages)
+      throw std::runtime_error("ct2ref_whisper_detect_language: num_languages mismatch");
+    for (int j = 0; j < num_languages; ++j) {
+      out_ids[b * num_languages + j] = static_cast<int32_t>(vocab.to_id(r[j].first));
+      out_probs[b * num_languages + j] = r[j].second;
+    }
+  }
+  CT2REF_CATCH
+}
+
+// Whisper::align (whisper.cc:425-560). text_tokens [batch, text_stride]; out_pairs
+// [batch, pair_capacity, 2] = (text index, time index), out_num_pairs [batch], out_token_probs
+// [batch, text_stride].
+int ct2ref_whisper_align(void* h, const float* features, int batch, int n_mels, int frames,
+                         const int32_t* start_sequence, int num_start, const int32_t* text_tokens,
+                         const int32_t* text_lengths, int text_stride, const int32_t* num_frames,
+                         int median_filter_width, int pair_capacity, int32_t* out_pairs,
+                         int32_t* out_num_pairs, float* out_token_probs) {
+  CT2REF_TRY
+  auto* w = static_cast<RefWhisper*>(h);
+  std::vector<size_t> start(start_sequence, start_sequence + num_start);
+  std::vector<std::vector<size_t>> text(batch);
+  std::vector<size_t> nf(batch);
+  for (int b = 0; b < batch; ++b) {
+    for (int i = 0; i < text_lengths[b]; ++i) text[b].push_back(text_tokens[b * text_stride + i]);
+    nf[b] = num_frames[b];
+  }
+  auto futures = w->pool->align(whisper_features(features, batch, n_mels, frames), start, text, nf,
+                                median_filter_width);
+  for (int b = 0; b < batch; ++b) {
+    const models::WhisperAlignmentResult r = futures[b].get();
+    out_num_pairs[b] = static_cast<int32_t>(r.alignments.size());
+    if (static_cast<int>(r.alignments.size()) > pair_capacity)
+      throw std::runtime_error("ct2ref_whisper_align: pair capacity too small");
+    for (size_t i = 0; i < r.alignments.size(); ++i) {
+      out_pairs[(static_cast<int64_t>(b) * pair_capacity + i) * 2] = static_cast<int32_t>(r.alignments[i].first);
+      out_pairs[(static_cast<int64_t>(b) * pair_capacity + i) * 2 + 1] = static_cast<int32_t>(r.alignments[i].second);
+    }
+    for (size_t i = 0; i < r.text_token_probs.size(); ++i)
+      out_token_probs[b * text_stride + i] = r.text_token_probs[i];
   }
   CT2REF_CATCH
 }

@@ -440,3 +440,120 @@ class RefModel:
                                         C.byref(v)))
         assert v.value == vocab_size, (v.value, vocab_size)
         return logits
+
+
+class WhisperOptions(C.Structure):
+    """models::WhisperOptions (include/ctranslate2/models/whisper.h:11-58); the product's
+    ct2x_whisper_options (include/ct2_mi355.h) has the same layout."""
+    _fields_ = [("beam_size", C.c_int32), ("patience", C.c_float), ("length_penalty", C.c_float),
+                ("repetition_penalty", C.c_float), ("no_repeat_ngram_size", C.c_int32),
+                ("max_length", C.c_int32), ("sampling_topk", C.c_int32),
+                ("sampling_temperature", C.c_float), ("num_hypotheses", C.c_int32),
+                ("return_scores", C.c_int32), ("return_no_speech_prob", C.c_int32),
+                ("max_initial_timestamp_index", C.c_int32), ("suppress_blank", C.c_int32),
+                ("num_suppress_tokens", C.c_int32), ("suppress_tokens", C.POINTER(C.c_int32))]
+
+
+def whisper_options(beam_size=5, patience=1.0, length_penalty=1.0, repetition_penalty=1.0,
+                    no_repeat_ngram_size=0, max_length=448, sampling_topk=1,
+                    sampling_temperature=1.0, num_hypotheses=1, return_scores=False,
+                    return_no_speech_prob=False, max_initial_timestamp_index=50,
+                    suppress_blank=True, suppress_tokens=(-1,)):
+    sup = np.array(list(suppress_tokens), np.int32)
+    o = WhisperOptions(beam_size, patience, length_penalty, repetition_penalty,
+                       no_repeat_ngram_size, max_length, sampling_topk, sampling_temperature,
+                       num_hypotheses, int(return_scores), int(return_no_speech_prob),
+                       max_initial_timestamp_index, int(suppress_blank), len(sup),
+                       sup.ctypes.data_as(C.POINTER(C.c_int32)))
+    o._keep = sup
+    return o
+
+
+class WhisperCalls:
+    """models::Whisper behind a C ABI: `prefix` + {encode, generate, detect_language, align}.
+    Shared by the reference shim (ct2ref_whisper_*) and the product (ct2x_whisper_*), whose entry
+    points take the same arguments."""
+
+    def __init__(self, L, prefix, handle, check):
+        self._L, self._prefix, self._h, self._check = L, prefix, handle, check
+
+    def _fn(self, name):
+        return getattr(self._L, self._prefix + name)
+
+    def info(self):
+        v = [C.c_int32() for _ in range(3)]
+        self._check(self._fn("info")(C.c_void_p(self._h), *[C.byref(x) for x in v]))
+        return dict(is_multilingual=bool(v[0].value), n_mels=v[1].value, num_languages=v[2].value)
+
+    def encode(self, features, d_model):
+        f = _f32(features)
+        b, m, t = f.shape
+        out = np.zeros((b, (t + 1) // 2 + 1, d_model), np.float32)
+        dims = np.zeros(3, np.int64)
+        self._check(self._fn("encode")(C.c_void_p(self._h), _p(f), C.c_int(b), C.c_int(m), C.c_int(t),
+                                       _p(out), C.c_int64(out.size), _p(dims)))
+        n = int(dims[0] * dims[1] * dims[2])
+        return out.reshape(-1)[:n].reshape(tuple(int(x) for x in dims)).copy()
+
+    def generate(self, features, prompts, max_len=64, **kw):
+        f = _f32(features)
+        b, m, t = f.shape
+        o = whisper_options(**kw)
+        ids, lengths, stride = RefModel._pack(prompts)
+        nh = o.num_hypotheses
+        out = np.zeros((b, nh, max_len), np.int32)
+        out_len = np.zeros((b, nh), np.int32)
+        scores = np.zeros((b, nh), np.float32)
+        nsp = np.zeros(b, np.float32)
+        self._check(self._fn("generate")(C.c_void_p(self._h), _p(f), C.c_int(b), C.c_int(m), C.c_int(t),
+                                         _p(ids), _p(lengths), C.c_int(stride), C.byref(o),
+                                         C.c_int(max_len), _p(out), _p(out_len), _p(scores), _p(nsp)))
+        hyps = [[out[i, k, :out_len[i, k]].tolist() for k in range(nh) if out_len[i, k] >= 0]
+                for i in range(b)]
+        return hyps, scores, nsp
+
+    def detect_language(self, features, num_languages):
+        f = _f32(features)
+        b, m, t = f.shape
+        ids = np.zeros((b, num_languages), np.int32)
+        probs = np.zeros((b, num_languages), np.float32)
+        self._check(self._fn("detect_language")(C.c_void_p(self._h), _p(f), C.c_int(b), C.c_int(m),
+                                                C.c_int(t), C.c_int(num_languages), _p(ids), _p(probs)))
+        return ids, probs
+
+    def align(self, features, start_sequence, text_tokens, num_frames, median_filter_width=7):
+        f = _f32(features)
+        b, m, t = f.shape
+        start = np.array(start_sequence, np.int32)
+        ids, lengths, stride = RefModel._pack(text_tokens)
+        nf = np.array(num_frames, np.int32)
+        cap = int(stride + 2 + t)
+        pairs = np.zeros((b, cap, 2), np.int32)
+        n_pairs = np.zeros(b, np.int32)
+        probs = np.zeros((b, stride), np.float32)
+        self._check(self._fn("align")(C.c_void_p(self._h), _p(f), C.c_int(b), C.c_int(m), C.c_int(t),
+                                      _p(start), C.c_int(len(start)), _p(ids), _p(lengths),
+                                      C.c_int(stride), _p(nf), C.c_int(median_filter_width),
+                                      C.c_int(cap), _p(pairs), _p(n_pairs), _p(probs)))
+        return ([pairs[i, :n_pairs[i]].tolist() for i in range(b)],
+                [probs[i, :lengths[i]].copy() for i in range(b)])
+
+
+class RefWhisper(WhisperCalls):
+    """The reference's models::Whisper (CPU, or Device::CUDA = this backend in the Level-1 build)."""
+
+    def __init__(self, path, compute_type="float32", intra_threads=0, device="cpu"):
+        L = lib()
+        L.ct2ref_whisper_load.restype = C.c_void_p
+        L.ct2ref_whisper_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.ct2ref_whisper_free.argtypes = [C.c_void_p]
+        h = L.ct2ref_whisper_load(path.encode(), device.encode(), compute_type.encode(),
+                                  C.c_int(intra_threads))
+        if not h:
+            raise RuntimeError(L.ct2ref_last_error().decode())
+        super().__init__(L, "ct2ref_whisper_", h, _check)
+
+    def close(self):
+        if self._h:
+            self._L.ct2ref_whisper_free(C.c_void_p(self._h))
+            self._h = None

@@ -247,14 +247,20 @@ namespace ctranslate2 {
 
   template<> template<>
   float primitives<Device::CUDA>::logsumexp(const float* x, dim_t size) {
+    // logsumexp = x[i] - log_softmax(x)[i] at the arg-max i: any other element may be a disabled
+    // token (numeric_limits<float>::lowest()), where the difference cancels to 0
     void* tmp = nullptr;
-    check(ct2x_malloc(&tmp, size * sizeof (float)));
+    check(ct2x_malloc(&tmp, size * sizeof (float) + 8));
+    char* top = static_cast<char*>(tmp) + size * sizeof (float);
+    check(ct2x_topk(x, CT2X_F32, 1, size, 1, top, reinterpret_cast<int32_t*>(top + 4), stream()));
     check(ct2x_softmax(x, nullptr, 1, size, /*log=*/1, tmp, CT2X_F32, stream()));
-    float x0 = 0.f, y0 = 0.f;
-    check(ct2x_copy_to_host(x, &x0, sizeof (float), stream()));
-    check(ct2x_copy_to_host(tmp, &y0, sizeof (float), stream()));
+    float best = 0.f, y = 0.f;
+    int32_t index = 0;
+    check(ct2x_copy_to_host(top, &best, sizeof (float), stream()));
+    check(ct2x_copy_to_host(top + 4, &index, sizeof (int32_t), stream()));
+    check(ct2x_copy_to_host(static_cast<float*>(tmp) + index, &y, sizeof (float), stream()));
     check(ct2x_free(tmp));
-    return x0 - y0;
+    return best - y;
   }
 
   // ---- cuda:: helper set (src/cuda/utils.h:98-134; bodies in src/cuda/utils.cc) ---------------

@@ -1,0 +1,185 @@
+"""-m gpu: Whisper (BASELINE configs[4] family) on the MI355X, two ways, against the
+reference's own models::Whisper on Device::CPU (tests/golden/whisper_golden.*, made by
+tests/golden/make_golden_whisper.py through oracle/_ref):
+
+  Level 2  ct2x_whisper_* (ctranslate2_amd/csrc/c_api_whisper.cc): the fused engine - im2col +
+           MFMA GEMM convolutions, the Translator path's encoder / decoder kernels, Whisper's
+           logits processors inside the decoding step's graph, the alignment post-processing;
+  Level 1  the reference's OWN src/models/whisper.cc + src/layers/whisper.cc compiled against the
+           stub units, op by op on this backend (tests/integration/run_level1_whisper.py).
+
+Every case of tests/whisper_cases.py: encode, 13 generate settings (greedy / beam, timestamp
+rules, previous-text prompts, text after the task tokens, suppress / penalty options),
+detect_language, align (uniform and per-entry frame counts)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import whisper_cases as WC
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "whisper_golden.json")) as f:
+        j = json.load(f)
+    z = np.load(os.path.join(HERE, "golden", "whisper_golden.npz"))
+    return j, z
+
+
+def product_whisper(path, compute_type):
+    """The product library behind the same call surface the golden generator drove."""
+    import _refshim as R
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+    L.ct2x_whisper_create.restype = C.c_void_p
+    L.ct2x_whisper_create.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+    L.ct2x_whisper_destroy.argtypes = [C.c_void_p]
+    h = L.ct2x_whisper_create(path.encode(), C.c_int(0), compute_type.encode())
+    assert h, L.ct2x_last_error().decode()
+    return R.WhisperCalls(L, "ct2x_whisper_", h, _lib.check), (lambda: L.ct2x_whisper_destroy(C.c_void_p(h)))
+
+
+def compare(res, want_json, want_encode, exact_tokens, enc_atol, label):
+    """res: whisper_cases.run_cases output. Returns the number of differing hypotheses."""
+    enc = res["encode@"] if "encode@" in res else res["encode"]
+    d = float(np.abs(enc - want_encode).max())
+    print("%s encoder output max|d| = %.3g (|x| up to %.2f)" % (label, d, float(np.abs(want_encode).max())))
+    assert enc.shape == want_encode.shape
+    assert d <= enc_atol
+    differing, total = 0, 0
+    for name in WC.GENERATE:
+        got, want = res["generate." + name], want_json["generate." + name]
+        for b, (hg, hw) in enumerate(zip(got["hypotheses"], want["hypotheses"])):
+            total += 1
+            if hg != hw:
+                differing += 1
+                print("%s generate.%s[%d]: %r != %r" % (label, name, b, hg, hw))
+                continue
+            if WC.GENERATE[name][1].get("return_scores"):
+                np.testing.assert_allclose(got["scores"][b][:len(hg)], want["scores"][b][:len(hw)],
+                                           rtol=2e-3, atol=2e-3, err_msg=name)
+        if WC.GENERATE[name][1].get("return_no_speech_prob"):
+            np.testing.assert_allclose(got["no_speech_prob"], want["no_speech_prob"], rtol=5e-3,
+                                       atol=1e-5 if exact_tokens else 1e-3, err_msg=name)
+    print("%s generate: %d / %d hypothesis lists identical to the reference on Device::CPU"
+          % (label, total - differing, total))
+    if exact_tokens:
+        assert differing == 0
+    else:
+        assert differing <= total // 4
+    g, w = res["detect_language"], want_json["detect_language"]
+    if exact_tokens:
+        assert g["ids"] == w["ids"]
+        np.testing.assert_allclose(g["probs"], w["probs"], rtol=1e-3, atol=1e-5)
+    for name in WC.ALIGN:
+        g, w = res["align." + name], want_json["align." + name]
+        for b in range(len(w["pairs"])):
+            np.testing.assert_allclose(g["token_probs"][b], w["token_probs"][b], rtol=2e-3,
+                                       atol=1e-5 if exact_tokens else 2e-3, err_msg=name)
+        same = sum(int(a == b) for a, b in zip(g["pairs"], w["pairs"]))
+        print("%s align.%s: %d / %d DTW paths identical" % (label, name, same, len(w["pairs"])))
+        if exact_tokens:
+            assert g["pairs"] == w["pairs"], name
+    return differing
+
+
+@pytest.mark.parametrize("quant,compute,exact", [("float32", "float32", True), ("int8", "int8", False)])
+def test_whisper_fused_engine_matches_the_reference_cpu(gpu, golden, quant, compute, exact):
+    """Level 2. float32: every token, language ranking and DTW path identical, scores /
+    probabilities within 2e-3. int8: the CPU reference quantises the im2col rows of its
+    convolutions and so does this backend (same integers); (c / w_scale) / x_scale is evaluated
+    in the other order by the shared Dense epilogue, so a few hypotheses may differ."""
+    j, z = golden
+    path = WC.build("/tmp/ct2x_whisper_%s" % quant, quant)
+    w, close = product_whisper(path, compute)
+    try:
+        info = w.info()
+        assert info == j[quant]["info"]
+        res = WC.run_cases(w)
+    finally:
+        close()
+    compare(res, j[quant], z[quant + ".encode"], exact, 5e-4 if exact else 0.08, "Level-2 " + quant)
+
+
+@pytest.mark.parametrize("compute", ["float16", "bfloat16"])
+def test_whisper_16bit_compute_types(gpu, golden, compute):
+    """float32 model run with 16-bit weights on the matrix pipe (BASELINE configs[4] is bf16):
+    the encoder output stays within the type's rounding of the float32 reference and greedy
+    decoding without timestamps follows the reference for most sentences."""
+    j, z = golden
+    path = WC.build("/tmp/ct2x_whisper_float32", "float32")
+    w, close = product_whisper(path, compute)
+    try:
+        enc = w.encode(WC.features(), WC.D_MODEL)
+        name = "greedy_notimestamps"
+        prompts, kw = WC.GENERATE[name]
+        hyps, scores, nsp = w.generate(WC.features()[:len(prompts)], prompts, **kw)
+    finally:
+        close()
+    d = float(np.abs(enc - z["float32.encode"]).max())
+    print("Level-2 %s encoder output max|d| = %.3g" % (compute, d))
+    assert d <= (0.02 if compute == "float16" else 0.12)
+    want = j["float32"]["generate." + name]["hypotheses"]
+    same = sum(int(a == b) for a, b in zip(hyps, want))
+    print("Level-2 %s %s: %d / %d identical" % (compute, name, same, len(want)))
+    if compute == "float16":
+        assert same >= len(want) - 1
+
+
+def test_whisper_python_mirror(gpu, golden):
+    """ctranslate2_amd.Whisper mirrors ctranslate2.models.Whisper (python/cpp/whisper.cc)."""
+    import ctranslate2_amd as ct2
+    j, _ = golden
+    path = WC.build("/tmp/ct2x_whisper_float32", "float32")
+    w = ct2.Whisper(path, device="cuda", compute_type="float32")
+    assert w.is_multilingual and w.n_mels == WC.MODEL["n_mels"] and w.num_languages == WC.NUM_LANGUAGES
+    f = WC.features()
+    prompts = [["<|startoftranscript|>", "<|en|>", "<|transcribe|>", "<|notimestamps|>"]] * 3
+    res = w.generate(f, prompts, beam_size=1, max_length=24, return_scores=True,
+                     return_no_speech_prob=True)
+    want = j["float32"]["generate.greedy_notimestamps"]
+    assert [r.sequences_ids for r in res] == want["hypotheses"]
+    assert all(isinstance(t, str) and t for t in res[0].sequences[0])
+    langs = w.detect_language(f)
+    assert [[w._id(t) for t, _ in row] for row in langs] == j["float32"]["detect_language"]["ids"]
+    al = w.align(f, [WC.SOT, WC.EN, WC.TRANSCRIBE], **{k: v for k, v in WC.ALIGN["uniform"].items()
+                                                       if k not in ("start_sequence",)})
+    assert [[list(p) for p in r.alignments] for r in al] == j["float32"]["align.uniform"]["pairs"]
+    enc = w.encode(f)
+    assert enc.shape == (3, WC.FRAMES // 2, WC.D_MODEL)
+    with pytest.raises(ct2.Ct2xError, match="startoftranscript"):
+        w.generate(f, [[5, 6]] * 3)
+    with pytest.raises(ct2.Ct2xError, match="Invalid input features shape"):
+        w.generate(np.zeros((1, 3, 24), np.float32), [[WC.SOT]])
+    with pytest.raises(ct2.Ct2xError, match="same position"):
+        w.generate(f[:2], [[WC.SOT, WC.EN], [WC.STARTOFPREV, 5, WC.SOT, WC.EN]])
+    w.close()
+
+
+def test_reference_whisper_on_device_cuda(gpu, golden, tmp_path):
+    """Level 1: the reference's own Whisper glue on this backend's kernels."""
+    lib = os.path.join(ROOT, "oracle", "_ref", "libct2ref_capi_mi355.so")
+    if not os.path.exists(lib):
+        pytest.skip("Level-1 integration library not built (make -C oracle mi355)")
+    j, z = golden
+    path = WC.build("/tmp/ct2x_whisper_float32", "float32")
+    out_json, out_npz = str(tmp_path / "l1.json"), str(tmp_path / "l1.npz")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "integration", "run_level1_whisper.py"),
+                        path, "float32", out_json, out_npz], capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    with open(out_json) as f:
+        res = json.load(f)
+    res["encode"] = np.load(out_npz)["encode"]
+    assert res["info"] == j["float32"]["info"]
+    compare(res, j["float32"], z["float32.encode"], True, 5e-4, "Level-1 float32")

@@ -1,0 +1,63 @@
+"""not gpu: the committed Whisper goldens are what the reference's own models::Whisper computes on
+Device::CPU (oracle/_ref) for the deterministic synthetic model of tests/whisper_cases.py, and the
+host-side pieces of the Whisper glue that need no device."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _refshim as R
+import whisper_cases as WC
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref (the reference CPU library) is not built")
+def test_golden_is_reproduced_by_the_reference():
+    with open(os.path.join(HERE, "golden", "whisper_golden.json")) as f:
+        j = json.load(f)
+    z = np.load(os.path.join(HERE, "golden", "whisper_golden.npz"))
+    path = WC.build("/tmp/ct2x_whisper_float32", "float32")
+    w = R.RefWhisper(path, compute_type="float32")
+    try:
+        assert w.info() == j["float32"]["info"]
+        res = WC.run_cases(w, only={"greedy_timestamps", "beam5_timestamps", "timestamp_in_prefix"})
+    finally:
+        w.close()
+    np.testing.assert_allclose(res["encode@"], z["float32.encode"], rtol=0, atol=1e-5)
+    for name in ("greedy_timestamps", "beam5_timestamps", "timestamp_in_prefix"):
+        assert res["generate." + name]["hypotheses"] == j["float32"]["generate." + name]["hypotheses"]
+    assert res["detect_language"]["ids"] == j["float32"]["detect_language"]["ids"]
+    for name in WC.ALIGN:
+        assert res["align." + name]["pairs"] == j["float32"]["align." + name]["pairs"]
+
+
+def test_golden_exercises_the_timestamp_rules():
+    """The fixture is only worth something if the rules fire: timestamps come in pairs, never
+    decrease, and runs without <|notimestamps|> start with a timestamp."""
+    with open(os.path.join(HERE, "golden", "whisper_golden.json")) as f:
+        j = json.load(f)["float32"]
+    pairs = 0
+    for name in ("greedy_timestamps", "beam5_timestamps", "sot_only", "options"):
+        for hyps in j["generate." + name]["hypotheses"]:
+            h = hyps[0]
+            assert h[0] >= WC.TS0, (name, h)
+            ts = [t for t in h if t >= WC.TS0]
+            assert ts == sorted(ts), (name, h)
+            pairs += sum(1 for a, b in zip(h, h[1:]) if a >= WC.TS0 and b >= WC.TS0)
+    assert pairs >= 4
+    for hyps in j["generate.greedy_notimestamps"]["hypotheses"]:
+        assert len(hyps[0]) >= 1
+    # hard prefix after the task tokens is part of the hypothesis (return_prefix)
+    assert j["generate.text_after_task"]["hypotheses"][0][0][:2] == [5, 9]
+
+
+def test_whisper_vocabulary_layout():
+    from ctranslate2_amd import model_builder as mb
+    tokens = mb.whisper_vocab_tokens(WC.MODEL["num_text_tokens"], WC.MODEL["languages"],
+                                     WC.MODEL["num_timestamps"])
+    assert tokens[WC.EOT] == "<|endoftext|>" and tokens[WC.SOT] == "<|startoftranscript|>"
+    assert tokens[WC.NOSPEECH] == "<|nospeech|>" and tokens[WC.NOTIMESTAMPS] == "<|notimestamps|>"
+    assert tokens[WC.TS0] == "<|0.00|>" and len(tokens) == WC.TS0 + WC.MODEL["num_timestamps"]
+    assert WC.NOSPEECH - WC.SOT - 5 == WC.NUM_LANGUAGES  # whisper.cc:77
