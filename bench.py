@@ -62,6 +62,9 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-l8", action="store_true",
                    help="skip the Llama-3-8B-shape leg (BASELINE configs[2], reported as config.l8)")
+    p.add_argument("--no-whisper", action="store_true",
+                   help="skip the Whisper-large-v3-shaped bfloat16 leg (BASELINE configs[4] family, "
+                        "reported as config.whisper)")
     p.add_argument("--no-nllb", action="store_true",
                    help="skip the NLLB-3.3B-shape float16 leg (BASELINE configs[3] geometry on one GPU, "
                         "reported as config.nllb)")
@@ -517,6 +520,28 @@ def main():
                 }
             except Exception as e:  # never break the headline line
                 result["config"]["nllb"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.no_whisper and args.beam == 1 and args.compute_type == "int8":
+            # BASELINE.json configs[4]'s model family (Whisper-large-v3 shape, bfloat16, 8 windows of
+            # 30 s, beam 5) on this one GPU: tools/bench_whisper.py in its own process.
+            try:
+                import subprocess
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_whisper.py"),
+                                      "--steps", "2", "--warmup", "1"],
+                                     capture_output=True, text=True, timeout=900)
+                wl = json.loads(out.stdout.strip().splitlines()[-1])
+                result["config"]["whisper"] = {
+                    "workload": wl["config"]["workload"], "value": wl["value"], "unit": wl["unit"],
+                    "dtype": wl["dtype"], "ms_per_call": wl["ms_per_step"],
+                    "encode_ms": wl["config"]["encode_ms"],
+                    "decode_ms_per_step": wl["config"]["decode_ms_per_step"],
+                    "audio_seconds_per_second": wl["config"]["audio_seconds_per_second"],
+                    "roofline": wl["encoder_roofline"],
+                    "parity": "float32 tokens / language ranking / DTW paths identical to the reference's "
+                              "models::Whisper on CPU, 16-bit arms within tolerance (synthetic 2 + 2 layer "
+                              "model): tests/test_whisper_gpu.py",
+                }
+            except Exception as e:  # never break the headline line
+                result["config"]["whisper"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(model_dir, sources, args)

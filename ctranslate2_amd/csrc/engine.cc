@@ -472,8 +472,14 @@ AttnW Engine::load_attention(const std::string& scope, bool self_attention, int6
         model_->attribute(scope + "/original_max_position_embeddings", 0));
     a.max_position_embeddings =
         static_cast<int64_t>(model_->attribute(scope + "/max_position_embeddings", 0));
-    if (a.rotary_scaling_type == 1)
-      throw std::runtime_error("Su rotary scaling is not supported by this backend yet");
+    if (a.rotary_scaling_type == 1) {
+      const Variable* lf = model_->find(scope + "/rotary_scaling_long_factor");
+      const Variable* sf = model_->find(scope + "/rotary_scaling_short_factor");
+      if (!lf || !sf)
+        throw std::runtime_error(scope + ": Su rotary scaling without its long / short factors");
+      a.rotary_long_factor = lf->to_float();
+      a.rotary_short_factor = sf->to_float();
+    }
   }
   if (a.dhead % 4 != 0 || a.dhead > 512)
     throw std::runtime_error("head dimension must be a multiple of 4 and <= 512");
@@ -596,20 +602,11 @@ void Engine::load_stack(const std::string& scope, bool decoder, StackW& out) {
   for (int64_t l = 0;; ++l) {
     const std::string ls = scope + "/layer_" + std::to_string(l);
     if (!m.has(ls + "/self_attention/linear_0/weight")) break;
-    for (const char* unsupported : {"/shared_layer_norm/gamma", "/input_layer_norm/gamma",
-                                    "/post_attention_layer_norm/gamma",
-                                    "/pre_feedforward_layer_norm/gamma",
-                                    "/post_feedforward_layer_norm/gamma",
-                                    "/external_pre_encoder_attention_layer_norm/gamma",
+    for (const char* unsupported : {"/external_pre_encoder_attention_layer_norm/gamma",
                                     "/external_post_encoder_attention_layer_norm/gamma"})
       if (m.has(ls + unsupported))
         throw std::runtime_error("layer variant with " + ls + unsupported +
                                  " is not supported by this backend yet");
-    // layer_scalar (src/layers/transformer.cc:189): a non-unit output scale would be silently
-    // dropped - refuse the model instead
-    if (m.has(ls + "/layer_scalar") && m.get(ls + "/layer_scalar").as_number() != 1.0)
-      throw std::runtime_error("layer variant with " + ls + "/layer_scalar is not supported by "
-                               "this backend yet");
     LayerW layer;
     layer.self = load_attention(ls + "/self_attention", true, out.num_heads);
     if (decoder && m.has(ls + "/attention/linear_0/weight")) {
@@ -617,6 +614,46 @@ void Engine::load_stack(const std::string& scope, bool decoder, StackW& out) {
       layer.cross = load_attention(ls + "/attention", false, out.num_heads);
     }
     layer.ffn = load_ffn(ls + "/ffn", activation);
+    // Layer variants (TransformerDecoderLayer, src/layers/transformer.cc:170-323). The encoder
+    // layer has none of these norms (TransformerEncoderLayer, :54-67).
+    const NormW shared_ln = load_norm(ls + "/shared_layer_norm");
+    const NormW input_ln = load_norm(ls + "/input_layer_norm");
+    const NormW post_attn_ln = load_norm(ls + "/post_attention_layer_norm");
+    const NormW pre_ff_ln = load_norm(ls + "/pre_feedforward_layer_norm");
+    const NormW post_ff_ln = load_norm(ls + "/post_feedforward_layer_norm");
+    const bool any_variant = shared_ln.present || input_ln.present || post_attn_ln.present ||
+                             pre_ff_ln.present || post_ff_ln.present;
+    if (any_variant) {
+      if (!decoder)
+        throw std::runtime_error(ls + ": layer-variant norms on an encoder layer");
+      if (layer.has_cross || !out.pre_norm || layer.self.ln.present || layer.ffn.ln.present || tp_)
+        throw std::runtime_error("layer variant of " + ls + " with encoder-decoder attention, "
+                                 "post-norm, sub-layer norms of its own or tensor parallelism is "
+                                 "not supported by this backend yet");
+      if (post_ff_ln.present && pre_ff_ln.present) {
+        if (!input_ln.present || !post_attn_ln.present)
+          throw std::runtime_error(ls + ": pre / post feed-forward norms without input / "
+                                   "post-attention norms");
+        layer.variant = 2;
+        layer.self.ln = input_ln;
+        layer.post_attn_ln = post_attn_ln;
+        layer.ffn.ln = pre_ff_ln;
+        layer.post_ff_ln = post_ff_ln;
+        layer.layer_scalar = static_cast<float>(m.attribute(ls + "/layer_scalar", 1.0));
+      } else if (shared_ln.present || input_ln.present) {
+        layer.variant = 1;
+        layer.self.ln = shared_ln.present ? shared_ln : input_ln;
+        // the feed-forward block reads post_attention_layer_norm(x) when that norm exists, else the
+        // same normalised input as the attention (transformer.cc:300-306)
+        layer.ffn.ln = post_attn_ln.present ? post_attn_ln : layer.self.ln;
+      } else {
+        throw std::runtime_error(ls + ": unsupported combination of layer-variant norms");
+      }
+      layer.self.no_residual = true;
+      layer.ffn.no_residual = true;
+    } else if (m.has(ls + "/layer_scalar") && m.get(ls + "/layer_scalar").as_number() != 1.0) {
+      // (only the pre + post norm arm applies it, transformer.cc:281-283)
+    }
     out.layers.emplace_back(std::move(layer));
   }
   if (out.layers.empty()) throw std::runtime_error("no layers found under " + scope);
@@ -776,11 +813,22 @@ const float* Engine::sinusoidal_table(int64_t positions, int64_t depth) {
 void make_rotary_tables(int64_t dim, bool interleave, int scaling_type, float scaling_factor,
                         float base, float low_freq_factor, float high_freq_factor,
                         int64_t original_max_position_embeddings, int64_t positions,
-                        std::vector<float>& s, std::vector<float>& c) {
+                        std::vector<float>& s, std::vector<float>& c,
+                        const std::vector<float>* su_long, const std::vector<float>* su_short,
+                        int64_t max_position_embeddings) {
   const int64_t half = dim / 2;
   std::vector<float> inv_freq(half);
   for (int64_t i = 0; i < half; ++i)
     inv_freq[i] = 1.f / std::pow(base, static_cast<float>(i * 2) / static_cast<float>(dim));
+  if (scaling_type == 1) {  // Su (attention_layer.cc:257-267): long factors once the table is
+                            // longer than the original context, else the short ones
+    const std::vector<float>* f = positions > original_max_position_embeddings ? su_long : su_short;
+    if (!f || static_cast<int64_t>(f->size()) < half)
+      throw std::invalid_argument("Su rotary scaling needs rotary_scaling_long_factor / "
+                                  "rotary_scaling_short_factor with rotary_dim / 2 entries");
+    for (int64_t i = 0; i < half; ++i)
+      inv_freq[i] = 1.f / ((*f)[i] * std::pow(base, static_cast<float>(i * 2) / static_cast<float>(dim)));
+  }
   if (scaling_type == 2) {  // Llama3
     std::vector<float> new_freqs = inv_freq;
     const float factor = scaling_factor;
@@ -824,6 +872,17 @@ void make_rotary_tables(int64_t dim, bool interleave, int scaling_type, float sc
       }
     }
   }
+  if (original_max_position_embeddings != 0 && max_position_embeddings != 0 && scaling_type != 2) {
+    // `float scale = _max_position_embeddings / _original_max_position_embeddings` divides two
+    // integers (attention_layer.cc:333)
+    const float scale = static_cast<float>(max_position_embeddings / original_max_position_embeddings);
+    if (scale > 1) {
+      const float factor = static_cast<float>(std::sqrt(
+          1 + std::log(scale) / std::log(static_cast<double>(original_max_position_embeddings))));
+      for (auto& v : s) v = v * factor;
+      for (auto& v : c) v = v * factor;
+    }
+  }
 }
 
 void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_out,
@@ -838,6 +897,7 @@ void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_
                           std::to_string(a.rotary_low_freq_factor) + "/" +
                           std::to_string(a.rotary_high_freq_factor) + "/" +
                           std::to_string(a.original_max_position_embeddings) + "/" +
+                          std::to_string(a.max_position_embeddings) + "/" +
                           (a.rotary_interleave ? "i" : "h");
   if (rope_sin_ && key != rope_key_) rope_positions_ = 0;  // rebuild below (old tables stay alive)
   rope_key_ = key;
@@ -846,11 +906,14 @@ void Engine::rotary_tables(const AttnW& a, int64_t positions, const float** sin_
     *cos_out = rope_cos_;
     return;
   }
-  positions = std::max<int64_t>(positions, 2048);
+  // RotaryEmbeddings::apply (attention_layer.cc:220-224) grows its tables by at least
+  // num_initial_positions = 2048 at a time
+  positions = std::max<int64_t>(positions, rope_positions_ + 2048);
   std::vector<float> s, c;
   make_rotary_tables(dim, a.rotary_interleave, a.rotary_scaling_type, a.rotary_scaling_factor,
                      a.rotary_base, a.rotary_low_freq_factor, a.rotary_high_freq_factor,
-                     a.original_max_position_embeddings, positions, s, c);
+                     a.original_max_position_embeddings, positions, s, c, &a.rotary_long_factor,
+                     &a.rotary_short_factor, a.max_position_embeddings);
   if (rope_sin_) {  // kept alive for sessions that captured the old pointers
     device_blocks_.push_back(rope_sin_);
     device_blocks_.push_back(rope_cos_);
@@ -1392,6 +1455,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   const int64_t wqkv = std::max(qkv_dim, enc_qkv);
   st->x0 = alloc<float>(*st, wrows * d);
   st->x1 = alloc<float>(*st, wrows * d);
+  for (const auto& l : dec_.layers)
+    if (l.variant == 1 && !st->x2) st->x2 = alloc<float>(*st, wrows * d);
   st->qkv = alloc<float>(*st, wrows * wqkv);
   st->ctx = alloc<float>(*st, wrows * d);
   st->inner = alloc<float>(*st, wrows * wffn);
@@ -1707,6 +1772,8 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
                      DecodeState& st, float* amax_buf, bool qin_ready) {
   QuantIn fq;
   const float* ffn_in = x;
+  // (layer variants: the caller adds what has to be added)
+  const float* resid = (ffn.ln.present && !ffn.no_residual) ? x : nullptr;
   if (qin_ready) {
     // the previous block's row-owning output projection already normalised and quantised x
     fq.q = st.qbuf;
@@ -1719,8 +1786,8 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
                      gemm_s8_qol_applicable(rows, ffn.l1.n, ffn.l1.k);
     if (dense_norm(ffn.ln, ffn.l0, x, rows, ffn.activation, nullptr, st.inner,
                    qol ? amax_buf : nullptr)) {
-      if (qol) dense_qol(ffn.l1, st.inner, amax_buf, rows, -1, x, y);
-      else dense(ffn.l1, st.inner, nullptr, rows, -1, x, y, &st);
+      if (qol) dense_qol(ffn.l1, st.inner, amax_buf, rows, -1, resid, y);
+      else dense(ffn.l1, st.inner, nullptr, rows, -1, resid, y, &st);
       std::swap(x, y);
       return;
     }
@@ -1783,7 +1850,7 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
       QuantIn iq;
       iq.q = st.qbuf;
       iq.s = st.qscale;
-      dense(ffn.l1, nullptr, &iq, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
+      dense(ffn.l1, nullptr, &iq, rows, -1, resid, y, &st);
       if (ffn.ln.present && !pre_norm) norm(ffn.ln, y, rows, d, y);
       std::swap(x, y);
       return;
@@ -1797,9 +1864,47 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
     end_kernel();
   }
   }
-  dense(ffn.l1, st.inner, nullptr, rows, -1, ffn.ln.present ? x : nullptr, y, &st);
+  dense(ffn.l1, st.inner, nullptr, rows, -1, resid, y, &st);
   if (ffn.ln.present && !pre_norm) norm(ffn.ln, y, rows, d, y);
   std::swap(x, y);
+}
+
+// The part of a layer variant (LayerW::variant) that follows its self-attention block: on entry
+// x = the layer input, y = Attention(norm(x)) without residual. On return x = the layer output.
+void Engine::finish_variant_layer(const LayerW& layer, int64_t rows, int64_t d, float*& x, float*& y,
+                                  DecodeState& st) {
+  auto add = [&](const float* a, const float* b, float* out) {
+    begin_kernel("add", double(rows) * d * 12, 0, rows, 0, d);
+    launch_add(a, b, rows * d, out, cur_stream());
+    end_kernel();
+  };
+  if (layer.variant == 2) {
+    // post_attention_layer_norm(context) + input (transformer.cc:239-240)
+    norm(layer.post_attn_ln, y, rows, d, y);
+    add(y, x, y);
+    std::swap(x, y);  // x = h, y free
+    run_ffn(layer.ffn, true, rows, d, x, y, st);  // x = FFN(pre_ff_norm(h)), y = h
+    norm(layer.post_ff_ln, x, rows, d, x);
+    add(x, y, x);  // ops::Add()(output, context, output) (:278)
+    if (layer.layer_scalar != 1.f) {
+      begin_kernel("mul_scalar", double(rows) * d * 8, 0, rows, 0, d);
+      launch_binary_scalar(/*mul*/ 2, layer.layer_scalar, x, x, rows * d, /*float32*/ 0, cur_stream());
+      end_kernel();
+    }
+  } else {
+    // parallel residual (transformer.cc:287-317): FFN(norm'(input)) + input + attention
+    CT2X_CHECK(st.x2 != nullptr, "parallel-residual layer without its third buffer");
+    float* in = x;
+    float* z = st.x2;
+    if (in == st.x2 || y == st.x2) z = (in != st.x0 && y != st.x0) ? st.x0 : st.x1;
+    float* fx = in;
+    float* fy = z;
+    run_ffn(layer.ffn, true, rows, d, fx, fy, st);  // fx = z = FFN(norm'(in)), fy = in
+    add(fx, in, fx);  // ops::Add()(output, input, output)
+    add(fx, y, fx);   // ops::Add()(output, attn, output)
+    x = fx;
+    y = in;
+  }
 }
 
 // Sequence-mode forward of a decoder-only model over the prompt (TransformerDecoder::decode with
@@ -1886,8 +1991,12 @@ void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time, float*
     begin_kernel("attention_prefill", 0, 0, rows, a.heads, a.dhead);
     launch_attention_full(f, cur_stream());
     end_kernel();
-    dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+    dense(a.lin[1], st.ctx, nullptr, rows, -1, (a.ln.present && !a.no_residual) ? x : nullptr, y, &st);
     if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
+    if (layer.variant != 0) {
+      finish_variant_layer(layer, rows, d, x, y, st);
+      continue;
+    }
     std::swap(x, y);
     if (layer.has_cross) {
       // encoder-decoder attention in sequence mode (the target prefix of decode_alternatives,
@@ -2023,6 +2132,8 @@ void Engine::launch_step(DecodeState& st) {
       tap_scope("dec.l" + std::to_string(l) + ".self");
       QuantIn qin;
       const float* attn_in = x;
+      // the sub-layer's input is added to its output unless a layer variant does its own sums
+      const float* resid = (a.ln.present && !a.no_residual) ? x : nullptr;
       const bool fused_in = !qin_ready && dec_.pre_norm &&
                             dense_norm(a.ln, a.lin[0], x, rows, -1, nullptr, st.qkv);
       if (qin_ready) {
@@ -2090,11 +2201,11 @@ void Engine::launch_step(DecodeState& st) {
         cq.s = st.qscale;
         const NormW* next_ln = layer.has_cross ? &layer.cross.ln : &layer.ffn.ln;
         const DenseW* next_dense = layer.has_cross ? &layer.cross.lin[0] : &layer.ffn.l0;
-        if (a.ln.present && (layer.has_cross || !layer.ffn.l0_noact.present) &&
+        if (a.ln.present && layer.variant == 0 && (layer.has_cross || !layer.ffn.l0_noact.present) &&
             dense_out_next_norm(a.lin[1], cq, rows, x, y, next_ln, next_dense, st))
           qin_ready = true;
         else
-          dense(a.lin[1], nullptr, &cq, rows, -1, a.ln.present ? x : nullptr, y, &st);
+          dense(a.lin[1], nullptr, &cq, rows, -1, resid, y, &st);
       } else if (split_quant && a.lin[1].quantized && !a.lin[1].row_parallel &&
                  attention_decode_emits_row_amax(p)) {
         // long caches / few rows: one workgroup per (row, head) + producer-side absmax, then an
@@ -2120,14 +2231,20 @@ void Engine::launch_step(DecodeState& st) {
         QuantIn cq;
         cq.q = st.qbuf;
         cq.s = st.qscale;
-        dense(a.lin[1], nullptr, &cq, rows, -1, a.ln.present ? x : nullptr, y, &st);
+        dense(a.lin[1], nullptr, &cq, rows, -1, resid, y, &st);
       } else {
         begin_kernel("attention_self_decode", 0, 0, rows, a.heads, a.dhead);
         launch_attention_decode(p, cur_stream());
         end_kernel();
-        dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+        dense(a.lin[1], st.ctx, nullptr, rows, -1, resid, y, &st);
       }
       if (a.ln.present && !dec_.pre_norm) norm(a.ln, y, rows, d, y);
+      if (layer.variant != 0) {
+        // parallel residual / pre + post norms: the rest of the layer (no cross attention)
+        tap_scope("dec.l" + std::to_string(l) + ".ffn");
+        finish_variant_layer(layer, rows, d, x, y, st);
+        continue;
+      }
       std::swap(x, y);
     }
     // ---- encoder-decoder attention -------------------------------------------------------

@@ -37,10 +37,16 @@ std::string compute_type_name(ComputeType t);
 // [positions, depth], sin half then cos half, through the host math backend (host_math.h).
 std::vector<float> make_sinusoidal_table(int64_t positions, int64_t depth);
 // Host side of the rotary tables (RotaryEmbeddings::initialize): s, c [positions, dim].
+// su_long / su_short (Su scaling): per-frequency divisors [dim / 2]; max_position_embeddings:
+// with original_max_position_embeddings, the sqrt(1 + log(scale) / log(original)) factor applied
+// to both tables for every scaling type but Llama3 (attention_layer.cc:331-343).
 void make_rotary_tables(int64_t dim, bool interleave, int scaling_type, float scaling_factor,
                         float base, float low_freq_factor, float high_freq_factor,
                         int64_t original_max_position_embeddings, int64_t positions,
-                        std::vector<float>& s, std::vector<float>& c);
+                        std::vector<float>& s, std::vector<float>& c,
+                        const std::vector<float>* su_long = nullptr,
+                        const std::vector<float>* su_short = nullptr,
+                        int64_t max_position_embeddings = 0);
 
 struct DenseW {
   // Tensor parallel: the K dimension is split over the ranks (attention-out / FFN-out); the
@@ -89,12 +95,17 @@ struct AttnW {
   float rotary_scaling_factor = 1.f;
   float rotary_low_freq_factor = 1.f, rotary_high_freq_factor = 4.f;
   int64_t original_max_position_embeddings = 0, max_position_embeddings = 0;
+  // Su scaling (rotary_scaling_type 1, Phi-3): per-frequency divisors [rotary_dim / 2]
+  std::vector<float> rotary_long_factor, rotary_short_factor;
+  // layer variants: `ln` is the layer's input norm, the block's output carries no residual
+  bool no_residual = false;
 };
 
 struct FfnW {
   NormW ln;
   DenseW l0, l0_noact, l1;
   int activation = 0;
+  bool no_residual = false;  // layer variants (see LayerW)
 };
 
 struct EmbW {
@@ -109,6 +120,18 @@ struct LayerW {
   bool has_cross = false;
   AttnW cross;
   FfnW ffn;
+  // TransformerDecoderLayer::operator() arms (src/layers/transformer.cc:196-366):
+  //   0  standard: every sub-layer owns its norm and adds its input
+  //   1  parallel residual (shared_layer_norm, or input_layer_norm [+ post_attention_layer_norm]):
+  //      out = FFN(norm'(x)) + x + Attention(norm(x))
+  //   2  pre + post norms (input / post_attention / pre_feedforward / post_feedforward):
+  //      h = post_attention_norm(Attention(input_norm(x))) + x;
+  //      out = (post_feedforward_norm(FFN(pre_feedforward_norm(h))) + h) * layer_scalar
+  // self.ln / ffn.ln hold the norm each sub-layer applies to its input; the sub-layers run with
+  // no_residual and launch_step / prefill add the rest.
+  int variant = 0;
+  NormW post_attn_ln, post_ff_ln;
+  float layer_scalar = 1.f;
 };
 
 struct StackW {  // encoder or decoder
@@ -390,6 +413,8 @@ private:
   // amax_buf: zeroed [rows] scratch for the producer-side absmax of the gated pair (decode steps)
   void run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, float*& x, float*& y,
                DecodeState& st, float* amax_buf = nullptr, bool qin_ready = false);
+  void finish_variant_layer(const LayerW& layer, int64_t rows, int64_t d, float*& x, float*& y,
+                            DecodeState& st);
   bool dense_out_next_norm(const DenseW& w, const QuantIn& cq, int64_t rows, const float* residual,
                            float* y, const NormW* next_ln, const DenseW* next_dense,
                            DecodeState& st);
@@ -458,6 +483,7 @@ struct DecodeState {
   std::vector<void*> owned;
   float* x0 = nullptr;       // residual stream [rows, d]
   float* x1 = nullptr;
+  float* x2 = nullptr;       // third residual-stream buffer (parallel-residual layers only)
   float* qkv = nullptr;      // [rows, q_dim + 2 * kv_dim]
   float* ctx = nullptr;      // [rows, d]
   float* inner = nullptr;    // [rows, ffn]

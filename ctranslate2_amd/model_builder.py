@@ -144,7 +144,7 @@ class _Builder:
         # direct_f16: the float16 weights are uniform multiples of absmax / 127 (same variance as
         # N(0, w_std^2)), drawn as int8 and scaled in float16 - a 3.3 B parameter model in about a
         # minute instead of ten
-        self.direct_f16 = direct_f16 and quantization == "float16"
+        self.direct_f16 = direct_f16 and quantization in ("float16", "bfloat16")
         self.vars = {}
         # awq = (layout, group, twin): layer linears are stored as AWQ int4 weights; with twin=True the
         # builder instead stores the float16 weight those int4 values dequantise to (the comparison
@@ -162,9 +162,14 @@ class _Builder:
             self.vars[name + "_scale"] = (127.0 / amax).astype(np.float32)
         elif self.direct_f16:
             q = self.rng.integers(-127, 128, (n, k), dtype=np.int8)
-            w = q.astype(np.float16)
-            w *= np.float16(self.w_std * np.sqrt(3.0) / 127.0)
-            self.vars[name] = w
+            if self.quantization == "bfloat16":
+                w = q.astype(np.float32)
+                w *= np.float32(self.w_std * np.sqrt(3.0) / 127.0)
+                self.vars[name] = to_bf16(w)
+            else:
+                w = q.astype(np.float16)
+                w *= np.float16(self.w_std * np.sqrt(3.0) / 127.0)
+                self.vars[name] = w
         else:
             self.weight(name, self.rng.normal(0, self.w_std, (n, k)).astype(np.float32))
 
@@ -302,34 +307,76 @@ def build_transformer(output_dir, num_encoder_layers=6, num_decoder_layers=6, d_
 
 def build_decoder_lm(output_dir, num_layers=32, d_model=4096, ffn_dim=14336, num_heads=32,
                      num_heads_kv=8, vocab_size=128256, seed=0, quantization="int8",
-                     rotary_base=500000.0, w_std=0.02, direct_int8=False, awq=None):
+                     rotary_base=500000.0, w_std=0.02, direct_int8=False, awq=None,
+                     layer_variant=None, layer_scalar=None, rotary_su=None, glu=True, bias=False,
+                     rms=True, activation=SWISH, norm_use_residual=False, rotary_interleave=False):
     """TransformerDecoderModelSpec.from_config(layers, heads, activation=SWISH, ffn_glu=True,
     rms_norm=True, rotary_dim=0, rotary_interleave=False, num_heads_kv=...) -- the Llama-3 shape
-    (python/ctranslate2/converters/transformers.py:1736-1752)."""
+    (python/ctranslate2/converters/transformers.py:1736-1752) when left at the defaults.
+
+    layer_variant (TransformerDecoderLayerSpec, python/ctranslate2/specs/transformer_spec.py):
+      "parallel_shared"      shared_layer_norm (GPT-J / Phi: parallel_residual + shared_layer_norm)
+      "parallel_input"       input_layer_norm only (parallel_residual, Falcon-7B style)
+      "parallel_input_post"  input_layer_norm + post_attention_layer_norm (GPT-NeoX / Falcon-40B)
+      "pre_post"             input / post_attention / pre_feedforward / post_feedforward norms
+                             (pre_post_layer_norm, Gemma 2 / 3); layer_scalar multiplies the output
+    rotary_su = (long_factors, short_factors, original_max_position_embeddings,
+    max_position_embeddings): Su scaling (Phi-3, RotaryScalingType.Su = 1)."""
     os.makedirs(output_dir, exist_ok=True)
     b = _Builder(seed, quantization, w_std=w_std, direct_int8=direct_int8)
     b.awq = awq  # None, or (layout "gemm" | "gemv", group size, twin)
     d = d_model
     dh = d // num_heads
+
+    def norm(scope):
+        b.layer_norm(scope, d, rms=rms)
+        if norm_use_residual:
+            b.attr(scope + "/layer_norm_use_residual", 1, np.int8)
+
     b.random_weight("decoder/embeddings/weight", vocab_size, d)
     for l in range(num_layers):
         s = "decoder/layer_%d" % l
-        b.layer_norm(s + "/self_attention/layer_norm", d, rms=True)
-        b.linear(s + "/self_attention/linear_0", (num_heads + 2 * num_heads_kv) * dh, d, bias=False, awq_ok=True)
-        b.linear(s + "/self_attention/linear_1", d, d, bias=False, awq_ok=True)
+        if layer_variant is None:
+            norm(s + "/self_attention/layer_norm")
+        elif layer_variant == "parallel_shared":
+            norm(s + "/shared_layer_norm")
+        elif layer_variant == "parallel_input":
+            norm(s + "/input_layer_norm")
+        elif layer_variant == "parallel_input_post":
+            norm(s + "/input_layer_norm")
+            norm(s + "/post_attention_layer_norm")
+        elif layer_variant == "pre_post":
+            for name in ("input_layer_norm", "post_attention_layer_norm",
+                         "pre_feedforward_layer_norm", "post_feedforward_layer_norm"):
+                norm(s + "/" + name)
+            if layer_scalar is not None:
+                b.attr(s + "/layer_scalar", layer_scalar, np.float32)
+        else:
+            raise ValueError("unknown layer_variant %r" % (layer_variant,))
+        b.linear(s + "/self_attention/linear_0", (num_heads + 2 * num_heads_kv) * dh, d, bias=bias, awq_ok=True)
+        b.linear(s + "/self_attention/linear_1", d, d, bias=bias, awq_ok=True)
         b.attr(s + "/self_attention/rotary_dim", 0, np.int32)
-        b.attr(s + "/self_attention/rotary_interleave", 0, np.int8)
+        b.attr(s + "/self_attention/rotary_interleave", int(rotary_interleave), np.int8)
         b.attr(s + "/self_attention/rotary_base", rotary_base, np.float32)
         b.attr(s + "/self_attention/num_heads_kv", num_heads_kv, np.int32)
-        b.layer_norm(s + "/ffn/layer_norm", d, rms=True)
-        b.linear(s + "/ffn/linear_0", ffn_dim, d, bias=False, awq_ok=True)
-        b.linear(s + "/ffn/linear_0_noact", ffn_dim, d, bias=False, awq_ok=True)
-        b.linear(s + "/ffn/linear_1", d, ffn_dim, bias=False, awq_ok=True)
-    b.layer_norm("decoder/layer_norm", d, rms=True)
+        if rotary_su is not None:
+            long_f, short_f, orig_max, max_pos = rotary_su
+            b.attr(s + "/self_attention/rotary_scaling_type", 1, np.int8)
+            b.vars[s + "/self_attention/rotary_scaling_long_factor"] = np.asarray(long_f, np.float32)
+            b.vars[s + "/self_attention/rotary_scaling_short_factor"] = np.asarray(short_f, np.float32)
+            b.attr(s + "/self_attention/original_max_position_embeddings", orig_max, np.int32)
+            b.attr(s + "/self_attention/max_position_embeddings", max_pos, np.int32)
+        if layer_variant is None:  # (drawn here: the seeds of the committed goldens depend on the order)
+            norm(s + "/ffn/layer_norm")
+        b.linear(s + "/ffn/linear_0", ffn_dim, d, bias=bias, awq_ok=True)
+        if glu:
+            b.linear(s + "/ffn/linear_0_noact", ffn_dim, d, bias=bias, awq_ok=True)
+        b.linear(s + "/ffn/linear_1", d, ffn_dim, bias=bias, awq_ok=True)
+    norm("decoder/layer_norm")
     b.linear("decoder/projection", vocab_size, d, bias=False)
     b.attr("decoder/num_heads", num_heads, np.int16)
     b.attr("decoder/pre_norm", 1, np.int8)
-    b.attr("decoder/activation", SWISH, np.int8)
+    b.attr("decoder/activation", activation, np.int8)
     b.attr("decoder/scale_embeddings", 0, np.int8)
     b.attr("decoder/alibi", 0, np.int8)
     b.attr("decoder/alibi_use_positive_positions", 0, np.int8)
@@ -390,6 +437,12 @@ def build_whisper(output_dir, num_encoder_layers=2, num_decoder_layers=2, d_mode
     d = d_model
 
     def conv(scope, out_c, in_c):
+        if b.direct_f16:
+            b.random_weight(scope + "/weight", out_c, in_c * 3)
+            w16 = b.vars[scope + "/weight"]
+            b.vars[scope + "/weight"] = w16.reshape(out_c, in_c, 3).view(type(w16))
+            b.vars[scope + "/bias"] = b.rng.normal(0, b.b_std, (out_c,)).astype(np.float32)
+            return
         w = b.rng.normal(0, w_std, (out_c, in_c, 3)).astype(np.float32)
         if quantization == "int8":
             # model_spec.py:229-243: scale per output channel over the [in, kernel] plane

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     } else if (mode == "reject") {
       ct2_mi355::Translator translator(model);
       ct2_mi355::TranslationOptions options;
-      options.return_attention = true;
+      options.replace_unknowns = true;  // needs the attention on the host side: not built
       try {
         translator.translate_batch({{"a"}}, options);
       } catch (const std::invalid_argument& e) {

@@ -74,3 +74,32 @@ NLLB_GEOMETRY = {
                   vocab_size=8192, seed=21, quantization="float16", direct_f16=True, share_embeddings=True),
     "data_seed": 22, "src_lengths": [24, 24, 17, 24, 9, 24], "max_len": 12, "logits_steps": 12,
 }
+
+# Decoder layer variants (TransformerDecoderLayer::operator(), src/layers/transformer.cc:196-323) and
+# Su rotary scaling (RotaryEmbeddings::initialize, src/layers/attention_layer.cc:254-343): small int8
+# decoder-only models, tests/golden/make_golden_layer_variants.py.
+_VARIANT_BASE = dict(num_layers=3, d_model=64, ffn_dim=128, num_heads=4, num_heads_kv=2,
+                     vocab_size=96, quantization="int8", w_std=0.2, rotary_base=10000.0)
+_SU_LONG = [1.0 + 0.37 * i for i in range(8)]
+_SU_SHORT = [1.0 + 0.05 * i for i in range(8)]
+LAYER_VARIANTS = {
+    # GPT-J / Phi-2 style: one norm feeds attention and feed-forward, LayerNorm with bias, GELU
+    "parallel_shared": dict(_VARIANT_BASE, seed=31, layer_variant="parallel_shared", rms=False,
+                            bias=True, glu=False, activation=3),
+    # Falcon-7B style: input_layer_norm only
+    "parallel_input": dict(_VARIANT_BASE, seed=32, layer_variant="parallel_input", rms=False,
+                           bias=True, glu=False, activation=3),
+    # GPT-NeoX / Falcon-40B style: a second norm for the feed-forward input
+    "parallel_input_post": dict(_VARIANT_BASE, seed=33, layer_variant="parallel_input_post",
+                                rms=False, bias=True, glu=False, activation=3),
+    # Gemma-2 style: norms before and after both blocks, (1 + gamma) RMSNorm, GELU-tanh gate,
+    # layer_scalar
+    "pre_post": dict(_VARIANT_BASE, seed=34, layer_variant="pre_post", layer_scalar=0.75,
+                     norm_use_residual=True, activation=1),
+    # Phi-3 style Su scaling: the 2048-position table exceeds the original context -> long factors
+    # and the sqrt(1 + log(scale) / log(original)) magnitude factor (scale = 128 / 32)
+    "su_long": dict(_VARIANT_BASE, seed=35, rotary_su=(_SU_LONG, _SU_SHORT, 32, 128)),
+    # ... within the original context -> short factors, no magnitude factor
+    "su_short": dict(_VARIANT_BASE, seed=36, rotary_su=(_SU_LONG, _SU_SHORT, 4096, 4096)),
+}
+LAYER_VARIANT_CASE = {"data_seed": 41, "batch": 4, "prompt_len": 7, "max_len": 10}

@@ -510,7 +510,7 @@ def test_cpp_api_translator(gpu):
     want = t.translate_batch([GC.AREN_SOURCES[0]], beam_size=2, return_scores=True)[0]
     assert abs(float(score) - want.scores[0]) < 1e-4
     rc, out, err = _cppapi.run("reject", model)
-    assert rc == 0 and "return_attention" in out, (out, err)
+    assert rc == 0 and "replace_unknowns" in out, (out, err)
     # Translator::score_batch through the C++ surface == the Python surface
     src, tgt = GC.AREN_SOURCES[0], ["a", "t", "z", "m", "o", "n"]
     rc, out, err = _cppapi.run("score", model, len(src), *(src + tgt))
