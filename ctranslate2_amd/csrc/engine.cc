@@ -1646,6 +1646,8 @@ void Engine::encode_features(DecodeState& st, const float* features, int64_t fra
   float* col1 = alloc<float>(st, B * frames * C * 3);
   float* h1 = alloc<float>(st, B * frames * enc_.conv1.n);
   float* col2 = alloc<float>(st, B * S * enc_.conv2.k);
+  // int32 accumulators of an int8 convolution (the larger of the two outputs)
+  float* conv_acc = enc_.conv1.quantized ? alloc<float>(st, B * frames * enc_.conv1.n) : nullptr;
   CT2X_HIP_CHECK(hipMemcpyAsync(d_feat, features, sizeof(float) * B * C * frames,
                                 hipMemcpyHostToDevice, cur_stream()));
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // `lens` and the caller's features may go away
@@ -1655,10 +1657,20 @@ void Engine::encode_features(DecodeState& st, const float* features, int64_t fra
       begin_kernel("quantize_s8", double(rows) * w.k * 5 + rows * 4, 0, rows, 0, w.k);
       launch_quantize_s8(cols, rows, w.k, /*round before cast, no u8 shift*/ 1, st.qbuf, st.qscale, cur_stream());
       end_kernel();
-      QuantIn q;
-      q.q = st.qbuf;
-      q.s = st.qscale;
-      dense(w, nullptr, &q, rows, kGelu, nullptr, y, &st);
+      // exact int32 product, then the reference's convolution form of Dequantize (weight scale as
+      // the reciprocal factor, input scale as the divisor: conv_dequantize_kernel), bias, GELU
+      int32_t* acc = reinterpret_cast<int32_t*>(conv_acc);
+      GemmS8Epilogue ep;
+      ep.mode = 0;
+      ep.c_i32 = acc;
+      ep.ldy = w.n;
+      begin_kernel("gemm_s8s8s32", double(rows) * w.k + double(w.n) * w.k + 4.0 * rows * w.n,
+                   2.0 * rows * w.n * w.k, rows, w.n, w.k);
+      launch_gemm_s8(st.qbuf, w.wq, rows, w.n, w.k, ep, cur_stream());
+      end_kernel();
+      begin_kernel("conv_dequantize", double(rows) * w.n * 8, 0, rows, w.n, 0);
+      launch_conv_dequantize(acc, st.qscale, w.wscale, w.bias, rows, w.n, kGelu, y, cur_stream());
+      end_kernel();
     } else {
       dense(w, cols, nullptr, rows, kGelu, nullptr, y, &st);
     }

@@ -548,4 +548,9 @@ void launch_gather_softmax(const float* logits, int64_t rows, int64_t vocab, con
 void launch_align_softmax(const float* scores, int64_t n_sel, int64_t tq, int64_t tk, int64_t length,
                           int64_t rows_out, int64_t frames, float* out, hipStream_t stream);
 
+// int32 product of an int8 convolution -> y = act((c * (1 / w_scale[col])) / x_scale[row] + bias)
+void launch_conv_dequantize(const int32_t* c, const float* x_scale, const float* w_scale,
+                            const float* bias, int64_t rows, int64_t n, int act, float* y,
+                            hipStream_t stream);
+
 }  // namespace ct2x

@@ -334,4 +334,31 @@ void launch_align_softmax(const float* scores, int64_t n_sel, int64_t tq, int64_
                      tk, length, rows_out, frames, out);
 }
 
+// Dequantize of the int8 convolution as the reference's CPU path evaluates it: its GEMM is
+// weight x im2col^T, so the WEIGHT scale is the row scale of cpu::dequantize_gemm_output
+// (src/cpu/kernels.cc:653-685: multiplied in as a reciprocal) and the input row's scale the
+// column scale (divided by) - the other way round from a Dense. Then bias and activation
+// (apply_bias_and_activation, src/ops/gemm.cc:11-25). c [rows, n] int32 -> y [rows, n].
+__global__ void conv_dequantize_kernel(const int32_t* __restrict__ c, const float* __restrict__ x_scale,
+                                       const float* __restrict__ w_scale,
+                                       const float* __restrict__ bias, int64_t n, int act,
+                                       int64_t total, float* __restrict__ y) {
+  const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (e >= total) return;
+  const int64_t row = e / n, col = e % n;
+  float v = static_cast<float>(c[e]) * (1.f / w_scale[col]);
+  v = v / x_scale[row];
+  if (bias) v = v + bias[col];
+  y[e] = act >= 0 ? apply_activation(v, act) : v;
+}
+
+void launch_conv_dequantize(const int32_t* c, const float* x_scale, const float* w_scale,
+                            const float* bias, int64_t rows, int64_t n, int act, float* y,
+                            hipStream_t stream) {
+  const int64_t total = rows * n;
+  if (total == 0) return;
+  hipLaunchKernelGGL(conv_dequantize_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
+                     dim3(256), 0, stream, c, x_scale, w_scale, bias, n, act, total, y);
+}
+
 }  // namespace ct2x

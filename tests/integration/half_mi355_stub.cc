@@ -218,6 +218,18 @@ namespace ctranslate2 {
                                       bool transpose_b, dim_t m, dim_t n, dim_t k, float alpha,     \
                                       const T* a, dim_t lda, const T* b, dim_t ldb, float beta,     \
                                       T* c, dim_t ldc, const T*) {                                  \
+    if (!transpose_a && transpose_b && lda == k && ldb == k && ldc == n && beta == 0 &&             \
+        alpha == 1.f && k % 8 == 0) {                                                               \
+      /* the layers::Dense layout (weight [n, k]): the 16-bit weight goes to the matrix cores as    \
+         it is (MFMA, fp32 accumulation, src/cuda/primitives.cu:519-569); the activation was 16-bit \
+         already, so its round trip through fp32 loses nothing */                                   \
+      In32<T> fa(a, m * lda);                                                                       \
+      Out32<T> fc(c, m * ldc);                                                                      \
+      check16(ct2x_gemm_f16w(fa.get(), b, Ct2xType<T>::value, m, n, k, nullptr, nullptr, -1,        \
+                             fc.get(), stream16()));                                                \
+      fc.commit();                                                                                  \
+      return;                                                                                       \
+    }                                                                                               \
     In32<T> fa(a, (transpose_a ? k : m) * lda), fb(b, (transpose_b ? n : k) * ldb);                 \
     Out32<T> fc(c, m * ldc);                                                                        \
     if (beta != 0)                                                                                  \
