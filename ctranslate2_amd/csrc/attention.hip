@@ -398,6 +398,10 @@ void launch_attention_decode_quantized(const AttnDecodeParams& p, int quant_mode
 // valid = min(length[b], q + 1) when causal.
 void launch_attention_full(const AttnFullParams& f, hipStream_t stream) {
   if (f.batch * f.tq == 0) return;
+  if (f.allow_inexact && attention_prefill_applicable(f)) {
+    launch_attention_prefill(f, stream);
+    return;
+  }
   if (attention_exact_full_applicable(f)) {
     launch_attention_exact_full(f, stream);  // bit-exact vs the CPU reference (K / V of a head in LDS)
     return;

@@ -334,8 +334,17 @@ int ct2x_gemm_f16w(const float* d_a, const void* d_w, int w_dtype, int64_t m, in
   API_TRY
   CT2X_CHECK(w_dtype == CT2X_F16 || w_dtype == CT2X_BF16,
              "ct2x_gemm_f16w: the weight type must be CT2X_F16 or CT2X_BF16");
+  // decode rows: K slices over workgroups need a partial-sum workspace (the engine owns one per
+  // session; here it comes from the stream-ordered allocator for the duration of the launch)
+  float* ws = nullptr;
+  size_t ws_floats = 0;
+  if (m <= 128 && m > 0 && n > 0) {
+    ws_floats = static_cast<size_t>(8) * m * n;
+    ws = static_cast<float*>(device_malloc(ws_floats * sizeof(float)));
+  }
   launch_gemm_h(d_a, d_w, w_dtype == CT2X_BF16, m, n, k, d_bias, d_residual, activation, d_c,
-                resolve_stream(stream));
+                resolve_stream(stream), ws, ws_floats);
+  if (ws) device_free(ws);
   check_last_launch("gemm_f16w");
   API_CATCH
 }

@@ -1484,6 +1484,10 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     // split-K partials of the 16-bit GEMM at a few hundred decode rows (beam search on large
     // batches): session owned, so a captured step never allocates
     st->splitk_floats = static_cast<size_t>(16) * rows * std::max(std::max(d, wffn), wqkv);
+    // (the vocabulary projection of a few rows: K slices of 512 over workgroups, gemm_h_rows_kernel)
+    if (rows <= 64)
+      st->splitk_floats = std::max(st->splitk_floats,
+                                   static_cast<size_t>((d + 511) / 512) * rows * static_cast<size_t>(V));
     st->splitk_ws = alloc<float>(*st, static_cast<int64_t>(st->splitk_floats));
   }
   st->logits = alloc<float>(*st, rows * V);
@@ -1737,6 +1741,7 @@ void Engine::encode_layers(DecodeState& st, float* x, float* y) {
     f.heads_kv = a.heads_kv;
     f.dhead = a.dhead;
     f.causal = false;
+    f.allow_inexact = half_compute();
     f.scale = a.queries_scale;
     f.out = st.ctx;
     begin_kernel("attention_encoder", 0, 0, rows, a.heads, a.dhead);
@@ -1997,6 +2002,7 @@ void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time, float*
     f.heads_kv = a.heads_kv;
     f.dhead = a.dhead;
     f.causal = true;
+    f.allow_inexact = half_compute();
     f.q_offset = 0;
     f.scale = a.queries_scale;
     f.out = st.ctx;
@@ -2064,6 +2070,7 @@ void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time, float*
         f.heads_kv = c.heads_kv;
         f.dhead = c.dhead;
         f.causal = false;
+        f.allow_inexact = half_compute();
         f.scale = c.queries_scale;
         f.out = st.ctx + j * time * qdim;
         f.out_batch_stride = st.beam * time * qdim;

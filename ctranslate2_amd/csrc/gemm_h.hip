@@ -19,6 +19,8 @@
 #include "kernels.h"
 #include "runtime.h"
 
+#include <cstdlib>
+
 namespace ct2x {
 
 namespace {
@@ -96,11 +98,18 @@ __device__ __forceinline__ float finish(float v, float bias, bool has_bias, int 
 // w, w + WAVES, ...; A fragments are read as fp32 (2 x 16 bytes per lane) and converted, W
 // fragments are 16 bytes per lane straight from memory; fp32 partial tiles are summed through LDS
 // in wave order (deterministic).
+// Split K over workgroups (gridDim.y > 1): slice z = blockIdx.y covers K elements
+// [z * k_slice, (z + 1) * k_slice) and stores its fp32 partial tile to partial[z][M][N];
+// gemm_h_splitk_reduce_kernel adds the slices in z order and applies the epilogue. A 40-row decode
+// step of the Whisper-large-v3 shape (N = K = 1280) is otherwise 80 workgroups whose waves walk
+// their K-steps through five dependent memory round trips (25.6 us per launch = 0.27 TB/s,
+// profiles/r03_whisper_kernel_stats_a.csv).
 template <bool kBF16, int MT, int NT, int WAVES, int U>
 __global__ __launch_bounds__(WAVES * 64) void gemm_h_skinny_kernel(const float* __restrict__ A,
                                                                    const uint16_t* __restrict__ W,
                                                                    int M, int N, int K,
-                                                                   HalfEpilogue ep) {
+                                                                   HalfEpilogue ep, int k_slice,
+                                                                   float* __restrict__ partial_out) {
   using Ops = HalfOps<kBF16>;
   using vec = typename Ops::vec;
   __shared__ float partial[WAVES][MT][NT][64][4];
@@ -111,7 +120,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_h_skinny_kernel(const float* 
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int64_t n0 = static_cast<int64_t>(blockIdx.x) * (NT * 16);
-  const int ksteps = (K + 31) / 32;
+  // this workgroup's K range, in 32-element steps (k_slice is a multiple of 32)
+  const int ks_begin = static_cast<int>(blockIdx.y) * (k_slice / 32);
+  const int ksteps = min((K + 31) / 32, ks_begin + k_slice / 32);
 
   float e_bias[OPT], e_res[OPT];
 #pragma unroll
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_h_skinny_kernel(const float* 
     const int row = (tile / NT) * 16 + (within >> 4);
     const int64_t col = n0 + (tile % NT) * 16 + (within & 15);
     e_bias[o] = e_res[o] = 0.f;
-    if (flat < OUTS && row < M && col < N) {
+    if (partial_out == nullptr && flat < OUTS && row < M && col < N) {
       if (ep.bias) e_bias[o] = ep.bias[col];
       if (ep.residual) e_res[o] = ep.residual[static_cast<int64_t>(row) * N + col];
     }
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_h_skinny_kernel(const float* 
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
-  for (int ks0 = wave; ks0 < ksteps; ks0 += WAVES * U) {
+  for (int ks0 = ks_begin + wave; ks0 < ksteps; ks0 += WAVES * U) {
     float4 alo[U][MT], ahi[U][MT];
     vec bf[U][NT];
 #pragma unroll
@@ -201,9 +212,116 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_h_skinny_kernel(const float* 
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) sum += partial[w][i][j][src_lane][rt & 3];
     if (row >= M || col >= N) continue;
-    ep.y[static_cast<int64_t>(row) * N + col] =
-        finish(sum, e_bias[o], ep.bias != nullptr, ep.act, e_res[o], ep.residual != nullptr);
+    if (partial_out != nullptr)
+      partial_out[(static_cast<int64_t>(blockIdx.y) * M + row) * N + col] = sum;
+    else
+      ep.y[static_cast<int64_t>(row) * N + col] =
+          finish(sum, e_bias[o], ep.bias != nullptr, ep.act, e_res[o], ep.residual != nullptr);
   }
+}
+
+// ---- row-staged form (decode rows, M <= 64) -----------------------------------------------------
+// The skinny form above re-reads the whole fp32 activation from L2 for every 16 output columns
+// (Whisper-large-v3 decode, 40 rows: 16 MB of activation reads for a 3.3 MB weight) and sums its
+// waves' K-step partials through LDS. Here a workgroup owns 64 output columns x one K slice of at
+// most 512 elements: the activation slice is converted to the 16-bit type ONCE on its way into
+// LDS (float16: hi and lo halves, see split_f16), every wave owns 16 columns for the whole slice -
+// all its weight fragments (16 x 16 bytes per lane) are requested before the first LDS access, so
+// the launch is one memory round trip deep - and no cross-wave reduction is needed. K slices
+// (gridDim.y) go through partial[z][M][N] and gemm_h_splitk_reduce_kernel as above.
+constexpr int kRowsKSlice = 512;  // K elements per workgroup
+template <bool kBF16, int MT>
+__global__ __launch_bounds__(256) void gemm_h_rows_kernel(const float* __restrict__ A,
+                                                          const uint16_t* __restrict__ W, int M,
+                                                          int N, int K, HalfEpilogue ep,
+                                                          float* __restrict__ partial_out) {
+  using Ops = HalfOps<kBF16>;
+  using vec = typename Ops::vec;
+  extern __shared__ __attribute__((aligned(16))) uint8_t rows_lds[];
+  constexpr int ROWS = MT * 16;
+  constexpr int KSTEPS = kRowsKSlice / 32;
+  constexpr int STRIDE = kRowsKSlice * 2 + 16;  // bytes per LDS row: 260 dwords, rows 4 banks apart
+  uint8_t* a_hi = rows_lds;
+  uint8_t* a_lo = rows_lds + ROWS * STRIDE;  // float16 only
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * 64 + wave * 16;
+  const int k0 = static_cast<int>(blockIdx.y) * kRowsKSlice;
+  const int kn = min(kRowsKSlice, K - k0);  // a multiple of 8 (K % 8 == 0)
+
+  // weight fragments of this wave's 16 columns over the whole slice: requested first
+  vec wf[KSTEPS];
+  {
+    const int64_t col = n0 + r;
+    const uint16_t* wrow = W + col * K + k0;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int kk = ks * 32 + g * 8;
+      vec z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = 0;
+      wf[ks] = (kk < kn && col < N) ? *reinterpret_cast<const vec*>(wrow + kk) : z;
+    }
+  }
+  // activation slice -> LDS in the 16-bit type (rows >= M and columns >= kn are zero)
+  constexpr int CHUNKS = kRowsKSlice / 8;  // 8-element chunks per row
+  for (int c = tid; c < ROWS * CHUNKS; c += 256) {
+    const int row = c / CHUNKS, kk = (c % CHUNKS) * 8;
+    float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+    if (row < M && kk < kn) {
+      const float4* p = reinterpret_cast<const float4*>(A + static_cast<int64_t>(row) * K + k0 + kk);
+      x0 = p[0];
+      x1 = p[1];
+    }
+    if constexpr (!kBF16) {
+      v8h hi, lo;
+      split_f16(x0, x1, hi, lo);
+      *reinterpret_cast<v8h*>(a_hi + row * STRIDE + kk * 2) = hi;
+      *reinterpret_cast<v8h*>(a_lo + row * STRIDE + kk * 2) = lo;
+    } else {
+      *reinterpret_cast<vec*>(a_hi + row * STRIDE + kk * 2) = Ops::from_f32(x0, x1);
+    }
+  }
+  __syncthreads();
+
+  v4f acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+  const int ksteps = (kn + 31) / 32;
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    if (ks < ksteps) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int off = (i * 16 + r) * STRIDE + (ks * 32 + g * 8) * 2;
+        if constexpr (!kBF16) {
+          const v8h lo = *reinterpret_cast<const v8h*>(a_lo + off);
+          const v8h hi = *reinterpret_cast<const v8h*>(a_hi + off);
+          acc[i] = Ops::mfma(lo, wf[ks], acc[i]);
+          acc[i] = Ops::mfma(hi, wf[ks], acc[i]);
+        } else {
+          acc[i] = Ops::mfma(*reinterpret_cast<const vec*>(a_hi + off), wf[ks], acc[i]);
+        }
+      }
+    }
+  }
+  // MFMA C layout: column = lane & 15, row = 4 * (lane >> 4) + register
+  const int64_t col = n0 + r;
+  if (col >= N) return;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = i * 16 + g * 4 + e;
+      if (row >= M) continue;
+      const int64_t idx = static_cast<int64_t>(row) * N + col;
+      if (partial_out != nullptr)
+        partial_out[static_cast<int64_t>(blockIdx.y) * M * N + idx] = acc[i][e];
+      else
+        ep.y[idx] = finish(acc[i][e], ep.bias ? ep.bias[col] : 0.f, ep.bias != nullptr, ep.act,
+                           ep.residual ? ep.residual[idx] : 0.f, ep.residual != nullptr);
+    }
 }
 
 // ---- LDS-tiled form (encoder / prefill rows) ------------------------------------------------
@@ -380,15 +498,68 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
                   hipStream_t stream, float* splitk_ws, size_t splitk_floats) {
 #define CT2X_HSKINNY(MT, NT, WAVES, U)                                                       \
   hipLaunchKernelGGL((gemm_h_skinny_kernel<kBF16, MT, NT, WAVES, U>),                        \
-                     dim3((N + 16 * NT - 1) / (16 * NT)), dim3(WAVES * 64), 0, stream, a, w, M, N, \
-                     K, ep)
+                     dim3((N + 16 * NT - 1) / (16 * NT), sk), dim3(WAVES * 64), 0, stream, a, w, M, \
+                     N, K, ep, sk > 1 ? K / sk : ((K + 31) / 32) * 32,                             \
+                     sk > 1 ? splitk_ws : static_cast<float*>(nullptr))
   if (M <= 128) {
     const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 64 ? 4 : 8));
     const bool wide = N >= 8192;
-    if (mt == 1) { if (wide) CT2X_HSKINNY(1, 4, 4, 2); else CT2X_HSKINNY(1, 1, 4, 4); }
-    else if (mt == 2) { if (wide) CT2X_HSKINNY(2, 4, 4, 2); else CT2X_HSKINNY(2, 1, 4, 4); }
-    else if (mt == 4) { if (wide) CT2X_HSKINNY(4, 2, 4, 2); else CT2X_HSKINNY(4, 1, 4, 2); }
-    else { if (wide) CT2X_HSKINNY(8, 2, 4, 1); else CT2X_HSKINNY(8, 1, 4, 2); }
+    // K slices over workgroups: enough of them to cover the chip twice, at most two rounds of
+    // K-steps per wave (8 waves x U = 2 x 32 elements = 512 per round), whole 32-element steps
+    static const int variant = [] {
+      const char* e = std::getenv("CT2X_HSKINNY_VARIANT");
+      return e ? std::atoi(e) : 2;
+    }();
+    if (variant >= 2 && M <= 64 && K >= 256) {
+      // row-staged form: 64 columns x one K slice per workgroup
+      const int slices = (K + kRowsKSlice - 1) / kRowsKSlice;
+      if (slices == 1 || (splitk_ws != nullptr &&
+                          static_cast<size_t>(slices) * M * N <= splitk_floats)) {
+        float* part = slices > 1 ? splitk_ws : nullptr;
+        const dim3 grid((N + 63) / 64, slices);
+#define CT2X_HROWS(MT)                                                                          \
+  do {                                                                                          \
+    const size_t lds = static_cast<size_t>(MT) * 16 * (kRowsKSlice * 2 + 16) * (kBF16 ? 1 : 2);  \
+    allow_big_lds(reinterpret_cast<const void*>(gemm_h_rows_kernel<kBF16, MT>), lds);           \
+    hipLaunchKernelGGL((gemm_h_rows_kernel<kBF16, MT>), grid, dim3(256), lds, stream, a, w, M, N, \
+                       K, ep, part);                                                            \
+  } while (0)
+        if (mt == 1) CT2X_HROWS(1);
+        else if (mt == 2) CT2X_HROWS(2);
+        else CT2X_HROWS(4);
+#undef CT2X_HROWS
+        if (slices > 1) {
+          const int64_t total = static_cast<int64_t>(M) * N;
+          hipLaunchKernelGGL(gemm_h_splitk_reduce_kernel,
+                             dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, stream,
+                             splitk_ws, slices, static_cast<int64_t>(N), total, ep);
+        }
+        return;
+      }
+    }
+    int sk = 1;
+    if (variant != 0 && splitk_ws != nullptr && !wide) {
+      const int col_tiles = (N + 15) / 16;
+      while (sk < 8 && col_tiles * sk < 512 && K / (sk * 2) >= 512 && (K / (sk * 2)) % 32 == 0 &&
+             static_cast<size_t>(sk) * 2 * M * N <= splitk_floats)
+        sk *= 2;
+    }
+    if (variant == 0) {
+      if (mt == 1) { if (wide) CT2X_HSKINNY(1, 4, 4, 2); else CT2X_HSKINNY(1, 1, 4, 4); }
+      else if (mt == 2) { if (wide) CT2X_HSKINNY(2, 4, 4, 2); else CT2X_HSKINNY(2, 1, 4, 4); }
+      else if (mt == 4) { if (wide) CT2X_HSKINNY(4, 2, 4, 2); else CT2X_HSKINNY(4, 1, 4, 2); }
+      else { if (wide) CT2X_HSKINNY(8, 2, 4, 1); else CT2X_HSKINNY(8, 1, 4, 2); }
+    } else {
+      if (mt == 1) { if (wide) CT2X_HSKINNY(1, 4, 4, 2); else CT2X_HSKINNY(1, 1, 8, 4); }
+      else if (mt == 2) { if (wide) CT2X_HSKINNY(2, 4, 4, 2); else CT2X_HSKINNY(2, 1, 8, 4); }
+      else if (mt == 4) { if (wide) CT2X_HSKINNY(4, 2, 4, 2); else CT2X_HSKINNY(4, 1, 8, 2); }
+      else { if (wide) CT2X_HSKINNY(8, 2, 4, 1); else CT2X_HSKINNY(8, 1, 4, 2); }
+    }
+    if (sk > 1) {
+      const int64_t total = static_cast<int64_t>(M) * N;
+      hipLaunchKernelGGL(gemm_h_splitk_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
+                         dim3(256), 0, stream, splitk_ws, sk, static_cast<int64_t>(N), total, ep);
+    }
     return;
   }
 #undef CT2X_HSKINNY

@@ -315,6 +315,9 @@ struct AttnFullParams {
   float scale = 1.f;
   float* out = nullptr;  // [B, Tq, H*dh]
   int64_t out_batch_stride = 0, out_time_stride = 0;
+  // 16-bit compute types: no CPU order to reproduce - skip the exact-order kernels (which
+  // materialise the scores) for the tiled fp32-MFMA one
+  bool allow_inexact = false;
 };
 
 void launch_attention_full(const AttnFullParams& p, hipStream_t stream);

@@ -225,7 +225,10 @@ def _from_bf16_bits(b):
 
 
 @pytest.mark.parametrize("m,n,k", [(32, 1536, 512), (16, 14336, 4096), (128, 2048, 512), (5, 43, 40),
-                                   (1000, 777, 264), (2048, 512, 2048)])
+                                   (1000, 777, 264), (2048, 512, 2048),
+                                   # decode rows with K slices over workgroups (2 / 8 / 8 / 4 / 4 slices)
+                                   (40, 1280, 1280), (40, 1280, 5120), (16, 4096, 4096),
+                                   (64, 2048, 2048), (33, 1000, 2048)])
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("act,with_res", [(-1, True), (0, False)])
 def test_gemm_half_weights(gpu, m, n, k, bf16, act, with_res):

@@ -93,12 +93,12 @@ def compare(res, want_json, want_encode, exact_tokens, enc_atol, label):
     return differing
 
 
-@pytest.mark.parametrize("quant,compute,exact", [("float32", "float32", True), ("int8", "int8", False)])
+@pytest.mark.parametrize("quant,compute,exact", [("float32", "float32", True), ("int8", "int8", True)])
 def test_whisper_fused_engine_matches_the_reference_cpu(gpu, golden, quant, compute, exact):
-    """Level 2. float32: every token, language ranking and DTW path identical, scores /
-    probabilities within 2e-3. int8: the CPU reference quantises the im2col rows of its
-    convolutions and so does this backend (same integers); (c / w_scale) / x_scale is evaluated
-    in the other order by the shared Dense epilogue, so a few hypotheses may differ."""
+    """Level 2, float32 and int8: encoder output bit for bit, every token, language ranking and DTW
+    path identical, scores / probabilities within 2e-3. int8: the CPU reference quantises the im2col
+    rows of its convolutions and so does this backend (same integers, then the convolution's
+    operand order of Dequantize: conv_dequantize_kernel)."""
     j, z = golden
     path = WC.build("/tmp/ct2x_whisper_%s" % quant, quant)
     w, close = product_whisper(path, compute)
@@ -108,7 +108,7 @@ def test_whisper_fused_engine_matches_the_reference_cpu(gpu, golden, quant, comp
         res = WC.run_cases(w)
     finally:
         close()
-    compare(res, j[quant], z[quant + ".encode"], exact, 5e-4 if exact else 0.08, "Level-2 " + quant)
+    compare(res, j[quant], z[quant + ".encode"], exact, 1e-6, "Level-2 " + quant)
 
 
 @pytest.mark.parametrize("compute", ["float16", "bfloat16"])
