@@ -1,0 +1,221 @@
+// Encoder-decoder attention of a decode step for the 16-bit compute types, d_head 64, with the
+// memory keys / values held in the compute type (float16 / bfloat16) - the first 16-bit cache of
+// this backend. MultiHeadAttention::operator() with cached memory keys
+// (src/layers/attention.cc:442-615; process_cross_attention :371-440): for every hypothesis row
+//   softmax(q . K^T * queries_scale, memory_lengths) . V.
+//
+// At the Whisper-large-v3 shape (1500 memory positions, 20 heads, beam 5, 8 windows) the fp32 memory
+// K/V is 123 MB per layer and 3.9 GB per decode step - more than the 1.7 GB of bfloat16 weights -
+// and the per-(row, head) kernel reads it once per hypothesis row. Here ONE workgroup owns a
+// (batch entry, head): the `beam` hypothesis rows of the entry share every key and value it reads
+// (5x fewer L2 reads), and the bytes are halved.
+//   scores   thread = key: the 128-byte key row is eight 16-byte loads (one cache line), dot
+//            products against all hypothesis queries (LDS broadcasts), scores parked in LDS;
+//   softmax  block max / sum per hypothesis, exp(x - max) as in src/cpu/kernels.cc:452-455,
+//            normalisation folded into the output;
+//   context  a wave takes tiles of 8 keys: 8 lanes per value row (16 bytes = 8 channels each),
+//            probabilities from LDS, partial sums over the lane's keys in registers, then a
+//            3-step butterfly over the 8 key lanes and a 4-wave sum through LDS.
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "device_utils.h"
+#include "kernels.h"
+#include "runtime.h"
+
+namespace ct2x {
+
+namespace {
+
+constexpr int kXhMaxBeam = 8;
+
+template <bool kBF16>
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (kBF16) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    } else {
+      const _Float16 lo = __builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] & 0xffffu));
+      const _Float16 hi = __builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] >> 16));
+      f[2 * i] = static_cast<float>(lo);
+      f[2 * i + 1] = static_cast<float>(hi);
+    }
+  }
+}
+
+template <bool kBF16>
+__global__ __launch_bounds__(256) void xattn_h_kernel(CrossAttnHParams p) {
+  extern __shared__ __attribute__((aligned(16))) float xh_lds[];
+  __shared__ float scratch[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / static_cast<int>(p.heads);
+  const int h = blockIdx.x % static_cast<int>(p.heads);
+  const int hk = h / static_cast<int>(p.heads / p.heads_kv);
+  const int beam = static_cast<int>(p.beam);
+  const int S = static_cast<int>(p.s_max);
+  const int s_pad = (S + 7) & ~7;
+  int length = p.lengths ? p.lengths[b] : S;
+  length = length < 0 ? 0 : (length > S ? S : length);
+
+  float* q_s = xh_lds;                               // [kXhMaxBeam][64]
+  float* probs = q_s + kXhMaxBeam * 64;              // [beam][s_pad]
+  float* part = probs + kXhMaxBeam * s_pad;          // [4 waves][kXhMaxBeam][64]
+
+  for (int e = tid; e < beam * 64; e += 256) {
+    const int j = e >> 6, c = e & 63;
+    const int64_t row = static_cast<int64_t>(b) * beam + j;
+    q_s[j * 64 + c] = p.q[row * p.q_row_stride + static_cast<int64_t>(h) * 64 + c] * p.scale;
+  }
+  __syncthreads();
+
+  const int64_t kv_time = 2 * p.heads_kv * 64;       // elements per memory position
+  const uint16_t* kbase = p.kv + static_cast<int64_t>(b) * S * kv_time + static_cast<int64_t>(hk) * 64;
+  const uint16_t* vbase = kbase + p.heads_kv * 64;
+
+  // ---- scores -------------------------------------------------------------------------------
+  float mx[kXhMaxBeam];
+#pragma unroll
+  for (int j = 0; j < kXhMaxBeam; ++j) mx[j] = -FLT_MAX;
+  for (int s = tid; s < s_pad; s += 256) {
+    float sc[kXhMaxBeam];
+#pragma unroll
+    for (int j = 0; j < kXhMaxBeam; ++j) sc[j] = 0.f;
+    if (s < length) {
+      const uint4* kr = reinterpret_cast<const uint4*>(kbase + static_cast<int64_t>(s) * kv_time);
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) {
+        float kf[8];
+        unpack8<kBF16>(kr[c8], kf);
+#pragma unroll
+        for (int j = 0; j < kXhMaxBeam; ++j) {
+          if (j < beam) {
+            const float4 qa = *reinterpret_cast<const float4*>(q_s + j * 64 + c8 * 8);
+            const float4 qb = *reinterpret_cast<const float4*>(q_s + j * 64 + c8 * 8 + 4);
+            sc[j] += kf[0] * qa.x + kf[1] * qa.y + kf[2] * qa.z + kf[3] * qa.w + kf[4] * qb.x +
+                     kf[5] * qb.y + kf[6] * qb.z + kf[7] * qb.w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kXhMaxBeam; ++j) {
+      if (j < beam) {
+        const float v = s < length ? sc[j] : -FLT_MAX;
+        probs[j * s_pad + s] = v;
+        mx[j] = fmaxf(mx[j], v);
+      }
+    }
+  }
+  // ---- softmax ------------------------------------------------------------------------------
+  float inv_sum[kXhMaxBeam];
+#pragma unroll
+  for (int j = 0; j < kXhMaxBeam; ++j) {
+    inv_sum[j] = 0.f;
+    if (j < beam) {
+      const float m = block_max(mx[j], scratch);  // (also orders the score stores before the reads)
+      float part_sum = 0.f;
+      for (int s = tid; s < s_pad; s += 256) {
+        const float x = probs[j * s_pad + s];
+        const float e = s < length ? expf(x - m) : 0.f;
+        probs[j * s_pad + s] = e;
+        part_sum += e;
+      }
+      const float tot = block_sum(part_sum, scratch);
+      inv_sum[j] = tot > 0.f ? 1.f / tot : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- context --------------------------------------------------------------------------------
+  const int kr = lane >> 3, cg = lane & 7;  // key within the tile, channel group of 8
+  float acc[kXhMaxBeam][8];
+#pragma unroll
+  for (int j = 0; j < kXhMaxBeam; ++j)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[j][c] = 0.f;
+  const int tiles = s_pad >> 3;
+  for (int t = wave; t < tiles; t += 4) {
+    const int s = t * 8 + kr;
+    if (s < length) {
+      const uint4 u = *reinterpret_cast<const uint4*>(vbase + static_cast<int64_t>(s) * kv_time + cg * 8);
+      float vf[8];
+      unpack8<kBF16>(u, vf);
+#pragma unroll
+      for (int j = 0; j < kXhMaxBeam; ++j) {
+        if (j < beam) {
+          const float pj = probs[j * s_pad + s];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[j][c] += pj * vf[c];
+        }
+      }
+    }
+  }
+  // sum over the 8 key lanes of a channel group (lane bits 3, 4, 5)
+#pragma unroll
+  for (int j = 0; j < kXhMaxBeam; ++j) {
+    if (j < beam) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float v = acc[j][c];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[j][c] = v;
+      }
+      if (kr == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) part[(wave * kXhMaxBeam + j) * 64 + cg * 8 + c] = acc[j][c];
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < beam * 64; e += 256) {
+    const int j = e >> 6, c = e & 63;
+    float v = part[(0 * kXhMaxBeam + j) * 64 + c];
+    v += part[(1 * kXhMaxBeam + j) * 64 + c];
+    v += part[(2 * kXhMaxBeam + j) * 64 + c];
+    v += part[(3 * kXhMaxBeam + j) * 64 + c];
+    // inv_sum lives in registers of every thread (block reductions return the same value to all)
+    float inv = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < kXhMaxBeam; ++jj)
+      if (jj == j) inv = inv_sum[jj];
+    const int64_t row = static_cast<int64_t>(b) * beam + j;
+    p.out[row * p.out_row_stride + static_cast<int64_t>(h) * 64 + c] = v * inv;
+  }
+}
+
+size_t xattn_h_lds_bytes(int64_t s_max) {
+  const int64_t s_pad = (s_max + 7) & ~static_cast<int64_t>(7);
+  return static_cast<size_t>(kXhMaxBeam * 64 + kXhMaxBeam * s_pad + 4 * kXhMaxBeam * 64) * sizeof(float);
+}
+
+}  // namespace
+
+bool cross_attention_h_applicable(const CrossAttnHParams& p) {
+  return p.dhead == 64 && p.beam >= 1 && p.beam <= kXhMaxBeam && p.heads_kv >= 1 &&
+         p.heads % p.heads_kv == 0 && p.s_max >= 1 && xattn_h_lds_bytes(p.s_max) <= 150 * 1024 &&
+         (reinterpret_cast<uintptr_t>(p.kv) & 15) == 0;
+}
+
+void launch_cross_attention_h(const CrossAttnHParams& p, hipStream_t stream) {
+  if (p.batch * p.heads == 0) return;
+  if (!cross_attention_h_applicable(p)) throw Error("launch_cross_attention_h: shape not supported");
+  const size_t lds = xattn_h_lds_bytes(p.s_max);
+  const dim3 grid(static_cast<unsigned>(p.batch * p.heads));
+  if (p.bf16) {
+    allow_big_lds(reinterpret_cast<const void*>(xattn_h_kernel<true>), lds);
+    hipLaunchKernelGGL(xattn_h_kernel<true>, grid, dim3(256), lds, stream, p);
+  } else {
+    allow_big_lds(reinterpret_cast<const void*>(xattn_h_kernel<false>), lds);
+    hipLaunchKernelGGL(xattn_h_kernel<false>, grid, dim3(256), lds, stream, p);
+  }
+}
+
+}  // namespace ct2x

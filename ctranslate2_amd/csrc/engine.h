@@ -516,6 +516,9 @@ struct DecodeState {
   float** d_cache_dst_alt = nullptr;
   // cross-attention K/V: per layer [batch, s_max, 2 * kv_dim] (GEMM output layout)
   std::vector<float*> cross_kv;
+  // 16-bit compute types, d_head 64: the same memory K/V in the compute type for the decode
+  // steps' encoder-decoder attention (attention_cross_h.hip); empty otherwise
+  std::vector<uint16_t*> cross_kv16;
   // history of sampled ids / scores: [t_max][rows]
   int32_t* hist_ids = nullptr;
   float* hist_scores = nullptr;

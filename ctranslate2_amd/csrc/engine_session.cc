@@ -252,6 +252,26 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       const AttnW& a = dec_.layers[l].cross;
       st->cross_kv.push_back(alloc<float>(*st, batch * s_max * a.lin[1].n));
     }
+    {
+      // a 16-bit copy of the memory K/V for the decode steps (bytes halved, one workgroup per
+      // (entry, head) shares every key / value among the entry's hypothesis rows)
+      bool ok = half_compute() && !tp_;
+      for (int l = 0; ok && l < n_layers; ++l) {
+        const AttnW& a = dec_.layers[l].cross;
+        CrossAttnHParams cp;
+        cp.kv = reinterpret_cast<const uint16_t*>(static_cast<uintptr_t>(256));
+        cp.batch = batch;
+        cp.beam = beam;
+        cp.heads = a.heads;
+        cp.heads_kv = a.heads_kv;
+        cp.dhead = a.dhead;
+        cp.s_max = s_max;
+        ok = s_max >= 1 && a.lin[1].n == 2 * a.heads_kv * a.dhead && cross_attention_h_applicable(cp);
+      }
+      if (ok)
+        for (int l = 0; l < n_layers; ++l)
+          st->cross_kv16.push_back(alloc<uint16_t>(*st, batch * s_max * dec_.layers[l].cross.lin[1].n));
+    }
     if (features)
       encode_features(*st, features, frames);
     else
@@ -432,6 +452,12 @@ void Engine::encode_layers(DecodeState& st, float* x, float* y) {
       mq.s = st.qscale;
     }
     dense(a.lin[1], x, mq.q ? &mq : nullptr, rows, -1, nullptr, st.cross_kv[l], &st);
+    if (!st.cross_kv16.empty()) {
+      const int type = compute_type_ == ComputeType::kBFloat16 ? kBF16 : kF16;  // DataType ids
+      begin_kernel("convert", double(rows) * a.lin[1].n * 6, 0, rows, a.lin[1].n, 0);
+      launch_convert(st.cross_kv[l], kF32, st.cross_kv16[l], type, rows * a.lin[1].n, cur_stream());
+      end_kernel();
+    }
   }
   check_last_launch("encode");
 }

@@ -257,6 +257,27 @@ void Engine::launch_step(DecodeState& st) {
           qin_ready = true;
         else
           dense(a.lin[2], nullptr, &cq, rows, -1, a.ln.present ? x : nullptr, y, &st);
+      } else if (!st.cross_kv16.empty()) {
+        // 16-bit memory K/V, one workgroup per (batch entry, head) for all its hypothesis rows
+        CrossAttnHParams cp;
+        cp.q = st.qkv;
+        cp.q_row_stride = a.heads * a.dhead;
+        cp.kv = st.cross_kv16[l];
+        cp.bf16 = compute_type_ == ComputeType::kBFloat16;
+        cp.lengths = st.mem_lengths;
+        cp.batch = st.batch;
+        cp.beam = st.beam;
+        cp.heads = a.heads;
+        cp.heads_kv = a.heads_kv;
+        cp.dhead = a.dhead;
+        cp.s_max = st.s_max;
+        cp.scale = a.queries_scale;
+        cp.out = st.ctx;
+        cp.out_row_stride = a.heads * a.dhead;
+        begin_kernel("attention_cross_decode_h", attn_bytes / 2, attn_ops, rows, a.heads, a.dhead);
+        launch_cross_attention_h(cp, cur_stream());
+        end_kernel();
+        dense(a.lin[2], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
       } else {
         begin_kernel("attention_cross_decode", attn_bytes, attn_ops, rows, a.heads, a.dhead);
         launch_attention_decode(p, cur_stream());

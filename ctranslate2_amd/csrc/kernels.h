@@ -556,4 +556,21 @@ void launch_conv_dequantize(const int32_t* c, const float* x_scale, const float*
                             const float* bias, int64_t rows, int64_t n, int act, float* y,
                             hipStream_t stream);
 
+// Encoder-decoder attention of a decode step over 16-bit memory keys / values (attention_cross_h.hip):
+// kv [batch, s_max, 2 * heads_kv * 64] in float16 / bfloat16 (keys, then values, per position - the
+// cross-attention K/V projection's layout), q / out fp32 rows (batch * beam hypotheses).
+struct CrossAttnHParams {
+  const float* q = nullptr;
+  int64_t q_row_stride = 0;
+  const uint16_t* kv = nullptr;
+  bool bf16 = false;
+  const int32_t* lengths = nullptr;  // [batch] valid memory positions (nullptr = s_max)
+  int64_t batch = 0, beam = 1, heads = 0, heads_kv = 0, dhead = 0, s_max = 0;
+  float scale = 1.f;
+  float* out = nullptr;
+  int64_t out_row_stride = 0;
+};
+bool cross_attention_h_applicable(const CrossAttnHParams& p);
+void launch_cross_attention_h(const CrossAttnHParams& p, hipStream_t stream);
+
 }  // namespace ct2x
