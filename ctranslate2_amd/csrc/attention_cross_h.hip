@@ -11,11 +11,11 @@
 // (5x fewer L2 reads), and the bytes are halved.
 //   scores   thread = key: the 128-byte key row is eight 16-byte loads (one cache line), dot
 //            products against all hypothesis queries (LDS broadcasts), scores parked in LDS;
-//   softmax  block max / sum per hypothesis, exp(x - max) as in src/cpu/kernels.cc:452-455,
-//            normalisation folded into the output;
-//   context  a wave takes tiles of 8 keys: 8 lanes per value row (16 bytes = 8 channels each),
-//            probabilities from LDS, partial sums over the lane's keys in registers, then a
-//            3-step butterfly over the 8 key lanes and a 4-wave sum through LDS.
+//   softmax  maxima / sums of all hypotheses in one LDS exchange each, exp(x - max) as in
+//            src/cpu/kernels.cc:452-455, normalisation folded into the output;
+//   context  a wave takes tiles of 8 keys, eight tiles in flight: 8 lanes per value row (16 bytes =
+//            8 channels each), probabilities from LDS, partial sums over the lane's keys in
+//            registers, then a 3-step butterfly over the 8 key lanes and an 8-wave sum through LDS.
 
 #include <hip/hip_runtime.h>
 
@@ -49,10 +49,14 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
   }
 }
 
+constexpr int kXhWaves = 8;          // 512 threads per workgroup
+constexpr int kXhThreads = kXhWaves * 64;
+constexpr int kXhUnroll = 8;         // value tiles in flight per wave
+
 template <bool kBF16>
-__global__ __launch_bounds__(256) void xattn_h_kernel(CrossAttnHParams p) {
+__global__ __launch_bounds__(kXhThreads) void xattn_h_kernel(CrossAttnHParams p) {
   extern __shared__ __attribute__((aligned(16))) float xh_lds[];
-  __shared__ float scratch[16];
+  __shared__ float red[kXhWaves][kXhMaxBeam];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / static_cast<int>(p.heads);
   const int h = blockIdx.x % static_cast<int>(p.heads);
@@ -64,10 +68,10 @@ __global__ __launch_bounds__(256) void xattn_h_kernel(CrossAttnHParams p) {
   length = length < 0 ? 0 : (length > S ? S : length);
 
   float* q_s = xh_lds;                               // [kXhMaxBeam][64]
-  float* probs = q_s + kXhMaxBeam * 64;              // [beam][s_pad]
-  float* part = probs + kXhMaxBeam * s_pad;          // [4 waves][kXhMaxBeam][64]
+  float* probs = q_s + kXhMaxBeam * 64;              // [kXhMaxBeam][s_pad]
+  float* part = probs + kXhMaxBeam * s_pad;          // [kXhWaves][kXhMaxBeam][64]
 
-  for (int e = tid; e < beam * 64; e += 256) {
+  for (int e = tid; e < beam * 64; e += kXhThreads) {
     const int j = e >> 6, c = e & 63;
     const int64_t row = static_cast<int64_t>(b) * beam + j;
     q_s[j * 64 + c] = p.q[row * p.q_row_stride + static_cast<int64_t>(h) * 64 + c] * p.scale;
@@ -78,20 +82,25 @@ __global__ __launch_bounds__(256) void xattn_h_kernel(CrossAttnHParams p) {
   const uint16_t* kbase = p.kv + static_cast<int64_t>(b) * S * kv_time + static_cast<int64_t>(hk) * 64;
   const uint16_t* vbase = kbase + p.heads_kv * 64;
 
-  // ---- scores -------------------------------------------------------------------------------
+  // ---- scores: thread = key (the 128-byte key row = one cache line, eight 16-byte loads in
+  // flight; measured faster than 8 lanes per key with DPP folds: 1096 vs 1015 tokens/s on the
+  // Whisper-large-v3 shape, profiles/r03_whisper_cross_kv16_ab.txt)
   float mx[kXhMaxBeam];
 #pragma unroll
   for (int j = 0; j < kXhMaxBeam; ++j) mx[j] = -FLT_MAX;
-  for (int s = tid; s < s_pad; s += 256) {
+  for (int s = tid; s < s_pad; s += kXhThreads) {
     float sc[kXhMaxBeam];
 #pragma unroll
     for (int j = 0; j < kXhMaxBeam; ++j) sc[j] = 0.f;
     if (s < length) {
       const uint4* kr = reinterpret_cast<const uint4*>(kbase + static_cast<int64_t>(s) * kv_time);
+      uint4 ku[8];
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) ku[c8] = kr[c8];
 #pragma unroll
       for (int c8 = 0; c8 < 8; ++c8) {
         float kf[8];
-        unpack8<kBF16>(kr[c8], kf);
+        unpack8<kBF16>(ku[c8], kf);
 #pragma unroll
         for (int j = 0; j < kXhMaxBeam; ++j) {
           if (j < beam) {
@@ -112,46 +121,90 @@ __global__ __launch_bounds__(256) void xattn_h_kernel(CrossAttnHParams p) {
       }
     }
   }
-  // ---- softmax ------------------------------------------------------------------------------
+  // ---- softmax: one exchange for the maxima of all hypotheses, one for the sums ----------------
+#pragma unroll
+  for (int j = 0; j < kXhMaxBeam; ++j) {
+    if (j < beam) {
+      const float v = wave_max(mx[j]);
+      if (lane == 0) red[wave][j] = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kXhMaxBeam; ++j) {
+    if (j < beam) {
+      float m = red[0][j];
+#pragma unroll
+      for (int w = 1; w < kXhWaves; ++w) m = fmaxf(m, red[w][j]);
+      mx[j] = m;
+    }
+  }
+  __syncthreads();  // every thread has read the maxima: `red` is reused for the sums
+  float sum[kXhMaxBeam];
+#pragma unroll
+  for (int j = 0; j < kXhMaxBeam; ++j) sum[j] = 0.f;
+  for (int s = tid; s < s_pad; s += kXhThreads) {  // (scores are visible: barrier of the exchange)
+#pragma unroll
+    for (int j = 0; j < kXhMaxBeam; ++j) {
+      if (j < beam) {
+        const float e = s < length ? expf(probs[j * s_pad + s] - mx[j]) : 0.f;
+        probs[j * s_pad + s] = e;
+        sum[j] += e;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kXhMaxBeam; ++j) {
+    if (j < beam) {
+      const float v = wave_sum(sum[j]);
+      if (lane == 0) red[wave][j] = v;
+    }
+  }
+  __syncthreads();  // sums exchanged, probabilities visible to every wave
   float inv_sum[kXhMaxBeam];
 #pragma unroll
   for (int j = 0; j < kXhMaxBeam; ++j) {
     inv_sum[j] = 0.f;
     if (j < beam) {
-      const float m = block_max(mx[j], scratch);  // (also orders the score stores before the reads)
-      float part_sum = 0.f;
-      for (int s = tid; s < s_pad; s += 256) {
-        const float x = probs[j * s_pad + s];
-        const float e = s < length ? expf(x - m) : 0.f;
-        probs[j * s_pad + s] = e;
-        part_sum += e;
-      }
-      const float tot = block_sum(part_sum, scratch);
-      inv_sum[j] = tot > 0.f ? 1.f / tot : 0.f;
+      float t = red[0][j];
+#pragma unroll
+      for (int w = 1; w < kXhWaves; ++w) t += red[w][j];
+      inv_sum[j] = t > 0.f ? 1.f / t : 0.f;
     }
   }
-  __syncthreads();
 
-  // ---- context --------------------------------------------------------------------------------
+  // ---- context: a wave takes tiles of 8 keys, kXhUnroll tiles in flight ---------------------------
   const int kr = lane >> 3, cg = lane & 7;  // key within the tile, channel group of 8
+  const int tiles = s_pad >> 3;
   float acc[kXhMaxBeam][8];
 #pragma unroll
   for (int j = 0; j < kXhMaxBeam; ++j)
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[j][c] = 0.f;
-  const int tiles = s_pad >> 3;
-  for (int t = wave; t < tiles; t += 4) {
-    const int s = t * 8 + kr;
-    if (s < length) {
-      const uint4 u = *reinterpret_cast<const uint4*>(vbase + static_cast<int64_t>(s) * kv_time + cg * 8);
-      float vf[8];
-      unpack8<kBF16>(u, vf);
+  for (int t0 = wave; t0 < tiles; t0 += kXhWaves * kXhUnroll) {
+    uint4 vu[kXhUnroll];
+    int vs[kXhUnroll];
 #pragma unroll
-      for (int j = 0; j < kXhMaxBeam; ++j) {
-        if (j < beam) {
-          const float pj = probs[j * s_pad + s];
+    for (int k = 0; k < kXhUnroll; ++k) {
+      const int t = t0 + k * kXhWaves;
+      const int s = t * 8 + kr;
+      vs[k] = (t < tiles && s < length) ? s : -1;
+      vu[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (vs[k] >= 0)
+        vu[k] = *reinterpret_cast<const uint4*>(vbase + static_cast<int64_t>(s) * kv_time + cg * 8);
+    }
 #pragma unroll
-          for (int c = 0; c < 8; ++c) acc[j][c] += pj * vf[c];
+    for (int k = 0; k < kXhUnroll; ++k) {
+      if (vs[k] >= 0) {
+        float vf[8];
+        unpack8<kBF16>(vu[k], vf);
+#pragma unroll
+        for (int j = 0; j < kXhMaxBeam; ++j) {
+          if (j < beam) {
+            const float pj = probs[j * s_pad + vs[k]];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[j][c] += pj * vf[c];
+          }
         }
       }
     }
@@ -175,13 +228,11 @@ __global__ __launch_bounds__(256) void xattn_h_kernel(CrossAttnHParams p) {
     }
   }
   __syncthreads();
-  for (int e = tid; e < beam * 64; e += 256) {
+  for (int e = tid; e < beam * 64; e += kXhThreads) {
     const int j = e >> 6, c = e & 63;
-    float v = part[(0 * kXhMaxBeam + j) * 64 + c];
-    v += part[(1 * kXhMaxBeam + j) * 64 + c];
-    v += part[(2 * kXhMaxBeam + j) * 64 + c];
-    v += part[(3 * kXhMaxBeam + j) * 64 + c];
-    // inv_sum lives in registers of every thread (block reductions return the same value to all)
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kXhWaves; ++w) v += part[(w * kXhMaxBeam + j) * 64 + c];
     float inv = 0.f;
 #pragma unroll
     for (int jj = 0; jj < kXhMaxBeam; ++jj)
@@ -193,7 +244,8 @@ __global__ __launch_bounds__(256) void xattn_h_kernel(CrossAttnHParams p) {
 
 size_t xattn_h_lds_bytes(int64_t s_max) {
   const int64_t s_pad = (s_max + 7) & ~static_cast<int64_t>(7);
-  return static_cast<size_t>(kXhMaxBeam * 64 + kXhMaxBeam * s_pad + 4 * kXhMaxBeam * 64) * sizeof(float);
+  return static_cast<size_t>(kXhMaxBeam * 64 + kXhMaxBeam * s_pad + kXhWaves * kXhMaxBeam * 64) *
+         sizeof(float);
 }
 
 }  // namespace
@@ -211,10 +263,10 @@ void launch_cross_attention_h(const CrossAttnHParams& p, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(p.batch * p.heads));
   if (p.bf16) {
     allow_big_lds(reinterpret_cast<const void*>(xattn_h_kernel<true>), lds);
-    hipLaunchKernelGGL(xattn_h_kernel<true>, grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(xattn_h_kernel<true>, grid, dim3(kXhThreads), lds, stream, p);
   } else {
     allow_big_lds(reinterpret_cast<const void*>(xattn_h_kernel<false>), lds);
-    hipLaunchKernelGGL(xattn_h_kernel<false>, grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(xattn_h_kernel<false>, grid, dim3(kXhThreads), lds, stream, p);
   }
 }
 
