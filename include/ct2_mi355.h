@@ -426,6 +426,16 @@ int ct2x_attention_decode(const float* d_q, const float* d_k_cache, const float*
                           int64_t heads_kv, int64_t dhead, int64_t t_max, int64_t kv_group,
                           float scale, float* d_out, void* stream);
 
+/* Encoder-decoder attention of one decode step over 16-bit memory keys / values (the float16 /
+ * bfloat16 compute types' memory cache, src/layers/attention.cc:371-440 + 442-615): q [batch * beam,
+ * heads * 64] fp32, kv [batch, s_max, 2 * heads_kv * 64] in kv_dtype (CT2X_F16 / CT2X_BF16; per
+ * position the keys of all heads, then the values), lengths [batch] valid positions (NULL = s_max);
+ * the beam rows of a batch entry share its memory. out [batch * beam, heads * 64] fp32. d_head 64,
+ * beam <= 8. */
+int ct2x_cross_attention_h(const float* d_q, const void* d_kv, int kv_dtype, const int32_t* d_lengths,
+                           int64_t batch, int64_t beam, int64_t heads, int64_t heads_kv,
+                           int64_t s_max, float scale, float* d_out, void* stream);
+
 /* Sequence-mode MultiHeadAttention core (src/layers/attention.cc:178-287 dot_product_attention:
  * MatMul QK^T * queries_scale -> length / causal mask -> SoftMax -> MatMul PV) for Tq > 1:
  * q [B, Tq, H*dh], k / v [B, Tk, Hkv*dh] (heads contiguous per token), lengths [B] valid keys

@@ -410,3 +410,19 @@ def attention_full(q, k, v, lengths, causal, q_offset, scale):
                                      i64(tq), i64(tk), i64(h), i64(hkv), i64(dh), C.c_int(int(causal)),
                                      i64(q_offset), C.c_float(scale), _lib.ptr(out), None))
     return host(out)
+
+
+def cross_attention_h(q, kv_bits, bf16, lengths, beam, heads_kv, scale):
+    """q [batch * beam, heads, 64] fp32, kv_bits [batch, s_max, 2, heads_kv, 64] uint16 bit patterns of
+    the 16-bit type -> [batch * beam, heads, 64]."""
+    L = _lib.lib()
+    rows, heads, dh = q.shape
+    batch, s_max = kv_bits.shape[0], kv_bits.shape[1]
+    qd = dev(q.astype(np.float32))
+    kvd = torch.from_numpy(np.ascontiguousarray(kv_bits).view(np.int16)).cuda()
+    ld = torch.from_numpy(np.ascontiguousarray(lengths, np.int32)).cuda() if lengths is not None else None
+    out = torch.empty((rows, heads, dh), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_cross_attention_h(_lib.ptr(qd), _lib.ptr(kvd), C.c_int(5 if bf16 else 4),
+                                        _lib.ptr(ld), i64(batch), i64(beam), i64(heads), i64(heads_kv),
+                                        i64(s_max), C.c_float(scale), _lib.ptr(out), None))
+    return host(out)

@@ -879,3 +879,39 @@ def test_gumbel_noise_is_exponential_and_seeded(gpu):
     assert not np.array_equal(z1, z2)  # successive calls draw fresh numbers
     _lib.check(gpu.ct2x_gumbel_noise(p(x), p(x), C.c_int64(n), C.c_uint32(7), None))  # in place
     assert abs((x - 3.0).mean().item() - 1.0) < 0.01
+
+
+@pytest.mark.parametrize("batch,beam,heads,hkv,s_max", [(3, 5, 4, 4, 1500), (2, 1, 8, 8, 37), (4, 4, 8, 2, 260),
+                                                       (1, 8, 2, 1, 8), (5, 3, 20, 20, 129)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_cross_attention_16bit_memory(gpu, batch, beam, heads, hkv, s_max, bf16):
+    """attention_cross_h.hip: the decode steps' encoder-decoder attention over float16 / bfloat16
+    memory keys and values, one workgroup per (batch entry, head) for all hypothesis rows. Oracle:
+    the same 16-bit values in float64 (softmax(q . K^T * scale, lengths) . V); what is left is the
+    fp32 evaluation order."""
+    import _gpuops as G
+    rng = np.random.default_rng(batch * 1000 + beam * 100 + heads + s_max + int(bf16))
+    q = rng.standard_normal((batch * beam, heads, 64)).astype(np.float32)
+    kv = rng.standard_normal((batch, s_max, 2, hkv, 64)).astype(np.float32)
+    lengths = rng.integers(max(1, s_max // 2), s_max + 1, batch).astype(np.int32)
+    lengths[0] = s_max
+    if bf16:
+        bits = _to_bf16_bits(kv)
+        kvr = _from_bf16_bits(bits)
+    else:
+        h16 = kv.astype(np.float16)
+        bits, kvr = h16.view(np.uint16), h16.astype(np.float32)
+    scale = 0.125
+    y = G.cross_attention_h(q, bits, bf16, lengths, beam, hkv, scale)
+    group = heads // hkv
+    ref = np.zeros_like(q, dtype=np.float64)
+    for r in range(batch * beam):
+        b = r // beam
+        n = int(lengths[b])
+        for h in range(heads):
+            k = kvr[b, :n, 0, h // group].astype(np.float64)
+            v = kvr[b, :n, 1, h // group].astype(np.float64)
+            sc = (k @ q[r, h].astype(np.float64)) * scale
+            w = np.exp(sc - sc.max())
+            ref[r, h] = (w / w.sum()) @ v
+    assert np.max(np.abs(y - ref)) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
