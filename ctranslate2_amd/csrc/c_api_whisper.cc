@@ -226,6 +226,15 @@ int ct2x_whisper_generate(void* whisper, const float* features, int32_t batch, i
   auto* w = static_cast<Whisper*>(whisper);
   CT2X_CHECK(w != nullptr && o != nullptr, "ct2x_whisper_generate: null argument");
   if (batch == 0) return 0;  // "if (prompts.empty()) return {}" (whisper.cc:239)
+  CT2X_CHECK(batch > 0 && features && prompts && prompt_lengths && out_ids && out_lengths &&
+                 max_len >= 0 && prompt_stride >= 0,
+             "ct2x_whisper_generate: null or negative argument");
+  CT2X_CHECK(o->num_suppress_tokens >= 0 && (o->num_suppress_tokens == 0 || o->suppress_tokens),
+             "ct2x_whisper_generate: suppress_tokens missing");
+  CT2X_CHECK(!o->return_scores || out_scores, "ct2x_whisper_generate: return_scores without out_scores");
+  for (int32_t b = 0; b < batch; ++b)
+    CT2X_CHECK(prompt_lengths[b] >= 0 && prompt_lengths[b] <= prompt_stride,
+               "ct2x_whisper_generate: prompt length out of range");
   std::lock_guard<std::mutex> lock(w->mutex);
   Engine& engine = *w->engine;
   check_features(*w, batch, n_mels, frames);
@@ -365,7 +374,7 @@ int ct2x_whisper_detect_language(void* whisper, const float* features, int32_t b
                                  int32_t* out_ids, float* out_probs) {
   API_TRY
   auto* w = static_cast<Whisper*>(whisper);
-  CT2X_CHECK(w != nullptr, "null whisper handle");
+  CT2X_CHECK(w != nullptr && features && out_ids && out_probs, "ct2x_whisper_detect_language: null argument");
   if (!w->is_multilingual)
     throw std::runtime_error("detect_language can only be called on multilingual models");
   std::lock_guard<std::mutex> lock(w->mutex);
@@ -416,6 +425,12 @@ int ct2x_whisper_align(void* whisper, const float* features, int32_t batch, int3
   auto* w = static_cast<Whisper*>(whisper);
   CT2X_CHECK(w != nullptr, "null whisper handle");
   if (batch == 0) return 0;
+  CT2X_CHECK(batch > 0 && features && text_tokens && text_lengths && num_frames && out_pairs &&
+                 out_num_pairs && out_token_probs && num_start >= 0 && (num_start == 0 || start_sequence),
+             "ct2x_whisper_align: null or negative argument");
+  for (int32_t b = 0; b < batch; ++b)
+    CT2X_CHECK(text_lengths[b] >= 0 && text_lengths[b] <= text_stride,
+               "ct2x_whisper_align: text length out of range");
   std::lock_guard<std::mutex> lock(w->mutex);
   Engine& engine = *w->engine;
   check_features(*w, batch, n_mels, frames);
