@@ -424,17 +424,22 @@ def build_whisper(output_dir, num_encoder_layers=2, num_decoder_layers=2, d_mode
                   num_heads=4, n_mels=8, max_source_positions=12, max_target_positions=32,
                   num_text_tokens=40, languages=("en", "fr", "de", "es"), num_timestamps=21,
                   seed=0, quantization="float32", w_std=0.08, alignment_heads=((1, 0), (1, 2), (0, 3)),
-                  direct_f16=False):
+                  direct_f16=False, awq=None):
     """WhisperSpec (python/ctranslate2/specs/whisper_spec.py): encoder = two Conv1D (kernel 3,
     padding 1, stride 1 / 2, GELU) + learned positions + pre-norm GELU encoder layers + layer_norm;
     decoder = TransformerDecoderSpec(activation=GELU) with learned positions, scale_embeddings
     False and the output projection aliased to the embeddings
     (python/ctranslate2/converters/transformers.py WhisperLoader). Whisper-large-v3 shape:
     32 + 32 layers, d_model 1280, 20 heads, ffn 5120, n_mels 128, 1500 / 448 positions,
-    51866 tokens."""
+    51866 tokens.
+
+    awq = (layout "gemm" | "gemv", group size, twin): the DECODER layers' Dense weights are stored as
+    AWQ int4 (BASELINE configs[4]: "bf16 + AWQ int4 weights"; the reference forces float16 for
+    such models) - or, with twin=True, as the float16 values those int4 weights dequantise to."""
     os.makedirs(output_dir, exist_ok=True)
     b = _Builder(seed, quantization, w_std=w_std, direct_f16=direct_f16)
     d = d_model
+    awq_layers = [False]  # set while the decoder layers are drawn
 
     def conv(scope, out_c, in_c):
         if b.direct_f16:
@@ -460,17 +465,17 @@ def build_whisper(output_dir, num_encoder_layers=2, num_decoder_layers=2, d_mode
     def mha(scope, self_attention):
         b.layer_norm(scope + "/layer_norm", d)
         if self_attention:
-            b.linear(scope + "/linear_0", 3 * d, d)
-            b.linear(scope + "/linear_1", d, d)
+            b.linear(scope + "/linear_0", 3 * d, d, awq_ok=awq_layers[0])
+            b.linear(scope + "/linear_1", d, d, awq_ok=awq_layers[0])
         else:
-            b.linear(scope + "/linear_0", d, d)
-            b.linear(scope + "/linear_1", 2 * d, d)
-            b.linear(scope + "/linear_2", d, d)
+            b.linear(scope + "/linear_0", d, d, awq_ok=awq_layers[0])
+            b.linear(scope + "/linear_1", 2 * d, d, awq_ok=awq_layers[0])
+            b.linear(scope + "/linear_2", d, d, awq_ok=awq_layers[0])
 
     def ffn(scope):
         b.layer_norm(scope + "/layer_norm", d)
-        b.linear(scope + "/linear_0", ffn_dim, d)
-        b.linear(scope + "/linear_1", d, ffn_dim)
+        b.linear(scope + "/linear_0", ffn_dim, d, awq_ok=awq_layers[0])
+        b.linear(scope + "/linear_1", d, ffn_dim, awq_ok=awq_layers[0])
 
     def positions(scope, n):
         t = b.rng.normal(0, w_std, (n, d)).astype(np.float32)
@@ -499,10 +504,13 @@ def build_whisper(output_dir, num_encoder_layers=2, num_decoder_layers=2, d_mode
     if "decoder/embeddings/weight_scale" in b.vars:
         aliases.append(("decoder/projection/weight_scale", "decoder/embeddings/weight_scale"))
     positions("decoder/position_encodings", max_target_positions)
+    b.awq = awq
+    awq_layers[0] = awq is not None
     for l in range(num_decoder_layers):
         mha("decoder/layer_%d/self_attention" % l, True)
         mha("decoder/layer_%d/attention" % l, False)
         ffn("decoder/layer_%d/ffn" % l)
+    awq_layers[0] = False
     b.layer_norm("decoder/layer_norm", d)
     b.attr("decoder/num_heads", num_heads, np.int16)
     b.attr("decoder/pre_norm", 1, np.int8)
@@ -530,6 +538,11 @@ def build_whisper(output_dir, num_encoder_layers=2, num_decoder_layers=2, d_mode
         "alignment_heads": [list(p) for p in alignment_heads],
     }
     assert no_timestamps + 1 + num_timestamps == vocab_size
+    if awq is not None and not awq[2]:
+        # common_spec.Quantization: CT2 = 0, AWQ_GEMM = 1, AWQ_GEMV = 2
+        config["quantization_type"] = 1 if awq[0] == "gemm" else 2
+        config["quantization_bits"] = 4
+        config["quantization_group_size"] = awq[1]
     with open(os.path.join(output_dir, "config.json"), "w") as f:
         json.dump(config, f, indent=2, sort_keys=True)
     with open(os.path.join(output_dir, "vocabulary.json"), "w", encoding="utf-8") as f:

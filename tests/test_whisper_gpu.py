@@ -183,3 +183,35 @@ def test_reference_whisper_on_device_cuda(gpu, golden, tmp_path):
     res["encode"] = np.load(out_npz)["encode"]
     assert res["info"] == j["float32"]["info"]
     compare(res, j["float32"], z["float32.encode"], True, 5e-4, "Level-1 float32")
+
+
+@pytest.mark.parametrize("layout", ["gemm", "gemv"])
+def test_whisper_awq_decoder_runs_like_its_float16_twin(gpu, layout, tmp_path):
+    """BASELINE configs[4] names "AWQ int4 weights": a Whisper model whose DECODER Dense weights are
+    AWQ int4 (weight / weight_scale / weight_zero + config.json quantization_type, the reference's
+    converter layout) against the float16 model holding the values those int4 weights dequantise
+    to: same encoder output, same greedy tokens with and without timestamps, language
+    probabilities within the summation order of two GEMM kernels. (Parity unpinned beyond the
+    twin: the reference has no CPU path for AWQ)"""
+    import ctranslate2_amd as ct2
+    from ctranslate2_amd import model_builder as mb
+    kw = dict(WC.MODEL, d_model=128, ffn_dim=256, num_heads=2, quantization="float16")
+    d_awq = mb.build_whisper(str(tmp_path / "awq"), awq=(layout, 64, False), **kw)
+    d_twin = mb.build_whisper(str(tmp_path / "twin"), awq=(layout, 64, True), **kw)
+    a = ct2.Whisper(d_awq, device="cuda", compute_type="float16")
+    b = ct2.Whisper(d_twin, device="cuda", compute_type="float16")
+    f = WC.features()
+    np.testing.assert_array_equal(a.encode(f), b.encode(f))
+    la, lb = a.detect_language(f), b.detect_language(f)
+    assert [[t for t, _ in row] for row in la] == [[t for t, _ in row] for row in lb]
+    np.testing.assert_allclose([[p for _, p in row] for row in la], [[p for _, p in row] for row in lb],
+                               rtol=5e-3, atol=1e-4)
+    same = 0
+    for prompt in ([WC.SOT, WC.EN, WC.TRANSCRIBE, WC.NOTIMESTAMPS], [WC.SOT, WC.EN, WC.TRANSCRIBE]):
+        ra = a.generate(f, [prompt] * 3, beam_size=1, max_length=24)
+        rb = b.generate(f, [prompt] * 3, beam_size=1, max_length=24)
+        same += sum(int(x.sequences_ids == y.sequences_ids) for x, y in zip(ra, rb))
+    print("Whisper AWQ %s decoder vs float16 twin: %d / 6 greedy hypotheses identical" % (layout, same))
+    assert same >= 5
+    a.close()
+    b.close()
