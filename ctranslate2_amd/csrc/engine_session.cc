@@ -255,7 +255,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     {
       // a 16-bit copy of the memory K/V for the decode steps (bytes halved, one workgroup per
       // (entry, head) shares every key / value among the entry's hypothesis rows)
-      static const bool disabled = std::getenv("CT2X_NO_CROSS_KV16") != nullptr;  // (A/B runs)
+      static const bool disabled = tuning_env("CT2X_NO_CROSS_KV16") != nullptr;  // (A/B runs, TUNING=1)
       bool ok = half_compute() && !tp_ && !disabled;
       for (int l = 0; ok && l < n_layers; ++l) {
         const AttnW& a = dec_.layers[l].cross;

@@ -507,7 +507,7 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
     // K slices over workgroups: enough of them to cover the chip twice, at most two rounds of
     // K-steps per wave (8 waves x U = 2 x 32 elements = 512 per round), whole 32-element steps
     static const int variant = [] {
-      const char* e = std::getenv("CT2X_HSKINNY_VARIANT");
+      const char* e = tuning_env("CT2X_HSKINNY_VARIANT");  // (make TUNING=1 builds only)
       return e ? std::atoi(e) : 2;
     }();
     if (variant >= 2 && M <= 64 && K >= 256) {
