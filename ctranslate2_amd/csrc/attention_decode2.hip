@@ -58,7 +58,7 @@ struct Attn2Args {
 #define CT2X_STAMP(K)                                                                   \
   if (a.trace != nullptr && blockIdx.x == 0 && lane == 0) a.trace[wave * 16 + (K)] = clock64();
 
-template <int DH, int GQ, int TW>
+template <int DH, int GQ, int TW, bool ANC = false>
 __global__ __launch_bounds__(TW == 1 ? 512 : TW * 64) void attn2_kernel(Attn2Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int E = DH / 64;  // channels per lane in the PV phase
@@ -104,6 +104,17 @@ __global__ __launch_bounds__(TW == 1 ? 512 : TW * 64) void attn2_kernel(Attn2Arg
               static_cast<int64_t>(hk) * p.kv_head_stride;
   float* vc = p.v_cache + static_cast<int64_t>(kvrow) * p.kv_row_stride +
               static_cast<int64_t>(hk) * p.kv_head_stride;
+  // Beam search without moving the caches (AttnDecodeParams::ancestry, 16-bit compute types):
+  // position t of this row's history lives in cache row anc[t * anc_stride]; the step's new key /
+  // value go to the row's own cache row. One dependent load in front of every batch of K / V
+  // requests - against a cache_gather launch that rewrites every live position of every layer
+  // (NLLB-3.3B shape, 256 rows: 1.03 ms of an 8.4 ms step).
+  // (ANC is a template parameter: the instantiations without the table are the round-2 kernels,
+  // instruction for instruction)
+  const int32_t* anc = ANC ? p.ancestry + row : nullptr;
+  const int64_t anc_stride = p.ancestry_stride;
+  const float* kc0 = p.k_cache + static_cast<int64_t>(hk) * p.kv_head_stride;
+  const float* vc0 = p.v_cache + static_cast<int64_t>(hk) * p.kv_head_stride;
 
   // As soon as the cache length is known, and before q and the new key are processed, the wave
   // requests the first 16 float4 per lane of its first K chunk and the first VB rows of its V
@@ -117,10 +128,24 @@ __global__ __launch_bounds__(TW == 1 ? 512 : TW * 64) void attn2_kernel(Attn2Arg
 #define CT2X_PVD(e) (E == 1 ? lane : 2 * lane + (e))
   const int kvs = static_cast<int>(p.kv_time_stride);  // a head's cache spans < 2^31 floats
 #define CT2X_STAGE_LOAD(ST, T0, COL0, TLIM)                                     \
-  _Pragma("unroll") for (int it = 0; it < 16; ++it) {                           \
-    const int i_ = it * 64 + lane; /* 16 float4 per half row */                 \
-    const int tl_ = min((T0) + i_ / 16, (TLIM));                                \
-    ST[it] = *reinterpret_cast<const v4f*>(kc + tl_ * kvs + (COL0) + (i_ % 16) * 4); \
+  if constexpr (!ANC) {                                                         \
+    _Pragma("unroll") for (int it = 0; it < 16; ++it) {                         \
+      const int i_ = it * 64 + lane; /* 16 float4 per half row */               \
+      const int tl_ = min((T0) + i_ / 16, (TLIM));                              \
+      ST[it] = *reinterpret_cast<const v4f*>(kc + tl_ * kvs + (COL0) + (i_ % 16) * 4); \
+    }                                                                           \
+  } else {                                                                      \
+    int ar_[16];                                                                \
+    _Pragma("unroll") for (int it = 0; it < 16; ++it) {                         \
+      const int tl_ = min((T0) + (it * 64 + lane) / 16, (TLIM));                \
+      ar_[it] = anc[tl_ * anc_stride];                                          \
+    }                                                                           \
+    _Pragma("unroll") for (int it = 0; it < 16; ++it) {                         \
+      const int i_ = it * 64 + lane;                                            \
+      const int tl_ = min((T0) + i_ / 16, (TLIM));                              \
+      ST[it] = *reinterpret_cast<const v4f*>(kc0 + static_cast<int64_t>(ar_[it]) * p.kv_row_stride + \
+                                             tl_ * kvs + (COL0) + (i_ % 16) * 4); \
+    }                                                                           \
   }
 #define CT2X_STAGE_STORE(ST)                                                    \
   _Pragma("unroll") for (int it = 0; it < 16; ++it) {                           \
@@ -130,14 +155,31 @@ __global__ __launch_bounds__(TW == 1 ? 512 : TW * 64) void attn2_kernel(Attn2Arg
   // wave-local key index u -> cache position (this wave owns chunks tw, tw + TW, ...)
 #define CT2X_T_OF(U) (((((U) >> 6) * TW + tw) << 6) + ((U)&63))
 #define CT2X_LOAD_V(VR, U0, TLIM)                                                              \
-  _Pragma("unroll") for (int j = 0; j < VB; ++j) {                                             \
-    const int tl_ = min(CT2X_T_OF((U0) + j), (TLIM));                                          \
-    if (E == 1) {                                                                              \
-      VR[j][0] = vc[tl_ * kvs + lane];                                                         \
-    } else {                                                                                   \
-      const float2 v2_ = *reinterpret_cast<const float2*>(vc + tl_ * kvs + 2 * lane);          \
-      VR[j][0] = v2_.x;                                                                        \
-      VR[j][E - 1] = v2_.y;                                                                    \
+  if constexpr (!ANC) {                                                                        \
+    _Pragma("unroll") for (int j = 0; j < VB; ++j) {                                           \
+      const int tl_ = min(CT2X_T_OF((U0) + j), (TLIM));                                        \
+      if (E == 1) {                                                                            \
+        VR[j][0] = vc[tl_ * kvs + lane];                                                       \
+      } else {                                                                                 \
+        const float2 v2_ = *reinterpret_cast<const float2*>(vc + tl_ * kvs + 2 * lane);        \
+        VR[j][0] = v2_.x;                                                                      \
+        VR[j][E - 1] = v2_.y;                                                                  \
+      }                                                                                        \
+    }                                                                                          \
+  } else {                                                                                     \
+    int vr_[VB];                                                                               \
+    _Pragma("unroll") for (int j = 0; j < VB; ++j)                                             \
+      vr_[j] = anc[min(CT2X_T_OF((U0) + j), (TLIM)) * anc_stride];                             \
+    _Pragma("unroll") for (int j = 0; j < VB; ++j) {                                           \
+      const int tl_ = min(CT2X_T_OF((U0) + j), (TLIM));                                        \
+      const float* vrow_ = vc0 + static_cast<int64_t>(vr_[j]) * p.kv_row_stride + tl_ * kvs;   \
+      if (E == 1) {                                                                            \
+        VR[j][0] = vrow_[lane];                                                                \
+      } else {                                                                                 \
+        const float2 v2_ = *reinterpret_cast<const float2*>(vrow_ + 2 * lane);                 \
+        VR[j][0] = v2_.x;                                                                      \
+        VR[j][E - 1] = v2_.y;                                                                  \
+      }                                                                                        \
     }                                                                                          \
   }
   v4f kpre[16];
@@ -497,7 +539,7 @@ __global__ __launch_bounds__(TW == 1 ? 512 : TW * 64) void attn2_kernel(Attn2Arg
   }
 }
 
-template <int DH, int GQ, int TW>
+template <int DH, int GQ, int TW, bool ANC = false>
 void launch(const Attn2Args& a, hipStream_t stream) {
   const int team_floats =
       (GQ * DH + GQ * a.t_pad + TW * GQ * 2 + (TW > 1 ? TW * GQ * DH : 0) + 3) & ~3;
@@ -509,14 +551,14 @@ void launch(const Attn2Args& a, hipStream_t stream) {
     int dev = 0;
     CT2X_HIP_CHECK(hipGetDevice(&dev));
     if (!configured[dev & 63].load(std::memory_order_acquire)) {
-      CT2X_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel<DH, GQ, TW>),
+      CT2X_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel<DH, GQ, TW, ANC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       configured[dev & 63].store(true, std::memory_order_release);
     }
   }
   const unsigned grid = static_cast<unsigned>(a.p.rows * a.wg_per_row);
-  hipLaunchKernelGGL((attn2_kernel<DH, GQ, TW>), dim3(grid), dim3(a.teams * TW * 64), lds, stream,
-                     a);
+  hipLaunchKernelGGL((attn2_kernel<DH, GQ, TW, ANC>), dim3(grid), dim3(a.teams * TW * 64), lds,
+                     stream, a);
 }
 
 template <int DH, int GQ>
@@ -527,6 +569,14 @@ void launch_tw(const Attn2Args& a, int tw, hipStream_t stream) {
 
 template <int DH>
 void launch_gq(const Attn2Args& a, int gq, int tw, hipStream_t stream) {
+  if (a.p.ancestry != nullptr) {
+    // split mode, one query head per team (attention_decode2_applicable): beam search through the
+    // ancestry table
+    if (gq != 1) throw Error("attn2: the ancestry table needs one query head per team");
+    if (tw == 1) launch<DH, 1, 1, true>(a, stream);
+    else launch<DH, 1, 4, true>(a, stream);
+    return;
+  }
   switch (gq) {
     case 1: launch_tw<DH, 1>(a, tw, stream); break;
     case 2: launch_tw<DH, 2>(a, tw, stream); break;
@@ -558,6 +608,8 @@ bool attention_decode2_applicable(const AttnDecodeParams& p, bool fused_quantize
       p.kv_head_stride % 4 != 0 || p.kv_row_stride % 4 != 0)
     return false;
   if (p.rot_dim > p.dhead) return false;
+  // the ancestry table is followed in split mode only (self-attention of a beam search)
+  if (p.ancestry != nullptr && (fused_quantize || p.kv_group != 1 || p.lengths != nullptr)) return false;
   const int64_t t_pad = ((p.t_max + 1 + 63) / 64) * 64;
   if (fused_quantize) {
     // row mode: all KV heads of a row in one workgroup of <= 16 waves, its LDS within 64 KiB

@@ -20,6 +20,7 @@
 
 #include "decoding.h"
 #include "engine.h"
+#include "engine_internal.h"
 #include "host_math.h"
 #include "model.h"
 #include "runtime.h"
@@ -1386,6 +1387,11 @@ int ct2x_debug_tap_data(int index, void* out) {
   std::lock_guard<std::mutex> tlock(g_taps_mutex);
   if (index < 0 || index >= static_cast<int>(g_taps.size())) return -1;
   std::memcpy(out, g_taps[index].data.data(), g_taps[index].data.size());
+  return 0;
+}
+
+int ct2x_debug_set_beam_ancestry(int enabled) {
+  g_debug_beam_ancestry.store(enabled);
   return 0;
 }
 

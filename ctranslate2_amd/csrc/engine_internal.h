@@ -3,6 +3,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 
 #include "engine.h"
@@ -12,6 +13,7 @@ namespace ct2x {
 
 // The stream of the session the calling thread is driving (one worker thread per session) and the
 // begin_kernel calls of this thread (kernels per step). Defined in engine.cc.
+extern std::atomic<int> g_debug_beam_ancestry;  // engine_session.cc (tests: 0 = no ancestry table)
 extern thread_local hipStream_t tls_stream;
 extern thread_local int64_t tls_launches;
 

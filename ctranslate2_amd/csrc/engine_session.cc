@@ -4,6 +4,7 @@
 #include "host_math.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,9 @@ namespace ct2x {
 // ---------------------------------------------------------------------------------------------
 // Session
 // ---------------------------------------------------------------------------------------------
+
+// tests only (ct2x_debug_set_beam_ancestry): 0 = beam search moves the caches every step
+std::atomic<int> g_debug_beam_ancestry{-1};
 
 DecodeState::~DecodeState() {
   if (engine) {
@@ -176,7 +180,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       const char* e = tuning_env("CT2X_BEAM_ANCESTRY");
       return e == nullptr || e[0] != '0';
     }();
-    bool ok = allowed;
+    bool ok = allowed && g_debug_beam_ancestry.load() != 0;
     const float* aligned = reinterpret_cast<const float*>(static_cast<uintptr_t>(256));
     for (int l = 0; ok && l < n_layers; ++l) {
       const AttnW& a = dec_.layers[l].self;
@@ -198,7 +202,9 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       p.ancestry = reinterpret_cast<const int32_t*>(aligned);
       p.ancestry_stride = rows;
       p.allow_inexact = half_compute();
-      ok = attention_exact_decode_applicable(p, false);
+      // (16-bit compute types: the split-mode kernel follows the table too, attention_decode2.hip)
+      ok = attention_exact_decode_applicable(p, false) ||
+           (p.allow_inexact && attention_decode2_applicable(p, false));
     }
     st->ancestry = ok;
     if (ok) {

@@ -646,6 +646,12 @@ int ct2x_host_rotary_tables(int64_t dim, int interleave, int scaling_type, float
                             int64_t original_max_position_embeddings, int64_t positions,
                             float* sin_out, float* cos_out);
 
+/* Tests: beam search normally follows an ancestry table instead of moving the self-attention
+ * caches after every step (Decoder::update_state, src/layers/decoder.cc:33-56) wherever the
+ * attention kernels support it; 0 switches the table off for sessions created afterwards (the
+ * caches are gathered every step), -1 restores the default. Results are identical either way. */
+int ct2x_debug_set_beam_ancestry(int enabled);
+
 /* ---- debugging taps (tests only; not part of the reference boundary) ----------------------
  * ct2x_debug_step_taps = ct2x_step_logits with every producer on the path (embedding, norm +
  * Quantize, Quantize, Dense, attention) copying its output to the host, named

@@ -519,3 +519,32 @@ def test_cpp_api_translator(gpu):
     want = t.score_batch([src], [tgt])[0]
     assert [r[0] for r in rows] == want.tokens
     np.testing.assert_allclose([float(r[1]) for r in rows], want.log_probs, atol=1e-5)
+
+
+@pytest.mark.parametrize("ct", ["float16", "bfloat16"])
+def test_half_beam_search_ancestry_table_equals_cache_gather(gpu, golden, ct):
+    """16-bit compute types, beam search, d_head 64 (Transformer-base shape): the self-attention
+    reads its history through the ancestry table (attention_decode2.hip, ANC instantiations)
+    instead of gathering every cache tensor after each step (Decoder::update_state,
+    src/layers/decoder.cc:33-56). Same arithmetic on the same values - the hypotheses and their
+    scores must be IDENTICAL to the run that moves the caches (ct2x_debug_set_beam_ancestry(0))."""
+    import ctranslate2_amd as ct2
+    from ctranslate2_amd import model_builder as mb
+    g = golden["tb"]
+    path = "/tmp/ct2x_test_tb"
+    if not os.path.exists(os.path.join(path, "model.bin")):
+        mb.build_transformer(path, **GC.SYNTHETIC["tb"]["model"])
+    t = ct2.Translator(path, device="cuda", compute_type=ct)
+    kw = dict(beam_size=4, max_decoding_length=24, min_decoding_length=1, num_hypotheses=2,
+              return_scores=True)
+    sources = g["sources"][:12]
+    try:
+        gpu.ct2x_debug_set_beam_ancestry(0)
+        hyp_gather, sc_gather = t.translate_ids(sources, **kw)
+        gpu.ct2x_debug_set_beam_ancestry(-1)
+        hyp_anc, sc_anc = t.translate_ids(sources, **kw)
+    finally:
+        gpu.ct2x_debug_set_beam_ancestry(-1)
+    assert hyp_anc == hyp_gather
+    np.testing.assert_array_equal(sc_anc, sc_gather)
+    assert len({tuple(h[0]) for h in hyp_anc}) > 1  # (not a degenerate run)

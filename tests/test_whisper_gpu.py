@@ -215,3 +215,28 @@ def test_whisper_awq_decoder_runs_like_its_float16_twin(gpu, layout, tmp_path):
     assert same >= 5
     a.close()
     b.close()
+
+
+def test_whisper_half_beam_search_ancestry_table_equals_cache_gather(gpu, golden):
+    """Whisper, float16, beam 5 with timestamps: the ancestry-table form of the self-attention
+    (attention_decode2.hip) against the per-step cache gather - identical hypotheses and scores."""
+    import ctranslate2_amd as ct2
+    from ctranslate2_amd import model_builder as mb
+    # (d_head 64: the split-mode attention kernel that follows the table serves d_head 64 / 128)
+    path = "/tmp/ct2x_whisper_dh64"
+    if not os.path.exists(os.path.join(path, "model.bin")):
+        mb.build_whisper(path, **dict(WC.MODEL, d_model=128, ffn_dim=256, num_heads=2))
+    w = ct2.Whisper(path, device="cuda", compute_type="float16")
+    f = WC.features()
+    prompts = [[WC.SOT, WC.EN, WC.TRANSCRIBE]] * 3
+    kw = dict(beam_size=5, num_hypotheses=2, max_length=24, return_scores=True)
+    try:
+        gpu.ct2x_debug_set_beam_ancestry(0)
+        a = w.generate(f, prompts, **kw)
+        gpu.ct2x_debug_set_beam_ancestry(-1)
+        b = w.generate(f, prompts, **kw)
+    finally:
+        gpu.ct2x_debug_set_beam_ancestry(-1)
+    assert [r.sequences_ids for r in a] == [r.sequences_ids for r in b]
+    assert [r.scores for r in a] == [r.scores for r in b]
+    w.close()
