@@ -521,8 +521,10 @@ def test_cpp_api_translator(gpu):
     np.testing.assert_allclose([float(r[1]) for r in rows], want.log_probs, atol=1e-5)
 
 
-@pytest.mark.parametrize("ct", ["float16", "bfloat16"])
-def test_half_beam_search_ancestry_table_equals_cache_gather(gpu, golden, ct):
+@pytest.mark.parametrize("ct,max_len,min_len", [("float16", 24, 1), ("bfloat16", 24, 1),
+                                                # > 64 cached positions: the four-wave split form
+                                                ("float16", 80, 72)])
+def test_half_beam_search_ancestry_table_equals_cache_gather(gpu, golden, ct, max_len, min_len):
     """16-bit compute types, beam search, d_head 64 (Transformer-base shape): the self-attention
     reads its history through the ancestry table (attention_decode2.hip, ANC instantiations)
     instead of gathering every cache tensor after each step (Decoder::update_state,
@@ -535,7 +537,7 @@ def test_half_beam_search_ancestry_table_equals_cache_gather(gpu, golden, ct):
     if not os.path.exists(os.path.join(path, "model.bin")):
         mb.build_transformer(path, **GC.SYNTHETIC["tb"]["model"])
     t = ct2.Translator(path, device="cuda", compute_type=ct)
-    kw = dict(beam_size=4, max_decoding_length=24, min_decoding_length=1, num_hypotheses=2,
+    kw = dict(beam_size=4, max_decoding_length=max_len, min_decoding_length=min_len, num_hypotheses=2,
               return_scores=True)
     sources = g["sources"][:12]
     try:
