@@ -495,6 +495,13 @@ def main():
                     "decode_ms_per_step": l8["config"]["decode_ms_per_step"],
                     "kernels_per_decode_step": l8["config"]["kernels_per_decode_step"],
                     "roofline": l8["decode_roofline"],
+                    "parity": "exact-order kernels on this path (attention_exact128.hip, RMSNorm, "
+                              "int8 Dense): teacher-forced int8 logits max |d| = 0 and greedy tokens "
+                              "identical to the reference's CPU path at this geometry (2 layers, "
+                              "goldens from oracle/_ref): tests/test_generator_gpu.py::"
+                              "test_llama3_geometry_teacher_forced_logits_int8, "
+                              "::test_llama3_geometry_generate_matches_reference; the random weights "
+                              "of this leg are not checked against anything",
                 }
             except Exception as e:  # never break the headline line
                 result["config"]["l8"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
