@@ -104,6 +104,25 @@ void check_features(const Whisper& w, int32_t batch, int32_t n_mels, int32_t fra
 
 extern "C" {
 
+int ct2x_host_whisper_check_prompts(const int32_t* prompts, const int32_t* lengths, int32_t batch,
+                                    int32_t stride, int32_t sot_id, int32_t no_timestamps_id,
+                                    int32_t* sot_index, int32_t* prompt_length) {
+  API_TRY
+  CT2X_CHECK(prompts && lengths && sot_index && prompt_length && batch >= 1 && stride >= 0,
+             "ct2x_host_whisper_check_prompts: bad arguments");
+  std::vector<std::vector<int32_t>> p(batch);
+  for (int32_t b = 0; b < batch; ++b) {
+    CT2X_CHECK(lengths[b] >= 0 && lengths[b] <= stride, "prompt length out of range");
+    p[b].assign(prompts + static_cast<int64_t>(b) * stride,
+                prompts + static_cast<int64_t>(b) * stride + lengths[b]);
+  }
+  size_t si = 0, pl = 0;
+  check_prompts(p, sot_id, no_timestamps_id, si, pl);
+  *sot_index = static_cast<int32_t>(si);
+  *prompt_length = static_cast<int32_t>(pl);
+  API_CATCH
+}
+
 void ct2x_whisper_options_default(struct ct2x_whisper_options* o) {
   static const int32_t kDefaultSuppress[1] = {-1};
   std::memset(o, 0, sizeof(*o));

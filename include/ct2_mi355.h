@@ -720,6 +720,16 @@ int ct2x_host_beam_step_select(int32_t beam_size, int32_t step, int32_t is_last_
 /* finalize_hypothesis_score without coverage penalty (src/decoding.cc:192-207). */
 float ct2x_host_finalize_score(float score, float length, float length_penalty);
 
+/* Host side of Whisper::generate's prompt handling (check_prompts / get_sot_index /
+ * get_prompt_length, src/models/whisper.cc:149-200): prompts [batch, stride] must all hold
+ * <|startoftranscript|> at the same position and the same number of task tokens (ids in
+ * [sot_id, no_timestamps_id]) after it. Writes the common sot index and prompt length (the
+ * tokens before the text tokens); non-zero with the reference's message in ct2x_last_error()
+ * otherwise. No device needed. */
+int ct2x_host_whisper_check_prompts(const int32_t* prompts, const int32_t* lengths, int32_t batch,
+                                    int32_t stride, int32_t sot_id, int32_t no_timestamps_id,
+                                    int32_t* sot_index, int32_t* prompt_length);
+
 /* negative_dtw (src/dtw.cc:40-82; Whisper word alignment, src/models/whisper.cc:418): dynamic time
  * warping over the NEGATED matrix x [n, m] (host memory), i.e. the monotone path from (0, 0) to
  * (n - 1, m - 1) that maximises the summed x, with the reference's tie rule (diagonal only when

@@ -61,3 +61,36 @@ def test_whisper_vocabulary_layout():
     assert tokens[WC.NOSPEECH] == "<|nospeech|>" and tokens[WC.NOTIMESTAMPS] == "<|notimestamps|>"
     assert tokens[WC.TS0] == "<|0.00|>" and len(tokens) == WC.TS0 + WC.MODEL["num_timestamps"]
     assert WC.NOSPEECH - WC.SOT - 5 == WC.NUM_LANGUAGES  # whisper.cc:77
+
+
+def test_prompt_layout_rules_on_the_host():
+    """check_prompts (src/models/whisper.cc:149-200) behind ct2x_host_whisper_check_prompts: the
+    start-of-transcript position and the number of task tokens must agree across the batch."""
+    import ctypes as C
+    from ctranslate2_amd import _lib
+    L = _lib.lib()
+
+    def run(prompts):
+        lengths = np.array([len(p) for p in prompts], np.int32)
+        stride = int(lengths.max())
+        ids = np.zeros((len(prompts), stride), np.int32)
+        for i, p in enumerate(prompts):
+            ids[i, :len(p)] = p
+        si, pl = C.c_int32(), C.c_int32()
+        rc = L.ct2x_host_whisper_check_prompts(_lib.ptr(ids), _lib.ptr(lengths), C.c_int32(len(prompts)),
+                                               C.c_int32(stride), C.c_int32(WC.SOT),
+                                               C.c_int32(WC.NOTIMESTAMPS), C.byref(si), C.byref(pl))
+        return rc, si.value, pl.value, L.ct2x_last_error().decode()
+
+    assert run([[WC.SOT, WC.EN, WC.TRANSCRIBE, WC.NOTIMESTAMPS]] * 2)[:3] == (0, 0, 4)
+    assert run([[WC.SOT, WC.EN, WC.TRANSCRIBE, WC.NOTIMESTAMPS, 5, 9]])[:3] == (0, 0, 4)
+    assert run([[WC.SOT]])[:3] == (0, 0, 1)
+    # timestamps are not task tokens: the prompt ends in front of them
+    assert run([[WC.SOT, WC.EN, WC.TRANSCRIBE, WC.TS0 + 4, 5]])[:3] == (0, 0, 3)
+    assert run([[WC.STARTOFPREV, 5, 6, 7, WC.SOT, WC.FR, WC.TRANSCRIBE]])[:3] == (0, 4, 7)
+    rc, _, _, msg = run([[5, 6]])
+    assert rc != 0 and "<|startoftranscript|> token was not found in the prompt" in msg
+    rc, _, _, msg = run([[WC.SOT, WC.EN], [WC.STARTOFPREV, 5, WC.SOT, WC.EN]])
+    assert rc != 0 and "to be at the same position" in msg
+    rc, _, _, msg = run([[WC.SOT, WC.EN, WC.TRANSCRIBE], [WC.SOT, WC.EN]])
+    assert rc != 0 and "same number of task tokens" in msg
