@@ -312,7 +312,10 @@ def test_hot_kernels_do_not_spill():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "ctranslate2_amd", "csrc")
     hot = {"gemm_s8_stream.hip": "stream_kernel", "gemm_s8.hip": "skinny_kernel",
-           "attention_exact.hip": "attn_x_decode_kernel", "gemm_s8_big.hip": "big_kernel"}
+           "attention_exact.hip": "attn_x_decode_kernel", "gemm_s8_big.hip": "big_kernel",
+           # round 3: the 16-bit decode GEMM and the 16-bit memory K/V attention
+           "gemm_h.hip": "gemm_h_rows_kernel", "attention_cross_h.hip": "xattn_h_kernel"}
+    minimum = {"attention_cross_h.hip": 2}
     with tempfile.TemporaryDirectory() as tmp:
         for src, needle in hot.items():
             out = os.path.join(tmp, src + ".s")
@@ -329,7 +332,7 @@ def test_hot_kernels_do_not_spill():
                 checked += 1
                 assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)) == 0, name
                 assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
-            assert checked >= 5, (src, checked)
+            assert checked >= minimum.get(src, 5), (src, checked)
 
 
 def test_streaming_gemm_plan_is_host_logic():
