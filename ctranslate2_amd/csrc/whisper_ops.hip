@@ -229,17 +229,39 @@ __global__ void layer_norm_axis_kernel(const float* __restrict__ x, int64_t axis
   if (col >= inner_used) return;
   const float* xo = x + o * axis * inner + col;
   float* yo = y + o * axis * inner + col;
-  // cpu::layer_norm_axis (src/cpu/kernels.cc:499-539): running sum and sum of squares in index
-  // order, variance = sum_squares / n - mean^2 clamped at 0; the reference's AVX2 / AVX512 builds
-  // contract x * x + s and q - mean * mean into fused operations
+  // cpu::layer_norm_axis (src/cpu/kernels.cc:499-539) AS COMPILED: the function sits inside
+  // CT2_FFAST_MATH_BEGIN / END (`#pragma GCC optimize("-ffast-math")`, kernels.cc:461-574), so GCC
+  // vectorises the reduction - four partial sums over k = l, l + 4, ... folded as
+  // (p0 + p2) + (p1 + p3), then the axis % 4 last elements one by one (axis <= 4: one chain) - and
+  // rewrites the divisions: mean = sum * (1 / n), variance = fma(sum_squares, 1 / n, -(mean * mean)).
+  // Read off the reference's object code, restated in oracle/whisper_oracle.py and pinned bit for
+  // bit against the library there (tests/test_whisper_oracle.py).
   float sum = 0.f, sum_squares = 0.f;
-  for (int64_t a = 0; a < axis; ++a) {
-    const float v = xo[a * inner];
-    sum += v;
-    sum_squares = fmaf(v, v, sum_squares);
+  int64_t first_tail = 0;
+  if (axis > 4) {
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t n4 = axis / 4;
+    for (int64_t g = 0; g < n4; ++g) {
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const float v = xo[(4 * g + l) * inner];
+        q4[l] = fmaf(v, v, q4[l]);
+        s4[l] = s4[l] + v;
+      }
+    }
+    sum = (s4[1] + s4[3]) + (s4[0] + s4[2]);
+    sum_squares = (q4[1] + q4[3]) + (q4[0] + q4[2]);
+    first_tail = 4 * n4;
   }
-  const float mean = sum / static_cast<float>(axis);
-  const float variance = fmaxf(fmaf(-mean, mean, sum_squares / static_cast<float>(axis)), 0.f);
+  for (int64_t a = first_tail; a < axis; ++a) {
+    const float v = xo[a * inner];
+    sum_squares = fmaf(v, v, sum_squares);
+    sum = sum + v;
+  }
+  const float inv_n = 1.f / static_cast<float>(axis);
+  const float mean = sum * inv_n;
+  const float mean2 = mean * mean;
+  const float variance = fmaxf(fmaf(sum_squares, inv_n, -mean2), 0.f);
   const float rstd = 1.f / sqrtf(variance);
   for (int64_t a = 0; a < axis; ++a) yo[a * inner] = (xo[a * inner] - mean) * rstd;
 }

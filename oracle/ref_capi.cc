@@ -903,4 +903,44 @@ int ct2ref_whisper_align(void* h, const float* features, int batch, int n_mels, 
   CT2REF_CATCH
 }
 
+// ops::Conv1D on Device::CPU (src/ops/conv1d_cpu.cc:128-207: im2col + Gemm; with qscale the int8
+// path - im2col rows quantised, s8 x s8 -> s32, Dequantize, then bias + activation).
+// x [batch, in_c, length] float, w [out_c, in_c, kernel] float or (w_scale != NULL) int8,
+// y [batch, out_c, out_len]. act < 0: none.
+int ct2ref_conv1d(const float* x, const void* w, const float* w_scale, const float* bias, int64_t batch,
+                  int64_t in_c, int64_t length, int64_t out_c, int64_t kernel, int64_t stride,
+                  int64_t padding, int act, float* y, int64_t* out_len) {
+  CT2REF_TRY
+  const ops::ActivationType type = static_cast<ops::ActivationType>(act);
+  const ops::Conv1D op(stride, padding, 1, 1, act >= 0 ? &type : nullptr);
+  StorageView input = view(x, {batch, in_c, length});
+  StorageView output(DataType::FLOAT32, Device::CPU);
+  StorageView b = bias ? view(bias, {out_c}) : StorageView();
+  if (w_scale) {
+    StorageView weight = view(static_cast<const int8_t*>(w), {out_c, in_c, kernel});
+    StorageView qscale = view(w_scale, {out_c});
+    if (bias) op(input, weight, b, output, &qscale);
+    else op(input, weight, output, &qscale);
+  } else {
+    StorageView weight = view(static_cast<const float*>(w), {out_c, in_c, kernel});
+    if (bias) op(input, weight, b, output, nullptr);
+    else op(input, weight, output, nullptr);
+  }
+  *out_len = output.dim(2);
+  copy_out<float>(output, y);
+  CT2REF_CATCH
+}
+
+// ops::LayerNorm(axis, epsilon) without gamma / beta on [outer, axis_size, inner]
+// (compute_alignments, src/models/whisper.cc:396).
+int ct2ref_layer_norm_axis(const float* x, int64_t outer, int64_t axis_size, int64_t inner, float eps,
+                           float* y) {
+  CT2REF_TRY
+  const StorageView input = view(x, {outer, axis_size, inner});
+  StorageView output(DataType::FLOAT32, Device::CPU);
+  ops::LayerNorm(-2, eps)(input, output);
+  copy_out<float>(output, y);
+  CT2REF_CATCH
+}
+
 }  // extern "C"

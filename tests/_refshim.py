@@ -557,3 +557,28 @@ class RefWhisper(WhisperCalls):
         if self._h:
             self._L.ct2ref_whisper_free(C.c_void_p(self._h))
             self._h = None
+
+
+def conv1d(x, w, bias=None, w_scale=None, stride=1, padding=0, act=-1):
+    """ops::Conv1D on CPU: x [batch, in_c, length], w [out_c, in_c, kernel] float32 or int8 (+ w_scale)."""
+    x = _f32(x)
+    b, c, length = x.shape
+    out_c, _, kernel = w.shape
+    w = np.ascontiguousarray(w, np.int8 if w_scale is not None else np.float32)
+    out_cap = (length + 2 * padding - kernel) // stride + 1
+    y = np.empty((b, out_c, out_cap), np.float32)
+    out_len = C.c_int64()
+    _check(lib().ct2ref_conv1d(_p(x), _p(w), _p(_f32(w_scale)), _p(_f32(bias)), C.c_int64(b), C.c_int64(c),
+                               C.c_int64(length), C.c_int64(out_c), C.c_int64(kernel), C.c_int64(stride),
+                               C.c_int64(padding), C.c_int(act), _p(y), C.byref(out_len)))
+    assert out_len.value == out_cap
+    return y
+
+
+def layer_norm_axis(x, eps=0.0):
+    x = _f32(x)
+    outer, n, inner = x.shape
+    y = np.empty_like(x)
+    _check(lib().ct2ref_layer_norm_axis(_p(x), C.c_int64(outer), C.c_int64(n), C.c_int64(inner),
+                                        C.c_float(eps), _p(y)))
+    return y

@@ -94,3 +94,52 @@ def test_prompt_layout_rules_on_the_host():
     assert rc != 0 and "to be at the same position" in msg
     rc, _, _, msg = run([[WC.SOT, WC.EN, WC.TRANSCRIBE], [WC.SOT, WC.EN]])
     assert rc != 0 and "same number of task tokens" in msg
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref (the reference CPU library) is not built")
+@pytest.mark.parametrize("stride,length,in_c,out_c", [(1, 24, 8, 64), (2, 24, 64, 64), (2, 37, 16, 40),
+                                                      (1, 5, 3, 7)])
+def test_int8_convolution_restatement_is_the_reference(stride, length, in_c, out_c):
+    """oracle/whisper_oracle.py conv1d_k3_s8 (what conv_dequantize_kernel + the int8 GEMM reproduce
+    on the device) against ops::Conv1D of the reference library on CPU: bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import whisper_oracle as W
+    import _oracle as O
+    from ctranslate2_amd import model_builder as mb
+    rng = np.random.default_rng(stride * 100 + length + in_c + out_c)
+    x = rng.standard_normal((3, in_c, length)).astype(np.float32)
+    w = (rng.standard_normal((out_c, in_c, 3)) * 0.2).astype(np.float32)
+    bias = (rng.standard_normal(out_c) * 0.1).astype(np.float32)
+    q, s = mb.quantize_int8(w.reshape(out_c, -1))
+    wq = q.reshape(out_c, in_c, 3)
+    for act in (3, -1):  # GELU (Whisper), none
+        ref = R.conv1d(x, wq, bias, w_scale=s, stride=stride, padding=1, act=act)
+        got = W.conv1d_k3_s8(O, x, wq, s, bias, stride, 1, act)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+    # the float arm is the same im2col through MKL's sgemm: float rounding of the sum order only
+    ref = R.conv1d(x, w, bias, stride=stride, padding=1, act=-1)
+    cols = W.im2col_k3(x, stride, 1)
+    got = np.einsum("btk,ok->bot", cols.astype(np.float64), w.reshape(out_c, -1).astype(np.float64)) + bias[:, None]
+    np.testing.assert_allclose(ref, got, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref (the reference CPU library) is not built")
+def test_axis_layer_norm_restatement_is_the_reference():
+    """layer_norm_axis (the device kernel of Whisper::align follows the same order, FMA
+    contractions included) against ops::LayerNorm(-2, 0) of the reference library: bit for bit,
+    also on nearly constant columns where the E[x^2] - mean^2 form cancels."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import whisper_oracle as W
+    rng = np.random.default_rng(5)
+    for shape in ((3, 9, 12), (6, 31, 750), (2, 1, 5)):
+        x = rng.random(shape).astype(np.float32)
+        x[0, :, 0] = 1.0 / 12            # constant column: variance 0 after the clamp -> inf / nan
+        x[-1, :, -1] += 1000.0           # large offset: catastrophic cancellation
+        ref = R.layer_norm_axis(x)
+        got = W.layer_norm_axis(x)
+        assert np.array_equal(np.isnan(ref), np.isnan(got))
+        ok = ~np.isnan(ref)
+        assert np.array_equal(ref[ok], got[ok]), float(np.nanmax(np.abs(ref - got)))
