@@ -18,6 +18,7 @@
 #include <functional>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ct2_mi355.h"
@@ -534,5 +535,226 @@ public:
 private:
   detail::Handle h_;
 };
+
+// ---- ctranslate2::models::Whisper (include/ctranslate2/models/whisper.h) ---------------------
+namespace models {
+
+// whisper.h:11-58 (return_logits_vocab is present and must stay false)
+struct WhisperOptions {
+  size_t beam_size = 5;
+  float patience = 1;
+  float length_penalty = 1;
+  float repetition_penalty = 1;
+  size_t no_repeat_ngram_size = 0;
+  size_t max_length = 448;
+  size_t sampling_topk = 1;
+  float sampling_temperature = 1;
+  size_t num_hypotheses = 1;
+  bool return_scores = false;
+  bool return_logits_vocab = false;  // not built
+  bool return_no_speech_prob = false;
+  size_t max_initial_timestamp_index = 50;
+  bool suppress_blank = true;
+  std::vector<int> suppress_tokens = {-1};
+};
+
+// whisper.h:60-74
+struct WhisperGenerationResult {
+  std::vector<std::vector<std::string>> sequences;
+  std::vector<std::vector<size_t>> sequences_ids;
+  std::vector<float> scores;
+  float no_speech_prob = 0;
+  size_t num_sequences() const { return sequences.size(); }
+  bool has_scores() const { return !scores.empty(); }
+};
+
+// whisper.h:76-79
+struct WhisperAlignmentResult {
+  std::vector<std::pair<int64_t, int64_t>> alignments;
+  std::vector<float> text_token_probs;
+};
+
+// Features are float32 [batch, n_mels, frames], row major (the reference's StorageView on CPU).
+struct WhisperFeatures {
+  const float* data = nullptr;
+  size_t batch = 0, n_mels = 0, frames = 0;
+};
+
+// whisper.h:152-189: the synchronous form of the replica pool's methods (one device, no futures).
+class Whisper {
+public:
+  Whisper(const std::string& model_path, Device device = Device::CUDA,
+          ComputeType compute_type = ComputeType::DEFAULT, const std::vector<int>& device_indices = {0}) {
+    if (device != Device::CUDA)
+      throw std::invalid_argument("the MI355X backend has no CPU arm: use Device::CUDA");
+    if (device_indices.size() != 1)
+      throw std::invalid_argument("one device index per Whisper object (one process per GPU)");
+    h_ = ct2x_whisper_create(model_path.c_str(), device_indices[0], compute_type_name(compute_type));
+    if (!h_) throw std::runtime_error(ct2x_last_error());
+    int32_t multi = 0, mels = 0, langs = 0;
+    detail::check(ct2x_whisper_info(h_, &multi, &mels, &langs));
+    is_multilingual_ = multi != 0;
+    n_mels_ = static_cast<size_t>(mels);
+    num_languages_ = static_cast<size_t>(langs);
+  }
+  ~Whisper() {
+    if (h_) ct2x_whisper_destroy(h_);
+  }
+  Whisper(const Whisper&) = delete;
+  Whisper& operator=(const Whisper&) = delete;
+
+  bool is_multilingual() const { return is_multilingual_; }
+  size_t n_mels() const { return n_mels_; }
+  size_t num_languages() const { return num_languages_; }
+
+  // Whisper::encode: [batch, (frames - 1) / 2 + 1, d_model] float32 on the host; dims receives the shape
+  std::vector<float> encode(const WhisperFeatures& f, std::vector<int64_t>* dims = nullptr) {
+    const int64_t d = ct2x_whisper_d_model(h_);
+    std::vector<float> out(f.batch * ((f.frames + 1) / 2 + 1) * static_cast<size_t>(d));
+    int64_t shape[3] = {0, 0, 0};
+    detail::check(ct2x_whisper_encode(h_, f.data, static_cast<int32_t>(f.batch),
+                                      static_cast<int32_t>(f.n_mels), static_cast<int32_t>(f.frames),
+                                      out.data(), static_cast<int64_t>(out.size()), shape));
+    out.resize(static_cast<size_t>(shape[0] * shape[1] * shape[2]));
+    if (dims) dims->assign(shape, shape + 3);
+    return out;
+  }
+
+  std::vector<WhisperGenerationResult> generate(const WhisperFeatures& f,
+                                                const std::vector<std::vector<size_t>>& prompts,
+                                                const WhisperOptions& options = WhisperOptions()) {
+    detail::reject(options.return_logits_vocab, "return_logits_vocab");
+    const size_t batch = prompts.size();
+    if (batch == 0) return {};
+    if (batch != f.batch) throw std::invalid_argument("one prompt per batch entry is required");
+    size_t stride = 1;
+    for (const auto& p : prompts) stride = std::max(stride, p.size());
+    std::vector<int32_t> ids(batch * stride, 0), lengths(batch, 0);
+    for (size_t b = 0; b < batch; ++b) {
+      lengths[b] = static_cast<int32_t>(prompts[b].size());
+      for (size_t i = 0; i < prompts[b].size(); ++i) ids[b * stride + i] = static_cast<int32_t>(prompts[b][i]);
+    }
+    std::vector<int32_t> suppress(options.suppress_tokens.begin(), options.suppress_tokens.end());
+    ct2x_whisper_options o;
+    ct2x_whisper_options_default(&o);
+    o.beam_size = static_cast<int32_t>(options.beam_size);
+    o.patience = options.patience;
+    o.length_penalty = options.length_penalty;
+    o.repetition_penalty = options.repetition_penalty;
+    o.no_repeat_ngram_size = static_cast<int32_t>(options.no_repeat_ngram_size);
+    o.max_length = static_cast<int32_t>(options.max_length);
+    o.sampling_topk = static_cast<int32_t>(options.sampling_topk);
+    o.sampling_temperature = options.sampling_temperature;
+    o.num_hypotheses = static_cast<int32_t>(options.num_hypotheses);
+    o.return_scores = options.return_scores;
+    o.return_no_speech_prob = options.return_no_speech_prob;
+    o.max_initial_timestamp_index = static_cast<int32_t>(options.max_initial_timestamp_index);
+    o.suppress_blank = options.suppress_blank;
+    o.num_suppress_tokens = static_cast<int32_t>(suppress.size());
+    o.suppress_tokens = suppress.data();
+    const size_t nh = options.num_hypotheses, max_len = std::max<size_t>(options.max_length, 1);
+    std::vector<int32_t> out(batch * nh * max_len, 0), out_len(batch * nh, 0);
+    std::vector<float> scores(batch * nh, 0.f), no_speech(batch, 0.f);
+    detail::check(ct2x_whisper_generate(h_, f.data, static_cast<int32_t>(batch),
+                                        static_cast<int32_t>(f.n_mels), static_cast<int32_t>(f.frames),
+                                        ids.data(), lengths.data(), static_cast<int32_t>(stride), &o,
+                                        static_cast<int32_t>(max_len), out.data(), out_len.data(),
+                                        scores.data(), no_speech.data()));
+    std::vector<WhisperGenerationResult> results(batch);
+    for (size_t b = 0; b < batch; ++b) {
+      WhisperGenerationResult& r = results[b];
+      for (size_t k = 0; k < nh; ++k) {
+        const int32_t len = out_len[b * nh + k];
+        if (len < 0) continue;  // fewer hypotheses than asked for
+        std::vector<size_t> seq;
+        std::vector<std::string> tokens;
+        for (int32_t i = 0; i < len && static_cast<size_t>(i) < max_len; ++i) {
+          const int32_t id = out[(b * nh + k) * max_len + i];
+          seq.push_back(static_cast<size_t>(id));
+          const char* t = ct2x_whisper_vocab_token(h_, id);
+          tokens.emplace_back(t ? t : "");
+        }
+        r.sequences_ids.emplace_back(std::move(seq));
+        r.sequences.emplace_back(std::move(tokens));
+        if (options.return_scores) r.scores.push_back(scores[b * nh + k]);
+      }
+      if (options.return_no_speech_prob) r.no_speech_prob = no_speech[b];
+    }
+    return results;
+  }
+
+  // prompts as tokens (Whisper::generate's other overload, whisper.h:170-173)
+  std::vector<WhisperGenerationResult> generate(const WhisperFeatures& f,
+                                                const std::vector<std::vector<std::string>>& prompts,
+                                                const WhisperOptions& options = WhisperOptions()) {
+    std::vector<std::vector<size_t>> ids(prompts.size());
+    for (size_t b = 0; b < prompts.size(); ++b)
+      for (const auto& t : prompts[b]) ids[b].push_back(static_cast<size_t>(ct2x_whisper_vocab_id(h_, t.c_str())));
+    return generate(f, ids, options);
+  }
+
+  // Whisper::detect_language: (language token, probability) by decreasing probability
+  std::vector<std::vector<std::pair<std::string, float>>> detect_language(const WhisperFeatures& f) {
+    const size_t n = num_languages_;
+    std::vector<int32_t> ids(f.batch * n, 0);
+    std::vector<float> probs(f.batch * n, 0.f);
+    detail::check(ct2x_whisper_detect_language(h_, f.data, static_cast<int32_t>(f.batch),
+                                               static_cast<int32_t>(f.n_mels),
+                                               static_cast<int32_t>(f.frames), static_cast<int32_t>(n),
+                                               ids.data(), probs.data()));
+    std::vector<std::vector<std::pair<std::string, float>>> results(f.batch);
+    for (size_t b = 0; b < f.batch; ++b)
+      for (size_t j = 0; j < n; ++j) {
+        const char* t = ct2x_whisper_vocab_token(h_, ids[b * n + j]);
+        results[b].emplace_back(t ? t : "", probs[b * n + j]);
+      }
+    return results;
+  }
+
+  // Whisper::align (whisper.h:181-187)
+  std::vector<WhisperAlignmentResult> align(const WhisperFeatures& f,
+                                            const std::vector<size_t>& start_sequence,
+                                            const std::vector<std::vector<size_t>>& text_tokens,
+                                            const std::vector<size_t>& num_frames,
+                                            int64_t median_filter_width) {
+    const size_t batch = text_tokens.size();
+    if (batch == 0) return {};
+    if (num_frames.size() != batch) throw std::invalid_argument("Invalid batch size for argument num_frames");
+    size_t stride = 1;
+    for (const auto& t : text_tokens) stride = std::max(stride, t.size());
+    std::vector<int32_t> start(start_sequence.begin(), start_sequence.end());
+    std::vector<int32_t> ids(batch * stride, 0), lengths(batch, 0), frames(batch, 0);
+    for (size_t b = 0; b < batch; ++b) {
+      lengths[b] = static_cast<int32_t>(text_tokens[b].size());
+      frames[b] = static_cast<int32_t>(num_frames[b]);
+      for (size_t i = 0; i < text_tokens[b].size(); ++i)
+        ids[b * stride + i] = static_cast<int32_t>(text_tokens[b][i]);
+    }
+    const size_t cap = stride + 2 + f.frames;
+    std::vector<int32_t> pairs(batch * cap * 2, 0), n_pairs(batch, 0);
+    std::vector<float> probs(batch * stride, 0.f);
+    detail::check(ct2x_whisper_align(h_, f.data, static_cast<int32_t>(batch),
+                                     static_cast<int32_t>(f.n_mels), static_cast<int32_t>(f.frames),
+                                     start.data(), static_cast<int32_t>(start.size()), ids.data(),
+                                     lengths.data(), static_cast<int32_t>(stride), frames.data(),
+                                     static_cast<int32_t>(median_filter_width), static_cast<int32_t>(cap),
+                                     pairs.data(), n_pairs.data(), probs.data()));
+    std::vector<WhisperAlignmentResult> results(batch);
+    for (size_t b = 0; b < batch; ++b) {
+      for (int32_t i = 0; i < n_pairs[b]; ++i)
+        results[b].alignments.emplace_back(pairs[(b * cap + i) * 2], pairs[(b * cap + i) * 2 + 1]);
+      results[b].text_token_probs.assign(probs.begin() + b * stride,
+                                         probs.begin() + b * stride + text_tokens[b].size());
+    }
+    return results;
+  }
+
+private:
+  void* h_ = nullptr;
+  bool is_multilingual_ = false;
+  size_t n_mels_ = 0, num_languages_ = 0;
+};
+
+}  // namespace models
 
 }  // namespace ct2_mi355

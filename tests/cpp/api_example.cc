@@ -3,6 +3,7 @@
 //   api_example translate <model_dir> <beam> <token> ...      -> hypothesis tokens + score
 //   api_example generate  <model_dir> <max_length> <token> ... -> generated tokens
 //   api_example score     <model_dir> <n_src> <src tokens> <tgt tokens> -> token log-probabilities
+//   api_example whisper   <model_dir> <n_mels> <frames>        -> models::Whisper generate / detect_language
 //   api_example reject    <model_dir>                          -> an unsupported option must throw
 // Exit code 0 on success, 2 when the backend reports an error (printed on stderr).
 #include <cstdio>
@@ -57,6 +58,30 @@ int main(int argc, char** argv) {
       const auto results = translator.score_batch(source, target);
       for (size_t i = 0; i < results[0].tokens.size(); ++i)
         std::cout << results[0].tokens[i] << ' ' << results[0].tokens_score[i] << std::endl;
+    } else if (mode == "whisper") {
+      // api_example whisper <model_dir> <n_mels> <frames>: greedy transcription of a deterministic
+      // feature pattern with the prompt <|startoftranscript|> <|en|> <|transcribe|> <|notimestamps|>
+      ct2_mi355::models::Whisper whisper(model, ct2_mi355::Device::CUDA, ct2_mi355::ComputeType::FLOAT32);
+      const size_t n_mels = static_cast<size_t>(std::atoi(argv[3])), frames = static_cast<size_t>(std::atoi(argv[4]));
+      std::vector<float> data(2 * n_mels * frames);
+      for (size_t i = 0; i < data.size(); ++i)
+        data[i] = static_cast<float>(static_cast<int>((i * 37 + 11) % 101) - 50) / 40.f;
+      ct2_mi355::models::WhisperFeatures f{data.data(), 2, n_mels, frames};
+      ct2_mi355::models::WhisperOptions options;
+      options.beam_size = 1;
+      options.max_length = 24;
+      options.return_scores = true;
+      options.return_no_speech_prob = true;
+      const std::vector<std::vector<std::string>> prompts(
+          2, {"<|startoftranscript|>", "<|en|>", "<|transcribe|>", "<|notimestamps|>"});
+      const auto results = whisper.generate(f, prompts, options);
+      for (const auto& r : results) {
+        for (size_t id : r.sequences_ids[0]) std::cout << id << ' ';
+        std::cout << "| " << r.scores[0] << " | " << r.no_speech_prob << std::endl;
+      }
+      const auto langs = whisper.detect_language(f);
+      std::cout << langs[0][0].first << ' ' << langs[0][0].second << std::endl;
+      std::cout << whisper.n_mels() << ' ' << whisper.num_languages() << ' ' << whisper.is_multilingual() << std::endl;
     } else if (mode == "reject") {
       ct2_mi355::Translator translator(model);
       ct2_mi355::TranslationOptions options;

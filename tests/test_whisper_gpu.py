@@ -240,3 +240,31 @@ def test_whisper_half_beam_search_ancestry_table_equals_cache_gather(gpu, golden
     assert [r.sequences_ids for r in a] == [r.sequences_ids for r in b]
     assert [r.scores for r in a] == [r.scores for r in b]
     w.close()
+
+
+def test_whisper_cpp_api(gpu):
+    """include/ct2_mi355.hpp ct2_mi355::models::Whisper (header only, over the C ABI; option and
+    result members carry the names of include/ctranslate2/models/whisper.h) against the Python
+    surface on the same features: same sequences, scores, no-speech probabilities, language."""
+    import _cppapi
+    import ctranslate2_amd as ct2
+    path = WC.build("/tmp/ct2x_whisper_float32", "float32")
+    n_mels, frames = WC.MODEL["n_mels"], WC.FRAMES
+    rc, out, err = _cppapi.run("whisper", path, n_mels, frames)
+    assert rc == 0, err
+    lines = out.strip().splitlines()
+    i = np.arange(2 * n_mels * frames, dtype=np.int64)
+    f = (((i * 37 + 11) % 101 - 50).astype(np.float32) / np.float32(40)).reshape(2, n_mels, frames)
+    w = ct2.Whisper(path, device="cuda", compute_type="float32")
+    res = w.generate(f, [[WC.SOT, WC.EN, WC.TRANSCRIBE, WC.NOTIMESTAMPS]] * 2, beam_size=1, max_length=24,
+                     return_scores=True, return_no_speech_prob=True)
+    for line, r in zip(lines[:2], res):
+        ids, score, nsp = [s.strip() for s in line.split("|")]
+        assert [int(x) for x in ids.split()] == r.sequences_ids[0]
+        assert abs(float(score) - r.scores[0]) <= 1e-4 * max(1.0, abs(r.scores[0]))
+        assert abs(float(nsp) - r.no_speech_prob) <= 1e-4
+    lang, prob = lines[2].split()
+    best = w.detect_language(f)[0][0]
+    assert lang == best[0] and abs(float(prob) - best[1]) <= 1e-4
+    assert lines[3].split() == [str(n_mels), str(WC.NUM_LANGUAGES), "1"]
+    w.close()
