@@ -321,6 +321,12 @@ void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
     const char* e = tuning_env("CT2X_EXACT_DIV");
     return e != nullptr && e[0] == '0';
   }();
+  // Round 4: gemm_s8_big3.hip is the default; this kernel stays for A/B timing in a tuning build.
+  static const bool use_v1 = [] {
+    const char* e = tuning_env("CT2X_BIG_GEMM_V");
+    return e != nullptr && e[0] == '1';
+  }();
+  if (!use_v1) return launch_gemm_s8_big3(a, b, M, N, K, ep_in, stream);
   GemmS8Epilogue ep = ep_in;
   ep.plain_division = plain_division;
   const int tiles_m = (M + BIG_BM - 1) / BIG_BM, tiles_n = (N + BIG_BN - 1) / BIG_BN;

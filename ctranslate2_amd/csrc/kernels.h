@@ -148,6 +148,10 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
 // 256x256-tile DMA-staged kernel for MFMA-bound shapes (gemm_s8_big.hip); launch_gemm_s8 picks
 // it when gemm_s8_big_applicable (env CT2X_NO_BIG_GEMM=1 disables, for A/B comparisons).
 bool gemm_s8_big_applicable(int64_t m, int64_t n, int64_t k);
+// Round-4 form of the same kernel (gemm_s8_big3.hip: 32x32x32 MFMA, swapped operands for 16-byte
+// stores, persistent tile stream); launch_gemm_s8_big forwards to it.
+void launch_gemm_s8_big3(const int8_t* a, const int8_t* b, int M, int N, int K,
+                         const GemmS8Epilogue& ep, hipStream_t stream);
 void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
                         const GemmS8Epilogue& ep, hipStream_t stream);
 

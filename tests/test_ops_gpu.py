@@ -39,6 +39,9 @@ GEMM_SHAPES = [
     # >= 96 tiles of 256x256 with K % 128 == 0: the DMA-staged 256x256 kernel (gemm_s8_big.hip),
     # full tiles and ragged M/N edges
     (2560, 2560, 256), (2500, 2700, 384), (513, 12289, 640),
+    # > 256 tiles: the persistent workgroups of gemm_s8_big3.hip walk more than one tile each
+    # (full tiles; ragged edges with a row pitch that allows / forbids 16-byte stores)
+    (4352, 4352, 256), (4200, 4404, 384), (4100, 4299, 256),
 ]
 
 
@@ -96,7 +99,7 @@ def test_dequantize_gemm_output(gpu, act):
 
 @pytest.mark.parametrize("m,n,k", [(32, 1536, 512), (32, 512, 2048), (128, 2048, 512),
                                    (16, 4096, 4096), (5, 43, 32), (70, 96, 32),
-                                   (2500, 2700, 256)])
+                                   (2500, 2700, 256), (4200, 4404, 256)])
 @pytest.mark.parametrize("act,with_res", [(-1, True), (0, False), (2, False), (-1, False)])
 def test_dense_fused_vs_unfused_oracle(gpu, m, n, k, act, with_res):
     """layers::Dense int8 (Quantize -> Gemm -> Dequantize(+bias,act) -> Add residual) as ONE fused
