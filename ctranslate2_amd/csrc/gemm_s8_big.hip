@@ -326,7 +326,19 @@ void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
     const char* e = tuning_env("CT2X_BIG_GEMM_V");
     return e != nullptr && e[0] == '1';
   }();
-  if (!use_v1) return launch_gemm_s8_big3(a, b, M, N, K, ep_in, stream);
+  static const bool use_v5 = [] {
+    const char* e = tuning_env("CT2X_BIG_GEMM_V");
+    return e != nullptr && e[0] == '5';
+  }();
+  if (use_v5) return launch_gemm_s8_big5(a, b, M, N, K, ep_in, stream);
+  // The fused forms run 4 - 9 % faster on gemm_s8_big3.hip (16-byte stores, operands by LDS-DMA,
+  // no predicates inside a tile); the raw int32 result leaves 5 - 10 % faster from this kernel
+  // (profiles/r04_gemm_bench_g.txt), so ops::Gemm's int32 form stays here.
+  static const bool force_v3 = [] {
+    const char* e = tuning_env("CT2X_BIG_GEMM_V");
+    return e != nullptr && e[0] == '3';
+  }();
+  if (!use_v1 && (ep_in.mode == 1 || force_v3)) return launch_gemm_s8_big3(a, b, M, N, K, ep_in, stream);
   GemmS8Epilogue ep = ep_in;
   ep.plain_division = plain_division;
   const int tiles_m = (M + BIG_BM - 1) / BIG_BM, tiles_n = (N + BIG_BN - 1) / BIG_BN;

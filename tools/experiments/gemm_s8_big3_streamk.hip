@@ -23,13 +23,27 @@
 //     through L2 while tile i+1 computes (gfx950 counts loads and stores on one in-order vmcnt,
 //     so the first DMA wait of the next tile is also the point where tile i's stores are known
 //     to have reached L2 - about three phases after they were issued).
-//   * (A STREAM-K work split - equal runs of K-tiles per workgroup, a tile shared by two
-//     workgroups finished by the last arriver through a 256 KiB slab of raw accumulators - was
-//     built on top of this kernel, bit-exact in all arms, and measured SLOWER: 160 - 165 us against
-//     130 - 137 at the Llama-3-8B prefill shape (448 tiles on 256 CUs). The balance it buys (1.75
-//     instead of 2 tile times) is lost twice over: the workgroups of an XCD no longer walk K in
-//     lockstep, so an operand line is no longer in L2 when the next CU asks for it, and the slab
-//     traffic comes on top. tools/experiments/gemm_s8_big3_streamk.hip, profiles/r04_gemm_bench_e / f.)
+//   * STREAM-K work split: the unit of work is one K-tile (128 bytes of K) of one output tile, and
+//     every workgroup gets the same number of consecutive units (+-1). A launch whose tile count
+//     is not a multiple of the CU count (Llama-3-8B prefill FFN-in: 448 tiles on 256 CUs = 1.75
+//     rounds, which data-parallel tiles pay as 2) then ends on every CU at the same time, and -
+//     as important - the tile boundaries of different CUs fall at DIFFERENT times, so the fp32
+//     results no longer leave all 256 CUs in the same few microseconds (a burst the HBM absorbs at
+//     ~5 TB/s with every matrix pipe idle). A tile split between two workgroups is finished by
+//     whichever of the two arrives last (ticket), so nobody ever waits for a workgroup that is
+//     not resident: the first arriver writes its raw int32 accumulators to a 256 KiB slab, waits
+//     for the stores (vmcnt = the bytes are in the XCD's L2) and publishes a flag carrying its
+//     XCC id; the second adds the slab with L1-bypassing (sc1) loads and runs the epilogue. The
+//     split runs INSIDE an XCD (every XCD owns whole tiles, its workgroups share them), so both
+//     contributors normally sit behind the same L2 and the slab needs no write-back: a first
+//     version with write-through (sc1) slab stores for any placement stalled each workgroup
+//     ~13 us on the drain and lost more than the balance gained (profiles/r04_gemm_*). The
+//     placement is only observed, never promised, so the second arriver compares the XCC id in
+//     the flag with its own (s_getreg HW_REG_XCC_ID) and, if they differ, ignores the slab and
+//     computes the missing K-tiles itself (slower, always correct; CT2X_BIG3_SK=3 in a tuning
+//     build forces that arm for the tests). int32 addition is exact and commutative: results are
+//     bit-identical to the unsplit tile. Counters are zeroed by a memset node in front of every
+//     launch (replay-safe).
 //   * Interior tiles take an epilogue without bounds predicates; edge tiles keep them.
 // Unchanged: 256 x 256 tile, K advanced 128 bytes per stage, L2 -> LDS by global_load_lds_dwordx4
 // with the bank swizzle on the source address (chunk c of tile row r at slot c ^ ((r >> 1) & 7):
@@ -43,6 +57,9 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace ct2x {
 
@@ -75,7 +92,9 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
                                                                  const int8_t* __restrict__ B,
                                                                  int M, int N, int K,
                                                                  int tiles_m, int tiles_n,
-                                                                 GemmS8Epilogue ep) {
+                                                                 GemmS8Epilogue ep,
+                                                                 int unit_align, int sk_mode,
+                                                                 int32_t* sk_slabs, unsigned* sk_counters) {
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];  // the ONLY LDS object
 
   const int tid = threadIdx.x;
@@ -85,25 +104,28 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
   const int group = wm;
   const int r = lane & 15, g = lane >> 4;
 
-  // Persistent tile list: hardware block b sits on XCD b % 8 (observed, speed only). XCD x owns
-  // the contiguous logical tile range [first, first + count) (band order below: an 8-row band
-  // walked column by column - shared A rows / B columns in that XCD's L2); its blocks walk it
-  // with a stride of the XCD's block count, all at the same K offset at the same time (an
-  // operand line is fetched once per XCD and found in L2 by the other CUs), and a ragged last
-  // round is spread over ALL XCDs (measured: a last round that left two XCDs idle and six full
-  // ran 6 % slower than the same tiles spread over eight - the clocks follow the load per XCD).
+  // Work list: hardware block b sits on XCD b % 8 (observed, speed only). XCD x owns the
+  // contiguous logical tiles [first, first + count) (band order: an 8-row band walked column by
+  // column, shared A rows / B columns in that XCD's L2) = count * ktiles units of one K-tile each;
+  // its P workgroups take consecutive, equally long unit ranges, rounded down to a multiple of
+  // unit_align: 1 for the stream-K split, ktiles for whole tiles (no slab workspace, or nothing
+  // to balance). count >= P (launcher), so a tile has at most two contributors: (x, idx) with its
+  // first K-tiles and (x, idx + 1) = hardware block b + 8 with the rest.
   const int ntiles = tiles_m * tiles_n;
   const int ktiles = K / T_BK;  // >= 2 (gemm_s8_big_applicable)
   const int G = gridDim.x;
-  int L, Lend, Lstep;
+  const int blk = blockIdx.x;
+  int u, u_end;
   {
-    const int b = blockIdx.x;
-    const int xcd = b & 7;
+    const int xcd = blk & 7, idx = blk >> 3;
+    const int P = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
     const int q = ntiles >> 3, rem = ntiles & 7;
     const int first = xcd * q + min(xcd, rem);
-    Lstep = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
-    L = first + (b >> 3);
-    Lend = first + q + (xcd < rem ? 1 : 0);
+    const int64_t Ux = static_cast<int64_t>(q + (xcd < rem ? 1 : 0)) * ktiles;
+    u = static_cast<int>(idx * Ux / P);
+    u_end = static_cast<int>((idx + 1) * Ux / P);
+    u = first * ktiles + u - u % unit_align;
+    u_end = first * ktiles + u_end - u_end % unit_align;
   }
   auto coords = [&](int L, int& tm, int& tn) {
     constexpr int BAND = 8;
@@ -201,11 +223,16 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
   int* slow_div = reinterpret_cast<int*>(lds + T_FLAG_OFFSET);
   if (tid == 0) *slow_div = ep.plain_division ? 1 : 0;
 
-  if (L >= Lend) return;  // (fewer tiles than blocks on this XCD: never with the launcher's grid)
+  if (u >= u_end) return;  // (never with the launcher's grid: G <= ntiles)
+  int L = u / ktiles;
+  int kb = u - L * ktiles;
+  int ke = min(ktiles, kb + (u_end - u));
+  int u_next = u + (ke - kb);
+  bool keep_acc = false, whole = false;  // (set when a split tile is completed by recomputation)
   int tm, tn;
   coords(L, tm, tn);
   set_sources(tm, tn);
-  stage(0, 0);
+  stage(0, kb * T_BK);
   stage_params(0, tm, tn);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   int gt = 0;      // K-tile counter across tiles: stage buffer = gt & 1
@@ -220,21 +247,25 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
   // requested in L(t,0) into the buffer both groups finished reading a phase ago, and every
   // wave waits for its own share before the barrier in front of group 0's L(t+1,0).
   while (true) {
-    const int Lnext = L + Lstep;
-    const bool has_next = Lnext < Lend;
+    // this segment: K-tiles [kb, ke) of tile L; the next one starts at a tile boundary
+    const bool has_next = u_next < u_end;
+    const int Lnext = L + 1;
     int tm_n = 0, tn_n = 0;
     if (has_next) coords(Lnext, tm_n, tn_n);
+    if (!keep_acc) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+    }
+    keep_acc = false;
 
     phase_barrier();  // this tile's first stage (and its parameters) are in LDS
     if (group == 1) phase_barrier();
-    for (int t = 0; t < ktiles; ++t) {
+    for (int t = kb; t < ke; ++t) {
       const int buf = gt & 1;
       load_frags(buf, 0);
-      if (t + 1 < ktiles) {
+      if (t + 1 < ke) {
         stage(buf ^ 1, (t + 1) * T_BK);
       } else if (has_next) {
         set_sources(tm_n, tn_n);
@@ -256,8 +287,78 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
     }
     if (group == 0) phase_barrier();
 
+    // ---- a tile shared with the neighbouring workgroup: the last arriver finishes it ----------
+    bool finish = true, merge = false;
+    __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc(sk_slabs, 0, 0, 0x00020000);
+    if (!whole && (kb > 0 || ke < ktiles)) {
+      const int idx = kb > 0 ? blk - 8 : blk;  // split id = the block that holds K-tile 0
+      unsigned* cnt = sk_counters + 2 * idx;
+      slab = __builtin_amdgcn_make_buffer_rsrc(sk_slabs + static_cast<int64_t>(idx) * (T_BM * T_BN), 0,
+                                               T_BM * T_BN * 4, 0x00020000);
+      unsigned my_xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(my_xcc));
+      unsigned* sk_lds = reinterpret_cast<unsigned*>(lds + T_FLAG_OFFSET) + 1;
+      if (tid == 0)
+        *sk_lds = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      phase_barrier();
+      const unsigned ticket = __builtin_amdgcn_readfirstlane(*sk_lds);
+      if (ticket == 0) {
+        // first arriver: raw accumulators out; every wave waits until its stores are in L2, then
+        // ONE lane raises the flag (agent-scope store) with this CU's XCC id in it
+        int voff = tid;  // (opaque: not worth a register across the K loop)
+        asm volatile("" : "+v"(voff));
+        voff *= 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(acc[i][j], slab, voff + (i * 4 + j) * (T_THREADS * 16), 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        phase_barrier();
+        if (tid == 0)
+          __hip_atomic_store(cnt + 1, 0x100u | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        finish = false;
+      } else {
+        // second arriver: the slab is complete once the flag is up (it usually has been for a
+        // long time; otherwise the first arriver is resident and past its K loop)
+        phase_barrier();  // (everyone has read the ticket before the word is reused)
+        if (tid == 0) {
+          unsigned spins = 0, f = 0;
+          while ((f = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u &&
+                 ++spins < (1u << 26))
+            __builtin_amdgcn_s_sleep(8);
+          *sk_lds = f;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        phase_barrier();
+        const unsigned flag = __builtin_amdgcn_readfirstlane(*sk_lds);
+        if ((flag & 0xffu) == my_xcc && flag != 0u && !(sk_mode & 2)) {
+          merge = true;  // same L2: the epilogue reads accumulator + slab (L1 bypassed)
+        } else {
+          // the slab may sit in another XCD's L2: compute the partner's K-tiles here instead
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          phase_barrier();
+          if (kb > 0) {
+            ke = kb;
+            kb = 0;
+          } else {
+            kb = ke;
+            ke = ktiles;
+          }
+          set_sources(tm, tn);
+          stage(gt & 1, kb * T_BK);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          keep_acc = true;
+          whole = true;
+          continue;
+        }
+      }
+    }
+    whole = false;
+
     // ---- epilogue of tile (tm, tn); both groups are aligned here -------------------------
-    {
+    if (finish) {
     // C/D layout of the 16x16 MFMA: col j = lane & 15, row i = (lane >> 4) * 4 + reg; with the
     // operands swapped i is the output column and j the output row.
     // (The lane coordinates are re-derived behind an opaque move so that no per-lane address of
@@ -265,6 +366,7 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int re = lane_e & 15, ge = lane_e >> 4;
+    const int voff = (lane_e + wave * 64) * 16;
     const int64_t m0 = static_cast<int64_t>(tm) * T_BM;
     const int64_t n0 = static_cast<int64_t>(tn) * T_BN;
     // 16-byte stores need the row pitch and the base addresses to allow them.
@@ -287,7 +389,8 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
         for (int i = 0; i < 8; ++i) {
           const int64_t row = m0 + wm * 128 + i * 16 + re;
           int32_t* p = c + row * ep.ldy + n0 + cl;
-          const v4i c4 = acc[i][j];
+          v4i c4 = acc[i][j];
+          if (merge) c4 += __builtin_amdgcn_raw_buffer_load_b128(slab, voff + (i * 4 + j) * (T_THREADS * 16), 0, 16);
           if (full) {
             *reinterpret_cast<v4i*>(p) = c4;
           } else if (row < M) {
@@ -316,14 +419,21 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
       float* __restrict__ y = ep.y;
       const float* __restrict__ res = ep.residual;
       const float* ra = par + wm * 128 + re;  // 1 / a_scale of the lane's rows: ra[i * 16]
-#define CT2X_BIG3_EPILOGUE(FAST)                                                                  \
+#define CT2X_BIG3_EPILOGUE(FAST, MERGE)                                                                  \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
     const int cl = wn * 64 + j * 16 + ge * 4;                                                     \
     const v4f ws = *reinterpret_cast<const v4f*>(par + 256 + cl);                                 \
     const v4f wi = *reinterpret_cast<const v4f*>(par + 768 + cl);                                 \
     const v4f bs = has_bias ? *reinterpret_cast<const v4f*>(par + 512 + cl) : v4f{0, 0, 0, 0};    \
+    v4i part[4];                                                                                  \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                               \
-      const v4i c4 = acc[i][j];                                                                   \
+      if (MERGE && (i & 3) == 0) {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) part[ii] =                               \
+            __builtin_amdgcn_raw_buffer_load_b128(slab, voff + ((i + ii) * 4 + j) * (T_THREADS * 16), 0, 16); \
+      }                                                                                           \
+      v4i c4 = acc[i][j];                                                                         \
+      if (MERGE) c4 += part[i & 3];                                                               \
       const int64_t row = m0 + wm * 128 + i * 16 + re;                                            \
       const int64_t at = row * ep.ldy + n0 + cl;                                                  \
       v4f rs = v4f{0, 0, 0, 0};                                                                   \
@@ -349,18 +459,24 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
       }                                                                                           \
     }                                                                                             \
   }
-      if (fast_div) {
-        CT2X_BIG3_EPILOGUE(true)
+      if (merge) {  // (rare: one tile per workgroup at most; plain division keeps the code small)
+        CT2X_BIG3_EPILOGUE(false, true)
+      } else if (fast_div) {
+        CT2X_BIG3_EPILOGUE(true, false)
       } else {
-        CT2X_BIG3_EPILOGUE(false)
+        CT2X_BIG3_EPILOGUE(false, false)
       }
 #undef CT2X_BIG3_EPILOGUE
     }
 
-    }
+    }  // finish
 
     if (!has_next) break;
+    u = u_next;
     L = Lnext;
+    kb = 0;
+    ke = min(ktiles, u_end - u);
+    u_next = u + ke;
     tm = tm_n;
     tn = tn_n;
     ++round;
@@ -380,9 +496,45 @@ int device_cu_count() {
   return v;
 }
 
+// Stream-K workspace of a stream: one 256 KiB slab of raw accumulators and two counters (ticket,
+// ready flag) per workgroup slot. Allocated on first use, kept for the life of the process (a
+// launch on a stream runs behind the previous one, so one set per stream is enough).
+struct SkWorkspace {
+  int32_t* slabs = nullptr;
+  unsigned* counters = nullptr;
+  int slots = 0;
+};
+SkWorkspace* sk_workspace(hipStream_t stream, int slots) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SkWorkspace> table;
+  int dev = 0;
+  CT2X_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  SkWorkspace& w = table[{dev, stream}];
+  if (w.slots >= slots) return &w;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;  // no allocation inside a capture: this launch runs whole tiles
+  }
+  int32_t* slabs = nullptr;
+  unsigned* counters = nullptr;
+  if (hipMalloc(&slabs, static_cast<size_t>(slots) * T_BM * T_BN * 4) != hipSuccess ||
+      hipMalloc(&counters, static_cast<size_t>(slots) * 2 * sizeof(unsigned)) != hipSuccess) {
+    (void)hipGetLastError();
+    if (slabs) (void)hipFree(slabs);
+    return nullptr;
+  }
+  // (a smaller earlier set stays allocated: a captured graph may still hold its addresses)
+  w.slabs = slabs;
+  w.counters = counters;
+  w.slots = slots;
+  return &w;
+}
+
 template <int ACT, int VAR = 0>
 void launch_big3(const int8_t* a, const int8_t* b, int M, int N, int K, int tiles_m, int tiles_n,
-                 const GemmS8Epilogue& ep, int grid, hipStream_t stream) {
+                 const GemmS8Epilogue& ep, int grid, int sk_mode, hipStream_t stream) {
   // > 64 KiB of dynamic LDS has to be opted into once per device.
   static std::atomic<bool> configured[64];
   int dev = 0;
@@ -392,8 +544,19 @@ void launch_big3(const int8_t* a, const int8_t* b, int M, int N, int K, int tile
                                        hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES));
     configured[dev & 63].store(true, std::memory_order_release);
   }
+  int unit_align = K / T_BK;  // whole tiles
+  int32_t* slabs = nullptr;
+  unsigned* counters = nullptr;
+  if (sk_mode) {
+    if (SkWorkspace* w = sk_workspace(stream, grid)) {
+      slabs = w->slabs;
+      counters = w->counters;
+      unit_align = 1;
+      CT2X_HIP_CHECK(hipMemsetAsync(counters, 0, static_cast<size_t>(grid) * 2 * sizeof(unsigned), stream));
+    }
+  }
   hipLaunchKernelGGL((gemm_s8_big3_kernel<ACT, VAR>), dim3(grid), dim3(T_THREADS), T_LDS_BYTES, stream,
-                     a, b, M, N, K, tiles_m, tiles_n, ep);
+                     a, b, M, N, K, tiles_m, tiles_n, ep, unit_align, sk_mode, slabs, counters);
 }
 
 }  // namespace
@@ -416,24 +579,35 @@ void launch_gemm_s8_big3(const int8_t* a, const int8_t* b, int M, int N, int K,
   int grid = std::min(ntiles, device_cu_count());
   if (grid_override == 0) grid = ntiles;
   else if (grid_override > 0) grid = std::min(ntiles, grid_override);
+  // Stream-K only where there is something to balance: more than one tile per workgroup and a
+  // ragged last round (CT2X_BIG3_SK=0 / 1 in a tuning build: never / whenever grid < tiles).
+  static const int sk_override = [] {
+    const char* e = tuning_env("CT2X_BIG3_SK");
+    return e ? std::atoi(e) : -1;
+  }();
+  int stream_k = (grid < ntiles && ntiles % grid != 0) ? 1 : 0;  // kernel's sk_mode
+  if (sk_override == 0) stream_k = 0;
+  if (sk_override == 1 && grid < ntiles) stream_k = 1;
+  if (sk_override == 3 && grid < ntiles) stream_k = 3;  // + treat every slab as foreign (tests)
+  if (ntiles / 8 < (grid + 7) / 8) stream_k = 0;  // an XCD with fewer tiles than workgroups
   const int act = (ep.mode == 1 && ep.act > 0) ? ep.act : -1;
 #ifdef CT2X_TUNING
   static const int var = [] {
     const char* e = tuning_env("CT2X_BIG3_VAR");
     return e ? std::atoi(e) : 0;
   }();
-  if (var == 1) return launch_big3<-1, 1>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream);
-  if (var == 2) return launch_big3<-1, 2>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream);
-  if (var == 3) return launch_big3<-1, 3>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream);
+  if (var == 1) return launch_big3<-1, 1>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream_k, stream);
+  if (var == 2) return launch_big3<-1, 2>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream_k, stream);
+  if (var == 3) return launch_big3<-1, 3>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream_k, stream);
 #endif
   switch (act) {
-    case 1: launch_big3<1>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    case 2: launch_big3<2>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    case 3: launch_big3<3>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    case 4: launch_big3<4>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    case 5: launch_big3<5>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    case 6: launch_big3<6>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    default: launch_big3<-1>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
+    case 1: launch_big3<1>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream_k, stream); break;
+    case 2: launch_big3<2>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream_k, stream); break;
+    case 3: launch_big3<3>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream_k, stream); break;
+    case 4: launch_big3<4>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream_k, stream); break;
+    case 5: launch_big3<5>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream_k, stream); break;
+    case 6: launch_big3<6>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream_k, stream); break;
+    default: launch_big3<-1>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream_k, stream); break;
   }
 }
 
