@@ -326,11 +326,13 @@ void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
     const char* e = tuning_env("CT2X_BIG_GEMM_V");
     return e != nullptr && e[0] == '1';
   }();
+#ifdef CT2X_TUNING  // the two-workgroups-per-CU experiment is only part of a tuning build
   static const bool use_v5 = [] {
     const char* e = tuning_env("CT2X_BIG_GEMM_V");
     return e != nullptr && e[0] == '5';
   }();
   if (use_v5) return launch_gemm_s8_big5(a, b, M, N, K, ep_in, stream);
+#endif
   // The fused forms run 4 - 9 % faster on gemm_s8_big3.hip (16-byte stores, operands by LDS-DMA,
   // no predicates inside a tile); the raw int32 result leaves 5 - 10 % faster from this kernel
   // (profiles/r04_gemm_bench_g.txt), so ops::Gemm's int32 form stays here.
