@@ -101,6 +101,20 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                                                  C.c_char_p(raw))
 
     @classmethod
+    def tensor_parallel_shm(cls, model_path: str, rank: int, world: int, segment: str,
+                            device_index: int = 0, compute_type: str = "default"):
+        """Rank `rank` of `world` tensor-parallel PROCESSES of one node connected without RCCL:
+        shared-memory bootstrap under the name `segment`, hipIpc mailboxes for the decode-step
+        exchanges (ct2x_translator_create_tp_shm). The ranks may share a device."""
+        L = _lib.lib()
+        h = L.ct2x_translator_create_tp_shm(model_path.encode(), C.c_int(device_index),
+                                            compute_type.encode(), C.c_int(rank), C.c_int(world),
+                                            segment.encode())
+        if not h:
+            raise Ct2xError(L.ct2x_last_error().decode("utf-8", "replace"))
+        return cls(model_path, device_index=device_index, compute_type=compute_type, _handle=h)
+
+    @classmethod
     def tensor_parallel_local(cls, model_path: str, world: int, device_index: int = 0,
                               compute_type: str = "default"):
         """`world` tensor-parallel ranks inside THIS process on one device, connected by the
@@ -134,6 +148,15 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         out["is_seq2seq"] = bool(out["is_seq2seq"])
         out["compute_type"] = buf.value.decode()
         return out
+
+    def tensor_parallel_info(self):
+        """rank, world, backend name and whether the one-shot mailboxes are mapped (ct2x_tp_info)."""
+        rank, world, boxes = C.c_int32(), C.c_int32(), C.c_int32()
+        buf = C.create_string_buffer(32)
+        _lib.check(self._L.ct2x_tp_info(C.c_void_p(self._h), C.byref(rank), C.byref(world),
+                                        C.byref(boxes), buf, C.c_int(32)))
+        return {"rank": rank.value, "world": world.value, "mailboxes": bool(boxes.value),
+                "backend": buf.value.decode()}
 
     def token_to_id(self, token: str, target: bool = False) -> int:
         return int(self._L.ct2x_vocab_id(C.c_void_p(self._h), C.c_int(int(target)), token.encode("utf-8")))

@@ -92,6 +92,11 @@ def lib():
         L.ct2x_translator_create_tp.restype = C.c_void_p
         L.ct2x_translator_create_tp.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                                 C.c_char_p]
+        L.ct2x_translator_create_tp_shm.restype = C.c_void_p
+        L.ct2x_translator_create_tp_shm.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                                    C.c_char_p]
+        L.ct2x_tp_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32), C.c_char_p, C.c_int]
         L.ct2x_translator_create_tp_local.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int,
                                                       C.POINTER(C.c_void_p)]
         L.ct2x_tp_unique_id.argtypes = [C.c_char_p]

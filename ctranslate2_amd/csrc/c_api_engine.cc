@@ -539,6 +539,25 @@ void* ct2x_translator_create_tp(const char* model_dir, int device_index, const c
   }
 }
 
+void* ct2x_translator_create_tp_shm(const char* model_dir, int device_index, const char* compute_type,
+                                    int rank, int world, const char* segment_name) {
+  try {
+    CT2X_CHECK(world >= 2 && rank >= 0 && rank < world, "invalid tensor-parallel rank / world size");
+    CT2X_CHECK(segment_name != nullptr && segment_name[0] != 0, "the shared-memory communicator needs a segment name");
+    auto t = std::make_unique<Translator>();
+    t->model = ModelFile::load(model_dir);
+    CT2X_HIP_CHECK(hipSetDevice(device_index));
+    std::shared_ptr<TpComm> comm = make_shm_comm(rank, world, segment_name);
+    t->engine = std::make_unique<Engine>(t->model, compute_type ? compute_type : "default",
+                                         device_index, comm);
+    load_vocabularies(*t);
+    return t.release();
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return nullptr;
+  }
+}
+
 int ct2x_translator_create_tp_local(const char* model_dir, int device_index,
                                     const char* compute_type, int world, void** handles_out) {
   API_TRY
@@ -1422,6 +1441,21 @@ int ct2x_model_info(void* translator, int32_t* is_seq2seq, int32_t* vocab_size, 
     const std::string s = compute_type_name(t->engine->compute_type());
     std::strncpy(compute_type, s.c_str(), ct_size - 1);
     compute_type[ct_size - 1] = 0;
+  }
+  API_CATCH
+}
+
+int ct2x_tp_info(void* translator, int32_t* rank, int32_t* world, int32_t* has_mailboxes,
+                 char* backend, int backend_size) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr, "null translator");
+  if (rank) *rank = t->engine->tp_rank();
+  if (world) *world = t->engine->tp_world();
+  if (has_mailboxes) *has_mailboxes = t->engine->tp_has_mailboxes() ? 1 : 0;
+  if (backend && backend_size > 0) {
+    std::strncpy(backend, t->engine->tp_backend(), backend_size - 1);
+    backend[backend_size - 1] = 0;
   }
   API_CATCH
 }

@@ -202,6 +202,8 @@ public:
   int device_index() const { return device_; }
   int tp_world() const { return tp_ ? tp_->world() : 1; }
   int tp_rank() const { return tp_ ? tp_->rank() : 0; }
+  const char* tp_backend() const { return tp_ ? tp_->backend() : "none"; }
+  bool tp_has_mailboxes() const { return tp_ && tp_->peer_box() != nullptr; }
   hipStream_t stream() const { return stream_; }
   hipStream_t cur_stream() const;  // stream of the session driven by the calling thread
   int64_t weight_bytes() const { return weight_bytes_; }

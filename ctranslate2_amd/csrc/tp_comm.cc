@@ -3,9 +3,15 @@
 #include "tp_comm.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -296,7 +302,212 @@ private:
   bool has_box_ = false;
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Node-local communicator WITHOUT RCCL: one process per rank, bootstrap and the (rare) large
+// collectives through a POSIX shared-memory segment, the decode-step exchanges through the same
+// hipIpc peer-mapped mailboxes and one-shot kernels as the RCCL communicator. Two uses: hosts
+// where RCCL is not installed, and - what the single-GPU test tier runs - TWO PROCESSES ON ONE
+// GPU: RCCL refuses two ranks on one device, this communicator does not, so the real
+// cross-process path (hipIpcGetMemHandle / hipIpcOpenMemHandle, system-scope granule stores into
+// another process's mailbox, polls inside kernels of two different processes that run
+// concurrently) is exercised where only one GPU is visible.
+// Segment layout: header (barrier words, one IPC handle per rank) | world x kShmChunk bytes.
+// The fallback collectives stage through host memory chunk by chunk (D2H, barrier, combine in
+// rank order on every rank, barrier, H2D): slow, deterministic, identical on every rank; they
+// serve the shapes outside the one-shot envelope (encoder / prefill rows), never a decode step.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kShmChunk = 8u << 20;
+struct ShmHeader {
+  std::atomic<uint32_t> ready;       // rank 0 has initialised the segment
+  std::atomic<uint32_t> arrived;     // barrier: arrivals of the running generation
+  std::atomic<uint32_t> generation;  // barrier: bumped by the last arriver
+  std::atomic<uint32_t> poisoned;    // a rank gave up
+  hipIpcMemHandle_t handles[kTpMaxWorld];
+  char pad[4096 - 16 - sizeof(hipIpcMemHandle_t) * kTpMaxWorld];
+};
+static_assert(sizeof(ShmHeader) == 4096, "segment header");
+
+class ShmComm : public TpComm {
+public:
+  ShmComm(int rank, int world, const std::string& name) : rank_(rank), world_(world), name_("/" + name) {
+    if (world < 2 || world > kTpMaxWorld) throw Error("shared-memory communicator: world size must be 2..8");
+    bytes_ = sizeof(ShmHeader) + static_cast<size_t>(world) * kShmChunk;
+    int fd = -1;
+    if (rank == 0) {
+      (void)shm_unlink(name_.c_str());
+      fd = shm_open(name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0 || ftruncate(fd, static_cast<off_t>(bytes_)) != 0)
+        throw Error("shared-memory communicator: cannot create " + name_);
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      struct stat st;
+      while ((fd = shm_open(name_.c_str(), O_RDWR, 0600)) < 0 ||
+             (fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) < bytes_)) {
+        if (fd >= 0) close(fd);
+        fd = -1;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+          throw Error("shared-memory communicator: rank 0 never created " + name_);
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+      }
+    }
+    void* p = mmap(nullptr, bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) throw Error("shared-memory communicator: mmap failed");
+    hdr_ = static_cast<ShmHeader*>(p);
+    data_ = static_cast<char*>(p) + sizeof(ShmHeader);
+    if (rank == 0) {
+      // (a fresh segment is zero filled; `ready` tells the others that it is THIS run's segment)
+      hdr_->ready.store(0x43543258u, std::memory_order_release);
+    } else {
+      wait_for([&] { return hdr_->ready.load(std::memory_order_acquire) == 0x43543258u; },
+               "rank 0 never initialised the segment");
+    }
+    const char* e = std::getenv("CT2X_TP_ONESHOT");
+    bool want_boxes = !(e && e[0] == '0');
+    // Every rank publishes a handle (or zeros) and takes part in both barriers, whatever happens
+    // to its own allocation: a refusal on one rank must not leave the others waiting.
+    hipIpcMemHandle_t mine;
+    std::memset(&mine, 0, sizeof(mine));
+    if (want_boxes) {
+      const size_t bytes = tp_box_bytes();
+      if (hipExtMallocWithFlags(reinterpret_cast<void**>(&own_box_), bytes, hipDeviceMallocFinegrained) != hipSuccess ||
+          hipMemset(own_box_, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+          hipIpcGetMemHandle(&mine, own_box_) != hipSuccess) {
+        (void)hipGetLastError();
+        std::memset(&mine, 0, sizeof(mine));
+        want_boxes = false;
+      }
+    }
+    hdr_->handles[rank] = mine;
+    barrier();
+    pb_.rank = rank;
+    pb_.world = world;
+    bool ok = want_boxes;
+    const hipIpcMemHandle_t zero = {};
+    for (int r = 0; r < world && ok; ++r) {
+      if (r == rank) {
+        pb_.box[r] = own_box_;
+      } else if (std::memcmp(&hdr_->handles[r], &zero, sizeof(zero)) == 0) {
+        ok = false;
+      } else {
+        void* q = nullptr;
+        if (hipIpcOpenMemHandle(&q, hdr_->handles[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+          (void)hipGetLastError();
+          ok = false;
+        } else {
+          pb_.box[r] = static_cast<char*>(q);
+          opened_[r] = true;
+        }
+      }
+    }
+    // all ranks or none: a rank without mailboxes would take the collective path alone
+    if (!ok) hdr_->poisoned.fetch_or(2u);
+    barrier();
+    has_box_ = ok && (hdr_->poisoned.load() & 2u) == 0;
+    barrier();
+    if (rank == 0) (void)shm_unlink(name_.c_str());  // the mapping outlives the name
+  }
+  ~ShmComm() override {
+    for (int r = 0; r < world_; ++r)
+      if (opened_[r]) (void)hipIpcCloseMemHandle(pb_.box[r]);
+    if (own_box_) (void)hipFree(own_box_);
+    if (hdr_) munmap(hdr_, bytes_);
+  }
+  const TpPeerBox* peer_box() const override { return has_box_ ? &pb_ : nullptr; }
+  int rank() const override { return rank_; }
+  int world() const override { return world_; }
+  const char* backend() const override { return "shared-memory"; }
+  bool capturable() const override { return false; }  // host staging inside every collective
+  void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+    for (size_t off = 0; off < bytes; off += kShmChunk) {
+      const size_t n = std::min(kShmChunk, bytes - off);
+      CT2X_HIP_CHECK(hipMemcpyAsync(data_ + rank_ * kShmChunk, static_cast<const char*>(send) + off, n,
+                                    hipMemcpyDeviceToHost, stream));
+      CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+      barrier();
+      for (int r = 0; r < world_; ++r)
+        CT2X_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(recv) + static_cast<size_t>(r) * bytes + off,
+                                      data_ + r * kShmChunk, n, hipMemcpyHostToDevice, stream));
+      CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+      barrier();
+    }
+  }
+  void all_reduce_sum_i32(int32_t* buf, int64_t count, hipStream_t stream) override {
+    reduce<int32_t>(buf, count, stream, [](int32_t a, int32_t b) { return a + b; });
+  }
+  void all_reduce_sum_f32(float* buf, int64_t count, hipStream_t stream) override {
+    reduce<float>(buf, count, stream, [](float a, float b) { return a + b; });
+  }
+  void all_reduce_max_f32(float* buf, int64_t count, hipStream_t stream) override {
+    reduce<float>(buf, count, stream, [](float a, float b) { return a > b ? a : b; });
+  }
+
+private:
+  template <typename F>
+  void wait_for(F&& cond, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (!cond()) {
+      if (hdr_->poisoned.load() & 1u) throw Error("shared-memory communicator: aborted by a peer");
+      if ((++spins & 1023u) == 0) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+          hdr_->poisoned.fetch_or(1u);
+          throw Error(std::string("shared-memory communicator: ") + what);
+        }
+        std::this_thread::yield();
+      }
+    }
+  }
+  void barrier() {
+    const uint32_t gen = hdr_->generation.load(std::memory_order_acquire);
+    if (hdr_->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == static_cast<uint32_t>(world_)) {
+      hdr_->arrived.store(0, std::memory_order_relaxed);
+      hdr_->generation.store(gen + 1, std::memory_order_release);
+    } else {
+      wait_for([&] { return hdr_->generation.load(std::memory_order_acquire) != gen; },
+               "a rank did not reach the collective");
+    }
+  }
+  template <typename T, typename Op>
+  void reduce(T* buf, int64_t count, hipStream_t stream, Op op) {
+    const int64_t per = static_cast<int64_t>(kShmChunk / sizeof(T));
+    std::vector<T> out;
+    for (int64_t off = 0; off < count; off += per) {
+      const int64_t n = std::min(per, count - off);
+      CT2X_HIP_CHECK(hipMemcpyAsync(data_ + rank_ * kShmChunk, buf + off, n * sizeof(T),
+                                    hipMemcpyDeviceToHost, stream));
+      CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+      barrier();
+      out.resize(n);
+      const T* first = reinterpret_cast<const T*>(data_);
+      for (int64_t i = 0; i < n; ++i) out[i] = first[i];
+      for (int r = 1; r < world_; ++r) {  // rank order: the same value on every rank
+        const T* src = reinterpret_cast<const T*>(data_ + r * kShmChunk);
+        for (int64_t i = 0; i < n; ++i) out[i] = op(out[i], src[i]);
+      }
+      barrier();  // everyone has read the chunk before the next one overwrites it
+      CT2X_HIP_CHECK(hipMemcpyAsync(buf + off, out.data(), n * sizeof(T), hipMemcpyHostToDevice, stream));
+      CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+  }
+
+  int rank_, world_;
+  std::string name_;
+  size_t bytes_ = 0;
+  ShmHeader* hdr_ = nullptr;
+  char* data_ = nullptr;
+  char* own_box_ = nullptr;
+  bool has_box_ = false;
+  bool opened_[kTpMaxWorld] = {false};
+  TpPeerBox pb_;
+};
+
 }  // namespace
+
+std::shared_ptr<TpComm> make_shm_comm(int rank, int world, const std::string& name) {
+  return std::make_shared<ShmComm>(rank, world, name);
+}
 
 void rccl_get_unique_id(void* id_out) {
   rccl_check(rccl().GetUniqueId(id_out), "ncclGetUniqueId");

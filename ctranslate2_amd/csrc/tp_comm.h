@@ -86,6 +86,11 @@ constexpr int kTpUniqueIdBytes = 128;
 void rccl_get_unique_id(void* id_out);
 std::shared_ptr<TpComm> make_rccl_comm(int rank, int world, const void* unique_id);
 
+// Node-local communicator without RCCL (tp_comm.cc, ShmComm): one PROCESS per rank, bootstrap
+// through the POSIX shared-memory segment "/<name>" (created by rank 0), hipIpc mailboxes for the
+// one-shot exchanges, host-staged fallback collectives. Ranks may share a device.
+std::shared_ptr<TpComm> make_shm_comm(int rank, int world, const std::string& name);
+
 // `world` communicators sharing one rendezvous object; comm i must be used by exactly one thread.
 std::vector<std::shared_ptr<TpComm>> make_local_comms(int world);
 

@@ -531,6 +531,19 @@ void ct2x_translation_options_default(struct ct2x_translation_options* opt);
 int ct2x_tp_unique_id(void* id_out_128_bytes);
 void* ct2x_translator_create_tp(const char* model_dir, int device_index, const char* compute_type,
                                 int rank, int world, const void* unique_id_128_bytes);
+/* The same sharded engine on a node-local communicator WITHOUT RCCL: one process per rank, bootstrap
+ * through the POSIX shared-memory segment "/<segment_name>" (rank 0 creates it; the name must be
+ * unique per group and agreed by the launcher), hipIpc peer-mapped mailboxes for the one-shot
+ * exchanges of the decode steps, host-staged collectives for the few larger ones. Ranks may share
+ * a device: this is how the cross-process exchange path runs on a single-GPU host (RCCL refuses
+ * two ranks on one device). */
+void* ct2x_translator_create_tp_shm(const char* model_dir, int device_index, const char* compute_type,
+                                    int rank, int world, const char* segment_name);
+/* What the handle's engine exchanges through: rank / world, whether the peer-mapped mailboxes of
+ * the one-shot exchanges are in place (0: every exchange is a collective call of the backend),
+ * and the communicator's name ("none", "rccl", "shared-memory", "in-process"). */
+int ct2x_tp_info(void* translator, int32_t* rank, int32_t* world, int32_t* has_mailboxes,
+                 char* backend, int backend_size);
 /* The same sharded engines with an in-process communicator: `world` ranks in THIS process on ONE
  * device, each handle driven by its own host thread (the single-GPU test double of the above). */
 /* Host-only: the rows of a column-parallel weight [n, k] owned by `rank` (Model::load,

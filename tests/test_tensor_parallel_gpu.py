@@ -208,6 +208,52 @@ def test_one_shot_off_is_the_collective_path(gpu):
         t.close()
 
 
+@pytest.mark.parametrize("key,beam,use_graph", [("tiny", 1, False), ("small", 1, True), ("small", 4, True)])
+def test_two_processes_one_gpu_int8_bit_identical(gpu, key, beam, use_graph):
+    """The CROSS-PROCESS exchange path on the one visible GPU: two rank processes, shared-memory
+    bootstrap, hipIpc peer-mapped mailboxes, one-shot exchanges polled inside kernels of two
+    different processes (ct2x_translator_create_tp_shm; RCCL would refuse two ranks on one device).
+    Both ranks must return the unsharded engine's hypotheses and scores bit for bit, twice."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    import ctranslate2_amd as ct2
+    path = _model_dir(key)
+    cfg = GC.SYNTHETIC[key]
+    src = _sources(key)
+    kw = dict(beam_size=beam, max_decoding_length=cfg["max_len"], min_decoding_length=cfg["min_len"],
+              return_scores=True, use_graph=use_graph)
+    single = ct2.Translator(path, compute_type="int8")
+    ref_h, ref_s = single.translate_ids(src, **kw)
+    single.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    seg = "ct2x_tp_test_%d_%s_%d" % (os.getpid(), key, beam)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = [os.path.join(tmp, "rank%d.json" % r) for r in range(2)]
+        procs = [subprocess.Popen([sys.executable, os.path.join(here, "_tp_shm_rank.py"), path, str(r),
+                                   "2", seg, "int8", outs[r], str(beam), str(int(use_graph))],
+                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for r in range(2)]
+        logs = []
+        for p in procs:
+            try:
+                logs.append(p.communicate(timeout=240))
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+        for p, (so, se) in zip(procs, logs):
+            assert p.returncode == 0, se[-3000:]
+        for r in range(2):
+            res = json.load(open(outs[r]))
+            assert res["tp"] == {"rank": r, "world": 2, "mailboxes": True, "backend": "shared-memory"}
+            for h, s in ((res["hyps"], res["scores"]), (res["hyps2"], res["scores2"])):
+                assert h == ref_h
+                assert np.array_equal(np.asarray(s, dtype=np.float32), ref_s)
+
+
 def test_rccl_two_process_tensor_parallel():
     """The REAL multi-GPU path - one process per GPU, RCCL bootstrap, peer-mapped mailboxes over
     xGMI (hipIpc), one-shot exchanges - through bench.py --tp under torch.distributed.run. Needs two
