@@ -328,6 +328,95 @@ int ct2x_gemm_s8_glu_packed(const int8_t* d_qa, const float* d_a_scale, const in
   API_CATCH
 }
 
+int ct2x_norm_gemm_s8_dequant_packed(const float* d_x, const float* d_gamma, float eps,
+                                     int rms_use_residual, int quant_flags, const int8_t* d_w_packed,
+                                     const float* d_w_scale, const float* d_bias,
+                                     const float* d_residual, int64_t m, int64_t n, int64_t k,
+                                     int activation, float* d_y, float* d_row_amax_out, void* stream) {
+  API_TRY
+  CT2X_CHECK(gemm_s8_stream_norm_applicable(m, n, k, false, false),
+             "ct2x_norm_gemm_s8_dequant_packed: needs m <= 16, k = 4096 and a n with a streaming form");
+  CT2X_CHECK(d_x != nullptr && d_gamma != nullptr, "ct2x_norm_gemm_s8_dequant_packed: d_x / d_gamma is NULL");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.w_scale = d_w_scale;
+  ep.bias = d_bias;
+  ep.residual = d_residual;
+  ep.y = d_y;
+  ep.act = activation;
+  ep.ldy = n;
+  ep.norm_x = d_x;
+  ep.norm_gamma = d_gamma;
+  ep.norm_eps = eps;
+  ep.norm_rms_residual = rms_use_residual != 0;
+  ep.quant_mode = quant_flags;
+  ep.row_amax_out = d_row_amax_out;
+  ep.packed_b = true;
+  launch_gemm_s8(nullptr, d_w_packed, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("norm_gemm_s8_dequant_packed");
+  API_CATCH
+}
+
+int ct2x_norm_gemm_s8_glu_packed(const float* d_x, const float* d_gamma, float eps,
+                                 int rms_use_residual, int quant_flags, const int8_t* d_w0_packed,
+                                 const float* d_w0_scale, const float* d_b0, const int8_t* d_w1_packed,
+                                 const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n,
+                                 int64_t k, int activation, float* d_y, float* d_row_amax_out,
+                                 void* stream) {
+  API_TRY
+  CT2X_CHECK(gemm_s8_stream_norm_applicable(m, n, k, true, false),
+             "ct2x_norm_gemm_s8_glu_packed: needs m <= 16, k = 4096 and a n with a gated streaming form");
+  CT2X_CHECK(d_x != nullptr && d_gamma != nullptr, "ct2x_norm_gemm_s8_glu_packed: d_x / d_gamma is NULL");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.w_scale = d_w0_scale;
+  ep.bias = d_b0;
+  ep.b2 = d_w1_packed;
+  ep.w_scale2 = d_w1_scale;
+  ep.bias2 = d_b1;
+  ep.y = d_y;
+  ep.act = activation;
+  ep.ldy = n;
+  ep.norm_x = d_x;
+  ep.norm_gamma = d_gamma;
+  ep.norm_eps = eps;
+  ep.norm_rms_residual = rms_use_residual != 0;
+  ep.quant_mode = quant_flags;
+  ep.row_amax_out = d_row_amax_out;
+  ep.packed_b = true;
+  launch_gemm_s8(nullptr, d_w0_packed, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("norm_gemm_s8_glu_packed");
+  API_CATCH
+}
+
+int ct2x_gemm_s8_dequant_quantizing_packed(const float* d_x, const float* d_row_amax, int amax_parts,
+                                           int quant_flags, const int8_t* d_w_packed,
+                                           const float* d_w_scale, const float* d_bias,
+                                           const float* d_residual, int64_t m, int64_t n, int64_t k,
+                                           int activation, float* d_y, void* stream) {
+  API_TRY
+  CT2X_CHECK(gemm_s8_stream_qol_applicable(m, n, k),
+             "ct2x_gemm_s8_dequant_quantizing_packed: needs m <= 16, k = 4096 and a n with a streaming form");
+  CT2X_CHECK(d_x != nullptr && d_row_amax != nullptr && amax_parts >= 1,
+             "ct2x_gemm_s8_dequant_quantizing_packed: d_x / d_row_amax is NULL or amax_parts < 1");
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.w_scale = d_w_scale;
+  ep.bias = d_bias;
+  ep.residual = d_residual;
+  ep.y = d_y;
+  ep.act = activation;
+  ep.ldy = n;
+  ep.a_f32 = d_x;
+  ep.a_amax = d_row_amax;
+  ep.a_amax_parts = amax_parts;
+  ep.quant_mode = quant_flags;
+  ep.packed_b = true;
+  launch_gemm_s8(nullptr, d_w_packed, m, n, k, ep, resolve_stream(stream));
+  check_last_launch("gemm_s8_dequant_quantizing_packed");
+  API_CATCH
+}
+
 int ct2x_gemm_f16w(const float* d_a, const void* d_w, int w_dtype, int64_t m, int64_t n, int64_t k,
                    const float* d_bias, const float* d_residual, int activation, float* d_c,
                    void* stream) {

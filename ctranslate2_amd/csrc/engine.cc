@@ -1076,9 +1076,13 @@ void Engine::norm_quant(const NormW& w, const float* x, int64_t rows, int64_t de
 // layers::Dense::operator() (src/layers/common.cc:339-442).
 bool Engine::dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_t m, int act,
                         const float* residual, float* y, float* row_amax_out) {
-  if (!gemm_s8_norm_fusion_enabled() || taps_ || !ln.present || !w.quantized || w.row_parallel ||
-      !gemm_s8_norm_applicable(m, w.n, w.k))
+  if (!gemm_s8_norm_fusion_enabled() || taps_ || !ln.present || !w.quantized || w.row_parallel)
     return false;
+  // streaming form (weights too large to stay cache resident, <= 16 rows, RMSNorm rows of 4096)
+  const bool stream = w.wq_stream != nullptr && !w.wq_stream_dual && !tp_ &&
+                      (gemm_s8_stream_prologue_mask() & 1) &&
+                      gemm_s8_stream_norm_applicable(m, w.n, w.k, false, ln.beta != nullptr);
+  if (!stream && !gemm_s8_norm_applicable(m, w.n, w.k)) return false;
   GemmS8Epilogue ep;
   ep.mode = 1;
   ep.w_scale = w.wscale;
@@ -1094,11 +1098,12 @@ bool Engine::dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_
   ep.norm_rms_residual = ln.use_residual;
   ep.quant_mode = quant_mode_;
   ep.row_amax_out = row_amax_out;
+  ep.packed_b = stream;
   const double M = double(m), N = double(w.n), K = double(w.k);
   begin_kernel("norm_gemm_s8_dequant", 4 * M * K + N * K + 4 * N + 8 * K + 4 * M * N +
                                            (residual ? 4 * M * N : 0) + (w.bias ? 4 * N : 0),
                2 * M * N * K, m, w.n, w.k);
-  launch_gemm_s8(nullptr, w.wq, m, w.n, w.k, ep, cur_stream());
+  launch_gemm_s8(nullptr, stream ? w.wq_stream : w.wq, m, w.n, w.k, ep, cur_stream());
   end_kernel();
   return true;
 }
@@ -1106,7 +1111,7 @@ bool Engine::dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_
 // An int8 Dense whose ops::Quantize is folded into the A-fragment fetch (gemm_s8.hip, QOL): x is the
 // fp32 activation, row_amax its row absmax left by the producing launch.
 void Engine::dense_qol(const DenseW& w, const float* x, const float* row_amax, int64_t m, int act,
-                       const float* residual, float* y) {
+                       const float* residual, float* y, int amax_parts) {
   GemmS8Epilogue ep;
   ep.mode = 1;
   ep.w_scale = w.wscale;
@@ -1117,13 +1122,24 @@ void Engine::dense_qol(const DenseW& w, const float* x, const float* row_amax, i
   ep.ldy = w.n;
   ep.a_f32 = x;
   ep.a_amax = row_amax;
+  ep.a_amax_parts = amax_parts;
   ep.quant_mode = quant_mode_;
+  // streaming form: the fragment-major weight copy
+  const bool stream = stream_qol_applicable(w, m);
+  ep.packed_b = stream;
   const double M = double(m), N = double(w.n), K = double(w.k);
   begin_kernel("qgemm_s8_dequant", 4 * M * K + N * K + 4 * N + 4 * M + 4 * M * N +
                                        (residual ? 4 * M * N : 0) + (w.bias ? 4 * N : 0),
                2 * M * N * K, m, w.n, w.k);
-  launch_gemm_s8(nullptr, w.wq, m, w.n, w.k, ep, cur_stream());
+  launch_gemm_s8(nullptr, stream ? w.wq_stream : w.wq, m, w.n, w.k, ep, cur_stream());
   end_kernel();
+}
+
+// Whether the Quantize in front of this Dense can run as the prologue of the streaming kernel
+// (gemm_s8_stream.hip AMODE 1: <= 16 rows, K = 4096, packed weight present).
+bool Engine::stream_qol_applicable(const DenseW& w, int64_t m) const {
+  return !tp_ && !taps_ && (gemm_s8_stream_prologue_mask() & 2) && w.quantized && !w.row_parallel &&
+         w.wq_stream != nullptr && !w.wq_stream_dual && gemm_s8_stream_qol_applicable(m, w.n, w.k);
 }
 
 // Output projection of an attention block + residual + the NEXT sub-layer's pre-norm + Quantize

@@ -372,7 +372,8 @@ private:
                   const float* residual, float* y, float* row_amax_out = nullptr);
   // int8 Dense that quantises its fp32 input while loading it (row absmax given by the producer)
   void dense_qol(const DenseW& w, const float* x, const float* row_amax, int64_t m, int act,
-                 const float* residual, float* y);
+                 const float* residual, float* y, int amax_parts = 1);
+  bool stream_qol_applicable(const DenseW& w, int64_t m) const;
   void load_weights();
   bool has_awq_ = false;
   void dense_awq(const DenseW& w, const float* x, int64_t m, int act, const float* residual, float* y,

@@ -496,7 +496,16 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
       return;
     }
   }
-  if (qin_ready) {
+  // Gated pair at <= 16 rows of a model with streamed weights: the RMSNorm + Quantize runs as the
+  // prologue of the pair's launch (gemm_s8_stream.hip AMODE 2)
+  const bool glu_norm =
+      !qin_ready && ffn.ln.present && pre_norm && ffn.l0_noact.present && ffn.l0.quantized &&
+      ffn.l0_noact.quantized && !tp_ && !taps_ && gemm_s8_norm_fusion_enabled() &&
+      (gemm_s8_stream_prologue_mask() & 1) &&
+      ffn.l0.wq_stream && ffn.l0.wq_stream_dual && ffn.l0_noact.wq_stream &&
+      ffn.l0_noact.wq_stream_dual && ffn.l0_noact.n == ffn.l0.n &&
+      gemm_s8_stream_norm_applicable(rows, ffn.l0.n, ffn.l0.k, true, ffn.ln.beta != nullptr);
+  if (qin_ready || glu_norm) {
   } else if (ffn.ln.present && pre_norm) {
     if (ffn.l0.quantized) {
       prefetch_weight(st, ffn.l0, 2);  // FFN input weight(s), next to the norm launch
@@ -513,13 +522,21 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
     fq.q = st.qbuf;
     fq.s = st.qscale;
   }
-  if (ffn.l0_noact.present && fq.q && ffn.l0.quantized && ffn.l0_noact.quantized && rows <= 32 &&
-      ffn.l0.k % 16 == 0 && ffn.l0_noact.n == ffn.l0.n) {
+  if (ffn.l0_noact.present && (fq.q || glu_norm) && ffn.l0.quantized && ffn.l0_noact.quantized &&
+      rows <= 32 && ffn.l0.k % 16 == 0 && ffn.l0_noact.n == ffn.l0.n) {
     // Decode rows: gate and up projection in ONE launch, y = act(gate) * up (no fp32
     // intermediates, no ops::Mul launch).
     GemmS8Epilogue ep;
     ep.mode = 1;
     ep.a_scale = fq.s;
+    if (glu_norm) {
+      ep.norm_x = x;
+      ep.norm_gamma = ffn.ln.gamma;
+      ep.norm_beta = ffn.ln.beta;
+      ep.norm_eps = ffn.ln.eps;
+      ep.norm_rms_residual = ffn.ln.use_residual;
+      ep.quant_mode = quant_mode_;
+    }
     ep.w_scale = ffn.l0.wscale;
     ep.bias = ffn.l0.bias;
     ep.act = ffn.activation;
@@ -533,7 +550,8 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
     const bool split_quant = amax_buf != nullptr && !tp_ && ffn.l1.quantized && !ffn.l1.row_parallel;
     if (split_quant) ep.row_amax_out = amax_buf;
     const double M = double(rows), N = double(ffn.l0.n), K = double(ffn.l0.k);
-    begin_kernel("gemm_s8_glu", M * K + 2 * N * K + 8 * N + 4 * M + 4 * M * N, 4 * M * N * K, rows,
+    begin_kernel(glu_norm ? "norm_gemm_s8_glu" : "gemm_s8_glu",
+                 (glu_norm ? 4 : 1) * M * K + 2 * N * K + 8 * N + 4 * M + 4 * M * N, 4 * M * N * K, rows,
                  ffn.l0.n, ffn.l0.k);
     const int8_t* w0 = ffn.l0.wq;
     if (ffn.l0.wq_stream && ffn.l0.wq_stream_dual && ffn.l0_noact.wq_stream &&

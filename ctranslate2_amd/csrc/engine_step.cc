@@ -154,6 +154,10 @@ void Engine::launch_step(DecodeState& st) {
         begin_kernel("attention_self_decode", 0, 0, rows, a.heads, a.dhead);
         launch_attention_decode(p, cur_stream());
         end_kernel();
+        if (stream_qol_applicable(a.lin[1], rows)) {
+          // ... and the element-wise Quantize is the prologue of the streaming out projection
+          dense_qol(a.lin[1], st.ctx, amax, rows, -1, resid, y, amax_parts);
+        } else {
         prefetch_weight(st, a.lin[1], 1);  // attention output weight, next to the Quantize launch
         begin_kernel("quantize_cols", double(rows) * qdim * 5, 0, rows, 0, qdim);
         launch_quantize_cols(st.ctx, amax, rows, qdim, quant_mode_, st.qbuf, st.qscale, cur_stream(),
@@ -164,6 +168,7 @@ void Engine::launch_step(DecodeState& st) {
         cq.q = st.qbuf;
         cq.s = st.qscale;
         dense(a.lin[1], nullptr, &cq, rows, -1, resid, y, &st);
+        }
       } else {
         begin_kernel("attention_self_decode", 0, 0, rows, a.heads, a.dhead);
         launch_attention_decode(p, cur_stream());

@@ -20,9 +20,24 @@
 // Fragment addressing is the skinny kernel's: v_mfma_i32_16x16x64_i8 takes 16 consecutive K bytes
 // per lane for A (row = lane & 15) and B (column = lane & 15), K-block = lane >> 4; wave w owns the
 // 64-byte K-steps w, w + WAVES, ...
+//
+// Round 4: the row-wide launches in front of these GEMMs (RMSNorm + Quantize: 10 us at [16, 4096];
+// the element-wise Quantize behind the attention: 5 us - both with HBM idle) run as PROLOGUES of the
+// weight stream (AMODE below): the first ring of weight requests leaves before the prologue starts,
+// so the norm's dependent chain hides under the stream's own latency instead of standing in front
+// of it. Every workgroup redoes the prologue for the 16 rows (256 KB of fp32 from L2).
+//   AMODE 1 (quantise on load, ops::Quantize given the row absmax the producer left): every lane
+//     converts the 16 floats of each of its A fragments itself (to_s8, src/cpu/kernels.cc:577-651).
+//   AMODE 2 (RMSNorm + Quantize, K = 4096): the reference's statistics are eight lane accumulators
+//     walking the row with stride 8 (row_norm.h) - 512 DEPENDENT steps per row that no layout can
+//     shorten. The threads park the floats of their own fragments transposed in LDS, one 1024-column
+//     chunk (= one K-step of all 16 waves) at a time through two buffers, and waves 0-3 (four rows
+//     each, 16 lanes per row) run the chains one chunk behind the writers; then every thread
+//     normalises, max-combines and quantises the 64 values it kept in registers.
 
 #include "device_utils.h"
 #include "kernels.h"
+#include "row_norm.h"
 #include "runtime.h"
 
 #include <algorithm>
@@ -32,38 +47,122 @@ namespace ct2x {
 
 namespace {
 
-template <int NT, int WAVES, int KS, int P, bool DUAL, bool PACKED>
+// Geometry of the AMODE 2 staging (floats): a chain of a 1024-column chunk is 128 elements; the
+// pitch 132 puts the eight chains' 16-byte reads on eight different bank quads, the row stride
+// 8 * 132 + 4 spreads the rows' 8-byte writes over the banks (two-way conflicts at worst).
+constexpr int kNormChainPitch = 132;
+constexpr int kNormRowStride = 8 * kNormChainPitch + 4;
+constexpr int kNormChunkFloats = 16 * kNormRowStride;
+
+template <int NT, int WAVES, int KS, bool DUAL, int AMODE>
+struct StreamLds {
+  static constexpr int ND = DUAL ? 2 : 1;
+  static constexpr int kPartialInts = 2 * ND * WAVES * NT * 256;
+  // region 0: the reduction tiles; during the prologues the two chunk buffers (AMODE 2) and the
+  // int8 activation tile
+  static constexpr int kTileInts = 16 * (4096 + 16) / 4;  // the int8 activation tile (AMODE 1 / 2)
+  static constexpr int kProInts = AMODE == 2 ? 2 * kNormChunkFloats : (AMODE == 1 ? kTileInts : 0);
+  static constexpr int kRegion0 = kProInts > kPartialInts ? kProInts : kPartialInts;
+  static constexpr int kTileAmax = kRegion0;            // [2][16] uint
+  static constexpr int kRowScale = kTileAmax + 32;      // [16] float (AMODE != 0)
+  static constexpr int kRowAmax = kRowScale + 16;       // [16] uint  (AMODE 2)
+  static constexpr int kRowMul = kRowAmax + 16;         // [16] float (AMODE 2)
+  static constexpr int kGamma = kRowMul + 16;           // [K] float  (AMODE 2)
+  static constexpr size_t bytes(int k) {
+    return sizeof(int) * static_cast<size_t>(AMODE == 0 ? kRowScale : (AMODE == 1 ? kRowAmax : kGamma + k));
+  }
+};
+
+// Four floats -> four int8 (to_s8, device_utils.h) packed into one word. The x86 default (u8 shift
+// + round to nearest even) is three VALU operations per element, the four low bytes gathered by two
+// v_perm and "- 128" on every byte as one xor (as in the skinny kernel's prologues).
+__device__ __forceinline__ int quantize_word_fast(const v4f v, float scale) {
+  int b[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b[e] = static_cast<int>(rintf(fmaf(v[e], scale, 128.f)));
+  const unsigned lo = __builtin_amdgcn_perm(static_cast<unsigned>(b[1]), static_cast<unsigned>(b[0]),
+                                            0x0c0c0400u);
+  const unsigned hi = __builtin_amdgcn_perm(static_cast<unsigned>(b[3]), static_cast<unsigned>(b[2]),
+                                            0x04000c0cu);
+  return static_cast<int>((lo | hi) ^ 0x80808080u);
+}
+__device__ __forceinline__ int quantize_word_any(const v4f v, float scale, int quant_mode) {
+  int word = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) word |= (static_cast<int>(to_s8(v[e], scale, quant_mode)) & 0xff) << (8 * e);
+  return word;
+}
+
+template <int NT, int WAVES, int KS, int P, bool DUAL, bool PACKED, int AMODE = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
-    int slabs_per_wg, int total_slabs, const int8_t* __restrict__ B2, GemmS8Epilogue ep) {
-  // (A .. B2 are preloaded into SGPRs; `ep` costs a kernarg round trip and is first touched after
+    int slabs_per_wg, int total_slabs, const int8_t* __restrict__ B2, const float* __restrict__ aux,
+    int aux_n, GemmS8Epilogue ep) {
+  // (A .. aux_n are preloaded into SGPRs; `ep` costs a kernarg round trip and is first touched after
   // the activation fragments and the first ring of weight requests have left. PACKED - the weight
   // is the fragment-major copy - is a template parameter: with both address forms live the long-K
-  // ring spilled 15 registers.)
+  // ring spilled 15 registers. AMODE 1 / 2: A is the fp32 activation [M, K]; aux = the producer's
+  // row absmax [M, aux_n] (AMODE 1) or the norm's gamma [K] (AMODE 2).)
   static_assert(KS % P == 0, "the ring slot of K-step i is i % P in every slab");
-  constexpr int ND = DUAL ? 2 : 1;
+    constexpr int ND = DUAL ? 2 : 1;
   constexpr int THREADS = WAVES * 64;
   constexpr int OUTS = NT * 256;
   constexpr int OPT = (OUTS + THREADS - 1) / THREADS;
-  // dynamic LDS (up to 128 KB: opted into by the launcher): the double-buffered reduction tiles
-  // [2][ND][WAVES][NT][64][4] int32, then the row-absmax words [2][16]
+  // dynamic LDS (up to 152 KB: opted into by the launcher): the double-buffered reduction tiles
+  // [2][ND][WAVES][NT][64][4] int32, the row-absmax words [2][16], then the prologue's words
+  typedef StreamLds<NT, WAVES, KS, DUAL, AMODE> Lds;
   extern __shared__ __attribute__((aligned(16))) int stream_lds[];
   typedef int PartialT[ND][WAVES][NT][64][4];
   PartialT* partial = reinterpret_cast<PartialT*>(stream_lds);
-  unsigned int (*tile_amax)[16] =
-      reinterpret_cast<unsigned int (*)[16]>(stream_lds + 2 * ND * WAVES * NT * 256);
+  unsigned int (*tile_amax)[16] = reinterpret_cast<unsigned int (*)[16]>(stream_lds + Lds::kTileAmax);
+  float* row_scale_lds = reinterpret_cast<float*>(stream_lds + Lds::kRowScale);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  // (packed weights: the wave index as a scalar keeps the wave-uniform address parts in SGPRs; the
+  // row-major forms allocate worse with it)
+  const int lane = tid & 63, wave = PACKED ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int r = lane & 15, g = lane >> 4;
 
   // activation fragments of this wave's K-steps: resident for the whole launch
   v4i af[KS];
+  if (AMODE == 0) {
 #pragma unroll
-  for (int i = 0; i < KS; ++i) {
-    const int kk = (wave + i * WAVES) * 64 + g * 16;
-    af[i] = (r < M) ? *reinterpret_cast<const v4i*>(A + static_cast<int64_t>(r) * K + kk)
-                    : v4i{0, 0, 0, 0};
+    for (int i = 0; i < KS; ++i) {
+      const int kk = (wave + i * WAVES) * 64 + g * 16;
+      af[i] = (r < M) ? *reinterpret_cast<const v4i*>(A + static_cast<int64_t>(r) * K + kk)
+                      : v4i{0, 0, 0, 0};
+    }
+  }
+  // AMODE 1 / 2: the fp32 activation arrives COALESCED - thread t holds float4 (t & 255) of every
+  // 1024-column chunk c of the rows 4 jj + (t >> 8): a wave's request is 1 KB of one row (the
+  // per-lane fetch of the MFMA fragment layout - 16 rows x 64-byte pieces per request - kept the
+  // CU's vector memory pipe busy for ~4 us, in front of the weight requests). The quantised rows go
+  // through an int8 tile in LDS (row stride K + 16 as in the skinny kernel's prologues) from which
+  // every lane reads its fragments. Rows past M repeat row 0: unconditional loads; what the MFMA
+  // computes for those rows is never stored.
+  static_assert(AMODE == 0 || (KS == 4 && WAVES == 16), "prologue forms: K = 4096 on 16 waves");
+  constexpr int XP = (AMODE == 0) ? 1 : 16;  // float4 pieces per thread: piece 4 c + jj
+  v4f xa[XP];
+  const int xq = tid >> 8, xc4 = tid & 255;
+  float q_amax[4] = {0.f, 0.f, 0.f, 0.f};
+  v4f gpre = v4f{0.f, 0.f, 0.f, 0.f};
+  if (AMODE != 0) {
+    const float* X = reinterpret_cast<const float*>(A);
+    const float* xbase[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int row = 4 * jj + xq;
+      const int rowc = row < M ? row : 0;
+      xbase[jj] = X + static_cast<int64_t>(rowc) * K + 4 * xc4;
+      if (AMODE == 1)
+        for (int p = 0; p < aux_n; ++p) q_amax[jj] = fmaxf(q_amax[jj], aux[rowc * aux_n + p]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) xa[4 * c + jj] = *reinterpret_cast<const v4f*>(xbase[jj] + 1024 * c);
+    if (AMODE == 2) gpre = reinterpret_cast<const v4f*>(aux)[tid];  // K / 4 == THREADS float4s
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // weight ring: slot i % P holds K-step i of the current slab (all NT column tiles, both weights)
@@ -83,8 +182,147 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
 
   const int first = blockIdx.x * slabs_per_wg;
   const int mine = min(slabs_per_wg, total_slabs - first);  // only the last workgroup has fewer
+  if (AMODE != 2) {
 #pragma unroll
-  for (int i = 0; i < P; ++i) request(first, i);
+    for (int i = 0; i < P; ++i) request(first, i);
+  }
+
+  int8_t* qtile = reinterpret_cast<int8_t*>(stream_lds);  // [16][K + 16] int8 (AMODE 1 / 2)
+  const int qstride = K + 16;
+  float q_scale[4] = {1.f, 1.f, 1.f, 1.f};
+  if (AMODE == 1) {
+    // ops::Quantize with the producer's absmax: scale = 127 / amax (1 for a zero row)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) q_scale[jj] = (q_amax[jj] != 0.f) ? 127.f / q_amax[jj] : 1.f;
+  }
+  if (AMODE == 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    float* chunk_lds = reinterpret_cast<float*>(stream_lds);
+    unsigned int* row_amax_lds = reinterpret_cast<unsigned int*>(stream_lds + Lds::kRowAmax);
+    float* row_mul_lds = reinterpret_cast<float*>(stream_lds + Lds::kRowMul);
+    float* gamma_lds = reinterpret_cast<float*>(stream_lds + Lds::kGamma);
+    reinterpret_cast<v4f*>(gamma_lds)[tid] = gpre;
+    if (tid < 16) row_amax_lds[tid] = 0u;
+    // chunk-local column 4 xc4 + e sits in chain (4 xc4 + e) & 7 = 4 (xc4 & 1) + e at slot xc4 >> 1
+    auto park = [&](int c) {
+      float* dst = chunk_lds + (c & 1) * kNormChunkFloats + xq * kNormRowStride +
+                   4 * (xc4 & 1) * kNormChainPitch + (xc4 >> 1);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          dst[jj * 4 * kNormRowStride + e * kNormChainPitch] = xa[4 * c + jj][e];
+    };
+    // Wave roles: waves 0-3 run the chains (four rows each, 16 lanes per row, lanes l and l + 8
+    // both chain l) and ask for their share of the first weight ring only afterwards - the ring's
+    // 32 registers are what lets eight 16-byte chain reads stay in flight ahead of the dependent
+    // FMAs (two in flight: ~23 cycles per chain step instead of ~13). Waves 4-15 ask for their
+    // weights right behind their fp32 loads and then only park their columns. Both arms execute
+    // the same barriers.
+    if (wave < 4) {
+      park(0);
+      __syncthreads();
+      const int crow = wave * 4 + g;
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        if (c + 1 < KS) park(c + 1);
+        const v4f* chain = reinterpret_cast<const v4f*>(chunk_lds + (c & 1) * kNormChunkFloats +
+                                                        crow * kNormRowStride + (lane & 7) * kNormChainPitch);
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) {
+          const v4f v = chain[q];
+          ss = fmaf(v.x, v.x, ss);
+          ss = fmaf(v.y, v.y, ss);
+          ss = fmaf(v.z, v.z, ss);
+          ss = fmaf(v.w, v.w, ss);
+        }
+        if (c + 1 == KS) {
+          ss = dpp_xor4(ss) + ss;
+          ss = dpp_move<0x4E, 0xf>(0.f, ss) + ss;
+          ss = dpp_move<0xB1, 0xf>(0.f, ss) + ss;
+          const NormStats st = norm_stats(0.f, ss, K, ep.norm_eps, false);
+          if (r == 0) row_mul_lds[crow] = st.mul;
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int i = 0; i < P; ++i) request(first, i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < P; ++i) request(first, i);
+      park(0);
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        if (c + 1 < KS) park(c + 1);
+        __syncthreads();
+      }
+    }
+    // normalise (src/cpu/kernels.cc:543-573 in its compiled order: norm_apply, no 4-wide remainder
+    // columns at K % 8 == 0): plain (x * gamma) * mul; use_residual (Gemma) (mul * x) * (gamma + 1) -
+    // both are (x * p) * q, the uniform choice is two selects per element, not a branch per element
+    const bool resid = ep.norm_rms_residual;
+    const v4f* gamma4 = reinterpret_cast<const v4f*>(gamma_lds) + xc4;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const float mul = row_mul_lds[4 * jj + xq];
+      float amax = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const v4f gv = gamma4[256 * c];
+        v4f y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = resid ? mul : gv[e];
+          const float q = resid ? gv[e] + 1.f : mul;
+          y[e] = (xa[4 * c + jj][e] * p) * q;
+          amax = fmaxf(amax, fabsf(y[e]));
+        }
+        xa[4 * c + jj] = y;
+      }
+      // row absmax: the 64 lanes of a wave share their rows (|y| >= 0: bits order like uints)
+      const float wm = wave_max(amax);
+      if (lane == 0) atomicMax(&row_amax_lds[4 * jj + xq], __float_as_uint(wm));
+    }
+    __syncthreads();  // (also: every chain read of the chunk buffers is done - the tile may land)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const float ra = __uint_as_float(row_amax_lds[4 * jj + xq]);
+      q_scale[jj] = (ra != 0.f) ? 127.f / ra : 1.f;
+    }
+  }
+  if (AMODE != 0) {
+    // Quantize (to_s8) into the LDS tile, then every lane's MFMA fragments out of it. The choice
+    // between the x86 default (u8 shift + round to nearest even: three VALU operations per element,
+    // bytes gathered by v_perm, "- 128" as one xor) and the general form is ONE uniform branch.
+    const bool fast = (ep.quant_mode & kQuantU8Shift) && (ep.quant_mode & kQuantRound);
+    if (fast) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        int* qrow = reinterpret_cast<int*>(qtile + (4 * jj + xq) * qstride) + xc4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qrow[256 * c] = quantize_word_fast(xa[4 * c + jj], q_scale[jj]);
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        int* qrow = reinterpret_cast<int*>(qtile + (4 * jj + xq) * qstride) + xc4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qrow[256 * c] = quantize_word_any(xa[4 * c + jj], q_scale[jj], ep.quant_mode);
+      }
+    }
+    if (xc4 == 0) {  // the epilogue's 1 / a_scale
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) row_scale_lds[4 * jj + xq] = q_scale[jj];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KS; ++i)
+      af[i] = *reinterpret_cast<const v4i*>(qtile + r * qstride + (wave + i * WAVES) * 64 + g * 16);
+    __syncthreads();  // the tile is dead before a reduction tile of slab 0 is written over it
+  }
 
   for (int t = 0; t < mine; ++t) {
     const int slab = first + t;
@@ -103,7 +341,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
       e_ra[o] = e_ws[o] = e_ws2[o] = 1.f;
       e_bias[o] = e_res[o] = e_bias2[o] = 0.f;
       if (ep.mode == 1 && flat < OUTS && row < M) {
-        e_ra[o] = ep.a_scale[row];
+        if (AMODE == 0) e_ra[o] = ep.a_scale[row];
         e_ws[o] = ep.w_scale[col];
         if (ep.bias) e_bias[o] = ep.bias[col];
         if (ep.residual) e_res[o] = ep.residual[static_cast<int64_t>(row) * ep.ldy + col];
@@ -161,7 +399,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
         ep.c_i32[idx] = sum;
       } else {
         // CPU formula order (src/cpu/kernels.cc:666-673): c * (1/a_scale) / b_scale + bias.
-        const float r_a = 1.f / e_ra[o];
+        const float r_a = 1.f / (AMODE == 0 ? e_ra[o] : row_scale_lds[rt]);
         float v = static_cast<float>(sum) * r_a;
         v = v / e_ws[o];
         if (ep.bias) v = v + e_bias[o];
@@ -316,6 +554,38 @@ bool weight_prefetch_range(const int8_t* packed, int64_t n, int64_t k, bool dual
   return true;
 }
 
+// The prologue forms (AMODE 1 / 2 of the kernel) in the engine. CT2X_STREAM_PROLOGUE (read once):
+// bit 0 = the RMSNorm + Quantize prologue, bit 1 = quantise on load. DEFAULT 0 - measured on the
+// Llama-3-8B shape (MI355X, alternating runs of one call, profiles/r04_l8_stream_prologue_ab.txt):
+// separate launches 3.12 - 3.14 ms per decode step, norm prologue 3.14, quantise on load 3.24, both
+// 3.36 (first version, per-lane fragment fetch: 3.40 / 3.23 / 3.51). The launches that disappear
+// (10 us and 5 us per use) are paid back in full by what replaces them: every one of the ~200
+// workgroups pulls the 16 x 4096 fp32 rows itself, 32 CUs of an XCD read the same 256 KB through
+// one L2 (8 MB per launch and XCD: ~4 us at the L2's bandwidth, against 2 MB for the int8 rows), and
+// the norm's 512-step chain cannot start before its first chunk is there. Bit-identical either way.
+int gemm_s8_stream_prologue_mask() {
+  static const int mask = [] {
+    const char* e = std::getenv("CT2X_STREAM_PROLOGUE");
+    return e != nullptr ? std::atoi(e) : 0;
+  }();
+  return mask;
+}
+
+// RMSNorm (no beta) + Quantize as the prologue: K = 4096 (one compiled chunk geometry), any N
+// with a streaming form. LayerNorm rows keep their own launch (gamma and beta do not fit LDS next
+// to the two chunk buffers).
+bool gemm_s8_stream_norm_applicable(int64_t m, int64_t n, int64_t k, bool dual, bool has_beta) {
+  if (has_beta || k != 4096 || !gemm_s8_stream_applicable(m, n, k, dual)) return false;
+  StreamPlan plan;
+  return plan_stream(n, k, dual, device_cus(), &plan) && (!dual || plan.nt == 2);
+}
+
+// Quantise on load: K = 4096, plain Dense (at K = 14336 the fp32 fragments of a lane - 224 floats -
+// would have to be pipelined through the K loop; that shape keeps the element-wise Quantize launch).
+bool gemm_s8_stream_qol_applicable(int64_t m, int64_t n, int64_t k) {
+  return k == 4096 && gemm_s8_stream_applicable(m, n, k, false);
+}
+
 void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K,
                            const GemmS8Epilogue& ep_in, hipStream_t stream) {
   const bool dual = ep_in.b2 != nullptr;
@@ -323,20 +593,33 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
   if (!plan_stream(N, K, dual, device_cus(), &plan))
     throw Error("launch_gemm_s8_stream: shape outside the streaming form");
   const GemmS8Epilogue& ep = ep_in;
-#define CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, PACKED)                                               \
+  const int amode = ep.norm_x != nullptr ? 2 : (ep.a_f32 != nullptr ? 1 : 0);
+  if (amode == 2 && !(ep.norm_beta == nullptr && K == 4096 && ep.mode == 1 && ep.norm_gamma != nullptr &&
+                      (reinterpret_cast<uintptr_t>(ep.norm_x) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(ep.norm_gamma) & 15) == 0))
+    throw Error("launch_gemm_s8_stream: the norm prologue needs RMSNorm rows of 4096 aligned floats");
+  if (amode == 1 && !(K == 4096 && !dual && ep.mode == 1 && ep.a_amax != nullptr &&
+                      (reinterpret_cast<uintptr_t>(ep.a_f32) & 15) == 0))
+    throw Error("launch_gemm_s8_stream: the quantise-on-load form needs K = 4096, a plain Dense and the row absmax");
+  const int8_t* a_arg = amode == 2 ? reinterpret_cast<const int8_t*>(ep.norm_x)
+                                   : (amode == 1 ? reinterpret_cast<const int8_t*>(ep.a_f32) : a);
+  const float* aux = amode == 2 ? ep.norm_gamma : (amode == 1 ? ep.a_amax : nullptr);
+  const int aux_n = amode == 1 ? (ep.a_amax_parts > 0 ? ep.a_amax_parts : 1) : 0;
+#define CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, PACKED, AMODE)                                        \
   do {                                                                                            \
-    auto fn = gemm_s8_stream_kernel<NT, 16, KS, P, DUAL, PACKED>;                                 \
-    const size_t lds = sizeof(int) * 2 * (DUAL ? 2 : 1) * 16 * NT * 256 + 2 * 16 * sizeof(int);   \
+    auto fn = gemm_s8_stream_kernel<NT, 16, KS, P, DUAL, PACKED, AMODE>;                          \
+    const size_t lds = StreamLds<NT, 16, KS, DUAL, AMODE>::bytes(K);                              \
     allow_big_lds(reinterpret_cast<const void*>(fn), lds);                                        \
-    hipLaunchKernelGGL(fn, dim3(plan.grid), dim3(1024), lds, stream, a, b, M, N, K,               \
-                       plan.slabs_per_wg, plan.slabs, ep.b2, ep);                                 \
+    hipLaunchKernelGGL(fn, dim3(plan.grid), dim3(1024), lds, stream, a_arg, b, M, N, K,           \
+                       plan.slabs_per_wg, plan.slabs, ep.b2, aux, aux_n, ep);                     \
   } while (0)
-#define CT2X_STREAM(NT, KS, P, DUAL)                                                              \
-  if (plan.nt == NT && plan.ks == KS && plan.p == P && dual == DUAL) {                            \
-    if (ep.packed_b) CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, true);                                   \
-    else CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, false);                                              \
+#define CT2X_STREAM_A(NT, KS, P, DUAL, AMODE)                                                     \
+  if (plan.nt == NT && plan.ks == KS && plan.p == P && dual == DUAL && amode == AMODE) {          \
+    if (ep.packed_b) CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, true, AMODE);                            \
+    else CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, false, AMODE);                                       \
     return;                                                                                       \
   }
+#define CT2X_STREAM(NT, KS, P, DUAL) CT2X_STREAM_A(NT, KS, P, DUAL, 0)
   // (forms whose register ring spills at 128 VGPRs - 16 waves per workgroup - are not compiled:
   // plan_stream never returns them)
   CT2X_STREAM(4, 4, 2, false) CT2X_STREAM(2, 4, 4, false) CT2X_STREAM(1, 4, 4, false)
@@ -344,7 +627,12 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
   CT2X_STREAM(1, 14, 7, false)
   CT2X_STREAM(2, 4, 2, true) CT2X_STREAM(1, 4, 4, true)
   CT2X_STREAM(2, 8, 2, true) CT2X_STREAM(1, 8, 4, true)
+  // K = 4096 with a prologue: quantise on load (plain Dense), RMSNorm + Quantize (plain and gated)
+  CT2X_STREAM_A(4, 4, 2, false, 1) CT2X_STREAM_A(2, 4, 4, false, 1) CT2X_STREAM_A(1, 4, 4, false, 1)
+  CT2X_STREAM_A(4, 4, 2, false, 2) CT2X_STREAM_A(2, 4, 4, false, 2) CT2X_STREAM_A(1, 4, 4, false, 2)
+  CT2X_STREAM_A(2, 4, 2, true, 2)  // (the one-tile gated form would spill a register)
 #undef CT2X_STREAM
+#undef CT2X_STREAM_A
 #undef CT2X_STREAM_LAUNCH
   throw Error("launch_gemm_s8_stream: no compiled form for this plan");
 }

@@ -127,6 +127,9 @@ struct GemmS8Epilogue {
   // launch left through row_amax_out. quant_mode as for the norm prologue.
   const float* a_f32 = nullptr;
   const float* a_amax = nullptr;
+  // Streaming form only: a_amax is [m, a_amax_parts] partial maxima (plain stores of the producer's
+  // workgroups, attention_exact128.hip) which the consumer folds; 0 / 1 = one value per row.
+  int a_amax_parts = 0;
   // 256 x 256 kernel: divide with the IEEE sequence even where exact_div applies (A/B timing:
   // CT2X_EXACT_DIV=0; the results are the same bits either way).
   bool plain_division = false;
@@ -162,6 +165,13 @@ void launch_gemm_s8_big(const int8_t* a, const int8_t* b, int M, int N, int K,
 // (gemm_s8_stream.hip); launch_gemm_s8 picks it when gemm_s8_stream_applicable
 // (CT2X_STREAM_GEMM=0 disables, for A/B comparisons; bit-identical).
 bool gemm_s8_stream_applicable(int64_t m, int64_t n, int64_t k, bool dual);
+// Prologue forms of the streaming kernel (round 4): GemmS8Epilogue::norm_x (RMSNorm + Quantize) and
+// ::a_f32 / ::a_amax (quantise on load) at K = 4096. The engine takes them only where
+// gemm_s8_stream_prologue_mask() says so (CT2X_STREAM_PROLOGUE: bit 0 norm, bit 1 quantise on load;
+// default 0 = measured not faster, see gemm_s8_stream.hip).
+bool gemm_s8_stream_norm_applicable(int64_t m, int64_t n, int64_t k, bool dual, bool has_beta);
+bool gemm_s8_stream_qol_applicable(int64_t m, int64_t n, int64_t k);
+int gemm_s8_stream_prologue_mask();
 void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K,
                            const GemmS8Epilogue& ep, hipStream_t stream);
 // Fragment-major copy of a weight for the streaming form (GemmS8Epilogue::packed_b): dst [n * k]

@@ -63,6 +63,9 @@ __host__ __device__ __forceinline__ int norm_chain_pad(int64_t depth) {
 __device__ __forceinline__ int norm_chain_slot(int col, int vsize, int pad) {
   return col < vsize ? (col & 7) * pad + (col >> 3) : 8 * pad + (col - vsize);
 }
+// WANT_SUM = false (RMSNorm: only the sum of squares enters the result) drops the second dependent
+// chain of the loop - at depth 4096 the statistics are 512 dependent steps per row.
+template <bool WANT_SUM = true>
 __device__ __forceinline__ void ordered_row_stats_t(const float* buf, int pad, int64_t depth,
                                                     float& sum, float& sumsq) {
   const int l = threadIdx.x & 7;
@@ -75,10 +78,10 @@ __device__ __forceinline__ void ordered_row_stats_t(const float* buf, int pad, i
 #pragma unroll 8
     for (int i = 0; i < n4; ++i) {
       const v4f v = c4[i];
-      ss = fmaf(v.x, v.x, ss); s = s + v.x;
-      ss = fmaf(v.y, v.y, ss); s = s + v.y;
-      ss = fmaf(v.z, v.z, ss); s = s + v.z;
-      ss = fmaf(v.w, v.w, ss); s = s + v.w;
+      ss = fmaf(v.x, v.x, ss); if (WANT_SUM) s = s + v.x;
+      ss = fmaf(v.y, v.y, ss); if (WANT_SUM) s = s + v.y;
+      ss = fmaf(v.z, v.z, ss); if (WANT_SUM) s = s + v.z;
+      ss = fmaf(v.w, v.w, ss); if (WANT_SUM) s = s + v.w;
     }
     for (int i = n4 * 4; i < n; ++i) {
       const float v = chain[i];

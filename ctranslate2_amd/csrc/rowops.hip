@@ -378,8 +378,10 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
   }
   __syncthreads();
   float sum, sumsq;
-  ordered_row_stats_t(chain_buf, pad, depth, sum, sumsq);  // every wave, redundantly
   const bool ln = beta != nullptr;
+  // every wave, redundantly (RMSNorm: the sum is not needed - one dependent chain instead of two)
+  if (ln) ordered_row_stats_t<true>(chain_buf, pad, depth, sum, sumsq);
+  else ordered_row_stats_t<false>(chain_buf, pad, depth, sum, sumsq);
   const NormStats st = norm_stats(sum, sumsq, depth, eps, ln);
   float amax = 0.f;
 #pragma unroll

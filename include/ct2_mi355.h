@@ -171,6 +171,34 @@ int ct2x_gemm_s8_glu_packed(const int8_t* d_qa, const float* d_a_scale, const in
                             int64_t k, int activation, float* d_y, float* d_row_amax_out,
                             void* stream);
 
+/* The row-wide launches in front of the streamed GEMMs as PROLOGUES of the weight stream (round 4;
+ * m <= 16, k = 4096, packed weights of ct2x_gemm_s8_stream_pack; an error for other shapes):
+ *  - ct2x_norm_gemm_s8_dequant_packed: layers::LayerNorm in its RMSNorm form (src/layers/common.cc:
+ *    464-472, src/cpu/kernels.cc:543-573) -> ops::Quantize -> Gemm -> Dequantize(+bias, activation)
+ *    -> Add(residual), bit-identical to ct2x_norm_quantize_s8 + ct2x_gemm_s8_dequant_packed;
+ *    d_row_amax_out may be NULL;
+ *  - ct2x_norm_gemm_s8_glu_packed: the same prologue in front of the gated pair
+ *    (ct2x_gemm_s8_glu_packed);
+ *  - ct2x_gemm_s8_dequant_quantizing_packed: ops::Quantize of the fp32 activation d_x folded into
+ *    the fragment fetch, its row absmax given as d_row_amax[m, amax_parts] partial maxima left by
+ *    the producing launch (src/ops/quantize.cc:21-51 split into its two halves). */
+int ct2x_norm_gemm_s8_dequant_packed(const float* d_x, const float* d_gamma, float eps,
+                                     int rms_use_residual, int quant_flags, const int8_t* d_w_packed,
+                                     const float* d_w_scale, const float* d_bias,
+                                     const float* d_residual, int64_t m, int64_t n, int64_t k,
+                                     int activation, float* d_y, float* d_row_amax_out, void* stream);
+int ct2x_norm_gemm_s8_glu_packed(const float* d_x, const float* d_gamma, float eps,
+                                 int rms_use_residual, int quant_flags, const int8_t* d_w0_packed,
+                                 const float* d_w0_scale, const float* d_b0, const int8_t* d_w1_packed,
+                                 const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n,
+                                 int64_t k, int activation, float* d_y, float* d_row_amax_out,
+                                 void* stream);
+int ct2x_gemm_s8_dequant_quantizing_packed(const float* d_x, const float* d_row_amax, int amax_parts,
+                                           int quant_flags, const int8_t* d_w_packed,
+                                           const float* d_w_scale, const float* d_bias,
+                                           const float* d_residual, int64_t m, int64_t n, int64_t k,
+                                           int activation, float* d_y, void* stream);
+
 /* A pre-norm int8 Dense at decode rows as ONE launch: layers::LayerNorm (LayerNorm when d_beta is
  * given, RMSNorm otherwise; src/layers/common.cc:464-472) -> ops::Quantize -> Gemm -> Dequantize
  * (+bias, activation) -> Add(residual); bit-identical to ct2x_norm_quantize_s8 followed by

@@ -201,6 +201,66 @@ def gemm_s8_glu_packed(q, sa, w0, sw0, b0, w1, sw1, b1, act):
     return host(y), host(amax)
 
 
+def norm_gemm_s8_dequant_packed(x, gamma, eps, use_residual, flags, w, sw, bias=None, residual=None,
+                                act=-1):
+    """RMSNorm + Quantize as the prologue of the streaming Dense -> (y, row absmax of y)"""
+    L = _lib.lib()
+    xd, gd = dev(x.astype(np.float32)), dev(gamma.astype(np.float32))
+    wd, swd = dev(w.astype(np.int8)), dev(sw.astype(np.float32))
+    biasd = dev(bias.astype(np.float32)) if bias is not None else None
+    rd = dev(residual.astype(np.float32)) if residual is not None else None
+    m, k = x.shape
+    n = w.shape[0]
+    packed = _stream_pack(wd, n, k, False)
+    y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    amax = torch.zeros((m,), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_norm_gemm_s8_dequant_packed(_lib.ptr(xd), _lib.ptr(gd), C.c_float(eps),
+                                                  C.c_int(int(use_residual)), C.c_int(flags),
+                                                  _lib.ptr(packed), _lib.ptr(swd), _lib.ptr(biasd),
+                                                  _lib.ptr(rd), i64(m), i64(n), i64(k), C.c_int(act),
+                                                  _lib.ptr(y), _lib.ptr(amax), None))
+    return host(y), host(amax)
+
+
+def norm_gemm_s8_glu_packed(x, gamma, eps, use_residual, flags, w0, sw0, b0, w1, sw1, b1, act):
+    L = _lib.lib()
+    xd, gd = dev(x.astype(np.float32)), dev(gamma.astype(np.float32))
+    w0d, s0d, w1d, s1d = dev(w0.astype(np.int8)), dev(sw0.astype(np.float32)), dev(w1.astype(np.int8)), dev(sw1.astype(np.float32))
+    b0d = dev(b0.astype(np.float32)) if b0 is not None else None
+    b1d = dev(b1.astype(np.float32)) if b1 is not None else None
+    m, k = x.shape
+    n = w0.shape[0]
+    p0, p1 = _stream_pack(w0d, n, k, True), _stream_pack(w1d, n, k, True)
+    y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    amax = torch.zeros((m,), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_norm_gemm_s8_glu_packed(_lib.ptr(xd), _lib.ptr(gd), C.c_float(eps),
+                                              C.c_int(int(use_residual)), C.c_int(flags), _lib.ptr(p0),
+                                              _lib.ptr(s0d), _lib.ptr(b0d), _lib.ptr(p1), _lib.ptr(s1d),
+                                              _lib.ptr(b1d), i64(m), i64(n), i64(k), C.c_int(act),
+                                              _lib.ptr(y), _lib.ptr(amax), None))
+    return host(y), host(amax)
+
+
+def gemm_s8_dequant_quantizing_packed(x, amax_parts, flags, w, sw, bias=None, residual=None, act=-1):
+    """amax_parts [m, parts]: partial row maxima as a producer's workgroups leave them"""
+    L = _lib.lib()
+    amax_parts = np.ascontiguousarray(amax_parts, np.float32)
+    xd, ad = dev(x.astype(np.float32)), dev(amax_parts)
+    wd, swd = dev(w.astype(np.int8)), dev(sw.astype(np.float32))
+    biasd = dev(bias.astype(np.float32)) if bias is not None else None
+    rd = dev(residual.astype(np.float32)) if residual is not None else None
+    m, k = x.shape
+    n = w.shape[0]
+    packed = _stream_pack(wd, n, k, False)
+    y = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    _lib.check(L.ct2x_gemm_s8_dequant_quantizing_packed(_lib.ptr(xd), _lib.ptr(ad),
+                                                        C.c_int(amax_parts.shape[1]), C.c_int(flags),
+                                                        _lib.ptr(packed), _lib.ptr(swd), _lib.ptr(biasd),
+                                                        _lib.ptr(rd), i64(m), i64(n), i64(k),
+                                                        C.c_int(act), _lib.ptr(y), None))
+    return host(y)
+
+
 def dequantize_rows(x, scale):
     L = _lib.lib()
     xd, sd = dev(x.astype(np.int8)), dev(scale.astype(np.float32))

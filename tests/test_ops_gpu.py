@@ -175,6 +175,104 @@ def test_dense_glu_streaming_form_with_row_amax(gpu, m, n, k):
     assert np.array_equal(y3, yo) and np.array_equal(amax3, amax)
 
 
+@pytest.mark.parametrize("m,n", [(16, 6144), (16, 4096), (16, 128256), (5, 6144), (1, 4096)])
+@pytest.mark.parametrize("use_residual,flags", [(False, 3), (True, 3), (False, 1), (False, 0)])
+def test_dense_streaming_norm_prologue(gpu, m, n, use_residual, flags):
+    """RMSNorm + Quantize as the prologue of the persistent streaming Dense (gemm_s8_stream.hip
+    AMODE 2: the reference's eight-lane statistics chain run chunk-wise through LDS by four waves
+    while the weight stream is already in flight) against the launches it replaces
+    (ct2x_norm_quantize_s8 + ct2x_gemm_s8_dequant_packed) and against the oracle's RMSNorm ->
+    Quantize -> Gemm -> Dequantize chain: bit for bit, both gamma forms, every Quantize mode."""
+    import _gpuops as G
+    k = 4096
+    rng = np.random.default_rng(m + n + flags + int(use_residual))
+    x = (rng.standard_normal((m, k)) * 2.5).astype(np.float32)
+    x[:, 7] *= 30.0   # an outlier channel, as residual streams have
+    if m > 2:
+        x[2, :] = 0.0  # zero row -> absmax 0 -> scale 1
+    gamma = (1 + 0.2 * rng.standard_normal(k)).astype(np.float32)
+    if use_residual:
+        gamma -= 1.0
+    wq = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    ws = rng.uniform(50, 4000, n).astype(np.float32)
+    bias = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32)
+    y, amax = G.norm_gemm_s8_dequant_packed(x, gamma, 1e-5, use_residual, flags, wq, ws, bias, res, 2)
+    _, q, s = G.norm_quantize_s8(x, gamma, None, 1e-5, use_residual, flags, False)
+    y2 = G.gemm_s8_dequant_packed(q, s, wq, ws, bias, res, 2)
+    assert np.array_equal(y, y2)
+    assert np.array_equal(amax, np.abs(y).max(axis=1))
+    if True:
+        xn = O.rms_norm(x, gamma, 1e-5, use_residual)
+        qo, so = O.quantize_s8(xn, flags)
+        assert np.array_equal(q, qo) and np.array_equal(s, so)
+        yo = _f32(res) + O.dequantize_gemm_output(O.gemm_s8(qo, wq), so, ws, bias, 2)
+        assert np.array_equal(y, yo)
+
+
+@pytest.mark.parametrize("m", [16, 3])
+def test_dense_glu_streaming_norm_prologue(gpu, m):
+    """The same prologue in front of the gated pair (Llama-3-8B feed-forward input at decode rows)."""
+    import _gpuops as G
+    n, k = 14336, 4096
+    rng = np.random.default_rng(m)
+    x = (rng.standard_normal((m, k)) * 2.5).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(k)).astype(np.float32)
+    w0q = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    w1q = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    w0s = rng.uniform(2000, 9000, n).astype(np.float32)
+    w1s = rng.uniform(2000, 9000, n).astype(np.float32)
+    y, amax = G.norm_gemm_s8_glu_packed(x, gamma, 1e-5, False, 3, w0q, w0s, None, w1q, w1s, None, 2)
+    _, q, s = G.norm_quantize_s8(x, gamma, None, 1e-5, False, 3, False)
+    y2, amax2 = G.gemm_s8_glu_packed(q, s, w0q, w0s, None, w1q, w1s, None, 2)
+    assert np.array_equal(y, y2) and np.array_equal(amax, amax2)
+    xn = O.rms_norm(x, gamma, 1e-5, False)
+    qo, so = O.quantize_s8(xn, 3)
+    c0, c1 = O.gemm_s8(qo, w0q), O.gemm_s8(qo, w1q)
+    yo = O.dequantize_gemm_output(c1, so, w1s, None, -1) * O.dequantize_gemm_output(c0, so, w0s, None, 2)
+    assert np.array_equal(y, yo)
+
+
+@pytest.mark.parametrize("m,n,parts", [(16, 4096, 8), (16, 4096, 1), (7, 6144, 4), (16, 128256, 1)])
+@pytest.mark.parametrize("flags", [3, 1, 0])
+def test_dense_streaming_quantize_on_load(gpu, m, n, parts, flags):
+    """ops::Quantize folded into the streaming Dense's fragment fetch (AMODE 1), the row absmax given
+    as per-workgroup partial maxima (what the d_head 128 attention leaves): against Quantize +
+    ct2x_gemm_s8_dequant_packed and the oracle's Dense chain, bit for bit."""
+    import _gpuops as G
+    k = 4096
+    rng = np.random.default_rng(m + n + parts + flags)
+    x = (rng.standard_normal((m, k)) * 1.7).astype(np.float32)
+    if m > 2:
+        x[2, :] = 0.0
+    wq = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    ws = rng.uniform(50, 4000, n).astype(np.float32)
+    bias = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32)
+    amax_parts = np.abs(x).reshape(m, parts, k // parts).max(axis=2)
+    y = G.gemm_s8_dequant_quantizing_packed(x, amax_parts, flags, wq, ws, bias, res, -1)
+    q, s = G.quantize_s8(x, flags)
+    y2 = G.gemm_s8_dequant_packed(q, s, wq, ws, bias, res, -1)
+    assert np.array_equal(y, y2)
+    assert np.array_equal(y, O.dense_s8(x, wq, ws, bias, res, -1, flags))
+
+
+def test_streaming_prologue_envelope(gpu):
+    """Shapes outside the prologue forms are refused, not computed some other way."""
+    import _gpuops as G
+    rng = np.random.default_rng(0)
+    for m, n, k in [(17, 6144, 4096), (16, 4096, 8192), (16, 512, 512)]:
+        x = rng.standard_normal((m, k)).astype(np.float32)
+        wq = rng.integers(-127, 128, (n, k), dtype=np.int8)
+        ws = np.ones(n, np.float32)
+        if not G.stream_packable(n, k):
+            continue
+        with pytest.raises(RuntimeError):
+            G.norm_gemm_s8_dequant_packed(x, np.ones(k, np.float32), 1e-6, False, 3, wq, ws)
+        with pytest.raises(RuntimeError):
+            G.gemm_s8_dequant_quantizing_packed(x, np.abs(x).max(axis=1, keepdims=True), 3, wq, ws)
+
+
 @pytest.mark.parametrize("scale_exp", [0, 31, -31])
 def test_dense_big_tile_division_guard(gpu, scale_exp):
     """The 256 x 256 kernel divides by the weight scale with exact_div (device_utils.h) when every
