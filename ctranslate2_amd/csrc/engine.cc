@@ -1043,7 +1043,7 @@ void Engine::quant(const float* x, int64_t rows, int64_t depth, int8_t* q, float
 void Engine::norm(const NormW& w, const float* x, int64_t rows, int64_t depth, float* y) {
   begin_kernel("norm", double(rows) * depth * 8 + depth * 8, 0, rows, 0, depth);
   launch_norm(x, w.gamma, w.beta, rows, depth, w.eps, w.use_residual, quant_mode_, y,
-              nullptr, nullptr, cur_stream());
+              nullptr, nullptr, cur_stream(), nullptr, half_compute() && !taps_);
   end_kernel();
 }
 

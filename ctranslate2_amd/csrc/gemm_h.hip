@@ -493,6 +493,54 @@ __global__ void gemm_h_splitk_reduce_kernel(const float* __restrict__ partial, i
                    ep.residual ? ep.residual[e] : 0.f, ep.residual != nullptr);
 }
 
+// The same sums, four columns per thread (n % 4 == 0, 16-byte aligned operands): every slice is
+// requested before the first add - the scalar form above is 5.9 us per use at [256, 2048] x 8 slices
+// (144 uses per NLLB decode step: 11 % of the step), bound by its dependent 4-byte loads.
+template <int SPLITS>
+__global__ void gemm_h_splitk_reduce4_kernel(const float* __restrict__ partial, int64_t n,
+                                            int64_t total4, HalfEpilogue ep) {
+  const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (e >= total4) return;
+  const v4f* p = reinterpret_cast<const v4f*>(partial) + e;
+  v4f s[SPLITS];
+#pragma unroll
+  for (int z = 0; z < SPLITS; ++z) s[z] = p[z * total4];
+  const int64_t col = (e * 4) % n;
+  v4f b = v4f{0.f, 0.f, 0.f, 0.f}, r = v4f{0.f, 0.f, 0.f, 0.f};
+  if (ep.bias) b = *reinterpret_cast<const v4f*>(ep.bias + col);
+  if (ep.residual) r = reinterpret_cast<const v4f*>(ep.residual)[e];
+  v4f v = s[0];
+#pragma unroll
+  for (int z = 1; z < SPLITS; ++z) v = v + s[z];  // fixed order: deterministic, same sums as above
+  v4f o;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    o[c] = finish(v[c], b[c], ep.bias != nullptr, ep.act, r[c], ep.residual != nullptr);
+  reinterpret_cast<v4f*>(ep.y)[e] = o;
+}
+
+static void launch_splitk_reduce(const float* partial, int splits, int64_t n, int64_t total,
+                                 const HalfEpilogue& ep, hipStream_t stream) {
+  const bool vec = n % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(ep.y) |
+                     reinterpret_cast<uintptr_t>(ep.bias) | reinterpret_cast<uintptr_t>(ep.residual)) & 15) == 0;
+  const int64_t total4 = total / 4;
+  const dim3 grid4(static_cast<unsigned>((total4 + 255) / 256));
+#define CT2X_RED4(SP)                                                                             \
+  hipLaunchKernelGGL(gemm_h_splitk_reduce4_kernel<SP>, grid4, dim3(256), 0, stream, partial, n, total4, ep)
+  if (vec && splits == 2) CT2X_RED4(2);
+  else if (vec && splits == 3) CT2X_RED4(3);
+  else if (vec && splits == 4) CT2X_RED4(4);
+  else if (vec && splits == 5) CT2X_RED4(5);
+  else if (vec && splits == 8) CT2X_RED4(8);
+  else if (vec && splits == 10) CT2X_RED4(10);
+  else if (vec && splits == 16) CT2X_RED4(16);
+  else
+    hipLaunchKernelGGL(gemm_h_splitk_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
+                       dim3(256), 0, stream, partial, splits, n, total, ep);
+#undef CT2X_RED4
+}
+
 template <bool kBF16>
 void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const HalfEpilogue& ep,
                   hipStream_t stream, float* splitk_ws, size_t splitk_floats) {
@@ -528,12 +576,7 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
         else if (mt == 2) CT2X_HROWS(2);
         else CT2X_HROWS(4);
 #undef CT2X_HROWS
-        if (slices > 1) {
-          const int64_t total = static_cast<int64_t>(M) * N;
-          hipLaunchKernelGGL(gemm_h_splitk_reduce_kernel,
-                             dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, stream,
-                             splitk_ws, slices, static_cast<int64_t>(N), total, ep);
-        }
+        if (slices > 1) launch_splitk_reduce(splitk_ws, slices, N, static_cast<int64_t>(M) * N, ep, stream);
         return;
       }
     }
@@ -555,11 +598,7 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
       else if (mt == 4) { if (wide) CT2X_HSKINNY(4, 2, 4, 2); else CT2X_HSKINNY(4, 1, 8, 2); }
       else { if (wide) CT2X_HSKINNY(8, 2, 4, 1); else CT2X_HSKINNY(8, 1, 4, 2); }
     }
-    if (sk > 1) {
-      const int64_t total = static_cast<int64_t>(M) * N;
-      hipLaunchKernelGGL(gemm_h_splitk_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
-                         dim3(256), 0, stream, splitk_ws, sk, static_cast<int64_t>(N), total, ep);
-    }
+    if (sk > 1) launch_splitk_reduce(splitk_ws, sk, N, static_cast<int64_t>(M) * N, ep, stream);
     return;
   }
 #undef CT2X_HSKINNY
@@ -578,9 +617,7 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
   }
   hipLaunchKernelGGL((gemm_h_tiled_kernel<kBF16>), dim3((N + 127) / 128, (M + 127) / 128, splits),
                      dim3(256), 0, stream, a, w, M, N, K, ep, K / splits, splitk_ws);
-  const int64_t total = static_cast<int64_t>(M) * N;
-  hipLaunchKernelGGL(gemm_h_splitk_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
-                     dim3(256), 0, stream, splitk_ws, splits, static_cast<int64_t>(N), total, ep);
+  launch_splitk_reduce(splitk_ws, splits, N, static_cast<int64_t>(M) * N, ep, stream);
 }
 
 }  // namespace

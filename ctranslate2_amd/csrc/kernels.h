@@ -50,7 +50,9 @@ void launch_reduce_ranks(const void* const* src, int world, int64_t n, bool is_i
 void launch_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
                  int64_t depth, float eps, bool rms_use_residual, int quant_mode,
                  float* y, int8_t* q, float* scales, hipStream_t stream,
-                 const PrefetchArgs* pf = nullptr);
+                 const PrefetchArgs* pf = nullptr, bool fast_stats = false);
+// fast_stats: tree-reduced statistics instead of the CPU path's ordered chain (NOT bit-identical
+// to the reference's CPU build; the engine asks for it under the 16-bit compute types only).
 
 void launch_softmax(const float* x, const int32_t* lengths, int64_t rows, int64_t depth,
                     bool log, float* y, hipStream_t stream);

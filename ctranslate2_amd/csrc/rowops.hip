@@ -341,7 +341,8 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
                                 const float* __restrict__ beta, int64_t depth, float eps,
                                 bool rms_use_residual, int quant_mode, int pad,
                                 float* __restrict__ y, int8_t* __restrict__ q,
-                                float* __restrict__ scales, int rows, PrefetchArgs pf) {
+                                float* __restrict__ scales, int rows, PrefetchArgs pf,
+                                bool fast_stats) {
   extern __shared__ __attribute__((aligned(16))) float chain_buf[];
   __shared__ float scratch[32];
   if (static_cast<int>(blockIdx.x) >= rows) {  // spare workgroups: warm the next GEMM's weight
@@ -365,6 +366,38 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
       if (beta != nullptr) bv[u] = b4[i];
     }
   }
+  float sum, sumsq;
+  const bool ln = beta != nullptr;
+  if (fast_stats) {
+    // 16-bit compute types: their GEMMs round to the 16-bit type anyway, parity is a tolerance, and
+    // the reference's own GPU kernel reduces in parallel (src/ops/layer_norm_gpu.cu:174-213): the
+    // statistics are a tree over the lanes (DPP) and waves instead of the CPU path's 8 x depth / 8
+    // dependent chain (at depth 2048: 256 dependent steps, most of this launch's 7 us)
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {  // (absent chunks hold zeros)
+      s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+      ss += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+    }
+    s = wave_sum_dpp(s);
+    ss = wave_sum_dpp(ss);
+    if (blockDim.x > 64) {
+      const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+      if ((threadIdx.x & 63) == 0) {
+        scratch[wave] = s;
+        scratch[8 + wave] = ss;
+      }
+      __syncthreads();
+      s = ss = 0.f;
+      for (int w = 0; w < nw; ++w) {
+        s += scratch[w];
+        ss += scratch[8 + w];
+      }
+      __syncthreads();  // scratch is reused by block_max below
+    }
+    sum = s;
+    sumsq = ss;
+  } else {
 #pragma unroll
   for (int u = 0; u < CH; ++u) {
     const int i = threadIdx.x + u * blockDim.x;
@@ -377,11 +410,10 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
     }
   }
   __syncthreads();
-  float sum, sumsq;
-  const bool ln = beta != nullptr;
   // every wave, redundantly (RMSNorm: the sum is not needed - one dependent chain instead of two)
   if (ln) ordered_row_stats_t<true>(chain_buf, pad, depth, sum, sumsq);
   else ordered_row_stats_t<false>(chain_buf, pad, depth, sum, sumsq);
+  }
   const NormStats st = norm_stats(sum, sumsq, depth, eps, ln);
   float amax = 0.f;
 #pragma unroll
@@ -422,7 +454,8 @@ __global__ void norm_vec_kernel(const float* __restrict__ x, const float* __rest
 
 void launch_norm(const float* x, const float* gamma, const float* beta, int64_t rows,
                  int64_t depth, float eps, bool rms_use_residual, int quant_mode,
-                 float* y, int8_t* q, float* scales, hipStream_t stream, const PrefetchArgs* pf_in) {
+                 float* y, int8_t* q, float* scales, hipStream_t stream, const PrefetchArgs* pf_in,
+                 bool fast_stats) {
   if (rows == 0 || depth == 0) return;
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) |
                          reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(y) |
@@ -438,7 +471,7 @@ void launch_norm(const float* x, const float* gamma, const float* beta, int64_t 
 #define CT2X_NORMV(CH)                                                                          \
   hipLaunchKernelGGL(norm_vec_kernel<CH>, dim3(rows + pf.wgs), dim3(threads), lds, stream, x, gamma,  \
                      beta, depth, eps, rms_use_residual, quant_mode, pad, y, q, scales,               \
-                     static_cast<int>(rows), pf)
+                     static_cast<int>(rows), pf, fast_stats && depth % 8 == 0)
     if (ch <= 1) CT2X_NORMV(1);
     else if (ch == 2) CT2X_NORMV(2);
     else CT2X_NORMV(4);
