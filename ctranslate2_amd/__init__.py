@@ -486,7 +486,10 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
     def last_stats(self) -> dict:
         st = ExecStats()
         _lib.check(self._L.ct2x_last_stats(C.c_void_p(self._h), C.byref(st)))
-        return {name: getattr(st, name) for name, _ in ExecStats._fields_}
+        out = {name: getattr(st, name) for name, _ in ExecStats._fields_}
+        self._L.ct2x_last_compactions.restype = C.c_int64
+        out["compactions"] = int(self._L.ct2x_last_compactions(C.c_void_p(self._h)))
+        return out
 
 
 class WhisperOptions(C.Structure):

@@ -97,6 +97,7 @@ struct Translator {
   int32_t start_id = 1, eos_id = 2, bos_id = 1;
   std::mutex mutex;
   ct2x_exec_stats last{};
+  int64_t last_compactions = 0;  // finished-row removals of the last call (greedy loop)
   WorkerPool pool;  // declared last: joined before the engine is destroyed
 };
 
@@ -747,6 +748,7 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
              "end_token is not in the target vocabulary");
   const double t0 = now_ms();
   t->last = ct2x_exec_stats{};
+  t->last_compactions = 0;
 
   // make_source_ids (sequence_to_sequence.cc:140-165) + Vocabulary::to_ids truncation
   // (src/vocabulary.cc:108-146).
@@ -900,6 +902,7 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
         encode_ms += te1 - te0;
         decode_ms += te2 - te1;
         t->last.decode_steps = std::max<int64_t>(t->last.decode_steps, ds.steps);
+        t->last_compactions += ds.compactions;
       }
     } catch (...) {
       std::lock_guard<std::mutex> lock(stats_mutex);
@@ -1012,6 +1015,7 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   const int32_t longest_prefix = max_len_prompt - min_len_prompt;
   const double t0 = now_ms();
   t->last = ct2x_exec_stats{};
+  t->last_compactions = 0;
   const int64_t t_max = static_cast<int64_t>(forward_length) + longest_prefix + dopt.max_length + 1;
   // Beam search: every hypothesis row starts from the same prefilled prompt state; the prompt is
   // forwarded once per row (beam x the prefill work instead of a cache replication pass).
@@ -1056,6 +1060,7 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
     t->last.num_tokens += len;
   }
   t->last.num_examples = batch;
+  t->last_compactions += ds.compactions;
   t->last.decode_steps = ds.steps;
   t->last.kernels_per_step = t->engine->kernels_per_step();
   t->last.encode_ms = te1 - te0;  // prompt prefill
@@ -1487,6 +1492,11 @@ int ct2x_last_stats(void* translator, struct ct2x_exec_stats* stats) {
   CT2X_CHECK(t != nullptr && stats != nullptr, "null argument");
   *stats = t->last;
   API_CATCH
+}
+
+int64_t ct2x_last_compactions(void* translator) {
+  auto* t = static_cast<Translator*>(translator);
+  return t != nullptr ? t->last_compactions : -1;
 }
 
 int ct2x_profile_begin(void* translator) {

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 #include <stdexcept>
 
@@ -94,6 +95,18 @@ void finalize(DecodingResult& r, size_t max_hypotheses, const DecodingOptions& o
 }  // namespace
 
 // GreedySearch::search (src/decoding.cc:733-974), num_hypotheses == 1, no prefix.
+// Row count from which the greedy loop drops finished rows (0 = never). Default 64: below that a
+// decode step is launch / weight-stream bound and costs the same for any row count (measured: §2 of
+// DESIGN.md), so a smaller batch buys nothing and costs a graph capture. CT2X_COMPACT_MIN_ROWS
+// overrides (tests run the goldens with 2).
+static int64_t compact_min_rows_setting() {
+  static const int64_t v = [] {
+    const char* e = std::getenv("CT2X_COMPACT_MIN_ROWS");
+    return e != nullptr ? static_cast<int64_t>(std::atoll(e)) : int64_t(64);
+  }();
+  return v;
+}
+
 std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
                                           const std::vector<int32_t>& start_ids, int32_t end_id,
                                           const DecodingOptions& opt, DecodeStats* stats,
@@ -164,35 +177,67 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
     return true;
   };
 
+  // Finished sentences leave the batch (the reference gathers the alive rows out of every state
+  // tensor at every step that finishes one: src/decoding.cc:916-956). Here the step is a captured
+  // graph of a fixed row count and the host runs up to two groups of steps behind the device, so
+  // rows are dropped in bulk: once at most half of the session's rows are alive, the groups in
+  // flight are examined (no new one is queued), Engine::compact_rows packs the alive rows and the
+  // loop goes on with a graph of the smaller batch. Row-wise arithmetic is batch-composition
+  // neutral (tests: test_batch_composition_is_result_neutral), so results do not change. Worth it
+  // only where a step's cost follows the row count (min_rows: above the skinny-GEMM regime, where a
+  // decode step costs the same for 1 or 32 rows).
+  const int64_t compact_min_rows = compact_min_rows_setting();
+  const bool may_compact = !gather_attention && compact_min_rows > 0 && engine.compactable(st);
+  std::vector<int64_t> origin(batch);  // session row -> index into results / alive / prefix_len
+  for (int64_t i = 0; i < batch; ++i) origin[i] = i;
+  bool compact_pending = false;
+
   launch_group();
-  while (!inflight.empty() && count_alive > 0) {
-    if (inflight.size() < 2) launch_group();  // keep the device busy while we scan group k
+  while ((!inflight.empty() || compact_pending) && count_alive > 0) {
+    if (compact_pending && inflight.empty()) {
+      std::vector<int32_t> keep;
+      std::vector<int64_t> new_origin;
+      for (int64_t r = 0; r < st.rows; ++r)
+        if (alive[origin[r]]) {
+          keep.push_back(static_cast<int32_t>(r));
+          new_origin.push_back(origin[r]);
+        }
+      engine.compact_rows(st, keep, launched);
+      origin.swap(new_origin);
+      compact_pending = false;
+      if (stats) ++stats->compactions;
+      if (!launch_group()) break;
+      continue;
+    }
+    if (!compact_pending && inflight.size() < 2) launch_group();  // keep the device busy while we scan group k
     const Group g = inflight.front();
     inflight.erase(inflight.begin());
     const int32_t* h_ids = nullptr;
     const float* h_scores = nullptr;
     engine.wait_history(st, g.slot, &h_ids, &h_scores);
+    const int64_t rows_now = st.rows;  // (no compaction while a group is in flight)
     if (gather_attention) {
       att_steps.resize(static_cast<size_t>(g.count) * batch * st.s_max);
       engine.read_attention(st, opt.start_step + g.first, g.count, att_steps.data());
     }
     for (int64_t s = 0; s < g.count && count_alive > 0; ++s) {
       const int64_t step = g.first + s;
-      for (int64_t i = 0; i < batch; ++i) {
+      for (int64_t row = 0; row < rows_now; ++row) {
+        const int64_t i = origin[row];
         if (!alive[i]) continue;
         // is_last_step (src/decoding.cc:376-382): max_length steps after the row's own prefix
         const bool last = (step + 1 == opt.max_length + extra * prefix_len[i]);
-        const int32_t word = h_ids[s * batch + i];
+        const int32_t word = h_ids[s * rows_now + row];
         const bool in_prefix = step < prefix_len[i];
         const bool eos = (word == end_id) && !in_prefix;
         if ((!in_prefix || opt.return_prefix) && (!eos || opt.include_eos_in_hypotheses)) {
           results[i].hypotheses[0].push_back(word);
           if (gather_attention) {
-            const float* a = att_steps.data() + (static_cast<size_t>(s) * batch + i) * st.s_max;
+            const float* a = att_steps.data() + (static_cast<size_t>(s) * rows_now + row) * st.s_max;
             results[i].attention[0].emplace_back(a, a + st.s_max);
           }
         }
-        if (opt.return_scores) score_sum[i] += h_scores[s * batch + i];  // forced steps add 0
+        if (opt.return_scores) score_sum[i] += h_scores[s * rows_now + row];  // forced steps add 0
         if (eos || last) {
           alive[i] = 0;
           --count_alive;
@@ -202,6 +247,9 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
       }
     }
     examined = g.first + g.count;
+    if (may_compact && !compact_pending && count_alive > 0 && st.rows >= compact_min_rows &&
+        count_alive * 2 <= st.rows)
+      compact_pending = true;
   }
   (void)examined;
   engine.synchronize();  // drain a speculative group before the state is torn down

@@ -66,6 +66,7 @@ struct DecodingResult {
 
 struct DecodeStats {
   int64_t steps = 0;
+  int64_t compactions = 0;  // times the greedy loop dropped its finished rows (Engine::compact_rows)
 };
 
 void validate_decoding_options(const DecodingOptions& options);

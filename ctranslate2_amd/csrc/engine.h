@@ -283,6 +283,15 @@ public:
   void wait_history(DecodeState& state, int slot, const int32_t** h_ids, const float** h_scores);
   void copy_logits_to_host(DecodeState& state, float* h_logits);
   void set_ids(DecodeState& state, const int32_t* h_ids);
+  // Finished-sentence removal of the greedy loop (the reference gathers the alive rows out of every
+  // state tensor whenever a sentence finishes: src/decoding.cc:916-956, Decoder::update_state
+  // src/layers/decoder.cc:33-56): keeps rows `keep` (ascending) of a beam-1 session - self-attention
+  // caches, memory K/V and lengths, next ids, the [step][row] histories, the hard prefix - as rows
+  // 0 .. keep.size() - 1; the step graph is captured again for the new row count on its next use.
+  // The device must be idle on this session (no step in flight). compactable(): whether the session
+  // holds nothing that this does not move.
+  bool compactable(const DecodeState& state) const;
+  void compact_rows(DecodeState& state, const std::vector<int32_t>& keep, int64_t steps_done);
   // Installs per-row forced tokens for the steps first_step, first_step + 1, ... (empty = none).
   void set_prefix(DecodeState& state, const std::vector<std::vector<int32_t>>& prefix,
                   int32_t first_step, bool extends_min_length = true);

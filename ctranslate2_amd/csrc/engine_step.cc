@@ -11,6 +11,8 @@
 #include <stdexcept>
 
 #include "engine_internal.h"
+
+#include <type_traits>
 #include "runtime.h"
 
 namespace ct2x {
@@ -663,6 +665,73 @@ void Engine::set_ids(DecodeState& st, const int32_t* h_ids) {
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_ids, h_ids, sizeof(int32_t) * st.rows,
                                 hipMemcpyHostToDevice, cur_stream()));
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // h_ids may be a temporary
+}
+
+bool Engine::compactable(const DecodeState& st) const {
+  return !tp_ && !taps_ && !profiling_ && st.beam == 1 && !st.beam_mode && !st.ancestry &&
+         st.att_hist == nullptr && !st.wh_active && st.wh_no_speech_id < 0 && st.rows > 1;
+}
+
+void Engine::compact_rows(DecodeState& st, const std::vector<int32_t>& keep, int64_t steps_done) {
+  CT2X_CHECK(compactable(st), "compact_rows: this session holds state that is not moved");
+  const int64_t n_new = static_cast<int64_t>(keep.size()), n_old = st.rows;
+  CT2X_CHECK(n_new >= 1 && n_new < n_old, "compact_rows: nothing to drop");
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  auto fresh = [&](size_t bytes) {
+    void* p = device_malloc(bytes);
+    st.owned.push_back(p);  // (the buffers it replaces stay owned until the session ends)
+    return p;
+  };
+  int32_t* d_keep = static_cast<int32_t*>(fresh(sizeof(int32_t) * n_new));
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_keep, keep.data(), sizeof(int32_t) * n_new, hipMemcpyHostToDevice,
+                                cur_stream()));
+  auto rows_of = [&](auto*& buf, int64_t row_elems) {
+    if (buf == nullptr || row_elems == 0) return;
+    using T = std::remove_reference_t<decltype(*buf)>;
+    const size_t row_bytes = static_cast<size_t>(row_elems) * sizeof(T);
+    T* out = static_cast<T*>(fresh(row_bytes * n_new));
+    launch_gather_rows(buf, d_keep, n_new, static_cast<int64_t>(row_bytes), out, cur_stream());
+    buf = out;
+  };
+  for (size_t l = 0; l < dec_.layers.size(); ++l) {
+    const AttnW& a = dec_.layers[l].self;
+    const int64_t row = a.heads_kv * st.t_max * a.dhead;
+    rows_of(st.self_k[0][l], row);
+    rows_of(st.self_v[0][l], row);
+    if (l < st.cross_kv.size()) {
+      const int64_t kv = 2 * dec_.layers[l].cross.heads_kv * dec_.layers[l].cross.dhead;
+      rows_of(st.cross_kv[l], st.s_max * kv);
+      if (l < st.cross_kv16.size()) rows_of(st.cross_kv16[l], st.s_max * kv);
+    }
+  }
+  rows_of(st.mem_lengths, 1);
+  rows_of(st.d_ids, 1);
+  if (st.d_prefix != nullptr) {
+    rows_of(st.d_prefix, st.prefix_stride);
+    rows_of(st.d_prefix_len, 1);
+  }
+  // histories [step][row]: the steps behind us in the new row numbering (the device-side logits
+  // processors read them), the steps ahead are written in it
+  const int64_t past = std::min<int64_t>(steps_done + st.prefix_first_step, st.t_max + 1);
+  {
+    int32_t* ids = static_cast<int32_t*>(fresh(sizeof(int32_t) * (st.t_max + 1) * n_new));
+    float* scores = static_cast<float*>(fresh(sizeof(float) * (st.t_max + 1) * n_new));
+    launch_gather_cols(st.hist_ids, d_keep, past, n_old, n_new, ids, cur_stream());
+    launch_gather_cols(st.hist_scores, d_keep, past, n_old, n_new, scores, cur_stream());
+    st.hist_ids = ids;
+    st.hist_scores = scores;
+  }
+  check_last_launch("compact_rows");
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // (`keep` may be a temporary)
+  st.rows = n_new;
+  st.batch = n_new;
+  for (int i = 0; i < 2; ++i) {
+    if (st.graph_exec[i]) (void)hipGraphExecDestroy(st.graph_exec[i]);
+    st.graph_exec[i] = nullptr;
+    st.graph_ready[i] = false;
+  }
 }
 
 void Engine::set_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>& prefix,

@@ -77,6 +77,9 @@ void launch_topk(const float* x, int64_t rows, int64_t depth, int64_t k, float* 
 
 void launch_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int64_t row_bytes,
                         void* out, hipStream_t stream);
+// out[t, i] = in[t, idx[i]], t < steps, 4-byte elements ([step][row] histories)
+void launch_gather_cols(const void* in, const int32_t* idx, int64_t steps, int64_t n_old, int64_t n_new,
+                        void* out, hipStream_t stream);
 
 // out[r,:] = table[ids[r],:] (dequantised with 1/scale[id] when table is int8) * emb_scale
 //            + pos[(pos_base + r % time) ...]   (see engine.cc for the position convention)

@@ -904,6 +904,26 @@ __global__ void gather_rows_kernel(const char* __restrict__ data, const int32_t*
   }
 }
 
+// out[t, i] = in[t, idx[i]] for t < steps (4-byte elements): the [step][row] histories of a decoding
+// session whose finished rows are being dropped (Engine::compact_rows).
+__global__ void gather_cols_kernel(const int32_t* __restrict__ in, const int32_t* __restrict__ idx,
+                                   int64_t n_old, int64_t n_new, int64_t total,
+                                   int32_t* __restrict__ out) {
+  const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (e >= total) return;
+  const int64_t t = e / n_new, i = e - t * n_new;
+  out[e] = in[t * n_old + idx[i]];
+}
+
+void launch_gather_cols(const void* in, const int32_t* idx, int64_t steps, int64_t n_old, int64_t n_new,
+                        void* out, hipStream_t stream) {
+  const int64_t total = steps * n_new;
+  if (total == 0) return;
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                     stream, static_cast<const int32_t*>(in), idx, n_old, n_new, total,
+                     static_cast<int32_t*>(out));
+}
+
 void launch_gather_rows(const void* data, const int32_t* idx, int64_t n_idx, int64_t row_bytes,
                         void* out, hipStream_t stream) {
   if (n_idx == 0 || row_bytes == 0) return;

@@ -731,6 +731,11 @@ struct ct2x_exec_stats {
   double decode_ms;
 };
 int ct2x_last_stats(void* translator, struct ct2x_exec_stats* stats);
+/* How many times the last translate / generate call dropped its finished rows from the running
+ * batch (greedy decoding; the reference removes finished sentences at every step,
+ * src/decoding.cc:916-956; here rows leave in bulk once at most half of a session's rows are alive
+ * and the session has at least 64 rows - CT2X_COMPACT_MIN_ROWS overrides, 0 = never). -1: bad handle. */
+int64_t ct2x_last_compactions(void* translator);
 
 /* Per-kernel profile of the next translate/generate calls, measured with HIP events on the
  * engine's stream around every launch (graph replay is disabled while profiling). profile_end
