@@ -375,24 +375,50 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
     return true;
   };
 
+  // Finished batch entries leave the session (src/decoding.cc:599-694 removes them at every step; see
+  // greedy_search for the bulk policy): the entries in flight are replayed, then
+  // Engine::compact_beam_entries packs what is per entry / per row and the ancestry tables.
+  const int64_t compact_min_rows = compact_min_rows_setting();
+  const bool may_compact = !gather_attention && compact_min_rows > 0 && engine.beam_compactable(st);
+  std::vector<int64_t> origin(batch);  // session entry -> index into results / finished / alive_seq
+  for (int64_t i = 0; i < batch; ++i) origin[i] = i;
+  bool compact_pending = false;
+
   launch_group();
-  while (!inflight.empty() && remaining > 0) {
-    if (inflight.size() < 2) launch_group();  // keep the device busy while this group is replayed
+  while ((!inflight.empty() || compact_pending) && remaining > 0) {
+    if (compact_pending && inflight.empty()) {
+      std::vector<int32_t> keep;
+      std::vector<int64_t> new_origin;
+      for (int64_t e = 0; e < st.batch; ++e)
+        if (!finished[origin[e]]) {
+          keep.push_back(static_cast<int32_t>(e));
+          new_origin.push_back(origin[e]);
+        }
+      engine.compact_beam_entries(st, keep, opt.start_step + launched);
+      origin.swap(new_origin);
+      compact_pending = false;
+      if (stats) ++stats->compactions;
+      if (!launch_group()) break;
+      continue;
+    }
+    if (!compact_pending && inflight.size() < 2) launch_group();  // keep the device busy while this group is replayed
     const Group g = inflight.front();
     inflight.erase(inflight.begin());
     const int32_t* h_word = nullptr;
     const float* h_score = nullptr;
     const int32_t* h_origin = nullptr;
     engine.wait_beam_history(st, g.slot, &h_word, &h_score, &h_origin);
+    const int64_t entries_now = st.batch;  // (no compaction while a group is in flight)
     if (gather_attention) {
       att_steps.resize(static_cast<size_t>(g.count) * rows * st.s_max);
       engine.read_attention(st, opt.start_step + g.first, g.count, att_steps.data());
     }
     for (int64_t s = 0; s < g.count && remaining > 0; ++s, ++step) {
-      for (int64_t i = 0; i < batch; ++i) {
+      for (int64_t e = 0; e < entries_now; ++e) {
+        const int64_t i = origin[e];
         if (finished[i]) continue;
         // candidates as the device selected from them: unflattened, hard prefix applied
-        const int64_t base = (s * batch + i) * num_candidates;
+        const int64_t base = (s * entries_now + e) * num_candidates;
         const int32_t* cand_word = h_word + base;
         const int32_t* cand_origin = h_origin + base;
         const float* sc = h_score + base;
@@ -411,7 +437,7 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
           for (int32_t j = 0; j < num_candidates; ++j) {
             cand_att[j] = alive_attention[i][cand_origin[j]];
             const float* a = att_steps.data() +
-                             (static_cast<size_t>(s) * rows + i * beam + cand_origin[j]) * st.s_max;
+                             (static_cast<size_t>(s) * rows + e * beam + cand_origin[j]) * st.s_max;
             cand_att[j].emplace_back(a, a + st.s_max);
           }
         }
@@ -471,6 +497,9 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
         }
       }
     }
+    if (may_compact && !compact_pending && remaining > 0 && st.rows >= compact_min_rows &&
+        remaining * 2 <= st.batch)
+      compact_pending = true;
   }
   engine.synchronize();  // drain a speculative group before the state is torn down
   st.fuse_beam = false;

@@ -292,6 +292,13 @@ public:
   // holds nothing that this does not move.
   bool compactable(const DecodeState& state) const;
   void compact_rows(DecodeState& state, const std::vector<int32_t>& keep, int64_t steps_done);
+  // The same for a beam-search session: keeps the batch ENTRIES `keep` (ascending) with all their
+  // beams (the reference drops a batch entry once it is finished, src/decoding.cc:599-694). Only for
+  // sessions that follow the ancestry table: the self-attention caches do not move at all - the
+  // table's columns of the kept rows are packed, and the rows write their next positions into slots
+  // no one has written yet.
+  bool beam_compactable(const DecodeState& state) const;
+  void compact_beam_entries(DecodeState& state, const std::vector<int32_t>& keep, int64_t positions_written);
   // Installs per-row forced tokens for the steps first_step, first_step + 1, ... (empty = none).
   void set_prefix(DecodeState& state, const std::vector<std::vector<int32_t>>& prefix,
                   int32_t first_step, bool extends_min_length = true);

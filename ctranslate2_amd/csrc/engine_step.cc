@@ -734,6 +734,84 @@ void Engine::compact_rows(DecodeState& st, const std::vector<int32_t>& keep, int
   }
 }
 
+bool Engine::beam_compactable(const DecodeState& st) const {
+  return !tp_ && !taps_ && !profiling_ && st.beam_mode && st.ancestry && st.anc[0] != nullptr &&
+         st.att_hist == nullptr && !st.wh_active && st.wh_no_speech_id < 0 && st.batch > 1;
+}
+
+void Engine::compact_beam_entries(DecodeState& st, const std::vector<int32_t>& keep,
+                                  int64_t positions_written) {
+  CT2X_CHECK(beam_compactable(st), "compact_beam_entries: this session holds state that is not moved");
+  const int64_t b_new = static_cast<int64_t>(keep.size()), b_old = st.batch, beam = st.beam;
+  CT2X_CHECK(b_new >= 1 && b_new < b_old, "compact_beam_entries: nothing to drop");
+  const int64_t r_new = b_new * beam, r_old = st.rows;
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  auto fresh = [&](size_t bytes) {
+    void* p = device_malloc(bytes);
+    st.owned.push_back(p);
+    return p;
+  };
+  std::vector<int32_t> keep_rows(static_cast<size_t>(r_new));
+  for (int64_t e = 0; e < b_new; ++e)
+    for (int64_t k = 0; k < beam; ++k) keep_rows[e * beam + k] = static_cast<int32_t>(keep[e] * beam + k);
+  int32_t* d_keep = static_cast<int32_t*>(fresh(sizeof(int32_t) * b_new));
+  int32_t* d_keep_rows = static_cast<int32_t*>(fresh(sizeof(int32_t) * r_new));
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_keep, keep.data(), sizeof(int32_t) * b_new, hipMemcpyHostToDevice,
+                                cur_stream()));
+  CT2X_HIP_CHECK(hipMemcpyAsync(d_keep_rows, keep_rows.data(), sizeof(int32_t) * r_new,
+                                hipMemcpyHostToDevice, cur_stream()));
+  auto gather = [&](auto*& buf, int64_t row_elems, const int32_t* idx, int64_t n) {
+    if (buf == nullptr || row_elems == 0) return;
+    using T = std::remove_reference_t<decltype(*buf)>;
+    const size_t row_bytes = static_cast<size_t>(row_elems) * sizeof(T);
+    T* out = static_cast<T*>(fresh(row_bytes * n));
+    launch_gather_rows(buf, idx, n, static_cast<int64_t>(row_bytes), out, cur_stream());
+    buf = out;
+  };
+  for (size_t l = 0; l < st.cross_kv.size(); ++l) {
+    const int64_t kv = 2 * dec_.layers[l].cross.heads_kv * dec_.layers[l].cross.dhead;
+    gather(st.cross_kv[l], st.s_max * kv, d_keep, b_new);
+    if (l < st.cross_kv16.size()) gather(st.cross_kv16[l], st.s_max * kv, d_keep, b_new);
+  }
+  gather(st.mem_lengths, 1, d_keep, b_new);
+  if (st.d_bprefix != nullptr) {
+    gather(st.d_bprefix, st.bprefix_stride, d_keep, b_new);
+    gather(st.d_bprefix_len, 1, d_keep, b_new);
+  }
+  gather(st.d_ids, 1, d_keep_rows, r_new);
+  gather(st.beam_scores, 1, d_keep_rows, r_new);
+  gather(st.d_parents, 1, d_keep_rows, r_new);
+  gather(st.d_diverged, 1, d_keep_rows, r_new);
+  gather(st.alive_seq[0], st.t_max, d_keep_rows, r_new);
+  gather(st.alive_seq[1], st.t_max, d_keep_rows, r_new);
+  // ancestry tables [t_max + 1][rows] -> [t_max + 1][rows']: for the positions written so far the
+  // entries (cache rows) stay what they are - the caches are not touched; the positions ahead are the
+  // identity of the NEW numbering (a row appends to its own cache row, attention_exact.hip, and
+  // beam_select_kernel copies only written positions: the slots (row', t >= written) are unwritten)
+  const int64_t written = std::min<int64_t>(std::max<int64_t>(positions_written, 0), st.t_max + 1);
+  std::vector<int32_t> identity(static_cast<size_t>((st.t_max + 1 - written) * r_new));
+  for (size_t e = 0; e < identity.size(); ++e) identity[e] = static_cast<int32_t>(e % r_new);
+  for (int i = 0; i < 2; ++i) {
+    int32_t* t = static_cast<int32_t*>(fresh(sizeof(int32_t) * (st.t_max + 1) * r_new));
+    launch_gather_cols(st.anc[i], d_keep_rows, written, r_old, r_new, t, cur_stream());
+    if (!identity.empty())
+      CT2X_HIP_CHECK(hipMemcpyAsync(t + written * r_new, identity.data(), identity.size() * sizeof(int32_t),
+                                    hipMemcpyHostToDevice, cur_stream()));
+    st.anc[i] = t;
+  }
+  check_last_launch("compact_beam_entries");
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+  st.batch = b_new;
+  st.rows = r_new;
+  for (int i = 0; i < 2; ++i) {
+    if (st.graph_exec[i]) (void)hipGraphExecDestroy(st.graph_exec[i]);
+    st.graph_exec[i] = nullptr;
+    st.graph_ready[i] = false;
+  }
+}
+
 void Engine::set_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>& prefix,
                         int32_t first_step, bool extends_min_length) {
   st.prefix_extends_min = extends_min_length;

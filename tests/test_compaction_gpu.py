@@ -41,6 +41,16 @@ out["aren_lp_compactions"] = t.last_stats()["compactions"]
 prefix = [r.hypotheses[0][: i %% 4] for i, r in enumerate(res)]
 res = t.translate_batch(src, target_prefix=prefix, beam_size=1, return_scores=True, max_decoding_length=30)
 out["aren_prefix"] = [[r.hypotheses[0], float(r.scores[0])] for r in res]
+# beam search: finished batch entries leave with all their beams (ancestry tables repacked, caches
+# untouched); two hypotheses per sentence, then with the device-side processors
+res = t.translate_batch(src, beam_size=4, num_hypotheses=2, return_scores=True, max_decoding_length=30)
+out["aren_beam"] = [[r.hypotheses, [float(x) for x in r.scores]] for r in res]
+out["aren_beam_compactions"] = t.last_stats()["compactions"]
+res = t.translate_batch(src, beam_size=3, return_scores=True, max_decoding_length=30, length_penalty=0.6,
+                        repetition_penalty=1.2, no_repeat_ngram_size=2)
+out["aren_beam_lp"] = [[r.hypotheses, [float(x) for x in r.scores]] for r in res]
+res = t.translate_batch(src, target_prefix=prefix, beam_size=2, return_scores=True, max_decoding_length=30)
+out["aren_beam_prefix"] = [[r.hypotheses, [float(x) for x in r.scores]] for r in res]
 # random sampling: the draw is a hash of (seed, step, ROW) - the row numbering changes with the batch,
 # so only the setting without removal is comparable; here: it still runs
 res = t.translate_batch(src, beam_size=1, sampling_topk=4, max_decoding_length=12)
@@ -62,6 +72,9 @@ ids, scores = g.generate_ids(prompts, max_length=34, return_scores=True, repetit
                              no_repeat_ngram_size=2, suppress_sequences_ids=[[7], [11, 12]])
 out["lm_lp"] = [ids, [float(s) for s in scores]]
 out["lm_lp_compactions"] = g.last_stats()["compactions"]
+ids, scores = g.generate_ids(prompts, max_length=34, return_scores=True, beam_size=3)
+out["lm_beam"] = [ids, [float(s) for s in scores]]
+out["lm_beam_compactions"] = g.last_stats()["compactions"]
 print(json.dumps(out))
 """
 
@@ -83,7 +96,9 @@ def test_dropping_finished_rows_changes_nothing(gpu):
     # the forced setting really did drop rows
     assert early["aren_compactions"] >= 1
     assert early["lm_compactions"] >= 1 and early["lm_lp_compactions"] >= 1
-    for key in ("aren", "aren_lp", "aren_prefix", "lm", "lm_lp"):
+    assert early["aren_beam_compactions"] >= 1 and early["lm_beam_compactions"] >= 1
+    for key in ("aren", "aren_lp", "aren_prefix", "lm", "lm_lp", "aren_beam", "aren_beam_lp",
+                "aren_beam_prefix", "lm_beam"):
         assert early[key] == base[key], key
     # sentences of different lengths finish at different steps in this batch (the premise)
     assert len({len(h) for h, _ in base["aren"]}) >= 3
