@@ -1,4 +1,6 @@
-// Encoder-decoder attention of a decode step for the 16-bit compute types, d_head 64, with the
+// Encoder-decoder attention of a decode step for the 16-bit compute types, d_head 64 / 128 (round 4:
+// 128 for the NLLB-3.3B geometry, whose per-(row, head) fp32 kernel read every entry's 32 memory
+// positions once per beam: 27 us per layer), with the
 // memory keys / values held in the compute type (float16 / bfloat16) - the first 16-bit cache of
 // this backend. MultiHeadAttention::operator() with cached memory keys
 // (src/layers/attention.cc:442-615; process_cross_attention :371-440): for every hypothesis row
@@ -53,8 +55,10 @@ constexpr int kXhWaves = 8;          // 512 threads per workgroup
 constexpr int kXhThreads = kXhWaves * 64;
 constexpr int kXhUnroll = 8;         // value tiles in flight per wave
 
-template <bool kBF16>
+template <bool kBF16, int DH>
 __global__ __launch_bounds__(kXhThreads) void xattn_h_kernel(CrossAttnHParams p) {
+  constexpr int CG = DH / 8;      // 16-byte channel groups of a key / value row
+  constexpr int KT = 64 / CG;     // keys per wave tile of the context phase
   extern __shared__ __attribute__((aligned(16))) float xh_lds[];
   __shared__ float red[kXhWaves][kXhMaxBeam];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,20 +71,20 @@ __global__ __launch_bounds__(kXhThreads) void xattn_h_kernel(CrossAttnHParams p)
   int length = p.lengths ? p.lengths[b] : S;
   length = length < 0 ? 0 : (length > S ? S : length);
 
-  float* q_s = xh_lds;                               // [kXhMaxBeam][64]
-  float* probs = q_s + kXhMaxBeam * 64;              // [kXhMaxBeam][s_pad]
-  float* part = probs + kXhMaxBeam * s_pad;          // [kXhWaves][kXhMaxBeam][64]
+  float* q_s = xh_lds;                               // [kXhMaxBeam][DH]
+  float* probs = q_s + kXhMaxBeam * DH;              // [kXhMaxBeam][s_pad]
+  float* part = probs + kXhMaxBeam * s_pad;          // [kXhWaves][kXhMaxBeam][DH]
 
-  for (int e = tid; e < beam * 64; e += kXhThreads) {
-    const int j = e >> 6, c = e & 63;
+  for (int e = tid; e < beam * DH; e += kXhThreads) {
+    const int j = e / DH, c = e % DH;
     const int64_t row = static_cast<int64_t>(b) * beam + j;
-    q_s[j * 64 + c] = p.q[row * p.q_row_stride + static_cast<int64_t>(h) * 64 + c] * p.scale;
+    q_s[j * DH + c] = p.q[row * p.q_row_stride + static_cast<int64_t>(h) * DH + c] * p.scale;
   }
   __syncthreads();
 
-  const int64_t kv_time = 2 * p.heads_kv * 64;       // elements per memory position
-  const uint16_t* kbase = p.kv + static_cast<int64_t>(b) * S * kv_time + static_cast<int64_t>(hk) * 64;
-  const uint16_t* vbase = kbase + p.heads_kv * 64;
+  const int64_t kv_time = 2 * p.heads_kv * DH;       // elements per memory position
+  const uint16_t* kbase = p.kv + static_cast<int64_t>(b) * S * kv_time + static_cast<int64_t>(hk) * DH;
+  const uint16_t* vbase = kbase + p.heads_kv * DH;
 
   // ---- scores: thread = key (the 128-byte key row = one cache line, eight 16-byte loads in
   // flight; measured faster than 8 lanes per key with DPP folds: 1096 vs 1015 tokens/s on the
@@ -94,18 +98,18 @@ __global__ __launch_bounds__(kXhThreads) void xattn_h_kernel(CrossAttnHParams p)
     for (int j = 0; j < kXhMaxBeam; ++j) sc[j] = 0.f;
     if (s < length) {
       const uint4* kr = reinterpret_cast<const uint4*>(kbase + static_cast<int64_t>(s) * kv_time);
-      uint4 ku[8];
+      uint4 ku[CG];
 #pragma unroll
-      for (int c8 = 0; c8 < 8; ++c8) ku[c8] = kr[c8];
+      for (int c8 = 0; c8 < CG; ++c8) ku[c8] = kr[c8];
 #pragma unroll
-      for (int c8 = 0; c8 < 8; ++c8) {
+      for (int c8 = 0; c8 < CG; ++c8) {
         float kf[8];
         unpack8<kBF16>(ku[c8], kf);
 #pragma unroll
         for (int j = 0; j < kXhMaxBeam; ++j) {
           if (j < beam) {
-            const float4 qa = *reinterpret_cast<const float4*>(q_s + j * 64 + c8 * 8);
-            const float4 qb = *reinterpret_cast<const float4*>(q_s + j * 64 + c8 * 8 + 4);
+            const float4 qa = *reinterpret_cast<const float4*>(q_s + j * DH + c8 * 8);
+            const float4 qb = *reinterpret_cast<const float4*>(q_s + j * DH + c8 * 8 + 4);
             sc[j] += kf[0] * qa.x + kf[1] * qa.y + kf[2] * qa.z + kf[3] * qa.w + kf[4] * qb.x +
                      kf[5] * qb.y + kf[6] * qb.z + kf[7] * qb.w;
           }
@@ -173,9 +177,9 @@ __global__ __launch_bounds__(kXhThreads) void xattn_h_kernel(CrossAttnHParams p)
     }
   }
 
-  // ---- context: a wave takes tiles of 8 keys, kXhUnroll tiles in flight ---------------------------
-  const int kr = lane >> 3, cg = lane & 7;  // key within the tile, channel group of 8
-  const int tiles = s_pad >> 3;
+  // ---- context: a wave takes tiles of KT keys, kXhUnroll tiles in flight --------------------------
+  const int kr = lane / CG, cg = lane % CG;  // key within the tile, channel group of 8
+  const int tiles = s_pad / KT;
   float acc[kXhMaxBeam][8];
 #pragma unroll
   for (int j = 0; j < kXhMaxBeam; ++j)
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(kXhThreads) void xattn_h_kernel(CrossAttnHParams p)
 #pragma unroll
     for (int k = 0; k < kXhUnroll; ++k) {
       const int t = t0 + k * kXhWaves;
-      const int s = t * 8 + kr;
+      const int s = t * KT + kr;
       vs[k] = (t < tiles && s < length) ? s : -1;
       vu[k] = make_uint4(0u, 0u, 0u, 0u);
       if (vs[k] >= 0)
@@ -209,65 +213,72 @@ __global__ __launch_bounds__(kXhThreads) void xattn_h_kernel(CrossAttnHParams p)
       }
     }
   }
-  // sum over the 8 key lanes of a channel group (lane bits 3, 4, 5)
+  // sum over the KT key lanes of a channel group (the lane bits above the channel group's)
 #pragma unroll
   for (int j = 0; j < kXhMaxBeam; ++j) {
     if (j < beam) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         float v = acc[j][c];
-        v += __shfl_xor(v, 8, 64);
+        if (CG <= 8) v += __shfl_xor(v, 8, 64);
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         acc[j][c] = v;
       }
       if (kr == 0) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) part[(wave * kXhMaxBeam + j) * 64 + cg * 8 + c] = acc[j][c];
+        for (int c = 0; c < 8; ++c) part[(wave * kXhMaxBeam + j) * DH + cg * 8 + c] = acc[j][c];
       }
     }
   }
   __syncthreads();
-  for (int e = tid; e < beam * 64; e += kXhThreads) {
-    const int j = e >> 6, c = e & 63;
+  for (int e = tid; e < beam * DH; e += kXhThreads) {
+    const int j = e / DH, c = e % DH;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < kXhWaves; ++w) v += part[(w * kXhMaxBeam + j) * 64 + c];
+    for (int w = 0; w < kXhWaves; ++w) v += part[(w * kXhMaxBeam + j) * DH + c];
     float inv = 0.f;
 #pragma unroll
     for (int jj = 0; jj < kXhMaxBeam; ++jj)
       if (jj == j) inv = inv_sum[jj];
     const int64_t row = static_cast<int64_t>(b) * beam + j;
-    p.out[row * p.out_row_stride + static_cast<int64_t>(h) * 64 + c] = v * inv;
+    p.out[row * p.out_row_stride + static_cast<int64_t>(h) * DH + c] = v * inv;
   }
 }
 
-size_t xattn_h_lds_bytes(int64_t s_max) {
+size_t xattn_h_lds_bytes(int64_t s_max, int64_t dhead) {
   const int64_t s_pad = (s_max + 7) & ~static_cast<int64_t>(7);
-  return static_cast<size_t>(kXhMaxBeam * 64 + kXhMaxBeam * s_pad + kXhWaves * kXhMaxBeam * 64) *
+  return static_cast<size_t>(kXhMaxBeam * dhead + kXhMaxBeam * s_pad + kXhWaves * kXhMaxBeam * dhead) *
          sizeof(float);
 }
 
 }  // namespace
 
 bool cross_attention_h_applicable(const CrossAttnHParams& p) {
-  return p.dhead == 64 && p.beam >= 1 && p.beam <= kXhMaxBeam && p.heads_kv >= 1 &&
-         p.heads % p.heads_kv == 0 && p.s_max >= 1 && xattn_h_lds_bytes(p.s_max) <= 150 * 1024 &&
+  return (p.dhead == 64 || p.dhead == 128) && p.beam >= 1 && p.beam <= kXhMaxBeam && p.heads_kv >= 1 &&
+         p.heads % p.heads_kv == 0 && p.s_max >= 1 &&
+         xattn_h_lds_bytes(p.s_max, p.dhead) <= 150 * 1024 &&
          (reinterpret_cast<uintptr_t>(p.kv) & 15) == 0;
 }
 
 void launch_cross_attention_h(const CrossAttnHParams& p, hipStream_t stream) {
   if (p.batch * p.heads == 0) return;
   if (!cross_attention_h_applicable(p)) throw Error("launch_cross_attention_h: shape not supported");
-  const size_t lds = xattn_h_lds_bytes(p.s_max);
+  const size_t lds = xattn_h_lds_bytes(p.s_max, p.dhead);
   const dim3 grid(static_cast<unsigned>(p.batch * p.heads));
-  if (p.bf16) {
-    allow_big_lds(reinterpret_cast<const void*>(xattn_h_kernel<true>), lds);
-    hipLaunchKernelGGL(xattn_h_kernel<true>, grid, dim3(kXhThreads), lds, stream, p);
+#define CT2X_XH(BF, DH)                                                                          \
+  do {                                                                                            \
+    allow_big_lds(reinterpret_cast<const void*>(xattn_h_kernel<BF, DH>), lds);                    \
+    hipLaunchKernelGGL((xattn_h_kernel<BF, DH>), grid, dim3(kXhThreads), lds, stream, p);         \
+  } while (0)
+  if (p.dhead == 64) {
+    if (p.bf16) CT2X_XH(true, 64);
+    else CT2X_XH(false, 64);
   } else {
-    allow_big_lds(reinterpret_cast<const void*>(xattn_h_kernel<false>), lds);
-    hipLaunchKernelGGL(xattn_h_kernel<false>, grid, dim3(kXhThreads), lds, stream, p);
+    if (p.bf16) CT2X_XH(true, 128);
+    else CT2X_XH(false, 128);
   }
+#undef CT2X_XH
 }
 
 }  // namespace ct2x

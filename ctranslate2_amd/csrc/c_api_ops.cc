@@ -939,12 +939,19 @@ int ct2x_attention_decode(const float* d_q, const float* d_k_cache, const float*
 int ct2x_cross_attention_h(const float* d_q, const void* d_kv, int kv_dtype, const int32_t* d_lengths,
                            int64_t batch, int64_t beam, int64_t heads, int64_t heads_kv,
                            int64_t s_max, float scale, float* d_out, void* stream) {
+  return ct2x_cross_attention_hd(d_q, d_kv, kv_dtype, d_lengths, batch, beam, heads, heads_kv, 64,
+                                 s_max, scale, d_out, stream);
+}
+
+int ct2x_cross_attention_hd(const float* d_q, const void* d_kv, int kv_dtype, const int32_t* d_lengths,
+                            int64_t batch, int64_t beam, int64_t heads, int64_t heads_kv,
+                            int64_t dhead, int64_t s_max, float scale, float* d_out, void* stream) {
   API_TRY
   CT2X_CHECK(kv_dtype == CT2X_F16 || kv_dtype == CT2X_BF16,
              "ct2x_cross_attention_h: the memory type must be CT2X_F16 or CT2X_BF16");
   CrossAttnHParams p;
   p.q = d_q;
-  p.q_row_stride = heads * 64;
+  p.q_row_stride = heads * dhead;
   p.kv = static_cast<const uint16_t*>(d_kv);
   p.bf16 = kv_dtype == CT2X_BF16;
   p.lengths = d_lengths;
@@ -952,12 +959,12 @@ int ct2x_cross_attention_h(const float* d_q, const void* d_kv, int kv_dtype, con
   p.beam = beam;
   p.heads = heads;
   p.heads_kv = heads_kv;
-  p.dhead = 64;
+  p.dhead = dhead;
   p.s_max = s_max;
   p.scale = scale;
   p.out = d_out;
-  p.out_row_stride = heads * 64;
-  CT2X_CHECK(cross_attention_h_applicable(p), "ct2x_cross_attention_h: unsupported shape (d_head 64, "
+  p.out_row_stride = heads * dhead;
+  CT2X_CHECK(cross_attention_h_applicable(p), "ct2x_cross_attention_h: unsupported shape (d_head 64 or 128, "
              "beam <= 8, heads a multiple of heads_kv, memory length within the LDS budget)");
   launch_cross_attention_h(p, resolve_stream(stream));
   check_last_launch("cross_attention_h");

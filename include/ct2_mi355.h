@@ -463,6 +463,10 @@ int ct2x_attention_decode(const float* d_q, const float* d_k_cache, const float*
 int ct2x_cross_attention_h(const float* d_q, const void* d_kv, int kv_dtype, const int32_t* d_lengths,
                            int64_t batch, int64_t beam, int64_t heads, int64_t heads_kv,
                            int64_t s_max, float scale, float* d_out, void* stream);
+/* The same with the head width as an argument: d_head 64 or 128 (round 4: the NLLB-3.3B geometry). */
+int ct2x_cross_attention_hd(const float* d_q, const void* d_kv, int kv_dtype, const int32_t* d_lengths,
+                            int64_t batch, int64_t beam, int64_t heads, int64_t heads_kv,
+                            int64_t dhead, int64_t s_max, float scale, float* d_out, void* stream);
 
 /* Sequence-mode MultiHeadAttention core (src/layers/attention.cc:178-287 dot_product_attention:
  * MatMul QK^T * queries_scale -> length / causal mask -> SoftMax -> MatMul PV) for Tq > 1:

@@ -482,7 +482,7 @@ def cross_attention_h(q, kv_bits, bf16, lengths, beam, heads_kv, scale):
     kvd = torch.from_numpy(np.ascontiguousarray(kv_bits).view(np.int16)).cuda()
     ld = torch.from_numpy(np.ascontiguousarray(lengths, np.int32)).cuda() if lengths is not None else None
     out = torch.empty((rows, heads, dh), dtype=torch.float32, device="cuda")
-    _lib.check(L.ct2x_cross_attention_h(_lib.ptr(qd), _lib.ptr(kvd), C.c_int(5 if bf16 else 4),
-                                        _lib.ptr(ld), i64(batch), i64(beam), i64(heads), i64(heads_kv),
-                                        i64(s_max), C.c_float(scale), _lib.ptr(out), None))
+    _lib.check(L.ct2x_cross_attention_hd(_lib.ptr(qd), _lib.ptr(kvd), C.c_int(5 if bf16 else 4),
+                                         _lib.ptr(ld), i64(batch), i64(beam), i64(heads), i64(heads_kv),
+                                         i64(dh), i64(s_max), C.c_float(scale), _lib.ptr(out), None))
     return host(out)

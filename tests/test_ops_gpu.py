@@ -982,18 +982,22 @@ def test_gumbel_noise_is_exponential_and_seeded(gpu):
     assert abs((x - 3.0).mean().item() - 1.0) < 0.01
 
 
-@pytest.mark.parametrize("batch,beam,heads,hkv,s_max", [(3, 5, 4, 4, 1500), (2, 1, 8, 8, 37), (4, 4, 8, 2, 260),
-                                                       (1, 8, 2, 1, 8), (5, 3, 20, 20, 129)])
+@pytest.mark.parametrize("batch,beam,heads,hkv,s_max,dh", [(3, 5, 4, 4, 1500, 64), (2, 1, 8, 8, 37, 64),
+                                                          (4, 4, 8, 2, 260, 64), (1, 8, 2, 1, 8, 64),
+                                                          (5, 3, 20, 20, 129, 64),
+                                                          # d_head 128 (NLLB-3.3B geometry: 16 heads, 32 positions)
+                                                          (6, 4, 16, 16, 32, 128), (2, 5, 4, 2, 700, 128),
+                                                          (3, 1, 8, 8, 5, 128), (1, 8, 2, 1, 1500, 128)])
 @pytest.mark.parametrize("bf16", [False, True])
-def test_cross_attention_16bit_memory(gpu, batch, beam, heads, hkv, s_max, bf16):
+def test_cross_attention_16bit_memory(gpu, batch, beam, heads, hkv, s_max, dh, bf16):
     """attention_cross_h.hip: the decode steps' encoder-decoder attention over float16 / bfloat16
     memory keys and values, one workgroup per (batch entry, head) for all hypothesis rows. Oracle:
     the same 16-bit values in float64 (softmax(q . K^T * scale, lengths) . V); what is left is the
     fp32 evaluation order."""
     import _gpuops as G
     rng = np.random.default_rng(batch * 1000 + beam * 100 + heads + s_max + int(bf16))
-    q = rng.standard_normal((batch * beam, heads, 64)).astype(np.float32)
-    kv = rng.standard_normal((batch, s_max, 2, hkv, 64)).astype(np.float32)
+    q = rng.standard_normal((batch * beam, heads, dh)).astype(np.float32)
+    kv = rng.standard_normal((batch, s_max, 2, hkv, dh)).astype(np.float32)
     lengths = rng.integers(max(1, s_max // 2), s_max + 1, batch).astype(np.int32)
     lengths[0] = s_max
     if bf16:
