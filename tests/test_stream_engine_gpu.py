@@ -48,3 +48,16 @@ def test_streaming_and_packed_weights_are_result_neutral(gpu):
     assert stream_rowmajor["tokens"] == base["tokens"] and stream_rowmajor["scores"] == base["scores"]
     assert packed["tokens"] == base["tokens"] and packed["scores"] == base["scores"]
     assert len(base["tokens"]) == 6 and all(len(t) == 24 for t in base["tokens"])
+
+
+@pytest.mark.gpu
+def test_streaming_prologues_are_result_neutral(gpu):
+    """RMSNorm + Quantize and the element-wise Quantize as prologues of the streaming GEMM
+    (gemm_s8_stream.hip AMODE 1 / 2; off by default - measured not faster): the engine
+    with them switched on generates the same tokens and scores, with fewer launches per step."""
+    base = _run({})
+    both = _run({"CT2X_STREAM_PROLOGUE": "3"})
+    norm_only = _run({"CT2X_STREAM_PROLOGUE": "1"})
+    assert both["tokens"] == base["tokens"] and both["scores"] == base["scores"]
+    assert norm_only["tokens"] == base["tokens"] and norm_only["scores"] == base["scores"]
+    assert both["kernels_per_step"] < norm_only["kernels_per_step"] < base["kernels_per_step"]
