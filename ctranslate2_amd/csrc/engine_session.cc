@@ -12,6 +12,7 @@
 #include <stdexcept>
 
 #include "engine_internal.h"
+
 #include "runtime.h"
 
 namespace ct2x {
@@ -30,12 +31,12 @@ DecodeState::~DecodeState() {
   }
   for (int i = 0; i < 2; ++i) {
     if (graph_exec[i]) (void)hipGraphExecDestroy(graph_exec[i]);
-    if (pin_ids[i]) (void)hipHostFree(pin_ids[i]);
-    if (pin_scores[i]) (void)hipHostFree(pin_scores[i]);
+    pinned_free(pin_ids[i]);
+    pinned_free(pin_scores[i]);
     if (pin_event[i]) (void)hipEventDestroy(pin_event[i]);
-    if (pin_cand_word[i]) (void)hipHostFree(pin_cand_word[i]);
-    if (pin_cand_score[i]) (void)hipHostFree(pin_cand_score[i]);
-    if (pin_cand_origin[i]) (void)hipHostFree(pin_cand_origin[i]);
+    pinned_free(pin_cand_word[i]);
+    pinned_free(pin_cand_score[i]);
+    pinned_free(pin_cand_origin[i]);
     if (pin_cand_event[i]) (void)hipEventDestroy(pin_cand_event[i]);
   }
   if (graph) (void)hipGraphDestroy(graph);

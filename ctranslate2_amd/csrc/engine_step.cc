@@ -532,12 +532,12 @@ void Engine::read_beam_history_async(DecodeState& st, int64_t first, int64_t cou
   const int64_t need = count * per_step;
   if (st.pin_cand_capacity < need) {
     for (int i = 0; i < 2; ++i) {
-      if (st.pin_cand_word[i]) (void)hipHostFree(st.pin_cand_word[i]);
-      if (st.pin_cand_score[i]) (void)hipHostFree(st.pin_cand_score[i]);
-      if (st.pin_cand_origin[i]) (void)hipHostFree(st.pin_cand_origin[i]);
-      CT2X_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.pin_cand_word[i]), need * sizeof(int32_t)));
-      CT2X_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.pin_cand_score[i]), need * sizeof(float)));
-      CT2X_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.pin_cand_origin[i]), need * sizeof(int32_t)));
+      pinned_free(st.pin_cand_word[i]);
+      pinned_free(st.pin_cand_score[i]);
+      pinned_free(st.pin_cand_origin[i]);
+      st.pin_cand_word[i] = static_cast<int32_t*>(pinned_malloc(need * sizeof(int32_t)));
+      st.pin_cand_score[i] = static_cast<float*>(pinned_malloc(need * sizeof(float)));
+      st.pin_cand_origin[i] = static_cast<int32_t*>(pinned_malloc(need * sizeof(int32_t)));
       if (!st.pin_cand_event[i])
         CT2X_HIP_CHECK(hipEventCreateWithFlags(&st.pin_cand_event[i], hipEventDisableTiming));
     }
@@ -629,10 +629,10 @@ void Engine::read_history_async(DecodeState& st, int64_t first, int64_t count, i
   const int64_t need = count * st.rows;
   if (st.pin_capacity < need) {
     for (int i = 0; i < 2; ++i) {
-      if (st.pin_ids[i]) (void)hipHostFree(st.pin_ids[i]);
-      if (st.pin_scores[i]) (void)hipHostFree(st.pin_scores[i]);
-      CT2X_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.pin_ids[i]), need * sizeof(int32_t)));
-      CT2X_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&st.pin_scores[i]), need * sizeof(float)));
+      pinned_free(st.pin_ids[i]);
+      pinned_free(st.pin_scores[i]);
+      st.pin_ids[i] = static_cast<int32_t*>(pinned_malloc(need * sizeof(int32_t)));
+      st.pin_scores[i] = static_cast<float*>(pinned_malloc(need * sizeof(float)));
       if (!st.pin_event[i]) CT2X_HIP_CHECK(hipEventCreateWithFlags(&st.pin_event[i], hipEventDisableTiming));
     }
     st.pin_capacity = need;

@@ -166,7 +166,66 @@ void device_free(void* ptr) {
   p.live.erase(it);
 }
 
+namespace {
+struct PinnedPool {
+  std::mutex mutex;
+  std::map<size_t, std::vector<void*>> free_blocks;  // size class -> buffers
+  std::map<void*, size_t> live;
+};
+PinnedPool& pinned_pool() {
+  static PinnedPool* p = new PinnedPool();  // (never destroyed: buffers may outlive static teardown)
+  return *p;
+}
+size_t pinned_class(size_t bytes) {
+  size_t c = 4096;
+  while (c < bytes) c <<= 1;
+  return c;
+}
+}  // namespace
+
+void* pinned_malloc(size_t bytes) {
+  const size_t c = pinned_class(bytes);
+  PinnedPool& p = pinned_pool();
+  {
+    std::lock_guard<std::mutex> lock(p.mutex);
+    auto it = p.free_blocks.find(c);
+    if (it != p.free_blocks.end() && !it->second.empty()) {
+      void* ptr = it->second.back();
+      it->second.pop_back();
+      p.live[ptr] = c;
+      return ptr;
+    }
+  }
+  void* ptr = nullptr;
+  CT2X_HIP_CHECK(hipHostMalloc(&ptr, c));
+  std::lock_guard<std::mutex> lock(p.mutex);
+  p.live[ptr] = c;
+  return ptr;
+}
+
+void pinned_free(void* ptr) {
+  if (ptr == nullptr) return;
+  PinnedPool& p = pinned_pool();
+  std::lock_guard<std::mutex> lock(p.mutex);
+  auto it = p.live.find(ptr);
+  if (it == p.live.end()) return;
+  p.free_blocks[it->second].push_back(ptr);
+  p.live.erase(it);
+}
+
 void clear_cache() {
+  {
+    PinnedPool& pp = pinned_pool();
+    std::vector<void*> host_blocks;
+    {
+      std::lock_guard<std::mutex> lock(pp.mutex);
+      for (auto& kv : pp.free_blocks) {
+        host_blocks.insert(host_blocks.end(), kv.second.begin(), kv.second.end());
+        kv.second.clear();
+      }
+    }
+    for (void* ptr : host_blocks) (void)hipHostFree(ptr);
+  }
   Pool& p = pool();
   std::vector<void*> to_free;
   {

@@ -60,6 +60,14 @@ void device_free(void* ptr);
 void clear_cache();
 int64_t allocated_bytes();
 
+// Page-locked host staging buffers (the read-back slots of the decoding loops), recycled by size
+// class (powers of two) and returned to the driver by clear_cache() only: hipHostMalloc /
+// hipHostFree cost 100 - 250 us each on this stack - a decoding session took four of them, 0.9 ms
+// of a 21 ms Transformer-base call in its destructor alone (measured). The caller
+// makes sure no copy into the buffer is in flight when it releases it.
+void* pinned_malloc(size_t bytes);
+void pinned_free(void* ptr);
+
 // Experiment switches (kernel-variant A/B knobs of tools/*): read only by a library built with
 // `make TUNING=1`; the shipped library ignores them (returns nullptr) and runs the measured winners.
 inline const char* tuning_env(const char* name) {
