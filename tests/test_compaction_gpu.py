@@ -3,7 +3,7 @@ rows out of every state tensor whenever a sentence finishes, src/decoding.cc:916
 finished rows must not change a single token or score of the rows that stay. The threshold is read
 once per process (CT2X_COMPACT_MIN_ROWS; default 64 rows), so every setting runs in its own
 interpreter: 0 = never, 2 = as early as the policy allows (at most half of the rows alive).
-The reference-golden suites run once more under the forced setting by tools/final_check.sh."""
+The reference-golden suites run once more under the forced setting by `tools/gpu_r4.sh compaction`."""
 import json
 import os
 import subprocess
