@@ -187,7 +187,10 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
   // only where a step's cost follows the row count (min_rows: above the skinny-GEMM regime, where a
   // decode step costs the same for 1 or 32 rows).
   const int64_t compact_min_rows = compact_min_rows_setting();
-  const bool may_compact = !gather_attention && compact_min_rows > 0 && engine.compactable(st);
+  // (random sampling draws from a hash of (seed, step, ROW): renumbering the rows would change the
+  // sample a seed produces - those sessions keep their rows)
+  const bool may_compact = !gather_attention && compact_min_rows > 0 && opt.sampling_topk == 1 &&
+                           engine.compactable(st);
   std::vector<int64_t> origin(batch);  // session row -> index into results / alive / prefix_len
   for (int64_t i = 0; i < batch; ++i) origin[i] = i;
   bool compact_pending = false;

@@ -51,10 +51,11 @@ res = t.translate_batch(src, beam_size=3, return_scores=True, max_decoding_lengt
 out["aren_beam_lp"] = [[r.hypotheses, [float(x) for x in r.scores]] for r in res]
 res = t.translate_batch(src, target_prefix=prefix, beam_size=2, return_scores=True, max_decoding_length=30)
 out["aren_beam_prefix"] = [[r.hypotheses, [float(x) for x in r.scores]] for r in res]
-# random sampling: the draw is a hash of (seed, step, ROW) - the row numbering changes with the batch,
-# so only the setting without removal is comparable; here: it still runs
-res = t.translate_batch(src, beam_size=1, sampling_topk=4, max_decoding_length=12)
-out["aren_sampling_ok"] = len(res) == len(src)
+# random sampling draws from a hash of (seed, step, ROW): such sessions keep their rows, so a seed
+# gives the same samples under either setting
+res = t.translate_batch(src, beam_size=1, sampling_topk=4, seed=11, return_scores=True, max_decoding_length=30)
+out["aren_sampling"] = [[r.hypotheses[0], float(r.scores[0])] for r in res]
+out["aren_sampling_compactions"] = t.last_stats()["compactions"]
 
 # (b) decoder-only generation, ragged prompts as hard prefixes: the rows' last step differs, so they
 #     finish at different steps without any EOS
@@ -97,8 +98,9 @@ def test_dropping_finished_rows_changes_nothing(gpu):
     assert early["aren_compactions"] >= 1
     assert early["lm_compactions"] >= 1 and early["lm_lp_compactions"] >= 1
     assert early["aren_beam_compactions"] >= 1 and early["lm_beam_compactions"] >= 1
+    assert early["aren_sampling_compactions"] == 0
     for key in ("aren", "aren_lp", "aren_prefix", "lm", "lm_lp", "aren_beam", "aren_beam_lp",
-                "aren_beam_prefix", "lm_beam"):
+                "aren_beam_prefix", "lm_beam", "aren_sampling"):
         assert early[key] == base[key], key
     # sentences of different lengths finish at different steps in this batch (the premise)
     assert len({len(h) for h, _ in base["aren"]}) >= 3
