@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 400 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_final.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_final.log | tail -2
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_final.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_final.log | tail -2
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; cut -c1-200 gpurun_out/bench_final.json
 export TMPDIR=/tmp
