@@ -17,12 +17,14 @@ __version__ = "0.1.0"
 
 
 class TranslationResult:
-    """ctranslate2.TranslationResult: hypotheses (token lists) and scores."""
+    """ctranslate2.TranslationResult: hypotheses (token lists), scores and, with return_attention,
+    one source attention vector per token of every hypothesis."""
 
-    def __init__(self, hypotheses, scores, hypotheses_ids):
+    def __init__(self, hypotheses, scores, hypotheses_ids, attention=None):
         self.hypotheses = hypotheses
         self.scores = scores
         self.hypotheses_ids = hypotheses_ids
+        self.attention = attention if attention is not None else []
 
     def __repr__(self):
         return "TranslationResult(hypotheses=%r, scores=%r)" % (self.hypotheses, self.scores)
@@ -305,12 +307,33 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         if target_prefix is not None:
             kwargs["target_prefix_ids"] = [[self.token_to_id(t, target=True) for t in (pfx or [])]
                                            for pfx in target_prefix]
-        hyps, scores = self.translate_ids(src_ids, **kwargs)
+        # replace_unknowns (TranslationOptions, include/ctranslate2/translation.h:81): an unknown
+        # target token becomes the source token with the highest attention - the decoding runs
+        # with return_attention (src/models/sequence_to_sequence.cc:352) and the vectors are dropped
+        # afterwards unless the caller asked for them (:414-422)
+        replace_unknowns = bool(kwargs.pop("replace_unknowns", False))
+        return_attention = bool(kwargs.get("return_attention", False))
+        if replace_unknowns:
+            kwargs["return_attention"] = True
+        atts = None
+        if kwargs.get("return_attention", False):
+            hyps, scores, atts = self.translate_ids(src_ids, **kwargs)
+        else:
+            hyps, scores = self.translate_ids(src_ids, **kwargs)
         results = []
         for b, sent_hyps in enumerate(hyps):
             tokens = [[self.id_to_token(i) for i in h] for h in sent_hyps]
+            if replace_unknowns:
+                # replace_unknown_tokens (sequence_to_sequence.cc:288-302): first maximum. (the id an
+                # absent token maps to IS the unknown token's, whatever the model calls it)
+                unk_id = self.token_to_id("<unk>", target=True)
+                for k, hyp in enumerate(tokens):
+                    for t in range(len(hyp)):
+                        if sent_hyps[k][t] == unk_id and t < len(atts[b][k]) and len(source[b]) > 0:
+                            hyp[t] = source[b][int(np.argmax(atts[b][k][t]))]
             sc = [float(scores[b, k]) for k in range(len(sent_hyps))] if return_scores else []
-            results.append(TranslationResult(tokens, sc, sent_hyps))
+            att = [a.tolist() for a in atts[b]] if (atts is not None and return_attention) else None
+            results.append(TranslationResult(tokens, sc, sent_hyps, att))
         return results
 
     def score_ids(self, source_ids: Sequence[Sequence[int]], target_ids: Sequence[Sequence[int]],

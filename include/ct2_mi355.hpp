@@ -71,7 +71,7 @@ struct TranslationOptions {
   bool return_attention = false;
   bool return_alternatives = false;
   float min_alternative_expansion_prob = 0;
-  bool replace_unknowns = false;         // not built: must stay false
+  bool replace_unknowns = false;         // unknown target tokens -> the source token with the highest attention
   // backend additions
   unsigned int seed = 0;                 // random sampling is reproducible for a seed
   bool use_graph = true;                 // replay decode steps from a hipGraph
@@ -290,7 +290,6 @@ public:
                   const std::vector<std::vector<std::string>>& target_prefix,
                   const TranslationOptions& options = TranslationOptions(),
                   size_t max_batch_size = 0) {
-    detail::reject(options.replace_unknowns, "replace_unknowns");
     if (!target_prefix.empty() && target_prefix.size() != source.size())
       throw std::invalid_argument("Batch size mismatch: got " + std::to_string(source.size()) +
                                   " for source and " + std::to_string(target_prefix.size()) +
@@ -330,7 +329,9 @@ public:
     o.prefix_bias_beta = options.prefix_bias_beta;
     o.coverage_penalty = options.coverage_penalty;
     std::vector<float> attention;
-    if (options.return_attention) {
+    // replace_unknowns decodes with the attention (src/models/sequence_to_sequence.cc:352)
+    const bool want_attention = options.return_attention || options.replace_unknowns;
+    if (want_attention) {
       attention.assign(batch * hyp * len * static_cast<size_t>(src.stride), 0.f);
       o.attention_out = attention.data();
       o.attention_stride = src.stride;
@@ -354,16 +355,30 @@ public:
           continue;  // fewer finished hypotheses (or alternatives) than requested
         std::vector<std::string> tokens;
         for (int32_t t = 0; t < n; ++t) tokens.push_back(h_.to_token(1, out[(b * hyp + k) * len + t]));
-        results[b].hypotheses.push_back(std::move(tokens));
-        if (options.return_scores) results[b].scores.push_back(scores[b * hyp + k]);
-        if (options.return_attention) {
+        if (want_attention) {
           std::vector<std::vector<float>> att(static_cast<size_t>(n));
           for (int32_t t = 0; t < n; ++t) {
             const float* row = attention.data() + ((b * hyp + k) * len + t) * static_cast<size_t>(src.stride);
             att[t].assign(row, row + source[b].size());
           }
-          results[b].attention.push_back(std::move(att));
+          if (options.replace_unknowns && !source[b].empty()) {
+            // replace_unknown_tokens (src/models/sequence_to_sequence.cc:288-302): the source token
+            // under the first maximum of the token's attention vector
+            // (the id an absent token maps to IS the unknown token's, whatever the model calls it)
+            const int32_t unk_id = h_.to_id(1, "<unk>");
+            for (int32_t t = 0; t < n; ++t)
+              if (out[(b * hyp + k) * len + t] == unk_id) {
+                const auto& v = att[static_cast<size_t>(t)];
+                size_t pos = 0;
+                for (size_t j = 1; j < v.size(); ++j)
+                  if (v[j] > v[pos]) pos = j;
+                tokens[static_cast<size_t>(t)] = source[b][pos];
+              }
+          }
+          if (options.return_attention) results[b].attention.push_back(std::move(att));
         }
+        results[b].hypotheses.push_back(std::move(tokens));
+        if (options.return_scores) results[b].scores.push_back(scores[b * hyp + k]);
       }
     }
     return results;

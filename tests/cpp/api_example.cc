@@ -85,14 +85,25 @@ int main(int argc, char** argv) {
     } else if (mode == "reject") {
       ct2_mi355::Translator translator(model);
       ct2_mi355::TranslationOptions options;
-      options.replace_unknowns = true;  // needs the attention on the host side: not built
-      try {
-        translator.translate_batch({{"a"}}, options);
+      try {  // one source, two prefixes
+        translator.translate_batch({{"a"}}, {{"b"}, {"c"}}, options);
       } catch (const std::invalid_argument& e) {
         std::cout << "rejected: " << e.what() << std::endl;
         return 0;
       }
       return 4;
+    } else if (mode == "replace_unknowns") {
+      // TranslationOptions::replace_unknowns: the prefix forces an unknown target token, which
+      // comes back as the source token under the attention's maximum; argv[3..] = source tokens
+      ct2_mi355::Translator translator(model);
+      ct2_mi355::TranslationOptions options;
+      options.beam_size = 1;
+      options.replace_unknowns = true;
+      std::vector<std::string> source;
+      for (int i = 3; i < argc; ++i) source.push_back(argv[i]);
+      const auto results = translator.translate_batch({source}, {{"<unk>"}}, options);
+      for (const auto& tok : results[0].hypotheses[0]) std::cout << tok << ' ';
+      std::cout << "| " << results[0].attention.size() << std::endl;
     } else {
       return 1;
     }

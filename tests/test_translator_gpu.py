@@ -495,6 +495,32 @@ def test_logits_processors_eager_equals_graph(gpu):
     assert a == b
 
 
+def test_replace_unknowns(gpu):
+    """TranslationOptions.replace_unknowns (src/models/sequence_to_sequence.cc:288-302, 352, 414-422):
+    an unknown target token is replaced by the source token with the highest attention; the
+    attention vectors are returned only with return_attention. The prefix forces an unknown token
+    into the hypothesis; the expected replacement is recomputed from a return_attention run."""
+    t = get_translator(gpu, "aren-transliteration-i8")
+    src = [GC.AREN_SOURCES[1], GC.AREN_SOURCES[2], GC.AREN_SOURCES[4]]
+    prefix = [["<unk>"], ["a", "<unk>"], []]
+    plain = t.translate_batch(src, target_prefix=prefix, beam_size=2, return_attention=True,
+                              return_scores=True)
+    got = t.translate_batch(src, target_prefix=prefix, beam_size=2, replace_unknowns=True,
+                            return_scores=True)
+    both = t.translate_batch(src, target_prefix=prefix, beam_size=2, replace_unknowns=True,
+                             return_attention=True)
+    for b in range(len(src)):
+        want = list(plain[b].hypotheses[0])
+        for i, tok in enumerate(want):
+            if tok == "<unk>":
+                want[i] = src[b][int(np.argmax(plain[b].attention[0][i]))]
+        assert got[b].hypotheses[0] == want and "<unk>" not in got[b].hypotheses[0]
+        assert got[b].scores == plain[b].scores and got[b].attention == []
+        assert both[b].hypotheses[0] == want
+        assert np.allclose(np.asarray(both[b].attention[0]), np.asarray(plain[b].attention[0]))
+    assert plain[0].hypotheses[0][0] == "<unk>" and plain[1].hypotheses[0][1] == "<unk>"
+
+
 def test_cpp_api_translator(gpu):
     """The C++ host API (include/ct2_mi355.hpp: Translator::translate_batch with the reference's
     option / result names) on the reference's transliteration KAT (tests/translator_test.cc:53-97),
@@ -510,7 +536,14 @@ def test_cpp_api_translator(gpu):
     want = t.translate_batch([GC.AREN_SOURCES[0]], beam_size=2, return_scores=True)[0]
     assert abs(float(score) - want.scores[0]) < 1e-4
     rc, out, err = _cppapi.run("reject", model)
-    assert rc == 0 and "replace_unknowns" in out, (out, err)
+    assert rc == 0 and "Batch size mismatch" in out, (out, err)
+    # replace_unknowns through the C++ surface == the Python surface
+    rc, out, err = _cppapi.run("replace_unknowns", model, *GC.AREN_SOURCES[1])
+    assert rc == 0, err
+    toks, n_att = [s.strip() for s in out.strip().split("|")]
+    want = t.translate_batch([GC.AREN_SOURCES[1]], target_prefix=[["<unk>"]], beam_size=1,
+                             replace_unknowns=True)[0]
+    assert toks.split() == want.hypotheses[0] and n_att == "0" and want.attention == []
     # Translator::score_batch through the C++ surface == the Python surface
     src, tgt = GC.AREN_SOURCES[0], ["a", "t", "z", "m", "o", "n"]
     rc, out, err = _cppapi.run("score", model, len(src), *(src + tgt))
