@@ -30,6 +30,27 @@ class TranslationResult:
         return "TranslationResult(hypotheses=%r, scores=%r)" % (self.hypotheses, self.scores)
 
 
+class GenerationStepResult:
+    """ctranslate2.GenerationStepResult (python/cpp/generation_result.cc:11-42): what the
+    `callback` of translate_batch / generate_ids receives for every generated token."""
+
+    def __init__(self, step, batch_id, token_id, token, log_prob, is_last):
+        self.step = step
+        self.batch_id = batch_id
+        self.token_id = token_id
+        self.hypothesis_id = 0
+        self.token = token
+        self.log_prob = log_prob
+        self.logits = None
+        self.is_last = is_last
+
+    def __repr__(self):
+        return ("GenerationStepResult(step=%r, batch_id=%r, token_id=%r, hypothesis_id=%r, "
+                "token=%r, log_prob=%r, logits=None, is_last=%r)"
+                % (self.step, self.batch_id, self.token_id, self.hypothesis_id, self.token,
+                   self.log_prob, self.is_last))
+
+
 class ScoringResult:
     """ctranslate2.ScoringResult: the scored tokens (target + </s>) and their log-probabilities."""
 
@@ -203,6 +224,31 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
             raise ValueError("%s token '%s' is not in the vocabulary" % (what, token))
         return idx
 
+    def _set_callback(self, opt, callback):
+        """TranslationOptions / GenerationOptions.callback (python/cpp/translator.cc:152-181): the
+        Python callable is called with a GenerationStepResult per generated token; returning True
+        stops that batch entry. Returns a holder whose `error` is an exception the callable raised
+        (the decoding of every entry is then stopped and the exception re-raised by the caller)."""
+        holder = type("CallbackHolder", (), {"error": None, "fn": None})()
+        if callback is None:
+            return holder
+
+        def trampoline(_user, step, batch_id, token_id, has_score, score, is_last):
+            if holder.error is not None:
+                return 1
+            try:
+                r = GenerationStepResult(int(step), int(batch_id), int(token_id),
+                                         self.id_to_token(int(token_id)),
+                                         float(score) if has_score else None, bool(is_last))
+                return 1 if callback(r) else 0
+            except BaseException as e:  # noqa: BLE001 - must not unwind through the C frames
+                holder.error = e
+                return 1
+
+        holder.fn = _lib.STEP_CALLBACK(trampoline)
+        opt.step_callback = holder.fn
+        return holder
+
     @staticmethod
     def _set_processors(opt, repetition_penalty, no_repeat_ngram_size, suppress_sequences_ids):
         """Fills the logits-processor fields of the options; returns the arrays the struct points
@@ -230,7 +276,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                       suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None,
                       end_token_id: Optional[int] = None, return_alternatives: bool = False,
                       min_alternative_expansion_prob: float = 0.0, prefix_bias_beta: float = 0.0,
-                      coverage_penalty: float = 0.0, return_attention: bool = False):
+                      coverage_penalty: float = 0.0, return_attention: bool = False,
+                      callback=None):
         """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores), plus
         the attention ([batch][hyp] arrays [tokens, source length]) when return_attention is set.
         return_alternatives / min_alternative_expansion_prob / prefix_bias_beta / coverage_penalty /
@@ -239,7 +286,9 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         sampling_* (reference names, python/cpp/translator.cc): random sampling among the best
         sampling_topk candidates (beam_size must be 1), reproducible for a `seed`.
         repetition_penalty / no_repeat_ngram_size as in the reference; suppress_sequences_ids:
-        id sequences that must not be generated (a single id is disabled at every step)."""
+        id sequences that must not be generated (a single id is disabled at every step).
+        callback: called with a GenerationStepResult for every generated token (beam_size 1);
+        returning True stops that batch entry."""
         batch = len(source_ids)
         lengths = np.array([len(s) for s in source_ids], np.int32)
         stride = max(1, int(lengths.max()) if batch else 1)
@@ -260,6 +309,7 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         opt.min_alternative_expansion_prob = float(min_alternative_expansion_prob)
         opt.prefix_bias_beta = float(prefix_bias_beta)
         opt.coverage_penalty = float(coverage_penalty)
+        cb = self._set_callback(opt, callback)
         att = None
         if return_attention:
             att = np.zeros((batch, num_hypotheses, max_decoding_length, stride), np.float32)
@@ -279,6 +329,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
             _lib.check(self._L.ct2x_translate_batch(
                 C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
                 C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
+        if cb.error is not None:
+            raise cb.error
         keep = [[k for k in range(num_hypotheses)
                  if (out_len[b, k] >= 0 if return_alternatives else (out_len[b, k] > 0 or k == 0))]
                 for b in range(batch)]
@@ -386,7 +438,7 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                      length_penalty: float = 1.0, repetition_penalty: float = 1.0,
                      no_repeat_ngram_size: int = 0,
                      suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None,
-                     end_token_id: Optional[int] = None):
+                     end_token_id: Optional[int] = None, callback=None):
         """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False.
         sampling_topk=1 is greedy; k >= 2 samples among the best k, 0 from the whole vocabulary (sampling_topp / temperature as
         in the reference). Returns (generated ids per prompt, scores)."""
@@ -405,9 +457,12 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         _keep = self._set_processors(opt, repetition_penalty, no_repeat_ngram_size,
                                      suppress_sequences_ids)
         opt.end_token_plus_one = 0 if end_token_id is None else int(end_token_id) + 1
+        cb = self._set_callback(opt, callback)
         _lib.check(self._L.ct2x_generate_batch(
             C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
             C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
+        if cb.error is not None:
+            raise cb.error
         return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
 
     @staticmethod

@@ -18,6 +18,12 @@ class Ct2xError(RuntimeError):
     pass
 
 
+# int (*step_callback)(void* user, int64 step, int64 batch_id, int32 token_id, int32 has_score,
+#                       float score, int32 is_last)
+STEP_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                            C.c_float, C.c_int32)
+
+
 class TranslationOptions(C.Structure):
     """struct ct2x_translation_options (include/ct2_mi355.h)."""
     _fields_ = [
@@ -50,6 +56,8 @@ class TranslationOptions(C.Structure):
         ("attention_stride", C.c_int32),
         ("reserved0", C.c_int32),
         ("attention_out", C.POINTER(C.c_float)),
+        ("step_callback", STEP_CALLBACK),
+        ("step_callback_data", C.c_void_p),
     ]
 
 

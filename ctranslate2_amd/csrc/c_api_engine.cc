@@ -178,6 +178,16 @@ DecodingOptions to_decoding_options(const ct2x_translation_options& o) {
   d.min_alternative_expansion_prob = o.min_alternative_expansion_prob;
   d.coverage_penalty = o.coverage_penalty;
   d.return_attention = o.attention_out != nullptr;
+  if (o.step_callback != nullptr) {
+    // (the callers below wrap it once more to restore the batch ids of their sub-batches,
+    // restore_batch_ids_in_callback, include/ctranslate2/generation.h:120-131)
+    auto fn = o.step_callback;
+    void* user = o.step_callback_data;
+    d.sync_every = 1;  // a streaming consumer: hand tokens over step by step (<= 2 steps late)
+    d.callback = [fn, user](const DecodingStepResult& r) {
+      return fn(user, r.step, r.batch_id, r.token_id, r.has_score ? 1 : 0, r.score, r.is_last ? 1 : 0) != 0;
+    };
+  }
   LogitsProcessing& lp = d.logits_processing;
   lp.repetition_penalty = o.repetition_penalty == 0.f ? 1.f : o.repetition_penalty;
   lp.no_repeat_ngram_size = o.no_repeat_ngram_size;
@@ -816,6 +826,7 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
   }
   streams = std::max<int32_t>(1, std::min<int32_t>(streams, 16));
   if (t->engine->profiling()) streams = 1;  // event bookkeeping is single-stream
+  if (dopt.callback) streams = 1;           // the callback is called from one thread
   const size_t ref_chunk = opt.max_batch_size > 0 ? static_cast<size_t>(opt.max_batch_size)
                                                   : std::max<size_t>(order.size(), 1);
   // Concurrent hipGraph captures from several threads are not reliable on ROCm 7.2 ("operation
@@ -890,11 +901,19 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
         }
         const std::vector<std::vector<int32_t>>* pf = any_prefix ? &prefix : nullptr;
         DecodeStats ds;
+        DecodingOptions gopt = dopt;
+        if (dopt.callback) {  // the callback sees the caller's batch indices
+          gopt.callback = [&dopt, &order, begin](const DecodingStepResult& r) {
+            DecodingStepResult m = r;
+            m.batch_id = order[begin + static_cast<size_t>(r.batch_id)];
+            return dopt.callback(m);
+          };
+        }
         // make_search_strategy (src/decoding.cc:1075-1087): biased decoding is a beam search
         std::vector<DecodingResult> results =
             (dopt.beam_size == 1 && !(dopt.prefix_bias_beta > 0 && pf))
-                ? greedy_search(*t->engine, *st, start_ids, end_id, dopt, &ds, pf)
-                : beam_search(*t->engine, *st, start_ids, end_id, dopt, &ds, pf);
+                ? greedy_search(*t->engine, *st, start_ids, end_id, gopt, &ds, pf)
+                : beam_search(*t->engine, *st, start_ids, end_id, gopt, &ds, pf);
         t->engine->synchronize();
         const double te2 = now_ms();
         for (int64_t i = 0; i < B; ++i) all_results[order[begin + i]] = std::move(results[i]);

@@ -45,6 +45,10 @@ void validate_decoding_options(const DecodingOptions& o) {
     throw std::invalid_argument("The minimum alternative expansion probability must be between 0 and 1");
   if (o.prefix_bias_beta > 0 && o.sampling_topk != 1)
     throw std::invalid_argument("Biased decoding runs a beam search: random sampling is not available with it");
+  // (src/decoding.cc:1052-1054)
+  if (o.callback && (o.beam_size != 1 || o.prefix_bias_beta > 0))
+    throw std::invalid_argument("The callback function is not compatible with "
+                                "beam_size > 1 or prefix_bias_beta > 0");
 }
 
 float finalize_score(float score, float length, float length_penalty) {
@@ -241,7 +245,18 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
           }
         }
         if (opt.return_scores) score_sum[i] += h_scores[s * rows_now + row];  // forced steps add 0
-        if (eos || last) {
+        bool stop = false;
+        if (opt.callback && (opt.return_prefix || !in_prefix)) {  // (src/decoding.cc:925-939)
+          DecodingStepResult r;
+          r.step = step;
+          r.batch_id = i;
+          r.token_id = word;
+          r.has_score = opt.return_scores;
+          r.score = opt.return_scores ? h_scores[s * rows_now + row] : 0.f;
+          r.is_last = eos || last;
+          stop = opt.callback(r);
+        }
+        if (eos || last || stop) {
           alive[i] = 0;
           --count_alive;
           results[i].scores.assign(1, score_sum[i]);

@@ -10,11 +10,21 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "engine.h"
 
 namespace ct2x {
+
+struct DecodingStepResult {
+  int64_t step = 0;
+  int64_t batch_id = 0;
+  int32_t token_id = 0;
+  bool has_score = false;
+  float score = 0.f;
+  bool is_last = false;
+};
 
 struct DecodingOptions {
   int32_t beam_size = 1;
@@ -55,6 +65,10 @@ struct DecodingOptions {
   // Whisper's logits processors (DecodingOptions::logits_processors + disable_ids_begin of
   // WhisperReplica::generate, src/models/whisper.cc:312-343); nullptr = none
   const WhisperProcessing* whisper = nullptr;
+  // DecodingOptions::callback (include/ctranslate2/decoding.h; src/decoding.cc:925-939): greedy
+  // search calls it for every token a row generates (hidden prefix tokens excepted); true ends the
+  // row. batch_id is the row's index in THIS search's batch.
+  std::function<bool(const DecodingStepResult&)> callback;
 };
 
 struct DecodingResult {

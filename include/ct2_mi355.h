@@ -545,6 +545,19 @@ struct ct2x_translation_options {
   int32_t attention_stride;
   int32_t reserved0;
   float* attention_out;
+  /* TranslationOptions / GenerationOptions::callback (include/ctranslate2/translation.h:85,
+   * generation.h:77; invoked by GreedySearch::search, src/decoding.cc:925-939): called for every
+   * generated token of every batch entry, in step order per entry, with the step (counted from the
+   * first decoding step), the entry's index in the call's batch, the token id, its log-probability
+   * when return_scores is set (has_score) and whether it is the entry's last token. A non-zero
+   * return value ends that entry's decoding there. beam_size 1 only (the reference's rule and error
+   * text). With a callback the host examines every step (instead of groups of 8) while the device
+   * runs one step ahead, so a token reaches the callback at most two steps after it was sampled;
+   * the calls come from the thread that made the translate / generate call (num_streams <= 1 is
+   * forced). NULL = none. */
+  int (*step_callback)(void* user_data, int64_t step, int64_t batch_id, int32_t token_id,
+                       int32_t has_score, float score, int32_t is_last);
+  void* step_callback_data;
 };
 
 void ct2x_translation_options_default(struct ct2x_translation_options* opt);

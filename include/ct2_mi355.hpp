@@ -15,7 +15,9 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <functional>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -47,6 +49,18 @@ inline const char* compute_type_name(ComputeType t) {
   return "default";
 }
 
+// generation.h:93-118: what TranslationOptions / GenerationOptions::callback receives for every
+// generated token (logits: return_logits_vocab is not built, the member is absent)
+struct GenerationStepResult {
+  size_t step = 0;
+  size_t batch_id = 0;
+  size_t token_id = 0;
+  size_t hypothesis_id = 0;
+  std::string token;
+  std::optional<float> score;
+  bool is_last = false;
+};
+
 // translation.h:11-96
 struct TranslationOptions {
   size_t beam_size = 2;
@@ -72,6 +86,8 @@ struct TranslationOptions {
   bool return_alternatives = false;
   float min_alternative_expansion_prob = 0;
   bool replace_unknowns = false;         // unknown target tokens -> the source token with the highest attention
+  // called for every generated token when beam_size is 1; returning true stops that batch entry
+  std::function<bool(GenerationStepResult)> callback = nullptr;
   // backend additions
   unsigned int seed = 0;                 // random sampling is reproducible for a seed
   bool use_graph = true;                 // replay decode steps from a hipGraph
@@ -136,6 +152,8 @@ struct GenerationOptions {
   std::vector<std::string> static_prompt;
   bool cache_static_prompt = true;       // accepted; the prompt is simply forwarded
   bool include_prompt_in_result = true;
+  // called for every generated token when beam_size is 1; returning true stops that batch entry
+  std::function<bool(GenerationStepResult)> callback = nullptr;
   unsigned int seed = 0;
   bool use_graph = true;
 };
@@ -265,6 +283,49 @@ inline int32_t sampling_topk_field(size_t topk) {
   return topk == 0 ? -1 : static_cast<int32_t>(topk);
 }
 
+// Carries a std::function callback through the C ABI's (function pointer, user data) pair. An
+// exception thrown by the callback must not unwind through the C frames: it is kept, every entry is
+// stopped, and rethrow() raises it once the C call has returned.
+class StepCallback {
+public:
+  StepCallback(const Handle& h, const std::function<bool(GenerationStepResult)>& fn, size_t step_offset)
+      : h_(h), fn_(fn), step_offset_(step_offset) {}
+
+  void attach(ct2x_translation_options& o) {
+    if (!fn_) return;
+    o.step_callback = &StepCallback::trampoline;
+    o.step_callback_data = this;
+  }
+  void rethrow() {
+    if (error_) std::rethrow_exception(error_);
+  }
+
+private:
+  static int trampoline(void* user, int64_t step, int64_t batch_id, int32_t token_id,
+                        int32_t has_score, float score, int32_t is_last) {
+    auto* self = static_cast<StepCallback*>(user);
+    if (self->error_) return 1;
+    try {
+      GenerationStepResult r;
+      r.step = static_cast<size_t>(step) + self->step_offset_;
+      r.batch_id = static_cast<size_t>(batch_id);
+      r.token_id = static_cast<size_t>(token_id);
+      r.token = self->h_.to_token(1, token_id);
+      if (has_score) r.score = score;
+      r.is_last = is_last != 0;
+      return self->fn_(std::move(r)) ? 1 : 0;
+    } catch (...) {
+      self->error_ = std::current_exception();
+      return 1;
+    }
+  }
+
+  const Handle& h_;
+  const std::function<bool(GenerationStepResult)>& fn_;
+  size_t step_offset_;
+  std::exception_ptr error_;
+};
+
 }  // namespace detail
 
 // ctranslate2::Translator (include/ctranslate2/translator.h:26-60)
@@ -336,6 +397,8 @@ public:
       o.attention_out = attention.data();
       o.attention_stride = src.stride;
     }
+    detail::StepCallback step_callback(h_, options.callback, 0);
+    step_callback.attach(o);
     if (target_prefix.empty()) {
       detail::check(ct2x_translate_batch(h_.get(), src.ids.data(), src.lengths.data(),
                                          static_cast<int32_t>(batch), src.stride, &o, out.data(),
@@ -347,6 +410,7 @@ public:
                                                 pfx.ids.data(), pfx.lengths.data(), pfx.stride, &o,
                                                 out.data(), out_len.data(), scores.data()));
     }
+    step_callback.rethrow();
     std::vector<TranslationResult> results(batch);
     for (size_t b = 0; b < batch; ++b) {
       for (size_t k = 0; k < hyp; ++k) {
@@ -477,9 +541,34 @@ public:
     const size_t len = options.max_length;
     std::vector<int32_t> out(batch * len, 0), out_len(batch, 0);
     std::vector<float> scores(batch, 0.f);
+    // The C entry decodes with include_prompt_in_result = false: the first generated token of the
+    // shortest prompt is step 0. With include_prompt_in_result the reference forces the start
+    // tokens as a decoding prefix and reports them too (return_prefix, src/decoding.cc:925): they
+    // are handed to the callback here, before the decoding, and the steps continue from them. (A
+    // forced token's log-probability is not computed on this path: return_scores is rejected.)
+    size_t step_offset = 0;
+    if (options.callback && options.include_prompt_in_result) {
+      detail::reject(options.return_scores, "a callback with return_scores and include_prompt_in_result");
+      size_t shortest = start_tokens[0].size();
+      for (const auto& s : start_tokens) shortest = std::min(shortest, s.size());
+      if (shortest == 0) throw std::invalid_argument("a callback with include_prompt_in_result needs start tokens");
+      step_offset = shortest - 1;
+      for (size_t b = 0; b < batch; ++b)
+        for (size_t t = 1; t < start_tokens[b].size(); ++t) {
+          GenerationStepResult r;
+          r.step = t - 1;
+          r.batch_id = b;
+          r.token = start_tokens[b][t];
+          r.token_id = static_cast<size_t>(h_.to_id(1, r.token));
+          options.callback(std::move(r));  // (a stop request during the prompt is not honoured)
+        }
+    }
+    detail::StepCallback step_callback(h_, options.callback, step_offset);
+    step_callback.attach(o);
     detail::check(ct2x_generate_batch(h_.get(), in.ids.data(), in.lengths.data(),
                                       static_cast<int32_t>(batch), in.stride, &o, out.data(),
                                       out_len.data(), scores.data()));
+    step_callback.rethrow();
     std::vector<GenerationResult> results(batch);
     for (size_t b = 0; b < batch; ++b) {
       std::vector<std::string> tokens;

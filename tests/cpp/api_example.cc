@@ -92,6 +92,41 @@ int main(int argc, char** argv) {
         return 0;
       }
       return 4;
+    } else if (mode == "callback") {
+      // TranslationOptions::callback: every generated token is handed over in step order; the
+      // second sentence is stopped after its 2nd token; argv[3] = tokens of the first source
+      // sentence, the rest is split evenly over two sentences
+      ct2_mi355::Translator translator(model);
+      ct2_mi355::TranslationOptions options;
+      options.beam_size = 1;
+      options.return_scores = true;
+      options.callback = [](ct2_mi355::GenerationStepResult r) {
+        std::cout << r.batch_id << ' ' << r.step << ' ' << r.token << ' ' << r.token_id << ' '
+                  << (r.score ? *r.score : 1.f) << ' ' << r.is_last << std::endl;
+        return r.batch_id == 1 && r.step == 1;
+      };
+      const int n0 = std::atoi(argv[3]);
+      std::vector<std::string> a, b;
+      for (int i = 4; i < argc; ++i) (i - 4 < n0 ? a : b).push_back(argv[i]);
+      const auto results = translator.translate_batch({a, b}, options);
+      for (const auto& r : results) {
+        std::cout << "=";
+        for (const auto& tok : r.hypotheses[0]) std::cout << ' ' << tok;
+        std::cout << std::endl;
+      }
+      options.beam_size = 2;
+      try {
+        translator.translate_batch({a}, options);
+      } catch (const std::exception& e) {
+        std::cout << "rejected: " << e.what() << std::endl;
+      }
+      options.beam_size = 1;
+      options.callback = [](ct2_mi355::GenerationStepResult) -> bool { throw std::logic_error("from the callback"); };
+      try {
+        translator.translate_batch({a}, options);
+      } catch (const std::logic_error& e) {
+        std::cout << "raised: " << e.what() << std::endl;
+      }
     } else if (mode == "replace_unknowns") {
       // TranslationOptions::replace_unknowns: the prefix forces an unknown target token, which
       // comes back as the source token under the attention's maximum; argv[3..] = source tokens

@@ -117,6 +117,34 @@ def test_generate_matches_reference(gpu, golden, key, ct):
         assert identical >= len(ref) // 2
 
 
+def test_generation_callback(gpu, golden):
+    """GenerationOptions.callback (include/ctranslate2/generation.h:77; src/decoding.cc:925-939):
+    the generated tokens of every prompt, step by step, ragged prompts included (the hidden part
+    of a longer prompt is forced, not reported: return_prefix is false); True stops an entry."""
+    g = golden["lm_small_f32"]
+    t = get_lm("lm_small", "float32")
+    prompts = [list(p) for p in g["prompts"][:4]]
+    prompts[1] = prompts[1][:-2]  # ragged: the others carry a 2-token forced prefix
+    want, want_scores = t.generate_ids(prompts, max_length=12, min_length=12, return_scores=True)
+    calls = []
+    got, got_scores = t.generate_ids(prompts, max_length=12, min_length=12, return_scores=True,
+                                     callback=lambda r: calls.append(r) and False)
+    assert got == want and np.array_equal(got_scores, want_scores)
+    for b in range(len(prompts)):
+        mine = [c for c in calls if c.batch_id == b]
+        first = 0 if b == 1 else 2
+        assert [c.token_id for c in mine] == want[b]
+        assert [c.step for c in mine] == list(range(first, first + 12))
+        assert [c.is_last for c in mine] == [False] * 11 + [True]
+        assert abs(sum(c.log_prob for c in mine) - float(want_scores[b])) < 1e-3
+    got, _ = t.generate_ids(prompts, max_length=12, min_length=12,
+                            callback=lambda r: r.batch_id == 2 and len(
+                                [c for c in calls if c.batch_id == 2 and c.step <= r.step]) == 5)
+    assert got[2] == want[2][:5] and got[0] == want[0] and got[3] == want[3]
+    with pytest.raises(Exception, match="The callback function is not compatible with beam_size > 1"):
+        t.generate_ids(prompts, max_length=4, beam_size=2, callback=lambda r: False)
+
+
 def test_prefill_equals_stepwise(gpu, golden):
     """The sequence-mode prefill must leave the same caches as feeding the prompt token by token
     (tests/model_test.cc:99-151 DecoderIterativeSequence): the continuation after a prefilled

@@ -521,6 +521,54 @@ def test_replace_unknowns(gpu):
     assert plain[0].hypotheses[0][0] == "<unk>" and plain[1].hypotheses[0][1] == "<unk>"
 
 
+def test_decoding_callback(gpu):
+    """TranslationOptions.callback (include/ctranslate2/translation.h:85; GreedySearch::search,
+    src/decoding.cc:925-939; restore_batch_ids_in_callback, generation.h:120-131): one call per
+    generated token in step order with the caller's batch index, the token's log-probability with
+    return_scores, is_last on the final token; True stops that entry; beam search raises the
+    reference's error. max_batch_size forces the length-sorted re-batching the ids are restored
+    from."""
+    t = get_translator(gpu, "aren-transliteration-i8")
+    src = GC.AREN_SOURCES[:5]
+    want = t.translate_batch(src, beam_size=1, return_scores=True, return_end_token=True)
+    for kw in (dict(), dict(max_batch_size=2)):
+        calls = []
+        got = t.translate_batch(src, beam_size=1, return_scores=True, return_end_token=True,
+                                callback=lambda r: calls.append(r) and False, **kw)
+        assert [g.hypotheses for g in got] == [w.hypotheses for w in want]
+        for b in range(len(src)):
+            mine = [c for c in calls if c.batch_id == b]
+            assert [c.step for c in mine] == list(range(len(mine)))
+            assert [c.token for c in mine] == want[b].hypotheses[0]
+            assert [c.token_id for c in mine] == want[b].hypotheses_ids[0]
+            assert [c.is_last for c in mine] == [False] * (len(mine) - 1) + [True]
+            assert all(c.hypothesis_id == 0 and c.logits is None for c in mine)
+            assert abs(sum(c.log_prob for c in mine) - want[b].scores[0]) < 1e-4
+    # without return_scores there is no log_prob; a target prefix is reported (return_prefix)
+    calls = []
+    pfx = t.translate_batch(src[:2], target_prefix=[["a"], []], beam_size=1,
+                            callback=lambda r: calls.append(r) and False)
+    assert all(c.log_prob is None for c in calls)
+    for b in range(2):
+        assert [c.token for c in calls if c.batch_id == b] + [] == pfx[b].hypotheses[0] + ["</s>"]
+    assert [c for c in calls if c.batch_id == 0][0].token == "a"
+    # early stop: entry 1 ends after its 3rd token, the others are untouched
+    got = t.translate_batch(src, beam_size=1, callback=lambda r: r.batch_id == 1 and r.step == 2)
+    assert got[1].hypotheses[0] == want[1].hypotheses[0][:3]
+    for b in (0, 2, 3, 4):
+        assert got[b].hypotheses[0] == want[b].hypotheses[0][:-1]
+    # the reference's rule and text
+    with pytest.raises(Exception, match="The callback function is not compatible with beam_size > 1"):
+        t.translate_batch(src, beam_size=2, callback=lambda r: False)
+    # an exception raised by the callable comes back out of the call
+    def boom(r):
+        raise KeyError("from the callback")
+    with pytest.raises(KeyError, match="from the callback"):
+        t.translate_batch(src, beam_size=1, callback=boom)
+    assert [g.hypotheses for g in t.translate_batch(src, beam_size=1, return_end_token=True)] == \
+        [w.hypotheses for w in want]
+
+
 def test_cpp_api_translator(gpu):
     """The C++ host API (include/ct2_mi355.hpp: Translator::translate_batch with the reference's
     option / result names) on the reference's transliteration KAT (tests/translator_test.cc:53-97),
@@ -544,6 +592,24 @@ def test_cpp_api_translator(gpu):
     want = t.translate_batch([GC.AREN_SOURCES[1]], target_prefix=[["<unk>"]], beam_size=1,
                              replace_unknowns=True)[0]
     assert toks.split() == want.hypotheses[0] and n_att == "0" and want.attention == []
+    # TranslationOptions::callback through the C++ surface
+    s0, s1 = GC.AREN_SOURCES[0], GC.AREN_SOURCES[1]
+    rc, out, err = _cppapi.run("callback", model, len(s0), *(s0 + s1))
+    assert rc == 0, err
+    lines = out.strip().splitlines()
+    want = t.translate_batch([s0, s1], beam_size=1, return_scores=True, return_end_token=True)
+    calls = [ln.split() for ln in lines if ln[0].isdigit()]
+    for b in range(2):
+        mine = [c for c in calls if c[0] == str(b)]
+        full = want[b].hypotheses[0]
+        assert [c[2] for c in mine] == (full if b == 0 else full[:2])
+        assert [int(c[1]) for c in mine] == list(range(len(mine)))
+        assert all(float(c[4]) <= 0 for c in mine)
+        assert [c[5] for c in mine] == (["0"] * (len(mine) - 1) + ["1"] if b == 0 else ["0", "0"])
+    hyps = [ln[1:].split() for ln in lines if ln.startswith("=")]
+    assert hyps == [want[0].hypotheses[0][:-1], want[1].hypotheses[0][:2]]
+    assert any(ln.startswith("rejected: The callback function is not compatible") for ln in lines)
+    assert "raised: from the callback" in lines
     # Translator::score_batch through the C++ surface == the Python surface
     src, tgt = GC.AREN_SOURCES[0], ["a", "t", "z", "m", "o", "n"]
     rc, out, err = _cppapi.run("score", model, len(src), *(src + tgt))
