@@ -125,10 +125,11 @@ def test_generation_callback(gpu, golden):
     t = get_lm("lm_small", "float32")
     prompts = [list(p) for p in g["prompts"][:4]]
     prompts[1] = prompts[1][:-2]  # ragged: the others carry a 2-token forced prefix
-    want, want_scores = t.generate_ids(prompts, max_length=12, min_length=12, return_scores=True)
+    want, want_scores = t.generate_ids(prompts, max_length=12, min_length=12, return_scores=True,
+                                       length_penalty=0)
     calls = []
     got, got_scores = t.generate_ids(prompts, max_length=12, min_length=12, return_scores=True,
-                                     callback=lambda r: calls.append(r) and False)
+                                     length_penalty=0, callback=lambda r: calls.append(r) and False)
     assert got == want and np.array_equal(got_scores, want_scores)
     for b in range(len(prompts)):
         mine = [c for c in calls if c.batch_id == b]

@@ -27,6 +27,42 @@ def test_library_exports_every_declared_symbol():
     assert L.ct2x_version() == 1
 
 
+def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
+    """The ctypes mirrors of the C ABI's structs (ctranslate2_amd/_lib.py, the Whisper options in
+    __init__.py) carry every field of the header at the header's offset: a C program prints
+    offsetof of every member, the ctypes classes must agree."""
+    import subprocess
+    import ctranslate2_amd as ct2
+    header = open(os.path.join(ROOT, "include", "ct2_mi355.h")).read()
+    structs = {"ct2x_translation_options": _lib.TranslationOptions, "ct2x_exec_stats": _lib.ExecStats,
+               "ct2x_whisper_options": ct2.WhisperOptions}
+    lines = []
+    for name, cls in structs.items():
+        body = re.search(r"struct %s\s*\{(.*?)\n\};" % name, header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.search(r"\(\*\s*(\w+)\)\s*\(", decl) or re.search(r"(\w+)\s*(\[\d+\])?$", decl)
+            fields.append(m.group(1))
+        assert fields == [f[0] for f in cls._fields_], (name, fields)
+        for f in fields:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(struct %s, %s));' % (name, f, name, f))
+        lines.append('printf("%s %%zu\\n", sizeof(struct %s));' % (name, name))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ct2_mi355.h"\n'
+                   'int main(void) {\n%s\nreturn 0; }\n' % "\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    got = dict(ln.split() for ln in subprocess.check_output([exe]).decode().splitlines())
+    for name, cls in structs.items():
+        assert int(got[name]) == C.sizeof(cls), name
+        for f, _t in cls._fields_:
+            assert int(got["%s.%s" % (name, f)]) == getattr(cls, f).offset, (name, f)
+
+
 def test_no_gpu_is_a_loud_error_not_a_fallback():
     import torch
     if torch.cuda.is_available():

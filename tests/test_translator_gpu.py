@@ -530,11 +530,12 @@ def test_decoding_callback(gpu):
     from."""
     t = get_translator(gpu, "aren-transliteration-i8")
     src = GC.AREN_SOURCES[:5]
-    want = t.translate_batch(src, beam_size=1, return_scores=True, return_end_token=True)
+    want = t.translate_batch(src, beam_size=1, return_scores=True, return_end_token=True,
+                             length_penalty=0)
     for kw in (dict(), dict(max_batch_size=2)):
         calls = []
         got = t.translate_batch(src, beam_size=1, return_scores=True, return_end_token=True,
-                                callback=lambda r: calls.append(r) and False, **kw)
+                                length_penalty=0, callback=lambda r: calls.append(r) and False, **kw)
         assert [g.hypotheses for g in got] == [w.hypotheses for w in want]
         for b in range(len(src)):
             mine = [c for c in calls if c.batch_id == b]
@@ -543,7 +544,9 @@ def test_decoding_callback(gpu):
             assert [c.token_id for c in mine] == want[b].hypotheses_ids[0]
             assert [c.is_last for c in mine] == [False] * (len(mine) - 1) + [True]
             assert all(c.hypothesis_id == 0 and c.logits is None for c in mine)
-            assert abs(sum(c.log_prob for c in mine) - want[b].scores[0]) < 1e-4
+            # (a sub-batch of max_batch_size is padded to its own longest source: its scores
+            # differ from the whole batch's in the last digits, here as in the reference)
+            assert abs(sum(c.log_prob for c in mine) - got[b].scores[0]) < 1e-5
     # without return_scores there is no log_prob; a target prefix is reported (return_prefix)
     calls = []
     pfx = t.translate_batch(src[:2], target_prefix=[["a"], []], beam_size=1,
