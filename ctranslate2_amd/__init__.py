@@ -34,11 +34,11 @@ class GenerationStepResult:
     """ctranslate2.GenerationStepResult (python/cpp/generation_result.cc:11-42): what the
     `callback` of translate_batch / generate_ids receives for every generated token."""
 
-    def __init__(self, step, batch_id, token_id, token, log_prob, is_last):
+    def __init__(self, step, batch_id, token_id, token, log_prob, is_last, hypothesis_id=0):
         self.step = step
         self.batch_id = batch_id
         self.token_id = token_id
-        self.hypothesis_id = 0
+        self.hypothesis_id = hypothesis_id
         self.token = token
         self.log_prob = log_prob
         self.logits = None
@@ -233,13 +233,14 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         if callback is None:
             return holder
 
-        def trampoline(_user, step, batch_id, token_id, has_score, score, is_last):
+        def trampoline(_user, step, batch_id, hypothesis_id, token_id, has_score, score, is_last):
             if holder.error is not None:
                 return 1
             try:
                 r = GenerationStepResult(int(step), int(batch_id), int(token_id),
                                          self.id_to_token(int(token_id)),
-                                         float(score) if has_score else None, bool(is_last))
+                                         float(score) if has_score else None, bool(is_last),
+                                         int(hypothesis_id))
                 return 1 if callback(r) else 0
             except BaseException as e:  # noqa: BLE001 - must not unwind through the C frames
                 holder.error = e
@@ -438,8 +439,11 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                      length_penalty: float = 1.0, repetition_penalty: float = 1.0,
                      no_repeat_ngram_size: int = 0,
                      suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None,
-                     end_token_id: Optional[int] = None, callback=None):
+                     end_token_id: Optional[int] = None, callback=None, num_hypotheses: int = 1,
+                     patience: float = 1.0):
         """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False.
+        num_hypotheses > 1 (the best of a beam search, or that many random samples per prompt,
+        ordered by score): the results become [batch][hypothesis][tokens] and scores [batch, hyp].
         sampling_topk=1 is greedy; k >= 2 samples among the best k, 0 from the whole vocabulary (sampling_topp / temperature as
         in the reference). Returns (generated ids per prompt, scores)."""
         batch = len(prompts)
@@ -448,11 +452,12 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         ids = np.zeros((batch, stride), np.int32)
         for i, p in enumerate(prompts):
             ids[i, :len(p)] = p
-        out = np.zeros((batch, max_length), np.int32)
-        out_len = np.zeros((batch,), np.int32)
-        scores = np.zeros((batch,), np.float32)
-        opt = self._options(beam_size, max_length, min_length, 1, return_scores, return_end_token,
-                            0, 0, length_penalty, 1.0, use_graph, 1, sampling_topk, sampling_topp,
+        nh = int(num_hypotheses)
+        out = np.zeros((batch, nh, max_length), np.int32)
+        out_len = np.zeros((batch, nh), np.int32)
+        scores = np.zeros((batch, nh), np.float32)
+        opt = self._options(beam_size, max_length, min_length, nh, return_scores, return_end_token,
+                            0, 0, length_penalty, patience, use_graph, 1, sampling_topk, sampling_topp,
                             sampling_temperature, seed)
         _keep = self._set_processors(opt, repetition_penalty, no_repeat_ngram_size,
                                      suppress_sequences_ids)
@@ -463,7 +468,10 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
             C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
         if cb.error is not None:
             raise cb.error
-        return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
+        if nh == 1:
+            return [out[b, 0, :out_len[b, 0]].tolist() for b in range(batch)], scores[:, 0]
+        return ([[out[b, k, :out_len[b, k]].tolist() for k in range(nh) if out_len[b, k] > 0 or k == 0]
+                 for b in range(batch)], scores)
 
     @staticmethod
     def _pack_ids(seqs):

@@ -18,10 +18,10 @@ class Ct2xError(RuntimeError):
     pass
 
 
-# int (*step_callback)(void* user, int64 step, int64 batch_id, int32 token_id, int32 has_score,
-#                       float score, int32 is_last)
-STEP_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
-                            C.c_float, C.c_int32)
+# int (*step_callback)(void* user, int64 step, int64 batch_id, int64 hypothesis_id, int32 token_id,
+#                       int32 has_score, float score, int32 is_last)
+STEP_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                            C.c_int32, C.c_float, C.c_int32)
 
 
 class TranslationOptions(C.Structure):

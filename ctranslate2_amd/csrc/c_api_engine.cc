@@ -185,7 +185,8 @@ DecodingOptions to_decoding_options(const ct2x_translation_options& o) {
     void* user = o.step_callback_data;
     d.sync_every = 1;  // a streaming consumer: hand tokens over step by step (<= 2 steps late)
     d.callback = [fn, user](const DecodingStepResult& r) {
-      return fn(user, r.step, r.batch_id, r.token_id, r.has_score ? 1 : 0, r.score, r.is_last ? 1 : 0) != 0;
+      return fn(user, r.step, r.batch_id, r.hypothesis_id, r.token_id, r.has_score ? 1 : 0, r.score,
+                r.is_last ? 1 : 0) != 0;
     };
   }
   LogitsProcessing& lp = d.logits_processing;
@@ -870,15 +871,21 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
         const size_t begin = groups[gi].begin, end = groups[gi].end;
         const int64_t B = static_cast<int64_t>(end - begin);
         const int64_t s_max = groups[gi].s_max;
-        std::vector<int32_t> ids(B * s_max, 0), lens(B);
-        for (int64_t i = 0; i < B; ++i) {
-          const auto& s = sources[order[begin + i]];
+        // Random sampling with num_hypotheses > 1 decodes every entry num_hypotheses times
+        // (greedy_search_samples; the reference repeats the encoded state, repeat_batch
+        // src/decoding.cc:753-757 - the encoder is row-wise, so encoding the repeated rows gives
+        // the same memory)
+        const int64_t samples = (dopt.beam_size == 1 && !(dopt.prefix_bias_beta > 0)) ? dopt.num_hypotheses : 1;
+        const int64_t R = B * samples;
+        std::vector<int32_t> ids(R * s_max, 0), lens(R);
+        for (int64_t i = 0; i < R; ++i) {
+          const auto& s = sources[order[begin + i / samples]];
           std::copy(s.begin(), s.end(), ids.begin() + i * s_max);
           lens[i] = static_cast<int32_t>(s.size());
         }
         const double te0 = now_ms();
         const bool biased = dopt.prefix_bias_beta > 0 && prefix_ids != nullptr;
-        auto st = t->engine->start(ids.data(), lens.data(), B, s_max, dopt.beam_size,
+        auto st = t->engine->start(ids.data(), lens.data(), R, s_max, dopt.beam_size,
                                    dopt.max_length, 0, /*beam_search_state=*/biased);
         t->engine->synchronize();
         const double te1 = now_ms();
@@ -912,7 +919,7 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
         // make_search_strategy (src/decoding.cc:1075-1087): biased decoding is a beam search
         std::vector<DecodingResult> results =
             (dopt.beam_size == 1 && !(dopt.prefix_bias_beta > 0 && pf))
-                ? greedy_search(*t->engine, *st, start_ids, end_id, gopt, &ds, pf)
+                ? greedy_search_samples(*t->engine, *st, start_ids, end_id, gopt, &ds, pf)
                 : beam_search(*t->engine, *st, start_ids, end_id, gopt, &ds, pf);
         t->engine->synchronize();
         const double te2 = now_ms();
@@ -1038,16 +1045,20 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   const int64_t t_max = static_cast<int64_t>(forward_length) + longest_prefix + dopt.max_length + 1;
   // Beam search: every hypothesis row starts from the same prefilled prompt state; the prompt is
   // forwarded once per row (beam x the prefill work instead of a cache replication pass).
-  auto st = t->engine->start_decoder_only(batch, beam, t_max, forward_length);
-  const int64_t rows = static_cast<int64_t>(batch) * beam;
+  // Random sampling with num_hypotheses > 1 (greedy_search_samples): num_hypotheses rows per prompt.
+  const int32_t nh = dopt.num_hypotheses;
+  const int32_t mult = beam > 1 ? beam : nh;  // rows per prompt
+  auto st = beam > 1 ? t->engine->start_decoder_only(batch, beam, t_max, forward_length)
+                     : t->engine->start_decoder_only(static_cast<int64_t>(batch) * nh, 1, t_max, forward_length);
+  const int64_t rows = static_cast<int64_t>(batch) * mult;
   std::vector<int32_t> prefill_ids(static_cast<size_t>(rows) * std::max(forward_length, 1));
   std::vector<int32_t> start_ids(batch);
   std::vector<std::vector<int32_t>> prefix(batch);
   for (int32_t b = 0; b < batch; ++b) {
     const int32_t* row = prompt_ids + static_cast<int64_t>(b) * stride;
-    for (int32_t k = 0; k < beam; ++k)
+    for (int32_t k = 0; k < mult; ++k)
       for (int32_t i = 0; i < forward_length; ++i)
-        prefill_ids[(static_cast<size_t>(b) * beam + k) * forward_length + i] = row[i];
+        prefill_ids[(static_cast<size_t>(b) * mult + k) * forward_length + i] = row[i];
     start_ids[b] = row[forward_length];
     prefix[b].assign(row + forward_length + 1, row + prompt_lengths[b]);
   }
@@ -1061,23 +1072,27 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   std::vector<DecodingResult> results =
       beam > 1 ? beam_search(*t->engine, *st, start_ids, end_id, dopt, &ds,
                              longest_prefix > 0 ? &prefix : nullptr)
-               : greedy_search(*t->engine, *st, start_ids, end_id, dopt, &ds,
-                               longest_prefix > 0 ? &prefix : nullptr);
+               : greedy_search_samples(*t->engine, *st, start_ids, end_id, dopt, &ds,
+                                       longest_prefix > 0 ? &prefix : nullptr);
   t->engine->synchronize();
   const double te2 = now_ms();
   const int32_t max_len = opt.max_decoding_length;
-  for (int32_t b = 0; b < batch; ++b) {
-    auto& hyp = results[b].hypotheses[0];
-    if (!opt.return_end_token)
-      while (!hyp.empty() && hyp.back() == end_id) hyp.pop_back();
-    const int32_t len = static_cast<int32_t>(hyp.size());
-    std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
-              out_ids + static_cast<int64_t>(b) * max_len);
-    out_lengths[b] = len;
-    if (opt.return_scores && out_scores && !results[b].scores.empty())
-      out_scores[b] = results[b].scores[0];
-    t->last.num_tokens += len;
-  }
+  // outputs [batch, num_hypotheses, max_decoding_length] / [batch, num_hypotheses], as ct2x_translate_batch
+  for (int32_t b = 0; b < batch; ++b)
+    for (int32_t k = 0; k < nh; ++k) {
+      out_lengths[b * nh + k] = 0;
+      if (k >= static_cast<int32_t>(results[b].hypotheses.size())) continue;
+      auto& hyp = results[b].hypotheses[k];
+      if (!opt.return_end_token)
+        while (!hyp.empty() && hyp.back() == end_id) hyp.pop_back();
+      const int32_t len = static_cast<int32_t>(hyp.size());
+      std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
+                out_ids + (static_cast<int64_t>(b) * nh + k) * max_len);
+      out_lengths[b * nh + k] = len;
+      if (opt.return_scores && out_scores && k < static_cast<int32_t>(results[b].scores.size()))
+        out_scores[b * nh + k] = results[b].scores[k];
+      if (k == 0) t->last.num_tokens += len;
+    }
   t->last.num_examples = batch;
   t->last_compactions += ds.compactions;
   t->last.decode_steps = ds.steps;

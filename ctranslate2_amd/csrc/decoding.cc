@@ -16,7 +16,8 @@ void validate_decoding_options(const DecodingOptions& o) {
   if (o.patience <= 0) throw std::invalid_argument("The patience factor must be > 0");
   if (o.num_hypotheses <= 0) throw std::invalid_argument("The number of hypotheses must be > 0");
   const int64_t max_candidates = std::llround(float(o.beam_size) * o.patience);
-  if (o.num_hypotheses > max_candidates && !o.return_alternatives)
+  if (o.num_hypotheses > max_candidates && !o.return_alternatives &&
+      !(o.beam_size == 1 && o.sampling_topk != 1))
     throw std::invalid_argument("The number of hypotheses cannot be greater than "
                                 "beam_size * patience");
   if (o.min_length > o.max_length)
@@ -273,6 +274,43 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
   engine.synchronize();  // drain a speculative group before the state is torn down
   st.fuse_greedy = false;
   if (stats) stats->steps = launched;
+  return results;
+}
+
+std::vector<DecodingResult> greedy_search_samples(Engine& engine, DecodeState& st,
+                                                  const std::vector<int32_t>& start_ids, int32_t end_id,
+                                                  const DecodingOptions& opt, DecodeStats* stats,
+                                                  const std::vector<std::vector<int32_t>>* prefix_ids) {
+  const int64_t nh = opt.num_hypotheses;
+  if (nh <= 1) return greedy_search(engine, st, start_ids, end_id, opt, stats, prefix_ids);
+  const size_t batch = start_ids.size();
+  std::vector<int32_t> rep_start;
+  std::vector<std::vector<int32_t>> rep_prefix;
+  for (size_t i = 0; i < batch; ++i)
+    for (int64_t k = 0; k < nh; ++k) {
+      rep_start.push_back(start_ids[i]);
+      if (prefix_ids) rep_prefix.push_back((*prefix_ids)[i]);
+    }
+  DecodingOptions inner = opt;
+  inner.num_hypotheses = 1;
+  inner.return_scores = true;  // the samples are ordered by score (:789)
+  if (opt.callback)
+    inner.callback = [&opt, nh](const DecodingStepResult& r) {  // (:766-771)
+      DecodingStepResult m = r;
+      m.hypothesis_id = r.batch_id % nh;
+      m.batch_id = r.batch_id / nh;
+      return opt.callback(m);
+    };
+  std::vector<DecodingResult> rows =
+      greedy_search(engine, st, rep_start, end_id, inner, stats, prefix_ids ? &rep_prefix : nullptr);
+  std::vector<DecodingResult> results(batch);
+  for (size_t r = 0; r < rows.size(); ++r) {
+    DecodingResult& out = results[r / static_cast<size_t>(nh)];
+    out.hypotheses.emplace_back(std::move(rows[r].hypotheses[0]));
+    out.scores.push_back(rows[r].scores[0]);
+    if (opt.return_attention) out.attention.emplace_back(std::move(rows[r].attention[0]));
+  }
+  for (auto& r : results) sort_and_trim(r, static_cast<size_t>(nh), opt.return_scores, opt.return_attention);
   return results;
 }
 

@@ -20,6 +20,7 @@ namespace ct2x {
 struct DecodingStepResult {
   int64_t step = 0;
   int64_t batch_id = 0;
+  int64_t hypothesis_id = 0;  // > 0 only for the samples of greedy_search_samples
   int32_t token_id = 0;
   bool has_score = false;
   float score = 0.f;
@@ -93,6 +94,15 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& state,
                                           const std::vector<int32_t>& start_ids, int32_t end_id,
                                           const DecodingOptions& options, DecodeStats* stats,
                                           const std::vector<std::vector<int32_t>>* prefix_ids = nullptr);
+
+// GreedySearch::search with num_hypotheses > 1 (src/decoding.cc:751-814): random sampling returns
+// several hypotheses by decoding every batch entry num_hypotheses times and sorting an entry's
+// samples by score. `state` holds start_ids.size() * num_hypotheses rows, entry-major (the
+// reference's repeat_batch); start_ids / prefix_ids have one entry per batch entry.
+std::vector<DecodingResult> greedy_search_samples(Engine& engine, DecodeState& state,
+                                                  const std::vector<int32_t>& start_ids, int32_t end_id,
+                                                  const DecodingOptions& options, DecodeStats* stats,
+                                                  const std::vector<std::vector<int32_t>>* prefix_ids = nullptr);
 
 std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& state,
                                         const std::vector<int32_t>& start_ids, int32_t end_id,

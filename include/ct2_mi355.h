@@ -548,15 +548,16 @@ struct ct2x_translation_options {
   /* TranslationOptions / GenerationOptions::callback (include/ctranslate2/translation.h:85,
    * generation.h:77; invoked by GreedySearch::search, src/decoding.cc:925-939): called for every
    * generated token of every batch entry, in step order per entry, with the step (counted from the
-   * first decoding step), the entry's index in the call's batch, the token id, its log-probability
+   * first decoding step), the entry's index in the call's batch, the hypothesis (0, or the sample's
+   * index when random sampling returns num_hypotheses > 1), the token id, its log-probability
    * when return_scores is set (has_score) and whether it is the entry's last token. A non-zero
    * return value ends that entry's decoding there. beam_size 1 only (the reference's rule and error
    * text). With a callback the host examines every step (instead of groups of 8) while the device
    * runs one step ahead, so a token reaches the callback at most two steps after it was sampled;
    * the calls come from the thread that made the translate / generate call (num_streams <= 1 is
    * forced). NULL = none. */
-  int (*step_callback)(void* user_data, int64_t step, int64_t batch_id, int32_t token_id,
-                       int32_t has_score, float score, int32_t is_last);
+  int (*step_callback)(void* user_data, int64_t step, int64_t batch_id, int64_t hypothesis_id,
+                       int32_t token_id, int32_t has_score, float score, int32_t is_last);
   void* step_callback_data;
 };
 
@@ -636,7 +637,11 @@ int ct2x_translate_batch_prefix(void* translator, const int32_t* src_ids,
                                 int32_t* out_lengths, float* out_scores);
 
 /* Generator::generate_batch for decoder-only models (src/generator.cc:8-24 ->
- * src/models/language_model.cc:150-282); prompts are consumed in one prefill call. */
+ * src/models/language_model.cc:150-282); prompts are consumed in one prefill call. Outputs as
+ * ct2x_translate_batch: out_ids [batch, num_hypotheses, max_decoding_length], out_lengths /
+ * out_scores [batch, num_hypotheses] (num_hypotheses > 1: the best hypotheses of a beam search, or
+ * - beam_size 1 with sampling_topk != 1 - that many samples per prompt ordered by score,
+ * GreedySearch::search src/decoding.cc:751-814; a length of 0 past the first: fewer finished). */
 int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
                         const int32_t* prompt_lengths, int32_t batch, int32_t stride,
                         const struct ct2x_translation_options* opt, int32_t* out_ids,

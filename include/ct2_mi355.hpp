@@ -146,7 +146,7 @@ struct GenerationOptions {
   size_t sampling_topk = 1;
   float sampling_topp = 1;
   float sampling_temperature = 1;
-  size_t num_hypotheses = 1;             // 1 only
+  size_t num_hypotheses = 1;
   bool return_scores = false;
   bool return_alternatives = false;      // not built: must stay false
   std::vector<std::string> static_prompt;
@@ -301,14 +301,15 @@ public:
   }
 
 private:
-  static int trampoline(void* user, int64_t step, int64_t batch_id, int32_t token_id,
-                        int32_t has_score, float score, int32_t is_last) {
+  static int trampoline(void* user, int64_t step, int64_t batch_id, int64_t hypothesis_id,
+                        int32_t token_id, int32_t has_score, float score, int32_t is_last) {
     auto* self = static_cast<StepCallback*>(user);
     if (self->error_) return 1;
     try {
       GenerationStepResult r;
       r.step = static_cast<size_t>(step) + self->step_offset_;
       r.batch_id = static_cast<size_t>(batch_id);
+      r.hypothesis_id = static_cast<size_t>(hypothesis_id);
       r.token_id = static_cast<size_t>(token_id);
       r.token = self->h_.to_token(1, token_id);
       if (has_score) r.score = score;
@@ -504,7 +505,6 @@ public:
   generate_batch(const std::vector<std::vector<std::string>>& start_tokens,
                  const GenerationOptions& options = GenerationOptions()) {
     detail::reject(options.return_alternatives, "return_alternatives");
-    detail::reject(options.num_hypotheses != 1, "num_hypotheses > 1 in generate_batch");
     const size_t batch = start_tokens.size();
     if (batch == 0) return {};
     // static_prompt + start_tokens is what the model consumes (language_model.cc:184-206)
@@ -526,7 +526,7 @@ public:
     o.sampling_topk = detail::sampling_topk_field(options.sampling_topk);
     o.sampling_topp = options.sampling_topp;
     o.sampling_temperature = options.sampling_temperature;
-    o.num_hypotheses = 1;
+    o.num_hypotheses = static_cast<int32_t>(options.num_hypotheses);
     o.return_scores = options.return_scores;
     o.max_input_length = 0;
     o.seed = options.seed;
@@ -538,9 +538,9 @@ public:
       o.end_token_plus_one = h_.known_id(1, options.end_token, "end_token") + 1;
 
     const detail::IdBatch in = detail::to_ids(h_, 1, prompts);
-    const size_t len = options.max_length;
-    std::vector<int32_t> out(batch * len, 0), out_len(batch, 0);
-    std::vector<float> scores(batch, 0.f);
+    const size_t len = options.max_length, hyp = options.num_hypotheses;
+    std::vector<int32_t> out(batch * hyp * len, 0), out_len(batch * hyp, 0);
+    std::vector<float> scores(batch * hyp, 0.f);
     // The C entry decodes with include_prompt_in_result = false: the first generated token of the
     // shortest prompt is step 0. With include_prompt_in_result the reference forces the start
     // tokens as a decoding prefix and reports them too (return_prefix, src/decoding.cc:925): they
@@ -570,23 +570,26 @@ public:
                                       out_len.data(), scores.data()));
     step_callback.rethrow();
     std::vector<GenerationResult> results(batch);
-    for (size_t b = 0; b < batch; ++b) {
-      std::vector<std::string> tokens;
-      std::vector<size_t> ids;
-      if (options.include_prompt_in_result) {
-        tokens = start_tokens[b];
-        for (int32_t t = static_cast<int32_t>(options.static_prompt.size()); t < in.lengths[b]; ++t)
-          ids.push_back(static_cast<size_t>(in.ids[b * in.stride + t]));
+    for (size_t b = 0; b < batch; ++b)
+      for (size_t k = 0; k < hyp; ++k) {
+        const int32_t n = out_len[b * hyp + k];
+        if (k > 0 && n == 0) continue;  // fewer finished hypotheses than requested
+        std::vector<std::string> tokens;
+        std::vector<size_t> ids;
+        if (options.include_prompt_in_result) {
+          tokens = start_tokens[b];
+          for (int32_t t = static_cast<int32_t>(options.static_prompt.size()); t < in.lengths[b]; ++t)
+            ids.push_back(static_cast<size_t>(in.ids[b * in.stride + t]));
+        }
+        for (int32_t t = 0; t < n; ++t) {
+          const int32_t id = out[(b * hyp + k) * len + t];
+          ids.push_back(static_cast<size_t>(id));
+          tokens.push_back(h_.to_token(1, id));
+        }
+        results[b].sequences.push_back(std::move(tokens));
+        results[b].sequences_ids.push_back(std::move(ids));
+        if (options.return_scores) results[b].scores.push_back(scores[b * hyp + k]);
       }
-      for (int32_t t = 0; t < out_len[b]; ++t) {
-        const int32_t id = out[b * len + t];
-        ids.push_back(static_cast<size_t>(id));
-        tokens.push_back(h_.to_token(1, id));
-      }
-      results[b].sequences.push_back(std::move(tokens));
-      results[b].sequences_ids.push_back(std::move(ids));
-      if (options.return_scores) results[b].scores.push_back(scores[b]);
-    }
     return results;
   }
 

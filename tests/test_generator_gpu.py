@@ -146,6 +146,31 @@ def test_generation_callback(gpu, golden):
         t.generate_ids(prompts, max_length=4, beam_size=2, callback=lambda r: False)
 
 
+def test_generate_several_hypotheses(gpu, golden):
+    """GenerationOptions::num_hypotheses: the n best hypotheses of a beam search (ordered by score,
+    the first one is what num_hypotheses = 1 returns) or, with random sampling, n samples per
+    prompt (src/decoding.cc:751-814) - the draws of rows b * n + k of a batch holding every prompt
+    n times."""
+    g = golden["lm_small_f32"]
+    t = get_lm("lm_small", "float32")
+    prompts = [list(p) for p in g["prompts"][:3]]
+    kw = dict(max_length=10, min_length=10, return_scores=True)
+    best, best_scores = t.generate_ids(prompts, beam_size=3, **kw)
+    hyps, scores = t.generate_ids(prompts, beam_size=3, num_hypotheses=3, **kw)
+    for b in range(len(prompts)):
+        assert len(hyps[b]) == 3 and hyps[b][0] == best[b]
+        assert scores[b, 0] == best_scores[b] and np.all(np.diff(scores[b]) <= 0)
+        assert len({tuple(h) for h in hyps[b]}) == 3
+    n = 2
+    skw = dict(kw, sampling_topk=5, sampling_temperature=1.3, seed=4)
+    hyps, scores = t.generate_ids(prompts, num_hypotheses=n, **skw)
+    flat, flat_scores = t.generate_ids([p for p in prompts for _ in range(n)], **skw)
+    for b in range(len(prompts)):
+        want = sorted(range(n), key=lambda k: -flat_scores[b * n + k])
+        assert [hyps[b][j] for j in range(n)] == [flat[b * n + k] for k in want]
+        np.testing.assert_array_equal(scores[b], [flat_scores[b * n + k] for k in want])
+
+
 def test_prefill_equals_stepwise(gpu, golden):
     """The sequence-mode prefill must leave the same caches as feeding the prompt token by token
     (tests/model_test.cc:99-151 DecoderIterativeSequence): the continuation after a prefilled

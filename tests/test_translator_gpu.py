@@ -356,6 +356,42 @@ def test_random_sampling(gpu):
         t.translate_ids(src, beam_size=2, sampling_topk=4)
 
 
+def test_random_sampling_returns_several_hypotheses(gpu):
+    """GreedySearch::search with num_hypotheses > 1 (src/decoding.cc:751-814): random sampling
+    decodes every entry num_hypotheses times (repeat_batch) and orders an entry's samples by
+    score. A row's draws are keyed by (seed, step, row): entry b's samples are what rows
+    b * n .. b * n + n - 1 of a batch holding every source n times draw. The callback tells the
+    samples apart by hypothesis_id; arg-max decoding keeps the reference's rule."""
+    t = get_translator(gpu, "small", "int8")
+    cfg = GC.SYNTHETIC["small"]
+    rng = np.random.default_rng(11)
+    src = [rng.integers(4, cfg["model"]["vocab_size"], 10).tolist() for _ in range(3)]
+    kw = dict(beam_size=1, max_decoding_length=8, min_decoding_length=8, return_scores=True,
+              sampling_topk=6, sampling_temperature=1.4, seed=21)
+    n = 3
+    calls = []
+    hyps, scores = t.translate_ids(src, num_hypotheses=n, callback=lambda r: calls.append(r) and False,
+                                   **kw)
+    flat, flat_scores = t.translate_ids([s for s in src for _ in range(n)], **kw)
+    for b in range(len(src)):
+        want = sorted(range(n), key=lambda k: -flat_scores[b * n + k, 0])
+        assert len(hyps[b]) == n
+        assert [hyps[b][j] for j in range(n)] == [flat[b * n + k][0] for k in want]
+        np.testing.assert_array_equal(scores[b], [flat_scores[b * n + k, 0] for k in want])
+        assert np.all(np.diff(scores[b]) <= 0)
+        for k in range(n):
+            mine = [c.token_id for c in calls if c.batch_id == b and c.hypothesis_id == k]
+            assert mine == flat[b * n + k][0]
+    assert len({tuple(h) for h in hyps[0]}) > 1  # the samples differ
+    again, _ = t.translate_ids(src, num_hypotheses=n, use_graph=False, **kw)
+    assert again == hyps
+    # without return_scores the samples are still ordered, the scores are dropped
+    plain, _ = t.translate_ids(src, num_hypotheses=n, **dict(kw, return_scores=False))
+    assert plain == hyps
+    with pytest.raises(Exception, match="cannot be greater than beam_size \\* patience"):
+        t.translate_ids(src, beam_size=1, num_hypotheses=2)
+
+
 def test_random_sampling_whole_vocabulary(gpu):
     """sampling_topk = 0 (the reference: no TopK restriction, src/sampling.cc:54-66): temperature
     -> TopPMask -> SoftMax -> Multinomial over the whole vocabulary. Checked: graph == eager for a
