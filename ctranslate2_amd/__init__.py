@@ -20,11 +20,14 @@ class TranslationResult:
     """ctranslate2.TranslationResult: hypotheses (token lists), scores and, with return_attention,
     one source attention vector per token of every hypothesis."""
 
-    def __init__(self, hypotheses, scores, hypotheses_ids, attention=None):
+    def __init__(self, hypotheses, scores, hypotheses_ids, attention=None, logits=None):
         self.hypotheses = hypotheses
         self.scores = scores
         self.hypotheses_ids = hypotheses_ids
         self.attention = attention if attention is not None else []
+        # return_logits_vocab: per hypothesis an array [steps, vocabulary] (the reference: a list
+        # of StorageView per hypothesis, python/cpp/translation_result.cc:19-20)
+        self.logits = logits if logits is not None else []
 
     def __repr__(self):
         return "TranslationResult(hypotheses=%r, scores=%r)" % (self.hypotheses, self.scores)
@@ -224,6 +227,16 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
             raise ValueError("%s token '%s' is not in the vocabulary" % (what, token))
         return idx
 
+    def _set_logits(self, opt, batch, hyps, steps):
+        """return_logits_vocab: the host buffers the C entry fills ([batch, hyps, steps, vocab] and
+        the per-hypothesis counts)."""
+        buf = np.zeros((batch, hyps, steps, self.vocab_size), np.float32)
+        counts = np.zeros((batch, hyps), np.int32)
+        opt.logits_out = buf.ctypes.data_as(C.POINTER(C.c_float))
+        opt.logits_counts_out = counts.ctypes.data_as(C.POINTER(C.c_int32))
+        opt.logits_steps = steps
+        return buf, counts
+
     def _set_callback(self, opt, callback):
         """TranslationOptions / GenerationOptions.callback (python/cpp/translator.cc:152-181): the
         Python callable is called with a GenerationStepResult per generated token; returning True
@@ -278,7 +291,7 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                       end_token_id: Optional[int] = None, return_alternatives: bool = False,
                       min_alternative_expansion_prob: float = 0.0, prefix_bias_beta: float = 0.0,
                       coverage_penalty: float = 0.0, return_attention: bool = False,
-                      callback=None):
+                      callback=None, return_logits_vocab: bool = False):
         """translate_batch on token ids. Returns (hypotheses ids [batch][hyp][tokens], scores), plus
         the attention ([batch][hyp] arrays [tokens, source length]) when return_attention is set.
         return_alternatives / min_alternative_expansion_prob / prefix_bias_beta / coverage_penalty /
@@ -289,7 +302,10 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         repetition_penalty / no_repeat_ngram_size as in the reference; suppress_sequences_ids:
         id sequences that must not be generated (a single id is disabled at every step).
         callback: called with a GenerationStepResult for every generated token (beam_size 1);
-        returning True stops that batch entry."""
+        returning True stops that batch entry.
+        return_logits_vocab (beam_size 1): one more result, [batch][hyp] arrays [steps, vocabulary]
+        of the logits every step sampled from (after the logits processors and the minimum-length
+        mask; one row per step the entry ran, the end token's step included)."""
         batch = len(source_ids)
         lengths = np.array([len(s) for s in source_ids], np.int32)
         stride = max(1, int(lengths.max()) if batch else 1)
@@ -311,6 +327,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         opt.prefix_bias_beta = float(prefix_bias_beta)
         opt.coverage_penalty = float(coverage_penalty)
         cb = self._set_callback(opt, callback)
+        if return_logits_vocab:
+            lbuf, lcnt = self._set_logits(opt, batch, num_hypotheses, max_decoding_length)
         att = None
         if return_attention:
             att = np.zeros((batch, num_hypotheses, max_decoding_length, stride), np.float32)
@@ -336,11 +354,14 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                  if (out_len[b, k] >= 0 if return_alternatives else (out_len[b, k] > 0 or k == 0))]
                 for b in range(batch)]
         hyps = [[out[b, k, :max(out_len[b, k], 0)].tolist() for k in keep[b]] for b in range(batch)]
+        extra = ()
+        if return_logits_vocab:
+            extra = ([[lbuf[b, k, :lcnt[b, k]].copy() for k in keep[b]] for b in range(batch)],)
         if return_attention:
             atts = [[att[b, k, :max(out_len[b, k], 0), :len(source_ids[b])].copy() for k in keep[b]]
                     for b in range(batch)]
-            return hyps, scores, atts
-        return hyps, scores
+            return (hyps, scores, atts) + extra
+        return (hyps, scores) + extra
 
     def translate_batch(self, source: List[List[str]], target_prefix: Optional[list] = None,
                         **kwargs) -> List[TranslationResult]:
@@ -368,11 +389,13 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         return_attention = bool(kwargs.get("return_attention", False))
         if replace_unknowns:
             kwargs["return_attention"] = True
-        atts = None
+        atts = logits = None
+        out = list(self.translate_ids(src_ids, **kwargs))
+        if kwargs.get("return_logits_vocab", False):
+            logits = out.pop()
         if kwargs.get("return_attention", False):
-            hyps, scores, atts = self.translate_ids(src_ids, **kwargs)
-        else:
-            hyps, scores = self.translate_ids(src_ids, **kwargs)
+            atts = out.pop()
+        hyps, scores = out
         results = []
         for b, sent_hyps in enumerate(hyps):
             tokens = [[self.id_to_token(i) for i in h] for h in sent_hyps]
@@ -386,7 +409,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                             hyp[t] = source[b][int(np.argmax(atts[b][k][t]))]
             sc = [float(scores[b, k]) for k in range(len(sent_hyps))] if return_scores else []
             att = [a.tolist() for a in atts[b]] if (atts is not None and return_attention) else None
-            results.append(TranslationResult(tokens, sc, sent_hyps, att))
+            results.append(TranslationResult(tokens, sc, sent_hyps, att,
+                                             logits[b] if logits is not None else None))
         return results
 
     def score_ids(self, source_ids: Sequence[Sequence[int]], target_ids: Sequence[Sequence[int]],
@@ -440,10 +464,13 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                      no_repeat_ngram_size: int = 0,
                      suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None,
                      end_token_id: Optional[int] = None, callback=None, num_hypotheses: int = 1,
-                     patience: float = 1.0):
+                     patience: float = 1.0, return_logits_vocab: bool = False):
         """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False.
         num_hypotheses > 1 (the best of a beam search, or that many random samples per prompt,
         ordered by score): the results become [batch][hypothesis][tokens] and scores [batch, hyp].
+        return_logits_vocab (beam_size 1): a third result, per prompt (and hypothesis) an array
+        [steps, vocabulary] of the logits every step sampled from - the forced steps of a longer
+        prompt included.
         sampling_topk=1 is greedy; k >= 2 samples among the best k, 0 from the whole vocabulary (sampling_topp / temperature as
         in the reference). Returns (generated ids per prompt, scores)."""
         batch = len(prompts)
@@ -463,15 +490,24 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                                      suppress_sequences_ids)
         opt.end_token_plus_one = 0 if end_token_id is None else int(end_token_id) + 1
         cb = self._set_callback(opt, callback)
+        if return_logits_vocab:
+            lbuf, lcnt = self._set_logits(opt, batch, nh,
+                                          max_length + int(lengths.max() - lengths.min()))
         _lib.check(self._L.ct2x_generate_batch(
             C.c_void_p(self._h), _lib.ptr(ids), _lib.ptr(lengths), C.c_int32(batch),
             C.c_int32(stride), C.byref(opt), _lib.ptr(out), _lib.ptr(out_len), _lib.ptr(scores)))
         if cb.error is not None:
             raise cb.error
+        extra = ()
         if nh == 1:
-            return [out[b, 0, :out_len[b, 0]].tolist() for b in range(batch)], scores[:, 0]
-        return ([[out[b, k, :out_len[b, k]].tolist() for k in range(nh) if out_len[b, k] > 0 or k == 0]
-                 for b in range(batch)], scores)
+            if return_logits_vocab:
+                extra = ([lbuf[b, 0, :lcnt[b, 0]].copy() for b in range(batch)],)
+            return ([out[b, 0, :out_len[b, 0]].tolist() for b in range(batch)], scores[:, 0]) + extra
+        kept = [[k for k in range(nh) if out_len[b, k] > 0 or k == 0] for b in range(batch)]
+        if return_logits_vocab:
+            extra = ([[lbuf[b, k, :lcnt[b, k]].copy() for k in kept[b]] for b in range(batch)],)
+        return ([[out[b, k, :out_len[b, k]].tolist() for k in kept[b]] for b in range(batch)],
+                scores) + extra
 
     @staticmethod
     def _pack_ids(seqs):

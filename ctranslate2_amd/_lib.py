@@ -58,6 +58,10 @@ class TranslationOptions(C.Structure):
         ("attention_out", C.POINTER(C.c_float)),
         ("step_callback", STEP_CALLBACK),
         ("step_callback_data", C.c_void_p),
+        ("logits_out", C.POINTER(C.c_float)),
+        ("logits_counts_out", C.POINTER(C.c_int32)),
+        ("logits_steps", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
 

@@ -178,6 +178,7 @@ DecodingOptions to_decoding_options(const ct2x_translation_options& o) {
   d.min_alternative_expansion_prob = o.min_alternative_expansion_prob;
   d.coverage_penalty = o.coverage_penalty;
   d.return_attention = o.attention_out != nullptr;
+  d.return_logits_vocab = o.logits_out != nullptr;
   if (o.step_callback != nullptr) {
     // (the callers below wrap it once more to restore the batch ids of their sub-batches,
     // restore_batch_ids_in_callback, include/ctranslate2/generation.h:120-131)
@@ -591,6 +592,18 @@ int ct2x_translator_create_tp_local(const char* model_dir, int device_index,
 void ct2x_translator_destroy(void* translator) { delete static_cast<Translator*>(translator); }
 
 // decode_alternatives (src/decoding.cc:1122-1290) for a batch of sentences: the target prefix is
+// (return_logits_vocab) hypothesis k of a result -> slot `slot` of the caller's buffer
+static void write_logits(const ct2x_translation_options& opt, const DecodingResult& r, int64_t slot,
+                         int32_t k, int64_t vocab) {
+  opt.logits_counts_out[slot] = 0;
+  if (k >= static_cast<int32_t>(r.logits_vocab.size())) return;
+  const auto& steps = r.logits_vocab[k];
+  const int64_t n = std::min<int64_t>(static_cast<int64_t>(steps.size()), opt.logits_steps);
+  float* dst = opt.logits_out + slot * opt.logits_steps * vocab;
+  for (int64_t s = 0; s < n; ++s) std::copy(steps[s].begin(), steps[s].end(), dst + s * vocab);
+  opt.logits_counts_out[slot] = static_cast<int32_t>(n);
+}
+
 // consumed by ONE sequence-mode pass of the decoder, the num_hypotheses best next tokens are
 // expanded by a one-step beam search, and every (sentence, alternative) pair is then continued
 // independently with the requested search. The reference runs this sentence by sentence; here
@@ -791,7 +804,13 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
   std::vector<DecodingResult> all_results(batch);
   double encode_ms = 0, decode_ms = 0;
   for (int32_t b = 0; b < batch; ++b)
-    for (int32_t k = 0; k < nh; ++k) out_lengths[b * nh + k] = 0;
+    for (int32_t k = 0; k < nh; ++k) {
+      out_lengths[b * nh + k] = 0;
+      if (opt.logits_out && opt.logits_counts_out) opt.logits_counts_out[b * nh + k] = 0;
+    }
+  if (opt.logits_out)
+    CT2X_CHECK(opt.logits_counts_out != nullptr && opt.logits_steps > 0,
+               "return_logits_vocab: logits_counts_out and logits_steps are required");
   if (opt.return_alternatives) {
     CT2X_CHECK(opt.prefix_bias_beta <= 0.f, "Biased decoding is not compatible with the "
                "return_alternatives mode");
@@ -979,6 +998,7 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
             row[j - first] = att[s_][j];
         }
       }
+      if (opt.logits_out) write_logits(opt, r, (static_cast<int64_t>(b) * nh + k), k, t->engine->vocab_size());
       if (k == 0) t->last.num_tokens += len;  // ExecutionStats: hypothesis 0 tokens
     }
   }
@@ -1091,6 +1111,11 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
       out_lengths[b * nh + k] = len;
       if (opt.return_scores && out_scores && k < static_cast<int32_t>(results[b].scores.size()))
         out_scores[b * nh + k] = results[b].scores[k];
+      if (opt.logits_out) {
+        CT2X_CHECK(opt.logits_counts_out != nullptr && opt.logits_steps > 0,
+                   "return_logits_vocab: logits_counts_out and logits_steps are required");
+        write_logits(opt, results[b], (static_cast<int64_t>(b) * nh + k), k, t->engine->vocab_size());
+      }
       if (k == 0) t->last.num_tokens += len;
     }
   t->last.num_examples = batch;

@@ -6,6 +6,7 @@
 #include "kernels.h"
 #include "runtime.h"
 
+#include <algorithm>
 #include <float.h>
 #include <limits.h>
 
@@ -223,6 +224,37 @@ void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int3
   hipLaunchKernelGGL(greedy_sample_kernel, dim3(rows), dim3(block), lds, stream, logits, vocab,
                      disable_id, min_length, with_scores, exp_scratch, el.chain_pad, pf, adv, step_ptr,
                      next_ids, hist_ids, hist_scores);
+}
+
+// return_logits_vocab (src/decoding.cc:868-872, 905-908): the logits a greedy step samples from -
+// after the logits processors and DisableTokens::apply (the end token below the minimum length is
+// lowest(), src/decoding.cc:384-408) - kept per step in a ring [ring][rows][out_vocab] indexed by
+// the device step counter. The samplers apply the same mask on the fly and never write it back.
+__global__ void record_logits_kernel(const float* __restrict__ logits, int64_t vocab,
+                                     int64_t out_vocab, int32_t disable_id, int32_t min_length,
+                                     const int32_t* __restrict__ prefix_lens, int extends_min,
+                                     const int32_t* __restrict__ step_ptr, int32_t ring,
+                                     float* __restrict__ hist) {
+  const int64_t row = blockIdx.x, rows = gridDim.x;
+  const int step = *step_ptr;
+  const int row_min = min_length + ((prefix_lens && extends_min) ? prefix_lens[row] : 0);
+  const int masked = (step < row_min) ? disable_id : -1;
+  const float* x = logits + row * vocab;
+  float* y = hist + (static_cast<int64_t>(step % ring) * rows + row) * out_vocab;
+  for (int64_t j = static_cast<int64_t>(blockIdx.y) * blockDim.x + threadIdx.x; j < out_vocab;
+       j += static_cast<int64_t>(gridDim.y) * blockDim.x)
+    y[j] = (j == masked) ? -FLT_MAX : x[j];
+}
+
+void launch_record_logits(const float* logits, int64_t rows, int64_t vocab, int64_t out_vocab,
+                          int32_t disable_id, int32_t min_length, const int32_t* prefix_lens,
+                          bool prefix_extends_min, const int32_t* step_ptr, int32_t ring, float* hist,
+                          hipStream_t stream) {
+  if (rows == 0) return;
+  const unsigned chunks = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(64, out_vocab / 1024)));
+  hipLaunchKernelGGL(record_logits_kernel, dim3(static_cast<unsigned>(rows), chunks), dim3(256), 0,
+                     stream, logits, vocab, out_vocab, disable_id, min_length, prefix_lens,
+                     prefix_extends_min ? 1 : 0, step_ptr, ring, hist);
 }
 
 // ---------------------------------------------------------------------------------------------

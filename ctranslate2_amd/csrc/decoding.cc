@@ -47,6 +47,9 @@ void validate_decoding_options(const DecodingOptions& o) {
   if (o.prefix_bias_beta > 0 && o.sampling_topk != 1)
     throw std::invalid_argument("Biased decoding runs a beam search: random sampling is not available with it");
   // (src/decoding.cc:1052-1054)
+  if (o.return_logits_vocab && (o.beam_size != 1 || o.prefix_bias_beta > 0 || o.return_alternatives))
+    throw std::invalid_argument("return_logits_vocab is built for greedy search and random sampling "
+                                "(beam_size 1) in this backend");
   if (o.callback && (o.beam_size != 1 || o.prefix_bias_beta > 0))
     throw std::invalid_argument("The callback function is not compatible with "
                                 "beam_size > 1 or prefix_bias_beta > 0");
@@ -70,6 +73,7 @@ void sort_and_trim(DecodingResult& r, size_t max_hypotheses, bool keep_scores, b
     out.hypotheses.emplace_back(std::move(r.hypotheses[i]));
     if (keep_scores) out.scores.push_back(r.scores[i]);
     if (keep_attention && i < r.attention.size()) out.attention.emplace_back(std::move(r.attention[i]));
+    if (i < r.logits_vocab.size()) out.logits_vocab.emplace_back(std::move(r.logits_vocab[i]));
   }
   r = std::move(out);
 }
@@ -130,6 +134,12 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
   if (gather_attention) {
     engine.enable_attention(st);
     for (auto& r : results) r.attention.resize(1);
+  }
+  std::vector<float> logit_steps;
+  const int64_t V = engine.vocab_size();
+  if (opt.return_logits_vocab) {
+    engine.enable_logits_history(st);
+    for (auto& r : results) r.logits_vocab.resize(1);
   }
 
   engine.set_ids(st, start_ids.data());
@@ -194,7 +204,8 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
   const int64_t compact_min_rows = compact_min_rows_setting();
   // (random sampling draws from a hash of (seed, step, ROW): renumbering the rows would change the
   // sample a seed produces - those sessions keep their rows)
-  const bool may_compact = !gather_attention && compact_min_rows > 0 && opt.sampling_topk == 1 &&
+  const bool may_compact = !gather_attention && !opt.return_logits_vocab && compact_min_rows > 0 &&
+                           opt.sampling_topk == 1 &&
                            engine.compactable(st);
   std::vector<int64_t> origin(batch);  // session row -> index into results / alive / prefix_len
   for (int64_t i = 0; i < batch; ++i) origin[i] = i;
@@ -228,11 +239,19 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
       att_steps.resize(static_cast<size_t>(g.count) * batch * st.s_max);
       engine.read_attention(st, opt.start_step + g.first, g.count, att_steps.data());
     }
+    if (opt.return_logits_vocab) {
+      logit_steps.resize(static_cast<size_t>(g.count) * batch * V);
+      engine.read_logits(st, opt.start_step + g.first, g.count, logit_steps.data());
+    }
     for (int64_t s = 0; s < g.count && count_alive > 0; ++s) {
       const int64_t step = g.first + s;
       for (int64_t row = 0; row < rows_now; ++row) {
         const int64_t i = origin[row];
         if (!alive[i]) continue;
+        if (opt.return_logits_vocab) {  // every step of a live row, whatever becomes of its token
+          const float* lg = logit_steps.data() + (static_cast<size_t>(s) * rows_now + row) * V;
+          results[i].logits_vocab[0].emplace_back(lg, lg + V);
+        }
         // is_last_step (src/decoding.cc:376-382): max_length steps after the row's own prefix
         const bool last = (step + 1 == opt.max_length + extra * prefix_len[i]);
         const int32_t word = h_ids[s * rows_now + row];
@@ -309,6 +328,7 @@ std::vector<DecodingResult> greedy_search_samples(Engine& engine, DecodeState& s
     out.hypotheses.emplace_back(std::move(rows[r].hypotheses[0]));
     out.scores.push_back(rows[r].scores[0]);
     if (opt.return_attention) out.attention.emplace_back(std::move(rows[r].attention[0]));
+    if (opt.return_logits_vocab) out.logits_vocab.emplace_back(std::move(rows[r].logits_vocab[0]));
   }
   for (auto& r : results) sort_and_trim(r, static_cast<size_t>(nh), opt.return_scores, opt.return_attention);
   return results;

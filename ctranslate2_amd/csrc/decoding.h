@@ -63,6 +63,9 @@ struct DecodingOptions {
   // record, per step and row, the attention vector of the alignment heads over the source.
   bool return_attention = false;
   float coverage_penalty = 0.f;
+  // return_logits_vocab (src/decoding.cc:868-872, 905-908), greedy search / random sampling: the
+  // logits every step of an entry sampled from (after the logits processors and DisableTokens)
+  bool return_logits_vocab = false;
   // Whisper's logits processors (DecodingOptions::logits_processors + disable_ids_begin of
   // WhisperReplica::generate, src/models/whisper.cc:312-343); nullptr = none
   const WhisperProcessing* whisper = nullptr;
@@ -77,6 +80,9 @@ struct DecodingResult {
   std::vector<float> scores;
   // return_attention: attention[h][t] = the source attention vector of token t of hypothesis h
   std::vector<std::vector<std::vector<float>>> attention;
+  // return_logits_vocab: logits_vocab[h][s] = the vocabulary logits of step s of hypothesis h
+  // (one entry per step the row ran - forced prefix steps and the end token's step included)
+  std::vector<std::vector<std::vector<float>>> logits_vocab;
 };
 
 struct DecodeStats {

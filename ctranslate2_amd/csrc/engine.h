@@ -309,6 +309,14 @@ public:
   // steps [first, first + count) to the host: out [count][rows][s_max].
   void enable_attention(DecodeState& state);
   void read_attention(DecodeState& state, int64_t first, int64_t count, float* out);
+  // return_logits_vocab (greedy search / random sampling): every step keeps the logits it samples
+  // from (after the logits processors and the minimum-length mask) in a ring of kLogitsRing steps;
+  // read_logits copies steps [first, first + count) to the host: out [count][rows][vocab_size()].
+  // The host must not fall more than kLogitsRing steps behind the device (the greedy loop keeps at
+  // most two groups of sync_every steps in flight).
+  static constexpr int32_t kLogitsRing = 32;
+  void enable_logits_history(DecodeState& state);
+  void read_logits(DecodeState& state, int64_t first, int64_t count, float* out);
   void synchronize();
   // Teacher-forced scoring (score_sequences, src/scoring.cc): runs `steps` decoder steps feeding
   // h_inputs[s][row] and leaves log P(h_outputs[s][row]) of every step in the score history
@@ -558,6 +566,7 @@ struct DecodeState {
   int32_t* d_bprefix_len = nullptr;  // [batch]
   int32_t bprefix_stride = 0;
   float* att_hist = nullptr;         // return_attention: [t_max + 1][rows][s_max] (enable_attention)
+  float* logit_hist = nullptr;       // return_logits_vocab: [kLogitsRing][rows][vocab] (enable_logits_history)
   bool beam_mode = false;            // the state holds the beam search's buffers (beam > 1, or forced)
   float bias_beta = 0.f;             // biased decoding (DecodingOptions::prefix_bias_beta)
   uint8_t* d_diverged = nullptr;     // [rows] beams that left their prefix

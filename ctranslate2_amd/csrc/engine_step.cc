@@ -356,6 +356,13 @@ void Engine::launch_step(DecodeState& st) {
       launch_whisper_rules(wp, cur_stream());
       end_kernel();
     }
+    if (st.logit_hist) {
+      begin_kernel("record_logits");
+      launch_record_logits(st.logits, st.rows, dec_.projection.n, vocab_size(), st.g_eos,
+                           st.g_min_length, st.d_prefix ? st.d_prefix_len : nullptr,
+                           st.prefix_extends_min, st.d_step, kLogitsRing, st.logit_hist, cur_stream());
+      end_kernel();
+    }
     if (st.g_topk == 1) {
       begin_kernel("greedy_sample");
       launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
@@ -669,7 +676,8 @@ void Engine::set_ids(DecodeState& st, const int32_t* h_ids) {
 
 bool Engine::compactable(const DecodeState& st) const {
   return !tp_ && !taps_ && !profiling_ && st.beam == 1 && !st.beam_mode && !st.ancestry &&
-         st.att_hist == nullptr && !st.wh_active && st.wh_no_speech_id < 0 && st.rows > 1;
+         st.att_hist == nullptr && st.logit_hist == nullptr && !st.wh_active &&
+         st.wh_no_speech_id < 0 && st.rows > 1;
 }
 
 void Engine::compact_rows(DecodeState& st, const std::vector<int32_t>& keep, int64_t steps_done) {
@@ -911,6 +919,30 @@ void Engine::read_attention(DecodeState& st, int64_t first, int64_t count, float
   const size_t per_step = static_cast<size_t>(st.rows) * st.s_max;
   CT2X_HIP_CHECK(hipMemcpyAsync(out, st.att_hist + first * per_step, sizeof(float) * count * per_step,
                                 hipMemcpyDeviceToHost, cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
+}
+
+void Engine::enable_logits_history(DecodeState& st) {
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  if (st.logit_hist) return;
+  const size_t n = static_cast<size_t>(kLogitsRing) * st.rows * vocab_size();
+  st.logit_hist = static_cast<float*>(device_malloc(n * sizeof(float)));
+  st.owned.push_back(st.logit_hist);
+  st.graph_ready[0] = st.graph_ready[1] = false;  // (called before the first step: nothing captured yet)
+}
+
+void Engine::read_logits(DecodeState& st, int64_t first, int64_t count, float* out) {
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_CHECK(st.logit_hist != nullptr && first >= 0 && count <= kLogitsRing,
+             "read_logits: no logits history for these steps");
+  const size_t per_step = static_cast<size_t>(st.rows) * vocab_size();
+  for (int64_t s = 0; s < count; ++s)
+    CT2X_HIP_CHECK(hipMemcpyAsync(out + s * per_step,
+                                  st.logit_hist + ((first + s) % kLogitsRing) * per_step,
+                                  sizeof(float) * per_step, hipMemcpyDeviceToHost, cur_stream()));
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
 }
 

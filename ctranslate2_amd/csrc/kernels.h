@@ -398,6 +398,13 @@ void launch_greedy_sample(const float* logits, int64_t rows, int64_t vocab, int3
                           int32_t* advance_step_ptr = nullptr, int32_t* done_counter = nullptr,
                           float* exp_scratch = nullptr /* [rows, vocab], needed with_scores */);
 
+// return_logits_vocab: hist[*step_ptr % ring][row][0 .. out_vocab) = the row's logits with the
+// end token masked (lowest()) below the row's minimum length (what the samplers mask on the fly)
+void launch_record_logits(const float* logits, int64_t rows, int64_t vocab, int64_t out_vocab,
+                          int32_t disable_id, int32_t min_length, const int32_t* prefix_lens,
+                          bool prefix_extends_min, const int32_t* step_ptr, int32_t ring, float* hist,
+                          hipStream_t stream);
+
 // *step_ptr += 1
 void launch_advance_step(int32_t* step_ptr, hipStream_t stream);
 

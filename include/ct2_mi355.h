@@ -559,6 +559,18 @@ struct ct2x_translation_options {
   int (*step_callback)(void* user_data, int64_t step, int64_t batch_id, int64_t hypothesis_id,
                        int32_t token_id, int32_t has_score, float score, int32_t is_last);
   void* step_callback_data;
+  /* TranslationOptions / GenerationOptions::return_logits_vocab (include/ctranslate2/translation.h:71,
+   * generation.h:57; GreedySearch::search, src/decoding.cc:868-872, 905-908): the vocabulary logits
+   * every decoding step of an entry sampled from - after the logits processors and the
+   * minimum-length mask of the end token (lowest()), before the log-softmax. One vector per step
+   * the entry ran: forced prefix steps and the end token's step included, so the count can exceed
+   * the hypothesis length. HOST buffer [batch, num_hypotheses, logits_steps, vocabulary size]
+   * (steps past logits_steps are dropped), logits_counts_out [batch, num_hypotheses] = vectors
+   * written. beam_size 1 only (greedy search, random sampling). NULL = off. */
+  float* logits_out;
+  int32_t* logits_counts_out;
+  int32_t logits_steps;
+  int32_t reserved1;
 };
 
 void ct2x_translation_options_default(struct ct2x_translation_options* opt);

@@ -50,7 +50,7 @@ inline const char* compute_type_name(ComputeType t) {
 }
 
 // generation.h:93-118: what TranslationOptions / GenerationOptions::callback receives for every
-// generated token (logits: return_logits_vocab is not built, the member is absent)
+// generated token (the per-step `logits` member is absent: return_logits_vocab delivers them with the result)
 struct GenerationStepResult {
   size_t step = 0;
   size_t batch_id = 0;
@@ -83,6 +83,7 @@ struct TranslationOptions {
   size_t num_hypotheses = 1;
   bool return_scores = false;
   bool return_attention = false;
+  bool return_logits_vocab = false;      // beam_size 1 (greedy search, random sampling)
   bool return_alternatives = false;
   float min_alternative_expansion_prob = 0;
   bool replace_unknowns = false;         // unknown target tokens -> the source token with the highest attention
@@ -98,6 +99,8 @@ struct TranslationResult {
   std::vector<std::vector<std::string>> hypotheses;
   std::vector<float> scores;
   std::vector<std::vector<std::vector<float>>> attention;  // [hypothesis][token][source position]
+  // return_logits_vocab: [hypothesis][step][vocabulary] (the reference: a StorageView per step)
+  std::vector<std::vector<std::vector<float>>> logits;
   bool has_attention() const { return !attention.empty(); }
 
   const std::vector<std::string>& output() const {
@@ -148,6 +151,7 @@ struct GenerationOptions {
   float sampling_temperature = 1;
   size_t num_hypotheses = 1;
   bool return_scores = false;
+  bool return_logits_vocab = false;      // beam_size 1 (greedy search, random sampling)
   bool return_alternatives = false;      // not built: must stay false
   std::vector<std::string> static_prompt;
   bool cache_static_prompt = true;       // accepted; the prompt is simply forwarded
@@ -163,6 +167,10 @@ struct GenerationResult {
   std::vector<std::vector<std::string>> sequences;
   std::vector<std::vector<size_t>> sequences_ids;
   std::vector<float> scores;
+  // return_logits_vocab: [sequence][step][vocabulary], one vector per decoding step: the steps
+  // that force what a longer prompt has beyond the shortest one come first, then the generated
+  // tokens' steps (the C entry decodes with include_prompt_in_result = false)
+  std::vector<std::vector<std::vector<float>>> logits;
   size_t num_sequences() const { return sequences.size(); }
   bool has_scores() const { return !scores.empty(); }
 };
@@ -193,6 +201,7 @@ public:
     char ct[32];
     check(ct2x_model_info(h_, &s2s, &vocab, &d, &layers, &heads, &bos, &eos, ct, sizeof(ct)));
     is_seq2seq_ = s2s != 0;
+    vocab_size_ = static_cast<size_t>(vocab);
     compute_type_ = ct;
   }
   ~Handle() {
@@ -203,6 +212,7 @@ public:
 
   void* get() const { return h_; }
   bool is_seq2seq() const { return is_seq2seq_; }
+  size_t vocab_size() const { return vocab_size_; }
   const std::string& compute_type() const { return compute_type_; }
 
   // Vocabulary::to_id / to_token (include/ctranslate2/vocabulary.h:16-70); which: 0 source, 1 target
@@ -225,6 +235,7 @@ public:
 private:
   void* h_ = nullptr;
   bool is_seq2seq_ = false;
+  size_t vocab_size_ = 0;
   std::string compute_type_;
 };
 
@@ -327,6 +338,32 @@ private:
   std::exception_ptr error_;
 };
 
+// return_logits_vocab: host buffers for the C entry and their conversion into the result member
+struct LogitsSink {
+  std::vector<float> data;
+  std::vector<int32_t> counts;
+  size_t hyp = 0, steps = 0, vocab = 0;
+
+  void attach(ct2x_translation_options& o, const Handle& h, size_t batch, size_t hypotheses, size_t max_steps) {
+    hyp = hypotheses;
+    steps = max_steps;
+    vocab = h.vocab_size();
+    data.assign(batch * hyp * steps * vocab, 0.f);
+    counts.assign(batch * hyp, 0);
+    o.logits_out = data.data();
+    o.logits_counts_out = counts.data();
+    o.logits_steps = static_cast<int32_t>(steps);
+  }
+  std::vector<std::vector<float>> take(size_t b, size_t k) const {
+    std::vector<std::vector<float>> out(static_cast<size_t>(counts[b * hyp + k]));
+    for (size_t s = 0; s < out.size(); ++s) {
+      const float* row = data.data() + ((b * hyp + k) * steps + s) * vocab;
+      out[s].assign(row, row + vocab);
+    }
+    return out;
+  }
+};
+
 }  // namespace detail
 
 // ctranslate2::Translator (include/ctranslate2/translator.h:26-60)
@@ -400,6 +437,8 @@ public:
     }
     detail::StepCallback step_callback(h_, options.callback, 0);
     step_callback.attach(o);
+    detail::LogitsSink logits;
+    if (options.return_logits_vocab) logits.attach(o, h_, batch, hyp, len);
     if (target_prefix.empty()) {
       detail::check(ct2x_translate_batch(h_.get(), src.ids.data(), src.lengths.data(),
                                          static_cast<int32_t>(batch), src.stride, &o, out.data(),
@@ -443,6 +482,7 @@ public:
           if (options.return_attention) results[b].attention.push_back(std::move(att));
         }
         results[b].hypotheses.push_back(std::move(tokens));
+        if (options.return_logits_vocab) results[b].logits.push_back(logits.take(b, k));
         if (options.return_scores) results[b].scores.push_back(scores[b * hyp + k]);
       }
     }
@@ -565,6 +605,15 @@ public:
     }
     detail::StepCallback step_callback(h_, options.callback, step_offset);
     step_callback.attach(o);
+    detail::LogitsSink logits;
+    if (options.return_logits_vocab) {
+      int32_t shortest = in.lengths[0], longest = in.lengths[0];
+      for (const int32_t n : in.lengths) {
+        shortest = std::min(shortest, n);
+        longest = std::max(longest, n);
+      }
+      logits.attach(o, h_, batch, hyp, len + static_cast<size_t>(longest - shortest));
+    }
     detail::check(ct2x_generate_batch(h_.get(), in.ids.data(), in.lengths.data(),
                                       static_cast<int32_t>(batch), in.stride, &o, out.data(),
                                       out_len.data(), scores.data()));
@@ -588,6 +637,7 @@ public:
         }
         results[b].sequences.push_back(std::move(tokens));
         results[b].sequences_ids.push_back(std::move(ids));
+        if (options.return_logits_vocab) results[b].logits.push_back(logits.take(b, k));
         if (options.return_scores) results[b].scores.push_back(scores[b * hyp + k]);
       }
     return results;

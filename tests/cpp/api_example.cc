@@ -114,6 +114,23 @@ int main(int argc, char** argv) {
         for (const auto& tok : r.hypotheses[0]) std::cout << ' ' << tok;
         std::cout << std::endl;
       }
+      {  // return_logits_vocab: the arg-max of every step's logits is the step's token
+        ct2_mi355::TranslationOptions lo;
+        lo.beam_size = 1;
+        lo.return_logits_vocab = true;
+        lo.return_end_token = true;
+        const auto r = translator.translate_batch({a}, lo);
+        std::cout << "logits:";
+        for (const auto& step : r[0].logits[0]) {
+          size_t best = 0;
+          for (size_t j = 1; j < step.size(); ++j)
+            if (step[j] > step[best]) best = j;
+          std::cout << ' ' << best;
+        }
+        std::cout << " |";
+        for (const auto& tok : r[0].hypotheses[0]) std::cout << ' ' << tok;
+        std::cout << std::endl;
+      }
       options.beam_size = 2;
       try {
         translator.translate_batch({a}, options);

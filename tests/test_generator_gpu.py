@@ -171,6 +171,30 @@ def test_generate_several_hypotheses(gpu, golden):
         np.testing.assert_array_equal(scores[b], [flat_scores[b * n + k] for k in want])
 
 
+def test_generate_return_logits_vocab(gpu, golden):
+    """GenerationOptions.return_logits_vocab: one logits vector per decoding step of a prompt - the
+    steps that force the tail of a longer prompt first (their tokens are not returned), then the
+    generated tokens' - equal to the teacher-forced logits of prompt + continuation."""
+    g = golden["lm_small_f32"]
+    t = get_lm("lm_small", "float32")
+    prompts = [list(p) for p in g["prompts"][:3]]
+    prompts[0] = prompts[0][:-2]
+    n = 6
+    want, _ = t.generate_ids(prompts, max_length=n, min_length=n)
+    got, _, logits = t.generate_ids(prompts, max_length=n, min_length=n, return_logits_vocab=True)
+    assert got == want
+    shortest = min(len(p) for p in prompts)
+    for b, p in enumerate(prompts):
+        forced = len(p) - shortest
+        assert logits[b].shape == (forced + n, t.vocab_size)
+        full = np.array([p + got[b]], np.int32)
+        ref = t.step_logits([], full[:, :-1])[:, 0, :]  # position i predicts token i + 1
+        rows = ref[shortest - 1:shortest - 1 + forced + n].copy()
+        rows[:, t.eos_id] = np.finfo(np.float32).min  # min_length (counted after the prompt) masks the end token
+        np.testing.assert_allclose(logits[b], rows, rtol=0, atol=2e-4)
+        assert np.array_equal(logits[b][forced:].argmax(-1), got[b])
+
+
 def test_prefill_equals_stepwise(gpu, golden):
     """The sequence-mode prefill must leave the same caches as feeding the prompt token by token
     (tests/model_test.cc:99-151 DecoderIterativeSequence): the continuation after a prefilled

@@ -392,6 +392,66 @@ def test_random_sampling_returns_several_hypotheses(gpu):
         t.translate_ids(src, beam_size=1, num_hypotheses=2)
 
 
+def test_return_logits_vocab(gpu):
+    """TranslationOptions.return_logits_vocab (GreedySearch::search, src/decoding.cc:868-872,
+    905-908): per step the logits the sampler saw - after the logits processors and DisableTokens
+    (end token = lowest() below min_decoding_length), before the log-softmax. Checked against the
+    teacher-forced logits of the returned hypothesis (same kernels, eager): equal bit for bit;
+    with a repetition penalty exactly the previous tokens differ, by the reference's rule
+    (primitives::penalize_previous_tokens: x < 0 ? x * p : x / p)."""
+    t = get_translator(gpu, "small", "int8")
+    cfg = GC.SYNTHETIC["small"]
+    rng = np.random.default_rng(17)
+    src = [rng.integers(4, cfg["model"]["vocab_size"], 12).tolist() for _ in range(4)]
+    lowest = np.finfo(np.float32).min
+    kw = dict(beam_size=1, max_decoding_length=9, min_decoding_length=3, return_end_token=True,
+              return_scores=True)
+    plain, plain_scores = t.translate_ids(src, **kw)
+    hyps, scores, logits = t.translate_ids(src, return_logits_vocab=True, **kw)
+    assert hyps == plain and np.array_equal(scores, plain_scores)
+
+    def teacher_forced(b, hyp, steps):
+        tgt_in = np.array([[t.bos_id] + list(hyp[:steps - 1])], np.int32)
+        return t.step_logits([src[b]], tgt_in)[:, 0, :]
+
+    for b in range(len(src)):
+        got = logits[b][0]
+        assert got.shape == (len(hyps[b][0]), t.vocab_size)  # one vector per step, the last one's included
+        want = teacher_forced(b, hyps[b][0], got.shape[0]).copy()
+        want[:3, t.eos_id] = lowest
+        np.testing.assert_array_equal(got, want)
+        assert np.array_equal(got.argmax(-1), hyps[b][0])
+    # logits processors come first
+    pen = 1.3
+    hyps, _, logits = t.translate_ids(src, return_logits_vocab=True, repetition_penalty=pen, **kw)
+    for b in range(len(src)):
+        got, hyp = logits[b][0], hyps[b][0]
+        raw = teacher_forced(b, hyp, got.shape[0])
+        for s in range(got.shape[0]):
+            want = raw[s].copy()
+            prev = sorted(set(hyp[:s]))
+            want[prev] = np.where(want[prev] < 0, want[prev] * np.float32(pen), want[prev] / np.float32(pen))
+            if s < 3:
+                want[t.eos_id] = lowest
+            np.testing.assert_array_equal(got[s], want)
+    # random sampling, several hypotheses: every sample comes with the logits of ITS steps
+    skw = dict(kw, sampling_topk=5, sampling_temperature=1.2, seed=2, num_hypotheses=2)
+    hyps, _, logits = t.translate_ids(src[:2], return_logits_vocab=True, **skw)
+    for b in range(2):
+        for k in range(2):
+            want = teacher_forced(b, hyps[b][k], logits[b][k].shape[0]).copy()
+            want[:3, t.eos_id] = lowest
+            np.testing.assert_array_equal(logits[b][k], want)
+    # the token-level surface carries them in TranslationResult.logits
+    tok = [[t.id_to_token(i, target=False) for i in s] for s in src[:2]]
+    res = t.translate_batch(tok, beam_size=1, max_decoding_length=9, return_logits_vocab=True)
+    assert [r.logits[0].shape[1] for r in res] == [t.vocab_size] * 2
+    # (+ the end token's step when it came before max_decoding_length)
+    assert [r.logits[0].shape[0] for r in res] == [min(len(r.hypotheses_ids[0]) + 1, 9) for r in res]
+    with pytest.raises(Exception, match="return_logits_vocab is built for greedy search"):
+        t.translate_ids(src, beam_size=2, return_logits_vocab=True)
+
+
 def test_random_sampling_whole_vocabulary(gpu):
     """sampling_topk = 0 (the reference: no TopK restriction, src/sampling.cc:54-66): temperature
     -> TopPMask -> SoftMax -> Multinomial over the whole vocabulary. Checked: graph == eager for a
@@ -648,6 +708,9 @@ def test_cpp_api_translator(gpu):
     hyps = [ln[1:].split() for ln in lines if ln.startswith("=")]
     assert hyps == [want[0].hypotheses[0][:-1], want[1].hypotheses[0][:2]]
     assert any(ln.startswith("rejected: The callback function is not compatible") for ln in lines)
+    # TranslationOptions::return_logits_vocab through the C++ surface: arg-max ids | tokens
+    ids, toks = [part.split() for part in next(ln for ln in lines if ln.startswith("logits:"))[7:].split("|")]
+    assert toks == want[0].hypotheses[0] and [int(i) for i in ids] == want[0].hypotheses_ids[0]
     assert "raised: from the callback" in lines
     # Translator::score_batch through the C++ surface == the Python surface
     src, tgt = GC.AREN_SOURCES[0], ["a", "t", "z", "m", "o", "n"]
