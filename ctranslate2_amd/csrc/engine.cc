@@ -114,6 +114,7 @@ uint16_t float_to_half_bits(float f) {  // IEEE binary16, round to nearest even
 }  // namespace
 
 thread_local DecodeState* Engine::pf_state_ = nullptr;
+thread_local const DecodeState* Engine::argmax_state_ = nullptr;
 
 hipStream_t Engine::cur_stream() const { return tls_stream ? tls_stream : stream_; }
 
@@ -1333,6 +1334,24 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
     ep.y = y;
     ep.act = act;
     ep.ldy = w.n;
+    if (argmax_state_ != nullptr && y == argmax_state_->logits) {
+      // the greedy sampler rides in this launch (GreedyFuse, kernels.h); no logits are stored
+      const DecodeState& gs = *argmax_state_;
+      ep.gf.slots = gs.gf_slots;
+      ep.gf.ticket = gs.gf_ticket;
+      ep.gf.step_ptr = gs.d_step;
+      ep.gf.disable_id = gs.g_eos;
+      ep.gf.min_length = gs.g_min_length;
+      ep.gf.prefix_ids = gs.d_prefix;
+      ep.gf.prefix_lens = gs.d_prefix_len;
+      ep.gf.prefix_stride = gs.prefix_stride;
+      ep.gf.prefix_first_step = gs.prefix_first_step;
+      ep.gf.prefix_extends_min = gs.prefix_extends_min ? 1 : 0;
+      ep.gf.next_ids = gs.d_ids;
+      ep.gf.hist_ids = gs.hist_ids;
+      ep.gf.hist_scores = gs.hist_scores;
+      ep.gf.advance_step_ptr = gs.d_step;
+    }
     {
       const double M = double(m), N = double(w.n), K = double(w.k);
       begin_kernel("gemm_s8_dequant", M * K + N * K + 4 * N + 4 * M + 4 * M * N +

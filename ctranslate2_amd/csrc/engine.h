@@ -407,6 +407,9 @@ private:
   bool weight_prefetch_ = false;
   int prefetch_wgs_ = 192;
   static thread_local DecodeState* pf_state_;  // session whose launch_step is running on this thread
+  // session whose vocabulary projection carries the fused greedy arg-max (set around that Dense)
+  static thread_local const DecodeState* argmax_state_;
+  bool fused_argmax_applicable(const DecodeState& state) const;
   int64_t prefetch_bytes_[4] = {0, 0, 0, 0};
   void pack_stream_weights();
   void pack_stream(DenseW& w, bool dual);
@@ -586,6 +589,10 @@ struct DecodeState {
   bool g_scores = false;
   // Hard decoding prefix of the fused sampler (ragged prompts): ids [rows, prefix_stride], lengths
   int32_t* d_done = nullptr;   // rows-finished counter of the fused sampler (advances d_step)
+  // greedy arg-max fused into the vocabulary projection (GreedyFuse, kernels.h): per-row packed
+  // maxima and the workgroup ticket, both zero between launches
+  unsigned long long* gf_slots = nullptr;
+  unsigned int* gf_ticket = nullptr;
   int32_t* d_prefix = nullptr;
   int32_t* d_prefix_len = nullptr;
   int32_t prefix_stride = 0, prefix_first_step = 0;

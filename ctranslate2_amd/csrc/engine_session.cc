@@ -154,6 +154,11 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   st->d_step = alloc<int32_t>(*st, 1);
   st->d_done = alloc<int32_t>(*st, 1);
   CT2X_HIP_CHECK(hipMemsetAsync(st->d_done, 0, sizeof(int32_t), cur_stream()));
+  st->gf_slots = alloc<unsigned long long>(*st, rows * GreedyFuse::kSubSlots);
+  st->gf_ticket = alloc<unsigned int>(*st, 1);
+  CT2X_HIP_CHECK(hipMemsetAsync(st->gf_slots, 0, sizeof(unsigned long long) * rows * GreedyFuse::kSubSlots,
+                                cur_stream()));
+  CT2X_HIP_CHECK(hipMemsetAsync(st->gf_ticket, 0, sizeof(unsigned int), cur_stream()));
   st->hist_ids = alloc<int32_t>(*st, (t_max + 1) * rows);
   st->hist_scores = alloc<float>(*st, (t_max + 1) * rows);
   CT2X_HIP_CHECK(hipMemsetAsync(st->d_step, 0, sizeof(int32_t), cur_stream()));

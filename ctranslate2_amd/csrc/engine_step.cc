@@ -308,6 +308,7 @@ void Engine::launch_step(DecodeState& st) {
   tap_scope("dec.out");
   QuantIn pq;
   const float* proj_in = x;
+  bool fused_argmax = false;  // the vocabulary projection sampled the step itself (GreedyFuse)
   if (!dense_norm(dec_.output_norm, dec_.projection, x, rows, -1, nullptr, st.logits)) {
     if (dec_.output_norm.present) {
       if (dec_.projection.quantized) {
@@ -319,7 +320,11 @@ void Engine::launch_step(DecodeState& st) {
         proj_in = st.ctx;
       }
     }
+    const bool ride = fused_argmax_applicable(st);
+    if (ride) argmax_state_ = &st;
     dense(dec_.projection, proj_in, pq.q ? &pq : nullptr, rows, -1, nullptr, st.logits, &st);
+    argmax_state_ = nullptr;
+    fused_argmax = ride;
   }
 
   if (st.wh_no_speech_id >= 0 && (st.fuse_greedy || st.fuse_beam)) {
@@ -363,7 +368,9 @@ void Engine::launch_step(DecodeState& st) {
                            st.prefix_extends_min, st.d_step, kLogitsRing, st.logit_hist, cur_stream());
       end_kernel();
     }
-    if (st.g_topk == 1) {
+    if (fused_argmax) {
+      // (sampled by the last workgroup of the projection)
+    } else if (st.g_topk == 1) {
       begin_kernel("greedy_sample");
       launch_greedy_sample(st.logits, st.rows, dec_.projection.n, st.g_eos, st.g_min_length,
                            st.g_scores, st.d_step, st.d_ids, st.hist_ids, st.hist_scores,
@@ -672,6 +679,24 @@ void Engine::set_ids(DecodeState& st, const int32_t* h_ids) {
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_ids, h_ids, sizeof(int32_t) * st.rows,
                                 hipMemcpyHostToDevice, cur_stream()));
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // h_ids may be a temporary
+}
+
+// The greedy sampler can ride in the vocabulary projection when the step needs nothing but each
+// row's arg-max (src/decoding.cc:874-880: no scores -> no LogSoftMax) and nothing else reads or
+// rewrites the logits: no logits processors, no Whisper rules / no-speech probe, no logits
+// history, no taps. CT2X_FUSED_ARGMAX=0 restores the sampler launch (same ids).
+bool Engine::fused_argmax_applicable(const DecodeState& st) const {
+  static const bool enabled = [] {
+    const char* e = std::getenv("CT2X_FUSED_ARGMAX");
+    return e == nullptr || e[0] != '0';
+  }();
+  const DenseW& w = dec_.projection;
+  return enabled && st.fuse_greedy && !st.fuse_beam && st.g_topk == 1 && !st.g_scores &&
+         !st.lp_active && !st.wh_active && st.wh_no_speech_id < 0 && st.logit_hist == nullptr &&
+         !taps_ && !tp_ && w.quantized && !w.awq && !w.row_parallel && st.gf_slots != nullptr &&
+         !(w.wq_stream && !w.wq_stream_dual && gemm_s8_stream_applicable(st.rows, w.n, w.k, false)) &&
+         gemm_s8_argmax_applicable(st.rows, w.n, w.k) &&
+         (reinterpret_cast<uintptr_t>(w.wq) & 15) == 0;
 }
 
 bool Engine::compactable(const DecodeState& st) const {

@@ -225,8 +225,12 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
 // step) a weight byte is used once, and keeping it out of the cache hierarchy's retention policy
 // shortens issue -> landed (MI355X_MICROARCH.md, "nt-weights"). Transformer-base (38 MB of decoder
 // weights, MALL resident from step to step) keeps the default policy.
+// ARGMAX: GreedyFuse (kernels.h) - the epilogue keeps, per row, the best (value, column) key of the
+// workgroup's columns (thread-local over its column tiles, then across the 16 lanes that share
+// the row), max-combines it into the row's global slot with one 64-bit atomic, and the workgroup
+// that draws the last ticket finishes the step.
 template <int MT, int NT, int WAVES, int U, bool DUAL = false, int NORM = 0, bool QOL = false,
-          bool NTW = false>
+          bool NTW = false, bool ARGMAX = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     const int8_t* __restrict__ A, const int8_t* __restrict__ B, int M, int N, int K,
     const float* __restrict__ aux, GemmS8Epilogue ep) {
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
   const int64_t n0 = static_cast<int64_t>(blockIdx.x) * (NT * 16);
   const int ksteps = (K + 63) / 64;
   const int rb = blockIdx.y * (MT * 16);  // this workgroup's block of MT * 16 rows (grid.y)
+  const int M_all = M;
   M -= rb;
   // NORM: the fp32 rows to normalise travel in the (otherwise unused) A slot, so that their request
   // does not wait for the argument block either
@@ -344,6 +349,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
         e_ws2[o] = ep.w_scale2[col];
         if (ep.bias2) e_bias2[o] = ep.bias2[col];
       }
+    }
+  }
+
+  // ARGMAX: the step and the row's minimum length decide which column is masked (the end token
+  // below the minimum length, apply_min_length src/decoding.cc:384-408); thread t finalises row
+  // i * 16 + (t >> 4) of every row tile i (THREADS == 256: `within` == t for every output).
+  static_assert(!ARGMAX || (WAVES == 4 && !DUAL && !NORM && !QOL), "ARGMAX: plain Dense on 4 waves");
+  // (requested here, consumed after the K loop: the requests ride along with the weight stream)
+  int gf_step = 0, gf_plen[MT];
+  if (ARGMAX) {
+    gf_step = *ep.gf.step_ptr;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = i * 16 + (tid >> 4);
+      gf_plen[i] = 0;
+      if (ep.gf.prefix_ids != nullptr && ep.gf.prefix_extends_min && row < M)
+        gf_plen[i] = ep.gf.prefix_lens[rb + row];
     }
   }
 
@@ -599,12 +621,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     __syncthreads();
   }
 
+  unsigned long long gf_best[MT];
+  int gf_masked[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    gf_best[i] = 0ull;
+    gf_masked[i] = (ARGMAX && gf_step < ep.gf.min_length + gf_plen[i]) ? ep.gf.disable_id : -1;
+  }
+
   // Cross-wave sum (exact int32) + fused epilogue, spread over ALL threads of the workgroup.
 #pragma unroll
   for (int o = 0; o < OPT; ++o) {
     const int flat = tid + o * THREADS;
     if (flat >= OUTS) continue;
-    const int tile = flat >> 8, within = flat & 255;
+    // (256 threads: output o of a thread lies in tile o - compile-time tile indices)
+    const int tile = THREADS == 256 ? o : (flat >> 8), within = THREADS == 256 ? tid : (flat & 255);
     const int i = tile / NT, j = tile % NT;
     const int rt = within >> 4, ct = within & 15;
     const int row = i * 16 + rt;
@@ -635,8 +666,91 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
         v = v2 * v;  // ops::Mul()(linear_0_noact_out, activated, out)
       }
       if (ep.residual) v = e_res[o] + v;
-      ep.y[idx] = v;
+      if (ARGMAX) {
+        // key order = (value, then LOWER column): the arg-max tie rule of the sampler (better())
+        if (static_cast<int>(col) != gf_masked[i] && v == v) {
+          const unsigned u = __float_as_uint(v);
+          const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+          const unsigned long long key =
+              (static_cast<unsigned long long>(ord) << 32) | (0xFFFFFFFFu - static_cast<unsigned>(col));
+          gf_best[i] = key > gf_best[i] ? key : gf_best[i];
+        }
+      } else {
+        ep.y[idx] = v;
+      }
       if (ep.row_amax_out != nullptr) atomicMax(&tile_amax[row], __float_as_uint(fabsf(v)));
+    }
+  }
+  if (ARGMAX) {
+    static_assert(!ARGMAX || (WAVES * 64 == 256 && (MT * NT * 256) % 256 == 0), "ARGMAX: tile o == output o");
+    __shared__ unsigned int gf_ticket;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      unsigned long long k = gf_best[i];
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        const unsigned long long other = __shfl_xor(k, off, 64);
+        k = other > k ? other : k;
+      }
+      const int row = i * 16 + (tid >> 4);
+      if ((tid & 15) == 0 && row < M && k != 0ull) {
+        // (a returning atomic: it has been performed when its value arrives, i.e. before the ticket)
+        const unsigned long long old =
+            atomicMax(ep.gf.slots + static_cast<int64_t>(rb + row) * GreedyFuse::kSubSlots +
+                          (blockIdx.x % GreedyFuse::kSubSlots), k);
+        asm volatile("" ::"v"(static_cast<unsigned>(old)));
+      }
+    }
+    __syncthreads();
+    if (tid == 0) gf_ticket = atomicAdd(ep.gf.ticket, 1u);
+    __syncthreads();
+    if (gf_ticket == gridDim.x * gridDim.y - 1) {
+      // every workgroup of the launch has combined its rows: finish the step (the tail of
+      // greedy_sample_kernel, decode_ops.hip)
+      // (thread t reads - and clears - sub-slot t % 16 of row t / 16; 16 lanes fold a row)
+      constexpr int RPP = THREADS / GreedyFuse::kSubSlots;  // rows per pass
+      constexpr int PASSES = (32 + RPP - 1) / RPP;          // M_all <= 32 (gemm_s8_argmax_applicable)
+      unsigned long long keys[PASSES];
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {  // every exchange of the workgroup in one round trip
+        const int row = ps * RPP + tid / GreedyFuse::kSubSlots;
+        keys[ps] = 0ull;
+        if (row < M_all)
+          keys[ps] = atomicExch(ep.gf.slots + static_cast<int64_t>(row) * GreedyFuse::kSubSlots +
+                                    (tid % GreedyFuse::kSubSlots), 0ull);
+      }
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int row = ps * RPP + tid / GreedyFuse::kSubSlots;
+        unsigned long long key = keys[ps];
+#pragma unroll
+        for (int off = GreedyFuse::kSubSlots / 2; off >= 1; off >>= 1) {
+          const unsigned long long other = __shfl_xor(key, off, 64);
+          key = other > key ? other : key;
+        }
+        if (row >= M_all || (tid % GreedyFuse::kSubSlots) != 0) continue;
+        int id = 0;
+        float score = 0.f;
+        if (key != 0ull) {
+          id = static_cast<int>(0xFFFFFFFFu - static_cast<unsigned>(key));
+          const unsigned ord = static_cast<unsigned>(key >> 32);
+          score = __uint_as_float((ord & 0x80000000u) ? (ord & 0x7FFFFFFFu) : ~ord);
+        }
+        if (ep.gf.prefix_ids != nullptr) {
+          const int local = gf_step - ep.gf.prefix_first_step;
+          if (local >= 0 && local < ep.gf.prefix_lens[row]) {
+            id = ep.gf.prefix_ids[static_cast<int64_t>(row) * ep.gf.prefix_stride + local];
+            score = 0.f;
+          }
+        }
+        ep.gf.next_ids[row] = id;
+        ep.gf.hist_ids[static_cast<int64_t>(gf_step) * M_all + row] = id;
+        ep.gf.hist_scores[static_cast<int64_t>(gf_step) * M_all + row] = score;
+      }
+      if (tid == 0) {
+        *ep.gf.ticket = 0u;
+        if (ep.gf.advance_step_ptr != nullptr) *ep.gf.advance_step_ptr = gf_step + 1;
+      }
     }
   }
   if (ep.row_amax_out != nullptr) {
@@ -670,6 +784,16 @@ __global__ void gemm_s8_naive_kernel(const int8_t* __restrict__ A, const int8_t*
 // (N < 8192: the vocabulary projection keeps its own norm launch).
 bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k) {
   return m >= 1 && m <= 128 && (k == 64 || k == 128 || k == 256 || k == 512) && n >= 1 && n < 8192;
+}
+
+// Shapes the fused greedy arg-max serves: the vocabulary-projection forms of the skinny kernel
+// (<= 32 rows as one or two 16-row tiles per workgroup, K short of the long-K forms).
+bool gemm_s8_argmax_applicable(int64_t m, int64_t n, int64_t k) {
+  static const bool plain = tuning_env("CT2X_GEMM_TILE") == nullptr &&
+                            tuning_env("CT2X_NO_SKINNY_GEMM") == nullptr &&
+                            tuning_env("CT2X_SKINNY_MT") == nullptr &&
+                            tuning_env("CT2X_SKINNY_CFG") == nullptr;
+  return plain && m >= 1 && m <= 32 && n >= 8192 && k % 16 == 0 && k > 0 && k < 4096;
 }
 
 // Shapes the quantise-on-load form serves: decode rows and a K that is whole MFMA K-steps and at
@@ -730,6 +854,10 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
                        ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&
                        ((reinterpret_cast<uintptr_t>(b) & 15) == 0);
   const int M = static_cast<int>(m), N = static_cast<int>(n), K = static_cast<int>(k);
+  if (ep.gf.slots != nullptr &&
+      !(mfma_ok && gemm_s8_argmax_applicable(m, n, k) && ep.mode == 1 && ep.norm_x == nullptr &&
+        ep.a_f32 == nullptr && ep.b2 == nullptr && !ep.packed_b))
+    throw Error("launch_gemm_s8: the fused arg-max form needs a plain int8 vocabulary projection of <= 32 rows");
   if (!mfma_ok) {
     hipLaunchKernelGGL(gemm_s8_naive_kernel, dim3((n + 63) / 64, m), dim3(64), 0, stream, a, b,
                        M, N, K, ep);
@@ -881,6 +1009,16 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
       else if (k >= 8192) CT2X_SKINNY(1, 1, 16, 4);   // [16, 4096, 14336] 20.5 -> 18.3 us
       else if (n >= 6144) CT2X_SKINNY(1, 2, 8, 8);    // [16, 6144, 4096]  10.4 ->  9.3 us
       else CT2X_SKINNY(1, 1, 16, 4);                  // [16, 4096, 4096]   7.6 ->  6.7 us
+    } else if (n >= 8192 && ep.gf.slots != nullptr) {
+      if (!(gemm_s8_argmax_applicable(m, n, k) && ep.mode == 1 && mt <= 2))
+        throw Error("launch_gemm_s8: the fused arg-max form needs a vocabulary projection of <= 32 rows");
+#define CT2X_SKINNY_ARGMAX(MT)                                                                      \
+  hipLaunchKernelGGL((gemm_s8_skinny_kernel<MT, 4, 4, 2, false, 0, false, false, true>),           \
+                     dim3((n + 63) / 64, (m + 16 * MT - 1) / (16 * MT)), dim3(256), 0, stream, a,   \
+                     b, M, N, K, static_cast<const float*>(nullptr), ep)
+      if (mt == 1) CT2X_SKINNY_ARGMAX(1);
+      else CT2X_SKINNY_ARGMAX(2);
+#undef CT2X_SKINNY_ARGMAX
     } else if (n >= 8192) {
       if (mt == 1) CT2X_SKINNY(1, 4, 4, 2);
       else if (mt == 2) CT2X_SKINNY(2, 4, 4, 2);

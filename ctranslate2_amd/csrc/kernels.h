@@ -97,6 +97,33 @@ void launch_mul(const float* a, const float* b, int64_t n, float* y, hipStream_t
 
 // ---- int8 GEMM (gemm_s8.hip) ---------------------------------------------------------
 
+// Greedy sampler fused into the vocabulary projection (gemm_s8.hip, ARGMAX form): a greedy step
+// that returns no scores only needs the arg-max of every logits row (src/decoding.cc:874-880), so
+// the projection's workgroups max-combine packed (value, column) keys per row and the LAST
+// workgroup to finish plays greedy_sample_kernel's tail (prefix forcing, id to the next step,
+// history, step counter): the logits never reach memory and the sampler launch disappears.
+struct GreedyFuse {
+  // Same-address atomics from 500 workgroups serialise: a row's maximum is spread over kSubSlots
+  // slots (workgroup index modulo kSubSlots) that the finishing workgroup folds.
+  static constexpr int kSubSlots = 16;
+  unsigned long long* slots = nullptr;  // [m, kSubSlots] packed maxima, zero between launches; nullptr = off
+  unsigned int* ticket = nullptr;       // workgroup arrival counter, zero between launches
+  const int32_t* step_ptr = nullptr;
+  int32_t disable_id = -1;              // DisableTokens below the minimum length (the end token)
+  int32_t min_length = 0;
+  const int32_t* prefix_ids = nullptr;  // SamplePrefix (decode_ops.hip)
+  const int32_t* prefix_lens = nullptr;
+  int32_t prefix_stride = 0;
+  int32_t prefix_first_step = 0;
+  int32_t prefix_extends_min = 0;
+  int32_t* next_ids = nullptr;
+  int32_t* hist_ids = nullptr;
+  float* hist_scores = nullptr;
+  int32_t* advance_step_ptr = nullptr;  // nullptr: the caller advances the step itself
+};
+// shapes the fused form serves (the skinny kernel's vocabulary-projection instantiations)
+bool gemm_s8_argmax_applicable(int64_t m, int64_t n, int64_t k);
+
 struct GemmS8Epilogue {
   // mode 0: raw int32 store to c_i32.
   // mode 1: y = act(acc * (1/a_scale[i]) / w_scale[j] + bias[j]) + residual[i,j]  (fp32 store)
@@ -142,6 +169,8 @@ struct GemmS8Epilogue {
   // layout pack_stream_weight() produced for this (n, k) - every 1 KB request of a wave is one
   // contiguous block and a wave's requests of a slab follow each other in memory.
   bool packed_b = false;
+  // gf.slots != nullptr: no logits store, fused greedy arg-max (gemm_s8_argmax_applicable shapes)
+  GreedyFuse gf;
 };
 
 bool gemm_s8_norm_applicable(int64_t m, int64_t n, int64_t k);
