@@ -68,6 +68,19 @@ calls = []
 hyps, _ = t.translate_ids(src[:3], beam_size=1, max_decoding_length=10,
                           callback=lambda r: calls.append((r.batch_id, r.step, r.token_id)) and False)
 out["callback"] = [hyps, sorted(calls)]
+# decoder-only generation: ragged prompts are hidden hard prefixes that also push the minimum
+# length out (apply_min_length with return_prefix = false)
+d = "/tmp/ct2x_fused_argmax_lm"
+if not os.path.exists(os.path.join(d, "model.bin")):
+    mb.build_decoder_lm(d, num_layers=2, d_model=256, ffn_dim=512, num_heads=8, num_heads_kv=2,
+                        vocab_size=V)
+g = ct2.Translator(d, device="cuda", compute_type="int8")
+prompts = [rng.integers(4, V, n).tolist() for n in (3, 9, 5, 12, 4, 3, 7)]
+ids, _ = g.generate_ids(prompts, max_length=16, min_length=5, return_end_token=True)
+out["lm"] = ids
+out["lm_kernels"] = g.last_stats()["kernels_per_step"]
+ids, _ = g.generate_ids(prompts, max_length=16, min_length=16, use_graph=False)
+out["lm_eager"] = ids
 print(json.dumps(out))
 """
 
@@ -93,6 +106,7 @@ def test_fused_greedy_argmax_equals_the_sampler_launch(gpu):
     # the fused form really ran where it applies (one launch less per step) and only there
     for rows in (1, 7, 16, 17, 32):
         assert fused["plain_%d_kernels" % rows] == base["plain_%d_kernels" % rows] - 1, rows
+    assert fused["lm_kernels"] == base["lm_kernels"] - 1
     for key in ("scores_kernels", "processors_kernels", "rows40_kernels"):
         assert fused[key] == base[key], key
     # the premise of the masked / forced cases
