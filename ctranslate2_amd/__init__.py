@@ -611,6 +611,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         out = {name: getattr(st, name) for name, _ in ExecStats._fields_}
         self._L.ct2x_last_compactions.restype = C.c_int64
         out["compactions"] = int(self._L.ct2x_last_compactions(C.c_void_p(self._h)))
+        self._L.ct2x_session_hits.restype = C.c_int64
+        out["session_hits"] = int(self._L.ct2x_session_hits(C.c_void_p(self._h)))
         return out
 
 

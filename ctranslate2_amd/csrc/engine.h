@@ -215,6 +215,10 @@ public:
                                      int64_t batch, int64_t s_max, int64_t beam, int64_t t_max,
                                      int64_t prefill_len = 0, bool beam_search_state = false,
                                      const float* features = nullptr, int64_t frames = 0);
+  // Session reuse (c_api_engine.cc keeps the last plain greedy session of a Translator): runs the
+  // encoder again, for new sentences of the SAME padded shape (batch, s_max), into the buffers of a
+  // finished session - allocations, tables and the step graphs captured over those buffers stay.
+  void reencode(DecodeState& state, const int32_t* src_ids, const int32_t* src_lengths);
   // Whisper: `features` [batch, n_mels, frames] (host) go through the convolutional front end and
   // the encoder (WhisperEncoder::operator(), src/layers/whisper.cc:26-62); the memory has
   // whisper_memory_length(frames) positions.
@@ -568,6 +572,8 @@ struct DecodeState {
   int32_t* d_bprefix = nullptr;      // [batch, bprefix_stride]
   int32_t* d_bprefix_len = nullptr;  // [batch]
   int32_t bprefix_stride = 0;
+  int32_t* d_src = nullptr;          // encoder input ids [batch * s_max] (kept for reencode)
+  int64_t graph_kernels = 0;         // launches of the captured step (kernels_per_step of a replay)
   float* att_hist = nullptr;         // return_attention: [t_max + 1][rows][s_max] (enable_attention)
   float* logit_hist = nullptr;       // return_logits_vocab: [kLogitsRing][rows][vocab] (enable_logits_history)
   bool beam_mode = false;            // the state holds the beam search's buffers (beam > 1, or forced)

@@ -297,6 +297,20 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   return st;
 }
 
+void Engine::reencode(DecodeState& st, const int32_t* src_ids, const int32_t* src_lengths) {
+  CT2X_CHECK(has_encoder_ && !is_whisper() && st.engine == this && st.beam == 1 && !st.beam_mode,
+             "reencode: a plain greedy encoder-decoder session of this engine");
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  // what a fresh session starts from: step 0, the first cache set, no fused tail selected (the
+  // done counter and the fused sampler's slots are zero between launches by construction)
+  CT2X_HIP_CHECK(hipMemsetAsync(st.d_step, 0, sizeof(int32_t), cur_stream()));
+  st.cur = 0;
+  st.fuse_greedy = st.fuse_beam = false;
+  encode(st, src_ids, src_lengths);
+}
+
 // TransformerEncoder::operator() (src/layers/transformer.cc:427-471) on padded rows followed by
 // the cross-attention K/V projection of every decoder layer (process_cross_attention,
 // src/layers/attention.cc:371-440), which the reference runs lazily at decoding step 0.
@@ -304,7 +318,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
 // attention kernels mask keys beyond lengths[b].
 void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_lengths) {
   const int64_t B = st.batch, S = st.s_max, d = enc_.d_model, rows = B * S;
-  int32_t* d_src = alloc<int32_t>(st, rows);
+  if (st.d_src == nullptr) st.d_src = alloc<int32_t>(st, rows);
+  int32_t* d_src = st.d_src;
   CT2X_HIP_CHECK(hipMemcpyAsync(d_src, src_ids, sizeof(int32_t) * rows, hipMemcpyHostToDevice,
                                 cur_stream()));
   CT2X_HIP_CHECK(hipMemcpyAsync(st.mem_lengths, src_lengths, sizeof(int32_t) * B,

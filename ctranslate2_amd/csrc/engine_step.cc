@@ -524,12 +524,14 @@ void Engine::step(DecodeState& st, bool graph) {
     } else {
     CT2X_HIP_CHECK(hipStreamEndCapture(cur_stream(), &g));
     kernels_per_step_ = tls_launches - before;
+    st.graph_kernels = kernels_per_step_;
     CT2X_HIP_CHECK(hipGraphInstantiate(&st.graph_exec[parity], g, nullptr, nullptr, 0));
     CT2X_HIP_CHECK(hipGraphDestroy(g));
     st.graph_ready[parity] = true;
     }
   }
   CT2X_HIP_CHECK(hipGraphLaunch(st.graph_exec[parity], cur_stream()));
+  if (st.graph_kernels > 0) kernels_per_step_ = st.graph_kernels;  // (a reused session replays at once)
   if (st.fuse_beam) st.cur ^= 1;
 }
 
