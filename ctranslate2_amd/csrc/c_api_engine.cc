@@ -98,8 +98,8 @@ struct Translator {
   std::mutex mutex;
   ct2x_exec_stats last{};
   int64_t last_compactions = 0;  // finished-row removals of the last call (greedy loop)
-  // The session of the last PLAIN greedy translate call (one group, no prefix / processors /
-  // attention / callback ...): a call of the same padded shape and device-side options runs its
+  // The session of the last PLAIN greedy or beam search translate call (one group, no prefix /
+  // processors / attention / callback ...): a call of the same padded shape and device-side options runs its
   // encoder into the same buffers and replays the step graph captured over them - no allocation,
   // no capture, no instantiation (0.4 - 0.5 ms of a 20 ms Transformer-base call). session_key
   // lists everything a captured step depends on. CT2X_SESSION_CACHE=0: every call builds its own.
@@ -918,14 +918,16 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
           return e == nullptr || e[0] != '0';
         }();
         const bool plain = session_cache && groups.size() == 1 && streams == 1 && samples == 1 &&
-                           dopt.beam_size == 1 && dopt.sampling_topk == 1 && dopt.num_hypotheses == 1 &&
-                           prefix_ids == nullptr && !(dopt.prefix_bias_beta > 0) &&
+                           dopt.sampling_topk == 1 && prefix_ids == nullptr && !(dopt.prefix_bias_beta > 0) &&
                            dopt.coverage_penalty == 0 && !dopt.return_attention &&
                            !dopt.return_logits_vocab && !dopt.callback &&
                            !dopt.logits_processing.active() && dopt.whisper == nullptr &&
                            t->engine->tp_world() == 1 && !t->engine->profiling();
+        int32_t patience_bits = 0;
+        std::memcpy(&patience_bits, &dopt.patience, sizeof(patience_bits));
         const std::vector<int64_t> key = {
-            R, s_max, dopt.max_length, dopt.min_length, dopt.return_scores ? 1 : 0, end_id,
+            R, s_max, dopt.beam_size, dopt.num_hypotheses, patience_bits,
+            dopt.max_length, dopt.min_length, dopt.return_scores ? 1 : 0, end_id,
             dopt.use_graph ? 1 : 0, dopt.sync_every, dopt.start_step,
             static_cast<int64_t>(reinterpret_cast<uintptr_t>(thread_stream()))};
         std::unique_ptr<DecodeState> st;
@@ -975,7 +977,7 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
         t->engine->synchronize();
         const double te2 = now_ms();
         for (int64_t i = 0; i < B; ++i) all_results[order[begin + i]] = std::move(results[i]);
-        if (plain && ds.compactions == 0 && st->rows == R && !st->graph_failed) {
+        if (plain && ds.compactions == 0 && st->rows == R * dopt.beam_size && !st->graph_failed) {
           t->session = std::move(st);  // (an exception on the way here leaves no session behind)
           t->session_key = key;
         }

@@ -573,6 +573,7 @@ struct DecodeState {
   int32_t* d_bprefix_len = nullptr;  // [batch]
   int32_t bprefix_stride = 0;
   int32_t* d_src = nullptr;          // encoder input ids [batch * s_max] (kept for reencode)
+  int32_t* anc_init = nullptr;       // the identity the ancestry tables start from (kept for reencode)
   int64_t graph_kernels = 0;         // launches of the captured step (kernels_per_step of a replay)
   float* att_hist = nullptr;         // return_attention: [t_max + 1][rows][s_max] (enable_attention)
   float* logit_hist = nullptr;       // return_logits_vocab: [kLogitsRing][rows][vocab] (enable_logits_history)

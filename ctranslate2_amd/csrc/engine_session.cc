@@ -222,6 +222,10 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
         CT2X_HIP_CHECK(hipMemcpy(st->anc[i], identity.data(), identity.size() * sizeof(int32_t),
                                  hipMemcpyHostToDevice));
       }
+      // (a pristine copy: a reused session starts from the identity again, Engine::reencode)
+      st->anc_init = alloc<int32_t>(*st, (t_max + 1) * rows);
+      CT2X_HIP_CHECK(hipMemcpy(st->anc_init, identity.data(), identity.size() * sizeof(int32_t),
+                               hipMemcpyHostToDevice));
     }
   }
   const int n_sets = (beam_mode && !st->ancestry) ? 2 : 1;
@@ -298,8 +302,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
 }
 
 void Engine::reencode(DecodeState& st, const int32_t* src_ids, const int32_t* src_lengths) {
-  CT2X_CHECK(has_encoder_ && !is_whisper() && st.engine == this && st.beam == 1 && !st.beam_mode,
-             "reencode: a plain greedy encoder-decoder session of this engine");
+  CT2X_CHECK(has_encoder_ && !is_whisper() && st.engine == this && (st.beam == 1) == !st.beam_mode,
+             "reencode: a plain greedy / beam search encoder-decoder session of this engine");
   CT2X_HIP_CHECK(hipSetDevice(device_));
   tls_stream = st.stream;
   set_active_stream(tls_stream);
@@ -308,6 +312,11 @@ void Engine::reencode(DecodeState& st, const int32_t* src_ids, const int32_t* sr
   CT2X_HIP_CHECK(hipMemsetAsync(st.d_step, 0, sizeof(int32_t), cur_stream()));
   st.cur = 0;
   st.fuse_greedy = st.fuse_beam = false;
+  if (st.ancestry) {
+    const size_t bytes = static_cast<size_t>((st.t_max + 1) * st.rows) * sizeof(int32_t);
+    for (int i = 0; i < 2; ++i)
+      CT2X_HIP_CHECK(hipMemcpyAsync(st.anc[i], st.anc_init, bytes, hipMemcpyDeviceToDevice, cur_stream()));
+  }
   encode(st, src_ids, src_lengths);
 }
 

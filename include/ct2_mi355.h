@@ -771,10 +771,10 @@ int ct2x_last_stats(void* translator, struct ct2x_exec_stats* stats);
  * and the session has at least 64 rows - CT2X_COMPACT_MIN_ROWS overrides, 0 = never). -1: bad handle. */
 int64_t ct2x_last_compactions(void* translator);
 /* Session reuse: a Translator keeps the decoding session (buffers + captured step graphs) of its
- * last PLAIN greedy ct2x_translate_batch call - beam_size 1, arg-max sampling, one hypothesis, no
- * prefix, no logits processors, no attention / logits / callback, one stream, the whole batch in one
- * group - and a call with the same padded shape (rows, longest source) and the same device-side
- * options (max / min decoding length, return_scores, end token, use_graph) re-runs its encoder into
+ * last PLAIN ct2x_translate_batch call - greedy or beam search with arg-max sampling, no prefix, no
+ * logits processors, no attention / logits / callback, one stream, the whole batch in one group -
+ * and a call with the same padded shape (rows, longest source) and the same device-side options
+ * (beam size, max / min decoding length, return_scores, end token, use_graph) re-runs its encoder into
  * those buffers and replays the graphs: no allocation, capture or instantiation (~0.45 ms of a 20 ms
  * Transformer-base call). Results are those of a fresh session (tests/test_session_reuse_gpu.py);
  * CT2X_SESSION_CACHE=0 switches it off; the session's device memory is released with the

@@ -39,7 +39,7 @@ run(A, **kw)                                  # miss: shape again
 run(A, **dict(kw, max_decoding_length=20))    # miss: option
 run(A, **dict(kw, max_decoding_length=20))    # hit
 run(A, **dict(kw, return_scores=False))       # miss: option
-run(A, beam_size=2, return_scores=True, max_decoding_length=24)   # not plain: drops the session
+run(A, beam_size=2, return_scores=True, max_decoding_length=24)   # miss: another search
 run(A, **kw)                                  # miss
 run(A, target_prefix=[["a"], [], ["b"], []], **kw)                # not plain
 run(A, **kw)                                  # miss
@@ -53,6 +53,15 @@ run(B[:3], min_decoding_length=9, **kw)       # hit
 # early stop by an end token other than </s> changes a kernel argument: part of the key
 run(A, end_token="t", **kw)
 run(B, end_token="t", **kw)
+# beam search sessions are kept too (ancestry tables back to the identity, first cache set)
+kwb = dict(beam_size=4, num_hypotheses=2, return_scores=True, max_decoding_length=24)
+run(A, **kwb)                                 # miss
+run(B, **kwb)                                 # hit
+run(A, **kwb)                                 # hit: identical to the first
+run(A, length_penalty=0.6, **kwb)             # hit: the length penalty is host arithmetic
+run(A, **dict(kwb, beam_size=3))              # miss
+run(C, **dict(kwb, beam_size=3))              # miss: shape
+run(C[::-1], **dict(kwb, beam_size=3))        # miss: other lengths per row, same padded shape -> hit
 # a synthetic Transformer with a vocabulary wide enough for the fused sampler, long forced decoding
 d = "/tmp/ct2x_session_tb"
 if not os.path.exists(os.path.join(d, "model.bin")):
@@ -89,6 +98,9 @@ def test_a_reused_session_returns_what_a_fresh_one_returns(gpu):
     # the calls marked "hit" above, cumulative
     assert reused["hits"][:19] == [0, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4, 4, 5, 5, 6]
     assert reused["hits"][20] == reused["hits"][19] + 1
+    h = reused["hits"][20]
+    assert reused["hits"][21:28] == [h, h + 1, h + 2, h + 3, h + 3, h + 3, h + 4]
+    assert reused["out"][21] == reused["out"][23]
     assert reused["hits"][-1] == 3
     # the same sentences gave the same result with and without a session in between
     assert reused["out"][0] == reused["out"][2]
