@@ -185,7 +185,8 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
     const int64_t target = std::min(max_step, launched + sync_every);
     if (target == launched) return false;
     Group g{launched, target - launched, next_slot};
-    for (; launched < target; ++launched) engine.step(st, opt.use_graph);
+    engine.step_group(st, static_cast<int>(g.count), opt.use_graph);
+    launched = target;
     engine.read_history_async(st, opt.start_step + g.first, g.count, g.slot);
     next_slot ^= 1;
     inflight.push_back(g);
@@ -444,7 +445,8 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
     const int64_t target = std::min(max_step, launched + sync_every);
     if (target == launched) return false;
     Group g{launched, target - launched, next_slot};
-    for (; launched < target; ++launched) engine.step(st, opt.use_graph);
+    engine.step_group(st, static_cast<int>(g.count), opt.use_graph);
+    launched = target;
     engine.read_beam_history_async(st, g.first, g.count, g.slot);
     next_slot ^= 1;
     inflight.push_back(g);

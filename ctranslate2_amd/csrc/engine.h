@@ -219,6 +219,10 @@ public:
   // encoder again, for new sentences of the SAME padded shape (batch, s_max), into the buffers of a
   // finished session - allocations, tables and the step graphs captured over those buffers stay.
   void reencode(DecodeState& state, const int32_t* src_ids, const int32_t* src_lengths);
+  // `count` consecutive greedy steps. A session that is being reused replays them from ONE graph
+  // (the step counter lives in device memory, so the captured sequence serves any `count` steps
+  // in a row); every other session - and every other count - takes them one by one (step()).
+  void step_group(DecodeState& state, int count, bool graph);
   // Whisper: `features` [batch, n_mels, frames] (host) go through the convolutional front end and
   // the encoder (WhisperEncoder::operator(), src/layers/whisper.cc:26-62); the memory has
   // whisper_memory_length(frames) positions.
@@ -627,6 +631,11 @@ struct DecodeState {
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // one per cache parity
   bool graph_failed = false;  // capture refused (tensor parallel + collective library): eager
   bool graph_ready[2] = {false, false};
+  // a whole group of greedy steps as ONE graph (Engine::step_group; reused sessions only)
+  hipGraphExec_t group_exec = nullptr;
+  int group_steps = 0;
+  int group_parity = 0;
+  int64_t reuses = 0;  // times Engine::reencode restarted this session
 
   ~DecodeState();
 };

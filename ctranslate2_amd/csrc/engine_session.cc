@@ -31,6 +31,7 @@ DecodeState::~DecodeState() {
   }
   for (int i = 0; i < 2; ++i) {
     if (graph_exec[i]) (void)hipGraphExecDestroy(graph_exec[i]);
+    if (i == 0 && group_exec) (void)hipGraphExecDestroy(group_exec);
     pinned_free(pin_ids[i]);
     pinned_free(pin_scores[i]);
     if (pin_event[i]) (void)hipEventDestroy(pin_event[i]);
@@ -312,6 +313,7 @@ void Engine::reencode(DecodeState& st, const int32_t* src_ids, const int32_t* sr
   CT2X_HIP_CHECK(hipMemsetAsync(st.d_step, 0, sizeof(int32_t), cur_stream()));
   st.cur = 0;
   st.fuse_greedy = st.fuse_beam = false;
+  ++st.reuses;
   if (st.ancestry) {
     const size_t bytes = static_cast<size_t>((st.t_max + 1) * st.rows) * sizeof(int32_t);
     for (int i = 0; i < 2; ++i)

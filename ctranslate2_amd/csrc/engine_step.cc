@@ -535,6 +535,55 @@ void Engine::step(DecodeState& st, bool graph) {
   if (st.fuse_beam) st.cur ^= 1;
 }
 
+void Engine::step_group(DecodeState& st, int count, bool graph) {
+  static const int group_graph = [] {
+    const char* e = std::getenv("CT2X_GROUP_GRAPH");
+    return e ? std::atoi(e) : 1;
+  }();
+  // (beam search alternates between two cache / table sets: an even count ends on the parity it
+  // started from, and the graph serves the groups that start on the parity it was captured at)
+  const bool eligible = graph && group_graph != 0 && count > 1 && (st.fuse_greedy != st.fuse_beam) &&
+                        (!st.fuse_beam || count % 2 == 0) &&
+                        !profiling_ && !tp_ && !taps_ && !st.graph_failed &&
+                        (st.reuses >= 1 || group_graph == 2) && st.graph_ready[st.cur] &&
+                        (st.group_exec == nullptr ||
+                         (st.group_steps == count && st.group_parity == st.cur));
+  if (!eligible) {
+    for (int i = 0; i < count; ++i) step(st, graph);
+    return;
+  }
+  tls_stream = st.stream;
+  set_active_stream(tls_stream);
+  CT2X_HIP_CHECK(hipSetDevice(device_));
+  if (st.group_exec == nullptr) {
+    static std::mutex capture_mutex;
+    std::lock_guard<std::mutex> capture_lock(capture_mutex);
+    hipGraph_t g = nullptr;
+    CT2X_HIP_CHECK(hipStreamBeginCapture(cur_stream(), hipStreamCaptureModeThreadLocal));
+    const int parity = st.cur;
+    try {
+      for (int i = 0; i < count; ++i) {
+        launch_step(st);
+        if (st.fuse_beam) st.cur ^= 1;
+      }
+    } catch (...) {
+      hipGraph_t dead = nullptr;
+      (void)hipStreamEndCapture(cur_stream(), &dead);
+      if (dead) (void)hipGraphDestroy(dead);
+      st.cur = parity;
+      throw;
+    }
+    st.cur = parity;  // (count is even under beam search)
+    CT2X_HIP_CHECK(hipStreamEndCapture(cur_stream(), &g));
+    CT2X_HIP_CHECK(hipGraphInstantiate(&st.group_exec, g, nullptr, nullptr, 0));
+    CT2X_HIP_CHECK(hipGraphDestroy(g));
+    st.group_steps = count;
+    st.group_parity = parity;
+  }
+  CT2X_HIP_CHECK(hipGraphLaunch(st.group_exec, cur_stream()));
+  if (st.graph_kernels > 0) kernels_per_step_ = st.graph_kernels;
+}
+
 void Engine::advance_step(DecodeState& st) {
   tls_stream = st.stream;
   set_active_stream(tls_stream);
@@ -767,6 +816,9 @@ void Engine::compact_rows(DecodeState& st, const std::vector<int32_t>& keep, int
     st.graph_exec[i] = nullptr;
     st.graph_ready[i] = false;
   }
+  if (st.group_exec) (void)hipGraphExecDestroy(st.group_exec);
+  st.group_exec = nullptr;
+  st.group_steps = 0;
 }
 
 bool Engine::beam_compactable(const DecodeState& st) const {
@@ -845,6 +897,9 @@ void Engine::compact_beam_entries(DecodeState& st, const std::vector<int32_t>& k
     st.graph_exec[i] = nullptr;
     st.graph_ready[i] = false;
   }
+  if (st.group_exec) (void)hipGraphExecDestroy(st.group_exec);
+  st.group_exec = nullptr;
+  st.group_steps = 0;
 }
 
 void Engine::set_prefix(DecodeState& st, const std::vector<std::vector<int32_t>>& prefix,
