@@ -17,6 +17,14 @@
 
 namespace ct2x {
 
+// One capture at a time per process: concurrent captures from several worker threads fail on
+// ROCm 7.2 ("operation failed due to a previous error during capture"); replays are free.
+static std::mutex& graph_capture_mutex() {
+  static std::mutex m;
+  return m;
+}
+
+
 // TransformerDecoder::decode for one step (src/layers/transformer.cc:621-871) with
 // TransformerDecoderLayer::operator() (standard pre/post-norm arm, :334-365).
 void Engine::launch_step(DecodeState& st) {
@@ -321,9 +329,13 @@ void Engine::launch_step(DecodeState& st) {
       }
     }
     const bool ride = fused_argmax_applicable(st);
-    if (ride) argmax_state_ = &st;
-    dense(dec_.projection, proj_in, pq.q ? &pq : nullptr, rows, -1, nullptr, st.logits, &st);
-    argmax_state_ = nullptr;
+    {
+      struct ArgmaxScope {  // (cleared on every way out: the pointer must not outlive the launch)
+        explicit ArgmaxScope(const DecodeState* s) { Engine::argmax_state_ = s; }
+        ~ArgmaxScope() { Engine::argmax_state_ = nullptr; }
+      } scope(ride ? &st : nullptr);
+      dense(dec_.projection, proj_in, pq.q ? &pq : nullptr, rows, -1, nullptr, st.logits, &st);
+    }
     fused_argmax = ride;
   }
 
@@ -488,8 +500,7 @@ void Engine::step(DecodeState& st, bool graph) {
   if (!st.graph_ready[parity]) {
     // One capture at a time per process: concurrent captures from several worker threads fail on
     // ROCm 7.2 ("operation failed due to a previous error during capture"); replays are free.
-    static std::mutex capture_mutex;
-    std::lock_guard<std::mutex> capture_lock(capture_mutex);
+    std::lock_guard<std::mutex> capture_lock(graph_capture_mutex());
     hipGraph_t g = nullptr;
     const int64_t before = tls_launches;
     CT2X_HIP_CHECK(hipStreamBeginCapture(cur_stream(), hipStreamCaptureModeThreadLocal));
@@ -556,8 +567,7 @@ void Engine::step_group(DecodeState& st, int count, bool graph) {
   set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipSetDevice(device_));
   if (st.group_exec == nullptr) {
-    static std::mutex capture_mutex;
-    std::lock_guard<std::mutex> capture_lock(capture_mutex);
+    std::lock_guard<std::mutex> capture_lock(graph_capture_mutex());
     hipGraph_t g = nullptr;
     CT2X_HIP_CHECK(hipStreamBeginCapture(cur_stream(), hipStreamCaptureModeThreadLocal));
     const int parity = st.cur;

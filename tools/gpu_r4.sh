@@ -55,11 +55,25 @@ library_ab)       # profiles/r04_pinned_cache_ab.txt: build_ab/libct2_prev.so (a
       echo "== beam 4, library: ${lib:-this build}"; CT2X_LIBRARY=$lib timeout 300 python bench.py --beam 4 --steps 20 --warmup 3 $NOLEGS 2>/dev/null | line
     done
   } 2>&1 | tee $O/library_ab.txt ;;
+switch_ab)        # profiles/r04_fused_argmax_ab.txt, r04_session_reuse_ab.txt: gpu_r4.sh switch_ab <ENV_NAME> [bench flags]
+  # e.g. switch_ab CT2X_FUSED_ARGMAX | switch_ab CT2X_SESSION_CACHE | switch_ab CT2X_GROUP_GRAPH --beam 4
+  V=$2; shift 2
+  { for f in 0 1 0 1; do echo "== $V=$f $*"; env $V=$f timeout 300 python bench.py --steps 20 --warmup 3 $NOLEGS "$@" 2>/dev/null | line; done
+  } 2>&1 | tee $O/switch_ab_$V.txt ;;
+switch_rocprof)   # per-launch times under both settings of a switch: gpu_r4.sh switch_rocprof <ENV_NAME> [bench flags]
+  V=$2; shift 2
+  for f in 0 1; do
+    ( cd /tmp && env $V=$f timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sw$f -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 $NOLEGS "$@" > /tmp/prof_sw$f.log 2>&1 )
+    cp "$(find /tmp/prof_sw$f -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_${V}_$f.csv; echo "== $V=$f"; head -10 $O/kernel_stats_${V}_$f.csv | cut -c1-160
+  done ;;
+beam4_rocprof)    # profiles/r04_kernel_stats_bench_tb_beam4.csv
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b4 -- python $GRAFT_REPO_ROOT/bench.py --beam 4 --steps 6 --warmup 2 $NOLEGS > /tmp/prof_b4.log 2>&1 )
+  cp "$(find /tmp/prof_b4 -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_bench_tb_beam4.csv; head -20 $O/kernel_stats_bench_tb_beam4.csv | cut -c1-160 ;;
 whisper)          # the Whisper-large-v3 shape
   timeout 900 python tools/bench_whisper.py --steps 2 --warmup 1 | tee $O/whisper.json | cut -c1-400 ;;
 all)              # the whole -m gpu suite, smoke and the default bench line
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -3 $O/pytest_all.log
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json ;;
-*) echo "sections: mfma_rate gemm_bench l8_prologue_ab l8_prologue_rocprof nllb gemm_h_bench compaction compaction_bench library_ab whisper all"; exit 2 ;;
+*) echo "sections: mfma_rate gemm_bench l8_prologue_ab l8_prologue_rocprof nllb gemm_h_bench compaction compaction_bench library_ab switch_ab switch_rocprof beam4_rocprof whisper all"; exit 2 ;;
 esac
