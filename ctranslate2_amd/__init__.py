@@ -596,6 +596,12 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                                                          C.c_int64(table.shape[0]),
                                                          C.c_int64(table.shape[1])))
 
+    def release_session(self):
+        """Frees the decoding session kept for reuse by the next translate call of the same shape
+        (ct2x_release_session; the reference's counterpart is Translator.unload_model's allocator
+        cache release)."""
+        _lib.check(self._L.ct2x_release_session(C.c_void_p(self._h)))
+
     def profile_begin(self):
         _lib.check(self._L.ct2x_profile_begin(C.c_void_p(self._h)))
 

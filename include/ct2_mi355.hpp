@@ -518,6 +518,10 @@ public:
     return results;
   }
 
+  // Frees the decoding session kept for reuse by the next call of the same shape (ct2_mi355.h,
+  // "Session reuse"); it is rebuilt by the next call.
+  void release_session() { detail::check(ct2x_release_session(h_.get())); }
+
   // ExecutionStats-like counters of the last call (include/ctranslate2/translator.h:9-13)
   ct2x_exec_stats last_stats() const {
     ct2x_exec_stats st;
