@@ -49,6 +49,9 @@ def parse_args():
     p.add_argument("--streams", type=int, default=0,
                    help="concurrent decode streams per GPU (0 = library default)")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-session-reuse", action="store_true",
+                   help="every translate call builds its own decoding session (CT2X_SESSION_CACHE=0): "
+                        "the A/B of DESIGN 5.000 'Session reuse'")
     p.add_argument("--compute-type", default="int8",
                    help="int8 (the metric), float16, bfloat16 or float32: same model, weights "
                         "converted at load")
@@ -316,6 +319,8 @@ def cpu_baseline(model_dir, sources, args):
 
 def main():
     args = parse_args()
+    if args.no_session_reuse:
+        os.environ["CT2X_SESSION_CACHE"] = "0"  # (read by the library at its first translate call)
     rank, local_rank, world = shard_info()
     import torch
     import torch.distributed as dist
