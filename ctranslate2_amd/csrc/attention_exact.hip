@@ -22,6 +22,7 @@
 // Checked bit for bit against oracle/ct2_oracle.c (orc_attention_decode), which is itself pinned
 // bit for bit against the reference library (tests/test_oracle.py::test_exact_*).
 
+#include "attention_exact_core.h"
 #include "device_utils.h"
 #include "kernels.h"
 #include "runtime.h"
@@ -34,62 +35,6 @@
 namespace ct2x {
 
 namespace {
-
-__device__ __forceinline__ float tree16(float (&a)[16]) {
-#pragma unroll
-  for (int w = 8; w >= 1; w >>= 1)
-#pragma unroll
-    for (int l = 0; l < w; ++l) a[l] = a[l] + a[l + w];
-  return a[0];
-}
-
-// MKL's m = 1 dot product over k = K (K <= 64; longer rows use another tail form that was not
-// recovered), "main" form (keys in the groups of four): lane accumulators over k = 1 .. body,
-// lane (k - 1) % 16, accumulator 0 seeded with q0*k0; the remainder k = body + 1 .. K - 1 goes
-// through a second 16-lane tree whose lane 0 fuses its product onto the first tree's sum.
-template <int K>
-__device__ __forceinline__ float dot_main(const float (&q)[K], const float (&k)[K]) {
-  constexpr int body = ((K - 1) / 16) * 16;
-  float acc[16], r[16];
-  acc[0] = q[0] * k[0];
-#pragma unroll
-  for (int l = 1; l < 16; ++l) acc[l] = 0.f;
-#pragma unroll
-  for (int t = 1; t <= body; ++t) acc[(t - 1) & 15] = fmaf(q[t], k[t], acc[(t - 1) & 15]);
-  const float s = tree16(acc);
-#pragma unroll
-  for (int l = 0; l < 16; ++l) r[l] = 0.f;
-  r[0] = fmaf(q[body + 1], k[body + 1], s);
-#pragma unroll
-  for (int t = body + 2; t < K; ++t) r[t - body - 1] = q[t] * k[t];
-  return tree16(r);
-}
-
-// ... and the "tail" forms (the n % 4 last keys): element 0 is added last as a rounded product;
-// type A (first and third tail key) adds the second 16-channel chunk as a rounded product when
-// the row is longer than two chunks, type B (second tail key) fuses every chunk.
-template <int K>
-__device__ __forceinline__ float dot_tail(const float (&q)[K], const float (&k)[K], bool type_a) {
-  float acc[16];
-#pragma unroll
-  for (int l = 0; l < 16; ++l) acc[l] = 0.f;
-#pragma unroll
-  for (int t = 1; t < K; ++t) {
-    const int l = (t - 1) & 15, c = (t - 1) >> 4;
-    if (c == 0) {
-      acc[l] = q[t] * k[t];
-    } else if (c == 1 && K > 33) {
-      const float prod = q[t] * k[t];
-      const float fused = fmaf(q[t], k[t], acc[l]);
-      acc[l] = type_a ? acc[l] + prod : fused;
-    } else {
-      acc[l] = fmaf(q[t], k[t], acc[l]);
-    }
-  }
-  const float s = tree16(acc);
-  const float p0 = q[0] * k[0];
-  return s + p0;
-}
 
 template <int K>
 __device__ __forceinline__ float dot_seq(const float (&q)[K], const float (&k)[K]) {

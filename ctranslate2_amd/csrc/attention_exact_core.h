@@ -1,0 +1,246 @@
+// The arithmetic core of the exact decode attention (attention_exact.hip), shared with the
+// cluster-resident decoder stack (decoder_cluster.hip): MKL's one-query-row dot-product forms and
+// ONE wave's pass over a (row, head) - QK^T, SoftMax, P.V - in the reference CPU path's order.
+// See the header comment of attention_exact.hip for where each order comes from; everything here
+// is checked bit for bit against oracle/ct2_oracle.c (orc_attention_decode).
+#pragma once
+
+#include <float.h>
+
+#include "device_utils.h"
+
+namespace ct2x {
+
+__device__ __forceinline__ float tree16(float (&a)[16]) {
+#pragma unroll
+  for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+    for (int l = 0; l < w; ++l) a[l] = a[l] + a[l + w];
+  return a[0];
+}
+
+// MKL's m = 1 dot product over k = K (K <= 64; longer rows use another tail form that was not
+// recovered), "main" form (keys in the groups of four): lane accumulators over k = 1 .. body,
+// lane (k - 1) % 16, accumulator 0 seeded with q0*k0; the remainder k = body + 1 .. K - 1 goes
+// through a second 16-lane tree whose lane 0 fuses its product onto the first tree's sum.
+template <int K>
+__device__ __forceinline__ float dot_main(const float (&q)[K], const float (&k)[K]) {
+  constexpr int body = ((K - 1) / 16) * 16;
+  float acc[16], r[16];
+  acc[0] = q[0] * k[0];
+#pragma unroll
+  for (int l = 1; l < 16; ++l) acc[l] = 0.f;
+#pragma unroll
+  for (int t = 1; t <= body; ++t) acc[(t - 1) & 15] = fmaf(q[t], k[t], acc[(t - 1) & 15]);
+  const float s = tree16(acc);
+#pragma unroll
+  for (int l = 0; l < 16; ++l) r[l] = 0.f;
+  r[0] = fmaf(q[body + 1], k[body + 1], s);
+#pragma unroll
+  for (int t = body + 2; t < K; ++t) r[t - body - 1] = q[t] * k[t];
+  return tree16(r);
+}
+
+// ... and the "tail" forms (the n % 4 last keys): element 0 is added last as a rounded product;
+// type A (first and third tail key) adds the second 16-channel chunk as a rounded product when
+// the row is longer than two chunks, type B (second tail key) fuses every chunk.
+template <int K>
+__device__ __forceinline__ float dot_tail(const float (&q)[K], const float (&k)[K], bool type_a) {
+  float acc[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) acc[l] = 0.f;
+#pragma unroll
+  for (int t = 1; t < K; ++t) {
+    const int l = (t - 1) & 15, c = (t - 1) >> 4;
+    if (c == 0) {
+      acc[l] = q[t] * k[t];
+    } else if (c == 1 && K > 33) {
+      const float prod = q[t] * k[t];
+      const float fused = fmaf(q[t], k[t], acc[l]);
+      acc[l] = type_a ? acc[l] + prod : fused;
+    } else {
+      acc[l] = fmaf(q[t], k[t], acc[l]);
+    }
+  }
+  const float s = tree16(acc);
+  const float p0 = q[0] * k[0];
+  return s + p0;
+}
+
+
+// One wave, one (row, head), d_head 64, one query row (the m = 1 forms), no RoPE, no ancestry
+// table: the body of attn_x_decode_kernel<64> without its launch-latency tricks, for callers that
+// already hold q and the new key / value in registers (lane = channel).
+//   qd, knew, vnew  this lane's channel of q, of the step's new key and value (has_new)
+//   kc, vc          cache rows of the (row, head): key t at kc + t * kvs; the caller has ALREADY
+//                   stored the new key / value at position t_cached (or will: they are taken from
+//                   the registers, never re-read)
+//   t_cached        keys in the cache before this step (self-attention) / valid memory length
+//   n_keys          n of the reference's MatMul: t_cached + 1 (self) or the PADDED memory length
+//   n_valid         size of the SoftMax
+//   tq [64], tp [t_pad], ks [64][68]: this wave's LDS scratch
+// Returns this lane's channel of the context.
+__device__ __noinline__ float attn_exact_wave64(float qd, bool has_new, float knew, float vnew,
+                                                   const float* __restrict__ kc,
+                                                   const float* __restrict__ vc, int kvs, int t_cached,
+                                                   int n_keys, int n_valid, float scale, float* tq,
+                                                   float* tp, int t_pad, float* ks) {
+  constexpr int DH = 64, XKS = DH + 4, R4 = DH / 4, KPI = 64 / R4, XVB = 16;
+  const int lane = threadIdx.x & 63;
+  const int cl = lane;
+  const int pos = t_cached;
+  const int t_last = max(t_cached - 1, 0);  // loads are clamped to rows that were written
+  v4f kpre[R4];
+#pragma unroll
+  for (int it = 0; it < R4; ++it) {
+    kpre[it] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (it * KPI < n_keys) {
+      const int i_ = it * 64 + lane;
+      const int tl = min(i_ / R4, t_last);
+      kpre[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+    }
+  }
+#define CT2X_CW_LOAD_V(VR, T0)                                            \
+  _Pragma("unroll") for (int j = 0; j < XVB; ++j) {                       \
+    const int t_ = (T0) + j;                                              \
+    const int tc_ = min(t_, t_last);                                      \
+    const float g_ = vc[tc_ * kvs + cl];                                  \
+    VR[j] = (has_new && t_ == pos) ? vnew : g_;                           \
+  }
+  float vr[4][XVB];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    if (b * XVB < n_keys) CT2X_CW_LOAD_V(vr[b], b * XVB)
+  tq[cl] = qd;
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- QK^T: lane = key
+  const int main_n = (n_keys / 4) * 4;
+  float s_reg = 0.f;
+  float m_run = -FLT_MAX;
+  const bool single = n_keys <= 64;
+  for (int t0 = 0; t0 < n_keys; t0 += 64) {
+    const int n_tile = min(64, n_keys - t0);
+    v4f st[R4];
+    if (t0 == 0) {
+#pragma unroll
+      for (int it = 0; it < R4; ++it) st[it] = kpre[it];
+    } else {
+#pragma unroll
+      for (int it = 0; it < R4; ++it) {
+        st[it] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (it * KPI < n_tile) {
+          const int i_ = it * 64 + lane;
+          const int tl = min(t0 + i_ / R4, t_last);
+          st[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < R4; ++it) {
+      if (it * KPI < n_tile) {
+        const int i_ = it * 64 + lane;
+        *reinterpret_cast<v4f*>(ks + (i_ / R4) * XKS + (i_ % R4) * 4) = st[it];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (has_new && pos >= t0 && pos < t0 + 64) ks[(pos - t0) * XKS + cl] = knew;
+    __builtin_amdgcn_wave_barrier();
+    const int t = t0 + lane;
+    float s = 0.f;
+    if (lane < n_tile) {
+      float qv[DH], kv[DH];
+      const v4f* krow = reinterpret_cast<const v4f*>(ks + lane * XKS);
+      const v4f* qrow = reinterpret_cast<const v4f*>(tq);
+#pragma unroll
+      for (int c = 0; c < R4; ++c) {
+        const v4f k4 = krow[c], q4 = qrow[c];
+        kv[4 * c + 0] = k4.x; kv[4 * c + 1] = k4.y; kv[4 * c + 2] = k4.z; kv[4 * c + 3] = k4.w;
+        qv[4 * c + 0] = q4.x; qv[4 * c + 1] = q4.y; qv[4 * c + 2] = q4.z; qv[4 * c + 3] = q4.w;
+      }
+      if (t < main_n) s = dot_main<DH>(qv, kv);
+      else s = dot_tail<DH>(qv, kv, (t - main_n) != 1);
+      s = s * scale;
+      if (!single) tp[t] = s;
+      if (t < n_valid) m_run = fmaxf(m_run, s);
+    }
+    s_reg = s;
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- SoftMax over the n_valid leading keys; masked keys get probability 0
+  const float m = wave_max_dpp(m_run);
+  float e_reg = 0.f;
+  if (single) {
+    e_reg = (lane < n_valid) ? exp_avx2(s_reg - m) : 0.f;
+    for (int t = lane; t < t_pad; t += 64) tp[t] = (t == lane) ? e_reg : 0.f;
+  } else {
+    for (int t = lane; t < t_pad; t += 64) {
+      const float sc = tp[t];
+      tp[t] = (t < n_valid) ? exp_avx2(sc - m) : 0.f;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float esum = ordered_sum8_short(tp, n_valid);
+  const float rcp = 1.f / esum;
+  __builtin_amdgcn_wave_barrier();
+  if (single) {
+    if (lane < n_valid) tp[lane] = e_reg * rcp;
+  } else {
+    for (int t = lane; t < n_valid; t += 64) tp[t] = tp[t] * rcp;
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- P.V: lane = channel
+  float y = 0.f;
+  bool has = false;
+  const int n_blocks = n_keys / 8;
+#define CT2X_CW_BLOCK(VR, J0, T0)                                                            \
+  {                                                                                          \
+    const v4f pa_ = *reinterpret_cast<const v4f*>(tp + (T0));                                \
+    const v4f pb_ = *reinterpret_cast<const v4f*>(tp + (T0) + 4);                            \
+    if ((T0) + 8 <= n_blocks * 8) {                                                          \
+      const float A_ = fmaf(pa_.x, VR[J0 + 0], pa_.z * VR[J0 + 2]);                          \
+      const float B_ = fmaf(pa_.y, VR[J0 + 1], pa_.w * VR[J0 + 3]);                          \
+      const float c6_ = has ? fmaf(pb_.z, VR[J0 + 6], y) : pb_.z * VR[J0 + 6];               \
+      const float C_ = fmaf(pb_.x, VR[J0 + 4], c6_);                                         \
+      const float D_ = fmaf(pb_.y, VR[J0 + 5], pb_.w * VR[J0 + 7]);                          \
+      y = (C_ + D_) + (A_ + B_);                                                             \
+      has = true;                                                                            \
+    } else {                                                                                 \
+      const float pj_[8] = {pa_.x, pa_.y, pa_.z, pa_.w, pb_.x, pb_.y, pb_.z, pb_.w};         \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
+        if ((T0) + j < n_keys) {                                                             \
+          y = has ? fmaf(pj_[j], VR[J0 + j], y) : pj_[j] * VR[J0 + j];                       \
+          has = true;                                                                        \
+        }                                                                                    \
+      }                                                                                      \
+    }                                                                                        \
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (b * XVB < n_keys) {
+      CT2X_CW_BLOCK(vr[b], 0, b * XVB)
+      if (b * XVB + 8 < n_keys) CT2X_CW_BLOCK(vr[b], 8, b * XVB + 8)
+    }
+  }
+  if (n_keys > 4 * XVB) {  // longer rows: two batches in flight, alternating
+    CT2X_CW_LOAD_V(vr[0], 4 * XVB)
+    for (int t0 = 4 * XVB; t0 < n_keys; t0 += 2 * XVB) {
+      CT2X_CW_LOAD_V(vr[1], t0 + XVB)
+      CT2X_CW_BLOCK(vr[0], 0, t0)
+      if (t0 + 8 < n_keys) CT2X_CW_BLOCK(vr[0], 8, t0 + 8)
+      if (!(t0 + XVB < n_keys)) break;
+      CT2X_CW_LOAD_V(vr[0], t0 + 2 * XVB)
+      CT2X_CW_BLOCK(vr[1], 0, t0 + XVB)
+      if (t0 + XVB + 8 < n_keys) CT2X_CW_BLOCK(vr[1], 8, t0 + XVB + 8)
+    }
+  }
+#undef CT2X_CW_LOAD_V
+#undef CT2X_CW_BLOCK
+  asm volatile("" ::"v"(y));
+  return y;
+}
+
+}  // namespace ct2x

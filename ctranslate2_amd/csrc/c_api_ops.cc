@@ -215,6 +215,40 @@ int ct2x_gemm_s8_dequant(const int8_t* d_qa, const float* d_a_scale, const int8_
   API_CATCH
 }
 
+// scratch layout: [m, kSubSlots] packed maxima | ticket, step | [m] history ids | [m] history scores
+int64_t ct2x_gemm_s8_argmax_scratch_bytes(int64_t m) {
+  return static_cast<int64_t>(sizeof(unsigned long long)) * m * GreedyFuse::kSubSlots + 64 + 8 * m;
+}
+
+int ct2x_gemm_s8_argmax(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w,
+                        const float* d_w_scale, const float* d_bias, int64_t m, int64_t n, int64_t k,
+                        int32_t* d_ids_out, void* d_scratch, void* stream) {
+  API_TRY
+  CT2X_CHECK(gemm_s8_argmax_applicable(m, n, k),
+             "ct2x_gemm_s8_argmax: needs m <= 32, n >= 8192, k % 16 == 0, k < 4096");
+  char* base = static_cast<char*>(d_scratch);
+  GemmS8Epilogue ep;
+  ep.mode = 1;
+  ep.a_scale = d_a_scale;
+  ep.w_scale = d_w_scale;
+  ep.bias = d_bias;
+  ep.y = reinterpret_cast<float*>(base);  // never written in this form
+  ep.ldy = n;
+  ep.gf.slots = reinterpret_cast<unsigned long long*>(base);
+  base += sizeof(unsigned long long) * m * GreedyFuse::kSubSlots;
+  ep.gf.ticket = reinterpret_cast<unsigned int*>(base);
+  ep.gf.step_ptr = reinterpret_cast<const int32_t*>(base + 16);  // stays 0: row 0 of the history
+  base += 64;
+  ep.gf.next_ids = d_ids_out;
+  ep.gf.hist_ids = reinterpret_cast<int32_t*>(base);
+  ep.gf.hist_scores = reinterpret_cast<float*>(base + 4 * m);
+  hipStream_t s = resolve_stream(stream);
+  launch_gemm_s8(d_qa, d_w, m, n, k, ep, s);
+  check_last_launch("gemm_s8_argmax");
+  CT2X_HIP_CHECK(hipMemsetAsync(ep.gf.hist_ids, 0, 8 * m, s));
+  API_CATCH
+}
+
 int ct2x_gemm_s8_glu(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w0,
                      const float* d_w0_scale, const float* d_b0, const int8_t* d_w1,
                      const float* d_w1_scale, const float* d_b1, int64_t m, int64_t n, int64_t k,

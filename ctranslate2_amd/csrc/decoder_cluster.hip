@@ -1,0 +1,415 @@
+// Cluster-resident decoder stack: ALL layers of one greedy decode step of an int8 encoder-decoder
+// Transformer (TransformerDecoder::operator() one step, src/layers/transformer.cc:621-871, the
+// layer body :196-366) as ONE launch, for gfx950.
+//
+// Why: at decode rows the step was 48 dependent launches of 5 - 8 us each, none of them bound by
+// bytes or flops: a launch boundary costs ~1.7 us plus the kernel's own chain of
+// dependent memory round trips. Measured this round (profiles/r05_row_resident_probe.txt): eight
+// workgroups hand a 256-byte line to each other through memory-side (sc1) atomics in 1.2 - 1.4 us,
+// and one CU pulls ~120 GB/s through its L2 whoever else reads the same lines. So:
+//
+//   * a batch ROW is owned by a CLUSTER of eight workgroups (one per attention head) for the whole
+//     step; member h computes head h's slice of every projection (an int8 GEMV over its own 1/8 of
+//     the weight rows: v_dot4_i32_i8, the row-wide MFMA tile would be 31/32 empty), runs head h's
+//     self- and encoder-decoder attention itself (QKV -> attention needs no hand-over at all), and
+//     every member redoes the row-wide LayerNorm / Quantize statistics for itself (redundant work
+//     is free here, a hand-over is not);
+//   * the members meet SIX times per layer (attention context x 2, residual stream x 3, the
+//     feed-forward inner row), never across clusters: no device-wide barrier exists in the launch;
+//   * the weights are re-packed once per model so that member h's slice of a Dense is contiguous
+//     and a wave's 64 lanes read 1 KB lines (chunk-major: 16 K-bytes of every row of the slice,
+//     then the next 16); blockIdx % 8 = member = the XCD the dispatcher deals the workgroup to, so
+//     an XCD's L2 only ever holds slice h of every weight (2.7 MB for Transformer-base);
+//   * the requests for the NEXT projection's weights leave before the member waits for its peers.
+//
+// Arithmetic: the int32 sums are exact in any order; every fp32 formula (Dequantize epilogue,
+// LayerNorm statistics, Quantize, attention) is the one the launch-per-op path runs (gemm_s8.hip,
+// row_norm.h, attention_exact_core.h) - the results are the same bits, which
+// tests/test_decoder_cluster_gpu.py checks against that path and the reference goldens.
+//
+// Hand-over rules (grid_sync.h): data published with agent-scope atomic stores, read with
+// agent-scope atomic loads, arrival = one relaxed atomicAdd after the stores have drained, bounded
+// polls - a lost peer raises the error flag, it never hangs the device.
+
+#include "attention_exact_core.h"
+#include "device_utils.h"
+#include "grid_sync.h"
+#include "kernels.h"
+#include "row_norm.h"
+#include "runtime.h"
+
+namespace ct2x {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kMembers = kClusterMembers;  // workgroups per row = attention heads
+constexpr int kThreads = 512;
+constexpr int kD = 512;      // d_model
+constexpr int kDH = 64;      // d_head
+constexpr int kFfn = 2048;   // feed-forward inner size
+constexpr int kXKS = kDH + 4;
+constexpr unsigned kSpinLimit = 1u << 21;
+
+// exchange areas of a row (floats): attention context, residual stream, feed-forward inner row
+constexpr int kXchCtx = 0, kXchX = kD, kXchInner = 2 * kD, kXchFloats = 2 * kD + kFfn;
+
+struct Shared {
+  float x_row[kD];                 // residual stream of the row
+  float stage[8 * 68 + 8];         // the row parked for the statistics chains (norm_chain_pad(512) = 68)
+  alignas(16) int8_t xq[kFfn];     // the quantised input row of the next GEMV
+  int part[kThreads];              // GEMV partial sums [kparts][rows of the slice]
+  float outv[256];                 // GEMV outputs of the slice (q | k | v, or the inner columns)
+  float red[16];
+  float tq[kDH];
+  float ks[64 * kXKS];
+  int dead;                        // a poll ran out: stop waiting, results are void
+};
+
+__device__ __forceinline__ int dot16(const v4i w, const v4i x, int acc) {
+  acc = __builtin_amdgcn_sdot4(w.x, x.x, acc, false);
+  acc = __builtin_amdgcn_sdot4(w.y, x.y, acc, false);
+  acc = __builtin_amdgcn_sdot4(w.z, x.z, acc, false);
+  acc = __builtin_amdgcn_sdot4(w.w, x.w, acc, false);
+  return acc;
+}
+
+// Member slice of a packed Dense: [chunks = K / 16][NS rows][16 bytes]. Thread t serves row
+// t % NS and the chunks [kp * CPT, (kp + 1) * CPT) with kp = t / NS (idle when kp >= KP).
+template <int NS, int KP, int CPT>
+struct Gemv {
+  v4i w[CPT];
+  __device__ __forceinline__ void request(const int8_t* __restrict__ slice) {
+    const int t = threadIdx.x, j = t % NS, kp = t / NS;
+    const v4i* base = reinterpret_cast<const v4i*>(slice) + static_cast<size_t>(kp) * CPT * NS + j;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) w[i] = (kp < KP) ? base[static_cast<size_t>(i) * NS] : v4i{0, 0, 0, 0};
+  }
+  // returns the int32 sum of row t of the slice to the threads t < NS (after two barriers)
+  __device__ __forceinline__ int finish(Shared& sh) {
+    const int t = threadIdx.x, kp = t / NS;
+    const v4i* xq4 = reinterpret_cast<const v4i*>(sh.xq) + (kp < KP ? kp : 0) * CPT;
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) acc = dot16(w[i], xq4[i], acc);
+    if (kp < KP) sh.part[t] = acc;
+    __syncthreads();
+    int sum = 0;
+    if (t < NS) {
+#pragma unroll
+      for (int p = 0; p < KP; ++p) sum += sh.part[p * NS + t];
+    }
+    return sum;
+  }
+};
+
+// Dequantize epilogue of layers::Dense (gemm_s8.hip: c * (1 / a_scale) / w_scale + bias, then the
+// activation, then the residual), one output column
+__device__ __forceinline__ float dense_epilogue(int sum, float r_a, float w_scale, bool has_bias, float bias,
+                                                int act) {
+  float v = static_cast<float>(sum) * r_a;
+  v = v / w_scale;
+  if (has_bias) v = v + bias;
+  return apply_activation(v, act);
+}
+
+__device__ __forceinline__ float block_absmax(float v, Shared& sh) {
+  float m = wave_max_dpp(fabsf(v));
+  __syncthreads();  // (red is reused)
+  if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = sh.red[0];
+#pragma unroll
+  for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, sh.red[w]);
+  return m;
+}
+
+// LayerNorm / RMSNorm of the row (element t in `v`) followed by ops::Quantize into sh.xq; returns
+// the quantisation scale. Every wave runs the statistics chain itself.
+__device__ __forceinline__ float norm_quantize_row(float v, const ClusterNormW& ln, int quant_mode, Shared& sh) {
+  const int t = threadIdx.x;
+  constexpr int pad = 68;
+  sh.stage[norm_chain_slot(t, kD, pad)] = v;
+  __syncthreads();
+  float sum, sumsq;
+  ordered_row_stats_t<true>(sh.stage, pad, kD, sum, sumsq);
+  const bool layer_norm = ln.beta != nullptr;
+  const NormStats st = norm_stats(sum, sumsq, kD, ln.eps, layer_norm);
+  const float y = norm_apply(v, ln.gamma[t], layer_norm ? ln.beta[t] : 0.f, st, layer_norm, ln.rms_use_residual != 0, t);
+  const float amax = block_absmax(y, sh);
+  const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+  sh.xq[t] = to_s8(y, scale, quant_mode);
+  __syncthreads();
+  return scale;
+}
+
+// ---- hand-over between the members of a cluster ---------------------------------------------
+struct Cluster {
+  unsigned* counter;
+  unsigned arrivals;  // value the counter reaches when every member has arrived at the NEXT meeting
+  int* error;
+};
+
+__device__ __forceinline__ void publish(float* dst, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(dst), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float observe(const float* src) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// first half: this member's published stores have left, it arrives
+__device__ __forceinline__ void arrive(Cluster& c) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_add(c.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  c.arrivals += kMembers;
+}
+// second half: wait until every member has arrived
+__device__ __forceinline__ void await(Cluster& c, Shared& sh) {
+  if (threadIdx.x == 0 && !sh.dead) {
+    unsigned spins = 0;
+    while (static_cast<int>(__hip_atomic_load(c.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - c.arrivals) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kSpinLimit) {
+        sh.dead = 1;
+        atomicExch(c.error, 1);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+}  // namespace
+
+// grid = rows * 8 workgroups of 512 threads; blockIdx = row * 8 + member
+__global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Shared& sh = *reinterpret_cast<Shared*>(smem_raw);
+  float* tp = reinterpret_cast<float*>(smem_raw + sizeof(Shared));  // attention scores [t_pad]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int member = blockIdx.x % kMembers, row = blockIdx.x / kMembers;
+  float* xch = a.xch + static_cast<size_t>(row) * kXchFloats;
+  Cluster cl;
+  cl.counter = a.counters + static_cast<size_t>(row) * 16;
+  cl.error = a.error;
+  if (t == 0) sh.dead = 0;
+  // where the counter stood when this launch began: the members of the previous launch all left
+  // at a multiple of kMembers, and at most kMembers - 1 early arrivals of THIS launch's first
+  // meeting can have been added since
+  cl.arrivals = __hip_atomic_load(cl.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / kMembers * kMembers;
+  const int step = *a.step_ptr;
+
+  // ---- embedding row (embed_kernel, rowops.hip), every member for itself ----------------------
+  float xv;
+  {
+    const int64_t id = a.ids[row];
+    const float* p = a.pos_table ? a.pos_table + static_cast<int64_t>(step) * kD : nullptr;
+    if (a.emb_int8) {
+      const int8_t* e = static_cast<const int8_t*>(a.emb_table) + id * kD;
+      const float r_s = 1.f / a.emb_scale[id];
+      xv = static_cast<float>(e[t]) * r_s;
+    } else {
+      xv = static_cast<const float*>(a.emb_table)[id * kD + t];
+    }
+    if (a.emb_apply_mul) xv = xv * a.emb_mul;
+    if (p) xv = xv + p[t];
+  }
+  sh.x_row[t] = xv;
+
+  Gemv<192, 2, 16> g_qkv;
+  g_qkv.request(a.layers[0].qkv.w + static_cast<size_t>(member) * 192 * kD);
+
+  for (int l = 0; l < a.n_layers; ++l) {
+    const ClusterLayerArgs& L = a.layers[l];
+    // ================= masked self-attention ==================================================
+    {
+      const float scale = norm_quantize_row(xv, L.ln_self, a.quant_mode, sh);
+      const int sum = g_qkv.finish(sh);
+      if (t < 192) {
+        const int col = (t >> 6) * kD + member * kDH + (t & 63);  // q | k | v sections of linear_0
+        sh.outv[t] = dense_epilogue(sum, 1.f / scale, L.qkv.wscale[col], L.qkv.bias != nullptr,
+                                    L.qkv.bias ? L.qkv.bias[col] : 0.f, -1);
+      }
+    }
+    Gemv<64, 8, 4> g_out;
+    g_out.request(L.self_out.w + static_cast<size_t>(member) * 64 * kD);
+    __syncthreads();
+    if (wave == 0) {
+      const int t_cached = max(0, min(step, a.t_max));
+      const float qd = sh.outv[lane], knew = sh.outv[64 + lane], vnew = sh.outv[128 + lane];
+      float* kc = L.self_k + (static_cast<int64_t>(row) * kMembers + member) * a.t_max * kDH;
+      float* vc = L.self_v + (static_cast<int64_t>(row) * kMembers + member) * a.t_max * kDH;
+      if (t_cached < a.t_max) {  // cache append in place of ops::Concat (attention.cc:541-546)
+        kc[t_cached * kDH + lane] = knew;
+        vc[t_cached * kDH + lane] = vnew;
+      }
+      const float ctx = attn_exact_wave64(qd, true, knew, vnew, kc, vc, kDH, t_cached, t_cached + 1,
+                                          t_cached + 1, L.self_scale, sh.tq, tp, a.t_pad, sh.ks);
+      publish(xch + kXchCtx + member * kDH + lane, ctx);
+    }
+    arrive(cl);
+    await(cl, sh);
+    // ---- attention output projection + residual ----------------------------------------------
+    {
+      const float c = observe(xch + kXchCtx + t);
+      const float amax = block_absmax(c, sh);
+      const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+      sh.xq[t] = to_s8(c, scale, a.quant_mode);
+      __syncthreads();
+      const int sum = g_out.finish(sh);
+      if (t < 64) {
+        const int col = member * kDH + t;
+        float v = dense_epilogue(sum, 1.f / scale, L.self_out.wscale[col], L.self_out.bias != nullptr,
+                                 L.self_out.bias ? L.self_out.bias[col] : 0.f, -1);
+        v = sh.x_row[col] + v;
+        publish(xch + kXchX + col, v);
+      }
+    }
+    arrive(cl);
+    Gemv<64, 8, 4> g_cq;
+    g_cq.request(L.cross_q.w + static_cast<size_t>(member) * 64 * kD);
+    await(cl, sh);
+    // ================= encoder-decoder attention ==============================================
+    xv = observe(xch + kXchX + t);
+    sh.x_row[t] = xv;
+    {
+      const float scale = norm_quantize_row(xv, L.ln_cross, a.quant_mode, sh);
+      const int sum = g_cq.finish(sh);
+      if (t < 64) {
+        const int col = member * kDH + t;
+        sh.outv[t] = dense_epilogue(sum, 1.f / scale, L.cross_q.wscale[col], L.cross_q.bias != nullptr,
+                                    L.cross_q.bias ? L.cross_q.bias[col] : 0.f, -1);
+      }
+    }
+    Gemv<64, 8, 4> g_co;
+    g_co.request(L.cross_out.w + static_cast<size_t>(member) * 64 * kD);
+    __syncthreads();
+    if (wave == 0) {
+      const int len = max(0, min(a.mem_lengths[row], a.s_max));
+      const float* kc = L.cross_kv + static_cast<int64_t>(row) * a.s_max * (2 * kD) + member * kDH;
+      const float ctx = attn_exact_wave64(sh.outv[lane], false, 0.f, 0.f, kc, kc + kD, 2 * kD, len, a.s_max,
+                                          len, L.cross_scale, sh.tq, tp, a.t_pad, sh.ks);
+      publish(xch + kXchCtx + member * kDH + lane, ctx);
+    }
+    arrive(cl);
+    await(cl, sh);
+    {
+      const float c = observe(xch + kXchCtx + t);
+      const float amax = block_absmax(c, sh);
+      const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+      sh.xq[t] = to_s8(c, scale, a.quant_mode);
+      __syncthreads();
+      const int sum = g_co.finish(sh);
+      if (t < 64) {
+        const int col = member * kDH + t;
+        float v = dense_epilogue(sum, 1.f / scale, L.cross_out.wscale[col], L.cross_out.bias != nullptr,
+                                 L.cross_out.bias ? L.cross_out.bias[col] : 0.f, -1);
+        v = sh.x_row[col] + v;
+        publish(xch + kXchX + col, v);
+      }
+    }
+    arrive(cl);
+    Gemv<256, 2, 16> g_f0;
+    g_f0.request(L.ffn0.w + static_cast<size_t>(member) * 256 * kD);
+    await(cl, sh);
+    // ================= feed forward ===========================================================
+    xv = observe(xch + kXchX + t);
+    sh.x_row[t] = xv;
+    {
+      const float scale = norm_quantize_row(xv, L.ln_ffn, a.quant_mode, sh);
+      const int sum = g_f0.finish(sh);
+      if (t < 256) {
+        const int col = member * 256 + t;
+        const float v = dense_epilogue(sum, 1.f / scale, L.ffn0.wscale[col], L.ffn0.bias != nullptr,
+                                       L.ffn0.bias ? L.ffn0.bias[col] : 0.f, a.act);
+        publish(xch + kXchInner + col, v);
+      }
+    }
+    arrive(cl);
+    Gemv<64, 8, 16> g_f1;
+    g_f1.request(L.ffn1.w + static_cast<size_t>(member) * 64 * kFfn);
+    await(cl, sh);
+    {
+      float iv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) iv[i] = observe(xch + kXchInner + i * kThreads + t);
+      const float amax =
+          block_absmax(fmaxf(fmaxf(fabsf(iv[0]), fabsf(iv[1])), fmaxf(fabsf(iv[2]), fabsf(iv[3]))), sh);
+      const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sh.xq[i * kThreads + t] = to_s8(iv[i], scale, a.quant_mode);
+      __syncthreads();
+      const int sum = g_f1.finish(sh);
+      if (t < 64) {
+        const int col = member * kDH + t;
+        float v = dense_epilogue(sum, 1.f / scale, L.ffn1.wscale[col], L.ffn1.bias != nullptr,
+                                 L.ffn1.bias ? L.ffn1.bias[col] : 0.f, -1);
+        v = sh.x_row[col] + v;
+        if (l + 1 < a.n_layers) publish(xch + kXchX + col, v);
+        else a.x_out[static_cast<int64_t>(row) * kD + col] = v;  // read by the next launch
+      }
+    }
+    if (l + 1 < a.n_layers) {
+      arrive(cl);
+      g_qkv.request(a.layers[l + 1].qkv.w + static_cast<size_t>(member) * 192 * kD);
+      await(cl, sh);
+      xv = observe(xch + kXchX + t);
+      __syncthreads();  // (the residual reads of x_row above are done)
+      sh.x_row[t] = xv;
+    }
+  }
+}
+
+// ---- weight re-pack (once per model) ----------------------------------------------------------
+// src [n, k] row-major int8 -> dst: member m's slice [k / 16][ns][16], ns = n / 8 rows; `sections`
+// > 1: the Dense is the concatenation of `sections` sub-matrices of n / sections rows each (Q | K
+// | V) and a member takes rows [m * ns / sections, ...) of EVERY section.
+__global__ void pack_cluster_weight_kernel(const int8_t* __restrict__ src, int n, int k, int sections,
+                                           int8_t* __restrict__ dst) {
+  const int ns = n / kMembers, per = ns / sections, section_rows = n / sections, chunks = k / 16;
+  const int64_t total = static_cast<int64_t>(n) * chunks;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int j = static_cast<int>(i % ns);
+    const int c = static_cast<int>((i / ns) % chunks);
+    const int m = static_cast<int>(i / (static_cast<int64_t>(ns) * chunks));
+    const int srow = (j / per) * section_rows + m * per + (j % per);
+    reinterpret_cast<uint4*>(dst)[i] =
+        *reinterpret_cast<const uint4*>(src + static_cast<int64_t>(srow) * k + c * 16);
+  }
+}
+
+void launch_pack_cluster_weight(const int8_t* w, int64_t n, int64_t k, int sections, int8_t* packed,
+                                hipStream_t stream) {
+  CT2X_CHECK(n % (kMembers * sections) == 0 && k % 16 == 0, "pack_cluster_weight: shape");
+  hipLaunchKernelGGL(pack_cluster_weight_kernel, dim3(256), dim3(256), 0, stream, w, static_cast<int>(n),
+                     static_cast<int>(k), sections, packed);
+}
+
+bool decoder_cluster_geometry_ok(int64_t d_model, int64_t heads, int64_t dhead, int64_t ffn) {
+  return d_model == kD && heads == kMembers && dhead == kDH && ffn == kFfn;
+}
+
+size_t decoder_cluster_xch_floats(int64_t rows) { return static_cast<size_t>(rows) * kXchFloats; }
+
+int decoder_cluster_t_pad(int64_t t_max, int64_t s_max) {
+  const int64_t keys = (t_max > s_max ? t_max : s_max) + 1;
+  return static_cast<int>((keys + 15) / 16 * 16 + 16);
+}
+
+void launch_decoder_cluster(const ClusterStackArgs& a, hipStream_t stream) {
+  const size_t lds = sizeof(Shared) + static_cast<size_t>(a.t_pad) * sizeof(float);
+  CT2X_CHECK(lds <= 160 * 1024, "decoder_cluster: the score row does not fit the LDS");
+  static bool opted = false;
+  if (!opted) {
+    CT2X_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_cluster_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    opted = true;
+  }
+  hipLaunchKernelGGL(decoder_cluster_kernel, dim3(static_cast<unsigned>(a.rows * kMembers)), dim3(kThreads), lds,
+                     stream, a);
+}
+
+}  // namespace ct2x

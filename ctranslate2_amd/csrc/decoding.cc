@@ -292,6 +292,7 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
   }
   (void)examined;
   engine.synchronize();  // drain a speculative group before the state is torn down
+  engine.check_cluster(st);  // (decoder-stack launch: a cluster that waited in vain voids the results)
   st.fuse_greedy = false;
   if (stats) stats->steps = launched;
   return results;

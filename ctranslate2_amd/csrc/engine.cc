@@ -689,6 +689,75 @@ void Engine::load_weights() {
       alignment_heads_ < 0 || alignment_heads_ > dec_.num_heads)
     throw std::runtime_error("decoder/alignment_layer or alignment_heads is out of range");
   pack_stream_weights();
+  pack_cluster_weights();
+}
+
+// The decoder stack as one launch per step (decoder_cluster.hip) serves the int8 pre-norm
+// encoder-decoder Transformer at the geometry its slices are cut for; CT2X_CLUSTER_STACK=0 keeps
+// the launch-per-op step (A/B runs, tests/test_decoder_cluster_gpu.py).
+void Engine::pack_cluster_weights() {
+  static const bool enabled = [] {
+    const char* e = std::getenv("CT2X_CLUSTER_STACK");
+    return e == nullptr || e[0] != '0';
+  }();
+  cluster_ready_ = false;
+  if (!enabled || tp_ || !has_encoder_ || is_whisper() || compute_type_ != ComputeType::kInt8Float32 ||
+      !dec_.pre_norm || dec_.layernorm_embedding.present || dec_.layers.empty())
+    return;
+  auto dense_ok = [](const DenseW& w, int64_t n, int64_t k) {
+    return w.present && w.quantized && !w.row_parallel && !w.awq && w.wq != nullptr && w.wscale != nullptr &&
+           w.n == n && w.k == k;
+  };
+  for (const LayerW& layer : dec_.layers) {
+    const AttnW& s = layer.self;
+    const AttnW& c = layer.cross;
+    if (layer.variant != 0 || !layer.has_cross || s.rotary || c.rotary || s.no_residual || c.no_residual ||
+        layer.ffn.no_residual || layer.ffn.l0_noact.present || !s.ln.present || !c.ln.present ||
+        !layer.ffn.ln.present || s.heads_kv != s.heads || c.heads_kv != c.heads || c.heads != s.heads ||
+        c.dhead != s.dhead || !decoder_cluster_geometry_ok(dec_.d_model, s.heads, s.dhead, layer.ffn.l0.n))
+      return;
+    const int64_t d = dec_.d_model, f = layer.ffn.l0.n;
+    if (!dense_ok(s.lin[0], 3 * d, d) || !dense_ok(s.lin[1], d, d) || !dense_ok(c.lin[0], d, d) ||
+        !dense_ok(c.lin[1], 2 * d, d) || !dense_ok(c.lin[2], d, d) || !dense_ok(layer.ffn.l0, f, d) ||
+        !dense_ok(layer.ffn.l1, d, f))
+      return;
+  }
+  auto pack = [&](const DenseW& w, int sections) {
+    int8_t* packed = static_cast<int8_t*>(device_malloc(static_cast<size_t>(w.n) * w.k));
+    device_blocks_.push_back(packed);
+    launch_pack_cluster_weight(w.wq, w.n, w.k, sections, packed, stream_);
+    ClusterDenseW out;
+    out.w = packed;
+    out.wscale = w.wscale;
+    out.bias = w.bias;
+    return out;
+  };
+  auto norm_of = [](const NormW& n) {
+    ClusterNormW out;
+    out.gamma = n.gamma;
+    out.beta = n.beta;
+    out.eps = n.eps;
+    out.rms_use_residual = n.use_residual ? 1 : 0;
+    return out;
+  };
+  cluster_layers_.clear();
+  for (const LayerW& layer : dec_.layers) {
+    ClusterLayerArgs a;
+    a.ln_self = norm_of(layer.self.ln);
+    a.ln_cross = norm_of(layer.cross.ln);
+    a.ln_ffn = norm_of(layer.ffn.ln);
+    a.qkv = pack(layer.self.lin[0], 3);
+    a.self_out = pack(layer.self.lin[1], 1);
+    a.cross_q = pack(layer.cross.lin[0], 1);
+    a.cross_out = pack(layer.cross.lin[2], 1);
+    a.ffn0 = pack(layer.ffn.l0, 1);
+    a.ffn1 = pack(layer.ffn.l1, 1);
+    a.self_scale = layer.self.queries_scale;
+    a.cross_scale = layer.cross.queries_scale;
+    cluster_layers_.push_back(a);
+  }
+  check_last_launch("pack_cluster_weights");
+  cluster_ready_ = true;
 }
 
 // Decode-step weights of models that cannot stay cache resident get a second, fragment-major copy

@@ -326,6 +326,9 @@ public:
   void enable_logits_history(DecodeState& state);
   void read_logits(DecodeState& state, int64_t first, int64_t count, float* out);
   void synchronize();
+  // Throws if a cluster of the decoder-stack launch waited in vain for a member during this
+  // session (another persistent launch held the compute units): its results are void.
+  void check_cluster(DecodeState& state);
   // Teacher-forced scoring (score_sequences, src/scoring.cc): runs `steps` decoder steps feeding
   // h_inputs[s][row] and leaves log P(h_outputs[s][row]) of every step in the score history
   // (read_history). Both arrays are [steps][rows]; nothing is read back between the steps.
@@ -421,6 +424,15 @@ private:
   int64_t prefetch_bytes_[4] = {0, 0, 0, 0};
   void pack_stream_weights();
   void pack_stream(DenseW& w, bool dual);
+  // Cluster-resident decoder stack (decoder_cluster.hip): every decoder layer of a greedy step in
+  // ONE launch. pack_cluster_weights() re-packs the six Dense weights of every layer member-major
+  // when the model qualifies (int8, pre-norm, encoder-decoder, Transformer-base geometry);
+  // cluster_bind() writes the session's layer table (weights + this session's caches) to the device.
+  void pack_cluster_weights();
+  bool cluster_ready_ = false;
+  std::vector<ClusterLayerArgs> cluster_layers_;  // weights part; caches filled per session
+  bool cluster_applicable(const DecodeState& state) const;
+  void cluster_bind(DecodeState& state);
   // How a Dense is split over the tensor-parallel ranks (Model::load, src/models/model.cc:
   // 662-743): kColumn = output rows; `blocks` lists the sizes of the fused sub-matrices that are
   // each split separately and re-concatenated (Q | K | V of linear_0, K | V of the cross
@@ -632,6 +644,13 @@ struct DecodeState {
   bool graph_failed = false;  // capture refused (tensor parallel + collective library): eager
   bool graph_ready[2] = {false, false};
   // a whole group of greedy steps as ONE graph (Engine::step_group; reused sessions only)
+  // cluster-resident decoder stack: layer table on the device, hand-over lines, arrival counters
+  // (zero at session start, monotonic afterwards), the "a member waited in vain" flag
+  ClusterLayerArgs* cl_layers = nullptr;
+  float* cl_xch = nullptr;
+  unsigned* cl_counters = nullptr;
+  int* cl_error = nullptr;
+  int cl_t_pad = 0;
   hipGraphExec_t group_exec = nullptr;
   int group_steps = 0;
   int group_parity = 0;

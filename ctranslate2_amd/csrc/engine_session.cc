@@ -294,12 +294,48 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
         for (int l = 0; l < n_layers; ++l)
           st->cross_kv16.push_back(alloc<uint16_t>(*st, batch * s_max * dec_.layers[l].cross.lin[1].n));
     }
+    if (cluster_ready_ && !beam_mode && beam == 1 && rows <= 32 && prefill_len == 0) {
+      // the decoder stack as one launch per step (decoder_cluster.hip)
+      st->cl_layers = alloc<ClusterLayerArgs>(*st, n_layers);
+      st->cl_xch = alloc<float>(*st, static_cast<int64_t>(decoder_cluster_xch_floats(rows)));
+      st->cl_counters = alloc<unsigned>(*st, rows * 16);
+      st->cl_error = alloc<int>(*st, 1);
+      st->cl_t_pad = decoder_cluster_t_pad(t_max, s_max);
+      CT2X_HIP_CHECK(hipMemsetAsync(st->cl_counters, 0, sizeof(unsigned) * rows * 16, cur_stream()));
+      CT2X_HIP_CHECK(hipMemsetAsync(st->cl_error, 0, sizeof(int), cur_stream()));
+      cluster_bind(*st);
+    }
     if (features)
       encode_features(*st, features, frames);
     else
       encode(*st, src_ids, src_lengths);
   }
   return st;
+}
+
+void Engine::cluster_bind(DecodeState& st) {
+  if (st.cl_layers == nullptr) return;
+  std::vector<ClusterLayerArgs> table = cluster_layers_;
+  for (size_t l = 0; l < table.size(); ++l) {
+    table[l].self_k = st.self_k[0][l];
+    table[l].self_v = st.self_v[0][l];
+    table[l].cross_kv = st.cross_kv[l];
+  }
+  CT2X_HIP_CHECK(hipMemcpyAsync(st.cl_layers, table.data(), sizeof(ClusterLayerArgs) * table.size(),
+                                hipMemcpyHostToDevice, cur_stream()));
+  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // (`table` is a temporary)
+}
+
+void Engine::check_cluster(DecodeState& st) {
+  if (st.cl_error == nullptr) return;
+  int flag = 0;
+  CT2X_HIP_CHECK(hipMemcpyAsync(&flag, st.cl_error, sizeof(int), hipMemcpyDeviceToHost, st.stream));
+  CT2X_HIP_CHECK(hipStreamSynchronize(st.stream));
+  if (flag != 0) {
+    CT2X_HIP_CHECK(hipMemsetAsync(st.cl_error, 0, sizeof(int), st.stream));
+    throw Error("decoder stack launch: a workgroup cluster waited in vain for one of its members (is another "
+                "persistent launch holding the device?); CT2X_CLUSTER_STACK=0 selects the launch-per-op step");
+  }
 }
 
 void Engine::reencode(DecodeState& st, const int32_t* src_ids, const int32_t* src_lengths) {

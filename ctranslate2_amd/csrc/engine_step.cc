@@ -53,6 +53,41 @@ void Engine::launch_step(DecodeState& st) {
   // (run_ffn / dense_qol). The slots are cleared by the step's first launch, not by a memset node.
   const bool ffn_amax = !tp_ && !taps_ && rows <= 32 && !dec_.layers.empty() && gemm_s8_qol_enabled();
   const bool zero_amax = split_quant || ffn_amax;
+  const bool cluster = cluster_applicable(st);
+  if (cluster) {
+    // embedding + every decoder layer: ONE launch (decoder_cluster.hip)
+    ClusterStackArgs ca;
+    ca.layers = st.cl_layers;
+    ca.n_layers = static_cast<int>(dec_.layers.size());
+    ca.rows = static_cast<int>(rows);
+    ca.t_max = static_cast<int>(st.t_max);
+    ca.s_max = static_cast<int>(st.s_max);
+    ca.t_pad = st.cl_t_pad;
+    ca.quant_mode = quant_mode_;
+    ca.act = dec_.layers[0].ffn.activation;
+    ca.emb_table = dec_.emb.table;
+    ca.emb_int8 = dec_.emb.is_int8 ? 1 : 0;
+    ca.emb_scale = dec_.emb.scale;
+    ca.emb_apply_mul = dec_.scale_embeddings ? 1 : 0;
+    ca.emb_mul = dec_.embeddings_scale;
+    ca.pos_table = pos;
+    ca.ids = st.d_ids;
+    ca.step_ptr = st.d_step;
+    ca.mem_lengths = st.mem_lengths;
+    ca.x_out = x;
+    ca.xch = st.cl_xch;
+    ca.counters = st.cl_counters;
+    ca.error = st.cl_error;
+    {
+      double wbytes = 0;
+      for (const LayerW& layer : dec_.layers)
+        wbytes += double(layer.self.lin[0].n + layer.self.lin[1].n + layer.cross.lin[0].n + layer.cross.lin[2].n) * d +
+                  2.0 * double(layer.ffn.l0.n) * d;
+      begin_kernel("decoder_stack", wbytes + double(rows) * d * 8, 2.0 * rows * wbytes, rows, d, d);
+    }
+    launch_decoder_cluster(ca, cur_stream());
+    end_kernel();
+  } else {
   begin_kernel("embed");
   launch_embed(dec_.emb.table, dec_.emb.is_int8, dec_.emb.scale, st.d_ids, rows, d,
                dec_.embeddings_scale, dec_.scale_embeddings, pos, 1, 0, st.d_step, x, cur_stream(),
@@ -308,6 +343,8 @@ void Engine::launch_step(DecodeState& st) {
             (split_quant || ffn_amax) ? st.row_amax + (2 * l + 1) * rows : nullptr, qin_ready);
     qin_ready = false;
   }
+
+  }  // !cluster
 
   st.pf_active = false;
   st.pf_pending = PrefetchArgs();
@@ -760,6 +797,12 @@ bool Engine::fused_argmax_applicable(const DecodeState& st) const {
          (reinterpret_cast<uintptr_t>(w.wq) & 15) == 0;
 }
 
+bool Engine::cluster_applicable(const DecodeState& st) const {
+  return cluster_ready_ && st.cl_layers != nullptr && !taps_ && !tp_ && st.beam == 1 && !st.beam_mode &&
+         !st.ancestry && st.att_hist == nullptr && st.cur == 0 && st.rows >= 1 && st.rows <= 32 &&
+         st.mem_lengths != nullptr;
+}
+
 bool Engine::compactable(const DecodeState& st) const {
   return !tp_ && !taps_ && !profiling_ && st.beam == 1 && !st.beam_mode && !st.ancestry &&
          st.att_hist == nullptr && st.logit_hist == nullptr && !st.wh_active &&
@@ -821,6 +864,7 @@ void Engine::compact_rows(DecodeState& st, const std::vector<int32_t>& keep, int
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // (`keep` may be a temporary)
   st.rows = n_new;
   st.batch = n_new;
+  cluster_bind(st);  // (the layer table of the decoder-stack launch names the caches that just moved)
   for (int i = 0; i < 2; ++i) {
     if (st.graph_exec[i]) (void)hipGraphExecDestroy(st.graph_exec[i]);
     st.graph_exec[i] = nullptr;

@@ -669,7 +669,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
       if (ARGMAX) {
         // key order = (value, then LOWER column): the arg-max tie rule of the sampler (better())
         if (static_cast<int>(col) != gf_masked[i] && v == v) {
-          const unsigned u = __float_as_uint(v);
+          // (-0.0 and +0.0 compare equal in the sampler's `>`: both signs pack as +0.0 so that
+          // the lower column wins between them as well; the value itself is not returned here)
+          const unsigned u = (v == 0.f) ? 0u : __float_as_uint(v);
           const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
           const unsigned long long key =
               (static_cast<unsigned long long>(ord) << 32) | (0xFFFFFFFFu - static_cast<unsigned>(col));

@@ -213,6 +213,55 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
 bool gemm_s8_stream_pack_applicable(int64_t n, int64_t k, bool dual);
 void launch_pack_stream_weight(const int8_t* src, int64_t n, int64_t k, bool dual, int8_t* dst,
                                hipStream_t stream);
+// ---- cluster-resident decoder stack (decoder_cluster.hip) -------------------------------------
+// All decoder layers of one greedy step as ONE launch: a batch row is owned by a cluster of eight
+// workgroups (one per attention head) that meet six times per layer through memory-side atomics.
+constexpr int kClusterMembers = 8;
+struct ClusterDenseW {
+  const int8_t* w = nullptr;      // launch_pack_cluster_weight layout
+  const float* wscale = nullptr;  // [n], the Dense's own order
+  const float* bias = nullptr;    // [n] or nullptr
+};
+struct ClusterNormW {
+  const float* gamma = nullptr;
+  const float* beta = nullptr;    // nullptr: RMSNorm
+  float eps = 1e-5f;
+  int rms_use_residual = 0;
+};
+struct ClusterLayerArgs {
+  ClusterNormW ln_self, ln_cross, ln_ffn;
+  ClusterDenseW qkv, self_out, cross_q, cross_out, ffn0, ffn1;
+  float* self_k = nullptr;         // [rows, heads, t_max, d_head]
+  float* self_v = nullptr;
+  const float* cross_kv = nullptr; // [batch, s_max, 2 * d_model] (K | V)
+  float self_scale = 1.f, cross_scale = 1.f;
+};
+struct ClusterStackArgs {
+  const ClusterLayerArgs* layers = nullptr;  // device array [n_layers]
+  int n_layers = 0, rows = 0, t_max = 0, s_max = 0, t_pad = 0, quant_mode = 0, act = 0;
+  const void* emb_table = nullptr;
+  int emb_int8 = 0, emb_apply_mul = 0;
+  const float* emb_scale = nullptr;
+  float emb_mul = 1.f;
+  const float* pos_table = nullptr;     // [positions, d_model] or nullptr
+  const int32_t* ids = nullptr;         // [rows] input ids of the step
+  const int32_t* step_ptr = nullptr;
+  const int32_t* mem_lengths = nullptr; // [rows]
+  float* x_out = nullptr;               // [rows, d_model]: the stack's output (before the output norm)
+  float* xch = nullptr;                 // decoder_cluster_xch_floats(rows): the hand-over lines
+  unsigned* counters = nullptr;         // [rows * 16], zero at session start, never reset
+  int* error = nullptr;                 // set when a member waited in vain (results void)
+};
+// d_model 512, 8 heads of 64, feed-forward 2048 (Transformer-base); everything else keeps the
+// launch-per-op path
+bool decoder_cluster_geometry_ok(int64_t d_model, int64_t heads, int64_t dhead, int64_t ffn);
+size_t decoder_cluster_xch_floats(int64_t rows);
+int decoder_cluster_t_pad(int64_t t_max, int64_t s_max);
+// member-major, chunk-major copy of a Dense weight [n, k]; sections = 3 for the fused Q | K | V
+void launch_pack_cluster_weight(const int8_t* w, int64_t n, int64_t k, int sections, int8_t* packed,
+                                hipStream_t stream);
+void launch_decoder_cluster(const ClusterStackArgs& a, hipStream_t stream);
+
 // Warm the memory-side cache with (a leading fraction of every wave's stream of) a packed weight:
 // up to two ranges carried by spare workgroups of a row-wide launch (launch_norm,
 // launch_quantize_cols) while HBM is otherwise idle. Piece c of a range is the (c % take16)-th

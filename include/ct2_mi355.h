@@ -134,6 +134,17 @@ int ct2x_gemm_s8_dequant(const int8_t* d_qa, const float* d_a_scale, const int8_
                          int64_t m, int64_t n, int64_t k, int activation, void* d_y, int dtype,
                          void* stream);
 
+/* The same Dense for the vocabulary projection of a greedy step that returns no scores
+ * (src/decoding.cc:874-880: GreedySearch takes ops::TopK(1) of the raw logits): the arg-max rides in
+ * the launch, the logits are never stored. d_ids_out[m] receives the index of every row's largest
+ * value, the LOWEST index among equal values (-0.0 == +0.0), NaN never chosen. d_scratch: at least
+ * ct2x_gemm_s8_argmax_scratch_bytes(m) bytes, zero on entry, zero again on return.
+ * m <= 32, n >= 8192, k % 16 == 0, k < 4096 (an error otherwise). */
+int ct2x_gemm_s8_argmax(const int8_t* d_qa, const float* d_a_scale, const int8_t* d_w,
+                        const float* d_w_scale, const float* d_bias, int64_t m, int64_t n, int64_t k,
+                        int32_t* d_ids_out, void* d_scratch, void* stream);
+int64_t ct2x_gemm_s8_argmax_scratch_bytes(int64_t m);
+
 /* The gated FFN input pair (FeedForwardNetwork::operator(), src/layers/transformer.cc:21-51 with
  * ffn_glu: linear_0 + activation, linear_0_noact, ops::Mul) as ONE launch for decode rows
  * (m <= 32):  y = act( (qa . W0^T) * (1/a_scale) / w0_scale + b0 ) * ( (qa . W1^T) * (1/a_scale)

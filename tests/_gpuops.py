@@ -486,3 +486,19 @@ def cross_attention_h(q, kv_bits, bf16, lengths, beam, heads_kv, scale):
                                          _lib.ptr(ld), i64(batch), i64(beam), i64(heads), i64(heads_kv),
                                          i64(dh), i64(s_max), C.c_float(scale), _lib.ptr(out), None))
     return host(out)
+
+
+def gemm_s8_argmax(q, sa, w, sw, bias=None):
+    """ct2x_gemm_s8_argmax: the vocabulary projection with the greedy arg-max riding in the launch"""
+    L = _lib.lib()
+    qd, sad, wd, swd = dev(q.astype(np.int8)), dev(sa.astype(np.float32)), dev(w.astype(np.int8)), dev(sw.astype(np.float32))
+    bd = dev(bias.astype(np.float32)) if bias is not None else None
+    m, k = q.shape
+    n = w.shape[0]
+    L.ct2x_gemm_s8_argmax_scratch_bytes.restype = C.c_int64
+    scratch = torch.zeros((int(L.ct2x_gemm_s8_argmax_scratch_bytes(i64(m))),), dtype=torch.uint8, device="cuda")
+    ids = torch.full((m,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(L.ct2x_gemm_s8_argmax(_lib.ptr(qd), _lib.ptr(sad), _lib.ptr(wd), _lib.ptr(swd), _lib.ptr(bd),
+                                     i64(m), i64(n), i64(k), _lib.ptr(ids), _lib.ptr(scratch), None))
+    assert int(scratch.sum().item()) == 0, "the scratch must be zero again after the launch"
+    return host(ids)

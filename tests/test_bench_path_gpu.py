@@ -1,0 +1,103 @@
+"""The exact code path bench.py times, held to the REAL reference's tokens.
+
+The headline leg runs greedy search WITHOUT scores: the sampler rides in the vocabulary projection
+(GreedyFuse), the second and later calls of a shape replay a reused session, and a reused session
+replays groups of steps from one graph (Engine::step_group). Every other golden comparison asks for
+scores and therefore takes the sampler-launch path; here the same goldens (tests/golden/
+make_golden.py: Transformer-base at the metric's shape, 32 sentences x 64 forced steps;
+make_golden_llama3_geometry.py) are compared on the fused path, over consecutive calls of one
+handle, with the launch count showing which path ran."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as GC
+from test_translator_gpu import get_translator, host_math_is_mkl
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_transformer_base_headline_path_matches_reference(gpu):
+    with open(os.path.join(HERE, "golden", "model_golden.json")) as f:
+        g = json.load(f)["tb"]
+    assert len(g["sources"]) == 32 and g["max_len"] == 64 and g["min_len"] == 64  # the metric's shape
+    ref = [h[0] for h in g["runs"]["beam1"]["hypotheses"]]
+    t = get_translator(gpu, "tb")
+    kw = dict(beam_size=1, max_decoding_length=g["max_len"], min_decoding_length=g["min_len"])
+    t.release_session()
+    _, _ = t.translate_ids(g["sources"], return_scores=True, **kw)
+    with_sampler = t.last_stats()["kernels_per_step"]
+    t.release_session()
+    hits0 = t.last_stats()["session_hits"]
+    # a different batch of the same shape in between: a reused session must not remember tokens
+    rng = np.random.default_rng(5)
+    other = [rng.integers(4, 32000, len(s)).tolist() for s in g["sources"]]
+    outs = []
+    for call in range(5):
+        src = other if call == 2 else g["sources"]
+        hyps, _ = t.translate_ids(src, **kw)
+        st = t.last_stats()
+        assert st["kernels_per_step"] == with_sampler - 1, "the fused arg-max path did not run"
+        assert st["num_tokens"] == 32 * 64
+        outs.append([h[0] for h in hyps])
+    assert t.last_stats()["session_hits"] - hits0 == 4, "calls 2..5 replay the kept session"
+    assert outs[0] == outs[1] == outs[3] == outs[4]
+    assert outs[2] != outs[0]
+    identical = sum(int(a == b) for a, b in zip(outs[0], ref))
+    print("tb, fused greedy path over reused sessions: %d/32 sentences token-identical" % identical)
+    if host_math_is_mkl():
+        assert outs[0] == ref
+    else:
+        assert identical >= 16
+
+
+@pytest.mark.parametrize("case", ["p40", "p200"])
+def test_llama3_geometry_fused_path_matches_reference(gpu, case):
+    from test_generator_gpu import get_l3g, _host_math_is_mkl
+    t, g = get_l3g()
+    c = g["cases"][case]
+    kw = dict(max_length=c["max_len"], min_length=c["max_len"])
+    _ = t.generate_ids(c["prompts"], return_scores=True, **kw)
+    with_sampler = t.last_stats()["kernels_per_step"]
+    for _call in range(3):
+        gen, _ = t.generate_ids(c["prompts"], **kw)
+        assert t.last_stats()["kernels_per_step"] == with_sampler - 1
+        if _host_math_is_mkl():
+            assert gen == c["generated"]
+        else:
+            assert sum(a == b for a, b in zip(gen, c["generated"])) >= len(gen) // 2
+
+
+def test_fused_argmax_signed_zero_tie(gpu):
+    """A row whose maximum is a signed zero at two columns: the sampler's `>` treats -0.0 and +0.0
+    as equal and keeps the LOWER column; the packed key of the fused form must do the same (it
+    used to rank +0.0 above -0.0). int8 Dense with a zero weight row gives +0.0, a bias of -0.0
+    on the lower column gives -0.0 there: 0 * x + (-0.0) = -0.0."""
+    import _gpuops as G
+    rng = np.random.default_rng(0)
+    m, n, k = 8, 8192 + 64, 64
+    xq = rng.integers(-127, 128, (m, k)).astype(np.int8)
+    xs = np.full(m, -10.0, np.float32)  # 0 * (1 / -10) = -0.0: the bias sign decides the zero
+    wq = np.zeros((n, k), np.int8)
+    ws = np.full(n, 5.0, np.float32)
+    bias = np.full(n, -1.0, np.float32)
+    bias[37] = -0.0
+    bias[8200] = 0.0
+    assert G.gemm_s8_argmax(xq, xs, wq, ws, bias).tolist() == [37] * m
+    bias[37] = 0.0
+    bias[8200] = -0.0
+    assert G.gemm_s8_argmax(xq, xs, wq, ws, bias).tolist() == [37] * m
+    # and on ordinary data: the arg-max (first among equals) of the Dense the oracle computes
+    import _oracle as O
+    for rows in (1, 16, 32):
+        x = rng.standard_normal((rows, 512)).astype(np.float32)
+        w = (rng.standard_normal((9000, 512)) * 0.02).astype(np.float32)
+        wq, ws = O.quantize_s8(w, 1)
+        q, s = O.quantize_s8(x, 3)
+        b = (rng.standard_normal(9000) * 0.01).astype(np.float32)
+        y = O.dense_s8(x, wq, ws, b, None, -1, 3)
+        assert G.gemm_s8_argmax(q, s, wq, ws, b).tolist() == y.argmax(axis=1).tolist()

@@ -1,0 +1,102 @@
+"""The cluster-resident decoder stack (decoder_cluster.hip): every decoder layer of a greedy step
+as ONE launch - a batch row owned by eight workgroups (one per head) that hand the row over through
+memory-side atomics - against the launch-per-op step it replaces (CT2X_CLUSTER_STACK=0, its own
+interpreter: the switch is read once per process). Same formulas in the same order, exact int32
+sums: tokens, scores and teacher-forced logits must be the same BITS. The reference goldens at this
+geometry (tests/test_translator_gpu.py "tb", tests/test_bench_path_gpu.py) run through the new
+launch by default; this file pins the shapes they do not visit (1 .. 32 rows, ragged sources, a
+target prefix, minimum lengths, session reuse, finished-row removal)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SCRIPT = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(here)r)
+import ctranslate2_amd as ct2
+from ctranslate2_amd import model_builder as mb
+import golden_cases as GC
+out = {}
+path = "/tmp/ct2x_test_tb"
+if not os.path.exists(os.path.join(path, "model.bin")):
+    mb.build_transformer(path, **GC.SYNTHETIC["tb"]["model"])
+t = ct2.Translator(path, device="cuda", compute_type="int8")
+rng = np.random.default_rng(11)
+V = 32000
+def sources(n, lo=5, hi=40):
+    return [rng.integers(4, V, int(rng.integers(lo, hi))).tolist() for _ in range(n)]
+for rows in (1, 2, 7, 16, 31, 32):
+    src = sources(rows)
+    hyps, scores = t.translate_ids(src, beam_size=1, max_decoding_length=24, min_decoding_length=3,
+                                   return_scores=True)
+    out["scores_%%d" %% rows] = [hyps, np.asarray(scores, np.float32).view(np.uint32).tolist()]
+    out["scores_%%d_kernels" %% rows] = t.last_stats()["kernels_per_step"]
+    hyps, _ = t.translate_ids(src, beam_size=1, max_decoding_length=24, min_decoding_length=3)
+    out["plain_%%d" %% rows] = hyps
+    out["plain_%%d_kernels" %% rows] = t.last_stats()["kernels_per_step"]
+# eager launches as well as the graph replay; more than 64 keys in the self-attention cache
+src = sources(9)
+hyps, _ = t.translate_ids(src, beam_size=1, max_decoding_length=90, min_decoding_length=90, use_graph=False)
+out["long_eager"] = hyps
+hyps, _ = t.translate_ids(src, beam_size=1, max_decoding_length=90, min_decoding_length=90)
+out["long_graph"] = hyps
+# reused sessions: the same shape again and again, different sentences
+fixed = [rng.integers(4, V, 20).tolist() for _ in range(12)]
+other = [rng.integers(4, V, 20).tolist() for _ in range(12)]
+seq = []
+for call in range(4):
+    hyps, _ = t.translate_ids(other if call == 1 else fixed, beam_size=1, max_decoding_length=16,
+                              min_decoding_length=16)
+    seq.append(hyps)
+out["reuse"] = seq
+# a hard target prefix and the end token (finished rows keep being stepped)
+hyps, _ = t.translate_ids(src, beam_size=1, max_decoding_length=20, return_end_token=True)
+out["eos"] = hyps
+prefix = [h[0][: i %% 4] for i, h in enumerate(hyps)]
+hyps, _ = t.translate_ids(src, beam_size=1, max_decoding_length=20, target_prefix_ids=prefix)
+out["prefix"] = hyps
+# teacher-forced logits of every step (Engine::step without the fused sampler)
+tgt = rng.integers(4, V, (6, 10)).astype(np.int32)
+logits = t.step_logits(sources(6), tgt)
+out["logits"] = np.ascontiguousarray(logits[:, :, ::97], np.float32).view(np.uint32).tolist()
+# beam search keeps the launch-per-op step
+hyps, _ = t.translate_ids(src[:4], beam_size=4, max_decoding_length=12)
+out["beam4"] = hyps
+out["beam4_kernels"] = t.last_stats()["kernels_per_step"]
+print(json.dumps(out))
+"""
+
+
+def _run(cluster):
+    env = dict(os.environ)
+    env["CT2X_CLUSTER_STACK"] = "1" if cluster else "0"
+    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT, "here": HERE}], env=env,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_cluster_stack_equals_launch_per_op(gpu):
+    base = _run(False)
+    fused = _run(True)
+    for key in base:
+        if key.endswith("_kernels"):
+            continue
+        assert fused[key] == base[key], key
+    for rows in (1, 2, 7, 16, 31, 32):
+        # embedding + 8 launches per layer x 6 layers became one launch
+        assert fused["plain_%d_kernels" % rows] == base["plain_%d_kernels" % rows] - 48, rows
+        assert fused["scores_%d_kernels" % rows] == base["scores_%d_kernels" % rows] - 48, rows
+    assert fused["beam4_kernels"] == base["beam4_kernels"]
+    assert fused["long_eager"] == fused["long_graph"]
+    assert fused["reuse"][0] == fused["reuse"][2] == fused["reuse"][3]
+    assert fused["reuse"][0] != fused["reuse"][1]

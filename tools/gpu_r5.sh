@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round 5: the GPU measurements of the round as named sections (one `gpurun` call each):
+#   gpurun --timeout 900 -- 'bash tools/gpu_r5.sh <section>'
+# Output goes to gpurun_out/r5/; what is kept is copied to profiles/ (profiles/README.md).
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r5
+O=gpurun_out/r5
+export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/ctranslate2_amd:$LD_LIBRARY_PATH
+export TMPDIR=/tmp
+NOLEGS="--no-cpu-baseline --no-profile --no-l8 --no-whisper --no-nllb"
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), 'tok/s', round(d['ms_per_step'],3), 'ms/call', 'kernels/step', d['config'].get('kernels_per_decode_step'))"; }
+
+case "$1" in
+probes)           # profiles/r05_row_resident_probe.txt, r05_persistent_layer_probe.txt
+  timeout 120 build/tools/row_resident_probe 2>&1 | tee $O/row_resident_probe.txt
+  timeout 120 build/tools/persistent_layer_probe 2>&1 | tee $O/persistent_layer_probe.txt ;;
+cluster_first)    # first run of the cluster-resident decoder stack: parity, then the A/B
+  timeout 600 python -m pytest tests/test_decoder_cluster_gpu.py tests/test_bench_path_gpu.py -x -q 2>&1 | tail -15 | tee $O/cluster_first_tests.txt
+  { for f in 0 1 0 1; do echo "== CT2X_CLUSTER_STACK=$f"; CT2X_CLUSTER_STACK=$f timeout 300 python bench.py --steps 20 --warmup 3 $NOLEGS 2>&1 | tail -1 | line; done
+  } 2>&1 | tee $O/cluster_ab.txt ;;
+cluster_ab)       # profiles/r05_cluster_stack_ab.txt
+  { for f in 0 1 0 1; do echo "== CT2X_CLUSTER_STACK=$f $2"; CT2X_CLUSTER_STACK=$f timeout 300 python bench.py --steps 20 --warmup 3 $NOLEGS $2 2>&1 | tail -1 | line; done
+  } 2>&1 | tee $O/cluster_ab.txt ;;
+tests)            # a list of test files
+  shift; timeout 1200 python -m pytest "$@" -x -q 2>&1 | tail -15 | tee $O/tests.txt ;;
+rocprof_tb)       # profiles/r05_kernel_stats_bench_tb_b32.csv
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tb -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 $NOLEGS > /tmp/prof_tb.log 2>&1 )
+  cp "$(find /tmp/prof_tb -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_bench_tb_b32.csv; head -12 $O/kernel_stats_bench_tb_b32.csv | cut -c1-200 ;;
+all)              # the whole -m gpu suite, smoke and the default bench line
+  timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -3 $O/pytest_all.log
+  python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+  timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json ;;
+*) echo "sections: probes cluster_first cluster_ab tests rocprof_tb all"; exit 2 ;;
+esac
