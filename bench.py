@@ -72,6 +72,14 @@ def parse_args():
                    help="skip the NLLB-3.3B-shape float16 leg (BASELINE configs[3] geometry on one GPU, "
                         "reported as config.nllb)")
     p.add_argument("--no-profile", action="store_true")
+    p.add_argument("--no-token-check", action="store_true",
+                   help="skip config.tokens_equal_unfused (a second interpreter decodes the last timed "
+                        "batch with every fusion of the step switched off)")
+    p.add_argument("--tp-shm", action="store_true",
+                   help="on ONE GPU: two PROCESSES share it and run the tensor-parallel engine through "
+                        "the shared-memory communicator (ShmComm) - the multi-rank code path without a "
+                        "second device; reported as config.tp_shm")
+    p.add_argument("--unfused-tokens-of", type=int, default=-1, help=argparse.SUPPRESS)
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline")
     return p.parse_args()
 
@@ -251,6 +259,43 @@ def tp_local_leg(model_dir, sources, kw, ref_hyps):
             "collective_calls_per_row_parallel_dense": 0, "device_side_exchanges_per_row_parallel_dense": 2}
 
 
+def tp_shm_leg(model_dir, args, ref_hyps):
+    """Tensor parallelism across two PROCESSES on the one visible GPU (tools/tp_shm_rank.py): the
+    sharded engine over the shared-memory / hipIpc communicator - separate address spaces, mailboxes
+    mapped through IPC handles, the bootstrap a multi-GPU node runs - minus the links. Functional
+    leg: tokens/s of the sharded decode with both ranks on ONE GPU is not a scaling number."""
+    import subprocess
+    import tempfile
+    seg = "/ct2x_bench_%d" % os.getpid()
+    tmp = tempfile.mkdtemp(prefix="ct2x_tp_shm_")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(2):
+        out = os.path.join(tmp, "rank%d.json" % r)
+        procs.append((out, subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tools", "tp_shm_rank.py"), model_dir, str(r), "2", seg, out,
+             str(args.batch), str(args.src_len), str(args.max_len)], env=env, stdout=subprocess.PIPE,
+            stderr=subprocess.PIPE, text=True)))
+    outs = []
+    for out, p in procs:
+        try:
+            _, err = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise RuntimeError("rank timed out")
+        if p.returncode != 0:
+            raise RuntimeError("rank failed: " + err[-400:])
+        with open(out) as f:
+            outs.append(json.load(f))
+    tokens = sum(len(h[0]) for h in outs[0]["hyps"])
+    return {"workload": "same model and batch, tensor parallel x2 as two PROCESSES on this one GPU (ShmComm: "
+                        "shared-memory bootstrap, IPC-mapped one-shot mailboxes; functional leg, not a scaling number)",
+            "value": tokens / max(o["seconds_per_call"] for o in outs), "unit": "tokens/s",
+            "tokens_equal_unsharded": bool(all(o["hyps"] == ref_hyps for o in outs)),
+            "backend": outs[0]["tp"].get("backend"), "world": outs[0]["tp"].get("world")}
+
+
 def physical_cores():
     """Distinct (socket, core) pairs of /proc/cpuinfo; falls back to os.cpu_count()."""
     try:
@@ -317,11 +362,54 @@ def cpu_baseline(model_dir, sources, args):
             "settings": runs, "host_logical_cpus": logical, "host_physical_cores": physical_cores()}
 
 
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks
+    ourselves (one process per GPU, rendezvous on 127.0.0.1) and hand over to them."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def unfused_tokens(args, which):
+    """The tokens of rotation batch `which` from a SECOND interpreter in which every fusion of the
+    decode step is off (separate sampler launch, launch-per-op layers, a session per call, eager
+    launches): what the timed path must reproduce token for token."""
+    import subprocess
+    env = dict(os.environ)
+    env.update(CT2X_FUSED_ARGMAX="0", CT2X_CLUSTER_STACK="0", CT2X_SESSION_CACHE="0", CT2X_GROUP_GRAPH="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--unfused-tokens-of", str(which), "--batch", str(args.batch),
+           "--beam", str(args.beam), "--src-len", str(args.src_len), "--max-len", str(args.max_len),
+           "--compute-type", args.compute_type]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return None
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def rotation_batches(args, rank, tp):
+    sources = make_sources(0 if tp else rank, args.batch, args.src_len, TB["vocab_size"])
+    return [sources] + [make_sources(1000 * (i + 1) + (0 if tp else rank), args.batch, args.src_len,
+                                     TB["vocab_size"]) for i in range(3)]
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     if args.no_session_reuse:
         os.environ["CT2X_SESSION_CACHE"] = "0"  # (read by the library at its first translate call)
     rank, local_rank, world = shard_info()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -340,6 +428,13 @@ def main():
     tp = args.tp and world > 1
     translator = ct2.Translator(model_dir, device="cuda", device_index=local_rank, compute_type=args.compute_type,
                                 tensor_parallel=tp)
+    if args.unfused_tokens_of >= 0:
+        # (child of unfused_tokens(): one eager call, tokens out, nothing else)
+        src = rotation_batches(args, 0, False)[args.unfused_tokens_of]
+        hyps, _ = translator.translate_ids(src, beam_size=args.beam, max_decoding_length=args.max_len,
+                                           min_decoding_length=args.max_len, use_graph=False)
+        print(json.dumps([h[0] for h in hyps]))
+        return
     # replicas: every rank has its own batch; tensor parallel: ONE batch, computed by all ranks
     sources = make_sources(0 if tp else rank, args.batch, args.src_len, TB["vocab_size"])
     kw = dict(beam_size=args.beam, max_decoding_length=args.max_len, min_decoding_length=args.max_len,
@@ -348,14 +443,16 @@ def main():
     # Every call of the timed region translates OTHER sentences of the same shape (four batches in
     # rotation; `sources` itself serves the later legs): the session reuse of the library
     #  skips allocation and graph capture, never a kernel of the encoder or decoder.
-    rotation = [sources] + [make_sources(1000 * (i + 1) + (0 if tp else rank), args.batch, args.src_len,
-                                         TB["vocab_size"]) for i in range(3)]
+    rotation = rotation_batches(args, rank, tp)
+    assert rotation[0] == sources
     calls = [0]
+    last = {}
 
     def one_step():
-        src = rotation[calls[0] % len(rotation)]
+        which = calls[0] % len(rotation)
         calls[0] += 1
-        hyps, _ = translator.translate_ids(src, **kw)
+        hyps, _ = translator.translate_ids(rotation[which], **kw)
+        last["which"], last["tokens"] = which, hyps
         return sum(len(h[0]) for h in hyps)
 
     for _ in range(args.warmup):
@@ -379,6 +476,7 @@ def main():
         total_tokens //= world
         value /= world
     stats = translator.last_stats()
+    timed_last = dict(last)
 
     result = {
         "metric": "generated tokens/sec (%s, batch=32, beam=%d), whole job" % (args.compute_type, args.beam),
@@ -412,6 +510,13 @@ def main():
             "encode_ms_last_call": stats["encode_ms"],
         },
     }
+
+    if rank == 0 and not tp and not args.no_token_check and timed_last:
+        # the LAST call of the timed region (fused arg-max, decoder-stack launch, reused session,
+        # grouped step graphs) against a second interpreter with all of that switched off
+        ref = unfused_tokens(args, timed_last["which"])
+        result["config"]["tokens_equal_unfused"] = (None if ref is None else
+                                                    bool([h[0] for h in timed_last["tokens"]] == ref))
 
     if tp and args.check_tp_parity:
         hyps_tp, _ = translator.translate_ids(sources, **kw)
@@ -487,6 +592,12 @@ def main():
                 result["config"]["tp_local"] = tp_local_leg(model_dir, sources, kw, ref_hyps)
             except Exception as e:  # never break the headline line
                 result["config"]["tp_local"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and (args.tp_shm or not args.no_profile) and args.compute_type == "int8" and args.beam == 1:
+            try:
+                ref_hyps, _ = translator.translate_ids(sources, **kw)
+                result["config"]["tp_shm"] = tp_shm_leg(model_dir, args, ref_hyps)
+            except Exception as e:  # never break the headline line
+                result["config"]["tp_shm"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_profile and args.compute_type == "int8":
             try:
                 result["config"]["prefill_gemm"] = prefill_gemm_leg()
