@@ -69,49 +69,30 @@ __device__ __forceinline__ float dot_tail(const float (&q)[K], const float (&k)[
 
 
 // One wave, one (row, head), d_head 64, one query row (the m = 1 forms), no RoPE, no ancestry
-// table: the body of attn_x_decode_kernel<64> without its launch-latency tricks, for callers that
-// already hold q and the new key / value in registers (lane = channel).
+// table: the arithmetic of attn_x_decode_kernel<64> for callers whose workgroup has already STAGED
+// the first 64 cache rows in LDS (the cache of past steps does not depend on the step's
+// activations, so its loads ride under the LayerNorm / projection that precede the attention):
 //   qd, knew, vnew  this lane's channel of q, of the step's new key and value (has_new)
-//   kc, vc          cache rows of the (row, head): key t at kc + t * kvs; the caller has ALREADY
-//                   stored the new key / value at position t_cached (or will: they are taken from
-//                   the registers, never re-read)
+//   ks [64][68]     keys 0 .. 63 (row min(t, t_last) for t < n_keys); position t_cached is patched
+//                   with knew here. vs [64][64]: values likewise (vnew taken from the register)
+//   kc, vc          the cache rows in memory for the keys >= 64: key t at kc + t * kvs
 //   t_cached        keys in the cache before this step (self-attention) / valid memory length
 //   n_keys          n of the reference's MatMul: t_cached + 1 (self) or the PADDED memory length
 //   n_valid         size of the SoftMax
-//   tq [64], tp [t_pad], ks [64][68]: this wave's LDS scratch
+//   tq [64], tp [t_pad]: this wave's LDS scratch
 // Returns this lane's channel of the context.
-__device__ __noinline__ float attn_exact_wave64(float qd, bool has_new, float knew, float vnew,
+__device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float knew, float vnew,
                                                    const float* __restrict__ kc,
                                                    const float* __restrict__ vc, int kvs, int t_cached,
                                                    int n_keys, int n_valid, float scale, float* tq,
-                                                   float* tp, int t_pad, float* ks) {
+                                                   float* tp, int t_pad, float* ks, const float* vs) {
   constexpr int DH = 64, XKS = DH + 4, R4 = DH / 4, KPI = 64 / R4, XVB = 16;
   const int lane = threadIdx.x & 63;
   const int cl = lane;
   const int pos = t_cached;
   const int t_last = max(t_cached - 1, 0);  // loads are clamped to rows that were written
-  v4f kpre[R4];
-#pragma unroll
-  for (int it = 0; it < R4; ++it) {
-    kpre[it] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (it * KPI < n_keys) {
-      const int i_ = it * 64 + lane;
-      const int tl = min(i_ / R4, t_last);
-      kpre[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
-    }
-  }
-#define CT2X_CW_LOAD_V(VR, T0)                                            \
-  _Pragma("unroll") for (int j = 0; j < XVB; ++j) {                       \
-    const int t_ = (T0) + j;                                              \
-    const int tc_ = min(t_, t_last);                                      \
-    const float g_ = vc[tc_ * kvs + cl];                                  \
-    VR[j] = (has_new && t_ == pos) ? vnew : g_;                           \
-  }
-  float vr[4][XVB];
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-    if (b * XVB < n_keys) CT2X_CW_LOAD_V(vr[b], b * XVB)
   tq[cl] = qd;
+  if (has_new && pos < 64) ks[pos * XKS + cl] = knew;
   __builtin_amdgcn_wave_barrier();
 
   // ---- QK^T: lane = key
@@ -121,11 +102,8 @@ __device__ __noinline__ float attn_exact_wave64(float qd, bool has_new, float kn
   const bool single = n_keys <= 64;
   for (int t0 = 0; t0 < n_keys; t0 += 64) {
     const int n_tile = min(64, n_keys - t0);
-    v4f st[R4];
-    if (t0 == 0) {
-#pragma unroll
-      for (int it = 0; it < R4; ++it) st[it] = kpre[it];
-    } else {
+    if (t0 != 0) {
+      v4f st[R4];
 #pragma unroll
       for (int it = 0; it < R4; ++it) {
         st[it] = v4f{0.f, 0.f, 0.f, 0.f};
@@ -135,18 +113,18 @@ __device__ __noinline__ float attn_exact_wave64(float qd, bool has_new, float kn
           st[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
         }
       }
-    }
-    __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < R4; ++it) {
-      if (it * KPI < n_tile) {
-        const int i_ = it * 64 + lane;
-        *reinterpret_cast<v4f*>(ks + (i_ / R4) * XKS + (i_ % R4) * 4) = st[it];
+      for (int it = 0; it < R4; ++it) {
+        if (it * KPI < n_tile) {
+          const int i_ = it * 64 + lane;
+          *reinterpret_cast<v4f*>(ks + (i_ / R4) * XKS + (i_ % R4) * 4) = st[it];
+        }
       }
+      __builtin_amdgcn_wave_barrier();
+      if (has_new && pos >= t0 && pos < t0 + 64) ks[(pos - t0) * XKS + cl] = knew;
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-    if (has_new && pos >= t0 && pos < t0 + 64) ks[(pos - t0) * XKS + cl] = knew;
-    __builtin_amdgcn_wave_barrier();
     const int t = t0 + lane;
     float s = 0.f;
     if (lane < n_tile) {
@@ -218,14 +196,26 @@ __device__ __noinline__ float attn_exact_wave64(float qd, bool has_new, float kn
       }                                                                                      \
     }                                                                                        \
   }
+  // keys 0 .. 63: values from the staged tile, eight at a time
+  for (int t0 = 0; t0 < min(n_keys, 64); t0 += 8) {
+    float v8[8];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    if (b * XVB < n_keys) {
-      CT2X_CW_BLOCK(vr[b], 0, b * XVB)
-      if (b * XVB + 8 < n_keys) CT2X_CW_BLOCK(vr[b], 8, b * XVB + 8)
+    for (int j = 0; j < 8; ++j) {
+      const int t_ = t0 + j;
+      const float g_ = vs[min(t_, t_last) * DH + cl];
+      v8[j] = (has_new && t_ == pos) ? vnew : g_;
     }
+    CT2X_CW_BLOCK(v8, 0, t0)
   }
-  if (n_keys > 4 * XVB) {  // longer rows: two batches in flight, alternating
+#define CT2X_CW_LOAD_V(VR, T0)                                            \
+  _Pragma("unroll") for (int j = 0; j < XVB; ++j) {                       \
+    const int t_ = (T0) + j;                                              \
+    const int tc_ = min(t_, t_last);                                      \
+    const float g_ = vc[tc_ * kvs + cl];                                  \
+    VR[j] = (has_new && t_ == pos) ? vnew : g_;                           \
+  }
+  if (n_keys > 4 * XVB) {  // longer rows from memory: two batches in flight, alternating
+    float vr[2][XVB];
     CT2X_CW_LOAD_V(vr[0], 4 * XVB)
     for (int t0 = 4 * XVB; t0 < n_keys; t0 += 2 * XVB) {
       CT2X_CW_LOAD_V(vr[1], t0 + XVB)
@@ -242,5 +232,36 @@ __device__ __noinline__ float attn_exact_wave64(float qd, bool has_new, float kn
   asm volatile("" ::"v"(y));
   return y;
 }
+
+// The staging that goes with it, by ALL threads of a 512-thread workgroup: rows t < min(n_keys, 64)
+// of the (row, head)'s keys and values - row min(t, t_last), as the one-wave kernel clamps its
+// loads - as two 16-byte pieces per thread and tensor. request() before the work that hides the
+// latency, store() after it (then a barrier before the attention wave reads the tiles).
+struct AttnStage64 {
+  v4f k[2], v[2];
+  __device__ __forceinline__ void request(const float* __restrict__ kc, const float* __restrict__ vc, int kvs,
+                                          int t_cached, int n_keys) {
+    const int t_last = max(t_cached - 1, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = i * 512 + static_cast<int>(threadIdx.x), r = piece >> 4, c4 = piece & 15;
+      k[i] = v4f{0.f, 0.f, 0.f, 0.f};
+      v[i] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (r < n_keys) {
+        const int rc = min(r, t_last);
+        k[i] = *reinterpret_cast<const v4f*>(kc + static_cast<int64_t>(rc) * kvs + c4 * 4);
+        v[i] = *reinterpret_cast<const v4f*>(vc + static_cast<int64_t>(rc) * kvs + c4 * 4);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* ks, float* vs) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = i * 512 + static_cast<int>(threadIdx.x), r = piece >> 4, c4 = piece & 15;
+      *reinterpret_cast<v4f*>(ks + r * 68 + c4 * 4) = k[i];
+      *reinterpret_cast<v4f*>(vs + r * 64 + c4 * 4) = v[i];
+    }
+  }
+};
 
 }  // namespace ct2x

@@ -63,7 +63,8 @@ struct Shared {
   float outv[256];                 // GEMV outputs of the slice (q | k | v, or the inner columns)
   float red[16];
   float tq[kDH];
-  float ks[64 * kXKS];
+  float ks[64 * kXKS];             // keys 0 .. 63 of the (row, head), staged by the whole workgroup
+  float vs[64 * kDH];              // values likewise
   int dead;                        // a poll ran out: stop waiting, results are void
 };
 
@@ -77,16 +78,27 @@ __device__ __forceinline__ int dot16(const v4i w, const v4i x, int acc) {
 
 // Member slice of a packed Dense: [chunks = K / 16][NS rows][16 bytes]. Thread t serves row
 // t % NS and the chunks [kp * CPT, (kp + 1) * CPT) with kp = t / NS (idle when kp >= KP).
-template <int NS, int KP, int CPT>
+// The shape is a template argument of the CALLS, not of the register array: ONE array serves the
+// input projections of all three sub-layers, so nothing but the array that is really in flight is
+// live across the attention core; every call sits in a branch that is uniform for the workgroup and
+// issues its loads back to back.
+template <int CAP>  // chunks per thread the register array can hold
 struct Gemv {
-  v4i w[CPT];
+  v4i w[CAP];
+  template <int NS, int KP, int CPT>
   __device__ __forceinline__ void request(const int8_t* __restrict__ slice) {
+    static_assert(CPT <= CAP && NS * KP <= kThreads, "Gemv shape");
     const int t = threadIdx.x, j = t % NS, kp = t / NS;
     const v4i* base = reinterpret_cast<const v4i*>(slice) + static_cast<size_t>(kp) * CPT * NS + j;
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) w[i] = (kp < KP) ? base[static_cast<size_t>(i) * NS] : v4i{0, 0, 0, 0};
+    for (int i = 0; i < CAP; ++i) w[i] = v4i{0, 0, 0, 0};
+    if (kp < KP) {
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) w[i] = __builtin_nontemporal_load(base + static_cast<size_t>(i) * NS);
+    }
   }
-  // returns the int32 sum of row t of the slice to the threads t < NS (after two barriers)
+  // returns the int32 sum of row t of the slice to the threads t < NS (after a barrier)
+  template <int NS, int KP, int CPT>
   __device__ __forceinline__ int finish(Shared& sh) {
     const int t = threadIdx.x, kp = t / NS;
     const v4i* xq4 = reinterpret_cast<const v4i*>(sh.xq) + (kp < KP ? kp : 0) * CPT;
@@ -123,25 +135,6 @@ __device__ __forceinline__ float block_absmax(float v, Shared& sh) {
 #pragma unroll
   for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, sh.red[w]);
   return m;
-}
-
-// LayerNorm / RMSNorm of the row (element t in `v`) followed by ops::Quantize into sh.xq; returns
-// the quantisation scale. Every wave runs the statistics chain itself.
-__device__ __forceinline__ float norm_quantize_row(float v, const ClusterNormW& ln, int quant_mode, Shared& sh) {
-  const int t = threadIdx.x;
-  constexpr int pad = 68;
-  sh.stage[norm_chain_slot(t, kD, pad)] = v;
-  __syncthreads();
-  float sum, sumsq;
-  ordered_row_stats_t<true>(sh.stage, pad, kD, sum, sumsq);
-  const bool layer_norm = ln.beta != nullptr;
-  const NormStats st = norm_stats(sum, sumsq, kD, ln.eps, layer_norm);
-  const float y = norm_apply(v, ln.gamma[t], layer_norm ? ln.beta[t] : 0.f, st, layer_norm, ln.rms_use_residual != 0, t);
-  const float amax = block_absmax(y, sh);
-  const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
-  sh.xq[t] = to_s8(y, scale, quant_mode);
-  __syncthreads();
-  return scale;
 }
 
 // ---- hand-over between the members of a cluster ---------------------------------------------
@@ -183,6 +176,54 @@ __device__ __forceinline__ void await(Cluster& c, Shared& sh) {
 
 }  // namespace
 
+// per-thread operands of a phase, requested together with the phase's weights (nothing on the
+// dependent chain of a phase should be a first-touch global load)
+struct ColRegs {  // Dequantize operands of this thread's output column
+  float wscale, bias;
+  bool has_bias;
+  __device__ __forceinline__ void request(const ClusterDenseW& w, int col, bool active) {
+    has_bias = w.bias != nullptr;
+    wscale = 1.f;
+    bias = 0.f;
+    if (active) {
+      wscale = w.wscale[col];
+      if (has_bias) bias = w.bias[col];
+    }
+  }
+};
+struct NormRegs {  // element t of the norm's parameters
+  float gamma, beta, eps;
+  bool layer_norm, rms_use_residual;
+  __device__ __forceinline__ void request(const ClusterNormW& n) {
+    layer_norm = n.beta != nullptr;
+    rms_use_residual = n.rms_use_residual != 0;
+    eps = n.eps;
+    gamma = n.gamma[threadIdx.x];
+    beta = layer_norm ? n.beta[threadIdx.x] : 0.f;
+  }
+};
+
+// LayerNorm / RMSNorm of the row (element t in `v`) followed by ops::Quantize into sh.xq; returns
+// the quantisation scale. Every wave runs the statistics chain itself.
+__device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, int quant_mode, Shared& sh) {
+  const int t = threadIdx.x;
+  constexpr int pad = 68;
+  sh.stage[norm_chain_slot(t, kD, pad)] = v;
+  __syncthreads();
+  float sum, sumsq;
+  ordered_row_stats_t<true>(sh.stage, pad, kD, sum, sumsq);
+  const NormStats st = norm_stats(sum, sumsq, kD, ln.eps, ln.layer_norm);
+  const float y = norm_apply(v, ln.gamma, ln.beta, st, ln.layer_norm, ln.rms_use_residual, t);
+  const float amax = block_absmax(y, sh);
+  const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+  sh.xq[t] = to_s8(y, scale, quant_mode);
+  __syncthreads();
+  return scale;
+}
+
+#define CT2X_CL_STAMP(i)                                                                     \
+  if (a.stamps != nullptr && blockIdx.x == 0 && t == 0) a.stamps[stamp_base + (i)] = wall_clock64();
+
 // grid = rows * 8 workgroups of 512 threads; blockIdx = row * 8 + member
 __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -195,11 +236,26 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
   cl.counter = a.counters + static_cast<size_t>(row) * 16;
   cl.error = a.error;
   if (t == 0) sh.dead = 0;
+  int stamp_base = 0;
+  CT2X_CL_STAMP(0)
   // where the counter stood when this launch began: the members of the previous launch all left
   // at a multiple of kMembers, and at most kMembers - 1 early arrivals of THIS launch's first
   // meeting can have been added since
   cl.arrivals = __hip_atomic_load(cl.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / kMembers * kMembers;
   const int step = *a.step_ptr;
+  const int mem_len = a.mem_lengths[row];
+
+  // operands of the NEXT input projection (QKV / cross-attention query / feed-forward input) and
+  // of the next output projection: requested one meeting ahead
+  Gemv<16> g_in;
+  Gemv<4> g_out;  // (the one array that is live across the attention core)
+  ColRegs c_in, c_out;
+  NormRegs n_in;
+  const int qkv_col = (t >> 6) * kD + member * kDH + (t & 63);  // Q | K | V sections of linear_0
+  const int out_col = member * kDH + (t & 63);                  // this thread's column of a 64-wide slice
+  g_in.request<192, 2, 16>(a.layers[0].qkv.w + static_cast<size_t>(member) * 192 * kD);
+  c_in.request(a.layers[0].qkv, qkv_col, t < 192);
+  n_in.request(a.layers[0].ln_self);
 
   // ---- embedding row (embed_kernel, rowops.hip), every member for itself ----------------------
   float xv;
@@ -217,120 +273,103 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
     if (p) xv = xv + p[t];
   }
   sh.x_row[t] = xv;
-
-  Gemv<192, 2, 16> g_qkv;
-  g_qkv.request(a.layers[0].qkv.w + static_cast<size_t>(member) * 192 * kD);
+  stamp_base = 1;
 
   for (int l = 0; l < a.n_layers; ++l) {
-    const ClusterLayerArgs& L = a.layers[l];
-    // ================= masked self-attention ==================================================
-    {
-      const float scale = norm_quantize_row(xv, L.ln_self, a.quant_mode, sh);
-      const int sum = g_qkv.finish(sh);
-      if (t < 192) {
-        const int col = (t >> 6) * kD + member * kDH + (t & 63);  // q | k | v sections of linear_0
-        sh.outv[t] = dense_epilogue(sum, 1.f / scale, L.qkv.wscale[col], L.qkv.bias != nullptr,
-                                    L.qkv.bias ? L.qkv.bias[col] : 0.f, -1);
+    const ClusterLayerArgs& L = a.layers[l];  // (kernel arguments: scalar loads)
+    CT2X_CL_STAMP(0)
+    // ====== masked self-attention (sub 0), encoder-decoder attention (sub 1): one body, so that
+    // ====== the attention core is instantiated once and keeps the whole register file
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+      const bool self = sub == 0;
+      const ClusterDenseW& W_out = self ? L.self_out : L.cross_out;
+      // self: keys = the cache + this step's; cross: the PADDED memory, SoftMax over its length
+      const int t_cached = self ? max(0, min(step, a.t_max)) : max(0, min(mem_len, a.s_max));
+      const int n_keys = self ? t_cached + 1 : a.s_max;
+      float* kc_self = L.self_k + (static_cast<int64_t>(row) * kMembers + member) * a.t_max * kDH;
+      float* vc_self = L.self_v + (static_cast<int64_t>(row) * kMembers + member) * a.t_max * kDH;
+      const float* kc_cross = L.cross_kv + static_cast<int64_t>(row) * a.s_max * (2 * kD) + member * kDH;
+      const float* kc = self ? kc_self : kc_cross;
+      const float* vc = self ? vc_self : kc_cross + kD;
+      const int kvs = self ? kDH : 2 * kD;
+      // the cache rows of past steps do not depend on this step: their loads ride under the norm
+      // and the projection
+      AttnStage64 stage;
+      stage.request(kc, vc, kvs, t_cached, n_keys);
+      {
+        const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh);
+        const int sum = self ? g_in.finish<192, 2, 16>(sh) : g_in.finish<64, 8, 4>(sh);
+        if (t < (self ? 192 : 64))
+          sh.outv[t] = dense_epilogue(sum, 1.f / scale, c_in.wscale, c_in.has_bias, c_in.bias, -1);
       }
-    }
-    Gemv<64, 8, 4> g_out;
-    g_out.request(L.self_out.w + static_cast<size_t>(member) * 64 * kD);
-    __syncthreads();
-    if (wave == 0) {
-      const int t_cached = max(0, min(step, a.t_max));
-      const float qd = sh.outv[lane], knew = sh.outv[64 + lane], vnew = sh.outv[128 + lane];
-      float* kc = L.self_k + (static_cast<int64_t>(row) * kMembers + member) * a.t_max * kDH;
-      float* vc = L.self_v + (static_cast<int64_t>(row) * kMembers + member) * a.t_max * kDH;
-      if (t_cached < a.t_max) {  // cache append in place of ops::Concat (attention.cc:541-546)
-        kc[t_cached * kDH + lane] = knew;
-        vc[t_cached * kDH + lane] = vnew;
-      }
-      const float ctx = attn_exact_wave64(qd, true, knew, vnew, kc, vc, kDH, t_cached, t_cached + 1,
-                                          t_cached + 1, L.self_scale, sh.tq, tp, a.t_pad, sh.ks);
-      publish(xch + kXchCtx + member * kDH + lane, ctx);
-    }
-    arrive(cl);
-    await(cl, sh);
-    // ---- attention output projection + residual ----------------------------------------------
-    {
-      const float c = observe(xch + kXchCtx + t);
-      const float amax = block_absmax(c, sh);
-      const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
-      sh.xq[t] = to_s8(c, scale, a.quant_mode);
+      stage.store(sh.ks, sh.vs);
+      g_out.request<64, 8, 4>(W_out.w + static_cast<size_t>(member) * 64 * kD);
+      c_out.request(W_out, out_col, t < 64);
       __syncthreads();
-      const int sum = g_out.finish(sh);
-      if (t < 64) {
-        const int col = member * kDH + t;
-        float v = dense_epilogue(sum, 1.f / scale, L.self_out.wscale[col], L.self_out.bias != nullptr,
-                                 L.self_out.bias ? L.self_out.bias[col] : 0.f, -1);
-        v = sh.x_row[col] + v;
-        publish(xch + kXchX + col, v);
+      CT2X_CL_STAMP(1 + 5 * sub)
+      if (wave == 0) {
+        const float qd = sh.outv[lane];
+        const float knew = self ? sh.outv[64 + lane] : 0.f, vnew = self ? sh.outv[128 + lane] : 0.f;
+        if (self && t_cached < a.t_max) {  // cache append in place of ops::Concat (attention.cc:541-546)
+          kc_self[t_cached * kDH + lane] = knew;
+          vc_self[t_cached * kDH + lane] = vnew;
+        }
+        const float ctx = attn_exact_wave64(qd, self, knew, vnew, kc, vc, kvs, t_cached, n_keys,
+                                            self ? t_cached + 1 : t_cached, self ? L.self_scale : L.cross_scale,
+                                            sh.tq, tp, a.t_pad, sh.ks, sh.vs);
+        publish(xch + kXchCtx + member * kDH + lane, ctx);
       }
-    }
-    arrive(cl);
-    Gemv<64, 8, 4> g_cq;
-    g_cq.request(L.cross_q.w + static_cast<size_t>(member) * 64 * kD);
-    await(cl, sh);
-    // ================= encoder-decoder attention ==============================================
-    xv = observe(xch + kXchX + t);
-    sh.x_row[t] = xv;
-    {
-      const float scale = norm_quantize_row(xv, L.ln_cross, a.quant_mode, sh);
-      const int sum = g_cq.finish(sh);
-      if (t < 64) {
-        const int col = member * kDH + t;
-        sh.outv[t] = dense_epilogue(sum, 1.f / scale, L.cross_q.wscale[col], L.cross_q.bias != nullptr,
-                                    L.cross_q.bias ? L.cross_q.bias[col] : 0.f, -1);
+      CT2X_CL_STAMP(2 + 5 * sub)
+      arrive(cl);
+      await(cl, sh);
+      CT2X_CL_STAMP(3 + 5 * sub)
+      // ---- attention output projection + residual --------------------------------------------
+      {
+        const float c = observe(xch + kXchCtx + t);
+        const float amax = block_absmax(c, sh);
+        const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+        sh.xq[t] = to_s8(c, scale, a.quant_mode);
+        __syncthreads();
+        const int sum = g_out.finish<64, 8, 4>(sh);
+        if (t < 64) {
+          float v = dense_epilogue(sum, 1.f / scale, c_out.wscale, c_out.has_bias, c_out.bias, -1);
+          v = sh.x_row[out_col] + v;
+          publish(xch + kXchX + out_col, v);
+        }
       }
-    }
-    Gemv<64, 8, 4> g_co;
-    g_co.request(L.cross_out.w + static_cast<size_t>(member) * 64 * kD);
-    __syncthreads();
-    if (wave == 0) {
-      const int len = max(0, min(a.mem_lengths[row], a.s_max));
-      const float* kc = L.cross_kv + static_cast<int64_t>(row) * a.s_max * (2 * kD) + member * kDH;
-      const float ctx = attn_exact_wave64(sh.outv[lane], false, 0.f, 0.f, kc, kc + kD, 2 * kD, len, a.s_max,
-                                          len, L.cross_scale, sh.tq, tp, a.t_pad, sh.ks);
-      publish(xch + kXchCtx + member * kDH + lane, ctx);
-    }
-    arrive(cl);
-    await(cl, sh);
-    {
-      const float c = observe(xch + kXchCtx + t);
-      const float amax = block_absmax(c, sh);
-      const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
-      sh.xq[t] = to_s8(c, scale, a.quant_mode);
-      __syncthreads();
-      const int sum = g_co.finish(sh);
-      if (t < 64) {
-        const int col = member * kDH + t;
-        float v = dense_epilogue(sum, 1.f / scale, L.cross_out.wscale[col], L.cross_out.bias != nullptr,
-                                 L.cross_out.bias ? L.cross_out.bias[col] : 0.f, -1);
-        v = sh.x_row[col] + v;
-        publish(xch + kXchX + col, v);
+      CT2X_CL_STAMP(4 + 5 * sub)
+      arrive(cl);
+      if (self) {
+        g_in.request<64, 8, 4>(L.cross_q.w + static_cast<size_t>(member) * 64 * kD);
+        c_in.request(L.cross_q, out_col, t < 64);
+        n_in.request(L.ln_cross);
+      } else {
+        g_in.request<256, 2, 16>(L.ffn0.w + static_cast<size_t>(member) * 256 * kD);
+        c_in.request(L.ffn0, member * 256 + (t & 255), t < 256);
+        n_in.request(L.ln_ffn);
       }
+      await(cl, sh);
+      CT2X_CL_STAMP(5 + 5 * sub)
+      xv = observe(xch + kXchX + t);
+      sh.x_row[t] = xv;
     }
-    arrive(cl);
-    Gemv<256, 2, 16> g_f0;
-    g_f0.request(L.ffn0.w + static_cast<size_t>(member) * 256 * kD);
-    await(cl, sh);
     // ================= feed forward ===========================================================
-    xv = observe(xch + kXchX + t);
-    sh.x_row[t] = xv;
     {
-      const float scale = norm_quantize_row(xv, L.ln_ffn, a.quant_mode, sh);
-      const int sum = g_f0.finish(sh);
+      const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh);
+      const int sum = g_in.finish<256, 2, 16>(sh);
       if (t < 256) {
-        const int col = member * 256 + t;
-        const float v = dense_epilogue(sum, 1.f / scale, L.ffn0.wscale[col], L.ffn0.bias != nullptr,
-                                       L.ffn0.bias ? L.ffn0.bias[col] : 0.f, a.act);
-        publish(xch + kXchInner + col, v);
+        const float v = dense_epilogue(sum, 1.f / scale, c_in.wscale, c_in.has_bias, c_in.bias, a.act);
+        publish(xch + kXchInner + member * 256 + t, v);
       }
     }
+    CT2X_CL_STAMP(11)
     arrive(cl);
-    Gemv<64, 8, 16> g_f1;
-    g_f1.request(L.ffn1.w + static_cast<size_t>(member) * 64 * kFfn);
+    Gemv<16> g_f1;
+    g_f1.request<64, 8, 16>(L.ffn1.w + static_cast<size_t>(member) * 64 * kFfn);
+    c_out.request(L.ffn1, out_col, t < 64);
     await(cl, sh);
+    CT2X_CL_STAMP(12)
     {
       float iv[4];
 #pragma unroll
@@ -341,26 +380,31 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
 #pragma unroll
       for (int i = 0; i < 4; ++i) sh.xq[i * kThreads + t] = to_s8(iv[i], scale, a.quant_mode);
       __syncthreads();
-      const int sum = g_f1.finish(sh);
+      const int sum = g_f1.finish<64, 8, 16>(sh);
       if (t < 64) {
-        const int col = member * kDH + t;
-        float v = dense_epilogue(sum, 1.f / scale, L.ffn1.wscale[col], L.ffn1.bias != nullptr,
-                                 L.ffn1.bias ? L.ffn1.bias[col] : 0.f, -1);
-        v = sh.x_row[col] + v;
-        if (l + 1 < a.n_layers) publish(xch + kXchX + col, v);
-        else a.x_out[static_cast<int64_t>(row) * kD + col] = v;  // read by the next launch
+        float v = dense_epilogue(sum, 1.f / scale, c_out.wscale, c_out.has_bias, c_out.bias, -1);
+        v = sh.x_row[out_col] + v;
+        if (l + 1 < a.n_layers) publish(xch + kXchX + out_col, v);
+        else a.x_out[static_cast<int64_t>(row) * kD + out_col] = v;  // read by the next launch
       }
     }
+    CT2X_CL_STAMP(13)
     if (l + 1 < a.n_layers) {
       arrive(cl);
-      g_qkv.request(a.layers[l + 1].qkv.w + static_cast<size_t>(member) * 192 * kD);
+      const ClusterLayerArgs& N = a.layers[l + 1];
+      g_in.request<192, 2, 16>(N.qkv.w + static_cast<size_t>(member) * 192 * kD);
+      c_in.request(N.qkv, qkv_col, t < 192);
+      n_in.request(N.ln_self);
       await(cl, sh);
       xv = observe(xch + kXchX + t);
       __syncthreads();  // (the residual reads of x_row above are done)
       sh.x_row[t] = xv;
     }
+    stamp_base += 14;
   }
+  CT2X_CL_STAMP(0)
 }
+#undef CT2X_CL_STAMP
 
 // ---- weight re-pack (once per model) ----------------------------------------------------------
 // src [n, k] row-major int8 -> dst: member m's slice [k / 16][ns][16], ns = n / 8 rows; `sections`

@@ -702,7 +702,8 @@ void Engine::pack_cluster_weights() {
   }();
   cluster_ready_ = false;
   if (!enabled || tp_ || !has_encoder_ || is_whisper() || compute_type_ != ComputeType::kInt8Float32 ||
-      !dec_.pre_norm || dec_.layernorm_embedding.present || dec_.layers.empty())
+      !dec_.pre_norm || dec_.layernorm_embedding.present || dec_.layers.empty() ||
+      dec_.layers.size() > static_cast<size_t>(kClusterMaxLayers))
     return;
   auto dense_ok = [](const DenseW& w, int64_t n, int64_t k) {
     return w.present && w.quantized && !w.row_parallel && !w.awq && w.wq != nullptr && w.wscale != nullptr &&

@@ -426,13 +426,12 @@ private:
   void pack_stream(DenseW& w, bool dual);
   // Cluster-resident decoder stack (decoder_cluster.hip): every decoder layer of a greedy step in
   // ONE launch. pack_cluster_weights() re-packs the six Dense weights of every layer member-major
-  // when the model qualifies (int8, pre-norm, encoder-decoder, Transformer-base geometry);
-  // cluster_bind() writes the session's layer table (weights + this session's caches) to the device.
+  // when the model qualifies (int8, pre-norm, encoder-decoder, Transformer-base geometry); a
+  // session's launch takes the layer table (weights + that session's caches) as kernel arguments.
   void pack_cluster_weights();
   bool cluster_ready_ = false;
   std::vector<ClusterLayerArgs> cluster_layers_;  // weights part; caches filled per session
   bool cluster_applicable(const DecodeState& state) const;
-  void cluster_bind(DecodeState& state);
   // How a Dense is split over the tensor-parallel ranks (Model::load, src/models/model.cc:
   // 662-743): kColumn = output rows; `blocks` lists the sizes of the fused sub-matrices that are
   // each split separately and re-concatenated (Q | K | V of linear_0, K | V of the cross
@@ -644,13 +643,13 @@ struct DecodeState {
   bool graph_failed = false;  // capture refused (tensor parallel + collective library): eager
   bool graph_ready[2] = {false, false};
   // a whole group of greedy steps as ONE graph (Engine::step_group; reused sessions only)
-  // cluster-resident decoder stack: layer table on the device, hand-over lines, arrival counters
-  // (zero at session start, monotonic afterwards), the "a member waited in vain" flag
-  ClusterLayerArgs* cl_layers = nullptr;
+  // cluster-resident decoder stack: hand-over lines, arrival counters (zero at session start,
+  // monotonic afterwards), the "a member waited in vain" flag
   float* cl_xch = nullptr;
   unsigned* cl_counters = nullptr;
   int* cl_error = nullptr;
   int cl_t_pad = 0;
+  unsigned long long* cl_stamps = nullptr;  // CT2X_CLUSTER_STAMPS=1: timeline of workgroup 0, last step
   hipGraphExec_t group_exec = nullptr;
   int group_steps = 0;
   int group_parity = 0;

@@ -1,6 +1,9 @@
 // Sessions of the engine (engine.h): the per-call device state, the encoder passes (token ids or
 // Whisper features), the feed-forward block, layer variants and the sequence-mode decoder pass.
 #include "engine.h"
+
+#include <cstdio>
+#include <cstdlib>
 #include "host_math.h"
 
 #include <algorithm>
@@ -296,14 +299,14 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     }
     if (cluster_ready_ && !beam_mode && beam == 1 && rows <= 32 && prefill_len == 0) {
       // the decoder stack as one launch per step (decoder_cluster.hip)
-      st->cl_layers = alloc<ClusterLayerArgs>(*st, n_layers);
       st->cl_xch = alloc<float>(*st, static_cast<int64_t>(decoder_cluster_xch_floats(rows)));
       st->cl_counters = alloc<unsigned>(*st, rows * 16);
       st->cl_error = alloc<int>(*st, 1);
       st->cl_t_pad = decoder_cluster_t_pad(t_max, s_max);
       CT2X_HIP_CHECK(hipMemsetAsync(st->cl_counters, 0, sizeof(unsigned) * rows * 16, cur_stream()));
       CT2X_HIP_CHECK(hipMemsetAsync(st->cl_error, 0, sizeof(int), cur_stream()));
-      cluster_bind(*st);
+      if (const char* e = std::getenv("CT2X_CLUSTER_STAMPS"); e != nullptr && e[0] == '1')
+        st->cl_stamps = alloc<unsigned long long>(*st, 2 + kClusterStampsPerLayer * n_layers);
     }
     if (features)
       encode_features(*st, features, frames);
@@ -313,21 +316,20 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   return st;
 }
 
-void Engine::cluster_bind(DecodeState& st) {
-  if (st.cl_layers == nullptr) return;
-  std::vector<ClusterLayerArgs> table = cluster_layers_;
-  for (size_t l = 0; l < table.size(); ++l) {
-    table[l].self_k = st.self_k[0][l];
-    table[l].self_v = st.self_v[0][l];
-    table[l].cross_kv = st.cross_kv[l];
-  }
-  CT2X_HIP_CHECK(hipMemcpyAsync(st.cl_layers, table.data(), sizeof(ClusterLayerArgs) * table.size(),
-                                hipMemcpyHostToDevice, cur_stream()));
-  CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // (`table` is a temporary)
-}
-
 void Engine::check_cluster(DecodeState& st) {
   if (st.cl_error == nullptr) return;
+  if (st.cl_stamps != nullptr) {
+    // phase timeline of workgroup 0 in the session's last step (wall_clock64: 100 MHz)
+    const size_t n = 2 + kClusterStampsPerLayer * dec_.layers.size();
+    std::vector<unsigned long long> h(n);
+    CT2X_HIP_CHECK(hipMemcpy(h.data(), st.cl_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "decoder_stack timeline (us since launch start):");
+    for (size_t i = 0; i < n; ++i) {
+      if (i >= 1 && (i - 1) % kClusterStampsPerLayer == 0) std::fprintf(stderr, "\n  ");
+      std::fprintf(stderr, " %.2f", static_cast<double>(h[i] - h[0]) * 0.01);
+    }
+    std::fprintf(stderr, "\n");
+  }
   int flag = 0;
   CT2X_HIP_CHECK(hipMemcpyAsync(&flag, st.cl_error, sizeof(int), hipMemcpyDeviceToHost, st.stream));
   CT2X_HIP_CHECK(hipStreamSynchronize(st.stream));

@@ -57,8 +57,13 @@ void Engine::launch_step(DecodeState& st) {
   if (cluster) {
     // embedding + every decoder layer: ONE launch (decoder_cluster.hip)
     ClusterStackArgs ca;
-    ca.layers = st.cl_layers;
     ca.n_layers = static_cast<int>(dec_.layers.size());
+    for (int l = 0; l < ca.n_layers; ++l) {
+      ca.layers[l] = cluster_layers_[l];
+      ca.layers[l].self_k = st.self_k[0][l];
+      ca.layers[l].self_v = st.self_v[0][l];
+      ca.layers[l].cross_kv = st.cross_kv[l];
+    }
     ca.rows = static_cast<int>(rows);
     ca.t_max = static_cast<int>(st.t_max);
     ca.s_max = static_cast<int>(st.s_max);
@@ -78,6 +83,7 @@ void Engine::launch_step(DecodeState& st) {
     ca.xch = st.cl_xch;
     ca.counters = st.cl_counters;
     ca.error = st.cl_error;
+    ca.stamps = st.cl_stamps;
     {
       double wbytes = 0;
       for (const LayerW& layer : dec_.layers)
@@ -798,7 +804,7 @@ bool Engine::fused_argmax_applicable(const DecodeState& st) const {
 }
 
 bool Engine::cluster_applicable(const DecodeState& st) const {
-  return cluster_ready_ && st.cl_layers != nullptr && !taps_ && !tp_ && st.beam == 1 && !st.beam_mode &&
+  return cluster_ready_ && st.cl_xch != nullptr && !taps_ && !tp_ && st.beam == 1 && !st.beam_mode &&
          !st.ancestry && st.att_hist == nullptr && st.cur == 0 && st.rows >= 1 && st.rows <= 32 &&
          st.mem_lengths != nullptr;
 }
@@ -864,7 +870,6 @@ void Engine::compact_rows(DecodeState& st, const std::vector<int32_t>& keep, int
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // (`keep` may be a temporary)
   st.rows = n_new;
   st.batch = n_new;
-  cluster_bind(st);  // (the layer table of the decoder-stack launch names the caches that just moved)
   for (int i = 0; i < 2; ++i) {
     if (st.graph_exec[i]) (void)hipGraphExecDestroy(st.graph_exec[i]);
     st.graph_exec[i] = nullptr;

@@ -236,8 +236,11 @@ struct ClusterLayerArgs {
   const float* cross_kv = nullptr; // [batch, s_max, 2 * d_model] (K | V)
   float self_scale = 1.f, cross_scale = 1.f;
 };
+constexpr int kClusterMaxLayers = 8;
 struct ClusterStackArgs {
-  const ClusterLayerArgs* layers = nullptr;  // device array [n_layers]
+  // by value: kernel arguments are read with scalar loads the compiler knows to be invariant (a
+  // table in device memory costs a vector load + a full drain of the memory pipe per field)
+  ClusterLayerArgs layers[kClusterMaxLayers];
   int n_layers = 0, rows = 0, t_max = 0, s_max = 0, t_pad = 0, quant_mode = 0, act = 0;
   const void* emb_table = nullptr;
   int emb_int8 = 0, emb_apply_mul = 0;
@@ -251,7 +254,10 @@ struct ClusterStackArgs {
   float* xch = nullptr;                 // decoder_cluster_xch_floats(rows): the hand-over lines
   unsigned* counters = nullptr;         // [rows * 16], zero at session start, never reset
   int* error = nullptr;                 // set when a member waited in vain (results void)
+  // timeline of workgroup 0 (CT2X_CLUSTER_STAMPS=1): 1 + 14 per layer + 1 wall_clock64 values
+  unsigned long long* stamps = nullptr;
 };
+constexpr int kClusterStampsPerLayer = 14;
 // d_model 512, 8 heads of 64, feed-forward 2048 (Transformer-base); everything else keeps the
 // launch-per-op path
 bool decoder_cluster_geometry_ok(int64_t d_model, int64_t heads, int64_t dhead, int64_t ffn);
