@@ -31,6 +31,8 @@
 // agent-scope atomic loads, arrival = one relaxed atomicAdd after the stores have drained, bounded
 // polls - a lost peer raises the error flag, it never hangs the device.
 
+#include <cstdlib>
+
 #include "attention_exact_core.h"
 #include "device_utils.h"
 #include "grid_sync.h"
@@ -67,6 +69,15 @@ struct Shared {
   float vs[64 * kDH];              // values likewise
   int dead;                        // a poll ran out: stop waiting, results are void
 };
+
+// Workgroup barrier for LDS hand-overs ONLY: waits for this wave's LDS traffic, not for its global
+// loads. __syncthreads() carries a workgroup-scope fence that drains vmcnt as well - and with it
+// the weight requests of the NEXT phase that are deliberately left in flight across the barriers of
+// this one (the workgroups of a launch never exchange global data except through Handover, whose
+// atomics carry their own ordering).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 __device__ __forceinline__ int dot16(const v4i w, const v4i x, int acc) {
   acc = __builtin_amdgcn_sdot4(w.x, x.x, acc, false);
@@ -106,7 +117,7 @@ struct Gemv {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) acc = dot16(w[i], xq4[i], acc);
     if (kp < KP) sh.part[t] = acc;
-    __syncthreads();
+    lds_barrier();
     int sum = 0;
     if (t < NS) {
 #pragma unroll
@@ -128,9 +139,9 @@ __device__ __forceinline__ float dense_epilogue(int sum, float r_a, float w_scal
 
 __device__ __forceinline__ float block_absmax(float v, Shared& sh) {
   float m = wave_max_dpp(fabsf(v));
-  __syncthreads();  // (red is reused)
+  lds_barrier();  // (red is reused)
   if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = m;
-  __syncthreads();
+  lds_barrier();
   m = sh.red[0];
 #pragma unroll
   for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, sh.red[w]);
@@ -138,41 +149,98 @@ __device__ __forceinline__ float block_absmax(float v, Shared& sh) {
 }
 
 // ---- hand-over between the members of a cluster ---------------------------------------------
-struct Cluster {
-  unsigned* counter;
-  unsigned arrivals;  // value the counter reaches when every member has arrived at the NEXT meeting
+// Two forms (CT2X_CLUSTER_HANDOVER, A/B in profiles/r05_cluster_handover_ab.txt):
+//   counter (TAGGED = false): the lines are plain floats; a member drains its stores, arrives with one
+//     relaxed atomicAdd on the cluster's counter, polls the counter, then reads the lines: four
+//     dependent trips to the memory side per meeting.
+//   tagged  (TAGGED = true): every float travels as a 64-bit slot {tag, value} written by ONE atomic
+//     store; the reader polls the slot it needs until it carries the meeting's tag: the data IS the
+//     flag - no drain, no counter, two trips. Tags never repeat within a session (launch epoch x 64
+//     + meeting index), so a stale slot can not be mistaken; a slot is only rewritten two meetings
+//     later, when every member has provably consumed it (each meeting needs all members' lines of
+//     the previous one).
+template <bool TAGGED>
+struct Handover {
+  float* lines;            // counter form: [kXchFloats] floats; tagged form: as many 64-bit slots
+  unsigned* counter;       // counter form: arrivals (monotonic)
+  unsigned arrivals;
+  unsigned tag;            // tagged form: tag of the NEXT meeting
   int* error;
-};
 
-__device__ __forceinline__ void publish(float* dst, float v) {
-  __hip_atomic_store(reinterpret_cast<unsigned*>(dst), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float observe(const float* src) {
-  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-// first half: this member's published stores have left, it arrives
-__device__ __forceinline__ void arrive(Cluster& c) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    __hip_atomic_fetch_add(c.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  c.arrivals += kMembers;
-}
-// second half: wait until every member has arrived
-__device__ __forceinline__ void await(Cluster& c, Shared& sh) {
-  if (threadIdx.x == 0 && !sh.dead) {
-    unsigned spins = 0;
-    while (static_cast<int>(__hip_atomic_load(c.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - c.arrivals) < 0) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > kSpinLimit) {
-        sh.dead = 1;
-        atomicExch(c.error, 1);
-        break;
-      }
+  __device__ __forceinline__ void publish(int idx, float v) {
+    if (TAGGED) {
+      const unsigned long long u = (static_cast<unsigned long long>(tag) << 32) | __float_as_uint(v);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(lines) + idx, u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(reinterpret_cast<unsigned*>(lines) + idx, __float_as_uint(v), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  __syncthreads();
-}
+  // after the publishing code of a meeting (all threads)
+  __device__ __forceinline__ void arrive() {
+    if (!TAGGED) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this member's published stores have left
+      lds_barrier();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      arrivals += kMembers;
+    }
+  }
+  // before the collecting code of a meeting (all threads); also the workgroup barrier between the
+  // LDS reads of the phase behind and the LDS writes of the phase ahead
+  __device__ __forceinline__ void await(Shared& sh) {
+    if (!TAGGED) {
+      if (threadIdx.x == 0 && !sh.dead) {
+        unsigned spins = 0;
+        while (static_cast<int>(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - arrivals) < 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > kSpinLimit) {
+            sh.dead = 1;
+            atomicExch(error, 1);
+            break;
+          }
+        }
+      }
+    }
+    lds_barrier();
+  }
+  // N lines of this meeting, idx[i] each; call done() once per meeting after the last collect
+  template <int N>
+  __device__ __forceinline__ void collect(const int (&idx)[N], float (&out)[N], Shared& sh) {
+    if (TAGGED) {
+      const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(lines);
+      unsigned long long u[N];
+      unsigned spins = 0;
+      bool ok;
+      do {
+#pragma unroll
+        for (int i = 0; i < N; ++i) u[i] = __hip_atomic_load(slots + idx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) ok = ok && static_cast<unsigned>(u[i] >> 32) == tag;
+        if (!ok && (++spins > kSpinLimit || sh.dead)) {
+          sh.dead = 1;
+          atomicExch(error, 1);
+          break;
+        }
+      } while (!ok);
+#pragma unroll
+      for (int i = 0; i < N; ++i) out[i] = __uint_as_float(static_cast<unsigned>(u[i]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        out[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(lines) + idx[i], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT));
+    }
+  }
+  __device__ __forceinline__ float collect1(int idx, Shared& sh) {
+    const int i1[1] = {idx};
+    float o1[1];
+    collect<1>(i1, o1, sh);
+    return o1[0];
+  }
+  __device__ __forceinline__ void done() { ++tag; }
+};
 
 }  // namespace
 
@@ -209,7 +277,7 @@ __device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, 
   const int t = threadIdx.x;
   constexpr int pad = 68;
   sh.stage[norm_chain_slot(t, kD, pad)] = v;
-  __syncthreads();
+  lds_barrier();
   float sum, sumsq;
   ordered_row_stats_t<true>(sh.stage, pad, kD, sum, sumsq);
   const NormStats st = norm_stats(sum, sumsq, kD, ln.eps, ln.layer_norm);
@@ -217,7 +285,7 @@ __device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, 
   const float amax = block_absmax(y, sh);
   const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
   sh.xq[t] = to_s8(y, scale, quant_mode);
-  __syncthreads();
+  lds_barrier();
   return scale;
 }
 
@@ -225,23 +293,28 @@ __device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, 
   if (a.stamps != nullptr && blockIdx.x == 0 && t == 0) a.stamps[stamp_base + (i)] = wall_clock64();
 
 // grid = rows * 8 workgroups of 512 threads; blockIdx = row * 8 + member
+template <bool TAGGED>
 __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Shared& sh = *reinterpret_cast<Shared*>(smem_raw);
   float* tp = reinterpret_cast<float*>(smem_raw + sizeof(Shared));  // attention scores [t_pad]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int member = blockIdx.x % kMembers, row = blockIdx.x / kMembers;
-  float* xch = a.xch + static_cast<size_t>(row) * kXchFloats;
-  Cluster cl;
-  cl.counter = a.counters + static_cast<size_t>(row) * 16;
-  cl.error = a.error;
+  Handover<TAGGED> ho;
+  ho.lines = a.xch + static_cast<size_t>(row) * kXchFloats * (TAGGED ? 2 : 1);
+  ho.counter = a.counters + static_cast<size_t>(row) * 16;
+  ho.error = a.error;
   if (t == 0) sh.dead = 0;
   int stamp_base = 0;
   CT2X_CL_STAMP(0)
-  // where the counter stood when this launch began: the members of the previous launch all left
-  // at a multiple of kMembers, and at most kMembers - 1 early arrivals of THIS launch's first
-  // meeting can have been added since
-  cl.arrivals = __hip_atomic_load(cl.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / kMembers * kMembers;
+  // counter form: where the counter stood when this launch began - the members of the previous
+  // launch all left at a multiple of kMembers, and at most kMembers - 1 early arrivals of THIS
+  // launch's first meeting can have been added since. Tagged form: the launch epoch of this row
+  // (advanced by member 0 when the launch ends; zero at session start, so is every slot's tag).
+  ho.arrivals = TAGGED ? 0u
+                       : __hip_atomic_load(ho.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / kMembers * kMembers;
+  const unsigned epoch = TAGGED ? ho.counter[1] : 0u;
+  ho.tag = epoch * 64u + 1u;
   const int step = *a.step_ptr;
   const int mem_len = a.mem_lengths[row];
 
@@ -306,7 +379,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       stage.store(sh.ks, sh.vs);
       g_out.request<64, 8, 4>(W_out.w + static_cast<size_t>(member) * 64 * kD);
       c_out.request(W_out, out_col, t < 64);
-      __syncthreads();
+      lds_barrier();
       CT2X_CL_STAMP(1 + 5 * sub)
       if (wave == 0) {
         const float qd = sh.outv[lane];
@@ -318,28 +391,29 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
         const float ctx = attn_exact_wave64(qd, self, knew, vnew, kc, vc, kvs, t_cached, n_keys,
                                             self ? t_cached + 1 : t_cached, self ? L.self_scale : L.cross_scale,
                                             sh.tq, tp, a.t_pad, sh.ks, sh.vs);
-        publish(xch + kXchCtx + member * kDH + lane, ctx);
+        ho.publish(kXchCtx + member * kDH + lane, ctx);
       }
       CT2X_CL_STAMP(2 + 5 * sub)
-      arrive(cl);
-      await(cl, sh);
+      ho.arrive();
+      ho.await(sh);
       CT2X_CL_STAMP(3 + 5 * sub)
       // ---- attention output projection + residual --------------------------------------------
       {
-        const float c = observe(xch + kXchCtx + t);
+        const float c = ho.collect1(kXchCtx + t, sh);
+        ho.done();
         const float amax = block_absmax(c, sh);
         const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
         sh.xq[t] = to_s8(c, scale, a.quant_mode);
-        __syncthreads();
+        lds_barrier();
         const int sum = g_out.finish<64, 8, 4>(sh);
         if (t < 64) {
           float v = dense_epilogue(sum, 1.f / scale, c_out.wscale, c_out.has_bias, c_out.bias, -1);
           v = sh.x_row[out_col] + v;
-          publish(xch + kXchX + out_col, v);
+          ho.publish(kXchX + out_col, v);
         }
       }
       CT2X_CL_STAMP(4 + 5 * sub)
-      arrive(cl);
+      ho.arrive();
       if (self) {
         g_in.request<64, 8, 4>(L.cross_q.w + static_cast<size_t>(member) * 64 * kD);
         c_in.request(L.cross_q, out_col, t < 64);
@@ -349,9 +423,10 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
         c_in.request(L.ffn0, member * 256 + (t & 255), t < 256);
         n_in.request(L.ln_ffn);
       }
-      await(cl, sh);
+      ho.await(sh);
       CT2X_CL_STAMP(5 + 5 * sub)
-      xv = observe(xch + kXchX + t);
+      xv = ho.collect1(kXchX + t, sh);
+      ho.done();
       sh.x_row[t] = xv;
     }
     // ================= feed forward ===========================================================
@@ -360,48 +435,63 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       const int sum = g_in.finish<256, 2, 16>(sh);
       if (t < 256) {
         const float v = dense_epilogue(sum, 1.f / scale, c_in.wscale, c_in.has_bias, c_in.bias, a.act);
-        publish(xch + kXchInner + member * 256 + t, v);
+        ho.publish(kXchInner + member * 256 + t, v);
       }
     }
     CT2X_CL_STAMP(11)
-    arrive(cl);
+    ho.arrive();
     Gemv<16> g_f1;
     g_f1.request<64, 8, 16>(L.ffn1.w + static_cast<size_t>(member) * 64 * kFfn);
     c_out.request(L.ffn1, out_col, t < 64);
-    await(cl, sh);
+    ho.await(sh);
     CT2X_CL_STAMP(12)
     {
       float iv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) iv[i] = observe(xch + kXchInner + i * kThreads + t);
+      const int inner_idx[4] = {kXchInner + t, kXchInner + kThreads + t, kXchInner + 2 * kThreads + t,
+                                kXchInner + 3 * kThreads + t};
+      ho.template collect<4>(inner_idx, iv, sh);
+      ho.done();
       const float amax =
           block_absmax(fmaxf(fmaxf(fabsf(iv[0]), fabsf(iv[1])), fmaxf(fabsf(iv[2]), fabsf(iv[3]))), sh);
       const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) sh.xq[i * kThreads + t] = to_s8(iv[i], scale, a.quant_mode);
-      __syncthreads();
+      lds_barrier();
       const int sum = g_f1.finish<64, 8, 16>(sh);
       if (t < 64) {
         float v = dense_epilogue(sum, 1.f / scale, c_out.wscale, c_out.has_bias, c_out.bias, -1);
         v = sh.x_row[out_col] + v;
-        if (l + 1 < a.n_layers) publish(xch + kXchX + out_col, v);
-        else a.x_out[static_cast<int64_t>(row) * kD + out_col] = v;  // read by the next launch
+        const bool last = l + 1 == a.n_layers;
+        if (!last || a.q_out != nullptr) ho.publish(kXchX + out_col, v);
+        if (last) a.x_out[static_cast<int64_t>(row) * kD + out_col] = v;  // read by the next launch
       }
     }
     CT2X_CL_STAMP(13)
     if (l + 1 < a.n_layers) {
-      arrive(cl);
+      ho.arrive();
       const ClusterLayerArgs& N = a.layers[l + 1];
       g_in.request<192, 2, 16>(N.qkv.w + static_cast<size_t>(member) * 192 * kD);
       c_in.request(N.qkv, qkv_col, t < 192);
       n_in.request(N.ln_self);
-      await(cl, sh);
-      xv = observe(xch + kXchX + t);
-      __syncthreads();  // (the residual reads of x_row above are done)
+      ho.await(sh);
+      xv = ho.collect1(kXchX + t, sh);
+      ho.done();
       sh.x_row[t] = xv;
+    } else if (a.q_out != nullptr) {
+      // ---- the decoder's output norm + Quantize: the input row of the vocabulary projection ----
+      ho.arrive();
+      n_in.request(a.out_norm);
+      ho.await(sh);
+      xv = ho.collect1(kXchX + t, sh);
+      ho.done();
+      const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh);
+      // (every member holds the whole quantised row: each stores its own 64 columns)
+      if (t < kDH) a.q_out[static_cast<int64_t>(row) * kD + out_col] = sh.xq[out_col];
+      if (member == 0 && t == 0) a.qscale_out[row] = scale;
     }
     stamp_base += 14;
   }
+  if (TAGGED && member == 0 && t == 0) ho.counter[1] = epoch + 1u;  // (read by the NEXT launch's members)
   CT2X_CL_STAMP(0)
 }
 #undef CT2X_CL_STAMP
@@ -436,7 +526,10 @@ bool decoder_cluster_geometry_ok(int64_t d_model, int64_t heads, int64_t dhead, 
   return d_model == kD && heads == kMembers && dhead == kDH && ffn == kFfn;
 }
 
-size_t decoder_cluster_xch_floats(int64_t rows) { return static_cast<size_t>(rows) * kXchFloats; }
+// (sized for the tagged form: a 64-bit slot per line)
+size_t decoder_cluster_xch_floats(int64_t rows) { return static_cast<size_t>(rows) * kXchFloats * 2; }
+
+bool decoder_cluster_lds_ok(int t_pad) { return sizeof(Shared) + static_cast<size_t>(t_pad) * sizeof(float) <= 64 * 1024; }
 
 int decoder_cluster_t_pad(int64_t t_max, int64_t s_max) {
   const int64_t keys = (t_max > s_max ? t_max : s_max) + 1;
@@ -445,15 +538,16 @@ int decoder_cluster_t_pad(int64_t t_max, int64_t s_max) {
 
 void launch_decoder_cluster(const ClusterStackArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(Shared) + static_cast<size_t>(a.t_pad) * sizeof(float);
-  CT2X_CHECK(lds <= 160 * 1024, "decoder_cluster: the score row does not fit the LDS");
-  static bool opted = false;
-  if (!opted) {
-    CT2X_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_cluster_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    opted = true;
-  }
-  hipLaunchKernelGGL(decoder_cluster_kernel, dim3(static_cast<unsigned>(a.rows * kMembers)), dim3(kThreads), lds,
-                     stream, a);
+  CT2X_CHECK(lds <= 64 * 1024, "decoder_cluster: the score row does not fit the LDS");
+  CT2X_CHECK(a.n_layers >= 1 && a.n_layers <= kClusterMaxLayers && a.n_layers * 6 + 3 < 64, "decoder_cluster: layers");
+  // CT2X_CLUSTER_HANDOVER=counter: the arrival-counter form of the hand-over (A/B runs)
+  static const bool tagged = [] {
+    const char* e = std::getenv("CT2X_CLUSTER_HANDOVER");
+    return e == nullptr || e[0] != 'c';
+  }();
+  const dim3 grid(static_cast<unsigned>(a.rows * kMembers)), block(kThreads);
+  if (tagged) hipLaunchKernelGGL(decoder_cluster_kernel<true>, grid, block, lds, stream, a);
+  else hipLaunchKernelGGL(decoder_cluster_kernel<false>, grid, block, lds, stream, a);
 }
 
 }  // namespace ct2x

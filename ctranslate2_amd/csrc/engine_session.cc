@@ -297,7 +297,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
         for (int l = 0; l < n_layers; ++l)
           st->cross_kv16.push_back(alloc<uint16_t>(*st, batch * s_max * dec_.layers[l].cross.lin[1].n));
     }
-    if (cluster_ready_ && !beam_mode && beam == 1 && rows <= 32 && prefill_len == 0) {
+    if (cluster_ready_ && !beam_mode && beam == 1 && rows <= 32 && prefill_len == 0 &&
+        decoder_cluster_lds_ok(decoder_cluster_t_pad(t_max, s_max))) {
       // the decoder stack as one launch per step (decoder_cluster.hip)
       st->cl_xch = alloc<float>(*st, static_cast<int64_t>(decoder_cluster_xch_floats(rows)));
       st->cl_counters = alloc<unsigned>(*st, rows * 16);

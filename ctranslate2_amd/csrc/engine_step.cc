@@ -54,6 +54,7 @@ void Engine::launch_step(DecodeState& st) {
   const bool ffn_amax = !tp_ && !taps_ && rows <= 32 && !dec_.layers.empty() && gemm_s8_qol_enabled();
   const bool zero_amax = split_quant || ffn_amax;
   const bool cluster = cluster_applicable(st);
+  bool cluster_out_quant = false;
   if (cluster) {
     // embedding + every decoder layer: ONE launch (decoder_cluster.hip)
     ClusterStackArgs ca;
@@ -84,6 +85,18 @@ void Engine::launch_step(DecodeState& st) {
     ca.counters = st.cl_counters;
     ca.error = st.cl_error;
     ca.stamps = st.cl_stamps;
+    // the output norm + Quantize ride in the launch's tail where the projection would otherwise
+    // take them from their own launch (dense_norm's prologue form stops below 8192 columns)
+    cluster_out_quant = dec_.output_norm.present && dec_.projection.quantized && !dec_.projection.awq &&
+                        !gemm_s8_norm_applicable(rows, dec_.projection.n, dec_.projection.k);
+    if (cluster_out_quant) {
+      ca.out_norm.gamma = dec_.output_norm.gamma;
+      ca.out_norm.beta = dec_.output_norm.beta;
+      ca.out_norm.eps = dec_.output_norm.eps;
+      ca.out_norm.rms_use_residual = dec_.output_norm.use_residual ? 1 : 0;
+      ca.q_out = st.qbuf;
+      ca.qscale_out = st.qscale;
+    }
     {
       double wbytes = 0;
       for (const LayerW& layer : dec_.layers)
@@ -360,8 +373,11 @@ void Engine::launch_step(DecodeState& st) {
   QuantIn pq;
   const float* proj_in = x;
   bool fused_argmax = false;  // the vocabulary projection sampled the step itself (GreedyFuse)
-  if (!dense_norm(dec_.output_norm, dec_.projection, x, rows, -1, nullptr, st.logits)) {
-    if (dec_.output_norm.present) {
+  if (cluster_out_quant || !dense_norm(dec_.output_norm, dec_.projection, x, rows, -1, nullptr, st.logits)) {
+    if (cluster_out_quant) {
+      pq.q = st.qbuf;
+      pq.s = st.qscale;
+    } else if (dec_.output_norm.present) {
       if (dec_.projection.quantized) {
         norm_quant(dec_.output_norm, x, rows, d, nullptr, st.qbuf, st.qscale);
         pq.q = st.qbuf;

@@ -251,6 +251,11 @@ struct ClusterStackArgs {
   const int32_t* step_ptr = nullptr;
   const int32_t* mem_lengths = nullptr; // [rows]
   float* x_out = nullptr;               // [rows, d_model]: the stack's output (before the output norm)
+  // q_out != nullptr: the launch also runs the decoder's output norm + ops::Quantize on that row
+  // (the input of the vocabulary projection): q_out [rows, d_model] int8, qscale_out [rows]
+  ClusterNormW out_norm;
+  int8_t* q_out = nullptr;
+  float* qscale_out = nullptr;
   float* xch = nullptr;                 // decoder_cluster_xch_floats(rows): the hand-over lines
   unsigned* counters = nullptr;         // [rows * 16], zero at session start, never reset
   int* error = nullptr;                 // set when a member waited in vain (results void)
@@ -263,6 +268,7 @@ constexpr int kClusterStampsPerLayer = 14;
 bool decoder_cluster_geometry_ok(int64_t d_model, int64_t heads, int64_t dhead, int64_t ffn);
 size_t decoder_cluster_xch_floats(int64_t rows);
 int decoder_cluster_t_pad(int64_t t_max, int64_t s_max);
+bool decoder_cluster_lds_ok(int t_pad);  // the score row of the longest cache fits next to the tiles
 // member-major, chunk-major copy of a Dense weight [n, k]; sections = 3 for the fused Q | K | V
 void launch_pack_cluster_weight(const int8_t* w, int64_t n, int64_t k, int sections, int8_t* packed,
                                 hipStream_t stream);

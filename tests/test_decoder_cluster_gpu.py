@@ -75,9 +75,11 @@ print(json.dumps(out))
 """
 
 
-def _run(cluster):
+def _run(cluster, handover=None):
     env = dict(os.environ)
     env["CT2X_CLUSTER_STACK"] = "1" if cluster else "0"
+    if handover:
+        env["CT2X_CLUSTER_HANDOVER"] = handover
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT, "here": HERE}], env=env,
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -93,10 +95,15 @@ def test_cluster_stack_equals_launch_per_op(gpu):
             continue
         assert fused[key] == base[key], key
     for rows in (1, 2, 7, 16, 31, 32):
-        # embedding + 8 launches per layer x 6 layers became one launch
-        assert fused["plain_%d_kernels" % rows] == base["plain_%d_kernels" % rows] - 48, rows
-        assert fused["scores_%d_kernels" % rows] == base["scores_%d_kernels" % rows] - 48, rows
+        # embedding + 8 launches per layer x 6 layers + the output norm became one launch
+        assert fused["plain_%d_kernels" % rows] == base["plain_%d_kernels" % rows] - 49, rows
+        assert fused["scores_%d_kernels" % rows] == base["scores_%d_kernels" % rows] - 49, rows
     assert fused["beam4_kernels"] == base["beam4_kernels"]
     assert fused["long_eager"] == fused["long_graph"]
     assert fused["reuse"][0] == fused["reuse"][2] == fused["reuse"][3]
     assert fused["reuse"][0] != fused["reuse"][1]
+    # the arrival-counter form of the hand-over (the default is the tagged one)
+    counter = _run(True, "counter")
+    for key in base:
+        if not key.endswith("_kernels"):
+            assert counter[key] == base[key], key

@@ -22,6 +22,7 @@ cluster_iter)     # parity of the cluster kernel, its phase timeline, the A/B
   timeout 600 python -m pytest tests/test_decoder_cluster_gpu.py tests/test_bench_path_gpu.py -x -q 2>&1 | tail -5 | tee $O/cluster_iter_tests.txt
   CT2X_CLUSTER_STAMPS=1 timeout 300 python bench.py --steps 2 --warmup 1 $NOLEGS --no-token-check 2>&1 | grep -A8 "decoder_stack timeline" | tail -9 | tee $O/cluster_timeline.txt
   { for f in 0 1 1; do echo "== CT2X_CLUSTER_STACK=$f"; CT2X_CLUSTER_STACK=$f timeout 300 python bench.py --steps 20 --warmup 3 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+    for h in counter tagged counter tagged; do echo "== CT2X_CLUSTER_HANDOVER=$h"; CT2X_CLUSTER_HANDOVER=$h timeout 300 python bench.py --steps 20 --warmup 3 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
   } 2>&1 | tee $O/cluster_ab.txt ;;
 cluster_ab)       # profiles/r05_cluster_stack_ab.txt
   { for f in 0 1 0 1; do echo "== CT2X_CLUSTER_STACK=$f $2"; CT2X_CLUSTER_STACK=$f timeout 300 python bench.py --steps 20 --warmup 3 $NOLEGS $2 2>&1 | tail -1 | line; done
