@@ -304,6 +304,9 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       st->cl_counters = alloc<unsigned>(*st, rows * 16);
       st->cl_error = alloc<int>(*st, 1);
       st->cl_t_pad = decoder_cluster_t_pad(t_max, s_max);
+      // (tagged hand-over: a slot's tag must never match by accident - the lines start at tag 0,
+      // which no meeting uses, and the row epochs start at 0)
+      CT2X_HIP_CHECK(hipMemsetAsync(st->cl_xch, 0, sizeof(float) * decoder_cluster_xch_floats(rows), cur_stream()));
       CT2X_HIP_CHECK(hipMemsetAsync(st->cl_counters, 0, sizeof(unsigned) * rows * 16, cur_stream()));
       CT2X_HIP_CHECK(hipMemsetAsync(st->cl_error, 0, sizeof(int), cur_stream()));
       if (const char* e = std::getenv("CT2X_CLUSTER_STAMPS"); e != nullptr && e[0] == '1')

@@ -57,6 +57,13 @@ for call in range(4):
                               min_decoding_length=16)
     seq.append(hyps)
 out["reuse"] = seq
+# sessions of different row counts one after the other: the hand-over lines of a new session come
+# from the allocator's pool with whatever an earlier session left in them
+big = sources(32, 32, 33)
+full, _ = t.translate_ids(big, beam_size=1, max_decoding_length=40, min_decoding_length=40)
+half, _ = t.translate_ids(big[:16], beam_size=1, max_decoding_length=40, min_decoding_length=40)
+again, _ = t.translate_ids(big, beam_size=1, max_decoding_length=40, min_decoding_length=40)
+out["pool_reuse"] = [full, half, again]
 # a hard target prefix and the end token (finished rows keep being stepped)
 hyps, _ = t.translate_ids(src, beam_size=1, max_decoding_length=20, return_end_token=True)
 out["eos"] = hyps
@@ -102,6 +109,7 @@ def test_cluster_stack_equals_launch_per_op(gpu):
     assert fused["long_eager"] == fused["long_graph"]
     assert fused["reuse"][0] == fused["reuse"][2] == fused["reuse"][3]
     assert fused["reuse"][0] != fused["reuse"][1]
+    assert fused["pool_reuse"][1] == fused["pool_reuse"][0][:16] and fused["pool_reuse"][2] == fused["pool_reuse"][0]
     # the arrival-counter form of the hand-over (the default is the tagged one)
     counter = _run(True, "counter")
     for key in base:

@@ -30,8 +30,10 @@ cluster_ab)       # profiles/r05_cluster_stack_ab.txt
 tests)            # a list of test files
   shift; timeout 1200 python -m pytest "$@" -x -q 2>&1 | tail -15 | tee $O/tests.txt ;;
 rocprof_tb)       # profiles/r05_kernel_stats_bench_tb_b32.csv
-  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tb -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 $NOLEGS > /tmp/prof_tb.log 2>&1 )
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tb -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 $NOLEGS --no-token-check > /tmp/prof_tb.log 2>&1 )
   cp "$(find /tmp/prof_tb -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_bench_tb_b32.csv; head -12 $O/kernel_stats_bench_tb_b32.csv | cut -c1-200 ;;
+suite)            # the whole -m gpu suite only
+  timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -5 $O/pytest_all.log ;;
 all)              # the whole -m gpu suite, smoke and the default bench line
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -3 $O/pytest_all.log
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
