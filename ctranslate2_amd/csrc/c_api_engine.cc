@@ -116,15 +116,19 @@ double now_ms() {
 
 // SequenceToSequenceModel::initialize + load_vocabularies (src/models/sequence_to_sequence.cc:13-77)
 // / LanguageModel (src/models/language_model.cc:13-40).
-void load_vocabularies(Translator& t) {
+void load_vocabularies(Translator& t, std::shared_ptr<Vocabulary> given_src = nullptr,
+                       std::shared_ptr<Vocabulary> given_tgt = nullptr) {
   const ModelFile& m = *t.model;
   const std::string unk = m.config_string("unk_token", "<unk>");
   const std::string bos = m.config_string("bos_token", "<s>");
   const std::string eos = m.config_string("eos_token", "</s>");
   const std::string& dir = m.dir;
   if (t.engine->is_seq2seq()) {
-    auto shared = Vocabulary::load(dir, "shared_vocabulary", unk, bos, eos);
-    if (shared) {
+    auto shared = given_tgt ? nullptr : Vocabulary::load(dir, "shared_vocabulary", unk, bos, eos);
+    if (given_tgt) {  // a model handed over in memory (ct2x_translator_create_from_memory)
+      t.tgt_vocab = given_tgt;
+      t.src_vocab = given_src ? given_src : given_tgt;
+    } else if (shared) {
       t.src_vocab = t.tgt_vocab = shared;
     } else {
       t.tgt_vocab = Vocabulary::load(dir, "target_vocabulary", unk, bos, eos);
@@ -141,7 +145,7 @@ void load_vocabularies(Translator& t) {
     t.add_source_bos = m.config_bool("add_source_bos", t.add_source_bos);
     t.add_source_eos = m.config_bool("add_source_eos", t.add_source_eos);
   } else {
-    t.src_vocab = t.tgt_vocab = Vocabulary::load(dir, "vocabulary", unk, bos, eos);
+    t.src_vocab = t.tgt_vocab = given_tgt ? given_tgt : Vocabulary::load(dir, "vocabulary", unk, bos, eos);
     if (!t.tgt_vocab) throw std::runtime_error("Cannot load the vocabulary from the model directory");
   }
   t.bos_id = static_cast<int32_t>(t.tgt_vocab->bos_id());
@@ -255,6 +259,47 @@ void* ct2x_translator_create(const char* model_dir, int device_index, const char
     t->engine = std::make_unique<Engine>(t->model, compute_type ? compute_type : "default",
                                          device_index);
     load_vocabularies(*t);
+    return t.release();
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return nullptr;
+  }
+}
+
+void* ct2x_translator_create_from_memory(const char* spec, uint32_t spec_revision, uint32_t binary_version,
+                                         const char* config_json, const struct ct2x_memory_variable* vars,
+                                         int64_t num_vars, const char* const* source_tokens,
+                                         int64_t num_source_tokens, const char* const* target_tokens,
+                                         int64_t num_target_tokens, int device_index,
+                                         const char* compute_type) {
+  try {
+    std::vector<Variable> list;
+    list.reserve(static_cast<size_t>(num_vars));
+    for (int64_t i = 0; i < num_vars; ++i) {
+      Variable v;
+      v.name = vars[i].name;
+      v.dtype = vars[i].dtype;
+      v.shape.assign(vars[i].shape, vars[i].shape + vars[i].rank);
+      const size_t bytes = static_cast<size_t>(v.size()) * dtype_size(v.dtype);
+      const char* src = static_cast<const char*>(vars[i].data);
+      v.data.assign(src, src + bytes);
+      list.emplace_back(std::move(v));
+    }
+    auto t = std::make_unique<Translator>();
+    t->model = ModelFile::from_memory(spec ? spec : "", spec_revision, binary_version,
+                                      config_json ? config_json : "", std::move(list));
+    t->engine = std::make_unique<Engine>(t->model, compute_type ? compute_type : "default", device_index);
+    const ModelFile& m = *t->model;
+    const std::string unk = m.config_string("unk_token", "<unk>");
+    const std::string bos = m.config_string("bos_token", "<s>");
+    const std::string eos = m.config_string("eos_token", "</s>");
+    auto make = [&](const char* const* tokens, int64_t n) -> std::shared_ptr<Vocabulary> {
+      if (tokens == nullptr || n <= 0) return nullptr;
+      return Vocabulary::from_tokens(std::vector<std::string>(tokens, tokens + n), unk, bos, eos);
+    };
+    auto tgt = make(target_tokens, num_target_tokens);
+    if (!tgt) throw std::runtime_error("ct2x_translator_create_from_memory: the target vocabulary is required");
+    load_vocabularies(*t, make(source_tokens, num_source_tokens), tgt);
     return t.release();
   } catch (const std::exception& e) {
     set_last_error(e.what());

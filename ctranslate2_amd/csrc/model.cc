@@ -473,6 +473,40 @@ std::shared_ptr<Vocabulary> Vocabulary::load(const std::string& dir, const std::
   return vocab;
 }
 
+std::shared_ptr<Vocabulary> Vocabulary::from_tokens(std::vector<std::string> tokens, const std::string& unk,
+                                                    const std::string& bos, const std::string& eos) {
+  auto vocab = std::make_shared<Vocabulary>();
+  vocab->unk_ = unk;
+  vocab->bos_ = bos;
+  vocab->eos_ = eos;
+  for (auto& t : tokens) {
+    vocab->ids_.emplace(t, vocab->tokens_.size());
+    vocab->tokens_.emplace_back(std::move(t));
+  }
+  if (!vocab->contains(unk)) {
+    vocab->ids_.emplace(unk, vocab->tokens_.size());
+    vocab->tokens_.push_back(unk);
+  }
+  return vocab;
+}
+
+std::shared_ptr<ModelFile> ModelFile::from_memory(const std::string& spec, uint32_t revision,
+                                                  uint32_t binary_version, const std::string& config_json,
+                                                  std::vector<Variable> vars) {
+  auto model = std::make_shared<ModelFile>();
+  model->binary_version = binary_version;
+  model->spec = spec;
+  model->revision = revision;
+  for (auto& v : vars) {
+    if (static_cast<size_t>(v.size()) * dtype_size(v.dtype) != v.data.size())
+      throw std::runtime_error("Variable " + v.name + " has an invalid payload size");
+    model->index_.emplace(v.name, model->variables.size());  // (the first of two equal names wins)
+    model->variables.emplace_back(std::move(v));
+  }
+  if (!config_json.empty()) model->config = Json::parse(config_json);
+  return model;
+}
+
 const std::string& Vocabulary::to_token(size_t id) const {
   if (id >= tokens_.size())
     throw std::invalid_argument("Invalid token ID " + std::to_string(id) +

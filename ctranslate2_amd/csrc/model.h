@@ -55,6 +55,13 @@ public:
   // Throws std::runtime_error with the reference's wording where practical
   // ("Unsupported model binary version", "has an invalid payload size", ...).
   static std::shared_ptr<ModelFile> load(const std::string& dir);
+  // The same container from variables that are already in memory (the reference's
+  // ModelMemoryReader use case, include/ctranslate2/models/model_reader.h:36-55; also how a host
+  // application that has loaded the model itself hands it to this backend): `vars` are copied,
+  // `config_json` may be empty. dir stays empty: vocabularies are given separately.
+  static std::shared_ptr<ModelFile> from_memory(const std::string& spec, uint32_t revision,
+                                                uint32_t binary_version, const std::string& config_json,
+                                                std::vector<Variable> vars);
 
   std::string dir;
   uint32_t binary_version = 0;
@@ -94,6 +101,8 @@ public:
   static std::shared_ptr<Vocabulary> load(const std::string& dir, const std::string& stem,
                                           const std::string& unk, const std::string& bos,
                                           const std::string& eos);  // nullptr if absent
+  static std::shared_ptr<Vocabulary> from_tokens(std::vector<std::string> tokens, const std::string& unk,
+                                                 const std::string& bos, const std::string& eos);
   size_t size() const { return tokens_.size(); }
   const std::string& to_token(size_t id) const;
   size_t to_id(const std::string& token) const;  // unknown -> unk id

@@ -497,6 +497,26 @@ int ct2x_attention_full(const float* d_q, const float* d_k, const float* d_v,
 void* ct2x_translator_create(const char* model_dir, int device_index, const char* compute_type);
 void ct2x_translator_destroy(void* translator);
 
+/* The same engine for a model that is already in the caller's memory - Model::load(ModelReader&)
+ * on a ModelMemoryReader (include/ctranslate2/models/model_reader.h:36-55), and the entry a host
+ * application uses that has loaded the model ITSELF: the reference's own Translator on this backend
+ * hands its variables over here (INTEGRATION.md "Level 1.5"). Variables in the layout of model.bin
+ * (dtype ids of include/ctranslate2/types.h:16-23; HOST pointers, copied), the text of config.json
+ * (or NULL), the vocabularies as token lists in id order (source NULL = shared with the target). */
+struct ct2x_memory_variable {
+  const char* name;
+  int32_t dtype;
+  int32_t rank;
+  const int64_t* shape;
+  const void* data;
+};
+void* ct2x_translator_create_from_memory(const char* spec, uint32_t spec_revision, uint32_t binary_version,
+                                         const char* config_json, const struct ct2x_memory_variable* vars,
+                                         int64_t num_vars, const char* const* source_tokens,
+                                         int64_t num_source_tokens, const char* const* target_tokens,
+                                         int64_t num_target_tokens, int device_index,
+                                         const char* compute_type);
+
 /* TranslationOptions subset on the hot path (include/ctranslate2/translation.h:11-96). */
 struct ct2x_translation_options {
   int32_t beam_size;            /* 1 = greedy */

@@ -27,6 +27,14 @@ def main():
         out["runs"].append({"beam": run["beam"], "hypotheses": [h[0] for h in hyps],
                             "scores": [float(s[0]) for s in scores]})
     m.close()
+    # Level 1.5: run_translation calls the fused engine served (level15_mi355_stub.cc)
+    import ctypes
+    try:
+        fn = ctypes.CDLL(None).ct2x_level15_served_calls
+        fn.restype = ctypes.c_int64
+        out["fused_calls"] = int(fn())
+    except AttributeError:
+        out["fused_calls"] = None
     print(json.dumps(out))
 
 

@@ -24,12 +24,15 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(ROOT, "oracle", "_ref", "libct2ref_capi_mi355.so")
 
 
-def run_level1(model_dir, compute_type, sources, runs):
+def run_level1(model_dir, compute_type, sources, runs, fused=None):
     if not os.path.exists(LIB):
         pytest.skip("Level-1 integration library not built (make -C oracle mi355)")
     spec = json.dumps({"sources": sources, "runs": runs})
+    env = dict(os.environ)
+    if fused is not None:
+        env["CT2X_LEVEL1_FUSED"] = "1" if fused else "0"
     p = subprocess.run([sys.executable, os.path.join(HERE, "integration", "run_level1.py"), model_dir,
-                        compute_type, spec], capture_output=True, text=True, timeout=900)
+                        compute_type, spec], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     return json.loads(p.stdout.strip().splitlines()[-1])
 
@@ -76,3 +79,38 @@ def test_reference_translator_on_device_cuda_synthetic(gpu, golden, key):
           % (key, same, len(want)))
     # the position table is made by the host's MKL VML here too; everything else is bit-exact
     assert same >= len(want) - max(1, len(want) // 16)
+
+
+def test_level15_reference_translator_on_the_fused_engine(gpu, golden):
+    """Level 1.5 (tests/integration/level15_mi355_stub.cc): the reference's own
+    ctranslate2::Translator(model, Device::CUDA) with EncoderDecoderReplica::run_translation served
+    by the fused engine - API identical, the model handed over from the reference's memory
+    (ct2x_translator_create_from_memory). Same tokens as the op-by-op route (CT2X_LEVEL1_FUSED=0)
+    and as the reference on Device::CPU, greedy and beam search; the served-call counter shows which
+    route ran."""
+    from ctranslate2_amd import model_builder as mb
+    for key, path in (("aren-transliteration-i8", os.path.join(HERE, "golden", "models", "aren-transliteration-i8")),
+                      ("tb", "/tmp/ct2x_test_tb")):
+        g = golden[key]
+        if key == "tb" and not os.path.exists(os.path.join(path, "model.bin")):
+            mb.build_transformer(path, **GC.SYNTHETIC[key]["model"])
+        runs = [{"beam": 1, "max_len": g["max_len"], "min_len": g["min_len"]},
+                {"beam": 4, "max_len": g["max_len"], "min_len": g["min_len"]}]
+        fused = run_level1(path, "int8", g["sources"], runs, fused=True)
+        plain = run_level1(path, "int8", g["sources"], runs, fused=False)
+        assert fused["fused_calls"] == len(runs) and plain["fused_calls"] == 0
+        for a, b, name in zip(fused["runs"], plain["runs"], ("beam1", "beam4")):
+            want = [h[0] for h in g["runs"][name]["hypotheses"]]
+            same = sum(int(x == y) for x, y in zip(a["hypotheses"], want))
+            print("Level 1.5 %s %s: %d/%d sentences identical to Device::CPU" % (key, name, same, len(want)))
+            assert a["hypotheses"] == want
+            # (the op-by-op route builds the position table and its softmax through generic ops: the
+            # bound of test_reference_translator_on_device_cuda_synthetic)
+            same_b = sum(int(x == y) for x, y in zip(b["hypotheses"], want))
+            assert same_b >= len(want) - max(1, len(want) // 8), same_b
+            ref_scores = [sc[0] for sc in g["runs"][name]["scores"]]
+            # (the fused engine restates the reference's LogSoftMax order; the op-by-op route's generic
+            # ops are within the int8 noise bound of the other Level-1 tests)
+            assert max(abs(x - y) for x, y in zip(a["scores"], ref_scores)) < (1e-4 if key == "tb" else 1e-2)
+            ok = [x == y for x, y in zip(b["hypotheses"], want)]
+            assert max(abs(x - y) for x, y, k in zip(b["scores"], ref_scores, ok) if k) < 1e-2

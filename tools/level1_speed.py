@@ -34,7 +34,16 @@ def main():
         hyps, _ = m.translate_ids(sources, **kw)
         n += sum(len(h[0]) for h in hyps)
     dt = time.perf_counter() - t0
+    import ctypes
+    try:
+        fn = ctypes.CDLL(None).ct2x_level15_served_calls
+        fn.restype = ctypes.c_int64
+        served = int(fn())
+    except AttributeError:
+        served = None
     print(json.dumps({"level1_tokens_per_s": n / dt, "ms_per_call": dt / 3 * 1e3,
+                      "calls_served_by_the_fused_engine": served,
+                      "CT2X_LEVEL1_FUSED": os.environ.get("CT2X_LEVEL1_FUSED", "1"),
                       "note": "reference Translator(Device::CUDA) on libct2_mi355.so through the stubs, "
                               "Transformer-base int8, batch 32, 64 forced steps"}))
     m.close()
