@@ -105,9 +105,20 @@ struct Translator {
   // lists everything a captured step depends on. CT2X_SESSION_CACHE=0: every call builds its own.
   std::unique_ptr<DecodeState> session;
   std::vector<int64_t> session_key;
+  int64_t session_bytes = 0;  // pool bytes the kept session took when it was built
   int64_t session_hits = 0;
   WorkerPool pool;  // declared last: joined before the engine is destroyed
 };
+
+// The session a plain translate call left for the next one of its shape (Translator::session) is
+// dropped by every OTHER entry point of the handle: they would otherwise run next to tens of GB
+// nobody is going to reuse.
+void release_kept_session(Translator* t) {
+  if (t == nullptr) return;
+  std::lock_guard<std::mutex> lock(t->mutex);
+  t->session.reset();
+  t->session_key.clear();
+}
 
 double now_ms() {
   using namespace std::chrono;
@@ -976,14 +987,17 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
             dopt.use_graph ? 1 : 0, dopt.sync_every, dopt.start_step,
             static_cast<int64_t>(reinterpret_cast<uintptr_t>(thread_stream()))};
         std::unique_ptr<DecodeState> st;
+        int64_t st_bytes = t->session_bytes;
         if (plain && t->session && t->session_key == key) {
           st = std::move(t->session);
           t->engine->reencode(*st, ids.data(), lens.data());
           ++t->session_hits;
         } else {
           t->session.reset();
+          const int64_t before = allocated_bytes();
           st = t->engine->start(ids.data(), lens.data(), R, s_max, dopt.beam_size,
                                 dopt.max_length, 0, /*beam_search_state=*/biased);
+          st_bytes = allocated_bytes() - before;
         }
         t->engine->synchronize();
         const double te1 = now_ms();
@@ -1022,9 +1036,18 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
         t->engine->synchronize();
         const double te2 = now_ms();
         for (int64_t i = 0; i < B; ++i) all_results[order[begin + i]] = std::move(results[i]);
-        if (plain && ds.compactions == 0 && st->rows == R * dopt.beam_size && !st->graph_failed) {
+        // A kept session holds its buffers until the next call: only sessions below
+        // CT2X_SESSION_CACHE_MB (default 2048) stay - a 256-row NLLB-3.3B session is tens of GB that
+        // the reference would have returned to its allocator.
+        static const int64_t keep_limit = [] {
+          const char* e = std::getenv("CT2X_SESSION_CACHE_MB");
+          return (e ? std::atoll(e) : 2048LL) << 20;
+        }();
+        if (plain && ds.compactions == 0 && st->rows == R * dopt.beam_size && !st->graph_failed &&
+            st_bytes <= keep_limit) {
           t->session = std::move(st);  // (an exception on the way here leaves no session behind)
           t->session_key = key;
+          t->session_bytes = st_bytes;
         }
         std::lock_guard<std::mutex> lock(stats_mutex);
         encode_ms += te1 - te0;
@@ -1117,6 +1140,7 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
                         int32_t* out_lengths, float* out_scores) {
   API_TRY
   auto* t = static_cast<Translator*>(translator);
+  release_kept_session(t);  // (the last plain translate call's buffers: not this entry point's to keep)
   CT2X_CHECK(t != nullptr, "null translator");
   std::lock_guard<std::mutex> lock(t->mutex);
   CT2X_CHECK(!t->engine->is_seq2seq(), "This model cannot be used as a sequence generator");
@@ -1235,6 +1259,7 @@ int ct2x_score_batch(void* translator, const int32_t* src_ids, const int32_t* sr
                      int32_t* out_lengths) {
   API_TRY
   auto* t = static_cast<Translator*>(translator);
+  release_kept_session(t);  // (the last plain translate call's buffers: not this entry point's to keep)
   CT2X_CHECK(t != nullptr, "null translator");
   std::lock_guard<std::mutex> lock(t->mutex);
   CT2X_CHECK(t->engine->is_seq2seq(), "This model cannot be used as a sequence-to-sequence model");
@@ -1320,6 +1345,7 @@ int ct2x_forward_batch(void* translator, const int32_t* ids, const int32_t* leng
                        int32_t stride, int32_t return_log_probs, float* out) {
   API_TRY
   auto* t = static_cast<Translator*>(translator);
+  release_kept_session(t);  // (the last plain translate call's buffers: not this entry point's to keep)
   CT2X_CHECK(t != nullptr, "null translator");
   std::lock_guard<std::mutex> lock(t->mutex);
   Engine& e = *t->engine;
@@ -1358,6 +1384,7 @@ int ct2x_generator_score_batch(void* translator, const int32_t* ids, const int32
                                float* out_scores, int32_t* out_lengths) {
   API_TRY
   auto* t = static_cast<Translator*>(translator);
+  release_kept_session(t);  // (the last plain translate call's buffers: not this entry point's to keep)
   CT2X_CHECK(t != nullptr, "null translator");
   std::lock_guard<std::mutex> lock(t->mutex);
   Engine& e = *t->engine;
@@ -1418,6 +1445,7 @@ int ct2x_step_logits(void* translator, const int32_t* src_ids, const int32_t* sr
                      float* logits_out) {
   API_TRY
   auto* t = static_cast<Translator*>(translator);
+  release_kept_session(t);  // (the last plain translate call's buffers: not this entry point's to keep)
   CT2X_CHECK(t != nullptr, "null translator");
   std::lock_guard<std::mutex> lock(t->mutex);
   Engine& e = *t->engine;
@@ -1495,6 +1523,7 @@ int ct2x_debug_step_taps(void* translator, const int32_t* src_ids, const int32_t
                          float* logits_out) {
   API_TRY
   auto* t = static_cast<Translator*>(translator);
+  release_kept_session(t);  // (the last plain translate call's buffers: not this entry point's to keep)
   CT2X_CHECK(t != nullptr, "null translator");
   std::lock_guard<std::mutex> lock(t->mutex);
   std::lock_guard<std::mutex> tlock(g_taps_mutex);
