@@ -36,14 +36,6 @@ namespace ct2x {
 
 namespace {
 
-template <int K>
-__device__ __forceinline__ float dot_seq(const float (&q)[K], const float (&k)[K]) {
-  float s = 0.f;
-#pragma unroll
-  for (int t = 0; t < K; ++t) s = fmaf(q[t], k[t], s);
-  return s;
-}
-
 struct AttnXArgs {
   AttnDecodeParams p;
   int8_t* q_out;

@@ -68,8 +68,16 @@ __device__ __forceinline__ float dot_tail(const float (&q)[K], const float (&k)[
 }
 
 
-// One wave, one (row, head), d_head 64, one query row (the m = 1 forms), no RoPE, no ancestry
-// table: the arithmetic of attn_x_decode_kernel<64> for callers whose workgroup has already STAGED
+template <int K>
+__device__ __forceinline__ float dot_seq(const float (&q)[K], const float (&k)[K]) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < K; ++t) s = fmaf(q[t], k[t], s);
+  return s;
+}
+
+// One wave, one (row, head), d_head 64, no RoPE: the arithmetic of attn_x_decode_kernel<64> for
+// callers whose workgroup has already STAGED
 // the first 64 cache rows in LDS (the cache of past steps does not depend on the step's
 // activations, so its loads ride under the LayerNorm / projection that precede the attention):
 //   qd, knew, vnew  this lane's channel of q, of the step's new key and value (has_new)
@@ -80,13 +88,26 @@ __device__ __forceinline__ float dot_tail(const float (&q)[K], const float (&k)[
 //   n_keys          n of the reference's MatMul: t_cached + 1 (self) or the PADDED memory length
 //   n_valid         size of the SoftMax
 //   tq [64], tp [t_pad]: this wave's LDS scratch
+//   m_rows          query rows that share these keys in the reference's MatMul: 1 = the one-row
+//                   forms; > 1 (beam search over the encoder memory, except at its first step) =
+//                   MKL's GEMM forms (k-ordered chains, alpha on the packed keys)
+//   anc             beam search: position t of this row's history lives in cache row
+//                   anc[t * anc_stride] (kc / vc point at THIS row's own cache row `own_row`;
+//                   rows are kv_row_stride floats apart); nullptr = the row's own
 // Returns this lane's channel of the context.
 __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float knew, float vnew,
                                                    const float* __restrict__ kc,
                                                    const float* __restrict__ vc, int kvs, int t_cached,
                                                    int n_keys, int n_valid, float scale, float* tq,
-                                                   float* tp, int t_pad, float* ks, const float* vs) {
+                                                   float* tp, int t_pad, float* ks, const float* vs,
+                                                   int m_rows = 1, const int32_t* anc = nullptr,
+                                                   int64_t anc_stride = 0, int64_t kv_row_stride = 0,
+                                                   int own_row = 0) {
   constexpr int DH = 64, XKS = DH + 4, R4 = DH / 4, KPI = 64 / R4, XVB = 16;
+  const bool seq = m_rows > 1;
+  const bool pack_b = seq && scale != 1.f && (n_keys >= 192 || (n_keys > m_rows && n_keys >= DH));
+#define CT2X_CW_HOP(T) \
+  (anc ? (static_cast<int64_t>(anc[static_cast<int64_t>(T) * anc_stride]) - own_row) * kv_row_stride : int64_t(0))
   const int lane = threadIdx.x & 63;
   const int cl = lane;
   const int pos = t_cached;
@@ -110,7 +131,7 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
         if (it * KPI < n_tile) {
           const int i_ = it * 64 + lane;
           const int tl = min(t0 + i_ / R4, t_last);
-          st[it] = *reinterpret_cast<const v4f*>(kc + tl * kvs + (i_ % R4) * 4);
+          st[it] = *reinterpret_cast<const v4f*>(kc + CT2X_CW_HOP(tl) + tl * kvs + (i_ % R4) * 4);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -127,19 +148,39 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
     }
     const int t = t0 + lane;
     float s = 0.f;
-    if (lane < n_tile) {
-      float qv[DH], kv[DH];
-      const v4f* krow = reinterpret_cast<const v4f*>(ks + lane * XKS);
+    // the query is the same for every lane (key): it lives in SCALAR registers - 64 vector
+    // registers less in the one phase that needs a whole key row per lane as well
+    float qv[DH];
+    {
       const v4f* qrow = reinterpret_cast<const v4f*>(tq);
 #pragma unroll
       for (int c = 0; c < R4; ++c) {
-        const v4f k4 = krow[c], q4 = qrow[c];
-        kv[4 * c + 0] = k4.x; kv[4 * c + 1] = k4.y; kv[4 * c + 2] = k4.z; kv[4 * c + 3] = k4.w;
-        qv[4 * c + 0] = q4.x; qv[4 * c + 1] = q4.y; qv[4 * c + 2] = q4.z; qv[4 * c + 3] = q4.w;
+        const v4f q4 = qrow[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          qv[4 * c + e] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(q4[e])));
       }
-      if (t < main_n) s = dot_main<DH>(qv, kv);
-      else s = dot_tail<DH>(qv, kv, (t - main_n) != 1);
-      s = s * scale;
+    }
+    if (lane < n_tile) {
+      float kv[DH];
+      const v4f* krow = reinterpret_cast<const v4f*>(ks + lane * XKS);
+#pragma unroll
+      for (int c = 0; c < R4; ++c) {
+        const v4f k4 = krow[c];
+        kv[4 * c + 0] = k4.x; kv[4 * c + 1] = k4.y; kv[4 * c + 2] = k4.z; kv[4 * c + 3] = k4.w;
+      }
+      if (seq) {
+        if (pack_b) {
+#pragma unroll
+          for (int c = 0; c < DH; ++c) kv[c] = kv[c] * scale;
+        }
+        s = dot_seq<DH>(qv, kv);
+      } else if (t < main_n) {
+        s = dot_main<DH>(qv, kv);
+      } else {
+        s = dot_tail<DH>(qv, kv, (t - main_n) != 1);
+      }
+      if (!pack_b) s = s * scale;
       if (!single) tp[t] = s;
       if (t < n_valid) m_run = fmaxf(m_run, s);
     }
@@ -173,7 +214,7 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
   // ---- P.V: lane = channel
   float y = 0.f;
   bool has = false;
-  const int n_blocks = n_keys / 8;
+  const int n_blocks = seq ? 0 : n_keys / 8;  // (the GEMM forms add one key at a time)
 #define CT2X_CW_BLOCK(VR, J0, T0)                                                            \
   {                                                                                          \
     const v4f pa_ = *reinterpret_cast<const v4f*>(tp + (T0));                                \
@@ -211,7 +252,7 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
   _Pragma("unroll") for (int j = 0; j < XVB; ++j) {                       \
     const int t_ = (T0) + j;                                              \
     const int tc_ = min(t_, t_last);                                      \
-    const float g_ = vc[tc_ * kvs + cl];                                  \
+    const float g_ = vc[CT2X_CW_HOP(tc_) + tc_ * kvs + cl];               \
     VR[j] = (has_new && t_ == pos) ? vnew : g_;                           \
   }
   if (n_keys > 4 * XVB) {  // longer rows from memory: two batches in flight, alternating
@@ -229,6 +270,7 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
   }
 #undef CT2X_CW_LOAD_V
 #undef CT2X_CW_BLOCK
+#undef CT2X_CW_HOP
   asm volatile("" ::"v"(y));
   return y;
 }
@@ -240,7 +282,8 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
 struct AttnStage64 {
   v4f k[2], v[2];
   __device__ __forceinline__ void request(const float* __restrict__ kc, const float* __restrict__ vc, int kvs,
-                                          int t_cached, int n_keys) {
+                                          int t_cached, int n_keys, const int32_t* anc = nullptr,
+                                          int64_t anc_stride = 0, int64_t kv_row_stride = 0, int own_row = 0) {
     const int t_last = max(t_cached - 1, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -249,8 +292,10 @@ struct AttnStage64 {
       v[i] = v4f{0.f, 0.f, 0.f, 0.f};
       if (r < n_keys) {
         const int rc = min(r, t_last);
-        k[i] = *reinterpret_cast<const v4f*>(kc + static_cast<int64_t>(rc) * kvs + c4 * 4);
-        v[i] = *reinterpret_cast<const v4f*>(vc + static_cast<int64_t>(rc) * kvs + c4 * 4);
+        const int64_t hop =
+            anc ? (static_cast<int64_t>(anc[static_cast<int64_t>(rc) * anc_stride]) - own_row) * kv_row_stride : 0;
+        k[i] = *reinterpret_cast<const v4f*>(kc + hop + static_cast<int64_t>(rc) * kvs + c4 * 4);
+        v[i] = *reinterpret_cast<const v4f*>(vc + hop + static_cast<int64_t>(rc) * kvs + c4 * 4);
       }
     }
   }

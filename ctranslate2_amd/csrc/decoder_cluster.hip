@@ -31,6 +31,7 @@
 // agent-scope atomic loads, arrival = one relaxed atomicAdd after the stores have drained, bounded
 // polls - a lost peer raises the error flag, it never hangs the device.
 
+#include <atomic>
 #include <cstdlib>
 
 #include "attention_exact_core.h"
@@ -137,16 +138,17 @@ __device__ __forceinline__ float dense_epilogue(int sum, float r_a, float w_scal
   return apply_activation(v, act);
 }
 
-__device__ __forceinline__ float block_absmax(float v, Shared& sh) {
+__device__ __forceinline__ float block_absmax_in(float v, float* red) {
   float m = wave_max_dpp(fabsf(v));
   lds_barrier();  // (red is reused)
-  if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = m;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   lds_barrier();
-  m = sh.red[0];
+  m = red[0];
 #pragma unroll
-  for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, sh.red[w]);
+  for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, red[w]);
   return m;
 }
+__device__ __forceinline__ float block_absmax(float v, Shared& sh) { return block_absmax_in(v, sh.red); }
 
 // ---- hand-over between the members of a cluster ---------------------------------------------
 // Two forms (CT2X_CLUSTER_HANDOVER, A/B in profiles/r05_cluster_handover_ab.txt):
@@ -159,6 +161,14 @@ __device__ __forceinline__ float block_absmax(float v, Shared& sh) {
 //     + meeting index), so a stale slot can not be mistaken; a slot is only rewritten two meetings
 //     later, when every member has provably consumed it (each meeting needs all members' lines of
 //     the previous one).
+// A per-lane index behind an opaque move: the 64-bit address built from it can not be hoisted out of
+// the layer loop (hoisted addresses were the values the allocator spilled, and a spill RELOAD is a
+// vmcnt(0) wait that drains the weight requests deliberately left in flight).
+__device__ __forceinline__ int opaque_index(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 template <bool TAGGED>
 struct Handover {
   float* lines;            // counter form: [kXchFloats] floats; tagged form: as many 64-bit slots
@@ -168,6 +178,7 @@ struct Handover {
   int* error;
 
   __device__ __forceinline__ void publish(int idx, float v) {
+    idx = opaque_index(idx);
     if (TAGGED) {
       const unsigned long long u = (static_cast<unsigned long long>(tag) << 32) | __float_as_uint(v);
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(lines) + idx, u, __ATOMIC_RELAXED,
@@ -188,7 +199,8 @@ struct Handover {
   }
   // before the collecting code of a meeting (all threads); also the workgroup barrier between the
   // LDS reads of the phase behind and the LDS writes of the phase ahead
-  __device__ __forceinline__ void await(Shared& sh) {
+  template <typename S>
+  __device__ __forceinline__ void await(S& sh) {
     if (!TAGGED) {
       if (threadIdx.x == 0 && !sh.dead) {
         unsigned spins = 0;
@@ -205,16 +217,19 @@ struct Handover {
     lds_barrier();
   }
   // N lines of this meeting, idx[i] each; call done() once per meeting after the last collect
-  template <int N>
-  __device__ __forceinline__ void collect(const int (&idx)[N], float (&out)[N], Shared& sh) {
+  template <int N, typename S>
+  __device__ __forceinline__ void collect(const int (&idx)[N], float (&out)[N], S& sh) {
     if (TAGGED) {
       const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(lines);
       unsigned long long u[N];
       unsigned spins = 0;
       bool ok;
+      int at[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) at[i] = opaque_index(idx[i]);
       do {
 #pragma unroll
-        for (int i = 0; i < N; ++i) u[i] = __hip_atomic_load(slots + idx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < N; ++i) u[i] = __hip_atomic_load(slots + at[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = true;
 #pragma unroll
         for (int i = 0; i < N; ++i) ok = ok && static_cast<unsigned>(u[i] >> 32) == tag;
@@ -229,11 +244,12 @@ struct Handover {
     } else {
 #pragma unroll
       for (int i = 0; i < N; ++i)
-        out[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(lines) + idx[i], __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT));
+        out[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(lines) + opaque_index(idx[i]),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
   }
-  __device__ __forceinline__ float collect1(int idx, Shared& sh) {
+  template <typename S>
+  __device__ __forceinline__ float collect1(int idx, S& sh) {
     const int i1[1] = {idx};
     float o1[1];
     collect<1>(i1, o1, sh);
@@ -494,6 +510,420 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
   if (TAGGED && member == 0 && t == 0) ho.counter[1] = epoch + 1u;  // (read by the NEXT launch's members)
   CT2X_CL_STAMP(0)
 }
+
+// ================================================================================================
+// Beam search: the cluster owns a batch ENTRY - its `beam` hypothesis rows (<= 4) travel through
+// the launch together. The weights of a phase are requested once and serve all rows (acc[r]); the
+// rows' LayerNorm chains interleave; the encoder-decoder attention of the entry's rows shares ONE
+// staged memory tile and takes MKL's several-row forms (m = beam query rows on the same keys,
+// except at the search's first step, which the reference still runs on one row per entry:
+// src/decoding.cc:453-454); the self-attention follows the beam search's ancestry table
+// (position t of row r lives in cache row anc[t][r]) and runs two rows at a time on two tiles.
+// Same arithmetic per row as the one-row launch above and as the launch-per-op step.
+// ================================================================================================
+constexpr int kBeamRows = 4;
+
+struct SharedBeam {
+  float x_row[kBeamRows][kD];       // residual stream of the entry's rows (the source of truth)
+  float stage[kBeamRows][8 * 68 + 8];  // the rows parked for their statistics chains
+  alignas(16) int8_t xq[kBeamRows][kFfn];
+  int part[kBeamRows][kThreads];
+  float outv[kBeamRows][256];
+  float red[kBeamRows][4];
+  float rs[kBeamRows];              // quantisation scale of every row's current input
+  float tq[kBeamRows][kDH];
+  float ks[2][64 * kXKS];           // two tiles: self-attention two rows at a time; the memory tile is [0]
+  float vs[2][64 * kDH];
+  int dead;
+};
+
+// Every loop over the entry's rows is ROLLED (one copy of the per-row code; the launch must stay
+// inside the instruction cache: an unrolled first version was 94 KB of code and ran at a third of
+// the speed); what is shared between the rows - the weights of a phase - stays in registers.
+template <int CAP>
+struct GemvRows {
+  v4i w[CAP];
+  template <int NS, int KP, int CPT>
+  __device__ __forceinline__ void request(const int8_t* __restrict__ slice) {
+    static_assert(CPT <= CAP && NS * KP <= kThreads, "Gemv shape");
+    const int t = threadIdx.x, j = t % NS, kp = t / NS;
+    const v4i* base = reinterpret_cast<const v4i*>(slice) + static_cast<size_t>(kp) * CPT * NS + j;
+#pragma unroll
+    for (int i = 0; i < CAP; ++i) w[i] = v4i{0, 0, 0, 0};
+    if (kp < KP) {
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) w[i] = __builtin_nontemporal_load(base + static_cast<size_t>(i) * NS);
+    }
+  }
+  // partial sums of every row into sh.part, then a barrier; row_sum() gives t < NS its column
+  template <int NS, int KP, int CPT>
+  __device__ __forceinline__ void finish(SharedBeam& sh, int nr) {
+    const int t = threadIdx.x, kp = t / NS;
+#pragma unroll 1
+    for (int r = 0; r < nr; ++r) {
+      const v4i* xq4 = reinterpret_cast<const v4i*>(sh.xq[r]) + (kp < KP ? kp : 0) * CPT;
+      int acc = 0;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) acc = dot16(w[i], xq4[i], acc);
+      if (kp < KP) sh.part[r][t] = acc;
+    }
+    lds_barrier();
+  }
+};
+
+template <int NS, int KP>
+__device__ __forceinline__ int row_sum(const SharedBeam& sh, int r) {
+  int sum = 0;
+#pragma unroll
+  for (int p = 0; p < KP; ++p) sum += sh.part[r][p * NS + threadIdx.x];
+  return sum;
+}
+
+// The row-wide phases run the entry's rows IN PARALLEL: row rw = wave / 2 is served by two waves (128
+// threads, elements tt + 128 i of the row); waves of absent rows only keep the barriers company.
+struct RowLane {
+  int rw, tt;
+  bool on;
+  __device__ __forceinline__ RowLane(int nr) : rw(threadIdx.x >> 7), tt(threadIdx.x & 127), on((threadIdx.x >> 7) < nr) {}
+};
+
+// absmax over a row's 128 threads (one value per thread); every thread of the row returns it
+__device__ __forceinline__ float row_absmax(float v, const RowLane& rl, SharedBeam& sh) {
+  const float m = wave_max_dpp(fabsf(v));
+  lds_barrier();  // (red is reused)
+  if ((threadIdx.x & 63) == 0) sh.red[rl.rw][(threadIdx.x >> 6) & 1] = m;
+  lds_barrier();
+  return fmaxf(sh.red[rl.rw][0], sh.red[rl.rw][1]);
+}
+
+// LayerNorm / RMSNorm + Quantize of every row of the entry: sh.x_row[r] -> sh.xq[r], sh.rs[r].
+// gamma / beta of a thread's four elements come from LDS-free registers: the caller passes NormRegs4.
+struct NormRegs4 {
+  float gamma[4], beta[4], eps;
+  bool layer_norm, rms_use_residual;
+  __device__ __forceinline__ void request(const ClusterNormW& n) {
+    layer_norm = n.beta != nullptr;
+    rms_use_residual = n.rms_use_residual != 0;
+    eps = n.eps;
+    const int tt = threadIdx.x & 127;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gamma[i] = n.gamma[tt + 128 * i];
+      beta[i] = layer_norm ? n.beta[tt + 128 * i] : 0.f;
+    }
+  }
+};
+
+__device__ __forceinline__ void norm_quantize_rows(int nr, const NormRegs4& ln, int quant_mode, SharedBeam& sh) {
+  const RowLane rl(nr);
+  constexpr int pad = 68;
+  float v[4], y[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = rl.on ? sh.x_row[rl.rw][rl.tt + 128 * i] : 0.f;
+    if (rl.on) sh.stage[rl.rw][norm_chain_slot(rl.tt + 128 * i, kD, pad)] = v[i];
+  }
+  lds_barrier();
+  float sum = 0.f, sumsq = 0.f;
+  if (rl.on) ordered_row_stats_t<true>(sh.stage[rl.rw], pad, kD, sum, sumsq);
+  const NormStats st = norm_stats(sum, sumsq, kD, ln.eps, ln.layer_norm);
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    y[i] = norm_apply(v[i], ln.gamma[i], ln.beta[i], st, ln.layer_norm, ln.rms_use_residual, rl.tt + 128 * i);
+    m = fmaxf(m, fabsf(y[i]));
+  }
+  const float amax = row_absmax(m, rl, sh);
+  const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+  if (rl.on) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sh.xq[rl.rw][rl.tt + 128 * i] = to_s8(y[i], scale, quant_mode);
+    if (rl.tt == 0) sh.rs[rl.rw] = scale;
+  }
+  lds_barrier();
+}
+
+#define CT2X_CL_STAMP(i)                                                                     \
+  if (a.stamps != nullptr && blockIdx.x == 0 && t == 0) a.stamps[stamp_base + (i)] = wall_clock64();
+
+// grid = batch * 8 workgroups of 512 threads; blockIdx = entry * 8 + member; rows entry * beam + r
+__global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterStackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  SharedBeam& sh = *reinterpret_cast<SharedBeam*>(smem_raw);
+  float* tp_base = reinterpret_cast<float*>(smem_raw + sizeof(SharedBeam));  // [kBeamRows][t_pad]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int member = blockIdx.x % kMembers, entry = blockIdx.x / kMembers;
+  const int nr = a.beam;  // rows of the entry (<= kBeamRows)
+  const int row0 = entry * nr;
+  Handover<true> ho;
+  ho.lines = a.xch + static_cast<size_t>(entry) * kBeamRows * kXchFloats * 2;
+  ho.counter = a.counters + static_cast<size_t>(entry) * 16;
+  ho.error = a.error;
+  ho.arrivals = 0u;
+  if (t == 0) sh.dead = 0;
+  const unsigned epoch = ho.counter[1];
+  ho.tag = epoch * 64u + 1u;
+  const int step = *a.step_ptr;
+  const int mem_len = a.mem_lengths[entry];
+  int stamp_base = 0;
+  CT2X_CL_STAMP(0)
+  stamp_base = 1;
+  // the reference's beam search has not expanded the batch at its first step: one query row per
+  // entry, the one-row forms of the encoder-decoder attention (src/decoding.cc:453-454, 700-712)
+  const int cross_m_rows = (step == a.one_row_step) ? 1 : nr;
+
+  GemvRows<16> g_in;
+  GemvRows<4> g_out;
+  ColRegs c_in, c_out;
+  NormRegs4 n_in;
+  const RowLane rl(nr);
+  const int qkv_col = (t >> 6) * kD + member * kDH + (t & 63);
+  const int out_col = member * kDH + (t & 63);
+  g_in.request<192, 2, 16>(a.layers[0].qkv.w + static_cast<size_t>(member) * 192 * kD);
+  c_in.request(a.layers[0].qkv, qkv_col, t < 192);
+  n_in.request(a.layers[0].ln_self);
+
+  if (rl.on) {  // embedding rows (embed_kernel, rowops.hip)
+    const int64_t id = a.ids[row0 + rl.rw];
+    const float* p = a.pos_table ? a.pos_table + static_cast<int64_t>(step) * kD : nullptr;
+    const float r_s = a.emb_int8 ? 1.f / a.emb_scale[id] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = rl.tt + 128 * i;
+      float v = a.emb_int8 ? static_cast<float>(static_cast<const int8_t*>(a.emb_table)[id * kD + e]) * r_s
+                           : static_cast<const float*>(a.emb_table)[id * kD + e];
+      if (a.emb_apply_mul) v = v * a.emb_mul;
+      if (p) v = v + p[e];
+      sh.x_row[rl.rw][e] = v;
+    }
+  }
+  // (a thread reads back only what it wrote: x_row[rw][tt + 128 i])
+
+  for (int l = 0; l < a.n_layers; ++l) {
+    const ClusterLayerArgs& L = a.layers[l];
+    CT2X_CL_STAMP(0)
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+      const bool self = sub == 0;
+      const ClusterDenseW& W_out = self ? L.self_out : L.cross_out;
+      const int t_cached = self ? max(0, min(step, a.t_max)) : max(0, min(mem_len, a.s_max));
+      const int n_keys = self ? t_cached + 1 : a.s_max;
+      const int64_t kv_row_stride = static_cast<int64_t>(kMembers) * a.t_max * kDH;  // self caches
+      const float* kc_cross = L.cross_kv + static_cast<int64_t>(entry) * a.s_max * (2 * kD) + member * kDH;
+      float* self_k0 = L.self_k + (static_cast<int64_t>(row0) * kMembers + member) * a.t_max * kDH;
+      float* self_v0 = L.self_v + (static_cast<int64_t>(row0) * kMembers + member) * a.t_max * kDH;
+      // cache rows of past steps: requested now, stored into the tiles after the projection. Self:
+      // rows 0, 1 into tiles 0, 1 (rows 2, 3 follow behind the first round); cross: the entry's memory.
+      // (every path DEFINES both register sets - an absent second row re-reads the first, the memory
+      // tile is requested twice: a conditional definition would keep 32 registers alive through the
+      // whole launch)
+      AttnStage64 stage_a[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ri = (i < nr) ? i : 0;
+        if (self)
+          stage_a[i].request(self_k0 + ri * kv_row_stride, self_v0 + ri * kv_row_stride, kDH, t_cached, n_keys,
+                             a.ancestry + row0 + ri, a.rows, kv_row_stride, row0 + ri);
+        else
+          stage_a[i].request(kc_cross, kc_cross + kD, 2 * kD, t_cached, n_keys);
+      }
+      norm_quantize_rows(nr, n_in, a.quant_mode, sh);
+      if (self) g_in.finish<192, 2, 16>(sh, nr);
+      else g_in.finish<64, 8, 4>(sh, nr);
+      if (t < (self ? 192 : 64)) {
+#pragma unroll 1
+        for (int r = 0; r < nr; ++r) {
+          const int sum = self ? row_sum<192, 2>(sh, r) : row_sum<64, 8>(sh, r);
+          sh.outv[r][t] = dense_epilogue(sum, 1.f / sh.rs[r], c_in.wscale, c_in.has_bias, c_in.bias, -1);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) stage_a[i].store(sh.ks[i], sh.vs[i]);
+      g_out.request<64, 8, 4>(W_out.w + static_cast<size_t>(member) * 64 * kD);
+      c_out.request(W_out, out_col, t < 64);
+      lds_barrier();
+      CT2X_CL_STAMP(1 + 5 * sub)
+      // ---- attention: ONE call site (the core keeps the register file). Self: two rows per round
+      // on the two tiles (waves 0, 1); cross: wave w = row w on the shared memory tile.
+      const float att_scale = self ? L.self_scale : L.cross_scale;
+      const int rounds = self ? (nr + 1) / 2 : 1;
+#pragma unroll 1
+      for (int rd = 0; rd < rounds; ++rd) {
+        if (rd > 0) {  // the tiles of rows 2, 3 (every thread: the first round has read its tiles)
+          lds_barrier();
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int ri = (2 + i < nr) ? 2 + i : 2;
+            AttnStage64 next;
+            next.request(self_k0 + ri * kv_row_stride, self_v0 + ri * kv_row_stride, kDH, t_cached, n_keys,
+                         a.ancestry + row0 + ri, a.rows, kv_row_stride, row0 + ri);
+            next.store(sh.ks[i], sh.vs[i]);
+          }
+          lds_barrier();
+        }
+        const int r = self ? rd * 2 + wave : wave;
+        const bool mine = self ? (wave < 2 && r < nr) : (wave < nr);
+        if (mine) {
+          float* tq = sh.tq[r];
+          float* tp = tp_base + static_cast<size_t>(r) * a.t_pad;
+          const int tile = self ? wave : 0;
+          const float qd = sh.outv[r][lane];
+          const float knew = self ? sh.outv[r][64 + lane] : 0.f, vnew = self ? sh.outv[r][128 + lane] : 0.f;
+          float* kc_w = self_k0 + r * kv_row_stride;
+          float* vc_w = self_v0 + r * kv_row_stride;
+          if (self && t_cached < a.t_max) {  // the row appends to its OWN cache row
+            kc_w[t_cached * kDH + lane] = knew;
+            vc_w[t_cached * kDH + lane] = vnew;
+          }
+          const float ctx = attn_exact_wave64(
+              qd, self, knew, vnew, self ? kc_w : kc_cross, self ? vc_w : kc_cross + kD, self ? kDH : 2 * kD,
+              t_cached, n_keys, self ? t_cached + 1 : t_cached, att_scale, tq, tp, a.t_pad, sh.ks[tile], sh.vs[tile],
+              self ? 1 : cross_m_rows, self ? a.ancestry + row0 + r : nullptr, a.rows, kv_row_stride, row0 + r);
+          ho.publish(r * kXchFloats + kXchCtx + member * kDH + lane, ctx);
+        }
+      }
+      CT2X_CL_STAMP(2 + 5 * sub)
+      ho.await(sh);
+      CT2X_CL_STAMP(3 + 5 * sub)
+      // ---- attention output projection + residual, every row -----------------------------------
+      {
+        float c[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rl.on) {
+          const int base = rl.rw * kXchFloats + kXchCtx + rl.tt;
+          const int idx[4] = {base, base + 128, base + 256, base + 384};
+          ho.template collect<4>(idx, c, sh);
+        }
+        ho.done();
+        const float amax = row_absmax(fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3]))), rl, sh);
+        const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+        if (rl.on) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sh.xq[rl.rw][rl.tt + 128 * i] = to_s8(c[i], scale, a.quant_mode);
+          if (rl.tt == 0) sh.rs[rl.rw] = scale;
+        }
+      }
+      lds_barrier();
+      g_out.finish<64, 8, 4>(sh, nr);
+      if (t < 64) {
+#pragma unroll 1
+        for (int r = 0; r < nr; ++r) {
+          float v = dense_epilogue(row_sum<64, 8>(sh, r), 1.f / sh.rs[r], c_out.wscale, c_out.has_bias, c_out.bias, -1);
+          v = sh.x_row[r][out_col] + v;
+          ho.publish(r * kXchFloats + kXchX + out_col, v);
+        }
+      }
+      CT2X_CL_STAMP(4 + 5 * sub)
+      if (self) {
+        g_in.request<64, 8, 4>(L.cross_q.w + static_cast<size_t>(member) * 64 * kD);
+        c_in.request(L.cross_q, out_col, t < 64);
+        n_in.request(L.ln_cross);
+      } else {
+        g_in.request<256, 2, 16>(L.ffn0.w + static_cast<size_t>(member) * 256 * kD);
+        c_in.request(L.ffn0, member * 256 + (t & 255), t < 256);
+        n_in.request(L.ln_ffn);
+      }
+      ho.await(sh);  // (also: the residual reads of x_row above are done)
+      CT2X_CL_STAMP(5 + 5 * sub)
+      if (rl.on) {
+        float xr[4];
+        const int base = rl.rw * kXchFloats + kXchX + rl.tt;
+        const int idx[4] = {base, base + 128, base + 256, base + 384};
+        ho.template collect<4>(idx, xr, sh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sh.x_row[rl.rw][rl.tt + 128 * i] = xr[i];
+      }
+      ho.done();
+    }
+    // ================= feed forward ===========================================================
+    norm_quantize_rows(nr, n_in, a.quant_mode, sh);
+    g_in.finish<256, 2, 16>(sh, nr);
+    if (t < 256) {
+#pragma unroll 1
+      for (int r = 0; r < nr; ++r)
+        ho.publish(r * kXchFloats + kXchInner + member * 256 + t,
+                   dense_epilogue(row_sum<256, 2>(sh, r), 1.f / sh.rs[r], c_in.wscale, c_in.has_bias, c_in.bias, a.act));
+    }
+    CT2X_CL_STAMP(11)
+    GemvRows<16> g_f1;
+    g_f1.request<64, 8, 16>(L.ffn1.w + static_cast<size_t>(member) * 64 * kFfn);
+    c_out.request(L.ffn1, out_col, t < 64);
+    ho.await(sh);
+    CT2X_CL_STAMP(12)
+    {
+      float iv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) iv[i] = 0.f;
+      if (rl.on) {
+        const int base = rl.rw * kXchFloats + kXchInner + rl.tt;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // two batches of eight polls
+          int idx[8];
+          float got[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) idx[i] = base + 128 * (h * 8 + i);
+          ho.template collect<8>(idx, got, sh);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) iv[h * 8 + i] = got[i];
+        }
+      }
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m = fmaxf(m, fabsf(iv[i]));
+      const float amax = row_absmax(m, rl, sh);
+      const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+      if (rl.on) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sh.xq[rl.rw][rl.tt + 128 * i] = to_s8(iv[i], scale, a.quant_mode);
+        if (rl.tt == 0) sh.rs[rl.rw] = scale;
+      }
+    }
+    ho.done();
+    lds_barrier();
+    g_f1.finish<64, 8, 16>(sh, nr);
+    const bool more = l + 1 < a.n_layers;
+    if (t < 64) {
+#pragma unroll 1
+      for (int r = 0; r < nr; ++r) {
+        float v = dense_epilogue(row_sum<64, 8>(sh, r), 1.f / sh.rs[r], c_out.wscale, c_out.has_bias, c_out.bias, -1);
+        v = sh.x_row[r][out_col] + v;
+        if (more || a.q_out != nullptr) ho.publish(r * kXchFloats + kXchX + out_col, v);
+        if (!more) a.x_out[static_cast<int64_t>(row0 + r) * kD + out_col] = v;
+      }
+    }
+    CT2X_CL_STAMP(13)
+    stamp_base += 14;
+    if (more || a.q_out != nullptr) {
+      if (more) {
+        const ClusterLayerArgs& N = a.layers[l + 1];
+        g_in.request<192, 2, 16>(N.qkv.w + static_cast<size_t>(member) * 192 * kD);
+        c_in.request(N.qkv, qkv_col, t < 192);
+        n_in.request(N.ln_self);
+      } else {
+        n_in.request(a.out_norm);
+      }
+      ho.await(sh);
+      if (rl.on) {
+        float xr[4];
+        const int base = rl.rw * kXchFloats + kXchX + rl.tt;
+        const int idx[4] = {base, base + 128, base + 256, base + 384};
+        ho.template collect<4>(idx, xr, sh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sh.x_row[rl.rw][rl.tt + 128 * i] = xr[i];
+      }
+      ho.done();
+      if (!more) {
+        norm_quantize_rows(nr, n_in, a.quant_mode, sh);
+#pragma unroll 1
+        for (int r = 0; r < nr; ++r) {
+          if (t < kDH) a.q_out[static_cast<int64_t>(row0 + r) * kD + out_col] = sh.xq[r][out_col];
+          if (member == 0 && t == 0) a.qscale_out[row0 + r] = sh.rs[r];
+        }
+      }
+    }
+  }
+  if (member == 0 && t == 0) ho.counter[1] = epoch + 1u;
+  CT2X_CL_STAMP(0)
+}
 #undef CT2X_CL_STAMP
 
 // ---- weight re-pack (once per model) ----------------------------------------------------------
@@ -528,6 +958,8 @@ bool decoder_cluster_geometry_ok(int64_t d_model, int64_t heads, int64_t dhead, 
 
 // (sized for the tagged form: a 64-bit slot per line)
 size_t decoder_cluster_xch_floats(int64_t rows) { return static_cast<size_t>(rows) * kXchFloats * 2; }
+// beam search: kBeamRows line sets per batch entry
+size_t decoder_cluster_beam_xch_floats(int64_t batch) { return static_cast<size_t>(batch) * kBeamRows * kXchFloats * 2; }
 
 bool decoder_cluster_lds_ok(int t_pad) { return sizeof(Shared) + static_cast<size_t>(t_pad) * sizeof(float) <= 64 * 1024; }
 
@@ -537,9 +969,23 @@ int decoder_cluster_t_pad(int64_t t_max, int64_t s_max) {
 }
 
 void launch_decoder_cluster(const ClusterStackArgs& a, hipStream_t stream) {
+  CT2X_CHECK(a.n_layers >= 1 && a.n_layers <= kClusterMaxLayers && a.n_layers * 6 + 3 < 64, "decoder_cluster: layers");
+  if (a.beam > 1) {
+    CT2X_CHECK(a.beam <= kBeamRows && a.ancestry != nullptr && a.rows % a.beam == 0, "decoder_cluster: beam rows");
+    const size_t lds = sizeof(SharedBeam) + static_cast<size_t>(kBeamRows) * a.t_pad * sizeof(float);
+    CT2X_CHECK(lds <= 160 * 1024, "decoder_cluster: the score rows do not fit the LDS");
+    static std::atomic<bool> opted{false};
+    if (!opted.load(std::memory_order_acquire)) {
+      CT2X_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_cluster_beam_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      opted.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(decoder_cluster_beam_kernel, dim3(static_cast<unsigned>(a.rows / a.beam * kMembers)),
+                       dim3(kThreads), lds, stream, a);
+    return;
+  }
   const size_t lds = sizeof(Shared) + static_cast<size_t>(a.t_pad) * sizeof(float);
   CT2X_CHECK(lds <= 64 * 1024, "decoder_cluster: the score row does not fit the LDS");
-  CT2X_CHECK(a.n_layers >= 1 && a.n_layers <= kClusterMaxLayers && a.n_layers * 6 + 3 < 64, "decoder_cluster: layers");
   // CT2X_CLUSTER_HANDOVER=counter: the arrival-counter form of the hand-over (A/B runs)
   static const bool tagged = [] {
     const char* e = std::getenv("CT2X_CLUSTER_HANDOVER");
@@ -548,6 +994,10 @@ void launch_decoder_cluster(const ClusterStackArgs& a, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(a.rows * kMembers)), block(kThreads);
   if (tagged) hipLaunchKernelGGL(decoder_cluster_kernel<true>, grid, block, lds, stream, a);
   else hipLaunchKernelGGL(decoder_cluster_kernel<false>, grid, block, lds, stream, a);
+}
+
+bool decoder_cluster_beam_lds_ok(int t_pad) {
+  return sizeof(SharedBeam) + static_cast<size_t>(kBeamRows) * t_pad * sizeof(float) <= 160 * 1024;
 }
 
 }  // namespace ct2x

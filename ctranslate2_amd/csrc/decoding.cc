@@ -581,6 +581,7 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
       compact_pending = true;
   }
   engine.synchronize();  // drain a speculative group before the state is torn down
+  engine.check_cluster(st);
   st.fuse_beam = false;
   if (stats) stats->steps = step;
   return results;

@@ -297,16 +297,21 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
         for (int l = 0; l < n_layers; ++l)
           st->cross_kv16.push_back(alloc<uint16_t>(*st, batch * s_max * dec_.layers[l].cross.lin[1].n));
     }
-    if (cluster_ready_ && !beam_mode && beam == 1 && rows <= 32 && prefill_len == 0 &&
-        decoder_cluster_lds_ok(decoder_cluster_t_pad(t_max, s_max))) {
+    const bool cluster_greedy = !beam_mode && beam == 1 && rows <= 32 &&
+                                decoder_cluster_lds_ok(decoder_cluster_t_pad(t_max, s_max));
+    // beam search: a cluster per batch entry with its (<= 4) rows, through the ancestry table
+    const bool cluster_beam = beam_mode && st->ancestry && beam >= 2 && beam <= 4 && batch <= 32 &&
+                              decoder_cluster_beam_lds_ok(decoder_cluster_t_pad(t_max, s_max));
+    if (cluster_ready_ && prefill_len == 0 && (cluster_greedy || cluster_beam)) {
       // the decoder stack as one launch per step (decoder_cluster.hip)
-      st->cl_xch = alloc<float>(*st, static_cast<int64_t>(decoder_cluster_xch_floats(rows)));
+      const size_t xch_floats = cluster_beam ? decoder_cluster_beam_xch_floats(batch) : decoder_cluster_xch_floats(rows);
+      st->cl_xch = alloc<float>(*st, static_cast<int64_t>(xch_floats));
       st->cl_counters = alloc<unsigned>(*st, rows * 16);
       st->cl_error = alloc<int>(*st, 1);
       st->cl_t_pad = decoder_cluster_t_pad(t_max, s_max);
       // (tagged hand-over: a slot's tag must never match by accident - the lines start at tag 0,
       // which no meeting uses, and the row epochs start at 0)
-      CT2X_HIP_CHECK(hipMemsetAsync(st->cl_xch, 0, sizeof(float) * decoder_cluster_xch_floats(rows), cur_stream()));
+      CT2X_HIP_CHECK(hipMemsetAsync(st->cl_xch, 0, sizeof(float) * xch_floats, cur_stream()));
       CT2X_HIP_CHECK(hipMemsetAsync(st->cl_counters, 0, sizeof(unsigned) * rows * 16, cur_stream()));
       CT2X_HIP_CHECK(hipMemsetAsync(st->cl_error, 0, sizeof(int), cur_stream()));
       if (const char* e = std::getenv("CT2X_CLUSTER_STAMPS"); e != nullptr && e[0] == '1')

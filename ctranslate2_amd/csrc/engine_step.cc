@@ -66,6 +66,11 @@ void Engine::launch_step(DecodeState& st) {
       ca.layers[l].cross_kv = st.cross_kv[l];
     }
     ca.rows = static_cast<int>(rows);
+    if (st.beam_mode) {
+      ca.beam = static_cast<int>(st.beam);
+      ca.ancestry = st.anc[st.cur];
+      ca.one_row_step = st.prefix_first_step;  // (the first step of the CPU beam search: one row per entry)
+    }
     ca.t_max = static_cast<int>(st.t_max);
     ca.s_max = static_cast<int>(st.s_max);
     ca.t_pad = st.cl_t_pad;
@@ -820,9 +825,17 @@ bool Engine::fused_argmax_applicable(const DecodeState& st) const {
 }
 
 bool Engine::cluster_applicable(const DecodeState& st) const {
-  return cluster_ready_ && st.cl_xch != nullptr && !taps_ && !tp_ && st.beam == 1 && !st.beam_mode &&
-         !st.ancestry && st.att_hist == nullptr && st.cur == 0 && st.rows >= 1 && st.rows <= 32 &&
-         st.mem_lengths != nullptr;
+  static const bool beam_enabled = [] {  // CT2X_CLUSTER_BEAM=0: beam search keeps the launch-per-op step
+    const char* e = std::getenv("CT2X_CLUSTER_BEAM");
+    return e == nullptr || e[0] != '0';
+  }();
+  if (!cluster_ready_ || st.cl_xch == nullptr || taps_ || tp_ || st.att_hist != nullptr ||
+      st.mem_lengths == nullptr || st.rows < 1)
+    return false;
+  if (st.beam_mode)  // a cluster per batch entry, the self-attention through the ancestry table
+    return beam_enabled && st.ancestry && st.beam >= 2 && st.beam <= 4 && st.batch <= 32 &&
+           st.rows == st.batch * st.beam;
+  return st.beam == 1 && !st.ancestry && st.cur == 0 && st.rows <= 32;
 }
 
 bool Engine::compactable(const DecodeState& st) const {

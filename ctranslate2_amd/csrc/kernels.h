@@ -242,6 +242,11 @@ struct ClusterStackArgs {
   // table in device memory costs a vector load + a full drain of the memory pipe per field)
   ClusterLayerArgs layers[kClusterMaxLayers];
   int n_layers = 0, rows = 0, t_max = 0, s_max = 0, t_pad = 0, quant_mode = 0, act = 0;
+  // beam search (beam > 1): a cluster owns a batch ENTRY with its `beam` rows (<= 4); the
+  // self-attention follows the ancestry table [t_max + 1][rows]; one_row_step = the search's first
+  // step (the reference has not expanded the batch there: one-row attention forms)
+  int beam = 1, one_row_step = -1;
+  const int32_t* ancestry = nullptr;
   const void* emb_table = nullptr;
   int emb_int8 = 0, emb_apply_mul = 0;
   const float* emb_scale = nullptr;
@@ -269,6 +274,8 @@ bool decoder_cluster_geometry_ok(int64_t d_model, int64_t heads, int64_t dhead, 
 size_t decoder_cluster_xch_floats(int64_t rows);
 int decoder_cluster_t_pad(int64_t t_max, int64_t s_max);
 bool decoder_cluster_lds_ok(int t_pad);  // the score row of the longest cache fits next to the tiles
+bool decoder_cluster_beam_lds_ok(int t_pad);
+size_t decoder_cluster_beam_xch_floats(int64_t batch);
 // member-major, chunk-major copy of a Dense weight [n, k]; sections = 3 for the fused Q | K | V
 void launch_pack_cluster_weight(const int8_t* w, int64_t n, int64_t k, int sections, int8_t* packed,
                                 hipStream_t stream);

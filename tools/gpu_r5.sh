@@ -32,6 +32,11 @@ tests)            # a list of test files
 rocprof_tb)       # profiles/r05_kernel_stats_bench_tb_b32.csv
   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tb -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 $NOLEGS --no-token-check > /tmp/prof_tb.log 2>&1 )
   cp "$(find /tmp/prof_tb -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_bench_tb_b32.csv; head -12 $O/kernel_stats_bench_tb_b32.csv | cut -c1-200 ;;
+beam_iter)        # the beam-search cluster launch: parity, then the A/B of bench.py --beam 4
+  timeout 900 python -m pytest tests/test_decoder_cluster_gpu.py -x -q 2>&1 | tail -12 | tee $O/beam_iter_tests.txt
+  CT2X_CLUSTER_STAMPS=1 timeout 300 python bench.py --beam 4 --steps 2 --warmup 1 $NOLEGS --no-token-check 2>&1 | grep -A8 "decoder_stack timeline" | tail -9 | tee $O/beam_timeline.txt
+  { for f in 0 1; do echo "== CT2X_CLUSTER_BEAM=$f --beam 4"; CT2X_CLUSTER_BEAM=$f timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+  } 2>&1 | tee $O/beam_ab.txt ;;
 pmc)              # profiles/r05_pmc_traffic.json
   timeout 600 python tools/pmc_bench.py $O/pmc > $O/pmc_traffic.json; cat $O/pmc_traffic.json | head -30; find $O/pmc -name "*.csv" -size +1M -delete; find $O/pmc -name "*.db" -delete ;;
 level15)          # Level 1.5: the reference's own Translator on the fused engine
