@@ -172,7 +172,11 @@ def prefill_gemm_leg():
     out = {}
     L.ct2x_thread_stream.restype = C.c_void_p
     stream = C.c_void_p(L.ct2x_thread_stream())
+    notes = {"tb_cross_kv": "a 1 GOP launch: latency bound (launch + one K loop of 4 stages), NOT an MFMA datum",
+             "tb_encoder_ffn_in_relu_8192": "K = 512: 17 GOP against 71 MB of fp32 output - bound by the result's "
+                                            "HBM write (hbm_frac), not by the matrix pipe"}
     for name, (m, n, k, act, reps) in {"l8_prefill_ffn_in_swish": (2048, 14336, 4096, 2, 20),
+                                       "tb_encoder_ffn_in_relu_8192": (8192, 2048, 512, 0, 50),
                                        "tb_cross_kv": (1024, 1024, 512, -1, 200)}.items():
         g = torch.Generator(device="cuda").manual_seed(m + n + k)
         qa = torch.randint(-127, 128, (m, k), dtype=torch.int8, device="cuda", generator=g)
@@ -204,12 +208,14 @@ def prefill_gemm_leg():
         ops = 2.0 * m * n * k
         nbytes = m * k + n * k + 4 * n + 4 * m + 4.0 * m * n
         tops = ops / (us * 1e-6) / 1e12
-        out[name] = {"m": m, "n": n, "k": k, "activation": {2: "swish", -1: "none"}[act],
+        out[name] = {"m": m, "n": n, "k": k, "activation": {2: "swish", 0: "relu", -1: "none"}[act],
                      "avg_us": us, "launches": reps,
                      "roofline": {"bound": "mfma", "achieved": tops, "peak": INT8_MFMA_PEAK_TOPS,
                                   "unit": "TOP/s", "frac": tops / INT8_MFMA_PEAK_TOPS,
                                   "ops_per_launch": ops, "bytes_per_launch": nbytes,
                                   "hbm_frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+        if name in notes:
+            out[name]["note"] = notes[name]
         del qa, w, y
     return out
 
@@ -517,6 +523,25 @@ def main():
         ref = unfused_tokens(args, timed_last["which"])
         result["config"]["tokens_equal_unfused"] = (None if ref is None else
                                                     bool([h[0] for h in timed_last["tokens"]] == ref))
+
+    if rank == 0 and not tp and not args.no_session_reuse and not args.no_profile and args.gpus == 1:
+        # the same timed loop WITHOUT session reuse (every call builds, captures and releases its own
+        # decoding session), in its own interpreter: the switch is read once per process
+        try:
+            import subprocess
+            env = dict(os.environ, CT2X_SESSION_CACHE="0")
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-session-reuse", "--steps", "10",
+                                  "--warmup", "2", "--batch", str(args.batch), "--beam", str(args.beam),
+                                  "--src-len", str(args.src_len), "--max-len", str(args.max_len),
+                                  "--compute-type", args.compute_type, "--no-cpu-baseline", "--no-profile",
+                                  "--no-l8", "--no-whisper", "--no-nllb", "--no-token-check"],
+                                 env=env, capture_output=True, text=True, timeout=300)
+            nsr = json.loads(out.stdout.strip().splitlines()[-1])
+            result["config"]["no_session_reuse"] = {"value": nsr["value"], "unit": nsr["unit"],
+                                                    "ms_per_step": nsr["ms_per_step"],
+                                                    "session_reuse_hits": nsr["config"]["session_reuse_hits"]}
+        except Exception as e:  # never break the headline line
+            result["config"]["no_session_reuse"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if tp and args.check_tp_parity:
         hyps_tp, _ = translator.translate_ids(sources, **kw)

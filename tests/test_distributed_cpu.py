@@ -143,3 +143,22 @@ def test_two_rank_tensor_parallel_bootstrap(tmp_path):
     assert outs[0]["cover"] == outs[1]["cover"] == [1, 1]      # every row owned exactly once
     for o in outs:
         assert o["error"] is not None and ("hip" in o["error"].lower() or "device" in o["error"].lower()), o
+
+
+def test_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a torch.distributed.run environment (the way a driver may
+    invoke it) must start two ranks itself, each seeing RANK / LOCAL_RANK / WORLD_SIZE = 2; and a
+    launcher that started a different number of ranks than --gpus says is an error, not a silent
+    one-rank run. No GPU here: every rank stops at bench.py's "needs an MI355X" line - after
+    shard_info() and the world check, which is what this test is about."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    # both ranks were started and both reached the GPU check
+    assert p.stderr.count("bench.py needs an MI355X") >= 2, p.stderr[-2000:]
+    # a launcher / flag mismatch is refused before anything else
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2,
+                       capture_output=True, text=True, timeout=120)
+    assert q.returncode != 0 and "--gpus 2 but the launcher started 1 rank" in q.stderr
