@@ -653,8 +653,11 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
   float* tp_base = reinterpret_cast<float*>(smem_raw + sizeof(SharedBeam));  // [kBeamRows][t_pad]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int member = blockIdx.x % kMembers, entry = blockIdx.x / kMembers;
-  const int nr = a.beam;  // rows of the entry (<= kBeamRows)
-  const int row0 = entry * nr;
+  // beam search: the cluster's rows are the hypotheses of batch entry `entry` (they share its
+  // encoder memory); greedy batches of more than 32 rows: rows_per_cluster independent rows
+  const bool shared = a.beam > 1;
+  const int row0 = entry * a.rows_per_cluster;
+  const int nr = min(a.rows_per_cluster, a.rows - row0);  // rows of this cluster (<= kBeamRows)
   Handover<true> ho;
   ho.lines = a.xch + static_cast<size_t>(entry) * kBeamRows * kXchFloats * 2;
   ho.counter = a.counters + static_cast<size_t>(entry) * 16;
@@ -664,13 +667,13 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
   const unsigned epoch = ho.counter[1];
   ho.tag = epoch * 64u + 1u;
   const int step = *a.step_ptr;
-  const int mem_len = a.mem_lengths[entry];
+  const int mem_base = shared ? entry : row0;  // first memory (length, K / V) of the cluster's rows
   int stamp_base = 0;
   CT2X_CL_STAMP(0)
   stamp_base = 1;
   // the reference's beam search has not expanded the batch at its first step: one query row per
   // entry, the one-row forms of the encoder-decoder attention (src/decoding.cc:453-454, 700-712)
-  const int cross_m_rows = (step == a.one_row_step) ? 1 : nr;
+  const int cross_m_rows = (!shared || step == a.one_row_step) ? 1 : nr;
 
   GemvRows<16> g_in;
   GemvRows<4> g_out;
@@ -706,27 +709,31 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
     for (int sub = 0; sub < 2; ++sub) {
       const bool self = sub == 0;
       const ClusterDenseW& W_out = self ? L.self_out : L.cross_out;
-      const int t_cached = self ? max(0, min(step, a.t_max)) : max(0, min(mem_len, a.s_max));
-      const int n_keys = self ? t_cached + 1 : a.s_max;
+      const int n_keys = self ? max(0, min(step, a.t_max)) + 1 : a.s_max;
       const int64_t kv_row_stride = static_cast<int64_t>(kMembers) * a.t_max * kDH;  // self caches
-      const float* kc_cross = L.cross_kv + static_cast<int64_t>(entry) * a.s_max * (2 * kD) + member * kDH;
+      const int64_t mem_stride = shared ? 0 : static_cast<int64_t>(a.s_max) * (2 * kD);  // memories of the rows
+      const float* kc_cross = L.cross_kv + static_cast<int64_t>(mem_base) * a.s_max * (2 * kD) + member * kDH;
       float* self_k0 = L.self_k + (static_cast<int64_t>(row0) * kMembers + member) * a.t_max * kDH;
       float* self_v0 = L.self_v + (static_cast<int64_t>(row0) * kMembers + member) * a.t_max * kDH;
-      // cache rows of past steps: requested now, stored into the tiles after the projection. Self:
-      // rows 0, 1 into tiles 0, 1 (rows 2, 3 follow behind the first round); cross: the entry's memory.
-      // (every path DEFINES both register sets - an absent second row re-reads the first, the memory
-      // tile is requested twice: a conditional definition would keep 32 registers alive through the
-      // whole launch)
+      // keys before this step (self) / valid memory length (cross) of the cluster's row r
+      auto cached_of = [&](int r) {
+        return self ? max(0, min(step, a.t_max)) : max(0, min(a.mem_lengths[mem_base + (shared ? 0 : r)], a.s_max));
+      };
+      // the tile of row r: requested now, stored after the projection. Self and independent
+      // memories: rows 0, 1 into tiles 0, 1 (rows 2, 3 follow behind the first round); a shared
+      // memory: one tile. (Every path DEFINES both register sets - an absent row re-reads the
+      // first: a conditional definition would keep 32 registers alive through the whole launch.)
+      auto request_tile = [&](AttnStage64& st, int r) {
+        if (self)
+          st.request(self_k0 + r * kv_row_stride, self_v0 + r * kv_row_stride, kDH, cached_of(r), n_keys,
+                     a.ancestry ? a.ancestry + row0 + r : nullptr, a.rows, kv_row_stride, row0 + r);
+        else
+          st.request(kc_cross + r * mem_stride, kc_cross + r * mem_stride + kD, 2 * kD, cached_of(r), n_keys);
+      };
+      const bool per_row_tiles = self || !shared;
       AttnStage64 stage_a[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ri = (i < nr) ? i : 0;
-        if (self)
-          stage_a[i].request(self_k0 + ri * kv_row_stride, self_v0 + ri * kv_row_stride, kDH, t_cached, n_keys,
-                             a.ancestry + row0 + ri, a.rows, kv_row_stride, row0 + ri);
-        else
-          stage_a[i].request(kc_cross, kc_cross + kD, 2 * kD, t_cached, n_keys);
-      }
+      for (int i = 0; i < 2; ++i) request_tile(stage_a[i], (i < nr) ? i : 0);
       norm_quantize_rows(nr, n_in, a.quant_mode, sh);
       if (self) g_in.finish<192, 2, 16>(sh, nr);
       else g_in.finish<64, 8, 4>(sh, nr);
@@ -746,27 +753,26 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
       // ---- attention: ONE call site (the core keeps the register file). Self: two rows per round
       // on the two tiles (waves 0, 1); cross: wave w = row w on the shared memory tile.
       const float att_scale = self ? L.self_scale : L.cross_scale;
-      const int rounds = self ? (nr + 1) / 2 : 1;
+      const int rounds = per_row_tiles ? (nr + 1) / 2 : 1;
 #pragma unroll 1
       for (int rd = 0; rd < rounds; ++rd) {
         if (rd > 0) {  // the tiles of rows 2, 3 (every thread: the first round has read its tiles)
           lds_barrier();
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const int ri = (2 + i < nr) ? 2 + i : 2;
             AttnStage64 next;
-            next.request(self_k0 + ri * kv_row_stride, self_v0 + ri * kv_row_stride, kDH, t_cached, n_keys,
-                         a.ancestry + row0 + ri, a.rows, kv_row_stride, row0 + ri);
+            request_tile(next, (2 + i < nr) ? 2 + i : 2);
             next.store(sh.ks[i], sh.vs[i]);
           }
           lds_barrier();
         }
-        const int r = self ? rd * 2 + wave : wave;
-        const bool mine = self ? (wave < 2 && r < nr) : (wave < nr);
+        const int r = per_row_tiles ? rd * 2 + wave : wave;
+        const bool mine = per_row_tiles ? (wave < 2 && r < nr) : (wave < nr);
         if (mine) {
           float* tq = sh.tq[r];
           float* tp = tp_base + static_cast<size_t>(r) * a.t_pad;
-          const int tile = self ? wave : 0;
+          const int tile = per_row_tiles ? wave : 0;
+          const int t_cached = cached_of(r);
           const float qd = sh.outv[r][lane];
           const float knew = self ? sh.outv[r][64 + lane] : 0.f, vnew = self ? sh.outv[r][128 + lane] : 0.f;
           float* kc_w = self_k0 + r * kv_row_stride;
@@ -775,10 +781,12 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
             kc_w[t_cached * kDH + lane] = knew;
             vc_w[t_cached * kDH + lane] = vnew;
           }
+          const float* kc_m = kc_cross + r * mem_stride;
           const float ctx = attn_exact_wave64(
-              qd, self, knew, vnew, self ? kc_w : kc_cross, self ? vc_w : kc_cross + kD, self ? kDH : 2 * kD,
-              t_cached, n_keys, self ? t_cached + 1 : t_cached, att_scale, tq, tp, a.t_pad, sh.ks[tile], sh.vs[tile],
-              self ? 1 : cross_m_rows, self ? a.ancestry + row0 + r : nullptr, a.rows, kv_row_stride, row0 + r);
+              qd, self, knew, vnew, self ? kc_w : kc_m, self ? vc_w : kc_m + kD, self ? kDH : 2 * kD, t_cached, n_keys,
+              self ? t_cached + 1 : t_cached, att_scale, tq, tp, a.t_pad, sh.ks[tile], sh.vs[tile],
+              self ? 1 : cross_m_rows, (self && a.ancestry) ? a.ancestry + row0 + r : nullptr, a.rows, kv_row_stride,
+              row0 + r);
           ho.publish(r * kXchFloats + kXchCtx + member * kDH + lane, ctx);
         }
       }
@@ -958,8 +966,9 @@ bool decoder_cluster_geometry_ok(int64_t d_model, int64_t heads, int64_t dhead, 
 
 // (sized for the tagged form: a 64-bit slot per line)
 size_t decoder_cluster_xch_floats(int64_t rows) { return static_cast<size_t>(rows) * kXchFloats * 2; }
-// beam search: kBeamRows line sets per batch entry
-size_t decoder_cluster_beam_xch_floats(int64_t batch) { return static_cast<size_t>(batch) * kBeamRows * kXchFloats * 2; }
+// several rows per cluster (beam search: a batch entry; greedy batches of more than 32 rows):
+// kBeamRows line sets per cluster
+size_t decoder_cluster_beam_xch_floats(int64_t clusters) { return static_cast<size_t>(clusters) * kBeamRows * kXchFloats * 2; }
 
 bool decoder_cluster_lds_ok(int t_pad) { return sizeof(Shared) + static_cast<size_t>(t_pad) * sizeof(float) <= 64 * 1024; }
 
@@ -970,8 +979,12 @@ int decoder_cluster_t_pad(int64_t t_max, int64_t s_max) {
 
 void launch_decoder_cluster(const ClusterStackArgs& a, hipStream_t stream) {
   CT2X_CHECK(a.n_layers >= 1 && a.n_layers <= kClusterMaxLayers && a.n_layers * 6 + 3 < 64, "decoder_cluster: layers");
-  if (a.beam > 1) {
-    CT2X_CHECK(a.beam <= kBeamRows && a.ancestry != nullptr && a.rows % a.beam == 0, "decoder_cluster: beam rows");
+  if (a.rows_per_cluster > 0) {  // beam search, or a greedy batch of more than 32 rows
+    const int R = a.rows_per_cluster;
+    CT2X_CHECK(R <= kBeamRows && (a.beam == 1 || (a.beam == R && a.ancestry != nullptr && a.rows % R == 0)),
+               "decoder_cluster: rows per cluster");
+    const int clusters = (a.rows + R - 1) / R;
+    CT2X_CHECK(clusters <= 32, "decoder_cluster: more clusters than the device holds");
     const size_t lds = sizeof(SharedBeam) + static_cast<size_t>(kBeamRows) * a.t_pad * sizeof(float);
     CT2X_CHECK(lds <= 160 * 1024, "decoder_cluster: the score rows do not fit the LDS");
     static std::atomic<bool> opted{false};
@@ -980,7 +993,7 @@ void launch_decoder_cluster(const ClusterStackArgs& a, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       opted.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(decoder_cluster_beam_kernel, dim3(static_cast<unsigned>(a.rows / a.beam * kMembers)),
+    hipLaunchKernelGGL(decoder_cluster_beam_kernel, dim3(static_cast<unsigned>(clusters * kMembers)),
                        dim3(kThreads), lds, stream, a);
     return;
   }

@@ -297,14 +297,19 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
         for (int l = 0; l < n_layers; ++l)
           st->cross_kv16.push_back(alloc<uint16_t>(*st, batch * s_max * dec_.layers[l].cross.lin[1].n));
     }
-    const bool cluster_greedy = !beam_mode && beam == 1 && rows <= 32 &&
-                                decoder_cluster_lds_ok(decoder_cluster_t_pad(t_max, s_max));
+    // greedy: a cluster per row up to 32 rows, two independent rows per cluster up to 64 (measured,
+    // profiles/r05_cluster_many_rows_ab.txt: +2.6 % at 64 rows; at 128 rows - four rows per cluster -
+    // the launch-per-op step with its 128-row MFMA tiles is 9 % faster and keeps the batch)
+    const bool cluster_greedy = !beam_mode && beam == 1 &&
+                                (rows <= 32 ? decoder_cluster_lds_ok(decoder_cluster_t_pad(t_max, s_max))
+                                            : (rows <= 64 && decoder_cluster_beam_lds_ok(decoder_cluster_t_pad(t_max, s_max))));
     // beam search: a cluster per batch entry with its (<= 4) rows, through the ancestry table
     const bool cluster_beam = beam_mode && st->ancestry && beam >= 2 && beam <= 4 && batch <= 32 &&
                               decoder_cluster_beam_lds_ok(decoder_cluster_t_pad(t_max, s_max));
     if (cluster_ready_ && prefill_len == 0 && (cluster_greedy || cluster_beam)) {
       // the decoder stack as one launch per step (decoder_cluster.hip)
-      const size_t xch_floats = cluster_beam ? decoder_cluster_beam_xch_floats(batch) : decoder_cluster_xch_floats(rows);
+      const size_t xch_floats = (cluster_beam || rows > 32) ? decoder_cluster_beam_xch_floats(std::min<int64_t>(rows, 32))
+                                                             : decoder_cluster_xch_floats(rows);
       st->cl_xch = alloc<float>(*st, static_cast<int64_t>(xch_floats));
       st->cl_counters = alloc<unsigned>(*st, rows * 16);
       st->cl_error = alloc<int>(*st, 1);

@@ -68,8 +68,11 @@ void Engine::launch_step(DecodeState& st) {
     ca.rows = static_cast<int>(rows);
     if (st.beam_mode) {
       ca.beam = static_cast<int>(st.beam);
+      ca.rows_per_cluster = ca.beam;
       ca.ancestry = st.anc[st.cur];
       ca.one_row_step = st.prefix_first_step;  // (the first step of the CPU beam search: one row per entry)
+    } else if (rows > 32) {
+      ca.rows_per_cluster = static_cast<int>((rows + 31) / 32);  // 2 - 4 independent rows per cluster
     }
     ca.t_max = static_cast<int>(st.t_max);
     ca.s_max = static_cast<int>(st.s_max);
@@ -835,7 +838,7 @@ bool Engine::cluster_applicable(const DecodeState& st) const {
   if (st.beam_mode)  // a cluster per batch entry, the self-attention through the ancestry table
     return beam_enabled && st.ancestry && st.beam >= 2 && st.beam <= 4 && st.batch <= 32 &&
            st.rows == st.batch * st.beam;
-  return st.beam == 1 && !st.ancestry && st.cur == 0 && st.rows <= 32;
+  return st.beam == 1 && !st.ancestry && st.cur == 0 && st.rows <= 64;
 }
 
 bool Engine::compactable(const DecodeState& st) const {

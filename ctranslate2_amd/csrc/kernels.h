@@ -247,6 +247,10 @@ struct ClusterStackArgs {
   // step (the reference has not expanded the batch there: one-row attention forms)
   int beam = 1, one_row_step = -1;
   const int32_t* ancestry = nullptr;
+  // > 0: the several-rows launch - a cluster owns rows_per_cluster (<= 4) rows: the hypotheses of a
+  // batch entry (beam search, = beam) or that many independent rows of a greedy batch of more than
+  // 32 rows (ceil(rows / rows_per_cluster) <= 32 clusters)
+  int rows_per_cluster = 0;
   const void* emb_table = nullptr;
   int emb_int8 = 0, emb_apply_mul = 0;
   const float* emb_scale = nullptr;
@@ -275,7 +279,7 @@ size_t decoder_cluster_xch_floats(int64_t rows);
 int decoder_cluster_t_pad(int64_t t_max, int64_t s_max);
 bool decoder_cluster_lds_ok(int t_pad);  // the score row of the longest cache fits next to the tiles
 bool decoder_cluster_beam_lds_ok(int t_pad);
-size_t decoder_cluster_beam_xch_floats(int64_t batch);
+size_t decoder_cluster_beam_xch_floats(int64_t clusters);
 // member-major, chunk-major copy of a Dense weight [n, k]; sections = 3 for the fused Q | K | V
 void launch_pack_cluster_weight(const int8_t* w, int64_t n, int64_t k, int sections, int8_t* packed,
                                 hipStream_t stream);

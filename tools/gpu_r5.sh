@@ -37,6 +37,9 @@ beam_iter)        # the beam-search cluster launch: parity, then the A/B of benc
   CT2X_CLUSTER_STAMPS=1 timeout 300 python bench.py --beam 4 --steps 2 --warmup 1 $NOLEGS --no-token-check 2>&1 | grep -A8 "decoder_stack timeline" | tail -9 | tee $O/beam_timeline.txt
   { for f in 0 1; do echo "== CT2X_CLUSTER_BEAM=$f --beam 4"; CT2X_CLUSTER_BEAM=$f timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
   } 2>&1 | tee $O/beam_ab.txt ;;
+many_rows)        # greedy batches of 64 / 128 rows: several rows per cluster against the launch-per-op step
+  { for b in 64 128; do for f in 0 1; do echo "== batch $b CT2X_CLUSTER_STACK=$f"; CT2X_CLUSTER_STACK=$f timeout 300 python bench.py --batch $b --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done; done
+  } 2>&1 | tee $O/many_rows_ab.txt ;;
 pmc)              # profiles/r05_pmc_traffic.json
   timeout 600 python tools/pmc_bench.py $O/pmc > $O/pmc_traffic.json; cat $O/pmc_traffic.json | head -30; find $O/pmc -name "*.csv" -size +1M -delete; find $O/pmc -name "*.db" -delete ;;
 level15)          # Level 1.5: the reference's own Translator on the fused engine
