@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "ctranslate2/layers/transformer.h"
+#include "ctranslate2/models/language_model.h"
 #include "ctranslate2/models/sequence_to_sequence.h"
 #include "ctranslate2/models/transformer.h"
 
@@ -65,7 +66,9 @@ namespace ctranslate2 {
         }
       }
 
-      std::shared_ptr<FusedHandle> make_handle(const SequenceToSequenceModel& model) {
+      // `source` may be null (decoder-only models, or a shared vocabulary)
+      std::shared_ptr<FusedHandle> make_handle(const Model& model, const char* spec, const Vocabulary* source,
+                                               const Vocabulary& target) {
         const char* ct = compute_type_name(model.effective_compute_type());
         if (ct == nullptr) return nullptr;
         // the variables as Model::load left them (converted to the compute type), copied to the host
@@ -94,16 +97,29 @@ namespace ctranslate2 {
         };
         std::vector<std::string> src_store, tgt_store;
         std::vector<const char*> src, tgt;
-        tokens_of(model.get_source_vocabulary(), src_store, src);
-        tokens_of(model.get_target_vocabulary(), tgt_store, tgt);
+        if (source != nullptr) tokens_of(*source, src_store, src);
+        tokens_of(target, tgt_store, tgt);
         const std::string config = model.config.dump();
         auto handle = std::make_shared<FusedHandle>();
         handle->h = ct2x_translator_create_from_memory(
-            "TransformerSpec", static_cast<uint32_t>(model.spec_revision()),
-            static_cast<uint32_t>(model.binary_version()), config.c_str(), vars.data(),
-            static_cast<int64_t>(vars.size()), src.data(), static_cast<int64_t>(src.size()), tgt.data(),
-            static_cast<int64_t>(tgt.size()), model.device_index(), ct);
+            spec, static_cast<uint32_t>(model.spec_revision()), static_cast<uint32_t>(model.binary_version()),
+            config.c_str(), vars.data(), static_cast<int64_t>(vars.size()), source ? src.data() : nullptr,
+            static_cast<int64_t>(src.size()), tgt.data(), static_cast<int64_t>(tgt.size()), model.device_index(), ct);
         if (handle->h == nullptr) return nullptr;  // (a model this engine does not take: Level 1 serves it)
+        return handle;
+      }
+
+      // the engine of a model object: made once, shared by the replicas of a pool
+      template <typename Make>
+      std::shared_ptr<FusedHandle> handle_of(const Model& base, Make make) {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        auto& slot = g_registry[&base];
+        auto handle = slot.lock();
+        if (!handle) {
+          const auto scoped_device_setter = base.get_scoped_device_setter();
+          handle = make();
+          slot = handle;
+        }
         return handle;
       }
 
@@ -227,14 +243,109 @@ namespace ctranslate2 {
         if (options.end_token.index() != 0 || !std::get<std::string>(options.end_token).empty()) return false;
         if (!_tried) {
           _tried = true;
-          std::lock_guard<std::mutex> lock(g_registry_mutex);
-          auto& slot = g_registry[&base];
-          _handle = slot.lock();
-          if (!_handle) {
-            const auto scoped_device_setter = base.get_scoped_device_setter();
-            _handle = make_handle(*m);
-            slot = _handle;
+          _handle = handle_of(base, [&] {
+            return make_handle(base, "TransformerSpec", &m->get_source_vocabulary(), m->get_target_vocabulary());
+          });
+        }
+        return _handle != nullptr;
+      }
+    };
+
+    // The same for ctranslate2::Generator: DecoderReplica::run_generation
+    // (src/models/language_model.cc:150-282) with include_prompt_in_result = false - the prompt is
+    // consumed by one sequence-mode pass, ragged prompts continue as hard prefixes - on
+    // ct2x_generate_batch. Everything else (the prompt in the result, static prompts, logits,
+    // alternatives, callbacks, sampling, custom end tokens) stays on the reference's own path.
+    class Mi355DecoderReplica : public DecoderReplica {
+    public:
+      using DecoderReplica::DecoderReplica;
+
+    protected:
+      std::vector<GenerationResult>
+      run_generation(const std::vector<std::vector<std::string>>& start_tokens,
+                     const GenerationOptions& options) override {
+        if (!serves(start_tokens, options)) return DecoderReplica::run_generation(start_tokens, options);
+        const auto& m = static_cast<const LanguageModel&>(*model());
+        const Vocabulary& vocab = m.get_vocabulary();
+        const size_t batch = start_tokens.size();
+        const auto ids = vocab.to_ids(start_tokens);
+        size_t stride = 1;
+        for (const auto& row : ids) stride = std::max(stride, row.size());
+        std::vector<int32_t> flat(batch * stride, 0), lengths(batch);
+        for (size_t b = 0; b < batch; ++b) {
+          lengths[b] = static_cast<int32_t>(ids[b].size());
+          for (size_t i = 0; i < ids[b].size(); ++i) flat[b * stride + i] = static_cast<int32_t>(ids[b][i]);
+        }
+        ct2x_translation_options opt;
+        ct2x_translation_options_default(&opt);
+        opt.beam_size = static_cast<int32_t>(options.beam_size);
+        opt.patience = options.patience;
+        opt.length_penalty = options.length_penalty;
+        opt.repetition_penalty = options.repetition_penalty;
+        opt.no_repeat_ngram_size = static_cast<int32_t>(options.no_repeat_ngram_size);
+        opt.max_decoding_length = static_cast<int32_t>(options.max_length);
+        opt.min_decoding_length = static_cast<int32_t>(options.min_length);
+        opt.num_hypotheses = static_cast<int32_t>(options.num_hypotheses);
+        opt.return_scores = options.return_scores ? 1 : 0;
+        opt.return_end_token = options.return_end_token ? 1 : 0;
+        std::vector<int32_t> sup_ids, sup_lengths;
+        for (const auto& seq : vocab.to_ids(options.suppress_sequences, 0, nullptr, nullptr, false)) {
+          sup_lengths.push_back(static_cast<int32_t>(seq.size()));
+          for (size_t id : seq) sup_ids.push_back(static_cast<int32_t>(id));
+        }
+        if (options.disable_unk) {
+          sup_lengths.push_back(1);
+          sup_ids.push_back(static_cast<int32_t>(vocab.unk_id()));
+        }
+        opt.num_suppress_sequences = static_cast<int32_t>(sup_lengths.size());
+        opt.suppress_ids = sup_ids.data();
+        opt.suppress_lengths = sup_lengths.data();
+
+        const size_t nh = options.num_hypotheses, max_len = options.max_length;
+        std::vector<int32_t> out_ids(batch * nh * max_len), out_lengths(batch * nh);
+        std::vector<float> out_scores(batch * nh);
+        if (ct2x_generate_batch(_handle->h, flat.data(), lengths.data(), static_cast<int32_t>(batch),
+                                static_cast<int32_t>(stride), &opt, out_ids.data(), out_lengths.data(),
+                                out_scores.data()) != 0)
+          throw std::runtime_error(std::string("MI355X fused engine: ") + ct2x_last_error());
+        ++g_served_calls;
+
+        std::vector<GenerationResult> results(batch);
+        for (size_t b = 0; b < batch; ++b) {
+          for (size_t h = 0; h < nh; ++h) {
+            const int32_t len = out_lengths[b * nh + h];
+            if (len < 0 || (h > 0 && len == 0)) continue;  // (fewer hypotheses than asked for)
+            const int32_t* row = out_ids.data() + (b * nh + h) * max_len;
+            results[b].sequences_ids.emplace_back(row, row + std::min<int32_t>(len, static_cast<int32_t>(max_len)));
+            if (options.return_scores) results[b].scores.push_back(out_scores[b * nh + h]);
           }
+          results[b].sequences = vocab.to_tokens(results[b].sequences_ids);
+        }
+        return results;
+      }
+
+    private:
+      std::shared_ptr<FusedHandle> _handle;
+      bool _tried = false;
+
+      bool serves(const std::vector<std::vector<std::string>>& start_tokens, const GenerationOptions& options) {
+        const Model& base = *model();
+        if (!fused_enabled() || base.device() != Device::CUDA || base.tensor_parallel() || start_tokens.empty())
+          return false;
+        const auto* m = dynamic_cast<const LanguageModel*>(&base);
+        if (m == nullptr) return false;
+        for (const auto& prompt : start_tokens)
+          if (prompt.empty()) return false;
+        if (options.include_prompt_in_result || !options.static_prompt.empty() || options.return_logits_vocab ||
+            options.return_alternatives || options.callback || options.sampling_topk != 1 ||
+            options.num_hypotheses < 1 || options.beam_size < 1 || options.num_hypotheses > options.beam_size)
+          return false;
+        if (options.end_token.index() != 0 || !std::get<std::string>(options.end_token).empty()) return false;
+        if (!base.get_variable_if_exists("num_heads") && !base.get_variable_if_exists("decoder/num_heads"))
+          return false;
+        if (!_tried) {
+          _tried = true;
+          _handle = handle_of(base, [&] { return make_handle(base, "TransformerDecoderSpec", nullptr, m->get_vocabulary()); });
         }
         return _handle != nullptr;
       }
@@ -250,7 +361,10 @@ extern "C" int64_t ct2x_level15_served_calls(void) {
 
 // The reference's translation unit, where it lies, with the replica it instantiates mapped to the
 // subclass above (every header it includes has been included already: the mapping only reaches
-// the file's own text - its one use is the make_unique in as_sequence_to_sequence).
+// the file's own text - their uses there are the make_unique of as_sequence_to_sequence and of
+// as_sequence_generator).
 #define EncoderDecoderReplica Mi355EncoderDecoderReplica
+#define DecoderReplica Mi355DecoderReplica
 #include "models/transformer.cc"
+#undef DecoderReplica
 #undef EncoderDecoderReplica

@@ -21,6 +21,11 @@ def main():
     m = R.RefModel(model_dir, compute_type, 1, 0, device="cuda")
     out = {"compute_type": m.compute_type(), "runs": []}
     for run in spec["runs"]:
+        if "prompts" in spec:  # decoder-only: Generator::generate_batch, include_prompt_in_result = false
+            ids, scores = m.generate_ids(spec["prompts"], beam_size=run["beam"], max_len=run["max_len"],
+                                         min_len=run["min_len"], return_scores=True)
+            out["runs"].append({"beam": run["beam"], "hypotheses": ids, "scores": [float(s) for s in scores]})
+            continue
         hyps, scores = m.translate_ids(spec["sources"], beam_size=run["beam"],
                                        max_len=run["max_len"], min_len=run["min_len"],
                                        length_penalty=1.0, num_hypotheses=1, return_scores=True)

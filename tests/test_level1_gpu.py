@@ -27,7 +27,8 @@ LIB = os.path.join(ROOT, "oracle", "_ref", "libct2ref_capi_mi355.so")
 def run_level1(model_dir, compute_type, sources, runs, fused=None):
     if not os.path.exists(LIB):
         pytest.skip("Level-1 integration library not built (make -C oracle mi355)")
-    spec = json.dumps({"sources": sources, "runs": runs})
+    spec = json.dumps({"prompts": sources["prompts"], "runs": runs} if isinstance(sources, dict)
+                      else {"sources": sources, "runs": runs})
     env = dict(os.environ)
     if fused is not None:
         env["CT2X_LEVEL1_FUSED"] = "1" if fused else "0"
@@ -114,3 +115,26 @@ def test_level15_reference_translator_on_the_fused_engine(gpu, golden):
             assert max(abs(x - y) for x, y in zip(a["scores"], ref_scores)) < (1e-4 if key == "tb" else 1e-2)
             ok = [x == y for x, y in zip(b["hypotheses"], want)]
             assert max(abs(x - y) for x, y, k in zip(b["scores"], ref_scores, ok) if k) < 1e-2
+
+
+@pytest.mark.parametrize("ct", ["int8", "float32"])
+def test_level15_reference_generator_on_the_fused_engine(gpu, golden, ct):
+    """The same for ctranslate2::Generator: DecoderReplica::run_generation (include_prompt_in_result =
+    false) of the reference's own Generator(model, Device::CUDA) served by ct2x_generate_batch - the
+    decoder-only golden continuations of the reference on Device::CPU, token for token."""
+    from ctranslate2_amd import model_builder as mb
+    key = "lm_small"
+    g = golden[key + ("_f32" if ct == "float32" else "")]
+    path = "/tmp/ct2x_test_%s" % key
+    if not os.path.exists(os.path.join(path, "model.bin")):
+        mb.build_decoder_lm(path, **GC.SYNTHETIC_LM[key]["model"])
+    runs = [{"beam": 1, "max_len": g["max_len"], "min_len": g["max_len"]}]
+    fused = run_level1(path, ct, {"prompts": g["prompts"]}, runs, fused=True)
+    plain = run_level1(path, ct, {"prompts": g["prompts"]}, runs, fused=False)
+    assert fused["fused_calls"] == 1 and plain["fused_calls"] == 0
+    same = sum(int(a == b) for a, b in zip(fused["runs"][0]["hypotheses"], g["generated"]))
+    print("Level 1.5 generator %s %s: %d/%d continuations identical to Device::CPU" % (key, ct, same, len(g["generated"])))
+    assert fused["runs"][0]["hypotheses"] == g["generated"]
+    assert max(abs(x - y) for x, y in zip(fused["runs"][0]["scores"], g["scores"])) < 1e-3
+    same_plain = sum(int(a == b) for a, b in zip(plain["runs"][0]["hypotheses"], g["generated"]))
+    assert same_plain >= len(g["generated"]) // 2
