@@ -230,7 +230,10 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
     def _set_logits(self, opt, batch, hyps, steps):
         """return_logits_vocab: the host buffers the C entry fills ([batch, hyps, steps, vocab] and
         the per-hypothesis counts)."""
-        buf = np.zeros((batch, hyps, steps, self.vocab_size), np.float32)
+        # (np.empty: the pages are only touched where the C entry writes a step - a dense zero-fill
+        # of batch x steps x vocabulary floats is gigabytes at a 256k vocabulary; `counts` says how
+        # many step vectors of a hypothesis are valid)
+        buf = np.empty((batch, hyps, steps, self.vocab_size), np.float32)
         counts = np.zeros((batch, hyps), np.int32)
         opt.logits_out = buf.ctypes.data_as(C.POINTER(C.c_float))
         opt.logits_counts_out = counts.ctypes.data_as(C.POINTER(C.c_int32))

@@ -46,10 +46,13 @@ void validate_decoding_options(const DecodingOptions& o) {
     throw std::invalid_argument("The minimum alternative expansion probability must be between 0 and 1");
   if (o.prefix_bias_beta > 0 && o.sampling_topk != 1)
     throw std::invalid_argument("Biased decoding runs a beam search: random sampling is not available with it");
-  // (src/decoding.cc:1052-1054)
+  // NOT a rule of the reference (its beam search records logits too: src/decoding.cc:529, 633-666,
+  // and so does decode_alternatives, :1198, :1262): a gap of this backend, rejected loudly and
+  // listed in README.md "Not supported"
   if (o.return_logits_vocab && (o.beam_size != 1 || o.prefix_bias_beta > 0 || o.return_alternatives))
     throw std::invalid_argument("return_logits_vocab is built for greedy search and random sampling "
                                 "(beam_size 1) in this backend");
+  // (src/decoding.cc:1052-1054)
   if (o.callback && (o.beam_size != 1 || o.prefix_bias_beta > 0))
     throw std::invalid_argument("The callback function is not compatible with "
                                 "beam_size > 1 or prefix_bias_beta > 0");

@@ -862,12 +862,16 @@ void Engine::compact_rows(DecodeState& st, const std::vector<int32_t>& keep, int
   int32_t* d_keep = static_cast<int32_t*>(fresh(sizeof(int32_t) * n_new));
   CT2X_HIP_CHECK(hipMemcpyAsync(d_keep, keep.data(), sizeof(int32_t) * n_new, hipMemcpyHostToDevice,
                                 cur_stream()));
+  // (the buffers a gather replaces go back to the pool once the stream has drained - a session that
+  // halves its rows several times must not keep every generation of its caches until it ends)
+  std::vector<void*> superseded;
   auto rows_of = [&](auto*& buf, int64_t row_elems) {
     if (buf == nullptr || row_elems == 0) return;
     using T = std::remove_reference_t<decltype(*buf)>;
     const size_t row_bytes = static_cast<size_t>(row_elems) * sizeof(T);
     T* out = static_cast<T*>(fresh(row_bytes * n_new));
     launch_gather_rows(buf, d_keep, n_new, static_cast<int64_t>(row_bytes), out, cur_stream());
+    superseded.push_back(const_cast<void*>(static_cast<const void*>(buf)));
     buf = out;
   };
   for (size_t l = 0; l < dec_.layers.size(); ++l) {
@@ -895,11 +899,20 @@ void Engine::compact_rows(DecodeState& st, const std::vector<int32_t>& keep, int
     float* scores = static_cast<float*>(fresh(sizeof(float) * (st.t_max + 1) * n_new));
     launch_gather_cols(st.hist_ids, d_keep, past, n_old, n_new, ids, cur_stream());
     launch_gather_cols(st.hist_scores, d_keep, past, n_old, n_new, scores, cur_stream());
+    superseded.push_back(st.hist_ids);
+    superseded.push_back(st.hist_scores);
     st.hist_ids = ids;
     st.hist_scores = scores;
   }
   check_last_launch("compact_rows");
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // (`keep` may be a temporary)
+  superseded.push_back(d_keep);
+  for (void* old : superseded) {
+    auto it = std::find(st.owned.begin(), st.owned.end(), old);
+    if (it == st.owned.end()) continue;  // (not a buffer of its own: part of a larger allocation)
+    st.owned.erase(it);
+    device_free(old);
+  }
   st.rows = n_new;
   st.batch = n_new;
   for (int i = 0; i < 2; ++i) {
