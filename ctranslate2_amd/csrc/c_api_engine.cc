@@ -998,6 +998,9 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
           st = t->engine->start(ids.data(), lens.data(), R, s_max, dopt.beam_size,
                                 dopt.max_length, 0, /*beam_search_state=*/biased);
           st_bytes = allocated_bytes() - before;
+          // (sub-batches decoding concurrently on several streams keep the launch-per-op step: the
+          // decoder-stack launch runs one session at a time per device, Engine::cluster_gate)
+          if (streams > 1) st->cl_xch = nullptr;
         }
         t->engine->synchronize();
         const double te1 = now_ms();

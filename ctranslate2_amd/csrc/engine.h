@@ -329,6 +329,13 @@ public:
   // Throws if a cluster of the decoder-stack launch waited in vain for a member during this
   // session (another persistent launch held the compute units): its results are void.
   void check_cluster(DecodeState& state);
+  // The decoder-stack launch keeps its workgroups resident and waiting for each other: two such
+  // launches of different sessions on one device could each hold part of the compute units and
+  // wait forever (the bounded polls turn that into an error, not a hang). Sessions that use the
+  // launch therefore decode one at a time per device and process: the decoding loops hold this
+  // gate from their first step to their last. (Other PROCESSES on the same GPU are not covered:
+  // CT2X_CLUSTER_STACK=0 there.)
+  static std::mutex& cluster_gate(int device_index);
   // Teacher-forced scoring (score_sequences, src/scoring.cc): runs `steps` decoder steps feeding
   // h_inputs[s][row] and leaves log P(h_outputs[s][row]) of every step in the score history
   // (read_history). Both arrays are [steps][rows]; nothing is read back between the steps.

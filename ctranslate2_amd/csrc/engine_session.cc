@@ -330,6 +330,11 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   return st;
 }
 
+std::mutex& Engine::cluster_gate(int device_index) {
+  static std::mutex gates[64];
+  return gates[device_index & 63];
+}
+
 void Engine::check_cluster(DecodeState& st) {
   if (st.cl_error == nullptr) return;
   if (st.cl_stamps != nullptr) {
