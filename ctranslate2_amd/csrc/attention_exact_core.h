@@ -285,9 +285,13 @@ struct AttnStage64 {
                                           int t_cached, int n_keys, const int32_t* anc = nullptr,
                                           int64_t anc_stride = 0, int64_t kv_row_stride = 0, int own_row = 0) {
     const int t_last = max(t_cached - 1, 0);
+    // (the lane's piece index behind an opaque move: the 64-bit addresses built from it are not
+    // hoisted out of the caller's layer loop - hoisted addresses get spilled)
+    int tid = static_cast<int>(threadIdx.x);
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int piece = i * 512 + static_cast<int>(threadIdx.x), r = piece >> 4, c4 = piece & 15;
+      const int piece = i * 512 + tid, r = piece >> 4, c4 = piece & 15;
       k[i] = v4f{0.f, 0.f, 0.f, 0.f};
       v[i] = v4f{0.f, 0.f, 0.f, 0.f};
       if (r < n_keys) {
@@ -300,9 +304,11 @@ struct AttnStage64 {
     }
   }
   __device__ __forceinline__ void store(float* ks, float* vs) const {
+    int tid = static_cast<int>(threadIdx.x);
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int piece = i * 512 + static_cast<int>(threadIdx.x), r = piece >> 4, c4 = piece & 15;
+      const int piece = i * 512 + tid, r = piece >> 4, c4 = piece & 15;
       *reinterpret_cast<v4f*>(ks + r * 68 + c4 * 4) = k[i];
       *reinterpret_cast<v4f*>(vs + r * 64 + c4 * 4) = v[i];
     }

@@ -80,6 +80,14 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// A per-lane index behind an opaque move: the 64-bit address built from it can not be hoisted out of
+// the layer loop (hoisted addresses were the values the allocator spilled, and a spill RELOAD is a
+// vmcnt(0) wait that drains the weight requests deliberately left in flight).
+__device__ __forceinline__ int opaque_index(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 __device__ __forceinline__ int dot16(const v4i w, const v4i x, int acc) {
   acc = __builtin_amdgcn_sdot4(w.x, x.x, acc, false);
   acc = __builtin_amdgcn_sdot4(w.y, x.y, acc, false);
@@ -100,7 +108,7 @@ struct Gemv {
   template <int NS, int KP, int CPT>
   __device__ __forceinline__ void request(const int8_t* __restrict__ slice) {
     static_assert(CPT <= CAP && NS * KP <= kThreads, "Gemv shape");
-    const int t = threadIdx.x, j = t % NS, kp = t / NS;
+    const int t = opaque_index(threadIdx.x), j = t % NS, kp = t / NS;
     const v4i* base = reinterpret_cast<const v4i*>(slice) + static_cast<size_t>(kp) * CPT * NS + j;
 #pragma unroll
     for (int i = 0; i < CAP; ++i) w[i] = v4i{0, 0, 0, 0};
@@ -112,7 +120,7 @@ struct Gemv {
   // returns the int32 sum of row t of the slice to the threads t < NS (after a barrier)
   template <int NS, int KP, int CPT>
   __device__ __forceinline__ int finish(Shared& sh) {
-    const int t = threadIdx.x, kp = t / NS;
+    const int t = opaque_index(threadIdx.x), kp = t / NS;
     const v4i* xq4 = reinterpret_cast<const v4i*>(sh.xq) + (kp < KP ? kp : 0) * CPT;
     int acc = 0;
 #pragma unroll
@@ -161,14 +169,6 @@ __device__ __forceinline__ float block_absmax(float v, Shared& sh) { return bloc
 //     + meeting index), so a stale slot can not be mistaken; a slot is only rewritten two meetings
 //     later, when every member has provably consumed it (each meeting needs all members' lines of
 //     the previous one).
-// A per-lane index behind an opaque move: the 64-bit address built from it can not be hoisted out of
-// the layer loop (hoisted addresses were the values the allocator spilled, and a spill RELOAD is a
-// vmcnt(0) wait that drains the weight requests deliberately left in flight).
-__device__ __forceinline__ int opaque_index(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-
 template <bool TAGGED>
 struct Handover {
   float* lines;            // counter form: [kXchFloats] floats; tagged form: as many 64-bit slots
@@ -270,6 +270,7 @@ struct ColRegs {  // Dequantize operands of this thread's output column
     wscale = 1.f;
     bias = 0.f;
     if (active) {
+      col = opaque_index(col);
       wscale = w.wscale[col];
       if (has_bias) bias = w.bias[col];
     }
@@ -282,8 +283,9 @@ struct NormRegs {  // element t of the norm's parameters
     layer_norm = n.beta != nullptr;
     rms_use_residual = n.rms_use_residual != 0;
     eps = n.eps;
-    gamma = n.gamma[threadIdx.x];
-    beta = layer_norm ? n.beta[threadIdx.x] : 0.f;
+    const int t = opaque_index(threadIdx.x);
+    gamma = n.gamma[t];
+    beta = layer_norm ? n.beta[t] : 0.f;
   }
 };
 
@@ -546,7 +548,7 @@ struct GemvRows {
   template <int NS, int KP, int CPT>
   __device__ __forceinline__ void request(const int8_t* __restrict__ slice) {
     static_assert(CPT <= CAP && NS * KP <= kThreads, "Gemv shape");
-    const int t = threadIdx.x, j = t % NS, kp = t / NS;
+    const int t = opaque_index(threadIdx.x), j = t % NS, kp = t / NS;
     const v4i* base = reinterpret_cast<const v4i*>(slice) + static_cast<size_t>(kp) * CPT * NS + j;
 #pragma unroll
     for (int i = 0; i < CAP; ++i) w[i] = v4i{0, 0, 0, 0};
@@ -558,7 +560,7 @@ struct GemvRows {
   // partial sums of every row into sh.part, then a barrier; row_sum() gives t < NS its column
   template <int NS, int KP, int CPT>
   __device__ __forceinline__ void finish(SharedBeam& sh, int nr) {
-    const int t = threadIdx.x, kp = t / NS;
+    const int t = opaque_index(threadIdx.x), kp = t / NS;
 #pragma unroll 1
     for (int r = 0; r < nr; ++r) {
       const v4i* xq4 = reinterpret_cast<const v4i*>(sh.xq[r]) + (kp < KP ? kp : 0) * CPT;
@@ -574,8 +576,9 @@ struct GemvRows {
 template <int NS, int KP>
 __device__ __forceinline__ int row_sum(const SharedBeam& sh, int r) {
   int sum = 0;
+  const int t = opaque_index(threadIdx.x);
 #pragma unroll
-  for (int p = 0; p < KP; ++p) sum += sh.part[r][p * NS + threadIdx.x];
+  for (int p = 0; p < KP; ++p) sum += sh.part[r][p * NS + t];
   return sum;
 }
 
@@ -605,7 +608,7 @@ struct NormRegs4 {
     layer_norm = n.beta != nullptr;
     rms_use_residual = n.rms_use_residual != 0;
     eps = n.eps;
-    const int tt = threadIdx.x & 127;
+    const int tt = opaque_index(threadIdx.x) & 127;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       gamma[i] = n.gamma[tt + 128 * i];

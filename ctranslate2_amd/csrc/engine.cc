@@ -690,6 +690,9 @@ void Engine::load_weights() {
     throw std::runtime_error("decoder/alignment_layer or alignment_heads is out of range");
   pack_stream_weights();
   pack_cluster_weights();
+  // the re-pack launches run on the engine's own stream, the sessions on their callers' streams:
+  // nothing orders the two but this (a first decode call could otherwise read a half-packed weight)
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
 // The decoder stack as one launch per step (decoder_cluster.hip) serves the int8 pre-norm
