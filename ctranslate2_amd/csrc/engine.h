@@ -336,6 +336,7 @@ public:
   // gate from their first step to their last. (Other PROCESSES on the same GPU are not covered:
   // CT2X_CLUSTER_STACK=0 there.)
   static std::mutex& cluster_gate(int device_index);
+  static int64_t cluster_max_rows();
   // Teacher-forced scoring (score_sequences, src/scoring.cc): runs `steps` decoder steps feeding
   // h_inputs[s][row] and leaves log P(h_outputs[s][row]) of every step in the score history
   // (read_history). Both arrays are [steps][rows]; nothing is read back between the steps.

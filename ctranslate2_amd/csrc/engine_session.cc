@@ -297,12 +297,12 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
         for (int l = 0; l < n_layers; ++l)
           st->cross_kv16.push_back(alloc<uint16_t>(*st, batch * s_max * dec_.layers[l].cross.lin[1].n));
     }
-    // greedy: a cluster per row up to 32 rows, two independent rows per cluster up to 64 (measured,
-    // profiles/r05_cluster_many_rows_ab.txt: +2.6 % at 64 rows; at 128 rows - four rows per cluster -
-    // the launch-per-op step with its 128-row MFMA tiles is 9 % faster and keeps the batch)
+    // greedy: a cluster per row up to 32 rows, 2 - 4 independent rows per cluster up to 128 rows
+    // (profiles/r05_cluster_many_rows_ab_b.txt: +31 % at 64 rows, +10 % at 96, +6.5 % at 128 against
+    // the launch-per-op step; the first, spilling build of the several-rows form lost 9 % at 128)
     const bool cluster_greedy = !beam_mode && beam == 1 &&
                                 (rows <= 32 ? decoder_cluster_lds_ok(decoder_cluster_t_pad(t_max, s_max))
-                                            : (rows <= 64 && decoder_cluster_beam_lds_ok(decoder_cluster_t_pad(t_max, s_max))));
+                                            : (rows <= cluster_max_rows() && decoder_cluster_beam_lds_ok(decoder_cluster_t_pad(t_max, s_max))));
     // beam search: a cluster per batch entry with its (<= 4) rows, through the ancestry table
     const bool cluster_beam = beam_mode && st->ancestry && beam >= 2 && beam <= 4 && batch <= 32 &&
                               decoder_cluster_beam_lds_ok(decoder_cluster_t_pad(t_max, s_max));
@@ -328,6 +328,16 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       encode(*st, src_ids, src_lengths);
   }
   return st;
+}
+
+// largest greedy batch on the decoder-stack launch (CT2X_CLUSTER_MAX_ROWS, A/B runs; <= 128)
+int64_t Engine::cluster_max_rows() {
+  static const int64_t rows = [] {
+    const char* e = std::getenv("CT2X_CLUSTER_MAX_ROWS");
+    const int64_t v = e ? std::atoll(e) : 128;
+    return std::max<int64_t>(32, std::min<int64_t>(v, 128));
+  }();
+  return rows;
 }
 
 std::mutex& Engine::cluster_gate(int device_index) {

@@ -838,7 +838,7 @@ bool Engine::cluster_applicable(const DecodeState& st) const {
   if (st.beam_mode)  // a cluster per batch entry, the self-attention through the ancestry table
     return beam_enabled && st.ancestry && st.beam >= 2 && st.beam <= 4 && st.batch <= 32 &&
            st.rows == st.batch * st.beam;
-  return st.beam == 1 && !st.ancestry && st.cur == 0 && st.rows <= 64;
+  return st.beam == 1 && !st.ancestry && st.cur == 0 && st.rows <= cluster_max_rows();
 }
 
 bool Engine::compactable(const DecodeState& st) const {

@@ -42,9 +42,9 @@ for rows in (1, 2, 7, 16, 31, 32):
     hyps, _ = t.translate_ids(src, beam_size=1, max_decoding_length=24, min_decoding_length=3)
     out["plain_%%d" %% rows] = hyps
     out["plain_%%d_kernels" %% rows] = t.last_stats()["kernels_per_step"]
-# 33 .. 64 rows: two independent rows per cluster (a ragged last cluster at 33 rows); beyond that
-# the launch-per-op step stays
-for rows in (33, 64, 100):
+# 33 .. 128 rows: 2 - 4 independent rows per cluster (a ragged last cluster at 33 and 100 rows);
+# beyond that the launch-per-op step stays
+for rows in (33, 64, 100, 128, 130):
     src = sources(rows)
     hyps, scores = t.translate_ids(src, beam_size=1, max_decoding_length=12, min_decoding_length=3,
                                    return_scores=True)
@@ -126,9 +126,9 @@ def test_cluster_stack_equals_launch_per_op(gpu):
         # embedding + 8 launches per layer x 6 layers + the output norm became one launch
         assert fused["plain_%d_kernels" % rows] == base["plain_%d_kernels" % rows] - 49, rows
         assert fused["scores_%d_kernels" % rows] == base["scores_%d_kernels" % rows] - 49, rows
-    for rows in (33, 64):
+    for rows in (33, 64, 100, 128):
         assert fused["many_%d_kernels" % rows] <= base["many_%d_kernels" % rows] - 40, rows
-    assert fused["many_100_kernels"] == base["many_100_kernels"]
+    assert fused["many_130_kernels"] == base["many_130_kernels"]
     for key in base:
         if key.startswith("beam") and key.endswith("_kernels"):
             assert fused[key] <= base[key] - 49, key

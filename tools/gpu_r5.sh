@@ -38,7 +38,7 @@ beam_iter)        # the beam-search cluster launch: parity, then the A/B of benc
   { for f in 0 1; do echo "== CT2X_CLUSTER_BEAM=$f --beam 4"; CT2X_CLUSTER_BEAM=$f timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
   } 2>&1 | tee $O/beam_ab.txt ;;
 many_rows)        # greedy batches of 64 / 128 rows: several rows per cluster against the launch-per-op step
-  { for b in 64 128; do for f in 0 1; do echo "== batch $b CT2X_CLUSTER_STACK=$f"; CT2X_CLUSTER_STACK=$f timeout 300 python bench.py --batch $b --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done; done
+  { for b in 64 96 128; do for f in 0 1; do echo "== batch $b CT2X_CLUSTER_STACK=$f (CT2X_CLUSTER_MAX_ROWS=128)"; CT2X_CLUSTER_MAX_ROWS=128 CT2X_CLUSTER_STACK=$f timeout 300 python bench.py --batch $b --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done; done
   } 2>&1 | tee $O/many_rows_ab.txt ;;
 pmc)              # profiles/r05_pmc_traffic.json
   timeout 600 python tools/pmc_bench.py $O/pmc > $O/pmc_traffic.json; cat $O/pmc_traffic.json | head -30; find $O/pmc -name "*.csv" -size +1M -delete; find $O/pmc -name "*.db" -delete ;;
