@@ -154,6 +154,22 @@ def roofline_entry(label, st):
     if tops is not None:
         entry["int8_tops"] = tops
         entry["mfma_frac"] = tops / INT8_MFMA_PEAK_TOPS
+    if label.startswith("decoder_stack"):
+        # The decoder-stack launch (csrc/decoder_cluster.hip) is bound by neither HBM nor MFMA: every
+        # cluster (one per batch row) streams its own copy of the weights through the L2 -> CU path
+        # (~120 GB/s per CU, profiles/r05_row_resident_probe.txt) and the layers are chains of 6
+        # hand-overs + 2 attention cores + 3 norm chains each. Both figures beside
+        # the HBM fraction the contract asks for:
+        rows = int(label.split("m=")[1].split(",")[0]) if "m=" in label else 32
+        l2_bytes = entry["bytes_per_launch"] * rows
+        entry["l2_to_cu"] = {"bytes_per_launch": l2_bytes,
+                             "achieved_GBps": l2_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
+                             "measured_ceiling_GBps": 28770.0,
+                             "note": "the same weight bytes once per cluster (batch row); ceiling = 256 CUs x "
+                                     "112 GB/s measured with every workgroup walking one weight set"}
+        entry["bound_note"] = ("latency: per layer 6 hand-overs between the 8 workgroups of a row, 2 attention cores, "
+                               "3 norm statistics chains on the dependent path; the HBM figure above is the "
+                               "contract's (weights once per launch / launch time)")
     return entry
 
 

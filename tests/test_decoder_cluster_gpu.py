@@ -65,6 +65,15 @@ for call in range(4):
                               min_decoding_length=16)
     seq.append(hyps)
 out["reuse"] = seq
+# sources of more than 64 tokens: the encoder-decoder attention walks several key tiles (the first
+# from the staged LDS tile, the rest from memory), greedy, several rows per cluster and beam search
+long_src = sources(6, 70, 140)
+hyps, scores = t.translate_ids(long_src, beam_size=1, max_decoding_length=10, return_scores=True)
+out["long_source"] = [hyps, np.asarray(scores, np.float32).view(np.uint32).tolist()]
+hyps, scores = t.translate_ids(sources(40, 60, 100), beam_size=1, max_decoding_length=8, return_scores=True)
+out["long_source_many"] = [hyps, np.asarray(scores, np.float32).view(np.uint32).tolist()]
+hyps, scores = t.translate_ids(long_src, beam_size=4, max_decoding_length=10, return_scores=True)
+out["long_source_beam4"] = [hyps, np.asarray(scores, np.float32).view(np.uint32).tolist()]
 # sessions of different row counts one after the other: the hand-over lines of a new session come
 # from the allocator's pool with whatever an earlier session left in them
 big = sources(32, 32, 33)
