@@ -48,6 +48,13 @@ level15)          # Level 1.5: the reference's own Translator on the fused engin
   } | tee $O/level15_speed.txt ;;
 suite)            # the whole -m gpu suite only
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -5 $O/pytest_all.log ;;
+final_prof)       # profiles/r05_final_kernel_stats_*: rocprofv3 kernel stats of the TB legs
+  for leg in "b32" "beam4 --beam 4"; do
+    set -- $leg; name=$1; shift
+    ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 $NOLEGS --no-token-check "$@" > /tmp/prof_$name.log 2>&1 )
+    f=$(ls -S $(find /tmp/prof_$name -name '*kernel_stats.csv') | head -1)
+    cp "$f" $O/final_kernel_stats_bench_tb_$name.csv; echo "== $name"; head -8 $O/final_kernel_stats_bench_tb_$name.csv | cut -c1-170
+  done ;;
 all)              # the whole -m gpu suite, smoke and the default bench line
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -3 $O/pytest_all.log
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
