@@ -369,6 +369,54 @@ def test_hot_kernels_do_not_spill():
                 assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)) == 0, name
                 assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
             assert checked >= minimum.get(src, 5), (src, checked)
+        # round 5, the decoder-stack launches: a spill RELOAD there is a vmcnt(0) wait that drains the
+        # weight requests left in flight across a phase (45k -> 75k tokens/s at beam 4
+        # came from removing them). One row per cluster: none at all; several rows: at most the
+        # handful the build of the round ended with.
+        out = os.path.join(tmp, "decoder_cluster.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                               "-ffp-contract=off", "-I" + os.path.join(root, "include"), "-mllvm",
+                               "-amdgpu-kernarg-preload-count=16", "-S", "--cuda-device-only", "-o", out,
+                               os.path.join(csrc, "decoder_cluster.hip")], stderr=subprocess.DEVNULL)
+        seen = {}
+        for block in open(out).read().split("  - .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block).group(1)
+            seen[name] = (int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)),
+                          int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)))
+        one_row = [v for k, v in seen.items() if "decoder_cluster_kernel" in k]
+        rows = [v for k, v in seen.items() if "decoder_cluster_beam_kernel" in k]
+        assert len(one_row) == 2 and all(v == (0, 0) for v in one_row), seen
+        assert len(rows) == 1 and rows[0][0] <= 64 and rows[0][1] <= 16, seen
+
+
+def test_translator_from_memory_is_checked_on_the_host():
+    """ct2x_translator_create_from_memory (Model::load on a ModelMemoryReader / the Level-1.5
+    hand-over): the variable table is read on the host before anything touches a device - an
+    unknown data type id, a missing target vocabulary and (here, without a GPU) the engine's own
+    loud HIP error all come back as NULL + ct2x_last_error, never as a crash or a fallback."""
+    L = _lib.lib()
+
+    class Var(C.Structure):
+        _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("rank", C.c_int32),
+                    ("shape", C.POINTER(C.c_int64)), ("data", C.c_void_p)]
+    L.ct2x_translator_create_from_memory.restype = C.c_void_p
+    L.ct2x_last_error.restype = C.c_char_p
+    data = np.zeros(8, np.float32)
+    shape = (C.c_int64 * 2)(2, 4)
+    tokens = (C.c_char_p * 3)(b"<unk>", b"<s>", b"</s>")
+    bad = Var(b"encoder/x", 7, 2, shape, data.ctypes.data)
+    h = L.ct2x_translator_create_from_memory(b"TransformerSpec", 1, 6, None, C.byref(bad), C.c_int64(1), None,
+                                             C.c_int64(0), tokens, C.c_int64(3), 0, b"float32")
+    assert not h and b"unknown data type id 7" in L.ct2x_last_error()
+    ok = Var(b"encoder/x", 0, 2, shape, data.ctypes.data)
+    h = L.ct2x_translator_create_from_memory(b"TransformerSpec", 1, 6, b"{not json", C.byref(ok), C.c_int64(1),
+                                             None, C.c_int64(0), tokens, C.c_int64(3), 0, b"float32")
+    assert not h and L.ct2x_last_error()
+    import torch
+    if not torch.cuda.is_available():
+        h = L.ct2x_translator_create_from_memory(b"TransformerSpec", 1, 6, None, C.byref(ok), C.c_int64(1), None,
+                                                 C.c_int64(0), tokens, C.c_int64(3), 0, b"float32")
+        assert not h and b"HIP" in L.ct2x_last_error()
 
 
 def test_streaming_gemm_plan_is_host_logic():
