@@ -233,10 +233,13 @@ struct Handover {
         ok = true;
 #pragma unroll
         for (int i = 0; i < N; ++i) ok = ok && static_cast<unsigned>(u[i] >> 32) == tag;
-        if (!ok && (++spins > kSpinLimit || sh.dead)) {
-          sh.dead = 1;
-          atomicExch(error, 1);
-          break;
+        if (!ok) {
+          if (++spins > kSpinLimit || sh.dead) {
+            sh.dead = 1;
+            atomicExch(error, 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);  // (a slot that is not there yet: do not hammer the fabric)
         }
       } while (!ok);
 #pragma unroll
@@ -322,6 +325,9 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
   ho.lines = a.xch + static_cast<size_t>(row) * kXchFloats * (TAGGED ? 2 : 1);
   ho.counter = a.counters + static_cast<size_t>(row) * 16;
   ho.error = a.error;
+  // (a session whose earlier launch lost a member is void: its remaining replays return at once
+  // instead of each waiting out the bounded polls again)
+  if (__hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   if (t == 0) sh.dead = 0;
   int stamp_base = 0;
   CT2X_CL_STAMP(0)
@@ -666,6 +672,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
   ho.counter = a.counters + static_cast<size_t>(entry) * 16;
   ho.error = a.error;
   ho.arrivals = 0u;
+  if (__hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   if (t == 0) sh.dead = 0;
   const unsigned epoch = ho.counter[1];
   ho.tag = epoch * 64u + 1u;
