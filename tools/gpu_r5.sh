@@ -40,6 +40,11 @@ beam_iter)        # the beam-search cluster launch: parity, then the A/B of benc
 many_rows)        # greedy batches of 64 / 128 rows: several rows per cluster against the launch-per-op step
   { for b in 64 96 128; do for f in 0 1; do echo "== batch $b CT2X_CLUSTER_STACK=$f (CT2X_CLUSTER_MAX_ROWS=128)"; CT2X_CLUSTER_MAX_ROWS=128 CT2X_CLUSTER_STACK=$f timeout 300 python bench.py --batch $b --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done; done
   } 2>&1 | tee $O/many_rows_ab.txt ;;
+evidence)         # profiles/r05_tb_kernel_trace_gaps.txt, r05_pmc_stream_gemm.json: the round's counter / gap refresh
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_gaps -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 $NOLEGS --no-token-check > /tmp/prof_gaps.log 2>&1 )
+  f=$(ls -S $(find /tmp/prof_gaps -name '*kernel_trace.csv') | head -1)
+  python tools/trace_gaps.py "$f" 2>&1 | head -40 | tee $O/tb_kernel_trace_gaps.txt
+  timeout 600 python tools/pmc_stream_gemm.py $O/pmc_stream > $O/pmc_stream_gemm.json 2> $O/pmc_stream.err; head -c 1500 $O/pmc_stream_gemm.json; find $O/pmc_stream -name "*.csv" -size +1M -delete; find $O/pmc_stream -name "*.db" -delete ;;
 pmc)              # profiles/r05_pmc_traffic.json
   timeout 600 python tools/pmc_bench.py $O/pmc > $O/pmc_traffic.json; cat $O/pmc_traffic.json | head -30; find $O/pmc -name "*.csv" -size +1M -delete; find $O/pmc -name "*.db" -delete ;;
 level15)          # Level 1.5: the reference's own Translator on the fused engine
