@@ -181,11 +181,9 @@ struct Handover {
     idx = opaque_index(idx);
     if (TAGGED) {
       const unsigned long long u = (static_cast<unsigned long long>(tag) << 32) | __float_as_uint(v);
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(lines) + idx, u, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      grid_publish(reinterpret_cast<unsigned long long*>(lines) + idx, u);
     } else {
-      __hip_atomic_store(reinterpret_cast<unsigned*>(lines) + idx, __float_as_uint(v), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      grid_publish(reinterpret_cast<unsigned*>(lines) + idx, __float_as_uint(v));
     }
   }
   // after the publishing code of a meeting (all threads)
@@ -229,7 +227,7 @@ struct Handover {
       for (int i = 0; i < N; ++i) at[i] = opaque_index(idx[i]);
       do {
 #pragma unroll
-        for (int i = 0; i < N; ++i) u[i] = __hip_atomic_load(slots + at[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < N; ++i) u[i] = grid_observe(slots + at[i]);
         ok = true;
 #pragma unroll
         for (int i = 0; i < N; ++i) ok = ok && static_cast<unsigned>(u[i] >> 32) == tag;
@@ -247,8 +245,7 @@ struct Handover {
     } else {
 #pragma unroll
       for (int i = 0; i < N; ++i)
-        out[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(lines) + opaque_index(idx[i]),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        out[i] = __uint_as_float(grid_observe(reinterpret_cast<const unsigned*>(lines) + opaque_index(idx[i])));
     }
   }
   template <typename S>

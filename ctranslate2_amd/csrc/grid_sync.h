@@ -19,8 +19,10 @@
 //     CU-slot the kernel's resources allow (persistent kernels), or let only workgroups wait that
 //     have finished their own work (the "last ticket finishes" form needs no residency at all).
 //
-// Not used by the product yet (round 4 ended on the measurement); DESIGN.md 8.00 describes the
-// persistent per-layer kernel it is meant for.
+// Round 5: grid_publish / grid_observe are the stores and loads of the decoder-stack launches'
+// hand-over (decoder_cluster.hip: 64-bit {tag, value} slots, or plain lines behind an arrival
+// counter); the device-wide barrier below was measured (4.4 us at 256 workgroups) and NOT built
+// on - the launches meet in clusters of eight, never device-wide.
 #pragma once
 
 #include <hip/hip_runtime.h>
