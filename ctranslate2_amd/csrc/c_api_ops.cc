@@ -1005,16 +1005,16 @@ int ct2x_cross_attention_hd(const float* d_q, const void* d_kv, int kv_dtype, co
   API_CATCH
 }
 
-int ct2x_attention_full(const float* d_q, const float* d_k, const float* d_v,
-                        const int32_t* d_lengths, int64_t batch, int64_t tq, int64_t tk,
-                        int64_t heads, int64_t heads_kv, int64_t dhead, int causal,
-                        int64_t q_offset, float scale, float* d_out, void* stream) {
+static int attention_full_entry(const char* name, const float* d_q, const float* d_k, const float* d_v,
+                                const int32_t* d_lengths, int64_t batch, int64_t tq, int64_t tk,
+                                int64_t heads, int64_t heads_kv, int64_t dhead, int causal,
+                                int64_t q_offset, float scale, float* d_out, int half_kind,
+                                void* stream) {
   API_TRY
-  CT2X_CHECK(dhead % 4 == 0 && dhead <= 512, "ct2x_attention_full: dhead must be a multiple of 4 "
-             "and <= 512");
-  CT2X_CHECK(heads_kv >= 1 && heads % heads_kv == 0, "ct2x_attention_full: heads must be a "
-             "multiple of heads_kv");
-  CT2X_CHECK(tk + 1 <= 16384, "ct2x_attention_full: tk > 16383 is not supported");
+  CT2X_CHECK(dhead % 4 == 0 && dhead <= 512, std::string(name) + ": dhead must be a multiple of 4 and <= 512");
+  CT2X_CHECK(heads_kv >= 1 && heads % heads_kv == 0, std::string(name) + ": heads must be a multiple of heads_kv");
+  CT2X_CHECK(tk + 1 <= 16384, std::string(name) + ": tk > 16383 is not supported");
+  CT2X_CHECK(half_kind >= 0 && half_kind <= 2, std::string(name) + ": compute kind must be 1 (float16) or 2 (bfloat16)");
   AttnFullParams f;
   f.q = d_q;
   f.k = d_k;
@@ -1037,9 +1037,34 @@ int ct2x_attention_full(const float* d_q, const float* d_k, const float* d_v,
   f.out = d_out;
   f.out_time_stride = heads * dhead;
   f.out_batch_stride = tq * heads * dhead;
+  f.allow_inexact = half_kind != 0;
+  f.half_kind = half_kind;
   launch_attention_full(f, resolve_stream(stream));
-  check_last_launch("attention_full");
+  check_last_launch(name);
   API_CATCH
+}
+
+int ct2x_attention_full(const float* d_q, const float* d_k, const float* d_v,
+                        const int32_t* d_lengths, int64_t batch, int64_t tq, int64_t tk,
+                        int64_t heads, int64_t heads_kv, int64_t dhead, int causal,
+                        int64_t q_offset, float scale, float* d_out, void* stream) {
+  return attention_full_entry("ct2x_attention_full", d_q, d_k, d_v, d_lengths, batch, tq, tk, heads,
+                              heads_kv, dhead, causal, q_offset, scale, d_out, 0, stream);
+}
+
+int ct2x_attention_full_half(const float* d_q, const float* d_k, const float* d_v,
+                             const int32_t* d_lengths, int64_t batch, int64_t tq, int64_t tk,
+                             int64_t heads, int64_t heads_kv, int64_t dhead, int causal,
+                             int64_t q_offset, float scale, int compute_kind, float* d_out,
+                             void* stream) {
+  if (compute_kind != 1 && compute_kind != 2) {
+    API_TRY
+    CT2X_CHECK(false, "ct2x_attention_full_half: compute kind must be 1 (float16) or 2 (bfloat16)");
+    API_CATCH
+  }
+  return attention_full_entry("ct2x_attention_full_half", d_q, d_k, d_v, d_lengths, batch, tq, tk,
+                              heads, heads_kv, dhead, causal, q_offset, scale, d_out, compute_kind,
+                              stream);
 }
 
 }  // extern "C"

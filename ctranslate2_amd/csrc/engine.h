@@ -190,6 +190,10 @@ public:
   bool half_compute() const {
     return compute_type_ == ComputeType::kFloat16 || compute_type_ == ComputeType::kBFloat16;
   }
+  // AttnFullParams::half_kind: which 16-bit matrix pipe sequence-mode attention may use
+  int half_kind() const {
+    return compute_type_ == ComputeType::kFloat16 ? 1 : compute_type_ == ComputeType::kBFloat16 ? 2 : 0;
+  }
   bool is_seq2seq() const { return has_encoder_; }
   bool is_whisper() const { return enc_.has_conv; }
   int64_t n_mels() const { return enc_.n_mels; }

@@ -526,6 +526,7 @@ void Engine::encode_layers(DecodeState& st, float* x, float* y) {
     f.dhead = a.dhead;
     f.causal = false;
     f.allow_inexact = half_compute();
+    f.half_kind = half_kind();
     f.scale = a.queries_scale;
     f.out = st.ctx;
     begin_kernel("attention_encoder", 0, 0, rows, a.heads, a.dhead);
@@ -811,6 +812,7 @@ void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time, float*
     f.dhead = a.dhead;
     f.causal = true;
     f.allow_inexact = half_compute();
+    f.half_kind = half_kind();
     f.q_offset = 0;
     f.scale = a.queries_scale;
     f.out = st.ctx;
@@ -879,6 +881,7 @@ void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time, float*
         f.dhead = c.dhead;
         f.causal = false;
         f.allow_inexact = half_compute();
+        f.half_kind = half_kind();
         f.scale = c.queries_scale;
         f.out = st.ctx + j * time * qdim;
         f.out_batch_stride = st.beam * time * qdim;

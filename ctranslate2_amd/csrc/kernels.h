@@ -441,6 +441,9 @@ struct AttnFullParams {
   // 16-bit compute types: no CPU order to reproduce - skip the exact-order kernels (which
   // materialise the scores) for the tiled fp32-MFMA one
   bool allow_inexact = false;
+  // 1 = float16, 2 = bfloat16 compute: the tiled kernel runs on the 16-bit matrix pipe with every
+  // fp32 operand split into hi + lo (attention_prefill.hip); 0 = the fp32 pipe
+  int half_kind = 0;
 };
 
 void launch_attention_full(const AttnFullParams& p, hipStream_t stream);

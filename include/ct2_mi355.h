@@ -487,6 +487,17 @@ int ct2x_attention_full(const float* d_q, const float* d_k, const float* d_v,
                         const int32_t* d_lengths, int64_t batch, int64_t tq, int64_t tk,
                         int64_t heads, int64_t heads_kv, int64_t dhead, int causal,
                         int64_t q_offset, float scale, float* d_out, void* stream);
+/* The same op as the engine runs it under compute type float16 (compute_kind 1) / bfloat16 (2):
+ * tensors stay fp32 (the engine keeps activations in fp32 under the 16-bit types), the two products
+ * run on the 16-bit matrix cores with every operand split into hi + lo 16-bit halves and fp32
+ * accumulation (attention_prefill.hip) - no CPU order to reproduce (the reference has no 16-bit CPU
+ * path), within 1e-5 / 2e-4 of the float64 statement. d_head 64 / 128 and Tq >= 16 take that form;
+ * other shapes run the fp32 kernels of ct2x_attention_full. */
+int ct2x_attention_full_half(const float* d_q, const float* d_k, const float* d_v,
+                             const int32_t* d_lengths, int64_t batch, int64_t tq, int64_t tk,
+                             int64_t heads, int64_t heads_kv, int64_t dhead, int causal,
+                             int64_t q_offset, float scale, int compute_kind, float* d_out,
+                             void* stream);
 
 /* ---- engine: ctranslate2::Translator / Generator ------------------------------- */
 

@@ -458,9 +458,21 @@ def attention_decode(q, k, v, lengths=None, length=0, kv_group=1, scale=1.0):
     return host(out)
 
 
-def attention_full(q, k, v, lengths, causal, q_offset, scale):
-    """q [B, Tq, H, dh], k / v [B, Tk, Hkv, dh] -> [B, Tq, H, dh]."""
+def attention_full(q, k, v, lengths, causal, q_offset, scale, compute_kind=0):
+    """q [B, Tq, H, dh], k / v [B, Tk, Hkv, dh] -> [B, Tq, H, dh]. compute_kind 1 / 2: the form the
+    engine runs under float16 / bfloat16 compute (ct2x_attention_full_half)."""
     L = _lib.lib()
+    if compute_kind:
+        b, tq, h, dh = q.shape
+        tk, hkv = k.shape[1], k.shape[2]
+        qd, kd, vd = dev(q.astype(np.float32)), dev(k.astype(np.float32)), dev(v.astype(np.float32))
+        ld = torch.from_numpy(np.ascontiguousarray(lengths, np.int32)).cuda() if lengths is not None else None
+        out = torch.empty((b, tq, h, dh), dtype=torch.float32, device="cuda")
+        _lib.check(L.ct2x_attention_full_half(_lib.ptr(qd), _lib.ptr(kd), _lib.ptr(vd), _lib.ptr(ld), i64(b),
+                                              i64(tq), i64(tk), i64(h), i64(hkv), i64(dh),
+                                              C.c_int(int(causal)), i64(q_offset), C.c_float(scale),
+                                              C.c_int(compute_kind), _lib.ptr(out), None))
+        return host(out)
     b, tq, h, dh = q.shape
     tk, hkv = k.shape[1], k.shape[2]
     qd, kd, vd = dev(q.astype(np.float32)), dev(k.astype(np.float32)), dev(v.astype(np.float32))

@@ -795,6 +795,64 @@ def test_attention_full(gpu, b, tq, tk, h, hkv, dh, causal):
                 assert np.array_equal(y[bi, :, hi], want), (bi, hi)
 
 
+def _attention_f64(q, k, v, lengths, causal, q_offset, scale):
+    b, tq, h, dh = q.shape
+    tk, hkv = k.shape[1], k.shape[2]
+    group = h // hkv
+    ref = np.zeros((b, tq, h, dh))
+    for bi in range(b):
+        for hi in range(h):
+            kk, vv = k[bi, :, hi // group].astype(np.float64), v[bi, :, hi // group].astype(np.float64)
+            s = scale * (q[bi, :, hi].astype(np.float64) @ kk.T)
+            mask = np.arange(tk)[None, :] < lengths[bi]
+            if causal:
+                mask = mask & (np.arange(tk)[None, :] <= np.arange(tq)[:, None] + q_offset)
+            s = np.where(mask, s, -np.inf)
+            with np.errstate(invalid="ignore"):
+                e = np.exp(s - np.max(s, axis=1, keepdims=True))
+            e = np.where(mask, e, 0.0)
+            den = e.sum(axis=1, keepdims=True)
+            ref[bi, :, hi] = np.divide(e, den, out=np.zeros_like(e), where=den > 0) @ vv
+    return ref
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("b,tq,tk,h,hkv,dh,causal,q_offset", [
+    (4, 32, 32, 8, 8, 64, False, 0),      # Transformer-base encoder tile; one empty batch entry
+    (3, 128, 128, 8, 2, 128, True, 0),    # Llama-style prefill: GQA, causal
+    (2, 100, 100, 4, 4, 64, True, 0),     # ragged query tile (100 = 64 + 36), ragged key tile (100 = 3 * 32 + 4)
+    (2, 70, 45, 4, 2, 128, False, 0),     # Tq != Tk
+    (9, 64, 333, 3, 3, 64, False, 0),     # 9 (batch, head) units over the 8 XCD slots: a partly empty round
+    (1, 200, 230, 6, 2, 64, True, 30),    # causal with an offset (chunked prefill), odd key count
+    (2, 17, 1500, 2, 2, 64, False, 0),    # Whisper memory length
+])
+def test_attention_full_half(gpu, b, tq, tk, h, hkv, dh, causal, q_offset, kind):
+    """Sequence-mode attention as float16 / bfloat16 compute runs it (ct2x_attention_full_half: the
+    16-bit matrix cores with hi + lo operand splitting) against the float64 statement of
+    dot_product_attention (src/layers/attention.cc:178-287). The split keeps 22 (float16) / 16
+    (bfloat16) significant bits per operand, so the bound is the fp32 kernel's for float16 and
+    2^-16-sized for bfloat16 - two to three orders tighter than one rounding to the 16-bit type,
+    which is what the reference's own 16-bit GPU path does to these tensors."""
+    import _gpuops as G
+    rng = np.random.default_rng(b + tq + tk + h + dh + kind)
+    q = rng.standard_normal((b, tq, h, dh)).astype(np.float32)
+    k = rng.standard_normal((b, tk, hkv, dh)).astype(np.float32)
+    v = rng.standard_normal((b, tk, hkv, dh)).astype(np.float32)
+    lengths = rng.integers(1, tk + 1, b).astype(np.int32)
+    lengths[0] = tk
+    if b > 2:
+        lengths[1] = 0
+    scale = 1.0 / np.sqrt(dh)
+    y = G.attention_full(q, k, v, lengths, causal, q_offset, scale, compute_kind=kind)
+    ref = _attention_f64(q, k, v, lengths, causal, q_offset, scale)
+    if kind == 1:
+        np.testing.assert_allclose(y, ref, rtol=2e-5, atol=3e-6)
+    else:
+        np.testing.assert_allclose(y, ref, rtol=1e-3, atol=2e-4)
+    if b > 2:
+        assert not y[1].any()   # no visible key -> zeros
+
+
 @pytest.mark.parametrize("batch,m,n,k,trans_b,alpha", [
     (256, 1, 33, 64, True, 0.125),     # decode QK^T: one query per (row, head), tail of 1 key
     (256, 1, 64, 33, False, 1.0),      # decode P.V: blocks of eight + one key
