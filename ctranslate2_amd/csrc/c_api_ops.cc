@@ -461,12 +461,17 @@ int ct2x_gemm_f16w(const float* d_a, const void* d_w, int w_dtype, int64_t m, in
   // session; here it comes from the stream-ordered allocator for the duration of the launch)
   float* ws = nullptr;
   size_t ws_floats = 0;
+  unsigned* tickets = nullptr;
+  const size_t n_tickets = 1024;
   if (m <= 128 && m > 0 && n > 0) {
-    ws_floats = static_cast<size_t>(8) * m * n;
-    ws = static_cast<float*>(device_malloc(ws_floats * sizeof(float)));
+    ws_floats = static_cast<size_t>(m <= 64 ? 20 : 8) * m * n;
+    ws = static_cast<float*>(device_malloc(ws_floats * sizeof(float) + n_tickets * sizeof(unsigned)));
+    // (the K slices of decode rows are summed inside the launch: a ticket per 64-column tile)
+    tickets = reinterpret_cast<unsigned*>(ws + ws_floats);
+    CT2X_HIP_CHECK(hipMemsetAsync(tickets, 0, n_tickets * sizeof(unsigned), resolve_stream(stream)));
   }
   launch_gemm_h(d_a, d_w, w_dtype == CT2X_BF16, m, n, k, d_bias, d_residual, activation, d_c,
-                resolve_stream(stream), ws, ws_floats);
+                resolve_stream(stream), ws, ws_floats, tickets, tickets ? n_tickets : 0);
   if (ws) device_free(ws);
   check_last_launch("gemm_f16w");
   API_CATCH
@@ -977,9 +982,10 @@ int ct2x_cross_attention_h(const float* d_q, const void* d_kv, int kv_dtype, con
                                  s_max, scale, d_out, stream);
 }
 
-int ct2x_cross_attention_hd(const float* d_q, const void* d_kv, int kv_dtype, const int32_t* d_lengths,
-                            int64_t batch, int64_t beam, int64_t heads, int64_t heads_kv,
-                            int64_t dhead, int64_t s_max, float scale, float* d_out, void* stream) {
+static int cross_attention_entry(const float* d_q, const void* d_kv, int kv_dtype, const int32_t* d_lengths,
+                                 int64_t batch, int64_t beam, int64_t heads, int64_t heads_kv,
+                                 int64_t dhead, int64_t s_max, float scale, float* d_out,
+                                 void* d_scratch, int64_t scratch_bytes, void* stream) {
   API_TRY
   CT2X_CHECK(kv_dtype == CT2X_F16 || kv_dtype == CT2X_BF16,
              "ct2x_cross_attention_h: the memory type must be CT2X_F16 or CT2X_BF16");
@@ -1000,10 +1006,52 @@ int ct2x_cross_attention_hd(const float* d_q, const void* d_kv, int kv_dtype, co
   p.out_row_stride = heads * dhead;
   CT2X_CHECK(cross_attention_h_applicable(p), "ct2x_cross_attention_h: unsupported shape (d_head 64 or 128, "
              "beam <= 8, heads a multiple of heads_kv, memory length within the LDS budget)");
-  launch_cross_attention_h(p, resolve_stream(stream));
+  hipStream_t s = resolve_stream(stream);
+  if (d_scratch != nullptr) {
+    const int64_t floats = cross_attention_h_scratch_floats(batch, beam, heads, dhead, s_max);
+    const int64_t need = floats * 4 + batch * heads * 4;
+    CT2X_CHECK(scratch_bytes >= need, "ct2x_cross_attention_hd_split: scratch smaller than "
+               "ct2x_cross_attention_split_scratch_bytes()");
+    if (floats > 0) {
+      p.split_scratch = static_cast<float*>(d_scratch);
+      p.split_tickets = reinterpret_cast<unsigned*>(p.split_scratch + floats);
+      CT2X_HIP_CHECK(hipMemsetAsync(p.split_tickets, 0, sizeof(unsigned) * batch * heads, s));
+    }
+  }
+  launch_cross_attention_h(p, s);
   check_last_launch("cross_attention_h");
   API_CATCH
 }
+
+int ct2x_cross_attention_hd(const float* d_q, const void* d_kv, int kv_dtype, const int32_t* d_lengths,
+                            int64_t batch, int64_t beam, int64_t heads, int64_t heads_kv,
+                            int64_t dhead, int64_t s_max, float scale, float* d_out, void* stream) {
+  return cross_attention_entry(d_q, d_kv, kv_dtype, d_lengths, batch, beam, heads, heads_kv, dhead,
+                               s_max, scale, d_out, nullptr, 0, stream);
+}
+
+int64_t ct2x_cross_attention_split_scratch_bytes(int64_t batch, int64_t beam, int64_t heads,
+                                                 int64_t dhead, int64_t s_max) {
+  return cross_attention_h_scratch_floats(batch, beam, heads, dhead, s_max) * 4 + batch * heads * 4;
+}
+
+int ct2x_cross_attention_hd_split(const float* d_q, const void* d_kv, int kv_dtype,
+                                  const int32_t* d_lengths, int64_t batch, int64_t beam,
+                                  int64_t heads, int64_t heads_kv, int64_t dhead, int64_t s_max,
+                                  float scale, float* d_out, void* d_scratch, int64_t scratch_bytes,
+                                  void* stream) {
+  return cross_attention_entry(d_q, d_kv, kv_dtype, d_lengths, batch, beam, heads, heads_kv, dhead,
+                               s_max, scale, d_out, d_scratch, scratch_bytes, stream);
+}
+
+#ifdef CT2X_TUNING
+// (TUNING builds only, not in include/ct2_mi355.h: phase stamps of the last 16-bit cross-attention launch)
+int ct2x_tuning_xattn_stamps(unsigned long long* host16) {
+  API_TRY
+  xattn_h_read_stamps(host16);
+  API_CATCH
+}
+#endif
 
 static int attention_full_entry(const char* name, const float* d_q, const float* d_k, const float* d_v,
                                 const int32_t* d_lengths, int64_t batch, int64_t tq, int64_t tk,

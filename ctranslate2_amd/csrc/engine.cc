@@ -1367,7 +1367,8 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
         begin_kernel("gemm_h", 4.0 * m * w.k + 2.0 * w.n * w.k + 4.0 * m * w.n, 2.0 * m * w.n * w.k,
                      m, w.n, w.k);
         launch_gemm_h(x, w.wh, w.wh_bf16, m, w.n, w.k, nullptr, nullptr, -1, acc, cur_stream(),
-                      ws ? ws->splitk_ws : nullptr, ws ? ws->splitk_floats : 0);
+                      ws ? ws->splitk_ws : nullptr, ws ? ws->splitk_floats : 0,
+                      ws ? ws->splitk_tickets : nullptr, ws && ws->splitk_tickets ? DecodeState::kSplitkTickets : 0);
       } else {
         begin_kernel("gemm_f32", 4.0 * (double(m) * w.k + double(w.n) * w.k + double(m) * w.n),
                      2.0 * m * w.n * w.k, m, w.n, w.k);
@@ -1445,7 +1446,8 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
                    2 * M * N * K, m, w.n, w.k);
     }
     launch_gemm_h(x, w.wh, w.wh_bf16, m, w.n, w.k, w.bias, residual, act, y, cur_stream(),
-                  ws ? ws->splitk_ws : nullptr, ws ? ws->splitk_floats : 0);
+                  ws ? ws->splitk_ws : nullptr, ws ? ws->splitk_floats : 0,
+                  ws ? ws->splitk_tickets : nullptr, ws && ws->splitk_tickets ? DecodeState::kSplitkTickets : 0);
     end_kernel();
   } else {
     {

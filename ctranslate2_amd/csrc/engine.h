@@ -559,6 +559,10 @@ struct DecodeState {
   uint16_t* hbuf = nullptr;  // [rows, max(d, ffn)] float16 activations (AWQ Dense only)
   float* splitk_ws = nullptr;  // split-K partial sums of the 16-bit GEMM (decode rows > 128)
   size_t splitk_floats = 0;
+  // tickets of the decode-row form that sums its K slices inside the launch (one per 64-column
+  // tile; zero at session start, left zero by every launch)
+  unsigned* splitk_tickets = nullptr;
+  static constexpr size_t kSplitkTickets = 2048;
   float* awq_ws = nullptr;   // split-K slices of the AWQ GEMM (kAwqGemmWorkspaceFloats)
   float* qscale = nullptr;   // [rows]
   int32_t* d_ids = nullptr;  // [rows] next input ids
@@ -662,6 +666,10 @@ struct DecodeState {
   int* cl_error = nullptr;
   int cl_t_pad = 0;
   unsigned long long* cl_stamps = nullptr;  // CT2X_CLUSTER_STAMPS=1: timeline of workgroup 0, last step
+  // 16-bit encoder-decoder attention with the memory split over workgroups (attention_cross_h.hip):
+  // per-chunk records and the (entry, head) tickets (zero at session start, left zero by a launch)
+  float* xh_scratch = nullptr;
+  unsigned* xh_tickets = nullptr;
   hipGraphExec_t group_exec = nullptr;
   int group_steps = 0;
   int group_parity = 0;

@@ -152,6 +152,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       st->splitk_floats = std::max(st->splitk_floats,
                                    static_cast<size_t>((d + 511) / 512) * rows * static_cast<size_t>(V));
     st->splitk_ws = alloc<float>(*st, static_cast<int64_t>(st->splitk_floats));
+    st->splitk_tickets = alloc<unsigned>(*st, static_cast<int64_t>(DecodeState::kSplitkTickets));
+    CT2X_HIP_CHECK(hipMemsetAsync(st->splitk_tickets, 0, sizeof(unsigned) * DecodeState::kSplitkTickets, cur_stream()));
   }
   st->logits = alloc<float>(*st, rows * V);
   st->d_ids = alloc<int32_t>(*st, rows);
@@ -293,9 +295,22 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
         // kernel over the fp32 memory is faster (measured: 7.2 - 7.5 against 8.1 ms per decode step)
         if (a.dhead == 128 && s_max < 128) ok = false;
       }
-      if (ok)
+      if (ok) {
         for (int l = 0; l < n_layers; ++l)
           st->cross_kv16.push_back(alloc<uint16_t>(*st, batch * s_max * dec_.layers[l].cross.lin[1].n));
+        // long memories: several workgroups per (entry, head), merged by the last to arrive
+        int64_t floats = 0, heads = 0;
+        for (int l = 0; l < n_layers; ++l) {
+          const AttnW& a = dec_.layers[l].cross;
+          floats = std::max(floats, cross_attention_h_scratch_floats(batch, beam, a.heads, a.dhead, s_max));
+          heads = std::max<int64_t>(heads, a.heads);
+        }
+        if (floats > 0) {
+          st->xh_scratch = alloc<float>(*st, floats);
+          st->xh_tickets = alloc<unsigned>(*st, batch * heads);
+          CT2X_HIP_CHECK(hipMemsetAsync(st->xh_tickets, 0, sizeof(unsigned) * batch * heads, cur_stream()));
+        }
+      }
     }
     // greedy: a cluster per row up to 32 rows, 2 - 4 independent rows per cluster up to 128 rows
     // (profiles/r05_cluster_many_rows_ab_b.txt: +31 % at 64 rows, +10 % at 96, +6.5 % at 128 against

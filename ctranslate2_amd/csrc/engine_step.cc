@@ -351,6 +351,8 @@ void Engine::launch_step(DecodeState& st) {
         cp.scale = a.queries_scale;
         cp.out = st.ctx;
         cp.out_row_stride = a.heads * a.dhead;
+        cp.split_scratch = st.xh_scratch;
+        cp.split_tickets = st.xh_tickets;
         begin_kernel("attention_cross_decode_h", attn_bytes / 2, attn_ops, rows, a.heads, a.dhead);
         launch_cross_attention_h(cp, cur_stream());
         end_kernel();

@@ -16,6 +16,7 @@
 // weight stream, one memory round trip) and an LDS-tiled 128x128x64 form for encoder / prefill.
 
 #include "device_utils.h"
+#include "grid_sync.h"
 #include "kernels.h"
 #include "runtime.h"
 
@@ -229,26 +230,45 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_h_skinny_kernel(const float* 
 // all its weight fragments (16 x 16 bytes per lane) are requested before the first LDS access, so
 // the launch is one memory round trip deep - and no cross-wave reduction is needed. K slices
 // (gridDim.y) go through partial[z][M][N] and gemm_h_splitk_reduce_kernel as above.
-constexpr int kRowsKSlice = 512;  // K elements per workgroup
-template <bool kBF16, int MT>
+//
+// Round 5: at the Whisper-large-v3 decode step (40 rows, d = 1280) a launch of the form above was
+// 60 - 240 workgroups of 64 KB of weights each, staged its activation slice through ten dependent
+// load rounds, and was followed by a second launch that summed the K slices: 11 + 5 us per Dense
+// for 3 - 13 MB of weights (0.3 - 0.8 TB/s; six of them per layer = more than half of the step,
+// profiles/r05_kernel_stats_bench_whisper_attn16.csv). Now
+//   * the K slice is a template parameter (256 when 512 leaves the chip half empty) and the
+//     activation staging is fully unrolled: every load of the slice is in flight at once, next to
+//     the weight fragments - one memory round trip before the MFMAs;
+//   * the slices are summed IN the launch: a workgroup publishes its [M, 64] partial tile
+//     (write-through stores into a region only it writes), takes a ticket of its column tile, and
+//     the last of the column tile's workgroups to arrive adds the slices in z order - the same
+//     sums as the separate reduce launch, deterministic - and applies the epilogue
+//     (grid_sync.h: nobody waits, so no residency requirement; the tickets end at zero).
+//     The partial tiles are read with plain 16-byte loads: every line has exactly one writer, was
+//     written through to memory before its writer's ticket, and cannot be in the reader's L2
+//     (invalidated at the kernel boundary, untouched by this launch before the tickets are complete).
+constexpr int kRowsKSlice = 512;  // K elements per workgroup (the unfused form; the fused one: 256 or 512)
+constexpr int kRowsMaxFusedSlices = 20;  // 3 x 20 partial loads in flight per thread of the last arrival
+template <bool kBF16, int MT, int KSL, bool kFused>
 __global__ __launch_bounds__(256) void gemm_h_rows_kernel(const float* __restrict__ A,
                                                           const uint16_t* __restrict__ W, int M,
                                                           int N, int K, HalfEpilogue ep,
-                                                          float* __restrict__ partial_out) {
+                                                          float* __restrict__ partial_out,
+                                                          unsigned* __restrict__ tickets) {
   using Ops = HalfOps<kBF16>;
   using vec = typename Ops::vec;
   extern __shared__ __attribute__((aligned(16))) uint8_t rows_lds[];
   constexpr int ROWS = MT * 16;
-  constexpr int KSTEPS = kRowsKSlice / 32;
-  constexpr int STRIDE = kRowsKSlice * 2 + 16;  // bytes per LDS row: 260 dwords, rows 4 banks apart
+  constexpr int KSTEPS = KSL / 32;
+  constexpr int STRIDE = KSL * 2 + 16;  // bytes per LDS row: rows 4 banks apart
   uint8_t* a_hi = rows_lds;
   uint8_t* a_lo = rows_lds + ROWS * STRIDE;  // float16 only
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int64_t n0 = static_cast<int64_t>(blockIdx.x) * 64 + wave * 16;
-  const int k0 = static_cast<int>(blockIdx.y) * kRowsKSlice;
-  const int kn = min(kRowsKSlice, K - k0);  // a multiple of 8 (K % 8 == 0)
+  const int k0 = static_cast<int>(blockIdx.y) * KSL;
+  const int kn = min(KSL, K - k0);  // a multiple of 8 (K % 8 == 0)
 
   // weight fragments of this wave's 16 columns over the whole slice: requested first
   vec wf[KSTEPS];
@@ -264,23 +284,38 @@ __global__ __launch_bounds__(256) void gemm_h_rows_kernel(const float* __restric
       wf[ks] = (kk < kn && col < N) ? *reinterpret_cast<const vec*>(wrow + kk) : z;
     }
   }
-  // activation slice -> LDS in the 16-bit type (rows >= M and columns >= kn are zero)
-  constexpr int CHUNKS = kRowsKSlice / 8;  // 8-element chunks per row
-  for (int c = tid; c < ROWS * CHUNKS; c += 256) {
-    const int row = c / CHUNKS, kk = (c % CHUNKS) * 8;
-    float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-    if (row < M && kk < kn) {
-      const float4* p = reinterpret_cast<const float4*>(A + static_cast<int64_t>(row) * K + k0 + kk);
-      x0 = p[0];
-      x1 = p[1];
+  // activation slice -> LDS in the 16-bit type (rows >= M and columns >= kn are zero); the loads of
+  // a batch of (up to) eight pieces per thread are all requested before the first conversion
+  constexpr int CHUNKS = KSL / 8;                 // 8-element pieces per row
+  constexpr int ITEMS = ROWS * CHUNKS / 256;      // pieces per thread
+  constexpr int BATCH = ITEMS <= 8 ? ITEMS : (ITEMS % 8 == 0 ? 8 : (ITEMS % 6 == 0 ? 6 : 4));
+  static_assert(ITEMS % BATCH == 0, "staging batches");
+#pragma unroll
+  for (int it0 = 0; it0 < ITEMS; it0 += BATCH) {
+    float4 x0[BATCH], x1[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int c = tid + (it0 + u) * 256;
+      const int row = c / CHUNKS, kk = (c % CHUNKS) * 8;
+      x0[u] = x1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < M && kk < kn) {
+        const float4* p = reinterpret_cast<const float4*>(A + static_cast<int64_t>(row) * K + k0 + kk);
+        x0[u] = p[0];
+        x1[u] = p[1];
+      }
     }
-    if constexpr (!kBF16) {
-      v8h hi, lo;
-      split_f16(x0, x1, hi, lo);
-      *reinterpret_cast<v8h*>(a_hi + row * STRIDE + kk * 2) = hi;
-      *reinterpret_cast<v8h*>(a_lo + row * STRIDE + kk * 2) = lo;
-    } else {
-      *reinterpret_cast<vec*>(a_hi + row * STRIDE + kk * 2) = Ops::from_f32(x0, x1);
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int c = tid + (it0 + u) * 256;
+      const int row = c / CHUNKS, kk = (c % CHUNKS) * 8;
+      if constexpr (!kBF16) {
+        v8h hi, lo;
+        split_f16(x0[u], x1[u], hi, lo);
+        *reinterpret_cast<v8h*>(a_hi + row * STRIDE + kk * 2) = hi;
+        *reinterpret_cast<v8h*>(a_lo + row * STRIDE + kk * 2) = lo;
+      } else {
+        *reinterpret_cast<vec*>(a_hi + row * STRIDE + kk * 2) = Ops::from_f32(x0[u], x1[u]);
+      }
     }
   }
   __syncthreads();
@@ -308,6 +343,47 @@ __global__ __launch_bounds__(256) void gemm_h_rows_kernel(const float* __restric
   }
   // MFMA C layout: column = lane & 15, row = 4 * (lane >> 4) + register
   const int64_t col = n0 + r;
+  if constexpr (kFused) {
+    // (N % 64 == 0 here: every column of the tile exists)
+    // partial tile of (slice z, column tile x): [M][64] floats in a region of its own
+    const int slices = static_cast<int>(gridDim.y);
+    const int64_t tile_floats = static_cast<int64_t>(M) * 64;
+    float* mine = partial_out + (static_cast<int64_t>(blockIdx.x) * slices + blockIdx.y) * tile_floats;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = i * 16 + g * 4 + e;
+        if (row < M) grid_publish(mine + row * 64 + wave * 16 + r, acc[i][e]);
+      }
+    if (!grid_last_arrival(tickets + blockIdx.x, static_cast<unsigned>(slices))) return;
+    asm volatile("" ::: "memory");
+    const float* tile = partial_out + static_cast<int64_t>(blockIdx.x) * slices * tile_floats;
+    const int quads = M * 16;  // float4 pieces of the [M][64] tile
+    for (int q = tid; q < quads; q += 256) {
+      v4f sl[kRowsMaxFusedSlices];
+#pragma unroll
+      for (int z = 0; z < kRowsMaxFusedSlices; ++z)
+        if (z < slices) sl[z] = *reinterpret_cast<const v4f*>(tile + z * tile_floats + q * 4);
+      v4f v = sl[0];
+#pragma unroll
+      for (int z = 1; z < kRowsMaxFusedSlices; ++z)
+        if (z < slices) v = v + sl[z];  // z order: the sums of the separate reduce launch
+      const int row = q >> 4;
+      const int64_t c0 = static_cast<int64_t>(blockIdx.x) * 64 + (q & 15) * 4;
+      const int64_t idx = static_cast<int64_t>(row) * N + c0;
+      v4f bv = v4f{0.f, 0.f, 0.f, 0.f}, rv = v4f{0.f, 0.f, 0.f, 0.f};
+      if (ep.bias) bv = *reinterpret_cast<const v4f*>(ep.bias + c0);
+      if (ep.residual) rv = *reinterpret_cast<const v4f*>(ep.residual + idx);
+      v4f o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        o[c] = finish(v[c], bv[c], ep.bias != nullptr, ep.act, rv[c], ep.residual != nullptr);
+      *reinterpret_cast<v4f*>(ep.y + idx) = o;
+    }
+    if (tid == 0) grid_publish(tickets + blockIdx.x, 0u);
+    return;
+  }
   if (col >= N) return;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -543,7 +619,8 @@ static void launch_splitk_reduce(const float* partial, int splits, int64_t n, in
 
 template <bool kBF16>
 void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const HalfEpilogue& ep,
-                  hipStream_t stream, float* splitk_ws, size_t splitk_floats) {
+                  hipStream_t stream, float* splitk_ws, size_t splitk_floats, unsigned* tickets,
+                  size_t n_tickets) {
 #define CT2X_HSKINNY(MT, NT, WAVES, U)                                                       \
   hipLaunchKernelGGL((gemm_h_skinny_kernel<kBF16, MT, NT, WAVES, U>),                        \
                      dim3((N + 16 * NT - 1) / (16 * NT), sk), dim3(WAVES * 64), 0, stream, a, w, M, \
@@ -560,6 +637,38 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
     }();
     if (variant >= 2 && M <= 64 && K >= 256) {
       // row-staged form: 64 columns x one K slice per workgroup
+      const int mt3 = (M > 32 && M <= 48) ? 3 : mt;
+      auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+      // fused K-slice sum: whole 64-column tiles, vector epilogue operands, a ticket per column tile
+      const int ksl = ((N / 64) * ((K + 511) / 512) >= 256 || K % 256 != 0) ? 512 : 256;
+      const int fslices = (K + ksl - 1) / ksl;
+      const bool fused = fslices > 1 && fslices <= kRowsMaxFusedSlices && tickets != nullptr && N % 64 == 0 &&
+                         static_cast<size_t>(N / 64) <= n_tickets && splitk_ws != nullptr &&
+                         static_cast<size_t>(fslices) * M * N <= splitk_floats && aligned16(ep.y) &&
+                         aligned16(ep.bias) && aligned16(ep.residual) && aligned16(splitk_ws);
+      if (fused) {
+        const dim3 grid(N / 64, fslices);
+#define CT2X_HROWS_F(MT, KSL)                                                                    \
+  do {                                                                                           \
+    const size_t lds = static_cast<size_t>(MT) * 16 * (KSL * 2 + 16) * (kBF16 ? 1 : 2);           \
+    allow_big_lds(reinterpret_cast<const void*>(gemm_h_rows_kernel<kBF16, MT, KSL, true>), lds); \
+    hipLaunchKernelGGL((gemm_h_rows_kernel<kBF16, MT, KSL, true>), grid, dim3(256), lds, stream,  \
+                       a, w, M, N, K, ep, splitk_ws, tickets);                                   \
+  } while (0)
+        if (ksl == 256) {
+          if (mt3 == 1) CT2X_HROWS_F(1, 256);
+          else if (mt3 == 2) CT2X_HROWS_F(2, 256);
+          else if (mt3 == 3) CT2X_HROWS_F(3, 256);
+          else CT2X_HROWS_F(4, 256);
+        } else {
+          if (mt3 == 1) CT2X_HROWS_F(1, 512);
+          else if (mt3 == 2) CT2X_HROWS_F(2, 512);
+          else if (mt3 == 3) CT2X_HROWS_F(3, 512);
+          else CT2X_HROWS_F(4, 512);
+        }
+#undef CT2X_HROWS_F
+        return;
+      }
       const int slices = (K + kRowsKSlice - 1) / kRowsKSlice;
       if (slices == 1 || (splitk_ws != nullptr &&
                           static_cast<size_t>(slices) * M * N <= splitk_floats)) {
@@ -568,9 +677,9 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
 #define CT2X_HROWS(MT)                                                                          \
   do {                                                                                          \
     const size_t lds = static_cast<size_t>(MT) * 16 * (kRowsKSlice * 2 + 16) * (kBF16 ? 1 : 2);  \
-    allow_big_lds(reinterpret_cast<const void*>(gemm_h_rows_kernel<kBF16, MT>), lds);           \
-    hipLaunchKernelGGL((gemm_h_rows_kernel<kBF16, MT>), grid, dim3(256), lds, stream, a, w, M, N, \
-                       K, ep, part);                                                            \
+    allow_big_lds(reinterpret_cast<const void*>(gemm_h_rows_kernel<kBF16, MT, kRowsKSlice, false>), lds); \
+    hipLaunchKernelGGL((gemm_h_rows_kernel<kBF16, MT, kRowsKSlice, false>), grid, dim3(256), lds, stream, a, w, M, N, \
+                       K, ep, part, static_cast<unsigned*>(nullptr));                           \
   } while (0)
         if (mt == 1) CT2X_HROWS(1);
         else if (mt == 2) CT2X_HROWS(2);
@@ -624,7 +733,8 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
 
 void launch_gemm_h(const float* a, const void* w, bool bf16, int64_t m, int64_t n, int64_t k,
                    const float* bias, const float* residual, int act, float* y,
-                   hipStream_t stream, float* splitk_ws, size_t splitk_floats) {
+                   hipStream_t stream, float* splitk_ws, size_t splitk_floats, unsigned* tickets,
+                   size_t n_tickets) {
   if (m == 0 || n == 0) return;
   if (k % 8 != 0 || (reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(w) & 15))
     throw Error("16-bit GEMM: K must be a multiple of 8 and the operands 16-byte aligned");
@@ -632,10 +742,10 @@ void launch_gemm_h(const float* a, const void* w, bool bf16, int64_t m, int64_t 
   const auto* wp = static_cast<const uint16_t*>(w);
   if (bf16)
     launch_typed<true>(a, wp, static_cast<int>(m), static_cast<int>(n), static_cast<int>(k), ep, stream,
-                       splitk_ws, splitk_floats);
+                       splitk_ws, splitk_floats, tickets, n_tickets);
   else
     launch_typed<false>(a, wp, static_cast<int>(m), static_cast<int>(n), static_cast<int>(k), ep, stream,
-                        splitk_ws, splitk_floats);
+                        splitk_ws, splitk_floats, tickets, n_tickets);
 }
 
 }  // namespace ct2x

@@ -323,11 +323,15 @@ void launch_gemm_f32(const float* a, const float* b, int64_t batch, int64_t m, i
 
 // splitk_ws (optional, caller owned, splitk_floats floats): lets launches with too few 128 x 128 tiles
 // for the chip split K over gridDim.z and reduce in a second launch (deterministic order).
+// tickets (optional, n_tickets counters, zero before the first launch and left zero by every launch):
+// decode rows (m <= 64) sum their K slices inside the launch instead (the last workgroup of a
+// column tile to arrive adds them in the same order).
 // y = act(a[m,k] (fp32, rounded to the weight type at the matrix pipe) . w[n,k]^T + bias) + residual,
 // fp32 accumulation on v_mfma_f32_16x16x32_{f16,bf16}. k % 8 == 0.
 void launch_gemm_h(const float* a, const void* w, bool bf16, int64_t m, int64_t n, int64_t k,
                    const float* bias, const float* residual, int act, float* y,
-                   hipStream_t stream, float* splitk_ws = nullptr, size_t splitk_floats = 0);
+                   hipStream_t stream, float* splitk_ws = nullptr, size_t splitk_floats = 0,
+                   unsigned* tickets = nullptr, size_t n_tickets = 0);
 
 // ---- attention (attention.hip) -------------------------------------------------------
 
@@ -702,8 +706,21 @@ struct CrossAttnHParams {
   float scale = 1.f;
   float* out = nullptr;
   int64_t out_row_stride = 0;
+  // Optional: the memory of a (batch entry, head) split over several workgroups.
+  // split_scratch: cross_attention_h_scratch_floats(...) floats; split_tickets: batch * heads
+  // counters, zero before the first launch (every launch leaves them zero). Both null = one
+  // workgroup per (entry, head). `splits` / `chunk` are filled in by the launcher.
+  float* split_scratch = nullptr;
+  unsigned* split_tickets = nullptr;
+  int splits = 1, chunk = 0;
 };
+int cross_attention_h_splits(int64_t batch, int64_t beam, int64_t heads, int64_t s_max);
+int64_t cross_attention_h_scratch_floats(int64_t batch, int64_t beam, int64_t heads, int64_t dhead,
+                                         int64_t s_max);
 bool cross_attention_h_applicable(const CrossAttnHParams& p);
+#ifdef CT2X_TUNING
+void xattn_h_read_stamps(unsigned long long* host16);  // tools/xattn_probe.py
+#endif
 void launch_cross_attention_h(const CrossAttnHParams& p, hipStream_t stream);
 
 }  // namespace ct2x

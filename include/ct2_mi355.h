@@ -478,6 +478,19 @@ int ct2x_cross_attention_h(const float* d_q, const void* d_kv, int kv_dtype, con
 int ct2x_cross_attention_hd(const float* d_q, const void* d_kv, int kv_dtype, const int32_t* d_lengths,
                             int64_t batch, int64_t beam, int64_t heads, int64_t heads_kv,
                             int64_t dhead, int64_t s_max, float scale, float* d_out, void* stream);
+/* The same with the memory of a (batch entry, head) cut into chunks that run as separate workgroups
+ * (long memories on few (entry, head) units - Whisper: 8 windows x 20 heads over 1500 positions are
+ * 160 workgroups on 256 CUs - leave the chip idle and walk the memory serially); the chunks are
+ * merged in the same launch by the last one to finish. d_scratch: at least
+ * ct2x_cross_attention_split_scratch_bytes(...) bytes of device memory, content irrelevant. Short
+ * memories / many units run the one-workgroup form unchanged. */
+int64_t ct2x_cross_attention_split_scratch_bytes(int64_t batch, int64_t beam, int64_t heads,
+                                                 int64_t dhead, int64_t s_max);
+int ct2x_cross_attention_hd_split(const float* d_q, const void* d_kv, int kv_dtype,
+                                  const int32_t* d_lengths, int64_t batch, int64_t beam,
+                                  int64_t heads, int64_t heads_kv, int64_t dhead, int64_t s_max,
+                                  float scale, float* d_out, void* d_scratch, int64_t scratch_bytes,
+                                  void* stream);
 
 /* Sequence-mode MultiHeadAttention core (src/layers/attention.cc:178-287 dot_product_attention:
  * MatMul QK^T * queries_scale -> length / causal mask -> SoftMax -> MatMul PV) for Tq > 1:

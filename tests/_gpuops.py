@@ -484,9 +484,10 @@ def attention_full(q, k, v, lengths, causal, q_offset, scale, compute_kind=0):
     return host(out)
 
 
-def cross_attention_h(q, kv_bits, bf16, lengths, beam, heads_kv, scale):
+def cross_attention_h(q, kv_bits, bf16, lengths, beam, heads_kv, scale, split=False, calls=1):
     """q [batch * beam, heads, 64] fp32, kv_bits [batch, s_max, 2, heads_kv, 64] uint16 bit patterns of
-    the 16-bit type -> [batch * beam, heads, 64]."""
+    the 16-bit type -> [batch * beam, heads, 64]. split: ct2x_cross_attention_hd_split (the memory
+    of an (entry, head) over several workgroups), `calls` launches on the same scratch."""
     L = _lib.lib()
     rows, heads, dh = q.shape
     batch, s_max = kv_bits.shape[0], kv_bits.shape[1]
@@ -494,6 +495,17 @@ def cross_attention_h(q, kv_bits, bf16, lengths, beam, heads_kv, scale):
     kvd = torch.from_numpy(np.ascontiguousarray(kv_bits).view(np.int16)).cuda()
     ld = torch.from_numpy(np.ascontiguousarray(lengths, np.int32)).cuda() if lengths is not None else None
     out = torch.empty((rows, heads, dh), dtype=torch.float32, device="cuda")
+    if split:
+        L.ct2x_cross_attention_split_scratch_bytes.restype = C.c_int64
+        nbytes = int(L.ct2x_cross_attention_split_scratch_bytes(i64(batch), i64(beam), i64(heads), i64(dh), i64(s_max)))
+        scratch = torch.full((max(nbytes, 4),), 0x7f, dtype=torch.uint8, device="cuda")  # content irrelevant
+        for _ in range(calls):
+            out.fill_(float("nan"))
+            _lib.check(L.ct2x_cross_attention_hd_split(_lib.ptr(qd), _lib.ptr(kvd), C.c_int(5 if bf16 else 4),
+                                                       _lib.ptr(ld), i64(batch), i64(beam), i64(heads),
+                                                       i64(heads_kv), i64(dh), i64(s_max), C.c_float(scale),
+                                                       _lib.ptr(out), _lib.ptr(scratch), i64(nbytes), None))
+        return host(out)
     _lib.check(L.ct2x_cross_attention_hd(_lib.ptr(qd), _lib.ptr(kvd), C.c_int(5 if bf16 else 4),
                                          _lib.ptr(ld), i64(batch), i64(beam), i64(heads), i64(heads_kv),
                                          i64(dh), i64(s_max), C.c_float(scale), _lib.ptr(out), None))

@@ -1047,7 +1047,8 @@ def test_gumbel_noise_is_exponential_and_seeded(gpu):
                                                           (6, 4, 16, 16, 32, 128), (2, 5, 4, 2, 700, 128),
                                                           (3, 1, 8, 8, 5, 128), (1, 8, 2, 1, 1500, 128)])
 @pytest.mark.parametrize("bf16", [False, True])
-def test_cross_attention_16bit_memory(gpu, batch, beam, heads, hkv, s_max, dh, bf16):
+@pytest.mark.parametrize("split", [False, True])
+def test_cross_attention_16bit_memory(gpu, batch, beam, heads, hkv, s_max, dh, bf16, split):
     """attention_cross_h.hip: the decode steps' encoder-decoder attention over float16 / bfloat16
     memory keys and values, one workgroup per (batch entry, head) for all hypothesis rows. Oracle:
     the same 16-bit values in float64 (softmax(q . K^T * scale, lengths) . V); what is left is the
@@ -1065,7 +1066,11 @@ def test_cross_attention_16bit_memory(gpu, batch, beam, heads, hkv, s_max, dh, b
         h16 = kv.astype(np.float16)
         bits, kvr = h16.view(np.uint16), h16.astype(np.float32)
     scale = 0.125
-    y = G.cross_attention_h(q, bits, bf16, lengths, beam, hkv, scale)
+    if split and batch > 1:
+        lengths[1] = max(1, min(s_max, 130))   # the later chunks of this entry see no valid key
+    # split: the memory of an (entry, head) over several workgroups merged by the last arrival
+    # (1500 / 700 / 260 positions cut into 8 / 5 / 2 chunks here); twice on one scratch = tickets back at zero
+    y = G.cross_attention_h(q, bits, bf16, lengths, beam, hkv, scale, split=split, calls=2)
     group = heads // hkv
     ref = np.zeros_like(q, dtype=np.float64)
     for r in range(batch * beam):

@@ -61,11 +61,13 @@ final_prof)       # profiles/r05_final_kernel_stats_*: rocprofv3 kernel stats of
     cp "$f" $O/final_kernel_stats_bench_tb_$name.csv; echo "== $name"; head -8 $O/final_kernel_stats_bench_tb_$name.csv | cut -c1-170
   done ;;
 attn_h)           # sequence-mode attention on the 16-bit matrix cores: parity, the 16-bit model tests, the Whisper line + its kernel stats
-  timeout 900 python -m pytest tests/test_ops_gpu.py -k "attention_full" -x -q 2>&1 | tail -5 | tee $O/attn_h_tests.txt
+  timeout 900 python -m pytest tests/test_ops_gpu.py -k "attention_full or cross_attention or gemm_half" -x -q 2>&1 | tail -5 | tee $O/attn_h_tests.txt
   timeout 1200 python -m pytest tests/test_whisper_gpu.py tests/test_translator_gpu.py tests/test_generator_gpu.py -k "half or float16 or bfloat16 or bf16 or fp16 or whisper or nllb or 16" -x -q 2>&1 | tail -5 | tee -a $O/attn_h_tests.txt
   timeout 600 python tools/bench_whisper.py 2>&1 | tail -1 | tee $O/whisper_attn_h.json
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_wh -- python $GRAFT_REPO_ROOT/tools/bench_whisper.py --steps 1 --warmup 1 > /tmp/prof_wh.log 2>&1 )
   f=$(ls -S $(find /tmp/prof_wh -name '*kernel_stats.csv') | head -1); cp "$f" $O/kernel_stats_bench_whisper.csv; head -10 $O/kernel_stats_bench_whisper.csv | cut -c1-200 ;;
+xattn_probe)      # profiles/r05_xattn_probe.txt: the 16-bit cross attention at the Whisper shape, chunks 1 .. 8 (TUNING library)
+  CT2X_LIBRARY=$GRAFT_REPO_ROOT/ctranslate2_amd/libct2_mi355_tuning.so timeout 300 python tools/xattn_probe.py 2>&1 | tee $O/xattn_probe.txt ;;
 all)              # the whole -m gpu suite, smoke and the default bench line
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -3 $O/pytest_all.log
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
