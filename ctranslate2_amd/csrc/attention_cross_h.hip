@@ -122,6 +122,8 @@ __global__ __launch_bounds__(kXhThreads) __attribute__((amdgpu_waves_per_eu(MB <
   constexpr int KT = 64 / CG;     // keys per wave tile of the context phase
   extern __shared__ __attribute__((aligned(16))) float xh_lds[];
   __shared__ float red[kXhWaves][kXhMaxBeam];
+  __shared__ float fin_max[kXhMaxBeam];
+  static_assert(kXhWaves == 8, "the maxima are folded over eight waves");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int splits = p.splits;
   const int bh = blockIdx.x / splits, chunk_id = blockIdx.x % splits;
@@ -254,6 +256,8 @@ __global__ __launch_bounds__(kXhThreads) __attribute__((amdgpu_waves_per_eu(MB <
       mx[j] = m;
     }
   }
+  if (tid < beam) fin_max[tid] = fmaxf(fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid])),
+                                      fmaxf(fmaxf(red[4][tid], red[5][tid]), fmaxf(red[6][tid], red[7][tid])));
   __syncthreads();  // every thread has read the maxima: `red` is reused for the sums
   CT2X_XH_STAMP(3);
   float sum[MB];
@@ -276,19 +280,8 @@ __global__ __launch_bounds__(kXhThreads) __attribute__((amdgpu_waves_per_eu(MB <
       if (lane == 0) red[wave][j] = v;
     }
   }
-  __syncthreads();  // sums exchanged, probabilities visible to every wave
-  float inv_sum[MB], tot[MB];
-#pragma unroll
-  for (int j = 0; j < MB; ++j) {
-    inv_sum[j] = tot[j] = 0.f;
-    if (j < beam) {
-      float t = red[0][j];
-#pragma unroll
-      for (int w = 1; w < kXhWaves; ++w) t += red[w][j];
-      tot[j] = t;
-      inv_sum[j] = t > 0.f ? 1.f / t : 0.f;
-    }
-  }
+  __syncthreads();  // sums exchanged (they stay in `red` until the end: registers are for the context
+                    // phase), probabilities visible to every wave
 
   CT2X_XH_STAMP(4);
   // ---- context: a wave takes tiles of KT keys, kXhUnroll tiles in flight --------------------------
@@ -337,10 +330,10 @@ __global__ __launch_bounds__(kXhThreads) __attribute__((amdgpu_waves_per_eu(MB <
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < kXhWaves; ++w) v += part[(w * kXhMaxBeam + j) * DH + c];
-      float inv = 0.f;
+      float t = red[0][j];
 #pragma unroll
-      for (int jj = 0; jj < MB; ++jj)
-        if (jj == j) inv = inv_sum[jj];
+      for (int w = 1; w < kXhWaves; ++w) t += red[w][j];
+      const float inv = t > 0.f ? 1.f / t : 0.f;
       const int64_t row = static_cast<int64_t>(b) * beam + j;
       p.out[row * p.out_row_stride + static_cast<int64_t>(h) * DH + c] = v * inv;
     }
@@ -358,14 +351,10 @@ __global__ __launch_bounds__(kXhThreads) __attribute__((amdgpu_waves_per_eu(MB <
     grid_publish(mine + j * REC + c, v);
   }
   if (tid < beam) {
-    float m = 0.f, t = 0.f;
+    float t = red[0][tid];
 #pragma unroll
-    for (int jj = 0; jj < MB; ++jj)
-      if (jj == tid) {
-        m = mx[jj];
-        t = tot[jj];
-      }
-    grid_publish(mine + tid * REC + DH, m);
+    for (int w = 1; w < kXhWaves; ++w) t += red[w][tid];
+    grid_publish(mine + tid * REC + DH, fin_max[tid]);
     grid_publish(mine + tid * REC + DH + 1, t);
   }
   CT2X_XH_STAMP(7);
