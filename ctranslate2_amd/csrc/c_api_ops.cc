@@ -1053,6 +1053,14 @@ int ct2x_tuning_xattn_stamps(unsigned long long* host16) {
 }
 #endif
 
+#ifdef CT2X_TUNING
+int ct2x_tuning_gemm_rows_stamps(unsigned long long* host16) {
+  API_TRY
+  gemm_h_rows_read_stamps(host16);
+  API_CATCH
+}
+#endif
+
 static int attention_full_entry(const char* name, const float* d_q, const float* d_k, const float* d_v,
                                 const int32_t* d_lengths, int64_t batch, int64_t tq, int64_t tk,
                                 int64_t heads, int64_t heads_kv, int64_t dhead, int causal,

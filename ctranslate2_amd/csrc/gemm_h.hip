@@ -247,6 +247,22 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_h_skinny_kernel(const float* 
 //     The partial tiles are read with plain 16-byte loads: every line has exactly one writer, was
 //     written through to memory before its writer's ticket, and cannot be in the reader's L2
 //     (invalidated at the kernel boundary, untouched by this launch before the tickets are complete).
+// TUNING builds: shader-clock stamps of workgroup (0, 0) and of column tile 0's last arrival
+// (tools/gemm_rows_probe.py)
+#ifdef CT2X_TUNING
+__device__ unsigned long long g_rows_stamps[16];
+#define CT2X_ROWS_STAMP(i)                                                                        \
+  do {                                                                                            \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_rows_stamps[i] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define CT2X_ROWS_STAMP_LAST(i)                                                                   \
+  do {                                                                                            \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_rows_stamps[i] = __builtin_amdgcn_s_memtime();     \
+  } while (0)
+#else
+#define CT2X_ROWS_STAMP(i)
+#define CT2X_ROWS_STAMP_LAST(i)
+#endif
 constexpr int kRowsKSlice = 512;  // K elements per workgroup (the unfused form; the fused one: 256 or 512)
 constexpr int kRowsMaxFusedSlices = 20;  // 3 x 20 partial loads in flight per thread of the last arrival
 template <bool kBF16, int MT, int KSL, bool kFused>
@@ -270,6 +286,7 @@ __global__ __launch_bounds__(256) void gemm_h_rows_kernel(const float* __restric
   const int k0 = static_cast<int>(blockIdx.y) * KSL;
   const int kn = min(KSL, K - k0);  // a multiple of 8 (K % 8 == 0)
 
+  CT2X_ROWS_STAMP(0);
   // weight fragments of this wave's 16 columns over the whole slice: requested first
   vec wf[KSTEPS];
   {
@@ -318,31 +335,38 @@ __global__ __launch_bounds__(256) void gemm_h_rows_kernel(const float* __restric
       }
     }
   }
+  CT2X_ROWS_STAMP(1);
   __syncthreads();
+  CT2X_ROWS_STAMP(2);
 
   v4f acc[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
-  const int ksteps = (kn + 31) / 32;
+  // (steps beyond the slice's end multiply zeros - both operands were zero-filled - so the loop is
+  // branch-free; the activation fragments of step ks + 1 are read from LDS before the MFMAs of
+  // step ks: read one after the other behind their uses they were 2.2k of the launch's shader clocks)
+  vec fa[2][MT], fl[2][MT];
+  auto read_step = [&](int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int off = (i * 16 + r) * STRIDE + (ks * 32 + g * 8) * 2;
+      fa[buf][i] = *reinterpret_cast<const vec*>(a_hi + off);
+      if constexpr (!kBF16) fl[buf][i] = *reinterpret_cast<const vec*>(a_lo + off);
+    }
+  };
+  read_step(0, 0);
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
-    if (ks < ksteps) {
+    if (ks + 1 < KSTEPS) read_step(ks + 1, (ks + 1) & 1);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int off = (i * 16 + r) * STRIDE + (ks * 32 + g * 8) * 2;
-        if constexpr (!kBF16) {
-          const v8h lo = *reinterpret_cast<const v8h*>(a_lo + off);
-          const v8h hi = *reinterpret_cast<const v8h*>(a_hi + off);
-          acc[i] = Ops::mfma(lo, wf[ks], acc[i]);
-          acc[i] = Ops::mfma(hi, wf[ks], acc[i]);
-        } else {
-          acc[i] = Ops::mfma(*reinterpret_cast<const vec*>(a_hi + off), wf[ks], acc[i]);
-        }
-      }
+    for (int i = 0; i < MT; ++i) {
+      if constexpr (!kBF16) acc[i] = Ops::mfma(fl[ks & 1][i], wf[ks], acc[i]);
+      acc[i] = Ops::mfma(fa[ks & 1][i], wf[ks], acc[i]);
     }
   }
   // MFMA C layout: column = lane & 15, row = 4 * (lane >> 4) + register
   const int64_t col = n0 + r;
+  CT2X_ROWS_STAMP(3);
   if constexpr (kFused) {
     // (N % 64 == 0 here: every column of the tile exists)
     // partial tile of (slice z, column tile x): [M][64] floats in a region of its own
@@ -356,31 +380,66 @@ __global__ __launch_bounds__(256) void gemm_h_rows_kernel(const float* __restric
         const int row = i * 16 + g * 4 + e;
         if (row < M) grid_publish(mine + row * 64 + wave * 16 + r, acc[i][e]);
       }
-    if (!grid_last_arrival(tickets + blockIdx.x, static_cast<unsigned>(slices))) return;
-    asm volatile("" ::: "memory");
-    const float* tile = partial_out + static_cast<int64_t>(blockIdx.x) * slices * tile_floats;
-    const int quads = M * 16;  // float4 pieces of the [M][64] tile
-    for (int q = tid; q < quads; q += 256) {
-      v4f sl[kRowsMaxFusedSlices];
+    // the epilogue's operands of the pieces this thread would finish do not depend on the other
+    // slices: requested BEFORE the ticket, they arrive during its round trip
+    const int quads = M * 16;  // float4 pieces of the [M][64] tile; thread t takes t, t + 256, ..
+    constexpr int QIT = MT;    // ROWS * 16 / 256 pieces per thread
+    v4f bv[QIT], rv[QIT];
 #pragma unroll
-      for (int z = 0; z < kRowsMaxFusedSlices; ++z)
-        if (z < slices) sl[z] = *reinterpret_cast<const v4f*>(tile + z * tile_floats + q * 4);
-      v4f v = sl[0];
-#pragma unroll
-      for (int z = 1; z < kRowsMaxFusedSlices; ++z)
-        if (z < slices) v = v + sl[z];  // z order: the sums of the separate reduce launch
-      const int row = q >> 4;
+    for (int i = 0; i < QIT; ++i) {
+      const int q = min(tid + i * 256, quads - 1);
       const int64_t c0 = static_cast<int64_t>(blockIdx.x) * 64 + (q & 15) * 4;
-      const int64_t idx = static_cast<int64_t>(row) * N + c0;
-      v4f bv = v4f{0.f, 0.f, 0.f, 0.f}, rv = v4f{0.f, 0.f, 0.f, 0.f};
-      if (ep.bias) bv = *reinterpret_cast<const v4f*>(ep.bias + c0);
-      if (ep.residual) rv = *reinterpret_cast<const v4f*>(ep.residual + idx);
-      v4f o;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        o[c] = finish(v[c], bv[c], ep.bias != nullptr, ep.act, rv[c], ep.residual != nullptr);
-      *reinterpret_cast<v4f*>(ep.y + idx) = o;
+      bv[i] = rv[i] = v4f{0.f, 0.f, 0.f, 0.f};
+      if (ep.bias) bv[i] = *reinterpret_cast<const v4f*>(ep.bias + c0);
+      if (ep.residual) rv[i] = *reinterpret_cast<const v4f*>(ep.residual + static_cast<int64_t>(q >> 4) * N + c0);
     }
+    CT2X_ROWS_STAMP(4);
+    const bool last_here = grid_last_arrival(tickets + blockIdx.x, static_cast<unsigned>(slices));
+    CT2X_ROWS_STAMP(5);
+    if (!last_here) return;
+    CT2X_ROWS_STAMP_LAST(6);
+    asm volatile("" ::: "memory");
+    // all partial tiles of a batch of slices in flight at once (the first form walked its pieces one
+    // after the other, two dependent round trips each: 12 - 22k shader clocks of a 14.5 us launch,
+    // profiles/r05_gemm_rows_probe.txt). Loads are unconditional (clamped indices), so the batch is
+    // straight-line code behind ONE wait; the sums keep the z order.
+    const float* tile = partial_out + static_cast<int64_t>(blockIdx.x) * slices * tile_floats;
+    constexpr int ZB = MT == 1 ? 20 : (MT <= 3 ? 10 : 8);
+    v4f v[QIT];
+#pragma unroll
+    for (int i = 0; i < QIT; ++i) v[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < slices; z0 += ZB) {
+      v4f sl[QIT][ZB];
+#pragma unroll
+      for (int zz = 0; zz < ZB; ++zz) {
+        const int z = min(z0 + zz, slices - 1);
+#pragma unroll
+        for (int i = 0; i < QIT; ++i) {
+          const int q = min(tid + i * 256, quads - 1);
+          sl[i][zz] = *reinterpret_cast<const v4f*>(tile + z * tile_floats + q * 4);
+        }
+      }
+#pragma unroll
+      for (int zz = 0; zz < ZB; ++zz)
+        if (z0 + zz < slices) {
+#pragma unroll
+          for (int i = 0; i < QIT; ++i) v[i] = (z0 + zz == 0) ? sl[i][zz] : v[i] + sl[i][zz];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QIT; ++i) {
+      const int q = tid + i * 256;
+      if (q < quads) {
+        const int64_t c0 = static_cast<int64_t>(blockIdx.x) * 64 + (q & 15) * 4;
+        const int64_t idx = static_cast<int64_t>(q >> 4) * N + c0;
+        v4f o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          o[c] = finish(v[i][c], bv[i][c], ep.bias != nullptr, ep.act, rv[i][c], ep.residual != nullptr);
+        *reinterpret_cast<v4f*>(ep.y + idx) = o;
+      }
+    }
+    CT2X_ROWS_STAMP_LAST(7);
     if (tid == 0) grid_publish(tickets + blockIdx.x, 0u);
     return;
   }
@@ -640,7 +699,9 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
       const int mt3 = (M > 32 && M <= 48) ? 3 : mt;
       auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
       // fused K-slice sum: whole 64-column tiles, vector epilogue operands, a ticket per column tile
-      const int ksl = ((N / 64) * ((K + 511) / 512) >= 256 || K % 256 != 0) ? 512 : 256;
+      // (256 when 512 leaves the chip half empty - but never more than 10 slices: the last arrival
+      // reads them in one batch, and 20 tickets on one counter were 6k shader clocks of waiting)
+      const int ksl = ((N / 64) * ((K + 511) / 512) >= 256 || K % 256 != 0 || K > 2560) ? 512 : 256;
       const int fslices = (K + ksl - 1) / ksl;
       const bool fused = fslices > 1 && fslices <= kRowsMaxFusedSlices && tickets != nullptr && N % 64 == 0 &&
                          static_cast<size_t>(N / 64) <= n_tickets && splitk_ws != nullptr &&
@@ -730,6 +791,13 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
 }
 
 }  // namespace
+
+#ifdef CT2X_TUNING
+void gemm_h_rows_read_stamps(unsigned long long* host16) {
+  CT2X_HIP_CHECK(hipDeviceSynchronize());
+  CT2X_HIP_CHECK(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_rows_stamps), sizeof(unsigned long long) * 16));
+}
+#endif
 
 void launch_gemm_h(const float* a, const void* w, bool bf16, int64_t m, int64_t n, int64_t k,
                    const float* bias, const float* residual, int act, float* y,

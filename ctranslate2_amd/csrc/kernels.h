@@ -720,6 +720,7 @@ int64_t cross_attention_h_scratch_floats(int64_t batch, int64_t beam, int64_t he
 bool cross_attention_h_applicable(const CrossAttnHParams& p);
 #ifdef CT2X_TUNING
 void xattn_h_read_stamps(unsigned long long* host16);  // tools/xattn_probe.py
+void gemm_h_rows_read_stamps(unsigned long long* host16);  // tools/gemm_rows_probe.py
 #endif
 void launch_cross_attention_h(const CrossAttnHParams& p, hipStream_t stream);
 

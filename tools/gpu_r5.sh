@@ -68,6 +68,8 @@ attn_h)           # sequence-mode attention on the 16-bit matrix cores: parity, 
   f=$(ls -S $(find /tmp/prof_wh -name '*kernel_stats.csv') | head -1); cp "$f" $O/kernel_stats_bench_whisper.csv; head -10 $O/kernel_stats_bench_whisper.csv | cut -c1-200 ;;
 xattn_probe)      # profiles/r05_xattn_probe.txt: the 16-bit cross attention at the Whisper shape, chunks 1 .. 8 (TUNING library)
   CT2X_LIBRARY=$GRAFT_REPO_ROOT/ctranslate2_amd/libct2_mi355_tuning.so timeout 300 python tools/xattn_probe.py 2>&1 | tee $O/xattn_probe.txt ;;
+rows_probe)       # profiles/r05_gemm_rows_probe.txt: the decode-row 16-bit GEMM at the Whisper shapes (TUNING library)
+  CT2X_LIBRARY=$GRAFT_REPO_ROOT/ctranslate2_amd/libct2_mi355_tuning.so timeout 300 python tools/gemm_rows_probe.py 2>&1 | tee $O/gemm_rows_probe.txt ;;
 all)              # the whole -m gpu suite, smoke and the default bench line
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -3 $O/pytest_all.log
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
