@@ -467,8 +467,13 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                      no_repeat_ngram_size: int = 0,
                      suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None,
                      end_token_id: Optional[int] = None, callback=None, num_hypotheses: int = 1,
-                     patience: float = 1.0, return_logits_vocab: bool = False):
+                     patience: float = 1.0, return_logits_vocab: bool = False,
+                     return_alternatives: bool = False, min_alternative_expansion_prob: float = 0.0):
         """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False.
+        return_alternatives: the num_hypotheses best FIRST tokens after the prompt, each continued
+        independently with the requested search (decode_alternatives, src/decoding.cc:1122-1290);
+        as in the reference, max_length / min_length then count from the first PROMPT position, and
+        the sequences of a longer prompt of a ragged batch begin with the rest of that prompt.
         num_hypotheses > 1 (the best of a beam search, or that many random samples per prompt,
         ordered by score): the results become [batch][hypothesis][tokens] and scores [batch, hyp].
         return_logits_vocab (beam_size 1): a third result, per prompt (and hypothesis) an array
@@ -492,6 +497,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         _keep = self._set_processors(opt, repetition_penalty, no_repeat_ngram_size,
                                      suppress_sequences_ids)
         opt.end_token_plus_one = 0 if end_token_id is None else int(end_token_id) + 1
+        opt.return_alternatives = int(return_alternatives)
+        opt.min_alternative_expansion_prob = float(min_alternative_expansion_prob)
         cb = self._set_callback(opt, callback)
         if return_logits_vocab:
             lbuf, lcnt = self._set_logits(opt, batch, nh,
@@ -502,10 +509,14 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         if cb.error is not None:
             raise cb.error
         extra = ()
-        if nh == 1:
+        if nh == 1 and not return_alternatives:
             if return_logits_vocab:
                 extra = ([lbuf[b, 0, :lcnt[b, 0]].copy() for b in range(batch)],)
             return ([out[b, 0, :out_len[b, 0]].tolist() for b in range(batch)], scores[:, 0]) + extra
+        if return_alternatives:  # (-1: fewer alternatives than num_hypotheses were expanded)
+            kept = [[k for k in range(nh) if out_len[b, k] >= 0] for b in range(batch)]
+            return ([[out[b, k, :out_len[b, k]].tolist() for k in kept[b]] for b in range(batch)],
+                    [[float(scores[b, k]) for k in kept[b]] for b in range(batch)])
         kept = [[k for k in range(nh) if out_len[b, k] > 0 or k == 0] for b in range(batch)]
         if return_logits_vocab:
             extra = ([[lbuf[b, k, :lcnt[b, k]].copy() for k in kept[b]] for b in range(batch)],)

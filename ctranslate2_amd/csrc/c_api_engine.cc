@@ -814,6 +814,134 @@ static void decode_alternatives(Translator& t, const std::vector<std::vector<int
   }
 }
 
+// decode_alternatives for a decoder-only model (DecoderReplica::run_generation ->
+// decode(..., return_alternatives), src/models/language_model.cc:218-245, src/decoding.cc:1122-1290):
+// per prompt, the tokens after the batch's common `forward_length` are its start_tokens - all but
+// the last are consumed in sequence mode and BEGIN every returned sequence, the num_hypotheses best
+// next tokens are expanded by a one-step beam search at start_step = tokens consumed, and every
+// alternative is continued independently; max_length / min_length count from step 0 of the
+// decoder, i.e. INCLUDING the consumed prompt (the reference's arithmetic: suffix length =
+// max_length - start_step). The reference runs prompt by prompt; prompts of one length share their
+// launches here (every op is row-wise). Longer prompts of a ragged batch: their whole head is
+// consumed by ONE sequence-mode pass here, by two in the reference (the batch's common part, then
+// the example's rest) - the same arithmetic in a different summation order.
+static void generate_alternatives(Translator& t, const std::vector<std::vector<int32_t>>& prompts,
+                                  int32_t forward_length, const ct2x_translation_options& opt,
+                                  const DecodingOptions& dopt, int32_t end_id,
+                                  std::vector<DecodingResult>& out) {
+  Engine& e = *t.engine;
+  const int32_t nh = dopt.num_hypotheses, max_length = dopt.max_length;
+  struct Plan {
+    std::vector<int32_t> head;    // tokens consumed in sequence mode
+    std::vector<int32_t> prefix;  // start_tokens[1:]: begins every returned sequence
+    int32_t last = 0;             // start_tokens.back(): the expansion's input
+  };
+  std::vector<Plan> plans(prompts.size());
+  std::map<size_t, std::vector<int32_t>> by_head;
+  for (size_t b = 0; b < prompts.size(); ++b) {
+    std::vector<int32_t> start_tokens(prompts[b].begin() + forward_length, prompts[b].end());
+    if (static_cast<int32_t>(start_tokens.size()) > max_length + 1) start_tokens.resize(max_length + 1);  // (:1138-1139)
+    Plan& pl = plans[b];
+    const int32_t prefix_length = static_cast<int32_t>(start_tokens.size()) - 1;
+    pl.prefix.assign(start_tokens.begin() + 1, start_tokens.end());
+    pl.last = start_tokens.back();
+    pl.head.assign(prompts[b].begin(), prompts[b].begin() + forward_length + prefix_length);
+    if (prefix_length > 0 && prefix_length == max_length) {  // (:1176-1177)
+      out[b].hypotheses.assign(nh, pl.prefix);
+      if (dopt.return_scores) out[b].scores.assign(nh, 0.f);
+      continue;
+    }
+    by_head[pl.head.size()].push_back(static_cast<int32_t>(b));
+  }
+  for (const auto& group : by_head) {
+    const int64_t consumed = static_cast<int64_t>(group.first);
+    const std::vector<int32_t>& members = group.second;
+    const int64_t B = static_cast<int64_t>(members.size());
+    auto make_state = [&](const std::vector<int32_t>& rows_of, int64_t beam, int64_t t_max) {
+      const int64_t R = static_cast<int64_t>(rows_of.size());
+      auto st = e.start_decoder_only(R, beam, t_max, consumed);
+      if (consumed > 0) {
+        std::vector<int32_t> pre(static_cast<size_t>(R * beam * consumed));
+        for (int64_t i = 0; i < R; ++i)
+          for (int64_t k = 0; k < beam; ++k)
+            std::copy(plans[rows_of[i]].head.begin(), plans[rows_of[i]].head.end(),
+                      pre.begin() + (i * beam + k) * consumed);
+        e.prefill(*st, pre.data(), consumed);
+      }
+      return st;
+    };
+    // ---- the num_hypotheses best next tokens: BeamSearch(num_hypotheses), one step (:1183-1202)
+    std::vector<int32_t> last_token(B);
+    for (int64_t i = 0; i < B; ++i) last_token[i] = plans[members[i]].last;
+    std::vector<DecodingResult> expansion;
+    {
+      auto st = make_state(members, nh, consumed + 2);
+      DecodingOptions d1;
+      d1.beam_size = nh;
+      d1.num_hypotheses = nh;
+      d1.max_length = 1;
+      d1.min_length = 1;
+      d1.length_penalty = 0.f;
+      d1.return_scores = true;
+      d1.use_graph = false;
+      d1.start_step = static_cast<int32_t>(consumed);
+      d1.logits_processing = dopt.logits_processing;
+      expansion = beam_search(e, *st, last_token, end_id, d1, nullptr, nullptr);
+      e.synchronize();
+    }
+    std::vector<int32_t> alt_prompt, alt_token;
+    for (int64_t i = 0; i < B; ++i) {
+      const int32_t b = members[i];
+      for (int32_t k = 0; k < nh && k < static_cast<int32_t>(expansion[i].hypotheses.size()); ++k) {
+        const float prob = std::exp(expansion[i].scores[k]);
+        if (prob < opt.min_alternative_expansion_prob) break;
+        std::vector<int32_t> hyp = plans[b].prefix;
+        hyp.push_back(expansion[i].hypotheses[k].back());
+        out[b].hypotheses.emplace_back(std::move(hyp));
+        if (dopt.return_scores) out[b].scores.push_back(expansion[i].scores[k]);
+        alt_prompt.push_back(b);
+        alt_token.push_back(expansion[i].hypotheses[k].back());
+      }
+    }
+    const int64_t start_step = consumed + 1;
+    if (start_step == max_length || alt_prompt.empty()) continue;  // (:1236-1238)
+    // ---- continue from each alternative independently (:1240-1256)
+    DecodingOptions d2 = dopt;
+    d2.max_length = std::max<int32_t>(max_length - static_cast<int32_t>(start_step), 0);
+    d2.min_length = std::max<int32_t>(dopt.min_length - static_cast<int32_t>(start_step), 0);
+    d2.num_hypotheses = 1;
+    d2.start_step = static_cast<int32_t>(start_step);
+    d2.return_prefix = false;
+    if (d2.max_length == 0) continue;  // (a search of zero steps returns empty suffixes)
+    auto st = make_state(alt_prompt, d2.beam_size, start_step + d2.max_length + 1);
+    {
+      // the decode step of the last prompt token (the expansion step of the reference, whose state
+      // the suffix search inherits)
+      std::vector<int32_t> ids(st->rows);
+      for (size_t a = 0; a < alt_prompt.size(); ++a)
+        for (int64_t k = 0; k < d2.beam_size; ++k) ids[a * d2.beam_size + k] = plans[alt_prompt[a]].last;
+      st->prefix_first_step = static_cast<int32_t>(consumed);
+      e.set_step(*st, static_cast<int32_t>(consumed));
+      e.set_ids(*st, ids.data());
+      e.step(*st, /*graph=*/false);
+      e.advance_step(*st);
+    }
+    std::vector<DecodingResult> suffix =
+        d2.beam_size == 1 ? greedy_search(e, *st, alt_token, end_id, d2, nullptr, nullptr)
+                          : beam_search(e, *st, alt_token, end_id, d2, nullptr, nullptr);
+    e.synchronize();
+    std::map<int32_t, int32_t> next_slot;
+    for (size_t a = 0; a < alt_prompt.size(); ++a) {
+      const int32_t b = alt_prompt[a];
+      const int32_t k = next_slot[b]++;
+      auto& hyp = out[b].hypotheses[k];
+      if (!suffix[a].hypotheses.empty())
+        hyp.insert(hyp.end(), suffix[a].hypotheses[0].begin(), suffix[a].hypotheses[0].end());
+      if (dopt.return_scores && !suffix[a].scores.empty()) out[b].scores[k] += suffix[a].scores[0];
+    }
+  }
+}
+
 static int translate_batch_impl(void* translator, const int32_t* src_ids,
                                 const int32_t* src_lengths, int32_t batch, int32_t src_stride,
                                 const int32_t* prefix_ids, const int32_t* prefix_lengths,
@@ -1172,6 +1300,43 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   const double t0 = now_ms();
   t->last = ct2x_exec_stats{};
   t->last_compactions = 0;
+  if (opt.return_alternatives) {
+    CT2X_CHECK(dopt.sampling_topk == 1, "return_alternatives with random sampling is not built for the "
+               "generator in this backend");
+    CT2X_CHECK(opt.logits_out == nullptr && !dopt.callback,
+               "return_logits_vocab / callbacks are not built together with return_alternatives for "
+               "the generator in this backend");
+    std::vector<std::vector<int32_t>> prompts(batch);
+    for (int32_t b = 0; b < batch; ++b) {
+      const int32_t* row = prompt_ids + static_cast<int64_t>(b) * stride;
+      prompts[b].assign(row, row + prompt_lengths[b]);
+      for (int32_t id : prompts[b])
+        CT2X_CHECK(id >= 0 && id < static_cast<int32_t>(t->engine->vocab_size()),
+                   "Invalid prompt token ID " + std::to_string(id));
+    }
+    std::vector<DecodingResult> results(batch);
+    generate_alternatives(*t, prompts, forward_length, opt, dopt, end_id, results);
+    const int32_t nh_alt = dopt.num_hypotheses, max_len_alt = opt.max_decoding_length;
+    for (int32_t b = 0; b < batch; ++b)
+      for (int32_t k = 0; k < nh_alt; ++k) {
+        // -1: fewer alternatives than num_hypotheses passed min_alternative_expansion_prob
+        out_lengths[b * nh_alt + k] = -1;
+        if (k >= static_cast<int32_t>(results[b].hypotheses.size())) continue;
+        auto& hyp = results[b].hypotheses[k];
+        if (!opt.return_end_token)
+          while (!hyp.empty() && hyp.back() == end_id) hyp.pop_back();
+        const int32_t len = static_cast<int32_t>(hyp.size());
+        std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len_alt),
+                  out_ids + (static_cast<int64_t>(b) * nh_alt + k) * max_len_alt);
+        out_lengths[b * nh_alt + k] = len;
+        if (opt.return_scores && out_scores && k < static_cast<int32_t>(results[b].scores.size()))
+          out_scores[b * nh_alt + k] = results[b].scores[k];
+        if (k == 0) t->last.num_tokens += len;
+      }
+    t->last.num_examples = batch;
+    t->last.total_ms = now_ms() - t0;
+    return 0;
+  }
   const int64_t t_max = static_cast<int64_t>(forward_length) + longest_prefix + dopt.max_length + 1;
   // Beam search: every hypothesis row starts from the same prefilled prompt state; the prompt is
   // forwarded once per row (beam x the prefill work instead of a cache replication pass).

@@ -586,7 +586,10 @@ struct ct2x_translation_options {
    *  return_alternatives: the num_hypotheses best FIRST tokens after the target prefix, each
    *    continued independently (decode_alternatives, src/decoding.cc:1122-1290); alternatives whose
    *    probability is below min_alternative_expansion_prob are dropped - the missing hypotheses of a
-   *    sentence get out_lengths -1;
+   *    sentence get out_lengths -1; ct2x_generate_batch honours it as well (round 5: the same
+   *    function behind DecoderReplica::run_generation, src/models/language_model.cc:241-245 - the
+   *    step arithmetic then counts the consumed prompt: a sequence has max_decoding_length -
+   *    prompt length + 1 tokens; greedy / beam search only);
    *  prefix_bias_beta in (0, 1): the target prefix is a BIAS instead of a constraint (BiasedDecoder,
    *    src/decoding.cc:256-343; always a beam search, beam_size 1 included);
    *  attention_out (return_attention): HOST buffer [batch, num_hypotheses, max_decoding_length,

@@ -481,6 +481,47 @@ int ct2ref_generate(void* h, const int32_t* prompt_ids, const int32_t* prompt_le
   CT2REF_CATCH
 }
 
+// Generator::generate_batch with num_hypotheses / return_alternatives /
+// min_alternative_expansion_prob (GenerationOptions, include/ctranslate2/generation.h;
+// decode_alternatives, src/decoding.cc:1122-1290 - reached from DecoderReplica::run_generation,
+// src/models/language_model.cc:241-245). out_ids [batch, num_hyp, max_len], out_lengths /
+// out_scores [batch, num_hyp] (length -1: the reference returned fewer sequences).
+int ct2ref_generate_ex(void* h, const int32_t* prompt_ids, const int32_t* prompt_lengths, int batch,
+                       int stride, int beam_size, int max_len, int min_len, int num_hyp,
+                       int return_alternatives, float min_alternative_expansion_prob,
+                       int32_t* out_ids, int32_t* out_lengths, float* out_scores) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const auto* lm = dynamic_cast<const models::LanguageModel*>(m->model.get());
+  if (!lm || !m->generator) throw std::runtime_error("not a language model");
+  auto prompts = ids_to_tokens(lm->get_vocabulary(), prompt_ids, prompt_lengths, batch, stride);
+  GenerationOptions opt;
+  opt.beam_size = beam_size;
+  opt.max_length = max_len;
+  opt.min_length = min_len;
+  opt.sampling_topk = 1;
+  opt.num_hypotheses = num_hyp;
+  opt.return_scores = true;
+  opt.return_alternatives = return_alternatives != 0;
+  opt.min_alternative_expansion_prob = min_alternative_expansion_prob;
+  opt.include_prompt_in_result = false;
+  auto futures = m->generator->generate_batch_async(prompts, opt);
+  std::vector<GenerationResult> results;
+  for (auto& f : futures) results.emplace_back(f.get());
+  for (int b = 0; b < batch; ++b)
+    for (int k = 0; k < num_hyp; ++k) {
+      const int64_t slot = static_cast<int64_t>(b) * num_hyp + k;
+      out_lengths[slot] = -1;
+      if (k >= static_cast<int>(results[b].sequences_ids.size())) continue;
+      const auto& ids = results[b].sequences_ids[k];
+      const int len = static_cast<int>(ids.size());
+      for (int t = 0; t < len && t < max_len; ++t) out_ids[slot * max_len + t] = static_cast<int32_t>(ids[t]);
+      out_lengths[slot] = len;
+      if (out_scores && k < static_cast<int>(results[b].scores.size())) out_scores[slot] = results[b].scores[k];
+    }
+  CT2REF_CATCH
+}
+
 // Generator::generate_batch with the logits-processor options (GenerationOptions::
 // repetition_penalty / no_repeat_ngram_size / suppress_sequences, include/ctranslate2/generation.h).
 int ct2ref_generate_processors(void* h, const int32_t* prompt_ids, const int32_t* prompt_lengths,

@@ -352,6 +352,25 @@ class RefModel:
                                      _p(out_len), _p(scores)))
         return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
 
+    def generate_ex_ids(self, prompts, beam_size=1, max_len=64, min_len=0, num_hypotheses=1,
+                        return_alternatives=False, min_alternative_expansion_prob=0.0):
+        """Generator::generate_batch with num_hypotheses / return_alternatives (ct2ref_generate_ex).
+        Returns (sequences [batch][<= num_hypotheses], scores likewise)."""
+        ids, lengths, stride = self._pack(prompts)
+        batch = len(prompts)
+        out = np.zeros((batch, num_hypotheses, max_len), np.int32)
+        out_len = np.zeros((batch, num_hypotheses), np.int32)
+        scores = np.zeros((batch, num_hypotheses), np.float32)
+        _check(lib().ct2ref_generate_ex(
+            C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch), C.c_int(stride),
+            C.c_int(beam_size), C.c_int(max_len), C.c_int(min_len), C.c_int(num_hypotheses),
+            C.c_int(int(return_alternatives)), C.c_float(min_alternative_expansion_prob), _p(out),
+            _p(out_len), _p(scores)))
+        seqs = [[out[b, k, :min(out_len[b, k], max_len)].tolist() for k in range(num_hypotheses) if out_len[b, k] >= 0]
+                for b in range(batch)]
+        scs = [[float(scores[b, k]) for k in range(num_hypotheses) if out_len[b, k] >= 0] for b in range(batch)]
+        return seqs, scs
+
     def generate_processors_ids(self, prompts, beam_size=1, max_len=64, min_len=0,
                                 return_scores=True, repetition_penalty=1.0, no_repeat_ngram_size=0,
                                 suppress_sequences_ids=()):
