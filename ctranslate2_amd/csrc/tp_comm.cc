@@ -324,7 +324,12 @@ struct ShmHeader {
   std::atomic<uint32_t> generation;  // barrier: bumped by the last arriver
   std::atomic<uint32_t> poisoned;    // a rank gave up
   hipIpcMemHandle_t handles[kTpMaxWorld];
-  char pad[4096 - 16 - sizeof(hipIpcMemHandle_t) * kTpMaxWorld];
+  // bootstrap handshake: rank r writes a token of its own making into hello[r], rank 0 echoes it
+  // into ack[r]. A rank that opened a STALE segment of the same name (left by a crashed run: its
+  // `ready` word is already set) never sees its token come back and opens the name again.
+  std::atomic<uint64_t> hello[kTpMaxWorld];
+  std::atomic<uint64_t> ack[kTpMaxWorld];
+  char pad[4096 - 16 - sizeof(hipIpcMemHandle_t) * kTpMaxWorld - 16 * kTpMaxWorld];
 };
 static_assert(sizeof(ShmHeader) == 4096, "segment header");
 
@@ -333,35 +338,74 @@ public:
   ShmComm(int rank, int world, const std::string& name) : rank_(rank), world_(world), name_("/" + name) {
     if (world < 2 || world > kTpMaxWorld) throw Error("shared-memory communicator: world size must be 2..8");
     bytes_ = sizeof(ShmHeader) + static_cast<size_t>(world) * kShmChunk;
-    int fd = -1;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto expired = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120); };
+    auto map_segment = [&](int fd) {
+      void* p = mmap(nullptr, bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if (p == MAP_FAILED) throw Error("shared-memory communicator: mmap failed");
+      hdr_ = static_cast<ShmHeader*>(p);
+      data_ = static_cast<char*>(p) + sizeof(ShmHeader);
+    };
     if (rank == 0) {
       (void)shm_unlink(name_.c_str());
-      fd = shm_open(name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      const int fd = shm_open(name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
       if (fd < 0 || ftruncate(fd, static_cast<off_t>(bytes_)) != 0)
         throw Error("shared-memory communicator: cannot create " + name_);
-    } else {
-      const auto t0 = std::chrono::steady_clock::now();
-      struct stat st;
-      while ((fd = shm_open(name_.c_str(), O_RDWR, 0600)) < 0 ||
-             (fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) < bytes_)) {
-        if (fd >= 0) close(fd);
-        fd = -1;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
-          throw Error("shared-memory communicator: rank 0 never created " + name_);
-        std::this_thread::sleep_for(std::chrono::milliseconds(5));
-      }
-    }
-    void* p = mmap(nullptr, bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) throw Error("shared-memory communicator: mmap failed");
-    hdr_ = static_cast<ShmHeader*>(p);
-    data_ = static_cast<char*>(p) + sizeof(ShmHeader);
-    if (rank == 0) {
-      // (a fresh segment is zero filled; `ready` tells the others that it is THIS run's segment)
+      map_segment(fd);
+      // (a fresh segment is zero filled)
       hdr_->ready.store(0x43543258u, std::memory_order_release);
+      // echo every peer's token: only then is it known to sit on THIS run's segment
+      int acked = 0;
+      std::vector<bool> done(world, false);
+      while (acked < world - 1) {
+        for (int r = 1; r < world; ++r) {
+          if (done[r]) continue;
+          const uint64_t token = hdr_->hello[r].load(std::memory_order_acquire);
+          if (token != 0) {
+            hdr_->ack[r].store(token, std::memory_order_release);
+            done[r] = true;
+            ++acked;
+          }
+        }
+        if (acked < world - 1) {
+          if (expired()) throw Error("shared-memory communicator: a rank never opened " + name_);
+          std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+      }
     } else {
-      wait_for([&] { return hdr_->ready.load(std::memory_order_acquire) == 0x43543258u; },
-               "rank 0 never initialised the segment");
+      const uint64_t token = ((static_cast<uint64_t>(getpid()) << 32) ^
+                              static_cast<uint64_t>(std::chrono::steady_clock::now().time_since_epoch().count())) | 1u;
+      for (;;) {
+        if (expired()) throw Error("shared-memory communicator: rank 0 never created " + name_);
+        struct stat st;
+        const int fd = shm_open(name_.c_str(), O_RDWR, 0600);
+        if (fd < 0 || fstat(fd, &st) != 0 || static_cast<size_t>(st.st_size) < bytes_) {
+          if (fd >= 0) close(fd);
+          std::this_thread::sleep_for(std::chrono::milliseconds(5));
+          continue;
+        }
+        map_segment(fd);
+        // this run's segment answers within moments of rank 0 reaching its handshake loop; a stale
+        // one (or one rank 0 is about to replace) never does: let go of it and open the name again
+        const auto t1 = std::chrono::steady_clock::now();
+        bool ok = false, said_hello = false;
+        while (std::chrono::steady_clock::now() - t1 < std::chrono::milliseconds(500)) {
+          if (!said_hello && hdr_->ready.load(std::memory_order_acquire) == 0x43543258u) {
+            hdr_->hello[rank].store(token, std::memory_order_release);
+            said_hello = true;
+          }
+          if (said_hello && hdr_->ack[rank].load(std::memory_order_acquire) == token) {
+            ok = true;
+            break;
+          }
+          std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (ok) break;
+        munmap(hdr_, bytes_);
+        hdr_ = nullptr;
+        data_ = nullptr;
+      }
     }
     const char* e = std::getenv("CT2X_TP_ONESHOT");
     bool want_boxes = !(e && e[0] == '0');

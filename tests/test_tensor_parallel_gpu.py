@@ -230,6 +230,13 @@ def test_two_processes_one_gpu_int8_bit_identical(gpu, key, beam, use_graph):
     here = os.path.dirname(os.path.abspath(__file__))
     seg = "ct2x_tp_test_%d_%s_%d" % (os.getpid(), key, beam)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if key == "small" and beam == 1:
+        # a STALE segment of the same name, as a crashed run leaves it: right size, `ready` word set.
+        # A rank that opens it before rank 0 has replaced it must notice (its handshake token never
+        # comes back) and open the name again instead of spinning on the dead segment's barrier.
+        with open("/dev/shm/" + seg, "wb") as f:
+            f.write(np.array([0x43543258], np.uint32).tobytes())
+            f.truncate(4096 + 2 * (8 << 20))
     with tempfile.TemporaryDirectory() as tmp:
         outs = [os.path.join(tmp, "rank%d.json" % r) for r in range(2)]
         procs = [subprocess.Popen([sys.executable, os.path.join(here, "_tp_shm_rank.py"), path, str(r),
