@@ -50,7 +50,8 @@ void validate_decoding_options(const DecodingOptions& o) {
     throw std::invalid_argument("Biased decoding runs a beam search: random sampling is not available with it");
   // NOT a rule of the reference (its beam search records logits too: src/decoding.cc:529, 633-666,
   // and so does decode_alternatives, :1198, :1262): a gap of this backend, rejected loudly and
-  // listed in README.md "Not supported"
+  // listed in README.md "Not supported" (what the reference's beam search records is one vector
+  // per finished hypothesis - row i * k of the finishing step, :633-636 - not per-step logits)
   if (o.return_logits_vocab && (o.beam_size != 1 || o.prefix_bias_beta > 0 || o.return_alternatives))
     throw std::invalid_argument("return_logits_vocab is built for greedy search and random sampling "
                                 "(beam_size 1) in this backend");
