@@ -11,23 +11,30 @@
 // and the per-(row, head) kernel reads it once per hypothesis row. Here ONE workgroup owns a
 // (batch entry, head): the `beam` hypothesis rows of the entry share every key and value it reads
 // (5x fewer L2 reads), and the bytes are halved.
-//   scores   thread = key: the 128-byte key row is eight 16-byte loads (one cache line), dot
-//            products against all hypothesis queries (LDS broadcasts), scores parked in LDS;
+//   scores   (round 5) S^T = K Q^T on the 16-bit matrix cores per tile of 16 keys: the key rows as
+//            they lie in memory are the A operand, Q^T (hypothesis rows as columns) split into
+//            16-bit terms of 22 / 24 bits is the B operand; scores parked in LDS. (Rounds 3 - 4:
+//            thread = key, dot products on the vector pipe against LDS broadcasts of the queries -
+//            80 ds_read_b128 per key, 25k of the launch's 72k shader clocks.)
 //   softmax  maxima / sums of all hypotheses in one LDS exchange each, exp(x - max) as in
-//            src/cpu/kernels.cc:452-455, normalisation folded into the output;
-//   context  a wave takes tiles of 8 keys, eight tiles in flight: 8 lanes per value row (16 bytes =
-//            8 channels each), probabilities from LDS, partial sums over the lane's keys in
-//            registers, then a 3-step butterfly over the 8 key lanes and an 8-wave sum through LDS.
-
+//            src/cpu/kernels.cc:452-455, normalisation folded into the output; the statistics wait
+//            in LDS while the context phase has the registers;
+//   context  a wave takes tiles of 8 keys, eight tiles in flight - the first batch requested
+//            before the softmax -: 8 ADJACENT lanes per value row (16 bytes = 8 channels each),
+//            probabilities from LDS, partial sums over the lane's keys in registers, three DPP adds
+//            over the 8 key lanes and an 8-wave sum through LDS.
 //
 // Round 5 - memory split over workgroups: 8 windows x 20 heads are 160 workgroups on 256 CUs, each
-// walking 1500 positions through three dependent memory round trips per phase (39 us per layer,
-// 1.6 TB/s: the largest kernel of the Whisper decode step). With a scratch buffer the memory of a
-// (batch entry, head) is cut into `splits` chunks of whole 8-key tiles, one workgroup each; a
-// chunk publishes (max, sum, unnormalised context) per hypothesis row with write-through stores,
-// takes a ticket, and the LAST arrival of the (entry, head) merges the chunks
+// walking 1500 positions (39 us per layer, 1.6 TB/s: the largest kernel of the Whisper decode step).
+// With a scratch buffer the memory of a (batch entry, head) is cut into `splits` chunks of whole
+// 8-key tiles, one workgroup each - as many chunks as keep every workgroup RESIDENT (two per CU at
+// <= 128 VGPRs: register arrays sized by a beam bucket, `amdgpu_waves_per_eu`; at 160 VGPRs and one
+// workgroup per CU five chunks ran in four rounds and took 68 us). A chunk publishes (max, sum,
+// unnormalised context) per hypothesis row with write-through stores, takes a ticket, and the LAST
+// arrival of the (entry, head) merges the chunks
 //   out = sum_c exp(m_c - M) o_c / sum_c exp(m_c - M) l_c
-// and puts the ticket back to zero (grid_sync.h: no workgroup waits, so no residency requirement).
+// and puts the ticket back to zero (grid_sync.h: no workgroup waits, so no residency REQUIREMENT).
+// 39.4 -> 24.9 us per layer (profiles/r05_xattn_probe.txt, r05_kernel_stats_bench_whisper_b.csv).
 
 #include <hip/hip_runtime.h>
 
