@@ -70,6 +70,12 @@ xattn_probe)      # profiles/r05_xattn_probe.txt: the 16-bit cross attention at 
   CT2X_LIBRARY=$GRAFT_REPO_ROOT/ctranslate2_amd/libct2_mi355_tuning.so timeout 300 python tools/xattn_probe.py 2>&1 | tee $O/xattn_probe.txt ;;
 rows_probe)       # profiles/r05_gemm_rows_probe.txt: the decode-row 16-bit GEMM at the Whisper shapes (TUNING library)
   CT2X_LIBRARY=$GRAFT_REPO_ROOT/ctranslate2_amd/libct2_mi355_tuning.so timeout 300 python tools/gemm_rows_probe.py 2>&1 | tee $O/gemm_rows_probe.txt ;;
+final_legs)       # profiles/r05_final_kernel_stats_bench_{nllb,whisper}.csv: rocprofv3 kernel stats of the 16-bit legs' own processes
+  for leg in nllb whisper; do
+    ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$leg -- python $GRAFT_REPO_ROOT/tools/bench_$leg.py --steps 1 --warmup 1 > /tmp/prof_$leg.log 2>&1 )
+    f=$(ls -S $(find /tmp/prof_$leg -name '*kernel_stats.csv') | head -1)
+    cp "$f" $O/final_kernel_stats_bench_$leg.csv; echo "== $leg"; tail -1 /tmp/prof_$leg.log | cut -c1-260; head -7 $O/final_kernel_stats_bench_$leg.csv | cut -c1-150
+  done ;;
 all)              # the whole -m gpu suite, smoke and the default bench line
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -3 $O/pytest_all.log
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
