@@ -76,6 +76,8 @@ final_legs)       # profiles/r05_final_kernel_stats_bench_{nllb,whisper}.csv: ro
     f=$(ls -S $(find /tmp/prof_$leg -name '*kernel_stats.csv') | head -1)
     cp "$f" $O/final_kernel_stats_bench_$leg.csv; echo "== $leg"; tail -1 /tmp/prof_$leg.log | cut -c1-260; head -7 $O/final_kernel_stats_bench_$leg.csv | cut -c1-150
   done ;;
+pmc_whisper)      # profiles/r05_pmc_whisper.json
+  timeout 700 python tools/pmc_whisper.py $O/pmc_whisper > $O/pmc_whisper.json; cat $O/pmc_whisper.json | head -40; find $O/pmc_whisper -name "*.csv" -size +1M -delete; find $O/pmc_whisper -name "*.db" -delete ;;
 all)              # the whole -m gpu suite, smoke and the default bench line
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -3 $O/pytest_all.log
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
