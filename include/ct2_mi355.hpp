@@ -152,7 +152,8 @@ struct GenerationOptions {
   size_t num_hypotheses = 1;
   bool return_scores = false;
   bool return_logits_vocab = false;      // beam_size 1 (greedy search, random sampling)
-  bool return_alternatives = false;      // not built: must stay false
+  bool return_alternatives = false;      // round 5 (greedy / beam search; no callback, logits)
+  float min_alternative_expansion_prob = 0;
   std::vector<std::string> static_prompt;
   bool cache_static_prompt = true;       // accepted; the prompt is simply forwarded
   bool include_prompt_in_result = true;
@@ -548,7 +549,6 @@ public:
   std::vector<GenerationResult>
   generate_batch(const std::vector<std::vector<std::string>>& start_tokens,
                  const GenerationOptions& options = GenerationOptions()) {
-    detail::reject(options.return_alternatives, "return_alternatives");
     const size_t batch = start_tokens.size();
     if (batch == 0) return {};
     // static_prompt + start_tokens is what the model consumes (language_model.cc:184-206)
@@ -575,6 +575,9 @@ public:
     o.max_input_length = 0;
     o.seed = options.seed;
     o.use_graph = options.use_graph;
+    // decode_alternatives behind run_generation (language_model.cc:241-245, decoding.cc:1122-1290)
+    o.return_alternatives = options.return_alternatives;
+    o.min_alternative_expansion_prob = options.min_alternative_expansion_prob;
     const detail::Suppressed sup =
         detail::suppressed_ids(h_, 1, options.suppress_sequences, options.disable_unk);
     detail::set_processors(o, options.repetition_penalty, options.no_repeat_ngram_size, sup);
@@ -626,13 +629,20 @@ public:
     for (size_t b = 0; b < batch; ++b)
       for (size_t k = 0; k < hyp; ++k) {
         const int32_t n = out_len[b * hyp + k];
-        if (k > 0 && n == 0) continue;  // fewer finished hypotheses than requested
+        if (options.return_alternatives ? n < 0 : (k > 0 && n == 0))
+          continue;  // fewer alternatives expanded / fewer finished hypotheses than requested
         std::vector<std::string> tokens;
         std::vector<size_t> ids;
         if (options.include_prompt_in_result) {
-          tokens = start_tokens[b];
-          for (int32_t t = static_cast<int32_t>(options.static_prompt.size()); t < in.lengths[b]; ++t)
+          // (alternatives: the sequences of a longer prompt of a ragged batch already begin with
+          // its tokens beyond the shortest prompt - as the reference returns them)
+          int32_t upto = in.lengths[b];
+          if (options.return_alternatives)
+            for (size_t i = 0; i < batch; ++i) upto = std::min(upto, in.lengths[i]);
+          for (int32_t t = static_cast<int32_t>(options.static_prompt.size()); t < upto; ++t) {
             ids.push_back(static_cast<size_t>(in.ids[b * in.stride + t]));
+            tokens.push_back(start_tokens[b][static_cast<size_t>(t) - options.static_prompt.size()]);
+          }
         }
         for (int32_t t = 0; t < n; ++t) {
           const int32_t id = out[(b * hyp + k) * len + t];

@@ -49,6 +49,21 @@ int main(int argc, char** argv) {
       const auto results = generator.generate_batch(batch, options);
       for (const auto& token : results[0].sequences[0]) std::cout << token << ' ';
       std::cout << std::endl;
+    } else if (mode == "alternatives") {
+      // api_example alternatives <model_dir> <max_length> <num_hypotheses> <prompt tokens...>:
+      // GenerationOptions::return_alternatives with the prompt in the result (the reference's default)
+      ct2_mi355::Generator generator(model, ct2_mi355::Device::CUDA);
+      ct2_mi355::GenerationOptions options;
+      options.max_length = static_cast<size_t>(std::atoi(argv[3]));
+      options.num_hypotheses = static_cast<size_t>(std::atoi(argv[4]));
+      options.return_alternatives = true;
+      options.return_scores = true;
+      const std::vector<std::vector<std::string>> batch = {std::vector<std::string>(argv + 5, argv + argc)};
+      const auto results = generator.generate_batch(batch, options);
+      for (size_t k = 0; k < results[0].sequences.size(); ++k) {
+        for (const auto& token : results[0].sequences[k]) std::cout << token << ' ';
+        std::cout << "| " << results[0].scores[k] << std::endl;
+      }
     } else if (mode == "score") {
       // api_example score <model_dir> <n_source> <source tokens...> <target tokens...>
       ct2_mi355::Translator translator(model);

@@ -294,6 +294,29 @@ def test_cpp_api_generator(gpu):
     assert out.split() == [t.id_to_token(i) for i in ids[0]]
 
 
+def test_cpp_api_generator_alternatives(gpu):
+    """Generator::generate_batch with GenerationOptions::return_alternatives through the C++ host API,
+    the prompt in the result (the reference's default): every sequence = the prompt, an alternative
+    first token, its continuation - what the id-level entry point returns behind the prompt."""
+    import _cppapi
+    # (the example opens the model with ComputeType::DEFAULT: compare at that compute type)
+    t = get_lm("lm_tiny", "default")
+    prompt = [5, 9, 13, 7]
+    seqs, scores = t.generate_ids([prompt], max_length=10, num_hypotheses=3, return_scores=True,
+                                  return_alternatives=True)
+    rc, out, err = _cppapi.run("alternatives", "/tmp/ct2x_test_lm_tiny", 10, 3,
+                               *[t.id_to_token(i) for i in prompt])
+    assert rc == 0, err
+    lines = [l for l in out.splitlines() if "|" in l]
+    assert len(lines) == len(seqs[0]) == 3
+    for k, line in enumerate(lines):
+        toks, score = line.split("|")
+        assert toks.split() == [t.id_to_token(i) for i in prompt + seqs[0][k]]
+        assert abs(float(score) - scores[0][k]) < 1e-4
+        assert len(seqs[0][k]) <= 1 + 10 - len(prompt)   # max_length counts the prompt in this mode
+    assert len(seqs[0][0]) == 1 + 10 - len(prompt)
+
+
 @pytest.mark.parametrize("key", ["lm_tiny", "lm_small"])
 @pytest.mark.parametrize("ct", ["float32", "int8"])
 def test_generator_beam_search_ragged_prompts(gpu, key, ct):
