@@ -82,5 +82,5 @@ all)              # the whole -m gpu suite, smoke and the default bench line
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -3 $O/pytest_all.log
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json ;;
-*) echo "sections: probes cluster_first cluster_ab tests rocprof_tb all"; exit 2 ;;
+*) echo "sections: probes cluster_first cluster_iter cluster_ab tests rocprof_tb beam_iter many_rows evidence pmc level15 suite final_prof attn_h xattn_probe rows_probe final_legs pmc_whisper all"; exit 2 ;;
 esac
