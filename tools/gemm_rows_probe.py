@@ -4,6 +4,9 @@ the launch) at the Whisper-large-v3 decode shapes (40 rows; bfloat16 weights): w
 through ct2x_gemm_f16w (which also allocates and clears its workspace: an upper bound) and the phase
 timeline of workgroup (0, 0) / of column tile 0's last arrival in shader clocks - a `make TUNING=1`
 library (CT2X_LIBRARY)."""
+# The TUNING library is built next to the shipped one (it never replaces it):
+#   make -C ctranslate2_amd/csrc all TUNING=1 OBJDIR=build_tuning OUT=../libct2_mi355_tuning.so
+#   CT2X_LIBRARY=$PWD/ctranslate2_amd/libct2_mi355_tuning.so python tools/<this file>
 import ctypes as C
 import os
 import sys

@@ -4,6 +4,9 @@ Whisper-large-v3 decode shape - 8 windows x beam 5, 20 heads of 64, 1500 memory 
 bfloat16 memory - with the memory of a (window, head) cut into 1 .. 8 chunks (CT2X_XATTN_SPLITS, read
 by a `make TUNING=1` library only: CT2X_LIBRARY points at it), and the phase timeline of workgroup 0
 (shader-clock stamps, TUNING builds). One line per variant: us per launch over 200 launches."""
+# The TUNING library is built next to the shipped one (it never replaces it):
+#   make -C ctranslate2_amd/csrc all TUNING=1 OBJDIR=build_tuning OUT=../libct2_mi355_tuning.so
+#   CT2X_LIBRARY=$PWD/ctranslate2_amd/libct2_mi355_tuning.so python tools/<this file>
 import ctypes as C
 import os
 import sys
