@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnFullParams p) {
 // The engine keeps activations in fp32 under float16 / bfloat16 compute (16-bit weights, fp32
 // accumulate: gemm_h.hip), so Q, K, V and the probabilities arrive as fp32. Each enters the 16-bit
 // matrix pipe as TWO 16-bit values, x = hi + lo (hi = RN16(x), lo = RN16(x - hi): 22 significant
-// bits as float16, 16 as bfloat16), and a product a.b is hi.hi + hi.lo + lo.hi accumulated in fp32:
+// bits as float16 - an absolute 2^-25 below |x| = 1/8, where lo is a float16 subnormal -, 16 as
+// bfloat16; tests/test_split16_cpu.py), and a product a.b is hi.hi + hi.lo + lo.hi accumulated in fp32:
 // three MFMAs of 17 cycles for a 16x16x32 block where the fp32 pipe above spends eight of 32 - the
 // tile's matrix time drops 5x and the result stays a float32 evaluation up to the dropped lo.lo
 // term (2^-22 / 2^-16 relative per product), well inside what the 16-bit types themselves resolve.
