@@ -550,3 +550,38 @@ def test_device_activation_source_matches_the_oracle_on_the_host(tmp_path):
     H.host_exp_avx2(x.ctypes.data_as(C.c_void_p), C.c_int64(x.size), y.ctypes.data_as(C.c_void_p))
     want = np.array([orc.orc_exp_avx2(float(v)) for v in x[::37]], np.float32)
     assert np.array_equal(y[::37].view(np.uint32), want.view(np.uint32))
+
+
+def test_split_cross_attention_scratch_covers_a_shrinking_session():
+    """ct2x_cross_attention_split_scratch_bytes (host arithmetic, attention_cross_h.hip): a decoding
+    session is sized ONCE for its first batch and shrinks as hypotheses finish - and fewer
+    (entry, head) units are cut into MORE chunks. The size must hold the chunk records of every
+    smaller batch: records = units x chunks, chunks = as many as keep every workgroup resident
+    (512 up to beam 5, 256 beyond), at most 8, chunks of at least 128 keys."""
+    L = _lib.lib()
+    L.ct2x_cross_attention_split_scratch_bytes.restype = C.c_int64
+    i64 = C.c_int64
+
+    def chunks(batch, beam, heads, s_max):
+        resident = 512 if beam <= 5 else 256
+        return max(1, min(resident // max(1, batch * heads), s_max // 128, 8))
+
+    for beam in (1, 4, 5, 8):
+        for heads in (4, 8, 20):
+            for dh in (64, 128):
+                for s_max in (100, 256, 1500, 4000):
+                    for batch in (1, 3, 8, 17, 40, 200):
+                        nbytes = int(L.ct2x_cross_attention_split_scratch_bytes(i64(batch), i64(beam), i64(heads),
+                                                                                i64(dh), i64(s_max)))
+                        tickets = batch * heads * 4
+                        floats = (nbytes - tickets) // 4
+                        assert nbytes >= tickets and (nbytes - tickets) % 4 == 0
+                        if floats == 0:
+                            # no scratch: the launcher then never splits, whatever the batch becomes
+                            assert chunks(batch, beam, heads, s_max) == 1 or batch * heads >= (512 if beam <= 5 else 256) \
+                                or s_max // 128 <= 1
+                            continue
+                        rec = beam * (dh + 2)
+                        for smaller in range(1, batch + 1):
+                            need = smaller * heads * chunks(smaller, beam, heads, s_max) * rec
+                            assert need <= floats, (batch, smaller, beam, heads, dh, s_max, need, floats)
