@@ -435,7 +435,13 @@ def main():
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU fallback")
+        sys.stderr.write("bench.py needs an MI355X: no GPU is visible and there is no CPU fallback\n")
+        sys.stderr.flush()
+        if world > 1:
+            # (a launcher tears the other ranks down the moment one exits: leave them the time to say the
+            # same thing, so that the log shows every rank got this far)
+            time.sleep(1.0 + 0.5 * rank)
+        raise SystemExit(1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

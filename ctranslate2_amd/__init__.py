@@ -616,6 +616,15 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         cache release)."""
         _lib.check(self._L.ct2x_release_session(C.c_void_p(self._h)))
 
+    def cluster_fallbacks(self) -> int:
+        """Groups decoded again on the launch-per-op step after a cluster of the decoder-stack
+        launch waited in vain (ct2x_cluster_fallbacks)."""
+        self._L.ct2x_cluster_fallbacks.restype = C.c_int64
+        return int(self._L.ct2x_cluster_fallbacks(C.c_void_p(self._h)))
+
+    def debug_inject_cluster_timeout(self):
+        _lib.check(self._L.ct2x_debug_inject_cluster_timeout(C.c_void_p(self._h)))
+
     def profile_begin(self):
         _lib.check(self._L.ct2x_profile_begin(C.c_void_p(self._h)))
 

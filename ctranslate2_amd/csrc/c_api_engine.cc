@@ -107,6 +107,7 @@ struct Translator {
   std::vector<int64_t> session_key;
   int64_t session_bytes = 0;  // pool bytes the kept session took when it was built
   int64_t session_hits = 0;
+  int64_t cluster_fallbacks = 0;  // groups re-run on the launch-per-op step after a ClusterTimeout
   WorkerPool pool;  // declared last: joined before the engine is destroyed
 };
 
@@ -1114,77 +1115,90 @@ static int translate_batch_impl(void* translator, const int32_t* src_ids,
             dopt.max_length, dopt.min_length, dopt.return_scores ? 1 : 0, end_id,
             dopt.use_graph ? 1 : 0, dopt.sync_every, dopt.start_step,
             static_cast<int64_t>(reinterpret_cast<uintptr_t>(thread_stream()))};
-        std::unique_ptr<DecodeState> st;
-        int64_t st_bytes = t->session_bytes;
-        if (plain && t->session && t->session_key == key) {
-          st = std::move(t->session);
-          t->engine->reencode(*st, ids.data(), lens.data());
-          ++t->session_hits;
-        } else {
-          t->session.reset();
-          const int64_t before = allocated_bytes();
-          st = t->engine->start(ids.data(), lens.data(), R, s_max, dopt.beam_size,
-                                dopt.max_length, 0, /*beam_search_state=*/biased);
-          st_bytes = allocated_bytes() - before;
-          // (sub-batches decoding concurrently on several streams keep the launch-per-op step: the
-          // decoder-stack launch runs one session at a time per device, Engine::cluster_gate)
-          if (streams > 1) st->cl_xch = nullptr;
-        }
-        t->engine->synchronize();
-        const double te1 = now_ms();
-        std::vector<int32_t> start_ids(B, t->start_id);
-        // target_prefix (make_target_ids with is_prefix, sequence_to_sequence.cc:168-186): forced
-        // after the decoder start token, part of the returned hypothesis (return_prefix).
-        std::vector<std::vector<int32_t>> prefix;
-        bool any_prefix = false;
-        if (prefix_ids != nullptr) {
-          prefix.resize(B);
-          for (int64_t i = 0; i < B; ++i) {
-            const int32_t b = order[begin + i];
-            const int32_t* p = prefix_ids + static_cast<int64_t>(b) * prefix_stride;
-            prefix[i].assign(p, p + prefix_lengths[b]);
-            for (int32_t id : prefix[i])
-              CT2X_CHECK(id >= 0 && id < static_cast<int32_t>(t->engine->vocab_size()),
-                         "Invalid target prefix token ID " + std::to_string(id));
-            any_prefix = any_prefix || !prefix[i].empty();
+        // A cluster of the decoder-stack launch that waited in vain (another process's persistent
+        // launch on this GPU, a debugger, ...) voids the group's results: the handle then decodes with
+        // the launch-per-op step from here on and the group runs again (Engine::check_cluster).
+        for (int attempt = 0;; ++attempt) {
+          try {
+            std::unique_ptr<DecodeState> st;
+            int64_t st_bytes = t->session_bytes;
+            if (plain && t->session && t->session_key == key) {
+              st = std::move(t->session);
+              t->engine->reencode(*st, ids.data(), lens.data());
+              ++t->session_hits;
+            } else {
+              t->session.reset();
+              const int64_t before = allocated_bytes();
+              st = t->engine->start(ids.data(), lens.data(), R, s_max, dopt.beam_size,
+                                    dopt.max_length, 0, /*beam_search_state=*/biased);
+              st_bytes = allocated_bytes() - before;
+              // (sub-batches decoding concurrently on several streams keep the launch-per-op step: the
+              // decoder-stack launch runs one session at a time per device, Engine::cluster_gate)
+              if (streams > 1) st->cl_xch = nullptr;
+            }
+            t->engine->synchronize();
+            const double te1 = now_ms();
+            std::vector<int32_t> start_ids(B, t->start_id);
+            // target_prefix (make_target_ids with is_prefix, sequence_to_sequence.cc:168-186): forced
+            // after the decoder start token, part of the returned hypothesis (return_prefix).
+            std::vector<std::vector<int32_t>> prefix;
+            bool any_prefix = false;
+            if (prefix_ids != nullptr) {
+              prefix.resize(B);
+              for (int64_t i = 0; i < B; ++i) {
+                const int32_t b = order[begin + i];
+                const int32_t* p = prefix_ids + static_cast<int64_t>(b) * prefix_stride;
+                prefix[i].assign(p, p + prefix_lengths[b]);
+                for (int32_t id : prefix[i])
+                  CT2X_CHECK(id >= 0 && id < static_cast<int32_t>(t->engine->vocab_size()),
+                             "Invalid target prefix token ID " + std::to_string(id));
+                any_prefix = any_prefix || !prefix[i].empty();
+              }
+            }
+            const std::vector<std::vector<int32_t>>* pf = any_prefix ? &prefix : nullptr;
+            DecodeStats ds;
+            DecodingOptions gopt = dopt;
+            if (dopt.callback) {  // the callback sees the caller's batch indices
+              gopt.callback = [&dopt, &order, begin](const DecodingStepResult& r) {
+                DecodingStepResult m = r;
+                m.batch_id = order[begin + static_cast<size_t>(r.batch_id)];
+                return dopt.callback(m);
+              };
+            }
+            // make_search_strategy (src/decoding.cc:1075-1087): biased decoding is a beam search
+            std::vector<DecodingResult> results =
+                (dopt.beam_size == 1 && !(dopt.prefix_bias_beta > 0 && pf))
+                    ? greedy_search_samples(*t->engine, *st, start_ids, end_id, gopt, &ds, pf)
+                    : beam_search(*t->engine, *st, start_ids, end_id, gopt, &ds, pf);
+            t->engine->synchronize();
+            const double te2 = now_ms();
+            for (int64_t i = 0; i < B; ++i) all_results[order[begin + i]] = std::move(results[i]);
+            // A kept session holds its buffers until the next call: only sessions below
+            // CT2X_SESSION_CACHE_MB (default 2048) stay - a 256-row NLLB-3.3B session is tens of GB that
+            // the reference would have returned to its allocator.
+            static const int64_t keep_limit = [] {
+              const char* e = std::getenv("CT2X_SESSION_CACHE_MB");
+              return (e ? std::atoll(e) : 2048LL) << 20;
+            }();
+            if (plain && ds.compactions == 0 && st->rows == R * dopt.beam_size && !st->graph_failed &&
+                st_bytes <= keep_limit) {
+              t->session = std::move(st);  // (an exception on the way here leaves no session behind)
+              t->session_key = key;
+              t->session_bytes = st_bytes;
+            }
+            std::lock_guard<std::mutex> lock(stats_mutex);
+            encode_ms += te1 - te0;
+            decode_ms += te2 - te1;
+            t->last.decode_steps = std::max<int64_t>(t->last.decode_steps, ds.steps);
+            t->last_compactions += ds.compactions;
+            break;
+          } catch (const ClusterTimeout&) {
+            if (attempt > 0) throw;
+            t->engine->disable_cluster();
+            t->session.reset();
+            ++t->cluster_fallbacks;
           }
         }
-        const std::vector<std::vector<int32_t>>* pf = any_prefix ? &prefix : nullptr;
-        DecodeStats ds;
-        DecodingOptions gopt = dopt;
-        if (dopt.callback) {  // the callback sees the caller's batch indices
-          gopt.callback = [&dopt, &order, begin](const DecodingStepResult& r) {
-            DecodingStepResult m = r;
-            m.batch_id = order[begin + static_cast<size_t>(r.batch_id)];
-            return dopt.callback(m);
-          };
-        }
-        // make_search_strategy (src/decoding.cc:1075-1087): biased decoding is a beam search
-        std::vector<DecodingResult> results =
-            (dopt.beam_size == 1 && !(dopt.prefix_bias_beta > 0 && pf))
-                ? greedy_search_samples(*t->engine, *st, start_ids, end_id, gopt, &ds, pf)
-                : beam_search(*t->engine, *st, start_ids, end_id, gopt, &ds, pf);
-        t->engine->synchronize();
-        const double te2 = now_ms();
-        for (int64_t i = 0; i < B; ++i) all_results[order[begin + i]] = std::move(results[i]);
-        // A kept session holds its buffers until the next call: only sessions below
-        // CT2X_SESSION_CACHE_MB (default 2048) stay - a 256-row NLLB-3.3B session is tens of GB that
-        // the reference would have returned to its allocator.
-        static const int64_t keep_limit = [] {
-          const char* e = std::getenv("CT2X_SESSION_CACHE_MB");
-          return (e ? std::atoll(e) : 2048LL) << 20;
-        }();
-        if (plain && ds.compactions == 0 && st->rows == R * dopt.beam_size && !st->graph_failed &&
-            st_bytes <= keep_limit) {
-          t->session = std::move(st);  // (an exception on the way here leaves no session behind)
-          t->session_key = key;
-          t->session_bytes = st_bytes;
-        }
-        std::lock_guard<std::mutex> lock(stats_mutex);
-        encode_ms += te1 - te0;
-        decode_ms += te2 - te1;
-        t->last.decode_steps = std::max<int64_t>(t->last.decode_steps, ds.steps);
-        t->last_compactions += ds.compactions;
       }
     } catch (...) {
       std::lock_guard<std::mutex> lock(stats_mutex);
@@ -1836,6 +1850,19 @@ int ct2x_last_stats(void* translator, struct ct2x_exec_stats* stats) {
 int64_t ct2x_last_compactions(void* translator) {
   auto* t = static_cast<Translator*>(translator);
   return t != nullptr ? t->last_compactions : -1;
+}
+
+int64_t ct2x_cluster_fallbacks(void* translator) {
+  auto* t = static_cast<Translator*>(translator);
+  return t != nullptr ? t->cluster_fallbacks : -1;
+}
+
+int ct2x_debug_inject_cluster_timeout(void* translator) {
+  API_TRY
+  auto* t = static_cast<Translator*>(translator);
+  CT2X_CHECK(t != nullptr && t->engine, "ct2x_debug_inject_cluster_timeout: null translator");
+  t->engine->debug_inject_cluster_timeout();
+  API_CATCH
 }
 
 int64_t ct2x_session_hits(void* translator) {

@@ -798,6 +798,22 @@ int ct2x_gumbel_noise(const float* d_x, float* d_y, int64_t size, uint32_t seed,
   API_CATCH
 }
 
+int ct2x_debug_fast_div_check(uint64_t pairs, uint32_t seed, uint64_t* mismatches) {
+  API_TRY
+  CT2X_CHECK(mismatches != nullptr, "ct2x_debug_fast_div_check: mismatches is null");
+  unsigned long long* d = static_cast<unsigned long long*>(device_malloc(sizeof(unsigned long long)));
+  hipStream_t stream = resolve_stream(nullptr);
+  CT2X_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(unsigned long long), stream));
+  launch_fast_div_check(pairs, seed, d, stream);
+  check_last_launch("fast_div_check");
+  unsigned long long h = 0;
+  CT2X_HIP_CHECK(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, stream));
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+  device_free(d);
+  *mismatches = h;
+  API_CATCH
+}
+
 int ct2x_random_sample(const float* d_logits, int64_t rows, int64_t vocab, int32_t sampling_topk,
                        float sampling_topp, float temperature, uint32_t seed,
                        const float* d_uniforms, const int32_t* d_step, int32_t* d_ids,

@@ -994,11 +994,15 @@ void launch_decoder_cluster(const ClusterStackArgs& a, hipStream_t stream) {
     CT2X_CHECK(clusters <= 32, "decoder_cluster: more clusters than the device holds");
     const size_t lds = sizeof(SharedBeam) + static_cast<size_t>(kBeamRows) * a.t_pad * sizeof(float);
     CT2X_CHECK(lds <= 160 * 1024, "decoder_cluster: the score rows do not fit the LDS");
-    static std::atomic<bool> opted{false};
-    if (!opted.load(std::memory_order_acquire)) {
+    // (the attribute belongs to the CURRENT device's function object: one flag per device, so that
+    // every Engine of a multi-GPU process gets it, not only the first to launch)
+    static std::atomic<bool> opted[64];
+    int dev = 0;
+    CT2X_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !opted[dev].load(std::memory_order_acquire)) {
       CT2X_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_cluster_beam_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      opted.store(true, std::memory_order_release);
+      if (dev >= 0 && dev < 64) opted[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(decoder_cluster_beam_kernel, dim3(static_cast<unsigned>(clusters * kMembers)),
                        dim3(kThreads), lds, stream, a);

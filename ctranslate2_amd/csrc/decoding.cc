@@ -128,9 +128,9 @@ std::vector<DecodingResult> greedy_search(Engine& engine, DecodeState& st,
                                           const std::vector<std::vector<int32_t>>* prefix_ids) {
   const int64_t batch = static_cast<int64_t>(start_ids.size());
   if (batch != st.rows) throw std::runtime_error("greedy_search: state/batch size mismatch");
-  // (one session at a time per device on the decoder-stack launch: Engine::cluster_gate)
-  std::unique_lock<std::mutex> cluster_lock;
-  if (st.cl_xch != nullptr) cluster_lock = std::unique_lock<std::mutex>(Engine::cluster_gate(engine.device_index()));
+  // (the decoder-stack launch only while this loop holds the device's gate; with a step callback -
+  // which a re-run after a ClusterTimeout would call twice - the launch-per-op step)
+  ClusterLease cluster_lease(engine, st, /*allowed=*/!opt.callback);
   std::vector<DecodingResult> results(batch);
   std::vector<float> score_sum(batch, 0.f);
   std::vector<char> alive(batch, 1);
@@ -389,8 +389,7 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   const int64_t rows = batch * beam;
   if (rows != st.rows || st.beam != beam)
     throw std::runtime_error("beam_search: state/batch size mismatch");
-  std::unique_lock<std::mutex> cluster_lock;
-  if (st.cl_xch != nullptr) cluster_lock = std::unique_lock<std::mutex>(Engine::cluster_gate(engine.device_index()));
+  ClusterLease cluster_lease(engine, st, /*allowed=*/!opt.callback);
   const size_t max_candidates = static_cast<size_t>(std::llround(float(beam) * opt.patience));
   const bool allow_early_exit = (opt.length_penalty == 0 && opt.coverage_penalty == 0);
 

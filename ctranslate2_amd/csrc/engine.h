@@ -23,6 +23,7 @@
 
 #include "kernels.h"
 #include "model.h"
+#include "runtime.h"
 #include "tp_comm.h"
 
 namespace ct2x {
@@ -330,16 +331,29 @@ public:
   void enable_logits_history(DecodeState& state);
   void read_logits(DecodeState& state, int64_t first, int64_t count, float* out);
   void synchronize();
-  // Throws if a cluster of the decoder-stack launch waited in vain for a member during this
-  // session (another persistent launch held the compute units): its results are void.
+  // Throws ClusterTimeout if a cluster of the decoder-stack launch waited in vain for a member
+  // during this session (something else held the compute units): its results are void. The
+  // translate entry points catch it, switch the handle to the launch-per-op step
+  // (disable_cluster) and run the call again.
   void check_cluster(DecodeState& state);
+  void disable_cluster() { cluster_ready_ = false; }
+  bool cluster_enabled() const { return cluster_ready_; }
+  // Tests: the next check_cluster of a session that ran the launch reports a starved cluster.
+  void debug_inject_cluster_timeout() { inject_cluster_timeout_ = true; }
   // The decoder-stack launch keeps its workgroups resident and waiting for each other: two such
   // launches of different sessions on one device could each hold part of the compute units and
-  // wait forever (the bounded polls turn that into an error, not a hang). Sessions that use the
-  // launch therefore decode one at a time per device and process: the decoding loops hold this
-  // gate from their first step to their last. (Other PROCESSES on the same GPU are not covered:
-  // CT2X_CLUSTER_STACK=0 there.)
-  static std::mutex& cluster_gate(int device_index);
+  // wait forever (the bounded polls turn that into an error, not a hang). A session therefore
+  // uses the launch only while it holds the device's gate (ClusterLease below): one holder per
+  // device across the threads of this process (an atomic flag) AND across processes (a
+  // non-blocking flock on a file named after the device's PCI bus id). The gate is only ever
+  // TRIED: a session that does not get it decodes with the launch-per-op step - same tokens -
+  // instead of waiting, so several Translator handles or replica processes on one GPU (a
+  // supported deployment: include/ctranslate2/replica_pool.h:339-359) overlap as before, and a
+  // callback that re-enters translate cannot deadlock.
+  static bool cluster_gate_try_acquire(int device_index);
+  static void cluster_gate_release(int device_index);
+  // Destroys the session's captured step graphs (the next step captures again).
+  void drop_graphs(DecodeState& state);
   static int64_t cluster_max_rows();
   // Teacher-forced scoring (score_sequences, src/scoring.cc): runs `steps` decoder steps feeding
   // h_inputs[s][row] and leaves log P(h_outputs[s][row]) of every step in the score history
@@ -442,6 +456,7 @@ private:
   // session's launch takes the layer table (weights + that session's caches) as kernel arguments.
   void pack_cluster_weights();
   bool cluster_ready_ = false;
+  bool inject_cluster_timeout_ = false;
   std::vector<ClusterLayerArgs> cluster_layers_;  // weights part; caches filled per session
   bool cluster_applicable(const DecodeState& state) const;
   // How a Dense is split over the tensor-parallel ranks (Model::load, src/models/model.cc:
@@ -663,6 +678,12 @@ struct DecodeState {
   // monotonic afterwards), the "a member waited in vain" flag
   float* cl_xch = nullptr;
   unsigned* cl_counters = nullptr;
+  size_t cl_xch_floats = 0, cl_counter_words = 0;
+  // Only a decoding loop that holds the device's gate (ClusterLease) runs the launch; every other
+  // caller of Engine::step (scoring, step_logits, the alternatives' pre-step) and a session that
+  // did not get the gate take the launch-per-op step.
+  bool cl_active = false;
+  int graph_cluster = -1;  // what the captured graphs contain: -1 nothing captured, 0 / 1 = cl_active then
   int* cl_error = nullptr;
   int cl_t_pad = 0;
   unsigned long long* cl_stamps = nullptr;  // CT2X_CLUSTER_STAMPS=1: timeline of workgroup 0, last step
@@ -676,6 +697,34 @@ struct DecodeState {
   int64_t reuses = 0;  // times Engine::reencode restarted this session
 
   ~DecodeState();
+};
+
+// Thrown by Engine::check_cluster (see there).
+class ClusterTimeout : public Error {
+public:
+  using Error::Error;
+};
+
+// Scope of a decoding loop's use of the decoder-stack launch: tries the device's gate and marks
+// the session accordingly; releases on destruction (Engine::cluster_gate_try_acquire).
+class ClusterLease {
+public:
+  ClusterLease(Engine& engine, DecodeState& st, bool allowed) : st_(st), device_(engine.device_index()) {
+    held_ = allowed && st.cl_xch != nullptr && Engine::cluster_gate_try_acquire(device_);
+    st.cl_active = held_;
+  }
+  ~ClusterLease() {
+    st_.cl_active = false;
+    if (held_) Engine::cluster_gate_release(device_);
+  }
+  ClusterLease(const ClusterLease&) = delete;
+  ClusterLease& operator=(const ClusterLease&) = delete;
+  bool held() const { return held_; }
+
+private:
+  DecodeState& st_;
+  int device_;
+  bool held_ = false;
 };
 
 }  // namespace ct2x

@@ -2,6 +2,11 @@
 // Whisper features), the feed-forward block, layer variants and the sequence-mode decoder pass.
 #include "engine.h"
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include "host_math.h"
@@ -327,6 +332,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
                                                              : decoder_cluster_xch_floats(rows);
       st->cl_xch = alloc<float>(*st, static_cast<int64_t>(xch_floats));
       st->cl_counters = alloc<unsigned>(*st, rows * 16);
+      st->cl_xch_floats = xch_floats;
+      st->cl_counter_words = static_cast<size_t>(rows) * 16;
       st->cl_error = alloc<int>(*st, 1);
       st->cl_t_pad = decoder_cluster_t_pad(t_max, s_max);
       // (tagged hand-over: a slot's tag must never match by accident - the lines start at tag 0,
@@ -355,9 +362,55 @@ int64_t Engine::cluster_max_rows() {
   return rows;
 }
 
-std::mutex& Engine::cluster_gate(int device_index) {
-  static std::mutex gates[64];
+namespace {
+struct ClusterGate {
+  std::atomic<bool> held{false};
+  int fd = -1;           // the lock file, opened on first use (-2: no directory took it)
+  std::mutex open_mutex;
+};
+ClusterGate& cluster_gate_of(int device_index) {
+  static ClusterGate gates[64];
   return gates[device_index & 63];
+}
+}  // namespace
+
+bool Engine::cluster_gate_try_acquire(int device_index) {
+  ClusterGate& g = cluster_gate_of(device_index);
+  bool expected = false;
+  if (!g.held.compare_exchange_strong(expected, true, std::memory_order_acquire)) return false;
+  // this process holds the gate; now the other processes on the same GPU
+  {
+    std::lock_guard<std::mutex> lock(g.open_mutex);
+    if (g.fd == -1) {
+      char bus[64] = "unknown";
+      if (hipDeviceGetPCIBusId(bus, sizeof(bus), device_index) != hipSuccess) (void)hipGetLastError();
+      for (char* c = bus; *c; ++c)
+        if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+      g.fd = -2;
+      for (const char* dir : {"/dev/shm", "/tmp"}) {
+        const std::string path = std::string(dir) + "/ct2x_cluster_gate_" + bus;
+        const int fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (fd >= 0) {
+          (void)::fchmod(fd, 0666);  // (another user's process must be able to open it too)
+          g.fd = fd;
+          break;
+        }
+      }
+    }
+  }
+  // (no lock file anywhere: only this process is guarded - a cluster that then starves is voided
+  // and the call re-run by the ClusterTimeout path)
+  if (g.fd >= 0 && ::flock(g.fd, LOCK_EX | LOCK_NB) != 0) {
+    g.held.store(false, std::memory_order_release);
+    return false;
+  }
+  return true;
+}
+
+void Engine::cluster_gate_release(int device_index) {
+  ClusterGate& g = cluster_gate_of(device_index);
+  if (g.fd >= 0) (void)::flock(g.fd, LOCK_UN);
+  g.held.store(false, std::memory_order_release);
 }
 
 void Engine::check_cluster(DecodeState& st) {
@@ -377,10 +430,15 @@ void Engine::check_cluster(DecodeState& st) {
   int flag = 0;
   CT2X_HIP_CHECK(hipMemcpyAsync(&flag, st.cl_error, sizeof(int), hipMemcpyDeviceToHost, st.stream));
   CT2X_HIP_CHECK(hipStreamSynchronize(st.stream));
+  if (inject_cluster_timeout_ && st.cl_active) {
+    inject_cluster_timeout_ = false;
+    flag = 1;
+  }
   if (flag != 0) {
     CT2X_HIP_CHECK(hipMemsetAsync(st.cl_error, 0, sizeof(int), st.stream));
-    throw Error("decoder stack launch: a workgroup cluster waited in vain for one of its members (is another "
-                "persistent launch holding the device?); CT2X_CLUSTER_STACK=0 selects the launch-per-op step");
+    throw ClusterTimeout("decoder stack launch: a workgroup cluster waited in vain for one of its members (is "
+                         "another persistent launch holding the device?); CT2X_CLUSTER_STACK=0 selects the "
+                         "launch-per-op step");
   }
 }
 

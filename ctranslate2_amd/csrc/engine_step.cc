@@ -565,6 +565,12 @@ void Engine::step(DecodeState& st, bool graph) {
     if (st.fuse_beam) st.cur ^= 1;  // the step reordered the caches into the other buffer set
     return;
   }
+  // (a kept session may hold graphs of the other step form: it got the cluster gate in one call
+  // and not in the next)
+  if (st.graph_cluster != static_cast<int>(st.cl_active)) {
+    if (st.graph_cluster >= 0) drop_graphs(st);
+    st.graph_cluster = static_cast<int>(st.cl_active);
+  }
   const int parity = st.cur;
   if (!st.graph_ready[parity]) {
     // One capture at a time per process: concurrent captures from several worker threads fail on
@@ -615,11 +621,26 @@ void Engine::step(DecodeState& st, bool graph) {
   if (st.fuse_beam) st.cur ^= 1;
 }
 
+void Engine::drop_graphs(DecodeState& st) {
+  for (int i = 0; i < 2; ++i) {
+    if (st.graph_exec[i]) (void)hipGraphExecDestroy(st.graph_exec[i]);
+    st.graph_exec[i] = nullptr;
+    st.graph_ready[i] = false;
+  }
+  if (st.group_exec) (void)hipGraphExecDestroy(st.group_exec);
+  st.group_exec = nullptr;
+  st.group_steps = 0;
+}
+
 void Engine::step_group(DecodeState& st, int count, bool graph) {
   static const int group_graph = [] {
     const char* e = std::getenv("CT2X_GROUP_GRAPH");
     return e ? std::atoi(e) : 1;
   }();
+  if (graph && st.graph_cluster >= 0 && st.graph_cluster != static_cast<int>(st.cl_active)) {
+    drop_graphs(st);
+    st.graph_cluster = -1;
+  }
   // (beam search alternates between two cache / table sets: an even count ends on the parity it
   // started from, and the graph serves the groups that start on the parity it was captured at)
   const bool eligible = graph && group_graph != 0 && count > 1 && (st.fuse_greedy != st.fuse_beam) &&
@@ -834,7 +855,7 @@ bool Engine::cluster_applicable(const DecodeState& st) const {
     const char* e = std::getenv("CT2X_CLUSTER_BEAM");
     return e == nullptr || e[0] != '0';
   }();
-  if (!cluster_ready_ || st.cl_xch == nullptr || taps_ || tp_ || st.att_hist != nullptr ||
+  if (!cluster_ready_ || st.cl_xch == nullptr || !st.cl_active || taps_ || tp_ || st.att_hist != nullptr ||
       st.mem_lengths == nullptr || st.rows < 1)
     return false;
   if (st.beam_mode)  // a cluster per batch entry, the self-attention through the ancestry table
@@ -905,6 +926,13 @@ void Engine::compact_rows(DecodeState& st, const std::vector<int32_t>& keep, int
     superseded.push_back(st.hist_scores);
     st.hist_ids = ids;
     st.hist_scores = scores;
+  }
+  // The several-rows form of the decoder-stack launch (> 32 rows) indexes the hand-over lines and
+  // the arrival counters per CLUSTER, the one-row form per ROW: a session that crosses 32 rows
+  // starts the other layout from clean lines (tag 0 = "never written", epoch 0).
+  if (st.cl_xch != nullptr && n_old > 32 && n_new <= 32) {
+    CT2X_HIP_CHECK(hipMemsetAsync(st.cl_xch, 0, sizeof(float) * st.cl_xch_floats, cur_stream()));
+    CT2X_HIP_CHECK(hipMemsetAsync(st.cl_counters, 0, sizeof(unsigned) * st.cl_counter_words, cur_stream()));
   }
   check_last_launch("compact_rows");
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));  // (`keep` may be a temporary)

@@ -68,9 +68,114 @@ __device__ __forceinline__ void glds4(const float* src, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((glb_void*)(src), (lds_void*)(lds_wave_base), 4, 0, 0);
 }
 
+// IEEE division t / d as the compiler expands it on gfx950 (v_div_scale x 2, v_rcp, the Newton /
+// residual FMA chain, v_div_fmas, v_div_fixup) MINUS the four instructions that are the identity
+// when nothing has to be rescaled: for 2^-20 <= |t| <= 2^6 and 1 <= d < 2^93 (callers check) both
+// v_div_scale return their operand unchanged with VCC = 0 (ISA: no denormal operand, reciprocal or
+// quotient, exponent difference inside +-96, numerator exponent > 23), v_div_fmas is then a plain
+// FMA and v_div_fixup passes a finite quotient of finite non-zero operands through. What is left is
+// the SAME FMA chain on the same values, so the result is the correctly rounded quotient the plain
+// `/` returns (checked on the device against `/`: ct2x_debug_fast_div_check, tests/test_ops_gpu.py).
+__device__ __forceinline__ float div_noscale(float t, float d) {
+  float y = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, y, 1.f);
+  y = __builtin_fmaf(e, y, y);
+  const float q0 = t * y;
+  const float r0 = __builtin_fmaf(-d, q0, t);
+  const float q1 = __builtin_fmaf(r0, y, q0);
+  const float r1 = __builtin_fmaf(-d, q1, t);
+  return __builtin_fmaf(r1, y, q1);
+}
+__device__ __forceinline__ bool div_noscale_numerator_ok(float t) {
+  const float a = __builtin_fabsf(t);
+  return a >= 9.5367431640625e-07f /* 2^-20 */ && a <= 64.f;
+}
+
+// The exponential family of activations on four values at once (x / (1 + exp(-s x)): Swish,
+// GELUSigmoid; 1 / (1 + exp(-x)): Sigmoid), the divisions on the reduced sequence when every
+// numerator of the WAVE is inside its range (wave-uniform branch; real activations are), the plain
+// division otherwise - bit-identical either way.
+template <int ACT>
+__device__ __forceinline__ v4f activation4(v4f v) {
+  v4f out;
+  if constexpr (ACT == 2 || ACT == 4 || ACT == 6) {
+    v4f d, t;
+    bool ok = true;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float arg = ACT == 4 ? -1.702f * v[e] : -v[e];
+      d[e] = 1.f + exact_exp_avx2(arg);
+      t[e] = ACT == 6 ? 1.f : v[e];
+      // d < 2^93 <=> the exponential's argument <= 64 (|v| <= 37 covers GELUSigmoid's 1.702 v)
+      ok = ok && (ACT == 6 ? __builtin_fabsf(v[e]) <= 64.f
+                           : (div_noscale_numerator_ok(v[e]) && (ACT != 4 || __builtin_fabsf(v[e]) <= 37.f)));
+    }
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = div_noscale(t[e], d[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = t[e] / d[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      out[e] = apply_activation(v[e], ACT);
+  }
+  return out;
+}
+
+// Epilogue of an interior tile (every 16-byte store in bounds and aligned, scales inside the range
+// of exact_div, no residual): y = act(c * (1 / a_scale) / w_scale + bias), CPU operand order.
+template <int ACT, bool HAS_BIAS, int NI, int NJ>
+__device__ __forceinline__ void big3_epilogue_interior(const v4i (&acc)[NI][NJ], const float* par, const float* ra,
+                                                       int cl0, float* __restrict__ y0, int64_t ldy) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const v4f ws = *reinterpret_cast<const v4f*>(par + 256 + cl0 + j * 16);
+    const v4f wi = *reinterpret_cast<const v4f*>(par + 768 + cl0 + j * 16);
+    v4f bs = v4f{0, 0, 0, 0};
+    if (HAS_BIAS) bs = *reinterpret_cast<const v4f*>(par + 512 + cl0 + j * 16);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const v4i c4 = acc[i][j];
+      const float r = ra[i * 16];
+      v4f v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = exact_div(static_cast<float>(c4[e]) * r, ws[e], wi[e]);
+        if (HAS_BIAS) v[e] = v[e] + bs[e];
+      }
+      *reinterpret_cast<v4f*>(y0 + static_cast<int64_t>(i) * 16 * ldy + j * 16) = activation4<ACT>(v);
+      // (one accumulator at a time: the four elements interleave, successive accumulators do not -
+      // the cheap forms otherwise pull every operand of the tile forward and spill)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// ACT: ops::ActivationType 1..6 of the fused form as a constant; -1 = ReLU / none (ep.act) and the int32-out mode.
 // VAR (timing experiments of a tuning build, ACT = -1 only): bit 0 = weight fragment in the outer
 // MFMA loop, bit 1 = no epilogue (K loops only).
-template <int ACT, int VAR = 0>
+// SHAPE (round 6): the output tile and the wave grid over it -
+//   0: 256 x 256, waves 2 (rows) x 4 (columns), 128 x 64 per wave   (8 x 4 accumulators)
+//   1: 256 x 224, waves 4 x 2,                   64 x 112 per wave   (4 x 7)
+//   2: 256 x 192, waves 4 x 2,                   64 x 96 per wave    (4 x 6)
+// The narrower tiles exist for the LAST ROUND: one workgroup per CU walks ceil(tiles / 256)
+// rounds of tiles, so [2048, 14336] in 256-wide tiles is 448 tiles = two rounds with 64 CUs idle
+// in the second, and in 224-wide tiles 512 tiles = two full rounds of 7/8 the work each
+// (launch_gemm_s8_big3 picks the width with the least rounds x width). The LDS image, the DMA map
+// and the K-loop schedule are the same; the weight rows past the tile's width are not fetched.
+template <int SHAPE>
+struct Big3Shape {
+  static constexpr bool kWide = SHAPE != 0;                 // 4 x 2 wave grid
+  static constexpr int NI = kWide ? 4 : 8;                  // activation-row fragments per wave
+  static constexpr int NJ = SHAPE == 0 ? 4 : (SHAPE == 1 ? 7 : 6);  // weight-row fragments per wave
+  static constexpr int BN = (kWide ? 2 : 4) * NJ * 16;
+};
+constexpr int big3_tile_n(int shape) { return shape == 0 ? 256 : (shape == 1 ? 224 : 192); }
+
+template <int ACT, int VAR = 0, int SHAPE = 0>
 __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* __restrict__ A,
                                                                  const int8_t* __restrict__ B,
                                                                  int M, int N, int K,
@@ -81,8 +186,12 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int group = wm;
+  using S = Big3Shape<SHAPE>;
+  constexpr int NI = S::NI, NJ = S::NJ, BN = S::BN;
+  constexpr int WROWS = NI * 16, WCOLS = NJ * 16;  // the wave's part of the tile
+  // (the two waves of a SIMD are w and w + 4: the ping-pong groups are the wave number's bit 2)
+  const int group = wave >> 2;
+  const int wm = S::kWide ? (wave & 3) : (wave >> 2), wn = S::kWide ? (wave >> 2) : (wave & 3);
   const int r = lane & 15, g = lane >> 4;
 
   // Persistent tile list: hardware block b sits on XCD b % 8 (observed, speed only). XCD x owns
@@ -126,7 +235,7 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
   const int8_t* a_base;
   const int8_t* b_base;
   auto set_sources = [&](int tm, int tn) {
-    const int m_last = M - 1 - tm * T_BM, n_last = N - 1 - tn * T_BN;
+    const int m_last = M - 1 - tm * T_BM, n_last = N - 1 - tn * BN;
     int row0 = ld_row;  // opaque: the four row numbers are not worth registers across the K loop
     asm volatile("" : "+v"(row0));
 #pragma unroll
@@ -135,7 +244,7 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
       b_rel[i] = static_cast<uint32_t>(min(i * 64 + row0, n_last)) * static_cast<uint32_t>(K) + ld_chunk;
     }
     a_base = A + static_cast<int64_t>(tm) * T_BM * K;
-    b_base = B + static_cast<int64_t>(tn) * T_BN * K;
+    b_base = B + static_cast<int64_t>(tn) * BN * K;
   };
   auto stage = [&](int buf, int k0) {
     int8_t* base = lds + buf * T_STAGE_BYTES + wave * 1024;
@@ -144,49 +253,53 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16(ak + a_rel[i], base + i * 8192);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(bk + b_rel[i], base + T_BM * T_BK + i * 8192);
+    for (int i = 0; i < 4; ++i) {
+      // (weight rows past the tile's width: the last request moves 32 rows - waves 0 - 3 - or none)
+      if (i * 64 + 64 <= BN || (i * 64 < BN && wave < (BN - i * 64) / 8))
+        glds16(bk + b_rel[i], base + T_BM * T_BK + i * 8192);
+    }
   };
   // Epilogue operands of a tile: waves 0-3 (group 0) fetch 64 floats each of the three arrays.
   auto stage_params = [&](int pbuf, int tm, int tn) {
     if (ep.mode != 1 || wave >= 4) return;
     float* p = reinterpret_cast<float*>(lds + T_RING_BYTES + pbuf * T_PARAM_BYTES) + wave * 64;
     const int row = min(tm * T_BM + wave * 64 + lane, M - 1);
-    const int col = min(tn * T_BN + wave * 64 + lane, N - 1);
+    const int col = min(tn * BN + wave * 64 + lane, N - 1);
     glds4(ep.a_scale + row, p);
     glds4(ep.w_scale + col, p + 256);
     if (ep.bias) glds4(ep.bias + col, p + 512);
   };
 
-  v4i acc[8][4];
+  v4i acc[NI][NJ];
 
   // Fragment addresses: tile row = base16 + r; K chunk c = ks * 4 + g of 8 (16 B each), stored at
   // slot c ^ ((r >> 1) & 7).
   const int swz = r >> 1;
-  const int x_off = (wm * 128 + r) * T_BK;
-  const int w_off = T_BM * T_BK + (wn * 64 + r) * T_BK;
-  v4i xf[8], wf[4];
+  const int x_off = (wm * WROWS + r) * T_BK;
+  const int w_off = T_BM * T_BK + (wn * WCOLS + r) * T_BK;
+  v4i xf[NI], wf[NJ];
   auto load_frags = [&](int buf, int ks) {
     const int8_t* tile = lds + buf * T_STAGE_BYTES + (((ks * 4 + g) ^ swz) << 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
       wf[j] = *reinterpret_cast<const v4i*>(tile + w_off + j * 16 * T_BK);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
       xf[i] = *reinterpret_cast<const v4i*>(tile + x_off + i * 16 * T_BK);
   };
   auto mfmas = [&]() {
     __builtin_amdgcn_s_setprio(1);
     if (VAR & 1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NI; ++i)
           acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], xf[i], acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], xf[i], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -225,9 +338,9 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
     int tm_n = 0, tn_n = 0;
     if (has_next) coords(Lnext, tm_n, tn_n);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = v4i{0, 0, 0, 0};
+      for (int j = 0; j < NJ; ++j) acc[i][j] = v4i{0, 0, 0, 0};
 
     phase_barrier();  // this tile's first stage (and its parameters) are in LDS
     if (group == 1) phase_barrier();
@@ -266,26 +379,26 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
     asm volatile("" : "+v"(lane_e));
     const int re = lane_e & 15, ge = lane_e >> 4;
     const int64_t m0 = static_cast<int64_t>(tm) * T_BM;
-    const int64_t n0 = static_cast<int64_t>(tn) * T_BN;
+    const int64_t n0 = static_cast<int64_t>(tn) * BN;
     // 16-byte stores need the row pitch and the base addresses to allow them.
-    const bool full = (m0 + T_BM <= M) && (n0 + T_BN <= N) && ((ep.ldy & 3) == 0) &&
+    const bool full = (m0 + T_BM <= M) && (n0 + BN <= N) && ((ep.ldy & 3) == 0) &&
                       (((reinterpret_cast<uintptr_t>(ep.y) | reinterpret_cast<uintptr_t>(ep.c_i32) |
                          reinterpret_cast<uintptr_t>(ep.residual)) & 15) == 0);
     if (VAR & 2) {  // K loops only: one conditional store keeps the accumulators alive
       int keep = 0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) keep ^= acc[i][j][0] ^ acc[i][j][1] ^ acc[i][j][2] ^ acc[i][j][3];
+        for (int j = 0; j < NJ; ++j) keep ^= acc[i][j][0] ^ acc[i][j][1] ^ acc[i][j][2] ^ acc[i][j][3];
       if (keep == 0x7fffffff && ep.c_i32) ep.c_i32[0] = keep;
     } else if (ep.mode == 0) {
       int32_t* __restrict__ c = ep.c_i32;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cl = wn * 64 + j * 16 + ge * 4;
+      for (int j = 0; j < NJ; ++j) {
+        const int cl = wn * WCOLS + j * 16 + ge * 4;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int64_t row = m0 + wm * 128 + i * 16 + re;
+        for (int i = 0; i < NI; ++i) {
+          const int64_t row = m0 + wm * WROWS + i * 16 + re;
           int32_t* p = c + row * ep.ldy + n0 + cl;
           const v4i c4 = acc[i][j];
           if (full) {
@@ -313,18 +426,28 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
       const bool fast_div = __builtin_amdgcn_readfirstlane(*slow_div) == 0;
       const bool has_bias = ep.bias != nullptr;
       const bool has_res = ep.residual != nullptr;
-      float* __restrict__ y = ep.y;
-      const float* __restrict__ res = ep.residual;
-      const float* ra = par + wm * 128 + re;  // 1 / a_scale of the lane's rows: ra[i * 16]
+      const float* ra = par + wm * WROWS + re;  // 1 / a_scale of the lane's rows: ra[i * 16]
+      // Interior tile with in-range scales and no residual (every tile of a Dense whose shape is a
+      // multiple of the tile): straight-line code, nothing but the arithmetic and the stores.
+      // (ACT > 0 only: the store-bound ReLU / plain forms keep the general code - with a second
+      // copy of the epilogue the register allocator spills inside their K loop)
+      if (ACT > 0 && fast_div && full && !has_res) {
+        const int cl0 = wn * WCOLS + ge * 4;  // the lane's first column of column fragment 0
+        float* y0 = ep.y + ((m0 + wm * WROWS + re) * ep.ldy + n0 + cl0);
+        if (has_bias) big3_epilogue_interior<ACT, true, NI, NJ>(acc, par, ra, cl0, y0, ep.ldy);
+        else big3_epilogue_interior<ACT, false, NI, NJ>(acc, par, ra, cl0, y0, ep.ldy);
+      } else {
+        float* __restrict__ y = ep.y;
+        const float* __restrict__ res = ep.residual;
 #define CT2X_BIG3_EPILOGUE(FAST)                                                                  \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
-    const int cl = wn * 64 + j * 16 + ge * 4;                                                     \
+  _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                \
+    const int cl = wn * WCOLS + j * 16 + ge * 4;                                                  \
     const v4f ws = *reinterpret_cast<const v4f*>(par + 256 + cl);                                 \
     const v4f wi = *reinterpret_cast<const v4f*>(par + 768 + cl);                                 \
     const v4f bs = has_bias ? *reinterpret_cast<const v4f*>(par + 512 + cl) : v4f{0, 0, 0, 0};    \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                               \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                              \
       const v4i c4 = acc[i][j];                                                                   \
-      const int64_t row = m0 + wm * 128 + i * 16 + re;                                            \
+      const int64_t row = m0 + wm * WROWS + i * 16 + re;                                          \
       const int64_t at = row * ep.ldy + n0 + cl;                                                  \
       v4f rs = v4f{0, 0, 0, 0};                                                                   \
       if (has_res) {                                                                              \
@@ -347,14 +470,16 @@ __global__ __launch_bounds__(T_THREADS) void gemm_s8_big3_kernel(const int8_t* _
       else if (row < M) {                                                                         \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) if (n0 + cl + e < N) y[at + e] = out[e];    \
       }                                                                                           \
+      if (ACT > 0) __builtin_amdgcn_sched_barrier(0); /* (their edge / slow path: registers first) */ \
     }                                                                                             \
   }
-      if (fast_div) {
-        CT2X_BIG3_EPILOGUE(true)
-      } else {
-        CT2X_BIG3_EPILOGUE(false)
-      }
+        if (fast_div) {
+          CT2X_BIG3_EPILOGUE(true)
+        } else {
+          CT2X_BIG3_EPILOGUE(false)
+        }
 #undef CT2X_BIG3_EPILOGUE
+      }
     }
 
     }
@@ -380,23 +505,88 @@ int device_cu_count() {
   return v;
 }
 
-template <int ACT, int VAR = 0>
-void launch_big3(const int8_t* a, const int8_t* b, int M, int N, int K, int tiles_m, int tiles_n,
-                 const GemmS8Epilogue& ep, int grid, hipStream_t stream) {
+template <int ACT, int VAR = 0, int SHAPE = 0>
+void launch_big3_shape(const int8_t* a, const int8_t* b, int M, int N, int K, int tiles_m, int tiles_n,
+                       const GemmS8Epilogue& ep, int grid, hipStream_t stream) {
   // > 64 KiB of dynamic LDS has to be opted into once per device.
   static std::atomic<bool> configured[64];
   int dev = 0;
   CT2X_HIP_CHECK(hipGetDevice(&dev));
   if (!configured[dev & 63].load(std::memory_order_acquire)) {
-    CT2X_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_s8_big3_kernel<ACT, VAR>),
+    CT2X_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_s8_big3_kernel<ACT, VAR, SHAPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES));
     configured[dev & 63].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL((gemm_s8_big3_kernel<ACT, VAR>), dim3(grid), dim3(T_THREADS), T_LDS_BYTES, stream,
+  hipLaunchKernelGGL((gemm_s8_big3_kernel<ACT, VAR, SHAPE>), dim3(grid), dim3(T_THREADS), T_LDS_BYTES, stream,
                      a, b, M, N, K, tiles_m, tiles_n, ep);
 }
 
+template <int ACT, int VAR = 0>
+void launch_big3(const int8_t* a, const int8_t* b, int M, int N, int K, int shape, int tiles_m, int tiles_n,
+                 const GemmS8Epilogue& ep, int grid, hipStream_t stream) {
+  if (shape == 1) launch_big3_shape<ACT, VAR, 1>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream);
+  else if (shape == 2) launch_big3_shape<ACT, VAR, 2>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream);
+  else launch_big3_shape<ACT, VAR, 0>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream);
+}
+
+// Tile width for [M, N]: the one whose walk costs least, rounds x width (a workgroup per CU walks
+// ceil(tiles / CUs) tiles; a tile's time follows its width). Ties go to the wider tile (fewer
+// operand bytes per product). CT2X_BIG3_SHAPE=0|1|2 (tuning builds) forces one.
+int big3_pick_shape(int M, int N, int cus) {
+  const int tiles_m = (M + T_BM - 1) / T_BM;
+  int best = 0;
+  long best_cost = 0;
+  for (int shape = 0; shape < 3; ++shape) {
+    const int bn = big3_tile_n(shape);
+    const long tiles = static_cast<long>(tiles_m) * ((N + bn - 1) / bn);
+    const long cost = ((tiles + cus - 1) / cus) * bn;
+    if (shape == 0 || cost < best_cost) {
+      best = shape;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
 }  // namespace
+
+// div_noscale against the plain division on the device: numerators t = +-2^u (1 + f) over the whole
+// admitted range (and its two ends exactly), denominators d = 1 + exp(-t) as Swish forms them for
+// one half of the pairs, any d in [1, 2^93) for the other half. Counts differing bit patterns.
+__global__ void fast_div_check_kernel(unsigned long long n, unsigned seed, unsigned long long* mismatches) {
+  unsigned long long i = blockIdx.x * static_cast<unsigned long long>(blockDim.x) + threadIdx.x;
+  const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
+  unsigned long long bad = 0;
+  for (; i < n; i += stride) {
+    unsigned h = static_cast<unsigned>(i * 2654435761ull) ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    unsigned g = h * 747796405u + 2891336453u;
+    g ^= g >> 16; g *= 2246822519u; g ^= g >> 13;
+    // t: exponent -20 .. 5 (and 64.0 itself), random mantissa and sign
+    const int ex = static_cast<int>(h % 26u) - 20;
+    float t = __builtin_bit_cast(float, static_cast<unsigned>((ex + 127) << 23) | (g & 0x7fffffu));
+    if ((h >> 8) % 1021u == 0) t = 64.f;
+    if ((h >> 8) % 1021u == 1) t = 9.5367431640625e-07f;
+    if (g & 0x800000u) t = -t;
+    float d;
+    if (h & 0x80000000u) {
+      d = 1.f + exact_exp_avx2(-t);
+    } else {
+      const int ed = static_cast<int>((h >> 5) % 93u);
+      d = __builtin_bit_cast(float, static_cast<unsigned>((ed + 127) << 23) | ((g >> 3) & 0x7fffffu));
+    }
+    const float a = div_noscale(t, d), b = t / d;
+    const float c = div_noscale(1.f, d), e = 1.f / d;
+    if (__builtin_bit_cast(unsigned, a) != __builtin_bit_cast(unsigned, b)) ++bad;
+    if (__builtin_bit_cast(unsigned, c) != __builtin_bit_cast(unsigned, e)) ++bad;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+void launch_fast_div_check(unsigned long long n, unsigned seed, unsigned long long* d_mismatches,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(fast_div_check_kernel, dim3(2048), dim3(256), 0, stream, n, seed, d_mismatches);
+}
 
 void launch_gemm_s8_big3(const int8_t* a, const int8_t* b, int M, int N, int K,
                          const GemmS8Epilogue& ep_in, hipStream_t stream) {
@@ -411,7 +601,14 @@ void launch_gemm_s8_big3(const int8_t* a, const int8_t* b, int M, int N, int K,
   }();
   GemmS8Epilogue ep = ep_in;
   ep.plain_division = plain_division;
-  const int tiles_m = (M + T_BM - 1) / T_BM, tiles_n = (N + T_BN - 1) / T_BN;
+  static const int shape_override = [] {
+    const char* e = tuning_env("CT2X_BIG3_SHAPE");
+    return e ? std::atoi(e) : -1;
+  }();
+  const int shape = (shape_override >= 0 && shape_override <= 2) ? shape_override
+                                                                 : big3_pick_shape(M, N, device_cu_count());
+  const int bn = big3_tile_n(shape);
+  const int tiles_m = (M + T_BM - 1) / T_BM, tiles_n = (N + bn - 1) / bn;
   const int ntiles = tiles_m * tiles_n;
   int grid = std::min(ntiles, device_cu_count());
   if (grid_override == 0) grid = ntiles;
@@ -422,18 +619,18 @@ void launch_gemm_s8_big3(const int8_t* a, const int8_t* b, int M, int N, int K,
     const char* e = tuning_env("CT2X_BIG3_VAR");
     return e ? std::atoi(e) : 0;
   }();
-  if (var == 1) return launch_big3<-1, 1>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream);
-  if (var == 2) return launch_big3<-1, 2>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream);
-  if (var == 3) return launch_big3<-1, 3>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream);
+  if (var == 1) return launch_big3<-1, 1>(a, b, M, N, K, shape, tiles_m, tiles_n, ep, grid, stream);
+  if (var == 2) return launch_big3<-1, 2>(a, b, M, N, K, shape, tiles_m, tiles_n, ep, grid, stream);
+  if (var == 3) return launch_big3<-1, 3>(a, b, M, N, K, shape, tiles_m, tiles_n, ep, grid, stream);
 #endif
   switch (act) {
-    case 1: launch_big3<1>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    case 2: launch_big3<2>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    case 3: launch_big3<3>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    case 4: launch_big3<4>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    case 5: launch_big3<5>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    case 6: launch_big3<6>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
-    default: launch_big3<-1>(a, b, M, N, K, tiles_m, tiles_n, ep, grid, stream); break;
+    case 1: launch_big3<1>(a, b, M, N, K, shape, tiles_m, tiles_n, ep, grid, stream); break;
+    case 2: launch_big3<2>(a, b, M, N, K, shape, tiles_m, tiles_n, ep, grid, stream); break;
+    case 3: launch_big3<3>(a, b, M, N, K, shape, tiles_m, tiles_n, ep, grid, stream); break;
+    case 4: launch_big3<4>(a, b, M, N, K, shape, tiles_m, tiles_n, ep, grid, stream); break;
+    case 5: launch_big3<5>(a, b, M, N, K, shape, tiles_m, tiles_n, ep, grid, stream); break;
+    case 6: launch_big3<6>(a, b, M, N, K, shape, tiles_m, tiles_n, ep, grid, stream); break;
+    default: launch_big3<-1>(a, b, M, N, K, shape, tiles_m, tiles_n, ep, grid, stream); break;
   }
 }
 

@@ -189,6 +189,10 @@ bool gemm_s8_big_applicable(int64_t m, int64_t n, int64_t k);
 // stores, persistent tile stream); launch_gemm_s8_big forwards to it.
 void launch_gemm_s8_big3(const int8_t* a, const int8_t* b, int M, int N, int K,
                          const GemmS8Epilogue& ep, hipStream_t stream);
+// Tests: the reduced division of the exponential activations' epilogue against `/` on n pairs
+// (gemm_s8_big3.hip div_noscale); adds the number of differing results to *d_mismatches.
+void launch_fast_div_check(unsigned long long n, unsigned seed, unsigned long long* d_mismatches,
+                           hipStream_t stream);
 // Two-workgroups-per-CU form (gemm_s8_big5.hip: 128 x 256 tiles, four waves, three-stage ring).
 void launch_gemm_s8_big5(const int8_t* a, const int8_t* b, int M, int N, int K,
                          const GemmS8Epilogue& ep, hipStream_t stream);

@@ -785,6 +785,13 @@ int ct2x_host_rotary_tables(int64_t dim, int interleave, int scaling_type, float
  * caches are gathered every step), -1 restores the default. Results are identical either way. */
 int ct2x_debug_set_beam_ancestry(int enabled);
 
+/* Tests: the MFMA-bound GEMM's epilogue divides by 1 + exp(..) (Swish, GELUSigmoid, Sigmoid:
+ * src/cpu/kernels.cc:146-207) with the compiler's own IEEE division sequence minus the steps that
+ * are the identity inside the admitted operand range; this runs that sequence against the plain
+ * division on `pairs` operand pairs on the device and returns the number of differing results
+ * (must be 0). */
+int ct2x_debug_fast_div_check(uint64_t pairs, uint32_t seed, uint64_t* mismatches);
+
 /* ---- debugging taps (tests only; not part of the reference boundary) ----------------------
  * ct2x_debug_step_taps = ct2x_step_logits with every producer on the path (embedding, norm +
  * Quantize, Quantize, Dense, attention) copying its output to the host, named
@@ -839,6 +846,18 @@ int64_t ct2x_last_compactions(void* translator);
  * translator or by ct2x_release_session. ct2x_session_hits: calls served that way so far (-1: bad
  * handle). */
 int64_t ct2x_session_hits(void* translator);
+
+/* The decoder-stack launch (one persistent launch per decode step, csrc/decoder_cluster.hip) needs
+ * its workgroups co-resident. A session uses it only while it holds the device's gate (one holder
+ * per GPU across threads and processes; a session that does not get the gate decodes with the
+ * launch-per-op step - same tokens). If a cluster nevertheless waits in vain, the group's results
+ * are discarded, the handle switches to the launch-per-op step for good and the group is decoded
+ * again: ct2x_cluster_fallbacks counts those re-runs (-1: bad handle).
+ * ct2x_debug_inject_cluster_timeout (tests): the next session that ran the launch reports a
+ * starved cluster. Several workers per device is a supported deployment of the reference
+ * (include/ctranslate2/replica_pool.h:339-359). */
+int64_t ct2x_cluster_fallbacks(void* translator);
+int ct2x_debug_inject_cluster_timeout(void* translator);
 int ct2x_release_session(void* translator);
 
 /* Per-kernel profile of the next translate/generate calls, measured with HIP events on the

@@ -151,3 +151,113 @@ def test_cluster_stack_equals_launch_per_op(gpu):
     for key in base:
         if not key.endswith("_kernels"):
             assert counter[key] == base[key], key
+
+
+# ---- round 6: the launch is safe to ship -----------------------------------------------------
+# Several workers per device is a supported deployment of the reference
+# (include/ctranslate2/replica_pool.h:339-359): the decoder-stack launch, whose workgroups wait for
+# each other, must not turn a second handle / process on the GPU into errors or wrong tokens.
+
+WORKER = r"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(here)r)
+import ctranslate2_amd as ct2
+from ctranslate2_amd import model_builder as mb
+import golden_cases as GC
+path = "/tmp/ct2x_test_tb"
+if not os.path.exists(os.path.join(path, "model.bin")):
+    mb.build_transformer(path, **GC.SYNTHETIC["tb"]["model"])
+t = ct2.Translator(path, device="cuda", compute_type="int8")
+rng = np.random.default_rng(3)
+src = [rng.integers(4, 32000, 24).tolist() for _ in range(16)]
+kw = dict(beam_size=1, max_decoding_length=48, min_decoding_length=48)
+mode = sys.argv[1]
+out = {}
+if mode == "loop":       # translate for a while next to another process doing the same
+    first, _ = t.translate_ids(src, **kw)
+    open(sys.argv[2], "w").write("up")
+    while not os.path.exists(sys.argv[3]):   # wait for the sibling to be up as well
+        time.sleep(0.01)
+    same, fused_calls, calls = True, 0, 0
+    end = time.time() + 6.0
+    while time.time() < end:
+        hyps, _ = t.translate_ids(src, **kw)
+        same = same and hyps == first
+        calls += 1
+        fused_calls += int(t.last_stats()["kernels_per_step"] <= 3)
+    out = {"hyps": first, "same": same, "calls": calls, "fused_calls": fused_calls,
+           "fallbacks": t.cluster_fallbacks()}
+elif mode == "inject":   # a starved cluster: the call is decoded again on the launch-per-op step
+    base, _ = t.translate_ids(src, **kw)
+    k_fused = t.last_stats()["kernels_per_step"]
+    t.debug_inject_cluster_timeout()
+    again, _ = t.translate_ids(src, **kw)
+    k_after = t.last_stats()["kernels_per_step"]
+    later, _ = t.translate_ids(src, **kw)
+    b4, s4 = t.translate_ids(src[:4], beam_size=4, max_decoding_length=12, return_scores=True)
+    out = {"base": base, "again": again, "later": later, "k_fused": k_fused, "k_after": k_after,
+           "fallbacks": t.cluster_fallbacks(), "beam": b4}
+elif mode == "callback":  # a step callback that re-enters translate on the same handle and device
+    inner = []
+    def cb(step):
+        if not inner:
+            inner.append(t.translate_ids(src[:2], **kw)[0])
+        return False
+    base, _ = t.translate_ids(src[:2], **kw)
+    hyps, _ = t.translate_ids(src[:2], callback=cb, **kw)
+    out = {"base": base, "hyps": hyps, "inner": inner[0]}
+print(json.dumps(out))
+"""
+
+
+def _worker(args, env=None, wait=True):
+    p = subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT, "here": HERE}] + args,
+                         env=env or dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if not wait:
+        return p
+    o, e = p.communicate(timeout=600)
+    assert p.returncode == 0, e[-3000:]
+    return json.loads(o.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_starved_cluster_is_decoded_again_not_thrown(gpu):
+    r = _worker(["inject"])
+    assert r["k_fused"] <= 3, "the decoder-stack launch did not run"
+    assert r["again"] == r["base"] and r["later"] == r["base"]
+    assert r["fallbacks"] == 1
+    assert r["k_after"] > 40, "after a starved cluster the handle stays on the launch-per-op step"
+    ref = _worker(["inject"], env=dict(os.environ, CT2X_CLUSTER_STACK="0"))
+    assert ref["base"] == r["base"] and ref["beam"] == r["beam"] and ref["fallbacks"] == 0
+
+
+@pytest.mark.gpu
+def test_two_processes_on_one_gpu_both_translate(gpu, tmp_path):
+    """Two replica processes on one GPU: whoever holds the device's gate runs the decoder-stack
+    launch, the other one the launch-per-op step; both return the same tokens as a lone process,
+    nobody throws, nobody is voided."""
+    alone = _worker(["inject"], env=dict(os.environ, CT2X_CLUSTER_STACK="0"))["base"]
+    fa, fb = str(tmp_path / "a_up"), str(tmp_path / "b_up")
+    pa = _worker(["loop", fa, fb], wait=False)
+    pb = _worker(["loop", fb, fa], wait=False)
+    outs = []
+    for p in (pa, pb):
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    for r in outs:
+        assert r["hyps"] == alone and r["same"] and r["calls"] >= 3
+        assert r["fallbacks"] == 0, "the gate, not the time-out, keeps two processes apart"
+    # the gate is tried per call: over six seconds each process ran the fused launch at least once
+    # and the two never held it together (no fallbacks above)
+    assert outs[0]["fused_calls"] + outs[1]["fused_calls"] >= 1
+    print("two processes: calls %s, on the decoder-stack launch %s" %
+          ([r["calls"] for r in outs], [r["fused_calls"] for r in outs]))
+
+
+@pytest.mark.gpu
+def test_callback_may_reenter_translate(gpu):
+    r = _worker(["callback"])
+    assert r["hyps"] == r["base"] and r["inner"] == r["base"]

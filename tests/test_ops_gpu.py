@@ -295,6 +295,43 @@ def test_dense_big_tile_division_guard(gpu, scale_exp):
     assert np.array_equal(y, yo)
 
 
+@pytest.mark.parametrize("act", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_dense_big_tile_activation_epilogue(gpu, act, with_bias):
+    """The 256 x 256 kernel's straight-line epilogue of interior tiles (round 6: constant activation,
+    four interleaved elements, the exponential activations' division on the reduced IEEE sequence
+    with a wave-uniform fall-back to the plain division) and the general epilogue of the edge tiles
+    return the oracle's bits for every activation of the reference (src/cpu/kernels.cc:146-207).
+    Rows of zeros and rows scaled by 2^12 put exact zeros, -0.0 and values far outside the reduced
+    sequence's range next to ordinary ones."""
+    import _gpuops as G
+    m, n, k = 1100, 1300, 256  # 4 x 5 interior tiles + an edge row and column of tiles
+    rng = np.random.default_rng(31 * act + with_bias)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    x[5] = 0
+    x[300:310] *= np.float32(4096)
+    x[700] = -np.abs(x[700]) * np.float32(1e-6)
+    w = rng.standard_normal((n, k)).astype(np.float32) * 0.02
+    w[17] = 0
+    wq, ws = O.quantize_s8(w, True)
+    bias = (rng.standard_normal(n) * 0.01).astype(np.float32) if with_bias else None
+    q, s = G.quantize_s8(x, True)
+    y = G.gemm_s8_dequant(q, s, wq, ws, bias, None, act)
+    yo = O.dequantize_gemm_output(O.gemm_s8(q, wq), s, ws, bias, act)
+    assert np.array_equal(y.view(np.uint32), yo.view(np.uint32))
+
+
+def test_reduced_division_equals_plain_division(gpu):
+    """div_noscale (gemm_s8_big3.hip) = the compiler's IEEE division minus the steps that are the
+    identity inside the admitted range: against `/` on 2 x 10^9 results on the device."""
+    import ctypes as C
+    from ctranslate2_amd import _lib
+    bad = C.c_uint64(1)
+    for seed in (1, 77):
+        _lib.check(_lib.lib().ct2x_debug_fast_div_check(C.c_uint64(500_000_000), C.c_uint32(seed), C.byref(bad)))
+        assert bad.value == 0
+
+
 @pytest.mark.parametrize("m,n,k", [(16, 14336, 4096), (32, 2048, 512), (5, 96, 64), (16, 1000, 2048)])
 @pytest.mark.parametrize("act,with_bias", [(2, False), (0, True), (3, True)])
 def test_dense_glu_fused(gpu, m, n, k, act, with_bias):

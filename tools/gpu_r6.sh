@@ -1,0 +1,43 @@
+#!/bin/bash
+# Round 6: the GPU measurements of the round as named sections (one `gpurun` call each):
+#   gpurun --timeout 900 -- 'bash tools/gpu_r6.sh <section>'
+# Output goes to gpurun_out/r6/; what is kept is copied to profiles/ (profiles/README.md).
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r6
+O=gpurun_out/r6
+export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/ctranslate2_amd:$LD_LIBRARY_PATH
+export TMPDIR=/tmp
+GB=build/tools/gemm_bench
+GBT=build/tools/gemm_bench_tuning
+NOLEGS="--no-cpu-baseline --no-profile --no-l8 --no-whisper --no-nllb"
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), 'tok/s', round(d['ms_per_step'],3), 'ms/call', 'kernels/step', d['config'].get('kernels_per_decode_step'))"; }
+L8SH="2048 14336 4096"
+
+case "$1" in
+pmc_big3)         # profiles/r06_pmc_gemm_big3.json: which unit the MFMA-bound GEMM keeps busy
+  timeout 900 python tools/pmc_gemm_big3.py $O/pmc_big3 > $O/pmc_gemm_big3.json 2> $O/pmc_big3.err
+  head -c 6000 $O/pmc_gemm_big3.json; tail -3 $O/pmc_big3.err
+  find $O/pmc_big3 -name "*.csv" -size +1M -delete; find $O/pmc_big3 -name "*.db" -delete
+  { echo "== shipped library"; timeout 300 $GB --act 2 $L8SH; timeout 300 $GB $L8SH 4096 4096 4096 8192 8192 8192; } 2>&1 | tee $O/gemm_bench_base.txt ;;
+gemm_bench)       # the big int8 GEMM forms, tuning build; extra args = env assignments to A/B
+  shift
+  { echo "== default"; timeout 300 $GBT --act 2 $L8SH; timeout 300 $GBT $L8SH 4096 4096 4096 8192 8192 8192 2048 6144 4096 2048 4096 14336 1024 2048 512
+    for e in "$@"; do echo "== $e"; env $e timeout 300 $GBT --act 2 $L8SH; env $e timeout 300 $GBT $L8SH 4096 4096 4096 8192 8192 8192; done
+  } 2>&1 | tee $O/gemm_bench.txt ;;
+gemm_ab)          # head (round 5) library vs this tree, then the tile shapes (tuning build)
+  SH="$L8SH 4096 4096 4096 8192 8192 8192 2048 6144 4096 2048 4096 4096 2048 4096 14336 1024 2048 512"
+  { echo "== head (round-5 kernel), swish"; timeout 300 build/tools/gemm_bench_head --act 2 $L8SH 2048 6144 4096
+    echo "== this tree, swish"; timeout 300 $GB --act 2 $L8SH 2048 6144 4096
+    echo "== head, relu"; timeout 300 build/tools/gemm_bench_head $SH
+    echo "== this tree, relu"; timeout 300 $GB $SH
+    for sh in 0 1 2; do echo "== tuning CT2X_BIG3_SHAPE=$sh swish"; CT2X_BIG3_SHAPE=$sh timeout 300 $GBT --act 2 $L8SH 4096 4096 4096; done
+    for sh in 0 1 2; do echo "== tuning CT2X_BIG3_SHAPE=$sh CT2X_BIG_GEMM_V=3 (int32-out on this kernel too)"; CT2X_BIG_GEMM_V=3 CT2X_BIG3_SHAPE=$sh timeout 300 $GBT $L8SH 4096 4096 4096; done
+    echo "== tuning K loops only (CT2X_BIG3_VAR=2) shapes 0 1"; for sh in 0 1; do CT2X_BIG_GEMM_V=3 CT2X_BIG3_VAR=2 CT2X_BIG3_SHAPE=$sh timeout 300 $GBT $L8SH; done
+    echo "== edges, this tree"; timeout 300 $GB 2500 2604 640 2500 2601 384 4200 4404 384 2561 2817 256 5000 5000 512
+  } 2>&1 | tee $O/gemm_ab.txt ;;
+tests)            # a list of test files / pytest args
+  shift; timeout 1500 python -m pytest "$@" -x -q 2>&1 | tail -15 | tee $O/tests.txt ;;
+suite)            # the whole -m gpu suite only
+  timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; tail -5 $O/pytest_all.log ;;
+*) echo "unknown section $1"; exit 2 ;;
+esac
