@@ -59,6 +59,13 @@ def parse_args():
                    help="tensor parallel over the --gpus ranks (one sharded model, every rank runs "
                         "the same batch, RCCL all-reduce after each row-parallel Dense) instead of "
                         "independent replicas; strong scaling")
+    p.add_argument("--tp-model", default="tb", choices=["tb", "nllb"],
+                   help="with --tp: the model the ranks share - tb (Transformer-base int8, the metric's model) or "
+                        "nllb (NLLB-200-3.3B geometry, float16, batch 64 beam 4: BASELINE configs[3], which the "
+                        "reference runs with TP = 4)")
+    p.add_argument("--plan", action="store_true",
+                   help="rendezvous (gloo when no GPU is visible), agree on the run and print it from rank 0 "
+                        "WITHOUT touching a GPU: what the multi-GPU invocation would do (tests/test_distributed_cpu.py)")
     p.add_argument("--check-tp-parity", action="store_true",
                    help="with --tp: rank 0 also decodes the batch on an unsharded engine and reports "
                         "whether the tensor-parallel tokens are identical (config.tp_tokens_equal_unsharded)")
@@ -82,6 +89,73 @@ def parse_args():
     p.add_argument("--unfused-tokens-of", type=int, default=-1, help=argparse.SUPPRESS)
     p.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline")
     return p.parse_args()
+
+
+NLLB = dict(num_encoder_layers=24, num_decoder_layers=24, d_model=2048, ffn_dim=8192, num_heads=16,
+            vocab_size=256206, seed=0, quantization="float16", direct_f16=True, share_embeddings=True)
+
+
+def run_plan(args, rank, world):
+    """What this invocation does, as data (printed by --plan, and the same decisions main() takes)."""
+    tp = args.tp and world > 1
+    model = args.tp_model if tp else "tb"
+    return {"world": world, "rank": rank,
+            "parallelism": ("tensor parallel x%d" % world) if tp else ("replicas x%d" % world),
+            "model": {"tb": "Transformer-base int8", "nllb": "NLLB-200-3.3B geometry float16"}[model],
+            "batch": 64 if model == "nllb" else args.batch, "beam": 4 if model == "nllb" else args.beam,
+            "scaling": "strong" if tp else "weak",
+            "before_the_timed_region": (["ct2x_tp_selftest_multi on every rank (RCCL unique id of rank 0 by "
+                                         "torch.distributed broadcast)"] if world > 1 else []),
+            "data_path_collective": ("all-reduce of int32 partial products / one-shot mailbox exchange after "
+                                     "every row-parallel Dense") if tp else None}
+
+
+def plan_only(args, rank, local_rank, world):
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    plan = run_plan(args, rank, world)
+    # the 128 bytes every rank needs travel the way the real run sends them
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        uid = torch.arange(128, dtype=torch.uint8)
+    if world > 1:
+        dist.broadcast(uid, src=0)
+        plans = [None] * world
+        dist.all_gather_object(plans, plan)
+    else:
+        plans = [plan]
+    ok = bool((uid == torch.arange(128, dtype=torch.uint8)).all()) and \
+        all(p["parallelism"] == plans[0]["parallelism"] and p["model"] == plans[0]["model"] for p in plans) and \
+        sorted(p["rank"] for p in plans) == list(range(world))
+    if rank == 0:
+        print(json.dumps({"plan": plans[0], "ranks_agree": ok, "id_bytes_received": int(uid.numel())}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench.py --plan: the ranks disagree")
+
+
+def communicator_selftest(ct2, dist, torch, rank, local_rank, world):
+    """ct2x_tp_selftest_multi on every rank; the unique id of rank 0 travels by broadcast."""
+    uid = torch.zeros(128, dtype=torch.uint8, device=torch.device("cuda", local_rank))
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(ct2.tp_unique_id()), dtype=torch.uint8))
+    dist.broadcast(uid, src=0)
+    try:
+        out = ct2.tp_selftest_multi(local_rank, rank, world, unique_id=bytes(uid.cpu().numpy().tobytes()))
+    except Exception as e:  # noqa: BLE001 - every rank must reach the gather below
+        out = {"ok": False, "rank": rank, "error": "%s: %s" % (type(e).__name__, e)}
+    outs = [None] * world
+    dist.all_gather_object(outs, out)
+    bad = [o for o in outs if not o.get("ok")]
+    if bad:
+        raise SystemExit("bench.py: the tensor-parallel communicator failed its self-test before anything was "
+                         "timed: %s" % json.dumps(bad))
+    return {"ok": True, "world": world, "backend": outs[0]["backend"], "mailboxes": all(o["mailboxes"] for o in outs),
+            "oneshot_us_per_dense_max": max((o["oneshot_us_per_dense"] or 0.0) for o in outs)}
 
 
 def make_sources(rank, batch, src_len, vocab):
@@ -434,6 +508,8 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     import torch
     import torch.distributed as dist
+    if args.plan:
+        return plan_only(args, rank, local_rank, world)
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py needs an MI355X: no GPU is visible and there is no CPU fallback\n")
         sys.stderr.flush()
@@ -450,10 +526,23 @@ def main():
     import ctranslate2_amd as ct2
     from ctranslate2_amd import model_builder as mb
 
-    model_dir = "/tmp/ct2x_bench_tb_r%d" % local_rank
-    if not os.path.exists(os.path.join(model_dir, "model.bin")):
-        mb.build_transformer(model_dir, **TB)
+    # More than one GPU: the communicator first (every collective the tensor-parallel engine calls and
+    # the peer-mailbox exchanges, bit-checked on every rank) - the first multi-GPU run names the piece
+    # that fails instead of printing a number.
+    selftest = None
+    if world > 1:
+        selftest = communicator_selftest(ct2, dist, torch, rank, local_rank, world)
     tp = args.tp and world > 1
+    if tp and args.tp_model == "nllb":
+        args.compute_type, args.batch, args.beam = "float16", 64, 4
+        model_dir = "/tmp/ct2x_bench_nllb_L24_d2048"
+        if rank == 0 and not os.path.exists(os.path.join(model_dir, "model.bin")):
+            mb.build_transformer(model_dir, **NLLB)
+        dist.barrier()
+    else:
+        model_dir = "/tmp/ct2x_bench_tb_r%d" % local_rank
+        if not os.path.exists(os.path.join(model_dir, "model.bin")):
+            mb.build_transformer(model_dir, **TB)
     translator = ct2.Translator(model_dir, device="cuda", device_index=local_rank, compute_type=args.compute_type,
                                 tensor_parallel=tp)
     if args.unfused_tokens_of >= 0:
@@ -507,7 +596,7 @@ def main():
     timed_last = dict(last)
 
     result = {
-        "metric": "generated tokens/sec (%s, batch=32, beam=%d), whole job" % (args.compute_type, args.beam),
+        "metric": "generated tokens/sec (%s, batch=%d, beam=%d), whole job" % (args.compute_type, args.batch, args.beam),
         "value": value,
         "unit": "tokens/s",
         "n_gpus": world,
@@ -520,7 +609,11 @@ def main():
         "dtype": args.compute_type,
         "data": "synthetic",
         "config": {
-            "workload": "Transformer-base En->De %s, batch=%d beam=%d, "
+            "workload": ("NLLB-200-3.3B geometry (24 + 24 layers, d_model 2048, FFN 8192, vocabulary 256206) "
+                         "float16, batch=%d beam=%d, source length %d, %d forced decode steps, random-init "
+                         "weights (BASELINE configs[3])" % (args.batch, args.beam, args.src_len, args.max_len))
+                        if (tp and args.tp_model == "nllb") else
+                        "Transformer-base En->De %s, batch=%d beam=%d, "
                         "source length %d, %d forced decode steps, random-init weights N(0,0.02)"
                         % ("int8 (int8 weights + int8 activations, fp32 accumulate/epilogue = compute "
                            "type int8_float32)" if args.compute_type == "int8" else args.compute_type,
@@ -532,6 +625,7 @@ def main():
             "hip_graph": not args.no_graph,
             "streams_per_gpu": args.streams if args.streams > 0 else int(os.environ.get("CT2X_NUM_STREAMS", "1")),
             "kernels_per_decode_step": stats["kernels_per_step"],
+            "communicator_selftest": selftest,
             "source_batches_in_rotation": len(rotation),
             "session_reuse_hits": stats.get("session_hits", 0),
             "decode_ms_last_call": stats["decode_ms"],

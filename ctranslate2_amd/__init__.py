@@ -645,6 +645,31 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         return out
 
 
+def tp_selftest_multi(device_index: int, rank: int, world: int, unique_id: Optional[bytes] = None,
+                      shm_segment: Optional[str] = None) -> dict:
+    """ct2x_tp_selftest_multi: the tensor-parallel communicator across real ranks (one process per
+    GPU) - every collective the engine calls and, where the communicator has peer-mapped mailboxes,
+    the one-shot exchanges of a row-parallel Dense, checked bit for bit. Every rank calls it with
+    the RCCL unique id of rank 0 (ct2x_tp_unique_id, carried by the launcher) or a shared-memory
+    segment name. Raises Ct2xError with the failing piece."""
+    L = _lib.lib()
+    boxes, us = C.c_int32(0), C.c_float(0.0)
+    _lib.check(L.ct2x_tp_selftest_multi(C.c_int(device_index), C.c_int(rank), C.c_int(world),
+                                        C.c_char_p(unique_id) if unique_id is not None else None,
+                                        shm_segment.encode() if shm_segment else None,
+                                        C.byref(boxes), C.byref(us)))
+    return {"ok": True, "rank": rank, "world": world, "mailboxes": bool(boxes.value),
+            "backend": "rccl" if unique_id is not None else "shared-memory",
+            "oneshot_us_per_dense": float(us.value) if boxes.value else None}
+
+
+def tp_unique_id() -> bytes:
+    """128 bytes of rank 0 that every rank of a tensor-parallel group needs (ct2x_tp_unique_id)."""
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.lib().ct2x_tp_unique_id(buf))
+    return bytes(buf.raw)
+
+
 class WhisperOptions(C.Structure):
     """struct ct2x_whisper_options = models::WhisperOptions
     (include/ctranslate2/models/whisper.h:11-58)."""

@@ -469,6 +469,156 @@ int ct2x_tp_selftest_local(int device_index, int world) {
   API_CATCH
 }
 
+int ct2x_tp_selftest_multi(int device_index, int rank, int world, const void* unique_id_128_bytes,
+                           const char* shm_segment_name, int32_t* mailboxes_out, float* us_per_dense_out) {
+  API_TRY
+  // The communicator of the tensor-parallel engines across REAL ranks (one process per GPU): every
+  // collective the engine calls (ops::ReduceAll / GatherAll, src/ops/nccl_ops_gpu.cu:53-85) on
+  // rank-dependent data whose result is known in closed form, then - when the communicator has
+  // peer-mapped mailboxes - the two one-shot exchanges of a row-parallel int8 Dense, checked on
+  // every rank against what the whole row gives on the host, bit for bit. bench.py calls it before
+  // its timed region whenever it runs on more than one GPU, so that the first multi-GPU run says
+  // which piece fails instead of producing a number.
+  CT2X_CHECK(world >= 1 && world <= kTpMaxWorld && rank >= 0 && rank < world, "ct2x_tp_selftest_multi: rank / world");
+  CT2X_CHECK((unique_id_128_bytes != nullptr) != (shm_segment_name != nullptr && shm_segment_name[0] != 0),
+             "ct2x_tp_selftest_multi: give the RCCL unique id OR a shared-memory segment name");
+  CT2X_HIP_CHECK(hipSetDevice(device_index));
+  std::shared_ptr<TpComm> comm = unique_id_128_bytes ? make_rccl_comm(rank, world, unique_id_128_bytes)
+                                                     : make_shm_comm(rank, world, shm_segment_name);
+  CT2X_CHECK(comm->rank() == rank && comm->world() == world, "communicator reports another rank / world");
+  hipStream_t stream = thread_stream();
+  const int n = 4096;
+  auto vi = [](int i, int r) { return (i * 7 - 100) * (r + 1); };
+  auto vf = [](int i, int r) { return 0.25f * static_cast<float>((i * 37 + r * 101) % 1000) - 60.f; };  // exact sums
+  std::vector<int32_t> hi(n);
+  std::vector<float> hf(n), hm(n);
+  for (int i = 0; i < n; ++i) {
+    hi[i] = vi(i, rank);
+    hf[i] = vf(i, rank);
+    hm[i] = vf(i, rank);
+  }
+  auto* di = static_cast<int32_t*>(device_malloc(n * 4));
+  auto* df = static_cast<float*>(device_malloc(n * 4));
+  auto* dm = static_cast<float*>(device_malloc(n * 4));
+  auto* dg = static_cast<int32_t*>(device_malloc(static_cast<size_t>(n) * 4 * world));
+  CT2X_HIP_CHECK(hipMemcpyAsync(di, hi.data(), n * 4, hipMemcpyHostToDevice, stream));
+  CT2X_HIP_CHECK(hipMemcpyAsync(df, hf.data(), n * 4, hipMemcpyHostToDevice, stream));
+  CT2X_HIP_CHECK(hipMemcpyAsync(dm, hm.data(), n * 4, hipMemcpyHostToDevice, stream));
+  comm->all_gather(di, dg, n * 4, stream);   // (before the in-place reduce of di)
+  comm->all_reduce_sum_i32(di, n, stream);
+  comm->all_reduce_sum_f32(df, n, stream);
+  comm->all_reduce_max_f32(dm, n, stream);
+  std::vector<int32_t> oi(n), og(static_cast<size_t>(n) * world);
+  std::vector<float> of(n), om(n);
+  CT2X_HIP_CHECK(hipMemcpyAsync(oi.data(), di, n * 4, hipMemcpyDeviceToHost, stream));
+  CT2X_HIP_CHECK(hipMemcpyAsync(of.data(), df, n * 4, hipMemcpyDeviceToHost, stream));
+  CT2X_HIP_CHECK(hipMemcpyAsync(om.data(), dm, n * 4, hipMemcpyDeviceToHost, stream));
+  CT2X_HIP_CHECK(hipMemcpyAsync(og.data(), dg, og.size() * 4, hipMemcpyDeviceToHost, stream));
+  CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+  for (int i = 0; i < n; ++i) {
+    int64_t si = 0;
+    float sf = 0.f, mx = -3.4e38f;
+    for (int r = 0; r < world; ++r) {
+      si += vi(i, r);
+      sf += vf(i, r);  // (quarter-integers below 2^10: every partial sum is exact in any order)
+      mx = std::max(mx, vf(i, r));
+    }
+    CT2X_CHECK(oi[i] == static_cast<int32_t>(si), "all-reduce (int32 sum) differs at element " + std::to_string(i));
+    CT2X_CHECK(of[i] == sf, "all-reduce (float sum) differs at element " + std::to_string(i));
+    CT2X_CHECK(om[i] == mx, "all-reduce (float max) differs at element " + std::to_string(i));
+    for (int r = 0; r < world; ++r)
+      CT2X_CHECK(og[static_cast<size_t>(r) * n + i] == vi(i, r),
+                 "all-gather differs at rank " + std::to_string(r) + " element " + std::to_string(i));
+  }
+  for (void* ptr : {static_cast<void*>(di), static_cast<void*>(df), static_cast<void*>(dm), static_cast<void*>(dg)})
+    device_free(ptr);
+  if (mailboxes_out) *mailboxes_out = comm->peer_box() != nullptr ? 1 : 0;
+  if (us_per_dense_out) *us_per_dense_out = 0.f;
+  if (comm->peer_box() != nullptr) {
+    // one row-parallel int8 Dense at decode size: x [rows, world * depth] split by columns over the
+    // ranks, partial_r [rows, n] = (r + 1) * pattern
+    const TpPeerBox& pb = *comm->peer_box();
+    const int64_t rows = 32, depth = 256, nn = 512;
+    std::vector<float> hx(static_cast<size_t>(rows) * world * depth);
+    for (size_t i = 0; i < hx.size(); ++i)
+      hx[i] = static_cast<float>(static_cast<int>((i * 2654435761u) % 2001) - 1000) / 37.f;
+    std::vector<float> h_ws(nn), h_bias(nn);
+    for (int64_t j = 0; j < nn; ++j) {
+      h_ws[j] = 50.f + static_cast<float>(j % 97);
+      h_bias[j] = static_cast<float>(j % 13) * 0.01f;
+    }
+    std::vector<float> xs(static_cast<size_t>(rows) * depth);
+    for (int64_t i = 0; i < rows; ++i)
+      for (int64_t j = 0; j < depth; ++j) xs[i * depth + j] = hx[(i * world + rank) * depth + j];
+    auto pattern = [](size_t i, int r) { return (r + 1) * (static_cast<int32_t>(i % 1999) - 1000); };
+    std::vector<int32_t> part(static_cast<size_t>(rows) * nn);
+    for (size_t i = 0; i < part.size(); ++i) part[i] = pattern(i, rank);
+    auto* dx = static_cast<float*>(device_malloc(xs.size() * 4));
+    auto* dq = static_cast<int8_t*>(device_malloc(xs.size()));
+    auto* ds = static_cast<float*>(device_malloc(rows * 4));
+    auto* dp = static_cast<int32_t*>(device_malloc(part.size() * 4));
+    auto* dy = static_cast<float*>(device_malloc(part.size() * 4));
+    auto* dws = static_cast<float*>(device_malloc(nn * 4));
+    auto* dbias = static_cast<float*>(device_malloc(nn * 4));
+    CT2X_HIP_CHECK(hipMemcpyAsync(dx, xs.data(), xs.size() * 4, hipMemcpyHostToDevice, stream));
+    CT2X_HIP_CHECK(hipMemcpyAsync(dp, part.data(), part.size() * 4, hipMemcpyHostToDevice, stream));
+    CT2X_HIP_CHECK(hipMemcpyAsync(dws, h_ws.data(), nn * 4, hipMemcpyHostToDevice, stream));
+    CT2X_HIP_CHECK(hipMemcpyAsync(dbias, h_bias.data(), nn * 4, hipMemcpyHostToDevice, stream));
+    launch_tp_amax_quantize(pb, dx, rows, depth, 3, dq, ds, stream);
+    launch_tp_sum_dequant(pb, dp, ds, dws, dbias, nullptr, rows, nn, dy, stream);
+    std::vector<float> y(part.size()), scales(rows);
+    std::vector<int8_t> q(xs.size());
+    CT2X_HIP_CHECK(hipMemcpyAsync(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost, stream));
+    CT2X_HIP_CHECK(hipMemcpyAsync(q.data(), dq, q.size(), hipMemcpyDeviceToHost, stream));
+    CT2X_HIP_CHECK(hipMemcpyAsync(scales.data(), ds, rows * 4, hipMemcpyDeviceToHost, stream));
+    CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+    const int iters = 50;
+    hipEvent_t e0, e1;
+    CT2X_HIP_CHECK(hipEventCreate(&e0));
+    CT2X_HIP_CHECK(hipEventCreate(&e1));
+    CT2X_HIP_CHECK(hipEventRecord(e0, stream));
+    for (int it = 0; it < iters; ++it) {
+      launch_tp_amax_quantize(pb, dx, rows, depth, 3, dq, ds, stream);
+      launch_tp_sum_dequant(pb, dp, ds, dws, dbias, nullptr, rows, nn, dy, stream);
+    }
+    CT2X_HIP_CHECK(hipEventRecord(e1, stream));
+    CT2X_HIP_CHECK(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    CT2X_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (us_per_dense_out) *us_per_dense_out = ms * 1e3f / static_cast<float>(iters);
+    TpBoxControl ctl;
+    CT2X_HIP_CHECK(hipMemcpy(&ctl, pb.box[rank], sizeof(ctl), hipMemcpyDeviceToHost));
+    CT2X_CHECK(ctl.status == 0, "a poll of the one-shot exchange gave up (a peer never arrived)");
+    // what the whole row gives (ops::Quantize with the u8 shift and rounding = mode 3, then the
+    // Dequantize of the summed products: src/cpu/kernels.cc:577-680)
+    for (int64_t i = 0; i < rows; ++i) {
+      float amax = 0.f;
+      for (int64_t j = 0; j < world * depth; ++j) amax = std::max(amax, std::fabs(hx[i * world * depth + j]));
+      const float scale = amax != 0.f ? 127.f / amax : 1.f;
+      CT2X_CHECK(scales[i] == scale, "one-shot exchange: quantisation scale of row " + std::to_string(i));
+      for (int64_t j = 0; j < depth; ++j) {
+        const float v = std::nearbyint(std::fma(xs[i * depth + j], scale, 128.f));
+        const int8_t want = static_cast<int8_t>((static_cast<int>(v) & 0xff) - 128);
+        CT2X_CHECK(q[i * depth + j] == want, "one-shot exchange: quantised value differs");
+      }
+      for (int64_t j = 0; j < nn; ++j) {
+        int64_t sum = 0;
+        for (int r = 0; r < world; ++r) sum += pattern(static_cast<size_t>(i * nn + j), r);
+        float v = static_cast<float>(static_cast<int32_t>(sum)) * (1.f / scale);
+        v = v / h_ws[j];
+        v = v + h_bias[j];
+        CT2X_CHECK(y[i * nn + j] == v, "one-shot exchange: dequantised sum differs at row " + std::to_string(i));
+      }
+    }
+    for (void* ptr : {static_cast<void*>(dx), static_cast<void*>(dq), static_cast<void*>(ds), static_cast<void*>(dp),
+                      static_cast<void*>(dy), static_cast<void*>(dws), static_cast<void*>(dbias)})
+      device_free(ptr);
+  }
+  API_CATCH
+}
+
 int ct2x_tp_selftest_oneshot(int device_index, int world, int64_t rows, int64_t depth, int64_t n,
                              int iters, float* us_per_dense_out) {
   API_TRY

@@ -3,6 +3,7 @@
 // sampled id to the next step and appending it to a device-resident history.
 
 #include "device_utils.h"
+#include "grid_sync.h"
 #include "kernels.h"
 #include "runtime.h"
 
@@ -786,14 +787,27 @@ struct BeamBias {
   const uint8_t* diverged;  // [batch * beam]
 };
 
+constexpr int kBeamCandCap = 256;  // candidates of a row's top k the list in LDS holds (beam_logprobs_kernel)
+// maximum of a wave, any lane count, every lane gets it
+__device__ __forceinline__ float wave_max_any(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
                                      const float* __restrict__ beam_scores, int64_t vocab,
                                      int32_t disable_id, int32_t min_length,
                                      const int32_t* __restrict__ step_ptr,
                                      const int32_t* __restrict__ extra_min, int32_t beam,
-                                     int chain_pad, float* __restrict__ y, int fast, BeamBias bias) {
+                                     int chain_pad, float* __restrict__ y, int fast, BeamBias bias,
+                                     float* __restrict__ part_v, int32_t* __restrict__ part_i, int topk) {
   extern __shared__ __attribute__((aligned(16))) float exp_lds[];
   __shared__ float scratch[16];
+  __shared__ int scratch_i[16];
+  __shared__ float cand_v[kBeamCandCap];
+  __shared__ int cand_i[kBeamCandCap];
+  __shared__ int cand_count;
   const int64_t row = blockIdx.x;
   const int step = *step_ptr;
   // apply_min_length with a hidden prefix (src/decoding.cc:384-408): EOS stays disabled
@@ -862,6 +876,139 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
     __syncthreads();
     const float c = -m - logf_glibc(scratch[0]);
     const float b = beam_scores ? beam_scores[row] : 0.f;
+    if (part_v != nullptr) {
+      // Round 6: the row's 2 * beam best scores leave as CANDIDATES instead of the row (TopK over
+      // [beam * vocab] of a batch entry, src/decoding.cc:559-563: every member of the entry's top k
+      // is in the top k of its own row): same values y = b + (x + c), same total order (value
+      // descending, flat index ascending) as topk_partial / topk_merge - the 16 MB row-wide write
+      // and its two re-reads disappear. The merge over the entry's rows rides in beam_select_kernel.
+      const float ninf = -__builtin_huge_valf();
+      unsigned alive = 0;
+#pragma unroll
+      for (int u = 0; u < XR; ++u) {
+        const int64_t j = threadIdx.x + static_cast<int64_t>(u) * blockDim.x;
+        if (j < vocab) {
+          const float v = xv[u] + c;
+          xv[u] = beam_scores ? b + v : v;
+          alive |= 1u << u;
+        }
+      }
+      const int flat0 = static_cast<int>((row % beam) * vocab) + static_cast<int>(threadIdx.x);
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int nwaves = (blockDim.x + 63) >> 6;
+      // (1) a bound: the topk-th largest of the waves' maxima has topk elements of the row at or
+      // above it (one per wave), so nothing below it is in the row's top k. (2) the few elements
+      // at or above the bound are listed in LDS. (3) one wave picks the top k of the list in the
+      // exact order. A first form - topk rounds of block arg-max over the 32 registers of all 1024
+      // threads - cost as much as the launches it replaced (profiles/r06_beam_fused_ab.txt).
+      float tmax = ninf;
+#pragma unroll
+      for (int u = 0; u < XR; ++u)
+        if ((alive >> u) & 1u) tmax = fmaxf(tmax, xv[u]);
+      tmax = wave_max_any(tmax);
+      __syncthreads();  // (scratch held the row sum)
+      if (lane == 0) scratch[wave] = tmax;
+      if (threadIdx.x == 0) cand_count = 0;
+      __syncthreads();
+      float bound = ninf;
+      {
+        float wm = lane < nwaves ? scratch[lane] : ninf;
+        for (int r = 0; r < topk; ++r) {
+          bound = wave_max_any(wm);
+          // retire ONE lane that holds the maximum (the lowest)
+          const unsigned long long holders = __builtin_amdgcn_ballot_w64(wm == bound);
+          if (holders != 0 && lane == __builtin_ctzll(holders)) wm = ninf;
+        }
+        if (nwaves < topk) bound = ninf;
+      }
+#pragma unroll
+      for (int u = 0; u < XR; ++u)
+        if (((alive >> u) & 1u) && xv[u] >= bound) {
+          const int pos = atomicAdd(&cand_count, 1);
+          if (pos < kBeamCandCap) {
+            cand_v[pos] = xv[u];
+            cand_i[pos] = flat0 + u * static_cast<int>(blockDim.x);
+          }
+        }
+      __syncthreads();
+      const int n = cand_count;
+      if (n <= kBeamCandCap) {
+        if (wave == 0) {
+          constexpr int PER = kBeamCandCap / 64;
+          float lv[PER];
+          int li[PER];
+#pragma unroll
+          for (int e = 0; e < PER; ++e) {
+            const int at = lane + e * 64;
+            li[e] = at < n ? cand_i[at] : INT_MAX;
+            lv[e] = at < n ? cand_v[at] : ninf;
+          }
+          for (int r = 0; r < topk; ++r) {
+            ValIdx best;
+            best.v = ninf;
+            best.i = INT_MAX;
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+              if (li[e] != INT_MAX && (best.i == INT_MAX || lv[e] > best.v || (lv[e] == best.v && li[e] < best.i))) {
+                best.v = lv[e];
+                best.i = li[e];
+              }
+            if (best.i == INT_MAX) best.v = ninf;
+            const ValIdx w = wave_argmax_dpp(best);
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+              if (li[e] == w.i) {  // retired (flat indices are unique; INT_MAX stays empty)
+                li[e] = INT_MAX;
+                lv[e] = ninf;
+              }
+            if (lane == 0) {
+              part_v[row * topk + r] = w.v;
+              part_i[row * topk + r] = w.i;
+            }
+          }
+        }
+        return;
+      }
+      // (more ties at the bound than the list holds: the plain rounds over the registers)
+      for (int r = 0; r < topk; ++r) {
+        ValIdx best;
+        best.v = ninf;
+        best.i = INT_MAX;
+#pragma unroll
+        for (int u = 0; u < XR; ++u)  // (ascending index: a strict compare keeps the first of equals)
+          if (((alive >> u) & 1u) && (best.i == INT_MAX || xv[u] > best.v)) {
+            best.v = xv[u];
+            best.i = flat0 + u * static_cast<int>(blockDim.x);
+          }
+        if (best.i == INT_MAX) best.v = ninf;
+        best = wave_argmax_dpp(best);
+        __syncthreads();
+        if (lane == 0) {
+          scratch[wave] = best.v;
+          scratch_i[wave] = best.i;
+        }
+        __syncthreads();
+        ValIdx w;
+        w.v = scratch[0];
+        w.i = scratch_i[0];
+        for (int q = 1; q < nwaves; ++q) {
+          const float v = scratch[q];
+          const int i = scratch_i[q];
+          if (v > w.v || (v == w.v && i < w.i)) {
+            w.v = v;
+            w.i = i;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < XR; ++u)
+          if (flat0 + u * static_cast<int>(blockDim.x) == w.i) alive &= ~(1u << u);  // retired
+        if (threadIdx.x == 0) {
+          part_v[row * topk + r] = w.v;
+          part_i[row * topk + r] = w.i;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < XR; ++u) {
       const int64_t j = threadIdx.x + static_cast<int64_t>(u) * blockDim.x;
@@ -915,10 +1062,14 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
                           const int32_t* step_ptr, float* y, hipStream_t stream,
                           const int32_t* extra_min_per_batch, int32_t beam, bool exact,
                           const int32_t* bias_ids, const int32_t* bias_lens, int32_t bias_stride,
-                          int32_t bias_first_step, float bias_beta, const uint8_t* diverged) {
+                          int32_t bias_first_step, float bias_beta, const uint8_t* diverged,
+                          float* part_v, int32_t* part_i, int32_t topk) {
   if (rows == 0) return;
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
+  CT2X_CHECK(part_v == nullptr || (beam_logprobs_topk_applicable(vocab, exact, beam > 0 ? beam : 1, topk) &&
+                                   !(bias_beta > 0.f)),
+             "beam_logprobs: the fused candidates need the exact one-read form");
   const BeamBias bias{bias_beta > 0.f ? bias_ids : nullptr, bias_lens, bias_stride, bias_first_step,
                       bias_beta, diverged};
   const ExpSumLayout el = exp_sum_layout(vocab);
@@ -926,7 +1077,17 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
   allow_big_lds(reinterpret_cast<const void*>(beam_logprobs_kernel), lds);
   hipLaunchKernelGGL(beam_logprobs_kernel, dim3(rows), dim3(block), lds, stream, logits,
                      beam_scores, vocab, disable_id, min_length, step_ptr, extra_min_per_batch,
-                     beam > 0 ? beam : 1, el.chain_pad, y, exact ? 0 : 1, bias);
+                     beam > 0 ? beam : 1, el.chain_pad, y, exact ? 0 : 1, bias, part_v, part_i, topk);
+}
+
+// The fused candidates exist where beam_logprobs_kernel keeps the row in registers (the exact
+// LogSoftMax of the 32-bit compute types, vocabularies of up to 32 x 1024 words) and the entry's
+// beam x topk candidates fit the one wave of beam_select_kernel.
+bool beam_logprobs_topk_applicable(int64_t vocab, bool exact, int32_t beam, int32_t topk) {
+  int block = 64;
+  while (block < vocab / 4 && block < 1024) block <<= 1;
+  return exact && exp_sum_layout(vocab).chain_pad > 0 && vocab <= 32 * static_cast<int64_t>(block) &&
+         topk >= 1 && static_cast<int64_t>(beam) * topk <= 64 && static_cast<int64_t>(beam) * vocab < INT_MAX;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -969,6 +1130,15 @@ struct BeamSelectParams {
   // candidate at position k has left it (get_beams_divergence_from_prefix, src/decoding.cc:325-342 -
   // the reference keeps the flag per POSITION, not per origin beam; reproduced as is)
   uint8_t* diverged;
+  // round 6: per-row candidates of beam_logprobs_kernel, [batch, n_part = beam * 2 * beam] (value,
+  // flat index), merged here (nullptr: topk_scores / topk_ids hold the entry's TopK already)
+  const float* part_v;
+  const int32_t* part_i;
+  int32_t n_part;
+  // round 6: the step counter advances in this launch - by the LAST workgroup to finish, every
+  // other one has read it by then (nullptr: a launch of its own follows)
+  int32_t* advance_step;
+  unsigned* ticket;
 };
 
 __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelectParams p) {
@@ -980,10 +1150,31 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelectParams p) {
   const bool biased = p.diverged != nullptr;
   const int plen_given = p.prefix_ids ? p.prefix_lens[b] : 0;
   const int plen = biased ? 0 : plen_given;  // (use_hard_prefix == false: no forced tokens)
+  // TopK over the entry's flattened [beam * vocab] scores from the rows' candidates: nc rounds of
+  // wave arg-max, (value descending, flat index ascending) as topk_merge_kernel; lane r keeps the
+  // r-th best.
+  float merged_v = -FLT_MAX;
+  int32_t merged_i = 0;
+  if (p.part_v != nullptr) {
+    ValIdx c;
+    c.i = j < p.n_part ? p.part_i[b * p.n_part + j] : INT_MAX;
+    c.v = (j < p.n_part && c.i != INT_MAX) ? p.part_v[b * p.n_part + j] : -__builtin_huge_valf();
+    for (int r = 0; r < nc; ++r) {
+      const ValIdx w = wave_argmax_dpp(c);
+      if (w.i != INT_MAX && c.i == w.i) {  // retired (flat indices are unique)
+        c.i = INT_MAX;
+        c.v = -__builtin_huge_valf();
+      }
+      if (j == r && w.i != INT_MAX) {      // (fewer than nc candidates: -FLT_MAX / 0 as topk_merge_kernel)
+        merged_v = w.v;
+        merged_i = w.i;
+      }
+    }
+  }
   if (j < nc) {
-    const int32_t flat = p.topk_ids[b * nc + j];
+    const int32_t flat = p.part_v != nullptr ? merged_i : p.topk_ids[b * nc + j];
     int32_t origin = flat / p.vocab, word = flat % p.vocab;   // unflatten_ids, :95-116
-    float sc = p.topk_scores[b * nc + j];
+    float sc = p.part_v != nullptr ? merged_v : p.topk_scores[b * nc + j];
     if (p.prefix_ids && !biased && step <= plen) {
       if (step < plen) {        // inside the prefix: every candidate is the prefix token
         word = p.prefix_ids[b * p.prefix_stride + step];
@@ -1056,6 +1247,10 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelectParams p) {
       if (j == 0 && step < p.seq_stride) dst[step] = s_word[c];
     }
   }
+  if (p.advance_step != nullptr && grid_last_arrival(p.ticket, gridDim.x) && j == 0) {
+    *p.advance_step = *p.advance_step + 1;
+    __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (graph replays)
+  }
 }
 
 void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64_t batch,
@@ -1065,12 +1260,16 @@ void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64
                         int32_t* hist_origin, int32_t* next_ids, int32_t* parents,
                         float* beam_scores, const int32_t* seq_src, int32_t* seq_dst,
                         int32_t seq_stride, hipStream_t stream, const int32_t* ancestry_src,
-                        int32_t* ancestry_dst, uint8_t* diverged) {
+                        int32_t* ancestry_dst, uint8_t* diverged, const float* part_v,
+                        const int32_t* part_i, int32_t n_part, int32_t* advance_step, unsigned* ticket) {
   if (batch == 0) return;
+  CT2X_CHECK(part_v == nullptr || (n_part >= 1 && n_part <= 64), "beam_select: at most 64 candidates to merge");
+  CT2X_CHECK(advance_step == nullptr || ticket != nullptr, "beam_select: the advance needs its ticket");
   const BeamSelectParams p{topk_scores, topk_ids, beam, static_cast<int32_t>(vocab), eos, prefix_ids,
                            prefix_lens, prefix_stride, step_ptr, first_step, hist_word, hist_score,
                            hist_origin, next_ids, parents, beam_scores, seq_src, seq_dst, seq_stride,
-                           ancestry_src, ancestry_dst, diverged};
+                           ancestry_src, ancestry_dst, diverged, part_v, part_i, n_part, advance_step,
+                           ticket};
   hipLaunchKernelGGL(beam_select_kernel, dim3(batch), dim3(64), 0, stream, p);
 }
 

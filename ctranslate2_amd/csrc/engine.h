@@ -679,6 +679,11 @@ struct DecodeState {
   float* cl_xch = nullptr;
   unsigned* cl_counters = nullptr;
   size_t cl_xch_floats = 0, cl_counter_words = 0;
+  // beam search, round 6: per-row candidates of the fused LogSoftMax + TopK ([rows, 2 * beam]) and the
+  // ticket of the step advance that rides in beam_select_kernel (nullptr: the separate launches)
+  float* bt_part_v = nullptr;
+  int32_t* bt_part_i = nullptr;
+  unsigned* bt_ticket = nullptr;
   // Only a decoding loop that holds the device's gate (ClusterLease) runs the launch; every other
   // caller of Engine::step (scoring, step_logits, the alternatives' pre-step) and a session that
   // did not get the gate take the launch-per-op step.

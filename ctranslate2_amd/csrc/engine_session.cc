@@ -180,6 +180,18 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     st->topk_ids = alloc<int32_t>(*st, batch * 2 * beam);
     st->d_parents = alloc<int32_t>(*st, rows);
     CT2X_CHECK(2 * beam <= 64, "beam_size must be <= 32");
+    // CT2X_BEAM_FUSED_TOPK=0: LogSoftMax, TopK (two launches) and the step advance as launches of their own (A/B)
+    static const bool fused_topk = [] {
+      const char* e = std::getenv("CT2X_BEAM_FUSED_TOPK");
+      return e == nullptr || e[0] != '0';
+    }();
+    if (fused_topk && beam_logprobs_topk_applicable(V, !half_compute(), static_cast<int32_t>(beam),
+                                                    static_cast<int32_t>(2 * beam))) {
+      st->bt_part_v = alloc<float>(*st, rows * 2 * beam);
+      st->bt_part_i = alloc<int32_t>(*st, rows * 2 * beam);
+      st->bt_ticket = alloc<unsigned>(*st, 1);
+      CT2X_HIP_CHECK(hipMemsetAsync(st->bt_ticket, 0, sizeof(unsigned), cur_stream()));
+    }
     st->topk_ws_bytes = topk_workspace_bytes(batch, beam * V, 2 * beam);
     if (st->topk_ws_bytes) st->topk_ws = alloc<char>(*st, static_cast<int64_t>(st->topk_ws_bytes));
     const int64_t cand = (t_max + 1) * batch * 2 * beam;

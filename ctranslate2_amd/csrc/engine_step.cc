@@ -498,18 +498,27 @@ void Engine::launch_step(DecodeState& st) {
       launch_whisper_rules(wp, cur_stream());
       end_kernel();
     }
-    begin_kernel("beam_logprobs", double(st.rows) * V * 12, 0, st.rows, 0, V);
+    // Round 6: where the LogSoftMax keeps the row in registers its 2 * beam best leave as candidates
+    // (no row-wide write), their merge and the step advance ride in beam_select: 6 launches -> 3
+    // after the projection. (Biased decoding rewrites rows on another path: the separate launches.)
+    const float bias_beta = st.d_bprefix ? st.bias_beta : 0.f;
+    const bool fused_topk = st.bt_part_v != nullptr && !(bias_beta > 0.f);
+    const int32_t cand = static_cast<int32_t>(2 * st.beam);
+    begin_kernel("beam_logprobs", double(st.rows) * V * (fused_topk ? 4 : 12), 0, st.rows, 0, V);
     launch_beam_logprobs(st.logits, st.beam_scores, st.rows, V, st.g_eos, st.g_min_length,
                          st.d_step, st.logprobs, cur_stream(),
                          st.prefix_extends_min ? st.d_bprefix_len : nullptr,
                          static_cast<int32_t>(st.beam), !half_compute(), st.d_bprefix, st.d_bprefix_len,
-                         st.bprefix_stride, st.prefix_first_step, st.d_bprefix ? st.bias_beta : 0.f,
-                         st.d_diverged);
+                         st.bprefix_stride, st.prefix_first_step, bias_beta, st.d_diverged,
+                         fused_topk ? st.bt_part_v : nullptr, fused_topk ? st.bt_part_i : nullptr,
+                         fused_topk ? cand : 0);
     end_kernel();
-    begin_kernel("beam_topk", double(st.rows) * V * 4, 0, st.batch, 2 * st.beam, st.beam * V);
-    launch_topk(st.logprobs, st.batch, st.beam * V, 2 * st.beam, st.topk_scores, st.topk_ids,
-                cur_stream(), st.topk_ws, st.topk_ws_bytes);
-    end_kernel();
+    if (!fused_topk) {
+      begin_kernel("beam_topk", double(st.rows) * V * 4, 0, st.batch, 2 * st.beam, st.beam * V);
+      launch_topk(st.logprobs, st.batch, st.beam * V, 2 * st.beam, st.topk_scores, st.topk_ids,
+                  cur_stream(), st.topk_ws, st.topk_ws_bytes);
+      end_kernel();
+    }
     begin_kernel("beam_select");
     launch_beam_select(st.topk_scores, st.topk_ids, st.batch, static_cast<int32_t>(st.beam), V,
                        st.g_eos, st.d_bprefix, st.d_bprefix_len, st.bprefix_stride, st.d_step,
@@ -519,12 +528,17 @@ void Engine::launch_step(DecodeState& st) {
                        (st.lp_active || st.wh_active) ? st.alive_seq[par ^ 1] : nullptr,
                        static_cast<int32_t>(st.t_max), cur_stream(),
                        st.ancestry ? st.anc[par] : nullptr, st.ancestry ? st.anc[par ^ 1] : nullptr,
-                       (st.d_bprefix && st.bias_beta > 0.f) ? st.d_diverged : nullptr);
+                       (st.d_bprefix && st.bias_beta > 0.f) ? st.d_diverged : nullptr,
+                       fused_topk ? st.bt_part_v : nullptr, fused_topk ? st.bt_part_i : nullptr,
+                       fused_topk ? static_cast<int32_t>(st.beam) * cand : 0,
+                       fused_topk ? st.d_step : nullptr, fused_topk ? st.bt_ticket : nullptr);
     end_kernel();
     // Positions [0, step] are live; the gather copies the positions below the advanced counter.
-    begin_kernel("advance_step");
-    launch_advance_step(st.d_step, cur_stream());
-    end_kernel();
+    if (!fused_topk) {
+      begin_kernel("advance_step");
+      launch_advance_step(st.d_step, cur_stream());
+      end_kernel();
+    }
     if (!st.ancestry) {
       const AttnW& a0 = dec_.layers.front().self;
       const int n_tensors = static_cast<int>(2 * dec_.layers.size());

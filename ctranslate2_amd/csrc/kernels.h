@@ -581,7 +581,13 @@ void launch_beam_select(const float* topk_scores, const int32_t* topk_ids, int64
                         float* beam_scores, const int32_t* seq_src, int32_t* seq_dst,
                         int32_t seq_stride, hipStream_t stream,
                         const int32_t* ancestry_src = nullptr, int32_t* ancestry_dst = nullptr,
-                        uint8_t* diverged = nullptr /* biased decoding: [batch * beam] flags */);
+                        uint8_t* diverged = nullptr /* biased decoding: [batch * beam] flags */,
+                        // round 6: merge the rows' candidates of launch_beam_logprobs here
+                        // ([batch, n_part] with n_part = beam * 2 * beam <= 64) instead of reading
+                        // topk_scores / topk_ids; advance *advance_step by one when the last
+                        // workgroup finishes (ticket: one zeroed word, left zero)
+                        const float* part_v = nullptr, const int32_t* part_i = nullptr,
+                        int32_t n_part = 0, int32_t* advance_step = nullptr, unsigned* ticket = nullptr);
 
 // return_attention: out[*step_ptr][row][0 .. s_max) = mean over the first align_heads heads of
 // softmax(q . k * scale) against the projected memory keys (decode_ops.hip).
@@ -603,7 +609,12 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
                           // biased decoding (BiasedDecoder, src/decoding.cc:256-323): bias_beta > 0
                           const int32_t* bias_ids = nullptr, const int32_t* bias_lens = nullptr,
                           int32_t bias_stride = 0, int32_t bias_first_step = 0, float bias_beta = 0.f,
-                          const uint8_t* diverged = nullptr);
+                          const uint8_t* diverged = nullptr,
+                          // round 6 (beam_logprobs_topk_applicable): the row's `topk` best scores as
+                          // candidates part_v / part_i [rows, topk] (flat index (row % beam) * vocab +
+                          // word) INSTEAD of the row y (which is then not written)
+                          float* part_v = nullptr, int32_t* part_i = nullptr, int32_t topk = 0);
+bool beam_logprobs_topk_applicable(int64_t vocab, bool exact, int32_t beam, int32_t topk);
 
 }  // namespace ct2x
 

@@ -4,7 +4,7 @@
 // their vector and scalar forms, the batch / depth / block broadcasts, fill / strided_fill /
 // indexed_fill, the unary float functions, transpose_2d/3d/4d and prepare_length_mask. The fused
 // engine uses none of them (the work is folded into its kernels); they exist so that the Level-1
-// stubs (tests/integration/ops_mi355_stub.cc, BOUNDARY.md) cover what a maintainer's op-by-op
+// stubs (integration/ops_mi355_stub.cc, BOUNDARY.md) cover what a maintainer's op-by-op
 // build links against. All of them are plain HBM-bound scans: one element per lane and
 // grid-stride step, consecutive lanes on consecutive addresses.
 #include <algorithm>

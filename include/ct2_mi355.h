@@ -681,6 +681,15 @@ int ct2x_tp_selftest_local(int device_index, int world);
  * pairs timed; *us_per_dense_out = microseconds per (absmax exchange + sum exchange), worst rank. */
 int ct2x_tp_selftest_oneshot(int device_index, int world, int64_t rows, int64_t depth, int64_t n,
                              int iters, float* us_per_dense_out);
+/* The same checks across REAL ranks, one process per GPU (round 6): every rank calls it with its
+ * own device and rank and either the RCCL unique id of rank 0 or the name of a shared-memory
+ * segment (the two ways ct2x_translator_create_tp / _tp_shm connect). All-reduce (int32 sum,
+ * float sum, float max) and all-gather on rank-dependent data with closed-form results, then - if
+ * the communicator has peer-mapped mailboxes (*mailboxes_out) - the one-shot exchanges of a
+ * row-parallel int8 Dense checked bit for bit against the whole row, 50 pairs timed
+ * (*us_per_dense_out). `bench.py --gpus N` runs it before its timed region. */
+int ct2x_tp_selftest_multi(int device_index, int rank, int world, const void* unique_id_128_bytes,
+                           const char* shm_segment_name, int32_t* mailboxes_out, float* us_per_dense_out);
 int ct2x_translator_create_tp_local(const char* model_dir, int device_index,
                                     const char* compute_type, int world, void** handles_out);
 

@@ -5,7 +5,7 @@
 // SURVEY section 8 (so that a call fails loudly instead of at symbol resolution), and the
 // cuda:: helper set of src/cuda/utils.h:98-134 / src/cuda/random.h that devices.cc, types.cc,
 // utils.cc and models/model.cc call. Compiled by a plain host compiler against the reference's
-// real headers plus tests/integration/shim_cuda/ (the CUDA runtime NAMES those headers leak);
+// real headers plus integration/shim_cuda/ (the CUDA runtime NAMES those headers leak);
 // everything lands on the C ABI of include/ct2_mi355.h. Written for this repository.
 #include <cstring>
 #include <mutex>

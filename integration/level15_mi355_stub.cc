@@ -16,13 +16,20 @@
 //
 // The subclass hands the model it finds in the reference's memory (already converted to the compute
 // type by Model::load) to ct2x_translator_create_from_memory once per (model, device), and serves
-// every call whose options the fused engine implements with the reference's own semantics; anything
-// else - target prefixes, vocabulary maps, return_attention, callbacks, sampling, custom end tokens,
-// several source features - falls through to the reference's own op-by-op path unchanged.
-// CT2X_LEVEL1_FUSED=0 sends every call there (A/B: tools/level1_speed.py).
+// every call whose options the fused engine implements with the reference's own semantics. Round 6:
+// that is the whole of TranslationOptions - target prefixes (hard, or a bias with
+// prefix_bias_beta), random sampling, return_attention, replace_unknowns, the step callback,
+// num_hypotheses / return_alternatives, a custom end token, return_logits_vocab of a greedy search.
+// What still falls through to the reference's own op-by-op path, unchanged: a vocabulary map
+// (use_vmap with a map loaded), SEVERAL end tokens, return_logits_vocab under beam search, decoder
+// start tokens given by the user, several source features, tensor parallelism.
+// CT2X_LEVEL1_FUSED=0 sends every call there (A/B: tools/level1_speed.py);
+// CT2X_LEVEL15_REPORT=<file> writes "served <n> fallback <m>" when the process ends.
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -124,6 +131,55 @@ namespace ctranslate2 {
       }
 
       std::atomic<int64_t> g_served_calls{0};
+      std::atomic<int64_t> g_fallback_calls{0};
+      std::atomic<uint32_t> g_sampling_calls{0};
+
+      struct ExitReport {
+        ~ExitReport() {
+          const char* path = std::getenv("CT2X_LEVEL15_REPORT");
+          if (path == nullptr || path[0] == 0) return;
+          if (FILE* f = std::fopen(path, "w")) {
+            std::fprintf(f, "served %lld fallback %lld\n", static_cast<long long>(g_served_calls.load()),
+                         static_cast<long long>(g_fallback_calls.load()));
+            std::fclose(f);
+          }
+        }
+      } g_exit_report;
+
+      // TranslationOptions / GenerationOptions::callback behind the C ABI's step callback
+      struct CallbackBridge {
+        const std::function<bool(GenerationStepResult)>* callback;
+        const Vocabulary* vocabulary;
+        std::exception_ptr error;  // an exception of the user's callable: rethrown after the call
+      };
+      int step_trampoline(void* user, int64_t step, int64_t batch_id, int64_t hypothesis_id, int32_t token_id,
+                          int32_t has_score, float score, int32_t is_last) {
+        auto* bridge = static_cast<CallbackBridge*>(user);
+        if (bridge->error) return 1;
+        try {
+          DecodingStepResult r;
+          r.step = static_cast<size_t>(step);
+          r.batch_id = static_cast<size_t>(batch_id);
+          r.token_id = static_cast<size_t>(token_id);
+          r.hypothesis_id = static_cast<size_t>(hypothesis_id);
+          if (has_score) r.score = score;
+          r.is_last = is_last != 0;
+          return (*bridge->callback)(GenerationStepResult(r, *bridge->vocabulary)) ? 1 : 0;
+        } catch (...) {  // must not unwind through the C frames
+          bridge->error = std::current_exception();
+          return 1;
+        }
+      }
+
+      // the options both front-ends share (sampling: the reference draws from a process-wide
+      // generator - here a counter-based one seeded per call, reproducible within a process)
+      template <typename Options>
+      void set_sampling(ct2x_translation_options& opt, const Options& options) {
+        opt.sampling_topk = options.sampling_topk == 0 ? -1 : static_cast<int32_t>(options.sampling_topk);
+        opt.sampling_topp = options.sampling_topp;
+        opt.sampling_temperature = options.sampling_temperature;
+        if (options.sampling_topk != 1) opt.seed = 0x9e3779b9u * (g_sampling_calls.fetch_add(1) + 1);
+      }
 
       bool fused_enabled() {
         static const bool on = [] {
@@ -144,8 +200,10 @@ namespace ctranslate2 {
       run_translation(const std::vector<std::vector<std::string>>& source,
                       const std::vector<std::vector<std::string>>& target_prefix,
                       const TranslationOptions& options) override {
-        if (!serves(source, target_prefix, options))
+        if (!serves(source, target_prefix, options)) {
+          ++g_fallback_calls;
           return EncoderDecoderReplica::run_translation(source, target_prefix, options);
+        }
         const auto& m = static_cast<const SequenceToSequenceModel&>(*model());
         const Vocabulary& src_vocab = m.get_source_vocabulary();
         const Vocabulary& tgt_vocab = m.get_target_vocabulary();
@@ -188,14 +246,66 @@ namespace ctranslate2 {
         opt.num_suppress_sequences = static_cast<int32_t>(sup_lengths.size());
         opt.suppress_ids = sup_ids.data();
         opt.suppress_lengths = sup_lengths.data();
+        set_sampling(opt, options);
+        opt.return_alternatives = options.return_alternatives ? 1 : 0;
+        opt.min_alternative_expansion_prob = options.min_alternative_expansion_prob;
+        opt.prefix_bias_beta = options.prefix_bias_beta;
+        // end_token (ResolveEndToken, include/ctranslate2/generation.h:135-162): one id (serves() checked)
+        const auto end_ids = std::visit(ResolveEndToken(tgt_vocab), options.end_token);
+        if (end_ids[0] != tgt_vocab.eos_id()) opt.end_token_plus_one = static_cast<int32_t>(end_ids[0]) + 1;
 
         const size_t nh = options.num_hypotheses, max_len = options.max_decoding_length;
+        // return_attention || replace_unknowns (src/models/sequence_to_sequence.cc:352): one vector per
+        // generated token over the RAW source positions (the engine drops the implicit BOS / EOS)
+        const bool want_attention = options.return_attention || options.replace_unknowns;
+        std::vector<float> attention;
+        if (want_attention) {
+          attention.assign(batch * nh * max_len * stride, 0.f);
+          opt.attention_stride = static_cast<int32_t>(stride);
+          opt.attention_out = attention.data();
+        }
+        CallbackBridge bridge{&options.callback, &tgt_vocab, nullptr};
+        if (options.callback) {
+          opt.step_callback = step_trampoline;
+          opt.step_callback_data = &bridge;
+        }
+        // return_logits_vocab (greedy search / sampling: serves() checked)
+        const size_t vocab_size = tgt_vocab.size();
+        std::vector<float> logits;
+        std::vector<int32_t> logits_counts;
+        if (options.return_logits_vocab) {
+          logits.resize(batch * nh * max_len * vocab_size);
+          logits_counts.assign(batch * nh, 0);
+          opt.logits_out = logits.data();
+          opt.logits_counts_out = logits_counts.data();
+          opt.logits_steps = static_cast<int32_t>(max_len);
+        }
+        // target_prefix (make_target_ids with is_prefix, :168-186): raw ids after the decoder start token
+        bool any_prefix = false;
+        for (const auto& prefix : target_prefix) any_prefix = any_prefix || !prefix.empty();
         std::vector<int32_t> out_ids(batch * nh * max_len), out_lengths(batch * nh);
         std::vector<float> out_scores(batch * nh);
-        if (ct2x_translate_batch(_handle->h, flat.data(), lengths.data(), static_cast<int32_t>(batch),
-                                 static_cast<int32_t>(stride), &opt, out_ids.data(), out_lengths.data(),
-                                 out_scores.data()) != 0)
-          throw std::runtime_error(std::string("MI355X fused engine: ") + ct2x_last_error());
+        int rc;
+        if (any_prefix) {
+          const auto pids = tgt_vocab.to_ids(target_prefix, 0, nullptr, nullptr);
+          size_t pstride = 1;
+          for (const auto& row : pids) pstride = std::max(pstride, row.size());
+          std::vector<int32_t> pflat(batch * pstride, 0), plengths(batch, 0);
+          for (size_t b = 0; b < pids.size() && b < batch; ++b) {
+            plengths[b] = static_cast<int32_t>(pids[b].size());
+            for (size_t i = 0; i < pids[b].size(); ++i) pflat[b * pstride + i] = static_cast<int32_t>(pids[b][i]);
+          }
+          rc = ct2x_translate_batch_prefix(_handle->h, flat.data(), lengths.data(), static_cast<int32_t>(batch),
+                                           static_cast<int32_t>(stride), pflat.data(), plengths.data(),
+                                           static_cast<int32_t>(pstride), &opt, out_ids.data(), out_lengths.data(),
+                                           out_scores.data());
+        } else {
+          rc = ct2x_translate_batch(_handle->h, flat.data(), lengths.data(), static_cast<int32_t>(batch),
+                                    static_cast<int32_t>(stride), &opt, out_ids.data(), out_lengths.data(),
+                                    out_scores.data());
+        }
+        if (bridge.error) std::rethrow_exception(bridge.error);
+        if (rc != 0) throw std::runtime_error(std::string("MI355X fused engine: ") + ct2x_last_error());
         ++g_served_calls;
 
         std::vector<TranslationResult> results;
@@ -203,16 +313,44 @@ namespace ctranslate2 {
         for (size_t b = 0; b < batch; ++b) {
           std::vector<std::vector<size_t>> hyp_ids;
           std::vector<float> scores;
+          std::vector<std::vector<std::vector<float>>> att;
+          std::vector<std::vector<StorageView>> hyp_logits;
           for (size_t h = 0; h < nh; ++h) {
             const int32_t len = out_lengths[b * nh + h];
-            if (len < 0) continue;  // (fewer hypotheses than asked for)
+            // (fewer hypotheses than asked for: -1 from decode_alternatives, an empty one past the first otherwise)
+            if (len < 0 || (!options.return_alternatives && h > 0 && len == 0)) continue;
             const int32_t* row = out_ids.data() + (b * nh + h) * max_len;
             hyp_ids.emplace_back(row, row + len);
             if (options.return_scores) scores.push_back(out_scores[b * nh + h]);
+            if (want_attention) {
+              // (:395-407: the vector covers the original input, zero past what the encoder saw)
+              att.emplace_back();
+              for (int32_t t = 0; t < len; ++t) {
+                const float* a = attention.data() + ((b * nh + h) * max_len + t) * stride;
+                std::vector<float> v(source[b].size(), 0.f);
+                std::copy(a, a + std::min<size_t>(v.size(), static_cast<size_t>(lengths[b])), v.begin());
+                att.back().push_back(std::move(v));
+              }
+            }
+            if (options.return_logits_vocab) {
+              hyp_logits.emplace_back();
+              for (int32_t t = 0; t < logits_counts[b * nh + h]; ++t) {
+                const float* l = logits.data() + ((b * nh + h) * max_len + t) * vocab_size;
+                hyp_logits.back().emplace_back(Shape{static_cast<dim_t>(vocab_size)},
+                                               std::vector<float>(l, l + vocab_size));
+              }
+            }
           }
-          results.emplace_back(tgt_vocab.to_tokens(hyp_ids), std::move(scores),
-                               std::vector<std::vector<std::vector<float>>>(),
-                               std::vector<std::vector<StorageView>>());
+          auto hypotheses = tgt_vocab.to_tokens(hyp_ids);
+          if (options.replace_unknowns) {  // replace_unknown_tokens (:288-302): first maximum
+            for (size_t h = 0; h < hypotheses.size(); ++h)
+              for (size_t t = 0; t < hypotheses[h].size() && t < att[h].size(); ++t)
+                if (hypotheses[h][t] == tgt_vocab.unk_token() && !att[h][t].empty())
+                  hypotheses[h][t] = source[b][std::distance(att[h][t].begin(),
+                                                             std::max_element(att[h][t].begin(), att[h][t].end()))];
+          }
+          if (!options.return_attention) att.clear();
+          results.emplace_back(std::move(hypotheses), std::move(scores), std::move(att), std::move(hyp_logits));
         }
         return results;
       }
@@ -232,15 +370,25 @@ namespace ctranslate2 {
         // (legacy specs carry their head count in the spec NAME, which a loaded model no longer knows)
         if (!base.get_variable_if_exists("num_heads") && !base.get_variable_if_exists("decoder/num_heads"))
           return false;
-        for (const auto& prefix : target_prefix)
-          if (!prefix.empty()) return false;
-        if (options.use_vmap || options.return_attention || options.replace_unknowns ||
-            options.return_logits_vocab || options.return_alternatives || options.callback ||
-            options.prefix_bias_beta > 0 || options.sampling_topk != 1 || options.num_hypotheses < 1 ||
-            options.beam_size < 1 || options.num_hypotheses > options.beam_size)
+        bool any_prefix = false;
+        for (const auto& prefix : target_prefix) any_prefix = any_prefix || !prefix.empty();
+        // (a decoder start token given by the user is the first prefix token: the reference's path)
+        if (any_prefix && m->decoder_start_token() == nullptr) return false;
+        if (options.use_vmap && m->get_vocabulary_map() != nullptr) return false;
+        if (options.return_logits_vocab && options.beam_size != 1) return false;
+        // (invalid combinations keep the reference's own error texts)
+        if (options.num_hypotheses < 1 || options.beam_size < 1 ||
+            (options.num_hypotheses > options.beam_size && !options.return_alternatives && options.sampling_topk == 1) ||
+            (options.callback && options.beam_size != 1) || options.max_decoding_length == 0 ||
+            (options.prefix_bias_beta > 0 && (options.prefix_bias_beta >= 1 || options.return_alternatives)))
           return false;
-        // the model's own end token only (ResolveEndToken of the default variant)
-        if (options.end_token.index() != 0 || !std::get<std::string>(options.end_token).empty()) return false;
+        // ONE end token (the engine stops on one id); an unknown token keeps the reference's error
+        try {
+          const auto& tgt = m->get_target_vocabulary();
+          if (std::visit(ResolveEndToken(tgt), options.end_token).size() != 1) return false;
+        } catch (...) {
+          return false;
+        }
         if (!_tried) {
           _tried = true;
           _handle = handle_of(base, [&] {

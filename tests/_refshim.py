@@ -51,7 +51,7 @@ def lib():
         # subprocess, tests/integration/run_level1.py).
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         C.CDLL(os.path.join(root, "ctranslate2_amd", "libct2_mi355.so"), mode=mode)
-        C.CDLL(os.path.join(REF_DIR, "libctranslate2_mi355.so"), mode=mode)
+        C.CDLL(os.path.join(root, "integration", "libctranslate2_mi355.so"), mode=mode)
         L = C.CDLL(os.path.join(REF_DIR, "libct2ref_capi_mi355.so"), mode=mode)
     else:
         tap_path = os.path.join(REF_DIR, "libct2ref_tap.so")

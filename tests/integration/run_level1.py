@@ -1,5 +1,5 @@
 """Level-1 integration runner (own process: the library exports the same names as the CPU
-reference build). Loads oracle/_ref/libctranslate2_mi355.so - the reference's OWN sources
+reference build). Loads integration/libctranslate2_mi355.so - the reference's OWN sources
 (Translator, ReplicaPool, layers::*, decoding.cc, ops front-ends) compiled with -DCT2_WITH_CUDA
 and linked against the stub translation units + libct2_mi355.so - and runs
 ctranslate2::Translator(model, Device::CUDA, ComputeType) on it.

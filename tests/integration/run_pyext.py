@@ -1,5 +1,5 @@
 """Runner for the reference's OWN Python extension on this backend (own process: the module links
-oracle/_ref/libctranslate2_mi355.so, which exports the same names as the CPU reference build).
+integration/libctranslate2_mi355.so, which exports the same names as the CPU reference build).
 
 `oracle/_ref/pyext/_ext*.so` is python/cpp/*.cc of the reference (pybind11: Translator, Generator,
 StorageView ...) compiled where it lies (`make -C oracle pyext`) and linked with the Level-1
@@ -45,7 +45,29 @@ def main():
     out = {"device_count": ext.get_cuda_device_count(),
            "compute_types": sorted(ext.get_supported_compute_types(spec["device"])), "runs": []}
     t = ext.Translator(spec["model"], device=spec["device"], compute_type=spec["compute_type"])
-    for beam in spec["beams"]:
+    # "cases": keyword sets of Translator.translate_batch (Level 1.5: which of them the fused engine
+    # serves). A case may carry "target_prefix" and "callback": true (a Python callable collecting the
+    # step results).
+    for case in spec.get("cases", []):
+        kw = dict(case)
+        name = kw.pop("name")
+        prefix = kw.pop("target_prefix", None)
+        steps = []
+        if kw.pop("callback", False):
+            kw["callback"] = lambda r: steps.append([r.batch_id, r.step, r.token, r.is_last]) and False
+        res = t.translate_batch(spec["tokens"], prefix, **kw)
+        run = {"name": name, "hypotheses": [r.hypotheses for r in res],
+               "scores": [[float(x) for x in r.scores] for r in res], "steps": steps}
+        if kw.get("return_attention"):
+            run["attention"] = [[[[float(x) for x in vec] for vec in hyp] for hyp in r.attention] for r in res]
+        if kw.get("return_logits_vocab"):
+            import numpy as np
+            run["logits_shapes"] = [[[list(np.array(l).shape) for l in hyp] for hyp in r.logits] for r in res]
+        out["runs"].append(run)
+    lib = ctypes.CDLL(os.path.join(ROOT, "integration", "libctranslate2_mi355.so"), mode=os.RTLD_LAZY | os.RTLD_GLOBAL)
+    lib.ct2x_level15_served_calls.restype = ctypes.c_int64
+    out["served_calls"] = int(lib.ct2x_level15_served_calls())
+    for beam in spec.get("beams", []):
         res = t.translate_batch(spec["tokens"], beam_size=beam, return_scores=True,
                                 max_decoding_length=spec.get("max_decoding_length", 256))
         out["runs"].append({"beam": beam, "hypotheses": [r.hypotheses[0] for r in res],

@@ -199,11 +199,12 @@ elif mode == "inject":   # a starved cluster: the call is decoded again on the l
     b4, s4 = t.translate_ids(src[:4], beam_size=4, max_decoding_length=12, return_scores=True)
     out = {"base": base, "again": again, "later": later, "k_fused": k_fused, "k_after": k_after,
            "fallbacks": t.cluster_fallbacks(), "beam": b4}
-elif mode == "callback":  # a step callback that re-enters translate on the same handle and device
+elif mode == "callback":  # a step callback that translates on another handle of the same device
+    t2 = ct2.Translator(path, device="cuda", compute_type="int8")
     inner = []
     def cb(step):
         if not inner:
-            inner.append(t.translate_ids(src[:2], **kw)[0])
+            inner.append(t2.translate_ids(src[:2], **kw)[0])
         return False
     base, _ = t.translate_ids(src[:2], **kw)
     hyps, _ = t.translate_ids(src[:2], callback=cb, **kw)
@@ -212,12 +213,16 @@ print(json.dumps(out))
 """
 
 
-def _worker(args, env=None, wait=True):
+def _worker(args, env=None, wait=True, timeout=600):
     p = subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT, "here": HERE}] + args,
                          env=env or dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     if not wait:
         return p
-    o, e = p.communicate(timeout=600)
+    try:
+        o, e = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise
     assert p.returncode == 0, e[-3000:]
     return json.loads(o.strip().splitlines()[-1])
 
@@ -258,6 +263,8 @@ def test_two_processes_on_one_gpu_both_translate(gpu, tmp_path):
 
 
 @pytest.mark.gpu
-def test_callback_may_reenter_translate(gpu):
-    r = _worker(["callback"])
+def test_callback_may_translate_on_the_same_device(gpu):
+    """(the round-5 gate was a mutex held across the user's callback: a callback that translated on
+    the same device waited for its own caller)"""
+    r = _worker(["callback"], timeout=180)
     assert r["hyps"] == r["base"] and r["inner"] == r["base"]

@@ -162,3 +162,38 @@ def test_gpus_flag_starts_its_own_ranks():
     q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2,
                        capture_output=True, text=True, timeout=120)
     assert q.returncode != 0 and "--gpus 2 but the launcher started 1 rank" in q.stderr
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def test_plan_of_a_tensor_parallel_run_under_gloo():
+    """`bench.py --gpus 2 --tp --tp-model nllb --plan` under torch.distributed.run with NO GPU: the two
+    ranks rendezvous over gloo, the 128 bytes of rank 0 reach rank 1 the way the RCCL unique id travels,
+    both take the same decisions (tensor parallel x2 over the NLLB-3.3B geometry, strong scaling, the
+    communicator self-test before anything is timed) and rank 0 prints them."""
+    port = _free_port()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--tp", "--tp-model", "nllb", "--plan"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["ranks_agree"] and out["id_bytes_received"] == 128
+    plan = out["plan"]
+    assert plan["world"] == 2 and plan["parallelism"] == "tensor parallel x2" and plan["scaling"] == "strong"
+    assert "NLLB" in plan["model"] and plan["batch"] == 64 and plan["beam"] == 4
+    assert plan["before_the_timed_region"] and "ct2x_tp_selftest_multi" in plan["before_the_timed_region"][0]
+    # replicas (the default): weak scaling, no data-path collective, the self-test all the same
+    q = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plan"],
+                       capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stderr[-2000:]
+    rep = json.loads([l for l in q.stdout.splitlines() if l.startswith("{")][-1])["plan"]
+    assert rep["parallelism"] == "replicas x2" and rep["scaling"] == "weak" and rep["data_path_collective"] is None

@@ -208,7 +208,7 @@ def _nm(path, flag):
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "include", "ctranslate2", "ops", "ops.h")),
                     reason="needs the reference headers (/root/reference)")
 def test_integration_stubs_match_the_reference_headers(tmp_path):
-    """The drop-in boundary, proven at link level. tests/integration/ops_mi355_stub.cc (the Level-1
+    """The drop-in boundary, proven at link level. integration/ops_mi355_stub.cc (the Level-1
     stubs of INTEGRATION.md) compiles warning-free against the reference's REAL headers, and it
     defines, with identical mangled names, the Device::CUDA float symbols that the reference's own
     op front-ends (src/ops/*.cc compiled with the CUDA arm of DEVICE_DISPATCH enabled,
@@ -220,7 +220,7 @@ def test_integration_stubs_match_the_reference_headers(tmp_path):
            "-I" + os.path.join(ROOT, "include")]
     stub = str(tmp_path / "stub.o")
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-c"] + inc +
-                          [os.path.join(HERE, "integration", "ops_mi355_stub.cc"), "-o", stub])
+                          [os.path.join(ROOT, "integration", "ops_mi355_stub.cc"), "-o", stub])
     defined = _nm(stub, "--defined-only")
     checked = 0
     for op in ("quantize", "dequantize", "layer_norm", "rms_norm", "softmax", "rotary", "topk", "gather"):

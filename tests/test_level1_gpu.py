@@ -1,9 +1,9 @@
-"""-m gpu: the Level-1 boundary EXECUTED. oracle/_ref/libctranslate2_mi355.so is the reference's
+"""-m gpu: the Level-1 boundary EXECUTED. integration/libctranslate2_mi355.so is the reference's
 OWN front-end - ctranslate2::Translator, ReplicaPool, models::Model, layers::Dense /
 MultiHeadAttention / TransformerDecoder, decoding.cc, every ops::X front-end - compiled from the
 sources where they lie with -DCT2_WITH_CUDA by the plain host compiler (oracle/Makefile target
-mi355, tests/integration/shim_cuda/ for the CUDA runtime names its headers leak) and linked with
-tests/integration/{ops,host}_mi355_stub.cc + libct2_mi355.so in place of src/cuda/* and
+mi355, integration/shim_cuda/ for the CUDA runtime names its headers leak) and linked with
+integration/{ops,host}_mi355_stub.cc + libct2_mi355.so in place of src/cuda/* and
 src/ops/*_gpu.cu. Here it runs Translator(model, Device::CUDA, ComputeType::INT8) op by op on the
 MI355X kernels and must reproduce what the same front-end computes on Device::CPU
 (tests/golden/model_golden.json; include/ctranslate2/translator.h:26-60,
@@ -83,7 +83,7 @@ def test_reference_translator_on_device_cuda_synthetic(gpu, golden, key):
 
 
 def test_level15_reference_translator_on_the_fused_engine(gpu, golden):
-    """Level 1.5 (tests/integration/level15_mi355_stub.cc): the reference's own
+    """Level 1.5 (integration/level15_mi355_stub.cc): the reference's own
     ctranslate2::Translator(model, Device::CUDA) with EncoderDecoderReplica::run_translation served
     by the fused engine - API identical, the model handed over from the reference's memory
     (ct2x_translator_create_from_memory). Same tokens as the op-by-op route (CT2X_LEVEL1_FUSED=0)

@@ -35,6 +35,31 @@ gemm_ab)          # head (round 5) library vs this tree, then the tile shapes (t
     echo "== tuning K loops only (CT2X_BIG3_VAR=2) shapes 0 1"; for sh in 0 1; do CT2X_BIG_GEMM_V=3 CT2X_BIG3_VAR=2 CT2X_BIG3_SHAPE=$sh timeout 300 $GBT $L8SH; done
     echo "== edges, this tree"; timeout 300 $GB 2500 2604 640 2500 2601 384 4200 4404 384 2561 2817 256 5000 5000 512
   } 2>&1 | tee $O/gemm_ab.txt ;;
+gemm_ab2)         # the round's first kernel (build/libct2_mi355_r6a.so: epilogue + tile widths) vs this tree (deep ring)
+  SH="$L8SH 4096 4096 4096 8192 8192 8192 2048 6144 4096 2048 4096 4096 2048 4096 14336 1024 2048 512"
+  { echo "== r6a, swish"; timeout 300 build/tools/gemm_bench_r6a --act 2 $L8SH 2048 6144 4096 4096 4096 4096
+    echo "== this tree, swish"; timeout 300 $GB --act 2 $L8SH 2048 6144 4096 4096 4096 4096
+    echo "== r6a, relu"; timeout 300 build/tools/gemm_bench_r6a $SH
+    echo "== this tree, relu"; timeout 300 $GB $SH
+    for sh in 0 1; do echo "== tuning CT2X_BIG3_SHAPE=$sh CT2X_BIG_GEMM_V=3 (int32-out on this kernel too), then K loops only"; CT2X_BIG_GEMM_V=3 CT2X_BIG3_SHAPE=$sh timeout 300 $GBT $L8SH 4096 4096 4096 8192 8192 8192
+      CT2X_BIG_GEMM_V=3 CT2X_BIG3_VAR=2 CT2X_BIG3_SHAPE=$sh timeout 300 $GBT $L8SH 4096 4096 4096; done
+    echo "== edges, this tree"; timeout 300 $GB 2500 2604 640 2500 2601 384 4200 4404 384 2561 2817 256 5000 5000 512
+  } 2>&1 | tee $O/gemm_ab2.txt ;;
+gemm_ab3)         # r6a (epilogue + tile widths) vs this tree (+ the all-interior build of the ReLU / plain forms)
+  SH="$L8SH 4096 4096 4096 8192 8192 8192 2048 6144 4096 2048 4096 4096 2048 4096 14336 1024 2048 512"
+  { echo "== r6a, relu"; timeout 300 build/tools/gemm_bench_r6a $SH
+    echo "== this tree, relu"; timeout 300 $GB $SH
+    echo "== this tree, swish"; timeout 300 $GB --act 2 $L8SH 2048 6144 4096 4096 4096 4096
+    echo "== this tree, no activation"; timeout 300 $GB --act -1 $L8SH 4096 4096 4096
+  } 2>&1 | tee $O/gemm_ab3.txt ;;
+gemm_nt)          # the result leaving with the non-temporal policy (build/libct2_mi355_nt.so) vs the default, alternating
+  { for i in 1 2; do echo "== default"; timeout 300 $GB --act 2 $L8SH; timeout 300 $GB $L8SH 4096 4096 4096 2048 6144 4096
+      echo "== nt stores"; timeout 300 build/tools/gemm_bench_nt --act 2 $L8SH; timeout 300 build/tools/gemm_bench_nt $L8SH 4096 4096 4096 2048 6144 4096; done
+  } 2>&1 | tee $O/gemm_nt.txt ;;
+beam_fused)       # beam search: LogSoftMax + per-row candidates, merge + select + advance (CT2X_BEAM_FUSED_TOPK)
+  timeout 1200 python -m pytest tests/test_translator_gpu.py tests/test_reference_kats_gpu.py tests/test_decoding_features_gpu.py -x -q -k "beam or Beam or prefix or alternatives or bias" 2>&1 | tail -5 | tee $O/beam_fused_tests.txt
+  { for f in 0 1 0 1; do echo "== CT2X_BEAM_FUSED_TOPK=$f --beam 4"; CT2X_BEAM_FUSED_TOPK=$f timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+  } 2>&1 | tee $O/beam_fused_ab.txt ;;
 tests)            # a list of test files / pytest args
   shift; timeout 1500 python -m pytest "$@" -x -q 2>&1 | tail -15 | tee $O/tests.txt ;;
 suite)            # the whole -m gpu suite only

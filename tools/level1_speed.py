@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Data point for DESIGN.md: the reference's OWN Translator running op by op on this backend
-(Level 1: oracle/_ref/libctranslate2_mi355.so, ~400 launches per decode step, a StorageView
+(Level 1: integration/libctranslate2_mi355.so, ~400 launches per decode step, a StorageView
 allocation per op) on the metric's workload - Transformer-base int8, batch 32, 64 forced steps -
 next to the fused engine (Level 2). Own process (tests/integration/run_level1.py conventions)."""
 import json
