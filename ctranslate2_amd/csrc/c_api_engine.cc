@@ -287,10 +287,25 @@ void* ct2x_translator_create_from_memory(const char* spec, uint32_t spec_revisio
   try {
     std::vector<Variable> list;
     list.reserve(static_cast<size_t>(num_vars));
+    if (num_vars < 0 || (num_vars > 0 && vars == nullptr))
+      throw std::runtime_error("ct2x_translator_create_from_memory: bad variable list");
     for (int64_t i = 0; i < num_vars; ++i) {
       Variable v;
+      if (vars[i].name == nullptr) throw std::runtime_error("ct2x_translator_create_from_memory: a variable has no name");
       v.name = vars[i].name;
       v.dtype = vars[i].dtype;
+      if (vars[i].rank < 0 || vars[i].rank > 8 || (vars[i].rank > 0 && vars[i].shape == nullptr))
+        throw std::runtime_error("Variable " + v.name + " has an invalid rank");
+      (void)dtype_size(v.dtype);  // (throws on an unknown data type id)
+      uint64_t elements = 1;
+      for (int32_t r = 0; r < vars[i].rank; ++r) {
+        const int64_t dim = vars[i].shape[r];
+        if (dim < 0 || (dim > 0 && elements > (uint64_t(1) << 40) / static_cast<uint64_t>(dim)))
+          throw std::runtime_error("Variable " + v.name + " has an invalid shape");
+        elements *= static_cast<uint64_t>(dim);
+      }
+      if (elements * dtype_size(v.dtype) != vars[i].nbytes || (vars[i].nbytes > 0 && vars[i].data == nullptr))
+        throw std::runtime_error("Variable " + v.name + " has an invalid payload size");
       v.shape.assign(vars[i].shape, vars[i].shape + vars[i].rank);
       const size_t bytes = static_cast<size_t>(v.size()) * dtype_size(v.dtype);
       const char* src = static_cast<const char*>(vars[i].data);

@@ -494,9 +494,13 @@ std::shared_ptr<ModelFile> ModelFile::from_memory(const std::string& spec, uint3
                                                   uint32_t binary_version, const std::string& config_json,
                                                   std::vector<Variable> vars) {
   auto model = std::make_shared<ModelFile>();
+  if (binary_version > kCurrentBinaryVersion)  // (the check of ModelFile::load)
+    throw std::runtime_error("Unsupported model binary version. This executable supports models "
+                             "with binary version v" + std::to_string(kCurrentBinaryVersion) +
+                             " or below, but the model has binary version v" + std::to_string(binary_version));
   model->binary_version = binary_version;
   model->spec = spec;
-  model->revision = revision;
+  model->revision = revision == 0 ? 1 : revision;
   for (auto& v : vars) {
     if (static_cast<size_t>(v.size()) * dtype_size(v.dtype) != v.data.size())
       throw std::runtime_error("Variable " + v.name + " has an invalid payload size");

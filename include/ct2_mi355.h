@@ -533,6 +533,12 @@ struct ct2x_memory_variable {
   int32_t rank;
   const int64_t* shape;
   const void* data;
+  /* bytes readable at `data`: must equal product(shape) x sizeof(dtype) - a mismatch, a negative
+   * rank or dimension or an unknown dtype is refused before anything is copied (round 6; the
+   * reader of model.bin checks the same against the byte count the file states,
+   * src/models/model.cc:594-661). The binary version handed to ct2x_translator_create_from_memory
+   * is checked like Model::load's (<= 6). */
+  uint64_t nbytes;
 };
 void* ct2x_translator_create_from_memory(const char* spec, uint32_t spec_revision, uint32_t binary_version,
                                          const char* config_json, const struct ct2x_memory_variable* vars,

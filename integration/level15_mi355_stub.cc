@@ -95,6 +95,7 @@ namespace ctranslate2 {
           vars[i].rank = static_cast<int32_t>(shapes[i].size());
           vars[i].shape = shapes[i].data();
           vars[i].data = host[i].buffer();
+          vars[i].nbytes = static_cast<uint64_t>(host[i].size()) * host[i].item_size();
         }
         auto tokens_of = [](const Vocabulary& v, std::vector<std::string>& store,
                             std::vector<const char*>& ptrs) {

@@ -104,3 +104,27 @@ def test_fused_argmax_signed_zero_tie(gpu):
         b = (rng.standard_normal(9000) * 0.01).astype(np.float32)
         y = O.dense_s8(x, wq, ws, b, None, -1, 3)
         assert G.gemm_s8_argmax(q, s, wq, ws, b).tolist() == y.argmax(axis=1).tolist()
+
+
+@pytest.mark.parametrize("case", ["rows64", "rows100_ragged_free_end"])
+def test_many_rows_cluster_form_matches_reference(gpu, case):
+    """33 .. 128 greedy rows take the several-rows-per-cluster form of the decoder-stack launch
+    (decoder_cluster_beam_kernel with beam 1). Until round 6 that form was held to the reference
+    only through the launch-per-op path; here 64 and 100 ragged sentences go against the REAL
+    reference's tokens and scores (tests/golden/make_golden_many_rows.py, Device::CPU int8)."""
+    with open(os.path.join(HERE, "golden", "many_rows_golden.json")) as f:
+        g = json.load(f)["cases"][case]
+    t = get_translator(gpu, "tb")
+    t.release_session()
+    hyps, scores = t.translate_ids(g["sources"], beam_size=1, max_decoding_length=g["max_len"],
+                                   min_decoding_length=g["min_len"], return_scores=True)
+    st = t.last_stats()
+    assert st["kernels_per_step"] <= 4, "the decoder-stack launch did not run (%d launches per step)" % st["kernels_per_step"]
+    got = [h[0] for h in hyps]
+    identical = sum(int(a == b) for a, b in zip(got, g["hypotheses"]))
+    print("tb %s: %d/%d sentences token-identical on the several-rows cluster form" % (case, identical, len(got)))
+    if host_math_is_mkl():
+        assert got == g["hypotheses"]
+        np.testing.assert_allclose(np.asarray(scores)[:, 0], np.array(g["scores"], np.float32), atol=1e-4)
+    else:
+        assert identical >= len(got) // 2

@@ -199,6 +199,21 @@ elif mode == "inject":   # a starved cluster: the call is decoded again on the l
     b4, s4 = t.translate_ids(src[:4], beam_size=4, max_decoding_length=12, return_scores=True)
     out = {"base": base, "again": again, "later": later, "k_fused": k_fused, "k_after": k_after,
            "fallbacks": t.cluster_fallbacks(), "beam": b4}
+elif mode == "compact":   # 40 rows whose finished ones leave: the session crosses from the several-rows
+    # form of the launch (per-cluster lines and counters) to the one-row form (per-row) at <= 32 rows
+    rng = np.random.default_rng(17)
+    many = [rng.integers(4, 32000, int(rng.integers(6, 30))).tolist() for _ in range(40)]
+    long_kw = dict(beam_size=1, max_decoding_length=40, min_decoding_length=1, return_scores=True)
+    free, _ = t.translate_ids(many, **long_kw)
+    # an end token that stops about half of the rows early: the most frequent token of steps 2 .. 9
+    from collections import Counter
+    cnt = Counter(tok for h in free for tok in set(h[0][2:10]))
+    end_tok, hits = cnt.most_common(1)[0]
+    hyps, scores = t.translate_ids(many, end_token_id=int(end_tok), **long_kw)
+    st = t.last_stats()
+    out = {"end_token": int(end_tok), "rows_hit": int(hits), "hyps": hyps,
+           "scores": np.asarray(scores, np.float32).view(np.uint32).tolist(),
+           "compactions": st["compactions"], "kernels": st["kernels_per_step"]}
 elif mode == "callback":  # a step callback that translates on another handle of the same device
     t2 = ct2.Translator(path, device="cuda", compute_type="int8")
     inner = []
@@ -268,3 +283,20 @@ def test_callback_may_translate_on_the_same_device(gpu):
     the same device waited for its own caller)"""
     r = _worker(["callback"], timeout=180)
     assert r["hyps"] == r["base"] and r["inner"] == r["base"]
+
+
+@pytest.mark.gpu
+def test_compaction_across_the_32_row_boundary_of_the_launch(gpu):
+    """A 40-row greedy session runs the several-rows form of the launch; once half of its rows have
+    ended they are dropped (CT2X_COMPACT_MIN_ROWS=2 here) and the session continues on the one-row
+    form, whose hand-over lines and counters are indexed differently (Engine::compact_rows clears
+    them when the form changes). Same tokens and score bits as the launch-per-op step."""
+    env = dict(os.environ, CT2X_COMPACT_MIN_ROWS="2")
+    fused = _worker(["compact"], env=env)
+    plain = _worker(["compact"], env=dict(env, CT2X_CLUSTER_STACK="0"))
+    assert fused["end_token"] == plain["end_token"] and fused["rows_hit"] >= 12
+    assert fused["compactions"] >= 1 and plain["compactions"] >= 1
+    assert fused["hyps"] == plain["hyps"] and fused["scores"] == plain["scores"]
+    lengths = sorted(len(h[0]) for h in fused["hyps"])
+    assert lengths[0] < 12 and lengths[-1] == 40, lengths  # (rows really ended at different steps)
+    assert fused["kernels"] <= 4 < plain["kernels"]

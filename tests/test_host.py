@@ -398,17 +398,27 @@ def test_translator_from_memory_is_checked_on_the_host():
 
     class Var(C.Structure):
         _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("rank", C.c_int32),
-                    ("shape", C.POINTER(C.c_int64)), ("data", C.c_void_p)]
+                    ("shape", C.POINTER(C.c_int64)), ("data", C.c_void_p), ("nbytes", C.c_uint64)]
     L.ct2x_translator_create_from_memory.restype = C.c_void_p
     L.ct2x_last_error.restype = C.c_char_p
     data = np.zeros(8, np.float32)
     shape = (C.c_int64 * 2)(2, 4)
     tokens = (C.c_char_p * 3)(b"<unk>", b"<s>", b"</s>")
-    bad = Var(b"encoder/x", 7, 2, shape, data.ctypes.data)
+    bad = Var(b"encoder/x", 7, 2, shape, data.ctypes.data, 32)
     h = L.ct2x_translator_create_from_memory(b"TransformerSpec", 1, 6, None, C.byref(bad), C.c_int64(1), None,
                                              C.c_int64(0), tokens, C.c_int64(3), 0, b"float32")
     assert not h and b"unknown data type id 7" in L.ct2x_last_error()
-    ok = Var(b"encoder/x", 0, 2, shape, data.ctypes.data)
+    # the byte count the caller states must be the shape's (a short buffer is never read past), no
+    # negative rank or dimension, the binary version as Model::load checks it
+    for var, version, text in ((Var(b"encoder/x", 0, 2, shape, data.ctypes.data, 16), 6, b"invalid payload size"),
+                               (Var(b"encoder/x", 0, -1, shape, data.ctypes.data, 32), 6, b"invalid rank"),
+                               (Var(b"encoder/x", 0, 2, (C.c_int64 * 2)(2, -4), data.ctypes.data, 32), 6, b"invalid shape"),
+                               (Var(b"encoder/x", 0, 2, (C.c_int64 * 2)(1 << 30, 1 << 30), data.ctypes.data, 32), 6, b"invalid shape"),
+                               (Var(b"encoder/x", 0, 2, shape, data.ctypes.data, 32), 7, b"Unsupported model binary version")):
+        h = L.ct2x_translator_create_from_memory(b"TransformerSpec", 1, version, None, C.byref(var), C.c_int64(1), None,
+                                                 C.c_int64(0), tokens, C.c_int64(3), 0, b"float32")
+        assert not h and text in L.ct2x_last_error(), (text, L.ct2x_last_error())
+    ok = Var(b"encoder/x", 0, 2, shape, data.ctypes.data, 32)
     h = L.ct2x_translator_create_from_memory(b"TransformerSpec", 1, 6, b"{not json", C.byref(ok), C.c_int64(1),
                                              None, C.c_int64(0), tokens, C.c_int64(3), 0, b"float32")
     assert not h and L.ct2x_last_error()

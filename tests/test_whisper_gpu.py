@@ -111,6 +111,12 @@ def test_whisper_fused_engine_matches_the_reference_cpu(gpu, golden, quant, comp
     compare(res, j[quant], z[quant + ".encode"], exact, 1e-6, "Level-2 " + quant)
 
 
+# floors of the bfloat16 arm against the float32 reference (measured on the MI355X, round 6: 3 / 3
+# sentences identical, every token; encoder output max |d| 0.041)
+BF16_WHISPER_MIN_IDENTICAL = 0.66
+BF16_WHISPER_MIN_LEADING = 0.8
+
+
 @pytest.mark.parametrize("compute", ["float16", "bfloat16"])
 def test_whisper_16bit_compute_types(gpu, golden, compute):
     """float32 model run with 16-bit weights on the matrix pipe (BASELINE configs[4] is bf16):
@@ -128,12 +134,21 @@ def test_whisper_16bit_compute_types(gpu, golden, compute):
         close()
     d = float(np.abs(enc - z["float32.encode"]).max())
     print("Level-2 %s encoder output max|d| = %.3g" % (compute, d))
-    assert d <= (0.02 if compute == "float16" else 0.12)
+    assert d <= (0.02 if compute == "float16" else 0.08)
     want = j["float32"]["generate." + name]["hypotheses"]
     same = sum(int(a == b) for a, b in zip(hyps, want))
-    print("Level-2 %s %s: %d / %d identical" % (compute, name, same, len(want)))
+    # tokens in common before the first difference, over all sentences
+    first = lambda h: h[0] if (h and isinstance(h[0], (list, tuple))) else h  # noqa: E731 - first hypothesis
+    lead = sum(next((i for i, (a, b) in enumerate(zip(first(h), first(r))) if a != b), min(len(first(h)), len(first(r))))
+               for h, r in zip(hyps, want))
+    total = sum(len(first(r)) for r in want)
+    print("Level-2 %s %s: %d / %d identical, %d / %d leading tokens agree" % (compute, name, same, len(want), lead, total))
     if compute == "float16":
         assert same >= len(want) - 1
+    else:
+        # bfloat16 (BASELINE configs[4]): 8 significant bits - a sentence may leave the float32
+        # reference at a near-tie and never return; the stated floor is on both counts
+        assert same >= BF16_WHISPER_MIN_IDENTICAL * len(want) and lead >= BF16_WHISPER_MIN_LEADING * total
 
 
 def test_whisper_python_mirror(gpu, golden):
