@@ -310,6 +310,42 @@ def prefill_gemm_leg():
     return out
 
 
+def ragged_leg(translator, args):
+    """What the padded source positions cost (the reference removes padding in the
+    encoder and the cross-attention K/V projection for the int8 compute types, src/padder.cc:56-74;
+    this backend computes all batch x longest rows). Batches of 32 and 256 sentences with lengths
+    ~ U[8, 32] against the same batches at the full length 32: tokens/s, the encoder + memory
+    projection time of a call (ct2x_last_stats.encode_ms), the share of padded rows, and the upper
+    bound of what gathering the valid rows could return = encode_ms x padded share / call time."""
+    out = {}
+    for batch in (32, 256):
+        rng = np.random.default_rng(100 + batch)
+        lengths = rng.integers(8, 33, batch)
+        ragged = [rng.integers(4, TB["vocab_size"], int(n)).tolist() for n in lengths]
+        full = [rng.integers(4, TB["vocab_size"], 32).tolist() for _ in range(batch)]
+        kw = dict(beam_size=1, max_decoding_length=args.max_len, min_decoding_length=args.max_len)
+        entry = {}
+        for name, src in (("full_length", full), ("ragged", ragged)):
+            for _ in range(2):
+                translator.translate_ids(src, **kw)
+            t0 = time.perf_counter()
+            reps = 5
+            enc = 0.0
+            for _ in range(reps):
+                translator.translate_ids(src, **kw)
+                enc += translator.last_stats()["encode_ms"]
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            entry[name] = {"ms_per_call": ms, "encode_ms": enc / reps,
+                           "tokens_per_s": batch * args.max_len / (ms * 1e-3)}
+        padded = 1.0 - float(lengths.sum()) / (batch * int(lengths.max()))
+        entry["padded_row_share"] = padded
+        entry["padding_cost_upper_bound_pct"] = 100.0 * entry["ragged"]["encode_ms"] * padded / entry["ragged"]["ms_per_call"]
+        out["batch%d" % batch] = entry
+    out["note"] = ("lengths ~ U[8, 32]; padding removal could return at most padding_cost_upper_bound_pct of a call "
+                   "(the decode steps are row-wise per sentence and never see the padding)")
+    return out
+
+
 def tp_local_leg(model_dir, sources, kw, ref_hyps):
     """Tensor parallelism on the ONE visible GPU: the model sharded over 2 ranks that live as threads
     of this process (in-process communicator), row-parallel layers exchanged through the one-shot
@@ -727,6 +763,11 @@ def main():
                          "GBps": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["total_ms"] else None}
                         for k, v in top],
             }
+        if world == 1 and not args.no_profile and args.beam == 1:
+            try:
+                result["config"]["ragged_sources"] = ragged_leg(translator, args)
+            except Exception as e:  # noqa: BLE001
+                result["config"]["ragged_sources"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_profile and args.compute_type == "int8" and args.beam == 1:
             try:
                 ref_hyps, _ = translator.translate_ids(sources, **kw)

@@ -66,3 +66,22 @@ def test_model_builder_packing_agrees_with_the_restatement():
         assert qz.shape[1] == A.gemv_widths(256, group)[0] and sc.shape[1] == A.gemv_widths(256, group)[1]
         assert np.array_equal(A.dequantize_gemv(qw, sc, qz, group), want)
         assert np.abs(want.astype(np.float32) - w).max() < 0.02  # 4-bit groups: coarse but sane
+
+
+def test_autoawq_published_order_known_answer():
+    """The GEMM layout's nibble order as AutoAWQ publishes it (awq/utils/packing_utils.py:
+    AWQ_ORDER = [0, 2, 4, 6, 1, 3, 5, 7], AWQ_REVERSE_ORDER = [0, 4, 1, 5, 2, 6, 3, 7]; the packer
+    ORs intweight[:, col * 8 + AWQ_ORDER[i]] << (4 * i) into the word) as known answers that do not
+    pass through this repository's own unpacker: the eight channels 0 .. 7 of one input row pack to
+    0x75316420, their complement 15 - c to 0x8ACE9BDF, and the unpack permutation is the published
+    reverse order."""
+    order, reverse = [0, 2, 4, 6, 1, 3, 5, 7], [0, 4, 1, 5, 2, 6, 3, 7]
+    assert A.GEMM_ORDER.tolist() == order and np.argsort(A.GEMM_ORDER).tolist() == reverse
+    qw, qz = A.pack_gemm(np.arange(8)[None, :], np.zeros((1, 8), np.int64), 1)
+    assert int(qw.view(np.uint32)[0, 0]) == 0x75316420 and int(qz.view(np.uint32)[0, 0]) == 0
+    qw, _ = A.pack_gemm(15 - np.arange(8)[None, :], np.zeros((1, 8), np.int64), 1)
+    assert int(qw.view(np.uint32)[0, 0]) == 0x8ACE9BDF
+    # ... and the dequantiser reads them back in channel order with scale 1, zero 0
+    s = np.ones((1, 8), np.float16)
+    assert A.dequantize_gemm(*A.pack_gemm(np.arange(8)[None, :], np.zeros((1, 8), np.int64), 1)[:1], s,
+                             qz).astype(np.int64).tolist() == [list(range(8))]

@@ -60,6 +60,24 @@ beam_fused)       # beam search: LogSoftMax + per-row candidates, merge + select
   timeout 1200 python -m pytest tests/test_translator_gpu.py tests/test_reference_kats_gpu.py tests/test_decoding_features_gpu.py -x -q -k "beam or Beam or prefix or alternatives or bias" 2>&1 | tail -5 | tee $O/beam_fused_tests.txt
   { for f in 0 1 0 1; do echo "== CT2X_BEAM_FUSED_TOPK=$f --beam 4"; CT2X_BEAM_FUSED_TOPK=$f timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
   } 2>&1 | tee $O/beam_fused_ab.txt ;;
+bench_full)       # the default bench line, as the driver runs it
+  timeout 1400 python bench.py > $O/bench_full.json 2> $O/bench_full.err; tail -c 400 $O/bench_full.err
+  python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r6/bench_full.json"))
+c = d["config"]
+print("value", round(d["value"], 1), "ms_per_step", round(d["ms_per_step"], 3), "kernels/step", c.get("kernels_per_decode_step"))
+print("beam4", c.get("beam4"))
+print("prefill", {k: (round(v.get("avg_us", 0), 1), round(v.get("roofline", {}).get("frac", 0), 4)) for k, v in c.get("prefill_gemm", {}).items() if isinstance(v, dict)})
+print("ragged", json.dumps(c.get("ragged_sources"))[:1200])
+for leg in ("l8", "nllb", "whisper", "tp_local", "tp_shm", "no_session_reuse"):
+    v = c.get(leg)
+    print(leg, (json.dumps(v)[:300] if v is not None else None))
+print("roofline", json.dumps(d.get("roofline"))[:600])
+print("cpu", d.get("cpu_baseline"))
+print("tokens_equal_unfused", c.get("tokens_equal_unfused"))
+PY
+  ;;
 tests)            # a list of test files / pytest args
   shift; timeout 1500 python -m pytest "$@" -x -q 2>&1 | tail -15 | tee $O/tests.txt ;;
 suite)            # the whole -m gpu suite only
