@@ -550,9 +550,20 @@ def main():
         sys.stderr.write("bench.py needs an MI355X: no GPU is visible and there is no CPU fallback\n")
         sys.stderr.flush()
         if world > 1:
-            # (a launcher tears the other ranks down the moment one exits: leave them the time to say the
-            # same thing, so that the log shows every rank got this far)
-            time.sleep(1.0 + 0.5 * rank)
+            # (a launcher tears the other ranks down the moment one exits: wait until every rank has
+            # said the same thing - one marker file per rank, keyed by the rendezvous port - so that
+            # the log shows every rank got this far even when their imports took very different times)
+            import tempfile
+            mark = os.path.join(tempfile.gettempdir(), "ct2x_bench_nogpu_%s_" % os.environ.get("MASTER_PORT", "0"))
+            open(mark + str(rank), "w").close()
+            deadline = time.time() + 180.0
+            while time.time() < deadline and not all(os.path.exists(mark + str(r)) for r in range(world)):
+                time.sleep(0.1)
+            time.sleep(0.5)
+            try:
+                os.remove(mark + str(rank))
+            except OSError:
+                pass
         raise SystemExit(1)
     torch.cuda.set_device(local_rank)
     if world > 1:

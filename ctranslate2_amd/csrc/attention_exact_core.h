@@ -102,7 +102,7 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
                                                    float* tp, int t_pad, float* ks, const float* vs,
                                                    int m_rows = 1, const int32_t* anc = nullptr,
                                                    int64_t anc_stride = 0, int64_t kv_row_stride = 0,
-                                                   int own_row = 0) {
+                                                   int own_row = 0, unsigned long long* phase_stamps = nullptr) {
   constexpr int DH = 64, XKS = DH + 4, R4 = DH / 4, KPI = 64 / R4, XVB = 16;
   const bool seq = m_rows > 1;
   const bool pack_b = seq && scale != 1.f && (n_keys >= 192 || (n_keys > m_rows && n_keys >= DH));
@@ -113,7 +113,10 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
   const int pos = t_cached;
   const int t_last = max(t_cached - 1, 0);  // loads are clamped to rows that were written
   tq[cl] = qd;
-  if (has_new && pos < 64) ks[pos * XKS + cl] = knew;
+  if (has_new && pos < 64) {
+    ks[pos * XKS + cl] = knew;
+    const_cast<float*>(vs)[pos * DH + cl] = vnew;  // (this lane's channel: read back by this lane only)
+  }
   __builtin_amdgcn_wave_barrier();
 
   // ---- QK^T: lane = key
@@ -188,6 +191,7 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
     __builtin_amdgcn_wave_barrier();
   }
 
+  if (phase_stamps != nullptr && lane == 0) phase_stamps[0] = wall_clock64();
   // ---- SoftMax over the n_valid leading keys; masked keys get probability 0
   const float m = wave_max_dpp(m_run);
   float e_reg = 0.f;
@@ -211,14 +215,17 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
   }
   __builtin_amdgcn_wave_barrier();
 
+  if (phase_stamps != nullptr && lane == 0) phase_stamps[1] = wall_clock64();
   // ---- P.V: lane = channel
   float y = 0.f;
   bool has = false;
   const int n_blocks = seq ? 0 : n_keys / 8;  // (the GEMM forms add one key at a time)
-#define CT2X_CW_BLOCK(VR, J0, T0)                                                            \
+#define CT2X_CW_BLOCK(VR, J0, T0) CT2X_CW_BLOCK_P(VR, J0, T0, *reinterpret_cast<const v4f*>(tp + (T0)), \
+                                                  *reinterpret_cast<const v4f*>(tp + (T0) + 4))
+#define CT2X_CW_BLOCK_P(VR, J0, T0, PA, PB)                                                  \
   {                                                                                          \
-    const v4f pa_ = *reinterpret_cast<const v4f*>(tp + (T0));                                \
-    const v4f pb_ = *reinterpret_cast<const v4f*>(tp + (T0) + 4);                            \
+    const v4f pa_ = PA;                                                                      \
+    const v4f pb_ = PB;                                                                      \
     if ((T0) + 8 <= n_blocks * 8) {                                                          \
       const float A_ = fmaf(pa_.x, VR[J0 + 0], pa_.z * VR[J0 + 2]);                          \
       const float B_ = fmaf(pa_.y, VR[J0 + 1], pa_.w * VR[J0 + 3]);                          \
@@ -237,16 +244,27 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
       }                                                                                      \
     }                                                                                        \
   }
-  // keys 0 .. 63: values from the staged tile, eight at a time
-  for (int t0 = 0; t0 < min(n_keys, 64); t0 += 8) {
-    float v8[8];
+  // keys 0 .. 63: values from the staged tile, eight at a time. ALL 64 reads leave before the first
+  // block (rows past the keys are clamped to a staged row, so every read is in bounds): the chain
+  // through y is 8 blocks x ~6 dependent operations, and a loop that waited for its eight LDS reads
+  // at the top of every block made this phase 2.4 us of the 3.9 us attention core (round 6 stamps)
+  {
+    // (row t of the staged tile IS row min(t, t_last) of the cache - AttnStage64 - and the step's
+    // own value was patched in next to its key above: 64 reads at constant offsets, no clamp, no
+    // select - the address arithmetic and selects of the first form were most of this phase)
+    float vall[64];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int t_ = t0 + j;
-      const float g_ = vs[min(t_, t_last) * DH + cl];
-      v8[j] = (has_new && t_ == pos) ? vnew : g_;
+    for (int j = 0; j < 64; ++j) vall[j] = vs[j * DH + cl];
+    // ... and so do the probabilities (the same address for every lane: 16 broadcast reads; the
+    // scratch row holds at least 32 entries, reads past it are clamped)
+    v4f pall[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) pall[c] = *reinterpret_cast<const v4f*>(tp + min(c * 4, t_pad - 4));
+    const int n_staged = min(n_keys, 64);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      if (b * 8 < n_staged) CT2X_CW_BLOCK_P(vall, b * 8, b * 8, pall[2 * b], pall[2 * b + 1])
     }
-    CT2X_CW_BLOCK(v8, 0, t0)
   }
 #define CT2X_CW_LOAD_V(VR, T0)                                            \
   _Pragma("unroll") for (int j = 0; j < XVB; ++j) {                       \
@@ -270,8 +288,10 @@ __device__ __forceinline__ float attn_exact_wave64(float qd, bool has_new, float
   }
 #undef CT2X_CW_LOAD_V
 #undef CT2X_CW_BLOCK
+#undef CT2X_CW_BLOCK_P
 #undef CT2X_CW_HOP
   asm volatile("" ::"v"(y));
+  if (phase_stamps != nullptr && lane == 0) phase_stamps[2] = wall_clock64();
   return y;
 }
 

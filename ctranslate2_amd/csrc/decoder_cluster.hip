@@ -291,24 +291,33 @@ struct NormRegs {  // element t of the norm's parameters
 
 // LayerNorm / RMSNorm of the row (element t in `v`) followed by ops::Quantize into sh.xq; returns
 // the quantisation scale. Every wave runs the statistics chain itself.
-__device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, int quant_mode, Shared& sh) {
+__device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, int quant_mode, Shared& sh,
+                                                   unsigned long long* dbg = nullptr) {
   const int t = threadIdx.x;
   constexpr int pad = 68;
   sh.stage[norm_chain_slot(t, kD, pad)] = v;
   lds_barrier();
   float sum, sumsq;
   ordered_row_stats_t<true>(sh.stage, pad, kD, sum, sumsq);
+  if (dbg != nullptr && t == 0) dbg[0] = wall_clock64();
   const NormStats st = norm_stats(sum, sumsq, kD, ln.eps, ln.layer_norm);
   const float y = norm_apply(v, ln.gamma, ln.beta, st, ln.layer_norm, ln.rms_use_residual, t);
   const float amax = block_absmax(y, sh);
+  if (dbg != nullptr && t == 0) dbg[1] = wall_clock64();
   const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
   sh.xq[t] = to_s8(y, scale, quant_mode);
   lds_barrier();
+  if (dbg != nullptr && t == 0) dbg[2] = wall_clock64();
   return scale;
 }
 
 #define CT2X_CL_STAMP(i)                                                                     \
   if (a.stamps != nullptr && blockIdx.x == 0 && t == 0) a.stamps[stamp_base + (i)] = wall_clock64();
+// what the three extra stamps of a layer (14 .. 16) show: 0 = inside the self-attention core (QK^T,
+// SoftMax, P.V), 1 = inside the self sub-layer's LayerNorm + Quantize (statistics, absmax, quantised)
+#ifndef CT2X_NORM_STAMPS
+#define CT2X_NORM_STAMPS 0
+#endif
 
 // grid = rows * 8 workgroups of 512 threads; blockIdx = row * 8 + member
 template <bool TAGGED>
@@ -392,7 +401,9 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       AttnStage64 stage;
       stage.request(kc, vc, kvs, t_cached, n_keys);
       {
-        const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh);
+        const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh,
+                                              (CT2X_NORM_STAMPS && a.stamps != nullptr && blockIdx.x == 0 && self)
+                                                  ? a.stamps + stamp_base + 14 : nullptr);
         const int sum = self ? g_in.finish<192, 2, 16>(sh) : g_in.finish<64, 8, 4>(sh);
         if (t < (self ? 192 : 64))
           sh.outv[t] = dense_epilogue(sum, 1.f / scale, c_in.wscale, c_in.has_bias, c_in.bias, -1);
@@ -411,7 +422,9 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
         }
         const float ctx = attn_exact_wave64(qd, self, knew, vnew, kc, vc, kvs, t_cached, n_keys,
                                             self ? t_cached + 1 : t_cached, self ? L.self_scale : L.cross_scale,
-                                            sh.tq, tp, a.t_pad, sh.ks, sh.vs);
+                                            sh.tq, tp, a.t_pad, sh.ks, sh.vs, 1, nullptr, 0, 0, 0,
+                                            (!CT2X_NORM_STAMPS && a.stamps != nullptr && blockIdx.x == 0 && self)
+                                                ? a.stamps + stamp_base + 14 : nullptr);
         ho.publish(kXchCtx + member * kDH + lane, ctx);
       }
       CT2X_CL_STAMP(2 + 5 * sub)
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       if (t < kDH) a.q_out[static_cast<int64_t>(row) * kD + out_col] = sh.xq[out_col];
       if (member == 0 && t == 0) a.qscale_out[row] = scale;
     }
-    stamp_base += 14;
+    stamp_base += kClusterStampsPerLayer;
   }
   if (TAGGED && member == 0 && t == 0) ho.counter[1] = epoch + 1u;  // (read by the NEXT launch's members)
   CT2X_CL_STAMP(0)
@@ -906,7 +919,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
       }
     }
     CT2X_CL_STAMP(13)
-    stamp_base += 14;
+    stamp_base += kClusterStampsPerLayer;
     if (more || a.q_out != nullptr) {
       if (more) {
         const ClusterLayerArgs& N = a.layers[l + 1];

@@ -403,8 +403,9 @@ namespace ctranslate2 {
     // The same for ctranslate2::Generator: DecoderReplica::run_generation
     // (src/models/language_model.cc:150-282) with include_prompt_in_result = false - the prompt is
     // consumed by one sequence-mode pass, ragged prompts continue as hard prefixes - on
-    // ct2x_generate_batch. Everything else (the prompt in the result, static prompts, logits,
-    // alternatives, callbacks, sampling, custom end tokens) stays on the reference's own path.
+    // ct2x_generate_batch, with sampling, the step callback, a custom end token and
+    // return_alternatives (round 6). The prompt in the result, static prompts and logits stay on the
+    // reference's own path.
     class Mi355DecoderReplica : public DecoderReplica {
     public:
       using DecoderReplica::DecoderReplica;
@@ -413,7 +414,10 @@ namespace ctranslate2 {
       std::vector<GenerationResult>
       run_generation(const std::vector<std::vector<std::string>>& start_tokens,
                      const GenerationOptions& options) override {
-        if (!serves(start_tokens, options)) return DecoderReplica::run_generation(start_tokens, options);
+        if (!serves(start_tokens, options)) {
+          ++g_fallback_calls;
+          return DecoderReplica::run_generation(start_tokens, options);
+        }
         const auto& m = static_cast<const LanguageModel&>(*model());
         const Vocabulary& vocab = m.get_vocabulary();
         const size_t batch = start_tokens.size();
@@ -449,21 +453,33 @@ namespace ctranslate2 {
         opt.num_suppress_sequences = static_cast<int32_t>(sup_lengths.size());
         opt.suppress_ids = sup_ids.data();
         opt.suppress_lengths = sup_lengths.data();
+        // round 6: sampling, the step callback, a custom end token, return_alternatives
+        set_sampling(opt, options);
+        opt.return_alternatives = options.return_alternatives ? 1 : 0;
+        opt.min_alternative_expansion_prob = options.min_alternative_expansion_prob;
+        const auto end_ids = std::visit(ResolveEndToken(vocab), options.end_token);
+        if (end_ids[0] != vocab.eos_id()) opt.end_token_plus_one = static_cast<int32_t>(end_ids[0]) + 1;
+        CallbackBridge bridge{&options.callback, &vocab, nullptr};
+        if (options.callback) {
+          opt.step_callback = step_trampoline;
+          opt.step_callback_data = &bridge;
+        }
 
         const size_t nh = options.num_hypotheses, max_len = options.max_length;
         std::vector<int32_t> out_ids(batch * nh * max_len), out_lengths(batch * nh);
         std::vector<float> out_scores(batch * nh);
-        if (ct2x_generate_batch(_handle->h, flat.data(), lengths.data(), static_cast<int32_t>(batch),
-                                static_cast<int32_t>(stride), &opt, out_ids.data(), out_lengths.data(),
-                                out_scores.data()) != 0)
-          throw std::runtime_error(std::string("MI355X fused engine: ") + ct2x_last_error());
+        const int rc = ct2x_generate_batch(_handle->h, flat.data(), lengths.data(), static_cast<int32_t>(batch),
+                                           static_cast<int32_t>(stride), &opt, out_ids.data(), out_lengths.data(),
+                                           out_scores.data());
+        if (bridge.error) std::rethrow_exception(bridge.error);
+        if (rc != 0) throw std::runtime_error(std::string("MI355X fused engine: ") + ct2x_last_error());
         ++g_served_calls;
 
         std::vector<GenerationResult> results(batch);
         for (size_t b = 0; b < batch; ++b) {
           for (size_t h = 0; h < nh; ++h) {
             const int32_t len = out_lengths[b * nh + h];
-            if (len < 0 || (h > 0 && len == 0)) continue;  // (fewer hypotheses than asked for)
+            if (len < 0 || (!options.return_alternatives && h > 0 && len == 0)) continue;  // (fewer hypotheses than asked for)
             const int32_t* row = out_ids.data() + (b * nh + h) * max_len;
             results[b].sequences_ids.emplace_back(row, row + std::min<int32_t>(len, static_cast<int32_t>(max_len)));
             if (options.return_scores) results[b].scores.push_back(out_scores[b * nh + h]);
@@ -485,11 +501,18 @@ namespace ctranslate2 {
         if (m == nullptr) return false;
         for (const auto& prompt : start_tokens)
           if (prompt.empty()) return false;
+        // (the prompt in the result - the reference's default - decodes the prompt step by step as a
+        // returned prefix, static prompts keep a cached state, logits: the reference's own path)
         if (options.include_prompt_in_result || !options.static_prompt.empty() || options.return_logits_vocab ||
-            options.return_alternatives || options.callback || options.sampling_topk != 1 ||
-            options.num_hypotheses < 1 || options.beam_size < 1 || options.num_hypotheses > options.beam_size)
+            options.num_hypotheses < 1 || options.beam_size < 1 || options.max_length == 0 ||
+            (options.num_hypotheses > options.beam_size && !options.return_alternatives && options.sampling_topk == 1) ||
+            (options.callback && options.beam_size != 1) || (options.return_alternatives && options.sampling_topk != 1))
           return false;
-        if (options.end_token.index() != 0 || !std::get<std::string>(options.end_token).empty()) return false;
+        try {
+          if (std::visit(ResolveEndToken(m->get_vocabulary()), options.end_token).size() != 1) return false;
+        } catch (...) {
+          return false;
+        }
         if (!base.get_variable_if_exists("num_heads") && !base.get_variable_if_exists("decoder/num_heads"))
           return false;
         if (!_tried) {

@@ -44,6 +44,24 @@ def main():
     ext = load_ext()
     out = {"device_count": ext.get_cuda_device_count(),
            "compute_types": sorted(ext.get_supported_compute_types(spec["device"])), "runs": []}
+    if "gen_cases" in spec:
+        # ctranslate2.Generator.generate_batch with include_prompt_in_result=False (Level 1.5:
+        # Mi355DecoderReplica::run_generation)
+        g = ext.Generator(spec["model"], device=spec["device"], compute_type=spec["compute_type"])
+        for case in spec["gen_cases"]:
+            kw = dict(case)
+            name = kw.pop("name")
+            steps = []
+            if kw.pop("callback", False):
+                kw["callback"] = lambda r: steps.append([r.batch_id, r.step, r.token, r.is_last]) and False
+            res = g.generate_batch(spec["tokens"], include_prompt_in_result=False, **kw)
+            out["runs"].append({"name": name, "sequences": [r.sequences for r in res],
+                                "scores": [[float(x) for x in r.scores] for r in res], "steps": steps})
+        lib = ctypes.CDLL(os.path.join(ROOT, "integration", "libctranslate2_mi355.so"), mode=os.RTLD_LAZY | os.RTLD_GLOBAL)
+        lib.ct2x_level15_served_calls.restype = ctypes.c_int64
+        out["served_calls"] = int(lib.ct2x_level15_served_calls())
+        print(json.dumps(out))
+        return
     t = ext.Translator(spec["model"], device=spec["device"], compute_type=spec["compute_type"])
     # "cases": keyword sets of Translator.translate_batch (Level 1.5: which of them the fused engine
     # serves). A case may carry "target_prefix" and "callback": true (a Python callable collecting the

@@ -146,3 +146,42 @@ def test_level15_serves_every_translation_option(gpu):
                 assert toks[b][:len(hyp[0])] == hyp[0]
         if name == "logits":
             assert f["logits_shapes"] == c["logits_shapes"], (f["logits_shapes"], c["logits_shapes"])
+
+
+LEVEL15_GEN_CASES = [
+    {"name": "greedy", "beam_size": 1, "max_length": 12, "min_length": 12, "return_scores": True},
+    {"name": "beam", "beam_size": 4, "num_hypotheses": 2, "max_length": 10, "return_scores": True},
+    {"name": "callback", "beam_size": 1, "max_length": 8, "callback": True},
+    {"name": "end_token", "beam_size": 1, "max_length": 16, "end_token": "tok8", "return_end_token": True},
+    {"name": "alternatives", "beam_size": 1, "num_hypotheses": 3, "return_alternatives": True, "max_length": 14,
+     "return_scores": True},
+    {"name": "sampling", "beam_size": 1, "sampling_topk": 5, "sampling_temperature": 0.9, "max_length": 8},
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _built(), reason="oracle/_ref/pyext is built where /root/reference exists")
+def test_level15_generator_options(gpu):
+    """The same for ctranslate2.Generator (include_prompt_in_result=False): greedy / beam search, the
+    step callback, a custom end token, return_alternatives and sampling reach the fused engine; the
+    sequences equal the reference's on Device::CPU and its own op-by-op route on the device."""
+    import golden_cases as GC
+    from ctranslate2_amd import model_builder as mb
+    path = "/tmp/ct2x_test_lm_small"
+    if not os.path.exists(os.path.join(path, "model.bin")):
+        mb.build_decoder_lm(path, **GC.SYNTHETIC_LM["lm_small"]["model"])
+    prompts = [["<s>", "tok17", "tok5", "tok230", "tok41"], ["<s>", "tok9", "tok77", "tok300", "tok12"]]
+    spec = {"model": path, "device": "cuda", "compute_type": "float32", "tokens": prompts,
+            "gen_cases": LEVEL15_GEN_CASES}
+    fused = _run(spec)
+    assert fused["served_calls"] == len(LEVEL15_GEN_CASES)
+    cpu = _run(dict(spec, device="cpu"))
+    for f, c in zip(fused["runs"], cpu["runs"]):
+        if f["name"] == "sampling":
+            assert all(len(s) == 1 and len(s[0]) == 8 for s in f["sequences"])
+            continue
+        assert f["sequences"] == c["sequences"], (f["name"], f["sequences"], c["sequences"])
+        for a, b in zip(f["scores"], c["scores"]):
+            assert len(a) == len(b) and all(abs(x - y) < 2e-3 for x, y in zip(a, b)), f["name"]
+        if f["name"] == "callback":
+            assert f["steps"] == c["steps"]
