@@ -54,6 +54,10 @@ constexpr int kDH = 64;      // d_head
 constexpr int kFfn = 2048;   // feed-forward inner size
 constexpr int kXKS = kDH + 4;
 constexpr unsigned kSpinLimit = 1u << 21;
+#ifndef CT2X_PACE_PARTS
+#define CT2X_PACE_PARTS 4
+#endif
+constexpr int kPaceParts = CT2X_PACE_PARTS;  // parts a 16-chunk weight request is issued in between a meeting's polls
 
 // exchange areas of a row (floats): attention context, residual stream, feed-forward inner row
 constexpr int kXchCtx = 0, kXchX = kD, kXchInner = 2 * kD, kXchFloats = 2 * kD + kFfn;
@@ -117,6 +121,26 @@ struct Gemv {
       for (int i = 0; i < CPT; ++i) w[i] = __builtin_nontemporal_load(base + static_cast<size_t>(i) * NS);
     }
   }
+  // the same request in PIECES parts (part p = chunks [p * CPT / PIECES, (p + 1) * CPT / PIECES)): issued
+  // between the polls of a meeting (Handover::collect_paced) - a poll behind the whole request
+  // returns only after all of it has landed (loads return in order), which made a meeting with a
+  // 16-chunk request 0.8 us longer than one without (round 6 timeline)
+  template <int NS, int KP, int CPT, int PIECES>
+  __device__ __forceinline__ void request_piece(const int8_t* __restrict__ slice, int p) {
+    static_assert(CPT <= CAP && NS * KP <= kThreads && CPT % PIECES == 0, "Gemv shape");
+    constexpr int PER = CPT / PIECES;
+    const int t = opaque_index(threadIdx.x), j = t % NS, kp = t / NS;
+    const v4i* base = reinterpret_cast<const v4i*>(slice) + static_cast<size_t>(kp) * CPT * NS + j;
+    if (p == 0) {
+#pragma unroll
+      for (int i = 0; i < CAP; ++i) w[i] = v4i{0, 0, 0, 0};
+    }
+    if (kp < KP) {
+#pragma unroll
+      for (int i = 0; i < CPT; ++i)
+        if (i / PER == p) w[i] = __builtin_nontemporal_load(base + static_cast<size_t>(i) * NS);
+    }
+  }
   // returns the int32 sum of row t of the slice to the threads t < NS (after a barrier)
   template <int NS, int KP, int CPT>
   __device__ __forceinline__ int finish(Shared& sh) {
@@ -176,6 +200,9 @@ struct Handover {
   unsigned arrivals;
   unsigned tag;            // tagged form: tag of the NEXT meeting
   int* error;
+#if CT2X_POLL_STAMPS
+  unsigned npoll = 0;      // polls of this thread since the last CT2X_CL_POLLS (timeline only)
+#endif
 
   __device__ __forceinline__ void publish(int idx, float v) {
     idx = opaque_index(idx);
@@ -226,6 +253,9 @@ struct Handover {
 #pragma unroll
       for (int i = 0; i < N; ++i) at[i] = opaque_index(idx[i]);
       do {
+#if CT2X_POLL_STAMPS
+        ++npoll;
+#endif
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i] = grid_observe(slots + at[i]);
         ok = true;
@@ -246,6 +276,54 @@ struct Handover {
 #pragma unroll
       for (int i = 0; i < N; ++i)
         out[i] = __uint_as_float(grid_observe(reinterpret_cast<const unsigned*>(lines) + opaque_index(idx[i])));
+    }
+  }
+  // collect, with `issue(p)`, p = 0 .. PIECES - 1 (parts of the next phase's weight request) issued
+  // one before each of the first polls; whatever is left after the lines have come is issued then
+  template <int N, int PIECES, typename S, typename F>
+  __device__ __forceinline__ void collect_paced(const int (&idx)[N], float (&out)[N], S& sh, F&& issue) {
+    if (TAGGED) {
+      const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(lines);
+      unsigned long long u[N];
+      int at[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) at[i] = opaque_index(idx[i]);
+      bool ok = false;
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) {
+        issue(p);
+        if (!ok) {
+  #if CT2X_POLL_STAMPS
+        ++npoll;
+#endif
+#pragma unroll
+          for (int i = 0; i < N; ++i) u[i] = grid_observe(slots + at[i]);
+          ok = true;
+#pragma unroll
+          for (int i = 0; i < N; ++i) ok = ok && static_cast<unsigned>(u[i] >> 32) == tag;
+        }
+      }
+      unsigned spins = 0;
+      while (!ok) {
+        if (++spins > kSpinLimit || sh.dead) {
+          sh.dead = 1;
+          atomicExch(error, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+#if CT2X_POLL_STAMPS
+        ++npoll;
+#endif
+#pragma unroll
+        for (int i = 0; i < N; ++i) u[i] = grid_observe(slots + at[i]);
+        ok = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) ok = ok && static_cast<unsigned>(u[i] >> 32) == tag;
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) out[i] = __uint_as_float(static_cast<unsigned>(u[i]));
+    } else {  // (counter form: the caller issued the whole request before it waited)
+      collect<N>(idx, out, sh);
     }
   }
   template <typename S>
@@ -291,12 +369,20 @@ struct NormRegs {  // element t of the norm's parameters
 
 // LayerNorm / RMSNorm of the row (element t in `v`) followed by ops::Quantize into sh.xq; returns
 // the quantisation scale. Every wave runs the statistics chain itself.
+struct NoRequests {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `parked()`: called once the row is parked in LDS and the statistics chains may start - requests
+// that do not depend on the row (the attention's cache tile) leave here, under the chains, instead
+// of in front of the store + barrier every wave's chain waits for
+template <typename F = NoRequests>
 __device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, int quant_mode, Shared& sh,
-                                                   unsigned long long* dbg = nullptr) {
+                                                   unsigned long long* dbg = nullptr, F&& parked = F()) {
   const int t = threadIdx.x;
   constexpr int pad = 68;
   sh.stage[norm_chain_slot(t, kD, pad)] = v;
   lds_barrier();
+  parked();
   float sum, sumsq;
   ordered_row_stats_t<true>(sh.stage, pad, kD, sum, sumsq);
   if (dbg != nullptr && t == 0) dbg[0] = wall_clock64();
@@ -313,11 +399,27 @@ __device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, 
 
 #define CT2X_CL_STAMP(i)                                                                     \
   if (a.stamps != nullptr && blockIdx.x == 0 && t == 0) a.stamps[stamp_base + (i)] = wall_clock64();
-// what the three extra stamps of a layer (14 .. 16) show: 0 = inside the self-attention core (QK^T,
-// SoftMax, P.V), 1 = inside the self sub-layer's LayerNorm + Quantize (statistics, absmax, quantised)
-#ifndef CT2X_NORM_STAMPS
-#define CT2X_NORM_STAMPS 0
+// polls the slowest lane of wave 0 needed in the meeting behind (shown as N.00). A build option
+// (-DCT2X_POLL_STAMPS=1): the counter costs a register the launch does not have (256 of 256; the
+// counted build ran 10 % slower). What it showed (round 6): EVERY meeting's first poll succeeds - a
+// meeting costs one store-to-visible plus one load round trip (0.96 us on an idle chip,
+// tools/xcd_local_handover_probe.cpp), there is nothing to gain from keeping several polls in flight
+#ifndef CT2X_POLL_STAMPS
+#define CT2X_POLL_STAMPS 0
 #endif
+#if CT2X_POLL_STAMPS
+#define CT2X_CL_POLLS(i)                                                                     \
+  if (a.stamps != nullptr && blockIdx.x == 0 && wave == 0) {                                 \
+    const float np_ = wave_max_dpp(static_cast<float>(ho.npoll));                            \
+    if (t == 0) a.stamps[stamp_base + (i)] = a.stamps[0] + static_cast<unsigned long long>(np_) * 100u; \
+    ho.npoll = 0;                                                                            \
+  }
+#else
+#define CT2X_CL_POLLS(i)
+#endif
+// the extra stamps of a layer: 14 .. 16 inside the self-attention core (QK^T, SoftMax, P.V), 17 .. 19
+// inside the self sub-layer's LayerNorm + Quantize (statistics, absmax, quantised), 20 the QKV sums
+// are there, 21 the K / V tile is staged
 
 // grid = rows * 8 workgroups of 512 threads; blockIdx = row * 8 + member
 template <bool TAGGED>
@@ -399,16 +501,18 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       // the cache rows of past steps do not depend on this step: their loads ride under the norm
       // and the projection
       AttnStage64 stage;
-      stage.request(kc, vc, kvs, t_cached, n_keys);
       {
         const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh,
-                                              (CT2X_NORM_STAMPS && a.stamps != nullptr && blockIdx.x == 0 && self)
-                                                  ? a.stamps + stamp_base + 14 : nullptr);
+                                              (a.stamps != nullptr && blockIdx.x == 0 && self)
+                                                  ? a.stamps + stamp_base + 17 : nullptr,
+                                              [&]() { stage.request(kc, vc, kvs, t_cached, n_keys); });
         const int sum = self ? g_in.finish<192, 2, 16>(sh) : g_in.finish<64, 8, 4>(sh);
+        if (self) { CT2X_CL_STAMP(20) }
         if (t < (self ? 192 : 64))
           sh.outv[t] = dense_epilogue(sum, 1.f / scale, c_in.wscale, c_in.has_bias, c_in.bias, -1);
       }
       stage.store(sh.ks, sh.vs);
+      if (self) { CT2X_CL_STAMP(21) }
       g_out.request<64, 8, 4>(W_out.w + static_cast<size_t>(member) * 64 * kD);
       c_out.request(W_out, out_col, t < 64);
       lds_barrier();
@@ -423,7 +527,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
         const float ctx = attn_exact_wave64(qd, self, knew, vnew, kc, vc, kvs, t_cached, n_keys,
                                             self ? t_cached + 1 : t_cached, self ? L.self_scale : L.cross_scale,
                                             sh.tq, tp, a.t_pad, sh.ks, sh.vs, 1, nullptr, 0, 0, 0,
-                                            (!CT2X_NORM_STAMPS && a.stamps != nullptr && blockIdx.x == 0 && self)
+                                            (a.stamps != nullptr && blockIdx.x == 0 && self)
                                                 ? a.stamps + stamp_base + 14 : nullptr);
         ho.publish(kXchCtx + member * kDH + lane, ctx);
       }
@@ -435,6 +539,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       {
         const float c = ho.collect1(kXchCtx + t, sh);
         ho.done();
+        CT2X_CL_POLLS(22 + 2 * sub)
         const float amax = block_absmax(c, sh);
         const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
         sh.xq[t] = to_s8(c, scale, a.quant_mode);
@@ -452,15 +557,23 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
         g_in.request<64, 8, 4>(L.cross_q.w + static_cast<size_t>(member) * 64 * kD);
         c_in.request(L.cross_q, out_col, t < 64);
         n_in.request(L.ln_cross);
+        ho.await(sh);
+        CT2X_CL_STAMP(5 + 5 * sub)
+        xv = ho.collect1(kXchX + t, sh);
       } else {
-        g_in.request<256, 2, 16>(L.ffn0.w + static_cast<size_t>(member) * 256 * kD);
+        const int8_t* w_ffn0 = L.ffn0.w + static_cast<size_t>(member) * 256 * kD;
+        if (!TAGGED) g_in.request<256, 2, 16>(w_ffn0);
         c_in.request(L.ffn0, member * 256 + (t & 255), t < 256);
         n_in.request(L.ln_ffn);
+        ho.await(sh);
+        CT2X_CL_STAMP(5 + 5 * sub)
+        const int xi[1] = {kXchX + t};
+        float xo[1];
+        ho.template collect_paced<1, kPaceParts>(xi, xo, sh, [&](int p) { g_in.request_piece<256, 2, 16, kPaceParts>(w_ffn0, p); });
+        xv = xo[0];
       }
-      ho.await(sh);
-      CT2X_CL_STAMP(5 + 5 * sub)
-      xv = ho.collect1(kXchX + t, sh);
       ho.done();
+      CT2X_CL_POLLS(23 + 2 * sub)
       sh.x_row[t] = xv;
     }
     // ================= feed forward ===========================================================
@@ -475,7 +588,8 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
     CT2X_CL_STAMP(11)
     ho.arrive();
     Gemv<16> g_f1;
-    g_f1.request<64, 8, 16>(L.ffn1.w + static_cast<size_t>(member) * 64 * kFfn);
+    const int8_t* w_ffn1 = L.ffn1.w + static_cast<size_t>(member) * 64 * kFfn;
+    if (!TAGGED) g_f1.request<64, 8, 16>(w_ffn1);
     c_out.request(L.ffn1, out_col, t < 64);
     ho.await(sh);
     CT2X_CL_STAMP(12)
@@ -483,8 +597,10 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       float iv[4];
       const int inner_idx[4] = {kXchInner + t, kXchInner + kThreads + t, kXchInner + 2 * kThreads + t,
                                 kXchInner + 3 * kThreads + t};
-      ho.template collect<4>(inner_idx, iv, sh);
+      ho.template collect_paced<4, kPaceParts>(inner_idx, iv, sh,
+                                               [&](int p) { g_f1.request_piece<64, 8, 16, kPaceParts>(w_ffn1, p); });
       ho.done();
+      CT2X_CL_POLLS(26)
       const float amax =
           block_absmax(fmaxf(fmaxf(fabsf(iv[0]), fabsf(iv[1])), fmaxf(fabsf(iv[2]), fabsf(iv[3]))), sh);
       const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
@@ -504,12 +620,17 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
     if (l + 1 < a.n_layers) {
       ho.arrive();
       const ClusterLayerArgs& N = a.layers[l + 1];
-      g_in.request<192, 2, 16>(N.qkv.w + static_cast<size_t>(member) * 192 * kD);
+      const int8_t* w_qkv = N.qkv.w + static_cast<size_t>(member) * 192 * kD;
+      if (!TAGGED) g_in.request<192, 2, 16>(w_qkv);
       c_in.request(N.qkv, qkv_col, t < 192);
       n_in.request(N.ln_self);
       ho.await(sh);
-      xv = ho.collect1(kXchX + t, sh);
+      const int xi[1] = {kXchX + t};
+      float xo[1];
+      ho.template collect_paced<1, kPaceParts>(xi, xo, sh, [&](int p) { g_in.request_piece<192, 2, 16, kPaceParts>(w_qkv, p); });
+      xv = xo[0];
       ho.done();
+      CT2X_CL_POLLS(27)
       sh.x_row[t] = xv;
     } else if (a.q_out != nullptr) {
       // ---- the decoder's output norm + Quantize: the input row of the vocabulary projection ----

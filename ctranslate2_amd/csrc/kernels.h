@@ -275,7 +275,7 @@ struct ClusterStackArgs {
   // timeline of workgroup 0 (CT2X_CLUSTER_STAMPS=1): 1 + 14 per layer + 1 wall_clock64 values
   unsigned long long* stamps = nullptr;
 };
-constexpr int kClusterStampsPerLayer = 17;  // 14 phase stamps + 3 inside the self-attention core (QK^T, SoftMax, P.V)
+constexpr int kClusterStampsPerLayer = 28;  // 14 phase stamps + 8 inside the self sub-layer + 6 poll counts (decoder_cluster.hip)
 // d_model 512, 8 heads of 64, feed-forward 2048 (Transformer-base); everything else keeps the
 // launch-per-op path
 bool decoder_cluster_geometry_ok(int64_t d_model, int64_t heads, int64_t dhead, int64_t ffn);

@@ -81,6 +81,10 @@ PY
 cluster_stamps)   # phase timeline of workgroup 0 of the decoder-stack launch (last step), incl. the attention core's phases
   CT2X_CLUSTER_STAMPS=1 timeout 300 python bench.py --steps 2 --warmup 1 $NOLEGS --no-token-check 2>&1 | grep -A8 "decoder_stack timeline" | tail -9 | tee $O/cluster_timeline.txt
   { for i in 1 2; do timeout 300 python bench.py --steps 20 --warmup 3 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done; } | tee $O/cluster_speed.txt ;;
+cluster_check)    # the decoder-stack launch's own tests, then the timeline and the speed
+  timeout 900 python -m pytest tests/test_decoder_cluster_gpu.py tests/test_bench_path_gpu.py -x -q 2>&1 | tail -4 | tee $O/cluster_tests.txt
+  CT2X_CLUSTER_STAMPS=1 timeout 300 python bench.py --steps 2 --warmup 1 $NOLEGS --no-token-check 2>&1 | grep -A8 "decoder_stack timeline" | tail -9 | tee $O/cluster_timeline.txt
+  { for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 3 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done; } | tee $O/cluster_speed.txt ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
