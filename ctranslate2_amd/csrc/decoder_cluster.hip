@@ -36,6 +36,7 @@
 
 #include "attention_exact_core.h"
 #include "device_utils.h"
+#include "greedy_fuse.h"
 #include "grid_sync.h"
 #include "kernels.h"
 #include "row_norm.h"
@@ -57,10 +58,19 @@ constexpr unsigned kSpinLimit = 1u << 21;
 #ifndef CT2X_PACE_PARTS
 #define CT2X_PACE_PARTS 4
 #endif
-constexpr int kPaceParts = CT2X_PACE_PARTS;  // parts a 16-chunk weight request is issued in between a meeting's polls
+constexpr int kPaceParts = CT2X_PACE_PARTS;
+static_assert(8 % kPaceParts == 0, "the projection tail's eight DMA requests per wave leave in kPaceParts parts");  // parts a 16-chunk weight request is issued in between a meeting's polls
 
 // exchange areas of a row (floats): attention context, residual stream, feed-forward inner row
 constexpr int kXchCtx = 0, kXchX = kD, kXchInner = 2 * kD, kXchFloats = 2 * kD + kFfn;
+
+// projection tail (ClusterProjArgs, kernels.h)
+constexpr int kProjRowSlots = kClusterProjRowSlots;
+constexpr int kProjCols = kClusterProjCols;
+constexpr int kProjWBytes = kProjCols * kD;   // 64 KB: the weight rows of a pass, fragment-major
+constexpr int kProjAStride = kD + 16;         // the quantised rows of all clusters [32][528]
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
 
 struct Shared {
   float x_row[kD];                 // residual stream of the row
@@ -89,6 +99,11 @@ __device__ __forceinline__ void lds_barrier() {
 // vmcnt(0) wait that drains the weight requests deliberately left in flight).
 __device__ __forceinline__ int opaque_index(int v) {
   asm volatile("" : "+v"(v));
+  return v;
+}
+// ... and a wave-uniform one (stays in a scalar register)
+__device__ __forceinline__ int opaque_uniform(int v) {
+  asm volatile("" : "+s"(v));
   return v;
 }
 
@@ -170,9 +185,14 @@ __device__ __forceinline__ float dense_epilogue(int sum, float r_a, float w_scal
   return apply_activation(v, act);
 }
 
-__device__ __forceinline__ float block_absmax_in(float v, float* red) {
+// `red`: two sets of eight partial maxima used alternately (`flip` toggles per call): a wave that
+// writes set A for call n + 2 can not meet a slow wave still reading set A of call n - the barrier
+// of call n + 1 lies between them - so the barrier that used to guard the reuse is gone (six calls
+// per layer)
+__device__ __forceinline__ float block_absmax(float v, Shared& sh, int& flip) {
   float m = wave_max_dpp(fabsf(v));
-  lds_barrier();  // (red is reused)
+  float* red = sh.red + flip * 8;
+  flip ^= 1;
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   lds_barrier();
   m = red[0];
@@ -180,7 +200,6 @@ __device__ __forceinline__ float block_absmax_in(float v, float* red) {
   for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, red[w]);
   return m;
 }
-__device__ __forceinline__ float block_absmax(float v, Shared& sh) { return block_absmax_in(v, sh.red); }
 
 // ---- hand-over between the members of a cluster ---------------------------------------------
 // Two forms (CT2X_CLUSTER_HANDOVER, A/B in profiles/r05_cluster_handover_ab.txt):
@@ -376,7 +395,7 @@ struct NoRequests {
 // that do not depend on the row (the attention's cache tile) leave here, under the chains, instead
 // of in front of the store + barrier every wave's chain waits for
 template <typename F = NoRequests>
-__device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, int quant_mode, Shared& sh,
+__device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, int quant_mode, Shared& sh, int& flip,
                                                    unsigned long long* dbg = nullptr, F&& parked = F()) {
   const int t = threadIdx.x;
   constexpr int pad = 68;
@@ -388,13 +407,42 @@ __device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, 
   if (dbg != nullptr && t == 0) dbg[0] = wall_clock64();
   const NormStats st = norm_stats(sum, sumsq, kD, ln.eps, ln.layer_norm);
   const float y = norm_apply(v, ln.gamma, ln.beta, st, ln.layer_norm, ln.rms_use_residual, t);
-  const float amax = block_absmax(y, sh);
+  const float amax = block_absmax(y, sh, flip);
   if (dbg != nullptr && t == 0) dbg[1] = wall_clock64();
   const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
   sh.xq[t] = to_s8(y, scale, quant_mode);
   lds_barrier();
   if (dbg != nullptr && t == 0) dbg[2] = wall_clock64();
   return scale;
+}
+
+// Projection tail: wave w's share of a pass's weight rows, global -> LDS by DMA (1 KB per
+// instruction, no registers): chunk (w, ks) = the B fragment of MFMA k-step ks for the wave's 16
+// columns - lane l supplies 16 bytes of column l % 16 at K offset ks * 64 + (l / 16) * 16, the LDS
+// image is lane-linear, so the fragment is read back with one conflict-free ds_read_b128. Columns
+// past the vocabulary read its last row (masked in the epilogue).
+__device__ __forceinline__ int8_t* proj_wbuf(unsigned char* smem_raw, int t_pad) {  // behind Shared and the score row
+  return reinterpret_cast<int8_t*>(smem_raw) + ((sizeof(Shared) + static_cast<size_t>(t_pad) * sizeof(float) + 1023) & ~size_t(1023));
+}
+// chunk c = (N tile c / 8, k-step c % 8) of a pass; the policy is non-temporal: a weight row is read
+// once per step and should not push the XCD's slice of the decoder weights out of its L2
+__device__ __forceinline__ void proj_request_chunk(const ClusterProjArgs& P, int8_t* wbuf, int col_base, int c, int lane) {
+  const int col = min(col_base + (c >> 3) * 16 + (lane & 15), P.vocab - 1);
+  const int8_t* src = P.w + static_cast<int64_t>(col) * kD + (c & 7) * 64 + (lane >> 4) * 16;
+  __builtin_amdgcn_global_load_lds((glb_void*)(src), (lds_void*)(wbuf + c * 1024), 16, 0, 2);
+}
+// a whole pass, by all eight waves (the passes after the first)
+__device__ __forceinline__ void proj_request(const ClusterProjArgs& P, int8_t* wbuf, int col_base) {
+  const int t = opaque_index(threadIdx.x), lane = t & 63, wave = t >> 6;
+  for (int ks = 0; ks < 8; ++ks) proj_request_chunk(P, wbuf, col_base, wave * 8 + ks, lane);
+}
+// the FIRST pass, by the seven waves that sit idle while wave 0 runs the last layer's
+// encoder-decoder attention core: the requests miss the L2 (16 MB of projection weights do not
+// live there), and loads return in order - in front of a meeting's polls they cost the meeting their
+// whole latency (+1.5 us measured), here they land while their waves have nothing to wait for
+__device__ __forceinline__ void proj_request_first(const ClusterProjArgs& P, int8_t* wbuf, int col_base) {
+  const int t = opaque_index(threadIdx.x), lane = t & 63, wave = t >> 6;
+  for (int c = wave - 1; c < 64; c += 7) proj_request_chunk(P, wbuf, col_base, c, lane);
 }
 
 #define CT2X_CL_STAMP(i)                                                                     \
@@ -433,22 +481,44 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
   ho.lines = a.xch + static_cast<size_t>(row) * kXchFloats * (TAGGED ? 2 : 1);
   ho.counter = a.counters + static_cast<size_t>(row) * 16;
   ho.error = a.error;
-  // (a session whose earlier launch lost a member is void: its remaining replays return at once
-  // instead of each waiting out the bounded polls again)
-  if (__hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-  if (t == 0) sh.dead = 0;
+  // The launch's first memory round trips, merged (round 6: the prologue was four dependent trips -
+  // error flag, epoch / step / id, embedding row behind the 96 KB of QKV weights - 3.5 us before
+  // the first layer began): everything that does not depend on anything leaves together, the
+  // embedding row leaves as soon as the id is here and BEFORE the weight requests (loads return in
+  // order, and the row is what the first LayerNorm waits for).
   int stamp_base = 0;
   CT2X_CL_STAMP(0)
+  const int err = __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // counter form: where the counter stood when this launch began - the members of the previous
   // launch all left at a multiple of kMembers, and at most kMembers - 1 early arrivals of THIS
   // launch's first meeting can have been added since. Tagged form: the launch epoch of this row
   // (advanced by member 0 when the launch ends; zero at session start, so is every slot's tag).
-  ho.arrivals = TAGGED ? 0u
-                       : __hip_atomic_load(ho.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / kMembers * kMembers;
+  const unsigned arrivals0 = TAGGED ? 0u : __hip_atomic_load(ho.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned epoch = TAGGED ? ho.counter[1] : 0u;
-  ho.tag = epoch * 64u + 1u;
   const int step = *a.step_ptr;
   const int mem_len = a.mem_lengths[row];
+  const bool proj = TAGGED && a.proj.w != nullptr;
+  const unsigned pseq = proj ? *a.proj.seq : 0u;
+  const int64_t id = a.ids[row];
+  // ---- embedding row (embed_kernel, rowops.hip), every member for itself ----------------------
+  float e_f = 0.f, e_scale = 1.f, e_pos = 0.f;
+  int e_q = 0;
+  {
+    const int te = opaque_index(threadIdx.x);
+    if (a.emb_int8) {
+      e_q = (static_cast<const int8_t*>(a.emb_table) + id * kD)[te];
+      e_scale = a.emb_scale[id];
+    } else {
+      e_f = static_cast<const float*>(a.emb_table)[id * kD + te];
+    }
+    if (a.pos_table) e_pos = (a.pos_table + static_cast<int64_t>(step) * kD)[te];
+  }
+  // (a session whose earlier launch lost a member is void: its remaining replays return at once
+  // instead of each waiting out the bounded polls again)
+  if (err != 0) return;
+  if (t == 0) sh.dead = 0;
+  ho.arrivals = arrivals0 / kMembers * kMembers;
+  ho.tag = epoch * 64u + 1u;
 
   // operands of the NEXT input projection (QKV / cross-attention query / feed-forward input) and
   // of the next output projection: requested one meeting ahead
@@ -462,23 +532,19 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
   c_in.request(a.layers[0].qkv, qkv_col, t < 192);
   n_in.request(a.layers[0].ln_self);
 
-  // ---- embedding row (embed_kernel, rowops.hip), every member for itself ----------------------
   float xv;
-  {
-    const int64_t id = a.ids[row];
-    const float* p = a.pos_table ? a.pos_table + static_cast<int64_t>(step) * kD : nullptr;
-    if (a.emb_int8) {
-      const int8_t* e = static_cast<const int8_t*>(a.emb_table) + id * kD;
-      const float r_s = 1.f / a.emb_scale[id];
-      xv = static_cast<float>(e[t]) * r_s;
-    } else {
-      xv = static_cast<const float*>(a.emb_table)[id * kD + t];
-    }
-    if (a.emb_apply_mul) xv = xv * a.emb_mul;
-    if (p) xv = xv + p[t];
+  if (a.emb_int8) {
+    const float r_s = 1.f / e_scale;
+    xv = static_cast<float>(e_q) * r_s;
+  } else {
+    xv = e_f;
   }
+  if (a.emb_apply_mul) xv = xv * a.emb_mul;
+  if (a.pos_table) xv = xv + e_pos;
   sh.x_row[t] = xv;
   stamp_base = 1;
+  float out_scale = 1.f;  // quantisation scale of the row the output norm leaves (projection tail)
+  int red_flip = 0;       // which set of sh.red the next block_absmax writes
 
   for (int l = 0; l < a.n_layers; ++l) {
     const ClusterLayerArgs& L = a.layers[l];  // (kernel arguments: scalar loads)
@@ -502,7 +568,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       // and the projection
       AttnStage64 stage;
       {
-        const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh,
+        const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh, red_flip,
                                               (a.stamps != nullptr && blockIdx.x == 0 && self)
                                                   ? a.stamps + stamp_base + 17 : nullptr,
                                               [&]() { stage.request(kc, vc, kvs, t_cached, n_keys); });
@@ -530,6 +596,8 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
                                             (a.stamps != nullptr && blockIdx.x == 0 && self)
                                                 ? a.stamps + stamp_base + 14 : nullptr);
         ho.publish(kXchCtx + member * kDH + lane, ctx);
+      } else if (proj && !self && l + 1 == a.n_layers) {
+        proj_request_first(a.proj, proj_wbuf(smem_raw, a.t_pad), static_cast<int>(blockIdx.x) * a.proj.cols_per_wg);
       }
       CT2X_CL_STAMP(2 + 5 * sub)
       ho.arrive();
@@ -540,7 +608,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
         const float c = ho.collect1(kXchCtx + t, sh);
         ho.done();
         CT2X_CL_POLLS(22 + 2 * sub)
-        const float amax = block_absmax(c, sh);
+        const float amax = block_absmax(c, sh, red_flip);
         const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
         sh.xq[t] = to_s8(c, scale, a.quant_mode);
         lds_barrier();
@@ -578,7 +646,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
     }
     // ================= feed forward ===========================================================
     {
-      const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh);
+      const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh, red_flip);
       const int sum = g_in.finish<256, 2, 16>(sh);
       if (t < 256) {
         const float v = dense_epilogue(sum, 1.f / scale, c_in.wscale, c_in.has_bias, c_in.bias, a.act);
@@ -602,7 +670,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       ho.done();
       CT2X_CL_POLLS(26)
       const float amax =
-          block_absmax(fmaxf(fmaxf(fabsf(iv[0]), fabsf(iv[1])), fmaxf(fabsf(iv[2]), fabsf(iv[3]))), sh);
+          block_absmax(fmaxf(fmaxf(fabsf(iv[0]), fabsf(iv[1])), fmaxf(fabsf(iv[2]), fabsf(iv[3]))), sh, red_flip);
       const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) sh.xq[i * kThreads + t] = to_s8(iv[i], scale, a.quant_mode);
@@ -612,8 +680,10 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
         float v = dense_epilogue(sum, 1.f / scale, c_out.wscale, c_out.has_bias, c_out.bias, -1);
         v = sh.x_row[out_col] + v;
         const bool last = l + 1 == a.n_layers;
-        if (!last || a.q_out != nullptr) ho.publish(kXchX + out_col, v);
-        if (last) a.x_out[static_cast<int64_t>(row) * kD + out_col] = v;  // read by the next launch
+        if (!last || a.q_out != nullptr || proj) ho.publish(kXchX + out_col, v);
+        // (read by the next launch; the address behind opaque moves - hoisted, it was spilled)
+        if (last)
+          a.x_out[static_cast<int64_t>(opaque_uniform(static_cast<int>(blockIdx.x)) / kMembers) * kD + opaque_index(out_col)] = v;
       }
     }
     CT2X_CL_STAMP(13)
@@ -622,7 +692,10 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       const ClusterLayerArgs& N = a.layers[l + 1];
       const int8_t* w_qkv = N.qkv.w + static_cast<size_t>(member) * 192 * kD;
       if (!TAGGED) g_in.request<192, 2, 16>(w_qkv);
-      c_in.request(N.qkv, qkv_col, t < 192);
+      {  // (recomputed from fresh indices: kept across the layer loop it was the register that got spilled)
+        const int tt = opaque_index(threadIdx.x);
+        c_in.request(N.qkv, (tt >> 6) * kD + member * kDH + (tt & 63), tt < 192);
+      }
       n_in.request(N.ln_self);
       ho.await(sh);
       const int xi[1] = {kXchX + t};
@@ -632,21 +705,187 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       ho.done();
       CT2X_CL_POLLS(27)
       sh.x_row[t] = xv;
-    } else if (a.q_out != nullptr) {
+    } else if (a.q_out != nullptr || proj) {
       // ---- the decoder's output norm + Quantize: the input row of the vocabulary projection ----
       ho.arrive();
       n_in.request(a.out_norm);
       ho.await(sh);
       xv = ho.collect1(kXchX + t, sh);
       ho.done();
-      const float scale = norm_quantize_row(xv, n_in, a.quant_mode, sh);
-      // (every member holds the whole quantised row: each stores its own 64 columns)
-      if (t < kDH) a.q_out[static_cast<int64_t>(row) * kD + out_col] = sh.xq[out_col];
-      if (member == 0 && t == 0) a.qscale_out[row] = scale;
+      out_scale = norm_quantize_row(xv, n_in, a.quant_mode, sh, red_flip);
+      if (!proj) {
+        // (every member holds the whole quantised row: each stores its own 64 columns)
+        // (the address behind opaque moves: hoisted out of the layer loop it was a spilled register pair)
+        if (t < kDH) {
+          const int oc = opaque_index(out_col);
+          a.q_out[static_cast<int64_t>(opaque_uniform(static_cast<int>(blockIdx.x)) / kMembers) * kD + oc] = sh.xq[oc];
+        }
+        if (member == 0 && t == 0) a.qscale_out[row] = out_scale;
+      }
     }
     stamp_base += kClusterStampsPerLayer;
   }
-  if (TAGGED && member == 0 && t == 0) ho.counter[1] = epoch + 1u;  // (read by the NEXT launch's members)
+  if (proj) {
+    {
+      {
+        // ================= vocabulary projection + greedy arg-max (ClusterProjArgs) =============
+        // Dense (gemm_s8.hip epilogue: c * (1 / a_scale) / w_scale + bias) of ALL rows against this
+        // workgroup's columns on the MFMA, the row's best (value, column) key max-combined per row,
+        // the last workgroup to arrive finishes the step (greedy_fuse.h).
+        const ClusterProjArgs& P = a.proj;
+        // (this block's own thread indices: nothing of it is live across the layer loop)
+        const int t = opaque_index(threadIdx.x), lane = t & 63, wave = t >> 6;
+        const int row = opaque_uniform(static_cast<int>(blockIdx.x)) / kMembers, member = static_cast<int>(blockIdx.x) % kMembers;
+        int8_t* wbuf = proj_wbuf(smem_raw, a.t_pad);
+        const int col0 = static_cast<int>(blockIdx.x) * P.cols_per_wg;
+        float ws0 = 1.f, bias0 = 0.f;
+        {  // (the first pass's column operands: requested ahead of the polls)
+          const int c = min(col0 + wave * 16 + (lane & 15), P.vocab - 1);
+          ws0 = P.wscale[opaque_index(c)];
+          if (P.bias != nullptr) bias0 = P.bias[opaque_index(c)];
+        }
+        int8_t* a_tile = reinterpret_cast<int8_t*>(sh.ks);   // [32][kProjAStride] (the tiles are dead)
+        float* r_a = sh.outv;                                // 1 / a_scale of every row
+        int* masked = sh.part;                               // the column DisableTokens masks, per row
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(sh.stage);
+        const unsigned ptag = pseq + 1u;
+        CT2X_CL_STAMP(1)  // (tail stamps: 1 = the output norm is done, 2 = all rows are here, 3 = the weights too,
+                          // 4 = the passes, 5 = the row maxima have left, 6 = the ticket is drawn, 0 = end)
+        if (member == 0) {  // (every member holds the row: one publishes it)
+          unsigned long long* rq = P.rows_q + static_cast<size_t>(row) * kProjRowSlots;
+          if (t < kD / 4)
+            grid_publish(rq + t, (static_cast<unsigned long long>(ptag) << 32) |
+                                     *reinterpret_cast<const unsigned*>(sh.xq + 4 * t));
+          else if (t == kD / 4)
+            grid_publish(rq + t, (static_cast<unsigned long long>(ptag) << 32) | __float_as_uint(out_scale));
+        }
+        if (t < 32) {
+          keys[t] = 0ull;
+          int plen = 0;
+          if (t < a.rows && P.gf.prefix_ids != nullptr && P.gf.prefix_extends_min) plen = P.gf.prefix_lens[t];
+          masked[t] = (t < a.rows && step < P.gf.min_length + plen) ? P.gf.disable_id : -1;
+        }
+        {
+          constexpr int NP = (32 * kProjRowSlots + kThreads - 1) / kThreads;
+          const int total = a.rows * kProjRowSlots;
+          unsigned pending = 0u;
+#pragma unroll
+          for (int i = 0; i < NP; ++i)
+            if (t + kThreads * i < total) pending |= 1u << i;
+          unsigned spins = 0;
+          while (pending != 0u) {
+            unsigned long long u[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+              if ((pending >> i) & 1u) u[i] = grid_observe(P.rows_q + opaque_index(t + kThreads * i));
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+              if (((pending >> i) & 1u) && static_cast<unsigned>(u[i] >> 32) == ptag) {
+                const int sidx = t + kThreads * i, rr = sidx / kProjRowSlots, j = sidx - rr * kProjRowSlots;
+                if (j < kD / 4)
+                  *reinterpret_cast<unsigned*>(a_tile + rr * kProjAStride + 4 * j) = static_cast<unsigned>(u[i]);
+                else
+                  r_a[rr] = 1.f / __uint_as_float(static_cast<unsigned>(u[i]));
+                pending &= ~(1u << i);
+              }
+            }
+            if (pending != 0u) {
+              if (++spins > kSpinLimit || sh.dead) {
+                sh.dead = 1;
+                atomicExch(a.error, 1);
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+        }
+        CT2X_CL_STAMP(2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the DMA of the first pass has landed)
+        lds_barrier();
+        CT2X_CL_STAMP(3)
+        unsigned long long best[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) best[i][q] = 0ull;
+        const int passes = P.cols_per_wg / kProjCols;
+        for (int p = 0; p < passes; ++p) {
+          float ws = ws0, bs = bias0;
+          const int col = col0 + p * kProjCols + wave * 16 + (lane & 15);
+          if (p > 0) {
+            lds_barrier();  // (the previous pass's fragments have been read)
+            proj_request(P, wbuf, col0 + p * kProjCols);
+            const int c = min(col, P.vocab - 1);
+            ws = P.wscale[c];
+            if (P.bias != nullptr) bs = P.bias[c];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+          }
+          v4i acc[2] = {v4i{0, 0, 0, 0}, v4i{0, 0, 0, 0}};
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            const v4i bf = *reinterpret_cast<const v4i*>(wbuf + (wave * 8 + ks) * 1024 + lane * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const v4i af = *reinterpret_cast<const v4i*>(a_tile + (i * 16 + (lane & 15)) * kProjAStride + ks * 64 +
+                                                           (lane >> 4) * 16);
+              acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf, acc[i], 0, 0, 0);
+            }
+          }
+          if (col < P.vocab) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int rr = i * 16 + (lane >> 4) * 4 + q;
+                float v = static_cast<float>(acc[i][q]) * r_a[rr];
+                v = v / ws;
+                if (P.bias != nullptr) v = v + bs;
+                if (col != masked[rr] && v == v) {
+                  const unsigned long long key = greedy_fuse_key(v, static_cast<unsigned>(col));
+                  best[i][q] = key > best[i][q] ? key : best[i][q];
+                }
+              }
+          }
+        }
+        CT2X_CL_STAMP(4)
+        // the 16 lanes that share a row, then the eight waves (LDS), then the launch (memory)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            unsigned long long k = best[i][q];
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+              const unsigned long long other = __shfl_xor(k, off, 64);
+              k = other > k ? other : k;
+            }
+            const int rr = i * 16 + (lane >> 4) * 4 + q;
+            if ((lane & 15) == 0 && rr < a.rows && k != 0ull) atomicMax(&keys[rr], k);
+          }
+        __syncthreads();
+        if (t < a.rows && keys[t] != 0ull) {
+          // (a returning atomic: it has been performed when its value arrives, i.e. before the ticket)
+          const unsigned long long old =
+              atomicMax(P.gf.slots + static_cast<int64_t>(t) * GreedyFuse::kSubSlots + (blockIdx.x % GreedyFuse::kSubSlots), keys[t]);
+          asm volatile("" ::"v"(static_cast<unsigned>(old)));
+        }
+        __syncthreads();
+        CT2X_CL_STAMP(5)
+        if (t == 0) masked[32] = static_cast<int>(atomicAdd(P.gf.ticket, 1u));
+        __syncthreads();
+        CT2X_CL_STAMP(6)
+        if (static_cast<unsigned>(masked[32]) == gridDim.x - 1) greedy_fuse_finish<kThreads>(P.gf, a.rows, step, t);
+        if (blockIdx.x == 0 && t == 0) *P.seq = pseq + 1u;  // (read by the NEXT launch)
+      }
+    }
+  }
+  // (read by the NEXT launch's members; re-read here: only this thread writes it. Fresh indices: the
+  // test's operands would otherwise be one more value kept alive - spilled - across the layer loop)
+  if (TAGGED && opaque_uniform(static_cast<int>(blockIdx.x)) % kMembers == 0 && opaque_index(threadIdx.x) == 0) {
+    unsigned* ep = a.counters + static_cast<size_t>(opaque_uniform(static_cast<int>(blockIdx.x)) / kMembers) * 16 + 1;
+    *ep = *ep + 1u;
+  }
   CT2X_CL_STAMP(0)
 }
 
@@ -1118,6 +1357,28 @@ int decoder_cluster_t_pad(int64_t t_max, int64_t s_max) {
   return static_cast<int>((keys + 15) / 16 * 16 + 16);
 }
 
+namespace {
+// CT2X_CLUSTER_HANDOVER=counter: the arrival-counter form of the hand-over (A/B runs)
+bool cluster_handover_tagged() {
+  static const bool tagged = [] {
+    const char* e = std::getenv("CT2X_CLUSTER_HANDOVER");
+    return e == nullptr || e[0] != 'c';
+  }();
+  return tagged;
+}
+}  // namespace
+
+int decoder_cluster_proj_cols(int64_t rows, int64_t vocab, int64_t k) {
+  static const bool enabled = [] {  // CT2X_CLUSTER_PROJ=0: the projection keeps its own launch (A/B runs)
+    const char* e = std::getenv("CT2X_CLUSTER_PROJ");
+    return e == nullptr || e[0] != '0';
+  }();
+  if (!enabled || !cluster_handover_tagged() || k != kD || rows < 1 || rows > 32 || vocab < 1) return 0;
+  const int64_t wgs = rows * kMembers;
+  const int64_t cols = ((vocab + wgs - 1) / wgs + kProjCols - 1) / kProjCols * kProjCols;
+  return cols / kProjCols <= kClusterProjMaxPasses ? static_cast<int>(cols) : 0;
+}
+
 void launch_decoder_cluster(const ClusterStackArgs& a, hipStream_t stream) {
   CT2X_CHECK(a.n_layers >= 1 && a.n_layers <= kClusterMaxLayers && a.n_layers * 6 + 3 < 64, "decoder_cluster: layers");
   if (a.rows_per_cluster > 0) {  // beam search, or a greedy batch of more than 32 rows
@@ -1142,13 +1403,25 @@ void launch_decoder_cluster(const ClusterStackArgs& a, hipStream_t stream) {
                        dim3(kThreads), lds, stream, a);
     return;
   }
-  const size_t lds = sizeof(Shared) + static_cast<size_t>(a.t_pad) * sizeof(float);
+  size_t lds = sizeof(Shared) + static_cast<size_t>(a.t_pad) * sizeof(float);
   CT2X_CHECK(lds <= 64 * 1024, "decoder_cluster: the score row does not fit the LDS");
-  // CT2X_CLUSTER_HANDOVER=counter: the arrival-counter form of the hand-over (A/B runs)
-  static const bool tagged = [] {
-    const char* e = std::getenv("CT2X_CLUSTER_HANDOVER");
-    return e == nullptr || e[0] != 'c';
-  }();
+  const bool tagged = cluster_handover_tagged();
+  if (a.proj.w != nullptr) {
+    CT2X_CHECK(tagged && a.proj.cols_per_wg > 0 && a.proj.cols_per_wg % kProjCols == 0 &&
+                   a.proj.cols_per_wg / kProjCols <= kClusterProjMaxPasses &&
+                   static_cast<int64_t>(a.rows) * kMembers * a.proj.cols_per_wg >= a.proj.vocab && a.rows <= 32 &&
+                   a.proj.rows_q != nullptr && a.proj.seq != nullptr && a.proj.gf.slots != nullptr,
+               "decoder_cluster: projection tail");
+    lds = ((lds + 1023) & ~size_t(1023)) + kProjWBytes;
+    static std::atomic<bool> opted[64];
+    int dev = 0;
+    CT2X_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !opted[dev].load(std::memory_order_acquire)) {
+      CT2X_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_cluster_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      if (dev >= 0 && dev < 64) opted[dev].store(true, std::memory_order_release);
+    }
+  }
   const dim3 grid(static_cast<unsigned>(a.rows * kMembers)), block(kThreads);
   if (tagged) hipLaunchKernelGGL(decoder_cluster_kernel<true>, grid, block, lds, stream, a);
   else hipLaunchKernelGGL(decoder_cluster_kernel<false>, grid, block, lds, stream, a);

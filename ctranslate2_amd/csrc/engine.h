@@ -679,6 +679,10 @@ struct DecodeState {
   float* cl_xch = nullptr;
   unsigned* cl_counters = nullptr;
   size_t cl_xch_floats = 0, cl_counter_words = 0;
+  // projection tail of the one-row launch (ClusterProjArgs): the clusters' quantised output rows
+  // as tagged slots, the session's launch count (the tag)
+  unsigned long long* cl_proj_q = nullptr;
+  unsigned* cl_proj_seq = nullptr;
   // beam search, round 6: per-row candidates of the fused LogSoftMax + TopK ([rows, 2 * beam]) and the
   // ticket of the step advance that rides in beam_select_kernel (nullptr: the separate launches)
   float* bt_part_v = nullptr;

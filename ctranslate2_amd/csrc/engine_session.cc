@@ -353,8 +353,14 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
       CT2X_HIP_CHECK(hipMemsetAsync(st->cl_xch, 0, sizeof(float) * xch_floats, cur_stream()));
       CT2X_HIP_CHECK(hipMemsetAsync(st->cl_counters, 0, sizeof(unsigned) * rows * 16, cur_stream()));
       CT2X_HIP_CHECK(hipMemsetAsync(st->cl_error, 0, sizeof(int), cur_stream()));
+      if (cluster_greedy && rows <= 32) {
+        st->cl_proj_q = alloc<unsigned long long>(*st, rows * kClusterProjRowSlots);
+        st->cl_proj_seq = alloc<unsigned>(*st, 1);
+        CT2X_HIP_CHECK(hipMemsetAsync(st->cl_proj_q, 0, sizeof(unsigned long long) * rows * kClusterProjRowSlots, cur_stream()));
+        CT2X_HIP_CHECK(hipMemsetAsync(st->cl_proj_seq, 0, sizeof(unsigned), cur_stream()));
+      }
       if (const char* e = std::getenv("CT2X_CLUSTER_STAMPS"); e != nullptr && e[0] == '1')
-        st->cl_stamps = alloc<unsigned long long>(*st, 2 + kClusterStampsPerLayer * n_layers);
+        st->cl_stamps = alloc<unsigned long long>(*st, 2 + kClusterStampsPerLayer * n_layers + 8);
     }
     if (features)
       encode_features(*st, features, frames);
@@ -429,7 +435,7 @@ void Engine::check_cluster(DecodeState& st) {
   if (st.cl_error == nullptr) return;
   if (st.cl_stamps != nullptr) {
     // phase timeline of workgroup 0 in the session's last step (wall_clock64: 100 MHz)
-    const size_t n = 2 + kClusterStampsPerLayer * dec_.layers.size();
+    const size_t n = 2 + kClusterStampsPerLayer * dec_.layers.size() + 8;  // (+ the projection tail's)
     std::vector<unsigned long long> h(n);
     CT2X_HIP_CHECK(hipMemcpy(h.data(), st.cl_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     std::fprintf(stderr, "decoder_stack timeline (us since launch start):");

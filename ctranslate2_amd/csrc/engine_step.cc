@@ -55,6 +55,7 @@ void Engine::launch_step(DecodeState& st) {
   const bool zero_amax = split_quant || ffn_amax;
   const bool cluster = cluster_applicable(st);
   bool cluster_out_quant = false;
+  bool cluster_proj = false;  // the vocabulary projection + greedy arg-max ran as the launch's tail
   if (cluster) {
     // embedding + every decoder layer: ONE launch (decoder_cluster.hip)
     ClusterStackArgs ca;
@@ -104,12 +105,47 @@ void Engine::launch_step(DecodeState& st) {
       ca.out_norm.rms_use_residual = dec_.output_norm.use_residual ? 1 : 0;
       ca.q_out = st.qbuf;
       ca.qscale_out = st.qscale;
+      // ... and so do the projection itself and the greedy sampler where the fused arg-max form
+      // applies (fused_argmax_applicable) and the launch's workgroups can hold their share of the
+      // weight rows: the step is then ONE launch
+      const int proj_cols = (!st.beam_mode && rows <= 32 && st.cl_proj_q != nullptr && fused_argmax_applicable(st) &&
+                             (reinterpret_cast<uintptr_t>(dec_.projection.wq) & 15) == 0)
+                                ? decoder_cluster_proj_cols(rows, dec_.projection.n, dec_.projection.k)
+                                : 0;
+      if (proj_cols > 0) {
+        cluster_proj = true;
+        const DenseW& w = dec_.projection;
+        ca.q_out = nullptr;
+        ca.qscale_out = nullptr;
+        ca.proj.w = w.wq;
+        ca.proj.wscale = w.wscale;
+        ca.proj.bias = w.bias;
+        ca.proj.vocab = static_cast<int>(w.n);
+        ca.proj.cols_per_wg = proj_cols;
+        ca.proj.rows_q = st.cl_proj_q;
+        ca.proj.seq = st.cl_proj_seq;
+        ca.proj.gf.slots = st.gf_slots;
+        ca.proj.gf.ticket = st.gf_ticket;
+        ca.proj.gf.step_ptr = st.d_step;
+        ca.proj.gf.disable_id = st.g_eos;
+        ca.proj.gf.min_length = st.g_min_length;
+        ca.proj.gf.prefix_ids = st.d_prefix;
+        ca.proj.gf.prefix_lens = st.d_prefix_len;
+        ca.proj.gf.prefix_stride = st.prefix_stride;
+        ca.proj.gf.prefix_first_step = st.prefix_first_step;
+        ca.proj.gf.prefix_extends_min = st.prefix_extends_min ? 1 : 0;
+        ca.proj.gf.next_ids = st.d_ids;
+        ca.proj.gf.hist_ids = st.hist_ids;
+        ca.proj.gf.hist_scores = st.hist_scores;
+        ca.proj.gf.advance_step_ptr = st.d_step;
+      }
     }
     {
       double wbytes = 0;
       for (const LayerW& layer : dec_.layers)
         wbytes += double(layer.self.lin[0].n + layer.self.lin[1].n + layer.cross.lin[0].n + layer.cross.lin[2].n) * d +
                   2.0 * double(layer.ffn.l0.n) * d;
+      if (cluster_proj) wbytes += double(dec_.projection.n) * (d + 4 + (dec_.projection.bias ? 4 : 0));
       begin_kernel("decoder_stack", wbytes + double(rows) * d * 8, 2.0 * rows * wbytes, rows, d, d);
     }
     launch_decoder_cluster(ca, cur_stream());
@@ -383,7 +419,9 @@ void Engine::launch_step(DecodeState& st) {
   QuantIn pq;
   const float* proj_in = x;
   bool fused_argmax = false;  // the vocabulary projection sampled the step itself (GreedyFuse)
-  if (cluster_out_quant || !dense_norm(dec_.output_norm, dec_.projection, x, rows, -1, nullptr, st.logits)) {
+  if (cluster_proj) {
+    fused_argmax = true;  // (projected and sampled in the decoder-stack launch's tail)
+  } else if (cluster_out_quant || !dense_norm(dec_.output_norm, dec_.projection, x, rows, -1, nullptr, st.logits)) {
     if (cluster_out_quant) {
       pq.q = st.qbuf;
       pq.s = st.qscale;

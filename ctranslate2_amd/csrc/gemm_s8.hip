@@ -14,6 +14,7 @@
 // Integer accumulation is exact, so any correct tiling is bit-identical to the oracle.
 
 #include "device_utils.h"
+#include "greedy_fuse.h"
 #include "kernels.h"
 #include "row_norm.h"
 #include "runtime.h"
@@ -667,14 +668,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
       }
       if (ep.residual) v = e_res[o] + v;
       if (ARGMAX) {
-        // key order = (value, then LOWER column): the arg-max tie rule of the sampler (better())
+        // key order = (value, then LOWER column): the arg-max tie rule of the sampler (greedy_fuse.h)
         if (static_cast<int>(col) != gf_masked[i] && v == v) {
-          // (-0.0 and +0.0 compare equal in the sampler's `>`: both signs pack as +0.0 so that
-          // the lower column wins between them as well; the value itself is not returned here)
-          const unsigned u = (v == 0.f) ? 0u : __float_as_uint(v);
-          const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-          const unsigned long long key =
-              (static_cast<unsigned long long>(ord) << 32) | (0xFFFFFFFFu - static_cast<unsigned>(col));
+          const unsigned long long key = greedy_fuse_key(v, static_cast<unsigned>(col));
           gf_best[i] = key > gf_best[i] ? key : gf_best[i];
         }
       } else {
@@ -707,52 +703,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_skinny_kernel(
     if (tid == 0) gf_ticket = atomicAdd(ep.gf.ticket, 1u);
     __syncthreads();
     if (gf_ticket == gridDim.x * gridDim.y - 1) {
-      // every workgroup of the launch has combined its rows: finish the step (the tail of
-      // greedy_sample_kernel, decode_ops.hip)
-      // (thread t reads - and clears - sub-slot t % 16 of row t / 16; 16 lanes fold a row)
-      constexpr int RPP = THREADS / GreedyFuse::kSubSlots;  // rows per pass
-      constexpr int PASSES = (32 + RPP - 1) / RPP;          // M_all <= 32 (gemm_s8_argmax_applicable)
-      unsigned long long keys[PASSES];
-#pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) {  // every exchange of the workgroup in one round trip
-        const int row = ps * RPP + tid / GreedyFuse::kSubSlots;
-        keys[ps] = 0ull;
-        if (row < M_all)
-          keys[ps] = atomicExch(ep.gf.slots + static_cast<int64_t>(row) * GreedyFuse::kSubSlots +
-                                    (tid % GreedyFuse::kSubSlots), 0ull);
-      }
-#pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) {
-        const int row = ps * RPP + tid / GreedyFuse::kSubSlots;
-        unsigned long long key = keys[ps];
-#pragma unroll
-        for (int off = GreedyFuse::kSubSlots / 2; off >= 1; off >>= 1) {
-          const unsigned long long other = __shfl_xor(key, off, 64);
-          key = other > key ? other : key;
-        }
-        if (row >= M_all || (tid % GreedyFuse::kSubSlots) != 0) continue;
-        int id = 0;
-        float score = 0.f;
-        if (key != 0ull) {
-          id = static_cast<int>(0xFFFFFFFFu - static_cast<unsigned>(key));
-          const unsigned ord = static_cast<unsigned>(key >> 32);
-          score = __uint_as_float((ord & 0x80000000u) ? (ord & 0x7FFFFFFFu) : ~ord);
-        }
-        if (ep.gf.prefix_ids != nullptr) {
-          const int local = gf_step - ep.gf.prefix_first_step;
-          if (local >= 0 && local < ep.gf.prefix_lens[row]) {
-            id = ep.gf.prefix_ids[static_cast<int64_t>(row) * ep.gf.prefix_stride + local];
-            score = 0.f;
-          }
-        }
-        ep.gf.next_ids[row] = id;
-        ep.gf.hist_ids[static_cast<int64_t>(gf_step) * M_all + row] = id;
-        ep.gf.hist_scores[static_cast<int64_t>(gf_step) * M_all + row] = score;
-      }
-      if (tid == 0) {
-        *ep.gf.ticket = 0u;
-        if (ep.gf.advance_step_ptr != nullptr) *ep.gf.advance_step_ptr = gf_step + 1;
-      }
+      // every workgroup of the launch has combined its rows: finish the step (greedy_fuse.h)
+      greedy_fuse_finish<THREADS>(ep.gf, M_all, gf_step, tid);
     }
   }
   if (ep.row_amax_out != nullptr) {

@@ -241,6 +241,24 @@ struct ClusterLayerArgs {
   float self_scale = 1.f, cross_scale = 1.f;
 };
 constexpr int kClusterMaxLayers = 8;
+// The vocabulary projection + the greedy arg-max as the TAIL of the one-row launch (round 6): the
+// launch's workgroups (rows * 8, all resident) each take cols_per_wg columns of the projection -
+// their weight rows travel into LDS by DMA under the last layer's last meeting -, the quantised
+// output rows of all clusters are exchanged through tagged slots, and the GreedyFuse machinery of
+// gemm_s8.hip finishes the step: the step is ONE launch.
+constexpr int kClusterProjCols = 128;      // columns of a pass: eight waves x one 16-column MFMA tile
+constexpr int kClusterProjMaxPasses = 4;
+constexpr int kClusterProjRowSlots = 512 / 4 + 1;  // a row's 128 x 4 int8 + its scale, 8-byte tagged slots
+struct ClusterProjArgs {
+  const int8_t* w = nullptr;       // [vocab, 512] int8, the Dense's own row-major layout; nullptr = off
+  const float* wscale = nullptr;   // [vocab]
+  const float* bias = nullptr;     // [vocab] or nullptr
+  int vocab = 0;
+  int cols_per_wg = 0;             // a multiple of kClusterProjCols; rows * 8 * cols_per_wg >= vocab
+  unsigned long long* rows_q = nullptr;  // [rows, kClusterProjRowSlots], zero at session start
+  unsigned* seq = nullptr;         // launches of the session so far (the slots' tag), zero at session start
+  GreedyFuse gf;
+};
 struct ClusterStackArgs {
   // by value: kernel arguments are read with scalar loads the compiler knows to be invariant (a
   // table in device memory costs a vector load + a full drain of the memory pipe per field)
@@ -269,6 +287,7 @@ struct ClusterStackArgs {
   ClusterNormW out_norm;
   int8_t* q_out = nullptr;
   float* qscale_out = nullptr;
+  ClusterProjArgs proj;                 // one-row launch, tagged hand-over only
   float* xch = nullptr;                 // decoder_cluster_xch_floats(rows): the hand-over lines
   unsigned* counters = nullptr;         // [rows * 16], zero at session start, never reset
   int* error = nullptr;                 // set when a member waited in vain (results void)
@@ -282,6 +301,9 @@ bool decoder_cluster_geometry_ok(int64_t d_model, int64_t heads, int64_t dhead, 
 size_t decoder_cluster_xch_floats(int64_t rows);
 int decoder_cluster_t_pad(int64_t t_max, int64_t s_max);
 bool decoder_cluster_lds_ok(int t_pad);  // the score row of the longest cache fits next to the tiles
+// the projection tail: cols_per_wg for (rows, vocab, k), 0 = not served (k != 512, too many passes,
+// the counter form of the hand-over)
+int decoder_cluster_proj_cols(int64_t rows, int64_t vocab, int64_t k);
 bool decoder_cluster_beam_lds_ok(int t_pad);
 size_t decoder_cluster_beam_xch_floats(int64_t clusters);
 // member-major, chunk-major copy of a Dense weight [n, k]; sections = 3 for the fused Q | K | V

@@ -41,7 +41,9 @@ def test_transformer_base_headline_path_matches_reference(gpu):
         src = other if call == 2 else g["sources"]
         hyps, _ = t.translate_ids(src, **kw)
         st = t.last_stats()
-        assert st["kernels_per_step"] == with_sampler - 1, "the fused arg-max path did not run"
+        # (scores asked for: stack launch + projection + sampler; none: the whole step is ONE launch -
+        # the projection and the greedy arg-max ride in the decoder-stack launch's tail, round 6)
+        assert with_sampler == 3 and st["kernels_per_step"] == 1, "the one-launch step did not run"
         assert st["num_tokens"] == 32 * 64
         outs.append([h[0] for h in hyps])
     assert t.last_stats()["session_hits"] - hits0 == 4, "calls 2..5 replay the kept session"
