@@ -1425,6 +1425,7 @@ void Engine::dense(const DenseW& w, const float* x, const QuantIn* qin, int64_t 
       ep.gf.hist_ids = gs.hist_ids;
       ep.gf.hist_scores = gs.hist_scores;
       ep.gf.advance_step_ptr = gs.d_step;
+      ep.gf.host_hist_ids = gs.host_hist_ids;
     }
     {
       const double M = double(m), N = double(w.n), K = double(w.k);

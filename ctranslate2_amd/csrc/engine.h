@@ -632,6 +632,13 @@ struct DecodeState {
   int64_t pin_cand_capacity = 0;
   hipEvent_t pin_cand_event[2] = {nullptr, nullptr};
   // pinned host staging for the pipelined history read-back (greedy loop)
+  // pinned mirror of hist_ids written by the fused greedy sampler itself (GreedyFuse::host_hist_ids):
+  // while a step group ran on that path (hist_on_host) the loop reads the ids from it and no copy
+  // is enqueued; pin_first = the group's first step per slot
+  int32_t* host_hist_ids = nullptr;
+  bool hist_on_host = false;
+  int64_t pin_first[2] = {0, 0};
+  bool pin_from_host[2] = {false, false};
   int32_t* pin_ids[2] = {nullptr, nullptr};
   float* pin_scores[2] = {nullptr, nullptr};
   int64_t pin_capacity = 0;

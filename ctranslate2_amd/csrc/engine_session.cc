@@ -40,6 +40,7 @@ DecodeState::~DecodeState() {
   for (int i = 0; i < 2; ++i) {
     if (graph_exec[i]) (void)hipGraphExecDestroy(graph_exec[i]);
     if (i == 0 && group_exec) (void)hipGraphExecDestroy(group_exec);
+    if (i == 0) pinned_free(host_hist_ids);
     pinned_free(pin_ids[i]);
     pinned_free(pin_scores[i]);
     if (pin_event[i]) (void)hipEventDestroy(pin_event[i]);
@@ -171,6 +172,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
                                 cur_stream()));
   CT2X_HIP_CHECK(hipMemsetAsync(st->gf_ticket, 0, sizeof(unsigned int), cur_stream()));
   st->hist_ids = alloc<int32_t>(*st, (t_max + 1) * rows);
+  st->host_hist_ids = static_cast<int32_t*>(pinned_malloc(sizeof(int32_t) * (t_max + 1) * rows));
   st->hist_scores = alloc<float>(*st, (t_max + 1) * rows);
   CT2X_HIP_CHECK(hipMemsetAsync(st->d_step, 0, sizeof(int32_t), cur_stream()));
   st->logprobs = alloc<float>(*st, rows * V);  // log-probabilities (beam search) / exp scratch

@@ -138,6 +138,7 @@ void Engine::launch_step(DecodeState& st) {
         ca.proj.gf.hist_ids = st.hist_ids;
         ca.proj.gf.hist_scores = st.hist_scores;
         ca.proj.gf.advance_step_ptr = st.d_step;
+        ca.proj.gf.host_hist_ids = st.host_hist_ids;
       }
     }
     {
@@ -487,6 +488,7 @@ void Engine::launch_step(DecodeState& st) {
                            st.prefix_extends_min, st.d_step, kLogitsRing, st.logit_hist, cur_stream());
       end_kernel();
     }
+    st.hist_on_host = fused_argmax && st.host_hist_ids != nullptr;
     if (fused_argmax) {
       // (sampled by the last workgroup of the projection)
     } else if (st.g_topk == 1) {
@@ -854,17 +856,23 @@ void Engine::read_history_async(DecodeState& st, int64_t first, int64_t count, i
     }
     st.pin_capacity = need;
   }
-  CT2X_HIP_CHECK(hipMemcpyAsync(st.pin_ids[slot], st.hist_ids + first * st.rows,
-                                sizeof(int32_t) * need, hipMemcpyDeviceToHost, cur_stream()));
-  CT2X_HIP_CHECK(hipMemcpyAsync(st.pin_scores[slot], st.hist_scores + first * st.rows,
-                                sizeof(float) * need, hipMemcpyDeviceToHost, cur_stream()));
+  // (the fused greedy sampler stored the ids of these steps in the pinned mirror itself: nothing to
+  // copy - the event alone says the group has run; scores only travel when somebody asked for them)
+  st.pin_from_host[slot] = st.hist_on_host;
+  st.pin_first[slot] = first;
+  if (!st.hist_on_host)
+    CT2X_HIP_CHECK(hipMemcpyAsync(st.pin_ids[slot], st.hist_ids + first * st.rows,
+                                  sizeof(int32_t) * need, hipMemcpyDeviceToHost, cur_stream()));
+  if (st.g_scores || !st.fuse_greedy)
+    CT2X_HIP_CHECK(hipMemcpyAsync(st.pin_scores[slot], st.hist_scores + first * st.rows,
+                                  sizeof(float) * need, hipMemcpyDeviceToHost, cur_stream()));
   CT2X_HIP_CHECK(hipEventRecord(st.pin_event[slot], cur_stream()));
 }
 
 void Engine::wait_history(DecodeState& st, int slot, const int32_t** h_ids,
                           const float** h_scores) {
   CT2X_HIP_CHECK(hipEventSynchronize(st.pin_event[slot]));
-  *h_ids = st.pin_ids[slot];
+  *h_ids = st.pin_from_host[slot] ? st.host_hist_ids + st.pin_first[slot] * st.rows : st.pin_ids[slot];
   *h_scores = st.pin_scores[slot];
 }
 

@@ -61,6 +61,7 @@ __device__ __forceinline__ void greedy_fuse_finish(const GreedyFuse& gf, int m_a
     }
     gf.next_ids[row] = id;
     gf.hist_ids[static_cast<int64_t>(gf_step) * m_all + row] = id;
+    if (gf.host_hist_ids != nullptr) gf.host_hist_ids[static_cast<int64_t>(gf_step) * m_all + row] = id;
     gf.hist_scores[static_cast<int64_t>(gf_step) * m_all + row] = score;
   }
   if (tid == 0) {

@@ -120,6 +120,9 @@ struct GreedyFuse {
   int32_t* hist_ids = nullptr;
   float* hist_scores = nullptr;
   int32_t* advance_step_ptr = nullptr;  // nullptr: the caller advances the step itself
+  // pinned host copy of hist_ids (same layout) or nullptr: the finishing workgroup stores the ids
+  // there as well, so the decoding loop reads them without a copy kernel after every group of steps
+  int32_t* host_hist_ids = nullptr;
 };
 // shapes the fused form serves (the skinny kernel's vocabulary-projection instantiations)
 bool gemm_s8_argmax_applicable(int64_t m, int64_t n, int64_t k);

@@ -85,6 +85,12 @@ cluster_check)    # the decoder-stack launch's own tests, then the timeline and 
   timeout 900 python -m pytest tests/test_decoder_cluster_gpu.py tests/test_bench_path_gpu.py -x -q 2>&1 | tail -4 | tee $O/cluster_tests.txt
   CT2X_CLUSTER_STAMPS=1 timeout 300 python bench.py --steps 2 --warmup 1 $NOLEGS --no-token-check 2>&1 | grep -A8 "decoder_stack timeline" | tail -9 | tee $O/cluster_timeline.txt
   { for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 3 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done; } | tee $O/cluster_speed.txt ;;
+trace_gaps)       # profiles/r06_tb_kernel_trace_gaps.txt + r06_kernel_stats_bench_tb_b32.csv: rocprofv3 kernel trace of the headline leg
+  cd /tmp; rm -rf /tmp/r6trace; ( cd $GRAFT_REPO_ROOT; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r6trace -- python bench.py --steps 12 --warmup 3 $NOLEGS --no-token-check > $O/trace_bench.log 2>&1 )
+  cd $GRAFT_REPO_ROOT
+  f=$(find /tmp/r6trace -name "*kernel_trace.csv" | head -1); python tools/trace_gaps.py "$f" 2>&1 | head -40 | tee $O/tb_kernel_trace_gaps.txt
+  g=$(find /tmp/r6trace -name "*kernel_stats.csv" | head -1); cp "$g" $O/kernel_stats_bench_tb_b32.csv; head -8 "$g" | cut -c1-200
+  tail -1 $O/trace_bench.log | cut -c1-300 ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
