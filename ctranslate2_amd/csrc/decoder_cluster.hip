@@ -416,6 +416,15 @@ __device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, 
   return scale;
 }
 
+// maximum over the row of 16 lanes a lane belongs to, to every lane of the row (row_ror 8, 4, 2, 1)
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+  v = max(v, static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x128, 0xf, 0xf, false)));
+  v = max(v, static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x124, 0xf, 0xf, false)));
+  v = max(v, static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x122, 0xf, 0xf, false)));
+  v = max(v, static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x121, 0xf, 0xf, false)));
+  return v;
+}
+
 // Projection tail: wave w's share of a pass's weight rows, global -> LDS by DMA (1 KB per
 // instruction, no registers): chunk (w, ks) = the B fragment of MFMA k-step ks for the wave's 16
 // columns - lane l supplies 16 bytes of column l % 16 at K offset ks * 64 + (l / 16) * 16, the LDS
@@ -849,21 +858,85 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
           }
         }
         CT2X_CL_STAMP(4)
-        // the 16 lanes that share a row, then the eight waves (LDS), then the launch (memory)
+        // the 16 lanes that share a row (a DPP row rotation is an all-reduce of a row of 16 lanes: the
+        // order word first, then the column word among the lanes that hold the maximum - the 64-bit
+        // shuffles of the first form were 2 us of this tail), then the eight waves (LDS), then the launch
+        {
+          unsigned long long* wave_keys = reinterpret_cast<unsigned long long*>(sh.vs);  // [8 waves][32 rows] (the value tile is dead)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            unsigned long long k = best[i][q];
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) {
-              const unsigned long long other = __shfl_xor(k, off, 64);
-              k = other > k ? other : k;
+            for (int q = 0; q < 4; ++q) {
+              const unsigned hi = static_cast<unsigned>(best[i][q] >> 32);
+              const unsigned m_hi = row16_max_u32(hi);
+              const unsigned lo = (hi == m_hi) ? static_cast<unsigned>(best[i][q]) : 0u;
+              const unsigned m_lo = row16_max_u32(lo);
+              const int rr = i * 16 + (lane >> 4) * 4 + q;
+              if ((lane & 15) == 0) wave_keys[wave * 32 + rr] = (static_cast<unsigned long long>(m_hi) << 32) | m_lo;
             }
-            const int rr = i * 16 + (lane >> 4) * 4 + q;
-            if ((lane & 15) == 0 && rr < a.rows && k != 0ull) atomicMax(&keys[rr], k);
+          lds_barrier();
+          if (t < 32) {
+            unsigned long long m = wave_keys[t];
+#pragma unroll
+            for (int w = 1; w < kThreads / 64; ++w) m = wave_keys[w * 32 + t] > m ? wave_keys[w * 32 + t] : m;
+            keys[t] = m;
           }
+        }
         __syncthreads();
+        if (P.board != nullptr) {
+          // ---- the board form: every workgroup posts its 32 row maxima, workgroup r finishes row r
+          const unsigned btag = pseq % 65535u + 1u;
+          const int wgs = static_cast<int>(gridDim.x);
+          if (t < a.rows) {
+            const unsigned long long k = keys[t];  // (ord << 32) | (0xFFFFFFFF - column), 0 = none
+            const unsigned long long k48 = (k == 0ull) ? 0ull : (((k >> 32) << 16) | (k & 0xFFFFull));
+            grid_publish(P.board + (static_cast<size_t>(t) * wgs + blockIdx.x), (k48 << 16) | btag);
+          }
+          CT2X_CL_STAMP(5)
+          if (static_cast<int>(blockIdx.x) < a.rows) {
+            const int r = static_cast<int>(blockIdx.x);
+            unsigned long long u = 0ull;
+            if (t < wgs) {
+              unsigned spins = 0;
+              const unsigned long long* slot = P.board + (static_cast<size_t>(r) * wgs + t);
+              for (;;) {
+                u = grid_observe(slot);
+                if (static_cast<unsigned>(u & 0xFFFFull) == btag) break;
+                if (++spins > kSpinLimit || sh.dead) {
+                  sh.dead = 1;
+                  atomicExch(a.error, 1);
+                  u = 0ull;
+                  break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+              }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+              const unsigned long long other = __shfl_xor(u, off, 64);
+              u = other > u ? other : u;
+            }
+            lds_barrier();  // (keys[] of the phase above have been read)
+            if (lane == 0) keys[wave] = u;
+            lds_barrier();
+            CT2X_CL_STAMP(6)
+            if (t == 0) {
+              unsigned long long m = keys[0];
+#pragma unroll
+              for (int w = 1; w < kThreads / 64; ++w) m = keys[w] > m ? keys[w] : m;
+              const unsigned long long k48 = m >> 16;
+              int id = 0;
+              float score = 0.f;
+              if (k48 != 0ull) {
+                id = static_cast<int>(0xFFFFu - static_cast<unsigned>(k48 & 0xFFFFull));
+                const unsigned ord = static_cast<unsigned>(k48 >> 16);
+                score = __uint_as_float((ord & 0x80000000u) ? (ord & 0x7FFFFFFFu) : ~ord);
+              }
+              greedy_fuse_finish_row(P.gf, a.rows, step, r, id, score);
+              if (r == 0 && P.gf.advance_step_ptr != nullptr) *P.gf.advance_step_ptr = step + 1;
+            }
+          }
+        } else {
         if (t < a.rows && keys[t] != 0ull) {
           // (a returning atomic: it has been performed when its value arrives, i.e. before the ticket)
           const unsigned long long old =
@@ -876,6 +949,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
         __syncthreads();
         CT2X_CL_STAMP(6)
         if (static_cast<unsigned>(masked[32]) == gridDim.x - 1) greedy_fuse_finish<kThreads>(P.gf, a.rows, step, t);
+        }
         if (blockIdx.x == 0 && t == 0) *P.seq = pseq + 1u;  // (read by the NEXT launch)
       }
     }

@@ -690,6 +690,7 @@ struct DecodeState {
   // as tagged slots, the session's launch count (the tag)
   unsigned long long* cl_proj_q = nullptr;
   unsigned* cl_proj_seq = nullptr;
+  unsigned long long* cl_proj_board = nullptr;  // [rows][rows * 8] row maxima of the workgroups (ClusterProjArgs::board)
   // beam search, round 6: per-row candidates of the fused LogSoftMax + TopK ([rows, 2 * beam]) and the
   // ticket of the step advance that rides in beam_select_kernel (nullptr: the separate launches)
   float* bt_part_v = nullptr;

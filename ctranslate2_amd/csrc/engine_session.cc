@@ -360,6 +360,8 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
         st->cl_proj_seq = alloc<unsigned>(*st, 1);
         CT2X_HIP_CHECK(hipMemsetAsync(st->cl_proj_q, 0, sizeof(unsigned long long) * rows * kClusterProjRowSlots, cur_stream()));
         CT2X_HIP_CHECK(hipMemsetAsync(st->cl_proj_seq, 0, sizeof(unsigned), cur_stream()));
+        st->cl_proj_board = alloc<unsigned long long>(*st, rows * rows * kClusterMembers);
+        CT2X_HIP_CHECK(hipMemsetAsync(st->cl_proj_board, 0, sizeof(unsigned long long) * rows * rows * kClusterMembers, cur_stream()));
       }
       if (const char* e = std::getenv("CT2X_CLUSTER_STAMPS"); e != nullptr && e[0] == '1')
         st->cl_stamps = alloc<unsigned long long>(*st, 2 + kClusterStampsPerLayer * n_layers + 8);

@@ -124,6 +124,11 @@ void Engine::launch_step(DecodeState& st) {
         ca.proj.cols_per_wg = proj_cols;
         ca.proj.rows_q = st.cl_proj_q;
         ca.proj.seq = st.cl_proj_seq;
+        static const bool board = [] {  // CT2X_CLUSTER_PROJ_BOARD=0: the slots / ticket form of the finish (A/B runs)
+          const char* e = std::getenv("CT2X_CLUSTER_PROJ_BOARD");
+          return e == nullptr || e[0] != '0';
+        }();
+        ca.proj.board = (board && w.n <= 65536) ? st.cl_proj_board : nullptr;
         ca.proj.gf.slots = st.gf_slots;
         ca.proj.gf.ticket = st.gf_ticket;
         ca.proj.gf.step_ptr = st.d_step;

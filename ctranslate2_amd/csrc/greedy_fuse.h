@@ -20,6 +20,23 @@ __device__ __forceinline__ unsigned long long greedy_fuse_key(float v, unsigned 
   return (static_cast<unsigned long long>(ord) << 32) | (0xFFFFFFFFu - col);
 }
 
+// One row's share of the tail: what the sampler does with the row's best (id, score) - force a
+// prefix token, hand the id to the next step, append to the history (one thread per row calls).
+__device__ __forceinline__ void greedy_fuse_finish_row(const GreedyFuse& gf, int m_all, int gf_step, int row, int id,
+                                                       float score) {
+  if (gf.prefix_ids != nullptr) {
+    const int local = gf_step - gf.prefix_first_step;
+    if (local >= 0 && local < gf.prefix_lens[row]) {
+      id = gf.prefix_ids[static_cast<int64_t>(row) * gf.prefix_stride + local];
+      score = 0.f;
+    }
+  }
+  gf.next_ids[row] = id;
+  gf.hist_ids[static_cast<int64_t>(gf_step) * m_all + row] = id;
+  if (gf.host_hist_ids != nullptr) gf.host_hist_ids[static_cast<int64_t>(gf_step) * m_all + row] = id;
+  gf.hist_scores[static_cast<int64_t>(gf_step) * m_all + row] = score;
+}
+
 // All THREADS threads of the finishing workgroup call. m_all <= 32 rows.
 template <int THREADS>
 __device__ __forceinline__ void greedy_fuse_finish(const GreedyFuse& gf, int m_all, int gf_step, int tid) {
@@ -52,17 +69,7 @@ __device__ __forceinline__ void greedy_fuse_finish(const GreedyFuse& gf, int m_a
       const unsigned ord = static_cast<unsigned>(key >> 32);
       score = __uint_as_float((ord & 0x80000000u) ? (ord & 0x7FFFFFFFu) : ~ord);
     }
-    if (gf.prefix_ids != nullptr) {
-      const int local = gf_step - gf.prefix_first_step;
-      if (local >= 0 && local < gf.prefix_lens[row]) {
-        id = gf.prefix_ids[static_cast<int64_t>(row) * gf.prefix_stride + local];
-        score = 0.f;
-      }
-    }
-    gf.next_ids[row] = id;
-    gf.hist_ids[static_cast<int64_t>(gf_step) * m_all + row] = id;
-    if (gf.host_hist_ids != nullptr) gf.host_hist_ids[static_cast<int64_t>(gf_step) * m_all + row] = id;
-    gf.hist_scores[static_cast<int64_t>(gf_step) * m_all + row] = score;
+    greedy_fuse_finish_row(gf, m_all, gf_step, row, id, score);
   }
   if (tid == 0) {
     *gf.ticket = 0u;

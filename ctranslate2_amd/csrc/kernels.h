@@ -260,6 +260,12 @@ struct ClusterProjArgs {
   int cols_per_wg = 0;             // a multiple of kClusterProjCols; rows * 8 * cols_per_wg >= vocab
   unsigned long long* rows_q = nullptr;  // [rows, kClusterProjRowSlots], zero at session start
   unsigned* seq = nullptr;         // launches of the session so far (the slots' tag), zero at session start
+  // Vocabularies of at most 65536 entries: the row maxima of the workgroups meet on a BOARD of tagged
+  // 8-byte slots [rows][workgroups] = {order of the value : 32 | 0xFFFF - column : 16 | tag : 16} -
+  // plain stores, and workgroup r (< rows) polls row r's slots and finishes that row: one store-to-
+  // load trip instead of a returning atomic + the ticket + the last workgroup's exchanges.
+  // nullptr: the GreedyFuse slots / ticket form (gemm_s8.hip's).
+  unsigned long long* board = nullptr;  // [rows * rows * 8], zero at session start
   GreedyFuse gf;
 };
 struct ClusterStackArgs {
