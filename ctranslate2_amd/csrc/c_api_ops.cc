@@ -463,8 +463,8 @@ int ct2x_gemm_f16w(const float* d_a, const void* d_w, int w_dtype, int64_t m, in
   size_t ws_floats = 0;
   unsigned* tickets = nullptr;
   const size_t n_tickets = 1024;
-  if (m <= 128 && m > 0 && n > 0) {
-    ws_floats = static_cast<size_t>(m <= 64 ? 20 : 8) * m * n;
+  if (m <= 256 && m > 0 && n > 0) {  // (129 .. 256 rows: up to 16 K slices, gemm_h_rows256_kernel)
+    ws_floats = static_cast<size_t>(m <= 64 ? 20 : (m <= 128 ? 8 : 16)) * m * n;
     ws = static_cast<float*>(device_malloc(ws_floats * sizeof(float) + n_tickets * sizeof(unsigned)));
     // (the K slices of decode rows are summed inside the launch: a ticket per 64-column tile)
     tickets = reinterpret_cast<unsigned*>(ws + ws_floats);

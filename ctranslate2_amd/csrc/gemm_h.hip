@@ -617,6 +617,198 @@ __global__ __launch_bounds__(256) void gemm_h_tiled_kernel(const float* __restri
   }
 }
 
+// ---- 129 .. 256 rows (a beam-search decode step of 64 x 4 hypotheses, round 6) -----------------
+// The LDS-tiled form above at 256 rows was 128 x 128 tiles whose weight tile is fetched by two
+// workgroups, one stage of register prefetch (a stage computes for ~1 us, a first-touch weight
+// line takes longer) and two barriers per stage: 29 us + a 5 us slice sum per Dense of the
+// NLLB-3.3B geometry, 0.7 TB/s. Here a workgroup of eight waves owns ALL rows x 128 columns x one
+// K slice: every weight byte is fetched once, stages are 32 K elements (one MFMA k-step), the
+// operands of stage s + 2 and s + 3 are in flight in registers while stage s is multiplied, LDS is
+// double-buffered with ONE barrier per stage, and both operand tiles live in LDS in MFMA fragment
+// order (1 KB per 16 rows x 32 K elements, a lane's 16 bytes at position r * 4 + (g ^ ((r >> 1) &
+// 3)): conflict-free for the coalesced staging writes AND the fragment reads).
+// float16: hi + lo split of the activation as in the other forms (split_f16), lo first.
+constexpr int R256_BN = 128, R256_BK = 32;
+__device__ __forceinline__ float4 as_float4(const v4f& v) { return make_float4(v.x, v.y, v.z, v.w); }
+template <bool kBF16>
+__global__ __launch_bounds__(512) void gemm_h_rows256_kernel(const float* __restrict__ A,
+                                                             const uint16_t* __restrict__ W, int M, int N, int K,
+                                                             HalfEpilogue ep, int k_slice,
+                                                             float* __restrict__ partial) {
+  using Ops = HalfOps<kBF16>;
+  using vec = typename Ops::vec;
+  constexpr int A_BYTES = 16 * 1024, W_BYTES = 8 * 1024;
+  constexpr int STAGE = (kBF16 ? 1 : 2) * A_BYTES + W_BYTES;
+  extern __shared__ __attribute__((aligned(16))) uint8_t r256_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * R256_BN;
+  const int k_begin = blockIdx.z * k_slice;
+  const int k_end = min(K, k_begin + k_slice);
+  const int stages = (k_end - k_begin + R256_BK - 1) / R256_BK;
+  // staging map: four consecutive threads cover the 32 K elements of a row (8 each)
+  const int s_g = tid & 3, s_row = tid >> 2;  // rows s_row and s_row + 128 of A, column s_row of W
+  const int s_pos = ((s_row & 15) * 4 + (s_g ^ (((s_row & 15) >> 1) & 3))) * 16;
+  const int sa_off0 = (s_row >> 4) * 1024 + s_pos, sa_off1 = ((s_row + 128) >> 4) * 1024 + s_pos;
+  const bool a_ok0 = s_row < M, a_ok1 = s_row + 128 < M;
+  const bool w_ok = n0 + s_row < N;
+  const float* a_src0 = A + static_cast<int64_t>(a_ok0 ? s_row : 0) * K + s_g * 8;
+  const float* a_src1 = A + static_cast<int64_t>(a_ok1 ? s_row + 128 : 0) * K + s_g * 8;
+  const uint16_t* w_src = W + (w_ok ? n0 + s_row : 0) * K + s_g * 8;
+  // fragment read map
+  const int r = lane & 15, g = lane >> 4;
+  const int f_pos = (r * 4 + (g ^ ((r >> 1) & 3))) * 16;
+
+  struct Regs {
+    v4f a[4];
+    vec w;
+  };
+  // The requests are inline assembly and so is the wait for them: the compiler's own counter
+  // bookkeeping gave up at the loop's back edge and waited for EVERYTHING in flight at the top of
+  // every stage (vmcnt(0): a prefetch distance of one stage instead of two, and with predicated loads
+  // - the first build - of none: 8.4 instead of 7.3 ms per NLLB step). Five requests per stage, always
+  // (clamped addresses: rows past M and columns past N compute on the clamped row's data - MFMA
+  // rows / columns are independent and those outputs are never stored; stages past the slice
+  // re-request its last stage and are never multiplied), nothing else touches vector memory inside
+  // the loop, so "all but the newest five have landed" is s_waitcnt vmcnt(5).
+  auto load = [&](Regs& R, int st) {
+    const int kk = k_begin + min(st, stages - 1) * R256_BK;
+    const float* p0 = a_src0 + kk;
+    const float* p1 = a_src1 + kk;
+    const uint16_t* pw = w_src + kk;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R.a[0]) : "v"(p0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(R.a[1]) : "v"(p0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R.a[2]) : "v"(p1) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(R.a[3]) : "v"(p1) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R.w) : "v"(pw) : "memory");
+  };
+  // the requests before the newest `newer` loads have landed (the registers are operands so that no
+  // use of them can be scheduled in front of the wait)
+  auto landed5 = [&](Regs& R) {
+    asm volatile("s_waitcnt vmcnt(5)" : "+v"(R.a[0]), "+v"(R.a[1]), "+v"(R.a[2]), "+v"(R.a[3]), "+v"(R.w)::"memory");
+  };
+  auto stash = [&](const Regs& R, int buf) {
+    uint8_t* base = r256_lds + buf * STAGE;
+    if constexpr (!kBF16) {
+      v8h h0, l0, h1, l1;
+      split_f16(as_float4(R.a[0]), as_float4(R.a[1]), h0, l0);
+      split_f16(as_float4(R.a[2]), as_float4(R.a[3]), h1, l1);
+      *reinterpret_cast<v8h*>(base + sa_off0) = h0;
+      *reinterpret_cast<v8h*>(base + sa_off1) = h1;
+      *reinterpret_cast<v8h*>(base + A_BYTES + sa_off0) = l0;
+      *reinterpret_cast<v8h*>(base + A_BYTES + sa_off1) = l1;
+    } else {
+      *reinterpret_cast<vec*>(base + sa_off0) = Ops::from_f32(as_float4(R.a[0]), as_float4(R.a[1]));
+      *reinterpret_cast<vec*>(base + sa_off1) = Ops::from_f32(as_float4(R.a[2]), as_float4(R.a[3]));
+    }
+    *reinterpret_cast<vec*>(base + (kBF16 ? 1 : 2) * A_BYTES + (s_row >> 4) * 1024 + s_pos) = R.w;
+  };
+
+  v4f acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](int buf) {
+    const uint8_t* base = r256_lds + buf * STAGE;
+    vec af[4], bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bfr[j] = *reinterpret_cast<const vec*>(base + (kBF16 ? 1 : 2) * A_BYTES + (wn * 4 + j) * 1024 + f_pos);
+    if constexpr (!kBF16) {
+      vec al[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        al[i] = *reinterpret_cast<const vec*>(base + A_BYTES + (wm * 4 + i) * 1024 + f_pos);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Ops::mfma(al[i], bfr[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const vec*>(base + (wm * 4 + i) * 1024 + f_pos);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = Ops::mfma(af[i], bfr[j], acc[i][j]);
+  };
+
+  // prologue: stages 0, 1, 2 requested; stage 0 parked in LDS
+  Regs Ra, Rb;
+  load(Ra, 0);
+  load(Rb, 1);
+  landed5(Ra);
+  stash(Ra, 0);
+  load(Ra, 2);
+  // stage s is multiplied from buffer s & 1 while stage s + 1 is parked (its registers were
+  // requested two stages ago) and stage s + 3 is requested into the registers that just emptied
+  for (int s = 0; s < stages; s += 2) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    landed5(Rb);
+    stash(Rb, 1);
+    load(Rb, s + 3);
+    multiply(0);
+    if (s + 1 >= stages) break;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    landed5(Ra);
+    stash(Ra, 0);
+    load(Ra, s + 4);
+    multiply(1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (requests past the slice: their registers are dead only now)
+
+  if (partial != nullptr) {  // split K: raw partial sums, the reduce kernel finishes
+    float* pz = partial + static_cast<int64_t>(blockIdx.z) * M * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t row = (wm * 4 + i) * 16 + g * 4 + e;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t col = n0 + (wn * 4 + j) * 16 + r;
+          if (col < N) pz[row * N + col] = acc[i][j][e];
+        }
+      }
+    return;
+  }
+  // Epilogue: operands first, then stores (as in the 128 x 128 form).
+  float bias[4];
+  bool col_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t col = n0 + (wn * 4 + j) * 16 + r;
+    col_ok[j] = col < N;
+    bias[j] = (ep.bias && col_ok[j]) ? ep.bias[col] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float res[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = (wm * 4 + i) * 16 + g * 4 + e;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = n0 + (wn * 4 + j) * 16 + r;
+        res[e][j] = (ep.residual && row < M && col_ok[j]) ? ep.residual[row * N + col] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = (wm * 4 + i) * 16 + g * 4 + e;
+      if (row >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = n0 + (wn * 4 + j) * 16 + r;
+        if (col_ok[j])
+          ep.y[row * N + col] = finish(acc[i][j][e], bias[j], ep.bias != nullptr, ep.act, res[e][j],
+                                       ep.residual != nullptr);
+      }
+    }
+  }
+}
+
 __global__ void gemm_h_splitk_reduce_kernel(const float* __restrict__ partial, int splits, int64_t n,
                                            int64_t total, HalfEpilogue ep) {
   const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
@@ -772,6 +964,27 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
     return;
   }
 #undef CT2X_HSKINNY
+  // 129 .. 256 rows: all rows x 128 columns x a K slice per workgroup (gemm_h_rows256_kernel);
+  // CT2X_H_ROWS256=0 keeps the 128 x 128 tiles (A/B runs)
+  static const bool rows256 = [] {
+    const char* e = std::getenv("CT2X_H_ROWS256");
+    return e == nullptr || e[0] != '0';
+  }();
+  if (rows256 && M > 128 && M <= 256 && K % 32 == 0 && K >= 256 &&
+      ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+    const int col_tiles = (N + R256_BN - 1) / R256_BN;
+    int splits = 1;
+    if (splitk_ws != nullptr)  // enough workgroups for three quarters of the chip, at least eight stages each
+      while (col_tiles * splits < 192 && splits < 16 && K / (splits * 2) >= 256 && (K / (splits * 2)) % 32 == 0 &&
+             static_cast<size_t>(splits) * 2 * M * N <= splitk_floats)  // (splits * 2 slices after the doubling)
+        splits *= 2;
+    const size_t lds = 2 * ((kBF16 ? 1 : 2) * 16 * 1024 + 8 * 1024);
+    allow_big_lds(reinterpret_cast<const void*>(gemm_h_rows256_kernel<kBF16>), lds);
+    hipLaunchKernelGGL((gemm_h_rows256_kernel<kBF16>), dim3(col_tiles, 1, splits), dim3(512), lds, stream, a, w, M, N,
+                       K, ep, K / splits, splits > 1 ? splitk_ws : static_cast<float*>(nullptr));
+    if (splits > 1) launch_splitk_reduce(splitk_ws, splits, N, static_cast<int64_t>(M) * N, ep, stream);
+    return;
+  }
   const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
   int splits = 1;
   if (splitk_ws != nullptr) {

@@ -366,7 +366,12 @@ def _from_bf16_bits(b):
                                    (1000, 777, 264), (2048, 512, 2048),
                                    # decode rows with K slices over workgroups (2 / 8 / 8 / 4 / 4 slices)
                                    (40, 1280, 1280), (40, 1280, 5120), (16, 4096, 4096),
-                                   (64, 2048, 2048), (33, 1000, 2048)])
+                                   (64, 2048, 2048), (33, 1000, 2048),
+                                   # 129 .. 256 rows (round 6, gemm_h_rows256_kernel): all rows x 128 columns
+                                   # x a K slice per workgroup - 4 / 16 / 8 / 4 slices, ragged rows and
+                                   # columns, and the single-slice epilogue
+                                   (256, 8192, 2048), (256, 2048, 8192), (200, 2048, 2048), (129, 1000, 2048),
+                                   (256, 6144, 2048), (250, 640, 256), (256, 33000, 512)])
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("act,with_res", [(-1, True), (0, False)])
 def test_gemm_half_weights(gpu, m, n, k, bf16, act, with_res):

@@ -91,6 +91,17 @@ trace_gaps)       # profiles/r06_tb_kernel_trace_gaps.txt + r06_kernel_stats_ben
   f=$(find /tmp/r6trace -name "*kernel_trace.csv" | head -1); python tools/trace_gaps.py "$f" 2>&1 | head -40 | tee $O/tb_kernel_trace_gaps.txt
   g=$(find /tmp/r6trace -name "*kernel_stats.csv" | head -1); cp "$g" $O/kernel_stats_bench_tb_b32.csv; head -8 "$g" | cut -c1-200
   tail -1 $O/trace_bench.log | cut -c1-300 ;;
+rows256)          # the 129 .. 256-row 16-bit GEMM: its tests, then the NLLB leg with CT2X_H_ROWS256=0 / 1 alternating
+  timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -k "gemm_half" 2>&1 | tail -3 | tee $O/rows256_tests.txt
+  timeout 900 python -m pytest tests/test_translator_gpu.py -x -q -k "nllb or half" 2>&1 | tail -3 | tee -a $O/rows256_tests.txt
+  { for f in 0 1 0 1; do echo "== CT2X_H_ROWS256=$f"; CT2X_H_ROWS256=$f timeout 600 python tools/bench_nllb.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'tok/s', d['config'].get('decode_ms_per_step'), 'ms/step', d['config'].get('kernels_per_decode_step'))"; done; } 2>&1 | tee $O/rows256_ab.txt ;;
+rows256_kernels)  # per-kernel times of the 256-row 16-bit GEMM forms (rocprofv3 --stats), NLLB decode shapes
+  SH="256:8192:2048 256:2048:8192 256:2048:2048 256:6144:2048"
+  for f in 0 1; do
+    rm -rf /tmp/r256p$f; ( cd /tmp; CT2X_H_ROWS256=$f rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r256p$f -- python $GRAFT_REPO_ROOT/tools/gemm_h_bench.py ${KIND:-f16} $SH > $GRAFT_REPO_ROOT/$O/rows256_bench_$f.txt 2>&1 )
+    echo "== CT2X_H_ROWS256=$f"; grep -v "^W20\|rocprof" $O/rows256_bench_$f.txt | tail -6
+    g=$(find /tmp/r256p$f -name "*kernel_stats.csv" | head -1); cp "$g" $O/rows256_kernel_stats_$f.csv; head -8 "$g" | cut -c1-60,150-260
+  done ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
