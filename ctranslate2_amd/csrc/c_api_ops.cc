@@ -3,6 +3,7 @@
 
 #include "../../include/ct2_mi355.h"
 
+#include <memory>
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -362,6 +363,30 @@ int ct2x_gemm_s8_glu_packed(const int8_t* d_qa, const float* d_a_scale, const in
   API_CATCH
 }
 
+namespace {
+// Row buffers of the leader forms (gemm_s8_stream.hip AMODE 3 / 4) for the duration of one op call:
+// the int8 rows, their scales and the zeroed tag words (the engine keeps these per session).
+struct LeadScratch {
+  void* base = nullptr;
+  LeadScratch(GemmS8Epilogue& ep, int64_t k, hipStream_t s) {
+    const size_t qbytes = static_cast<size_t>(16) * k;
+    base = device_malloc(qbytes + 2 * 16 * sizeof(float));
+    ep.lead_q = static_cast<int8_t*>(base);
+    ep.lead_scale = reinterpret_cast<float*>(static_cast<char*>(base) + qbytes);
+    ep.lead_flag = reinterpret_cast<unsigned*>(ep.lead_scale + 16);
+    ep.lead_tag = 1;
+    CT2X_HIP_CHECK(hipMemsetAsync(ep.lead_flag, 0, 16 * sizeof(unsigned), s));
+  }
+  ~LeadScratch() { device_free(base); }
+  LeadScratch(const LeadScratch&) = delete;
+  LeadScratch& operator=(const LeadScratch&) = delete;
+};
+}  // namespace
+
+int ct2x_debug_set_stream_prologue(int mask) {
+  return gemm_s8_stream_set_prologue_mask(mask);
+}
+
 int ct2x_norm_gemm_s8_dequant_packed(const float* d_x, const float* d_gamma, float eps,
                                      int rms_use_residual, int quant_flags, const int8_t* d_w_packed,
                                      const float* d_w_scale, const float* d_bias,
@@ -386,6 +411,9 @@ int ct2x_norm_gemm_s8_dequant_packed(const float* d_x, const float* d_gamma, flo
   ep.quant_mode = quant_flags;
   ep.row_amax_out = d_row_amax_out;
   ep.packed_b = true;
+  std::unique_ptr<LeadScratch> lead;  // CT2X_STREAM_PROLOGUE bit 2: the norm by sixteen leader workgroups
+  if ((gemm_s8_stream_prologue_mask() & 4) && gemm_s8_stream_lead_norm_applicable(m, n, k, false, false))
+    lead.reset(new LeadScratch(ep, k, resolve_stream(stream)));
   launch_gemm_s8(nullptr, d_w_packed, m, n, k, ep, resolve_stream(stream));
   check_last_launch("norm_gemm_s8_dequant_packed");
   API_CATCH
@@ -418,6 +446,9 @@ int ct2x_norm_gemm_s8_glu_packed(const float* d_x, const float* d_gamma, float e
   ep.quant_mode = quant_flags;
   ep.row_amax_out = d_row_amax_out;
   ep.packed_b = true;
+  std::unique_ptr<LeadScratch> lead;
+  if ((gemm_s8_stream_prologue_mask() & 4) && gemm_s8_stream_lead_norm_applicable(m, n, k, true, false))
+    lead.reset(new LeadScratch(ep, k, resolve_stream(stream)));
   launch_gemm_s8(nullptr, d_w0_packed, m, n, k, ep, resolve_stream(stream));
   check_last_launch("norm_gemm_s8_glu_packed");
   API_CATCH
@@ -429,7 +460,9 @@ int ct2x_gemm_s8_dequant_quantizing_packed(const float* d_x, const float* d_row_
                                            const float* d_residual, int64_t m, int64_t n, int64_t k,
                                            int activation, float* d_y, void* stream) {
   API_TRY
-  CT2X_CHECK(gemm_s8_stream_qol_applicable(m, n, k),
+  // (CT2X_STREAM_PROLOGUE bit 3: ops::Quantize by sixteen leader workgroups - any K with a streaming form)
+  const bool lead_q = (gemm_s8_stream_prologue_mask() & 8) && gemm_s8_stream_lead_quant_applicable(m, n, k);
+  CT2X_CHECK(lead_q || gemm_s8_stream_qol_applicable(m, n, k),
              "ct2x_gemm_s8_dequant_quantizing_packed: needs m <= 16, k = 4096 and a n with a streaming form");
   CT2X_CHECK(d_x != nullptr && d_row_amax != nullptr && amax_parts >= 1,
              "ct2x_gemm_s8_dequant_quantizing_packed: d_x / d_row_amax is NULL or amax_parts < 1");
@@ -446,6 +479,8 @@ int ct2x_gemm_s8_dequant_quantizing_packed(const float* d_x, const float* d_row_
   ep.a_amax_parts = amax_parts;
   ep.quant_mode = quant_flags;
   ep.packed_b = true;
+  std::unique_ptr<LeadScratch> lead;
+  if (lead_q) lead.reset(new LeadScratch(ep, k, resolve_stream(stream)));
   launch_gemm_s8(nullptr, d_w_packed, m, n, k, ep, resolve_stream(stream));
   check_last_launch("gemm_s8_dequant_quantizing_packed");
   API_CATCH

@@ -403,7 +403,7 @@ __device__ __forceinline__ float norm_quantize_row(float v, const NormRegs& ln, 
   lds_barrier();
   parked();
   float sum, sumsq;
-  ordered_row_stats_t<true>(sh.stage, pad, kD, sum, sumsq);
+  ordered_row_stats_t<true, 0>(sh.stage, pad, kD, sum, sumsq);
   if (dbg != nullptr && t == 0) dbg[0] = wall_clock64();
   const NormStats st = norm_stats(sum, sumsq, kD, ln.eps, ln.layer_norm);
   const float y = norm_apply(v, ln.gamma, ln.beta, st, ln.layer_norm, ln.rms_use_residual, t);
@@ -1078,7 +1078,7 @@ __device__ __forceinline__ void norm_quantize_rows(int nr, const NormRegs4& ln, 
   }
   lds_barrier();
   float sum = 0.f, sumsq = 0.f;
-  if (rl.on) ordered_row_stats_t<true>(sh.stage[rl.rw], pad, kD, sum, sumsq);
+  if (rl.on) ordered_row_stats_t<true, 0>(sh.stage[rl.rw], pad, kD, sum, sumsq);
   const NormStats st = norm_stats(sum, sumsq, kD, ln.eps, ln.layer_norm);
   float m = 0.f;
 #pragma unroll

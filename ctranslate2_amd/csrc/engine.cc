@@ -1153,11 +1153,15 @@ bool Engine::dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_
   if (!gemm_s8_norm_fusion_enabled() || taps_ || !ln.present || !w.quantized || w.row_parallel)
     return false;
   // streaming form (weights too large to stay cache resident, <= 16 rows, RMSNorm rows of 4096)
-  const bool stream = w.wq_stream != nullptr && !w.wq_stream_dual && !tp_ &&
-                      (gemm_s8_stream_prologue_mask() & 1) &&
-                      gemm_s8_stream_norm_applicable(m, w.n, w.k, false, ln.beta != nullptr);
-  if (!stream && !gemm_s8_norm_applicable(m, w.n, w.k)) return false;
+  const bool streamable = w.wq_stream != nullptr && !w.wq_stream_dual && !tp_;
+  // (round 6: the norm by sixteen leader workgroups of the launch, CT2X_STREAM_PROLOGUE bit 2)
   GemmS8Epilogue ep;
+  const bool lead = streamable && (gemm_s8_stream_prologue_mask() & 4) &&
+                    gemm_s8_stream_lead_norm_applicable(m, w.n, w.k, false, ln.beta != nullptr) &&
+                    lead_fill(ep, m);
+  const bool stream = lead || (streamable && (gemm_s8_stream_prologue_mask() & 1) &&
+                               gemm_s8_stream_norm_applicable(m, w.n, w.k, false, ln.beta != nullptr));
+  if (!stream && !gemm_s8_norm_applicable(m, w.n, w.k)) return false;
   ep.mode = 1;
   ep.w_scale = w.wscale;
   ep.bias = w.bias;
@@ -1201,6 +1205,7 @@ void Engine::dense_qol(const DenseW& w, const float* x, const float* row_amax, i
   // streaming form: the fragment-major weight copy
   const bool stream = stream_qol_applicable(w, m);
   ep.packed_b = stream;
+  if (stream && stream_lead_quant_applicable(w, m)) lead_fill(ep, m);
   const double M = double(m), N = double(w.n), K = double(w.k);
   begin_kernel("qgemm_s8_dequant", 4 * M * K + N * K + 4 * N + 4 * M + 4 * M * N +
                                        (residual ? 4 * M * N : 0) + (w.bias ? 4 * N : 0),
@@ -1212,8 +1217,39 @@ void Engine::dense_qol(const DenseW& w, const float* x, const float* row_amax, i
 // Whether the Quantize in front of this Dense can run as the prologue of the streaming kernel
 // (gemm_s8_stream.hip AMODE 1: <= 16 rows, K = 4096, packed weight present).
 bool Engine::stream_qol_applicable(const DenseW& w, int64_t m) const {
+  if (stream_lead_quant_applicable(w, m)) return true;
   return !tp_ && !taps_ && (gemm_s8_stream_prologue_mask() & 2) && w.quantized && !w.row_parallel &&
          w.wq_stream != nullptr && !w.wq_stream_dual && gemm_s8_stream_qol_applicable(m, w.n, w.k);
+}
+
+// ... or as the work of the launch's first sixteen workgroups (AMODE 4, round 6: any K with a
+// streaming form; needs the session's tag words).
+bool Engine::stream_lead_quant_applicable(const DenseW& w, int64_t m) const {
+  const DecodeState* st = pf_state_;
+  return !tp_ && !taps_ && (gemm_s8_stream_prologue_mask() & 8) && st != nullptr &&
+         st->lead_flag != nullptr && st->rows <= 16 && w.quantized && !w.row_parallel &&
+         w.wq_stream != nullptr && !w.wq_stream_dual && gemm_s8_stream_lead_quant_applicable(m, w.n, w.k);
+}
+
+bool Engine::lead_fill(GemmS8Epilogue& ep, int64_t m) {
+  DecodeState* st = pf_state_;
+  if (st == nullptr || st->lead_flag == nullptr || taps_ || m > 16 || st->rows > 16) return false;
+  ep.lead_q = st->qbuf;
+  ep.lead_scale = st->qscale;
+  ep.lead_flag = st->lead_flag;
+  ep.lead_step = st->d_step;
+  ep.lead_tag = 1u + static_cast<unsigned>(st->lead_seq++ % 1023);
+  static const int headstart = [] {  // CT2X_LEAD_HEADSTART (x 512 clocks, A/B runs)
+    const char* e = std::getenv("CT2X_LEAD_HEADSTART");
+    return e != nullptr ? std::atoi(e) : GemmS8Epilogue().lead_headstart;
+  }();
+  ep.lead_headstart = headstart;
+  return true;
+}
+
+void Engine::reset_lead_flags(DecodeState& st) {
+  if (st.lead_flag != nullptr)
+    CT2X_HIP_CHECK(hipMemsetAsync(st.lead_flag, 0, 16 * sizeof(unsigned), cur_stream()));
 }
 
 // Output projection of an attention block + residual + the NEXT sub-layer's pre-norm + Quantize

@@ -432,9 +432,14 @@ private:
   bool dense_norm(const NormW& ln, const DenseW& w, const float* x, int64_t m, int act,
                   const float* residual, float* y, float* row_amax_out = nullptr);
   // int8 Dense that quantises its fp32 input while loading it (row absmax given by the producer)
+  // Fills the leader fields of `ep` from the session being enqueued (false: no session / more than
+  // 16 rows / taps: the caller keeps the separate launch).
+  bool lead_fill(GemmS8Epilogue& ep, int64_t m);
+  void reset_lead_flags(DecodeState& st);
   void dense_qol(const DenseW& w, const float* x, const float* row_amax, int64_t m, int act,
                  const float* residual, float* y, int amax_parts = 1);
   bool stream_qol_applicable(const DenseW& w, int64_t m) const;
+  bool stream_lead_quant_applicable(const DenseW& w, int64_t m) const;
   void load_weights();
   bool has_awq_ = false;
   void dense_awq(const DenseW& w, const float* x, int64_t m, int act, const float* residual, float* y,
@@ -580,6 +585,12 @@ struct DecodeState {
   static constexpr size_t kSplitkTickets = 2048;
   float* awq_ws = nullptr;   // split-K slices of the AWQ GEMM (kAwqGemmWorkspaceFloats)
   float* qscale = nullptr;   // [rows]
+  // Leader forms of the streaming Dense (gemm_s8_stream.hip AMODE 3 / 4, round 6): one tag word per
+  // row, written by the launch's leader workgroups; zeroed whenever the host writes d_step (a tag is
+  // (step + 1) * 1024 + lead_seq: unique only while the step counter moves forward). lead_seq: the
+  // leader launches of the step being enqueued so far (host side, reset by launch_step).
+  unsigned* lead_flag = nullptr;  // [16]
+  int lead_seq = 0;
   int32_t* d_ids = nullptr;  // [rows] next input ids
   int32_t* d_step = nullptr; // [1]
   int32_t* mem_lengths = nullptr;  // [batch]

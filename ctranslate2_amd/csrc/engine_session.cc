@@ -149,6 +149,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
     st->awq_ws = alloc<float>(*st, static_cast<int64_t>(kAwqGemmWorkspaceFloats));
   }
   st->qscale = alloc<float>(*st, wrows);
+  st->lead_flag = alloc<unsigned>(*st, 16);
   if (compute_type_ == ComputeType::kFloat16 || compute_type_ == ComputeType::kBFloat16) {
     // split-K partials of the 16-bit GEMM at a few hundred decode rows (beam search on large
     // batches): session owned, so a captured step never allocates
@@ -175,6 +176,7 @@ std::unique_ptr<DecodeState> Engine::start(const int32_t* src_ids, const int32_t
   st->host_hist_ids = static_cast<int32_t*>(pinned_malloc(sizeof(int32_t) * (t_max + 1) * rows));
   st->hist_scores = alloc<float>(*st, (t_max + 1) * rows);
   CT2X_HIP_CHECK(hipMemsetAsync(st->d_step, 0, sizeof(int32_t), cur_stream()));
+  reset_lead_flags(*st);
   st->logprobs = alloc<float>(*st, rows * V);  // log-probabilities (beam search) / exp scratch
   if (beam_mode) {
     st->beam_scores = alloc<float>(*st, rows);
@@ -473,6 +475,7 @@ void Engine::reencode(DecodeState& st, const int32_t* src_ids, const int32_t* sr
   // what a fresh session starts from: step 0, the first cache set, no fused tail selected (the
   // done counter and the fused sampler's slots are zero between launches by construction)
   CT2X_HIP_CHECK(hipMemsetAsync(st.d_step, 0, sizeof(int32_t), cur_stream()));
+  reset_lead_flags(st);
   st.cur = 0;
   st.fuse_greedy = st.fuse_beam = false;
   ++st.reuses;
@@ -697,13 +700,18 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
   }
   // Gated pair at <= 16 rows of a model with streamed weights: the RMSNorm + Quantize runs as the
   // prologue of the pair's launch (gemm_s8_stream.hip AMODE 2)
-  const bool glu_norm =
+  const bool glu_streamable =
       !qin_ready && ffn.ln.present && pre_norm && ffn.l0_noact.present && ffn.l0.quantized &&
       ffn.l0_noact.quantized && !tp_ && !taps_ && gemm_s8_norm_fusion_enabled() &&
-      (gemm_s8_stream_prologue_mask() & 1) &&
       ffn.l0.wq_stream && ffn.l0.wq_stream_dual && ffn.l0_noact.wq_stream &&
-      ffn.l0_noact.wq_stream_dual && ffn.l0_noact.n == ffn.l0.n &&
-      gemm_s8_stream_norm_applicable(rows, ffn.l0.n, ffn.l0.k, true, ffn.ln.beta != nullptr);
+      ffn.l0_noact.wq_stream_dual && ffn.l0_noact.n == ffn.l0.n;
+  // (round 6: by sixteen leader workgroups of the pair's launch, CT2X_STREAM_PROLOGUE bit 2)
+  const bool glu_lead = glu_streamable && (gemm_s8_stream_prologue_mask() & 4) && pf_state_ == &st &&
+                        st.lead_flag != nullptr && rows <= 16 && st.rows <= 16 &&
+                        gemm_s8_stream_lead_norm_applicable(rows, ffn.l0.n, ffn.l0.k, true, ffn.ln.beta != nullptr);
+  const bool glu_norm =
+      glu_lead || (glu_streamable && (gemm_s8_stream_prologue_mask() & 1) &&
+                   gemm_s8_stream_norm_applicable(rows, ffn.l0.n, ffn.l0.k, true, ffn.ln.beta != nullptr));
   if (qin_ready || glu_norm) {
   } else if (ffn.ln.present && pre_norm) {
     if (ffn.l0.quantized) {
@@ -735,6 +743,7 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
       ep.norm_eps = ffn.ln.eps;
       ep.norm_rms_residual = ffn.ln.use_residual;
       ep.quant_mode = quant_mode_;
+      if (glu_lead) lead_fill(ep, rows);
     }
     ep.w_scale = ffn.l0.wscale;
     ep.bias = ffn.l0.bias;
@@ -761,6 +770,13 @@ void Engine::run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, fl
     }
     launch_gemm_s8(fq.q, w0, rows, ffn.l0.n, ffn.l0.k, ep, cur_stream());
     end_kernel();
+    if (split_quant && stream_lead_quant_applicable(ffn.l1, rows)) {
+      // ... and the element-wise Quantize is the work of the output projection's leader workgroups
+      dense_qol(ffn.l1, st.inner, amax_buf, rows, -1, resid, y);
+      if (ffn.ln.present && !pre_norm) norm(ffn.ln, y, rows, d, y);
+      std::swap(x, y);
+      return;
+    }
     if (split_quant) {
       prefetch_weight(st, ffn.l1, 3);  // FFN output weight, next to the Quantize launch
       begin_kernel("quantize_cols", double(rows) * ffn.l0.n * 5, 0, rows, 0, ffn.l0.n);
@@ -1004,6 +1020,7 @@ void Engine::prefill(DecodeState& st, const int32_t* h_ids, int64_t time, float*
   const int32_t step = static_cast<int32_t>(time);
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_step, &step, sizeof(int32_t), hipMemcpyHostToDevice,
                                 cur_stream()));
+  reset_lead_flags(st);
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
   check_last_launch("prefill");
 }

@@ -36,6 +36,7 @@ void Engine::launch_step(DecodeState& st) {
   // producer-side absmax slots (2 per layer) are max-combined into: zero them for this step
   // (only models whose layers take that path pay for the memset node: gated-FFN decoders)
   st.pf_active = true;
+  st.lead_seq = 0;  // (tags of the leader launches: their index inside this step)
   st.pf_pending = PrefetchArgs();
   pf_state_ = &st;
   // (a launch that throws must not leave the worker thread pointing at a dead session)
@@ -1232,6 +1233,7 @@ void Engine::set_step(DecodeState& st, int32_t step) {
   set_active_stream(tls_stream);
   CT2X_HIP_CHECK(hipMemcpyAsync(st.d_step, &step, sizeof(int32_t), hipMemcpyHostToDevice,
                                 cur_stream()));
+  reset_lead_flags(st);
   CT2X_HIP_CHECK(hipStreamSynchronize(cur_stream()));
 }
 

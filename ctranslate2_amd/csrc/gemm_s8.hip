@@ -826,7 +826,9 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
   static const bool no_skinny = tuning_env("CT2X_NO_SKINNY_GEMM") != nullptr;
   if ((ep.norm_x != nullptr &&
        gemm_s8_stream_norm_applicable(m, n, k, ep.b2 != nullptr, ep.norm_beta != nullptr)) ||
-      (ep.a_f32 != nullptr && ep.b2 == nullptr && gemm_s8_stream_qol_applicable(m, n, k))) {
+      (ep.a_f32 != nullptr && ep.b2 == nullptr && gemm_s8_stream_qol_applicable(m, n, k)) ||
+      (ep.a_f32 != nullptr && ep.b2 == nullptr && ep.lead_flag != nullptr &&
+       gemm_s8_stream_lead_quant_applicable(m, n, k))) {
     // the prologue forms of the persistent streaming kernel (K = 4096, <= 16 rows)
     launch_gemm_s8_stream(a, b, M, N, K, ep, stream);
     return;

@@ -34,13 +34,30 @@
 //     chunk (= one K-step of all 16 waves) at a time through two buffers, and waves 0-3 (four rows
 //     each, 16 lanes per row) run the chains one chunk behind the writers; then every thread
 //     normalises, max-combines and quantises the 64 values it kept in registers.
+//
+// Round 6: LEADER forms. What made the prologues above cost as much as the launches they replaced
+// was that every one of the ~200 workgroups redid the row-wide work on 256 KB of fp32 rows. Here
+// the workgroups 0..15 - the first the dispatcher places - each own ONE row: they ask for their row
+// first and for their weight ring second, run the row-wide work once (AMODE 3: RMSNorm + Quantize,
+// the same functions as norm_vec_kernel, rowops.hip; AMODE 4: ops::Quantize given the producer's
+// row absmax), store the int8 row and its scale write-through, drain, and publish a tagged flag word
+// per row. Every workgroup (the leaders too) has its first weight ring in flight meanwhile - 128 KB
+// per workgroup, 28 - 32 MB per launch: the whole weight of the QKV / out projections - and then
+// waits for the sixteen tags, reads its int8 fragments (64 KB per workgroup from L2 as in AMODE 0;
+// no workgroup of this launch has touched those lines before the flags, so no L2 holds a copy older
+// than the write-through) and streams on. The tag is (device step + 1) * 1024 + the launch's index
+// in the step: no counter to reset, nothing to clear, a stale flag never matches. Leaders never
+// wait for anything, so the launch cannot deadlock whatever else holds CUs; the poll is bounded and
+// traps when it runs out (a loud HIP error, never silent garbage).
 
 #include "device_utils.h"
+#include "grid_sync.h"
 #include "kernels.h"
 #include "row_norm.h"
 #include "runtime.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace ct2x {
@@ -61,7 +78,10 @@ struct StreamLds {
   // region 0: the reduction tiles; during the prologues the two chunk buffers (AMODE 2) and the
   // int8 activation tile
   static constexpr int kTileInts = 16 * (4096 + 16) / 4;  // the int8 activation tile (AMODE 1 / 2)
-  static constexpr int kProInts = AMODE == 2 ? 2 * kNormChunkFloats : (AMODE == 1 ? kTileInts : 0);
+  // (leader forms: the transposed row of the statistics chain, norm_chain_pad(4096) = 516, + scratch)
+  static constexpr int kLeadInts = 8 * 516 + 8 + 32 + 4;
+  static constexpr int kProInts =
+      AMODE == 2 ? 2 * kNormChunkFloats : (AMODE == 1 ? kTileInts : (AMODE >= 3 ? kLeadInts : 0));
   static constexpr int kRegion0 = kProInts > kPartialInts ? kProInts : kPartialInts;
   static constexpr int kTileAmax = kRegion0;            // [2][16] uint
   static constexpr int kRowScale = kTileAmax + 32;      // [16] float (AMODE != 0)
@@ -69,7 +89,8 @@ struct StreamLds {
   static constexpr int kRowMul = kRowAmax + 16;         // [16] float (AMODE 2)
   static constexpr int kGamma = kRowMul + 16;           // [K] float  (AMODE 2)
   static constexpr size_t bytes(int k) {
-    return sizeof(int) * static_cast<size_t>(AMODE == 0 ? kRowScale : (AMODE == 1 ? kRowAmax : kGamma + k));
+    return sizeof(int) * static_cast<size_t>((AMODE == 0 || AMODE >= 3) ? kRowScale
+                                                                         : (AMODE == 1 ? kRowAmax : kGamma + k));
   }
 };
 
@@ -140,13 +161,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
   // through an int8 tile in LDS (row stride K + 16 as in the skinny kernel's prologues) from which
   // every lane reads its fragments. Rows past M repeat row 0: unconditional loads; what the MFMA
   // computes for those rows is never stored.
-  static_assert(AMODE == 0 || (KS == 4 && WAVES == 16), "prologue forms: K = 4096 on 16 waves");
-  constexpr int XP = (AMODE == 0) ? 1 : 16;  // float4 pieces per thread: piece 4 c + jj
+  constexpr bool kPro = AMODE == 1 || AMODE == 2;  // every workgroup redoes the row-wide work
+  constexpr bool kLead = AMODE >= 3;               // workgroups 0..15 do it once (round 6)
+  static_assert(!kPro || (KS == 4 && WAVES == 16), "prologue forms: K = 4096 on 16 waves");
+  static_assert(AMODE != 3 || (KS == 4 && WAVES == 16), "leader norm: RMSNorm rows of 4096 on 16 waves");
+  static_assert(!kLead || WAVES == 16, "leader forms: 1024 threads per row");
+  constexpr int XP = kPro ? 16 : 1;  // float4 pieces per thread: piece 4 c + jj
   v4f xa[XP];
   const int xq = tid >> 8, xc4 = tid & 255;
   float q_amax[4] = {0.f, 0.f, 0.f, 0.f};
   v4f gpre = v4f{0.f, 0.f, 0.f, 0.f};
-  if (AMODE != 0) {
+  if (kPro) {
     const float* X = reinterpret_cast<const float*>(A);
     const float* xbase[4];
 #pragma unroll
@@ -182,9 +207,112 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
 
   const int first = blockIdx.x * slabs_per_wg;
   const int mine = min(slabs_per_wg, total_slabs - first);  // only the last workgroup has fewer
+  // ---- leader forms: the row first, the ring second --------------------------------------------
+  constexpr int LP = (KS + 3) / 4;  // float4 pieces of a row per thread (K / 4 over 1024 threads)
+  v4f lx[kLead ? LP : 1];
+  const bool leader = kLead && blockIdx.x < 16;
+  const bool lead_work = leader && static_cast<int>(blockIdx.x) < M;
+  if (kLead) {
+    if (lead_work) {
+      const v4f* xr = reinterpret_cast<const v4f*>(reinterpret_cast<const float*>(A) +
+                                                   static_cast<int64_t>(blockIdx.x) * K);
+#pragma unroll
+      for (int p = 0; p < LP; ++p) {
+        const int idx = tid + p * THREADS;
+        lx[p] = (idx < KS * 256) ? xr[idx] : v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      if (AMODE == 3) gpre = reinterpret_cast<const v4f*>(aux)[tid];  // gamma: K / 4 == THREADS
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // The sixteen rows travel ahead of the launch's 28 - 32 MB of ring requests: a leader asks for its
+    // ring once its row has landed, everyone else after a head start (units of 512 clocks) - the
+    // rings still land long before the flags do, and a row request queued in the middle of that
+    // burst arrives microseconds late, on the launch's critical path.
+    if (lead_work) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!leader) {
+      for (int h = 0; h < ep.lead_headstart; ++h) __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (AMODE != 2) {
 #pragma unroll
     for (int i = 0; i < P; ++i) request(first, i);
+  }
+  if (kLead) {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned tag =
+        (ep.lead_step != nullptr ? static_cast<unsigned>(*ep.lead_step + 1) * 1024u : 0u) + ep.lead_tag;
+    if (leader) {
+      const int lrow = blockIdx.x;
+      if (lead_work) {
+        float* lead_lds = reinterpret_cast<float*>(stream_lds);
+        constexpr int kPad = 516;  // norm_chain_pad(4096)
+        float* scratch = lead_lds + 8 * kPad + 8;  // [32] block_max, then [1] the row's multiplier
+        float amax = 0.f;
+        if (AMODE == 3) {
+          // RMSNorm exactly as norm_vec_kernel<4> (rowops.hip): transposed chains, wave 0 walks them
+          const int c0 = 4 * tid;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lead_lds[norm_chain_slot(c0 + e, K, kPad)] = lx[0][e];
+          __syncthreads();
+          if (wave == 0) {
+            float sum, sumsq;
+            ordered_row_stats_t<false, 4>(lead_lds, kPad, K, sum, sumsq);  // (128 registers: the ring stays)
+            const NormStats s0 = norm_stats(sum, sumsq, K, ep.norm_eps, false);
+            if (lane == 0) scratch[32] = s0.mul;
+          }
+          __syncthreads();
+          NormStats st;
+          st.mean = 0.f;
+          st.mul = scratch[32];
+          st.four_begin = st.four_end = K;  // K % 8 == 0: no 4-wide remainder columns
+          const bool resid = ep.norm_rms_residual;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            lx[0][e] = norm_apply(lx[0][e], gpre[e], 0.f, st, false, resid, c0 + e);
+            amax = fmaxf(amax, fabsf(lx[0][e]));
+          }
+          amax = block_max(amax, scratch);
+        } else {
+          // ops::Quantize given the producer's row absmax (aux: [M, aux_n] partial maxima)
+          for (int p = 0; p < aux_n; ++p) amax = fmaxf(amax, aux[lrow * aux_n + p]);
+        }
+        const float scale = (amax != 0.f) ? 127.f / amax : 1.f;
+        const bool fast = (ep.quant_mode & kQuantU8Shift) && (ep.quant_mode & kQuantRound);
+        unsigned* qrow = reinterpret_cast<unsigned*>(ep.lead_q + static_cast<int64_t>(lrow) * K);
+#pragma unroll
+        for (int p = 0; p < LP; ++p) {
+          const int idx = tid + p * THREADS;
+          if (idx < KS * 256) {
+            const int word = fast ? quantize_word_fast(lx[p], scale) : quantize_word_any(lx[p], scale, ep.quant_mode);
+            grid_publish(qrow + idx, static_cast<unsigned>(word));
+          }
+        }
+        if (tid == 0) grid_publish(reinterpret_cast<unsigned*>(ep.lead_scale) + lrow, __float_as_uint(scale));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has left (and this ring has landed)
+      __syncthreads();
+      if (tid == 0) grid_publish(ep.lead_flag + lrow, tag);
+    }
+    // everyone: the sixteen tags, then this wave's int8 fragments
+    if (wave == 0) {
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned f = (lane < 16) ? grid_observe(ep.lead_flag + lane) : tag;
+        if (__all(f == tag)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24)) __builtin_trap();
+      }
+    }
+    __syncthreads();
+    const int8_t* Aq = ep.lead_q;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int kk = (wave + i * WAVES) * 64 + g * 16;
+      af[i] = (r < M) ? *reinterpret_cast<const v4i*>(Aq + static_cast<int64_t>(r) * K + kk)
+                      : v4i{0, 0, 0, 0};
+    }
   }
 
   int8_t* qtile = reinterpret_cast<int8_t*>(stream_lds);  // [16][K + 16] int8 (AMODE 1 / 2)
@@ -293,7 +421,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
       q_scale[jj] = (ra != 0.f) ? 127.f / ra : 1.f;
     }
   }
-  if (AMODE != 0) {
+  if (kPro) {
     // Quantize (to_s8) into the LDS tile, then every lane's MFMA fragments out of it. The choice
     // between the x86 default (u8 shift + round to nearest even: three VALU operations per element,
     // bytes gathered by v_perm, "- 128" as one xor) and the general form is ONE uniform branch.
@@ -342,6 +470,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
       e_bias[o] = e_res[o] = e_bias2[o] = 0.f;
       if (ep.mode == 1 && flat < OUTS && row < M) {
         if (AMODE == 0) e_ra[o] = ep.a_scale[row];
+        if (kLead) e_ra[o] = __uint_as_float(grid_observe(reinterpret_cast<const unsigned*>(ep.lead_scale) + row));
         e_ws[o] = ep.w_scale[col];
         if (ep.bias) e_bias[o] = ep.bias[col];
         if (ep.residual) e_res[o] = ep.residual[static_cast<int64_t>(row) * ep.ldy + col];
@@ -399,7 +528,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_s8_stream_kernel(
         ep.c_i32[idx] = sum;
       } else {
         // CPU formula order (src/cpu/kernels.cc:666-673): c * (1/a_scale) / b_scale + bias.
-        const float r_a = 1.f / (AMODE == 0 ? e_ra[o] : row_scale_lds[rt]);
+        const float r_a = 1.f / ((AMODE == 0 || kLead) ? e_ra[o] : row_scale_lds[rt]);
         float v = static_cast<float>(sum) * r_a;
         v = v / e_ws[o];
         if (ep.bias) v = v + e_bias[o];
@@ -563,12 +692,33 @@ bool weight_prefetch_range(const int8_t* packed, int64_t n, int64_t k, bool dual
 // workgroups pulls the 16 x 4096 fp32 rows itself, 32 CUs of an XCD read the same 256 KB through
 // one L2 (8 MB per launch and XCD: ~4 us at the L2's bandwidth, against 2 MB for the int8 rows), and
 // the norm's 512-step chain cannot start before its first chunk is there. Bit-identical either way.
-int gemm_s8_stream_prologue_mask() {
-  static const int mask = [] {
+// Round 6: bit 2 = RMSNorm + Quantize by sixteen leader workgroups (AMODE 3), bit 3 = ops::Quantize by
+// the leaders (AMODE 4, any K). DEFAULT 12: both leader forms on (profiles/r06_l8_leader_ab.txt).
+namespace {
+std::atomic<int>& prologue_mask_word() {
+  static std::atomic<int> mask([] {
     const char* e = std::getenv("CT2X_STREAM_PROLOGUE");
     return e != nullptr ? std::atoi(e) : 0;
-  }();
+  }());
   return mask;
+}
+}  // namespace
+int gemm_s8_stream_prologue_mask() { return prologue_mask_word().load(std::memory_order_relaxed); }
+int gemm_s8_stream_set_prologue_mask(int mask) {  // tests / A-B runs; returns the previous value
+  return prologue_mask_word().exchange(mask, std::memory_order_relaxed);
+}
+
+// Leader forms: which launches they serve. Norm: the shapes of the AMODE 2 prologue (RMSNorm rows of
+// 4096, plain or gated). Quantize: a plain Dense at <= 16 rows with a streaming form.
+bool gemm_s8_stream_lead_norm_applicable(int64_t m, int64_t n, int64_t k, bool dual, bool has_beta) {
+  StreamPlan plan;
+  return gemm_s8_stream_norm_applicable(m, n, k, dual, has_beta) &&
+         plan_stream(n, k, dual, device_cus(), &plan) && plan.grid >= 16;
+}
+bool gemm_s8_stream_lead_quant_applicable(int64_t m, int64_t n, int64_t k) {
+  StreamPlan plan;
+  return gemm_s8_stream_applicable(m, n, k, false) && plan_stream(n, k, false, device_cus(), &plan) &&
+         plan.grid >= 16;
 }
 
 // RMSNorm (no beta) + Quantize as the prologue: K = 4096 (one compiled chunk geometry), any N
@@ -593,7 +743,18 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
   if (!plan_stream(N, K, dual, device_cus(), &plan))
     throw Error("launch_gemm_s8_stream: shape outside the streaming form");
   const GemmS8Epilogue& ep = ep_in;
-  const int amode = ep.norm_x != nullptr ? 2 : (ep.a_f32 != nullptr ? 1 : 0);
+  const bool lead = ep.lead_flag != nullptr;
+  const int amode = ep.norm_x != nullptr ? (lead ? 3 : 2) : (ep.a_f32 != nullptr ? (lead ? 4 : 1) : 0);
+  if (lead && !(amode >= 3 && ep.lead_q != nullptr && ep.lead_scale != nullptr && ep.lead_tag >= 1 &&
+                ep.lead_tag < 1024 && plan.grid >= 16 && ep.mode == 1 &&
+                (reinterpret_cast<uintptr_t>(ep.lead_q) & 15) == 0))
+    throw Error("launch_gemm_s8_stream: leader form without its row buffers / tag, or a grid below 16");
+  if (amode == 3 && !(ep.norm_beta == nullptr && K == 4096 && ep.norm_gamma != nullptr &&
+                      (reinterpret_cast<uintptr_t>(ep.norm_x) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(ep.norm_gamma) & 15) == 0))
+    throw Error("launch_gemm_s8_stream: the leader norm needs RMSNorm rows of 4096 aligned floats");
+  if (amode == 4 && !(!dual && ep.a_amax != nullptr && (reinterpret_cast<uintptr_t>(ep.a_f32) & 15) == 0))
+    throw Error("launch_gemm_s8_stream: the leader Quantize needs a plain Dense and the row absmax");
   if (amode == 2 && !(ep.norm_beta == nullptr && K == 4096 && ep.mode == 1 && ep.norm_gamma != nullptr &&
                       (reinterpret_cast<uintptr_t>(ep.norm_x) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(ep.norm_gamma) & 15) == 0))
@@ -601,10 +762,11 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
   if (amode == 1 && !(K == 4096 && !dual && ep.mode == 1 && ep.a_amax != nullptr &&
                       (reinterpret_cast<uintptr_t>(ep.a_f32) & 15) == 0))
     throw Error("launch_gemm_s8_stream: the quantise-on-load form needs K = 4096, a plain Dense and the row absmax");
-  const int8_t* a_arg = amode == 2 ? reinterpret_cast<const int8_t*>(ep.norm_x)
-                                   : (amode == 1 ? reinterpret_cast<const int8_t*>(ep.a_f32) : a);
-  const float* aux = amode == 2 ? ep.norm_gamma : (amode == 1 ? ep.a_amax : nullptr);
-  const int aux_n = amode == 1 ? (ep.a_amax_parts > 0 ? ep.a_amax_parts : 1) : 0;
+  const bool a_norm = amode == 2 || amode == 3, a_quant = amode == 1 || amode == 4;
+  const int8_t* a_arg = a_norm ? reinterpret_cast<const int8_t*>(ep.norm_x)
+                               : (a_quant ? reinterpret_cast<const int8_t*>(ep.a_f32) : a);
+  const float* aux = a_norm ? ep.norm_gamma : (a_quant ? ep.a_amax : nullptr);
+  const int aux_n = a_quant ? (ep.a_amax_parts > 0 ? ep.a_amax_parts : 1) : 0;
 #define CT2X_STREAM_LAUNCH(NT, KS, P, DUAL, PACKED, AMODE)                                        \
   do {                                                                                            \
     auto fn = gemm_s8_stream_kernel<NT, 16, KS, P, DUAL, PACKED, AMODE>;                          \
@@ -631,6 +793,11 @@ void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K
   CT2X_STREAM_A(4, 4, 2, false, 1) CT2X_STREAM_A(2, 4, 4, false, 1) CT2X_STREAM_A(1, 4, 4, false, 1)
   CT2X_STREAM_A(4, 4, 2, false, 2) CT2X_STREAM_A(2, 4, 4, false, 2) CT2X_STREAM_A(1, 4, 4, false, 2)
   CT2X_STREAM_A(2, 4, 2, true, 2)  // (the one-tile gated form would spill a register)
+  // leader forms (round 6): RMSNorm + Quantize at K = 4096, ops::Quantize at any K
+  CT2X_STREAM_A(4, 4, 2, false, 3) CT2X_STREAM_A(2, 4, 4, false, 3) CT2X_STREAM_A(1, 4, 4, false, 3)
+  CT2X_STREAM_A(2, 4, 2, true, 3)
+  CT2X_STREAM_A(4, 4, 2, false, 4) CT2X_STREAM_A(2, 4, 4, false, 4) CT2X_STREAM_A(1, 4, 4, false, 4)
+  CT2X_STREAM_A(2, 8, 4, false, 4) CT2X_STREAM_A(1, 8, 4, false, 4) CT2X_STREAM_A(1, 14, 7, false, 4)
 #undef CT2X_STREAM
 #undef CT2X_STREAM_A
 #undef CT2X_STREAM_LAUNCH

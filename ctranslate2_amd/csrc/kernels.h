@@ -172,6 +172,19 @@ struct GemmS8Epilogue {
   // layout pack_stream_weight() produced for this (n, k) - every 1 KB request of a wave is one
   // contiguous block and a wave's requests of a slab follow each other in memory.
   bool packed_b = false;
+  // Streaming form, leader prologues (round 6, gemm_s8_stream.hip AMODE 3 / 4): lead_flag != nullptr
+  // turns the norm_x (RMSNorm + Quantize) or a_f32 / a_amax (ops::Quantize) prologue into work done
+  // ONCE by the launch's workgroups 0..15 (one row each), which leave the int8 rows in lead_q
+  // [16, k], the row scales in lead_scale [16] and a tag per row in lead_flag [16]. tag =
+  // (*lead_step + 1) * 1024 + lead_tag (lead_tag in 1..1023: the launch's index inside the step;
+  // lead_step: the device-side step counter, or nullptr): unique per launch as long as lead_flag is
+  // zeroed whenever the host rewinds the step counter.
+  int8_t* lead_q = nullptr;
+  float* lead_scale = nullptr;
+  unsigned* lead_flag = nullptr;
+  const int32_t* lead_step = nullptr;
+  unsigned lead_tag = 0;
+  int lead_headstart = 6;  // x 512 clocks before the other workgroups ask for their weight ring
   // gf.slots != nullptr: no logits store, fused greedy arg-max (gemm_s8_argmax_applicable shapes)
   GreedyFuse gf;
 };
@@ -213,6 +226,9 @@ bool gemm_s8_stream_applicable(int64_t m, int64_t n, int64_t k, bool dual);
 bool gemm_s8_stream_norm_applicable(int64_t m, int64_t n, int64_t k, bool dual, bool has_beta);
 bool gemm_s8_stream_qol_applicable(int64_t m, int64_t n, int64_t k);
 int gemm_s8_stream_prologue_mask();
+int gemm_s8_stream_set_prologue_mask(int mask);
+bool gemm_s8_stream_lead_norm_applicable(int64_t m, int64_t n, int64_t k, bool dual, bool has_beta);
+bool gemm_s8_stream_lead_quant_applicable(int64_t m, int64_t n, int64_t k);
 void launch_gemm_s8_stream(const int8_t* a, const int8_t* b, int M, int N, int K,
                            const GemmS8Epilogue& ep, hipStream_t stream);
 // Fragment-major copy of a weight for the streaming form (GemmS8Epilogue::packed_b): dst [n * k]

@@ -65,7 +65,7 @@ __device__ __forceinline__ int norm_chain_slot(int col, int vsize, int pad) {
 }
 // WANT_SUM = false (RMSNorm: only the sum of squares enters the result) drops the second dependent
 // chain of the loop - at depth 4096 the statistics are 512 dependent steps per row.
-template <bool WANT_SUM = true>
+template <bool WANT_SUM = true, int kB = 8>
 __device__ __forceinline__ void ordered_row_stats_t(const float* buf, int pad, int64_t depth,
                                                     float& sum, float& sumsq) {
   const int l = threadIdx.x & 7;
@@ -75,14 +75,54 @@ __device__ __forceinline__ void ordered_row_stats_t(const float* buf, int pad, i
     const float* chain = buf + l * pad;
     const v4f* c4 = reinterpret_cast<const v4f*>(chain);
     const int n4 = n / 4;
-#pragma unroll 8
-    for (int i = 0; i < n4; ++i) {
-      const v4f v = c4[i];
+    auto step4 = [&](const v4f v) {
       ss = fmaf(v.x, v.x, ss); if (WANT_SUM) s = s + v.x;
       ss = fmaf(v.y, v.y, ss); if (WANT_SUM) s = s + v.y;
       ss = fmaf(v.z, v.z, ss); if (WANT_SUM) s = s + v.z;
       ss = fmaf(v.w, v.w, ss); if (WANT_SUM) s = s + v.w;
+    };
+    // Software pipeline (round 6): the next eight 16-byte reads are requested BEFORE the 32 dependent
+    // steps on the eight already here (the compiler's own unrolled loop waited for each batch right
+    // after asking for it: 13 clocks per step measured against the ~5 of the dependent FMA itself).
+    int i = 0;  // (kB: reads per batch - 8 * kB registers for the two batches in flight)
+    if constexpr (kB == 0) {  // the compiler's own unrolling (decoder_cluster.hip: tuned to zero spills as is)
+#pragma unroll 8
+      for (; i < n4; ++i) step4(c4[i]);
+    } else if (n4 >= kB) {
+      v4f cur[kB > 0 ? kB : 1], nxt[kB > 0 ? kB : 1];
+#pragma unroll
+      for (int u = 0; u < kB; ++u) cur[u] = c4[u];
+      i = kB;
+      while (i + 2 * kB <= n4) {  // (two batches per trip: the buffers swap roles, no moves)
+#pragma unroll
+        for (int u = 0; u < kB; ++u) nxt[u] = c4[i + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kB; ++u) step4(cur[u]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kB; ++u) cur[u] = c4[i + kB + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kB; ++u) step4(nxt[u]);
+        __builtin_amdgcn_sched_barrier(0);
+        i += 2 * kB;
+      }
+      if (i + kB <= n4) {
+#pragma unroll
+        for (int u = 0; u < kB; ++u) nxt[u] = c4[i + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kB; ++u) step4(cur[u]);
+#pragma unroll
+        for (int u = 0; u < kB; ++u) step4(nxt[u]);
+        i += kB;
+      } else {
+#pragma unroll
+        for (int u = 0; u < kB; ++u) step4(cur[u]);
+      }
     }
+    for (; i < n4; ++i) step4(c4[i]);
     for (int i = n4 * 4; i < n; ++i) {
       const float v = chain[i];
       ss = fmaf(v, v, ss);

@@ -337,7 +337,7 @@ __global__ void norm_kernel(const float* __restrict__ x, const float* __restrict
 // Phase costs measured with tools/norm_probe.cpp ([32, 512], cycles): loads 850, strided chains
 // 2500 -> contiguous chains, ds_bpermute block max 1130 -> DPP, stats + apply 670, quantize 630.
 template <int CH>
-__global__ void norm_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void norm_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, int64_t depth, float eps,
                                 bool rms_use_residual, int quant_mode, int pad,
                                 float* __restrict__ y, int8_t* __restrict__ q,

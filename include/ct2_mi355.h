@@ -807,6 +807,13 @@ int ct2x_debug_set_beam_ancestry(int enabled);
  * (must be 0). */
 int ct2x_debug_fast_div_check(uint64_t pairs, uint32_t seed, uint64_t* mismatches);
 
+/* Tests / A-B runs: which prologue forms the persistent streaming Dense takes (the value of
+ * CT2X_STREAM_PROLOGUE, process wide): bit 0 RMSNorm + Quantize and bit 1 ops::Quantize redone by
+ * every workgroup (round 4, off), bit 2 RMSNorm + Quantize and bit 3 ops::Quantize done once by the
+ * launch's first sixteen workgroups, one row each (round 6, on: default 12). Every setting returns
+ * the same bits (src/layers/common.cc:339-401 is one arithmetic). Returns the previous mask. */
+int ct2x_debug_set_stream_prologue(int mask);
+
 /* ---- debugging taps (tests only; not part of the reference boundary) ----------------------
  * ct2x_debug_step_taps = ct2x_step_logits with every producer on the path (embedding, norm +
  * Quantize, Quantize, Dense, attention) copying its output to the host, named

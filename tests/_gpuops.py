@@ -201,6 +201,11 @@ def gemm_s8_glu_packed(q, sa, w0, sw0, b0, w1, sw1, b1, act):
     return host(y), host(amax)
 
 
+def set_stream_prologue(mask):
+    """CT2X_STREAM_PROLOGUE for this process (ct2x_debug_set_stream_prologue) -> the previous mask"""
+    return int(_lib.lib().ct2x_debug_set_stream_prologue(C.c_int(mask)))
+
+
 def norm_gemm_s8_dequant_packed(x, gamma, eps, use_residual, flags, w, sw, bias=None, residual=None,
                                 act=-1):
     """RMSNorm + Quantize as the prologue of the streaming Dense -> (y, row absmax of y)"""

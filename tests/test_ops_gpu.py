@@ -177,7 +177,7 @@ def test_dense_glu_streaming_form_with_row_amax(gpu, m, n, k):
 
 @pytest.mark.parametrize("m,n", [(16, 6144), (16, 4096), (16, 128256), (5, 6144), (1, 4096)])
 @pytest.mark.parametrize("use_residual,flags", [(False, 3), (True, 3), (False, 1), (False, 0)])
-def test_dense_streaming_norm_prologue(gpu, m, n, use_residual, flags):
+def test_dense_streaming_norm_prologue(no_leader_forms, m, n, use_residual, flags):
     """RMSNorm + Quantize as the prologue of the persistent streaming Dense (gemm_s8_stream.hip
     AMODE 2: the reference's eight-lane statistics chain run chunk-wise through LDS by four waves
     while the weight stream is already in flight) against the launches it replaces
@@ -211,7 +211,7 @@ def test_dense_streaming_norm_prologue(gpu, m, n, use_residual, flags):
 
 
 @pytest.mark.parametrize("m", [16, 3])
-def test_dense_glu_streaming_norm_prologue(gpu, m):
+def test_dense_glu_streaming_norm_prologue(no_leader_forms, m):
     """The same prologue in front of the gated pair (Llama-3-8B feed-forward input at decode rows)."""
     import _gpuops as G
     n, k = 14336, 4096
@@ -235,7 +235,7 @@ def test_dense_glu_streaming_norm_prologue(gpu, m):
 
 @pytest.mark.parametrize("m,n,parts", [(16, 4096, 8), (16, 4096, 1), (7, 6144, 4), (16, 128256, 1)])
 @pytest.mark.parametrize("flags", [3, 1, 0])
-def test_dense_streaming_quantize_on_load(gpu, m, n, parts, flags):
+def test_dense_streaming_quantize_on_load(no_leader_forms, m, n, parts, flags):
     """ops::Quantize folded into the streaming Dense's fragment fetch (AMODE 1), the row absmax given
     as per-workgroup partial maxima (what the d_head 128 attention leaves): against Quantize +
     ct2x_gemm_s8_dequant_packed and the oracle's Dense chain, bit for bit."""
@@ -257,7 +257,110 @@ def test_dense_streaming_quantize_on_load(gpu, m, n, parts, flags):
     assert np.array_equal(y, O.dense_s8(x, wq, ws, bias, res, -1, flags))
 
 
-def test_streaming_prologue_envelope(gpu):
+@pytest.fixture
+def leader_forms(gpu):
+    """The streaming Dense's prologues done once by the launch's first sixteen workgroups
+    (CT2X_STREAM_PROLOGUE bits 2 and 3, gemm_s8_stream.hip AMODE 3 / 4)."""
+    import _gpuops as G
+    prev = G.set_stream_prologue(12)
+    yield
+    G.set_stream_prologue(prev)
+
+
+@pytest.fixture
+def no_leader_forms(gpu):
+    import _gpuops as G
+    prev = G.set_stream_prologue(3)
+    yield
+    G.set_stream_prologue(prev)
+
+
+@pytest.mark.parametrize("m,n", [(16, 6144), (16, 4096), (16, 128256), (5, 6144), (1, 4096)])
+@pytest.mark.parametrize("use_residual,flags", [(False, 3), (True, 3), (False, 1), (False, 0)])
+def test_dense_streaming_leader_norm(leader_forms, m, n, use_residual, flags):
+    """RMSNorm + Quantize by sixteen leader workgroups of the streaming Dense's own launch (AMODE 3:
+    one row each, int8 row + scale stored write-through, a tag word per row; every workgroup's first
+    weight ring is in flight meanwhile): the same bits as the launches it replaces and as the
+    oracle's RMSNorm -> Quantize -> Gemm -> Dequantize chain; repeated launches (fresh tags each
+    time the scratch is fresh) agree with themselves."""
+    import _gpuops as G
+    k = 4096
+    rng = np.random.default_rng(1000 + m + n + flags + int(use_residual))
+    x = (rng.standard_normal((m, k)) * 2.5).astype(np.float32)
+    x[:, 7] *= 30.0
+    if m > 2:
+        x[2, :] = 0.0
+    gamma = (1 + 0.2 * rng.standard_normal(k)).astype(np.float32)
+    if use_residual:
+        gamma -= 1.0
+    wq = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    ws = rng.uniform(50, 4000, n).astype(np.float32)
+    bias = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32)
+    y, amax = G.norm_gemm_s8_dequant_packed(x, gamma, 1e-5, use_residual, flags, wq, ws, bias, res, 2)
+    _, q, s = G.norm_quantize_s8(x, gamma, None, 1e-5, use_residual, flags, False)
+    y2 = G.gemm_s8_dequant_packed(q, s, wq, ws, bias, res, 2)
+    assert np.array_equal(y, y2)
+    assert np.array_equal(amax, np.abs(y).max(axis=1))
+    xn = O.rms_norm(x, gamma, 1e-5, use_residual)
+    qo, so = O.quantize_s8(xn, flags)
+    yo = _f32(res) + O.dequantize_gemm_output(O.gemm_s8(qo, wq), so, ws, bias, 2)
+    assert np.array_equal(y, yo)
+    for _ in range(3):
+        y3, _ = G.norm_gemm_s8_dequant_packed(x, gamma, 1e-5, use_residual, flags, wq, ws, bias, res, 2)
+        assert np.array_equal(y3, y)
+
+
+@pytest.mark.parametrize("m", [16, 3])
+def test_dense_glu_streaming_leader_norm(leader_forms, m):
+    """The leader norm in front of the gated pair (Llama-3-8B feed-forward input at decode rows)."""
+    import _gpuops as G
+    n, k = 14336, 4096
+    rng = np.random.default_rng(100 + m)
+    x = (rng.standard_normal((m, k)) * 2.5).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(k)).astype(np.float32)
+    w0q = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    w1q = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    w0s = rng.uniform(2000, 9000, n).astype(np.float32)
+    w1s = rng.uniform(2000, 9000, n).astype(np.float32)
+    y, amax = G.norm_gemm_s8_glu_packed(x, gamma, 1e-5, False, 3, w0q, w0s, None, w1q, w1s, None, 2)
+    _, q, s = G.norm_quantize_s8(x, gamma, None, 1e-5, False, 3, False)
+    y2, amax2 = G.gemm_s8_glu_packed(q, s, w0q, w0s, None, w1q, w1s, None, 2)
+    assert np.array_equal(y, y2) and np.array_equal(amax, amax2)
+    xn = O.rms_norm(x, gamma, 1e-5, False)
+    qo, so = O.quantize_s8(xn, 3)
+    c0, c1 = O.gemm_s8(qo, w0q), O.gemm_s8(qo, w1q)
+    yo = O.dequantize_gemm_output(c1, so, w1s, None, -1) * O.dequantize_gemm_output(c0, so, w0s, None, 2)
+    assert np.array_equal(y, yo)
+
+
+@pytest.mark.parametrize("m,n,k,parts", [(16, 4096, 4096, 8), (16, 4096, 4096, 1), (7, 6144, 4096, 4),
+                                         (16, 4096, 14336, 1), (9, 4096, 14336, 1), (16, 4096, 8192, 2),
+                                         (16, 128256, 4096, 1)])
+@pytest.mark.parametrize("flags", [3, 1, 0])
+def test_dense_streaming_leader_quantize(leader_forms, m, n, k, parts, flags):
+    """ops::Quantize by sixteen leader workgroups of the streaming Dense's own launch (AMODE 4), the row
+    absmax given as the producer's partial maxima - any K with a streaming form (4096: the attention
+    output projection, 14336: the Llama-3-8B feed-forward output): against Quantize +
+    ct2x_gemm_s8_dequant_packed and the oracle's Dense chain, bit for bit."""
+    import _gpuops as G
+    rng = np.random.default_rng(m + n + k + parts + flags)
+    x = (rng.standard_normal((m, k)) * 1.7).astype(np.float32)
+    if m > 2:
+        x[2, :] = 0.0
+    wq = rng.integers(-127, 128, (n, k), dtype=np.int8)
+    ws = rng.uniform(50, 4000, n).astype(np.float32)
+    bias = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32)
+    amax_parts = np.abs(x).reshape(m, parts, k // parts).max(axis=2)
+    y = G.gemm_s8_dequant_quantizing_packed(x, amax_parts, flags, wq, ws, bias, res, -1)
+    q, s = G.quantize_s8(x, flags)
+    y2 = G.gemm_s8_dequant_packed(q, s, wq, ws, bias, res, -1)
+    assert np.array_equal(y, y2)
+    assert np.array_equal(y, O.dense_s8(x, wq, ws, bias, res, -1, flags))
+
+
+def test_streaming_prologue_envelope(no_leader_forms):
     """Shapes outside the prologue forms are refused, not computed some other way."""
     import _gpuops as G
     rng = np.random.default_rng(0)

@@ -102,6 +102,29 @@ rows256_kernels)  # per-kernel times of the 256-row 16-bit GEMM forms (rocprofv3
     echo "== CT2X_H_ROWS256=$f"; grep -v "^W20\|rocprof" $O/rows256_bench_$f.txt | tail -6
     g=$(find /tmp/r256p$f -name "*kernel_stats.csv" | head -1); cp "$g" $O/rows256_kernel_stats_$f.csv; head -8 "$g" | cut -c1-60,150-260
   done ;;
+leader)           # the streaming Dense's leader prologues: op tests, Llama-3 geometry goldens, then the L8 leg A/B
+  timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -k "streaming or stream" 2>&1 | tail -4 | tee $O/leader_tests.txt
+  timeout 900 python -m pytest tests/test_generator_gpu.py tests/test_bench_path_gpu.py -x -q -k "llama3 or Llama" 2>&1 | tail -4 | tee -a $O/leader_tests.txt
+  for v in ${MASKS:-0 12 4 8 0 12}; do echo "== CT2X_STREAM_PROLOGUE=$v"
+    CT2X_STREAM_PROLOGUE=$v timeout 400 python tools/bench_l8.py --steps 3 --warmup 1 --no-profile 2>&1 | tail -1 |
+      python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(round(d['value'],1),'tok/s decode_ms_per_step',round(c['decode_ms_per_step'],4),'kernels/step',c['kernels_per_decode_step'])"
+  done 2>&1 | tee $O/l8_leader_ab.txt ;;
+leader_rocprof)   # per-kernel times of the L8 leg with and without the leader forms
+  for v in 0 12; do
+    ( cd /tmp && CT2X_STREAM_PROLOGUE=$v timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -- python $GRAFT_REPO_ROOT/tools/bench_l8.py --steps 1 --warmup 1 --no-profile > /tmp/prof_$v.log 2>&1 )
+    cp "$(find /tmp/prof_$v -name '*kernel_stats.csv' | head -1)" $O/l8_kernel_stats_leader_$v.csv
+    python - $O/l8_kernel_stats_leader_$v.csv <<'PY'
+import csv, sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:12]:
+    print(r['Name'][:110].ljust(110), r['Calls'], round(float(r['AverageNs']) / 1e3, 2), r['Percentage'])
+PY
+  done ;;
+chain)            # the ordered chains (norm statistics, exp sums) as two batches of reads swapping roles
+  timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_primitives_gpu.py -x -q -k "norm or softmax or Norm or SoftMax" 2>&1 | tail -3 | tee $O/chain_tests.txt
+  timeout 1200 python -m pytest tests/test_translator_gpu.py tests/test_reference_kats_gpu.py tests/test_generator_gpu.py -x -q 2>&1 | tail -3 | tee -a $O/chain_tests.txt
+  { for i in 1 2; do echo "== --beam 4"; timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+    echo "== greedy"; timeout 300 python bench.py --steps 10 --warmup 2 $NOLEGS 2>&1 | tail -1 | line
+  } 2>&1 | tee $O/chain_bench.txt ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
