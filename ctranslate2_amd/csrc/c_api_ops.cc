@@ -634,6 +634,47 @@ int ct2x_awq_dequantize_gemv(const int32_t* d_qweight, const void* d_scales_f16,
   API_CATCH
 }
 
+int ct2x_awq_dequantize_bf16(const int32_t* d_qweight, const void* d_scales_bf16, const int32_t* d_qzeros,
+                             int64_t in_c, int64_t out_c, int64_t group, void* d_out_bf16, void* stream) {
+  API_TRY
+  launch_awq_dequantize_gemm(d_qweight, d_scales_bf16, d_qzeros, in_c, out_c, group, d_out_bf16,
+                             resolve_stream(stream), true);
+  check_last_launch("awq_dequantize_bf16");
+  API_CATCH
+}
+
+int ct2x_awq_gemm_bf16(const void* d_x_bf16, const int32_t* d_qweight, const void* d_scales_bf16,
+                       const int32_t* d_qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
+                       void* d_y_bf16, float* d_y_f32, void* stream) {
+  API_TRY
+  CT2X_CHECK(d_y_bf16 != nullptr || d_y_f32 != nullptr, "ct2x_awq_gemm_bf16: no output given");
+  launch_awq_gemm(d_x_bf16, d_qweight, d_scales_bf16, d_qzeros, m, in_c, out_c, group, d_y_bf16,
+                  d_y_f32, resolve_stream(stream), nullptr, true);
+  check_last_launch("awq_gemm_bf16");
+  API_CATCH
+}
+
+int ct2x_awq_gemv_bf16(const void* d_x_bf16, const int32_t* d_qweight, const void* d_scales_bf16,
+                       const int32_t* d_qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
+                       int64_t zeros_w, int64_t sf_w, void* d_y_bf16, float* d_y_f32, void* stream) {
+  API_TRY
+  CT2X_CHECK(d_y_bf16 != nullptr || d_y_f32 != nullptr, "ct2x_awq_gemv_bf16: no output given");
+  launch_awq_gemv(d_x_bf16, d_qweight, d_scales_bf16, d_qzeros, m, in_c, out_c, group, zeros_w, sf_w,
+                  d_y_bf16, d_y_f32, resolve_stream(stream), true);
+  check_last_launch("awq_gemv_bf16");
+  API_CATCH
+}
+
+int ct2x_awq_dequantize_gemv_bf16(const int32_t* d_qweight, const void* d_scales_bf16,
+                                  const int32_t* d_qzeros, int64_t out_c, int64_t in_c, int64_t group,
+                                  int64_t zeros_w, int64_t sf_w, void* d_out_bf16, void* stream) {
+  API_TRY
+  launch_awq_dequantize_gemv(d_qweight, d_scales_bf16, d_qzeros, out_c, in_c, group, zeros_w, sf_w,
+                             d_out_bf16, resolve_stream(stream), true);
+  check_last_launch("awq_dequantize_gemv_bf16");
+  API_CATCH
+}
+
 int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,
                          void* d_y, int dtype, void* stream) {
   API_TRY

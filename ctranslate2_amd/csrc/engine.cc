@@ -86,6 +86,32 @@ uint16_t float_to_bf16_bits(float f) {  // round to nearest even, NaN kept quiet
   return static_cast<uint16_t>(u >> 16);
 }
 
+float half_bits_to_float(uint16_t h) {  // IEEE binary16 -> float, exact
+  const uint32_t sign = static_cast<uint32_t>(h & 0x8000u) << 16;
+  const uint32_t exp = (h >> 10) & 31u, man = h & 0x3ffu;
+  uint32_t bits;
+  if (exp == 0) {
+    if (man == 0) {
+      bits = sign;
+    } else {  // subnormal: normalise
+      int e = -1;
+      uint32_t m = man;
+      do {
+        ++e;
+        m <<= 1;
+      } while ((m & 0x400u) == 0);
+      bits = sign | (static_cast<uint32_t>(127 - 15 - e) << 23) | ((m & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) {
+    bits = sign | 0x7f800000u | (man << 13);
+  } else {
+    bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  }
+  float f;
+  std::memcpy(&f, &bits, 4);
+  return f;
+}
+
 uint16_t float_to_half_bits(float f) {  // IEEE binary16, round to nearest even
   uint32_t x;
   std::memcpy(&x, &f, 4);
@@ -251,7 +277,6 @@ DenseW Engine::load_dense(const std::string& scope, bool required, Shard shard,
         scale->dtype != kF16 || scale->shape.size() != 2 || zero->shape.size() != 2)
       throw std::invalid_argument(scope + ": malformed AWQ weight (needs quantization_type 1 / 2, "
                                   "int32 weight / zeros, float16 scales)");
-    if (tp_) throw std::invalid_argument(scope + ": AWQ weights are not supported under tensor parallelism");
     d.present = true;
     d.awq = method;
     if (method == 1) {  // GEMM layout: weight [in_c, out_c / 8]
@@ -268,10 +293,95 @@ DenseW Engine::load_dense(const std::string& scope, bool required, Shard shard,
       d.aq_group = static_cast<int64_t>(
           model_->config_number("quantization_group_size", static_cast<double>(d.k / d.aq_sw)));
     }
-    d.aq_w = static_cast<const int32_t*>(upload(w->data.data(), w->data.size()));
-    d.aq_s = upload(scale->data.data(), scale->data.size());
-    d.aq_z = static_cast<const int32_t*>(upload(zero->data.data(), zero->data.size()));
-    if (const Variable* b = model_->find(scope + "/bias")) d.bias = upload_floats(b->to_float());
+    // host copies: words, scales as 16-bit patterns, zero words
+    std::vector<int32_t> qw(w->data.size() / 4), qz(zero->data.size() / 4);
+    std::vector<uint16_t> sc(scale->data.size() / 2);
+    std::memcpy(qw.data(), w->data.data(), qw.size() * 4);
+    std::memcpy(qz.data(), zero->data.data(), qz.size() * 4);
+    std::memcpy(sc.data(), scale->data.data(), sc.size() * 2);
+    // Compute type bfloat16 (round 6; BASELINE configs[4]): the scales are rounded to bfloat16 once
+    // here and the bf16 arm of the kernels runs (awq.hip) - the reference has float16 only.
+    d.aq_bf16 = compute_type_ == ComputeType::kBFloat16;
+    if (d.aq_bf16)
+      for (uint16_t& v : sc) v = float_to_bf16_bits(half_bits_to_float(v));
+    std::vector<float> bias;
+    if (const Variable* b = model_->find(scope + "/bias")) bias = b->to_float();
+    if (tp_ && shard != Shard::kNone) {
+      // Tensor parallelism (round 6; Model::load shards every Dense alike, src/models/model.cc:
+      // 662-743 - the reference never meets AWQ there because its CUDA-only kernels are not in the
+      // ROCm build): the packed words, scales and zero points are cut along the same axis as a
+      // float weight would be; cuts fall on words (8 channels) and on quantisation groups.
+      const int world = tp_->world(), rank = tp_->rank();
+      const int64_t G = d.aq_group, groups = d.k / G;
+      if (shard == Shard::kColumn) {
+        const auto rows = column_shard_rows(d.n, blocks, rank, world, scope);
+        int64_t n_local = 0;
+        for (const auto& r : rows) {
+          if (r.first % 8 != 0 || r.second % 8 != 0)
+            throw std::invalid_argument(scope + ": an AWQ column shard must start and end on a packed word (8 channels)");
+          n_local += r.second;
+        }
+        if (method == 1) {
+          std::vector<int32_t> qw2, qz2;
+          std::vector<uint16_t> sc2;
+          const int64_t qout = d.n / 8;
+          for (int64_t kk = 0; kk < d.k; ++kk)
+            for (const auto& r : rows)
+              qw2.insert(qw2.end(), qw.begin() + kk * qout + r.first / 8,
+                         qw.begin() + kk * qout + (r.first + r.second) / 8);
+          for (int64_t g = 0; g < groups; ++g)
+            for (const auto& r : rows) {
+              qz2.insert(qz2.end(), qz.begin() + g * qout + r.first / 8,
+                         qz.begin() + g * qout + (r.first + r.second) / 8);
+              sc2.insert(sc2.end(), sc.begin() + g * d.n + r.first, sc.begin() + g * d.n + r.first + r.second);
+            }
+          qw.swap(qw2); qz.swap(qz2); sc.swap(sc2);
+        } else {
+          qw = take_rows(qw.data(), d.k / 8, rows);
+          qz = take_rows(qz.data(), d.aq_zw, rows);
+          sc = take_rows(sc.data(), d.aq_sw, rows);
+        }
+        if (!bias.empty()) bias = take_rows(bias.data(), 1, rows);
+        d.n = n_local;
+      } else {  // Shard::kRow: K / world input channels, whole groups
+        if (d.k % world != 0 || (d.k / world) % G != 0 || (d.k / world) % 128 != 0)
+          throw std::invalid_argument(scope + ": an AWQ row shard must hold whole quantisation groups "
+                                              "and a multiple of 128 input channels");
+        const int64_t kl = d.k / world, k0 = rank * kl, g0 = k0 / G, gl = kl / G;
+        if (method == 1) {
+          const int64_t qout = d.n / 8;
+          qw = std::vector<int32_t>(qw.begin() + k0 * qout, qw.begin() + (k0 + kl) * qout);
+          qz = std::vector<int32_t>(qz.begin() + g0 * qout, qz.begin() + (g0 + gl) * qout);
+          sc = std::vector<uint16_t>(sc.begin() + g0 * d.n, sc.begin() + (g0 + gl) * d.n);
+        } else {
+          // GEMV layout: zero points are nibbles (group g = nibble g % 8 of word g / 8) and both
+          // side tables are padded to the widths the layout prescribes for the LOCAL in_c
+          // (src/ops/awq/gemv_gpu.cu:296-302, 365-369; oracle/awq_oracle.py gemv_widths)
+          auto md = [](int64_t c, int64_t dv) { return (c + dv - 1) / dv; };
+          const int64_t zw2 = G == 64 ? md(md(gl, 8), 2) * 2 : md(gl, 8), sw2 = zw2 * 8;
+          std::vector<int32_t> qw2 = take_cols(qw.data(), d.n, d.k / 8, k0 / 8, (k0 + kl) / 8);
+          std::vector<int32_t> qz2(static_cast<size_t>(d.n) * zw2, 0);
+          std::vector<uint16_t> sc2(static_cast<size_t>(d.n) * sw2, 0);
+          for (int64_t oc = 0; oc < d.n; ++oc)
+            for (int64_t g = 0; g < gl; ++g) {
+              const int64_t gs = g0 + g;
+              const uint32_t z = (static_cast<uint32_t>(qz[oc * d.aq_zw + gs / 8]) >> (4 * (gs % 8))) & 15u;
+              qz2[oc * zw2 + g / 8] = static_cast<int32_t>(static_cast<uint32_t>(qz2[oc * zw2 + g / 8]) |
+                                                           (z << (4 * (g % 8))));
+              sc2[oc * sw2 + g] = sc[oc * d.aq_sw + gs];
+            }
+          qw.swap(qw2); qz.swap(qz2); sc.swap(sc2);
+          d.aq_zw = zw2;
+          d.aq_sw = sw2;
+        }
+        d.k = kl;
+        d.row_parallel = true;  // bias stays whole: applied once, after the rank sum
+      }
+    }
+    d.aq_w = static_cast<const int32_t*>(upload(qw.data(), qw.size() * 4));
+    d.aq_s = upload(sc.data(), sc.size() * 2);
+    d.aq_z = static_cast<const int32_t*>(upload(qz.data(), qz.size() * 4));
+    if (!bias.empty()) d.bias = upload_floats(bias);
     has_awq_ = true;
     return d;
   }
@@ -1279,18 +1389,37 @@ bool Engine::dense_out_next_norm(const DenseW& w, const QuantIn& cq, int64_t row
 void Engine::dense_awq(const DenseW& w, const float* x, int64_t m, int act, const float* residual,
                        float* y, DecodeState* ws) {
   CT2X_CHECK(ws != nullptr && ws->hbuf != nullptr, "AWQ Dense without its float16 scratch buffer");
-  begin_kernel("convert_f16", double(m) * w.k * 6, 0, m, 0, w.k);
-  launch_convert(x, kF32, ws->hbuf, kF16, m * w.k, cur_stream());  // DType values = ct2x_dtype
+  begin_kernel(w.aq_bf16 ? "convert_bf16" : "convert_f16", double(m) * w.k * 6, 0, m, 0, w.k);
+  launch_convert(x, kF32, ws->hbuf, w.aq_bf16 ? kBF16 : kF16, m * w.k, cur_stream());  // DType values = ct2x_dtype
   end_kernel();
+  // Row-parallel (tensor parallelism, round 6): this rank's K / world input channels give a partial
+  // product; the ranks' fp32 partials are summed, then bias and residual once (as the float arm of
+  // Engine::dense does).
+  const bool rowp = w.row_parallel && tp_;
+  if (rowp) {
+    CT2X_CHECK(act < 0, "row-parallel Dense takes no activation");
+    CT2X_CHECK(ws->tp_acc != nullptr, "tensor-parallel scratch buffers are missing");
+  }
+  float* out = rowp ? reinterpret_cast<float*>(ws->tp_acc) : y;
   const double bytes = double(w.n) * w.k / 2 + 2.0 * m * w.k + 4.0 * m * w.n;
   begin_kernel(w.awq == 1 ? "awq_gemm" : "awq_gemv", bytes, 2.0 * m * w.n * w.k, m, w.n, w.k);
   if (w.awq == 1)
-    launch_awq_gemm(ws->hbuf, w.aq_w, w.aq_s, w.aq_z, m, w.k, w.n, w.aq_group, nullptr, y, cur_stream(),
-                    ws->awq_ws);
+    launch_awq_gemm(ws->hbuf, w.aq_w, w.aq_s, w.aq_z, m, w.k, w.n, w.aq_group, nullptr, out, cur_stream(),
+                    ws->awq_ws, w.aq_bf16);
   else
     launch_awq_gemv(ws->hbuf, w.aq_w, w.aq_s, w.aq_z, m, w.k, w.n, w.aq_group, w.aq_zw, w.aq_sw,
-                    nullptr, y, cur_stream());
+                    nullptr, out, cur_stream(), w.aq_bf16);
   end_kernel();
+  if (rowp) {
+    begin_kernel("tp_all_reduce_sum", double(m) * w.n * 4, 0, m, w.n, 0);
+    tp_->all_reduce_sum_f32(out, m * w.n, cur_stream());
+    end_kernel();
+    begin_kernel("bias_residual", double(m) * w.n * 8, 0, m, w.n, 0);
+    launch_bias_residual(out, w.bias, residual, m, w.n, y, cur_stream());
+    end_kernel();
+    if (taps_) tap("d", y, 0, m, w.n);
+    return;
+  }
   // apply_bias_and_activation (src/ops/gemm.cc:11-25): bias, activation, then the residual
   if (act >= 0) {
     if (w.bias) {

@@ -69,7 +69,8 @@ struct DenseW {
   // AWQ int4 weight (awq.hip): 1 = GEMM layout [k, n / 8], 2 = GEMV layout [n, k / 8]
   int awq = 0;
   const int32_t* aq_w = nullptr;
-  const void* aq_s = nullptr;      // float16 scales
+  const void* aq_s = nullptr;      // float16 scales (bfloat16 when aq_bf16)
+  bool aq_bf16 = false;            // compute type bfloat16: the bf16 arm of the AWQ kernels (round 6)
   const int32_t* aq_z = nullptr;
   int64_t aq_group = 0, aq_zw = 0, aq_sw = 0;
 };

@@ -346,21 +346,24 @@ bool weight_prefetch_range(const int8_t* packed, int64_t n, int64_t k, bool dual
 
 // ---- AWQ int4 weights (awq.hip; ops::DequantizeAwq / GemmAwq / GemvAwq, src/ops/awq/*) ----------
 // GEMM layout: qweight [in_c, out_c / 8], scales [in_c / G, out_c] f16, qzeros [in_c / G, out_c / 8].
+// bf16 = true (round 6): x / scales / 16-bit outputs are bfloat16 (the arm the reference lacks).
 void launch_awq_dequantize_gemm(const int32_t* qweight, const void* scales_f16, const int32_t* qzeros,
                                 int64_t in_c, int64_t out_c, int64_t group, void* out_f16,
-                                hipStream_t stream);
+                                hipStream_t stream, bool bf16 = false);
 // Split-K workspace of launch_awq_gemm (floats): pass one to keep the launch allocation free.
 constexpr size_t kAwqGemmWorkspaceFloats = size_t(1) << 20;
 void launch_awq_gemm(const void* x_f16, const int32_t* qweight, const void* scales_f16,
                      const int32_t* qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
-                     void* y_f16, float* y_f32, hipStream_t stream, float* slices_ws = nullptr);
+                     void* y_f16, float* y_f32, hipStream_t stream, float* slices_ws = nullptr,
+                     bool bf16 = false);
 // GEMV layout: qweight [out_c, in_c / 8], scales [out_c, sf_w] f16, qzeros [out_c, zeros_w].
 void launch_awq_dequantize_gemv(const int32_t* qweight, const void* scales_f16, const int32_t* qzeros,
                                 int64_t out_c, int64_t in_c, int64_t group, int64_t zeros_w,
-                                int64_t sf_w, void* out_f16, hipStream_t stream);
+                                int64_t sf_w, void* out_f16, hipStream_t stream, bool bf16 = false);
 void launch_awq_gemv(const void* x_f16, const int32_t* qweight, const void* scales_f16,
                      const int32_t* qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
-                     int64_t zeros_w, int64_t sf_w, void* y_f16, float* y_f32, hipStream_t stream);
+                     int64_t zeros_w, int64_t sf_w, void* y_f16, float* y_f32, hipStream_t stream,
+                     bool bf16 = false);
 
 // ---- fp32 GEMM (gemm_f32.hip) --------------------------------------------------------
 

@@ -103,6 +103,21 @@ def awq_dequantize(q, z, s, group):
     return ((q - zz).astype(np.float32) * ss).astype(np.float16)
 
 
+def _bf16_round(a):
+    """float32 array -> the nearest bfloat16 values (round to nearest even), as float32"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def awq_dequantize_bf16(q, z, s, group):
+    """The weight the bfloat16 arm of the AWQ kernels multiplies with (awq.hip, round 6): the float16
+    scale rounded to bfloat16 once, (q - z) * s rounded to bfloat16 once; float32 [out_c, in_c]."""
+    zz = np.repeat(z, group, axis=1)
+    ss = np.repeat(_bf16_round(s.astype(np.float32)), group, axis=1)
+    return _bf16_round((q - zz).astype(np.float32) * ss)
+
+
 def _pack_nibbles(m, order):
     r, c = m.shape
     blocks = m.reshape(r, c // 8, 8).astype(np.uint32)
@@ -178,7 +193,9 @@ class _Builder:
             layout, group, twin = self.awq
             w = self.rng.normal(0, self.w_std, (n, k)).astype(np.float32)
             q, z, s = awq_quantize(w, group)
-            if twin:
+            if twin == "bf16":  # the bfloat16 arm's weights, stored exactly (float32)
+                self.vars[scope + "/weight"] = awq_dequantize_bf16(q, z, s, group)
+            elif twin:
                 self.vars[scope + "/weight"] = awq_dequantize(q, z, s, group)
             else:
                 qw, sc, qz = awq_pack(q, z, s, group, layout)

@@ -272,6 +272,24 @@ int ct2x_awq_dequantize_gemv(const int32_t* d_qweight, const void* d_scales_f16,
                              const int32_t* d_qzeros, int64_t out_c, int64_t in_c, int64_t group,
                              int64_t zeros_w, int64_t sf_w, void* d_out_f16, void* stream);
 
+/* The bfloat16 arm of the four entry points above (round 6; SURVEY 8(f3) asks for "a bf16 variant
+ * the reference lacks" - the reference instantiates float16 only, src/ops/awq/gemm_gpu.cu:541, and
+ * forces FLOAT16 for AWQ models, src/models/model.cc:754-757): the same formats with bfloat16
+ * activations / scales / 16-bit outputs (raw 2-byte data). Arithmetic, defined here and restated in
+ * oracle/awq_oracle.py (bf16=True): w = (q - z) * s rounded ONCE to bfloat16 (the product is exact
+ * in fp32), products with the bfloat16 activation accumulate in fp32. Same shape preconditions. */
+int ct2x_awq_dequantize_bf16(const int32_t* d_qweight, const void* d_scales_bf16, const int32_t* d_qzeros,
+                             int64_t in_c, int64_t out_c, int64_t group, void* d_out_bf16, void* stream);
+int ct2x_awq_gemm_bf16(const void* d_x_bf16, const int32_t* d_qweight, const void* d_scales_bf16,
+                       const int32_t* d_qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
+                       void* d_y_bf16, float* d_y_f32, void* stream);
+int ct2x_awq_gemv_bf16(const void* d_x_bf16, const int32_t* d_qweight, const void* d_scales_bf16,
+                       const int32_t* d_qzeros, int64_t m, int64_t in_c, int64_t out_c, int64_t group,
+                       int64_t zeros_w, int64_t sf_w, void* d_y_bf16, float* d_y_f32, void* stream);
+int ct2x_awq_dequantize_gemv_bf16(const int32_t* d_qweight, const void* d_scales_bf16,
+                                  const int32_t* d_qzeros, int64_t out_c, int64_t in_c, int64_t group,
+                                  int64_t zeros_w, int64_t sf_w, void* d_out_bf16, void* stream);
+
 /* ops::Dequantize::dequantize<Device::CUDA,int8_t,T> (src/ops/dequantize_gpu.cu:17-28):
  * y[r,:] = x[r,:] / scale[r]  (int8 embedding rows, src/layers/common.cc:64-81). */
 int ct2x_dequantize_rows(const int8_t* d_x, const float* d_scale, int64_t rows, int64_t depth,

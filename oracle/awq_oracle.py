@@ -15,6 +15,32 @@ import numpy as np
 GEMM_ORDER = np.array([0, 2, 4, 6, 1, 3, 5, 7])
 
 
+def bf16_bits(a):
+    """float32 array -> bfloat16 bit patterns (uint16), round to nearest even"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_to_f32(bits):
+    """bfloat16 bit patterns (uint16) -> float32"""
+    return (np.ascontiguousarray(bits, np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def _round_16(product_f32, bf16):
+    """one rounding of the exact fp32 product to the arm's 16-bit type: float16 values, or bfloat16
+    bit patterns (uint16) for the bfloat16 arm (awq.hip, round 6 - defined there, the reference has
+    float16 only)"""
+    return bf16_bits(product_f32) if bf16 else product_f32.astype(np.float16)
+
+
+def _scales_f32(scales, bf16):
+    return bf16_to_f32(scales) if bf16 else scales.astype(np.float32)
+
+
+def _weights_f64(w16, bf16):
+    return (bf16_to_f32(w16) if bf16 else w16).astype(np.float64)
+
+
 def _nibbles(words):
     """[..., W] int32 -> [..., W, 8] values 0..15, nibble 0 = least significant."""
     w = words.astype(np.uint32)[..., None]
@@ -34,7 +60,7 @@ def pack_gemm(q, zeros, group):
     return pack(q), pack(zeros)
 
 
-def dequantize_gemm(qweight, scales, qzeros):
+def dequantize_gemm(qweight, scales, qzeros, bf16=False):
     """DequantizeAwq (src/ops/awq/dequantize_gpu.cu:8-64, shapes :71-76): qweight [in_c, out_c / 8]
     int32, scales [in_c / G, out_c] float16, qzeros [in_c / G, out_c / 8] int32 -> float16
     [in_c, out_c]: w = (q - z) * s, the subtraction exact and the product rounded once to float16
@@ -46,17 +72,17 @@ def dequantize_gemm(qweight, scales, qzeros):
     q = _nibbles(qweight)[:, :, inv].reshape(in_c, out_c)
     z = _nibbles(qzeros)[:, :, inv].reshape(-1, out_c)
     z = np.repeat(z, group, axis=0)
-    s = np.repeat(scales.astype(np.float32), group, axis=0)
-    return ((q - z).astype(np.float32) * s).astype(np.float16)
+    s = np.repeat(_scales_f32(scales, bf16), group, axis=0)
+    return _round_16((q - z).astype(np.float32) * s, bf16)
 
 
-def gemm(x, qweight, scales, qzeros):
+def gemm(x, qweight, scales, qzeros, bf16=False):
     """GemmAwq (src/ops/awq/gemm.cc:9-31 + gemm_gpu.cu:470-530): x [m, in_c] float16 -> float16
     [m, out_c] = x . dequantize(qweight). The CUDA kernel accumulates eight K-interleaved partial
     sums in fp32, rounds each to float16 and ops::Sum adds them; the restatement keeps the exact
     product of the rounded operands (float64) - the comparison tolerance covers that difference."""
-    w = dequantize_gemm(qweight, scales, qzeros).astype(np.float64)
-    return x.astype(np.float64) @ w
+    w = _weights_f64(dequantize_gemm(qweight, scales, qzeros, bf16), bf16)
+    return _weights_f64(x, bf16) @ w
 
 
 def gemv_widths(in_c, group):
@@ -92,7 +118,7 @@ def pack_gemv(q, zeros, scales, group):
     return qw.view(np.int32), qz.view(np.int32), sc
 
 
-def dequantize_gemv(qweight, scales, qzeros, group):
+def dequantize_gemv(qweight, scales, qzeros, group, bf16=False):
     """The weight the GEMV kernels multiply with (src/ops/awq/gemv_gpu.cu:140-150 for the
     tensor-core form: __float2half(scale * (q - z)); :318-331 for the vector form, which keeps the
     product in fp32): returned as float16 [out_c, in_c]."""
@@ -102,11 +128,11 @@ def dequantize_gemv(qweight, scales, qzeros, group):
     q = _nibbles(qweight).reshape(out_c, in_c)
     z = _nibbles(qzeros).reshape(out_c, -1)[:, :groups]
     z = np.repeat(z, group, axis=1)
-    s = np.repeat(scales[:, :groups].astype(np.float32), group, axis=1)
-    return ((q - z).astype(np.float32) * s).astype(np.float16)
+    s = np.repeat(_scales_f32(scales[:, :groups], bf16), group, axis=1)
+    return _round_16((q - z).astype(np.float32) * s, bf16)
 
 
-def gemv(x, qweight, scales, qzeros, group):
+def gemv(x, qweight, scales, qzeros, group, bf16=False):
     """GemvAwq (src/ops/awq/gemv.cc:9-37): x [m, in_c] float16 -> [m, out_c] = x . W^T."""
-    w = dequantize_gemv(qweight, scales, qzeros, group).astype(np.float64)
-    return x.astype(np.float64) @ w.T
+    w = _weights_f64(dequantize_gemv(qweight, scales, qzeros, group, bf16), bf16)
+    return _weights_f64(x, bf16) @ w.T

@@ -85,3 +85,30 @@ def test_autoawq_published_order_known_answer():
     s = np.ones((1, 8), np.float16)
     assert A.dequantize_gemm(*A.pack_gemm(np.arange(8)[None, :], np.zeros((1, 8), np.int64), 1)[:1], s,
                              qz).astype(np.int64).tolist() == [list(range(8))]
+
+
+def test_bfloat16_arm_of_the_restatement():
+    """Round 6: the bfloat16 arm (defined in awq.hip, the reference has float16 only). The rounding
+    helper against hand-computed patterns (ties to even, carry into the exponent), and the arm's
+    dequantised weight - scale rounded to bfloat16 once, (q - z) * s rounded to bfloat16 once -
+    against ctranslate2_amd.model_builder's own statement of it, both layouts."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ctranslate2_amd import model_builder as mb
+    x = np.array([1.0, 1.00390625, 1.01171875, 1.99609375, -3.140625, 0.0, 65280.0], np.float32)
+    # 1 + 2^-8 is a tie -> even (1.0); 1 + 3 * 2^-8 is a tie -> even (1 + 2^-6); 2 - 2^-8 is a tie -> 2.0
+    assert A.bf16_bits(x).tolist() == [0x3f80, 0x3f80, 0x3f82, 0x4000, 0xc049, 0x0000, 0x477f]
+    assert np.array_equal(A.bf16_to_f32(A.bf16_bits(x)),
+                          np.array([1.0, 1.0, 1.015625, 2.0, -3.140625, 0.0, 65280.0], np.float32))
+    rng = np.random.default_rng(9)
+    w = rng.normal(0, 0.05, (48, 256)).astype(np.float32)
+    for group in (64, 128):
+        q, z, s = mb.awq_quantize(w, group)
+        want = mb.awq_dequantize_bf16(q, z, s, group)                 # float32 holding bfloat16 values
+        assert np.array_equal(A.bf16_to_f32(A.bf16_bits(want)), want)
+        qw, sc, qz = mb.awq_pack(q, z, s, group, "gemm")
+        got = A.dequantize_gemm(qw, A.bf16_bits(sc.astype(np.float32)), qz, bf16=True)
+        assert np.array_equal(A.bf16_to_f32(got), want.T)
+        qw, sc, qz = mb.awq_pack(q, z, s, group, "gemv")
+        got = A.dequantize_gemv(qw, A.bf16_bits(sc.astype(np.float32)), qz, group, bf16=True)
+        assert np.array_equal(A.bf16_to_f32(got), want)
+        assert np.abs(want - w).max() < 0.02
