@@ -630,18 +630,32 @@ __global__ __launch_bounds__(256) void gemm_h_tiled_kernel(const float* __restri
 // float16: hi + lo split of the activation as in the other forms (split_f16), lo first.
 constexpr int R256_BN = 128, R256_BK = 32;
 __device__ __forceinline__ float4 as_float4(const v4f& v) { return make_float4(v.x, v.y, v.z, v.w); }
-template <bool kBF16>
+// ROWS = 128 (second half of round 6): the same stage machinery on 128 rows x 128 columns - waves
+// 2 x 4 instead of 4 x 2, three requests per stage instead of five, 48 KB of LDS (24 KB bfloat16)
+// so that two or three workgroups share a CU. Why: a stage is LDS traffic (~1100 clocks), 32 matrix
+// instructions per wave (2 x 512 clocks on a SIMD) and the float16 split's VALU IN LOCKSTEP behind
+// one barrier - nothing overlaps inside a workgroup, and the 256-row form puts only
+// column tiles x K slices workgroups on the chip (64 at [256, 2048] x 2048: three of the six Dense
+// layers of an NLLB decoder layer ran on a quarter of the CUs, 31 us for 8 MB of weights). Half the
+// rows per workgroup = twice the workgroups: idle CUs fill, and where the chip was already full two
+// workgroups per CU interleave their phases. The weight tile is fetched by two workgroups (the
+// second read comes from the memory-side cache).
+template <bool kBF16, int ROWS>
 __global__ __launch_bounds__(512) void gemm_h_rows256_kernel(const float* __restrict__ A,
                                                              const uint16_t* __restrict__ W, int M, int N, int K,
                                                              HalfEpilogue ep, int k_slice,
                                                              float* __restrict__ partial) {
   using Ops = HalfOps<kBF16>;
   using vec = typename Ops::vec;
-  constexpr int A_BYTES = 16 * 1024, W_BYTES = 8 * 1024;
+  static_assert(ROWS == 256 || ROWS == 128, "row tiles of 256 or 128");
+  constexpr int WN = ROWS == 256 ? 2 : 4;  // waves along the columns; 8 / WN along the rows (64 rows each)
+  constexpr int NJ = 8 / WN;               // 16-column tiles of a wave
+  constexpr int A_BYTES = ROWS * 64, W_BYTES = 8 * 1024;
   constexpr int STAGE = (kBF16 ? 1 : 2) * A_BYTES + W_BYTES;
   extern __shared__ __attribute__((aligned(16))) uint8_t r256_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * ROWS;
   const int64_t n0 = static_cast<int64_t>(blockIdx.x) * R256_BN;
   const int k_begin = blockIdx.z * k_slice;
   const int k_end = min(K, k_begin + k_slice);
@@ -650,10 +664,10 @@ __global__ __launch_bounds__(512) void gemm_h_rows256_kernel(const float* __rest
   const int s_g = tid & 3, s_row = tid >> 2;  // rows s_row and s_row + 128 of A, column s_row of W
   const int s_pos = ((s_row & 15) * 4 + (s_g ^ (((s_row & 15) >> 1) & 3))) * 16;
   const int sa_off0 = (s_row >> 4) * 1024 + s_pos, sa_off1 = ((s_row + 128) >> 4) * 1024 + s_pos;
-  const bool a_ok0 = s_row < M, a_ok1 = s_row + 128 < M;
+  const bool a_ok0 = m0 + s_row < M, a_ok1 = ROWS == 256 && m0 + s_row + 128 < M;
   const bool w_ok = n0 + s_row < N;
-  const float* a_src0 = A + static_cast<int64_t>(a_ok0 ? s_row : 0) * K + s_g * 8;
-  const float* a_src1 = A + static_cast<int64_t>(a_ok1 ? s_row + 128 : 0) * K + s_g * 8;
+  const float* a_src0 = A + static_cast<int64_t>(a_ok0 ? m0 + s_row : 0) * K + s_g * 8;
+  const float* a_src1 = A + static_cast<int64_t>(a_ok1 ? m0 + s_row + 128 : 0) * K + s_g * 8;
   const uint16_t* w_src = W + (w_ok ? n0 + s_row : 0) * K + s_g * 8;
   // fragment read map
   const int r = lane & 15, g = lane >> 4;
@@ -678,43 +692,52 @@ __global__ __launch_bounds__(512) void gemm_h_rows256_kernel(const float* __rest
     const uint16_t* pw = w_src + kk;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R.a[0]) : "v"(p0) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(R.a[1]) : "v"(p0) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R.a[2]) : "v"(p1) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(R.a[3]) : "v"(p1) : "memory");
+    if constexpr (ROWS == 256) {
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R.a[2]) : "v"(p1) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(R.a[3]) : "v"(p1) : "memory");
+    }
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R.w) : "v"(pw) : "memory");
   };
   // the requests before the newest `newer` loads have landed (the registers are operands so that no
   // use of them can be scheduled in front of the wait)
-  auto landed5 = [&](Regs& R) {
-    asm volatile("s_waitcnt vmcnt(5)" : "+v"(R.a[0]), "+v"(R.a[1]), "+v"(R.a[2]), "+v"(R.a[3]), "+v"(R.w)::"memory");
+  auto landed5 = [&](Regs& R) {  // (three requests per stage in the 128-row form)
+    if constexpr (ROWS == 256)
+      asm volatile("s_waitcnt vmcnt(5)" : "+v"(R.a[0]), "+v"(R.a[1]), "+v"(R.a[2]), "+v"(R.a[3]), "+v"(R.w)::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(3)" : "+v"(R.a[0]), "+v"(R.a[1]), "+v"(R.w)::"memory");
   };
   auto stash = [&](const Regs& R, int buf) {
     uint8_t* base = r256_lds + buf * STAGE;
     if constexpr (!kBF16) {
-      v8h h0, l0, h1, l1;
+      v8h h0, l0;
       split_f16(as_float4(R.a[0]), as_float4(R.a[1]), h0, l0);
-      split_f16(as_float4(R.a[2]), as_float4(R.a[3]), h1, l1);
       *reinterpret_cast<v8h*>(base + sa_off0) = h0;
-      *reinterpret_cast<v8h*>(base + sa_off1) = h1;
       *reinterpret_cast<v8h*>(base + A_BYTES + sa_off0) = l0;
-      *reinterpret_cast<v8h*>(base + A_BYTES + sa_off1) = l1;
+      if constexpr (ROWS == 256) {
+        v8h h1, l1;
+        split_f16(as_float4(R.a[2]), as_float4(R.a[3]), h1, l1);
+        *reinterpret_cast<v8h*>(base + sa_off1) = h1;
+        *reinterpret_cast<v8h*>(base + A_BYTES + sa_off1) = l1;
+      }
     } else {
       *reinterpret_cast<vec*>(base + sa_off0) = Ops::from_f32(as_float4(R.a[0]), as_float4(R.a[1]));
-      *reinterpret_cast<vec*>(base + sa_off1) = Ops::from_f32(as_float4(R.a[2]), as_float4(R.a[3]));
+      if constexpr (ROWS == 256)
+        *reinterpret_cast<vec*>(base + sa_off1) = Ops::from_f32(as_float4(R.a[2]), as_float4(R.a[3]));
     }
     *reinterpret_cast<vec*>(base + (kBF16 ? 1 : 2) * A_BYTES + (s_row >> 4) * 1024 + s_pos) = R.w;
   };
 
-  v4f acc[4][4];
+  v4f acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
   auto multiply = [&](int buf) {
     const uint8_t* base = r256_lds + buf * STAGE;
-    vec af[4], bfr[4];
+    vec af[4], bfr[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      bfr[j] = *reinterpret_cast<const vec*>(base + (kBF16 ? 1 : 2) * A_BYTES + (wn * 4 + j) * 1024 + f_pos);
+    for (int j = 0; j < NJ; ++j)
+      bfr[j] = *reinterpret_cast<const vec*>(base + (kBF16 ? 1 : 2) * A_BYTES + (wn * NJ + j) * 1024 + f_pos);
     if constexpr (!kBF16) {
       vec al[4];
 #pragma unroll
@@ -723,14 +746,14 @@ __global__ __launch_bounds__(512) void gemm_h_rows256_kernel(const float* __rest
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Ops::mfma(al[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = Ops::mfma(al[i], bfr[j], acc[i][j]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const vec*>(base + (wm * 4 + i) * 1024 + f_pos);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = Ops::mfma(af[i], bfr[j], acc[i][j]);
+      for (int j = 0; j < NJ; ++j) acc[i][j] = Ops::mfma(af[i], bfr[j], acc[i][j]);
   };
 
   // prologue: stages 0, 1, 2 requested; stage 0 parked in LDS
@@ -763,44 +786,44 @@ __global__ __launch_bounds__(512) void gemm_h_rows256_kernel(const float* __rest
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int64_t row = (wm * 4 + i) * 16 + g * 4 + e;
+        const int64_t row = m0 + (wm * 4 + i) * 16 + g * 4 + e;
         if (row >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int64_t col = n0 + (wn * 4 + j) * 16 + r;
+        for (int j = 0; j < NJ; ++j) {
+          const int64_t col = n0 + (wn * NJ + j) * 16 + r;
           if (col < N) pz[row * N + col] = acc[i][j][e];
         }
       }
     return;
   }
   // Epilogue: operands first, then stores (as in the 128 x 128 form).
-  float bias[4];
-  bool col_ok[4];
+  float bias[NJ];
+  bool col_ok[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int64_t col = n0 + (wn * 4 + j) * 16 + r;
+  for (int j = 0; j < NJ; ++j) {
+    const int64_t col = n0 + (wn * NJ + j) * 16 + r;
     col_ok[j] = col < N;
     bias[j] = (ep.bias && col_ok[j]) ? ep.bias[col] : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float res[4][4];
+    float res[4][NJ];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int64_t row = (wm * 4 + i) * 16 + g * 4 + e;
+      const int64_t row = m0 + (wm * 4 + i) * 16 + g * 4 + e;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t col = n0 + (wn * 4 + j) * 16 + r;
+      for (int j = 0; j < NJ; ++j) {
+        const int64_t col = n0 + (wn * NJ + j) * 16 + r;
         res[e][j] = (ep.residual && row < M && col_ok[j]) ? ep.residual[row * N + col] : 0.f;
       }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int64_t row = (wm * 4 + i) * 16 + g * 4 + e;
+      const int64_t row = m0 + (wm * 4 + i) * 16 + g * 4 + e;
       if (row >= M) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t col = n0 + (wn * 4 + j) * 16 + r;
+      for (int j = 0; j < NJ; ++j) {
+        const int64_t col = n0 + (wn * NJ + j) * 16 + r;
         if (col_ok[j])
           ep.y[row * N + col] = finish(acc[i][j][e], bias[j], ep.bias != nullptr, ep.act, res[e][j],
                                        ep.residual != nullptr);
@@ -964,24 +987,39 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
     return;
   }
 #undef CT2X_HSKINNY
-  // 129 .. 256 rows: all rows x 128 columns x a K slice per workgroup (gemm_h_rows256_kernel);
-  // CT2X_H_ROWS256=0 keeps the 128 x 128 tiles (A/B runs)
-  static const bool rows256 = [] {
+  // 129 .. 256 rows: row tile x 128 columns x a K slice per workgroup (gemm_h_rows256_kernel).
+  // CT2X_H_ROWS256: 0 = the 128 x 128 tiles below, 1 = all rows per workgroup, 2 (default) = 128-row
+  // tiles; CT2X_H_ROWS_TARGET = workgroups a launch should reach before it stops slicing K (A/B runs).
+  static const int rows_mode = [] {
     const char* e = std::getenv("CT2X_H_ROWS256");
-    return e == nullptr || e[0] != '0';
+    return e == nullptr ? 2 : std::atoi(e);
   }();
-  if (rows256 && M > 128 && M <= 256 && K % 32 == 0 && K >= 256 &&
+  static const int rows_target = [] {
+    const char* e = std::getenv("CT2X_H_ROWS_TARGET");
+    return e == nullptr ? 256 : std::atoi(e);
+  }();
+  if (rows_mode != 0 && M > 128 && M <= 256 && K % 32 == 0 && K >= 256 &&
       ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
     const int col_tiles = (N + R256_BN - 1) / R256_BN;
+    const int row_tiles = rows_mode == 1 ? 1 : (M + 127) / 128;
+    const int target = rows_mode == 1 ? 192 : rows_target;
     int splits = 1;
-    if (splitk_ws != nullptr)  // enough workgroups for three quarters of the chip, at least eight stages each
-      while (col_tiles * splits < 192 && splits < 16 && K / (splits * 2) >= 256 && (K / (splits * 2)) % 32 == 0 &&
+    if (splitk_ws != nullptr)  // at least eight stages per workgroup
+      while (col_tiles * row_tiles * splits < target && splits < 16 && K / (splits * 2) >= 256 &&
+             (K / (splits * 2)) % 32 == 0 &&
              static_cast<size_t>(splits) * 2 * M * N <= splitk_floats)  // (splits * 2 slices after the doubling)
         splits *= 2;
-    const size_t lds = 2 * ((kBF16 ? 1 : 2) * 16 * 1024 + 8 * 1024);
-    allow_big_lds(reinterpret_cast<const void*>(gemm_h_rows256_kernel<kBF16>), lds);
-    hipLaunchKernelGGL((gemm_h_rows256_kernel<kBF16>), dim3(col_tiles, 1, splits), dim3(512), lds, stream, a, w, M, N,
-                       K, ep, K / splits, splits > 1 ? splitk_ws : static_cast<float*>(nullptr));
+    float* part = splits > 1 ? splitk_ws : static_cast<float*>(nullptr);
+    if (row_tiles == 1) {
+      const size_t lds = 2 * ((kBF16 ? 1 : 2) * 16 * 1024 + 8 * 1024);
+      allow_big_lds(reinterpret_cast<const void*>(gemm_h_rows256_kernel<kBF16, 256>), lds);
+      hipLaunchKernelGGL((gemm_h_rows256_kernel<kBF16, 256>), dim3(col_tiles, 1, splits), dim3(512), lds, stream,
+                         a, w, M, N, K, ep, K / splits, part);
+    } else {
+      const size_t lds = 2 * ((kBF16 ? 1 : 2) * 8 * 1024 + 8 * 1024);
+      hipLaunchKernelGGL((gemm_h_rows256_kernel<kBF16, 128>), dim3(col_tiles, row_tiles, splits), dim3(512), lds,
+                         stream, a, w, M, N, K, ep, K / splits, part);
+    }
     if (splits > 1) launch_splitk_reduce(splitk_ws, splits, N, static_cast<int64_t>(M) * N, ep, stream);
     return;
   }

@@ -125,6 +125,38 @@ chain)            # the ordered chains (norm statistics, exp sums) as two batche
   { for i in 1 2; do echo "== --beam 4"; timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
     echo "== greedy"; timeout 300 python bench.py --steps 10 --warmup 2 $NOLEGS 2>&1 | tail -1 | line
   } 2>&1 | tee $O/chain_bench.txt ;;
+leg_stats)        # rocprofv3 kernel stats of the legs: profiles/r06_final_kernel_stats_bench_{l8,nllb,whisper,tb_beam4}.csv
+  show() { python - "$1" <<'PY'
+import csv, sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:14]:
+    print(r['Name'][:105].ljust(105), r['Calls'].rjust(6), str(round(float(r['AverageNs']) / 1e3, 2)).rjust(8), r['Percentage'])
+PY
+  }
+  for leg in ${LEGS:-nllb whisper beam4 l8}; do
+    case $leg in
+      nllb)    cmd="tools/bench_nllb.py --steps 1 --warmup 1" ;;
+      whisper) cmd="tools/bench_whisper.py --steps 1 --warmup 1" ;;
+      l8)      cmd="tools/bench_l8.py --steps 1 --warmup 1 --no-profile" ;;
+      beam4)   cmd="bench.py --beam 4 --steps 5 --warmup 2 $NOLEGS --no-token-check" ;;
+    esac
+    rm -rf /tmp/prof_$leg
+    ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$leg -- python $GRAFT_REPO_ROOT/$cmd > /tmp/prof_$leg.log 2>&1 )
+    f=$(find /tmp/prof_$leg -name '*kernel_stats.csv' | head -1)
+    echo "== $leg"; tail -1 /tmp/prof_$leg.log | cut -c1-200
+    [ -n "$f" ] && cp "$f" $O/final_kernel_stats_bench_$leg.csv && show $O/final_kernel_stats_bench_$leg.csv
+  done ;;
+awq_bench)        # decode-row AWQ launches, both 16-bit arms
+  { timeout 300 python tools/awq_bench.py 16; timeout 300 python tools/awq_bench.py 16 bf16; } 2>&1 | grep "^awq" | tee $O/awq_bench.txt ;;
+rows128)          # the 128-row form of the 129 .. 256-row 16-bit GEMM: tests (both forms), launches, NLLB leg
+  timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -k "gemm_half" 2>&1 | tail -2 | tee $O/rows128_tests.txt
+  CT2X_H_ROWS256=1 timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -k "gemm_half" 2>&1 | tail -2 | tee -a $O/rows128_tests.txt
+  timeout 900 python -m pytest tests/test_translator_gpu.py -x -q -k "nllb or half" 2>&1 | tail -2 | tee -a $O/rows128_tests.txt
+  SH="256:2048:2048 256:6144:2048 256:8192:2048 256:2048:8192"
+  { for cfg in "CT2X_H_ROWS256=1" "CT2X_H_ROWS256=2" "CT2X_H_ROWS256=2 CT2X_H_ROWS_TARGET=512" "CT2X_H_ROWS256=2 CT2X_H_ROWS_TARGET=128"; do
+      echo "== $cfg"; env $cfg timeout 300 python tools/gemm_h_bench.py ${KIND:-f16} $SH 2>&1 | grep "per launch"; done
+    echo "== bf16, CT2X_H_ROWS256=1 then 2"; for m in 1 2; do CT2X_H_ROWS256=$m timeout 300 python tools/gemm_h_bench.py bf16 $SH 2>&1 | grep "per launch"; done
+  } 2>&1 | tee $O/rows128_bench.txt
+  { for cfg in "CT2X_H_ROWS256=1" "CT2X_H_ROWS256=2" "CT2X_H_ROWS256=2 CT2X_H_ROWS_TARGET=512" "CT2X_H_ROWS256=1" "CT2X_H_ROWS256=2"; do echo "== $cfg"; env $cfg timeout 600 python tools/bench_nllb.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'tok/s', d['config'].get('decode_ms_per_step'), 'ms/step', d['config'].get('kernels_per_decode_step'))"; done; } 2>&1 | tee $O/rows128_ab.txt ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
