@@ -7,6 +7,7 @@
 #include "kernels.h"
 #include "runtime.h"
 
+#include <cstdlib>
 #include <algorithm>
 #include <float.h>
 #include <limits.h>
@@ -795,6 +796,38 @@ __device__ __forceinline__ float wave_max_any(float v) {
   return v;
 }
 
+// f(j, x[j]) for every element of a row, each thread taking 8-byte pieces sixteen at a time (a
+// 1 MB row scanned by ONE workgroup is bound by what it keeps in flight: 4-byte loads a few deep
+// read 2.4 TB/s over 256 rows). Rows of the 256 206-word vocabulary start 8 bytes off a 16-byte
+// boundary every other row, so 8-byte pieces are what every row allows.
+template <typename F>
+__device__ __forceinline__ void row_scan(const float* __restrict__ x, int64_t vocab, F&& f) {
+  int64_t done = 0;
+  if ((reinterpret_cast<uintptr_t>(x) & 7) == 0) {
+    const int64_t n2 = vocab / 2;
+    const float2* x2 = reinterpret_cast<const float2*>(x);
+    constexpr int U = 16;
+    for (int64_t i = threadIdx.x; i < n2; i += static_cast<int64_t>(blockDim.x) * U) {
+      float2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t idx = i + static_cast<int64_t>(u) * blockDim.x;
+        v[u] = idx < n2 ? x2[idx] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t idx = i + static_cast<int64_t>(u) * blockDim.x;
+        if (idx < n2) {
+          f(2 * idx, v[u].x);
+          f(2 * idx + 1, v[u].y);
+        }
+      }
+    }
+    done = 2 * n2;
+  }
+  for (int64_t j = done + threadIdx.x; j < vocab; j += blockDim.x) f(j, x[j]);
+}
+
 __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
                                      const float* __restrict__ beam_scores, int64_t vocab,
                                      int32_t disable_id, int32_t min_length,
@@ -1020,16 +1053,22 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
     return;
   }
   float m = -FLT_MAX;
-  for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
-    m = fmaxf(m, (j == masked) ? -FLT_MAX : x[j]);
+  if (fast) {
+    row_scan(x, vocab, [&](int64_t j, float xj) { m = fmaxf(m, (j == masked) ? -FLT_MAX : xj); });
+  } else {
+    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
+      m = fmaxf(m, (j == masked) ? -FLT_MAX : x[j]);
+  }
+  const float thread_max = m;  // (the fused candidates' bound, below)
   m = block_max(m, scratch);
   if (fast) {
     // 16-bit compute types (no CPU counterpart to reproduce bit for bit): a parallel sum instead of
     // the reference's eight dependent chains - 32 000 sequential adds per row of a 256 206-word
     // vocabulary cost 4.8 ms per beam step of the NLLB shape (profiles/r03_nllb_kernel_stats_b.csv)
     float part = 0.f;
-    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x)
-      if (j != masked) part += __expf(x[j] - m);
+    row_scan(x, vocab, [&](int64_t j, float xj) {
+      if (j != masked) part += __expf(xj - m);
+    });
     part = wave_sum(part);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = part;
@@ -1038,10 +1077,140 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
     for (int w = 0; w < static_cast<int>((blockDim.x + 63) >> 6); ++w) tot += scratch[w];
     const float c = -m - logf(tot);
     const float b = beam_scores ? beam_scores[row] : 0.f;
-    for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {
-      const float v = ((j == masked) ? -FLT_MAX : x[j]) + c;
-      yr[j] = beam_scores ? b + v : v;
+    if (part_v != nullptr) {
+      // Round 6 (second half): the candidates of the register form above for rows of ANY length
+      // (the 256 206-word vocabulary of the NLLB shape): the row is read a third time instead of
+      // being written as 1 MB of log-probabilities that TopK's partial pass reads back (441 + 156 +
+      // 12 us per step there). Same values y = b + (x + c) and the same total order as topk_partial /
+      // topk_merge (value descending, flat index ascending). The bound: the topk-th largest of the
+      // waves' maxima has topk elements of the row at or above it; it is applied to y, which is
+      // monotone in x, so elements whose y collapses onto the bound's by rounding are listed too.
+      const float ninf = -__builtin_huge_valf();
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int nwaves = (blockDim.x + 63) >> 6;
+      const int flat_row = static_cast<int>((row % beam) * vocab);
+      auto score_of = [&](int64_t j, float xj) {
+        const float v = ((j == masked) ? -FLT_MAX : xj) + c;
+        return beam_scores ? b + v : v;
+      };
+      auto score = [&](int64_t j) { return score_of(j, x[j]); };
+      const float wmax = wave_max_any(thread_max);
+      __syncthreads();  // (scratch held the waves' sums)
+      if (lane == 0) scratch[wave] = wmax;
+      if (threadIdx.x == 0) cand_count = 0;
+      __syncthreads();
+      float bound_x = ninf;
+      {
+        float wm = lane < nwaves ? scratch[lane] : ninf;
+        for (int r = 0; r < topk; ++r) {
+          bound_x = wave_max_any(wm);
+          const unsigned long long holders = __builtin_amdgcn_ballot_w64(wm == bound_x);
+          if (holders != 0 && lane == __builtin_ctzll(holders)) wm = ninf;
+        }
+      }
+      const bool bounded = nwaves >= topk && bound_x > -FLT_MAX;
+      if (bounded) {
+        const float vb = bound_x + c;
+        const float y_bound = beam_scores ? b + vb : vb;
+        row_scan(x, vocab, [&](int64_t j, float xj) {
+          const float y = score_of(j, xj);
+          if (y >= y_bound) {
+            const int pos = atomicAdd(&cand_count, 1);
+            if (pos < kBeamCandCap) {
+              cand_v[pos] = y;
+              cand_i[pos] = flat_row + static_cast<int>(j);
+            }
+          }
+        });
+      }
+      __syncthreads();
+      const int n = cand_count;
+      if (bounded && n <= kBeamCandCap) {
+        if (wave == 0) {
+          constexpr int PER = kBeamCandCap / 64;
+          float lv[PER];
+          int li[PER];
+#pragma unroll
+          for (int e = 0; e < PER; ++e) {
+            const int at = lane + e * 64;
+            li[e] = at < n ? cand_i[at] : INT_MAX;
+            lv[e] = at < n ? cand_v[at] : ninf;
+          }
+          for (int r = 0; r < topk; ++r) {
+            ValIdx best;
+            best.v = ninf;
+            best.i = INT_MAX;
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+              if (li[e] != INT_MAX && (best.i == INT_MAX || lv[e] > best.v || (lv[e] == best.v && li[e] < best.i))) {
+                best.v = lv[e];
+                best.i = li[e];
+              }
+            if (best.i == INT_MAX) best.v = ninf;
+            const ValIdx w = wave_argmax_dpp(best);
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+              if (li[e] == w.i) {
+                li[e] = INT_MAX;
+                lv[e] = ninf;
+              }
+            if (lane == 0) {
+              part_v[row * topk + r] = w.v;
+              part_i[row * topk + r] = w.i;
+            }
+          }
+        }
+        return;
+      }
+      // (no bound - fewer waves than candidates - or more ties at it than the list holds: topk
+      // rounds of a block-wide arg-max over the row; the winners so far sit in cand_i[0 .. r))
+      for (int r = 0; r < topk; ++r) {
+        ValIdx best;
+        best.v = ninf;
+        best.i = INT_MAX;
+        for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {  // (ascending index: strict compare)
+          const int fi = flat_row + static_cast<int>(j);
+          bool taken = false;
+          for (int q = 0; q < r; ++q) taken = taken || (cand_i[q] == fi);
+          if (taken) continue;
+          const float y = score(j);
+          if (best.i == INT_MAX || y > best.v) {
+            best.v = y;
+            best.i = fi;
+          }
+        }
+        if (best.i == INT_MAX) best.v = ninf;
+        best = wave_argmax_dpp(best);
+        __syncthreads();
+        if (lane == 0) {
+          scratch[wave] = best.v;
+          scratch_i[wave] = best.i;
+        }
+        __syncthreads();
+        ValIdx w;
+        w.v = scratch[0];
+        w.i = scratch_i[0];
+        for (int q = 1; q < nwaves; ++q) {
+          const float v = scratch[q];
+          const int i = scratch_i[q];
+          if (i != INT_MAX && (w.i == INT_MAX || v > w.v || (v == w.v && i < w.i))) {
+            w.v = v;
+            w.i = i;
+          }
+        }
+        if (threadIdx.x == 0) {
+          cand_i[r] = w.i;
+          part_v[row * topk + r] = w.v;
+          part_i[row * topk + r] = w.i;
+        }
+        __syncthreads();
+      }
+      return;
     }
+    row_scan(x, vocab, [&](int64_t j, float xj) {
+      const float v = ((j == masked) ? -FLT_MAX : xj) + c;
+      yr[j] = beam_scores ? b + v : v;
+    });
     return;
   }
   // the reference's LogSoftMax bit for bit: exp polynomial, sum order, libm logf (the output row
@@ -1069,7 +1238,7 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
   while (block < vocab / 4 && block < 1024) block <<= 1;
   CT2X_CHECK(part_v == nullptr || (beam_logprobs_topk_applicable(vocab, exact, beam > 0 ? beam : 1, topk) &&
                                    !(bias_beta > 0.f)),
-             "beam_logprobs: the fused candidates need the exact one-read form");
+             "beam_logprobs: the fused candidates need the exact one-read form or the parallel-sum form");
   const BeamBias bias{bias_beta > 0.f ? bias_ids : nullptr, bias_lens, bias_stride, bias_first_step,
                       bias_beta, diverged};
   const ExpSumLayout el = exp_sum_layout(vocab);
@@ -1086,8 +1255,16 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
 bool beam_logprobs_topk_applicable(int64_t vocab, bool exact, int32_t beam, int32_t topk) {
   int block = 64;
   while (block < vocab / 4 && block < 1024) block <<= 1;
-  return exact && exp_sum_layout(vocab).chain_pad > 0 && vocab <= 32 * static_cast<int64_t>(block) &&
-         topk >= 1 && static_cast<int64_t>(beam) * topk <= 64 && static_cast<int64_t>(beam) * vocab < INT_MAX;
+  if (!(topk >= 1 && topk <= kBeamCandCap && static_cast<int64_t>(beam) * topk <= 64 &&
+        static_cast<int64_t>(beam) * vocab < INT_MAX))
+    return false;
+  // 16-bit compute types (the parallel-sum form, any row length: the row is re-read, round 6)
+  static const bool fast_fused = [] {
+    const char* e = std::getenv("CT2X_BEAM_FUSED_FAST");
+    return e == nullptr || e[0] != '0';
+  }();
+  if (!exact) return fast_fused;
+  return exp_sum_layout(vocab).chain_pad > 0 && vocab <= 32 * static_cast<int64_t>(block);
 }
 
 // ---------------------------------------------------------------------------------------------

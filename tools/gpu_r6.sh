@@ -157,6 +157,12 @@ rows128)          # the 128-row form of the 129 .. 256-row 16-bit GEMM: tests (b
     echo "== bf16, CT2X_H_ROWS256=1 then 2"; for m in 1 2; do CT2X_H_ROWS256=$m timeout 300 python tools/gemm_h_bench.py bf16 $SH 2>&1 | grep "per launch"; done
   } 2>&1 | tee $O/rows128_bench.txt
   { for cfg in "CT2X_H_ROWS256=1" "CT2X_H_ROWS256=2" "CT2X_H_ROWS256=2 CT2X_H_ROWS_TARGET=512" "CT2X_H_ROWS256=1" "CT2X_H_ROWS256=2"; do echo "== $cfg"; env $cfg timeout 600 python tools/bench_nllb.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'tok/s', d['config'].get('decode_ms_per_step'), 'ms/step', d['config'].get('kernels_per_decode_step'))"; done; } 2>&1 | tee $O/rows128_ab.txt ;;
+beam_fast)        # 16-bit beam search: candidates instead of rows (CT2X_BEAM_FUSED_FAST): A/B test, NLLB + Whisper legs
+  timeout 1200 python -m pytest tests/test_beam_fused_fast_gpu.py -x -q 2>&1 | tail -3 | tee $O/beam_fast_tests.txt
+  timeout 1200 python -m pytest tests/test_translator_gpu.py tests/test_whisper_gpu.py -x -q -k "half or nllb or float16 or bfloat16 or beam" 2>&1 | tail -3 | tee -a $O/beam_fast_tests.txt
+  { for f in 0 1 0 1; do echo "== nllb CT2X_BEAM_FUSED_FAST=$f"; CT2X_BEAM_FUSED_FAST=$f timeout 600 python tools/bench_nllb.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'tok/s', d['config'].get('decode_ms_per_step'), 'ms/step', d['config'].get('kernels_per_decode_step'))"; done
+    for f in 0 1; do echo "== whisper CT2X_BEAM_FUSED_FAST=$f"; CT2X_BEAM_FUSED_FAST=$f timeout 600 python tools/bench_whisper.py --steps 2 --warmup 1 2>&1 | tail -1 | cut -c1-260; done
+  } 2>&1 | tee $O/beam_fast_ab.txt ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
