@@ -1023,6 +1023,21 @@ void launch_typed(const float* a, const uint16_t* w, int M, int N, int K, const 
     if (splits > 1) launch_splitk_reduce(splitk_ws, splits, N, static_cast<int64_t>(M) * N, ep, stream);
     return;
   }
+  // More than 256 rows (sequence mode: the Whisper encoder's 12000): the same 128-row stage machinery,
+  // no K slices - two workgroups per CU interleave their phases where the 128 x 128 form below keeps
+  // one stage of register prefetch and two barriers per stage. CT2X_H_ROWS128_BIG=0 keeps that form.
+  static const bool rows128_big = [] {
+    const char* e = std::getenv("CT2X_H_ROWS128_BIG");
+    return e == nullptr || e[0] != '0';
+  }();
+  if (rows128_big && M > 256 && K % 32 == 0 && K >= 256 && (M + 127) / 128 <= 65535 &&
+      static_cast<int64_t>((N + 127) / 128) * ((M + 127) / 128) >= 256 &&
+      ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+    const size_t lds = 2 * ((kBF16 ? 1 : 2) * 8 * 1024 + 8 * 1024);
+    hipLaunchKernelGGL((gemm_h_rows256_kernel<kBF16, 128>), dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(512),
+                       lds, stream, a, w, M, N, K, ep, K, static_cast<float*>(nullptr));
+    return;
+  }
   const int tiles = ((N + 127) / 128) * ((M + 127) / 128);
   int splits = 1;
   if (splitk_ws != nullptr) {

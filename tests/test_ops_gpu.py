@@ -474,7 +474,10 @@ def _from_bf16_bits(b):
                                    # x a K slice per workgroup - 4 / 16 / 8 / 4 slices, ragged rows and
                                    # columns, and the single-slice epilogue
                                    (256, 8192, 2048), (256, 2048, 8192), (200, 2048, 2048), (129, 1000, 2048),
-                                   (256, 6144, 2048), (250, 640, 256), (256, 33000, 512)])
+                                   (256, 6144, 2048), (250, 640, 256), (256, 33000, 512),
+                                   # more than 256 rows on the 128-row stage machinery (sequence mode:
+                                   # at least 256 tiles), ragged rows and columns
+                                   (4000, 1280, 640), (3001, 1500, 512)])
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("act,with_res", [(-1, True), (0, False)])
 def test_gemm_half_weights(gpu, m, n, k, bf16, act, with_res):

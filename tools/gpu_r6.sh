@@ -163,6 +163,15 @@ beam_fast)        # 16-bit beam search: candidates instead of rows (CT2X_BEAM_FU
   { for f in 0 1 0 1; do echo "== nllb CT2X_BEAM_FUSED_FAST=$f"; CT2X_BEAM_FUSED_FAST=$f timeout 600 python tools/bench_nllb.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'tok/s', d['config'].get('decode_ms_per_step'), 'ms/step', d['config'].get('kernels_per_decode_step'))"; done
     for f in 0 1; do echo "== whisper CT2X_BEAM_FUSED_FAST=$f"; CT2X_BEAM_FUSED_FAST=$f timeout 600 python tools/bench_whisper.py --steps 2 --warmup 1 2>&1 | tail -1 | cut -c1-260; done
   } 2>&1 | tee $O/beam_fast_ab.txt ;;
+rows128_big)      # more than 256 rows on the 128-row form (CT2X_H_ROWS128_BIG): tests, launches, Whisper leg
+  timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -k "gemm_half" 2>&1 | tail -2 | tee $O/rows128_big_tests.txt
+  timeout 900 python -m pytest tests/test_whisper_gpu.py tests/test_translator_gpu.py -x -q -k "half or float16 or bfloat16 or nllb or whisper" 2>&1 | tail -2 | tee -a $O/rows128_big_tests.txt
+  SH="12000:1280:1280 12000:3840:1280 12000:5120:1280 12000:1280:5120 2048:8192:2048 2048:2048:8192"
+  { for f in 0 1; do for kind in bf16 f16; do echo "== CT2X_H_ROWS128_BIG=$f $kind"; CT2X_H_ROWS128_BIG=$f timeout 300 python tools/gemm_h_bench.py $kind $SH 2>&1 | grep "per launch"; done; done
+  } 2>&1 | tee $O/rows128_big_bench.txt
+  { for f in 0 1 0 1; do echo "== whisper CT2X_H_ROWS128_BIG=$f"; CT2X_H_ROWS128_BIG=$f timeout 600 python tools/bench_whisper.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(round(d['value'],1), 'tok/s', {k: (round(v,2) if isinstance(v,float) else v) for k,v in c.items() if 'ms' in k})"; done
+    for f in 0 1; do echo "== nllb CT2X_H_ROWS128_BIG=$f"; CT2X_H_ROWS128_BIG=$f timeout 600 python tools/bench_nllb.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'tok/s', d['config'].get('decode_ms_per_step'), 'ms/step', d['ms_per_step'])"; done
+  } 2>&1 | tee $O/rows128_big_ab.txt ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
