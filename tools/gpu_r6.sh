@@ -172,6 +172,13 @@ rows128_big)      # more than 256 rows on the 128-row form (CT2X_H_ROWS128_BIG):
   { for f in 0 1 0 1; do echo "== whisper CT2X_H_ROWS128_BIG=$f"; CT2X_H_ROWS128_BIG=$f timeout 600 python tools/bench_whisper.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(round(d['value'],1), 'tok/s', {k: (round(v,2) if isinstance(v,float) else v) for k,v in c.items() if 'ms' in k})"; done
     for f in 0 1; do echo "== nllb CT2X_H_ROWS128_BIG=$f"; CT2X_H_ROWS128_BIG=$f timeout 600 python tools/bench_nllb.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'tok/s', d['config'].get('decode_ms_per_step'), 'ms/step', d['ms_per_step'])"; done
   } 2>&1 | tee $O/rows128_big_ab.txt ;;
+pmc)              # profiles/r06_pmc_traffic.json: memory-side bytes per launch of the headline leg's kernels
+  timeout 600 python tools/pmc_bench.py $O/pmc > $O/pmc_traffic.json; head -30 $O/pmc_traffic.json; find $O/pmc -name "*.csv" -size +1M -delete; find $O/pmc -name "*.db" -delete ;;
+final)            # the round's closing evidence in one call: bench line, kernel trace of the headline leg, leg stats, PMC traffic
+  bash tools/gpu_r6.sh bench_full
+  bash tools/gpu_r6.sh trace_gaps
+  LEGS="l8 nllb whisper beam4" bash tools/gpu_r6.sh leg_stats > $O/leg_stats.txt 2>&1; tail -70 $O/leg_stats.txt | cut -c1-150
+  bash tools/gpu_r6.sh pmc ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
