@@ -828,6 +828,11 @@ __device__ __forceinline__ void row_scan(const float* __restrict__ x, int64_t vo
   for (int64_t j = done + threadIdx.x; j < vocab; j += blockDim.x) f(j, x[j]);
 }
 
+// CAND: the candidate form (part_v != nullptr) as an instantiation of its own - its row registers
+// die after the exps (round 6, last change: with both forms in one kernel the 32 row registers
+// lived across the 4000-step chain, 47 of them in scratch memory, and the candidate listing that
+// followed reloaded them one dependent scratch round trip at a time: 11 us of a 54 us launch).
+template <bool CAND>
 __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
                                      const float* __restrict__ beam_scores, int64_t vocab,
                                      int32_t disable_id, int32_t min_length,
@@ -841,6 +846,7 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
   __shared__ float cand_v[kBeamCandCap];
   __shared__ int cand_i[kBeamCandCap];
   __shared__ int cand_count;
+  __shared__ float wave_max_s[16];
   const int64_t row = blockIdx.x;
   const int step = *step_ptr;
   // apply_min_length with a hidden prefix (src/decoding.cc:384-408): EOS stays disabled
@@ -887,7 +893,54 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
     float m = -FLT_MAX;
 #pragma unroll
     for (int u = 0; u < XR; ++u) m = fmaxf(m, xv[u]);
+    const float thread_max_x = m;
     m = block_max(m, scratch);
+    const float b = beam_scores ? beam_scores[row] : 0.f;
+    bool listed = false;
+    if (CAND) {
+      // The candidates are listed HERE, by x, while the row is in registers anyway: y = b + (x + c)
+      // is monotone in x, so the row's top k by y are among the elements at or above the topk-th
+      // largest of the waves' maxima (topk elements of the row sit at or above it, one per wave) -
+      // lowered by a margin that covers every x the two roundings of y can collapse onto the
+      // bound's y (c = -m - log(sum), sum in [1, vocab], is not known yet: |c| <= |m| + 17). The
+      // list keeps x; wave 0 forms y once c is known and picks the exact order (value descending,
+      // flat index ascending) - what topk_partial / topk_merge would return over the written row.
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int nwaves = (blockDim.x + 63) >> 6;
+      const float wm_own = wave_max_any(thread_max_x);
+      if (lane == 0) wave_max_s[wave] = wm_own;
+      if (threadIdx.x == 0) cand_count = 0;
+      __syncthreads();
+      if (nwaves >= topk) {
+        // rank of each wave's maximum among the waves' maxima (ties by wave index): no rounds
+        const float mine = lane < nwaves ? wave_max_s[lane] : -__builtin_huge_valf();
+        int rank = 0;
+        for (int q = 0; q < nwaves; ++q) {
+          const float o = wave_max_s[q];
+          rank += (o > mine || (o == mine && q < lane)) ? 1 : 0;
+        }
+        const unsigned long long holder = __builtin_amdgcn_ballot_w64(lane < nwaves && rank == topk - 1);
+        const float bound_x = __uint_as_float(static_cast<unsigned>(
+            __builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(mine)), __builtin_ctzll(holder))));
+        if (bound_x > -FLT_MAX) {
+          const float mag = fabsf(b) + fabsf(bound_x) + fabsf(m) + 17.f;
+          const float thr = bound_x - mag * 9.5367431640625e-07f;  // 8 ulps at that magnitude (2^-20)
+          const int flat0 = static_cast<int>((row % beam) * vocab) + static_cast<int>(threadIdx.x);
+#pragma unroll
+          for (int u = 0; u < XR; ++u) {
+            const int64_t j = threadIdx.x + static_cast<int64_t>(u) * blockDim.x;
+            if (j < vocab && xv[u] >= thr) {
+              const int pos = atomicAdd(&cand_count, 1);
+              if (pos < kBeamCandCap) {
+                cand_v[pos] = xv[u];
+                cand_i[pos] = flat0 + u * static_cast<int>(blockDim.x);
+              }
+            }
+          }
+          listed = true;
+        }
+      }
+    }
     const int64_t vsize = vocab > 8 ? vocab - vocab % 8 : 0;
     float* tail = exp_lds + 8 * chain_pad;
 #pragma unroll
@@ -908,64 +961,16 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
     }
     __syncthreads();
     const float c = -m - logf_glibc(scratch[0]);
-    const float b = beam_scores ? beam_scores[row] : 0.f;
-    if (part_v != nullptr) {
-      // Round 6: the row's 2 * beam best scores leave as CANDIDATES instead of the row (TopK over
-      // [beam * vocab] of a batch entry, src/decoding.cc:559-563: every member of the entry's top k
-      // is in the top k of its own row): same values y = b + (x + c), same total order (value
-      // descending, flat index ascending) as topk_partial / topk_merge - the 16 MB row-wide write
-      // and its two re-reads disappear. The merge over the entry's rows rides in beam_select_kernel.
+    if (CAND) {
       const float ninf = -__builtin_huge_valf();
-      unsigned alive = 0;
-#pragma unroll
-      for (int u = 0; u < XR; ++u) {
-        const int64_t j = threadIdx.x + static_cast<int64_t>(u) * blockDim.x;
-        if (j < vocab) {
-          const float v = xv[u] + c;
-          xv[u] = beam_scores ? b + v : v;
-          alive |= 1u << u;
-        }
-      }
-      const int flat0 = static_cast<int>((row % beam) * vocab) + static_cast<int>(threadIdx.x);
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       const int nwaves = (blockDim.x + 63) >> 6;
-      // (1) a bound: the topk-th largest of the waves' maxima has topk elements of the row at or
-      // above it (one per wave), so nothing below it is in the row's top k. (2) the few elements
-      // at or above the bound are listed in LDS. (3) one wave picks the top k of the list in the
-      // exact order. A first form - topk rounds of block arg-max over the 32 registers of all 1024
-      // threads - cost as much as the launches it replaced (profiles/r06_beam_fused_ab.txt).
-      float tmax = ninf;
-#pragma unroll
-      for (int u = 0; u < XR; ++u)
-        if ((alive >> u) & 1u) tmax = fmaxf(tmax, xv[u]);
-      tmax = wave_max_any(tmax);
-      __syncthreads();  // (scratch held the row sum)
-      if (lane == 0) scratch[wave] = tmax;
-      if (threadIdx.x == 0) cand_count = 0;
-      __syncthreads();
-      float bound = ninf;
-      {
-        float wm = lane < nwaves ? scratch[lane] : ninf;
-        for (int r = 0; r < topk; ++r) {
-          bound = wave_max_any(wm);
-          // retire ONE lane that holds the maximum (the lowest)
-          const unsigned long long holders = __builtin_amdgcn_ballot_w64(wm == bound);
-          if (holders != 0 && lane == __builtin_ctzll(holders)) wm = ninf;
-        }
-        if (nwaves < topk) bound = ninf;
-      }
-#pragma unroll
-      for (int u = 0; u < XR; ++u)
-        if (((alive >> u) & 1u) && xv[u] >= bound) {
-          const int pos = atomicAdd(&cand_count, 1);
-          if (pos < kBeamCandCap) {
-            cand_v[pos] = xv[u];
-            cand_i[pos] = flat0 + u * static_cast<int>(blockDim.x);
-          }
-        }
-      __syncthreads();
-      const int n = cand_count;
-      if (n <= kBeamCandCap) {
+      const int n = cand_count;  // (written before the exps: two barriers ago)
+      auto score_of = [&](float xj) {
+        const float v = xj + c;
+        return beam_scores ? b + v : v;
+      };
+      if (listed && n <= kBeamCandCap) {
         if (wave == 0) {
           constexpr int PER = kBeamCandCap / 64;
           float lv[PER];
@@ -974,7 +979,7 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
           for (int e = 0; e < PER; ++e) {
             const int at = lane + e * 64;
             li[e] = at < n ? cand_i[at] : INT_MAX;
-            lv[e] = at < n ? cand_v[at] : ninf;
+            lv[e] = at < n ? score_of(cand_v[at]) : ninf;
           }
           for (int r = 0; r < topk; ++r) {
             ValIdx best;
@@ -1002,17 +1007,26 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
         }
         return;
       }
-      // (more ties at the bound than the list holds: the plain rounds over the registers)
+      // (no bound - fewer waves than candidates - or more elements near it than the list holds:
+      // topk rounds of a block-wide arg-max over the row, re-read from memory; the winners so far
+      // sit in cand_i[0 .. r))
+      const int flat_row = static_cast<int>((row % beam) * vocab);
+      __syncthreads();
       for (int r = 0; r < topk; ++r) {
         ValIdx best;
         best.v = ninf;
         best.i = INT_MAX;
-#pragma unroll
-        for (int u = 0; u < XR; ++u)  // (ascending index: a strict compare keeps the first of equals)
-          if (((alive >> u) & 1u) && (best.i == INT_MAX || xv[u] > best.v)) {
-            best.v = xv[u];
-            best.i = flat0 + u * static_cast<int>(blockDim.x);
+        for (int64_t j = threadIdx.x; j < vocab; j += blockDim.x) {  // (ascending index: strict compare)
+          const int fi = flat_row + static_cast<int>(j);
+          bool taken = false;
+          for (int q = 0; q < r; ++q) taken = taken || (cand_i[q] == fi);
+          if (taken) continue;
+          const float y = score_of((j == masked) ? -FLT_MAX : x[j]);
+          if (best.i == INT_MAX || y > best.v) {
+            best.v = y;
+            best.i = fi;
           }
+        }
         if (best.i == INT_MAX) best.v = ninf;
         best = wave_argmax_dpp(best);
         __syncthreads();
@@ -1027,18 +1041,17 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
         for (int q = 1; q < nwaves; ++q) {
           const float v = scratch[q];
           const int i = scratch_i[q];
-          if (v > w.v || (v == w.v && i < w.i)) {
+          if (i != INT_MAX && (w.i == INT_MAX || v > w.v || (v == w.v && i < w.i))) {
             w.v = v;
             w.i = i;
           }
         }
-#pragma unroll
-        for (int u = 0; u < XR; ++u)
-          if (flat0 + u * static_cast<int>(blockDim.x) == w.i) alive &= ~(1u << u);  // retired
         if (threadIdx.x == 0) {
+          cand_i[r] = w.i;
           part_v[row * topk + r] = w.v;
           part_i[row * topk + r] = w.i;
         }
+        __syncthreads();
       }
       return;
     }
@@ -1077,7 +1090,7 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
     for (int w = 0; w < static_cast<int>((blockDim.x + 63) >> 6); ++w) tot += scratch[w];
     const float c = -m - logf(tot);
     const float b = beam_scores ? beam_scores[row] : 0.f;
-    if (part_v != nullptr) {
+    if (CAND) {
       // Round 6 (second half): the candidates of the register form above for rows of ANY length
       // (the 256 206-word vocabulary of the NLLB shape): the row is read a third time instead of
       // being written as 1 MB of log-probabilities that TopK's partial pass reads back (441 + 156 +
@@ -1243,10 +1256,16 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
                       bias_beta, diverged};
   const ExpSumLayout el = exp_sum_layout(vocab);
   const size_t lds = static_cast<size_t>(el.lds_floats) * sizeof(float);
-  allow_big_lds(reinterpret_cast<const void*>(beam_logprobs_kernel), lds);
-  hipLaunchKernelGGL(beam_logprobs_kernel, dim3(rows), dim3(block), lds, stream, logits,
-                     beam_scores, vocab, disable_id, min_length, step_ptr, extra_min_per_batch,
-                     beam > 0 ? beam : 1, el.chain_pad, y, exact ? 0 : 1, bias, part_v, part_i, topk);
+  allow_big_lds(part_v != nullptr ? reinterpret_cast<const void*>(beam_logprobs_kernel<true>)
+                                  : reinterpret_cast<const void*>(beam_logprobs_kernel<false>), lds);
+  if (part_v != nullptr)
+    hipLaunchKernelGGL(beam_logprobs_kernel<true>, dim3(rows), dim3(block), lds, stream, logits,
+                       beam_scores, vocab, disable_id, min_length, step_ptr, extra_min_per_batch,
+                       beam > 0 ? beam : 1, el.chain_pad, y, exact ? 0 : 1, bias, part_v, part_i, topk);
+  else
+    hipLaunchKernelGGL(beam_logprobs_kernel<false>, dim3(rows), dim3(block), lds, stream, logits,
+                       beam_scores, vocab, disable_id, min_length, step_ptr, extra_min_per_batch,
+                       beam > 0 ? beam : 1, el.chain_pad, y, exact ? 0 : 1, bias, part_v, part_i, topk);
 }
 
 // The fused candidates exist where beam_logprobs_kernel keeps the row in registers (the exact

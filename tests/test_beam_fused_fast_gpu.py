@@ -37,8 +37,9 @@ print("RESULT" + json.dumps(out))
 """
 
 
-def _run(cfg, fused):
-    env = dict(os.environ, CT2X_BEAM_FUSED_FAST="1" if fused else "0")
+def _run(cfg, fused, switch="CT2X_BEAM_FUSED_FAST"):
+    env = dict(os.environ)
+    env[switch] = "1" if fused else "0"
     r = subprocess.run([sys.executable, "-c", _SCRIPT % {"root": ROOT}, json.dumps(cfg)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -54,4 +55,18 @@ def test_fused_candidates_equal_rows_plus_topk(gpu, vocab, compute_type):
     block-wide rounds."""
     cfg = {"vocab": vocab, "compute_type": compute_type, "beams": [4, 2, 5]}
     a, b = _run(cfg, True), _run(cfg, False)
+    assert a == b
+
+
+@pytest.mark.parametrize("vocab,compute_type", [(32000, "int8"), (32000, "float32"), (300, "int8"),
+                                                (20001, "float32")])
+def test_exact_candidates_equal_rows_plus_topk(gpu, vocab, compute_type):
+    """The exact LogSoftMax's candidate form (int8 / float32 compute: the row in registers, the
+    candidates listed by x BEFORE the ordered exp sum - within a margin below the topk-th largest
+    wave maximum that covers every x the two roundings of y = b + (x + c) can collapse onto the
+    bound's y - and turned into y by one wave once c is known) against the written rows + TopK
+    (CT2X_BEAM_FUSED_TOPK=0): identical hypotheses and scores. 300 words: fewer waves than candidates
+    (block-wide rounds over the re-read row); 20001: a ragged last register."""
+    cfg = {"vocab": vocab, "compute_type": compute_type, "beams": [4, 2, 5]}
+    a, b = _run(cfg, True, "CT2X_BEAM_FUSED_TOPK"), _run(cfg, False, "CT2X_BEAM_FUSED_TOPK")
     assert a == b
