@@ -1476,6 +1476,44 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   }
   const int32_t forward_length = min_len_prompt - 1;
   const int32_t longest_prefix = max_len_prompt - min_len_prompt;
+  // The reference's front-end decodes a batch sorted from the longest to the shortest example
+  // (rebatch_input, src/batch_reader.cc:187-199) and returns the results in the caller's order.
+  // Results do not depend on the order of a batch - except in ONE configuration: a hidden prefix
+  // under beam search with min_length > 0, where apply_min_length disables the end token by the
+  // INDEX of the live entry (see beam_search / beam_logprobs_kernel). There the entries are decoded
+  // in the reference's order: the same std::sort call with the same comparator on the same input
+  // (a batch that is already in non-increasing order is left alone: the reference's own front-end
+  // on top of this entry point has sorted it).
+  std::vector<int32_t> order(batch);
+  std::iota(order.begin(), order.end(), 0);
+  std::vector<int32_t> sorted_ids, sorted_lengths;
+  {
+    static const bool per_entry_min = [] {
+      const char* e = std::getenv("CT2X_HIDDEN_PREFIX_MIN_LENGTH_PER_ENTRY");
+      return e != nullptr && e[0] == '1';
+    }();
+    bool non_increasing = true;
+    for (int32_t b = 1; b < batch; ++b) non_increasing = non_increasing && prompt_lengths[b] <= prompt_lengths[b - 1];
+    if (beam > 1 && longest_prefix > 0 && dopt.min_length > 0 && !per_entry_min && !non_increasing &&
+        !opt.return_alternatives) {
+      std::vector<size_t> example_index(static_cast<size_t>(batch));
+      std::iota(example_index.begin(), example_index.end(), size_t(0));
+      std::sort(example_index.begin(), example_index.end(), [&](size_t i1, size_t i2) {
+        return prompt_lengths[i1] > prompt_lengths[i2];
+      });
+      sorted_ids.resize(static_cast<size_t>(batch) * stride);
+      sorted_lengths.resize(batch);
+      for (int32_t b = 0; b < batch; ++b) {
+        order[b] = static_cast<int32_t>(example_index[b]);
+        sorted_lengths[b] = prompt_lengths[order[b]];
+        std::copy(prompt_ids + static_cast<int64_t>(order[b]) * stride,
+                  prompt_ids + static_cast<int64_t>(order[b]) * stride + prompt_lengths[order[b]],
+                  sorted_ids.begin() + static_cast<int64_t>(b) * stride);
+      }
+      prompt_ids = sorted_ids.data();
+      prompt_lengths = sorted_lengths.data();
+    }
+  }
   const double t0 = now_ms();
   t->last = ct2x_exec_stats{};
   t->last_compactions = 0;
@@ -1552,23 +1590,24 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   const double te2 = now_ms();
   const int32_t max_len = opt.max_decoding_length;
   // outputs [batch, num_hypotheses, max_decoding_length] / [batch, num_hypotheses], as ct2x_translate_batch
-  for (int32_t b = 0; b < batch; ++b)
+  for (int32_t sb = 0; sb < batch; ++sb)
     for (int32_t k = 0; k < nh; ++k) {
+      const int32_t b = order[sb];  // (the caller's index of the entry decoded as entry sb)
       out_lengths[b * nh + k] = 0;
-      if (k >= static_cast<int32_t>(results[b].hypotheses.size())) continue;
-      auto& hyp = results[b].hypotheses[k];
+      if (k >= static_cast<int32_t>(results[sb].hypotheses.size())) continue;
+      auto& hyp = results[sb].hypotheses[k];
       if (!opt.return_end_token)
         while (!hyp.empty() && hyp.back() == end_id) hyp.pop_back();
       const int32_t len = static_cast<int32_t>(hyp.size());
       std::copy(hyp.begin(), hyp.begin() + std::min(len, max_len),
                 out_ids + (static_cast<int64_t>(b) * nh + k) * max_len);
       out_lengths[b * nh + k] = len;
-      if (opt.return_scores && out_scores && k < static_cast<int32_t>(results[b].scores.size()))
-        out_scores[b * nh + k] = results[b].scores[k];
+      if (opt.return_scores && out_scores && k < static_cast<int32_t>(results[sb].scores.size()))
+        out_scores[b * nh + k] = results[sb].scores[k];
       if (opt.logits_out) {
         CT2X_CHECK(opt.logits_counts_out != nullptr && opt.logits_steps > 0,
                    "return_logits_vocab: logits_counts_out and logits_steps are required");
-        write_logits(opt, results[b], (static_cast<int64_t>(b) * nh + k), k, t->engine->vocab_size());
+        write_logits(opt, results[sb], (static_cast<int64_t>(b) * nh + k), k, t->engine->vocab_size());
       }
       if (k == 0) t->last.num_tokens += len;
     }

@@ -838,7 +838,7 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
                                      int32_t disable_id, int32_t min_length,
                                      const int32_t* __restrict__ step_ptr,
                                      const int32_t* __restrict__ extra_min, int32_t beam,
-                                     int chain_pad, float* __restrict__ y, int fast, BeamBias bias,
+                                     int chain_pad, float* __restrict__ y, int flags, BeamBias bias,
                                      float* __restrict__ part_v, int32_t* __restrict__ part_i, int topk) {
   extern __shared__ __attribute__((aligned(16))) float exp_lds[];
   __shared__ float scratch[16];
@@ -850,9 +850,26 @@ __global__ void beam_logprobs_kernel(const float* __restrict__ logits,
   const int64_t row = blockIdx.x;
   const int step = *step_ptr;
   // apply_min_length with a hidden prefix (src/decoding.cc:384-408): EOS stays disabled
-  // prefix_length steps longer for that batch entry
-  const int row_min = min_length + (extra_min ? extra_min[row / beam] : 0);
+  // prefix_length steps longer for that batch entry. The reference adds the entry's end token with
+  // disable_tokens.add(i, end_id), i the index of the live BATCH ENTRY - a row index of the
+  // [entries * beam, vocab] logits once the beams are expanded (every step after the first on
+  // Device::CPU, src/decoding.cc:494): row i < entries is masked by entry i's threshold, the rows
+  // from `entries` on are not masked at all. Reproduced as it is (the goldens of a hidden prefix
+  // under beam search with min_length > 0 need it); flags & 2 = every beam of the entry by the
+  // entry's own threshold (CT2X_HIDDEN_PREFIX_MIN_LENGTH_PER_ENTRY=1).
+  int row_min = min_length;
+  if (extra_min != nullptr) {
+    const int64_t entries = gridDim.x / beam;
+    // (min_length == 0: the rule only ever masks rows inside their own forced prefix steps when the
+    // entries are in the reference's order, longest first - where scores are reset anyway,
+    // update_sample_with_prefix; the per-entry form is the same thing for any order)
+    if ((flags & 2) != 0 || step <= bias.first_step || min_length <= bias.first_step)
+      row_min = min_length + extra_min[row / beam];
+    else
+      row_min = row < entries ? min_length + extra_min[row] : INT_MIN;
+  }
   const int masked = (step < row_min) ? disable_id : -1;
+  const int fast = flags & 1;
   const float* x = logits + row * vocab;
   float* yr = y + row * vocab;
   if (bias.ids != nullptr) {
@@ -1256,16 +1273,23 @@ void launch_beam_logprobs(const float* logits, const float* beam_scores, int64_t
                       bias_beta, diverged};
   const ExpSumLayout el = exp_sum_layout(vocab);
   const size_t lds = static_cast<size_t>(el.lds_floats) * sizeof(float);
+  // (kernel flags: 1 = the parallel-sum LogSoftMax of the 16-bit compute types; 2 = a hidden
+  // prefix's min_length per entry instead of the reference's row rule, see the kernel)
+  static const bool per_entry_min = [] {
+    const char* e = std::getenv("CT2X_HIDDEN_PREFIX_MIN_LENGTH_PER_ENTRY");
+    return e != nullptr && e[0] == '1';
+  }();
+  const int flags = (exact ? 0 : 1) | (per_entry_min ? 2 : 0);
   allow_big_lds(part_v != nullptr ? reinterpret_cast<const void*>(beam_logprobs_kernel<true>)
                                   : reinterpret_cast<const void*>(beam_logprobs_kernel<false>), lds);
   if (part_v != nullptr)
     hipLaunchKernelGGL(beam_logprobs_kernel<true>, dim3(rows), dim3(block), lds, stream, logits,
                        beam_scores, vocab, disable_id, min_length, step_ptr, extra_min_per_batch,
-                       beam > 0 ? beam : 1, el.chain_pad, y, exact ? 0 : 1, bias, part_v, part_i, topk);
+                       beam > 0 ? beam : 1, el.chain_pad, y, flags, bias, part_v, part_i, topk);
   else
     hipLaunchKernelGGL(beam_logprobs_kernel<false>, dim3(rows), dim3(block), lds, stream, logits,
                        beam_scores, vocab, disable_id, min_length, step_ptr, extra_min_per_batch,
-                       beam > 0 ? beam : 1, el.chain_pad, y, exact ? 0 : 1, bias, part_v, part_i, topk);
+                       beam > 0 ? beam : 1, el.chain_pad, y, flags, bias, part_v, part_i, topk);
 }
 
 // The fused candidates exist where beam_logprobs_kernel keeps the row in registers (the exact

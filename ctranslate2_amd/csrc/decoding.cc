@@ -421,6 +421,7 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   int64_t longest_prefix = 0;
   // biased decoding (src/decoding.cc:478-483): the prefix biases the distributions on the device
   // (beam_logprobs_kernel) and constrains nothing - no forced tokens, no effect on the lengths
+  const std::vector<std::vector<int32_t>>* const prefix_ids_in = prefix_ids;
   const bool bias_towards_prefix = prefix_ids && opt.prefix_bias_beta > 0;
   if (bias_towards_prefix) {
     engine.set_beam_prefix(st, *prefix_ids, opt.start_step, !opt.return_prefix, opt.prefix_bias_beta);
@@ -447,7 +448,21 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
   }
 
   const int64_t max_step = opt.max_length + extra * longest_prefix;
-  const int64_t sync_every = std::max<int32_t>(1, opt.sync_every);
+  // A hidden prefix with min_length > 0: the reference disables the end token by BATCH index in the
+  // rows of the expanded logits (apply_min_length, src/decoding.cc:392-402: row i < live entries by
+  // live entry i's threshold, no other row) - which rows are masked depends on how many entries are
+  // still alive AT THAT STEP. beam_logprobs_kernel applies that rule to the session's entries; for
+  // it to see the reference's live entries the loop runs in lock step in this one configuration:
+  // one step per group, nothing launched ahead of the replay, an entry leaves the session at the
+  // step it finishes (as src/decoding.cc:678-694 does). Sessions that cannot be compacted keep every
+  // entry: exact until the first entry finishes.
+  static const bool per_entry_min = [] {
+    const char* e = std::getenv("CT2X_HIDDEN_PREFIX_MIN_LENGTH_PER_ENTRY");
+    return e != nullptr && e[0] == '1';
+  }();
+  const bool row_rule_lockstep = prefix_ids_in != nullptr && !opt.return_prefix && beam > 1 &&
+                                 opt.min_length > 0 && batch > 1 && !per_entry_min;
+  const int64_t sync_every = row_rule_lockstep ? 1 : std::max<int32_t>(1, opt.sync_every);
   int64_t launched = 0, step = 0;
   struct Group { int64_t first, count; int slot; };
   std::vector<Group> inflight;
@@ -490,7 +505,8 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
       if (!launch_group()) break;
       continue;
     }
-    if (!compact_pending && inflight.size() < 2) launch_group();  // keep the device busy while this group is replayed
+    if (!compact_pending && inflight.size() < 2 && !row_rule_lockstep)
+      launch_group();  // keep the device busy while this group is replayed
     const Group g = inflight.front();
     inflight.erase(inflight.begin());
     const int32_t* h_word = nullptr;
@@ -589,6 +605,12 @@ std::vector<DecodingResult> beam_search(Engine& engine, DecodeState& st,
     if (may_compact && !compact_pending && remaining > 0 && st.rows >= compact_min_rows &&
         remaining * 2 <= st.batch)
       compact_pending = true;
+    if (row_rule_lockstep && remaining > 0) {
+      if (engine.beam_compactable(st) && !gather_attention && remaining < st.batch && remaining >= 1)
+        compact_pending = true;
+      else if (inflight.empty() && !compact_pending)
+        launch_group();
+    }
   }
   engine.synchronize();  // drain a speculative group before the state is torn down
   engine.check_cluster(st);

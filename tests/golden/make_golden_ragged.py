@@ -52,16 +52,23 @@ def main():
             # return_prefix = false (hidden prefix; max length counts from its end). min_length = 0
             # on purpose: with a hidden prefix the reference's apply_min_length disables EOS in the
             # flattened rows 0..batch-1 of the [batch * beam, vocab] logits (disable_tokens.add(i,
-            # end_id) with i a BATCH index, src/decoding.cc:392-402), i.e. in the wrong rows - a
-            # quirk this backend does not reproduce (it disables EOS in every beam of the entry).
+            # end_id) with i a BATCH index, src/decoding.cc:392-402), i.e. in the wrong rows.
             rgen, rscores = m.generate_ids(prompts, beam_size=4, max_len=cfg["max_len"],
                                            min_len=0, return_scores=True)
+            # ... and WITH min_length > 0 (round 6): the quirk above is reproduced on the device
+            # (beam_logprobs_kernel: row i < live entries masked by entry i's threshold, the other
+            # rows not at all, from the second step on)
+            qgen, qscores = m.generate_ids(prompts, beam_size=4, max_len=cfg["max_len"],
+                                           min_len=cfg["max_len"] // 2, return_scores=True)
             out[key + suffix] = {"prompts": prompts, "max_len": cfg["max_len"], "runs": runs,
                                  "compute_type": m.compute_type(),
                                  "beam4": {"prompts": eq_prompts, "min_len": cfg["max_len"] // 2,
                                            "generated": gen, "scores": scores.tolist()},
                                  "beam4_ragged": {"min_len": 0, "generated": rgen,
-                                                  "scores": rscores.tolist()}}
+                                                  "scores": rscores.tolist()},
+                                 "beam4_ragged_minlen": {"min_len": cfg["max_len"] // 2,
+                                                         "generated": qgen,
+                                                         "scores": qscores.tolist()}}
             m.close()
     with open(os.path.join(HERE, "ragged_golden.json"), "w") as f:
         json.dump(out, f)

@@ -179,6 +179,9 @@ final)            # the round's closing evidence in one call: bench line, kernel
   bash tools/gpu_r6.sh trace_gaps
   LEGS="l8 nllb whisper beam4" bash tools/gpu_r6.sh leg_stats > $O/leg_stats.txt 2>&1; tail -70 $O/leg_stats.txt | cut -c1-150
   bash tools/gpu_r6.sh pmc ;;
+beam_proj_sweep)  # beam 4: the 128-row vocabulary projection's row tiles per workgroup (tuning build, CT2X_SKINNY_MT)
+  { for mt in 1 2 4 8 1 2 4 8; do echo "== CT2X_SKINNY_MT=$mt --beam 4"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/ctranslate2_amd/libct2_mi355_tuning.so CT2X_SKINNY_MT=$mt timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+  } 2>&1 | tee $O/beam_proj_sweep.txt ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
