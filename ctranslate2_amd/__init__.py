@@ -468,8 +468,12 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                      suppress_sequences_ids: Optional[Sequence[Sequence[int]]] = None,
                      end_token_id: Optional[int] = None, callback=None, num_hypotheses: int = 1,
                      patience: float = 1.0, return_logits_vocab: bool = False,
-                     return_alternatives: bool = False, min_alternative_expansion_prob: float = 0.0):
-        """ctranslate2.Generator.generate_batch on token ids with include_prompt_in_result=False.
+                     return_alternatives: bool = False, min_alternative_expansion_prob: float = 0.0,
+                     include_prompt_in_result: bool = False):
+        """ctranslate2.Generator.generate_batch on token ids (include_prompt_in_result=False unless
+        asked for: the reference's default True decodes the prompt step by step as a RETURNED hard
+        prefix - it counts towards max / min_length and the sequences begin with the prompt, token 0
+        included unless it is the BOS token, src/models/language_model.cc:150-282).
         return_alternatives: the num_hypotheses best FIRST tokens after the prompt, each continued
         independently with the requested search (decode_alternatives, src/decoding.cc:1122-1290);
         as in the reference, max_length / min_length then count from the first PROMPT position, and
@@ -499,6 +503,7 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         opt.end_token_plus_one = 0 if end_token_id is None else int(end_token_id) + 1
         opt.return_alternatives = int(return_alternatives)
         opt.min_alternative_expansion_prob = float(min_alternative_expansion_prob)
+        opt.include_prompt_in_result = int(include_prompt_in_result)
         cb = self._set_callback(opt, callback)
         if return_logits_vocab:
             lbuf, lcnt = self._set_logits(opt, batch, nh,
@@ -509,10 +514,14 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         if cb.error is not None:
             raise cb.error
         extra = ()
+        # "Forward the start token to the output if it is not the special BOS token"
+        # (language_model.cc:262-267)
+        head = [[int(p[0])] if include_prompt_in_result and int(p[0]) != self.bos_id else []
+                for p in prompts]
         if nh == 1 and not return_alternatives:
             if return_logits_vocab:
                 extra = ([lbuf[b, 0, :lcnt[b, 0]].copy() for b in range(batch)],)
-            return ([out[b, 0, :out_len[b, 0]].tolist() for b in range(batch)], scores[:, 0]) + extra
+            return ([head[b] + out[b, 0, :out_len[b, 0]].tolist() for b in range(batch)], scores[:, 0]) + extra
         if return_alternatives:  # (-1: fewer alternatives than num_hypotheses were expanded)
             kept = [[k for k in range(nh) if out_len[b, k] >= 0] for b in range(batch)]
             return ([[out[b, k, :out_len[b, k]].tolist() for k in kept[b]] for b in range(batch)],
@@ -520,7 +529,7 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         kept = [[k for k in range(nh) if out_len[b, k] > 0 or k == 0] for b in range(batch)]
         if return_logits_vocab:
             extra = ([[lbuf[b, k, :lcnt[b, k]].copy() for k in kept[b]] for b in range(batch)],)
-        return ([[out[b, k, :out_len[b, k]].tolist() for k in kept[b]] for b in range(batch)],
+        return ([[head[b] + out[b, k, :out_len[b, k]].tolist() for k in kept[b]] for b in range(batch)],
                 scores) + extra
 
     @staticmethod

@@ -61,7 +61,7 @@ class TranslationOptions(C.Structure):
         ("logits_out", C.POINTER(C.c_float)),
         ("logits_counts_out", C.POINTER(C.c_int32)),
         ("logits_steps", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("include_prompt_in_result", C.c_int32),
     ]
 
 

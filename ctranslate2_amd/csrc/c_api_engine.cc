@@ -1474,8 +1474,14 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
     min_len_prompt = std::min(min_len_prompt, prompt_lengths[b]);
     max_len_prompt = std::max(max_len_prompt, prompt_lengths[b]);
   }
-  const int32_t forward_length = min_len_prompt - 1;
-  const int32_t longest_prefix = max_len_prompt - min_len_prompt;
+  // include_prompt_in_result (the reference's default, language_model.cc:218-238 skipped): nothing
+  // is forwarded in sequence mode; token 0 starts the decoding, the rest of the prompt is a hard
+  // prefix that is part of the result (DecodingOptions::return_prefix stays true).
+  const bool with_prompt = opt.include_prompt_in_result != 0;
+  CT2X_CHECK(!(with_prompt && opt.return_alternatives),
+             "include_prompt_in_result with return_alternatives is not built for the generator in this backend");
+  const int32_t forward_length = with_prompt ? 0 : min_len_prompt - 1;
+  const int32_t longest_prefix = with_prompt ? max_len_prompt - 1 : max_len_prompt - min_len_prompt;
   // The reference's front-end decodes a batch sorted from the longest to the shortest example
   // (rebatch_input, src/batch_reader.cc:187-199) and returns the results in the caller's order.
   // Results do not depend on the order of a batch - except in ONE configuration: a hidden prefix
@@ -1495,7 +1501,7 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
     bool non_increasing = true;
     for (int32_t b = 1; b < batch; ++b) non_increasing = non_increasing && prompt_lengths[b] <= prompt_lengths[b - 1];
     if (beam > 1 && longest_prefix > 0 && dopt.min_length > 0 && !per_entry_min && !non_increasing &&
-        !opt.return_alternatives) {
+        !opt.return_alternatives && !with_prompt) {
       std::vector<size_t> example_index(static_cast<size_t>(batch));
       std::iota(example_index.begin(), example_index.end(), size_t(0));
       std::sort(example_index.begin(), example_index.end(), [&](size_t i1, size_t i2) {
@@ -1579,7 +1585,7 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   t->engine->synchronize();
   const double te1 = now_ms();
   dopt.start_step = forward_length;
-  dopt.return_prefix = false;  // include_prompt_in_result = false
+  dopt.return_prefix = with_prompt;
   DecodeStats ds;
   std::vector<DecodingResult> results =
       beam > 1 ? beam_search(*t->engine, *st, start_ids, end_id, dopt, &ds,

@@ -652,7 +652,16 @@ struct ct2x_translation_options {
   float* logits_out;
   int32_t* logits_counts_out;
   int32_t logits_steps;
-  int32_t reserved1;
+  /* ct2x_generate_batch only - GenerationOptions::include_prompt_in_result (include/ctranslate2/
+   * generation.h:61, the reference's default; DecoderReplica::run_generation,
+   * src/models/language_model.cc:150-282): non-zero = no sequence-mode pass over the prompt; the
+   * first prompt token starts the decoding, the rest of the prompt is a hard decoding prefix that
+   * is RETURNED (return_prefix: it counts towards max / min_decoding_length, forced tokens score 0,
+   * the step callback sees them). The returned sequences then begin with prompt token 1; putting
+   * token 0 in front of them when it is not the BOS token (language_model.cc:262-267) is the
+   * caller's side (include/ct2_mi355.hpp, the Level 1.5 replica). Not with return_alternatives.
+   * 0 = the prompt is consumed by one sequence-mode pass and not returned. */
+  int32_t include_prompt_in_result;
 };
 
 void ct2x_translation_options_default(struct ct2x_translation_options* opt);

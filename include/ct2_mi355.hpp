@@ -203,6 +203,7 @@ public:
     check(ct2x_model_info(h_, &s2s, &vocab, &d, &layers, &heads, &bos, &eos, ct, sizeof(ct)));
     is_seq2seq_ = s2s != 0;
     vocab_size_ = static_cast<size_t>(vocab);
+    bos_id_ = bos;
     compute_type_ = ct;
   }
   ~Handle() {
@@ -214,6 +215,7 @@ public:
   void* get() const { return h_; }
   bool is_seq2seq() const { return is_seq2seq_; }
   size_t vocab_size() const { return vocab_size_; }
+  int32_t bos_id() const { return bos_id_; }
   const std::string& compute_type() const { return compute_type_; }
 
   // Vocabulary::to_id / to_token (include/ctranslate2/vocabulary.h:16-70); which: 0 source, 1 target
@@ -237,6 +239,7 @@ private:
   void* h_ = nullptr;
   bool is_seq2seq_ = false;
   size_t vocab_size_ = 0;
+  int32_t bos_id_ = -1;
   std::string compute_type_;
 };
 
@@ -588,13 +591,20 @@ public:
     const size_t len = options.max_length, hyp = options.num_hypotheses;
     std::vector<int32_t> out(batch * hyp * len, 0), out_len(batch * hyp, 0);
     std::vector<float> scores(batch * hyp, 0.f);
-    // The C entry decodes with include_prompt_in_result = false: the first generated token of the
-    // shortest prompt is step 0. With include_prompt_in_result the reference forces the start
-    // tokens as a decoding prefix and reports them too (return_prefix, src/decoding.cc:925): they
-    // are handed to the callback here, before the decoding, and the steps continue from them. (A
-    // forced token's log-probability is not computed on this path: return_scores is rejected.)
+    // include_prompt_in_result (the reference's default): the C entry decodes the prompt step by
+    // step as a returned hard prefix, exactly as DecoderReplica::run_generation does
+    // (src/models/language_model.cc:150-282) - lengths, scores and callbacks are the reference's.
+    // Together with a static prompt, return_alternatives or return_logits_vocab the entry decodes
+    // with include_prompt_in_result = false (one sequence-mode pass over the prompt, the first
+    // generated token of the shortest prompt is step 0) and the prompt is put in front of the
+    // sequences here: the start tokens are handed to the callback before the decoding and the steps
+    // continue from them (a forced token's log-probability is not computed on that path:
+    // return_scores is rejected).
+    const bool exact_prompt = options.include_prompt_in_result && !options.return_alternatives &&
+                              options.static_prompt.empty() && !options.return_logits_vocab;
+    o.include_prompt_in_result = exact_prompt ? 1 : 0;
     size_t step_offset = 0;
-    if (options.callback && options.include_prompt_in_result) {
+    if (options.callback && options.include_prompt_in_result && !exact_prompt) {
       detail::reject(options.return_scores, "a callback with return_scores and include_prompt_in_result");
       size_t shortest = start_tokens[0].size();
       for (const auto& s : start_tokens) shortest = std::min(shortest, s.size());
@@ -633,7 +643,14 @@ public:
           continue;  // fewer alternatives expanded / fewer finished hypotheses than requested
         std::vector<std::string> tokens;
         std::vector<size_t> ids;
-        if (options.include_prompt_in_result) {
+        if (exact_prompt) {
+          // "Forward the start token to the output if it is not the special BOS token"
+          // (language_model.cc:262-267); the rest of the prompt is in the decoded sequence
+          if (in.ids[b * in.stride] != h_.bos_id()) {
+            ids.push_back(static_cast<size_t>(in.ids[b * in.stride]));
+            tokens.push_back(start_tokens[b][0]);
+          }
+        } else if (options.include_prompt_in_result) {
           // (alternatives: the sequences of a longer prompt of a ragged batch already begin with
           // its tokens beyond the shortest prompt - as the reference returns them)
           int32_t upto = in.lengths[b];

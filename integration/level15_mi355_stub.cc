@@ -404,8 +404,10 @@ namespace ctranslate2 {
     // (src/models/language_model.cc:150-282) with include_prompt_in_result = false - the prompt is
     // consumed by one sequence-mode pass, ragged prompts continue as hard prefixes - on
     // ct2x_generate_batch, with sampling, the step callback, a custom end token and
-    // return_alternatives (round 6). The prompt in the result, static prompts and logits stay on the
-    // reference's own path.
+    // return_alternatives (round 6) - and with include_prompt_in_result = true, the reference's
+    // default: the prompt decoded step by step as a returned hard prefix on the fused engine, the
+    // start token put in front here (language_model.cc:262-267). Static prompts, logits and the
+    // prompt in the result together with return_alternatives stay on the reference's own path.
     class Mi355DecoderReplica : public DecoderReplica {
     public:
       using DecoderReplica::DecoderReplica;
@@ -457,6 +459,7 @@ namespace ctranslate2 {
         set_sampling(opt, options);
         opt.return_alternatives = options.return_alternatives ? 1 : 0;
         opt.min_alternative_expansion_prob = options.min_alternative_expansion_prob;
+        opt.include_prompt_in_result = options.include_prompt_in_result ? 1 : 0;
         const auto end_ids = std::visit(ResolveEndToken(vocab), options.end_token);
         if (end_ids[0] != vocab.eos_id()) opt.end_token_plus_one = static_cast<int32_t>(end_ids[0]) + 1;
         CallbackBridge bridge{&options.callback, &vocab, nullptr};
@@ -482,6 +485,9 @@ namespace ctranslate2 {
             if (len < 0 || (!options.return_alternatives && h > 0 && len == 0)) continue;  // (fewer hypotheses than asked for)
             const int32_t* row = out_ids.data() + (b * nh + h) * max_len;
             results[b].sequences_ids.emplace_back(row, row + std::min<int32_t>(len, static_cast<int32_t>(max_len)));
+            // "Forward the start token to the output if it is not the special BOS token"
+            if (options.include_prompt_in_result && ids[b][0] != vocab.bos_id())
+              results[b].sequences_ids.back().insert(results[b].sequences_ids.back().begin(), ids[b][0]);
             if (options.return_scores) results[b].scores.push_back(out_scores[b * nh + h]);
           }
           results[b].sequences = vocab.to_tokens(results[b].sequences_ids);
@@ -501,9 +507,10 @@ namespace ctranslate2 {
         if (m == nullptr) return false;
         for (const auto& prompt : start_tokens)
           if (prompt.empty()) return false;
-        // (the prompt in the result - the reference's default - decodes the prompt step by step as a
-        // returned prefix, static prompts keep a cached state, logits: the reference's own path)
-        if (options.include_prompt_in_result || !options.static_prompt.empty() || options.return_logits_vocab ||
+        // (static prompts keep a cached state, logits, the prompt in the result of
+        // return_alternatives: the reference's own path)
+        if ((options.include_prompt_in_result && options.return_alternatives) ||
+            !options.static_prompt.empty() || options.return_logits_vocab ||
             options.num_hypotheses < 1 || options.beam_size < 1 || options.max_length == 0 ||
             (options.num_hypotheses > options.beam_size && !options.return_alternatives && options.sampling_topk == 1) ||
             (options.callback && options.beam_size != 1) || (options.return_alternatives && options.sampling_topk != 1))

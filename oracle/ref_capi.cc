@@ -481,6 +481,38 @@ int ct2ref_generate(void* h, const int32_t* prompt_ids, const int32_t* prompt_le
   CT2REF_CATCH
 }
 
+// Generator::generate_batch with include_prompt_in_result = true (the reference's default: the
+// prompt is decoded step by step as a returned hard prefix, src/models/language_model.cc:150-282;
+// the sequences begin with the prompt). out_ids [batch, out_stride], out_stride >= max_len + 1.
+int ct2ref_generate_with_prompt(void* h, const int32_t* prompt_ids, const int32_t* prompt_lengths,
+                                int batch, int stride, int beam_size, int max_len, int min_len,
+                                int return_scores, int out_stride, int32_t* out_ids,
+                                int32_t* out_lengths, float* out_scores) {
+  CT2REF_TRY
+  auto* m = static_cast<RefModel*>(h);
+  const auto* lm = dynamic_cast<const models::LanguageModel*>(m->model.get());
+  if (!lm || !m->generator) throw std::runtime_error("not a language model");
+  auto prompts = ids_to_tokens(lm->get_vocabulary(), prompt_ids, prompt_lengths, batch, stride);
+  GenerationOptions opt;
+  opt.beam_size = beam_size;
+  opt.max_length = max_len;
+  opt.min_length = min_len;
+  opt.sampling_topk = 1;
+  opt.return_scores = return_scores != 0;
+  opt.include_prompt_in_result = true;
+  auto futures = m->generator->generate_batch_async(prompts, opt);
+  std::vector<GenerationResult> results;
+  for (auto& f : futures) results.emplace_back(f.get());
+  for (int b = 0; b < batch; ++b) {
+    const auto& ids = results[b].sequences_ids[0];
+    const int len = static_cast<int>(ids.size());
+    for (int t = 0; t < len && t < out_stride; ++t) out_ids[b * out_stride + t] = ids[t];
+    out_lengths[b] = len;
+    if (return_scores && out_scores) out_scores[b] = results[b].scores[0];
+  }
+  CT2REF_CATCH
+}
+
 // Generator::generate_batch with num_hypotheses / return_alternatives /
 // min_alternative_expansion_prob (GenerationOptions, include/ctranslate2/generation.h;
 // decode_alternatives, src/decoding.cc:1122-1290 - reached from DecoderReplica::run_generation,

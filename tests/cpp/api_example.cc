@@ -49,6 +49,17 @@ int main(int argc, char** argv) {
       const auto results = generator.generate_batch(batch, options);
       for (const auto& token : results[0].sequences[0]) std::cout << token << ' ';
       std::cout << std::endl;
+    } else if (mode == "generate_prompt") {
+      // api_example generate_prompt <model_dir> <max_length> <prompt tokens...>: the reference's
+      // default GenerationOptions (include_prompt_in_result = true) + return_scores
+      ct2_mi355::Generator generator(model, ct2_mi355::Device::CUDA);
+      ct2_mi355::GenerationOptions options;
+      options.max_length = static_cast<size_t>(std::atoi(argv[3]));
+      options.return_scores = true;
+      const std::vector<std::vector<std::string>> batch = {std::vector<std::string>(argv + 4, argv + argc)};
+      const auto results = generator.generate_batch(batch, options);
+      for (const auto& token : results[0].sequences[0]) std::cout << token << ' ';
+      std::cout << "| " << results[0].scores[0] << std::endl;
     } else if (mode == "alternatives") {
       // api_example alternatives <model_dir> <max_length> <num_hypotheses> <prompt tokens...>:
       // GenerationOptions::return_alternatives with the prompt in the result (the reference's default)

@@ -45,8 +45,8 @@ def main():
     out = {"device_count": ext.get_cuda_device_count(),
            "compute_types": sorted(ext.get_supported_compute_types(spec["device"])), "runs": []}
     if "gen_cases" in spec:
-        # ctranslate2.Generator.generate_batch with include_prompt_in_result=False (Level 1.5:
-        # Mi355DecoderReplica::run_generation)
+        # ctranslate2.Generator.generate_batch (include_prompt_in_result=False unless the case sets
+        # it; Level 1.5: Mi355DecoderReplica::run_generation)
         g = ext.Generator(spec["model"], device=spec["device"], compute_type=spec["compute_type"])
         for case in spec["gen_cases"]:
             kw = dict(case)
@@ -54,7 +54,9 @@ def main():
             steps = []
             if kw.pop("callback", False):
                 kw["callback"] = lambda r: steps.append([r.batch_id, r.step, r.token, r.is_last]) and False
-            res = g.generate_batch(spec["tokens"], include_prompt_in_result=False, **kw)
+            kw.setdefault("include_prompt_in_result", False)
+            tokens = kw.pop("tokens", spec["tokens"])
+            res = g.generate_batch(tokens, **kw)
             out["runs"].append({"name": name, "sequences": [r.sequences for r in res],
                                 "scores": [[float(x) for x in r.scores] for r in res], "steps": steps})
         lib = ctypes.CDLL(os.path.join(ROOT, "integration", "libctranslate2_mi355.so"), mode=os.RTLD_LAZY | os.RTLD_GLOBAL)

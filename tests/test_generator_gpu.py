@@ -294,6 +294,23 @@ def test_cpp_api_generator(gpu):
     assert out.split() == [t.id_to_token(i) for i in ids[0]]
 
 
+def test_cpp_api_generator_prompt_in_result(gpu):
+    """Generator::generate_batch of the C++ host API with the reference's default options
+    (include_prompt_in_result = true): the id-level entry point's exact form - the prompt decoded as a
+    returned hard prefix, max_length counting it, the start token in front."""
+    import _cppapi
+    t = get_lm("lm_tiny", "default")
+    prompt = [5, 9, 13, 7]
+    ids, scores = t.generate_ids([prompt], max_length=9, return_scores=True, include_prompt_in_result=True)
+    assert ids[0][:4] == prompt and len(ids[0]) <= 1 + 9
+    rc, out, err = _cppapi.run("generate_prompt", "/tmp/ct2x_test_lm_tiny", 9,
+                               *[t.id_to_token(i) for i in prompt])
+    assert rc == 0, err
+    toks, score = out.strip().split("|")
+    assert toks.split() == [t.id_to_token(i) for i in ids[0]]
+    assert abs(float(score) - float(scores[0])) < 1e-4
+
+
 def test_cpp_api_generator_alternatives(gpu):
     """Generator::generate_batch with GenerationOptions::return_alternatives through the C++ host API,
     the prompt in the result (the reference's default): every sequence = the prompt, an alternative
@@ -519,3 +536,31 @@ def test_generator_return_alternatives_rules(gpu):
     seqs, _ = t.generate_ids(p, max_length=8, num_hypotheses=2, return_alternatives=True,
                              min_alternative_expansion_prob=1.0)
     assert seqs == [[]]
+
+
+@pytest.mark.parametrize("key", ["lm_tiny", "lm_small"])
+@pytest.mark.parametrize("ct", ["float32", "int8"])
+def test_generator_include_prompt_in_result(gpu, key, ct):
+    """GenerationOptions::include_prompt_in_result = true, the reference's default: no sequence-mode
+    pass; the prompt is decoded step by step as a RETURNED hard prefix (return_prefix: it counts
+    towards max / min_length, forced tokens score 0, a BOS start token is not forwarded to the
+    output; src/models/language_model.cc:150-282, src/decoding.cc:21-63, 357-408) - ragged prompts
+    down to a single token, greedy / forced length / a max_length that ends inside the prompts /
+    beam 4 with and without min_length, against the real reference Generator
+    (tests/golden/make_golden_generator_prompt.py)."""
+    with open(os.path.join(HERE, "golden", "generator_prompt_golden.json")) as f:
+        g = json.load(f)[key + ("_f32" if ct == "float32" else "")]
+    t = get_lm(key, ct)
+    for name, run in g["runs"].items():
+        gen, scores = t.generate_ids(g["prompts"], max_length=run["max_len"], min_length=run["min_len"],
+                                     return_scores=True, beam_size=run["beam"],
+                                     include_prompt_in_result=True)
+        same = [x == y for x, y in zip(gen, run["generated"])]
+        print("%s %s %s: %d/%d token-identical" % (key, ct, name, sum(same), len(same)))
+        if ct == "float32":
+            assert all(same), (name, gen, run["generated"])
+            np.testing.assert_allclose(scores, np.array(run["scores"], np.float32), atol=1e-3)
+        else:
+            assert sum(same) >= len(same) - 2, (name, gen, run["generated"])
+            ok = np.array(same)
+            np.testing.assert_allclose(scores[ok], np.array(run["scores"], np.float32)[ok], atol=2e-2)

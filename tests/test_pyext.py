@@ -156,14 +156,23 @@ LEVEL15_GEN_CASES = [
     {"name": "alternatives", "beam_size": 1, "num_hypotheses": 3, "return_alternatives": True, "max_length": 14,
      "return_scores": True},
     {"name": "sampling", "beam_size": 1, "sampling_topk": 5, "sampling_temperature": 0.9, "max_length": 8},
+    # the reference's DEFAULT: the prompt decoded step by step as a returned hard prefix
+    {"name": "prompt_greedy", "beam_size": 1, "max_length": 12, "include_prompt_in_result": True,
+     "return_scores": True},
+    {"name": "prompt_beam_ragged", "beam_size": 4, "max_length": 14, "min_length": 9, "include_prompt_in_result": True,
+     "return_scores": True,
+     "tokens": [["tok17", "tok5", "tok230"], ["<s>", "tok9", "tok77", "tok300", "tok12", "tok40"], ["tok9"]]},
+    {"name": "prompt_callback", "beam_size": 1, "max_length": 9, "include_prompt_in_result": True, "callback": True},
 ]
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not _built(), reason="oracle/_ref/pyext is built where /root/reference exists")
 def test_level15_generator_options(gpu):
-    """The same for ctranslate2.Generator (include_prompt_in_result=False): greedy / beam search, the
-    step callback, a custom end token, return_alternatives and sampling reach the fused engine; the
+    """The same for ctranslate2.Generator: greedy / beam search, the step callback, a custom end
+    token, return_alternatives and sampling with include_prompt_in_result=False, and the reference's
+    default include_prompt_in_result=True (greedy, ragged beam search with min_length, the callback
+    over the forced prompt steps) reach the fused engine; the
     sequences equal the reference's on Device::CPU and its own op-by-op route on the device."""
     import golden_cases as GC
     from ctranslate2_amd import model_builder as mb
@@ -183,5 +192,5 @@ def test_level15_generator_options(gpu):
         assert f["sequences"] == c["sequences"], (f["name"], f["sequences"], c["sequences"])
         for a, b in zip(f["scores"], c["scores"]):
             assert len(a) == len(b) and all(abs(x - y) < 2e-3 for x, y in zip(a, b)), f["name"]
-        if f["name"] == "callback":
-            assert f["steps"] == c["steps"]
+        if "callback" in f["name"]:
+            assert f["steps"] == c["steps"] and len(f["steps"]) > 0
