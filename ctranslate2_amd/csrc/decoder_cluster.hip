@@ -588,6 +588,8 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
       }
       stage.store(sh.ks, sh.vs);
       if (self) { CT2X_CL_STAMP(21) }
+      // (behind the tiles' stores: a store waits for every request ahead of it in the queue, and the
+      // next phase's weights are meant to arrive under the attention)
       g_out.request<64, 8, 4>(W_out.w + static_cast<size_t>(member) * 64 * kD);
       c_out.request(W_out, out_col, t < 64);
       lds_barrier();
@@ -970,24 +972,46 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_kernel(ClusterStackA
 // staged memory tile and takes MKL's several-row forms (m = beam query rows on the same keys,
 // except at the search's first step, which the reference still runs on one row per entry:
 // src/decoding.cc:453-454); the self-attention follows the beam search's ancestry table
-// (position t of row r lives in cache row anc[t][r]) and runs two rows at a time on two tiles.
+// (position t of row r lives in cache row anc[t][r]) and runs every row on a wave and a tile of its own.
 // Same arithmetic per row as the one-row launch above and as the launch-per-op step.
 // ================================================================================================
 constexpr int kBeamRows = 4;
 
+// Round 6 (last session): FOUR K / V tiles, one per row of the entry, so that the self-attention of
+// the entry's rows runs in ONE round on four waves (it was two rows at a time on two tiles: 12.2 of
+// a layer's 47 us, profiles/r05_cluster_beam_timeline_c.txt). Four tiles are 132 KB; they fit the
+// CU's 160 KB because the fourth lies over what only the row-wide phases use (the parked rows of
+// the statistics chains, the quantised rows, the GEMV partial sums: all dead while the attention
+// runs; a barrier separates their last readers from the tile's store, Handover::await's barrier the
+// tile's last readers from their next writers).
 struct SharedBeam {
+  // (the row-wide phases' arrays FIRST: within reach of the LDS instructions' 16-bit immediate
+  // offsets - behind 100 KB of tiles every access needed an address register of its own and the
+  // launch kept 30 more values in scratch memory)
+  union {
+    struct {
+      float stage[kBeamRows][8 * 68 + 8];  // the rows parked for their statistics chains
+      alignas(16) int8_t xq[kBeamRows][kFfn];
+      int part[kBeamRows][kThreads];
+    };
+    struct {                               // tile 3
+      float ks3[64 * kXKS];
+      float vs3[64 * kDH];
+    };
+  };
   float x_row[kBeamRows][kD];       // residual stream of the entry's rows (the source of truth)
-  float stage[kBeamRows][8 * 68 + 8];  // the rows parked for their statistics chains
-  alignas(16) int8_t xq[kBeamRows][kFfn];
-  int part[kBeamRows][kThreads];
   float outv[kBeamRows][256];
   float red[kBeamRows][4];
   float rs[kBeamRows];              // quantisation scale of every row's current input
   float tq[kBeamRows][kDH];
-  float ks[2][64 * kXKS];           // two tiles: self-attention two rows at a time; the memory tile is [0]
-  float vs[2][64 * kDH];
   int dead;
+  int pad_[3];
+  float ks[3][64 * kXKS];           // tiles 0 .. 2 (the shared memory tile of beam search is [0])
+  float vs[3][64 * kDH];
+  __device__ __forceinline__ float* k_tile(int i) { return i < 3 ? ks[i] : ks3; }
+  __device__ __forceinline__ float* v_tile(int i) { return i < 3 ? vs[i] : vs3; }
 };
+static_assert(sizeof(SharedBeam) % 16 == 0 && offsetof(SharedBeam, ks) % 16 == 0, "SharedBeam: 16-byte tiles");
 
 // Every loop over the entry's rows is ROLLED (one copy of the per-row code; the launch must stay
 // inside the instruction cache: an unrolled first version was 94 KB of code and ran at a third of
@@ -1173,10 +1197,15 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
       auto cached_of = [&](int r) {
         return self ? max(0, min(step, a.t_max)) : max(0, min(a.mem_lengths[mem_base + (shared ? 0 : r)], a.s_max));
       };
-      // the tile of row r: requested now, stored after the projection. Self and independent
-      // memories: rows 0, 1 into tiles 0, 1 (rows 2, 3 follow behind the first round); a shared
-      // memory: one tile. (Every path DEFINES both register sets - an absent row re-reads the
-      // first: a conditional definition would keep 32 registers alive through the whole launch.)
+      // the tile of row r. Self and independent memories: rows 0, 1 are requested here and stored
+      // after the projection, rows 2, 3 then travel in the same registers (one exposed trip to the
+      // L2 instead of a second attention round); a shared memory: one tile. (The first pair is
+      // DEFINED on every path - an absent row re-reads the first: a conditional definition would
+      // keep 32 registers alive through the whole launch.)
+      // Measured (profiles/r06_beam_four_tiles_ab.txt, beam 4): the second pair requested right
+      // behind the statistics chains 85.3 - 86.9k tokens/s; requested here with the next phase's
+      // weight request AHEAD of its stores 86.9 - 87.1k; this order 87.7 - 87.9k (two tiles, two
+      // rounds: 83.8k).
       auto request_tile = [&](AttnStage64& st, int r) {
         if (self)
           st.request(self_k0 + r * kv_row_stride, self_v0 + r * kv_row_stride, kDH, cached_of(r), n_keys,
@@ -1200,17 +1229,32 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) stage_a[i].store(sh.ks[i], sh.vs[i]);
+      const bool more_tiles = per_row_tiles && nr > 2;  // (uniform over the workgroup)
+      if (more_tiles) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) request_tile(stage_a[i], (2 + i < nr) ? 2 + i : 2);
+      }
+      if (more_tiles) {
+        lds_barrier();  // (the partial sums have been read: tile 3 lies over them)
+        stage_a[0].store(sh.ks[2], sh.vs[2]);
+        stage_a[1].store(sh.ks3, sh.vs3);
+      }
       g_out.request<64, 8, 4>(W_out.w + static_cast<size_t>(member) * 64 * kD);
       c_out.request(W_out, out_col, t < 64);
       lds_barrier();
       CT2X_CL_STAMP(1 + 5 * sub)
-      // ---- attention: ONE call site (the core keeps the register file). Self: two rows per round
-      // on the two tiles (waves 0, 1); cross: wave w = row w on the shared memory tile.
+      // ---- attention: ONE call site (the core keeps the register file), ONE round: wave w = row w,
+      // on its own tile (self, independent memories) or on the shared memory tile (beam search).
       const float att_scale = self ? L.self_scale : L.cross_scale;
-      const int rounds = per_row_tiles ? (nr + 1) / 2 : 1;
+      // (The loop runs ONCE - an entry has at most four rows - and its rd > 0 arm never: they are
+      // what round 5's two-round form looked like, and with them the register allocator finds the
+      // assignment it found then (13 values in scratch memory, none reloaded on a hot path); as
+      // straight-line code, or as a one-trip loop without the arm, the same kernel kept 42 - 73 values
+      // there and every phase of the launch slowed down: 84.1k -> 80.7k tokens/s instead of a gain.)
+      const int rounds = per_row_tiles ? (nr + 3) / 4 : 1;
 #pragma unroll 1
       for (int rd = 0; rd < rounds; ++rd) {
-        if (rd > 0) {  // the tiles of rows 2, 3 (every thread: the first round has read its tiles)
+        if (rd > 0) {  // (never: an entry has at most four rows; the loop keeps the core a region of its own)
           lds_barrier();
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
@@ -1220,8 +1264,8 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
           }
           lds_barrier();
         }
-        const int r = per_row_tiles ? rd * 2 + wave : wave;
-        const bool mine = per_row_tiles ? (wave < 2 && r < nr) : (wave < nr);
+        const int r = per_row_tiles ? rd * 4 + wave : wave;
+        const bool mine = per_row_tiles ? (wave < 4 && r < nr) : (wave < nr);
         if (mine) {
           float* tq = sh.tq[r];
           float* tp = tp_base + static_cast<size_t>(r) * a.t_pad;
@@ -1238,7 +1282,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
           const float* kc_m = kc_cross + r * mem_stride;
           const float ctx = attn_exact_wave64(
               qd, self, knew, vnew, self ? kc_w : kc_m, self ? vc_w : kc_m + kD, self ? kDH : 2 * kD, t_cached, n_keys,
-              self ? t_cached + 1 : t_cached, att_scale, tq, tp, a.t_pad, sh.ks[tile], sh.vs[tile],
+              self ? t_cached + 1 : t_cached, att_scale, tq, tp, a.t_pad, sh.k_tile(tile), sh.v_tile(tile),
               self ? 1 : cross_m_rows, (self && a.ancestry) ? a.ancestry + row0 + r : nullptr, a.rows, kv_row_stride,
               row0 + r);
           ho.publish(r * kXchFloats + kXchCtx + member * kDH + lane, ctx);

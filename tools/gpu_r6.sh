@@ -182,6 +182,14 @@ final)            # the round's closing evidence in one call: bench line, kernel
 beam_proj_sweep)  # beam 4: the 128-row vocabulary projection's row tiles per workgroup (tuning build, CT2X_SKINNY_MT)
   { for mt in 1 2 4 8 1 2 4 8; do echo "== CT2X_SKINNY_MT=$mt --beam 4"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/ctranslate2_amd/libct2_mi355_tuning.so CT2X_SKINNY_MT=$mt timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
   } 2>&1 | tee $O/beam_proj_sweep.txt ;;
+beam_tiles)       # beam search's decoder-stack launch: four K / V tiles, one attention round (build/libct2_mi355_new*.so) vs two tiles, two rounds (_old.so)
+  timeout 900 python -m pytest tests/test_decoder_cluster_gpu.py tests/test_bench_path_gpu.py -x -q 2>&1 | tail -4 | tee $O/beam_tiles_tests.txt
+  { for v in old new new2 old new new2; do echo "== $v --beam 4"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+    for v in old new new2; do echo "== $v --beam 2"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python bench.py --beam 2 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+    for v in old new new2; do echo "== $v --batch 128 (greedy, several rows per cluster)"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python bench.py --batch 128 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+    for v in old new new2; do echo "== $v --batch 64 (greedy, two rows per cluster)"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python bench.py --batch 64 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+  } 2>&1 | tee $O/beam_tiles_ab.txt
+  for v in old new new2; do echo "== timeline $v"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so CT2X_CLUSTER_STAMPS=1 timeout 300 python bench.py --beam 4 --steps 2 --warmup 1 $NOLEGS --no-token-check 2>&1 | grep -A8 "decoder_stack timeline" | tail -9 | head -8 | cut -c1-110; done | tee $O/beam_tiles_timeline.txt ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
