@@ -492,6 +492,7 @@ private:
   void encode_features(DecodeState& st, const float* features, int64_t frames);
   // encoder layers + output norm + the cross-attention K/V projections, on x (scratch y)
   void encode_layers(DecodeState& st, float* x, float* y);
+  bool padding_removal_pays(int64_t padded_rows, int64_t valid_rows) const;  // (Padder, engine_session.cc)
   // amax_buf: zeroed [rows] scratch for the producer-side absmax of the gated pair (decode steps)
   void run_ffn(const FfnW& ffn, bool pre_norm, int64_t rows, int64_t d, float*& x, float*& y,
                DecodeState& st, float* amax_buf = nullptr, bool qin_ready = false);
@@ -631,6 +632,15 @@ struct DecodeState {
   int32_t* d_bprefix_len = nullptr;  // [batch]
   int32_t bprefix_stride = 0;
   int32_t* d_src = nullptr;          // encoder input ids [batch * s_max] (kept for reencode)
+  // Padder (src/padder.cc:8-74; TransformerEncoder::operator(), src/layers/transformer.cc:440-470):
+  // the encoder's row-wise layers run on the valid source positions only. pad_rows = their count
+  // (0: the padded layout throughout); the two index maps of the reference's Padder on the device.
+  int64_t pad_rows = 0;
+  int32_t* d_padded_to_flat = nullptr;  // [pad_rows] padded row of every valid position
+  int32_t* d_flat_to_padded = nullptr;  // [batch * s_max] valid row a padded position shows (its own, or
+                                        // the sentence's last valid one behind its end)
+  std::vector<int32_t> h_pad_maps;      // host copies the uploads read from
+  float* pad_qkv = nullptr;             // the re-padded fused projection when the feed-forward's inner buffer is too narrow for it
   int32_t* anc_init = nullptr;       // the identity the ancestry tables start from (kept for reencode)
   int64_t graph_kernels = 0;         // launches of the captured step (kernels_per_step of a replay)
   float* att_hist = nullptr;         // return_attention: [t_max + 1][rows][s_max] (enable_attention)

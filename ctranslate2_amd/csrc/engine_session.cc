@@ -513,7 +513,67 @@ void Engine::encode(DecodeState& st, const int32_t* src_ids, const int32_t* src_
   tap_scope("enc");
   tap("emb", x, 0, rows, d);
   if (enc_.layernorm_embedding.present) norm(enc_.layernorm_embedding, x, rows, d, x);
+  // Padder::remove_padding (src/layers/transformer.cc:443-450, src/padder.cc:8-66): the layers run
+  // on the valid positions only; attention re-pads its projections and un-pads its context
+  // (src/layers/attention.cc:390-403, 590-596), the encoder output is padded again at the end - a
+  // padded position then shows its sentence's LAST valid row, as Padder::add_padding's gather does.
+  st.pad_rows = 0;
+  int64_t total = 0;
+  for (int64_t b = 0; b < B; ++b) total += std::max<int64_t>(0, std::min<int64_t>(src_lengths[b], S));
+  bool all_positive = true;
+  for (int64_t b = 0; b < B; ++b) all_positive = all_positive && src_lengths[b] >= 1;
+  if (all_positive && !enc_.layers.empty() && padding_removal_pays(rows, total) && !tp_ && !taps_) {
+    // (the re-padded projection borrows the feed-forward's inner buffer where a row of it fits)
+    int64_t widest = 0;
+    bool fits = true;
+    for (const LayerW& layer : enc_.layers) {
+      widest = std::max(widest, layer.self.lin[0].n);
+      fits = fits && layer.self.lin[0].n <= layer.ffn.l0.n;
+    }
+    if (!fits && st.pad_qkv == nullptr) st.pad_qkv = alloc<float>(st, rows * widest);
+    st.h_pad_maps.resize(static_cast<size_t>(total + rows));
+    int32_t* p2f = st.h_pad_maps.data();
+    int32_t* f2p = p2f + total;
+    int64_t flat = 0;
+    for (int64_t b = 0; b < B; ++b) {
+      const int64_t len = std::min<int64_t>(src_lengths[b], S);
+      for (int64_t t = 0; t < len; ++t) {
+        p2f[flat + t] = static_cast<int32_t>(b * S + t);
+        f2p[b * S + t] = static_cast<int32_t>(flat + t);
+      }
+      for (int64_t t = len; t < S; ++t) f2p[b * S + t] = static_cast<int32_t>(flat + len - 1);
+      flat += len;
+    }
+    if (st.d_padded_to_flat == nullptr) {
+      st.d_padded_to_flat = alloc<int32_t>(st, rows);
+      st.d_flat_to_padded = alloc<int32_t>(st, rows);
+    }
+    CT2X_HIP_CHECK(hipMemcpyAsync(st.d_padded_to_flat, p2f, sizeof(int32_t) * total, hipMemcpyHostToDevice,
+                                  cur_stream()));
+    CT2X_HIP_CHECK(hipMemcpyAsync(st.d_flat_to_padded, f2p, sizeof(int32_t) * rows, hipMemcpyHostToDevice,
+                                  cur_stream()));
+    begin_kernel("padder_remove", double(total) * d * 8, 0, total, 0, d);
+    launch_gather_rows(x, st.d_padded_to_flat, total, d * sizeof(float), y, cur_stream());
+    end_kernel();
+    std::swap(x, y);
+    st.pad_rows = total;
+  }
   encode_layers(st, x, y);
+}
+
+// Whether the reference's padding removal is applied (it always is when a length differs,
+// src/layers/transformer.cc:446-450): here only where it returns more than its four gathers per
+// layer cost - from a few thousand rows up with an eighth of them padding (below that an encoder
+// layer is launch bound and costs the same for any row count; measured: DESIGN 5.00000).
+// CT2X_PADDER=1 / 0: always (when a length differs) / never. Same results for every valid position.
+bool Engine::padding_removal_pays(int64_t padded_rows, int64_t valid_rows) const {
+  static const int mode = [] {
+    const char* e = std::getenv("CT2X_PADDER");
+    return e == nullptr ? -1 : (e[0] == '0' ? 0 : 1);
+  }();
+  if (valid_rows >= padded_rows || valid_rows < 1) return false;
+  if (mode >= 0) return mode == 1;
+  return padded_rows >= 4096 && (padded_rows - valid_rows) * 8 >= padded_rows;
 }
 
 // WhisperEncoder::operator() (src/layers/whisper.cc:26-62): conv1 -> conv2 -> Transpose ->
@@ -581,7 +641,10 @@ void Engine::encode_features(DecodeState& st, const float* features, int64_t fra
 }
 
 void Engine::encode_layers(DecodeState& st, float* x, float* y) {
-  const int64_t B = st.batch, S = st.s_max, d = enc_.d_model, rows = B * S;
+  const int64_t B = st.batch, S = st.s_max, d = enc_.d_model, padded_rows = B * S;
+  // (Padder: the row-wise layers see the valid positions only, Engine::encode)
+  const bool unpadded = st.pad_rows > 0;
+  const int64_t rows = unpadded ? st.pad_rows : padded_rows;
   int enc_layer_index = 0;
   for (const LayerW& layer : enc_.layers) {
     const AttnW& a = layer.self;
@@ -603,10 +666,20 @@ void Engine::encode_layers(DecodeState& st, float* x, float* y) {
     dense(a.lin[0], attn_in, qin.q ? &qin : nullptr, rows, -1, nullptr, st.qkv, &st);
     const int64_t qdim = a.heads * a.dhead, kvdim = a.heads_kv * a.dhead;
     const int64_t ld = qdim + 2 * kvdim;
+    // Padder::add_padding on the fused projection (src/layers/attention.cc:390-403): one gather
+    // into the padded layout the attention kernels index (the feed-forward's inner buffer is free here)
+    const float* qkv_in = st.qkv;
+    if (unpadded) {
+      begin_kernel("padder_add", double(padded_rows) * ld * 8, 0, padded_rows, 0, ld);
+      float* padded = st.pad_qkv ? st.pad_qkv : st.inner;
+      launch_gather_rows(st.qkv, st.d_flat_to_padded, padded_rows, ld * sizeof(float), padded, cur_stream());
+      end_kernel();
+      qkv_in = padded;
+    }
     AttnFullParams f;
-    f.q = st.qkv;
-    f.k = st.qkv + qdim;
-    f.v = st.qkv + qdim + kvdim;
+    f.q = qkv_in;
+    f.k = qkv_in + qdim;
+    f.v = qkv_in + qdim + kvdim;
     f.q_batch_stride = S * ld;
     f.q_time_stride = ld;
     f.k_batch_stride = S * ld;
@@ -627,11 +700,18 @@ void Engine::encode_layers(DecodeState& st, float* x, float* y) {
     f.half_kind = half_kind();
     f.scale = a.queries_scale;
     f.out = st.ctx;
-    begin_kernel("attention_encoder", 0, 0, rows, a.heads, a.dhead);
+    begin_kernel("attention_encoder", 0, 0, padded_rows, a.heads, a.dhead);
     launch_attention_full(f, cur_stream());
     end_kernel();
-    tap("ctx", st.ctx, 0, rows, a.heads * a.dhead);
-    dense(a.lin[1], st.ctx, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
+    const float* ctx_in = st.ctx;
+    if (unpadded) {  // Padder::remove_padding on the context (attention.cc:590-596); st.qkv is free
+      begin_kernel("padder_remove", double(rows) * qdim * 8, 0, rows, 0, qdim);
+      launch_gather_rows(st.ctx, st.d_padded_to_flat, rows, qdim * sizeof(float), st.qkv, cur_stream());
+      end_kernel();
+      ctx_in = st.qkv;
+    }
+    tap("ctx", ctx_in, 0, rows, a.heads * a.dhead);
+    dense(a.lin[1], ctx_in, nullptr, rows, -1, a.ln.present ? x : nullptr, y, &st);
     if (a.ln.present && !enc_.pre_norm) norm(a.ln, y, rows, d, y);
     std::swap(x, y);
 
@@ -641,9 +721,15 @@ void Engine::encode_layers(DecodeState& st, float* x, float* y) {
     ++enc_layer_index;
   }
   if (enc_.output_norm.present) norm(enc_.output_norm, x, rows, d, x);
+  if (unpadded) {  // Padder::add_padding on the output (src/layers/transformer.cc:469-470)
+    begin_kernel("padder_add", double(padded_rows) * d * 8, 0, padded_rows, 0, d);
+    launch_gather_rows(x, st.d_flat_to_padded, padded_rows, d * sizeof(float), y, cur_stream());
+    end_kernel();
+    std::swap(x, y);
+  }
   st.enc_out = x;
   tap_scope("enc.out");
-  tap("x", x, 0, rows, d);
+  tap("x", x, 0, padded_rows, d);
 
   // Cross-attention memory projections: linear_1(memory) -> [B*S, 2*kv_dim], kept in the GEMM
   // output layout (the attention kernel takes strides; no split_heads transpose).
@@ -654,17 +740,17 @@ void Engine::encode_layers(DecodeState& st, float* x, float* y) {
     QuantIn mq;
     if (a.lin[1].quantized) {
       if (!quantized_once) {  // the same memory feeds every layer: quantise it once
-        quant(x, rows, d, st.qbuf, st.qscale);
+        quant(x, padded_rows, d, st.qbuf, st.qscale);
         quantized_once = true;
       }
       mq.q = st.qbuf;
       mq.s = st.qscale;
     }
-    dense(a.lin[1], x, mq.q ? &mq : nullptr, rows, -1, nullptr, st.cross_kv[l], &st);
+    dense(a.lin[1], x, mq.q ? &mq : nullptr, padded_rows, -1, nullptr, st.cross_kv[l], &st);
     if (!st.cross_kv16.empty()) {
       const int type = compute_type_ == ComputeType::kBFloat16 ? kBF16 : kF16;  // DataType ids
-      begin_kernel("convert", double(rows) * a.lin[1].n * 6, 0, rows, a.lin[1].n, 0);
-      launch_convert(st.cross_kv[l], kF32, st.cross_kv16[l], type, rows * a.lin[1].n, cur_stream());
+      begin_kernel("convert", double(padded_rows) * a.lin[1].n * 6, 0, padded_rows, a.lin[1].n, 0);
+      launch_convert(st.cross_kv[l], kF32, st.cross_kv16[l], type, padded_rows * a.lin[1].n, cur_stream());
       end_kernel();
     }
   }

@@ -923,8 +923,10 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
     }();
     int mt = 1;
     if (m > 16) {
-      // (the vocabulary projection at <= 32 rows streams 16 MB of weights: read them once)
-      mt = mt_env ? mt_env : ((n >= 8192 && m <= 32) ? 2 : 1);
+      // (the vocabulary projection streams 16 MB of weights: read them once per 32 / 64 rows, not
+      // once per 16 - [128, 32000] x 512 fused 28.2 -> 24.0 us with four row tiles per workgroup,
+      // [64, 32000] 15.7 -> 14.4 with two; profiles/r06_proj128_row_tiles.txt)
+      mt = mt_env ? mt_env : (n >= 8192 ? (m <= 64 ? 2 : 4) : 1);
       while (mt > 1 && (mt / 2) * 16 >= m) mt /= 2;  // never more tiles than rows
     }
     // Tuning override (tools/gemm_bench.cpp): CT2X_SKINNY_CFG="NT,WAVES,U" for m <= 32.

@@ -190,6 +190,18 @@ beam_tiles)       # beam search's decoder-stack launch: four K / V tiles, one at
     for v in old new new2; do echo "== $v --batch 64 (greedy, two rows per cluster)"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python bench.py --batch 64 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
   } 2>&1 | tee $O/beam_tiles_ab.txt
   for v in old new new2; do echo "== timeline $v"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so CT2X_CLUSTER_STAMPS=1 timeout 300 python bench.py --beam 4 --steps 2 --warmup 1 $NOLEGS --no-token-check 2>&1 | grep -A8 "decoder_stack timeline" | tail -9 | head -8 | cut -c1-110; done | tee $O/beam_tiles_timeline.txt ;;
+proj128)          # the 128-row vocabulary projection of beam 4 ([128, 32000] x 512): skinny row tiles / the MFMA tile kernels (tuning build)
+  { for e in "X=1" "CT2X_SKINNY_MT=2" "CT2X_SKINNY_MT=4" "CT2X_SKINNY_MT=8" "CT2X_NO_SKINNY_GEMM=1" "CT2X_NO_SKINNY_GEMM=1 CT2X_NO_BIG_GEMM=1"; do echo "== $e"; env $e timeout 300 $GBT --act -1 128 32000 512 64 32000 512 32 32000 512 2>&1 | tail -8; done
+  } 2>&1 | tee $O/proj128.txt ;;
+padder)           # Padder: its test, then the ragged-source leg with CT2X_PADDER=0 / 1 (batches of 32 and 256 sentences)
+  timeout 900 python -m pytest tests/test_padder_gpu.py -x -q 2>&1 | tail -5 | tee $O/padder_tests.txt
+  { for f in 0 1 0 1; do echo "== CT2X_PADDER=$f"; CT2X_PADDER=$f timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-l8 --no-whisper --no-nllb --no-token-check 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); r = d['config'].get('ragged_sources', {})
+for k in ('batch32', 'batch256'):
+    e = r.get(k, {})
+    print(k, 'ragged', round(e['ragged']['ms_per_call'], 3), 'ms/call, encode', round(e['ragged']['encode_ms'], 3), 'ms | full length', round(e['full_length']['ms_per_call'], 3), 'encode', round(e['full_length']['encode_ms'], 3), '| padded share', round(e['padded_row_share'], 3))
+"; done; } 2>&1 | tee $O/padder_ab.txt ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
