@@ -162,7 +162,11 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
         res[e][j] = (has_res && row < M && col_ok[j]) ? p[j * 16] : 0.f;
     }
   };
-  auto store_group = [&](int i, const float (&res)[4][TN]) {
+  // (ACT = false: no activation - decided ONCE per launch; with the activation's eight-way choice
+  // inside the 64 unrolled elements of a 128 x 128 tile the epilogue was several kilobytes of code
+  // per element group and the fused form ran 29 us where the int32 form runs 12.5, [128, 32000] x 512)
+  auto store_group = [&](int i, const float (&res)[4][TN], auto act_tag) {
+    constexpr bool ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t row = m0 + wm * WTM + i * 16 + g4 * 4 + e;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
           float v = static_cast<float>(acc[i][j][e]) * r_a;
           v = v / ws[j];
           if (ep.bias) v = v + bias[j];
-          v = apply_activation(v, ep.act);
+          if (ACT) v = apply_activation(v, ep.act);
           if (has_res) v = res[e][j] + v;
           if (col_ok[j]) p[j * 16] = v;
         }
@@ -190,12 +194,22 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
   };
   float res_a[4][TN], res_b[4][TN];
   load_residual(0, res_a);
+  if (ep.mode == 0 || ep.act < 0) {
 #pragma unroll
-  for (int i = 0; i < TM; i += 2) {
-    if (i + 1 < TM) load_residual(i + 1, res_b);
-    store_group(i, res_a);
-    if (i + 2 < TM) load_residual(i + 2, res_a);
-    if (i + 1 < TM) store_group(i + 1, res_b);
+    for (int i = 0; i < TM; i += 2) {
+      if (i + 1 < TM) load_residual(i + 1, res_b);
+      store_group(i, res_a, std::false_type{});
+      if (i + 2 < TM) load_residual(i + 2, res_a);
+      if (i + 1 < TM) store_group(i + 1, res_b, std::false_type{});
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; i += 2) {
+      if (i + 1 < TM) load_residual(i + 1, res_b);
+      store_group(i, res_a, std::true_type{});
+      if (i + 2 < TM) load_residual(i + 2, res_a);
+      if (i + 1 < TM) store_group(i + 1, res_b, std::true_type{});
+    }
   }
 }
 
@@ -906,7 +920,13 @@ void launch_gemm_s8(const int8_t* a, const int8_t* b, int64_t m, int64_t n, int6
 #undef CT2X_DUAL
     return;
   }
-  if (m <= 128 && !forced && !no_skinny) {
+  // 65 .. 128 rows against a wide, shallow weight (the vocabulary projection of beam search,
+  // [128, 32000] x 512): the 128 x 128 tile kernel reads the weight once and runs 17.1 us where the
+  // skinny form takes 24.0 (four row tiles per workgroup; 28.2 with one) - since its epilogue decides
+  // "no activation" once per launch (profiles/r06_proj128_row_tiles.txt). 64 rows: skinny 14.3 / tile 16.0.
+  const bool tile_wins = m > 64 && n >= 8192 && k <= 1024 && ep.mode == 1 && ep.gf.slots == nullptr &&
+                         ep.b2 == nullptr && ep.a_f32 == nullptr && ep.norm_x == nullptr && !ep.packed_b;
+  if (m <= 128 && !forced && !no_skinny && !tile_wins) {
     // Decode-step shapes (rows = batch * beam): one memory round trip per launch
     // (see gemm_s8_skinny_kernel). MT = row tiles of 16, NT = column tiles per workgroup.
 #define CT2X_SKINNY(MT, NT, WAVES, U)                                                          \
