@@ -202,6 +202,13 @@ for k in ('batch32', 'batch256'):
     e = r.get(k, {})
     print(k, 'ragged', round(e['ragged']['ms_per_call'], 3), 'ms/call, encode', round(e['ragged']['encode_ms'], 3), 'ms | full length', round(e['full_length']['ms_per_call'], 3), 'encode', round(e['full_length']['encode_ms'], 3), '| padded share', round(e['padded_row_share'], 3))
 "; done; } 2>&1 | tee $O/padder_ab.txt ;;
+act_once)         # the tiled GEMMs' epilogues with the activation as a constant (build/libct2_mi355_new.so) vs decided per element (_old.so)
+  timeout 900 python -m pytest tests/test_ops_gpu.py -x -q 2>&1 | tail -2 | tee $O/act_once_tests.txt
+  SH="12000:1280:1280 12000:3840:1280 12000:5120:1280 12000:1280:5120 2048:8192:2048"
+  { for v in old new old new; do echo "== $v bf16"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python tools/gemm_h_bench.py bf16 $SH 2>&1 | grep "per launch"; done
+    for v in old new old new; do echo "== whisper $v"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 600 python tools/bench_whisper.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(round(d['value'],1), 'tok/s', {k: c[k] for k in c if 'ms' in k})"; done
+    for v in old new old new; do echo "== headline $v"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python bench.py --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'tok/s', round(d['ms_per_step'],3), 'encode', d['config'].get('encode_ms_last_call'))"; done
+  } 2>&1 | tee $O/act_once_ab.txt ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
