@@ -162,11 +162,11 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
         res[e][j] = (has_res && row < M && col_ok[j]) ? p[j * 16] : 0.f;
     }
   };
-  // (ACT: the activation as a constant, -1 = none - decided ONCE per launch; with the eight-way choice
+  // (ACT = false: no activation - decided ONCE per launch; with the activation's eight-way choice
   // inside the 64 unrolled elements of a 128 x 128 tile the epilogue was several kilobytes of code
   // per element group and the fused form ran 29 us where the int32 form runs 12.5, [128, 32000] x 512)
   auto store_group = [&](int i, const float (&res)[4][TN], auto act_tag) {
-    constexpr int ACT = decltype(act_tag)::value;
+    constexpr bool ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t row = m0 + wm * WTM + i * 16 + g4 * 4 + e;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
           float v = static_cast<float>(acc[i][j][e]) * r_a;
           v = v / ws[j];
           if (ep.bias) v = v + bias[j];
-          if (ACT >= 0) v = apply_activation(v, ACT);
+          if (ACT) v = apply_activation(v, ep.act);
           if (has_res) v = res[e][j] + v;
           if (col_ok[j]) p[j * 16] = v;
         }
@@ -194,24 +194,24 @@ __global__ __launch_bounds__(256) void gemm_s8_mfma_kernel(const int8_t* __restr
   };
   float res_a[4][TN], res_b[4][TN];
   load_residual(0, res_a);
-  auto store_all = [&](auto act_tag) {
+  // (two arms, no more: with one arm per activation - eight instantiations behind a switch - the
+  // accumulators went to scratch memory, 992 bytes per lane, and the launch ran 81 us instead of 17)
+  if (ep.mode == 0 || ep.act < 0) {
 #pragma unroll
     for (int i = 0; i < TM; i += 2) {
       if (i + 1 < TM) load_residual(i + 1, res_b);
-      store_group(i, res_a, act_tag);
+      store_group(i, res_a, std::false_type{});
       if (i + 2 < TM) load_residual(i + 2, res_a);
-      if (i + 1 < TM) store_group(i + 1, res_b, act_tag);
+      if (i + 1 < TM) store_group(i + 1, res_b, std::false_type{});
     }
-  };
-  switch (ep.mode == 0 ? -1 : ep.act) {  // (ops::ActivationType 0 .. 6)
-    case 0: store_all(std::integral_constant<int, 0>{}); break;
-    case 1: store_all(std::integral_constant<int, 1>{}); break;
-    case 2: store_all(std::integral_constant<int, 2>{}); break;
-    case 3: store_all(std::integral_constant<int, 3>{}); break;
-    case 4: store_all(std::integral_constant<int, 4>{}); break;
-    case 5: store_all(std::integral_constant<int, 5>{}); break;
-    case 6: store_all(std::integral_constant<int, 6>{}); break;
-    default: store_all(std::integral_constant<int, -1>{}); break;
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; i += 2) {
+      if (i + 1 < TM) load_residual(i + 1, res_b);
+      store_group(i, res_a, std::true_type{});
+      if (i + 2 < TM) load_residual(i + 2, res_a);
+      if (i + 1 < TM) store_group(i + 1, res_b, std::true_type{});
+    }
   }
 }
 
