@@ -469,11 +469,13 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
                      end_token_id: Optional[int] = None, callback=None, num_hypotheses: int = 1,
                      patience: float = 1.0, return_logits_vocab: bool = False,
                      return_alternatives: bool = False, min_alternative_expansion_prob: float = 0.0,
-                     include_prompt_in_result: bool = False):
+                     include_prompt_in_result: bool = False, static_prompt_length: int = 0):
         """ctranslate2.Generator.generate_batch on token ids (include_prompt_in_result=False unless
         asked for: the reference's default True decodes the prompt step by step as a RETURNED hard
         prefix - it counts towards max / min_length and the sequences begin with the prompt, token 0
-        included unless it is the BOS token, src/models/language_model.cc:150-282).
+        included unless it is the BOS token, src/models/language_model.cc:150-282; static_prompt_length:
+        that many leading tokens of every prompt are GenerationOptions::static_prompt - forwarded in one
+        pass, never returned or counted).
         return_alternatives: the num_hypotheses best FIRST tokens after the prompt, each continued
         independently with the requested search (decode_alternatives, src/decoding.cc:1122-1290);
         as in the reference, max_length / min_length then count from the first PROMPT position, and
@@ -504,6 +506,7 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         opt.return_alternatives = int(return_alternatives)
         opt.min_alternative_expansion_prob = float(min_alternative_expansion_prob)
         opt.include_prompt_in_result = int(include_prompt_in_result)
+        opt.static_prompt_length = int(static_prompt_length)
         cb = self._set_callback(opt, callback)
         if return_logits_vocab:
             lbuf, lcnt = self._set_logits(opt, batch, nh,
@@ -516,7 +519,8 @@ class Translator:  # also serves decoder-only models (ctranslate2.Generator) via
         extra = ()
         # "Forward the start token to the output if it is not the special BOS token"
         # (language_model.cc:262-267)
-        head = [[int(p[0])] if include_prompt_in_result and int(p[0]) != self.bos_id else []
+        sp = int(static_prompt_length)  # (GenerationOptions::static_prompt: the head of every prompt row)
+        head = [[int(p[sp])] if include_prompt_in_result and int(p[sp]) != self.bos_id else []
                 for p in prompts]
         if nh == 1 and not return_alternatives:
             if return_logits_vocab:

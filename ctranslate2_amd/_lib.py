@@ -54,7 +54,7 @@ class TranslationOptions(C.Structure):
         ("prefix_bias_beta", C.c_float),
         ("coverage_penalty", C.c_float),
         ("attention_stride", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("static_prompt_length", C.c_int32),
         ("attention_out", C.POINTER(C.c_float)),
         ("step_callback", STEP_CALLBACK),
         ("step_callback_data", C.c_void_p),

@@ -1480,8 +1480,18 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   const bool with_prompt = opt.include_prompt_in_result != 0;
   CT2X_CHECK(!(with_prompt && opt.return_alternatives),
              "include_prompt_in_result with return_alternatives is not built for the generator in this backend");
-  const int32_t forward_length = with_prompt ? 0 : min_len_prompt - 1;
-  const int32_t longest_prefix = with_prompt ? max_len_prompt - 1 : max_len_prompt - min_len_prompt;
+  // ... behind a static prompt (language_model.cc:184-206): its tokens - the head of every row - are
+  // forwarded in sequence mode and neither returned nor counted
+  const int32_t static_len = std::max<int32_t>(0, opt.static_prompt_length);
+  CT2X_CHECK(static_len < min_len_prompt, "generate_batch: a prompt needs a start token behind the static prompt");
+  // Without the prompt in the result the reference forwards the shortest prompt minus one token -
+  // and when that is NO token (a one-token prompt in the batch) it forwards nothing and
+  // DecodingOptions::return_prefix keeps its default, true (language_model.cc:224-237: the
+  // assignment sits inside `if (forward_length > 0)`): the rest of the longer prompts is then
+  // returned and counted like with include_prompt_in_result, only the start token is not put in front.
+  const bool returns_prefix = with_prompt || min_len_prompt - static_len - 1 == 0;
+  const int32_t forward_length = returns_prefix ? static_len : min_len_prompt - 1;
+  const int32_t longest_prefix = max_len_prompt - forward_length - 1;
   // The reference's front-end decodes a batch sorted from the longest to the shortest example
   // (rebatch_input, src/batch_reader.cc:187-199) and returns the results in the caller's order.
   // Results do not depend on the order of a batch - except in ONE configuration: a hidden prefix
@@ -1501,7 +1511,7 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
     bool non_increasing = true;
     for (int32_t b = 1; b < batch; ++b) non_increasing = non_increasing && prompt_lengths[b] <= prompt_lengths[b - 1];
     if (beam > 1 && longest_prefix > 0 && dopt.min_length > 0 && !per_entry_min && !non_increasing &&
-        !opt.return_alternatives && !with_prompt) {
+        !opt.return_alternatives && !returns_prefix) {
       std::vector<size_t> example_index(static_cast<size_t>(batch));
       std::iota(example_index.begin(), example_index.end(), size_t(0));
       std::sort(example_index.begin(), example_index.end(), [&](size_t i1, size_t i2) {
@@ -1585,7 +1595,7 @@ int ct2x_generate_batch(void* translator, const int32_t* prompt_ids,
   t->engine->synchronize();
   const double te1 = now_ms();
   dopt.start_step = forward_length;
-  dopt.return_prefix = with_prompt;
+  dopt.return_prefix = returns_prefix;
   DecodeStats ds;
   std::vector<DecodingResult> results =
       beam > 1 ? beam_search(*t->engine, *st, start_ids, end_id, dopt, &ds,

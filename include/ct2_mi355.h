@@ -625,7 +625,16 @@ struct ct2x_translation_options {
   float prefix_bias_beta;
   float coverage_penalty;
   int32_t attention_stride;
-  int32_t reserved0;
+  /* ct2x_generate_batch - GenerationOptions::static_prompt (include/ctranslate2/generation.h:66-70;
+   * src/models/language_model.cc:184-206): the first static_prompt_length tokens of every prompt row
+   * are the static prompt - consumed by one sequence-mode pass, never returned, not counted by max /
+   * min_decoding_length; with include_prompt_in_result the decoding starts from the token behind
+   * them. Without it the static prompt is the head of what the sequence-mode pass consumes anyway;
+   * the length still matters in one corner the reference has: when the shortest prompt behind the
+   * static one is a single token nothing more is forwarded and the rest of the longer prompts is
+   * RETURNED (return_prefix keeps its default, language_model.cc:224-237). The reference's cache of
+   * the static prompt's state is an optimisation this entry does not make. */
+  int32_t static_prompt_length;
   float* attention_out;
   /* TranslationOptions / GenerationOptions::callback (include/ctranslate2/translation.h:85,
    * generation.h:77; invoked by GreedySearch::search, src/decoding.cc:925-939): called for every
@@ -660,6 +669,7 @@ struct ct2x_translation_options {
    * the step callback sees them). The returned sequences then begin with prompt token 1; putting
    * token 0 in front of them when it is not the BOS token (language_model.cc:262-267) is the
    * caller's side (include/ct2_mi355.hpp, the Level 1.5 replica). Not with return_alternatives.
+   * A static prompt: static_prompt_length above.
    * 0 = the prompt is consumed by one sequence-mode pass and not returned. */
   int32_t include_prompt_in_result;
 };

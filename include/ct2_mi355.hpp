@@ -594,15 +594,16 @@ public:
     // include_prompt_in_result (the reference's default): the C entry decodes the prompt step by
     // step as a returned hard prefix, exactly as DecoderReplica::run_generation does
     // (src/models/language_model.cc:150-282) - lengths, scores and callbacks are the reference's.
-    // Together with a static prompt, return_alternatives or return_logits_vocab the entry decodes
+    // Together with return_alternatives or return_logits_vocab the entry decodes
     // with include_prompt_in_result = false (one sequence-mode pass over the prompt, the first
     // generated token of the shortest prompt is step 0) and the prompt is put in front of the
     // sequences here: the start tokens are handed to the callback before the decoding and the steps
     // continue from them (a forced token's log-probability is not computed on that path:
     // return_scores is rejected).
     const bool exact_prompt = options.include_prompt_in_result && !options.return_alternatives &&
-                              options.static_prompt.empty() && !options.return_logits_vocab;
+                              !options.return_logits_vocab;
     o.include_prompt_in_result = exact_prompt ? 1 : 0;
+    o.static_prompt_length = static_cast<int32_t>(options.static_prompt.size());
     size_t step_offset = 0;
     if (options.callback && options.include_prompt_in_result && !exact_prompt) {
       detail::reject(options.return_scores, "a callback with return_scores and include_prompt_in_result");
@@ -646,8 +647,9 @@ public:
         if (exact_prompt) {
           // "Forward the start token to the output if it is not the special BOS token"
           // (language_model.cc:262-267); the rest of the prompt is in the decoded sequence
-          if (in.ids[b * in.stride] != h_.bos_id()) {
-            ids.push_back(static_cast<size_t>(in.ids[b * in.stride]));
+          const size_t first = b * in.stride + options.static_prompt.size();  // (behind the static prompt)
+          if (in.ids[first] != h_.bos_id()) {
+            ids.push_back(static_cast<size_t>(in.ids[first]));
             tokens.push_back(start_tokens[b][0]);
           }
         } else if (options.include_prompt_in_result) {

@@ -406,8 +406,10 @@ namespace ctranslate2 {
     // ct2x_generate_batch, with sampling, the step callback, a custom end token and
     // return_alternatives (round 6) - and with include_prompt_in_result = true, the reference's
     // default: the prompt decoded step by step as a returned hard prefix on the fused engine, the
-    // start token put in front here (language_model.cc:262-267). Static prompts, logits and the
-    // prompt in the result together with return_alternatives stay on the reference's own path.
+    // start token put in front here (language_model.cc:262-267), and with a static prompt (forwarded
+    // with the rest; its cached state is the reference's optimisation, not made here). Logits and the
+    // prompt in the result / a static prompt together with return_alternatives stay on the reference's
+    // own path.
     class Mi355DecoderReplica : public DecoderReplica {
     public:
       using DecoderReplica::DecoderReplica;
@@ -423,7 +425,13 @@ namespace ctranslate2 {
         const auto& m = static_cast<const LanguageModel&>(*model());
         const Vocabulary& vocab = m.get_vocabulary();
         const size_t batch = start_tokens.size();
-        const auto ids = vocab.to_ids(start_tokens);
+        // static_prompt + start_tokens is what the model consumes (language_model.cc:184-206): the
+        // static tokens lead every row, ct2x_translation_options.static_prompt_length says how many
+        const auto start_ids = vocab.to_ids(start_tokens);
+        std::vector<size_t> static_ids;
+        for (const auto& token : options.static_prompt) static_ids.push_back(vocab.to_id(token));
+        std::vector<std::vector<size_t>> ids(batch, static_ids);
+        for (size_t b = 0; b < batch; ++b) ids[b].insert(ids[b].end(), start_ids[b].begin(), start_ids[b].end());
         size_t stride = 1;
         for (const auto& row : ids) stride = std::max(stride, row.size());
         std::vector<int32_t> flat(batch * stride, 0), lengths(batch);
@@ -460,6 +468,7 @@ namespace ctranslate2 {
         opt.return_alternatives = options.return_alternatives ? 1 : 0;
         opt.min_alternative_expansion_prob = options.min_alternative_expansion_prob;
         opt.include_prompt_in_result = options.include_prompt_in_result ? 1 : 0;
+        opt.static_prompt_length = static_cast<int32_t>(static_ids.size());
         const auto end_ids = std::visit(ResolveEndToken(vocab), options.end_token);
         if (end_ids[0] != vocab.eos_id()) opt.end_token_plus_one = static_cast<int32_t>(end_ids[0]) + 1;
         CallbackBridge bridge{&options.callback, &vocab, nullptr};
@@ -486,8 +495,8 @@ namespace ctranslate2 {
             const int32_t* row = out_ids.data() + (b * nh + h) * max_len;
             results[b].sequences_ids.emplace_back(row, row + std::min<int32_t>(len, static_cast<int32_t>(max_len)));
             // "Forward the start token to the output if it is not the special BOS token"
-            if (options.include_prompt_in_result && ids[b][0] != vocab.bos_id())
-              results[b].sequences_ids.back().insert(results[b].sequences_ids.back().begin(), ids[b][0]);
+            if (options.include_prompt_in_result && start_ids[b][0] != vocab.bos_id())
+              results[b].sequences_ids.back().insert(results[b].sequences_ids.back().begin(), start_ids[b][0]);
             if (options.return_scores) results[b].scores.push_back(out_scores[b * nh + h]);
           }
           results[b].sequences = vocab.to_tokens(results[b].sequences_ids);
@@ -507,10 +516,10 @@ namespace ctranslate2 {
         if (m == nullptr) return false;
         for (const auto& prompt : start_tokens)
           if (prompt.empty()) return false;
-        // (static prompts keep a cached state, logits, the prompt in the result of
-        // return_alternatives: the reference's own path)
+        // (logits, the prompt in the result or a static prompt together with return_alternatives: the
+        // reference's own path)
         if ((options.include_prompt_in_result && options.return_alternatives) ||
-            !options.static_prompt.empty() || options.return_logits_vocab ||
+            (!options.static_prompt.empty() && options.return_alternatives) || options.return_logits_vocab ||
             options.num_hypotheses < 1 || options.beam_size < 1 || options.max_length == 0 ||
             (options.num_hypotheses > options.beam_size && !options.return_alternatives && options.sampling_topk == 1) ||
             (options.callback && options.beam_size != 1) || (options.return_alternatives && options.sampling_topk != 1))

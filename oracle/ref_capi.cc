@@ -484,10 +484,25 @@ int ct2ref_generate(void* h, const int32_t* prompt_ids, const int32_t* prompt_le
 // Generator::generate_batch with include_prompt_in_result = true (the reference's default: the
 // prompt is decoded step by step as a returned hard prefix, src/models/language_model.cc:150-282;
 // the sequences begin with the prompt). out_ids [batch, out_stride], out_stride >= max_len + 1.
+int ct2ref_generate_static(void* h, const int32_t* prompt_ids, const int32_t* prompt_lengths,
+                           int batch, int stride, int static_len, int include_prompt, int beam_size, int max_len,
+                           int min_len, int return_scores, int out_stride, int32_t* out_ids,
+                           int32_t* out_lengths, float* out_scores);
+
 int ct2ref_generate_with_prompt(void* h, const int32_t* prompt_ids, const int32_t* prompt_lengths,
                                 int batch, int stride, int beam_size, int max_len, int min_len,
                                 int return_scores, int out_stride, int32_t* out_ids,
                                 int32_t* out_lengths, float* out_scores) {
+  return ct2ref_generate_static(h, prompt_ids, prompt_lengths, batch, stride, 0, 1, beam_size, max_len, min_len,
+                                return_scores, out_stride, out_ids, out_lengths, out_scores);
+}
+
+// ... and with GenerationOptions::static_prompt = the first static_len tokens of prompt row 0 (every
+// row must begin with them; src/models/language_model.cc:184-206), include_prompt_in_result as given.
+int ct2ref_generate_static(void* h, const int32_t* prompt_ids, const int32_t* prompt_lengths,
+                           int batch, int stride, int static_len, int include_prompt, int beam_size, int max_len,
+                           int min_len, int return_scores, int out_stride, int32_t* out_ids,
+                           int32_t* out_lengths, float* out_scores) {
   CT2REF_TRY
   auto* m = static_cast<RefModel*>(h);
   const auto* lm = dynamic_cast<const models::LanguageModel*>(m->model.get());
@@ -499,7 +514,12 @@ int ct2ref_generate_with_prompt(void* h, const int32_t* prompt_ids, const int32_
   opt.min_length = min_len;
   opt.sampling_topk = 1;
   opt.return_scores = return_scores != 0;
-  opt.include_prompt_in_result = true;
+  opt.include_prompt_in_result = include_prompt != 0;
+  if (static_len > 0) {
+    opt.static_prompt.assign(prompts[0].begin(), prompts[0].begin() + static_len);
+    opt.cache_static_prompt = false;
+    for (auto& p : prompts) p.erase(p.begin(), p.begin() + static_len);
+  }
   auto futures = m->generator->generate_batch_async(prompts, opt);
   std::vector<GenerationResult> results;
   for (auto& f : futures) results.emplace_back(f.get());

@@ -366,6 +366,21 @@ class RefModel:
             C.c_int(width), _p(out), _p(out_len), _p(scores)))
         return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
 
+    def generate_ids_static(self, prompts, static_len, include_prompt, beam_size=1, max_len=64, min_len=0):
+        """Generator::generate_batch with static_prompt = the first static_len tokens of every prompt
+        (ct2ref_generate_static); returns (sequences, scores)."""
+        ids, lengths, stride = self._pack(prompts)
+        batch = len(prompts)
+        width = max_len + 1
+        out = np.zeros((batch, width), np.int32)
+        out_len = np.zeros((batch,), np.int32)
+        scores = np.zeros((batch,), np.float32)
+        _check(lib().ct2ref_generate_static(
+            C.c_void_p(self._h), _p(ids), _p(lengths), C.c_int(batch), C.c_int(stride), C.c_int(static_len),
+            C.c_int(int(include_prompt)), C.c_int(beam_size), C.c_int(max_len), C.c_int(min_len), C.c_int(1),
+            C.c_int(width), _p(out), _p(out_len), _p(scores)))
+        return [out[b, :out_len[b]].tolist() for b in range(batch)], scores
+
     def generate_ex_ids(self, prompts, beam_size=1, max_len=64, min_len=0, num_hypotheses=1,
                         return_alternatives=False, min_alternative_expansion_prob=0.0):
         """Generator::generate_batch with num_hypotheses / return_alternatives (ct2ref_generate_ex).

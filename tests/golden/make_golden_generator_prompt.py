@@ -24,6 +24,7 @@ from ctranslate2_amd import model_builder as mb  # noqa: E402
 
 LENGTHS = {"lm_tiny": [6, 3, 5, 6, 1], "lm_small": [16, 11, 16, 7, 13, 9]}
 BOS = 1  # model_builder's vocabulary: <blank> <s> </s> <unk> tok4 ...
+STATIC = 5  # tokens of the static prompt
 
 
 def main():
@@ -39,6 +40,8 @@ def main():
         prompts[0][0] = BOS  # (a BOS start token is NOT forwarded to the output)
         longest = max(LENGTHS[key])
         room = longest + cfg["max_len"] // 2
+        rng_static = np.random.default_rng(cfg["data_seed"] + 400)
+        static = None
         for ct, suffix in (("float32", "_f32"), ("int8", "")):
             m = R.RefModel(path, ct, 1, 4)
             runs = {}
@@ -52,7 +55,23 @@ def main():
                                                          min_len=min_len, return_scores=True)
                 runs[name] = {"beam": beam, "max_len": max_len, "min_len": min_len, "generated": gen,
                               "scores": scores.tolist()}
-            out[key + suffix] = {"prompts": prompts, "runs": runs, "compute_type": m.compute_type()}
+            # GenerationOptions::static_prompt (language_model.cc:184-206): a shared head of STATIC tokens in
+            # front of every prompt - forwarded in one pass, never returned or counted - with the prompt in
+            # the result (the reference's default) and without
+            static = rng_static.integers(4, vocab, STATIC).tolist() if suffix == "_f32" else static
+            sprompts = [static + p for p in prompts]
+            sruns = {}
+            for name, include, beam, max_len, min_len in (
+                    ("with_prompt_greedy", True, 1, room, 0),
+                    ("with_prompt_beam4", True, 4, room, longest + 2),
+                    ("hidden_greedy", False, 1, cfg["max_len"], 0),
+                    ("hidden_beam4", False, 4, cfg["max_len"], 0)):
+                gen, scores = m.generate_ids_static(sprompts, STATIC, include, beam_size=beam, max_len=max_len,
+                                                    min_len=min_len)
+                sruns[name] = {"include_prompt": include, "beam": beam, "max_len": max_len, "min_len": min_len,
+                               "generated": gen, "scores": scores.tolist()}
+            out[key + suffix] = {"prompts": prompts, "runs": runs, "compute_type": m.compute_type(),
+                                 "static": {"length": STATIC, "prompts": sprompts, "runs": sruns}}
             m.close()
     with open(os.path.join(HERE, "generator_prompt_golden.json"), "w") as f:
         json.dump(out, f)

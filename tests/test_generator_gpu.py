@@ -564,3 +564,20 @@ def test_generator_include_prompt_in_result(gpu, key, ct):
             assert sum(same) >= len(same) - 2, (name, gen, run["generated"])
             ok = np.array(same)
             np.testing.assert_allclose(scores[ok], np.array(run["scores"], np.float32)[ok], atol=2e-2)
+    # GenerationOptions::static_prompt: a shared head forwarded in one pass, never returned or counted -
+    # with the prompt in the result and without (lm_tiny's batch holds a one-token prompt: without the
+    # prompt in the result the reference then forwards nothing more and RETURNS the rest of the longer
+    # prompts, language_model.cc:224-237 - reproduced)
+    st = g["static"]
+    for name, run in st["runs"].items():
+        gen, scores = t.generate_ids(st["prompts"], max_length=run["max_len"], min_length=run["min_len"],
+                                     return_scores=True, beam_size=run["beam"],
+                                     include_prompt_in_result=run["include_prompt"],
+                                     static_prompt_length=st["length"])
+        same = [x == y for x, y in zip(gen, run["generated"])]
+        print("%s %s static %s: %d/%d token-identical" % (key, ct, name, sum(same), len(same)))
+        if ct == "float32":
+            assert all(same), (name, gen, run["generated"])
+            np.testing.assert_allclose(scores, np.array(run["scores"], np.float32), atol=1e-3)
+        else:
+            assert sum(same) >= len(same) - 2, (name, gen, run["generated"])

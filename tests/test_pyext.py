@@ -163,6 +163,12 @@ LEVEL15_GEN_CASES = [
      "return_scores": True,
      "tokens": [["tok17", "tok5", "tok230"], ["<s>", "tok9", "tok77", "tok300", "tok12", "tok40"], ["tok9"]]},
     {"name": "prompt_callback", "beam_size": 1, "max_length": 9, "include_prompt_in_result": True, "callback": True},
+    # GenerationOptions::static_prompt, with the prompt in the result and without
+    {"name": "static_prompt", "beam_size": 1, "max_length": 10, "include_prompt_in_result": True,
+     "return_scores": True, "static_prompt": ["tok33", "tok71", "tok250"]},
+    {"name": "static_hidden_beam", "beam_size": 4, "max_length": 8, "return_scores": True,
+     "static_prompt": ["tok33", "tok71", "tok250"],
+     "tokens": [["tok17", "tok5", "tok230"], ["tok9", "tok77", "tok300", "tok12", "tok40"]]},
 ]
 
 
