@@ -480,6 +480,25 @@ namespace ctranslate2 {
         const size_t nh = options.num_hypotheses, max_len = options.max_length;
         std::vector<int32_t> out_ids(batch * nh * max_len), out_lengths(batch * nh);
         std::vector<float> out_scores(batch * nh);
+        // return_logits_vocab (greedy search / sampling: serves() checked): one vector per step an
+        // entry ran - the forced steps of a longer prompt and the end token's step included
+        const size_t vocab_size = vocab.size();
+        size_t logits_steps = 0;
+        std::vector<float> logits;
+        std::vector<int32_t> logits_counts;
+        if (options.return_logits_vocab) {
+          size_t shortest = ids[0].size(), longest = ids[0].size();
+          for (const auto& row : ids) {
+            shortest = std::min(shortest, row.size());
+            longest = std::max(longest, row.size());
+          }
+          logits_steps = max_len + (longest - shortest) + 1;
+          logits.resize(batch * nh * logits_steps * vocab_size);
+          logits_counts.assign(batch * nh, 0);
+          opt.logits_out = logits.data();
+          opt.logits_counts_out = logits_counts.data();
+          opt.logits_steps = static_cast<int32_t>(logits_steps);
+        }
         const int rc = ct2x_generate_batch(_handle->h, flat.data(), lengths.data(), static_cast<int32_t>(batch),
                                            static_cast<int32_t>(stride), &opt, out_ids.data(), out_lengths.data(),
                                            out_scores.data());
@@ -498,6 +517,14 @@ namespace ctranslate2 {
             if (options.include_prompt_in_result && start_ids[b][0] != vocab.bos_id())
               results[b].sequences_ids.back().insert(results[b].sequences_ids.back().begin(), start_ids[b][0]);
             if (options.return_scores) results[b].scores.push_back(out_scores[b * nh + h]);
+            if (options.return_logits_vocab) {
+              results[b].logits.emplace_back();
+              for (int32_t t = 0; t < logits_counts[b * nh + h]; ++t) {
+                const float* l = logits.data() + ((b * nh + h) * logits_steps + t) * vocab_size;
+                results[b].logits.back().emplace_back(Shape{static_cast<dim_t>(vocab_size)},
+                                                      std::vector<float>(l, l + vocab_size));
+              }
+            }
           }
           results[b].sequences = vocab.to_tokens(results[b].sequences_ids);
         }
@@ -516,10 +543,11 @@ namespace ctranslate2 {
         if (m == nullptr) return false;
         for (const auto& prompt : start_tokens)
           if (prompt.empty()) return false;
-        // (logits, the prompt in the result or a static prompt together with return_alternatives: the
-        // reference's own path)
+        // (logits under beam search, the prompt in the result or a static prompt together with
+        // return_alternatives: the reference's own path)
         if ((options.include_prompt_in_result && options.return_alternatives) ||
-            (!options.static_prompt.empty() && options.return_alternatives) || options.return_logits_vocab ||
+            (!options.static_prompt.empty() && options.return_alternatives) ||
+            (options.return_logits_vocab && (options.beam_size != 1 || options.return_alternatives)) ||
             options.num_hypotheses < 1 || options.beam_size < 1 || options.max_length == 0 ||
             (options.num_hypotheses > options.beam_size && !options.return_alternatives && options.sampling_topk == 1) ||
             (options.callback && options.beam_size != 1) || (options.return_alternatives && options.sampling_topk != 1))

@@ -57,8 +57,12 @@ def main():
             kw.setdefault("include_prompt_in_result", False)
             tokens = kw.pop("tokens", spec["tokens"])
             res = g.generate_batch(tokens, **kw)
-            out["runs"].append({"name": name, "sequences": [r.sequences for r in res],
-                                "scores": [[float(x) for x in r.scores] for r in res], "steps": steps})
+            run = {"name": name, "sequences": [r.sequences for r in res],
+                   "scores": [[float(x) for x in r.scores] for r in res], "steps": steps}
+            if kw.get("return_logits_vocab"):
+                import numpy as np
+                run["logits"] = [[[np.array(l).astype(float).tolist() for l in hyp] for hyp in r.logits] for r in res]
+            out["runs"].append(run)
         lib = ctypes.CDLL(os.path.join(ROOT, "integration", "libctranslate2_mi355.so"), mode=os.RTLD_LAZY | os.RTLD_GLOBAL)
         lib.ct2x_level15_served_calls.restype = ctypes.c_int64
         out["served_calls"] = int(lib.ct2x_level15_served_calls())

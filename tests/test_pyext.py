@@ -166,6 +166,12 @@ LEVEL15_GEN_CASES = [
     # GenerationOptions::static_prompt, with the prompt in the result and without
     {"name": "static_prompt", "beam_size": 1, "max_length": 10, "include_prompt_in_result": True,
      "return_scores": True, "static_prompt": ["tok33", "tok71", "tok250"]},
+    # return_logits_vocab of a greedy search: the prompt hidden (ragged: forced steps first) and returned
+    {"name": "logits_hidden", "beam_size": 1, "max_length": 6, "return_logits_vocab": True,
+     "tokens": [["tok17", "tok5", "tok230"], ["tok9", "tok77", "tok300", "tok12", "tok40"]]},
+    {"name": "logits_prompt", "beam_size": 1, "max_length": 8, "return_logits_vocab": True,
+     "include_prompt_in_result": True,
+     "tokens": [["tok17", "tok5", "tok230"], ["<s>", "tok9", "tok77", "tok300"]]},
     {"name": "static_hidden_beam", "beam_size": 4, "max_length": 8, "return_scores": True,
      "static_prompt": ["tok33", "tok71", "tok250"],
      "tokens": [["tok17", "tok5", "tok230"], ["tok9", "tok77", "tok300", "tok12", "tok40"]]},
@@ -200,3 +206,10 @@ def test_level15_generator_options(gpu):
             assert len(a) == len(b) and all(abs(x - y) < 2e-3 for x, y in zip(a, b)), f["name"]
         if "callback" in f["name"]:
             assert f["steps"] == c["steps"] and len(f["steps"]) > 0
+        if "logits" in f["name"]:
+            import numpy as np
+            assert len(f["logits"]) == len(c["logits"])
+            for fa, ca in zip(f["logits"], c["logits"]):
+                assert [len(h) for h in fa] == [len(h) for h in ca], f["name"]   # one vector per step, per hypothesis
+                for fh, ch in zip(fa, ca):
+                    np.testing.assert_allclose(np.array(fh), np.array(ch), atol=2e-4)
