@@ -209,6 +209,12 @@ act_once)         # the tiled GEMMs' epilogues with the activation as a constant
     for v in old new old new; do echo "== whisper $v"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 600 python tools/bench_whisper.py --steps 2 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(round(d['value'],1), 'tok/s', {k: c[k] for k in c if 'ms' in k})"; done
     for v in old new old new; do echo "== headline $v"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python bench.py --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'tok/s', round(d['ms_per_step'],3), 'encode', d['config'].get('encode_ms_last_call'))"; done
   } 2>&1 | tee $O/act_once_ab.txt ;;
+gemv_chains)      # the cluster launches' GEMVs on two integer chains per thread (build/libct2_mi355_new.so) vs one (_old.so)
+  timeout 900 python -m pytest tests/test_decoder_cluster_gpu.py tests/test_bench_path_gpu.py -x -q 2>&1 | tail -2 | tee $O/gemv_chains_tests.txt
+  { for v in old new old new old new; do echo "== $v headline"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python bench.py --steps 20 --warmup 3 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+    for v in old new old new; do echo "== $v --beam 4"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python bench.py --beam 4 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+    for v in old new; do echo "== $v --batch 128"; CT2X_LIBRARY=$GRAFT_REPO_ROOT/build/libct2_mi355_$v.so timeout 300 python bench.py --batch 128 --steps 10 --warmup 2 $NOLEGS --no-token-check 2>&1 | tail -1 | line; done
+  } 2>&1 | tee $O/gemv_chains_ab.txt ;;
 suite_rest)       # the -m gpu suite from a given test file on (after a fix)
   shift; timeout 2400 python -m pytest "$@" -m gpu -x -q > $O/pytest_rest.log 2>&1; tail -5 $O/pytest_rest.log ;;
 tests)            # a list of test files / pytest args
