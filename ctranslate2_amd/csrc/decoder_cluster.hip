@@ -1053,6 +1053,15 @@ struct GemvRows {
   }
 };
 
+// (column `col` of row r for a thread that is not thread `col`: the rows' epilogues in parallel)
+template <int NS, int KP>
+__device__ __forceinline__ int row_sum_col(const SharedBeam& sh, int r, int col) {
+  int sum = 0;
+#pragma unroll
+  for (int p = 0; p < KP; ++p) sum += sh.part[r][p * NS + col];
+  return sum;
+}
+
 template <int NS, int KP>
 __device__ __forceinline__ int row_sum(const SharedBeam& sh, int r) {
   int sum = 0;
@@ -1246,7 +1255,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
         stage_a[1].store(sh.ks3, sh.vs3);
       }
       g_out.request<64, 8, 4>(W_out.w + static_cast<size_t>(member) * 64 * kD);
-      c_out.request(W_out, out_col, t < 64);
+      c_out.request(W_out, out_col, t < 64 * kBeamRows);
       lds_barrier();
       CT2X_CL_STAMP(1 + 5 * sub)
       // ---- attention: ONE call site (the core keeps the register file), ONE round: wave w = row w,
@@ -1316,13 +1325,12 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
       }
       lds_barrier();
       g_out.finish<64, 8, 4>(sh, nr);
-      if (t < 64) {
-#pragma unroll 1
-        for (int r = 0; r < nr; ++r) {
-          float v = dense_epilogue(row_sum<64, 8>(sh, r), 1.f / sh.rs[r], c_out.wscale, c_out.has_bias, c_out.bias, -1);
-          v = sh.x_row[r][out_col] + v;
-          ho.publish(r * kXchFloats + kXchX + out_col, v);
-        }
+      if (t < 64 * nr) {  // the rows' epilogues in parallel: thread t = (row t / 64, column t % 64)
+        const int r = t >> 6;
+        float v = dense_epilogue(row_sum_col<64, 8>(sh, r, t & 63), 1.f / sh.rs[r], c_out.wscale, c_out.has_bias,
+                                 c_out.bias, -1);
+        v = sh.x_row[r][out_col] + v;
+        ho.publish(r * kXchFloats + kXchX + out_col, v);
       }
       CT2X_CL_STAMP(4 + 5 * sub)
       if (self) {
@@ -1358,7 +1366,7 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
     CT2X_CL_STAMP(11)
     GemvRows<16> g_f1;
     g_f1.request<64, 8, 16>(L.ffn1.w + static_cast<size_t>(member) * 64 * kFfn);
-    c_out.request(L.ffn1, out_col, t < 64);
+    c_out.request(L.ffn1, out_col, t < 64 * kBeamRows);
     ho.await(sh);
     CT2X_CL_STAMP(12)
     {
@@ -1393,14 +1401,13 @@ __global__ __launch_bounds__(kThreads) void decoder_cluster_beam_kernel(ClusterS
     lds_barrier();
     g_f1.finish<64, 8, 16>(sh, nr);
     const bool more = l + 1 < a.n_layers;
-    if (t < 64) {
-#pragma unroll 1
-      for (int r = 0; r < nr; ++r) {
-        float v = dense_epilogue(row_sum<64, 8>(sh, r), 1.f / sh.rs[r], c_out.wscale, c_out.has_bias, c_out.bias, -1);
-        v = sh.x_row[r][out_col] + v;
-        if (more || a.q_out != nullptr) ho.publish(r * kXchFloats + kXchX + out_col, v);
-        if (!more) a.x_out[static_cast<int64_t>(row0 + r) * kD + out_col] = v;
-      }
+    if (t < 64 * nr) {  // (rows in parallel, as behind the attention)
+      const int r = t >> 6;
+      float v = dense_epilogue(row_sum_col<64, 8>(sh, r, t & 63), 1.f / sh.rs[r], c_out.wscale, c_out.has_bias,
+                               c_out.bias, -1);
+      v = sh.x_row[r][out_col] + v;
+      if (more || a.q_out != nullptr) ho.publish(r * kXchFloats + kXchX + out_col, v);
+      if (!more) a.x_out[static_cast<int64_t>(row0 + r) * kD + out_col] = v;
     }
     CT2X_CL_STAMP(13)
     stamp_base += kClusterStampsPerLayer;
